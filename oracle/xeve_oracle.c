@@ -1,0 +1,399 @@
+/*
+ * oracle/xeve_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the XEVE hot-path arithmetic; see xeve_oracle.h for the
+ * scope, the usage restriction and the parity status (PINNED against the
+ * unmodified reference compiled in place, oracle/_ref).
+ *
+ * The code below is written from the arithmetic definitions, not transcribed:
+ * distortions are straight double loops, the Hadamard is a generic separable
+ * Walsh-Hadamard butterfly, the DCT matrices are generated from the closed form
+ * of the EVC integer DCT-II, and the 1-D transforms are plain 64-bit matrix
+ * products (the reference's partial butterflies are an exact integer
+ * factorisation of the same product, so results are identical).
+ */
+#include "xeve_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* helpers                                                                   */
+/* ------------------------------------------------------------------------- */
+static inline int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------------- */
+/* a1  SAD   (reference: xeve_sad.c:40-61; abs macro xeve_util.h:55)          */
+/* ------------------------------------------------------------------------- */
+int xo_sad(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int bit_depth)
+{
+    int acc = 0;
+    for(int y = 0; y < h; y++) {
+        for(int x = 0; x < w; x++) {
+            /* The reference uses the 16-bit sign-mask abs on an int difference
+             * ((d ^ (d>>15)) - (d>>15)); it equals |d| whenever |d| < 32768,
+             * i.e. on the whole codec domain.  Restated literally so that the
+             * oracle agrees with the reference C path on ANY int16 input. */
+            int d = (int)s1[y * st1 + x] - (int)s2[y * st2 + x];
+            int m = d >> 15;
+            acc += (d ^ m) - m;
+        }
+    }
+    return acc >> (bit_depth - 8);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a2  SSD   (reference: xeve_sad.c:275-297) -- shift applied PER PIXEL       */
+/* ------------------------------------------------------------------------- */
+int64_t xo_ssd(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int bit_depth)
+{
+    const int sh  = (bit_depth - 8) * 2;
+    int64_t   acc = 0;
+    for(int y = 0; y < h; y++) {
+        for(int x = 0; x < w; x++) {
+            int d = (int)s1[y * st1 + x] - (int)s2[y * st2 + x];
+            acc += (d * d) >> sh;
+        }
+    }
+    return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a3  DIFF  (reference: xeve_sad.c:160-178)                                  */
+/* ------------------------------------------------------------------------- */
+void xo_diff(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int st_diff, int16_t *diff)
+{
+    for(int y = 0; y < h; y++)
+        for(int x = 0; x < w; x++)
+            diff[y * st_diff + x] = (int16_t)((int)s1[y * st1 + x] - (int)s2[y * st2 + x]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a4  SATD  (reference: xeve_sad.c:394-1140)                                 */
+/* ------------------------------------------------------------------------- */
+/* In-place unnormalised Walsh-Hadamard transform of n values with stride st. */
+static void wht(int *v, int n, int st)
+{
+    for(int len = 1; len < n; len <<= 1) {
+        for(int base = 0; base < n; base += 2 * len) {
+            for(int i = base; i < base + len; i++) {
+                int a = v[i * st], b = v[(i + len) * st];
+                v[i * st]         = a + b;
+                v[(i + len) * st] = a - b;
+            }
+        }
+    }
+}
+
+/* Sum of |2-D Hadamard coefficients| of one tw x th tile of (org - cur), with
+ * the DC term taken >> 2 (reference: xeve_sad.c:411,501,592,740,...).        */
+static int had_tile_sum(const xo_pel *org, const xo_pel *cur, int s_org, int s_cur, int tw, int th)
+{
+    int t[16 * 16];
+    for(int y = 0; y < th; y++)
+        for(int x = 0; x < tw; x++)
+            t[y * tw + x] = (int)org[y * s_org + x] - (int)cur[y * s_cur + x];
+    for(int y = 0; y < th; y++) wht(t + y * tw, tw, 1);
+    for(int x = 0; x < tw; x++) wht(t + x, th, tw);
+    int sum = iabs(t[0]) >> 2;
+    for(int i = 1; i < tw * th; i++) sum += iabs(t[i]);
+    return sum;
+}
+
+static int had_tile(const xo_pel *org, const xo_pel *cur, int s_org, int s_cur, int tw, int th)
+{
+    int s = had_tile_sum(org, cur, s_org, s_cur, tw, th);
+    if(tw == 2 && th == 2) return s;                                   /* xeve_sad.c:394-416  */
+    if(tw == 4 && th == 4) return (s + 1) >> 1;                        /* xeve_sad.c:507      */
+    if(tw == 8 && th == 8) return (s + 2) >> 2;                        /* xeve_sad.c:602      */
+    if((tw == 16 && th == 8) || (tw == 8 && th == 16))                 /* xeve_sad.c:748,885  */
+        return (int)(s / (2.0 * sqrt(8.0)));
+    /* 8x4 and 4x8: xeve_sad.c:964,1038 */
+    return (int)(s / sqrt(8.0));
+}
+
+int xo_satd(int w, int h, const xo_pel *org, const xo_pel *cur, int s_org, int s_cur, int bit_depth)
+{
+    int tw, th;
+    /* tile selection, same precedence as xeve_had (xeve_sad.c:1051-1135) */
+    if(w > h && (h & 7) == 0 && (w & 15) == 0)      { tw = 16; th = 8; }
+    else if(w < h && (w & 7) == 0 && (h & 15) == 0) { tw = 8;  th = 16; }
+    else if(w > h && (h & 3) == 0 && (w & 7) == 0)  { tw = 8;  th = 4; }
+    else if(w < h && (w & 3) == 0 && (h & 7) == 0)  { tw = 4;  th = 8; }
+    else if((w % 8 == 0) && (h % 8 == 0))           { tw = 8;  th = 8; }
+    else if((w % 4 == 0) && (h % 4 == 0))           { tw = 4;  th = 4; }
+    else if((w % 2 == 0) && (h % 2 == 0))           { tw = 2;  th = 2; }
+    else abort();
+    int sum = 0;
+    for(int y = 0; y < h; y += th)
+        for(int x = 0; x < w; x += tw)
+            sum += had_tile(org + y * s_org + x, cur + y * s_cur + x, s_org, s_cur, tw, th);
+    return sum >> (bit_depth - 8);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5/a6  motion compensation  (reference: xeve_mc.c:39-381, xeve_mc.h:36-62)  */
+/* ------------------------------------------------------------------------- */
+/* Baseline luma filter: only the quarter-pel rows 0,4,8,12 of the 1/16-pel
+ * table are populated (xeve_mc.c:39-57). */
+const int16_t xo_mc_l_coeff[16][8] = {
+    [0]  = {0, 0, 0, 64, 0, 0, 0, 0},
+    [4]  = {0, 1, -5, 52, 20, -5, 1, 0},
+    [8]  = {0, 2, -10, 40, 40, -10, 2, 0},
+    [12] = {0, 1, -5, 20, 52, -5, 1, 0},
+};
+/* Baseline chroma filter: 1/8-pel rows 0,4,...,28 of the 1/32-pel table
+ * (xeve_mc.c:59-93). */
+const int16_t xo_mc_c_coeff[32][4] = {
+    [0]  = {0, 64, 0, 0},   [4]  = {-2, 58, 10, -2}, [8]  = {-4, 52, 20, -4}, [12] = {-6, 46, 30, -6},
+    [16] = {-8, 40, 40, -8}, [20] = {-6, 30, 46, -6}, [24] = {-4, 20, 52, -4}, [28] = {-2, 10, 58, -2},
+};
+
+/* Generic separable interpolation with `taps` taps (8 luma / 4 chroma) and
+ * fractional-position mask fmask (15 luma / 31 chroma), fshift (4 / 5). */
+static void mc_generic(int taps, int fshift, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y,
+                       int s_ref, int s_pred, xo_pel *pred, int w, int h, int bit_depth, const int16_t *coef)
+{
+    const int fmask = (1 << fshift) - 1;
+    const int back  = taps / 2 - 1; /* 3 for luma, 1 for chroma */
+    const int maxv  = (1 << bit_depth) - 1;
+    const int ix = gmv_x >> fshift, iy = gmv_y >> fshift;
+    const int16_t *cx = coef + (gmv_x & fmask) * taps;
+    const int16_t *cy = coef + (gmv_y & fmask) * taps;
+
+    if(!frac_x && !frac_y) { /* _00: row copies (xeve_mc.c:99-121, 259-280) */
+        for(int y = 0; y < h; y++)
+            memcpy(pred + y * s_pred, ref + (iy + y) * s_ref + ix, sizeof(xo_pel) * w);
+        return;
+    }
+    if(frac_x && !frac_y) { /* _n0: (sum + 0) >> 6, clip (xeve_mc.c:123-156; xeve_mc.h:36-46) */
+        for(int y = 0; y < h; y++)
+            for(int x = 0; x < w; x++) {
+                const xo_pel *r = ref + (iy + y) * s_ref + ix + x - back;
+                int acc = 0;
+                for(int t = 0; t < taps; t++) acc += cx[t] * r[t];
+                pred[y * s_pred + x] = (xo_pel)clip3i(0, maxv, acc >> 6);
+            }
+        return;
+    }
+    if(!frac_x && frac_y) { /* _0n (xeve_mc.c:158-192) */
+        for(int y = 0; y < h; y++)
+            for(int x = 0; x < w; x++) {
+                const xo_pel *r = ref + (iy + y - back) * s_ref + ix + x;
+                int acc = 0;
+                for(int t = 0; t < taps; t++) acc += cy[t] * r[t * s_ref];
+                pred[y * s_pred + x] = (xo_pel)clip3i(0, maxv, acc >> 6);
+            }
+        return;
+    }
+    /* _nn: horizontal pass to an int16 buffer with shift1 and NO rounding
+     * offset, then vertical pass with rounding (xeve_mc.c:194-254, 333-381) */
+    const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4;
+    const int shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
+    const int round2 = 1 << (shift2 - 1);
+    const int rows   = h + taps - 1;
+    int16_t  *buf    = (int16_t *)malloc(sizeof(int16_t) * (size_t)w * rows);
+    for(int y = 0; y < rows; y++)
+        for(int x = 0; x < w; x++) {
+            const xo_pel *r = ref + (iy + y - back) * s_ref + ix + x - back;
+            int acc = 0;
+            for(int t = 0; t < taps; t++) acc += cx[t] * r[t];
+            buf[y * w + x] = (int16_t)(acc >> shift1);
+        }
+    for(int y = 0; y < h; y++)
+        for(int x = 0; x < w; x++) {
+            int acc = 0;
+            for(int t = 0; t < taps; t++) acc += cy[t] * buf[(y + t) * w + x];
+            pred[y * s_pred + x] = (xo_pel)clip3i(0, maxv, (acc + round2) >> shift2);
+        }
+    free(buf);
+}
+
+void xo_mc_l(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred,
+             xo_pel *pred, int w, int h, int bit_depth, const int16_t (*coef)[8])
+{
+    mc_generic(8, 4, frac_x, frac_y, ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, &coef[0][0]);
+}
+
+void xo_mc_c(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred,
+             xo_pel *pred, int w, int h, int bit_depth, const int16_t (*coef)[4])
+{
+    mc_generic(4, 5, frac_x, frac_y, ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, &coef[0][0]);
+}
+
+/* a7 (reference: xeve_mc.c:449-463) */
+void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h)
+{
+    for(int y = 0; y < h; y++)
+        for(int x = 0; x < w; x++)
+            dst[y * s_dst + x] = (int16_t)(((int)src[y * s_src + x] + (int)ref[y * s_ref + x] + 1) >> 1);
+}
+
+/* ------------------------------------------------------------------------- */
+/* transforms                                                                */
+/* ------------------------------------------------------------------------- */
+/* The EVC integer DCT-II family (xeve_tbl.c:83-236): every entry of every
+ * size derives from g[j] = round(64*sqrt(2)*cos(j*pi/128)), j = 1..63 (g[0]=64):
+ *   M_N[k][x] = +-g[fold((2x+1) * k * 64/N mod 256)].
+ * tests/test_oracle_vs_ref.py checks all six generated matrices against the
+ * reference's xeve_tbl_tm{2..64} symbols. */
+void xo_dct_matrix(int n, int8_t *m)
+{
+    int g[65];
+    g[0] = 64;
+    for(int j = 1; j < 64; j++) g[j] = (int)floor(64.0 * sqrt(2.0) * cos(j * 3.14159265358979323846 / 128.0) + 0.5);
+    g[64] = 0;
+    for(int k = 0; k < n; k++)
+        for(int x = 0; x < n; x++) {
+            int th = ((2 * x + 1) * k * (64 / n)) % 256, sg = 1;
+            if(th > 128) th = 256 - th;
+            if(th > 64) { sg = -1; th = 128 - th; }
+            m[k * n + x] = (int8_t)(sg * g[th]);
+        }
+}
+
+static const int8_t *dct(int log2n)
+{
+    static int8_t tm[7][64 * 64];
+    static int    ready[7];
+    if(!ready[log2n]) { xo_dct_matrix(1 << log2n, tm[log2n]); ready[log2n] = 1; }
+    return tm[log2n];
+}
+
+/* a9 forward 1-D (reference: xeve_tq.c:40-392).
+ * dst[k*line + j] = (T)((sum_x M[k][x]*src[j*N + x] + add) >> shift); the cast
+ * to the destination type truncates (no clip); the 64-point transform forces
+ * outputs k >= 32 to zero (xeve_tq.c:321-381). step 0: s16 -> s32, step 1:
+ * s32 -> s16. */
+void xo_tx(int log2n, const void *src, void *dst, int shift, int line, int step)
+{
+    const int     n   = 1 << log2n;
+    const int8_t *m   = dct(log2n);
+    const int64_t add = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    for(int j = 0; j < line; j++)
+        for(int k = 0; k < n; k++) {
+            int64_t acc = 0;
+            if(!(n == 64 && k >= 32)) {
+                for(int x = 0; x < n; x++) {
+                    int64_t v = step == 0 ? ((const int16_t *)src)[j * n + x] : ((const int32_t *)src)[j * n + x];
+                    acc += m[k * n + x] * v;
+                }
+                acc = (acc + add) >> shift;
+            }
+            if(step == 0) ((int32_t *)dst)[k * line + j] = (int32_t)acc;
+            else          ((int16_t *)dst)[k * line + j] = (int16_t)acc;
+        }
+}
+
+/* a12 inverse 1-D (reference: xeve_itdq.c:34-430, clips xeve_itdq.h:41-48).
+ * dst[j*N + x] = clip((sum_k M[k][x]*src[k*line + j] + add) >> shift). */
+void xo_itx(int log2n, const void *src, void *dst, int shift, int line, int step)
+{
+    const int     n   = 1 << log2n;
+    const int8_t *m   = dct(log2n);
+    const int64_t add = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    for(int j = 0; j < line; j++)
+        for(int x = 0; x < n; x++) {
+            int64_t acc = 0;
+            for(int k = 0; k < n; k++) {
+                int64_t v = step == 0 ? ((const int16_t *)src)[k * line + j] : ((const int32_t *)src)[k * line + j];
+                acc += m[k * n + x] * v;
+            }
+            acc = (acc + add) >> shift;
+            if(step == 0) {
+                if(acc < INT32_MIN) acc = INT32_MIN;
+                if(acc > INT32_MAX) acc = INT32_MAX;
+                ((int32_t *)dst)[j * n + x] = (int32_t)acc;
+            }
+            else {
+                if(acc < -32768) acc = -32768;
+                if(acc > 32767) acc = 32767;
+                ((int16_t *)dst)[j * n + x] = (int16_t)acc;
+            }
+        }
+}
+
+/* reference: xeve_tq.c:396-404, shifts xeve_util.c:34-35 */
+void xo_trans(int16_t *coef, int log2w, int log2h, int bit_depth)
+{
+    int32_t   tb[64 * 64];
+    const int shift1 = log2w - 1 + bit_depth - 8;
+    const int shift2 = log2h + 6;
+    xo_tx(log2w, coef, tb, 0, 1 << log2h, 0);
+    xo_tx(log2h, tb, coef, shift1 + shift2, 1 << log2w, 1);
+}
+
+/* reference: xeve_itdq.c:435-440, shifts xeve_itdq.h:38-39 */
+void xo_itrans(int16_t *coef, int log2w, int log2h, int bit_depth)
+{
+    int32_t tb[64 * 64];
+    xo_itx(log2h, coef, tb, 0, 1 << log2w, 0);
+    xo_itx(log2w, tb, coef, 7 + (12 - (bit_depth - 8)), 1 << log2h, 1);
+}
+
+/* quantisation scale tables (reference: xeve_tq.c:37-38, xeve_tbl.c:237) */
+const int xo_quant_scale[2][6] = {{26214, 23302, 20560, 18396, 16384, 14764}, {26214, 23302, 20560, 18396, 16384, 14564}};
+const int xo_dq_scale[6]       = {40, 45, 51, 57, 64, 71};
+
+/* a10 (reference: xeve_tq.c:704-727; constants xeve_def.h:793-798) */
+int xo_quant(int16_t *coef, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth)
+{
+    const int     log2_size = (log2w + log2h) >> 1;
+    const int     tr_shift  = 15 - bit_depth - log2_size;
+    const int     shift     = 14 + tr_shift + qp / 6;
+    const int32_t offset    = (int32_t)(is_intra_slice ? 171 : 85) << (shift - 9);
+    int           nnz       = 0;
+    for(int i = 0; i < (1 << (log2w + log2h)); i++) {
+        int     neg = coef[i] < 0;
+        int32_t lev = (int32_t)iabs(coef[i]) * (int32_t)scale;
+        lev         = (int16_t)((lev + offset) >> shift);
+        coef[i]     = (int16_t)(neg ? -lev : lev);
+        nnz += coef[i] != 0;
+    }
+    return nnz;
+}
+
+/* RDOQ zero-block pre-test (reference: xeve_tq.c:666-699) */
+int xo_rdoq_zero_test(const int16_t *coef, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth)
+{
+    const int     odd       = (log2w + log2h) & 1;
+    const int     log2_size = (log2w + log2h) >> 1;
+    const int     tr_shift  = 15 - bit_depth - log2_size + (odd ? 7 : 0);
+    const int     shift     = 14 + tr_shift + qp / 6;
+    const int64_t offset    = (int64_t)(is_intra_slice ? 201 : 153) << (shift - 9);
+    const int64_t thr       = ((int64_t)1 << shift) - offset;
+    for(int i = 0; i < (1 << (log2w + log2h)); i++) {
+        int64_t lev = (int64_t)iabs(coef[i]) * (int64_t)scale * (odd ? 181 : 1);
+        if(lev >= thr) return 1;
+    }
+    return 0;
+}
+
+/* a13 (reference: xeve_itdq.c:442-475) */
+void xo_dquant(int16_t *coef, int log2w, int log2h, int scale, int bit_depth)
+{
+    const int     odd       = (log2w + log2h) & 1;
+    const int     log2_size = (log2w + log2h) >> 1;
+    const int     tr_shift  = 15 - bit_depth - log2_size;
+    const int     shift     = (uint8_t)(20 - 14 - tr_shift + (odd ? 8 : 0));
+    const int32_t offset    = shift == 0 ? 0 : 1 << (shift - 1);
+    for(int i = 0; i < (1 << (log2w + log2h)); i++) {
+        int64_t lev = ((int64_t)coef[i] * ((int64_t)scale * (odd ? 181 : 1)) + offset) >> shift;
+        if(lev < -32768) lev = -32768;
+        if(lev > 32767) lev = 32767;
+        coef[i] = (int16_t)lev;
+    }
+}
+
+/* a15 (reference: xeve_recon.c:34-57) -- the sum wraps to int16 before the clip */
+void xo_recon(const int16_t *coef, const xo_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xo_pel *rec, int bit_depth)
+{
+    const int maxv = (1 << bit_depth) - 1;
+    for(int y = 0; y < cuh; y++)
+        for(int x = 0; x < cuw; x++) {
+            int16_t t = is_coef ? (int16_t)(coef[y * cuw + x] + pred[y * cuw + x]) : pred[y * cuw + x];
+            rec[y * s_rec + x] = (xo_pel)clip3i(0, maxv, t);
+        }
+}

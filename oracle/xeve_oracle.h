@@ -1,0 +1,83 @@
+/*
+ * oracle/xeve_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the arithmetic of XEVE's inter-prediction / RDO hot
+ * path.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (xeve_amd/) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit against
+ * the unmodified reference compiled in place (oracle/_ref/libxeveb_ref.so, see
+ * oracle/Makefile) by tests/test_oracle_vs_ref.py, and against the committed
+ * golden vectors in tests/golden/ (generated from that same reference build by
+ * tests/golden/make_golden.py).
+ *
+ * Conventions (reference: src_base/xeve_port.h:54):
+ *   pel = int16_t; all strides are in ELEMENTS; bit depth is the codec-internal
+ *   depth (10 for every BASELINE config).
+ */
+#ifndef XEVE_ORACLE_H
+#define XEVE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int16_t xo_pel;
+
+/* ---- block distortion (reference: src_base/xeve_sad.c) ------------------- */
+/* a1: sad_16b            xeve_sad.c:40-61   */
+int     xo_sad(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int bit_depth);
+/* a2: ssd_16b            xeve_sad.c:275-297 */
+int64_t xo_ssd(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int bit_depth);
+/* a3: diff_16b           xeve_sad.c:160-178 */
+void    xo_diff(int w, int h, const xo_pel *s1, const xo_pel *s2, int st1, int st2, int st_diff, int16_t *diff);
+/* a4: xeve_had           xeve_sad.c:394-1140 */
+int     xo_satd(int w, int h, const xo_pel *org, const xo_pel *cur, int s_org, int s_cur, int bit_depth);
+
+/* ---- motion compensation (reference: src_base/xeve_mc.c) ------------------ */
+/* Baseline interpolation coefficient tables, xeve_mc.c:39-93 */
+extern const int16_t xo_mc_l_coeff[16][8];
+extern const int16_t xo_mc_c_coeff[32][4];
+/* a5: xeve_mc_l_{00,n0,0n,nn}  xeve_mc.c:99-254.
+ * frac_x / frac_y select the table entry exactly as the reference macro
+ * xeve_mc_l does (xeve_mc.h:96-99): index [frac_x != 0][frac_y != 0]. */
+void xo_mc_l(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred,
+             xo_pel *pred, int w, int h, int bit_depth, const int16_t (*coef)[8]);
+/* a6: xeve_mc_c_{00,n0,0n,nn}  xeve_mc.c:259-381 */
+void xo_mc_c(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred,
+             xo_pel *pred, int w, int h, int bit_depth, const int16_t (*coef)[4]);
+/* a7: xeve_average_16b_no_clip xeve_mc.c:449-463 */
+void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h);
+
+/* ---- transforms (reference: src_base/xeve_tq.c, xeve_itdq.c, xeve_tbl.c) -- */
+/* DCT-II integer matrix of size n x n (n = 2..64), xeve_tbl.c:83-236. */
+void xo_dct_matrix(int n, int8_t *m /* n*n, row-major [k][x] */);
+/* a9: tx_pb{2..64}b  xeve_tq.c:40-392   (1-D forward, transposing write) */
+void xo_tx(int log2n, const void *src, void *dst, int shift, int line, int step);
+/* a12: xeve_itx_pb{2..64}b xeve_itdq.c:34-430 (1-D inverse) */
+void xo_itx(int log2n, const void *src, void *dst, int shift, int line, int step);
+/* xeve_trans  xeve_tq.c:396-404  (2-D forward, in place on dense coef[w*h]) */
+void xo_trans(int16_t *coef, int log2w, int log2h, int bit_depth);
+/* xeve_itrans xeve_itdq.c:435-440 (2-D inverse, in place) */
+void xo_itrans(int16_t *coef, int log2w, int log2h, int bit_depth);
+/* a10: plain-quant branch of xeve_quant_nnz xeve_tq.c:704-727; returns nnz.
+ * scale = xeve_quant_scale[tool_iqt][qp % 6] (xeve_tq.c:37-38). */
+extern const int xo_quant_scale[2][6];
+int  xo_quant(int16_t *coef, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth);
+/* RDOQ all-zero pre-test of xeve_quant_nnz xeve_tq.c:666-699: returns 1 when
+ * some coefficient may quantise to non-zero (block is "coded"), 0 otherwise. */
+int  xo_rdoq_zero_test(const int16_t *coef, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth);
+/* a13: xeve_dquant + shift/offset derivation of itdq_cu xeve_itdq.c:442-475.
+ * scale = xeve_tbl_dq_scale_b[qp % 6] << (qp / 6) (xeve_tbl.c:237, xeve_itdq.c:549). */
+extern const int xo_dq_scale[6];
+void xo_dquant(int16_t *coef, int log2w, int log2h, int scale, int bit_depth);
+/* a15: xeve_recon_blk xeve_recon.c:34-57 */
+void xo_recon(const int16_t *coef, const xo_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xo_pel *rec, int bit_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

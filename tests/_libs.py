@@ -1,0 +1,129 @@
+"""ctypes access to the CHECKERS used by the tests (never by the product):
+
+  * oracle/libxeve_oracle.so  -- our plain-C restatement (always available; built on demand)
+  * oracle/_ref/libxeveb_ref.so -- the unmodified reference compiled in place by oracle/Makefile
+    (present in the build container and, prebuilt, on the GPU box; absent -> `ref()` returns None)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libxeve_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libxeveb_ref.so")
+REF_APP = os.path.join(ORACLE_DIR, "_ref", "xeveb_app")
+
+c_int, c_void_p, c_i64 = C.c_int, C.c_void_p, C.c_int64
+_oracle = None
+_ref = None
+
+
+def ptr(a, elem_off=0):
+    """void* to element `elem_off` of a contiguous int16/int32 numpy array."""
+    return C.c_void_p(a.ctypes.data + elem_off * a.itemsize)
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("xeve_oracle.c", "xeve_oracle.h"))
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < src_m:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
+        L = C.CDLL(ORACLE_SO)
+        L.xo_sad.restype = c_int
+        L.xo_sad.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int]
+        L.xo_ssd.restype = c_i64
+        L.xo_ssd.argtypes = L.xo_sad.argtypes
+        L.xo_satd.restype = c_int
+        L.xo_satd.argtypes = L.xo_sad.argtypes
+        L.xo_diff.restype = None
+        L.xo_diff.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+        mc = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+        L.xo_mc_l.restype = None
+        L.xo_mc_l.argtypes = mc
+        L.xo_mc_c.restype = None
+        L.xo_mc_c.argtypes = mc
+        L.xo_avg.restype = None
+        L.xo_avg.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+        L.xo_dct_matrix.restype = None
+        L.xo_dct_matrix.argtypes = [c_int, c_void_p]
+        for f in (L.xo_tx, L.xo_itx):
+            f.restype = None
+            f.argtypes = [c_int, c_void_p, c_void_p, c_int, c_int, c_int]
+        for f in (L.xo_trans, L.xo_itrans):
+            f.restype = None
+            f.argtypes = [c_void_p, c_int, c_int, c_int]
+        L.xo_quant.restype = c_int
+        L.xo_quant.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]
+        L.xo_rdoq_zero_test.restype = c_int
+        L.xo_rdoq_zero_test.argtypes = L.xo_quant.argtypes
+        L.xo_dquant.restype = None
+        L.xo_dquant.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+        L.xo_recon.restype = None
+        L.xo_recon.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]
+        L.mc_l_coeff = (C.c_int16 * (16 * 8)).in_dll(L, "xo_mc_l_coeff")
+        L.mc_c_coeff = (C.c_int16 * (32 * 4)).in_dll(L, "xo_mc_c_coeff")
+        L.quant_scale = (C.c_int * 12).in_dll(L, "xo_quant_scale")
+        L.dq_scale = (C.c_int * 6).in_dll(L, "xo_dq_scale")
+        _oracle = L
+    return _oracle
+
+
+FN_SAD = C.CFUNCTYPE(c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_SSD = C.CFUNCTYPE(c_i64, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_DIFF = C.CFUNCTYPE(None, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int)
+FN_MC = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p)
+FN_AVG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int)
+FN_TXB = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int)
+
+
+class Ref:
+    """The reference's own dispatch tables (reference: src_base/xeve_enc.c:722-779 lists them)."""
+
+    def __init__(self, L):
+        self.L = L
+        self.variants = {}
+        for suffix, names in (
+            ("c", dict(sad="xeve_tbl_sad_16b", ssd="xeve_tbl_ssd_16b", diff="xeve_tbl_diff_16b", satd="xeve_tbl_satd_16b",
+                       mc_l="xeve_tbl_mc_l", mc_c="xeve_tbl_mc_c", txb="xeve_tbl_txb", itxb="xeve_tbl_itxb",
+                       avg="xeve_average_16b_no_clip")),
+            ("sse", dict(sad="xeve_tbl_sad_16b_sse", ssd="xeve_tbl_ssd_16b_sse", diff="xeve_tbl_diff_16b_sse",
+                         satd="xeve_tbl_satd_16b_sse", mc_l="xeve_tbl_mc_l_sse", mc_c="xeve_tbl_mc_c_sse",
+                         txb="xeve_tbl_txb", itxb="xeve_tbl_itxb_sse", avg="xeve_average_16b_no_clip_sse")),
+            ("avx", dict(sad="xeve_tbl_sad_16b_avx", ssd="xeve_tbl_ssd_16b_sse", diff="xeve_tbl_diff_16b_sse",
+                         satd="xeve_tbl_satd_16b_sse", mc_l="xeve_tbl_mc_l_avx", mc_c="xeve_tbl_mc_c_avx",
+                         txb="xeve_tbl_txb_avx", itxb="xeve_tbl_itxb_avx", avg="xeve_average_16b_no_clip_sse")),
+        ):
+            v = type("V", (), {})()
+            v.sad = (FN_SAD * 64).in_dll(L, names["sad"])
+            v.ssd = (FN_SSD * 64).in_dll(L, names["ssd"])
+            v.diff = (FN_DIFF * 64).in_dll(L, names["diff"])
+            v.satd = (FN_SAD * 1).in_dll(L, names["satd"])
+            v.mc_l = (FN_MC * 4).in_dll(L, names["mc_l"])
+            v.mc_c = (FN_MC * 4).in_dll(L, names["mc_c"])
+            v.txb = (FN_TXB * 6).in_dll(L, names["txb"])
+            v.itxb = (FN_TXB * 6).in_dll(L, names["itxb"])
+            v.avg = FN_AVG((names["avg"], L))
+            self.variants[suffix] = v
+        self.recon = L.xeve_recon_blk
+        self.recon.restype = None
+        self.recon.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]
+        self.mc_l_coeff = (C.c_int16 * (16 * 8)).in_dll(L, "xeve_tbl_mc_l_coeff")
+        self.mc_c_coeff = (C.c_int16 * (32 * 4)).in_dll(L, "xeve_tbl_mc_c_coeff")
+
+    def tm(self, n):
+        return np.frombuffer((C.c_int8 * (n * n)).in_dll(self.L, "xeve_tbl_tm%d" % n), dtype=np.int8).reshape(n, n).copy()
+
+
+def ref():
+    global _ref
+    if _ref is None and os.path.exists(REF_SO):
+        _ref = Ref(C.CDLL(REF_SO))
+    return _ref
+
+
+def ilog2(v):
+    return int(v).bit_length() - 1
