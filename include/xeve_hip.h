@@ -1,0 +1,158 @@
+/*
+ * include/xeve_hip.h -- C-ABI of libxeve_hip.so, the MI355X (gfx950) implementation of XEVE's
+ * inter-prediction / RDO arithmetic hot path.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *  (1) DROP-IN DISPATCH TABLES with exactly the reference's function-pointer types and index
+ *      conventions.  They take borrowed HOST pointers, run the HIP kernel for that one call and
+ *      return synchronously -- the literal replacement for the SIMD tables that
+ *      xeve_platform_init_func installs (reference: src_base/xeve_enc.c:722-779).  See INTEGRATION.md.
+ *
+ *  (2) BATCHED DEVICE API: the same arithmetic over many blocks per launch, on picture planes that
+ *      are already resident in HBM, asynchronous on a caller-supplied hipStream_t.  This is the form
+ *      the GPU is actually fast in (one table call is 128 B..16 KB of work).
+ *
+ * Error convention: the reference's table functions cannot report failure.  The
+ * table layer therefore aborts the process with a message on any HIP error (there is NO CPU
+ * fallback, by design); the batched layer returns 0 on success or a negative XEVE_HIP_ERR_* code and
+ * keeps a message retrievable with xeve_hip_last_error().
+ *
+ * Common conventions (reference: src_base/xeve_port.h:54): pel = int16_t, all
+ * strides and offsets are in ELEMENTS (not bytes), bit_depth is the codec-internal depth.
+ */
+#ifndef XEVE_HIP_H
+#define XEVE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int16_t xeve_hip_pel;
+
+#define XEVE_HIP_OK            0
+#define XEVE_HIP_ERR_DEVICE   (-1) /* no usable gfx950 device / HIP runtime error */
+#define XEVE_HIP_ERR_ARG      (-2) /* invalid argument */
+#define XEVE_HIP_ERR_UNINIT   (-3) /* xeve_hip_init() not called */
+
+/* ------------------------------------------------------------------------------------------- */
+/* lifecycle                                                                                   */
+/* ------------------------------------------------------------------------------------------- */
+/* Binds the calling PROCESS to one GPU (the reference's dispatch globals are process-wide,
+ * src_base/xeve_sad.c:34-37, so the binding is too: one encoder process per GPU / GOP shard). */
+int         xeve_hip_init(int device_ordinal);
+void        xeve_hip_shutdown(void);
+const char *xeve_hip_last_error(void);
+/* number of table-layer calls served since init (to let tests prove the HIP path ran) */
+uint64_t    xeve_hip_table_calls(void);
+
+/* ------------------------------------------------------------------------------------------- */
+/* (1) drop-in dispatch tables                                                                 */
+/* ------------------------------------------------------------------------------------------- */
+/* reference: src_base/xeve_sad.h:41-45 */
+typedef int     (*XEVE_HIP_FN_SAD)(int w, int h, void *src1, void *src2, int s_src1, int s_src2, int bit_depth);
+typedef int     (*XEVE_HIP_FN_SATD)(int w, int h, void *src1, void *src2, int s_src1, int s_src2, int bit_depth);
+typedef int64_t (*XEVE_HIP_FN_SSD)(int w, int h, void *src1, void *src2, int s_src1, int s_src2, int bit_depth);
+typedef void    (*XEVE_HIP_FN_DIFF)(int w, int h, void *src1, void *src2, int s_src1, int s_src2, int s_diff,
+                                    int16_t *diff, int bit_depth);
+/* reference: src_base/xeve_mc.h:85-87 */
+typedef void (*XEVE_HIP_MC_L)(xeve_hip_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xeve_hip_pel *pred,
+                              int w, int h, int bit_depth, const int16_t (*mc_l_coeff)[8]);
+typedef void (*XEVE_HIP_MC_C)(xeve_hip_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xeve_hip_pel *pred,
+                              int w, int h, int bit_depth, const int16_t (*mc_c_coeff)[4]);
+typedef void (*XEVE_HIP_AVG_NO_CLIP)(int16_t *src, int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst,
+                                     int wd, int ht);
+/* reference: src_base/xeve_type.h:169-170 */
+typedef void (*XEVE_HIP_TXB)(void *coef, void *t, int shift, int line, int step);
+typedef void (*XEVE_HIP_ITXB)(void *coef, void *t, int shift, int line, int step);
+
+/* replaces xeve_tbl_sad_16b{,_sse,_avx}   (xeve_sad.c:66, sse/xeve_sad_sse.c:254, avx/xeve_sad_avx.c:108); [log2 w][log2 h] */
+extern const XEVE_HIP_FN_SAD  xeve_tbl_sad_16b_hip[8][8];
+/* replaces xeve_tbl_ssd_16b{,_sse}        (xeve_sad.c:300, sse/xeve_sad_sse.c:1003) */
+extern const XEVE_HIP_FN_SSD  xeve_tbl_ssd_16b_hip[8][8];
+/* replaces xeve_tbl_diff_16b{,_sse}       (xeve_sad.c:183, sse/xeve_sad_sse.c:523) */
+extern const XEVE_HIP_FN_DIFF xeve_tbl_diff_16b_hip[8][8];
+/* replaces xeve_tbl_satd_16b{,_sse}       (xeve_sad.c:1143, sse/xeve_sad_sse.c:2722) */
+extern const XEVE_HIP_FN_SATD xeve_tbl_satd_16b_hip[1];
+/* replaces xeve_tbl_mc_l/_c{,_sse,_avx}   (xeve_mc.c:383-399); [dx != 0][dy != 0] */
+extern const XEVE_HIP_MC_L    xeve_tbl_mc_l_hip[2][2];
+extern const XEVE_HIP_MC_C    xeve_tbl_mc_c_hip[2][2];
+/* replaces xeve_average_16b_no_clip{,_sse} (xeve_mc.c:449) */
+void xeve_average_16b_no_clip_hip(int16_t *src, int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int wd, int ht);
+/* replaces xeve_tbl_txb{,_avx} (xeve_tq.c:394) and xeve_tbl_itxb{,_sse,_avx} (xeve_itdq.c:432); [log2 N - 1];
+ * these two are installed BY ADDRESS (&table), like the reference's (xeve_enc.c:752-753) */
+extern const XEVE_HIP_TXB     xeve_tbl_txb_hip[6];
+extern const XEVE_HIP_ITXB    xeve_tbl_itxb_hip[6];
+/* replaces xeve_recon_blk (xeve_recon.c:34; installed as ctx->fn_recon, xeve_enc.c:822) */
+void xeve_recon_blk_hip(int16_t *coef, xeve_hip_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xeve_hip_pel *rec, int bit_depth);
+
+/* Zero-edit installation: overwrites the reference library's exported pointer globals
+ * (xeve_func_sad/ssd/diff/satd, xeve_func_mc_l/mc_c, xeve_func_average_no_clip, xeve_func_txb --
+ * xeve_sad.c:34-37, xeve_mc.c:34-36, xeve_tq.c:36) found with dlsym(RTLD_DEFAULT) in the calling
+ * process.  `fn_itxb_slot` is the address of ctx->fn_itxb (xeve_type.h:984) or NULL.  Returns the number
+ * of pointers patched (8 + 1), or a negative error when the reference library is not loaded. */
+int xeve_hip_install_tables(void *fn_itxb_slot);
+
+/* ------------------------------------------------------------------------------------------- */
+/* (2) batched device API -- every pointer below is a DEVICE pointer unless stated; `stream` is   */
+/*     a hipStream_t (NULL = default stream); calls are asynchronous on that stream.             */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_job {
+    int32_t off1; /* element offset of the block's top-left sample inside plane 1 (e.g. the original) */
+    int32_t off2; /* element offset inside plane 2 (e.g. the reference picture at the search centre)    */
+} xeve_hip_job;
+
+#define XEVE_HIP_SRC1_SIGNED 1 /* plane 1 may hold negative samples (org_bi = 2*org - pred, xeve_pinter.c:143-156) */
+
+/* out[j * ncand + c] = sad(w, h, p1 + jobs[j].off1, p2 + jobs[j].off2 + cand_off[c], s1, s2, bit_depth)
+ * (reference semantics: sad_16b, xeve_sad.c:40-61).  cand_off = element offsets (dy * s2 + dx) of the
+ * candidates of one search round relative to the job's centre; ncand >= 1. */
+int xeve_hip_sad_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
+                      const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int flags, int32_t *out, void *stream);
+/* same job structure; ssd_16b (xeve_sad.c:275-297) and xeve_had (xeve_sad.c:1043-1140) */
+int xeve_hip_ssd_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
+                      const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int64_t *out, void *stream);
+int xeve_hip_satd_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
+                       const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int32_t *out, void *stream);
+/* diff[j][y][x] (dense w*h per job) = p1[..] - p2[..]   (diff_16b, xeve_sad.c:160-178) */
+int xeve_hip_diff_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
+                       int w, int h, int16_t *diff, void *stream);
+
+typedef struct xeve_hip_mc_job {
+    int32_t gmv_x, gmv_y; /* absolute position relative to `ref`, 1/16 pel luma, 1/32 pel chroma (xeve_mc.c:481-488) */
+    int32_t pred_off;     /* element offset of the output block inside `pred` */
+    int32_t frac;         /* bit0: horizontal filter, bit1: vertical filter -- the table index [dx!=0][dy!=0],
+                             which the reference derives from the UNCLIPPED mv (xeve_mc.h:96-104) */
+} xeve_hip_mc_job;
+/* xeve_mc_l_{00,n0,0n,nn} (xeve_mc.c:99-254); coef is a HOST pointer to the [16][8] table in use */
+int xeve_hip_mc_l_jobs(const xeve_hip_pel *ref, int s_ref, xeve_hip_pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
+                       int w, int h, int bit_depth, const int16_t (*coef)[8], void *stream);
+/* xeve_mc_c_{00,n0,0n,nn} (xeve_mc.c:259-381); coef is a HOST pointer to the [32][4] table in use */
+int xeve_hip_mc_c_jobs(const xeve_hip_pel *ref, int s_ref, xeve_hip_pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
+                       int w, int h, int bit_depth, const int16_t (*coef)[4], void *stream);
+/* dst = (a + b + 1) >> 1 over n dense samples (xeve_average_16b_no_clip, xeve_mc.c:449-463) */
+int xeve_hip_avg(const int16_t *a, const int16_t *b, int16_t *dst, int64_t n, void *stream);
+
+/* 2-D forward transform of nblk dense blocks, in place: xeve_trans (xeve_tq.c:396-404) */
+int xeve_hip_trans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream);
+/* 2-D inverse transform, in place: xeve_itrans (xeve_itdq.c:435-440) */
+int xeve_hip_itrans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream);
+/* plain quantisation (xeve_quant_nnz, rdoq == 0 branch, xeve_tq.c:704-727); nnz[b] = non-zero count; may be NULL */
+int xeve_hip_quant(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth,
+                   int32_t *nnz, void *stream);
+/* RDOQ all-zero pre-test (xeve_tq.c:666-699): coded[b] = 1 if the block survives, else 0 and the block is zeroed */
+int xeve_hip_rdoq_zero_test(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice,
+                            int bit_depth, int32_t *coded, void *stream);
+/* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
+int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
+/* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;
+ * is_coef[b] as in the reference (xeve_recon.c:34-57); is_coef == NULL means all 1 */
+int xeve_hip_recon(const int16_t *coef, const xeve_hip_pel *pred, const uint8_t *is_coef, int nblk, int cuw, int cuh,
+                   const int32_t *rec_off, int s_rec, xeve_hip_pel *rec, int bit_depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XEVE_HIP_H */

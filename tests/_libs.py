@@ -127,3 +127,46 @@ def ref():
 
 def ilog2(v):
     return int(v).bit_length() - 1
+
+
+class OracleTables:
+    """The oracle behind the same Python call interface as xeve_amd.tables.HipTables (checker side only)."""
+
+    def __init__(self):
+        self.O = oracle()
+
+    def sad(self, w, h, a, oa, b, ob, s1, s2, bd):
+        return self.O.xo_sad(w, h, ptr(a, oa), ptr(b, ob), s1, s2, bd)
+
+    def ssd(self, w, h, a, oa, b, ob, s1, s2, bd):
+        return self.O.xo_ssd(w, h, ptr(a, oa), ptr(b, ob), s1, s2, bd)
+
+    def satd(self, w, h, a, oa, b, ob, s1, s2, bd):
+        return self.O.xo_satd(w, h, ptr(a, oa), ptr(b, ob), s1, s2, bd)
+
+    def diff(self, w, h, a, oa, b, ob, s1, s2, s_diff, out, bd):
+        self.O.xo_diff(w, h, ptr(a, oa), ptr(b, ob), s1, s2, s_diff, ptr(out))
+
+    def mc_l(self, fx, fy, ref, gx, gy, s_ref, s_pred, pred, w, h, bd, coef):
+        self.O.xo_mc_l(fx, fy, ptr(ref), gx, gy, s_ref, s_pred, ptr(pred), w, h, bd, ptr(coef))
+
+    def mc_c(self, fx, fy, ref, gx, gy, s_ref, s_pred, pred, w, h, bd, coef):
+        self.O.xo_mc_c(fx, fy, ptr(ref), gx, gy, s_ref, s_pred, ptr(pred), w, h, bd, ptr(coef))
+
+    def avg(self, a, b, d, sa, sb, sd, w, h):
+        self.O.xo_avg(ptr(a), ptr(b), ptr(d), sa, sb, sd, w, h)
+
+    def tx(self, log2n, src, dst, shift, line, step):
+        self.O.xo_tx(log2n, ptr(src), ptr(dst), shift, line, step)
+
+    def itx(self, log2n, src, dst, shift, line, step):
+        self.O.xo_itx(log2n, ptr(src), ptr(dst), shift, line, step)
+
+    def trans(self, coef, lw, lh, bd):
+        self.O.xo_trans(ptr(coef), lw, lh, bd)
+
+    def itrans(self, coef, lw, lh, bd):
+        self.O.xo_itrans(ptr(coef), lw, lh, bd)
+
+    def recon(self, coef, pred, is_coef, cuw, cuh, s_rec, rec, bd):
+        self.O.xo_recon(ptr(coef), ptr(pred), is_coef, cuw, cuh, s_rec, ptr(rec), bd)

@@ -1,0 +1,246 @@
+// xeve_amd/csrc/mc.hip -- sub-pel motion-compensation interpolation for gfx950.
+//
+//   luma   8-tap, 1/16-pel positions   reference: xeve_mc_l_{00,n0,0n,nn}  src_base/xeve_mc.c:99-254
+//   chroma 4-tap, 1/32-pel positions   reference: xeve_mc_c_{00,n0,0n,nn}  src_base/xeve_mc.c:259-381
+//   average (bi-prediction)            reference: xeve_average_16b_no_clip src_base/xeve_mc.c:449-463
+//
+// Rounding rules that must be kept bit-exact (xeve_mc.h:36-62, xeve_mc.c:211-214):
+//   n0 / 0n : (sum + 0) >> 6, then clip to [0, 2^bd - 1]
+//   nn      : horizontal pass over h + taps - 1 rows, (sum + 0) >> shift1 stored as int16
+//             (shift1 = min(4, bd - 8)); vertical pass (sum + 2^(shift2-1)) >> shift2, clip
+//             (shift2 = max(8, 20 - bd)).
+//
+// One workgroup per job (one predicted block, or one tile of a whole-picture phase plane).  Every
+// thread produces SEG horizontally adjacent pels from two vector loads; the nn case stages the
+// horizontal pass in LDS ((h + taps - 1) x w int16, <= 9 KB) and reads it back column-aligned.
+#include <cstring>
+#include "xh_common.h"
+
+template <int TAPS> struct CoefTab {
+    int16_t c[(TAPS == 8 ? 16 : 32)][TAPS]; // passed by value in the kernarg segment (256 B)
+};
+
+template <int SEG> struct SegIO;
+template <> struct SegIO<8> {
+    typedef u32x4 vec;
+    static __device__ __forceinline__ vec ld(const pel *p) { return xh_ld8(p); }
+    static __device__ __forceinline__ void st(pel *p, vec v) { xh_st8(p, v); }
+};
+template <> struct SegIO<4> {
+    typedef u32x2 vec;
+    static __device__ __forceinline__ vec ld(const pel *p) { return xh_ld4(p); }
+    static __device__ __forceinline__ void st(pel *p, vec v) { xh_st4(p, v); }
+};
+
+template <int SEG, typename V> __device__ __forceinline__ void unpack(V v, int *dst)
+{
+#pragma unroll
+    for(int k = 0; k < SEG / 2; k++) {
+        dst[2 * k]     = xh_lo16(v[k]);
+        dst[2 * k + 1] = xh_hi16(v[k]);
+    }
+}
+template <int SEG> __device__ __forceinline__ typename SegIO<SEG>::vec pack(const int *src)
+{
+    typename SegIO<SEG>::vec v;
+#pragma unroll
+    for(int k = 0; k < SEG / 2; k++) v[k] = xh_pack16(src[2 * k], src[2 * k + 1]);
+    return v;
+}
+
+// horizontal FIR of SEG outputs starting at row pointer r (already moved back by TAPS/2-1 pels)
+template <int TAPS, int SEG> __device__ __forceinline__ void hfir(const pel *r, const int16_t *c, int *acc)
+{
+    int px[2 * SEG];
+    unpack<SEG>(SegIO<SEG>::ld(r), px);
+    unpack<SEG>(SegIO<SEG>::ld(r + SEG), px + SEG);
+#pragma unroll
+    for(int i = 0; i < SEG; i++) {
+        int a = 0;
+#pragma unroll
+        for(int t = 0; t < TAPS; t++) a += (int)c[t] * px[i + t];
+        acc[i] = a;
+    }
+}
+
+__device__ __forceinline__ int clipi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+template <int TAPS, int SEG>
+__global__ void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
+                     const xeve_hip_mc_job *__restrict__ jobs, int w, int h, int bit_depth, CoefTab<TAPS> tab)
+{
+    static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
+    extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // nn only: (h + TAPS - 1) * w
+    constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
+    const xeve_hip_mc_job jb = jobs[blockIdx.x];
+    const int ix = jb.gmv_x >> FS, iy = jb.gmv_y >> FS;
+    const int16_t *cx = tab.c[jb.gmv_x & FM], *cy = tab.c[jb.gmv_y & FM];
+    const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
+    const int  maxv = (1 << bit_depth) - 1, segs = w / SEG;
+    pel       *out  = pred + jb.pred_off;
+    const pel *src  = ref + (long)iy * s_ref + ix;
+
+    if(!hx && !vy) {
+        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
+            int y = u / segs, x0 = (u % segs) * SEG;
+            SegIO<SEG>::st(out + y * s_pred + x0, SegIO<SEG>::ld(src + y * s_ref + x0));
+        }
+        return;
+    }
+    if(hx && !vy) {
+        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
+            int y = u / segs, x0 = (u % segs) * SEG, acc[SEG];
+            hfir<TAPS, SEG>(src + y * s_ref + x0 - BACK, cx, acc);
+#pragma unroll
+            for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
+            SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
+        }
+        return;
+    }
+    if(!hx && vy) {
+        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
+            int y = u / segs, x0 = (u % segs) * SEG, acc[SEG] = {0};
+#pragma unroll
+            for(int t = 0; t < TAPS; t++) {
+                int px[SEG];
+                unpack<SEG>(SegIO<SEG>::ld(src + (y - BACK + t) * s_ref + x0), px);
+#pragma unroll
+                for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
+            }
+#pragma unroll
+            for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
+            SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
+        }
+        return;
+    }
+    const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4;
+    const int shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
+    const int round2 = 1 << (shift2 - 1);
+    const int rows   = h + TAPS - 1;
+    for(int u = threadIdx.x; u < rows * segs; u += blockDim.x) {
+        int y = u / segs, x0 = (u % segs) * SEG, acc[SEG];
+        hfir<TAPS, SEG>(src + (y - BACK) * s_ref + x0 - BACK, cx, acc);
+#pragma unroll
+        for(int i = 0; i < SEG; i++) acc[i] = (int)(int16_t)(acc[i] >> shift1);
+        *reinterpret_cast<typename SegIO<SEG>::vec *>(hbuf + y * w + x0) = pack<SEG>(acc);
+    }
+    __syncthreads();
+    for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
+        int y = u / segs, x0 = (u % segs) * SEG, acc[SEG] = {0};
+#pragma unroll
+        for(int t = 0; t < TAPS; t++) {
+            int px[SEG];
+            unpack<SEG>(*reinterpret_cast<const typename SegIO<SEG>::vec *>(hbuf + (y + t) * w + x0), px);
+#pragma unroll
+            for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
+        }
+#pragma unroll
+        for(int i = 0; i < SEG; i++) acc[i] = clipi((acc[i] + round2) >> shift2, maxv);
+        SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
+    }
+}
+
+// Fallback for widths that are not a multiple of 4 (or luma width 4): one thread per output pel.
+template <int TAPS>
+__global__ void k_mc_any(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
+                         const xeve_hip_mc_job *__restrict__ jobs, int w, int h, int bit_depth, CoefTab<TAPS> tab)
+{
+    constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
+    const xeve_hip_mc_job jb = jobs[blockIdx.x];
+    const int ix = jb.gmv_x >> FS, iy = jb.gmv_y >> FS;
+    const int16_t *cx = tab.c[jb.gmv_x & FM], *cy = tab.c[jb.gmv_y & FM];
+    const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
+    const int  maxv = (1 << bit_depth) - 1;
+    const int  shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
+    for(int u = threadIdx.x; u < w * h; u += blockDim.x) {
+        int y = u / w, x = u % w, v;
+        const pel *p = ref + (long)(iy + y) * s_ref + ix + x;
+        if(!hx && !vy) v = p[0];
+        else if(hx && !vy) {
+            int a = 0;
+            for(int t = 0; t < TAPS; t++) a += (int)cx[t] * p[t - BACK];
+            v = clipi(a >> 6, maxv);
+        }
+        else if(!hx && vy) {
+            int a = 0;
+            for(int t = 0; t < TAPS; t++) a += (int)cy[t] * p[(t - BACK) * s_ref];
+            v = clipi(a >> 6, maxv);
+        }
+        else {
+            int a = 0;
+            for(int t = 0; t < TAPS; t++) {
+                int hsum = 0;
+                for(int k = 0; k < TAPS; k++) hsum += (int)cx[k] * p[(t - BACK) * s_ref + k - BACK];
+                a += (int)cy[t] * (int)(int16_t)(hsum >> shift1);
+            }
+            v = clipi((a + (1 << (shift2 - 1))) >> shift2, maxv);
+        }
+        pred[jb.pred_off + y * s_pred + x] = (pel)v;
+    }
+}
+
+__global__ void k_avg(const int16_t *__restrict__ a, const int16_t *__restrict__ b, int16_t *__restrict__ d, long n)
+{
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if(i + 8 <= n) {
+        u32x4 va = xh_ld8(a + i), vb = xh_ld8(b + i), vd;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+            vd[k] = xh_pack16((xh_lo16(va[k]) + xh_lo16(vb[k]) + 1) >> 1, (xh_hi16(va[k]) + xh_hi16(vb[k]) + 1) >> 1);
+        xh_st8(d + i, vd);
+    }
+    else {
+        for(; i < n; i++) d[i] = (int16_t)(((int)a[i] + (int)b[i] + 1) >> 1);
+    }
+}
+
+template <int TAPS>
+static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs, int w, int h,
+                     int bit_depth, const int16_t *coef, hipStream_t st)
+{
+    XH_ENTER();
+    XH_REQUIRE(ref && pred && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
+    XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
+    if(njobs == 0) return XEVE_HIP_OK;
+    CoefTab<TAPS> tab;
+    memcpy(tab.c, coef, sizeof(tab.c));
+    const int    threads = (w * h <= 256) ? 64 : 256;
+    const size_t lds     = sizeof(int16_t) * (size_t)(h + TAPS - 1) * w;
+    bool done = false;
+    if(w % 8 == 0) {
+        k_mc<TAPS, 8><<<njobs, threads, lds, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+        done = true;
+    }
+    if constexpr(TAPS == 4) {
+        if(!done && w % 4 == 0) {
+            k_mc<4, 4><<<njobs, threads, lds, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+            done = true;
+        }
+    }
+    if(!done) k_mc_any<TAPS><<<njobs, 64, 0, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_mc_l_jobs(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
+                                  int w, int h, int bit_depth, const int16_t (*coef)[8], void *stream)
+{
+    return mc_launch<8>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
+}
+
+extern "C" int xeve_hip_mc_c_jobs(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
+                                  int w, int h, int bit_depth, const int16_t (*coef)[4], void *stream)
+{
+    return mc_launch<4>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
+}
+
+extern "C" int xeve_hip_avg(const int16_t *a, const int16_t *b, int16_t *dst, int64_t n, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(a && b && dst && n >= 0);
+    if(n == 0) return XEVE_HIP_OK;
+    const long threads = (n + 7) / 8;
+    k_avg<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a, b, dst, n);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

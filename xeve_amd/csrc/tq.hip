@@ -1,0 +1,304 @@
+// xeve_amd/csrc/tq.hip -- integer DCT (forward / inverse), quantisation, dequantisation, reconstruction.
+//
+//   forward 1-D   tx_pb{2..64}b        reference: src_base/xeve_tq.c:40-392     (partial butterflies)
+//   forward 2-D   xeve_trans           reference: src_base/xeve_tq.c:396-404
+//   inverse 1-D   xeve_itx_pb{2..64}b  reference: src_base/xeve_itdq.c:34-430
+//   inverse 2-D   xeve_itrans          reference: src_base/xeve_itdq.c:435-440
+//   quant         xeve_quant_nnz       reference: src_base/xeve_tq.c:651-727    (zero pre-test + plain branch)
+//   dequant       xeve_dquant/itdq_cu  reference: src_base/xeve_itdq.c:442-475
+//   recon         xeve_recon_blk       reference: src_base/xeve_recon.c:34-57
+//
+// The reference's partial butterflies are an exact integer factorisation of y = M x with the EVC
+// DCT-II matrix M (src_base/xeve_tbl.c:83-236), and pass 1 of the 2-D transforms uses shift 0, so a
+// 2-D transform is ONE exact integer double product followed by ONE rounding shift:
+//   forward:  C = (Mh * X * Mw^T + 2^(s-1)) >> s   (64-point: rows/cols >= 32 forced to 0)
+//   inverse:  X = clip16((Mw^T-side sum of clip32(Mh^T-side sum) + 2^(s-1)) >> s)
+// Any exact evaluation order is bit-identical; we evaluate the products directly.
+#include <cmath>
+#include "xh_common.h"
+
+// All six matrices, row-major [k][x], concatenated; offset of size 2^l is XH_TM_OFF(l).
+__device__ __constant__ int8_t c_tm[4 + 16 + 64 + 256 + 1024 + 4096];
+__host__ __device__ constexpr int xh_tm_off(int log2n) { return ((1 << (2 * log2n)) - 4) / 3; } // 0,4,20,84,340,1364
+
+// EVC integer DCT-II: M_N[k][x] = +-g[fold((2x+1) * k * 64/N mod 256)], g[j] = round(64*sqrt(2)*cos(j*pi/128)).
+int xh_tq_init()
+{
+    static int8_t tm[4 + 16 + 64 + 256 + 1024 + 4096];
+    int g[65];
+    g[0] = 64, g[64] = 0;
+    for(int j = 1; j < 64; j++) g[j] = (int)floor(64.0 * 1.4142135623730951 * cos(j * 3.14159265358979323846 / 128.0) + 0.5);
+    for(int l = 1; l <= 6; l++) {
+        const int n = 1 << l;
+        for(int k = 0; k < n; k++)
+            for(int x = 0; x < n; x++) {
+                int th = ((2 * x + 1) * k * (64 / n)) % 256, sg = 1;
+                if(th > 128) th = 256 - th;
+                if(th > 64) sg = -1, th = 128 - th;
+                tm[xh_tm_off(l) + k * n + x] = (int8_t)(sg * g[th]);
+            }
+    }
+    XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tm), tm, sizeof(tm)));
+    return XEVE_HIP_OK;
+}
+
+// ---- 1-D (table-layer granularity): one thread per output -------------------------------------------
+template <bool FWD>
+__global__ void k_tx1d(const void *__restrict__ src, void *__restrict__ dst, int log2n, int shift, int line, int step)
+{
+    const int n = 1 << log2n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n * line) return;
+    const int8_t *m = c_tm + xh_tm_off(log2n);
+    const int64_t add = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    int64_t acc = 0;
+    if(FWD) { // dst[k*line + j] = sum_x M[k][x] * src[j*n + x]
+        const int k = i / line, j = i % line;
+        if(!(n == 64 && k >= 32)) {
+            for(int x = 0; x < n; x++) {
+                int64_t v = step == 0 ? (int64_t)((const int16_t *)src)[j * n + x] : (int64_t)((const int32_t *)src)[j * n + x];
+                acc += (int64_t)m[k * n + x] * v;
+            }
+            acc = (acc + add) >> shift;
+        }
+        if(step == 0) ((int32_t *)dst)[i] = (int32_t)acc;
+        else ((int16_t *)dst)[i] = (int16_t)acc;
+    }
+    else { // dst[j*n + x] = clip(sum_k M[k][x] * src[k*line + j])
+        const int j = i / n, x = i % n;
+        for(int k = 0; k < n; k++) {
+            int64_t v = step == 0 ? (int64_t)((const int16_t *)src)[k * line + j] : (int64_t)((const int32_t *)src)[k * line + j];
+            acc += (int64_t)m[k * n + x] * v;
+        }
+        acc = (acc + add) >> shift;
+        if(step == 0) {
+            acc = acc < INT32_MIN ? INT32_MIN : (acc > INT32_MAX ? INT32_MAX : acc);
+            ((int32_t *)dst)[i] = (int32_t)acc;
+        }
+        else {
+            acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+            ((int16_t *)dst)[i] = (int16_t)acc;
+        }
+    }
+}
+
+// ---- 2-D, one workgroup per block, both passes through LDS (VALU path) ----------------------------
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_trans2d(int16_t *__restrict__ coef, int log2w, int log2h, int shift)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = 1 << log2w, h = 1 << log2h, n = w * h;
+    int32_t *T = reinterpret_cast<int32_t *>(smem);          // [kx][y]   (n int32)
+    int16_t *X = reinterpret_cast<int16_t *>(smem + 4 * n);  // input block (n int16)
+    int16_t *blk = coef + (size_t)blockIdx.x * n;
+    const int8_t *mw = c_tm + xh_tm_off(log2w), *mh = c_tm + xh_tm_off(log2h);
+    for(int i = threadIdx.x; i < n; i += blockDim.x) X[i] = blk[i];
+    __syncthreads();
+    const int64_t add = (int64_t)1 << (shift - 1);
+    if(FWD) {
+        for(int i = threadIdx.x; i < n; i += blockDim.x) { // T[kx][y] = sum_x Mw[kx][x] * X[y][x]
+            const int kx = i / h, y = i % h;
+            int acc = 0;
+            if(!(w == 64 && kx >= 32))
+                for(int x = 0; x < w; x++) acc += (int)mw[kx * w + x] * (int)X[y * w + x];
+            T[i] = acc;
+        }
+        __syncthreads();
+        for(int i = threadIdx.x; i < n; i += blockDim.x) { // C[ky][kx] = sum_y Mh[ky][y] * T[kx][y]
+            const int ky = i / w, kx = i % w;
+            int64_t acc = 0;
+            if(!(h == 64 && ky >= 32)) {
+                for(int y = 0; y < h; y++) acc += (int64_t)mh[ky * h + y] * (int64_t)T[kx * h + y];
+                acc = (acc + add) >> shift;
+            }
+            blk[i] = (int16_t)acc;
+        }
+    }
+    else {
+        for(int i = threadIdx.x; i < n; i += blockDim.x) { // T[kx][y] = sum_ky Mh[ky][y] * C[ky][kx]
+            const int kx = i / h, y = i % h;
+            int acc = 0;
+            for(int ky = 0; ky < h; ky++) acc += (int)mh[ky * h + y] * (int)X[ky * w + kx];
+            T[i] = acc;
+        }
+        __syncthreads();
+        for(int i = threadIdx.x; i < n; i += blockDim.x) { // X[y][x] = sum_kx Mw[kx][x] * T[kx][y]
+            const int y = i / w, x = i % w;
+            int64_t acc = 0;
+            for(int kx = 0; kx < w; kx++) acc += (int64_t)mw[kx * w + x] * (int64_t)T[kx * h + y];
+            acc = (acc + add) >> shift;
+            acc = acc < -32768 ? -32768 : (acc > 32767 ? 32767 : acc);
+            blk[i] = (int16_t)acc;
+        }
+    }
+}
+
+// ---- quantisation family: one workgroup per block -------------------------------------------------
+__device__ __forceinline__ int block_sum(int v, int *scratch)
+{
+    v = xh_group_sum<64>(v);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    int t = 0;
+    for(int i = 0; i < nw; i++) t += scratch[i];
+    return t;
+}
+
+__global__ void k_quant(int16_t *__restrict__ coef, int n, int scale, int shift, int offset, int32_t *__restrict__ nnz)
+{
+    __shared__ int scratch[4];
+    int16_t *blk = coef + (size_t)blockIdx.x * n;
+    int cnt = 0;
+    for(int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = blk[i], neg = c < 0;
+        int lev = (neg ? -c : c) * scale;
+        lev     = (int)(int16_t)((lev + offset) >> shift);
+        const int16_t q = (int16_t)(neg ? -lev : lev);
+        blk[i] = q;
+        cnt += q != 0;
+    }
+    if(nnz) {
+        cnt = block_sum(cnt, scratch);
+        if(threadIdx.x == 0) nnz[blockIdx.x] = cnt;
+    }
+}
+
+__global__ void k_rdoq_zero_test(int16_t *__restrict__ coef, int n, int64_t scale_ns, int64_t thr, int32_t *__restrict__ coded)
+{
+    __shared__ int scratch[4];
+    int16_t *blk = coef + (size_t)blockIdx.x * n;
+    int hit = 0;
+    for(int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = blk[i];
+        hit |= ((int64_t)(c < 0 ? -c : c) * scale_ns) >= thr;
+    }
+    hit = block_sum(hit, scratch);
+    if(!hit)
+        for(int i = threadIdx.x; i < n; i += blockDim.x) blk[i] = 0;
+    if(threadIdx.x == 0) coded[blockIdx.x] = hit != 0;
+}
+
+__global__ void k_dquant(int16_t *__restrict__ coef, long total, int64_t scale_ns, int offset, int shift)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= total) return;
+    int64_t lev = ((int64_t)coef[i] * scale_ns + offset) >> shift;
+    lev         = lev < -32768 ? -32768 : (lev > 32767 ? 32767 : lev);
+    coef[i]     = (int16_t)lev;
+}
+
+__global__ void k_recon(const int16_t *__restrict__ coef, const pel *__restrict__ pred, const uint8_t *__restrict__ is_coef,
+                        int cuw, int cuh, const int32_t *__restrict__ rec_off, int s_rec, pel *__restrict__ rec, int maxv)
+{
+    const int b = blockIdx.x, n = cuw * cuh;
+    const bool add = is_coef ? is_coef[b] != 0 : true;
+    pel *r = rec + rec_off[b];
+    for(int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / cuw, x = i % cuw;
+        // the reference forms coef + pred in an int16 (wraps) before clipping, xeve_recon.c:50-51
+        const int16_t t = add ? (int16_t)(coef[(size_t)b * n + i] + pred[(size_t)b * n + i]) : pred[(size_t)b * n + i];
+        r[y * s_rec + x] = (pel)(t < 0 ? 0 : (t > maxv ? maxv : t));
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+int xh_tx1d(bool fwd, const void *src, void *dst, int log2n, int shift, int line, int step, hipStream_t st)
+{
+    const int total = (1 << log2n) * line;
+    if(fwd) k_tx1d<true><<<(total + 255) / 256, 256, 0, st>>>(src, dst, log2n, shift, line, step);
+    else k_tx1d<false><<<(total + 255) / 256, 256, 0, st>>>(src, dst, log2n, shift, line, step);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+static int trans_common(bool fwd, int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, hipStream_t st)
+{
+    XH_ENTER();
+    XH_REQUIRE(coef && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && bit_depth >= 8 && bit_depth <= 16);
+    if(nblk == 0) return XEVE_HIP_OK;
+    const int n = 1 << (log2w + log2h);
+    const int threads = n >= 256 ? 256 : 64;
+    const size_t lds = (size_t)n * 6;
+    // forward: TX_SHIFT1 + TX_SHIFT2 (xeve_util.c:34-35); inverse: ITX_SHIFT1 + ITX_SHIFT2 (xeve_itdq.h:38-39)
+    const int shift = fwd ? (log2w - 1 + bit_depth - 8) + (log2h + 6) : 7 + (12 - (bit_depth - 8));
+    if(fwd) k_trans2d<true><<<nblk, threads, lds, st>>>(coef, log2w, log2h, shift);
+    else k_trans2d<false><<<nblk, threads, lds, st>>>(coef, log2w, log2h, shift);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_trans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream)
+{
+    return trans_common(true, coef, nblk, log2w, log2h, bit_depth, (hipStream_t)stream);
+}
+extern "C" int xeve_hip_itrans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream)
+{
+    return trans_common(false, coef, nblk, log2w, log2h, bit_depth, (hipStream_t)stream);
+}
+
+#define XH_Q_ARGS_OK()                                                                                               \
+    XH_ENTER();                                                                                                      \
+    XH_REQUIRE(coef && nblk >= 0 && log2w >= 1 && log2w <= 7 && log2h >= 1 && log2h <= 7 && bit_depth >= 8 && bit_depth <= 14); \
+    if(nblk == 0) return XEVE_HIP_OK
+
+extern "C" int xeve_hip_quant(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice,
+                              int bit_depth, int32_t *nnz, void *stream)
+{
+    XH_Q_ARGS_OK();
+    XH_REQUIRE(qp >= 0 && qp <= 63 && scale > 0 && scale < 65536);
+    // xeve_tq.c:716-718 with MAX_TX_DYNAMIC_RANGE 15, QUANT_SHIFT 14 (xeve_def.h:793-797)
+    const int log2_size = (log2w + log2h) >> 1;
+    const int shift     = 14 + (15 - bit_depth - log2_size) + qp / 6;
+    XH_REQUIRE(shift >= 9 && shift <= 30);
+    const int offset = (is_intra_slice ? 171 : 85) << (shift - 9);
+    const int n      = 1 << (log2w + log2h);
+    k_quant<<<nblk, n >= 256 ? 256 : 64, 0, (hipStream_t)stream>>>(coef, n, scale, shift, offset, nnz);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_rdoq_zero_test(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice,
+                                       int bit_depth, int32_t *coded, void *stream)
+{
+    XH_Q_ARGS_OK();
+    XH_REQUIRE(coded && qp >= 0 && qp <= 63 && scale > 0 && scale < 65536);
+    // xeve_tq.c:673-683
+    const int odd       = (log2w + log2h) & 1;
+    const int log2_size = (log2w + log2h) >> 1;
+    const int shift     = 14 + (15 - bit_depth - log2_size + (odd ? 7 : 0)) + qp / 6;
+    XH_REQUIRE(shift >= 9 && shift <= 40);
+    const int64_t offset = (int64_t)(is_intra_slice ? 201 : 153) << (shift - 9);
+    const int64_t thr    = ((int64_t)1 << shift) - offset;
+    const int     n      = 1 << (log2w + log2h);
+    k_rdoq_zero_test<<<nblk, n >= 256 ? 256 : 64, 0, (hipStream_t)stream>>>(coef, n, (int64_t)scale * (odd ? 181 : 1), thr, coded);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream)
+{
+    XH_Q_ARGS_OK();
+    XH_REQUIRE(scale > 0);
+    // itdq_cu, xeve_itdq.c:457-473 with QUANT_IQUANT_SHIFT 20, QUANT_SHIFT 14
+    const int odd       = (log2w + log2h) & 1;
+    const int log2_size = (log2w + log2h) >> 1;
+    const int shift     = (uint8_t)(20 - 14 - (15 - bit_depth - log2_size) + (odd ? 8 : 0));
+    const int offset    = shift == 0 ? 0 : 1 << (shift - 1);
+    const long total    = (long)nblk << (log2w + log2h);
+    k_dquant<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(coef, total, (int64_t)scale * (odd ? 181 : 1), offset, shift);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_recon(const int16_t *coef, const pel *pred, const uint8_t *is_coef, int nblk, int cuw, int cuh,
+                              const int32_t *rec_off, int s_rec, pel *rec, int bit_depth, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(coef && pred && rec_off && rec && nblk >= 0 && cuw >= 1 && cuh >= 1 && cuw <= 128 && cuh <= 128);
+    XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
+    if(nblk == 0) return XEVE_HIP_OK;
+    k_recon<<<nblk, cuw * cuh >= 256 ? 256 : 64, 0, (hipStream_t)stream>>>(coef, pred, is_coef, cuw, cuh, rec_off, s_rec, rec, (1 << bit_depth) - 1);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

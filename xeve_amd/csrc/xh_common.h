@@ -1,0 +1,83 @@
+// xeve_amd/csrc/xh_common.h -- shared by the HIP translation units of libxeve_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/xeve_hip.h"
+
+typedef int16_t pel;
+
+#define XH_WAVE 64
+
+// ---- error plumbing (abi.cpp) -------------------------------------------------------------
+void xh_set_error(const char *fmt, ...);
+bool xh_ready();
+
+#define XH_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if(e_ != hipSuccess) {                                                                     \
+            xh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return XEVE_HIP_ERR_DEVICE;                                                            \
+        }                                                                                          \
+    } while(0)
+
+#define XH_REQUIRE(cond)                                                         \
+    do {                                                                         \
+        if(!(cond)) {                                                            \
+            xh_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+            return XEVE_HIP_ERR_ARG;                                             \
+        }                                                                        \
+    } while(0)
+
+#define XH_ENTER()                                                   \
+    do {                                                             \
+        if(!xh_ready()) {                                            \
+            xh_set_error("xeve_hip_init() has not been called");     \
+            return XEVE_HIP_ERR_UNINIT;                              \
+        }                                                            \
+    } while(0)
+
+static inline int xh_ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
+static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+#ifdef __HIPCC__
+// ---- device helpers -------------------------------------------------------------------------
+// 16-byte vector of 8 pels that may sit at any 2-byte-aligned address (block rows inside a plane
+// start at arbitrary x).  gfx950 under amdhsa runs in unaligned-access mode, so this is ONE
+// global_load_dwordx4.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a2 __attribute__((aligned(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a2 __attribute__((aligned(2)));
+
+__device__ __forceinline__ u32x4 xh_ld8(const pel *p) { return *reinterpret_cast<const u32x4_a2 *>(p); }
+__device__ __forceinline__ u32x2 xh_ld4(const pel *p) { return *reinterpret_cast<const u32x2_a2 *>(p); }
+__device__ __forceinline__ void  xh_st8(pel *p, u32x4 v) { *reinterpret_cast<u32x4_a2 *>(p) = v; }
+__device__ __forceinline__ void  xh_st4(pel *p, u32x2 v) { *reinterpret_cast<u32x2_a2 *>(p) = v; }
+
+__device__ __forceinline__ int xh_lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int xh_hi16(uint32_t v) { return ((int)v) >> 16; }
+__device__ __forceinline__ uint32_t xh_pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+// DPP lane exchanges (wave64): the cross-lane step of every per-block reduction.
+#define XH_DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define XH_DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define XH_DPP_ROW_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8-lane group
+#define XH_DPP_ROW_MIRROR 0x140      // lane i <-> 15-i inside each 16-lane row
+template <int CTRL> __device__ __forceinline__ int xh_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// Sum over aligned groups of N lanes; every lane of the group receives the total.
+template <int N> __device__ __forceinline__ int xh_group_sum(int v)
+{
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "group size");
+    if(N >= 2) v += xh_dpp<XH_DPP_QUAD_XOR1>(v);
+    if(N >= 4) v += xh_dpp<XH_DPP_QUAD_XOR2>(v);
+    if(N >= 8) v += xh_dpp<XH_DPP_ROW_HALF_MIRROR>(v);
+    if(N >= 16) v += xh_dpp<XH_DPP_ROW_MIRROR>(v);
+    if(N >= 32) v += __shfl_xor(v, 16, 64);
+    if(N >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+#endif

@@ -1,0 +1,154 @@
+"""Batched device API of libxeve_hip.so on torch-owned HBM buffers (torch = device memory + streams only).
+
+Every function forwards device pointers, sizes and the CURRENT torch stream to the C-ABI
+(include/xeve_hip.h, section 2) and returns torch tensors living on the GPU.  No arithmetic happens in
+torch or on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+_COEF_L = None
+_COEF_C = None
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i16(t):
+    assert t.dtype == torch.int16 and t.is_cuda and t.is_contiguous()
+    return t
+
+
+def make_jobs(off1, off2, device):
+    """xeve_hip_job[n] as an int32 [n, 2] device tensor."""
+    j = np.stack([np.asarray(off1, np.int32), np.asarray(off2, np.int32)], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(j)).to(device)
+
+
+def make_mc_jobs(gmv_x, gmv_y, pred_off, frac, device):
+    j = np.stack([np.asarray(a, np.int32) for a in (gmv_x, gmv_y, pred_off, frac)], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(j)).to(device)
+
+
+def _dist(fn, out_dtype, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, extra=()):
+    L = _lib.load()
+    njobs, ncand = jobs.shape[0], cand_off.numel()
+    out = torch.empty((njobs, ncand), dtype=out_dtype, device=p1.device)
+    _lib.check(getattr(L, fn)(_ptr(_i16(p1)), s1, _ptr(_i16(p2)), s2, _ptr(jobs), njobs, _ptr(cand_off), ncand, w, h, bit_depth,
+                              *extra, _ptr(out), _stream()))
+    return out
+
+
+def sad_jobs(p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None):
+    if out is None:
+        return _dist("xeve_hip_sad_jobs", torch.int32, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, (1 if signed else 0,))
+    L = _lib.load()
+    _lib.check(L.xeve_hip_sad_jobs(_ptr(p1), s1, _ptr(p2), s2, _ptr(jobs), jobs.shape[0], _ptr(cand_off), cand_off.numel(), w, h,
+                                   bit_depth, 1 if signed else 0, _ptr(out), _stream()))
+    return out
+
+
+def ssd_jobs(p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth):
+    return _dist("xeve_hip_ssd_jobs", torch.int64, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth)
+
+
+def satd_jobs(p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth):
+    return _dist("xeve_hip_satd_jobs", torch.int32, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth)
+
+
+def diff_jobs(p1, s1, p2, s2, jobs, w, h, out=None):
+    L = _lib.load()
+    if out is None:
+        out = torch.empty((jobs.shape[0], h, w), dtype=torch.int16, device=p1.device)
+    _lib.check(L.xeve_hip_diff_jobs(_ptr(_i16(p1)), s1, _ptr(_i16(p2)), s2, _ptr(jobs), jobs.shape[0], w, h, _ptr(out), _stream()))
+    return out
+
+
+# Baseline interpolation filters (reference: src_base/xeve_mc.c:39-93): quarter-pel rows of the 1/16-pel luma
+# table and eighth-pel rows of the 1/32-pel chroma table; all other rows are zero.
+def baseline_coef_l():
+    global _COEF_L
+    if _COEF_L is None:
+        t = np.zeros((16, 8), np.int16)
+        t[0], t[4], t[8], t[12] = [0, 0, 0, 64, 0, 0, 0, 0], [0, 1, -5, 52, 20, -5, 1, 0], [0, 2, -10, 40, 40, -10, 2, 0], [0, 1, -5, 20, 52, -5, 1, 0]
+        _COEF_L = t
+    return _COEF_L
+
+
+def baseline_coef_c():
+    global _COEF_C
+    if _COEF_C is None:
+        t = np.zeros((32, 4), np.int16)
+        rows = [[0, 64, 0, 0], [-2, 58, 10, -2], [-4, 52, 20, -4], [-6, 46, 30, -6], [-8, 40, 40, -8], [-6, 30, 46, -6], [-4, 20, 52, -4], [-2, 10, 58, -2]]
+        for i, r in enumerate(rows):
+            t[4 * i] = r
+        _COEF_C = t
+    return _COEF_C
+
+
+def mc_jobs(luma, ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, coef=None):
+    L = _lib.load()
+    if coef is None:
+        coef = baseline_coef_l() if luma else baseline_coef_c()
+    fn = L.xeve_hip_mc_l_jobs if luma else L.xeve_hip_mc_c_jobs
+    _lib.check(fn(_ptr(_i16(ref)), s_ref, _ptr(_i16(pred)), s_pred, _ptr(jobs), jobs.shape[0], w, h, bit_depth,
+                  C.c_void_p(coef.ctypes.data), _stream()))
+    return pred
+
+
+def avg(a, b, out=None):
+    L = _lib.load()
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(L.xeve_hip_avg(_ptr(_i16(a)), _ptr(_i16(b)), _ptr(out), a.numel(), _stream()))
+    return out
+
+
+def trans(coef, log2w, log2h, bit_depth):
+    """in place on an int16 [nblk, h*w] tensor"""
+    _lib.check(_lib.load().xeve_hip_trans(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, bit_depth, _stream()))
+    return coef
+
+
+def itrans(coef, log2w, log2h, bit_depth):
+    _lib.check(_lib.load().xeve_hip_itrans(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, bit_depth, _stream()))
+    return coef
+
+
+def quant(coef, log2w, log2h, qp, scale, is_intra_slice, bit_depth, want_nnz=True):
+    nnz = torch.empty(coef.shape[0], dtype=torch.int32, device=coef.device) if want_nnz else None
+    _lib.check(_lib.load().xeve_hip_quant(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, qp, scale, int(is_intra_slice), bit_depth,
+                                          _ptr(nnz) if want_nnz else None, _stream()))
+    return nnz
+
+
+def rdoq_zero_test(coef, log2w, log2h, qp, scale, is_intra_slice, bit_depth):
+    coded = torch.empty(coef.shape[0], dtype=torch.int32, device=coef.device)
+    _lib.check(_lib.load().xeve_hip_rdoq_zero_test(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, qp, scale, int(is_intra_slice),
+                                                   bit_depth, _ptr(coded), _stream()))
+    return coded
+
+
+def dquant(coef, log2w, log2h, scale, bit_depth):
+    _lib.check(_lib.load().xeve_hip_dquant(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, scale, bit_depth, _stream()))
+    return coef
+
+
+def recon(coef, pred, is_coef, cuw, cuh, rec_off, s_rec, rec, bit_depth):
+    _lib.check(_lib.load().xeve_hip_recon(_ptr(_i16(coef)), _ptr(_i16(pred)), _ptr(is_coef) if is_coef is not None else None,
+                                          coef.shape[0], cuw, cuh, _ptr(rec_off), s_rec, _ptr(_i16(rec)), bit_depth, _stream()))
+    return rec
+
+
+# quantiser scale tables of the standard (reference: src_base/xeve_tq.c:37-38, xeve_tbl.c:237)
+QUANT_SCALE = ((26214, 23302, 20560, 18396, 16384, 14764), (26214, 23302, 20560, 18396, 16384, 14564))
+DQ_SCALE = (40, 45, 51, 57, 64, 71)

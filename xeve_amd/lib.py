@@ -1,0 +1,103 @@
+"""ctypes binding of libxeve_hip.so (C-ABI: include/xeve_hip.h).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxeve_hip.so")
+
+c_int, c_void_p, c_i64 = C.c_int, C.c_void_p, C.c_int64
+
+
+class XeveHipError(RuntimeError):
+    pass
+
+
+class Job(C.Structure):  # xeve_hip_job
+    _fields_ = [("off1", C.c_int32), ("off2", C.c_int32)]
+
+
+class McJob(C.Structure):  # xeve_hip_mc_job
+    _fields_ = [("gmv_x", C.c_int32), ("gmv_y", C.c_int32), ("pred_off", C.c_int32), ("frac", C.c_int32)]
+
+
+# reference: src_base/xeve_sad.h:41-45, xeve_mc.h:85-87, xeve_type.h:169-170
+FN_SAD = C.CFUNCTYPE(c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_SATD = FN_SAD
+FN_SSD = C.CFUNCTYPE(c_i64, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_DIFF = C.CFUNCTYPE(None, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int)
+FN_MC = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p)
+FN_AVG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int)
+FN_TXB = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_RECON = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int)
+
+# every symbol include/xeve_hip.h declares: name -> (restype, argtypes) for functions, ctypes array type for tables
+_JOB_ARGS = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int]
+FUNCTIONS = {
+    "xeve_hip_init": (c_int, [c_int]),
+    "xeve_hip_shutdown": (None, []),
+    "xeve_hip_last_error": (C.c_char_p, []),
+    "xeve_hip_table_calls": (C.c_uint64, []),
+    "xeve_hip_install_tables": (c_int, [c_void_p]),
+    "xeve_average_16b_no_clip_hip": (None, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "xeve_recon_blk_hip": (None, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
+    "xeve_hip_sad_jobs": (c_int, _JOB_ARGS + [c_int, c_void_p, c_void_p]),
+    "xeve_hip_ssd_jobs": (c_int, _JOB_ARGS + [c_void_p, c_void_p]),
+    "xeve_hip_satd_jobs": (c_int, _JOB_ARGS + [c_void_p, c_void_p]),
+    "xeve_hip_diff_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_mc_l_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_mc_c_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_avg": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "xeve_hip_trans": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "xeve_hip_itrans": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "xeve_hip_quant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_rdoq_zero_test": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_dquant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+}
+TABLES = {
+    "xeve_tbl_sad_16b_hip": FN_SAD * 64,
+    "xeve_tbl_ssd_16b_hip": FN_SSD * 64,
+    "xeve_tbl_diff_16b_hip": FN_DIFF * 64,
+    "xeve_tbl_satd_16b_hip": FN_SATD * 1,
+    "xeve_tbl_mc_l_hip": FN_MC * 4,
+    "xeve_tbl_mc_c_hip": FN_MC * 4,
+    "xeve_tbl_txb_hip": FN_TXB * 6,
+    "xeve_tbl_itxb_hip": FN_TXB * 6,
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libxeve_hip.so and bind every symbol of the C-ABI.  No GPU is touched here."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XeveHipError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C xeve_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in FUNCTIONS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        L.tables = {name: ty.in_dll(L, name) for name, ty in TABLES.items()}
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return (load().xeve_hip_last_error() or b"").decode()
+
+
+def check(rc):
+    if rc != 0:
+        raise XeveHipError("libxeve_hip rc=%d: %s" % (rc, last_error()))
+
+
+def init(device=0):
+    """Bind this process to GPU `device` (must be gfx950).  Raises if that is impossible."""
+    check(load().xeve_hip_init(int(device)))
+
+
+def table_calls():
+    return int(load().xeve_hip_table_calls())
