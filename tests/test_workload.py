@@ -1,0 +1,69 @@
+"""GPU suite: the bench workload (xeve_amd/workload.py) on a small picture, end results checked against the oracle --
+so the thing bench.py times is proven to compute the reference's arithmetic, not just to run."""
+import numpy as np
+import pytest
+
+from _libs import oracle, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hot_path_pass_small_picture_vs_oracle():
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd.workload import N_LIST, PAD_C, PAD_L, HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(256, 128, dev, seed=11)
+    wl.run(time_sad=True)
+    torch.cuda.synchronize()
+    assert set(wl.sad_time_ms()) == set(wl.sizes)
+    O = oracle()
+    bd, qp, s_l, s_c = wl.bd, wl.qp, wl.s_l, wl.s_c
+    qs, dqs = D.QUANT_SCALE[0][qp % 6], D.DQ_SCALE[qp % 6] << (qp // 6)
+    org = [p.cpu().numpy() for p in wl.org]
+    ref = [[p.cpu().numpy() for p in l] for l in wl.ref]
+    r = np.random.default_rng(0)
+    for S in wl.sizes:
+        lv = wl.lv[S]
+        Sc = S // 2
+        # A: the last integer-search round left its SADs in sad_out
+        jobs = lv["me_jobs"][-1].cpu().numpy()
+        li = (len(lv["me_jobs"]) - 1) % N_LIST
+        got = lv["sad_out"].cpu().numpy()
+        cand = wl.cand_l.cpu().numpy()
+        for j in r.choice(lv["n"], size=min(6, lv["n"]), replace=False):
+            for c in range(len(cand)):
+                assert got[j, c] == O.xo_sad(S, S, ptr(org[0], jobs[j, 0]), ptr(ref[li][0], jobs[j, 1] + int(cand[c])), s_l, s_l, bd)
+        # D: reconstruction planes = clip(IDCT(dequant(quant(DCT(org - bipred)))) + bipred), for Y, U, V
+        rec = [p.cpu().numpy() for p in lv["rec"]]
+        fj = [[t.cpu().numpy() for t in pair] for pair in lv["final_jobs"]]
+        for j in r.choice(lv["n"], size=min(6, lv["n"]), replace=False):
+            for c in range(3):
+                w, lg, st = (S, S.bit_length() - 1, s_l) if c == 0 else (Sc, S.bit_length() - 2, s_c)
+                pr = []
+                for l in range(N_LIST):
+                    gx, gy, _, frac = (int(v) for v in fj[l][0 if c == 0 else 1][j])
+                    p = np.zeros((w, w), np.int16)
+                    (O.xo_mc_l if c == 0 else O.xo_mc_c)(frac & 1, frac >> 1, ptr(ref[l][c]), gx, gy, st, w, ptr(p), w, w, bd,
+                                                          O.mc_l_coeff if c == 0 else O.mc_c_coeff)
+                    pr.append(p)
+                pred = np.zeros((w, w), np.int16)
+                O.xo_avg(ptr(pr[0]), ptr(pr[1]), ptr(pred), w, w, w, w, w)
+                off = int((lv["off_l"] if c == 0 else lv["off_c"])[j])
+                coef = np.zeros(w * w, np.int16)
+                O.xo_diff(w, w, ptr(org[c], off), ptr(pred), st, w, w, ptr(coef))
+                O.xo_trans(ptr(coef), lg, lg, bd)
+                if O.xo_rdoq_zero_test(ptr(coef), lg, lg, qp, qs, 0, bd):
+                    O.xo_quant(ptr(coef), lg, lg, qp, qs, 0, bd)
+                else:
+                    coef[:] = 0
+                O.xo_dquant(ptr(coef), lg, lg, dqs, bd)
+                O.xo_itrans(ptr(coef), lg, lg, bd)
+                e = np.zeros((w, w), np.int16)
+                O.xo_recon(ptr(coef), ptr(pred), 1, w, w, w, ptr(e), bd)
+                y0, x0 = off // st, off % st
+                assert np.array_equal(rec[c][y0:y0 + w, x0:x0 + w], e), (S, j, c)

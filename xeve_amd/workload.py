@@ -1,0 +1,192 @@
+"""The hot-path pass over ONE inter picture: the unit of work bench.py times and tests/test_workload.py checks.
+
+What the reference does per inter picture on this path -- for every quad-tree
+level S in {8,16,32,64} and every block of that size (mode_coding_tree visits all levels, xeve_mode.c:2007):
+
+  A. integer motion search, per reference list (2 lists): `me_ipel_diamond` rounds (xeve_pinter.c:363-551) --
+     a dense 5x5 grid plus 4/8/16-point diamonds of growing radius around a centre, ~80-100 SAD calls per
+     pass, repeated while the best moves (xeve_pinter.c:784-822).  Modelled as N_PASS = 3 passes of the
+     90-candidate pattern per list => 540 SAD calls per block, matching the probed 533..619 calls per block
+     per picture.
+  B. half-pel refinement, per list: 4 positions (preset medium, xeve_enc.c:2464), each = one luma
+     interpolation (n0, nn, 0n, nn) + one SAD against the dense prediction (xeve_pinter.c:593-627).
+  C. skip/merge analysis: 3 candidates (merge_num 3) x [MC Y,U,V + SSD Y,U,V] (xeve_pinter.c:1337-1458).
+  D. inter residual RDO of the winner (pinter_residue_rdo, xeve_pinter.c:906-1051): bi-predicted MC (two
+     lists + average) for Y,U,V; DIFF; forward transform; quantisation (RDOQ zero pre-test + plain quant);
+     dequantisation; inverse transform; reconstruction; SSD of prediction and of reconstruction.
+  E. intra gate: SATD of the block against the prediction (xeve_mode.c:1252).
+
+Everything runs through the batched C-ABI on planes resident in HBM.  Motion vectors are synthetic (uniform
+in +-MV_RANGE) because the sequential RDO that would choose them is outside this tier's scope; the amount and
+shape of arithmetic per picture is the reference's.
+"""
+import numpy as np
+import torch
+
+from . import device as D
+
+PAD_L, PAD_C = 144, 72  # picture plane padding (reference: src_base/xeve_def.h:380-381)
+SIZES = (8, 16, 32, 64)
+N_LIST, N_PASS = 2, 3
+HALF_PEL = ((-8, 0), (-8, 8), (0, 8), (8, 8))  # 1/16-pel offsets of the 4 medium-preset half-pel points (xeve_pinter.c:67-70)
+N_MERGE = 3
+MV_RANGE = 48  # integer-pel; keeps centre +- 64 diamond inside the 144-pel padding
+
+
+def diamond_pattern():
+    """(dx, dy) of one me_ipel_diamond pass: 5x5 dense, then steps 4 (4 pts), 8 (8 pts), 16/32/64 (16 pts), each
+    followed by a re-test of the centre (xeve_pinter.c:405-540)."""
+    c = [(dx, dy) for dy in range(-2, 3) for dx in range(-2, 3)]
+    for st in (4, 8, 16, 32, 64):
+        n = 4 if st == 4 else (8 if st == 8 else 16)
+        q = n // 4
+        for i in range(n):
+            a, b = i % q, i // q
+            dx, dy = [(a, -(q - a)), (q - a, a), (-a, q - a), (-(q - a), -a)][b]
+            c.append((dx * st // q, dy * st // q))
+        c.append((0, 0))
+    return c
+
+
+class HotPathPass:
+    def __init__(self, width, height, device, seed=4, bit_depth=10, qp=32, sizes=SIZES):
+        assert width % 64 == 0 and height % 8 == 0
+        self.W, self.H, self.dev, self.bd, self.qp, self.sizes = width, height, device, bit_depth, qp, tuple(sizes)
+        self.s_l, self.s_c = width + 2 * PAD_L, width // 2 + 2 * PAD_C
+        g = torch.Generator(device=device).manual_seed(seed)
+        mk = lambda h, s: torch.randint(0, 1 << bit_depth, (h, s), generator=g, device=device, dtype=torch.int16)
+        hl, hc = height + 2 * PAD_L, height // 2 + 2 * PAD_C
+        # synthetic i.i.d. uniform picture planes (8-bit source << 2 in the reference; here uniform 10-bit)
+        self.org = [mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)]
+        self.ref = [[mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)] for _ in range(N_LIST)]
+        self.pattern = diamond_pattern()
+        self.cand_l = torch.tensor([dy * self.s_l + dx for dx, dy in self.pattern], dtype=torch.int32, device=device)
+        self.zero_cand = torch.zeros(1, dtype=torch.int32, device=device)
+        rng = np.random.default_rng(seed)
+        self.lv = {}
+        for S in self.sizes:
+            self.lv[S] = self._level(S, rng)
+        self.sad_calls = sum(lv["n"] * (N_LIST * N_PASS * len(self.pattern) + N_LIST * len(HALF_PEL)) for lv in self.lv.values())
+        # algorithmic bytes of the SAD kernel, SURVEY.md 8(d): 4*w*h + 4 per table call
+        self.sad_bytes = {S: lv["n"] * (N_LIST * N_PASS * len(self.pattern) + N_LIST * len(HALF_PEL)) * (4 * S * S + 4)
+                          for S, lv in self.lv.items()}
+        self.sad_events = []
+
+    def _level(self, S, rng):
+        dev, W, H = self.dev, self.W, self.H
+        nx, ny = W // S, H // S
+        ys, xs = np.meshgrid(np.arange(ny) * S, np.arange(nx) * S, indexing="ij")
+        ys, xs = ys.ravel(), xs.ravel()
+        n = len(xs)
+        off_l = (PAD_L + ys) * self.s_l + PAD_L + xs
+        Sc = S // 2
+        off_c = (PAD_C + ys // 2) * self.s_c + PAD_C + xs // 2
+        lv = dict(n=n, S=S, off_l=torch.from_numpy(off_l.astype(np.int32)).to(dev), off_c=torch.from_numpy(off_c.astype(np.int32)).to(dev))
+        # A: search centres per list and pass
+        lv["me_jobs"] = []
+        for _ in range(N_LIST * N_PASS):
+            mvx, mvy = rng.integers(-MV_RANGE, MV_RANGE + 1, n), rng.integers(-MV_RANGE, MV_RANGE + 1, n)
+            lv["me_jobs"].append(D.make_jobs(off_l, off_l + mvy * self.s_l + mvx, dev))
+        lv["sad_out"] = torch.empty((n, len(self.pattern)), dtype=torch.int32, device=dev)
+        # B: half-pel interpolation jobs into a dense prediction buffer, then SAD org-vs-dense
+        dense = np.arange(n) * S * S
+        lv["pred_l"] = [torch.empty((n, S, S), dtype=torch.int16, device=dev) for _ in range(2)]
+        lv["pred_c"] = [torch.empty((n, Sc, Sc), dtype=torch.int16, device=dev) for _ in range(4)]
+        lv["dense_jobs"] = D.make_jobs(off_l, dense, dev)
+        lv["dense_jobs_c"] = D.make_jobs(off_c, np.arange(n) * Sc * Sc, dev)
+        lv["sad1"] = torch.empty((n, 1), dtype=torch.int32, device=dev)
+        lv["hp_jobs"] = []
+        for _ in range(N_LIST):
+            mvx, mvy = rng.integers(-MV_RANGE, MV_RANGE + 1, n), rng.integers(-MV_RANGE, MV_RANGE + 1, n)
+            per = []
+            for hx, hy in HALF_PEL:
+                gx, gy = (PAD_L + xs + mvx) * 16 + hx, (PAD_L + ys + mvy) * 16 + hy
+                frac = ((gx & 15) != 0).astype(np.int32) | (((gy & 15) != 0).astype(np.int32) << 1)
+                per.append(D.make_mc_jobs(gx, gy, dense, frac, dev))
+            lv["hp_jobs"].append(per)
+        # C/D: quarter-pel motion for merge candidates and the final bi-prediction (any of the 16 phases)
+        def qpel_jobs():
+            mvx, mvy = rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, n), rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, n)  # 1/4 pel
+            gx, gy = (PAD_L + xs) * 16 + mvx * 4, (PAD_L + ys) * 16 + mvy * 4
+            fl = ((gx & 15) != 0).astype(np.int32) | (((gy & 15) != 0).astype(np.int32) << 1)
+            # chroma position in 1/32 pel = luma 1/16-pel position relative to the chroma plane origin (xeve_mc.c:487-488)
+            cx, cy = (PAD_C + xs // 2) * 32 + mvx * 4, (PAD_C + ys // 2) * 32 + mvy * 4
+            fc = ((cx & 31) != 0).astype(np.int32) | (((cy & 31) != 0).astype(np.int32) << 1)
+            return (D.make_mc_jobs(gx, gy, dense, fl, dev), D.make_mc_jobs(cx, cy, np.arange(n) * Sc * Sc, fc, dev))
+        lv["merge_jobs"] = [qpel_jobs() for _ in range(N_MERGE)]
+        lv["final_jobs"] = [qpel_jobs() for _ in range(N_LIST)]
+        lv["resi"] = [torch.empty((n, S * S), dtype=torch.int16, device=dev)] + [torch.empty((n, Sc * Sc), dtype=torch.int16, device=dev) for _ in range(2)]
+        lv["coef"] = [torch.empty_like(t) for t in lv["resi"]]
+        lv["rec"] = [torch.zeros_like(p) for p in self.org]
+        return lv
+
+    # ------------------------------------------------------------------------------------------------------
+    def run(self, time_sad=False):
+        bd, qp, s_l, s_c = self.bd, self.qp, self.s_l, self.s_c
+        qs, dqs = D.QUANT_SCALE[0][qp % 6], D.DQ_SCALE[qp % 6] << (qp // 6)
+        org = self.org
+        for S in self.sizes:
+            lv = self.lv[S]
+            Sc, l2, l2c = S // 2, S.bit_length() - 1, S.bit_length() - 2
+            if time_sad:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            # A. integer motion search rounds
+            for i, jobs in enumerate(lv["me_jobs"]):
+                D.sad_jobs(org[0], s_l, self.ref[i % N_LIST][0], s_l, jobs, self.cand_l, S, S, bd, out=lv["sad_out"])
+            if time_sad:
+                e1.record()
+                self.sad_events.append((S, "me", e0, e1))
+            # B. half-pel refinement
+            for l in range(N_LIST):
+                for jobs in lv["hp_jobs"][l]:
+                    D.mc_jobs(True, self.ref[l][0], s_l, lv["pred_l"][0], S, jobs, S, S, bd)
+                    D.sad_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd, out=lv["sad1"])
+            # C. skip / merge candidates
+            for jl, jc in lv["merge_jobs"]:
+                D.mc_jobs(True, self.ref[0][0], s_l, lv["pred_l"][0], S, jl, S, S, bd)
+                D.ssd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
+                for c in (1, 2):
+                    D.mc_jobs(False, self.ref[0][c], s_c, lv["pred_c"][c - 1], Sc, jc, Sc, Sc, bd)
+                    D.ssd_jobs(org[c], s_c, lv["pred_c"][c - 1], Sc, lv["dense_jobs_c"], self.zero_cand, Sc, Sc, bd)
+            # D. residual RDO of the (bi-predicted) winner
+            for l in range(N_LIST):
+                jl, jc = lv["final_jobs"][l]
+                D.mc_jobs(True, self.ref[l][0], s_l, lv["pred_l"][l], S, jl, S, S, bd)
+                for c in (1, 2):
+                    D.mc_jobs(False, self.ref[l][c], s_c, lv["pred_c"][2 * l + c - 1], Sc, jc, Sc, Sc, bd)
+            D.avg(lv["pred_l"][0].view(-1), lv["pred_l"][1].view(-1), out=lv["pred_l"][0].view(-1))
+            for c in (1, 2):
+                D.avg(lv["pred_c"][c - 1].view(-1), lv["pred_c"][2 + c - 1].view(-1), out=lv["pred_c"][c - 1].view(-1))
+            for c in range(3):
+                w, lg, st = (S, l2, s_l) if c == 0 else (Sc, l2c, s_c)
+                pred = lv["pred_l"][0] if c == 0 else lv["pred_c"][c - 1]
+                dj = lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"]
+                D.diff_jobs(org[c], st, pred, w, dj, w, w, out=lv["resi"][c])
+                D.ssd_jobs(org[c], st, pred, w, dj, self.zero_cand, w, w, bd)
+                lv["coef"][c].copy_(lv["resi"][c])
+                D.trans(lv["coef"][c], lg, lg, bd)
+                D.rdoq_zero_test(lv["coef"][c], lg, lg, qp, qs, False, bd)
+                D.quant(lv["coef"][c], lg, lg, qp, qs, False, bd)
+                D.dquant(lv["coef"][c], lg, lg, dqs, bd)
+                D.itrans(lv["coef"][c], lg, lg, bd)
+                D.recon(lv["coef"][c], pred.view(lv["n"], -1), None, w, w, lv["off_l"] if c == 0 else lv["off_c"], st, lv["rec"][c], bd)
+                D.ssd_jobs(org[c], st, lv["rec"][c], st, D_same_jobs(lv, c), self.zero_cand, w, w, bd)
+            # E. intra gate
+            D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
+
+    def sad_time_ms(self):
+        """sum of HIP-event durations of the integer-search SAD launches recorded by run(time_sad=True), per size"""
+        torch.cuda.synchronize()
+        out = {}
+        for S, _, e0, e1 in self.sad_events:
+            out[S] = out.get(S, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def D_same_jobs(lv, c):
+    key = "same_jobs_%d" % c
+    if key not in lv:
+        off = lv["off_l"] if c == 0 else lv["off_c"]
+        lv[key] = torch.stack([off, off], dim=1).contiguous()
+    return lv[key]
