@@ -23,7 +23,7 @@ _ref = None
 
 def ptr(a, elem_off=0):
     """void* to element `elem_off` of a contiguous int16/int32 numpy array."""
-    return C.c_void_p(a.ctypes.data + elem_off * a.itemsize)
+    return C.c_void_p(int(a.ctypes.data) + int(elem_off) * int(a.itemsize))
 
 
 def oracle():
