@@ -1,0 +1,38 @@
+"""End-to-end helpers: seeded synthetic YUV (SURVEY.md 8d recipe) and runs of the reference app built in oracle/_ref."""
+import hashlib
+import os
+import random
+import subprocess
+
+from _libs import REF_APP, ROOT
+
+SHIM = os.path.join(ROOT, "oracle", "_ref", "libxeve_hip_shim.so")
+HIP_LIB = os.path.join(ROOT, "xeve_amd", "lib", "libxeve_hip.so")
+
+# name -> (width, height, frames, seed, extra CLI)   -- all with -m 1 (the bitstream depends on --threads)
+CASES = {
+    "cfg1_cif_allintra_fast": (352, 288, 8, 1234, ["--preset", "fast", "-I", "1", "-b", "0"]),
+    "tiny_ldb_fast": (128, 128, 2, 7, ["--preset", "fast", "-I", "0", "-b", "0"]),
+    "tiny_ra_medium": (128, 64, 4, 9, ["--preset", "medium", "-b", "1"]),
+    "tiny_closed_gop": (128, 64, 8, 10, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "1"]),
+}
+
+
+def make_yuv(path, w, h, frames, seed):
+    random.seed(seed)
+    with open(path, "wb") as f:
+        f.write(bytes(random.getrandbits(8) for _ in range(w * h * 3 // 2 * frames)))
+
+
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500):
+    cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
+    if seek is not None:
+        cmd += ["--seek", str(seek)]
+    env = dict(os.environ)
+    if hip:
+        env["LD_PRELOAD"] = SHIM
+        env["XEVE_HIP_LIB"] = HIP_LIB
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    data = open(out, "rb").read()
+    return hashlib.md5(data).hexdigest(), len(data), p.stderr

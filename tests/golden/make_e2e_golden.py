@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/e2e_v1.json: md5 + size of the bitstreams the UNMODIFIED reference app (oracle/_ref/xeveb_app,
+plain CPU dispatch) produces for the seeded synthetic clips of tests/_e2e.py.  Build container only."""
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from _e2e import CASES, make_yuv, run_app  # noqa: E402
+
+out = {}
+with tempfile.TemporaryDirectory() as d:
+    for name, (w, h, n, seed, extra) in CASES.items():
+        yuv = os.path.join(d, name + ".yuv")
+        make_yuv(yuv, w, h, n, seed)
+        md5, size, _ = run_app(yuv, os.path.join(d, name + ".evc"), w, h, n, extra)
+        out[name] = {"md5": md5, "bytes": size, "w": w, "h": h, "frames": n, "seed": seed, "cli": extra}
+        print(name, md5, size)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "e2e_v1.json"), "w"), indent=1)

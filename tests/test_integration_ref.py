@@ -1,0 +1,61 @@
+"""End-to-end parity: the UNMODIFIED reference encoder (oracle/_ref/xeveb_app + libxeveb_ref.so, compiled in place from
+/root/reference) must produce byte-identical bitstreams
+  (cpu)  to the committed goldens                                     -- pins the reference build itself;
+  (cpu)  when closed-GOP shards are encoded separately and concatenated -- the multi-GPU path, SURVEY.md 4(2);
+  (gpu)  when every hot-path dispatch table is replaced by libxeve_hip.so's tables (LD_PRELOAD interposer
+         oracle/ref_shim.c = the integration INTEGRATION.md describes), with xeve_pinter.c / xeve_mode.c unchanged.
+"""
+import json
+import os
+import re
+
+import pytest
+
+from _e2e import CASES, SHIM, make_yuv, run_app
+from _libs import REF_APP
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_v1.json")))
+needs_ref = pytest.mark.skipif(not (os.path.exists(REF_APP) and os.path.exists(SHIM)), reason="oracle/_ref not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_app_reproduces_golden_bitstreams(tmp_path, name):
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, _ = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra)
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+def test_closed_gop_shards_concatenate_byte_identically(tmp_path):
+    """xeve_amd.gop plans the shards; each is encoded by its own process; concatenation == monolithic encode."""
+    from xeve_amd import gop
+
+    w, h, n, seed, extra = CASES["tiny_closed_gop"]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    whole = str(tmp_path / "whole.evc")
+    run_app(yuv, whole, w, h, n, extra)
+    parts = b""
+    per_rank = [gop.shards_for_rank(n, 4, r, 2) for r in range(2)]
+    for sh in gop.concat_order(per_rank):
+        out = str(tmp_path / ("s%d.evc" % sh.gop))
+        run_app(yuv, out, w, h, sh.frames, extra, seek=sh.seek)
+        parts += open(out, "rb").read()
+    assert parts == open(whole, "rb").read()
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium"])
+def test_bitstream_identical_with_hip_tables_installed(tmp_path, name):
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000)
+    assert "HIP dispatch tables installed" in err
+    served = int(re.search(r"calls served by HIP: (\d+)", err).group(1))
+    assert served > 10000, err  # the encode really went through the HIP tables
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with HIP tables installed"
