@@ -111,6 +111,14 @@ typedef struct xeve_hip_job {
  * candidates of one search round relative to the job's centre; ncand >= 1. */
 int xeve_hip_sad_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
                       const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int flags, int32_t *out, void *stream);
+/* Alignment-optimised form.  On gfx950 a vector load from a non-dword-aligned address (odd pel position) runs at
+ * about a third of the aligned rate, and half of all search candidates sit at odd x.  The caller keeps, next to each
+ * reference plane, a copy shifted by one element (p2_shift1[i] == p2[i + 1], made once per picture with
+ * xeve_hip_plane_shift1); odd positions are then read from the copy at an even address.  Same results. */
+int xeve_hip_plane_shift1(const xeve_hip_pel *src, xeve_hip_pel *dst, int64_t n_elements, void *stream);
+int xeve_hip_sad_jobs_dual(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, const xeve_hip_pel *p2_shift1, int s2,
+                           const xeve_hip_job *jobs, int njobs, const int32_t *cand_off, int ncand, int w, int h, int bit_depth,
+                           int flags, int32_t *out, void *stream);
 /* same job structure; ssd_16b (xeve_sad.c:275-297) and xeve_had (xeve_sad.c:1043-1140) */
 int xeve_hip_ssd_jobs(const xeve_hip_pel *p1, int s1, const xeve_hip_pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
                       const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int64_t *out, void *stream);

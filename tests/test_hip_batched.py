@@ -66,6 +66,10 @@ def test_sad_jobs_vs_oracle(dev, size, signed):
     jobs = D.make_jobs(offs1, offs2, dev)
     got = D.sad_jobs(torch.from_numpy(org).to(dev), s, torch.from_numpy(ref).to(dev), s, jobs, torch.from_numpy(cand).to(dev),
                      size, size, bd, signed=signed).cpu().numpy()
+    d_ref = torch.from_numpy(ref).to(dev)
+    dual = D.sad_jobs_dual(torch.from_numpy(org).to(dev), s, d_ref, D.plane_shift1(d_ref), s, jobs, torch.from_numpy(cand).to(dev),
+                           size, size, bd, signed=signed).cpu().numpy()
+    assert np.array_equal(dual, got)  # alignment-optimised form: same numbers
     O = oracle()
     pick = r.choice(len(offs1), size=min(24, len(offs1)), replace=False)
     for j in pick:

@@ -41,15 +41,25 @@ template <bool SIGNED> __device__ __forceinline__ int sad8(u32x4 a, u32x4 b, int
     return acc;
 }
 
-template <int S, bool SIGNED>
-__global__ __launch_bounds__(256) void k_sad_sq(const pel *__restrict__ p1, int s1, const pel *__restrict__ p2, int s2,
+// SPLIT waves share one job (each takes every SPLIT-th group of candidates): large blocks have few jobs
+// per picture, so the candidates -- not the jobs -- must supply the waves that hide L2 latency.
+// UNROLL candidate groups are in flight per wave (independent loads and accumulators).
+//
+// Alignment: a vector load whose address is not dword-aligned (odd pel position) runs at roughly a
+// third of the aligned rate on gfx950 (tools/probe_align.py).  When the caller supplies `p2s`, a copy of
+// plane 2 shifted by one element (p2s[i] == p2[i + 1], xeve_hip_plane_shift1), odd positions are read
+// from it at the even address one element to the left, so EVERY load is dword-aligned.
+template <int S, bool SIGNED, int SPLIT, int UNROLL, int MODE>
+__global__ __launch_bounds__(256) void k_sad_sq(const pel *__restrict__ p1, int s1, const pel *__restrict__ p2,
+                                                const pel *__restrict__ p2s, int s2,
                                                 const xeve_hip_job *__restrict__ jobs, int njobs,
                                                 const int32_t *__restrict__ cand_off, int ncand, int shift,
                                                 int32_t *__restrict__ out)
 {
     using G        = Geo<S>;
     const int lane = threadIdx.x & 63;
-    const int job  = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int widx = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int job  = widx / SPLIT, part = widx % SPLIT;
     if(job >= njobs) return;
     const xeve_hip_job jb = jobs[job];
 
@@ -62,18 +72,51 @@ __global__ __launch_bounds__(256) void k_sad_sq(const pel *__restrict__ p1, int 
 #pragma unroll
     for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + jb.off1 + (row0 + p * G::RPP) * s1 + col);
 
-    const pel *base2 = p2 + jb.off2 + row0 * s2 + col;
+    const long base2 = (long)jb.off2 + row0 * s2 + col; // element index into plane 2
     int32_t   *o     = out + (size_t)job * ncand;
-    for(int c0 = 0; c0 < ncand; c0 += G::CPP) {
-        const int c   = c0 + slot;
-        int       acc = 0;
-        if(c < ncand) {
-            const pel *r = base2 + cand_off[c];
+    constexpr int STEP = G::CPP * SPLIT;
+    for(int c0 = part * G::CPP; c0 < ncand; c0 += STEP * UNROLL) {
+        int  acc[UNROLL];
+        bool ok[UNROLL];
+        long e[UNROLL];
 #pragma unroll
-            for(int p = 0; p < G::NP; p++) acc = sad8<SIGNED>(org[p], xh_ld8(r + p * G::RPP * s2), acc);
+        for(int u = 0; u < UNROLL; u++) {
+            const int c = c0 + u * STEP + slot;
+            ok[u]       = c < ncand;
+            e[u]        = base2 + cand_off[ok[u] ? c : 0];
         }
-        acc = xh_group_sum<G::GROUP>(acc);
-        if(gl == 0 && c < ncand) o[c] = acc >> shift;
+        u32x4 v[UNROLL][G::NP];
+#pragma unroll
+        for(int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for(int p = 0; p < G::NP; p++) {
+                const long ei = e[u] + (long)p * G::RPP * s2;
+                if(MODE == 1) { // dual plane
+                    const pel *r = (ei & 1) ? p2s + (ei - 1) : p2 + ei;
+                    v[u][p]      = xh_ld8(r);
+                }
+                else if(MODE == 2) { // aligned load + funnel shift; the 9th pel comes from the next lane of the row
+                    const int  odd = (int)(ei & 1);
+                    const pel *r   = p2 + (ei - odd);
+                    const u32x4 a  = xh_ld8(r);
+                    uint32_t nxt   = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+                    if((gl % G::LPR) == G::LPR - 1) nxt = *reinterpret_cast<const uint32_t *>(r + 8);
+                    const uint32_t sh = odd * 16;
+                    v[u][p].x = __builtin_amdgcn_alignbit(a.y, a.x, sh);
+                    v[u][p].y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
+                    v[u][p].z = __builtin_amdgcn_alignbit(a.w, a.z, sh);
+                    v[u][p].w = __builtin_amdgcn_alignbit(nxt, a.w, sh);
+                }
+                else v[u][p] = xh_ld8(p2 + ei);
+            }
+#pragma unroll
+        for(int u = 0; u < UNROLL; u++) {
+            acc[u] = 0;
+#pragma unroll
+            for(int p = 0; p < G::NP; p++) acc[u] = sad8<SIGNED>(org[p], v[u][p], acc[u]);
+            acc[u] = xh_group_sum<G::GROUP>(acc[u]);
+            if(gl == 0 && ok[u]) o[c0 + u * STEP + slot] = acc[u] >> shift;
+        }
     }
 }
 
@@ -335,25 +378,77 @@ static inline dim3 wave_grid(long waves) { return dim3((unsigned)((waves + 3) / 
     XH_REQUIRE(bit_depth >= 8 && bit_depth <= 16);                                                \
     if(njobs == 0) return XEVE_HIP_OK
 
+static int sad_jobs_impl(const pel *p1, int s1, const pel *p2, const pel *p2s, int s2, const xeve_hip_job *jobs, int njobs,
+                         const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int flags, int32_t *out,
+                         void *stream)
+{
+    XH_JOB_ARGS_OK();
+    XH_REQUIRE(p2s == nullptr || (((uintptr_t)p2 & 3) == 0 && ((uintptr_t)p2s & 3) == 0));
+    hipStream_t st    = (hipStream_t)stream;
+    const int   shift = bit_depth - 8;
+    const bool  sg    = (flags & XEVE_HIP_SRC1_SIGNED) != 0;
+    // how odd-pel (non-dword-aligned) reference rows are fetched: 0 plain, 1 dual plane (needs p2s), 2 aligned + funnel
+    // flags bits 4-5 (developer override): 0 auto, 1 dual, 2 funnel, 3 plain
+    int mode = (flags >> 4) & 3;
+    if(mode == 3) mode = 0;
+    else if(mode == 0) mode = p2s ? 1 : (((uintptr_t)p2 & 3) == 0 ? 2 : 0);
+    if(mode == 1 && !p2s) mode = 0;
+    if(mode == 2 && ((uintptr_t)p2 & 3) != 0) mode = 0;
+#define LAUNCH_SQ2(S, SPLIT, UNROLL, SG, MD)                                                                        \
+    k_sad_sq<S, SG, SPLIT, UNROLL, MD><<<wave_grid((long)njobs * SPLIT), 256, 0, st>>>(p1, s1, p2, p2s, s2, jobs, njobs, cand_off, ncand, shift, out)
+#define LAUNCH_SQ(S, SPLIT, UNROLL)                                                                               \
+    do {                                                                                                         \
+        if(sg) { if(mode == 1) LAUNCH_SQ2(S, SPLIT, UNROLL, true, 1); else if(mode == 2) LAUNCH_SQ2(S, SPLIT, UNROLL, true, 2); else LAUNCH_SQ2(S, SPLIT, UNROLL, true, 0); } \
+        else   { if(mode == 1) LAUNCH_SQ2(S, SPLIT, UNROLL, false, 1); else if(mode == 2) LAUNCH_SQ2(S, SPLIT, UNROLL, false, 2); else LAUNCH_SQ2(S, SPLIT, UNROLL, false, 0); } \
+    } while(0)
+    // one-candidate calls (the table layer, sub-pel rounds) take the unsplit form
+    const bool many = ncand >= 32;
+    if(w == h && w == 8) LAUNCH_SQ(8, 1, 4);
+    else if(w == h && w == 16) LAUNCH_SQ(16, 1, 4);
+    else if(w == h && w == 32) { if(many) LAUNCH_SQ(32, 2, 2); else LAUNCH_SQ(32, 1, 1); }
+    else if(w == h && w == 64) { if(many) LAUNCH_SQ(64, 4, 1); else LAUNCH_SQ(64, 1, 1); }
+    else k_sad_any<<<wave_grid((long)njobs * ncand), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, w, h, shift, out);
+#undef LAUNCH_SQ2
+#undef LAUNCH_SQ
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
 extern "C" int xeve_hip_sad_jobs(const pel *p1, int s1, const pel *p2, int s2, const xeve_hip_job *jobs, int njobs,
                                  const int32_t *cand_off, int ncand, int w, int h, int bit_depth, int flags, int32_t *out,
                                  void *stream)
 {
-    XH_JOB_ARGS_OK();
-    hipStream_t st    = (hipStream_t)stream;
-    const int   shift = bit_depth - 8;
-    const bool  sg    = (flags & XEVE_HIP_SRC1_SIGNED) != 0;
-#define LAUNCH_SQ(S)                                                                                             \
-    do {                                                                                                         \
-        if(sg) k_sad_sq<S, true><<<wave_grid(njobs), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, shift, out); \
-        else   k_sad_sq<S, false><<<wave_grid(njobs), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, shift, out); \
-    } while(0)
-    if(w == h && w == 8) LAUNCH_SQ(8);
-    else if(w == h && w == 16) LAUNCH_SQ(16);
-    else if(w == h && w == 32) LAUNCH_SQ(32);
-    else if(w == h && w == 64) LAUNCH_SQ(64);
-    else k_sad_any<<<wave_grid((long)njobs * ncand), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, w, h, shift, out);
-#undef LAUNCH_SQ
+    return sad_jobs_impl(p1, s1, p2, nullptr, s2, jobs, njobs, cand_off, ncand, w, h, bit_depth, flags, out, stream);
+}
+
+extern "C" int xeve_hip_sad_jobs_dual(const pel *p1, int s1, const pel *p2, const pel *p2_shift1, int s2,
+                                      const xeve_hip_job *jobs, int njobs, const int32_t *cand_off, int ncand, int w, int h,
+                                      int bit_depth, int flags, int32_t *out, void *stream)
+{
+    XH_REQUIRE(p2_shift1 != nullptr);
+    return sad_jobs_impl(p1, s1, p2, p2_shift1, s2, jobs, njobs, cand_off, ncand, w, h, bit_depth, flags, out, stream);
+}
+
+// dst[i] = src[i + 1] for i in [0, n - 1), dst[n - 1] = 0
+__global__ void k_shift1(const pel *__restrict__ src, pel *__restrict__ dst, long n)
+{
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if(i + 2 < n) {
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(src + i), b = *reinterpret_cast<const uint32_t *>(src + i + 2);
+        *reinterpret_cast<uint32_t *>(dst + i) = (a >> 16) | (b << 16);
+    }
+    else {
+        for(long k = i; k < n; k++) dst[k] = k + 1 < n ? src[k + 1] : (pel)0;
+    }
+}
+
+extern "C" int xeve_hip_plane_shift1(const pel *src, pel *dst, int64_t n, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(src && dst && n >= 0 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 3) == 0);
+    if(n == 0) return XEVE_HIP_OK;
+    const long threads = (n + 1) / 2;
+    k_shift1<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, (hipStream_t)stream>>>(src, dst, n);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -59,6 +59,15 @@ __device__ __forceinline__ int xh_lo16(uint32_t v) { return (int)(int16_t)(v & 0
 __device__ __forceinline__ int xh_hi16(uint32_t v) { return ((int)v) >> 16; }
 __device__ __forceinline__ uint32_t xh_pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
+// XCD-aware workgroup index: the dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Job lists are
+// in picture raster order, so handing XCD k the k-th CONTIGUOUS eighth of the grid keeps each XCD's private 4 MB L2
+// on one horizontal band of the planes instead of the whole picture.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xh_xcd_block(unsigned bid, unsigned nblk)
+{
+    const unsigned per = nblk >> 3, main = per << 3;
+    return bid < main ? (bid & 7u) * per + (bid >> 3) : bid;
+}
+
 // DPP lane exchanges (wave64): the cross-lane step of every per-block reduction.
 #define XH_DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
 #define XH_DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]

@@ -48,12 +48,29 @@ def _dist(fn, out_dtype, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, extra=
     return out
 
 
-def sad_jobs(p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None):
+def sad_jobs(p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None, mode=0):
+    flags = (1 if signed else 0) | (mode << 4)
     if out is None:
-        return _dist("xeve_hip_sad_jobs", torch.int32, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, (1 if signed else 0,))
+        return _dist("xeve_hip_sad_jobs", torch.int32, p1, s1, p2, s2, jobs, cand_off, w, h, bit_depth, (flags,))
     L = _lib.load()
     _lib.check(L.xeve_hip_sad_jobs(_ptr(p1), s1, _ptr(p2), s2, _ptr(jobs), jobs.shape[0], _ptr(cand_off), cand_off.numel(), w, h,
-                                   bit_depth, 1 if signed else 0, _ptr(out), _stream()))
+                                   bit_depth, flags, _ptr(out), _stream()))
+    return out
+
+
+def plane_shift1(plane):
+    """copy of a plane shifted by one element (out.view(-1)[i] == plane.view(-1)[i + 1]); see xeve_hip_sad_jobs_dual"""
+    out = torch.empty_like(plane)
+    _lib.check(_lib.load().xeve_hip_plane_shift1(_ptr(_i16(plane)), _ptr(out), plane.numel(), _stream()))
+    return out
+
+
+def sad_jobs_dual(p1, s1, p2, p2_shift1, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None):
+    if out is None:
+        out = torch.empty((jobs.shape[0], cand_off.numel()), dtype=torch.int32, device=p1.device)
+    _lib.check(_lib.load().xeve_hip_sad_jobs_dual(_ptr(_i16(p1)), s1, _ptr(_i16(p2)), _ptr(_i16(p2_shift1)), s2, _ptr(jobs), jobs.shape[0],
+                                                  _ptr(cand_off), cand_off.numel(), w, h, bit_depth, 1 if signed else 0, _ptr(out),
+                                                  _stream()))
     return out
 
 

@@ -41,6 +41,9 @@ FUNCTIONS = {
     "xeve_average_16b_no_clip_hip": (None, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "xeve_recon_blk_hip": (None, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "xeve_hip_sad_jobs": (c_int, _JOB_ARGS + [c_int, c_void_p, c_void_p]),
+    "xeve_hip_sad_jobs_dual": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p, c_void_p]),
+    "xeve_hip_plane_shift1": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "xeve_hip_ssd_jobs": (c_int, _JOB_ARGS + [c_void_p, c_void_p]),
     "xeve_hip_satd_jobs": (c_int, _JOB_ARGS + [c_void_p, c_void_p]),
     "xeve_hip_diff_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -30,6 +30,8 @@ SIZES = (8, 16, 32, 64)
 N_LIST, N_PASS = 2, 3
 HALF_PEL = ((-8, 0), (-8, 8), (0, 8), (8, 8))  # 1/16-pel offsets of the 4 medium-preset half-pel points (xeve_pinter.c:67-70)
 N_MERGE = 3
+import os
+SORT_JOBS = os.environ.get("XEVE_SORT_JOBS", "1") == "1"
 MV_RANGE = 48  # integer-pel; keeps centre +- 64 diamond inside the 144-pel padding
 
 
@@ -59,6 +61,8 @@ class HotPathPass:
         # synthetic i.i.d. uniform picture planes (8-bit source << 2 in the reference; here uniform 10-bit)
         self.org = [mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)]
         self.ref = [[mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)] for _ in range(N_LIST)]
+        # alignment copies of the luma reference planes (xeve_hip_sad_jobs_dual): made once per reference picture
+        self.ref_s1 = [D.plane_shift1(r[0]) for r in self.ref]
         self.pattern = diamond_pattern()
         self.cand_l = torch.tensor([dy * self.s_l + dx for dx, dy in self.pattern], dtype=torch.int32, device=device)
         self.zero_cand = torch.zeros(1, dtype=torch.int32, device=device)
@@ -86,7 +90,14 @@ class HotPathPass:
         lv["me_jobs"] = []
         for _ in range(N_LIST * N_PASS):
             mvx, mvy = rng.integers(-MV_RANGE, MV_RANGE + 1, n), rng.integers(-MV_RANGE, MV_RANGE + 1, n)
-            lv["me_jobs"].append(D.make_jobs(off_l, off_l + mvy * self.s_l + mvx, dev))
+            o1, o2 = off_l, off_l + mvy * self.s_l + mvx
+            if SORT_JOBS:
+                # launch order = raster order of the SEARCH CENTRES in (8-row, 64-pel = one 128-byte line) bins, so
+                # that the waves of a workgroup (consecutive jobs) read the same reference lines and hit in L1
+                cy, cx = o2 // self.s_l, o2 % self.s_l
+                order = np.lexsort((cx // 64, cy // 8))
+                o1, o2 = o1[order], o2[order]
+            lv["me_jobs"].append(D.make_jobs(o1, o2, dev))
         lv["sad_out"] = torch.empty((n, len(self.pattern)), dtype=torch.int32, device=dev)
         # B: half-pel interpolation jobs into a dense prediction buffer, then SAD org-vs-dense
         dense = np.arange(n) * S * S
@@ -133,7 +144,8 @@ class HotPathPass:
                 e0.record()
             # A. integer motion search rounds
             for i, jobs in enumerate(lv["me_jobs"]):
-                D.sad_jobs(org[0], s_l, self.ref[i % N_LIST][0], s_l, jobs, self.cand_l, S, S, bd, out=lv["sad_out"])
+                D.sad_jobs_dual(org[0], s_l, self.ref[i % N_LIST][0], self.ref_s1[i % N_LIST], s_l, jobs, self.cand_l, S, S, bd,
+                                out=lv["sad_out"])
             if time_sad:
                 e1.record()
                 self.sad_events.append((S, "me", e0, e1))
