@@ -267,3 +267,34 @@ def test_full_size_properties_4k(dev):
     # (5) avg(a, a) = a over the whole padded plane
     assert torch.equal(D.avg(org.view(-1), org.view(-1)), org.view(-1))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("lg", [5, 6])
+def test_dct_matrix_core_path_full_int16_range(dev, lg):
+    """32x32 / 64x64 run on v_mfma_i32_32x32x32_i8 with byte-split operands (xeve_amd/csrc/dct_mfma.hip): exact for
+    EVERY int16 input, including the extremes that stress the byte split and the offset-binary correction terms."""
+    import torch
+
+    from xeve_amd import device as D
+
+    r = np.random.default_rng(600 + lg)
+    O = oracle()
+    n = 1 << (2 * lg)
+    x = r.integers(-32768, 32768, size=(12, n), dtype=np.int16)
+    x[0], x[1], x[2], x[3] = 32767, -32768, 0, 1
+    x[4, ::2], x[4, 1::2] = 32767, -32768
+    x[5] = (np.arange(n) % 251 - 125) * 262  # smooth-ish, asymmetric: catches transposed layouts
+    d = torch.from_numpy(x).to(dev)
+    D.trans(d, lg, lg, 10)
+    got = d.cpu().numpy()
+    for b in range(12):
+        e = x[b].copy()
+        O.xo_trans(ptr(e), lg, lg, 10)
+        assert np.array_equal(got[b], e), ("fwd", lg, b)
+    d = torch.from_numpy(x).to(dev)
+    D.itrans(d, lg, lg, 10)
+    got = d.cpu().numpy()
+    for b in range(12):
+        e = x[b].copy()
+        O.xo_itrans(ptr(e), lg, lg, 10)
+        assert np.array_equal(got[b], e), ("inv", lg, b)

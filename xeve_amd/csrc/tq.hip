@@ -15,7 +15,13 @@
 //   inverse:  X = clip16((Mw^T-side sum of clip32(Mh^T-side sum) + 2^(s-1)) >> s)
 // Any exact evaluation order is bit-identical; we evaluate the products directly.
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include "xh_common.h"
+
+int xh_dct_mfma_init(const int8_t *m32, const int8_t *m64);
+int xh_dct_mfma(bool fwd, int16_t *coef, int nblk, int n, int shift, hipStream_t st);
+static bool g_use_mfma = true;
 
 // All six matrices, row-major [k][x], concatenated; offset of size 2^l is XH_TM_OFF(l).
 __device__ __constant__ int8_t c_tm[4 + 16 + 64 + 256 + 1024 + 4096];
@@ -39,7 +45,9 @@ int xh_tq_init()
             }
     }
     XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tm), tm, sizeof(tm)));
-    return XEVE_HIP_OK;
+    const char *e = getenv("XEVE_HIP_DCT"); // developer switch: "valu" forces the LDS/VALU path for 32/64 too
+    g_use_mfma    = !(e && strcmp(e, "valu") == 0);
+    return xh_dct_mfma_init(tm + xh_tm_off(5), tm + xh_tm_off(6));
 }
 
 // ---- 1-D (table-layer granularity): one thread per output -------------------------------------------
@@ -222,6 +230,8 @@ static int trans_common(bool fwd, int16_t *coef, int nblk, int log2w, int log2h,
     const size_t lds = (size_t)n * 6;
     // forward: TX_SHIFT1 + TX_SHIFT2 (xeve_util.c:34-35); inverse: ITX_SHIFT1 + ITX_SHIFT2 (xeve_itdq.h:38-39)
     const int shift = fwd ? (log2w - 1 + bit_depth - 8) + (log2h + 6) : 7 + (12 - (bit_depth - 8));
+    // 32x32 and 64x64: matrix cores (dct_mfma.hip); everything else: the LDS/VALU kernel
+    if(g_use_mfma && log2w == log2h && log2w >= 5) return xh_dct_mfma(fwd, coef, nblk, 1 << log2w, shift, st);
     if(fwd) k_trans2d<true><<<nblk, threads, lds, st>>>(coef, log2w, log2h, shift);
     else k_trans2d<false><<<nblk, threads, lds, st>>>(coef, log2w, log2h, shift);
     XH_HIP(hipGetLastError());
