@@ -13,6 +13,7 @@
 // One workgroup per job (one predicted block, or one tile of a whole-picture phase plane).  Every
 // thread produces SEG horizontally adjacent pels from two vector loads; the nn case stages the
 // horizontal pass in LDS ((h + taps - 1) x w int16, <= 9 KB) and reads it back column-aligned.
+#include <algorithm>
 #include <cstring>
 #include "xh_common.h"
 
@@ -65,78 +66,84 @@ template <int TAPS, int SEG> __device__ __forceinline__ void hfir(const pel *r, 
 
 __device__ __forceinline__ int clipi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
+// `jpb` jobs per workgroup: small blocks (8x8 luma = 8 row units) are packed so that all 256 threads have a unit.
+// Phase 1 (only for jobs with both filters): horizontal pass of h + TAPS - 1 rows into LDS.  Phase 2: every output
+// unit, by the job's own variant.  Jobs of one launch may mix variants (quarter-pel merge / final MC).
 template <int TAPS, int SEG>
-__global__ void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
-                     const xeve_hip_mc_job *__restrict__ jobs, int w, int h, int bit_depth, CoefTab<TAPS> tab)
+__global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
+                                            const xeve_hip_mc_job *__restrict__ jobs, int njobs, int jpb, int w, int h,
+                                            int bit_depth, CoefTab<TAPS> tab)
 {
     static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
-    extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // nn only: (h + TAPS - 1) * w
+    extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // jpb * (h + TAPS - 1) * w
     constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
-    const xeve_hip_mc_job jb = jobs[blockIdx.x];
-    const int ix = jb.gmv_x >> FS, iy = jb.gmv_y >> FS;
-    const int16_t *cx = tab.c[jb.gmv_x & FM], *cy = tab.c[jb.gmv_y & FM];
-    const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
-    const int  maxv = (1 << bit_depth) - 1, segs = w / SEG;
-    pel       *out  = pred + jb.pred_off;
-    const pel *src  = ref + (long)iy * s_ref + ix;
-
-    if(!hx && !vy) {
-        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
-            int y = u / segs, x0 = (u % segs) * SEG;
-            SegIO<SEG>::st(out + y * s_pred + x0, SegIO<SEG>::ld(src + y * s_ref + x0));
-        }
-        return;
-    }
-    if(hx && !vy) {
-        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
-            int y = u / segs, x0 = (u % segs) * SEG, acc[SEG];
-            hfir<TAPS, SEG>(src + y * s_ref + x0 - BACK, cx, acc);
-#pragma unroll
-            for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
-            SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
-        }
-        return;
-    }
-    if(!hx && vy) {
-        for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
-            int y = u / segs, x0 = (u % segs) * SEG, acc[SEG] = {0};
-#pragma unroll
-            for(int t = 0; t < TAPS; t++) {
-                int px[SEG];
-                unpack<SEG>(SegIO<SEG>::ld(src + (y - BACK + t) * s_ref + x0), px);
-#pragma unroll
-                for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
-            }
-#pragma unroll
-            for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
-            SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
-        }
-        return;
-    }
+    typedef typename SegIO<SEG>::vec vec;
+    const int j0 = xh_xcd_block(blockIdx.x, gridDim.x) * jpb;
+    const int nj = min(jpb, njobs - j0);
+    if(nj <= 0) return;
+    const int maxv = (1 << bit_depth) - 1, segs = w / SEG, rows = h + TAPS - 1;
     const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4;
     const int shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
     const int round2 = 1 << (shift2 - 1);
-    const int rows   = h + TAPS - 1;
-    for(int u = threadIdx.x; u < rows * segs; u += blockDim.x) {
-        int y = u / segs, x0 = (u % segs) * SEG, acc[SEG];
-        hfir<TAPS, SEG>(src + (y - BACK) * s_ref + x0 - BACK, cx, acc);
+
+    const int per1 = rows * segs;
+    for(int u = threadIdx.x; u < nj * per1; u += blockDim.x) {
+        const int jl = u / per1, r = u - jl * per1, y = r / segs, x0 = (r - y * segs) * SEG;
+        const xeve_hip_mc_job jb = jobs[j0 + jl];
+        if((jb.frac & 3) != 3) continue;
+        const pel *src = ref + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
+        int acc[SEG];
+        hfir<TAPS, SEG>(src, tab.c[jb.gmv_x & FM], acc);
 #pragma unroll
         for(int i = 0; i < SEG; i++) acc[i] = (int)(int16_t)(acc[i] >> shift1);
-        *reinterpret_cast<typename SegIO<SEG>::vec *>(hbuf + y * w + x0) = pack<SEG>(acc);
+        *reinterpret_cast<vec *>(hbuf + (jl * rows + y) * w + x0) = pack<SEG>(acc);
     }
     __syncthreads();
-    for(int u = threadIdx.x; u < h * segs; u += blockDim.x) {
-        int y = u / segs, x0 = (u % segs) * SEG, acc[SEG] = {0};
-#pragma unroll
-        for(int t = 0; t < TAPS; t++) {
-            int px[SEG];
-            unpack<SEG>(*reinterpret_cast<const typename SegIO<SEG>::vec *>(hbuf + (y + t) * w + x0), px);
-#pragma unroll
-            for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
+    const int per2 = h * segs;
+    for(int u = threadIdx.x; u < nj * per2; u += blockDim.x) {
+        const int jl = u / per2, r = u - jl * per2, y = r / segs, x0 = (r - y * segs) * SEG;
+        const xeve_hip_mc_job jb = jobs[j0 + jl];
+        const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
+        const pel *src = ref + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
+        pel *out = pred + jb.pred_off + y * s_pred + x0;
+        if(!hx && !vy) {
+            SegIO<SEG>::st(out, SegIO<SEG>::ld(src));
+            continue;
         }
+        int acc[SEG];
+        if(hx && !vy) {
+            hfir<TAPS, SEG>(src - BACK, tab.c[jb.gmv_x & FM], acc);
 #pragma unroll
-        for(int i = 0; i < SEG; i++) acc[i] = clipi((acc[i] + round2) >> shift2, maxv);
-        SegIO<SEG>::st(out + y * s_pred + x0, pack<SEG>(acc));
+            for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
+        }
+        else {
+            const int16_t *cy = tab.c[jb.gmv_y & FM];
+#pragma unroll
+            for(int i = 0; i < SEG; i++) acc[i] = 0;
+            if(!hx) {
+#pragma unroll
+                for(int t = 0; t < TAPS; t++) {
+                    int px[SEG];
+                    unpack<SEG>(SegIO<SEG>::ld(src + (t - BACK) * s_ref), px);
+#pragma unroll
+                    for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
+                }
+#pragma unroll
+                for(int i = 0; i < SEG; i++) acc[i] = clipi(acc[i] >> 6, maxv);
+            }
+            else {
+#pragma unroll
+                for(int t = 0; t < TAPS; t++) {
+                    int px[SEG];
+                    unpack<SEG>(*reinterpret_cast<const vec *>(hbuf + (jl * rows + y + t) * w + x0), px);
+#pragma unroll
+                    for(int i = 0; i < SEG; i++) acc[i] += (int)cy[t] * px[i];
+                }
+#pragma unroll
+                for(int i = 0; i < SEG; i++) acc[i] = clipi((acc[i] + round2) >> shift2, maxv);
+            }
+        }
+        SegIO<SEG>::st(out, pack<SEG>(acc));
     }
 }
 
@@ -204,16 +211,18 @@ static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xev
     if(njobs == 0) return XEVE_HIP_OK;
     CoefTab<TAPS> tab;
     memcpy(tab.c, coef, sizeof(tab.c));
-    const int    threads = (w * h <= 256) ? 64 : 256;
-    const size_t lds     = sizeof(int16_t) * (size_t)(h + TAPS - 1) * w;
     bool done = false;
     if(w % 8 == 0) {
-        k_mc<TAPS, 8><<<njobs, threads, lds, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+        const int jpb = std::max(1, 256 / (h * (w / 8)));
+        const size_t lds = sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w;
+        k_mc<TAPS, 8><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab);
         done = true;
     }
     if constexpr(TAPS == 4) {
         if(!done && w % 4 == 0) {
-            k_mc<4, 4><<<njobs, threads, lds, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+            const int jpb = std::max(1, 256 / (h * (w / 4)));
+            const size_t lds = sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w;
+            k_mc<4, 4><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab);
             done = true;
         }
     }

@@ -391,7 +391,7 @@ static int sad_jobs_impl(const pel *p1, int s1, const pel *p2, const pel *p2s, i
     // flags bits 4-5 (developer override): 0 auto, 1 dual, 2 funnel, 3 plain
     int mode = (flags >> 4) & 3;
     if(mode == 3) mode = 0;
-    else if(mode == 0) mode = p2s ? 1 : (((uintptr_t)p2 & 3) == 0 ? 2 : 0);
+    else if(mode == 0) mode = p2s ? 1 : 0; // measured: the funnel form never beats plain loads (tools/probe_align.py)
     if(mode == 1 && !p2s) mode = 0;
     if(mode == 2 && ((uintptr_t)p2 & 3) != 0) mode = 0;
 #define LAUNCH_SQ2(S, SPLIT, UNROLL, SG, MD)                                                                        \
