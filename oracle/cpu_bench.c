@@ -10,8 +10,9 @@
  *                     come from the oracle restatement;
  *   kind "port"     : the oracle restatement only (when oracle/_ref is absent).
  *
- * usage: cpu_bench <path/to/libxeveb_ref.so | port> <width> <height> <threads> [frac_percent]
- *   frac_percent: process only the first N % of the blocks of every level (bounded sample), default 100.
+ * usage: cpu_bench <path/to/libxeveb_ref.so | port> <width> <height> <threads> [frac_percent [reps]]
+ *   frac_percent: process only the first N % of the blocks of every level (bounded sample), default 100;
+ *   reps: repeat the pass that many times (to get a stable >= 10 s sample on many-core hosts), default 1.
  * prints one JSON object on stdout.
  */
 #define _GNU_SOURCE
@@ -110,7 +111,7 @@ static void bind(const char *path)
 #define N_PASS 3
 #define N_MERGE 3
 #define MV_RANGE 48
-static int   W, H, s_l, s_c, BD = 10, QP = 32, FRAC = 100;
+static int   W, H, s_l, s_c, BD = 10, QP = 32, FRAC = 100, REPS = 1;
 static pel  *org[3], *ref[N_LIST][3], *rec[3];
 static int   pat[128][2], npat;
 
@@ -166,6 +167,7 @@ static void *worker(void *vp)
     pl[0] = malloc(2 * 64 * 64), pl[1] = malloc(2 * 64 * 64);
     for(int i = 0; i < 4; i++) pc[i] = malloc(2 * 32 * 32);
     resi = malloc(2 * 64 * 64), coef = malloc(2 * 64 * 64);
+    for(int rep = 0; rep < REPS; rep++)
     for(int lg = 3; lg <= 6; lg++) {
         const int S = 1 << lg, Sc = S / 2, nx = W / S, ny = H / S, n = (int)((int64_t)nx * ny * FRAC / 100);
         for(int b = A->tid; b < n; b += A->nthr) {
@@ -236,6 +238,8 @@ int main(int argc, char **argv)
     W = atoi(argv[2]), H = atoi(argv[3]);
     int nthr = atoi(argv[4]);
     if(argc > 5) FRAC = atoi(argv[5]);
+    if(argc > 6) REPS = atoi(argv[6]);
+    if(REPS < 1) REPS = 1;
     if(nthr < 1) nthr = 1;
     s_l = W + 2 * PAD_L, s_c = W / 2 + 2 * PAD_C;
     make_pattern();
@@ -253,8 +257,8 @@ int main(int argc, char **argv)
     for(int i = 0; i < nthr; i++) { pthread_join(th[i], NULL); calls += args[i].sad_calls, sink += args[i].sink; }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-    printf("{\"seconds\": %.6f, \"kind\": \"%s\", \"threads\": %d, \"width\": %d, \"height\": %d, \"frac_percent\": %d, "
+    printf("{\"seconds\": %.6f, \"kind\": \"%s\", \"threads\": %d, \"width\": %d, \"height\": %d, \"frac_percent\": %d, \"reps\": %d, "
            "\"sad_calls\": %lld, \"checksum\": %lld}\n",
-           sec, T.is_ref ? "reference" : "port", nthr, W, H, FRAC, (long long)calls, (long long)sink);
+           sec, T.is_ref ? "reference" : "port", nthr, W, H, FRAC, REPS, (long long)calls, (long long)sink);
     return 0;
 }
