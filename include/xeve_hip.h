@@ -160,6 +160,20 @@ int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, in
 int xeve_hip_recon(const int16_t *coef, const xeve_hip_pel *pred, const uint8_t *is_coef, int nblk, int cuw, int cuh,
                    const int32_t *rec_off, int s_rec, xeve_hip_pel *rec, int bit_depth, void *stream);
 
+/* Fused residual chain of one inter CU component -- the arithmetic core of pinter_residue_rdo
+ * (src_base/xeve_pinter.c:962-1051) in ONE launch, with the block held on-chip between the steps:
+ *   resi = org - pred (xeve_diff_pred, xeve_mode.c:2737)      ssd[j][0] = SSD(org, pred)         (xeve_pinter.c:984)
+ *   coef = quant(DCT(resi))  (xeve_trans + RDOQ zero pre-test + plain quant, xeve_tq.c:396-404,666-727)
+ *   resi' = IDCT(dequant(coef))                                (itdq_cu, xeve_itdq.c:454-497)
+ *   rec = clip(resi' + pred)  (xeve_recon_blk)                 ssd[j][1] = SSD(org, rec)          (xeve_pinter.c:1037-1051)
+ * jobs[j].off1 = block position in `org` AND in `rec` (two planes of identical geometry, strides s_org / s_rec);
+ * jobs[j].off2 = position of the prediction block inside `pred` (stride s_pred; a dense [njobs][h*w] buffer has
+ * s_pred = w, off2 = j*w*h).  coef receives the quantised levels ([njobs][h*w]); nnz[j] their count.
+ * zero_test != 0 applies the RDOQ all-zero pre-test before quantising, as the presets with rdoq = 1 do. */
+int xeve_hip_residual_rdo(const xeve_hip_pel *org, int s_org, const xeve_hip_pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs,
+                          int log2w, int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
+                          int16_t *coef, xeve_hip_pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,3 +298,52 @@ def test_dct_matrix_core_path_full_int16_range(dev, lg):
         e = x[b].copy()
         O.xo_itrans(ptr(e), lg, lg, 10)
         assert np.array_equal(got[b], e), ("inv", lg, b)
+
+
+@pytest.mark.parametrize("lw,lh", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (2, 4), (5, 3), (6, 5)])
+def test_fused_residual_rdo_vs_oracle(dev, lw, lh):
+    """xeve_hip_residual_rdo = DIFF, SSD, DCT, zero pre-test, quant, dequant, IDCT, recon, SSD in one launch
+    (matrix cores for 32x32 / 64x64) against the oracle's step-by-step chain."""
+    import torch
+
+    from xeve_amd import device as D
+
+    r = np.random.default_rng(700 + lw * 8 + lh)
+    O = oracle()
+    w, h, bd = 1 << lw, 1 << lh, 10
+    n, nblk = w * h, 21
+    s = 4 * 64 + 32
+    org = r.integers(0, 1024, size=(6 * 64 + 16, s), dtype=np.int16)
+    pred = r.integers(0, 1024, size=(nblk, n), dtype=np.int16)
+    offs = [(8 + (b // 4) * h) * s + 8 + (b % 4) * w for b in range(nblk)]
+    for b in (0, 1, 2):  # near-perfect predictions: exercise the all-zero pre-test and small levels
+        blk = org.reshape(-1)[np.add.outer(np.arange(h) * s, np.arange(w)).ravel() + offs[b]]
+        pred[b] = np.clip(blk + r.integers(-b - 1, b + 2, size=n), 0, 1023)
+    for qp, intra, zt in ((27, 0, 1), (37, 1, 1), (32, 0, 0)):
+        d_org, d_pred = torch.from_numpy(org).to(dev), torch.from_numpy(pred).to(dev)
+        jobs = D.make_jobs(offs, np.arange(nblk) * n, dev)
+        coef = torch.full((nblk, n), 77, dtype=torch.int16, device=dev)
+        rec = torch.zeros_like(d_org)
+        nnz = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        ssd = torch.zeros((nblk, 2), dtype=torch.int64, device=dev)
+        D.residual_rdo(d_org, s, d_pred, w, jobs, lw, lh, bd, qp, intra, zt, coef, rec, s, nnz, ssd)
+        coef, rec, nnz, ssd = coef.cpu().numpy(), rec.cpu().numpy(), nnz.cpu().numpy(), ssd.cpu().numpy()
+        qs, dqs = D.QUANT_SCALE[0][qp % 6], D.DQ_SCALE[qp % 6] << (qp // 6)
+        for b in range(nblk):
+            c = np.zeros(n, np.int16)
+            O.xo_diff(w, h, ptr(org, offs[b]), ptr(pred, b * n), s, w, w, ptr(c))
+            assert ssd[b, 0] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(pred, b * n), s, w, bd)
+            O.xo_trans(ptr(c), lw, lh, bd)
+            if zt and not O.xo_rdoq_zero_test(ptr(c), lw, lh, qp, qs, intra, bd):
+                c[:] = 0
+                e_nnz = 0
+            else:
+                e_nnz = O.xo_quant(ptr(c), lw, lh, qp, qs, intra, bd)
+            assert nnz[b] == e_nnz and np.array_equal(coef[b], c), ("levels", lw, lh, qp, b)
+            O.xo_dquant(ptr(c), lw, lh, dqs, bd)
+            O.xo_itrans(ptr(c), lw, lh, bd)
+            e = np.zeros((h, s), np.int16)
+            O.xo_recon(ptr(c), ptr(pred, b * n), 1, w, h, s, ptr(e), bd)
+            y0, x0 = offs[b] // s, offs[b] % s
+            assert np.array_equal(rec[y0:y0 + h, x0:x0 + w], e[:, :w]), ("rec", lw, lh, qp, b)
+            assert ssd[b, 1] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(rec, offs[b]), s, s, bd)

@@ -31,7 +31,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // row-major [k][x] matrices and their transposes [x][k] for N = 32 and N = 64, plus row / column sums
 struct DctTabs {
     int8_t  m32[32 * 32], t32[32 * 32], m64[64 * 64], t64[64 * 64];
-    int32_t rs32[32], cs32[32], rs64[64], cs64[64];
+    int32_t rs32[32], cs32[32], rs64[64], cs64[64], cs64lo[64];
 };
 __device__ DctTabs g_dct;
 
@@ -49,6 +49,8 @@ int xh_dct_mfma_init(const int8_t *m32, const int8_t *m64)
     for(int i = 0; i < 64; i++) {
         h.rs64[i] = h.cs64[i] = 0;
         for(int j = 0; j < 64; j++) h.rs64[i] += m64[i * 64 + j], h.cs64[i] += m64[j * 64 + i];
+        h.cs64lo[i] = 0;
+        for(int j = 0; j < 32; j++) h.cs64lo[i] += m64[j * 64 + i];
     }
     XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dct), &h, sizeof(h)));
     return XEVE_HIP_OK;
@@ -204,6 +206,234 @@ int xh_dct_mfma(bool fwd, int16_t *coef, int nblk, int n, int shift, hipStream_t
         if(fwd) k_dct_mfma<64, true><<<grid, 256, 0, st>>>(coef, nblk, shift);
         else k_dct_mfma<64, false><<<grid, 256, 0, st>>>(coef, nblk, shift);
     }
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+
+// ======================================================================================================
+// Fused residual chain for 32x32 / 64x64 blocks (xeve_hip_residual_rdo): one wave per block.
+//   DIFF + SSD(pred) -> DCT (MFMA) -> zero pre-test + quant -> levels out -> dequant -> [LDS transpose of the 32x32
+//   coefficient corner] -> IDCT (MFMA, K = 32 only: a 64-point forward transform leaves nothing outside the corner)
+//   -> [LDS transpose back to row layout] -> recon + SSD(rec).
+// ======================================================================================================
+struct RdoParams {
+    int shift_fwd, shift_inv;               // transform rounding shifts
+    int q_scale, q_shift, q_offset;         // plain quant (xeve_tq.c:704-727)
+    long z_scale, z_thr;                    // RDOQ zero pre-test (xeve_tq.c:666-699); z_thr < 0 disables it
+    long dq_scale; int dq_shift, dq_offset; // dequant (xeve_itdq.c:442-475)
+    int ssd_shift, maxv;
+};
+
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return xh_pack16(xh_lo16(a) - xh_lo16(b), xh_hi16(a) - xh_hi16(b));
+}
+__device__ __forceinline__ long wave_sum64(long v)
+{
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)((unsigned long)v >> 32), m, 64);
+        v += (long)(((unsigned long)hi << 32) | lo);
+    }
+    return v;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, int s_org, const pel *__restrict__ pred, int s_pred,
+                                                  const xeve_hip_job *__restrict__ jobs, int njobs, RdoParams P,
+                                                  int16_t *__restrict__ coef, pel *__restrict__ rec, int s_rec,
+                                                  int32_t *__restrict__ nnz_out, int64_t *__restrict__ ssd_out)
+{
+    constexpr int NT = N / 32;
+    __shared__ __attribute__((aligned(16))) int16_t tile[4][32 * 32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l32 = lane & 31, kg = lane >> 5;
+    const int j = blockIdx.x * 4 + wave;
+    if(j >= njobs) return;
+    const xeve_hip_job jb = jobs[j];
+    int16_t *T = tile[wave];
+    const int8_t  *M  = N == 32 ? g_dct.m32 : g_dct.m64;
+    const int8_t  *MT = N == 32 ? g_dct.t32 : g_dct.t64;
+    const int32_t *RS = N == 32 ? g_dct.rs32 : g_dct.rs64, *CSP = N == 32 ? g_dct.cs32 : g_dct.cs64lo;
+
+    // ---- a/b: rows of org and pred in A layout, residual, SSD(org, pred)
+    u32x4 o[NT][NT][2], p[NT][NT][2];
+    v4i   alo[NT][NT], ahi[NT][NT];
+    long  ssd_pred = 0;
+#pragma unroll
+    for(int mt = 0; mt < NT; mt++)
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) {
+            const int y = 32 * mt + l32, x = 32 * ks + 16 * kg;
+            const pel *po = org + jb.off1 + (long)y * s_org + x, *pp = pred + jb.off2 + (long)y * s_pred + x;
+            u32x4 d[2];
+#pragma unroll
+            for(int hq = 0; hq < 2; hq++) {
+                o[mt][ks][hq] = xh_ld8(po + 8 * hq);
+                p[mt][ks][hq] = xh_ld8(pp + 8 * hq);
+#pragma unroll
+                for(int k = 0; k < 4; k++) {
+                    d[hq][k] = pk_sub(o[mt][ks][hq][k], p[mt][ks][hq][k]);
+                    const int d0 = xh_lo16(d[hq][k]), d1 = xh_hi16(d[hq][k]);
+                    ssd_pred += (uint32_t)((d0 * d0) >> P.ssd_shift) + (uint32_t)((d1 * d1) >> P.ssd_shift);
+                }
+            }
+            split16(d[0], d[1], alo[mt][ks], ahi[mt][ks]);
+        }
+
+    // ---- c: forward DCT, low-frequency 32x32 corner (the whole spectrum for N = 32)
+    v4i b1[NT];
+#pragma unroll
+    for(int ks = 0; ks < NT; ks++) b1[ks] = load16(M + l32 * N + 32 * ks + 16 * kg);
+    const int c1 = 128 * RS[l32];
+    v4i tb[NT][4];
+#pragma unroll
+    for(int mt = 0; mt < NT; mt++) {
+        v16i dl = {0}, dh = {0};
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) {
+            dl = MFMA(alo[mt][ks], b1[ks], dl);
+            dh = MFMA(ahi[mt][ks], b1[ks], dh);
+        }
+        v16i t;
+#pragma unroll
+        for(int i = 0; i < 16; i++) t[i] = (int)((uint32_t)dh[i] << 8) + dl[i] + c1;
+        split32(t, tb[mt]);
+    }
+    int cf[16]; // C[ky = frow(kg, r)][kx = l32]
+    {
+        v4i a2[NT];
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) a2[ks] = load_a2(M, N, l32, 32 * ks, kg);
+        v16i hacc = {0}, lacc = {0};
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) hacc = MFMA(a2[ks], tb[ks][3], hacc);
+        hacc = shl8(hacc);
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) hacc = MFMA(a2[ks], tb[ks][2], hacc);
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) lacc = MFMA(a2[ks], tb[ks][1], lacc);
+        lacc = shl8(lacc);
+#pragma unroll
+        for(int ks = 0; ks < NT; ks++) lacc = MFMA(a2[ks], tb[ks][0], lacc);
+        const long add = 1L << (P.shift_fwd - 1);
+#pragma unroll
+        for(int r = 0; r < 16; r++) {
+            const long v = (long)hacc[r] * 65536L + (long)lacc[r] + K3 * (long)RS[frow(kg, r)];
+            cf[r] = (int)(int16_t)((v + add) >> P.shift_fwd);
+        }
+    }
+    // ---- d: zero pre-test, quant, levels out, dequant
+    bool hit = true;
+    if(P.z_thr >= 0) {
+        bool h = false;
+#pragma unroll
+        for(int r = 0; r < 16; r++) h |= ((long)(cf[r] < 0 ? -cf[r] : cf[r]) * P.z_scale) >= P.z_thr;
+        hit = __any(h);
+    }
+    int cnt = 0;
+    int16_t *cb = coef + (size_t)j * N * N;
+#pragma unroll
+    for(int r = 0; r < 16; r++) {
+        int lev = 0;
+        if(hit) {
+            const int c = cf[r], neg = c < 0;
+            lev = (int)(int16_t)((((neg ? -c : c) * P.q_scale) + P.q_offset) >> P.q_shift);
+            lev = (int)(int16_t)(neg ? -lev : lev);
+        }
+        cnt += lev != 0;
+        cb[frow(kg, r) * N + l32] = (int16_t)lev;
+        long dq = ((long)lev * P.dq_scale + P.dq_offset) >> P.dq_shift;
+        dq      = dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq);
+        T[frow(kg, r) * 32 + l32] = (int16_t)dq; // e: transpose through LDS
+    }
+    if(N == 64) {
+        const u32x4 z = {0, 0, 0, 0};
+        for(int i = lane; i < 64 * 8; i += 64) {
+            const int row = i >> 3, ch = i & 7;
+            if(row >= 32 || ch >= 4) *reinterpret_cast<u32x4 *>(cb + row * 64 + ch * 8) = z;
+        }
+    }
+    cnt = xh_group_sum<64>(cnt);
+    __builtin_amdgcn_wave_barrier();
+    // ---- f: inverse DCT of the 32x32 coefficient tile (K = 32)
+    v4i clo, chi;
+    {
+        const int16_t *row = T + l32 * 32 + 16 * kg;
+        split16(*reinterpret_cast<const u32x4 *>(row), *reinterpret_cast<const u32x4 *>(row + 8), clo, chi);
+    }
+    __builtin_amdgcn_wave_barrier();
+    long ssd_rec = 0;
+#pragma unroll
+    for(int nt = 0; nt < NT; nt++) { // x tile
+        const v4i bi = load16(MT + (32 * nt + l32) * N + 16 * kg); // Mw[kx = 16kg + j][x]
+        v16i dl = {0}, dh = {0};
+        dl = MFMA(clo, bi, dl);
+        dh = MFMA(chi, bi, dh);
+        const int ci = 128 * CSP[32 * nt + l32];
+        v16i u;
+#pragma unroll
+        for(int i = 0; i < 16; i++) u[i] = (int)((uint32_t)dh[i] << 8) + dl[i] + ci;
+        v4i ub[4];
+        split32(u, ub);
+#pragma unroll
+        for(int ot = 0; ot < NT; ot++) { // y tile
+            const v4i a2 = load_a2(MT, N, 32 * ot + l32, 0, kg); // Mh[ky = f(kg, j)][y]
+            v16i hacc = {0}, lacc = {0};
+            hacc = MFMA(a2, ub[3], hacc);
+            hacc = shl8(hacc);
+            hacc = MFMA(a2, ub[2], hacc);
+            lacc = MFMA(a2, ub[1], lacc);
+            lacc = shl8(lacc);
+            lacc = MFMA(a2, ub[0], lacc);
+            const long add = 1L << (P.shift_inv - 1);
+            // ---- g: residual tile (lane = x, regs = y) back to row layout through LDS, then recon + SSD(rec)
+#pragma unroll
+            for(int r = 0; r < 16; r++) {
+                long v = (long)hacc[r] * 65536L + (long)lacc[r] + K3 * (long)CSP[32 * ot + frow(kg, r)];
+                v      = (v + add) >> P.shift_inv;
+                v      = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+                T[frow(kg, r) * 32 + l32] = (int16_t)v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int16_t *row = T + l32 * 32 + 16 * kg;
+            const u32x4 r0 = *reinterpret_cast<const u32x4 *>(row), r1 = *reinterpret_cast<const u32x4 *>(row + 8);
+            __builtin_amdgcn_wave_barrier();
+            pel *pr = rec + jb.off1 + (long)(32 * ot + l32) * s_rec + 32 * nt + 16 * kg;
+#pragma unroll
+            for(int hq = 0; hq < 2; hq++) {
+                const u32x4 rr = hq ? r1 : r0;
+                u32x4 out;
+#pragma unroll
+                for(int k = 0; k < 4; k++) {
+                    const uint32_t pw = p[ot][nt][hq][k], ow = o[ot][nt][hq][k];
+                    int t0 = (int)(int16_t)(xh_lo16(rr[k]) + xh_lo16(pw)), t1 = (int)(int16_t)(xh_hi16(rr[k]) + xh_hi16(pw));
+                    t0 = t0 < 0 ? 0 : (t0 > P.maxv ? P.maxv : t0);
+                    t1 = t1 < 0 ? 0 : (t1 > P.maxv ? P.maxv : t1);
+                    out[k] = xh_pack16(t0, t1);
+                    const int e0 = xh_lo16(ow) - t0, e1 = xh_hi16(ow) - t1;
+                    ssd_rec += (uint32_t)((e0 * e0) >> P.ssd_shift) + (uint32_t)((e1 * e1) >> P.ssd_shift);
+                }
+                xh_st8(pr + 8 * hq, out);
+            }
+        }
+    }
+    ssd_pred = wave_sum64(ssd_pred);
+    ssd_rec  = wave_sum64(ssd_rec);
+    if(lane == 0) {
+        nnz_out[j]         = cnt;
+        ssd_out[2 * j]     = ssd_pred;
+        ssd_out[2 * j + 1] = ssd_rec;
+    }
+}
+
+int xh_rdo_mfma(int n, const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, const void *params,
+                int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st)
+{
+    const RdoParams P = *static_cast<const RdoParams *>(params);
+    const dim3 grid((njobs + 3) / 4);
+    if(n == 32) k_rdo_mfma<32><<<grid, 256, 0, st>>>(org, s_org, pred, s_pred, jobs, njobs, P, coef, rec, s_rec, nnz, ssd);
+    else k_rdo_mfma<64><<<grid, 256, 0, st>>>(org, s_org, pred, s_pred, jobs, njobs, P, coef, rec, s_rec, nnz, ssd);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -312,3 +312,171 @@ extern "C" int xeve_hip_recon(const int16_t *coef, const pel *pred, const uint8_
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+
+// =========================================================================================================
+// Fused residual chain (xeve_hip_residual_rdo), LDS/VALU form: any w, h in 2..64.  A workgroup of 256 threads
+// holds 256/n blocks (n = w*h <= 256) or one block; every step of pinter_residue_rdo's arithmetic core runs
+// on the block while it sits in LDS.  32x32 / 64x64 go to the matrix-core form in dct_mfma.hip instead.
+// =========================================================================================================
+struct RdoParams { // must match dct_mfma.hip
+    int shift_fwd, shift_inv;
+    int q_scale, q_shift, q_offset;
+    long z_scale, z_thr;
+    long dq_scale; int dq_shift, dq_offset;
+    int ssd_shift, maxv;
+};
+int xh_rdo_mfma(int n, const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, const void *params,
+                int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st);
+
+__global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, int s_org, const pel *__restrict__ pred, int s_pred,
+                                                  const xeve_hip_job *__restrict__ jobs, int njobs, int log2w, int log2h, RdoParams P,
+                                                  int16_t *__restrict__ coef, pel *__restrict__ rec, int s_rec,
+                                                  int32_t *__restrict__ nnz_out, int64_t *__restrict__ ssd_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = 1 << log2w, h = 1 << log2h, n = w * h;
+    const int tpb = n < 256 ? n : 256, bpw = 256 / tpb;
+    const int bl = threadIdx.x / tpb, t = threadIdx.x - bl * tpb;
+    const int j  = blockIdx.x * bpw + bl;
+    const bool live = j < njobs;
+    int32_t *X  = reinterpret_cast<int32_t *>(smem) + (size_t)bl * 2 * n;
+    int32_t *Tm = X + n;
+    unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(smem + (size_t)bpw * 8 * n) + 2 * bl; // [ssd_pred, ssd_rec]
+    int *acc32 = reinterpret_cast<int *>(smem + (size_t)bpw * 8 * n + (size_t)bpw * 16) + 2 * bl;              // [zero-test hit, nnz]
+    const int8_t *mw = c_tm + xh_tm_off(log2w), *mh = c_tm + xh_tm_off(log2h);
+    const xeve_hip_job jb = live ? jobs[j] : xeve_hip_job{0, 0};
+    if(t == 0) acc64[0] = acc64[1] = 0, acc32[0] = acc32[1] = 0;
+    __syncthreads();
+    // 1. residual + SSD(org, pred)
+    if(live) {
+        unsigned long long s = 0;
+        for(int i = t; i < n; i += tpb) {
+            const int y = i >> log2w, x = i & (w - 1);
+            const int d = (int)org[jb.off1 + y * s_org + x] - (int)pred[jb.off2 + y * s_pred + x];
+            X[i] = d;
+            s += (unsigned)((d * d) >> P.ssd_shift);
+        }
+        atomicAdd(&acc64[0], s);
+    }
+    __syncthreads();
+    // 2. forward pass 1: Tm[kx][y] = sum_x Mw[kx][x] X[y][x]
+    if(live)
+        for(int i = t; i < n; i += tpb) {
+            const int kx = i >> log2h, y = i & (h - 1);
+            int a = 0;
+            if(!(w == 64 && kx >= 32))
+                for(int x = 0; x < w; x++) a += (int)mw[kx * w + x] * X[y * w + x];
+            Tm[i] = a;
+        }
+    __syncthreads();
+    // 3. forward pass 2 + zero pre-test: X[ky][kx] = coefficient
+    if(live) {
+        const int64_t add = (int64_t)1 << (P.shift_fwd - 1);
+        int hit = 0;
+        for(int i = t; i < n; i += tpb) {
+            const int ky = i >> log2w, kx = i & (w - 1);
+            int64_t a = 0;
+            if(!(h == 64 && ky >= 32)) {
+                for(int y = 0; y < h; y++) a += (int64_t)mh[ky * h + y] * (int64_t)Tm[kx * h + y];
+                a = (a + add) >> P.shift_fwd;
+            }
+            const int c = (int)(int16_t)a;
+            X[i] = c;
+            hit |= ((int64_t)(c < 0 ? -c : c) * P.z_scale) >= P.z_thr;
+        }
+        if(P.z_thr < 0) hit = 1;
+        if(hit) atomicOr(&acc32[0], 1);
+    }
+    __syncthreads();
+    // 4. quant, levels out, dequant
+    if(live) {
+        const bool hit = acc32[0] != 0;
+        int cnt = 0;
+        for(int i = t; i < n; i += tpb) {
+            int lev = 0;
+            if(hit) {
+                const int c = X[i], neg = c < 0;
+                lev = (int)(int16_t)((((neg ? -c : c) * P.q_scale) + P.q_offset) >> P.q_shift);
+                lev = (int)(int16_t)(neg ? -lev : lev);
+            }
+            cnt += lev != 0;
+            coef[(size_t)j * n + i] = (int16_t)lev;
+            int64_t dq = ((int64_t)lev * P.dq_scale + P.dq_offset) >> P.dq_shift;
+            X[i] = (int)(dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq));
+        }
+        if(cnt) atomicAdd(&acc32[1], cnt);
+    }
+    __syncthreads();
+    // 5. inverse pass 1: Tm[kx][y] = sum_ky Mh[ky][y] C[ky][kx]
+    if(live)
+        for(int i = t; i < n; i += tpb) {
+            const int kx = i >> log2h, y = i & (h - 1);
+            int a = 0;
+            for(int ky = 0; ky < h; ky++) a += (int)mh[ky * h + y] * X[ky * w + kx];
+            Tm[i] = a;
+        }
+    __syncthreads();
+    // 6. inverse pass 2, recon, SSD(org, rec)
+    if(live) {
+        const int64_t add = (int64_t)1 << (P.shift_inv - 1);
+        unsigned long long s = 0;
+        for(int i = t; i < n; i += tpb) {
+            const int y = i >> log2w, x = i & (w - 1);
+            int64_t a = 0;
+            for(int kx = 0; kx < w; kx++) a += (int64_t)mw[kx * w + x] * (int64_t)Tm[kx * h + y];
+            a = (a + add) >> P.shift_inv;
+            a = a < -32768 ? -32768 : (a > 32767 ? 32767 : a);
+            int r = (int)(int16_t)((int)a + (int)pred[jb.off2 + y * s_pred + x]);
+            r     = r < 0 ? 0 : (r > P.maxv ? P.maxv : r);
+            rec[jb.off1 + y * s_rec + x] = (pel)r;
+            const int e = (int)org[jb.off1 + y * s_org + x] - r;
+            s += (unsigned)((e * e) >> P.ssd_shift);
+        }
+        atomicAdd(&acc64[1], s);
+    }
+    __syncthreads();
+    if(live && t == 0) {
+        nnz_out[j]         = acc32[1];
+        ssd_out[2 * j]     = (int64_t)acc64[0];
+        ssd_out[2 * j + 1] = (int64_t)acc64[1];
+    }
+}
+
+extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
+                                     int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
+                                     int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && pred && jobs && coef && rec && nnz && ssd && njobs >= 0);
+    XH_REQUIRE(log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && bit_depth >= 8 && bit_depth <= 14);
+    XH_REQUIRE(qp >= 0 && qp <= 63 && qscale > 0 && qscale < 65536 && dqscale > 0);
+    if(njobs == 0) return XEVE_HIP_OK;
+    const int odd = (log2w + log2h) & 1, log2_size = (log2w + log2h) >> 1;
+    RdoParams P;
+    P.shift_fwd = (log2w - 1 + bit_depth - 8) + (log2h + 6); // xeve_util.c:34-35
+    P.shift_inv = 7 + (12 - (bit_depth - 8));                // xeve_itdq.h:38-39
+    P.q_scale   = qscale;
+    P.q_shift   = 14 + (15 - bit_depth - log2_size) + qp / 6; // xeve_tq.c:716-717
+    XH_REQUIRE(P.q_shift >= 9 && P.q_shift <= 30);
+    P.q_offset = (is_intra_slice ? 171 : 85) << (P.q_shift - 9);
+    if(zero_test) { // xeve_tq.c:673-683
+        const int zs = 14 + (15 - bit_depth - log2_size + (odd ? 7 : 0)) + qp / 6;
+        P.z_scale    = (long)qscale * (odd ? 181 : 1);
+        P.z_thr      = (1L << zs) - ((long)(is_intra_slice ? 201 : 153) << (zs - 9));
+    }
+    else P.z_scale = 0, P.z_thr = -1;
+    P.dq_scale  = (long)dqscale * (odd ? 181 : 1);            // xeve_itdq.c:442-475
+    P.dq_shift  = (uint8_t)(20 - 14 - (15 - bit_depth - log2_size) + (odd ? 8 : 0));
+    P.dq_offset = P.dq_shift == 0 ? 0 : 1 << (P.dq_shift - 1);
+    P.ssd_shift = (bit_depth - 8) * 2;
+    P.maxv      = (1 << bit_depth) - 1;
+    hipStream_t st = (hipStream_t)stream;
+    if(g_use_mfma && log2w == log2h && log2w >= 5)
+        return xh_rdo_mfma(1 << log2w, org, s_org, pred, s_pred, jobs, njobs, &P, coef, rec, s_rec, nnz, ssd, st);
+    const int n = 1 << (log2w + log2h), tpb = n < 256 ? n : 256, bpw = 256 / tpb;
+    const size_t lds = (size_t)bpw * 8 * n + (size_t)bpw * 16 + (size_t)bpw * 8;
+    k_rdo_valu<<<(njobs + bpw - 1) / bpw, 256, lds, st>>>(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, P, coef, rec, s_rec, nnz, ssd);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -166,6 +166,13 @@ def recon(coef, pred, is_coef, cuw, cuh, rec_off, s_rec, rec, bit_depth):
     return rec
 
 
+def residual_rdo(org, s_org, pred, s_pred, jobs, log2w, log2h, bit_depth, qp, is_intra_slice, zero_test, coef, rec, s_rec, nnz, ssd):
+    """fused DIFF/SSD/DCT/quant/dequant/IDCT/recon/SSD (xeve_hip_residual_rdo); all outputs preallocated by the caller"""
+    _lib.check(_lib.load().xeve_hip_residual_rdo(_ptr(_i16(org)), s_org, _ptr(_i16(pred)), s_pred, _ptr(jobs), jobs.shape[0], log2w, log2h,
+                                                 bit_depth, qp, QUANT_SCALE[0][qp % 6], DQ_SCALE[qp % 6] << (qp // 6), int(is_intra_slice),
+                                                 int(zero_test), _ptr(_i16(coef)), _ptr(_i16(rec)), s_rec, _ptr(nnz), _ptr(ssd), _stream()))
+
+
 # quantiser scale tables of the standard (reference: src_base/xeve_tq.c:37-38, xeve_tbl.c:237)
 QUANT_SCALE = ((26214, 23302, 20560, 18396, 16384, 14764), (26214, 23302, 20560, 18396, 16384, 14564))
 DQ_SCALE = (40, 45, 51, 57, 64, 71)

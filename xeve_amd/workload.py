@@ -129,12 +129,13 @@ class HotPathPass:
         lv["resi"] = [torch.empty((n, S * S), dtype=torch.int16, device=dev)] + [torch.empty((n, Sc * Sc), dtype=torch.int16, device=dev) for _ in range(2)]
         lv["coef"] = [torch.empty_like(t) for t in lv["resi"]]
         lv["rec"] = [torch.zeros_like(p) for p in self.org]
+        lv["nnz"] = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        lv["ssd2"] = [torch.empty((n, 2), dtype=torch.int64, device=dev) for _ in range(3)]
         return lv
 
     # ------------------------------------------------------------------------------------------------------
     def run(self, time_sad=False):
         bd, qp, s_l, s_c = self.bd, self.qp, self.s_l, self.s_c
-        qs, dqs = D.QUANT_SCALE[0][qp % 6], D.DQ_SCALE[qp % 6] << (qp // 6)
         org = self.org
         for S in self.sizes:
             lv = self.lv[S]
@@ -173,17 +174,9 @@ class HotPathPass:
             for c in range(3):
                 w, lg, st = (S, l2, s_l) if c == 0 else (Sc, l2c, s_c)
                 pred = lv["pred_l"][0] if c == 0 else lv["pred_c"][c - 1]
-                dj = lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"]
-                D.diff_jobs(org[c], st, pred, w, dj, w, w, out=lv["resi"][c])
-                D.ssd_jobs(org[c], st, pred, w, dj, self.zero_cand, w, w, bd)
-                lv["coef"][c].copy_(lv["resi"][c])
-                D.trans(lv["coef"][c], lg, lg, bd)
-                D.rdoq_zero_test(lv["coef"][c], lg, lg, qp, qs, False, bd)
-                D.quant(lv["coef"][c], lg, lg, qp, qs, False, bd)
-                D.dquant(lv["coef"][c], lg, lg, dqs, bd)
-                D.itrans(lv["coef"][c], lg, lg, bd)
-                D.recon(lv["coef"][c], pred.view(lv["n"], -1), None, w, w, lv["off_l"] if c == 0 else lv["off_c"], st, lv["rec"][c], bd)
-                D.ssd_jobs(org[c], st, lv["rec"][c], st, D_same_jobs(lv, c), self.zero_cand, w, w, bd)
+                # DIFF, SSD(pred), DCT, zero pre-test, quant, dequant, IDCT, recon, SSD(rec): one fused launch
+                D.residual_rdo(org[c], st, pred, w, lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"], lg, lg, bd, qp, False, True,
+                               lv["coef"][c], lv["rec"][c], st, lv["nnz"][c], lv["ssd2"][c])
             # E. intra gate
             D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
 
