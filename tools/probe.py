@@ -45,5 +45,8 @@ for S in wl.sizes:
     print("SAD %2dx%-2d  %7.3f ms/picture  %8.1f GB/s algorithmic" % (S, S, ms, by / ms / 1e6))
 print("SAD total %.3f ms" % tot)
 if what == "all":
+    for ph, name in (("A", "A integer ME SAD"), ("B", "B half-pel MC+SAD"), ("C", "C merge MC+SSD"), ("D1", "D1 bi-pred MC+avg"),
+                     ("D2", "D2 fused residual chain"), ("E", "E SATD gate")):
+        print("phase %-26s %.3f ms" % (name, timeit(lambda: wl.run(only=ph))))
     ms = timeit(lambda: wl.run())
     print("full pass %.3f ms  -> %.1f pictures/s" % (ms, 1e3 / ms))

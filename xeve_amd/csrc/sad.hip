@@ -140,6 +140,26 @@ __global__ void k_sad_any(const pel *__restrict__ p1, int s1, const pel *__restr
     if(lane == 0) out[item] = acc >> shift;
 }
 
+// Tiny blocks (w, h <= 4: 4x4 chroma of an 8x8 CU, 2x2 / 4x4 intra): one THREAD per (job, candidate).
+template <bool SSD>
+__global__ void k_dist_tiny(const pel *__restrict__ p1, int s1, const pel *__restrict__ p2, int s2,
+                            const xeve_hip_job *__restrict__ jobs, long items, const int32_t *__restrict__ cand_off, int ncand,
+                            int w, int h, int shift, void *__restrict__ out)
+{
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(item >= items) return;
+    const xeve_hip_job jb = jobs[item / ncand];
+    const pel *a = p1 + jb.off1, *b = p2 + jb.off2 + cand_off[item % ncand];
+    long acc = 0;
+    for(int y = 0; y < h; y++)
+        for(int x = 0; x < w; x++) {
+            const int d = (int)a[y * s1 + x] - (int)b[y * s2 + x];
+            acc += SSD ? (long)((d * d) >> shift) : (long)(d < 0 ? -d : d);
+        }
+    if(SSD) static_cast<int64_t *>(out)[item] = acc;
+    else static_cast<int32_t *>(out)[item] = (int32_t)(acc >> shift);
+}
+
 // ------------------------------------------------------------------------------------------------
 // SSD
 // ------------------------------------------------------------------------------------------------
@@ -407,6 +427,10 @@ static int sad_jobs_impl(const pel *p1, int s1, const pel *p2, const pel *p2s, i
     else if(w == h && w == 16) LAUNCH_SQ(16, 1, 4);
     else if(w == h && w == 32) { if(many) LAUNCH_SQ(32, 2, 2); else LAUNCH_SQ(32, 1, 1); }
     else if(w == h && w == 64) { if(many) LAUNCH_SQ(64, 4, 1); else LAUNCH_SQ(64, 1, 1); }
+    else if(w <= 4 && h <= 4) {
+        const long items = (long)njobs * ncand;
+        k_dist_tiny<false><<<dim3((unsigned)((items + 255) / 256)), 256, 0, st>>>(p1, s1, p2, s2, jobs, items, cand_off, ncand, w, h, shift, out);
+    }
     else k_sad_any<<<wave_grid((long)njobs * ncand), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, w, h, shift, out);
 #undef LAUNCH_SQ2
 #undef LAUNCH_SQ
@@ -463,6 +487,10 @@ extern "C" int xeve_hip_ssd_jobs(const pel *p1, int s1, const pel *p2, int s2, c
     else if(w == h && w == 16) k_ssd_sq<16><<<wave_grid(njobs), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, sh, out);
     else if(w == h && w == 32) k_ssd_sq<32><<<wave_grid(njobs), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, sh, out);
     else if(w == h && w == 64) k_ssd_sq<64><<<wave_grid(njobs), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, sh, out);
+    else if(w <= 4 && h <= 4) {
+        const long items = (long)njobs * ncand;
+        k_dist_tiny<true><<<dim3((unsigned)((items + 255) / 256)), 256, 0, st>>>(p1, s1, p2, s2, jobs, items, cand_off, ncand, w, h, sh, out);
+    }
     else k_ssd_any<<<wave_grid((long)njobs * ncand), 256, 0, st>>>(p1, s1, p2, s2, jobs, njobs, cand_off, ncand, w, h, sh, out);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

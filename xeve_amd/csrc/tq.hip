@@ -344,7 +344,12 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     int32_t *Tm = X + n;
     unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(smem + (size_t)bpw * 8 * n) + 2 * bl; // [ssd_pred, ssd_rec]
     int *acc32 = reinterpret_cast<int *>(smem + (size_t)bpw * 8 * n + (size_t)bpw * 16) + 2 * bl;              // [zero-test hit, nnz]
-    const int8_t *mw = c_tm + xh_tm_off(log2w), *mh = c_tm + xh_tm_off(log2h);
+    // the two DCT matrices, widened to int32, staged in LDS once per workgroup (lane-varying constant-memory reads
+    // would go through the vector memory path)
+    int32_t *mw = reinterpret_cast<int32_t *>(smem + (size_t)bpw * 8 * n + (size_t)bpw * 24);
+    int32_t *mh = mw + w * w;
+    for(int i = threadIdx.x; i < w * w; i += blockDim.x) mw[i] = c_tm[xh_tm_off(log2w) + i];
+    for(int i = threadIdx.x; i < h * h; i += blockDim.x) mh[i] = c_tm[xh_tm_off(log2h) + i];
     const xeve_hip_job jb = live ? jobs[j] : xeve_hip_job{0, 0};
     if(t == 0) acc64[0] = acc64[1] = 0, acc32[0] = acc32[1] = 0;
     __syncthreads();
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
             const int kx = i >> log2h, y = i & (h - 1);
             int a = 0;
             if(!(w == 64 && kx >= 32))
-                for(int x = 0; x < w; x++) a += (int)mw[kx * w + x] * X[y * w + x];
+                for(int x = 0; x < w; x++) a += mw[kx * w + x] * X[y * w + x];
             Tm[i] = a;
         }
     __syncthreads();
@@ -475,7 +480,7 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
     if(g_use_mfma && log2w == log2h && log2w >= 5)
         return xh_rdo_mfma(1 << log2w, org, s_org, pred, s_pred, jobs, njobs, &P, coef, rec, s_rec, nnz, ssd, st);
     const int n = 1 << (log2w + log2h), tpb = n < 256 ? n : 256, bpw = 256 / tpb;
-    const size_t lds = (size_t)bpw * 8 * n + (size_t)bpw * 16 + (size_t)bpw * 8;
+    const size_t lds = (size_t)bpw * 8 * n + (size_t)bpw * 24 + 4 * ((size_t)(1 << (2 * log2w)) + (size_t)(1 << (2 * log2h)));
     k_rdo_valu<<<(njobs + bpw - 1) / bpw, 256, lds, st>>>(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, P, coef, rec, s_rec, nnz, ssd);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

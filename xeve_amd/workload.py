@@ -134,7 +134,7 @@ class HotPathPass:
         return lv
 
     # ------------------------------------------------------------------------------------------------------
-    def run(self, time_sad=False):
+    def run(self, time_sad=False, only=None):
         bd, qp, s_l, s_c = self.bd, self.qp, self.s_l, self.s_c
         org = self.org
         for S in self.sizes:
@@ -144,41 +144,45 @@ class HotPathPass:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             # A. integer motion search rounds
-            for i, jobs in enumerate(lv["me_jobs"]):
+            for i, jobs in enumerate(lv["me_jobs"] if only in (None, "A") else ()):
                 D.sad_jobs_dual(org[0], s_l, self.ref[i % N_LIST][0], self.ref_s1[i % N_LIST], s_l, jobs, self.cand_l, S, S, bd,
                                 out=lv["sad_out"])
             if time_sad:
                 e1.record()
                 self.sad_events.append((S, "me", e0, e1))
             # B. half-pel refinement
-            for l in range(N_LIST):
+            for l in range(N_LIST if only in (None, "B") else 0):
                 for jobs in lv["hp_jobs"][l]:
                     D.mc_jobs(True, self.ref[l][0], s_l, lv["pred_l"][0], S, jobs, S, S, bd)
                     D.sad_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd, out=lv["sad1"])
             # C. skip / merge candidates
-            for jl, jc in lv["merge_jobs"]:
+            for jl, jc in (lv["merge_jobs"] if only in (None, "C") else ()):
                 D.mc_jobs(True, self.ref[0][0], s_l, lv["pred_l"][0], S, jl, S, S, bd)
                 D.ssd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
                 for c in (1, 2):
                     D.mc_jobs(False, self.ref[0][c], s_c, lv["pred_c"][c - 1], Sc, jc, Sc, Sc, bd)
                     D.ssd_jobs(org[c], s_c, lv["pred_c"][c - 1], Sc, lv["dense_jobs_c"], self.zero_cand, Sc, Sc, bd)
+            if only not in (None, "D", "D1", "D2", "E"):
+                continue
             # D. residual RDO of the (bi-predicted) winner
-            for l in range(N_LIST):
+            for l in range(N_LIST if only in (None, "D", "D1") else 0):
                 jl, jc = lv["final_jobs"][l]
                 D.mc_jobs(True, self.ref[l][0], s_l, lv["pred_l"][l], S, jl, S, S, bd)
                 for c in (1, 2):
                     D.mc_jobs(False, self.ref[l][c], s_c, lv["pred_c"][2 * l + c - 1], Sc, jc, Sc, Sc, bd)
-            D.avg(lv["pred_l"][0].view(-1), lv["pred_l"][1].view(-1), out=lv["pred_l"][0].view(-1))
-            for c in (1, 2):
+            if only in (None, "D", "D1"):
+                D.avg(lv["pred_l"][0].view(-1), lv["pred_l"][1].view(-1), out=lv["pred_l"][0].view(-1))
+            for c in ((1, 2) if only in (None, "D", "D1") else ()):
                 D.avg(lv["pred_c"][c - 1].view(-1), lv["pred_c"][2 + c - 1].view(-1), out=lv["pred_c"][c - 1].view(-1))
-            for c in range(3):
+            for c in (range(3) if only in (None, "D", "D2") else ()):
                 w, lg, st = (S, l2, s_l) if c == 0 else (Sc, l2c, s_c)
                 pred = lv["pred_l"][0] if c == 0 else lv["pred_c"][c - 1]
                 # DIFF, SSD(pred), DCT, zero pre-test, quant, dequant, IDCT, recon, SSD(rec): one fused launch
                 D.residual_rdo(org[c], st, pred, w, lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"], lg, lg, bd, qp, False, True,
                                lv["coef"][c], lv["rec"][c], st, lv["nnz"][c], lv["ssd2"][c])
             # E. intra gate
-            D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
+            if only in (None, "E"):
+                D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
 
     def sad_time_ms(self):
         """sum of HIP-event durations of the integer-search SAD launches recorded by run(time_sad=True), per size"""
