@@ -174,6 +174,43 @@ int xeve_hip_residual_rdo(const xeve_hip_pel *org, int s_org, const xeve_hip_pel
                           int log2w, int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
                           int16_t *coef, xeve_hip_pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* (3) GPU-side consumer of the SAD kernel: one complete me_ipel_diamond per job (SURVEY.md 8(f)   */
+/*     rank 2).  reference: src_base/xeve_pinter.c:363-551 (+ get_mv_bits :74-120, MV_COST :47,    */
+/*     get_range_ipel :122-140).  Bit-exact incl. the tie-break (first strictly smaller cost in   */
+/*     evaluation order).  One wave per job; per-candidate sums and the per-round minimum are     */
+/*     wave64 cross-lane reductions.                                                              */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_me_params {
+    uint32_t lambda_mv;        /* pi->lambda_mv */
+    int32_t  refi_bits;        /* xeve_tbl_refi_bits[num_refp][refi] */
+    int32_t  extra_bits;       /* bi ? pi->mot_bits[other list] : 0 */
+    int32_t  bi;               /* 0 BI_NON; 1 BI_NORMAL (+-5 grid, one round); 2/3 BI_FL0/BI_FL1 (xeve_def.h:504-507) */
+    int32_t  faststep;         /* MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP (xeve_pred.h:63-69) */
+    int32_t  max_search_range; /* pi->max_search_range */
+    int32_t  range_recentre;   /* range get_range_ipel derives for this reference picture (POC-distance scaled) */
+    int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / pi->max_clip */
+    int32_t  beststep_in;      /* *beststep on entry */
+} xeve_hip_me_params;
+typedef struct xeve_hip_me_job {
+    int32_t x, y;     /* block position (integer pel, picture coordinates) */
+    int32_t org_off;  /* bi != 0: element offset of the job's dense org_bi block (stride w) inside `org_bi` */
+    int16_t range[4]; /* min x, min y, max x, max y */
+    int16_t gmvp[2];  /* MVP, picture coordinates, quarter pel */
+    int16_t mvi[2];   /* initial MV, picture coordinates, quarter pel */
+} xeve_hip_me_job;
+typedef struct xeve_hip_me_result {
+    int16_t  mv[2];    /* best MV relative to the block (quarter-pel units) */
+    uint32_t cost;     /* cost_best (MV_COST + SAD) */
+    int32_t  beststep; /* *beststep on exit */
+    int32_t  best_mv_bits;
+} xeve_hip_me_result;
+/* org0 / ref0 point at sample (0,0) of the picture inside its padded plane (device memory); org_bi may be NULL when
+ * params->bi == 0; params is a HOST pointer; square blocks 8..64. */
+int xeve_hip_me_ipel_diamond_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref,
+                                  const xeve_hip_me_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
+                                  const xeve_hip_me_params *params, xeve_hip_me_result *results, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -397,3 +397,100 @@ void xo_recon(const int16_t *coef, const xo_pel *pred, int is_coef, int cuw, int
             rec[y * s_rec + x] = (xo_pel)clip3i(0, maxv, t);
         }
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* integer-pel diamond search (reference: xeve_pinter.c:74-140, 363-551)      */
+/* ------------------------------------------------------------------------- */
+/* One component of get_mv_bits.  The reference reads xeve_tbl_mv_bits[mvd] for -2048 < mvd <= 2048
+ * (xeve_tbl.c:286-496: 1 bit for 0, else 2*floor(log2(|mvd|+1)) + 2; the table's first entry, mvd = -2047,
+ * holds 22 where the formula gives 24 -- restated as is) and an exp-Golomb length beyond (xeve_pinter.c:74-93). */
+static int mvd_bits(int mvd)
+{
+    if(mvd > 2048 || mvd <= -2048) {
+        unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd), nn = (a + 1) >> 12;
+        int len_i;
+        for(len_i = 11; len_i < 16 && nn != 0; len_i++) nn >>= 1;
+        return (len_i << 1) + 1 + 1;
+    }
+    if(mvd == 0) return 1;
+    if(mvd == -2047) return 22;
+    unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd) + 1;
+    int l = 0;
+    while((a >> (l + 1)) != 0) l++;
+    return 2 * l + 2;
+}
+int xo_mv_bits(int mvd_x, int mvd_y) { return mvd_bits(mvd_x) + mvd_bits(mvd_y); }
+
+/* 16-point diamond, unit L1 radius 4 (xeve_pinter.c:57-65); the 8-point form is every other point halved */
+static const int8_t dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1, 3}, {0, 4}, {1, 3}, {2, 2}, {3, 1},
+                                    {4, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -4}, {-1, -3}, {-2, -2}, {-3, -1}};
+
+void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job,
+                        int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res)
+{
+    const int w = 1 << log2w, h = 1 << log2h;
+    const xo_pel *org = p->bi ? org_bi + job->org_off : org0 + job->y * s_org + job->x;
+    const int so = p->bi ? w : s_org;
+    int range[4] = {job->range[0], job->range[1], job->range[2], job->range[3]};
+    uint32_t cost_best = 0xFFFFFFFFu;
+    int best_bits = 0, beststep = p->beststep_in, step = 0, not_found = 0;
+    int bx = clip3i(p->min_clip[0], p->max_clip[0], job->mvi[0] >> 2);
+    int by = clip3i(p->min_clip[1], p->max_clip[1], job->mvi[1] >> 2);
+    const int ix = bx, iy = by;
+
+    for(;;) {
+        not_found++;
+        int cand[128][2], nc = 0, round_step;
+        if(step <= 2) {
+            const int d = p->bi == 1 ? 5 : 2; /* BI_STEP : 2 */
+            const int x0 = bx <= range[0] ? bx : bx - d, y0 = by <= range[1] ? by : by - d;
+            const int x1 = bx >= range[2] ? bx : bx + d, y1 = by >= range[3] ? by : by + d;
+            for(int yy = y0; yy <= y1; yy++)
+                for(int xx = x0; xx <= x1; xx++) cand[nc][0] = xx, cand[nc][1] = yy, nc++;
+            round_step = 2;
+        }
+        else {
+            const int coarse = step > 8;
+            for(int i = 0; i < 16; i++) {
+                if(!coarse && i > 8) continue;                                  /* 8-point ring + centre */
+                if(step == 4 && (i == 1 || i == 3 || i == 5 || i == 7)) continue; /* 4-point ring + centre */
+                int dx, dy;
+                if(coarse) dx = dia16[i][0], dy = dia16[i][1];
+                else if(i < 8) dx = dia16[2 * i][0] / 2, dy = dia16[2 * i][1] / 2;
+                else dx = dy = 0;
+                cand[nc][0] = ix + (step >> (coarse ? 2 : 1)) * dx;
+                cand[nc][1] = iy + (step >> (coarse ? 2 : 1)) * dy;
+                nc++;
+            }
+            round_step = step;
+        }
+        for(int k = 0; k < nc; k++) {
+            const int mx = cand[k][0], my = cand[k][1];
+            if(mx > range[2] || mx < range[0] || my > range[3] || my < range[1]) continue;
+            int bits = xo_mv_bits((mx << 2) - job->gmvp[0], (my << 2) - job->gmvp[1]) + p->refi_bits;
+            if(p->bi) bits += p->extra_bits;
+            uint32_t cost = (uint32_t)(p->lambda_mv * (uint32_t)bits + (1u << 15)) >> 16; /* u32 arithmetic as MV_COST, xeve_pinter.c:47 */
+            int sad = xo_sad(w, h, org, ref0 + my * s_ref + mx, so, s_ref, bit_depth);
+            cost += (uint32_t)(p->bi ? sad >> 1 : sad);
+            if(cost < cost_best) bx = mx, by = my, beststep = round_step, not_found = 0, cost_best = cost, best_bits = bits;
+        }
+        if(step <= 2) {
+            const int sr = p->bi == 1 ? 5 : p->range_recentre; /* get_range_ipel (xeve_pinter.c:122-140) */
+            range[0] = clip3i(p->min_clip[0], p->max_clip[0], bx - sr);
+            range[2] = clip3i(p->min_clip[0], p->max_clip[0], bx + sr);
+            range[1] = clip3i(p->min_clip[1], p->max_clip[1], by - sr);
+            range[3] = clip3i(p->min_clip[1], p->max_clip[1], by + sr);
+            step += 2;
+        }
+        if(not_found == p->faststep) break;
+        if(p->bi == 1) break;
+        step <<= 1;
+        if(step > p->max_search_range) break;
+    }
+    res->mv[0] = (int16_t)((bx - job->x) << 2);
+    res->mv[1] = (int16_t)((by - job->y) << 2);
+    res->cost = cost_best;
+    res->beststep = beststep;
+    res->best_mv_bits = best_bits;
+}

@@ -77,6 +77,42 @@ void xo_dquant(int16_t *coef, int log2w, int log2h, int scale, int bit_depth);
 /* a15: xeve_recon_blk xeve_recon.c:34-57 */
 void xo_recon(const int16_t *coef, const xo_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xo_pel *rec, int bit_depth);
 
+/* ---- integer-pel motion search (reference: src_base/xeve_pinter.c) ------------ */
+/* get_mv_bits (xeve_pinter.c:74-120) without the reference-index term; table xeve_tbl_mv_bits (xeve_tbl.c:286-496)
+ * restated in closed form */
+int xo_mv_bits(int mvd_x, int mvd_y);
+
+typedef struct xo_me_params {
+    uint32_t lambda_mv;        /* pi->lambda_mv                          (xeve_pinter.c:47,1763) */
+    int32_t  refi_bits;        /* xeve_tbl_refi_bits[num_refp][refi]     (xeve_pinter.c:118)     */
+    int32_t  extra_bits;       /* bi ? pi->mot_bits[other list] : 0      (xeve_pinter.c:429)     */
+    int32_t  bi;               /* 0 = BI_NON, 1 = BI_NORMAL (11x11 grid, one round, SAD >> 1), 2 = BI_FL0/FL1-like (normal rounds, SAD >> 1) */
+    int32_t  faststep;         /* MAX_FIRST_SEARCH_STEP 3 / MAX_REFINE_SEARCH_STEP 2 (xeve_pred.h:63-69) */
+    int32_t  max_search_range; /* pi->max_search_range                   (xeve_pinter.c:535)     */
+    int32_t  range_recentre;   /* the search range get_range_ipel derives for this reference picture (xeve_pinter.c:124-129) */
+    int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / max_clip        (xeve_pinter.c:132-136) */
+    int32_t  beststep_in;      /* value of *beststep on entry                                     */
+} xo_me_params;
+
+typedef struct xo_me_job {
+    int32_t x, y;       /* block position in the picture (integer pel) */
+    int32_t org_off;    /* bi != 0: element offset of this job's dense org_bi block (stride = w); else unused */
+    int16_t range[4];   /* min x, min y, max x, max y (absolute integer-pel positions, xeve_pinter.c:122-140) */
+    int16_t gmvp[2];    /* MVP in picture coordinates, quarter pel */
+    int16_t mvi[2];     /* initial MV in picture coordinates, quarter pel */
+} xo_me_job;
+
+typedef struct xo_me_result {
+    int16_t  mv[2];     /* best MV relative to the block, quarter-pel units (integer positions) */
+    uint32_t cost;      /* cost_best */
+    int32_t  beststep;  /* *beststep on exit */
+    int32_t  best_mv_bits;
+} xo_me_result;
+
+/* me_ipel_diamond (xeve_pinter.c:363-551).  org0 / ref0 point at sample (0,0) of the picture inside its padded plane. */
+void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job,
+                        int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res);
+
 #ifdef __cplusplus
 }
 #endif

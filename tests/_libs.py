@@ -170,3 +170,49 @@ class OracleTables:
 
     def recon(self, coef, pred, is_coef, cuw, cuh, s_rec, rec, bd):
         self.O.xo_recon(ptr(coef), ptr(pred), is_coef, cuw, cuh, s_rec, ptr(rec), bd)
+
+
+# ---- integer-pel motion search: oracle structs + the wrapper around the reference's static me_ipel_diamond ----
+class MeParams(C.Structure):
+    _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
+                ("faststep", C.c_int32), ("max_search_range", C.c_int32), ("range_recentre", C.c_int32),
+                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("beststep_in", C.c_int32)]
+
+
+class MeJob(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("org_off", C.c_int32), ("range", C.c_int16 * 4), ("gmvp", C.c_int16 * 2),
+                ("mvi", C.c_int16 * 2)]
+
+
+class MeResult(C.Structure):
+    _fields_ = [("mv", C.c_int16 * 2), ("cost", C.c_uint32), ("beststep", C.c_int32), ("best_mv_bits", C.c_int32)]
+
+
+REF_ME_SO = os.path.join(ORACLE_DIR, "_ref", "libref_me.so")
+_ref_me = None
+
+
+def ref_me():
+    global _ref_me
+    if _ref_me is None and os.path.exists(REF_ME_SO):
+        L = C.CDLL(REF_ME_SO)
+        L.refdrv_me_ipel_diamond.restype = C.c_uint32
+        L.refdrv_me_ipel_diamond.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_int, C.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_int, c_void_p]
+        L.refdrv_mv_bits.restype = c_int
+        L.refdrv_mv_bits.argtypes = [c_int] * 4
+        L.refdrv_refi_bits.restype = c_int
+        L.refdrv_refi_bits.argtypes = [c_int] * 2
+        _ref_me = L
+    return _ref_me
+
+
+def oracle_me():
+    L = oracle()
+    L.xo_mv_bits.restype = c_int
+    L.xo_mv_bits.argtypes = [c_int, c_int]
+    L.xo_me_ipel_diamond.restype = None
+    L.xo_me_ipel_diamond.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, C.POINTER(MeJob), c_int, c_int, c_int,
+                                     C.POINTER(MeParams), C.POINTER(MeResult)]
+    return L

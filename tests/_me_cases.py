@@ -1,0 +1,65 @@
+"""Seeded cases for the integer-pel diamond search, shared by the reference-pinning test, the golden generator and
+the GPU test."""
+import ctypes as C
+
+import numpy as np
+
+from _libs import MeJob, MeParams, MeResult, oracle_me, ptr
+
+PAD = 144
+REFI_BITS_2_0 = 1  # xeve_tbl_refi_bits[2][0] (xeve_tbl.c:498-517)
+
+
+def make_planes(r, textured, W=256, H=192):
+    s = W + 2 * PAD
+    if textured:  # smooth moving texture: the search actually walks, the far rings get used
+        yy, xx = np.mgrid[0:H + 2 * PAD, 0:s]
+        base = (512 + 300 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + 150 * np.sin((xx + yy) / 41.0))
+        org = np.clip(base + r.integers(-6, 7, size=base.shape), 0, 1023).astype(np.int16)
+        shift = (int(r.integers(-30, 31)), int(r.integers(-30, 31)))
+        ref = np.roll(org, shift, axis=(0, 1))
+        ref = np.clip(ref + r.integers(-6, 7, size=base.shape), 0, 1023).astype(np.int16)
+    else:
+        org = r.integers(0, 1024, size=(H + 2 * PAD, s), dtype=np.int16)
+        ref = r.integers(0, 1024, size=(H + 2 * PAD, s), dtype=np.int16)
+    return dict(org=org, ref=ref, s=s, W=W, H=H)
+
+
+def make_job(r, pl, S, bi):
+    W, H = pl["W"], pl["H"]
+    x, y = int(r.integers(0, (W - S) // 8 + 1)) * 8, int(r.integers(0, (H - S) // 8 + 1)) * 8
+    min_clip, max_clip = (-128, -128), (W - 1 + 128, H - 1 + 128)  # -MAX_CU_SIZE .. pic + MAX_CU_SIZE (xeve_pinter.c:1795-1798)
+    mvp = (int(r.integers(-160, 161)), int(r.integers(-160, 161)))  # quarter pel
+    msr = int(r.choice([32, 64, 128]))
+    sr = 5 if bi == 1 else int(r.choice([msr // 4, msr // 2, msr]))
+    cx = min(max(x + (mvp[0] >> 2), min_clip[0]), max_clip[0])
+    cy = min(max(y + (mvp[1] >> 2), min_clip[1]), max_clip[1])
+    rng = [min(max(cx - sr, min_clip[0]), max_clip[0]), min(max(cy - sr, min_clip[1]), max_clip[1]),
+           min(max(cx + sr, min_clip[0]), max_clip[0]), min(max(cy + sr, min_clip[1]), max_clip[1])]
+    org_bi = (2 * r.integers(0, 1024, size=S * S) - r.integers(0, 1024, size=S * S)).astype(np.int16)
+    return dict(org=pl["org"], ref=pl["ref"], s=pl["s"], x=x, y=y, S=S, bi=bi, min_clip=min_clip, max_clip=max_clip, range=rng,
+                gmvp=(mvp[0] + (x << 2), mvp[1] + (y << 2)), mvi=(mvp[0] + (x << 2), mvp[1] + (y << 2)), msr=msr, sr=sr,
+                lambda_mv=int(r.integers(1 << 16, 1 << 23)), faststep=int(r.choice([2, 3])), mot_other=int(r.integers(2, 30)),
+                org_bi=org_bi, beststep_in=int(r.integers(0, 3)))
+
+
+def make_case(r, S, bi, textured):
+    return make_job(r, make_planes(r, textured), S, bi)
+
+
+def params_of(c):
+    return MeParams(c["lambda_mv"], REFI_BITS_2_0, c["mot_other"], c["bi"], c["faststep"], c["msr"], c["sr"],
+                    (C.c_int32 * 2)(*c["min_clip"]), (C.c_int32 * 2)(*c["max_clip"]), c["beststep_in"])
+
+
+def job_of(c, org_off=0):
+    return MeJob(c["x"], c["y"], org_off, (C.c_int16 * 4)(*c["range"]), (C.c_int16 * 2)(*c["gmvp"]), (C.c_int16 * 2)(*c["mvi"]))
+
+
+def run_oracle(c):
+    O = oracle_me()
+    lg = c["S"].bit_length() - 1
+    p, j, res = params_of(c), job_of(c), MeResult()
+    O.xo_me_ipel_diamond(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], C.byref(j), lg, lg,
+                         10, C.byref(p), C.byref(res))
+    return res

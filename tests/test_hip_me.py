@@ -1,0 +1,74 @@
+"""GPU suite: xeve_hip_me_ipel_diamond_jobs (one complete me_ipel_diamond per wave) against the reference goldens and
+against the oracle on batches of seeded jobs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _me_cases import PAD, make_job, make_planes, run_oracle
+from _me_golden import golden_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_run(cases):
+    """all cases share planes, block size and every launch-level parameter"""
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    c0 = cases[0]
+    S = c0["S"]
+    jobs = np.zeros(len(cases), dtype=lib.ME_JOB_DTYPE)
+    bi_buf = np.zeros((len(cases), S * S), np.int16)
+    for i, c in enumerate(cases):
+        jobs[i] = (c["x"], c["y"], i * S * S, c["range"], c["gmvp"], c["mvi"])
+        bi_buf[i] = c["org_bi"]
+    P = lib.MeParams(c0["lambda_mv"], 1, c0["mot_other"], c0["bi"], c0["faststep"], c0["msr"], c0["sr"], (C.c_int32 * 2)(*c0["min_clip"]),
+                     (C.c_int32 * 2)(*c0["max_clip"]), c0["beststep_in"])
+    org, ref = torch.from_numpy(c0["org"]).to(dev), torch.from_numpy(c0["ref"]).to(dev)
+    o0 = PAD * c0["s"] + PAD
+    return D.me_ipel_diamond_jobs(org, o0, c0["s"], torch.from_numpy(bi_buf).to(dev), ref, o0, c0["s"], jobs, S.bit_length() - 1, 10, P)
+
+
+def test_me_matches_reference_goldens():
+    n = 0
+    for c, (cost, mvx, mvy, beststep) in golden_cases():
+        res = gpu_run([c])[0]
+        assert (int(res["cost"]), int(res["mv"][0]), int(res["mv"][1]), int(res["beststep"])) == (cost, mvx, mvy, beststep), (n, c["S"], c["bi"])
+        n += 1
+    assert n == 96
+
+
+@pytest.mark.parametrize("S", [8, 16, 32, 64])
+@pytest.mark.parametrize("bi", [0, 1, 2])
+@pytest.mark.parametrize("textured", [False, True])
+def test_me_batches_vs_oracle(S, bi, textured):
+    r = np.random.default_rng(1000 + S + bi * 7 + textured)
+    pl = make_planes(r, textured)
+    base = make_job(r, pl, S, bi)
+    cases = []
+    for _ in range(150):
+        c = make_job(r, pl, S, bi)
+        for k in ("lambda_mv", "mot_other", "faststep", "msr", "sr", "beststep_in"):  # launch-level parameters are shared
+            c[k] = base[k]
+        # the job's own range must be derived with the shared search range
+        sr = base["sr"]
+        cx = min(max(c["x"] + ((c["gmvp"][0] - (c["x"] << 2)) >> 2), c["min_clip"][0]), c["max_clip"][0])
+        cy = min(max(c["y"] + ((c["gmvp"][1] - (c["y"] << 2)) >> 2), c["min_clip"][1]), c["max_clip"][1])
+        c["range"] = [min(max(cx - sr, c["min_clip"][0]), c["max_clip"][0]), min(max(cy - sr, c["min_clip"][1]), c["max_clip"][1]),
+                      min(max(cx + sr, c["min_clip"][0]), c["max_clip"][0]), min(max(cy + sr, c["min_clip"][1]), c["max_clip"][1])]
+        cases.append(c)
+    got = gpu_run(cases)
+    steps = set()
+    for i, c in enumerate(cases):
+        e = run_oracle(c)
+        g = got[i]
+        assert (int(g["cost"]), int(g["mv"][0]), int(g["mv"][1]), int(g["beststep"]), int(g["best_mv_bits"])) == \
+               (e.cost, e.mv[0], e.mv[1], e.beststep, e.best_mv_bits), (S, bi, textured, i)
+        steps.add(e.beststep)
+    assert len(steps) >= 1

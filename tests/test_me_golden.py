@@ -1,0 +1,13 @@
+"""CPU suite: the oracle's integer-pel diamond search against the committed results of the reference's own
+me_ipel_diamond (tests/golden/me_v1.npz, made by tests/golden/make_me_golden.py)."""
+from _me_cases import run_oracle
+from _me_golden import golden_cases
+
+
+def test_oracle_me_matches_reference_goldens():
+    n = 0
+    for c, (cost, mvx, mvy, beststep) in golden_cases():
+        res = run_oracle(c)
+        assert (res.cost, res.mv[0], res.mv[1], res.beststep) == (cost, mvx, mvy, beststep), (n, c["S"], c["bi"])
+        n += 1
+    assert n == 96

@@ -1,0 +1,53 @@
+"""Pins the oracle's integer-pel diamond search (xo_me_ipel_diamond, xo_mv_bits) against the REAL static functions of
+the reference (src_base/xeve_pinter.c:74-120, 363-551), reached through oracle/ref_me_driver.c, which compiles the
+reference's xeve_pinter.c in place."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _libs import oracle_me, ptr, ref_me
+from _me_cases import PAD, REFI_BITS_2_0, make_case, run_oracle
+
+pytestmark = pytest.mark.skipif(ref_me() is None, reason="oracle/_ref/libref_me.so not built (needs /root/reference)")
+
+
+def test_mv_bits_table_closed_form():
+    O, R = oracle_me(), ref_me()
+    assert R.refdrv_refi_bits(2, 0) == REFI_BITS_2_0
+    for mvd in list(range(-2100, 2101)) + [-5000, 5000, -32768, 32767, 4095, 4096, -4096, 8191, 8192, 16383, 16384]:
+        assert O.xo_mv_bits(mvd, 0) + R.refdrv_refi_bits(2, 1) == R.refdrv_mv_bits(mvd, 0, 2, 1), mvd
+        assert O.xo_mv_bits(3, mvd) + R.refdrv_refi_bits(1, 0) == R.refdrv_mv_bits(3, mvd, 1, 0), mvd
+
+
+def run_ref(c):
+    R = ref_me()
+    lg = c["S"].bit_length() - 1
+    out = (C.c_int * 4)()
+    org0, ref0 = ptr(c["org"], PAD * c["s"] + PAD), ptr(c["ref"], PAD * c["s"] + PAD)
+    rng = np.array(c["range"], np.int16)
+    gmvp, mvi = np.array(c["gmvp"], np.int16), np.array(c["mvi"], np.int16)
+    mn, mx = np.array(c["min_clip"], np.int32), np.array(c["max_clip"], np.int32)
+    # gop_size / poc chosen so that get_range_ipel derives exactly c["sr"]: (msr * |poc - ref_poc| + gop/2) / gop = sr
+    gop, poc, ref_poc = c["msr"], c["sr"], 0
+    cost = R.refdrv_me_ipel_diamond(org0, c["s"], ptr(c["org_bi"]), ref0, c["s"], c["x"], c["y"], lg, lg, 10, ptr(rng), ptr(gmvp), ptr(mvi),
+                                    c["bi"], c["faststep"], c["lambda_mv"], 2, 0, c["mot_other"], c["msr"], gop, poc, ref_poc, ptr(mn), ptr(mx),
+                                    c["beststep_in"], out)
+    return cost, out[0], out[1], out[2], out[3]
+
+
+@pytest.mark.parametrize("bi", [0, 1, 2])
+@pytest.mark.parametrize("textured", [False, True])
+def test_me_ipel_diamond_matches_reference(bi, textured):
+    r = np.random.default_rng(900 + bi * 2 + textured)
+    steps = set()
+    for it in range(60):
+        c = make_case(r, int(r.choice([8, 16, 32, 64])), bi, textured)
+        cost, mvx, mvy, beststep, mot = run_ref(c)
+        res = run_oracle(c)
+        assert (res.cost, res.mv[0], res.mv[1], res.beststep) == (cost, mvx, mvy, beststep), (it, c["S"], c["x"], c["y"])
+        if bi != 1 and res.best_mv_bits > 0:
+            assert mot == res.best_mv_bits
+        steps.add(beststep)
+    if textured and bi != 1:
+        assert max(steps) >= 4  # the diamond rings were actually exercised

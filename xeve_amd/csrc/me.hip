@@ -1,0 +1,195 @@
+// xeve_amd/csrc/me.hip -- integer-pel diamond motion search on the GPU: the consumer of the SAD kernel.
+//
+// reference: me_ipel_diamond  src_base/xeve_pinter.c:363-551, with get_mv_bits (:74-120), MV_COST (:47) and the
+// re-centring of get_range_ipel (:122-140).  ONE WAVE PER JOB runs the whole data-dependent search: round 0 is the
+// dense (2d+1)^2 grid around the clipped start, later rounds are 4 / 8 / 16-point diamonds of doubling radius around
+// the INITIAL centre, until `faststep` rounds pass without improvement.  Per candidate the block SAD is a DPP
+// butterfly over the candidate's lane group (same lane layout as k_sad_sq); per round the winner is a wave-wide
+// minimum over 64-bit keys (cost << 32 | evaluation order), which reproduces the reference's
+// "first strictly smaller cost wins" tie-break exactly.
+#include "xh_common.h"
+
+template <int S> struct MGeo {
+    static constexpr int LPR = S / 8, RPP = XH_WAVE / LPR, CPP = RPP >= S ? RPP / S : 1, NP = RPP >= S ? 1 : S / RPP, GROUP = XH_WAVE / CPP;
+};
+
+// 16-point diamond of L1 radius 4 (xeve_pinter.c:57-65); the 8-point ring is every other point halved
+__device__ __constant__ int8_t c_dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1, 3}, {0, 4}, {1, 3}, {2, 2}, {3, 1},
+                                                 {4, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -4}, {-1, -3}, {-2, -2}, {-3, -1}};
+
+// one component of get_mv_bits: xeve_tbl_mv_bits in closed form (incl. its -2047 entry) / exp-Golomb beyond +-2048
+__device__ __forceinline__ int mvd_bits(int mvd)
+{
+    const unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd);
+    if(mvd > 2048 || mvd <= -2048) {
+        unsigned nn = (a + 1) >> 12;
+        int len_i = 11;
+        while(len_i < 16 && nn != 0) nn >>= 1, len_i++;
+        return (len_i << 1) + 2;
+    }
+    if(mvd == 0) return 1;
+    if(mvd == -2047) return 22;
+    return 2 * (31 - __clz((int)(a + 1))) + 2;
+}
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int S, bool BI>
+__global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi,
+                                                    const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job *__restrict__ jobs,
+                                                    int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out)
+{
+    using G = MGeo<S>;
+    const int lane = threadIdx.x & 63;
+    const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(j >= njobs) return;
+    const xeve_hip_me_job jb = jobs[j];
+    const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
+
+    // the original block (org_bi for bi-prediction refinement: 2*org - pred, may be negative) stays in registers
+    u32x4 org[G::NP];
+    {
+        const pel *o  = BI ? org_bi + jb.org_off : org0 + (long)jb.y * s_org + jb.x;
+        const int  so = BI ? S : s_org;
+#pragma unroll
+        for(int p = 0; p < G::NP; p++) {
+            org[p] = xh_ld8(o + (row0 + p * G::RPP) * so + col);
+            if(BI) org[p] ^= 0x80008000u; // bias once: v_sad_u16 is unsigned
+        }
+    }
+    int r0 = jb.range[0], r1 = jb.range[1], r2 = jb.range[2], r3 = jb.range[3];
+    int bx = clip3(P.min_clip[0], P.max_clip[0], jb.mvi[0] >> 2), by = clip3(P.min_clip[1], P.max_clip[1], jb.mvi[1] >> 2);
+    const int ix = bx, iy = by;
+    unsigned long long best_key = 0xFFFFFFFF00000000ull; // cost_best = UINT32_MAX, order 0 (nothing evaluated beats it on a tie)
+    int best_bits = 0, beststep = P.beststep_in, step = 0, not_found = 0;
+    unsigned order = 1;
+    const int d = P.bi == 1 ? 5 : 2; // BI_STEP : 2 (xeve_pinter.c:409-416)
+
+    for(;;) {
+        not_found++;
+        // ---- candidate set of this round
+        const bool dense = step <= 2, coarse = step > 8;
+        int x0 = 0, y0 = 0, wd = 1, nc;
+        if(dense) {
+            x0 = bx <= r0 ? bx : bx - d, y0 = by <= r1 ? by : by - d;
+            const int x1 = bx >= r2 ? bx : bx + d, y1 = by >= r3 ? by : by + d;
+            wd = x1 - x0 + 1;
+            nc = wd * (y1 - y0 + 1);
+        }
+        else nc = coarse ? 16 : (step == 4 ? 5 : 9);
+        unsigned long long round_key = ~0ull;
+        int round_bits = 0;
+        for(int c0 = 0; c0 < nc; c0 += G::CPP) {
+            const int k = c0 + slot;
+            int mx, my;
+            if(dense) {
+                const int q = k / wd;
+                mx = x0 + (k - q * wd), my = y0 + q;
+            }
+            else if(coarse) mx = ix + (step >> 2) * c_dia16[k & 15][0], my = iy + (step >> 2) * c_dia16[k & 15][1];
+            else {
+                const int i = step == 4 ? 2 * k : k; // 4-point ring skips the odd points; i == 8 is the centre
+                const int dx = i < 8 ? c_dia16[(2 * i) & 15][0] / 2 : 0, dy = i < 8 ? c_dia16[(2 * i) & 15][1] / 2 : 0;
+                mx = ix + (step >> 1) * dx, my = iy + (step >> 1) * dy;
+            }
+            const bool valid = k < nc && mx <= r2 && mx >= r0 && my <= r3 && my >= r1;
+            int acc = 0;
+            if(valid) {
+                const pel *r = ref0 + (long)(my + row0) * s_ref + mx + col;
+#pragma unroll
+                for(int p = 0; p < G::NP; p++) {
+                    u32x4 v = xh_ld8(r + (long)p * G::RPP * s_ref);
+                    if(BI) v ^= 0x80008000u;
+                    acc = __builtin_amdgcn_sad_u16(org[p].x, v.x, acc);
+                    acc = __builtin_amdgcn_sad_u16(org[p].y, v.y, acc);
+                    acc = __builtin_amdgcn_sad_u16(org[p].z, v.z, acc);
+                    acc = __builtin_amdgcn_sad_u16(org[p].w, v.w, acc);
+                }
+            }
+            acc = xh_group_sum<G::GROUP>(acc);
+            int bits = mvd_bits((mx << 2) - jb.gmvp[0]) + mvd_bits((my << 2) - jb.gmvp[1]) + P.refi_bits;
+            if(BI) bits += P.extra_bits;
+            const int sad = acc >> shift;
+            const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(BI ? sad >> 1 : sad);
+            unsigned long long key = valid ? ((unsigned long long)cost << 32) | (order + (unsigned)k) : ~0ull;
+            int kb = bits;
+            // minimum over the CPP candidate groups of this pass (every lane of a group holds the same key)
+#pragma unroll
+            for(int m = G::GROUP; m < 64; m <<= 1) {
+                const unsigned lo = __shfl_xor((unsigned)key, m, 64), hi = __shfl_xor((unsigned)(key >> 32), m, 64);
+                const int ob = __shfl_xor(kb, m, 64);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                if(o < key) key = o, kb = ob;
+            }
+            if(key < round_key) round_key = key, round_bits = kb;
+        }
+        // ---- wave-uniform bookkeeping (everything below is identical in all lanes; force it into SGPRs)
+        const unsigned rk_hi = (unsigned)uni((int)(round_key >> 32)), rk_lo = (unsigned)uni((int)round_key);
+        round_key  = ((unsigned long long)rk_hi << 32) | rk_lo;
+        round_bits = uni(round_bits);
+        if(round_key < best_key) { // cost < cost_best, earliest candidate on ties
+            best_key = round_key, best_bits = round_bits, not_found = 0;
+            const int k = (int)(rk_lo - order);
+            if(dense) {
+                const int q = k / wd;
+                bx = x0 + (k - q * wd), by = y0 + q, beststep = 2;
+            }
+            else {
+                int dx, dy, mul;
+                if(coarse) dx = c_dia16[k][0], dy = c_dia16[k][1], mul = step >> 2;
+                else {
+                    const int i = step == 4 ? 2 * k : k;
+                    dx = i < 8 ? c_dia16[(2 * i) & 15][0] / 2 : 0, dy = i < 8 ? c_dia16[(2 * i) & 15][1] / 2 : 0, mul = step >> 1;
+                }
+                bx = ix + mul * dx, by = iy + mul * dy, beststep = step;
+            }
+            bx = uni(bx), by = uni(by);
+        }
+        order += (unsigned)nc;
+        if(dense) { // get_range_ipel around the best position so far (xeve_pinter.c:463-468, 122-140)
+            const int sr = P.bi == 1 ? 5 : P.range_recentre;
+            r0 = clip3(P.min_clip[0], P.max_clip[0], bx - sr), r2 = clip3(P.min_clip[0], P.max_clip[0], bx + sr);
+            r1 = clip3(P.min_clip[1], P.max_clip[1], by - sr), r3 = clip3(P.min_clip[1], P.max_clip[1], by + sr);
+            step += 2;
+        }
+        if(not_found == P.faststep) break;
+        if(P.bi == 1) break;
+        step <<= 1;
+        if(step > P.max_search_range) break;
+    }
+    if(lane == 0) {
+        xeve_hip_me_result res;
+        res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
+        res.cost = (uint32_t)(best_key >> 32), res.beststep = beststep, res.best_mv_bits = best_bits;
+        out[j] = res;
+    }
+}
+
+extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref,
+                                             const xeve_hip_me_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
+                                             const xeve_hip_me_params *params, xeve_hip_me_result *results, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org0 && ref0 && jobs && params && results && njobs >= 0);
+    XH_REQUIRE(log2w == log2h && log2w >= 3 && log2w <= 6); // Baseline inter CUs are square 8..64 (xeve_enc.c:2440-2443)
+    XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14 && params->bi >= 0 && params->bi <= 3 && params->faststep >= 1);
+    XH_REQUIRE(params->bi == 0 || org_bi != nullptr);
+    if(njobs == 0) return XEVE_HIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3  grid((njobs + 3) / 4);
+    const int   shift = bit_depth - 8;
+    const xeve_hip_me_params P = *params;
+#define ME_LAUNCH(S)                                                                                                          \
+    do {                                                                                                                      \
+        if(P.bi) k_me_diamond<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results);  \
+        else k_me_diamond<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results);     \
+    } while(0)
+    if(log2w == 3) ME_LAUNCH(8);
+    else if(log2w == 4) ME_LAUNCH(16);
+    else if(log2w == 5) ME_LAUNCH(32);
+    else ME_LAUNCH(64);
+#undef ME_LAUNCH
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -173,6 +173,21 @@ def residual_rdo(org, s_org, pred, s_pred, jobs, log2w, log2h, bit_depth, qp, is
                                                  int(zero_test), _ptr(_i16(coef)), _ptr(_i16(rec)), s_rec, _ptr(nnz), _ptr(ssd), _stream()))
 
 
+def me_ipel_diamond_jobs(org_plane, org_origin, s_org, org_bi, ref_plane, ref_origin, s_ref, jobs_np, log2, bit_depth, params):
+    """One complete me_ipel_diamond per job (xeve_hip_me_ipel_diamond_jobs).  org_plane / ref_plane are padded int16 planes,
+    *_origin the element offset of picture sample (0,0) inside them; jobs_np a numpy array of lib.ME_JOB_DTYPE; params a
+    lib.MeParams.  Returns a numpy array of lib.ME_RESULT_DTYPE."""
+    L = _lib.load()
+    dev = org_plane.device
+    jobs = torch.from_numpy(jobs_np.view(np.uint8).reshape(len(jobs_np), -1).copy()).to(dev)
+    res = torch.empty((len(jobs_np), np.dtype(_lib.ME_RESULT_DTYPE).itemsize), dtype=torch.uint8, device=dev)
+    _lib.check(L.xeve_hip_me_ipel_diamond_jobs(C.c_void_p(_i16(org_plane).data_ptr() + 2 * org_origin), s_org,
+                                               _ptr(_i16(org_bi)) if org_bi is not None else None,
+                                               C.c_void_p(_i16(ref_plane).data_ptr() + 2 * ref_origin), s_ref, _ptr(jobs), len(jobs_np), log2, log2,
+                                               bit_depth, C.byref(params), _ptr(res), _stream()))
+    return res.cpu().numpy().view(_lib.ME_RESULT_DTYPE).reshape(-1)
+
+
 # quantiser scale tables of the standard (reference: src_base/xeve_tq.c:37-38, xeve_tbl.c:237)
 QUANT_SCALE = ((26214, 23302, 20560, 18396, 16384, 14764), (26214, 23302, 20560, 18396, 16384, 14564))
 DQ_SCALE = (40, 45, 51, 57, 64, 71)

@@ -20,6 +20,16 @@ class McJob(C.Structure):  # xeve_hip_mc_job
     _fields_ = [("gmv_x", C.c_int32), ("gmv_y", C.c_int32), ("pred_off", C.c_int32), ("frac", C.c_int32)]
 
 
+class MeParams(C.Structure):  # xeve_hip_me_params
+    _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
+                ("faststep", C.c_int32), ("max_search_range", C.c_int32), ("range_recentre", C.c_int32),
+                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("beststep_in", C.c_int32)]
+
+
+ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_me_job
+ME_RESULT_DTYPE = [("mv", "<i2", 2), ("cost", "<u4"), ("beststep", "<i4"), ("best_mv_bits", "<i4")]  # xeve_hip_me_result
+
+
 # reference: src_base/xeve_sad.h:41-45, xeve_mc.h:85-87, xeve_type.h:169-170
 FN_SAD = C.CFUNCTYPE(c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int)
 FN_SATD = FN_SAD
@@ -57,6 +67,8 @@ FUNCTIONS = {
     "xeve_hip_dquant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_residual_rdo": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_me_ipel_diamond_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 TABLES = {
