@@ -89,6 +89,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if not os.path.exists(os.path.join(ROOT, "xeve_amd", "lib", "libxeve_hip.so")) and local == 0:
+        import __graft_entry__
+
+        __graft_entry__.build()  # fresh checkout on the GPU box: compile once (hipcc is in the image)
+    if world > 1:
+        dist.barrier()
     import xeve_amd
     from xeve_amd.workload import N_LIST, N_PASS, HotPathPass
 

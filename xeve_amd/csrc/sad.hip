@@ -423,10 +423,13 @@ static int sad_jobs_impl(const pel *p1, int s1, const pel *p2, const pel *p2s, i
     } while(0)
     // one-candidate calls (the table layer, sub-pel rounds) take the unsplit form
     const bool many = ncand >= 32;
-    if(w == h && w == 8) LAUNCH_SQ(8, 1, 4);
-    else if(w == h && w == 16) LAUNCH_SQ(16, 1, 4);
-    else if(w == h && w == 32) { if(many) LAUNCH_SQ(32, 2, 2); else LAUNCH_SQ(32, 1, 1); }
-    else if(w == h && w == 64) { if(many) LAUNCH_SQ(64, 4, 1); else LAUNCH_SQ(64, 1, 1); }
+    const int  tune = (flags >> 8) & 15; // developer override of the (SPLIT, UNROLL) choice, tools/probe_tune.py
+    // defaults from the sweeps of tools/probe_tune.py on the 90-candidate search round (more loads in flight per wave,
+    // and for the large blocks more waves per job, until the L1/TA path saturates)
+    if(w == h && w == 8) { if(!many) LAUNCH_SQ(8, 1, 1); else if(tune == 1) LAUNCH_SQ(8, 1, 6); else LAUNCH_SQ(8, 1, 12); }
+    else if(w == h && w == 16) { if(!many) LAUNCH_SQ(16, 1, 1); else if(tune == 1) LAUNCH_SQ(16, 2, 8); else LAUNCH_SQ(16, 4, 6); }
+    else if(w == h && w == 32) { if(!many) LAUNCH_SQ(32, 1, 1); else if(tune == 1) LAUNCH_SQ(32, 2, 8); else LAUNCH_SQ(32, 4, 8); }
+    else if(w == h && w == 64) { if(!many) LAUNCH_SQ(64, 1, 1); else if(tune == 1) LAUNCH_SQ(64, 4, 2); else LAUNCH_SQ(64, 4, 4); }
     else if(w <= 4 && h <= 4) {
         const long items = (long)njobs * ncand;
         k_dist_tiny<false><<<dim3((unsigned)((items + 255) / 256)), 256, 0, st>>>(p1, s1, p2, s2, jobs, items, cand_off, ncand, w, h, shift, out);

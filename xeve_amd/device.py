@@ -65,11 +65,11 @@ def plane_shift1(plane):
     return out
 
 
-def sad_jobs_dual(p1, s1, p2, p2_shift1, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None):
+def sad_jobs_dual(p1, s1, p2, p2_shift1, s2, jobs, cand_off, w, h, bit_depth, signed=False, out=None, tune=0):
     if out is None:
         out = torch.empty((jobs.shape[0], cand_off.numel()), dtype=torch.int32, device=p1.device)
     _lib.check(_lib.load().xeve_hip_sad_jobs_dual(_ptr(_i16(p1)), s1, _ptr(_i16(p2)), _ptr(_i16(p2_shift1)), s2, _ptr(jobs), jobs.shape[0],
-                                                  _ptr(cand_off), cand_off.numel(), w, h, bit_depth, 1 if signed else 0, _ptr(out),
+                                                  _ptr(cand_off), cand_off.numel(), w, h, bit_depth, (1 if signed else 0) | (tune << 8), _ptr(out),
                                                   _stream()))
     return out
 
