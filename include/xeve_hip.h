@@ -140,6 +140,15 @@ int xeve_hip_mc_l_jobs(const xeve_hip_pel *ref, int s_ref, xeve_hip_pel *pred, i
 /* xeve_mc_c_{00,n0,0n,nn} (xeve_mc.c:259-381); coef is a HOST pointer to the [32][4] table in use */
 int xeve_hip_mc_c_jobs(const xeve_hip_pel *ref, int s_ref, xeve_hip_pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
                        int w, int h, int bit_depth, const int16_t (*coef)[4], void *stream);
+/* Fused forms: the interpolated block is compared with the original at org + jobs[j].pred_off (pred_off is reused as the
+ * block's offset inside `org`) and never written.  sad[j] as xeve_mc_l + xeve_sad_16b in me_spel_pattern
+ * (xeve_pinter.c:593-627); ssd[j] as the MC + xeve_ssd_16b of the skip/merge analysis (xeve_pinter.c:1437-1458).
+ * luma: w % 8 == 0; chroma: w % 4 == 0. */
+int xeve_hip_mc_l_sad_jobs(const xeve_hip_pel *ref, int s_ref, const xeve_hip_pel *org, int s_org, const xeve_hip_mc_job *jobs, int njobs,
+                           int w, int h, int bit_depth, const int16_t (*coef)[8], int32_t *sad, void *stream);
+int xeve_hip_mc_ssd_jobs(int luma, const xeve_hip_pel *ref, int s_ref, const xeve_hip_pel *org, int s_org, const xeve_hip_mc_job *jobs,
+                         int njobs, int w, int h, int bit_depth, const void *coef /* [16][8] luma or [32][4] chroma */, int64_t *ssd,
+                         void *stream);
 /* dst = (a + b + 1) >> 1 over n dense samples (xeve_average_16b_no_clip, xeve_mc.c:449-463) */
 int xeve_hip_avg(const int16_t *a, const int16_t *b, int16_t *dst, int64_t n, void *stream);
 

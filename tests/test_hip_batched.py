@@ -347,3 +347,36 @@ def test_fused_residual_rdo_vs_oracle(dev, lw, lh):
             y0, x0 = offs[b] // s, offs[b] % s
             assert np.array_equal(rec[y0:y0 + h, x0:x0 + w], e[:, :w]), ("rec", lw, lh, qp, b)
             assert ssd[b, 1] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(rec, offs[b]), s, s, bd)
+
+
+@pytest.mark.parametrize("luma", [True, False])
+def test_fused_mc_distortion_vs_oracle(dev, luma):
+    """xeve_hip_mc_l_sad_jobs / xeve_hip_mc_ssd_jobs: interpolate and compare with the original in one launch."""
+    import torch
+
+    from xeve_amd import device as D
+
+    r = np.random.default_rng(800 + luma)
+    O = oracle()
+    pad, W, H = 72, 192, 128
+    s = W + 2 * pad
+    ref = r.integers(0, 1024, size=(H + 2 * pad, s), dtype=np.int16)
+    org = r.integers(0, 1024, size=(H + 2 * pad, s), dtype=np.int16)
+    d_ref, d_org = torch.from_numpy(ref).to(dev), torch.from_numpy(org).to(dev)
+    unit = 16 if luma else 32
+    for (w, h) in ([(8, 8), (16, 16), (32, 32), (64, 64)] if luma else [(4, 4), (8, 8), (16, 16), (32, 32)]):
+        n = 70
+        gx = [(pad + int(r.integers(-30, W + 30 - w))) * unit + int(r.integers(0, unit // 4)) * 4 for _ in range(n)]
+        gy = [(pad + int(r.integers(-30, H + 30 - h))) * unit + int(r.integers(0, unit // 4)) * 4 for _ in range(n)]
+        frac = [int((x & (unit - 1)) != 0) | (int((y & (unit - 1)) != 0) << 1) for x, y in zip(gx, gy)]
+        ooff = [(pad + int(r.integers(0, H - h))) * s + pad + int(r.integers(0, W - w)) for _ in range(n)]
+        jobs = D.make_mc_jobs(gx, gy, ooff, frac, dev)
+        ssd = D.mc_ssd_jobs(luma, d_ref, s, d_org, s, jobs, w, h, 10, torch.zeros(n, dtype=torch.int64, device=dev)).cpu().numpy()
+        sad = D.mc_l_sad_jobs(d_ref, s, d_org, s, jobs, w, h, 10, torch.zeros(n, dtype=torch.int32, device=dev)).cpu().numpy() if luma else None
+        for i in range(n):
+            e = np.zeros((h, w), np.int16)
+            (O.xo_mc_l if luma else O.xo_mc_c)(frac[i] & 1, frac[i] >> 1, ptr(ref), gx[i], gy[i], s, w, ptr(e), w, h, 10,
+                                               O.mc_l_coeff if luma else O.mc_c_coeff)
+            assert ssd[i] == O.xo_ssd(w, h, ptr(org, ooff[i]), ptr(e), s, w, 10), (luma, w, i)
+            if luma:
+                assert sad[i] == O.xo_sad(w, h, ptr(org, ooff[i]), ptr(e), s, w, 10), (w, i)

@@ -69,10 +69,15 @@ __device__ __forceinline__ int clipi(int v, int hi) { return v < 0 ? 0 : (v > hi
 // `jpb` jobs per workgroup: small blocks (8x8 luma = 8 row units) are packed so that all 256 threads have a unit.
 // Phase 1 (only for jobs with both filters): horizontal pass of h + TAPS - 1 rows into LDS.  Phase 2: every output
 // unit, by the job's own variant.  Jobs of one launch may mix variants (quarter-pel merge / final MC).
-template <int TAPS, int SEG>
+//
+// OUT = 0: the predicted block is stored (pred + job.pred_off).  OUT = 1 / 2: it is compared on the fly with the original
+// block at org + job.pred_off and only the SAD / SSD leaves the CU (me_spel_pattern's xeve_mc_l + xeve_sad_16b,
+// xeve_pinter.c:593-627; skip/merge analysis' MC + xeve_ssd_16b, xeve_pinter.c:1437-1458).
+template <int TAPS, int SEG, int OUT>
 __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
                                             const xeve_hip_mc_job *__restrict__ jobs, int njobs, int jpb, int w, int h,
-                                            int bit_depth, CoefTab<TAPS> tab)
+                                            int bit_depth, CoefTab<TAPS> tab, const pel *__restrict__ org, int s_org, int dshift,
+                                            void *__restrict__ dist_out)
 {
     static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
     extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // jpb * (h + TAPS - 1) * w
@@ -82,6 +87,10 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
     const int nj = min(jpb, njobs - j0);
     if(nj <= 0) return;
     const int maxv = (1 << bit_depth) - 1, segs = w / SEG, rows = h + TAPS - 1;
+    // per-job distortion accumulators live behind the horizontal-pass buffer
+    unsigned long long *dacc = reinterpret_cast<unsigned long long *>(hbuf + (((size_t)jpb * rows * w + 3) & ~(size_t)3));
+    if(OUT != 0)
+        for(int i = threadIdx.x; i < nj; i += blockDim.x) dacc[i] = 0;
     const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4;
     const int shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
     const int round2 = 1 << (shift2 - 1);
@@ -106,11 +115,15 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
         const pel *src = ref + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
         pel *out = pred + jb.pred_off + y * s_pred + x0;
-        if(!hx && !vy) {
-            SegIO<SEG>::st(out, SegIO<SEG>::ld(src));
-            continue;
-        }
         int acc[SEG];
+        if(!hx && !vy) {
+            if(OUT == 0) {
+                SegIO<SEG>::st(out, SegIO<SEG>::ld(src));
+                continue;
+            }
+            unpack<SEG>(SegIO<SEG>::ld(src), acc);
+        }
+        else
         if(hx && !vy) {
             hfir<TAPS, SEG>(src - BACK, tab.c[jb.gmv_x & FM], acc);
 #pragma unroll
@@ -143,7 +156,25 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
                 for(int i = 0; i < SEG; i++) acc[i] = clipi((acc[i] + round2) >> shift2, maxv);
             }
         }
-        SegIO<SEG>::st(out, pack<SEG>(acc));
+        if(OUT == 0) SegIO<SEG>::st(out, pack<SEG>(acc));
+        else {
+            int o[SEG];
+            unpack<SEG>(SegIO<SEG>::ld(org + jb.pred_off + (long)y * s_org + x0), o);
+            unsigned long long dsum = 0;
+#pragma unroll
+            for(int i = 0; i < SEG; i++) {
+                const int df = o[i] - acc[i];
+                dsum += OUT == 1 ? (unsigned)(df < 0 ? -df : df) : (unsigned)((df * df) >> dshift);
+            }
+            atomicAdd(&dacc[jl], dsum);
+        }
+    }
+    if(OUT != 0) {
+        __syncthreads();
+        for(int i = threadIdx.x; i < nj; i += blockDim.x) {
+            if(OUT == 1) static_cast<int32_t *>(dist_out)[j0 + i] = (int32_t)(dacc[i] >> dshift);
+            else static_cast<int64_t *>(dist_out)[j0 + i] = (int64_t)dacc[i];
+        }
     }
 }
 
@@ -201,32 +232,40 @@ __global__ void k_avg(const int16_t *__restrict__ a, const int16_t *__restrict__
     }
 }
 
-template <int TAPS>
+template <int TAPS, int OUT>
 static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs, int w, int h,
-                     int bit_depth, const int16_t *coef, hipStream_t st)
+                     int bit_depth, const int16_t *coef, hipStream_t st, const pel *org = nullptr, int s_org = 0, void *dist_out = nullptr)
 {
     XH_ENTER();
-    XH_REQUIRE(ref && pred && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
+    XH_REQUIRE(ref && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
+    XH_REQUIRE(OUT != 0 ? (org && dist_out) : (pred != nullptr));
     XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
     if(njobs == 0) return XEVE_HIP_OK;
     CoefTab<TAPS> tab;
     memcpy(tab.c, coef, sizeof(tab.c));
+    const int dshift = OUT == 1 ? bit_depth - 8 : (bit_depth - 8) * 2;
     bool done = false;
     if(w % 8 == 0) {
         const int jpb = std::max(1, 256 / (h * (w / 8)));
-        const size_t lds = sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w;
-        k_mc<TAPS, 8><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab);
+        const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
+        k_mc<TAPS, 8, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out);
         done = true;
     }
     if constexpr(TAPS == 4) {
         if(!done && w % 4 == 0) {
             const int jpb = std::max(1, 256 / (h * (w / 4)));
-            const size_t lds = sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w;
-            k_mc<4, 4><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab);
+            const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
+            k_mc<4, 4, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out);
             done = true;
         }
     }
-    if(!done) k_mc_any<TAPS><<<njobs, 64, 0, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+    if(!done) {
+        if(OUT != 0) {
+            xh_set_error("fused MC + distortion needs w %% %d == 0 (got %dx%d); use the unfused calls", TAPS == 8 ? 8 : 4, w, h);
+            return XEVE_HIP_ERR_ARG;
+        }
+        k_mc_any<TAPS><<<njobs, 64, 0, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+    }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
@@ -234,13 +273,26 @@ static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xev
 extern "C" int xeve_hip_mc_l_jobs(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
                                   int w, int h, int bit_depth, const int16_t (*coef)[8], void *stream)
 {
-    return mc_launch<8>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
+    return mc_launch<8, 0>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
 }
 
 extern "C" int xeve_hip_mc_c_jobs(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs,
                                   int w, int h, int bit_depth, const int16_t (*coef)[4], void *stream)
 {
-    return mc_launch<4>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
+    return mc_launch<4, 0>(ref, s_ref, pred, s_pred, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream);
+}
+
+extern "C" int xeve_hip_mc_l_sad_jobs(const pel *ref, int s_ref, const pel *org, int s_org, const xeve_hip_mc_job *jobs, int njobs, int w,
+                                      int h, int bit_depth, const int16_t (*coef)[8], int32_t *sad, void *stream)
+{
+    return mc_launch<8, 1>(ref, s_ref, nullptr, 0, jobs, njobs, w, h, bit_depth, coef ? &coef[0][0] : nullptr, (hipStream_t)stream, org, s_org, sad);
+}
+
+extern "C" int xeve_hip_mc_ssd_jobs(int luma, const pel *ref, int s_ref, const pel *org, int s_org, const xeve_hip_mc_job *jobs, int njobs,
+                                    int w, int h, int bit_depth, const void *coef, int64_t *ssd, void *stream)
+{
+    if(luma) return mc_launch<8, 2>(ref, s_ref, nullptr, 0, jobs, njobs, w, h, bit_depth, (const int16_t *)coef, (hipStream_t)stream, org, s_org, ssd);
+    return mc_launch<4, 2>(ref, s_ref, nullptr, 0, jobs, njobs, w, h, bit_depth, (const int16_t *)coef, (hipStream_t)stream, org, s_org, ssd);
 }
 
 extern "C" int xeve_hip_avg(const int16_t *a, const int16_t *b, int16_t *dst, int64_t n, void *stream)

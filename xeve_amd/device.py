@@ -122,6 +122,23 @@ def mc_jobs(luma, ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, coef=None):
     return pred
 
 
+def mc_l_sad_jobs(ref, s_ref, org, s_org, jobs, w, h, bit_depth, out, coef=None):
+    """fused luma interpolation + SAD against the original (jobs[:, 2] = block offset inside `org`)"""
+    coef = baseline_coef_l() if coef is None else coef
+    _lib.check(_lib.load().xeve_hip_mc_l_sad_jobs(_ptr(_i16(ref)), s_ref, _ptr(_i16(org)), s_org, _ptr(jobs), jobs.shape[0], w, h, bit_depth,
+                                                  C.c_void_p(coef.ctypes.data), _ptr(out), _stream()))
+    return out
+
+
+def mc_ssd_jobs(luma, ref, s_ref, org, s_org, jobs, w, h, bit_depth, out, coef=None):
+    """fused interpolation + SSD against the original"""
+    if coef is None:
+        coef = baseline_coef_l() if luma else baseline_coef_c()
+    _lib.check(_lib.load().xeve_hip_mc_ssd_jobs(int(luma), _ptr(_i16(ref)), s_ref, _ptr(_i16(org)), s_org, _ptr(jobs), jobs.shape[0], w, h, bit_depth,
+                                                C.c_void_p(coef.ctypes.data), _ptr(out), _stream()))
+    return out
+
+
 def avg(a, b, out=None):
     L = _lib.load()
     if out is None:

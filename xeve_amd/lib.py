@@ -59,6 +59,8 @@ FUNCTIONS = {
     "xeve_hip_diff_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xeve_hip_mc_l_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xeve_hip_mc_c_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_mc_l_sad_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_mc_ssd_jobs": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_avg": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "xeve_hip_trans": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_itrans": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -124,7 +124,14 @@ class HotPathPass:
             cx, cy = (PAD_C + xs // 2) * 32 + mvx * 4, (PAD_C + ys // 2) * 32 + mvy * 4
             fc = ((cx & 31) != 0).astype(np.int32) | (((cy & 31) != 0).astype(np.int32) << 1)
             return (D.make_mc_jobs(gx, gy, dense, fl, dev), D.make_mc_jobs(cx, cy, np.arange(n) * Sc * Sc, fc, dev))
+        def with_org_off(j, off):
+            j = j.clone()
+            j[:, 2] = off
+            return j
+        lv["hp_jobs_org"] = [[with_org_off(j, lv["off_l"]) for j in per] for per in lv["hp_jobs"]]
+        lv["ssd1"] = torch.empty(n, dtype=torch.int64, device=dev)
         lv["merge_jobs"] = [qpel_jobs() for _ in range(N_MERGE)]
+        lv["merge_jobs_org"] = [(with_org_off(jl, lv["off_l"]), with_org_off(jc, lv["off_c"])) for jl, jc in lv["merge_jobs"]]
         lv["final_jobs"] = [qpel_jobs() for _ in range(N_LIST)]
         lv["resi"] = [torch.empty((n, S * S), dtype=torch.int16, device=dev)] + [torch.empty((n, Sc * Sc), dtype=torch.int16, device=dev) for _ in range(2)]
         lv["coef"] = [torch.empty_like(t) for t in lv["resi"]]
@@ -150,18 +157,15 @@ class HotPathPass:
             if time_sad:
                 e1.record()
                 self.sad_events.append((S, "me", e0, e1))
-            # B. half-pel refinement
+            # B. half-pel refinement: interpolation + SAD fused (the prediction never leaves the CU)
             for l in range(N_LIST if only in (None, "B") else 0):
-                for jobs in lv["hp_jobs"][l]:
-                    D.mc_jobs(True, self.ref[l][0], s_l, lv["pred_l"][0], S, jobs, S, S, bd)
-                    D.sad_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd, out=lv["sad1"])
-            # C. skip / merge candidates
-            for jl, jc in (lv["merge_jobs"] if only in (None, "C") else ()):
-                D.mc_jobs(True, self.ref[0][0], s_l, lv["pred_l"][0], S, jl, S, S, bd)
-                D.ssd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
+                for jobs in lv["hp_jobs_org"][l]:
+                    D.mc_l_sad_jobs(self.ref[l][0], s_l, org[0], s_l, jobs, S, S, bd, lv["sad1"])
+            # C. skip / merge candidates: interpolation + SSD fused, Y / U / V
+            for jl, jc in (lv["merge_jobs_org"] if only in (None, "C") else ()):
+                D.mc_ssd_jobs(True, self.ref[0][0], s_l, org[0], s_l, jl, S, S, bd, lv["ssd1"])
                 for c in (1, 2):
-                    D.mc_jobs(False, self.ref[0][c], s_c, lv["pred_c"][c - 1], Sc, jc, Sc, Sc, bd)
-                    D.ssd_jobs(org[c], s_c, lv["pred_c"][c - 1], Sc, lv["dense_jobs_c"], self.zero_cand, Sc, Sc, bd)
+                    D.mc_ssd_jobs(False, self.ref[0][c], s_c, org[c], s_c, jc, Sc, Sc, bd, lv["ssd1"])
             if only not in (None, "D", "D1", "D2", "E"):
                 continue
             # D. residual RDO of the (bi-predicted) winner
