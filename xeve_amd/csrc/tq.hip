@@ -21,10 +21,12 @@
 
 int xh_dct_mfma_init(const int8_t *m32, const int8_t *m64);
 int xh_dct_mfma(bool fwd, int16_t *coef, int nblk, int n, int shift, hipStream_t st);
-static bool g_use_mfma = true;
+static bool g_use_mfma = true, g_use_rows = true;
 
 // All six matrices, row-major [k][x], concatenated; offset of size 2^l is XH_TM_OFF(l).
 __device__ __constant__ int8_t c_tm[4 + 16 + 64 + 256 + 1024 + 4096];
+// the 4-, 8- and 16-point matrices widened to int32: read with wave-uniform indices (scalar loads) by k_rdo_rows
+__device__ __constant__ int32_t c_tm32[4 + 16 + 64 + 256];
 __host__ __device__ constexpr int xh_tm_off(int log2n) { return ((1 << (2 * log2n)) - 4) / 3; } // 0,4,20,84,340,1364
 
 // EVC integer DCT-II: M_N[k][x] = +-g[fold((2x+1) * k * 64/N mod 256)], g[j] = round(64*sqrt(2)*cos(j*pi/128)).
@@ -45,8 +47,12 @@ int xh_tq_init()
             }
     }
     XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tm), tm, sizeof(tm)));
+    static int32_t tm32[4 + 16 + 64 + 256];
+    for(int i = 0; i < 4 + 16 + 64 + 256; i++) tm32[i] = tm[i];
+    XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tm32), tm32, sizeof(tm32)));
     const char *e = getenv("XEVE_HIP_DCT"); // developer switch: "valu" forces the LDS/VALU path for 32/64 too
     g_use_mfma    = !(e && strcmp(e, "valu") == 0);
+    g_use_rows    = g_use_mfma; // "valu" also selects the generic LDS form of the fused chain for every size
     return xh_dct_mfma_init(tm + xh_tm_off(5), tm + xh_tm_off(6));
 }
 
@@ -448,6 +454,172 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused residual chain for square 4x4 / 8x8 / 16x16 blocks, ROW-PER-LANE form: N lanes hold the N rows of a block in
+// registers (64/N blocks per wave), the 1-D transforms are fully unrolled MAC chains whose matrix entries come from
+// scalar loads, and the only exchanges are two N x N transposes through a wave-private LDS tile (no workgroup
+// barriers).  64-bit sums of pass 2 are formed exactly as two 32-bit chains over the 16-bit halves of the operand.
+// ---------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ int tm32_at(int k, int x) { return c_tm32[xh_tm_off(N == 4 ? 2 : (N == 8 ? 3 : 4)) + k * N + x]; }
+
+// out[k] = sum_x M[k][x] * in[x]   (TRANSPOSED = false)   or   sum_k M[k][x] * in[k]   (TRANSPOSED = true), 32-bit
+template <int N, bool TRANSPOSED> __device__ __forceinline__ void mat32(const int (&in)[N], int (&out)[N])
+{
+#pragma unroll
+    for(int o = 0; o < N; o++) {
+        int a = 0;
+#pragma unroll
+        for(int i = 0; i < N; i++) a += (TRANSPOSED ? tm32_at<N>(i, o) : tm32_at<N>(o, i)) * in[i];
+        out[o] = a;
+    }
+}
+// same with an exact 64-bit result: in = hi * 65536 + lo (lo unsigned 16 bit), both chains fit int32
+template <int N, bool TRANSPOSED> __device__ __forceinline__ void mat64(const int (&in)[N], long (&out)[N])
+{
+    int hi[N], lo[N];
+#pragma unroll
+    for(int i = 0; i < N; i++) hi[i] = in[i] >> 16, lo[i] = in[i] & 0xffff;
+#pragma unroll
+    for(int o = 0; o < N; o++) {
+        int ah = 0, al = 0;
+#pragma unroll
+        for(int i = 0; i < N; i++) {
+            const int m = TRANSPOSED ? tm32_at<N>(i, o) : tm32_at<N>(o, i);
+            ah += m * hi[i], al += m * lo[i];
+        }
+        out[o] = (long)ah * 65536L + (long)al;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, int s_org, const pel *__restrict__ pred, int s_pred,
+                                                  const xeve_hip_job *__restrict__ jobs, int njobs, RdoParams P,
+                                                  int16_t *__restrict__ coef, pel *__restrict__ rec, int s_rec,
+                                                  int32_t *__restrict__ nnz_out, int64_t *__restrict__ ssd_out)
+{
+    constexpr int BPW = 64 / N, PITCH = N + 1;
+    __shared__ int tile[4][BPW * N * PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, bl = lane / N, y = lane % N;
+    int *T = tile[wave] + bl * N * PITCH;
+    const int  j    = (xh_xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * BPW + bl;
+    const bool live = j < njobs;
+    const xeve_hip_job jb = live ? jobs[j] : xeve_hip_job{0, 0};
+    // 1. my row of the original and of the prediction; residual; SSD(org, pred)
+    int o[N], p[N], v[N];
+    unsigned long long ssd_p = 0, ssd_r = 0;
+    if(live) { // one row = N pels: 8-byte (N = 4) or 16-byte vector loads at any 2-byte alignment
+        const pel *po = org + jb.off1 + (long)y * s_org, *pp = pred + jb.off2 + (long)y * s_pred;
+        if(N == 4) {
+            const u32x2 a = xh_ld4(po), b = xh_ld4(pp);
+#pragma unroll
+            for(int k = 0; k < 2; k++) o[2 * k] = xh_lo16(a[k]), o[2 * k + 1] = xh_hi16(a[k]), p[2 * k] = xh_lo16(b[k]), p[2 * k + 1] = xh_hi16(b[k]);
+        }
+        else {
+#pragma unroll
+            for(int q = 0; q < N / 8; q++) {
+                const u32x4 a = xh_ld8(po + 8 * q), b = xh_ld8(pp + 8 * q);
+#pragma unroll
+                for(int k = 0; k < 4; k++) {
+                    o[8 * q + 2 * k] = xh_lo16(a[k]), o[8 * q + 2 * k + 1] = xh_hi16(a[k]);
+                    p[8 * q + 2 * k] = xh_lo16(b[k]), p[8 * q + 2 * k + 1] = xh_hi16(b[k]);
+                }
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for(int x = 0; x < N; x++) o[x] = p[x] = 0;
+    }
+#pragma unroll
+    for(int x = 0; x < N; x++) {
+        v[x] = o[x] - p[x];
+        ssd_p += (unsigned)((v[x] * v[x]) >> P.ssd_shift);
+    }
+    // 2. forward: rows (lane = y), transpose, columns (lane = kx)
+    int t[N];
+    mat32<N, false>(v, t); // t[kx] = sum_x Mw[kx][x] d[y][x]
+#pragma unroll
+    for(int k = 0; k < N; k++) T[k * PITCH + y] = t[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int k = 0; k < N; k++) t[k] = T[y * PITCH + k]; // lane kx (= y) now holds T[kx][0..N-1]
+    __builtin_amdgcn_wave_barrier();
+    long c64[N];
+    mat64<N, false>(t, c64); // c[ky] = sum_yy Mh[ky][yy] T[kx][yy]
+    int  c[N];
+    bool hit = P.z_thr < 0;
+    const long addf = 1L << (P.shift_fwd - 1);
+#pragma unroll
+    for(int k = 0; k < N; k++) {
+        c[k] = (int)(int16_t)((c64[k] + addf) >> P.shift_fwd);
+        hit |= ((long)(c[k] < 0 ? -c[k] : c[k]) * P.z_scale) >= P.z_thr;
+    }
+    // 3. zero pre-test over the block (N lanes), quant, levels out (lane kx holds column kx), dequant
+    const unsigned long long blk_mask = (N == 64 ? ~0ull : ((1ull << N) - 1)) << (bl * N);
+    hit = (__ballot(hit) & blk_mask) != 0;
+    int cnt = 0;
+#pragma unroll
+    for(int k = 0; k < N; k++) {
+        int lev = 0;
+        if(hit) {
+            const int neg = c[k] < 0;
+            lev = (int)(int16_t)((((neg ? -c[k] : c[k]) * P.q_scale) + P.q_offset) >> P.q_shift);
+            lev = (int)(int16_t)(neg ? -lev : lev);
+        }
+        cnt += lev != 0;
+        if(live) coef[(size_t)j * N * N + k * N + y] = (int16_t)lev;
+        long dq = ((long)lev * P.dq_scale + P.dq_offset) >> P.dq_shift;
+        c[k]    = (int)(dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq));
+    }
+    cnt = xh_group_sum<N>(cnt);
+    // 4. inverse: columns (lane = kx): t[yy] = sum_ky Mh[ky][yy] C[ky][kx]; transpose; rows (lane = y)
+    mat32<N, true>(c, t);
+#pragma unroll
+    for(int k = 0; k < N; k++) T[k * PITCH + y] = t[k]; // T[yy][kx]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int k = 0; k < N; k++) t[k] = T[y * PITCH + k]; // lane y holds T'[y][kx = 0..N-1]
+    mat64<N, true>(t, c64); // r[x] = sum_kx Mw[kx][x] T'[y][kx]
+    const long addi = 1L << (P.shift_inv - 1);
+#pragma unroll
+    for(int x = 0; x < N; x++) {
+        long r = (c64[x] + addi) >> P.shift_inv;
+        r      = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+        int q  = (int)(int16_t)((int)r + p[x]);
+        q      = q < 0 ? 0 : (q > P.maxv ? P.maxv : q);
+        v[x]   = q;
+        const int e = o[x] - q;
+        ssd_r += (unsigned)((e * e) >> P.ssd_shift);
+    }
+    if(live) {
+        pel *pr = rec + jb.off1 + (long)y * s_rec;
+        if(N == 4) {
+            u32x2 w2;
+            w2[0] = xh_pack16(v[0], v[1]), w2[1] = xh_pack16(v[2], v[3]);
+            xh_st4(pr, w2);
+        }
+        else {
+#pragma unroll
+            for(int q = 0; q < N / 8; q++) {
+                u32x4 w4;
+#pragma unroll
+                for(int k = 0; k < 4; k++) w4[k] = xh_pack16(v[8 * q + 2 * k], v[8 * q + 2 * k + 1]);
+                xh_st8(pr + 8 * q, w4);
+            }
+        }
+    }
+    // 5. per-block sums over the N lanes
+    for(int m = 1; m < N; m <<= 1) {
+        ssd_p += ((unsigned long long)__shfl_xor((unsigned)(ssd_p >> 32), m, 64) << 32) | __shfl_xor((unsigned)ssd_p, m, 64);
+        ssd_r += ((unsigned long long)__shfl_xor((unsigned)(ssd_r >> 32), m, 64) << 32) | __shfl_xor((unsigned)ssd_r, m, 64);
+    }
+    if(live && y == 0) {
+        nnz_out[j]         = cnt;
+        ssd_out[2 * j]     = (int64_t)ssd_p;
+        ssd_out[2 * j + 1] = (int64_t)ssd_r;
+    }
+}
+
 extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
                                      int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
                                      int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream)
@@ -479,6 +651,15 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
     hipStream_t st = (hipStream_t)stream;
     if(g_use_mfma && log2w == log2h && log2w >= 5)
         return xh_rdo_mfma(1 << log2w, org, s_org, pred, s_pred, jobs, njobs, &P, coef, rec, s_rec, nnz, ssd, st);
+    if(g_use_rows && log2w == log2h && log2w >= 2 && log2w <= 4) { // 4x4, 8x8, 16x16: row-per-lane register form
+        const int bpw = 4 * (64 >> log2w);
+        const dim3 grid((njobs + bpw - 1) / bpw);
+        if(log2w == 2) k_rdo_rows<4><<<grid, 256, 0, st>>>(org, s_org, pred, s_pred, jobs, njobs, P, coef, rec, s_rec, nnz, ssd);
+        else if(log2w == 3) k_rdo_rows<8><<<grid, 256, 0, st>>>(org, s_org, pred, s_pred, jobs, njobs, P, coef, rec, s_rec, nnz, ssd);
+        else k_rdo_rows<16><<<grid, 256, 0, st>>>(org, s_org, pred, s_pred, jobs, njobs, P, coef, rec, s_rec, nnz, ssd);
+        XH_HIP(hipGetLastError());
+        return XEVE_HIP_OK;
+    }
     const int n = 1 << (log2w + log2h), tpb = n < 256 ? n : 256, bpw = 256 / tpb;
     const size_t lds = (size_t)bpw * 8 * n + (size_t)bpw * 24 + 4 * ((size_t)(1 << (2 * log2w)) + (size_t)(1 << (2 * log2h)));
     k_rdo_valu<<<(njobs + bpw - 1) / bpw, 256, lds, st>>>(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, P, coef, rec, s_rec, nnz, ssd);
