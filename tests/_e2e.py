@@ -15,6 +15,8 @@ CASES = {
     "tiny_ldb_fast": (128, 128, 2, 7, ["--preset", "fast", "-I", "0", "-b", "0"]),
     "tiny_ra_medium": (128, 64, 4, 9, ["--preset", "medium", "-b", "1"]),
     "tiny_closed_gop": (128, 64, 8, 10, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "1"]),
+    # two CTU-row worker threads (the reference calls the tables concurrently, xeve_enc.c:336-365); `-m` given last wins
+    "tiny_ldb_fast_2threads": (128, 128, 2, 7, ["--preset", "fast", "-I", "0", "-b", "0", "-m", "2"]),
 }
 
 

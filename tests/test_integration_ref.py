@@ -49,7 +49,7 @@ def test_closed_gop_shards_concatenate_byte_identically(tmp_path):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium"])
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads"])
 def test_bitstream_identical_with_hip_tables_installed(tmp_path, name):
     w, h, n, seed, extra = CASES[name]
     yuv = str(tmp_path / "in.yuv")
