@@ -188,6 +188,20 @@ class HotPathPass:
             if only in (None, "E"):
                 D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
 
+    def capture(self):
+        """Record one pass into a HIP graph (all launches of run() go to torch's current stream, which is the capture
+        stream here); replay() then re-issues the ~150 launches with one host call.  Matters for small pictures, where
+        the eager pass is bound by host launch overhead rather than by the GPU."""
+        self.run()  # warm-up outside capture: allocator pools, lazy module loading
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.run()
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+
     def sad_time_ms(self):
         """sum of HIP-event durations of the integer-search SAD launches recorded by run(time_sad=True), per size"""
         torch.cuda.synchronize()
