@@ -24,6 +24,7 @@
 #ifndef XEVE_HIP_H
 #define XEVE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -219,6 +220,29 @@ typedef struct xeve_hip_me_result {
 int xeve_hip_me_ipel_diamond_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref,
                                   const xeve_hip_me_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
                                   const xeve_hip_me_params *params, xeve_hip_me_result *results, void *stream);
+
+/* Sub-pel refinement: one complete me_spel_pattern per job (src_base/xeve_pinter.c:553-697): `hpel_cnt` half-pel points
+ * around the integer result (xeve_pinter.c:67-70), then -- when qpel_cnt > 0, i.e. me_level > ME_LEV_HPEL -- `qpel_cnt`
+ * quarter-pel points around the half-pel winner (xeve_pinter.c:50-55); each candidate = xeve_mc_l + xeve_sad_16b (fused,
+ * k_mc<OUT=1>) + MV_COST, first strictly smaller cost wins.  results[j].best_mv_bits follows the reference (only the
+ * quarter-pel stage updates it); results[j].beststep is 0. */
+typedef struct xeve_hip_spel_params {
+    uint32_t lambda_mv;
+    int32_t  refi_bits, extra_bits, bi; /* as in xeve_hip_me_params */
+    int32_t  hpel_cnt, qpel_cnt;        /* pi->search_pattern_hpel_cnt; pi->search_pattern_qpel_cnt or 0 */
+} xeve_hip_spel_params;
+typedef struct xeve_hip_spel_job {
+    int32_t x, y;     /* block position (integer pel) */
+    int32_t org_off;  /* bi != 0: offset of the job's dense org_bi block */
+    int16_t gmvp[2];  /* MVP, picture coordinates, quarter pel */
+    int16_t mvi[2];   /* starting MV relative to the block, quarter pel (the integer search's result) */
+} xeve_hip_spel_job;
+/* workspace: device scratch of at least xeve_hip_me_spel_workspace(njobs) bytes; coef: HOST pointer to the [16][8] table */
+size_t xeve_hip_me_spel_workspace(int njobs);
+int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref,
+                                  const xeve_hip_spel_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
+                                  const int16_t (*coef)[8], const xeve_hip_spel_params *params, xeve_hip_me_result *results,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -43,3 +43,33 @@ unsigned refdrv_me_ipel_diamond(pel *org0, int s_org, const s16 *org_bi, pel *re
 
 int refdrv_mv_bits(int mvd_x, int mvd_y, int num_refp, int refi) { return get_mv_bits(mvd_x, mvd_y, num_refp, refi); }
 int refdrv_refi_bits(int num_refp, int refi) { return xeve_tbl_refi_bits[num_refp][refi]; }
+
+
+/* me_spel_pattern (static, xeve_pinter.c:553): returns cost; out[0..1] = mv, out[2] = mot_bits[lidx] after the call */
+unsigned refdrv_me_spel_pattern(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h,
+                                int bit_depth, const s16 gmvp_in[2], const s16 mvi_in[2], int bi, unsigned lambda_mv, int num_refp, int refi,
+                                int mot_bits_other, int hpel_cnt, int qpel_cnt, int out[3])
+{
+    static XEVE_PINTER *pi;
+    static XEVE_PIC     pic;
+    static XEVE_REFP    refp[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    if(!pi) pi = calloc(1, sizeof(*pi));
+    xeve_func_sad  = xeve_tbl_sad_16b;
+    xeve_func_mc_l = xeve_tbl_mc_l;
+    const int lidx = REFP_0, lidx_r = REFP_1;
+    pi->o[Y_C] = org0, pi->s_o[Y_C] = s_org;
+    pic.y = ref0, pic.s_l = s_ref;
+    refp[refi][lidx].pic = &pic;
+    pi->refp = refp;
+    if(org_bi) memcpy(pi->org_bi, org_bi, sizeof(s16) << (log2w + log2h));
+    pi->num_refp = num_refp, pi->lambda_mv = lambda_mv;
+    pi->mot_bits[lidx_r] = mot_bits_other, pi->mot_bits[lidx] = -1;
+    pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = hpel_cnt;
+    pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = qpel_cnt;
+    pi->me_level = qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL;
+    pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
+    s16 gmvp[MV_D] = {gmvp_in[0], gmvp_in[1]}, mvi[MV_D] = {mvi_in[0], mvi_in[1]}, mv[MV_D];
+    unsigned cost = me_spel_pattern(pi, x, y, log2w, log2h, (s8)refi, lidx, gmvp, mvi, mv, bi, bit_depth);
+    out[0] = mv[MV_X], out[1] = mv[MV_Y], out[2] = pi->mot_bits[lidx];
+    return cost;
+}

@@ -494,3 +494,43 @@ void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
     res->beststep = beststep;
     res->best_mv_bits = best_bits;
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* sub-pel pattern search (reference: xeve_pinter.c:50-70, 553-697)           */
+/* ------------------------------------------------------------------------- */
+static const int8_t pat_hpel[8][2] = {{-2, 0}, {-2, 2}, {0, 2}, {2, 2}, {2, 0}, {2, -2}, {0, -2}, {-2, -2}};
+static const int8_t pat_qpel[8][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, -1}, {-1, 1}, {1, 1}, {-1, -1}, {1, -1}};
+
+void xo_me_spel_pattern(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_spel_job *job,
+                        int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_spel_params *p, xo_me_result *res)
+{
+    const int w = 1 << log2w, h = 1 << log2h;
+    const xo_pel *org = p->bi ? org_bi + job->org_off : org0 + job->y * s_org + job->x;
+    const int so = p->bi ? w : s_org;
+    xo_pel *pred = (xo_pel *)malloc(sizeof(xo_pel) * (size_t)w * h);
+    uint32_t cost_best = 0xFFFFFFFFu;
+    int best_bits = 0, mvx = job->mvi[0], mvy = job->mvi[1];
+    for(int stage = 0; stage < 2; stage++) {
+        const int cnt = stage ? p->qpel_cnt : p->hpel_cnt;
+        const int8_t(*pat)[2] = stage ? pat_qpel : pat_hpel;
+        const int cx = mvx + (job->x << 2), cy = mvy + (job->y << 2); /* centre of this stage: picture coordinates, quarter pel */
+        for(int i = 0; i < cnt; i++) {
+            const int mx = cx + pat[i][0], my = cy + pat[i][1];
+            int bits = xo_mv_bits(mx - job->gmvp[0], my - job->gmvp[1]) + p->refi_bits;
+            if(p->bi) bits += p->extra_bits;
+            uint32_t cost = (uint32_t)(p->lambda_mv * (uint32_t)bits + (1u << 15)) >> 16;
+            /* xeve_mc_l picks the variant from the low 4 bits of (mv << 2) and positions with the same value */
+            xo_mc_l((mx << 2) & 15, (my << 2) & 15, ref0, mx << 2, my << 2, s_ref, w, pred, w, h, bit_depth, coef);
+            const int sad = xo_sad(w, h, org, pred, so, w, bit_depth);
+            cost += (uint32_t)(p->bi ? sad >> 1 : sad);
+            if(cost < cost_best) {
+                mvx = mx - (job->x << 2), mvy = my - (job->y << 2), cost_best = cost;
+                if(stage) best_bits = bits; /* only the quarter-pel loop records the bits, xeve_pinter.c:683 */
+            }
+        }
+    }
+    free(pred);
+    res->mv[0] = (int16_t)mvx, res->mv[1] = (int16_t)mvy;
+    res->cost = cost_best, res->beststep = 0, res->best_mv_bits = best_bits;
+}

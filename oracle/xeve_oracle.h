@@ -113,6 +113,19 @@ typedef struct xo_me_result {
 void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job,
                         int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res);
 
+/* me_spel_pattern (xeve_pinter.c:553-697): half-pel points around mvi, then (qpel_cnt > 0) quarter-pel points around
+ * the half-pel winner; each candidate = xeve_mc_l + SAD + MV_COST.  mvi / result mv are relative to the block. */
+typedef struct xo_spel_params {
+    uint32_t lambda_mv;
+    int32_t  refi_bits, extra_bits, bi, hpel_cnt, qpel_cnt;
+} xo_spel_params;
+typedef struct xo_spel_job {
+    int32_t x, y, org_off;
+    int16_t gmvp[2], mvi[2];
+} xo_spel_job;
+void xo_me_spel_pattern(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_spel_job *job,
+                        int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_spel_params *p, xo_me_result *res);
+
 #ifdef __cplusplus
 }
 #endif

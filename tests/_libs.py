@@ -216,3 +216,30 @@ def oracle_me():
     L.xo_me_ipel_diamond.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, C.POINTER(MeJob), c_int, c_int, c_int,
                                      C.POINTER(MeParams), C.POINTER(MeResult)]
     return L
+
+
+class SpelParams(C.Structure):
+    _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
+                ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
+
+
+class SpelJob(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("org_off", C.c_int32), ("gmvp", C.c_int16 * 2), ("mvi", C.c_int16 * 2)]
+
+
+def oracle_spel():
+    L = oracle_me()
+    L.xo_me_spel_pattern.restype = None
+    L.xo_me_spel_pattern.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, C.POINTER(SpelJob), c_int, c_int, c_int, c_void_p,
+                                     C.POINTER(SpelParams), C.POINTER(MeResult)]
+    return L
+
+
+def ref_spel():
+    L = ref_me()
+    if L is not None and not hasattr(L, "_spel_bound"):
+        L.refdrv_me_spel_pattern.restype = C.c_uint32
+        L.refdrv_me_spel_pattern.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                             c_int, C.c_uint32, c_int, c_int, c_int, c_int, c_int, c_void_p]
+        L._spel_bound = True
+    return L

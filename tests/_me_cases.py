@@ -63,3 +63,30 @@ def run_oracle(c):
     O.xo_me_ipel_diamond(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], C.byref(j), lg, lg,
                          10, C.byref(p), C.byref(res))
     return res
+
+
+# ---- sub-pel pattern search (me_spel_pattern) ----------------------------------------------------------------------
+def make_spel_job(r, pl, S, bi):
+    from _libs import oracle
+
+    W, H = pl["W"], pl["H"]
+    x, y = int(r.integers(0, (W - S) // 8 + 1)) * 8, int(r.integers(0, (H - S) // 8 + 1)) * 8
+    mvp = (int(r.integers(-160, 161)), int(r.integers(-160, 161)))
+    mvi = (int(r.integers(-30, 31)) * 4, int(r.integers(-30, 31)) * 4)  # an integer-pel MV, quarter-pel units
+    org_bi = (2 * r.integers(0, 1024, size=S * S) - r.integers(0, 1024, size=S * S)).astype(np.int16)
+    return dict(org=pl["org"], ref=pl["ref"], s=pl["s"], x=x, y=y, S=S, bi=bi, gmvp=(mvp[0] + (x << 2), mvp[1] + (y << 2)), mvi=mvi,
+                lambda_mv=int(r.integers(1 << 16, 1 << 23)), mot_other=int(r.integers(2, 30)), org_bi=org_bi,
+                hpel_cnt=int(r.choice([2, 4, 8])), qpel_cnt=int(r.choice([0, 4, 8])))
+
+
+def run_oracle_spel(c):
+    from _libs import SpelJob, SpelParams, oracle_spel
+
+    O = oracle_spel()
+    lg = c["S"].bit_length() - 1
+    p = SpelParams(c["lambda_mv"], REFI_BITS_2_0, c["mot_other"], c["bi"], c["hpel_cnt"], c["qpel_cnt"])
+    j = SpelJob(c["x"], c["y"], 0, (C.c_int16 * 2)(*c["gmvp"]), (C.c_int16 * 2)(*c["mvi"]))
+    res = MeResult()
+    O.xo_me_spel_pattern(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], C.byref(j), lg, lg, 10,
+                         O.mc_l_coeff, C.byref(p), C.byref(res))
+    return res

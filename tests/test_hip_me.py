@@ -72,3 +72,57 @@ def test_me_batches_vs_oracle(S, bi, textured):
                (e.cost, e.mv[0], e.mv[1], e.beststep, e.best_mv_bits), (S, bi, textured, i)
         steps.add(e.beststep)
     assert len(steps) >= 1
+
+
+def gpu_run_spel(cases):
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    c0 = cases[0]
+    S = c0["S"]
+    jobs = np.zeros(len(cases), dtype=lib.SPEL_JOB_DTYPE)
+    bi_buf = np.zeros((len(cases), S * S), np.int16)
+    for i, c in enumerate(cases):
+        jobs[i] = (c["x"], c["y"], i * S * S, c["gmvp"], c["mvi"])
+        bi_buf[i] = c["org_bi"]
+    P = lib.SpelParams(c0["lambda_mv"], 1, c0["mot_other"], c0["bi"], c0["hpel_cnt"], c0["qpel_cnt"])
+    org, ref = torch.from_numpy(c0["org"]).to(dev), torch.from_numpy(c0["ref"]).to(dev)
+    o0 = PAD * c0["s"] + PAD
+    return D.me_spel_pattern_jobs(org, o0, c0["s"], torch.from_numpy(bi_buf).to(dev), ref, o0, c0["s"], jobs, S.bit_length() - 1, 10, P)
+
+
+def test_spel_matches_reference_goldens():
+    from _me_golden import golden_spel_cases
+
+    n = 0
+    for c, (cost, mvx, mvy) in golden_spel_cases():
+        res = gpu_run_spel([c])[0]
+        assert (int(res["cost"]), int(res["mv"][0]), int(res["mv"][1])) == (cost, mvx, mvy), (n, c["S"], c["bi"])
+        n += 1
+    assert n == 64
+
+
+@pytest.mark.parametrize("S", [8, 16, 32, 64])
+@pytest.mark.parametrize("bi", [0, 1])
+def test_spel_batches_vs_oracle(S, bi):
+    from _me_cases import make_spel_job, run_oracle_spel
+
+    r = np.random.default_rng(1100 + S + bi)
+    pl = make_planes(r, True)
+    base = make_spel_job(r, pl, S, bi)
+    cases = []
+    for _ in range(120):
+        c = make_spel_job(r, pl, S, bi)
+        for k in ("lambda_mv", "mot_other", "hpel_cnt", "qpel_cnt"):
+            c[k] = base[k]
+        cases.append(c)
+    got = gpu_run_spel(cases)
+    for i, c in enumerate(cases):
+        e = run_oracle_spel(c)
+        g = got[i]
+        assert (int(g["cost"]), int(g["mv"][0]), int(g["mv"][1]), int(g["best_mv_bits"])) == (e.cost, e.mv[0], e.mv[1], e.best_mv_bits), (S, bi, i)

@@ -11,3 +11,15 @@ def test_oracle_me_matches_reference_goldens():
         assert (res.cost, res.mv[0], res.mv[1], res.beststep) == (cost, mvx, mvy, beststep), (n, c["S"], c["bi"])
         n += 1
     assert n == 96
+
+
+def test_oracle_spel_matches_reference_goldens():
+    from _me_cases import run_oracle_spel
+    from _me_golden import golden_spel_cases
+
+    n = 0
+    for c, (cost, mvx, mvy) in golden_spel_cases():
+        res = run_oracle_spel(c)
+        assert (res.cost, res.mv[0], res.mv[1]) == (cost, mvx, mvy), (n, c["S"], c["bi"])
+        n += 1
+    assert n == 64

@@ -51,3 +51,31 @@ def test_me_ipel_diamond_matches_reference(bi, textured):
         steps.add(beststep)
     if textured and bi != 1:
         assert max(steps) >= 4  # the diamond rings were actually exercised
+
+
+def run_ref_spel(c):
+    from _libs import ref_spel
+
+    R = ref_spel()
+    lg = c["S"].bit_length() - 1
+    out = (C.c_int * 3)()
+    gmvp, mvi = np.array(c["gmvp"], np.int16), np.array(c["mvi"], np.int16)
+    cost = R.refdrv_me_spel_pattern(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"],
+                                    lg, lg, 10, ptr(gmvp), ptr(mvi), c["bi"], c["lambda_mv"], 2, 0, c["mot_other"], c["hpel_cnt"], c["qpel_cnt"], out)
+    return cost, out[0], out[1], out[2]
+
+
+@pytest.mark.parametrize("bi", [0, 1])
+@pytest.mark.parametrize("textured", [False, True])
+def test_me_spel_pattern_matches_reference(bi, textured):
+    from _me_cases import make_planes, make_spel_job, run_oracle_spel
+
+    r = np.random.default_rng(950 + bi * 2 + textured)
+    pl = make_planes(r, textured)
+    for it in range(60):
+        c = make_spel_job(r, pl, int(r.choice([8, 16, 32, 64])), bi)
+        cost, mvx, mvy, mot = run_ref_spel(c)
+        res = run_oracle_spel(c)
+        assert (res.cost, res.mv[0], res.mv[1]) == (cost, mvx, mvy), (it, c["S"], c["hpel_cnt"], c["qpel_cnt"])
+        if not bi and res.best_mv_bits > 0:
+            assert mot == res.best_mv_bits

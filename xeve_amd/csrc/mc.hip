@@ -305,3 +305,91 @@ extern "C" int xeve_hip_avg(const int16_t *a, const int16_t *b, int16_t *dst, in
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+
+// =========================================================================================================
+// me_spel_pattern on the GPU (xeve_hip_me_spel_pattern_jobs): per stage, ALL candidates of ALL jobs go through one
+// fused interpolation + SAD launch (k_mc<8, 8, 1>); two elementwise kernels build the candidate jobs and pick the
+// winner in the reference's evaluation order.  reference: src_base/xeve_pinter.c:553-697.
+// =========================================================================================================
+__device__ __constant__ int8_t c_pat_hpel[8][2] = {{-2, 0}, {-2, 2}, {0, 2}, {2, 2}, {2, 0}, {2, -2}, {0, -2}, {-2, -2}}; // xeve_pinter.c:67-70
+__device__ __constant__ int8_t c_pat_qpel[8][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, -1}, {-1, 1}, {1, 1}, {-1, -1}, {1, -1}}; // xeve_pinter.c:50-55
+
+// stage 0: centre = mvi; stage 1: centre = the half-pel winner stored in res[j].mv
+__global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, int s_org, int blk_elems, int bi,
+                            const xeve_hip_me_result *__restrict__ res, xeve_hip_mc_job *__restrict__ mc)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= njobs * cnt) return;
+    const int j = t / cnt, i = t - j * cnt;
+    const xeve_hip_spel_job jb = jobs[j];
+    const int mvx = stage ? res[j].mv[0] : jb.mvi[0], mvy = stage ? res[j].mv[1] : jb.mvi[1];
+    const int8_t(*pat)[2] = stage ? c_pat_qpel : c_pat_hpel;
+    const int mx = mvx + (jb.x << 2) + pat[i][0], my = mvy + (jb.y << 2) + pat[i][1]; // quarter pel, picture coordinates
+    xeve_hip_mc_job m;
+    m.gmv_x = mx << 2, m.gmv_y = my << 2; // 1/16 pel, as the reference passes (mv_x << 2), xeve_pinter.c:608
+    m.pred_off = bi ? jb.org_off : jb.y * s_org + jb.x;
+    m.frac = ((mx & 3) != 0 ? 1 : 0) | ((my & 3) != 0 ? 2 : 0);
+    (void)blk_elems;
+    mc[t] = m;
+}
+
+__global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, xeve_hip_spel_params P,
+                              const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= njobs) return;
+    const xeve_hip_spel_job jb = jobs[j];
+    xeve_hip_me_result r;
+    if(stage) r = res[j];
+    else r.mv[0] = jb.mvi[0], r.mv[1] = jb.mvi[1], r.cost = 0xFFFFFFFFu, r.beststep = 0, r.best_mv_bits = 0;
+    const int cx = r.mv[0] + (jb.x << 2), cy = r.mv[1] + (jb.y << 2);
+    const int8_t(*pat)[2] = stage ? c_pat_qpel : c_pat_hpel;
+    for(int i = 0; i < cnt; i++) {
+        const int mx = cx + pat[i][0], my = cy + pat[i][1];
+        int bits = xh_mvd_bits(mx - jb.gmvp[0]) + xh_mvd_bits(my - jb.gmvp[1]) + P.refi_bits;
+        if(P.bi) bits += P.extra_bits;
+        const int s = sad[j * cnt + i];
+        const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(P.bi ? s >> 1 : s);
+        if(cost < r.cost) {
+            r.mv[0] = (int16_t)(mx - (jb.x << 2)), r.mv[1] = (int16_t)(my - (jb.y << 2)), r.cost = cost;
+            if(stage) r.best_mv_bits = bits; // only the quarter-pel stage records the bits (xeve_pinter.c:683)
+        }
+    }
+    res[j] = r;
+}
+
+extern "C" size_t xeve_hip_me_spel_workspace(int njobs) { return (size_t)(njobs > 0 ? njobs : 0) * 8 * (sizeof(xeve_hip_mc_job) + sizeof(int32_t)); }
+
+extern "C" int xeve_hip_me_spel_pattern_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref,
+                                             const xeve_hip_spel_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
+                                             const int16_t (*coef)[8], const xeve_hip_spel_params *params, xeve_hip_me_result *results,
+                                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
+    XH_REQUIRE(log2w >= 3 && log2w <= 6 && log2h >= 3 && log2h <= 6);
+    XH_REQUIRE(params->hpel_cnt >= 1 && params->hpel_cnt <= 8 && params->qpel_cnt >= 0 && params->qpel_cnt <= 8);
+    XH_REQUIRE(params->bi == 0 || org_bi != nullptr);
+    XH_REQUIRE(workspace_bytes >= xeve_hip_me_spel_workspace(njobs));
+    if(njobs == 0) return XEVE_HIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const xeve_hip_spel_params P = *params;
+    const int w = 1 << log2w, h = 1 << log2h;
+    xeve_hip_mc_job *mc  = static_cast<xeve_hip_mc_job *>(workspace);
+    int32_t         *sad = reinterpret_cast<int32_t *>(mc + (size_t)njobs * 8);
+    const pel *cmp = P.bi ? org_bi : org0;
+    const int  s_c = P.bi ? w : s_org;
+    for(int stage = 0; stage < 2; stage++) {
+        const int cnt = stage ? P.qpel_cnt : P.hpel_cnt;
+        if(cnt == 0) break;
+        const int items = njobs * cnt;
+        k_spel_make<<<(items + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, s_org, w * h, P.bi, results, mc);
+        XH_HIP(hipGetLastError());
+        int rc = mc_launch<8, 1>(ref0, s_ref, nullptr, 0, mc, items, w, h, bit_depth, &coef[0][0], st, cmp, s_c, sad);
+        if(rc != XEVE_HIP_OK) return rc;
+        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, sad, results);
+        XH_HIP(hipGetLastError());
+    }
+    return XEVE_HIP_OK;
+}

@@ -17,21 +17,6 @@ template <int S> struct MGeo {
 __device__ __constant__ int8_t c_dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1, 3}, {0, 4}, {1, 3}, {2, 2}, {3, 1},
                                                  {4, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -4}, {-1, -3}, {-2, -2}, {-3, -1}};
 
-// one component of get_mv_bits: xeve_tbl_mv_bits in closed form (incl. its -2047 entry) / exp-Golomb beyond +-2048
-__device__ __forceinline__ int mvd_bits(int mvd)
-{
-    const unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd);
-    if(mvd > 2048 || mvd <= -2048) {
-        unsigned nn = (a + 1) >> 12;
-        int len_i = 11;
-        while(len_i < 16 && nn != 0) nn >>= 1, len_i++;
-        return (len_i << 1) + 2;
-    }
-    if(mvd == 0) return 1;
-    if(mvd == -2047) return 22;
-    return 2 * (31 - __clz((int)(a + 1))) + 2;
-}
-
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -108,7 +93,7 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
                 }
             }
             acc = xh_group_sum<G::GROUP>(acc);
-            int bits = mvd_bits((mx << 2) - jb.gmvp[0]) + mvd_bits((my << 2) - jb.gmvp[1]) + P.refi_bits;
+            int bits = xh_mvd_bits((mx << 2) - jb.gmvp[0]) + xh_mvd_bits((my << 2) - jb.gmvp[1]) + P.refi_bits;
             if(BI) bits += P.extra_bits;
             const int sad = acc >> shift;
             const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(BI ? sad >> 1 : sad);

@@ -68,6 +68,22 @@ __device__ __forceinline__ unsigned xh_xcd_block(unsigned bid, unsigned nblk)
     return bid < main ? (bid & 7u) * per + (bid >> 3) : bid;
 }
 
+// one component of get_mv_bits: xeve_tbl_mv_bits in closed form (incl. its -2047 entry) / exp-Golomb beyond +-2048
+__device__ __forceinline__ int xh_mvd_bits(int mvd)
+{
+    const unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd);
+    if(mvd > 2048 || mvd <= -2048) {
+        unsigned nn = (a + 1) >> 12;
+        int len_i = 11;
+        while(len_i < 16 && nn != 0) nn >>= 1, len_i++;
+        return (len_i << 1) + 2;
+    }
+    if(mvd == 0) return 1;
+    if(mvd == -2047) return 22;
+    return 2 * (31 - __clz((int)(a + 1))) + 2;
+}
+
+
 // DPP lane exchanges (wave64): the cross-lane step of every per-block reduction.
 #define XH_DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
 #define XH_DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]

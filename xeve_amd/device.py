@@ -205,6 +205,22 @@ def me_ipel_diamond_jobs(org_plane, org_origin, s_org, org_bi, ref_plane, ref_or
     return res.cpu().numpy().view(_lib.ME_RESULT_DTYPE).reshape(-1)
 
 
+def me_spel_pattern_jobs(org_plane, org_origin, s_org, org_bi, ref_plane, ref_origin, s_ref, jobs_np, log2, bit_depth, params, coef=None):
+    """One complete me_spel_pattern per job (xeve_hip_me_spel_pattern_jobs); jobs_np: numpy array of lib.SPEL_JOB_DTYPE."""
+    L = _lib.load()
+    dev = org_plane.device
+    coef = baseline_coef_l() if coef is None else coef
+    jobs = torch.from_numpy(jobs_np.view(np.uint8).reshape(len(jobs_np), -1).copy()).to(dev)
+    res = torch.empty((len(jobs_np), np.dtype(_lib.ME_RESULT_DTYPE).itemsize), dtype=torch.uint8, device=dev)
+    ws_bytes = int(L.xeve_hip_me_spel_workspace(len(jobs_np)))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(L.xeve_hip_me_spel_pattern_jobs(C.c_void_p(_i16(org_plane).data_ptr() + 2 * org_origin), s_org,
+                                               _ptr(_i16(org_bi)) if org_bi is not None else None,
+                                               C.c_void_p(_i16(ref_plane).data_ptr() + 2 * ref_origin), s_ref, _ptr(jobs), len(jobs_np), log2, log2,
+                                               bit_depth, C.c_void_p(coef.ctypes.data), C.byref(params), _ptr(res), _ptr(ws), ws_bytes, _stream()))
+    return res.cpu().numpy().view(_lib.ME_RESULT_DTYPE).reshape(-1)
+
+
 # quantiser scale tables of the standard (reference: src_base/xeve_tq.c:37-38, xeve_tbl.c:237)
 QUANT_SCALE = ((26214, 23302, 20560, 18396, 16384, 14764), (26214, 23302, 20560, 18396, 16384, 14564))
 DQ_SCALE = (40, 45, 51, 57, 64, 71)

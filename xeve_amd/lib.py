@@ -26,6 +26,12 @@ class MeParams(C.Structure):  # xeve_hip_me_params
                 ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("beststep_in", C.c_int32)]
 
 
+class SpelParams(C.Structure):  # xeve_hip_spel_params
+    _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
+                ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
+
+
+SPEL_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_spel_job
 ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_me_job
 ME_RESULT_DTYPE = [("mv", "<i2", 2), ("cost", "<u4"), ("beststep", "<i4"), ("best_mv_bits", "<i4")]  # xeve_hip_me_result
 
@@ -71,6 +77,9 @@ FUNCTIONS = {
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_me_ipel_diamond_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p]),
+    "xeve_hip_me_spel_workspace": (C.c_size_t, [c_int]),
+    "xeve_hip_me_spel_pattern_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 TABLES = {
