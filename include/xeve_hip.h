@@ -200,7 +200,7 @@ typedef struct xeve_hip_me_params {
     int32_t  max_search_range; /* pi->max_search_range */
     int32_t  range_recentre;   /* range get_range_ipel derives for this reference picture (POC-distance scaled) */
     int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / pi->max_clip */
-    int32_t  beststep_in;      /* *beststep on entry */
+    int32_t  reserved;         /* (was beststep_in; now per job) */
 } xeve_hip_me_params;
 typedef struct xeve_hip_me_job {
     int32_t x, y;     /* block position (integer pel, picture coordinates) */
@@ -208,6 +208,7 @@ typedef struct xeve_hip_me_job {
     int16_t range[4]; /* min x, min y, max x, max y */
     int16_t gmvp[2];  /* MVP, picture coordinates, quarter pel */
     int16_t mvi[2];   /* initial MV, picture coordinates, quarter pel */
+    int32_t beststep_in; /* *beststep on entry (the reference threads `tmpstep` through successive calls) */
 } xeve_hip_me_job;
 typedef struct xeve_hip_me_result {
     int16_t  mv[2];    /* best MV relative to the block (quarter-pel units) */

@@ -73,3 +73,39 @@ unsigned refdrv_me_spel_pattern(pel *org0, int s_org, const s16 *org_bi, pel *re
     out[0] = mv[MV_X], out[1] = mv[MV_Y], out[2] = pi->mot_bits[lidx];
     return cost;
 }
+
+
+/* pinter_me_epzs (static, xeve_pinter.c:699) with me_complexity 1 (no raster); mv_io: in = start for bi == BI_NORMAL, out = result */
+unsigned refdrv_me_epzs(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h, int bit_depth,
+                        const s16 mvp_in[2], s16 mv_io[2], int bi, unsigned lambda_mv, int num_refp, int refi_in, int mot_bits_other,
+                        int max_search_range, int gop_size, int poc, int ref_poc, const int min_clip[2], const int max_clip[2], int hpel_cnt,
+                        int qpel_cnt)
+{
+    static XEVE_PINTER *pi;
+    static XEVE_PIC     pic;
+    static XEVE_REFP    refp[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    if(!pi) pi = calloc(1, sizeof(*pi));
+    xeve_func_sad  = xeve_tbl_sad_16b;
+    xeve_func_mc_l = xeve_tbl_mc_l;
+    const int lidx = REFP_0, lidx_r = REFP_1;
+    pi->o[Y_C] = org0, pi->s_o[Y_C] = s_org;
+    pic.y = ref0, pic.s_l = s_ref;
+    refp[refi_in][lidx].pic = &pic, refp[refi_in][lidx].poc = ref_poc;
+    pi->refp = refp;
+    if(org_bi) memcpy(pi->org_bi, org_bi, sizeof(s16) << (log2w + log2h));
+    pi->min_clip[MV_X] = min_clip[0], pi->min_clip[MV_Y] = min_clip[1];
+    pi->max_clip[MV_X] = max_clip[0], pi->max_clip[MV_Y] = max_clip[1];
+    pi->num_refp = num_refp, pi->lambda_mv = lambda_mv;
+    pi->mot_bits[lidx_r] = mot_bits_other, pi->mot_bits[lidx] = -1;
+    pi->max_search_range = max_search_range, pi->gop_size = gop_size, pi->poc = poc;
+    pi->me_complexity = 1;
+    pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = hpel_cnt;
+    pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = qpel_cnt;
+    pi->me_level = qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL;
+    pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
+    s16 mvp[MV_D] = {mvp_in[0], mvp_in[1]}, mv[MV_D] = {mv_io[0], mv_io[1]};
+    s8  refi = (s8)refi_in;
+    unsigned cost = pinter_me_epzs(pi, x, y, log2w, log2h, &refi, lidx, mvp, mv, bi, bit_depth);
+    mv_io[0] = mv[MV_X], mv_io[1] = mv[MV_Y];
+    return cost;
+}

@@ -434,7 +434,7 @@ void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
     const int so = p->bi ? w : s_org;
     int range[4] = {job->range[0], job->range[1], job->range[2], job->range[3]};
     uint32_t cost_best = 0xFFFFFFFFu;
-    int best_bits = 0, beststep = p->beststep_in, step = 0, not_found = 0;
+    int best_bits = 0, beststep = job->beststep_in, step = 0, not_found = 0;
     int bx = clip3i(p->min_clip[0], p->max_clip[0], job->mvi[0] >> 2);
     int by = clip3i(p->min_clip[1], p->max_clip[1], job->mvi[1] >> 2);
     const int ix = bx, iy = by;
@@ -533,4 +533,62 @@ void xo_me_spel_pattern(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
     free(pred);
     res->mv[0] = (int16_t)mvx, res->mv[1] = (int16_t)mvy;
     res->cost = cost_best, res->beststep = 0, res->best_mv_bits = best_bits;
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* EPZS driver (reference: pinter_me_epzs, xeve_pinter.c:699-869)             */
+/* ------------------------------------------------------------------------- */
+static void epzs_range(const xo_me_params *p, int cx, int cy, int16_t range[4])
+{
+    const int sr = p->bi == 1 ? 5 : p->range_recentre; /* get_range_ipel, xeve_pinter.c:122-140 */
+    range[0] = (int16_t)clip3i(p->min_clip[0], p->max_clip[0], cx - sr);
+    range[1] = (int16_t)clip3i(p->min_clip[1], p->max_clip[1], cy - sr);
+    range[2] = (int16_t)clip3i(p->min_clip[0], p->max_clip[0], cx + sr);
+    range[3] = (int16_t)clip3i(p->min_clip[1], p->max_clip[1], cy + sr);
+}
+
+uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
+                    int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p)
+{
+    xo_me_params me = p->me;
+    xo_me_job    job;
+    xo_me_result r;
+    uint32_t     cost_best = 0xFFFFFFFFu;
+    int          beststep = 0, tmpstep = 0;
+    job.x = x, job.y = y, job.org_off = 0;
+    job.gmvp[0] = (int16_t)(mvp[0] + (x << 2)), job.gmvp[1] = (int16_t)(mvp[1] + (y << 2));
+    const int16_t *start = me.bi == 1 ? mv : mvp;
+    job.mvi[0] = (int16_t)(start[0] + (x << 2)), job.mvi[1] = (int16_t)(start[1] + (y << 2));
+    epzs_range(&me, clip3i(me.min_clip[0], me.max_clip[0], x + (start[0] >> 2)), clip3i(me.min_clip[1], me.max_clip[1], y + (start[1] >> 2)),
+               job.range);
+    me.faststep = 3; /* MAX_FIRST_SEARCH_STEP */
+    job.beststep_in = tmpstep;
+    xo_me_ipel_diamond(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r);
+    tmpstep = r.beststep;
+    if(r.cost < cost_best) {
+        cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
+        beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
+    }
+    while(me.bi != 1 && beststep > 0) { /* REFINE_SEARCH_THD 0 */
+        /* note: get_range_ipel is given the UNCLIPPED centre here (xeve_pinter.c:785-788) */
+        epzs_range(&me, x + (mv[0] >> 2), y + (mv[1] >> 2), job.range);
+        job.mvi[0] = (int16_t)(mv[0] + (x << 2)), job.mvi[1] = (int16_t)(mv[1] + (y << 2));
+        beststep = 0;
+        me.faststep = 2; /* MAX_REFINE_SEARCH_STEP */
+        job.beststep_in = tmpstep;
+        xo_me_ipel_diamond(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r);
+        tmpstep = r.beststep;
+        if(r.cost < cost_best) {
+            cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
+            beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
+        }
+    }
+    xo_spel_params sp = p->spel;
+    sp.lambda_mv = me.lambda_mv, sp.refi_bits = me.refi_bits, sp.extra_bits = me.extra_bits, sp.bi = me.bi;
+    xo_spel_job sj;
+    sj.x = x, sj.y = y, sj.org_off = 0, sj.gmvp[0] = job.gmvp[0], sj.gmvp[1] = job.gmvp[1], sj.mvi[0] = mv[0], sj.mvi[1] = mv[1];
+    xo_me_spel_pattern(org0, s_org, org_bi, ref0, s_ref, &sj, log2w, log2h, bit_depth, coef, &sp, &r);
+    if(r.cost < cost_best) cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
+    return cost_best;
 }

@@ -91,7 +91,7 @@ typedef struct xo_me_params {
     int32_t  max_search_range; /* pi->max_search_range                   (xeve_pinter.c:535)     */
     int32_t  range_recentre;   /* the search range get_range_ipel derives for this reference picture (xeve_pinter.c:124-129) */
     int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / max_clip        (xeve_pinter.c:132-136) */
-    int32_t  beststep_in;      /* value of *beststep on entry                                     */
+    int32_t  reserved;         /* (was beststep_in; now per job)                                  */
 } xo_me_params;
 
 typedef struct xo_me_job {
@@ -100,6 +100,7 @@ typedef struct xo_me_job {
     int16_t range[4];   /* min x, min y, max x, max y (absolute integer-pel positions, xeve_pinter.c:122-140) */
     int16_t gmvp[2];    /* MVP in picture coordinates, quarter pel */
     int16_t mvi[2];     /* initial MV in picture coordinates, quarter pel */
+    int32_t beststep_in; /* *beststep on entry (the reference threads `tmpstep` through successive calls) */
 } xo_me_job;
 
 typedef struct xo_me_result {
@@ -125,6 +126,16 @@ typedef struct xo_spel_job {
 } xo_spel_job;
 void xo_me_spel_pattern(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_spel_job *job,
                         int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_spel_params *p, xo_me_result *res);
+
+/* pinter_me_epzs (xeve_pinter.c:699-869) for me_complexity == 1 (no raster search) and me_level > ME_LEV_IPEL: first
+ * diamond search from the MVP (faststep 3), refinement searches from the running best while beststep > 0 (faststep 2),
+ * then me_spel_pattern.  mvp / mv are relative to the block (quarter pel); for bi == 1 `mv` is also the starting point. */
+typedef struct xo_epzs_params {
+    xo_me_params   me;   /* faststep is ignored (3 / 2 as in the reference) */
+    xo_spel_params spel; /* lambda_mv, refi_bits, extra_bits, bi are taken from `me` */
+} xo_epzs_params;
+uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
+                    int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p);
 
 #ifdef __cplusplus
 }

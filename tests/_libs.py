@@ -176,12 +176,12 @@ class OracleTables:
 class MeParams(C.Structure):
     _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
                 ("faststep", C.c_int32), ("max_search_range", C.c_int32), ("range_recentre", C.c_int32),
-                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("beststep_in", C.c_int32)]
+                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("reserved", C.c_int32)]
 
 
 class MeJob(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("org_off", C.c_int32), ("range", C.c_int16 * 4), ("gmvp", C.c_int16 * 2),
-                ("mvi", C.c_int16 * 2)]
+                ("mvi", C.c_int16 * 2), ("beststep_in", C.c_int32)]
 
 
 class MeResult(C.Structure):
@@ -242,4 +242,26 @@ def ref_spel():
         L.refdrv_me_spel_pattern.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_int, C.c_uint32, c_int, c_int, c_int, c_int, c_int, c_void_p]
         L._spel_bound = True
+    return L
+
+
+class EpzsParams(C.Structure):
+    _fields_ = [("me", MeParams), ("spel", SpelParams)]
+
+
+def oracle_epzs():
+    L = oracle_spel()
+    L.xo_me_epzs.restype = C.c_uint32
+    L.xo_me_epzs.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                             C.POINTER(EpzsParams)]
+    return L
+
+
+def ref_epzs():
+    L = ref_spel()
+    if L is not None and not hasattr(L, "_epzs_bound"):
+        L.refdrv_me_epzs.restype = C.c_uint32
+        L.refdrv_me_epzs.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                     C.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]
+        L._epzs_bound = True
     return L

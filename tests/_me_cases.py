@@ -49,11 +49,11 @@ def make_case(r, S, bi, textured):
 
 def params_of(c):
     return MeParams(c["lambda_mv"], REFI_BITS_2_0, c["mot_other"], c["bi"], c["faststep"], c["msr"], c["sr"],
-                    (C.c_int32 * 2)(*c["min_clip"]), (C.c_int32 * 2)(*c["max_clip"]), c["beststep_in"])
+                    (C.c_int32 * 2)(*c["min_clip"]), (C.c_int32 * 2)(*c["max_clip"]), 0)
 
 
 def job_of(c, org_off=0):
-    return MeJob(c["x"], c["y"], org_off, (C.c_int16 * 4)(*c["range"]), (C.c_int16 * 2)(*c["gmvp"]), (C.c_int16 * 2)(*c["mvi"]))
+    return MeJob(c["x"], c["y"], org_off, (C.c_int16 * 4)(*c["range"]), (C.c_int16 * 2)(*c["gmvp"]), (C.c_int16 * 2)(*c["mvi"]), c["beststep_in"])
 
 
 def run_oracle(c):
@@ -90,3 +90,35 @@ def run_oracle_spel(c):
     O.xo_me_spel_pattern(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], C.byref(j), lg, lg, 10,
                          O.mc_l_coeff, C.byref(p), C.byref(res))
     return res
+
+
+# ---- EPZS driver (pinter_me_epzs) ------------------------------------------------------------------------------------
+def make_epzs_job(r, pl, S, bi):
+    W, H = pl["W"], pl["H"]
+    x, y = int(r.integers(0, (W - S) // 8 + 1)) * 8, int(r.integers(0, (H - S) // 8 + 1)) * 8
+    msr = int(r.choice([32, 64]))
+    return dict(org=pl["org"], ref=pl["ref"], s=pl["s"], x=x, y=y, S=S, bi=bi, min_clip=(-128, -128), max_clip=(W - 1 + 128, H - 1 + 128),
+                mvp=(int(r.integers(-100, 101)), int(r.integers(-100, 101))), mv0=(int(r.integers(-25, 26)) * 4, int(r.integers(-25, 26)) * 4),
+                msr=msr, sr=int(r.choice([msr // 4, msr // 2, msr])), lambda_mv=int(r.integers(1 << 16, 1 << 22)), mot_other=int(r.integers(2, 30)),
+                org_bi=(2 * r.integers(0, 1024, size=S * S) - r.integers(0, 1024, size=S * S)).astype(np.int16),
+                hpel_cnt=int(r.choice([2, 4, 8])), qpel_cnt=int(r.choice([0, 4, 8])))
+
+
+def epzs_params_of(c):
+    from _libs import EpzsParams, SpelParams
+
+    me = MeParams(c["lambda_mv"], REFI_BITS_2_0, c["mot_other"], c["bi"], 3, c["msr"], c["sr"], (C.c_int32 * 2)(*c["min_clip"]),
+                  (C.c_int32 * 2)(*c["max_clip"]), 0)
+    return EpzsParams(me, SpelParams(0, 0, 0, 0, c["hpel_cnt"], c["qpel_cnt"]))
+
+
+def run_oracle_epzs(c):
+    from _libs import oracle_epzs
+
+    O = oracle_epzs()
+    lg = c["S"].bit_length() - 1
+    mvp, mv = np.array(c["mvp"], np.int16), np.array(c["mv0"], np.int16)
+    p = epzs_params_of(c)
+    cost = O.xo_me_epzs(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], ptr(mvp),
+                        ptr(mv), lg, lg, 10, O.mc_l_coeff, C.byref(p))
+    return cost, int(mv[0]), int(mv[1])

@@ -26,10 +26,10 @@ def gpu_run(cases):
     jobs = np.zeros(len(cases), dtype=lib.ME_JOB_DTYPE)
     bi_buf = np.zeros((len(cases), S * S), np.int16)
     for i, c in enumerate(cases):
-        jobs[i] = (c["x"], c["y"], i * S * S, c["range"], c["gmvp"], c["mvi"])
+        jobs[i] = (c["x"], c["y"], i * S * S, c["range"], c["gmvp"], c["mvi"], c["beststep_in"])
         bi_buf[i] = c["org_bi"]
     P = lib.MeParams(c0["lambda_mv"], 1, c0["mot_other"], c0["bi"], c0["faststep"], c0["msr"], c0["sr"], (C.c_int32 * 2)(*c0["min_clip"]),
-                     (C.c_int32 * 2)(*c0["max_clip"]), c0["beststep_in"])
+                     (C.c_int32 * 2)(*c0["max_clip"]), 0)
     org, ref = torch.from_numpy(c0["org"]).to(dev), torch.from_numpy(c0["ref"]).to(dev)
     o0 = PAD * c0["s"] + PAD
     return D.me_ipel_diamond_jobs(org, o0, c0["s"], torch.from_numpy(bi_buf).to(dev), ref, o0, c0["s"], jobs, S.bit_length() - 1, 10, P)
@@ -54,7 +54,7 @@ def test_me_batches_vs_oracle(S, bi, textured):
     cases = []
     for _ in range(150):
         c = make_job(r, pl, S, bi)
-        for k in ("lambda_mv", "mot_other", "faststep", "msr", "sr", "beststep_in"):  # launch-level parameters are shared
+        for k in ("lambda_mv", "mot_other", "faststep", "msr", "sr"):  # launch-level parameters are shared
             c[k] = base[k]
         # the job's own range must be derived with the shared search range
         sr = base["sr"]
@@ -126,3 +126,35 @@ def test_spel_batches_vs_oracle(S, bi):
         e = run_oracle_spel(c)
         g = got[i]
         assert (int(g["cost"]), int(g["mv"][0]), int(g["mv"][1]), int(g["best_mv_bits"])) == (e.cost, e.mv[0], e.mv[1], e.best_mv_bits), (S, bi, i)
+
+
+@pytest.mark.parametrize("S", [8, 16, 32, 64])
+@pytest.mark.parametrize("bi", [0, 1])
+def test_epzs_search_vs_oracle(S, bi):
+    """xeve_amd.me.epzs_search = pinter_me_epzs per block (diamond, refinement loop, sub-pel) on the GPU, vs the oracle"""
+    import torch
+
+    import xeve_amd
+    from _me_cases import make_epzs_job, run_oracle_epzs
+    from xeve_amd import me
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    r = np.random.default_rng(1200 + S + bi)
+    pl = make_planes(r, True)
+    base = make_epzs_job(r, pl, S, bi)
+    cases = []
+    for _ in range(100):
+        c = make_epzs_job(r, pl, S, bi)
+        for k in ("lambda_mv", "mot_other", "msr", "sr", "hpel_cnt", "qpel_cnt"):
+            c[k] = base[k]
+        cases.append(c)
+    org, ref = torch.from_numpy(pl["org"]).to(dev), torch.from_numpy(pl["ref"]).to(dev)
+    o0 = PAD * pl["s"] + PAD
+    org_bi = torch.from_numpy(np.stack([c["org_bi"] for c in cases])).to(dev)
+    cost, mv = me.epzs_search(org, o0, pl["s"], ref, o0, pl["s"], [c["x"] for c in cases], [c["y"] for c in cases], [c["mvp"] for c in cases],
+                              S.bit_length() - 1, 10, base["lambda_mv"], 1, base["msr"], base["sr"], base["min_clip"], base["max_clip"],
+                              base["hpel_cnt"], base["qpel_cnt"], bi=bi, org_bi=org_bi, mv_start=[c["mv0"] for c in cases],
+                              extra_bits=base["mot_other"])
+    for i, c in enumerate(cases):
+        assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == run_oracle_epzs(c), (S, bi, i)

@@ -79,3 +79,27 @@ def test_me_spel_pattern_matches_reference(bi, textured):
         assert (res.cost, res.mv[0], res.mv[1]) == (cost, mvx, mvy), (it, c["S"], c["hpel_cnt"], c["qpel_cnt"])
         if not bi and res.best_mv_bits > 0:
             assert mot == res.best_mv_bits
+
+
+@pytest.mark.parametrize("bi", [0, 1])
+@pytest.mark.parametrize("textured", [False, True])
+def test_me_epzs_matches_reference(bi, textured):
+    """the whole per-list search of pinter_me_epzs (me_complexity 1): diamond, refinement loop, sub-pel pattern"""
+    from _libs import ref_epzs
+    from _me_cases import make_epzs_job, make_planes, run_oracle_epzs
+
+    R = ref_epzs()
+    r = np.random.default_rng(970 + bi * 2 + textured)
+    pl = make_planes(r, textured)
+    moved = 0
+    for it in range(50):
+        c = make_epzs_job(r, pl, int(r.choice([8, 16, 32, 64])), bi)
+        lg = c["S"].bit_length() - 1
+        mvp, mv = np.array(c["mvp"], np.int16), np.array(c["mv0"], np.int16)
+        mn, mx = np.array(c["min_clip"], np.int32), np.array(c["max_clip"], np.int32)
+        cost = R.refdrv_me_epzs(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], lg, lg,
+                                10, ptr(mvp), ptr(mv), bi, c["lambda_mv"], 2, 0, c["mot_other"], c["msr"], c["msr"], c["sr"], 0, ptr(mn), ptr(mx),
+                                c["hpel_cnt"], c["qpel_cnt"])
+        assert run_oracle_epzs(c) == (cost, int(mv[0]), int(mv[1])), (it, c["S"])
+        moved += (int(mv[0]), int(mv[1])) != tuple(c["mvp"])
+    assert moved > 25

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
     int bx = clip3(P.min_clip[0], P.max_clip[0], jb.mvi[0] >> 2), by = clip3(P.min_clip[1], P.max_clip[1], jb.mvi[1] >> 2);
     const int ix = bx, iy = by;
     unsigned long long best_key = 0xFFFFFFFF00000000ull; // cost_best = UINT32_MAX, order 0 (nothing evaluated beats it on a tie)
-    int best_bits = 0, beststep = P.beststep_in, step = 0, not_found = 0;
+    int best_bits = 0, beststep = jb.beststep_in, step = 0, not_found = 0;
     unsigned order = 1;
     const int d = P.bi == 1 ? 5 : 2; // BI_STEP : 2 (xeve_pinter.c:409-416)
 

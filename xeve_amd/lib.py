@@ -23,7 +23,7 @@ class McJob(C.Structure):  # xeve_hip_mc_job
 class MeParams(C.Structure):  # xeve_hip_me_params
     _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
                 ("faststep", C.c_int32), ("max_search_range", C.c_int32), ("range_recentre", C.c_int32),
-                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("beststep_in", C.c_int32)]
+                ("min_clip", C.c_int32 * 2), ("max_clip", C.c_int32 * 2), ("reserved", C.c_int32)]
 
 
 class SpelParams(C.Structure):  # xeve_hip_spel_params
@@ -32,7 +32,7 @@ class SpelParams(C.Structure):  # xeve_hip_spel_params
 
 
 SPEL_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_spel_job
-ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_me_job
+ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2), ("beststep_in", "<i4")]  # xeve_hip_me_job
 ME_RESULT_DTYPE = [("mv", "<i2", 2), ("cost", "<u4"), ("beststep", "<i4"), ("best_mv_bits", "<i4")]  # xeve_hip_me_result
 
 
