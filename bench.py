@@ -83,11 +83,19 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    # harness self-test only: XEVE_BENCH_SHARE_GPU=1 runs every rank on GPU 0 with the gloo backend, so that the N > 1
+    # control path (barriers, max-over-ranks, rank-0 JSON) can be exercised on a one-GPU box; never used for numbers
+    share = os.environ.get("XEVE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if not os.path.exists(os.path.join(ROOT, "xeve_amd", "lib", "libxeve_hip.so")) and local == 0:
         import __graft_entry__
@@ -117,7 +125,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -146,7 +154,8 @@ def main():
                             "dequant+IDCT, recon, SSD, SATD) over one %dx%d Baseline-medium inter picture per step per GPU; call mix of "
                             "SURVEY.md 8(d); sequential RDO/CABAC control (out of this tier's scope) not included" % (a.width, a.height),
                 "bit_depth": 10, "qp": 32, "ctu": 64, "cu_sizes": list(wl.sizes), "ref_lists": N_LIST,
-                "sad_calls_per_picture": wl.sad_calls, "parallelism": "closed-GOP shard per GPU, no collectives",
+                "sad_calls_per_picture": wl.sad_calls, "parallelism": "closed-GOP shard per GPU, no collectives"
+                + (" [SELF-TEST: all ranks share GPU 0, gloo]" if share else ""),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_sad_sq<8|16|32|64> (xeve_hip_sad_jobs)",

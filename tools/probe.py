@@ -96,3 +96,26 @@ if what == "me":
         ms = (_t.perf_counter() - t0) / 3 * 1e3
         print("me_ipel_diamond %2dx%-2d  %7d jobs  %.3f ms (incl. job upload / result download)  mean |mv| %.1f qpel, beststep>2 in %.0f%%"
               % (S, S, n, ms, np.abs(res["mv"]).mean(), 100.0 * (res["beststep"] > 2).mean()))
+if what == "epzs":
+    import numpy as np, time as _t
+    from xeve_amd import me
+    from xeve_amd.workload import PAD_L
+    W, H = 3840, 2160
+    s = W + 2 * PAD_L
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:H + 2 * PAD_L, 0:s].astype(np.float32)
+    base = 512 + 300 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + 150 * np.sin((xx + yy) / 41.0)
+    org = torch.from_numpy(np.clip(base + rng.integers(-6, 7, size=base.shape), 0, 1023).astype(np.int16)).to(dev)
+    ref = torch.from_numpy(np.clip(np.roll(base, (9, -13), axis=(0, 1)) + rng.integers(-6, 7, size=base.shape), 0, 1023).astype(np.int16)).to(dev)
+    o0 = PAD_L * s + PAD_L
+    tot = 0.0
+    for S in (8, 16, 32, 64):
+        ys, xs = np.meshgrid(np.arange(H // S) * S, np.arange(W // S) * S, indexing="ij")
+        x, y = xs.ravel(), ys.ravel()
+        mvp = rng.integers(-32, 33, size=(x.size, 2))
+        f = lambda: me.epzs_search(org, o0, s, ref, o0, s, x, y, mvp, S.bit_length() - 1, 10, 1 << 20, 1, 64, 64, (-128, -128), (W + 127, H + 127), 4, 0)
+        f(); torch.cuda.synchronize()
+        t0 = _t.perf_counter(); cost, mv = f(); torch.cuda.synchronize(); ms = (_t.perf_counter() - t0) * 1e3
+        tot += ms
+        print("epzs %2dx%-2d %7d blocks %.2f ms  (mean |mv| %.1f qpel)" % (S, S, x.size, ms, np.abs(mv).mean()))
+    print("epzs all levels, one list: %.2f ms" % tot)
