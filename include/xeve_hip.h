@@ -245,6 +245,27 @@ int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xev
                                   const int16_t (*coef)[8], const xeve_hip_spel_params *params, xeve_hip_me_result *results,
                                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* The whole per-list search of one block: pinter_me_epzs (src_base/xeve_pinter.c:699-869) for me_complexity == 1 (no
+ * raster search) and me_level > ME_LEV_IPEL -- first diamond search from the MVP (or, bi == 1, from mv_start), refinement
+ * diamond searches from the running best while beststep > 0, then the sub-pel pattern search.  All bookkeeping between
+ * the searches runs in device kernels; the host only reads one "jobs still refining" counter per iteration, so this call
+ * SYNCHRONISES `stream`.  results[j].mv / .cost are what pinter_me_epzs returns; .beststep / .best_mv_bits are 0. */
+typedef struct xeve_hip_epzs_job {
+    int32_t x, y;        /* block position (integer pel) */
+    int32_t org_off;     /* bi != 0: offset of the job's dense org_bi block */
+    int16_t mvp[2];      /* MV predictor relative to the block, quarter pel */
+    int16_t mv_start[2]; /* bi == 1 only: the MV to refine */
+} xeve_hip_epzs_job;
+typedef struct xeve_hip_epzs_params {
+    xeve_hip_me_params me; /* faststep is ignored: 3 for the first search, 2 for refinements (xeve_pred.h:64-65) */
+    int32_t hpel_cnt, qpel_cnt;
+} xeve_hip_epzs_params;
+size_t xeve_hip_me_epzs_workspace(int njobs);
+int xeve_hip_me_epzs_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref,
+                          const xeve_hip_epzs_job *jobs, int njobs, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                          const xeve_hip_epzs_params *params, xeve_hip_me_result *results, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

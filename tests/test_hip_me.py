@@ -152,9 +152,11 @@ def test_epzs_search_vs_oracle(S, bi):
     org, ref = torch.from_numpy(pl["org"]).to(dev), torch.from_numpy(pl["ref"]).to(dev)
     o0 = PAD * pl["s"] + PAD
     org_bi = torch.from_numpy(np.stack([c["org_bi"] for c in cases])).to(dev)
-    cost, mv = me.epzs_search(org, o0, pl["s"], ref, o0, pl["s"], [c["x"] for c in cases], [c["y"] for c in cases], [c["mvp"] for c in cases],
-                              S.bit_length() - 1, 10, base["lambda_mv"], 1, base["msr"], base["sr"], base["min_clip"], base["max_clip"],
-                              base["hpel_cnt"], base["qpel_cnt"], bi=bi, org_bi=org_bi, mv_start=[c["mv0"] for c in cases],
-                              extra_bits=base["mot_other"])
-    for i, c in enumerate(cases):
-        assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == run_oracle_epzs(c), (S, bi, i)
+    args = (org, o0, pl["s"], ref, o0, pl["s"], [c["x"] for c in cases], [c["y"] for c in cases], [c["mvp"] for c in cases],
+            S.bit_length() - 1, 10, base["lambda_mv"], 1, base["msr"], base["sr"], base["min_clip"], base["max_clip"], base["hpel_cnt"], base["qpel_cnt"])
+    kw = dict(bi=bi, org_bi=org_bi, mv_start=[c["mv0"] for c in cases], extra_bits=base["mot_other"])
+    exp = [run_oracle_epzs(c) for c in cases]
+    for impl in (me.epzs_search, me.epzs_search_device):  # host-loop composition and the C entry point xeve_hip_me_epzs_jobs
+        cost, mv = impl(*args, **kw)
+        for i in range(len(cases)):
+            assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == exp[i], (impl.__name__, S, bi, i)

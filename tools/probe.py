@@ -113,7 +113,7 @@ if what == "epzs":
         ys, xs = np.meshgrid(np.arange(H // S) * S, np.arange(W // S) * S, indexing="ij")
         x, y = xs.ravel(), ys.ravel()
         mvp = rng.integers(-32, 33, size=(x.size, 2))
-        f = lambda: me.epzs_search(org, o0, s, ref, o0, s, x, y, mvp, S.bit_length() - 1, 10, 1 << 20, 1, 64, 64, (-128, -128), (W + 127, H + 127), 4, 0)
+        f = lambda: me.epzs_search_device(org, o0, s, ref, o0, s, x, y, mvp, S.bit_length() - 1, 10, 1 << 20, 1, 64, 64, (-128, -128), (W + 127, H + 127), 4, 0)
         f(); torch.cuda.synchronize()
         t0 = _t.perf_counter(); cost, mv = f(); torch.cuda.synchronize(); ms = (_t.perf_counter() - t0) * 1e3
         tot += ms

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     const xeve_hip_me_job jb = jobs[j];
+    if(jb.range[0] > jb.range[2]) return; // empty range = job parked by the EPZS driver (its result slot is left untouched)
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
 
     // the original block (org_bi for bi-prediction refinement: 2*org - pred, may be negative) stays in registers
@@ -176,5 +177,152 @@ extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const p
     else ME_LAUNCH(64);
 #undef ME_LAUNCH
     XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+
+// =========================================================================================================
+// pinter_me_epzs per job (xeve_hip_me_epzs_jobs): the reference's host loop between the searches, as device kernels
+// =========================================================================================================
+struct EpzsState {
+    uint32_t cost;
+    int16_t  mv[2];
+    int32_t  tmpstep, searches;
+};
+
+__device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, int cy, int16_t (&range)[4])
+{
+    const int sr = P.bi == 1 ? 5 : P.range_recentre; // get_range_ipel, xeve_pinter.c:122-140
+    range[0] = (int16_t)clip3(P.min_clip[0], P.max_clip[0], cx - sr), range[1] = (int16_t)clip3(P.min_clip[1], P.max_clip[1], cy - sr);
+    range[2] = (int16_t)clip3(P.min_clip[0], P.max_clip[0], cx + sr), range[3] = (int16_t)clip3(P.min_clip[1], P.max_clip[1], cy + sr);
+}
+
+__global__ void k_epzs_init(const xeve_hip_epzs_job *__restrict__ jobs, int n, xeve_hip_me_params P, xeve_hip_me_job *__restrict__ mj,
+                            EpzsState *__restrict__ st)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n) return;
+    const xeve_hip_epzs_job e = jobs[j];
+    const int sx = P.bi == 1 ? e.mv_start[0] : e.mvp[0], sy = P.bi == 1 ? e.mv_start[1] : e.mvp[1];
+    xeve_hip_me_job m;
+    m.x = e.x, m.y = e.y, m.org_off = e.org_off, m.beststep_in = 0;
+    m.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), m.gmvp[1] = (int16_t)(e.mvp[1] + (e.y << 2));
+    m.mvi[0] = (int16_t)(sx + (e.x << 2)), m.mvi[1] = (int16_t)(sy + (e.y << 2));
+    // the first call clips the search centre (xeve_pinter.c:738-741)
+    epzs_range(P, clip3(P.min_clip[0], P.max_clip[0], e.x + (sx >> 2)), clip3(P.min_clip[1], P.max_clip[1], e.y + (sy >> 2)), m.range);
+    mj[j] = m;
+    EpzsState s;
+    s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0;
+    st[j] = s;
+}
+
+// after a diamond launch: fold its result into the running best, then either park the job or set up the next
+// refinement search from the new best (xeve_pinter.c:757-822)
+__global__ void k_epzs_update(const xeve_hip_epzs_job *__restrict__ jobs, int n, xeve_hip_me_params P, const xeve_hip_me_result *__restrict__ res,
+                              xeve_hip_me_job *__restrict__ mj, EpzsState *__restrict__ st, int *__restrict__ active)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n) return;
+    xeve_hip_me_job m = mj[j];
+    if(m.range[0] > m.range[2]) return; // was parked
+    const xeve_hip_epzs_job e = jobs[j];
+    const xeve_hip_me_result r = res[j];
+    EpzsState s = st[j];
+    s.tmpstep = r.beststep, s.searches++;
+    int beststep = 0;
+    if(r.cost < s.cost) {
+        s.cost = r.cost, s.mv[0] = r.mv[0], s.mv[1] = r.mv[1];
+        const int dx = e.mvp[0] - s.mv[0], dy = e.mvp[1] - s.mv[1];
+        beststep = ((dx < 0 ? -dx : dx) < 2 && (dy < 0 ? -dy : dy) < 2) ? 0 : s.tmpstep;
+    }
+    st[j] = s;
+    if(P.bi != 1 && beststep > 0) { // REFINE_SEARCH_THD 0; the refinement centre is NOT clipped (xeve_pinter.c:785-788)
+        epzs_range(P, e.x + (s.mv[0] >> 2), e.y + (s.mv[1] >> 2), m.range);
+        m.mvi[0] = (int16_t)(s.mv[0] + (e.x << 2)), m.mvi[1] = (int16_t)(s.mv[1] + (e.y << 2));
+        m.beststep_in = s.tmpstep;
+        atomicAdd(active, 1);
+    }
+    else m.range[0] = 1, m.range[2] = 0; // park
+    mj[j] = m;
+}
+
+__global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n) return;
+    const xeve_hip_epzs_job e = jobs[j];
+    xeve_hip_spel_job s;
+    s.x = e.x, s.y = e.y, s.org_off = e.org_off;
+    s.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), s.gmvp[1] = (int16_t)(e.mvp[1] + (e.y << 2));
+    s.mvi[0] = st[j].mv[0], s.mvi[1] = st[j].mv[1];
+    sj[j] = s;
+}
+
+__global__ void k_epzs_finish(int n, const EpzsState *__restrict__ st, const xeve_hip_me_result *__restrict__ spel, xeve_hip_me_result *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n) return;
+    xeve_hip_me_result r;
+    r.cost = st[j].cost, r.mv[0] = st[j].mv[0], r.mv[1] = st[j].mv[1], r.beststep = 0, r.best_mv_bits = 0;
+    if(spel[j].cost < r.cost) r.cost = spel[j].cost, r.mv[0] = spel[j].mv[0], r.mv[1] = spel[j].mv[1]; // xeve_pinter.c:828-833
+    out[j] = r;
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t xeve_hip_me_epzs_workspace(int njobs)
+{
+    const size_t n = njobs > 0 ? njobs : 0;
+    return al256(n * sizeof(xeve_hip_me_job)) + 2 * al256(n * sizeof(xeve_hip_me_result)) + al256(n * sizeof(EpzsState)) +
+           al256(n * sizeof(xeve_hip_spel_job)) + al256(xeve_hip_me_spel_workspace(njobs)) + 256;
+}
+
+extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs,
+                                     int njobs, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                                     const xeve_hip_epzs_params *params, xeve_hip_me_result *results, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
+    XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
+    XH_REQUIRE(params->me.bi == 0 || params->me.bi == 1);
+    if(njobs == 0) return XEVE_HIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char *w = static_cast<char *>(workspace);
+    const size_t n = njobs;
+    xeve_hip_me_job    *mj   = reinterpret_cast<xeve_hip_me_job *>(w);      w += al256(n * sizeof(xeve_hip_me_job));
+    xeve_hip_me_result *mres = reinterpret_cast<xeve_hip_me_result *>(w);   w += al256(n * sizeof(xeve_hip_me_result));
+    xeve_hip_me_result *sres = reinterpret_cast<xeve_hip_me_result *>(w);   w += al256(n * sizeof(xeve_hip_me_result));
+    EpzsState          *state = reinterpret_cast<EpzsState *>(w);           w += al256(n * sizeof(EpzsState));
+    xeve_hip_spel_job  *sj   = reinterpret_cast<xeve_hip_spel_job *>(w);    w += al256(n * sizeof(xeve_hip_spel_job));
+    void               *sws  = w;                                            w += al256(xeve_hip_me_spel_workspace(njobs));
+    int                *active = reinterpret_cast<int *>(w);
+    const dim3 g((njobs + 255) / 256);
+    xeve_hip_me_params P = params->me;
+    k_epzs_init<<<g, 256, 0, st>>>(jobs, njobs, P, mj, state);
+    XH_HIP(hipGetLastError());
+    for(int it = 0; it < 64; it++) { // the reference's loop ends when no block improves any more; 64 is a safety bound
+        P.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
+        int rc = xeve_hip_me_ipel_diamond_jobs(org0, s_org, org_bi, ref0, s_ref, mj, njobs, log2w, log2h, bit_depth, &P, mres, st);
+        if(rc != XEVE_HIP_OK) return rc;
+        XH_HIP(hipMemsetAsync(active, 0, sizeof(int), st));
+        k_epzs_update<<<g, 256, 0, st>>>(jobs, njobs, P, mres, mj, state, active);
+        XH_HIP(hipGetLastError());
+        int h_active = 0;
+        XH_HIP(hipMemcpyAsync(&h_active, active, sizeof(int), hipMemcpyDeviceToHost, st));
+        XH_HIP(hipStreamSynchronize(st));
+        if(h_active == 0) break;
+    }
+    k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj);
+    XH_HIP(hipGetLastError());
+    xeve_hip_spel_params SP;
+    SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;
+    SP.hpel_cnt = params->hpel_cnt, SP.qpel_cnt = params->qpel_cnt;
+    int rc = xeve_hip_me_spel_pattern_jobs(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, sres, sws,
+                                           xeve_hip_me_spel_workspace(njobs), st);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_epzs_finish<<<g, 256, 0, st>>>(njobs, state, sres, results);
+    XH_HIP(hipGetLastError());
+    XH_HIP(hipStreamSynchronize(st));
     return XEVE_HIP_OK;
 }

@@ -31,6 +31,11 @@ class SpelParams(C.Structure):  # xeve_hip_spel_params
                 ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
 
 
+class EpzsParams(C.Structure):  # xeve_hip_epzs_params
+    _fields_ = [("me", MeParams), ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
+
+
+EPZS_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("mvp", "<i2", 2), ("mv_start", "<i2", 2)]  # xeve_hip_epzs_job
 SPEL_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_spel_job
 ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2), ("beststep_in", "<i4")]  # xeve_hip_me_job
 ME_RESULT_DTYPE = [("mv", "<i2", 2), ("cost", "<u4"), ("beststep", "<i4"), ("best_mv_bits", "<i4")]  # xeve_hip_me_result
@@ -80,6 +85,9 @@ FUNCTIONS = {
     "xeve_hip_me_spel_workspace": (C.c_size_t, [c_int]),
     "xeve_hip_me_spel_pattern_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_me_epzs_workspace": (C.c_size_t, [c_int]),
+    "xeve_hip_me_epzs_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 TABLES = {
