@@ -163,6 +163,20 @@ int xeve_hip_quant(int16_t *coef, int nblk, int log2w, int log2h, int qp, int sc
 /* RDOQ all-zero pre-test (xeve_tq.c:666-699): coded[b] = 1 if the block survives, else 0 and the block is zeroed */
 int xeve_hip_rdoq_zero_test(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice,
                             int bit_depth, int32_t *coded, void *stream);
+/* RDOQ: xeve_rdoq_run_length_cc (xeve_tq.c:497-649) over nblk dense blocks, in place; nnz[b] = its return value.
+ * The reference walks the zig-zag scan sequentially (the rate of a coefficient depends on whether the previous one in
+ * scan order was quantised to zero, the "last" position on a running cost).  In Baseline the context index is constant
+ * per component (xeve_rdoq_set_ctx_cc, xeve_tq.c:492-495), so the dependency is a two-state automaton: the kernel
+ * evaluates both outcomes per coefficient and resolves states, running costs and the best last position with parallel
+ * prefix scans -- same levels, same nnz.  `est` (HOST pointer) holds the CABAC-derived bit estimates the reference keeps
+ * in XEVE_CORE (xeve_type.h:737-747): cbf = the pair chosen for this component / slice type (xeve_tq.c:565-583).
+ * lambda as the reference receives it (double); tool_iqt selects the row of xeve_quant_scale (0 in Baseline). */
+typedef struct xeve_hip_rdoq_est {
+    int32_t cbf[2];
+    int32_t run[24][2], level[24][2], last[2][2];
+} xeve_hip_rdoq_est;
+int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                  const xeve_hip_rdoq_est *est, int32_t *nnz, void *stream);
 /* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
 int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
 /* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;

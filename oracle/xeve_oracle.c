@@ -592,3 +592,104 @@ uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const x
     if(r.cost < cost_best) cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
     return cost_best;
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* RDOQ (reference: xeve_tq.c:406-649)                                        */
+/* ------------------------------------------------------------------------- */
+void xo_zigzag(int log2w, int log2h, uint16_t *scan)
+{
+    const int w = 1 << log2w, h = 1 << log2h;
+    int pos = 0;
+    /* anti-diagonals x + y = l; odd l run down-left (x decreasing), even l run up-right (xeve_util.c:1301-1325) */
+    for(int l = 0; l < w + h - 1; l++) {
+        if(l & 1) {
+            for(int x = l < w - 1 ? l : w - 1, y = l - x; x >= 0 && y < h; x--, y++) scan[pos++] = (uint16_t)(y * w + x);
+        }
+        else {
+            for(int y = l < h - 1 ? l : h - 1, x = l - y; y >= 0 && x < w; x++, y--) scan[pos++] = (uint16_t)(y * w + x);
+        }
+    }
+}
+
+int64_t xo_err_scale(int qp_rem, int log2_size, int bit_depth, int tool_iqt)
+{
+    const int tr_shift = 15 - bit_depth - log2_size; /* MAX_TX_DYNAMIC_RANGE - bd - (i + 1), i = log2_size - 1 */
+    double e = (double)(1 << 15) * pow(2.0, -tr_shift);
+    e = e / xo_quant_scale[tool_iqt][qp_rem] / (1 << (bit_depth - 8));
+    return (int64_t)(e * (double)(1 << 20));
+}
+
+/* rate of coding |level| after `run_nonzero ? run > 0 : run == 0` zeros (get_ic_rate_cost_rl, xeve_tq.c:425-456);
+ * s32 arithmetic as the reference, context index c = 0 (luma) / 2 (chroma) (xeve_rdoq_set_ctx_cc, xeve_tq.c:492-495) */
+static int64_t rl_cost(uint32_t abs_level, int run_nonzero, int c, int64_t lambda, const xo_rdoq_est *e)
+{
+    uint32_t rate;
+    if(abs_level == 0) rate = (uint32_t)e->run[c + run_nonzero][1];
+    else {
+        rate = 32768u + (uint32_t)e->run[c + run_nonzero][0];
+        if(abs_level == 1) rate += (uint32_t)e->level[c][0];
+        else rate += (uint32_t)e->level[c][1] + (uint32_t)e->level[c + 1][1] * (abs_level - 2) + (uint32_t)e->level[c + 1][0];
+    }
+    return (int64_t)(int32_t)rate * lambda;
+}
+
+int xo_rdoq(int16_t *coef, int log2w, int log2h, int qp, double d_lambda, int is_luma, int bit_depth, int tool_iqt, const xo_rdoq_est *est)
+{
+    const int odd = (log2w + log2h) & 1, ns_shift = odd ? 7 : 0, ns_scale = odd ? 181 : 1, ns_offset = odd ? 1 << (ns_shift - 1) : 0;
+    const int q_value   = (xo_quant_scale[tool_iqt][qp % 6] * ns_scale + ns_offset) >> ns_shift;
+    const int log2_size = (log2w + log2h) >> 1;
+    const int q_bits    = 14 + (15 - bit_depth - log2_size) + qp / 6;
+    const int n = 1 << (log2w + log2h), c = is_luma ? 0 : 2, ctx_last = is_luma ? 0 : 1;
+    const int64_t lambda = (int64_t)(d_lambda * (double)(1 << 15) + 0.5);
+    const int64_t es     = xo_err_scale(qp % 6, log2_size, bit_depth, tool_iqt);
+    uint16_t *scan = (uint16_t *)malloc(sizeof(uint16_t) * n);
+    int64_t  *ld   = (int64_t *)malloc(sizeof(int64_t) * n);
+    int      *mx   = (int *)malloc(sizeof(int) * n);
+    int16_t  *out  = (int16_t *)calloc(n, sizeof(int16_t));
+    xo_zigzag(log2w, log2h, scan);
+    int64_t block_uncoded = 0;
+    int     sum_all = 0, nnz = 0;
+    for(int p = 0; p < n; p++) {
+        const int     v = coef[scan[p]];
+        const int64_t t = (int64_t)iabs(v) * q_value, cap = (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1));
+        const int64_t level_double = (int)(t < cap ? t : cap);
+        uint32_t m = (uint32_t)(level_double >> q_bits);
+        if(!((level_double - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
+        const int64_t err = (level_double * es) >> 20;
+        block_uncoded += err * err;
+        ld[p] = level_double, mx[p] = v > 0 ? (int16_t)m : -(int16_t)m;
+        sum_all += (int)m;
+    }
+    if(sum_all != 0) {
+        int64_t best_cost = block_uncoded + (int64_t)est->cbf[0] * lambda, base_cost = block_uncoded + (int64_t)est->cbf[1] * lambda;
+        uint32_t run = 0, best_last = 0;
+        for(int p = 0; p < n; p++) {
+            const uint32_t max_abs = (uint32_t)iabs(mx[p]);
+            const int64_t  e1 = (ld[p] * es) >> 20, uncoded = e1 * e1;
+            int64_t  coded = uncoded + rl_cost(0, run != 0, c, lambda, est);
+            uint32_t best = 0;
+            const uint32_t lo = max_abs > 1 ? max_abs - 1 : 1;
+            for(uint32_t a = max_abs; a >= lo; a--) { /* get_coded_level_rl, xeve_tq.c:458-490 */
+                const int64_t d = ld[p] - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, run != 0, c, lambda, est);
+                if(cost < coded) best = a, coded = cost;
+            }
+            out[scan[p]] = (int16_t)(mx[p] < 0 ? -(int32_t)best : (int32_t)best);
+            base_cost += coded - uncoded;
+            if(best) {
+                const int64_t cur_is_last = base_cost + (int64_t)est->last[ctx_last][1] * lambda;
+                base_cost += (int64_t)est->last[ctx_last][0] * lambda;
+                if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)p + 1;
+                run = 0;
+            }
+            else run++;
+        }
+        for(int p = 0; p < n; p++) {
+            if((uint32_t)p < best_last) nnz += out[scan[p]] != 0;
+            else out[scan[p]] = 0;
+        }
+    }
+    memcpy(coef, out, sizeof(int16_t) * n);
+    free(scan), free(ld), free(mx), free(out);
+    return nnz;
+}

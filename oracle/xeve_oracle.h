@@ -77,6 +77,20 @@ void xo_dquant(int16_t *coef, int log2w, int log2h, int scale, int bit_depth);
 /* a15: xeve_recon_blk xeve_recon.c:34-57 */
 void xo_recon(const int16_t *coef, const xo_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xo_pel *rec, int bit_depth);
 
+/* ---- RDOQ (a11; reference: xeve_rdoq_run_length_cc, src_base/xeve_tq.c:497-649) -------------------------------- */
+/* zig-zag scan of a w x h block, xeve_tbl_scan[log2w-1][log2h-1] (xeve_tbl.c:625; generator xeve_util.c:1289-1327) */
+void xo_zigzag(int log2w, int log2h, uint16_t *scan);
+/* ctx->err_scale[qp % 6][log2_size - 1]  (xeve_init_err_scale, xeve_tq.c:406-423) */
+int64_t xo_err_scale(int qp_rem, int log2_size, int bit_depth, int tool_iqt);
+/* CABAC-derived bit estimates the reference keeps in XEVE_CORE (xeve_type.h:737-747, filled by xeve_rdoq_bit_est,
+ * xeve_mode.c:326-372); cbf = the pair the reference picks for this component / slice type (xeve_tq.c:565-583) */
+typedef struct xo_rdoq_est {
+    int32_t cbf[2];
+    int32_t run[24][2], level[24][2], last[2][2];
+} xo_rdoq_est;
+/* in place on coef (dense w*h); returns nnz.  lambda as the reference receives it (double). */
+int xo_rdoq(int16_t *coef, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt, const xo_rdoq_est *est);
+
 /* ---- integer-pel motion search (reference: src_base/xeve_pinter.c) ------------ */
 /* get_mv_bits (xeve_pinter.c:74-120) without the reference-index term; table xeve_tbl_mv_bits (xeve_tbl.c:286-496)
  * restated in closed form */

@@ -265,3 +265,37 @@ def ref_epzs():
                                      C.c_uint32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int]
         L._epzs_bound = True
     return L
+
+
+# ---- RDOQ ----------------------------------------------------------------------------------------------------------
+class RdoqEst(C.Structure):
+    _fields_ = [("cbf", C.c_int32 * 2), ("run", (C.c_int32 * 2) * 24), ("level", (C.c_int32 * 2) * 24), ("last", (C.c_int32 * 2) * 2)]
+
+
+REF_RDOQ_SO = os.path.join(ORACLE_DIR, "_ref", "libref_rdoq.so")
+_ref_rdoq = None
+
+
+def ref_rdoq():
+    global _ref_rdoq
+    if _ref_rdoq is None and os.path.exists(REF_RDOQ_SO):
+        L = C.CDLL(REF_RDOQ_SO)
+        L.refdrv_rdoq.restype = c_int
+        L.refdrv_rdoq.argtypes = [c_void_p, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_int, C.POINTER(RdoqEst)]
+        L.refdrv_scan.restype = C.POINTER(C.c_uint16)
+        L.refdrv_scan.argtypes = [c_int, c_int]
+        L.refdrv_err_scale.restype = C.c_longlong
+        L.refdrv_err_scale.argtypes = [c_int] * 4
+        _ref_rdoq = L
+    return _ref_rdoq
+
+
+def oracle_rdoq():
+    L = oracle()
+    L.xo_zigzag.restype = None
+    L.xo_zigzag.argtypes = [c_int, c_int, c_void_p]
+    L.xo_err_scale.restype = c_i64
+    L.xo_err_scale.argtypes = [c_int] * 4
+    L.xo_rdoq.restype = c_int
+    L.xo_rdoq.argtypes = [c_void_p, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, C.POINTER(RdoqEst)]
+    return L

@@ -1,0 +1,278 @@
+// xeve_amd/csrc/rdoq.hip -- rate-distortion optimised quantisation as a parallel scan.
+//
+// reference: xeve_rdoq_run_length_cc  src_base/xeve_tq.c:497-649 (+ get_coded_level_rl :458-490, get_ic_rate_cost_rl
+// :425-456, xeve_init_err_scale :406-423, zig-zag scan xeve_tbl.c:625 / xeve_util.c:1289-1327).
+//
+// The reference is a sequential walk over the zig-zag scan with three carried quantities:
+//   run        -- zeros since the last non-zero level; only "run == 0 or not" enters the rate (the context index is a
+//                 per-component constant in Baseline), i.e. a TWO-STATE automaton driven by "was the previous level 0";
+//   base cost  -- running sum of (coded - uncoded) cost and of the "not last" flag cost of every non-zero level;
+//   best last  -- first position whose "I am the last coefficient" cost beats everything before (strictly).
+// Per coefficient both automaton outcomes (level and cost for run == 0 and for run > 0) are computed independently;
+// the states are then resolved by a prefix scan of 2-bit transition functions, the base cost by a 64-bit prefix sum and
+// the best last position by an (cost, position) arg-min -- bit-identical to the walk.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include "xh_common.h"
+
+struct RdoqK {
+    int  n, log2n, q_value, q_bits, c, ctx_last;
+    long lambda, err_scale;
+    xeve_hip_rdoq_est est;
+};
+
+__device__ __forceinline__ long rl_cost(unsigned abs_level, int rs, const RdoqK &P)
+{
+    unsigned rate;
+    if(abs_level == 0) rate = (unsigned)P.est.run[P.c + rs][1];
+    else {
+        rate = 32768u + (unsigned)P.est.run[P.c + rs][0];
+        if(abs_level == 1) rate += (unsigned)P.est.level[P.c][0];
+        else rate += (unsigned)P.est.level[P.c][1] + (unsigned)P.est.level[P.c + 1][1] * (abs_level - 2) + (unsigned)P.est.level[P.c + 1][0];
+    }
+    return (long)(int)rate * P.lambda; // s32 rate as the reference, then GET_I_COST
+}
+
+// one coefficient: both automaton outcomes
+struct Cand {
+    unsigned lev[2]; // level if run == 0 / run > 0
+    long     d[2];   // coded - uncoded cost for the two cases
+    long     unc;
+    unsigned maxabs;
+    int      neg;
+};
+__device__ __forceinline__ Cand eval_coef(int v, const RdoqK &P)
+{
+    Cand c;
+    const long t = (long)(v < 0 ? -v : v) * P.q_value, cap = (long)INT32_MAX - (1L << (P.q_bits - 1));
+    const long ld = (long)(int)(t < cap ? t : cap);
+    unsigned m = (unsigned)(ld >> P.q_bits);
+    if(!((ld - ((long)m << P.q_bits)) < (1L << (P.q_bits - 1)))) m++;
+    const long e1 = (ld * P.err_scale) >> 20;
+    c.unc = e1 * e1, c.maxabs = m, c.neg = !(v > 0);
+    const unsigned lo = m > 1 ? m - 1 : 1;
+#pragma unroll
+    for(int rs = 0; rs < 2; rs++) {
+        long coded = c.unc + rl_cost(0, rs, P);
+        unsigned best = 0;
+        for(unsigned a = m; a >= lo; a--) {
+            const long dd = ld - ((long)a << P.q_bits), e2 = (dd * P.err_scale) >> 20, cost = e2 * e2 + rl_cost(a, rs, P);
+            if(cost < coded) best = a, coded = cost;
+        }
+        c.lev[rs] = best, c.d[rs] = coded - c.unc;
+    }
+    return c;
+}
+
+// ---- wave / block primitives (WPB waves of 64 lanes form one block's thread group) --------------------
+__device__ __forceinline__ long shfl_up64(long v, int d)
+{
+    const unsigned lo = __shfl_up((unsigned)v, d, 64), hi = __shfl_up((unsigned)((unsigned long)v >> 32), d, 64);
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ long shfl_xor64(long v, int m)
+{
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)((unsigned long)v >> 32), m, 64);
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+// transition functions on {0,1}: bit s = next state from state s; identity = 0b10
+__device__ __forceinline__ int fcompose(int later, int earlier) { return ((later >> (earlier & 1)) & 1) | (((later >> ((earlier >> 1) & 1)) & 1) << 1); }
+
+template <int K, int WPB>
+__global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nblk, RdoqK P, const uint16_t *__restrict__ scan,
+                                              int32_t *__restrict__ nnz_out)
+{
+    constexpr int TPB = 64 * WPB, BPW = 4 / WPB; // threads per block, blocks per workgroup
+    __shared__ long s_long[4][4];                  // [wave in workgroup][slot]
+    __shared__ int  s_int[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bl = wave / WPB, wib = wave % WPB, t = wib * 64 + lane; // block-local thread id
+    const int b = blockIdx.x * BPW + bl;
+    const bool live = b < nblk;
+    int16_t *blk = coef + (size_t)(live ? b : 0) * P.n;
+    const int w0 = bl * WPB; // first wave of my block in the s_* arrays
+
+    // ---- phase 1: candidates of my K consecutive scan positions
+    unsigned lev0[K], lev1[K];
+    long     d0[K], d1[K];
+    int      neg[K];
+    long     unc_sum = 0;
+    int      sum_all = 0, F = 2; // chunk transition function, starts as identity
+#pragma unroll
+    for(int i = 0; i < K; i++) {
+        const int p = t * K + i;
+        int v = 0;
+        if(live && p < P.n) v = blk[scan[p]];
+        const Cand c = eval_coef(v, P);
+        lev0[i] = c.lev[0], lev1[i] = c.lev[1], d0[i] = c.d[0], d1[i] = c.d[1], neg[i] = c.neg;
+        if(p < P.n) {
+            unc_sum += c.unc, sum_all += (int)c.maxabs;
+            F = fcompose((c.lev[0] == 0 ? 1 : 0) | ((c.lev[1] == 0 ? 1 : 0) << 1), F);
+        }
+    }
+    // block totals: sum_all, uncoded cost
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) sum_all += __shfl_xor(sum_all, m, 64), unc_sum += shfl_xor64(unc_sum, m);
+    if(lane == 0) s_int[wave][0] = sum_all, s_long[wave][0] = unc_sum;
+    __syncthreads();
+    sum_all = 0, unc_sum = 0;
+#pragma unroll
+    for(int i = 0; i < WPB; i++) sum_all += s_int[w0 + i][0], unc_sum += s_long[w0 + i][0];
+    __syncthreads();
+
+    // ---- phase 2: incoming automaton state of my chunk = (F_{t-1} o ... o F_0)(0)
+    int incl = F;
+#pragma unroll
+    for(int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, 64);
+        if(lane >= dlt) incl = fcompose(incl, o);
+    }
+    if(lane == 63) s_int[wave][1] = incl;
+    __syncthreads();
+    int pre = 2; // functions of the earlier waves of my block
+    for(int i = 0; i < wib; i++) pre = fcompose(s_int[w0 + i][1], pre);
+    int excl = __shfl_up(incl, 1, 64);
+    if(lane == 0) excl = 2;
+    const int state_in = fcompose(excl, pre) & 1; // applied to the initial state 0 (run = 0)
+    __syncthreads();
+
+    // ---- phase 3: resolve my chunk, running base cost
+    const long lz = (long)P.est.last[P.ctx_last][0] * P.lambda, lone = (long)P.est.last[P.ctx_last][1] * P.lambda;
+    unsigned lev[K];
+    long     inc[K], dsel[K];
+    long     chunk = 0;
+    int      st = state_in;
+#pragma unroll
+    for(int i = 0; i < K; i++) {
+        const int p = t * K + i;
+        lev[i]  = st ? lev1[i] : lev0[i];
+        dsel[i] = st ? d1[i] : d0[i];
+        inc[i]  = p < P.n ? dsel[i] + (lev[i] ? lz : 0) : 0;
+        if(p >= P.n) lev[i] = 0;
+        chunk += inc[i];
+        st = lev[i] == 0 ? 1 : 0;
+    }
+    long incl_sum = chunk;
+#pragma unroll
+    for(int dlt = 1; dlt < 64; dlt <<= 1) {
+        const long o = shfl_up64(incl_sum, dlt);
+        if(lane >= dlt) incl_sum += o;
+    }
+    if(lane == 63) s_long[wave][1] = incl_sum;
+    __syncthreads();
+    long base = unc_sum + (long)P.est.cbf[1] * P.lambda + (incl_sum - chunk); // d64_base_cost before my chunk
+    for(int i = 0; i < wib; i++) base += s_long[w0 + i][1];
+    // best "I am last" candidate of my chunk: strictly smaller cost wins, earlier position on ties
+    long best_cost = 0x7fffffffffffffffL;
+    int  best_pos  = 0x7fffffff;
+#pragma unroll
+    for(int i = 0; i < K; i++) {
+        if(lev[i]) {
+            const long cur = base + dsel[i] + lone;
+            if(cur < best_cost) best_cost = cur, best_pos = t * K + i;
+        }
+        base += inc[i];
+    }
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) {
+        const long oc = shfl_xor64(best_cost, m);
+        const int  op = __shfl_xor(best_pos, m, 64);
+        if(oc < best_cost || (oc == best_cost && op < best_pos)) best_cost = oc, best_pos = op;
+    }
+    __syncthreads();
+    if(lane == 0) s_long[wave][2] = best_cost, s_int[wave][2] = best_pos;
+    __syncthreads();
+    best_cost = s_long[w0][2], best_pos = s_int[w0][2];
+    for(int i = 1; i < WPB; i++)
+        if(s_long[w0 + i][2] < best_cost || (s_long[w0 + i][2] == best_cost && s_int[w0 + i][2] < best_pos)) best_cost = s_long[w0 + i][2], best_pos = s_int[w0 + i][2];
+    const long best0 = unc_sum + (long)P.est.cbf[0] * P.lambda; // d64_best_cost: "code nothing"
+    const int best_last = (sum_all != 0 && best_cost < best0) ? best_pos + 1 : 0;
+
+    // ---- phase 4: levels out
+    int cnt = 0;
+#pragma unroll
+    for(int i = 0; i < K; i++) {
+        const int p = t * K + i;
+        if(live && p < P.n) {
+            const int q = p < best_last ? (int)lev[i] : 0;
+            blk[scan[p]] = (int16_t)(neg[i] ? -q : q);
+            cnt += q != 0;
+        }
+    }
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
+    if(lane == 0) s_int[wave][3] = cnt;
+    __syncthreads();
+    if(live && t == 0) {
+        int tot = 0;
+        for(int i = 0; i < WPB; i++) tot += s_int[w0 + i][3];
+        nnz_out[b] = tot;
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+// zig-zag scans (xeve_tbl_scan, generator xeve_util.c:1289-1327), built once per (log2w, log2h) and kept on the device
+static uint16_t *g_scan[7][7];
+static std::mutex g_scan_mu;
+static int get_scan(int log2w, int log2h, const uint16_t **out)
+{
+    std::lock_guard<std::mutex> lk(g_scan_mu);
+    if(!g_scan[log2w][log2h]) {
+        const int w = 1 << log2w, h = 1 << log2h;
+        uint16_t *hs = new uint16_t[(size_t)w * h];
+        int pos = 0;
+        for(int l = 0; l < w + h - 1; l++) { // odd anti-diagonals run down-left, even ones up-right
+            if(l & 1) for(int x = l < w - 1 ? l : w - 1, y = l - x; x >= 0 && y < h; x--, y++) hs[pos++] = (uint16_t)(y * w + x);
+            else for(int y = l < h - 1 ? l : h - 1, x = l - y; y >= 0 && x < w; x++, y--) hs[pos++] = (uint16_t)(y * w + x);
+        }
+        uint16_t *d = nullptr;
+        XH_HIP(hipMalloc((void **)&d, sizeof(uint16_t) * w * h));
+        XH_HIP(hipMemcpy(d, hs, sizeof(uint16_t) * w * h, hipMemcpyHostToDevice));
+        delete[] hs;
+        g_scan[log2w][log2h] = d;
+    }
+    *out = g_scan[log2w][log2h];
+    return XEVE_HIP_OK;
+}
+
+static const int k_quant_scale[2][6] = {{26214, 23302, 20560, 18396, 16384, 14764}, {26214, 23302, 20560, 18396, 16384, 14564}}; // xeve_tq.c:37-38
+
+extern "C" int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                             const xeve_hip_rdoq_est *est, int32_t *nnz, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(coef && est && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
+    XH_REQUIRE(qp >= 0 && qp <= 63 && bit_depth >= 8 && bit_depth <= 14 && (tool_iqt == 0 || tool_iqt == 1));
+    if(nblk == 0) return XEVE_HIP_OK;
+    const uint16_t *scan;
+    int rc = get_scan(log2w, log2h, &scan);
+    if(rc != XEVE_HIP_OK) return rc;
+    RdoqK P;
+    const int odd = (log2w + log2h) & 1, ns_shift = odd ? 7 : 0, ns_scale = odd ? 181 : 1, ns_offset = odd ? 1 << (ns_shift - 1) : 0;
+    const int log2_size = (log2w + log2h) >> 1;
+    P.n = 1 << (log2w + log2h), P.log2n = log2w + log2h;
+    P.q_value = (k_quant_scale[tool_iqt][qp % 6] * ns_scale + ns_offset) >> ns_shift;
+    P.q_bits  = 14 + (15 - bit_depth - log2_size) + qp / 6;
+    XH_REQUIRE(P.q_bits >= 1 && P.q_bits <= 30);
+    P.c = is_luma ? 0 : 2, P.ctx_last = is_luma ? 0 : 1;
+    P.lambda = (long)(lambda * (double)(1 << 15) + 0.5); // SCALE_BITS, xeve_tq.c:528
+    { // ctx->err_scale[qp % 6][log2_size - 1], xeve_init_err_scale (xeve_tq.c:406-423)
+        const int tr_shift = 15 - bit_depth - log2_size;
+        double e = (double)(1 << 15) * pow(2.0, -tr_shift);
+        e = e / k_quant_scale[tool_iqt][qp % 6] / (1 << (bit_depth - 8));
+        P.err_scale = (long)(e * (double)(1 << 20));
+    }
+    P.est = *est;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = P.n;
+    if(n <= 64) k_rdoq<1, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 128) k_rdoq<2, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 256) k_rdoq<1, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 512) k_rdoq<2, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 1024) k_rdoq<4, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 2048) k_rdoq<8, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else k_rdoq<16, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -172,6 +172,15 @@ def rdoq_zero_test(coef, log2w, log2h, qp, scale, is_intra_slice, bit_depth):
     return coded
 
 
+def rdoq(coef, log2w, log2h, qp, lam, is_luma, bit_depth, est, tool_iqt=0, nnz=None):
+    """xeve_rdoq_run_length_cc over an int16 [nblk, h*w] tensor, in place (xeve_hip_rdoq); est: lib.RdoqEst"""
+    if nnz is None:
+        nnz = torch.empty(coef.shape[0], dtype=torch.int32, device=coef.device)
+    _lib.check(_lib.load().xeve_hip_rdoq(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, qp, float(lam), int(is_luma), bit_depth, tool_iqt,
+                                         C.byref(est), _ptr(nnz), _stream()))
+    return nnz
+
+
 def dquant(coef, log2w, log2h, scale, bit_depth):
     _lib.check(_lib.load().xeve_hip_dquant(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, scale, bit_depth, _stream()))
     return coef

@@ -20,6 +20,10 @@ class McJob(C.Structure):  # xeve_hip_mc_job
     _fields_ = [("gmv_x", C.c_int32), ("gmv_y", C.c_int32), ("pred_off", C.c_int32), ("frac", C.c_int32)]
 
 
+class RdoqEst(C.Structure):  # xeve_hip_rdoq_est
+    _fields_ = [("cbf", C.c_int32 * 2), ("run", (C.c_int32 * 2) * 24), ("level", (C.c_int32 * 2) * 24), ("last", (C.c_int32 * 2) * 2)]
+
+
 class MeParams(C.Structure):  # xeve_hip_me_params
     _fields_ = [("lambda_mv", C.c_uint32), ("refi_bits", C.c_int32), ("extra_bits", C.c_int32), ("bi", C.c_int32),
                 ("faststep", C.c_int32), ("max_search_range", C.c_int32), ("range_recentre", C.c_int32),
@@ -77,6 +81,7 @@ FUNCTIONS = {
     "xeve_hip_itrans": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_quant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xeve_hip_rdoq_zero_test": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_rdoq": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_dquant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_residual_rdo": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
