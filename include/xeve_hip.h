@@ -177,6 +177,9 @@ typedef struct xeve_hip_rdoq_est {
 } xeve_hip_rdoq_est;
 int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
                   const xeve_hip_rdoq_est *est, int32_t *nnz, void *stream);
+/* xeve_quant_nnz with use_rdoq = 1 (xeve_tq.c:651-703): the all-zero pre-test (zero_test != 0), then RDOQ */
+int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                     const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream);
 /* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
 int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
 /* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;
@@ -197,6 +200,13 @@ int xeve_hip_recon(const int16_t *coef, const xeve_hip_pel *pred, const uint8_t 
 int xeve_hip_residual_rdo(const xeve_hip_pel *org, int s_org, const xeve_hip_pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs,
                           int log2w, int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
                           int16_t *coef, xeve_hip_pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream);
+/* The same chain with the quantiser the presets configure (rdoq = 1): zero pre-test + xeve_rdoq_run_length_cc between the
+ * forward and the inverse half (three launches: front half, RDOQ scan kernel, back half).  est / lambda / is_luma /
+ * tool_iqt as for xeve_hip_rdoq. */
+int xeve_hip_residual_rdoq(const xeve_hip_pel *org, int s_org, const xeve_hip_pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs,
+                           int log2w, int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda,
+                           int is_luma, int tool_iqt, const xeve_hip_rdoq_est *est, int16_t *coef, xeve_hip_pel *rec, int s_rec,
+                           int32_t *nnz, int64_t *ssd, void *stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* (3) GPU-side consumer of the SAD kernel: one complete me_ipel_diamond per job (SURVEY.md 8(f)   */

@@ -73,3 +73,61 @@ def test_hip_rdoq_batches_vs_oracle(lw, lh):
             e = blocks[b].copy()
             en = O.xo_rdoq(ptr(e), lw, lh, qp, lam, luma, bd, 0, C.byref(est))
             assert nnz[b] == en and np.array_equal(got[b], e), (lw, lh, rep, b, qp, bd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lw,lh", [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5)])
+def test_residual_chain_with_rdoq_vs_oracle(lw, lh):
+    """xeve_hip_residual_rdoq = DIFF, SSD, DCT | zero pre-test + RDOQ | dequant, IDCT, recon, SSD, against the oracle chain"""
+    import torch
+
+    import xeve_amd
+    from _libs import oracle
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    O, OR = oracle(), oracle_rdoq()
+    r = np.random.default_rng(1500 + lw * 8 + lh)
+    w, h, bd = 1 << lw, 1 << lh, 10
+    n, nblk = w * h, 19
+    s = 4 * 64 + 32
+    org = r.integers(0, 1024, size=(5 * 64 + 16, s), dtype=np.int16)
+    pred = r.integers(0, 1024, size=(nblk, n), dtype=np.int16)
+    offs = [(8 + (b // 4) * h) * s + 8 + (b % 4) * w for b in range(nblk)]
+    for b in range(8):  # good predictions: small residuals, where RDOQ actually decides things
+        blk = org.reshape(-1)[np.add.outer(np.arange(h) * s, np.arange(w)).ravel() + offs[b]]
+        pred[b] = np.clip(blk + r.integers(-3 * b - 1, 3 * b + 2, size=n), 0, 1023)
+    for qp, intra, luma, lam in ((27, 0, 1, 38.5), (37, 1, 0, 310.25), (32, 0, 1, 96.0)):
+        est = make_est(r)
+        d_org, d_pred = torch.from_numpy(org).to(dev), torch.from_numpy(pred).to(dev)
+        jobs = D.make_jobs(offs, np.arange(nblk) * n, dev)
+        coef = torch.full((nblk, n), 77, dtype=torch.int16, device=dev)
+        rec = torch.zeros_like(d_org)
+        nnz = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        ssd = torch.zeros((nblk, 2), dtype=torch.int64, device=dev)
+        D.residual_rdoq(d_org, s, d_pred, w, jobs, lw, lh, bd, qp, intra, lam, luma, lib.RdoqEst.from_buffer_copy(bytes(est)), coef, rec, s, nnz, ssd)
+        coef, rec, nnz, ssd = coef.cpu().numpy(), rec.cpu().numpy(), nnz.cpu().numpy(), ssd.cpu().numpy()
+        qs, dqs = D.QUANT_SCALE[0][qp % 6], D.DQ_SCALE[qp % 6] << (qp // 6)
+        coded = 0
+        for b in range(nblk):
+            c = np.zeros(n, np.int16)
+            O.xo_diff(w, h, ptr(org, offs[b]), ptr(pred, b * n), s, w, w, ptr(c))
+            assert ssd[b, 0] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(pred, b * n), s, w, bd)
+            O.xo_trans(ptr(c), lw, lh, bd)
+            if O.xo_rdoq_zero_test(ptr(c), lw, lh, qp, qs, intra, bd):
+                e_nnz = OR.xo_rdoq(ptr(c), lw, lh, qp, lam, luma, bd, 0, C.byref(est))
+            else:
+                c[:] = 0
+                e_nnz = 0
+            assert nnz[b] == e_nnz and np.array_equal(coef[b], c), ("levels", lw, lh, qp, b)
+            coded += e_nnz
+            O.xo_dquant(ptr(c), lw, lh, dqs, bd)
+            O.xo_itrans(ptr(c), lw, lh, bd)
+            e = np.zeros((h, s), np.int16)
+            O.xo_recon(ptr(c), ptr(pred, b * n), 1, w, h, s, ptr(e), bd)
+            y0, x0 = offs[b] // s, offs[b] % s
+            assert np.array_equal(rec[y0:y0 + h, x0:x0 + w], e[:, :w]), ("rec", lw, lh, qp, b)
+            assert ssd[b, 1] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(rec, offs[b]), s, s, bd)
+        assert coded > 0

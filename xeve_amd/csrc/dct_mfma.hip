@@ -223,6 +223,7 @@ struct RdoParams {
     long z_scale, z_thr;                    // RDOQ zero pre-test (xeve_tq.c:666-699); z_thr < 0 disables it
     long dq_scale; int dq_shift, dq_offset; // dequant (xeve_itdq.c:442-475)
     int ssd_shift, maxv;
+    int stage; // 0 whole chain, 1 front half (DCT coefficients + SSD(pred) out), 2 back half (levels in); see tq.hip
 };
 
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
@@ -281,6 +282,10 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
             split16(d[0], d[1], alo[mt][ks], ahi[mt][ks]);
         }
 
+    int16_t *cb = coef + (size_t)j * N * N;
+    int  cnt = 0;
+    v4i  clo, chi;
+    if(P.stage != 2) {
     // ---- c: forward DCT, low-frequency 32x32 corner (the whole spectrum for N = 32)
     v4i b1[NT];
 #pragma unroll
@@ -331,8 +336,20 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
         for(int r = 0; r < 16; r++) h |= ((long)(cf[r] < 0 ? -cf[r] : cf[r]) * P.z_scale) >= P.z_thr;
         hit = __any(h);
     }
-    int cnt = 0;
-    int16_t *cb = coef + (size_t)j * N * N;
+    if(P.stage == 1) { // front half: raw coefficients (and the zero rows / columns of a 64-point block) out
+#pragma unroll
+        for(int r = 0; r < 16; r++) cb[frow(kg, r) * N + l32] = (int16_t)cf[r];
+        if(N == 64) {
+            const u32x4 z = {0, 0, 0, 0};
+            for(int i = lane; i < 64 * 8; i += 64) {
+                const int row = i >> 3, ch = i & 7;
+                if(row >= 32 || ch >= 4) *reinterpret_cast<u32x4 *>(cb + row * 64 + ch * 8) = z;
+            }
+        }
+        ssd_pred = wave_sum64(ssd_pred);
+        if(lane == 0) ssd_out[2 * j] = ssd_pred;
+        return;
+    }
 #pragma unroll
     for(int r = 0; r < 16; r++) {
         int lev = 0;
@@ -357,12 +374,25 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
     cnt = xh_group_sum<64>(cnt);
     __builtin_amdgcn_wave_barrier();
     // ---- f: inverse DCT of the 32x32 coefficient tile (K = 32)
-    v4i clo, chi;
     {
         const int16_t *row = T + l32 * 32 + 16 * kg;
         split16(*reinterpret_cast<const u32x4 *>(row), *reinterpret_cast<const u32x4 *>(row + 8), clo, chi);
     }
     __builtin_amdgcn_wave_barrier();
+    }
+    else { // back half: levels of row ky = l32, columns 16*kg .. +15 straight from memory (A layout), dequantised in place
+        const int16_t *row = cb + l32 * N + 16 * kg;
+        u32x4 q[2] = {*reinterpret_cast<const u32x4 *>(row), *reinterpret_cast<const u32x4 *>(row + 8)};
+#pragma unroll
+        for(int hq = 0; hq < 2; hq++)
+#pragma unroll
+            for(int k = 0; k < 4; k++) {
+                long a = ((long)xh_lo16(q[hq][k]) * P.dq_scale + P.dq_offset) >> P.dq_shift, b = ((long)xh_hi16(q[hq][k]) * P.dq_scale + P.dq_offset) >> P.dq_shift;
+                a = a < -32768 ? -32768 : (a > 32767 ? 32767 : a), b = b < -32768 ? -32768 : (b > 32767 ? 32767 : b);
+                q[hq][k] = xh_pack16((int)a, (int)b);
+            }
+        split16(q[0], q[1], clo, chi);
+    }
     long ssd_rec = 0;
 #pragma unroll
     for(int nt = 0; nt < NT; nt++) { // x tile
@@ -421,8 +451,7 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
     ssd_pred = wave_sum64(ssd_pred);
     ssd_rec  = wave_sum64(ssd_rec);
     if(lane == 0) {
-        nnz_out[j]         = cnt;
-        ssd_out[2 * j]     = ssd_pred;
+        if(P.stage == 0) nnz_out[j] = cnt, ssd_out[2 * j] = ssd_pred;
         ssd_out[2 * j + 1] = ssd_rec;
     }
 }

@@ -19,6 +19,7 @@
 struct RdoqK {
     int  n, log2n, q_value, q_bits, c, ctx_last;
     long lambda, err_scale;
+    long z_scale, z_thr; // zero pre-test of xeve_quant_nnz (xeve_tq.c:666-699); z_thr < 0: off
     xeve_hip_rdoq_est est;
 };
 
@@ -99,11 +100,13 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     int      neg[K];
     long     unc_sum = 0;
     int      sum_all = 0, F = 2; // chunk transition function, starts as identity
+    int      zhit = P.z_thr < 0 ? 1 : 0;
 #pragma unroll
     for(int i = 0; i < K; i++) {
         const int p = t * K + i;
         int v = 0;
         if(live && p < P.n) v = blk[scan[p]];
+        zhit |= ((long)(v < 0 ? -v : v) * P.z_scale) >= P.z_thr;
         const Cand c = eval_coef(v, P);
         lev0[i] = c.lev[0], lev1[i] = c.lev[1], d0[i] = c.d[0], d1[i] = c.d[1], neg[i] = c.neg;
         if(p < P.n) {
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     // block totals: sum_all, uncoded cost
 #pragma unroll
     for(int m = 1; m < 64; m <<= 1) sum_all += __shfl_xor(sum_all, m, 64), unc_sum += shfl_xor64(unc_sum, m);
-    if(lane == 0) s_int[wave][0] = sum_all, s_long[wave][0] = unc_sum;
+    zhit = __any(zhit) ? 1 : 0;
+    if(lane == 0) s_int[wave][0] = sum_all, s_long[wave][0] = unc_sum, s_int[wave][3] = zhit;
     __syncthreads();
-    sum_all = 0, unc_sum = 0;
+    sum_all = 0, unc_sum = 0, zhit = 0;
 #pragma unroll
-    for(int i = 0; i < WPB; i++) sum_all += s_int[w0 + i][0], unc_sum += s_long[w0 + i][0];
+    for(int i = 0; i < WPB; i++) sum_all += s_int[w0 + i][0], unc_sum += s_long[w0 + i][0], zhit |= s_int[w0 + i][3];
+    if(!zhit) sum_all = 0; // the pre-test found nothing codable: the block is zeroed exactly like sum_all == 0
     __syncthreads();
 
     // ---- phase 2: incoming automaton state of my chunk = (F_{t-1} o ... o F_0)(0)
@@ -238,8 +243,17 @@ static int get_scan(int log2w, int log2h, const uint16_t **out)
 
 static const int k_quant_scale[2][6] = {{26214, 23302, 20560, 18396, 16384, 14764}, {26214, 23302, 20560, 18396, 16384, 14564}}; // xeve_tq.c:37-38
 
+extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                                const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream);
+
 extern "C" int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
                              const xeve_hip_rdoq_est *est, int32_t *nnz, void *stream)
+{
+    return xeve_hip_rdoq_zt(coef, nblk, log2w, log2h, qp, lambda, is_luma, bit_depth, tool_iqt, est, 0, 0, nnz, stream);
+}
+
+extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                                const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(coef && est && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
@@ -263,6 +277,12 @@ extern "C" int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int 
         e = e / k_quant_scale[tool_iqt][qp % 6] / (1 << (bit_depth - 8));
         P.err_scale = (long)(e * (double)(1 << 20));
     }
+    if(zero_test) { // xeve_tq.c:673-683
+        const int zs = 14 + (15 - bit_depth - log2_size + (odd ? 7 : 0)) + qp / 6;
+        P.z_scale    = (long)k_quant_scale[tool_iqt][qp % 6] * (odd ? 181 : 1);
+        P.z_thr      = (1L << zs) - ((long)(is_intra_slice ? 201 : 153) << (zs - 9));
+    }
+    else P.z_scale = 0, P.z_thr = -1;
     P.est = *est;
     hipStream_t st = (hipStream_t)stream;
     const int n = P.n;

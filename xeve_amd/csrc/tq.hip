@@ -331,7 +331,11 @@ struct RdoParams { // must match dct_mfma.hip
     long z_scale, z_thr;
     long dq_scale; int dq_shift, dq_offset;
     int ssd_shift, maxv;
+    int stage; // 0: whole chain (plain quant); 1: front half, stops after the DCT and writes the coefficients + SSD(pred);
+               // 2: back half, reads quantised levels from `coef` (e.g. left there by xeve_hip_rdoq) and reconstructs
 };
+extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                                const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream);
 int xh_rdo_mfma(int n, const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, const void *params,
                 int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st);
 
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     if(t == 0) acc64[0] = acc64[1] = 0, acc32[0] = acc32[1] = 0;
     __syncthreads();
     // 1. residual + SSD(org, pred)
-    if(live) {
+    if(live && P.stage != 2) {
         unsigned long long s = 0;
         for(int i = t; i < n; i += tpb) {
             const int y = i >> log2w, x = i & (w - 1);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     }
     __syncthreads();
     // 2. forward pass 1: Tm[kx][y] = sum_x Mw[kx][x] X[y][x]
-    if(live)
+    if(live && P.stage != 2)
         for(int i = t; i < n; i += tpb) {
             const int kx = i >> log2h, y = i & (h - 1);
             int a = 0;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
         }
     __syncthreads();
     // 3. forward pass 2 + zero pre-test: X[ky][kx] = coefficient
-    if(live) {
+    if(live && P.stage != 2) {
         const int64_t add = (int64_t)1 << (P.shift_fwd - 1);
         int hit = 0;
         for(int i = t; i < n; i += tpb) {
@@ -394,25 +398,31 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
             }
             const int c = (int)(int16_t)a;
             X[i] = c;
+            if(P.stage == 1) coef[(size_t)j * n + i] = (int16_t)c;
             hit |= ((int64_t)(c < 0 ? -c : c) * P.z_scale) >= P.z_thr;
         }
         if(P.z_thr < 0) hit = 1;
         if(hit) atomicOr(&acc32[0], 1);
     }
     __syncthreads();
+    if(P.stage == 1) { // front half ends here
+        if(live && t == 0) ssd_out[2 * j] = (int64_t)acc64[0];
+        return;
+    }
     // 4. quant, levels out, dequant
     if(live) {
         const bool hit = acc32[0] != 0;
         int cnt = 0;
         for(int i = t; i < n; i += tpb) {
             int lev = 0;
-            if(hit) {
+            if(P.stage == 2) lev = coef[(size_t)j * n + i];
+            else if(hit) {
                 const int c = X[i], neg = c < 0;
                 lev = (int)(int16_t)((((neg ? -c : c) * P.q_scale) + P.q_offset) >> P.q_shift);
                 lev = (int)(int16_t)(neg ? -lev : lev);
             }
             cnt += lev != 0;
-            coef[(size_t)j * n + i] = (int16_t)lev;
+            if(P.stage == 0) coef[(size_t)j * n + i] = (int16_t)lev;
             int64_t dq = ((int64_t)lev * P.dq_scale + P.dq_offset) >> P.dq_shift;
             X[i] = (int)(dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq));
         }
@@ -448,8 +458,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     }
     __syncthreads();
     if(live && t == 0) {
-        nnz_out[j]         = acc32[1];
-        ssd_out[2 * j]     = (int64_t)acc64[0];
+        if(P.stage == 0) nnz_out[j] = acc32[1], ssd_out[2 * j] = (int64_t)acc64[0];
         ssd_out[2 * j + 1] = (int64_t)acc64[1];
     }
 }
@@ -535,8 +544,11 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
         v[x] = o[x] - p[x];
         ssd_p += (unsigned)((v[x] * v[x]) >> P.ssd_shift);
     }
+    int  t[N], c[N];
+    long c64[N];
+    int  cnt = 0;
+    if(P.stage != 2) {
     // 2. forward: rows (lane = y), transpose, columns (lane = kx)
-    int t[N];
     mat32<N, false>(v, t); // t[kx] = sum_x Mw[kx][x] d[y][x]
 #pragma unroll
     for(int k = 0; k < N; k++) T[k * PITCH + y] = t[k];
@@ -544,9 +556,7 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
 #pragma unroll
     for(int k = 0; k < N; k++) t[k] = T[y * PITCH + k]; // lane kx (= y) now holds T[kx][0..N-1]
     __builtin_amdgcn_wave_barrier();
-    long c64[N];
     mat64<N, false>(t, c64); // c[ky] = sum_yy Mh[ky][yy] T[kx][yy]
-    int  c[N];
     bool hit = P.z_thr < 0;
     const long addf = 1L << (P.shift_fwd - 1);
 #pragma unroll
@@ -557,7 +567,15 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
     // 3. zero pre-test over the block (N lanes), quant, levels out (lane kx holds column kx), dequant
     const unsigned long long blk_mask = (N == 64 ? ~0ull : ((1ull << N) - 1)) << (bl * N);
     hit = (__ballot(hit) & blk_mask) != 0;
-    int cnt = 0;
+    if(P.stage == 1) { // front half: raw coefficients out (lane kx holds column kx), SSD(pred), done
+#pragma unroll
+        for(int k = 0; k < N; k++)
+            if(live) coef[(size_t)j * N * N + k * N + y] = (int16_t)c[k];
+        for(int m = 1; m < N; m <<= 1)
+            ssd_p += ((unsigned long long)__shfl_xor((unsigned)(ssd_p >> 32), m, 64) << 32) | __shfl_xor((unsigned)ssd_p, m, 64);
+        if(live && y == 0) ssd_out[2 * j] = (int64_t)ssd_p;
+        return;
+    }
 #pragma unroll
     for(int k = 0; k < N; k++) {
         int lev = 0;
@@ -568,10 +586,19 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
         }
         cnt += lev != 0;
         if(live) coef[(size_t)j * N * N + k * N + y] = (int16_t)lev;
-        long dq = ((long)lev * P.dq_scale + P.dq_offset) >> P.dq_shift;
-        c[k]    = (int)(dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq));
+        c[k] = lev;
     }
     cnt = xh_group_sum<N>(cnt);
+    }
+    else { // back half: the levels are already in `coef`
+#pragma unroll
+        for(int k = 0; k < N; k++) c[k] = live ? coef[(size_t)j * N * N + k * N + y] : 0;
+    }
+#pragma unroll
+    for(int k = 0; k < N; k++) {
+        long dq = ((long)c[k] * P.dq_scale + P.dq_offset) >> P.dq_shift;
+        c[k]    = (int)(dq < -32768 ? -32768 : (dq > 32767 ? 32767 : dq));
+    }
     // 4. inverse: columns (lane = kx): t[yy] = sum_ky Mh[ky][yy] C[ky][kx]; transpose; rows (lane = y)
     mat32<N, true>(c, t);
 #pragma unroll
@@ -614,15 +641,14 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
         ssd_r += ((unsigned long long)__shfl_xor((unsigned)(ssd_r >> 32), m, 64) << 32) | __shfl_xor((unsigned)ssd_r, m, 64);
     }
     if(live && y == 0) {
-        nnz_out[j]         = cnt;
-        ssd_out[2 * j]     = (int64_t)ssd_p;
+        if(P.stage == 0) nnz_out[j] = cnt, ssd_out[2 * j] = (int64_t)ssd_p;
         ssd_out[2 * j + 1] = (int64_t)ssd_r;
     }
 }
 
-extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
-                                     int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
-                                     int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream)
+static int residual_launch(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h,
+                           int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test, int stage, int16_t *coef,
+                           pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st)
 {
     XH_ENTER();
     XH_REQUIRE(org && pred && jobs && coef && rec && nnz && ssd && njobs >= 0);
@@ -631,6 +657,7 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
     if(njobs == 0) return XEVE_HIP_OK;
     const int odd = (log2w + log2h) & 1, log2_size = (log2w + log2h) >> 1;
     RdoParams P;
+    P.stage     = stage;
     P.shift_fwd = (log2w - 1 + bit_depth - 8) + (log2h + 6); // xeve_util.c:34-35
     P.shift_inv = 7 + (12 - (bit_depth - 8));                // xeve_itdq.h:38-39
     P.q_scale   = qscale;
@@ -648,7 +675,6 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
     P.dq_offset = P.dq_shift == 0 ? 0 : 1 << (P.dq_shift - 1);
     P.ssd_shift = (bit_depth - 8) * 2;
     P.maxv      = (1 << bit_depth) - 1;
-    hipStream_t st = (hipStream_t)stream;
     if(g_use_mfma && log2w == log2h && log2w >= 5)
         return xh_rdo_mfma(1 << log2w, org, s_org, pred, s_pred, jobs, njobs, &P, coef, rec, s_rec, nnz, ssd, st);
     if(g_use_rows && log2w == log2h && log2w >= 2 && log2w <= 4) { // 4x4, 8x8, 16x16: row-per-lane register form
@@ -665,4 +691,29 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
     k_rdo_valu<<<(njobs + bpw - 1) / bpw, 256, lds, st>>>(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, P, coef, rec, s_rec, nnz, ssd);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
+                                     int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, int zero_test,
+                                     int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, void *stream)
+{
+    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, zero_test, 0, coef,
+                           rec, s_rec, nnz, ssd, (hipStream_t)stream);
+}
+
+// The chain as the presets actually run it (rdoq = 1, xeve_enc.c:2452,2469): front half (DIFF, SSD, DCT), then
+// xeve_quant_nnz's zero pre-test + xeve_rdoq_run_length_cc (rdoq.hip), then the back half (dequant, IDCT, recon, SSD).
+extern "C" int xeve_hip_residual_rdoq(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
+                                      int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda, int is_luma,
+                                      int tool_iqt, const xeve_hip_rdoq_est *est, int16_t *coef, pel *rec, int s_rec, int32_t *nnz,
+                                      int64_t *ssd, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 1, coef, rec,
+                             s_rec, nnz, ssd, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    rc = xeve_hip_rdoq_zt(coef, njobs, log2w, log2h, qp, lambda, is_luma, bit_depth, tool_iqt, est, 1, is_intra_slice, nnz, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 2, coef, rec,
+                           s_rec, nnz, ssd, st);
 }

@@ -230,6 +230,15 @@ def me_spel_pattern_jobs(org_plane, org_origin, s_org, org_bi, ref_plane, ref_or
     return res.cpu().numpy().view(_lib.ME_RESULT_DTYPE).reshape(-1)
 
 
+def residual_rdoq(org, s_org, pred, s_pred, jobs, log2w, log2h, bit_depth, qp, is_intra_slice, lam, is_luma, est, coef, rec, s_rec, nnz, ssd,
+                  tool_iqt=0):
+    """the residual chain with zero pre-test + RDOQ as quantiser (xeve_hip_residual_rdoq)"""
+    _lib.check(_lib.load().xeve_hip_residual_rdoq(_ptr(_i16(org)), s_org, _ptr(_i16(pred)), s_pred, _ptr(jobs), jobs.shape[0], log2w, log2h,
+                                                  bit_depth, qp, QUANT_SCALE[tool_iqt][qp % 6], DQ_SCALE[qp % 6] << (qp // 6), int(is_intra_slice),
+                                                  float(lam), int(is_luma), tool_iqt, C.byref(est), _ptr(_i16(coef)), _ptr(_i16(rec)), s_rec,
+                                                  _ptr(nnz), _ptr(ssd), _stream()))
+
+
 # quantiser scale tables of the standard (reference: src_base/xeve_tq.c:37-38, xeve_tbl.c:237)
 QUANT_SCALE = ((26214, 23302, 20560, 18396, 16384, 14764), (26214, 23302, 20560, 18396, 16384, 14564))
 DQ_SCALE = (40, 45, 51, 57, 64, 71)

@@ -82,6 +82,9 @@ FUNCTIONS = {
     "xeve_hip_quant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xeve_hip_rdoq_zero_test": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xeve_hip_rdoq": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_rdoq_zt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "xeve_hip_residual_rdoq": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, C.c_double,
+                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_dquant": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_residual_rdo": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
