@@ -17,6 +17,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -46,6 +47,7 @@ static struct {
     FN_AVG    avg;
     FN_TXB   *txb, *itxb;
     FN_RECON  recon;
+    int (*rdoq)(int16_t *, int, int, int, double, int, int, int, int, const xo_rdoq_est *); /* reference driver or NULL */
     int       is_ref;
 } T;
 
@@ -102,6 +104,14 @@ static void bind(const char *path)
     T.itxb = need(h, avx2 ? "xeve_tbl_itxb_avx" : "xeve_tbl_itxb_sse");
     T.recon = need(h, "xeve_recon_blk");
     T.is_ref = 1;
+    { /* the reference's own xeve_rdoq_run_length_cc through oracle/_ref/libref_rdoq.so (next to libxeveb_ref.so) */
+        char buf[4096];
+        snprintf(buf, sizeof(buf), "%s", path);
+        char *slash = strrchr(buf, '/');
+        snprintf(slash ? slash + 1 : buf, sizeof(buf) - (slash ? (size_t)(slash + 1 - buf) : 0), "libref_rdoq.so");
+        void *hr = dlopen(buf, RTLD_NOW | RTLD_LOCAL);
+        T.rdoq = hr ? (int (*)(int16_t *, int, int, int, double, int, int, int, int, const xo_rdoq_est *))dlsym(hr, "refdrv_rdoq") : NULL;
+    }
 }
 
 /* ---- workload (mirrors xeve_amd/workload.py) ------------------------------------------------------- */
@@ -144,13 +154,18 @@ static pel *plane(int h, int s)
 
 typedef struct { int tid, nthr; int64_t sad_calls; int64_t sink; } Arg;
 
-static void tq_chain(int16_t *coef, int lg, int64_t *sink)
+static xo_rdoq_est EST;
+static double      LAMBDA;
+
+static void tq_chain(int16_t *coef, int lg, int is_luma, int64_t *sink)
 {
     int32_t tb[64 * 64];
     const int qs = xo_quant_scale[0][QP % 6], dqs = xo_dq_scale[QP % 6] << (QP / 6);
     T.txb[lg - 1](coef, tb, 0, 1 << lg, 0);
     T.txb[lg - 1](tb, coef, (lg - 1 + BD - 8) + (lg + 6), 1 << lg, 1);
-    if(xo_rdoq_zero_test(coef, lg, lg, QP, qs, 0, BD)) *sink += xo_quant(coef, lg, lg, QP, qs, 0, BD);
+    /* xeve_quant_nnz with rdoq = 1 (preset medium): zero pre-test, then RDOQ */
+    if(xo_rdoq_zero_test(coef, lg, lg, QP, qs, 0, BD))
+        *sink += T.rdoq ? T.rdoq(coef, lg, lg, QP, LAMBDA, 0, is_luma ? 0 : 1, BD, 0, &EST) : xo_rdoq(coef, lg, lg, QP, LAMBDA, is_luma, BD, 0, &EST);
     else memset(coef, 0, sizeof(int16_t) << (2 * lg));
     xo_dquant(coef, lg, lg, dqs, BD);
     T.itxb[lg - 1](coef, tb, 0, 1 << lg, 0);
@@ -220,7 +235,7 @@ static void *worker(void *vp)
                 T.diff[l2][l2](w, w, oc, pr, st, w, w, resi, BD);
                 A->sink += T.ssd[l2][l2](w, w, oc, pr, st, w, BD);
                 memcpy(coef, resi, sizeof(int16_t) * w * w);
-                tq_chain(coef, l2, &A->sink);
+                tq_chain(coef, l2, c == 0, &A->sink);
                 T.recon(coef, pr, 1, w, w, st, rc, BD);
                 A->sink += T.ssd[l2][l2](w, w, oc, rc, st, st, BD);
             }
@@ -243,6 +258,11 @@ int main(int argc, char **argv)
     if(nthr < 1) nthr = 1;
     s_l = W + 2 * PAD_L, s_c = W / 2 + 2 * PAD_C;
     make_pattern();
+    /* same RDOQ inputs as xeve_amd/workload.py: lambda for qp 32, one-bit estimates */
+    LAMBDA = 0.57 * pow(2.0, (QP - 12) / 3.0);
+    EST.cbf[0] = EST.cbf[1] = 32768;
+    for(int i = 0; i < 24; i++) EST.run[i][0] = EST.run[i][1] = EST.level[i][0] = EST.level[i][1] = 32768;
+    for(int i = 0; i < 2; i++) EST.last[i][0] = EST.last[i][1] = 32768;
     for(int c = 0; c < 3; c++) {
         int h = c ? H / 2 + 2 * PAD_C : H + 2 * PAD_L, s = c ? s_c : s_l;
         org[c] = plane(h, s), rec[c] = plane(h, s);

@@ -11,12 +11,16 @@ typedef struct { int cbf[2]; int run[24][2], level[24][2], last[2][2]; } drv_est
 
 int refdrv_rdoq(s16 *coef, int log2w, int log2h, int qp, double lambda, int is_intra, int ch_type, int bit_depth, int tool_iqt, const drv_est *e)
 {
-    static XEVE_CTX  *ctx;
-    static XEVE_CORE *core;
+    static __thread XEVE_CTX  *ctx;  /* per thread: oracle/cpu_bench.c calls this from its worker threads */
+    static __thread XEVE_CORE *core;
+    static __thread int        last_iqt = -1, last_bd = -1;
     if(!ctx) ctx = calloc(1, sizeof(*ctx)), core = calloc(1, sizeof(*core));
-    ctx->param.tool_iqt = tool_iqt, ctx->param.codec_bit_depth = bit_depth;
-    ctx->fn_rdoq_set_ctx_cc = xeve_rdoq_set_ctx_cc;
-    xeve_init_err_scale(ctx);
+    if(last_iqt != tool_iqt || last_bd != bit_depth) {
+        ctx->param.tool_iqt = tool_iqt, ctx->param.codec_bit_depth = bit_depth;
+        ctx->fn_rdoq_set_ctx_cc = xeve_rdoq_set_ctx_cc;
+        xeve_init_err_scale(ctx);
+        last_iqt = tool_iqt, last_bd = bit_depth;
+    }
     core->ctx = ctx;
     /* the caller passes the cbf pair the reference would pick; load it into all four slots */
     for(int b = 0; b < 2; b++) core->rdoq_est_cbf_all[b] = core->rdoq_est_cbf_luma[b] = core->rdoq_est_cbf_cb[b] = core->rdoq_est_cbf_cr[b] = e->cbf[b];

@@ -67,9 +67,9 @@ __device__ __forceinline__ Cand eval_coef(int v, const RdoqK &P)
 }
 
 // ---- wave / block primitives (WPB waves of 64 lanes form one block's thread group) --------------------
-__device__ __forceinline__ long shfl_up64(long v, int d)
+__device__ __forceinline__ long shfl_up64(long v, int d, int width = 64)
 {
-    const unsigned lo = __shfl_up((unsigned)v, d, 64), hi = __shfl_up((unsigned)((unsigned long)v >> 32), d, 64);
+    const unsigned lo = __shfl_up((unsigned)v, d, width), hi = __shfl_up((unsigned)((unsigned long)v >> 32), d, width);
     return (long)(((unsigned long)hi << 32) | lo);
 }
 __device__ __forceinline__ long shfl_xor64(long v, int m)
@@ -80,19 +80,23 @@ __device__ __forceinline__ long shfl_xor64(long v, int m)
 // transition functions on {0,1}: bit s = next state from state s; identity = 0b10
 __device__ __forceinline__ int fcompose(int later, int earlier) { return ((later >> (earlier & 1)) & 1) | (((later >> ((earlier >> 1) & 1)) & 1) << 1); }
 
-template <int K, int WPB>
+// LPB = lanes per block: 64 normally; 16 for n <= 16 (4x4 chroma of an 8x8 CU), where four blocks share one wave and
+// every wave-level scan / reduction below is segmented to LPB lanes (WPB must be 1 then).
+template <int K, int WPB, int LPB = 64>
 __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nblk, RdoqK P, const uint16_t *__restrict__ scan,
                                               int32_t *__restrict__ nnz_out)
 {
-    constexpr int TPB = 64 * WPB, BPW = 4 / WPB; // threads per block, blocks per workgroup
+    static_assert(LPB == 64 || WPB == 1, "sub-wave blocks cannot span waves");
+    constexpr int SUB = 64 / LPB;                  // blocks per wave
+    constexpr int BPW = (4 / WPB) * SUB;           // blocks per workgroup
     __shared__ long s_long[4][4];                  // [wave in workgroup][slot]
     __shared__ int  s_int[4][4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bl = wave / WPB, wib = wave % WPB, t = wib * 64 + lane; // block-local thread id
+    const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63, sub = wlane / LPB, lane = wlane % LPB;
+    const int bl = (wave / WPB) * SUB + sub, wib = wave % WPB, t = wib * 64 + lane; // block-local thread id
     const int b = blockIdx.x * BPW + bl;
     const bool live = b < nblk;
     int16_t *blk = coef + (size_t)(live ? b : 0) * P.n;
-    const int w0 = bl * WPB; // first wave of my block in the s_* arrays
+    const int w0 = (wave / WPB) * WPB; // first wave of my block in the s_* arrays
 
     // ---- phase 1: candidates of my K consecutive scan positions
     unsigned lev0[K], lev1[K];
@@ -116,28 +120,29 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     }
     // block totals: sum_all, uncoded cost
 #pragma unroll
-    for(int m = 1; m < 64; m <<= 1) sum_all += __shfl_xor(sum_all, m, 64), unc_sum += shfl_xor64(unc_sum, m);
-    zhit = __any(zhit) ? 1 : 0;
-    if(lane == 0) s_int[wave][0] = sum_all, s_long[wave][0] = unc_sum, s_int[wave][3] = zhit;
-    __syncthreads();
-    sum_all = 0, unc_sum = 0, zhit = 0;
+    for(int m = 1; m < LPB; m <<= 1) sum_all += __shfl_xor(sum_all, m, 64), unc_sum += shfl_xor64(unc_sum, m), zhit |= __shfl_xor(zhit, m, 64);
+    if(LPB == 64) {
+        if(lane == 0) s_int[wave][0] = sum_all, s_long[wave][0] = unc_sum, s_int[wave][3] = zhit;
+        __syncthreads();
+        sum_all = 0, unc_sum = 0, zhit = 0;
 #pragma unroll
-    for(int i = 0; i < WPB; i++) sum_all += s_int[w0 + i][0], unc_sum += s_long[w0 + i][0], zhit |= s_int[w0 + i][3];
+        for(int i = 0; i < WPB; i++) sum_all += s_int[w0 + i][0], unc_sum += s_long[w0 + i][0], zhit |= s_int[w0 + i][3];
+    }
     if(!zhit) sum_all = 0; // the pre-test found nothing codable: the block is zeroed exactly like sum_all == 0
     __syncthreads();
 
     // ---- phase 2: incoming automaton state of my chunk = (F_{t-1} o ... o F_0)(0)
     int incl = F;
 #pragma unroll
-    for(int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int o = __shfl_up(incl, dlt, 64);
+    for(int dlt = 1; dlt < LPB; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, LPB);
         if(lane >= dlt) incl = fcompose(incl, o);
     }
-    if(lane == 63) s_int[wave][1] = incl;
+    if(LPB == 64 && lane == 63) s_int[wave][1] = incl;
     __syncthreads();
     int pre = 2; // functions of the earlier waves of my block
     for(int i = 0; i < wib; i++) pre = fcompose(s_int[w0 + i][1], pre);
-    int excl = __shfl_up(incl, 1, 64);
+    int excl = __shfl_up(incl, 1, LPB);
     if(lane == 0) excl = 2;
     const int state_in = fcompose(excl, pre) & 1; // applied to the initial state 0 (run = 0)
     __syncthreads();
@@ -160,11 +165,11 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     }
     long incl_sum = chunk;
 #pragma unroll
-    for(int dlt = 1; dlt < 64; dlt <<= 1) {
-        const long o = shfl_up64(incl_sum, dlt);
+    for(int dlt = 1; dlt < LPB; dlt <<= 1) {
+        const long o = shfl_up64(incl_sum, dlt, LPB);
         if(lane >= dlt) incl_sum += o;
     }
-    if(lane == 63) s_long[wave][1] = incl_sum;
+    if(LPB == 64 && lane == 63) s_long[wave][1] = incl_sum;
     __syncthreads();
     long base = unc_sum + (long)P.est.cbf[1] * P.lambda + (incl_sum - chunk); // d64_base_cost before my chunk
     for(int i = 0; i < wib; i++) base += s_long[w0 + i][1];
@@ -180,17 +185,19 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
         base += inc[i];
     }
 #pragma unroll
-    for(int m = 1; m < 64; m <<= 1) {
+    for(int m = 1; m < LPB; m <<= 1) {
         const long oc = shfl_xor64(best_cost, m);
         const int  op = __shfl_xor(best_pos, m, 64);
         if(oc < best_cost || (oc == best_cost && op < best_pos)) best_cost = oc, best_pos = op;
     }
     __syncthreads();
-    if(lane == 0) s_long[wave][2] = best_cost, s_int[wave][2] = best_pos;
-    __syncthreads();
-    best_cost = s_long[w0][2], best_pos = s_int[w0][2];
-    for(int i = 1; i < WPB; i++)
-        if(s_long[w0 + i][2] < best_cost || (s_long[w0 + i][2] == best_cost && s_int[w0 + i][2] < best_pos)) best_cost = s_long[w0 + i][2], best_pos = s_int[w0 + i][2];
+    if(LPB == 64) {
+        if(lane == 0) s_long[wave][2] = best_cost, s_int[wave][2] = best_pos;
+        __syncthreads();
+        best_cost = s_long[w0][2], best_pos = s_int[w0][2];
+        for(int i = 1; i < WPB; i++)
+            if(s_long[w0 + i][2] < best_cost || (s_long[w0 + i][2] == best_cost && s_int[w0 + i][2] < best_pos)) best_cost = s_long[w0 + i][2], best_pos = s_int[w0 + i][2];
+    }
     const long best0 = unc_sum + (long)P.est.cbf[0] * P.lambda; // d64_best_cost: "code nothing"
     const int best_last = (sum_all != 0 && best_cost < best0) ? best_pos + 1 : 0;
 
@@ -206,14 +213,17 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
         }
     }
 #pragma unroll
-    for(int m = 1; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
-    if(lane == 0) s_int[wave][3] = cnt;
-    __syncthreads();
-    if(live && t == 0) {
-        int tot = 0;
-        for(int i = 0; i < WPB; i++) tot += s_int[w0 + i][3];
-        nnz_out[b] = tot;
+    for(int m = 1; m < LPB; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
+    if(LPB == 64) {
+        if(lane == 0) s_int[wave][3] = cnt;
+        __syncthreads();
+        if(live && t == 0) {
+            int tot = 0;
+            for(int i = 0; i < WPB; i++) tot += s_int[w0 + i][3];
+            nnz_out[b] = tot;
+        }
     }
+    else if(live && lane == 0) nnz_out[b] = cnt;
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
@@ -286,7 +296,8 @@ extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, i
     P.est = *est;
     hipStream_t st = (hipStream_t)stream;
     const int n = P.n;
-    if(n <= 64) k_rdoq<1, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    if(n <= 16) k_rdoq<1, 1, 16><<<(nblk + 15) / 16, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n <= 64) k_rdoq<1, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
     else if(n == 128) k_rdoq<2, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
     else if(n == 256) k_rdoq<1, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
     else if(n == 512) k_rdoq<2, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);

@@ -32,6 +32,7 @@ HALF_PEL = ((-8, 0), (-8, 8), (0, 8), (8, 8))  # 1/16-pel offsets of the 4 mediu
 N_MERGE = 3
 import os
 SORT_JOBS = os.environ.get("XEVE_SORT_JOBS", "1") == "1"
+USE_RDOQ = os.environ.get("XEVE_RDOQ", "1") == "1"  # developer switch: 0 = plain quantiser in phase D
 MV_RANGE = 48  # integer-pel; keeps centre +- 64 diamond inside the 144-pel padding
 
 
@@ -64,6 +65,18 @@ class HotPathPass:
         # alignment copies of the luma reference planes (xeve_hip_sad_jobs_dual): made once per reference picture
         self.ref_s1 = [D.plane_shift1(r[0]) for r in self.ref]
         self.pattern = diamond_pattern()
+        # RDOQ inputs: lambda of the reference for this qp (xeve_enc.c: lambda = 0.57 * 2^((qp - 12) / 3)) and bit estimates of
+        # equiprobable context models (entropy_bits of state 256, xeve_mode.c:304-325) -- the values a fresh CABAC state gives
+        self.lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+        from .lib import RdoqEst
+        e = RdoqEst()
+        eq = 32768  # -32768 * (log2(256.5 / 512) - 9 + 9) ~ one bit
+        e.cbf[0] = e.cbf[1] = eq
+        for i in range(24):
+            e.run[i][0] = e.run[i][1] = e.level[i][0] = e.level[i][1] = eq
+        for i in range(2):
+            e.last[i][0] = e.last[i][1] = eq
+        self.rdoq_est = e
         self.cand_l = torch.tensor([dy * self.s_l + dx for dx, dy in self.pattern], dtype=torch.int32, device=device)
         self.zero_cand = torch.zeros(1, dtype=torch.int32, device=device)
         rng = np.random.default_rng(seed)
@@ -181,9 +194,15 @@ class HotPathPass:
             for c in (range(3) if only in (None, "D", "D2") else ()):
                 w, lg, st = (S, l2, s_l) if c == 0 else (Sc, l2c, s_c)
                 pred = lv["pred_l"][0] if c == 0 else lv["pred_c"][c - 1]
-                # DIFF, SSD(pred), DCT, zero pre-test, quant, dequant, IDCT, recon, SSD(rec): one fused launch
-                D.residual_rdo(org[c], st, pred, w, lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"], lg, lg, bd, qp, False, True,
-                               lv["coef"][c], lv["rec"][c], st, lv["nnz"][c], lv["ssd2"][c])
+                dj = lv["dense_jobs"] if c == 0 else lv["dense_jobs_c"]
+                if USE_RDOQ:
+                    # the chain as preset medium configures it (rdoq = 1, xeve_enc.c:2469): DIFF, SSD, DCT | zero pre-test +
+                    # RDOQ (parallel scan) | dequant, IDCT, recon, SSD
+                    D.residual_rdoq(org[c], st, pred, w, dj, lg, lg, bd, qp, False, self.lam, c == 0, self.rdoq_est, lv["coef"][c], lv["rec"][c], st,
+                                    lv["nnz"][c], lv["ssd2"][c])
+                else:
+                    # plain quantiser (rdoq = 0): the whole chain in one fused launch
+                    D.residual_rdo(org[c], st, pred, w, dj, lg, lg, bd, qp, False, True, lv["coef"][c], lv["rec"][c], st, lv["nnz"][c], lv["ssd2"][c])
             # E. intra gate
             if only in (None, "E"):
                 D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
