@@ -693,3 +693,240 @@ int xo_rdoq(int16_t *coef, int log2w, int log2h, int qp, double d_lambda, int is
     free(scan), free(ld), free(mx), free(out);
     return nnz;
 }
+
+/* ===================================================================================================================
+ * CABAC (SBAC) bit counting -- reference: src_base/xeve_eco.c, src_base/xeve_mode.c
+ * =================================================================================================================== */
+void xo_sbac_reset(xo_sbac *s)
+{   /* xeve_eco.c:597-620 */
+    memset(s, 0, sizeof(*s));
+    s->range = 16384, s->code_bits = 11;
+    for(int i = 0; i < XO_SBAC_NCTX; i++) s->ctx[i] = 512;
+}
+
+void xo_sbac_bit_reset(xo_sbac *s)
+{   /* xeve_mode.c:39-49 */
+    s->code &= 0x7FFFF;
+    s->code_bits = 11;
+    s->pending_byte = s->is_pending_byte = s->stacked_ff = s->stacked_zero = s->bitcounter = s->bin_counter = 0;
+}
+
+uint32_t xo_sbac_bits(const xo_sbac *s)
+{   /* xeve_mode.c:51-55 */
+    return s->bitcounter + 8 * (s->stacked_zero + s->stacked_ff) + 8 * (s->is_pending_byte ? 1 : 0) + 8 - s->code_bits + 3;
+}
+
+/* sbac_put_byte with is_bitcount set (xeve_eco.c:397-427): written bytes only advance bitcounter (xeve_bsw_write_est, :392) */
+static void sbac_byte(xo_sbac *s, uint8_t b)
+{
+    if(s->is_pending_byte) {
+        if(s->pending_byte == 0) s->stacked_zero++;
+        else {
+            s->bitcounter += 8 * s->stacked_zero + 8;
+            s->stacked_zero = 0;
+        }
+    }
+    s->pending_byte = b, s->is_pending_byte = 1;
+}
+
+/* sbac_carry_propagate (xeve_eco.c:429-453) */
+static void sbac_carry(xo_sbac *s)
+{
+    uint32_t out = s->code >> 17;
+    s->code &= (1u << 17) - 1;
+    if(out < 0xFF) {
+        for(; s->stacked_ff; s->stacked_ff--) sbac_byte(s, 0xFF);
+        sbac_byte(s, (uint8_t)out);
+    }
+    else if(out > 0xFF) {
+        s->pending_byte++;
+        for(; s->stacked_ff; s->stacked_ff--) sbac_byte(s, 0x00);
+        sbac_byte(s, (uint8_t)(out & 0xFF));
+    }
+    else s->stacked_ff++;
+}
+
+static void sbac_shift(xo_sbac *s)
+{
+    s->code <<= 1;
+    if(--s->code_bits == 0) {
+        sbac_carry(s);
+        s->code_bits = 8;
+    }
+}
+
+void xo_sbac_bin_ep(xo_sbac *s, uint32_t bin)
+{   /* xeve_eco.c:455-472 -- note the range loses its LSB */
+    s->bin_counter++;
+    s->range >>= 1;
+    if(bin) s->code += s->range;
+    s->range <<= 1;
+    sbac_shift(s);
+}
+
+void xo_sbac_bin(xo_sbac *s, int ci, uint32_t bin)
+{   /* xeve_eco.c:521-575 */
+    uint16_t state = s->ctx[ci] >> 1, mps = s->ctx[ci] & 1;
+    uint32_t lps = ((uint32_t)state * s->range) >> 9;
+    if(lps < 437) lps = 437;
+    s->bin_counter++;
+    s->range -= lps;
+    if(bin != mps) {
+        if(s->range >= lps) {
+            s->code += s->range;
+            s->range = lps;
+        }
+        state = state + ((512 - state + 16) >> 5);
+        if(state > 256) mps = 1 - mps, state = 512 - state;
+    }
+    else state = state - ((state + 16) >> 5);
+    s->ctx[ci] = (uint16_t)((state << 1) + mps);
+    while(s->range < 8192) {
+        s->range <<= 1;
+        sbac_shift(s);
+    }
+}
+
+/* sbac_write_unary_sym (xeve_eco.c:474-490) with num_ctx = 2 */
+static void sbac_unary2(xo_sbac *s, uint32_t sym, int ci)
+{
+    xo_sbac_bin(s, ci, sym ? 1 : 0);
+    while(sym) {
+        sym--;
+        xo_sbac_bin(s, ci + 1, sym ? 1 : 0);
+    }
+}
+
+void xo_eco_run_length_cc(xo_sbac *s, const int16_t *coef, int log2w, int log2h, int num_sig, int ch, int cm_init)
+{   /* xeve_eco.c:707-771 */
+    uint16_t scan[64 * 64];
+    uint32_t n = 1u << (log2w + log2h), run = 0, prev_level = 6;
+    xo_zigzag(log2w, log2h, scan);
+    for(uint32_t pos = 0; pos < n; pos++) {
+        int c = coef[scan[pos]];
+        if(!c) {
+            run++;
+            continue;
+        }
+        uint32_t level = (uint32_t)(c < 0 ? -c : c) & 0xFFFF; /* XEVE_ABS16 */
+        uint32_t pl = prev_level - 1 < 5 ? prev_level - 1 : 5;
+        int t0 = cm_init == 1 ? (int)(pl << 1) + (ch ? 12 : 0) : (ch ? 2 : 0);
+        sbac_unary2(s, run, XO_CTX_RUN + t0);
+        sbac_unary2(s, level - 1, XO_CTX_LEVEL + t0);
+        xo_sbac_bin_ep(s, c < 0);
+        if(pos == n - 1) break;
+        run = 0, prev_level = level, num_sig--;
+        xo_sbac_bin(s, XO_CTX_LAST + (ch ? 1 : 0), num_sig == 0);
+        if(num_sig == 0) break;
+    }
+}
+
+/* xeve_eco_abs_mvd + sign (xeve_eco.c:1205-1270) */
+static void sbac_mvd1(xo_sbac *s, int v)
+{
+    uint32_t a = (uint32_t)(v < 0 ? -v : v), nn = (a + 1) >> 1;
+    int len = 0;
+    for(; len < 16 && nn; len++) nn >>= 1;
+    uint32_t code = (1u << len) | ((a + 1 - (1u << len)) & ((1u << len) - 1));
+    int nbin = 2 * len + 1;
+    for(int i = 0; i < nbin; i++) {
+        uint32_t b = (code >> (nbin - 1 - i)) & 1;
+        if(i <= 1) xo_sbac_bin(s, XO_CTX_MVD, b);
+        else xo_sbac_bin_ep(s, b);
+    }
+    if(a) xo_sbac_bin_ep(s, v < 0);
+}
+
+/* xeve_eco_mvp_idx = sbac_write_truncate_unary_sym(idx, 3, 4) (xeve_eco.c:492-511, 1190-1203) */
+static void sbac_mvp_idx(xo_sbac *s, int idx)
+{
+    for(int i = 0; i < 3; i++) {
+        int sym = i == idx ? 0 : 1;
+        xo_sbac_bin(s, XO_CTX_MVP_IDX + i, sym);
+        if(!sym) break;
+    }
+}
+
+/* xeve_eco_refi (xeve_eco.c:1158-1188) */
+static void sbac_refi(xo_sbac *s, int num_refp, int refi)
+{
+    if(num_refp <= 1) return;
+    if(refi == 0) {
+        xo_sbac_bin(s, XO_CTX_REFI, 0);
+        return;
+    }
+    xo_sbac_bin(s, XO_CTX_REFI, 1);
+    for(int i = 2; i < num_refp; i++) {
+        int bin = i == refi + 1 ? 0 : 1;
+        if(i == 2) xo_sbac_bin(s, XO_CTX_REFI + 1, bin);
+        else xo_sbac_bin_ep(s, bin);
+        if(!bin) break;
+    }
+}
+
+/* xeve_eco_coef -> xeve_eco_coefficient (xeve_eco.c:925-1089) for MODE_INTER, one transform block per component,
+ * no delta QP, b_no_cbf 0; run[] = the components this call covers */
+static void sbac_coef_inter(xo_sbac *s, const xo_cu_bits_params *p, const xo_cu_bits_job *j, const int16_t *coef, const int run[3])
+{
+    int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1;
+    int cbf[3] = {!!j->nnz[0], !!j->nnz[1], !!j->nnz[2]}, cbf_all = 0;
+    for(int c = 0; c < 3; c++) cbf_all += run[c] && cbf[c];
+    /* xeve_eco_cbf (xeve_eco.c:793-894), inter branch, sub_pos 0, is_sub 0 */
+    if(run[0] + run[1] + run[2] == 3) {
+        xo_sbac_bin(s, XO_CTX_CBF_ALL, cbf_all != 0);
+        if(!cbf_all) return;
+    }
+    if(run[1] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CB, cbf[1]);
+    if(run[2] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CR, cbf[2]);
+    if(run[0] && cbf[1] + cbf[2] != 0) xo_sbac_bin(s, XO_CTX_CBF_LUMA, cbf[0]);
+    for(int c = 0; c < 3; c++)
+        if(j->nnz[c] && run[c])
+            xo_eco_run_length_cc(s, coef + j->coef_off[c], p->log2_cuw - (c ? ws : 0), p->log2_cuh - (c ? hs : 0), j->nnz[c], c != 0, p->cm_init);
+}
+
+uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p, const xo_cu_bits_job *j, const int16_t *coef)
+{
+    xo_sbac s = in[j->sbac];
+    xo_sbac_bit_reset(&s);
+    if(j->mode == XO_BITS_CU_SKIP) { /* xeve_mode.c:276-295 */
+        if(p->slice_type != 2) {
+            xo_sbac_bin(&s, XO_CTX_SKIP_FLAG + j->ctx_skip, 1);
+            sbac_mvp_idx(&s, j->mvp_idx[0]);
+            if(p->slice_type == 0) sbac_mvp_idx(&s, j->mvp_idx[1]);
+        }
+    }
+    else if(j->mode == XO_BITS_CU_INTER) { /* xeve_mode.c:201-274 */
+        static const int run_all[3] = {1, 1, 1};
+        if(p->slice_type != 2) {
+            xo_sbac_bin(&s, XO_CTX_SKIP_FLAG + j->ctx_skip, 0);
+            xo_sbac_bin(&s, XO_CTX_PRED_MODE + j->ctx_pred_mode, 0); /* xeve_eco_pred_mode(MODE_INTER) */
+            xo_sbac_bin(&s, XO_CTX_DIRECT, j->dir_flag);
+            if(!j->dir_flag) {
+                /* xeve_eco_inter_pred_idc (xeve_eco.c:1123-1156); check_bi_applicability == slice B without admvp */
+                int v0 = j->refi[0] >= 0, v1 = j->refi[1] >= 0;
+                if(v0 && v1) xo_sbac_bin(&s, XO_CTX_INTER_DIR, 0);
+                else {
+                    if(p->slice_type == 0) xo_sbac_bin(&s, XO_CTX_INTER_DIR, 1);
+                    xo_sbac_bin(&s, XO_CTX_INTER_DIR + 1, v0 ? 0 : 1);
+                }
+                if(v0) {
+                    sbac_refi(&s, p->num_refp[0], j->refi[0]);
+                    sbac_mvp_idx(&s, j->mvp_idx[0]);
+                    sbac_mvd1(&s, j->mvd[0][0]), sbac_mvd1(&s, j->mvd[0][1]);
+                }
+                if(p->slice_type == 0 && v1) {
+                    sbac_refi(&s, p->num_refp[1], j->refi[1]);
+                    sbac_mvp_idx(&s, j->mvp_idx[1]);
+                    sbac_mvd1(&s, j->mvd[1][0]), sbac_mvd1(&s, j->mvd[1][1]);
+                }
+            }
+        }
+        sbac_coef_inter(&s, p, j, coef, run_all);
+    }
+    else { /* xeve_mode.c:177-199: one component, RUN_L / RUN_CB / RUN_CR */
+        int run[3] = {j->mode == XO_BITS_COMP_Y, j->mode == XO_BITS_COMP_U, j->mode == XO_BITS_COMP_V};
+        sbac_coef_inter(&s, p, j, coef, run);
+    }
+    if(out) *out = s;
+    return xo_sbac_bits(&s);
+}

@@ -151,6 +151,63 @@ typedef struct xo_epzs_params {
 uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
                     int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p);
 
+/* ---- CABAC (SBAC) bit counting for the inter RDO (reference: src_base/xeve_eco.c, xeve_mode.c) -- */
+/* The fields of XEVE_SBAC (xeve_type.h:527-540) plus the context models of XEVE_SBAC_CTX (xeve_def.h:736-790) that the
+ * inter-CU syntax touches, in the order below (ctx[XO_CTX_x + i] = sbac->ctx.x[i]). */
+enum {
+    XO_CTX_SKIP_FLAG = 0,  /* [2]  */
+    XO_CTX_PRED_MODE = 2,  /* [3]  */
+    XO_CTX_DIRECT    = 5,  /* [1]  direct_mode_flag */
+    XO_CTX_INTER_DIR = 6,  /* [2]  */
+    XO_CTX_REFI      = 8,  /* [2]  */
+    XO_CTX_MVP_IDX   = 10, /* [3]  */
+    XO_CTX_MVD       = 13, /* [1]  */
+    XO_CTX_CBF_ALL   = 14, XO_CTX_CBF_LUMA = 15, XO_CTX_CBF_CB = 16, XO_CTX_CBF_CR = 17,
+    XO_CTX_RUN       = 18, /* [24] */
+    XO_CTX_LAST      = 42, /* [2]  */
+    XO_CTX_LEVEL     = 44, /* [24] */
+    XO_SBAC_NCTX     = 68
+};
+typedef struct xo_sbac {
+    uint32_t range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter;
+    uint16_t ctx[XO_SBAC_NCTX];
+} xo_sbac;
+/* xeve_sbac_reset (xeve_eco.c:597-620): every model = PROB_INIT */
+void     xo_sbac_reset(xo_sbac *s);
+/* xeve_sbac_bit_reset / xeve_get_bit_number (xeve_mode.c:39-55) */
+void     xo_sbac_bit_reset(xo_sbac *s);
+uint32_t xo_sbac_bits(const xo_sbac *s);
+/* xeve_sbac_encode_bin (xeve_eco.c:521-575) / sbac_encode_bin_ep (:455-472) in bit-count mode (is_bitcount = 1) */
+void     xo_sbac_bin(xo_sbac *s, int ctx, uint32_t bin);
+void     xo_sbac_bin_ep(xo_sbac *s, uint32_t bin);
+/* xeve_eco_run_length_cc (xeve_eco.c:707-771); ch = 0 luma / 1 chroma; cm_init = sbac->ctx.sps_cm_init_flag */
+void     xo_eco_run_length_cc(xo_sbac *s, const int16_t *coef, int log2w, int log2h, int num_sig, int ch, int cm_init);
+
+typedef struct xo_cu_bits_params {
+    int32_t log2_cuw, log2_cuh;
+    int32_t slice_type;          /* XEVE_ST_B 0 / XEVE_ST_P 1 / XEVE_ST_I 2 (inc/xeve.h:170-172)           */
+    int32_t num_refp[2];         /* ctx->rpm.num_refp                                                     */
+    int32_t cm_init;             /* sps_cm_init_flag (0 in Baseline)                                      */
+    int32_t chroma_format_idc;   /* 0 = 4:0:0 ... 3 = 4:4:4; w/h shift as XEVE_GET_CHROMA_{W,H}_SHIFT     */
+} xo_cu_bits_params;
+enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4 };
+typedef struct xo_cu_bits_job {
+    int32_t coef_off[3];   /* element offsets of the dense Y / U / V coefficient blocks            */
+    int32_t nnz[3];        /* core->nnz_sub[c][0] (0 = cbf 0, the block is not coded)              */
+    int32_t sbac;          /* index of the entry state                                             */
+    int16_t mvd[2][2];
+    int8_t  refi[2];
+    uint8_t mvp_idx[2];
+    uint8_t mode;          /* XO_BITS_*                                                            */
+    uint8_t dir_flag;      /* pidx == PRED_DIR (direct mode: no inter_pred_idc / refi / mvp / mvd) */
+    uint8_t ctx_skip, ctx_pred_mode; /* core->ctx_flags[CNID_SKIP_FLAG], [CNID_PRED_MODE]          */
+} xo_cu_bits_job;
+/* SBAC_LOAD + xeve_sbac_bit_reset + { xeve_rdo_bit_cnt_cu_inter (xeve_mode.c:201-274) | xeve_rdo_bit_cnt_cu_inter_comp
+ * (:177-199) | xeve_rdo_bit_cnt_cu_skip (:276-295) } + xeve_get_bit_number, as pinter_residue_rdo strings them together
+ * (xeve_pinter.c:1112-1131 ...); Baseline tool set (tool_admvp 0, no delta QP, CU <= 64x64 so one transform block per
+ * component).  *out = the state SBAC_STORE would keep. */
+uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p, const xo_cu_bits_job *job, const int16_t *coef);
+
 #ifdef __cplusplus
 }
 #endif

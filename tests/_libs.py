@@ -299,3 +299,55 @@ def oracle_rdoq():
     L.xo_rdoq.restype = c_int
     L.xo_rdoq.argtypes = [c_void_p, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, C.POINTER(RdoqEst)]
     return L
+
+
+# ---- CABAC (SBAC) bit counting ------------------------------------------------------------------------------------
+SBAC_NCTX = 68
+SBAC_DTYPE = np.dtype([("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"),
+                       ("pending_byte", "<u4"), ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"),
+                       ("ctx", "<u2", (SBAC_NCTX,))])
+CU_BITS_JOB_DTYPE = np.dtype([("coef_off", "<i4", (3,)), ("nnz", "<i4", (3,)), ("sbac", "<i4"), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)),
+                              ("mvp_idx", "u1", (2,)), ("mode", "u1"), ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1")])
+assert SBAC_DTYPE.itemsize == 172 and CU_BITS_JOB_DTYPE.itemsize == 44
+
+
+class CuBitsParams(C.Structure):
+    _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("slice_type", C.c_int32), ("num_refp", C.c_int32 * 2),
+                ("cm_init", C.c_int32), ("chroma_format_idc", C.c_int32)]
+
+
+REF_SBAC_SO = os.path.join(ORACLE_DIR, "_ref", "libref_sbac.so")
+_ref_sbac = None
+
+
+def ref_sbac():
+    global _ref_sbac
+    if _ref_sbac is None and os.path.exists(REF_SBAC_SO):
+        L = C.CDLL(REF_SBAC_SO)
+        L.refdrv_cu_bits.restype = C.c_uint32
+        L.refdrv_cu_bits.argtypes = [c_void_p, c_void_p, C.POINTER(CuBitsParams), c_void_p, c_void_p]
+        L.refdrv_sbac_bin.restype = None
+        L.refdrv_sbac_bin.argtypes = [c_void_p, c_int, C.c_uint32, c_int]
+        L.refdrv_run_length_cc.restype = None
+        L.refdrv_run_length_cc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+        _ref_sbac = L
+    return _ref_sbac
+
+
+def oracle_sbac():
+    L = oracle()
+    L.xo_sbac_reset.restype = None
+    L.xo_sbac_reset.argtypes = [c_void_p]
+    L.xo_sbac_bit_reset.restype = None
+    L.xo_sbac_bit_reset.argtypes = [c_void_p]
+    L.xo_sbac_bits.restype = C.c_uint32
+    L.xo_sbac_bits.argtypes = [c_void_p]
+    L.xo_sbac_bin.restype = None
+    L.xo_sbac_bin.argtypes = [c_void_p, c_int, C.c_uint32]
+    L.xo_sbac_bin_ep.restype = None
+    L.xo_sbac_bin_ep.argtypes = [c_void_p, C.c_uint32]
+    L.xo_eco_run_length_cc.restype = None
+    L.xo_eco_run_length_cc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+    L.xo_cu_bits.restype = C.c_uint32
+    L.xo_cu_bits.argtypes = [c_void_p, c_void_p, C.POINTER(CuBitsParams), c_void_p, c_void_p]
+    return L

@@ -1,0 +1,73 @@
+"""Pins the oracle's CABAC restatement (xo_sbac_*, xo_eco_run_length_cc, xo_cu_bits) against the UNMODIFIED reference
+(oracle/_ref/libref_sbac.so wraps xeve_sbac_encode_bin, xeve_eco_run_length_cc, xeve_rdo_bit_cnt_cu_inter/_comp/_skip)."""
+import numpy as np
+import pytest
+
+from _libs import SBAC_DTYPE, oracle_sbac, ptr, ref_sbac
+from _sbac_cases import clamp_refi, make_jobs, make_levels, make_params, make_states
+
+pytestmark = pytest.mark.skipif(ref_sbac() is None, reason="oracle/_ref not built (no /root/reference here)")
+
+
+def same(a, b):
+    for f in SBAC_DTYPE.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_bins_random_walk():
+    """long random bin sequences: every field of the coder state after each bin"""
+    O, R = oracle_sbac(), ref_sbac()
+    r = np.random.default_rng(11)
+    for trial in range(6):
+        a = make_states(r, 2)[1:2].copy()
+        a["code_bits"], a["stacked_ff"], a["bitcounter"] = 11, 0, 0
+        b = a.copy()
+        for k in range(4000):
+            ci, ep = int(r.integers(0, 68)), int(r.random() < 0.25)
+            bias = 0.08 if trial % 2 else 0.5  # skewed sources drive the models into their corners
+            bit = int(r.random() < bias)
+            if ep:
+                O.xo_sbac_bin_ep(ptr(a), bit)
+            else:
+                O.xo_sbac_bin(ptr(a), ci, bit)
+            R.refdrv_sbac_bin(ptr(b), ci, bit, ep)
+            same(a, b)
+        assert O.xo_sbac_bits(ptr(a)) > 0
+
+
+@pytest.mark.parametrize("cm_init", [0, 1])
+def test_run_length_cc(cm_init):
+    O, R = oracle_sbac(), ref_sbac()
+    r = np.random.default_rng(12 + cm_init)
+    for lw in range(1, 7):
+        for lh in range(1, 7):
+            for kind in range(5):
+                c = make_levels(r, 1 << (lw + lh), kind)
+                nnz = int(np.count_nonzero(c))
+                for num_sig in {nnz, max(1, nnz - 1), nnz + 3}:
+                    a = make_states(r, 2)[1:2].copy()
+                    O.xo_sbac_bit_reset(ptr(a))
+                    b = a.copy()
+                    ch = int(r.integers(0, 2))
+                    O.xo_eco_run_length_cc(ptr(a), ptr(c), lw, lh, num_sig, ch, cm_init)
+                    R.refdrv_run_length_cc(ptr(b), ptr(c), lw, lh, num_sig, ch, cm_init)
+                    same(a, b)
+
+
+@pytest.mark.parametrize("slice_type,num_refp,cm_init,idc", [(0, (2, 2), 0, 1), (1, (1, 0), 0, 1), (0, (4, 3), 0, 1), (0, (3, 1), 1, 1),
+                                                             (2, (0, 0), 0, 1), (0, (2, 2), 0, 0), (0, (2, 2), 0, 2), (0, (2, 2), 0, 3)])
+def test_cu_bits(slice_type, num_refp, cm_init, idc):
+    O, R = oracle_sbac(), ref_sbac()
+    r = np.random.default_rng(13 + slice_type + 10 * cm_init + 100 * idc)
+    states = make_states(r, 8)
+    for lw in range(2, 7):
+        for lh in range(2, 7):
+            p = make_params(lw, lh, slice_type, num_refp, cm_init, idc)
+            jobs, coef = make_jobs(r, 10, lw, lh, len(states), idc, nnz_mode=(lw + lh) & 1)
+            clamp_refi(jobs, num_refp)
+            for i in range(len(jobs)):
+                a, b = np.zeros(1, SBAC_DTYPE), np.zeros(1, SBAC_DTYPE)
+                ba = O.xo_cu_bits(ptr(states), ptr(a), p, ptr(jobs[i:i + 1]), ptr(coef))
+                bb = R.refdrv_cu_bits(ptr(states), ptr(b), p, ptr(jobs[i:i + 1]), ptr(coef))
+                assert ba == bb, (lw, lh, i, jobs[i])
+                same(a, b)

@@ -217,14 +217,6 @@ int xh_dct_mfma(bool fwd, int16_t *coef, int nblk, int n, int shift, hipStream_t
 //   coefficient corner] -> IDCT (MFMA, K = 32 only: a 64-point forward transform leaves nothing outside the corner)
 //   -> [LDS transpose back to row layout] -> recon + SSD(rec).
 // ======================================================================================================
-struct RdoParams {
-    int shift_fwd, shift_inv;               // transform rounding shifts
-    int q_scale, q_shift, q_offset;         // plain quant (xeve_tq.c:704-727)
-    long z_scale, z_thr;                    // RDOQ zero pre-test (xeve_tq.c:666-699); z_thr < 0 disables it
-    long dq_scale; int dq_shift, dq_offset; // dequant (xeve_itdq.c:442-475)
-    int ssd_shift, maxv;
-    int stage; // 0 whole chain, 1 front half (DCT coefficients + SSD(pred) out), 2 back half (levels in); see tq.hip
-};
 
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
 {

@@ -325,15 +325,6 @@ extern "C" int xeve_hip_recon(const int16_t *coef, const pel *pred, const uint8_
 // holds 256/n blocks (n = w*h <= 256) or one block; every step of pinter_residue_rdo's arithmetic core runs
 // on the block while it sits in LDS.  32x32 / 64x64 go to the matrix-core form in dct_mfma.hip instead.
 // =========================================================================================================
-struct RdoParams { // must match dct_mfma.hip
-    int shift_fwd, shift_inv;
-    int q_scale, q_shift, q_offset;
-    long z_scale, z_thr;
-    long dq_scale; int dq_shift, dq_offset;
-    int ssd_shift, maxv;
-    int stage; // 0: whole chain (plain quant); 1: front half, stops after the DCT and writes the coefficients + SSD(pred);
-               // 2: back half, reads quantised levels from `coef` (e.g. left there by xeve_hip_rdoq) and reconstructs
-};
 extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
                                 const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream);
 int xh_rdo_mfma(int n, const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, const void *params,

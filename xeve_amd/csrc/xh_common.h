@@ -37,6 +37,18 @@ bool xh_ready();
         }                                                            \
     } while(0)
 
+// parameters of the fused residual chain (tq.hip: k_rdo_valu / k_rdo_rows, dct_mfma.hip: k_rdo_mfma)
+struct RdoParams {
+    int  shift_fwd, shift_inv;        // transform rounding shifts (xeve_util.c:34-35, xeve_itdq.h:38-39)
+    int  q_scale, q_shift, q_offset;  // plain quant (xeve_tq.c:704-727)
+    long z_scale, z_thr;              // RDOQ zero pre-test (xeve_tq.c:666-699); z_thr < 0 disables it
+    long dq_scale;                    // dequant (xeve_itdq.c:442-475)
+    int  dq_shift, dq_offset;
+    int  ssd_shift, maxv;
+    int  stage; // 0: whole chain (plain quant); 1: front half, stops after the DCT and writes the coefficients + SSD(pred);
+                // 2: back half, reads quantised levels from `coef` (e.g. left there by xeve_hip_rdoq) and reconstructs
+};
+
 static inline int xh_ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
 static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
