@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rate", action="store_true", help="skip the (untimed) CABAC rate-term measurement")
     a = ap.parse_args()
 
     import torch
@@ -129,6 +130,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    rate_term = None
+    if rank == 0 and not a.no_rate:
+        # the rate term of the same RDO (CABAC bit counts of the CUs phase D quantised; xeve_amd/workload.py phase F), measured
+        # on its own AFTER the timed region: an arithmetic coder's cost is set by the data, and i.i.d. synthetic pictures
+        # quantise to ~100x the bins of real video, so folding it into `value` would measure the synthetic data, not the path
+        wl.rate()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        bits = wl.rate()
+        e1.record()
+        torch.cuda.synchronize()
+        rate_term = {"ms_per_picture": round(e0.elapsed_time(e1), 3), "jobs_per_picture": int(sum(b.numel() for b in bits.values())),
+                     "coded_bits_per_picture": int(sum(int(b[:, 1].sum().item()) for b in bits.values())),
+                     "in_timed_region": False,
+                     "note": "xeve_hip_cu_bits_jobs over every CU of all four levels, 8 bit-count jobs per CU as pinter_residue_rdo issues them"}
     if rank == 0:
         sad_ms = wl.sad_time_ms()  # per size, summed over the timed steps
         npat = len(wl.pattern)
@@ -168,6 +185,8 @@ def main():
                         "reuse lets the algorithmic rate exceed physical HBM traffic (profiles/ holds the PMC numbers)",
             },
         }
+        if rate_term is not None:
+            out["rate_term"] = rate_term
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.width, a.height)
         print(json.dumps(out), flush=True)

@@ -290,6 +290,66 @@ int xeve_hip_me_epzs_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pe
                           const xeve_hip_epzs_params *params, xeve_hip_me_result *results, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* (4) CABAC (SBAC) bit counting of an inter CU -- the rate term of pinter_residue_rdo and of   */
+/*     the skip / merge analysis.  reference: src_base/xeve_mode.c:39-295 */
+/*     (xeve_sbac_bit_reset, xeve_get_bit_number, xeve_rdo_bit_cnt_cu_inter / _cu_inter_comp /   */
+/*     _cu_skip) over src_base/xeve_eco.c (xeve_sbac_encode_bin :521-575, sbac_encode_bin_ep     */
+/*     :455-472, sbac_carry_propagate :429-453, xeve_eco_run_length_cc :707-771, xeve_eco_cbf    */
+/*     :793-894, xeve_eco_mvd :1235-1280, xeve_eco_refi :1158-1188, xeve_eco_mvp_idx :1190-1203, */
+/*     xeve_eco_inter_pred_idc :1123-1156).  Baseline tool set: tool_admvp 0, no delta QP, CU <=  */
+/*     64x64 (one transform block per component).  The arithmetic coder is inherently serial per  */
+/*     CU, so the unit of parallelism is the job: one lane per job, every lane stepping the same  */
+/*     one-bin-per-iteration state machine.                                                       */
+/* ------------------------------------------------------------------------------------------- */
+/* the fields of XEVE_SBAC (xeve_type.h:527-540) and the context models of XEVE_SBAC_CTX (xeve_def.h:736-790) the
+ * inter-CU syntax touches: ctx[XEVE_HIP_CTX_x + i] = sbac->ctx.x[i] */
+enum {
+    XEVE_HIP_CTX_SKIP_FLAG = 0,  /* [2]  */
+    XEVE_HIP_CTX_PRED_MODE = 2,  /* [3]  */
+    XEVE_HIP_CTX_DIRECT    = 5,  /* [1]  direct_mode_flag */
+    XEVE_HIP_CTX_INTER_DIR = 6,  /* [2]  */
+    XEVE_HIP_CTX_REFI      = 8,  /* [2]  */
+    XEVE_HIP_CTX_MVP_IDX   = 10, /* [3]  */
+    XEVE_HIP_CTX_MVD       = 13, /* [1]  */
+    XEVE_HIP_CTX_CBF_ALL   = 14, XEVE_HIP_CTX_CBF_LUMA = 15, XEVE_HIP_CTX_CBF_CB = 16, XEVE_HIP_CTX_CBF_CR = 17,
+    XEVE_HIP_CTX_RUN       = 18, /* [24] */
+    XEVE_HIP_CTX_LAST      = 42, /* [2]  */
+    XEVE_HIP_CTX_LEVEL     = 44, /* [24] */
+    XEVE_HIP_SBAC_NCTX     = 68
+};
+typedef struct xeve_hip_sbac {
+    uint32_t range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter;
+    uint16_t ctx[XEVE_HIP_SBAC_NCTX];
+} xeve_hip_sbac;
+typedef struct xeve_hip_cu_bits_params {
+    int32_t log2_cuw, log2_cuh;  /* 2..6 */
+    int32_t slice_type;          /* XEVE_ST_B 0 / XEVE_ST_P 1 / XEVE_ST_I 2 (inc/xeve.h:170-172) */
+    int32_t num_refp[2];         /* ctx->rpm.num_refp */
+    int32_t cm_init;             /* sps_cm_init_flag (0 in Baseline) */
+    int32_t chroma_format_idc;   /* 0..3; chroma block = (w >> w_shift) x (h >> h_shift), XEVE_GET_CHROMA_{W,H}_SHIFT */
+} xeve_hip_cu_bits_params;
+enum { XEVE_HIP_BITS_CU_INTER = 0, XEVE_HIP_BITS_COMP_Y = 1, XEVE_HIP_BITS_COMP_U = 2, XEVE_HIP_BITS_COMP_V = 3, XEVE_HIP_BITS_CU_SKIP = 4 };
+typedef struct xeve_hip_cu_bits_job {
+    int32_t coef_off[3];   /* element offsets of the dense Y / U / V blocks of quantised levels inside `coef` */
+    int32_t nnz[3];        /* core->nnz_sub[c][0]: 0 = cbf 0 (the block is not coded whatever it holds)     */
+    int32_t sbac;          /* index of the entry state in `sbac_in` (SBAC_LOAD source)                      */
+    int16_t mvd[2][2];     /* pi->mvd[pidx]                                                                 */
+    int8_t  refi[2];       /* pi->refi[pidx] (< 0 = list unused)                                            */
+    uint8_t mvp_idx[2];
+    uint8_t mode;          /* XEVE_HIP_BITS_*                                                               */
+    uint8_t dir_flag;      /* pidx == PRED_DIR                                                              */
+    uint8_t ctx_skip, ctx_pred_mode; /* core->ctx_flags[CNID_SKIP_FLAG], [CNID_PRED_MODE]                   */
+} xeve_hip_cu_bits_job;
+/* Per job: SBAC_LOAD(sbac_in[job.sbac]) + xeve_sbac_bit_reset + the syntax of job.mode + xeve_get_bit_number -> bits[j];
+ * sbac_out (may be NULL) receives the coder state SBAC_STORE would keep, field for field.  coef (coef_elems int16
+ * elements), sbac_in, jobs, bits, sbac_out and workspace (>= xeve_hip_cu_bits_workspace(njobs, coef_elems) bytes) are
+ * device memory; params is a HOST pointer.  Jobs may share coefficient blocks and entry states. */
+size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems);
+int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                          const xeve_hip_cu_bits_params *params, void *workspace, size_t workspace_bytes, uint32_t *bits,
+                          xeve_hip_sbac *sbac_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,8 +27,9 @@ def make_levels(r, n, kind):
         c = np.zeros(n, np.int64)
         k = max(1, n // 64)
         c[r.integers(0, n, size=k)] = r.integers(-2000, 2001, size=k)
-    elif kind == 3:  # extremes of the s16 range, last position occupied
-        c = np.where(r.random(n) < 0.3, r.choice([-32768, 32767, 1, -1], size=n), 0)
+    elif kind == 3:  # extremes of the s16 range (a few: each costs 32768 bins), last position occupied
+        c = np.where(r.random(n) < 0.3, r.choice([1, -1, 2, -7], size=n), 0)
+        c[r.integers(0, n, size=3)] = r.choice([-32768, 32767, 32766], size=3)
         c[-1] = -32768
     else:  # DC only
         c = np.zeros(n, np.int64)

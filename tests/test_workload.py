@@ -33,9 +33,24 @@ def test_hot_path_pass_small_picture_vs_oracle():
     org = [p.cpu().numpy() for p in wl.org]
     ref = [[p.cpu().numpy() for p in l] for l in wl.ref]
     r = np.random.default_rng(0)
+    rate = {S: b.cpu().numpy() for S, b in wl.rate().items()}
+    torch.cuda.synchronize()
+    from _libs import CU_BITS_JOB_DTYPE, SBAC_DTYPE, CuBitsParams, oracle_sbac
+
+    OS = oracle_sbac()
     for S in wl.sizes:
         lv = wl.lv[S]
         Sc = S // 2
+        # F: CABAC bit counts of the quantised CUs (the eight jobs per CU of pinter_residue_rdo's rate term)
+        rt = lv["rate"]
+        rjobs = rt["jobs"].cpu().numpy().view(CU_BITS_JOB_DTYPE).reshape(lv["n"], wl.RATE_JOBS)
+        rcoef, rstate = lv["coef_flat"].cpu().numpy(), rt["state"].cpu().numpy().view(SBAC_DTYPE)
+        rp = CuBitsParams.from_buffer_copy(bytes(rt["params"]))
+        nnz_dev = np.stack([t.cpu().numpy() for t in lv["nnz"]], axis=1)
+        for j in r.choice(lv["n"], size=min(6, lv["n"]), replace=False):
+            assert np.array_equal(rjobs["nnz"][j, 1], nnz_dev[j]) and not rjobs["nnz"][j, 0].any()
+            for v in range(wl.RATE_JOBS):
+                assert rate[S][j, v] == OS.xo_cu_bits(ptr(rstate), None, rp, ptr(rjobs[j, v:v + 1].copy()), ptr(rcoef)), (S, j, v)
         # A: the last integer-search round left its SADs in sad_out
         jobs = lv["me_jobs"][-1].cpu().numpy()
         li = (len(lv["me_jobs"]) - 1) % N_LIST

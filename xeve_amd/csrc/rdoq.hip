@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
 // zig-zag scans (xeve_tbl_scan, generator xeve_util.c:1289-1327), built once per (log2w, log2h) and kept on the device
 static uint16_t *g_scan[7][7];
 static std::mutex g_scan_mu;
-static int get_scan(int log2w, int log2h, const uint16_t **out)
+int xh_get_scan(int log2w, int log2h, const uint16_t **out)
 {
     std::lock_guard<std::mutex> lk(g_scan_mu);
     if(!g_scan[log2w][log2h]) {
@@ -270,7 +270,7 @@ extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, i
     XH_REQUIRE(qp >= 0 && qp <= 63 && bit_depth >= 8 && bit_depth <= 14 && (tool_iqt == 0 || tool_iqt == 1));
     if(nblk == 0) return XEVE_HIP_OK;
     const uint16_t *scan;
-    int rc = get_scan(log2w, log2h, &scan);
+    int rc = xh_get_scan(log2w, log2h, &scan);
     if(rc != XEVE_HIP_OK) return rc;
     RdoqK P;
     const int odd = (log2w + log2h) & 1, ns_shift = odd ? 7 : 0, ns_scale = odd ? 181 : 1, ns_offset = odd ? 1 << (ns_shift - 1) : 0;

@@ -1,0 +1,427 @@
+// xeve_amd/csrc/sbac.hip -- CABAC (SBAC) bit counting of an inter CU: the rate term of the inter RDO.
+//
+// reference: src_base/xeve_mode.c:39-295 (xeve_sbac_bit_reset, xeve_get_bit_number, xeve_rdo_bit_cnt_cu_inter,
+// _cu_inter_comp, _cu_skip) over src_base/xeve_eco.c (xeve_sbac_encode_bin :521-575, sbac_encode_bin_ep :455-472,
+// sbac_carry_propagate :429-453, sbac_put_byte :397-427, xeve_eco_run_length_cc :707-771, xeve_eco_cbf :793-894, ...).
+//
+// An adaptive binary arithmetic coder is a serial chain per CU (range and context states feed forward bin by bin), so
+// the parallel axis is the JOB: one lane per job.  To keep 64 lanes with 64 different bin sequences converged, the
+// syntax is flattened into "exactly one bin per loop iteration":
+//   * k_coef_events (wave-cooperative, coalesced): every coded coefficient block is compacted, in zig-zag order, into
+//     a list of (zero-run, |level| - 1, sign, is-last-position) events -- ballot + popcount, no serial walk;
+//   * k_cu_bits (one lane per job): the few header bins (skip / pred_mode / direct / inter_dir / refi / mvp_idx / mvd /
+//     cbf) are queued per lane in LDS and drained by one uniform loop; the coefficient bins come from a six-phase
+//     automaton over the event list (run-first, run-rest, level-first, level-rest, sign, last), the five context models
+//     a component uses held in registers.  Every lane executes the same straight-line encoder each iteration.
+// The coder state is carried field for field (code register, pending / stacked bytes, bit counter), so the exit state
+// is what SBAC_STORE would keep and xeve_get_bit_number's formula applies unchanged.
+#include "xh_common.h"
+
+#define NCTX XEVE_HIP_SBAC_NCTX
+#define QMAX 200 // header queue: 5 + 2 * (20 refi + 3 mvp + 2 * 34 mvd) + 4 cbf = 191 bins at most
+
+struct CuBitsK {
+    int n[3], log2n[3];
+    int slice_type, num_refp[2], cm_init, idc;
+    const uint16_t *scan[3];
+};
+
+// ---- event list ---------------------------------------------------------------------------------------------------
+// bits 0..14 |level| - 1, 15 sign, 16..27 zero run before it, 28 the coefficient sits at the last scan position
+__device__ __forceinline__ unsigned ev_pack(int v, int run, int at_end)
+{
+    const unsigned a = (unsigned)(v < 0 ? -v : v) & 0xFFFFu; // XEVE_ABS16
+    return ((a - 1) & 0x7FFFu) | ((unsigned)(v < 0) << 15) | ((unsigned)run << 16) | ((unsigned)at_end << 28);
+}
+
+// which components of a job are coded (xeve_eco_coefficient: nnz_sub[c] && run[c]; cbf_all == 0 codes nothing)
+__device__ __forceinline__ unsigned coded_mask(const xeve_hip_cu_bits_job &j)
+{
+    if(j.mode == XEVE_HIP_BITS_CU_SKIP) return 0;
+    unsigned m = (j.nnz[0] ? 1u : 0u) | (j.nnz[1] ? 2u : 0u) | (j.nnz[2] ? 4u : 0u);
+    if(j.mode != XEVE_HIP_BITS_CU_INTER) m &= 1u << (j.mode - 1);
+    return m;
+}
+
+// LPB lanes per (job, component) block
+template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const int16_t *__restrict__ coef, const xeve_hip_cu_bits_job *__restrict__ jobs,
+                                                                        int njobs, CuBitsK P, unsigned *__restrict__ ev, int *__restrict__ nev)
+{
+    constexpr int GPW = 64 / LPB;
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int g = lane / LPB, l = lane % LPB;
+    const int item = wave * GPW + g, job = item / 3, c = item % 3;
+    bool on = job < njobs;
+    int off = 0;
+    if(on) {
+        const xeve_hip_cu_bits_job &J = jobs[job];
+        on = (coded_mask(J) >> c) & 1;
+        off = J.coef_off[c];
+    }
+    const int n = P.n[c];
+    const uint16_t *scan = P.scan[c];
+    int count = 0, prev = -1;
+    // the trip count is uniform per wave only when all its groups work on equally sized blocks: use the largest
+    const int nmax = P.n[0];
+    for(int chunk = 0; chunk < nmax; chunk += LPB) {
+        const int pos = chunk + l;
+        int v = 0;
+        if(on && pos < n) v = coef[off + scan[pos]];
+        const unsigned long long ball = __ballot(v != 0);
+        unsigned long long mask = ball;
+        if constexpr(LPB < 64) mask = (ball >> (g * LPB)) & ((1ull << LPB) - 1);
+        const unsigned long long below = mask & ((1ull << l) - 1);
+        if(v != 0) {
+            const int before = below ? chunk + 63 - __clzll((long long)below) : prev;
+            ev[off + count + __popcll(below)] = ev_pack(v, pos - before - 1, pos == n - 1);
+        }
+        if(mask) prev = chunk + 63 - __clzll((long long)mask);
+        count += __popcll(mask);
+    }
+    if(job < njobs && l == 0) nev[job * 3 + c] = on ? count : 0;
+}
+
+// ---- the coder (count mode), state in registers --------------------------------------------------------------------
+// FULL carries every field of XEVE_SBAC (code register, pending / stacked bytes, bit counter) so that the exit state is
+// what SBAC_STORE would keep.  Without it only what feeds forward is kept: range, the models, and the number of
+// renormalisation shifts -- which IS xeve_get_bit_number after xeve_sbac_bit_reset: every shift moves one bit out of the
+// 11 + 8k bit window the formula measures (bitcounter + 8 * (stacked + pending) + 8 - code_bits + 3 == total shifts;
+// tests/test_sbac_golden.py::test_bit_count_is_the_number_of_renormalisation_shifts).
+struct Sbac {
+    unsigned range, shifts, bins;
+    unsigned code, cb, sff, sz, pb, ipb, bc; // FULL only
+};
+
+// sbac_put_byte with is_bitcount set: written bytes only advance the bit counter
+__device__ __forceinline__ void sb_byte(Sbac &s, unsigned b)
+{
+    if(s.ipb) {
+        if(s.pb == 0) s.sz++;
+        else s.bc += 8 * s.sz + 8, s.sz = 0;
+    }
+    s.pb = b, s.ipb = 1;
+}
+
+// sbac_carry_propagate with its while loops in closed form
+__device__ __forceinline__ void sb_carry(Sbac &s)
+{
+    const unsigned out = s.code >> 17;
+    s.code &= (1u << 17) - 1;
+    if(out == 0xFF) {
+        s.sff++;
+        return;
+    }
+    if(out > 0xFF) {
+        s.pb++;
+        if(s.sff) { // the first 0x00 flushes the pending byte, the others stack up as zeros
+            sb_byte(s, 0);
+            s.sz += s.sff - 1, s.sff = 0;
+        }
+    }
+    else if(s.sff) { // the first 0xFF flushes the pending byte, each further one writes an 0xFF
+        sb_byte(s, 0xFF);
+        if(s.sff > 1) s.bc += 8 * s.sz + 8 * (s.sff - 1), s.sz = 0;
+        s.sff = 0;
+    }
+    sb_byte(s, out & 0xFF);
+}
+
+// xeve_sbac_encode_bin on model m (returns the updated model) / sbac_encode_bin_ep (ep; m passes through).  Branch-free
+// in the part every bin executes: 64 lanes are at 64 different places of 64 different bin strings.
+template <bool FULL> __device__ __forceinline__ unsigned sb_encode(Sbac &s, unsigned m, unsigned bin, bool ep)
+{
+    const unsigned R = s.range, state = m >> 1, mps = m & 1;
+    unsigned lps = (state * R) >> 9;
+    lps = lps < 437 ? 437 : lps;
+    const unsigned rm = R - lps;                      // range after taking the MPS branch
+    const bool     isl = bin != mps, cut = isl && rm >= lps;
+    const unsigned r = cut ? lps : rm;
+    unsigned sl = state + ((528 - state) >> 5);       // LPS: towards 1/2, swapping the MPS past it
+    const bool flip = sl > 256;
+    sl = flip ? 512 - sl : sl;
+    const unsigned sm = state - ((state + 16) >> 5);  // MPS
+    const unsigned m1 = ((isl ? sl : sm) << 1) | (isl && flip ? mps ^ 1 : mps);
+    const int      lz = __clz((int)r) - 18;           // r >= 437: at most 5 shifts back to >= 8192
+    unsigned n = lz > 0 ? (unsigned)lz : 0;
+    const unsigned half = R >> 1;                     // bypass: the range loses its LSB (xeve_eco.c:459-467), one shift
+    s.range = ep ? half << 1 : r << n;
+    n = ep ? 1 : n;
+    s.shifts += n, s.bins++;
+    if(FULL) {
+        s.code += ep ? (bin ? half : 0) : (cut ? rm : 0);
+        if(n >= s.cb) { // a byte leaves the register (n <= 7: at most one)
+            s.code <<= s.cb, n -= s.cb;
+            sb_carry(s);
+            s.cb = 8;
+        }
+        s.code <<= n, s.cb -= n;
+    }
+    return ep ? m : m1;
+}
+
+// ---- header queue ----------------------------------------------------------------------------------------------------
+// entry: bit 0 bin, bit 1 bypass, bits 2..7 context index (the header only uses models 0..17)
+struct Queue {
+    uint8_t *q; // &s_q[0][lane], stride 64
+    int      n;
+    __device__ __forceinline__ void ctx(int ci, unsigned bin) { q[64 * n++] = (uint8_t)((ci << 2) | (bin & 1)); }
+    __device__ __forceinline__ void ep(unsigned bin) { q[64 * n++] = (uint8_t)(2 | (bin & 1)); }
+};
+
+__device__ __forceinline__ void q_mvd1(Queue &Q, int v)
+{ // xeve_eco_abs_mvd + sign (xeve_eco.c:1205-1270)
+    const unsigned a = (unsigned)(v < 0 ? -v : v);
+    unsigned nn = (a + 1) >> 1;
+    int len = 0;
+    for(; len < 16 && nn; len++) nn >>= 1;
+    const unsigned code = (1u << len) | ((a + 1 - (1u << len)) & ((1u << len) - 1));
+    const int nbin = 2 * len + 1;
+    for(int i = 0; i < nbin; i++) {
+        const unsigned b = (code >> (nbin - 1 - i)) & 1;
+        if(i <= 1) Q.ctx(XEVE_HIP_CTX_MVD, b);
+        else Q.ep(b);
+    }
+    if(a) Q.ep(v < 0);
+}
+__device__ __forceinline__ void q_mvp_idx(Queue &Q, int idx)
+{ // sbac_write_truncate_unary_sym(idx, 3, 4) (xeve_eco.c:492-511)
+    for(int i = 0; i < 3; i++) {
+        Q.ctx(XEVE_HIP_CTX_MVP_IDX + i, i != idx);
+        if(i == idx) break;
+    }
+}
+__device__ __forceinline__ void q_refi(Queue &Q, int num_refp, int refi)
+{ // xeve_eco_refi (xeve_eco.c:1158-1188)
+    if(num_refp <= 1) return;
+    Q.ctx(XEVE_HIP_CTX_REFI, refi != 0);
+    if(refi == 0) return;
+    for(int i = 2; i < num_refp; i++) {
+        const unsigned bin = i != refi + 1;
+        if(i == 2) Q.ctx(XEVE_HIP_CTX_REFI + 1, bin);
+        else Q.ep(bin);
+        if(!bin) break;
+    }
+}
+
+// returns the mask of components whose coefficients follow
+__device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_job &J, const CuBitsK &P)
+{
+    const int st = P.slice_type;
+    if(J.mode == XEVE_HIP_BITS_CU_SKIP) { // xeve_mode.c:276-295
+        if(st != 2) {
+            Q.ctx(XEVE_HIP_CTX_SKIP_FLAG + J.ctx_skip, 1);
+            q_mvp_idx(Q, J.mvp_idx[0]);
+            if(st == 0) q_mvp_idx(Q, J.mvp_idx[1]);
+        }
+        return 0;
+    }
+    unsigned run = 7;
+    if(J.mode == XEVE_HIP_BITS_CU_INTER) { // xeve_mode.c:201-274
+        if(st != 2) {
+            Q.ctx(XEVE_HIP_CTX_SKIP_FLAG + J.ctx_skip, 0);
+            Q.ctx(XEVE_HIP_CTX_PRED_MODE + J.ctx_pred_mode, 0);
+            Q.ctx(XEVE_HIP_CTX_DIRECT, J.dir_flag != 0);
+            if(!J.dir_flag) {
+                const bool v0 = J.refi[0] >= 0, v1 = J.refi[1] >= 0;
+                if(v0 && v1) Q.ctx(XEVE_HIP_CTX_INTER_DIR, 0); // xeve_eco_inter_pred_idc (xeve_eco.c:1123-1156)
+                else {
+                    if(st == 0) Q.ctx(XEVE_HIP_CTX_INTER_DIR, 1);
+                    Q.ctx(XEVE_HIP_CTX_INTER_DIR + 1, !v0);
+                }
+                if(v0) {
+                    q_refi(Q, P.num_refp[0], J.refi[0]);
+                    q_mvp_idx(Q, J.mvp_idx[0]);
+                    q_mvd1(Q, J.mvd[0][0]), q_mvd1(Q, J.mvd[0][1]);
+                }
+                if(st == 0 && v1) {
+                    q_refi(Q, P.num_refp[1], J.refi[1]);
+                    q_mvp_idx(Q, J.mvp_idx[1]);
+                    q_mvd1(Q, J.mvd[1][0]), q_mvd1(Q, J.mvd[1][1]);
+                }
+            }
+        }
+    }
+    else run = 1u << (J.mode - 1);
+    // xeve_eco_cbf (xeve_eco.c:793-894), inter branch, one transform block
+    const unsigned cbf = (J.nnz[0] ? 1u : 0u) | (J.nnz[1] ? 2u : 0u) | (J.nnz[2] ? 4u : 0u);
+    if(run == 7) {
+        Q.ctx(XEVE_HIP_CTX_CBF_ALL, cbf != 0);
+        if(!cbf) return 0;
+    }
+    if((run & 2) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CB, (cbf >> 1) & 1);
+    if((run & 4) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CR, (cbf >> 2) & 1);
+    if((run & 1) && (cbf & 6)) Q.ctx(XEVE_HIP_CTX_CBF_LUMA, cbf & 1);
+    return cbf & run;
+}
+
+// ---- one lane per job ------------------------------------------------------------------------------------------------
+#define RING 32 // events staged per lane in LDS
+#define WIN 32  // iterations between two refills; an event takes >= 4 bins, so a window consumes <= 8 of them
+#define FILL 16 // events fetched per refill
+#define BURST 8 // MPS bins a lane may take in one go after its general step
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs,
+                                                CuBitsK P, const unsigned *__restrict__ ev, const int *__restrict__ nev,
+                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout)
+{
+    __shared__ uint16_t s_ctx[NCTX][64];
+    __shared__ uint8_t  s_q[QMAX][64];
+    __shared__ unsigned s_ring[RING][64];
+    const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+    if(j >= njobs) return;
+    const xeve_hip_cu_bits_job J = jobs[j];
+    const xeve_hip_sbac &in = sin[J.sbac];
+    Sbac s;
+    s.range = in.range, s.shifts = s.bins = 0;
+    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
+    for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
+
+    Queue Q{&s_q[0][lane], 0};
+    const unsigned coded = q_header(Q, J, P);
+
+    // The coded components' event lists form ONE stream per lane: [0, b1) luma, [b1, b2) Cb, [b2, total) Cr.  A list ends
+    // with its nnz-th event (the reference stops at num_sig == 0) or when it runs out.
+    const int l0 = (coded & 1) ? min(nev[j * 3], J.nnz[0]) : 0, l1 = (coded & 2) ? min(nev[j * 3 + 1], J.nnz[1]) : 0;
+    const int l2 = (coded & 4) ? min(nev[j * 3 + 2], J.nnz[2]) : 0;
+    const int b1 = l0, b2 = l0 + l1, total = l0 + l1 + l2;
+    const int o0 = J.coef_off[0], o1 = J.coef_off[1] - b1, o2 = J.coef_off[2] - b2;
+    const int d1 = o1 - o0, d2 = o2 - o1; // (additive form: a select between three bases makes the compiler build a pointer table in scratch)
+    auto fetch = [&](int q) -> unsigned { return q < total ? ev[o0 + (q >= b1 ? d1 : 0) + (q >= b2 ? d2 : 0) + q] : 0u; };
+
+    // events travel global -> registers (in flight during a whole window) -> LDS ring -> automaton, so that no iteration
+    // of the bin loop waits on a global load
+    unsigned buf[FILL];
+    int      filled = 0, cnt = min(FILL, total);
+#pragma unroll
+    for(int i = 0; i < FILL; i++) buf[i] = fetch(i);
+
+    for(int i = 0; i < Q.n; i++) { // header bins (the first events are in flight meanwhile)
+        const unsigned e = s_q[i][lane], ci = e >> 2;
+        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, (e & 2) != 0); // (bypass entries pass model 0 through)
+        s_ctx[ci][lane] = (uint16_t)m;
+    }
+
+    // coefficient automaton: one bin per general step
+    int      e = 0, phase = 0, numsig = b1 > 0 ? J.nnz[0] : b2 > 0 ? J.nnz[1] : J.nnz[2];
+    int      ch = b1 > 0 ? 0 : 1;                                   // 0 luma, 1 chroma
+    int      t0 = P.cm_init == 1 ? 10 + ch * 12 : ch * 2;          // prev_level = 6 at the start of a block (xeve_eco.c:722,731-733)
+    unsigned k = 0, cur = 0, nxt = 0;
+    bool     primed = false;
+    while(e < total) {
+#pragma unroll
+        for(int i = 0; i < FILL; i++) // commit the refill that was in flight
+            if(i < cnt) s_ring[(filled + i) & (RING - 1)][lane] = buf[i];
+        filled += cnt;
+        cnt = min(min(FILL, RING - (filled - e)), total - filled);
+#pragma unroll
+        for(int i = 0; i < FILL; i++) // issue the next one
+            if(i < cnt) buf[i] = fetch(filled + i);
+        if(!primed) cur = s_ring[0][lane], nxt = s_ring[1][lane], primed = true;
+
+        for(int it = 0; it < WIN; it++) {
+            if(e < total) {
+                // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag
+                const unsigned run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1;
+                const bool     at_end = (cur >> 28) & 1;
+                const unsigned kn = phase == 0 ? run : phase == 2 ? lev1 : k - 1;
+                const unsigned bin = phase == 4 ? sign : phase == 5 ? (unsigned)(numsig == 0) : (unsigned)(kn != 0);
+                const int      ci = phase == 5 ? XEVE_HIP_CTX_LAST + ch : (phase >= 2 ? XEVE_HIP_CTX_LEVEL : XEVE_HIP_CTX_RUN) + t0 + (phase & 1);
+                const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], bin, phase == 4);
+                s_ctx[ci][lane] = (uint16_t)m;
+                const bool adv = phase == 5 || (phase == 4 && at_end); // no last flag at scan_pos == num_coeff - 1 (xeve_eco.c:744-746)
+                const int  nphase = phase < 4 ? (phase | 1) + (kn == 0) : (phase == 4 && !at_end ? 5 : 0);
+                numsig -= phase == 4;
+                if(adv) {
+                    e++;
+                    const bool newc = e == b1 || e == b2;
+                    ch = e >= b1;
+                    numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
+                    const unsigned plev = newc ? 5 : (lev1 < 5 ? lev1 : 5); // min(prev_level - 1, 5)
+                    t0 = P.cm_init == 1 ? (int)(plev << 1) + ch * 12 : ch * 2;
+                    cur = nxt;
+                    nxt = s_ring[(e + 1) & (RING - 1)][lane]; // (stale beyond the stream's end; never consumed)
+                }
+                k = kn, phase = nphase;
+                // ---- burst: most bins are the "1"s of a unary code (zero runs, large levels) on an adapted model, i.e.
+                // a run of MPS bins on ONE context -- range and state recurrence only, the model stays in a register
+                // (taken only when at least half of the lanes still at work have >= 6 such bins ahead: the burst costs
+                // about one general step, whoever uses it)
+                const bool unary = !FULL && (phase & 1) && phase < 4 && k >= 2;
+                const bool worth = 2 * __popcll(__ballot(unary && k >= 7)) >= __popcll(__ballot(true));
+                if(worth && unary) {
+                    const int cb = (phase == 1 ? XEVE_HIP_CTX_RUN : XEVE_HIP_CTX_LEVEL) + t0 + 1;
+                    const unsigned mb = s_ctx[cb][lane];
+                    if(mb & 1) {
+                        unsigned st = mb >> 1, R = s.range;
+                        const unsigned steps = k - 1 < BURST ? k - 1 : BURST;
+#pragma unroll
+                        for(unsigned u = 0; u < BURST; u++)
+                            if(u < steps) {
+                                unsigned lps = (st * R) >> 9;
+                                lps = lps < 437 ? 437 : lps;
+                                R -= lps, st -= (st + 16) >> 5;
+                                const unsigned sh = R < 8192;
+                                R <<= sh, s.shifts += sh;
+                            }
+                        s.range = R, s.bins += steps, k -= steps;
+                        s_ctx[cb][lane] = (uint16_t)((st << 1) | 1);
+                    }
+                }
+            }
+        }
+    }
+
+    bits[j] = s.shifts;
+    if(FULL) {
+        // xeve_get_bit_number (xeve_mode.c:51-55) -- equal to s.shifts, kept as the reference computes it
+        bits[j] = s.bc + 8 * (s.sz + s.sff) + 8 * (s.ipb ? 1 : 0) + 8 - s.cb + 3;
+        xeve_hip_sbac &o = sout[j];
+        o.range = s.range, o.code = s.code, o.code_bits = s.cb, o.stacked_ff = s.sff, o.stacked_zero = s.sz;
+        o.pending_byte = s.pb, o.is_pending_byte = s.ipb, o.bitcounter = s.bc, o.bin_counter = s.bins;
+        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------
+extern "C" size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems)
+{
+    return sizeof(unsigned) * coef_elems + sizeof(int) * 3 * (size_t)(njobs > 0 ? njobs : 0);
+}
+
+extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                                     const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits,
+                                     xeve_hip_sbac *sbac_out, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(p && njobs >= 0);
+    XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6);
+    XH_REQUIRE(p->slice_type >= 0 && p->slice_type <= 2 && p->chroma_format_idc >= 0 && p->chroma_format_idc <= 3);
+    XH_REQUIRE(p->num_refp[0] >= 0 && p->num_refp[0] <= 21 && p->num_refp[1] >= 0 && p->num_refp[1] <= 21);
+    if(njobs == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(coef && sbac_in && jobs && bits && workspace);
+    XH_REQUIRE(workspace_bytes >= xeve_hip_cu_bits_workspace(njobs, coef_elems));
+    CuBitsK P;
+    const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT (xeve_util.h:92-94)
+    for(int c = 0; c < 3; c++) {
+        const int lw = p->log2_cuw - (c ? ws : 0), lh = p->log2_cuh - (c ? hs : 0);
+        P.log2n[c] = lw + lh, P.n[c] = 1 << (lw + lh);
+        const int rc = xh_get_scan(lw, lh, &P.scan[c]);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    P.slice_type = p->slice_type, P.num_refp[0] = p->num_refp[0], P.num_refp[1] = p->num_refp[1];
+    P.cm_init = p->cm_init, P.idc = p->chroma_format_idc;
+    unsigned *ev  = (unsigned *)workspace;
+    int      *nev = (int *)(ev + coef_elems);
+    hipStream_t st = (hipStream_t)stream;
+    const long items = 3L * njobs;
+    if(P.n[0] <= 64) {
+        const long waves = (items + 3) / 4;
+        k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
+    }
+    else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
+    if(sbac_out) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
+    else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -49,6 +49,9 @@ struct RdoParams {
                 // 2: back half, reads quantised levels from `coef` (e.g. left there by xeve_hip_rdoq) and reconstructs
 };
 
+// zig-zag scan of a (1 << log2w) x (1 << log2h) block (xeve_tbl_scan), device memory, built once (rdoq.hip)
+int xh_get_scan(int log2w, int log2h, const uint16_t **out);
+
 static inline int xh_ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
 static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 

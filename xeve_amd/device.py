@@ -181,6 +181,24 @@ def rdoq(coef, log2w, log2h, qp, lam, is_luma, bit_depth, est, tool_iqt=0, nnz=N
     return nnz
 
 
+def cu_bits_jobs(coef, sbac_in, jobs, params, want_state=True, workspace=None, bits=None, sbac_out=None):
+    """CABAC bit count of inter-CU jobs (xeve_hip_cu_bits_jobs).  coef: flat int16 tensor; sbac_in / jobs: uint8 tensors holding
+    arrays of lib.SBAC_DTYPE / lib.CU_BITS_JOB_DTYPE records; params: lib.CuBitsParams.  Returns (bits u32-as-int32 [njobs],
+    exit states as a uint8 [njobs, 172] tensor or None)."""
+    L = _lib.load()
+    njobs = jobs.numel() // 44
+    need = L.xeve_hip_cu_bits_workspace(njobs, coef.numel())
+    if workspace is None:
+        workspace = torch.empty(max(int(need), 4), dtype=torch.uint8, device=coef.device)
+    if bits is None:
+        bits = torch.empty(njobs, dtype=torch.int32, device=coef.device)
+    if sbac_out is None and want_state:
+        sbac_out = torch.empty((njobs, 172), dtype=torch.uint8, device=coef.device)
+    _lib.check(L.xeve_hip_cu_bits_jobs(_ptr(_i16(coef)), coef.numel(), _ptr(sbac_in), _ptr(jobs), njobs, C.byref(params), _ptr(workspace),
+                                       workspace.numel(), _ptr(bits), _ptr(sbac_out) if sbac_out is not None else None, _stream()))
+    return bits, sbac_out
+
+
 def dquant(coef, log2w, log2h, scale, bit_depth):
     _lib.check(_lib.load().xeve_hip_dquant(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, scale, bit_depth, _stream()))
     return coef

@@ -39,6 +39,16 @@ class EpzsParams(C.Structure):  # xeve_hip_epzs_params
     _fields_ = [("me", MeParams), ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
 
 
+class CuBitsParams(C.Structure):  # xeve_hip_cu_bits_params
+    _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("slice_type", C.c_int32), ("num_refp", C.c_int32 * 2),
+                ("cm_init", C.c_int32), ("chroma_format_idc", C.c_int32)]
+
+
+SBAC_NCTX = 68
+SBAC_DTYPE = [("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"), ("pending_byte", "<u4"),
+              ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"), ("ctx", "<u2", (SBAC_NCTX,))]  # xeve_hip_sbac (172 B)
+CU_BITS_JOB_DTYPE = [("coef_off", "<i4", (3,)), ("nnz", "<i4", (3,)), ("sbac", "<i4"), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)),
+                     ("mvp_idx", "u1", (2,)), ("mode", "u1"), ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1")]  # xeve_hip_cu_bits_job (44 B)
 EPZS_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("mvp", "<i2", 2), ("mv_start", "<i2", 2)]  # xeve_hip_epzs_job
 SPEL_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("gmvp", "<i2", 2), ("mvi", "<i2", 2)]  # xeve_hip_spel_job
 ME_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("range", "<i2", 4), ("gmvp", "<i2", 2), ("mvi", "<i2", 2), ("beststep_in", "<i4")]  # xeve_hip_me_job
@@ -96,6 +106,8 @@ FUNCTIONS = {
     "xeve_hip_me_epzs_workspace": (C.c_size_t, [c_int]),
     "xeve_hip_me_epzs_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
+    "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 TABLES = {

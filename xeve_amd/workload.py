@@ -147,7 +147,10 @@ class HotPathPass:
         lv["merge_jobs_org"] = [(with_org_off(jl, lv["off_l"]), with_org_off(jc, lv["off_c"])) for jl, jc in lv["merge_jobs"]]
         lv["final_jobs"] = [qpel_jobs() for _ in range(N_LIST)]
         lv["resi"] = [torch.empty((n, S * S), dtype=torch.int16, device=dev)] + [torch.empty((n, Sc * Sc), dtype=torch.int16, device=dev) for _ in range(2)]
-        lv["coef"] = [torch.empty_like(t) for t in lv["resi"]]
+        # quantised levels of Y, U, V in ONE buffer (the bit-count jobs address all three components of a CU by offset)
+        flat = torch.empty(n * (S * S + 2 * Sc * Sc), dtype=torch.int16, device=dev)
+        lv["coef_flat"] = flat
+        lv["coef"] = [flat[:n * S * S].view(n, S * S), flat[n * S * S:n * (S * S + Sc * Sc)].view(n, Sc * Sc), flat[n * (S * S + Sc * Sc):].view(n, Sc * Sc)]
         lv["rec"] = [torch.zeros_like(p) for p in self.org]
         lv["nnz"] = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
         lv["ssd2"] = [torch.empty((n, 2), dtype=torch.int64, device=dev) for _ in range(3)]
@@ -206,6 +209,54 @@ class HotPathPass:
             # E. intra gate
             if only in (None, "E"):
                 D.satd_jobs(org[0], s_l, lv["pred_l"][0], S, lv["dense_jobs"], self.zero_cand, S, S, bd)
+
+    # ------------------------------------------------------------------------------------------------------
+    # F. rate term of pinter_residue_rdo (xeve_pinter.c:1103-1260): CABAC bit counts of the quantised CU left by phase D.
+    # Per CU the reference counts: the all-zero alternative, the CU as quantised, and every component with and without its
+    # coefficients (xeve_rdo_bit_cnt_cu_inter x2, xeve_rdo_bit_cnt_cu_inter_comp x6) = RATE_JOBS jobs.  (The reference
+    # threads the coder state from one component test to the next; here all eight start from the CU's entry state.)
+    RATE_JOBS = 8
+
+    def _rate_setup(self, lv):
+        from . import lib
+        S, n, dev = lv["S"], lv["n"], self.dev
+        Sc, ny, nc = S // 2, S * S, S * S // 4
+        j = np.zeros((n, self.RATE_JOBS), lib.CU_BITS_JOB_DTYPE)
+        cu = np.arange(n)
+        j["coef_off"][:, :, 0], j["coef_off"][:, :, 1], j["coef_off"][:, :, 2] = (cu * ny)[:, None], (n * ny + cu * nc)[:, None], (n * (ny + nc) + cu * nc)[:, None]
+        j["mode"] = np.array([0, 0, 1, 1, 2, 2, 3, 3], np.uint8)[None, :]
+        rng = np.random.default_rng(9)
+        j["refi"] = 0  # bi-prediction from reference 0 of both lists
+        j["mvd"] = rng.integers(-16, 17, size=(n, 1, 2, 2))
+        j["mvp_idx"] = rng.integers(0, 4, size=(n, 1, 2))
+        # which components keep their coefficient count in each of the eight jobs
+        keep = np.array([[0, 0, 0], [1, 1, 1], [0, 1, 1], [1, 1, 1], [1, 0, 1], [1, 1, 1], [1, 1, 0], [1, 1, 1]], np.int32)
+        st = np.zeros(1, lib.SBAC_DTYPE)
+        st["range"], st["ctx"] = 16384, 512  # xeve_sbac_reset: the state at the start of a slice
+        p = lib.CuBitsParams()
+        p.log2_cuw = p.log2_cuh = S.bit_length() - 1
+        p.slice_type, p.cm_init, p.chroma_format_idc = 0, 0, 1
+        p.num_refp[0] = p.num_refp[1] = 2
+        r = dict(params=p, jobs=torch.from_numpy(j.reshape(-1).view(np.uint8).copy()).to(dev), keep=torch.from_numpy(keep).to(dev),
+                 state=torch.from_numpy(st.view(np.uint8).copy()).to(dev), bits=torch.empty(n * self.RATE_JOBS, dtype=torch.int32, device=dev))
+        need = lib.load().xeve_hip_cu_bits_workspace(n * self.RATE_JOBS, lv["coef_flat"].numel())
+        r["ws"] = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        return r
+
+    def rate(self):
+        """phase F for every level; returns {S: int32 tensor [n, RATE_JOBS] of bit counts}"""
+        out = {}
+        for S in self.sizes:
+            lv = self.lv[S]
+            if "rate" not in lv:
+                lv["rate"] = self._rate_setup(lv)
+            r = lv["rate"]
+            # the coefficient counts come from the quantiser on the device: write them into the job records there
+            nnz3 = torch.stack(lv["nnz"], dim=1)  # [n, 3]
+            r["jobs"].view(torch.int32).view(lv["n"], self.RATE_JOBS, 11)[:, :, 3:6] = nnz3[:, None, :] * r["keep"][None, :, :]
+            D.cu_bits_jobs(lv["coef_flat"], r["state"], r["jobs"], r["params"], want_state=False, workspace=r["ws"], bits=r["bits"])
+            out[S] = r["bits"].view(lv["n"], self.RATE_JOBS)
+        return out
 
     def capture(self):
         """Record one pass into a HIP graph (all launches of run() go to torch's current stream, which is the capture
