@@ -132,20 +132,26 @@ def main():
 
     rate_term = None
     if rank == 0 and not a.no_rate:
-        # the rate term of the same RDO (CABAC bit counts of the CUs phase D quantised; xeve_amd/workload.py phase F), measured
-        # on its own AFTER the timed region: an arithmetic coder's cost is set by the data, and i.i.d. synthetic pictures
-        # quantise to ~100x the bins of real video, so folding it into `value` would measure the synthetic data, not the path
-        wl.rate()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        bits = wl.rate()
-        e1.record()
-        torch.cuda.synchronize()
-        rate_term = {"ms_per_picture": round(e0.elapsed_time(e1), 3), "jobs_per_picture": int(sum(b.numel() for b in bits.values())),
-                     "coded_bits_per_picture": int(sum(int(b[:, 1].sum().item()) for b in bits.values())),
-                     "in_timed_region": False,
+        # The rate term of the same RDO (CABAC bit counts of the CUs phase D quantised; xeve_amd/workload.py phase F), measured on
+        # its own AFTER the timed region: an arithmetic coder's cost is set by the data, and i.i.d. synthetic pictures quantise
+        # to ~100x the bins of real video -- folded into `value` it would measure the synthetic data, not the path.  Reported for
+        # the i.i.d. picture of the timed pass and for SURVEY.md 8(d)'s structured input (moving gradient + 3-bit noise).
+        def rate_of(w):
+            w.rate()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bits = w.rate()
+            e1.record()
+            torch.cuda.synchronize()
+            return {"ms_per_picture": round(e0.elapsed_time(e1), 3), "jobs_per_picture": int(sum(b.numel() for b in bits.values())),
+                    "coded_bits_per_picture": int(sum(int(b[:, 1].sum().item()) for b in bits.values()))}
+        rate_term = {"in_timed_region": False, "iid": rate_of(wl),
                      "note": "xeve_hip_cu_bits_jobs over every CU of all four levels, 8 bit-count jobs per CU as pinter_residue_rdo issues them"}
+        ws = HotPathPass(a.width, a.height, dev, seed=5, content="structured")
+        ws.run(only="D")
+        rate_term["structured"] = rate_of(ws)
+        del ws
     if rank == 0:
         sad_ms = wl.sad_time_ms()  # per size, summed over the timed steps
         npat = len(wl.pattern)

@@ -180,6 +180,19 @@ int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int qp, double 
 /* xeve_quant_nnz with use_rdoq = 1 (xeve_tq.c:651-703): the all-zero pre-test (zero_test != 0), then RDOQ */
 int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
                      const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream);
+/* The estimates as the reference derives them: xeve_rdoq_bit_est (xeve_mode.c:326-372) turns a coder state into
+ * core->rdoq_est_* (xeve_type.h:737-747) through the table of xeve_init_bits_est (xeve_mode.c:304-313).  One record per
+ * state, device memory; xeve_hip_rdoq_dev then quantises block b with record est[est_idx[b]] (est_idx == NULL: record 0)
+ * and picks the cbf pair like xeve_tq.c:565-583 (ch_type 0 Y / 1 U / 2 V). */
+struct xeve_hip_sbac;
+typedef struct xeve_hip_rdoq_est_full {
+    int32_t cbf_all[2], cbf_luma[2], cbf_cb[2], cbf_cr[2];
+    int32_t run[24][2], level[24][2], last[2][2];
+} xeve_hip_rdoq_est_full;
+int xeve_hip_rdoq_bit_est(const struct xeve_hip_sbac *sbac, int nstates, xeve_hip_rdoq_est_full *est, void *stream);
+int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
+                      const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int32_t *nnz,
+                      void *stream);
 /* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
 int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
 /* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;

@@ -4,11 +4,11 @@
  * xeve_rdo_bit_cnt_cu_inter / _cu_inter_comp / _cu_skip + xeve_get_bit_number (src_base/xeve_mode.c:39-295), exactly as
  * pinter_residue_rdo strings them together (src_base/xeve_pinter.c:1112-1131).  XEVE_CTX / XEVE_CORE / XEVE_SBAC come
  * from the reference's own headers; the flat structs below mirror oracle/xeve_oracle.h (xo_sbac, xo_cu_bits_*).
+ * Also wraps the static xeve_rdoq_bit_est (xeve_mode.c:326-372) and the entropy_bits table (xeve_init_bits_est, :304-313).
  */
 #include <stdlib.h>
 #include <string.h>
-#include "xeve_type.h"
-#include "xeve_mode.h"
+#include "xeve_mode.c" /* the reference's file, compiled in place: xeve_rdoq_bit_est and entropy_bits are static there */
 #include "xeve_eco.h"
 
 enum { C_SKIP = 0, C_PRED_MODE = 2, C_DIRECT = 5, C_INTER_DIR = 6, C_REFI = 8, C_MVP_IDX = 10, C_MVD = 13, C_CBF_ALL = 14,
@@ -108,4 +108,24 @@ void refdrv_run_length_cc(drv_sbac *s, const s16 *coef, int log2w, int log2h, in
     memcpy(tmp, coef, sizeof(s16) << (log2w + log2h));
     xeve_eco_run_length_cc(NULL, &bs, tmp, log2w, log2h, num_sig, ch);
     from_ref(s, &r);
+}
+
+/* xeve_rdoq_bit_est on a flat state; out = cbf_all[2], cbf_luma[2], cbf_cb[2], cbf_cr[2], run[24][2], level[24][2], last[2][2] */
+void refdrv_rdoq_bit_est(const drv_sbac *s, int *out)
+{
+    static __thread XEVE_CORE *core;
+    XEVE_SBAC r;
+    if(!core) core = calloc(1, sizeof(*core)), xeve_init_bits_est();
+    to_ref(&r, s, 0);
+    xeve_rdoq_bit_est(&r, core);
+    memcpy(out, core->rdoq_est_cbf_all, 8), memcpy(out + 2, core->rdoq_est_cbf_luma, 8);
+    memcpy(out + 4, core->rdoq_est_cbf_cb, 8), memcpy(out + 6, core->rdoq_est_cbf_cr, 8);
+    memcpy(out + 8, core->rdoq_est_run, sizeof(core->rdoq_est_run));
+    memcpy(out + 56, core->rdoq_est_level, sizeof(core->rdoq_est_level));
+    memcpy(out + 104, core->rdoq_est_last, sizeof(core->rdoq_est_last));
+}
+void refdrv_entropy_bits(int *out)
+{
+    xeve_init_bits_est();
+    memcpy(out, entropy_bits, sizeof(entropy_bits));
 }

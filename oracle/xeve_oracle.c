@@ -930,3 +930,34 @@ uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p,
     if(out) *out = s;
     return xo_sbac_bits(&s);
 }
+
+/* xeve_init_bits_est (xeve_mode.c:304-313) */
+int32_t xo_entropy_bits(int i)
+{
+    double p = (512 * (i + 0.5)) / 1024;
+    return (int32_t)(-32768 * (log(p) / log(2.0) - 9));
+}
+/* biari_no_bits (xeve_mode.c:315-324) */
+static int32_t no_bits(int symbol, uint16_t cm)
+{
+    uint16_t mps = cm & 1, state = cm >> 1;
+    state = ((uint16_t)(symbol != 0) != mps) ? state : (uint16_t)(512 - state);
+    return xo_entropy_bits(state << 1);
+}
+void xo_rdoq_bit_est(const xo_sbac *s, xo_rdoq_est_full *e)
+{   /* xeve_mode.c:326-372 (the tables the Baseline run-level syntax uses) */
+    for(int b = 0; b < 2; b++) {
+        e->cbf_luma[b] = no_bits(b, s->ctx[XO_CTX_CBF_LUMA]), e->cbf_cb[b] = no_bits(b, s->ctx[XO_CTX_CBF_CB]);
+        e->cbf_cr[b] = no_bits(b, s->ctx[XO_CTX_CBF_CR]), e->cbf_all[b] = no_bits(b, s->ctx[XO_CTX_CBF_ALL]);
+        for(int c = 0; c < 24; c++) e->run[c][b] = no_bits(b, s->ctx[XO_CTX_RUN + c]), e->level[c][b] = no_bits(b, s->ctx[XO_CTX_LEVEL + c]);
+        for(int c = 0; c < 2; c++) e->last[c][b] = no_bits(b, s->ctx[XO_CTX_LAST + c]);
+    }
+}
+void xo_rdoq_est_select(const xo_rdoq_est_full *f, int ch_type, int is_intra, xo_rdoq_est *e)
+{
+    const int32_t *cbf = (!is_intra && ch_type == 0) ? f->cbf_all : ch_type == 0 ? f->cbf_luma : ch_type == 1 ? f->cbf_cb : f->cbf_cr;
+    e->cbf[0] = cbf[0], e->cbf[1] = cbf[1];
+    memcpy(e->run, f->run, sizeof(e->run));
+    memcpy(e->level, f->level, sizeof(e->level));
+    memcpy(e->last, f->last, sizeof(e->last));
+}

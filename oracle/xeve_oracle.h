@@ -183,6 +183,17 @@ void     xo_sbac_bin_ep(xo_sbac *s, uint32_t bin);
 /* xeve_eco_run_length_cc (xeve_eco.c:707-771); ch = 0 luma / 1 chroma; cm_init = sbac->ctx.sps_cm_init_flag */
 void     xo_eco_run_length_cc(xo_sbac *s, const int16_t *coef, int log2w, int log2h, int num_sig, int ch, int cm_init);
 
+/* xeve_rdoq_bit_est (xeve_mode.c:326-372): the bit estimates RDOQ reads, derived from the live coder state with the table of
+ * xeve_init_bits_est (xeve_mode.c:304-313); the fields mirror core->rdoq_est_* (xeve_type.h:737-747) for the run-level syntax */
+typedef struct xo_rdoq_est_full {
+    int32_t cbf_all[2], cbf_luma[2], cbf_cb[2], cbf_cr[2];
+    int32_t run[24][2], level[24][2], last[2][2];
+} xo_rdoq_est_full;
+int32_t  xo_entropy_bits(int i); /* entropy_bits[i], i = 0..1023 */
+void     xo_rdoq_bit_est(const xo_sbac *s, xo_rdoq_est_full *e);
+/* the cbf pair xeve_rdoq_run_length_cc picks (xeve_tq.c:565-583); ch_type 0 Y / 1 U / 2 V */
+void     xo_rdoq_est_select(const xo_rdoq_est_full *f, int ch_type, int is_intra, xo_rdoq_est *e);
+
 typedef struct xo_cu_bits_params {
     int32_t log2_cuw, log2_cuh;
     int32_t slice_type;          /* XEVE_ST_B 0 / XEVE_ST_P 1 / XEVE_ST_I 2 (inc/xeve.h:170-172)           */

@@ -330,6 +330,10 @@ def ref_sbac():
         L.refdrv_sbac_bin.argtypes = [c_void_p, c_int, C.c_uint32, c_int]
         L.refdrv_run_length_cc.restype = None
         L.refdrv_run_length_cc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+        L.refdrv_rdoq_bit_est.restype = None
+        L.refdrv_rdoq_bit_est.argtypes = [c_void_p, c_void_p]
+        L.refdrv_entropy_bits.restype = None
+        L.refdrv_entropy_bits.argtypes = [c_void_p]
         _ref_sbac = L
     return _ref_sbac
 
@@ -350,4 +354,13 @@ def oracle_sbac():
     L.xo_eco_run_length_cc.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
     L.xo_cu_bits.restype = C.c_uint32
     L.xo_cu_bits.argtypes = [c_void_p, c_void_p, C.POINTER(CuBitsParams), c_void_p, c_void_p]
+    L.xo_entropy_bits.restype = C.c_int32
+    L.xo_entropy_bits.argtypes = [c_int]
+    L.xo_rdoq_bit_est.restype = None
+    L.xo_rdoq_bit_est.argtypes = [c_void_p, c_void_p]
+    L.xo_rdoq_est_select.restype = None
+    L.xo_rdoq_est_select.argtypes = [c_void_p, c_int, c_int, C.POINTER(RdoqEst)]
     return L
+
+
+EST_FULL_INTS = 108  # xo_rdoq_est_full / xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr [2] each, run[24][2], level[24][2], last[2][2]

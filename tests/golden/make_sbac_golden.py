@@ -33,6 +33,16 @@ for (lw, lh, st, nref, cm, idc) in [(2, 2, 0, (2, 2), 0, 1), (3, 3, 0, (2, 2), 0
     d["out%d" % k] = out.view(np.uint8)
     d["bits%d" % k] = bits
     k += 1
+# xeve_init_bits_est's table and xeve_rdoq_bit_est (static in xeve_mode.c) on 64 coder states
+from _libs import EST_FULL_INTS  # noqa: E402
+
+tab = np.zeros(1024, np.int32)
+R.refdrv_entropy_bits(ptr(tab))
+est_states = make_states(r, 64)
+est = np.zeros((64, EST_FULL_INTS), np.int32)
+for i in range(64):
+    R.refdrv_rdoq_bit_est(ptr(est_states[i:i + 1]), ptr(est[i]))
+d["entropy_bits"], d["est_states"], d["est"] = tab, est_states.view(np.uint8), est
 d["n"] = np.array(k)
 np.savez_compressed(OUT, **d)
 print("wrote", OUT, os.path.getsize(OUT), k)

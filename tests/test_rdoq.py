@@ -131,3 +131,79 @@ def test_residual_chain_with_rdoq_vs_oracle(lw, lh):
             assert np.array_equal(rec[y0:y0 + h, x0:x0 + w], e[:, :w]), ("rec", lw, lh, qp, b)
             assert ssd[b, 1] == O.xo_ssd(w, h, ptr(org, offs[b]), ptr(rec, offs[b]), s, s, bd)
         assert coded > 0
+
+
+@pytest.mark.gpu
+def test_hip_rdoq_bit_est_vs_goldens_and_oracle():
+    """xeve_rdoq_bit_est on the device (entropy table built by the library) == the reference's (goldens) == the oracle's"""
+    import torch
+
+    import xeve_amd
+    from _libs import EST_FULL_INTS, SBAC_DTYPE, oracle_sbac
+    from _sbac_cases import make_states
+    from _sbac_golden import GOLD
+    from xeve_amd import device as D
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    g = np.load(GOLD)
+    st = np.ascontiguousarray(g["est_states"])
+    got = D.rdoq_bit_est(torch.from_numpy(st.copy()).to(dev)).cpu().numpy()
+    assert np.array_equal(got, g["est"])
+    O = oracle_sbac()
+    states = make_states(np.random.default_rng(5), 300)
+    got = D.rdoq_bit_est(torch.from_numpy(states.view(np.uint8).copy()).to(dev)).cpu().numpy()
+    for i in range(len(states)):
+        e = np.zeros(EST_FULL_INTS, np.int32)
+        O.xo_rdoq_bit_est(ptr(states[i:i + 1]), ptr(e))
+        assert np.array_equal(got[i], e), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lw,lh", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (2, 4), (5, 3)])
+def test_hip_rdoq_with_device_estimates_vs_oracle(lw, lh):
+    """the loop the reference closes per CU: coder state -> xeve_rdoq_bit_est -> RDOQ, estimates picked per block on the device"""
+    import torch
+
+    import xeve_amd
+    from _libs import EST_FULL_INTS, oracle_sbac
+    from _sbac_cases import make_states
+    from xeve_amd import device as D
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    O, OS = oracle_rdoq(), oracle_sbac()
+    r = np.random.default_rng(3300 + lw * 8 + lh)
+    states = make_states(r, 9)
+    est_dev = D.rdoq_bit_est(torch.from_numpy(states.view(np.uint8).copy()).to(dev))
+    for ch_type in range(3):
+        for is_intra in (0, 1):
+            bd, qp = int(r.choice([8, 10])), int(r.integers(14, 48))
+            lam = float(r.choice([0.9, 11.3, 140.5])) * (1.0 + float(r.random()))
+            blocks = np.stack([make_coef(r, lw, lh, bd, k % 4) for k in range(41)])
+            idx = r.integers(0, len(states), size=len(blocks)).astype(np.int32)
+            d = torch.from_numpy(blocks.copy()).to(dev)
+            nnz = D.rdoq_dev(d, lw, lh, qp, lam, ch_type, bd, est_dev, torch.from_numpy(idx).to(dev), zero_test=True, is_intra_slice=bool(is_intra)).cpu().numpy()
+            got = d.cpu().numpy()
+            qs = D.QUANT_SCALE[0][qp % 6]
+            for b in range(len(blocks)):
+                full = np.zeros(EST_FULL_INTS, np.int32)
+                OS.xo_rdoq_bit_est(ptr(states[idx[b]:idx[b] + 1]), ptr(full))
+                est = RdoqEst()
+                OS.xo_rdoq_est_select(ptr(full), ch_type, is_intra, C.byref(est))
+                e = blocks[b].copy()
+                if O.xo_rdoq_zero_test(ptr(e), lw, lh, qp, qs, is_intra, bd):
+                    en = O.xo_rdoq(ptr(e), lw, lh, qp, lam, int(ch_type == 0), bd, 0, C.byref(est))
+                else:
+                    e[:], en = 0, 0
+                assert nnz[b] == en and np.array_equal(got[b], e), (lw, lh, ch_type, is_intra, b)
+            # record 0 for every block when no index is given
+            d2 = torch.from_numpy(blocks.copy()).to(dev)
+            nnz2 = D.rdoq_dev(d2, lw, lh, qp, lam, ch_type, bd, est_dev, None, zero_test=False, is_intra_slice=bool(is_intra)).cpu().numpy()
+            full = np.zeros(EST_FULL_INTS, np.int32)
+            OS.xo_rdoq_bit_est(ptr(states[0:1]), ptr(full))
+            est = RdoqEst()
+            OS.xo_rdoq_est_select(ptr(full), ch_type, is_intra, C.byref(est))
+            for b in range(0, len(blocks), 5):
+                e = blocks[b].copy()
+                assert nnz2[b] == O.xo_rdoq(ptr(e), lw, lh, qp, lam, int(ch_type == 0), bd, 0, C.byref(est)) and np.array_equal(d2[b].cpu().numpy(), e)

@@ -71,3 +71,20 @@ def test_cu_bits(slice_type, num_refp, cm_init, idc):
                 bb = R.refdrv_cu_bits(ptr(states), ptr(b), p, ptr(jobs[i:i + 1]), ptr(coef))
                 assert ba == bb, (lw, lh, i, jobs[i])
                 same(a, b)
+
+
+def test_rdoq_bit_est_and_entropy_table():
+    """xo_rdoq_bit_est == the reference's static xeve_rdoq_bit_est on the same coder state; entropy_bits table identical"""
+    from _libs import EST_FULL_INTS
+
+    O, R = oracle_sbac(), ref_sbac()
+    tab = np.zeros(1024, np.int32)
+    R.refdrv_entropy_bits(ptr(tab))
+    assert [O.xo_entropy_bits(i) for i in range(1024)] == tab.tolist()
+    r = np.random.default_rng(21)
+    st = make_states(r, 200)
+    for i in range(len(st)):
+        a, b = np.zeros(EST_FULL_INTS, np.int32), np.zeros(EST_FULL_INTS, np.int32)
+        O.xo_rdoq_bit_est(ptr(st[i:i + 1]), ptr(a))
+        R.refdrv_rdoq_bit_est(ptr(st[i:i + 1]), ptr(b))
+        assert np.array_equal(a, b), i

@@ -16,21 +16,29 @@
 #include <mutex>
 #include "xh_common.h"
 
+// the twelve estimates one component uses in Baseline: run / level models c, c + 1 (c = 0 luma, 2 chroma), the last-flag
+// model of the component and the cbf pair (xeve_rdoq_set_ctx_cc, xeve_tq.c:492-495; cbf choice :565-583)
+struct Est12 {
+    int run[2][2], level[2][2], last[2], cbf[2];
+};
 struct RdoqK {
-    int  n, log2n, q_value, q_bits, c, ctx_last;
+    int  n, log2n, q_value, q_bits;
     long lambda, err_scale;
     long z_scale, z_thr; // zero pre-test of xeve_quant_nnz (xeve_tq.c:666-699); z_thr < 0: off
-    xeve_hip_rdoq_est est;
+    Est12 est;           // uniform estimates (host parameter) ...
+    // ... or per block from device memory: record est_dev[est_idx[b]] of xeve_hip_rdoq_est_full, fields at these int offsets
+    const int *est_dev, *est_idx;
+    int        o_run, o_level, o_last, o_cbf;
 };
 
-__device__ __forceinline__ long rl_cost(unsigned abs_level, int rs, const RdoqK &P)
+__device__ __forceinline__ long rl_cost(unsigned abs_level, int rs, const RdoqK &P, const Est12 &E)
 {
     unsigned rate;
-    if(abs_level == 0) rate = (unsigned)P.est.run[P.c + rs][1];
+    if(abs_level == 0) rate = (unsigned)E.run[rs][1];
     else {
-        rate = 32768u + (unsigned)P.est.run[P.c + rs][0];
-        if(abs_level == 1) rate += (unsigned)P.est.level[P.c][0];
-        else rate += (unsigned)P.est.level[P.c][1] + (unsigned)P.est.level[P.c + 1][1] * (abs_level - 2) + (unsigned)P.est.level[P.c + 1][0];
+        rate = 32768u + (unsigned)E.run[rs][0];
+        if(abs_level == 1) rate += (unsigned)E.level[0][0];
+        else rate += (unsigned)E.level[0][1] + (unsigned)E.level[1][1] * (abs_level - 2) + (unsigned)E.level[1][0];
     }
     return (long)(int)rate * P.lambda; // s32 rate as the reference, then GET_I_COST
 }
@@ -43,7 +51,7 @@ struct Cand {
     unsigned maxabs;
     int      neg;
 };
-__device__ __forceinline__ Cand eval_coef(int v, const RdoqK &P)
+__device__ __forceinline__ Cand eval_coef(int v, const RdoqK &P, const Est12 &E)
 {
     Cand c;
     const long t = (long)(v < 0 ? -v : v) * P.q_value, cap = (long)INT32_MAX - (1L << (P.q_bits - 1));
@@ -55,10 +63,10 @@ __device__ __forceinline__ Cand eval_coef(int v, const RdoqK &P)
     const unsigned lo = m > 1 ? m - 1 : 1;
 #pragma unroll
     for(int rs = 0; rs < 2; rs++) {
-        long coded = c.unc + rl_cost(0, rs, P);
+        long coded = c.unc + rl_cost(0, rs, P, E);
         unsigned best = 0;
         for(unsigned a = m; a >= lo; a--) {
-            const long dd = ld - ((long)a << P.q_bits), e2 = (dd * P.err_scale) >> 20, cost = e2 * e2 + rl_cost(a, rs, P);
+            const long dd = ld - ((long)a << P.q_bits), e2 = (dd * P.err_scale) >> 20, cost = e2 * e2 + rl_cost(a, rs, P, E);
             if(cost < coded) best = a, coded = cost;
         }
         c.lev[rs] = best, c.d[rs] = coded - c.unc;
@@ -82,7 +90,7 @@ __device__ __forceinline__ int fcompose(int later, int earlier) { return ((later
 
 // LPB = lanes per block: 64 normally; 16 for n <= 16 (4x4 chroma of an 8x8 CU), where four blocks share one wave and
 // every wave-level scan / reduction below is segmented to LPB lanes (WPB must be 1 then).
-template <int K, int WPB, int LPB = 64>
+template <int K, int WPB, int LPB = 64, bool DEV = false>
 __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nblk, RdoqK P, const uint16_t *__restrict__ scan,
                                               int32_t *__restrict__ nnz_out)
 {
@@ -97,6 +105,15 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     const bool live = b < nblk;
     int16_t *blk = coef + (size_t)(live ? b : 0) * P.n;
     const int w0 = (wave / WPB) * WPB; // first wave of my block in the s_* arrays
+    Est12 E = P.est;
+    if(DEV) { // this block's estimates (xeve_rdoq_bit_est of the coder state its CU starts from)
+        const int *rec = P.est_dev + (size_t)(sizeof(xeve_hip_rdoq_est_full) / sizeof(int)) * (P.est_idx ? P.est_idx[live ? b : 0] : 0);
+#pragma unroll
+        for(int i = 0; i < 2; i++)
+#pragma unroll
+            for(int j = 0; j < 2; j++) E.run[i][j] = rec[P.o_run + 2 * i + j], E.level[i][j] = rec[P.o_level + 2 * i + j];
+        E.last[0] = rec[P.o_last], E.last[1] = rec[P.o_last + 1], E.cbf[0] = rec[P.o_cbf], E.cbf[1] = rec[P.o_cbf + 1];
+    }
 
     // ---- phase 1: candidates of my K consecutive scan positions
     unsigned lev0[K], lev1[K];
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
         int v = 0;
         if(live && p < P.n) v = blk[scan[p]];
         zhit |= ((long)(v < 0 ? -v : v) * P.z_scale) >= P.z_thr;
-        const Cand c = eval_coef(v, P);
+        const Cand c = eval_coef(v, P, E);
         lev0[i] = c.lev[0], lev1[i] = c.lev[1], d0[i] = c.d[0], d1[i] = c.d[1], neg[i] = c.neg;
         if(p < P.n) {
             unc_sum += c.unc, sum_all += (int)c.maxabs;
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     __syncthreads();
 
     // ---- phase 3: resolve my chunk, running base cost
-    const long lz = (long)P.est.last[P.ctx_last][0] * P.lambda, lone = (long)P.est.last[P.ctx_last][1] * P.lambda;
+    const long lz = (long)E.last[0] * P.lambda, lone = (long)E.last[1] * P.lambda;
     unsigned lev[K];
     long     inc[K], dsel[K];
     long     chunk = 0;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
     }
     if(LPB == 64 && lane == 63) s_long[wave][1] = incl_sum;
     __syncthreads();
-    long base = unc_sum + (long)P.est.cbf[1] * P.lambda + (incl_sum - chunk); // d64_base_cost before my chunk
+    long base = unc_sum + (long)E.cbf[1] * P.lambda + (incl_sum - chunk); // d64_base_cost before my chunk
     for(int i = 0; i < wib; i++) base += s_long[w0 + i][1];
     // best "I am last" candidate of my chunk: strictly smaller cost wins, earlier position on ties
     long best_cost = 0x7fffffffffffffffL;
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
         for(int i = 1; i < WPB; i++)
             if(s_long[w0 + i][2] < best_cost || (s_long[w0 + i][2] == best_cost && s_int[w0 + i][2] < best_pos)) best_cost = s_long[w0 + i][2], best_pos = s_int[w0 + i][2];
     }
-    const long best0 = unc_sum + (long)P.est.cbf[0] * P.lambda; // d64_best_cost: "code nothing"
+    const long best0 = unc_sum + (long)E.cbf[0] * P.lambda; // d64_best_cost: "code nothing"
     const int best_last = (sum_all != 0 && best_cost < best0) ? best_pos + 1 : 0;
 
     // ---- phase 4: levels out
@@ -262,12 +279,27 @@ extern "C" int xeve_hip_rdoq(int16_t *coef, int nblk, int log2w, int log2h, int 
     return xeve_hip_rdoq_zt(coef, nblk, log2w, log2h, qp, lambda, is_luma, bit_depth, tool_iqt, est, 0, 0, nnz, stream);
 }
 
-extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
-                                const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream)
+// common launcher: est != NULL -> uniform estimates; otherwise per block from est_dev / est_idx
+template <bool DEV> static void rdoq_launch(int16_t *coef, int nblk, const RdoqK &P, const uint16_t *scan, int32_t *nnz, hipStream_t st)
+{
+    const int n = P.n;
+    if(n <= 16) k_rdoq<1, 1, 16, DEV><<<(nblk + 15) / 16, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n <= 64) k_rdoq<1, 1, 64, DEV><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 128) k_rdoq<2, 1, 64, DEV><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 256) k_rdoq<1, 4, 64, DEV><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 512) k_rdoq<2, 4, 64, DEV><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 1024) k_rdoq<4, 4, 64, DEV><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else if(n == 2048) k_rdoq<8, 4, 64, DEV><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    else k_rdoq<16, 4, 64, DEV><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+}
+
+static int rdoq_common(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
+                       const xeve_hip_rdoq_est *est, const xeve_hip_rdoq_est_full *est_dev, const int32_t *est_idx, int zero_test,
+                       int is_intra_slice, int32_t *nnz, void *stream)
 {
     XH_ENTER();
-    XH_REQUIRE(coef && est && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
-    XH_REQUIRE(qp >= 0 && qp <= 63 && bit_depth >= 8 && bit_depth <= 14 && (tool_iqt == 0 || tool_iqt == 1));
+    XH_REQUIRE(coef && (est || est_dev) && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
+    XH_REQUIRE(qp >= 0 && qp <= 63 && bit_depth >= 8 && bit_depth <= 14 && (tool_iqt == 0 || tool_iqt == 1) && ch_type >= 0 && ch_type <= 2);
     if(nblk == 0) return XEVE_HIP_OK;
     const uint16_t *scan;
     int rc = xh_get_scan(log2w, log2h, &scan);
@@ -279,7 +311,7 @@ extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, i
     P.q_value = (k_quant_scale[tool_iqt][qp % 6] * ns_scale + ns_offset) >> ns_shift;
     P.q_bits  = 14 + (15 - bit_depth - log2_size) + qp / 6;
     XH_REQUIRE(P.q_bits >= 1 && P.q_bits <= 30);
-    P.c = is_luma ? 0 : 2, P.ctx_last = is_luma ? 0 : 1;
+    const int c = ch_type == 0 ? 0 : 2, ctx_last = ch_type == 0 ? 0 : 1; // xeve_rdoq_set_ctx_cc with sps_cm_init_flag 0 (xeve_tq.c:492-495)
     P.lambda = (long)(lambda * (double)(1 << 15) + 0.5); // SCALE_BITS, xeve_tq.c:528
     { // ctx->err_scale[qp % 6][log2_size - 1], xeve_init_err_scale (xeve_tq.c:406-423)
         const int tr_shift = 15 - bit_depth - log2_size;
@@ -293,17 +325,87 @@ extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, i
         P.z_thr      = (1L << zs) - ((long)(is_intra_slice ? 201 : 153) << (zs - 9));
     }
     else P.z_scale = 0, P.z_thr = -1;
-    P.est = *est;
+    memset(&P.est, 0, sizeof(P.est));
+    P.est_dev = nullptr, P.est_idx = nullptr, P.o_run = P.o_level = P.o_last = P.o_cbf = 0;
     hipStream_t st = (hipStream_t)stream;
-    const int n = P.n;
-    if(n <= 16) k_rdoq<1, 1, 16><<<(nblk + 15) / 16, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n <= 64) k_rdoq<1, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n == 128) k_rdoq<2, 1><<<(nblk + 3) / 4, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n == 256) k_rdoq<1, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n == 512) k_rdoq<2, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n == 1024) k_rdoq<4, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else if(n == 2048) k_rdoq<8, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
-    else k_rdoq<16, 4><<<nblk, 256, 0, st>>>(coef, nblk, P, scan, nnz);
+    if(est) {
+        for(int i = 0; i < 2; i++)
+            for(int j = 0; j < 2; j++) P.est.run[i][j] = est->run[c + i][j], P.est.level[i][j] = est->level[c + i][j];
+        P.est.last[0] = est->last[ctx_last][0], P.est.last[1] = est->last[ctx_last][1], P.est.cbf[0] = est->cbf[0], P.est.cbf[1] = est->cbf[1];
+        rdoq_launch<false>(coef, nblk, P, scan, nnz, st);
+    }
+    else { // int offsets of the fields inside xeve_hip_rdoq_est_full; cbf pair as xeve_tq.c:565-583 picks it
+        P.est_dev = (const int *)est_dev, P.est_idx = est_idx;
+        P.o_run   = (int)(offsetof(xeve_hip_rdoq_est_full, run) / sizeof(int)) + 2 * c;
+        P.o_level = (int)(offsetof(xeve_hip_rdoq_est_full, level) / sizeof(int)) + 2 * c;
+        P.o_last  = (int)(offsetof(xeve_hip_rdoq_est_full, last) / sizeof(int)) + 2 * ctx_last;
+        const size_t o = (!is_intra_slice && ch_type == 0) ? offsetof(xeve_hip_rdoq_est_full, cbf_all)
+                         : ch_type == 0                   ? offsetof(xeve_hip_rdoq_est_full, cbf_luma)
+                         : ch_type == 1                   ? offsetof(xeve_hip_rdoq_est_full, cbf_cb)
+                                                          : offsetof(xeve_hip_rdoq_est_full, cbf_cr);
+        P.o_cbf = (int)(o / sizeof(int));
+        rdoq_launch<true>(coef, nblk, P, scan, nnz, st);
+    }
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int is_luma, int bit_depth, int tool_iqt,
+                                const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream)
+{
+    XH_REQUIRE(est);
+    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, is_luma ? 0 : 1, bit_depth, tool_iqt, est, nullptr, nullptr, zero_test, is_intra_slice, nnz, stream);
+}
+
+extern "C" int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
+                                 const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int32_t *nnz,
+                                 void *stream)
+{
+    XH_REQUIRE(est);
+    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, nullptr, est, est_idx, zero_test, is_intra_slice, nnz, stream);
+}
+
+// ---- xeve_rdoq_bit_est (xeve_mode.c:326-372): estimates from a coder state ----------------------------------------------
+static int *g_entropy; // entropy_bits[1024] of xeve_init_bits_est (xeve_mode.c:304-313), device copy
+static std::mutex g_entropy_mu;
+
+__global__ void k_rdoq_bit_est(const xeve_hip_sbac *__restrict__ sbac, int n, const int *__restrict__ entropy, int *__restrict__ out)
+{
+    // one thread per (state, model): biari_no_bits for bin 0 and 1 (xeve_mode.c:315-324)
+    constexpr int NM = sizeof(xeve_hip_rdoq_est_full) / sizeof(int) / 2; // 54 models
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n * NM) return;
+    const int s = i / NM, m = i % NM;
+    // order of xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr, run[24], level[24], last[2]
+    const int ci = m == 0 ? XEVE_HIP_CTX_CBF_ALL : m == 1 ? XEVE_HIP_CTX_CBF_LUMA : m == 2 ? XEVE_HIP_CTX_CBF_CB : m == 3 ? XEVE_HIP_CTX_CBF_CR
+                   : m < 28 ? XEVE_HIP_CTX_RUN + (m - 4) : m < 52 ? XEVE_HIP_CTX_LEVEL + (m - 28) : XEVE_HIP_CTX_LAST + (m - 52);
+    const unsigned cm = sbac[s].ctx[ci], mps = cm & 1, state = cm >> 1;
+#pragma unroll
+    for(unsigned b = 0; b < 2; b++) out[(size_t)s * 2 * NM + 2 * m + b] = entropy[((b != mps) ? state : 512 - state) << 1];
+}
+
+extern "C" int xeve_hip_rdoq_bit_est(const xeve_hip_sbac *sbac, int nstates, xeve_hip_rdoq_est_full *est, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(nstates >= 0);
+    if(nstates == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(sbac && est);
+    {
+        std::lock_guard<std::mutex> lk(g_entropy_mu);
+        if(!g_entropy) {
+            int h[1024];
+            for(int i = 0; i < 1024; i++) {
+                const double p = (512 * (i + 0.5)) / 1024;
+                h[i] = (int)(-32768 * (log(p) / log(2.0) - 9));
+            }
+            int *d = nullptr;
+            XH_HIP(hipMalloc((void **)&d, sizeof(h)));
+            XH_HIP(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+            g_entropy = d;
+        }
+    }
+    const int total = nstates * (int)(sizeof(xeve_hip_rdoq_est_full) / sizeof(int) / 2);
+    k_rdoq_bit_est<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(sbac, nstates, g_entropy, (int *)est);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -181,6 +181,24 @@ def rdoq(coef, log2w, log2h, qp, lam, is_luma, bit_depth, est, tool_iqt=0, nnz=N
     return nnz
 
 
+def rdoq_bit_est(sbac):
+    """xeve_rdoq_bit_est for an array of coder states (uint8 tensor of lib.SBAC_DTYPE records) -> int32 [n, 108] (xeve_hip_rdoq_est_full)"""
+    n = sbac.numel() // 172
+    est = torch.empty((n, _lib.EST_FULL_INTS), dtype=torch.int32, device=sbac.device)
+    _lib.check(_lib.load().xeve_hip_rdoq_bit_est(_ptr(sbac), n, _ptr(est), _stream()))
+    return est
+
+
+def rdoq_dev(coef, log2w, log2h, qp, lam, ch_type, bit_depth, est, est_idx=None, zero_test=False, is_intra_slice=False, tool_iqt=0, nnz=None):
+    """RDOQ with per-block estimates from device memory (xeve_hip_rdoq_dev): est = rdoq_bit_est(...), est_idx int32 [nblk] or None"""
+    if nnz is None:
+        nnz = torch.empty(coef.shape[0], dtype=torch.int32, device=coef.device)
+    _lib.check(_lib.load().xeve_hip_rdoq_dev(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, qp, float(lam), int(ch_type), bit_depth, tool_iqt,
+                                             _ptr(est), _ptr(est_idx) if est_idx is not None else None, int(zero_test), int(is_intra_slice),
+                                             _ptr(nnz), _stream()))
+    return nnz
+
+
 def cu_bits_jobs(coef, sbac_in, jobs, params, want_state=True, workspace=None, bits=None, sbac_out=None):
     """CABAC bit count of inter-CU jobs (xeve_hip_cu_bits_jobs).  coef: flat int16 tensor; sbac_in / jobs: uint8 tensors holding
     arrays of lib.SBAC_DTYPE / lib.CU_BITS_JOB_DTYPE records; params: lib.CuBitsParams.  Returns (bits u32-as-int32 [njobs],

@@ -44,6 +44,7 @@ class CuBitsParams(C.Structure):  # xeve_hip_cu_bits_params
                 ("cm_init", C.c_int32), ("chroma_format_idc", C.c_int32)]
 
 
+EST_FULL_INTS = 108  # xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr [2] each, run[24][2], level[24][2], last[2][2]
 SBAC_NCTX = 68
 SBAC_DTYPE = [("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"), ("pending_byte", "<u4"),
               ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"), ("ctx", "<u2", (SBAC_NCTX,))]  # xeve_hip_sbac (172 B)
@@ -106,6 +107,9 @@ FUNCTIONS = {
     "xeve_hip_me_epzs_workspace": (C.c_size_t, [c_int]),
     "xeve_hip_me_epzs_jobs": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_rdoq_bit_est": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "xeve_hip_rdoq_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),

@@ -52,16 +52,29 @@ def diamond_pattern():
 
 
 class HotPathPass:
-    def __init__(self, width, height, device, seed=4, bit_depth=10, qp=32, sizes=SIZES):
+    def __init__(self, width, height, device, seed=4, bit_depth=10, qp=32, sizes=SIZES, content="iid"):
         assert width % 64 == 0 and height % 8 == 0
         self.W, self.H, self.dev, self.bd, self.qp, self.sizes = width, height, device, bit_depth, qp, tuple(sizes)
         self.s_l, self.s_c = width + 2 * PAD_L, width // 2 + 2 * PAD_C
         g = torch.Generator(device=device).manual_seed(seed)
-        mk = lambda h, s: torch.randint(0, 1 << bit_depth, (h, s), generator=g, device=device, dtype=torch.int16)
         hl, hc = height + 2 * PAD_L, height // 2 + 2 * PAD_C
-        # synthetic i.i.d. uniform picture planes (8-bit source << 2 in the reference; here uniform 10-bit)
-        self.org = [mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)]
-        self.ref = [[mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)] for _ in range(N_LIST)]
+        self.content = content
+        if content == "iid":
+            # synthetic i.i.d. uniform picture planes (8-bit source << 2 in the reference; here uniform 10-bit)
+            mk = lambda h, s: torch.randint(0, 1 << bit_depth, (h, s), generator=g, device=device, dtype=torch.int16)
+            self.org = [mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)]
+            self.ref = [[mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)] for _ in range(N_LIST)]
+        else:
+            # SURVEY.md 8(d)'s structured input: a moving gradient + 3-bit noise, ((x + 3f) * 2 + (y + f) + rand3) & 255 as an
+            # 8-bit source (<< 2).  The current picture is frame 1, list 0 holds frame 0, list 1 frame 2, so the true motion
+            # is (+3, +1) / (-3, -1) luma samples and phase D predicts as well as real video does.
+            def frame(f, h, s, pad, sub):
+                y = (torch.arange(h, device=device) - pad)[:, None] * sub
+                x = (torch.arange(s, device=device) - pad)[None, :] * sub
+                n = torch.randint(0, 8, (h, s), generator=g, device=device)
+                return ((((x + 3 * f) * 2 + (y + f) + n) & 255) << (bit_depth - 8)).to(torch.int16)
+            planes = lambda f: [frame(f, hl, self.s_l, PAD_L, 1), frame(f, hc, self.s_c, PAD_C, 2), frame(f, hc, self.s_c, PAD_C, 2)]
+            self.org, self.ref = planes(1), [planes(0), planes(2)]
         # alignment copies of the luma reference planes (xeve_hip_sad_jobs_dual): made once per reference picture
         self.ref_s1 = [D.plane_shift1(r[0]) for r in self.ref]
         self.pattern = diamond_pattern()
@@ -129,8 +142,10 @@ class HotPathPass:
                 per.append(D.make_mc_jobs(gx, gy, dense, frac, dev))
             lv["hp_jobs"].append(per)
         # C/D: quarter-pel motion for merge candidates and the final bi-prediction (any of the 16 phases)
-        def qpel_jobs():
+        def qpel_jobs(true_motion=None):
             mvx, mvy = rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, n), rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, n)  # 1/4 pel
+            if true_motion is not None:
+                mvx, mvy = np.full(n, true_motion[0]), np.full(n, true_motion[1])
             gx, gy = (PAD_L + xs) * 16 + mvx * 4, (PAD_L + ys) * 16 + mvy * 4
             fl = ((gx & 15) != 0).astype(np.int32) | (((gy & 15) != 0).astype(np.int32) << 1)
             # chroma position in 1/32 pel = luma 1/16-pel position relative to the chroma plane origin (xeve_mc.c:487-488)
@@ -145,7 +160,7 @@ class HotPathPass:
         lv["ssd1"] = torch.empty(n, dtype=torch.int64, device=dev)
         lv["merge_jobs"] = [qpel_jobs() for _ in range(N_MERGE)]
         lv["merge_jobs_org"] = [(with_org_off(jl, lv["off_l"]), with_org_off(jc, lv["off_c"])) for jl, jc in lv["merge_jobs"]]
-        lv["final_jobs"] = [qpel_jobs() for _ in range(N_LIST)]
+        lv["final_jobs"] = [qpel_jobs(None if self.content == "iid" else ((12, 4), (-12, -4))[l]) for l in range(N_LIST)]
         lv["resi"] = [torch.empty((n, S * S), dtype=torch.int16, device=dev)] + [torch.empty((n, Sc * Sc), dtype=torch.int16, device=dev) for _ in range(2)]
         # quantised levels of Y, U, V in ONE buffer (the bit-count jobs address all three components of a CU by offset)
         flat = torch.empty(n * (S * S + 2 * Sc * Sc), dtype=torch.int16, device=dev)
