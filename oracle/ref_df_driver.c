@@ -1,0 +1,80 @@
+/*
+ * oracle/ref_df_driver.c -- TEST INFRASTRUCTURE (build container only; output oracle/_ref/libref_df.so).
+ * Runs the reference's own in-loop deblocking driver on caller-supplied planes and maps: the loop of xeve_loop_filter
+ * (src_base/xeve_enc.c:2355-2415: both edge directions, vertical edges first, COD bits cleared before each) around the
+ * real xeve_deblock -> xeve_deblock_tree -> xeve_deblock_unit -> xeve_deblock_cu_ver / _cu_hor (src_base/xeve_df.c).
+ * The CTU split_mode arrays xeve_deblock_tree reads are filled with the reference's own xeve_set_split_mode /
+ * xeve_split_get_part_structure from the CU sizes recorded in map_cu_mode.  Also wraps xeve_picbuf_expand.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "xeve_type.h"
+#include "xeve_df.h"
+
+typedef struct {
+    int w, h, w_scu, h_scu, log2_max_cuwh, bit_depth_luma, bit_depth_chroma, chroma_format_idc, qp_u_offset, qp_v_offset;
+    int qp_chroma[2][100];
+} drv_df_params;
+
+static void set_tree(XEVE_CTX *ctx, int lcu, int x, int y, int cuw, int cud, int cup)
+{
+    int t = (x >> MIN_CU_LOG2) + (y >> MIN_CU_LOG2) * ctx->w_scu;
+    int split = (1 << MCU_GET_LOGW(ctx->map_cu_mode[t])) < cuw;
+    xeve_set_split_mode(split ? SPLIT_QUAD : NO_SPLIT, cud, cup, cuw, cuw, ctx->max_cuwh, ctx->map_cu_data[lcu].split_mode);
+    if(split) {
+        XEVE_SPLIT_STRUCT ss;
+        xeve_split_get_part_structure(SPLIT_QUAD, x, y, cuw, cuw, cup, cud, ctx->log2_culine, &ss);
+        for(int k = 0; k < ss.part_count; k++)
+            if(ss.x_pos[k] < ctx->w && ss.y_pos[k] < ctx->h) set_tree(ctx, lcu, ss.x_pos[k], ss.y_pos[k], ss.width[k], ss.cud[k], ss.cup[k]);
+    }
+}
+
+int refdrv_deblock_picture(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_scu, u32 *map_cu_mode, s8 *map_refi, s16 *map_mv,
+                           const drv_df_params *p)
+{
+    XEVE_CTX  *ctx  = calloc(1, sizeof(*ctx));
+    XEVE_CORE *core = calloc(1, sizeof(*core));
+    XEVE_PIC   pic;
+    XEVE_SH    sh;
+    XEVE_TILE  tile;
+    int        ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
+    memset(&pic, 0, sizeof(pic)), memset(&sh, 0, sizeof(sh)), memset(&tile, 0, sizeof(tile));
+    ctx->w = p->w, ctx->h = p->h, ctx->w_scu = p->w_scu, ctx->h_scu = p->h_scu, ctx->f_scu = p->w_scu * p->h_scu;
+    ctx->log2_max_cuwh = p->log2_max_cuwh, ctx->max_cuwh = 1 << p->log2_max_cuwh;
+    ctx->log2_culine = p->log2_max_cuwh - MIN_CU_LOG2;
+    ctx->w_lcu = (p->w + ctx->max_cuwh - 1) >> p->log2_max_cuwh, ctx->h_lcu = (p->h + ctx->max_cuwh - 1) >> p->log2_max_cuwh;
+    ctx->f_lcu = ctx->w_lcu * ctx->h_lcu;
+    ctx->map_scu = map_scu, ctx->map_cu_mode = map_cu_mode, ctx->map_refi = (void *)map_refi, ctx->map_mv = (void *)map_mv;
+    ctx->map_unrefined_mv = calloc(ctx->f_scu, sizeof(s16) * REFP_NUM * MV_D);
+    ctx->map_tidx = calloc(ctx->f_scu, 1);
+    ctx->map_cu_data = calloc(ctx->f_lcu, sizeof(XEVE_CU_DATA));
+    ctx->tile = &tile, tile.ctba_rs_first = 0, tile.w_ctb = ctx->w_lcu, tile.h_ctb = ctx->h_lcu;
+    ctx->sh = &sh, sh.qp_u_offset = p->qp_u_offset, sh.qp_v_offset = p->qp_v_offset;
+    ctx->sps.bit_depth_luma_minus8 = p->bit_depth_luma - 8, ctx->sps.bit_depth_chroma_minus8 = p->bit_depth_chroma - 8;
+    ctx->sps.chroma_format_idc = p->chroma_format_idc;
+    ctx->param.codec_bit_depth = p->bit_depth_chroma;
+    for(int c = 0; c < 2; c++) {
+        memcpy(ctx->qp_chroma_dynamic_ext[c], p->qp_chroma[c], sizeof(int) * 100);
+        ctx->qp_chroma_dynamic[c] = &ctx->qp_chroma_dynamic_ext[c][6 * (p->bit_depth_chroma - 8)]; /* xeve_util.c:1845-1846 */
+    }
+    ctx->fn_deblock_tree = xeve_deblock_tree, ctx->fn_deblock_unit = xeve_deblock_unit;
+    pic.y = y, pic.u = u, pic.v = v, pic.s_l = s_l, pic.s_c = s_c, pic.w_l = p->w, pic.h_l = p->h, pic.w_c = p->w >> ws, pic.h_c = p->h >> hs;
+    for(int ly = 0; ly < ctx->h_lcu; ly++)
+        for(int lx = 0; lx < ctx->w_lcu; lx++) set_tree(ctx, ly * ctx->w_lcu + lx, lx << p->log2_max_cuwh, ly << p->log2_max_cuwh, ctx->max_cuwh, 0, 0);
+    core->ctx = ctx;
+    for(int is_hor_edge = 0; is_hor_edge <= 1; is_hor_edge++) { /* xeve_loop_filter, one slice, one tile */
+        for(u32 i = 0; i < ctx->f_scu; i++) MCU_CLR_COD(ctx->map_scu[i]);
+        core->deblock_is_hor = is_hor_edge;
+        xeve_deblock(ctx, &pic, 0, 0, core);
+    }
+    free(ctx->map_unrefined_mv), free(ctx->map_tidx), free(ctx->map_cu_data), free(ctx), free(core);
+    return 0;
+}
+
+void refdrv_picbuf_expand(pel *y, pel *u, pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l, int exp_c, int chroma_format_idc)
+{
+    XEVE_PIC pic;
+    memset(&pic, 0, sizeof(pic));
+    pic.y = y, pic.u = u, pic.v = v, pic.s_l = s_l, pic.s_c = s_c, pic.w_l = w_l, pic.h_l = h_l, pic.w_c = w_c, pic.h_c = h_c;
+    xeve_picbuf_expand(&pic, exp_l, exp_c, chroma_format_idc);
+}

@@ -961,3 +961,143 @@ void xo_rdoq_est_select(const xo_rdoq_est_full *f, int ch_type, int is_intra, xo
     memcpy(e->level, f->level, sizeof(e->level));
     memcpy(e->last, f->last, sizeof(e->last));
 }
+
+/* ===================================================================================================================
+ * Deblocking filter and picture padding -- reference: src_base/xeve_df.c, src_base/xeve_util.c:190-248
+ * =================================================================================================================== */
+const uint8_t xo_df_st[4][52] = { /* xeve_tbl.c:239-257: intra; luma cbf; mv difference >= 4 / other reference; no filtering */
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 12, 12, 12, 12, 12},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 11, 11, 11, 11},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10, 10},
+    {0}};
+
+#define SCU_IF(m)   (((m) >> 15) & 1)
+#define SCU_QP(m)   (((m) >> 16) & 0x7F)
+#define SCU_CBFL(m) (((m) >> 24) & 1)
+#define SCU_IBC(m)  (((m) >> 26) & 1)
+#define SCU_COD(m)  (((m) >> 31) & 1)
+
+/* get_tbl_qp_to_st (xeve_df.c:34-87): filter strength class of the edge between two 4x4 units */
+static int df_class(uint32_t m0, uint32_t m1, const int8_t *r0, const int8_t *r1, const int16_t *mv0, const int16_t *mv1)
+{
+    if(SCU_IF(m0) || SCU_IF(m1)) return 0;
+    if(SCU_CBFL(m0) == 1 || SCU_CBFL(m1) == 1) return 1;
+    if(SCU_IBC(m0) || SCU_IBC(m1)) return 2;
+    int a0[2] = {mv0[0], mv0[1]}, a1[2] = {mv0[2], mv0[3]}, b0[2] = {mv1[0], mv1[1]}, b1[2] = {mv1[2], mv1[3]};
+    if(r0[0] < 0) a0[0] = a0[1] = 0;
+    if(r0[1] < 0) a1[0] = a1[1] = 0;
+    if(r1[0] < 0) b0[0] = b0[1] = 0;
+    if(r1[1] < 0) b1[0] = b1[1] = 0;
+    if(r0[0] == r1[0] && r0[1] == r1[1])
+        return (iabs(a0[0] - b0[0]) >= 4 || iabs(a0[1] - b0[1]) >= 4 || iabs(a1[0] - b1[0]) >= 4 || iabs(a1[1] - b1[1]) >= 4) ? 2 : 3;
+    if(r0[0] == r1[1] && r0[1] == r1[0])
+        return (iabs(a0[0] - b1[0]) >= 4 || iabs(a0[1] - b1[1]) >= 4 || iabs(a1[0] - b0[0]) >= 4 || iabs(a1[1] - b0[1]) >= 4) ? 2 : 3;
+    return 2;
+}
+
+/* deblock_scu_hor / _ver and their chroma forms (xeve_df.c:89-251): `n` samples along the edge (step `along`), the four
+ * samples A B | C D across it at -2, -1, 0, +1 times `across`; s16 arithmetic as the reference */
+static void df_edge(xo_pel *buf, int n, int along, int across, int st, int maxv, int chroma)
+{
+    if(!st) return;
+    for(int i = 0; i < n; i++, buf += along) {
+        int16_t A = buf[-2 * across], B = buf[-across], C = buf[0], D = buf[across];
+        int16_t d = (int16_t)((A - (B << 2) + (C << 2) - D) / 8);
+        int16_t abs = (int16_t)((d ^ (d >> 15)) - (d >> 15)), sign = d < 0;
+        int16_t t16 = (int16_t)(((abs - st) << 1) > 0 ? ((abs - st) << 1) : 0);
+        int16_t clip = (int16_t)((abs - t16) > 0 ? (abs - t16) : 0);
+        int16_t d1 = (int16_t)(sign ? -clip : clip);
+        if(!chroma) {
+            clip >>= 1;
+            int16_t d2 = (int16_t)clip3i(-clip, clip, (A - D) / 4);
+            A = (int16_t)(A - d2), D = (int16_t)(D + d2);
+            buf[-2 * across] = (xo_pel)clip3i(0, maxv, A), buf[across] = (xo_pel)clip3i(0, maxv, D);
+        }
+        B = (int16_t)(B + d1), C = (int16_t)(C - d1);
+        buf[-across] = (xo_pel)clip3i(0, maxv, B), buf[0] = (xo_pel)clip3i(0, maxv, C);
+    }
+}
+
+typedef struct df_ctx {
+    xo_pel *y, *u, *v;
+    int s_l, s_c, ws, hs;
+    uint32_t *map_scu;
+    const uint32_t *map_cu_mode;
+    const int8_t *refi;
+    const int16_t *mv;
+    const xo_deblock_params *p;
+} df_ctx;
+
+/* one 4-sample edge segment: luma + both chroma planes; `cur` = the unit whose QP is used, `nb` = the unit across the edge */
+static void df_segment(const df_ctx *c, int cur, int nb, int x, int y, int hor)
+{
+    const xo_deblock_params *p = c->p;
+    int cls = df_class(c->map_scu[cur], c->map_scu[nb], c->refi + 2 * cur, c->refi + 2 * nb, c->mv + 4 * cur, c->mv + 4 * nb);
+    int qp = SCU_QP(c->map_scu[cur]), bl = p->bit_depth_luma - 8, bc = p->bit_depth_chroma - 8;
+    xo_pel *py = c->y + y * c->s_l + x;
+    if(hor) df_edge(py, 4, 1, c->s_l, xo_df_st[cls][qp] << bl, (1 << p->bit_depth_luma) - 1, 0);
+    else df_edge(py, 4, c->s_l, 1, xo_df_st[cls][qp] << bl, (1 << p->bit_depth_luma) - 1, 0);
+    if(p->chroma_format_idc) {
+        int qu = clip3i(-6 * bc, 57, qp + p->qp_u_offset), qv = clip3i(-6 * bc, 57, qp + p->qp_v_offset);
+        int off = (y >> c->hs) * c->s_c + (x >> c->ws);
+        int st_u = xo_df_st[cls][p->qp_chroma[0][qu + 6 * bc]] << bc, st_v = xo_df_st[cls][p->qp_chroma[1][qv + 6 * bc]] << bc;
+        /* the reference sizes the chroma segment with the W shift for horizontal and the H shift for vertical edges (xeve_df.c:143,225) */
+        if(hor) df_edge(c->u + off, 4 >> c->ws, 1, c->s_c, st_u, (1 << p->bit_depth_chroma) - 1, 1), df_edge(c->v + off, 4 >> c->ws, 1, c->s_c, st_v, (1 << p->bit_depth_chroma) - 1, 1);
+        else df_edge(c->u + off, 4 >> c->hs, c->s_c, 1, st_u, (1 << p->bit_depth_chroma) - 1, 1), df_edge(c->v + off, 4 >> c->hs, c->s_c, 1, st_v, (1 << p->bit_depth_chroma) - 1, 1);
+    }
+}
+
+/* xeve_deblock_cu_hor (xeve_df.c:253-333) / xeve_deblock_cu_ver (:335-471) */
+static void df_cu(const df_ctx *c, int x, int y, int cuw, int cuh, int hor)
+{
+    int w_scu = c->p->w_scu, t = (x >> 2) + (y >> 2) * w_scu, w = cuw >> 2, h = cuh >> 2;
+    if(hor) {
+        if(y > 0)
+            for(int i = 0; i < w; i++) df_segment(c, t + i, t + i - w_scu, x + 4 * i, y, 1);
+    }
+    else {
+        if(x > 0 && SCU_COD(c->map_scu[t - 1]))
+            for(int i = 0; i < h; i++) df_segment(c, t + i * w_scu, t + i * w_scu - 1, x, y + 4 * i, 0);
+        if(x + cuw < c->p->w && SCU_COD(c->map_scu[t + w])) /* right neighbour already filtered in this pass */
+            for(int i = 0; i < h; i++) df_segment(c, t + i * w_scu + w, t + i * w_scu + w - 1, x + cuw, y + 4 * i, 0);
+    }
+    for(int j = 0; j < h; j++)
+        for(int i = 0; i < w; i++) c->map_scu[t + j * w_scu + i] |= 1u << 31;
+}
+
+/* xeve_deblock_tree (xeve_df.c:575-639): quad-tree walk; a node is a leaf when the CU recorded at its origin has its size */
+static void df_tree(const df_ctx *c, int x, int y, int size, int hor)
+{
+    int t = (x >> 2) + (y >> 2) * c->p->w_scu;
+    int logw = (c->map_cu_mode[t] >> 24) & 0xF;
+    if((1 << logw) < size) {
+        int hs = size >> 1;
+        for(int k = 0; k < 4; k++) {
+            int xs = x + (k & 1) * hs, ys = y + (k >> 1) * hs;
+            if(xs < c->p->w && ys < c->p->h) df_tree(c, xs, ys, hs, hor);
+        }
+    }
+    else df_cu(c, x, y, size, size, hor);
+}
+
+void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode,
+                        const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p)
+{
+    df_ctx c = {y, u, v, s_l, s_c, p->chroma_format_idc <= 2, p->chroma_format_idc <= 1, map_scu, map_cu_mode, map_refi, map_mv, p};
+    int ctu = 1 << p->log2_max_cuwh;
+    for(int hor = 0; hor <= 1; hor++) { /* xeve_loop_filter: vertical edges of the whole picture first */
+        for(int i = 0; i < p->w_scu * p->h_scu; i++) map_scu[i] &= 0x7FFFFFFFu;
+        for(int cy = 0; cy < p->h; cy += ctu)
+            for(int cx = 0; cx < p->w; cx += ctu) df_tree(&c, cx, cy, ctu, hor);
+    }
+}
+
+void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp)
+{   /* xeve_util.c:190-238 */
+    for(int i = 0; i < h; i++)
+        for(int j = 0; j < exp; j++) a[i * s - exp + j] = a[i * s], a[i * s + w + j] = a[i * s + w - 1];
+    for(int i = 0; i < exp; i++) {
+        memcpy(a - exp - (i + 1) * s, a - exp, s * sizeof(xo_pel));
+        memcpy(a + (h - 1) * s - exp + (i + 1) * s, a + (h - 1) * s - exp, s * sizeof(xo_pel));
+    }
+}

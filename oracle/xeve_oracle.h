@@ -219,6 +219,27 @@ typedef struct xo_cu_bits_job {
  * component).  *out = the state SBAC_STORE would keep. */
 uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p, const xo_cu_bits_job *job, const int16_t *coef);
 
+/* ---- in-loop deblocking + reference-picture padding (reference: src_base/xeve_df.c, xeve_util.c) -- */
+/* xeve_tbl_df_st (xeve_tbl.c:239-257) */
+extern const uint8_t xo_df_st[4][52];
+typedef struct xo_deblock_params {
+    int32_t w, h;                    /* picture size in luma samples (pic->w_l, pic->h_l) */
+    int32_t w_scu, h_scu;            /* ctx->w_scu, ctx->h_scu (4x4 units) */
+    int32_t log2_max_cuwh;           /* CTU size (6 in Baseline) */
+    int32_t bit_depth_luma, bit_depth_chroma, chroma_format_idc;
+    int32_t qp_u_offset, qp_v_offset; /* pic->pic_qp_u_offset / pic_qp_v_offset (slice header) */
+    int32_t qp_chroma[2][100];       /* ctx->qp_chroma_dynamic[c][q] at index q + 6 * (bit_depth_chroma - 8), q = -6 * (bd - 8) .. 57 */
+} xo_deblock_params;
+/* xeve_loop_filter (xeve_enc.c:2355-2415) = for both edge directions (vertical edges first): xeve_deblock (xeve_df.c:522-573)
+ * walking every CTU's quad-tree (xeve_deblock_tree :575-639) into xeve_deblock_cu_ver / _cu_hor (:253-471); one tile, one slice.
+ * y / u / v point at sample (0, 0) of the planes; map_scu (MCU_* bit fields, xeve_def.h:585-640), map_cu_mode (CU size in
+ * bits 24-31, xeve_def.h:679-683), map_refi [f_scu][2], map_mv [f_scu][2][2] are per 4x4 unit.  map_scu's COD bits are
+ * scratch, as in the reference. */
+void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode,
+                        const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p);
+/* xeve_picbuf_expand (xeve_util.c:190-248) on one plane: a = sample (0, 0) */
+void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,3 +364,35 @@ def oracle_sbac():
 
 
 EST_FULL_INTS = 108  # xo_rdoq_est_full / xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr [2] each, run[24][2], level[24][2], last[2][2]
+
+
+# ---- deblocking + padding ------------------------------------------------------------------------------------------
+class DeblockParams(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("w_scu", C.c_int32), ("h_scu", C.c_int32), ("log2_max_cuwh", C.c_int32),
+                ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32), ("chroma_format_idc", C.c_int32),
+                ("qp_u_offset", C.c_int32), ("qp_v_offset", C.c_int32), ("qp_chroma", (C.c_int32 * 100) * 2)]
+
+
+REF_DF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_df.so")
+_ref_df = None
+
+
+def ref_df():
+    global _ref_df
+    if _ref_df is None and os.path.exists(REF_DF_SO):
+        L = C.CDLL(REF_DF_SO)
+        L.refdrv_deblock_picture.restype = c_int
+        L.refdrv_deblock_picture.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams)]
+        L.refdrv_picbuf_expand.restype = None
+        L.refdrv_picbuf_expand.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 9
+        _ref_df = L
+    return _ref_df
+
+
+def oracle_df():
+    L = oracle()
+    L.xo_deblock_picture.restype = None
+    L.xo_deblock_picture.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams)]
+    L.xo_picbuf_expand.restype = None
+    L.xo_picbuf_expand.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    return L
