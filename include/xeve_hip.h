@@ -363,6 +363,32 @@ int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip
                           const xeve_hip_cu_bits_params *params, void *workspace, size_t workspace_bytes, uint32_t *bits,
                           xeve_hip_sbac *sbac_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* (5) In-loop deblocking and reference-picture padding: from the        */
+/*     reconstruction the residual kernels leave in HBM to the planes the next picture's motion  */
+/*     search reads, without leaving the device.  reference: xeve_loop_filter (xeve_enc.c:2355-  */
+/*     2415) -> xeve_deblock / xeve_deblock_tree / xeve_deblock_cu_ver / _cu_hor (xeve_df.c),     */
+/*     xeve_picbuf_expand (xeve_util.c:190-248).                                                  */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_deblock_params {
+    int32_t w, h;                     /* picture size in luma samples */
+    int32_t w_scu, h_scu;             /* ctx->w_scu, ctx->h_scu: the maps' dimensions in 4x4 units */
+    int32_t log2_max_cuwh;            /* CTU size (unused by the device path: it reads CU sizes from map_cu_mode) */
+    int32_t bit_depth_luma, bit_depth_chroma, chroma_format_idc; /* 4:0:0, 4:2:0, 4:4:4 */
+    int32_t qp_u_offset, qp_v_offset; /* sh->qp_u_offset / qp_v_offset (pic->pic_qp_*_offset) */
+    int32_t qp_chroma[2][100];        /* ctx->qp_chroma_dynamic[c][q] stored at index q + 6 * (bit_depth_chroma - 8) */
+} xeve_hip_deblock_params;
+/* Both edge directions of one picture (vertical edges first), one tile / one slice, quad-tree CUs.  y / u / v point at sample
+ * (0, 0) of planes resident in HBM (filtered in place); the maps are the reference's per-4x4-unit arrays, device memory:
+ * map_scu (ctx->map_scu: MCU_* bit fields, xeve_def.h:585-640; the COD bits are not used or changed), map_cu_mode
+ * (ctx->map_cu_mode: CU log2 width / height in bits 24-31), map_refi [f_scu][2], map_mv [f_scu][2][2] (ctx->map_unrefined_mv,
+ * which equals ctx->map_mv in Baseline).  params is a HOST pointer. */
+int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, const uint32_t *map_scu, const uint32_t *map_cu_mode,
+                     const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params, void *stream);
+/* xeve_picbuf_expand: replicate the border samples exp_l / exp_c deep around the three planes */
+int xeve_hip_picbuf_expand(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
+                           int exp_c, int chroma_format_idc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,193 @@
+// xeve_amd/csrc/df.hip -- in-loop deblocking and reference-picture padding on the device: the steps
+// between the reconstruction the residual kernels leave in HBM and the reference planes motion search / compensation read.
+//
+// reference: xeve_loop_filter (src_base/xeve_enc.c:2355-2415) -> xeve_deblock (src_base/xeve_df.c:522-573) -> xeve_deblock_tree
+// (:575-639) -> xeve_deblock_cu_ver / _cu_hor (:253-471) with get_tbl_qp_to_st (:34-87) and deblock_scu_* (:89-251);
+// xeve_picbuf_expand (src_base/xeve_util.c:190-248).
+//
+// The reference walks every CTU's quad-tree twice (vertical edges of the whole picture, then horizontal ones) and filters, per
+// CU, the 4-sample segments of its left / top edge.  Filtered segments of one direction are independent of each other in luma
+// (edges are >= 4 samples apart, the filter touches 2 either side), so one thread per 4x4 unit decides "is my left / top side a
+// CU edge" from the CU size recorded in map_cu_mode and filters its segment.  4:2:0 chroma is the exception: with 4-wide (high)
+// CUs two edges are 2 chroma samples apart and the later one reads what the earlier one wrote.  The reference's order along a
+// row (column) is left to right (top to bottom) -- z-order is monotone in x for fixed y -- so the first unit of every run of
+// consecutive edge units walks its run sequentially; isolated edges (the common case) stay fully parallel.
+#include "xh_common.h"
+
+struct DfK {
+    int w, h, w_scu, h_scu, bl, bc, idc, ws, hs, qp_u_offset, qp_v_offset, s_l, s_c;
+    int qp_chroma[2][100];
+};
+
+__constant__ uint8_t c_df_st[4][52] = { // xeve_tbl_df_st (xeve_tbl.c:239-257)
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 12, 12, 12, 12, 12},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 11, 11, 11, 11},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10, 10},
+    {0}};
+
+// get_tbl_qp_to_st (xeve_df.c:34-87): strength class of the edge between units `a` (whose QP counts) and `b`
+__device__ __forceinline__ int df_class(unsigned m0, unsigned m1, const int8_t *__restrict__ refi, const int16_t *__restrict__ mv, int a, int b)
+{
+    if(((m0 | m1) >> 15) & 1) return 0;          // MCU_GET_IF
+    if(((m0 | m1) >> 24) & 1) return 1;          // MCU_GET_CBFL
+    if(((m0 | m1) >> 26) & 1) return 2;          // MCU_GET_IBC
+    const int r00 = refi[2 * a], r01 = refi[2 * a + 1], r10 = refi[2 * b], r11 = refi[2 * b + 1];
+    const int2 *pa = (const int2 *)(mv + 4 * a), *pb = (const int2 *)(mv + 4 * b); // {l0.x | l0.y << 16, l1.x | l1.y << 16}
+    const int2 va = *pa, vb = *pb;
+    int a0x = (int16_t)va.x, a0y = va.x >> 16, a1x = (int16_t)va.y, a1y = va.y >> 16;
+    int b0x = (int16_t)vb.x, b0y = vb.x >> 16, b1x = (int16_t)vb.y, b1y = vb.y >> 16;
+    if(r00 < 0) a0x = a0y = 0;
+    if(r01 < 0) a1x = a1y = 0;
+    if(r10 < 0) b0x = b0y = 0;
+    if(r11 < 0) b1x = b1y = 0;
+    if(r00 == r10 && r01 == r11) return (abs(a0x - b0x) >= 4 || abs(a0y - b0y) >= 4 || abs(a1x - b1x) >= 4 || abs(a1y - b1y) >= 4) ? 2 : 3;
+    if(r00 == r11 && r01 == r10) return (abs(a0x - b1x) >= 4 || abs(a0y - b1y) >= 4 || abs(a1x - b0x) >= 4 || abs(a1y - b0y) >= 4) ? 2 : 3;
+    return 2;
+}
+
+// deblock_scu_* (xeve_df.c:89-251) on one line A B | C D, s16 arithmetic as the reference
+__device__ __forceinline__ void df_line(int &A, int &B, int &C, int &D, int st, int maxv, bool chroma)
+{
+    const int d = (int)(int16_t)((A - (B << 2) + (C << 2) - D) / 8);
+    const int ab = d < 0 ? -d : d;
+    int t16 = (ab - st) << 1;
+    t16 = t16 > 0 ? t16 : 0;
+    int clip = ab - t16;
+    clip = clip > 0 ? clip : 0;
+    const int d1 = d < 0 ? -clip : clip;
+    if(!chroma) {
+        clip >>= 1;
+        int d2 = (A - D) / 4;
+        d2 = d2 < -clip ? -clip : (d2 > clip ? clip : d2);
+        A = (int)(int16_t)(A - d2), D = (int)(int16_t)(D + d2);
+        A = A < 0 ? 0 : (A > maxv ? maxv : A), D = D < 0 ? 0 : (D > maxv ? maxv : D);
+    }
+    B = (int)(int16_t)(B + d1), C = (int)(int16_t)(C - d1);
+    B = B < 0 ? 0 : (B > maxv ? maxv : B), C = C < 0 ? 0 : (C > maxv ? maxv : C);
+}
+
+// `n` lines of one segment; along / across in elements
+__device__ __forceinline__ void df_segment(pel *buf, int n, int along, int across, int st, int maxv, bool chroma)
+{
+    if(!st) return;
+    for(int i = 0; i < n; i++, buf += along) {
+        int A = buf[-2 * across], B = buf[-across], C = buf[0], D = buf[across];
+        df_line(A, B, C, D, st, maxv, chroma);
+        if(!chroma) buf[-2 * across] = (pel)A, buf[across] = (pel)D;
+        buf[-across] = (pel)B, buf[0] = (pel)C;
+    }
+}
+
+template <bool HOR> __device__ __forceinline__ bool df_is_edge(const unsigned *__restrict__ map_cu_mode, const DfK &P, int sx, int sy)
+{
+    if(sx >= P.w_scu || sy >= P.h_scu) return false;
+    const unsigned m = map_cu_mode[sy * P.w_scu + sx];
+    if(HOR) return sy > 0 && (sy & ((1 << (((m >> 28) & 0xF) - 2)) - 1)) == 0; // MCU_GET_LOGH: top row of its CU
+    return sx > 0 && (sx & ((1 << (((m >> 24) & 0xF) - 2)) - 1)) == 0;         // MCU_GET_LOGW: left column of its CU
+}
+
+template <bool HOR>
+__global__ __launch_bounds__(256) void k_deblock(pel *__restrict__ y, pel *__restrict__ u, pel *__restrict__ v, const unsigned *__restrict__ map_scu,
+                                                 const unsigned *__restrict__ map_cu_mode, const int8_t *__restrict__ refi, const int16_t *__restrict__ mv, DfK P)
+{
+    const int sx = blockIdx.x * 64 + (threadIdx.x & 63), sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(!df_is_edge<HOR>(map_cu_mode, P, sx, sy)) return;
+    const int t = sy * P.w_scu + sx, nb = HOR ? t - P.w_scu : t - 1;
+    const unsigned m0 = map_scu[t], m1 = map_scu[nb];
+    const int cls = df_class(m0, m1, refi, mv, t, nb), qp = (m0 >> 16) & 0x7F;
+    // luma: 4 lines, independent of every other segment of this pass
+    {
+        pel *b = y + (size_t)(4 * sy) * P.s_l + 4 * sx;
+        df_segment(b, 4, HOR ? 1 : P.s_l, HOR ? P.s_l : 1, c_df_st[cls][qp] << P.bl, (1 << (P.bl + 8)) - 1, false);
+    }
+    if(!P.idc) return;
+    // chroma.  The segment length follows the reference: W shift for horizontal, H shift for vertical edges (xeve_df.c:143,225)
+    const bool chained = HOR ? P.hs != 0 : P.ws != 0; // edges of neighbouring units are 2 samples apart: order matters
+    if(chained && df_is_edge<HOR>(map_cu_mode, P, HOR ? sx : sx - 1, HOR ? sy - 1 : sy)) return; // not the head of its run
+    const int maxc = (1 << (P.bc + 8)) - 1, nline = HOR ? 4 >> P.ws : 4 >> P.hs;
+    int cx = sx, cy = sy, ct = t, ccls = cls, cqp = qp;
+    for(;;) {
+        const int qu = min(57, max(-6 * P.bc, cqp + P.qp_u_offset)), qv = min(57, max(-6 * P.bc, cqp + P.qp_v_offset));
+        const int st_u = c_df_st[ccls][P.qp_chroma[0][qu + 6 * P.bc]] << P.bc, st_v = c_df_st[ccls][P.qp_chroma[1][qv + 6 * P.bc]] << P.bc;
+        const size_t off = (size_t)((4 * cy) >> P.hs) * P.s_c + ((4 * cx) >> P.ws);
+        df_segment(u + off, nline, HOR ? 1 : P.s_c, HOR ? P.s_c : 1, st_u, maxc, true);
+        df_segment(v + off, nline, HOR ? 1 : P.s_c, HOR ? P.s_c : 1, st_v, maxc, true);
+        if(!chained) break;
+        if(HOR) cy++; else cx++;
+        if(!df_is_edge<HOR>(map_cu_mode, P, cx, cy)) break;
+        ct = cy * P.w_scu + cx;
+        const int cnb = HOR ? ct - P.w_scu : ct - 1;
+        const unsigned n0 = map_scu[ct], n1 = map_scu[cnb];
+        ccls = df_class(n0, n1, refi, mv, ct, cnb), cqp = (n0 >> 16) & 0x7F;
+    }
+}
+
+extern "C" int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, const uint32_t *map_scu, const uint32_t *map_cu_mode,
+                                const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *p, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(p && y && map_scu && map_cu_mode && map_refi && map_mv);
+    XH_REQUIRE(p->w > 0 && p->h > 0 && p->w_scu == (p->w + 3) / 4 && p->h_scu == (p->h + 3) / 4);
+    XH_REQUIRE(p->bit_depth_luma >= 8 && p->bit_depth_luma <= 14 && p->bit_depth_chroma >= 8 && p->bit_depth_chroma <= 14);
+    // 4:2:2 is left out: the reference steps chroma rows of a vertical edge by the W shift (xeve_df.c:411-412), a case of its own
+    XH_REQUIRE(p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3);
+    XH_REQUIRE(p->chroma_format_idc == 0 || (u && v));
+    DfK P;
+    P.w = p->w, P.h = p->h, P.w_scu = p->w_scu, P.h_scu = p->h_scu, P.bl = p->bit_depth_luma - 8, P.bc = p->bit_depth_chroma - 8;
+    P.idc = p->chroma_format_idc, P.ws = p->chroma_format_idc <= 2, P.hs = p->chroma_format_idc <= 1;
+    P.qp_u_offset = p->qp_u_offset, P.qp_v_offset = p->qp_v_offset, P.s_l = s_l, P.s_c = s_c;
+    for(int c = 0; c < 2; c++)
+        for(int i = 0; i < 100; i++) {
+            const int q = p->qp_chroma[c][i];
+            // the mapped chroma QP indexes xeve_tbl_df_st[.][52]; entries below index 6 * (bd - 8) stand for negative QPs, which
+            // the reference would read out of bounds with -- clamp those, insist on the rest
+            XH_REQUIRE(i < 6 * P.bc || i > 57 + 6 * P.bc || (q >= 0 && q < 52));
+            P.qp_chroma[c][i] = q < 0 ? 0 : (q > 51 ? 51 : q);
+        }
+    const dim3 grid((P.w_scu + 63) / 64, (P.h_scu + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    k_deblock<false><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_refi, map_mv, P); // vertical edges of the whole picture first
+    k_deblock<true><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_refi, map_mv, P);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+// ---- xeve_picbuf_expand ------------------------------------------------------------------------------------------------------
+__global__ void k_pad_lr(pel *a, int s, int w, int h, int exp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= h * exp) return;
+    const int r = i / exp, j = i % exp;
+    a[(size_t)r * s - exp + j] = a[(size_t)r * s];
+    a[(size_t)r * s + w + j]   = a[(size_t)r * s + w - 1];
+}
+__global__ void k_pad_tb(pel *a, int s, int h, int exp)
+{ // the reference copies `s` elements per row starting at x = -exp (xeve_util.c:224-238)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= (long)exp * s) return;
+    const int r = (int)(i / s), x = (int)(i % s);
+    a[-(long)exp - (long)(r + 1) * s + x]                  = a[-(long)exp + x];
+    a[(long)(h - 1) * s - exp + (long)(r + 1) * s + x] = a[(long)(h - 1) * s - exp + x];
+}
+
+static void pad_plane(pel *a, int s, int w, int h, int exp, hipStream_t st)
+{
+    k_pad_lr<<<(h * exp + 255) / 256, 256, 0, st>>>(a, s, w, h, exp);
+    k_pad_tb<<<(unsigned)(((long)exp * s + 255) / 256), 256, 0, st>>>(a, s, h, exp);
+}
+
+extern "C" int xeve_hip_picbuf_expand(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
+                                      int exp_c, int chroma_format_idc, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(y && w_l > 0 && h_l > 0 && exp_l > 0 && s_l >= w_l + exp_l);
+    hipStream_t st = (hipStream_t)stream;
+    pad_plane(y, s_l, w_l, h_l, exp_l, st);
+    if(chroma_format_idc) {
+        XH_REQUIRE(u && v && w_c > 0 && h_c > 0 && exp_c > 0 && s_c >= w_c + exp_c);
+        pad_plane(u, s_c, w_c, h_c, exp_c, st);
+        pad_plane(v, s_c, w_c, h_c, exp_c, st);
+    }
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

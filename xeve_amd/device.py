@@ -199,6 +199,23 @@ def rdoq_dev(coef, log2w, log2h, qp, lam, ch_type, bit_depth, est, est_idx=None,
     return nnz
 
 
+def _ptr_at(t, elem_off):
+    return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
+
+
+def deblock(planes, origins, s_l, s_c, map_scu, map_cu_mode, map_refi, map_mv, params):
+    """in-loop deblocking of one picture in place (xeve_hip_deblock).  planes: three int16 tensors; origins: element offsets of
+    sample (0, 0) in each; maps: device tensors laid out like the reference's per-4x4-unit arrays; params: lib.DeblockParams"""
+    _lib.check(_lib.load().xeve_hip_deblock(_ptr_at(_i16(planes[0]), origins[0]), _ptr_at(_i16(planes[1]), origins[1]), _ptr_at(_i16(planes[2]), origins[2]),
+                                            s_l, s_c, _ptr(map_scu), _ptr(map_cu_mode), _ptr(map_refi), _ptr(map_mv), C.byref(params), _stream()))
+
+
+def picbuf_expand(planes, origins, s_l, s_c, w_l, h_l, w_c, h_c, exp_l, exp_c, chroma_format_idc=1):
+    """xeve_picbuf_expand on planes resident in HBM (xeve_hip_picbuf_expand)"""
+    _lib.check(_lib.load().xeve_hip_picbuf_expand(_ptr_at(_i16(planes[0]), origins[0]), _ptr_at(_i16(planes[1]), origins[1]), _ptr_at(_i16(planes[2]), origins[2]),
+                                                  s_l, s_c, w_l, h_l, w_c, h_c, exp_l, exp_c, chroma_format_idc, _stream()))
+
+
 def cu_bits_jobs(coef, sbac_in, jobs, params, want_state=True, workspace=None, bits=None, sbac_out=None):
     """CABAC bit count of inter-CU jobs (xeve_hip_cu_bits_jobs).  coef: flat int16 tensor; sbac_in / jobs: uint8 tensors holding
     arrays of lib.SBAC_DTYPE / lib.CU_BITS_JOB_DTYPE records; params: lib.CuBitsParams.  Returns (bits u32-as-int32 [njobs],

@@ -39,6 +39,12 @@ class EpzsParams(C.Structure):  # xeve_hip_epzs_params
     _fields_ = [("me", MeParams), ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
 
 
+class DeblockParams(C.Structure):  # xeve_hip_deblock_params
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("w_scu", C.c_int32), ("h_scu", C.c_int32), ("log2_max_cuwh", C.c_int32),
+                ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32), ("chroma_format_idc", C.c_int32),
+                ("qp_u_offset", C.c_int32), ("qp_v_offset", C.c_int32), ("qp_chroma", (C.c_int32 * 100) * 2)]
+
+
 class CuBitsParams(C.Structure):  # xeve_hip_cu_bits_params
     _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("slice_type", C.c_int32), ("num_refp", C.c_int32 * 2),
                 ("cm_init", C.c_int32), ("chroma_format_idc", C.c_int32)]
@@ -110,6 +116,8 @@ FUNCTIONS = {
     "xeve_hip_rdoq_bit_est": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_rdoq_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                   c_void_p]),
+    "xeve_hip_deblock": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_picbuf_expand": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
