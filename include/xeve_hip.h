@@ -389,6 +389,32 @@ int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l,
 int xeve_hip_picbuf_expand(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
                            int exp_c, int chroma_format_idc, void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* (6) a8: the CU motion-compensation driver.  reference: xeve_mc (src_base/xeve_mc.c:465-610)   */
+/*     = xeve_mv_clip (:401-447) + xeve_mc_l / xeve_mc_c per used list (variant from the         */
+/*     unclipped vector's fraction, position from the clipped one) + the identical-motion        */
+/*     shortcut (:546-551) + xeve_average_16b_no_clip for bi-prediction.                          */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_refpic {
+    const xeve_hip_pel *y, *u, *v; /* sample (0, 0) of refp[refi][list].pic's planes (device memory, padded like the reference's) */
+    int32_t             poc;       /* refp[refi][list].pic->poc */
+    int32_t             pad_;
+} xeve_hip_refpic;
+typedef struct xeve_hip_cu_mc_job {
+    int32_t x, y;      /* CU position in luma samples */
+    int16_t mv[2][2];  /* quarter pel */
+    int8_t  refi[2];   /* < 0: list unused */
+    int8_t  pad_[2];
+} xeve_hip_cu_mc_job;
+/* refp: HOST array indexed [refi * 2 + list] (entries up to max(num_refp0, num_refp1) - 1); all pictures share s_l / s_c.
+ * pred_y [njobs][h*w], pred_u / pred_v [njobs][(h >> h_shift) * (w >> w_shift)] receive what the reference leaves in pred[0];
+ * jobs, pred_*, workspace: device memory; coefficient tables: HOST pointers (xeve_tbl_mc_l_coeff / xeve_tbl_mc_c_coeff). */
+size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp0, int num_refp1);
+int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h,
+                        const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h, int bit_depth_luma, int bit_depth_chroma,
+                        int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_pel *pred_y,
+                        xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 #include <string.h>
 #include "xeve_type.h"
 #include "xeve_df.h"
+#include "xeve_mc.h"
 
 typedef struct {
     int w, h, w_scu, h_scu, log2_max_cuwh, bit_depth_luma, bit_depth_chroma, chroma_format_idc, qp_u_offset, qp_v_offset;
@@ -77,4 +78,30 @@ void refdrv_picbuf_expand(pel *y, pel *u, pel *v, int s_l, int s_c, int w_l, int
     memset(&pic, 0, sizeof(pic));
     pic.y = y, pic.u = u, pic.v = v, pic.s_l = s_l, pic.s_c = s_c, pic.w_l = w_l, pic.h_l = h_l, pic.w_c = w_c, pic.h_c = h_c;
     xeve_picbuf_expand(&pic, exp_l, exp_c, chroma_format_idc);
+}
+
+/* xeve_mc (src_base/xeve_mc.c:465-610) on caller-supplied planes: refs[refi * 2 + list] = {y, u, v (sample (0,0)), poc}.  The
+ * dispatch pointers are process globals that the encoder sets in xeve_platform_init_func; here: the plain-C tables. */
+typedef struct { pel *y, *u, *v; int poc, pad_; } drv_refpic;
+typedef struct { int x, y; s16 mv[2][2]; s8 refi[2]; s8 pad_[2]; } drv_mc_job;
+void refdrv_mc_cu(const drv_refpic *refs, int nref, int s_l, int s_c, int pic_w, int pic_h, const drv_mc_job *job, int w, int h, int bd_l, int bd_c,
+                  int chroma_format_idc, pel *pred_y, pel *pred_u, pel *pred_v)
+{
+    static __thread XEVE_PIC  pics[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    static __thread XEVE_REFP refp[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    static __thread pel(*pred)[N_C][MAX_CU_DIM];
+    if(!pred) pred = calloc(REFP_NUM, sizeof(*pred));
+    xeve_func_mc_l = xeve_tbl_mc_l, xeve_func_mc_c = xeve_tbl_mc_c, xeve_func_average_no_clip = &xeve_average_16b_no_clip;
+    for(int r = 0; r < nref; r++)
+        for(int l = 0; l < REFP_NUM; l++) {
+            const drv_refpic *s = &refs[r * 2 + l];
+            pics[r][l].y = s->y, pics[r][l].u = s->u, pics[r][l].v = s->v, pics[r][l].s_l = s_l, pics[r][l].s_c = s_c, pics[r][l].poc = s->poc;
+            refp[r][l].pic = &pics[r][l], refp[r][l].poc = s->poc;
+        }
+    s8  refi[REFP_NUM] = {job->refi[0], job->refi[1]};
+    s16 mv[REFP_NUM][MV_D] = {{job->mv[0][0], job->mv[0][1]}, {job->mv[1][0], job->mv[1][1]}};
+    xeve_mc(job->x, job->y, pic_w, pic_h, w, h, refi, mv, refp, pred, bd_l, bd_c, chroma_format_idc);
+    int cw = w >> XEVE_GET_CHROMA_W_SHIFT(chroma_format_idc), ch = h >> XEVE_GET_CHROMA_H_SHIFT(chroma_format_idc);
+    memcpy(pred_y, pred[0][Y_C], sizeof(pel) * w * h);
+    if(chroma_format_idc) memcpy(pred_u, pred[0][U_C], sizeof(pel) * cw * ch), memcpy(pred_v, pred[0][V_C], sizeof(pel) * cw * ch);
 }

@@ -1101,3 +1101,53 @@ void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp)
         memcpy(a + (h - 1) * s - exp + (i + 1) * s, a + (h - 1) * s - exp, s * sizeof(xo_pel));
     }
 }
+
+/* ===================================================================================================================
+ * a8: xeve_mc (src_base/xeve_mc.c:465-610) -- clip, per-list interpolation of Y / U / V, bi-prediction average
+ * =================================================================================================================== */
+void xo_mc_cu(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_cu_mc_job *job, int w, int h, int bit_depth_luma,
+              int bit_depth_chroma, int chroma_format_idc, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v)
+{
+    const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1, wfac = 2 / (ws + 1), hfac = 2 / (hs + 1);
+    const int cw = w >> ws, chh = h >> hs;
+    int mvt[2][2], valid[2] = {job->refi[0] >= 0, job->refi[1] >= 0}, bidx = 0;
+    xo_pel *p1[3] = {0, 0, 0};
+    /* xeve_mv_clip (xeve_mc.c:401-447): the block may leave the picture by at most MAX_CU_SIZE (128) samples */
+    for(int l = 0; l < 2; l++) {
+        const int x4 = job->x << 2, y4 = job->y << 2, w4 = w << 2, h4 = h << 2;
+        const int min_c = -(128 << 2), max_x = (pic_w - 1 + 128) << 2, max_y = (pic_h - 1 + 128) << 2;
+        mvt[l][0] = job->mv[l][0], mvt[l][1] = job->mv[l][1];
+        if(!valid[l]) continue;
+        if(x4 + job->mv[l][0] < min_c) mvt[l][0] = (int16_t)(min_c - x4);
+        if(y4 + job->mv[l][1] < min_c) mvt[l][1] = (int16_t)(min_c - y4);
+        if(x4 + job->mv[l][0] + w4 - 4 > max_x) mvt[l][0] = (int16_t)(max_x - x4 - w4 + 4);
+        if(y4 + job->mv[l][1] + h4 - 4 > max_y) mvt[l][1] = (int16_t)(max_y - y4 - h4 + 4);
+    }
+    for(int l = 0; l < 2; l++) {
+        if(!valid[l]) continue;
+        if(l == 1 && valid[0]) { /* identical motion: the second list adds nothing (xeve_mc.c:546-551) */
+            const xo_refpic *r0 = &refp[job->refi[0] * 2], *r1 = &refp[job->refi[1] * 2 + 1];
+            if(r0->poc == r1->poc && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1]) return;
+        }
+        const xo_refpic *r = &refp[job->refi[l] * 2 + l];
+        const int gx = ((job->x << 2) + mvt[l][0]) << 2, gy = ((job->y << 2) + mvt[l][1]) << 2;
+        /* the filter variant follows the UNCLIPPED vector's fraction, the position the clipped one (xeve_mc.c:490-507, xeve_mc.h:95-104) */
+        const int ox = job->mv[l][0] << 2, oy = job->mv[l][1] << 2;
+        xo_pel *py = pred_y, *pu = pred_u, *pv = pred_v;
+        if(bidx == 1) {
+            for(int c = 0; c < 3; c++) p1[c] = malloc(sizeof(xo_pel) * (size_t)(c ? cw * chh : w * h));
+            py = p1[0], pu = p1[1], pv = p1[2];
+        }
+        xo_mc_l(ox & 0xF, oy & 0xF, r->y, gx, gy, s_l, w, py, w, h, bit_depth_luma, xo_mc_l_coeff);
+        if(chroma_format_idc) {
+            xo_mc_c(ox & 0x1F, oy & 0x1F, r->u, gx * wfac, gy * hfac, s_c, cw, pu, cw, chh, bit_depth_chroma, xo_mc_c_coeff);
+            xo_mc_c(ox & 0x1F, oy & 0x1F, r->v, gx * wfac, gy * hfac, s_c, cw, pv, cw, chh, bit_depth_chroma, xo_mc_c_coeff);
+        }
+        bidx++;
+    }
+    if(bidx == 2) {
+        xo_avg(pred_y, p1[0], pred_y, w, w, w, w, h);
+        if(chroma_format_idc) xo_avg(pred_u, p1[1], pred_u, cw, cw, cw, cw, chh), xo_avg(pred_v, p1[2], pred_v, cw, cw, cw, cw, chh);
+    }
+    for(int c = 0; c < 3; c++) free(p1[c]);
+}

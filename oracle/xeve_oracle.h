@@ -240,6 +240,22 @@ void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint3
 /* xeve_picbuf_expand (xeve_util.c:190-248) on one plane: a = sample (0, 0) */
 void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp);
 
+/* ---- a8: the motion-compensation driver of one CU (reference: xeve_mc, src_base/xeve_mc.c:465-610, with xeve_mv_clip :401-447) -- */
+typedef struct xo_refpic {
+    const xo_pel *y, *u, *v; /* sample (0, 0) of the three planes of refp[refi][list].pic */
+    int32_t       poc;       /* refp[refi][list].pic->poc (identical-motion test, xeve_mc.c:546-551) */
+    int32_t       pad_;
+} xo_refpic;
+typedef struct xo_cu_mc_job {
+    int32_t x, y;      /* CU position, luma samples */
+    int16_t mv[2][2];  /* quarter pel, relative to the CU */
+    int8_t  refi[2];   /* < 0: list unused */
+    int8_t  pad_[2];
+} xo_cu_mc_job;
+/* refp[refi * 2 + list]; pred_* receive what the reference leaves in pred[0][Y_C / U_C / V_C] (dense, stride w resp. w >> w_shift) */
+void xo_mc_cu(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_cu_mc_job *job, int w, int h, int bit_depth_luma,
+              int bit_depth_chroma, int chroma_format_idc, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v);
+
 #ifdef __cplusplus
 }
 #endif

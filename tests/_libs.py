@@ -396,3 +396,25 @@ def oracle_df():
     L.xo_picbuf_expand.restype = None
     L.xo_picbuf_expand.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     return L
+
+
+# ---- a8: xeve_mc driver ----------------------------------------------------------------------------------------------
+REFPIC_DTYPE = np.dtype([("y", "<u8"), ("u", "<u8"), ("v", "<u8"), ("poc", "<i4"), ("pad_", "<i4")])  # xo_refpic / xeve_hip_refpic (pointers)
+CU_MC_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("refi", "i1", (2,)), ("pad_", "i1", (2,))])
+assert REFPIC_DTYPE.itemsize == 32 and CU_MC_JOB_DTYPE.itemsize == 20
+
+
+def ref_mc_cu():
+    L = ref_df()
+    if L is not None and not hasattr(L, "_mc_bound"):
+        L.refdrv_mc_cu.restype = None
+        L.refdrv_mc_cu.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+        L._mc_bound = True
+    return L
+
+
+def oracle_mc_cu():
+    L = oracle()
+    L.xo_mc_cu.restype = None
+    L.xo_mc_cu.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    return L

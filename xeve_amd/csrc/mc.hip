@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
     for(int u = threadIdx.x; u < nj * per1; u += blockDim.x) {
         const int jl = u / per1, r = u - jl * per1, y = r / segs, x0 = (r - y * segs) * SEG;
         const xeve_hip_mc_job jb = jobs[j0 + jl];
-        if((jb.frac & 3) != 3) continue;
+        if((jb.frac & 7) != 3) continue; // bit 2 = job switched off (xeve_hip_mc_cu_jobs)
         const pel *src = ref + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
         int acc[SEG];
         hfir<TAPS, SEG>(src, tab.c[jb.gmv_x & FM], acc);
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
     for(int u = threadIdx.x; u < nj * per2; u += blockDim.x) {
         const int jl = u / per2, r = u - jl * per2, y = r / segs, x0 = (r - y * segs) * SEG;
         const xeve_hip_mc_job jb = jobs[j0 + jl];
+        if(jb.frac & 4) continue;
         const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
         const pel *src = ref + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
         pel *out = pred + jb.pred_off + y * s_pred + x0;
@@ -185,6 +186,7 @@ __global__ void k_mc_any(const pel *__restrict__ ref, int s_ref, pel *__restrict
 {
     constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
     const xeve_hip_mc_job jb = jobs[blockIdx.x];
+    if(jb.frac & 4) return; // job switched off
     const int ix = jb.gmv_x >> FS, iy = jb.gmv_y >> FS;
     const int16_t *cx = tab.c[jb.gmv_x & FM], *cy = tab.c[jb.gmv_y & FM];
     const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
@@ -391,5 +393,134 @@ extern "C" int xeve_hip_me_spel_pattern_jobs(const pel *org0, int s_org, const p
         k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, sad, results);
         XH_HIP(hipGetLastError());
     }
+    return XEVE_HIP_OK;
+}
+
+// ---- a8: the CU driver xeve_mc (src_base/xeve_mc.c:465-610) --------------------------------------------------------------
+// per job: clip both vectors (xeve_mv_clip), interpolate Y / U / V from every used list -- filter variant from the UNCLIPPED
+// vector's fraction, position from the clipped one --, drop list 1 when it repeats list 0 (same POC, same clipped vector),
+// average when two predictions remain.  One small kernel turns the jobs into per-(list, reference picture) interpolation jobs
+// (switched off where a job does not use that picture); list 0 lands in the caller's buffers, list 1 in the workspace; a
+// last kernel averages / copies per job.
+#define XH_MAX_REF 8
+struct CuMcK {
+    int pic_w, pic_h, w, h, cw, ch, wfac, hfac, nref[2], poc[2][XH_MAX_REF];
+};
+
+__global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int njobs, CuMcK P, xeve_hip_mc_job *__restrict__ jl,
+                             xeve_hip_mc_job *__restrict__ jc, uint8_t *__restrict__ mode)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= njobs) return;
+    const xeve_hip_cu_mc_job J = jobs[j];
+    const int x4 = J.x << 2, y4 = J.y << 2, w4 = P.w << 2, h4 = P.h << 2;
+    const int min_c = -(128 << 2), max_x = (P.pic_w - 1 + 128) << 2, max_y = (P.pic_h - 1 + 128) << 2; // MAX_CU_SIZE margin
+    int  mvt[2][2];
+    bool valid[2];
+#pragma unroll
+    for(int l = 0; l < 2; l++) {
+        valid[l] = J.refi[l] >= 0;
+        int mx = J.mv[l][0], my = J.mv[l][1];
+        if(valid[l]) {
+            if(x4 + J.mv[l][0] < min_c) mx = (int16_t)(min_c - x4);
+            if(y4 + J.mv[l][1] < min_c) my = (int16_t)(min_c - y4);
+            if(x4 + J.mv[l][0] + w4 - 4 > max_x) mx = (int16_t)(max_x - x4 - w4 + 4);
+            if(y4 + J.mv[l][1] + h4 - 4 > max_y) my = (int16_t)(max_y - y4 - h4 + 4);
+        }
+        mvt[l][0] = mx, mvt[l][1] = my;
+    }
+    bool use1 = valid[1];
+    if(valid[0] && valid[1] && P.poc[0][J.refi[0]] == P.poc[1][J.refi[1]] && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1]) use1 = false;
+    mode[j] = (uint8_t)(use1 ? (valid[0] ? 1 : 2) : 0); // 1 average the two, 2 list 1 alone: copy it over
+    int q = 0;
+#pragma unroll
+    for(int l = 0; l < 2; l++) {
+        const bool on = l == 0 ? valid[0] : use1;
+        const int  gx = (x4 + mvt[l][0]) << 2, gy = (y4 + mvt[l][1]) << 2;
+        xeve_hip_mc_job a, c;
+        a.gmv_x = gx, a.gmv_y = gy, a.pred_off = j * P.w * P.h;
+        a.frac = ((J.mv[l][0] & 3) ? 1 : 0) | ((J.mv[l][1] & 3) ? 2 : 0);
+        c.gmv_x = gx * P.wfac, c.gmv_y = gy * P.hfac, c.pred_off = j * P.cw * P.ch;
+        c.frac = ((J.mv[l][0] & 7) ? 1 : 0) | ((J.mv[l][1] & 7) ? 2 : 0);
+        for(int r = 0; r < P.nref[l]; r++, q++) {
+            const int off = (on && J.refi[l] == r) ? 0 : 4;
+            xeve_hip_mc_job al = a, cl = c;
+            al.frac |= off, cl.frac |= off;
+            jl[(size_t)q * njobs + j] = al, jc[(size_t)q * njobs + j] = cl;
+        }
+    }
+}
+
+__global__ void k_cu_mc_combine(pel *__restrict__ p0, const pel *__restrict__ p1, const uint8_t *__restrict__ mode, int njobs, int n)
+{ // n = samples per job (a multiple of 4)
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if(i >= (long)njobs * n) return;
+    const int m = mode[i / n];
+    if(!m) return;
+    u32x2 a = xh_ld4(p0 + i), b = xh_ld4(p1 + i);
+    if(m == 1) {
+#pragma unroll
+        for(int k = 0; k < 2; k++) a[k] = xh_pack16((xh_lo16(a[k]) + xh_lo16(b[k]) + 1) >> 1, (xh_hi16(a[k]) + xh_hi16(b[k]) + 1) >> 1); // xeve_average_16b_no_clip
+    }
+    else a = b;
+    xh_st4(p0 + i, a);
+}
+
+extern "C" size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp0, int num_refp1)
+{
+    const size_t n = njobs > 0 ? njobs : 0, q = (size_t)(num_refp0 + num_refp1);
+    return ((n + 15) & ~(size_t)15) + 2 * q * n * sizeof(xeve_hip_mc_job) + 3 * n * (size_t)w * h * sizeof(pel);
+}
+
+extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h,
+                                   const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h, int bit_depth_luma, int bit_depth_chroma,
+                                   int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], pel *pred_y, pel *pred_u,
+                                   pel *pred_v, void *workspace, size_t workspace_bytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(refp && jobs && njobs >= 0 && coef_l && pred_y && workspace);
+    XH_REQUIRE(num_refp0 >= 0 && num_refp0 <= XH_MAX_REF && num_refp1 >= 0 && num_refp1 <= XH_MAX_REF && num_refp0 + num_refp1 > 0);
+    XH_REQUIRE(w >= 4 && h >= 4 && w <= 128 && h <= 128 && (w & 3) == 0 && (h & 3) == 0 && chroma_format_idc >= 0 && chroma_format_idc <= 3);
+    XH_REQUIRE(chroma_format_idc == 0 || (pred_u && pred_v && coef_c));
+    XH_REQUIRE(workspace_bytes >= xeve_hip_mc_cu_workspace(njobs, w, h, num_refp0, num_refp1));
+    if(njobs == 0) return XEVE_HIP_OK;
+    const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT
+    CuMcK P;
+    P.pic_w = pic_w, P.pic_h = pic_h, P.w = w, P.h = h, P.cw = w >> ws, P.ch = h >> hs, P.wfac = 2 / (ws + 1), P.hfac = 2 / (hs + 1);
+    P.nref[0] = num_refp0, P.nref[1] = num_refp1;
+    const int nmax = num_refp0 > num_refp1 ? num_refp0 : num_refp1;
+    for(int r = 0; r < XH_MAX_REF; r++)
+        for(int l = 0; l < 2; l++) P.poc[l][r] = r < nmax ? refp[r * 2 + l].poc : 0;
+    const size_t n = njobs, q = (size_t)(num_refp0 + num_refp1);
+    uint8_t         *mode = (uint8_t *)workspace;
+    xeve_hip_mc_job *jl   = (xeve_hip_mc_job *)(mode + ((n + 15) & ~(size_t)15)), *jc = jl + q * n;
+    pel             *p1[3];
+    p1[0] = (pel *)(jc + q * n), p1[1] = p1[0] + n * w * h, p1[2] = p1[1] + n * P.cw * P.ch;
+    hipStream_t st = (hipStream_t)stream;
+    k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, P, jl, jc, mode);
+    XH_HIP(hipGetLastError());
+    int qi = 0;
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < P.nref[l]; r++, qi++) {
+            const xeve_hip_refpic &R = refp[r * 2 + l];
+            XH_REQUIRE(R.y && (chroma_format_idc == 0 || (R.u && R.v)));
+            int rc = mc_launch<8, 0>(R.y, s_l, l ? p1[0] : pred_y, w, jl + (size_t)qi * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st);
+            if(rc != XEVE_HIP_OK) return rc;
+            if(chroma_format_idc) {
+                rc = mc_launch<4, 0>(R.u, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)qi * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st);
+                if(rc != XEVE_HIP_OK) return rc;
+                rc = mc_launch<4, 0>(R.v, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)qi * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st);
+                if(rc != XEVE_HIP_OK) return rc;
+            }
+        }
+    if(num_refp1 > 0) {
+        const long tl = ((long)njobs * w * h) / 4, tc = ((long)njobs * P.cw * P.ch) / 4;
+        k_cu_mc_combine<<<(unsigned)((tl + 255) / 256), 256, 0, st>>>(pred_y, p1[0], mode, njobs, w * h);
+        if(chroma_format_idc) {
+            k_cu_mc_combine<<<(unsigned)((tc + 255) / 256), 256, 0, st>>>(pred_u, p1[1], mode, njobs, P.cw * P.ch);
+            k_cu_mc_combine<<<(unsigned)((tc + 255) / 256), 256, 0, st>>>(pred_v, p1[2], mode, njobs, P.cw * P.ch);
+        }
+    }
+    XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -199,6 +199,26 @@ def rdoq_dev(coef, log2w, log2h, qp, lam, ch_type, bit_depth, est, est_idx=None,
     return nnz
 
 
+def mc_cu_jobs(refp, num_refp, s_l, s_c, pic_w, pic_h, jobs, w, h, bit_depth, chroma_format_idc=1, pred=None, workspace=None):
+    """the CU motion-compensation driver xeve_mc for a batch of CUs (xeve_hip_mc_cu_jobs).  refp: HOST numpy array of
+    lib.REFPIC_DTYPE records [refi * 2 + list] holding device addresses; jobs: uint8 tensor of lib.CU_MC_JOB_DTYPE records.
+    Returns [pred_y, pred_u, pred_v] (dense per job)."""
+    L = _lib.load()
+    njobs = jobs.numel() // 20
+    ws, hs = (1 if chroma_format_idc <= 2 else 0), (1 if chroma_format_idc <= 1 else 0)
+    dev = jobs.device
+    if pred is None:
+        pred = [torch.empty((njobs, h * w), dtype=torch.int16, device=dev)] + [torch.empty((njobs, (h >> hs) * (w >> ws)), dtype=torch.int16, device=dev) for _ in range(2)]
+    need = L.xeve_hip_mc_cu_workspace(njobs, w, h, num_refp[0], num_refp[1])
+    if workspace is None:
+        workspace = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+    cl, cc = C.c_void_p(baseline_coef_l().ctypes.data), C.c_void_p(baseline_coef_c().ctypes.data)
+    _lib.check(L.xeve_hip_mc_cu_jobs(refp.ctypes.data_as(C.c_void_p), num_refp[0], num_refp[1], s_l, s_c, pic_w, pic_h, _ptr(jobs), njobs, w, h,
+                                     bit_depth, bit_depth, chroma_format_idc, cl, cc, _ptr(pred[0]), _ptr(pred[1]), _ptr(pred[2]), _ptr(workspace),
+                                     workspace.numel(), _stream()))
+    return pred
+
+
 def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 

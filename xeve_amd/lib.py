@@ -51,6 +51,8 @@ class CuBitsParams(C.Structure):  # xeve_hip_cu_bits_params
 
 
 EST_FULL_INTS = 108  # xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr [2] each, run[24][2], level[24][2], last[2][2]
+REFPIC_DTYPE = [("y", "<u8"), ("u", "<u8"), ("v", "<u8"), ("poc", "<i4"), ("pad_", "<i4")]  # xeve_hip_refpic (device addresses), host array
+CU_MC_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("refi", "i1", (2,)), ("pad_", "i1", (2,))]  # xeve_hip_cu_mc_job (20 B)
 SBAC_NCTX = 68
 SBAC_DTYPE = [("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"), ("pending_byte", "<u4"),
               ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"), ("ctx", "<u2", (SBAC_NCTX,))]  # xeve_hip_sbac (172 B)
@@ -118,6 +120,9 @@ FUNCTIONS = {
                                   c_void_p]),
     "xeve_hip_deblock": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_picbuf_expand": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "xeve_hip_mc_cu_workspace": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "xeve_hip_mc_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
