@@ -183,7 +183,8 @@ int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, int qp, doub
 /* The estimates as the reference derives them: xeve_rdoq_bit_est (xeve_mode.c:326-372) turns a coder state into
  * core->rdoq_est_* (xeve_type.h:737-747) through the table of xeve_init_bits_est (xeve_mode.c:304-313).  One record per
  * state, device memory; xeve_hip_rdoq_dev then quantises block b with record est[est_idx[b]] (est_idx == NULL: record 0)
- * and picks the cbf pair like xeve_tq.c:565-583 (ch_type 0 Y / 1 U / 2 V). */
+ * and picks the cbf pair like xeve_tq.c:565-583 (ch_type 0 Y / 1 U / 2 V; is_intra_cu = the CU's own mode, while the zero
+ * pre-test's threshold follows the SLICE type, xeve_tq.c:684-686). */
 struct xeve_hip_sbac;
 typedef struct xeve_hip_rdoq_est_full {
     int32_t cbf_all[2], cbf_luma[2], cbf_cb[2], cbf_cr[2];
@@ -191,8 +192,8 @@ typedef struct xeve_hip_rdoq_est_full {
 } xeve_hip_rdoq_est_full;
 int xeve_hip_rdoq_bit_est(const struct xeve_hip_sbac *sbac, int nstates, xeve_hip_rdoq_est_full *est, void *stream);
 int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
-                      const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int32_t *nnz,
-                      void *stream);
+                      const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int is_intra_cu,
+                      int32_t *nnz, void *stream);
 /* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
 int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
 /* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;

@@ -1,0 +1,112 @@
+/*
+ * oracle/ref_rdo_driver.c -- TEST INFRASTRUCTURE (build container only; output oracle/_ref/libref_rdo.so).
+ * Calls the reference's static pinter_residue_rdo (src_base/xeve_pinter.c:906-1336) -- prediction, residual, transform + RDOQ,
+ * reconstruction, CABAC bit counting and the coded-block-flag decision of ONE inter CU candidate -- on caller-supplied pictures
+ * and coder state.  xeve_pinter.c and xeve_mode.c are compiled in place (their static functions pinter_residue_rdo, pinter_mc,
+ * xeve_rdoq_bit_est are needed); everything else (xeve_mc, xeve_sub_block_tq, xeve_itdq, xeve_recon, xeve_eco_coef, the SAD /
+ * MC / transform tables) is linked from oracle/_ref/libxeveb_ref.so.  The context is set up the way xeve_platform_init_func,
+ * xeve_pic_prepare and mode_coding_unit leave it for a Baseline encoder with rdoq = 1, rdo_dbk_switch = 0, no delta QP.
+ */
+#include "xeve_pinter.c"
+#include "xeve_mode.c"
+#include "xeve_eco.h"
+#include "xeve_tq.h"
+#include "xeve_itdq.h"
+
+enum { C_SKIP = 0, C_PRED_MODE = 2, C_DIRECT = 5, C_INTER_DIR = 6, C_REFI = 8, C_MVP_IDX = 10, C_MVD = 13, C_CBF_ALL = 14,
+       C_CBF_LUMA = 15, C_CBF_CB = 16, C_CBF_CR = 17, C_RUN = 18, C_LAST = 42, C_LEVEL = 44, C_N = 68 };
+typedef struct { u32 range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter; u16 ctx[C_N]; } drv_sbac;
+#define MAP(F)                                                                          \
+    F(skip_flag, C_SKIP, 2) F(pred_mode, C_PRED_MODE, 3) F(direct_mode_flag, C_DIRECT, 1) \
+    F(inter_dir, C_INTER_DIR, 2) F(refi, C_REFI, 2) F(mvp_idx, C_MVP_IDX, 3) F(mvd, C_MVD, 1) \
+    F(cbf_all, C_CBF_ALL, 1) F(cbf_luma, C_CBF_LUMA, 1) F(cbf_cb, C_CBF_CB, 1) F(cbf_cr, C_CBF_CR, 1) \
+    F(run, C_RUN, 24) F(last, C_LAST, 2) F(level, C_LEVEL, 24)
+static void to_ref(XEVE_SBAC *d, const drv_sbac *s)
+{
+    xeve_sbac_reset(d, 0, 0, 0);
+    d->range = s->range, d->code = s->code, d->code_bits = s->code_bits, d->stacked_ff = s->stacked_ff, d->stacked_zero = s->stacked_zero;
+    d->pending_byte = s->pending_byte, d->is_pending_byte = s->is_pending_byte, d->bitcounter = s->bitcounter, d->bin_counter = s->bin_counter;
+    d->is_bitcount = 1;
+#define F(name, at, n) memcpy(d->ctx.name, s->ctx + at, 2 * n);
+    MAP(F)
+#undef F
+}
+static void from_ref(drv_sbac *d, const XEVE_SBAC *s)
+{
+    d->range = s->range, d->code = s->code, d->code_bits = s->code_bits, d->stacked_ff = s->stacked_ff, d->stacked_zero = s->stacked_zero;
+    d->pending_byte = s->pending_byte, d->is_pending_byte = s->is_pending_byte, d->bitcounter = s->bitcounter, d->bin_counter = s->bin_counter;
+#define F(name, at, n) memcpy(d->ctx + at, s->ctx.name, 2 * n);
+    MAP(F)
+#undef F
+}
+
+typedef struct { pel *y, *u, *v; int poc, pad_; } drv_refpic;
+typedef struct { int log2_cuw, log2_cuh, pic_w, pic_h, slice_type, num_refp[2], chroma_format_idc, bit_depth, tool_iqt, qp[3], pad_; double lambda[3], dist_chroma_weight[2]; } drv_rdo_params;
+typedef struct { int x, y; s16 mv[2][2], mvd[2][2]; s8 refi[2]; u8 mvp_idx[2]; u8 dir_flag, ctx_skip, ctx_pred_mode, pad_; int sbac; } drv_rdo_job;
+typedef struct { double cost; int nnz[3], pad_; s64 dist[2][3]; } drv_rdo_result;
+
+void refdrv_residue_rdo(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, const drv_refpic *refs, int s_l, int s_c, const drv_sbac *states,
+                        const drv_rdo_params *p, const drv_rdo_job *job, drv_rdo_result *res, s16 *coef_y, s16 *coef_u, s16 *coef_v, drv_sbac *best)
+{
+    static XEVE_CTX  *ctx;
+    static XEVE_CORE *core;
+    static XEVE_PIC   pic_o, pics[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    static XEVE_REFP  refp[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
+    static XEVE_SH    sh;
+    if(!ctx) ctx = calloc(1, sizeof(*ctx)), core = calloc(1, sizeof(*core)), xeve_init_bits_est();
+    XEVE_PINTER *pi = &ctx->pinter[0];
+    const int ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
+    const int lw = p->log2_cuw, lh = p->log2_cuh;
+    /* dispatch tables (xeve_platform_init_func, xeve_enc.c:722-825): the plain-C ones */
+    xeve_func_sad = xeve_tbl_sad_16b, xeve_func_ssd = xeve_tbl_ssd_16b, xeve_func_diff = xeve_tbl_diff_16b, xeve_func_satd = xeve_tbl_satd_16b;
+    xeve_func_mc_l = xeve_tbl_mc_l, xeve_func_mc_c = xeve_tbl_mc_c, xeve_func_average_no_clip = &xeve_average_16b_no_clip;
+    xeve_func_txb = &xeve_tbl_txb, ctx->fn_itxb = &xeve_tbl_itxb;
+    ctx->fn_tq = xeve_sub_block_tq, ctx->fn_itdp = xeve_itdq, ctx->fn_recon = xeve_recon, ctx->fn_eco_coef = xeve_eco_coef;
+    ctx->fn_rdoq_set_ctx_cc = xeve_rdoq_set_ctx_cc;
+    ctx->param.tool_iqt = p->tool_iqt, ctx->param.codec_bit_depth = p->bit_depth, ctx->param.rdoq = 1, ctx->param.rdo_dbk_switch = 0;
+    ctx->param.cs_w_shift = ws, ctx->param.cs_h_shift = hs;
+    xeve_init_err_scale(ctx);
+    ctx->sps.bit_depth_luma_minus8 = ctx->sps.bit_depth_chroma_minus8 = p->bit_depth - 8;
+    ctx->sps.chroma_format_idc = p->chroma_format_idc, ctx->sps.tool_admvp = 0, ctx->pps.cu_qp_delta_enabled_flag = 0;
+    ctx->w = p->pic_w, ctx->h = p->pic_h;
+    ctx->rpm.num_refp[0] = p->num_refp[0], ctx->rpm.num_refp[1] = p->num_refp[1];
+    ctx->sh = &sh, sh.slice_type = p->slice_type;
+    /* pictures */
+    pic_o.y = org_y, pic_o.u = org_u, pic_o.v = org_v, pic_o.s_l = s_org_l, pic_o.s_c = s_org_c;
+    int nref = p->num_refp[0] > p->num_refp[1] ? p->num_refp[0] : p->num_refp[1];
+    for(int r = 0; r < nref; r++)
+        for(int l = 0; l < REFP_NUM; l++) {
+            const drv_refpic *s = &refs[r * 2 + l];
+            pics[r][l].y = s->y, pics[r][l].u = s->u, pics[r][l].v = s->v, pics[r][l].s_l = s_l, pics[r][l].s_c = s_c, pics[r][l].poc = s->poc;
+            refp[r][l].pic = &pics[r][l], refp[r][l].poc = s->poc;
+        }
+    pi->pic_o = &pic_o, pi->o[Y_C] = org_y, pi->o[U_C] = org_u, pi->o[V_C] = org_v, pi->s_o[Y_C] = s_org_l, pi->s_o[U_C] = pi->s_o[V_C] = s_org_c;
+    pi->refp = refp, pi->slice_type = p->slice_type, pi->fn_mc = pinter_mc;
+    /* the candidate */
+    const int pidx = job->dir_flag ? PRED_DIR : (job->refi[0] >= 0 ? (job->refi[1] >= 0 ? PRED_BI : PRED_L0) : PRED_L1);
+    for(int l = 0; l < REFP_NUM; l++) {
+        pi->refi[pidx][l] = job->refi[l], pi->mvp_idx[pidx][l] = job->mvp_idx[l];
+        for(int d = 0; d < MV_D; d++) pi->mv[pidx][l][d] = job->mv[l][d], pi->mvd[pidx][l][d] = job->mvd[l][d];
+    }
+    /* the core as mode_coding_unit leaves it (xeve_mode.c:760-800) */
+    core->ctx = ctx, core->thread_cnt = 0, core->log2_cuw = lw, core->log2_cuh = lh, core->cuw = 1 << lw, core->cuh = 1 << lh;
+    core->qp_y = p->qp[0], core->qp_u = p->qp[1], core->qp_v = p->qp[2];
+    for(int c = 0; c < 3; c++) core->lambda[c] = p->lambda[c];
+    core->dist_chroma_weight[0] = p->dist_chroma_weight[0], core->dist_chroma_weight[1] = p->dist_chroma_weight[1];
+    core->tree_cons.changed = 0, core->tree_cons.tree_type = TREE_LC, core->tree_cons.mode_cons = eAll;
+    core->ctx_flags[CNID_SKIP_FLAG] = job->ctx_skip, core->ctx_flags[CNID_PRED_MODE] = job->ctx_pred_mode;
+    core->bs_temp.pdata[1] = &core->s_temp_run;
+    core->cost_best = MAX_COST;
+    to_ref(&core->s_curr_best[lw - 2][lh - 2], &states[job->sbac]);
+    xeve_rdoq_bit_est(&core->s_curr_best[lw - 2][lh - 2], core); /* xeve_mode.c:792 */
+
+    res->cost = pinter_residue_rdo(ctx, core, job->x, job->y, lw, lh, pi->pred[pidx], pi->coef[pidx], pidx, pi->mvp_idx[pidx]);
+    for(int c = 0; c < N_C; c++) res->nnz[c] = core->nnz[c];
+    memset(res->dist, 0, sizeof(res->dist)); /* locals of the reference function: not observable */
+    memcpy(coef_y, pi->coef[pidx][Y_C], sizeof(s16) << (lw + lh));
+    if(p->chroma_format_idc) {
+        memcpy(coef_u, pi->coef[pidx][U_C], sizeof(s16) << (lw + lh - ws - hs));
+        memcpy(coef_v, pi->coef[pidx][V_C], sizeof(s16) << (lw + lh - ws - hs));
+    }
+    from_ref(best, &core->s_temp_best);
+}

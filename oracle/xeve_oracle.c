@@ -1151,3 +1151,139 @@ void xo_mc_cu(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, con
     }
     for(int c = 0; c < 3; c++) free(p1[c]);
 }
+
+/* ===================================================================================================================
+ * pinter_residue_rdo (src_base/xeve_pinter.c:906-1336)
+ * =================================================================================================================== */
+void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                    const xo_rdo_params *p, const xo_rdo_job *job, xo_rdo_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                    xo_sbac *best)
+{
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth;
+    const int lw[3] = {p->log2_cuw, p->log2_cuw - ws, p->log2_cuw - ws}, lh[3] = {p->log2_cuh, p->log2_cuh - hs, p->log2_cuh - hs};
+    const int ncomp = idc ? 3 : 1;
+    int16_t  *coef[3] = {coef_y, coef_u, coef_v};
+    xo_pel   *pred[3], *rec;
+    int16_t  *tmp;
+    int64_t   dist[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int       nnz_store[3] = {0, 0, 0}, tnnz = 0;
+    xo_rdoq_est_full full;
+
+    for(int c = 0; c < 3; c++) pred[c] = malloc(sizeof(xo_pel) << (lw[0] + lh[0]));
+    rec = malloc(sizeof(xo_pel) << (lw[0] + lh[0])), tmp = malloc(sizeof(int16_t) << (lw[0] + lh[0]));
+    /* prediction (pi->fn_mc = pinter_mc -> xeve_mc, :962) */
+    xo_cu_mc_job mj;
+    memset(&mj, 0, sizeof(mj));
+    mj.x = job->x, mj.y = job->y, memcpy(mj.mv, job->mv, sizeof(mj.mv)), mj.refi[0] = job->refi[0], mj.refi[1] = job->refi[1];
+    xo_mc_cu(refp, s_l, s_c, p->pic_w, p->pic_h, &mj, 1 << lw[0], 1 << lh[0], bd, bd, idc, pred[0], pred[1], pred[2]);
+    /* the estimates RDOQ reads: xeve_rdoq_bit_est(&core->s_curr_best[..]) (xeve_mode.c:792) */
+    xo_rdoq_bit_est(&states[job->sbac], &full);
+    /* residual, SSD of the prediction, transform + quantisation (:969-998) */
+    for(int c = 0; c < ncomp; c++) {
+        const int w = 1 << lw[c], h = 1 << lh[c], so = c ? s_org_c : s_org_l;
+        const xo_pel *o = org[c] + (c ? (job->y >> hs) * so + (job->x >> ws) : job->y * so + job->x);
+        xo_diff(w, h, o, pred[c], so, w, w, coef[c]);
+        dist[0][c] = xo_ssd(w, h, pred[c], o, w, so, bd);
+        xo_trans(coef[c], lw[c], lh[c], bd);
+        if(xo_rdoq_zero_test(coef[c], lw[c], lh[c], p->qp[c], xo_quant_scale[p->tool_iqt][p->qp[c] % 6], p->slice_type == 2, bd)) {
+            xo_rdoq_est e;
+            xo_rdoq_est_select(&full, c, 0, &e);
+            nnz_store[c] = xo_rdoq(coef[c], lw[c], lh[c], p->qp[c], p->lambda[c], c == 0, bd, p->tool_iqt, &e);
+        }
+        else memset(coef[c], 0, sizeof(int16_t) << (lw[c] + lh[c])), nnz_store[c] = 0;
+        tnnz += nnz_store[c];
+    }
+    for(int c = ncomp; c < 3; c++) dist[0][c] = 0;
+
+    xo_cu_bits_params bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
+    bp.cm_init = 0, bp.chroma_format_idc = idc;
+    xo_cu_bits_job bj;
+    memset(&bj, 0, sizeof(bj));
+    bj.coef_off[0] = bj.coef_off[1] = bj.coef_off[2] = 0; /* blocks are passed as separate buffers below */
+    memcpy(bj.mvd, job->mvd, sizeof(bj.mvd)), bj.refi[0] = job->refi[0], bj.refi[1] = job->refi[1];
+    bj.mvp_idx[0] = job->mvp_idx[0], bj.mvp_idx[1] = job->mvp_idx[1], bj.dir_flag = job->dir_flag, bj.ctx_skip = job->ctx_skip, bj.ctx_pred_mode = job->ctx_pred_mode;
+    /* xo_cu_bits addresses Y / U / V through offsets into one buffer: lay the three blocks out back to back */
+    const int n0 = 1 << (lw[0] + lh[0]), n1 = idc ? 1 << (lw[1] + lh[1]) : 0;
+    int16_t *all = malloc(sizeof(int16_t) * (n0 + 2 * n1 + 1));
+    bj.coef_off[1] = n0, bj.coef_off[2] = n0 + n1;
+#define PACK() (memcpy(all, coef[0], sizeof(int16_t) * n0), (void)(idc ? (memcpy(all + n0, coef[1], sizeof(int16_t) * n1), memcpy(all + n0 + n1, coef[2], sizeof(int16_t) * n1)) : 0))
+    PACK();
+    const xo_sbac *entry = &states[job->sbac];
+    xo_sbac run;
+    double cost, cost_best = 1.7e+308; /* MAX_COST */
+    int    cbf_idx[3] = {0, 0, 0}, nnz[3];
+#define FULL_BITS(N0, N1, N2) (bj.mode = XO_BITS_CU_INTER, bj.sbac = 0, bj.nnz[0] = (N0), bj.nnz[1] = (N1), bj.nnz[2] = (N2), xo_cu_bits(entry, &run, &bp, &bj, all))
+#define SUM_COST(IY, IU, IV) ((double)dist[IY][0] + (((double)dist[IU][1] * p->dist_chroma_weight[0]) + ((double)dist[IV][2] * p->dist_chroma_weight[1])))
+    if(tnnz) {
+        /* reconstruct what was quantised (:1000-1051): dist[1] */
+        for(int c = 0; c < ncomp; c++) {
+            if(!nnz_store[c]) {
+                dist[1][c] = dist[0][c];
+                continue;
+            }
+            const int w = 1 << lw[c], h = 1 << lh[c], so = c ? s_org_c : s_org_l;
+            const xo_pel *o = org[c] + (c ? (job->y >> hs) * so + (job->x >> ws) : job->y * so + job->x);
+            memcpy(tmp, coef[c], sizeof(int16_t) << (lw[c] + lh[c]));
+            xo_dquant(tmp, lw[c], lh[c], xo_dq_scale[p->qp[c] % 6] << (p->qp[c] / 6), bd);
+            xo_itrans(tmp, lw[c], lh[c], bd);
+            xo_recon(tmp, pred[c], nnz_store[c], w, h, w, rec, bd);
+            dist[1][c] = xo_ssd(w, h, rec, o, w, so, bd);
+        }
+        for(int c = ncomp; c < 3; c++) dist[1][c] = 0;
+        if(!job->dir_flag) { /* all-zero alternative (:1103-1142) */
+            cost = SUM_COST(0, 0, 0);
+            cost += (double)(int)FULL_BITS(0, 0, 0) * p->lambda[0];
+            if(cost < cost_best) cost_best = cost, cbf_idx[0] = cbf_idx[1] = cbf_idx[2] = 0, *best = run;
+        }
+        /* as quantised (:1144-1178) */
+        int iy = nnz_store[0] > 0, iu = nnz_store[1] > 0, iv = nnz_store[2] > 0;
+        cost = SUM_COST(iy, iu, iv);
+        cost += (double)(int)FULL_BITS(nnz_store[0], nnz_store[1], nnz_store[2]) * p->lambda[0];
+        if(cost < cost_best) cost_best = cost, cbf_idx[0] = iy, cbf_idx[1] = iu, cbf_idx[2] = iv, *best = run;
+        /* each component with / without its coefficients, the coder state handed on (:1180-1218) */
+        xo_sbac prev_best = *entry, prev_run;
+        int     idx_best[3] = {0, 0, 0};
+        nnz[0] = nnz_store[0], nnz[1] = nnz_store[1], nnz[2] = nnz_store[2];
+        for(int i = 0; i < 3; i++) {
+            if(nnz_store[i] <= 0) continue;
+            double comp_best = 1.7e+308;
+            prev_run = prev_best;
+            for(int j = 0; j < 2; j++) {
+                cost = (double)dist[j][i] * (i == 0 ? 1 : p->dist_chroma_weight[i - 1]);
+                nnz[i] = j ? nnz_store[i] : 0;
+                bj.mode = (uint8_t)(XO_BITS_COMP_Y + i), bj.sbac = 0, bj.nnz[0] = nnz[0], bj.nnz[1] = nnz[1], bj.nnz[2] = nnz[2];
+                cost += (double)(int)xo_cu_bits(&prev_run, &run, &bp, &bj, all) * p->lambda[i];
+                if(cost < comp_best) comp_best = cost, idx_best[i] = j, prev_best = run;
+            }
+        }
+        if(idx_best[0] || idx_best[1] || idx_best[2]) {
+            iy = idx_best[0], iu = idx_best[1], iv = idx_best[2];
+            nnz[0] = iy ? nnz_store[0] : 0, nnz[1] = iu ? nnz_store[1] : 0, nnz[2] = iv ? nnz_store[2] : 0;
+        }
+        if(nnz[0] != nnz_store[0] || nnz[1] != nnz_store[1] || nnz[2] != nnz_store[2]) { /* the combination the component tests chose (:1220-1262) */
+            cost = SUM_COST(iy, iu, iv);
+            cost += (double)(int)FULL_BITS(nnz[0], nnz[1], nnz[2]) * p->lambda[0];
+            if(cost < cost_best) cost_best = cost, cbf_idx[0] = iy, cbf_idx[1] = iu, cbf_idx[2] = iv, *best = run;
+        }
+        for(int c = 0; c < 3; c++) {
+            res->nnz[c] = cbf_idx[c] ? nnz_store[c] : 0;
+            if(res->nnz[c] == 0 && nnz_store[c] != 0) memset(coef[c], 0, sizeof(int16_t) << (lw[c] + lh[c]));
+        }
+    }
+    else { /* nothing survived quantisation (:1276-1331) */
+        dist[1][0] = dist[1][1] = dist[1][2] = 0;
+        cost_best = (double)dist[0][0] + (p->dist_chroma_weight[0] * (double)dist[0][1]) + (p->dist_chroma_weight[1] * (double)dist[0][2]);
+        cost_best += (double)(int)FULL_BITS(0, 0, 0) * p->lambda[0];
+        *best = run;
+        res->nnz[0] = res->nnz[1] = res->nnz[2] = 0;
+    }
+    res->cost = cost_best, res->pad_ = 0;
+    memcpy(res->dist, dist, sizeof(dist));
+    free(all), free(tmp), free(rec);
+    for(int c = 0; c < 3; c++) free(pred[c]);
+#undef PACK
+#undef FULL_BITS
+#undef SUM_COST
+}

@@ -256,6 +256,39 @@ typedef struct xo_cu_mc_job {
 void xo_mc_cu(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_cu_mc_job *job, int w, int h, int bit_depth_luma,
               int bit_depth_chroma, int chroma_format_idc, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v);
 
+/* ---- the whole of pinter_residue_rdo (reference: src_base/xeve_pinter.c:906-1336) for one CU candidate ------------------------ */
+/* prediction (xeve_mc), residual, SSD, transform + RDOQ with the estimates of the entry coder state, reconstruction, and the
+ * rate-distortion decision about the coded-block flags: all-zero alternative, as quantised, each component with / without its
+ * coefficients (coder state threaded from component to component), final combination.  Presets with rdo_dbk_switch = 0
+ * (fast, medium), no delta QP, CU <= 64x64. */
+typedef struct xo_rdo_params {
+    int32_t log2_cuw, log2_cuh, pic_w, pic_h;
+    int32_t slice_type, num_refp[2], chroma_format_idc, bit_depth, tool_iqt;
+    int32_t qp[3];                 /* core->qp_y / qp_u / qp_v (already offset by the bit depth, xeve_def.h:52) */
+    int32_t pad_;
+    double  lambda[3];             /* core->lambda */
+    double  dist_chroma_weight[2]; /* core->dist_chroma_weight */
+} xo_rdo_params;
+typedef struct xo_rdo_job {
+    int32_t x, y;
+    int16_t mv[2][2], mvd[2][2];   /* pi->mv[pidx], pi->mvd[pidx] */
+    int8_t  refi[2];
+    uint8_t mvp_idx[2];
+    uint8_t dir_flag;              /* pidx == PRED_DIR: direct mode (no all-zero test, no motion syntax) */
+    uint8_t ctx_skip, ctx_pred_mode, pad_;
+    int32_t sbac;                  /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] in the state array */
+} xo_rdo_job;
+typedef struct xo_rdo_result {
+    double   cost;                 /* the return value */
+    int32_t  nnz[3];               /* core->nnz on exit */
+    int32_t  pad_;
+    int64_t  dist[2][3];           /* [0] no residual, [1] as quantised */
+} xo_rdo_result;
+/* org[c] / refp planes point at sample (0, 0); coef_y/u/v receive pi->coef[pidx] on exit (dense); best = core->s_temp_best */
+void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                    const xo_rdo_params *p, const xo_rdo_job *job, xo_rdo_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                    xo_sbac *best);
+
 #ifdef __cplusplus
 }
 #endif

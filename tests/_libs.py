@@ -418,3 +418,38 @@ def oracle_mc_cu():
     L.xo_mc_cu.restype = None
     L.xo_mc_cu.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     return L
+
+
+# ---- pinter_residue_rdo ------------------------------------------------------------------------------------------------
+class RdoParams(C.Structure):
+    _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("slice_type", C.c_int32),
+                ("num_refp", C.c_int32 * 2), ("chroma_format_idc", C.c_int32), ("bit_depth", C.c_int32), ("tool_iqt", C.c_int32),
+                ("qp", C.c_int32 * 3), ("pad_", C.c_int32), ("lambda_", C.c_double * 3), ("dist_chroma_weight", C.c_double * 2)]
+
+
+RDO_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)),
+                          ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1"), ("sbac", "<i4")])
+RDO_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))])
+assert RDO_JOB_DTYPE.itemsize == 36 and RDO_RESULT_DTYPE.itemsize == 72 and C.sizeof(RdoParams) == 96
+
+REF_RDO_SO = os.path.join(ORACLE_DIR, "_ref", "libref_rdo.so")
+_ref_rdo = None
+
+
+def ref_rdo():
+    global _ref_rdo
+    if _ref_rdo is None and os.path.exists(REF_RDO_SO):
+        L = C.CDLL(REF_RDO_SO)
+        L.refdrv_residue_rdo.restype = None
+        L.refdrv_residue_rdo.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]
+        _ref_rdo = L
+    return _ref_rdo
+
+
+def oracle_rdo():
+    L = oracle()
+    L.xo_residue_rdo.restype = None
+    L.xo_residue_rdo.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]
+    return L

@@ -178,12 +178,14 @@ def test_hip_rdoq_with_device_estimates_vs_oracle(lw, lh):
     est_dev = D.rdoq_bit_est(torch.from_numpy(states.view(np.uint8).copy()).to(dev))
     for ch_type in range(3):
         for is_intra in (0, 1):
+            slice_i = int(r.integers(0, 2))  # the zero pre-test follows the slice type, the cbf pair the CU's own mode
             bd, qp = int(r.choice([8, 10])), int(r.integers(14, 48))
             lam = float(r.choice([0.9, 11.3, 140.5])) * (1.0 + float(r.random()))
             blocks = np.stack([make_coef(r, lw, lh, bd, k % 4) for k in range(41)])
             idx = r.integers(0, len(states), size=len(blocks)).astype(np.int32)
             d = torch.from_numpy(blocks.copy()).to(dev)
-            nnz = D.rdoq_dev(d, lw, lh, qp, lam, ch_type, bd, est_dev, torch.from_numpy(idx).to(dev), zero_test=True, is_intra_slice=bool(is_intra)).cpu().numpy()
+            nnz = D.rdoq_dev(d, lw, lh, qp, lam, ch_type, bd, est_dev, torch.from_numpy(idx).to(dev), zero_test=True, is_intra_slice=bool(slice_i),
+                             is_intra_cu=bool(is_intra)).cpu().numpy()
             got = d.cpu().numpy()
             qs = D.QUANT_SCALE[0][qp % 6]
             for b in range(len(blocks)):
@@ -192,14 +194,14 @@ def test_hip_rdoq_with_device_estimates_vs_oracle(lw, lh):
                 est = RdoqEst()
                 OS.xo_rdoq_est_select(ptr(full), ch_type, is_intra, C.byref(est))
                 e = blocks[b].copy()
-                if O.xo_rdoq_zero_test(ptr(e), lw, lh, qp, qs, is_intra, bd):
+                if O.xo_rdoq_zero_test(ptr(e), lw, lh, qp, qs, slice_i, bd):
                     en = O.xo_rdoq(ptr(e), lw, lh, qp, lam, int(ch_type == 0), bd, 0, C.byref(est))
                 else:
                     e[:], en = 0, 0
                 assert nnz[b] == en and np.array_equal(got[b], e), (lw, lh, ch_type, is_intra, b)
             # record 0 for every block when no index is given
             d2 = torch.from_numpy(blocks.copy()).to(dev)
-            nnz2 = D.rdoq_dev(d2, lw, lh, qp, lam, ch_type, bd, est_dev, None, zero_test=False, is_intra_slice=bool(is_intra)).cpu().numpy()
+            nnz2 = D.rdoq_dev(d2, lw, lh, qp, lam, ch_type, bd, est_dev, None, zero_test=False, is_intra_cu=bool(is_intra)).cpu().numpy()
             full = np.zeros(EST_FULL_INTS, np.int32)
             OS.xo_rdoq_bit_est(ptr(states[0:1]), ptr(full))
             est = RdoqEst()

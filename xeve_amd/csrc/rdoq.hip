@@ -295,7 +295,7 @@ template <bool DEV> static void rdoq_launch(int16_t *coef, int nblk, const RdoqK
 
 static int rdoq_common(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
                        const xeve_hip_rdoq_est *est, const xeve_hip_rdoq_est_full *est_dev, const int32_t *est_idx, int zero_test,
-                       int is_intra_slice, int32_t *nnz, void *stream)
+                       int is_intra_slice, int is_intra_cu, int32_t *nnz, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(coef && (est || est_dev) && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
@@ -339,7 +339,7 @@ static int rdoq_common(int16_t *coef, int nblk, int log2w, int log2h, int qp, do
         P.o_run   = (int)(offsetof(xeve_hip_rdoq_est_full, run) / sizeof(int)) + 2 * c;
         P.o_level = (int)(offsetof(xeve_hip_rdoq_est_full, level) / sizeof(int)) + 2 * c;
         P.o_last  = (int)(offsetof(xeve_hip_rdoq_est_full, last) / sizeof(int)) + 2 * ctx_last;
-        const size_t o = (!is_intra_slice && ch_type == 0) ? offsetof(xeve_hip_rdoq_est_full, cbf_all)
+        const size_t o = (!is_intra_cu && ch_type == 0) ? offsetof(xeve_hip_rdoq_est_full, cbf_all)
                          : ch_type == 0                   ? offsetof(xeve_hip_rdoq_est_full, cbf_luma)
                          : ch_type == 1                   ? offsetof(xeve_hip_rdoq_est_full, cbf_cb)
                                                           : offsetof(xeve_hip_rdoq_est_full, cbf_cr);
@@ -354,15 +354,15 @@ extern "C" int xeve_hip_rdoq_zt(int16_t *coef, int nblk, int log2w, int log2h, i
                                 const xeve_hip_rdoq_est *est, int zero_test, int is_intra_slice, int32_t *nnz, void *stream)
 {
     XH_REQUIRE(est);
-    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, is_luma ? 0 : 1, bit_depth, tool_iqt, est, nullptr, nullptr, zero_test, is_intra_slice, nnz, stream);
+    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, is_luma ? 0 : 1, bit_depth, tool_iqt, est, nullptr, nullptr, zero_test, is_intra_slice, 0, nnz, stream);
 }
 
 extern "C" int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
-                                 const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int32_t *nnz,
-                                 void *stream)
+                                 const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int is_intra_cu,
+                                 int32_t *nnz, void *stream)
 {
     XH_REQUIRE(est);
-    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, nullptr, est, est_idx, zero_test, is_intra_slice, nnz, stream);
+    return rdoq_common(coef, nblk, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, nullptr, est, est_idx, zero_test, is_intra_slice, is_intra_cu, nnz, stream);
 }
 
 // ---- xeve_rdoq_bit_est (xeve_mode.c:326-372): estimates from a coder state ----------------------------------------------

@@ -189,13 +189,14 @@ def rdoq_bit_est(sbac):
     return est
 
 
-def rdoq_dev(coef, log2w, log2h, qp, lam, ch_type, bit_depth, est, est_idx=None, zero_test=False, is_intra_slice=False, tool_iqt=0, nnz=None):
+def rdoq_dev(coef, log2w, log2h, qp, lam, ch_type, bit_depth, est, est_idx=None, zero_test=False, is_intra_slice=False, is_intra_cu=False, tool_iqt=0,
+             nnz=None):
     """RDOQ with per-block estimates from device memory (xeve_hip_rdoq_dev): est = rdoq_bit_est(...), est_idx int32 [nblk] or None"""
     if nnz is None:
         nnz = torch.empty(coef.shape[0], dtype=torch.int32, device=coef.device)
     _lib.check(_lib.load().xeve_hip_rdoq_dev(_ptr(_i16(coef)), coef.shape[0], log2w, log2h, qp, float(lam), int(ch_type), bit_depth, tool_iqt,
                                              _ptr(est), _ptr(est_idx) if est_idx is not None else None, int(zero_test), int(is_intra_slice),
-                                             _ptr(nnz), _stream()))
+                                             int(is_intra_cu), _ptr(nnz), _stream()))
     return nnz
 
 
