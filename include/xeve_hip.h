@@ -416,6 +416,46 @@ int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp
                         int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_pel *pred_y,
                         xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* (7) The whole of pinter_residue_rdo (src_base/xeve_pinter.c:906-1336) for a batch of inter    */
+/*     CU candidates of one size: prediction, residual + SSD, transform + RDOQ with the estimates */
+/*     of each candidate's entry coder state, reconstruction + SSD, CABAC bit counts and the      */
+/*     coded-block-flag decision (all-zero / as quantised / per component with the coder state    */
+/*     handed on / chosen combination), in the reference's double-precision expression order.      */
+/*     Presets with rdo_dbk_switch = 0 (fast, medium), no delta QP, tool_iqt 0, CU <= 64x64.        */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_rdo_params {
+    int32_t log2_cuw, log2_cuh, pic_w, pic_h;
+    int32_t slice_type, num_refp[2], chroma_format_idc, bit_depth, tool_iqt;
+    int32_t qp[3];                 /* core->qp_y / qp_u / qp_v */
+    int32_t pad_;
+    double  lambda[3];             /* core->lambda */
+    double  dist_chroma_weight[2]; /* core->dist_chroma_weight */
+} xeve_hip_rdo_params;
+typedef struct xeve_hip_rdo_job {
+    int32_t x, y;
+    int16_t mv[2][2], mvd[2][2];   /* pi->mv[pidx], pi->mvd[pidx] */
+    int8_t  refi[2];
+    uint8_t mvp_idx[2];
+    uint8_t dir_flag;              /* pidx == PRED_DIR */
+    uint8_t ctx_skip, ctx_pred_mode, pad_;
+    int32_t sbac;                  /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] in `states` */
+} xeve_hip_rdo_job;
+typedef struct xeve_hip_rdo_result {
+    double  cost;                  /* the return value of pinter_residue_rdo */
+    int32_t nnz[3];                /* core->nnz on exit */
+    int32_t pad_;
+    int64_t dist[2][3];            /* SSD without residual / as quantised */
+} xeve_hip_rdo_result;
+/* org (HOST array of three device pointers at sample (0, 0)), refp (HOST, as for xeve_hip_mc_cu_jobs), params, coefficient
+ * tables: host memory.  states, jobs, results, coef, best, workspace: device memory.  coef receives pi->coef[pidx]: the Y blocks
+ * of all candidates ([njobs][h*w]), then the U blocks, then the V blocks; best[j] = core->s_temp_best. */
+size_t xeve_hip_residue_rdo_workspace(int njobs, int nstates, const xeve_hip_rdo_params *params, int s_org_l, int s_org_c);
+int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                              const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *params, const xeve_hip_rdo_job *jobs, int njobs,
+                              const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_rdo_result *results, int16_t *coef,
+                              xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""pinter_residue_rdo on the GPU (xeve_hip_residue_rdo_jobs): cost (bit pattern of the double), core->nnz, distortions, coefficient
+buffers and core->s_temp_best against the reference goldens and the pinned oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from _libs import RDO_RESULT_DTYPE, SBAC_DTYPE, oracle_rdo, ptr
+from _mc_cases import refpic_table
+from _rdo_cases import make_jobs, make_params, make_picture, states
+from _rdo_golden import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(refs, org, st, p, jobs):
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    dplanes = [[torch.from_numpy(x).to(dev) for x in pic] for pic in refs["pics"]]
+    lut = {id(x): t for pic, dp in zip(refs["pics"], dplanes) for x, t in zip(pic, dp)}
+    dev_tab = refpic_table(refs, lambda a, off: lut[id(a)].data_ptr() + 2 * off).view(lib.REFPIC_DTYPE)
+    dorg = [torch.from_numpy(x).to(dev) for x in org]
+    org_ptrs = [dorg[0].data_ptr() + 2 * refs["org_l"], dorg[1].data_ptr() + 2 * refs["org_c"], dorg[2].data_ptr() + 2 * refs["org_c"]]
+    hp = lib.RdoParams.from_buffer_copy(bytes(p))
+    res, coef, best = D.residue_rdo_jobs(org_ptrs, refs["s_l"], refs["s_c"], dev_tab, refs["s_l"], refs["s_c"], torch.from_numpy(st.view(np.uint8).copy()).to(dev), hp,
+                                         torch.from_numpy(jobs.view(np.uint8).copy()).to(dev))
+    torch.cuda.synchronize()
+    n = len(jobs)
+    n0 = 1 << (p.log2_cuw + p.log2_cuh)
+    n1 = (n0 >> (refs["ws"] + refs["hs"])) if p.chroma_format_idc else 0
+    c = coef.cpu().numpy()
+    return (res.cpu().numpy().reshape(-1).view(RDO_RESULT_DTYPE), [c[:n * n0].reshape(n, n0), c[n * n0:n * (n0 + n1)].reshape(n, n1), c[n * (n0 + n1):n * (n0 + 2 * n1)].reshape(n, n1)],
+            best.cpu().numpy().reshape(-1).view(SBAC_DTYPE))
+
+
+def test_hip_residue_rdo_matches_reference_goldens():
+    n = 0
+    for c in golden():
+        res, coef, best = run_hip(c["refs"], c["org"], c["states"], c["p"], c["jobs"])
+        assert res["cost"].tobytes() == np.ascontiguousarray(c["cost"]).tobytes(), (n, np.flatnonzero(res["cost"] != c["cost"])[:5])
+        assert np.array_equal(res["nnz"], c["nnz"]), n
+        for k in range(3 if c["idc"] else 1):
+            assert np.array_equal(coef[k], c["coef"][k]), (n, k)
+        assert best.tobytes() == c["best"].tobytes(), n
+        n += 1
+    assert n == 6
+
+
+@pytest.mark.parametrize("w,h,bd,nref,idc,slice_type", [(128, 96, 10, 2, 1, 0), (128, 64, 10, 1, 1, 1), (96, 64, 8, 2, 1, 0), (64, 64, 10, 2, 0, 0),
+                                                        (256, 128, 10, 3, 1, 0)])
+def test_hip_residue_rdo_vs_oracle(w, h, bd, nref, idc, slice_type):
+    O = oracle_rdo()
+    r = np.random.default_rng(5 * w + h + bd + nref + idc + slice_type)
+    refs, org = make_picture(r, w, h, bd, nref, idc)
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    st = states(r, 7)
+    org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]],
+                        np.uint64)
+    seen = dict(zero=0, kept=0, dropped=0)
+    for (lw, lh) in [(3, 3), (4, 4), (5, 5), (6, 6), (2, 2), (4, 3), (3, 5)]:
+        cuw, cuh = 1 << lw, 1 << lh
+        if cuw > w or cuh > h:
+            continue
+        p = make_params(r, lw, lh, w, h, bd, nref, idc, slice_type)
+        jobs = make_jobs(r, 60, w, h, cuw, cuh, nref, len(st), slice_type)
+        res, coef, best = run_hip(refs, org, st, p, jobs)
+        nc = (cuw >> refs["ws"]) * (cuh >> refs["hs"])
+        for i in range(len(jobs)):
+            er, eb = np.zeros(1, RDO_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec = [np.zeros(cuw * cuh, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            O.xo_residue_rdo(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), p, ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]),
+                             ptr(ec[1]), ptr(ec[2]), ptr(eb))
+            key = (lw, lh, i, jobs[i], res[i], er[0])
+            assert res["cost"][i].tobytes() == er["cost"][0].tobytes(), key
+            assert np.array_equal(res["nnz"][i], er["nnz"][0]) and np.array_equal(res["dist"][i], er["dist"][0]), key
+            for k in range(3 if idc else 1):
+                assert np.array_equal(coef[k][i], ec[k]), (k,) + key
+            assert best[i:i + 1].tobytes() == eb.tobytes(), key
+            nz = er["nnz"][0][:3 if idc else 1]
+            seen["zero"] += int(not nz.any())
+            seen["kept"] += int(nz.all())
+            seen["dropped"] += int(nz.any() and not nz.all())
+    assert seen["zero"] and seen["kept"], seen

@@ -1,0 +1,333 @@
+// xeve_amd/csrc/rdo.hip -- pinter_residue_rdo for a batch of inter CU candidates, composed on the device.
+//
+// reference: pinter_residue_rdo (src_base/xeve_pinter.c:906-1336): prediction (xeve_mc), residual + SSD, transform + RDOQ with the
+// estimates of the entry coder state (xeve_rdoq_bit_est, xeve_mode.c:792), reconstruction + SSD, and the coded-block-flag decision
+// from CABAC bit counts: all-zero alternative, as quantised, every component with / without its coefficients (the coder state is
+// handed from one component test to the next), the combination those tests chose.  rdo_dbk_switch = 0 (presets fast / medium).
+//
+// Everything heavy already exists as a batched entry point (xeve_hip_mc_cu_jobs, the fused residual chain, xeve_hip_rdoq_dev,
+// xeve_hip_cu_bits_jobs); this file strings them together and adds the per-candidate decision kernels (double precision, the
+// reference's expression order; compiled with -ffp-contract=off).  The decision is a dependent chain of four bit-count rounds:
+//   round 1: {all-zero, as-is, Y without, Y with} from the entry state         -> best so far, Y's choice, state after Y
+//   round 2: {U without, U with} from the state after Y                         -> U's choice, state after U
+//   round 3: {V without, V with} from the state after U                         -> V's choice
+//   round 4: {the chosen combination} from the entry state (when it differs from "as is")
+// Jobs of a round run in parallel over all candidates.
+#include "xh_common.h"
+
+extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h,
+                                          int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda, int ch_type, int tool_iqt,
+                                          const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int16_t *coef, pel *rec, int s_rec, int32_t *nnz,
+                                          int64_t *ssd, void *stream);
+
+struct RdoK {
+    int    n0, n1, ncomp, njobs, dir_unused;
+    int    w, h, ws, hs, s_org_l, s_org_c;
+    double lambda[3], wgt[2];
+};
+
+struct Cand { // per candidate, between the rounds
+    double cost_best;
+    int    nnz_store[3], idx_best[3], cbf_idx[3], iy, iu, iv, tnnz, round4;
+};
+
+#define MAX_COST 1.7e+308
+
+__device__ __forceinline__ void copy_state(xeve_hip_sbac *d, const xeve_hip_sbac *s)
+{
+    const unsigned *a = (const unsigned *)s;
+    unsigned       *b = (unsigned *)d;
+#pragma unroll
+    for(int i = 0; i < (int)(sizeof(xeve_hip_sbac) / 4); i++) b[i] = a[i];
+}
+
+__device__ __forceinline__ void fill_bits_job(xeve_hip_cu_bits_job &b, const xeve_hip_rdo_job &J, const RdoK &P, int j, int mode, int n0, int n1, int n2, int sbac)
+{
+    b.coef_off[0] = j * P.n0, b.coef_off[1] = P.njobs * P.n0 + j * P.n1, b.coef_off[2] = P.njobs * (P.n0 + P.n1) + j * P.n1;
+    b.nnz[0] = n0, b.nnz[1] = n1, b.nnz[2] = n2, b.sbac = sbac;
+    b.mvd[0][0] = J.mvd[0][0], b.mvd[0][1] = J.mvd[0][1], b.mvd[1][0] = J.mvd[1][0], b.mvd[1][1] = J.mvd[1][1];
+    b.refi[0] = J.refi[0], b.refi[1] = J.refi[1], b.mvp_idx[0] = J.mvp_idx[0], b.mvp_idx[1] = J.mvp_idx[1];
+    b.mode = (uint8_t)mode, b.dir_flag = J.dir_flag, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = J.ctx_pred_mode;
+}
+
+// jobs of the building blocks: prediction, residual chain (luma / chroma), estimate record per block
+__global__ void k_rdo_prep(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, xeve_hip_cu_mc_job *__restrict__ mc, xeve_hip_job *__restrict__ rl,
+                           xeve_hip_job *__restrict__ rc, int *__restrict__ est_idx)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    xeve_hip_cu_mc_job m;
+    m.x = J.x, m.y = J.y, m.mv[0][0] = J.mv[0][0], m.mv[0][1] = J.mv[0][1], m.mv[1][0] = J.mv[1][0], m.mv[1][1] = J.mv[1][1];
+    m.refi[0] = J.refi[0], m.refi[1] = J.refi[1], m.pad_[0] = m.pad_[1] = 0;
+    mc[j] = m;
+    rl[j].off1 = J.y * P.s_org_l + J.x, rl[j].off2 = j * P.n0;
+    rc[j].off1 = (J.y >> P.hs) * P.s_org_c + (J.x >> P.ws), rc[j].off2 = j * P.n1;
+    est_idx[j] = J.sbac;
+}
+
+// round 1 jobs: all-zero, as quantised, Y without / with its coefficients -- all from the entry state
+__global__ void k_rdo_round1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const int *__restrict__ nnz_y, const int *__restrict__ nnz_u,
+                             const int *__restrict__ nnz_v, Cand *__restrict__ cand, xeve_hip_cu_bits_job *__restrict__ bj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    Cand c;
+    c.nnz_store[0] = nnz_y[j], c.nnz_store[1] = P.ncomp > 1 ? nnz_u[j] : 0, c.nnz_store[2] = P.ncomp > 1 ? nnz_v[j] : 0;
+    c.tnnz = c.nnz_store[0] + c.nnz_store[1] + c.nnz_store[2];
+    c.cost_best = MAX_COST, c.idx_best[0] = c.idx_best[1] = c.idx_best[2] = 0, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0;
+    c.iy = c.nnz_store[0] > 0, c.iu = c.nnz_store[1] > 0, c.iv = c.nnz_store[2] > 0, c.round4 = 0;
+    cand[j] = c;
+    xeve_hip_cu_bits_job *b = bj + 4 * j;
+    fill_bits_job(b[0], J, P, j, XEVE_HIP_BITS_CU_INTER, 0, 0, 0, J.sbac);
+    fill_bits_job(b[1], J, P, j, XEVE_HIP_BITS_CU_INTER, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
+    fill_bits_job(b[2], J, P, j, XEVE_HIP_BITS_COMP_Y, 0, c.nnz_store[1], c.nnz_store[2], J.sbac);
+    fill_bits_job(b[3], J, P, j, XEVE_HIP_BITS_COMP_Y, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
+}
+
+__device__ __forceinline__ double sum_cost(const long *d0, const long *d1, int iy, int iu, int iv, const RdoK &P)
+{ // (double)dist[idx_y][Y] + (((double)dist[idx_u][U] * w0) + ((double)dist[idx_v][V] * w1))  (xeve_pinter.c:1112-1113)
+    return (double)(iy ? d1[0] : d0[0]) + (((double)(iu ? d1[1] : d0[1]) * P.wgt[0]) + ((double)(iv ? d1[2] : d0[2]) * P.wgt[1]));
+}
+
+__device__ __forceinline__ void load_dist(const long *ssd_y, const long *ssd_u, const long *ssd_v, int j, const RdoK &P, long *d0, long *d1)
+{
+    d0[0] = ssd_y[2 * j], d1[0] = ssd_y[2 * j + 1];
+    d0[1] = P.ncomp > 1 ? ssd_u[2 * j] : 0, d1[1] = P.ncomp > 1 ? ssd_u[2 * j + 1] : 0;
+    d0[2] = P.ncomp > 1 ? ssd_v[2 * j] : 0, d1[2] = P.ncomp > 1 ? ssd_v[2 * j + 1] : 0;
+}
+
+// after round 1: best so far; Y's choice; jobs of round 2 (U without / with) from the state after Y
+__global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v,
+                              const unsigned *__restrict__ bits, const xeve_hip_sbac *__restrict__ st_out, const xeve_hip_sbac *__restrict__ entry,
+                              Cand *__restrict__ cand, xeve_hip_sbac *__restrict__ best, xeve_hip_sbac *__restrict__ prev,
+                              xeve_hip_cu_bits_job *__restrict__ bj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    Cand c = cand[j];
+    long d0[3], d1[3];
+    load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
+    const unsigned *b = bits + 4 * j;
+    const xeve_hip_sbac *so = st_out + 4 * j;
+    if(c.tnnz == 0) { // nothing survived quantisation (xeve_pinter.c:1276-1331)
+        c.cost_best = (double)d0[0] + (P.wgt[0] * (double)d0[1]) + (P.wgt[1] * (double)d0[2]);
+        c.cost_best += (double)(int)b[0] * P.lambda[0];
+        copy_state(best + j, so + 0);
+        copy_state(prev + j, entry + J.sbac);
+    }
+    else {
+        if(!J.dir_flag) { // all-zero alternative (:1103-1142)
+            double cost = sum_cost(d0, d1, 0, 0, 0, P);
+            cost += (double)(int)b[0] * P.lambda[0];
+            if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0, copy_state(best + j, so + 0);
+        }
+        { // as quantised (:1144-1178)
+            double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
+            cost += (double)(int)b[1] * P.lambda[0];
+            if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, copy_state(best + j, so + 1);
+        }
+        // Y with / without its coefficients (:1180-1218, i = 0)
+        if(c.nnz_store[0] > 0) {
+            double c0 = (double)d0[0] * 1.0, c1 = (double)d1[0] * 1.0;
+            c0 += (double)(int)b[2] * P.lambda[0], c1 += (double)(int)b[3] * P.lambda[0];
+            const int pick = c1 < c0; // j = 0 is taken first, j = 1 must be strictly smaller
+            c.idx_best[0] = pick;
+            copy_state(prev + j, so + 2 + pick);
+        }
+        else copy_state(prev + j, entry + J.sbac);
+    }
+    cand[j] = c;
+    xeve_hip_cu_bits_job *o = bj + 2 * j;
+    fill_bits_job(o[0], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], 0, c.nnz_store[2], j);
+    fill_bits_job(o[1], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
+}
+
+// after round 2 (comp = 1) / round 3 (comp = 2): that component's choice; next round's jobs
+__global__ void k_rdo_decide_comp(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, int comp, const long *ssd_y, const long *ssd_u, const long *ssd_v,
+                                  const unsigned *__restrict__ bits, const xeve_hip_sbac *__restrict__ st_out, Cand *__restrict__ cand,
+                                  xeve_hip_sbac *__restrict__ prev, xeve_hip_cu_bits_job *__restrict__ bj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    Cand c = cand[j];
+    long d0[3], d1[3];
+    load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
+    if(c.tnnz != 0 && c.nnz_store[comp] > 0) {
+        double c0 = (double)d0[comp] * P.wgt[comp - 1], c1 = (double)d1[comp] * P.wgt[comp - 1];
+        c0 += (double)(int)bits[2 * j] * P.lambda[comp], c1 += (double)(int)bits[2 * j + 1] * P.lambda[comp];
+        const int pick = c1 < c0;
+        c.idx_best[comp] = pick;
+        copy_state(prev + j, st_out + 2 * j + pick);
+    }
+    if(comp == 1) {
+        xeve_hip_cu_bits_job *o = bj + 2 * j;
+        fill_bits_job(o[0], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], 0, j);
+        fill_bits_job(o[1], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
+    }
+    else { // the combination the component tests chose (:1220-1262)
+        int n[3] = {c.nnz_store[0], c.nnz_store[1], c.nnz_store[2]};
+        if(c.tnnz != 0 && (c.idx_best[0] || c.idx_best[1] || c.idx_best[2])) {
+            c.iy = c.idx_best[0], c.iu = c.idx_best[1], c.iv = c.idx_best[2];
+            n[0] = c.iy ? n[0] : 0, n[1] = c.iu ? n[1] : 0, n[2] = c.iv ? n[2] : 0;
+        }
+        c.round4 = c.tnnz != 0 && (n[0] != c.nnz_store[0] || n[1] != c.nnz_store[1] || n[2] != c.nnz_store[2]);
+        fill_bits_job(bj[j], J, P, j, c.round4 ? XEVE_HIP_BITS_CU_INTER : XEVE_HIP_BITS_CU_SKIP, n[0], n[1], n[2], J.sbac);
+    }
+    cand[j] = c;
+}
+
+// after round 4: final comparison, results, dropped coefficient blocks zeroed (:1264-1275)
+__global__ void k_rdo_finish(RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v, const unsigned *__restrict__ bits,
+                             const xeve_hip_sbac *__restrict__ st_out, Cand *__restrict__ cand, xeve_hip_sbac *__restrict__ best,
+                             xeve_hip_rdo_result *__restrict__ res, unsigned char *__restrict__ drop)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    Cand c = cand[j];
+    long d0[3], d1[3];
+    load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
+    if(c.round4) {
+        double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
+        cost += (double)(int)bits[j] * P.lambda[0];
+        if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, copy_state(best + j, st_out + j);
+    }
+    xeve_hip_rdo_result r;
+    r.cost = c.cost_best, r.pad_ = 0;
+    for(int k = 0; k < 3; k++) {
+        r.nnz[k] = c.tnnz != 0 && c.cbf_idx[k] ? c.nnz_store[k] : 0;
+        drop[3 * j + k] = r.nnz[k] == 0 && c.nnz_store[k] != 0;
+        r.dist[0][k] = d0[k], r.dist[1][k] = c.tnnz != 0 ? d1[k] : 0;
+    }
+    res[j] = r;
+}
+
+__global__ void k_rdo_zero_dropped(int16_t *__restrict__ coef, const unsigned char *__restrict__ drop, RdoK P)
+{ // one workgroup per (candidate, component)
+    const int j = blockIdx.x / 3, k = blockIdx.x % 3;
+    if(!drop[3 * j + k]) return;
+    const int n = k ? P.n1 : P.n0;
+    int16_t *b = coef + (k == 0 ? (size_t)j * P.n0 : (size_t)P.njobs * P.n0 + (size_t)(k - 1) * P.njobs * P.n1 + (size_t)j * P.n1);
+    for(int i = threadIdx.x; i < n; i += blockDim.x) b[i] = 0;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct RdoLayout {
+    size_t mc, rl, rc, est_idx, est, pred[3], rec[3], nnz[3], ssd[3], cand, prev, bj, bits, st_out, drop, mcws, bitws, total;
+};
+static RdoLayout rdo_layout(int njobs, int n0, int n1, int nstates, size_t rec_l, size_t rec_c, int w, int h, int nr0, int nr1)
+{
+    RdoLayout L;
+    size_t o = 0, n = njobs;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    L.mc = take(n * sizeof(xeve_hip_cu_mc_job)), L.rl = take(n * sizeof(xeve_hip_job)), L.rc = take(n * sizeof(xeve_hip_job));
+    L.est_idx = take(n * 4), L.est = take((size_t)nstates * sizeof(xeve_hip_rdoq_est_full));
+    L.pred[0] = take(n * n0 * 2), L.pred[1] = take(n * n1 * 2 + 8), L.pred[2] = take(n * n1 * 2 + 8);
+    L.rec[0] = take(rec_l * 2), L.rec[1] = take(rec_c * 2 + 8), L.rec[2] = take(rec_c * 2 + 8);
+    for(int k = 0; k < 3; k++) L.nnz[k] = take(n * 4), L.ssd[k] = take(n * 16);
+    L.cand = take(n * sizeof(Cand)), L.prev = take(n * sizeof(xeve_hip_sbac));
+    L.bj = take(4 * n * sizeof(xeve_hip_cu_bits_job)), L.bits = take(4 * n * 4), L.st_out = take(4 * n * sizeof(xeve_hip_sbac));
+    L.drop = take(3 * n);
+    L.mcws = take(xeve_hip_mc_cu_workspace(njobs, w, h, nr0, nr1));
+    L.bitws = take(xeve_hip_cu_bits_workspace(4 * njobs, n * ((size_t)n0 + 2 * (size_t)n1)));
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t xeve_hip_residue_rdo_workspace(int njobs, int nstates, const xeve_hip_rdo_params *p, int s_org_l, int s_org_c)
+{
+    if(!p || njobs <= 0) return 256;
+    const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1;
+    const int n0 = 1 << (p->log2_cuw + p->log2_cuh), n1 = p->chroma_format_idc ? n0 >> (ws + hs) : 0;
+    return rdo_layout(njobs, n0, n1, nstates > 0 ? nstates : 1, (size_t)s_org_l * p->pic_h, (size_t)s_org_c * (p->pic_h >> hs), 1 << p->log2_cuw, 1 << p->log2_cuh,
+                      p->num_refp[0], p->num_refp[1]).total;
+}
+
+static const int k_q_scale[6]  = {26214, 23302, 20560, 18396, 16384, 14764}; // xeve_quant_scale[0] (xeve_tq.c:37)
+static const int k_dq_scale[6] = {40, 45, 51, 57, 64, 71};                   // xeve_tbl_dq_scale_b (xeve_tbl.c:237)
+
+extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                                         const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *p, const xeve_hip_rdo_job *jobs, int njobs,
+                                         const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_rdo_result *results, int16_t *coef,
+                                         xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && best && workspace && coef_l);
+    XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6 && p->tool_iqt == 0);
+    XH_REQUIRE(p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3);
+    XH_REQUIRE(org[0] && (p->chroma_format_idc == 0 || (org[1] && org[2] && coef_c)));
+    if(njobs == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(workspace_bytes >= xeve_hip_residue_rdo_workspace(njobs, nstates, p, s_org_l, s_org_c));
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth;
+    const int lw[3] = {p->log2_cuw, p->log2_cuw - ws, p->log2_cuw - ws}, lh[3] = {p->log2_cuh, p->log2_cuh - hs, p->log2_cuh - hs};
+    RdoK P;
+    P.n0 = 1 << (lw[0] + lh[0]), P.n1 = idc ? 1 << (lw[1] + lh[1]) : 0, P.ncomp = idc ? 3 : 1, P.njobs = njobs, P.dir_unused = 0;
+    P.w = 1 << lw[0], P.h = 1 << lh[0], P.ws = ws, P.hs = hs, P.s_org_l = s_org_l, P.s_org_c = s_org_c;
+    for(int k = 0; k < 3; k++) P.lambda[k] = p->lambda[k];
+    P.wgt[0] = p->dist_chroma_weight[0], P.wgt[1] = p->dist_chroma_weight[1];
+    const RdoLayout L = rdo_layout(njobs, P.n0, P.n1, nstates, (size_t)s_org_l * p->pic_h, (size_t)s_org_c * (p->pic_h >> hs), P.w, P.h, p->num_refp[0], p->num_refp[1]);
+    char *W = (char *)workspace;
+    auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
+    auto *rl = (xeve_hip_job *)(W + L.rl), *rc = (xeve_hip_job *)(W + L.rc);
+    int  *est_idx = (int *)(W + L.est_idx);
+    auto *est = (xeve_hip_rdoq_est_full *)(W + L.est);
+    pel  *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
+    pel  *rec[3]  = {(pel *)(W + L.rec[0]), (pel *)(W + L.rec[1]), (pel *)(W + L.rec[2])};
+    int  *nnz[3]  = {(int *)(W + L.nnz[0]), (int *)(W + L.nnz[1]), (int *)(W + L.nnz[2])};
+    long *ssd[3]  = {(long *)(W + L.ssd[0]), (long *)(W + L.ssd[1]), (long *)(W + L.ssd[2])};
+    auto *cand = (Cand *)(W + L.cand);
+    auto *prev = (xeve_hip_sbac *)(W + L.prev), *st_out = (xeve_hip_sbac *)(W + L.st_out);
+    auto *bj = (xeve_hip_cu_bits_job *)(W + L.bj);
+    auto *bits = (unsigned *)(W + L.bits);
+    auto *drop = (unsigned char *)(W + L.drop);
+    hipStream_t st = (hipStream_t)stream;
+    const int   G  = (njobs + 255) / 256;
+    int rc_;
+
+    k_rdo_prep<<<G, 256, 0, st>>>(jobs, P, mc, rl, rc, est_idx);
+    // prediction (:962)
+    rc_ = xeve_hip_mc_cu_jobs(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, mc, njobs, P.w, P.h, bd, bd, idc, coef_l, coef_c, pred[0],
+                              pred[1], pred[2], W + L.mcws, L.bitws - L.mcws, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    // the estimates of every entry state (xeve_mode.c:792)
+    rc_ = xeve_hip_rdoq_bit_est(states, nstates, est, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    // residual, SSD, transform, zero pre-test + RDOQ, reconstruction, SSD (:969-1051)
+    int16_t *cf[3] = {coef, coef + (size_t)njobs * P.n0, coef + (size_t)njobs * (P.n0 + P.n1)};
+    for(int k = 0; k < P.ncomp; k++) {
+        const int q = p->qp[k];
+        XH_REQUIRE(q >= 0 && q <= 63);
+        rc_ = xeve_hip_residual_rdoq_dev(org[k], k ? s_org_c : s_org_l, pred[k], 1 << lw[k], k ? rc : rl, njobs, lw[k], lh[k], bd, q, k_q_scale[q % 6],
+                                         k_dq_scale[q % 6] << (q / 6), p->slice_type == 2, p->lambda[k], k, p->tool_iqt, est, est_idx, cf[k], rec[k],
+                                         k ? s_org_c : s_org_l, nnz[k], (int64_t *)ssd[k], stream);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+    }
+    // the decision
+    xeve_hip_cu_bits_params bp;
+    bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
+    bp.cm_init = 0, bp.chroma_format_idc = idc;
+    const size_t coef_elems = (size_t)njobs * (P.n0 + 2 * (size_t)P.n1), bws = workspace_bytes - L.bitws;
+    k_rdo_round1<<<G, 256, 0, st>>>(jobs, P, nnz[0], nnz[1], nnz[2], cand, bj);
+    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    k_rdo_decide1<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, st_out, states, cand, best, prev, bj);
+    if(P.ncomp > 1) {
+        for(int comp = 1; comp <= 2; comp++) {
+            rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, prev, bj, 2 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+            if(rc_ != XEVE_HIP_OK) return rc_;
+            k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, comp, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj);
+        }
+    }
+    else k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, 2, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj); // (no chroma: only builds the round 4 job)
+    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    k_rdo_finish<<<G, 256, 0, st>>>(P, ssd[0], ssd[1], ssd[2], bits, st_out, cand, best, results, drop);
+    k_rdo_zero_dropped<<<3 * njobs, 64, 0, st>>>(coef, drop, P);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

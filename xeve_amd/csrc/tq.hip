@@ -708,3 +708,23 @@ extern "C" int xeve_hip_residual_rdoq(const pel *org, int s_org, const pel *pred
     return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 2, coef, rec,
                            s_rec, nnz, ssd, st);
 }
+
+// ... and with the estimates the reference derives from the CU's entry coder state, one record per block, all on the device
+// (xeve_hip_rdoq_bit_est -> xeve_hip_rdoq_dev); ch_type 0 Y / 1 U / 2 V selects the context set and the cbf pair of an inter CU
+extern "C" int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
+                                 const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int is_intra_cu,
+                                 int32_t *nnz, void *stream);
+extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
+                                          int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda, int ch_type,
+                                          int tool_iqt, const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int16_t *coef, pel *rec, int s_rec,
+                                          int32_t *nnz, int64_t *ssd, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 1, coef, rec,
+                             s_rec, nnz, ssd, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    rc = xeve_hip_rdoq_dev(coef, njobs, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, est, est_idx, 1, is_intra_slice, 0, nnz, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 2, coef, rec,
+                           s_rec, nnz, ssd, st);
+}

@@ -220,6 +220,28 @@ def mc_cu_jobs(refp, num_refp, s_l, s_c, pic_w, pic_h, jobs, w, h, bit_depth, ch
     return pred
 
 
+def residue_rdo_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None):
+    """pinter_residue_rdo for a batch of candidates (xeve_hip_residue_rdo_jobs).  org_ptrs: three device addresses of sample (0, 0);
+    refp: HOST numpy array of lib.REFPIC_DTYPE; states / jobs: uint8 tensors of lib.SBAC_DTYPE / lib.RDO_JOB_DTYPE records.
+    Returns (results uint8 [njobs, 72], coef int16 flat, best uint8 [njobs, 172])."""
+    L = _lib.load()
+    njobs, nstates, dev = jobs.numel() // 36, states.numel() // 172, jobs.device
+    ws, hs = (1 if params.chroma_format_idc <= 2 else 0), (1 if params.chroma_format_idc <= 1 else 0)
+    n0 = 1 << (params.log2_cuw + params.log2_cuh)
+    n1 = (n0 >> (ws + hs)) if params.chroma_format_idc else 0
+    res = torch.empty((njobs, 72), dtype=torch.uint8, device=dev)
+    coef = torch.empty(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
+    best = torch.empty((njobs, 172), dtype=torch.uint8, device=dev)
+    need = L.xeve_hip_residue_rdo_workspace(njobs, nstates, C.byref(params), s_org_l, s_org_c)
+    if workspace is None:
+        workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
+    cl, cc = C.c_void_p(baseline_coef_l().ctypes.data), C.c_void_p(baseline_coef_c().ctypes.data)
+    _lib.check(L.xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp.ctypes.data_as(C.c_void_p), s_l, s_c, _ptr(states), nstates, C.byref(params), _ptr(jobs),
+                                           njobs, cl, cc, _ptr(res), _ptr(coef), _ptr(best), _ptr(workspace), workspace.numel(), _stream()))
+    return res, coef, best
+
+
 def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 

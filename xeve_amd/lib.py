@@ -39,6 +39,17 @@ class EpzsParams(C.Structure):  # xeve_hip_epzs_params
     _fields_ = [("me", MeParams), ("hpel_cnt", C.c_int32), ("qpel_cnt", C.c_int32)]
 
 
+class RdoParams(C.Structure):  # xeve_hip_rdo_params
+    _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("slice_type", C.c_int32),
+                ("num_refp", C.c_int32 * 2), ("chroma_format_idc", C.c_int32), ("bit_depth", C.c_int32), ("tool_iqt", C.c_int32),
+                ("qp", C.c_int32 * 3), ("pad_", C.c_int32), ("lambda_", C.c_double * 3), ("dist_chroma_weight", C.c_double * 2)]
+
+
+RDO_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)),
+                 ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1"), ("sbac", "<i4")]  # xeve_hip_rdo_job (36 B)
+RDO_RESULT_DTYPE = [("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))]  # xeve_hip_rdo_result (72 B)
+
+
 class DeblockParams(C.Structure):  # xeve_hip_deblock_params
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("w_scu", C.c_int32), ("h_scu", C.c_int32), ("log2_max_cuwh", C.c_int32),
                 ("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32), ("chroma_format_idc", C.c_int32),
@@ -123,6 +134,9 @@ FUNCTIONS = {
     "xeve_hip_mc_cu_workspace": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "xeve_hip_mc_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_residue_rdo_workspace": (C.c_size_t, [c_int, c_int, c_void_p, c_int, c_int]),
+    "xeve_hip_residue_rdo_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
