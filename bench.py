@@ -22,6 +22,8 @@ import subprocess
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -151,6 +153,18 @@ def main():
         ws = HotPathPass(a.width, a.height, dev, seed=5, content="structured")
         ws.run(only="D")
         rate_term["structured"] = rate_of(ws)
+        # and the function those bit counts belong to, end to end: pinter_residue_rdo for one bi-predicted candidate per CU of every level
+        # (xeve_hip_residue_rdo_jobs: prediction, residual chain with RDOQ from the entry coder state, four bit-count rounds, cbf decision)
+        ws.rdo()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rd = ws.rdo()
+        e1.record()
+        torch.cuda.synchronize()
+        nnz = [np.frombuffer(v[0].cpu().numpy().tobytes(), dtype=[("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))])["nnz"] for v in rd.values()]
+        rate_term["residue_rdo_structured"] = {"ms_per_picture": round(e0.elapsed_time(e1), 3), "candidates_per_picture": int(sum(len(v) for v in nnz)),
+                                               "coded_fraction": round(float(sum(int(v.any(axis=1).sum()) for v in nnz)) / sum(len(v) for v in nnz), 4)}
         del ws
     if rank == 0:
         sad_ms = wl.sad_time_ms()  # per size, summed over the timed steps

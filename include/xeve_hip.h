@@ -360,6 +360,12 @@ typedef struct xeve_hip_cu_bits_job {
  * elements), sbac_in, jobs, bits, sbac_out and workspace (>= xeve_hip_cu_bits_workspace(njobs, coef_elems) bytes) are
  * device memory; params is a HOST pointer.  Jobs may share coefficient blocks and entry states. */
 size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems);
+/* The same counts from the count-only kernel, handing on only what later counts depend on: state_out[j].range and .ctx (the other
+ * fields are reset, as xeve_sbac_bit_reset would leave them; .code is 0).  For chains of tests such as the per-component cbf
+ * tests of pinter_residue_rdo, where the intermediate states are only ever SBAC_LOADed into further bit counts. */
+int xeve_hip_cu_bits_jobs_chain(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                                const xeve_hip_cu_bits_params *params, void *workspace, size_t workspace_bytes, uint32_t *bits,
+                                xeve_hip_sbac *state_out, void *stream);
 int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *params, void *workspace, size_t workspace_bytes, uint32_t *bits,
                           xeve_hip_sbac *sbac_out, void *stream);
@@ -449,7 +455,8 @@ typedef struct xeve_hip_rdo_result {
 } xeve_hip_rdo_result;
 /* org (HOST array of three device pointers at sample (0, 0)), refp (HOST, as for xeve_hip_mc_cu_jobs), params, coefficient
  * tables: host memory.  states, jobs, results, coef, best, workspace: device memory.  coef receives pi->coef[pidx]: the Y blocks
- * of all candidates ([njobs][h*w]), then the U blocks, then the V blocks; best[j] = core->s_temp_best. */
+ * of all candidates ([njobs][h*w]), then the U blocks, then the V blocks; best[j] = core->s_temp_best (may be NULL: saves one
+ * bit-count round). */
 size_t xeve_hip_residue_rdo_workspace(int njobs, int nstates, const xeve_hip_rdo_params *params, int s_org_l, int s_org_c);
 int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
                               const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *params, const xeve_hip_rdo_job *jobs, int njobs,

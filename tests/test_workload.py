@@ -91,3 +91,44 @@ def test_hot_path_pass_small_picture_vs_oracle():
                 O.xo_recon(ptr(coef), ptr(pred), 1, w, w, w, ptr(e), bd)
                 y0, x0 = off // st, off % st
                 assert np.array_equal(rec[c][y0:y0 + w, x0:x0 + w], e), (S, j, c)
+
+
+def test_structured_content_rdo_phase_vs_oracle():
+    """phase G (xeve_hip_residue_rdo_jobs on the structured picture, true-motion bi-prediction) against the oracle's pinter_residue_rdo"""
+    import torch
+
+    import xeve_amd
+    from _libs import RDO_JOB_DTYPE, RDO_RESULT_DTYPE, SBAC_DTYPE, RdoParams, oracle_rdo
+    from _libs import REFPIC_DTYPE
+    from xeve_amd.workload import PAD_C, PAD_L, HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(256, 128, dev, seed=3, content="structured")
+    out = wl.rdo()
+    torch.cuda.synchronize()
+    O = oracle_rdo()
+    org = [p.cpu().numpy() for p in wl.org]
+    ref = [[p.cpu().numpy() for p in l] for l in wl.ref]
+    ol, oc = PAD_L * wl.s_l + PAD_L, PAD_C * wl.s_c + PAD_C
+    tab = np.zeros(2, REFPIC_DTYPE)
+    for l in range(2):
+        tab["y"][l], tab["u"][l], tab["v"][l] = ref[l][0].ctypes.data + 2 * ol, ref[l][1].ctypes.data + 2 * oc, ref[l][2].ctypes.data + 2 * oc
+        tab["poc"][l] = 2 * l
+    org_ptrs = np.array([org[0].ctypes.data + 2 * ol, org[1].ctypes.data + 2 * oc, org[2].ctypes.data + 2 * oc], np.uint64)
+    r = np.random.default_rng(1)
+    coded = 0
+    for S in wl.sizes:
+        rd = wl.lv[S]["rdo"]
+        res = out[S][0].cpu().numpy().reshape(-1).view(RDO_RESULT_DTYPE)
+        jobs = rd["jobs"].cpu().numpy().view(RDO_JOB_DTYPE)
+        st = rd["state"].cpu().numpy().view(SBAC_DTYPE)
+        p = RdoParams.from_buffer_copy(bytes(rd["params"]))
+        for j in r.choice(len(jobs), size=min(8, len(jobs)), replace=False):
+            er, eb = np.zeros(1, RDO_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec = [np.zeros(S * S, np.int16), np.zeros(S * S // 4, np.int16), np.zeros(S * S // 4, np.int16)]
+            O.xo_residue_rdo(ptr(org_ptrs), wl.s_l, wl.s_c, ptr(tab), wl.s_l, wl.s_c, ptr(st), p, ptr(jobs[j:j + 1].copy()), ptr(er), ptr(ec[0]), ptr(ec[1]),
+                             ptr(ec[2]), ptr(eb))
+            assert res["cost"][j].tobytes() == er["cost"][0].tobytes() and np.array_equal(res["nnz"][j], er["nnz"][0]), (S, j)
+            coded += int(er["nnz"][0].any())
+    assert coded > 0

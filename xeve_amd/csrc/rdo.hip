@@ -12,7 +12,9 @@
 //   round 2: {U without, U with} from the state after Y                         -> U's choice, state after U
 //   round 3: {V without, V with} from the state after U                         -> V's choice
 //   round 4: {the chosen combination} from the entry state (when it differs from "as is")
-// Jobs of a round run in parallel over all candidates.
+// Jobs of a round run in parallel over all candidates.  Rounds 2 and 3 always use the count-only kernel (their states are only ever
+// loaded into further counts: range and models suffice); rounds 1 and 4 carry the complete coder state when the caller asks for
+// core->s_temp_best.
 #include "xh_common.h"
 
 extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h,
@@ -28,7 +30,7 @@ struct RdoK {
 
 struct Cand { // per candidate, between the rounds
     double cost_best;
-    int    nnz_store[3], idx_best[3], cbf_idx[3], iy, iu, iv, tnnz, round4;
+    int    nnz_store[3], idx_best[3], cbf_idx[3], iy, iu, iv, tnnz, round4, win; // win: 0 all-zero, 1 as quantised, 2 the combination
 };
 
 #define MAX_COST 1.7e+308
@@ -77,7 +79,7 @@ __global__ void k_rdo_round1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, 
     c.nnz_store[0] = nnz_y[j], c.nnz_store[1] = P.ncomp > 1 ? nnz_u[j] : 0, c.nnz_store[2] = P.ncomp > 1 ? nnz_v[j] : 0;
     c.tnnz = c.nnz_store[0] + c.nnz_store[1] + c.nnz_store[2];
     c.cost_best = MAX_COST, c.idx_best[0] = c.idx_best[1] = c.idx_best[2] = 0, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0;
-    c.iy = c.nnz_store[0] > 0, c.iu = c.nnz_store[1] > 0, c.iv = c.nnz_store[2] > 0, c.round4 = 0;
+    c.iy = c.nnz_store[0] > 0, c.iu = c.nnz_store[1] > 0, c.iv = c.nnz_store[2] > 0, c.round4 = 0, c.win = 0;
     cand[j] = c;
     xeve_hip_cu_bits_job *b = bj + 4 * j;
     fill_bits_job(b[0], J, P, j, XEVE_HIP_BITS_CU_INTER, 0, 0, 0, J.sbac);
@@ -101,8 +103,8 @@ __device__ __forceinline__ void load_dist(const long *ssd_y, const long *ssd_u, 
 // after round 1: best so far; Y's choice; jobs of round 2 (U without / with) from the state after Y
 __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v,
                               const unsigned *__restrict__ bits, const xeve_hip_sbac *__restrict__ st_out, const xeve_hip_sbac *__restrict__ entry,
-                              Cand *__restrict__ cand, xeve_hip_sbac *__restrict__ best, xeve_hip_sbac *__restrict__ prev,
-                              xeve_hip_cu_bits_job *__restrict__ bj)
+                              Cand *__restrict__ cand, xeve_hip_sbac *__restrict__ prev, xeve_hip_cu_bits_job *__restrict__ bj,
+                              xeve_hip_sbac *__restrict__ best)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.njobs) return;
@@ -115,19 +117,26 @@ __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P,
     if(c.tnnz == 0) { // nothing survived quantisation (xeve_pinter.c:1276-1331)
         c.cost_best = (double)d0[0] + (P.wgt[0] * (double)d0[1]) + (P.wgt[1] * (double)d0[2]);
         c.cost_best += (double)(int)b[0] * P.lambda[0];
-        copy_state(best + j, so + 0);
+        c.win = 0;
+        if(best) copy_state(best + j, so + 0);
         copy_state(prev + j, entry + J.sbac);
     }
     else {
         if(!J.dir_flag) { // all-zero alternative (:1103-1142)
             double cost = sum_cost(d0, d1, 0, 0, 0, P);
             cost += (double)(int)b[0] * P.lambda[0];
-            if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0, copy_state(best + j, so + 0);
+            if(cost < c.cost_best) {
+                c.cost_best = cost, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0, c.win = 0;
+                if(best) copy_state(best + j, so + 0);
+            }
         }
         { // as quantised (:1144-1178)
             double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
             cost += (double)(int)b[1] * P.lambda[0];
-            if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, copy_state(best + j, so + 1);
+            if(cost < c.cost_best) {
+                c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, c.win = 1;
+                if(best) copy_state(best + j, so + 1);
+            }
         }
         // Y with / without its coefficients (:1180-1218, i = 0)
         if(c.nnz_store[0] > 0) {
@@ -181,9 +190,9 @@ __global__ void k_rdo_decide_comp(const xeve_hip_rdo_job *__restrict__ jobs, Rdo
 }
 
 // after round 4: final comparison, results, dropped coefficient blocks zeroed (:1264-1275)
-__global__ void k_rdo_finish(RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v, const unsigned *__restrict__ bits,
-                             const xeve_hip_sbac *__restrict__ st_out, Cand *__restrict__ cand, xeve_hip_sbac *__restrict__ best,
-                             xeve_hip_rdo_result *__restrict__ res, unsigned char *__restrict__ drop)
+__global__ void k_rdo_finish(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v,
+                             const unsigned *__restrict__ bits, Cand *__restrict__ cand, xeve_hip_rdo_result *__restrict__ res,
+                             unsigned char *__restrict__ drop, const xeve_hip_sbac *__restrict__ st_out, xeve_hip_sbac *__restrict__ best)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.njobs) return;
@@ -193,7 +202,10 @@ __global__ void k_rdo_finish(RdoK P, const long *ssd_y, const long *ssd_u, const
     if(c.round4) {
         double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
         cost += (double)(int)bits[j] * P.lambda[0];
-        if(cost < c.cost_best) c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, copy_state(best + j, st_out + j);
+        if(cost < c.cost_best) {
+            c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, c.win = 2;
+            if(best) copy_state(best + j, st_out + j);
+        }
     }
     xeve_hip_rdo_result r;
     r.cost = c.cost_best, r.pad_ = 0;
@@ -257,7 +269,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
                                          xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
-    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && best && workspace && coef_l);
+    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && workspace && coef_l);
     XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6 && p->tool_iqt == 0);
     XH_REQUIRE(p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3);
     XH_REQUIRE(org[0] && (p->chroma_format_idc == 0 || (org[1] && org[2] && coef_c)));
@@ -313,20 +325,23 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     bp.cm_init = 0, bp.chroma_format_idc = idc;
     const size_t coef_elems = (size_t)njobs * (P.n0 + 2 * (size_t)P.n1), bws = workspace_bytes - L.bitws;
     k_rdo_round1<<<G, 256, 0, st>>>(jobs, P, nnz[0], nnz[1], nnz[2], cand, bj);
-    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+    // (the complete coder state is carried only where core->s_temp_best can come from -- the whole-CU counts of rounds 1 and 4 -- and only
+    // when the caller wants it; the component tests' states are only ever loaded into further counts: range and models suffice)
+    rc_ = best ? xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream)
+               : xeve_hip_cu_bits_jobs_chain(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
-    k_rdo_decide1<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, st_out, states, cand, best, prev, bj);
+    k_rdo_decide1<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, st_out, states, cand, prev, bj, best);
     if(P.ncomp > 1) {
         for(int comp = 1; comp <= 2; comp++) {
-            rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, prev, bj, 2 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+            rc_ = xeve_hip_cu_bits_jobs_chain(coef, coef_elems, prev, bj, 2 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
             if(rc_ != XEVE_HIP_OK) return rc_;
             k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, comp, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj);
         }
     }
     else k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, 2, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj); // (no chroma: only builds the round 4 job)
-    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
-    k_rdo_finish<<<G, 256, 0, st>>>(P, ssd[0], ssd[1], ssd[2], bits, st_out, cand, best, results, drop);
+    k_rdo_finish<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cand, results, drop, st_out, best);
     k_rdo_zero_dropped<<<3 * njobs, 64, 0, st>>>(coef, drop, P);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

@@ -15,6 +15,8 @@
 //     a component uses held in registers.  Every lane executes the same straight-line encoder each iteration.
 // The coder state is carried field for field (code register, pending / stacked bytes, bit counter), so the exit state
 // is what SBAC_STORE would keep and xeve_get_bit_number's formula applies unchanged.
+#include <cstdlib>
+#include <type_traits>
 #include "xh_common.h"
 
 #define NCTX XEVE_HIP_SBAC_NCTX
@@ -22,7 +24,7 @@
 
 struct CuBitsK {
     int n[3], log2n[3];
-    int slice_type, num_refp[2], cm_init, idc;
+    int slice_type, num_refp[2], cm_init, idc, burst;
     const uint16_t *scan[3];
 };
 
@@ -306,8 +308,12 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     int      e = 0, phase = 0, numsig = b1 > 0 ? J.nnz[0] : b2 > 0 ? J.nnz[1] : J.nnz[2];
     int      ch = b1 > 0 ? 0 : 1;                                   // 0 luma, 1 chroma
     int      t0 = P.cm_init == 1 ? 10 + ch * 12 : ch * 2;          // prev_level = 6 at the start of a block (xeve_eco.c:722,731-733)
-    unsigned k = 0, cur = 0, nxt = 0;
-    bool     primed = false;
+    unsigned k = 0;
+    // Two compiled forms of the loop: with and without the burst.  The burst pays when zero runs (or levels) are long; where most bins
+    // are first bins, signs and last flags its vote and code only lengthen the serial step.  Each wave picks once, from the mean
+    // number of scan positions per event of its jobs.
+    auto loop = [&](auto with_burst) {
+    constexpr bool WB = decltype(with_burst)::value;
     while(e < total) {
 #pragma unroll
         for(int i = 0; i < FILL; i++) // commit the refill that was in flight
@@ -317,11 +323,12 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
 #pragma unroll
         for(int i = 0; i < FILL; i++) // issue the next one
             if(i < cnt) buf[i] = fetch(filled + i);
-        if(!primed) cur = s_ring[0][lane], nxt = s_ring[1][lane], primed = true;
 
         for(int it = 0; it < WIN; it++) {
             if(e < total) {
-                // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag
+                // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag.
+                // Written without branches on purpose: 64 lanes are in 64 different phases, and any `if` some lane takes is paid by all.
+                const unsigned cur = s_ring[e & (RING - 1)][lane];
                 const unsigned run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1;
                 const bool     at_end = (cur >> 28) & 1;
                 const unsigned kn = phase == 0 ? run : phase == 2 ? lev1 : k - 1;
@@ -332,22 +339,22 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
                 const bool adv = phase == 5 || (phase == 4 && at_end); // no last flag at scan_pos == num_coeff - 1 (xeve_eco.c:744-746)
                 const int  nphase = phase < 4 ? (phase | 1) + (kn == 0) : (phase == 4 && !at_end ? 5 : 0);
                 numsig -= phase == 4;
-                if(adv) {
-                    e++;
-                    const bool newc = e == b1 || e == b2;
-                    ch = e >= b1;
-                    numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
-                    const unsigned plev = newc ? 5 : (lev1 < 5 ? lev1 : 5); // min(prev_level - 1, 5)
-                    t0 = P.cm_init == 1 ? (int)(plev << 1) + ch * 12 : ch * 2;
-                    cur = nxt;
-                    nxt = s_ring[(e + 1) & (RING - 1)][lane]; // (stale beyond the stream's end; never consumed)
+                e += adv;
+                const bool newc = adv && (e == b1 || e == b2);
+                ch = e >= b1;
+                numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
+                if(P.cm_init == 1) { // the context pair follows the previous level: min(prev_level - 1, 5), 5 at the start of a block
+                    const unsigned plev = newc ? 5 : (lev1 < 5 ? lev1 : 5);
+                    t0 = adv ? (int)(plev << 1) + ch * 12 : t0;
                 }
+                else t0 = ch * 2;
                 k = kn, phase = nphase;
                 // ---- burst: most bins are the "1"s of a unary code (zero runs, large levels) on an adapted model, i.e.
                 // a run of MPS bins on ONE context -- range and state recurrence only, the model stays in a register
                 // (taken only when at least half of the lanes still at work have >= 6 such bins ahead: the burst costs
                 // about one general step, whoever uses it)
-                const bool unary = !FULL && (phase & 1) && phase < 4 && k >= 2;
+                if constexpr(WB) {
+                const bool unary = (phase & 1) && phase < 4 && k >= 2;
                 const bool worth = 2 * __popcll(__ballot(unary && k >= 7)) >= __popcll(__ballot(true));
                 if(worth && unary) {
                     const int cb = (phase == 1 ? XEVE_HIP_CTX_RUN : XEVE_HIP_CTX_LEVEL) + t0 + 1;
@@ -368,11 +375,29 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
                         s_ctx[cb][lane] = (uint16_t)((st << 1) | 1);
                     }
                 }
+                }
             }
         }
     }
+    };
+    bool burst = false;
+    if(!FULL && P.burst) {
+        int npos = ((coded & 1) ? P.n[0] : 0) + ((coded & 2) ? P.n[1] : 0) + ((coded & 4) ? P.n[2] : 0), nevt = total;
+#pragma unroll
+        for(int m = 1; m < 64; m <<= 1) npos += __shfl_xor(npos, m, 64), nevt += __shfl_xor(nevt, m, 64);
+        burst = npos >= 10 * nevt; // (lanes past the end of the job list have left already: the shuffles read their own value back)
+    }
+    if(burst) loop(std::true_type{});
+    else loop(std::false_type{});
 
     bits[j] = s.shifts;
+    if(!FULL && sout) { // what feeds forward into later bit counts: the range and the models (xeve_sbac_bit_reset discards the rest but the
+                        // low bits of the code register, and those never reach a bit count)
+        xeve_hip_sbac &o = sout[j];
+        o.range = s.range, o.code = 0, o.code_bits = 11, o.stacked_ff = o.stacked_zero = o.pending_byte = o.is_pending_byte = o.bitcounter = 0;
+        o.bin_counter = s.bins;
+        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
+    }
     if(FULL) {
         // xeve_get_bit_number (xeve_mode.c:51-55) -- equal to s.shifts, kept as the reference computes it
         bits[j] = s.bc + 8 * (s.sz + s.sff) + 8 * (s.ipb ? 1 : 0) + 8 - s.cb + 3;
@@ -389,9 +414,28 @@ extern "C" size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems)
     return sizeof(unsigned) * coef_elems + sizeof(int) * 3 * (size_t)(njobs > 0 ? njobs : 0);
 }
 
+static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                          const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
+                          void *stream);
+
 extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                                      const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits,
                                      xeve_hip_sbac *sbac_out, void *stream)
+{
+    return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, sbac_out, sbac_out != nullptr, stream);
+}
+
+// count-only kernel, but handing on what later bit counts depend on (range + context models; every other field of state_out is reset)
+extern "C" int xeve_hip_cu_bits_jobs_chain(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits,
+                                           xeve_hip_sbac *state_out, void *stream)
+{
+    return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, state_out, false, stream);
+}
+
+static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                          const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
+                          void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(p && njobs >= 0);
@@ -411,6 +455,8 @@ extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, con
     }
     P.slice_type = p->slice_type, P.num_refp[0] = p->num_refp[0], P.num_refp[1] = p->num_refp[1];
     P.cm_init = p->cm_init, P.idc = p->chroma_format_idc;
+    static const int burst = getenv("XEVE_HIP_SBAC_BURST") ? atoi(getenv("XEVE_HIP_SBAC_BURST")) : 1; // developer switch
+    P.burst = burst;
     unsigned *ev  = (unsigned *)workspace;
     int      *nev = (int *)(ev + coef_elems);
     hipStream_t st = (hipStream_t)stream;
@@ -420,7 +466,7 @@ extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, con
         k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
     }
     else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
-    if(sbac_out) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
+    if(full) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
     else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

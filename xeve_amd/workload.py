@@ -273,6 +273,55 @@ class HotPathPass:
             out[S] = r["bits"].view(lv["n"], self.RATE_JOBS)
         return out
 
+    # ------------------------------------------------------------------------------------------------------
+    # G. pinter_residue_rdo end to end (xeve_hip_residue_rdo_jobs): one bi-predicted candidate per CU of every level, with the
+    # vectors phase D uses -- prediction, residual chain with RDOQ from the entry coder state, bit-count rounds, cbf decision.
+    def _rdo_setup(self, lv):
+        from . import lib
+        S, n, dev = lv["S"], lv["n"], self.dev
+        j = np.zeros(n, lib.RDO_JOB_DTYPE)
+        nx = self.W // S
+        idx = np.arange(n)
+        j["x"], j["y"] = (idx % nx) * S, (idx // nx) * S
+        mv = ((12, 4), (-12, -4)) if self.content != "iid" else None
+        rng = np.random.default_rng(17)
+        for l in range(N_LIST):
+            j["mv"][:, l] = mv[l] if mv else rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, size=(n, 2))
+        j["mvd"] = rng.integers(-16, 17, size=(n, 2, 2))
+        j["mvp_idx"] = rng.integers(0, 4, size=(n, 2))
+        st = np.zeros(1, lib.SBAC_DTYPE)
+        st["range"], st["ctx"] = 16384, 512
+        p = lib.RdoParams()
+        p.log2_cuw = p.log2_cuh = S.bit_length() - 1
+        p.pic_w, p.pic_h, p.slice_type, p.chroma_format_idc, p.bit_depth, p.tool_iqt = self.W, self.H, 0, 1, self.bd, 0
+        p.num_refp[0] = p.num_refp[1] = 1
+        p.qp[0] = p.qp[1] = p.qp[2] = self.qp
+        p.lambda_[0] = p.lambda_[1] = p.lambda_[2] = self.lam
+        p.dist_chroma_weight[0] = p.dist_chroma_weight[1] = 1.0
+        refp = np.zeros(2, lib.REFPIC_DTYPE)  # [refi 0][list 0 / 1]
+        for l in range(N_LIST):
+            r = self.ref[l]
+            refp["y"][l], refp["u"][l], refp["v"][l] = (r[0].data_ptr() + 2 * (PAD_L * self.s_l + PAD_L), r[1].data_ptr() + 2 * (PAD_C * self.s_c + PAD_C),
+                                                        r[2].data_ptr() + 2 * (PAD_C * self.s_c + PAD_C))
+            refp["poc"][l] = 2 * l
+        org = [self.org[0].data_ptr() + 2 * (PAD_L * self.s_l + PAD_L), self.org[1].data_ptr() + 2 * (PAD_C * self.s_c + PAD_C),
+               self.org[2].data_ptr() + 2 * (PAD_C * self.s_c + PAD_C)]
+        import ctypes as C
+        need = lib.load().xeve_hip_residue_rdo_workspace(n, 1, C.byref(p), self.s_l, self.s_c)
+        return dict(params=p, jobs=torch.from_numpy(j.view(np.uint8).copy()).to(dev), state=torch.from_numpy(st.view(np.uint8).copy()).to(dev), refp=refp,
+                    org=org, ws=torch.empty(int(need), dtype=torch.uint8, device=dev))
+
+    def rdo(self):
+        """phase G for every level; returns {S: (results uint8 [n, 72], coef, best)}"""
+        out = {}
+        for S in self.sizes:
+            lv = self.lv[S]
+            if "rdo" not in lv:
+                lv["rdo"] = self._rdo_setup(lv)
+            r = lv["rdo"]
+            out[S] = D.residue_rdo_jobs(r["org"], self.s_l, self.s_c, r["refp"], self.s_l, self.s_c, r["state"], r["params"], r["jobs"], workspace=r["ws"])
+        return out
+
     def capture(self):
         """Record one pass into a HIP graph (all launches of run() go to torch's current stream, which is the capture
         stream here); replay() then re-issues the ~150 launches with one host call.  Matters for small pictures, where
