@@ -392,6 +392,12 @@ typedef struct xeve_hip_deblock_params {
  * which equals ctx->map_mv in Baseline).  params is a HOST pointer. */
 int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, const uint32_t *map_scu, const uint32_t *map_cu_mode,
                      const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params, void *stream);
+/* The same on HOST memory, synchronous, whole padded planes staged per call (pad_l / pad_c = how far the buffers extend around
+ * the picture): what ctx->fn_loop_filter / ctx->fn_picbuf_expand can be pointed at without the caller owning device memory */
+int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int pad_l, int pad_c, const uint32_t *map_scu,
+                          const uint32_t *map_cu_mode, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params);
+int xeve_hip_picbuf_expand_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
+                                int exp_c, int chroma_format_idc);
 /* xeve_picbuf_expand: replicate the border samples exp_l / exp_c deep around the three planes */
 int xeve_hip_picbuf_expand(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
                            int exp_c, int chroma_format_idc, void *stream);

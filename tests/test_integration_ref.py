@@ -59,3 +59,19 @@ def test_bitstream_identical_with_hip_tables_installed(tmp_path, name):
     served = int(re.search(r"calls served by HIP: (\d+)", err).group(1))
     assert served > 10000, err  # the encode really went through the HIP tables
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with HIP tables installed"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium", "tiny_closed_gop"])
+def test_bitstream_identical_with_deblocking_and_padding_on_the_gpu(tmp_path, name):
+    """on top of the dispatch tables: ctx->fn_loop_filter -> xeve_hip_deblock_host, ctx->fn_picbuf_expand -> xeve_hip_picbuf_expand_host.
+    Every reconstructed picture is filtered and padded by the GPU before it becomes a reference, so any deviation changes the stream."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, df=True)
+    assert "loop filter and picture padding routed to the GPU" in err
+    m = re.search(r"pictures deblocked on the GPU: (\d+), padded on the GPU: (\d+)", err)
+    assert m and int(m.group(1)) >= n and int(m.group(2)) >= n, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the loop filter on the GPU"

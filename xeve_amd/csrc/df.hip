@@ -191,3 +191,74 @@ extern "C" int xeve_hip_picbuf_expand(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// ---- host-memory forms (the table layer's style: synchronous, caller's buffers in host memory) -----------------------------------
+// What a maintainer points ctx->fn_loop_filter / ctx->fn_picbuf_expand at; tests/test_integration_ref.py runs the
+// unmodified encoder this way.  Whole padded planes are staged per call -- a correctness path, like the other table entries.
+static int stage_plane(pel **d, const pel *h0, size_t elems)
+{
+    XH_HIP(hipMalloc((void **)d, elems * sizeof(pel)));
+    XH_HIP(hipMemcpy(*d, h0, elems * sizeof(pel), hipMemcpyHostToDevice));
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int pad_l, int pad_c, const uint32_t *map_scu,
+                                     const uint32_t *map_cu_mode, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *p)
+{
+    XH_ENTER();
+    XH_REQUIRE(p && y && map_scu && map_cu_mode && map_refi && map_mv && pad_l >= 0 && pad_c >= 0);
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
+    const size_t n = (size_t)p->w_scu * p->h_scu;
+    const size_t el = (size_t)s_l * (p->h + 2 * pad_l), ec = idc ? (size_t)s_c * ((p->h >> hs) + 2 * pad_c) : 0;
+    const size_t ol = (size_t)pad_l * s_l + pad_l, oc = (size_t)pad_c * s_c + pad_c;
+    pel *d[3] = {nullptr, nullptr, nullptr};
+    void *m[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void *hm[4] = {map_scu, map_cu_mode, map_refi, map_mv};
+    const size_t ms[4] = {n * 4, n * 4, n * 2, n * 8};
+    int rc = stage_plane(&d[0], y - ol, el);
+    if(rc == XEVE_HIP_OK && idc) rc = stage_plane(&d[1], u - oc, ec);
+    if(rc == XEVE_HIP_OK && idc) rc = stage_plane(&d[2], v - oc, ec);
+    for(int i = 0; i < 4 && rc == XEVE_HIP_OK; i++) {
+        if(hipMalloc(&m[i], ms[i]) != hipSuccess || hipMemcpy(m[i], hm[i], ms[i], hipMemcpyHostToDevice) != hipSuccess) {
+            xh_set_error("staging the deblocking maps failed");
+            rc = XEVE_HIP_ERR_DEVICE;
+        }
+    }
+    if(rc == XEVE_HIP_OK)
+        rc = xeve_hip_deblock(d[0] + ol, idc ? d[1] + oc : nullptr, idc ? d[2] + oc : nullptr, s_l, s_c, (const uint32_t *)m[0], (const uint32_t *)m[1],
+                              (const int8_t *)m[2], (const int16_t *)m[3], p, nullptr);
+    if(rc == XEVE_HIP_OK) {
+        if(hipMemcpy(y - ol, d[0], el * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE;
+        if(idc && (hipMemcpy(u - oc, d[1], ec * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess ||
+                   hipMemcpy(v - oc, d[2], ec * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess)) rc = XEVE_HIP_ERR_DEVICE;
+        if(rc != XEVE_HIP_OK) xh_set_error("copying the filtered planes back failed");
+    }
+    for(int i = 0; i < 3; i++) (void)hipFree(d[i]);
+    for(int i = 0; i < 4; i++) (void)hipFree(m[i]);
+    (void)ws;
+    return rc;
+}
+
+extern "C" int xeve_hip_picbuf_expand_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c,
+                                           int exp_l, int exp_c, int chroma_format_idc)
+{
+    XH_ENTER();
+    XH_REQUIRE(y && exp_l > 0 && (chroma_format_idc == 0 || (u && v && exp_c > 0)));
+    const size_t el = (size_t)s_l * (h_l + 2 * exp_l), ec = chroma_format_idc ? (size_t)s_c * (h_c + 2 * exp_c) : 0;
+    const size_t ol = (size_t)exp_l * s_l + exp_l, oc = (size_t)exp_c * s_c + exp_c;
+    pel *d[3] = {nullptr, nullptr, nullptr};
+    int rc = stage_plane(&d[0], y - ol, el);
+    if(rc == XEVE_HIP_OK && chroma_format_idc) rc = stage_plane(&d[1], u - oc, ec);
+    if(rc == XEVE_HIP_OK && chroma_format_idc) rc = stage_plane(&d[2], v - oc, ec);
+    if(rc == XEVE_HIP_OK)
+        rc = xeve_hip_picbuf_expand(d[0] + ol, chroma_format_idc ? d[1] + oc : nullptr, chroma_format_idc ? d[2] + oc : nullptr, s_l, s_c, w_l, h_l, w_c, h_c,
+                                    exp_l, exp_c, chroma_format_idc, nullptr);
+    if(rc == XEVE_HIP_OK) {
+        if(hipMemcpy(y - ol, d[0], el * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE;
+        if(chroma_format_idc && (hipMemcpy(u - oc, d[1], ec * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess ||
+                                 hipMemcpy(v - oc, d[2], ec * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess)) rc = XEVE_HIP_ERR_DEVICE;
+        if(rc != XEVE_HIP_OK) xh_set_error("copying the padded planes back failed");
+    }
+    for(int i = 0; i < 3; i++) (void)hipFree(d[i]);
+    return rc;
+}
