@@ -287,7 +287,8 @@ int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xev
  * raster search) and me_level > ME_LEV_IPEL -- first diamond search from the MVP (or, bi == 1, from mv_start), refinement
  * diamond searches from the running best while beststep > 0, then the sub-pel pattern search.  All bookkeeping between
  * the searches runs in device kernels; the host only reads one "jobs still refining" counter per iteration, so this call
- * SYNCHRONISES `stream`.  results[j].mv / .cost are what pinter_me_epzs returns; .beststep / .best_mv_bits are 0. */
+ * SYNCHRONISES `stream`.  results[j].mv / .cost are what pinter_me_epzs returns; .best_mv_bits is what the searches leave in
+ * pi->mot_bits[lidx] (0: they leave it untouched; xeve_pinter.c:546-548,690-692); .beststep is 0. */
 typedef struct xeve_hip_epzs_job {
     int32_t x, y;        /* block position (integer pel) */
     int32_t org_off;     /* bi != 0: offset of the job's dense org_bi block */
@@ -468,6 +469,12 @@ int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s_org_l, int
                               const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *params, const xeve_hip_rdo_job *jobs, int njobs,
                               const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_rdo_result *results, int16_t *coef,
                               xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream);
+
+/* One pinter_me_epzs call on HOST memory (synchronous; both luma planes staged per call): what pi->fn_me can be pointed at.
+ * org0 / ref0 = sample (0, 0) of the original / reference luma plane; the reference plane has `pad` samples around the picture. */
+int xeve_hip_me_epzs_host(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref, int pad, int pic_h,
+                          const xeve_hip_epzs_job *job, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                          const xeve_hip_epzs_params *params, xeve_hip_me_result *result);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ unsigned refdrv_me_spel_pattern(pel *org0, int s_org, const s16 *org_bi, pel *re
 }
 
 
+static int g_last_mot_bits;
 /* pinter_me_epzs (static, xeve_pinter.c:699) with me_complexity 1 (no raster); mv_io: in = start for bi == BI_NORMAL, out = result */
 unsigned refdrv_me_epzs(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h, int bit_depth,
                         const s16 mvp_in[2], s16 mv_io[2], int bi, unsigned lambda_mv, int num_refp, int refi_in, int mot_bits_other,
@@ -107,5 +108,8 @@ unsigned refdrv_me_epzs(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int 
     s8  refi = (s8)refi_in;
     unsigned cost = pinter_me_epzs(pi, x, y, log2w, log2h, &refi, lidx, mvp, mv, bi, bit_depth);
     mv_io[0] = mv[MV_X], mv_io[1] = mv[MV_Y];
+    g_last_mot_bits = pi->mot_bits[lidx];
     return cost;
 }
+/* pi->mot_bits[lidx] after the last refdrv_me_epzs call (-1: the searches left it untouched) */
+int refdrv_me_epzs_mot_bits(void) { return g_last_mot_bits; }

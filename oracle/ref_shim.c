@@ -72,9 +72,48 @@ static void shim_pic_expand(XEVE_CTX *ctx, XEVE_PIC *pic)
     pad_calls++;
 }
 
+/* XEVE_HIP_SHIM_ME=1: the per-list motion search runs on the GPU -- pi->fn_me (pinter_me_epzs, xeve_pinter.c:699-869,2104) is routed to
+ * xeve_hip_me_epzs_host.  The adapter passes what pinter_me_epzs reads from XEVE_PINTER (original and reference luma planes, org_bi,
+ * lambda_mv, clip window, search ranges as get_range_ipel derives them (:122-129), sub-pel pattern sizes, the other list's mot_bits) and
+ * applies its side effect on pi->mot_bits[lidx]. */
+typedef struct { unsigned lambda_mv; int refi_bits, extra_bits, bi, faststep, max_search_range, range_recentre, min_clip[2], max_clip[2], reserved; int hpel_cnt, qpel_cnt; } hip_epzs_params;
+typedef struct { int x, y, org_off; s16 mvp[2], mv_start[2]; } hip_epzs_job;
+typedef struct { s16 mv[2]; unsigned cost; int beststep, best_mv_bits; } hip_me_result;
+static int (*hip_me_epzs_host)(const pel *, int, const pel *, const pel *, int, int, int, const hip_epzs_job *, int, int, int, const void *, const hip_epzs_params *,
+                               hip_me_result *);
+static unsigned long long me_calls;
+
+static u32 shim_me(XEVE_PINTER *pi, int x, int y, int log2_cuw, int log2_cuh, s8 *refi, int lidx, s16 mvp[MV_D], s16 mv[MV_D], int bi, int bit_depth_luma)
+{
+    const int ri = *refi, lidx_r = lidx == REFP_0 ? REFP_1 : REFP_0;
+    XEVE_PIC *rp = pi->refp[ri][lidx].pic;
+    hip_epzs_params p;
+    hip_epzs_job    j;
+    hip_me_result   r;
+    const int offset = pi->gop_size >> 1; /* get_range_ipel (xeve_pinter.c:122-129) */
+    p.lambda_mv = pi->lambda_mv, p.refi_bits = xeve_tbl_refi_bits[pi->num_refp][ri], p.extra_bits = bi ? pi->mot_bits[lidx_r] : 0, p.bi = bi, p.faststep = 3;
+    p.max_search_range = pi->max_search_range;
+    p.range_recentre = XEVE_CLIP3(pi->max_search_range >> 2, pi->max_search_range,
+                                  (pi->max_search_range * XEVE_ABS(pi->poc - (int)pi->refp[ri][lidx].poc) + offset) / pi->gop_size);
+    p.min_clip[0] = pi->min_clip[MV_X], p.min_clip[1] = pi->min_clip[MV_Y], p.max_clip[0] = pi->max_clip[MV_X], p.max_clip[1] = pi->max_clip[MV_Y], p.reserved = 0;
+    p.hpel_cnt = pi->search_pattern_hpel_cnt, p.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    j.x = x, j.y = y, j.org_off = 0, j.mvp[0] = mvp[MV_X], j.mvp[1] = mvp[MV_Y], j.mv_start[0] = mv[MV_X], j.mv_start[1] = mv[MV_Y];
+    if(pi->me_level <= ME_LEV_IPEL || pi->me_complexity > 1) { fprintf(stderr, "[xeve_hip_shim] this preset's search (raster / integer refinement) is not on the GPU\n"); abort(); }
+    if(hip_me_epzs_host(pi->o[Y_C], pi->s_o[Y_C], bi ? (const pel *)pi->org_bi : NULL, rp->y, rp->s_l, rp->pad_l, rp->h_l, &j, log2_cuw, log2_cuh, bit_depth_luma,
+                        pi->mc_l_coeff, &p, &r) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] me: %s\n", hip_err());
+        abort();
+    }
+    mv[MV_X] = r.mv[0], mv[MV_Y] = r.mv[1];
+    if(r.best_mv_bits > 0) pi->mot_bits[lidx] = r.best_mv_bits;
+    me_calls++;
+    return r.cost;
+}
+
 static void report(void)
 {
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
+    if(me_calls) fprintf(stderr, "[xeve_hip_shim] motion searches (pinter_me_epzs) served by the GPU: %llu\n", me_calls);
     if(df_calls || pad_calls) fprintf(stderr, "[xeve_hip_shim] pictures deblocked on the GPU: %llu, padded on the GPU: %llu\n", df_calls, pad_calls);
 }
 
@@ -102,6 +141,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_deblock_host || !hip_expand_host) { fprintf(stderr, "[xeve_hip_shim] deblock / expand entry points missing\n"); abort(); }
         ctx->fn_loop_filter = shim_loop_filter, ctx->fn_picbuf_expand = shim_pic_expand;
         fprintf(stderr, "[xeve_hip_shim] loop filter and picture padding routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
+        hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;
+        if(!hip_me_epzs_host) { fprintf(stderr, "[xeve_hip_shim] motion-search entry point missing\n"); abort(); }
+        for(int i = 0; i < ctx->param.threads; i++) ctx->pinter[i].fn_me = shim_me;
+        fprintf(stderr, "[xeve_hip_shim] motion search routed to the GPU\n");
     }
     atexit(report);
     fprintf(stderr, "[xeve_hip_shim] HIP dispatch tables installed (%d pointers + fn_recon)\n", n);

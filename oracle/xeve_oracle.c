@@ -551,6 +551,13 @@ static void epzs_range(const xo_me_params *p, int cx, int cy, int16_t range[4])
 uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
                     int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p)
 {
+    int mot = 0;
+    return xo_me_epzs_mot(org0, s_org, org_bi, ref0, s_ref, x, y, mvp, mv, log2w, log2h, bit_depth, coef, p, &mot);
+}
+
+uint32_t xo_me_epzs_mot(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
+                        int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p, int *mot_bits)
+{
     xo_me_params me = p->me;
     xo_me_job    job;
     xo_me_result r;
@@ -566,6 +573,7 @@ uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const x
     job.beststep_in = tmpstep;
     xo_me_ipel_diamond(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r);
     tmpstep = r.beststep;
+    if(me.bi != 1 && r.best_mv_bits > 0) *mot_bits = r.best_mv_bits; /* pi->mot_bits[lidx] (xeve_pinter.c:546-548) */
     if(r.cost < cost_best) {
         cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
         beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
@@ -579,6 +587,7 @@ uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const x
         job.beststep_in = tmpstep;
         xo_me_ipel_diamond(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r);
         tmpstep = r.beststep;
+        if(r.best_mv_bits > 0) *mot_bits = r.best_mv_bits;
         if(r.cost < cost_best) {
             cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
             beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
@@ -589,6 +598,7 @@ uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const x
     xo_spel_job sj;
     sj.x = x, sj.y = y, sj.org_off = 0, sj.gmvp[0] = job.gmvp[0], sj.gmvp[1] = job.gmvp[1], sj.mvi[0] = mv[0], sj.mvi[1] = mv[1];
     xo_me_spel_pattern(org0, s_org, org_bi, ref0, s_ref, &sj, log2w, log2h, bit_depth, coef, &sp, &r);
+    if(!me.bi && r.best_mv_bits > 0) *mot_bits = r.best_mv_bits; /* xeve_pinter.c:690-692 */
     if(r.cost < cost_best) cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
     return cost_best;
 }

@@ -150,6 +150,9 @@ typedef struct xo_epzs_params {
 } xo_epzs_params;
 uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
                     int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p);
+/* the same, also reporting what the searches leave in pi->mot_bits[lidx] (*mot_bits is only written when they change it) */
+uint32_t xo_me_epzs_mot(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
+                        int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p, int *mot_bits);
 
 /* ---- CABAC (SBAC) bit counting for the inter RDO (reference: src_base/xeve_eco.c, xeve_mode.c) -- */
 /* The fields of XEVE_SBAC (xeve_type.h:527-540) plus the context models of XEVE_SBAC_CTX (xeve_def.h:736-790) that the

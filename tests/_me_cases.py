@@ -112,13 +112,17 @@ def epzs_params_of(c):
     return EpzsParams(me, SpelParams(0, 0, 0, 0, c["hpel_cnt"], c["qpel_cnt"]))
 
 
-def run_oracle_epzs(c):
+def run_oracle_epzs(c, with_mot=False):
+    """(cost, mv) of pinter_me_epzs; with_mot: also what it leaves in pi->mot_bits[lidx] (-1 = untouched)"""
     from _libs import oracle_epzs
 
     O = oracle_epzs()
     lg = c["S"].bit_length() - 1
     mvp, mv = np.array(c["mvp"], np.int16), np.array(c["mv0"], np.int16)
     p = epzs_params_of(c)
-    cost = O.xo_me_epzs(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], ptr(mvp),
-                        ptr(mv), lg, lg, 10, O.mc_l_coeff, C.byref(p))
-    return cost, int(mv[0]), int(mv[1])
+    mot = C.c_int(-1)
+    O.xo_me_epzs_mot.restype = C.c_uint32
+    O.xo_me_epzs_mot.argtypes = O.xo_me_epzs.argtypes + [C.POINTER(C.c_int)]
+    cost = O.xo_me_epzs_mot(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], ptr(mvp),
+                            ptr(mv), lg, lg, 10, O.mc_l_coeff, C.byref(p), C.byref(mot))
+    return (cost, int(mv[0]), int(mv[1]), mot.value) if with_mot else (cost, int(mv[0]), int(mv[1]))

@@ -160,3 +160,8 @@ def test_epzs_search_vs_oracle(S, bi):
         cost, mv = impl(*args, **kw)
         for i in range(len(cases)):
             assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == exp[i], (impl.__name__, S, bi, i)
+    # the side effect on pi->mot_bits[lidx] (the next bi-directional search reads it): oracle -1 = untouched = 0 here
+    cost, mv, mot = me.epzs_search_device(*args, with_mot_bits=True, **kw)
+    for i, c in enumerate(cases):
+        e = run_oracle_epzs(c, with_mot=True)
+        assert int(mot[i]) == (e[3] if e[3] > 0 else 0), (S, bi, i)

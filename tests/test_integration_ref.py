@@ -75,3 +75,19 @@ def test_bitstream_identical_with_deblocking_and_padding_on_the_gpu(tmp_path, na
     m = re.search(r"pictures deblocked on the GPU: (\d+), padded on the GPU: (\d+)", err)
     assert m and int(m.group(1)) >= n and int(m.group(2)) >= n, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the loop filter on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium"])
+def test_bitstream_identical_with_motion_search_on_the_gpu(tmp_path, name):
+    """on top of everything above: pi->fn_me (pinter_me_epzs) -> xeve_hip_me_epzs_host.  The vectors, costs and the mot_bits side effect
+    the GPU search returns steer every inter mode decision of the encoder, so any deviation changes the stream."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, df=True, me=True)
+    assert "motion search routed to the GPU" in err
+    m = re.search(r"motion searches \(pinter_me_epzs\) served by the GPU: (\d+)", err)
+    assert m and int(m.group(1)) > 100, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the motion search on the GPU"

@@ -100,6 +100,7 @@ def test_me_epzs_matches_reference(bi, textured):
         cost = R.refdrv_me_epzs(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], lg, lg,
                                 10, ptr(mvp), ptr(mv), bi, c["lambda_mv"], 2, 0, c["mot_other"], c["msr"], c["msr"], c["sr"], 0, ptr(mn), ptr(mx),
                                 c["hpel_cnt"], c["qpel_cnt"])
-        assert run_oracle_epzs(c) == (cost, int(mv[0]), int(mv[1])), (it, c["S"])
+        R.refdrv_me_epzs_mot_bits.restype = C.c_int
+        assert run_oracle_epzs(c, with_mot=True) == (cost, int(mv[0]), int(mv[1]), R.refdrv_me_epzs_mot_bits()), (it, c["S"])
         moved += (int(mv[0]), int(mv[1])) != tuple(c["mvp"])
     assert moved > 25

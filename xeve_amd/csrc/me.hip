@@ -188,6 +188,7 @@ struct EpzsState {
     uint32_t cost;
     int16_t  mv[2];
     int32_t  tmpstep, searches;
+    int32_t  mot_bits; // what the searches leave in pi->mot_bits[lidx] (0 = untouched; xeve_pinter.c:546-548,690-692)
 };
 
 __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, int cy, int16_t (&range)[4])
@@ -212,7 +213,7 @@ __global__ void k_epzs_init(const xeve_hip_epzs_job *__restrict__ jobs, int n, x
     epzs_range(P, clip3(P.min_clip[0], P.max_clip[0], e.x + (sx >> 2)), clip3(P.min_clip[1], P.max_clip[1], e.y + (sy >> 2)), m.range);
     mj[j] = m;
     EpzsState s;
-    s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0;
+    s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0, s.mot_bits = 0;
     st[j] = s;
 }
 
@@ -229,6 +230,7 @@ __global__ void k_epzs_update(const xeve_hip_epzs_job *__restrict__ jobs, int n,
     const xeve_hip_me_result r = res[j];
     EpzsState s = st[j];
     s.tmpstep = r.beststep, s.searches++;
+    if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect (xeve_pinter.c:546-548)
     int beststep = 0;
     if(r.cost < s.cost) {
         s.cost = r.cost, s.mv[0] = r.mv[0], s.mv[1] = r.mv[1];
@@ -258,12 +260,13 @@ __global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int
     sj[j] = s;
 }
 
-__global__ void k_epzs_finish(int n, const EpzsState *__restrict__ st, const xeve_hip_me_result *__restrict__ spel, xeve_hip_me_result *__restrict__ out)
+__global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, const xeve_hip_me_result *__restrict__ spel, xeve_hip_me_result *__restrict__ out)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= n) return;
     xeve_hip_me_result r;
-    r.cost = st[j].cost, r.mv[0] = st[j].mv[0], r.mv[1] = st[j].mv[1], r.beststep = 0, r.best_mv_bits = 0;
+    r.cost = st[j].cost, r.mv[0] = st[j].mv[0], r.mv[1] = st[j].mv[1], r.beststep = 0;
+    r.best_mv_bits = (!bi && spel[j].best_mv_bits > 0) ? spel[j].best_mv_bits : st[j].mot_bits; // me_spel_pattern's side effect (:690-692)
     if(spel[j].cost < r.cost) r.cost = spel[j].cost, r.mv[0] = spel[j].mv[0], r.mv[1] = spel[j].mv[1]; // xeve_pinter.c:828-833
     out[j] = r;
 }
@@ -321,8 +324,40 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
     int rc = xeve_hip_me_spel_pattern_jobs(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, sres, sws,
                                            xeve_hip_me_spel_workspace(njobs), st);
     if(rc != XEVE_HIP_OK) return rc;
-    k_epzs_finish<<<g, 256, 0, st>>>(njobs, state, sres, results);
+    k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
     XH_HIP(hipGetLastError());
     XH_HIP(hipStreamSynchronize(st));
     return XEVE_HIP_OK;
+}
+
+
+// ---- host-memory form of one pinter_me_epzs call (the table layer's style: synchronous, planes staged per call) ------------------
+// What pi->fn_me can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org0 / ref0: sample (0, 0) of
+// the original luma plane (rows 0 .. pic_h - 1 are read) and of the padded reference luma plane (pad samples around the picture).
+extern "C" int xeve_hip_me_epzs_host(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, int pad, int pic_h,
+                                     const xeve_hip_epzs_job *job, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                                     const xeve_hip_epzs_params *params, xeve_hip_me_result *result)
+{
+    XH_ENTER();
+    XH_REQUIRE(org0 && ref0 && job && params && result && pad >= 0 && pic_h > 0);
+    const size_t eo = (size_t)s_org * pic_h, er = (size_t)s_ref * (pic_h + 2 * pad), ro = (size_t)pad * s_ref + pad, nb = (size_t)1 << (log2w + log2h);
+    const size_t wsb = xeve_hip_me_epzs_workspace(1);
+    pel *d_org = nullptr, *d_ref = nullptr, *d_bi = nullptr;
+    char *d_misc = nullptr; // job | result | workspace
+    int rc = XEVE_HIP_OK;
+    auto ok = [&](hipError_t e) { if(e != hipSuccess && rc == XEVE_HIP_OK) xh_set_error("xeve_hip_me_epzs_host: %s", hipGetErrorString(e)), rc = XEVE_HIP_ERR_DEVICE; return e == hipSuccess; };
+    ok(hipMalloc((void **)&d_org, eo * sizeof(pel))) && ok(hipMemcpy(d_org, org0, eo * sizeof(pel), hipMemcpyHostToDevice));
+    ok(hipMalloc((void **)&d_ref, er * sizeof(pel))) && ok(hipMemcpy(d_ref, ref0 - ro, er * sizeof(pel), hipMemcpyHostToDevice));
+    if(org_bi) ok(hipMalloc((void **)&d_bi, nb * sizeof(pel))) && ok(hipMemcpy(d_bi, org_bi, nb * sizeof(pel), hipMemcpyHostToDevice));
+    ok(hipMalloc((void **)&d_misc, 512 + wsb)) && ok(hipMemcpy(d_misc, job, sizeof(*job), hipMemcpyHostToDevice));
+    if(rc == XEVE_HIP_OK) {
+        xeve_hip_epzs_job j0 = *job;
+        j0.org_off = 0; // one job: its org_bi block is the whole buffer
+        ok(hipMemcpy(d_misc, &j0, sizeof(j0), hipMemcpyHostToDevice));
+        rc = xeve_hip_me_epzs_jobs(d_org, s_org, d_bi, d_ref + ro, s_ref, (const xeve_hip_epzs_job *)d_misc, 1, log2w, log2h, bit_depth, coef, params,
+                                   (xeve_hip_me_result *)(d_misc + 256), d_misc + 512, wsb, nullptr);
+        if(rc == XEVE_HIP_OK) ok(hipMemcpy(result, d_misc + 256, sizeof(*result), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_org), (void)hipFree(d_ref), (void)hipFree(d_bi), (void)hipFree(d_misc);
+    return rc;
 }

@@ -78,7 +78,8 @@ def epzs_search(org_plane, org_origin, s_org, ref_plane, ref_origin, s_ref, x, y
 
 
 def epzs_search_device(org_plane, org_origin, s_org, ref_plane, ref_origin, s_ref, x, y, mvp, log2, bit_depth, lambda_mv, refi_bits,
-                       max_search_range, range_recentre, min_clip, max_clip, hpel_cnt, qpel_cnt, bi=0, org_bi=None, mv_start=None, extra_bits=0):
+                       max_search_range, range_recentre, min_clip, max_clip, hpel_cnt, qpel_cnt, bi=0, org_bi=None, mv_start=None, extra_bits=0,
+                       with_mot_bits=False):
     """Same search through the C entry point xeve_hip_me_epzs_jobs: the bookkeeping between the searches runs in device
     kernels, the job / state / result arrays never leave the GPU until the final result."""
     import torch
@@ -104,4 +105,6 @@ def epzs_search_device(org_plane, org_origin, s_org, ref_plane, ref_origin, s_re
                                        C.c_void_p(coef.ctypes.data), C.byref(P), C.c_void_p(res.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes,
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     r = res.cpu().numpy().view(_lib.ME_RESULT_DTYPE).reshape(-1)
+    if with_mot_bits:  # what the searches leave in pi->mot_bits[lidx]; 0 = untouched
+        return r["cost"].copy(), r["mv"].copy(), r["best_mv_bits"].copy()
     return r["cost"].copy(), r["mv"].copy()
