@@ -194,6 +194,12 @@ int xeve_hip_rdoq_bit_est(const struct xeve_hip_sbac *sbac, int nstates, xeve_hi
 int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
                       const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int is_intra_cu,
                       int32_t *nnz, void *stream);
+/* One transform block in HOST memory, synchronous (the table layer's style): xeve_tq_nnz (xeve_tq.c:729-748: xeve_trans + xeve_quant_nnz with
+ * the zero pre-test and RDOQ, or the plain quantiser) and itdq_cu (xeve_itdq.c:454-497: xeve_dquant + xeve_itrans) -- what the per-component loops
+ * of ctx->fn_tq (xeve_sub_block_tq) and ctx->fn_itdp (xeve_itdq) call.  est: HOST record holding core->rdoq_est_* (may be NULL when !use_rdoq). */
+int xeve_hip_tq_nnz_host(int16_t *coef, int log2w, int log2h, int qp, double lambda, int ch_type, int is_intra_cu, int is_intra_slice, int bit_depth,
+                         int tool_iqt, const xeve_hip_rdoq_est_full *est, int use_rdoq, int32_t *nnz);
+int xeve_hip_itdq_host(int16_t *coef, int log2w, int log2h, int qp, int bit_depth);
 /* xeve_dquant with itdq_cu's shift/offset (xeve_itdq.c:442-475) */
 int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
 /* xeve_recon_blk over nblk dense blocks; rec block b is written at rec + rec_off[b] with stride s_rec;

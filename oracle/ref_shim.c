@@ -110,9 +110,60 @@ static u32 shim_me(XEVE_PINTER *pi, int x, int y, int log2_cuw, int log2_cuh, s8
     return r.cost;
 }
 
+/* XEVE_HIP_SHIM_TQ=1: transform + quantisation (zero pre-test + RDOQ, the quantiser every preset configures) and dequantisation + inverse
+ * transform of every transform block run on the GPU -- ctx->fn_tq (xeve_sub_block_tq, xeve_tq.c:750-864) and ctx->fn_itdp (xeve_itdq,
+ * xeve_itdq.c:499-580) are replaced by the same per-component loops around xeve_hip_tq_nnz_host / xeve_hip_itdq_host, with core->rdoq_est_*
+ * (filled by the reference's xeve_rdoq_bit_est) handed over as the estimate record.  Baseline: one transform block per component (CU <= 64). */
+typedef struct { int cbf_all[2], cbf_luma[2], cbf_cb[2], cbf_cr[2], run[24][2], level[24][2], last[2][2]; } hip_est_full;
+static int (*hip_tq_nnz_host)(s16 *, int, int, int, double, int, int, int, int, int, const hip_est_full *, int, int *);
+static int (*hip_itdq_host)(s16 *, int, int, int, int);
+static unsigned long long tq_calls, itdq_calls;
+
+static int shim_tq(XEVE_CTX *ctx, XEVE_CORE *core, s16 coef[N_C][MAX_CU_DIM], int log2_cuw, int log2_cuh, int slice_type, int nnz[N_C], int is_intra, int run_stats)
+{
+    int run[N_C] = {run_stats & 1, (run_stats >> 1) & 1, (run_stats >> 2) & 1};
+    const int ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
+    const u8  qp[N_C] = {core->qp_y, core->qp_u, core->qp_v};
+    hip_est_full e;
+    if(log2_cuw > MAX_TR_LOG2 || log2_cuh > MAX_TR_LOG2) { fprintf(stderr, "[xeve_hip_shim] CU larger than one transform block\n"); abort(); }
+    memcpy(e.cbf_all, core->rdoq_est_cbf_all, 8), memcpy(e.cbf_luma, core->rdoq_est_cbf_luma, 8), memcpy(e.cbf_cb, core->rdoq_est_cbf_cb, 8), memcpy(e.cbf_cr, core->rdoq_est_cbf_cr, 8);
+    memcpy(e.run, core->rdoq_est_run, sizeof(e.run)), memcpy(e.level, core->rdoq_est_level, sizeof(e.level)), memcpy(e.last, core->rdoq_est_last, sizeof(e.last));
+    xeve_mset(core->nnz_sub, 0, sizeof(int) * N_C * MAX_SUB_TB_NUM);
+    if(!ctx->sps.chroma_format_idc) run[1] = run[2] = 0;
+    for(int c = 0; c < N_C; c++) {
+        nnz[c] = 0;
+        if(!run[c]) continue;
+        int n = 0;
+        if(hip_tq_nnz_host(coef[c], log2_cuw - (c ? ws : 0), log2_cuh - (c ? hs : 0), qp[c], core->lambda[c], c, is_intra, slice_type == SLICE_I,
+                           ctx->sps.bit_depth_luma_minus8 + 8, ctx->param.tool_iqt, &e, ctx->param.rdoq, &n) != 0) {
+            fprintf(stderr, "[xeve_hip_shim] tq: %s\n", hip_err());
+            abort();
+        }
+        core->nnz_sub[c][0] = nnz[c] = n;
+        tq_calls++;
+    }
+    return nnz[Y_C] + nnz[U_C] + nnz[V_C];
+}
+
+static void shim_itdq(XEVE_CTX *ctx, XEVE_CORE *core, s16 coef[N_C][MAX_CU_DIM], int nnz_sub[N_C][MAX_SUB_TB_NUM])
+{
+    const int ws = XEVE_GET_CHROMA_W_SHIFT(ctx->sps.chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(ctx->sps.chroma_format_idc);
+    const u8  qp[N_C] = {core->qp_y, core->qp_u, core->qp_v};
+    if(core->log2_cuw > MAX_TR_LOG2 || core->log2_cuh > MAX_TR_LOG2) { fprintf(stderr, "[xeve_hip_shim] CU larger than one transform block\n"); abort(); }
+    for(int c = 0; c < N_C; c++) {
+        if((c && !ctx->sps.chroma_format_idc) || !nnz_sub[c][0]) continue;
+        if(hip_itdq_host(coef[c], core->log2_cuw - (c ? ws : 0), core->log2_cuh - (c ? hs : 0), qp[c], ctx->sps.bit_depth_luma_minus8 + 8) != 0) {
+            fprintf(stderr, "[xeve_hip_shim] itdq: %s\n", hip_err());
+            abort();
+        }
+        itdq_calls++;
+    }
+}
+
 static void report(void)
 {
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
+    if(tq_calls) fprintf(stderr, "[xeve_hip_shim] transform blocks quantised (RDOQ) on the GPU: %llu, dequantised + inverse transformed: %llu\n", tq_calls, itdq_calls);
     if(me_calls) fprintf(stderr, "[xeve_hip_shim] motion searches (pinter_me_epzs) served by the GPU: %llu\n", me_calls);
     if(df_calls || pad_calls) fprintf(stderr, "[xeve_hip_shim] pictures deblocked on the GPU: %llu, padded on the GPU: %llu\n", df_calls, pad_calls);
 }
@@ -141,6 +192,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_deblock_host || !hip_expand_host) { fprintf(stderr, "[xeve_hip_shim] deblock / expand entry points missing\n"); abort(); }
         ctx->fn_loop_filter = shim_loop_filter, ctx->fn_picbuf_expand = shim_pic_expand;
         fprintf(stderr, "[xeve_hip_shim] loop filter and picture padding routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_TQ") && atoi(getenv("XEVE_HIP_SHIM_TQ"))) {
+        hip_tq_nnz_host = dlsym(h, "xeve_hip_tq_nnz_host"), hip_itdq_host = dlsym(h, "xeve_hip_itdq_host"), hip_err = err;
+        if(!hip_tq_nnz_host || !hip_itdq_host) { fprintf(stderr, "[xeve_hip_shim] tq / itdq entry points missing\n"); abort(); }
+        ctx->fn_tq = shim_tq, ctx->fn_itdp = shim_itdq;
+        fprintf(stderr, "[xeve_hip_shim] transform + RDOQ and dequantisation + inverse transform routed to the GPU\n");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

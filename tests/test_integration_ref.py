@@ -91,3 +91,23 @@ def test_bitstream_identical_with_motion_search_on_the_gpu(tmp_path, name):
     m = re.search(r"motion searches \(pinter_me_epzs\) served by the GPU: (\d+)", err)
     assert m and int(m.group(1)) > 100, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the motion search on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium", "cfg1_cif_allintra_fast"])
+def test_bitstream_identical_with_rdoq_on_the_gpu(tmp_path, name):
+    """ctx->fn_tq / ctx->fn_itdp: every transform block of the encode (inter and intra, luma and chroma, 2x2 ... 64x64) is transformed and
+    quantised -- zero pre-test + RDOQ with the estimates the reference derived from its live CABAC state -- and reconstructed by the GPU."""
+    w, h, n, seed, extra = CASES[name]
+    if name.startswith("cfg1"):
+        n = 1  # one intra picture is plenty (each block is staged separately)
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    ref_md5, ref_size, _ = run_app(yuv, str(tmp_path / "ref.evc"), w, h, n, extra)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, tq=True)
+    m = re.search(r"quantised \(RDOQ\) on the GPU: (\d+), dequantised \+ inverse transformed: (\d+)", err)
+    assert m and int(m.group(1)) > 1000 and int(m.group(2)) > 100, err
+    assert (md5, size) == (ref_md5, ref_size), "bitstream differs with RDOQ on the GPU"
+    if not name.startswith("cfg1"):
+        assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])

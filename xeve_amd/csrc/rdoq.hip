@@ -409,3 +409,54 @@ extern "C" int xeve_hip_rdoq_bit_est(const xeve_hip_sbac *sbac, int nstates, xev
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// ---- host-memory forms of one transform block (the table layer's style) ------------------------------------------------------------
+// xeve_tq_nnz (xeve_tq.c:729-748) = xeve_trans + xeve_quant_nnz, and itdq_cu (xeve_itdq.c:454-497) = xeve_dquant + xeve_itrans, on a
+// dense block in HOST memory: what the per-component loops of ctx->fn_tq (xeve_sub_block_tq) / ctx->fn_itdp (xeve_itdq) call.
+extern "C" int xeve_hip_trans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream);
+extern "C" int xeve_hip_itrans(int16_t *coef, int nblk, int log2w, int log2h, int bit_depth, void *stream);
+extern "C" int xeve_hip_quant(int16_t *coef, int nblk, int log2w, int log2h, int qp, int scale, int is_intra_slice, int bit_depth, int32_t *nnz, void *stream);
+extern "C" int xeve_hip_dquant(int16_t *coef, int nblk, int log2w, int log2h, int scale, int bit_depth, void *stream);
+
+extern "C" int xeve_hip_tq_nnz_host(int16_t *coef, int log2w, int log2h, int qp, double lambda, int ch_type, int is_intra_cu, int is_intra_slice,
+                                    int bit_depth, int tool_iqt, const xeve_hip_rdoq_est_full *est, int use_rdoq, int32_t *nnz)
+{
+    XH_ENTER();
+    XH_REQUIRE(coef && nnz && (est || !use_rdoq) && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 63);
+    const size_t n = (size_t)1 << (log2w + log2h), off_nnz = (n * 2 + 15) & ~(size_t)15, off_est = off_nnz + 16;
+    char *d = nullptr;
+    XH_HIP(hipMalloc((void **)&d, off_est + sizeof(*est)));
+    int rc = XEVE_HIP_OK;
+    if(hipMemcpy(d, coef, n * 2, hipMemcpyHostToDevice) != hipSuccess || (use_rdoq && hipMemcpy(d + off_est, est, sizeof(*est), hipMemcpyHostToDevice) != hipSuccess)) {
+        xh_set_error("xeve_hip_tq_nnz_host: staging failed");
+        rc = XEVE_HIP_ERR_DEVICE;
+    }
+    if(rc == XEVE_HIP_OK) rc = xeve_hip_trans((int16_t *)d, 1, log2w, log2h, bit_depth, nullptr);
+    if(rc == XEVE_HIP_OK)
+        rc = use_rdoq ? xeve_hip_rdoq_dev((int16_t *)d, 1, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, (const xeve_hip_rdoq_est_full *)(d + off_est), nullptr,
+                                          1, is_intra_slice, is_intra_cu, (int32_t *)(d + off_nnz), nullptr)
+                      : xeve_hip_quant((int16_t *)d, 1, log2w, log2h, qp, k_quant_scale[tool_iqt][qp % 6], is_intra_slice, bit_depth, (int32_t *)(d + off_nnz), nullptr);
+    if(rc == XEVE_HIP_OK && (hipMemcpy(coef, d, n * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(nnz, d + off_nnz, 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+        xh_set_error("xeve_hip_tq_nnz_host: copy back failed");
+        rc = XEVE_HIP_ERR_DEVICE;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int xeve_hip_itdq_host(int16_t *coef, int log2w, int log2h, int qp, int bit_depth)
+{
+    XH_ENTER();
+    XH_REQUIRE(coef && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 63);
+    static const int dq[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237), scale << (qp / 6) (xeve_itdq.c:549)
+    const size_t n = (size_t)1 << (log2w + log2h);
+    int16_t *d = nullptr;
+    XH_HIP(hipMalloc((void **)&d, n * 2));
+    int rc = hipMemcpy(d, coef, n * 2, hipMemcpyHostToDevice) == hipSuccess ? XEVE_HIP_OK : XEVE_HIP_ERR_DEVICE;
+    if(rc == XEVE_HIP_OK) rc = xeve_hip_dquant(d, 1, log2w, log2h, dq[qp % 6] << (qp / 6), bit_depth, nullptr);
+    if(rc == XEVE_HIP_OK) rc = xeve_hip_itrans(d, 1, log2w, log2h, bit_depth, nullptr);
+    if(rc == XEVE_HIP_OK && hipMemcpy(coef, d, n * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE;
+    if(rc == XEVE_HIP_ERR_DEVICE) xh_set_error("xeve_hip_itdq_host: staging failed");
+    (void)hipFree(d);
+    return rc;
+}
