@@ -350,7 +350,11 @@ typedef struct xeve_hip_cu_bits_params {
     int32_t cm_init;             /* sps_cm_init_flag (0 in Baseline) */
     int32_t chroma_format_idc;   /* 0..3; chroma block = (w >> w_shift) x (h >> h_shift), XEVE_GET_CHROMA_{W,H}_SHIFT */
 } xeve_hip_cu_bits_params;
-enum { XEVE_HIP_BITS_CU_INTER = 0, XEVE_HIP_BITS_COMP_Y = 1, XEVE_HIP_BITS_COMP_U = 2, XEVE_HIP_BITS_COMP_V = 3, XEVE_HIP_BITS_CU_SKIP = 4 };
+enum { XEVE_HIP_BITS_CU_INTER = 0, XEVE_HIP_BITS_COMP_Y = 1, XEVE_HIP_BITS_COMP_U = 2, XEVE_HIP_BITS_COMP_V = 3, XEVE_HIP_BITS_CU_SKIP = 4,
+       XEVE_HIP_BITS_ECO_COEF = 5 /* ctx->fn_eco_coef = xeve_eco_coef (xeve_eco.c:1067-1089) on its own: cbf flags + coefficients */ };
+/* XEVE_HIP_BITS_ECO_COEF: job.dir_flag holds these flags.  NO_RESET continues the coder where the entry state stands instead of applying
+ * xeve_sbac_bit_reset (needs sbac_out: only the kernel that carries the complete coder state can do it). */
+enum { XEVE_HIP_ECO_INTRA = 1, XEVE_HIP_ECO_NO_CBF = 2, XEVE_HIP_ECO_RUN_Y = 4, XEVE_HIP_ECO_RUN_U = 8, XEVE_HIP_ECO_RUN_V = 16, XEVE_HIP_ECO_NO_RESET = 32 };
 typedef struct xeve_hip_cu_bits_job {
     int32_t coef_off[3];   /* element offsets of the dense Y / U / V blocks of quantised levels inside `coef` */
     int32_t nnz[3];        /* core->nnz_sub[c][0]: 0 = cbf 0 (the block is not coded whatever it holds)     */
@@ -359,7 +363,7 @@ typedef struct xeve_hip_cu_bits_job {
     int8_t  refi[2];       /* pi->refi[pidx] (< 0 = list unused)                                            */
     uint8_t mvp_idx[2];
     uint8_t mode;          /* XEVE_HIP_BITS_*                                                               */
-    uint8_t dir_flag;      /* pidx == PRED_DIR                                                              */
+    uint8_t dir_flag;      /* pidx == PRED_DIR (mode XEVE_HIP_BITS_ECO_COEF: XEVE_HIP_ECO_* flags)                 */
     uint8_t ctx_skip, ctx_pred_mode; /* core->ctx_flags[CNID_SKIP_FLAG], [CNID_PRED_MODE]                   */
 } xeve_hip_cu_bits_job;
 /* Per job: SBAC_LOAD(sbac_in[job.sbac]) + xeve_sbac_bit_reset + the syntax of job.mode + xeve_get_bit_number -> bits[j];
@@ -367,6 +371,11 @@ typedef struct xeve_hip_cu_bits_job {
  * elements), sbac_in, jobs, bits, sbac_out and workspace (>= xeve_hip_cu_bits_workspace(njobs, coef_elems) bytes) are
  * device memory; params is a HOST pointer.  Jobs may share coefficient blocks and entry states. */
 size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems);
+/* One xeve_eco_coef call in bit-count mode on HOST memory (synchronous): the cbf flags and coefficients of one CU continue the coder from
+ * *state where it stands and leave *state as the reference's coder would -- what ctx->fn_eco_coef can be pointed at while sbac->is_bitcount.
+ * flags: XEVE_HIP_ECO_INTRA / _NO_CBF / _RUN_Y|U|V; coef_*: the CU's dense coefficient blocks; nnz: core->nnz_sub[c][0]. */
+int xeve_hip_eco_coef_host(xeve_hip_sbac *state, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v, int log2_cuw, int log2_cuh,
+                           const int32_t nnz[3], int flags, int chroma_format_idc, int cm_init);
 /* The same counts from the count-only kernel, handing on only what later counts depend on: state_out[j].range and .ctx (the other
  * fields are reset, as xeve_sbac_bit_reset would leave them; .code is 0).  For chains of tests such as the per-component cbf
  * tests of pinter_residue_rdo, where the intermediate states are only ever SBAC_LOADed into further bit counts. */

@@ -66,6 +66,13 @@ unsigned refdrv_cu_bits(const drv_sbac *in, drv_sbac *out, const drv_params *p, 
         memcpy(cbuf[c], coef + j->coef_off[c], n * sizeof(s16));
     }
     to_ref(&core->s_temp_run, in + j->sbac, p->cm_init); /* SBAC_LOAD */
+    if(j->mode == 5) { /* ctx->fn_eco_coef alone; flags in dir_flag: 1 intra, 2 b_no_cbf, 4/8/16 run Y/U/V, 32 no bit_reset */
+        const int f = j->dir_flag;
+        if(!(f & 32)) xeve_sbac_bit_reset(&core->s_temp_run);
+        xeve_eco_coef(ctx, core, &core->bs_temp, cbuf, (f & 1) ? MODE_INTRA : MODE_INTER, 0, (f & 2) ? 1 : 0, (f >> 2) & 7);
+        if(out) from_ref(out, &core->s_temp_run);
+        return xeve_get_bit_number(&core->s_temp_run);
+    }
     xeve_sbac_bit_reset(&core->s_temp_run);
     s8  refi[REFP_NUM] = {j->refi[0], j->refi[1]};
     s16 mvd[REFP_NUM][MV_D] = {{j->mvd[0][0], j->mvd[0][1]}, {j->mvd[1][0], j->mvd[1][1]}};

@@ -160,9 +160,49 @@ static void shim_itdq(XEVE_CTX *ctx, XEVE_CORE *core, s16 coef[N_C][MAX_CU_DIM],
     }
 }
 
+/* XEVE_HIP_SHIM_ECO=1: while the encoder counts bits (sbac->is_bitcount, i.e. inside the RDO), the coefficient syntax of every CU -- cbf flags
+ * and run / level / sign / last bins through the adaptive arithmetic coder -- runs on the GPU: ctx->fn_eco_coef (xeve_eco_coef, xeve_eco.c:1067-1089)
+ * hands the live XEVE_SBAC over, field by field, and takes it back as xeve_hip_eco_coef_host leaves it.  Writing the real bitstream stays with the
+ * reference's function. */
+typedef struct { u32 range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter; u16 ctx[68]; } hip_sbac;
+static int (*hip_eco_coef_host)(hip_sbac *, const s16 *, const s16 *, const s16 *, int, int, const int *, int, int, int);
+static int (*orig_eco_coef)(XEVE_CTX *, XEVE_CORE *, XEVE_BSW *, s16 coef[N_C][MAX_CU_DIM], u8, int, int, int);
+static unsigned long long eco_calls;
+#define SBAC_MAP(F)                                                                                                             \
+    F(skip_flag, 0, 2) F(pred_mode, 2, 3) F(direct_mode_flag, 5, 1) F(inter_dir, 6, 2) F(refi, 8, 2) F(mvp_idx, 10, 3) F(mvd, 13, 1)  \
+    F(cbf_all, 14, 1) F(cbf_luma, 15, 1) F(cbf_cb, 16, 1) F(cbf_cr, 17, 1) F(run, 18, 24) F(last, 42, 2) F(level, 44, 24)
+
+static int shim_eco_coef(XEVE_CTX *ctx, XEVE_CORE *core, XEVE_BSW *bs, s16 coef[N_C][MAX_CU_DIM], u8 pred_mode, int enc_dqp, int b_no_cbf, int run_stats)
+{
+    XEVE_SBAC *sbac = (XEVE_SBAC *)bs->pdata[1];
+    if(!sbac->is_bitcount || ctx->pps.cu_qp_delta_enabled_flag || core->log2_cuw > MAX_TR_LOG2 || core->log2_cuh > MAX_TR_LOG2 ||
+       core->tree_cons.tree_type != TREE_LC || core->tree_cons.mode_cons != eAll)
+        return orig_eco_coef(ctx, core, bs, coef, pred_mode, enc_dqp, b_no_cbf, run_stats);
+    hip_sbac h;
+    h.range = sbac->range, h.code = sbac->code, h.code_bits = sbac->code_bits, h.stacked_ff = sbac->stacked_ff, h.stacked_zero = sbac->stacked_zero;
+    h.pending_byte = sbac->pending_byte, h.is_pending_byte = sbac->is_pending_byte, h.bitcounter = sbac->bitcounter, h.bin_counter = sbac->bin_counter;
+#define F(name, at, n) memcpy(h.ctx + at, sbac->ctx.name, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    const int nnz[3] = {core->nnz_sub[Y_C][0], core->nnz_sub[U_C][0], core->nnz_sub[V_C][0]};
+    const int flags = (pred_mode == MODE_INTRA ? 1 : 0) | (b_no_cbf == 1 ? 2 : 0) | ((run_stats & 7) << 2);
+    if(hip_eco_coef_host(&h, coef[Y_C], coef[U_C], coef[V_C], core->log2_cuw, core->log2_cuh, nnz, flags, ctx->sps.chroma_format_idc, sbac->ctx.sps_cm_init_flag) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] eco_coef: %s\n", hip_err());
+        abort();
+    }
+    sbac->range = h.range, sbac->code = h.code, sbac->code_bits = h.code_bits, sbac->stacked_ff = h.stacked_ff, sbac->stacked_zero = h.stacked_zero;
+    sbac->pending_byte = h.pending_byte, sbac->is_pending_byte = h.is_pending_byte, sbac->bitcounter = h.bitcounter, sbac->bin_counter = h.bin_counter;
+#define F(name, at, n) memcpy(sbac->ctx.name, h.ctx + at, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    eco_calls++;
+    return XEVE_OK;
+}
+
 static void report(void)
 {
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
+    if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
     if(tq_calls) fprintf(stderr, "[xeve_hip_shim] transform blocks quantised (RDOQ) on the GPU: %llu, dequantised + inverse transformed: %llu\n", tq_calls, itdq_calls);
     if(me_calls) fprintf(stderr, "[xeve_hip_shim] motion searches (pinter_me_epzs) served by the GPU: %llu\n", me_calls);
     if(df_calls || pad_calls) fprintf(stderr, "[xeve_hip_shim] pictures deblocked on the GPU: %llu, padded on the GPU: %llu\n", df_calls, pad_calls);
@@ -192,6 +232,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_deblock_host || !hip_expand_host) { fprintf(stderr, "[xeve_hip_shim] deblock / expand entry points missing\n"); abort(); }
         ctx->fn_loop_filter = shim_loop_filter, ctx->fn_picbuf_expand = shim_pic_expand;
         fprintf(stderr, "[xeve_hip_shim] loop filter and picture padding routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_ECO") && atoi(getenv("XEVE_HIP_SHIM_ECO"))) {
+        hip_eco_coef_host = dlsym(h, "xeve_hip_eco_coef_host"), hip_err = err;
+        if(!hip_eco_coef_host) { fprintf(stderr, "[xeve_hip_shim] eco_coef entry point missing\n"); abort(); }
+        orig_eco_coef = ctx->fn_eco_coef, ctx->fn_eco_coef = shim_eco_coef;
+        fprintf(stderr, "[xeve_hip_shim] CABAC bit counting of the coefficient syntax routed to the GPU\n");
     }
     if(getenv("XEVE_HIP_SHIM_TQ") && atoi(getenv("XEVE_HIP_SHIM_TQ"))) {
         hip_tq_nnz_host = dlsym(h, "xeve_hip_tq_nnz_host"), hip_itdq_host = dlsym(h, "xeve_hip_itdq_host"), hip_err = err;

@@ -876,19 +876,26 @@ static void sbac_refi(xo_sbac *s, int num_refp, int refi)
 
 /* xeve_eco_coef -> xeve_eco_coefficient (xeve_eco.c:925-1089) for MODE_INTER, one transform block per component,
  * no delta QP, b_no_cbf 0; run[] = the components this call covers */
-static void sbac_coef_inter(xo_sbac *s, const xo_cu_bits_params *p, const xo_cu_bits_job *j, const int16_t *coef, const int run[3])
+static void sbac_coef(xo_sbac *s, const xo_cu_bits_params *p, const xo_cu_bits_job *j, const int16_t *coef, const int run[3], int is_intra, int b_no_cbf)
 {
     int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1;
     int cbf[3] = {!!j->nnz[0], !!j->nnz[1], !!j->nnz[2]}, cbf_all = 0;
     for(int c = 0; c < 3; c++) cbf_all += run[c] && cbf[c];
-    /* xeve_eco_cbf (xeve_eco.c:793-894), inter branch, sub_pos 0, is_sub 0 */
-    if(run[0] + run[1] + run[2] == 3) {
-        xo_sbac_bin(s, XO_CTX_CBF_ALL, cbf_all != 0);
-        if(!cbf_all) return;
+    /* xeve_eco_cbf (xeve_eco.c:793-894), sub_pos 0, is_sub 0 */
+    if(!is_intra) {
+        if(b_no_cbf != 1 && run[0] + run[1] + run[2] == 3) { /* (b_no_cbf: the flag is implied, xeve_eco.c:817-819) */
+            xo_sbac_bin(s, XO_CTX_CBF_ALL, cbf_all != 0);
+            if(!cbf_all) return;
+        }
+        if(run[1] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CB, cbf[1]);
+        if(run[2] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CR, cbf[2]);
+        if(run[0] && cbf[1] + cbf[2] != 0) xo_sbac_bin(s, XO_CTX_CBF_LUMA, cbf[0]);
     }
-    if(run[1] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CB, cbf[1]);
-    if(run[2] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CR, cbf[2]);
-    if(run[0] && cbf[1] + cbf[2] != 0) xo_sbac_bin(s, XO_CTX_CBF_LUMA, cbf[0]);
+    else { /* intra: one flag per component that is coded (xeve_eco.c:864-890) */
+        if(run[1] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CB, cbf[1]);
+        if(run[2] && p->chroma_format_idc) xo_sbac_bin(s, XO_CTX_CBF_CR, cbf[2]);
+        if(run[0]) xo_sbac_bin(s, XO_CTX_CBF_LUMA, cbf[0]);
+    }
     for(int c = 0; c < 3; c++)
         if(j->nnz[c] && run[c])
             xo_eco_run_length_cc(s, coef + j->coef_off[c], p->log2_cuw - (c ? ws : 0), p->log2_cuh - (c ? hs : 0), j->nnz[c], c != 0, p->cm_init);
@@ -897,6 +904,13 @@ static void sbac_coef_inter(xo_sbac *s, const xo_cu_bits_params *p, const xo_cu_
 uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p, const xo_cu_bits_job *j, const int16_t *coef)
 {
     xo_sbac s = in[j->sbac];
+    if(j->mode == XO_BITS_ECO_COEF) { /* ctx->fn_eco_coef = xeve_eco_coef (xeve_eco.c:1067-1089) alone, wherever the coder stands */
+        const int f = j->dir_flag, run[3] = {(f >> 2) & 1, (f >> 3) & 1, (f >> 4) & 1};
+        if(!(f & XO_ECO_NO_RESET)) xo_sbac_bit_reset(&s);
+        sbac_coef(&s, p, j, coef, run, f & XO_ECO_INTRA, (f & XO_ECO_NO_CBF) ? 1 : 0);
+        if(out) *out = s;
+        return xo_sbac_bits(&s);
+    }
     xo_sbac_bit_reset(&s);
     if(j->mode == XO_BITS_CU_SKIP) { /* xeve_mode.c:276-295 */
         if(p->slice_type != 2) {
@@ -931,11 +945,11 @@ uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p,
                 }
             }
         }
-        sbac_coef_inter(&s, p, j, coef, run_all);
+        sbac_coef(&s, p, j, coef, run_all, 0, 0);
     }
     else { /* xeve_mode.c:177-199: one component, RUN_L / RUN_CB / RUN_CR */
         int run[3] = {j->mode == XO_BITS_COMP_Y, j->mode == XO_BITS_COMP_U, j->mode == XO_BITS_COMP_V};
-        sbac_coef_inter(&s, p, j, coef, run);
+        sbac_coef(&s, p, j, coef, run, 0, 0);
     }
     if(out) *out = s;
     return xo_sbac_bits(&s);

@@ -204,7 +204,9 @@ typedef struct xo_cu_bits_params {
     int32_t cm_init;             /* sps_cm_init_flag (0 in Baseline)                                      */
     int32_t chroma_format_idc;   /* 0 = 4:0:0 ... 3 = 4:4:4; w/h shift as XEVE_GET_CHROMA_{W,H}_SHIFT     */
 } xo_cu_bits_params;
-enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4 };
+enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4, XO_BITS_ECO_COEF = 5 };
+/* XO_BITS_ECO_COEF: xeve_eco_coef (cbf flags + coefficients) on its own; job.dir_flag then holds these flags */
+enum { XO_ECO_INTRA = 1, XO_ECO_NO_CBF = 2, XO_ECO_RUN_Y = 4, XO_ECO_RUN_U = 8, XO_ECO_RUN_V = 16, XO_ECO_NO_RESET = 32 /* continue the coder where the state stands */ };
 typedef struct xo_cu_bits_job {
     int32_t coef_off[3];   /* element offsets of the dense Y / U / V coefficient blocks            */
     int32_t nnz[3];        /* core->nnz_sub[c][0] (0 = cbf 0, the block is not coded)              */

@@ -103,3 +103,32 @@ def test_hip_cu_bits_rejects_bad_arguments():
         p.log2_cuw, p.log2_cuh, p.chroma_format_idc = lw, lh, idc
         with pytest.raises(RuntimeError):
             D.cu_bits_jobs(z, st, jb, p)
+
+
+@pytest.mark.parametrize("idc", [1, 0])
+def test_hip_eco_coef_alone_vs_oracle(idc):
+    """job mode XEVE_HIP_BITS_ECO_COEF: xeve_eco_coef on its own -- inter / intra cbf syntax, subsets of components, implied cbf, and continuing
+    the coder in mid-stream (pending / stacked bytes, any code_bits) instead of resetting it"""
+    O = oracle_sbac()
+    r = np.random.default_rng(4100 + idc)
+    for lw, lh in [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5), (6, 4)]:
+        p = make_params(lw, lh, 0, (2, 2), 0, idc)
+        jobs, coef = make_jobs(r, 90, lw, lh, 12, idc)
+        jobs["mode"] = 5
+        states = make_states(r, 12)
+        states["code_bits"] = r.integers(1, 9, size=len(states))
+        states["code"] = r.integers(0, 1 << 17, size=len(states)) << (8 - states["code_bits"]).astype(np.uint32)
+        states["is_pending_byte"], states["pending_byte"] = r.integers(0, 2, size=len(states)), r.integers(0, 256, size=len(states))
+        states["stacked_ff"], states["stacked_zero"] = r.integers(0, 3, size=len(states)), r.integers(0, 3, size=len(states))
+        for i in range(len(jobs)):
+            runs = int(r.integers(1, 8)) if idc else 1
+            intra, nocbf, noreset = int(r.random() < 0.4), int(r.random() < 0.2), int(r.random() < 0.6)
+            if nocbf and not (intra or any(jobs["nnz"][i][c] for c in range(3) if (runs >> c) & 1)):
+                nocbf = 0
+            jobs["dir_flag"][i] = intra | (nocbf << 1) | (runs << 2) | (noreset << 5)
+        exp_bits, exp = np.zeros(len(jobs), np.uint32), np.zeros(len(jobs), SBAC_DTYPE)
+        for i in range(len(jobs)):
+            exp_bits[i] = O.xo_cu_bits(ptr(states), ptr(exp[i:i + 1]), p, ptr(jobs[i:i + 1]), ptr(coef))
+        got_bits, got = run_hip(p, states, jobs, coef)
+        assert np.array_equal(got_bits, exp_bits), (lw, lh, np.flatnonzero(got_bits != exp_bits)[:5])
+        assert got.tobytes() == exp.tobytes(), (lw, lh)

@@ -111,3 +111,32 @@ def test_bitstream_identical_with_rdoq_on_the_gpu(tmp_path, name):
     assert (md5, size) == (ref_md5, ref_size), "bitstream differs with RDOQ on the GPU"
     if not name.startswith("cfg1"):
         assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium"])
+def test_bitstream_identical_with_cabac_bit_counting_on_the_gpu(tmp_path, name):
+    """ctx->fn_eco_coef in bit-count mode: the rate of every candidate the RDO weighs (inter and intra CUs, every cbf test of pinter_residue_rdo)
+    comes from the GPU's arithmetic coder, continuing the encoder's live XEVE_SBAC and handing it back field for field."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, eco=True)
+    m = re.search(r"coefficient bits were counted on the GPU: (\d+)", err)
+    assert m and int(m.group(1)) > 1000, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the CABAC bit counting on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_bitstream_identical_with_everything_on_the_gpu(tmp_path):
+    """all routes at once: dispatch tables + recon, motion search, transform / RDOQ / inverse, CABAC bit counting, loop filter, padding"""
+    name = "tiny_ra_medium"
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, df=True, me=True, tq=True, eco=True)
+    for needle in ("HIP dispatch tables installed", "motion search routed", "transform + RDOQ", "CABAC bit counting", "loop filter and picture padding"):
+        assert needle in err, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])

@@ -88,3 +88,33 @@ def test_rdoq_bit_est_and_entropy_table():
         O.xo_rdoq_bit_est(ptr(st[i:i + 1]), ptr(a))
         R.refdrv_rdoq_bit_est(ptr(st[i:i + 1]), ptr(b))
         assert np.array_equal(a, b), i
+
+
+@pytest.mark.parametrize("idc", [1, 0])
+def test_eco_coef_alone(idc):
+    """job mode 5 = ctx->fn_eco_coef (xeve_eco_coef) on its own: inter / intra cbf syntax, any subset of components, b_no_cbf, and
+    continuing the coder where the state stands (no xeve_sbac_bit_reset)"""
+    O, R = oracle_sbac(), ref_sbac()
+    r = np.random.default_rng(31 + idc)
+    for lw in range(2, 7):
+        for lh in range(2, 7):
+            p = make_params(lw, lh, 0, (2, 2), 0, idc)
+            jobs, coef = make_jobs(r, 24, lw, lh, 8, idc)
+            jobs["mode"] = 5
+            states = make_states(r, 8)
+            for i in range(len(jobs)):
+                runs = int(r.integers(1, 8)) if idc else 1
+                intra, nocbf, noreset = int(r.random() < 0.4), int(r.random() < 0.2), int(r.random() < 0.5)
+                if nocbf and not (intra or any(jobs["nnz"][i][c] for c in range(3) if (runs >> c) & 1)):
+                    nocbf = 0  # the reference asserts cbf_all != 0 when the flag is implied
+                jobs["dir_flag"][i] = intra | (nocbf << 1) | (runs << 2) | (noreset << 5)
+                if noreset:  # a state in mid-stream, as it stands after earlier bins
+                    states["code_bits"] = r.integers(1, 9, size=len(states))
+                    states["code"] = r.integers(0, 1 << 17, size=len(states)) << (8 - states["code_bits"]).astype(np.uint32)
+                    states["is_pending_byte"], states["pending_byte"] = 1, r.integers(0, 256, size=len(states))
+                    states["stacked_ff"], states["stacked_zero"] = r.integers(0, 3, size=len(states)), r.integers(0, 3, size=len(states))
+                a, b = np.zeros(1, SBAC_DTYPE), np.zeros(1, SBAC_DTYPE)
+                ba = O.xo_cu_bits(ptr(states), ptr(a), p, ptr(jobs[i:i + 1]), ptr(coef))
+                bb = R.refdrv_cu_bits(ptr(states), ptr(b), p, ptr(jobs[i:i + 1]), ptr(coef))
+                assert ba == bb, (lw, lh, i, jobs[i])
+                same(a, b)

@@ -16,6 +16,7 @@
 // The coder state is carried field for field (code register, pending / stacked bytes, bit counter), so the exit state
 // is what SBAC_STORE would keep and xeve_get_bit_number's formula applies unchanged.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "xh_common.h"
 
@@ -41,6 +42,7 @@ __device__ __forceinline__ unsigned coded_mask(const xeve_hip_cu_bits_job &j)
 {
     if(j.mode == XEVE_HIP_BITS_CU_SKIP) return 0;
     unsigned m = (j.nnz[0] ? 1u : 0u) | (j.nnz[1] ? 2u : 0u) | (j.nnz[2] ? 4u : 0u);
+    if(j.mode == XEVE_HIP_BITS_ECO_COEF) return m & ((j.dir_flag >> 2) & 7u);
     if(j.mode != XEVE_HIP_BITS_CU_INTER) m &= 1u << (j.mode - 1);
     return m;
 }
@@ -217,6 +219,24 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
         }
         return 0;
     }
+    if(J.mode == XEVE_HIP_BITS_ECO_COEF) { // ctx->fn_eco_coef on its own: xeve_eco_cbf (xeve_eco.c:793-894) for an inter or an intra CU
+        const unsigned f = J.dir_flag, run = (f >> 2) & 7, cbf = (J.nnz[0] ? 1u : 0u) | (J.nnz[1] ? 2u : 0u) | (J.nnz[2] ? 4u : 0u);
+        if(!(f & XEVE_HIP_ECO_INTRA)) {
+            if(!(f & XEVE_HIP_ECO_NO_CBF) && run == 7) {
+                Q.ctx(XEVE_HIP_CTX_CBF_ALL, (cbf & run) != 0);
+                if(!(cbf & run)) return 0;
+            }
+            if((run & 2) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CB, (cbf >> 1) & 1);
+            if((run & 4) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CR, (cbf >> 2) & 1);
+            if((run & 1) && (cbf & 6)) Q.ctx(XEVE_HIP_CTX_CBF_LUMA, cbf & 1);
+        }
+        else {
+            if((run & 2) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CB, (cbf >> 1) & 1);
+            if((run & 4) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CR, (cbf >> 2) & 1);
+            if(run & 1) Q.ctx(XEVE_HIP_CTX_CBF_LUMA, cbf & 1);
+        }
+        return cbf & run;
+    }
     unsigned run = 7;
     if(J.mode == XEVE_HIP_BITS_CU_INTER) { // xeve_mode.c:201-274
         if(st != 2) {
@@ -277,6 +297,10 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     Sbac s;
     s.range = in.range, s.shifts = s.bins = 0;
     s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
+    if(FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET)) { // continue the coder where the state stands
+        s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
+        s.bc = in.bitcounter, s.bins = in.bin_counter;
+    }
     for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
 
     Queue Q{&s_q[0][lane], 0};
@@ -470,4 +494,43 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
+}
+
+
+// ---- host-memory form of one xeve_eco_coef call in bit-count mode (the table layer's style) -----------------------------------------
+// What ctx->fn_eco_coef can be pointed at while the encoder is counting bits (sbac->is_bitcount): the cbf flags and the coefficients of one
+// CU go through the GPU coder, continuing from *state exactly where it stands, and *state is left as the reference's coder would leave it.
+extern "C" int xeve_hip_eco_coef_host(xeve_hip_sbac *state, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v, int log2_cuw, int log2_cuh,
+                                      const int32_t nnz[3], int flags, int chroma_format_idc, int cm_init)
+{
+    XH_ENTER();
+    XH_REQUIRE(state && coef_y && nnz && log2_cuw >= 2 && log2_cuw <= 6 && log2_cuh >= 2 && log2_cuh <= 6 && chroma_format_idc >= 0 && chroma_format_idc <= 3);
+    XH_REQUIRE(chroma_format_idc == 0 || (coef_u && coef_v));
+    const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1;
+    const size_t n0 = (size_t)1 << (log2_cuw + log2_cuh), n1 = chroma_format_idc ? n0 >> (ws + hs) : 0, ne = n0 + 2 * n1;
+    xeve_hip_cu_bits_params p;
+    p.log2_cuw = log2_cuw, p.log2_cuh = log2_cuh, p.slice_type = 0, p.num_refp[0] = p.num_refp[1] = 0, p.cm_init = cm_init, p.chroma_format_idc = chroma_format_idc;
+    xeve_hip_cu_bits_job j;
+    memset(&j, 0, sizeof(j));
+    j.coef_off[0] = 0, j.coef_off[1] = (int)n0, j.coef_off[2] = (int)(n0 + n1), j.nnz[0] = nnz[0], j.nnz[1] = nnz[1], j.nnz[2] = nnz[2];
+    j.mode = XEVE_HIP_BITS_ECO_COEF, j.dir_flag = (uint8_t)(flags | XEVE_HIP_ECO_NO_RESET);
+    const size_t o_job = (ne * 2 + 255) & ~(size_t)255, o_st = o_job + 256, o_bits = o_st + 2 * 256, o_ws = o_bits + 256;
+    const size_t wsb = xeve_hip_cu_bits_workspace(1, ne);
+    char *d = nullptr;
+    XH_HIP(hipMalloc((void **)&d, o_ws + wsb));
+    int rc = XEVE_HIP_OK;
+    auto up = [&](size_t off, const void *src, size_t bytes) { if(rc == XEVE_HIP_OK && hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE; };
+    up(0, coef_y, n0 * 2);
+    if(n1) up(n0 * 2, coef_u, n1 * 2), up((n0 + n1) * 2, coef_v, n1 * 2);
+    up(o_job, &j, sizeof(j)), up(o_st, state, sizeof(*state));
+    if(rc == XEVE_HIP_OK)
+        rc = xeve_hip_cu_bits_jobs((const int16_t *)d, ne, (const xeve_hip_sbac *)(d + o_st), (const xeve_hip_cu_bits_job *)(d + o_job), 1, &p, d + o_ws, wsb,
+                                   (uint32_t *)(d + o_bits), (xeve_hip_sbac *)(d + o_st + 256), nullptr);
+    else xh_set_error("xeve_hip_eco_coef_host: staging failed");
+    if(rc == XEVE_HIP_OK && hipMemcpy(state, d + o_st + 256, sizeof(*state), hipMemcpyDeviceToHost) != hipSuccess) {
+        xh_set_error("xeve_hip_eco_coef_host: copy back failed");
+        rc = XEVE_HIP_ERR_DEVICE;
+    }
+    (void)hipFree(d);
+    return rc;
 }
