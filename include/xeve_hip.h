@@ -439,6 +439,11 @@ typedef struct xeve_hip_cu_mc_job {
  * pred_y [njobs][h*w], pred_u / pred_v [njobs][(h >> h_shift) * (w >> w_shift)] receive what the reference leaves in pred[0];
  * jobs, pred_*, workspace: device memory; coefficient tables: HOST pointers (xeve_tbl_mc_l_coeff / xeve_tbl_mc_c_coeff). */
 size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp0, int num_refp1);
+/* One xeve_mc call on HOST memory (synchronous; the reference planes the job uses are staged per call): what pi->fn_mc (pinter_mc) can be pointed
+ * at.  refp holds HOST plane pointers; the planes extend pad_l / pad_c samples around the picture; pred_* are the caller's pred[0][Y_C / U_C / V_C]. */
+int xeve_hip_mc_cu_host(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pad_l, int pad_c, int pic_w, int pic_h,
+                        const xeve_hip_cu_mc_job *job, int w, int h, int bit_depth_luma, int bit_depth_chroma, int chroma_format_idc,
+                        const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v);
 int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h,
                         const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h, int bit_depth_luma, int bit_depth_chroma,
                         int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_pel *pred_y,

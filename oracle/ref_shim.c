@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "xeve_type.h"
+#include "xeve_mc.h"
 
 static void (*hip_recon_blk)(s16 *, pel *, int, int, int, int, pel *, int);
 static unsigned long long (*hip_table_calls)(void);
@@ -70,6 +71,39 @@ static void shim_pic_expand(XEVE_CTX *ctx, XEVE_PIC *pic)
         abort();
     }
     pad_calls++;
+}
+
+/* XEVE_HIP_SHIM_MC=1: the CU motion-compensation driver -- pi->fn_mc (pinter_mc -> xeve_mc, xeve_pinter.c:2058-2085,2106) -- runs on the GPU as a
+ * whole (clip, per-list interpolation of Y / U / V, identical-motion shortcut, bi-prediction average): xeve_hip_mc_cu_host. */
+typedef struct { const pel *y, *u, *v; int poc, pad_; } hip_refpic;
+typedef struct { int x, y; s16 mv[2][2]; s8 refi[2]; s8 pad_[2]; } hip_mc_job;
+static int (*hip_mc_cu_host)(const hip_refpic *, int, int, int, int, int, int, int, int, const hip_mc_job *, int, int, int, int, int, const void *, const void *, pel *, pel *, pel *);
+static unsigned long long mc_calls;
+
+static void shim_mc(XEVE_CTX *ctx, XEVE_CORE *core, int x, int y, int w, int h, s8 refi[REFP_NUM], s16 (*mv)[MV_D], XEVE_REFP (*refp)[REFP_NUM],
+                    pel pred[REFP_NUM][N_C][MAX_CU_DIM], int poc_c, int apply_dmvr, s16 dmvr_mv[MAX_CU_CNT_IN_LCU][REFP_NUM][MV_D])
+{
+    hip_refpic tab[2 * XEVE_MAX_NUM_REF_PICS];
+    hip_mc_job j;
+    const int n0 = ctx->rpm.num_refp[REFP_0], n1 = ctx->rpm.num_refp[REFP_1], nmax = n0 > n1 ? n0 : n1;
+    XEVE_PIC *any = NULL;
+    memset(tab, 0, sizeof(tab));
+    for(int r = 0; r < nmax; r++)
+        for(int l = 0; l < REFP_NUM; l++) {
+            XEVE_PIC *p = r < ctx->rpm.num_refp[l] ? refp[r][l].pic : NULL;
+            if(!p) continue;
+            tab[r * 2 + l].y = p->y, tab[r * 2 + l].u = p->u, tab[r * 2 + l].v = p->v, tab[r * 2 + l].poc = p->poc;
+            any = p;
+        }
+    j.x = x, j.y = y, j.refi[0] = refi[REFP_0], j.refi[1] = refi[REFP_1], j.pad_[0] = j.pad_[1] = 0;
+    for(int l = 0; l < REFP_NUM; l++) j.mv[l][0] = mv[l][MV_X], j.mv[l][1] = mv[l][MV_Y];
+    if(hip_mc_cu_host(tab, n0, n1, any->s_l, any->s_c, any->pad_l, any->pad_c, ctx->w, ctx->h, &j, w, h, ctx->sps.bit_depth_luma_minus8 + 8,
+                      ctx->sps.bit_depth_chroma_minus8 + 8, ctx->sps.chroma_format_idc, xeve_tbl_mc_l_coeff, xeve_tbl_mc_c_coeff, pred[0][Y_C], pred[0][U_C],
+                      pred[0][V_C]) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] mc: %s\n", hip_err());
+        abort();
+    }
+    mc_calls++;
 }
 
 /* XEVE_HIP_SHIM_ME=1: the per-list motion search runs on the GPU -- pi->fn_me (pinter_me_epzs, xeve_pinter.c:699-869,2104) is routed to
@@ -204,6 +238,7 @@ static void report(void)
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
     if(tq_calls) fprintf(stderr, "[xeve_hip_shim] transform blocks quantised (RDOQ) on the GPU: %llu, dequantised + inverse transformed: %llu\n", tq_calls, itdq_calls);
+    if(mc_calls) fprintf(stderr, "[xeve_hip_shim] CU predictions (xeve_mc) made on the GPU: %llu\n", mc_calls);
     if(me_calls) fprintf(stderr, "[xeve_hip_shim] motion searches (pinter_me_epzs) served by the GPU: %llu\n", me_calls);
     if(df_calls || pad_calls) fprintf(stderr, "[xeve_hip_shim] pictures deblocked on the GPU: %llu, padded on the GPU: %llu\n", df_calls, pad_calls);
 }
@@ -244,6 +279,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_tq_nnz_host || !hip_itdq_host) { fprintf(stderr, "[xeve_hip_shim] tq / itdq entry points missing\n"); abort(); }
         ctx->fn_tq = shim_tq, ctx->fn_itdp = shim_itdq;
         fprintf(stderr, "[xeve_hip_shim] transform + RDOQ and dequantisation + inverse transform routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_MC") && atoi(getenv("XEVE_HIP_SHIM_MC"))) {
+        hip_mc_cu_host = dlsym(h, "xeve_hip_mc_cu_host"), hip_err = err;
+        if(!hip_mc_cu_host) { fprintf(stderr, "[xeve_hip_shim] mc entry point missing\n"); abort(); }
+        for(int i = 0; i < ctx->param.threads; i++) ctx->pinter[i].fn_mc = shim_mc;
+        fprintf(stderr, "[xeve_hip_shim] CU motion compensation routed to the GPU\n");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

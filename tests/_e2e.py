@@ -26,7 +26,7 @@ def make_yuv(path, w, h, frames, seed):
         f.write(bytes(random.getrandbits(8) for _ in range(w * h * 3 // 2 * frames)))
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -34,6 +34,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
     if hip:
         env["LD_PRELOAD"] = SHIM
         env["XEVE_HIP_LIB"] = HIP_LIB
+        if mc:
+            env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:
             env["XEVE_HIP_SHIM_ECO"] = "1"  # also ctx->fn_eco_coef while the encoder counts bits (the RDO's rate term)
         if tq:

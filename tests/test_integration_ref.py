@@ -131,12 +131,26 @@ def test_bitstream_identical_with_cabac_bit_counting_on_the_gpu(tmp_path, name):
 @needs_ref
 @pytest.mark.gpu
 def test_bitstream_identical_with_everything_on_the_gpu(tmp_path):
-    """all routes at once: dispatch tables + recon, motion search, transform / RDOQ / inverse, CABAC bit counting, loop filter, padding"""
+    """all routes at once: dispatch tables + recon, motion search, CU prediction, transform / RDOQ / inverse, CABAC bit counting, loop filter, padding"""
     name = "tiny_ra_medium"
     w, h, n, seed, extra = CASES[name]
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
-    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, df=True, me=True, tq=True, eco=True)
-    for needle in ("HIP dispatch tables installed", "motion search routed", "transform + RDOQ", "CABAC bit counting", "loop filter and picture padding"):
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, df=True, me=True, tq=True, eco=True, mc=True)
+    for needle in ("HIP dispatch tables installed", "motion search routed", "CU motion compensation routed", "transform + RDOQ", "CABAC bit counting", "loop filter and picture padding"):
         assert needle in err, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium"])
+def test_bitstream_identical_with_cu_prediction_on_the_gpu(tmp_path, name):
+    """pi->fn_mc (pinter_mc -> xeve_mc): clip, per-list interpolation of Y / U / V, identical-motion shortcut and bi-prediction average as ONE call"""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, mc=True)
+    m = re.search(r"CU predictions \(xeve_mc\) made on the GPU: (\d+)", err)
+    assert m and int(m.group(1)) > 500, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with xeve_mc on the GPU"

@@ -524,3 +524,66 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+
+// ---- host-memory form of one xeve_mc call (the table layer's style): what pi->fn_mc (pinter_mc, xeve_pinter.c:2058-2085) can be pointed at ------
+// refp: table [refi * 2 + list] of HOST plane pointers (sample (0, 0)); the planes extend pad_l / pad_c samples around the picture.  Only the
+// (at most two) pictures the job uses are staged.
+extern "C" int xeve_hip_mc_cu_host(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pad_l, int pad_c, int pic_w, int pic_h,
+                                   const xeve_hip_cu_mc_job *job, int w, int h, int bit_depth_luma, int bit_depth_chroma, int chroma_format_idc,
+                                   const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], pel *pred_y, pel *pred_u, pel *pred_v)
+{
+    XH_ENTER();
+    XH_REQUIRE(refp && job && pred_y && num_refp0 >= 0 && num_refp0 <= XH_MAX_REF && num_refp1 >= 0 && num_refp1 <= XH_MAX_REF);
+    const int idc = chroma_format_idc, ws = idc <= 2, hs = idc <= 1, nmax = num_refp0 > num_refp1 ? num_refp0 : num_refp1;
+    const size_t el = (size_t)s_l * (pic_h + 2 * pad_l), ec = idc ? (size_t)s_c * ((pic_h >> hs) + 2 * pad_c) : 0;
+    const size_t ol = (size_t)pad_l * s_l + pad_l, oc = (size_t)pad_c * s_c + pad_c;
+    const size_t n0 = (size_t)w * h, n1 = idc ? n0 >> (ws + hs) : 0;
+    xeve_hip_refpic tab[2 * XH_MAX_REF];
+    pel *staged[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    memset(tab, 0, sizeof(tab));
+    int rc = XEVE_HIP_OK;
+    for(int r = 0; r < nmax; r++)
+        for(int l = 0; l < 2; l++) tab[r * 2 + l].poc = refp[r * 2 + l].poc;
+    for(int l = 0; l < 2 && rc == XEVE_HIP_OK; l++) {
+        const int ri = job->refi[l];
+        if(ri < 0) continue;
+        XH_REQUIRE(ri < (l ? num_refp1 : num_refp0));
+        const xeve_hip_refpic &src = refp[ri * 2 + l];
+        const pel *hp[3] = {src.y, src.u, src.v};
+        for(int c = 0; c < (idc ? 3 : 1) && rc == XEVE_HIP_OK; c++) {
+            const size_t e = c ? ec : el, o = c ? oc : ol;
+            if(hipMalloc((void **)&staged[l][c], e * sizeof(pel)) != hipSuccess || hipMemcpy(staged[l][c], hp[c] - o, e * sizeof(pel), hipMemcpyHostToDevice) != hipSuccess) {
+                xh_set_error("xeve_hip_mc_cu_host: staging a reference plane failed");
+                rc = XEVE_HIP_ERR_DEVICE;
+            }
+        }
+        // every picture a list holds must be addressable for the per-picture launches; unused ones alias the staged one (their jobs are switched off)
+        for(int r = 0; r < (l ? num_refp1 : num_refp0); r++)
+            tab[r * 2 + l].y = staged[l][0] + ol, tab[r * 2 + l].u = idc ? staged[l][1] + oc : nullptr, tab[r * 2 + l].v = idc ? staged[l][2] + oc : nullptr;
+    }
+    // a list the job does not use still needs valid pointers for its (switched-off) launches: borrow the other list's planes
+    for(int l = 0; l < 2; l++)
+        if(job->refi[l] < 0)
+            for(int r = 0; r < (l ? num_refp1 : num_refp0); r++) tab[r * 2 + l].y = tab[(job->refi[1 - l]) * 2 + (1 - l)].y, tab[r * 2 + l].u = tab[(job->refi[1 - l]) * 2 + (1 - l)].u, tab[r * 2 + l].v = tab[(job->refi[1 - l]) * 2 + (1 - l)].v;
+    const size_t wsb = xeve_hip_mc_cu_workspace(1, w, h, num_refp0, num_refp1), o_pred = 256, o_ws = (o_pred + (n0 + 2 * n1) * sizeof(pel) + 255) & ~(size_t)255;
+    char *d = nullptr;
+    if(rc == XEVE_HIP_OK && (hipMalloc((void **)&d, o_ws + wsb) != hipSuccess || hipMemcpy(d, job, sizeof(*job), hipMemcpyHostToDevice) != hipSuccess)) {
+        xh_set_error("xeve_hip_mc_cu_host: staging failed");
+        rc = XEVE_HIP_ERR_DEVICE;
+    }
+    pel *dp = (pel *)(d + o_pred);
+    if(rc == XEVE_HIP_OK)
+        rc = xeve_hip_mc_cu_jobs(tab, num_refp0, num_refp1, s_l, s_c, pic_w, pic_h, (const xeve_hip_cu_mc_job *)d, 1, w, h, bit_depth_luma, bit_depth_chroma, idc, coef_l,
+                                 coef_c, dp, dp + n0, dp + n0 + n1, d + o_ws, wsb, nullptr);
+    if(rc == XEVE_HIP_OK) {
+        if(hipMemcpy(pred_y, dp, n0 * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE;
+        if(idc && (hipMemcpy(pred_u, dp + n0, n1 * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(pred_v, dp + n0 + n1, n1 * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess))
+            rc = XEVE_HIP_ERR_DEVICE;
+        if(rc != XEVE_HIP_OK) xh_set_error("xeve_hip_mc_cu_host: copy back failed");
+    }
+    (void)hipFree(d);
+    for(int l = 0; l < 2; l++)
+        for(int c = 0; c < 3; c++) (void)hipFree(staged[l][c]);
+    return rc;
+}

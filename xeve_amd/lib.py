@@ -146,6 +146,7 @@ FUNCTIONS = {
     "xeve_hip_tq_nnz_host": (c_int, [c_void_p, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "xeve_hip_itdq_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "xeve_hip_eco_coef_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int]),
+    "xeve_hip_mc_cu_host": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p] + [c_int] * 5 + [c_void_p] * 5),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 TABLES = {
