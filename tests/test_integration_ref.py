@@ -130,9 +130,10 @@ def test_bitstream_identical_with_cabac_bit_counting_on_the_gpu(tmp_path, name):
 
 @needs_ref
 @pytest.mark.gpu
-def test_bitstream_identical_with_everything_on_the_gpu(tmp_path):
-    """all routes at once: dispatch tables + recon, motion search, CU prediction, transform / RDOQ / inverse, CABAC bit counting, loop filter, padding"""
-    name = "tiny_ra_medium"
+@pytest.mark.parametrize("name", ["tiny_ra_medium", "tiny_ldb_fast_2threads"])
+def test_bitstream_identical_with_everything_on_the_gpu(tmp_path, name):
+    """all routes at once: dispatch tables + recon, motion search, CU prediction, transform / RDOQ / inverse, CABAC bit counting, loop filter, padding
+    (the two-thread clip drives every host-memory entry point from two CTU-row workers concurrently)"""
     w, h, n, seed, extra = CASES[name]
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
