@@ -288,8 +288,11 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
                                                 unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout)
 {
     __shared__ uint16_t s_ctx[NCTX][64];
-    __shared__ uint8_t  s_q[QMAX][64];
-    __shared__ unsigned s_ring[RING][64];
+    // the header queue is drained before the first event reaches the ring: the two share their LDS (one wave per workgroup, so the
+    // order within the wave is the only order there is)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[QMAX * 64 > RING * 64 * 4 ? QMAX * 64 : RING * 64 * 4];
+    uint8_t(*s_q)[64]     = reinterpret_cast<uint8_t(*)[64]>(s_raw);
+    unsigned(*s_ring)[64] = reinterpret_cast<unsigned(*)[64]>(s_raw);
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
@@ -353,23 +356,30 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
                 // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag.
                 // Written without branches on purpose: 64 lanes are in 64 different phases, and any `if` some lane takes is paid by all.
                 const unsigned cur = s_ring[e & (RING - 1)][lane];
-                const unsigned run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1;
-                const bool     at_end = (cur >> 28) & 1;
-                const unsigned kn = phase == 0 ? run : phase == 2 ? lev1 : k - 1;
-                const unsigned bin = phase == 4 ? sign : phase == 5 ? (unsigned)(numsig == 0) : (unsigned)(kn != 0);
-                const int      ci = phase == 5 ? XEVE_HIP_CTX_LAST + ch : (phase >= 2 ? XEVE_HIP_CTX_LEVEL : XEVE_HIP_CTX_RUN) + t0 + (phase & 1);
-                const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], bin, phase == 4);
+                const unsigned run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1, at_end = (cur >> 28) & 1;
+                // phase-dependent values by mask arithmetic and packed tables (a ternary chain over `phase` comes back from the compiler as a
+                // ladder of exec-mask branches)
+                const unsigned ph = (unsigned)phase;
+                const unsigned m0 = 0u - (unsigned)(ph == 0), m2 = 0u - (unsigned)(ph == 2), m4 = 0u - (unsigned)(ph == 4), m5 = 0u - (unsigned)(ph == 5);
+                const unsigned lt4 = 0u - (unsigned)(ph < 4);
+                const unsigned kn = (run & m0) | (lev1 & m2) | ((k - 1) & ~(m0 | m2));
+                const unsigned bin = (sign & m4) | ((unsigned)(numsig == 0) & m5) | ((unsigned)(kn != 0) & lt4);
+                // context index: RUN, RUN + 1, LEVEL, LEVEL + 1, (unused), LAST -- plus t0 (phases 0..3) or the component (phase 5)
+                const unsigned base = (unsigned)((0x2A2C2D2C1312ull >> (ph * 8)) & 0xFF);
+                const int      ci = (int)(base + (((unsigned)t0) & ~m5) + (((unsigned)ch) & m5));
+                const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], bin, ph == 4);
                 s_ctx[ci][lane] = (uint16_t)m;
-                const bool adv = phase == 5 || (phase == 4 && at_end); // no last flag at scan_pos == num_coeff - 1 (xeve_eco.c:744-746)
-                const int  nphase = phase < 4 ? (phase | 1) + (kn == 0) : (phase == 4 && !at_end ? 5 : 0);
-                numsig -= phase == 4;
-                e += adv;
-                const bool newc = adv && (e == b1 || e == b2);
+                const unsigned adv = (m5 | (m4 & (0u - at_end))) & 1u; // no last flag at scan_pos == num_coeff - 1 (xeve_eco.c:744-746)
+                const int  nphase = (int)((((ph | 1) + (unsigned)(kn == 0)) & lt4) | (5u & m4 & ~(0u - at_end)));
+                numsig -= (int)(m4 & 1u);
+                e += (int)adv;
+                const unsigned newc = (0u - adv) & (0u - (unsigned)(e == b1 || e == b2));
                 ch = e >= b1;
-                numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
+                numsig = (int)(((unsigned)(e >= b2 ? J.nnz[2] : J.nnz[1]) & newc) | ((unsigned)numsig & ~newc));
                 if(P.cm_init == 1) { // the context pair follows the previous level: min(prev_level - 1, 5), 5 at the start of a block
-                    const unsigned plev = newc ? 5 : (lev1 < 5 ? lev1 : 5);
-                    t0 = adv ? (int)(plev << 1) + ch * 12 : t0;
+                    const unsigned plev = (5u & newc) | ((lev1 < 5 ? lev1 : 5u) & ~newc);
+                    const unsigned am = 0u - adv;
+                    t0 = (int)((((plev << 1) + (unsigned)ch * 12u) & am) | ((unsigned)t0 & ~am));
                 }
                 else t0 = ch * 2;
                 k = kn, phase = nphase;
