@@ -291,9 +291,9 @@ int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xev
 
 /* The whole per-list search of one block: pinter_me_epzs (src_base/xeve_pinter.c:699-869) for me_complexity == 1 (no
  * raster search) and me_level > ME_LEV_IPEL -- first diamond search from the MVP (or, bi == 1, from mv_start), refinement
- * diamond searches from the running best while beststep > 0, then the sub-pel pattern search.  All bookkeeping between
- * the searches runs in device kernels; the host only reads one "jobs still refining" counter per iteration, so this call
- * SYNCHRONISES `stream`.  results[j].mv / .cost are what pinter_me_epzs returns; .best_mv_bits is what the searches leave in
+ * diamond searches from the running best while beststep > 0, then the sub-pel pattern search.  The integer stage is ONE
+ * kernel (a wave per block loops over its searches, the original block in registers throughout); the call is asynchronous
+ * on `stream` like the rest of the batched API.  results[j].mv / .cost are what pinter_me_epzs returns; .best_mv_bits is what the searches leave in
  * pi->mot_bits[lidx] (0: they leave it untouched; xeve_pinter.c:546-548,690-692); .beststep is 0. */
 typedef struct xeve_hip_epzs_job {
     int32_t x, y;        /* block position (integer pel) */

@@ -20,30 +20,29 @@ __device__ __constant__ int8_t c_dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1,
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// the original block of a job (org_bi for bi-prediction refinement: 2*org - pred, may be negative): loaded once, kept in registers
 template <int S, bool BI>
-__global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi,
-                                                    const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job *__restrict__ jobs,
-                                                    int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out)
+__device__ __forceinline__ void me_load_org(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, int x, int y, int org_off, int lane,
+                                            u32x4 (&org)[MGeo<S>::NP])
 {
     using G = MGeo<S>;
-    const int lane = threadIdx.x & 63;
-    const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if(j >= njobs) return;
-    const xeve_hip_me_job jb = jobs[j];
-    if(jb.range[0] > jb.range[2]) return; // empty range = job parked by the EPZS driver (its result slot is left untouched)
-    const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
-
-    // the original block (org_bi for bi-prediction refinement: 2*org - pred, may be negative) stays in registers
-    u32x4 org[G::NP];
-    {
-        const pel *o  = BI ? org_bi + jb.org_off : org0 + (long)jb.y * s_org + jb.x;
-        const int  so = BI ? S : s_org;
+    const int gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
+    const pel *o  = BI ? org_bi + org_off : org0 + (long)y * s_org + x;
+    const int  so = BI ? S : s_org;
 #pragma unroll
-        for(int p = 0; p < G::NP; p++) {
-            org[p] = xh_ld8(o + (row0 + p * G::RPP) * so + col);
-            if(BI) org[p] ^= 0x80008000u; // bias once: v_sad_u16 is unsigned
-        }
+    for(int p = 0; p < G::NP; p++) {
+        org[p] = xh_ld8(o + (row0 + p * G::RPP) * so + col);
+        if(BI) org[p] ^= 0x80008000u; // bias once: v_sad_u16 is unsigned
     }
+}
+
+// one complete me_ipel_diamond by the calling wave; the result is wave-uniform
+template <int S, bool BI>
+__device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo<S>::NP], const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job &jb, int shift,
+                                                         const xeve_hip_me_params &P, int lane)
+{
+    using G = MGeo<S>;
+    const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
     int r0 = jb.range[0], r1 = jb.range[1], r2 = jb.range[2], r3 = jb.range[3];
     int bx = clip3(P.min_clip[0], P.max_clip[0], jb.mvi[0] >> 2), by = clip3(P.min_clip[1], P.max_clip[1], jb.mvi[1] >> 2);
     const int ix = bx, iy = by;
@@ -144,12 +143,26 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
         step <<= 1;
         if(step > P.max_search_range) break;
     }
-    if(lane == 0) {
-        xeve_hip_me_result res;
-        res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
-        res.cost = (uint32_t)(best_key >> 32), res.beststep = beststep, res.best_mv_bits = best_bits;
-        out[j] = res;
-    }
+    xeve_hip_me_result res;
+    res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
+    res.cost = (uint32_t)(best_key >> 32), res.beststep = beststep, res.best_mv_bits = best_bits;
+    return res;
+}
+
+template <int S, bool BI>
+__global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi,
+                                                    const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job *__restrict__ jobs,
+                                                    int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(j >= njobs) return;
+    const xeve_hip_me_job jb = jobs[j];
+    if(jb.range[0] > jb.range[2]) return; // empty range = parked job (its result slot is left untouched)
+    u32x4 org[MGeo<S>::NP];
+    me_load_org<S, BI>(org0, s_org, org_bi, jb.x, jb.y, jb.org_off, lane, org);
+    const xeve_hip_me_result res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane);
+    if(lane == 0) out[j] = res;
 }
 
 extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref,
@@ -182,7 +195,7 @@ extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const p
 
 
 // =========================================================================================================
-// pinter_me_epzs per job (xeve_hip_me_epzs_jobs): the reference's host loop between the searches, as device kernels
+// pinter_me_epzs per job (xeve_hip_me_epzs_jobs)
 // =========================================================================================================
 struct EpzsState {
     uint32_t cost;
@@ -198,54 +211,45 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
     range[2] = (int16_t)clip3(P.min_clip[0], P.max_clip[0], cx + sr), range[3] = (int16_t)clip3(P.min_clip[1], P.max_clip[1], cy + sr);
 }
 
-__global__ void k_epzs_init(const xeve_hip_epzs_job *__restrict__ jobs, int n, xeve_hip_me_params P, xeve_hip_me_job *__restrict__ mj,
-                            EpzsState *__restrict__ st)
+// The whole integer stage of pinter_me_epzs by ONE WAVE PER JOB: first search, then refinement searches from the running best while the
+// reference's rule asks for one (xeve_pinter.c:757-822) without leaving the kernel: no
+// launch, no host round trip between the searches, the original block stays in registers across them.
+template <int S, bool BI>
+__global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
+                                                 const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P, EpzsState *__restrict__ st)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if(j >= njobs) return;
     const xeve_hip_epzs_job e = jobs[j];
     const int sx = P.bi == 1 ? e.mv_start[0] : e.mvp[0], sy = P.bi == 1 ? e.mv_start[1] : e.mvp[1];
     xeve_hip_me_job m;
     m.x = e.x, m.y = e.y, m.org_off = e.org_off, m.beststep_in = 0;
     m.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), m.gmvp[1] = (int16_t)(e.mvp[1] + (e.y << 2));
     m.mvi[0] = (int16_t)(sx + (e.x << 2)), m.mvi[1] = (int16_t)(sy + (e.y << 2));
-    // the first call clips the search centre (xeve_pinter.c:738-741)
-    epzs_range(P, clip3(P.min_clip[0], P.max_clip[0], e.x + (sx >> 2)), clip3(P.min_clip[1], P.max_clip[1], e.y + (sy >> 2)), m.range);
-    mj[j] = m;
+    epzs_range(P, clip3(P.min_clip[0], P.max_clip[0], e.x + (sx >> 2)), clip3(P.min_clip[1], P.max_clip[1], e.y + (sy >> 2)), m.range); // clipped centre (:738-741)
     EpzsState s;
     s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0, s.mot_bits = 0;
-    st[j] = s;
-}
-
-// after a diamond launch: fold its result into the running best, then either park the job or set up the next
-// refinement search from the new best (xeve_pinter.c:757-822)
-__global__ void k_epzs_update(const xeve_hip_epzs_job *__restrict__ jobs, int n, xeve_hip_me_params P, const xeve_hip_me_result *__restrict__ res,
-                              xeve_hip_me_job *__restrict__ mj, EpzsState *__restrict__ st, int *__restrict__ active)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= n) return;
-    xeve_hip_me_job m = mj[j];
-    if(m.range[0] > m.range[2]) return; // was parked
-    const xeve_hip_epzs_job e = jobs[j];
-    const xeve_hip_me_result r = res[j];
-    EpzsState s = st[j];
-    s.tmpstep = r.beststep, s.searches++;
-    if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect (xeve_pinter.c:546-548)
-    int beststep = 0;
-    if(r.cost < s.cost) {
-        s.cost = r.cost, s.mv[0] = r.mv[0], s.mv[1] = r.mv[1];
-        const int dx = e.mvp[0] - s.mv[0], dy = e.mvp[1] - s.mv[1];
-        beststep = ((dx < 0 ? -dx : dx) < 2 && (dy < 0 ? -dy : dy) < 2) ? 0 : s.tmpstep;
-    }
-    st[j] = s;
-    if(P.bi != 1 && beststep > 0) { // REFINE_SEARCH_THD 0; the refinement centre is NOT clipped (xeve_pinter.c:785-788)
-        epzs_range(P, e.x + (s.mv[0] >> 2), e.y + (s.mv[1] >> 2), m.range);
+    u32x4 org[MGeo<S>::NP];
+    me_load_org<S, BI>(org0, s_org, org_bi, e.x, e.y, e.org_off, lane, org);
+    xeve_hip_me_params Q = P;
+    for(int it = 0; it < 64; it++) { // (the reference's loop ends when a search no longer improves; 64 is a safety bound)
+        Q.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
+        const xeve_hip_me_result r = me_diamond<S, BI>(org, ref0, s_ref, m, shift, Q, lane);
+        s.tmpstep = r.beststep, s.searches++;
+        if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect on pi->mot_bits (:546-548)
+        int beststep = 0;
+        if(r.cost < s.cost) {
+            s.cost = r.cost, s.mv[0] = r.mv[0], s.mv[1] = r.mv[1];
+            const int dx = e.mvp[0] - s.mv[0], dy = e.mvp[1] - s.mv[1];
+            beststep = ((dx < 0 ? -dx : dx) < 2 && (dy < 0 ? -dy : dy) < 2) ? 0 : s.tmpstep;
+        }
+        if(P.bi == 1 || beststep <= 0) break;
+        epzs_range(P, e.x + (s.mv[0] >> 2), e.y + (s.mv[1] >> 2), m.range); // the refinement centre is NOT clipped (:785-788)
         m.mvi[0] = (int16_t)(s.mv[0] + (e.x << 2)), m.mvi[1] = (int16_t)(s.mv[1] + (e.y << 2));
         m.beststep_in = s.tmpstep;
-        atomicAdd(active, 1);
     }
-    else m.range[0] = 1, m.range[2] = 0; // park
-    mj[j] = m;
+    if(lane == 0) st[j] = s;
 }
 
 __global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj)
@@ -276,8 +280,8 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t xeve_hip_me_epzs_workspace(int njobs)
 {
     const size_t n = njobs > 0 ? njobs : 0;
-    return al256(n * sizeof(xeve_hip_me_job)) + 2 * al256(n * sizeof(xeve_hip_me_result)) + al256(n * sizeof(EpzsState)) +
-           al256(n * sizeof(xeve_hip_spel_job)) + al256(xeve_hip_me_spel_workspace(njobs)) + 256;
+    return al256(n * sizeof(xeve_hip_me_result)) + al256(n * sizeof(EpzsState)) + al256(n * sizeof(xeve_hip_spel_job)) +
+           al256(xeve_hip_me_spel_workspace(njobs)) + 256;
 }
 
 extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs,
@@ -289,32 +293,31 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
     XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
     XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
     XH_REQUIRE(params->me.bi == 0 || params->me.bi == 1);
+    XH_REQUIRE(log2w == log2h && log2w >= 3 && log2w <= 6 && bit_depth >= 8 && bit_depth <= 14 && (params->me.bi == 0 || org_bi != nullptr));
     if(njobs == 0) return XEVE_HIP_OK;
     hipStream_t st = (hipStream_t)stream;
     char *w = static_cast<char *>(workspace);
     const size_t n = njobs;
-    xeve_hip_me_job    *mj   = reinterpret_cast<xeve_hip_me_job *>(w);      w += al256(n * sizeof(xeve_hip_me_job));
-    xeve_hip_me_result *mres = reinterpret_cast<xeve_hip_me_result *>(w);   w += al256(n * sizeof(xeve_hip_me_result));
     xeve_hip_me_result *sres = reinterpret_cast<xeve_hip_me_result *>(w);   w += al256(n * sizeof(xeve_hip_me_result));
     EpzsState          *state = reinterpret_cast<EpzsState *>(w);           w += al256(n * sizeof(EpzsState));
     xeve_hip_spel_job  *sj   = reinterpret_cast<xeve_hip_spel_job *>(w);    w += al256(n * sizeof(xeve_hip_spel_job));
-    void               *sws  = w;                                            w += al256(xeve_hip_me_spel_workspace(njobs));
-    int                *active = reinterpret_cast<int *>(w);
+    void               *sws  = w;
     const dim3 g((njobs + 255) / 256);
     xeve_hip_me_params P = params->me;
-    k_epzs_init<<<g, 256, 0, st>>>(jobs, njobs, P, mj, state);
-    XH_HIP(hipGetLastError());
-    for(int it = 0; it < 64; it++) { // the reference's loop ends when no block improves any more; 64 is a safety bound
-        P.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
-        int rc = xeve_hip_me_ipel_diamond_jobs(org0, s_org, org_bi, ref0, s_ref, mj, njobs, log2w, log2h, bit_depth, &P, mres, st);
-        if(rc != XEVE_HIP_OK) return rc;
-        XH_HIP(hipMemsetAsync(active, 0, sizeof(int), st));
-        k_epzs_update<<<g, 256, 0, st>>>(jobs, njobs, P, mres, mj, state, active);
+    {
+        const dim3 grid((njobs + 3) / 4);
+        const int  shift = bit_depth - 8;
+#define EPZS_LAUNCH(S)                                                                                                     \
+    do {                                                                                                                   \
+        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, state);   \
+        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, state);      \
+    } while(0)
+        if(log2w == 3) EPZS_LAUNCH(8);
+        else if(log2w == 4) EPZS_LAUNCH(16);
+        else if(log2w == 5) EPZS_LAUNCH(32);
+        else EPZS_LAUNCH(64);
+#undef EPZS_LAUNCH
         XH_HIP(hipGetLastError());
-        int h_active = 0;
-        XH_HIP(hipMemcpyAsync(&h_active, active, sizeof(int), hipMemcpyDeviceToHost, st));
-        XH_HIP(hipStreamSynchronize(st));
-        if(h_active == 0) break;
     }
     k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj);
     XH_HIP(hipGetLastError());
@@ -326,7 +329,6 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
     if(rc != XEVE_HIP_OK) return rc;
     k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
     XH_HIP(hipGetLastError());
-    XH_HIP(hipStreamSynchronize(st));
     return XEVE_HIP_OK;
 }
 
