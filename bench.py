@@ -149,7 +149,8 @@ def main():
             return {"ms_per_picture": round(e0.elapsed_time(e1), 3), "jobs_per_picture": int(sum(b.numel() for b in bits.values())),
                     "coded_bits_per_picture": int(sum(int(b[:, 1].sum().item()) for b in bits.values()))}
         rate_term = {"in_timed_region": False, "iid": rate_of(wl),
-                     "note": "xeve_hip_cu_bits_jobs over every CU of all four levels, 8 bit-count jobs per CU as pinter_residue_rdo issues them"}
+                     "note": "xeve_hip_cu_bits_jobs over every CU of all four levels, 8 bit-count jobs per CU as pinter_residue_rdo issues them; "
+                             "one stream per level (the large-CU levels are latency-bound and hide under the small-CU ones)"}
         ws = HotPathPass(a.width, a.height, dev, seed=5, content="structured")
         ws.run(only="D")
         rate_term["structured"] = rate_of(ws)

@@ -259,18 +259,27 @@ class HotPathPass:
         return r
 
     def rate(self):
-        """phase F for every level; returns {S: int32 tensor [n, RATE_JOBS] of bit counts}"""
+        """phase F for every level; returns {S: int32 tensor [n, RATE_JOBS] of bit counts}.  One stream per level: the large-CU levels are
+        latency-bound (few, long bit strings) and hide under the throughput-bound small-CU ones."""
         out = {}
-        for S in self.sizes:
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+        for S in sorted(self.sizes, reverse=True):
             lv = self.lv[S]
             if "rate" not in lv:
                 lv["rate"] = self._rate_setup(lv)
             r = lv["rate"]
-            # the coefficient counts come from the quantiser on the device: write them into the job records there
-            nnz3 = torch.stack(lv["nnz"], dim=1)  # [n, 3]
-            r["jobs"].view(torch.int32).view(lv["n"], self.RATE_JOBS, 11)[:, :, 3:6] = nnz3[:, None, :] * r["keep"][None, :, :]
-            D.cu_bits_jobs(lv["coef_flat"], r["state"], r["jobs"], r["params"], want_state=False, workspace=r["ws"], bits=r["bits"])
+            st = self._side[S]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                # the coefficient counts come from the quantiser on the device: write them into the job records there
+                nnz3 = torch.stack(lv["nnz"], dim=1)  # [n, 3]
+                r["jobs"].view(torch.int32).view(lv["n"], self.RATE_JOBS, 11)[:, :, 3:6] = nnz3[:, None, :] * r["keep"][None, :, :]
+                D.cu_bits_jobs(lv["coef_flat"], r["state"], r["jobs"], r["params"], want_state=False, workspace=r["ws"], bits=r["bits"])
             out[S] = r["bits"].view(lv["n"], self.RATE_JOBS)
+        for S in self.sizes:
+            main.wait_stream(self._side[S])
         return out
 
     # ------------------------------------------------------------------------------------------------------
@@ -313,13 +322,23 @@ class HotPathPass:
 
     def rdo(self):
         """phase G for every level; returns {S: (results uint8 [n, 72], coef, best)}"""
+        # The levels are independent and the large-CU ones are latency-bound (few, long bit strings): each level runs on its own stream so
+        # that the 64x64 and 32x32 levels' serial coder chains hide under the throughput-bound small-CU levels.
         out = {}
-        for S in self.sizes:
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+        for S in sorted(self.sizes, reverse=True):  # longest chains first
             lv = self.lv[S]
             if "rdo" not in lv:
                 lv["rdo"] = self._rdo_setup(lv)
             r = lv["rdo"]
-            out[S] = D.residue_rdo_jobs(r["org"], self.s_l, self.s_c, r["refp"], self.s_l, self.s_c, r["state"], r["params"], r["jobs"], workspace=r["ws"])
+            st = self._side[S]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out[S] = D.residue_rdo_jobs(r["org"], self.s_l, self.s_c, r["refp"], self.s_l, self.s_c, r["state"], r["params"], r["jobs"], workspace=r["ws"])
+        for S in self.sizes:
+            main.wait_stream(self._side[S])
         return out
 
     def capture(self):
