@@ -85,3 +85,53 @@ def test_hip_residue_rdo_vs_oracle(w, h, bd, nref, idc, slice_type):
             seen["kept"] += int(nz.all())
             seen["dropped"] += int(nz.any() and not nz.all())
     assert seen["zero"] and seen["kept"], seen
+
+
+def test_residue_rdo_full_size_properties():
+    """3840x2160, every CU of every level (172 020 candidates): properties that hold for any input --
+    core->nnz equals the number of non-zero levels left in the coefficient buffers (dropped components are zeroed);
+    the returned cost never exceeds the all-zero alternative's cost (distortion without residual + lambda * its bits), recomputed here from the
+    reported distortions and an independent xeve_hip_cu_bits_jobs call; two runs agree bit for bit."""
+    import torch
+
+    import xeve_amd
+    from _libs import CU_BITS_JOB_DTYPE, RDO_JOB_DTYPE
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from xeve_amd.workload import HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(3840, 2160, dev, seed=5, content="structured")
+    first = wl.rdo()
+    torch.cuda.synchronize()
+    snap = {S: (v[0].clone(), v[1].clone(), v[2].clone()) for S, v in first.items()}
+    second = wl.rdo()
+    torch.cuda.synchronize()
+    total = 0
+    for S in wl.sizes:
+        for a, b in zip(snap[S], second[S]):
+            assert torch.equal(a, b), S
+        n, n0, n1 = wl.lv[S]["n"], S * S, S * S // 4
+        res = second[S][0].cpu().numpy().reshape(-1).view(RDO_RESULT_DTYPE)
+        coef = second[S][1]
+        cnt = torch.stack([(coef[:n * n0].view(n, n0) != 0).sum(1), (coef[n * n0:n * (n0 + n1)].view(n, n1) != 0).sum(1),
+                           (coef[n * (n0 + n1):n * (n0 + 2 * n1)].view(n, n1) != 0).sum(1)], dim=1).cpu().numpy()
+        assert np.array_equal(cnt, res["nnz"]), S
+        # the all-zero alternative, counted independently
+        rd = wl.lv[S]["rdo"]
+        jobs = rd["jobs"].cpu().numpy().view(RDO_JOB_DTYPE)
+        bj = np.zeros(n, CU_BITS_JOB_DTYPE)
+        bj["mvd"], bj["refi"], bj["mvp_idx"], bj["ctx_skip"], bj["ctx_pred_mode"] = jobs["mvd"], jobs["refi"], jobs["mvp_idx"], jobs["ctx_skip"], jobs["ctx_pred_mode"]
+        p = lib.CuBitsParams()
+        p.log2_cuw = p.log2_cuh = S.bit_length() - 1
+        p.slice_type, p.chroma_format_idc = 0, 1
+        p.num_refp[0] = p.num_refp[1] = 1
+        bits, _ = D.cu_bits_jobs(torch.zeros(8, dtype=torch.int16, device=dev), rd["state"], torch.from_numpy(bj.view(np.uint8).copy()).to(dev), p, want_state=False)
+        bits = bits.cpu().numpy().astype(np.float64)
+        lam = rd["params"].lambda_[0]
+        zero_cost = res["dist"][:, 0, 0].astype(np.float64) + (res["dist"][:, 0, 1].astype(np.float64) + res["dist"][:, 0, 2].astype(np.float64)) + bits * lam
+        assert np.all(res["cost"] <= zero_cost), (S, int(np.argmax(res["cost"] - zero_cost)))
+        assert np.all(res["cost"][~res["nnz"].any(axis=1)] == zero_cost[~res["nnz"].any(axis=1)])  # all-zero winners cost exactly that
+        total += n
+    assert total == 172020

@@ -132,3 +132,43 @@ def test_hip_eco_coef_alone_vs_oracle(idc):
         got_bits, got = run_hip(p, states, jobs, coef)
         assert np.array_equal(got_bits, exp_bits), (lw, lh, np.flatnonzero(got_bits != exp_bits)[:5])
         assert got.tobytes() == exp.tobytes(), (lw, lh)
+
+
+def test_cu_bits_full_size_properties():
+    """3840x2160 i.i.d. picture, the eight rate jobs of every CU of every level (1 376 160 jobs on the quantiser's real output): the count-only
+    kernel (with its per-wave choice of loop form), the kernel that carries the complete coder state and the chain variant agree on every
+    bit count; the all-zero job never costs more than the as-quantised one."""
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from xeve_amd.workload import HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(3840, 2160, dev, seed=4)
+    wl.run(only="D")
+    fast = {S: b.clone() for S, b in wl.rate().items()}
+    torch.cuda.synchronize()
+    njobs = 0
+    for S in wl.sizes:
+        lv, r = wl.lv[S], wl.lv[S]["rate"]
+        full_bits, st = D.cu_bits_jobs(lv["coef_flat"], r["state"], r["jobs"], r["params"], want_state=True)
+        assert torch.equal(full_bits.view(lv["n"], wl.RATE_JOBS), fast[S]), S
+        L = lib.load()
+        import ctypes as C
+        chain_bits = torch.empty_like(full_bits)
+        chain_st = torch.empty_like(st)
+        lib.check(L.xeve_hip_cu_bits_jobs_chain(C.c_void_p(lv["coef_flat"].data_ptr()), lv["coef_flat"].numel(), C.c_void_p(r["state"].data_ptr()),
+                                                C.c_void_p(r["jobs"].data_ptr()), lv["n"] * wl.RATE_JOBS, C.byref(r["params"]), C.c_void_p(r["ws"].data_ptr()),
+                                                r["ws"].numel(), C.c_void_p(chain_bits.data_ptr()), C.c_void_p(chain_st.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert torch.equal(chain_bits, full_bits), S
+        # range and context models of the chain variant == those of the full state
+        a, b = st.cpu().numpy().reshape(-1).view(SBAC_DTYPE), chain_st.cpu().numpy().reshape(-1).view(SBAC_DTYPE)
+        assert np.array_equal(a["range"], b["range"]) and np.array_equal(a["ctx"], b["ctx"]), S
+        bits = fast[S].cpu().numpy()
+        assert np.all(bits[:, 0] <= bits[:, 1]), S
+        njobs += bits.size
+    assert njobs == 1376160
