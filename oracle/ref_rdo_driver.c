@@ -45,15 +45,18 @@ typedef struct { int log2_cuw, log2_cuh, pic_w, pic_h, slice_type, num_refp[2], 
 typedef struct { int x, y; s16 mv[2][2], mvd[2][2]; s8 refi[2]; u8 mvp_idx[2]; u8 dir_flag, ctx_skip, ctx_pred_mode, pad_; int sbac; } drv_rdo_job;
 typedef struct { double cost; int nnz[3], pad_; s64 dist[2][3]; } drv_rdo_result;
 
+static XEVE_CTX  *g_ctx;
+static XEVE_CORE *g_core;
+
 void refdrv_residue_rdo(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, const drv_refpic *refs, int s_l, int s_c, const drv_sbac *states,
                         const drv_rdo_params *p, const drv_rdo_job *job, drv_rdo_result *res, s16 *coef_y, s16 *coef_u, s16 *coef_v, drv_sbac *best)
 {
-    static XEVE_CTX  *ctx;
-    static XEVE_CORE *core;
     static XEVE_PIC   pic_o, pics[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
     static XEVE_REFP  refp[XEVE_MAX_NUM_REF_PICS][REFP_NUM];
     static XEVE_SH    sh;
-    if(!ctx) ctx = calloc(1, sizeof(*ctx)), core = calloc(1, sizeof(*core)), xeve_init_bits_est();
+    if(!g_ctx) g_ctx = calloc(1, sizeof(*g_ctx)), g_core = calloc(1, sizeof(*g_core)), xeve_init_bits_est();
+    XEVE_CTX  *ctx  = g_ctx;
+    XEVE_CORE *core = g_core;
     XEVE_PINTER *pi = &ctx->pinter[0];
     const int ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
     const int lw = p->log2_cuw, lh = p->log2_cuh;
@@ -108,5 +111,56 @@ void refdrv_residue_rdo(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_o
         memcpy(coef_u, pi->coef[pidx][U_C], sizeof(s16) << (lw + lh - ws - hs));
         memcpy(coef_v, pi->coef[pidx][V_C], sizeof(s16) << (lw + lh - ws - hs));
     }
+    from_ref(best, &core->s_temp_best);
+}
+
+
+/* xeve_analyze_skip (static, xeve_pinter.c:1337-1530).  The merge candidates come from the reference's own xeve_get_motion (xeve_util.c:526-573),
+ * untouched: the neighbour maps it reads (left, up, up-right unit of ctx->map_mv; the collocated unit of refp[0][list].map_mv) are loaded with the
+ * caller's four vectors per list, all neighbours available -- Baseline always pairs them with reference index 0. */
+typedef struct { int x, y; s16 mvp[2][4][2]; s8 refi_pred[2][4]; int ncand, sbac; u8 ctx_skip, pad_[3]; } drv_skip_job;
+typedef struct { double cost; s64 best_ssd; int idx0, idx1; s16 mv[2][2]; s8 refi[2]; s8 pad_[6]; } drv_skip_result;
+
+void refdrv_analyze_skip(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, const drv_refpic *refs, int s_l, int s_c, const drv_sbac *states,
+                         const drv_rdo_params *p, const drv_skip_job *job, drv_skip_result *res, pel *pred_y, pel *pred_u, pel *pred_v, drv_sbac *best)
+{
+    /* reuse the context set-up of refdrv_residue_rdo through a dummy candidate, then run the skip analysis */
+    drv_rdo_job dj;
+    drv_rdo_result dr;
+    static s16 c0[MAX_CU_DIM], c1[MAX_CU_DIM], c2[MAX_CU_DIM];
+    drv_sbac   tmp;
+    memset(&dj, 0, sizeof(dj));
+    dj.x = job->x, dj.y = job->y, dj.refi[0] = 0, dj.refi[1] = -1, dj.sbac = job->sbac, dj.ctx_skip = job->ctx_skip;
+    refdrv_residue_rdo(org_y, org_u, org_v, s_org_l, s_org_c, refs, s_l, s_c, states, p, &dj, &dr, c0, c1, c2, &tmp);
+    XEVE_CTX  *ctx  = g_ctx;
+    XEVE_CORE *core = g_core;
+    XEVE_PINTER *pi = &ctx->pinter[0];
+    const int lw = p->log2_cuw, lh = p->log2_cuh, ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
+    ctx->slice_type = p->slice_type, pi->skip_merge_cand_num = job->ncand;
+    core->cost_best = MAX_COST, core->scup = 0, core->avail_cu = 0;
+    core->ctx_flags[CNID_SKIP_FLAG] = job->ctx_skip;
+    to_ref(&core->s_curr_best[lw - 2][lh - 2], &states[job->sbac]);
+    memset(&core->s_temp_best, 0, sizeof(core->s_temp_best));
+    {
+        enum { W_SCU = 32, SCUP = W_SCU + 1 };
+        static s16 map_mv[2 * W_SCU + 32][REFP_NUM][MV_D], col_mv[REFP_NUM][2 * W_SCU][REFP_NUM][MV_D];
+        static s8  map_refi[2 * W_SCU + 32][REFP_NUM];
+        const int  cuw_scu = (1 << lw) >> MIN_CU_LOG2;
+        ctx->map_mv = map_mv, ctx->map_refi = map_refi, ctx->w_scu = W_SCU;
+        core->scup = SCUP, core->avail_cu = AVAIL_LE | AVAIL_UP | AVAIL_UP_RI;
+        for(int l = 0; l < REFP_NUM; l++) {
+            for(int d = 0; d < MV_D; d++) {
+                map_mv[SCUP - 1][l][d] = job->mvp[l][0][d], map_mv[SCUP - W_SCU][l][d] = job->mvp[l][1][d];
+                map_mv[SCUP - W_SCU + cuw_scu][l][d] = job->mvp[l][2][d], col_mv[l][SCUP][0][d] = job->mvp[l][3][d];
+            }
+            pi->refp[0][l].map_mv = col_mv[l];
+        }
+    }
+    res->cost = xeve_analyze_skip(ctx, core, job->x, job->y, lw, lh);
+    res->best_ssd = pi->best_ssd, res->idx0 = pi->mvp_idx[PRED_SKIP][REFP_0], res->idx1 = pi->mvp_idx[PRED_SKIP][REFP_1];
+    for(int l = 0; l < 2; l++) res->mv[l][0] = pi->mv[PRED_SKIP][l][MV_X], res->mv[l][1] = pi->mv[PRED_SKIP][l][MV_Y], res->refi[l] = pi->refi[PRED_SKIP][l];
+    memset(res->pad_, 0, sizeof(res->pad_));
+    memcpy(pred_y, pi->pred[PRED_SKIP][0][Y_C], sizeof(pel) << (lw + lh));
+    if(p->chroma_format_idc) memcpy(pred_u, pi->pred[PRED_SKIP][0][U_C], sizeof(pel) << (lw + lh - ws - hs)), memcpy(pred_v, pi->pred[PRED_SKIP][0][V_C], sizeof(pel) << (lw + lh - ws - hs));
     from_ref(best, &core->s_temp_best);
 }

@@ -1311,3 +1311,61 @@ void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const 
 #undef FULL_BITS
 #undef SUM_COST
 }
+
+/* ===================================================================================================================
+ * xeve_analyze_skip (src_base/xeve_pinter.c:1337-1530), rdo_dbk_switch 0
+ * =================================================================================================================== */
+void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                     const xo_rdo_params *p, const xo_skip_job *job, xo_skip_result *res, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v, xo_sbac *best)
+{
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth;
+    const int w = 1 << p->log2_cuw, h = 1 << p->log2_cuh, cw = w >> ws, ch = h >> hs, isb = p->slice_type == 0;
+    xo_pel *t[3];
+    double  cost_best = 1.7e+308;
+    for(int c = 0; c < 3; c++) t[c] = malloc(sizeof(xo_pel) * (size_t)w * h);
+    memset(res, 0, sizeof(*res));
+    res->best_ssd = (int64_t)1 << (p->log2_cuw + p->log2_cuh + 16);
+    xo_cu_bits_params bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
+    bp.chroma_format_idc = idc;
+    for(int i0 = 0; i0 < job->ncand; i0++) {
+        int dup = 0;
+        for(int k = i0 - 1; k >= 0 && !dup; k--) dup = job->mvp[0][k][0] == job->mvp[0][i0][0] && job->mvp[0][k][1] == job->mvp[0][i0][1];
+        if(dup) continue; /* encoder side pruning (:1396-1409) */
+        const int cnt = isb ? job->ncand : 1;
+        for(int i1 = 0; i1 < cnt; i1++) {
+            dup = 0;
+            for(int k = i1 - 1; k >= 0 && !dup; k--) dup = job->mvp[1][k][0] == job->mvp[1][i1][0] && job->mvp[1][k][1] == job->mvp[1][i1][1];
+            if(dup) continue;
+            xo_cu_mc_job mj;
+            memset(&mj, 0, sizeof(mj));
+            mj.x = job->x, mj.y = job->y;
+            mj.mv[0][0] = job->mvp[0][i0][0], mj.mv[0][1] = job->mvp[0][i0][1], mj.mv[1][0] = job->mvp[1][i1][0], mj.mv[1][1] = job->mvp[1][i1][1];
+            mj.refi[0] = job->refi_pred[0][i0], mj.refi[1] = isb ? job->refi_pred[1][i1] : -1;
+            if(mj.refi[0] < 0 && mj.refi[1] < 0) continue;
+            xo_mc_cu(refp, s_l, s_c, p->pic_w, p->pic_h, &mj, w, h, bd, bd, idc, t[0], t[1], t[2]);
+            int64_t cy = xo_ssd(w, h, t[0], org[0] + job->y * s_org_l + job->x, w, s_org_l, bd), cu = 0, cv = 0;
+            if(idc) {
+                const int off = (job->y >> hs) * s_org_c + (job->x >> ws);
+                cu = xo_ssd(cw, ch, t[1], org[1] + off, cw, s_org_c, bd), cv = xo_ssd(cw, ch, t[2], org[2] + off, cw, s_org_c, bd);
+            }
+            double cost = (double)cy + (p->dist_chroma_weight[0] * (double)cu) + (p->dist_chroma_weight[1] * (double)cv);
+            xo_cu_bits_job bj;
+            memset(&bj, 0, sizeof(bj));
+            bj.mode = XO_BITS_CU_SKIP, bj.mvp_idx[0] = (uint8_t)i0, bj.mvp_idx[1] = (uint8_t)i1, bj.ctx_skip = job->ctx_skip, bj.sbac = job->sbac;
+            xo_sbac run;
+            cost += (double)(int)xo_cu_bits(states, &run, &bp, &bj, (const int16_t *)t[0]) * p->lambda[0];
+            if(cost < cost_best) {
+                cost_best = cost;
+                res->idx0 = i0, res->idx1 = i1, res->best_ssd = cy + cu + cv;
+                memcpy(res->mv, mj.mv, sizeof(res->mv)), res->refi[0] = mj.refi[0], res->refi[1] = mj.refi[1];
+                memcpy(pred_y, t[0], sizeof(xo_pel) * (size_t)w * h);
+                if(idc) memcpy(pred_u, t[1], sizeof(xo_pel) * (size_t)cw * ch), memcpy(pred_v, t[2], sizeof(xo_pel) * (size_t)cw * ch);
+                *best = run;
+            }
+        }
+    }
+    res->cost = cost_best;
+    for(int c = 0; c < 3; c++) free(t[c]);
+}

@@ -294,6 +294,31 @@ void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const 
                     const xo_rdo_params *p, const xo_rdo_job *job, xo_rdo_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
                     xo_sbac *best);
 
+/* ---- xeve_analyze_skip (reference: src_base/xeve_pinter.c:1337-1530): the skip / merge analysis of one CU -------------------------- */
+/* every (idx0, idx1) pair of the two lists' merge candidates (duplicates of an earlier candidate pruned): prediction (xeve_mc), SSD of
+ * Y / U / V against the original, cost = distortion + lambda * bits of the skip syntax; the first strictly smaller cost wins.  The candidate
+ * lists are what xeve_get_motion (xeve_util.c:526-573) derived from the neighbouring CUs -- an input here.  Uses xo_rdo_params (log2_cuw/h,
+ * pic_w/h, slice_type, num_refp, chroma_format_idc, bit_depth, lambda[0], dist_chroma_weight). */
+typedef struct xo_skip_job {
+    int32_t x, y;
+    int16_t mvp[2][4][2];   /* pi->mvp[list][idx] */
+    int8_t  refi_pred[2][4]; /* pi->refi_pred[list][idx] */
+    int32_t ncand;          /* pi->skip_merge_cand_num (<= 4) */
+    int32_t sbac;           /* index of the entry coder state */
+    uint8_t ctx_skip, pad_[3];
+} xo_skip_job;
+typedef struct xo_skip_result {
+    double  cost;           /* the return value (MAX_COST 1.7e308 when no candidate is usable) */
+    int64_t best_ssd;       /* pi->best_ssd */
+    int32_t idx0, idx1;     /* pi->mvp_idx[PRED_SKIP] */
+    int16_t mv[2][2];       /* pi->mv[PRED_SKIP] */
+    int8_t  refi[2];        /* pi->refi[PRED_SKIP] */
+    int8_t  pad_[6];
+} xo_skip_result;
+/* pred_* receive pi->pred[PRED_SKIP][0] (untouched when no candidate is usable); best = core->s_temp_best (ditto) */
+void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                     const xo_rdo_params *p, const xo_skip_job *job, xo_skip_result *res, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v, xo_sbac *best);
+
 #ifdef __cplusplus
 }
 #endif

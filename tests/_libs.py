@@ -453,3 +453,29 @@ def oracle_rdo():
     L.xo_residue_rdo.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]
     return L
+
+
+# ---- xeve_analyze_skip ----------------------------------------------------------------------------------------------
+SKIP_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (2, 4, 2)), ("refi_pred", "i1", (2, 4)), ("ncand", "<i4"), ("sbac", "<i4"),
+                           ("ctx_skip", "u1"), ("pad_", "u1", (3,))])
+SKIP_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("best_ssd", "<i8"), ("idx0", "<i4"), ("idx1", "<i4"), ("mv", "<i2", (2, 2)), ("refi", "i1", (2,)),
+                              ("pad_", "i1", (6,))])
+assert SKIP_JOB_DTYPE.itemsize == 60 and SKIP_RESULT_DTYPE.itemsize == 40
+
+
+def ref_skip():
+    L = ref_rdo()
+    if L is not None and not hasattr(L, "_skip_bound"):
+        L.refdrv_analyze_skip.restype = None
+        L.refdrv_analyze_skip.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]
+        L._skip_bound = True
+    return L
+
+
+def oracle_skip():
+    L = oracle()
+    L.xo_analyze_skip.restype = None
+    L.xo_analyze_skip.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]
+    return L

@@ -56,3 +56,24 @@ def make_jobs(r, n, w, h, cuw, cuh, nref, nstates, slice_type=0):
 
 def states(r, n):
     return make_states(r, n)
+
+
+def make_skip_jobs(r, n, w, h, cuw, cuh, nstates, ncand):
+    """merge candidates as xeve_get_motion derives them in Baseline: four vectors per list, reference index 0; duplicates (pruned by the
+    reference), the (1, 1) vector of an unavailable neighbour, near and far vectors"""
+    from _libs import SKIP_JOB_DTYPE
+
+    j = np.zeros(n, SKIP_JOB_DTYPE)
+    j["x"] = r.integers(0, max(1, (w - cuw) // 4 + 1), size=n) * 4
+    j["y"] = r.integers(0, max(1, (h - cuh) // 4 + 1), size=n) * 4
+    mv = np.where(r.random((n, 2, 4, 1)) < 0.7, r.integers(-6, 7, size=(n, 2, 4, 2)), r.integers(-300, 301, size=(n, 2, 4, 2)))
+    mv[r.random((n, 2, 4)) < 0.15] = 1
+    dup = r.random((n, 2)) < 0.4
+    for l in range(2):
+        mv[dup[:, l], l, 1] = mv[dup[:, l], l, 0]
+    j["mvp"] = mv
+    j["refi_pred"] = 0
+    j["ncand"] = ncand
+    j["sbac"] = r.integers(0, nstates, size=n)
+    j["ctx_skip"] = r.integers(0, 2, size=n)
+    return j
