@@ -490,6 +490,36 @@ int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s_org_l, int
                               const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_rdo_result *results, int16_t *coef,
                               xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream);
 
+/* xeve_analyze_skip (src_base/xeve_pinter.c:1337-1530) for a batch of CUs of one size: every (idx0, idx1) pair of the merge
+ * candidate list (pi->mvp / pi->refi_pred as xeve_get_motion left them) that survives the encoder side pruning is predicted, measured
+ * (SSD Y + weighted U, V) and priced (skip flag + candidate indices through the CABAC counter from the CU's entry state); the first
+ * pair with the strictly smallest cost wins.  rdo_dbk_switch = 0.  In P slices only list 0 is walked (idx1 = 0, refi[1] = -1) and
+ * result.mv[1] is pi->mvp[REFP_1][0] as handed in. */
+typedef struct xeve_hip_skip_job {
+    int32_t x, y;
+    int16_t mvp[2][4][2];    /* pi->mvp[list][idx] */
+    int8_t  refi_pred[2][4]; /* pi->refi_pred[list][idx] */
+    int32_t ncand;           /* pi->skip_merge_cand_num (<= max_cand) */
+    int32_t sbac;            /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] in `states` */
+    uint8_t ctx_skip, pad_[3];
+} xeve_hip_skip_job;
+typedef struct xeve_hip_skip_result {
+    double  cost;            /* the return value (MAX_COST 1.7e308 when no pair is usable) */
+    int64_t best_ssd;        /* pi->best_ssd */
+    int32_t idx0, idx1;      /* pi->mvp_idx[PRED_SKIP] */
+    int16_t mv[2][2];        /* pi->mv[PRED_SKIP] */
+    int8_t  refi[2];         /* pi->refi[PRED_SKIP] */
+    int8_t  pad_[6];
+} xeve_hip_skip_result;
+/* Pointer kinds as for xeve_hip_residue_rdo_jobs.  pred_y [njobs][h*w], pred_u / pred_v [njobs][ch*cw] receive pi->pred[PRED_SKIP][0] of
+ * the winner, best[j] (may be NULL) core->s_temp_best; both are left untouched for a CU without a usable pair.  max_cand in 1..4. */
+size_t xeve_hip_analyze_skip_workspace(int njobs, const xeve_hip_rdo_params *params, int max_cand);
+int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                               const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *params, const xeve_hip_skip_job *jobs, int njobs,
+                               int max_cand, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_skip_result *results,
+                               xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, xeve_hip_sbac *best, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* One pinter_me_epzs call on HOST memory (synchronous; both luma planes staged per call): what pi->fn_me can be pointed at.
  * org0 / ref0 = sample (0, 0) of the original / reference luma plane; the reference plane has `pad` samples around the picture. */
 int xeve_hip_me_epzs_host(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref, int pad, int pic_h,

@@ -346,3 +346,187 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// =============================================================================================================================
+// xeve_analyze_skip (src_base/xeve_pinter.c:1337-1530) for a batch of CUs of one size: every (idx0, idx1) pair of the merge candidate
+// list that survives the encoder side pruning is predicted (xeve_mc), measured (SSD Y + weighted U, V) and priced (skip flag + the two
+// candidate indices through the CABAC counter, from the CU's entry state); the first pair with the strictly smallest cost wins.
+// One slot per pair (max_cand^2 in B slices, max_cand in P slices): slots run in parallel through the batched building blocks, pruned /
+// unusable slots are switched off, and one thread per CU walks its slots in the reference's loop order for the decision.
+// =============================================================================================================================
+struct SkipK {
+    int    njobs, S, mc, isb, n0, n1, ncomp, ws, hs, s_org_l, s_org_c, best_shift;
+    double lambda0, wgt[2];
+};
+
+__global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, xeve_hip_cu_mc_job *__restrict__ mc, xeve_hip_job *__restrict__ rl,
+                            xeve_hip_job *__restrict__ rc, xeve_hip_cu_bits_job *__restrict__ bj, unsigned char *__restrict__ valid)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= P.njobs * P.S) return;
+    const int j = t / P.S, s = t % P.S;
+    const int i0 = P.isb ? s / P.mc : s, i1 = P.isb ? s % P.mc : 0;
+    const xeve_hip_skip_job J = jobs[j];
+    const int cnt1 = P.isb ? J.ncand : 1;
+    bool ok = i0 < J.ncand && i1 < cnt1;
+    // encoder side pruning (:1396-1409, :1420-1433): an earlier candidate of the same list with the same vector
+    for(int k = 0; k < 3; k++) {
+        if(k < i0 && J.mvp[0][k][0] == J.mvp[0][i0][0] && J.mvp[0][k][1] == J.mvp[0][i0][1]) ok = false;
+        if(k < i1 && J.mvp[1][k][0] == J.mvp[1][i1][0] && J.mvp[1][k][1] == J.mvp[1][i1][1]) ok = false;
+    }
+    xeve_hip_cu_mc_job m;
+    m.x = J.x, m.y = J.y, m.mv[0][0] = J.mvp[0][i0][0], m.mv[0][1] = J.mvp[0][i0][1], m.mv[1][0] = J.mvp[1][i1][0], m.mv[1][1] = J.mvp[1][i1][1];
+    m.refi[0] = J.refi_pred[0][i0], m.refi[1] = P.isb ? J.refi_pred[1][i1] : -1, m.pad_[0] = m.pad_[1] = 0;
+    if(m.refi[0] < 0 && m.refi[1] < 0) ok = false; // (:1444)
+    if(!ok) m.refi[0] = m.refi[1] = -1;            // no prediction work for a slot that is not evaluated
+    mc[t] = m;
+    rl[t].off1 = J.y * P.s_org_l + J.x, rl[t].off2 = t * P.n0;
+    rc[t].off1 = (J.y >> P.hs) * P.s_org_c + (J.x >> P.ws), rc[t].off2 = t * P.n1;
+    xeve_hip_cu_bits_job b;
+    b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
+    b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0, b.refi[0] = b.refi[1] = 0;
+    b.mvp_idx[0] = (uint8_t)i0, b.mvp_idx[1] = (uint8_t)i1, b.mode = XEVE_HIP_BITS_CU_SKIP, b.dir_flag = 0, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = 0;
+    bj[t] = b;
+    valid[t] = ok;
+}
+
+// the walk over the slots in (idx0, idx1) order (:1391-1521); also the winner's bit-count job for the state pass
+__global__ void k_skip_decide(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, const xeve_hip_cu_mc_job *__restrict__ mc, const unsigned char *__restrict__ valid,
+                              const long *__restrict__ ssd_y, const long *__restrict__ ssd_u, const long *__restrict__ ssd_v, const unsigned *__restrict__ bits,
+                              const xeve_hip_cu_bits_job *__restrict__ bj, xeve_hip_skip_result *__restrict__ res, int *__restrict__ win,
+                              xeve_hip_cu_bits_job *__restrict__ bj_win)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    double cost_best = MAX_COST;
+    int    sb = -1;
+    long   ssd_best = 1L << P.best_shift;
+    for(int s = 0; s < P.S; s++) {
+        const int t = j * P.S + s;
+        if(!valid[t]) continue;
+        const long cy = ssd_y[t], cu = P.ncomp > 1 ? ssd_u[t] : 0, cv = P.ncomp > 1 ? ssd_v[t] : 0;
+        double cost = (double)cy + (P.wgt[0] * (double)cu) + (P.wgt[1] * (double)cv); // (:1467-1473)
+        cost += (double)(int)bits[t] * P.lambda0;                                      // RATE_TO_COST_LAMBDA (:1488)
+        if(cost < cost_best) cost_best = cost, sb = s, ssd_best = cy + cu + cv;
+    }
+    xeve_hip_skip_result r;
+    r.cost = cost_best, r.best_ssd = ssd_best, r.idx0 = r.idx1 = 0;
+    r.mv[0][0] = r.mv[0][1] = r.mv[1][0] = r.mv[1][1] = 0, r.refi[0] = r.refi[1] = 0;
+    for(int k = 0; k < 6; k++) r.pad_[k] = 0;
+    if(sb >= 0) {
+        const xeve_hip_cu_mc_job m = mc[j * P.S + sb];
+        r.idx0 = P.isb ? sb / P.mc : sb, r.idx1 = P.isb ? sb % P.mc : 0;
+        r.mv[0][0] = m.mv[0][0], r.mv[0][1] = m.mv[0][1], r.mv[1][0] = m.mv[1][0], r.mv[1][1] = m.mv[1][1], r.refi[0] = m.refi[0], r.refi[1] = m.refi[1];
+    }
+    res[j] = r;
+    win[j] = sb;
+    bj_win[j] = bj[j * P.S + (sb >= 0 ? sb : 0)];
+}
+
+// pi->pred[PRED_SKIP][0] and core->s_temp_best of the winner (both untouched when no pair was usable)
+__global__ void k_skip_copy(SkipK P, const int *__restrict__ win, const pel *__restrict__ sy, const pel *__restrict__ su, const pel *__restrict__ sv,
+                            pel *__restrict__ py, pel *__restrict__ pu, pel *__restrict__ pv, const xeve_hip_sbac *__restrict__ st, xeve_hip_sbac *__restrict__ best)
+{
+    const int j = blockIdx.x / 3, k = blockIdx.x % 3, sb = win[j];
+    if(sb < 0 || (k && P.ncomp == 1)) return;
+    const int    n = k ? P.n1 : P.n0;
+    const size_t t = (size_t)j * P.S + sb;
+    const pel   *s = (k == 0 ? sy : k == 1 ? su : sv) + t * n;
+    pel         *d = (k == 0 ? py : k == 1 ? pu : pv) + (size_t)j * n;
+    for(int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    if(k == 0 && best && threadIdx.x == 0) copy_state(best + j, st + j);
+}
+
+struct SkipLayout {
+    size_t mc, rl, rc, bj, valid, pred[3], ssd[3], bits, win, bjw, bitsw, stw, zero, mcws, bitws, total;
+};
+static SkipLayout skip_layout(int njobs, int S, int n0, int n1, int w, int h, int nr0, int nr1)
+{
+    SkipLayout L;
+    size_t o = 0, n = (size_t)njobs * S;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    L.mc = take(n * sizeof(xeve_hip_cu_mc_job)), L.rl = take(n * sizeof(xeve_hip_job)), L.rc = take(n * sizeof(xeve_hip_job));
+    L.bj = take(n * sizeof(xeve_hip_cu_bits_job)), L.valid = take(n);
+    L.pred[0] = take(n * n0 * 2), L.pred[1] = take(n * n1 * 2 + 8), L.pred[2] = take(n * n1 * 2 + 8);
+    for(int k = 0; k < 3; k++) L.ssd[k] = take(n * 8);
+    L.bits = take(n * 4), L.win = take((size_t)njobs * 4), L.bjw = take((size_t)njobs * sizeof(xeve_hip_cu_bits_job));
+    L.bitsw = take((size_t)njobs * 4), L.stw = take((size_t)njobs * sizeof(xeve_hip_sbac)), L.zero = take(256);
+    L.mcws = take(xeve_hip_mc_cu_workspace((int)n, w, h, nr0, nr1));
+    L.bitws = take(xeve_hip_cu_bits_workspace((int)n, 64));
+    L.total = o;
+    return L;
+}
+
+static int skip_slots(const xeve_hip_rdo_params *p, int max_cand) { return p->slice_type == 0 ? max_cand * max_cand : max_cand; }
+
+extern "C" size_t xeve_hip_analyze_skip_workspace(int njobs, const xeve_hip_rdo_params *p, int max_cand)
+{
+    if(!p || njobs <= 0 || max_cand < 1 || max_cand > 4) return 256;
+    const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1;
+    const int n0 = 1 << (p->log2_cuw + p->log2_cuh), n1 = p->chroma_format_idc ? n0 >> (ws + hs) : 0;
+    return skip_layout(njobs, skip_slots(p, max_cand), n0, n1, 1 << p->log2_cuw, 1 << p->log2_cuh, p->num_refp[0], p->num_refp[1]).total;
+}
+
+extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_rdo_params *p, const xeve_hip_skip_job *jobs, int njobs,
+                                          int max_cand, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_skip_result *results,
+                                          xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, xeve_hip_sbac *best, void *workspace,
+                                          size_t workspace_bytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && pred_y && workspace && coef_l);
+    XH_REQUIRE(max_cand >= 1 && max_cand <= 4 && (p->slice_type == 0 || p->slice_type == 1));
+    XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6);
+    XH_REQUIRE(p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3);
+    XH_REQUIRE(org[0] && (p->chroma_format_idc == 0 || (org[1] && org[2] && coef_c && pred_u && pred_v)));
+    if(njobs == 0) return XEVE_HIP_OK;
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth;
+    SkipK P;
+    P.njobs = njobs, P.mc = max_cand, P.isb = p->slice_type == 0, P.S = skip_slots(p, max_cand);
+    XH_REQUIRE((long)njobs * P.S < (1L << 30) / 64);
+    P.n0 = 1 << (p->log2_cuw + p->log2_cuh), P.n1 = idc ? P.n0 >> (ws + hs) : 0, P.ncomp = idc ? 3 : 1, P.ws = ws, P.hs = hs;
+    P.s_org_l = s_org_l, P.s_org_c = s_org_c, P.best_shift = p->log2_cuw + p->log2_cuh + 16; // pi->best_ssd's reset value
+    P.lambda0 = p->lambda[0], P.wgt[0] = p->dist_chroma_weight[0], P.wgt[1] = p->dist_chroma_weight[1];
+    const int w = 1 << p->log2_cuw, h = 1 << p->log2_cuh, nt = njobs * P.S;
+    const SkipLayout L = skip_layout(njobs, P.S, P.n0, P.n1, w, h, p->num_refp[0], p->num_refp[1]);
+    XH_REQUIRE(workspace_bytes >= L.total);
+    char *W  = (char *)workspace;
+    auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
+    auto *rl = (xeve_hip_job *)(W + L.rl), *rc = (xeve_hip_job *)(W + L.rc);
+    auto *bj = (xeve_hip_cu_bits_job *)(W + L.bj), *bjw = (xeve_hip_cu_bits_job *)(W + L.bjw);
+    auto *valid = (unsigned char *)(W + L.valid);
+    pel  *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
+    long *ssd[3]  = {(long *)(W + L.ssd[0]), (long *)(W + L.ssd[1]), (long *)(W + L.ssd[2])};
+    auto *bits = (unsigned *)(W + L.bits), *bitsw = (unsigned *)(W + L.bitsw);
+    int  *win = (int *)(W + L.win), *zero = (int *)(W + L.zero);
+    auto *stw = (xeve_hip_sbac *)(W + L.stw);
+    hipStream_t st = (hipStream_t)stream;
+    int rc_;
+
+    XH_HIP(hipMemsetAsync(zero, 0, 256, st));
+    k_skip_prep<<<(nt + 255) / 256, 256, 0, st>>>(jobs, P, mc, rl, rc, bj, valid);
+    // xeve_mc of every pair (:1453)
+    rc_ = xeve_hip_mc_cu_jobs(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, mc, nt, w, h, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
+                              pred[2], W + L.mcws, L.bitws - L.mcws, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    // xeve_ssd per component (:1455-1465)
+    for(int k = 0; k < P.ncomp; k++) {
+        rc_ = xeve_hip_ssd_jobs(org[k], k ? s_org_c : s_org_l, pred[k], k ? w >> ws : w, k ? rc : rl, nt, zero, 1, k ? w >> ws : w, k ? h >> hs : h, bd,
+                                (int64_t *)ssd[k], stream);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+    }
+    // skip flag + candidate indices from the entry state (:1479-1487)
+    xeve_hip_cu_bits_params bp;
+    bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
+    bp.cm_init = 0, bp.chroma_format_idc = idc;
+    rc_ = xeve_hip_cu_bits_jobs((const int16_t *)pred[0], 64, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, nullptr, stream);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    k_skip_decide<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, P, mc, valid, ssd[0], ssd[1], ssd[2], bits, bj, results, win, bjw);
+    if(best) { // the winner's complete coder state (SBAC_STORE(core->s_temp_best, *sbac), :1519)
+        rc_ = xeve_hip_cu_bits_jobs((const int16_t *)pred[0], 64, states, bjw, njobs, &bp, W + L.bitws, workspace_bytes - L.bitws, bitsw, stw, stream);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+    }
+    k_skip_copy<<<3 * njobs, 64, 0, st>>>(P, win, pred[0], pred[1], pred[2], pred_y, pred_u, pred_v, stw, best);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

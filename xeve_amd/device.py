@@ -242,6 +242,30 @@ def residue_rdo_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params,
     return res, coef, best
 
 
+def analyze_skip_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, max_cand=4, want_state=True, workspace=None):
+    """xeve_analyze_skip for a batch of CUs (xeve_hip_analyze_skip_jobs).  jobs: uint8 tensor of lib.SKIP_JOB_DTYPE records.
+    Returns (results uint8 [njobs, 40], pred_y, pred_u, pred_v int16 [njobs, n], best uint8 [njobs, 172] or None); predictions and
+    states of CUs without a usable pair keep the zero fill."""
+    L = _lib.load()
+    njobs, nstates, dev = jobs.numel() // 60, states.numel() // 172, jobs.device
+    ws, hs = (1 if params.chroma_format_idc <= 2 else 0), (1 if params.chroma_format_idc <= 1 else 0)
+    n0 = 1 << (params.log2_cuw + params.log2_cuh)
+    n1 = (n0 >> (ws + hs)) if params.chroma_format_idc else 0
+    res = torch.empty((njobs, 40), dtype=torch.uint8, device=dev)
+    py = torch.zeros((njobs, n0), dtype=torch.int16, device=dev)
+    pu, pv = (torch.zeros((njobs, max(n1, 1)), dtype=torch.int16, device=dev) for _ in range(2))
+    best = torch.zeros((njobs, 172), dtype=torch.uint8, device=dev) if want_state else None
+    need = L.xeve_hip_analyze_skip_workspace(njobs, C.byref(params), max_cand)
+    if workspace is None:
+        workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
+    cl, cc = C.c_void_p(baseline_coef_l().ctypes.data), C.c_void_p(baseline_coef_c().ctypes.data)
+    _lib.check(L.xeve_hip_analyze_skip_jobs(org, s_org_l, s_org_c, refp.ctypes.data_as(C.c_void_p), s_l, s_c, _ptr(states), nstates, C.byref(params), _ptr(jobs),
+                                            njobs, max_cand, cl, cc, _ptr(res), _ptr(py), _ptr(pu), _ptr(pv), _ptr(best) if best is not None else None,
+                                            _ptr(workspace), workspace.numel(), _stream()))
+    return res, py, pu, pv, best
+
+
 def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 

@@ -48,6 +48,10 @@ class RdoParams(C.Structure):  # xeve_hip_rdo_params
 RDO_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)),
                  ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1"), ("sbac", "<i4")]  # xeve_hip_rdo_job (36 B)
 RDO_RESULT_DTYPE = [("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))]  # xeve_hip_rdo_result (72 B)
+SKIP_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (2, 4, 2)), ("refi_pred", "i1", (2, 4)), ("ncand", "<i4"), ("sbac", "<i4"),
+                  ("ctx_skip", "u1"), ("pad_", "u1", (3,))]  # xeve_hip_skip_job (60 B)
+SKIP_RESULT_DTYPE = [("cost", "<f8"), ("best_ssd", "<i8"), ("idx0", "<i4"), ("idx1", "<i4"), ("mv", "<i2", (2, 2)), ("refi", "i1", (2,)),
+                     ("pad_", "i1", (6,))]  # xeve_hip_skip_result (40 B)
 
 
 class DeblockParams(C.Structure):  # xeve_hip_deblock_params
@@ -139,6 +143,9 @@ FUNCTIONS = {
     "xeve_hip_residue_rdo_workspace": (C.c_size_t, [c_int, c_int, c_void_p, c_int, c_int]),
     "xeve_hip_residue_rdo_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_analyze_skip_workspace": (C.c_size_t, [c_int, c_void_p, c_int]),
+    "xeve_hip_analyze_skip_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_cu_bits_jobs_chain": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
