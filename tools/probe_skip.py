@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Timing of xeve_hip_analyze_skip_jobs: every CU of a picture at one size, B slice, 4 candidates (16 pairs)."""
+import ctypes
 import os
 import sys
 import time
@@ -37,7 +38,7 @@ for lw in (3, 4, 5, 6):
         jobs = make_skip_jobs(r, n, w, h, c, c, len(st), ncand)
         jobs["x"], jobs["y"] = (np.arange(n) % (w // c)) * c, (np.arange(n) // (w // c)) * c
         dj = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
-        need = lib.load().xeve_hip_analyze_skip_workspace(n, hp, ncand)
+        need = lib.load().xeve_hip_analyze_skip_workspace(n, ctypes.byref(hp), ncand)
         ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
         for it in range(3):
             torch.cuda.synchronize()
