@@ -143,7 +143,7 @@ void refdrv_analyze_skip(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_
     memset(&core->s_temp_best, 0, sizeof(core->s_temp_best));
     {
         enum { W_SCU = 32, SCUP = W_SCU + 1 };
-        static s16 map_mv[2 * W_SCU + 32][REFP_NUM][MV_D], col_mv[REFP_NUM][2 * W_SCU][REFP_NUM][MV_D];
+        static s16 map_mv[2 * W_SCU + 32][REFP_NUM][MV_D], col_mv[REFP_NUM][1024][REFP_NUM][MV_D];
         static s8  map_refi[2 * W_SCU + 32][REFP_NUM];
         const int  cuw_scu = (1 << lw) >> MIN_CU_LOG2;
         ctx->map_mv = map_mv, ctx->map_refi = map_refi, ctx->w_scu = W_SCU;
@@ -163,4 +163,72 @@ void refdrv_analyze_skip(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_
     memcpy(pred_y, pi->pred[PRED_SKIP][0][Y_C], sizeof(pel) << (lw + lh));
     if(p->chroma_format_idc) memcpy(pred_u, pi->pred[PRED_SKIP][0][U_C], sizeof(pel) << (lw + lh - ws - hs)), memcpy(pred_v, pi->pred[PRED_SKIP][0][V_C], sizeof(pel) << (lw + lh - ws - hs));
     from_ref(best, &core->s_temp_best);
+}
+
+
+/* xeve_pinter_analyze_cu (xeve_pinter.c:1839-2047) = ctx->fn_pinter_analyze_cu: the whole inter analysis of one CU, with the reference's own
+ * xeve_get_motion / xeve_get_mv_dir reading neighbour maps loaded with the caller's vectors (as in refdrv_analyze_skip), pinter_me_epzs as
+ * pi->fn_me (me_complexity 1, the caller's sub-pel pattern sizes), get_range_ipel deriving the ranges from gop_size and the POCs. */
+typedef struct { unsigned lambda_mv; int refi_bits, extra_bits, bi, faststep, max_search_range, range_recentre, min_clip[2], max_clip[2], reserved; } drv_me_params;
+typedef struct { unsigned lambda_mv; int refi_bits, extra_bits, bi, hpel_cnt, qpel_cnt; } drv_spel_params;
+typedef struct { drv_rdo_params rdo; drv_me_params me; drv_spel_params spel; int refi_bits[2][8], range_recentre[2][8], max_cand, poc, col_list_poc0, pad_; double skip_th; } drv_inter_params;
+typedef struct { int x, y; s16 mvp[2][4][2]; s16 mv_col[2]; int sbac; u8 ctx_skip, ctx_pred_mode, pad_[2]; } drv_inter_job;
+typedef struct { double cost, cost_inter[5]; int cu_mode, best_idx; s16 mv[2][2], mvd[2][2]; s8 refi[2]; u8 mvp_idx[2]; int nnz[3], pad_[2]; } drv_inter_result;
+
+void refdrv_pinter_analyze_cu(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, const drv_refpic *refs, int s_l, int s_c, const drv_sbac *states,
+                              const drv_inter_params *P, int gop_size, const drv_inter_job *job, drv_inter_result *res, s16 *coef_y, s16 *coef_u, s16 *coef_v,
+                              pel *rec_y, pel *rec_u, pel *rec_v, drv_sbac *next_best)
+{
+    const drv_rdo_params *p = &P->rdo;
+    /* context, pictures, neighbour maps: as for the skip analysis */
+    drv_skip_job    sj;
+    drv_skip_result sr;
+    drv_sbac        tmp;
+    static pel      t0[MAX_CU_DIM], t1[MAX_CU_DIM], t2[MAX_CU_DIM];
+    memset(&sj, 0, sizeof(sj));
+    sj.x = job->x, sj.y = job->y, memcpy(sj.mvp, job->mvp, sizeof(sj.mvp)), sj.ncand = P->max_cand, sj.sbac = job->sbac, sj.ctx_skip = job->ctx_skip;
+    refdrv_analyze_skip(org_y, org_u, org_v, s_org_l, s_org_c, refs, s_l, s_c, states, p, &sj, &sr, t0, t1, t2, &tmp);
+    XEVE_CTX    *ctx  = g_ctx;
+    XEVE_CORE   *core = g_core;
+    XEVE_PINTER *pi   = &ctx->pinter[0];
+    const int lw = p->log2_cuw, lh = p->log2_cuh, ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
+    /* motion search set-up (pinter_init_lcu / pinter_set_complexity, :1716-1771, :2049-2140) */
+    pi->fn_me = pinter_me_epzs;
+    pi->min_clip[MV_X] = P->me.min_clip[0], pi->min_clip[MV_Y] = P->me.min_clip[1], pi->max_clip[MV_X] = P->me.max_clip[0], pi->max_clip[MV_Y] = P->me.max_clip[1];
+    pi->lambda_mv = P->me.lambda_mv, pi->max_search_range = P->me.max_search_range, pi->gop_size = gop_size, pi->poc = P->poc, pi->me_complexity = 1;
+    pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = P->spel.hpel_cnt;
+    pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = P->spel.qpel_cnt;
+    pi->me_level = P->spel.qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL, pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
+    memset(pi->mot_bits, 0, sizeof(pi->mot_bits));
+    /* temporal direct (xeve_get_mv_dir): POCs and the collocated vector at the CU's bottom-right unit */
+    ctx->poc.poc_val = P->poc, ctx->h_scu = 64, ctx->param.skip_th = P->skip_th;
+    static u32 list_poc[XEVE_MAX_NUM_REF_PICS];
+    list_poc[0] = P->col_list_poc0, pi->refp[0][REFP_1].list_poc = list_poc;
+    {
+        const int corner = core->scup + ((1 << (lw - MIN_CU_LOG2)) - 1) + ((1 << (lh - MIN_CU_LOG2)) - 1) * ctx->w_scu;
+        pi->refp[0][REFP_1].map_mv[corner][0][MV_X] = job->mv_col[0], pi->refp[0][REFP_1].map_mv[corner][0][MV_Y] = job->mv_col[1];
+    }
+    core->ctx_flags[CNID_PRED_MODE] = job->ctx_pred_mode, core->cu_mode = MODE_INTRA, core->cost_best = MAX_COST;
+    memset(&core->s_next_best[lw - 2][lh - 2], 0, sizeof(XEVE_SBAC));
+    static XEVE_MODE mi;
+    static s16       coef[N_C][MAX_CU_DIM];
+    pel             *rec[N_C];
+    int              s_rec[N_C];
+    memset(&mi, 0, sizeof(mi)), memset(coef, 0, sizeof(coef));
+    res->cost = xeve_pinter_analyze_cu(ctx, core, job->x, job->y, lw, lh, &mi, coef, rec, s_rec);
+    for(int m = 0; m < 5; m++) res->cost_inter[m] = 0; /* locals of the reference function: not observable */
+    res->cu_mode = core->cu_mode, res->best_idx = -1;
+    for(int l = 0; l < 2; l++) {
+        res->refi[l] = mi.refi[l], res->mvp_idx[l] = mi.mvp_idx[l];
+        for(int d = 0; d < 2; d++) res->mv[l][d] = mi.mv[l][d], res->mvd[l][d] = mi.mvd[l][d];
+    }
+    for(int c = 0; c < N_C; c++) res->nnz[c] = core->nnz[c];
+    res->pad_[0] = res->pad_[1] = 0;
+    const int n0 = 1 << (lw + lh), n1 = n0 >> (ws + hs);
+    memcpy(coef_y, coef[Y_C], sizeof(s16) * n0), memcpy(rec_y, rec[Y_C], sizeof(pel) * n0);
+    if(p->chroma_format_idc) {
+        memcpy(coef_u, coef[U_C], sizeof(s16) * n1), memcpy(coef_v, coef[V_C], sizeof(s16) * n1);
+        memcpy(rec_u, rec[U_C], sizeof(pel) * n1), memcpy(rec_v, rec[V_C], sizeof(pel) * n1);
+    }
+    from_ref(next_best, &core->s_next_best[lw - 2][lh - 2]);
 }

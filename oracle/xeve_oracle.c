@@ -947,6 +947,10 @@ uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p,
         }
         sbac_coef(&s, p, j, coef, run_all, 0, 0);
     }
+    else if(j->mode == XO_BITS_MVP) { /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79), pidx != PRED_DIR */
+        if(p->slice_type != 2 && j->refi[0] >= 0) sbac_mvp_idx(&s, j->mvp_idx[0]), sbac_mvd1(&s, j->mvd[0][0]), sbac_mvd1(&s, j->mvd[0][1]);
+        if(p->slice_type == 0 && j->refi[1] >= 0) sbac_mvp_idx(&s, j->mvp_idx[1]), sbac_mvd1(&s, j->mvd[1][0]), sbac_mvd1(&s, j->mvd[1][1]);
+    }
     else { /* xeve_mode.c:177-199: one component, RUN_L / RUN_CB / RUN_CR */
         int run[3] = {j->mode == XO_BITS_COMP_Y, j->mode == XO_BITS_COMP_U, j->mode == XO_BITS_COMP_V};
         sbac_coef(&s, p, j, coef, run, 0, 0);
@@ -1368,4 +1372,198 @@ void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const
     }
     res->cost = cost_best;
     for(int c = 0; c < 3; c++) free(t[c]);
+}
+
+/* ===================================================================================================================
+ * xeve_pinter_analyze_cu (src_base/xeve_pinter.c:1839-2047), Baseline
+ * =================================================================================================================== */
+int xo_check_best_mvp(const xo_sbac *entry, int slice_type, const int8_t refi[2], int lidx, const int16_t mvp[4][2], const int16_t mv[2], int mvp_idx,
+                      double lambda0, int16_t mvd[2])
+{
+    xo_cu_bits_params bp;
+    xo_cu_bits_job    bj;
+    memset(&bp, 0, sizeof(bp)), memset(&bj, 0, sizeof(bj));
+    bp.log2_cuw = bp.log2_cuh = 3, bp.slice_type = slice_type; /* (the CU size does not enter this syntax) */
+    bj.mode = XO_BITS_MVP, bj.refi[0] = refi[0], bj.refi[1] = refi[1];
+#define MVP_COST(IDX) (bj.mvp_idx[0] = bj.mvp_idx[1] = (uint8_t)(IDX), bj.mvd[lidx][0] = (int16_t)(mv[0] - mvp[IDX][0]), bj.mvd[lidx][1] = (int16_t)(mv[1] - mvp[IDX][1]), \
+                       (double)(int)xo_cu_bits(entry, NULL, &bp, &bj, NULL) * lambda0)
+    const double best_cost = MVP_COST(mvp_idx); /* never updated below: the LAST index cheaper than the entry index wins (:1829-1831) */
+    int best_idx = mvp_idx;
+    for(int idx = 0; idx < 4; idx++) { /* ORG_MAX_NUM_MVP */
+        int same = 0;
+        for(int t = idx - 1; t >= 0 && !same; t--) same = mvp[idx][0] == mvp[t][0] && mvp[idx][1] == mvp[t][1];
+        if(same) continue; /* encoder side pruning */
+        if(MVP_COST(idx) < best_cost) best_idx = idx;
+    }
+#undef MVP_COST
+    mvd[0] = (int16_t)(mv[0] - mvp[best_idx][0]), mvd[1] = (int16_t)(mv[1] - mvp[best_idx][1]);
+    return best_idx;
+}
+
+void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                          const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                          xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best)
+{
+    enum { L0 = 0, L1 = 1, BI = 2, SKIP = 3, DIR = 4, NP = 5 };
+    const xo_rdo_params *p = &P->rdo;
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth, isb = p->slice_type == 0;
+    const int lw = p->log2_cuw, lh = p->log2_cuh, w = 1 << lw, h = 1 << lh, n0 = w * h, n1 = idc ? n0 >> (ws + hs) : 0, ncomp = idc ? 3 : 1;
+    const int x = job->x, y = job->y;
+    double  cost_inter[NP], cost_best = 1.7e+308, cost;
+    int     best_idx = SKIP, cu_mode = -1;
+    /* per mode: motion data, coefficients, nnz */
+    int16_t mv[NP][2][2], mvd[NP][2][2];
+    int8_t  refi[NP][2];
+    uint8_t mvpi[NP][2];
+    int     nnz[NP][3];
+    int16_t *coef[NP][3];
+    xo_pel  *pred_skip[3];
+    memset(mv, 0, sizeof(mv)), memset(mvd, 0, sizeof(mvd)), memset(refi, 0, sizeof(refi)), memset(mvpi, 0, sizeof(mvpi)), memset(nnz, 0, sizeof(nnz));
+    for(int m = 0; m < NP; m++) {
+        cost_inter[m] = 1.7e+308;
+        for(int c = 0; c < 3; c++) coef[m][c] = calloc((size_t)n0, sizeof(int16_t));
+    }
+    for(int c = 0; c < 3; c++) pred_skip[c] = calloc((size_t)n0, sizeof(xo_pel));
+    xo_rdo_result rr;
+    xo_sbac       st;
+
+    /* skip mode (:1872-1883) */
+    xo_skip_job    sj;
+    xo_skip_result sr;
+    memset(&sj, 0, sizeof(sj));
+    sj.x = x, sj.y = y, memcpy(sj.mvp, job->mvp, sizeof(sj.mvp)), sj.ncand = P->max_cand, sj.sbac = job->sbac, sj.ctx_skip = job->ctx_skip;
+    xo_analyze_skip(org, s_org_l, s_org_c, refp, s_l, s_c, states, p, &sj, &sr, pred_skip[0], pred_skip[1], pred_skip[2], &st);
+    cost = cost_inter[SKIP] = sr.cost;
+    memcpy(mv[SKIP], sr.mv, sizeof(sr.mv)), refi[SKIP][0] = sr.refi[0], refi[SKIP][1] = sr.refi[1], mvpi[SKIP][0] = (uint8_t)sr.idx0, mvpi[SKIP][1] = (uint8_t)sr.idx1;
+    if(!isb) mv[SKIP][1][0] = mv[SKIP][1][1] = 0; /* (stale in the reference) */
+    if(cost < cost_best) cu_mode = 2, best_idx = SKIP, cost_best = cost, *next_best = st;
+
+    if(cu_mode == 2 && (double)sr.best_ssd > (double)((int64_t)1 << (lw + lh + (bd - 8) + (bd - 8))) * P->skip_th) { /* (:1885-1887) */
+        xo_rdo_job rj;
+        if(isb) { /* analyze_t_direct (:1534-1565) + xeve_get_mv_dir (xeve_util.c:619-650) */
+            const int dpoc_co = refp[0 * 2 + 1].poc - P->col_list_poc0, dpoc_l0 = P->poc - refp[0 * 2 + 0].poc, dpoc_l1 = refp[0 * 2 + 1].poc - P->poc;
+            if(dpoc_co != 0) {
+                mv[DIR][0][0] = (int16_t)(dpoc_l0 * job->mv_col[0] / dpoc_co), mv[DIR][0][1] = (int16_t)(dpoc_l0 * job->mv_col[1] / dpoc_co);
+                mv[DIR][1][0] = (int16_t)(-dpoc_l1 * job->mv_col[0] / dpoc_co), mv[DIR][1][1] = (int16_t)(-dpoc_l1 * job->mv_col[1] / dpoc_co);
+            }
+            memset(&rj, 0, sizeof(rj));
+            rj.x = x, rj.y = y, memcpy(rj.mv, mv[DIR], sizeof(rj.mv)), rj.dir_flag = 1, rj.ctx_skip = job->ctx_skip, rj.ctx_pred_mode = job->ctx_pred_mode, rj.sbac = job->sbac;
+            xo_residue_rdo(org, s_org_l, s_org_c, refp, s_l, s_c, states, p, &rj, &rr, coef[DIR][0], coef[DIR][1], coef[DIR][2], &st);
+            memcpy(nnz[DIR], rr.nnz, sizeof(rr.nnz));
+            cost = cost_inter[DIR] = rr.cost;
+            if(cost < cost_best) cu_mode = 3, best_idx = DIR, cost_best = cost, *next_best = st;
+        }
+        /* motion search per list (:1906-1989) */
+        int16_t  mv_scale[2][XO_MAX_REFP][2];
+        int      mot_bits[2] = {0, 0};
+        uint8_t  mvp_idx[2] = {0, 0};
+        xo_epzs_params ep = P->me;
+        for(int l = 0; l <= (isb ? 1 : 0); l++) {
+            uint32_t best_mecost = 0xFFFFFFFFu;
+            int      refi_temp = 0;
+            mvp_idx[l] = mvpi[SKIP][l];
+            for(int r = 0; r < p->num_refp[l]; r++) {
+                ep.me.bi = 0, ep.me.extra_bits = 0, ep.me.refi_bits = P->refi_bits[l][r], ep.me.range_recentre = P->range_recentre[l][r];
+                int16_t m[2] = {0, 0};
+                const uint32_t mecost = xo_me_epzs_mot(org[0], s_org_l, NULL, refp[r * 2 + l].y, s_l, x, y, job->mvp[l][mvp_idx[l]], m, lw, lh, bd, xo_mc_l_coeff, &ep,
+                                                       &mot_bits[l]);
+                mv_scale[l][r][0] = m[0], mv_scale[l][r][1] = m[1];
+                if(mecost < best_mecost) best_mecost = mecost, refi_temp = r;
+            }
+            mv[l][l][0] = mv_scale[l][refi_temp][0], mv[l][l][1] = mv_scale[l][refi_temp][1];
+            refi[l][0] = (int8_t)(l == 0 ? refi_temp : -1), refi[l][1] = (int8_t)(l == 1 ? refi_temp : -1);
+            mvp_idx[l] = (uint8_t)xo_check_best_mvp(&states[job->sbac], p->slice_type, refi[l], l, job->mvp[l], mv[l][l], mvp_idx[l], p->lambda[0], mvd[l][l]);
+            mvpi[l][0] = mvp_idx[0], mvpi[l][1] = mvp_idx[1]; /* (the local pair is what pinter_residue_rdo is given) */
+            memset(&rj, 0, sizeof(rj));
+            rj.x = x, rj.y = y, memcpy(rj.mv, mv[l], sizeof(rj.mv)), memcpy(rj.mvd, mvd[l], sizeof(rj.mvd)), rj.refi[0] = refi[l][0], rj.refi[1] = refi[l][1];
+            rj.mvp_idx[0] = mvp_idx[0], rj.mvp_idx[1] = mvp_idx[1], rj.ctx_skip = job->ctx_skip, rj.ctx_pred_mode = job->ctx_pred_mode, rj.sbac = job->sbac;
+            xo_residue_rdo(org, s_org_l, s_org_c, refp, s_l, s_c, states, p, &rj, &rr, coef[l][0], coef[l][1], coef[l][2], &st);
+            memcpy(nnz[l], rr.nnz, sizeof(rr.nnz));
+            cost = cost_inter[l] = rr.cost;
+            if(cost < cost_best) cu_mode = 1, best_idx = l, cost_best = cost, *next_best = st;
+        }
+        if(isb) { /* analyze_bi (:1567-1714) */
+            int      lidx_ref = cost_inter[L0] <= cost_inter[L1] ? 0 : 1, lidx_cnd = 1 - lidx_ref, t;
+            int8_t   rf[2];
+            uint32_t best_mecost = 0xFFFFFFFFu;
+            int      refi_best = 0, changed;
+            const int nb = p->num_refp[1]; /* pi->num_refp as the list-1 search left it */
+            xo_pel  *pr[3];
+            int16_t *org_bi = malloc(sizeof(int16_t) * (size_t)n0);
+            for(int c = 0; c < 3; c++) pr[c] = malloc(sizeof(xo_pel) * (size_t)n0);
+            mvpi[BI][0] = mvpi[L0][0], mvpi[BI][1] = mvpi[L1][1], refi[BI][0] = refi[L0][0], refi[BI][1] = refi[L1][1];
+            memcpy(mv[BI][0], mv[L0][0], 4), memcpy(mv[BI][1], mv[L1][1], 4);
+            rf[lidx_ref] = refi[BI][lidx_ref], rf[lidx_cnd] = -1;
+            for(int i = 0; i < 4; i++) { /* BI_ITER */
+                xo_cu_mc_job mj;
+                memset(&mj, 0, sizeof(mj));
+                mj.x = x, mj.y = y, memcpy(mj.mv, mv[BI], sizeof(mj.mv)), mj.refi[0] = rf[0], mj.refi[1] = rf[1];
+                xo_mc_cu(refp, s_l, s_c, p->pic_w, p->pic_h, &mj, w, h, bd, bd, idc, pr[0], pr[1], pr[2]);
+                for(int yy = 0; yy < h; yy++) /* get_org_bi (:143-156) */
+                    for(int xx = 0; xx < w; xx++) org_bi[yy * w + xx] = (int16_t)((org[0][(y + yy) * s_org_l + x + xx] << 1) - pr[0][yy * w + xx]);
+                t = rf[lidx_ref], rf[lidx_ref] = rf[lidx_cnd], rf[lidx_cnd] = (int8_t)t;
+                t = lidx_ref, lidx_ref = lidx_cnd, lidx_cnd = t;
+                const int idx = mvpi[BI][lidx_ref];
+                changed = 0;
+                for(int r = 0; r < nb; r++) {
+                    rf[lidx_ref] = (int8_t)r;
+                    ep.me.bi = 1, ep.me.extra_bits = mot_bits[lidx_cnd], ep.me.refi_bits = P->refi_bits[1][r], ep.me.range_recentre = P->range_recentre[lidx_ref][r];
+                    int dummy = 0;
+                    const uint32_t mecost = xo_me_epzs_mot(org[0], s_org_l, org_bi, refp[r * 2 + lidx_ref].y, s_l, x, y, job->mvp[lidx_ref][idx], mv_scale[lidx_ref][r], lw,
+                                                           lh, bd, xo_mc_l_coeff, &ep, &dummy);
+                    if(mecost < best_mecost) {
+                        refi_best = r, best_mecost = mecost, changed = 1;
+                        refi[BI][lidx_ref] = (int8_t)refi_best; /* (the other list keeps pi->refi[pidx][lidx_cnd]) */
+                        mv[BI][lidx_ref][0] = mv_scale[lidx_ref][r][0], mv[BI][lidx_ref][1] = mv_scale[lidx_ref][r][1];
+                    }
+                }
+                rf[lidx_ref] = (int8_t)refi_best, rf[lidx_cnd] = -1;
+                if(!changed) break;
+            }
+            for(int l = 0; l < 2; l++)
+                for(int d = 0; d < 2; d++) mvd[BI][l][d] = (int16_t)(mv[BI][l][d] - job->mvp[l][mvpi[BI][l]][d]);
+            memset(&rj, 0, sizeof(rj));
+            rj.x = x, rj.y = y, memcpy(rj.mv, mv[BI], sizeof(rj.mv)), memcpy(rj.mvd, mvd[BI], sizeof(rj.mvd)), rj.refi[0] = refi[BI][0], rj.refi[1] = refi[BI][1];
+            rj.mvp_idx[0] = mvpi[BI][0], rj.mvp_idx[1] = mvpi[BI][1], rj.ctx_skip = job->ctx_skip, rj.ctx_pred_mode = job->ctx_pred_mode, rj.sbac = job->sbac;
+            xo_residue_rdo(org, s_org_l, s_org_c, refp, s_l, s_c, states, p, &rj, &rr, coef[BI][0], coef[BI][1], coef[BI][2], &st);
+            memcpy(nnz[BI], rr.nnz, sizeof(rr.nnz));
+            cost = cost_inter[BI] = rr.cost;
+            if(cost < cost_best) cu_mode = 1, best_idx = BI, cost_best = cost, *next_best = st;
+            free(org_bi);
+            for(int c = 0; c < 3; c++) free(pr[c]);
+        }
+    }
+
+    /* the winner: coefficients, reconstruction (:2004-2032), motion data (:2036-2046) */
+    int16_t *co[3] = {coef_y, coef_u, coef_v};
+    xo_pel  *rec[3] = {rec_y, rec_u, rec_v}, *pr[3];
+    int16_t *tmp = malloc(sizeof(int16_t) * (size_t)n0);
+    for(int c = 0; c < 3; c++) pr[c] = malloc(sizeof(xo_pel) * (size_t)n0);
+    if(best_idx == SKIP) for(int c = 0; c < ncomp; c++) memcpy(pr[c], pred_skip[c], sizeof(xo_pel) * (size_t)(c ? n1 : n0));
+    else {
+        xo_cu_mc_job mj;
+        memset(&mj, 0, sizeof(mj));
+        mj.x = x, mj.y = y, memcpy(mj.mv, mv[best_idx], sizeof(mj.mv)), mj.refi[0] = refi[best_idx][0], mj.refi[1] = refi[best_idx][1];
+        xo_mc_cu(refp, s_l, s_c, p->pic_w, p->pic_h, &mj, w, h, bd, bd, idc, pr[0], pr[1], pr[2]);
+    }
+    for(int c = 0; c < ncomp; c++) {
+        const int n = c ? n1 : n0, l2w = c ? lw - ws : lw, l2h = c ? lh - hs : lh;
+        memcpy(co[c], coef[best_idx][c], sizeof(int16_t) * (size_t)n);
+        memcpy(tmp, co[c], sizeof(int16_t) * (size_t)n);
+        if(nnz[best_idx][c]) xo_dquant(tmp, l2w, l2h, xo_dq_scale[p->qp[c] % 6] << (p->qp[c] / 6), bd), xo_itrans(tmp, l2w, l2h, bd);
+        xo_recon(tmp, pr[c], nnz[best_idx][c], 1 << l2w, 1 << l2h, 1 << l2w, rec[c], bd);
+    }
+    memset(res, 0, sizeof(*res));
+    res->cost = cost_inter[best_idx], memcpy(res->cost_inter, cost_inter, sizeof(cost_inter)), res->cu_mode = cu_mode, res->best_idx = best_idx;
+    for(int l = 0; l < 2; l++) {
+        const int used = refi[best_idx][l] >= 0 && (isb || l == 0);
+        res->refi[l] = (isb || l == 0) ? refi[best_idx][l] : -1;
+        if(used) memcpy(res->mv[l], mv[best_idx][l], 4), memcpy(res->mvd[l], mvd[best_idx][l], 4), res->mvp_idx[l] = mvpi[best_idx][l];
+    }
+    if(best_idx == DIR) res->mvp_idx[0] = res->mvp_idx[1] = 0;
+    memcpy(res->nnz, nnz[best_idx], sizeof(res->nnz));
+    free(tmp);
+    for(int c = 0; c < 3; c++) free(pr[c]), free(pred_skip[c]);
+    for(int m = 0; m < NP; m++)
+        for(int c = 0; c < 3; c++) free(coef[m][c]);
 }

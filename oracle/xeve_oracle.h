@@ -204,7 +204,8 @@ typedef struct xo_cu_bits_params {
     int32_t cm_init;             /* sps_cm_init_flag (0 in Baseline)                                      */
     int32_t chroma_format_idc;   /* 0 = 4:0:0 ... 3 = 4:4:4; w/h shift as XEVE_GET_CHROMA_{W,H}_SHIFT     */
 } xo_cu_bits_params;
-enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4, XO_BITS_ECO_COEF = 5 };
+enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4, XO_BITS_ECO_COEF = 5,
+       XO_BITS_MVP = 6 /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list */ };
 /* XO_BITS_ECO_COEF: xeve_eco_coef (cbf flags + coefficients) on its own; job.dir_flag then holds these flags */
 enum { XO_ECO_INTRA = 1, XO_ECO_NO_CBF = 2, XO_ECO_RUN_Y = 4, XO_ECO_RUN_U = 8, XO_ECO_RUN_V = 16, XO_ECO_NO_RESET = 32 /* continue the coder where the state stands */ };
 typedef struct xo_cu_bits_job {
@@ -318,6 +319,49 @@ typedef struct xo_skip_result {
 /* pred_* receive pi->pred[PRED_SKIP][0] (untouched when no candidate is usable); best = core->s_temp_best (ditto) */
 void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
                      const xo_rdo_params *p, const xo_skip_job *job, xo_skip_result *res, xo_pel *pred_y, xo_pel *pred_u, xo_pel *pred_v, xo_sbac *best);
+
+
+/* ---- the whole inter analysis of one CU: xeve_pinter_analyze_cu (src_base/xeve_pinter.c:1839-2047) = ctx->fn_pinter_analyze_cu ----
+ * Baseline (tool_admvp 0): skip / merge analysis; unless the skip residual is below the skip_th threshold: temporal direct (B), per list the
+ * motion search over every reference picture (pinter_me_epzs) + check_best_mvp + pinter_residue_rdo, the iterated bi-prediction search (B)
+ * + pinter_residue_rdo; the cheapest mode's coefficients, reconstruction, motion data and coder state. */
+#define XO_MAX_REFP 8
+typedef struct xo_inter_params {
+    xo_rdo_params  rdo;
+    xo_epzs_params me;                             /* lambda_mv, max_search_range, clips, hpel / qpel counts; the four below are set per search */
+    int32_t        refi_bits[2][XO_MAX_REFP];      /* xeve_tbl_refi_bits[num_refp[l]][refi] */
+    int32_t        range_recentre[2][XO_MAX_REFP]; /* get_range_ipel's POC-distance scaled range of refp[refi][l] */
+    int32_t        max_cand;                       /* pi->skip_merge_cand_num */
+    int32_t        poc, col_list_poc0;             /* ctx->poc.poc_val; refp[0][REFP_1].list_poc[0] (temporal direct) */
+    int32_t        pad_;
+    double         skip_th;                        /* ctx->param.skip_th */
+} xo_inter_params;
+typedef struct xo_inter_job {
+    int32_t x, y;
+    int16_t mvp[2][4][2]; /* xeve_get_motion's candidates per list (left, up, up-right, collocated); reference index 0 each */
+    int16_t mv_col[2];    /* refp[0][REFP_1].map_mv[bottom-right unit of the CU][0] (xeve_get_mv_dir) */
+    int32_t sbac;
+    uint8_t ctx_skip, ctx_pred_mode, pad_[2];
+} xo_inter_job;
+typedef struct xo_inter_result {
+    double  cost;          /* the return value: cost_inter[best_idx] */
+    double  cost_inter[5]; /* PRED_L0, PRED_L1, PRED_BI, PRED_SKIP, PRED_DIR (1.7e308 where not evaluated; locals of the reference function) */
+    int32_t cu_mode;       /* MODE_INTER 1 / MODE_SKIP 2 / MODE_DIR 3 */
+    int32_t best_idx;
+    int16_t mv[2][2], mvd[2][2]; /* mi->mv, mi->mvd; entries of an unused list are 0 here (stale in the reference) */
+    int8_t  refi[2];
+    uint8_t mvp_idx[2];
+    int32_t nnz[3];
+    int32_t pad_[2];
+} xo_inter_result;
+/* coef_*: the `coef` argument (zero for MODE_SKIP, where the reference leaves stale data behind nnz = 0); rec_*: pi->rec[best_idx] (dense);
+ * next_best: core->s_next_best[log2_cuw - 2][log2_cuh - 2] */
+void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                          const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                          xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best);
+/* check_best_mvp (xeve_pinter.c:1773-1837): returns the chosen index; mvd is recomputed against it */
+int xo_check_best_mvp(const xo_sbac *entry, int slice_type, const int8_t refi[2], int lidx, const int16_t mvp[4][2], const int16_t mv[2], int mvp_idx,
+                      double lambda0, int16_t mvd[2]);
 
 #ifdef __cplusplus
 }

@@ -479,3 +479,34 @@ def oracle_skip():
     L.xo_analyze_skip.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(RdoParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]
     return L
+
+
+# ---- xeve_pinter_analyze_cu (the whole inter analysis of a CU) -------------------------------------------------------------------
+class InterParams(C.Structure):  # xo_inter_params
+    _fields_ = [("rdo", RdoParams), ("me", MeParams), ("spel", SpelParams), ("refi_bits", (C.c_int32 * 8) * 2), ("range_recentre", (C.c_int32 * 8) * 2),
+                ("max_cand", C.c_int32), ("poc", C.c_int32), ("col_list_poc0", C.c_int32), ("pad_", C.c_int32), ("skip_th", C.c_double)]
+
+
+INTER_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (2, 4, 2)), ("mv_col", "<i2", (2,)), ("sbac", "<i4"), ("ctx_skip", "u1"),
+                            ("ctx_pred_mode", "u1"), ("pad_", "u1", (2,))])
+INTER_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("cost_inter", "<f8", (5,)), ("cu_mode", "<i4"), ("best_idx", "<i4"), ("mv", "<i2", (2, 2)),
+                               ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)), ("nnz", "<i4", (3,)), ("pad_", "<i4", (2,))])
+assert INTER_JOB_DTYPE.itemsize == 52 and INTER_RESULT_DTYPE.itemsize == 96 and C.sizeof(InterParams) == 320
+
+
+def ref_inter():
+    L = ref_skip()
+    if L is not None and not hasattr(L, "_inter_bound"):
+        L.refdrv_pinter_analyze_cu.restype = None
+        L.refdrv_pinter_analyze_cu.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(InterParams), c_int] + [c_void_p] * 9
+        L._inter_bound = True
+    return L
+
+
+def oracle_inter():
+    L = oracle()
+    L.xo_pinter_analyze_cu.restype = None
+    L.xo_pinter_analyze_cu.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, C.POINTER(InterParams)] + [c_void_p] * 9
+    L.xo_check_best_mvp.restype = c_int
+    L.xo_check_best_mvp.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, C.c_double, c_void_p]
+    return L
