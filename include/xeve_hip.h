@@ -311,6 +311,13 @@ int xeve_hip_me_epzs_jobs(const xeve_hip_pel *org0, int s_org, const xeve_hip_pe
                           const xeve_hip_epzs_params *params, xeve_hip_me_result *results, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* The same with pi->mot_bits[other list] per job (bi == 1: a batch of bi-prediction searches whose CUs searched the other list with
+ * different outcomes): extra_bits[j] replaces params->me.extra_bits; device memory, NULL = the common value. */
+int xeve_hip_me_epzs_jobs_x(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref,
+                            const xeve_hip_epzs_job *jobs, int njobs, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                            const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* (4) CABAC (SBAC) bit counting of an inter CU -- the rate term of pinter_residue_rdo and of   */
 /*     the skip / merge analysis.  reference: src_base/xeve_mode.c:39-295 */
@@ -351,7 +358,8 @@ typedef struct xeve_hip_cu_bits_params {
     int32_t chroma_format_idc;   /* 0..3; chroma block = (w >> w_shift) x (h >> h_shift), XEVE_GET_CHROMA_{W,H}_SHIFT */
 } xeve_hip_cu_bits_params;
 enum { XEVE_HIP_BITS_CU_INTER = 0, XEVE_HIP_BITS_COMP_Y = 1, XEVE_HIP_BITS_COMP_U = 2, XEVE_HIP_BITS_COMP_V = 3, XEVE_HIP_BITS_CU_SKIP = 4,
-       XEVE_HIP_BITS_ECO_COEF = 5 /* ctx->fn_eco_coef = xeve_eco_coef (xeve_eco.c:1067-1089) on its own: cbf flags + coefficients */ };
+       XEVE_HIP_BITS_ECO_COEF = 5, /* ctx->fn_eco_coef = xeve_eco_coef (xeve_eco.c:1067-1089) on its own: cbf flags + coefficients */
+       XEVE_HIP_BITS_MVP = 6 /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list -- what check_best_mvp prices */ };
 /* XEVE_HIP_BITS_ECO_COEF: job.dir_flag holds these flags.  NO_RESET continues the coder where the entry state stands instead of applying
  * xeve_sbac_bit_reset (needs sbac_out: only the kernel that carries the complete coder state can do it). */
 enum { XEVE_HIP_ECO_INTRA = 1, XEVE_HIP_ECO_NO_CBF = 2, XEVE_HIP_ECO_RUN_Y = 4, XEVE_HIP_ECO_RUN_U = 8, XEVE_HIP_ECO_RUN_V = 16, XEVE_HIP_ECO_NO_RESET = 32 };
@@ -519,6 +527,54 @@ int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int s_org_l, in
                                int max_cand, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_skip_result *results,
                                xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, xeve_hip_sbac *best, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* (8) The whole inter analysis of a CU: xeve_pinter_analyze_cu (src_base/xeve_pinter.c:1839-2047) */
+/*     = ctx->fn_pinter_analyze_cu, for a batch of CUs of one (square, 8..64) size.  Baseline:      */
+/*     skip / merge analysis; unless the skip residual is below the skip_th threshold: temporal   */
+/*     direct (B slices), per list the motion search over every reference picture + check_best_mvp */
+/*     + pinter_residue_rdo, the iterated bi-prediction search (analyze_bi, B slices) +           */
+/*     pinter_residue_rdo; the cheapest mode's coefficients, reconstruction, motion data and      */
+/*     coder state.  me_complexity 1, me_level > IPEL, rdo_dbk_switch 0 (presets fast / medium).   */
+/* ------------------------------------------------------------------------------------------- */
+#define XEVE_HIP_MAX_REFP 8
+typedef struct xeve_hip_inter_params {
+    xeve_hip_rdo_params  rdo;
+    xeve_hip_epzs_params me;   /* lambda_mv, max_search_range, clips, hpel / qpel counts; bi, extra_bits, refi_bits, range_recentre are set per search */
+    int32_t refi_bits[2][XEVE_HIP_MAX_REFP];      /* xeve_tbl_refi_bits[rdo.num_refp[l]][refi] (xeve_tbl.c:498-517) */
+    int32_t range_recentre[2][XEVE_HIP_MAX_REFP]; /* get_range_ipel's POC-distance scaled range of refp[refi][l] (xeve_pinter.c:124-129) */
+    int32_t max_cand;                             /* pi->skip_merge_cand_num */
+    int32_t poc, col_list_poc0;                   /* ctx->poc.poc_val; refp[0][REFP_1].list_poc[0] (xeve_get_mv_dir, xeve_util.c:634) */
+    int32_t pad_;
+    double  skip_th;                              /* ctx->param.skip_th */
+} xeve_hip_inter_params;
+typedef struct xeve_hip_inter_job {
+    int32_t x, y;
+    int16_t mvp[2][4][2]; /* xeve_get_motion's candidates per list (left, up, up-right, collocated; xeve_util.c:526-573); reference index 0 each */
+    int16_t mv_col[2];    /* refp[0][REFP_1].map_mv[bottom-right unit of the CU][0] (xeve_get_mv_dir, xeve_util.c:631-632) */
+    int32_t sbac;         /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] in `states` */
+    uint8_t ctx_skip, ctx_pred_mode, pad_[2];
+} xeve_hip_inter_job;
+typedef struct xeve_hip_inter_result {
+    double  cost;          /* the return value: cost_inter[best_idx] */
+    double  cost_inter[5]; /* PRED_L0, PRED_L1, PRED_BI, PRED_SKIP, PRED_DIR (1.7e308 where not evaluated) */
+    int32_t cu_mode;       /* core->cu_mode: MODE_INTER 1 / MODE_SKIP 2 / MODE_DIR 3 */
+    int32_t best_idx;      /* PRED_* of the winner */
+    int16_t mv[2][2], mvd[2][2]; /* mi->mv, mi->mvd; entries of a list the winner does not use are 0 (stale in the reference) */
+    int8_t  refi[2];       /* mi->refi */
+    uint8_t mvp_idx[2];    /* mi->mvp_idx (0 for MODE_DIR and unused lists) */
+    int32_t nnz[3];        /* core->nnz */
+    int32_t pad_[2];
+} xeve_hip_inter_result;
+/* Pointer kinds as for xeve_hip_residue_rdo_jobs.  coef: the `coef` argument of the reference function, laid out like pi->coef there (Y blocks of
+ * all CUs, then U, then V; zero for skipped CUs); rec_y [njobs][w*w], rec_u / rec_v [njobs][cw*ch]: pi->rec[best_idx]; next_best[j]:
+ * core->s_next_best[log2_cuw - 2][log2_cuh - 2].  B slices: rdo.num_refp[1] <= rdo.num_refp[0] (analyze_bi walks both lists with num_refp[1]). */
+size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_inter_params *params, int s_org_l, int s_org_c);
+int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                                    const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *params, const xeve_hip_inter_job *jobs,
+                                    int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *results, int16_t *coef,
+                                    xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *next_best, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* One pinter_me_epzs call on HOST memory (synchronous; both luma planes staged per call): what pi->fn_me can be pointed at.
  * org0 / ref0 = sample (0, 0) of the original / reference luma plane; the reference plane has `pad` samples around the picture. */

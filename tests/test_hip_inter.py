@@ -1,0 +1,103 @@
+"""The whole inter analysis of a CU on the GPU (xeve_hip_pinter_analyze_cu_jobs = ctx->fn_pinter_analyze_cu for a batch): cost (bit pattern of the
+double), cu_mode, motion data, core->nnz, coefficients, reconstruction and core->s_next_best against the reference goldens and the pinned oracle,
+through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _inter_cases import make_inter_jobs, make_inter_params, make_inter_picture, mask_unobservable
+from _inter_golden import CASES, golden
+from _libs import INTER_RESULT_DTYPE, SBAC_DTYPE, oracle_inter, ptr
+from _mc_cases import refpic_table
+from _rdo_cases import states
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_params(P):
+    """tests' InterParams (the oracle's layout) -> lib.InterParams (the library's: xeve_hip_epzs_params holds the sub-pel counts directly)"""
+    from xeve_amd import lib
+
+    H = lib.InterParams()
+    C.memmove(C.byref(H.rdo), C.byref(P.rdo), C.sizeof(P.rdo))
+    C.memmove(C.byref(H.me.me), C.byref(P.me), C.sizeof(P.me))
+    H.me.hpel_cnt, H.me.qpel_cnt = P.spel.hpel_cnt, P.spel.qpel_cnt
+    for l in range(2):
+        for i in range(8):
+            H.refi_bits[l][i], H.range_recentre[l][i] = P.refi_bits[l][i], P.range_recentre[l][i]
+    H.max_cand, H.poc, H.col_list_poc0, H.skip_th = P.max_cand, P.poc, P.col_list_poc0, P.skip_th
+    return H
+
+
+def run_hip(refs, org, st, P, jobs):
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    dplanes = [[torch.from_numpy(x).to(dev) for x in pic] for pic in refs["pics"]]
+    lut = {id(x): t for pic, dp in zip(refs["pics"], dplanes) for x, t in zip(pic, dp)}
+    dev_tab = refpic_table(refs, lambda a, off: lut[id(a)].data_ptr() + 2 * off).view(lib.REFPIC_DTYPE)
+    dorg = [torch.from_numpy(x).to(dev) for x in org]
+    org_ptrs = [dorg[0].data_ptr() + 2 * refs["org_l"], dorg[1].data_ptr() + 2 * refs["org_c"], dorg[2].data_ptr() + 2 * refs["org_c"]]
+    res, coef, ry, ru, rv, nb = D.pinter_analyze_cu_jobs(org_ptrs, refs["s_l"], refs["s_c"], dev_tab, refs["s_l"], refs["s_c"],
+                                                         torch.from_numpy(st.view(np.uint8).copy()).to(dev), hip_params(P),
+                                                         torch.from_numpy(jobs.view(np.uint8).copy()).to(dev))
+    torch.cuda.synchronize()
+    n = len(jobs)
+    n0 = 1 << (2 * P.rdo.log2_cuw)
+    n1 = (n0 >> (refs["ws"] + refs["hs"])) if P.rdo.chroma_format_idc else 0
+    c = coef.cpu().numpy()
+    return (res.cpu().numpy().reshape(-1).view(INTER_RESULT_DTYPE), [c[:n * n0].reshape(n, n0), c[n * n0:n * (n0 + n1)].reshape(n, n1), c[n * (n0 + n1):n * (n0 + 2 * n1)].reshape(n, n1)],
+            [ry.cpu().numpy(), ru.cpu().numpy(), rv.cpu().numpy()], nb.cpu().numpy().reshape(-1).view(SBAC_DTYPE))
+
+
+def test_hip_pinter_analyze_cu_matches_reference_goldens():
+    n = 0
+    for c in golden():
+        res, coef, rec, best = run_hip(c["refs"], c["org"], c["states"], c["P"], c["jobs"])
+        got = mask_unobservable(res, c["slice_type"])
+        for i in range(len(res)):
+            assert got[i:i + 1].tobytes() == c["res"][i:i + 1].tobytes(), (n, i, res[i], c["res"][i])
+        for k in range(3 if c["idc"] else 1):
+            assert np.array_equal(coef[k], c["coef"][k]), (n, k)
+            assert np.array_equal(rec[k], c["rec"][k]), (n, k)
+        assert best.tobytes() == c["best"].tobytes(), n
+        n += 1
+    assert n == len(CASES)
+
+
+@pytest.mark.parametrize("w,h,bd,nref,idc,slice_type,skip_th", [(128, 96, 10, 2, 1, 0, 0.0), (128, 64, 10, 2, 1, 1, 0.0), (96, 64, 8, 1, 1, 0, 0.0),
+                                                                (64, 64, 10, 2, 0, 0, 0.0), (192, 128, 10, 3, 1, 0, 0.0), (128, 96, 10, 2, 1, 0, 6.0)])
+def test_hip_pinter_analyze_cu_vs_oracle(w, h, bd, nref, idc, slice_type, skip_th):
+    O = oracle_inter()
+    r = np.random.default_rng(13 * w + h + bd + nref + idc + slice_type)
+    refs, org = make_inter_picture(r, w, h, bd, nref, idc, slice_type)
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    st = states(r, 7)
+    org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]],
+                        np.uint64)
+    modes = set()
+    for lw in (3, 4, 5, 6):
+        cu = 1 << lw
+        P = make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th)
+        jobs = make_inter_jobs(r, 70, w, h, cu, len(st), refs, slice_type)
+        res, coef, rec, best = run_hip(refs, org, st, P, jobs)
+        nc = max(1, (cu >> refs["ws"]) * (cu >> refs["hs"]))
+        for i in range(len(jobs)):
+            er, eb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec = [np.zeros(cu * cu, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            ep = [x.copy() for x in ec]
+            O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]),
+                                   ptr(ec[1]), ptr(ec[2]), ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
+            key = (lw, i, jobs[i], res[i], er[0])
+            assert res[i:i + 1].tobytes() == er.tobytes(), key
+            for k in range(3 if idc else 1):
+                assert np.array_equal(coef[k][i], ec[k]) and np.array_equal(rec[k][i], ep[k]), (k,) + key
+            assert best[i:i + 1].tobytes() == eb.tobytes(), key
+            modes.add(int(er["best_idx"][0]))
+    assert len(modes) >= (4 if slice_type == 0 else 2), modes

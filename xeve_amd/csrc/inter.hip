@@ -1,0 +1,514 @@
+// xeve_amd/csrc/inter.hip -- the whole inter analysis of a batch of CUs of one size, composed on the device.
+//
+// reference: xeve_pinter_analyze_cu (src_base/xeve_pinter.c:1839-2047) = ctx->fn_pinter_analyze_cu, Baseline (tool_admvp 0):
+//   skip / merge analysis (xeve_analyze_skip)                                   -> xeve_hip_analyze_skip_jobs
+//   temporal direct (analyze_t_direct + xeve_get_mv_dir)                         -> a candidate of xeve_hip_residue_rdo_jobs
+//   per list: motion search over every reference picture (pi->fn_me = pinter_me_epzs), best reference picture, check_best_mvp
+//   (CABAC bit counts of mvp_idx + mvd for every predictor), pinter_residue_rdo  -> xeve_hip_me_epzs_jobs, xeve_hip_cu_bits_jobs, ..residue_rdo_jobs
+//   analyze_bi: up to BI_ITER rounds of {predict from the fixed list, org_bi = 2 * org - pred, search the other list over every reference
+//   picture from where its last search ended}, pinter_residue_rdo                -> xeve_hip_mc_cu_jobs, xeve_hip_me_epzs_jobs_x, ..residue_rdo_jobs
+//   the cheapest mode (first strictly smaller cost in the order skip, direct, L0, L1, bi), its coefficients, reconstruction
+//   (xeve_itdq + xeve_recon), motion data and coder state.
+// Everything heavy is one of the batched entry points; this file adds the per-CU glue kernels (one thread per CU: a few dozen scalar
+// operations each) that turn the results of one stage into the jobs of the next, so that the whole analysis of all CUs of a level runs
+// without a host round trip.  CUs whose skip residual is below the skip_th threshold stop after the skip mode in the reference; here they
+// ride along (skip_th is 0 in every preset, so this only concerns CUs with a perfect skip prediction) and are masked in the decision.
+#include "xh_common.h"
+
+#define MAXR XEVE_HIP_MAX_REFP
+#define MAX_COST 1.7e+308
+enum { M_L0 = 0, M_L1 = 1, M_BI = 2, M_SKIP = 3, M_DIR = 4, M_NUM = 5 }; // PRED_* (xeve_def.h:461-469)
+
+struct InterK {
+    int    n, isb, lw, n0, n1, ncomp, bd, max_cand, nref[2], nb, na; // na: candidates of the first pinter_residue_rdo batch (3n in B, n in P)
+    int    s_org_l;
+    int    dpoc_co, dpoc_l0, dpoc_l1;
+    double thr, lambda0;
+};
+
+struct InterSt { // per CU, between the stages
+    int16_t  mv[M_NUM][2][2], mvd[M_NUM][2][2];
+    int8_t   refi[M_NUM][2];
+    uint8_t  mvpi[M_NUM][2];
+    int16_t  mv_scale[2][MAXR][2];
+    int32_t  mot_bits[2];
+    int32_t  go, refi_sel[2];
+    // analyze_bi
+    int32_t  lidx_ref, active, refi_best;
+    uint32_t best_mecost;
+    int8_t   rf[2];
+    int8_t   pad_[2];
+};
+
+__device__ __forceinline__ void copy_sbac(xeve_hip_sbac *d, const xeve_hip_sbac *s)
+{
+    const unsigned *a = (const unsigned *)s;
+    unsigned       *b = (unsigned *)d;
+#pragma unroll
+    for(int i = 0; i < (int)(sizeof(xeve_hip_sbac) / 4); i++) b[i] = a[i];
+}
+
+__device__ __forceinline__ void rdo_job(xeve_hip_rdo_job &r, const xeve_hip_inter_job &J, const InterSt &S, int m, int dir)
+{
+    r.x = J.x, r.y = J.y;
+    for(int l = 0; l < 2; l++) r.mv[l][0] = S.mv[m][l][0], r.mv[l][1] = S.mv[m][l][1], r.mvd[l][0] = S.mvd[m][l][0], r.mvd[l][1] = S.mvd[m][l][1];
+    r.refi[0] = S.refi[m][0], r.refi[1] = S.refi[m][1], r.mvp_idx[0] = S.mvpi[m][0], r.mvp_idx[1] = S.mvpi[m][1];
+    r.dir_flag = (uint8_t)dir, r.ctx_skip = J.ctx_skip, r.ctx_pred_mode = J.ctx_pred_mode, r.pad_ = 0, r.sbac = J.sbac;
+}
+
+// ---- skip --------------------------------------------------------------------------------------------------------------------
+__global__ void k_inter_skip_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, xeve_hip_skip_job *__restrict__ sj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job J = jobs[j];
+    xeve_hip_skip_job s;
+    s.x = J.x, s.y = J.y;
+    for(int l = 0; l < 2; l++)
+        for(int i = 0; i < 4; i++) s.mvp[l][i][0] = J.mvp[l][i][0], s.mvp[l][i][1] = J.mvp[l][i][1], s.refi_pred[l][i] = 0; // xeve_get_motion: always index 0
+    s.ncand = P.max_cand, s.sbac = J.sbac, s.ctx_skip = J.ctx_skip, s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
+    sj[j] = s;
+}
+
+// after the skip analysis: does the CU go on (:1885-1887); the direct candidate (analyze_t_direct, xeve_get_mv_dir); the search jobs
+__global__ void k_inter_stage1(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const xeve_hip_skip_result *__restrict__ sres, InterSt *__restrict__ st,
+                               xeve_hip_rdo_job *__restrict__ rj, xeve_hip_epzs_job *__restrict__ ej)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job   J = jobs[j];
+    const xeve_hip_skip_result R = sres[j];
+    InterSt S;
+    for(int i = 0; i < (int)(sizeof(S) / 4); i++) ((int *)&S)[i] = 0;
+    for(int l = 0; l < 2; l++) S.mv[M_SKIP][l][0] = R.mv[l][0], S.mv[M_SKIP][l][1] = R.mv[l][1], S.refi[M_SKIP][l] = R.refi[l];
+    if(!P.isb) S.mv[M_SKIP][1][0] = S.mv[M_SKIP][1][1] = 0;
+    S.mvpi[M_SKIP][0] = (uint8_t)R.idx0, S.mvpi[M_SKIP][1] = (uint8_t)R.idx1;
+    S.go = R.cost < MAX_COST && (double)R.best_ssd > P.thr;
+    S.active = 1, S.best_mecost = 0xFFFFFFFFu;
+    if(P.isb) {
+        if(P.dpoc_co != 0) {
+            S.mv[M_DIR][0][0] = (int16_t)(P.dpoc_l0 * J.mv_col[0] / P.dpoc_co), S.mv[M_DIR][0][1] = (int16_t)(P.dpoc_l0 * J.mv_col[1] / P.dpoc_co);
+            S.mv[M_DIR][1][0] = (int16_t)(-P.dpoc_l1 * J.mv_col[0] / P.dpoc_co), S.mv[M_DIR][1][1] = (int16_t)(-P.dpoc_l1 * J.mv_col[1] / P.dpoc_co);
+        }
+        rdo_job(rj[j], J, S, M_DIR, 1);
+    }
+    for(int l = 0; l <= P.isb; l++) {
+        xeve_hip_epzs_job e;
+        const int idx = S.mvpi[M_SKIP][l]; // mvp_idx[lidx] = pi->mvp_idx[PRED_SKIP][lidx] (:1927)
+        e.x = J.x, e.y = J.y, e.org_off = 0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1], e.mv_start[0] = e.mv_start[1] = 0;
+        ej[l * P.n + j] = e;
+    }
+    st[j] = S;
+}
+
+// ---- uni-directional modes -------------------------------------------------------------------------------------------------------
+// after the searches of one list: best reference picture (first strictly smaller mecost, :1945-1948), pi->mot_bits as the LAST search left it,
+// and the five bit-count jobs of check_best_mvp (entry index, then indices 0..3)
+__global__ void k_inter_uni_a(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const xeve_hip_me_result *__restrict__ mres, InterSt *__restrict__ st,
+                              xeve_hip_cu_bits_job *__restrict__ bj)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= P.n * (1 + P.isb)) return;
+    const int l = t / P.n, j = t - l * P.n;
+    const xeve_hip_inter_job J = jobs[j];
+    InterSt &S = st[j];
+    unsigned best = 0xFFFFFFFFu;
+    int      rsel = 0;
+    for(int r = 0; r < P.nref[l]; r++) {
+        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + j];
+        S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1];
+        if(m.cost < best) best = m.cost, rsel = r;
+        if(m.best_mv_bits > 0) S.mot_bits[l] = m.best_mv_bits;
+    }
+    S.refi_sel[l] = rsel;
+    const int mvx = S.mv_scale[l][rsel][0], mvy = S.mv_scale[l][rsel][1];
+    S.mv[l][l][0] = (int16_t)mvx, S.mv[l][l][1] = (int16_t)mvy;
+    S.refi[l][l] = (int8_t)rsel, S.refi[l][1 - l] = -1;
+    const int entry = S.mvpi[M_SKIP][l];
+    for(int k = 0; k < 5; k++) {
+        const int idx = k == 0 ? entry : k - 1;
+        xeve_hip_cu_bits_job b;
+        b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
+        b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0;
+        b.mvd[l][0] = (int16_t)(mvx - J.mvp[l][idx][0]), b.mvd[l][1] = (int16_t)(mvy - J.mvp[l][idx][1]);
+        b.refi[l] = (int8_t)rsel, b.refi[1 - l] = -1, b.mvp_idx[0] = b.mvp_idx[1] = (uint8_t)idx;
+        b.mode = XEVE_HIP_BITS_MVP, b.dir_flag = 0, b.ctx_skip = 0, b.ctx_pred_mode = 0;
+        bj[(size_t)t * 5 + k] = b;
+    }
+}
+
+// check_best_mvp (:1773-1837): the LAST unpruned index cheaper than the entry index wins (best_cost is never updated); the candidates of
+// pinter_residue_rdo for L0 / L1 with the local mvp_idx pair as it stands after each list
+__global__ void k_inter_uni_b(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const unsigned *__restrict__ bits, InterSt *__restrict__ st,
+                              xeve_hip_rdo_job *__restrict__ rj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job J = jobs[j];
+    InterSt S = st[j];
+    uint8_t pair[2] = {0, 0};
+    for(int l = 0; l <= P.isb; l++) {
+        const unsigned *b = bits + ((size_t)l * P.n + j) * 5;
+        const double best_cost = (double)(int)b[0] * P.lambda0;
+        int best_idx = S.mvpi[M_SKIP][l];
+        for(int idx = 0; idx < 4; idx++) {
+            bool same = false;
+            for(int t = 0; t < idx; t++) same = same || (J.mvp[l][idx][0] == J.mvp[l][t][0] && J.mvp[l][idx][1] == J.mvp[l][t][1]);
+            if(same) continue;
+            if((double)(int)b[1 + idx] * P.lambda0 < best_cost) best_idx = idx;
+        }
+        pair[l] = (uint8_t)best_idx;
+        S.mvd[l][l][0] = (int16_t)(S.mv[l][l][0] - J.mvp[l][best_idx][0]), S.mvd[l][l][1] = (int16_t)(S.mv[l][l][1] - J.mvp[l][best_idx][1]);
+        S.mvpi[l][0] = pair[0], S.mvpi[l][1] = pair[1];
+        rdo_job(rj[(size_t)(P.isb ? 1 + l : 0) * P.n + j], J, S, l, 0);
+    }
+    st[j] = S;
+}
+
+// ---- analyze_bi (:1567-1714) -------------------------------------------------------------------------------------------------------
+__global__ void k_bi_init(InterK P, const xeve_hip_rdo_result *__restrict__ rres, InterSt *__restrict__ st)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    InterSt &S = st[j];
+    const int lref = rres[P.n + j].cost <= rres[2 * (size_t)P.n + j].cost ? 0 : 1; // cost_inter[PRED_L0] <= cost_inter[PRED_L1]
+    S.lidx_ref = lref;
+    S.mvpi[M_BI][0] = S.mvpi[M_L0][0], S.mvpi[M_BI][1] = S.mvpi[M_L1][1], S.refi[M_BI][0] = S.refi[M_L0][0], S.refi[M_BI][1] = S.refi[M_L1][1];
+    S.mv[M_BI][0][0] = S.mv[M_L0][0][0], S.mv[M_BI][0][1] = S.mv[M_L0][0][1], S.mv[M_BI][1][0] = S.mv[M_L1][1][0], S.mv[M_BI][1][1] = S.mv[M_L1][1][1];
+    S.rf[lref] = S.refi[M_BI][lref], S.rf[1 - lref] = -1;
+}
+
+// one round, first half: the prediction from the fixed list
+__global__ void k_bi_mc_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, xeve_hip_cu_mc_job *__restrict__ mc)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const InterSt &S = st[j];
+    xeve_hip_cu_mc_job m;
+    m.x = jobs[j].x, m.y = jobs[j].y, m.pad_[0] = m.pad_[1] = 0;
+    for(int l = 0; l < 2; l++) m.mv[l][0] = S.mv[M_BI][l][0], m.mv[l][1] = S.mv[M_BI][l][1], m.refi[l] = S.active ? S.rf[l] : -1;
+    mc[j] = m;
+}
+
+// get_org_bi (:143-156) for every CU, then the list swap and the search jobs of the round: both lists for every CU (the CUs of a batch
+// differ in which list they search; the results of the other one are not used)
+__global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const pel *__restrict__ org, const pel *__restrict__ pred, int16_t *__restrict__ org_bi)
+{
+    const int nbx = P.n0 >= 1024 ? 4 : 1, j = blockIdx.x / nbx, bx = blockIdx.x % nbx, w = 1 << P.lw;
+    const xeve_hip_inter_job J = jobs[j];
+    for(int i = bx * blockDim.x + threadIdx.x; i < P.n0; i += nbx * blockDim.x) {
+        const int yy = i >> P.lw, xx = i & (w - 1);
+        org_bi[(size_t)j * P.n0 + i] = (int16_t)((org[(size_t)(J.y + yy) * P.s_org_l + J.x + xx] << 1) - pred[(size_t)j * P.n0 + i]);
+    }
+}
+
+__global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_epzs_job *__restrict__ ej,
+                             int32_t *__restrict__ extra)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job J = jobs[j];
+    InterSt &S = st[j];
+    if(S.active) { // SWAP(refi[lidx_ref], refi[lidx_cnd]), SWAP(lidx_ref, lidx_cnd) (:1626-1628)
+        const int8_t t = S.rf[0];
+        S.rf[0] = S.rf[1], S.rf[1] = t;
+        S.lidx_ref = 1 - S.lidx_ref;
+    }
+    for(int l = 0; l < 2; l++) {
+        const int idx = S.mvpi[M_BI][l];
+        extra[(size_t)l * P.n + j] = S.mot_bits[1 - l];
+        for(int r = 0; r < P.nb; r++) {
+            xeve_hip_epzs_job e;
+            e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
+            e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
+            ej[((size_t)l * MAXR + r) * P.n + j] = e;
+        }
+    }
+}
+
+// one round, second half (:1633-1663): every reference picture of the searched list against the running best
+__global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mres, InterSt *__restrict__ st)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    InterSt &S = st[j];
+    if(!S.active) return;
+    const int l = S.lidx_ref;
+    int changed = 0;
+    for(int r = 0; r < P.nb; r++) {
+        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + j];
+        S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1]; // fn_me refines pi->mv_scale[lidx_ref][refi_cur] in place
+        if(m.cost < S.best_mecost) {
+            S.refi_best = r, S.best_mecost = m.cost, changed = 1;
+            S.refi[M_BI][l] = (int8_t)r;
+            S.mv[M_BI][l][0] = m.mv[0], S.mv[M_BI][l][1] = m.mv[1];
+        }
+    }
+    S.rf[l] = (int8_t)S.refi_best, S.rf[1 - l] = -1;
+    if(!changed) S.active = 0;
+}
+
+__global__ void k_bi_finish(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_rdo_job *__restrict__ rj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job J = jobs[j];
+    InterSt &S = st[j];
+    for(int l = 0; l < 2; l++)
+        for(int d = 0; d < 2; d++) S.mvd[M_BI][l][d] = (int16_t)(S.mv[M_BI][l][d] - J.mvp[l][S.mvpi[M_BI][l]][d]);
+    rdo_job(rj[j], J, S, M_BI, 0);
+}
+
+// ---- the decision (:1872-2001) and the winner's data ---------------------------------------------------------------------------------
+__global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, const xeve_hip_skip_result *__restrict__ sres,
+                               const xeve_hip_rdo_result *__restrict__ ra, const xeve_hip_rdo_result *__restrict__ rb, xeve_hip_inter_result *__restrict__ res,
+                               int *__restrict__ win, xeve_hip_cu_mc_job *__restrict__ mc)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const InterSt &S = st[j];
+    double ci[M_NUM];
+    int    nz[M_NUM][3];
+    for(int m = 0; m < M_NUM; m++) ci[m] = MAX_COST, nz[m][0] = nz[m][1] = nz[m][2] = 0;
+    ci[M_SKIP] = sres[j].cost;
+    if(S.go) {
+        auto take = [&](int m, const xeve_hip_rdo_result &r) { ci[m] = r.cost, nz[m][0] = r.nnz[0], nz[m][1] = r.nnz[1], nz[m][2] = r.nnz[2]; };
+        if(P.isb) take(M_DIR, ra[j]), take(M_L0, ra[P.n + j]), take(M_L1, ra[2 * (size_t)P.n + j]), take(M_BI, rb[j]);
+        else take(M_L0, ra[j]);
+    }
+    double cost_best = MAX_COST;
+    int    best = M_SKIP, cu_mode = -1;
+    const int order[5] = {M_SKIP, M_DIR, M_L0, M_L1, M_BI};
+    for(int k = 0; k < 5; k++) {
+        const int m = order[k];
+        if(ci[m] < cost_best) cost_best = ci[m], best = m, cu_mode = m == M_SKIP ? 2 : m == M_DIR ? 3 : 1;
+    }
+    xeve_hip_inter_result R;
+    for(int i = 0; i < (int)(sizeof(R) / 4); i++) ((int *)&R)[i] = 0;
+    R.cost = ci[best];
+    for(int m = 0; m < M_NUM; m++) R.cost_inter[m] = ci[m];
+    R.cu_mode = cu_mode, R.best_idx = best;
+    for(int l = 0; l < 2; l++) {
+        const bool lst = P.isb || l == 0, used = lst && S.refi[best][l] >= 0;
+        R.refi[l] = lst ? S.refi[best][l] : -1;
+        if(used) R.mv[l][0] = S.mv[best][l][0], R.mv[l][1] = S.mv[best][l][1], R.mvd[l][0] = S.mvd[best][l][0], R.mvd[l][1] = S.mvd[best][l][1], R.mvp_idx[l] = S.mvpi[best][l];
+    }
+    if(best == M_DIR) R.mvp_idx[0] = R.mvp_idx[1] = 0;
+    R.nnz[0] = nz[best][0], R.nnz[1] = nz[best][1], R.nnz[2] = nz[best][2];
+    res[j] = R;
+    win[j] = best;
+    xeve_hip_cu_mc_job m; // the winner's prediction (a skipped CU keeps the one the skip analysis produced)
+    m.x = jobs[j].x, m.y = jobs[j].y, m.pad_[0] = m.pad_[1] = 0;
+    for(int l = 0; l < 2; l++) m.mv[l][0] = S.mv[best][l][0], m.mv[l][1] = S.mv[best][l][1], m.refi[l] = best == M_SKIP ? -1 : S.refi[best][l];
+    mc[j] = m;
+}
+
+// per (CU, component): the winner's coefficients out (zero for a skipped CU) and into the scratch block that is dequantised; the skip
+// prediction where the CU is skipped; is_coef; the coder state
+__global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hip_inter_result *__restrict__ res, const int16_t *__restrict__ coef_a,
+                            const int16_t *__restrict__ coef_b, int16_t *__restrict__ coef_out, int16_t *__restrict__ tmp, pel *__restrict__ pred_y,
+                            pel *__restrict__ pred_u, pel *__restrict__ pred_v, const pel *__restrict__ sk_y, const pel *__restrict__ sk_u, const pel *__restrict__ sk_v,
+                            unsigned char *__restrict__ is_coef, const xeve_hip_sbac *__restrict__ st_skip, const xeve_hip_sbac *__restrict__ st_a,
+                            const xeve_hip_sbac *__restrict__ st_b, xeve_hip_sbac *__restrict__ next_best)
+{
+    const int j = blockIdx.x / 3, k = blockIdx.x % 3, best = win[j];
+    if(k && P.ncomp == 1) return;
+    const int    nk = k ? P.n1 : P.n0;
+    const size_t n = P.n;
+    // where the winner's block lives: batch A holds [DIR, L0, L1] (B slices) or [L0] (P slices), batch B the bi candidate
+    const int      slot = best == M_BI ? j : (P.isb ? (best == M_DIR ? 0 : best == M_L0 ? 1 : 2) * P.n + j : j);
+    const size_t   nn = best == M_BI ? n : (size_t)P.na;
+    const int16_t *src = (best == M_BI ? coef_b : coef_a) + (k == 0 ? (size_t)slot * P.n0 : nn * P.n0 + (size_t)(k - 1) * nn * P.n1 + (size_t)slot * P.n1);
+    int16_t       *dst = coef_out + (k == 0 ? (size_t)j * P.n0 : n * P.n0 + (size_t)(k - 1) * n * P.n1 + (size_t)j * P.n1);
+    int16_t       *t = tmp + (k == 0 ? (size_t)j * P.n0 : n * P.n0 + (size_t)(k - 1) * n * P.n1 + (size_t)j * P.n1);
+    const bool     skip = best == M_SKIP;
+    for(int i = threadIdx.x; i < nk; i += blockDim.x) {
+        const int16_t v = skip ? (int16_t)0 : src[i];
+        dst[i] = v, t[i] = v;
+    }
+    if(skip) {
+        const pel *s = (k == 0 ? sk_y : k == 1 ? sk_u : sk_v) + (size_t)j * nk;
+        pel       *d = (k == 0 ? pred_y : k == 1 ? pred_u : pred_v) + (size_t)j * nk;
+        for(int i = threadIdx.x; i < nk; i += blockDim.x) d[i] = s[i];
+    }
+    if(threadIdx.x == 0) {
+        is_coef[(size_t)k * n + j] = res[j].nnz[k] != 0;
+        if(k == 0 && res[j].cu_mode >= 0) copy_sbac(next_best + j, skip ? st_skip + j : best == M_BI ? st_b + j : st_a + slot);
+    }
+}
+
+__global__ void k_iota_off(int n, int step, int32_t *__restrict__ off)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < n) off[j] = j * step;
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------------
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+struct InterLayout {
+    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, win, tmp, is_coef, off[2],
+        scratch, scratch_bytes, total;
+};
+
+static xeve_hip_rdo_params rdo_of(const xeve_hip_inter_params *p) { return p->rdo; }
+
+static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params *p, int s_org_l, int s_org_c)
+{
+    InterLayout L;
+    const xeve_hip_rdo_params rp = rdo_of(p);
+    const int    isb = rp.slice_type == 0, idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
+    const size_t N = n, n0 = (size_t)1 << (rp.log2_cuw + rp.log2_cuh), n1 = idc ? n0 >> (ws + hs) : 0, na = isb ? 3 * N : N, ne = n0 + 2 * n1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    L.st = take(N * sizeof(InterSt)), L.sj = take(N * sizeof(xeve_hip_skip_job)), L.sres = take(N * sizeof(xeve_hip_skip_result));
+    L.sk[0] = take(N * n0 * 2), L.sk[1] = take(N * n1 * 2 + 8), L.sk[2] = take(N * n1 * 2 + 8), L.st_skip = take(N * sizeof(xeve_hip_sbac));
+    L.ej = take(2 * MAXR * N * sizeof(xeve_hip_epzs_job)), L.mres = take(2 * MAXR * N * sizeof(xeve_hip_me_result));
+    L.bjm = take(10 * N * sizeof(xeve_hip_cu_bits_job)), L.bitsm = take(10 * N * 4);
+    L.rja = take(na * sizeof(xeve_hip_rdo_job)), L.rra = take(na * sizeof(xeve_hip_rdo_result)), L.coef_a = take(na * ne * 2), L.st_a = take(na * sizeof(xeve_hip_sbac));
+    L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2), L.st_b = take(N * sizeof(xeve_hip_sbac));
+    L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
+    L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
+    L.org_bi = take(N * n0 * 2), L.extra = take(2 * N * 4), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
+    L.off[0] = take(N * 4), L.off[1] = take(N * 4);
+    // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
+    size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
+    s = max2(s, xeve_hip_me_epzs_workspace(n));
+    s = max2(s, xeve_hip_cu_bits_workspace(10 * n, 64));
+    s = max2(s, xeve_hip_residue_rdo_workspace((int)na, nstates, &rp, s_org_l, s_org_c));
+    s = max2(s, xeve_hip_mc_cu_workspace(n, 1 << rp.log2_cuw, 1 << rp.log2_cuh, rp.num_refp[0], rp.num_refp[1]));
+    L.scratch = take(s), L.scratch_bytes = s;
+    L.total = o;
+    return L;
+}
+
+static bool inter_params_ok(const xeve_hip_inter_params *p)
+{
+    const xeve_hip_rdo_params &r = p->rdo;
+    return r.log2_cuw == r.log2_cuh && r.log2_cuw >= 3 && r.log2_cuw <= 6 && (r.slice_type == 0 || r.slice_type == 1) && r.tool_iqt == 0 &&
+           (r.chroma_format_idc == 0 || r.chroma_format_idc == 1 || r.chroma_format_idc == 3) && r.num_refp[0] >= 1 && r.num_refp[0] <= MAXR &&
+           (r.slice_type == 1 || (r.num_refp[1] >= 1 && r.num_refp[1] <= r.num_refp[0])) && p->max_cand >= 1 && p->max_cand <= 4;
+}
+
+extern "C" size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_inter_params *p, int s_org_l, int s_org_c)
+{
+    if(!p || njobs <= 0 || nstates <= 0 || !inter_params_ok(p)) return 256;
+    return inter_layout(njobs, nstates, p, s_org_l, s_org_c).total;
+}
+
+extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
+                                               const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *p, const xeve_hip_inter_job *jobs,
+                                               int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *results,
+                                               int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *next_best,
+                                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && rec_y && next_best && workspace && coef_l);
+    XH_REQUIRE(inter_params_ok(p));
+    const xeve_hip_rdo_params rp = p->rdo;
+    const int idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = rp.bit_depth, lw = rp.log2_cuw, w = 1 << lw;
+    XH_REQUIRE(org[0] && (idc == 0 || (org[1] && org[2] && coef_c && rec_u && rec_v)));
+    if(njobs == 0) return XEVE_HIP_OK;
+    const InterLayout L = inter_layout(njobs, nstates, p, s_org_l, s_org_c);
+    XH_REQUIRE(workspace_bytes >= L.total);
+    InterK P;
+    P.n = njobs, P.isb = rp.slice_type == 0, P.lw = lw, P.n0 = w * w, P.n1 = idc ? P.n0 >> (ws + hs) : 0, P.ncomp = idc ? 3 : 1, P.bd = bd;
+    P.max_cand = p->max_cand, P.nref[0] = rp.num_refp[0], P.nref[1] = P.isb ? rp.num_refp[1] : 0, P.nb = rp.num_refp[1], P.na = P.isb ? 3 * njobs : njobs;
+    P.s_org_l = s_org_l;
+    P.dpoc_co = refp[0 * 2 + 1].poc - p->col_list_poc0, P.dpoc_l0 = p->poc - refp[0 * 2 + 0].poc, P.dpoc_l1 = refp[0 * 2 + 1].poc - p->poc; // xeve_util.c:634-636
+    P.thr = (double)((int64_t)1 << (2 * lw + 2 * (bd - 8))) * p->skip_th, P.lambda0 = rp.lambda[0];
+    char *W = (char *)workspace;
+    auto *st = (InterSt *)(W + L.st);
+    auto *sj = (xeve_hip_skip_job *)(W + L.sj);
+    auto *sres = (xeve_hip_skip_result *)(W + L.sres);
+    pel  *sk[3] = {(pel *)(W + L.sk[0]), (pel *)(W + L.sk[1]), (pel *)(W + L.sk[2])}, *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
+    auto *st_skip = (xeve_hip_sbac *)(W + L.st_skip), *st_a = (xeve_hip_sbac *)(W + L.st_a), *st_b = (xeve_hip_sbac *)(W + L.st_b);
+    auto *ej = (xeve_hip_epzs_job *)(W + L.ej);
+    auto *mres = (xeve_hip_me_result *)(W + L.mres);
+    auto *bjm = (xeve_hip_cu_bits_job *)(W + L.bjm);
+    auto *bitsm = (unsigned *)(W + L.bitsm);
+    auto *rja = (xeve_hip_rdo_job *)(W + L.rja), *rjb = (xeve_hip_rdo_job *)(W + L.rjb);
+    auto *rra = (xeve_hip_rdo_result *)(W + L.rra), *rrb = (xeve_hip_rdo_result *)(W + L.rrb);
+    auto *coef_a = (int16_t *)(W + L.coef_a), *coef_b = (int16_t *)(W + L.coef_b), *tmp = (int16_t *)(W + L.tmp), *org_bi = (int16_t *)(W + L.org_bi);
+    auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
+    auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win), *off0 = (int32_t *)(W + L.off[0]), *off1 = (int32_t *)(W + L.off[1]);
+    auto *is_coef = (unsigned char *)(W + L.is_coef);
+    void *scr = W + L.scratch;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (njobs + 255) / 256;
+    int rc;
+
+    // skip mode
+    k_inter_skip_jobs<<<G, 256, 0, s>>>(jobs, P, sj);
+    rc = xeve_hip_analyze_skip_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, sj, njobs, p->max_cand, coef_l, coef_c, sres, sk[0], sk[1], sk[2],
+                                    st_skip, scr, L.scratch_bytes, stream);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_inter_stage1<<<G, 256, 0, s>>>(jobs, P, sres, st, rja, ej);
+    // motion search per list and reference picture (:1906-1950)
+    xeve_hip_epzs_params ep = p->me;
+    for(int l = 0; l <= P.isb; l++)
+        for(int r = 0; r < P.nref[l]; r++) {
+            XH_REQUIRE(refp[r * 2 + l].y);
+            ep.me.bi = 0, ep.me.extra_bits = 0, ep.me.refi_bits = p->refi_bits[l][r], ep.me.range_recentre = p->range_recentre[l][r];
+            rc = xeve_hip_me_epzs_jobs(org[0], s_org_l, nullptr, refp[r * 2 + l].y, s_l, ej + (size_t)l * njobs, njobs, lw, lw, bd, coef_l, &ep,
+                                       mres + ((size_t)l * MAXR + r) * njobs, scr, L.scratch_bytes, stream);
+            if(rc != XEVE_HIP_OK) return rc;
+        }
+    // check_best_mvp, then pinter_residue_rdo of direct + L0 + L1 in one batch
+    const int nl = 1 + P.isb;
+    k_inter_uni_a<<<(nl * njobs + 255) / 256, 256, 0, s>>>(jobs, P, mres, st, bjm);
+    xeve_hip_cu_bits_params bp;
+    bp.log2_cuw = lw, bp.log2_cuh = lw, bp.slice_type = rp.slice_type, bp.num_refp[0] = rp.num_refp[0], bp.num_refp[1] = rp.num_refp[1], bp.cm_init = 0,
+    bp.chroma_format_idc = idc;
+    rc = xeve_hip_cu_bits_jobs((const int16_t *)sk[0], 64, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_inter_uni_b<<<G, 256, 0, s>>>(jobs, P, bitsm, st, rja);
+    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream);
+    if(rc != XEVE_HIP_OK) return rc;
+    if(P.isb) { // analyze_bi
+        k_bi_init<<<G, 256, 0, s>>>(P, rra, st);
+        for(int it = 0; it < 4; it++) { // BI_ITER
+            k_bi_mc_jobs<<<G, 256, 0, s>>>(jobs, P, st, mc);
+            rc = xeve_hip_mc_cu_jobs(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, mc, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
+                                     pred[2], scr, L.scratch_bytes, stream);
+            if(rc != XEVE_HIP_OK) return rc;
+            k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], org_bi);
+            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra);
+            for(int l = 0; l < 2; l++)
+                for(int r = 0; r < P.nb; r++) {
+                    ep.me.bi = 1, ep.me.extra_bits = 0, ep.me.refi_bits = p->refi_bits[1][r], ep.me.range_recentre = p->range_recentre[l][r];
+                    rc = xeve_hip_me_epzs_jobs_x(org[0], s_org_l, (const pel *)org_bi, refp[r * 2 + l].y, s_l, ej + ((size_t)l * MAXR + r) * njobs, njobs, lw, lw, bd, coef_l,
+                                                 &ep, extra + (size_t)l * njobs, mres + ((size_t)l * MAXR + r) * njobs, scr, L.scratch_bytes, stream);
+                    if(rc != XEVE_HIP_OK) return rc;
+                }
+            k_bi_update<<<G, 256, 0, s>>>(P, mres, st);
+        }
+        k_bi_finish<<<G, 256, 0, s>>>(jobs, P, st, rjb);
+        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, st_b, scr, L.scratch_bytes,
+                                       stream);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    // the decision; the winner's prediction, coefficients, reconstruction (:2004-2032) and coder state
+    k_inter_decide<<<G, 256, 0, s>>>(jobs, P, st, sres, rra, rrb, results, win, mc);
+    rc = xeve_hip_mc_cu_jobs(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, mc, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1], pred[2],
+                             scr, L.scratch_bytes, stream);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, tmp, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], is_coef, st_skip, st_a, st_b, next_best);
+    k_iota_off<<<G, 256, 0, s>>>(njobs, P.n0, off0);
+    k_iota_off<<<G, 256, 0, s>>>(njobs, P.n1, off1);
+    static const int k_dq_scale[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237)
+    pel *rec[3] = {rec_y, rec_u, rec_v};
+    for(int k = 0; k < P.ncomp; k++) {
+        const int lk = k ? lw - ws : lw, lhk = k ? lw - hs : lw, q = rp.qp[k];
+        XH_REQUIRE(q >= 0 && q <= 63);
+        int16_t *t = tmp + (k == 0 ? 0 : (size_t)njobs * P.n0 + (size_t)(k - 1) * njobs * P.n1);
+        rc = xeve_hip_dquant(t, njobs, lk, lhk, k_dq_scale[q % 6] << (q / 6), bd, stream);
+        if(rc == XEVE_HIP_OK) rc = xeve_hip_itrans(t, njobs, lk, lhk, bd, stream);
+        if(rc == XEVE_HIP_OK)
+            rc = xeve_hip_recon(t, pred[k], is_coef + (size_t)k * njobs, njobs, 1 << lk, 1 << lhk, k ? off1 : off0, 1 << lk, rec[k], bd, stream);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -337,7 +337,7 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
 }
 
 __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, xeve_hip_spel_params P,
-                              const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res)
+                              const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
@@ -350,7 +350,7 @@ __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int nj
     for(int i = 0; i < cnt; i++) {
         const int mx = cx + pat[i][0], my = cy + pat[i][1];
         int bits = xh_mvd_bits(mx - jb.gmvp[0]) + xh_mvd_bits(my - jb.gmvp[1]) + P.refi_bits;
-        if(P.bi) bits += P.extra_bits;
+        if(P.bi) bits += extra ? extra[j] : P.extra_bits;
         const int s = sad[j * cnt + i];
         const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(P.bi ? s >> 1 : s);
         if(cost < r.cost) {
@@ -367,6 +367,15 @@ extern "C" int xeve_hip_me_spel_pattern_jobs(const pel *org0, int s_org, const p
                                              const xeve_hip_spel_job *jobs, int njobs, int log2w, int log2h, int bit_depth,
                                              const int16_t (*coef)[8], const xeve_hip_spel_params *params, xeve_hip_me_result *results,
                                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, log2w, log2h, bit_depth, coef, params, nullptr, results, workspace,
+                                     workspace_bytes, stream);
+}
+
+// extra: pi->mot_bits[other list] per job (device memory) instead of params->extra_bits; NULL = the common value
+int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
+                              int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
+                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
@@ -390,7 +399,7 @@ extern "C" int xeve_hip_me_spel_pattern_jobs(const pel *org0, int s_org, const p
         XH_HIP(hipGetLastError());
         int rc = mc_launch<8, 1>(ref0, s_ref, nullptr, 0, mc, items, w, h, bit_depth, &coef[0][0], st, cmp, s_c, sad);
         if(rc != XEVE_HIP_OK) return rc;
-        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, sad, results);
+        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, extra, sad, results);
         XH_HIP(hipGetLastError());
     }
     return XEVE_HIP_OK;

@@ -216,12 +216,14 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
 // launch, no host round trip between the searches, the original block stays in registers across them.
 template <int S, bool BI>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
-                                                 const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P, EpzsState *__restrict__ st)
+                                                 const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
+                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st)
 {
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     const xeve_hip_epzs_job e = jobs[j];
+    if(BI && extra) P.extra_bits = uni(extra[j]); // pi->mot_bits[other list] of this CU
     const int sx = P.bi == 1 ? e.mv_start[0] : e.mvp[0], sy = P.bi == 1 ? e.mv_start[1] : e.mvp[1];
     xeve_hip_me_job m;
     m.x = e.x, m.y = e.y, m.org_off = e.org_off, m.beststep_in = 0;
@@ -289,6 +291,15 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
                                      const xeve_hip_epzs_params *params, xeve_hip_me_result *results, void *workspace, size_t workspace_bytes,
                                      void *stream)
 {
+    return xeve_hip_me_epzs_jobs_x(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, log2w, log2h, bit_depth, coef, params, nullptr, results, workspace,
+                                   workspace_bytes, stream);
+}
+
+extern "C" int xeve_hip_me_epzs_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs,
+                                       int njobs, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
+                                       const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
     XH_ENTER();
     XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
     XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
@@ -309,8 +320,8 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
         const int  shift = bit_depth - 8;
 #define EPZS_LAUNCH(S)                                                                                                     \
     do {                                                                                                                   \
-        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, state);   \
-        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, state);      \
+        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state);   \
+        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state);      \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);
         else if(log2w == 4) EPZS_LAUNCH(16);
@@ -324,8 +335,8 @@ extern "C" int xeve_hip_me_epzs_jobs(const pel *org0, int s_org, const pel *org_
     xeve_hip_spel_params SP;
     SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;
     SP.hpel_cnt = params->hpel_cnt, SP.qpel_cnt = params->qpel_cnt;
-    int rc = xeve_hip_me_spel_pattern_jobs(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, sres, sws,
-                                           xeve_hip_me_spel_workspace(njobs), st);
+    int rc = xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, extra_bits, sres, sws,
+                                       xeve_hip_me_spel_workspace(njobs), st);
     if(rc != XEVE_HIP_OK) return rc;
     k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
     XH_HIP(hipGetLastError());

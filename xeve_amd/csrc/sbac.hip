@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned ev_pack(int v, int run, int at_end)
 // which components of a job are coded (xeve_eco_coefficient: nnz_sub[c] && run[c]; cbf_all == 0 codes nothing)
 __device__ __forceinline__ unsigned coded_mask(const xeve_hip_cu_bits_job &j)
 {
-    if(j.mode == XEVE_HIP_BITS_CU_SKIP) return 0;
+    if(j.mode == XEVE_HIP_BITS_CU_SKIP || j.mode == XEVE_HIP_BITS_MVP) return 0;
     unsigned m = (j.nnz[0] ? 1u : 0u) | (j.nnz[1] ? 2u : 0u) | (j.nnz[2] ? 4u : 0u);
     if(j.mode == XEVE_HIP_BITS_ECO_COEF) return m & ((j.dir_flag >> 2) & 7u);
     if(j.mode != XEVE_HIP_BITS_CU_INTER) m &= 1u << (j.mode - 1);
@@ -217,6 +217,11 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
             q_mvp_idx(Q, J.mvp_idx[0]);
             if(st == 0) q_mvp_idx(Q, J.mvp_idx[1]);
         }
+        return 0;
+    }
+    if(J.mode == XEVE_HIP_BITS_MVP) { // xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): what check_best_mvp prices
+        if(st != 2 && J.refi[0] >= 0) q_mvp_idx(Q, J.mvp_idx[0]), q_mvd1(Q, J.mvd[0][0]), q_mvd1(Q, J.mvd[0][1]);
+        if(st == 0 && J.refi[1] >= 0) q_mvp_idx(Q, J.mvp_idx[1]), q_mvd1(Q, J.mvd[1][0]), q_mvd1(Q, J.mvd[1][1]);
         return 0;
     }
     if(J.mode == XEVE_HIP_BITS_ECO_COEF) { // ctx->fn_eco_coef on its own: xeve_eco_cbf (xeve_eco.c:793-894) for an inter or an intra CU

@@ -266,6 +266,32 @@ def analyze_skip_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params
     return res, py, pu, pv, best
 
 
+def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None):
+    """the whole inter analysis of a batch of CUs (xeve_hip_pinter_analyze_cu_jobs).  params: lib.InterParams; jobs: uint8 tensor of lib.INTER_JOB_DTYPE
+    records.  Returns (results uint8 [njobs, 96], coef int16 flat [Y blocks | U blocks | V blocks], rec_y, rec_u, rec_v int16 [njobs, n],
+    next_best uint8 [njobs, 172])."""
+    L = _lib.load()
+    rp = params.rdo
+    njobs, nstates, dev = jobs.numel() // 52, states.numel() // 172, jobs.device
+    ws, hs = (1 if rp.chroma_format_idc <= 2 else 0), (1 if rp.chroma_format_idc <= 1 else 0)
+    n0 = 1 << (rp.log2_cuw + rp.log2_cuh)
+    n1 = (n0 >> (ws + hs)) if rp.chroma_format_idc else 0
+    res = torch.empty((njobs, 96), dtype=torch.uint8, device=dev)
+    coef = torch.empty(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
+    ry = torch.zeros((njobs, n0), dtype=torch.int16, device=dev)
+    ru, rv = (torch.zeros((njobs, max(n1, 1)), dtype=torch.int16, device=dev) for _ in range(2))
+    nb = torch.zeros((njobs, 172), dtype=torch.uint8, device=dev)
+    need = L.xeve_hip_pinter_analyze_cu_workspace(njobs, nstates, C.byref(params), s_org_l, s_org_c)
+    if workspace is None:
+        workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
+    cl, cc = C.c_void_p(baseline_coef_l().ctypes.data), C.c_void_p(baseline_coef_c().ctypes.data)
+    _lib.check(L.xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, refp.ctypes.data_as(C.c_void_p), s_l, s_c, _ptr(states), nstates, C.byref(params),
+                                                 _ptr(jobs), njobs, cl, cc, _ptr(res), _ptr(coef), _ptr(ry), _ptr(ru), _ptr(rv), _ptr(nb), _ptr(workspace),
+                                                 workspace.numel(), _stream()))
+    return res, coef, ry, ru, rv, nb
+
+
 def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 

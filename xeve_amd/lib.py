@@ -45,6 +45,15 @@ class RdoParams(C.Structure):  # xeve_hip_rdo_params
                 ("qp", C.c_int32 * 3), ("pad_", C.c_int32), ("lambda_", C.c_double * 3), ("dist_chroma_weight", C.c_double * 2)]
 
 
+class InterParams(C.Structure):  # xeve_hip_inter_params
+    _fields_ = [("rdo", RdoParams), ("me", EpzsParams), ("refi_bits", (C.c_int32 * 8) * 2), ("range_recentre", (C.c_int32 * 8) * 2), ("max_cand", C.c_int32),
+                ("poc", C.c_int32), ("col_list_poc0", C.c_int32), ("pad_", C.c_int32), ("skip_th", C.c_double)]
+
+
+INTER_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (2, 4, 2)), ("mv_col", "<i2", (2,)), ("sbac", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"),
+                   ("pad_", "u1", (2,))]  # xeve_hip_inter_job (52 B)
+INTER_RESULT_DTYPE = [("cost", "<f8"), ("cost_inter", "<f8", (5,)), ("cu_mode", "<i4"), ("best_idx", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)),
+                      ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)), ("nnz", "<i4", (3,)), ("pad_", "<i4", (2,))]  # xeve_hip_inter_result (96 B)
 RDO_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)), ("mvp_idx", "u1", (2,)),
                  ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1"), ("sbac", "<i4")]  # xeve_hip_rdo_job (36 B)
 RDO_RESULT_DTYPE = [("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))]  # xeve_hip_rdo_result (72 B)
@@ -146,6 +155,11 @@ FUNCTIONS = {
     "xeve_hip_analyze_skip_workspace": (C.c_size_t, [c_int, c_void_p, c_int]),
     "xeve_hip_analyze_skip_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_pinter_analyze_cu_workspace": (C.c_size_t, [c_int, c_int, c_void_p, c_int, c_int]),
+    "xeve_hip_pinter_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_me_epzs_jobs_x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_cu_bits_workspace": (C.c_size_t, [c_int, C.c_size_t]),
     "xeve_hip_cu_bits_jobs": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_cu_bits_jobs_chain": (c_int, [c_void_p, C.c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.c_size_t, c_void_p, c_void_p, c_void_p]),
