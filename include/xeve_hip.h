@@ -294,7 +294,8 @@ int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xev
  * diamond searches from the running best while beststep > 0, then the sub-pel pattern search.  The integer stage is ONE
  * kernel (a wave per block loops over its searches, the original block in registers throughout); the call is asynchronous
  * on `stream` like the rest of the batched API.  results[j].mv / .cost are what pinter_me_epzs returns; .best_mv_bits is what the searches leave in
- * pi->mot_bits[lidx] (0: they leave it untouched; xeve_pinter.c:546-548,690-692); .beststep is 0. */
+ * pi->mot_bits[lidx] (0: they leave it untouched; xeve_pinter.c:546-548,690-692); .beststep is 0.  A job with x < 0 is switched off (no work;
+ * its result is unspecified). */
 typedef struct xeve_hip_epzs_job {
     int32_t x, y;        /* block position (integer pel) */
     int32_t org_off;     /* bi != 0: offset of the job's dense org_bi block */
@@ -377,7 +378,8 @@ typedef struct xeve_hip_cu_bits_job {
 /* Per job: SBAC_LOAD(sbac_in[job.sbac]) + xeve_sbac_bit_reset + the syntax of job.mode + xeve_get_bit_number -> bits[j];
  * sbac_out (may be NULL) receives the coder state SBAC_STORE would keep, field for field.  coef (coef_elems int16
  * elements), sbac_in, jobs, bits, sbac_out and workspace (>= xeve_hip_cu_bits_workspace(njobs, coef_elems) bytes) are
- * device memory; params is a HOST pointer.  Jobs may share coefficient blocks and entry states. */
+ * device memory; params is a HOST pointer.  Jobs may share coefficient blocks and entry states.  coef may be NULL (coef_elems 0) when no job
+ * codes coefficients (XEVE_HIP_BITS_CU_SKIP / _MVP jobs only): the event pass is then left out. */
 size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems);
 /* One xeve_eco_coef call in bit-count mode on HOST memory (synchronous): the cbf flags and coefficients of one CU continue the coder from
  * *state where it stands and leave *state as the reference's coder would -- what ctx->fn_eco_coef can be pointed at while sbac->is_bitcount.
@@ -568,7 +570,8 @@ typedef struct xeve_hip_inter_result {
 } xeve_hip_inter_result;
 /* Pointer kinds as for xeve_hip_residue_rdo_jobs.  coef: the `coef` argument of the reference function, laid out like pi->coef there (Y blocks of
  * all CUs, then U, then V; zero for skipped CUs); rec_y [njobs][w*w], rec_u / rec_v [njobs][cw*ch]: pi->rec[best_idx]; next_best[j]:
- * core->s_next_best[log2_cuw - 2][log2_cuh - 2].  B slices: rdo.num_refp[1] <= rdo.num_refp[0] (analyze_bi walks both lists with num_refp[1]). */
+ * core->s_next_best[log2_cuw - 2][log2_cuh - 2].  B slices: rdo.num_refp[1] <= rdo.num_refp[0] (analyze_bi walks both lists with num_refp[1]).
+ * Asynchronous on `stream` like the rest of the batched API (levels of a picture can be analysed concurrently on separate streams). */
 size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_inter_params *params, int s_org_l, int s_org_c);
 int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
                                     const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *params, const xeve_hip_inter_job *jobs,

@@ -34,11 +34,12 @@ struct InterSt { // per CU, between the stages
     int32_t  mot_bits[2];
     int32_t  go, refi_sel[2];
     // analyze_bi
-    int32_t  lidx_ref, active, refi_best;
+    int32_t  lidx_ref, active, refi_best, bi_slot;
     uint32_t best_mecost;
     int8_t   rf[2];
     int8_t   pad_[2];
 };
+static_assert(sizeof(InterSt) % 4 == 0, "InterSt is cleared word by word");
 
 __device__ __forceinline__ void copy_sbac(xeve_hip_sbac *d, const xeve_hip_sbac *s)
 {
@@ -190,8 +191,7 @@ __global__ void k_bi_mc_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK
     mc[j] = m;
 }
 
-// get_org_bi (:143-156) for every CU, then the list swap and the search jobs of the round: both lists for every CU (the CUs of a batch
-// differ in which list they search; the results of the other one are not used)
+// get_org_bi (:143-156), then the list swap and the search jobs of the round
 __global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const pel *__restrict__ org, const pel *__restrict__ pred, int16_t *__restrict__ org_bi)
 {
     const int nbx = P.n0 >= 1024 ? 4 : 1, j = blockIdx.x / nbx, bx = blockIdx.x % nbx, w = 1 << P.lw;
@@ -203,27 +203,48 @@ __global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, 
 }
 
 __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_epzs_job *__restrict__ ej,
-                             int32_t *__restrict__ extra)
+                             int32_t *__restrict__ extra, int32_t *__restrict__ cnt)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n) return;
-    const xeve_hip_inter_job J = jobs[j];
-    InterSt &S = st[j];
-    if(S.active) { // SWAP(refi[lidx_ref], refi[lidx_cnd]), SWAP(lidx_ref, lidx_cnd) (:1626-1628)
+    const int  j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool act = j < P.n && st[j].active;
+    int l = 0;
+    if(act) { // SWAP(refi[lidx_ref], refi[lidx_cnd]), SWAP(lidx_ref, lidx_cnd) (:1626-1628)
+        InterSt &S = st[j];
         const int8_t t = S.rf[0];
         S.rf[0] = S.rf[1], S.rf[1] = t;
-        S.lidx_ref = 1 - S.lidx_ref;
+        l = S.lidx_ref = 1 - S.lidx_ref;
     }
-    for(int l = 0; l < 2; l++) {
-        const int idx = S.mvpi[M_BI][l];
-        extra[(size_t)l * P.n + j] = S.mot_bits[1 - l];
-        for(int r = 0; r < P.nb; r++) {
-            xeve_hip_epzs_job e;
-            e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
-            e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
-            ej[((size_t)l * MAXR + r) * P.n + j] = e;
-        }
+    // The CUs of a batch differ in which list they search: one compacted job array per list (slots handed out per wave with one atomic
+    // per list; the order inside is arbitrary, results come back through bi_slot).  Slots beyond the count stay switched off.
+    const unsigned long long m0 = __ballot(act && l == 0), m1 = __ballot(act && l == 1);
+    int b0 = 0, b1 = 0;
+    if(lane == 0) {
+        if(m0) b0 = atomicAdd(&cnt[0], __popcll(m0));
+        if(m1) b1 = atomicAdd(&cnt[1], __popcll(m1));
     }
+    b0 = __shfl(b0, 0, 64), b1 = __shfl(b1, 0, 64);
+    if(!act) return;
+    const unsigned long long below = (1ull << lane) - 1;
+    const int k = l == 0 ? b0 + __popcll(m0 & below) : b1 + __popcll(m1 & below);
+    const xeve_hip_inter_job J = jobs[j];
+    InterSt &S = st[j];
+    const int idx = S.mvpi[M_BI][l];
+    S.bi_slot = k;
+    extra[(size_t)l * P.n + k] = S.mot_bits[1 - l];
+    for(int r = 0; r < P.nb; r++) {
+        xeve_hip_epzs_job e;
+        e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
+        e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
+        ej[((size_t)l * MAXR + r) * P.n + k] = e;
+    }
+}
+
+__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= 2 * P.nb * P.n) return;
+    const int lr = t / P.n, k = t - lr * P.n, l = lr / P.nb, r = lr - l * P.nb;
+    ej[((size_t)l * MAXR + r) * P.n + k].x = -1;
 }
 
 // one round, second half (:1633-1663): every reference picture of the searched list against the running best
@@ -236,7 +257,7 @@ __global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mre
     const int l = S.lidx_ref;
     int changed = 0;
     for(int r = 0; r < P.nb; r++) {
-        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + j];
+        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + S.bi_slot];
         S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1]; // fn_me refines pi->mv_scale[lidx_ref][refi_cur] in place
         if(m.cost < S.best_mecost) {
             S.refi_best = r, S.best_mecost = m.cost, changed = 1;
@@ -348,7 +369,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, win, tmp, is_coef, off[2],
+    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, cnt, win, tmp, is_coef, off[2],
         scratch, scratch_bytes, total;
 };
 
@@ -370,7 +391,7 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2), L.st_b = take(N * sizeof(xeve_hip_sbac));
     L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
     L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
-    L.org_bi = take(N * n0 * 2), L.extra = take(2 * N * 4), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
+    L.org_bi = take(N * n0 * 2), L.extra = take(2 * N * 4), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
     L.off[0] = take(N * 4), L.off[1] = take(N * 4);
     // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
     size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
@@ -434,6 +455,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
     auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win), *off0 = (int32_t *)(W + L.off[0]), *off1 = (int32_t *)(W + L.off[1]);
     auto *is_coef = (unsigned char *)(W + L.is_coef);
+    auto *cnt = (int32_t *)(W + L.cnt);
     void *scr = W + L.scratch;
     hipStream_t s = (hipStream_t)stream;
     const int G = (njobs + 255) / 256;
@@ -461,7 +483,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     xeve_hip_cu_bits_params bp;
     bp.log2_cuw = lw, bp.log2_cuh = lw, bp.slice_type = rp.slice_type, bp.num_refp[0] = rp.num_refp[0], bp.num_refp[1] = rp.num_refp[1], bp.cm_init = 0,
     bp.chroma_format_idc = idc;
-    rc = xeve_hip_cu_bits_jobs((const int16_t *)sk[0], 64, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
+    rc = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_uni_b<<<G, 256, 0, s>>>(jobs, P, bitsm, st, rja);
     rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream);
@@ -474,7 +496,9 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
                                      pred[2], scr, L.scratch_bytes, stream);
             if(rc != XEVE_HIP_OK) return rc;
             k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], org_bi);
-            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra);
+            XH_HIP(hipMemsetAsync(cnt, 0, 8, s));
+            k_bi_jobs_off<<<(2 * P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej);
+            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt);
             for(int l = 0; l < 2; l++)
                 for(int r = 0; r < P.nb; r++) {
                     ep.me.bi = 1, ep.me.extra_bits = 0, ep.me.refi_bits = p->refi_bits[1][r], ep.me.range_recentre = p->range_recentre[l][r];

@@ -332,6 +332,7 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
     m.gmv_x = mx << 2, m.gmv_y = my << 2; // 1/16 pel, as the reference passes (mv_x << 2), xeve_pinter.c:608
     m.pred_off = bi ? jb.org_off : jb.y * s_org + jb.x;
     m.frac = ((mx & 3) != 0 ? 1 : 0) | ((my & 3) != 0 ? 2 : 0);
+    if(jb.x < 0) m.gmv_x = m.gmv_y = 0, m.pred_off = 0, m.frac = 4; // job switched off
     (void)blk_elems;
     mc[t] = m;
 }

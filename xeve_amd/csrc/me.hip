@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     const xeve_hip_epzs_job e = jobs[j];
+    if(e.x < 0) { // job switched off
+        EpzsState z;
+        z.cost = 0xFFFFFFFFu, z.mv[0] = e.mv_start[0], z.mv[1] = e.mv_start[1], z.tmpstep = 0, z.searches = 0, z.mot_bits = 0;
+        if(lane == 0) st[j] = z;
+        return;
+    }
     if(BI && extra) P.extra_bits = uni(extra[j]); // pi->mot_bits[other list] of this CU
     const int sx = P.bi == 1 ? e.mv_start[0] : e.mvp[0], sy = P.bi == 1 ? e.mv_start[1] : e.mvp[1];
     xeve_hip_me_job m;

@@ -519,11 +519,11 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
     xeve_hip_cu_bits_params bp;
     bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
     bp.cm_init = 0, bp.chroma_format_idc = idc;
-    rc_ = xeve_hip_cu_bits_jobs((const int16_t *)pred[0], 64, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, nullptr, stream);
+    rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, nullptr, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_skip_decide<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, P, mc, valid, ssd[0], ssd[1], ssd[2], bits, bj, results, win, bjw);
     if(best) { // the winner's complete coder state (SBAC_STORE(core->s_temp_best, *sbac), :1519)
-        rc_ = xeve_hip_cu_bits_jobs((const int16_t *)pred[0], 64, states, bjw, njobs, &bp, W + L.bitws, workspace_bytes - L.bitws, bitsw, stw, stream);
+        rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjw, njobs, &bp, W + L.bitws, workspace_bytes - L.bitws, bitsw, stw, stream);
         if(rc_ != XEVE_HIP_OK) return rc_;
     }
     k_skip_copy<<<3 * njobs, 64, 0, st>>>(P, win, pred[0], pred[1], pred[2], pred_y, pred_u, pred_v, stw, best);

@@ -482,7 +482,7 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     XH_REQUIRE(p->slice_type >= 0 && p->slice_type <= 2 && p->chroma_format_idc >= 0 && p->chroma_format_idc <= 3);
     XH_REQUIRE(p->num_refp[0] >= 0 && p->num_refp[0] <= 21 && p->num_refp[1] >= 0 && p->num_refp[1] <= 21);
     if(njobs == 0) return XEVE_HIP_OK;
-    XH_REQUIRE(coef && sbac_in && jobs && bits && workspace);
+    XH_REQUIRE(sbac_in && jobs && bits && workspace); // coef == NULL: no job codes coefficients (skip / mvp jobs only) -- the event pass is left out
     XH_REQUIRE(workspace_bytes >= xeve_hip_cu_bits_workspace(njobs, coef_elems));
     CuBitsK P;
     const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT (xeve_util.h:92-94)
@@ -500,7 +500,8 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     int      *nev = (int *)(ev + coef_elems);
     hipStream_t st = (hipStream_t)stream;
     const long items = 3L * njobs;
-    if(P.n[0] <= 64) {
+    if(!coef) {}
+    else if(P.n[0] <= 64) {
         const long waves = (items + 3) / 4;
         k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
     }
