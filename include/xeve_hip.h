@@ -569,15 +569,23 @@ typedef struct xeve_hip_inter_result {
     int32_t pad_[2];
 } xeve_hip_inter_result;
 /* Pointer kinds as for xeve_hip_residue_rdo_jobs.  coef: the `coef` argument of the reference function, laid out like pi->coef there (Y blocks of
- * all CUs, then U, then V; zero for skipped CUs); rec_y [njobs][w*w], rec_u / rec_v [njobs][cw*ch]: pi->rec[best_idx]; next_best[j]:
+ * all CUs, then U, then V; zero for skipped CUs); rec_y [njobs][w*w], rec_u / rec_v [njobs][cw*ch]: pi->rec[best_idx]; pred_y [njobs][w*w] (may be
+ * NULL): mi->pred_y_best; next_best[j]:
  * core->s_next_best[log2_cuw - 2][log2_cuh - 2].  B slices: rdo.num_refp[1] <= rdo.num_refp[0] (analyze_bi walks both lists with num_refp[1]).
  * Asynchronous on `stream` like the rest of the batched API (levels of a picture can be analysed concurrently on separate streams). */
 size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_inter_params *params, int s_org_l, int s_org_c);
 int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
                                     const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *params, const xeve_hip_inter_job *jobs,
                                     int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *results, int16_t *coef,
-                                    xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *next_best, void *workspace,
-                                    size_t workspace_bytes, void *stream);
+                                    xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y, xeve_hip_sbac *next_best,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+/* One xeve_pinter_analyze_cu call on HOST memory (synchronous; the original and every reference picture of both lists staged per call): what
+ * ctx->fn_pinter_analyze_cu can be pointed at.  org / refp: HOST pointers to sample (0, 0); the reference planes extend pad_l / pad_c samples around
+ * the picture; *state: core->s_curr_best[log2_cuw - 2][log2_cuh - 2] (job->sbac is ignored); coef_* / rec_*: the CU's dense blocks. */
+int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, int pad_l, int pad_c,
+                                    const xeve_hip_sbac *state, const xeve_hip_inter_params *params, const xeve_hip_inter_job *job, const int16_t (*coef_l)[8],
+                                    const int16_t (*coef_c)[4], xeve_hip_inter_result *result, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                                    xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y, xeve_hip_sbac *next_best);
 
 /* One pinter_me_epzs call on HOST memory (synchronous; both luma planes staged per call): what pi->fn_me can be pointed at.
  * org0 / ref0 = sample (0, 0) of the original / reference luma plane; the reference plane has `pad` samples around the picture. */

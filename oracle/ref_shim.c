@@ -233,8 +233,116 @@ static int shim_eco_coef(XEVE_CTX *ctx, XEVE_CORE *core, XEVE_BSW *bs, s16 coef[
     return XEVE_OK;
 }
 
+/* XEVE_HIP_SHIM_INTER=1: the WHOLE inter analysis of a CU -- ctx->fn_pinter_analyze_cu (xeve_pinter_analyze_cu, xeve_pinter.c:1839-2047): skip / merge
+ * analysis, temporal direct, per-list motion search + check_best_mvp + pinter_residue_rdo, the iterated bi-prediction search, the mode decision and
+ * the reconstruction -- runs on the GPU (xeve_hip_pinter_analyze_cu_host).  The adapter derives the merge / MVP candidates with the reference's own
+ * xeve_get_motion from the live maps, hands the entry coder state over field by field, and leaves what the reference's function leaves for
+ * mode_check_inter / copy_to_cu_data: core->cu_mode, core->nnz / nnz_sub, mi->*, the coefficient and reconstruction buffers, core->s_next_best,
+ * core->cost_best.  Square CUs 8..64 (every inter CU of the Baseline quad-tree at these presets); anything else goes to the reference's function. */
+typedef struct { int log2_cuw, log2_cuh, pic_w, pic_h, slice_type, num_refp[2], chroma_format_idc, bit_depth, tool_iqt, qp[3], pad_; double lambda[3], dist_chroma_weight[2]; } hip_rdo_params;
+typedef struct { hip_rdo_params rdo; hip_epzs_params me; int refi_bits[2][8], range_recentre[2][8], max_cand, poc, col_list_poc0, pad_; double skip_th; } hip_inter_params;
+typedef struct { int x, y; s16 mvp[2][4][2]; s16 mv_col[2]; int sbac; u8 ctx_skip, ctx_pred_mode, pad_[2]; } hip_inter_job;
+typedef struct { double cost, cost_inter[5]; int cu_mode, best_idx; s16 mv[2][2], mvd[2][2]; s8 refi[2]; u8 mvp_idx[2]; int nnz[3], pad_[2]; } hip_inter_result;
+static int (*hip_inter_host)(const pel *const *, int, int, const hip_refpic *, int, int, int, int, const hip_sbac *, const hip_inter_params *, const hip_inter_job *,
+                             const void *, const void *, hip_inter_result *, s16 *, s16 *, s16 *, pel *, pel *, pel *, pel *, hip_sbac *);
+static double (*orig_pinter_analyze_cu)(XEVE_CTX *, XEVE_CORE *, int, int, int, int, XEVE_MODE *, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C], int s_rec[N_C]);
+static unsigned long long inter_calls, inter_fallbacks;
+
+static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int y, int log2_cuw, int log2_cuh, XEVE_MODE *mi, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C],
+                                     int s_rec[N_C])
+{
+    XEVE_PINTER *pi = &ctx->pinter[core->thread_cnt];
+    const int isb = pi->slice_type == SLICE_B, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
+    const int nr[2] = {ctx->rpm.num_refp[REFP_0], isb ? ctx->rpm.num_refp[REFP_1] : 0};
+    if(log2_cuw != log2_cuh || log2_cuw < 3 || log2_cuw > 6 || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || pi->me_level <= ME_LEV_IPEL ||
+       pi->me_complexity > 1 || nr[0] > 8 || nr[1] > nr[0] || nr[0] < 1 || (isb && nr[1] < 1) || core->tree_cons.tree_type != TREE_LC || core->tree_cons.mode_cons != eAll) {
+        inter_fallbacks++;
+        return orig_pinter_analyze_cu(ctx, core, x, y, log2_cuw, log2_cuh, mi, coef, rec, s_rec);
+    }
+    hip_inter_params P;
+    memset(&P, 0, sizeof(P));
+    P.rdo.log2_cuw = log2_cuw, P.rdo.log2_cuh = log2_cuh, P.rdo.pic_w = ctx->w, P.rdo.pic_h = ctx->h, P.rdo.slice_type = pi->slice_type;
+    P.rdo.num_refp[0] = nr[0], P.rdo.num_refp[1] = nr[1], P.rdo.chroma_format_idc = idc, P.rdo.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8, P.rdo.tool_iqt = ctx->param.tool_iqt;
+    P.rdo.qp[0] = core->qp_y, P.rdo.qp[1] = core->qp_u, P.rdo.qp[2] = core->qp_v;
+    for(int c = 0; c < 3; c++) P.rdo.lambda[c] = core->lambda[c];
+    P.rdo.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.rdo.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    P.me.lambda_mv = pi->lambda_mv, P.me.faststep = 3, P.me.max_search_range = pi->max_search_range;
+    P.me.min_clip[0] = pi->min_clip[MV_X], P.me.min_clip[1] = pi->min_clip[MV_Y], P.me.max_clip[0] = pi->max_clip[MV_X], P.me.max_clip[1] = pi->max_clip[MV_Y];
+    P.me.hpel_cnt = pi->search_pattern_hpel_cnt, P.me.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    hip_refpic tab[16];
+    memset(tab, 0, sizeof(tab));
+    XEVE_PIC *any = pi->refp[0][REFP_0].pic;
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            XEVE_PIC *rp = pi->refp[r][l].pic;
+            tab[r * 2 + l].y = rp->y, tab[r * 2 + l].u = rp->u, tab[r * 2 + l].v = rp->v, tab[r * 2 + l].poc = pi->refp[r][l].poc;
+            P.refi_bits[l][r] = xeve_tbl_refi_bits[nr[l]][r];
+            P.range_recentre[l][r] = XEVE_CLIP3(pi->max_search_range >> 2, pi->max_search_range, /* get_range_ipel (xeve_pinter.c:122-129) */
+                                                (pi->max_search_range * XEVE_ABS(pi->poc - (int)pi->refp[r][l].poc) + (pi->gop_size >> 1)) / pi->gop_size);
+        }
+    P.max_cand = pi->skip_merge_cand_num, P.poc = ctx->poc.poc_val, P.col_list_poc0 = isb ? (int)pi->refp[0][REFP_1].list_poc[0] : 0, P.skip_th = ctx->param.skip_th;
+    hip_inter_job J;
+    memset(&J, 0, sizeof(J));
+    J.x = x, J.y = y, J.ctx_skip = core->ctx_flags[CNID_SKIP_FLAG], J.ctx_pred_mode = core->ctx_flags[CNID_PRED_MODE];
+    for(int l = 0; l <= isb; l++) { /* the candidates of xeve_analyze_skip and of the per-list search: the reference's own derivation (xeve_util.c:526-573) */
+        s8 refi_tmp[MAX_NUM_MVP];
+        xeve_get_motion(core->scup, l, ctx->map_refi, ctx->map_mv, pi->refp, core->cuw, core->cuh, ctx->w_scu, core->avail_cu, refi_tmp, J.mvp[l]);
+    }
+    if(isb) {
+        const int corner = core->scup + ((1 << (log2_cuw - MIN_CU_LOG2)) - 1) + ((1 << (log2_cuh - MIN_CU_LOG2)) - 1) * ctx->w_scu; /* xeve_get_mv_dir's scup (:1543) */
+        J.mv_col[0] = pi->refp[0][REFP_1].map_mv[corner][0][MV_X], J.mv_col[1] = pi->refp[0][REFP_1].map_mv[corner][0][MV_Y];
+    }
+    const XEVE_SBAC *sb = &core->s_curr_best[log2_cuw - 2][log2_cuh - 2];
+    hip_sbac h, nb;
+    h.range = sb->range, h.code = sb->code, h.code_bits = sb->code_bits, h.stacked_ff = sb->stacked_ff, h.stacked_zero = sb->stacked_zero;
+    h.pending_byte = sb->pending_byte, h.is_pending_byte = sb->is_pending_byte, h.bitcounter = sb->bitcounter, h.bin_counter = sb->bin_counter;
+#define F(name, at, n) memcpy(h.ctx + at, sb->ctx.name, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    hip_inter_result R;
+    static __thread s16 cf[N_C][MAX_CU_DIM];
+    static __thread pel rc[N_C][MAX_CU_DIM], py[MAX_CU_DIM];
+    const pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+    if(hip_inter_host(org, pi->s_o[Y_C], pi->s_o[U_C], tab, any->s_l, any->s_c, any->pad_l, any->pad_c, &h, &P, &J, pi->mc_l_coeff, pi->mc_c_coeff, &R, cf[Y_C], cf[U_C],
+                      cf[V_C], rc[Y_C], rc[U_C], rc[V_C], py, &nb) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] inter analysis: %s\n", hip_err());
+        abort();
+    }
+    /* what xeve_pinter_analyze_cu leaves behind (:2004-2046) */
+    const int best = R.best_idx, n0 = 1 << (log2_cuw + log2_cuh), n1 = n0 >> (ws + hs);
+    core->cu_mode = R.cu_mode;
+    for(int c = 0; c < N_C; c++) {
+        if(c && !idc) continue;
+        const int n = c ? n1 : n0;
+        memcpy(coef[c], cf[c], sizeof(s16) * n);
+        memcpy(pi->rec[best][c], rc[c], sizeof(pel) * n);
+        rec[c] = pi->rec[best][c], s_rec[c] = c ? (1 << log2_cuw) >> ws : 1 << log2_cuw;
+        core->nnz[c] = R.nnz[c];
+        memset(core->nnz_sub[c], 0, sizeof(int) * MAX_SUB_TB_NUM);
+        core->nnz_sub[c][0] = R.nnz[c];
+    }
+    memcpy(pi->pred[best][0][Y_C], py, sizeof(pel) * n0);
+    mi->pred_y_best = pi->pred[best][0][Y_C];
+    for(int l = 0; l < REFP_NUM; l++) {
+        mi->refi[l] = R.refi[l], mi->mvp_idx[l] = R.mvp_idx[l];
+        mi->mv[l][MV_X] = R.mv[l][0], mi->mv[l][MV_Y] = R.mv[l][1], mi->mvd[l][MV_X] = R.mvd[l][0], mi->mvd[l][MV_Y] = R.mvd[l][1];
+    }
+    XEVE_SBAC *out = &core->s_next_best[log2_cuw - 2][log2_cuh - 2];
+    *out = *sb; /* fields the analysis does not touch (is_bitcount, the context models of other syntax) */
+    out->range = nb.range, out->code = nb.code, out->code_bits = nb.code_bits, out->stacked_ff = nb.stacked_ff, out->stacked_zero = nb.stacked_zero;
+    out->pending_byte = nb.pending_byte, out->is_pending_byte = nb.is_pending_byte, out->bitcounter = nb.bitcounter, out->bin_counter = nb.bin_counter;
+#define F(name, at, n) memcpy(out->ctx.name, nb.ctx + at, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    core->dqp_next_best[log2_cuw - 2][log2_cuh - 2] = core->dqp_curr_best[log2_cuw - 2][log2_cuh - 2];
+    if(R.cost < core->cost_best) core->cost_best = R.cost;
+    inter_calls++;
+    return R.cost;
+}
+
 static void report(void)
 {
+    if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
     if(tq_calls) fprintf(stderr, "[xeve_hip_shim] transform blocks quantised (RDOQ) on the GPU: %llu, dequantised + inverse transformed: %llu\n", tq_calls, itdq_calls);
@@ -285,6 +393,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_mc_cu_host) { fprintf(stderr, "[xeve_hip_shim] mc entry point missing\n"); abort(); }
         for(int i = 0; i < ctx->param.threads; i++) ctx->pinter[i].fn_mc = shim_mc;
         fprintf(stderr, "[xeve_hip_shim] CU motion compensation routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_INTER") && atoi(getenv("XEVE_HIP_SHIM_INTER")) && ctx->fn_pinter_analyze_cu) {
+        hip_inter_host = dlsym(h, "xeve_hip_pinter_analyze_cu_host"), hip_err = err;
+        if(!hip_inter_host) { fprintf(stderr, "[xeve_hip_shim] inter-analysis entry point missing\n"); abort(); }
+        orig_pinter_analyze_cu = ctx->fn_pinter_analyze_cu, ctx->fn_pinter_analyze_cu = shim_pinter_analyze_cu;
+        fprintf(stderr, "[xeve_hip_shim] whole inter analysis of a CU routed to the GPU\n");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

@@ -17,16 +17,34 @@ CASES = {
     "tiny_closed_gop": (128, 64, 8, 10, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "1"]),
     # two CTU-row worker threads (the reference calls the tables concurrently, xeve_enc.c:336-365); `-m` given last wins
     "tiny_ldb_fast_2threads": (128, 128, 2, 7, ["--preset", "fast", "-I", "0", "-b", "0", "-m", "2"]),
+    # drifting texture (seed >= 5000): skip / direct / bi-prediction win here, unlike on noise
+    "moving_ra_medium": (128, 64, 5, 5001, ["--preset", "medium", "-b", "1"]),
+    "moving_ldb_fast": (128, 128, 3, 5002, ["--preset", "fast", "-I", "0", "-b", "0"]),
 }
 
 
 def make_yuv(path, w, h, frames, seed):
+    """seeds below 5000: i.i.d. noise (SURVEY.md 8d recipe); from 5000: a smooth texture drifting over the frames plus light noise -- content on
+    which skip / merge, temporal direct and bi-prediction actually win"""
     random.seed(seed)
+    if seed < 5000:
+        with open(path, "wb") as f:
+            f.write(bytes(random.getrandbits(8) for _ in range(w * h * 3 // 2 * frames)))
+        return
+    import numpy as np
+
+    r = np.random.default_rng(seed)
     with open(path, "wb") as f:
-        f.write(bytes(random.getrandbits(8) for _ in range(w * h * 3 // 2 * frames)))
+        for t in range(frames):
+            for (pw, ph, sc, base) in ((w, h, 1.0, 128.0), (w // 2, h // 2, 2.0, 110.0), (w // 2, h // 2, 2.0, 140.0)):
+                yy, xx = np.mgrid[0:ph, 0:pw].astype(np.float64) * sc
+                xs, ys = xx + 3.0 * t, yy + 2.0 * t
+                a = base + 60 * np.sin(xs / 9.0) * np.cos(ys / 7.0) + 30 * np.sin((xs + ys) / 13.0) + 12 * np.sin(xs / 3.0)
+                a[ph // 2:, :] += 25 * np.sin((xx[ph // 2:, :] - 5.0 * t) / 6.0)  # a second motion in the lower half
+                f.write(np.clip(a + r.integers(-2, 3, size=a.shape), 0, 255).astype(np.uint8).tobytes())
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -34,6 +52,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
     if hip:
         env["LD_PRELOAD"] = SHIM
         env["XEVE_HIP_LIB"] = HIP_LIB
+        if inter:
+            env["XEVE_HIP_SHIM_INTER"] = "1"  # the whole inter analysis of a CU (ctx->fn_pinter_analyze_cu)
         if mc:
             env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:

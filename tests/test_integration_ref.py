@@ -155,3 +155,20 @@ def test_bitstream_identical_with_cu_prediction_on_the_gpu(tmp_path, name):
     m = re.search(r"CU predictions \(xeve_mc\) made on the GPU: (\d+)", err)
     assert m and int(m.group(1)) > 500, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with xeve_mc on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads"])
+def test_bitstream_identical_with_the_whole_inter_analysis_on_the_gpu(tmp_path, name):
+    """ctx->fn_pinter_analyze_cu -> xeve_hip_pinter_analyze_cu_host: skip / merge analysis, temporal direct, both lists' motion searches over every
+    reference picture, check_best_mvp, the iterated bi-prediction search, every pinter_residue_rdo, the mode decision and the reconstruction of
+    every inter CU come from the GPU; the reference keeps the quad-tree recursion, the intra modes and the bitstream writer."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True)
+    assert "whole inter analysis of a CU routed to the GPU" in err
+    m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    assert m and int(m.group(1)) > 200 and int(m.group(2)) == 0, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the inter analysis on the GPU"

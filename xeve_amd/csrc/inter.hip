@@ -13,6 +13,7 @@
 // operations each) that turn the results of one stage into the jobs of the next, so that the whole analysis of all CUs of a level runs
 // without a host round trip.  CUs whose skip residual is below the skip_th threshold stop after the skip mode in the reference; here they
 // ride along (skip_th is 0 in every preset, so this only concerns CUs with a perfect skip prediction) and are masked in the decision.
+#include <cstring>
 #include "xh_common.h"
 
 #define MAXR XEVE_HIP_MAX_REFP
@@ -421,8 +422,8 @@ extern "C" size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, c
 extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
                                                const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *p, const xeve_hip_inter_job *jobs,
                                                int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *results,
-                                               int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *next_best,
-                                               void *workspace, size_t workspace_bytes, void *stream)
+                                               int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y,
+                                               xeve_hip_sbac *next_best, void *workspace, size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && rec_y && next_best && workspace && coef_l);
@@ -533,6 +534,94 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
             rc = xeve_hip_recon(t, pred[k], is_coef + (size_t)k * njobs, njobs, 1 << lk, 1 << lhk, k ? off1 : off0, 1 << lk, rec[k], bd, stream);
         if(rc != XEVE_HIP_OK) return rc;
     }
+    if(pred_y) XH_HIP(hipMemcpyAsync(pred_y, pred[0], (size_t)njobs * P.n0 * sizeof(pel), hipMemcpyDeviceToDevice, s)); // mi->pred_y_best (:2040)
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
+}
+
+// ---- host-memory form of one xeve_pinter_analyze_cu call (the table layer's style: synchronous, every plane staged per call) ----------
+// What ctx->fn_pinter_analyze_cu can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org / refp: HOST pointers to
+// sample (0, 0); the reference planes extend pad_l / pad_c samples around the picture.
+extern "C" int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, int pad_l,
+                                               int pad_c, const xeve_hip_sbac *state, const xeve_hip_inter_params *p, const xeve_hip_inter_job *job,
+                                               const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *result, int16_t *coef_y,
+                                               int16_t *coef_u, int16_t *coef_v, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v,
+                                               xeve_hip_pel *pred_y, xeve_hip_sbac *next_best)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && org[0] && refp && state && p && job && result && coef_y && rec_y && next_best && inter_params_ok(p) && pad_l >= 0 && pad_c >= 0);
+    const xeve_hip_rdo_params &rp = p->rdo;
+    const int idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, isb = rp.slice_type == 0;
+    XH_REQUIRE(idc == 0 || (org[1] && org[2] && coef_u && coef_v && rec_u && rec_v));
+    const size_t n0 = (size_t)1 << (2 * rp.log2_cuw), n1 = idc ? n0 >> (ws + hs) : 0;
+    const size_t eo[3] = {(size_t)s_org_l * rp.pic_h, (size_t)s_org_c * (rp.pic_h >> hs), (size_t)s_org_c * (rp.pic_h >> hs)};
+    const size_t er[3] = {(size_t)s_l * (rp.pic_h + 2 * pad_l), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c)};
+    const size_t orr[3] = {(size_t)pad_l * s_l + pad_l, (size_t)pad_c * s_c + pad_c, (size_t)pad_c * s_c + pad_c};
+    // the pictures both lists hold (a picture may sit in both: staged once)
+    const int nr[2] = {rp.num_refp[0], isb ? rp.num_refp[1] : 0};
+    const xeve_hip_pel *uniq[2 * MAXR];
+    int nu = 0, which[2 * MAXR];
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            const xeve_hip_refpic &e = refp[r * 2 + l];
+            XH_REQUIRE(e.y && (idc == 0 || (e.u && e.v)));
+            int k = 0;
+            while(k < nu && uniq[k] != e.y) k++;
+            if(k == nu) uniq[nu++] = e.y;
+            which[r * 2 + l] = k;
+        }
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    size_t o_org[3], o_ref[2 * MAXR][3];
+    for(int c = 0; c < ncomp; c++) o_org[c] = take(eo[c] * sizeof(pel));
+    for(int k = 0; k < nu; k++)
+        for(int c = 0; c < ncomp; c++) o_ref[k][c] = take(er[c] * sizeof(pel));
+    const size_t o_state = take(sizeof(xeve_hip_sbac)), o_job = take(sizeof(xeve_hip_inter_job)), o_res = take(sizeof(xeve_hip_inter_result));
+    const size_t o_coef = take((n0 + 2 * n1) * 2), o_rec = take((n0 + 2 * n1 + 16) * 2), o_pred = take(n0 * 2), o_nb = take(sizeof(xeve_hip_sbac));
+    const size_t wsb = xeve_hip_pinter_analyze_cu_workspace(1, 1, p, s_org_l, s_org_c), o_ws = take(wsb);
+    char *d = nullptr;
+    XH_HIP(hipMalloc((void **)&d, o));
+    int rc = XEVE_HIP_OK;
+    auto up = [&](size_t off, const void *src, size_t bytes) { if(rc == XEVE_HIP_OK && hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE; };
+    auto down = [&](void *dst, size_t off, size_t bytes) { if(rc == XEVE_HIP_OK && hipMemcpy(dst, d + off, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE; };
+    for(int c = 0; c < ncomp; c++) up(o_org[c], org[c], eo[c] * sizeof(pel));
+    xeve_hip_refpic tab[2 * MAXR];
+    memset(tab, 0, sizeof(tab));
+    bool done[2 * MAXR] = {};
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            const xeve_hip_refpic &e = refp[r * 2 + l];
+            const int k = which[r * 2 + l];
+            const xeve_hip_pel *hp[3] = {e.y, e.u, e.v};
+            if(!done[k])
+                for(int c = 0; c < ncomp; c++) up(o_ref[k][c], hp[c] - orr[c], er[c] * sizeof(pel));
+            done[k] = true;
+            xeve_hip_refpic &t = tab[r * 2 + l];
+            t.y = (pel *)(d + o_ref[k][0]) + orr[0], t.poc = e.poc;
+            if(idc) t.u = (pel *)(d + o_ref[k][1]) + orr[1], t.v = (pel *)(d + o_ref[k][2]) + orr[2];
+        }
+    if(!isb) tab[0 * 2 + 1] = tab[0 * 2 + 0]; // (P slices never read list 1; keep the table addressable)
+    xeve_hip_inter_job j0 = *job;
+    j0.sbac = 0;
+    up(o_state, state, sizeof(*state)), up(o_job, &j0, sizeof(j0));
+    if(rc != XEVE_HIP_OK) xh_set_error("xeve_hip_pinter_analyze_cu_host: staging failed");
+    if(rc == XEVE_HIP_OK) {
+        const pel *dorg[3] = {(pel *)(d + o_org[0]), idc ? (pel *)(d + o_org[1]) : nullptr, idc ? (pel *)(d + o_org[2]) : nullptr};
+        pel *drec = (pel *)(d + o_rec);
+        rc = xeve_hip_pinter_analyze_cu_jobs(dorg, s_org_l, s_org_c, tab, s_l, s_c, (const xeve_hip_sbac *)(d + o_state), 1, p, (const xeve_hip_inter_job *)(d + o_job), 1,
+                                             coef_l, coef_c, (xeve_hip_inter_result *)(d + o_res), (int16_t *)(d + o_coef), drec, drec + n0 + 8, drec + n0 + n1 + 16,
+                                             (pel *)(d + o_pred), (xeve_hip_sbac *)(d + o_nb), d + o_ws, wsb, nullptr);
+        if(rc == XEVE_HIP_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE, xh_set_error("xeve_hip_pinter_analyze_cu_host: device error");
+        if(rc == XEVE_HIP_OK) {
+            down(result, o_res, sizeof(*result)), down(coef_y, o_coef, n0 * 2), down(rec_y, o_rec, n0 * 2), down(next_best, o_nb, sizeof(*next_best));
+            if(pred_y) down(pred_y, o_pred, n0 * 2);
+            if(idc) {
+                down(coef_u, o_coef + n0 * 2, n1 * 2), down(coef_v, o_coef + (n0 + n1) * 2, n1 * 2);
+                down(rec_u, o_rec + (n0 + 8) * 2, n1 * 2), down(rec_v, o_rec + (n0 + n1 + 16) * 2, n1 * 2);
+            }
+            if(rc != XEVE_HIP_OK) xh_set_error("xeve_hip_pinter_analyze_cu_host: copy back failed");
+        }
+    }
+    (void)hipFree(d);
+    return rc;
 }

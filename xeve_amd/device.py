@@ -266,10 +266,10 @@ def analyze_skip_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params
     return res, py, pu, pv, best
 
 
-def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None):
+def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None, want_pred=False):
     """the whole inter analysis of a batch of CUs (xeve_hip_pinter_analyze_cu_jobs).  params: lib.InterParams; jobs: uint8 tensor of lib.INTER_JOB_DTYPE
     records.  Returns (results uint8 [njobs, 96], coef int16 flat [Y blocks | U blocks | V blocks], rec_y, rec_u, rec_v int16 [njobs, n],
-    next_best uint8 [njobs, 172])."""
+    next_best uint8 [njobs, 172]) and, with want_pred, the winner's luma prediction int16 [njobs, n] (mi->pred_y_best)."""
     L = _lib.load()
     rp = params.rdo
     njobs, nstates, dev = jobs.numel() // 52, states.numel() // 172, jobs.device
@@ -281,15 +281,16 @@ def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, p
     ry = torch.zeros((njobs, n0), dtype=torch.int16, device=dev)
     ru, rv = (torch.zeros((njobs, max(n1, 1)), dtype=torch.int16, device=dev) for _ in range(2))
     nb = torch.zeros((njobs, 172), dtype=torch.uint8, device=dev)
+    py = torch.zeros((njobs, n0), dtype=torch.int16, device=dev) if want_pred else None
     need = L.xeve_hip_pinter_analyze_cu_workspace(njobs, nstates, C.byref(params), s_org_l, s_org_c)
     if workspace is None:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
     org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
     cl, cc = C.c_void_p(baseline_coef_l().ctypes.data), C.c_void_p(baseline_coef_c().ctypes.data)
     _lib.check(L.xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, refp.ctypes.data_as(C.c_void_p), s_l, s_c, _ptr(states), nstates, C.byref(params),
-                                                 _ptr(jobs), njobs, cl, cc, _ptr(res), _ptr(coef), _ptr(ry), _ptr(ru), _ptr(rv), _ptr(nb), _ptr(workspace),
-                                                 workspace.numel(), _stream()))
-    return res, coef, ry, ru, rv, nb
+                                                 _ptr(jobs), njobs, cl, cc, _ptr(res), _ptr(coef), _ptr(ry), _ptr(ru), _ptr(rv), _ptr(py) if py is not None else None, _ptr(nb),
+                                                 _ptr(workspace), workspace.numel(), _stream()))
+    return (res, coef, ry, ru, rv, nb, py) if want_pred else (res, coef, ry, ru, rv, nb)
 
 
 def _ptr_at(t, elem_off):
