@@ -166,6 +166,21 @@ def main():
         nnz = [np.frombuffer(v[0].cpu().numpy().tobytes(), dtype=[("cost", "<f8"), ("nnz", "<i4", (3,)), ("pad_", "<i4"), ("dist", "<i8", (2, 3))])["nnz"] for v in rd.values()]
         rate_term["residue_rdo_structured"] = {"ms_per_picture": round(e0.elapsed_time(e1), 3), "candidates_per_picture": int(sum(len(v) for v in nnz)),
                                                "coded_fraction": round(float(sum(int(v.any(axis=1).sum()) for v in nnz)) / sum(len(v) for v in nnz), 4)}
+        # one level up: xeve_pinter_analyze_cu (= ctx->fn_pinter_analyze_cu) for every CU of every level -- skip / merge analysis, temporal direct,
+        # both lists' searches + check_best_mvp, the iterated bi-prediction search, every pinter_residue_rdo, decision, reconstruction
+        ws.inter()
+        torch.cuda.synchronize()
+        e0.record()
+        ia = ws.inter()
+        e1.record()
+        torch.cuda.synchronize()
+        from xeve_amd import lib as _xl
+        modes = np.concatenate([v.cpu().numpy().reshape(-1).view(np.dtype(_xl.INTER_RESULT_DTYPE))["best_idx"] for v in ia.values()])
+        cnt = np.bincount(modes, minlength=5)
+        rate_term["inter_analysis_structured"] = {"ms_per_picture": round(e0.elapsed_time(e1), 3), "cus_per_picture": int(len(modes)),
+                                                  "winners": {"l0": int(cnt[0]), "l1": int(cnt[1]), "bi": int(cnt[2]), "skip": int(cnt[3]), "direct": int(cnt[4])},
+                                                  "note": "B picture, one reference picture per list, 3 merge candidates; all four CU levels of the picture, "
+                                                          "one stream per level"}
         del ws
     if rank == 0:
         sad_ms = wl.sad_time_ms()  # per size, summed over the timed steps

@@ -341,6 +341,61 @@ class HotPathPass:
             main.wait_stream(self._side[S])
         return out
 
+    def _inter_setup(self, lv):
+        from . import lib
+        import ctypes as C
+        S, n, dev = lv["S"], lv["n"], self.dev
+        r = lv["rdo"] if "rdo" in lv else self._rdo_setup(lv)
+        lv["rdo"] = r
+        P = lib.InterParams()
+        C.memmove(C.byref(P.rdo), C.byref(r["params"]), C.sizeof(P.rdo))
+        lam_mv = int(np.floor(65536.0 * np.sqrt(self.lam)))  # pi->lambda_mv (xeve_pinter.c:1763)
+        P.me.me.lambda_mv, P.me.me.faststep, P.me.me.max_search_range = lam_mv, 3, 64
+        P.me.me.min_clip[0], P.me.me.min_clip[1], P.me.me.max_clip[0], P.me.me.max_clip[1] = -127, -127, self.W - 1 + 127, self.H - 1 + 127
+        P.me.hpel_cnt, P.me.qpel_cnt = 8, 8
+        for l in range(2):
+            P.refi_bits[l][0], P.range_recentre[l][0] = 0, 16  # one reference picture per list, one picture away (gop 8: 64 / 8 -> clipped to 64 >> 2)
+        P.max_cand, P.poc, P.col_list_poc0, P.skip_th = 3, 1, 0, 0.0
+        j = np.zeros(n, lib.INTER_JOB_DTYPE)
+        nx = self.W // S
+        idx = np.arange(n)
+        j["x"], j["y"] = (idx % nx) * S, (idx // nx) * S
+        rng = np.random.default_rng(23)
+        # merge / MVP candidates as a coded neighbourhood gives them: mostly the true motion (+-12, +-4 quarter pel for the structured picture),
+        # sometimes a slightly different vector, sometimes the (1, 1) of an unavailable neighbour; random on the i.i.d. picture
+        for l in range(N_LIST):
+            true = np.array(((12, 4), (-12, -4))[l]) if self.content != "iid" else None
+            for k in range(4):
+                kind = rng.integers(0, 10, size=n)
+                v = np.tile(true, (n, 1)) if true is not None else rng.integers(-MV_RANGE * 4, MV_RANGE * 4 + 1, size=(n, 2))
+                v = np.where((kind == 7)[:, None], v + rng.integers(-6, 7, size=(n, 2)), v)
+                v = np.where((kind >= 8)[:, None], 1, v)
+                j["mvp"][:, l, k] = v
+        j["mv_col"] = rng.integers(-8, 9, size=(n, 2))
+        refp = r["refp"].copy()
+        refp["poc"][0], refp["poc"][1] = 0, 2
+        need = lib.load().xeve_hip_pinter_analyze_cu_workspace(n, 1, C.byref(P), self.s_l, self.s_c)
+        return dict(params=P, jobs=torch.from_numpy(j.view(np.uint8).copy()).to(dev), refp=refp, ws=torch.empty(int(need), dtype=torch.uint8, device=dev))
+
+    def inter(self):
+        """phase H: the whole inter analysis (xeve_pinter_analyze_cu) of every CU of every level, one stream per level; returns {S: results uint8 [n, 96]}"""
+        out = {}
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+        for S in sorted(self.sizes, reverse=True):
+            lv = self.lv[S]
+            if "inter" not in lv:
+                lv["inter"] = self._inter_setup(lv)
+            h, r = lv["inter"], lv["rdo"]
+            st = self._side[S]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out[S] = D.pinter_analyze_cu_jobs(r["org"], self.s_l, self.s_c, h["refp"], self.s_l, self.s_c, r["state"], h["params"], h["jobs"], workspace=h["ws"])[0]
+        for S in self.sizes:
+            main.wait_stream(self._side[S])
+        return out
+
     def capture(self):
         """Record one pass into a HIP graph (all launches of run() go to torch's current stream, which is the capture
         stream here); replay() then re-issues the ~150 launches with one host call.  Matters for small pictures, where
