@@ -57,3 +57,26 @@ def test_init_without_gpu_raises():
 
     with pytest.raises(xeve_amd.XeveHipError):
         xeve_amd.init(0)
+
+
+def test_workspace_sizes_of_the_composites_without_a_gpu():
+    """host-side arithmetic only: monotone in the job count, 256 for unusable parameters, and every new composite refuses to run
+    before xeve_hip_init()"""
+    from xeve_amd import lib
+
+    L = lib.load()
+    P = lib.InterParams()
+    P.rdo.log2_cuw = P.rdo.log2_cuh = 4
+    P.rdo.pic_w, P.rdo.pic_h, P.rdo.slice_type, P.rdo.chroma_format_idc, P.rdo.bit_depth = 128, 64, 0, 1, 10
+    P.rdo.num_refp[0] = P.rdo.num_refp[1] = 2
+    P.max_cand = 3
+    a = L.xeve_hip_pinter_analyze_cu_workspace(100, 4, C.byref(P), 416, 352)
+    b = L.xeve_hip_pinter_analyze_cu_workspace(200, 4, C.byref(P), 416, 352)
+    assert 256 < a < b
+    P.rdo.log2_cuw = 2  # 4x4 CUs are not on this path
+    assert L.xeve_hip_pinter_analyze_cu_workspace(100, 4, C.byref(P), 416, 352) == 256
+    P.rdo.log2_cuw = 4
+    assert 256 < L.xeve_hip_analyze_skip_workspace(100, C.byref(P.rdo), 4) < L.xeve_hip_analyze_skip_workspace(300, C.byref(P.rdo), 4)
+    assert L.xeve_hip_analyze_skip_workspace(100, C.byref(P.rdo), 5) == 256
+    rc = L.xeve_hip_pinter_analyze_cu_jobs(None, 0, 0, None, 0, 0, None, 0, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, None)
+    assert rc != 0 and "xeve_hip_init" in lib.last_error()

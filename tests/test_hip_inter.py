@@ -101,3 +101,43 @@ def test_hip_pinter_analyze_cu_vs_oracle(w, h, bd, nref, idc, slice_type, skip_t
             assert best[i:i + 1].tobytes() == eb.tobytes(), key
             modes.add(int(er["best_idx"][0]))
     assert len(modes) >= (4 if slice_type == 0 else 2), modes
+
+
+def test_hip_pinter_analyze_cu_edge_cases():
+    """empty batch; parameters outside the path are refused with an error code and a message (no silent fallback); one CU at the picture corner"""
+    import torch
+
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    r = np.random.default_rng(4)
+    refs, org = make_inter_picture(r, 64, 64, 10, 1, 1, 0)
+    st = states(r, 2)
+    P = make_inter_params(r, 6, 64, 64, 10, 1, 1, 0, refs)
+    jobs = make_inter_jobs(r, 1, 64, 64, 64, len(st), refs, 0)
+    res, coef, rec, best = run_hip(refs, org, st, P, jobs)  # the whole picture is one 64x64 CU
+    O = oracle_inter()
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]], np.uint64)
+    er, eb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+    ec = [np.zeros(4096, np.int16), np.zeros(1024, np.int16), np.zeros(1024, np.int16)]
+    ep = [x.copy() for x in ec]
+    O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs), ptr(er), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]),
+                           ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
+    assert res.tobytes() == er.tobytes() and np.array_equal(rec[0][0], ep[0]) and best.tobytes() == eb.tobytes()
+    # empty batch
+    H = hip_params(P)
+    dst = torch.from_numpy(st.view(np.uint8).copy()).to(dev)
+    empty = torch.empty(0, dtype=torch.uint8, device=dev)
+    out = D.pinter_analyze_cu_jobs([1, 1, 1], refs["s_l"], refs["s_c"], np.zeros(2, lib.REFPIC_DTYPE), refs["s_l"], refs["s_c"], dst, H, empty)
+    assert out[0].numel() == 0
+    # refused: 4x4 CUs, more list-1 than list-0 pictures
+    for mutate in (lambda h: setattr(h.rdo, "log2_cuw", 2), lambda h: h.rdo.num_refp.__setitem__(1, 3)):
+        H = hip_params(P)
+        mutate(H)
+        with pytest.raises(xeve_amd.XeveHipError):
+            D.pinter_analyze_cu_jobs([1, 1, 1], refs["s_l"], refs["s_c"], np.zeros(8, lib.REFPIC_DTYPE), refs["s_l"], refs["s_c"], dst, H,
+                                     torch.zeros(52, dtype=torch.uint8, device=dev), workspace=torch.empty(1 << 20, dtype=torch.uint8, device=dev))

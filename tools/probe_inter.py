@@ -64,3 +64,28 @@ for it in range(3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 print("all four levels, one stream per level: %.2f ms" % (dt * 1e3))
+
+# the same four calls recorded into one HIP graph (every launch of the composite goes to the caller's stream; no host round trip inside)
+try:
+    outs = {}
+    pre = {c: [torch.empty_like(t) for t in D.pinter_analyze_cu_jobs(org_ptrs, refs["s_l"], refs["s_c"], tab, refs["s_l"], refs["s_c"], dst, hp, dj, workspace=ws)]
+           for (c, n, hp, dj, ws, strm) in levels}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        for (c, n, hp, dj, ws, strm) in reversed(levels):
+            strm.wait_stream(main)
+            with torch.cuda.stream(strm):
+                outs[c] = D.pinter_analyze_cu_jobs(org_ptrs, refs["s_l"], refs["s_c"], tab, refs["s_l"], refs["s_c"], dst, hp, dj, workspace=ws)
+        for (c, n, hp, dj, ws, strm) in levels:
+            main.wait_stream(strm)
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print("all four levels, one HIP graph (a stream per level inside): %.2f ms" % (dt * 1e3))
+except Exception as e:  # noqa: BLE001
+    print("graph capture failed:", repr(e)[:300])

@@ -426,12 +426,12 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
                                                xeve_hip_sbac *next_best, void *workspace, size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
-    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && rec_y && next_best && workspace && coef_l);
-    XH_REQUIRE(inter_params_ok(p));
+    XH_REQUIRE(p && njobs >= 0 && inter_params_ok(p));
+    if(njobs == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(org && refp && states && nstates > 0 && jobs && results && coef && rec_y && next_best && workspace && coef_l);
     const xeve_hip_rdo_params rp = p->rdo;
     const int idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = rp.bit_depth, lw = rp.log2_cuw, w = 1 << lw;
     XH_REQUIRE(org[0] && (idc == 0 || (org[1] && org[2] && coef_c && rec_u && rec_v)));
-    if(njobs == 0) return XEVE_HIP_OK;
     const InterLayout L = inter_layout(njobs, nstates, p, s_org_l, s_org_c);
     XH_REQUIRE(workspace_bytes >= L.total);
     InterK P;

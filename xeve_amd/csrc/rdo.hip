@@ -474,8 +474,9 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
                                           size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
-    XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && pred_y && workspace && coef_l);
-    XH_REQUIRE(max_cand >= 1 && max_cand <= 4 && (p->slice_type == 0 || p->slice_type == 1));
+    XH_REQUIRE(p && njobs >= 0 && max_cand >= 1 && max_cand <= 4 && (p->slice_type == 0 || p->slice_type == 1));
+    if(njobs == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(org && refp && states && nstates > 0 && jobs && results && pred_y && workspace && coef_l);
     XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6);
     XH_REQUIRE(p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3);
     XH_REQUIRE(org[0] && (p->chroma_format_idc == 0 || (org[1] && org[2] && coef_c && pred_u && pred_v)));
