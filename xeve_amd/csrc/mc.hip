@@ -66,6 +66,15 @@ template <int TAPS, int SEG> __device__ __forceinline__ void hfir(const pel *r, 
 
 __device__ __forceinline__ int clipi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
+// Jobs of one launch may read different reference pictures: bits 3.. of job.frac then index this table (n == 0: every job reads `ref`).
+// Used by the CU prediction driver and the sub-pel searches, which would otherwise need one launch per reference picture.
+#define XH_MAX_PLANES 16
+struct PlaneTab {
+    const pel *p[XH_MAX_PLANES];
+    int        n;
+};
+__device__ __forceinline__ const pel *plane_of(const PlaneTab &pt, const pel *ref, int frac) { return pt.n ? pt.p[(frac >> 3) & (XH_MAX_PLANES - 1)] : ref; }
+
 // `jpb` jobs per workgroup: small blocks (8x8 luma = 8 row units) are packed so that all 256 threads have a unit.
 // Phase 1 (only for jobs with both filters): horizontal pass of h + TAPS - 1 rows into LDS.  Phase 2: every output
 // unit, by the job's own variant.  Jobs of one launch may mix variants (quarter-pel merge / final MC).
@@ -77,7 +86,7 @@ template <int TAPS, int SEG, int OUT>
 __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
                                             const xeve_hip_mc_job *__restrict__ jobs, int njobs, int jpb, int w, int h,
                                             int bit_depth, CoefTab<TAPS> tab, const pel *__restrict__ org, int s_org, int dshift,
-                                            void *__restrict__ dist_out)
+                                            void *__restrict__ dist_out, PlaneTab pt)
 {
     static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
     extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // jpb * (h + TAPS - 1) * w
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         const int jl = u / per1, r = u - jl * per1, y = r / segs, x0 = (r - y * segs) * SEG;
         const xeve_hip_mc_job jb = jobs[j0 + jl];
         if((jb.frac & 7) != 3) continue; // bit 2 = job switched off (xeve_hip_mc_cu_jobs)
-        const pel *src = ref + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
+        const pel *src = plane_of(pt, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
         int acc[SEG];
         hfir<TAPS, SEG>(src, tab.c[jb.gmv_x & FM], acc);
 #pragma unroll
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         const xeve_hip_mc_job jb = jobs[j0 + jl];
         if(jb.frac & 4) continue;
         const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
-        const pel *src = ref + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
+        const pel *src = plane_of(pt, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
         pel *out = pred + jb.pred_off + y * s_pred + x0;
         int acc[SEG];
         if(!hx && !vy) {
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
 // Fallback for widths that are not a multiple of 4 (or luma width 4): one thread per output pel.
 template <int TAPS>
 __global__ void k_mc_any(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
-                         const xeve_hip_mc_job *__restrict__ jobs, int w, int h, int bit_depth, CoefTab<TAPS> tab)
+                         const xeve_hip_mc_job *__restrict__ jobs, int w, int h, int bit_depth, CoefTab<TAPS> tab, PlaneTab pt)
 {
     constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
     const xeve_hip_mc_job jb = jobs[blockIdx.x];
@@ -194,7 +203,7 @@ __global__ void k_mc_any(const pel *__restrict__ ref, int s_ref, pel *__restrict
     const int  shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
     for(int u = threadIdx.x; u < w * h; u += blockDim.x) {
         int y = u / w, x = u % w, v;
-        const pel *p = ref + (long)(iy + y) * s_ref + ix + x;
+        const pel *p = plane_of(pt, ref, jb.frac) + (long)(iy + y) * s_ref + ix + x;
         if(!hx && !vy) v = p[0];
         else if(hx && !vy) {
             int a = 0;
@@ -236,28 +245,32 @@ __global__ void k_avg(const int16_t *__restrict__ a, const int16_t *__restrict__
 
 template <int TAPS, int OUT>
 static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs, int w, int h,
-                     int bit_depth, const int16_t *coef, hipStream_t st, const pel *org = nullptr, int s_org = 0, void *dist_out = nullptr)
+                     int bit_depth, const int16_t *coef, hipStream_t st, const pel *org = nullptr, int s_org = 0, void *dist_out = nullptr,
+                     const PlaneTab *planes = nullptr)
 {
     XH_ENTER();
-    XH_REQUIRE(ref && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
+    XH_REQUIRE((ref || (planes && planes->n > 0)) && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
     XH_REQUIRE(OUT != 0 ? (org && dist_out) : (pred != nullptr));
     XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
     if(njobs == 0) return XEVE_HIP_OK;
     CoefTab<TAPS> tab;
     memcpy(tab.c, coef, sizeof(tab.c));
+    PlaneTab pt;
+    if(planes) pt = *planes;
+    else pt.n = 0;
     const int dshift = OUT == 1 ? bit_depth - 8 : (bit_depth - 8) * 2;
     bool done = false;
     if(w % 8 == 0) {
         const int jpb = std::max(1, 256 / (h * (w / 8)));
         const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-        k_mc<TAPS, 8, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out);
+        k_mc<TAPS, 8, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt);
         done = true;
     }
     if constexpr(TAPS == 4) {
         if(!done && w % 4 == 0) {
             const int jpb = std::max(1, 256 / (h * (w / 4)));
             const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-            k_mc<4, 4, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out);
+            k_mc<4, 4, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt);
             done = true;
         }
     }
@@ -266,7 +279,7 @@ static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xev
             xh_set_error("fused MC + distortion needs w %% %d == 0 (got %dx%d); use the unfused calls", TAPS == 8 ? 8 : 4, w, h);
             return XEVE_HIP_ERR_ARG;
         }
-        k_mc_any<TAPS><<<njobs, 64, 0, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab);
+        k_mc_any<TAPS><<<njobs, 64, 0, st>>>(ref, s_ref, pred, s_pred, jobs, w, h, bit_depth, tab, pt);
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
@@ -442,7 +455,6 @@ __global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int nj
     bool use1 = valid[1];
     if(valid[0] && valid[1] && P.poc[0][J.refi[0]] == P.poc[1][J.refi[1]] && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1]) use1 = false;
     mode[j] = (uint8_t)(use1 ? (valid[0] ? 1 : 2) : 0); // 1 average the two, 2 list 1 alone: copy it over
-    int q = 0;
 #pragma unroll
     for(int l = 0; l < 2; l++) {
         const bool on = l == 0 ? valid[0] : use1;
@@ -452,12 +464,10 @@ __global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int nj
         a.frac = ((J.mv[l][0] & 3) ? 1 : 0) | ((J.mv[l][1] & 3) ? 2 : 0);
         c.gmv_x = gx * P.wfac, c.gmv_y = gy * P.hfac, c.pred_off = j * P.cw * P.ch;
         c.frac = ((J.mv[l][0] & 7) ? 1 : 0) | ((J.mv[l][1] & 7) ? 2 : 0);
-        for(int r = 0; r < P.nref[l]; r++, q++) {
-            const int off = (on && J.refi[l] == r) ? 0 : 4;
-            xeve_hip_mc_job al = a, cl = c;
-            al.frac |= off, cl.frac |= off;
-            jl[(size_t)q * njobs + j] = al, jc[(size_t)q * njobs + j] = cl;
-        }
+        // one job array per list; the reference picture rides in frac bits 3.. (PlaneTab); bit 2 switches a job off
+        const int sel = (on && J.refi[l] < P.nref[l]) ? (J.refi[l] << 3) : 4;
+        a.frac |= sel, c.frac |= sel;
+        jl[(size_t)l * njobs + j] = a, jc[(size_t)l * njobs + j] = c;
     }
 }
 
@@ -478,7 +488,8 @@ __global__ void k_cu_mc_combine(pel *__restrict__ p0, const pel *__restrict__ p1
 
 extern "C" size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp0, int num_refp1)
 {
-    const size_t n = njobs > 0 ? njobs : 0, q = (size_t)(num_refp0 + num_refp1);
+    const size_t n = njobs > 0 ? njobs : 0, q = 2; // one job array per list and plane type
+    (void)num_refp0, (void)num_refp1;
     return ((n + 15) & ~(size_t)15) + 2 * q * n * sizeof(xeve_hip_mc_job) + 3 * n * (size_t)w * h * sizeof(pel);
 }
 
@@ -501,7 +512,7 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     const int nmax = num_refp0 > num_refp1 ? num_refp0 : num_refp1;
     for(int r = 0; r < XH_MAX_REF; r++)
         for(int l = 0; l < 2; l++) P.poc[l][r] = r < nmax ? refp[r * 2 + l].poc : 0;
-    const size_t n = njobs, q = (size_t)(num_refp0 + num_refp1);
+    const size_t n = njobs, q = 2;
     uint8_t         *mode = (uint8_t *)workspace;
     xeve_hip_mc_job *jl   = (xeve_hip_mc_job *)(mode + ((n + 15) & ~(size_t)15)), *jc = jl + q * n;
     pel             *p1[3];
@@ -509,20 +520,24 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     hipStream_t st = (hipStream_t)stream;
     k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, P, jl, jc, mode);
     XH_HIP(hipGetLastError());
-    int qi = 0;
-    for(int l = 0; l < 2; l++)
-        for(int r = 0; r < P.nref[l]; r++, qi++) {
-            const xeve_hip_refpic &R = refp[r * 2 + l];
+    for(int l = 0; l < 2; l++) { // one launch per list and component: the jobs pick their reference picture from the table
+        if(!P.nref[l]) continue;
+        PlaneTab ty, tu, tv;
+        ty.n = tu.n = tv.n = P.nref[l];
+        for(int r = 0; r < XH_MAX_PLANES; r++) {
+            const xeve_hip_refpic &R = refp[(r < P.nref[l] ? r : 0) * 2 + l];
             XH_REQUIRE(R.y && (chroma_format_idc == 0 || (R.u && R.v)));
-            int rc = mc_launch<8, 0>(R.y, s_l, l ? p1[0] : pred_y, w, jl + (size_t)qi * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st);
-            if(rc != XEVE_HIP_OK) return rc;
-            if(chroma_format_idc) {
-                rc = mc_launch<4, 0>(R.u, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)qi * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st);
-                if(rc != XEVE_HIP_OK) return rc;
-                rc = mc_launch<4, 0>(R.v, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)qi * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st);
-                if(rc != XEVE_HIP_OK) return rc;
-            }
+            ty.p[r] = R.y, tu.p[r] = R.u, tv.p[r] = R.v;
         }
+        int rc = mc_launch<8, 0>(nullptr, s_l, l ? p1[0] : pred_y, w, jl + (size_t)l * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st, nullptr, 0, nullptr, &ty);
+        if(rc != XEVE_HIP_OK) return rc;
+        if(chroma_format_idc) {
+            rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tu);
+            if(rc != XEVE_HIP_OK) return rc;
+            rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tv);
+            if(rc != XEVE_HIP_OK) return rc;
+        }
+    }
     if(num_refp1 > 0) {
         const long tl = ((long)njobs * w * h) / 4, tc = ((long)njobs * P.cw * P.ch) / 4;
         k_cu_mc_combine<<<(unsigned)((tl + 255) / 256), 256, 0, st>>>(pred_y, p1[0], mode, njobs, w * h);
