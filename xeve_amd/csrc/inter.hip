@@ -21,7 +21,7 @@
 enum { M_L0 = 0, M_L1 = 1, M_BI = 2, M_SKIP = 3, M_DIR = 4, M_NUM = 5 }; // PRED_* (xeve_def.h:461-469)
 
 struct InterK {
-    int    n, isb, lw, n0, n1, ncomp, bd, max_cand, nref[2], nb, na; // na: candidates of the first pinter_residue_rdo batch (3n in B, n in P)
+    int    n, isb, lw, n0, n1, ncomp, bd, max_cand, nref[2], nb, na, np; // np: planes per list in the search job / result arrays // na: candidates of the first pinter_residue_rdo batch (3n in B, n in P)
     int    s_org_l;
     int    dpoc_co, dpoc_l0, dpoc_l1;
     double thr, lambda0;
@@ -97,8 +97,11 @@ __global__ void k_inter_stage1(const xeve_hip_inter_job *__restrict__ jobs, Inte
     for(int l = 0; l <= P.isb; l++) {
         xeve_hip_epzs_job e;
         const int idx = S.mvpi[M_SKIP][l]; // mvp_idx[lidx] = pi->mvp_idx[PRED_SKIP][lidx] (:1927)
-        e.x = J.x, e.y = J.y, e.org_off = 0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1], e.mv_start[0] = e.mv_start[1] = 0;
-        ej[l * P.n + j] = e;
+        e.y = J.y, e.org_off = 0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1], e.mv_start[0] = e.mv_start[1] = 0;
+        for(int r = 0; r < P.np; r++) { // the same search against every reference picture of the list (planes the list does not hold: off)
+            e.x = r < P.nref[l] ? J.x : -1;
+            ej[((size_t)l * P.np + r) * P.n + j] = e;
+        }
     }
     st[j] = S;
 }
@@ -117,7 +120,7 @@ __global__ void k_inter_uni_a(const xeve_hip_inter_job *__restrict__ jobs, Inter
     unsigned best = 0xFFFFFFFFu;
     int      rsel = 0;
     for(int r = 0; r < P.nref[l]; r++) {
-        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + j];
+        const xeve_hip_me_result m = mres[((size_t)l * P.np + r) * P.n + j];
         S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1];
         if(m.cost < best) best = m.cost, rsel = r;
         if(m.best_mv_bits > 0) S.mot_bits[l] = m.best_mv_bits;
@@ -231,21 +234,20 @@ __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK
     InterSt &S = st[j];
     const int idx = S.mvpi[M_BI][l];
     S.bi_slot = k;
-    extra[(size_t)l * P.n + k] = S.mot_bits[1 - l];
     for(int r = 0; r < P.nb; r++) {
         xeve_hip_epzs_job e;
         e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
         e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
-        ej[((size_t)l * MAXR + r) * P.n + k] = e;
+        ej[((size_t)l * P.np + r) * P.n + k] = e, extra[((size_t)l * P.np + r) * P.n + k] = S.mot_bits[1 - l];
     }
 }
 
 __global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if(t >= 2 * P.nb * P.n) return;
-    const int lr = t / P.n, k = t - lr * P.n, l = lr / P.nb, r = lr - l * P.nb;
-    ej[((size_t)l * MAXR + r) * P.n + k].x = -1;
+    if(t >= 2 * P.np * P.n) return;
+    const int lr = t / P.n, k = t - lr * P.n, l = lr / P.np, r = lr - l * P.np;
+    ej[((size_t)l * P.np + r) * P.n + k].x = -1;
 }
 
 // one round, second half (:1633-1663): every reference picture of the searched list against the running best
@@ -258,7 +260,7 @@ __global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mre
     const int l = S.lidx_ref;
     int changed = 0;
     for(int r = 0; r < P.nb; r++) {
-        const xeve_hip_me_result m = mres[((size_t)l * MAXR + r) * P.n + S.bi_slot];
+        const xeve_hip_me_result m = mres[((size_t)l * P.np + r) * P.n + S.bi_slot];
         S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1]; // fn_me refines pi->mv_scale[lidx_ref][refi_cur] in place
         if(m.cost < S.best_mecost) {
             S.refi_best = r, S.best_mecost = m.cost, changed = 1;
@@ -392,11 +394,11 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2), L.st_b = take(N * sizeof(xeve_hip_sbac));
     L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
     L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
-    L.org_bi = take(N * n0 * 2), L.extra = take(2 * N * 4), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
+    L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
     L.off[0] = take(N * 4), L.off[1] = take(N * 4);
     // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
     size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
-    s = max2(s, xeve_hip_me_epzs_workspace(n));
+    s = max2(s, xeve_hip_me_epzs_workspace(2 * (rp.num_refp[0] > rp.num_refp[1] ? rp.num_refp[0] : rp.num_refp[1]) * n));
     s = max2(s, xeve_hip_cu_bits_workspace(10 * n, 64));
     s = max2(s, xeve_hip_residue_rdo_workspace((int)na, nstates, &rp, s_org_l, s_org_c));
     s = max2(s, xeve_hip_mc_cu_workspace(n, 1 << rp.log2_cuw, 1 << rp.log2_cuh, rp.num_refp[0], rp.num_refp[1]));
@@ -436,7 +438,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     XH_REQUIRE(workspace_bytes >= L.total);
     InterK P;
     P.n = njobs, P.isb = rp.slice_type == 0, P.lw = lw, P.n0 = w * w, P.n1 = idc ? P.n0 >> (ws + hs) : 0, P.ncomp = idc ? 3 : 1, P.bd = bd;
-    P.max_cand = p->max_cand, P.nref[0] = rp.num_refp[0], P.nref[1] = P.isb ? rp.num_refp[1] : 0, P.nb = rp.num_refp[1], P.na = P.isb ? 3 * njobs : njobs;
+    P.max_cand = p->max_cand, P.nref[0] = rp.num_refp[0], P.nref[1] = P.isb ? rp.num_refp[1] : 0, P.nb = rp.num_refp[1], P.na = P.isb ? 3 * njobs : njobs, P.np = rp.num_refp[0] > P.nref[1] ? rp.num_refp[0] : P.nref[1];
     P.s_org_l = s_org_l;
     P.dpoc_co = refp[0 * 2 + 1].poc - p->col_list_poc0, P.dpoc_l0 = p->poc - refp[0 * 2 + 0].poc, P.dpoc_l1 = refp[0 * 2 + 1].poc - p->poc; // xeve_util.c:634-636
     P.thr = (double)((int64_t)1 << (2 * lw + 2 * (bd - 8))) * p->skip_th, P.lambda0 = rp.lambda[0];
@@ -469,15 +471,24 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_stage1<<<G, 256, 0, s>>>(jobs, P, sres, st, rja, ej);
     // motion search per list and reference picture (:1906-1950)
+    // ONE launch chain over every (list, reference picture): the job arrays are laid out [list][plane][CU], the plane supplies the picture
     xeve_hip_epzs_params ep = p->me;
+    XhSearchPlanes pl;
+    pl.per_plane = njobs;
+    auto planes_for = [&](int nlists, int bi) {
+        pl.n = nlists * P.np;
+        for(int l = 0; l < nlists; l++)
+            for(int r = 0; r < P.np; r++) {
+                const int q = l * P.np + r, rr = r < rp.num_refp[l] ? r : 0;
+                pl.ref[q] = refp[rr * 2 + l].y, pl.refi_bits[q] = bi ? p->refi_bits[1][rr] : p->refi_bits[l][rr], pl.range[q] = p->range_recentre[l][rr];
+            }
+    };
     for(int l = 0; l <= P.isb; l++)
-        for(int r = 0; r < P.nref[l]; r++) {
-            XH_REQUIRE(refp[r * 2 + l].y);
-            ep.me.bi = 0, ep.me.extra_bits = 0, ep.me.refi_bits = p->refi_bits[l][r], ep.me.range_recentre = p->range_recentre[l][r];
-            rc = xeve_hip_me_epzs_jobs(org[0], s_org_l, nullptr, refp[r * 2 + l].y, s_l, ej + (size_t)l * njobs, njobs, lw, lw, bd, coef_l, &ep,
-                                       mres + ((size_t)l * MAXR + r) * njobs, scr, L.scratch_bytes, stream);
-            if(rc != XEVE_HIP_OK) return rc;
-        }
+        for(int r = 0; r < P.nref[l]; r++) XH_REQUIRE(refp[r * 2 + l].y);
+    planes_for(1 + P.isb, 0);
+    ep.me.bi = 0, ep.me.extra_bits = 0;
+    rc = xh_me_epzs_jobs_planes(org[0], s_org_l, nullptr, nullptr, s_l, ej, pl.n * njobs, lw, lw, bd, coef_l, &ep, nullptr, mres, scr, L.scratch_bytes, stream, &pl);
+    if(rc != XEVE_HIP_OK) return rc;
     // check_best_mvp, then pinter_residue_rdo of direct + L0 + L1 in one batch
     const int nl = 1 + P.isb;
     k_inter_uni_a<<<(nl * njobs + 255) / 256, 256, 0, s>>>(jobs, P, mres, st, bjm);
@@ -500,13 +511,11 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
             XH_HIP(hipMemsetAsync(cnt, 0, 8, s));
             k_bi_jobs_off<<<(2 * P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej);
             k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt);
-            for(int l = 0; l < 2; l++)
-                for(int r = 0; r < P.nb; r++) {
-                    ep.me.bi = 1, ep.me.extra_bits = 0, ep.me.refi_bits = p->refi_bits[1][r], ep.me.range_recentre = p->range_recentre[l][r];
-                    rc = xeve_hip_me_epzs_jobs_x(org[0], s_org_l, (const pel *)org_bi, refp[r * 2 + l].y, s_l, ej + ((size_t)l * MAXR + r) * njobs, njobs, lw, lw, bd, coef_l,
-                                                 &ep, extra + (size_t)l * njobs, mres + ((size_t)l * MAXR + r) * njobs, scr, L.scratch_bytes, stream);
-                    if(rc != XEVE_HIP_OK) return rc;
-                }
+            planes_for(2, 1);
+            ep.me.bi = 1, ep.me.extra_bits = 0;
+            rc = xh_me_epzs_jobs_planes(org[0], s_org_l, (const pel *)org_bi, nullptr, s_l, ej, pl.n * njobs, lw, lw, bd, coef_l, &ep, extra, mres, scr, L.scratch_bytes, stream,
+                                        &pl);
+            if(rc != XEVE_HIP_OK) return rc;
             k_bi_update<<<G, 256, 0, s>>>(P, mres, st);
         }
         k_bi_finish<<<G, 256, 0, s>>>(jobs, P, st, rjb);

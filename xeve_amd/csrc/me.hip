@@ -217,11 +217,15 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
 template <int S, bool BI>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
                                                  const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
-                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st)
+                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl)
 {
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
+    if(pl.n) { // several reference pictures in one launch: the job's plane supplies picture, index bits and range
+        const int q = uni(j / pl.per_plane);
+        ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q];
+    }
     const xeve_hip_epzs_job e = jobs[j];
     if(e.x < 0) { // job switched off
         EpzsState z;
@@ -306,8 +310,23 @@ extern "C" int xeve_hip_me_epzs_jobs_x(const pel *org0, int s_org, const pel *or
                                        const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results, void *workspace,
                                        size_t workspace_bytes, void *stream)
 {
+    return xh_me_epzs_jobs_planes(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, log2w, log2h, bit_depth, coef, params, extra_bits, results, workspace,
+                                  workspace_bytes, stream, nullptr);
+}
+
+int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs, int njobs, int log2w, int log2h,
+                           int bit_depth, const int16_t (*coef)[8], const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results,
+                           void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes)
+{
     XH_ENTER();
-    XH_REQUIRE(org0 && ref0 && jobs && coef && params && results && workspace && njobs >= 0);
+    XH_REQUIRE(org0 && (ref0 || (planes && planes->n > 0)) && jobs && coef && params && results && workspace && njobs >= 0);
+    XhSearchPlanes pl;
+    pl.n = 0, pl.per_plane = 1;
+    if(planes && planes->n > 0) {
+        XH_REQUIRE(planes->n <= XH_MAX_PLANES && planes->per_plane > 0 && (long)planes->n * planes->per_plane >= njobs);
+        pl = *planes;
+        for(int i = pl.n; i < XH_MAX_PLANES; i++) pl.ref[i] = pl.ref[0], pl.refi_bits[i] = pl.refi_bits[0], pl.range[i] = pl.range[0];
+    }
     XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
     XH_REQUIRE(params->me.bi == 0 || params->me.bi == 1);
     XH_REQUIRE(log2w == log2h && log2w >= 3 && log2w <= 6 && bit_depth >= 8 && bit_depth <= 14 && (params->me.bi == 0 || org_bi != nullptr));
@@ -326,8 +345,8 @@ extern "C" int xeve_hip_me_epzs_jobs_x(const pel *org0, int s_org, const pel *or
         const int  shift = bit_depth - 8;
 #define EPZS_LAUNCH(S)                                                                                                     \
     do {                                                                                                                   \
-        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state);   \
-        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state);      \
+        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl);   \
+        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl);      \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);
         else if(log2w == 4) EPZS_LAUNCH(16);
@@ -342,7 +361,7 @@ extern "C" int xeve_hip_me_epzs_jobs_x(const pel *org0, int s_org, const pel *or
     SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;
     SP.hpel_cnt = params->hpel_cnt, SP.qpel_cnt = params->qpel_cnt;
     int rc = xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, extra_bits, sres, sws,
-                                       xeve_hip_me_spel_workspace(njobs), st);
+                                       xeve_hip_me_spel_workspace(njobs), st, pl.n ? &pl : nullptr);
     if(rc != XEVE_HIP_OK) return rc;
     k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
     XH_HIP(hipGetLastError());

@@ -51,9 +51,20 @@ struct RdoParams {
 
 // zig-zag scan of a (1 << log2w) x (1 << log2h) block (xeve_tbl_scan), device memory, built once (rdoq.hip)
 int xh_get_scan(int log2w, int log2h, const uint16_t **out);
+// One launch over the searches of several reference pictures: job j belongs to plane j / per_plane; the plane supplies the picture, the
+// reference index bits and (integer stage) the re-centred range.  n == 0: the single-picture form.
+#define XH_MAX_PLANES 16
+struct XhSearchPlanes {
+    const pel *ref[XH_MAX_PLANES];
+    int        refi_bits[XH_MAX_PLANES], range[XH_MAX_PLANES];
+    int        n, per_plane;
+};
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
-                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream); // mc.hip
+                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes = nullptr); // mc.hip
+int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs, int njobs, int log2w, int log2h,
+                           int bit_depth, const int16_t (*coef)[8], const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results,
+                           void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes); // me.hip
 
 static inline int xh_ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
 static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
