@@ -207,7 +207,7 @@ __global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, 
 }
 
 __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_epzs_job *__restrict__ ej,
-                             int32_t *__restrict__ extra, int32_t *__restrict__ cnt)
+                             int32_t *__restrict__ extra, int32_t *__restrict__ cnt, unsigned char *__restrict__ job_plane)
 {
     const int  j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const bool act = j < P.n && st[j].active;
@@ -218,18 +218,15 @@ __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK
         S.rf[0] = S.rf[1], S.rf[1] = t;
         l = S.lidx_ref = 1 - S.lidx_ref;
     }
-    // The CUs of a batch differ in which list they search: one compacted job array per list (slots handed out per wave with one atomic
-    // per list; the order inside is arbitrary, results come back through bi_slot).  Slots beyond the count stay switched off.
-    const unsigned long long m0 = __ballot(act && l == 0), m1 = __ballot(act && l == 1);
-    int b0 = 0, b1 = 0;
-    if(lane == 0) {
-        if(m0) b0 = atomicAdd(&cnt[0], __popcll(m0));
-        if(m1) b1 = atomicAdd(&cnt[1], __popcll(m1));
-    }
-    b0 = __shfl(b0, 0, 64), b1 = __shfl(b1, 0, 64);
+    // The still-searching CUs are compacted to the front of the job arrays (slots handed out per wave with one atomic; the order is
+    // arbitrary, results come back through bi_slot); a CU's jobs -- one per reference picture of the list it searches -- carry their plane
+    // (list, picture) in job_plane.  Slots beyond the count stay switched off.
+    const unsigned long long m = __ballot(act);
+    int b = 0;
+    if(lane == 0 && m) b = atomicAdd(&cnt[0], __popcll(m));
+    b = __shfl(b, 0, 64);
     if(!act) return;
-    const unsigned long long below = (1ull << lane) - 1;
-    const int k = l == 0 ? b0 + __popcll(m0 & below) : b1 + __popcll(m1 & below);
+    const int k = b + __popcll(m & ((1ull << lane) - 1));
     const xeve_hip_inter_job J = jobs[j];
     InterSt &S = st[j];
     const int idx = S.mvpi[M_BI][l];
@@ -238,16 +235,16 @@ __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK
         xeve_hip_epzs_job e;
         e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
         e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
-        ej[((size_t)l * P.np + r) * P.n + k] = e, extra[((size_t)l * P.np + r) * P.n + k] = S.mot_bits[1 - l];
+        const size_t at = (size_t)r * P.n + k;
+        ej[at] = e, extra[at] = S.mot_bits[1 - l], job_plane[at] = (unsigned char)(l * P.np + r);
     }
 }
 
-__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej)
+__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej, unsigned char *__restrict__ job_plane)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if(t >= 2 * P.np * P.n) return;
-    const int lr = t / P.n, k = t - lr * P.n, l = lr / P.np, r = lr - l * P.np;
-    ej[((size_t)l * P.np + r) * P.n + k].x = -1;
+    if(t >= P.nb * P.n) return;
+    ej[t].x = -1, job_plane[t] = 0;
 }
 
 // one round, second half (:1633-1663): every reference picture of the searched list against the running best
@@ -260,7 +257,7 @@ __global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mre
     const int l = S.lidx_ref;
     int changed = 0;
     for(int r = 0; r < P.nb; r++) {
-        const xeve_hip_me_result m = mres[((size_t)l * P.np + r) * P.n + S.bi_slot];
+        const xeve_hip_me_result m = mres[(size_t)r * P.n + S.bi_slot];
         S.mv_scale[l][r][0] = m.mv[0], S.mv_scale[l][r][1] = m.mv[1]; // fn_me refines pi->mv_scale[lidx_ref][refi_cur] in place
         if(m.cost < S.best_mecost) {
             S.refi_best = r, S.best_mecost = m.cost, changed = 1;
@@ -372,7 +369,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, cnt, win, tmp, is_coef, off[2],
+    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
         scratch, scratch_bytes, total;
 };
 
@@ -394,7 +391,7 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2), L.st_b = take(N * sizeof(xeve_hip_sbac));
     L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
     L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
-    L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
+    L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.job_plane = take(MAXR * N), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
     L.off[0] = take(N * 4), L.off[1] = take(N * 4);
     // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
     size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
@@ -459,6 +456,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win), *off0 = (int32_t *)(W + L.off[0]), *off1 = (int32_t *)(W + L.off[1]);
     auto *is_coef = (unsigned char *)(W + L.is_coef);
     auto *cnt = (int32_t *)(W + L.cnt);
+    auto *job_plane = (unsigned char *)(W + L.job_plane);
     void *scr = W + L.scratch;
     hipStream_t s = (hipStream_t)stream;
     const int G = (njobs + 255) / 256;
@@ -474,7 +472,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     // ONE launch chain over every (list, reference picture): the job arrays are laid out [list][plane][CU], the plane supplies the picture
     xeve_hip_epzs_params ep = p->me;
     XhSearchPlanes pl;
-    pl.per_plane = njobs;
+    pl.per_plane = njobs, pl.job_plane = nullptr;
     auto planes_for = [&](int nlists, int bi) {
         pl.n = nlists * P.np;
         for(int l = 0; l < nlists; l++)
@@ -509,11 +507,12 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
             if(rc != XEVE_HIP_OK) return rc;
             k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], org_bi);
             XH_HIP(hipMemsetAsync(cnt, 0, 8, s));
-            k_bi_jobs_off<<<(2 * P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej);
-            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt);
+            k_bi_jobs_off<<<(P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej, job_plane);
+            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt, job_plane);
             planes_for(2, 1);
+            pl.job_plane = job_plane;
             ep.me.bi = 1, ep.me.extra_bits = 0;
-            rc = xh_me_epzs_jobs_planes(org[0], s_org_l, (const pel *)org_bi, nullptr, s_l, ej, pl.n * njobs, lw, lw, bd, coef_l, &ep, extra, mres, scr, L.scratch_bytes, stream,
+            rc = xh_me_epzs_jobs_planes(org[0], s_org_l, (const pel *)org_bi, nullptr, s_l, ej, P.nb * njobs, lw, lw, bd, coef_l, &ep, extra, mres, scr, L.scratch_bytes, stream,
                                         &pl);
             if(rc != XEVE_HIP_OK) return rc;
             k_bi_update<<<G, 256, 0, s>>>(P, mres, st);

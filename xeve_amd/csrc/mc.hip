@@ -331,7 +331,7 @@ __device__ __constant__ int8_t c_pat_qpel[8][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, 
 
 // stage 0: centre = mvi; stage 1: centre = the half-pel winner stored in res[j].mv
 __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, int s_org, int blk_elems, int bi,
-                            const xeve_hip_me_result *__restrict__ res, xeve_hip_mc_job *__restrict__ mc, int per_plane)
+                            const xeve_hip_me_result *__restrict__ res, xeve_hip_mc_job *__restrict__ mc, int per_plane, const unsigned char *__restrict__ job_plane)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= njobs * cnt) return;
@@ -344,7 +344,7 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
     m.gmv_x = mx << 2, m.gmv_y = my << 2; // 1/16 pel, as the reference passes (mv_x << 2), xeve_pinter.c:608
     m.pred_off = bi ? jb.org_off : jb.y * s_org + jb.x;
     m.frac = ((mx & 3) != 0 ? 1 : 0) | ((my & 3) != 0 ? 2 : 0);
-    if(per_plane) m.frac |= (j / per_plane) << 3; // the job's reference picture (PlaneTab)
+    if(per_plane) m.frac |= xh_plane_of_job(job_plane, per_plane, j) << 3; // the job's reference picture (PlaneTab)
     if(jb.x < 0) m.gmv_x = m.gmv_y = 0, m.pred_off = 0, m.frac = 4; // job switched off
     (void)blk_elems;
     mc[t] = m;
@@ -352,13 +352,14 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
 
 struct SpelBits {
     int refi_bits[XH_MAX_PLANES], per_plane;
+    const unsigned char *job_plane;
 };
 __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, xeve_hip_spel_params P,
                               const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res, SpelBits sb)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
-    if(sb.per_plane) P.refi_bits = sb.refi_bits[j / sb.per_plane];
+    if(sb.per_plane) P.refi_bits = sb.refi_bits[xh_plane_of_job(sb.job_plane, sb.per_plane, j)];
     const xeve_hip_spel_job jb = jobs[j];
     xeve_hip_me_result r;
     if(stage) r = res[j];
@@ -399,10 +400,10 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
     XH_REQUIRE(org0 && (ref0 || (planes && planes->n > 0)) && jobs && coef && params && results && workspace && njobs >= 0);
     PlaneTab pt;
     SpelBits sb;
-    pt.n = 0, sb.per_plane = 0;
+    pt.n = 0, sb.per_plane = 0, sb.job_plane = nullptr;
     if(planes && planes->n > 0) {
         XH_REQUIRE(planes->n <= XH_MAX_PLANES && planes->per_plane > 0);
-        pt.n = planes->n, sb.per_plane = planes->per_plane;
+        pt.n = planes->n, sb.per_plane = planes->per_plane, sb.job_plane = planes->job_plane;
         for(int i = 0; i < XH_MAX_PLANES; i++) pt.p[i] = planes->ref[i < planes->n ? i : 0], sb.refi_bits[i] = planes->refi_bits[i < planes->n ? i : 0];
     }
     XH_REQUIRE(log2w >= 3 && log2w <= 6 && log2h >= 3 && log2h <= 6);
@@ -421,7 +422,7 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
         const int cnt = stage ? P.qpel_cnt : P.hpel_cnt;
         if(cnt == 0) break;
         const int items = njobs * cnt;
-        k_spel_make<<<(items + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, s_org, w * h, P.bi, results, mc, sb.per_plane);
+        k_spel_make<<<(items + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, s_org, w * h, P.bi, results, mc, sb.per_plane, sb.job_plane);
         XH_HIP(hipGetLastError());
         int rc = mc_launch<8, 1>(ref0, s_ref, nullptr, 0, mc, items, w, h, bit_depth, &coef[0][0], st, cmp, s_c, sad, pt.n ? &pt : nullptr);
         if(rc != XEVE_HIP_OK) return rc;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     if(pl.n) { // several reference pictures in one launch: the job's plane supplies picture, index bits and range
-        const int q = uni(j / pl.per_plane);
+        const int q = uni(xh_plane_of_job(pl.job_plane, pl.per_plane, j));
         ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q];
     }
     const xeve_hip_epzs_job e = jobs[j];
@@ -321,9 +321,9 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     XH_ENTER();
     XH_REQUIRE(org0 && (ref0 || (planes && planes->n > 0)) && jobs && coef && params && results && workspace && njobs >= 0);
     XhSearchPlanes pl;
-    pl.n = 0, pl.per_plane = 1;
+    pl.n = 0, pl.per_plane = 1, pl.job_plane = nullptr;
     if(planes && planes->n > 0) {
-        XH_REQUIRE(planes->n <= XH_MAX_PLANES && planes->per_plane > 0 && (long)planes->n * planes->per_plane >= njobs);
+        XH_REQUIRE(planes->n <= XH_MAX_PLANES && planes->per_plane > 0 && (planes->job_plane || (long)planes->n * planes->per_plane >= njobs));
         pl = *planes;
         for(int i = pl.n; i < XH_MAX_PLANES; i++) pl.ref[i] = pl.ref[0], pl.refi_bits[i] = pl.refi_bits[0], pl.range[i] = pl.range[0];
     }

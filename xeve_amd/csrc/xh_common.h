@@ -58,7 +58,9 @@ struct XhSearchPlanes {
     const pel *ref[XH_MAX_PLANES];
     int        refi_bits[XH_MAX_PLANES], range[XH_MAX_PLANES];
     int        n, per_plane;
+    const unsigned char *job_plane; // device array or NULL: the plane of job j when the jobs are not laid out plane by plane
 };
+__device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
                               xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes = nullptr); // mc.hip
