@@ -33,7 +33,7 @@ struct InterSt { // per CU, between the stages
     uint8_t  mvpi[M_NUM][2];
     int16_t  mv_scale[2][MAXR][2];
     int32_t  mot_bits[2];
-    int32_t  go, refi_sel[2];
+    int32_t  go;
     // analyze_bi
     int32_t  lidx_ref, active, refi_best, bi_slot;
     uint32_t best_mecost;
@@ -125,7 +125,6 @@ __global__ void k_inter_uni_a(const xeve_hip_inter_job *__restrict__ jobs, Inter
         if(m.cost < best) best = m.cost, rsel = r;
         if(m.best_mv_bits > 0) S.mot_bits[l] = m.best_mv_bits;
     }
-    S.refi_sel[l] = rsel;
     const int mvx = S.mv_scale[l][rsel][0], mvy = S.mv_scale[l][rsel][1];
     S.mv[l][l][0] = (int16_t)mvx, S.mv[l][l][1] = (int16_t)mvy;
     S.refi[l][l] = (int8_t)rsel, S.refi[l][1 - l] = -1;
@@ -373,12 +372,10 @@ struct InterLayout {
         scratch, scratch_bytes, total;
 };
 
-static xeve_hip_rdo_params rdo_of(const xeve_hip_inter_params *p) { return p->rdo; }
-
 static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params *p, int s_org_l, int s_org_c)
 {
     InterLayout L;
-    const xeve_hip_rdo_params rp = rdo_of(p);
+    const xeve_hip_rdo_params rp = p->rdo;
     const int    isb = rp.slice_type == 0, idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
     const size_t N = n, n0 = (size_t)1 << (rp.log2_cuw + rp.log2_cuh), n1 = idc ? n0 >> (ws + hs) : 0, na = isb ? 3 * N : N, ne = n0 + 2 * n1;
     size_t o = 0;
