@@ -327,19 +327,19 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     k_rdo_round1<<<G, 256, 0, st>>>(jobs, P, nnz[0], nnz[1], nnz[2], cand, bj);
     // (the complete coder state is carried only where core->s_temp_best can come from -- the whole-CU counts of rounds 1 and 4 -- and only
     // when the caller wants it; the component tests' states are only ever loaded into further counts: range and models suffice)
-    rc_ = best ? xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream)
-               : xeve_hip_cu_bits_jobs_chain(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+    // (the event lists of the coefficient blocks are made in round 1 -- its "as quantised" jobs code every non-zero block -- and reused after)
+    rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, best != nullptr, 0, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_rdo_decide1<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, st_out, states, cand, prev, bj, best);
     if(P.ncomp > 1) {
         for(int comp = 1; comp <= 2; comp++) {
-            rc_ = xeve_hip_cu_bits_jobs_chain(coef, coef_elems, prev, bj, 2 * njobs, &bp, W + L.bitws, bws, bits, st_out, stream);
+            rc_ = xh_cu_bits_jobs_round(coef, coef_elems, prev, bj, 2 * njobs, &bp, W + L.bitws, bws, bits, st_out, 0, 1, stream);
             if(rc_ != XEVE_HIP_OK) return rc_;
             k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, comp, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj);
         }
     }
     else k_rdo_decide_comp<<<G, 256, 0, st>>>(jobs, P, 2, ssd[0], ssd[1], ssd[2], bits, st_out, cand, prev, bj); // (no chroma: only builds the round 4 job)
-    rc_ = xeve_hip_cu_bits_jobs(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, stream);
+    rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, best != nullptr, 1, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_rdo_finish<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cand, results, drop, st_out, best);
     k_rdo_zero_dropped<<<3 * njobs, 64, 0, st>>>(coef, drop, P);

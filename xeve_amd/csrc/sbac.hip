@@ -316,8 +316,9 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
 
     // The coded components' event lists form ONE stream per lane: [0, b1) luma, [b1, b2) Cb, [b2, total) Cr.  A list ends
     // with its nnz-th event (the reference stops at num_sig == 0) or when it runs out.
-    const int l0 = (coded & 1) ? min(nev[j * 3], J.nnz[0]) : 0, l1 = (coded & 2) ? min(nev[j * 3 + 1], J.nnz[1]) : 0;
-    const int l2 = (coded & 4) ? min(nev[j * 3 + 2], J.nnz[2]) : 0;
+    // (nev == NULL: the event lists were made by an earlier launch over the same coefficient buffer and the jobs' nnz are exact counts)
+    const int l0 = (coded & 1) ? (nev ? min(nev[j * 3], J.nnz[0]) : J.nnz[0]) : 0, l1 = (coded & 2) ? (nev ? min(nev[j * 3 + 1], J.nnz[1]) : J.nnz[1]) : 0;
+    const int l2 = (coded & 4) ? (nev ? min(nev[j * 3 + 2], J.nnz[2]) : J.nnz[2]) : 0;
     const int b1 = l0, b2 = l0 + l1, total = l0 + l1 + l2;
     const int o0 = J.coef_off[0], o1 = J.coef_off[1] - b1, o2 = J.coef_off[2] - b2;
     const int d1 = o1 - o0, d2 = o2 - o1; // (additive form: a select between three bases makes the compiler build a pointer table in scratch)
@@ -455,7 +456,7 @@ extern "C" size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems)
 
 static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
-                          void *stream);
+                          void *stream, bool reuse_events = false);
 
 extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                                      const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits,
@@ -472,9 +473,18 @@ extern "C" int xeve_hip_cu_bits_jobs_chain(const int16_t *coef, size_t coef_elem
     return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, state_out, false, stream);
 }
 
+// A chain of bit-count rounds over ONE coefficient buffer (pinter_residue_rdo's four) needs the event lists only once: later rounds pass
+// reuse = 1 with the same workspace (jobs' nnz must then be the exact non-zero counts, as RDOQ returns them).
+int xh_cu_bits_jobs_round(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
+                          const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *state_out, int full, int reuse,
+                          void *stream)
+{
+    return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, state_out, full != 0, stream, reuse != 0);
+}
+
 static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
-                          void *stream)
+                          void *stream, bool reuse_events)
 {
     XH_ENTER();
     XH_REQUIRE(p && njobs >= 0);
@@ -500,7 +510,8 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     int      *nev = (int *)(ev + coef_elems);
     hipStream_t st = (hipStream_t)stream;
     const long items = 3L * njobs;
-    if(!coef) {}
+    if(reuse_events) nev = nullptr;
+    if(!coef || reuse_events) {}
     else if(P.n[0] <= 64) {
         const long waves = (items + 3) / 4;
         k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
