@@ -20,6 +20,8 @@ CASES = {
     # drifting texture (seed >= 5000): skip / direct / bi-prediction win here, unlike on noise
     "moving_ra_medium": (128, 64, 5, 5001, ["--preset", "medium", "-b", "1"]),
     "moving_ldb_fast": (128, 128, 3, 5002, ["--preset", "fast", "-I", "0", "-b", "0"]),
+    "moving_ldb_ref3": (128, 128, 5, 5003, ["--preset", "fast", "-I", "0", "-b", "0", "--ref", "3"]),  # several reference pictures per list
+    "moving_ra_b3_medium": (128, 64, 9, 5004, ["--preset", "medium", "-b", "3"]),  # hierarchical B pictures
 }
 
 

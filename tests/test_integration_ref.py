@@ -159,7 +159,7 @@ def test_bitstream_identical_with_cu_prediction_on_the_gpu(tmp_path, name):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads"])
+@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads", "moving_ldb_ref3", "moving_ra_b3_medium"])
 def test_bitstream_identical_with_the_whole_inter_analysis_on_the_gpu(tmp_path, name):
     """ctx->fn_pinter_analyze_cu -> xeve_hip_pinter_analyze_cu_host: skip / merge analysis, temporal direct, both lists' motion searches over every
     reference picture, check_best_mvp, the iterated bi-prediction search, every pinter_residue_rdo, the mode decision and the reconstruction of
@@ -172,3 +172,19 @@ def test_bitstream_identical_with_the_whole_inter_analysis_on_the_gpu(tmp_path, 
     m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
     assert m and int(m.group(1)) > 200 and int(m.group(2)) == 0, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the inter analysis on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_ref3"])
+def test_bitstream_identical_with_inter_analysis_and_every_other_route_on_the_gpu(tmp_path, name):
+    """the inter analysis on the GPU as one call per CU, and everything the encoder still does itself around it (intra CUs' transform / RDOQ / bit
+    counting, reconstruction, loop filter, padding) through the other GPU routes"""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, df=True, tq=True, eco=True, mc=True, me=True)
+    m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    assert m and int(m.group(1)) > 200 and int(m.group(2)) == 0, err
+    assert "loop filter and picture padding" in err and "transform + RDOQ" in err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
