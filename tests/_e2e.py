@@ -22,6 +22,7 @@ CASES = {
     "moving_ldb_fast": (128, 128, 3, 5002, ["--preset", "fast", "-I", "0", "-b", "0"]),
     "moving_ldb_ref3": (128, 128, 5, 5003, ["--preset", "fast", "-I", "0", "-b", "0", "--ref", "3"]),  # several reference pictures per list
     "moving_ra_b3_medium": (128, 64, 9, 5004, ["--preset", "medium", "-b", "3"]),  # hierarchical B pictures
+    "moving_cif_ra_medium": (352, 288, 5, 5006, ["--preset", "medium", "-b", "1"]),  # 5.5 x 4.5 CTUs: partial CTUs at the right and bottom edge
 }
 
 

@@ -159,7 +159,7 @@ def test_bitstream_identical_with_cu_prediction_on_the_gpu(tmp_path, name):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads", "moving_ldb_ref3", "moving_ra_b3_medium"])
+@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads", "moving_ldb_ref3", "moving_ra_b3_medium", "moving_cif_ra_medium"])
 def test_bitstream_identical_with_the_whole_inter_analysis_on_the_gpu(tmp_path, name):
     """ctx->fn_pinter_analyze_cu -> xeve_hip_pinter_analyze_cu_host: skip / merge analysis, temporal direct, both lists' motion searches over every
     reference picture, check_best_mvp, the iterated bi-prediction search, every pinter_residue_rdo, the mode decision and the reconstruction of
