@@ -579,6 +579,13 @@ int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_
                                     int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_inter_result *results, int16_t *coef,
                                     xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y, xeve_hip_sbac *next_best,
                                     void *workspace, size_t workspace_bytes, void *stream);
+/* The candidates an xeve_hip_inter_job carries, from the maps the encoder keeps per 4x4 unit (device memory): xeve_get_avail_inter
+ * (xeve_util.c:652-714; the left / up / up-right bits) + xeve_get_motion (xeve_util.c:526-573) per list + the collocated vector xeve_get_mv_dir
+ * reads (xeve_util.c:631-632, the CU's bottom-right unit).  map_scu: ctx->map_scu; map_tidx: ctx->map_tidx (NULL = one tile); map_mv: ctx->map_mv
+ * ([unit][list][x, y]); col_mv0 / col_mv1: refp[0][REFP_0 / REFP_1].map_mv.  jobs[j].x / y are read, jobs[j].mvp / mv_col are written (list 1 and
+ * mv_col stay 0 in P slices); the other fields are the caller's. */
+int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t *map_mv, const int16_t *col_mv0, const int16_t *col_mv1, int w_scu,
+                              int h_scu, int log2_cuw, int log2_cuh, int slice_type, xeve_hip_inter_job *jobs, int njobs, void *stream);
 /* One xeve_pinter_analyze_cu call on HOST memory (synchronous; the original and every reference picture of both lists staged per call): what
  * ctx->fn_pinter_analyze_cu can be pointed at.  org / refp: HOST pointers to sample (0, 0); the reference planes extend pad_l / pad_c samples around
  * the picture; *state: core->s_curr_best[log2_cuw - 2][log2_cuh - 2] (job->sbac is ignored); coef_* / rec_*: the CU's dense blocks. */

@@ -232,3 +232,25 @@ void refdrv_pinter_analyze_cu(pel *org_y, pel *org_u, pel *org_v, int s_org_l, i
     }
     from_ref(next_best, &core->s_next_best[lw - 2][lh - 2]);
 }
+
+
+/* the candidates of a drv_inter_job from the encoder's per-unit maps, by the reference's exported xeve_get_avail_inter + xeve_get_motion, and the
+ * collocated vector xeve_get_mv_dir would read */
+void refdrv_inter_candidates(u32 *map_scu, u8 *map_tidx, s16 (*map_mv)[REFP_NUM][MV_D], s16 (*col0)[REFP_NUM][MV_D], s16 (*col1)[REFP_NUM][MV_D], int w_scu, int h_scu,
+                             int log2_cuw, int log2_cuh, int slice_type, drv_inter_job *job)
+{
+    static XEVE_REFP refp[1][REFP_NUM];
+    static s8        map_refi[1][REFP_NUM]; /* not read by the Baseline derivation */
+    const int x_scu = job->x >> MIN_CU_LOG2, y_scu = job->y >> MIN_CU_LOG2, scup = y_scu * w_scu + x_scu, cuw = 1 << log2_cuw, cuh = 1 << log2_cuh;
+    refp[0][REFP_0].map_mv = col0, refp[0][REFP_1].map_mv = col1;
+    const u16 avail = xeve_get_avail_inter(x_scu, y_scu, w_scu, h_scu, scup, cuw, cuh, map_scu, map_tidx);
+    memset(job->mvp, 0, sizeof(job->mvp)), job->mv_col[0] = job->mv_col[1] = 0;
+    for(int l = 0; l <= (slice_type == SLICE_B ? 1 : 0); l++) {
+        s8 refi[MAX_NUM_MVP];
+        xeve_get_motion(scup, l, map_refi, map_mv, refp, cuw, cuh, w_scu, avail, refi, job->mvp[l]);
+    }
+    if(slice_type == SLICE_B) {
+        const int corner = scup + ((1 << (log2_cuw - MIN_CU_LOG2)) - 1) + ((1 << (log2_cuh - MIN_CU_LOG2)) - 1) * w_scu; /* xeve_pinter.c:1543 */
+        job->mv_col[0] = col1[corner][0][MV_X], job->mv_col[1] = col1[corner][0][MV_Y];
+    }
+}

@@ -1567,3 +1567,42 @@ void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
     for(int m = 0; m < NP; m++)
         for(int c = 0; c < 3; c++) free(coef[m][c]);
 }
+
+/* xeve_get_avail_inter (left, up, up-right) + xeve_get_motion + the collocated vector of the temporal direct mode */
+void xo_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t (*map_mv)[2][2], const int16_t (*col0)[2][2],
+                         const int16_t (*col1)[2][2], int w_scu, int h_scu, int log2_cuw, int log2_cuh, int slice_type, xo_inter_job *job)
+{
+#define M_IF(m) (((m) >> 15) & 1)
+#define M_IBC(m) (((m) >> 26) & 1)
+#define M_COD(m) (((m) >> 31) & 1)
+    const int x_scu = job->x >> 2, y_scu = job->y >> 2, scup = y_scu * w_scu + x_scu, scuw = 1 << (log2_cuw - 2), scuh = 1 << (log2_cuh - 2);
+    (void)h_scu;
+    const int t = map_tidx[scup];
+    int le = 0, up = 0, ur = 0;
+    if(x_scu > 0) {
+        const uint32_t m = map_scu[scup - 1];
+        le = !M_IF(m) && M_COD(m) && map_tidx[scup - 1] == t && !M_IBC(m);
+    }
+    if(y_scu > 0) {
+        const uint32_t m = map_scu[scup - w_scu];
+        up = !M_IF(m) && map_tidx[scup - w_scu] == t && !M_IBC(m); /* (no COD test for this one, :681-684) */
+        if(x_scu + scuw < w_scu) {
+            const uint32_t r = map_scu[scup - w_scu + scuw];
+            ur = (((r >> 15) & 0x10001) == 0x10000) && M_COD(r) && map_tidx[scup - w_scu + scuw] == t; /* MCU_IS_COD_NIF */
+        }
+    }
+    memset(job->mvp, 0, sizeof(job->mvp)), job->mv_col[0] = job->mv_col[1] = 0;
+    for(int l = 0; l <= (slice_type == 0 ? 1 : 0); l++) {
+        const int16_t(*col)[2][2] = l ? col1 : col0;
+        const int at[3] = {scup - 1, scup - w_scu, scup - w_scu + scuw}, ok[3] = {le, up, ur};
+        for(int k = 0; k < 3; k++) job->mvp[l][k][0] = ok[k] ? map_mv[at[k]][l][0] : 1, job->mvp[l][k][1] = ok[k] ? map_mv[at[k]][l][1] : 1;
+        job->mvp[l][3][0] = col[scup][0][0], job->mvp[l][3][1] = col[scup][0][1];
+    }
+    if(slice_type == 0) {
+        const int corner = scup + (scuw - 1) + (scuh - 1) * w_scu;
+        job->mv_col[0] = col1[corner][0][0], job->mv_col[1] = col1[corner][0][1];
+    }
+#undef M_IF
+#undef M_IBC
+#undef M_COD
+}

@@ -359,6 +359,12 @@ typedef struct xo_inter_result {
 void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
                           const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
                           xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best);
+/* The candidates an xo_inter_job carries, from the maps the encoder keeps per 4x4 unit: xeve_get_avail_inter (xeve_util.c:652-714; only the
+ * left / up / up-right bits matter here) + xeve_get_motion (xeve_util.c:526-573) per list + the collocated vector xeve_get_mv_dir reads
+ * (xeve_util.c:631-632, unit = the CU's bottom-right one).  map_mv / col0 / col1: [unit][list][x, y]; col0 / col1 = refp[0][REFP_0 / REFP_1].map_mv.
+ * job->x / y are read; job->mvp / mv_col are written (list 1 and mv_col stay 0 in P slices). */
+void xo_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t (*map_mv)[2][2], const int16_t (*col0)[2][2],
+                         const int16_t (*col1)[2][2], int w_scu, int h_scu, int log2_cuw, int log2_cuh, int slice_type, xo_inter_job *job);
 /* check_best_mvp (xeve_pinter.c:1773-1837): returns the chosen index; mvd is recomputed against it */
 int xo_check_best_mvp(const xo_sbac *entry, int slice_type, const int8_t refi[2], int lidx, const int16_t mvp[4][2], const int16_t mv[2], int mvp_idx,
                       double lambda0, int16_t mvd[2]);

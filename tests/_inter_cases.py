@@ -95,3 +95,16 @@ def mask_unobservable(res, slice_type):
     res["mvp_idx"][d] = 0
     res["cost_inter"], res["best_idx"] = 0, 0
     return res
+
+
+def make_maps(r, w_scu, h_scu, tiles=1):
+    """per-4x4-unit maps as the encoder keeps them: map_scu (bit 15 intra, 26 IBC, 31 coded), map_tidx, map_mv and the two collocated maps"""
+    n = w_scu * h_scu
+    coded = r.random(n) < 0.8
+    intra = r.random(n) < 0.2
+    ibc = r.random(n) < 0.05
+    junk = r.integers(0, 1 << 15, size=n).astype(np.uint32)  # qp / depth bits below
+    map_scu = (junk | (intra.astype(np.uint32) << 15) | (ibc.astype(np.uint32) << 26) | (coded.astype(np.uint32) << 31)).astype(np.uint32)
+    tidx = np.zeros(n, np.uint8) if tiles == 1 else (np.arange(n) % w_scu >= w_scu // 2).astype(np.uint8)
+    mk = lambda: r.integers(-300, 301, size=(n, 2, 2)).astype(np.int16)
+    return map_scu, tidx, mk(), mk(), mk()

@@ -510,3 +510,19 @@ def oracle_inter():
     L.xo_check_best_mvp.restype = c_int
     L.xo_check_best_mvp.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, C.c_double, c_void_p]
     return L
+
+
+def ref_cand():
+    L = ref_inter()
+    if L is not None and not hasattr(L, "_cand_bound"):
+        L.refdrv_inter_candidates.restype = None
+        L.refdrv_inter_candidates.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
+        L._cand_bound = True
+    return L
+
+
+def oracle_cand():
+    L = oracle()
+    L.xo_inter_candidates.restype = None
+    L.xo_inter_candidates.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
+    return L

@@ -141,3 +141,35 @@ def test_hip_pinter_analyze_cu_edge_cases():
         with pytest.raises(xeve_amd.XeveHipError):
             D.pinter_analyze_cu_jobs([1, 1, 1], refs["s_l"], refs["s_c"], np.zeros(8, lib.REFPIC_DTYPE), refs["s_l"], refs["s_c"], dst, H,
                                      torch.zeros(52, dtype=torch.uint8, device=dev), workspace=torch.empty(1 << 20, dtype=torch.uint8, device=dev))
+
+
+@pytest.mark.parametrize("slice_type,tiles", [(0, 1), (1, 1), (0, 2)])
+def test_hip_inter_candidates_vs_oracle(slice_type, tiles):
+    """xeve_hip_inter_candidates: every CU position of a 192x128 picture at every size, against the pinned oracle"""
+    import torch
+
+    import xeve_amd
+    from _inter_cases import make_maps
+    from _libs import INTER_JOB_DTYPE, oracle_cand
+    from xeve_amd import device as D
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    O = oracle_cand()
+    r = np.random.default_rng(41 + slice_type + tiles)
+    w_scu, h_scu = 48, 32
+    map_scu, tidx, map_mv, c0, c1 = make_maps(r, w_scu, h_scu, tiles)
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+    d = [up(map_scu), up(tidx) if tiles > 1 else None, up(map_mv), up(c0), up(c1)]
+    for lw in (3, 4, 5, 6):
+        s = 1 << (lw - 2)
+        xs, ys = np.meshgrid(np.arange(w_scu // s) * s * 4, np.arange(h_scu // s) * s * 4)
+        jobs = np.zeros(xs.size, INTER_JOB_DTYPE)
+        jobs["x"], jobs["y"], jobs["sbac"], jobs["ctx_skip"] = xs.ravel(), ys.ravel(), 7, 1
+        dj = up(jobs)
+        D.inter_candidates(d[0], d[1], d[2], d[3], d[4] if slice_type == 0 else None, w_scu, h_scu, lw, lw, slice_type, dj)
+        got = dj.cpu().numpy().view(INTER_JOB_DTYPE)
+        for i in range(len(jobs)):
+            e = jobs[i:i + 1].copy()
+            O.xo_inter_candidates(ptr(map_scu), ptr(tidx), ptr(map_mv), ptr(c0), ptr(c1), w_scu, h_scu, lw, lw, slice_type, ptr(e))
+            assert got[i:i + 1].tobytes() == e.tobytes(), (lw, i, got[i], e[0])

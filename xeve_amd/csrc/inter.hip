@@ -544,6 +544,65 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     return XEVE_HIP_OK;
 }
 
+// ---- the candidates of the jobs from the encoder's per-unit maps ---------------------------------------------------------------------
+// xeve_get_avail_inter (left / up / up-right; xeve_util.c:652-714) + xeve_get_motion (xeve_util.c:526-573) + the collocated vector of the
+// temporal direct mode.  One thread per CU; the maps are [unit][list][x, y] as the reference keeps them.
+__global__ void k_inter_candidates(const uint32_t *__restrict__ map_scu, const uint8_t *__restrict__ map_tidx, const int16_t *__restrict__ map_mv,
+                                   const int16_t *__restrict__ col0, const int16_t *__restrict__ col1, int w_scu, int scuw, int scuh, int isb,
+                                   xeve_hip_inter_job *__restrict__ jobs, int njobs)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= njobs) return;
+    xeve_hip_inter_job J = jobs[j];
+    const int x_scu = J.x >> 2, y_scu = J.y >> 2, scup = y_scu * w_scu + x_scu;
+    auto tile = [&](int at) { return map_tidx ? (int)map_tidx[at] : 0; };
+    const int t = tile(scup);
+    bool ok[3] = {false, false, false};
+    const int at[3] = {scup - 1, scup - w_scu, scup - w_scu + scuw};
+    if(x_scu > 0) {
+        const uint32_t m = map_scu[at[0]];
+        ok[0] = !((m >> 15) & 1) && (m >> 31) && tile(at[0]) == t && !((m >> 26) & 1); // !IF && COD && same tile && !IBC
+    }
+    if(y_scu > 0) {
+        const uint32_t m = map_scu[at[1]];
+        ok[1] = !((m >> 15) & 1) && tile(at[1]) == t && !((m >> 26) & 1); // (no COD test for the unit above, :681-684)
+        if(x_scu + scuw < w_scu) {
+            const uint32_t r = map_scu[at[2]];
+            ok[2] = (((r >> 15) & 0x10001u) == 0x10000u) && (r >> 31) && tile(at[2]) == t; // MCU_IS_COD_NIF && COD
+        }
+    }
+    for(int l = 0; l < 2; l++) {
+        const int16_t *col = l ? col1 : col0;
+        for(int k = 0; k < 4; k++) {
+            int vx = 0, vy = 0;
+            if(l <= isb) {
+                if(k < 3) vx = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2] : 1, vy = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2 + 1] : 1;
+                else vx = col[((size_t)scup * 2 + 0) * 2], vy = col[((size_t)scup * 2 + 0) * 2 + 1]; // refp[0][l].map_mv[scup][0]
+            }
+            J.mvp[l][k][0] = (int16_t)vx, J.mvp[l][k][1] = (int16_t)vy;
+        }
+    }
+    J.mv_col[0] = J.mv_col[1] = 0;
+    if(isb) {
+        const size_t corner = (size_t)scup + (scuw - 1) + (size_t)(scuh - 1) * w_scu;
+        J.mv_col[0] = col1[(corner * 2 + 0) * 2], J.mv_col[1] = col1[(corner * 2 + 0) * 2 + 1];
+    }
+    jobs[j] = J;
+}
+
+extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t *map_mv, const int16_t *col_mv0, const int16_t *col_mv1,
+                                         int w_scu, int h_scu, int log2_cuw, int log2_cuh, int slice_type, xeve_hip_inter_job *jobs, int njobs, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(njobs >= 0 && w_scu > 0 && h_scu > 0 && log2_cuw >= 2 && log2_cuw <= 7 && log2_cuh >= 2 && log2_cuh <= 7 && (slice_type == 0 || slice_type == 1));
+    if(njobs == 0) return XEVE_HIP_OK;
+    XH_REQUIRE(map_scu && map_mv && col_mv0 && jobs && (slice_type == 1 || col_mv1));
+    k_inter_candidates<<<(njobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, 1 << (log2_cuw - 2), 1 << (log2_cuh - 2),
+                                                                            slice_type == 0, jobs, njobs);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
 // ---- host-memory form of one xeve_pinter_analyze_cu call (the table layer's style: synchronous, every plane staged per call) ----------
 // What ctx->fn_pinter_analyze_cu can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org / refp: HOST pointers to
 // sample (0, 0); the reference planes extend pad_l / pad_c samples around the picture.

@@ -293,6 +293,14 @@ def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, p
     return (res, coef, ry, ru, rv, nb, py) if want_pred else (res, coef, ry, ru, rv, nb)
 
 
+def inter_candidates(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, h_scu, log2_cuw, log2_cuh, slice_type, jobs):
+    """fills jobs[].mvp / mv_col (uint8 tensor of lib.INTER_JOB_DTYPE records, in place) from the per-unit maps (xeve_hip_inter_candidates)"""
+    _lib.check(_lib.load().xeve_hip_inter_candidates(_ptr(map_scu), _ptr(map_tidx) if map_tidx is not None else None, _ptr(map_mv), _ptr(col_mv0),
+                                                     _ptr(col_mv1) if col_mv1 is not None else None, w_scu, h_scu, log2_cuw, log2_cuh, slice_type, _ptr(jobs),
+                                                     jobs.numel() // 52, _stream()))
+    return jobs
+
+
 def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 
