@@ -173,3 +173,41 @@ def test_hip_inter_candidates_vs_oracle(slice_type, tiles):
             e = jobs[i:i + 1].copy()
             O.xo_inter_candidates(ptr(map_scu), ptr(tidx), ptr(map_mv), ptr(c0), ptr(c1), w_scu, h_scu, lw, lw, slice_type, ptr(e))
             assert got[i:i + 1].tobytes() == e.tobytes(), (lw, i, got[i], e[0])
+
+
+def test_hip_pinter_analyze_cu_full_size_properties():
+    """every 16x16 CU of a 1920x1088 B picture (8160 CUs): the results do not depend on how the batch is cut or on the order the bi rounds hand out
+    their slots (two runs, whole vs two halves, are identical); the returned cost is the minimum of the evaluated modes and belongs to the winner;
+    a skipped CU has no coefficients; a sample of CUs agrees with the oracle"""
+    w, h, bd, nref, lw = 1920, 1088, 10, 2, 4
+    r = np.random.default_rng(77)
+    refs, org = make_inter_picture(r, w, h, bd, nref, 1, 0)
+    st = states(r, 16)
+    P = make_inter_params(r, lw, w, h, bd, nref, 1, 0, refs, 0.0, max_cand=3)
+    n = (w // 16) * (h // 16)
+    jobs = make_inter_jobs(r, n, w, h, 16, len(st), refs, 0)
+    jobs["x"], jobs["y"] = (np.arange(n) % (w // 16)) * 16, (np.arange(n) // (w // 16)) * 16
+    a = run_hip(refs, org, st, P, jobs)
+    b = run_hip(refs, org, st, P, jobs)
+    c0, c1 = run_hip(refs, org, st, P, jobs[:n // 2]), run_hip(refs, org, st, P, jobs[n // 2:])
+    assert a[0].tobytes() == b[0].tobytes() and a[3].tobytes() == b[3].tobytes()
+    assert a[0].tobytes() == c0[0].tobytes() + c1[0].tobytes() and a[3].tobytes() == c0[3].tobytes() + c1[3].tobytes()
+    for k in range(3):
+        assert np.array_equal(a[1][k], b[1][k]) and np.array_equal(a[2][k], b[2][k])
+        assert np.array_equal(a[1][k], np.concatenate([c0[1][k], c1[1][k]])) and np.array_equal(a[2][k], np.concatenate([c0[2][k], c1[2][k]]))
+    res = a[0]
+    assert (res["cost"] == res["cost_inter"].min(axis=1)).all() and (res["cost"] == res["cost_inter"][np.arange(n), res["best_idx"]]).all()
+    assert (res["cost_inter"] < 1e300).all()  # skip_th 0 and a noisy picture: every mode was evaluated everywhere
+    skip = res["cu_mode"] == 2
+    assert skip.any() and (~skip).any() and not res["nnz"][skip].any() and not a[1][0][skip].any()
+    assert set(np.unique(res["best_idx"])) >= {0, 1, 2, 3}
+    O = oracle_inter()
+    tab = refpic_table(refs, lambda x, off: int(x.ctypes.data) + 2 * off)
+    org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]], np.uint64)
+    for i in r.integers(0, n, size=120):
+        er, eb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+        ec = [np.zeros(256, np.int16), np.zeros(64, np.int16), np.zeros(64, np.int16)]
+        ep = [x.copy() for x in ec]
+        O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]),
+                               ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
+        assert res[i:i + 1].tobytes() == er.tobytes() and np.array_equal(a[2][0][i], ep[0]) and a[3][i:i + 1].tobytes() == eb.tobytes(), i
