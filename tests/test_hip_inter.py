@@ -72,7 +72,8 @@ def test_hip_pinter_analyze_cu_matches_reference_goldens():
 
 
 @pytest.mark.parametrize("w,h,bd,nref,idc,slice_type,skip_th", [(128, 96, 10, 2, 1, 0, 0.0), (128, 64, 10, 2, 1, 1, 0.0), (96, 64, 8, 1, 1, 0, 0.0),
-                                                                (64, 64, 10, 2, 0, 0, 0.0), (192, 128, 10, 3, 1, 0, 0.0), (128, 96, 10, 2, 1, 0, 6.0)])
+                                                                (64, 64, 10, 2, 0, 0, 0.0), (192, 128, 10, 3, 1, 0, 0.0), (128, 96, 10, 2, 1, 0, 6.0), (96, 64, 10, 2, 3, 0, 0.0),
+                                                                (128, 128, 10, 4, 1, 1, 0.0)])
 def test_hip_pinter_analyze_cu_vs_oracle(w, h, bd, nref, idc, slice_type, skip_th):
     O = oracle_inter()
     r = np.random.default_rng(13 * w + h + bd + nref + idc + slice_type)

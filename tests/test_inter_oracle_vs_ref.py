@@ -51,7 +51,7 @@ def run_both(w, h, bd, nref, idc, slice_type, skip_th, sizes, n, seed):
 
 
 @pytest.mark.parametrize("w,h,bd,nref,idc,slice_type", [(128, 96, 10, 2, 1, 0), (128, 64, 10, 2, 1, 1), (96, 64, 8, 1, 1, 0), (64, 64, 10, 2, 0, 0),
-                                                        (192, 128, 10, 3, 1, 0), (128, 128, 10, 4, 1, 1)])
+                                                        (192, 128, 10, 3, 1, 0), (128, 128, 10, 4, 1, 1), (96, 64, 10, 2, 3, 0)])
 def test_pinter_analyze_cu(w, h, bd, nref, idc, slice_type):
     modes = run_both(w, h, bd, nref, idc, slice_type, 0.0, [3, 4, 5, 6], 25, 11 * w + h + bd + nref + idc + slice_type)
     assert len(set(modes)) >= (3 if slice_type == 0 else 2), modes
