@@ -66,6 +66,70 @@ def cpu_baseline(width, height):
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
 
+def cpu_inter_baseline(ws, budget_s=8.0):
+    """times xeve_pinter_analyze_cu on one host core over a sample of the CUs of ws.inter() (checker infrastructure used as a baseline only)"""
+    import ctypes as C
+    import sys as _sys
+
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from _libs import INTER_JOB_DTYPE, INTER_RESULT_DTYPE, SBAC_DTYPE, InterParams, oracle_inter, ptr, ref_inter
+
+    from xeve_amd.workload import PAD_C, PAD_L
+
+    R = ref_inter()
+    O = oracle_inter() if R is None else None
+    org = [t.cpu().numpy() for t in ws.org]
+    refs = [[t.cpu().numpy() for t in pl] for pl in ws.ref]
+    ol, oc = PAD_L * ws.s_l + PAD_L, PAD_C * ws.s_c + PAD_C
+    per_level, total_s = {}, 0.0
+    if R is not None:
+        R.refdrv_set_simd(1)
+    try:
+        for S in ws.sizes:
+            lv = ws.lv[S]
+            h = lv["inter"]
+            hp = h["params"]
+            P = InterParams()  # the oracle-side layout of the same parameters
+            C.memmove(C.byref(P.rdo), C.byref(hp.rdo), C.sizeof(P.rdo))
+            C.memmove(C.byref(P.me), C.byref(hp.me.me), C.sizeof(P.me))
+            P.spel.lambda_mv, P.spel.hpel_cnt, P.spel.qpel_cnt = hp.me.me.lambda_mv, hp.me.hpel_cnt, hp.me.qpel_cnt
+            for l in range(2):
+                for i in range(8):
+                    P.refi_bits[l][i], P.range_recentre[l][i] = hp.refi_bits[l][i], hp.range_recentre[l][i]
+            P.max_cand, P.poc, P.col_list_poc0, P.skip_th = hp.max_cand, hp.poc, hp.col_list_poc0, hp.skip_th
+            jobs = h["jobs"].cpu().numpy().view(INTER_JOB_DTYPE)
+            st = lv["rdo"]["state"].cpu().numpy().view(SBAC_DTYPE)
+            tab = h["refp"].copy()
+            for l in range(2):
+                tab["y"][l], tab["u"][l], tab["v"][l] = (refs[l][0].ctypes.data + 2 * ol, refs[l][1].ctypes.data + 2 * oc, refs[l][2].ctypes.data + 2 * oc)
+            n0, nc = S * S, S * S // 4
+            res, nb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            cf = [np.zeros(n0, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            rc = [x.copy() for x in cf]
+            optr = np.array([org[0].ctypes.data + 2 * ol, org[1].ctypes.data + 2 * oc, org[2].ctypes.data + 2 * oc], np.uint64)
+            pick = np.random.default_rng(S).permutation(len(jobs))
+            t0, done = time.perf_counter(), 0
+            for i in pick:
+                j = jobs[i:i + 1]
+                if R is not None:
+                    R.refdrv_pinter_analyze_cu(ptr(org[0], ol), ptr(org[1], oc), ptr(org[2], oc), ws.s_l, ws.s_c, ptr(tab), ws.s_l, ws.s_c, ptr(st), P, 8, ptr(j), ptr(res),
+                                               ptr(cf[0]), ptr(cf[1]), ptr(cf[2]), ptr(rc[0]), ptr(rc[1]), ptr(rc[2]), ptr(nb))
+                else:
+                    O.xo_pinter_analyze_cu(ptr(optr), ws.s_l, ws.s_c, ptr(tab), ws.s_l, ws.s_c, ptr(st), P, ptr(j), ptr(res), ptr(cf[0]), ptr(cf[1]), ptr(cf[2]),
+                                           ptr(rc[0]), ptr(rc[1]), ptr(rc[2]), ptr(nb))
+                done += 1
+                if time.perf_counter() - t0 > budget_s / len(ws.sizes):
+                    break
+            dt = time.perf_counter() - t0
+            per_level[str(S)] = {"us_per_cu": round(dt / done * 1e6, 1), "sampled_cus": done}
+            total_s += dt / done * len(jobs)
+    finally:
+        if R is not None:
+            R.refdrv_set_simd(0)
+    return {"kind": "reference" if R is not None else "port", "cores": 1, "s_per_picture": round(total_s, 2), "per_level": per_level,
+            "sample": "random CUs of the same jobs, %.0f s of host time per level" % (budget_s / len(ws.sizes))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +245,12 @@ def main():
                                                   "winners": {"l0": int(cnt[0]), "l1": int(cnt[1]), "bi": int(cnt[2]), "skip": int(cnt[3]), "direct": int(cnt[4])},
                                                   "note": "B picture, one reference picture per list, 3 merge candidates; all four CU levels of the picture, "
                                                           "one stream per level"}
+        # the same function on one host core, on a bounded sample of the same CUs: the reference's xeve_pinter_analyze_cu compiled in place with the
+        # tables it picks for this CPU (oracle/_ref/libref_rdo.so), else the oracle's restatement
+        try:
+            rate_term["inter_analysis_structured"]["cpu"] = cpu_inter_baseline(ws, budget_s=8.0)
+        except Exception as e:  # noqa: BLE001 -- a baseline, never fatal
+            rate_term["inter_analysis_structured"]["cpu"] = {"error": repr(e)[:200]}
         del ws
     if rank == 0:
         sad_ms = wl.sad_time_ms()  # per size, summed over the timed steps

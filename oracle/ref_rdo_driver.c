@@ -47,6 +47,8 @@ typedef struct { double cost; int nnz[3], pad_; s64 dist[2][3]; } drv_rdo_result
 
 static XEVE_CTX  *g_ctx;
 static XEVE_CORE *g_core;
+static int        g_simd;
+void refdrv_set_simd(int on) { g_simd = on; }
 
 void refdrv_residue_rdo(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, const drv_refpic *refs, int s_l, int s_c, const drv_sbac *states,
                         const drv_rdo_params *p, const drv_rdo_job *job, drv_rdo_result *res, s16 *coef_y, s16 *coef_u, s16 *coef_v, drv_sbac *best)
@@ -60,10 +62,14 @@ void refdrv_residue_rdo(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_o
     XEVE_PINTER *pi = &ctx->pinter[0];
     const int ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
     const int lw = p->log2_cuw, lh = p->log2_cuh;
-    /* dispatch tables (xeve_platform_init_func, xeve_enc.c:722-825): the plain-C ones */
-    xeve_func_sad = xeve_tbl_sad_16b, xeve_func_ssd = xeve_tbl_ssd_16b, xeve_func_diff = xeve_tbl_diff_16b, xeve_func_satd = xeve_tbl_satd_16b;
-    xeve_func_mc_l = xeve_tbl_mc_l, xeve_func_mc_c = xeve_tbl_mc_c, xeve_func_average_no_clip = &xeve_average_16b_no_clip;
-    xeve_func_txb = &xeve_tbl_txb, ctx->fn_itxb = &xeve_tbl_itxb;
+    /* dispatch tables (xeve_platform_init_func, xeve_enc.c:722-825): the plain-C ones; refdrv_set_simd(1) lets the reference pick the tables for this
+     * CPU instead (same results; used when the reference is timed as the CPU baseline) */
+    if(g_simd) xeve_platform_init_func(ctx);
+    else {
+        xeve_func_sad = xeve_tbl_sad_16b, xeve_func_ssd = xeve_tbl_ssd_16b, xeve_func_diff = xeve_tbl_diff_16b, xeve_func_satd = xeve_tbl_satd_16b;
+        xeve_func_mc_l = xeve_tbl_mc_l, xeve_func_mc_c = xeve_tbl_mc_c, xeve_func_average_no_clip = &xeve_average_16b_no_clip;
+        xeve_func_txb = &xeve_tbl_txb, ctx->fn_itxb = &xeve_tbl_itxb;
+    }
     ctx->fn_tq = xeve_sub_block_tq, ctx->fn_itdp = xeve_itdq, ctx->fn_recon = xeve_recon, ctx->fn_eco_coef = xeve_eco_coef;
     ctx->fn_rdoq_set_ctx_cc = xeve_rdoq_set_ctx_cc;
     ctx->param.tool_iqt = p->tool_iqt, ctx->param.codec_bit_depth = p->bit_depth, ctx->param.rdoq = 1, ctx->param.rdo_dbk_switch = 0;

@@ -61,3 +61,14 @@ def test_pinter_analyze_cu_skip_threshold():
     """a positive skip_th ends the analysis after the skip mode for CUs whose skip residual is small"""
     modes = run_both(128, 96, 10, 2, 1, 0, 6.0, [3, 4, 5], 12, 5)
     assert 3 in modes and len(set(modes)) >= 2, modes
+
+
+def test_pinter_analyze_cu_same_with_the_simd_tables():
+    """the driver can let the reference pick its SSE / AVX2 tables (the CPU baseline is timed that way): same results as with the plain-C tables"""
+    R = ref_inter()
+    R.refdrv_set_simd(1)
+    try:
+        modes = run_both(128, 96, 10, 2, 1, 0, 0.0, [3, 4, 5, 6], 8, 321)
+    finally:
+        R.refdrv_set_simd(0)
+    assert len(set(modes)) >= 2
