@@ -44,9 +44,11 @@ def refi_bits(num_refp, refi):
     return 0 if num_refp < 2 else min(refi + 1, num_refp - 1)
 
 
-def make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th=0.0, max_cand=None):
+def make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th=0.0, max_cand=None, nref1=None):
     P = InterParams()
     rp = make_params(r, lw, lw, w, h, bd, nref, idc, slice_type)
+    if nref1 is not None and slice_type == 0:
+        rp.num_refp[1] = nref1  # list 1 shorter than list 0 (analyze_bi then walks both lists with list 1's count)
     P.rdo = rp
     msr = int(r.choice([32, 64]))
     lam_mv = int(np.floor(65536.0 * np.sqrt(rp.lambda_[0])))

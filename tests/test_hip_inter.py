@@ -212,3 +212,29 @@ def test_hip_pinter_analyze_cu_full_size_properties():
         O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]),
                                ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
         assert res[i:i + 1].tobytes() == er.tobytes() and np.array_equal(a[2][0][i], ep[0]) and a[3][i:i + 1].tobytes() == eb.tobytes(), i
+
+
+def test_hip_pinter_analyze_cu_list1_shorter_than_list0():
+    O = oracle_inter()
+    w, h, bd, nref = 128, 96, 10, 3
+    r = np.random.default_rng(780)
+    refs, org = make_inter_picture(r, w, h, bd, nref, 1, 0)
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    st = states(r, 5)
+    org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]], np.uint64)
+    modes = set()
+    for lw in (3, 4, 5):
+        cu = 1 << lw
+        P = make_inter_params(r, lw, w, h, bd, nref, 1, 0, refs, 0.0, nref1=2)
+        jobs = make_inter_jobs(r, 60, w, h, cu, len(st), refs, 0)
+        res, coef, rec, best = run_hip(refs, org, st, P, jobs)
+        nc = (cu // 2) ** 2
+        for i in range(len(jobs)):
+            er, eb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec = [np.zeros(cu * cu, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            ep = [x.copy() for x in ec]
+            O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]), ptr(ec[1]),
+                                   ptr(ec[2]), ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
+            assert res[i:i + 1].tobytes() == er.tobytes() and np.array_equal(rec[0][i], ep[0]) and best[i:i + 1].tobytes() == eb.tobytes(), (lw, i, res[i], er[0])
+            modes.add(int(er["best_idx"][0]))
+    assert len(modes) >= 3, modes

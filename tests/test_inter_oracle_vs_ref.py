@@ -12,7 +12,7 @@ from _rdo_cases import states
 pytestmark = pytest.mark.skipif(ref_inter() is None, reason="oracle/_ref not built (no /root/reference here)")
 
 
-def run_both(w, h, bd, nref, idc, slice_type, skip_th, sizes, n, seed):
+def run_both(w, h, bd, nref, idc, slice_type, skip_th, sizes, n, seed, nref1=None):
     O, R = oracle_inter(), ref_inter()
     r = np.random.default_rng(seed)
     refs, org = make_inter_picture(r, w, h, bd, nref, idc, slice_type)
@@ -23,7 +23,7 @@ def run_both(w, h, bd, nref, idc, slice_type, skip_th, sizes, n, seed):
     modes = []
     for lw in sizes:
         cu = 1 << lw
-        P = make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th)
+        P = make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th, nref1=nref1)
         jobs = make_inter_jobs(r, n, w, h, cu, len(st), refs, slice_type)
         nc = max(1, (cu >> refs["ws"]) * (cu >> refs["hs"]))
         for i in range(len(jobs)):
@@ -72,3 +72,10 @@ def test_pinter_analyze_cu_same_with_the_simd_tables():
     finally:
         R.refdrv_set_simd(0)
     assert len(set(modes)) >= 2
+
+
+def test_pinter_analyze_cu_list1_shorter_than_list0():
+    """three pictures in list 0, two in list 1: the uni-directional searches walk each list's own count, analyze_bi walks BOTH lists with list 1's
+    (pi->num_refp as the list-1 search left it) and prices the reference index with list 1's table"""
+    modes = run_both(128, 96, 10, 3, 1, 0, 0.0, [3, 4, 5], 20, 780, nref1=2)
+    assert 2 in modes, modes
