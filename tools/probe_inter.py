@@ -21,7 +21,7 @@ from xeve_amd import lib  # noqa: E402
 
 xeve_amd.init(0)
 dev = torch.device("cuda:0")
-(w, h), bd, nref = ((3840, 2176) if "--4k" in sys.argv else (1920, 1088)), 10, 2
+(w, h), bd, nref = ((3840, 2176) if "--4k" in sys.argv else (1920, 1088)), 10, (1 if "--medium" in sys.argv else 2)  # me_ref_num = 1 in fast / medium / slow
 st_type = 1 if "--p" in sys.argv else 0
 r = np.random.default_rng(1)
 refs, org = make_inter_picture(r, w, h, bd, nref, 1, st_type)
@@ -38,6 +38,8 @@ for lw in (3, 4, 5, 6):
     c = 1 << lw
     n = (w // c) * (h // c)
     P = make_inter_params(r, lw, w, h, bd, nref, 1, st_type, refs, 0.0, max_cand=3)
+    if "--medium" in sys.argv:  # preset medium: me_range 64, half-pel search with 4 positions, no quarter-pel stage, 3 merge candidates (xeve_enc.c:2455-2471)
+        P.me.max_search_range, P.spel.hpel_cnt, P.spel.qpel_cnt = 64, 4, 0
     hp = hip_params(P)
     jobs = make_inter_jobs(r, n, w, h, c, len(st), refs, st_type)
     jobs["x"], jobs["y"] = (np.arange(n) % (w // c)) * c, (np.arange(n) // (w // c)) * c
