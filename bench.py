@@ -68,11 +68,11 @@ def cpu_baseline(width, height):
 
 def cpu_inter_baseline(ws, budget_s=8.0):
     """times xeve_pinter_analyze_cu on one host core over a sample of the CUs of ws.inter() (checker infrastructure used as a baseline only)"""
-    import ctypes as C
     import sys as _sys
 
     _sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-    from _libs import INTER_JOB_DTYPE, INTER_RESULT_DTYPE, SBAC_DTYPE, InterParams, oracle_inter, ptr, ref_inter
+    from _inter_cases import oracle_params_from_hip
+    from _libs import INTER_JOB_DTYPE, INTER_RESULT_DTYPE, SBAC_DTYPE, oracle_inter, ptr, ref_inter
 
     from xeve_amd.workload import PAD_C, PAD_L
 
@@ -89,14 +89,7 @@ def cpu_inter_baseline(ws, budget_s=8.0):
             lv = ws.lv[S]
             h = lv["inter"]
             hp = h["params"]
-            P = InterParams()  # the oracle-side layout of the same parameters
-            C.memmove(C.byref(P.rdo), C.byref(hp.rdo), C.sizeof(P.rdo))
-            C.memmove(C.byref(P.me), C.byref(hp.me.me), C.sizeof(P.me))
-            P.spel.lambda_mv, P.spel.hpel_cnt, P.spel.qpel_cnt = hp.me.me.lambda_mv, hp.me.hpel_cnt, hp.me.qpel_cnt
-            for l in range(2):
-                for i in range(8):
-                    P.refi_bits[l][i], P.range_recentre[l][i] = hp.refi_bits[l][i], hp.range_recentre[l][i]
-            P.max_cand, P.poc, P.col_list_poc0, P.skip_th = hp.max_cand, hp.poc, hp.col_list_poc0, hp.skip_th
+            P = oracle_params_from_hip(hp)  # the oracle-side layout of the same parameters
             jobs = h["jobs"].cpu().numpy().view(INTER_JOB_DTYPE)
             st = lv["rdo"]["state"].cpu().numpy().view(SBAC_DTYPE)
             tab = h["refp"].copy()

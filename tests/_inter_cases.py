@@ -110,3 +110,18 @@ def make_maps(r, w_scu, h_scu, tiles=1):
     tidx = np.zeros(n, np.uint8) if tiles == 1 else (np.arange(n) % w_scu >= w_scu // 2).astype(np.uint8)
     mk = lambda: r.integers(-300, 301, size=(n, 2, 2)).astype(np.int16)
     return map_scu, tidx, mk(), mk(), mk()
+
+
+def oracle_params_from_hip(hp):
+    """lib.InterParams (the library's layout) -> _libs.InterParams (the oracle's: xo_epzs_params carries a separate sub-pel record)"""
+    import ctypes as C
+
+    P = InterParams()
+    C.memmove(C.byref(P.rdo), C.byref(hp.rdo), C.sizeof(P.rdo))
+    C.memmove(C.byref(P.me), C.byref(hp.me.me), C.sizeof(P.me))
+    P.spel.lambda_mv, P.spel.hpel_cnt, P.spel.qpel_cnt = hp.me.me.lambda_mv, hp.me.hpel_cnt, hp.me.qpel_cnt
+    for l in range(2):
+        for i in range(8):
+            P.refi_bits[l][i], P.range_recentre[l][i] = hp.refi_bits[l][i], hp.range_recentre[l][i]
+    P.max_cand, P.poc, P.col_list_poc0, P.skip_th = hp.max_cand, hp.poc, hp.col_list_poc0, hp.skip_th
+    return P

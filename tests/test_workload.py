@@ -132,3 +132,46 @@ def test_structured_content_rdo_phase_vs_oracle():
             assert res["cost"][j].tobytes() == er["cost"][0].tobytes() and np.array_equal(res["nnz"][j], er["nnz"][0]), (S, j)
             coded += int(er["nnz"][0].any())
     assert coded > 0
+
+
+@pytest.mark.gpu
+def test_structured_content_inter_phase_vs_oracle():
+    """phase H (xeve_hip_pinter_analyze_cu_jobs on the structured picture: the whole inter analysis of every CU of every level) against the oracle"""
+    import torch
+
+    import xeve_amd
+    from _inter_cases import oracle_params_from_hip
+    from _libs import INTER_JOB_DTYPE, INTER_RESULT_DTYPE, REFPIC_DTYPE, SBAC_DTYPE, oracle_inter
+    from xeve_amd.workload import PAD_C, PAD_L, HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(256, 128, dev, seed=3, content="structured")
+    out = wl.inter()
+    torch.cuda.synchronize()
+    O = oracle_inter()
+    org = [p.cpu().numpy() for p in wl.org]
+    ref = [[p.cpu().numpy() for p in l] for l in wl.ref]
+    ol, oc = PAD_L * wl.s_l + PAD_L, PAD_C * wl.s_c + PAD_C
+    org_ptrs = np.array([org[0].ctypes.data + 2 * ol, org[1].ctypes.data + 2 * oc, org[2].ctypes.data + 2 * oc], np.uint64)
+    r = np.random.default_rng(2)
+    modes = set()
+    for S in wl.sizes:
+        h = wl.lv[S]["inter"]
+        tab = np.zeros(2, REFPIC_DTYPE)
+        for l in range(2):
+            tab["y"][l], tab["u"][l], tab["v"][l] = ref[l][0].ctypes.data + 2 * ol, ref[l][1].ctypes.data + 2 * oc, ref[l][2].ctypes.data + 2 * oc
+            tab["poc"][l] = int(h["refp"]["poc"][l])
+        res = out[S].cpu().numpy().reshape(-1).view(INTER_RESULT_DTYPE)
+        jobs = h["jobs"].cpu().numpy().view(INTER_JOB_DTYPE)
+        st = wl.lv[S]["rdo"]["state"].cpu().numpy().view(SBAC_DTYPE)
+        P = oracle_params_from_hip(h["params"])
+        for j in r.choice(len(jobs), size=min(6, len(jobs)), replace=False):
+            er, eb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec = [np.zeros(S * S, np.int16), np.zeros(S * S // 4, np.int16), np.zeros(S * S // 4, np.int16)]
+            ep = [x.copy() for x in ec]
+            O.xo_pinter_analyze_cu(ptr(org_ptrs), wl.s_l, wl.s_c, ptr(tab), wl.s_l, wl.s_c, ptr(st), P, ptr(jobs[j:j + 1].copy()), ptr(er), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]),
+                                   ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
+            assert res[j:j + 1].tobytes() == er.tobytes(), (S, j, res[j], er[0])
+            modes.add(int(er["best_idx"][0]))
+    assert len(modes) >= 2, modes
