@@ -218,12 +218,14 @@ __global__ void k_rdo_finish(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, 
 }
 
 __global__ void k_rdo_zero_dropped(int16_t *__restrict__ coef, const unsigned char *__restrict__ drop, RdoK P)
-{ // one workgroup per (candidate, component)
-    const int j = blockIdx.x / 3, k = blockIdx.x % 3;
+{ // one wave per (candidate, component), four to a workgroup (most have nothing to do: keep the launch small)
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if(item >= 3 * P.njobs) return;
+    const int j = item / 3, k = item % 3;
     if(!drop[3 * j + k]) return;
     const int n = k ? P.n1 : P.n0;
     int16_t *b = coef + (k == 0 ? (size_t)j * P.n0 : (size_t)P.njobs * P.n0 + (size_t)(k - 1) * P.njobs * P.n1 + (size_t)j * P.n1);
-    for(int i = threadIdx.x; i < n; i += blockDim.x) b[i] = 0;
+    for(int i = lane; i < n; i += 64) b[i] = 0;
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
@@ -342,7 +344,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, best != nullptr, 1, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_rdo_finish<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cand, results, drop, st_out, best);
-    k_rdo_zero_dropped<<<3 * njobs, 64, 0, st>>>(coef, drop, P);
+    k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
