@@ -53,7 +53,7 @@ def make_inter_params(r, lw, w, h, bd, nref, idc, slice_type, refs, skip_th=0.0,
     msr = int(r.choice([32, 64]))
     lam_mv = int(np.floor(65536.0 * np.sqrt(rp.lambda_[0])))
     P.me.lambda_mv, P.me.max_search_range, P.me.faststep = lam_mv, msr, 3
-    P.me.min_clip[0], P.me.min_clip[1], P.me.max_clip[0], P.me.max_clip[1] = -128, -128, w - 1 + 128, h - 1 + 128
+    P.me.min_clip[0], P.me.min_clip[1], P.me.max_clip[0], P.me.max_clip[1] = -127, -127, w - 1, h - 1  # -MAX_CU_SIZE + 1 .. pic - 1 (xeve_pinter.c:2124-2127)
     P.spel.lambda_mv, P.spel.hpel_cnt, P.spel.qpel_cnt = lam_mv, int(r.choice([4, 8])), int(r.choice([0, 8, 8]))
     for l in range(2):
         for i in range(nref):
@@ -125,3 +125,39 @@ def oracle_params_from_hip(hp):
             P.refi_bits[l][i], P.range_recentre[l][i] = hp.refi_bits[l][i], hp.range_recentre[l][i]
     P.max_cand, P.poc, P.col_list_poc0, P.skip_th = hp.max_cand, hp.poc, hp.col_list_poc0, hp.skip_th
     return P
+
+
+def fuzz_cases(n_iter, seed0=0, n_jobs=36):
+    """random configurations for the whole inter analysis: picture size, bit depth 8 / 10 / 12, chroma format, slice type, 1-3 reference pictures
+    (list 1 possibly shorter), skip_th, and per level one of: plain, QP / lambda extremes, candidates far outside the picture with the CU on a
+    picture corner, all candidates equal / zero.  Yields (refs, org, states, P, jobs, meta)."""
+    from _rdo_cases import states
+
+    for it in range(n_iter):
+        r = np.random.default_rng(10_000 + seed0 + it)
+        w, h = int(r.choice([64, 128, 192])), int(r.choice([64, 128]))
+        bd, idc, st_type = int(r.choice([8, 10, 10, 12])), int(r.choice([0, 1, 1, 1, 3])), int(r.choice([0, 0, 1]))
+        nref = int(r.choice([1, 2, 3]))
+        refs, org = make_inter_picture(r, w, h, bd, nref, idc, st_type)
+        st = states(r, 6)
+        for lw in (3, 4, 5, 6):
+            cu = 1 << lw
+            P = make_inter_params(r, lw, w, h, bd, nref, idc, st_type, refs, float(r.choice([0.0, 0.0, 3.0, 50.0])),
+                                  nref1=(int(r.integers(1, nref + 1)) if st_type == 0 else None))
+            kind = int(r.integers(0, 4))
+            if kind == 1:  # extreme QP / lambda
+                q = int(r.choice([0, 4, 51 + 6 * (bd - 8)]))
+                P.rdo.qp[0] = P.rdo.qp[1] = P.rdo.qp[2] = q
+                lam = float(r.choice([1e-3, 0.5, 5e4]))
+                P.rdo.lambda_[0] = P.rdo.lambda_[1] = P.rdo.lambda_[2] = lam
+                P.me.lambda_mv = P.spel.lambda_mv = int(np.floor(65536.0 * np.sqrt(lam))) & 0xFFFFFFFF
+            jobs = make_inter_jobs(r, n_jobs, w, h, cu, len(st), refs, st_type)
+            if kind == 2:  # candidates far outside the picture, CUs on the corners
+                jobs["mvp"] = r.integers(-1200, 1201, size=jobs["mvp"].shape)
+                jobs["x"] = r.choice([0, w - cu], size=len(jobs))
+                jobs["y"] = r.choice([0, h - cu], size=len(jobs))
+                jobs["mv_col"] = r.integers(-2000, 2001, size=jobs["mv_col"].shape)
+            if kind == 3:  # all candidates equal (everything pruned but the first), zero vectors
+                jobs["mvp"][:] = jobs["mvp"][:, :, :1]
+                jobs["mvp"][: len(jobs) // 2] = 0
+            yield refs, org, st, P, jobs, dict(it=it, lw=lw, kind=kind, w=w, h=h, bd=bd, idc=idc, slice_type=st_type, nref=nref)

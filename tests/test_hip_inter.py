@@ -238,3 +238,14 @@ def test_hip_pinter_analyze_cu_list1_shorter_than_list0():
             assert res[i:i + 1].tobytes() == er.tobytes() and np.array_equal(rec[0][i], ep[0]) and best[i:i + 1].tobytes() == eb.tobytes(), (lw, i, res[i], er[0])
             modes.add(int(er["best_idx"][0]))
     assert len(modes) >= 3, modes
+
+
+def test_hip_pinter_analyze_cu_fuzz():
+    """tools/fuzz_inter.py, a short run: random configurations incl. 12-bit, 4:4:4, QP / lambda extremes, far candidates on picture corners"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_inter.py"), "8", "900"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "0 mismatches" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])

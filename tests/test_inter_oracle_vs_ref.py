@@ -79,3 +79,37 @@ def test_pinter_analyze_cu_list1_shorter_than_list0():
     (pi->num_refp as the list-1 search left it) and prices the reference index with list 1's table"""
     modes = run_both(128, 96, 10, 3, 1, 0, 0.0, [3, 4, 5], 20, 780, nref1=2)
     assert 2 in modes, modes
+
+
+def test_pinter_analyze_cu_fuzz_vs_reference():
+    """the oracle against the reference over random configurations incl. 12-bit, 4:4:4, QP / lambda extremes, candidates far outside the picture
+    with the CU on a picture corner, all candidates equal, list 1 shorter than list 0, positive skip_th (_inter_cases.fuzz_cases)"""
+    from _inter_cases import fuzz_cases
+
+    O, R = oracle_inter(), ref_inter()
+    total, kinds = 0, set()
+    for refs, org, st, P, jobs, meta in fuzz_cases(16, 500, n_jobs=14):
+        cu, idc = 1 << meta["lw"], meta["idc"]
+        tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+        org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]],
+                            np.uint64)
+        nc = max(1, (cu >> refs["ws"]) * (cu >> refs["hs"]))
+        for i in range(len(jobs)):
+            ra, rb = np.zeros(1, INTER_RESULT_DTYPE), np.zeros(1, INTER_RESULT_DTYPE)
+            ca = [np.zeros(cu * cu, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            cb, pa, pb = [x.copy() for x in ca], [x.copy() for x in ca], [x.copy() for x in ca]
+            ba, bb = np.zeros(1, SBAC_DTYPE), np.zeros(1, SBAC_DTYPE)
+            O.xo_pinter_analyze_cu(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), P, ptr(jobs[i:i + 1]), ptr(ra), ptr(ca[0]),
+                                   ptr(ca[1]), ptr(ca[2]), ptr(pa[0]), ptr(pa[1]), ptr(pa[2]), ptr(ba))
+            R.refdrv_pinter_analyze_cu(ptr(org[0], refs["org_l"]), ptr(org[1], refs["org_c"]), ptr(org[2], refs["org_c"]), refs["s_l"], refs["s_c"], ptr(tab),
+                                       refs["s_l"], refs["s_c"], ptr(st), P, refs["gop"], ptr(jobs[i:i + 1]), ptr(rb), ptr(cb[0]), ptr(cb[1]), ptr(cb[2]), ptr(pb[0]),
+                                       ptr(pb[1]), ptr(pb[2]), ptr(bb))
+            key = (meta, i, jobs[i], ra[0], rb[0])
+            assert mask_unobservable(ra, meta["slice_type"]).tobytes() == mask_unobservable(rb, meta["slice_type"]).tobytes(), key
+            skip = int(ra["cu_mode"][0]) == 2
+            for k in range(3 if idc else 1):
+                assert (skip or np.array_equal(ca[k], cb[k])) and np.array_equal(pa[k], pb[k]), (k,) + key
+            assert ba.tobytes() == bb.tobytes(), key
+            total += 1
+        kinds.add(meta["kind"])
+    assert total > 800 and kinds == {0, 1, 2, 3}

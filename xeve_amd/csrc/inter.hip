@@ -531,7 +531,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     pel *rec[3] = {rec_y, rec_u, rec_v};
     for(int k = 0; k < P.ncomp; k++) {
         const int lk = k ? lw - ws : lw, lhk = k ? lw - hs : lw, q = rp.qp[k];
-        XH_REQUIRE(q >= 0 && q <= 63);
+        XH_REQUIRE(q >= 0 && q <= 51 + 6 * (bd - 8)); // MAX_QUANT + the bit-depth offset
         int16_t *t = tmp + (k == 0 ? 0 : (size_t)njobs * P.n0 + (size_t)(k - 1) * njobs * P.n1);
         rc = xeve_hip_dquant(t, njobs, lk, lhk, k_dq_scale[q % 6] << (q / 6), bd, stream);
         if(rc == XEVE_HIP_OK) rc = xeve_hip_itrans(t, njobs, lk, lhk, bd, stream);

@@ -315,7 +315,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     int16_t *cf[3] = {coef, coef + (size_t)njobs * P.n0, coef + (size_t)njobs * (P.n0 + P.n1)};
     for(int k = 0; k < P.ncomp; k++) {
         const int q = p->qp[k];
-        XH_REQUIRE(q >= 0 && q <= 63);
+        XH_REQUIRE(q >= 0 && q <= 51 + 6 * (bd - 8)); // MAX_QUANT + the bit-depth offset
         rc_ = xeve_hip_residual_rdoq_dev(org[k], k ? s_org_c : s_org_l, pred[k], 1 << lw[k], k ? rc : rl, njobs, lw[k], lh[k], bd, q, k_q_scale[q % 6],
                                          k_dq_scale[q % 6] << (q / 6), p->slice_type == 2, p->lambda[k], k, p->tool_iqt, est, est_idx, cf[k], rec[k],
                                          k ? s_org_c : s_org_l, nnz[k], (int64_t *)ssd[k], stream);

@@ -299,7 +299,7 @@ static int rdoq_common(int16_t *coef, int nblk, int log2w, int log2h, int qp, do
 {
     XH_ENTER();
     XH_REQUIRE(coef && (est || est_dev) && nnz && nblk >= 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
-    XH_REQUIRE(qp >= 0 && qp <= 63 && bit_depth >= 8 && bit_depth <= 14 && (tool_iqt == 0 || tool_iqt == 1) && ch_type >= 0 && ch_type <= 2);
+    XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14 && qp >= 0 && qp <= 51 + 6 * (bit_depth - 8) && (tool_iqt == 0 || tool_iqt == 1) && ch_type >= 0 && ch_type <= 2);
     if(nblk == 0) return XEVE_HIP_OK;
     const uint16_t *scan;
     int rc = xh_get_scan(log2w, log2h, &scan);
@@ -422,7 +422,7 @@ extern "C" int xeve_hip_tq_nnz_host(int16_t *coef, int log2w, int log2h, int qp,
                                     int bit_depth, int tool_iqt, const xeve_hip_rdoq_est_full *est, int use_rdoq, int32_t *nnz)
 {
     XH_ENTER();
-    XH_REQUIRE(coef && nnz && (est || !use_rdoq) && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 63);
+    XH_REQUIRE(coef && nnz && (est || !use_rdoq) && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 87);
     const size_t n = (size_t)1 << (log2w + log2h), off_nnz = (n * 2 + 15) & ~(size_t)15, off_est = off_nnz + 16;
     char *d = nullptr;
     XH_HIP(hipMalloc((void **)&d, off_est + sizeof(*est)));
@@ -447,7 +447,7 @@ extern "C" int xeve_hip_tq_nnz_host(int16_t *coef, int log2w, int log2h, int qp,
 extern "C" int xeve_hip_itdq_host(int16_t *coef, int log2w, int log2h, int qp, int bit_depth)
 {
     XH_ENTER();
-    XH_REQUIRE(coef && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 63);
+    XH_REQUIRE(coef && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && qp >= 0 && qp <= 87);
     static const int dq[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237), scale << (qp / 6) (xeve_itdq.c:549)
     const size_t n = (size_t)1 << (log2w + log2h);
     int16_t *d = nullptr;

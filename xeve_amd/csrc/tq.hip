@@ -262,7 +262,7 @@ extern "C" int xeve_hip_quant(int16_t *coef, int nblk, int log2w, int log2h, int
                               int bit_depth, int32_t *nnz, void *stream)
 {
     XH_Q_ARGS_OK();
-    XH_REQUIRE(qp >= 0 && qp <= 63 && scale > 0 && scale < 65536);
+    XH_REQUIRE(qp >= 0 && qp <= 87 && scale > 0 && scale < 65536);
     // xeve_tq.c:716-718 with MAX_TX_DYNAMIC_RANGE 15, QUANT_SHIFT 14 (xeve_def.h:793-797)
     const int log2_size = (log2w + log2h) >> 1;
     const int shift     = 14 + (15 - bit_depth - log2_size) + qp / 6;
@@ -278,7 +278,7 @@ extern "C" int xeve_hip_rdoq_zero_test(int16_t *coef, int nblk, int log2w, int l
                                        int bit_depth, int32_t *coded, void *stream)
 {
     XH_Q_ARGS_OK();
-    XH_REQUIRE(coded && qp >= 0 && qp <= 63 && scale > 0 && scale < 65536);
+    XH_REQUIRE(coded && qp >= 0 && qp <= 87 && scale > 0 && scale < 65536);
     // xeve_tq.c:673-683
     const int odd       = (log2w + log2h) & 1;
     const int log2_size = (log2w + log2h) >> 1;
@@ -644,7 +644,7 @@ static int residual_launch(const pel *org, int s_org, const pel *pred, int s_pre
     XH_ENTER();
     XH_REQUIRE(org && pred && jobs && coef && rec && nnz && ssd && njobs >= 0);
     XH_REQUIRE(log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6 && bit_depth >= 8 && bit_depth <= 14);
-    XH_REQUIRE(qp >= 0 && qp <= 63 && qscale > 0 && qscale < 65536 && dqscale > 0);
+    XH_REQUIRE(qp >= 0 && qp <= 87 && qscale > 0 && qscale < 65536 && dqscale > 0);
     if(njobs == 0) return XEVE_HIP_OK;
     const int odd = (log2w + log2h) & 1, log2_size = (log2w + log2h) >> 1;
     RdoParams P;

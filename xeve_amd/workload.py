@@ -351,7 +351,7 @@ class HotPathPass:
         C.memmove(C.byref(P.rdo), C.byref(r["params"]), C.sizeof(P.rdo))
         lam_mv = int(np.floor(65536.0 * np.sqrt(self.lam)))  # pi->lambda_mv (xeve_pinter.c:1763)
         P.me.me.lambda_mv, P.me.me.faststep, P.me.me.max_search_range = lam_mv, 3, 64
-        P.me.me.min_clip[0], P.me.me.min_clip[1], P.me.me.max_clip[0], P.me.me.max_clip[1] = -127, -127, self.W - 1 + 127, self.H - 1 + 127
+        P.me.me.min_clip[0], P.me.me.min_clip[1], P.me.me.max_clip[0], P.me.me.max_clip[1] = -127, -127, self.W - 1, self.H - 1  # xeve_pinter.c:2124-2127
         P.me.hpel_cnt, P.me.qpel_cnt = 8, 8
         for l in range(2):
             P.refi_bits[l][0], P.range_recentre[l][0] = 0, 16  # one reference picture per list, one picture away (gop 8: 64 / 8 -> clipped to 64 >> 2)
