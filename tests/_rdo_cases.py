@@ -77,3 +77,40 @@ def make_skip_jobs(r, n, w, h, cuw, cuh, nstates, ncand):
     j["sbac"] = r.integers(0, nstates, size=n)
     j["ctx_skip"] = r.integers(0, 2, size=n)
     return j
+
+
+def fuzz_cases(n_iter, seed0=0, n_jobs=40, n_skip=30):
+    """random configurations for pinter_residue_rdo and xeve_analyze_skip: bit depth 8 / 10 / 12, chroma format, slice type, 1-3 reference pictures, square
+    and non-square CUs, and per size one of: plain, QP / lambda extremes, vectors far outside the picture with the CU on a picture corner.
+    Yields (refs, org, states, p, lw, lh, rdo_jobs, skip_jobs or None, ncand, meta)."""
+    for it in range(n_iter):
+        r = np.random.default_rng(20_000 + seed0 + it)
+        w, h = int(r.choice([64, 128, 192])), int(r.choice([64, 128]))
+        bd, idc, st_type, nref = int(r.choice([8, 10, 10, 12])), int(r.choice([0, 1, 1, 3])), int(r.choice([0, 0, 1])), int(r.choice([1, 2, 3]))
+        refs, org = make_picture(r, w, h, bd, nref, idc)
+        st = states(r, 6)
+        for (lw, lh) in [(3, 3), (4, 4), (5, 5), (6, 6), (2, 2), (4, 3), (3, 5), (6, 4)]:
+            cuw, cuh = 1 << lw, 1 << lh
+            if cuw > w or cuh > h:
+                continue
+            p = make_params(r, lw, lh, w, h, bd, nref, idc, st_type)
+            kind = int(r.integers(0, 3))
+            if kind == 1:
+                q = int(r.choice([0, 4, 51 + 6 * (bd - 8)]))
+                p.qp[0] = p.qp[1] = p.qp[2] = q
+                lam = float(r.choice([1e-3, 0.5, 5e4]))
+                p.lambda_[0] = p.lambda_[1] = p.lambda_[2] = lam
+            jobs = make_jobs(r, n_jobs, w, h, cuw, cuh, nref, len(st), st_type)
+            if kind == 2:
+                jobs["mv"] = r.integers(-1500, 1501, size=jobs["mv"].shape)
+                jobs["x"], jobs["y"] = r.choice([0, w - cuw], size=len(jobs)), r.choice([0, h - cuh], size=len(jobs))
+                jobs["mvd"] = r.integers(-4000, 4001, size=jobs["mvd"].shape)
+            sj, ncand = None, 0
+            if lw == lh:
+                ncand = int(r.integers(1, 5))
+                sj = make_skip_jobs(r, n_skip, w, h, cuw, cuh, len(st), ncand)
+                sj["refi_pred"] = r.integers(-1, nref, size=sj["refi_pred"].shape)
+                if kind == 2:
+                    sj["mvp"] = r.integers(-1500, 1501, size=sj["mvp"].shape)
+                    sj["x"], sj["y"] = r.choice([0, w - cuw], size=len(sj)), r.choice([0, h - cuh], size=len(sj))
+            yield refs, org, st, p, lw, lh, jobs, sj, ncand, dict(it=it, lw=lw, lh=lh, kind=kind, w=w, h=h, bd=bd, idc=idc, slice_type=st_type, nref=nref)

@@ -135,3 +135,14 @@ def test_residue_rdo_full_size_properties():
         assert np.all(res["cost"][~res["nnz"].any(axis=1)] == zero_cost[~res["nnz"].any(axis=1)])  # all-zero winners cost exactly that
         total += n
     assert total == 172020
+
+
+def test_hip_residue_rdo_and_skip_fuzz():
+    """tools/fuzz_rdo.py, a short run: pinter_residue_rdo and xeve_analyze_skip over random configurations incl. 12-bit, 4:4:4, QP / lambda extremes, far vectors"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_rdo.py"), "6", "700"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "0 mismatches" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])

@@ -61,3 +61,35 @@ def test_residue_rdo(w, h, bd, nref, idc, slice_type):
         for k in tot:
             tot[k] += s[k]
     assert tot["n"] >= 100 and tot["zero"] > 0 and tot["kept"] > 0, tot  # the cases reach the different branches of the decision
+
+
+def test_residue_rdo_fuzz_vs_reference():
+    """pinter_residue_rdo, oracle against the reference, over _rdo_cases.fuzz_cases: 12-bit, 4:4:4, QP 0 ... 51 + 6 (bd - 8), lambda 1e-3 ... 5e4, vectors far
+    outside the picture with the CU on a picture corner, non-square CUs"""
+    from _rdo_cases import fuzz_cases
+
+    O, R = oracle_rdo(), ref_rdo()
+    total, kinds = 0, set()
+    for refs, org, st, p, lw, lh, jobs, sj, ncand, meta in fuzz_cases(10, 300, n_jobs=16):
+        cuw, cuh, idc = 1 << lw, 1 << lh, meta["idc"]
+        tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+        org_ptrs = np.array([int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]],
+                            np.uint64)
+        nc = max(1, (cuw >> refs["ws"]) * (cuh >> refs["hs"]))
+        for i in range(len(jobs)):
+            ra, rb = np.zeros(1, RDO_RESULT_DTYPE), np.zeros(1, RDO_RESULT_DTYPE)
+            ca = [np.zeros(cuw * cuh, np.int16), np.zeros(nc, np.int16), np.zeros(nc, np.int16)]
+            cb = [x.copy() for x in ca]
+            ba, bb = np.zeros(1, SBAC_DTYPE), np.zeros(1, SBAC_DTYPE)
+            O.xo_residue_rdo(ptr(org_ptrs), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"], refs["s_c"], ptr(st), p, ptr(jobs[i:i + 1]), ptr(ra), ptr(ca[0]), ptr(ca[1]),
+                             ptr(ca[2]), ptr(ba))
+            R.refdrv_residue_rdo(ptr(org[0], refs["org_l"]), ptr(org[1], refs["org_c"]), ptr(org[2], refs["org_c"]), refs["s_l"], refs["s_c"], ptr(tab), refs["s_l"],
+                                 refs["s_c"], ptr(st), p, ptr(jobs[i:i + 1]), ptr(rb), ptr(cb[0]), ptr(cb[1]), ptr(cb[2]), ptr(bb))
+            key = (meta, i, jobs[i], ra[0], rb[0])
+            assert ra["cost"].tobytes() == rb["cost"].tobytes() and np.array_equal(ra["nnz"], rb["nnz"]), key
+            for k in range(3 if idc else 1):
+                assert np.array_equal(ca[k], cb[k]), (k,) + key
+            assert ba.tobytes() == bb.tobytes(), key
+            total += 1
+        kinds.add(meta["kind"])
+    assert total > 800 and kinds == {0, 1, 2}
