@@ -28,7 +28,7 @@ def make_planes(r, textured, W=256, H=192):
 def make_job(r, pl, S, bi):
     W, H = pl["W"], pl["H"]
     x, y = int(r.integers(0, (W - S) // 8 + 1)) * 8, int(r.integers(0, (H - S) // 8 + 1)) * 8
-    min_clip, max_clip = (-128, -128), (W - 1 + 128, H - 1 + 128)  # -MAX_CU_SIZE .. pic + MAX_CU_SIZE (xeve_pinter.c:1795-1798)
+    min_clip, max_clip = (-127, -127), (W - 1, H - 1)  # -MAX_CU_SIZE + 1 .. pic - 1 (xeve_pinter.c:2124-2127): every block read stays inside the 144-sample padding
     mvp = (int(r.integers(-160, 161)), int(r.integers(-160, 161)))  # quarter pel
     msr = int(r.choice([32, 64, 128]))
     sr = 5 if bi == 1 else int(r.choice([msr // 4, msr // 2, msr]))
@@ -97,7 +97,7 @@ def make_epzs_job(r, pl, S, bi):
     W, H = pl["W"], pl["H"]
     x, y = int(r.integers(0, (W - S) // 8 + 1)) * 8, int(r.integers(0, (H - S) // 8 + 1)) * 8
     msr = int(r.choice([32, 64]))
-    return dict(org=pl["org"], ref=pl["ref"], s=pl["s"], x=x, y=y, S=S, bi=bi, min_clip=(-128, -128), max_clip=(W - 1 + 128, H - 1 + 128),
+    return dict(org=pl["org"], ref=pl["ref"], s=pl["s"], x=x, y=y, S=S, bi=bi, min_clip=(-127, -127), max_clip=(W - 1, H - 1),
                 mvp=(int(r.integers(-100, 101)), int(r.integers(-100, 101))), mv0=(int(r.integers(-25, 26)) * 4, int(r.integers(-25, 26)) * 4),
                 msr=msr, sr=int(r.choice([msr // 4, msr // 2, msr])), lambda_mv=int(r.integers(1 << 16, 1 << 22)), mot_other=int(r.integers(2, 30)),
                 org_bi=(2 * r.integers(0, 1024, size=S * S) - r.integers(0, 1024, size=S * S)).astype(np.int16),

@@ -15,7 +15,7 @@ def golden_cases():
         W, H = 128, 96
         for row, obi in zip(g["jobs%d" % t], g["org_bi%d" % t]):
             (S, bi, x, y, r0, r1, r2, r3, gx, gy, ix, iy, msr, sr, lam, fast, mot, bs_in, cost, mvx, mvy, beststep) = (int(v) for v in row)
-            c = dict(org=org, ref=ref, s=W + 2 * PAD, x=x, y=y, S=S, bi=bi, min_clip=(-128, -128), max_clip=(W - 1 + 128, H - 1 + 128),
+            c = dict(org=org, ref=ref, s=W + 2 * PAD, x=x, y=y, S=S, bi=bi, min_clip=(-127, -127), max_clip=(W - 1, H - 1),
                      range=[r0, r1, r2, r3], gmvp=(gx, gy), mvi=(ix, iy), msr=msr, sr=sr, lambda_mv=lam, faststep=fast, mot_other=mot,
                      org_bi=np.ascontiguousarray(obi[:S * S]), beststep_in=bs_in)
             yield c, (cost, mvx, mvy, beststep)
