@@ -48,6 +48,11 @@ void        xeve_hip_shutdown(void);
 const char *xeve_hip_last_error(void);
 /* number of table-layer calls served since init (to let tests prove the HIP path ran) */
 uint64_t    xeve_hip_table_calls(void);
+/* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
+ * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
+ * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result (0 .. 23); -1 past the end.  For bindings in
+ * other languages to check their record layouts at load time (no GPU needed). */
+int         xeve_hip_sizeof(int i);
 
 /* ------------------------------------------------------------------------------------------- */
 /* (1) drop-in dispatch tables                                                                 */

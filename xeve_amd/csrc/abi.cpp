@@ -44,6 +44,16 @@ bool xh_ready() { return g_device.load() >= 0; }
 
 extern "C" const char *xeve_hip_last_error(void) { return t_err[0] ? t_err : g_err; }
 extern "C" uint64_t    xeve_hip_table_calls(void) { return g_table_calls.load(); }
+extern "C" int xeve_hip_sizeof(int i)
+{
+    static const int sz[] = {(int)sizeof(xeve_hip_job), (int)sizeof(xeve_hip_mc_job), (int)sizeof(xeve_hip_me_params), (int)sizeof(xeve_hip_me_job),
+                             (int)sizeof(xeve_hip_me_result), (int)sizeof(xeve_hip_spel_params), (int)sizeof(xeve_hip_spel_job), (int)sizeof(xeve_hip_epzs_job),
+                             (int)sizeof(xeve_hip_epzs_params), (int)sizeof(xeve_hip_sbac), (int)sizeof(xeve_hip_cu_bits_params), (int)sizeof(xeve_hip_cu_bits_job),
+                             (int)sizeof(xeve_hip_rdoq_est_full), (int)sizeof(xeve_hip_deblock_params), (int)sizeof(xeve_hip_refpic), (int)sizeof(xeve_hip_cu_mc_job),
+                             (int)sizeof(xeve_hip_rdo_params), (int)sizeof(xeve_hip_rdo_job), (int)sizeof(xeve_hip_rdo_result), (int)sizeof(xeve_hip_skip_job),
+                             (int)sizeof(xeve_hip_skip_result), (int)sizeof(xeve_hip_inter_params), (int)sizeof(xeve_hip_inter_job), (int)sizeof(xeve_hip_inter_result)};
+    return i >= 0 && i < (int)(sizeof(sz) / sizeof(sz[0])) ? sz[i] : -1;
+}
 
 extern "C" int xeve_hip_init(int device_ordinal)
 {

@@ -158,6 +158,7 @@ FUNCTIONS = {
     "xeve_hip_pinter_analyze_cu_workspace": (C.c_size_t, [c_int, c_int, c_void_p, c_int, c_int]),
     "xeve_hip_pinter_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_inter_candidates": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "xeve_hip_pinter_analyze_cu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 14),
     "xeve_hip_me_epzs_jobs_x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
