@@ -190,7 +190,7 @@ def main():
         dt = float(t.item())
 
     rate_term = None
-    if rank == 0 and not a.no_rate:
+    if rank == 0 and world == 1 and not a.no_rate:  # (single-GPU runs only: the scaling runs time the pass, nothing else)
         # The rate term of the same RDO (CABAC bit counts of the CUs phase D quantised; xeve_amd/workload.py phase F), measured on
         # its own AFTER the timed region: an arithmetic coder's cost is set by the data, and i.i.d. synthetic pictures quantise
         # to ~100x the bins of real video -- folded into `value` it would measure the synthetic data, not the path.  Reported for
