@@ -249,7 +249,7 @@ typedef struct xeve_hip_me_params {
     int32_t  max_search_range; /* pi->max_search_range */
     int32_t  range_recentre;   /* range get_range_ipel derives for this reference picture (POC-distance scaled) */
     int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / pi->max_clip */
-    int32_t  reserved;         /* (was beststep_in; now per job) */
+    int32_t  reserved;         /* xeve_hip_me_epzs_jobs only: bit 0 = me_raster on (pi->me_complexity > 1), bits 8..15 = refi (its step scales with refi + 1) */
 } xeve_hip_me_params;
 typedef struct xeve_hip_me_job {
     int32_t x, y;     /* block position (integer pel, picture coordinates) */
@@ -300,7 +300,9 @@ int xeve_hip_me_spel_pattern_jobs(const xeve_hip_pel *org0, int s_org, const xev
  * kernel (a wave per block loops over its searches, the original block in registers throughout); the call is asynchronous
  * on `stream` like the rest of the batched API.  results[j].mv / .cost are what pinter_me_epzs returns; .best_mv_bits is what the searches leave in
  * pi->mot_bits[lidx] (0: they leave it untouched; xeve_pinter.c:546-548,690-692); .beststep is 0.  A job with x < 0 is switched off (no work;
- * its result is unspecified). */
+ * its result is unspecified).  The other branches of the function: params->me.reserved bit 0 adds me_raster (xeve_pinter.c:158-268) after a first
+ * search that ended with beststep > 5 (me_complexity > 1: preset placebo); params->hpel_cnt == 0 replaces the sub-pel stage by me_ipel_refinement
+ * (xeve_pinter.c:270-361; me_level = ME_LEV_IPEL). */
 typedef struct xeve_hip_epzs_job {
     int32_t x, y;        /* block position (integer pel) */
     int32_t org_off;     /* bi != 0: offset of the job's dense org_bi block */
@@ -542,12 +544,13 @@ int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int s_org_l, in
 /*     direct (B slices), per list the motion search over every reference picture + check_best_mvp */
 /*     + pinter_residue_rdo, the iterated bi-prediction search (analyze_bi, B slices) +           */
 /*     pinter_residue_rdo; the cheapest mode's coefficients, reconstruction, motion data and      */
-/*     coder state.  me_complexity 1, me_level > IPEL, rdo_dbk_switch 0 (presets fast / medium).   */
+/*     coder state.  Every me_algo / me_sub setting; rdo_dbk_switch 0 (presets fast / medium).     */
 /* ------------------------------------------------------------------------------------------- */
 #define XEVE_HIP_MAX_REFP 8
 typedef struct xeve_hip_inter_params {
     xeve_hip_rdo_params  rdo;
-    xeve_hip_epzs_params me;   /* lambda_mv, max_search_range, clips, hpel / qpel counts; bi, extra_bits, refi_bits, range_recentre are set per search */
+    xeve_hip_epzs_params me;   /* lambda_mv, max_search_range, clips, hpel / qpel counts (hpel 0 = ME_LEV_IPEL), me.reserved bit 0 = me_raster on;
+                                  bi, extra_bits, refi_bits, range_recentre and the refi of me.reserved are set per search */
     int32_t refi_bits[2][XEVE_HIP_MAX_REFP];      /* xeve_tbl_refi_bits[rdo.num_refp[l]][refi] (xeve_tbl.c:498-517) */
     int32_t range_recentre[2][XEVE_HIP_MAX_REFP]; /* get_range_ipel's POC-distance scaled range of refp[refi][l] (xeve_pinter.c:124-129) */
     int32_t max_cand;                             /* pi->skip_merge_cand_num */

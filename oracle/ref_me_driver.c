@@ -66,7 +66,7 @@ unsigned refdrv_me_spel_pattern(pel *org0, int s_org, const s16 *org_bi, pel *re
     pi->mot_bits[lidx_r] = mot_bits_other, pi->mot_bits[lidx] = -1;
     pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = hpel_cnt;
     pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = qpel_cnt;
-    pi->me_level = qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL;
+    pi->me_level = hpel_cnt == 0 ? ME_LEV_IPEL : (qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL);
     pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
     s16 gmvp[MV_D] = {gmvp_in[0], gmvp_in[1]}, mvi[MV_D] = {mvi_in[0], mvi_in[1]}, mv[MV_D];
     unsigned cost = me_spel_pattern(pi, x, y, log2w, log2h, (s8)refi, lidx, gmvp, mvi, mv, bi, bit_depth);
@@ -76,11 +76,25 @@ unsigned refdrv_me_spel_pattern(pel *org0, int s_org, const s16 *org_bi, pel *re
 
 
 static int g_last_mot_bits;
+unsigned refdrv_me_epzs_x(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h, int bit_depth,
+                          const s16 mvp_in[2], s16 mv_io[2], int bi, unsigned lambda_mv, int num_refp, int refi_in, int mot_bits_other,
+                          int max_search_range, int gop_size, int poc, int ref_poc, const int min_clip[2], const int max_clip[2], int hpel_cnt,
+                          int qpel_cnt, int me_complexity);
 /* pinter_me_epzs (static, xeve_pinter.c:699) with me_complexity 1 (no raster); mv_io: in = start for bi == BI_NORMAL, out = result */
 unsigned refdrv_me_epzs(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h, int bit_depth,
                         const s16 mvp_in[2], s16 mv_io[2], int bi, unsigned lambda_mv, int num_refp, int refi_in, int mot_bits_other,
                         int max_search_range, int gop_size, int poc, int ref_poc, const int min_clip[2], const int max_clip[2], int hpel_cnt,
                         int qpel_cnt)
+{
+    return refdrv_me_epzs_x(org0, s_org, org_bi, ref0, s_ref, x, y, log2w, log2h, bit_depth, mvp_in, mv_io, bi, lambda_mv, num_refp, refi_in, mot_bits_other,
+                            max_search_range, gop_size, poc, ref_poc, min_clip, max_clip, hpel_cnt, qpel_cnt, 1);
+}
+
+/* the same with me_complexity (pi->me_complexity = param.me_algo: 2 adds me_raster) as an argument; hpel_cnt == 0 selects me_level = ME_LEV_IPEL */
+unsigned refdrv_me_epzs_x(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int s_ref, int x, int y, int log2w, int log2h, int bit_depth,
+                          const s16 mvp_in[2], s16 mv_io[2], int bi, unsigned lambda_mv, int num_refp, int refi_in, int mot_bits_other,
+                          int max_search_range, int gop_size, int poc, int ref_poc, const int min_clip[2], const int max_clip[2], int hpel_cnt,
+                          int qpel_cnt, int me_complexity)
 {
     static XEVE_PINTER *pi;
     static XEVE_PIC     pic;
@@ -99,10 +113,10 @@ unsigned refdrv_me_epzs(pel *org0, int s_org, const s16 *org_bi, pel *ref0, int 
     pi->num_refp = num_refp, pi->lambda_mv = lambda_mv;
     pi->mot_bits[lidx_r] = mot_bits_other, pi->mot_bits[lidx] = -1;
     pi->max_search_range = max_search_range, pi->gop_size = gop_size, pi->poc = poc;
-    pi->me_complexity = 1;
+    pi->me_complexity = me_complexity;
     pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = hpel_cnt;
     pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = qpel_cnt;
-    pi->me_level = qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL;
+    pi->me_level = hpel_cnt == 0 ? ME_LEV_IPEL : (qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL);
     pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
     s16 mvp[MV_D] = {mvp_in[0], mvp_in[1]}, mv[MV_D] = {mv_io[0], mv_io[1]};
     s8  refi = (s8)refi_in;

@@ -201,10 +201,11 @@ void refdrv_pinter_analyze_cu(pel *org_y, pel *org_u, pel *org_v, int s_org_l, i
     /* motion search set-up (pinter_init_lcu / pinter_set_complexity, :1716-1771, :2049-2140) */
     pi->fn_me = pinter_me_epzs;
     pi->min_clip[MV_X] = P->me.min_clip[0], pi->min_clip[MV_Y] = P->me.min_clip[1], pi->max_clip[MV_X] = P->me.max_clip[0], pi->max_clip[MV_Y] = P->me.max_clip[1];
-    pi->lambda_mv = P->me.lambda_mv, pi->max_search_range = P->me.max_search_range, pi->gop_size = gop_size, pi->poc = P->poc, pi->me_complexity = 1;
+    pi->lambda_mv = P->me.lambda_mv, pi->max_search_range = P->me.max_search_range, pi->gop_size = gop_size, pi->poc = P->poc;
+    pi->me_complexity = (P->me.reserved & 1) ? 2 : 1; /* bit 0: me_raster on */
     pi->search_pattern_hpel = tbl_search_pattern_hpel_partial, pi->search_pattern_hpel_cnt = P->spel.hpel_cnt;
     pi->search_pattern_qpel = tbl_search_pattern_qpel_8point, pi->search_pattern_qpel_cnt = P->spel.qpel_cnt;
-    pi->me_level = P->spel.qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL, pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
+    pi->me_level = P->spel.hpel_cnt == 0 ? ME_LEV_IPEL : (P->spel.qpel_cnt > 0 ? ME_LEV_QPEL : ME_LEV_HPEL), pi->mc_l_coeff = xeve_tbl_mc_l_coeff;
     memset(pi->mot_bits, 0, sizeof(pi->mot_bits));
     /* temporal direct (xeve_get_mv_dir): POCs and the collocated vector at the CU's bottom-right unit */
     ctx->poc.poc_val = P->poc, ctx->h_scu = 64, ctx->param.skip_th = P->skip_th;

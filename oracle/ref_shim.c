@@ -126,13 +126,13 @@ static u32 shim_me(XEVE_PINTER *pi, int x, int y, int log2_cuw, int log2_cuh, s8
     hip_me_result   r;
     const int offset = pi->gop_size >> 1; /* get_range_ipel (xeve_pinter.c:122-129) */
     p.lambda_mv = pi->lambda_mv, p.refi_bits = xeve_tbl_refi_bits[pi->num_refp][ri], p.extra_bits = bi ? pi->mot_bits[lidx_r] : 0, p.bi = bi, p.faststep = 3;
+    p.reserved = (pi->me_complexity > 1 ? 1 : 0) | (ri << 8); /* me_raster on; its step scales with refi + 1 */
     p.max_search_range = pi->max_search_range;
     p.range_recentre = XEVE_CLIP3(pi->max_search_range >> 2, pi->max_search_range,
                                   (pi->max_search_range * XEVE_ABS(pi->poc - (int)pi->refp[ri][lidx].poc) + offset) / pi->gop_size);
-    p.min_clip[0] = pi->min_clip[MV_X], p.min_clip[1] = pi->min_clip[MV_Y], p.max_clip[0] = pi->max_clip[MV_X], p.max_clip[1] = pi->max_clip[MV_Y], p.reserved = 0;
-    p.hpel_cnt = pi->search_pattern_hpel_cnt, p.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    p.min_clip[0] = pi->min_clip[MV_X], p.min_clip[1] = pi->min_clip[MV_Y], p.max_clip[0] = pi->max_clip[MV_X], p.max_clip[1] = pi->max_clip[MV_Y];
+    p.hpel_cnt = pi->me_level > ME_LEV_IPEL ? pi->search_pattern_hpel_cnt : 0, p.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
     j.x = x, j.y = y, j.org_off = 0, j.mvp[0] = mvp[MV_X], j.mvp[1] = mvp[MV_Y], j.mv_start[0] = mv[MV_X], j.mv_start[1] = mv[MV_Y];
-    if(pi->me_level <= ME_LEV_IPEL || pi->me_complexity > 1) { fprintf(stderr, "[xeve_hip_shim] this preset's search (raster / integer refinement) is not on the GPU\n"); abort(); }
     if(hip_me_epzs_host(pi->o[Y_C], pi->s_o[Y_C], bi ? (const pel *)pi->org_bi : NULL, rp->y, rp->s_l, rp->pad_l, rp->h_l, &j, log2_cuw, log2_cuh, bit_depth_luma,
                         pi->mc_l_coeff, &p, &r) != 0) {
         fprintf(stderr, "[xeve_hip_shim] me: %s\n", hip_err());
@@ -254,8 +254,7 @@ static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
     XEVE_PINTER *pi = &ctx->pinter[core->thread_cnt];
     const int isb = pi->slice_type == SLICE_B, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
     const int nr[2] = {ctx->rpm.num_refp[REFP_0], isb ? ctx->rpm.num_refp[REFP_1] : 0};
-    if(log2_cuw != log2_cuh || log2_cuw < 3 || log2_cuw > 6 || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || pi->me_level <= ME_LEV_IPEL ||
-       pi->me_complexity > 1 || nr[0] > 8 || nr[1] > nr[0] || nr[0] < 1 || (isb && nr[1] < 1) || core->tree_cons.tree_type != TREE_LC || core->tree_cons.mode_cons != eAll) {
+    if(log2_cuw != log2_cuh || log2_cuw < 3 || log2_cuw > 6 || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || nr[0] > 8 || nr[1] > nr[0] || nr[0] < 1 || (isb && nr[1] < 1) || core->tree_cons.tree_type != TREE_LC || core->tree_cons.mode_cons != eAll) {
         inter_fallbacks++;
         return orig_pinter_analyze_cu(ctx, core, x, y, log2_cuw, log2_cuh, mi, coef, rec, s_rec);
     }
@@ -268,7 +267,8 @@ static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
     P.rdo.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.rdo.dist_chroma_weight[1] = core->dist_chroma_weight[1];
     P.me.lambda_mv = pi->lambda_mv, P.me.faststep = 3, P.me.max_search_range = pi->max_search_range;
     P.me.min_clip[0] = pi->min_clip[MV_X], P.me.min_clip[1] = pi->min_clip[MV_Y], P.me.max_clip[0] = pi->max_clip[MV_X], P.me.max_clip[1] = pi->max_clip[MV_Y];
-    P.me.hpel_cnt = pi->search_pattern_hpel_cnt, P.me.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    P.me.hpel_cnt = pi->me_level > ME_LEV_IPEL ? pi->search_pattern_hpel_cnt : 0, P.me.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    P.me.reserved = pi->me_complexity > 1 ? 1 : 0;
     hip_refpic tab[16];
     memset(tab, 0, sizeof(tab));
     XEVE_PIC *any = pi->refp[0][REFP_0].pic;
@@ -356,6 +356,16 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
     void (*orig)(XEVE_CTX *) = (void (*)(XEVE_CTX *))dlsym(RTLD_NEXT, "xeve_platform_init_func");
     if(!orig) { fprintf(stderr, "[xeve_hip_shim] reference xeve_platform_init_func not found\n"); abort(); }
     orig(ctx);
+    /* XEVE_SHIM_ME_COMPLEXITY / XEVE_SHIM_ME_LEVEL: settings of the motion search the app has no option for (pi->me_complexity = param.me_algo: 2 adds
+     * me_raster; pi->me_level = param.me_sub: 1 = integer refinement instead of the sub-pel pattern) -- applied to plain and GPU runs alike, so that the
+     * other branches of pinter_me_epzs can be compared inside the encoder too */
+    {
+        const char *mc = getenv("XEVE_SHIM_ME_COMPLEXITY"), *ml = getenv("XEVE_SHIM_ME_LEVEL");
+        for(int i = 0; i < ctx->param.threads && (mc || ml); i++) {
+            if(mc) ctx->pinter[i].me_complexity = atoi(mc);
+            if(ml) ctx->pinter[i].me_level = atoi(ml);
+        }
+    }
     const char *lib = getenv("XEVE_HIP_LIB");
     if(!lib) return; /* plain reference run */
     void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);

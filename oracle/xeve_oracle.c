@@ -426,8 +426,17 @@ int xo_mv_bits(int mvd_x, int mvd_y) { return mvd_bits(mvd_x) + mvd_bits(mvd_y);
 static const int8_t dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1, 3}, {0, 4}, {1, 3}, {2, 2}, {3, 1},
                                     {4, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -4}, {-1, -3}, {-2, -2}, {-3, -1}};
 
+static void me_ipel_diamond_ex(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job, int log2w, int log2h,
+                               int bit_depth, const xo_me_params *p, xo_me_result *res, int16_t range_out[4]);
 void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job,
                         int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res)
+{
+    me_ipel_diamond_ex(org0, s_org, org_bi, ref0, s_ref, job, log2w, log2h, bit_depth, p, res, NULL);
+}
+/* range_out: the caller's `range` array as the function leaves it -- it is re-centred in place after the dense round (xeve_pinter.c:463-468), and
+ * pinter_me_epzs hands that array on to me_raster */
+static void me_ipel_diamond_ex(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_me_job *job, int log2w, int log2h,
+                               int bit_depth, const xo_me_params *p, xo_me_result *res, int16_t range_out[4])
 {
     const int w = 1 << log2w, h = 1 << log2h;
     const xo_pel *org = p->bi ? org_bi + job->org_off : org0 + job->y * s_org + job->x;
@@ -493,6 +502,8 @@ void xo_me_ipel_diamond(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
     res->cost = cost_best;
     res->beststep = beststep;
     res->best_mv_bits = best_bits;
+    if(range_out)
+        for(int i = 0; i < 4; i++) range_out[i] = (int16_t)range[i];
 }
 
 
@@ -548,6 +559,61 @@ static void epzs_range(const xo_me_params *p, int cx, int cy, int16_t range[4])
     range[3] = (int16_t)clip3i(p->min_clip[1], p->max_clip[1], cy + sr);
 }
 
+static uint32_t me_cand_cost(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, int mx, int my, const int16_t gmvp[2],
+                             int log2w, int log2h, int bit_depth, const xo_me_params *p, int *bits)
+{   /* get_mv_bits + MV_COST + SAD at one integer position (xeve_pinter.c:200-209, 323-341) */
+    const int w = 1 << log2w, h = 1 << log2h;
+    int mv_bits = xo_mv_bits((mx << 2) - gmvp[0], (my << 2) - gmvp[1]) + p->refi_bits;
+    if(p->bi) mv_bits += p->extra_bits;
+    uint32_t cost = (uint32_t)(((uint64_t)p->lambda_mv * (uint32_t)mv_bits + (1u << 15)) >> 16);
+    const xo_pel *ref = ref0 + (long)my * s_ref + mx;
+    if(p->bi) cost += (uint32_t)(xo_sad(w, h, org_bi, ref, w, s_ref, bit_depth) >> 1);
+    else cost += (uint32_t)xo_sad(w, h, org0 + (long)y * s_org + x, ref, s_org, s_ref, bit_depth);
+    *bits = mv_bits;
+    return cost;
+}
+
+void xo_me_raster(const xo_pel *org0, int s_org, const xo_pel *ref0, int s_ref, int x, int y, const int16_t range[4], const int16_t gmvp[2], int log2w, int log2h,
+                  int bit_depth, const xo_me_params *p, int refi, xo_me_result *res)
+{
+    const int lmin = log2w < log2h ? log2w : log2h, st = (1 << (lmin - 1)) > 5 ? (1 << (lmin - 1)) : 5; /* max(RASTER_SEARCH_STEP, half the CU) */
+    uint32_t cost_best = 0xFFFFFFFFu;
+    int best_bits = 0, bits;
+    int mvx = res->mv[0], mvy = res->mv[1]; /* (the reference leaves `mv` as handed in when nothing is evaluated) */
+    for(int i = range[1]; i <= range[3]; i += st * (refi + 1))
+        for(int j = range[0]; j <= range[2]; j += st * (refi + 1)) {
+            const uint32_t c = me_cand_cost(org0, s_org, NULL, ref0, s_ref, x, y, j, i, gmvp, log2w, log2h, bit_depth, p, &bits);
+            if(c < cost_best) mvx = (j - x) << 2, mvy = (i - y) << 2, cost_best = c, best_bits = bits;
+        }
+    for(int ss = ((refi + 1) * st) >> 1; ss > 0; ss >>= 1) {
+        const int cx = mvx, cy = mvy;
+        for(int i = -ss; i <= ss; i += ss)
+            for(int j = -ss; j <= ss; j += ss) {
+                const int mx = (cx >> 2) + x + j, my = (cy >> 2) + y + i;
+                if(mx < range[0] || mx > range[2] || my < range[1] || my > range[3]) continue;
+                const uint32_t c = me_cand_cost(org0, s_org, NULL, ref0, s_ref, x, y, mx, my, gmvp, log2w, log2h, bit_depth, p, &bits);
+                if(c < cost_best) mvx = (mx - x) << 2, mvy = (my - y) << 2, cost_best = c, best_bits = bits;
+            }
+    }
+    res->mv[0] = (int16_t)mvx, res->mv[1] = (int16_t)mvy, res->cost = cost_best, res->beststep = 0, res->best_mv_bits = best_bits;
+}
+
+void xo_me_ipel_refinement(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t range[4],
+                           const int16_t gmvp[2], const int16_t mvi[2], int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res)
+{
+    static const int pos[9][2] = {{0, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
+    const int ix = clip3i(p->min_clip[0], p->max_clip[0], mvi[0] >> 2), iy = clip3i(p->min_clip[1], p->max_clip[1], mvi[1] >> 2);
+    int bx = ix, by = iy, best_bits = 0, bits;
+    uint32_t cost_best = 0xFFFFFFFFu;
+    for(int i = 0; i < 9; i++) {
+        const int mx = ix + pos[i][0], my = iy + pos[i][1];
+        if(mx > range[2] || mx < range[0] || my > range[3] || my < range[1]) continue;
+        const uint32_t c = me_cand_cost(org0, s_org, org_bi, ref0, s_ref, x, y, mx, my, gmvp, log2w, log2h, bit_depth, p, &bits);
+        if(c < cost_best) bx = mx, by = my, cost_best = c, best_bits = bits;
+    }
+    res->mv[0] = (int16_t)((bx - x) << 2), res->mv[1] = (int16_t)((by - y) << 2), res->cost = cost_best, res->beststep = 0, res->best_mv_bits = best_bits;
+}
+
 uint32_t xo_me_epzs(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t mvp[2],
                     int16_t mv[2], int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_epzs_params *p)
 {
@@ -571,12 +637,20 @@ uint32_t xo_me_epzs_mot(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
                job.range);
     me.faststep = 3; /* MAX_FIRST_SEARCH_STEP */
     job.beststep_in = tmpstep;
-    xo_me_ipel_diamond(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r);
+    int16_t range_after[4];
+    me_ipel_diamond_ex(org0, s_org, org_bi, ref0, s_ref, &job, log2w, log2h, bit_depth, &me, &r, range_after);
     tmpstep = r.beststep;
     if(me.bi != 1 && r.best_mv_bits > 0) *mot_bits = r.best_mv_bits; /* pi->mot_bits[lidx] (xeve_pinter.c:546-548) */
     if(r.cost < cost_best) {
         cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
         beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
+    }
+    if(me.bi == 0 && beststep > 5 && (p->me.reserved & 1)) { /* me_raster: bi == BI_NON && beststep > RASTER_SEARCH_THD && me_complexity > 1 (:757-767) */
+        xo_me_result rr;
+        rr.mv[0] = r.mv[0], rr.mv[1] = r.mv[1]; /* mvt as the diamond search left it */
+        xo_me_raster(org0, s_org, ref0, s_ref, x, y, range_after, job.gmvp, log2w, log2h, bit_depth, &me, (p->me.reserved >> 8) & 0xFF, &rr);
+        if(rr.best_mv_bits > 0) *mot_bits = rr.best_mv_bits;
+        if(rr.cost < cost_best) beststep = 5, cost_best = rr.cost, mv[0] = rr.mv[0], mv[1] = rr.mv[1];
     }
     while(me.bi != 1 && beststep > 0) { /* REFINE_SEARCH_THD 0 */
         /* note: get_range_ipel is given the UNCLIPPED centre here (xeve_pinter.c:785-788) */
@@ -592,6 +666,14 @@ uint32_t xo_me_epzs_mot(const xo_pel *org0, int s_org, const xo_pel *org_bi, con
             cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
             beststep = (abs(mvp[0] - mv[0]) < 2 && abs(mvp[1] - mv[1]) < 2) ? 0 : tmpstep;
         }
+    }
+    if(p->spel.hpel_cnt == 0) { /* me_level <= ME_LEV_IPEL: integer refinement instead of the sub-pel pattern (:835-866) */
+        int16_t mvi[2] = {(int16_t)(mv[0] + (x << 2)), (int16_t)(mv[1] + (y << 2))};
+        epzs_range(&me, x + (mv[0] >> 2), y + (mv[1] >> 2), job.range);
+        xo_me_ipel_refinement(org0, s_org, org_bi, ref0, s_ref, x, y, job.range, job.gmvp, mvi, log2w, log2h, bit_depth, &me, &r);
+        if(me.bi != 1 && r.best_mv_bits > 0) *mot_bits = r.best_mv_bits;
+        if(r.cost < cost_best) cost_best = r.cost, mv[0] = r.mv[0], mv[1] = r.mv[1];
+        return cost_best;
     }
     xo_spel_params sp = p->spel;
     sp.lambda_mv = me.lambda_mv, sp.refi_bits = me.refi_bits, sp.extra_bits = me.extra_bits, sp.bi = me.bi;
@@ -1464,6 +1546,7 @@ void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
             mvp_idx[l] = mvpi[SKIP][l];
             for(int r = 0; r < p->num_refp[l]; r++) {
                 ep.me.bi = 0, ep.me.extra_bits = 0, ep.me.refi_bits = P->refi_bits[l][r], ep.me.range_recentre = P->range_recentre[l][r];
+                ep.me.reserved = (P->me.me.reserved & 1) | (r << 8); /* me_raster's step scales with refi + 1 */
                 int16_t m[2] = {0, 0};
                 const uint32_t mecost = xo_me_epzs_mot(org[0], s_org_l, NULL, refp[r * 2 + l].y, s_l, x, y, job->mvp[l][mvp_idx[l]], m, lw, lh, bd, xo_mc_l_coeff, &ep,
                                                        &mot_bits[l]);

@@ -105,7 +105,7 @@ typedef struct xo_me_params {
     int32_t  max_search_range; /* pi->max_search_range                   (xeve_pinter.c:535)     */
     int32_t  range_recentre;   /* the search range get_range_ipel derives for this reference picture (xeve_pinter.c:124-129) */
     int32_t  min_clip[2], max_clip[2]; /* pi->min_clip / max_clip        (xeve_pinter.c:132-136) */
-    int32_t  reserved;         /* (was beststep_in; now per job)                                  */
+    int32_t  reserved;         /* pinter_me_epzs only: bit 0 = raster search on (pi->me_complexity > 1), bits 8..15 = refi (MULTI_REF_ME_STEP) */
 } xo_me_params;
 
 typedef struct xo_me_job {
@@ -141,7 +141,14 @@ typedef struct xo_spel_job {
 void xo_me_spel_pattern(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, const xo_spel_job *job,
                         int log2w, int log2h, int bit_depth, const int16_t (*coef)[8], const xo_spel_params *p, xo_me_result *res);
 
-/* pinter_me_epzs (xeve_pinter.c:699-869) for me_complexity == 1 (no raster search) and me_level > ME_LEV_IPEL: first
+/* me_raster (xeve_pinter.c:158-268): grid of step max(5, S / 2) * (refi + 1) over the range, then 3x3 grids of halving step around the best;
+ * me_ipel_refinement (:270-361): the nine integer positions around mvi.  Both: cost, mv (relative, quarter pel), best_mv_bits in *res. */
+void xo_me_raster(const xo_pel *org0, int s_org, const xo_pel *ref0, int s_ref, int x, int y, const int16_t range[4], const int16_t gmvp[2], int log2w, int log2h,
+                  int bit_depth, const xo_me_params *p, int refi, xo_me_result *res);
+void xo_me_ipel_refinement(const xo_pel *org0, int s_org, const xo_pel *org_bi, const xo_pel *ref0, int s_ref, int x, int y, const int16_t range[4],
+                           const int16_t gmvp[2], const int16_t mvi[2], int log2w, int log2h, int bit_depth, const xo_me_params *p, xo_me_result *res);
+/* pinter_me_epzs (xeve_pinter.c:699-869); p->me.reserved bit 0 adds the raster search (me_complexity > 1), p->spel.hpel_cnt == 0 replaces the
+ * sub-pel stage by me_ipel_refinement (me_level <= ME_LEV_IPEL).  With neither: first
  * diamond search from the MVP (faststep 3), refinement searches from the running best while beststep > 0 (faststep 2),
  * then me_spel_pattern.  mvp / mv are relative to the block (quarter pel); for bi == 1 `mv` is also the starting point. */
 typedef struct xo_epzs_params {

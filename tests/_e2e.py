@@ -22,6 +22,7 @@ CASES = {
     "moving_ldb_fast": (128, 128, 3, 5002, ["--preset", "fast", "-I", "0", "-b", "0"]),
     "moving_ldb_ref3": (128, 128, 5, 5003, ["--preset", "fast", "-I", "0", "-b", "0", "--ref", "3"]),  # several reference pictures per list
     "moving_ra_b3_medium": (128, 64, 9, 5004, ["--preset", "medium", "-b", "3"]),  # hierarchical B pictures
+    "jumpy_ldb_fast": (192, 128, 4, 6001, ["--preset", "fast", "-I", "0", "-b", "0"]),  # 23 x 17 samples of motion per frame
     "moving_cif_ra_medium": (352, 288, 5, 5006, ["--preset", "medium", "-b", "1"]),  # 5.5 x 4.5 CTUs: partial CTUs at the right and bottom edge
 }
 
@@ -41,17 +42,20 @@ def make_yuv(path, w, h, frames, seed):
         for t in range(frames):
             for (pw, ph, sc, base) in ((w, h, 1.0, 128.0), (w // 2, h // 2, 2.0, 110.0), (w // 2, h // 2, 2.0, 140.0)):
                 yy, xx = np.mgrid[0:ph, 0:pw].astype(np.float64) * sc
-                xs, ys = xx + 3.0 * t, yy + 2.0 * t
+                xs, ys = (xx + 3.0 * t, yy + 2.0 * t) if seed < 6000 else (xx + 23.0 * t, yy + 17.0 * t)  # (seeds from 6000: jumps the first search only finds on its far rings)
                 a = base + 60 * np.sin(xs / 9.0) * np.cos(ys / 7.0) + 30 * np.sin((xs + ys) / 13.0) + 12 * np.sin(xs / 3.0)
                 a[ph // 2:, :] += 25 * np.sin((xx[ph // 2:, :] - 5.0 * t) / 6.0)  # a second motion in the lower half
                 f.write(np.clip(a + r.integers(-2, 3, size=a.shape), 0, 255).astype(np.uint8).tobytes())
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
     env = dict(os.environ)
+    if shim_env:  # settings of the motion search the app has no option for (oracle/ref_shim.c), for plain and GPU runs alike
+        env["LD_PRELOAD"] = SHIM
+        env.update(shim_env)
     if hip:
         env["LD_PRELOAD"] = SHIM
         env["XEVE_HIP_LIB"] = HIP_LIB

@@ -144,6 +144,10 @@ def fuzz_cases(n_iter, seed0=0, n_jobs=36):
             cu = 1 << lw
             P = make_inter_params(r, lw, w, h, bd, nref, idc, st_type, refs, float(r.choice([0.0, 0.0, 3.0, 50.0])),
                                   nref1=(int(r.integers(1, nref + 1)) if st_type == 0 else None))
+            if r.random() < 0.3:  # me_complexity > 1: me_raster after a first search that ended far from its start
+                P.me.reserved = 1
+            if r.random() < 0.25:  # me_level = ME_LEV_IPEL: integer refinement instead of the sub-pel pattern
+                P.spel.hpel_cnt = P.spel.qpel_cnt = 0
             kind = int(r.integers(0, 4))
             if kind == 1:  # extreme QP / lambda
                 q = int(r.choice([0, 4, 51 + 6 * (bd - 8)]))

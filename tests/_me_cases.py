@@ -107,8 +107,9 @@ def make_epzs_job(r, pl, S, bi):
 def epzs_params_of(c):
     from _libs import EpzsParams, SpelParams
 
+    # reserved: bit 0 = raster search on (me_complexity > 1), bits 8.. = refi (the raster step scales with it); refi_bits [2][0] == [2][1]
     me = MeParams(c["lambda_mv"], REFI_BITS_2_0, c["mot_other"], c["bi"], 3, c["msr"], c["sr"], (C.c_int32 * 2)(*c["min_clip"]),
-                  (C.c_int32 * 2)(*c["max_clip"]), 0)
+                  (C.c_int32 * 2)(*c["max_clip"]), int(c.get("raster", 0)) | (int(c.get("refi", 0)) << 8))
     return EpzsParams(me, SpelParams(0, 0, 0, 0, c["hpel_cnt"], c["qpel_cnt"]))
 
 

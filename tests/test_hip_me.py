@@ -165,3 +165,45 @@ def test_epzs_search_vs_oracle(S, bi):
     for i, c in enumerate(cases):
         e = run_oracle_epzs(c, with_mot=True)
         assert int(mot[i]) == (e[3] if e[3] > 0 else 0), (S, bi, i)
+
+
+@pytest.mark.parametrize("S", [8, 16, 32, 64])
+def test_hip_epzs_raster_search_and_integer_refinement_vs_oracle(S):
+    """the branches of pinter_me_epzs outside presets fast / medium: me_raster (me_complexity > 1) after a first search that ended far from its start,
+    with refi 0 / 1, and me_ipel_refinement instead of the sub-pel pattern (me_level = ME_LEV_IPEL), uni- and bi-directional"""
+    import torch
+
+    import xeve_amd
+    from _me_cases import make_epzs_job, run_oracle_epzs
+    from xeve_amd import me
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    r = np.random.default_rng(3100 + S)
+    pl = make_planes(r, True)
+    org, ref = torch.from_numpy(pl["org"]).to(dev), torch.from_numpy(pl["ref"]).to(dev)
+    o0 = PAD * pl["s"] + PAD
+    rastered = 0
+    for (bi, raster, refi, ipel) in [(0, 1, 0, 0), (0, 1, 1, 0), (0, 1, 1, 1), (0, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0)]:
+        base = make_epzs_job(r, pl, S, bi)
+        if ipel:
+            base["hpel_cnt"], base["qpel_cnt"] = 0, 0
+        cases = []
+        for _ in range(60):
+            c = make_epzs_job(r, pl, S, bi)
+            for k in ("lambda_mv", "mot_other", "msr", "sr", "hpel_cnt", "qpel_cnt"):
+                c[k] = base[k]
+            c["mvp"] = (int(r.integers(-160, 161)), int(r.integers(-160, 161)))
+            c["raster"], c["refi"] = raster, refi
+            cases.append(c)
+        org_bi = torch.from_numpy(np.stack([c["org_bi"] for c in cases])).to(dev)
+        cost, mv, mot = me.epzs_search_device(org, o0, pl["s"], ref, o0, pl["s"], [c["x"] for c in cases], [c["y"] for c in cases], [c["mvp"] for c in cases],
+                                              S.bit_length() - 1, 10, base["lambda_mv"], 1, base["msr"], base["sr"], base["min_clip"], base["max_clip"], base["hpel_cnt"],
+                                              base["qpel_cnt"], bi=bi, org_bi=org_bi, mv_start=[c["mv0"] for c in cases], extra_bits=base["mot_other"], with_mot_bits=True,
+                                              raster=bool(raster), refi=refi)
+        for i, c in enumerate(cases):
+            e = run_oracle_epzs(c, with_mot=True)
+            assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1]), int(mot[i])) == (e[0], e[1], e[2], e[3] if e[3] > 0 else 0), (S, bi, raster, refi, ipel, i, c["mvp"])
+            if raster and bi == 0:
+                rastered += run_oracle_epzs(dict(c, raster=0), with_mot=True) != e
+    assert rastered > 0

@@ -159,7 +159,7 @@ def test_bitstream_identical_with_cu_prediction_on_the_gpu(tmp_path, name):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads", "moving_ldb_ref3", "moving_ra_b3_medium", "moving_cif_ra_medium"])
+@pytest.mark.parametrize("name", ["moving_ra_medium", "moving_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads", "moving_ldb_ref3", "moving_ra_b3_medium", "moving_cif_ra_medium", "jumpy_ldb_fast"])
 def test_bitstream_identical_with_the_whole_inter_analysis_on_the_gpu(tmp_path, name):
     """ctx->fn_pinter_analyze_cu -> xeve_hip_pinter_analyze_cu_host: skip / merge analysis, temporal direct, both lists' motion searches over every
     reference picture, check_best_mvp, the iterated bi-prediction search, every pinter_residue_rdo, the mode decision and the reconstruction of
@@ -188,3 +188,24 @@ def test_bitstream_identical_with_inter_analysis_and_every_other_route_on_the_gp
     assert m and int(m.group(1)) > 200 and int(m.group(2)) == 0, err
     assert "loop filter and picture padding" in err and "transform + RDOQ" in err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,me_env", [("jumpy_ldb_fast", {"XEVE_SHIM_ME_COMPLEXITY": "2"}), ("jumpy_ldb_fast", {"XEVE_SHIM_ME_COMPLEXITY": "2", "XEVE_SHIM_ME_LEVEL": "1"}),
+                                         ("moving_ldb_ref3", {"XEVE_SHIM_ME_COMPLEXITY": "2", "XEVE_SHIM_ME_LEVEL": "1"})])
+def test_bitstream_identical_with_raster_search_and_integer_refinement_on_the_gpu(tmp_path, name, me_env):
+    """the branches of pinter_me_epzs no preset below placebo takes -- me_raster (me_algo 2) and me_ipel_refinement (me_sub 1) -- switched on in the
+    unmodified encoder through the shim's overrides: the plain run and the runs with pi->fn_me / ctx->fn_pinter_analyze_cu on the GPU agree byte for byte
+    (and the override does change the stream, so the branches are really taken)"""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    ref = run_app(yuv, str(tmp_path / "ref.evc"), w, h, n, extra, shim_env=me_env)
+    assert ref[:2] != (GOLD[name]["md5"], GOLD[name]["bytes"]), "the override did not change the encode"
+    got_me = run_app(yuv, str(tmp_path / "me.evc"), w, h, n, extra, hip=True, timeout=3000, me=True, shim_env=me_env)
+    assert got_me[:2] == ref[:2], "bitstream differs with the raster / integer-refinement search on the GPU"
+    got_inter = run_app(yuv, str(tmp_path / "inter.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, shim_env=me_env)
+    m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", got_inter[2])
+    assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, got_inter[2]
+    assert got_inter[:2] == ref[:2], "bitstream differs with the inter analysis (raster / integer refinement inside) on the GPU"

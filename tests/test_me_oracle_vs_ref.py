@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from _libs import oracle_me, ptr, ref_me
+from ctypes import c_int, c_void_p
 from _me_cases import PAD, REFI_BITS_2_0, make_case, run_oracle
 
 pytestmark = pytest.mark.skipif(ref_me() is None, reason="oracle/_ref/libref_me.so not built (needs /root/reference)")
@@ -104,3 +105,37 @@ def test_me_epzs_matches_reference(bi, textured):
         assert run_oracle_epzs(c, with_mot=True) == (cost, int(mv[0]), int(mv[1]), R.refdrv_me_epzs_mot_bits()), (it, c["S"])
         moved += (int(mv[0]), int(mv[1])) != tuple(c["mvp"])
     assert moved > 25
+
+
+def test_epzs_with_raster_search_and_integer_refinement_matches_reference():
+    """the branches of pinter_me_epzs the presets fast / medium do not take: me_raster (me_complexity > 1: placebo) after a first search that ended far
+    from its start, with the step scaled by refi + 1, and me_ipel_refinement in place of the sub-pel pattern (me_level = ME_LEV_IPEL)"""
+    from _me_cases import make_epzs_job, make_planes, run_oracle_epzs
+
+    R = ref_me()
+    R.refdrv_me_epzs_x.restype = C.c_uint32
+    R.refdrv_me_epzs_x.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, C.c_uint32] + [c_int] * 7 + \
+                                  [c_void_p, c_void_p, c_int, c_int, c_int]
+    R.refdrv_me_epzs_mot_bits.restype = C.c_int
+    r = np.random.default_rng(2024)
+    rastered = refined = 0
+    for it in range(160):
+        pl = make_planes(r, textured=it % 4 != 0)
+        S, bi = int(r.choice([8, 16, 32, 64])), int(r.choice([0, 0, 0, 1]))
+        c = make_epzs_job(r, pl, S, bi)
+        c["raster"], c["refi"] = int(r.random() < 0.75), int(r.integers(0, 2))
+        if r.random() < 0.4:
+            c["hpel_cnt"], c["qpel_cnt"] = 0, 0
+            refined += 1
+        c["mvp"] = (int(r.integers(-160, 161)), int(r.integers(-160, 161)))  # far from the true motion: the first search walks, beststep grows
+        lg = S.bit_length() - 1
+        mvp, mv = np.array(c["mvp"], np.int16), np.array(c["mv0"], np.int16)
+        mn, mx = np.array(c["min_clip"], np.int32), np.array(c["max_clip"], np.int32)
+        cost = R.refdrv_me_epzs_x(ptr(c["org"], PAD * c["s"] + PAD), c["s"], ptr(c["org_bi"]), ptr(c["ref"], PAD * c["s"] + PAD), c["s"], c["x"], c["y"], lg, lg, 10,
+                                  ptr(mvp), ptr(mv), bi, c["lambda_mv"], 2, c["refi"], c["mot_other"], c["msr"], c["msr"], c["sr"], 0, ptr(mn), ptr(mx), c["hpel_cnt"],
+                                  c["qpel_cnt"], 2 if c["raster"] else 1)
+        got = run_oracle_epzs(c, with_mot=True)
+        assert got == (cost, int(mv[0]), int(mv[1]), R.refdrv_me_epzs_mot_bits()), (it, S, bi, c["raster"], c["refi"], c["hpel_cnt"], got, cost, mv)
+        c0 = dict(c, raster=0)
+        rastered += c["raster"] and bi == 0 and run_oracle_epzs(c0, with_mot=True) != got
+    assert rastered > 10 and refined > 30, (rastered, refined)

@@ -475,13 +475,13 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
         for(int l = 0; l < nlists; l++)
             for(int r = 0; r < P.np; r++) {
                 const int q = l * P.np + r, rr = r < rp.num_refp[l] ? r : 0;
-                pl.ref[q] = refp[rr * 2 + l].y, pl.refi_bits[q] = bi ? p->refi_bits[1][rr] : p->refi_bits[l][rr], pl.range[q] = p->range_recentre[l][rr];
+                pl.ref[q] = refp[rr * 2 + l].y, pl.refi_bits[q] = bi ? p->refi_bits[1][rr] : p->refi_bits[l][rr], pl.range[q] = p->range_recentre[l][rr], pl.refi[q] = rr;
             }
     };
     for(int l = 0; l <= P.isb; l++)
         for(int r = 0; r < P.nref[l]; r++) XH_REQUIRE(refp[r * 2 + l].y);
     planes_for(1 + P.isb, 0);
-    ep.me.bi = 0, ep.me.extra_bits = 0;
+    ep.me.bi = 0, ep.me.extra_bits = 0, ep.me.reserved = p->me.me.reserved & 1; // (bit 0: me_raster on; the plane supplies refi)
     rc = xh_me_epzs_jobs_planes(org[0], s_org_l, nullptr, nullptr, s_l, ej, pl.n * njobs, lw, lw, bd, coef_l, &ep, nullptr, mres, scr, L.scratch_bytes, stream, &pl);
     if(rc != XEVE_HIP_OK) return rc;
     // check_best_mvp, then pinter_residue_rdo of direct + L0 + L1 in one batch

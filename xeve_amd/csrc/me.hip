@@ -39,7 +39,7 @@ __device__ __forceinline__ void me_load_org(const pel *__restrict__ org0, int s_
 // one complete me_ipel_diamond by the calling wave; the result is wave-uniform
 template <int S, bool BI>
 __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo<S>::NP], const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job &jb, int shift,
-                                                         const xeve_hip_me_params &P, int lane)
+                                                         const xeve_hip_me_params &P, int lane, int *range_out = nullptr)
 {
     using G = MGeo<S>;
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
@@ -146,7 +146,60 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
     xeve_hip_me_result res;
     res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
     res.cost = (uint32_t)(best_key >> 32), res.beststep = beststep, res.best_mv_bits = best_bits;
+    if(range_out) range_out[0] = r0, range_out[1] = r1, range_out[2] = r2, range_out[3] = r3; // the caller's `range`, re-centred in place (:463-468)
     return res;
+}
+
+// A list of integer positions evaluated by the calling wave in the list's order: cost = MV_COST + SAD, a position wins only with a strictly
+// smaller cost than `cost_best`, the earliest on ties (me_raster, its 3x3 refinement grids, me_ipel_refinement).  gen(k, mx, my) -> valid.
+template <int S, bool BI, class Gen>
+__device__ __forceinline__ void me_eval(const u32x4 (&org)[MGeo<S>::NP], const pel *__restrict__ ref0, int s_ref, int nc, Gen gen, int gmvp_x, int gmvp_y, int shift,
+                                        const xeve_hip_me_params &P, int lane, unsigned &cost_best, int &best_bits, int &bx, int &by)
+{
+    using G = MGeo<S>;
+    const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
+    unsigned long long best_key = (unsigned long long)cost_best << 32; // order 0: an equal cost never beats it
+    int win = -1, win_bits = 0;
+    for(int c0 = 0; c0 < nc; c0 += G::CPP) {
+        const int k = c0 + slot;
+        int mx = 0, my = 0;
+        const bool valid = k < nc && gen(k, mx, my);
+        int acc = 0;
+        if(valid) {
+            const pel *r = ref0 + (long)(my + row0) * s_ref + mx + col;
+#pragma unroll
+            for(int p = 0; p < G::NP; p++) {
+                u32x4 v = xh_ld8(r + (long)p * G::RPP * s_ref);
+                if(BI) v ^= 0x80008000u;
+                acc = __builtin_amdgcn_sad_u16(org[p].x, v.x, acc);
+                acc = __builtin_amdgcn_sad_u16(org[p].y, v.y, acc);
+                acc = __builtin_amdgcn_sad_u16(org[p].z, v.z, acc);
+                acc = __builtin_amdgcn_sad_u16(org[p].w, v.w, acc);
+            }
+        }
+        acc = xh_group_sum<G::GROUP>(acc);
+        int bits = xh_mvd_bits((mx << 2) - gmvp_x) + xh_mvd_bits((my << 2) - gmvp_y) + P.refi_bits;
+        if(BI) bits += P.extra_bits;
+        const int sad = acc >> shift;
+        const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(BI ? sad >> 1 : sad);
+        unsigned long long key = valid ? ((unsigned long long)cost << 32) | (unsigned)(k + 1) : ~0ull;
+        int kb = bits;
+#pragma unroll
+        for(int m = G::GROUP; m < 64; m <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)key, m, 64), hi = __shfl_xor((unsigned)(key >> 32), m, 64);
+            const int ob = __shfl_xor(kb, m, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            if(o < key) key = o, kb = ob;
+        }
+        if(key < best_key) best_key = key, win = (int)(unsigned)key - 1, win_bits = kb;
+    }
+    win = uni(win);
+    if(win >= 0) {
+        cost_best = (unsigned)uni((int)(best_key >> 32)), best_bits = uni(win_bits);
+        int mx = 0, my = 0;
+        (void)gen(win, mx, my);
+        bx = uni(mx), by = uni(my);
+    }
 }
 
 template <int S, bool BI>
@@ -214,17 +267,18 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
 // The whole integer stage of pinter_me_epzs by ONE WAVE PER JOB: first search, then refinement searches from the running best while the
 // reference's rule asks for one (xeve_pinter.c:757-822) without leaving the kernel: no
 // launch, no host round trip between the searches, the original block stays in registers across them.
-template <int S, bool BI>
+// EXTRA: compiled with the branches presets fast / medium never take (me_raster, me_ipel_refinement); the plain form keeps its registers
+template <int S, bool BI, bool EXTRA>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
                                                  const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
-                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl)
+                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl, int ipel_only)
 {
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     if(pl.n) { // several reference pictures in one launch: the job's plane supplies picture, index bits and range
         const int q = uni(xh_plane_of_job(pl.job_plane, pl.per_plane, j));
-        ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q];
+        ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q], P.reserved = (P.reserved & 0xFF) | (pl.refi[q] << 8);
     }
     const xeve_hip_epzs_job e = jobs[j];
     if(e.x < 0) { // job switched off
@@ -247,7 +301,8 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     xeve_hip_me_params Q = P;
     for(int it = 0; it < 64; it++) { // (the reference's loop ends when a search no longer improves; 64 is a safety bound)
         Q.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
-        const xeve_hip_me_result r = me_diamond<S, BI>(org, ref0, s_ref, m, shift, Q, lane);
+        int rng[4];
+        const xeve_hip_me_result r = me_diamond<S, BI>(org, ref0, s_ref, m, shift, Q, lane, rng);
         s.tmpstep = r.beststep, s.searches++;
         if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect on pi->mot_bits (:546-548)
         int beststep = 0;
@@ -256,10 +311,48 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
             const int dx = e.mvp[0] - s.mv[0], dy = e.mvp[1] - s.mv[1];
             beststep = ((dx < 0 ? -dx : dx) < 2 && (dy < 0 ? -dy : dy) < 2) ? 0 : s.tmpstep;
         }
+        if(EXTRA && !BI && it == 0 && (P.reserved & 1) && beststep > 5) {
+            // me_raster (:158-268; me_complexity > 1, beststep > RASTER_SEARCH_THD): a grid of step max(5, S / 2) * (refi + 1) over the range as the first
+            // search left it, then 3x3 grids of halving step around the best
+            const int mult = ((P.reserved >> 8) & 0xFF) + 1, st0 = (S / 2 > 5 ? S / 2 : 5), stp = st0 * mult;
+            const int nx = (rng[2] - rng[0]) / stp + 1, ny = (rng[3] - rng[1]) / stp + 1;
+            unsigned rc = 0xFFFFFFFFu;
+            int rbits = 0, rx = (r.mv[0] >> 2) + e.x, ry = (r.mv[1] >> 2) + e.y; // (`mv` as the diamond search left it)
+            me_eval<S, BI>(org, ref0, s_ref, nx * ny, [&](int k, int &mx, int &my) { mx = rng[0] + (k % nx) * stp, my = rng[1] + (k / nx) * stp; return true; },
+                           m.gmvp[0], m.gmvp[1], shift, Q, lane, rc, rbits, rx, ry);
+            for(int ss = (mult * st0) >> 1; ss > 0; ss >>= 1) {
+                const int cx = rx, cy = ry;
+                me_eval<S, BI>(org, ref0, s_ref, 9,
+                               [&](int k, int &mx, int &my) {
+                                   mx = cx + (k % 3 - 1) * ss, my = cy + (k / 3 - 1) * ss;
+                                   return mx >= rng[0] && mx <= rng[2] && my >= rng[1] && my <= rng[3];
+                               },
+                               m.gmvp[0], m.gmvp[1], shift, Q, lane, rc, rbits, rx, ry);
+            }
+            if(rbits > 0) s.mot_bits = rbits;
+            if(rc < s.cost) beststep = 5, s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2); // (:760-767)
+        }
         if(P.bi == 1 || beststep <= 0) break;
         epzs_range(P, e.x + (s.mv[0] >> 2), e.y + (s.mv[1] >> 2), m.range); // the refinement centre is NOT clipped (:785-788)
         m.mvi[0] = (int16_t)(s.mv[0] + (e.x << 2)), m.mvi[1] = (int16_t)(s.mv[1] + (e.y << 2));
         m.beststep_in = s.tmpstep;
+    }
+    if(EXTRA && ipel_only) { // me_level <= ME_LEV_IPEL: me_ipel_refinement instead of the sub-pel pattern (:835-866, 270-361)
+        int16_t rg[4];
+        epzs_range(P, e.x + (s.mv[0] >> 2), e.y + (s.mv[1] >> 2), rg);
+        const int ix = clip3(P.min_clip[0], P.max_clip[0], (s.mv[0] + (e.x << 2)) >> 2), iy = clip3(P.min_clip[1], P.max_clip[1], (s.mv[1] + (e.y << 2)) >> 2);
+        unsigned rc = 0xFFFFFFFFu;
+        int rbits = 0, rx = ix, ry = iy;
+        me_eval<S, BI>(org, ref0, s_ref, 9,
+                       [&](int k, int &mx, int &my) {
+                           // test_pos (:311): the centre, then x = -1, 0, 1 with y = -1, 0, 1 (the centre left out)
+                           const int q = k == 0 ? 4 : (k <= 4 ? k - 1 : k);
+                           mx = ix + (q / 3 - 1), my = iy + (q % 3 - 1);
+                           return mx >= rg[0] && mx <= rg[2] && my >= rg[1] && my <= rg[3];
+                       },
+                       m.gmvp[0], m.gmvp[1], shift, P, lane, rc, rbits, rx, ry);
+        if(P.bi != 1 && rbits > 0) s.mot_bits = rbits;
+        if(rc < s.cost) s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2);
     }
     if(lane == 0) st[j] = s;
 }
@@ -282,8 +375,11 @@ __global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, c
     if(j >= n) return;
     xeve_hip_me_result r;
     r.cost = st[j].cost, r.mv[0] = st[j].mv[0], r.mv[1] = st[j].mv[1], r.beststep = 0;
-    r.best_mv_bits = (!bi && spel[j].best_mv_bits > 0) ? spel[j].best_mv_bits : st[j].mot_bits; // me_spel_pattern's side effect (:690-692)
-    if(spel[j].cost < r.cost) r.cost = spel[j].cost, r.mv[0] = spel[j].mv[0], r.mv[1] = spel[j].mv[1]; // xeve_pinter.c:828-833
+    r.best_mv_bits = st[j].mot_bits;
+    if(spel) { // (NULL: the integer refinement of the ME_LEV_IPEL branch already ran inside the search kernel)
+        if(!bi && spel[j].best_mv_bits > 0) r.best_mv_bits = spel[j].best_mv_bits; // me_spel_pattern's side effect (:690-692)
+        if(spel[j].cost < r.cost) r.cost = spel[j].cost, r.mv[0] = spel[j].mv[0], r.mv[1] = spel[j].mv[1]; // xeve_pinter.c:828-833
+    }
     out[j] = r;
 }
 
@@ -325,7 +421,7 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     if(planes && planes->n > 0) {
         XH_REQUIRE(planes->n <= XH_MAX_PLANES && planes->per_plane > 0 && (planes->job_plane || (long)planes->n * planes->per_plane >= njobs));
         pl = *planes;
-        for(int i = pl.n; i < XH_MAX_PLANES; i++) pl.ref[i] = pl.ref[0], pl.refi_bits[i] = pl.refi_bits[0], pl.range[i] = pl.range[0];
+        for(int i = pl.n; i < XH_MAX_PLANES; i++) pl.ref[i] = pl.ref[0], pl.refi_bits[i] = pl.refi_bits[0], pl.range[i] = pl.range[0], pl.refi[i] = pl.refi[0];
     }
     XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
     XH_REQUIRE(params->me.bi == 0 || params->me.bi == 1);
@@ -340,13 +436,19 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     void               *sws  = w;
     const dim3 g((njobs + 255) / 256);
     xeve_hip_me_params P = params->me;
+    const int ipel_only = params->hpel_cnt == 0; // me_level <= ME_LEV_IPEL: no sub-pel stage, an integer refinement inside the search kernel
+    const bool extra_branches = ipel_only || (P.reserved & 1);
     {
         const dim3 grid((njobs + 3) / 4);
         const int  shift = bit_depth - 8;
 #define EPZS_LAUNCH(S)                                                                                                     \
     do {                                                                                                                   \
-        if(P.bi) k_me_epzs<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl);   \
-        else k_me_epzs<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl);      \
+        if(extra_branches) {                                                                                               \
+            if(P.bi) k_me_epzs<S, true, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, ipel_only);   \
+            else k_me_epzs<S, false, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, ipel_only);      \
+        }                                                                                                                  \
+        else if(P.bi) k_me_epzs<S, true, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, 0);   \
+        else k_me_epzs<S, false, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, 0);      \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);
         else if(log2w == 4) EPZS_LAUNCH(16);
@@ -354,6 +456,11 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         else EPZS_LAUNCH(64);
 #undef EPZS_LAUNCH
         XH_HIP(hipGetLastError());
+    }
+    if(ipel_only) {
+        k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, nullptr, results);
+        XH_HIP(hipGetLastError());
+        return XEVE_HIP_OK;
     }
     k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj);
     XH_HIP(hipGetLastError());

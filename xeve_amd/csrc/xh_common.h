@@ -59,7 +59,7 @@ int xh_cu_bits_jobs_round(const int16_t *coef, size_t coef_elems, const xeve_hip
 #define XH_MAX_PLANES 16
 struct XhSearchPlanes {
     const pel *ref[XH_MAX_PLANES];
-    int        refi_bits[XH_MAX_PLANES], range[XH_MAX_PLANES];
+    int        refi_bits[XH_MAX_PLANES], range[XH_MAX_PLANES], refi[XH_MAX_PLANES]; // refi: me_raster's step scales with it
     int        n, per_plane;
     const unsigned char *job_plane; // device array or NULL: the plane of job j when the jobs are not laid out plane by plane
 };

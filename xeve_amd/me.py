@@ -79,9 +79,11 @@ def epzs_search(org_plane, org_origin, s_org, ref_plane, ref_origin, s_ref, x, y
 
 def epzs_search_device(org_plane, org_origin, s_org, ref_plane, ref_origin, s_ref, x, y, mvp, log2, bit_depth, lambda_mv, refi_bits,
                        max_search_range, range_recentre, min_clip, max_clip, hpel_cnt, qpel_cnt, bi=0, org_bi=None, mv_start=None, extra_bits=0,
-                       with_mot_bits=False):
+                       with_mot_bits=False, raster=False, refi=0):
     """Same search through the C entry point xeve_hip_me_epzs_jobs: the bookkeeping between the searches runs in device
-    kernels, the job / state / result arrays never leave the GPU until the final result."""
+    kernels, the job / state / result arrays never leave the GPU until the final result.  raster: me_complexity > 1 (me_raster after a
+    first search that ended far from its start; its step scales with refi + 1); hpel_cnt == 0: me_level = ME_LEV_IPEL (integer refinement
+    instead of the sub-pel pattern)."""
     import torch
 
     L = _lib.load()
@@ -98,7 +100,7 @@ def epzs_search_device(org_plane, org_origin, s_org, ref_plane, ref_origin, s_re
     ws_bytes = int(L.xeve_hip_me_epzs_workspace(n))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
     P = _lib.EpzsParams(_lib.MeParams(lambda_mv, refi_bits, extra_bits, bi, 3, max_search_range, range_recentre, (C.c_int32 * 2)(*min_clip),
-                                      (C.c_int32 * 2)(*max_clip), 0), hpel_cnt, qpel_cnt)
+                                      (C.c_int32 * 2)(*max_clip), (1 if raster else 0) | (int(refi) << 8)), hpel_cnt, qpel_cnt)
     coef = D.baseline_coef_l()
     _lib.check(L.xeve_hip_me_epzs_jobs(C.c_void_p(org_plane.data_ptr() + 2 * org_origin), s_org, C.c_void_p(org_bi.data_ptr()) if org_bi is not None else None,
                                        C.c_void_p(ref_plane.data_ptr() + 2 * ref_origin), s_ref, C.c_void_p(d_jobs.data_ptr()), n, log2, log2, bit_depth,
