@@ -23,3 +23,21 @@ def test_oracle_spel_matches_reference_goldens():
         assert (res.cost, res.mv[0], res.mv[1]) == (cost, mvx, mvy), (n, c["S"], c["bi"])
         n += 1
     assert n == 64
+
+
+def test_oracle_epzs_matches_reference_goldens():
+    """pinter_me_epzs, every branch (plain, me_raster, me_ipel_refinement, bi), against tests/golden/me_epzs_v1.npz"""
+    import numpy as np
+
+    from _epzs_golden import GOLD, cases
+    from _me_cases import run_oracle_epzs
+
+    g = np.load(GOLD)["res"]
+    cs = cases()
+    assert len(cs) == len(g)
+    kinds = set()
+    for c, e in zip(cs, g):
+        assert (c["S"], c["bi"], c["raster"], c["refi"], c["hpel_cnt"]) == tuple(int(v) for v in e[4:9])
+        assert run_oracle_epzs(c, with_mot=True) == tuple(int(v) for v in e[:4]), (c["S"], c["bi"], c["raster"], c["hpel_cnt"])
+        kinds.add((c["bi"], c["raster"], c["hpel_cnt"] == 0))
+    assert len(kinds) >= 6
