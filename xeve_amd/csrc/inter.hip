@@ -324,12 +324,11 @@ __global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, Inte
 }
 
 // per (CU, component): the winner's coefficients out (zero for a skipped CU) and into the scratch block that is dequantised; the skip
-// prediction where the CU is skipped; is_coef; the coder state
+// prediction where the CU is skipped; is_coef
 __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hip_inter_result *__restrict__ res, const int16_t *__restrict__ coef_a,
                             const int16_t *__restrict__ coef_b, int16_t *__restrict__ coef_out, int16_t *__restrict__ tmp, pel *__restrict__ pred_y,
                             pel *__restrict__ pred_u, pel *__restrict__ pred_v, const pel *__restrict__ sk_y, const pel *__restrict__ sk_u, const pel *__restrict__ sk_v,
-                            unsigned char *__restrict__ is_coef, const xeve_hip_sbac *__restrict__ st_skip, const xeve_hip_sbac *__restrict__ st_a,
-                            const xeve_hip_sbac *__restrict__ st_b, xeve_hip_sbac *__restrict__ next_best)
+                            unsigned char *__restrict__ is_coef)
 {
     const int j = blockIdx.x / 3, k = blockIdx.x % 3, best = win[j];
     if(k && P.ncomp == 1) return;
@@ -353,8 +352,33 @@ __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hi
     }
     if(threadIdx.x == 0) {
         is_coef[(size_t)k * n + j] = res[j].nnz[k] != 0;
-        if(k == 0 && res[j].cu_mode >= 0) copy_sbac(next_best + j, skip ? st_skip + j : best == M_BI ? st_b + j : st_a + slot);
     }
+}
+
+// core->s_next_best: the winner's syntax once more through the exact coder from the CU's entry state -- skip flag + candidate indices for a skipped CU, the
+// inter-CU syntax with the final coded-block flags and coefficients otherwise.  (Every candidate evaluation above only counts bits; carrying the exact coder
+// through all of them, as SBAC_STORE does in the reference, would be four exact rounds per candidate for a state only the winner's is kept of.)
+__global__ void k_inter_bits_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, const xeve_hip_inter_result *__restrict__ res,
+                                  xeve_hip_cu_bits_job *__restrict__ bj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.n) return;
+    const xeve_hip_inter_job    J = jobs[j];
+    const xeve_hip_inter_result R = res[j];
+    const InterSt &S = st[j];
+    const int m = R.best_idx;
+    xeve_hip_cu_bits_job b;
+    b.coef_off[0] = j * P.n0, b.coef_off[1] = P.n * P.n0 + j * P.n1, b.coef_off[2] = P.n * (P.n0 + P.n1) + j * P.n1;
+    b.nnz[0] = R.nnz[0], b.nnz[1] = R.nnz[1], b.nnz[2] = R.nnz[2], b.sbac = J.sbac;
+    for(int l = 0; l < 2; l++) b.mvd[l][0] = S.mvd[m][l][0], b.mvd[l][1] = S.mvd[m][l][1], b.refi[l] = S.refi[m][l], b.mvp_idx[l] = S.mvpi[m][l];
+    b.mode = m == M_SKIP ? XEVE_HIP_BITS_CU_SKIP : XEVE_HIP_BITS_CU_INTER, b.dir_flag = m == M_DIR, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = J.ctx_pred_mode;
+    bj[j] = b;
+}
+
+__global__ void k_inter_states(InterK P, const xeve_hip_inter_result *__restrict__ res, const xeve_hip_sbac *__restrict__ stw, xeve_hip_sbac *__restrict__ next_best)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < P.n && res[j].cu_mode >= 0) copy_sbac(next_best + j, stw + j);
 }
 
 __global__ void k_iota_off(int n, int step, int32_t *__restrict__ off)
@@ -368,7 +392,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_skip, ej, mres, bjm, bitsm, rja, rra, coef_a, st_a, rjb, rrb, coef_b, st_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
+    size_t st, sj, sres, sk[3], st_w, bjw, bits_w, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
         scratch, scratch_bytes, total;
 };
 
@@ -381,11 +405,12 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
     L.st = take(N * sizeof(InterSt)), L.sj = take(N * sizeof(xeve_hip_skip_job)), L.sres = take(N * sizeof(xeve_hip_skip_result));
-    L.sk[0] = take(N * n0 * 2), L.sk[1] = take(N * n1 * 2 + 8), L.sk[2] = take(N * n1 * 2 + 8), L.st_skip = take(N * sizeof(xeve_hip_sbac));
+    L.sk[0] = take(N * n0 * 2), L.sk[1] = take(N * n1 * 2 + 8), L.sk[2] = take(N * n1 * 2 + 8);
+    L.st_w = take(N * sizeof(xeve_hip_sbac)), L.bjw = take(N * sizeof(xeve_hip_cu_bits_job)), L.bits_w = take(N * 4);
     L.ej = take(2 * MAXR * N * sizeof(xeve_hip_epzs_job)), L.mres = take(2 * MAXR * N * sizeof(xeve_hip_me_result));
     L.bjm = take(10 * N * sizeof(xeve_hip_cu_bits_job)), L.bitsm = take(10 * N * 4);
-    L.rja = take(na * sizeof(xeve_hip_rdo_job)), L.rra = take(na * sizeof(xeve_hip_rdo_result)), L.coef_a = take(na * ne * 2), L.st_a = take(na * sizeof(xeve_hip_sbac));
-    L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2), L.st_b = take(N * sizeof(xeve_hip_sbac));
+    L.rja = take(na * sizeof(xeve_hip_rdo_job)), L.rra = take(na * sizeof(xeve_hip_rdo_result)), L.coef_a = take(na * ne * 2);
+    L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2);
     L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
     L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
     L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.job_plane = take(MAXR * N), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
@@ -393,7 +418,7 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
     size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
     s = max2(s, xeve_hip_me_epzs_workspace(2 * (rp.num_refp[0] > rp.num_refp[1] ? rp.num_refp[0] : rp.num_refp[1]) * n));
-    s = max2(s, xeve_hip_cu_bits_workspace(10 * n, 64));
+    s = max2(s, xeve_hip_cu_bits_workspace(10 * n, N * ne));
     s = max2(s, xeve_hip_residue_rdo_workspace((int)na, nstates, &rp, s_org_l, s_org_c));
     s = max2(s, xeve_hip_mc_cu_workspace(n, 1 << rp.log2_cuw, 1 << rp.log2_cuh, rp.num_refp[0], rp.num_refp[1]));
     L.scratch = take(s), L.scratch_bytes = s;
@@ -441,7 +466,9 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *sj = (xeve_hip_skip_job *)(W + L.sj);
     auto *sres = (xeve_hip_skip_result *)(W + L.sres);
     pel  *sk[3] = {(pel *)(W + L.sk[0]), (pel *)(W + L.sk[1]), (pel *)(W + L.sk[2])}, *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
-    auto *st_skip = (xeve_hip_sbac *)(W + L.st_skip), *st_a = (xeve_hip_sbac *)(W + L.st_a), *st_b = (xeve_hip_sbac *)(W + L.st_b);
+    auto *st_w = (xeve_hip_sbac *)(W + L.st_w);
+    auto *bjw = (xeve_hip_cu_bits_job *)(W + L.bjw);
+    auto *bits_w = (unsigned *)(W + L.bits_w);
     auto *ej = (xeve_hip_epzs_job *)(W + L.ej);
     auto *mres = (xeve_hip_me_result *)(W + L.mres);
     auto *bjm = (xeve_hip_cu_bits_job *)(W + L.bjm);
@@ -462,7 +489,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     // skip mode
     k_inter_skip_jobs<<<G, 256, 0, s>>>(jobs, P, sj);
     rc = xeve_hip_analyze_skip_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, sj, njobs, p->max_cand, coef_l, coef_c, sres, sk[0], sk[1], sk[2],
-                                    st_skip, scr, L.scratch_bytes, stream);
+                                    nullptr, scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_stage1<<<G, 256, 0, s>>>(jobs, P, sres, st, rja, ej);
     // motion search per list and reference picture (:1906-1950)
@@ -493,7 +520,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     rc = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_uni_b<<<G, 256, 0, s>>>(jobs, P, bitsm, st, rja);
-    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream);
+    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, nullptr, scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
     if(P.isb) { // analyze_bi
         k_bi_init<<<G, 256, 0, s>>>(P, rra, st);
@@ -515,7 +542,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
             k_bi_update<<<G, 256, 0, s>>>(P, mres, st);
         }
         k_bi_finish<<<G, 256, 0, s>>>(jobs, P, st, rjb);
-        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, st_b, scr, L.scratch_bytes,
+        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, nullptr, scr, L.scratch_bytes,
                                        stream);
         if(rc != XEVE_HIP_OK) return rc;
     }
@@ -524,7 +551,12 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     rc = xeve_hip_mc_cu_jobs(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, mc, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1], pred[2],
                              scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
-    k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, tmp, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], is_coef, st_skip, st_a, st_b, next_best);
+    k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, tmp, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], is_coef);
+    // core->s_next_best of the winners
+    k_inter_bits_jobs<<<G, 256, 0, s>>>(jobs, P, st, results, bjw);
+    rc = xeve_hip_cu_bits_jobs(coef, (size_t)njobs * (P.n0 + 2 * (size_t)P.n1), states, bjw, njobs, &bp, scr, L.scratch_bytes, bits_w, st_w, stream);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_inter_states<<<G, 256, 0, s>>>(P, results, st_w, next_best);
     k_iota_off<<<G, 256, 0, s>>>(njobs, P.n0, off0);
     k_iota_off<<<G, 256, 0, s>>>(njobs, P.n1, off1);
     static const int k_dq_scale[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237)
