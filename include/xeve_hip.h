@@ -580,7 +580,8 @@ typedef struct xeve_hip_inter_result {
  * all CUs, then U, then V; zero for skipped CUs); rec_y [njobs][w*w], rec_u / rec_v [njobs][cw*ch]: pi->rec[best_idx]; pred_y [njobs][w*w] (may be
  * NULL): mi->pred_y_best; next_best[j]:
  * core->s_next_best[log2_cuw - 2][log2_cuh - 2].  B slices: rdo.num_refp[1] <= rdo.num_refp[0] (analyze_bi walks both lists with num_refp[1]).
- * Asynchronous on `stream` like the rest of the batched API (levels of a picture can be analysed concurrently on separate streams). */
+ * Asynchronous on `stream` like the rest of the batched API; levels of a picture can be analysed concurrently on separate streams, each call with its
+ * own workspace and output buffers (the workspace holds every intermediate of the call).  Capturable into a HIP graph. */
 size_t xeve_hip_pinter_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_inter_params *params, int s_org_l, int s_org_c);
 int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c,
                                     const xeve_hip_sbac *states, int nstates, const xeve_hip_inter_params *params, const xeve_hip_inter_job *jobs,
