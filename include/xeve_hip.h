@@ -54,6 +54,18 @@ uint64_t    xeve_hip_table_calls(void);
  * other languages to check their record layouts at load time (no GPU needed). */
 int         xeve_hip_sizeof(int i);
 
+/* Kernel-class timers for measurement (bench.py's roofline block): for the classes whose bit is set in class_mask (0 = all off) the batched
+ * entry points bracket their launches
+ * with HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON and count algorithmic units on the device.  Not for use under stream capture.
+ * Classes: 0 integer motion search (k_me_epzs / k_me_diamond; unit = 64 sample pairs of evaluated block SADs, i.e. a w x h evaluation counts
+ * w*h/64 units = 256 algorithmic bytes each by SURVEY.md 8d's 4*w*h + 4 per table call), 1 sub-pel stage of the search (fused interpolation
+ * + SAD), 2 CABAC bit counting (k_cu_bits; unit = one coded bin), 3 CU prediction (xeve_hip_mc_cu_jobs), 4 residual chain (DIFF .. SSD),
+ * 5 RDOQ; classes 1, 3, 4, 5 are timed only (units stay 0).  xeve_hip_prof_read waits for the recorded events, adds up their durations per class and resets the tallies;
+ * arrays of n <= 8 entries (NULL to skip one). */
+#define XEVE_HIP_PROF_CLASSES 8
+int         xeve_hip_prof_enable(int class_mask);
+int         xeve_hip_prof_read(double *ms, uint64_t *launches, uint64_t *units, int n);
+
 /* ------------------------------------------------------------------------------------------- */
 /* (1) drop-in dispatch tables                                                                 */
 /* ------------------------------------------------------------------------------------------- */

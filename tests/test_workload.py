@@ -135,8 +135,10 @@ def test_structured_content_rdo_phase_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_structured_content_inter_phase_vs_oracle():
-    """phase H (xeve_hip_pinter_analyze_cu_jobs on the structured picture: the whole inter analysis of every CU of every level) against the oracle"""
+@pytest.mark.parametrize("content", ["structured", "iid"])
+def test_inter_phase_vs_oracle(content):
+    """phase H = the step bench.py times (xeve_hip_pinter_analyze_cu_jobs: the whole inter analysis of every CU of every level), on the structured and on the
+    i.i.d. picture, against the oracle"""
     import torch
 
     import xeve_amd
@@ -146,7 +148,7 @@ def test_structured_content_inter_phase_vs_oracle():
 
     xeve_amd.init(0)
     dev = torch.device("cuda:0")
-    wl = HotPathPass(256, 128, dev, seed=3, content="structured")
+    wl = HotPathPass(256, 128, dev, seed=3, content=content)
     out = wl.inter()
     torch.cuda.synchronize()
     O = oracle_inter()
@@ -174,4 +176,4 @@ def test_structured_content_inter_phase_vs_oracle():
                                    ptr(ep[0]), ptr(ep[1]), ptr(ep[2]), ptr(eb))
             assert res[j:j + 1].tobytes() == er.tobytes(), (S, j, res[j], er[0])
             modes.add(int(er["best_idx"][0]))
-    assert len(modes) >= 2, modes
+    assert len(modes) >= (2 if content == "structured" else 1), modes

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <vector>
 
 #include "xh_common.h"
 
@@ -27,7 +28,8 @@ int xh_tx1d(bool fwd, const void *src, void *dst, int log2n, int shift, int line
 // ------------------------------------------------------------------------------------------------
 static std::atomic<int>      g_device{-1};
 static std::atomic<uint64_t> g_table_calls{0};
-static std::mutex            g_init_mu;
+static std::atomic<uint32_t> g_generation{0}; // bumped by every init / shutdown: per-thread staging re-creates itself when it changes
+static std::mutex            g_init_mu, g_err_mu;
 static thread_local char     t_err[512];
 static char                  g_err[512];
 
@@ -37,12 +39,20 @@ void xh_set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(t_err, sizeof(t_err), fmt, ap);
     va_end(ap);
-    std::lock_guard<std::mutex> lk(g_init_mu);
+    std::lock_guard<std::mutex> lk(g_err_mu);
     memcpy(g_err, t_err, sizeof(g_err));
 }
 bool xh_ready() { return g_device.load() >= 0; }
 
-extern "C" const char *xeve_hip_last_error(void) { return t_err[0] ? t_err : g_err; }
+// the calling thread's last message; a thread that has none gets a copy of the process-wide last one (taken under the lock)
+extern "C" const char *xeve_hip_last_error(void)
+{
+    if(!t_err[0]) {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        memcpy(t_err, g_err, sizeof(t_err));
+    }
+    return t_err;
+}
 extern "C" uint64_t    xeve_hip_table_calls(void) { return g_table_calls.load(); }
 extern "C" int xeve_hip_sizeof(int i)
 {
@@ -55,12 +65,14 @@ extern "C" int xeve_hip_sizeof(int i)
     return i >= 0 && i < (int)(sizeof(sz) / sizeof(sz[0])) ? sz[i] : -1;
 }
 
+int  xh_rdoq_tables_init(); // rdoq.hip: zig-zag scans + entropy table, built once per device binding
+void xh_rdoq_tables_free();
+static void prof_reset_locked();
+
 extern "C" int xeve_hip_init(int device_ordinal)
 {
-    {
-        std::lock_guard<std::mutex> lk(g_init_mu);
-        if(g_device.load() == device_ordinal && device_ordinal >= 0) return XEVE_HIP_OK;
-    }
+    std::lock_guard<std::mutex> lk(g_init_mu); // the whole initialisation is one critical section (concurrent first calls)
+    if(g_device.load() == device_ordinal && device_ordinal >= 0) return XEVE_HIP_OK;
     int n = 0;
     XH_HIP(hipGetDeviceCount(&n));
     if(device_ordinal < 0 || device_ordinal >= n) {
@@ -73,17 +85,119 @@ extern "C" int xeve_hip_init(int device_ordinal)
         xh_set_error("xeve_hip_init: device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
         return XEVE_HIP_ERR_DEVICE;
     }
+    if(g_device.load() >= 0) { // re-binding to another device: everything built for the old one goes first
+        (void)hipSetDevice(g_device.load());
+        (void)hipDeviceSynchronize();
+        xh_rdoq_tables_free();
+        g_device.store(-1);
+    }
     XH_HIP(hipSetDevice(device_ordinal));
     int rc = xh_tq_init();
     if(rc != XEVE_HIP_OK) return rc;
-    g_device.store(device_ordinal);
+    g_device.store(device_ordinal); // (the table builders below go through entry-point checks that want a bound device)
+    rc = xh_rdoq_tables_init();
+    if(rc != XEVE_HIP_OK) {
+        g_device.store(-1);
+        return rc;
+    }
+    g_generation++;
     return XEVE_HIP_OK;
 }
 
 extern "C" void xeve_hip_shutdown(void)
 {
-    if(g_device.load() >= 0) (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if(g_device.load() >= 0) {
+        (void)hipSetDevice(g_device.load());
+        (void)hipDeviceSynchronize();
+        prof_reset_locked();
+        xh_rdoq_tables_free();
+    }
     g_device.store(-1);
+    g_generation++;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-class timers (include/xeve_hip.h: xeve_hip_prof_enable / _read)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ProfTok {
+    int        cls;
+    hipEvent_t e0, e1;
+};
+std::mutex               g_prof_mu;
+std::atomic<unsigned>    g_prof_mask{0}; // bit per class
+std::vector<ProfTok *>   g_prof_done;
+unsigned long long      *g_prof_units = nullptr; // device, XEVE_HIP_PROF_CLASSES counters
+} // namespace
+bool xh_prof_on(int cls) { return (g_prof_mask.load(std::memory_order_relaxed) >> cls) & 1u; }
+unsigned long long *xh_prof_units(int cls) { return xh_prof_on(cls) && g_prof_units ? g_prof_units + cls : nullptr; }
+void *xh_prof_begin(int cls, hipStream_t st)
+{
+    ProfTok *t = new ProfTok{cls, nullptr, nullptr};
+    if(hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess || hipEventRecord(t->e0, st) != hipSuccess) {
+        if(t->e0) (void)hipEventDestroy(t->e0);
+        if(t->e1) (void)hipEventDestroy(t->e1);
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void xh_prof_end(void *tok, hipStream_t st)
+{
+    ProfTok *t = static_cast<ProfTok *>(tok);
+    (void)hipEventRecord(t->e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_done.push_back(t);
+}
+static void prof_reset_locked()
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for(ProfTok *t : g_prof_done) {
+        (void)hipEventDestroy(t->e0), (void)hipEventDestroy(t->e1);
+        delete t;
+    }
+    g_prof_done.clear();
+    g_prof_mask.store(0);
+    if(g_prof_units) (void)hipFree(g_prof_units), g_prof_units = nullptr;
+}
+extern "C" int xeve_hip_prof_enable(int class_mask)
+{
+    XH_ENTER();
+    if(class_mask && !g_prof_units) {
+        XH_HIP(hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES));
+        XH_HIP(hipMemset(g_prof_units, 0, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES));
+    }
+    g_prof_mask.store((unsigned)class_mask & ((1u << XEVE_HIP_PROF_CLASSES) - 1));
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_prof_read(double *ms, uint64_t *launches, uint64_t *units, int n)
+{
+    XH_ENTER();
+    XH_REQUIRE(n >= 0 && n <= XEVE_HIP_PROF_CLASSES);
+    XH_HIP(hipDeviceSynchronize());
+    double   t[XEVE_HIP_PROF_CLASSES] = {};
+    uint64_t c[XEVE_HIP_PROF_CLASSES] = {}, u[XEVE_HIP_PROF_CLASSES] = {};
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for(ProfTok *k : g_prof_done) {
+            float f = 0.f;
+            if(hipEventElapsedTime(&f, k->e0, k->e1) == hipSuccess && k->cls >= 0 && k->cls < XEVE_HIP_PROF_CLASSES) t[k->cls] += f, c[k->cls]++;
+            (void)hipEventDestroy(k->e0), (void)hipEventDestroy(k->e1);
+            delete k;
+        }
+        g_prof_done.clear();
+    }
+    if(g_prof_units) {
+        XH_HIP(hipMemcpy(u, g_prof_units, sizeof(u), hipMemcpyDeviceToHost));
+        XH_HIP(hipMemset(g_prof_units, 0, sizeof(u)));
+    }
+    for(int i = 0; i < n; i++) {
+        if(ms) ms[i] = t[i];
+        if(launches) launches[i] = c[i];
+        if(units) units[i] = u[i];
+    }
+    return XEVE_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -116,7 +230,8 @@ struct Stage {
     hipStream_t st   = nullptr;
     char       *host = nullptr; // pinned, device-mapped
     char       *dev  = nullptr;
-    Stage()
+    uint32_t    gen  = 0;       // g_generation this staging was created under
+    void create()
     {
         if(!xh_ready()) {
             xh_set_error("dispatch table used before xeve_hip_init()");
@@ -127,7 +242,16 @@ struct Stage {
         TBL_HIP(hipHostMalloc((void **)&host, REG_TOTAL, hipHostMallocMapped));
         TBL_HIP(hipHostGetDevicePointer((void **)&dev, host, 0));
         memset(host, 0, REG_TOTAL);
+        gen = g_generation.load();
     }
+    void destroy()
+    { // (errors ignored: after a shutdown the old context may be gone already)
+        if(st) (void)hipStreamDestroy(st);
+        if(host) (void)hipHostFree(host);
+        st = nullptr, host = dev = nullptr;
+    }
+    Stage() { create(); }
+    ~Stage() { destroy(); }
     template <typename T> T *h(size_t off) { return reinterpret_cast<T *>(host + off); }
     template <typename T> T *d(size_t off) { return reinterpret_cast<T *>(dev + off); }
     void sync() { TBL_HIP(hipStreamSynchronize(st)); }
@@ -135,6 +259,7 @@ struct Stage {
 Stage &stage()
 {
     static thread_local Stage s;
+    if(s.gen != g_generation.load()) s.destroy(), s.create(); // the library was shut down or re-bound since: fresh stream + buffer
     return s;
 }
 

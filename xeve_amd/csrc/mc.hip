@@ -531,6 +531,7 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     pel             *p1[3];
     p1[0] = (pel *)(jc + q * n), p1[1] = p1[0] + n * w * h, p1[2] = p1[1] + n * P.cw * P.ch;
     hipStream_t st = (hipStream_t)stream;
+    XhProf prof(XH_PROF_MC, st);
     k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, P, jl, jc, mode);
     XH_HIP(hipGetLastError());
     for(int l = 0; l < 2; l++) { // one launch per list and component: the jobs pick their reference picture from the table

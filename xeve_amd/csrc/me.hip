@@ -7,10 +7,21 @@
 // butterfly over the candidate's lane group (same lane layout as k_sad_sq); per round the winner is a wave-wide
 // minimum over 64-bit keys (cost << 32 | evaluation order), which reproduces the reference's
 // "first strictly smaller cost wins" tie-break exactly.
+#include <cstdlib>
 #include "xh_common.h"
 
 template <int S> struct MGeo {
     static constexpr int LPR = S / 8, RPP = XH_WAVE / LPR, CPP = RPP >= S ? RPP / S : 1, NP = RPP >= S ? 1 : S / RPP, GROUP = XH_WAVE / CPP;
+};
+
+// The dense round's window in LDS (LDSM != 0): every candidate of the (2d+1)^2 grid reads its rows out of ONE staged copy of the
+// (S + 2d) x (S + 2d) samples the grid covers -- staged with coalesced dword loads (a row of the window is contiguous in the plane),
+// read back as 16-byte row segments.  d = 2 (uni) / 5 (bi-prediction refinement), xeve_pinter.c:409-416.  One window per wave.
+// LDSM 1: one copy, segments at any 2-byte offset (unaligned ds_read_b128); LDSM 2: a second copy one sample to the left, so that
+// every segment read is dword-aligned (two ds_read2_b32).
+template <int S, bool BI> struct MWin {
+    static constexpr int DMAX = BI ? 5 : 2, H = S + 2 * DMAX, NDW = S / 2 + DMAX + 1, PITCH = 2 * NDW; // NDW dwords = S + 2 DMAX + 2 samples: + parity, + round-up
+    static constexpr int PELS = H * PITCH;
 };
 
 // 16-point diamond of L1 radius 4 (xeve_pinter.c:57-65); the 8-point ring is every other point halved
@@ -37,12 +48,15 @@ __device__ __forceinline__ void me_load_org(const pel *__restrict__ org0, int s_
 }
 
 // one complete me_ipel_diamond by the calling wave; the result is wave-uniform
-template <int S, bool BI>
+template <int S, bool BI, int LDSM = 0>
 __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo<S>::NP], const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job &jb, int shift,
-                                                         const xeve_hip_me_params &P, int lane, int *range_out = nullptr)
+                                                         const xeve_hip_me_params &P, int lane, int *range_out = nullptr, unsigned *evals = nullptr,
+                                                         pel *win = nullptr)
 {
+    using W = MWin<S, BI>;
     using G = MGeo<S>;
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
+    unsigned nev = 0; // block SADs evaluated (measurement only: xeve_hip_prof_*)
     int r0 = jb.range[0], r1 = jb.range[1], r2 = jb.range[2], r3 = jb.range[3];
     int bx = clip3(P.min_clip[0], P.max_clip[0], jb.mvi[0] >> 2), by = clip3(P.min_clip[1], P.max_clip[1], jb.mvi[1] >> 2);
     const int ix = bx, iy = by;
@@ -65,6 +79,27 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
         else nc = coarse ? 16 : (step == 4 ? 5 : 9);
         unsigned long long round_key = ~0ull;
         int round_bits = 0;
+        // ---- the dense grid out of the LDS window
+        bool staged = false;
+        int  wpar = 0;
+        if(LDSM && dense && !(s_ref & 1) && wd <= 2 * W::DMAX + 1 && nc <= (2 * W::DMAX + 1) * wd) {
+            const pel      *g0   = ref0 + (long)y0 * s_ref + x0;
+            wpar                 = (int)(((uintptr_t)g0 >> 1) & 1);
+            const uint32_t *ga   = reinterpret_cast<const uint32_t *>(g0 - wpar); // dword-aligned; row r starts s_ref / 2 dwords further
+            const int       nrow = nc / wd + S - 1, tot = nrow * W::NDW, sdw = s_ref >> 1;
+            uint32_t       *wa   = reinterpret_cast<uint32_t *>(win);
+            for(int i = lane; i < tot; i += 64) {
+                const int r = i / W::NDW, k = i - r * W::NDW;
+                const uint32_t *gp = ga + (long)r * sdw + k;
+                if(LDSM == 2) {
+                    const uint32_t a = gp[0], b = gp[1];
+                    wa[i] = a, wa[W::PELS / 2 + i] = __builtin_amdgcn_alignbit(b, a, 16); // second copy: one sample to the left
+                }
+                else wa[i] = gp[0];
+            }
+            __builtin_amdgcn_wave_barrier(); // (LDS operations of one wave execute in order; this only pins the compiler's schedule)
+            staged = true;
+        }
         for(int c0 = 0; c0 < nc; c0 += G::CPP) {
             const int k = c0 + slot;
             int mx, my;
@@ -79,8 +114,29 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
                 mx = ix + (step >> 1) * dx, my = iy + (step >> 1) * dy;
             }
             const bool valid = k < nc && mx <= r2 && mx >= r0 && my <= r3 && my >= r1;
+            if(evals) nev += (unsigned)__popcll(__ballot(valid && gl == 0));
             int acc = 0;
-            if(valid) {
+            if(LDSM && staged) {
+                if(valid) {
+                    const int wx = mx - x0 + wpar + col; // sample offset inside a window row
+                    // (explicit LDS address space: with a generic pointer the compiler folds this load and the global one below into one flat load)
+                    typedef __attribute__((address_space(3))) const pel lds_pel;
+                    lds_pel *r = (lds_pel *)win + (my - y0 + row0) * W::PITCH + wx;
+                    if(LDSM == 2) r = (wx & 1) ? r + W::PELS - 1 : r;
+#pragma unroll
+                    for(int p = 0; p < G::NP; p++) {
+                        u32x4 v;
+                        if(LDSM == 2) v = *(__attribute__((address_space(3))) const u32x4_a4 *)(r + p * G::RPP * W::PITCH);
+                        else v = *(__attribute__((address_space(3))) const u32x4_a2 *)(r + p * G::RPP * W::PITCH);
+                        if(BI) v ^= 0x80008000u;
+                        acc = __builtin_amdgcn_sad_u16(org[p].x, v.x, acc);
+                        acc = __builtin_amdgcn_sad_u16(org[p].y, v.y, acc);
+                        acc = __builtin_amdgcn_sad_u16(org[p].z, v.z, acc);
+                        acc = __builtin_amdgcn_sad_u16(org[p].w, v.w, acc);
+                    }
+                }
+            }
+            else if(valid) {
                 const pel *r = ref0 + (long)(my + row0) * s_ref + mx + col;
 #pragma unroll
                 for(int p = 0; p < G::NP; p++) {
@@ -147,6 +203,7 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
     res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
     res.cost = (uint32_t)(best_key >> 32), res.beststep = beststep, res.best_mv_bits = best_bits;
     if(range_out) range_out[0] = r0, range_out[1] = r1, range_out[2] = r2, range_out[3] = r3; // the caller's `range`, re-centred in place (:463-468)
+    if(evals) *evals += nev;
     return res;
 }
 
@@ -205,7 +262,8 @@ __device__ __forceinline__ void me_eval(const u32x4 (&org)[MGeo<S>::NP], const p
 template <int S, bool BI>
 __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi,
                                                     const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job *__restrict__ jobs,
-                                                    int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out)
+                                                    int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out,
+                                                    unsigned long long *__restrict__ units)
 {
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -214,8 +272,10 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
     if(jb.range[0] > jb.range[2]) return; // empty range = parked job (its result slot is left untouched)
     u32x4 org[MGeo<S>::NP];
     me_load_org<S, BI>(org0, s_org, org_bi, jb.x, jb.y, jb.org_off, lane, org);
-    const xeve_hip_me_result res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane);
+    unsigned nev = 0;
+    const xeve_hip_me_result res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane, nullptr, units ? &nev : nullptr);
     if(lane == 0) out[j] = res;
+    if(units && lane == 0) atomicAdd(units, (unsigned long long)nev * (S * S / 64));
 }
 
 extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref,
@@ -232,10 +292,12 @@ extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const p
     const dim3  grid((njobs + 3) / 4);
     const int   shift = bit_depth - 8;
     const xeve_hip_me_params P = *params;
+    XhProf prof(XH_PROF_SEARCH, st);
+    unsigned long long *units = xh_prof_units(XH_PROF_SEARCH);
 #define ME_LAUNCH(S)                                                                                                          \
     do {                                                                                                                      \
-        if(P.bi) k_me_diamond<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results);  \
-        else k_me_diamond<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results);     \
+        if(P.bi) k_me_diamond<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);  \
+        else k_me_diamond<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);     \
     } while(0)
     if(log2w == 3) ME_LAUNCH(8);
     else if(log2w == 4) ME_LAUNCH(16);
@@ -268,11 +330,14 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
 // reference's rule asks for one (xeve_pinter.c:757-822) without leaving the kernel: no
 // launch, no host round trip between the searches, the original block stays in registers across them.
 // EXTRA: compiled with the branches presets fast / medium never take (me_raster, me_ipel_refinement); the plain form keeps its registers
-template <int S, bool BI, bool EXTRA>
+template <int S, bool BI, bool EXTRA, int LDSM>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
                                                  const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
-                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl, int ipel_only)
+                                                 const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl, int ipel_only,
+                                                 unsigned long long *__restrict__ units)
 {
+    __shared__ __attribute__((aligned(16))) pel s_win[LDSM ? 4 * LDSM * MWin<S, BI>::PELS : 8];
+    pel *win = s_win + (threadIdx.x >> 6) * (LDSM * MWin<S, BI>::PELS);
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
@@ -298,11 +363,12 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0, s.mot_bits = 0;
     u32x4 org[MGeo<S>::NP];
     me_load_org<S, BI>(org0, s_org, org_bi, e.x, e.y, e.org_off, lane, org);
+    unsigned nev = 0; // (measurement only; the raster / integer-refinement branches are not counted)
     xeve_hip_me_params Q = P;
     for(int it = 0; it < 64; it++) { // (the reference's loop ends when a search no longer improves; 64 is a safety bound)
         Q.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
         int rng[4];
-        const xeve_hip_me_result r = me_diamond<S, BI>(org, ref0, s_ref, m, shift, Q, lane, rng);
+        const xeve_hip_me_result r = me_diamond<S, BI, LDSM>(org, ref0, s_ref, m, shift, Q, lane, rng, units ? &nev : nullptr, win);
         s.tmpstep = r.beststep, s.searches++;
         if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect on pi->mot_bits (:546-548)
         int beststep = 0;
@@ -355,6 +421,7 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         if(rc < s.cost) s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2);
     }
     if(lane == 0) st[j] = s;
+    if(units && lane == 0) atomicAdd(units, (unsigned long long)nev * (S * S / 64));
 }
 
 __global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj)
@@ -384,6 +451,8 @@ __global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, c
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// developer switch (measurement): 0 = every candidate row through the vector L1, 1 = dense round from an LDS window (default), 2 = two-copy window
+static const int g_me_lds = getenv("XEVE_HIP_ME_LDS") ? atoi(getenv("XEVE_HIP_ME_LDS")) : 1;
 
 extern "C" size_t xeve_hip_me_epzs_workspace(int njobs)
 {
@@ -441,20 +510,31 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     {
         const dim3 grid((njobs + 3) / 4);
         const int  shift = bit_depth - 8;
-#define EPZS_LAUNCH(S)                                                                                                     \
-    do {                                                                                                                   \
-        if(extra_branches) {                                                                                               \
-            if(P.bi) k_me_epzs<S, true, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, ipel_only);   \
-            else k_me_epzs<S, false, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, ipel_only);      \
-        }                                                                                                                  \
-        else if(P.bi) k_me_epzs<S, true, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, 0);   \
-        else k_me_epzs<S, false, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl, 0);      \
+        XhProf prof(XH_PROF_SEARCH, st);
+        unsigned long long *units = xh_prof_units(XH_PROF_SEARCH);
+#define EPZS_ARGS org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl
+#define EPZS_LAUNCH_M(S, M)                                                                                        \
+    do {                                                                                                           \
+        if(extra_branches) {                                                                                       \
+            if(P.bi) k_me_epzs<S, true, true, 1><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
+            else k_me_epzs<S, false, true, 1><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);                  \
+        }                                                                                                          \
+        else if(P.bi) k_me_epzs<S, true, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                     \
+        else k_me_epzs<S, false, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                             \
+    } while(0)
+#define EPZS_LAUNCH(S)                                                                                             \
+    do {                                                                                                           \
+        if(g_me_lds == 0) EPZS_LAUNCH_M(S, 0);                                                                     \
+        else if(g_me_lds == 2) EPZS_LAUNCH_M(S, 2);                                                                \
+        else EPZS_LAUNCH_M(S, 1);                                                                                  \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);
         else if(log2w == 4) EPZS_LAUNCH(16);
         else if(log2w == 5) EPZS_LAUNCH(32);
         else EPZS_LAUNCH(64);
 #undef EPZS_LAUNCH
+#undef EPZS_LAUNCH_M
+#undef EPZS_ARGS
         XH_HIP(hipGetLastError());
     }
     if(ipel_only) {
@@ -467,8 +547,12 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     xeve_hip_spel_params SP;
     SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;
     SP.hpel_cnt = params->hpel_cnt, SP.qpel_cnt = params->qpel_cnt;
-    int rc = xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, extra_bits, sres, sws,
+    int rc;
+    {
+        XhProf prof(XH_PROF_SPEL, st);
+        rc = xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, extra_bits, sres, sws,
                                        xeve_hip_me_spel_workspace(njobs), st, pl.n ? &pl : nullptr);
+    }
     if(rc != XEVE_HIP_OK) return rc;
     k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
     XH_HIP(hipGetLastError());

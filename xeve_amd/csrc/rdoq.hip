@@ -245,26 +245,58 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
 
 // ---- host ---------------------------------------------------------------------------------------------------
 // zig-zag scans (xeve_tbl_scan, generator xeve_util.c:1289-1327), built once per (log2w, log2h) and kept on the device
+// All of them (log2 0..6 each way) are built by xeve_hip_init and freed by xeve_hip_shutdown (xh_rdoq_tables_init / _free below): entry points
+// only look them up, so a first call inside a stream capture or on a latency-sensitive stream never allocates or synchronises.
 static uint16_t *g_scan[7][7];
-static std::mutex g_scan_mu;
+static int      *g_entropy; // entropy_bits[1024] of xeve_init_bits_est (xeve_mode.c:304-313), device copy
 int xh_get_scan(int log2w, int log2h, const uint16_t **out)
 {
-    std::lock_guard<std::mutex> lk(g_scan_mu);
-    if(!g_scan[log2w][log2h]) {
-        const int w = 1 << log2w, h = 1 << log2h;
-        uint16_t *hs = new uint16_t[(size_t)w * h];
-        int pos = 0;
-        for(int l = 0; l < w + h - 1; l++) { // odd anti-diagonals run down-left, even ones up-right
-            if(l & 1) for(int x = l < w - 1 ? l : w - 1, y = l - x; x >= 0 && y < h; x--, y++) hs[pos++] = (uint16_t)(y * w + x);
-            else for(int y = l < h - 1 ? l : h - 1, x = l - y; y >= 0 && x < w; x++, y--) hs[pos++] = (uint16_t)(y * w + x);
-        }
-        uint16_t *d = nullptr;
-        XH_HIP(hipMalloc((void **)&d, sizeof(uint16_t) * w * h));
-        XH_HIP(hipMemcpy(d, hs, sizeof(uint16_t) * w * h, hipMemcpyHostToDevice));
-        delete[] hs;
-        g_scan[log2w][log2h] = d;
+    if(log2w < 0 || log2w > 6 || log2h < 0 || log2h > 6 || !g_scan[log2w][log2h]) {
+        xh_set_error("xh_get_scan: no scan table for log2 %d x %d (xeve_hip_init builds them)", log2w, log2h);
+        return XEVE_HIP_ERR_UNINIT;
     }
     *out = g_scan[log2w][log2h];
+    return XEVE_HIP_OK;
+}
+void xh_rdoq_tables_free()
+{
+    for(auto &row : g_scan)
+        for(auto &d : row)
+            if(d) (void)hipFree(d), d = nullptr;
+    if(g_entropy) (void)hipFree(g_entropy), g_entropy = nullptr;
+}
+int xh_rdoq_tables_init()
+{
+    xh_rdoq_tables_free();
+    // one host image of every table, one allocation per table (they are handed out as separate pointers)
+    uint16_t hs[64 * 64];
+    for(int log2w = 0; log2w <= 6; log2w++)
+        for(int log2h = 0; log2h <= 6; log2h++) {
+            const int w = 1 << log2w, h = 1 << log2h;
+            int pos = 0;
+            for(int l = 0; l < w + h - 1; l++) { // odd anti-diagonals run down-left, even ones up-right
+                if(l & 1) for(int x = l < w - 1 ? l : w - 1, y = l - x; x >= 0 && y < h; x--, y++) hs[pos++] = (uint16_t)(y * w + x);
+                else for(int y = l < h - 1 ? l : h - 1, x = l - y; y >= 0 && x < w; x++, y--) hs[pos++] = (uint16_t)(y * w + x);
+            }
+            uint16_t *d = nullptr;
+            if(hipMalloc((void **)&d, sizeof(uint16_t) * w * h) != hipSuccess || hipMemcpy(d, hs, sizeof(uint16_t) * w * h, hipMemcpyHostToDevice) != hipSuccess) {
+                if(d) (void)hipFree(d);
+                xh_rdoq_tables_free();
+                xh_set_error("xeve_hip_init: building the scan tables failed");
+                return XEVE_HIP_ERR_DEVICE;
+            }
+            g_scan[log2w][log2h] = d;
+        }
+    int he[1024];
+    for(int i = 0; i < 1024; i++) {
+        const double p = (512 * (i + 0.5)) / 1024;
+        he[i] = (int)(-32768 * (log(p) / log(2.0) - 9));
+    }
+    if(hipMalloc((void **)&g_entropy, sizeof(he)) != hipSuccess || hipMemcpy(g_entropy, he, sizeof(he), hipMemcpyHostToDevice) != hipSuccess) {
+        xh_rdoq_tables_free();
+        xh_set_error("xeve_hip_init: building the entropy table failed");
+        return XEVE_HIP_ERR_DEVICE;
+    }
     return XEVE_HIP_OK;
 }
 
@@ -328,6 +360,7 @@ static int rdoq_common(int16_t *coef, int nblk, int log2w, int log2h, int qp, do
     memset(&P.est, 0, sizeof(P.est));
     P.est_dev = nullptr, P.est_idx = nullptr, P.o_run = P.o_level = P.o_last = P.o_cbf = 0;
     hipStream_t st = (hipStream_t)stream;
+    XhProf prof(XH_PROF_RDOQ, st);
     if(est) {
         for(int i = 0; i < 2; i++)
             for(int j = 0; j < 2; j++) P.est.run[i][j] = est->run[c + i][j], P.est.level[i][j] = est->level[c + i][j];
@@ -366,8 +399,6 @@ extern "C" int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, 
 }
 
 // ---- xeve_rdoq_bit_est (xeve_mode.c:326-372): estimates from a coder state ----------------------------------------------
-static int *g_entropy; // entropy_bits[1024] of xeve_init_bits_est (xeve_mode.c:304-313), device copy
-static std::mutex g_entropy_mu;
 
 __global__ void k_rdoq_bit_est(const xeve_hip_sbac *__restrict__ sbac, int n, const int *__restrict__ entropy, int *__restrict__ out)
 {
@@ -390,20 +421,7 @@ extern "C" int xeve_hip_rdoq_bit_est(const xeve_hip_sbac *sbac, int nstates, xev
     XH_REQUIRE(nstates >= 0);
     if(nstates == 0) return XEVE_HIP_OK;
     XH_REQUIRE(sbac && est);
-    {
-        std::lock_guard<std::mutex> lk(g_entropy_mu);
-        if(!g_entropy) {
-            int h[1024];
-            for(int i = 0; i < 1024; i++) {
-                const double p = (512 * (i + 0.5)) / 1024;
-                h[i] = (int)(-32768 * (log(p) / log(2.0) - 9));
-            }
-            int *d = nullptr;
-            XH_HIP(hipMalloc((void **)&d, sizeof(h)));
-            XH_HIP(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
-            g_entropy = d;
-        }
-    }
+    XH_REQUIRE(g_entropy != nullptr); // built by xeve_hip_init
     const int total = nstates * (int)(sizeof(xeve_hip_rdoq_est_full) / sizeof(int) / 2);
     k_rdoq_bit_est<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(sbac, nstates, g_entropy, (int *)est);
     XH_HIP(hipGetLastError());

@@ -290,7 +290,7 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
 template <bool FULL>
 __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs,
                                                 CuBitsK P, const unsigned *__restrict__ ev, const int *__restrict__ nev,
-                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout)
+                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units)
 {
     __shared__ uint16_t s_ctx[NCTX][64];
     // the header queue is drained before the first event reaches the ring: the two share their LDS (one wave per workgroup, so the
@@ -431,6 +431,14 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     else loop(std::false_type{});
 
     bits[j] = s.shifts;
+    if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave.  Lanes past the job list have left, so the sum goes through one
+                // LDS word (one wave per workgroup: program order is the only order there is)
+        unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);
+        const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
+        if(first) *cnt = 0;
+        atomicAdd(cnt, s.bins - (FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET) ? in.bin_counter : 0u));
+        if(first) atomicAdd(units, (unsigned long long)*cnt);
+    }
     if(!FULL && sout) { // what feeds forward into later bit counts: the range and the models (xeve_sbac_bit_reset discards the rest but the
                         // low bits of the code register, and those never reach a bit count)
         xeve_hip_sbac &o = sout[j];
@@ -517,8 +525,12 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
         k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
     }
     else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
-    if(full) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
-    else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out);
+    {
+        XhProf prof(XH_PROF_CU_BITS, st);
+        unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS);
+        if(full) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+    }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

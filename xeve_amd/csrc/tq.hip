@@ -666,6 +666,7 @@ static int residual_launch(const pel *org, int s_org, const pel *pred, int s_pre
     P.dq_offset = P.dq_shift == 0 ? 0 : 1 << (P.dq_shift - 1);
     P.ssd_shift = (bit_depth - 8) * 2;
     P.maxv      = (1 << bit_depth) - 1;
+    XhProf prof(XH_PROF_RESID, st);
     if(g_use_mfma && log2w == log2h && log2w >= 5)
         return xh_rdo_mfma(1 << log2w, org, s_org, pred, s_pred, jobs, njobs, &P, coef, rec, s_rec, nnz, ssd, st);
     if(g_use_rows && log2w == log2h && log2w >= 2 && log2w <= 4) { // 4x4, 8x8, 16x16: row-per-lane register form

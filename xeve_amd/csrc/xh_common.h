@@ -37,6 +37,19 @@ bool xh_ready();
         }                                                            \
     } while(0)
 
+// ---- kernel-class timers (abi.cpp; include/xeve_hip.h "xeve_hip_prof_*") ----------------------
+enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3, XH_PROF_RESID = 4, XH_PROF_RDOQ = 5 };
+bool  xh_prof_on(int cls);
+void *xh_prof_begin(int cls, hipStream_t st);
+void  xh_prof_end(void *tok, hipStream_t st);
+unsigned long long *xh_prof_units(int cls); // device counter of the class, NULL while the timers are off
+struct XhProf {
+    void       *tok;
+    hipStream_t st;
+    XhProf(int cls, hipStream_t s) : tok(xh_prof_on(cls) ? xh_prof_begin(cls, s) : nullptr), st(s) {}
+    ~XhProf() { if(tok) xh_prof_end(tok, st); }
+};
+
 // parameters of the fused residual chain (tq.hip: k_rdo_valu / k_rdo_rows, dct_mfma.hip: k_rdo_mfma)
 struct RdoParams {
     int  shift_fwd, shift_inv;        // transform rounding shifts (xeve_util.c:34-35, xeve_itdq.h:38-39)
@@ -81,6 +94,7 @@ static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // global_load_dwordx4.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_a2 __attribute__((aligned(2)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 u32x2_a2 __attribute__((aligned(2)));
 

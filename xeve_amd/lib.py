@@ -159,6 +159,8 @@ FUNCTIONS = {
     "xeve_hip_pinter_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
+    "xeve_hip_prof_enable": (c_int, [c_int]),
+    "xeve_hip_prof_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "xeve_hip_inter_candidates": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "xeve_hip_pinter_analyze_cu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 14),
     "xeve_hip_me_epzs_jobs_x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -220,3 +222,21 @@ def init(device=0):
 
 def table_calls():
     return int(load().xeve_hip_table_calls())
+
+
+PROF_CLASSES = ("search", "spel", "cu_bits", "mc", "resid", "rdoq")  # include/xeve_hip.h: xeve_hip_prof_*
+
+
+def prof_enable(classes=PROF_CLASSES):
+    """switch the kernel-class timers on for the named classes (an empty list / None: all off)"""
+    mask = 0
+    for c in classes or ():
+        mask |= 1 << PROF_CLASSES.index(c)
+    check(load().xeve_hip_prof_enable(mask))
+
+
+def prof_read():
+    """{class: (ms, launches, units)} since the last read (waits for the device)"""
+    ms, n, u = (C.c_double * 8)(), (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    check(load().xeve_hip_prof_read(ms, n, u, 8))
+    return {name: (ms[i], int(n[i]), int(u[i])) for i, name in enumerate(PROF_CLASSES)}

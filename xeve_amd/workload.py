@@ -60,9 +60,11 @@ class HotPathPass:
         hl, hc = height + 2 * PAD_L, height // 2 + 2 * PAD_C
         self.content = content
         if content == "iid":
-            # synthetic i.i.d. uniform picture planes (8-bit source << 2 in the reference; here uniform 10-bit)
+            # synthetic i.i.d. uniform picture planes: the original is an 8-bit source << (bit_depth - 8), as the encoder sees the BASELINE configs' random
+            # 8-bit YUV (xeve_app converts on input); the reference pictures are reconstructions, any value of the internal depth
             mk = lambda h, s: torch.randint(0, 1 << bit_depth, (h, s), generator=g, device=device, dtype=torch.int16)
-            self.org = [mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)]
+            mk8 = lambda h, s: (torch.randint(0, 256, (h, s), generator=g, device=device, dtype=torch.int16) << (bit_depth - 8))
+            self.org = [mk8(hl, self.s_l), mk8(hc, self.s_c), mk8(hc, self.s_c)]
             self.ref = [[mk(hl, self.s_l), mk(hc, self.s_c), mk(hc, self.s_c)] for _ in range(N_LIST)]
         else:
             # SURVEY.md 8(d)'s structured input: a moving gradient + 3-bit noise, ((x + 3f) * 2 + (y + f) + rand3) & 255 as an
