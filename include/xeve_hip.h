@@ -607,7 +607,16 @@ int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_
  * mv_col stay 0 in P slices); the other fields are the caller's. */
 int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t *map_mv, const int16_t *col_mv0, const int16_t *col_mv1, int w_scu,
                               int h_scu, int log2_cuw, int log2_cuh, int slice_type, xeve_hip_inter_job *jobs, int njobs, void *stream);
-/* One xeve_pinter_analyze_cu call on HOST memory (synchronous; the original and every reference picture of both lists staged per call): what
+/* Resident pictures (serving layer, first slice).  The reference keeps its pictures in host memory and calls the path once per CU; a caller that
+ * announces every new picture with xeve_hip_picture_begin() -- the reference's hook is ctx->fn_mode_analyze_frame, called once per picture before the
+ * CTU loop (src_base/xeve_enc.c:275, xeve_mode.c:2441) -- gets each host plane uploaded ONCE per picture (the first time a host-memory entry point sees
+ * it) and served from HBM for all later calls of that picture.  Contract: no host-memory call in flight during xeve_hip_picture_begin(); planes do not
+ * change between two of them.  Never called: every host-memory call stages its planes itself (the round-1 behaviour).  _stats: pictures announced, planes
+ * uploaded (+ bytes) and cache hits since init. */
+int xeve_hip_picture_begin(void);
+int xeve_hip_resident_stats(uint64_t *pictures, uint64_t *uploads, uint64_t *upload_bytes, uint64_t *hits);
+
+/* One xeve_pinter_analyze_cu call on HOST memory (synchronous; without resident pictures the original and every reference picture of both lists are staged per call): what
  * ctx->fn_pinter_analyze_cu can be pointed at.  org / refp: HOST pointers to sample (0, 0); the reference planes extend pad_l / pad_c samples around
  * the picture; *state: core->s_curr_best[log2_cuw - 2][log2_cuh - 2] (job->sbac is ignored); coef_* / rec_*: the CU's dense blocks. */
 int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, int pad_l, int pad_c,

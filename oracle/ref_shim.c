@@ -340,8 +340,28 @@ static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
     return R.cost;
 }
 
+/* XEVE_HIP_SHIM_RESIDENT=1 (with XEVE_HIP_SHIM_INTER): resident pictures.  ctx->fn_mode_analyze_frame is the reference's once-per-picture hook (called
+ * by xeve_pic before the CTU loop, xeve_enc.c:275; mode_analyze_frame itself does nothing, xeve_mode.c:2441): it announces the new picture to the
+ * library, which from then on uploads each plane the inter analysis is handed once per picture instead of once per CU. */
+static int (*hip_picture_begin)(void);
+static int (*hip_resident_stats)(unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *);
+static int (*orig_analyze_frame)(XEVE_CTX *);
+static int shim_analyze_frame(XEVE_CTX *ctx)
+{
+    if(hip_picture_begin() != 0) {
+        fprintf(stderr, "[xeve_hip_shim] picture_begin: %s\n", hip_err());
+        abort();
+    }
+    return orig_analyze_frame ? orig_analyze_frame(ctx) : XEVE_OK;
+}
+
 static void report(void)
 {
+    if(hip_resident_stats) {
+        unsigned long long pics = 0, up = 0, bytes = 0, hits = 0;
+        hip_resident_stats(&pics, &up, &bytes, &hits);
+        fprintf(stderr, "[xeve_hip_shim] resident pictures: %llu pictures announced, %llu planes uploaded (%llu bytes), %llu plane look-ups served from HBM\n", pics, up, bytes, hits);
+    }
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
@@ -409,6 +429,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_inter_host) { fprintf(stderr, "[xeve_hip_shim] inter-analysis entry point missing\n"); abort(); }
         orig_pinter_analyze_cu = ctx->fn_pinter_analyze_cu, ctx->fn_pinter_analyze_cu = shim_pinter_analyze_cu;
         fprintf(stderr, "[xeve_hip_shim] whole inter analysis of a CU routed to the GPU\n");
+        if(getenv("XEVE_HIP_SHIM_RESIDENT") && atoi(getenv("XEVE_HIP_SHIM_RESIDENT"))) {
+            hip_picture_begin = dlsym(h, "xeve_hip_picture_begin"), hip_resident_stats = dlsym(h, "xeve_hip_resident_stats");
+            if(!hip_picture_begin || !hip_resident_stats) { fprintf(stderr, "[xeve_hip_shim] resident-picture entry points missing\n"); abort(); }
+            orig_analyze_frame = ctx->fn_mode_analyze_frame, ctx->fn_mode_analyze_frame = shim_analyze_frame;
+            fprintf(stderr, "[xeve_hip_shim] pictures resident in HBM (one upload per plane and picture)\n");
+        }
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

@@ -26,6 +26,14 @@ CASES = {
     "moving_cif_ra_medium": (352, 288, 5, 5006, ["--preset", "medium", "-b", "1"]),  # 5.5 x 4.5 CTUs: partial CTUs at the right and bottom edge
 }
 
+# BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes (first frames only): goldens are made by tests/golden/make_e2e_golden.py from the reference app; the
+# GPU suite encodes them once with the whole inter analysis served by the GPU (tests/test_e2e_real_sizes.py).  Not part of CASES: the CPU suite does not re-encode them.
+REAL_CASES = {
+    "cfg2_720p_ldb_fast": (1280, 720, 2, 2, ["--preset", "fast", "-b", "0", "-I", "0"]),  # 20 x 12 CTUs, the last row 16 samples high; low-delay B, ME range 64
+    "cfg3_1080p_ra_medium": (1920, 1080, 3, 3, ["--preset", "medium"]),  # 30 x 17 CTUs (last row 56 high); default random-access GOP (-b 15): I, then B pictures by POC distance
+    "cfg4_2160p_closedgop_medium": (3840, 2160, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8"]),  # 60 x 34 CTUs (last row 48 high): IDR + one inter picture
+}
+
 
 def make_yuv(path, w, h, frames, seed):
     """seeds below 5000: i.i.d. noise (SURVEY.md 8d recipe); from 5000: a smooth texture drifting over the frames plus light noise -- content on
@@ -48,7 +56,7 @@ def make_yuv(path, w, h, frames, seed):
                 f.write(np.clip(a + r.integers(-2, 3, size=a.shape), 0, 255).astype(np.uint8).tobytes())
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -61,6 +69,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
         env["XEVE_HIP_LIB"] = HIP_LIB
         if inter:
             env["XEVE_HIP_SHIM_INTER"] = "1"  # the whole inter analysis of a CU (ctx->fn_pinter_analyze_cu)
+            if resident:
+                env["XEVE_HIP_SHIM_RESIDENT"] = "1"  # planes uploaded once per picture (xeve_hip_picture_begin from ctx->fn_mode_analyze_frame)
         if mc:
             env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:

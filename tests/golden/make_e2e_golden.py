@@ -7,11 +7,11 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _e2e import CASES, make_yuv, run_app  # noqa: E402
+from _e2e import CASES, REAL_CASES, make_yuv, run_app  # noqa: E402
 
 out = {}
 with tempfile.TemporaryDirectory() as d:
-    for name, (w, h, n, seed, extra) in CASES.items():
+    for name, (w, h, n, seed, extra) in list(CASES.items()) + list(REAL_CASES.items()):
         yuv = os.path.join(d, name + ".yuv")
         make_yuv(yuv, w, h, n, seed)
         md5, size, _ = run_app(yuv, os.path.join(d, name + ".evc"), w, h, n, extra)

@@ -1,0 +1,54 @@
+"""GPU suite: BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes, once through the unmodified reference encoder with the whole inter analysis
+of every CU served by the GPU (ctx->fn_pinter_analyze_cu -> xeve_hip_pinter_analyze_cu_host, pictures resident in HBM: one upload per plane and picture).
+Byte-identical to the goldens the reference app itself produced (tests/golden/make_e2e_golden.py).  What these sizes pin that the small clips cannot: partial
+CTU rows (720 = 11*64 + 16, 1080 = 16*64 + 56, 2160 = 33*64 + 48), the MV clip window and search ranges at real picture extents, get_range_ipel's POC scaling
+on the default 16-picture random-access GOP, 64x64 CUs in quantity."""
+import json
+import os
+import re
+import time
+
+import pytest
+
+from _e2e import CASES, REAL_CASES, SHIM, make_yuv, run_app
+from _libs import REF_APP
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_v1.json")))
+needs_ref = pytest.mark.skipif(not (os.path.exists(REF_APP) and os.path.exists(SHIM)), reason="oracle/_ref not built")
+pytestmark = [pytest.mark.gpu, needs_ref]
+
+
+def _encode(tmp_path, name, cases, min_cus):
+    w, h, n, seed, extra = cases[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    t0 = time.perf_counter()
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, resident=True)
+    dt = time.perf_counter() - t0
+    m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    r = re.search(r"resident pictures: (\d+) pictures announced, (\d+) planes uploaded \((\d+) bytes\), (\d+) plane look-ups", err)
+    assert m and r, err
+    cus, left = int(m.group(1)), int(m.group(2))
+    pics, uploads, hits = int(r.group(1)), int(r.group(2)), int(r.group(4))
+    print("%s: %d CUs on the GPU in %.1f s (%.0f us per CU incl. the host side of the encoder), %d pictures, %d plane uploads, %d look-ups from HBM" % (name, cus, dt, 1e6 * dt / max(1, cus), pics, uploads, hits))
+    assert cus >= min_cus and left == 0, err
+    assert pics == n and uploads <= 9 * pics and hits > 5 * cus, err  # (each inter picture: the original + at most two reference pictures, three planes each)
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the inter analysis on the GPU at %dx%d" % (w, h)
+
+
+@pytest.mark.parametrize("name", ["moving_ra_medium", "tiny_ldb_fast_2threads"])
+def test_small_clips_with_resident_pictures(tmp_path, name):
+    """the resident-picture path on the small clips first (two encoder threads share the plane store in the second one)"""
+    _encode(tmp_path, name, CASES, 200)
+
+
+def test_cfg2_1280x720_low_delay_fast(tmp_path):
+    _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000)
+
+
+def test_cfg3_1920x1080_random_access_medium(tmp_path):
+    _encode(tmp_path, "cfg3_1080p_ra_medium", REAL_CASES, 60000)
+
+
+def test_cfg4_3840x2160_closed_gop_medium(tmp_path):
+    _encode(tmp_path, "cfg4_2160p_closedgop_medium", REAL_CASES, 100000)

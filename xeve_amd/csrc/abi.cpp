@@ -43,6 +43,7 @@ void xh_set_error(const char *fmt, ...)
     memcpy(g_err, t_err, sizeof(g_err));
 }
 bool xh_ready() { return g_device.load() >= 0; }
+uint32_t xh_generation() { return g_generation.load(); }
 
 // the calling thread's last message; a thread that has none gets a copy of the process-wide last one (taken under the lock)
 extern "C" const char *xeve_hip_last_error(void)
@@ -89,6 +90,7 @@ extern "C" int xeve_hip_init(int device_ordinal)
         (void)hipSetDevice(g_device.load());
         (void)hipDeviceSynchronize();
         xh_rdoq_tables_free();
+        xh_resident_free_all();
         g_device.store(-1);
     }
     XH_HIP(hipSetDevice(device_ordinal));
@@ -112,6 +114,7 @@ extern "C" void xeve_hip_shutdown(void)
         (void)hipDeviceSynchronize();
         prof_reset_locked();
         xh_rdoq_tables_free();
+        xh_resident_free_all();
     }
     g_device.store(-1);
     g_generation++;

@@ -635,6 +635,111 @@ extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t 
     return XEVE_HIP_OK;
 }
 
+// ---- per-thread device state of the host-memory form with resident pictures --------------------------------------------------------------
+// One stream, one device arena (job | state | result | coefficients | reconstruction | prediction | exit state | workspace) and one pinned
+// host mirror of the small records per encoder thread: a call is one upload of (job, state), the launches, one download of the outputs.
+namespace {
+struct InterHostCtx {
+    uint32_t    gen = 0;
+    hipStream_t st  = nullptr;
+    char       *dev = nullptr, *pin = nullptr;
+    size_t      dev_bytes = 0;
+    static constexpr size_t IN_BYTES = 512, OUT_BYTES = 64 << 10; // in: job + state; out: result, exit state, coef, rec, pred (64x64: 12 + 12.1 + 8 KB)
+    void release()
+    {
+        if(st) (void)hipStreamDestroy(st);
+        if(dev) (void)hipFree(dev);
+        if(pin) (void)hipHostFree(pin);
+        st = nullptr, dev = pin = nullptr, dev_bytes = 0;
+    }
+    int ensure(size_t ws_bytes)
+    {
+        if(gen != xh_generation()) release(), gen = xh_generation(); // the library was shut down or re-bound since
+        if(!st) XH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if(!pin) XH_HIP(hipHostMalloc((void **)&pin, IN_BYTES + OUT_BYTES, hipHostMallocDefault));
+        const size_t need = IN_BYTES + OUT_BYTES + 256 + ws_bytes;
+        if(dev_bytes < need) {
+            if(dev) {
+                XH_HIP(hipStreamSynchronize(st));
+                (void)hipFree(dev);
+                dev = nullptr, dev_bytes = 0;
+            }
+            XH_HIP(hipMalloc((void **)&dev, need + (need >> 2)));
+            dev_bytes = need + (need >> 2);
+        }
+        return XEVE_HIP_OK;
+    }
+    ~InterHostCtx() { release(); }
+};
+} // namespace
+
+static int inter_host_resident(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, int pad_l, int pad_c,
+                               const xeve_hip_sbac *state, const xeve_hip_inter_params *p, const xeve_hip_inter_job *job, const int16_t (*coef_l)[8],
+                               const int16_t (*coef_c)[4], xeve_hip_inter_result *result, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, xeve_hip_pel *rec_y,
+                               xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y, xeve_hip_sbac *next_best)
+{
+    static thread_local InterHostCtx C;
+    const xeve_hip_rdo_params &rp = p->rdo;
+    const int idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, isb = rp.slice_type == 0;
+    const size_t n0 = (size_t)1 << (2 * rp.log2_cuw), n1 = idc ? n0 >> (ws + hs) : 0;
+    const size_t eo[3] = {(size_t)s_org_l * rp.pic_h, (size_t)s_org_c * (rp.pic_h >> hs), (size_t)s_org_c * (rp.pic_h >> hs)};
+    const size_t er[3] = {(size_t)s_l * (rp.pic_h + 2 * pad_l), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c)};
+    const size_t orr[3] = {(size_t)pad_l * s_l + pad_l, (size_t)pad_c * s_c + pad_c, (size_t)pad_c * s_c + pad_c};
+    const size_t wsb = xeve_hip_pinter_analyze_cu_workspace(1, 1, p, s_org_l, s_org_c);
+    int rc = C.ensure(wsb);
+    if(rc != XEVE_HIP_OK) return rc;
+    // planes: the picture's resident copies (uploaded on first sight)
+    const pel *dorg[3] = {nullptr, nullptr, nullptr};
+    for(int c = 0; c < ncomp; c++) {
+        dorg[c] = (const pel *)xh_resident(org[c], eo[c] * sizeof(pel));
+        if(!dorg[c]) return XEVE_HIP_ERR_DEVICE;
+    }
+    xeve_hip_refpic tab[2 * MAXR];
+    memset(tab, 0, sizeof(tab));
+    const int nr[2] = {rp.num_refp[0], isb ? rp.num_refp[1] : 0};
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            const xeve_hip_refpic &e = refp[r * 2 + l];
+            XH_REQUIRE(e.y && (idc == 0 || (e.u && e.v)));
+            const xeve_hip_pel *hp[3] = {e.y, e.u, e.v};
+            const pel *dp[3] = {nullptr, nullptr, nullptr};
+            for(int c = 0; c < ncomp; c++) {
+                const pel *d = (const pel *)xh_resident(hp[c] - orr[c], er[c] * sizeof(pel));
+                if(!d) return XEVE_HIP_ERR_DEVICE;
+                dp[c] = d + orr[c];
+            }
+            xeve_hip_refpic &t = tab[r * 2 + l];
+            t.y = dp[0], t.u = dp[1], t.v = dp[2], t.poc = e.poc;
+        }
+    if(!isb) tab[0 * 2 + 1] = tab[0 * 2 + 0]; // (P slices never read list 1; keep the table addressable)
+    // arena layout
+    char *d = C.dev, *h = C.pin;
+    const size_t o_job = 0, o_state = 256;                                                                       // in
+    const size_t o_res = InterHostCtx::IN_BYTES, o_nb = o_res + 256, o_coef = o_nb + 256, o_rec = o_coef + (((n0 + 2 * n1) * 2 + 255) & ~(size_t)255),
+                 o_pred = o_rec + (((n0 + 2 * n1 + 16) * 2 + 255) & ~(size_t)255), o_end = o_pred + n0 * 2;     // out
+    XH_REQUIRE(o_end <= InterHostCtx::IN_BYTES + InterHostCtx::OUT_BYTES);
+    const size_t o_ws = (InterHostCtx::IN_BYTES + InterHostCtx::OUT_BYTES + 255) & ~(size_t)255;
+    xeve_hip_inter_job j0 = *job;
+    j0.sbac = 0;
+    memcpy(h + o_job, &j0, sizeof(j0)), memcpy(h + o_state, state, sizeof(*state));
+    XH_HIP(hipMemcpyAsync(d, h, InterHostCtx::IN_BYTES, hipMemcpyHostToDevice, C.st));
+    pel *drec = (pel *)(d + o_rec);
+    rc = xeve_hip_pinter_analyze_cu_jobs(dorg, s_org_l, s_org_c, tab, s_l, s_c, (const xeve_hip_sbac *)(d + o_state), 1, p, (const xeve_hip_inter_job *)(d + o_job), 1, coef_l,
+                                         coef_c, (xeve_hip_inter_result *)(d + o_res), (int16_t *)(d + o_coef), drec, drec + n0 + 8, drec + n0 + n1 + 16, (pel *)(d + o_pred),
+                                         (xeve_hip_sbac *)(d + o_nb), d + o_ws, wsb, C.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    XH_HIP(hipMemcpyAsync(h + o_res, d + o_res, o_end - o_res, hipMemcpyDeviceToHost, C.st));
+    XH_HIP(hipStreamSynchronize(C.st));
+    memcpy(result, h + o_res, sizeof(*result)), memcpy(next_best, h + o_nb, sizeof(*next_best));
+    memcpy(coef_y, h + o_coef, n0 * 2), memcpy(rec_y, h + o_rec, n0 * 2);
+    if(pred_y) memcpy(pred_y, h + o_pred, n0 * 2);
+    if(idc) {
+        memcpy(coef_u, h + o_coef + n0 * 2, n1 * 2), memcpy(coef_v, h + o_coef + (n0 + n1) * 2, n1 * 2);
+        memcpy(rec_u, h + o_rec + (n0 + 8) * 2, n1 * 2), memcpy(rec_v, h + o_rec + (n0 + n1 + 16) * 2, n1 * 2);
+    }
+    return XEVE_HIP_OK;
+}
+
 // ---- host-memory form of one xeve_pinter_analyze_cu call (the table layer's style: synchronous, every plane staged per call) ----------
 // What ctx->fn_pinter_analyze_cu can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org / refp: HOST pointers to
 // sample (0, 0); the reference planes extend pad_l / pad_c samples around the picture.
@@ -649,6 +754,9 @@ extern "C" int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3],
     const xeve_hip_rdo_params &rp = p->rdo;
     const int idc = rp.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, isb = rp.slice_type == 0;
     XH_REQUIRE(idc == 0 || (org[1] && org[2] && coef_u && coef_v && rec_u && rec_v));
+    if(xh_resident_on()) // the caller announces its pictures: planes are resident, the call moves a job and a CU's worth of results
+        return inter_host_resident(org, s_org_l, s_org_c, refp, s_l, s_c, pad_l, pad_c, state, p, job, coef_l, coef_c, result, coef_y, coef_u, coef_v, rec_y, rec_u, rec_v,
+                                   pred_y, next_best);
     const size_t n0 = (size_t)1 << (2 * rp.log2_cuw), n1 = idc ? n0 >> (ws + hs) : 0;
     const size_t eo[3] = {(size_t)s_org_l * rp.pic_h, (size_t)s_org_c * (rp.pic_h >> hs), (size_t)s_org_c * (rp.pic_h >> hs)};
     const size_t er[3] = {(size_t)s_l * (rp.pic_h + 2 * pad_l), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c), (size_t)s_c * ((rp.pic_h >> hs) + 2 * pad_c)};

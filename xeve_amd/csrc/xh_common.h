@@ -50,6 +50,12 @@ struct XhProf {
     ~XhProf() { if(tok) xh_prof_end(tok, st); }
 };
 
+// ---- resident pictures (resident.cpp) and the library's generation counter (abi.cpp) -----------
+bool     xh_resident_on();                              // xeve_hip_picture_begin() has been called: host planes are cached per picture
+void    *xh_resident(const void *host, size_t bytes);   // device copy of host[0 .. bytes) for the current picture (uploaded on first sight)
+void     xh_resident_free_all();
+uint32_t xh_generation();                               // bumped by every xeve_hip_init / _shutdown: per-thread device state re-creates itself
+
 // parameters of the fused residual chain (tq.hip: k_rdo_valu / k_rdo_rows, dct_mfma.hip: k_rdo_mfma)
 struct RdoParams {
     int  shift_fwd, shift_inv;        // transform rounding shifts (xeve_util.c:34-35, xeve_itdq.h:38-39)

@@ -159,6 +159,8 @@ FUNCTIONS = {
     "xeve_hip_pinter_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
+    "xeve_hip_picture_begin": (c_int, []),
+    "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_prof_enable": (c_int, [c_int]),
     "xeve_hip_prof_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "xeve_hip_inter_candidates": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
