@@ -430,17 +430,19 @@ typedef struct xeve_hip_deblock_params {
     int32_t qp_u_offset, qp_v_offset; /* sh->qp_u_offset / qp_v_offset (pic->pic_qp_*_offset) */
     int32_t qp_chroma[2][100];        /* ctx->qp_chroma_dynamic[c][q] stored at index q + 6 * (bit_depth_chroma - 8) */
 } xeve_hip_deblock_params;
-/* Both edge directions of one picture (vertical edges first), one tile / one slice, quad-tree CUs.  y / u / v point at sample
+/* Both edge directions of one picture (vertical edges first), one slice, quad-tree CUs.  y / u / v point at sample
  * (0, 0) of planes resident in HBM (filtered in place); the maps are the reference's per-4x4-unit arrays, device memory:
  * map_scu (ctx->map_scu: MCU_* bit fields, xeve_def.h:585-640; the COD bits are not used or changed), map_cu_mode
- * (ctx->map_cu_mode: CU log2 width / height in bits 24-31), map_refi [f_scu][2], map_mv [f_scu][2][2] (ctx->map_unrefined_mv,
- * which equals ctx->map_mv in Baseline).  params is a HOST pointer. */
+ * (ctx->map_cu_mode: CU log2 width / height in bits 24-31), map_tidx (ctx->map_tidx: the tile of every unit; NULL = one tile): an edge between
+ * units of different tiles is not filtered, as in xeve_deblock_cu_hor / _ver (xeve_df.c:296-302,386-391; boundary_filtering is always 0, :528),
+ * map_refi [f_scu][2], map_mv [f_scu][2][2] (ctx->map_unrefined_mv, which equals ctx->map_mv in Baseline).  params is a HOST pointer. */
 int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, const uint32_t *map_scu, const uint32_t *map_cu_mode,
-                     const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params, void *stream);
+                     const uint8_t *map_tidx, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params, void *stream);
 /* The same on HOST memory, synchronous, whole padded planes staged per call (pad_l / pad_c = how far the buffers extend around
  * the picture): what ctx->fn_loop_filter / ctx->fn_picbuf_expand can be pointed at without the caller owning device memory */
 int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int pad_l, int pad_c, const uint32_t *map_scu,
-                          const uint32_t *map_cu_mode, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *params);
+                          const uint32_t *map_cu_mode, const uint8_t *map_tidx, const int8_t *map_refi, const int16_t *map_mv,
+                          const xeve_hip_deblock_params *params);
 int xeve_hip_picbuf_expand_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int w_l, int h_l, int w_c, int h_c, int exp_l,
                                 int exp_c, int chroma_format_idc);
 /* xeve_picbuf_expand: replicate the border samples exp_l / exp_c deep around the three planes */

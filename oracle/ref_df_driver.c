@@ -30,16 +30,27 @@ static void set_tree(XEVE_CTX *ctx, int lcu, int x, int y, int cuw, int cud, int
     }
 }
 
+int refdrv_deblock_picture_tiles(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_scu, u32 *map_cu_mode, s8 *map_refi, s16 *map_mv,
+                                 const drv_df_params *p, int split_x_lcu, int split_y_lcu, u8 *map_tidx_out);
 int refdrv_deblock_picture(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_scu, u32 *map_cu_mode, s8 *map_refi, s16 *map_mv,
                            const drv_df_params *p)
+{
+    return refdrv_deblock_picture_tiles(y, u, v, s_l, s_c, map_scu, map_cu_mode, map_refi, map_mv, p, 0, 0, NULL);
+}
+
+/* split_x_lcu / split_y_lcu > 0: a tile boundary after that many CTU columns / rows (up to 2 x 2 tiles, numbered in raster order as xeve_set_tile_info
+ * does); the loop of xeve_loop_filter then runs xeve_deblock once per tile and direction.  map_tidx_out (f_scu bytes or NULL) receives the tile of every unit. */
+int refdrv_deblock_picture_tiles(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_scu, u32 *map_cu_mode, s8 *map_refi, s16 *map_mv,
+                                 const drv_df_params *p, int split_x_lcu, int split_y_lcu, u8 *map_tidx_out)
 {
     XEVE_CTX  *ctx  = calloc(1, sizeof(*ctx));
     XEVE_CORE *core = calloc(1, sizeof(*core));
     XEVE_PIC   pic;
     XEVE_SH    sh;
-    XEVE_TILE  tile;
+    XEVE_TILE  tile[4];
+    int        ntile = 0;
     int        ws = XEVE_GET_CHROMA_W_SHIFT(p->chroma_format_idc), hs = XEVE_GET_CHROMA_H_SHIFT(p->chroma_format_idc);
-    memset(&pic, 0, sizeof(pic)), memset(&sh, 0, sizeof(sh)), memset(&tile, 0, sizeof(tile));
+    memset(&pic, 0, sizeof(pic)), memset(&sh, 0, sizeof(sh)), memset(tile, 0, sizeof(tile));
     ctx->w = p->w, ctx->h = p->h, ctx->w_scu = p->w_scu, ctx->h_scu = p->h_scu, ctx->f_scu = p->w_scu * p->h_scu;
     ctx->log2_max_cuwh = p->log2_max_cuwh, ctx->max_cuwh = 1 << p->log2_max_cuwh;
     ctx->log2_culine = p->log2_max_cuwh - MIN_CU_LOG2;
@@ -49,7 +60,21 @@ int refdrv_deblock_picture(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_sc
     ctx->map_unrefined_mv = calloc(ctx->f_scu, sizeof(s16) * REFP_NUM * MV_D);
     ctx->map_tidx = calloc(ctx->f_scu, 1);
     ctx->map_cu_data = calloc(ctx->f_lcu, sizeof(XEVE_CU_DATA));
-    ctx->tile = &tile, tile.ctba_rs_first = 0, tile.w_ctb = ctx->w_lcu, tile.h_ctb = ctx->h_lcu;
+    ctx->tile = tile;
+    {
+        const int sx = split_x_lcu > 0 && split_x_lcu < ctx->w_lcu ? split_x_lcu : ctx->w_lcu, sy = split_y_lcu > 0 && split_y_lcu < ctx->h_lcu ? split_y_lcu : ctx->h_lcu;
+        const int x0[2] = {0, sx}, x1[2] = {sx, ctx->w_lcu}, y0[2] = {0, sy}, y1[2] = {sy, ctx->h_lcu};
+        for(int ty = 0; ty < 2; ty++)
+            for(int tx = 0; tx < 2; tx++) {
+                if(x0[tx] >= x1[tx] || y0[ty] >= y1[ty]) continue;
+                tile[ntile].ctba_rs_first = y0[ty] * ctx->w_lcu + x0[tx], tile[ntile].w_ctb = x1[tx] - x0[tx], tile[ntile].h_ctb = y1[ty] - y0[ty];
+                const int per = ctx->max_cuwh >> MIN_CU_LOG2;
+                for(int j = y0[ty] * per; j < y1[ty] * per && j < ctx->h_scu; j++)
+                    for(int i = x0[tx] * per; i < x1[tx] * per && i < ctx->w_scu; i++) ctx->map_tidx[j * ctx->w_scu + i] = (u8)ntile;
+                ntile++;
+            }
+        if(map_tidx_out) memcpy(map_tidx_out, ctx->map_tidx, ctx->f_scu);
+    }
     ctx->sh = &sh, sh.qp_u_offset = p->qp_u_offset, sh.qp_v_offset = p->qp_v_offset;
     ctx->sps.bit_depth_luma_minus8 = p->bit_depth_luma - 8, ctx->sps.bit_depth_chroma_minus8 = p->bit_depth_chroma - 8;
     ctx->sps.chroma_format_idc = p->chroma_format_idc;
@@ -63,10 +88,10 @@ int refdrv_deblock_picture(pel *y, pel *u, pel *v, int s_l, int s_c, u32 *map_sc
     for(int ly = 0; ly < ctx->h_lcu; ly++)
         for(int lx = 0; lx < ctx->w_lcu; lx++) set_tree(ctx, ly * ctx->w_lcu + lx, lx << p->log2_max_cuwh, ly << p->log2_max_cuwh, ctx->max_cuwh, 0, 0);
     core->ctx = ctx;
-    for(int is_hor_edge = 0; is_hor_edge <= 1; is_hor_edge++) { /* xeve_loop_filter, one slice, one tile */
+    for(int is_hor_edge = 0; is_hor_edge <= 1; is_hor_edge++) { /* xeve_loop_filter, one slice, tile after tile */
         for(u32 i = 0; i < ctx->f_scu; i++) MCU_CLR_COD(ctx->map_scu[i]);
         core->deblock_is_hor = is_hor_edge;
-        xeve_deblock(ctx, &pic, 0, 0, core);
+        for(int t = 0; t < ntile; t++) xeve_deblock(ctx, &pic, t, 0, core);
     }
     free(ctx->map_unrefined_mv), free(ctx->map_tidx), free(ctx->map_cu_data), free(ctx), free(core);
     return 0;

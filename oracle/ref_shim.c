@@ -34,7 +34,7 @@ static void shim_recon(XEVE_CTX *ctx, XEVE_CORE *core, s16 *coef, pel *pred, int
  * xeve_hip_picbuf_expand_host.  The adapter hands over what xeve_loop_filter would read from the context and leaves the side effects
  * the reference's filter leaves (COD bits set, map_unrefined_mv = map_mv, slice offsets copied into the picture). */
 typedef struct { int w, h, w_scu, h_scu, log2_max_cuwh, bit_depth_luma, bit_depth_chroma, chroma_format_idc, qp_u_offset, qp_v_offset, qp_chroma[2][100]; } hip_df_params;
-static int (*hip_deblock_host)(pel *, pel *, pel *, int, int, int, int, const u32 *, const u32 *, const s8 *, const s16 *, const hip_df_params *);
+static int (*hip_deblock_host)(pel *, pel *, pel *, int, int, int, int, const u32 *, const u32 *, const u8 *, const s8 *, const s16 *, const hip_df_params *);
 static int (*hip_expand_host)(pel *, pel *, pel *, int, int, int, int, int, int, int, int, int);
 static const char *(*hip_err)(void);
 static unsigned long long df_calls, pad_calls;
@@ -52,7 +52,7 @@ static int shim_loop_filter(XEVE_CTX *ctx, XEVE_CORE *core)
         for(int i = 0; i < 100; i++) p.qp_chroma[c][i] = i <= 57 + 6 * bc ? ctx->qp_chroma_dynamic_ext[c][i] : 0;
     for(u32 i = 0; i < ctx->f_scu; i++) /* xeve_deblock (xeve_df.c:545-556) */
         if(!MCU_GET_DMVRF(ctx->map_scu[i])) memcpy(ctx->map_unrefined_mv[i], ctx->map_mv[i], sizeof(ctx->map_mv[i]));
-    if(hip_deblock_host(pic->y, pic->u, pic->v, pic->s_l, pic->s_c, pic->pad_l, pic->pad_c, ctx->map_scu, ctx->map_cu_mode, (const s8 *)ctx->map_refi,
+    if(hip_deblock_host(pic->y, pic->u, pic->v, pic->s_l, pic->s_c, pic->pad_l, pic->pad_c, ctx->map_scu, ctx->map_cu_mode, ctx->map_tidx, (const s8 *)ctx->map_refi,
                         (const s16 *)ctx->map_unrefined_mv, &p) != 0) {
         fprintf(stderr, "[xeve_hip_shim] deblock: %s\n", hip_err());
         abort();

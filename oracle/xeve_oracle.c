@@ -1136,7 +1136,11 @@ typedef struct df_ctx {
     const int8_t *refi;
     const int16_t *mv;
     const xo_deblock_params *p;
+    const uint8_t *tidx; /* ctx->map_tidx or NULL (one tile) */
 } df_ctx;
+
+/* no_boundary of xeve_deblock_cu_hor / _ver (xeve_df.c:296-302,386-391,419-427) with boundary_filtering = 0 (xeve_df.c:528): the two units share a tile */
+static int df_same_tile(const df_ctx *c, int a, int b) { return !c->tidx || c->tidx[a] == c->tidx[b]; }
 
 /* one 4-sample edge segment: luma + both chroma planes; `cur` = the unit whose QP is used, `nb` = the unit across the edge */
 static void df_segment(const df_ctx *c, int cur, int nb, int x, int y, int hor)
@@ -1162,13 +1166,13 @@ static void df_cu(const df_ctx *c, int x, int y, int cuw, int cuh, int hor)
 {
     int w_scu = c->p->w_scu, t = (x >> 2) + (y >> 2) * w_scu, w = cuw >> 2, h = cuh >> 2;
     if(hor) {
-        if(y > 0)
+        if(y > 0 && df_same_tile(c, t, t - w_scu))
             for(int i = 0; i < w; i++) df_segment(c, t + i, t + i - w_scu, x + 4 * i, y, 1);
     }
     else {
-        if(x > 0 && SCU_COD(c->map_scu[t - 1]))
+        if(x > 0 && SCU_COD(c->map_scu[t - 1]) && df_same_tile(c, t, t - 1))
             for(int i = 0; i < h; i++) df_segment(c, t + i * w_scu, t + i * w_scu - 1, x, y + 4 * i, 0);
-        if(x + cuw < c->p->w && SCU_COD(c->map_scu[t + w])) /* right neighbour already filtered in this pass */
+        if(x + cuw < c->p->w && SCU_COD(c->map_scu[t + w]) && df_same_tile(c, t, t + w)) /* right neighbour already filtered in this pass */
             for(int i = 0; i < h; i++) df_segment(c, t + i * w_scu + w, t + i * w_scu + w - 1, x + cuw, y + 4 * i, 0);
     }
     for(int j = 0; j < h; j++)
@@ -1193,7 +1197,15 @@ static void df_tree(const df_ctx *c, int x, int y, int size, int hor)
 void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode,
                         const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p)
 {
-    df_ctx c = {y, u, v, s_l, s_c, p->chroma_format_idc <= 2, p->chroma_format_idc <= 1, map_scu, map_cu_mode, map_refi, map_mv, p};
+    xo_deblock_picture_tiles(y, u, v, s_l, s_c, map_scu, map_cu_mode, NULL, map_refi, map_mv, p);
+}
+
+/* ... with the tile map (ctx->map_tidx): the reference filters tile after tile (xeve_loop_filter -> xeve_deblock per tile, xeve_enc.c:2355-2415), each in
+ * raster CTU order; since no edge between two tiles is ever filtered the tiles are independent and one raster walk over the picture gives the same planes */
+void xo_deblock_picture_tiles(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode, const uint8_t *map_tidx,
+                              const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p)
+{
+    df_ctx c = {y, u, v, s_l, s_c, p->chroma_format_idc <= 2, p->chroma_format_idc <= 1, map_scu, map_cu_mode, map_refi, map_mv, p, map_tidx};
     int ctu = 1 << p->log2_max_cuwh;
     for(int hor = 0; hor <= 1; hor++) { /* xeve_loop_filter: vertical edges of the whole picture first */
         for(int i = 0; i < p->w_scu * p->h_scu; i++) map_scu[i] &= 0x7FFFFFFFu;

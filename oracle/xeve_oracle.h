@@ -250,6 +250,8 @@ typedef struct xo_deblock_params {
  * scratch, as in the reference. */
 void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode,
                         const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p);
+void xo_deblock_picture_tiles(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode, const uint8_t *map_tidx,
+                              const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p);
 /* xeve_picbuf_expand (xeve_util.c:190-248) on one plane: a = sample (0, 0) */
 void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp);
 

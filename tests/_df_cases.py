@@ -65,6 +65,25 @@ def make_case(r, w, h, bd=10, idc=1, min_cu=4, log2_ctu=6):
     return dict(planes=planes, s_l=s_l, s_c=s_c, map_scu=map_scu, map_cu_mode=map_cu_mode, refi=refi, mv=mv, p=p, ws=ws, hs=hs)
 
 
+def tile_map(case, split_x_lcu, split_y_lcu):
+    """ctx->map_tidx of a picture cut into up to 2 x 2 tiles after split_x_lcu CTU columns / split_y_lcu CTU rows (0 = no cut), tiles numbered in raster
+    order (xeve_set_tile_info)"""
+    p = case["p"]
+    per = (1 << p.log2_max_cuwh) // 4
+    w_lcu, h_lcu = (p.w + (1 << p.log2_max_cuwh) - 1) >> p.log2_max_cuwh, (p.h + (1 << p.log2_max_cuwh) - 1) >> p.log2_max_cuwh
+    sx = split_x_lcu if 0 < split_x_lcu < w_lcu else w_lcu
+    sy = split_y_lcu if 0 < split_y_lcu < h_lcu else h_lcu
+    t = np.zeros((p.h_scu, p.w_scu), np.uint8)
+    n = 0
+    for (y0, y1) in ((0, sy), (sy, h_lcu)):
+        for (x0, x1) in ((0, sx), (sx, w_lcu)):
+            if x0 >= x1 or y0 >= y1:
+                continue
+            t[y0 * per:y1 * per, x0 * per:x1 * per] = n
+            n += 1
+    return t.reshape(-1).copy()
+
+
 def origin(case, c):
     """element offset of sample (0, 0) in plane c"""
     return PAD * (case["s_l"] if c == 0 else case["s_c"]) + PAD

@@ -383,6 +383,8 @@ def ref_df():
         L = C.CDLL(REF_DF_SO)
         L.refdrv_deblock_picture.restype = c_int
         L.refdrv_deblock_picture.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams)]
+        L.refdrv_deblock_picture_tiles.restype = c_int
+        L.refdrv_deblock_picture_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams), c_int, c_int, c_void_p]
         L.refdrv_picbuf_expand.restype = None
         L.refdrv_picbuf_expand.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 9
         _ref_df = L
@@ -393,6 +395,8 @@ def oracle_df():
     L = oracle()
     L.xo_deblock_picture.restype = None
     L.xo_deblock_picture.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams)]
+    L.xo_deblock_picture_tiles.restype = None
+    L.xo_deblock_picture_tiles.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(DeblockParams)]
     L.xo_picbuf_expand.restype = None
     L.xo_picbuf_expand.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     return L

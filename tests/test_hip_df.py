@@ -3,14 +3,14 @@ the pinned oracle, through the C-ABI."""
 import numpy as np
 import pytest
 
-from _df_cases import PAD, make_case, origin
+from _df_cases import PAD, make_case, origin, tile_map
 from _df_golden import golden, golden_pad
 from _libs import oracle_df, ptr
 
 pytestmark = pytest.mark.gpu
 
 
-def run_hip(c):
+def run_hip(c, tidx=None):
     import torch
 
     import xeve_amd
@@ -22,7 +22,7 @@ def run_hip(c):
     planes = [torch.from_numpy(p.copy()).to(dev) for p in c["planes"]]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
     D.deblock(planes, [origin(c, k) for k in range(3)], c["s_l"], c["s_c"], up(c["map_scu"]), up(c["map_cu_mode"]), up(c["refi"]), up(c["mv"]),
-              lib.DeblockParams.from_buffer_copy(bytes(c["p"])))
+              lib.DeblockParams.from_buffer_copy(bytes(c["p"])), map_tidx=None if tidx is None else up(tidx))
     torch.cuda.synchronize()
     return [p.cpu().numpy() for p in planes]
 
@@ -51,6 +51,24 @@ def test_hip_deblock_vs_oracle(w, h, bd, idc, min_cu):
         got = run_hip(c)
         for k in range(3):
             assert np.array_equal(got[k], e[k]), (rep, k, np.argwhere(got[k] != e[k])[:4])
+
+
+@pytest.mark.parametrize("w,h,min_cu,sx,sy", [(256, 128, 8, 2, 0), (320, 200, 4, 3, 2), (1920, 1080, 8, 15, 8)])
+def test_hip_deblock_with_tiles_vs_oracle(w, h, min_cu, sx, sy):
+    """edges between units of different tiles stay unfiltered (ctx->map_tidx; the oracle's tile path is pinned to the reference's per-tile loop)"""
+    O = oracle_df()
+    r = np.random.default_rng(w + h + sx + sy)
+    c = make_case(r, w, h, 10, 1, min_cu)
+    tid = tile_map(c, sx, sy)
+    e = [p.copy() for p in c["planes"]]
+    ms = c["map_scu"].copy()
+    O.xo_deblock_picture_tiles(ptr(e[0], origin(c, 0)), ptr(e[1], origin(c, 1)), ptr(e[2], origin(c, 2)), c["s_l"], c["s_c"], ptr(ms), ptr(c["map_cu_mode"]), ptr(tid),
+                               ptr(c["refi"]), ptr(c["mv"]), c["p"])
+    got = run_hip(c, tid)
+    for k in range(3):
+        assert np.array_equal(got[k], e[k]), (k, np.argwhere(got[k] != e[k])[:4])
+    one = run_hip(c)
+    assert any(not np.array_equal(one[k], got[k]) for k in range(3))
 
 
 def test_hip_deblock_runs_of_4x4_cus():

@@ -48,6 +48,46 @@ def test_closed_gop_shards_concatenate_byte_identically(tmp_path):
 
 
 @needs_ref
+def test_shard_driver_concatenates_byte_identically(tmp_path):
+    """xeve_amd.gop.run_shards: one encoder process per "device" slot (here plain reference processes, two side by side), shard bitstreams concatenated by
+    the driver == the monolithic encode == the committed golden"""
+    from xeve_amd import gop
+
+    w, h, n, seed, extra = CASES["tiny_closed_gop"]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "-m", "1", "-v", "0"] + list(extra)
+    out = str(tmp_path / "sharded.evc")
+    r = gop.run_shards(cmd, yuv, out, n, 4, devices=[0, 1])
+    import hashlib
+    data = open(out, "rb").read()
+    assert r["bytes"] == len(data) and [g for g, _, _ in r["shards"]] == [0, 1] and {d for _, d, _ in r["shards"]} == {0, 1}
+    assert (hashlib.md5(data).hexdigest(), len(data)) == (GOLD["tiny_closed_gop"]["md5"], GOLD["tiny_closed_gop"]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_shard_driver_with_the_gpu_routes_on(tmp_path):
+    """the same driver with the encoder processes bound to the GPU (HIP_VISIBLE_DEVICES per process, whole inter analysis + resident pictures through the
+    shim): two shards on the one GPU of this box, byte-identical to the monolithic golden"""
+    import hashlib
+
+    from _e2e import HIP_LIB
+    from xeve_amd import gop
+
+    w, h, n, seed, extra = CASES["tiny_closed_gop"]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "-m", "1", "-v", "0"] + list(extra)
+    env = {"LD_PRELOAD": SHIM, "XEVE_HIP_LIB": HIP_LIB, "XEVE_HIP_SHIM_INTER": "1", "XEVE_HIP_SHIM_RESIDENT": "1"}
+    out = str(tmp_path / "sharded.evc")
+    r = gop.run_shards(cmd, yuv, out, n, 4, devices=[0], per_device=2, env=env)
+    data = open(out, "rb").read()
+    assert len(r["shards"]) == 2
+    assert (hashlib.md5(data).hexdigest(), len(data)) == (GOLD["tiny_closed_gop"]["md5"], GOLD["tiny_closed_gop"]["bytes"])
+
+
+@needs_ref
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny_ldb_fast", "tiny_ra_medium", "tiny_ldb_fast_2threads"])
 def test_bitstream_identical_with_hip_tables_installed(tmp_path, name):

@@ -78,20 +78,28 @@ __device__ __forceinline__ void df_segment(pel *buf, int n, int along, int acros
     }
 }
 
-template <bool HOR> __device__ __forceinline__ bool df_is_edge(const unsigned *__restrict__ map_cu_mode, const DfK &P, int sx, int sy)
+// an edge the reference filters: a CU boundary whose two sides lie in the SAME TILE (xeve_deblock_cu_hor / _ver: no_boundary =
+// map_tidx equal || boundary_filtering, and xeve_deblock always passes boundary_filtering = 0; xeve_df.c:296-302,386-391,528)
+template <bool HOR> __device__ __forceinline__ bool df_is_edge(const unsigned *__restrict__ map_cu_mode, const uint8_t *__restrict__ tidx, const DfK &P, int sx, int sy)
 {
     if(sx >= P.w_scu || sy >= P.h_scu) return false;
-    const unsigned m = map_cu_mode[sy * P.w_scu + sx];
-    if(HOR) return sy > 0 && (sy & ((1 << (((m >> 28) & 0xF) - 2)) - 1)) == 0; // MCU_GET_LOGH: top row of its CU
-    return sx > 0 && (sx & ((1 << (((m >> 24) & 0xF) - 2)) - 1)) == 0;         // MCU_GET_LOGW: left column of its CU
+    const int t = sy * P.w_scu + sx;
+    const unsigned m = map_cu_mode[t];
+    if(HOR) {
+        if(!(sy > 0 && (sy & ((1 << (((m >> 28) & 0xF) - 2)) - 1)) == 0)) return false; // MCU_GET_LOGH: top row of its CU
+        return !tidx || tidx[t] == tidx[t - P.w_scu];
+    }
+    if(!(sx > 0 && (sx & ((1 << (((m >> 24) & 0xF) - 2)) - 1)) == 0)) return false; // MCU_GET_LOGW: left column of its CU
+    return !tidx || tidx[t] == tidx[t - 1];
 }
 
 template <bool HOR>
 __global__ __launch_bounds__(256) void k_deblock(pel *__restrict__ y, pel *__restrict__ u, pel *__restrict__ v, const unsigned *__restrict__ map_scu,
-                                                 const unsigned *__restrict__ map_cu_mode, const int8_t *__restrict__ refi, const int16_t *__restrict__ mv, DfK P)
+                                                 const unsigned *__restrict__ map_cu_mode, const uint8_t *__restrict__ tidx, const int8_t *__restrict__ refi,
+                                                 const int16_t *__restrict__ mv, DfK P)
 {
     const int sx = blockIdx.x * 64 + (threadIdx.x & 63), sy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if(!df_is_edge<HOR>(map_cu_mode, P, sx, sy)) return;
+    if(!df_is_edge<HOR>(map_cu_mode, tidx, P, sx, sy)) return;
     const int t = sy * P.w_scu + sx, nb = HOR ? t - P.w_scu : t - 1;
     const unsigned m0 = map_scu[t], m1 = map_scu[nb];
     const int cls = df_class(m0, m1, refi, mv, t, nb), qp = (m0 >> 16) & 0x7F;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void k_deblock(pel *__restrict__ y, pel *__res
     if(!P.idc) return;
     // chroma.  The segment length follows the reference: W shift for horizontal, H shift for vertical edges (xeve_df.c:143,225)
     const bool chained = HOR ? P.hs != 0 : P.ws != 0; // edges of neighbouring units are 2 samples apart: order matters
-    if(chained && df_is_edge<HOR>(map_cu_mode, P, HOR ? sx : sx - 1, HOR ? sy - 1 : sy)) return; // not the head of its run
+    if(chained && df_is_edge<HOR>(map_cu_mode, tidx, P, HOR ? sx : sx - 1, HOR ? sy - 1 : sy)) return; // not the head of its run
     const int maxc = (1 << (P.bc + 8)) - 1, nline = HOR ? 4 >> P.ws : 4 >> P.hs;
     int cx = sx, cy = sy, ct = t, ccls = cls, cqp = qp;
     for(;;) {
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void k_deblock(pel *__restrict__ y, pel *__res
         df_segment(v + off, nline, HOR ? 1 : P.s_c, HOR ? P.s_c : 1, st_v, maxc, true);
         if(!chained) break;
         if(HOR) cy++; else cx++;
-        if(!df_is_edge<HOR>(map_cu_mode, P, cx, cy)) break;
+        if(!df_is_edge<HOR>(map_cu_mode, tidx, P, cx, cy)) break;
         ct = cy * P.w_scu + cx;
         const int cnb = HOR ? ct - P.w_scu : ct - 1;
         const unsigned n0 = map_scu[ct], n1 = map_scu[cnb];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_deblock(pel *__restrict__ y, pel *__res
 }
 
 extern "C" int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, const uint32_t *map_scu, const uint32_t *map_cu_mode,
-                                const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *p, void *stream)
+                                const uint8_t *map_tidx, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *p, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(p && y && map_scu && map_cu_mode && map_refi && map_mv);
@@ -146,8 +154,8 @@ extern "C" int xeve_hip_deblock(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *
         }
     const dim3 grid((P.w_scu + 63) / 64, (P.h_scu + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    k_deblock<false><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_refi, map_mv, P); // vertical edges of the whole picture first
-    k_deblock<true><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_refi, map_mv, P);
+    k_deblock<false><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_tidx, map_refi, map_mv, P); // vertical edges of the whole picture first
+    k_deblock<true><<<grid, 256, 0, st>>>(y, u, v, map_scu, map_cu_mode, map_tidx, map_refi, map_mv, P);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
@@ -203,7 +211,8 @@ static int stage_plane(pel **d, const pel *h0, size_t elems)
 }
 
 extern "C" int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_pel *v, int s_l, int s_c, int pad_l, int pad_c, const uint32_t *map_scu,
-                                     const uint32_t *map_cu_mode, const int8_t *map_refi, const int16_t *map_mv, const xeve_hip_deblock_params *p)
+                                     const uint32_t *map_cu_mode, const uint8_t *map_tidx, const int8_t *map_refi, const int16_t *map_mv,
+                                     const xeve_hip_deblock_params *p)
 {
     XH_ENTER();
     XH_REQUIRE(p && y && map_scu && map_cu_mode && map_refi && map_mv && pad_l >= 0 && pad_c >= 0);
@@ -212,13 +221,14 @@ extern "C" int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_
     const size_t el = (size_t)s_l * (p->h + 2 * pad_l), ec = idc ? (size_t)s_c * ((p->h >> hs) + 2 * pad_c) : 0;
     const size_t ol = (size_t)pad_l * s_l + pad_l, oc = (size_t)pad_c * s_c + pad_c;
     pel *d[3] = {nullptr, nullptr, nullptr};
-    void *m[4] = {nullptr, nullptr, nullptr, nullptr};
-    const void *hm[4] = {map_scu, map_cu_mode, map_refi, map_mv};
-    const size_t ms[4] = {n * 4, n * 4, n * 2, n * 8};
+    void *m[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void *hm[5] = {map_scu, map_cu_mode, map_refi, map_mv, map_tidx};
+    const size_t ms[5] = {n * 4, n * 4, n * 2, n * 8, n};
     int rc = stage_plane(&d[0], y - ol, el);
     if(rc == XEVE_HIP_OK && idc) rc = stage_plane(&d[1], u - oc, ec);
     if(rc == XEVE_HIP_OK && idc) rc = stage_plane(&d[2], v - oc, ec);
-    for(int i = 0; i < 4 && rc == XEVE_HIP_OK; i++) {
+    for(int i = 0; i < 5 && rc == XEVE_HIP_OK; i++) {
+        if(!hm[i]) continue; // (map_tidx == NULL: one tile)
         if(hipMalloc(&m[i], ms[i]) != hipSuccess || hipMemcpy(m[i], hm[i], ms[i], hipMemcpyHostToDevice) != hipSuccess) {
             xh_set_error("staging the deblocking maps failed");
             rc = XEVE_HIP_ERR_DEVICE;
@@ -226,7 +236,7 @@ extern "C" int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_
     }
     if(rc == XEVE_HIP_OK)
         rc = xeve_hip_deblock(d[0] + ol, idc ? d[1] + oc : nullptr, idc ? d[2] + oc : nullptr, s_l, s_c, (const uint32_t *)m[0], (const uint32_t *)m[1],
-                              (const int8_t *)m[2], (const int16_t *)m[3], p, nullptr);
+                              (const uint8_t *)m[4], (const int8_t *)m[2], (const int16_t *)m[3], p, nullptr);
     if(rc == XEVE_HIP_OK) {
         if(hipMemcpy(y - ol, d[0], el * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess) rc = XEVE_HIP_ERR_DEVICE;
         if(idc && (hipMemcpy(u - oc, d[1], ec * sizeof(pel), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -234,7 +244,7 @@ extern "C" int xeve_hip_deblock_host(xeve_hip_pel *y, xeve_hip_pel *u, xeve_hip_
         if(rc != XEVE_HIP_OK) xh_set_error("copying the filtered planes back failed");
     }
     for(int i = 0; i < 3; i++) (void)hipFree(d[i]);
-    for(int i = 0; i < 4; i++) (void)hipFree(m[i]);
+    for(int i = 0; i < 5; i++) (void)hipFree(m[i]);
     (void)ws;
     return rc;
 }

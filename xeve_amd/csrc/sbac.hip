@@ -287,7 +287,13 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
 #define FILL 16 // events fetched per refill
 #define BURST 8 // MPS bins a lane may take in one go after its general step
 
-template <bool FULL>
+// REGCTX (sps_cm_init_flag 0, i.e. the Baseline profile): a component type -- luma / chroma -- then uses exactly five models (run first / rest, level
+// first / rest, last; xeve_eco.c:722-760), and they live PACKED IN THREE REGISTERS (A = run, B = level: first model in the low half, rest model in the high
+// half; C = last in the high half) instead of LDS: selecting and writing back a model is a handful of VALU operations, where the LDS round trip was two
+// exposed ~100-cycle latencies per bin at the one wave per SIMD the large-CU levels run at.  The next event is read from the LDS ring at the TOP of the
+// step that may consume the current one, so that its latency hides under the step.  The automaton is: unary value (run, then level: a first bin on the
+// first model, further bins on the rest model), sign (bypass), last flag.
+template <bool FULL, bool REGCTX>
 __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs,
                                                 CuBitsK P, const unsigned *__restrict__ ev, const int *__restrict__ nev,
                                                 unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units)
@@ -345,6 +351,21 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     // Two compiled forms of the loop: with and without the burst.  The burst pays when zero runs (or levels) are long; where most bins
     // are first bins, signs and last flags its vote and code only lengthen the serial step.  Each wave picks once, from the mean
     // number of scan positions per event of its jobs.
+    // ---- REGCTX state
+    unsigned cA = 0, cB = 0, cC = 0, cur = 0, u = 0;
+    int      p = 0, f = 1; // p: 0 run, 1 level, 2 sign, 3 last flag; f: the next unary bin is the first of its value
+    bool     have = false;
+    auto ctx_load = [&](int c) {
+        cA = (unsigned)s_ctx[XEVE_HIP_CTX_RUN + 2 * c][lane] | ((unsigned)s_ctx[XEVE_HIP_CTX_RUN + 2 * c + 1][lane] << 16);
+        cB = (unsigned)s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c][lane] | ((unsigned)s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c + 1][lane] << 16);
+        cC = (unsigned)s_ctx[XEVE_HIP_CTX_LAST + c][lane] << 16;
+    };
+    auto ctx_store = [&](int c) {
+        s_ctx[XEVE_HIP_CTX_RUN + 2 * c][lane] = (uint16_t)cA, s_ctx[XEVE_HIP_CTX_RUN + 2 * c + 1][lane] = (uint16_t)(cA >> 16);
+        s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c][lane] = (uint16_t)cB, s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c + 1][lane] = (uint16_t)(cB >> 16);
+        s_ctx[XEVE_HIP_CTX_LAST + c][lane] = (uint16_t)(cC >> 16);
+    };
+    if(REGCTX && total > 0) ctx_load(ch);
     auto loop = [&](auto with_burst) {
     constexpr bool WB = decltype(with_burst)::value;
     while(e < total) {
@@ -357,7 +378,65 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
         for(int i = 0; i < FILL; i++) // issue the next one
             if(i < cnt) buf[i] = fetch(filled + i);
 
+        if constexpr(REGCTX) {
+            if(!have) cur = s_ring[e & (RING - 1)][lane], u = (cur >> 16) & 0xFFF, have = true; // (first window: the first event has just reached the ring)
+        }
         for(int it = 0; it < WIN; it++) {
+            if constexpr(REGCTX) {
+            if(e < total) {
+                const unsigned pre = s_ring[(e + 1) & (RING - 1)][lane]; // the next event: landed by the time this step ends
+                const unsigned lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1, at_end = (cur >> 28) & 1;
+                const bool unary = p < 2, ub = u != 0;
+                const unsigned bin = unary ? (unsigned)ub : (p == 2 ? sign : (unsigned)(numsig == 0));
+                const unsigned w = p == 0 ? cA : (p == 1 ? cB : cC);
+                const unsigned sh = (unary && f) ? 0u : 16u;
+                const unsigned m = (w >> sh) & 0xFFFFu;
+                const unsigned m1 = sb_encode<FULL>(s, m, bin, p == 2); // (bypass hands the model back unchanged)
+                const unsigned nw = w ^ ((m ^ m1) << sh);
+                cA = p == 0 ? nw : cA, cB = p == 1 ? nw : cB, cC = p == 3 ? nw : cC;
+                // transitions: a 1 of a unary value stays (one less to go, rest model); its 0 moves on; the sign ends the event at the last scan
+                // position (no last flag there, xeve_eco.c:744-746), else the last flag does
+                const bool stay = unary && ub, adv = p == 3 || (p == 2 && at_end), to_level = p == 0 && !ub;
+                numsig -= (int)(p == 2);
+                const int np = stay ? p : (p == 0 ? 1 : (p == 1 ? 2 : ((p == 2 && !at_end) ? 3 : 0)));
+                e += (int)adv;
+                cur = adv ? pre : cur;
+                u = stay ? u - 1 : (to_level ? lev1 : (adv ? (pre >> 16) & 0xFFF : u));
+                f = stay ? 0 : ((to_level || adv) ? 1 : f);
+                p = np;
+                const bool newc = adv && (e == b1 || e == b2);
+                numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
+                const int nch = e >= b1 ? 1 : 0;
+                if(__ballot(newc && nch != ch)) { // luma -> chroma: swap the packed models (once per job at most; Cb -> Cr keeps them)
+                    if(newc && nch != ch) ctx_store(ch), ctx_load(nch);
+                }
+                ch = nch;
+                if constexpr(WB) { // burst: up to BURST further 1s of a unary value on the rest model, while that model's MPS is 1 (see below)
+                    const bool can = p < 2 && f == 0 && u >= 1;
+                    const bool worth = 2 * __popcll(__ballot(can && u >= 6)) >= __popcll(__ballot(true));
+                    if(worth && can) {
+                        const unsigned wb = p == 0 ? cA : cB, mb = wb >> 16;
+                        if(mb & 1) {
+                            unsigned st = mb >> 1, R = s.range;
+                            const unsigned steps = u < BURST ? u : BURST;
+#pragma unroll
+                            for(unsigned q = 0; q < BURST; q++)
+                                if(q < steps) {
+                                    unsigned lps = (st * R) >> 9;
+                                    lps = lps < 437 ? 437 : lps;
+                                    R -= lps, st -= (st + 16) >> 5;
+                                    const unsigned shf = R < 8192;
+                                    R <<= shf, s.shifts += shf;
+                                }
+                            s.range = R, s.bins += steps, u -= steps;
+                            const unsigned nb2 = (wb & 0xFFFFu) | (((st << 1) | 1u) << 16);
+                            cA = p == 0 ? nb2 : cA, cB = p == 1 ? nb2 : cB;
+                        }
+                    }
+                }
+            }
+            }
+            else
             if(e < total) {
                 // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag.
                 // Written without branches on purpose: 64 lanes are in 64 different phases, and any `if` some lane takes is paid by all.
@@ -429,6 +508,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     }
     if(burst) loop(std::true_type{});
     else loop(std::false_type{});
+    if(REGCTX && total > 0) ctx_store(ch);
 
     bits[j] = s.shifts;
     if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave.  Lanes past the job list have left, so the sum goes through one
@@ -528,8 +608,12 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     {
         XhProf prof(XH_PROF_CU_BITS, st);
         unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS);
-        if(full) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
-        else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        static const int use_reg = getenv("XEVE_HIP_SBAC_REG") ? atoi(getenv("XEVE_HIP_SBAC_REG")) : 1; // developer switch (measurement)
+        const bool reg = use_reg && P.cm_init == 0;
+        if(full && reg) k_cu_bits<true, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        else if(full) k_cu_bits<true, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        else if(reg) k_cu_bits<false, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        else k_cu_bits<false, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

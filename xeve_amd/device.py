@@ -305,11 +305,13 @@ def _ptr_at(t, elem_off):
     return C.c_void_p(t.data_ptr() + int(elem_off) * t.element_size())
 
 
-def deblock(planes, origins, s_l, s_c, map_scu, map_cu_mode, map_refi, map_mv, params):
+def deblock(planes, origins, s_l, s_c, map_scu, map_cu_mode, map_refi, map_mv, params, map_tidx=None):
     """in-loop deblocking of one picture in place (xeve_hip_deblock).  planes: three int16 tensors; origins: element offsets of
-    sample (0, 0) in each; maps: device tensors laid out like the reference's per-4x4-unit arrays; params: lib.DeblockParams"""
+    sample (0, 0) in each; maps: device tensors laid out like the reference's per-4x4-unit arrays (map_tidx: uint8 tile index per unit, None = one
+    tile); params: lib.DeblockParams"""
     _lib.check(_lib.load().xeve_hip_deblock(_ptr_at(_i16(planes[0]), origins[0]), _ptr_at(_i16(planes[1]), origins[1]), _ptr_at(_i16(planes[2]), origins[2]),
-                                            s_l, s_c, _ptr(map_scu), _ptr(map_cu_mode), _ptr(map_refi), _ptr(map_mv), C.byref(params), _stream()))
+                                            s_l, s_c, _ptr(map_scu), _ptr(map_cu_mode), _ptr(map_tidx) if map_tidx is not None else None, _ptr(map_refi), _ptr(map_mv),
+                                            C.byref(params), _stream()))
 
 
 def picbuf_expand(planes, origins, s_l, s_c, w_l, h_l, w_c, h_c, exp_l, exp_c, chroma_format_idc=1):

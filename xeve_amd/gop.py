@@ -39,3 +39,80 @@ def concat_order(per_rank: List[List[Shard]]) -> List[Shard]:
     if [s.gop for s in allsh] != list(range(len(allsh))):
         raise ValueError("shards do not tile the sequence exactly once")
     return allsh
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the shard driver: one encoder process per GPU, each encoding its closed GOPs, the host concatenating the bitstreams
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_shards(encoder_cmd, yuv, out, total_frames, keyint, devices, env=None, work_dir=None, per_device=1, timeout=None):
+    """Encode `yuv` as independent closed GOPs, one encoder PROCESS per entry of `devices` (several GOPs of a device one after the other,
+    `per_device` processes side by side on each), and concatenate the shard bitstreams in GOP order into `out`.
+
+    encoder_cmd : argv of the encoder up to the shard-specific options, e.g. [xeveb_app, "-i", yuv, "-w", "3840", "-h", "2160", "--preset",
+                  "medium", "--closed-gop", "-I", "8", "-m", "1"] -- "--seek S --frames K -o PART" are appended per shard.  The encoder is the
+                  reference's own (the host code stays C, BASELINE.json north_star); the GPU comes in through the environment: `env` is
+                  merged into every process's environment (e.g. LD_PRELOAD of the integration shim, XEVE_HIP_LIB, XEVE_HIP_SHIM_*) and the
+                  process for device d additionally gets HIP_VISIBLE_DEVICES=d and XEVE_HIP_DEVICE=0, so every process sees exactly ONE GPU:
+                  the process-wide dispatch tables of the reference (src_base/xeve_sad.c:34-37) bind one process to one GPU.
+    There is no exchange between the processes at all (no RCCL, nothing over xGMI): the only joint operation is the concatenation.
+    Returns {"bytes": n, "shards": [(gop, device, seconds)], "seconds": wall, "fps": frames / wall}."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    import time
+
+    shards = plan(total_frames, keyint)
+    if not shards:
+        raise ValueError("nothing to encode")
+    slots = [d for d in devices for _ in range(per_device)]
+    if not slots:
+        raise ValueError("no device given")
+    own_dir = work_dir is None
+    work_dir = work_dir or tempfile.mkdtemp(prefix="xeve_shards_")
+    queues = {i: [s for s in shards if s.gop % len(slots) == i] for i in range(len(slots))}  # GOP g -> slot g mod n, as shards_for_rank
+    running, done, t0 = {}, [], time.perf_counter()
+
+    def start(i):
+        if not queues[i]:
+            return
+        s = queues[i].pop(0)
+        part = os.path.join(work_dir, "gop%06d.evc" % s.gop)
+        e = dict(os.environ)
+        e.update(env or {})
+        e["HIP_VISIBLE_DEVICES"], e["XEVE_HIP_DEVICE"] = str(slots[i]), "0"
+        p = subprocess.Popen(list(encoder_cmd) + app_args(s) + ["-o", part], env=e, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        running[i] = (p, s, part, time.perf_counter())
+
+    try:
+        for i in range(len(slots)):
+            start(i)
+        while running:
+            for i in list(running):
+                p, s, part, ts = running[i]
+                if p.poll() is None:
+                    if timeout and time.perf_counter() - t0 > timeout:
+                        raise TimeoutError("shard encode exceeded %s s" % timeout)
+                    continue
+                err = p.stderr.read()
+                if p.returncode != 0 or not os.path.exists(part):
+                    raise RuntimeError("encoder failed on GOP %d (device %s, rc %s): %s" % (s.gop, slots[i], p.returncode, err[-800:]))
+                done.append((s.gop, slots[i], time.perf_counter() - ts, part))
+                del running[i]
+                start(i)
+            time.sleep(0.02)
+        wall = time.perf_counter() - t0
+        done.sort()
+        if [g for g, _, _, _ in done] != list(range(len(shards))):
+            raise RuntimeError("shards do not tile the sequence exactly once")
+        n = 0
+        with open(out, "wb") as f:
+            for _, _, _, part in done:
+                with open(part, "rb") as g:
+                    n += f.write(g.read())
+        return {"bytes": n, "shards": [(g, d, round(t, 3)) for g, d, t, _ in done], "seconds": wall, "fps": total_frames / wall}
+    finally:
+        for p, _, _, _ in running.values():
+            p.kill()
+        if own_dir:
+            shutil.rmtree(work_dir, ignore_errors=True)

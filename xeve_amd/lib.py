@@ -142,8 +142,8 @@ FUNCTIONS = {
     "xeve_hip_rdoq_bit_est": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_rdoq_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
-    "xeve_hip_deblock": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "xeve_hip_deblock_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_deblock": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_deblock_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_picbuf_expand_host": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9),
     "xeve_hip_picbuf_expand": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "xeve_hip_mc_cu_workspace": (C.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
