@@ -14,6 +14,8 @@
 // without a host round trip.  CUs whose skip residual is below the skip_th threshold stop after the skip mode in the reference; here they
 // ride along (skip_th is 0 in every preset, so this only concerns CUs with a perfect skip prediction) and are masked in the decision.
 #include <cstring>
+#include <cstdlib>
+#include <vector>
 #include "xh_common.h"
 
 #define MAXR XEVE_HIP_MAX_REFP
@@ -639,14 +641,33 @@ extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t 
 // One stream, one device arena (job | state | result | coefficients | reconstruction | prediction | exit state | workspace) and one pinned
 // host mirror of the small records per encoder thread: a call is one upload of (job, state), the launches, one download of the outputs.
 namespace {
+// One CU's call is ~200 small dependent launches: issued one by one they cost the host 5-7 ms per CU (measured, 1280x720 and 1920x1080 encodes); the
+// whole call -- upload of (job, state), every launch, download of the results -- is therefore captured ONCE per (CU size, picture parameters) into a HIP
+// graph and replayed for every further CU of that size in the picture (all operands sit at fixed addresses of the per-thread arena; the planes are the
+// picture's resident copies).  The key is everything the launches bake in: the parameter record, the plane table, strides, the coefficient tables.
+struct HostGraph {
+    std::vector<char> key;
+    hipGraph_t        graph = nullptr;
+    hipGraphExec_t    exec  = nullptr;
+};
 struct InterHostCtx {
     uint32_t    gen = 0;
     hipStream_t st  = nullptr;
     char       *dev = nullptr, *pin = nullptr;
     size_t      dev_bytes = 0;
+    std::vector<HostGraph> graphs;
+    void drop_graphs()
+    {
+        for(auto &g : graphs) {
+            if(g.exec) (void)hipGraphExecDestroy(g.exec);
+            if(g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+    }
     static constexpr size_t IN_BYTES = 512, OUT_BYTES = 64 << 10; // in: job + state; out: result, exit state, coef, rec, pred (64x64: 12 + 12.1 + 8 KB)
     void release()
     {
+        drop_graphs();
         if(st) (void)hipStreamDestroy(st);
         if(dev) (void)hipFree(dev);
         if(pin) (void)hipHostFree(pin);
@@ -661,6 +682,7 @@ struct InterHostCtx {
         if(dev_bytes < need) {
             if(dev) {
                 XH_HIP(hipStreamSynchronize(st));
+                drop_graphs(); // (they hold the old arena's addresses)
                 (void)hipFree(dev);
                 dev = nullptr, dev_bytes = 0;
             }
@@ -722,13 +744,55 @@ static int inter_host_resident(const xeve_hip_pel *const org[3], int s_org_l, in
     xeve_hip_inter_job j0 = *job;
     j0.sbac = 0;
     memcpy(h + o_job, &j0, sizeof(j0)), memcpy(h + o_state, state, sizeof(*state));
-    XH_HIP(hipMemcpyAsync(d, h, InterHostCtx::IN_BYTES, hipMemcpyHostToDevice, C.st));
     pel *drec = (pel *)(d + o_rec);
-    rc = xeve_hip_pinter_analyze_cu_jobs(dorg, s_org_l, s_org_c, tab, s_l, s_c, (const xeve_hip_sbac *)(d + o_state), 1, p, (const xeve_hip_inter_job *)(d + o_job), 1, coef_l,
-                                         coef_c, (xeve_hip_inter_result *)(d + o_res), (int16_t *)(d + o_coef), drec, drec + n0 + 8, drec + n0 + n1 + 16, (pel *)(d + o_pred),
-                                         (xeve_hip_sbac *)(d + o_nb), d + o_ws, wsb, C.st);
-    if(rc != XEVE_HIP_OK) return rc;
-    XH_HIP(hipMemcpyAsync(h + o_res, d + o_res, o_end - o_res, hipMemcpyDeviceToHost, C.st));
+    auto enqueue = [&]() -> int { // the whole call on C.st
+        XH_HIP(hipMemcpyAsync(d, h, InterHostCtx::IN_BYTES, hipMemcpyHostToDevice, C.st));
+        int r = xeve_hip_pinter_analyze_cu_jobs(dorg, s_org_l, s_org_c, tab, s_l, s_c, (const xeve_hip_sbac *)(d + o_state), 1, p, (const xeve_hip_inter_job *)(d + o_job), 1,
+                                                coef_l, coef_c, (xeve_hip_inter_result *)(d + o_res), (int16_t *)(d + o_coef), drec, drec + n0 + 8, drec + n0 + n1 + 16,
+                                                (pel *)(d + o_pred), (xeve_hip_sbac *)(d + o_nb), d + o_ws, wsb, C.st);
+        if(r != XEVE_HIP_OK) return r;
+        XH_HIP(hipMemcpyAsync(h + o_res, d + o_res, o_end - o_res, hipMemcpyDeviceToHost, C.st));
+        return XEVE_HIP_OK;
+    };
+    static const int use_graph = getenv("XEVE_HIP_HOST_GRAPH") ? atoi(getenv("XEVE_HIP_HOST_GRAPH")) : 1; // developer switch (measurement)
+    if(use_graph && !xh_prof_on(XH_PROF_SEARCH) && !xh_prof_on(XH_PROF_CU_BITS)) {
+        std::vector<char> key(sizeof(*p) + sizeof(tab) + sizeof(dorg) + 4 * sizeof(int) + 2 * sizeof(void *));
+        char *k = key.data();
+        memcpy(k, p, sizeof(*p)), k += sizeof(*p);
+        memcpy(k, tab, sizeof(tab)), k += sizeof(tab);
+        memcpy(k, dorg, sizeof(dorg)), k += sizeof(dorg);
+        const int strides[4] = {s_org_l, s_org_c, s_l, s_c};
+        memcpy(k, strides, sizeof(strides)), k += sizeof(strides);
+        const void *ct[2] = {(const void *)coef_l, (const void *)coef_c};
+        memcpy(k, ct, sizeof(ct));
+        HostGraph *g = nullptr;
+        for(auto &c : C.graphs)
+            if(c.key == key) {
+                g = &c;
+                break;
+            }
+        if(!g) {
+            if(C.graphs.size() >= 64) C.drop_graphs();
+            HostGraph ng;
+            XH_HIP(hipStreamBeginCapture(C.st, hipStreamCaptureModeThreadLocal));
+            rc = enqueue();
+            const hipError_t ec = hipStreamEndCapture(C.st, &ng.graph);
+            if(rc != XEVE_HIP_OK) {
+                if(ng.graph) (void)hipGraphDestroy(ng.graph);
+                return rc;
+            }
+            XH_HIP(ec);
+            XH_HIP(hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+            ng.key = key;
+            C.graphs.push_back(std::move(ng));
+            g = &C.graphs.back();
+        }
+        XH_HIP(hipGraphLaunch(g->exec, C.st));
+    }
+    else {
+        rc = enqueue();
+        if(rc != XEVE_HIP_OK) return rc;
+    }
     XH_HIP(hipStreamSynchronize(C.st));
     memcpy(result, h + o_res, sizeof(*result)), memcpy(next_best, h + o_nb, sizeof(*next_best));
     memcpy(coef_y, h + o_coef, n0 * 2), memcpy(rec_y, h + o_rec, n0 * 2);

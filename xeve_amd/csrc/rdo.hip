@@ -81,11 +81,13 @@ __global__ void k_rdo_round1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, 
     c.cost_best = MAX_COST, c.idx_best[0] = c.idx_best[1] = c.idx_best[2] = 0, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0;
     c.iy = c.nnz_store[0] > 0, c.iu = c.nnz_store[1] > 0, c.iv = c.nnz_store[2] > 0, c.round4 = 0, c.win = 0;
     cand[j] = c;
-    xeve_hip_cu_bits_job *b = bj + 4 * j;
-    fill_bits_job(b[0], J, P, j, XEVE_HIP_BITS_CU_INTER, 0, 0, 0, J.sbac);
-    fill_bits_job(b[1], J, P, j, XEVE_HIP_BITS_CU_INTER, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
-    fill_bits_job(b[2], J, P, j, XEVE_HIP_BITS_COMP_Y, 0, c.nnz_store[1], c.nnz_store[2], J.sbac);
-    fill_bits_job(b[3], J, P, j, XEVE_HIP_BITS_COMP_Y, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
+    // job arrays are KIND-MAJOR (kind k of candidate j at k * njobs + j): a wave of the bit counter then holds 64 jobs of one kind -- 64 whole-CU counts or 64
+    // one-bin "without" counts -- instead of a mix in which the one-bin lanes idle while the wave waits for its longest string
+    const int N = P.njobs;
+    fill_bits_job(bj[0 * N + j], J, P, j, XEVE_HIP_BITS_CU_INTER, 0, 0, 0, J.sbac);
+    fill_bits_job(bj[1 * N + j], J, P, j, XEVE_HIP_BITS_CU_INTER, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
+    fill_bits_job(bj[2 * N + j], J, P, j, XEVE_HIP_BITS_COMP_Y, 0, c.nnz_store[1], c.nnz_store[2], J.sbac);
+    fill_bits_job(bj[3 * N + j], J, P, j, XEVE_HIP_BITS_COMP_Y, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
 }
 
 __device__ __forceinline__ double sum_cost(const long *d0, const long *d1, int iy, int iu, int iv, const RdoK &P)
@@ -112,13 +114,14 @@ __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P,
     Cand c = cand[j];
     long d0[3], d1[3];
     load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
-    const unsigned *b = bits + 4 * j;
-    const xeve_hip_sbac *so = st_out + 4 * j;
+    const int N = P.njobs; // (kind-major arrays, see k_rdo_round1)
+    const unsigned b[4] = {bits[j], bits[N + j], bits[2 * N + j], bits[3 * N + j]};
+    auto so = [&](int k) { return st_out + (size_t)k * N + j; };
     if(c.tnnz == 0) { // nothing survived quantisation (xeve_pinter.c:1276-1331)
         c.cost_best = (double)d0[0] + (P.wgt[0] * (double)d0[1]) + (P.wgt[1] * (double)d0[2]);
         c.cost_best += (double)(int)b[0] * P.lambda[0];
         c.win = 0;
-        if(best) copy_state(best + j, so + 0);
+        if(best) copy_state(best + j, so(0));
         copy_state(prev + j, entry + J.sbac);
     }
     else {
@@ -127,7 +130,7 @@ __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P,
             cost += (double)(int)b[0] * P.lambda[0];
             if(cost < c.cost_best) {
                 c.cost_best = cost, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0, c.win = 0;
-                if(best) copy_state(best + j, so + 0);
+                if(best) copy_state(best + j, so(0));
             }
         }
         { // as quantised (:1144-1178)
@@ -135,7 +138,7 @@ __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P,
             cost += (double)(int)b[1] * P.lambda[0];
             if(cost < c.cost_best) {
                 c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, c.win = 1;
-                if(best) copy_state(best + j, so + 1);
+                if(best) copy_state(best + j, so(1));
             }
         }
         // Y with / without its coefficients (:1180-1218, i = 0)
@@ -144,14 +147,13 @@ __global__ void k_rdo_decide1(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P,
             c0 += (double)(int)b[2] * P.lambda[0], c1 += (double)(int)b[3] * P.lambda[0];
             const int pick = c1 < c0; // j = 0 is taken first, j = 1 must be strictly smaller
             c.idx_best[0] = pick;
-            copy_state(prev + j, so + 2 + pick);
+            copy_state(prev + j, so(2 + pick));
         }
         else copy_state(prev + j, entry + J.sbac);
     }
     cand[j] = c;
-    xeve_hip_cu_bits_job *o = bj + 2 * j;
-    fill_bits_job(o[0], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], 0, c.nnz_store[2], j);
-    fill_bits_job(o[1], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
+    fill_bits_job(bj[j], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], 0, c.nnz_store[2], j);
+    fill_bits_job(bj[N + j], J, P, j, XEVE_HIP_BITS_COMP_U, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
 }
 
 // after round 2 (comp = 1) / round 3 (comp = 2): that component's choice; next round's jobs
@@ -167,15 +169,14 @@ __global__ void k_rdo_decide_comp(const xeve_hip_rdo_job *__restrict__ jobs, Rdo
     load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
     if(c.tnnz != 0 && c.nnz_store[comp] > 0) {
         double c0 = (double)d0[comp] * P.wgt[comp - 1], c1 = (double)d1[comp] * P.wgt[comp - 1];
-        c0 += (double)(int)bits[2 * j] * P.lambda[comp], c1 += (double)(int)bits[2 * j + 1] * P.lambda[comp];
+        c0 += (double)(int)bits[j] * P.lambda[comp], c1 += (double)(int)bits[P.njobs + j] * P.lambda[comp];
         const int pick = c1 < c0;
         c.idx_best[comp] = pick;
-        copy_state(prev + j, st_out + 2 * j + pick);
+        copy_state(prev + j, st_out + (size_t)pick * P.njobs + j);
     }
     if(comp == 1) {
-        xeve_hip_cu_bits_job *o = bj + 2 * j;
-        fill_bits_job(o[0], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], 0, j);
-        fill_bits_job(o[1], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
+        fill_bits_job(bj[j], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], 0, j);
+        fill_bits_job(bj[P.njobs + j], J, P, j, XEVE_HIP_BITS_COMP_V, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], j);
     }
     else { // the combination the component tests chose (:1220-1262)
         int n[3] = {c.nnz_store[0], c.nnz_store[1], c.nnz_store[2]};

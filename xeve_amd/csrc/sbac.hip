@@ -384,31 +384,34 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
         for(int it = 0; it < WIN; it++) {
             if constexpr(REGCTX) {
             if(e < total) {
+                // Written as mask arithmetic on purpose (as the general step below): 64 lanes are in 64 different phases, and every ternary chain over `p`
+                // comes back from the compiler as a ladder of exec-mask branches that all lanes pay for.
                 const unsigned pre = s_ring[(e + 1) & (RING - 1)][lane]; // the next event: landed by the time this step ends
-                const unsigned lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1, at_end = (cur >> 28) & 1;
-                const bool unary = p < 2, ub = u != 0;
-                const unsigned bin = unary ? (unsigned)ub : (p == 2 ? sign : (unsigned)(numsig == 0));
-                const unsigned w = p == 0 ? cA : (p == 1 ? cB : cC);
-                const unsigned sh = (unary && f) ? 0u : 16u;
+                const unsigned lev1 = cur & 0x7FFF, sgn = 0u - ((cur >> 15) & 1), atend = 0u - ((cur >> 28) & 1);
+                const unsigned up = (unsigned)p;
+                const unsigned is0 = 0u - (unsigned)(up == 0), is1 = 0u - (unsigned)(up == 1), is2 = 0u - (unsigned)(up == 2), is3 = 0u - (unsigned)(up == 3);
+                const unsigned un = is0 | is1, ub = 0u - (unsigned)(u != 0), fm = 0u - (unsigned)f;
+                const unsigned bin = ((ub & un) | (sgn & is2) | ((0u - (unsigned)(numsig == 0)) & is3)) & 1u;
+                const unsigned w = (cA & is0) | (cB & is1) | (cC & ~un);
+                const unsigned sh = ~(un & fm) & 16u; // first bins in the low halves; rest bins and `last` in the high halves
                 const unsigned m = (w >> sh) & 0xFFFFu;
-                const unsigned m1 = sb_encode<FULL>(s, m, bin, p == 2); // (bypass hands the model back unchanged)
+                const unsigned m1 = sb_encode<FULL>(s, m, bin, is2 != 0); // (bypass hands the model back unchanged)
                 const unsigned nw = w ^ ((m ^ m1) << sh);
-                cA = p == 0 ? nw : cA, cB = p == 1 ? nw : cB, cC = p == 3 ? nw : cC;
+                cA = (nw & is0) | (cA & ~is0), cB = (nw & is1) | (cB & ~is1), cC = (nw & is3) | (cC & ~is3);
                 // transitions: a 1 of a unary value stays (one less to go, rest model); its 0 moves on; the sign ends the event at the last scan
                 // position (no last flag there, xeve_eco.c:744-746), else the last flag does
-                const bool stay = unary && ub, adv = p == 3 || (p == 2 && at_end), to_level = p == 0 && !ub;
-                numsig -= (int)(p == 2);
-                const int np = stay ? p : (p == 0 ? 1 : (p == 1 ? 2 : ((p == 2 && !at_end) ? 3 : 0)));
-                e += (int)adv;
-                cur = adv ? pre : cur;
-                u = stay ? u - 1 : (to_level ? lev1 : (adv ? (pre >> 16) & 0xFFF : u));
-                f = stay ? 0 : ((to_level || adv) ? 1 : f);
-                p = np;
-                const bool newc = adv && (e == b1 || e == b2);
-                numsig = newc ? (e >= b2 ? J.nnz[2] : J.nnz[1]) : numsig;
+                const unsigned stay = un & ub, adv = is3 | (is2 & atend), to_level = is0 & ~ub, fresh = to_level | adv;
+                numsig -= (int)(is2 & 1u);
+                p = (int)((up & stay) | (~stay & ((1u & is0) | (2u & is1) | (3u & is2 & ~atend))));
+                e += (int)(adv & 1u);
+                cur = (pre & adv) | (cur & ~adv);
+                u = ((u - 1) & stay) | (~stay & ((lev1 & to_level) | (((pre >> 16) & 0xFFFu) & adv) | (u & ~fresh)));
+                f = (int)(~stay & (fresh | fm) & 1u);
+                const unsigned newc = adv & (0u - (unsigned)(e == b1 || e == b2));
+                numsig = (int)(((unsigned)(e >= b2 ? J.nnz[2] : J.nnz[1]) & newc) | ((unsigned)numsig & ~newc));
                 const int nch = e >= b1 ? 1 : 0;
-                if(__ballot(newc && nch != ch)) { // luma -> chroma: swap the packed models (once per job at most; Cb -> Cr keeps them)
-                    if(newc && nch != ch) ctx_store(ch), ctx_load(nch);
+                if(__ballot(newc != 0 && nch != ch)) { // luma -> chroma: swap the packed models (once per job at most; Cb -> Cr keeps them)
+                    if(newc != 0 && nch != ch) ctx_store(ch), ctx_load(nch);
                 }
                 ch = nch;
                 if constexpr(WB) { // burst: up to BURST further 1s of a unary value on the rest model, while that model's MPS is 1 (see below)
@@ -608,7 +611,7 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     {
         XhProf prof(XH_PROF_CU_BITS, st);
         unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS);
-        static const int use_reg = getenv("XEVE_HIP_SBAC_REG") ? atoi(getenv("XEVE_HIP_SBAC_REG")) : 1; // developer switch (measurement)
+        static const int use_reg = getenv("XEVE_HIP_SBAC_REG") ? atoi(getenv("XEVE_HIP_SBAC_REG")) : 0; // developer switch (measurement)
         const bool reg = use_reg && P.cm_init == 0;
         if(full && reg) k_cu_bits<true, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
         else if(full) k_cu_bits<true, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
