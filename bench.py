@@ -190,7 +190,7 @@ def main():
     for _ in range(a.warmup):
         wl.inter()
     fence()
-    lib.prof_enable(["search", "cu_bits"])  # the two kernels that can dominate: timed live, on their launch streams
+    lib.prof_enable(["search", "cu_bits", "cu_bits_slow"])  # the two kernels that can dominate: timed live, on their launch streams
     lib.prof_read()
     fence()
     t0 = time.perf_counter()
@@ -265,7 +265,8 @@ def main():
             "roofline": roof,
             "kernels_in_timed_region": {"search": {"ms_per_picture": round(s_ms / a.steps, 3), "launches_per_picture": s_n // a.steps},
                                         "cu_bits": {"ms_per_picture": round(b_ms / a.steps, 3), "launches_per_picture": b_n // a.steps, "bins_per_picture": int(b_u / a.steps),
-                                                    "Gbin_per_s": round(b_u / (b_ms * 1e-3) / 1e9, 3) if b_ms > 0 else None},
+                                                    "Gbin_per_s": round(b_u / (b_ms * 1e-3) / 1e9, 3) if b_ms > 0 else None,
+                                                    "jobs_on_the_slow_path_per_picture": int(live["cu_bits_slow"][2] / a.steps)},
                                         "note": "sums of per-launch HIP-event times on the launch streams; the four levels run on four streams, so the sums can exceed the wall time"},
         }
 

@@ -60,7 +60,8 @@ int         xeve_hip_sizeof(int i);
  * Classes: 0 integer motion search (k_me_epzs / k_me_diamond; unit = 64 sample pairs of evaluated block SADs, i.e. a w x h evaluation counts
  * w*h/64 units = 256 algorithmic bytes each by SURVEY.md 8d's 4*w*h + 4 per table call), 1 sub-pel stage of the search (fused interpolation
  * + SAD), 2 CABAC bit counting (k_cu_bits; unit = one coded bin), 3 CU prediction (xeve_hip_mc_cu_jobs), 4 residual chain (DIFF .. SSD),
- * 5 RDOQ; classes 1, 3, 4, 5 are timed only (units stay 0).  xeve_hip_prof_read waits for the recorded events, adds up their durations per class and resets the tallies;
+ * 5 RDOQ; classes 1, 3, 4, 5 are timed only (units stay 0); 6 is a pure counter: bit-count jobs that could not use their blocks' bin strings
+ * (string overflow or an inconsistent coefficient count) and took the slower event automaton.  xeve_hip_prof_read waits for the recorded events, adds up their durations per class and resets the tallies;
  * arrays of n <= 8 entries (NULL to skip one). */
 #define XEVE_HIP_PROF_CLASSES 8
 int         xeve_hip_prof_enable(int class_mask);

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "xeve_type.h"
 #include "xeve_mc.h"
@@ -247,6 +248,7 @@ static int (*hip_inter_host)(const pel *const *, int, int, const hip_refpic *, i
                              const void *, const void *, hip_inter_result *, s16 *, s16 *, s16 *, pel *, pel *, pel *, pel *, hip_sbac *);
 static double (*orig_pinter_analyze_cu)(XEVE_CTX *, XEVE_CORE *, int, int, int, int, XEVE_MODE *, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C], int s_rec[N_C]);
 static unsigned long long inter_calls, inter_fallbacks;
+static double inter_seconds; /* wall time inside xeve_hip_pinter_analyze_cu_host, all threads */
 
 static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int y, int log2_cuw, int log2_cuh, XEVE_MODE *mi, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C],
                                      int s_rec[N_C])
@@ -303,11 +305,15 @@ static double shim_pinter_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
     static __thread s16 cf[N_C][MAX_CU_DIM];
     static __thread pel rc[N_C][MAX_CU_DIM], py[MAX_CU_DIM];
     const pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     if(hip_inter_host(org, pi->s_o[Y_C], pi->s_o[U_C], tab, any->s_l, any->s_c, any->pad_l, any->pad_c, &h, &P, &J, pi->mc_l_coeff, pi->mc_c_coeff, &R, cf[Y_C], cf[U_C],
                       cf[V_C], rc[Y_C], rc[U_C], rc[V_C], py, &nb) != 0) {
         fprintf(stderr, "[xeve_hip_shim] inter analysis: %s\n", hip_err());
         abort();
     }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    inter_seconds += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec); /* (a statistic: races between encoder threads only blur it) */
     /* what xeve_pinter_analyze_cu leaves behind (:2004-2046) */
     const int best = R.best_idx, n0 = 1 << (log2_cuw + log2_cuh), n1 = n0 >> (ws + hs);
     core->cu_mode = R.cu_mode;
@@ -363,6 +369,7 @@ static void report(void)
         fprintf(stderr, "[xeve_hip_shim] resident pictures: %llu pictures announced, %llu planes uploaded (%llu bytes), %llu plane look-ups served from HBM\n", pics, up, bytes, hits);
     }
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
+    if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
     if(tq_calls) fprintf(stderr, "[xeve_hip_shim] transform blocks quantised (RDOQ) on the GPU: %llu, dequantised + inverse transformed: %llu\n", tq_calls, itdq_calls);

@@ -32,6 +32,10 @@ REAL_CASES = {
     "cfg2_720p_ldb_fast": (1280, 720, 2, 2, ["--preset", "fast", "-b", "0", "-I", "0"]),  # 20 x 12 CTUs, the last row 16 samples high; low-delay B, ME range 64
     "cfg3_1080p_ra_medium": (1920, 1080, 3, 3, ["--preset", "medium"]),  # 30 x 17 CTUs (last row 56 high); default random-access GOP (-b 15): I, then B pictures by POC distance
     "cfg4_2160p_closedgop_medium": (3840, 2160, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8"]),  # 60 x 34 CTUs (last row 48 high): IDR + one inter picture
+    # the same two with the reference's maximum of 8 CTU-row threads (`-m` given last wins): a different but equally deterministic bitstream (checked: two runs,
+    # same md5), and eight encoder threads calling the GPU side by side -- what makes 86 000 / 173 000 per-CU calls fit the GPU suite's time budget
+    "cfg3_1080p_ra_medium_m8": (1920, 1080, 3, 3, ["--preset", "medium", "-m", "8"]),
+    "cfg4_2160p_closedgop_medium_m8": (3840, 2160, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8", "-m", "8"]),
 }
 
 

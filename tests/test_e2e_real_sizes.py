@@ -29,8 +29,10 @@ def _encode(tmp_path, name, cases, min_cus):
     r = re.search(r"resident pictures: (\d+) pictures announced, (\d+) planes uploaded \((\d+) bytes\), (\d+) plane look-ups", err)
     assert m and r, err
     cus, left = int(m.group(1)), int(m.group(2))
+    t = re.search(r"time inside the GPU calls: ([0-9.]+) s = (\d+) us per CU", err)
     pics, uploads, hits = int(r.group(1)), int(r.group(2)), int(r.group(4))
-    print("%s: %d CUs on the GPU in %.1f s (%.0f us per CU incl. the host side of the encoder), %d pictures, %d plane uploads, %d look-ups from HBM" % (name, cus, dt, 1e6 * dt / max(1, cus), pics, uploads, hits))
+    print("%s: %d CUs on the GPU in %.1f s wall (%.0f us per CU incl. the host side of the encoder; inside the GPU calls, summed over the encoder threads: %s s = %s us per CU), "
+          "%d pictures, %d plane uploads, %d look-ups from HBM" % (name, cus, dt, 1e6 * dt / max(1, cus), t.group(1) if t else "?", t.group(2) if t else "?", pics, uploads, hits))
     assert cus >= min_cus and left == 0, err
     assert pics == n and uploads <= 9 * pics and hits > 5 * cus, err  # (each inter picture: the original + at most two reference pictures, three planes each)
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the inter analysis on the GPU at %dx%d" % (w, h)
@@ -47,8 +49,13 @@ def test_cfg2_1280x720_low_delay_fast(tmp_path):
 
 
 def test_cfg3_1920x1080_random_access_medium(tmp_path):
-    _encode(tmp_path, "cfg3_1080p_ra_medium", REAL_CASES, 60000)
+    _encode(tmp_path, "cfg3_1080p_ra_medium_m8", REAL_CASES, 60000)
 
 
 def test_cfg4_3840x2160_closed_gop_medium(tmp_path):
-    _encode(tmp_path, "cfg4_2160p_closedgop_medium", REAL_CASES, 100000)
+    _encode(tmp_path, "cfg4_2160p_closedgop_medium_m8", REAL_CASES, 100000)
+
+
+@pytest.mark.skipif(os.environ.get("XEVE_E2E_SLOW") != "1", reason="one encoder thread at 1920x1080 takes ~7 min of per-CU calls: set XEVE_E2E_SLOW=1 (passed in round 2, see DESIGN.md)")
+def test_cfg3_1920x1080_random_access_medium_one_thread(tmp_path):
+    _encode(tmp_path, "cfg3_1080p_ra_medium", REAL_CASES, 60000)

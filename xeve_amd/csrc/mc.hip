@@ -73,6 +73,15 @@ struct PlaneTab {
     int        n;
 };
 __device__ __forceinline__ const pel *plane_of(const PlaneTab &pt, const pel *ref, int frac) { return pt.n ? pt.p[(frac >> 3) & (XH_MAX_PLANES - 1)] : ref; }
+// Several interpolation passes of one shape in ONE launch: blockIdx.y picks the pass -- its job array, destination and plane table (the CU prediction
+// driver: both lists of luma in one launch, both lists x {Cb, Cr} in another, instead of six).  n == 0: the single pass described by the plain arguments.
+#define XH_MC_VARS 4
+struct McMulti {
+    const xeve_hip_mc_job *jobs[XH_MC_VARS];
+    pel                   *pred[XH_MC_VARS];
+    PlaneTab               pt[XH_MC_VARS];
+    int                    n;
+};
 
 // `jpb` jobs per workgroup: small blocks (8x8 luma = 8 row units) are packed so that all 256 threads have a unit.
 // Phase 1 (only for jobs with both filters): horizontal pass of h + TAPS - 1 rows into LDS.  Phase 2: every output
@@ -85,9 +94,10 @@ template <int TAPS, int SEG, int OUT>
 __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
                                             const xeve_hip_mc_job *__restrict__ jobs, int njobs, int jpb, int w, int h,
                                             int bit_depth, CoefTab<TAPS> tab, const pel *__restrict__ org, int s_org, int dshift,
-                                            void *__restrict__ dist_out, PlaneTab pt)
+                                            void *__restrict__ dist_out, PlaneTab pt, McMulti mv)
 {
     static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
+    if(mv.n) jobs = mv.jobs[blockIdx.y], pred = mv.pred[blockIdx.y], pt = mv.pt[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // jpb * (h + TAPS - 1) * w
     constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
     typedef typename SegIO<SEG>::vec vec;
@@ -245,11 +255,12 @@ __global__ void k_avg(const int16_t *__restrict__ a, const int16_t *__restrict__
 template <int TAPS, int OUT>
 static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xeve_hip_mc_job *jobs, int njobs, int w, int h,
                      int bit_depth, const int16_t *coef, hipStream_t st, const pel *org = nullptr, int s_org = 0, void *dist_out = nullptr,
-                     const PlaneTab *planes = nullptr)
+                     const PlaneTab *planes = nullptr, const McMulti *multi = nullptr)
 {
     XH_ENTER();
-    XH_REQUIRE((ref || (planes && planes->n > 0)) && jobs && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
-    XH_REQUIRE(OUT != 0 ? (org && dist_out) : (pred != nullptr));
+    XH_REQUIRE((ref || (planes && planes->n > 0) || multi) && (jobs || multi) && coef && njobs >= 0 && w >= 1 && h >= 1 && w <= 128 && h <= 128);
+    XH_REQUIRE(OUT != 0 ? (org && dist_out) : (pred != nullptr || multi != nullptr));
+    XH_REQUIRE(!multi || (OUT == 0 && multi->n >= 1 && multi->n <= XH_MC_VARS && (w % (TAPS == 8 ? 8 : 4)) == 0));
     XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
     if(njobs == 0) return XEVE_HIP_OK;
     CoefTab<TAPS> tab;
@@ -257,19 +268,23 @@ static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xev
     PlaneTab pt;
     if(planes) pt = *planes;
     else pt.n = 0;
+    McMulti mv;
+    if(multi) mv = *multi;
+    else mv.n = 0;
+    const unsigned gy = multi ? (unsigned)multi->n : 1u;
     const int dshift = OUT == 1 ? bit_depth - 8 : (bit_depth - 8) * 2;
     bool done = false;
     if(w % 8 == 0) {
         const int jpb = std::max(1, 256 / (h * (w / 8)));
         const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-        k_mc<TAPS, 8, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt);
+        k_mc<TAPS, 8, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt, mv);
         done = true;
     }
     if constexpr(TAPS == 4) {
         if(!done && w % 4 == 0) {
             const int jpb = std::max(1, 256 / (h * (w / 4)));
             const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-            k_mc<4, 4, OUT><<<(njobs + jpb - 1) / jpb, 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt);
+            k_mc<4, 4, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt, mv);
             done = true;
         }
     }
@@ -499,6 +514,26 @@ __global__ void k_cu_mc_combine(pel *__restrict__ p0, const pel *__restrict__ p1
     xh_st4(p0 + i, a);
 }
 
+// the three components of k_cu_mc_combine in one launch (blockIdx.y = component)
+__global__ __launch_bounds__(256) void k_cu_mc_combine3(pel *py, const pel *qy, pel *pu, const pel *qu, pel *pv, const pel *qv, const uint8_t *__restrict__ mode, int njobs,
+                                                        int n0, int n1)
+{
+    const int  k = blockIdx.y, n = k ? n1 : n0;
+    pel       *p0 = k == 0 ? py : (k == 1 ? pu : pv);
+    const pel *p1 = k == 0 ? qy : (k == 1 ? qu : qv);
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if(i >= (long)njobs * n) return;
+    const int m = mode[i / n];
+    if(!m) return;
+    u32x2 a = xh_ld4(p0 + i), b = xh_ld4(p1 + i);
+    if(m == 1) {
+#pragma unroll
+        for(int q = 0; q < 2; q++) a[q] = xh_pack16((xh_lo16(a[q]) + xh_lo16(b[q]) + 1) >> 1, (xh_hi16(a[q]) + xh_hi16(b[q]) + 1) >> 1); // xeve_average_16b_no_clip
+    }
+    else a = b;
+    xh_st4(p0 + i, a);
+}
+
 extern "C" size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp0, int num_refp1)
 {
     const size_t n = njobs > 0 ? njobs : 0, q = 2; // one job array per list and plane type
@@ -534,31 +569,61 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     XhProf prof(XH_PROF_MC, st);
     k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, P, jl, jc, mode);
     XH_HIP(hipGetLastError());
-    for(int l = 0; l < 2; l++) { // one launch per list and component: the jobs pick their reference picture from the table
+    // two interpolation launches: luma of both lists, then {Cb, Cr} of both lists (blockIdx.y picks list / plane; the jobs pick their reference
+    // picture from the pass's table).  Shapes the packed kernel cannot take (chroma width not a multiple of 4) go list by list, plane by plane.
+    PlaneTab ty[2], tu[2], tv[2];
+    int nl = 0, lists[2] = {0, 0};
+    for(int l = 0; l < 2; l++) {
         if(!P.nref[l]) continue;
-        PlaneTab ty, tu, tv;
-        ty.n = tu.n = tv.n = P.nref[l];
+        lists[nl++] = l;
+        ty[l].n = tu[l].n = tv[l].n = P.nref[l];
         for(int r = 0; r < XH_MAX_PLANES; r++) {
             const xeve_hip_refpic &R = refp[(r < P.nref[l] ? r : 0) * 2 + l];
             XH_REQUIRE(R.y && (chroma_format_idc == 0 || (R.u && R.v)));
-            ty.p[r] = R.y, tu.p[r] = R.u, tv.p[r] = R.v;
+            ty[l].p[r] = R.y, tu[l].p[r] = R.u, tv[l].p[r] = R.v;
         }
-        int rc = mc_launch<8, 0>(nullptr, s_l, l ? p1[0] : pred_y, w, jl + (size_t)l * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st, nullptr, 0, nullptr, &ty);
+    }
+    const bool packed_l = w % 8 == 0, packed_c = chroma_format_idc && P.cw % 4 == 0;
+    if(packed_l) {
+        McMulti mv;
+        mv.n = nl;
+        for(int i = 0; i < nl; i++) {
+            const int l = lists[i];
+            mv.jobs[i] = jl + (size_t)l * n, mv.pred[i] = l ? p1[0] : pred_y, mv.pt[i] = ty[l];
+        }
+        int rc = mc_launch<8, 0>(nullptr, s_l, nullptr, w, nullptr, njobs, w, h, bit_depth_luma, &coef_l[0][0], st, nullptr, 0, nullptr, nullptr, &mv);
         if(rc != XEVE_HIP_OK) return rc;
-        if(chroma_format_idc) {
-            rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tu);
+    }
+    if(packed_c) {
+        McMulti mv;
+        mv.n = 2 * nl;
+        for(int i = 0; i < nl; i++) {
+            const int l = lists[i];
+            mv.jobs[2 * i] = mv.jobs[2 * i + 1] = jc + (size_t)l * n;
+            mv.pred[2 * i] = l ? p1[1] : pred_u, mv.pred[2 * i + 1] = l ? p1[2] : pred_v, mv.pt[2 * i] = tu[l], mv.pt[2 * i + 1] = tv[l];
+        }
+        int rc = mc_launch<4, 0>(nullptr, s_c, nullptr, P.cw, nullptr, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, nullptr, &mv);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    for(int i = 0; i < nl; i++) {
+        const int l = lists[i];
+        if(!packed_l) {
+            int rc = mc_launch<8, 0>(nullptr, s_l, l ? p1[0] : pred_y, w, jl + (size_t)l * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st, nullptr, 0, nullptr, &ty[l]);
             if(rc != XEVE_HIP_OK) return rc;
-            rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tv);
+        }
+        if(chroma_format_idc && !packed_c) {
+            int rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tu[l]);
+            if(rc != XEVE_HIP_OK) return rc;
+            rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tv[l]);
             if(rc != XEVE_HIP_OK) return rc;
         }
     }
     if(num_refp1 > 0) {
         const long tl = ((long)njobs * w * h) / 4, tc = ((long)njobs * P.cw * P.ch) / 4;
-        k_cu_mc_combine<<<(unsigned)((tl + 255) / 256), 256, 0, st>>>(pred_y, p1[0], mode, njobs, w * h);
-        if(chroma_format_idc) {
-            k_cu_mc_combine<<<(unsigned)((tc + 255) / 256), 256, 0, st>>>(pred_u, p1[1], mode, njobs, P.cw * P.ch);
-            k_cu_mc_combine<<<(unsigned)((tc + 255) / 256), 256, 0, st>>>(pred_v, p1[2], mode, njobs, P.cw * P.ch);
-        }
+        if(chroma_format_idc)
+            k_cu_mc_combine3<<<dim3((unsigned)((tl + 255) / 256), 3), 256, 0, st>>>(pred_y, p1[0], pred_u, p1[1], pred_v, p1[2], mode, njobs, w * h, P.cw * P.ch);
+        else k_cu_mc_combine<<<(unsigned)((tl + 255) / 256), 256, 0, st>>>(pred_y, p1[0], mode, njobs, w * h);
+        (void)tc;
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

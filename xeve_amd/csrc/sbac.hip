@@ -47,9 +47,22 @@ __device__ __forceinline__ unsigned coded_mask(const xeve_hip_cu_bits_job &j)
     return m;
 }
 
+// ---- bin streams ---------------------------------------------------------------------------------------------------------
+// The serial part of the coder only ever needs, per bin, WHICH model and WHAT value: both are functions of the coefficient block alone (the
+// models of run / level / last depend on the component type -- and with sps_cm_init_flag 1 on the previous level -- never on the coder state).
+// So the event pass also expands every coded block, in parallel, into its bin string: one byte per bin, (model index << 1) | value, model index
+// BYP for the bypass-coded sign.  The block's string lives in the workspace at byte offset coef_off * BINK behind a 16-byte header {bins, events};
+// a block whose string does not fit its BINK bytes per coefficient is marked OVF and its jobs take the event automaton below (exact, slower).
+// The serial kernel (k_cu_bits_s) is then a loop of "fetch byte, model, encode, write model back": a third of the instructions of the automaton.
+#define BINK 32          // bytes of bin-stream space per coefficient (header included)
+#define BIN_HDR 16
+#define BIN_OVF 0xFFFFFFFFu
+#define BYP NCTX         // model index of bypass bins (a dummy row of the model table)
+
 // LPB lanes per (job, component) block
 template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const int16_t *__restrict__ coef, const xeve_hip_cu_bits_job *__restrict__ jobs,
-                                                                        int njobs, CuBitsK P, unsigned *__restrict__ ev, int *__restrict__ nev)
+                                                                        int njobs, CuBitsK P, unsigned *__restrict__ ev, int *__restrict__ nev,
+                                                                        unsigned char *__restrict__ bins)
 {
     constexpr int GPW = 64 / LPB;
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -65,6 +78,13 @@ template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const in
     const int n = P.n[c];
     const uint16_t *scan = P.scan[c];
     int count = 0, prev = -1;
+    // bin stream of this block
+    unsigned char *bo = bins ? bins + (size_t)off * BINK + BIN_HDR : nullptr;
+    const unsigned cap = (unsigned)n * BINK - BIN_HDR;
+    unsigned base = 0;        // bins of the events before this chunk
+    int      lfp = -1;        // where the most recent event's last-position flag sits (-1: it has none)
+    unsigned plev = 5;        // min(previous level - 1, 5); 5 at the start of a block (xeve_eco.c:722,731-733)
+    const int ch = c != 0;
     // the trip count is uniform per wave only when all its groups work on equally sized blocks: use the largest
     const int nmax = P.n[0];
     for(int chunk = 0; chunk < nmax; chunk += LPB) {
@@ -75,14 +95,66 @@ template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const in
         unsigned long long mask = ball;
         if constexpr(LPB < 64) mask = (ball >> (g * LPB)) & ((1ull << LPB) - 1);
         const unsigned long long below = mask & ((1ull << l) - 1);
+        const unsigned a = (unsigned)(v < 0 ? -v : v) & 0xFFFFu, lev1 = (a - 1) & 0x7FFFu;
+        int run = 0;
         if(v != 0) {
             const int before = below ? chunk + 63 - __clzll((long long)below) : prev;
-            ev[off + count + __popcll(below)] = ev_pack(v, pos - before - 1, pos == n - 1);
+            run = pos - before - 1;
+            ev[off + count + __popcll(below)] = ev_pack(v, run, pos == n - 1);
+        }
+        if(bins) { // (uniform)
+            const bool at_end = pos == n - 1;
+            unsigned cntb = v != 0 ? (run ? run + 1 : 1) + (lev1 ? lev1 + 1 : 1) + 1 + (at_end ? 0 : 1) : 0;
+            unsigned incl = cntb;
+#pragma unroll
+            for(int d = 1; d < LPB; d <<= 1) {
+                const unsigned t = __shfl_up(incl, d, LPB);
+                if(l >= d) incl += t;
+            }
+            const unsigned tot = __shfl(incl, LPB - 1, LPB);
+            // the level before this event (sps_cm_init_flag 1 picks the models by it): the previous non-zero lane's, or the last chunk's
+            const int pl = below ? 63 - __clzll((long long)below) : 0;
+            const unsigned lev_prev = __shfl(lev1, pl, LPB);
+            if(v != 0) {
+                const unsigned pv = below ? (lev_prev < 5 ? lev_prev : 5u) : plev;
+                const unsigned t0 = P.cm_init == 1 ? (pv << 1) + ch * 12 : ch * 2;
+                const unsigned r0 = (XEVE_HIP_CTX_RUN + t0) << 1, l0 = (XEVE_HIP_CTX_LEVEL + t0) << 1;
+                unsigned q = base + incl - cntb;
+                if(q + cntb <= cap) { // (a string that overflows is not used at all: no point in writing part of it)
+                    bo[q++] = (unsigned char)(r0 | (run != 0));
+                    if(run) {
+                        for(int i = 1; i < run; i++) bo[q++] = (unsigned char)((r0 + 2) | 1);
+                        bo[q++] = (unsigned char)(r0 + 2);
+                    }
+                    bo[q++] = (unsigned char)(l0 | (lev1 != 0));
+                    if(lev1) {
+                        for(unsigned i = 1; i < lev1; i++) bo[q++] = (unsigned char)((l0 + 2) | 1);
+                        bo[q++] = (unsigned char)(l0 + 2);
+                    }
+                    bo[q++] = (unsigned char)((BYP << 1) | (unsigned)(v < 0));
+                    if(!at_end) bo[q] = (unsigned char)((XEVE_HIP_CTX_LAST + ch) << 1); // "not the last coefficient" until the patch below says otherwise
+                }
+            }
+            if(mask) { // the chunk's last event: remember where its last-position flag sits and its level
+                const int hi = 63 - __clzll((long long)mask);
+                const unsigned ie = __shfl(incl, hi, LPB), le = __shfl(lev1, hi, LPB);
+                lfp = (chunk + hi == n - 1) ? -1 : (int)(base + ie - 1);
+                plev = le < 5 ? le : 5u;
+            }
+            base += tot;
         }
         if(mask) prev = chunk + 63 - __clzll((long long)mask);
         count += __popcll(mask);
     }
-    if(job < njobs && l == 0) nev[job * 3 + c] = on ? count : 0;
+    if(job < njobs && l == 0) {
+        if(nev) nev[job * 3 + c] = on ? count : 0;
+        if(bins && on) {
+            const bool fits = base <= cap;
+            if(fits && lfp >= 0) bo[lfp] |= 1; // the final event's flag: this was the last coefficient
+            unsigned *hdr = reinterpret_cast<unsigned *>(bo - BIN_HDR);
+            hdr[0] = fits ? base : BIN_OVF, hdr[1] = (unsigned)count;
+        }
+    }
 }
 
 // ---- the coder (count mode), state in registers --------------------------------------------------------------------
@@ -296,7 +368,8 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
 template <bool FULL, bool REGCTX>
 __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs,
                                                 CuBitsK P, const unsigned *__restrict__ ev, const int *__restrict__ nev,
-                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units)
+                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units,
+                                                const unsigned char *__restrict__ done)
 {
     __shared__ uint16_t s_ctx[NCTX][64];
     // the header queue is drained before the first event reaches the ring: the two share their LDS (one wave per workgroup, so the
@@ -306,6 +379,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     unsigned(*s_ring)[64] = reinterpret_cast<unsigned(*)[64]>(s_raw);
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
+    if(done && done[j]) return; // counted from the bin strings already (k_cu_bits_s)
     const xeve_hip_cu_bits_job J = jobs[j];
     const xeve_hip_sbac &in = sin[J.sbac];
     Sbac s;
@@ -539,10 +613,126 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     }
 }
 
+// ---- one lane per job, bins from the blocks' bin strings --------------------------------------------------------------------------
+// Jobs whose coded blocks all have a string (no OVF) and whose coefficient counts are the blocks' true counts (J.nnz == events) are counted here and
+// marked in done[]; every other job is left to k_cu_bits.  Per bin: the byte, its model (read from LDS one bin AHEAD, with the just-written model
+// forwarded when two consecutive bins share it), the coder step, the model write-back.  The string is fetched 16 bytes at a time, the next chunk while
+// the current one is coded, so neither the global nor the LDS latency sits on the serial chain.
+typedef u32x4 u32x4_a4g __attribute__((aligned(4)));
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_cu_bits_s(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs, CuBitsK P,
+                                                  const unsigned char *__restrict__ bins, unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout,
+                                                  unsigned long long *__restrict__ units, unsigned char *__restrict__ done, unsigned long long *__restrict__ slow)
+{
+    __shared__ uint16_t s_ctx[NCTX + 1][64]; // (+ the dummy row of the bypass bins)
+    __shared__ uint8_t  s_q[QMAX][64];
+    const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+    if(j >= njobs) return;
+    const xeve_hip_cu_bits_job J = jobs[j];
+    const unsigned coded = coded_mask(J);
+    const unsigned char *sp[3] = {nullptr, nullptr, nullptr};
+    unsigned nb[3] = {0, 0, 0};
+    bool fast = true;
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+        if((coded >> c) & 1) {
+            const unsigned *hdr = reinterpret_cast<const unsigned *>(bins + (size_t)J.coef_off[c] * BINK);
+            const unsigned n = hdr[0], m = hdr[1];
+            fast = fast && n != BIN_OVF && m == (unsigned)J.nnz[c];
+            sp[c] = reinterpret_cast<const unsigned char *>(hdr) + BIN_HDR, nb[c] = n;
+        }
+    done[j] = fast;
+    if(!fast) {
+        if(slow) atomicAdd(slow, 1ull); // measurement only: jobs left to the event automaton
+        return;
+    }
+    const xeve_hip_sbac &in = sin[J.sbac];
+    Sbac s;
+    s.range = in.range, s.shifts = s.bins = 0;
+    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
+    if(FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET)) { // continue the coder where the state stands
+        s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
+        s.bc = in.bitcounter, s.bins = in.bin_counter;
+    }
+    for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
+    s_ctx[BYP][lane] = 0;
+    Queue Q{&s_q[0][lane], 0};
+    (void)q_header(Q, J, P);
+    for(int i = 0; i < Q.n; i++) { // header bins
+        const unsigned e = s_q[i][lane], ci = e >> 2;
+        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, (e & 2) != 0);
+        s_ctx[ci][lane] = (uint16_t)m;
+    }
+    // the coded components' strings, one after the other
+    for(int c = 0; c < 3; c++) {
+        int rem = (int)nb[c];
+        if(rem <= 0) continue;
+        const u32x4_a4g *gp = reinterpret_cast<const u32x4_a4g *>(sp[c]);
+        u32x4 cur = gp[0];
+        unsigned ci = (cur.x & 0xFFu) >> 1;
+        ci = ci < BYP ? ci : BYP;
+        unsigned m = s_ctx[ci][lane];
+        auto step = [&](unsigned b, unsigned b1) { // code bin b on model ci (value m); b1: the byte after it
+            unsigned ci1 = (b1 & 0xFFu) >> 1;
+            ci1 = ci1 < BYP ? ci1 : BYP; // (past the end of the string: any byte)
+            const unsigned mp = s_ctx[ci1][lane];
+            const unsigned m1 = sb_encode<FULL>(s, m, b & 1u, ci == BYP);
+            s_ctx[ci][lane] = (uint16_t)m1;
+            m = ci1 == ci ? m1 : mp, ci = ci1;
+        };
+        while(rem > 0) {
+            gp++;
+            const u32x4 nxt = gp[0]; // (reads up to 31 bytes past the string: inside the block's region, the next one, or the slack behind the last)
+            if(rem >= 16) {
+#pragma unroll
+                for(int i = 0; i < 16; i++) {
+                    const unsigned wv = cur[i >> 2], wn = i < 15 ? cur[(i + 1) >> 2] : nxt.x;
+                    step(wv >> (8 * (i & 3)), wn >> (8 * ((i + 1) & 3)));
+                }
+            }
+            else {
+                for(int i = 0; i < rem; i++) {
+                    const int i1 = i + 1;
+                    const unsigned wv = (i >> 2) == 0 ? cur.x : (i >> 2) == 1 ? cur.y : (i >> 2) == 2 ? cur.z : cur.w;
+                    const unsigned wn = (i1 >> 2) == 0 ? cur.x : (i1 >> 2) == 1 ? cur.y : (i1 >> 2) == 2 ? cur.z : cur.w; // (i1 <= 15 here)
+                    step(wv >> (8 * (i & 3)), wn >> (8 * (i1 & 3)));
+                }
+            }
+            cur = nxt, rem -= 16;
+        }
+    }
+    bits[j] = s.shifts;
+    if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave (lanes may have left: the sum goes through one LDS word)
+        unsigned *cnt = reinterpret_cast<unsigned *>(&s_q[0][0]);
+        const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
+        if(first) *cnt = 0;
+        atomicAdd(cnt, s.bins - (FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET) ? in.bin_counter : 0u));
+        if(first) atomicAdd(units, (unsigned long long)*cnt);
+    }
+    if(!FULL && sout) {
+        xeve_hip_sbac &o = sout[j];
+        o.range = s.range, o.code = 0, o.code_bits = 11, o.stacked_ff = o.stacked_zero = o.pending_byte = o.is_pending_byte = o.bitcounter = 0;
+        o.bin_counter = s.bins;
+        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
+    }
+    if(FULL) {
+        bits[j] = s.bc + 8 * (s.sz + s.sff) + 8 * (s.ipb ? 1 : 0) + 8 - s.cb + 3; // xeve_get_bit_number (xeve_mode.c:51-55)
+        xeve_hip_sbac &o = sout[j];
+        o.range = s.range, o.code = s.code, o.code_bits = s.cb, o.stacked_ff = s.sff, o.stacked_zero = s.sz;
+        o.pending_byte = s.pb, o.is_pending_byte = s.ipb, o.bitcounter = s.bc, o.bin_counter = s.bins;
+        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
+    }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------------
+// layout: event lists [4 B x coef_elems] | bin strings [BINK B x coef_elems + slack] | event counts [3 x njobs ints] | done flags [njobs]
+// (the first two do not move with njobs: the rounds of one RDO batch pass different job counts over the same coefficient buffer and workspace)
+static size_t ws_bins_off(size_t coef_elems) { return (sizeof(unsigned) * coef_elems + 255) & ~(size_t)255; }
+static size_t ws_nev_off(size_t coef_elems) { return ws_bins_off(coef_elems) + (((size_t)BINK * coef_elems + 64 + 255) & ~(size_t)255); }
 extern "C" size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems)
 {
-    return sizeof(unsigned) * coef_elems + sizeof(int) * 3 * (size_t)(njobs > 0 ? njobs : 0);
+    const size_t n = njobs > 0 ? njobs : 0;
+    return ws_nev_off(coef_elems) + ((sizeof(int) * 3 * n + 255) & ~(size_t)255) + n + 256;
 }
 
 static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
@@ -597,26 +787,37 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     P.cm_init = p->cm_init, P.idc = p->chroma_format_idc;
     static const int burst = getenv("XEVE_HIP_SBAC_BURST") ? atoi(getenv("XEVE_HIP_SBAC_BURST")) : 1; // developer switch
     P.burst = burst;
-    unsigned *ev  = (unsigned *)workspace;
-    int      *nev = (int *)(ev + coef_elems);
+    char          *W    = (char *)workspace;
+    unsigned      *ev   = (unsigned *)W;
+    unsigned char *bins = (unsigned char *)(W + ws_bins_off(coef_elems));
+    int           *nev  = (int *)(W + ws_nev_off(coef_elems));
+    unsigned char *done = (unsigned char *)(nev + 3 * (size_t)njobs);
+    XH_REQUIRE(((uintptr_t)workspace & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const long items = 3L * njobs;
+    static const int use_stream = getenv("XEVE_HIP_SBAC_STREAM") ? atoi(getenv("XEVE_HIP_SBAC_STREAM")) : 1; // developer switch (measurement): 0 = event automaton only
+    const bool streams = use_stream && coef != nullptr; // (no coefficient buffer: header-only jobs, nothing to expand)
     if(reuse_events) nev = nullptr;
     if(!coef || reuse_events) {}
     else if(P.n[0] <= 64) {
         const long waves = (items + 3) / 4;
-        k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
+        k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev, streams ? bins : nullptr);
     }
-    else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev);
+    else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev, streams ? bins : nullptr);
     {
         XhProf prof(XH_PROF_CU_BITS, st);
         unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS);
         static const int use_reg = getenv("XEVE_HIP_SBAC_REG") ? atoi(getenv("XEVE_HIP_SBAC_REG")) : 0; // developer switch (measurement)
         const bool reg = use_reg && P.cm_init == 0;
-        if(full && reg) k_cu_bits<true, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
-        else if(full) k_cu_bits<true, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
-        else if(reg) k_cu_bits<false, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
-        else k_cu_bits<false, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units);
+        if(streams) { // jobs with a usable bin string first; the automaton below takes what is left
+            if(full) k_cu_bits_s<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, bits, sbac_out, units, done, xh_prof_units(XH_PROF_CU_BITS_SLOW));
+            else k_cu_bits_s<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, bits, sbac_out, units, done, xh_prof_units(XH_PROF_CU_BITS_SLOW));
+        }
+        const unsigned char *dn = streams ? done : nullptr;
+        if(full && reg) k_cu_bits<true, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
+        else if(full) k_cu_bits<true, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
+        else if(reg) k_cu_bits<false, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
+        else k_cu_bits<false, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

@@ -38,7 +38,7 @@ bool xh_ready();
     } while(0)
 
 // ---- kernel-class timers (abi.cpp; include/xeve_hip.h "xeve_hip_prof_*") ----------------------
-enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3, XH_PROF_RESID = 4, XH_PROF_RDOQ = 5 };
+enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3, XH_PROF_RESID = 4, XH_PROF_RDOQ = 5, XH_PROF_CU_BITS_SLOW = 6 };
 bool  xh_prof_on(int cls);
 void *xh_prof_begin(int cls, hipStream_t st);
 void  xh_prof_end(void *tok, hipStream_t st);

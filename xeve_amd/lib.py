@@ -226,7 +226,7 @@ def table_calls():
     return int(load().xeve_hip_table_calls())
 
 
-PROF_CLASSES = ("search", "spel", "cu_bits", "mc", "resid", "rdoq")  # include/xeve_hip.h: xeve_hip_prof_*
+PROF_CLASSES = ("search", "spel", "cu_bits", "mc", "resid", "rdoq", "cu_bits_slow")  # include/xeve_hip.h: xeve_hip_prof_*
 
 
 def prof_enable(classes=PROF_CLASSES):
