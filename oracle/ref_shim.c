@@ -404,9 +404,15 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
     hip_table_calls          = (unsigned long long (*)(void))dlsym(h, "xeve_hip_table_calls");
     const char *dev          = getenv("XEVE_HIP_DEVICE");
     if(init(dev ? atoi(dev) : 0) != 0) { fprintf(stderr, "[xeve_hip_shim] init: %s\n", err()); abort(); }
-    int n = install(&ctx->fn_itxb);
-    if(n != 9) { fprintf(stderr, "[xeve_hip_shim] install: %d (%s)\n", n, err()); abort(); }
-    ctx->fn_recon = shim_recon;
+    /* XEVE_HIP_SHIM_TABLES=0: leave the per-call dispatch tables (and fn_recon) with the reference -- for runs that route the coarse entry points only (the
+     * real-size encodes: the table layer's launch + sync per 128-byte block would dominate their wall time without adding coverage the table tests lack) */
+    const int tables = !(getenv("XEVE_HIP_SHIM_TABLES") && atoi(getenv("XEVE_HIP_SHIM_TABLES")) == 0);
+    int n = 0;
+    if(tables) {
+        n = install(&ctx->fn_itxb);
+        if(n != 9) { fprintf(stderr, "[xeve_hip_shim] install: %d (%s)\n", n, err()); abort(); }
+        ctx->fn_recon = shim_recon;
+    }
     if(getenv("XEVE_HIP_SHIM_DF") && atoi(getenv("XEVE_HIP_SHIM_DF"))) {
         hip_deblock_host = dlsym(h, "xeve_hip_deblock_host"), hip_expand_host = dlsym(h, "xeve_hip_picbuf_expand_host"), hip_err = err;
         if(!hip_deblock_host || !hip_expand_host) { fprintf(stderr, "[xeve_hip_shim] deblock / expand entry points missing\n"); abort(); }
@@ -450,5 +456,6 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         fprintf(stderr, "[xeve_hip_shim] motion search routed to the GPU\n");
     }
     atexit(report);
-    fprintf(stderr, "[xeve_hip_shim] HIP dispatch tables installed (%d pointers + fn_recon)\n", n);
+    if(tables) fprintf(stderr, "[xeve_hip_shim] HIP dispatch tables installed (%d pointers + fn_recon)\n", n);
+    else fprintf(stderr, "[xeve_hip_shim] dispatch tables left with the reference (XEVE_HIP_SHIM_TABLES=0)\n");
 }

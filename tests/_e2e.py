@@ -60,7 +60,7 @@ def make_yuv(path, w, h, frames, seed):
                 f.write(np.clip(a + r.integers(-2, 3, size=a.shape), 0, 255).astype(np.uint8).tobytes())
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False, tables=True):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -71,6 +71,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
     if hip:
         env["LD_PRELOAD"] = SHIM
         env["XEVE_HIP_LIB"] = HIP_LIB
+        if not tables:
+            env["XEVE_HIP_SHIM_TABLES"] = "0"  # the per-call dispatch tables stay the reference's; only the coarse routes below go to the GPU
         if inter:
             env["XEVE_HIP_SHIM_INTER"] = "1"  # the whole inter analysis of a CU (ctx->fn_pinter_analyze_cu)
             if resident:

@@ -12,5 +12,5 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o st -- python $GRAFT_REPO_ROOT/tools/probe_step.py 3 > $O/prof_step.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_struct -o st -- python $GRAFT_REPO_ROOT/tools/probe_step.py 3 --structured > $O/prof_struct.log 2>&1
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_e2e_real_sizes.py -x -q -s -m gpu -k "small or 720" > $O/pytest_e2e.log 2>&1
+timeout 600 python -m pytest tests/test_e2e_real_sizes.py -x -q -s -m gpu -k "small or 720 or 3840" > $O/pytest_e2e.log 2>&1
 tail -8 $O/pytest_e2e.log

@@ -91,13 +91,15 @@ struct McMulti {
 // block at org + job.pred_off and only the SAD / SSD leaves the CU (me_spel_pattern's xeve_mc_l + xeve_sad_16b,
 // xeve_pinter.c:593-627; skip/merge analysis' MC + xeve_ssd_16b, xeve_pinter.c:1437-1458).
 template <int TAPS, int SEG, int OUT>
-__global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, pel *__restrict__ pred, int s_pred,
-                                            const xeve_hip_mc_job *__restrict__ jobs, int njobs, int jpb, int w, int h,
+__global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_ref, int s_pred, int njobs, int jpb, int w, int h,
                                             int bit_depth, CoefTab<TAPS> tab, const pel *__restrict__ org, int s_org, int dshift,
-                                            void *__restrict__ dist_out, PlaneTab pt, McMulti mv)
+                                            void *__restrict__ dist_out, McMulti mv)
 {
     static_assert(SEG + TAPS - 1 <= 2 * SEG, "two vector loads must cover the FIR footprint");
-    if(mv.n) jobs = mv.jobs[blockIdx.y], pred = mv.pred[blockIdx.y], pt = mv.pt[blockIdx.y];
+    // the pass of this workgroup (always read straight out of the kernel-argument segment: a local copy of a pass's table would live in scratch)
+    const PlaneTab &ptv = mv.pt[blockIdx.y];
+    const xeve_hip_mc_job *__restrict__ jobs = mv.jobs[blockIdx.y];
+    pel *__restrict__ pred = mv.pred[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) int16_t hbuf[]; // jpb * (h + TAPS - 1) * w
     constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
     typedef typename SegIO<SEG>::vec vec;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         const int jl = u / per1, r = u - jl * per1, y = r / segs, x0 = (r - y * segs) * SEG;
         const xeve_hip_mc_job jb = jobs[j0 + jl];
         if((jb.frac & 7) != 3) continue; // bit 2 = job switched off (xeve_hip_mc_cu_jobs)
-        const pel *src = plane_of(pt, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
+        const pel *src = plane_of(ptv, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y - BACK) * s_ref + (jb.gmv_x >> FS) + x0 - BACK;
         int acc[SEG];
         hfir<TAPS, SEG>(src, tab.c[jb.gmv_x & FM], acc);
 #pragma unroll
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         const xeve_hip_mc_job jb = jobs[j0 + jl];
         if(jb.frac & 4) continue;
         const bool hx = (jb.frac & 1) != 0, vy = (jb.frac & 2) != 0;
-        const pel *src = plane_of(pt, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
+        const pel *src = plane_of(ptv, ref, jb.frac) + (long)((jb.gmv_y >> FS) + y) * s_ref + (jb.gmv_x >> FS) + x0;
         pel *out = pred + jb.pred_off + y * s_pred + x0;
         int acc[SEG];
         if(!hx && !vy) {
@@ -270,21 +272,21 @@ static int mc_launch(const pel *ref, int s_ref, pel *pred, int s_pred, const xev
     else pt.n = 0;
     McMulti mv;
     if(multi) mv = *multi;
-    else mv.n = 0;
-    const unsigned gy = multi ? (unsigned)multi->n : 1u;
+    else mv.n = 1, mv.jobs[0] = jobs, mv.pred[0] = pred, mv.pt[0] = pt; // the single pass described by the plain arguments
+    const unsigned gy = (unsigned)mv.n;
     const int dshift = OUT == 1 ? bit_depth - 8 : (bit_depth - 8) * 2;
     bool done = false;
     if(w % 8 == 0) {
         const int jpb = std::max(1, 256 / (h * (w / 8)));
         const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-        k_mc<TAPS, 8, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt, mv);
+        k_mc<TAPS, 8, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, s_pred, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, mv);
         done = true;
     }
     if constexpr(TAPS == 4) {
         if(!done && w % 4 == 0) {
             const int jpb = std::max(1, 256 / (h * (w / 4)));
             const size_t lds = ((sizeof(int16_t) * (size_t)jpb * (h + TAPS - 1) * w + 7) & ~(size_t)7) + 8 * (size_t)jpb;
-            k_mc<4, 4, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, pred, s_pred, jobs, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, pt, mv);
+            k_mc<4, 4, OUT><<<dim3((njobs + jpb - 1) / jpb, gy), 256, lds, st>>>(ref, s_ref, s_pred, njobs, jpb, w, h, bit_depth, tab, org, s_org, dshift, dist_out, mv);
             done = true;
         }
     }

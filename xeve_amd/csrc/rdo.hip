@@ -15,6 +15,7 @@
 // Jobs of a round run in parallel over all candidates.  Rounds 2 and 3 always use the count-only kernel (their states are only ever
 // loaded into further counts: range and models suffice); rounds 1 and 4 carry the complete coder state when the caller asks for
 // core->s_temp_best.
+#include <cstdlib>
 #include "xh_common.h"
 
 extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h,
@@ -229,6 +230,135 @@ __global__ void k_rdo_zero_dropped(int16_t *__restrict__ coef, const unsigned ch
     for(int i = lane; i < n; i += 64) b[i] = 0;
 }
 
+// ---- the same decision in ONE bit-count round (batches small enough to be latency-bound) ----------------------------------------------
+// The four rounds above are a dependent chain: on a level with few, large CUs (64x64: 2 040 per 4K picture) each round is a handful of waves waiting
+// for their longest bin string, and the chain is the critical path of the whole level.  Every count the chain can ever ask for is known up front,
+// though: the all-zero and as-quantised CU, the per-component tests under each of the four possible (Y choice, U choice) outcomes (k_cu_bits_chain: one
+// lane per outcome), and the whole CU under each of the six combinations of kept components the tests can choose (CU_INTER jobs).  They are all
+// launched together -- 8 whole-CU jobs + 4 chain lanes per candidate, against at most 8 jobs in four rounds -- and one kernel then walks the reference's
+// decision over the counts.  More bins in total (the large levels have the lanes to spare), a third of the serial length.
+// whole-CU jobs: kind k = (keep Y) | (keep U) << 1 | (keep V) << 2 of candidate j at k * njobs + j; kind 0 = all-zero, kind 7 = as quantised.
+__global__ void k_rdo_spec_jobs(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const int *__restrict__ nnz_y, const int *__restrict__ nnz_u,
+                                const int *__restrict__ nnz_v, Cand *__restrict__ cand, xeve_hip_cu_bits_job *__restrict__ bj, xeve_hip_cu_bits_job *__restrict__ cj)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    Cand c;
+    c.nnz_store[0] = nnz_y[j], c.nnz_store[1] = P.ncomp > 1 ? nnz_u[j] : 0, c.nnz_store[2] = P.ncomp > 1 ? nnz_v[j] : 0;
+    c.tnnz = c.nnz_store[0] + c.nnz_store[1] + c.nnz_store[2];
+    c.cost_best = MAX_COST, c.idx_best[0] = c.idx_best[1] = c.idx_best[2] = 0, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0;
+    c.iy = c.nnz_store[0] > 0, c.iu = c.nnz_store[1] > 0, c.iv = c.nnz_store[2] > 0, c.round4 = 0, c.win = 0;
+    cand[j] = c;
+    const int N = P.njobs, all = c.iy | (c.iu << 1) | (c.iv << 2);
+    for(int k = 0; k < 8; k++) {
+        // a combination is a job of its own only when it keeps nothing but stored components and is neither all-zero (kind 0) nor everything stored
+        // (kind 7 stands for that one whatever `all` is); the others are switched off (a skip-mode job: a handful of header bins)
+        const bool on = k == 0 || k == 7 || ((k & ~all) == 0 && k != all);
+        const int  kk = k == 7 ? all : k;
+        fill_bits_job(bj[(size_t)k * N + j], J, P, j, on ? XEVE_HIP_BITS_CU_INTER : XEVE_HIP_BITS_CU_SKIP, (kk & 1) ? c.nnz_store[0] : 0, (kk & 2) ? c.nnz_store[1] : 0,
+                      (kk & 4) ? c.nnz_store[2] : 0, J.sbac);
+    }
+    for(int l = 0; l < 4; l++) { // chain lane l assumes (Y kept = l & 1, U kept = l >> 1); impossible assumptions are switched off
+        const bool on = c.tnnz != 0 && (!(l & 1) || c.iy) && (!(l & 2) || c.iu);
+        xeve_hip_cu_bits_job &b = cj[(size_t)l * N + j];
+        fill_bits_job(b, J, P, j, on ? XEVE_HIP_BITS_COMP_Y : XEVE_HIP_BITS_CU_SKIP, c.nnz_store[0], c.nnz_store[1], c.nnz_store[2], J.sbac);
+        b.dir_flag = (uint8_t)l;
+    }
+}
+
+// the reference's decision (xeve_pinter.c:1103-1275) over the counts of the one round; also zeroes nothing: k_rdo_zero_dropped follows
+__global__ void k_rdo_spec_decide(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, const long *ssd_y, const long *ssd_u, const long *ssd_v,
+                                  const unsigned *__restrict__ bits, const unsigned *__restrict__ cbits, const xeve_hip_sbac *__restrict__ st_out,
+                                  Cand *__restrict__ cand, xeve_hip_rdo_result *__restrict__ res, unsigned char *__restrict__ drop, xeve_hip_sbac *__restrict__ best)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= P.njobs) return;
+    const xeve_hip_rdo_job J = jobs[j];
+    Cand c = cand[j];
+    long d0[3], d1[3];
+    load_dist(ssd_y, ssd_u, ssd_v, j, P, d0, d1);
+    const size_t N = P.njobs;
+    auto wb = [&](int k) { return (double)(int)bits[(size_t)k * N + j]; };                        // whole-CU count of combination k
+    auto cb = [&](int lane, int which) { return (double)(int)cbits[4 * ((size_t)lane * N + j) + which]; }; // chain lane: 0 Y, 1 U, 2 V without, 3 V with
+    if(c.tnnz == 0) { // nothing survived quantisation (:1276-1331)
+        c.cost_best = (double)d0[0] + (P.wgt[0] * (double)d0[1]) + (P.wgt[1] * (double)d0[2]);
+        c.cost_best += wb(0) * P.lambda[0];
+        c.win = 0;
+        if(best) copy_state(best + j, st_out + j);
+    }
+    else {
+        if(!J.dir_flag) { // all-zero alternative (:1103-1142)
+            double cost = sum_cost(d0, d1, 0, 0, 0, P);
+            cost += wb(0) * P.lambda[0];
+            if(cost < c.cost_best) {
+                c.cost_best = cost, c.cbf_idx[0] = c.cbf_idx[1] = c.cbf_idx[2] = 0, c.win = 0;
+                if(best) copy_state(best + j, st_out + j);
+            }
+        }
+        { // as quantised (:1144-1178)
+            double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
+            cost += wb(7) * P.lambda[0];
+            if(cost < c.cost_best) {
+                c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, c.win = 1;
+                if(best) copy_state(best + j, st_out + 7 * N + j);
+            }
+        }
+        // the component tests (:1180-1218): without is taken first, with must be strictly cheaper; each test reads the lane that assumed the picks so far
+        int lane = 0;
+        if(c.nnz_store[0] > 0) {
+            double c0 = (double)d0[0] * 1.0, c1 = (double)d1[0] * 1.0;
+            c0 += cb(0, 0) * P.lambda[0], c1 += cb(1, 0) * P.lambda[0];
+            c.idx_best[0] = c1 < c0;
+            lane |= c.idx_best[0];
+        }
+        if(c.nnz_store[1] > 0) {
+            double c0 = (double)d0[1] * P.wgt[0], c1 = (double)d1[1] * P.wgt[0];
+            c0 += cb(lane, 1) * P.lambda[1], c1 += cb(lane | 2, 1) * P.lambda[1];
+            c.idx_best[1] = c1 < c0;
+            lane |= c.idx_best[1] << 1;
+        }
+        if(c.nnz_store[2] > 0) {
+            double c0 = (double)d0[2] * P.wgt[1], c1 = (double)d1[2] * P.wgt[1];
+            c0 += cb(lane, 2) * P.lambda[2], c1 += cb(lane, 3) * P.lambda[2];
+            c.idx_best[2] = c1 < c0;
+        }
+        // the combination the tests chose (:1220-1262)
+        int n[3] = {c.nnz_store[0], c.nnz_store[1], c.nnz_store[2]};
+        if(c.idx_best[0] || c.idx_best[1] || c.idx_best[2]) {
+            c.iy = c.idx_best[0], c.iu = c.idx_best[1], c.iv = c.idx_best[2];
+            n[0] = c.iy ? n[0] : 0, n[1] = c.iu ? n[1] : 0, n[2] = c.iv ? n[2] : 0;
+        }
+        c.round4 = n[0] != c.nnz_store[0] || n[1] != c.nnz_store[1] || n[2] != c.nnz_store[2];
+        if(c.round4) {
+            const int k = (n[0] ? 1 : 0) | (n[1] ? 2 : 0) | (n[2] ? 4 : 0);
+            double cost = sum_cost(d0, d1, c.iy, c.iu, c.iv, P);
+            cost += wb(k) * P.lambda[0];
+            if(cost < c.cost_best) {
+                c.cost_best = cost, c.cbf_idx[0] = c.iy, c.cbf_idx[1] = c.iu, c.cbf_idx[2] = c.iv, c.win = 2;
+                if(best) copy_state(best + j, st_out + (size_t)k * N + j);
+            }
+        }
+    }
+    cand[j] = c;
+    xeve_hip_rdo_result r;
+    r.cost = c.cost_best, r.pad_ = 0;
+    for(int k = 0; k < 3; k++) {
+        r.nnz[k] = c.tnnz != 0 && c.cbf_idx[k] ? c.nnz_store[k] : 0;
+        drop[3 * j + k] = r.nnz[k] == 0 && c.nnz_store[k] != 0;
+        r.dist[0][k] = d0[k], r.dist[1][k] = c.tnnz != 0 ? d1[k] : 0;
+    }
+    res[j] = r;
+}
+
+// candidates x 12 lanes up to which the one-round form is used (above it the level has enough waves for the four-round form to be throughput-bound)
+static int rdo_spec_limit()
+{
+    static const int v = getenv("XEVE_HIP_RDO_SPEC") ? atoi(getenv("XEVE_HIP_RDO_SPEC")) : 26000; // developer switch: 0 = never
+    return v;
+}
+static bool rdo_use_spec(int njobs) { return njobs <= rdo_spec_limit(); }
+
 // ---- host ------------------------------------------------------------------------------------------------------------------
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -246,10 +376,11 @@ static RdoLayout rdo_layout(int njobs, int n0, int n1, int nstates, size_t rec_l
     L.rec[0] = take(rec_l * 2), L.rec[1] = take(rec_c * 2 + 8), L.rec[2] = take(rec_c * 2 + 8);
     for(int k = 0; k < 3; k++) L.nnz[k] = take(n * 4), L.ssd[k] = take(n * 16);
     L.cand = take(n * sizeof(Cand)), L.prev = take(n * sizeof(xeve_hip_sbac));
-    L.bj = take(4 * n * sizeof(xeve_hip_cu_bits_job)), L.bits = take(4 * n * 4), L.st_out = take(4 * n * sizeof(xeve_hip_sbac));
+    const size_t kinds = rdo_use_spec(njobs) ? 8 : 4; // whole-CU job kinds per candidate (the one-round form adds 4 chain lanes with 4 counts each)
+    L.bj = take((kinds + 4) * n * sizeof(xeve_hip_cu_bits_job)), L.bits = take((kinds + 16) * n * 4), L.st_out = take(kinds * n * sizeof(xeve_hip_sbac));
     L.drop = take(3 * n);
     L.mcws = take(xeve_hip_mc_cu_workspace(njobs, w, h, nr0, nr1));
-    L.bitws = take(xeve_hip_cu_bits_workspace(4 * njobs, n * ((size_t)n0 + 2 * (size_t)n1)));
+    L.bitws = take(xeve_hip_cu_bits_workspace((int)kinds * njobs, n * ((size_t)n0 + 2 * (size_t)n1)));
     L.total = o;
     return L;
 }
@@ -327,11 +458,25 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
     bp.cm_init = 0, bp.chroma_format_idc = idc;
     const size_t coef_elems = (size_t)njobs * (P.n0 + 2 * (size_t)P.n1), bws = workspace_bytes - L.bitws;
+    if(rdo_use_spec(njobs)) { // one bit-count round: every count the decision can ask for, side by side
+        xeve_hip_cu_bits_job *cj = bj + 8 * (size_t)njobs;
+        unsigned             *cbits = bits + 8 * (size_t)njobs;
+        k_rdo_spec_jobs<<<G, 256, 0, st>>>(jobs, P, nnz[0], nnz[1], nnz[2], cand, bj, cj);
+        // (events and bin strings from the as-quantised jobs alone: they code every stored block exactly once)
+        rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, 8 * njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, best != nullptr, 0, stream, 7 * njobs, njobs);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+        rc_ = xh_cu_bits_chain_round(coef_elems, states, cj, 4 * njobs, &bp, W + L.bitws, bws, cbits, stream);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+        k_rdo_spec_decide<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cbits, st_out, cand, results, drop, best);
+        k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
+        XH_HIP(hipGetLastError());
+        return XEVE_HIP_OK;
+    }
     k_rdo_round1<<<G, 256, 0, st>>>(jobs, P, nnz[0], nnz[1], nnz[2], cand, bj);
     // (the complete coder state is carried only where core->s_temp_best can come from -- the whole-CU counts of rounds 1 and 4 -- and only
     // when the caller wants it; the component tests' states are only ever loaded into further counts: range and models suffice)
     // (the event lists of the coefficient blocks are made in round 1 -- its "as quantised" jobs code every non-zero block -- and reused after)
-    rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, best != nullptr, 0, stream);
+    rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, 4 * njobs, &bp, W + L.bitws, bws, bits, st_out, best != nullptr, 0, stream, njobs, njobs); // (events from the as-quantised jobs)
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_rdo_decide1<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, st_out, states, cand, prev, bj, best);
     if(P.ncomp > 1) {

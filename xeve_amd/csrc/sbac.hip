@@ -354,246 +354,142 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
 }
 
 // ---- one lane per job ------------------------------------------------------------------------------------------------
-#define RING 32 // events staged per lane in LDS
-#define WIN 32  // iterations between two refills; an event takes >= 4 bins, so a window consumes <= 8 of them
-#define FILL 16 // events fetched per refill
-#define BURST 8 // MPS bins a lane may take in one go after its general step
+// The models live in LDS ([model][lane], one wave per workgroup), the header bins are queued per lane and drained by one loop, and the coefficient bins
+// of every coded block come from the block's bin string (k_coef_events): per bin the byte, its model (read from LDS one bin AHEAD, with the just-written
+// model forwarded when two consecutive bins share it), the coder step, the model write-back.  The string is fetched 16 bytes at a time, the next chunk
+// while the current one is coded, so neither the global nor the LDS latency sits on the serial chain.  A block without a usable string (BIN_OVF: levels so
+// large that the string does not fit; or a job whose coefficient count is not the block's true count -- the reference then stops after nnz events) goes
+// through code_events: the same bins generated on the fly from the event list, one at a time (exact, slow, rare).
+typedef u32x4 u32x4_a4g __attribute__((aligned(4)));
+typedef uint16_t (*CtxTab)[64];
 
-// REGCTX (sps_cm_init_flag 0, i.e. the Baseline profile): a component type -- luma / chroma -- then uses exactly five models (run first / rest, level
-// first / rest, last; xeve_eco.c:722-760), and they live PACKED IN THREE REGISTERS (A = run, B = level: first model in the low half, rest model in the high
-// half; C = last in the high half) instead of LDS: selecting and writing back a model is a handful of VALU operations, where the LDS round trip was two
-// exposed ~100-cycle latencies per bin at the one wave per SIMD the large-CU levels run at.  The next event is read from the LDS ring at the TOP of the
-// step that may consume the current one, so that its latency hides under the step.  The automaton is: unary value (run, then level: a first bin on the
-// first model, further bins on the rest model), sign (bypass), last flag.
-template <bool FULL, bool REGCTX>
-__global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs,
-                                                CuBitsK P, const unsigned *__restrict__ ev, const int *__restrict__ nev,
-                                                unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units,
-                                                const unsigned char *__restrict__ done)
+template <bool FULL> __device__ __forceinline__ void code_queue(Sbac &s, CtxTab s_ctx, const uint8_t (*s_q)[64], int lane, int n)
 {
-    __shared__ uint16_t s_ctx[NCTX][64];
-    // the header queue is drained before the first event reaches the ring: the two share their LDS (one wave per workgroup, so the
-    // order within the wave is the only order there is)
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[QMAX * 64 > RING * 64 * 4 ? QMAX * 64 : RING * 64 * 4];
-    uint8_t(*s_q)[64]     = reinterpret_cast<uint8_t(*)[64]>(s_raw);
-    unsigned(*s_ring)[64] = reinterpret_cast<unsigned(*)[64]>(s_raw);
-    const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
-    if(j >= njobs) return;
-    if(done && done[j]) return; // counted from the bin strings already (k_cu_bits_s)
-    const xeve_hip_cu_bits_job J = jobs[j];
-    const xeve_hip_sbac &in = sin[J.sbac];
-    Sbac s;
-    s.range = in.range, s.shifts = s.bins = 0;
-    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
-    if(FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET)) { // continue the coder where the state stands
-        s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
-        s.bc = in.bitcounter, s.bins = in.bin_counter;
-    }
-    for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
-
-    Queue Q{&s_q[0][lane], 0};
-    const unsigned coded = q_header(Q, J, P);
-
-    // The coded components' event lists form ONE stream per lane: [0, b1) luma, [b1, b2) Cb, [b2, total) Cr.  A list ends
-    // with its nnz-th event (the reference stops at num_sig == 0) or when it runs out.
-    // (nev == NULL: the event lists were made by an earlier launch over the same coefficient buffer and the jobs' nnz are exact counts)
-    const int l0 = (coded & 1) ? (nev ? min(nev[j * 3], J.nnz[0]) : J.nnz[0]) : 0, l1 = (coded & 2) ? (nev ? min(nev[j * 3 + 1], J.nnz[1]) : J.nnz[1]) : 0;
-    const int l2 = (coded & 4) ? (nev ? min(nev[j * 3 + 2], J.nnz[2]) : J.nnz[2]) : 0;
-    const int b1 = l0, b2 = l0 + l1, total = l0 + l1 + l2;
-    const int o0 = J.coef_off[0], o1 = J.coef_off[1] - b1, o2 = J.coef_off[2] - b2;
-    const int d1 = o1 - o0, d2 = o2 - o1; // (additive form: a select between three bases makes the compiler build a pointer table in scratch)
-    auto fetch = [&](int q) -> unsigned { return q < total ? ev[o0 + (q >= b1 ? d1 : 0) + (q >= b2 ? d2 : 0) + q] : 0u; };
-
-    // events travel global -> registers (in flight during a whole window) -> LDS ring -> automaton, so that no iteration
-    // of the bin loop waits on a global load
-    unsigned buf[FILL];
-    int      filled = 0, cnt = min(FILL, total);
-#pragma unroll
-    for(int i = 0; i < FILL; i++) buf[i] = fetch(i);
-
-    for(int i = 0; i < Q.n; i++) { // header bins (the first events are in flight meanwhile)
+    for(int i = 0; i < n; i++) {
         const unsigned e = s_q[i][lane], ci = e >> 2;
         const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, (e & 2) != 0); // (bypass entries pass model 0 through)
         s_ctx[ci][lane] = (uint16_t)m;
     }
+}
 
-    // coefficient automaton: one bin per general step
-    int      e = 0, phase = 0, numsig = b1 > 0 ? J.nnz[0] : b2 > 0 ? J.nnz[1] : J.nnz[2];
-    int      ch = b1 > 0 ? 0 : 1;                                   // 0 luma, 1 chroma
-    int      t0 = P.cm_init == 1 ? 10 + ch * 12 : ch * 2;          // prev_level = 6 at the start of a block (xeve_eco.c:722,731-733)
-    unsigned k = 0;
-    // Two compiled forms of the loop: with and without the burst.  The burst pays when zero runs (or levels) are long; where most bins
-    // are first bins, signs and last flags its vote and code only lengthen the serial step.  Each wave picks once, from the mean
-    // number of scan positions per event of its jobs.
-    // ---- REGCTX state
-    unsigned cA = 0, cB = 0, cC = 0, cur = 0, u = 0;
-    int      p = 0, f = 1; // p: 0 run, 1 level, 2 sign, 3 last flag; f: the next unary bin is the first of its value
-    bool     have = false;
-    auto ctx_load = [&](int c) {
-        cA = (unsigned)s_ctx[XEVE_HIP_CTX_RUN + 2 * c][lane] | ((unsigned)s_ctx[XEVE_HIP_CTX_RUN + 2 * c + 1][lane] << 16);
-        cB = (unsigned)s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c][lane] | ((unsigned)s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c + 1][lane] << 16);
-        cC = (unsigned)s_ctx[XEVE_HIP_CTX_LAST + c][lane] << 16;
+template <bool FULL> __device__ __forceinline__ void code_string(Sbac &s, CtxTab s_ctx, int lane, const unsigned char *sp, int rem)
+{
+    if(rem <= 0) return;
+    const u32x4_a4g *gp = reinterpret_cast<const u32x4_a4g *>(sp);
+    u32x4 cur = gp[0];
+    unsigned ci = (cur.x & 0xFFu) >> 1;
+    ci = ci < BYP ? ci : BYP;
+    unsigned m = s_ctx[ci][lane];
+    auto step = [&](unsigned b, unsigned b1) { // code bin b on model ci (value m); b1: the byte after it
+        unsigned ci1 = (b1 & 0xFFu) >> 1;
+        ci1 = ci1 < BYP ? ci1 : BYP; // (past the end of the string: any byte)
+        const unsigned mp = s_ctx[ci1][lane];
+        const unsigned m1 = sb_encode<FULL>(s, m, b & 1u, ci == BYP);
+        s_ctx[ci][lane] = (uint16_t)m1;
+        m = ci1 == ci ? m1 : mp, ci = ci1;
     };
-    auto ctx_store = [&](int c) {
-        s_ctx[XEVE_HIP_CTX_RUN + 2 * c][lane] = (uint16_t)cA, s_ctx[XEVE_HIP_CTX_RUN + 2 * c + 1][lane] = (uint16_t)(cA >> 16);
-        s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c][lane] = (uint16_t)cB, s_ctx[XEVE_HIP_CTX_LEVEL + 2 * c + 1][lane] = (uint16_t)(cB >> 16);
-        s_ctx[XEVE_HIP_CTX_LAST + c][lane] = (uint16_t)(cC >> 16);
-    };
-    if(REGCTX && total > 0) ctx_load(ch);
-    auto loop = [&](auto with_burst) {
-    constexpr bool WB = decltype(with_burst)::value;
-    while(e < total) {
+    while(rem > 0) {
+        gp++;
+        const u32x4 nxt = gp[0]; // (reads up to 31 bytes past the string: inside the block's region, the next one, or the slack behind the last)
+        if(rem >= 16) {
 #pragma unroll
-        for(int i = 0; i < FILL; i++) // commit the refill that was in flight
-            if(i < cnt) s_ring[(filled + i) & (RING - 1)][lane] = buf[i];
-        filled += cnt;
-        cnt = min(min(FILL, RING - (filled - e)), total - filled);
-#pragma unroll
-        for(int i = 0; i < FILL; i++) // issue the next one
-            if(i < cnt) buf[i] = fetch(filled + i);
-
-        if constexpr(REGCTX) {
-            if(!have) cur = s_ring[e & (RING - 1)][lane], u = (cur >> 16) & 0xFFF, have = true; // (first window: the first event has just reached the ring)
-        }
-        for(int it = 0; it < WIN; it++) {
-            if constexpr(REGCTX) {
-            if(e < total) {
-                // Written as mask arithmetic on purpose (as the general step below): 64 lanes are in 64 different phases, and every ternary chain over `p`
-                // comes back from the compiler as a ladder of exec-mask branches that all lanes pay for.
-                const unsigned pre = s_ring[(e + 1) & (RING - 1)][lane]; // the next event: landed by the time this step ends
-                const unsigned lev1 = cur & 0x7FFF, sgn = 0u - ((cur >> 15) & 1), atend = 0u - ((cur >> 28) & 1);
-                const unsigned up = (unsigned)p;
-                const unsigned is0 = 0u - (unsigned)(up == 0), is1 = 0u - (unsigned)(up == 1), is2 = 0u - (unsigned)(up == 2), is3 = 0u - (unsigned)(up == 3);
-                const unsigned un = is0 | is1, ub = 0u - (unsigned)(u != 0), fm = 0u - (unsigned)f;
-                const unsigned bin = ((ub & un) | (sgn & is2) | ((0u - (unsigned)(numsig == 0)) & is3)) & 1u;
-                const unsigned w = (cA & is0) | (cB & is1) | (cC & ~un);
-                const unsigned sh = ~(un & fm) & 16u; // first bins in the low halves; rest bins and `last` in the high halves
-                const unsigned m = (w >> sh) & 0xFFFFu;
-                const unsigned m1 = sb_encode<FULL>(s, m, bin, is2 != 0); // (bypass hands the model back unchanged)
-                const unsigned nw = w ^ ((m ^ m1) << sh);
-                cA = (nw & is0) | (cA & ~is0), cB = (nw & is1) | (cB & ~is1), cC = (nw & is3) | (cC & ~is3);
-                // transitions: a 1 of a unary value stays (one less to go, rest model); its 0 moves on; the sign ends the event at the last scan
-                // position (no last flag there, xeve_eco.c:744-746), else the last flag does
-                const unsigned stay = un & ub, adv = is3 | (is2 & atend), to_level = is0 & ~ub, fresh = to_level | adv;
-                numsig -= (int)(is2 & 1u);
-                p = (int)((up & stay) | (~stay & ((1u & is0) | (2u & is1) | (3u & is2 & ~atend))));
-                e += (int)(adv & 1u);
-                cur = (pre & adv) | (cur & ~adv);
-                u = ((u - 1) & stay) | (~stay & ((lev1 & to_level) | (((pre >> 16) & 0xFFFu) & adv) | (u & ~fresh)));
-                f = (int)(~stay & (fresh | fm) & 1u);
-                const unsigned newc = adv & (0u - (unsigned)(e == b1 || e == b2));
-                numsig = (int)(((unsigned)(e >= b2 ? J.nnz[2] : J.nnz[1]) & newc) | ((unsigned)numsig & ~newc));
-                const int nch = e >= b1 ? 1 : 0;
-                if(__ballot(newc != 0 && nch != ch)) { // luma -> chroma: swap the packed models (once per job at most; Cb -> Cr keeps them)
-                    if(newc != 0 && nch != ch) ctx_store(ch), ctx_load(nch);
-                }
-                ch = nch;
-                if constexpr(WB) { // burst: up to BURST further 1s of a unary value on the rest model, while that model's MPS is 1 (see below)
-                    const bool can = p < 2 && f == 0 && u >= 1;
-                    const bool worth = 2 * __popcll(__ballot(can && u >= 6)) >= __popcll(__ballot(true));
-                    if(worth && can) {
-                        const unsigned wb = p == 0 ? cA : cB, mb = wb >> 16;
-                        if(mb & 1) {
-                            unsigned st = mb >> 1, R = s.range;
-                            const unsigned steps = u < BURST ? u : BURST;
-#pragma unroll
-                            for(unsigned q = 0; q < BURST; q++)
-                                if(q < steps) {
-                                    unsigned lps = (st * R) >> 9;
-                                    lps = lps < 437 ? 437 : lps;
-                                    R -= lps, st -= (st + 16) >> 5;
-                                    const unsigned shf = R < 8192;
-                                    R <<= shf, s.shifts += shf;
-                                }
-                            s.range = R, s.bins += steps, u -= steps;
-                            const unsigned nb2 = (wb & 0xFFFFu) | (((st << 1) | 1u) << 16);
-                            cA = p == 0 ? nb2 : cA, cB = p == 1 ? nb2 : cB;
-                        }
-                    }
-                }
-            }
-            }
-            else
-            if(e < total) {
-                // ---- general step: phases 0 run first bin, 1 run rest, 2 level first bin, 3 level rest, 4 sign, 5 last flag.
-                // Written without branches on purpose: 64 lanes are in 64 different phases, and any `if` some lane takes is paid by all.
-                const unsigned cur = s_ring[e & (RING - 1)][lane];
-                const unsigned run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1, at_end = (cur >> 28) & 1;
-                // phase-dependent values by mask arithmetic and packed tables (a ternary chain over `phase` comes back from the compiler as a
-                // ladder of exec-mask branches)
-                const unsigned ph = (unsigned)phase;
-                const unsigned m0 = 0u - (unsigned)(ph == 0), m2 = 0u - (unsigned)(ph == 2), m4 = 0u - (unsigned)(ph == 4), m5 = 0u - (unsigned)(ph == 5);
-                const unsigned lt4 = 0u - (unsigned)(ph < 4);
-                const unsigned kn = (run & m0) | (lev1 & m2) | ((k - 1) & ~(m0 | m2));
-                const unsigned bin = (sign & m4) | ((unsigned)(numsig == 0) & m5) | ((unsigned)(kn != 0) & lt4);
-                // context index: RUN, RUN + 1, LEVEL, LEVEL + 1, (unused), LAST -- plus t0 (phases 0..3) or the component (phase 5)
-                const unsigned base = (unsigned)((0x2A2C2D2C1312ull >> (ph * 8)) & 0xFF);
-                const int      ci = (int)(base + (((unsigned)t0) & ~m5) + (((unsigned)ch) & m5));
-                const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], bin, ph == 4);
-                s_ctx[ci][lane] = (uint16_t)m;
-                const unsigned adv = (m5 | (m4 & (0u - at_end))) & 1u; // no last flag at scan_pos == num_coeff - 1 (xeve_eco.c:744-746)
-                const int  nphase = (int)((((ph | 1) + (unsigned)(kn == 0)) & lt4) | (5u & m4 & ~(0u - at_end)));
-                numsig -= (int)(m4 & 1u);
-                e += (int)adv;
-                const unsigned newc = (0u - adv) & (0u - (unsigned)(e == b1 || e == b2));
-                ch = e >= b1;
-                numsig = (int)(((unsigned)(e >= b2 ? J.nnz[2] : J.nnz[1]) & newc) | ((unsigned)numsig & ~newc));
-                if(P.cm_init == 1) { // the context pair follows the previous level: min(prev_level - 1, 5), 5 at the start of a block
-                    const unsigned plev = (5u & newc) | ((lev1 < 5 ? lev1 : 5u) & ~newc);
-                    const unsigned am = 0u - adv;
-                    t0 = (int)((((plev << 1) + (unsigned)ch * 12u) & am) | ((unsigned)t0 & ~am));
-                }
-                else t0 = ch * 2;
-                k = kn, phase = nphase;
-                // ---- burst: most bins are the "1"s of a unary code (zero runs, large levels) on an adapted model, i.e.
-                // a run of MPS bins on ONE context -- range and state recurrence only, the model stays in a register
-                // (taken only when at least half of the lanes still at work have >= 6 such bins ahead: the burst costs
-                // about one general step, whoever uses it)
-                if constexpr(WB) {
-                const bool unary = (phase & 1) && phase < 4 && k >= 2;
-                const bool worth = 2 * __popcll(__ballot(unary && k >= 7)) >= __popcll(__ballot(true));
-                if(worth && unary) {
-                    const int cb = (phase == 1 ? XEVE_HIP_CTX_RUN : XEVE_HIP_CTX_LEVEL) + t0 + 1;
-                    const unsigned mb = s_ctx[cb][lane];
-                    if(mb & 1) {
-                        unsigned st = mb >> 1, R = s.range;
-                        const unsigned steps = k - 1 < BURST ? k - 1 : BURST;
-#pragma unroll
-                        for(unsigned u = 0; u < BURST; u++)
-                            if(u < steps) {
-                                unsigned lps = (st * R) >> 9;
-                                lps = lps < 437 ? 437 : lps;
-                                R -= lps, st -= (st + 16) >> 5;
-                                const unsigned sh = R < 8192;
-                                R <<= sh, s.shifts += sh;
-                            }
-                        s.range = R, s.bins += steps, k -= steps;
-                        s_ctx[cb][lane] = (uint16_t)((st << 1) | 1);
-                    }
-                }
-                }
+            for(int i = 0; i < 16; i++) {
+                const unsigned wv = cur[i >> 2], wn = i < 15 ? cur[(i + 1) >> 2] : nxt.x;
+                step(wv >> (8 * (i & 3)), wn >> (8 * ((i + 1) & 3)));
             }
         }
+        else {
+            for(int i = 0; i < rem; i++) {
+                const int i1 = i + 1;
+                const unsigned wv = (i >> 2) == 0 ? cur.x : (i >> 2) == 1 ? cur.y : (i >> 2) == 2 ? cur.z : cur.w;
+                const unsigned wn = (i1 >> 2) == 0 ? cur.x : (i1 >> 2) == 1 ? cur.y : (i1 >> 2) == 2 ? cur.z : cur.w; // (i1 <= 15 here)
+                step(wv >> (8 * (i & 3)), wn >> (8 * (i1 & 3)));
+            }
+        }
+        cur = nxt, rem -= 16;
     }
-    };
-    bool burst = false;
-    if(!FULL && P.burst) {
-        int npos = ((coded & 1) ? P.n[0] : 0) + ((coded & 2) ? P.n[1] : 0) + ((coded & 4) ? P.n[2] : 0), nevt = total;
-#pragma unroll
-        for(int m = 1; m < 64; m <<= 1) npos += __shfl_xor(npos, m, 64), nevt += __shfl_xor(nevt, m, 64);
-        burst = npos >= 10 * nevt; // (lanes past the end of the job list have left already: the shuffles read their own value back)
-    }
-    if(burst) loop(std::true_type{});
-    else loop(std::false_type{});
-    if(REGCTX && total > 0) ctx_store(ch);
+}
 
+// xeve_eco_run_length_cc (xeve_eco.c:707-771) straight from the event list: `nevents` events, the last-position flag driven by num_sig as the reference's
+template <bool FULL>
+__device__ __forceinline__ void code_events(Sbac &s, CtxTab s_ctx, int lane, const unsigned *__restrict__ ev, int nevents, int num_sig, int ch, int cm_init)
+{
+    auto bin = [&](int ci, unsigned b) {
+        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], b, false);
+        s_ctx[ci][lane] = (uint16_t)m;
+    };
+    unsigned plev = 5; // min(previous level - 1, 5); 5 at the start of a block
+    for(int e = 0; e < nevents; e++) {
+        const unsigned cur = ev[e], run = (cur >> 16) & 0xFFF, lev1 = cur & 0x7FFF, sign = (cur >> 15) & 1, at_end = (cur >> 28) & 1;
+        const int t0 = cm_init == 1 ? (int)(plev << 1) + ch * 12 : ch * 2;
+        bin(XEVE_HIP_CTX_RUN + t0, run != 0);
+        if(run) {
+            for(unsigned i = 1; i < run; i++) bin(XEVE_HIP_CTX_RUN + t0 + 1, 1);
+            bin(XEVE_HIP_CTX_RUN + t0 + 1, 0);
+        }
+        bin(XEVE_HIP_CTX_LEVEL + t0, lev1 != 0);
+        if(lev1) {
+            for(unsigned i = 1; i < lev1; i++) bin(XEVE_HIP_CTX_LEVEL + t0 + 1, 1);
+            bin(XEVE_HIP_CTX_LEVEL + t0 + 1, 0);
+        }
+        (void)sb_encode<FULL>(s, 0, sign, true);
+        num_sig--;
+        if(!at_end) bin(XEVE_HIP_CTX_LAST + ch, num_sig == 0);
+        plev = lev1 < 5 ? lev1 : 5u;
+    }
+}
+
+// the coefficients of component c of a job: from the block's bin string when it has one and the job's count is the block's, else from the events
+template <bool FULL>
+__device__ __forceinline__ void code_block(Sbac &s, CtxTab s_ctx, int lane, const unsigned char *__restrict__ bins, const unsigned *__restrict__ ev, int coef_off, int nnz,
+                                           int c, int cm_init, unsigned long long *slow)
+{
+    const unsigned *hdr = reinterpret_cast<const unsigned *>(bins + (size_t)coef_off * BINK);
+    const unsigned nb = hdr[0], nev = hdr[1];
+    if(nb != BIN_OVF && nev == (unsigned)nnz) code_string<FULL>(s, s_ctx, lane, reinterpret_cast<const unsigned char *>(hdr) + BIN_HDR, (int)nb);
+    else {
+        if(slow) atomicAdd(slow, 1ull); // measurement only: blocks coded from their event lists
+        code_events<FULL>(s, s_ctx, lane, ev + coef_off, (int)(nev < (unsigned)nnz ? nev : (unsigned)nnz), nnz, c != 0, cm_init);
+    }
+}
+
+__device__ __forceinline__ void sbac_load(Sbac &s, const xeve_hip_sbac &in, CtxTab s_ctx, int lane, bool continue_coder)
+{
+    s.range = in.range, s.shifts = s.bins = 0;
+    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
+    if(continue_coder) { // continue the coder where the state stands
+        s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
+        s.bc = in.bitcounter, s.bins = in.bin_counter;
+    }
+    for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
+    s_ctx[BYP][lane] = 0;
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs, CuBitsK P,
+                                                const unsigned char *__restrict__ bins, const unsigned *__restrict__ ev, unsigned *__restrict__ bits,
+                                                xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units, unsigned long long *__restrict__ slow)
+{
+    __shared__ uint16_t s_ctx[NCTX + 1][64]; // (+ the dummy row of the bypass bins)
+    __shared__ uint8_t  s_q[QMAX][64];
+    const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
+    if(j >= njobs) return;
+    const xeve_hip_cu_bits_job J = jobs[j];
+    const xeve_hip_sbac &in = sin[J.sbac];
+    const bool cont = FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET);
+    Sbac s;
+    sbac_load(s, in, s_ctx, lane, cont);
+    Queue Q{&s_q[0][lane], 0};
+    const unsigned coded = q_header(Q, J, P);
+    code_queue<FULL>(s, s_ctx, s_q, lane, Q.n);
+    for(int c = 0; c < 3; c++)
+        if((coded >> c) & 1) code_block<FULL>(s, s_ctx, lane, bins, ev, J.coef_off[c], J.nnz[c], c, P.cm_init, slow);
     bits[j] = s.shifts;
-    if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave.  Lanes past the job list have left, so the sum goes through one
-                // LDS word (one wave per workgroup: program order is the only order there is)
-        unsigned *cnt = reinterpret_cast<unsigned *>(s_raw);
+    if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave (lanes may have left: the sum goes through one LDS word)
+        unsigned *cnt = reinterpret_cast<unsigned *>(&s_q[0][0]);
         const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
         if(first) *cnt = 0;
-        atomicAdd(cnt, s.bins - (FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET) ? in.bin_counter : 0u));
+        atomicAdd(cnt, s.bins - (cont ? in.bin_counter : 0u));
         if(first) atomicAdd(units, (unsigned long long)*cnt);
     }
     if(!FULL && sout) { // what feeds forward into later bit counts: the range and the models (xeve_sbac_bit_reset discards the rest but the
@@ -613,114 +509,58 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     }
 }
 
-// ---- one lane per job, bins from the blocks' bin strings --------------------------------------------------------------------------
-// Jobs whose coded blocks all have a string (no OVF) and whose coefficient counts are the blocks' true counts (J.nnz == events) are counted here and
-// marked in done[]; every other job is left to k_cu_bits.  Per bin: the byte, its model (read from LDS one bin AHEAD, with the just-written model
-// forwarded when two consecutive bins share it), the coder step, the model write-back.  The string is fetched 16 bytes at a time, the next chunk while
-// the current one is coded, so neither the global nor the LDS latency sits on the serial chain.
-typedef u32x4 u32x4_a4g __attribute__((aligned(4)));
-template <bool FULL>
-__global__ __launch_bounds__(64) void k_cu_bits_s(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs, CuBitsK P,
-                                                  const unsigned char *__restrict__ bins, unsigned *__restrict__ bits, xeve_hip_sbac *__restrict__ sout,
-                                                  unsigned long long *__restrict__ units, unsigned char *__restrict__ done, unsigned long long *__restrict__ slow)
+// ---- the per-component cbf tests of pinter_residue_rdo as ONE job per (Y choice, U choice) ---------------------------------------------
+// xeve_pinter.c:1180-1218 tests every component with and without its coefficients, handing the coder state of the cheaper alternative to the next
+// component: three dependent bit-count rounds.  A lane here ASSUMES the outcome of the Y and of the U test (job.dir_flag bit 0 / bit 1: coefficients kept)
+// and codes the whole chain under that assumption -- Y alternative, bit reset, U alternative, bit reset, then both V alternatives (the one-bin "without"
+// on a copy of range and model) -- so that all four assumptions run side by side in one launch and the decision afterwards reads the lane that matches
+// what the costs picked.  out[4 * j + {0, 1, 2, 3}] = bits of the Y segment, the U segment, V without, V with.  job.nnz = the stored counts; a component
+// whose stored count is 0 has no test and no segment (the state passes through).  Count-only: these states are only ever loaded into further counts.
+__global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs, CuBitsK P,
+                                                      const unsigned char *__restrict__ bins, const unsigned *__restrict__ ev, unsigned *__restrict__ out,
+                                                      unsigned long long *__restrict__ units, unsigned long long *__restrict__ slow)
 {
-    __shared__ uint16_t s_ctx[NCTX + 1][64]; // (+ the dummy row of the bypass bins)
+    __shared__ uint16_t s_ctx[NCTX + 1][64];
     __shared__ uint8_t  s_q[QMAX][64];
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
-    const unsigned coded = coded_mask(J);
-    const unsigned char *sp[3] = {nullptr, nullptr, nullptr};
-    unsigned nb[3] = {0, 0, 0};
-    bool fast = true;
-#pragma unroll
-    for(int c = 0; c < 3; c++)
-        if((coded >> c) & 1) {
-            const unsigned *hdr = reinterpret_cast<const unsigned *>(bins + (size_t)J.coef_off[c] * BINK);
-            const unsigned n = hdr[0], m = hdr[1];
-            fast = fast && n != BIN_OVF && m == (unsigned)J.nnz[c];
-            sp[c] = reinterpret_cast<const unsigned char *>(hdr) + BIN_HDR, nb[c] = n;
-        }
-    done[j] = fast;
-    if(!fast) {
-        if(slow) atomicAdd(slow, 1ull); // measurement only: jobs left to the event automaton
-        return;
-    }
-    const xeve_hip_sbac &in = sin[J.sbac];
+    if(J.mode == XEVE_HIP_BITS_CU_SKIP) return; // lane switched off (an assumption that cannot occur: the component has no coefficients)
     Sbac s;
-    s.range = in.range, s.shifts = s.bins = 0;
-    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
-    if(FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET)) { // continue the coder where the state stands
-        s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
-        s.bc = in.bitcounter, s.bins = in.bin_counter;
-    }
-    for(int i = 0; i < NCTX; i++) s_ctx[i][lane] = in.ctx[i];
-    s_ctx[BYP][lane] = 0;
-    Queue Q{&s_q[0][lane], 0};
-    (void)q_header(Q, J, P);
-    for(int i = 0; i < Q.n; i++) { // header bins
-        const unsigned e = s_q[i][lane], ci = e >> 2;
-        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, (e & 2) != 0);
-        s_ctx[ci][lane] = (uint16_t)m;
-    }
-    // the coded components' strings, one after the other
+    sbac_load(s, sin[J.sbac], s_ctx, lane, false);
+    const int keep[3] = {J.dir_flag & 1, (J.dir_flag >> 1) & 1, 1};
+    unsigned total_bins = 0;
     for(int c = 0; c < 3; c++) {
-        int rem = (int)nb[c];
-        if(rem <= 0) continue;
-        const u32x4_a4g *gp = reinterpret_cast<const u32x4_a4g *>(sp[c]);
-        u32x4 cur = gp[0];
-        unsigned ci = (cur.x & 0xFFu) >> 1;
-        ci = ci < BYP ? ci : BYP;
-        unsigned m = s_ctx[ci][lane];
-        auto step = [&](unsigned b, unsigned b1) { // code bin b on model ci (value m); b1: the byte after it
-            unsigned ci1 = (b1 & 0xFFu) >> 1;
-            ci1 = ci1 < BYP ? ci1 : BYP; // (past the end of the string: any byte)
-            const unsigned mp = s_ctx[ci1][lane];
-            const unsigned m1 = sb_encode<FULL>(s, m, b & 1u, ci == BYP);
-            s_ctx[ci][lane] = (uint16_t)m1;
-            m = ci1 == ci ? m1 : mp, ci = ci1;
-        };
-        while(rem > 0) {
-            gp++;
-            const u32x4 nxt = gp[0]; // (reads up to 31 bytes past the string: inside the block's region, the next one, or the slack behind the last)
-            if(rem >= 16) {
-#pragma unroll
-                for(int i = 0; i < 16; i++) {
-                    const unsigned wv = cur[i >> 2], wn = i < 15 ? cur[(i + 1) >> 2] : nxt.x;
-                    step(wv >> (8 * (i & 3)), wn >> (8 * ((i + 1) & 3)));
-                }
+        if(J.nnz[c] <= 0) continue; // no test for a component without coefficients (:1182)
+        xeve_hip_cu_bits_job T = J;
+        T.mode = (uint8_t)(XEVE_HIP_BITS_COMP_Y + c);
+        if(c == 2) { // V without: one cbf bin, on a copy (range + that model; nothing is written back)
+            T.nnz[2] = 0;
+            Queue Q0{&s_q[0][lane], 0};
+            (void)q_header(Q0, T, P);
+            Sbac t = s;
+            for(int i = 0; i < Q0.n; i++) {
+                const unsigned e = s_q[i][lane];
+                (void)sb_encode<false>(t, s_ctx[e >> 2][lane], e & 1, (e & 2) != 0); // (a single header bin: no model is used twice)
             }
-            else {
-                for(int i = 0; i < rem; i++) {
-                    const int i1 = i + 1;
-                    const unsigned wv = (i >> 2) == 0 ? cur.x : (i >> 2) == 1 ? cur.y : (i >> 2) == 2 ? cur.z : cur.w;
-                    const unsigned wn = (i1 >> 2) == 0 ? cur.x : (i1 >> 2) == 1 ? cur.y : (i1 >> 2) == 2 ? cur.z : cur.w; // (i1 <= 15 here)
-                    step(wv >> (8 * (i & 3)), wn >> (8 * (i1 & 3)));
-                }
-            }
-            cur = nxt, rem -= 16;
+            out[4 * j + 2] = t.shifts;
+            T.nnz[2] = J.nnz[2];
         }
+        else if(!keep[c]) T.nnz[c] = 0;
+        Queue Q{&s_q[0][lane], 0};
+        const unsigned coded = q_header(Q, T, P);
+        code_queue<false>(s, s_ctx, s_q, lane, Q.n);
+        if((coded >> c) & 1) code_block<false>(s, s_ctx, lane, bins, ev, J.coef_off[c], J.nnz[c], c, P.cm_init, slow);
+        out[4 * j + (c == 2 ? 3 : c)] = s.shifts;
+        total_bins += s.bins;
+        s.shifts = 0, s.bins = 0; // xeve_sbac_bit_reset before the next component's test
     }
-    bits[j] = s.shifts;
-    if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave (lanes may have left: the sum goes through one LDS word)
+    if(units) {
         unsigned *cnt = reinterpret_cast<unsigned *>(&s_q[0][0]);
         const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
         if(first) *cnt = 0;
-        atomicAdd(cnt, s.bins - (FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET) ? in.bin_counter : 0u));
+        atomicAdd(cnt, total_bins);
         if(first) atomicAdd(units, (unsigned long long)*cnt);
-    }
-    if(!FULL && sout) {
-        xeve_hip_sbac &o = sout[j];
-        o.range = s.range, o.code = 0, o.code_bits = 11, o.stacked_ff = o.stacked_zero = o.pending_byte = o.is_pending_byte = o.bitcounter = 0;
-        o.bin_counter = s.bins;
-        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
-    }
-    if(FULL) {
-        bits[j] = s.bc + 8 * (s.sz + s.sff) + 8 * (s.ipb ? 1 : 0) + 8 - s.cb + 3; // xeve_get_bit_number (xeve_mode.c:51-55)
-        xeve_hip_sbac &o = sout[j];
-        o.range = s.range, o.code = s.code, o.code_bits = s.cb, o.stacked_ff = s.sff, o.stacked_zero = s.sz;
-        o.pending_byte = s.pb, o.is_pending_byte = s.ipb, o.bitcounter = s.bc, o.bin_counter = s.bins;
-        for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
     }
 }
 
@@ -737,7 +577,7 @@ extern "C" size_t xeve_hip_cu_bits_workspace(int njobs, size_t coef_elems)
 
 static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
-                          void *stream, bool reuse_events = false);
+                          void *stream, bool reuse_events = false, int ev_first = 0, int ev_count = -1);
 
 extern "C" int xeve_hip_cu_bits_jobs(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                                      const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits,
@@ -758,14 +598,48 @@ extern "C" int xeve_hip_cu_bits_jobs_chain(const int16_t *coef, size_t coef_elem
 // reuse = 1 with the same workspace (jobs' nnz must then be the exact non-zero counts, as RDOQ returns them).
 int xh_cu_bits_jobs_round(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *state_out, int full, int reuse,
-                          void *stream)
+                          void *stream, int ev_first, int ev_count)
 {
-    return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, state_out, full != 0, stream, reuse != 0);
+    return cu_bits_launch(coef, coef_elems, sbac_in, jobs, njobs, p, workspace, workspace_bytes, bits, state_out, full != 0, stream, reuse != 0, ev_first, ev_count);
+}
+
+static int fill_k(CuBitsK &P, const xeve_hip_cu_bits_params *p)
+{
+    const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT (xeve_util.h:92-94)
+    for(int c = 0; c < 3; c++) {
+        const int lw = p->log2_cuw - (c ? ws : 0), lh = p->log2_cuh - (c ? hs : 0);
+        P.log2n[c] = lw + lh, P.n[c] = 1 << (lw + lh);
+        const int rc = xh_get_scan(lw, lh, &P.scan[c]);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    P.slice_type = p->slice_type, P.num_refp[0] = p->num_refp[0], P.num_refp[1] = p->num_refp[1];
+    P.cm_init = p->cm_init, P.idc = p->chroma_format_idc, P.burst = 0;
+    return XEVE_HIP_OK;
+}
+
+// the chain jobs of one RDO batch (k_cu_bits_chain) over the event lists / bin strings an earlier xh_cu_bits_jobs_round over the SAME coefficient buffer and
+// workspace left behind; out: 4 counts per job
+int xh_cu_bits_chain_round(size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs, const xeve_hip_cu_bits_params *p,
+                           void *workspace, size_t workspace_bytes, uint32_t *out, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(p && njobs >= 0 && sbac_in && jobs && out && workspace && workspace_bytes >= xeve_hip_cu_bits_workspace(njobs, coef_elems));
+    if(njobs == 0) return XEVE_HIP_OK;
+    CuBitsK P;
+    const int rc = fill_k(P, p);
+    if(rc != XEVE_HIP_OK) return rc;
+    char *W = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    XhProf prof(XH_PROF_CU_BITS, st);
+    k_cu_bits_chain<<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, (const unsigned char *)(W + ws_bins_off(coef_elems)), (const unsigned *)W, out,
+                                                     xh_prof_units(XH_PROF_CU_BITS), xh_prof_units(XH_PROF_CU_BITS_SLOW));
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
 }
 
 static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *sbac_out, bool full,
-                          void *stream, bool reuse_events)
+                          void *stream, bool reuse_events, int ev_first, int ev_count)
 {
     XH_ENTER();
     XH_REQUIRE(p && njobs >= 0);
@@ -776,48 +650,31 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     XH_REQUIRE(sbac_in && jobs && bits && workspace); // coef == NULL: no job codes coefficients (skip / mvp jobs only) -- the event pass is left out
     XH_REQUIRE(workspace_bytes >= xeve_hip_cu_bits_workspace(njobs, coef_elems));
     CuBitsK P;
-    const int ws = p->chroma_format_idc <= 2, hs = p->chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT (xeve_util.h:92-94)
-    for(int c = 0; c < 3; c++) {
-        const int lw = p->log2_cuw - (c ? ws : 0), lh = p->log2_cuh - (c ? hs : 0);
-        P.log2n[c] = lw + lh, P.n[c] = 1 << (lw + lh);
-        const int rc = xh_get_scan(lw, lh, &P.scan[c]);
+    {
+        const int rc = fill_k(P, p);
         if(rc != XEVE_HIP_OK) return rc;
     }
-    P.slice_type = p->slice_type, P.num_refp[0] = p->num_refp[0], P.num_refp[1] = p->num_refp[1];
-    P.cm_init = p->cm_init, P.idc = p->chroma_format_idc;
-    static const int burst = getenv("XEVE_HIP_SBAC_BURST") ? atoi(getenv("XEVE_HIP_SBAC_BURST")) : 1; // developer switch
-    P.burst = burst;
     char          *W    = (char *)workspace;
     unsigned      *ev   = (unsigned *)W;
     unsigned char *bins = (unsigned char *)(W + ws_bins_off(coef_elems));
     int           *nev  = (int *)(W + ws_nev_off(coef_elems));
-    unsigned char *done = (unsigned char *)(nev + 3 * (size_t)njobs);
     XH_REQUIRE(((uintptr_t)workspace & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    const long items = 3L * njobs;
-    static const int use_stream = getenv("XEVE_HIP_SBAC_STREAM") ? atoi(getenv("XEVE_HIP_SBAC_STREAM")) : 1; // developer switch (measurement): 0 = event automaton only
-    const bool streams = use_stream && coef != nullptr; // (no coefficient buffer: header-only jobs, nothing to expand)
-    if(reuse_events) nev = nullptr;
-    if(!coef || reuse_events) {}
+    // the event / bin pass over jobs [ev_first, ev_first + ev_count) only: a caller whose jobs share blocks names a sub-range that covers every coded block once
+    if(ev_count < 0) ev_first = 0, ev_count = njobs;
+    XH_REQUIRE(ev_first >= 0 && ev_first + ev_count <= njobs);
+    const long items = 3L * ev_count;
+    if(!coef || reuse_events || ev_count == 0) {} // (no coefficient buffer: header-only jobs; reuse: the lists and strings of an earlier round over the same buffer)
     else if(P.n[0] <= 64) {
         const long waves = (items + 3) / 4;
-        k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev, streams ? bins : nullptr);
+        k_coef_events<16><<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(coef, jobs + ev_first, ev_count, P, ev, nev, bins);
     }
-    else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs, njobs, P, ev, nev, streams ? bins : nullptr);
+    else k_coef_events<64><<<(unsigned)((items + 3) / 4), 256, 0, st>>>(coef, jobs + ev_first, ev_count, P, ev, nev, bins);
     {
         XhProf prof(XH_PROF_CU_BITS, st);
-        unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS);
-        static const int use_reg = getenv("XEVE_HIP_SBAC_REG") ? atoi(getenv("XEVE_HIP_SBAC_REG")) : 0; // developer switch (measurement)
-        const bool reg = use_reg && P.cm_init == 0;
-        if(streams) { // jobs with a usable bin string first; the automaton below takes what is left
-            if(full) k_cu_bits_s<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, bits, sbac_out, units, done, xh_prof_units(XH_PROF_CU_BITS_SLOW));
-            else k_cu_bits_s<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, bits, sbac_out, units, done, xh_prof_units(XH_PROF_CU_BITS_SLOW));
-        }
-        const unsigned char *dn = streams ? done : nullptr;
-        if(full && reg) k_cu_bits<true, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
-        else if(full) k_cu_bits<true, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
-        else if(reg) k_cu_bits<false, true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
-        else k_cu_bits<false, false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, ev, nev, bits, sbac_out, units, dn);
+        unsigned long long *units = xh_prof_units(XH_PROF_CU_BITS), *slow = xh_prof_units(XH_PROF_CU_BITS_SLOW);
+        if(full) k_cu_bits<true><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, ev, bits, sbac_out, units, slow);
+        else k_cu_bits<false><<<(njobs + 63) / 64, 64, 0, st>>>(sbac_in, jobs, njobs, P, bins, ev, bits, sbac_out, units, slow);
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

@@ -72,7 +72,9 @@ struct RdoParams {
 int xh_get_scan(int log2w, int log2h, const uint16_t **out);
 int xh_cu_bits_jobs_round(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *state_out, int full, int reuse,
-                          void *stream); // sbac.hip
+                          void *stream, int ev_first = 0, int ev_count = -1); // sbac.hip
+int xh_cu_bits_chain_round(size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs, const xeve_hip_cu_bits_params *p,
+                           void *workspace, size_t workspace_bytes, uint32_t *out, void *stream); // sbac.hip
 // One launch over the searches of several reference pictures: job j belongs to plane j / per_plane; the plane supplies the picture, the
 // reference index bits and (integer stage) the re-centred range.  n == 0: the single-picture form.
 #define XH_MAX_PLANES 16
