@@ -16,9 +16,10 @@ template <int S> struct MGeo {
 
 // The dense round's window in LDS (LDSM != 0): every candidate of the (2d+1)^2 grid reads its rows out of ONE staged copy of the
 // (S + 2d) x (S + 2d) samples the grid covers -- staged with coalesced dword loads (a row of the window is contiguous in the plane),
-// read back as 16-byte row segments.  d = 2 (uni) / 5 (bi-prediction refinement), xeve_pinter.c:409-416.  One window per wave.
-// LDSM 1: one copy, segments at any 2-byte offset (unaligned ds_read_b128); LDSM 2: a second copy one sample to the left, so that
-// every segment read is dword-aligned (two ds_read2_b32).
+// read back as 16-byte row segments at any 2-byte offset (unaligned ds_read_b128).  d = 2 (uni) / 5 (bi-prediction refinement),
+// xeve_pinter.c:409-416.  One window per wave.  MEASURED (profiles/r02_lds_search.md): on one MI355X the window does not pay -- the search class of a
+// 3840x2160 picture takes 16.4 ms through the vector L1, 17.3 ms with the window, 18.4 ms with a second, dword-aligned copy of it (two ds_read2_b32 per
+// segment; since removed) -- so the L1 path stays the default and this form is kept behind XEVE_HIP_ME_LDS=1 for reproduction.
 template <int S, bool BI> struct MWin {
     static constexpr int DMAX = BI ? 5 : 2, H = S + 2 * DMAX, NDW = S / 2 + DMAX + 1, PITCH = 2 * NDW; // NDW dwords = S + 2 DMAX + 2 samples: + parity, + round-up
     static constexpr int PELS = H * PITCH;
@@ -91,11 +92,7 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
             for(int i = lane; i < tot; i += 64) {
                 const int r = i / W::NDW, k = i - r * W::NDW;
                 const uint32_t *gp = ga + (long)r * sdw + k;
-                if(LDSM == 2) {
-                    const uint32_t a = gp[0], b = gp[1];
-                    wa[i] = a, wa[W::PELS / 2 + i] = __builtin_amdgcn_alignbit(b, a, 16); // second copy: one sample to the left
-                }
-                else wa[i] = gp[0];
+                wa[i] = gp[0];
             }
             __builtin_amdgcn_wave_barrier(); // (LDS operations of one wave execute in order; this only pins the compiler's schedule)
             staged = true;
@@ -122,12 +119,9 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
                     // (explicit LDS address space: with a generic pointer the compiler folds this load and the global one below into one flat load)
                     typedef __attribute__((address_space(3))) const pel lds_pel;
                     lds_pel *r = (lds_pel *)win + (my - y0 + row0) * W::PITCH + wx;
-                    if(LDSM == 2) r = (wx & 1) ? r + W::PELS - 1 : r;
 #pragma unroll
                     for(int p = 0; p < G::NP; p++) {
-                        u32x4 v;
-                        if(LDSM == 2) v = *(__attribute__((address_space(3))) const u32x4_a4 *)(r + p * G::RPP * W::PITCH);
-                        else v = *(__attribute__((address_space(3))) const u32x4_a2 *)(r + p * G::RPP * W::PITCH);
+                        u32x4 v = *(__attribute__((address_space(3))) const u32x4_a2 *)(r + p * G::RPP * W::PITCH);
                         if(BI) v ^= 0x80008000u;
                         acc = __builtin_amdgcn_sad_u16(org[p].x, v.x, acc);
                         acc = __builtin_amdgcn_sad_u16(org[p].y, v.y, acc);
@@ -451,8 +445,8 @@ __global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, c
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-// developer switch (measurement): 0 = every candidate row through the vector L1, 1 = dense round from an LDS window (default), 2 = two-copy window
-static const int g_me_lds = getenv("XEVE_HIP_ME_LDS") ? atoi(getenv("XEVE_HIP_ME_LDS")) : 1;
+// developer switch (measurement): 0 = every candidate row through the vector L1 (default: measured fastest), 1 = dense round from an LDS window
+static const int g_me_lds = getenv("XEVE_HIP_ME_LDS") ? atoi(getenv("XEVE_HIP_ME_LDS")) : 0;
 
 extern "C" size_t xeve_hip_me_epzs_workspace(int njobs)
 {
@@ -516,8 +510,8 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
 #define EPZS_LAUNCH_M(S, M)                                                                                        \
     do {                                                                                                           \
         if(extra_branches) {                                                                                       \
-            if(P.bi) k_me_epzs<S, true, true, 1><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
-            else k_me_epzs<S, false, true, 1><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);                  \
+            if(P.bi) k_me_epzs<S, true, true, 0><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
+            else k_me_epzs<S, false, true, 0><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);                  \
         }                                                                                                          \
         else if(P.bi) k_me_epzs<S, true, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                     \
         else k_me_epzs<S, false, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                             \
@@ -525,7 +519,6 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
 #define EPZS_LAUNCH(S)                                                                                             \
     do {                                                                                                           \
         if(g_me_lds == 0) EPZS_LAUNCH_M(S, 0);                                                                     \
-        else if(g_me_lds == 2) EPZS_LAUNCH_M(S, 2);                                                                \
         else EPZS_LAUNCH_M(S, 1);                                                                                  \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);

@@ -351,10 +351,13 @@ __global__ void k_rdo_spec_decide(const xeve_hip_rdo_job *__restrict__ jobs, Rdo
     res[j] = r;
 }
 
-// candidates x 12 lanes up to which the one-round form is used (above it the level has enough waves for the four-round form to be throughput-bound)
+// Candidates per batch up to which the one-round form is used.  MEASURED (3840x2160 i.i.d. picture, all four levels side by side on four streams): with the form
+// on for the 64x64 and 32x32 levels (limit 26 000) a step takes 56.2 ms, with the four-round form everywhere 49.1 ms -- once the four levels share the chip the
+// extra bins (667 M against 600 M per picture) cost more than the shorter chain saves.  It stays for what IS latency-bound: the per-CU calls of the host form
+// (one to three candidates; three fewer dependent bit-count launches per batch).
 static int rdo_spec_limit()
 {
-    static const int v = getenv("XEVE_HIP_RDO_SPEC") ? atoi(getenv("XEVE_HIP_RDO_SPEC")) : 26000; // developer switch: 0 = never
+    static const int v = getenv("XEVE_HIP_RDO_SPEC") ? atoi(getenv("XEVE_HIP_RDO_SPEC")) : 256; // developer switch: 0 = never
     return v;
 }
 static bool rdo_use_spec(int njobs) { return njobs <= rdo_spec_limit(); }
