@@ -10,6 +10,11 @@
 #include <cstdlib>
 #include "xh_common.h"
 
+// developer switch (measurement): 0 = every candidate row through the vector L1 (default: measured fastest), 1 = dense round from an LDS window
+static const int g_me_lds = getenv("XEVE_HIP_ME_LDS") ? atoi(getenv("XEVE_HIP_ME_LDS")) : 0;
+// developer switch (measurement): 1 = one candidate per lane (cpl_*), 0 = the block spread over the lanes (me_*)
+static const int g_me_cpl = getenv("XEVE_HIP_ME_CPL") ? atoi(getenv("XEVE_HIP_ME_CPL")) : 1;
+
 template <int S> struct MGeo {
     static constexpr int LPR = S / 8, RPP = XH_WAVE / LPR, CPP = RPP >= S ? RPP / S : 1, NP = RPP >= S ? 1 : S / RPP, GROUP = XH_WAVE / CPP;
 };
@@ -253,21 +258,216 @@ __device__ __forceinline__ void me_eval(const u32x4 (&org)[MGeo<S>::NP], const p
     }
 }
 
+// =========================================================================================================
+// One CANDIDATE per lane.  The mapping above spreads a block over the lanes and pays for it per candidate: a cross-lane sum, the vector cost and a
+// 64-bit cross-group minimum for every 1 .. 8 candidates -- counters (profiles/r02_search_pmc.json): 2 700 VALU + 2 000 SALU instructions per 8x8 job of
+// which ~5 % are v_sad_u16; the kernel is bound by its own bookkeeping, not by any memory level.  Here a lane owns a candidate: it walks the block's
+// rows itself (reference row segment from the plane, original row segment broadcast from a per-wave LDS copy), so a SAD needs no reduction, the vector
+// cost is computed once per candidate, and a round's winner is one 32-bit wave minimum plus a ballot (lanes are in evaluation order, so the lowest
+// lane among the minima is the reference's "first strictly smaller").  The dense (2d+1)^2 round is one pass (two for the 121 candidates of the
+// bi-prediction refinement); the rings that are certain to be evaluated -- the search only stops after `faststep` rounds without improvement -- share
+// one pass as well, and the bookkeeping then consumes their minima ring by ring, in the reference's order.
+// =========================================================================================================
+typedef __attribute__((address_space(3))) const pel lds_cpel;
+
+// the original block (org_bi for the bi-prediction refinement, biased once for the unsigned SAD) into the wave's LDS copy, dense S x S
 template <int S, bool BI>
+__device__ __forceinline__ void cpl_load_org(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, int x, int y, int org_off, int lane, pel *lorg)
+{
+    const pel *o  = BI ? org_bi + org_off : org0 + (long)y * s_org + x;
+    const int  so = BI ? S : s_org;
+    for(int i = lane; i < S * S / 8; i += 64) {
+        const int r = i / (S / 8), c = (i % (S / 8)) * 8;
+        u32x4 v = xh_ld8(o + (long)r * so + c);
+        if(BI) v ^= 0x80008000u;
+        *reinterpret_cast<u32x4 *>(lorg + r * S + c) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int S, bool BI> __device__ __forceinline__ int cpl_sad(const pel *lorg, const pel *__restrict__ r, int s_ref)
+{
+    int acc = 0;
+    lds_cpel *o = (lds_cpel *)lorg;
+#pragma unroll 2
+    for(int y = 0; y < S; y++) {
+#pragma unroll
+        for(int x = 0; x < S; x += 8) {
+            u32x4 v = xh_ld8(r + x);
+            if(BI) v ^= 0x80008000u;
+            const u32x4 q = *(__attribute__((address_space(3))) const u32x4 *)(o + x);
+            acc = __builtin_amdgcn_sad_u16(q.x, v.x, acc);
+            acc = __builtin_amdgcn_sad_u16(q.y, v.y, acc);
+            acc = __builtin_amdgcn_sad_u16(q.z, v.z, acc);
+            acc = __builtin_amdgcn_sad_u16(q.w, v.w, acc);
+        }
+        r += s_ref, o += S;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ unsigned cpl_wave_min(unsigned v)
+{
+    v = min(v, (unsigned)xh_dpp<XH_DPP_QUAD_XOR1>((int)v));
+    v = min(v, (unsigned)xh_dpp<XH_DPP_QUAD_XOR2>((int)v));
+    v = min(v, (unsigned)xh_dpp<XH_DPP_ROW_HALF_MIRROR>((int)v));
+    v = min(v, (unsigned)xh_dpp<XH_DPP_ROW_MIRROR>((int)v));
+    v = min(v, (unsigned)__shfl_xor((int)v, 16, 64));
+    v = min(v, (unsigned)__shfl_xor((int)v, 32, 64));
+    return v;
+}
+
+template <bool BI> __device__ __forceinline__ unsigned cpl_cost(int mx, int my, int sad_raw, int shift, int gx, int gy, const xeve_hip_me_params &P, int &bits)
+{
+    bits = xh_mvd_bits((mx << 2) - gx) + xh_mvd_bits((my << 2) - gy) + P.refi_bits;
+    if(BI) bits += P.extra_bits;
+    const int sad = sad_raw >> shift;
+    return ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(BI ? sad >> 1 : sad);
+}
+
+// one complete me_ipel_diamond by the calling wave (candidate per lane); the result is wave-uniform
+template <int S, bool BI>
+__device__ __forceinline__ xeve_hip_me_result cpl_diamond(const pel *lorg, const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job &jb, int shift,
+                                                          const xeve_hip_me_params &P, int lane, int *range_out = nullptr, unsigned *evals = nullptr)
+{
+    int r0 = jb.range[0], r1 = jb.range[1], r2 = jb.range[2], r3 = jb.range[3];
+    int bx = clip3(P.min_clip[0], P.max_clip[0], jb.mvi[0] >> 2), by = clip3(P.min_clip[1], P.max_clip[1], jb.mvi[1] >> 2);
+    const int ix = bx, iy = by;
+    unsigned cost_best = 0xFFFFFFFFu, nev = 0;
+    int best_bits = 0, beststep = jb.beststep_in, not_found = 0;
+    const int d = P.bi == 1 ? 5 : 2; // BI_STEP : 2 (xeve_pinter.c:409-416)
+    // ---- round 0: the dense grid around the clipped start
+    {
+        not_found++;
+        const int x0 = bx <= r0 ? bx : bx - d, y0 = by <= r1 ? by : by - d;
+        const int x1 = bx >= r2 ? bx : bx + d, y1 = by >= r3 ? by : by + d;
+        const int wd = x1 - x0 + 1, nc = wd * (y1 - y0 + 1);
+        unsigned rcost = 0xFFFFFFFFu;
+        int rk = -1, rbits = 0;
+        for(int c0 = 0; c0 < nc; c0 += 64) {
+            const int k = c0 + lane, q = k / wd, mx = x0 + (k - q * wd), my = y0 + q;
+            const bool valid = k < nc && mx <= r2 && mx >= r0 && my <= r3 && my >= r1;
+            if(evals) nev += (unsigned)__popcll(__ballot(valid));
+            int bits = 0;
+            unsigned cost = 0xFFFFFFFFu;
+            if(valid) cost = cpl_cost<BI>(mx, my, cpl_sad<S, BI>(lorg, ref0 + (long)my * s_ref + mx, s_ref), shift, jb.gmvp[0], jb.gmvp[1], P, bits);
+            // (a real cost never reaches 0xFFFFFFFF: 15 bits of SAD scale + the vector cost)
+            const unsigned mn = cpl_wave_min(cost);
+            const unsigned long long at = __ballot(valid && cost == mn);
+            if(at && mn < rcost) { // strictly smaller than an earlier pass's minimum; inside the pass the lowest lane = the earliest candidate
+                const int wl = (int)__ffsll((long long)at) - 1;
+                rcost = mn, rk = c0 + wl, rbits = __builtin_amdgcn_readlane(bits, wl);
+            }
+        }
+        if(rk >= 0 && rcost < cost_best) {
+            const int q = rk / wd;
+            cost_best = rcost, best_bits = rbits, not_found = 0, bx = x0 + (rk - q * wd), by = y0 + q, beststep = 2;
+        }
+        // get_range_ipel around the best position so far (xeve_pinter.c:463-468, 122-140)
+        const int sr = P.bi == 1 ? 5 : P.range_recentre;
+        r0 = clip3(P.min_clip[0], P.max_clip[0], bx - sr), r2 = clip3(P.min_clip[0], P.max_clip[0], bx + sr);
+        r1 = clip3(P.min_clip[1], P.max_clip[1], by - sr), r3 = clip3(P.min_clip[1], P.max_clip[1], by + sr);
+    }
+    // ---- the rings around the INITIAL centre: steps 4 (4 points + centre), 8 (8 + centre), 16, 32, ... (16 points), xeve_pinter.c:470-540
+    if(not_found != P.faststep && P.bi != 1) {
+        int step = 4;
+        while(step <= P.max_search_range) {
+            // the next (faststep - not_found) rings are evaluated whatever they find: one pass for all of them (at most three: 5 + 9 + 16 candidates, or 48)
+            // (ring g of the batch has step `step << g` and 5 / 9 / 16 candidates for step 4 / 8 / larger; no arrays: they would be indexed dynamically)
+            auto ring_n = [](int s2) { return s2 > 8 ? 16 : (s2 == 4 ? 5 : 9); };
+            const int nr = P.faststep - not_found;
+            int tot = 0, m = 0;
+            for(int s2 = step; m < nr && m < 3 && s2 <= P.max_search_range; s2 <<= 1, m++) tot += ring_n(s2);
+            // lane -> (ring, index inside the ring), in evaluation order
+            const int c0n = ring_n(step), c1n = ring_n(step << 1);
+            int ri = 0, k = lane;
+            if(m > 1 && k >= c0n) k -= c0n, ri = 1;
+            if(m > 2 && ri == 1 && k >= c1n) k -= c1n, ri = 2;
+            const int st = step << ri;
+            int mx, my;
+            if(st > 8) mx = ix + (st >> 2) * c_dia16[k & 15][0], my = iy + (st >> 2) * c_dia16[k & 15][1];
+            else {
+                const int i = st == 4 ? 2 * k : k; // the 4-point ring skips the odd points; i == 8 is the centre
+                const int dx = i < 8 ? c_dia16[(2 * i) & 15][0] / 2 : 0, dy = i < 8 ? c_dia16[(2 * i) & 15][1] / 2 : 0;
+                mx = ix + (st >> 1) * dx, my = iy + (st >> 1) * dy;
+            }
+            const bool valid = lane < tot && mx <= r2 && mx >= r0 && my <= r3 && my >= r1;
+            if(evals) nev += (unsigned)__popcll(__ballot(valid));
+            int bits = 0;
+            unsigned cost = 0xFFFFFFFFu;
+            if(valid) cost = cpl_cost<BI>(mx, my, cpl_sad<S, BI>(lorg, ref0 + (long)my * s_ref + mx, s_ref), shift, jb.gmvp[0], jb.gmvp[1], P, bits);
+            bool stop = false;
+            for(int g = 0; g < m; g++) { // the rings' minima, consumed in the reference's order
+                not_found++;
+                const unsigned cg = ri == g ? cost : 0xFFFFFFFFu, mn = cpl_wave_min(cg);
+                const unsigned long long at = __ballot(valid && ri == g && cost == mn);
+                if(at && mn < cost_best) {
+                    const int wl = (int)__ffsll((long long)at) - 1;
+                    cost_best = mn, best_bits = __builtin_amdgcn_readlane(bits, wl), not_found = 0;
+                    bx = __builtin_amdgcn_readlane(mx, wl), by = __builtin_amdgcn_readlane(my, wl), beststep = step << g;
+                }
+                if(not_found == P.faststep) {
+                    stop = true;
+                    break;
+                }
+            }
+            if(stop || m == 0) break;
+            step <<= m;
+        }
+    }
+    xeve_hip_me_result res;
+    res.mv[0] = (int16_t)((bx - jb.x) << 2), res.mv[1] = (int16_t)((by - jb.y) << 2);
+    res.cost = cost_best, res.beststep = beststep, res.best_mv_bits = best_bits;
+    if(range_out) range_out[0] = r0, range_out[1] = r1, range_out[2] = r2, range_out[3] = r3;
+    if(evals) *evals += nev;
+    return res;
+}
+
+// A list of integer positions in the list's order (me_raster, its 3x3 grids, me_ipel_refinement): a position wins only with a strictly smaller cost
+// than `cost_best`, the earliest on ties.  gen(k, mx, my) -> valid.
+template <int S, bool BI, class Gen>
+__device__ __forceinline__ void cpl_eval(const pel *lorg, const pel *__restrict__ ref0, int s_ref, int nc, Gen gen, int gmvp_x, int gmvp_y, int shift,
+                                         const xeve_hip_me_params &P, int lane, unsigned &cost_best, int &best_bits, int &bx, int &by)
+{
+    for(int c0 = 0; c0 < nc; c0 += 64) {
+        const int k = c0 + lane;
+        int mx = 0, my = 0, bits = 0;
+        const bool valid = k < nc && gen(k, mx, my);
+        unsigned cost = 0xFFFFFFFFu;
+        if(valid) cost = cpl_cost<BI>(mx, my, cpl_sad<S, BI>(lorg, ref0 + (long)my * s_ref + mx, s_ref), shift, gmvp_x, gmvp_y, P, bits);
+        const unsigned mn = cpl_wave_min(cost);
+        const unsigned long long at = __ballot(valid && cost == mn);
+        if(at && mn < cost_best) {
+            const int wl = (int)__ffsll((long long)at) - 1;
+            cost_best = mn, best_bits = __builtin_amdgcn_readlane(bits, wl), bx = __builtin_amdgcn_readlane(mx, wl), by = __builtin_amdgcn_readlane(my, wl);
+        }
+    }
+}
+
+template <int S, bool BI, bool CPL>
 __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi,
                                                     const pel *__restrict__ ref0, int s_ref, const xeve_hip_me_job *__restrict__ jobs,
                                                     int njobs, int shift, xeve_hip_me_params P, xeve_hip_me_result *__restrict__ out,
                                                     unsigned long long *__restrict__ units)
 {
+    __shared__ __attribute__((aligned(16))) pel s_lorg[CPL ? 4 * S * S : 8];
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
     const xeve_hip_me_job jb = jobs[j];
     if(jb.range[0] > jb.range[2]) return; // empty range = parked job (its result slot is left untouched)
-    u32x4 org[MGeo<S>::NP];
-    me_load_org<S, BI>(org0, s_org, org_bi, jb.x, jb.y, jb.org_off, lane, org);
     unsigned nev = 0;
-    const xeve_hip_me_result res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane, nullptr, units ? &nev : nullptr);
+    xeve_hip_me_result res;
+    if constexpr(CPL) {
+        pel *lorg = s_lorg + (threadIdx.x >> 6) * (S * S);
+        cpl_load_org<S, BI>(org0, s_org, org_bi, jb.x, jb.y, jb.org_off, lane, lorg);
+        res = cpl_diamond<S, BI>(lorg, ref0, s_ref, jb, shift, P, lane, nullptr, units ? &nev : nullptr);
+    }
+    else {
+        u32x4 org[MGeo<S>::NP];
+        me_load_org<S, BI>(org0, s_org, org_bi, jb.x, jb.y, jb.org_off, lane, org);
+        res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane, nullptr, units ? &nev : nullptr);
+    }
     if(lane == 0) out[j] = res;
     if(units && lane == 0) atomicAdd(units, (unsigned long long)nev * (S * S / 64));
 }
@@ -290,8 +490,12 @@ extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const p
     unsigned long long *units = xh_prof_units(XH_PROF_SEARCH);
 #define ME_LAUNCH(S)                                                                                                          \
     do {                                                                                                                      \
-        if(P.bi) k_me_diamond<S, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);  \
-        else k_me_diamond<S, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);     \
+        if(g_me_cpl) {                                                                                                        \
+            if(P.bi) k_me_diamond<S, true, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);  \
+            else k_me_diamond<S, false, true><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);     \
+        }                                                                                                                     \
+        else if(P.bi) k_me_diamond<S, true, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);  \
+        else k_me_diamond<S, false, false><<<grid, 256, 0, st>>>(org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, results, units);     \
     } while(0)
     if(log2w == 3) ME_LAUNCH(8);
     else if(log2w == 4) ME_LAUNCH(16);
@@ -324,14 +528,16 @@ __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, 
 // reference's rule asks for one (xeve_pinter.c:757-822) without leaving the kernel: no
 // launch, no host round trip between the searches, the original block stays in registers across them.
 // EXTRA: compiled with the branches presets fast / medium never take (me_raster, me_ipel_refinement); the plain form keeps its registers
-template <int S, bool BI, bool EXTRA, int LDSM>
+template <int S, bool BI, bool EXTRA, int LDSM, bool CPL>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
                                                  const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
                                                  const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl, int ipel_only,
                                                  unsigned long long *__restrict__ units)
 {
     __shared__ __attribute__((aligned(16))) pel s_win[LDSM ? 4 * LDSM * MWin<S, BI>::PELS : 8];
+    __shared__ __attribute__((aligned(16))) pel s_lorg[CPL ? 4 * S * S : 8];
     pel *win = s_win + (threadIdx.x >> 6) * (LDSM * MWin<S, BI>::PELS);
+    pel *lorg = s_lorg + (threadIdx.x >> 6) * (CPL ? S * S : 0);
     const int lane = threadIdx.x & 63;
     const int j    = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(j >= njobs) return;
@@ -356,13 +562,23 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     EpzsState s;
     s.cost = 0xFFFFFFFFu, s.mv[0] = e.mv_start[0], s.mv[1] = e.mv_start[1], s.tmpstep = 0, s.searches = 0, s.mot_bits = 0;
     u32x4 org[MGeo<S>::NP];
-    me_load_org<S, BI>(org0, s_org, org_bi, e.x, e.y, e.org_off, lane, org);
+    if constexpr(CPL) cpl_load_org<S, BI>(org0, s_org, org_bi, e.x, e.y, e.org_off, lane, lorg);
+    else me_load_org<S, BI>(org0, s_org, org_bi, e.x, e.y, e.org_off, lane, org);
+    // the two lane mappings behind one face
+    auto diamond = [&](const xeve_hip_me_job &jb, const xeve_hip_me_params &pp, int *rng, unsigned *ne) {
+        if constexpr(CPL) return cpl_diamond<S, BI>(lorg, ref0, s_ref, jb, shift, pp, lane, rng, ne);
+        else return me_diamond<S, BI, LDSM>(org, ref0, s_ref, jb, shift, pp, lane, rng, ne, win);
+    };
+    auto eval = [&](int nc, auto gen, int gx, int gy, const xeve_hip_me_params &pp, unsigned &cb, int &bb, int &px, int &py) {
+        if constexpr(CPL) cpl_eval<S, BI>(lorg, ref0, s_ref, nc, gen, gx, gy, shift, pp, lane, cb, bb, px, py);
+        else me_eval<S, BI>(org, ref0, s_ref, nc, gen, gx, gy, shift, pp, lane, cb, bb, px, py);
+    };
     unsigned nev = 0; // (measurement only; the raster / integer-refinement branches are not counted)
     xeve_hip_me_params Q = P;
     for(int it = 0; it < 64; it++) { // (the reference's loop ends when a search no longer improves; 64 is a safety bound)
         Q.faststep = it == 0 ? 3 : 2; // MAX_FIRST_SEARCH_STEP / MAX_REFINE_SEARCH_STEP
         int rng[4];
-        const xeve_hip_me_result r = me_diamond<S, BI, LDSM>(org, ref0, s_ref, m, shift, Q, lane, rng, units ? &nev : nullptr, win);
+        const xeve_hip_me_result r = diamond(m, Q, rng, units ? &nev : nullptr);
         s.tmpstep = r.beststep, s.searches++;
         if(P.bi != 1 && r.best_mv_bits > 0) s.mot_bits = r.best_mv_bits; // me_ipel_diamond's side effect on pi->mot_bits (:546-548)
         int beststep = 0;
@@ -378,16 +594,16 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
             const int nx = (rng[2] - rng[0]) / stp + 1, ny = (rng[3] - rng[1]) / stp + 1;
             unsigned rc = 0xFFFFFFFFu;
             int rbits = 0, rx = (r.mv[0] >> 2) + e.x, ry = (r.mv[1] >> 2) + e.y; // (`mv` as the diamond search left it)
-            me_eval<S, BI>(org, ref0, s_ref, nx * ny, [&](int k, int &mx, int &my) { mx = rng[0] + (k % nx) * stp, my = rng[1] + (k / nx) * stp; return true; },
-                           m.gmvp[0], m.gmvp[1], shift, Q, lane, rc, rbits, rx, ry);
+            eval(nx * ny, [&](int k, int &mx, int &my) { mx = rng[0] + (k % nx) * stp, my = rng[1] + (k / nx) * stp; return true; }, m.gmvp[0], m.gmvp[1], Q, rc, rbits,
+                 rx, ry);
             for(int ss = (mult * st0) >> 1; ss > 0; ss >>= 1) {
                 const int cx = rx, cy = ry;
-                me_eval<S, BI>(org, ref0, s_ref, 9,
-                               [&](int k, int &mx, int &my) {
-                                   mx = cx + (k % 3 - 1) * ss, my = cy + (k / 3 - 1) * ss;
-                                   return mx >= rng[0] && mx <= rng[2] && my >= rng[1] && my <= rng[3];
-                               },
-                               m.gmvp[0], m.gmvp[1], shift, Q, lane, rc, rbits, rx, ry);
+                eval(9,
+                     [&](int k, int &mx, int &my) {
+                         mx = cx + (k % 3 - 1) * ss, my = cy + (k / 3 - 1) * ss;
+                         return mx >= rng[0] && mx <= rng[2] && my >= rng[1] && my <= rng[3];
+                     },
+                     m.gmvp[0], m.gmvp[1], Q, rc, rbits, rx, ry);
             }
             if(rbits > 0) s.mot_bits = rbits;
             if(rc < s.cost) beststep = 5, s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2); // (:760-767)
@@ -403,14 +619,14 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         const int ix = clip3(P.min_clip[0], P.max_clip[0], (s.mv[0] + (e.x << 2)) >> 2), iy = clip3(P.min_clip[1], P.max_clip[1], (s.mv[1] + (e.y << 2)) >> 2);
         unsigned rc = 0xFFFFFFFFu;
         int rbits = 0, rx = ix, ry = iy;
-        me_eval<S, BI>(org, ref0, s_ref, 9,
-                       [&](int k, int &mx, int &my) {
-                           // test_pos (:311): the centre, then x = -1, 0, 1 with y = -1, 0, 1 (the centre left out)
-                           const int q = k == 0 ? 4 : (k <= 4 ? k - 1 : k);
-                           mx = ix + (q / 3 - 1), my = iy + (q % 3 - 1);
-                           return mx >= rg[0] && mx <= rg[2] && my >= rg[1] && my <= rg[3];
-                       },
-                       m.gmvp[0], m.gmvp[1], shift, P, lane, rc, rbits, rx, ry);
+        eval(9,
+             [&](int k, int &mx, int &my) {
+                 // test_pos (:311): the centre, then x = -1, 0, 1 with y = -1, 0, 1 (the centre left out)
+                 const int q = k == 0 ? 4 : (k <= 4 ? k - 1 : k);
+                 mx = ix + (q / 3 - 1), my = iy + (q % 3 - 1);
+                 return mx >= rg[0] && mx <= rg[2] && my >= rg[1] && my <= rg[3];
+             },
+             m.gmvp[0], m.gmvp[1], P, rc, rbits, rx, ry);
         if(P.bi != 1 && rbits > 0) s.mot_bits = rbits;
         if(rc < s.cost) s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2);
     }
@@ -445,8 +661,6 @@ __global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, c
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-// developer switch (measurement): 0 = every candidate row through the vector L1 (default: measured fastest), 1 = dense round from an LDS window
-static const int g_me_lds = getenv("XEVE_HIP_ME_LDS") ? atoi(getenv("XEVE_HIP_ME_LDS")) : 0;
 
 extern "C" size_t xeve_hip_me_epzs_workspace(int njobs)
 {
@@ -507,19 +721,20 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         XhProf prof(XH_PROF_SEARCH, st);
         unsigned long long *units = xh_prof_units(XH_PROF_SEARCH);
 #define EPZS_ARGS org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl
-#define EPZS_LAUNCH_M(S, M)                                                                                        \
+#define EPZS_LAUNCH_M(S, M, C)                                                                                     \
     do {                                                                                                           \
         if(extra_branches) {                                                                                       \
-            if(P.bi) k_me_epzs<S, true, true, 0><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
-            else k_me_epzs<S, false, true, 0><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);                  \
+            if(P.bi) k_me_epzs<S, true, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);            \
+            else k_me_epzs<S, false, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
         }                                                                                                          \
-        else if(P.bi) k_me_epzs<S, true, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                     \
-        else k_me_epzs<S, false, false, M><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                             \
+        else if(P.bi) k_me_epzs<S, true, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                  \
+        else k_me_epzs<S, false, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                          \
     } while(0)
 #define EPZS_LAUNCH(S)                                                                                             \
     do {                                                                                                           \
-        if(g_me_lds == 0) EPZS_LAUNCH_M(S, 0);                                                                     \
-        else EPZS_LAUNCH_M(S, 1);                                                                                  \
+        if(g_me_cpl) EPZS_LAUNCH_M(S, 0, true);                                                                    \
+        else if(g_me_lds == 0) EPZS_LAUNCH_M(S, 0, false);                                                         \
+        else EPZS_LAUNCH_M(S, 1, false);                                                                           \
     } while(0)
         if(log2w == 3) EPZS_LAUNCH(8);
         else if(log2w == 4) EPZS_LAUNCH(16);
