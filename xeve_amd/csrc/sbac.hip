@@ -5,14 +5,14 @@
 // sbac_carry_propagate :429-453, sbac_put_byte :397-427, xeve_eco_run_length_cc :707-771, xeve_eco_cbf :793-894, ...).
 //
 // An adaptive binary arithmetic coder is a serial chain per CU (range and context states feed forward bin by bin), so
-// the parallel axis is the JOB: one lane per job.  To keep 64 lanes with 64 different bin sequences converged, the
-// syntax is flattened into "exactly one bin per loop iteration":
-//   * k_coef_events (wave-cooperative, coalesced): every coded coefficient block is compacted, in zig-zag order, into
-//     a list of (zero-run, |level| - 1, sign, is-last-position) events -- ballot + popcount, no serial walk;
-//   * k_cu_bits (one lane per job): the few header bins (skip / pred_mode / direct / inter_dir / refi / mvp_idx / mvd /
-//     cbf) are queued per lane in LDS and drained by one uniform loop; the coefficient bins come from a six-phase
-//     automaton over the event list (run-first, run-rest, level-first, level-rest, sign, last), the five context models
-//     a component uses held in registers.  Every lane executes the same straight-line encoder each iteration.
+// the parallel axis is the JOB: one lane per job, and the lever is instructions per bin.  Which model a bin uses and what value it has
+// depend on the coefficient block alone, never on the coder state, so:
+//   * k_coef_events (wave-cooperative): every coded coefficient block is compacted, in zig-zag order, into a list of (zero-run, |level| - 1,
+//     sign, is-last-position) events by ballot + popcount AND expanded into its BIN STRING -- one byte per bin: (model << 1) | value;
+//   * k_cu_bits (one lane per job): the few header bins (skip / pred_mode / direct / inter_dir / refi / mvp_idx / mvd / cbf) are queued per lane
+//     in LDS and drained by one loop; the coefficient bins are streamed from the blocks' strings (fetch byte, model, coder step, model write-back);
+//     blocks without a usable string are coded from their event lists (code_events);
+//   * k_cu_bits_chain: the per-component cbf tests of pinter_residue_rdo under an assumed outcome, one lane per assumption.
 // The coder state is carried field for field (code register, pending / stacked bytes, bit counter), so the exit state
 // is what SBAC_STORE would keep and xeve_get_bit_number's formula applies unchanged.
 #include <cstdlib>
@@ -25,7 +25,7 @@
 
 struct CuBitsK {
     int n[3], log2n[3];
-    int slice_type, num_refp[2], cm_init, idc, burst;
+    int slice_type, num_refp[2], cm_init, idc;
     const uint16_t *scan[3];
 };
 
@@ -613,7 +613,7 @@ static int fill_k(CuBitsK &P, const xeve_hip_cu_bits_params *p)
         if(rc != XEVE_HIP_OK) return rc;
     }
     P.slice_type = p->slice_type, P.num_refp[0] = p->num_refp[0], P.num_refp[1] = p->num_refp[1];
-    P.cm_init = p->cm_init, P.idc = p->chroma_format_idc, P.burst = 0;
+    P.cm_init = p->cm_init, P.idc = p->chroma_format_idc;
     return XEVE_HIP_OK;
 }
 
