@@ -48,6 +48,8 @@ void        xeve_hip_shutdown(void);
 const char *xeve_hip_last_error(void);
 /* number of table-layer calls served since init (to let tests prove the HIP path ran) */
 uint64_t    xeve_hip_table_calls(void);
+/* of those, the calls served by the Main-profile entries (xevem_tbl_*_hip, xeve_tbl_tx_hip / _itx_hip) */
+uint64_t    xeve_hip_table_calls_main(void);
 /* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
  * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
  * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result (0 .. 23); -1 past the end.  For bindings in
@@ -106,6 +108,25 @@ extern const XEVE_HIP_TXB     xeve_tbl_txb_hip[6];
 extern const XEVE_HIP_ITXB    xeve_tbl_itxb_hip[6];
 /* replaces xeve_recon_blk (xeve_recon.c:34; installed as ctx->fn_recon, xeve_enc.c:822) */
 void xeve_recon_blk_hip(int16_t *coef, xeve_hip_pel *pred, int is_coef, int cuw, int cuh, int s_rec, xeve_hip_pel *rec, int bit_depth);
+
+/* ---- Main profile, first slice: the entries the Main tools add to the dispatch layer ---- */
+/* reference: src_main/xevem_mc.h:45 (XEVEM_MC: like XEVE_MC_L without the coefficient argument -- the Main filters are fixed) */
+typedef void (*XEVE_HIP_MCM)(xeve_hip_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xeve_hip_pel *pred, int w, int h, int bit_depth);
+/* reference: XEVE_TX / XEVE_ITX, the 16-bit-intermediate 1-D transforms of tool_iqt (src_main/xevem_tq.c:58, xevem_itdq.c:302) */
+typedef void (*XEVE_HIP_TX)(int16_t *coef, int16_t *t, int shift, int line);
+/* replace xevem_tbl_dmvr_mc_l / _c{,_sse} and xevem_tbl_bl_mc_l{,_sse} (xevem_mc.c:465-485); [dx != 0][dy != 0].
+ * DMVR: `ref` points AT the block, only the fraction of gmv counts; bilinear: gmv's integer part moves ref, footprint (w+1) x (h+1). */
+extern const XEVE_HIP_MCM     xevem_tbl_dmvr_mc_l_hip[2][2];
+extern const XEVE_HIP_MCM     xevem_tbl_dmvr_mc_c_hip[2][2];
+extern const XEVE_HIP_MCM     xevem_tbl_bl_mc_l_hip[2][2];
+/* replace xeve_tbl_tx{,_avx} (xevem_tq.c:702) and xeve_tbl_itx{,_avx} (xevem_itdq.c:549); [log2 N - 1]; shift >= 1 for N >= 4
+ * (the reference forms 1 << (shift - 1) unguarded there); installed BY ADDRESS like xeve_func_txb (xevem_util.c:3948-3963) */
+extern const XEVE_HIP_TX      xeve_tbl_tx_hip[6];
+extern const XEVE_HIP_TX      xeve_tbl_itx_hip[6];
+/* Zero-edit installation into a loaded MAIN-profile reference library: everything xeve_hip_install_tables patches (the Main
+ * library carries the same Baseline globals) plus xevem_func_dmvr_mc_l / _c, xevem_func_bl_mc_l (xevem_mc.c:39-41), xeve_func_tx
+ * (xevem_tq.c:41) and xeve_func_itx (xevem_itdq.c:39).  Returns the number of pointers patched (8 + 5 [+ 1]) or a negative error. */
+int xeve_hip_install_tables_main(void *fn_itxb_slot);
 
 /* Zero-edit installation: overwrites the reference library's exported pointer globals
  * (xeve_func_sad/ssd/diff/satd, xeve_func_mc_l/mc_c, xeve_func_average_no_clip, xeve_func_txb --

@@ -223,6 +223,44 @@ void xo_mc_c(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, in
     mc_generic(4, 5, frac_x, frac_y, ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, &coef[0][0]);
 }
 
+/* ------------------------------------------------------------------------- */
+/* Main profile, first slice: the interpolation variants the   */
+/* Main tools add to the dispatch tables.  Reference: src_main/xevem_mc.c.       */
+/* ------------------------------------------------------------------------- */
+/* Main luma 1/16-pel and chroma 1/32-pel filters (all phases populated; ISO/IEC 23094-1 8.5.4.3.2/3; the reference's copy is
+ * xevem_mc.c:48-104).  tests/test_main_oracle_vs_ref.py compares both with the library's xevem_tbl_mc_l_coeff / _c_coeff. */
+const int16_t xom_mc_l_coeff[16][8] = {
+    {0, 0, 0, 64, 0, 0, 0, 0},      {0, 1, -3, 63, 4, -2, 1, 0},    {-1, 2, -5, 62, 8, -3, 1, 0},    {-1, 3, -8, 60, 13, -4, 1, 0},
+    {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 52, 26, -8, 3, -1}, {-1, 3, -9, 47, 31, -10, 4, -1}, {-1, 4, -11, 45, 34, -10, 4, -1},
+    {-1, 4, -11, 40, 40, -11, 4, -1}, {-1, 4, -10, 34, 45, -11, 4, -1}, {-1, 4, -10, 31, 47, -9, 3, -1}, {-1, 3, -8, 26, 52, -11, 4, -1},
+    {0, 1, -5, 17, 58, -10, 4, -1}, {0, 1, -4, 13, 60, -8, 3, -1},  {0, 1, -3, 8, 62, -5, 2, -1},    {0, 1, -2, 4, 63, -3, 1, 0},
+};
+const int16_t xom_mc_c_coeff[32][4] = {
+    {0, 64, 0, 0},   {-1, 63, 2, 0},  {-2, 62, 4, 0},  {-2, 60, 7, -1},  {-2, 58, 10, -2}, {-3, 57, 12, -2}, {-4, 56, 14, -2}, {-4, 55, 15, -2},
+    {-4, 54, 16, -2}, {-5, 53, 18, -2}, {-6, 52, 20, -2}, {-6, 49, 24, -3}, {-6, 46, 28, -4}, {-5, 44, 29, -4}, {-4, 42, 30, -4}, {-4, 39, 33, -4},
+    {-4, 36, 36, -4}, {-4, 33, 39, -4}, {-4, 30, 42, -4}, {-4, 29, 44, -5}, {-4, 28, 46, -6}, {-3, 24, 49, -6}, {-2, 20, 52, -6}, {-2, 18, 53, -5},
+    {-2, 16, 54, -4}, {-2, 15, 55, -4}, {-2, 14, 56, -4}, {-2, 12, 57, -3}, {-2, 10, 58, -2}, {-1, 7, 60, -2},  {0, 4, 62, -2},   {0, 2, 63, -1},
+};
+
+/* xevem_tbl_dmvr_mc_l / _c / xevem_tbl_bl_mc_l [frac_x != 0][frac_y != 0] (xevem_mc.c:167-463).
+ *   kind 0, DMVR luma   (xevem_mc.c:167-291): 8 taps of xom_mc_l_coeff.  `ref` already points AT the block: the variants use only the
+ *           FRACTION of gmv (gmv & 15) -- the _00 variant shifts gmv and then ignores it -- so the integer part is dropped here;
+ *   kind 1, DMVR chroma (xevem_mc.c:383-463): the same with 4 taps of xom_mc_c_coeff and gmv & 31;
+ *   kind 2, bilinear luma (xevem_mc.c:293-378): 2 taps {64 - 4f, 4f} (xevem_mc.c:108-126), the integer part of gmv DOES move ref, the taps
+ *           start AT the sample (no step back), and the _nn variant filters h + 1 rows with the same two-stage shifts as the 8-tap one.
+ * All share MAC_*_N0 / _0N / _NN_S1 / _NN_S2 with the Baseline functions (xeve_mc.h:36-73), which is what mc_generic restates. */
+void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xo_pel *pred, int w, int h,
+                int bit_depth)
+{
+    if(kind == 0) mc_generic(8, 4, frac_x, frac_y, ref, gmv_x & 15, gmv_y & 15, s_ref, s_pred, pred, w, h, bit_depth, &xom_mc_l_coeff[0][0]);
+    else if(kind == 1) mc_generic(4, 5, frac_x, frac_y, ref, gmv_x & 31, gmv_y & 31, s_ref, s_pred, pred, w, h, bit_depth, &xom_mc_c_coeff[0][0]);
+    else {
+        int16_t bl[16][2];
+        for(int f = 0; f < 16; f++) { bl[f][0] = (int16_t)(64 - 4 * f); bl[f][1] = (int16_t)(4 * f); }
+        mc_generic(2, 4, frac_x, frac_y, ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, &bl[0][0]);
+    }
+}
+
 /* a7 (reference: xeve_mc.c:449-463) */
 void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h)
 {
@@ -266,7 +304,10 @@ static const int8_t *dct(int log2n)
  * dst[k*line + j] = (T)((sum_x M[k][x]*src[j*N + x] + add) >> shift); the cast
  * to the destination type truncates (no clip); the 64-point transform forces
  * outputs k >= 32 to zero (xeve_tq.c:321-381). step 0: s16 -> s32, step 1:
- * s32 -> s16. */
+ * s32 -> s16.  step 2: s16 -> s16 -- the Main profile's tx_pb{2..64}
+ * (src_main/xevem_tq.c:58-330; the 16-bit intermediate the iqt tool uses):
+ * the same sums (a butterfly there, no intermediate overflow: |sum| <=
+ * 64 * 90 * 32768 < 2^31), the same truncating store. */
 void xo_tx(int log2n, const void *src, void *dst, int shift, int line, int step)
 {
     const int     n   = 1 << log2n;
@@ -277,7 +318,7 @@ void xo_tx(int log2n, const void *src, void *dst, int shift, int line, int step)
             int64_t acc = 0;
             if(!(n == 64 && k >= 32)) {
                 for(int x = 0; x < n; x++) {
-                    int64_t v = step == 0 ? ((const int16_t *)src)[j * n + x] : ((const int32_t *)src)[j * n + x];
+                    int64_t v = step != 1 ? ((const int16_t *)src)[j * n + x] : ((const int32_t *)src)[j * n + x];
                     acc += m[k * n + x] * v;
                 }
                 acc = (acc + add) >> shift;
@@ -288,7 +329,9 @@ void xo_tx(int log2n, const void *src, void *dst, int shift, int line, int step)
 }
 
 /* a12 inverse 1-D (reference: xeve_itdq.c:34-430, clips xeve_itdq.h:41-48).
- * dst[j*N + x] = clip((sum_k M[k][x]*src[k*line + j] + add) >> shift). */
+ * dst[j*N + x] = clip((sum_k M[k][x]*src[k*line + j] + add) >> shift).
+ * step 2: s16 -> s16 with ITX_CLIP -- the Main profile's itx_pb{2..64}
+ * (src_main/xevem_itdq.c:302-547). */
 void xo_itx(int log2n, const void *src, void *dst, int shift, int line, int step)
 {
     const int     n   = 1 << log2n;
@@ -298,7 +341,7 @@ void xo_itx(int log2n, const void *src, void *dst, int shift, int line, int step
         for(int x = 0; x < n; x++) {
             int64_t acc = 0;
             for(int k = 0; k < n; k++) {
-                int64_t v = step == 0 ? ((const int16_t *)src)[k * line + j] : ((const int32_t *)src)[k * line + j];
+                int64_t v = step != 1 ? ((const int16_t *)src)[k * line + j] : ((const int32_t *)src)[k * line + j];
                 acc += m[k * n + x] * v;
             }
             acc = (acc + add) >> shift;

@@ -52,6 +52,14 @@ void xo_mc_c(int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, in
 /* a7: xeve_average_16b_no_clip xeve_mc.c:449-463 */
 void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h);
 
+/* ---- Main profile, first slice (reference: src_main/xevem_mc.c, xevem_tq.c, xevem_itdq.c) ---- */
+extern const int16_t xom_mc_l_coeff[16][8]; /* xevem_tbl_mc_l_coeff, xevem_mc.c:48-66  */
+extern const int16_t xom_mc_c_coeff[32][4]; /* xevem_tbl_mc_c_coeff, xevem_mc.c:68-104 */
+/* xevem_tbl_dmvr_mc_l (kind 0), xevem_tbl_dmvr_mc_c (kind 1), xevem_tbl_bl_mc_l (kind 2); entry [frac_x != 0][frac_y != 0]
+ * (xevem_mc.c:167-463).  The Main 1-D transforms tx_pb / itx_pb are xo_tx / xo_itx with step == 2. */
+void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xo_pel *pred, int w, int h,
+                int bit_depth);
+
 /* ---- transforms (reference: src_base/xeve_tq.c, xeve_itdq.c, xeve_tbl.c) -- */
 /* DCT-II integer matrix of size n x n (n = 2..64), xeve_tbl.c:83-236. */
 void xo_dct_matrix(int n, int8_t *m /* n*n, row-major [k][x] */);

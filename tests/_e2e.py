@@ -60,6 +60,29 @@ def make_yuv(path, w, h, frames, seed):
                 f.write(np.clip(a + r.integers(-2, 3, size=a.shape), 0, 255).astype(np.uint8).tobytes())
 
 
+# Main-profile clips (oracle/_ref/xevem_app = the same app source on the Main library): every Main tool at its default (affine, DMVR, MMVD, ADMVP, IQT, ATS, ...);
+# goldens in tests/golden/e2e_main_v1.json (tests/golden/make_e2e_main_golden.py)
+MAIN_APP = os.path.join(ROOT, "oracle", "_ref", "xevem_app")
+SHIM_MAIN = os.path.join(ROOT, "oracle", "_ref", "libxeve_hip_shim_main.so")
+MAIN_CASES = {
+    # hierarchical B pictures: bi-predicted merge candidates with references at equal distance on both sides -> DMVR (5 600 luma + 11 200 chroma calls), the
+    # MMVD search's bilinear predictions (110 000), tool_iqt's 16-bit transforms (116 000) -- counted with an interposer on the reference's own tables
+    "main_moving_ra_b3_fast": (64, 64, 5, 5004, ["--profile", "main", "--preset", "fast", "-b", "3"]),
+    "main_moving_ldb_medium": (64, 64, 3, 5002, ["--profile", "main", "--preset", "medium", "-I", "0", "-b", "0"]),
+}
+
+
+def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500):
+    cmd = [MAIN_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
+    env = dict(os.environ)
+    if hip:
+        env["LD_PRELOAD"], env["XEVE_HIP_LIB"] = SHIM_MAIN, HIP_LIB
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    data = open(out, "rb").read()
+    return hashlib.md5(data).hexdigest(), len(data), p.stderr
+
+
 def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False, tables=True):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:

@@ -1,0 +1,86 @@
+"""Main-profile first slice through the HIP library:
+  (gpu) the five *_hip tables against the committed golden outputs of the reference's own Main tables and against the oracle;
+  (cpu) the Main-profile reference app reproduces its golden bitstreams (pins the build);
+  (gpu) the UNMODIFIED Main-profile encoder with xeve_hip_install_tables_main() applied by the LD_PRELOAD interposer oracle/ref_shim_main.c
+        writes the byte-identical bitstream while DMVR, the MMVD search's bilinear predictions and tool_iqt's transforms run on the GPU."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _e2e import MAIN_APP, MAIN_CASES, SHIM_MAIN, make_yuv, run_app_main
+from _main_cases import HIP_NAMES, OracleMain, TableMain, check_golden, run_all
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_main_v1.json")))
+needs_ref = pytest.mark.skipif(not (os.path.exists(MAIN_APP) and os.path.exists(SHIM_MAIN)), reason="oracle/_ref (Main profile) not built")
+
+
+@pytest.fixture(scope="module")
+def hip_tables():
+    import xeve_amd
+    from xeve_amd import lib
+
+    xeve_amd.init(0)
+    return TableMain(lib.load(), HIP_NAMES)
+
+
+@pytest.mark.gpu
+def test_hip_main_tables_match_golden(hip_tables):
+    from xeve_amd import lib
+
+    L = lib.load()
+    before = L.xeve_hip_table_calls_main()
+    assert check_golden(hip_tables) > 200000
+    assert L.xeve_hip_table_calls_main() - before > 700  # every case went through a Main-profile HIP entry
+
+
+@pytest.mark.gpu
+def test_hip_main_tables_match_oracle(hip_tables):
+    a, b = run_all(OracleMain()), run_all(hip_tables)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), i
+
+
+@pytest.mark.gpu
+def test_hip_main_tables_touch_only_the_reference_footprint(hip_tables):
+    """the staging reads exactly the samples the reference variant reads: a block at the very corner of an allocation (bilinear: one sample / row beyond the
+    block and nothing before it; DMVR: 3 / 4 around) must not fault and must match the oracle"""
+    O = OracleMain()
+    r = np.random.default_rng(5)
+    for kind, back, fwd in ((2, 0, 1), (0, 3, 4), (1, 1, 2)):
+        w = h = 8
+        s = w + back + fwd
+        plane = r.integers(0, 1024, size=(h + back + fwd, s)).astype(np.int16)
+        for fx, fy in ((1, 1), (1, 0), (0, 1), (0, 0)):
+            gx, gy = (5 if fx else 0), (9 if fy else 0)
+            a, b = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+            O.mc(kind, fx, fy, plane, back * s + back, gx, gy, s, w, a, w, h, 10)
+            hip_tables.mc(kind, fx, fy, plane, back * s + back, gx, gy, s, w, b, w, h, 10)
+            assert np.array_equal(a, b), (kind, fx, fy)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(MAIN_CASES))
+def test_main_reference_app_reproduces_golden_bitstreams(tmp_path, name):
+    w, h, n, seed, extra = MAIN_CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, _ = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra)
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MAIN_CASES))
+def test_main_bitstream_identical_with_hip_tables_installed(tmp_path, name):
+    w, h, n, seed, extra = MAIN_CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000)
+    assert "Main-profile entries included (13 pointers)" in err
+    m = re.search(r"calls served by HIP: (\d+), of them by the Main-profile entries: (\d+)", err)
+    assert m and int(m.group(2)) > 50000 and int(m.group(1)) > int(m.group(2)), err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the HIP tables installed"

@@ -27,7 +27,7 @@ int xh_tx1d(bool fwd, const void *src, void *dst, int log2n, int shift, int line
 // state
 // ------------------------------------------------------------------------------------------------
 static std::atomic<int>      g_device{-1};
-static std::atomic<uint64_t> g_table_calls{0};
+static std::atomic<uint64_t> g_table_calls{0}, g_table_calls_main{0};
 static std::atomic<uint32_t> g_generation{0}; // bumped by every init / shutdown: per-thread staging re-creates itself when it changes
 static std::mutex            g_init_mu, g_err_mu;
 static thread_local char     t_err[512];
@@ -55,6 +55,7 @@ extern "C" const char *xeve_hip_last_error(void)
     return t_err;
 }
 extern "C" uint64_t    xeve_hip_table_calls(void) { return g_table_calls.load(); }
+extern "C" uint64_t    xeve_hip_table_calls_main(void) { return g_table_calls_main.load(); }
 extern "C" int xeve_hip_sizeof(int i)
 {
     static const int sz[] = {(int)sizeof(xeve_hip_job), (int)sizeof(xeve_hip_mc_job), (int)sizeof(xeve_hip_me_params), (int)sizeof(xeve_hip_me_job),
@@ -339,13 +340,14 @@ const XEVE_HIP_FN_SATD xeve_tbl_satd_16b_hip[1]    = {tbl_satd};
 // ---- MC ---------------------------------------------------------------------------------------------
 // Stages exactly the footprint the reference variant reads (never more host memory than the
 // reference touches) into a zero-padded tile whose origin is (ix - BACK, iy - BACK).
-template <int TAPS, bool HX, bool VY>
-static void tbl_mc(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth, const int16_t *coef)
+// `at` is the integer sample position the filter is centred on; REAL = taps the reference variant really applies (8 luma, 4 chroma, 2 bilinear:
+// its footprint starts REAL / 2 - 1 samples before `at`), TAPS = width of the kernel's coefficient rows (REAL <= TAPS, the rows zero-padded).
+template <int TAPS, int REAL>
+static void mc_stage(const pel *at, int fx, int fy, bool hx, bool vy, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth, const int16_t *coef)
 {
-    constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1, BACK = TAPS / 2 - 1;
+    constexpr int FS = TAPS == 8 ? 4 : 5, BACK = TAPS / 2 - 1, RBACK = REAL / 2 - 1;
     Stage &S = stage();
     g_table_calls++;
-    const int ix = gmv_x >> FS, iy = gmv_y >> FS;
     const int sw = w + 16, sh = h + TAPS - 1;
     if((size_t)sw * sh * 2 > (64 << 10) || (size_t)w * h * 2 > (64 << 10)) {
         xh_set_error("mc table call %dx%d exceeds the staging tile", w, h);
@@ -353,18 +355,24 @@ static void tbl_mc(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *p
     }
     int16_t *tile = S.h<int16_t>(REG_A);
     memset(tile, 0, sizeof(int16_t) * (size_t)sw * sh);
-    const int x_lo = HX ? 0 : BACK, cw = HX ? w + TAPS - 1 : w;
-    const int y_lo = VY ? 0 : BACK, ch = VY ? h + TAPS - 1 : h;
-    gather(tile + y_lo * sw + x_lo, sw, ref + (long)(iy - BACK + y_lo) * s_ref + (ix - BACK + x_lo), s_ref, cw, ch);
+    const int x_lo = hx ? BACK - RBACK : BACK, cw = hx ? w + REAL - 1 : w;
+    const int y_lo = vy ? BACK - RBACK : BACK, ch = vy ? h + REAL - 1 : h;
+    gather(tile + y_lo * sw + x_lo, sw, at + (long)(y_lo - BACK) * s_ref + (x_lo - BACK), s_ref, cw, ch);
     xeve_hip_mc_job *job = S.h<xeve_hip_mc_job>(REG_MISC);
-    job->gmv_x    = (BACK << FS) | (gmv_x & FM);
-    job->gmv_y    = (BACK << FS) | (gmv_y & FM);
+    job->gmv_x    = (BACK << FS) | fx;
+    job->gmv_y    = (BACK << FS) | fy;
     job->pred_off = 0;
-    job->frac     = (HX ? 1 : 0) | (VY ? 2 : 0);
+    job->frac     = (hx ? 1 : 0) | (vy ? 2 : 0);
     if(TAPS == 8) TBL_RC(xeve_hip_mc_l_jobs(S.d<pel>(REG_A), sw, S.d<pel>(REG_OUT), w, S.d<xeve_hip_mc_job>(REG_MISC), 1, w, h, bit_depth, (const int16_t(*)[8])coef, S.st));
     else TBL_RC(xeve_hip_mc_c_jobs(S.d<pel>(REG_A), sw, S.d<pel>(REG_OUT), w, S.d<xeve_hip_mc_job>(REG_MISC), 1, w, h, bit_depth, (const int16_t(*)[4])coef, S.st));
     S.sync();
     gather(pred, s_pred, S.h<int16_t>(REG_OUT), w, w, h);
+}
+template <int TAPS, bool HX, bool VY>
+static void tbl_mc(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth, const int16_t *coef)
+{
+    constexpr int FS = TAPS == 8 ? 4 : 5, FM = (1 << FS) - 1;
+    mc_stage<TAPS, TAPS>(ref + (long)(gmv_y >> FS) * s_ref + (gmv_x >> FS), gmv_x & FM, gmv_y & FM, HX, VY, s_ref, s_pred, pred, w, h, bit_depth, coef);
 }
 template <bool HX, bool VY>
 static void tbl_mc_l(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth, const int16_t (*c)[8])
@@ -380,6 +388,52 @@ extern "C" {
 // index [dx != 0][dy != 0]  (xeve_mc.c:383-399)
 const XEVE_HIP_MC_L xeve_tbl_mc_l_hip[2][2] = {{tbl_mc_l<false, false>, tbl_mc_l<false, true>}, {tbl_mc_l<true, false>, tbl_mc_l<true, true>}};
 const XEVE_HIP_MC_C xeve_tbl_mc_c_hip[2][2] = {{tbl_mc_c<false, false>, tbl_mc_c<false, true>}, {tbl_mc_c<true, false>, tbl_mc_c<true, true>}};
+
+}
+
+// ---- Main profile, first slice: the interpolation variants the Main tools add (src_main/xevem_mc.c:167-485) ------------------------------
+// The Main filters are fixed tables of the standard (the reference's copy: xevem_mc.c:48-126); the variants take no coefficient argument.
+static const int16_t k_main_l[16][8] = {
+    {0, 0, 0, 64, 0, 0, 0, 0},        {0, 1, -3, 63, 4, -2, 1, 0},      {-1, 2, -5, 62, 8, -3, 1, 0},     {-1, 3, -8, 60, 13, -4, 1, 0},
+    {-1, 4, -10, 58, 17, -5, 1, 0},   {-1, 4, -11, 52, 26, -8, 3, -1},  {-1, 3, -9, 47, 31, -10, 4, -1},  {-1, 4, -11, 45, 34, -10, 4, -1},
+    {-1, 4, -11, 40, 40, -11, 4, -1}, {-1, 4, -10, 34, 45, -11, 4, -1}, {-1, 4, -10, 31, 47, -9, 3, -1},  {-1, 3, -8, 26, 52, -11, 4, -1},
+    {0, 1, -5, 17, 58, -10, 4, -1},   {0, 1, -4, 13, 60, -8, 3, -1},    {0, 1, -3, 8, 62, -5, 2, -1},     {0, 1, -2, 4, 63, -3, 1, 0}};
+static const int16_t k_main_c[32][4] = {
+    {0, 64, 0, 0},    {-1, 63, 2, 0},   {-2, 62, 4, 0},   {-2, 60, 7, -1},  {-2, 58, 10, -2}, {-3, 57, 12, -2}, {-4, 56, 14, -2}, {-4, 55, 15, -2},
+    {-4, 54, 16, -2}, {-5, 53, 18, -2}, {-6, 52, 20, -2}, {-6, 49, 24, -3}, {-6, 46, 28, -4}, {-5, 44, 29, -4}, {-4, 42, 30, -4}, {-4, 39, 33, -4},
+    {-4, 36, 36, -4}, {-4, 33, 39, -4}, {-4, 30, 42, -4}, {-4, 29, 44, -5}, {-4, 28, 46, -6}, {-3, 24, 49, -6}, {-2, 20, 52, -6}, {-2, 18, 53, -5},
+    {-2, 16, 54, -4}, {-2, 15, 55, -4}, {-2, 14, 56, -4}, {-2, 12, 57, -3}, {-2, 10, 58, -2}, {-1, 7, 60, -2},  {0, 4, 62, -2},   {0, 2, 63, -1}};
+// bilinear {64 - 4f, 4f} (xevem_mc.c:108-126) as rows of the 8-tap kernel: the two taps sit at positions 3 and 4, i.e. AT the sample and one after
+static const int16_t (*main_bl())[8]
+{
+    static int16_t t[16][8];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for(int f = 0; f < 16; f++) { t[f][3] = (int16_t)(64 - 4 * f); t[f][4] = (int16_t)(4 * f); }
+    });
+    return t;
+}
+// DMVR (xevem_mc.c:167-291, 383-463): `ref` points AT the block already, only the fraction of gmv is used
+template <bool HX, bool VY> static void tbl_dmvr_l(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth)
+{
+    g_table_calls_main++;
+    mc_stage<8, 8>(ref, gmv_x & 15, gmv_y & 15, HX, VY, s_ref, s_pred, pred, w, h, bit_depth, &k_main_l[0][0]);
+}
+template <bool HX, bool VY> static void tbl_dmvr_c(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth)
+{
+    g_table_calls_main++;
+    mc_stage<4, 4>(ref, gmv_x & 31, gmv_y & 31, HX, VY, s_ref, s_pred, pred, w, h, bit_depth, &k_main_c[0][0]);
+}
+// bilinear (xevem_mc.c:293-378): the integer part of gmv moves ref; footprint (w + 1) x (h + 1)
+template <bool HX, bool VY> static void tbl_bl_l(pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, pel *pred, int w, int h, int bit_depth)
+{
+    g_table_calls_main++;
+    mc_stage<8, 2>(ref + (long)(gmv_y >> 4) * s_ref + (gmv_x >> 4), gmv_x & 15, gmv_y & 15, HX, VY, s_ref, s_pred, pred, w, h, bit_depth, &main_bl()[0][0]);
+}
+extern "C" {
+const XEVE_HIP_MCM xevem_tbl_dmvr_mc_l_hip[2][2] = {{tbl_dmvr_l<false, false>, tbl_dmvr_l<false, true>}, {tbl_dmvr_l<true, false>, tbl_dmvr_l<true, true>}};
+const XEVE_HIP_MCM xevem_tbl_dmvr_mc_c_hip[2][2] = {{tbl_dmvr_c<false, false>, tbl_dmvr_c<false, true>}, {tbl_dmvr_c<true, false>, tbl_dmvr_c<true, true>}};
+const XEVE_HIP_MCM xevem_tbl_bl_mc_l_hip[2][2]   = {{tbl_bl_l<false, false>, tbl_bl_l<false, true>}, {tbl_bl_l<true, false>, tbl_bl_l<true, true>}};
 
 void xeve_average_16b_no_clip_hip(int16_t *src, int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int wd, int ht)
 {
@@ -413,7 +467,7 @@ template <bool FWD, int LOG2N> static void tbl_tx(void *src, void *dst, int shif
 {
     Stage &S = stage();
     g_table_calls++;
-    const size_t n = (size_t)(1 << LOG2N) * line, in_b = n * (step == 0 ? 2 : 4), out_b = n * (step == 0 ? 4 : 2);
+    const size_t n = (size_t)(1 << LOG2N) * line, in_b = n * (step != 1 ? 2 : 4), out_b = n * (step == 0 ? 4 : 2); // step 2: s16 -> s16 (Main)
     if(in_b > (64 << 10) || out_b > (64 << 10)) {
         xh_set_error("transform table call N=%d line=%d exceeds the staging tile", 1 << LOG2N, line);
         die(__func__);
@@ -427,31 +481,63 @@ extern "C" {
 const XEVE_HIP_TXB  xeve_tbl_txb_hip[6]  = {tbl_tx<true, 1>, tbl_tx<true, 2>, tbl_tx<true, 3>, tbl_tx<true, 4>, tbl_tx<true, 5>, tbl_tx<true, 6>};
 const XEVE_HIP_ITXB xeve_tbl_itxb_hip[6] = {tbl_tx<false, 1>, tbl_tx<false, 2>, tbl_tx<false, 3>, tbl_tx<false, 4>, tbl_tx<false, 5>, tbl_tx<false, 6>};
 }
+// Main profile (tool_iqt): tx_pb{2..64} / itx_pb{2..64} keep the intermediate in 16 bit (src_main/xevem_tq.c:58-330, xevem_itdq.c:302-547)
+template <bool FWD, int LOG2N> static void tbl_txm(int16_t *src, int16_t *dst, int shift, int line)
+{
+    g_table_calls_main++;
+    tbl_tx<FWD, LOG2N>(src, dst, shift, line, 2);
+}
+extern "C" {
+const XEVE_HIP_TX xeve_tbl_tx_hip[6]  = {tbl_txm<true, 1>, tbl_txm<true, 2>, tbl_txm<true, 3>, tbl_txm<true, 4>, tbl_txm<true, 5>, tbl_txm<true, 6>};
+const XEVE_HIP_TX xeve_tbl_itx_hip[6] = {tbl_txm<false, 1>, tbl_txm<false, 2>, tbl_txm<false, 3>, tbl_txm<false, 4>, tbl_txm<false, 5>, tbl_txm<false, 6>};
+}
 
 // ---- zero-edit installation into a loaded reference library ---------------------------------------------
+struct Patch {
+    const char *name;
+    const void *value;
+};
+static int patch_globals(const Patch *pats, int npat, const char *who)
+{
+    for(int i = 0; i < npat; i++) // all or nothing: look every symbol up before the first store
+        if(!dlsym(RTLD_DEFAULT, pats[i].name)) {
+            xh_set_error("%s: symbol %s not found (is the reference library loaded RTLD_GLOBAL?)", who, pats[i].name);
+            return XEVE_HIP_ERR_ARG;
+        }
+    for(int i = 0; i < npat; i++) *(void **)dlsym(RTLD_DEFAULT, pats[i].name) = const_cast<void *>(pats[i].value);
+    return npat;
+}
+static const Patch k_base_patches[] = {
+    {"xeve_func_sad", xeve_tbl_sad_16b_hip},   {"xeve_func_ssd", xeve_tbl_ssd_16b_hip},
+    {"xeve_func_diff", xeve_tbl_diff_16b_hip}, {"xeve_func_satd", xeve_tbl_satd_16b_hip},
+    {"xeve_func_mc_l", xeve_tbl_mc_l_hip},     {"xeve_func_mc_c", xeve_tbl_mc_c_hip},
+    {"xeve_func_average_no_clip", (const void *)xeve_average_16b_no_clip_hip},
+    {"xeve_func_txb", &xeve_tbl_txb_hip},
+};
+static const Patch k_main_patches[] = {
+    {"xevem_func_dmvr_mc_l", xevem_tbl_dmvr_mc_l_hip}, {"xevem_func_dmvr_mc_c", xevem_tbl_dmvr_mc_c_hip}, {"xevem_func_bl_mc_l", xevem_tbl_bl_mc_l_hip},
+    {"xeve_func_tx", &xeve_tbl_tx_hip},                {"xeve_func_itx", &xeve_tbl_itx_hip},
+};
 extern "C" int xeve_hip_install_tables(void *fn_itxb_slot)
 {
     XH_ENTER();
-    struct {
-        const char *name;
-        const void *value;
-    } pats[] = {
-        {"xeve_func_sad", xeve_tbl_sad_16b_hip},   {"xeve_func_ssd", xeve_tbl_ssd_16b_hip},
-        {"xeve_func_diff", xeve_tbl_diff_16b_hip}, {"xeve_func_satd", xeve_tbl_satd_16b_hip},
-        {"xeve_func_mc_l", xeve_tbl_mc_l_hip},     {"xeve_func_mc_c", xeve_tbl_mc_c_hip},
-        {"xeve_func_average_no_clip", (const void *)xeve_average_16b_no_clip_hip},
-        {"xeve_func_txb", &xeve_tbl_txb_hip},
-    };
-    int n = 0;
-    for(auto &p : pats) {
-        void **slot = (void **)dlsym(RTLD_DEFAULT, p.name);
-        if(!slot) {
-            xh_set_error("xeve_hip_install_tables: symbol %s not found (is the reference library loaded RTLD_GLOBAL?)", p.name);
-            return XEVE_HIP_ERR_ARG;
-        }
-        *slot = const_cast<void *>(p.value);
+    int n = patch_globals(k_base_patches, (int)(sizeof(k_base_patches) / sizeof(Patch)), __func__);
+    if(n < 0) return n;
+    if(fn_itxb_slot) {
+        *(const void **)fn_itxb_slot = &xeve_tbl_itxb_hip;
         n++;
     }
+    return n;
+}
+extern "C" int xeve_hip_install_tables_main(void *fn_itxb_slot)
+{
+    XH_ENTER();
+    const int NB = (int)(sizeof(k_base_patches) / sizeof(Patch)), NM = (int)(sizeof(k_main_patches) / sizeof(Patch));
+    Patch all[NB + NM];
+    for(int i = 0; i < NB; i++) all[i] = k_base_patches[i];
+    for(int i = 0; i < NM; i++) all[NB + i] = k_main_patches[i];
+    int n = patch_globals(all, NB + NM, __func__);
+    if(n < 0) return n;
     if(fn_itxb_slot) {
         *(const void **)fn_itxb_slot = &xeve_tbl_itxb_hip;
         n++;

@@ -70,7 +70,7 @@ __global__ void k_tx1d(const void *__restrict__ src, void *__restrict__ dst, int
         const int k = i / line, j = i % line;
         if(!(n == 64 && k >= 32)) {
             for(int x = 0; x < n; x++) {
-                int64_t v = step == 0 ? (int64_t)((const int16_t *)src)[j * n + x] : (int64_t)((const int32_t *)src)[j * n + x];
+                int64_t v = step != 1 ? (int64_t)((const int16_t *)src)[j * n + x] : (int64_t)((const int32_t *)src)[j * n + x];
                 acc += (int64_t)m[k * n + x] * v;
             }
             acc = (acc + add) >> shift;
@@ -81,7 +81,7 @@ __global__ void k_tx1d(const void *__restrict__ src, void *__restrict__ dst, int
     else { // dst[j*n + x] = clip(sum_k M[k][x] * src[k*line + j])
         const int j = i / n, x = i % n;
         for(int k = 0; k < n; k++) {
-            int64_t v = step == 0 ? (int64_t)((const int16_t *)src)[k * line + j] : (int64_t)((const int32_t *)src)[k * line + j];
+            int64_t v = step != 1 ? (int64_t)((const int16_t *)src)[k * line + j] : (int64_t)((const int32_t *)src)[k * line + j];
             acc += (int64_t)m[k * n + x] * v;
         }
         acc = (acc + add) >> shift;

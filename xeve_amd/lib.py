@@ -96,6 +96,8 @@ FN_DIFF = C.CFUNCTYPE(None, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_in
 FN_MC = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p)
 FN_AVG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int)
 FN_TXB = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int)
+FN_MCM = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int)  # XEVEM_MC (src_main/xevem_mc.h:45)
+FN_TX = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int)  # XEVE_TX / XEVE_ITX
 FN_RECON = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int)
 
 # every symbol include/xeve_hip.h declares: name -> (restype, argtypes) for functions, ctypes array type for tables
@@ -105,7 +107,9 @@ FUNCTIONS = {
     "xeve_hip_shutdown": (None, []),
     "xeve_hip_last_error": (C.c_char_p, []),
     "xeve_hip_table_calls": (C.c_uint64, []),
+    "xeve_hip_table_calls_main": (C.c_uint64, []),
     "xeve_hip_install_tables": (c_int, [c_void_p]),
+    "xeve_hip_install_tables_main": (c_int, [c_void_p]),
     "xeve_average_16b_no_clip_hip": (None, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "xeve_recon_blk_hip": (None, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "xeve_hip_sad_jobs": (c_int, _JOB_ARGS + [c_int, c_void_p, c_void_p]),
@@ -186,6 +190,12 @@ TABLES = {
     "xeve_tbl_mc_c_hip": FN_MC * 4,
     "xeve_tbl_txb_hip": FN_TXB * 6,
     "xeve_tbl_itxb_hip": FN_TXB * 6,
+    # Main profile, first slice (src_main/xevem_mc.c:465-485, xevem_tq.c:702, xevem_itdq.c:549)
+    "xevem_tbl_dmvr_mc_l_hip": FN_MCM * 4,
+    "xevem_tbl_dmvr_mc_c_hip": FN_MCM * 4,
+    "xevem_tbl_bl_mc_l_hip": FN_MCM * 4,
+    "xeve_tbl_tx_hip": FN_TX * 6,
+    "xeve_tbl_itx_hip": FN_TX * 6,
 }
 
 _lib = None

@@ -31,6 +31,12 @@ class HipTables:
         self.func_mc_c = [[t["xeve_tbl_mc_c_hip"][i * 2 + j] for j in range(2)] for i in range(2)]
         self.func_txb = list(t["xeve_tbl_txb_hip"])
         self.fn_itxb = list(t["xeve_tbl_itxb_hip"])
+        # Main profile, first slice (src_main/xevem_mc.h:52-54, xevem_tq.h:51, xevem_itdq.c:39); raw XEVEM_MC / XEVE_TX entries: call them with ctypes pointers
+        self.func_dmvr_mc_l = [[t["xevem_tbl_dmvr_mc_l_hip"][i * 2 + j] for j in range(2)] for i in range(2)]
+        self.func_dmvr_mc_c = [[t["xevem_tbl_dmvr_mc_c_hip"][i * 2 + j] for j in range(2)] for i in range(2)]
+        self.func_bl_mc_l = [[t["xevem_tbl_bl_mc_l_hip"][i * 2 + j] for j in range(2)] for i in range(2)]
+        self.func_tx = list(t["xeve_tbl_tx_hip"])
+        self.func_itx = list(t["xeve_tbl_itx_hip"])
         self.func_average_no_clip = L.xeve_average_16b_no_clip_hip
         self.fn_recon = L.xeve_recon_blk_hip
 
