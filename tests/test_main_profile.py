@@ -33,7 +33,7 @@ def test_hip_main_tables_match_golden(hip_tables):
     L = lib.load()
     before = L.xeve_hip_table_calls_main()
     assert check_golden(hip_tables) > 200000
-    assert L.xeve_hip_table_calls_main() - before > 700  # every case went through a Main-profile HIP entry
+    assert L.xeve_hip_table_calls_main() - before > 500  # every case went through a Main-profile HIP entry
 
 
 @pytest.mark.gpu
