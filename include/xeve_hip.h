@@ -386,7 +386,10 @@ enum {
     XEVE_HIP_CTX_RUN       = 18, /* [24] */
     XEVE_HIP_CTX_LAST      = 42, /* [2]  */
     XEVE_HIP_CTX_LEVEL     = 44, /* [24] */
-    XEVE_HIP_SBAC_NCTX     = 68
+    XEVE_HIP_CTX_INTRA_DIR = 68, /* [2] sbac->ctx.intra_dir (the Baseline intra prediction mode)  */
+    XEVE_HIP_CTX_SPLIT_CU  = 70, /* [1] sbac->ctx.split_cu_flag                                     */
+    XEVE_HIP_CTX_DELTA_QP  = 71, /* [1] sbac->ctx.delta_qp                                          */
+    XEVE_HIP_SBAC_NCTX     = 72
 };
 typedef struct xeve_hip_sbac {
     uint32_t range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter;

@@ -12,7 +12,7 @@
 #include "xeve_eco.h"
 
 enum { C_SKIP = 0, C_PRED_MODE = 2, C_DIRECT = 5, C_INTER_DIR = 6, C_REFI = 8, C_MVP_IDX = 10, C_MVD = 13, C_CBF_ALL = 14,
-       C_CBF_LUMA = 15, C_CBF_CB = 16, C_CBF_CR = 17, C_RUN = 18, C_LAST = 42, C_LEVEL = 44, C_N = 68 };
+       C_CBF_LUMA = 15, C_CBF_CB = 16, C_CBF_CR = 17, C_RUN = 18, C_LAST = 42, C_LEVEL = 44, C_INTRA_DIR = 68, C_SPLIT_CU = 70, C_DELTA_QP = 71, C_N = 72 };
 typedef struct { u32 range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter; u16 ctx[C_N]; } drv_sbac;
 typedef struct { int log2_cuw, log2_cuh, slice_type, num_refp[2], cm_init, chroma_format_idc; } drv_params;
 typedef struct { int coef_off[3], nnz[3], sbac; s16 mvd[2][2]; s8 refi[2]; u8 mvp_idx[2]; u8 mode, dir_flag, ctx_skip, ctx_pred_mode; } drv_job;
@@ -21,7 +21,8 @@ typedef struct { int coef_off[3], nnz[3], sbac; s16 mvd[2][2]; s8 refi[2]; u8 mv
     F(skip_flag, C_SKIP, 2) F(pred_mode, C_PRED_MODE, 3) F(direct_mode_flag, C_DIRECT, 1) \
     F(inter_dir, C_INTER_DIR, 2) F(refi, C_REFI, 2) F(mvp_idx, C_MVP_IDX, 3) F(mvd, C_MVD, 1) \
     F(cbf_all, C_CBF_ALL, 1) F(cbf_luma, C_CBF_LUMA, 1) F(cbf_cb, C_CBF_CB, 1) F(cbf_cr, C_CBF_CR, 1) \
-    F(run, C_RUN, 24) F(last, C_LAST, 2) F(level, C_LEVEL, 24)
+    F(run, C_RUN, 24) F(last, C_LAST, 2) F(level, C_LEVEL, 24) \
+    F(intra_dir, C_INTRA_DIR, 2) F(split_cu_flag, C_SPLIT_CU, 1) F(delta_qp, C_DELTA_QP, 1)
 
 static void to_ref(XEVE_SBAC *d, const drv_sbac *s, int cm_init)
 {

@@ -199,13 +199,14 @@ static void shim_itdq(XEVE_CTX *ctx, XEVE_CORE *core, s16 coef[N_C][MAX_CU_DIM],
  * and run / level / sign / last bins through the adaptive arithmetic coder -- runs on the GPU: ctx->fn_eco_coef (xeve_eco_coef, xeve_eco.c:1067-1089)
  * hands the live XEVE_SBAC over, field by field, and takes it back as xeve_hip_eco_coef_host leaves it.  Writing the real bitstream stays with the
  * reference's function. */
-typedef struct { u32 range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter; u16 ctx[68]; } hip_sbac;
+typedef struct { u32 range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter; u16 ctx[72]; } hip_sbac;
 static int (*hip_eco_coef_host)(hip_sbac *, const s16 *, const s16 *, const s16 *, int, int, const int *, int, int, int);
 static int (*orig_eco_coef)(XEVE_CTX *, XEVE_CORE *, XEVE_BSW *, s16 coef[N_C][MAX_CU_DIM], u8, int, int, int);
 static unsigned long long eco_calls;
 #define SBAC_MAP(F)                                                                                                             \
     F(skip_flag, 0, 2) F(pred_mode, 2, 3) F(direct_mode_flag, 5, 1) F(inter_dir, 6, 2) F(refi, 8, 2) F(mvp_idx, 10, 3) F(mvd, 13, 1)  \
-    F(cbf_all, 14, 1) F(cbf_luma, 15, 1) F(cbf_cb, 16, 1) F(cbf_cr, 17, 1) F(run, 18, 24) F(last, 42, 2) F(level, 44, 24)
+    F(cbf_all, 14, 1) F(cbf_luma, 15, 1) F(cbf_cb, 16, 1) F(cbf_cr, 17, 1) F(run, 18, 24) F(last, 42, 2) F(level, 44, 24) \
+    F(intra_dir, 68, 2) F(split_cu_flag, 70, 1) F(delta_qp, 71, 1)
 
 static int shim_eco_coef(XEVE_CTX *ctx, XEVE_CORE *core, XEVE_BSW *bs, s16 coef[N_C][MAX_CU_DIM], u8 pred_mode, int enc_dqp, int b_no_cbf, int run_stats)
 {

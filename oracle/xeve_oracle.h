@@ -184,7 +184,10 @@ enum {
     XO_CTX_RUN       = 18, /* [24] */
     XO_CTX_LAST      = 42, /* [2]  */
     XO_CTX_LEVEL     = 44, /* [24] */
-    XO_SBAC_NCTX     = 68
+    XO_CTX_INTRA_DIR = 68, /* [2]  intra_dir (xeve_eco_intra_dir, xeve_eco.c:1104-1121) */
+    XO_CTX_SPLIT_CU  = 70, /* [1]  split_cu_flag */
+    XO_CTX_DELTA_QP  = 71, /* [1]  delta_qp */
+    XO_SBAC_NCTX     = 72
 };
 typedef struct xo_sbac {
     uint32_t range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter;

@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 from _inter_cases import make_inter_jobs, make_inter_params, make_inter_picture
-from _libs import INTER_RESULT_DTYPE, SBAC_DTYPE
+from _libs import INTER_RESULT_DTYPE, SBAC_DTYPE, sbac_from_golden
 from _rdo_cases import states
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inter_v1.npz")
@@ -25,5 +25,5 @@ def golden():
         jobs = make_inter_jobs(r, N_JOBS, w, h, 1 << lw, len(st), refs, st_type)
         assert bytes(P) == np.ascontiguousarray(g["params%d" % k]).tobytes() and jobs.tobytes() == np.ascontiguousarray(g["jobs%d" % k]).tobytes()
         yield dict(refs=refs, org=org, states=st, P=P, jobs=jobs, res=np.ascontiguousarray(g["res%d" % k]).view(INTER_RESULT_DTYPE),
-                   best=np.ascontiguousarray(g["best%d" % k]).view(SBAC_DTYPE), coef=[g["coef%d_%d" % (k, c)] for c in range(3)],
+                   best=sbac_from_golden(g["best%d" % k], st[jobs["sbac"]]), coef=[g["coef%d_%d" % (k, c)] for c in range(3)],
                    rec=[g["rec%d_%d" % (k, c)] for c in range(3)], idc=idc, lw=lw, slice_type=st_type)

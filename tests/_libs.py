@@ -302,13 +302,30 @@ def oracle_rdoq():
 
 
 # ---- CABAC (SBAC) bit counting ------------------------------------------------------------------------------------
-SBAC_NCTX = 68
+SBAC_NCTX = 72
 SBAC_DTYPE = np.dtype([("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"),
                        ("pending_byte", "<u4"), ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"),
                        ("ctx", "<u2", (SBAC_NCTX,))])
 CU_BITS_JOB_DTYPE = np.dtype([("coef_off", "<i4", (3,)), ("nnz", "<i4", (3,)), ("sbac", "<i4"), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)),
                               ("mvp_idx", "u1", (2,)), ("mode", "u1"), ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1")])
-assert SBAC_DTYPE.itemsize == 172 and CU_BITS_JOB_DTYPE.itemsize == 44
+assert SBAC_DTYPE.itemsize == 180 and CU_BITS_JOB_DTYPE.itemsize == 44
+_SBAC_V1 = np.dtype(SBAC_DTYPE.descr[:-1] + [("ctx", "<u2", (68,))])  # the 172-byte state of the goldens made before the intra models were added
+
+
+def sbac_from_golden(raw, like):
+    """coder states stored in a committed golden file -> today's SBAC_DTYPE.  Files made with the 68-model state (no "sbac_nctx" key) hold exit states of
+    inter-CU syntax, which never touches the models added since: those are taken from `like`, the entry state of the same job (array of the same length)."""
+    raw = np.ascontiguousarray(raw)
+    if raw.nbytes % SBAC_DTYPE.itemsize == 0 and raw.nbytes // SBAC_DTYPE.itemsize == len(like):
+        return raw.view(SBAC_DTYPE).reshape(-1)
+    old = raw.view(_SBAC_V1).reshape(-1)
+    assert len(old) == len(like)
+    out = np.zeros(len(old), SBAC_DTYPE)
+    for f in SBAC_DTYPE.names[:-1]:
+        out[f] = old[f]
+    out["ctx"][:, :68] = old["ctx"]
+    out["ctx"][:, 68:] = like["ctx"][:, 68:]
+    return out
 
 
 class CuBitsParams(C.Structure):

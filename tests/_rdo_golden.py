@@ -3,7 +3,7 @@ import os
 
 import numpy as np
 
-from _libs import RDO_JOB_DTYPE, SBAC_DTYPE, RdoParams
+from _libs import RDO_JOB_DTYPE, SBAC_DTYPE, sbac_from_golden, RdoParams
 from _rdo_cases import make_jobs, make_params, make_picture, states
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdo_v1.npz")
@@ -20,4 +20,4 @@ def golden():
         jobs = make_jobs(r, 24, w, h, 1 << lw, 1 << lh, nref, len(st), st_type)
         assert bytes(p) == np.ascontiguousarray(g["params%d" % k]).tobytes() and jobs.tobytes() == np.ascontiguousarray(g["jobs%d" % k]).tobytes()
         yield dict(refs=refs, org=org, states=st, p=p, jobs=jobs, cost=g["cost%d" % k], nnz=g["nnz%d" % k],
-                   best=np.ascontiguousarray(g["best%d" % k]).view(SBAC_DTYPE), coef=[g["coef%d_%d" % (k, c)] for c in range(3)], idc=idc, lw=lw, lh=lh)
+                   best=sbac_from_golden(g["best%d" % k], st[jobs["sbac"]]), coef=[g["coef%d_%d" % (k, c)] for c in range(3)], idc=idc, lw=lw, lh=lh)

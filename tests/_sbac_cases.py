@@ -12,7 +12,11 @@ def make_states(r, n):
     s["code_bits"] = r.integers(1, 12, size=n)  # xeve_sbac_bit_reset overwrites these; the values must not matter
     s["stacked_ff"] = r.integers(0, 3, size=n)
     s["bitcounter"] = r.integers(0, 1000, size=n)
-    s["ctx"] = (r.integers(1, 257, size=(n, SBAC_NCTX)) << 1) | r.integers(0, 2, size=(n, SBAC_NCTX))
+    # the 68 models of the inter-CU syntax come from `r` exactly as when the committed goldens were made (their inputs are regenerated from the seeds);
+    # the models added since (intra_dir, split_cu_flag, delta_qp: indices 68..71) from a generator of their own, so the stream of `r` is unchanged
+    s["ctx"][:, :68] = (r.integers(1, 257, size=(n, 68)) << 1) | r.integers(0, 2, size=(n, 68))
+    r2 = np.random.default_rng(int(s["code"][0]) + 68)
+    s["ctx"][:, 68:] = (r2.integers(1, 257, size=(n, SBAC_NCTX - 68)) << 1) | r2.integers(0, 2, size=(n, SBAC_NCTX - 68))
     s["ctx"][0] = 512  # PROB_INIT everywhere: the state at the start of a slice
     return s
 

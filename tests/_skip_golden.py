@@ -3,7 +3,7 @@ import os
 
 import numpy as np
 
-from _libs import SBAC_DTYPE, SKIP_RESULT_DTYPE
+from _libs import SBAC_DTYPE, sbac_from_golden, SKIP_RESULT_DTYPE
 from _rdo_cases import make_params, make_picture, make_skip_jobs, states
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skip_v1.npz")
@@ -21,5 +21,5 @@ def golden():
         jobs = make_skip_jobs(r, 24, w, h, 1 << lw, 1 << lh, len(st), ncand)
         assert bytes(p) == np.ascontiguousarray(g["params%d" % k]).tobytes() and jobs.tobytes() == np.ascontiguousarray(g["jobs%d" % k]).tobytes()
         yield dict(refs=refs, org=org, states=st, p=p, jobs=jobs, res=np.ascontiguousarray(g["res%d" % k]).view(SKIP_RESULT_DTYPE),
-                   best=np.ascontiguousarray(g["best%d" % k]).view(SBAC_DTYPE), pred=[g["pred%d_%d" % (k, c)] for c in range(3)], idc=idc, lw=lw, lh=lh,
+                   best=sbac_from_golden(g["best%d" % k], st[jobs["sbac"]]), pred=[g["pred%d_%d" % (k, c)] for c in range(3)], idc=idc, lw=lw, lh=lh,
                    slice_type=st_type, ncand=ncand)

@@ -96,7 +96,7 @@ def test_hip_cu_bits_rejects_bad_arguments():
     xeve_amd.init(0)
     dev = torch.device("cuda:0")
     z = torch.zeros(64, dtype=torch.int16, device=dev)
-    st = torch.zeros(172, dtype=torch.uint8, device=dev)
+    st = torch.zeros(SBAC_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     jb = torch.zeros(44, dtype=torch.uint8, device=dev)
     for lw, lh, idc in ((1, 3, 1), (7, 3, 1), (3, 3, 4)):
         p = lib.CuBitsParams()

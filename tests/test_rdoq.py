@@ -141,13 +141,13 @@ def test_hip_rdoq_bit_est_vs_goldens_and_oracle():
     import xeve_amd
     from _libs import EST_FULL_INTS, SBAC_DTYPE, oracle_sbac
     from _sbac_cases import make_states
-    from _sbac_golden import GOLD
+    from _sbac_golden import GOLD, est_states
     from xeve_amd import device as D
 
     xeve_amd.init(0)
     dev = torch.device("cuda:0")
     g = np.load(GOLD)
-    st = np.ascontiguousarray(g["est_states"])
+    st = est_states().view(np.uint8)
     got = D.rdoq_bit_est(torch.from_numpy(st.copy()).to(dev)).cpu().numpy()
     assert np.array_equal(got, g["est"])
     O = oracle_sbac()

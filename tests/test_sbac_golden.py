@@ -49,12 +49,12 @@ def test_bit_count_is_the_number_of_renormalisation_shifts():
 
 def test_oracle_rdoq_bit_est_matches_reference_goldens():
     from _libs import EST_FULL_INTS
-    from _sbac_golden import GOLD
+    from _sbac_golden import GOLD, est_states
 
     O = oracle_sbac()
     g = np.load(GOLD)
     assert [O.xo_entropy_bits(i) for i in range(1024)] == g["entropy_bits"].tolist()
-    st = np.ascontiguousarray(g["est_states"]).view(SBAC_DTYPE)
+    st = est_states()
     for i in range(len(st)):
         a = np.zeros(EST_FULL_INTS, np.int32)
         O.xo_rdoq_bit_est(ptr(st[i:i + 1]), ptr(a))

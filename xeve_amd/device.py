@@ -11,6 +11,8 @@ import torch
 
 from . import lib as _lib
 
+SBAC_BYTES = 36 + 2 * _lib.SBAC_NCTX  # sizeof(xeve_hip_sbac)
+
 _COEF_L = None
 _COEF_C = None
 
@@ -183,7 +185,7 @@ def rdoq(coef, log2w, log2h, qp, lam, is_luma, bit_depth, est, tool_iqt=0, nnz=N
 
 def rdoq_bit_est(sbac):
     """xeve_rdoq_bit_est for an array of coder states (uint8 tensor of lib.SBAC_DTYPE records) -> int32 [n, 108] (xeve_hip_rdoq_est_full)"""
-    n = sbac.numel() // 172
+    n = sbac.numel() // SBAC_BYTES
     est = torch.empty((n, _lib.EST_FULL_INTS), dtype=torch.int32, device=sbac.device)
     _lib.check(_lib.load().xeve_hip_rdoq_bit_est(_ptr(sbac), n, _ptr(est), _stream()))
     return est
@@ -223,15 +225,15 @@ def mc_cu_jobs(refp, num_refp, s_l, s_c, pic_w, pic_h, jobs, w, h, bit_depth, ch
 def residue_rdo_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None):
     """pinter_residue_rdo for a batch of candidates (xeve_hip_residue_rdo_jobs).  org_ptrs: three device addresses of sample (0, 0);
     refp: HOST numpy array of lib.REFPIC_DTYPE; states / jobs: uint8 tensors of lib.SBAC_DTYPE / lib.RDO_JOB_DTYPE records.
-    Returns (results uint8 [njobs, 72], coef int16 flat, best uint8 [njobs, 172])."""
+    Returns (results uint8 [njobs, 72], coef int16 flat, best uint8 [njobs, 180])."""
     L = _lib.load()
-    njobs, nstates, dev = jobs.numel() // 36, states.numel() // 172, jobs.device
+    njobs, nstates, dev = jobs.numel() // 36, states.numel() // SBAC_BYTES, jobs.device
     ws, hs = (1 if params.chroma_format_idc <= 2 else 0), (1 if params.chroma_format_idc <= 1 else 0)
     n0 = 1 << (params.log2_cuw + params.log2_cuh)
     n1 = (n0 >> (ws + hs)) if params.chroma_format_idc else 0
     res = torch.empty((njobs, 72), dtype=torch.uint8, device=dev)
     coef = torch.empty(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
-    best = torch.empty((njobs, 172), dtype=torch.uint8, device=dev)
+    best = torch.empty((njobs, SBAC_BYTES), dtype=torch.uint8, device=dev)
     need = L.xeve_hip_residue_rdo_workspace(njobs, nstates, C.byref(params), s_org_l, s_org_c)
     if workspace is None:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
@@ -244,17 +246,17 @@ def residue_rdo_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params,
 
 def analyze_skip_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, max_cand=4, want_state=True, workspace=None):
     """xeve_analyze_skip for a batch of CUs (xeve_hip_analyze_skip_jobs).  jobs: uint8 tensor of lib.SKIP_JOB_DTYPE records.
-    Returns (results uint8 [njobs, 40], pred_y, pred_u, pred_v int16 [njobs, n], best uint8 [njobs, 172] or None); predictions and
+    Returns (results uint8 [njobs, 40], pred_y, pred_u, pred_v int16 [njobs, n], best uint8 [njobs, 180] or None); predictions and
     states of CUs without a usable pair keep the zero fill."""
     L = _lib.load()
-    njobs, nstates, dev = jobs.numel() // 60, states.numel() // 172, jobs.device
+    njobs, nstates, dev = jobs.numel() // 60, states.numel() // SBAC_BYTES, jobs.device
     ws, hs = (1 if params.chroma_format_idc <= 2 else 0), (1 if params.chroma_format_idc <= 1 else 0)
     n0 = 1 << (params.log2_cuw + params.log2_cuh)
     n1 = (n0 >> (ws + hs)) if params.chroma_format_idc else 0
     res = torch.empty((njobs, 40), dtype=torch.uint8, device=dev)
     py = torch.zeros((njobs, n0), dtype=torch.int16, device=dev)
     pu, pv = (torch.zeros((njobs, max(n1, 1)), dtype=torch.int16, device=dev) for _ in range(2))
-    best = torch.zeros((njobs, 172), dtype=torch.uint8, device=dev) if want_state else None
+    best = torch.zeros((njobs, SBAC_BYTES), dtype=torch.uint8, device=dev) if want_state else None
     need = L.xeve_hip_analyze_skip_workspace(njobs, C.byref(params), max_cand)
     if workspace is None:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
@@ -269,10 +271,10 @@ def analyze_skip_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params
 def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, params, jobs, workspace=None, want_pred=False):
     """the whole inter analysis of a batch of CUs (xeve_hip_pinter_analyze_cu_jobs).  params: lib.InterParams; jobs: uint8 tensor of lib.INTER_JOB_DTYPE
     records.  Returns (results uint8 [njobs, 96], coef int16 flat [Y blocks | U blocks | V blocks], rec_y, rec_u, rec_v int16 [njobs, n],
-    next_best uint8 [njobs, 172]) and, with want_pred, the winner's luma prediction int16 [njobs, n] (mi->pred_y_best)."""
+    next_best uint8 [njobs, 180]) and, with want_pred, the winner's luma prediction int16 [njobs, n] (mi->pred_y_best)."""
     L = _lib.load()
     rp = params.rdo
-    njobs, nstates, dev = jobs.numel() // 52, states.numel() // 172, jobs.device
+    njobs, nstates, dev = jobs.numel() // 52, states.numel() // SBAC_BYTES, jobs.device
     ws, hs = (1 if rp.chroma_format_idc <= 2 else 0), (1 if rp.chroma_format_idc <= 1 else 0)
     n0 = 1 << (rp.log2_cuw + rp.log2_cuh)
     n1 = (n0 >> (ws + hs)) if rp.chroma_format_idc else 0
@@ -280,7 +282,7 @@ def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, p
     coef = torch.empty(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
     ry = torch.zeros((njobs, n0), dtype=torch.int16, device=dev)
     ru, rv = (torch.zeros((njobs, max(n1, 1)), dtype=torch.int16, device=dev) for _ in range(2))
-    nb = torch.zeros((njobs, 172), dtype=torch.uint8, device=dev)
+    nb = torch.zeros((njobs, SBAC_BYTES), dtype=torch.uint8, device=dev)
     py = torch.zeros((njobs, n0), dtype=torch.int16, device=dev) if want_pred else None
     need = L.xeve_hip_pinter_analyze_cu_workspace(njobs, nstates, C.byref(params), s_org_l, s_org_c)
     if workspace is None:
@@ -323,7 +325,7 @@ def picbuf_expand(planes, origins, s_l, s_c, w_l, h_l, w_c, h_c, exp_l, exp_c, c
 def cu_bits_jobs(coef, sbac_in, jobs, params, want_state=True, workspace=None, bits=None, sbac_out=None):
     """CABAC bit count of inter-CU jobs (xeve_hip_cu_bits_jobs).  coef: flat int16 tensor; sbac_in / jobs: uint8 tensors holding
     arrays of lib.SBAC_DTYPE / lib.CU_BITS_JOB_DTYPE records; params: lib.CuBitsParams.  Returns (bits u32-as-int32 [njobs],
-    exit states as a uint8 [njobs, 172] tensor or None)."""
+    exit states as a uint8 [njobs, 180] tensor or None)."""
     L = _lib.load()
     njobs = jobs.numel() // 44
     need = L.xeve_hip_cu_bits_workspace(njobs, coef.numel())
@@ -332,7 +334,7 @@ def cu_bits_jobs(coef, sbac_in, jobs, params, want_state=True, workspace=None, b
     if bits is None:
         bits = torch.empty(njobs, dtype=torch.int32, device=coef.device)
     if sbac_out is None and want_state:
-        sbac_out = torch.empty((njobs, 172), dtype=torch.uint8, device=coef.device)
+        sbac_out = torch.empty((njobs, SBAC_BYTES), dtype=torch.uint8, device=coef.device)
     _lib.check(L.xeve_hip_cu_bits_jobs(_ptr(_i16(coef)), coef.numel(), _ptr(sbac_in), _ptr(jobs), njobs, C.byref(params), _ptr(workspace),
                                        workspace.numel(), _ptr(bits), _ptr(sbac_out) if sbac_out is not None else None, _stream()))
     return bits, sbac_out

@@ -77,9 +77,9 @@ class CuBitsParams(C.Structure):  # xeve_hip_cu_bits_params
 EST_FULL_INTS = 108  # xeve_hip_rdoq_est_full: cbf_all, cbf_luma, cbf_cb, cbf_cr [2] each, run[24][2], level[24][2], last[2][2]
 REFPIC_DTYPE = [("y", "<u8"), ("u", "<u8"), ("v", "<u8"), ("poc", "<i4"), ("pad_", "<i4")]  # xeve_hip_refpic (device addresses), host array
 CU_MC_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mv", "<i2", (2, 2)), ("refi", "i1", (2,)), ("pad_", "i1", (2,))]  # xeve_hip_cu_mc_job (20 B)
-SBAC_NCTX = 68
+SBAC_NCTX = 72
 SBAC_DTYPE = [("range", "<u4"), ("code", "<u4"), ("code_bits", "<u4"), ("stacked_ff", "<u4"), ("stacked_zero", "<u4"), ("pending_byte", "<u4"),
-              ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"), ("ctx", "<u2", (SBAC_NCTX,))]  # xeve_hip_sbac (172 B)
+              ("is_pending_byte", "<u4"), ("bitcounter", "<u4"), ("bin_counter", "<u4"), ("ctx", "<u2", (SBAC_NCTX,))]  # xeve_hip_sbac (180 B)
 CU_BITS_JOB_DTYPE = [("coef_off", "<i4", (3,)), ("nnz", "<i4", (3,)), ("sbac", "<i4"), ("mvd", "<i2", (2, 2)), ("refi", "i1", (2,)),
                      ("mvp_idx", "u1", (2,)), ("mode", "u1"), ("dir_flag", "u1"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1")]  # xeve_hip_cu_bits_job (44 B)
 EPZS_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("org_off", "<i4"), ("mvp", "<i2", 2), ("mv_start", "<i2", 2)]  # xeve_hip_epzs_job
