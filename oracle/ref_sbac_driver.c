@@ -78,7 +78,18 @@ unsigned refdrv_cu_bits(const drv_sbac *in, drv_sbac *out, const drv_params *p, 
     s8  refi[REFP_NUM] = {j->refi[0], j->refi[1]};
     s16 mvd[REFP_NUM][MV_D] = {{j->mvd[0][0], j->mvd[0][1]}, {j->mvd[1][0], j->mvd[1][1]}};
     u8  mvp_idx[REFP_NUM] = {j->mvp_idx[0], j->mvp_idx[1]};
-    if(j->mode == 4) xeve_rdo_bit_cnt_cu_skip(ctx, core, p->slice_type, 0, j->mvp_idx[0], j->mvp_idx[1], 0, 0);
+    if(j->mode >= 7 && j->mode <= 9) { /* intra CU: job.mvp_idx[0] = the unary index mpm[ipm]; realised as mode 0 of a list whose entry 0 is that index */
+        static __thread u8 mpm[IPD_CNT_B];
+        mpm[0] = j->mvp_idx[0], core->mpm_b_list = mpm, core->ipm[0] = 0;
+        ctx->fn_mode_rdo_bit_cnt_intra_dir = xeve_rdo_bit_cnt_intra_dir, ctx->fn_rdo_intra_ext = NULL, ctx->fn_rdo_intra_ext_c = NULL;
+        if(j->mode == 7) xeve_rdo_bit_cnt_cu_intra(ctx, core, p->slice_type, 0, cbuf);
+        else if(j->mode == 8) {
+            core->nnz_sub[U_C][0] = core->nnz_sub[V_C][0] = 0; /* (xeve_sub_block_tq run for luma alone leaves them cleared) */
+            xeve_rdo_bit_cnt_cu_intra_luma(ctx, core, p->slice_type, 0, cbuf);
+        }
+        else xeve_rdo_bit_cnt_intra_dir(ctx, core, 0);
+    }
+    else if(j->mode == 4) xeve_rdo_bit_cnt_cu_skip(ctx, core, p->slice_type, 0, j->mvp_idx[0], j->mvp_idx[1], 0, 0);
     else if(j->mode == 0)
         xeve_rdo_bit_cnt_cu_inter(ctx, core, p->slice_type, 0, refi, mvd, cbuf, j->dir_flag ? PRED_DIR : (refi[0] >= 0 ? (refi[1] >= 0 ? PRED_BI : PRED_L0) : PRED_L1),
                                   mvp_idx, 0, 0, NULL);

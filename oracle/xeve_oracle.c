@@ -1072,6 +1072,19 @@ uint32_t xo_cu_bits(const xo_sbac *in, xo_sbac *out, const xo_cu_bits_params *p,
         }
         sbac_coef(&s, p, j, coef, run_all, 0, 0);
     }
+    else if(j->mode == XO_BITS_CU_INTRA || j->mode == XO_BITS_INTRA_LUMA) {
+        /* xeve_rdo_bit_cnt_cu_intra (xeve_mode.c:141-175) / xeve_rdo_bit_cnt_cu_intra_luma (:81-117): Baseline (tool_admvp 0, xeve_check_all_preds true,
+         * no fn_rdo_intra_ext, no delta QP): outside I slices skip_flag = 0 and pred_mode = MODE_INTRA, the prediction mode as the unary index
+         * mpm[ipm] over the two intra_dir models (xeve_eco_intra_dir, xeve_eco.c:1104-1121), the cbf flags and coefficients of an intra CU */
+        static const int run_all[3] = {1, 1, 1}, run_y[3] = {1, 0, 0};
+        if(p->slice_type != 2) {
+            xo_sbac_bin(&s, XO_CTX_SKIP_FLAG + j->ctx_skip, 0);
+            xo_sbac_bin(&s, XO_CTX_PRED_MODE + j->ctx_pred_mode, 1);
+        }
+        sbac_unary2(&s, j->mvp_idx[0], XO_CTX_INTRA_DIR);
+        sbac_coef(&s, p, j, coef, j->mode == XO_BITS_CU_INTRA ? run_all : run_y, 1, 0);
+    }
+    else if(j->mode == XO_BITS_INTRA_DIR) sbac_unary2(&s, j->mvp_idx[0], XO_CTX_INTRA_DIR); /* xeve_rdo_bit_cnt_intra_dir (xeve_mode.c:136-139) */
     else if(j->mode == XO_BITS_MVP) { /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79), pidx != PRED_DIR */
         if(p->slice_type != 2 && j->refi[0] >= 0) sbac_mvp_idx(&s, j->mvp_idx[0]), sbac_mvd1(&s, j->mvd[0][0]), sbac_mvd1(&s, j->mvd[0][1]);
         if(p->slice_type == 0 && j->refi[1] >= 0) sbac_mvp_idx(&s, j->mvp_idx[1]), sbac_mvd1(&s, j->mvd[1][0]), sbac_mvd1(&s, j->mvd[1][1]);
@@ -1743,4 +1756,232 @@ void xo_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const
 #undef M_IF
 #undef M_IBC
 #undef M_COD
+}
+
+
+/* ===================================================================================================================
+ * Intra analysis of one CU: pintra_analyze_cu (src_base/xeve_pintra.c:544-698) = ctx->fn_pintra_analyze_cu, Baseline profile,
+ * rdo_dbk_switch 0, no delta QP.  Neighbour samples (xeve_get_nbr, xeve_ipred.c:32-105), the five Baseline predictors
+ * (xeve_ipred.c:107-202), the most-probable-mode list (xeve_get_mpm, :229-252), the SATD + mode-bits candidate list
+ * (make_ipred_list, xeve_pintra.c:308-374), the luma RDO of the list and the chroma RDO of its winner (pintra_residue_rdo, :69-272).
+ * =================================================================================================================== */
+#define SCU_COD_(m) (((m) >> 31) & 1)
+#define SCU_IF_(m)  (((m) >> 15) & 1)
+const uint8_t xo_tbl_mpm[6][6][5] = { /* xeve_tbl_mpm (xeve_tbl.c:40-48): [left mode + 1 | 0][up mode + 1 | 0] -> rank of every mode */
+    {{0, 2, 3, 1, 4}, {0, 2, 1, 3, 4}, {0, 2, 1, 3, 4}, {1, 2, 0, 3, 4}, {0, 2, 1, 3, 4}, {0, 1, 2, 3, 4}},
+    {{1, 0, 2, 3, 4}, {0, 1, 2, 3, 4}, {0, 1, 2, 3, 4}, {1, 2, 0, 3, 4}, {0, 1, 3, 2, 4}, {0, 2, 1, 4, 3}},
+    {{1, 0, 2, 3, 4}, {1, 0, 2, 3, 4}, {1, 0, 2, 3, 4}, {2, 0, 1, 3, 4}, {1, 0, 3, 2, 4}, {0, 1, 2, 4, 3}},
+    {{1, 0, 2, 3, 4}, {0, 2, 1, 3, 4}, {1, 0, 2, 3, 4}, {1, 2, 0, 3, 4}, {0, 1, 2, 3, 4}, {0, 2, 1, 4, 3}},
+    {{0, 1, 2, 3, 4}, {0, 3, 2, 1, 4}, {1, 0, 2, 3, 4}, {1, 2, 0, 3, 4}, {1, 2, 3, 0, 4}, {0, 2, 1, 4, 3}},
+    {{0, 1, 2, 3, 4}, {0, 1, 2, 4, 3}, {0, 1, 2, 4, 3}, {0, 2, 1, 4, 3}, {0, 1, 2, 3, 4}, {0, 1, 2, 4, 3}}};
+
+/* xeve_get_nbr (xeve_ipred.c:32-105) for one component.  x, y, cuw, cuh in samples OF THAT COMPONENT; src = the component's plane of the picture
+ * being reconstructed (PIC_MODE) at (x, y).  up[-1 .. cuw + cuh - 1], left[-1 .. cuw + cuh - 1]: the caller passes pointers to element 0.
+ * Unavailable 4x4 units (not yet coded, outside the picture, another tile, or -- with constrained intra prediction -- not intra) read as mid-grey.
+ * Only the up-left bit of avail_cu is used (xeve_get_avail_intra, xeve_util.c:753-755). */
+void xo_get_nbr(int x, int y, int cuw, int cuh, const xo_pel *src, int s_src, const uint32_t *map_scu, const uint8_t *map_tidx, int w_scu, int h_scu, int ch,
+                int constrained_intra_pred, int bit_depth, int chroma_format_idc, xo_pel *left, xo_pel *up)
+{
+    const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1; /* XEVE_GET_CHROMA_W/H_SHIFT for idc 1, 2, 3 (0: no chroma call) */
+    int scuw = ch == 0 ? cuw >> 2 : cuw >> (2 - ws), scuh = ch == 0 ? cuh >> 2 : cuh >> (2 - hs);
+    int unit = ch == 0 ? 4 : 2;
+    const int x_scu = (ch == 0 ? x : x << ws) >> 2, y_scu = (ch == 0 ? y : y << hs) >> 2, scup = y_scu * w_scu + x_scu;
+    const xo_pel grey = (xo_pel)(1 << (bit_depth - 1));
+    if(ch != 0 && chroma_format_idc == 2) scuh *= 2;
+    if(ch != 0 && chroma_format_idc == 3) unit *= 2;
+#define USABLE(u) (SCU_COD_(map_scu[u]) && (!constrained_intra_pred || SCU_IF_(map_scu[u])) && map_tidx[scup] == map_tidx[u])
+    /* the up-left sample: avail_cu & AVAIL_UP_LE = (x_scu > 0 && y_scu > 0 && coded && same tile), then the constrained-intra test */
+    if(x_scu > 0 && y_scu > 0 && SCU_COD_(map_scu[scup - w_scu - 1]) && map_tidx[scup] == map_tidx[scup - w_scu - 1] &&
+       (!constrained_intra_pred || SCU_IF_(map_scu[scup - w_scu - 1])))
+        up[-1] = src[-s_src - 1];
+    else up[-1] = grey;
+    for(int i = 0; i < scuw + scuh; i++) {
+        const int ok = y_scu > 0 && x_scu + i < w_scu && USABLE(scup - w_scu + i);
+        for(int k = 0; k < unit; k++) up[i * unit + k] = ok ? src[-s_src + i * unit + k] : grey;
+    }
+    for(int i = 0; i < scuh + scuw; i++) {
+        const int ok = x_scu > 0 && y_scu + i < h_scu && USABLE(scup - 1 + i * w_scu);
+        for(int k = 0; k < unit; k++) left[i * unit + k] = ok ? src[(i * unit + k) * s_src - 1] : grey;
+    }
+    left[-1] = up[-1];
+#undef USABLE
+}
+
+/* xeve_ipred / xeve_ipred_uv (xeve_ipred.c:107-227): DC 0, horizontal 1, vertical 2, up-left diagonal 3, up-right average 4; dst dense w x h */
+void xo_ipred(const xo_pel *left, const xo_pel *up, xo_pel *dst, int ipm, int w, int h)
+{
+    if(ipm == 0) {
+        int dc = 0, sh = 0;
+        for(int i = 0; i < h; i++) dc += left[i];
+        for(int j = 0; j < w; j++) dc += up[j];
+        while((1 << sh) < w) sh++;     /* xeve_tbl_log2[w] */
+        dc = (dc + w) >> (sh + 1);     /* (the divisor is 2w whatever h is: the reference's expression, exact for square blocks) */
+        for(int i = 0; i < w * h; i++) dst[i] = (xo_pel)dc;
+        return;
+    }
+    for(int i = 0; i < h; i++)
+        for(int j = 0; j < w; j++) {
+            int v;
+            if(ipm == 1) v = left[i];
+            else if(ipm == 2) v = up[j];
+            else if(ipm == 3) v = i > j ? left[i - j - 1] : (i == j ? up[-1] : up[j - i - 1]);
+            else v = (up[i + j + 1] + left[i + j + 1]) >> 1;
+            dst[i * w + j] = (xo_pel)v;
+        }
+}
+
+/* xeve_get_mpm (xeve_ipred.c:229-252): the row of xeve_tbl_mpm the left and upper neighbours' luma modes select */
+const uint8_t *xo_get_mpm(int x_scu, int y_scu, const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, int w_scu)
+{
+    const int scup = y_scu * w_scu + x_scu;
+    int l = 0, u = 0;
+    if(x_scu > 0 && SCU_IF_(map_scu[scup - 1]) && SCU_COD_(map_scu[scup - 1]) && map_tidx[scup] == map_tidx[scup - 1]) l = map_ipm[scup - 1] + 1;
+    if(y_scu > 0 && SCU_IF_(map_scu[scup - w_scu]) && SCU_COD_(map_scu[scup - w_scu]) && map_tidx[scup] == map_tidx[scup - w_scu]) u = map_ipm[scup - w_scu] + 1;
+    return xo_tbl_mpm[l][u];
+}
+
+void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_pel *const mod[3], int s_mod_l, int s_mod_c, const uint32_t *map_scu,
+                          const int8_t *map_ipm, const uint8_t *map_tidx, const xo_sbac *states, const xo_intra_params *p, const xo_intra_job *job,
+                          xo_intra_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *best)
+{
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, bd = p->bit_depth;
+    const int lw[3] = {p->log2_cuw, p->log2_cuw - ws, p->log2_cuw - ws}, lh[3] = {p->log2_cuh, p->log2_cuh - hs, p->log2_cuh - hs};
+    const int cuw = 1 << lw[0], cuh = 1 << lh[0], n0 = cuw * cuh, n1 = idc ? 1 << (lw[1] + lh[1]) : 0;
+    const int x = job->x, y = job->y;
+    const xo_sbac *entry = &states[job->sbac];
+    int16_t *coef[3] = {coef_y, coef_u, coef_v};
+    xo_pel  *rec[3]  = {rec_y, rec_u, rec_v};
+    xo_pel   nb[3][2][2 * 64 + 2 * 64 + 8];
+#define LEFT(c) (nb[c][0] + 2)
+#define UP(c)   (nb[c][1] + 2)
+    /* neighbours (pintra_get_nbr, :390-461) and the mode ranks (pintra_get_mpm) */
+    xo_get_nbr(x, y, cuw, cuh, mod[0] + (size_t)y * s_mod_l + x, s_mod_l, map_scu, map_tidx, p->w_scu, p->h_scu, 0, p->constrained_intra_pred, bd, idc, LEFT(0), UP(0));
+    for(int c = 1; c < 3 && idc; c++)
+        xo_get_nbr(x >> ws, y >> hs, cuw >> ws, cuh >> hs, mod[c] + (size_t)(y >> hs) * s_mod_c + (x >> ws), s_mod_c, map_scu, map_tidx, p->w_scu, p->h_scu, c,
+                   p->constrained_intra_pred, bd, idc, LEFT(c), UP(c));
+    const uint8_t *mpm = xo_get_mpm(x >> 2, y >> 2, map_scu, map_ipm, map_tidx, p->w_scu);
+
+    xo_cu_bits_params bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.log2_cuw = lw[0], bp.log2_cuh = lh[0], bp.slice_type = p->slice_type, bp.cm_init = 0, bp.chroma_format_idc = idc;
+    xo_cu_bits_job bj;
+    memset(&bj, 0, sizeof(bj));
+    bj.ctx_skip = job->ctx_skip, bj.ctx_pred_mode = job->ctx_pred_mode, bj.coef_off[1] = n0, bj.coef_off[2] = n0 + n1;
+    int16_t *all = malloc(sizeof(int16_t) * (n0 + 2 * n1 + 1));
+    xo_pel  *pred_cache = malloc(sizeof(xo_pel) * 5 * n0), *pred_c = malloc(sizeof(xo_pel) * (n1 + 1)), *rec_t = malloc(sizeof(xo_pel) * n0);
+    int16_t *tmp = malloc(sizeof(int16_t) * n0), *coef_t = malloc(sizeof(int16_t) * n0);
+    const xo_pel *o[3] = {org[0] + (size_t)y * s_org_l + x, idc ? org[1] + (size_t)(y >> hs) * s_org_c + (x >> ws) : NULL,
+                          idc ? org[2] + (size_t)(y >> hs) * s_org_c + (x >> ws) : NULL};
+
+    /* make_ipred_list (:308-374): SATD + sqrt(lambda) * bits of the mode, an insertion-sorted list of the IPD_RDO_CNT (5; 4 for 1:4 shapes) cheapest, cut
+     * from the tail while the SATD alone exceeds 1.2 x the SATD of the best inter prediction */
+    const int rdo_cnt = iabs(lw[0] - lh[0]) >= 2 ? 4 : 5;
+    int       list[5];
+    double    cand_cost[5];
+    uint32_t  cand_satd[5];
+    for(int i = 0; i < rdo_cnt; i++) list[i] = 0, cand_cost[i] = 1.7e+308, cand_satd[i] = 0xFFFFFFFFu;
+    for(int m = 0; m < 5; m++) {
+        xo_sbac run;
+        xo_ipred(LEFT(0), UP(0), pred_cache + m * n0, m, cuw, cuh);
+        const uint32_t satd = (uint32_t)xo_satd(cuw, cuh, o[0], pred_cache + m * n0, s_org_l, cuw, bd);
+        bj.mode = XO_BITS_INTRA_DIR, bj.sbac = 0, bj.mvp_idx[0] = mpm[m];
+        const int bits = (int)xo_cu_bits(entry, &run, &bp, &bj, all);
+        const double cost = (double)satd + (double)bits * p->sqrt_lambda0;
+        int shift = 0;
+        while(shift < rdo_cnt && cost < cand_cost[rdo_cnt - 1 - shift]) shift++;
+        if(shift) {
+            for(int j = 1; j < shift; j++)
+                list[rdo_cnt - j] = list[rdo_cnt - 1 - j], cand_cost[rdo_cnt - j] = cand_cost[rdo_cnt - 1 - j], cand_satd[rdo_cnt - j] = cand_satd[rdo_cnt - 1 - j];
+            list[rdo_cnt - shift] = m, cand_cost[rdo_cnt - shift] = cost, cand_satd[rdo_cnt - shift] = satd;
+        }
+    }
+    int pred_cnt = rdo_cnt;
+    for(int i = rdo_cnt - 1; i >= 1; i--) {
+        if((double)cand_satd[i] > (double)job->inter_satd * (1.2)) pred_cnt--;
+        else break;
+    }
+
+    /* luma RDO of the list (:604-637; pintra_residue_rdo mode 0, :102-148): every candidate starts from the entry coder state */
+    xo_rdoq_est_full full;
+    xo_rdoq_est      e;
+    xo_rdoq_bit_est(entry, &full); /* core->rdoq_est_* of mode_coding_unit (xeve_mode.c:792) */
+    double  cost_best = 1.7e+308;
+    int     best_ipd = -1, nnz_best[3] = {0, 0, 0};
+    int32_t best_dist_y = 0, best_dist_c = 0;
+    xo_sbac run;
+    for(int j = 0; j < pred_cnt; j++) {
+        const int     m = list[j];
+        const xo_pel *pr = pred_cache + m * n0;
+        int           nnz = 0;
+        xo_diff(cuw, cuh, o[0], pr, s_org_l, cuw, cuw, coef_t);
+        xo_trans(coef_t, lw[0], lh[0], bd);
+        if(xo_rdoq_zero_test(coef_t, lw[0], lh[0], p->qp[0], xo_quant_scale[p->tool_iqt][p->qp[0] % 6], p->slice_type == 2, bd)) {
+            xo_rdoq_est_select(&full, 0, 1, &e);
+            nnz = xo_rdoq(coef_t, lw[0], lh[0], p->qp[0], p->lambda[0], 1, bd, p->tool_iqt, &e);
+        }
+        else memset(coef_t, 0, sizeof(int16_t) * n0);
+        memcpy(all, coef_t, sizeof(int16_t) * n0);
+        bj.mode = XO_BITS_INTRA_LUMA, bj.sbac = 0, bj.mvp_idx[0] = mpm[m], bj.nnz[0] = nnz, bj.nnz[1] = bj.nnz[2] = 0;
+        const int bits = (int)xo_cu_bits(entry, &run, &bp, &bj, all); /* `run` = core->s_temp_run: the chroma count below continues from the LAST candidate's */
+        memcpy(tmp, coef_t, sizeof(int16_t) * n0);
+        if(nnz) {
+            xo_dquant(tmp, lw[0], lh[0], xo_dq_scale[p->qp[0] % 6] << (p->qp[0] / 6), bd);
+            xo_itrans(tmp, lw[0], lh[0], bd);
+        }
+        xo_recon(tmp, pr, nnz, cuw, cuh, cuw, rec_t, bd);
+        double cost = 0;
+        cost += (double)xo_ssd(cuw, cuh, rec_t, o[0], cuw, s_org_l, bd);
+        const int32_t dist = (int32_t)cost;
+        cost += (double)bits * p->lambda[0];
+        if(cost < cost_best) {
+            cost_best = cost, best_dist_y = dist, best_ipd = m, nnz_best[0] = nnz;
+            memcpy(coef[0], coef_t, sizeof(int16_t) * n0), memcpy(rec[0], rec_t, sizeof(xo_pel) * n0);
+        }
+    }
+
+    /* chroma with the luma winner's mode (:639-658; pintra_residue_rdo mode 1, :150-269): bits counted after xeve_sbac_bit_reset on the coder state the
+     * last luma candidate left (no SBAC_LOAD there) */
+    if(idc) {
+        double cost = 0;
+        for(int c = 1; c < 3; c++) {
+            const int w = 1 << lw[c], h = 1 << lh[c];
+            int nnz = 0;
+            xo_ipred(LEFT(c), UP(c), pred_c, best_ipd, w, h);
+            xo_diff(w, h, o[c], pred_c, s_org_c, w, w, coef[c]);
+            xo_trans(coef[c], lw[c], lh[c], bd);
+            if(xo_rdoq_zero_test(coef[c], lw[c], lh[c], p->qp[c], xo_quant_scale[p->tool_iqt][p->qp[c] % 6], p->slice_type == 2, bd)) {
+                xo_rdoq_est_select(&full, c, 1, &e);
+                nnz = xo_rdoq(coef[c], lw[c], lh[c], p->qp[c], p->lambda[c], 0, bd, p->tool_iqt, &e);
+            }
+            else memset(coef[c], 0, sizeof(int16_t) * n1);
+            nnz_best[c] = nnz;
+            memcpy(tmp, coef[c], sizeof(int16_t) * n1);
+            if(nnz) {
+                xo_dquant(tmp, lw[c], lh[c], xo_dq_scale[p->qp[c] % 6] << (p->qp[c] / 6), bd);
+                xo_itrans(tmp, lw[c], lh[c], bd);
+            }
+            xo_recon(tmp, pred_c, nnz, w, h, w, rec[c], bd);
+        }
+        memcpy(all + n0, coef[1], sizeof(int16_t) * n1), memcpy(all + n0 + n1, coef[2], sizeof(int16_t) * n1);
+        bj.mode = XO_BITS_ECO_COEF, bj.dir_flag = XO_ECO_INTRA | XO_ECO_RUN_U | XO_ECO_RUN_V, bj.sbac = 0, bj.nnz[0] = 0, bj.nnz[1] = nnz_best[1], bj.nnz[2] = nnz_best[2];
+        xo_sbac after_luma = run;
+        (void)xo_cu_bits(&after_luma, &run, &bp, &bj, all); /* (its bits only enter the local cost the reference discards: cost_t is not used after, :643-646) */
+        cost += p->dist_chroma_weight[0] * (double)xo_ssd(1 << lw[1], 1 << lh[1], rec[1], o[1], 1 << lw[1], s_org_c, bd);
+        cost += p->dist_chroma_weight[1] * (double)xo_ssd(1 << lw[2], 1 << lh[2], rec[2], o[2], 1 << lw[2], s_org_c, bd);
+        best_dist_c = (int32_t)cost;
+    }
+
+    /* the CU's cost (:679-695): the whole syntax from the entry state */
+    memcpy(all, coef[0], sizeof(int16_t) * n0);
+    bj.mode = XO_BITS_CU_INTRA, bj.dir_flag = 0, bj.sbac = 0, bj.mvp_idx[0] = mpm[best_ipd], bj.nnz[0] = nnz_best[0], bj.nnz[1] = nnz_best[1], bj.nnz[2] = nnz_best[2];
+    const int bits = (int)xo_cu_bits(entry, best, &bp, &bj, all);
+    double cost = (double)bits * p->lambda[0];
+    cost += best_dist_y;
+    if(idc) cost += best_dist_c;
+    memset(res, 0, sizeof(*res));
+    res->cost = cost, res->dist_cu = best_dist_y + (idc ? best_dist_c : 0), res->ipm[0] = (int8_t)best_ipd, res->ipm[1] = (int8_t)(idc ? best_ipd : 0);
+    res->nnz[0] = nnz_best[0], res->nnz[1] = nnz_best[1], res->nnz[2] = nnz_best[2], res->pred_cnt = pred_cnt;
+    free(all), free(pred_cache), free(pred_c), free(rec_t), free(tmp), free(coef_t);
+#undef LEFT
+#undef UP
 }

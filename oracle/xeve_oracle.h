@@ -223,7 +223,10 @@ typedef struct xo_cu_bits_params {
     int32_t chroma_format_idc;   /* 0 = 4:0:0 ... 3 = 4:4:4; w/h shift as XEVE_GET_CHROMA_{W,H}_SHIFT     */
 } xo_cu_bits_params;
 enum { XO_BITS_CU_INTER = 0, XO_BITS_COMP_Y = 1, XO_BITS_COMP_U = 2, XO_BITS_COMP_V = 3, XO_BITS_CU_SKIP = 4, XO_BITS_ECO_COEF = 5,
-       XO_BITS_MVP = 6 /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list */ };
+       XO_BITS_MVP = 6 /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list */,
+       /* intra CU (Baseline): job.mvp_idx[0] holds the unary index mpm[ipm] of the luma mode (xeve_eco_intra_dir) */
+       XO_BITS_CU_INTRA = 7 /* xeve_rdo_bit_cnt_cu_intra (xeve_mode.c:141-175) */, XO_BITS_INTRA_LUMA = 8 /* ..._intra_luma (:81-117) */,
+       XO_BITS_INTRA_DIR = 9 /* xeve_rdo_bit_cnt_intra_dir (:136-139) */ };
 /* XO_BITS_ECO_COEF: xeve_eco_coef (cbf flags + coefficients) on its own; job.dir_flag then holds these flags */
 enum { XO_ECO_INTRA = 1, XO_ECO_NO_CBF = 2, XO_ECO_RUN_Y = 4, XO_ECO_RUN_U = 8, XO_ECO_RUN_V = 16, XO_ECO_NO_RESET = 32 /* continue the coder where the state stands */ };
 typedef struct xo_cu_bits_job {
@@ -388,6 +391,41 @@ void xo_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const
 /* check_best_mvp (xeve_pinter.c:1773-1837): returns the chosen index; mvd is recomputed against it */
 int xo_check_best_mvp(const xo_sbac *entry, int slice_type, const int8_t refi[2], int lidx, const int16_t mvp[4][2], const int16_t mv[2], int mvp_idx,
                       double lambda0, int16_t mvd[2]);
+
+/* ---- the intra analysis of one CU: pintra_analyze_cu (src_base/xeve_pintra.c:544-698) = ctx->fn_pintra_analyze_cu, Baseline ---- */
+extern const uint8_t xo_tbl_mpm[6][6][5];
+void xo_get_nbr(int x, int y, int cuw, int cuh, const xo_pel *src, int s_src, const uint32_t *map_scu, const uint8_t *map_tidx, int w_scu, int h_scu, int ch,
+                int constrained_intra_pred, int bit_depth, int chroma_format_idc, xo_pel *left, xo_pel *up);
+void xo_ipred(const xo_pel *left, const xo_pel *up, xo_pel *dst, int ipm, int w, int h);
+const uint8_t *xo_get_mpm(int x_scu, int y_scu, const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, int w_scu);
+typedef struct xo_intra_params {
+    int32_t log2_cuw, log2_cuh, w_scu, h_scu;   /* picture size in 4x4 units (ctx->w_scu, ctx->h_scu) */
+    int32_t slice_type, chroma_format_idc, bit_depth, tool_iqt;
+    int32_t constrained_intra_pred, qp[3];      /* pps.constrained_intra_pred_flag; core->qp_y / qp_u / qp_v */
+    double  lambda[3];                          /* core->lambda */
+    double  sqrt_lambda0;                       /* core->sqrt_lambda[0] */
+    double  dist_chroma_weight[2];
+} xo_intra_params;
+typedef struct xo_intra_job {
+    int32_t  x, y;
+    uint32_t inter_satd;   /* core->inter_satd: SATD of the best inter prediction, 0xFFFFFFFF when there is none (mode_check_intra, xeve_mode.c:1250-1262) */
+    int32_t  sbac;         /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] */
+    uint8_t  ctx_skip, ctx_pred_mode, pad_[2];
+} xo_intra_job;
+typedef struct xo_intra_result {
+    double  cost;          /* the return value */
+    int32_t dist_cu;       /* core->dist_cu */
+    int32_t nnz[3];        /* core->nnz */
+    int32_t pred_cnt;      /* candidates that went through the luma RDO (local of the reference function) */
+    int8_t  ipm[2];        /* core->ipm */
+    int8_t  pad_[2];
+} xo_intra_result;
+/* org: original planes; mod: the planes of the picture being reconstructed (pi->m = PIC_MODE(ctx)), whose samples left of and above the CU are the
+ * predictors' input; map_scu / map_ipm / map_tidx: ctx->map_scu, ctx->map_ipm, ctx->map_tidx.  coef_*: the `coef` argument; rec_*: pi->rec (dense);
+ * best: core->s_temp_best. */
+void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_pel *const mod[3], int s_mod_l, int s_mod_c, const uint32_t *map_scu,
+                          const int8_t *map_ipm, const uint8_t *map_tidx, const xo_sbac *states, const xo_intra_params *p, const xo_intra_job *job,
+                          xo_intra_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *best);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,24 @@ def test_eco_coef_alone(idc):
                 bb = R.refdrv_cu_bits(ptr(states), ptr(b), p, ptr(jobs[i:i + 1]), ptr(coef))
                 assert ba == bb, (lw, lh, i, jobs[i])
                 same(a, b)
+
+
+@pytest.mark.parametrize("slice_type,idc", [(2, 1), (0, 1), (1, 1), (2, 0), (0, 3)])
+def test_cu_bits_intra_syntax(slice_type, idc):
+    """job modes 7 / 8 / 9 = xeve_rdo_bit_cnt_cu_intra / _cu_intra_luma / _intra_dir (xeve_mode.c:81-175): skip flag and pred_mode outside I slices, the
+    prediction mode as the unary index mpm[ipm] over the two intra_dir models, intra cbf flags, coefficients"""
+    O, R = oracle_sbac(), ref_sbac()
+    r = np.random.default_rng(41 + slice_type + 10 * idc)
+    states = make_states(r, 8)
+    for lw in range(2, 7):
+        p = make_params(lw, lw, slice_type, (2, 2), 0, idc)
+        jobs, coef = make_jobs(r, 30, lw, lw, len(states), idc)
+        jobs["mode"] = r.integers(7, 10, size=len(jobs))
+        jobs["mvp_idx"][:, 0] = r.integers(0, 5, size=len(jobs))
+        jobs["nnz"][jobs["mode"] == 8, 1:] = 0  # luma alone: the chroma counts are cleared (xeve_sub_block_tq ran for Y only)
+        for i in range(len(jobs)):
+            a, b = np.zeros(1, SBAC_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ba = O.xo_cu_bits(ptr(states), ptr(a), p, ptr(jobs[i:i + 1]), ptr(coef))
+            bb = R.refdrv_cu_bits(ptr(states), ptr(b), p, ptr(jobs[i:i + 1]), ptr(coef))
+            assert ba == bb, (lw, i, jobs[i])
+            same(a, b)
