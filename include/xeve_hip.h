@@ -52,7 +52,7 @@ uint64_t    xeve_hip_table_calls(void);
 uint64_t    xeve_hip_table_calls_main(void);
 /* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
  * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
- * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result (0 .. 23); -1 past the end.  For bindings in
+ * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result (0 .. 26); -1 past the end.  For bindings in
  * other languages to check their record layouts at load time (no GPU needed). */
 int         xeve_hip_sizeof(int i);
 
@@ -404,7 +404,11 @@ typedef struct xeve_hip_cu_bits_params {
 } xeve_hip_cu_bits_params;
 enum { XEVE_HIP_BITS_CU_INTER = 0, XEVE_HIP_BITS_COMP_Y = 1, XEVE_HIP_BITS_COMP_U = 2, XEVE_HIP_BITS_COMP_V = 3, XEVE_HIP_BITS_CU_SKIP = 4,
        XEVE_HIP_BITS_ECO_COEF = 5, /* ctx->fn_eco_coef = xeve_eco_coef (xeve_eco.c:1067-1089) on its own: cbf flags + coefficients */
-       XEVE_HIP_BITS_MVP = 6 /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list -- what check_best_mvp prices */ };
+       XEVE_HIP_BITS_MVP = 6, /* xeve_rdo_bit_cnt_mvp (xeve_mode.c:57-79): mvp_idx + mvd of every used list -- what check_best_mvp prices */
+       /* intra CU, Baseline: job.mvp_idx[0] holds the unary index mpm[ipm] of the luma mode (xeve_eco_intra_dir, xeve_eco.c:1104-1121) */
+       XEVE_HIP_BITS_CU_INTRA = 7,   /* xeve_rdo_bit_cnt_cu_intra (xeve_mode.c:141-175): skip flag + pred_mode outside I slices, mode, Y / U / V */
+       XEVE_HIP_BITS_INTRA_LUMA = 8, /* xeve_rdo_bit_cnt_cu_intra_luma (:81-117): the same with luma alone                                   */
+       XEVE_HIP_BITS_INTRA_DIR = 9   /* xeve_rdo_bit_cnt_intra_dir (:136-139): the mode alone                                                */ };
 /* XEVE_HIP_BITS_ECO_COEF: job.dir_flag holds these flags.  NO_RESET continues the coder where the entry state stands instead of applying
  * xeve_sbac_bit_reset (needs sbac_out: only the kernel that carries the complete coder state can do it). */
 enum { XEVE_HIP_ECO_INTRA = 1, XEVE_HIP_ECO_NO_CBF = 2, XEVE_HIP_ECO_RUN_Y = 4, XEVE_HIP_ECO_RUN_U = 8, XEVE_HIP_ECO_RUN_V = 16, XEVE_HIP_ECO_NO_RESET = 32 };
@@ -656,6 +660,50 @@ int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_
 int xeve_hip_me_epzs_host(const xeve_hip_pel *org0, int s_org, const xeve_hip_pel *org_bi, const xeve_hip_pel *ref0, int s_ref, int pad, int pic_h,
                           const xeve_hip_epzs_job *job, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
                           const xeve_hip_epzs_params *params, xeve_hip_me_result *result);
+
+/* ------------------------------------------------------------------------------------------- */
+/* The intra analysis of a batch of CUs of one size: pintra_analyze_cu (src_base/xeve_pintra.c:544-698)  */
+/* = ctx->fn_pintra_analyze_cu.  Baseline profile, rdo_dbk_switch 0, no delta QP, square CUs 4..64.  */
+/* Neighbour samples from the picture being reconstructed + the 4x4-unit maps (xeve_get_nbr), the    */
+/* five predictors, the SATD + mode-bits candidate list cut against the best inter prediction's    */
+/* SATD (make_ipred_list), the luma RDO of the list, the chroma RDO of its winner                  */
+/* (pintra_residue_rdo), the CU's cost from the whole intra syntax.                                */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_intra_params {
+    int32_t log2_cuw, log2_cuh, w_scu, h_scu;   /* picture size in 4x4 units (ctx->w_scu, ctx->h_scu) */
+    int32_t slice_type, chroma_format_idc, bit_depth, tool_iqt;
+    int32_t constrained_intra_pred, qp[3];      /* pps.constrained_intra_pred_flag; core->qp_y / qp_u / qp_v */
+    double  lambda[3];                          /* core->lambda */
+    double  sqrt_lambda0;                       /* core->sqrt_lambda[0] */
+    double  dist_chroma_weight[2];
+} xeve_hip_intra_params;
+typedef struct xeve_hip_intra_job {
+    int32_t  x, y;
+    uint32_t inter_satd;   /* core->inter_satd: SATD of the best inter prediction, 0xFFFFFFFF without one (mode_check_intra, xeve_mode.c:1250-1262) */
+    int32_t  sbac;         /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] in `states` */
+    int32_t  pic;          /* picture of a multi-picture batch (0 with pic_elems == NULL) */
+    uint8_t  ctx_skip, ctx_pred_mode, pad_[2];
+} xeve_hip_intra_job;
+typedef struct xeve_hip_intra_result {
+    double  cost;          /* the return value */
+    int32_t dist_cu;       /* core->dist_cu */
+    int32_t nnz[3];        /* core->nnz */
+    int32_t pred_cnt;      /* candidates that went through the luma RDO */
+    int8_t  ipm[2];        /* core->ipm */
+    int8_t  pad_[2];
+} xeve_hip_intra_result;
+/* org / mod: HOST arrays of three device pointers at sample (0, 0): the original planes and the planes of the picture being
+ * reconstructed (pi->m = PIC_MODE(ctx)); map_scu / map_ipm / map_tidx: ctx->map_scu, ctx->map_ipm, ctx->map_tidx (device).
+ * pic_elems (HOST, or NULL for one picture): element distance between consecutive pictures of a batch that spans several --
+ * {org luma, org chroma, mod luma, mod chroma, maps}; job.pic selects the picture.  params: host.  states, jobs, results, coef, rec,
+ * best, workspace: device.  coef receives the `coef` argument: the Y blocks of all CUs ([njobs][h*w]), then U, then V; rec
+ * receives pi->rec in the same layout (dense blocks); best[j] = core->s_temp_best (may be NULL). */
+size_t xeve_hip_pintra_analyze_cu_workspace(int njobs, int nstates, const xeve_hip_intra_params *params);
+int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                    const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, const int64_t *pic_elems,
+                                    const xeve_hip_sbac *states, int nstates, const xeve_hip_intra_params *params, const xeve_hip_intra_job *jobs, int njobs,
+                                    xeve_hip_intra_result *results, int16_t *coef, xeve_hip_pel *rec, xeve_hip_sbac *best, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ static void from_ref(drv_sbac *d, const XEVE_SBAC *s)
 }
 
 typedef struct { int log2_cuw, log2_cuh, w_scu, h_scu, slice_type, chroma_format_idc, bit_depth, tool_iqt, constrained_intra_pred, qp[3]; double lambda[3], sqrt_lambda0, dist_chroma_weight[2]; } drv_intra_params;
-typedef struct { int x, y; u32 inter_satd; int sbac; u8 ctx_skip, ctx_pred_mode, pad_[2]; } drv_intra_job;
+typedef struct { int x, y; u32 inter_satd; int sbac, pic; u8 ctx_skip, ctx_pred_mode, pad_[2]; } drv_intra_job;
 typedef struct { double cost; int dist_cu, nnz[3], pred_cnt; s8 ipm[2], pad_[2]; } drv_intra_result;
 
 void refdrv_pintra_analyze_cu(pel *org_y, pel *org_u, pel *org_v, int s_org_l, int s_org_c, pel *mod_y, pel *mod_u, pel *mod_v, int s_mod_l, int s_mod_c,

@@ -410,6 +410,7 @@ typedef struct xo_intra_job {
     int32_t  x, y;
     uint32_t inter_satd;   /* core->inter_satd: SATD of the best inter prediction, 0xFFFFFFFF when there is none (mode_check_intra, xeve_mode.c:1250-1262) */
     int32_t  sbac;         /* index of core->s_curr_best[log2_cuw - 2][log2_cuh - 2] */
+    int32_t  pic;          /* which picture of a multi-picture batch the CU belongs to (the HIP batched form; not read here: the caller passes that picture) */
     uint8_t  ctx_skip, ctx_pred_mode, pad_[2];
 } xo_intra_job;
 typedef struct xo_intra_result {

@@ -19,9 +19,9 @@ class IntraParams(C.Structure):  # xo_intra_params / xeve_hip_intra_params
                 ("sqrt_lambda0", C.c_double), ("dist_chroma_weight", C.c_double * 2)]
 
 
-INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("inter_satd", "<u4"), ("sbac", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1", (2,))])
+INTRA_JOB_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("inter_satd", "<u4"), ("sbac", "<i4"), ("pic", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"), ("pad_", "u1", (2,))])
 INTRA_RESULT_DTYPE = np.dtype([("cost", "<f8"), ("dist_cu", "<i4"), ("nnz", "<i4", (3,)), ("pred_cnt", "<i4"), ("ipm", "i1", (2,)), ("pad_", "i1", (2,))])
-assert C.sizeof(IntraParams) == 96 and INTRA_JOB_DTYPE.itemsize == 20 and INTRA_RESULT_DTYPE.itemsize == 32
+assert C.sizeof(IntraParams) == 96 and INTRA_JOB_DTYPE.itemsize == 24 and INTRA_RESULT_DTYPE.itemsize == 32
 
 # seed, w, h, bit depth, chroma_format_idc, slice type (0 B, 1 P, 2 I), log2 CU size, constrained intra prediction, tiles
 CASES = [(1101, 128, 96, 10, 1, 2, 3, 0, 0), (1102, 128, 96, 10, 1, 2, 4, 0, 0), (1103, 128, 128, 10, 1, 2, 5, 0, 0), (1104, 128, 128, 10, 1, 2, 6, 0, 0),

@@ -172,3 +172,25 @@ def test_cu_bits_full_size_properties():
         assert np.all(bits[:, 0] <= bits[:, 1]), S
         njobs += bits.size
     assert njobs == 1376160
+
+
+@pytest.mark.parametrize("slice_type,idc", [(2, 1), (0, 1), (1, 0), (0, 3)])
+def test_hip_cu_bits_intra_syntax_vs_oracle(slice_type, idc):
+    """job modes 7 / 8 / 9: the intra CU syntax (skip flag + pred_mode outside I slices, the mode index over the two intra_dir models, intra cbf flags)"""
+    O = oracle_sbac()
+    r = np.random.default_rng(2300 + slice_type + 10 * idc)
+    states = make_states(r, 16)
+    for lw in range(2, 7):
+        p = make_params(lw, lw, slice_type, (2, 2), 0, idc)
+        jobs, coef = make_jobs(r, 90, lw, lw, len(states), idc)
+        jobs["mode"] = r.integers(7, 10, size=len(jobs))
+        jobs["mvp_idx"][:, 0] = r.integers(0, 5, size=len(jobs))
+        jobs["nnz"][jobs["mode"] == 8, 1:] = 0
+        exp_bits, exp = np.zeros(len(jobs), np.uint32), np.zeros(len(jobs), SBAC_DTYPE)
+        for i in range(len(jobs)):
+            exp_bits[i] = O.xo_cu_bits(ptr(states), ptr(exp[i:i + 1]), p, ptr(jobs[i:i + 1]), ptr(coef))
+        got_bits, got = run_hip(p, states, jobs, coef)
+        assert np.array_equal(got_bits, exp_bits), (lw, np.flatnonzero(got_bits != exp_bits)[:5])
+        assert got.tobytes() == exp.tobytes(), lw
+        fast_bits, _ = run_hip(p, states, jobs, coef, want_state=False)
+        assert np.array_equal(fast_bits, exp_bits), lw

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
             const int16_t *row = T + l32 * 32 + 16 * kg;
             const u32x4 r0 = *reinterpret_cast<const u32x4 *>(row), r1 = *reinterpret_cast<const u32x4 *>(row + 8);
             __builtin_amdgcn_wave_barrier();
-            pel *pr = rec + jb.off1 + (long)(32 * ot + l32) * s_rec + 32 * nt + 16 * kg;
+            pel *pr = (s_rec > 0 ? rec + jb.off1 + (long)(32 * ot + l32) * s_rec : rec + (long)j * (N * N) - (long)(32 * ot + l32) * s_rec) + 32 * nt + 16 * kg; // (s_rec < 0: dense blocks)
 #pragma unroll
             for(int hq = 0; hq < 2; hq++) {
                 const u32x4 rr = hq ? r1 : r0;

@@ -40,10 +40,11 @@ __device__ __forceinline__ unsigned ev_pack(int v, int run, int at_end)
 // which components of a job are coded (xeve_eco_coefficient: nnz_sub[c] && run[c]; cbf_all == 0 codes nothing)
 __device__ __forceinline__ unsigned coded_mask(const xeve_hip_cu_bits_job &j)
 {
-    if(j.mode == XEVE_HIP_BITS_CU_SKIP || j.mode == XEVE_HIP_BITS_MVP) return 0;
+    if(j.mode == XEVE_HIP_BITS_CU_SKIP || j.mode == XEVE_HIP_BITS_MVP || j.mode == XEVE_HIP_BITS_INTRA_DIR) return 0;
     unsigned m = (j.nnz[0] ? 1u : 0u) | (j.nnz[1] ? 2u : 0u) | (j.nnz[2] ? 4u : 0u);
     if(j.mode == XEVE_HIP_BITS_ECO_COEF) return m & ((j.dir_flag >> 2) & 7u);
-    if(j.mode != XEVE_HIP_BITS_CU_INTER) m &= 1u << (j.mode - 1);
+    if(j.mode == XEVE_HIP_BITS_INTRA_LUMA) return m & 1u;
+    if(j.mode != XEVE_HIP_BITS_CU_INTER && j.mode != XEVE_HIP_BITS_CU_INTRA) m &= 1u << (j.mode - 1);
     return m;
 }
 
@@ -236,13 +237,21 @@ template <bool FULL> __device__ __forceinline__ unsigned sb_encode(Sbac &s, unsi
 }
 
 // ---- header queue ----------------------------------------------------------------------------------------------------
-// entry: bit 0 bin, bit 1 bypass, bits 2..7 context index (the header only uses models 0..17)
+// entry: the byte of the bin strings -- (model << 1) | bin, bypass bins as model BYP (the dummy row of the model table)
 struct Queue {
     uint8_t *q; // &s_q[0][lane], stride 64
     int      n;
-    __device__ __forceinline__ void ctx(int ci, unsigned bin) { q[64 * n++] = (uint8_t)((ci << 2) | (bin & 1)); }
-    __device__ __forceinline__ void ep(unsigned bin) { q[64 * n++] = (uint8_t)(2 | (bin & 1)); }
+    __device__ __forceinline__ void ctx(int ci, unsigned bin) { q[64 * n++] = (uint8_t)((ci << 1) | (bin & 1)); }
+    __device__ __forceinline__ void ep(unsigned bin) { q[64 * n++] = (uint8_t)((BYP << 1) | (bin & 1)); }
 };
+__device__ __forceinline__ void q_intra_dir(Queue &Q, unsigned sym)
+{ // xeve_eco_intra_dir (xeve_eco.c:1104-1121): sbac_write_unary_sym(mpm[ipm], 2 models) (:474-490)
+    Q.ctx(XEVE_HIP_CTX_INTRA_DIR, sym != 0);
+    while(sym) {
+        sym--;
+        Q.ctx(XEVE_HIP_CTX_INTRA_DIR + 1, sym != 0);
+    }
+}
 
 __device__ __forceinline__ void q_mvd1(Queue &Q, int v)
 { // xeve_eco_abs_mvd + sign (xeve_eco.c:1205-1270)
@@ -314,6 +323,22 @@ __device__ __forceinline__ unsigned q_header(Queue &Q, const xeve_hip_cu_bits_jo
         }
         return cbf & run;
     }
+    if(J.mode == XEVE_HIP_BITS_INTRA_DIR) { // xeve_rdo_bit_cnt_intra_dir (xeve_mode.c:136-139)
+        q_intra_dir(Q, J.mvp_idx[0]);
+        return 0;
+    }
+    if(J.mode == XEVE_HIP_BITS_CU_INTRA || J.mode == XEVE_HIP_BITS_INTRA_LUMA) { // xeve_rdo_bit_cnt_cu_intra (xeve_mode.c:141-175) / _cu_intra_luma (:81-117), Baseline
+        if(st != 2) {
+            Q.ctx(XEVE_HIP_CTX_SKIP_FLAG + J.ctx_skip, 0);
+            Q.ctx(XEVE_HIP_CTX_PRED_MODE + J.ctx_pred_mode, 1); // xeve_eco_pred_mode(MODE_INTRA)
+        }
+        q_intra_dir(Q, J.mvp_idx[0]);
+        const unsigned runi = J.mode == XEVE_HIP_BITS_CU_INTRA ? 7u : 1u, cbfi = (J.nnz[0] ? 1u : 0u) | (J.nnz[1] ? 2u : 0u) | (J.nnz[2] ? 4u : 0u);
+        if((runi & 2) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CB, (cbfi >> 1) & 1); // xeve_eco_cbf, intra branch (xeve_eco.c:864-890)
+        if((runi & 4) && P.idc) Q.ctx(XEVE_HIP_CTX_CBF_CR, (cbfi >> 2) & 1);
+        Q.ctx(XEVE_HIP_CTX_CBF_LUMA, cbfi & 1);
+        return cbfi & runi;
+    }
     unsigned run = 7;
     if(J.mode == XEVE_HIP_BITS_CU_INTER) { // xeve_mode.c:201-274
         if(st != 2) {
@@ -366,8 +391,8 @@ typedef uint16_t (*CtxTab)[64];
 template <bool FULL> __device__ __forceinline__ void code_queue(Sbac &s, CtxTab s_ctx, const uint8_t (*s_q)[64], int lane, int n)
 {
     for(int i = 0; i < n; i++) {
-        const unsigned e = s_q[i][lane], ci = e >> 2;
-        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, (e & 2) != 0); // (bypass entries pass model 0 through)
+        const unsigned e = s_q[i][lane], ci = e >> 1;
+        const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, ci == BYP); // (bypass entries pass the dummy row through)
         s_ctx[ci][lane] = (uint16_t)m;
     }
 }
@@ -541,7 +566,7 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
             Sbac t = s;
             for(int i = 0; i < Q0.n; i++) {
                 const unsigned e = s_q[i][lane];
-                (void)sb_encode<false>(t, s_ctx[e >> 2][lane], e & 1, (e & 2) != 0); // (a single header bin: no model is used twice)
+                (void)sb_encode<false>(t, s_ctx[e >> 1][lane], e & 1, (e >> 1) == BYP); // (a single header bin: no model is used twice)
             }
             out[4 * j + 2] = t.shifts;
             T.nnz[2] = J.nnz[2];

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
             a = a < -32768 ? -32768 : (a > 32767 ? 32767 : a);
             int r = (int)(int16_t)((int)a + (int)pred[jb.off2 + y * s_pred + x]);
             r     = r < 0 ? 0 : (r > P.maxv ? P.maxv : r);
-            rec[jb.off1 + y * s_rec + x] = (pel)r;
+            rec[(s_rec > 0 ? (long)jb.off1 + (long)y * s_rec : (long)j * n - (long)y * s_rec) + x] = (pel)r; // (s_rec < 0: dense blocks, block j at j * n, pitch -s_rec)
             const int e = (int)org[jb.off1 + y * s_org + x] - r;
             s += (unsigned)((e * e) >> P.ssd_shift);
         }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
         ssd_r += (unsigned)((e * e) >> P.ssd_shift);
     }
     if(live) {
-        pel *pr = rec + jb.off1 + (long)y * s_rec;
+        pel *pr = s_rec > 0 ? rec + jb.off1 + (long)y * s_rec : rec + (long)j * (N * N) - (long)y * s_rec; // (s_rec < 0: dense blocks)
         if(N == 4) {
             u32x2 w2;
             w2[0] = xh_pack16(v[0], v[1]), w2[1] = xh_pack16(v[2], v[3]);
@@ -715,17 +715,25 @@ extern "C" int xeve_hip_residual_rdoq(const pel *org, int s_org, const pel *pred
 extern "C" int xeve_hip_rdoq_dev(int16_t *coef, int nblk, int log2w, int log2h, int qp, double lambda, int ch_type, int bit_depth, int tool_iqt,
                                  const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int zero_test, int is_intra_slice, int is_intra_cu,
                                  int32_t *nnz, void *stream);
+// the fused chain with the estimates picked per block on the device; is_intra_cu selects the cbf pair an intra CU's luma block is priced with (xeve_tq.c:565-583);
+// s_rec < 0: reconstruction stored as dense blocks (block j at j * n, pitch -s_rec) instead of in a plane laid out like the original
+int xh_residual_rdoq(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h, int bit_depth, int qp,
+                     int qscale, int dqscale, int is_intra_slice, int is_intra_cu, double lambda, int ch_type, int tool_iqt, const xeve_hip_rdoq_est_full *est,
+                     const int32_t *est_idx, int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st)
+{
+    int rc = residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 1, coef, rec,
+                             s_rec, nnz, ssd, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    rc = xeve_hip_rdoq_dev(coef, njobs, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, est, est_idx, 1, is_intra_slice, is_intra_cu, nnz, st);
+    if(rc != XEVE_HIP_OK) return rc;
+    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 2, coef, rec,
+                           s_rec, nnz, ssd, st);
+}
 extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,
                                           int log2h, int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda, int ch_type,
                                           int tool_iqt, const xeve_hip_rdoq_est_full *est, const int32_t *est_idx, int16_t *coef, pel *rec, int s_rec,
                                           int32_t *nnz, int64_t *ssd, void *stream)
 {
-    hipStream_t st = (hipStream_t)stream;
-    int rc = residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 1, coef, rec,
-                             s_rec, nnz, ssd, st);
-    if(rc != XEVE_HIP_OK) return rc;
-    rc = xeve_hip_rdoq_dev(coef, njobs, log2w, log2h, qp, lambda, ch_type, bit_depth, tool_iqt, est, est_idx, 1, is_intra_slice, 0, nnz, st);
-    if(rc != XEVE_HIP_OK) return rc;
-    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, 2, coef, rec,
-                           s_rec, nnz, ssd, st);
+    return xh_residual_rdoq(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, qscale, dqscale, is_intra_slice, 0, lambda, ch_type, tool_iqt, est,
+                            est_idx, coef, rec, s_rec, nnz, ssd, (hipStream_t)stream);
 }

@@ -295,6 +295,34 @@ def pinter_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, refp, s_l, s_c, states, p
     return (res, coef, ry, ru, rv, nb, py) if want_pred else (res, coef, ry, ru, rv, nb)
 
 
+def pintra_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, states, params, jobs, pic_elems=None, workspace=None):
+    """the intra analysis of a batch of CUs (xeve_hip_pintra_analyze_cu_jobs).  params: lib.IntraParams; jobs: uint8 tensor of lib.INTRA_JOB_DTYPE records; org_ptrs /
+    mod_ptrs: device addresses of sample (0, 0) of the three planes of the original and of the picture being reconstructed; pic_elems: five element distances between
+    the pictures of a multi-picture batch (org luma, org chroma, mod luma, mod chroma, maps) or None.  Returns (results uint8 [njobs, 32], coef int16 flat [Y | U | V
+    blocks], rec int16 flat in the same layout, best uint8 [njobs, 180])."""
+    L = _lib.load()
+    njobs, nstates, dev = jobs.numel() // 24, states.numel() // SBAC_BYTES, jobs.device
+    ws, hs = (1 if params.chroma_format_idc <= 2 else 0), (1 if params.chroma_format_idc <= 1 else 0)
+    n0 = 1 << (params.log2_cuw + params.log2_cuh)
+    n1 = (n0 >> (ws + hs)) if params.chroma_format_idc else 0
+    res = torch.empty((njobs, 32), dtype=torch.uint8, device=dev)
+    coef = torch.zeros(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
+    rec = torch.zeros(max(1, njobs * (n0 + 2 * n1)), dtype=torch.int16, device=dev)
+    best = torch.zeros((njobs, SBAC_BYTES), dtype=torch.uint8, device=dev)
+    need = L.xeve_hip_pintra_analyze_cu_workspace(njobs, nstates, C.byref(params))
+    if need == 0 and njobs:
+        raise _lib.XeveHipError("xeve_hip_pintra_analyze_cu_workspace: parameters outside the supported set")
+    if workspace is None:
+        workspace = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
+    org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
+    mod = (C.c_void_p * 3)(*[int(a) for a in mod_ptrs])
+    pe = (C.c_int64 * 5)(*[int(v) for v in pic_elems]) if pic_elems is not None else None
+    _lib.check(L.xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, _ptr(map_scu), _ptr(map_ipm), _ptr(map_tidx), pe, _ptr(states), nstates,
+                                                 C.byref(params), _ptr(jobs), njobs, _ptr(res), _ptr(coef), _ptr(rec), _ptr(best), _ptr(workspace), workspace.numel(),
+                                                 _stream()))
+    return res, coef, rec, best
+
+
 def inter_candidates(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, h_scu, log2_cuw, log2_cuh, slice_type, jobs):
     """fills jobs[].mvp / mv_col (uint8 tensor of lib.INTER_JOB_DTYPE records, in place) from the per-unit maps (xeve_hip_inter_candidates)"""
     _lib.check(_lib.load().xeve_hip_inter_candidates(_ptr(map_scu), _ptr(map_tidx) if map_tidx is not None else None, _ptr(map_mv), _ptr(col_mv0),

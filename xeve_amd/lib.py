@@ -50,6 +50,15 @@ class InterParams(C.Structure):  # xeve_hip_inter_params
                 ("poc", C.c_int32), ("col_list_poc0", C.c_int32), ("pad_", C.c_int32), ("skip_th", C.c_double)]
 
 
+class IntraParams(C.Structure):  # xeve_hip_intra_params
+    _fields_ = [("log2_cuw", C.c_int32), ("log2_cuh", C.c_int32), ("w_scu", C.c_int32), ("h_scu", C.c_int32), ("slice_type", C.c_int32),
+                ("chroma_format_idc", C.c_int32), ("bit_depth", C.c_int32), ("tool_iqt", C.c_int32), ("constrained_intra_pred", C.c_int32), ("qp", C.c_int32 * 3),
+                ("lambda_", C.c_double * 3), ("sqrt_lambda0", C.c_double), ("dist_chroma_weight", C.c_double * 2)]
+
+
+INTRA_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("inter_satd", "<u4"), ("sbac", "<i4"), ("pic", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"),
+                   ("pad_", "u1", (2,))]  # xeve_hip_intra_job (24 B)
+INTRA_RESULT_DTYPE = [("cost", "<f8"), ("dist_cu", "<i4"), ("nnz", "<i4", (3,)), ("pred_cnt", "<i4"), ("ipm", "i1", (2,)), ("pad_", "i1", (2,))]  # xeve_hip_intra_result (32 B)
 INTER_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (2, 4, 2)), ("mv_col", "<i2", (2,)), ("sbac", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"),
                    ("pad_", "u1", (2,))]  # xeve_hip_inter_job (52 B)
 INTER_RESULT_DTYPE = [("cost", "<f8"), ("cost_inter", "<f8", (5,)), ("cu_mode", "<i4"), ("best_idx", "<i4"), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2)),
@@ -162,6 +171,9 @@ FUNCTIONS = {
     "xeve_hip_pinter_analyze_cu_workspace": (C.c_size_t, [c_int, c_int, c_void_p, c_int, c_int]),
     "xeve_hip_pinter_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "xeve_hip_pintra_analyze_cu_workspace": (C.c_size_t, [c_int, c_int, c_void_p]),
+    "xeve_hip_pintra_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 5 +
+                                        [C.c_size_t, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
