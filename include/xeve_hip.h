@@ -705,6 +705,15 @@ int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3], int s_org_
                                     xeve_hip_intra_result *results, int16_t *coef, xeve_hip_pel *rec, xeve_hip_sbac *best, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* Host-memory form of ONE call of ctx->fn_pintra_analyze_cu: every pointer is HOST memory -- org / mod = sample (0, 0) of the original picture's planes and of
+ * the picture being reconstructed (pi->o / pi->m with their strides), the maps = ctx->map_scu / map_ipm / map_tidx, state = core->s_curr_best[..][..] (job->sbac
+ * and job->pic are ignored).  Moves the CU's block of the original, the line above and the column left of the CU (cuw + cuh samples each, clipped to the
+ * picture) and the map entries of their 4x4 units; returns what the reference's function leaves behind (rec_* = pi->rec, dense; best = core->s_temp_best). */
+int xeve_hip_pintra_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                    const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, const xeve_hip_sbac *state,
+                                    const xeve_hip_intra_params *params, const xeve_hip_intra_job *job, xeve_hip_intra_result *result, int16_t *coef_y, int16_t *coef_u,
+                                    int16_t *coef_v, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *best);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,6 +362,80 @@ static int shim_analyze_frame(XEVE_CTX *ctx)
     return orig_analyze_frame ? orig_analyze_frame(ctx) : XEVE_OK;
 }
 
+/* XEVE_HIP_SHIM_INTRA=1: ctx->fn_pintra_analyze_cu (the static pintra_analyze_cu, xeve_pintra.c:544-698) -> xeve_hip_pintra_analyze_cu_host: the neighbour
+ * samples from the mode picture, the five predictors, the SATD + mode-bits candidate list, the luma RDO of the list, the chroma RDO of its winner, the CU's cost and
+ * exit coder state.  The adapter hands over the planes, the 4x4-unit maps and the entry coder state as they stand and leaves behind what the reference's function
+ * leaves for mode_check_intra / copy_to_cu_data: coef, rec / s_rec (pi->rec), core->nnz / nnz_sub, core->ipm, core->dist_cu, core->s_temp_best, core->dqp_temp_best.
+ * Square CUs 4..64 of the Baseline quad-tree; anything else goes to the reference's function. */
+typedef struct { int log2_cuw, log2_cuh, w_scu, h_scu, slice_type, chroma_format_idc, bit_depth, tool_iqt, constrained_intra_pred, qp[3]; double lambda[3], sqrt_lambda0, dist_chroma_weight[2]; } hip_intra_params;
+typedef struct { int x, y; u32 inter_satd; int sbac, pic; u8 ctx_skip, ctx_pred_mode, pad_[2]; } hip_intra_job;
+typedef struct { double cost; int dist_cu, nnz[3], pred_cnt; s8 ipm[2], pad_[2]; } hip_intra_result;
+static int (*hip_intra_host)(const pel *const *, int, int, const pel *const *, int, int, const u32 *, const s8 *, const u8 *, const hip_sbac *, const hip_intra_params *,
+                             const hip_intra_job *, hip_intra_result *, s16 *, s16 *, s16 *, pel *, pel *, pel *, hip_sbac *);
+static double (*orig_pintra_analyze_cu)(XEVE_CTX *, XEVE_CORE *, int, int, int, int, XEVE_MODE *, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C], int s_rec[N_C]);
+static unsigned long long intra_calls, intra_fallbacks;
+
+static double shim_pintra_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int y, int log2_cuw, int log2_cuh, XEVE_MODE *mi, s16 coef[N_C][MAX_CU_DIM], pel *rec[N_C],
+                                     int s_rec[N_C])
+{
+    XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
+    const int idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
+    if(log2_cuw != log2_cuh || log2_cuw < 2 || log2_cuw > 6 || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || idc == 2 ||
+       core->tree_cons.tree_type != TREE_LC || core->tree_cons.mode_cons != eAll || ctx->fn_rdo_intra_ext || ctx->fn_rdo_intra_ext_c || ctx->sps.tool_admvp) {
+        intra_fallbacks++;
+        return orig_pintra_analyze_cu(ctx, core, x, y, log2_cuw, log2_cuh, mi, coef, rec, s_rec);
+    }
+    hip_intra_params P;
+    memset(&P, 0, sizeof(P));
+    P.log2_cuw = log2_cuw, P.log2_cuh = log2_cuh, P.w_scu = ctx->w_scu, P.h_scu = ctx->h_scu, P.slice_type = ctx->sh->slice_type, P.chroma_format_idc = idc;
+    P.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8, P.tool_iqt = ctx->param.tool_iqt, P.constrained_intra_pred = ctx->pps.constrained_intra_pred_flag;
+    P.qp[0] = core->qp_y, P.qp[1] = core->qp_u, P.qp[2] = core->qp_v;
+    for(int c = 0; c < 3; c++) P.lambda[c] = core->lambda[c];
+    P.sqrt_lambda0 = core->sqrt_lambda[0], P.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    hip_intra_job J;
+    memset(&J, 0, sizeof(J));
+    J.x = x, J.y = y, J.inter_satd = core->inter_satd, J.ctx_skip = core->ctx_flags[CNID_SKIP_FLAG], J.ctx_pred_mode = core->ctx_flags[CNID_PRED_MODE];
+    const XEVE_SBAC *sb = &core->s_curr_best[log2_cuw - 2][log2_cuh - 2];
+    hip_sbac h, nb;
+    h.range = sb->range, h.code = sb->code, h.code_bits = sb->code_bits, h.stacked_ff = sb->stacked_ff, h.stacked_zero = sb->stacked_zero;
+    h.pending_byte = sb->pending_byte, h.is_pending_byte = sb->is_pending_byte, h.bitcounter = sb->bitcounter, h.bin_counter = sb->bin_counter;
+#define F(name, at, n) memcpy(h.ctx + at, sb->ctx.name, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    hip_intra_result R;
+    static __thread s16 cf[N_C][MAX_CU_DIM];
+    const pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]}, *mod[3] = {pi->m[Y_C], pi->m[U_C], pi->m[V_C]};
+    if(hip_intra_host(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pi->s_m[Y_C], pi->s_m[U_C], ctx->map_scu, ctx->map_ipm, ctx->map_tidx, &h, &P, &J, &R, cf[Y_C], cf[U_C], cf[V_C],
+                      pi->rec[Y_C], pi->rec[U_C], pi->rec[V_C], &nb) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] intra analysis: %s\n", hip_err());
+        abort();
+    }
+    __atomic_fetch_add(&intra_calls, 1, __ATOMIC_RELAXED);
+    /* what pintra_analyze_cu leaves behind (:660-697) */
+    const int n0 = 1 << (log2_cuw + log2_cuh), n1 = n0 >> (ws + hs);
+    for(int c = 0; c < N_C; c++) {
+        if(c && !idc) continue;
+        memcpy(coef[c], cf[c], sizeof(s16) * (c ? n1 : n0));
+        rec[c] = pi->rec[c], s_rec[c] = c ? (1 << log2_cuw) >> ws : 1 << log2_cuw;
+        core->nnz[c] = R.nnz[c];
+        memset(core->nnz_sub[c], 0, sizeof(int) * MAX_SUB_TB_NUM);
+        core->nnz_sub[c][0] = R.nnz[c];
+    }
+    core->ipm[0] = R.ipm[0];
+    if(idc) core->ipm[1] = R.ipm[1];
+    core->dist_cu = R.dist_cu;
+    xeve_get_mpm(core->x_scu, core->y_scu, 1 << log2_cuw, 1 << log2_cuh, ctx->map_scu, ctx->map_ipm, core->scup, ctx->w_scu, &core->mpm_b_list, ctx->map_tidx); /* (pintra_get_mpm, :376-388) */
+    XEVE_SBAC *out = &core->s_temp_best;
+    *out = *sb; /* fields the analysis does not touch (is_bitcount, the context models of other syntax) */
+    out->range = nb.range, out->code = nb.code, out->code_bits = nb.code_bits, out->stacked_ff = nb.stacked_ff, out->stacked_zero = nb.stacked_zero;
+    out->pending_byte = nb.pending_byte, out->is_pending_byte = nb.is_pending_byte, out->bitcounter = nb.bitcounter, out->bin_counter = nb.bin_counter;
+#define F(name, at, n) memcpy(out->ctx.name, nb.ctx + at, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    core->dqp_temp_run = core->dqp_curr_best[log2_cuw - 2][log2_cuh - 2], core->dqp_temp_best = core->dqp_temp_run; /* (:681, :696) */
+    return R.cost;
+}
+
 static void report(void)
 {
     if(hip_resident_stats) {
@@ -370,6 +444,7 @@ static void report(void)
         fprintf(stderr, "[xeve_hip_shim] resident pictures: %llu pictures announced, %llu planes uploaded (%llu bytes), %llu plane look-ups served from HBM\n", pics, up, bytes, hits);
     }
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
+    if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
@@ -449,6 +524,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
             orig_analyze_frame = ctx->fn_mode_analyze_frame, ctx->fn_mode_analyze_frame = shim_analyze_frame;
             fprintf(stderr, "[xeve_hip_shim] pictures resident in HBM (one upload per plane and picture)\n");
         }
+    }
+    if(getenv("XEVE_HIP_SHIM_INTRA") && atoi(getenv("XEVE_HIP_SHIM_INTRA")) && ctx->fn_pintra_analyze_cu) {
+        hip_intra_host = dlsym(h, "xeve_hip_pintra_analyze_cu_host"), hip_err = err;
+        if(!hip_intra_host) { fprintf(stderr, "[xeve_hip_shim] intra-analysis entry point missing\n"); abort(); }
+        orig_pintra_analyze_cu = ctx->fn_pintra_analyze_cu, ctx->fn_pintra_analyze_cu = shim_pintra_analyze_cu;
+        fprintf(stderr, "[xeve_hip_shim] intra analysis of a CU routed to the GPU\n");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

@@ -24,6 +24,9 @@ CASES = {
     "moving_ra_b3_medium": (128, 64, 9, 5004, ["--preset", "medium", "-b", "3"]),  # hierarchical B pictures
     "jumpy_ldb_fast": (192, 128, 4, 6001, ["--preset", "fast", "-I", "0", "-b", "0"]),  # 23 x 17 samples of motion per frame
     "moving_cif_ra_medium": (352, 288, 5, 5006, ["--preset", "medium", "-b", "1"]),  # 5.5 x 4.5 CTUs: partial CTUs at the right and bottom edge
+    # all-intra on structured content (the predictors matter) and on noise, two frames each: every CU of every level 64 .. 4 goes through the intra analysis
+    "moving_cif_allintra_fast": (352, 288, 2, 5007, ["--preset", "fast", "-I", "1", "-b", "0"]),
+    "noise_allintra_medium": (128, 128, 2, 11, ["--preset", "medium", "-I", "1", "-b", "0"]),
 }
 
 # BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes (first frames only): goldens are made by tests/golden/make_e2e_golden.py from the reference app; the
@@ -83,7 +86,8 @@ def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500):
     return hashlib.md5(data).hexdigest(), len(data), p.stderr
 
 
-def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False, tables=True):
+def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False, tables=True,
+            intra=False):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -100,6 +104,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
             env["XEVE_HIP_SHIM_INTER"] = "1"  # the whole inter analysis of a CU (ctx->fn_pinter_analyze_cu)
             if resident:
                 env["XEVE_HIP_SHIM_RESIDENT"] = "1"  # planes uploaded once per picture (xeve_hip_picture_begin from ctx->fn_mode_analyze_frame)
+        if intra:
+            env["XEVE_HIP_SHIM_INTRA"] = "1"  # the intra analysis of a CU (ctx->fn_pintra_analyze_cu)
         if mc:
             env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:

@@ -249,3 +249,36 @@ def test_bitstream_identical_with_raster_search_and_integer_refinement_on_the_gp
     m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", got_inter[2])
     assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, got_inter[2]
     assert got_inter[:2] == ref[:2], "bitstream differs with the inter analysis (raster / integer refinement inside) on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["noise_allintra_medium", "moving_cif_allintra_fast", "tiny_ldb_fast", "moving_ra_medium"])
+def test_bitstream_identical_with_the_intra_analysis_on_the_gpu(tmp_path, name):
+    """ctx->fn_pintra_analyze_cu -> xeve_hip_pintra_analyze_cu_host: neighbours from the picture being reconstructed, the five predictors, the candidate list, the
+    luma / chroma RDO and the CU's cost + exit coder state of EVERY intra-analysed CU (all of them in the I pictures, the coded ones in P / B pictures) come
+    from the GPU; each result feeds the next CU's neighbours, so any deviation changes the stream."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, intra=True, tables=False)
+    assert "intra analysis of a CU routed to the GPU" in err
+    m = re.search(r"CUs whose intra analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    assert m and int(m.group(1)) > 300 and int(m.group(2)) == 0, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the intra analysis on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["moving_ra_medium", "tiny_ldb_fast_2threads", "moving_cif_ra_medium"])
+def test_bitstream_identical_with_inter_and_intra_analysis_on_the_gpu(tmp_path, name):
+    """both analyses of every CU on the GPU: what stays with the reference is the quad-tree recursion with its cost comparisons, the bitstream writer, the
+    loop filter's caller and rate control"""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, intra=True, resident=True, df=True, tables=False)
+    mi = re.search(r"CUs whose intra analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    me = re.search(r"CUs whose whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
+    assert mi and me and int(mi.group(1)) > 300 and int(me.group(1)) > 300 and int(mi.group(2)) == 0, err
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])

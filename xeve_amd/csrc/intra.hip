@@ -15,6 +15,8 @@
 // All candidates of a CU start from the same entry state, so the slots of step 4 are independent; the bit count of the chroma RDO (which the reference
 // runs on the state the last luma candidate left) never reaches an output -- cost_t of that call is discarded (:643-646) -- and is not computed.
 // Slots past the cut are computed and ignored (the list always holds five modes).
+#include <algorithm>
+#include <cstring>
 #include "xh_common.h"
 
 extern "C" int xeve_hip_satd_jobs(const pel *p1, int s1, const pel *p2, int s2, const xeve_hip_job *jobs, int njobs, const int32_t *cand_off, int ncand, int w, int h,
@@ -392,5 +394,123 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     if(rc != XEVE_HIP_OK) return rc;
     k_intra_finish<<<GJ, 256, 0, st>>>(P, bits, ipd, cnt, dist_y, nnz_y, nnz_c[0], nnz_c[1], ssd_c[0], ssd_c[1], results);
     XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+// ---- host-memory form of ONE call of ctx->fn_pintra_analyze_cu (the table layer's style: stage, launch, synchronise) ---------------------------------------------
+// Every pointer is HOST memory: org / mod = sample (0, 0) of the original picture's planes and of the picture being reconstructed (pi->o, pi->m), the maps =
+// ctx->map_scu / map_ipm / map_tidx.  Only what the analysis reads is moved: the CU's block of the original, the line above and the column left of the CU in the
+// mode picture (cuw + cuh samples each, clipped to the picture), the map entries of the 4x4 units those samples lie in.  They are laid out as a small local
+// picture (the CU at unit (1, 1), or on the edge where the real CU is on the picture's edge) so that the batched entry point runs unchanged on it.
+namespace {
+struct IntraHostCtx {
+    uint32_t    gen = 0;
+    hipStream_t st  = nullptr;
+    char       *dev = nullptr, *pin = nullptr;
+    size_t      dev_bytes = 0, pin_bytes = 0;
+    void release()
+    {
+        if(st) (void)hipStreamDestroy(st);
+        if(dev) (void)hipFree(dev);
+        if(pin) (void)hipHostFree(pin);
+        st = nullptr, dev = pin = nullptr, dev_bytes = pin_bytes = 0;
+    }
+    int ensure(size_t io_bytes, size_t ws_bytes)
+    {
+        if(gen != xh_generation()) release(), gen = xh_generation(); // the library was shut down or re-bound since
+        if(!st) XH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if(pin_bytes < io_bytes) {
+            if(pin) (void)hipHostFree(pin);
+            pin = nullptr, pin_bytes = 0;
+            XH_HIP(hipHostMalloc((void **)&pin, io_bytes + (io_bytes >> 1), hipHostMallocDefault));
+            pin_bytes = io_bytes + (io_bytes >> 1);
+        }
+        const size_t need = io_bytes + 256 + ws_bytes;
+        if(dev_bytes < need) {
+            if(dev) {
+                XH_HIP(hipStreamSynchronize(st));
+                (void)hipFree(dev);
+                dev = nullptr, dev_bytes = 0;
+            }
+            XH_HIP(hipMalloc((void **)&dev, need + (need >> 2)));
+            dev_bytes = need + (need >> 2);
+        }
+        return XEVE_HIP_OK;
+    }
+    ~IntraHostCtx() { release(); }
+};
+} // namespace
+
+extern "C" int xeve_hip_pintra_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                               const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, const xeve_hip_sbac *state,
+                                               const xeve_hip_intra_params *p, const xeve_hip_intra_job *job, xeve_hip_intra_result *result, int16_t *coef_y,
+                                               int16_t *coef_u, int16_t *coef_v, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *best)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && mod && map_scu && map_ipm && map_tidx && state && job && result && coef_y && rec_y && best && intra_params_ok(p));
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, lw = p->log2_cuw;
+    XH_REQUIRE(org[0] && mod[0] && (!idc || (org[1] && org[2] && mod[1] && mod[2] && coef_u && coef_v && rec_u && rec_v)));
+    const int cu = 1 << lw, n = cu >> 2, x_scu = job->x >> 2, y_scu = job->y >> 2, scup = y_scu * p->w_scu + x_scu;
+    XH_REQUIRE(job->x >= 0 && job->y >= 0 && (job->x & 3) == 0 && (job->y & 3) == 0 && x_scu + n <= p->w_scu && y_scu + n <= p->h_scu);
+    const int lx = x_scu > 0, ly = y_scu > 0, nw = std::min(2 * n, p->w_scu - x_scu), nh = std::min(2 * n, p->h_scu - y_scu), Wl = lx + nw, Hl = ly + nh;
+    const size_t n0 = (size_t)cu * cu, n1 = idc ? n0 >> (ws + hs) : 0, nmap = (size_t)Wl * Hl;
+    // staging layout (identical in the pinned buffer and in the device arena)
+    const int    pw[3] = {Wl * 4, Wl * (4 >> ws), Wl * (4 >> ws)}, ph[3] = {Hl * 4, Hl * (4 >> hs), Hl * (4 >> hs)};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 63) & ~(size_t)63; return at; };
+    const size_t o_job = take(sizeof(*job)), o_st = take(sizeof(*state)), o_scu = take(nmap * 4), o_ipm = take(nmap), o_tidx = take(nmap);
+    size_t o_org[3] = {0, 0, 0}, o_mod[3] = {0, 0, 0};
+    for(int c = 0; c < ncomp; c++) o_org[c] = take((size_t)pw[c] * ph[c] * 2), o_mod[c] = take((size_t)pw[c] * ph[c] * 2);
+    const size_t in_bytes = o;
+    const size_t o_res = take(sizeof(*result)), o_best = take(sizeof(*best)), o_coef = take((n0 + 2 * n1) * 2), o_rec = take((n0 + 2 * n1) * 2);
+    const size_t io_bytes = o;
+    xeve_hip_intra_params pl = *p;
+    pl.w_scu = Wl, pl.h_scu = Hl;
+    const size_t wsb = xeve_hip_pintra_analyze_cu_workspace(1, 1, &pl);
+    static thread_local IntraHostCtx C;
+    int rc = C.ensure(io_bytes, wsb);
+    if(rc != XEVE_HIP_OK) return rc;
+    char *H = C.pin, *D = C.dev;
+    // the job in local coordinates, the entry state, the maps
+    xeve_hip_intra_job jl = *job;
+    jl.x = 4 * lx, jl.y = 4 * ly, jl.sbac = 0, jl.pic = 0;
+    memcpy(H + o_job, &jl, sizeof(jl)), memcpy(H + o_st, state, sizeof(*state));
+    memset(H + o_scu, 0, o_org[0] - o_scu);
+    auto *ls = (uint32_t *)(H + o_scu);
+    auto *li = (int8_t *)(H + o_ipm);
+    auto *lt = (uint8_t *)(H + o_tidx);
+    auto unit = [&](int lu, int gu) { ls[lu] = map_scu[gu], li[lu] = map_ipm[gu], lt[lu] = map_tidx[gu]; };
+    unit(ly * Wl + lx, scup);
+    if(ly) for(int i = -lx; i < nw; i++) unit((ly - 1) * Wl + lx + i, scup - p->w_scu + i);
+    if(lx) for(int i = 0; i < nh; i++) unit((ly + i) * Wl + lx - 1, scup - 1 + i * p->w_scu);
+    // the planes: the original's block; the line above and the column to the left of the mode picture
+    for(int c = 0; c < ncomp; c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, uw = 4 >> sx, uh = 4 >> sy, bw = cu >> sx, bh = cu >> sy;
+        const int so = c ? s_org_c : s_org_l, sm = c ? s_mod_c : s_mod_l, x = job->x >> sx, y = job->y >> sy, xl = lx * uw, yl = ly * uh;
+        pel *lo = (pel *)(H + o_org[c]), *lm = (pel *)(H + o_mod[c]);
+        memset(lo, 0, (size_t)pw[c] * ph[c] * 2), memset(lm, 0, (size_t)pw[c] * ph[c] * 2);
+        for(int r = 0; r < bh; r++) memcpy(lo + (size_t)(yl + r) * pw[c] + xl, org[c] + (size_t)(y + r) * so + x, sizeof(pel) * bw);
+        if(ly) memcpy(lm + (size_t)(yl - 1) * pw[c], mod[c] + (size_t)(y - 1) * sm + (x - xl), sizeof(pel) * (size_t)(xl + nw * uw));
+        if(lx) for(int r = 0; r < nh * uh; r++) lm[(size_t)(yl + r) * pw[c] + xl - 1] = mod[c][(size_t)(y + r) * sm + x - 1];
+    }
+    XH_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, C.st));
+    const pel *d_org[3] = {(const pel *)(D + o_org[0]), idc ? (const pel *)(D + o_org[1]) : nullptr, idc ? (const pel *)(D + o_org[2]) : nullptr};
+    const pel *d_mod[3] = {(const pel *)(D + o_mod[0]), idc ? (const pel *)(D + o_mod[1]) : nullptr, idc ? (const pel *)(D + o_mod[2]) : nullptr};
+    char *d_ws = D + ((io_bytes + 255) & ~(size_t)255);
+    rc = xeve_hip_pintra_analyze_cu_jobs(d_org, pw[0], pw[1], d_mod, pw[0], pw[1], (const uint32_t *)(D + o_scu), (const int8_t *)(D + o_ipm), (const uint8_t *)(D + o_tidx),
+                                         nullptr, (const xeve_hip_sbac *)(D + o_st), 1, &pl, (const xeve_hip_intra_job *)(D + o_job), 1,
+                                         (xeve_hip_intra_result *)(D + o_res), (int16_t *)(D + o_coef), (pel *)(D + o_rec), (xeve_hip_sbac *)(D + o_best), d_ws,
+                                         C.dev_bytes - (size_t)(d_ws - D), C.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    XH_HIP(hipMemcpyAsync(H + o_res, D + o_res, io_bytes - o_res, hipMemcpyDeviceToHost, C.st));
+    XH_HIP(hipStreamSynchronize(C.st));
+    memcpy(result, H + o_res, sizeof(*result)), memcpy(best, H + o_best, sizeof(*best));
+    const int16_t *hc = (const int16_t *)(H + o_coef);
+    const pel     *hr = (const pel *)(H + o_rec);
+    memcpy(coef_y, hc, n0 * 2), memcpy(rec_y, hr, n0 * 2);
+    if(idc) {
+        memcpy(coef_u, hc + n0, n1 * 2), memcpy(coef_v, hc + n0 + n1, n1 * 2);
+        memcpy(rec_u, hr + n0, n1 * 2), memcpy(rec_v, hr + n0 + n1, n1 * 2);
+    }
     return XEVE_HIP_OK;
 }

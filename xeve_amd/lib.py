@@ -174,6 +174,7 @@ FUNCTIONS = {
     "xeve_hip_pintra_analyze_cu_workspace": (C.c_size_t, [c_int, c_int, c_void_p]),
     "xeve_hip_pintra_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 5 +
                                         [C.c_size_t, c_void_p]),
+    "xeve_hip_pintra_analyze_cu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 14),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
