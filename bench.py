@@ -20,7 +20,7 @@ The JSON line also carries
                  ceiling the counters say binds it, and the physical HBM / L2 / LDS figures of the PMC passes in profiles/;
   kernels      : per kernel class, HIP-event time per picture (search, sub-pel, CABAC bit counting, prediction, residual
                  chain, RDOQ) from an untimed pass with every class's timer on;
-  secondary    : the same step on SURVEY 8(d)'s structured input, at 1920x1080, and the round-1 synthetic-vector pass A..E;
+  secondary    : the same step on SURVEY 8(d)'s structured input, at 1920x1080, the round-1 synthetic-vector pass A..E, the intra analysis of every CU;
   cpu_baseline : the reference encoder itself (oracle/_ref/xeveb_app, compiled in place from the reference) on this box's
                  host cores, -m 8 and -m 1, on the first frames of the same kind of input -- rank 0, N = 1 only.
 """
@@ -304,6 +304,13 @@ def main():
         sec["synthetic_vector_pass_A_to_E"] = {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 2),
                                                "note": "xeve_amd/workload.py run(): fixed candidate pattern x %d lists x %d rounds, half-pel MC+SAD, merge MC+SSD, bi-pred MC, residual "
                                                        "chain with RDOQ, SATD -- kernels of the table layer, not of the inter analysis" % (N_LIST, N_PASS)}
+        # (4) the intra analysis (xeve_hip_pintra_analyze_cu_jobs) of every CU of every level 64 .. 4 of the same picture: neighbours from a reconstruction, all
+        # five predictors through the luma RDO (I picture: nothing to prune against)
+        ws.intra()
+        ms = time_steps(ws.intra, 10, sync)
+        sec["intra_analysis_structured_%dx%d" % (a.width, a.height)] = {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 2),
+                                                                        "cus": int(sum(v["n"] for v in ws._ilv.values())),
+                                                                        "note": "xeve_amd/workload.py intra(): pintra_analyze_cu of every CU of the levels 64, 32, 16, 8, 4"}
         del ws
         torch.cuda.empty_cache()
         for content in ("iid", "structured"):

@@ -177,3 +177,52 @@ def test_inter_phase_vs_oracle(content):
             assert res[j:j + 1].tobytes() == er.tobytes(), (S, j, res[j], er[0])
             modes.add(int(er["best_idx"][0]))
     assert len(modes) >= (2 if content == "structured" else 1), modes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("content", ["structured", "iid"])
+def test_intra_phase_vs_oracle(content):
+    """phase I (xeve_hip_pintra_analyze_cu_jobs on every CU of every level 64 .. 4, neighbours from reference picture 0) against the oracle on sampled CUs"""
+    import ctypes as C
+
+    import torch
+
+    import xeve_amd
+    from _intra_cases import INTRA_JOB_DTYPE, INTRA_RESULT_DTYPE, IntraParams, oracle_intra
+    from _libs import SBAC_DTYPE
+    from xeve_amd.workload import PAD_C, PAD_L, HotPathPass
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    wl = HotPathPass(256, 128, dev, seed=3, content=content)
+    out = wl.intra()
+    torch.cuda.synchronize()
+    O = oracle_intra()
+    org = [p.cpu().numpy() for p in wl.org]
+    mod = [p.cpu().numpy() for p in wl.ref[0]]
+    ol, oc = PAD_L * wl.s_l + PAD_L, PAD_C * wl.s_c + PAD_C
+    optr = (C.c_void_p * 3)(org[0].ctypes.data + 2 * ol, org[1].ctypes.data + 2 * oc, org[2].ctypes.data + 2 * oc)
+    mptr = (C.c_void_p * 3)(mod[0].ctypes.data + 2 * ol, mod[1].ctypes.data + 2 * oc, mod[2].ctypes.data + 2 * oc)
+    m = wl._intra_maps
+    scu, ipm, tidx = m["scu"].cpu().numpy().view(np.uint32), m["ipm"].cpu().numpy(), m["tidx"].cpu().numpy()
+    st = m["state"].cpu().numpy().view(SBAC_DTYPE)
+    r = np.random.default_rng(4)
+    modes = set()
+    for S in wl.INTRA_SIZES:
+        h = wl._ilv[S]
+        res, coef, rec, best = (t.cpu().numpy() for t in out[S])
+        res, best = res.reshape(-1).view(INTRA_RESULT_DTYPE), best.reshape(-1).view(SBAC_DTYPE)
+        jobs = h["jobs"].cpu().numpy().view(INTRA_JOB_DTYPE)
+        P = IntraParams.from_buffer_copy(bytes(h["params"]))
+        n, n0, n1 = len(jobs), S * S, S * S // 4
+        for i in [0, n - 1] + [int(v) for v in r.integers(0, n, size=6)]:
+            er, eb = np.zeros(1, INTRA_RESULT_DTYPE), np.zeros(1, SBAC_DTYPE)
+            ec, ek = [np.zeros(n0, np.int16), np.zeros(n1, np.int16), np.zeros(n1, np.int16)], [np.zeros(n0, np.int16), np.zeros(n1, np.int16), np.zeros(n1, np.int16)]
+            O.xo_pintra_analyze_cu(optr, wl.s_l, wl.s_c, mptr, wl.s_l, wl.s_c, ptr(scu), ptr(ipm), ptr(tidx), ptr(st), C.byref(P), ptr(jobs[i:i + 1]), ptr(er), ptr(ec[0]),
+                                   ptr(ec[1]), ptr(ec[2]), ptr(ek[0]), ptr(ek[1]), ptr(ek[2]), ptr(eb))
+            assert res[i:i + 1].tobytes() == er.tobytes(), (S, i, res[i], er[0])
+            assert best[i:i + 1].tobytes() == eb.tobytes(), (S, i)
+            for c, (base, nn) in enumerate(((i * n0, n0), (n * n0 + i * n1, n1), (n * (n0 + n1) + i * n1, n1))):
+                assert np.array_equal(coef[base:base + nn], ec[c]) and np.array_equal(rec[base:base + nn], ek[c]), (S, i, c)
+            modes.add(int(er["ipm"][0, 0]))
+    assert len(modes) >= 3

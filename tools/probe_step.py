@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One bench.py step under a profiler: HotPathPass.inter() (the whole inter analysis of every CU of every level of one picture), `reps` times after one
-warm-up call.  Usage: probe_step.py [reps] [--1080p] [--structured] [--serial] [--mfma]
+warm-up call.  Usage: probe_step.py [reps] [--1080p] [--structured] [--serial] [--mfma] [--intra]
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_step -o st -- python tools/probe_step.py 3
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python tools/probe_step.py 1
 --serial runs the four levels one after the other on one stream (per-kernel counters are cleaner without overlap);
@@ -31,6 +31,17 @@ if "--mfma" in sys.argv:
             D.residual_rdo(wl.org[0], wl.s_l, lv["pred_l"][0], S, lv["dense_jobs"], l2, l2, wl.bd, wl.qp, False, True, lv["coef"][0], lv["rec"][0], wl.s_l, lv["nnz"][0],
                            lv["ssd2"][0])
     torch.cuda.synchronize()
+    sys.exit(0)
+if "--intra" in sys.argv:  # phase I: the intra analysis of every CU of every level (64 .. 4)
+    wl.intra()
+    torch.cuda.synchronize()
+    for sizes in (None,) + tuple((S,) for S in wl.INTRA_SIZES):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.intra(sizes)
+        torch.cuda.synchronize()
+        print("%dx%d %s intra %s: %.2f ms per step (%d reps)" % (w, h, wl.content, "all levels" if sizes is None else "%dx%d" % (sizes[0], sizes[0]),
+                                                                  1e3 * (time.perf_counter() - t0) / reps, reps), flush=True)
     sys.exit(0)
 if "--serial" in sys.argv:
     one = torch.cuda.current_stream()

@@ -398,6 +398,63 @@ class HotPathPass:
             main.wait_stream(self._side[S])
         return out
 
+    # ------------------------------------------------------------------------------------------------------
+    # I. the intra analysis (xeve_hip_pintra_analyze_cu_jobs) of every CU of the levels 64 .. 8 and of every 4x4 CU: neighbours from a reconstruction of
+    # the picture (reference picture 0 of list 0 stands in for PIC_MODE), every 4x4 unit coded and intra with a random luma mode, no inter candidate to
+    # prune against (I picture: all five predictors go through the luma RDO -- the most work the analysis can be asked for).
+    INTRA_SIZES = (64, 32, 16, 8, 4)
+
+    def _intra_setup(self, S):
+        from . import lib
+        import ctypes as C
+        dev = self.dev
+        nx, ny = self.W // S, self.H // S
+        n = nx * ny
+        j = np.zeros(n, lib.INTRA_JOB_DTYPE)
+        idx = np.arange(n)
+        j["x"], j["y"] = (idx % nx) * S, (idx // nx) * S
+        j["inter_satd"] = 0xFFFFFFFF
+        P = lib.IntraParams()
+        P.log2_cuw = P.log2_cuh = S.bit_length() - 1
+        P.w_scu, P.h_scu, P.slice_type, P.chroma_format_idc, P.bit_depth, P.tool_iqt, P.constrained_intra_pred = self.W // 4, self.H // 4, 2, 1, self.bd, 0, 0
+        P.qp[0] = P.qp[1] = P.qp[2] = self.qp
+        P.lambda_[0] = P.lambda_[1] = P.lambda_[2] = self.lam
+        P.sqrt_lambda0 = float(np.sqrt(self.lam))
+        P.dist_chroma_weight[0] = P.dist_chroma_weight[1] = 1.0
+        if not hasattr(self, "_intra_maps"):
+            nu = (self.W // 4) * (self.H // 4)
+            rng = np.random.default_rng(29)
+            st = np.zeros(1, lib.SBAC_DTYPE)
+            st["range"], st["ctx"] = 16384, 512
+            self._intra_maps = dict(scu=torch.full((nu,), -(1 << 31) | (1 << 15), dtype=torch.int32, device=dev),  # MCU COD | IF
+                                    ipm=torch.from_numpy(rng.integers(0, 5, size=nu).astype(np.int8)).to(dev), tidx=torch.zeros(nu, dtype=torch.uint8, device=dev),
+                                    state=torch.from_numpy(st.view(np.uint8).copy()).to(dev))
+        at = lambda t, pad, s: t.data_ptr() + 2 * (pad * s + pad)
+        org = [at(self.org[0], PAD_L, self.s_l), at(self.org[1], PAD_C, self.s_c), at(self.org[2], PAD_C, self.s_c)]
+        mod = [at(self.ref[0][0], PAD_L, self.s_l), at(self.ref[0][1], PAD_C, self.s_c), at(self.ref[0][2], PAD_C, self.s_c)]
+        need = lib.load().xeve_hip_pintra_analyze_cu_workspace(n, 1, C.byref(P))
+        return dict(params=P, jobs=torch.from_numpy(j.view(np.uint8).copy()).to(dev), org=org, mod=mod, n=n, ws=torch.empty(int(need), dtype=torch.uint8, device=dev))
+
+    def intra(self, sizes=None):
+        """phase I: the intra analysis of every CU of every level, one stream per level; returns {S: (results uint8 [n, 32], coef, rec, best)}"""
+        out = {}
+        sizes = tuple(sizes or self.INTRA_SIZES)
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_iside"):
+            self._iside, self._ilv = {S: torch.cuda.Stream(device=self.dev) for S in self.INTRA_SIZES}, {}
+        for S in sizes:
+            if S not in self._ilv:
+                self._ilv[S] = self._intra_setup(S)
+            h, m = self._ilv[S], self._intra_maps
+            st = self._iside[S]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out[S] = D.pintra_analyze_cu_jobs(h["org"], self.s_l, self.s_c, h["mod"], self.s_l, self.s_c, m["scu"], m["ipm"], m["tidx"], m["state"], h["params"], h["jobs"],
+                                                  workspace=h["ws"])
+        for S in sizes:
+            main.wait_stream(self._iside[S])
+        return out
+
     def capture(self):
         """Record one pass into a HIP graph (all launches of run() go to torch's current stream, which is the capture
         stream here); replay() then re-issues the ~150 launches with one host call.  Matters for small pictures, where
