@@ -59,6 +59,7 @@ class HotPathPass:
         g = torch.Generator(device=device).manual_seed(seed)
         hl, hc = height + 2 * PAD_L, height // 2 + 2 * PAD_C
         self.content = content
+        self.level_threads = os.environ.get("XEVE_HIP_LEVEL_THREADS", "0") == "1"
         if content == "iid":
             # synthetic i.i.d. uniform picture planes: the original is an 8-bit source << (bit_depth - 8), as the encoder sees the BASELINE configs' random
             # 8-bit YUV (xeve_app converts on input); the reference pictures are reconstructions, any value of the internal depth
@@ -385,15 +386,36 @@ class HotPathPass:
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
             self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
-        for S in sorted(self.sizes, reverse=True):
+        for S in self.sizes:
+            if "inter" not in self.lv[S]:
+                self.lv[S]["inter"] = self._inter_setup(self.lv[S])
+
+        def level(S):
             lv = self.lv[S]
-            if "inter" not in lv:
-                lv["inter"] = self._inter_setup(lv)
             h, r = lv["inter"], lv["rdo"]
-            st = self._side[S]
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                out[S] = D.pinter_analyze_cu_jobs(r["org"], self.s_l, self.s_c, h["refp"], self.s_l, self.s_c, r["state"], h["params"], h["jobs"], workspace=h["ws"])[0]
+            with torch.cuda.stream(self._side[S]):
+                return D.pinter_analyze_cu_jobs(r["org"], self.s_l, self.s_c, h["refp"], self.s_l, self.s_c, r["state"], h["params"], h["jobs"], workspace=h["ws"])[0]
+        order = sorted(self.sizes, reverse=True)
+        for S in order:
+            self._side[S].wait_stream(main)
+        # XEVE_HIP_LEVEL_THREADS=1: one host thread per level (the library call releases the GIL), the four launch sequences issued side by side.  MEASURED
+        # (gpurun_out/r02c12, 4K i.i.d.): 46.4 ms against 45.6 ms from one thread -- the step is bound by the GPU (the bit counter), not by the host's issue
+        # order, although a kernel trace taken UNDER rocprofv3 suggests otherwise (the profiler's per-launch cost delays the later levels' first kernels by
+        # 17 ms); GPU_MAX_HW_QUEUES=8 (a hardware queue per level instead of three for four) makes it worse, 52.2 ms.  Off by default.
+        if self.level_threads and len(order) > 1 and not torch.cuda.is_current_stream_capturing():
+            if not hasattr(self, "_pool"):
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=len(order))
+            dev_idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+
+            def worker(S):
+                torch.cuda.set_device(dev_idx)
+                return level(S)
+            for S, f in [(S, self._pool.submit(worker, S)) for S in order]:
+                out[S] = f.result()
+        else:
+            for S in order:
+                out[S] = level(S)
         for S in self.sizes:
             main.wait_stream(self._side[S])
         return out
