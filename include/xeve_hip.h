@@ -123,9 +123,21 @@ extern const XEVE_HIP_MCM     xevem_tbl_bl_mc_l_hip[2][2];
  * (the reference forms 1 << (shift - 1) unguarded there); installed BY ADDRESS like xeve_func_txb (xevem_util.c:3948-3963) */
 extern const XEVE_HIP_TX      xeve_tbl_tx_hip[6];
 extern const XEVE_HIP_TX      xeve_tbl_itx_hip[6];
+/* reference: XEVE_INV_TRANS (src_main/xevem_type.h:47): (coef, block, shift, line, skip_line, skip_line_2) */
+typedef void (*XEVE_HIP_INV_TRANS)(int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
+/* replaces xeve_itrans_map_tbl{,_sse} (xevem_itdq.c:42-47): [0] DCT-VIII, [1] DST-VII; [.][log2 N - 1], N = 4 .. 32 ([.][0] and rows 2 .. 15 are NULL there too) */
+extern const XEVE_HIP_INV_TRANS xeve_itrans_map_tbl_hip[16][5];
+/* replace xevem_scaled_horizontal / _vertical_sobel_filter{,_sse} and xevem_equal_coeff_computer{,_sse} (xevem_mc.c:2341-2447): the kernels of the affine
+ * gradient search; 3 <= width, height <= 128; equal_coeff is accumulated into (the caller zeroes it); residue is read with derivate_buf_stride, as the reference does */
+void xevem_scaled_horizontal_sobel_filter_hip(xeve_hip_pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height);
+void xevem_scaled_vertical_sobel_filter_hip(xeve_hip_pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height);
+void xevem_equal_coeff_computer_hip(xeve_hip_pel *residue, int residue_stride, int **derivate, int derivate_buf_stride, int64_t (*equal_coeff)[7], int width,
+                                    int height, int vertex_num);
 /* Zero-edit installation into a loaded MAIN-profile reference library: everything xeve_hip_install_tables patches (the Main
  * library carries the same Baseline globals) plus xevem_func_dmvr_mc_l / _c, xevem_func_bl_mc_l (xevem_mc.c:39-41), xeve_func_tx
- * (xevem_tq.c:41) and xeve_func_itx (xevem_itdq.c:39).  Returns the number of pointers patched (8 + 5 [+ 1]) or a negative error. */
+ * (xevem_tq.c:41), xeve_func_itx (xevem_itdq.c:39), xeve_func_itrans (xevem_itdq.c:51) and xevem_func_aff_h_sobel_flt / _v_sobel_flt / _eq_coef_comp
+ * (xevem_mc.c:42-44) -- every entry of xevem_platform_init_func except xeve_func_intra_pred_ang.  Returns the number of pointers patched (8 + 9 [+ 1]) or a
+ * negative error. */
 int xeve_hip_install_tables_main(void *fn_itxb_slot);
 
 /* Zero-edit installation: overwrites the reference library's exported pointer globals

@@ -261,6 +261,76 @@ void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, 
     }
 }
 
+/* ---- Main profile: the other entries of xevem_platform_init_func's dispatch list (src_main/xevem_util.c:3917-3966) ---- */
+/* The ATS matrices xevem_tbl_tr[DCT8 | DST7][log2 N - 2] (xevem_tbl.c:421-565) in closed form -- every entry of all eight equals
+ *   round(64 * sqrt(N) * sqrt(4 / (2N + 1)) * { cos(pi (2k + 1)(2j + 1) / (4N + 2)) | sin(pi (2k + 1)(j + 1) / (2N + 1)) })      [k][j]
+ * (tests/test_main_oracle_vs_ref.py compares them with the library's table).  type 0 = DCT-VIII, 1 = DST-VII (xeve_def.h:557). */
+void xo_ats_matrix(int type, int log2n, int8_t *m)
+{
+    const int    n = 1 << log2n;
+    const double pi = 3.14159265358979323846, sc = 64.0 * sqrt((double)n) * sqrt(4.0 / (2 * n + 1));
+    for(int k = 0; k < n; k++)
+        for(int j = 0; j < n; j++) {
+            const double v = sc * (type ? sin(pi * (2 * k + 1) * (j + 1) / (2 * n + 1)) : cos(pi * (2 * k + 1) * (2 * j + 1) / (4 * n + 2)));
+            m[k * n + j] = (int8_t)(v >= 0 ? (int)floor(v + 0.5) : -(int)floor(-v + 0.5));
+        }
+}
+/* xeve_itrans_map_tbl[type][log2 N - 1] (xevem_itdq.c:42-47, the functions :63-276): 1-D inverse ATS of `line` columns,
+ *   block[i * N + j] = clip16((sum_{k < cut} coef[k * line + i] * M[k][j] + (1 << (shift - 1))) >> shift)   for i < line - skip_line, 0 for the other rows;
+ * cut = N - skip_line_2, except that the 4-point forms are written out over all four inputs (:63-90, :170-198: the factorised DST-VII / DCT-VIII, equal to the
+ * matrix product because the 4-point matrices satisfy a + b = d). */
+void xo_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2)
+{
+    const int n = 1 << log2n, cut = log2n == 2 ? 4 : n - skip_line_2, rnd = 1 << (shift - 1);
+    int8_t    m[32 * 32];
+    xo_ats_matrix(type, log2n, m);
+    for(int i = 0; i < line; i++)
+        for(int j = 0; j < n; j++) {
+            int sum = 0;
+            if(i < line - skip_line) {
+                for(int k = 0; k < cut; k++) sum += coef[k * line + i] * m[k * n + j];
+                sum = clip3i(-32768, 32767, (sum + rnd) >> shift);
+            }
+            block[i * n + j] = (int16_t)sum;
+        }
+}
+/* xevem_scaled_horizontal / _vertical_sobel_filter (xevem_mc.c:2341-2395): 3x3 Sobel gradient (weights 1 2 1, unnormalised) of the interior samples; the border
+ * row / column / corner take the value of the nearest interior sample -- both functions write the border that way, in different orders.  w, h >= 3. */
+void xo_sobel(int vertical, const xo_pel *pred, int s_pred, int32_t *der, int s_der, int w, int h)
+{
+    for(int y = 0; y < h; y++)
+        for(int x = 0; x < w; x++) {
+            const int cy = clip3i(1, h - 2, y), cx = clip3i(1, w - 2, x);
+            const xo_pel *c = pred + cy * s_pred + cx;
+            der[y * s_der + x] = vertical ? c[s_pred - 1] - c[-s_pred - 1] + 2 * c[s_pred] - 2 * c[-s_pred] + c[s_pred + 1] - c[-s_pred + 1]
+                                          : c[1 - s_pred] - c[-1 - s_pred] + 2 * c[1] - 2 * c[-1] + c[1 + s_pred] - c[-1 + s_pred];
+        }
+}
+/* xevem_equal_coeff_computer (xevem_mc.c:2397-2447): accumulates the normal equations of the affine gradient search into eq[1 .. 2v][0 .. 2v] (64-bit sums of
+ * products of the 32-bit terms iC[]; the right-hand side x 8).  The residual is read with the DERIVATIVE buffers' pitch (the reference indexes both with
+ * j * derivate_buf_stride + k; residue_stride is unused there). */
+void xo_equal_coeff(const xo_pel *residue, const int32_t *d0, const int32_t *d1, int s_der, int64_t (*eq)[7], int w, int h, int vertex_num)
+{
+    const int np = vertex_num << 1;
+    for(int j = 0; j < h; j++)
+        for(int k = 0; k < w; k++) {
+            const int i = j * s_der + k;
+            int32_t   c[6];
+            if(vertex_num == 2) {
+                c[0] = d0[i], c[1] = (int32_t)((uint32_t)k * (uint32_t)d0[i] + (uint32_t)j * (uint32_t)d1[i]);
+                c[2] = d1[i], c[3] = (int32_t)((uint32_t)j * (uint32_t)d0[i] - (uint32_t)k * (uint32_t)d1[i]);
+            }
+            else {
+                c[0] = d0[i], c[1] = (int32_t)((uint32_t)k * (uint32_t)d0[i]), c[2] = d1[i], c[3] = (int32_t)((uint32_t)k * (uint32_t)d1[i]);
+                c[4] = (int32_t)((uint32_t)j * (uint32_t)d0[i]), c[5] = (int32_t)((uint32_t)j * (uint32_t)d1[i]);
+            }
+            for(int col = 0; col < np; col++) {
+                for(int row = 0; row < np; row++) eq[col + 1][row] += (int64_t)c[col] * c[row];
+                eq[col + 1][np] += (int64_t)c[col] * residue[i] * 8;
+            }
+        }
+}
+
 /* a7 (reference: xeve_mc.c:449-463) */
 void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h)
 {

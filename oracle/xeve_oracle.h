@@ -60,6 +60,12 @@ extern const int16_t xom_mc_c_coeff[32][4]; /* xevem_tbl_mc_c_coeff, xevem_mc.c:
 void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, xo_pel *pred, int w, int h,
                 int bit_depth);
 
+/* the rest of the Main dispatch list: inverse ATS (xeve_func_itrans), the affine gradient search's Sobel filters and normal equations */
+void xo_ats_matrix(int type, int log2n, int8_t *m);
+void xo_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
+void xo_sobel(int vertical, const xo_pel *pred, int s_pred, int32_t *der, int s_der, int w, int h);
+void xo_equal_coeff(const xo_pel *residue, const int32_t *d0, const int32_t *d1, int s_der, int64_t (*eq)[7], int w, int h, int vertex_num);
+
 /* ---- transforms (reference: src_base/xeve_tq.c, xeve_itdq.c, xeve_tbl.c) -- */
 /* DCT-II integer matrix of size n x n (n = 2..64), xeve_tbl.c:83-236. */
 void xo_dct_matrix(int n, int8_t *m /* n*n, row-major [k][x] */);

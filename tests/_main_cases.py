@@ -51,6 +51,40 @@ def tx_cases():
                 yield False, log2n, line, 12 - (bd - 8), src  # ITX_SHIFT2
 
 
+def ats_cases():
+    """(type, log2n, line, shift, skip_line, skip_line_2, coef): both passes of xeve_it_MxN_ats_intra (xevem_itdq.c:278-300; shift 7, then 20 - bit depth), every (N, line) of
+    4 .. 32, DCT-VIII and DST-VII, without and with skipped lines / inputs, residual-range and full-range amplitudes"""
+    r = np.random.default_rng(278)
+    for typ in (0, 1):
+        for log2n in range(2, 6):
+            n = 1 << log2n
+            for line in (4, 8, 16, 32):
+                for shift in (7, 10):
+                    for (sl, s2) in ((0, 0), (line // 2, 0), (0, n // 2), (line // 4, n // 4)):
+                        amp = 32767 if (line + n + shift + sl) % 3 == 0 else 2000
+                        yield typ, log2n, line, shift, sl, s2, r.integers(-amp, amp + 1, size=n * line, dtype=np.int16)
+
+
+def sobel_cases():
+    """(vertical, w, h, pred, s_pred): the predictions the affine gradient search differentiates (xevem_pinter.c: CU sizes 8 .. 128), 10-bit samples"""
+    r = np.random.default_rng(2341)
+    for (w, h) in ((8, 8), (16, 8), (8, 16), (16, 16), (32, 16), (32, 32), (64, 32), (64, 64), (128, 64), (128, 128)):
+        s_pred = w + int(r.integers(0, 3)) * 4
+        pred = r.integers(0, 1024, size=(h, s_pred)).astype(np.int16)
+        for vertical in (0, 1):
+            yield vertical, w, h, pred, s_pred
+
+
+def eq_cases():
+    """(vertex_num, w, h, residue, d0, d1, eq0): the normal equations of the 4- and the 6-parameter model; the accumulators start non-zero (the function adds)"""
+    r = np.random.default_rng(2397)
+    for (w, h) in ((8, 8), (16, 16), (32, 16), (64, 64), (128, 128)):
+        for vn in (2, 3):
+            res = r.integers(-1023, 1024, size=(h, w)).astype(np.int16)
+            d0, d1 = (r.integers(-4092, 4093, size=(h, w)).astype(np.int32) for _ in range(2))
+            yield vn, w, h, res, d0, d1, r.integers(-1000, 1000, size=(7, 7)).astype(np.int64)
+
+
 def run_all(impl, mult=1):
     """mult: only blocks whose sides are multiples of it (the reference's SSE variants store whole groups of four samples / rows)"""
     out = []
@@ -65,6 +99,20 @@ def run_all(impl, mult=1):
         dst = np.zeros(src.size, np.int16)
         impl.tx(fwd, log2n, src.copy(), dst, shift, line)
         out.append(dst)
+    for typ, log2n, line, shift, sl, s2, coef in ats_cases():
+        if (line | (1 << log2n)) % mult or (mult > 1 and (sl or s2)):
+            continue
+        dst = np.full(coef.size, -9, np.int16)
+        impl.itrans_ats(typ, log2n, coef.copy(), dst, shift, line, sl, s2)
+        out.append(dst)
+    for vertical, w, h, pred, s_pred in sobel_cases():
+        der = np.full((h, w), -5, np.int32)
+        impl.sobel(vertical, pred.copy(), s_pred, der, w, w, h)
+        out.append(der.ravel().view(np.int16))
+    for vn, w, h, res, d0, d1, eq0 in eq_cases():
+        eq = eq0.copy() if mult == 1 else np.zeros_like(eq0)  # (the reference's SSE variant stores its sums: it needs the zeroed accumulators its caller hands it)
+        impl.eq_coef(res.copy(), w, d0.copy(), d1.copy(), w, eq, w, h, vn)
+        out.append(eq.ravel().view(np.int16))
     return out
 
 
@@ -80,6 +128,26 @@ class OracleMain:
     def tx(self, fwd, log2n, src, dst, shift, line):
         (self.O.xo_tx if fwd else self.O.xo_itx)(log2n, ptr(src), ptr(dst), shift, line, 2)
 
+    def itrans_ats(self, typ, log2n, coef, dst, shift, line, sl, s2):
+        self.O.xo_itrans_ats.restype = None
+        self.O.xo_itrans_ats.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int]
+        self.O.xo_itrans_ats(typ, log2n, ptr(coef), ptr(dst), shift, line, sl, s2)
+
+    def sobel(self, vertical, pred, s_pred, der, s_der, w, h):
+        self.O.xo_sobel.restype = None
+        self.O.xo_sobel.argtypes = [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int]
+        self.O.xo_sobel(vertical, ptr(pred), s_pred, ptr(der), s_der, w, h)
+
+    def eq_coef(self, res, s_res, d0, d1, s_der, eq, w, h, vn):
+        self.O.xo_equal_coeff.restype = None
+        self.O.xo_equal_coeff.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int]
+        self.O.xo_equal_coeff(ptr(res), ptr(d0), ptr(d1), s_der, ptr(eq), w, h, vn)
+
+
+FN_ITR = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INV_TRANS (xevem_type.h:47)
+FN_SOBEL = C.CFUNCTYPE(None, c_void_p, c_int, c_void_p, c_int, c_int, c_int)  # XEVE_AFFINE_H / V_SOBEL_FLT (xevem_mc.h:157-168)
+FN_EQ = C.CFUNCTYPE(None, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int)  # XEVE_AFFINE_EQUAL_COEF (xevem_mc.h:169-176)
+
 
 class TableMain:
     """any library exporting the five tables under `names` (the reference's C or SIMD variants, or libxeve_hip.so's *_hip tables)"""
@@ -89,6 +157,9 @@ class TableMain:
         self.t = [(FN_MCM * 4).in_dll(L, names[k]) for k in range(3)]
         self.f = (FN_TX * 6).in_dll(L, names[3])
         self.i = (FN_TX * 6).in_dll(L, names[4])
+        self.itr = (FN_ITR * 80).in_dll(L, names[5])  # [16][5], rows 0 (DCT-VIII) and 1 (DST-VII) populated
+        self.sob = [FN_SOBEL((names[6], L)), FN_SOBEL((names[7], L))]
+        self.eq = FN_EQ((names[8], L))
 
     def mc(self, kind, fx, fy, plane, org, gx, gy, s_ref, sp, pred, w, h, bd):
         self.t[kind][int(fx) * 2 + int(fy)](ptr(plane, org), gx, gy, s_ref, sp, ptr(pred), w, h, bd)
@@ -96,12 +167,25 @@ class TableMain:
     def tx(self, fwd, log2n, src, dst, shift, line):
         (self.f if fwd else self.i)[log2n - 1](ptr(src), ptr(dst), shift, line)
 
+    def itrans_ats(self, typ, log2n, coef, dst, shift, line, sl, s2):
+        self.itr[typ * 5 + log2n - 1](ptr(coef), ptr(dst), shift, line, sl, s2)
+
+    def sobel(self, vertical, pred, s_pred, der, s_der, w, h):
+        self.sob[vertical](ptr(pred), s_pred, ptr(der), s_der, w, h)
+
+    def eq_coef(self, res, s_res, d0, d1, s_der, eq, w, h, vn):
+        dd = (c_void_p * 2)(d0.ctypes.data, d1.ctypes.data)  # int **derivate
+        self.eq(ptr(res), s_res, dd, s_der, ptr(eq), w, h, vn)
+
 
 REF_NAMES = {
-    "c": ("xevem_tbl_dmvr_mc_l", "xevem_tbl_dmvr_mc_c", "xevem_tbl_bl_mc_l", "xeve_tbl_tx", "xeve_tbl_itx"),
-    "sse": ("xeve_tbl_dmvr_mc_l_sse", "xeve_tbl_dmvr_mc_c_sse", "xeve_tbl_bl_mc_l_sse", "xeve_tbl_tx", "xeve_tbl_itx"),
+    "c": ("xevem_tbl_dmvr_mc_l", "xevem_tbl_dmvr_mc_c", "xevem_tbl_bl_mc_l", "xeve_tbl_tx", "xeve_tbl_itx", "xeve_itrans_map_tbl",
+          "xevem_scaled_horizontal_sobel_filter", "xevem_scaled_vertical_sobel_filter", "xevem_equal_coeff_computer"),
+    "sse": ("xeve_tbl_dmvr_mc_l_sse", "xeve_tbl_dmvr_mc_c_sse", "xeve_tbl_bl_mc_l_sse", "xeve_tbl_tx", "xeve_tbl_itx", "xeve_itrans_map_tbl_sse",
+            "xevem_scaled_horizontal_sobel_filter_sse", "xevem_scaled_vertical_sobel_filter_sse", "xevem_equal_coeff_computer_sse"),
 }
-HIP_NAMES = ("xevem_tbl_dmvr_mc_l_hip", "xevem_tbl_dmvr_mc_c_hip", "xevem_tbl_bl_mc_l_hip", "xeve_tbl_tx_hip", "xeve_tbl_itx_hip")
+HIP_NAMES = ("xevem_tbl_dmvr_mc_l_hip", "xevem_tbl_dmvr_mc_c_hip", "xevem_tbl_bl_mc_l_hip", "xeve_tbl_tx_hip", "xeve_tbl_itx_hip", "xeve_itrans_map_tbl_hip",
+             "xevem_scaled_horizontal_sobel_filter_hip", "xevem_scaled_vertical_sobel_filter_hip", "xevem_equal_coeff_computer_hip")
 _refm = None
 
 
@@ -119,6 +203,13 @@ def input_checksum():
         c = zlib.crc32(case[6].tobytes(), zlib.crc32(np.array(case[:6] + case[7:], np.int64).tobytes(), c))
     for case in tx_cases():
         c = zlib.crc32(case[4].tobytes(), zlib.crc32(np.array(case[:4], np.int64).tobytes(), c))
+    for case in ats_cases():
+        c = zlib.crc32(case[6].tobytes(), zlib.crc32(np.array(case[:6], np.int64).tobytes(), c))
+    for case in sobel_cases():
+        c = zlib.crc32(case[3].tobytes(), zlib.crc32(np.array(case[:3] + case[4:], np.int64).tobytes(), c))
+    for case in eq_cases():
+        for a in case[3:]:
+            c = zlib.crc32(a.tobytes(), c)
     return c
 
 

@@ -23,6 +23,20 @@ def test_main_coefficient_tables():
         assert bytes((C.c_int8 * (n * n)).in_dll(L, "xeve_tbl_tm%d" % n)) == m.tobytes()
 
 
+def test_ats_matrices_closed_form():
+    """all eight matrices of xevem_tbl_tr[DCT8 | DST7][4 .. 32] from the oracle's closed form == the library's table (xevem_tbl.c:421-565)"""
+    L, O = ref_main_lib(), oracle()
+    T = np.frombuffer((C.c_int8 * (2 * 4 * 1024)).in_dll(L, "xevem_tbl_tr"), np.int8).reshape(2, 4, 1024)
+    O.xo_ats_matrix.restype = None
+    O.xo_ats_matrix.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    for typ in (0, 1):
+        for log2n in range(2, 6):
+            n = 1 << log2n
+            m = np.zeros(n * n, np.int8)
+            O.xo_ats_matrix(typ, log2n, m.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(m, T[typ, log2n - 2, :n * n]), (typ, n)
+
+
 @pytest.mark.parametrize("variant", ["c", "sse"])
 def test_main_tables(variant):
     m = 4 if variant == "sse" else 1

@@ -5,7 +5,7 @@ set -x
 export TMPDIR=/tmp
 O=gpurun_out/r02c8
 mkdir -p $O
-timeout 900 python -m pytest tests/test_main_profile.py tests/test_hip_tables.py tests/test_abi_symbols.py -x -q -m gpu --durations=8 > $O/pytest_main.log 2>&1
+timeout 900 python -m pytest tests/test_main_profile.py tests/test_abi_symbols.py -x -q -m gpu --durations=8 > $O/pytest_main.log 2>&1
 tail -15 $O/pytest_main.log
 for spec in ; do
   XEVE_HIP_RDO_SPEC=$spec python tools/probe_step.py 5 2>&1 | tail -1

@@ -21,7 +21,8 @@ reps = int(args[0]) if args else 3
 w, h = (1920, 1080) if "--1080p" in sys.argv else (3840, 2160)
 xeve_amd.init(0)
 dev = torch.device("cuda:0")
-wl = HotPathPass(w, h, dev, seed=4, content="structured" if "--structured" in sys.argv else "iid")
+sizes = tuple(int(v) for v in [x for x in sys.argv if x.startswith("--sizes=")][0].split("=")[1].split(",")) if any(x.startswith("--sizes=") for x in sys.argv) else (8, 16, 32, 64)
+wl = HotPathPass(w, h, dev, seed=4, content="structured" if "--structured" in sys.argv else "iid", sizes=sizes)  # --sizes=64,32: only those CU levels
 if "--mfma" in sys.argv:
     wl.run(only="D1")  # predictions
     for _ in range(reps + 1):
@@ -46,10 +47,15 @@ if "--intra" in sys.argv:  # phase I: the intra analysis of every CU of every le
 if "--serial" in sys.argv:
     one = torch.cuda.current_stream()
     wl._side = {S: one for S in wl.sizes}
-wl.inter()
+npic = int([x for x in sys.argv if x.startswith("--pictures=")][0].split("=")[1]) if any(x.startswith("--pictures=") for x in sys.argv) else 1
+wls = [wl] + [HotPathPass(w, h, dev, seed=4 + k, content=wl.content) for k in range(1, npic)]  # --pictures=N: N independent pictures in flight, each on its own streams
+for p in wls:
+    p.inter()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    wl.inter()
+    for p in wls:
+        p.inter()
 torch.cuda.synchronize()
-print("%dx%d %s: %.2f ms per step (%d reps)" % (w, h, wl.content, 1e3 * (time.perf_counter() - t0) / reps, reps), flush=True)
+dt = (time.perf_counter() - t0) / reps
+print("%dx%d %s: %.2f ms per step (%d reps)%s" % (w, h, wl.content, 1e3 * dt, reps, "" if npic == 1 else ", %d pictures per step = %.2f pictures/s" % (npic, npic / dt)), flush=True)

@@ -21,6 +21,10 @@
 #include "xh_common.h"
 
 int xh_tq_init();
+int xh_main_tools_init(); // main_tools.hip: the ATS matrices
+int xh_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2, hipStream_t st);
+int xh_sobel(int vertical, const pel *pred, int s_pred, int32_t *der, int s_der, int w, int h, hipStream_t st);
+int xh_equal_coeff(const pel *residue, const int32_t *d0, const int32_t *d1, int s_der, long *eq, int w, int h, int vertex_num, hipStream_t st);
 int xh_tx1d(bool fwd, const void *src, void *dst, int log2n, int shift, int line, int step, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
@@ -99,6 +103,8 @@ extern "C" int xeve_hip_init(int device_ordinal)
     int rc = xh_tq_init();
     if(rc != XEVE_HIP_OK) return rc;
     g_device.store(device_ordinal); // (the table builders below go through entry-point checks that want a bound device)
+    rc = xh_main_tools_init();
+    if(rc != XEVE_HIP_OK) return rc;
     rc = xh_rdoq_tables_init();
     if(rc != XEVE_HIP_OK) {
         g_device.store(-1);
@@ -492,6 +498,70 @@ extern "C" {
 const XEVE_HIP_TX xeve_tbl_tx_hip[6]  = {tbl_txm<true, 1>, tbl_txm<true, 2>, tbl_txm<true, 3>, tbl_txm<true, 4>, tbl_txm<true, 5>, tbl_txm<true, 6>};
 const XEVE_HIP_TX xeve_tbl_itx_hip[6] = {tbl_txm<false, 1>, tbl_txm<false, 2>, tbl_txm<false, 3>, tbl_txm<false, 4>, tbl_txm<false, 5>, tbl_txm<false, 6>};
 }
+// inverse ATS passes (xeve_func_itrans[type][log2 N - 1], xevem_itdq.c:42-47): DCT-VIII (row 0) and DST-VII (row 1) of 4 .. 32 points
+template <int TYPE, int LOG2N> static void tbl_itrans_ats(int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2)
+{
+    Stage &S = stage();
+    g_table_calls++, g_table_calls_main++;
+    const size_t bytes = sizeof(int16_t) * (size_t)(1 << LOG2N) * line;
+    if(bytes > (64 << 10)) {
+        xh_set_error("inverse ATS table call N=%d line=%d exceeds the staging tile", 1 << LOG2N, line);
+        die(__func__);
+    }
+    memcpy(S.h<char>(REG_A), coef, bytes);
+    TBL_RC(xh_itrans_ats(TYPE, LOG2N, S.d<int16_t>(REG_A), S.d<int16_t>(REG_OUT), shift, line, skip_line, skip_line_2, S.st));
+    S.sync();
+    memcpy(block, S.h<char>(REG_OUT), bytes);
+}
+// Sobel derivatives of an affine prediction (xevem_func_aff_h / v_sobel_flt, xevem_mc.c:2341-2395)
+template <int VERTICAL> static void tbl_sobel(pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height)
+{
+    Stage &S = stage();
+    g_table_calls++, g_table_calls_main++;
+    if(width > 128 || height > 128 || width < 3 || height < 3) {
+        xh_set_error("sobel table call %dx%d outside 3 .. 128", width, height);
+        die(__func__);
+    }
+    gather(S.h<int16_t>(REG_A), width, pred, pred_stride, width, height);
+    TBL_RC(xh_sobel(VERTICAL, S.d<pel>(REG_A), width, S.d<int32_t>(REG_OUT), width, width, height, S.st));
+    S.sync();
+    const int32_t *o = S.h<int32_t>(REG_OUT);
+    for(int y = 0; y < height; y++) memcpy(derivate + (size_t)y * derivate_buf_stride, o + (size_t)y * width, sizeof(int32_t) * width);
+}
+extern "C" {
+const XEVE_HIP_INV_TRANS xeve_itrans_map_tbl_hip[16][5] = {
+    {nullptr, tbl_itrans_ats<0, 2>, tbl_itrans_ats<0, 3>, tbl_itrans_ats<0, 4>, tbl_itrans_ats<0, 5>},
+    {nullptr, tbl_itrans_ats<1, 2>, tbl_itrans_ats<1, 3>, tbl_itrans_ats<1, 4>, tbl_itrans_ats<1, 5>},
+};
+void xevem_scaled_horizontal_sobel_filter_hip(pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height)
+{
+    tbl_sobel<0>(pred, pred_stride, derivate, derivate_buf_stride, width, height);
+}
+void xevem_scaled_vertical_sobel_filter_hip(pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height)
+{
+    tbl_sobel<1>(pred, pred_stride, derivate, derivate_buf_stride, width, height);
+}
+// the normal equations (xevem_func_aff_eq_coef_comp, xevem_mc.c:2397-2447); residue is read with the derivative pitch, like the reference does
+void xevem_equal_coeff_computer_hip(pel *residue, int residue_stride, int **derivate, int derivate_buf_stride, int64_t (*equal_coeff)[7], int width, int height, int vertex_num)
+{
+    (void)residue_stride;
+    Stage &S = stage();
+    g_table_calls++, g_table_calls_main++;
+    if(width > 128 || height > 128 || width < 1 || height < 1 || (vertex_num != 2 && vertex_num != 3)) {
+        xh_set_error("equal-coefficient table call %dx%d, %d vertices: outside the supported set", width, height, vertex_num);
+        die(__func__);
+    }
+    // REG_A (64 KB): the residual (dense, pitch = width), REG_B: the two derivative planes (dense), REG_MISC: the 7 x 7 accumulators
+    gather(S.h<int16_t>(REG_A), width, residue, derivate_buf_stride, width, height);
+    int32_t *d = S.h<int32_t>(REG_B);
+    for(int k = 0; k < 2; k++)
+        for(int y = 0; y < height; y++) memcpy(d + ((size_t)k * height + y) * width, derivate[k] + (size_t)y * derivate_buf_stride, sizeof(int32_t) * width);
+    memcpy(S.h<char>(REG_MISC), equal_coeff, sizeof(int64_t) * 49);
+    TBL_RC(xh_equal_coeff(S.d<pel>(REG_A), S.d<int32_t>(REG_B), S.d<int32_t>(REG_B) + (size_t)width * height, width, S.d<long>(REG_MISC), width, height, vertex_num, S.st));
+    S.sync();
+    memcpy(equal_coeff, S.h<char>(REG_MISC), sizeof(int64_t) * 49);
+}
+}
 
 // ---- zero-edit installation into a loaded reference library ---------------------------------------------
 struct Patch {
@@ -518,6 +588,10 @@ static const Patch k_base_patches[] = {
 static const Patch k_main_patches[] = {
     {"xevem_func_dmvr_mc_l", xevem_tbl_dmvr_mc_l_hip}, {"xevem_func_dmvr_mc_c", xevem_tbl_dmvr_mc_c_hip}, {"xevem_func_bl_mc_l", xevem_tbl_bl_mc_l_hip},
     {"xeve_func_tx", &xeve_tbl_tx_hip},                {"xeve_func_itx", &xeve_tbl_itx_hip},
+    {"xeve_func_itrans", xeve_itrans_map_tbl_hip},
+    {"xevem_func_aff_h_sobel_flt", (const void *)xevem_scaled_horizontal_sobel_filter_hip},
+    {"xevem_func_aff_v_sobel_flt", (const void *)xevem_scaled_vertical_sobel_filter_hip},
+    {"xevem_func_aff_eq_coef_comp", (const void *)xevem_equal_coeff_computer_hip},
 };
 extern "C" int xeve_hip_install_tables(void *fn_itxb_slot)
 {

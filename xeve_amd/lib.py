@@ -107,6 +107,7 @@ FN_AVG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_
 FN_TXB = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int)
 FN_MCM = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int)  # XEVEM_MC (src_main/xevem_mc.h:45)
 FN_TX = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int)  # XEVE_TX / XEVE_ITX
+FN_ITR = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INV_TRANS (src_main/xevem_type.h:47)
 FN_RECON = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int)
 
 # every symbol include/xeve_hip.h declares: name -> (restype, argtypes) for functions, ctypes array type for tables
@@ -119,6 +120,9 @@ FUNCTIONS = {
     "xeve_hip_table_calls_main": (C.c_uint64, []),
     "xeve_hip_install_tables": (c_int, [c_void_p]),
     "xeve_hip_install_tables_main": (c_int, [c_void_p]),
+    "xevem_scaled_horizontal_sobel_filter_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
+    "xevem_scaled_vertical_sobel_filter_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
+    "xevem_equal_coeff_computer_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
     "xeve_average_16b_no_clip_hip": (None, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "xeve_recon_blk_hip": (None, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "xeve_hip_sad_jobs": (c_int, _JOB_ARGS + [c_int, c_void_p, c_void_p]),
@@ -209,6 +213,7 @@ TABLES = {
     "xevem_tbl_bl_mc_l_hip": FN_MCM * 4,
     "xeve_tbl_tx_hip": FN_TX * 6,
     "xeve_tbl_itx_hip": FN_TX * 6,
+    "xeve_itrans_map_tbl_hip": FN_ITR * 80,  # [16][5]
 }
 
 _lib = None

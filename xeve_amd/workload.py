@@ -105,6 +105,15 @@ class HotPathPass:
                           for S, lv in self.lv.items()}
         self.sad_events = []
 
+    def _level_streams(self):
+        """one stream per CU level.  XEVE_HIP_LEVEL_PRIO=1: the levels with few, long serial chains (64x64, 32x32) on high-priority streams, so that their short
+        kernels are not queued behind the bulk levels' grids"""
+        prio = os.environ.get("XEVE_HIP_LEVEL_PRIO", "0")
+        if prio == "0":
+            return {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        return {S: torch.cuda.Stream(device=self.dev, priority=(hi if S >= (64 if prio == "1" else 32) else lo)) for S in self.sizes}
+
     def _level(self, S, rng):
         dev, W, H = self.dev, self.W, self.H
         nx, ny = W // S, H // S
@@ -267,7 +276,7 @@ class HotPathPass:
         out = {}
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
-            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+            self._side = self._level_streams()
         for S in sorted(self.sizes, reverse=True):
             lv = self.lv[S]
             if "rate" not in lv:
@@ -330,7 +339,7 @@ class HotPathPass:
         out = {}
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
-            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+            self._side = self._level_streams()
         for S in sorted(self.sizes, reverse=True):  # longest chains first
             lv = self.lv[S]
             if "rdo" not in lv:
@@ -385,7 +394,7 @@ class HotPathPass:
         out = {}
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
-            self._side = {S: torch.cuda.Stream(device=self.dev) for S in self.sizes}
+            self._side = self._level_streams()
         for S in self.sizes:
             if "inter" not in self.lv[S]:
                 self.lv[S]["inter"] = self._inter_setup(self.lv[S])
