@@ -123,6 +123,11 @@ extern const XEVE_HIP_MCM     xevem_tbl_bl_mc_l_hip[2][2];
  * (the reference forms 1 << (shift - 1) unguarded there); installed BY ADDRESS like xeve_func_txb (xevem_util.c:3948-3963) */
 extern const XEVE_HIP_TX      xeve_tbl_tx_hip[6];
 extern const XEVE_HIP_TX      xeve_tbl_itx_hip[6];
+/* reference: XEVE_INTRA_PRED_ANG (src_main/xevem_ipred.h:104-112); src_* point at index 0 of neighbour lines indexed -1 .. w + h - 1 */
+typedef void (*XEVE_HIP_INTRA_PRED_ANG)(xeve_hip_pel *src_le, xeve_hip_pel *src_up, xeve_hip_pel *src_ri, uint16_t avail_lr, xeve_hip_pel *dst, int w, int h, int ipm,
+                                        int bit_depth);
+/* replaces xeve_tbl_intra_pred_ang (xevem_ipred.c:811-815): [ipm < IPD_VER | ipm > IPD_HOR | between][right line used]; ipm 3 .. 32 except 12 and 24 */
+extern const XEVE_HIP_INTRA_PRED_ANG xeve_tbl_intra_pred_ang_hip[3][2];
 /* reference: XEVE_INV_TRANS (src_main/xevem_type.h:47): (coef, block, shift, line, skip_line, skip_line_2) */
 typedef void (*XEVE_HIP_INV_TRANS)(int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
 /* replaces xeve_itrans_map_tbl{,_sse} (xevem_itdq.c:42-47): [0] DCT-VIII, [1] DST-VII; [.][log2 N - 1], N = 4 .. 32 ([.][0] and rows 2 .. 15 are NULL there too) */
@@ -136,8 +141,8 @@ void xevem_equal_coeff_computer_hip(xeve_hip_pel *residue, int residue_stride, i
 /* Zero-edit installation into a loaded MAIN-profile reference library: everything xeve_hip_install_tables patches (the Main
  * library carries the same Baseline globals) plus xevem_func_dmvr_mc_l / _c, xevem_func_bl_mc_l (xevem_mc.c:39-41), xeve_func_tx
  * (xevem_tq.c:41), xeve_func_itx (xevem_itdq.c:39), xeve_func_itrans (xevem_itdq.c:51) and xevem_func_aff_h_sobel_flt / _v_sobel_flt / _eq_coef_comp
- * (xevem_mc.c:42-44) -- every entry of xevem_platform_init_func except xeve_func_intra_pred_ang.  Returns the number of pointers patched (8 + 9 [+ 1]) or a
- * negative error. */
+ * (xevem_mc.c:42-44) and xeve_func_intra_pred_ang (xevem_ipred.c:38) -- every entry of xevem_platform_init_func.  Returns the number of pointers patched
+ * (8 + 10 [+ 1]) or a negative error. */
 int xeve_hip_install_tables_main(void *fn_itxb_slot);
 
 /* Zero-edit installation: overwrites the reference library's exported pointer globals

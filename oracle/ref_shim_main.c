@@ -34,7 +34,7 @@ void xevem_platform_init_func(void)
     if(init(dev ? atoi(dev) : 0) != 0) { fprintf(stderr, "[xeve_hip_shim_main] init: %s\n", err()); abort(); }
     /* the inverse pass-through slot ctx->fn_itxb is not reachable from here (this hook has no ctx): it stays with the reference, which only uses it with tool_iqt off */
     int n = install(NULL);
-    if(n != 17) { fprintf(stderr, "[xeve_hip_shim_main] install: %d (%s)\n", n, err()); abort(); }
+    if(n != 18) { fprintf(stderr, "[xeve_hip_shim_main] install: %d (%s)\n", n, err()); abort(); }
     fprintf(stderr, "[xeve_hip_shim_main] HIP dispatch tables installed, Main-profile entries included (%d pointers)\n", n);
     atexit(report);
 }

@@ -331,6 +331,51 @@ void xo_equal_coeff(const xo_pel *residue, const int32_t *d0, const int32_t *d1,
         }
 }
 
+/* xeve_tbl_intra_pred_ang[group][right] (src_main/xevem_ipred.c:456-815): the angular predictors of the Main profile.  Every sample is a 4-tap interpolation
+ * {32 - f, 64 - f, 32 + f, f} / 128 (xevem_tbl_ipred_adi, xevem_tbl.c:54-88: f = the 1/32 position) of one of the three neighbour lines, at a position that the
+ * mode's slopes (xevem_tbl_ipred_dxdy, xevem_tbl.c:90-100: {dx/dy, dy/dx} << 10) project the sample onto; positions are clipped to [-1, w + h - 1].
+ *   group 0 (ipm < IPD_VER): from the line above, to the right;  with `right`: the part that projects beyond the block's width comes from the right line
+ *   group 1 (ipm > IPD_HOR): from the left line, downwards;      with `right`: from above (projected from the right edge) or from the right line
+ *   group 2 (between):       from above (leftwards) or from the left line; with `right`: the second source is the right line, projected from the right edge */
+static const int xo_ipred_dxdy[33][2] = {
+    {0, 0}, {0, 0}, {0, 0}, {2816, 372}, {2048, 512}, {1408, 744}, {1024, 1024}, {744, 1408}, {512, 2048}, {372, 2816}, {256, 4096},
+    {128, 8192}, {0, 0}, {128, 8192}, {256, 4096}, {372, 2816}, {512, 2048}, {744, 1408}, {1024, 1024}, {1408, 744}, {2048, 512},
+    {2816, 372}, {4096, 256}, {8192, 128}, {0, 0}, {8192, 128}, {4096, 256}, {2816, 372}, {2048, 512}, {1408, 744}, {1024, 1024}, {744, 1408}, {512, 2048}};
+void xo_ipred_ang(int group, int right, const xo_pel *le, const xo_pel *up, const xo_pel *ri, xo_pel *dst, int w, int h, int ipm, int bit_depth)
+{
+    const int *mt = xo_ipred_dxdy[ipm], pmax = w + h - 1, maxv = (1 << bit_depth) - 1;
+    for(int j = 0; j < h; j++)
+        for(int i = 0; i < w; i++) {
+            const xo_pel *src;
+            int pos, dir, d; /* taps at pos - dir, pos, pos + dir, pos + 2 dir; d = the projected distance << 10 whose 1/32 fraction picks the filter */
+#define PROJ(D_IN, M) (d = (D_IN) * (M))
+            if(group == 0) {
+                PROJ(j + 1, mt[0]);
+                if(!right || i < w - (d >> 10)) src = up, pos = i + (d >> 10), dir = 1;
+                else PROJ(w - i, mt[1]), src = ri, pos = j - (d >> 10), dir = -1;
+            }
+            else if(group == 1) {
+                if(!right) PROJ(i + 1, mt[1]), src = le, pos = j + (d >> 10), dir = 1;
+                else {
+                    PROJ(w - i, mt[1]);
+                    if(j < (d >> 10)) PROJ(w - i, mt[0]), src = up, pos = i + (d >> 10), dir = 1;
+                    else src = ri, pos = j - (d >> 10), dir = -1;
+                }
+            }
+            else {
+                PROJ(i + 1, mt[1]);
+                if(j < (d >> 10)) PROJ(j + 1, mt[0]), src = up, pos = i - (d >> 10), dir = -1;
+                else if(!right) src = le, pos = j - (d >> 10), dir = -1;
+                else PROJ(w - i, mt[1]), src = ri, pos = j + (d >> 10), dir = 1;
+            }
+#undef PROJ
+            const int f = (d >> 5) - ((d >> 10) << 5);
+            const int a = src[clip3i(-1, pmax, pos - dir)], b = src[clip3i(-1, pmax, pos)], c = src[clip3i(-1, pmax, pos + dir)], e = src[clip3i(-1, pmax, pos + 2 * dir)];
+            const int16_t t = (int16_t)((a * (32 - f) + b * (64 - f) + c * (32 + f) + e * f + 64) >> 7);
+            dst[j * w + i] = (xo_pel)clip3i(0, maxv, t);
+        }
+}
+
 /* a7 (reference: xeve_mc.c:449-463) */
 void xo_avg(const int16_t *src, const int16_t *ref, int16_t *dst, int s_src, int s_ref, int s_dst, int w, int h)
 {

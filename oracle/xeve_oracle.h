@@ -61,6 +61,8 @@ void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, 
                 int bit_depth);
 
 /* the rest of the Main dispatch list: inverse ATS (xeve_func_itrans), the affine gradient search's Sobel filters and normal equations */
+/* xeve_tbl_intra_pred_ang[group][right] (xevem_ipred.c:456-815); le / up / ri point at element 0 of lines indexed -1 .. w + h - 1 */
+void xo_ipred_ang(int group, int right, const xo_pel *le, const xo_pel *up, const xo_pel *ri, xo_pel *dst, int w, int h, int ipm, int bit_depth);
 void xo_ats_matrix(int type, int log2n, int8_t *m);
 void xo_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
 void xo_sobel(int vertical, const xo_pel *pred, int s_pred, int32_t *der, int s_der, int w, int h);

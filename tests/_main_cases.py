@@ -85,6 +85,18 @@ def eq_cases():
             yield vn, w, h, res, d0, d1, r.integers(-1000, 1000, size=(7, 7)).astype(np.int64)
 
 
+def ang_cases():
+    """(group, right, w, h, ipm, bit depth, le, up, ri): every angular mode of every group, with and without the right line, block shapes 4 .. 64; the three neighbour
+    lines are indexed -1 .. w + h - 1 (element 0 of the arrays is index -1)"""
+    r = np.random.default_rng(456)
+    for g, ipms in ((0, range(3, 12)), (1, range(25, 33)), (2, range(13, 24))):
+        for right in (0, 1):
+            for (w, h) in ((4, 4), (8, 4), (4, 8), (8, 8), (16, 16), (32, 8), (32, 32), (64, 64)):
+                for ipm in ipms:
+                    bd = 10 if (ipm + w) % 3 else 8
+                    yield (g, right, w, h, ipm, bd) + tuple(r.integers(0, 1 << bd, size=w + h + 1).astype(np.int16) for _ in range(3))
+
+
 def run_all(impl, mult=1):
     """mult: only blocks whose sides are multiples of it (the reference's SSE variants store whole groups of four samples / rows)"""
     out = []
@@ -109,6 +121,10 @@ def run_all(impl, mult=1):
         der = np.full((h, w), -5, np.int32)
         impl.sobel(vertical, pred.copy(), s_pred, der, w, w, h)
         out.append(der.ravel().view(np.int16))
+    for g, right, w, h, ipm, bd, le, up, ri in ang_cases():
+        dst = np.full(w * h, -3, np.int16)
+        impl.ang(g, right, le.copy(), up.copy(), ri.copy(), dst, w, h, ipm, bd)
+        out.append(dst)
     for vn, w, h, res, d0, d1, eq0 in eq_cases():
         eq = eq0.copy() if mult == 1 else np.zeros_like(eq0)  # (the reference's SSE variant stores its sums: it needs the zeroed accumulators its caller hands it)
         impl.eq_coef(res.copy(), w, d0.copy(), d1.copy(), w, eq, w, h, vn)
@@ -133,6 +149,11 @@ class OracleMain:
         self.O.xo_itrans_ats.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int]
         self.O.xo_itrans_ats(typ, log2n, ptr(coef), ptr(dst), shift, line, sl, s2)
 
+    def ang(self, g, right, le, up, ri, dst, w, h, ipm, bd):
+        self.O.xo_ipred_ang.restype = None
+        self.O.xo_ipred_ang.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]
+        self.O.xo_ipred_ang(g, right, ptr(le, 1), ptr(up, 1), ptr(ri, 1), ptr(dst), w, h, ipm, bd)
+
     def sobel(self, vertical, pred, s_pred, der, s_der, w, h):
         self.O.xo_sobel.restype = None
         self.O.xo_sobel.argtypes = [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int]
@@ -146,6 +167,7 @@ class OracleMain:
 
 FN_ITR = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INV_TRANS (xevem_type.h:47)
 FN_SOBEL = C.CFUNCTYPE(None, c_void_p, c_int, c_void_p, c_int, c_int, c_int)  # XEVE_AFFINE_H / V_SOBEL_FLT (xevem_mc.h:157-168)
+FN_ANG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, C.c_uint16, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INTRA_PRED_ANG (xevem_ipred.h:104-112)
 FN_EQ = C.CFUNCTYPE(None, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int)  # XEVE_AFFINE_EQUAL_COEF (xevem_mc.h:169-176)
 
 
@@ -160,6 +182,7 @@ class TableMain:
         self.itr = (FN_ITR * 80).in_dll(L, names[5])  # [16][5], rows 0 (DCT-VIII) and 1 (DST-VII) populated
         self.sob = [FN_SOBEL((names[6], L)), FN_SOBEL((names[7], L))]
         self.eq = FN_EQ((names[8], L))
+        self.angt = (FN_ANG * 6).in_dll(L, names[9])  # [3][2]
 
     def mc(self, kind, fx, fy, plane, org, gx, gy, s_ref, sp, pred, w, h, bd):
         self.t[kind][int(fx) * 2 + int(fy)](ptr(plane, org), gx, gy, s_ref, sp, ptr(pred), w, h, bd)
@@ -169,6 +192,9 @@ class TableMain:
 
     def itrans_ats(self, typ, log2n, coef, dst, shift, line, sl, s2):
         self.itr[typ * 5 + log2n - 1](ptr(coef), ptr(dst), shift, line, sl, s2)
+
+    def ang(self, g, right, le, up, ri, dst, w, h, ipm, bd):
+        self.angt[g * 2 + right](ptr(le, 1), ptr(up, 1), ptr(ri, 1), 0, ptr(dst), w, h, ipm, bd)
 
     def sobel(self, vertical, pred, s_pred, der, s_der, w, h):
         self.sob[vertical](ptr(pred), s_pred, ptr(der), s_der, w, h)
@@ -180,12 +206,12 @@ class TableMain:
 
 REF_NAMES = {
     "c": ("xevem_tbl_dmvr_mc_l", "xevem_tbl_dmvr_mc_c", "xevem_tbl_bl_mc_l", "xeve_tbl_tx", "xeve_tbl_itx", "xeve_itrans_map_tbl",
-          "xevem_scaled_horizontal_sobel_filter", "xevem_scaled_vertical_sobel_filter", "xevem_equal_coeff_computer"),
+          "xevem_scaled_horizontal_sobel_filter", "xevem_scaled_vertical_sobel_filter", "xevem_equal_coeff_computer", "xeve_tbl_intra_pred_ang"),
     "sse": ("xeve_tbl_dmvr_mc_l_sse", "xeve_tbl_dmvr_mc_c_sse", "xeve_tbl_bl_mc_l_sse", "xeve_tbl_tx", "xeve_tbl_itx", "xeve_itrans_map_tbl_sse",
-            "xevem_scaled_horizontal_sobel_filter_sse", "xevem_scaled_vertical_sobel_filter_sse", "xevem_equal_coeff_computer_sse"),
+            "xevem_scaled_horizontal_sobel_filter_sse", "xevem_scaled_vertical_sobel_filter_sse", "xevem_equal_coeff_computer_sse", "xeve_tbl_intra_pred_ang"),
 }
 HIP_NAMES = ("xevem_tbl_dmvr_mc_l_hip", "xevem_tbl_dmvr_mc_c_hip", "xevem_tbl_bl_mc_l_hip", "xeve_tbl_tx_hip", "xeve_tbl_itx_hip", "xeve_itrans_map_tbl_hip",
-             "xevem_scaled_horizontal_sobel_filter_hip", "xevem_scaled_vertical_sobel_filter_hip", "xevem_equal_coeff_computer_hip")
+             "xevem_scaled_horizontal_sobel_filter_hip", "xevem_scaled_vertical_sobel_filter_hip", "xevem_equal_coeff_computer_hip", "xeve_tbl_intra_pred_ang_hip")
 _refm = None
 
 
@@ -209,6 +235,10 @@ def input_checksum():
         c = zlib.crc32(case[3].tobytes(), zlib.crc32(np.array(case[:3] + case[4:], np.int64).tobytes(), c))
     for case in eq_cases():
         for a in case[3:]:
+            c = zlib.crc32(a.tobytes(), c)
+    for case in ang_cases():
+        c = zlib.crc32(np.array(case[:6], np.int64).tobytes(), c)
+        for a in case[6:]:
             c = zlib.crc32(a.tobytes(), c)
     return c
 

@@ -80,7 +80,7 @@ def test_main_bitstream_identical_with_hip_tables_installed(tmp_path, name):
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000)
-    assert "Main-profile entries included (17 pointers)" in err
+    assert "Main-profile entries included (18 pointers)" in err
     m = re.search(r"calls served by HIP: (\d+), of them by the Main-profile entries: (\d+)", err)
     assert m and int(m.group(2)) > 50000 and int(m.group(1)) > int(m.group(2)), err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the HIP tables installed"

@@ -24,6 +24,7 @@ int xh_tq_init();
 int xh_main_tools_init(); // main_tools.hip: the ATS matrices
 int xh_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2, hipStream_t st);
 int xh_sobel(int vertical, const pel *pred, int s_pred, int32_t *der, int s_der, int w, int h, hipStream_t st);
+int xh_ipred_ang(int group, int right, const pel *lines, pel *dst, int w, int h, int ipm, int bit_depth, hipStream_t st);
 int xh_equal_coeff(const pel *residue, const int32_t *d0, const int32_t *d1, int s_der, long *eq, int w, int h, int vertex_num, hipStream_t st);
 int xh_tx1d(bool fwd, const void *src, void *dst, int log2n, int shift, int line, int step, hipStream_t st);
 
@@ -528,7 +529,31 @@ template <int VERTICAL> static void tbl_sobel(pel *pred, int pred_stride, int *d
     const int32_t *o = S.h<int32_t>(REG_OUT);
     for(int y = 0; y < height; y++) memcpy(derivate + (size_t)y * derivate_buf_stride, o + (size_t)y * width, sizeof(int32_t) * width);
 }
+// angular intra prediction (xeve_func_intra_pred_ang[group][right], xevem_ipred.c:811-815).  Only the neighbour lines the variant reads are staged (element
+// -1 .. w + h - 1 of each): above for every variant but [1][0], left for the variants without the right line except [0][0], right for the `right` variants.
+template <int GROUP, int RIGHT>
+static void tbl_ipred_ang(pel *src_le, pel *src_up, pel *src_ri, uint16_t avail_lr, pel *dst, int w, int h, int ipm, int bit_depth)
+{
+    (void)avail_lr;
+    Stage &S = stage();
+    g_table_calls++, g_table_calls_main++;
+    if(w > 128 || h > 128 || w < 1 || h < 1) {
+        xh_set_error("angular prediction table call %dx%d outside 1 .. 128", w, h);
+        die(__func__);
+    }
+    const int L = w + h + 1;
+    pel *lines = S.h<pel>(REG_A);
+    memset(lines, 0, sizeof(pel) * 3 * (size_t)L);
+    if(!(GROUP == 0) && !RIGHT) memcpy(lines, src_le - 1, sizeof(pel) * L);
+    if(!(GROUP == 1 && !RIGHT)) memcpy(lines + L, src_up - 1, sizeof(pel) * L);
+    if(RIGHT) memcpy(lines + 2 * L, src_ri - 1, sizeof(pel) * L);
+    TBL_RC(xh_ipred_ang(GROUP, RIGHT, S.d<pel>(REG_A), S.d<pel>(REG_OUT), w, h, ipm, bit_depth, S.st));
+    S.sync();
+    memcpy(dst, S.h<pel>(REG_OUT), sizeof(pel) * (size_t)w * h);
+}
 extern "C" {
+const XEVE_HIP_INTRA_PRED_ANG xeve_tbl_intra_pred_ang_hip[3][2] = {{tbl_ipred_ang<0, 0>, tbl_ipred_ang<0, 1>}, {tbl_ipred_ang<1, 0>, tbl_ipred_ang<1, 1>},
+                                                                   {tbl_ipred_ang<2, 0>, tbl_ipred_ang<2, 1>}};
 const XEVE_HIP_INV_TRANS xeve_itrans_map_tbl_hip[16][5] = {
     {nullptr, tbl_itrans_ats<0, 2>, tbl_itrans_ats<0, 3>, tbl_itrans_ats<0, 4>, tbl_itrans_ats<0, 5>},
     {nullptr, tbl_itrans_ats<1, 2>, tbl_itrans_ats<1, 3>, tbl_itrans_ats<1, 4>, tbl_itrans_ats<1, 5>},
@@ -589,6 +614,7 @@ static const Patch k_main_patches[] = {
     {"xevem_func_dmvr_mc_l", xevem_tbl_dmvr_mc_l_hip}, {"xevem_func_dmvr_mc_c", xevem_tbl_dmvr_mc_c_hip}, {"xevem_func_bl_mc_l", xevem_tbl_bl_mc_l_hip},
     {"xeve_func_tx", &xeve_tbl_tx_hip},                {"xeve_func_itx", &xeve_tbl_itx_hip},
     {"xeve_func_itrans", xeve_itrans_map_tbl_hip},
+    {"xeve_func_intra_pred_ang", xeve_tbl_intra_pred_ang_hip},
     {"xevem_func_aff_h_sobel_flt", (const void *)xevem_scaled_horizontal_sobel_filter_hip},
     {"xevem_func_aff_v_sobel_flt", (const void *)xevem_scaled_vertical_sobel_filter_hip},
     {"xevem_func_aff_eq_coef_comp", (const void *)xevem_equal_coeff_computer_hip},

@@ -121,3 +121,53 @@ int xh_equal_coeff(const pel *residue, const int32_t *d0, const int32_t *d1, int
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// ---- angular intra prediction of the Main profile (xeve_tbl_intra_pred_ang[group][right], src_main/xevem_ipred.c:456-815) ------------------------------------
+// Every sample = a 4-tap interpolation {32 - f, 64 - f, 32 + f, f} / 128 (xevem_tbl_ipred_adi) of one of the three neighbour lines at the position the mode's slopes
+// (xevem_tbl_ipred_dxdy: {dx/dy, dy/dx} << 10) project it onto, positions clipped to [-1, w + h - 1]; the six table entries differ in which line and direction.
+// lines: [3][w + h + 1] (left, up, right; element 0 = index -1); one thread per sample.
+__constant__ int c_ipred_dxdy[33][2] = {
+    {0, 0}, {0, 0}, {0, 0}, {2816, 372}, {2048, 512}, {1408, 744}, {1024, 1024}, {744, 1408}, {512, 2048}, {372, 2816}, {256, 4096},
+    {128, 8192}, {0, 0}, {128, 8192}, {256, 4096}, {372, 2816}, {512, 2048}, {744, 1408}, {1024, 1024}, {1408, 744}, {2048, 512},
+    {2816, 372}, {4096, 256}, {8192, 128}, {0, 0}, {8192, 128}, {4096, 256}, {2816, 372}, {2048, 512}, {1408, 744}, {1024, 1024}, {744, 1408}, {512, 2048}};
+__global__ void k_ipred_ang(const pel *__restrict__ lines, pel *__restrict__ dst, int group, int right, int w, int h, int ipm, int maxv)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= w * h) return;
+    const int j = t / w, i = t - j * w, pmax = w + h - 1, L = w + h + 1;
+    const int m0 = c_ipred_dxdy[ipm][0], m1 = c_ipred_dxdy[ipm][1];
+    int line, pos, dir, d; // taps at pos - dir, pos, pos + dir, pos + 2 dir of line (0 left, 1 up, 2 right); d = projected distance << 10
+    if(group == 0) {
+        d = (j + 1) * m0;
+        if(!right || i < w - (d >> 10)) line = 1, pos = i + (d >> 10), dir = 1;
+        else d = (w - i) * m1, line = 2, pos = j - (d >> 10), dir = -1;
+    }
+    else if(group == 1) {
+        if(!right) d = (i + 1) * m1, line = 0, pos = j + (d >> 10), dir = 1;
+        else {
+            d = (w - i) * m1;
+            if(j < (d >> 10)) d = (w - i) * m0, line = 1, pos = i + (d >> 10), dir = 1;
+            else line = 2, pos = j - (d >> 10), dir = -1;
+        }
+    }
+    else {
+        d = (i + 1) * m1;
+        if(j < (d >> 10)) d = (j + 1) * m0, line = 1, pos = i - (d >> 10), dir = -1;
+        else if(!right) line = 0, pos = j - (d >> 10), dir = -1;
+        else d = (w - i) * m1, line = 2, pos = j + (d >> 10), dir = 1;
+    }
+    const int f = (d >> 5) - ((d >> 10) << 5);
+    const pel *src = lines + line * L + 1;
+    auto at = [&](int p) { return (int)src[min(max(p, -1), pmax)]; };
+    const int v = (int)(int16_t)((at(pos - dir) * (32 - f) + at(pos) * (64 - f) + at(pos + dir) * (32 + f) + at(pos + 2 * dir) * f + 64) >> 7);
+    dst[t] = (pel)(v < 0 ? 0 : (v > maxv ? maxv : v));
+}
+int xh_ipred_ang(int group, int right, const pel *lines, pel *dst, int w, int h, int ipm, int bit_depth, hipStream_t st)
+{
+    XH_ENTER();
+    XH_REQUIRE(lines && dst && group >= 0 && group <= 2 && (right == 0 || right == 1) && w >= 1 && h >= 1 && w <= 128 && h <= 128 && ipm >= 3 && ipm <= 32);
+    XH_REQUIRE(bit_depth >= 8 && bit_depth <= 14);
+    k_ipred_ang<<<(w * h + 255) / 256, 256, 0, st>>>(lines, dst, group, right, w, h, ipm, (1 << bit_depth) - 1);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -107,6 +107,7 @@ FN_AVG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_
 FN_TXB = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int)
 FN_MCM = C.CFUNCTYPE(None, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int)  # XEVEM_MC (src_main/xevem_mc.h:45)
 FN_TX = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int)  # XEVE_TX / XEVE_ITX
+FN_ANG = C.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, C.c_uint16, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INTRA_PRED_ANG (src_main/xevem_ipred.h:104)
 FN_ITR = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int)  # XEVE_INV_TRANS (src_main/xevem_type.h:47)
 FN_RECON = C.CFUNCTYPE(None, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int)
 
@@ -214,6 +215,7 @@ TABLES = {
     "xeve_tbl_tx_hip": FN_TX * 6,
     "xeve_tbl_itx_hip": FN_TX * 6,
     "xeve_itrans_map_tbl_hip": FN_ITR * 80,  # [16][5]
+    "xeve_tbl_intra_pred_ang_hip": FN_ANG * 6,  # [3][2]
 }
 
 _lib = None

@@ -40,6 +40,7 @@ class HipTables:
         self.func_itrans = [[t["xeve_itrans_map_tbl_hip"][i * 5 + j] for j in range(5)] for i in range(16)]  # xeve_func_itrans[type][log2 N - 1] (xevem_itdq.c:51)
         self.func_aff_h_sobel_flt, self.func_aff_v_sobel_flt = L.xevem_scaled_horizontal_sobel_filter_hip, L.xevem_scaled_vertical_sobel_filter_hip
         self.func_aff_eq_coef_comp = L.xevem_equal_coeff_computer_hip
+        self.func_intra_pred_ang = [[t["xeve_tbl_intra_pred_ang_hip"][i * 2 + j] for j in range(2)] for i in range(3)]
         self.func_average_no_clip = L.xeve_average_16b_no_clip_hip
         self.fn_recon = L.xeve_recon_blk_hip
 
