@@ -131,7 +131,7 @@ def test_spel_batches_vs_oracle(S, bi):
 @pytest.mark.parametrize("S", [8, 16, 32, 64])
 @pytest.mark.parametrize("bi", [0, 1])
 def test_epzs_search_vs_oracle(S, bi):
-    """xeve_amd.me.epzs_search = pinter_me_epzs per block (diamond, refinement loop, sub-pel) on the GPU, vs the oracle"""
+    """xeve_amd.me.epzs_search_device = xeve_hip_me_epzs_jobs: pinter_me_epzs per block (diamond, refinement loop, sub-pel) on the GPU, vs the oracle"""
     import torch
 
     import xeve_amd
@@ -156,10 +156,9 @@ def test_epzs_search_vs_oracle(S, bi):
             S.bit_length() - 1, 10, base["lambda_mv"], 1, base["msr"], base["sr"], base["min_clip"], base["max_clip"], base["hpel_cnt"], base["qpel_cnt"])
     kw = dict(bi=bi, org_bi=org_bi, mv_start=[c["mv0"] for c in cases], extra_bits=base["mot_other"])
     exp = [run_oracle_epzs(c) for c in cases]
-    for impl in (me.epzs_search, me.epzs_search_device):  # host-loop composition and the C entry point xeve_hip_me_epzs_jobs
-        cost, mv = impl(*args, **kw)
-        for i in range(len(cases)):
-            assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == exp[i], (impl.__name__, S, bi, i)
+    cost, mv = me.epzs_search_device(*args, **kw)
+    for i in range(len(cases)):
+        assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == exp[i], (S, bi, i)
     # the side effect on pi->mot_bits[lidx] (the next bi-directional search reads it): oracle -1 = untouched = 0 here
     cost, mv, mot = me.epzs_search_device(*args, with_mot_bits=True, **kw)
     for i, c in enumerate(cases):
