@@ -166,7 +166,14 @@ template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const in
 // tests/test_sbac_golden.py::test_bit_count_is_the_number_of_renormalisation_shifts).
 struct Sbac {
     unsigned range, shifts, bins;
-    unsigned code, cb, sff, sz, pb, ipb, bc; // FULL only
+    // FULL only.  code / cb are the reference's code register and code_bits, bin for bin (the byte that leaves at a boundary is cut out branch-free).  What is
+    // DEFERRED is the bookkeeping of the bytes that left (sbac_carry_propagate / sbac_put_byte: pending byte, stacked 0xFF / 0x00, bit counter): they queue up in
+    // `fifo` (16 bits each, oldest on top) and sb_drain() works them off in order every four bins.  64 lanes cross byte boundaries at 64 different bins, so a
+    // per-bin "a byte leaves" branch is taken by some lane on nearly every bin and the whole wave pays the branchy bookkeeping each time; a drain every four bins
+    // (at most one byte leaves per bin: n <= 7) costs a fraction of it.  (Keeping the register 64 bits wide and cutting the bytes out late is cheaper still but
+    // NOT field-exact: a carry that arrives after its byte has left stays in `code` until the next boundary in the reference -- measured and rejected.)
+    unsigned long long fifo;
+    unsigned code, cb, cnt, sff, sz, pb, ipb, bc;
 };
 
 // sbac_put_byte with is_bitcount set: written bytes only advance the bit counter
@@ -179,11 +186,9 @@ __device__ __forceinline__ void sb_byte(Sbac &s, unsigned b)
     s.pb = b, s.ipb = 1;
 }
 
-// sbac_carry_propagate with its while loops in closed form
-__device__ __forceinline__ void sb_carry(Sbac &s)
+// sbac_carry_propagate with its while loops in closed form; out = the reference's code >> 17 at the byte boundary
+__device__ __forceinline__ void sb_carry(Sbac &s, unsigned out)
 {
-    const unsigned out = s.code >> 17;
-    s.code &= (1u << 17) - 1;
     if(out == 0xFF) {
         s.sff++;
         return;
@@ -201,6 +206,14 @@ __device__ __forceinline__ void sb_carry(Sbac &s)
         s.sff = 0;
     }
     sb_byte(s, out & 0xFF);
+}
+// the queued bytes, oldest first
+__device__ __forceinline__ void sb_drain(Sbac &s)
+{
+    while(s.cnt) {
+        s.cnt--;
+        sb_carry(s, (unsigned)(s.fifo >> (16 * s.cnt)) & 0xFFFFu);
+    }
 }
 
 // xeve_sbac_encode_bin on model m (returns the updated model) / sbac_encode_bin_ep (ep; m passes through).  Branch-free
@@ -224,14 +237,14 @@ template <bool FULL> __device__ __forceinline__ unsigned sb_encode(Sbac &s, unsi
     s.range = ep ? half << 1 : r << n;
     n = ep ? 1 : n;
     s.shifts += n, s.bins++;
-    if(FULL) {
-        s.code += ep ? (bin ? half : 0) : (cut ? rm : 0);
-        if(n >= s.cb) { // a byte leaves the register (n <= 7: at most one)
-            s.code <<= s.cb, n -= s.cb;
-            sb_carry(s);
-            s.cb = 8;
-        }
-        s.code <<= n, s.cb -= n;
+    if(FULL) { // the code register as the reference moves it; a byte that leaves (n >= cb; at most one: n <= 7) is queued for sb_drain
+        const unsigned c0 = s.code + (ep ? (bin ? half : 0) : (cut ? rm : 0));
+        const bool     crossed = n >= s.cb;
+        const unsigned n1 = crossed ? s.cb : n, c1 = c0 << n1; // up to the boundary (or all the shifts)
+        s.fifo = crossed ? (s.fifo << 16) | (c1 >> 17) : s.fifo; // (the byte and what the reference finds above it: 9 bits, 13 right after a bit reset)
+        s.cnt += crossed ? 1u : 0u;
+        s.code = (crossed ? c1 & 0x1FFFFu : c1) << (n - n1);
+        s.cb   = crossed ? 8 - (n - n1) : s.cb - n;
     }
     return ep ? m : m1;
 }
@@ -394,7 +407,9 @@ template <bool FULL> __device__ __forceinline__ void code_queue(Sbac &s, CtxTab 
         const unsigned e = s_q[i][lane], ci = e >> 1;
         const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], e & 1, ci == BYP); // (bypass entries pass the dummy row through)
         s_ctx[ci][lane] = (uint16_t)m;
+        if(FULL && (i & 3) == 3) sb_drain(s);
     }
+    if(FULL) sb_drain(s);
 }
 
 template <bool FULL> __device__ __forceinline__ void code_string(Sbac &s, CtxTab s_ctx, int lane, const unsigned char *sp, int rem)
@@ -421,6 +436,7 @@ template <bool FULL> __device__ __forceinline__ void code_string(Sbac &s, CtxTab
             for(int i = 0; i < 16; i++) {
                 const unsigned wv = cur[i >> 2], wn = i < 15 ? cur[(i + 1) >> 2] : nxt.x;
                 step(wv >> (8 * (i & 3)), wn >> (8 * ((i + 1) & 3)));
+                if(FULL && (i & 3) == 3) sb_drain(s);
             }
         }
         else {
@@ -429,7 +445,9 @@ template <bool FULL> __device__ __forceinline__ void code_string(Sbac &s, CtxTab
                 const unsigned wv = (i >> 2) == 0 ? cur.x : (i >> 2) == 1 ? cur.y : (i >> 2) == 2 ? cur.z : cur.w;
                 const unsigned wn = (i1 >> 2) == 0 ? cur.x : (i1 >> 2) == 1 ? cur.y : (i1 >> 2) == 2 ? cur.z : cur.w; // (i1 <= 15 here)
                 step(wv >> (8 * (i & 3)), wn >> (8 * (i1 & 3)));
+                if(FULL && (i & 3) == 3) sb_drain(s);
             }
+            if(FULL) sb_drain(s);
         }
         cur = nxt, rem -= 16;
     }
@@ -442,6 +460,7 @@ __device__ __forceinline__ void code_events(Sbac &s, CtxTab s_ctx, int lane, con
     auto bin = [&](int ci, unsigned b) {
         const unsigned m = sb_encode<FULL>(s, s_ctx[ci][lane], b, false);
         s_ctx[ci][lane] = (uint16_t)m;
+        if(FULL) sb_drain(s); // (the slow path: every bin)
     };
     unsigned plev = 5; // min(previous level - 1, 5); 5 at the start of a block
     for(int e = 0; e < nevents; e++) {
@@ -458,6 +477,7 @@ __device__ __forceinline__ void code_events(Sbac &s, CtxTab s_ctx, int lane, con
             bin(XEVE_HIP_CTX_LEVEL + t0 + 1, 0);
         }
         (void)sb_encode<FULL>(s, 0, sign, true);
+        if(FULL) sb_drain(s);
         num_sig--;
         if(!at_end) bin(XEVE_HIP_CTX_LAST + ch, num_sig == 0);
         plev = lev1 < 5 ? lev1 : 5u;
@@ -481,7 +501,7 @@ __device__ __forceinline__ void code_block(Sbac &s, CtxTab s_ctx, int lane, cons
 __device__ __forceinline__ void sbac_load(Sbac &s, const xeve_hip_sbac &in, CtxTab s_ctx, int lane, bool continue_coder)
 {
     s.range = in.range, s.shifts = s.bins = 0;
-    s.code = in.code & 0x7FFFF, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
+    s.code = in.code & 0x7FFFF, s.fifo = 0, s.cnt = 0, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
     if(continue_coder) { // continue the coder where the state stands
         s.code = in.code, s.cb = in.code_bits, s.sff = in.stacked_ff, s.sz = in.stacked_zero, s.pb = in.pending_byte, s.ipb = in.is_pending_byte;
         s.bc = in.bitcounter, s.bins = in.bin_counter;
@@ -525,6 +545,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
         for(int i = 0; i < NCTX; i++) o.ctx[i] = s_ctx[i][lane];
     }
     if(FULL) {
+        sb_drain(s);
         // xeve_get_bit_number (xeve_mode.c:51-55) -- equal to s.shifts, kept as the reference computes it
         bits[j] = s.bc + 8 * (s.sz + s.sff) + 8 * (s.ipb ? 1 : 0) + 8 - s.cb + 3;
         xeve_hip_sbac &o = sout[j];
