@@ -21,7 +21,10 @@
 #include "xh_common.h"
 
 #define NCTX XEVE_HIP_SBAC_NCTX
-#define QMAX 200 // header queue: 5 + 2 * (20 refi + 3 mvp + 2 * 34 mvd) + 4 cbf = 191 bins at most
+// Header queue in LDS: QCAP entries per lane.  A header has up to 5 + 2 * (20 refi + 3 mvp + 2 * 34 mvd) + 4 cbf = 191 bins, but more than a few dozen only with
+// vector differences of thousands of samples: the queue holds a WINDOW of the header, and a job whose header is longer generates it again for the next window
+// (q_header is a pure function of the job).  48 entries = 3 KB per wave instead of 12.5: LDS per workgroup 22 -> 12.5 KB, 7 -> 12 waves per CU.
+#define QCAP 48
 
 struct CuBitsK {
     int n[3], log2n[3];
@@ -253,9 +256,15 @@ template <bool FULL> __device__ __forceinline__ unsigned sb_encode(Sbac &s, unsi
 // entry: the byte of the bin strings -- (model << 1) | bin, bypass bins as model BYP (the dummy row of the model table)
 struct Queue {
     uint8_t *q; // &s_q[0][lane], stride 64
-    int      n;
-    __device__ __forceinline__ void ctx(int ci, unsigned bin) { q[64 * n++] = (uint8_t)((ci << 1) | (bin & 1)); }
-    __device__ __forceinline__ void ep(unsigned bin) { q[64 * n++] = (uint8_t)((BYP << 1) | (bin & 1)); }
+    int      n; // bins generated so far
+    int      base; // first bin of the window the LDS queue holds
+    __device__ __forceinline__ void put(unsigned e)
+    {
+        if((unsigned)(n - base) < (unsigned)QCAP) q[64 * (n - base)] = (uint8_t)e;
+        n++;
+    }
+    __device__ __forceinline__ void ctx(int ci, unsigned bin) { put(((unsigned)ci << 1) | (bin & 1)); }
+    __device__ __forceinline__ void ep(unsigned bin) { put((BYP << 1) | (bin & 1)); }
 };
 __device__ __forceinline__ void q_intra_dir(Queue &Q, unsigned sym)
 { // xeve_eco_intra_dir (xeve_eco.c:1104-1121): sbac_write_unary_sym(mpm[ipm], 2 models) (:474-490)
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
                                                 xeve_hip_sbac *__restrict__ sout, unsigned long long *__restrict__ units, unsigned long long *__restrict__ slow)
 {
     __shared__ uint16_t s_ctx[NCTX + 1][64]; // (+ the dummy row of the bypass bins)
-    __shared__ uint8_t  s_q[QMAX][64];
+    __shared__ uint8_t  s_q[QCAP][64];
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
@@ -524,9 +533,14 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     const bool cont = FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET);
     Sbac s;
     sbac_load(s, in, s_ctx, lane, cont);
-    Queue Q{&s_q[0][lane], 0};
+    Queue Q{&s_q[0][lane], 0, 0};
     const unsigned coded = q_header(Q, J, P);
-    code_queue<FULL>(s, s_ctx, s_q, lane, Q.n);
+    code_queue<FULL>(s, s_ctx, s_q, lane, Q.n < QCAP ? Q.n : QCAP);
+    for(int base = QCAP; base < Q.n; base += QCAP) { // (a header longer than the window: rare)
+        Queue W{&s_q[0][lane], 0, base};
+        (void)q_header(W, J, P);
+        code_queue<FULL>(s, s_ctx, s_q, lane, Q.n - base < QCAP ? Q.n - base : QCAP);
+    }
     for(int c = 0; c < 3; c++)
         if((coded >> c) & 1) code_block<FULL>(s, s_ctx, lane, bins, ev, J.coef_off[c], J.nnz[c], c, P.cm_init, slow);
     bits[j] = s.shifts;
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
                                                       unsigned long long *__restrict__ units, unsigned long long *__restrict__ slow)
 {
     __shared__ uint16_t s_ctx[NCTX + 1][64];
-    __shared__ uint8_t  s_q[QMAX][64];
+    __shared__ uint8_t  s_q[QCAP][64];
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
         T.mode = (uint8_t)(XEVE_HIP_BITS_COMP_Y + c);
         if(c == 2) { // V without: one cbf bin, on a copy (range + that model; nothing is written back)
             T.nnz[2] = 0;
-            Queue Q0{&s_q[0][lane], 0};
+            Queue Q0{&s_q[0][lane], 0, 0};
             (void)q_header(Q0, T, P);
             Sbac t = s;
             for(int i = 0; i < Q0.n; i++) {
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
             T.nnz[2] = J.nnz[2];
         }
         else if(!keep[c]) T.nnz[c] = 0;
-        Queue Q{&s_q[0][lane], 0};
+        Queue Q{&s_q[0][lane], 0, 0}; // (a component test's header is the cbf flags: a few bins)
         const unsigned coded = q_header(Q, T, P);
         code_queue<false>(s, s_ctx, s_q, lane, Q.n);
         if((coded >> c) & 1) code_block<false>(s, s_ctx, lane, bins, ev, J.coef_off[c], J.nnz[c], c, P.cm_init, slow);
