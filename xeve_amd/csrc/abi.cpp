@@ -139,18 +139,31 @@ struct ProfTok {
 };
 std::mutex               g_prof_mu;
 std::atomic<unsigned>    g_prof_mask{0}; // bit per class
-std::vector<ProfTok *>   g_prof_done;
+std::vector<ProfTok *>   g_prof_done, g_prof_free; // (events are pooled: creating a pair per timed launch cost ~60 us of host time each -- measured)
 unsigned long long      *g_prof_units = nullptr; // device, XEVE_HIP_PROF_CLASSES counters
 } // namespace
 bool xh_prof_on(int cls) { return (g_prof_mask.load(std::memory_order_relaxed) >> cls) & 1u; }
-unsigned long long *xh_prof_units(int cls) { return xh_prof_on(cls) && g_prof_units ? g_prof_units + cls : nullptr; }
+unsigned long long *xh_prof_units(int cls) { return xh_prof_on(cls) && g_prof_units ? g_prof_units + (size_t)cls * XH_PROF_STRIPES : nullptr; }
 void *xh_prof_begin(int cls, hipStream_t st)
 {
-    ProfTok *t = new ProfTok{cls, nullptr, nullptr};
-    if(hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess || hipEventRecord(t->e0, st) != hipSuccess) {
-        if(t->e0) (void)hipEventDestroy(t->e0);
-        if(t->e1) (void)hipEventDestroy(t->e1);
-        delete t;
+    ProfTok *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if(!g_prof_free.empty()) t = g_prof_free.back(), g_prof_free.pop_back();
+    }
+    if(!t) {
+        t = new ProfTok{cls, nullptr, nullptr};
+        if(hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) {
+            if(t->e0) (void)hipEventDestroy(t->e0);
+            if(t->e1) (void)hipEventDestroy(t->e1);
+            delete t;
+            return nullptr;
+        }
+    }
+    t->cls = cls;
+    if(hipEventRecord(t->e0, st) != hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_free.push_back(t);
         return nullptr;
     }
     return t;
@@ -165,11 +178,13 @@ void xh_prof_end(void *tok, hipStream_t st)
 static void prof_reset_locked()
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for(ProfTok *t : g_prof_done) {
-        (void)hipEventDestroy(t->e0), (void)hipEventDestroy(t->e1);
-        delete t;
+    for(std::vector<ProfTok *> *v : {&g_prof_done, &g_prof_free}) {
+        for(ProfTok *t : *v) {
+            (void)hipEventDestroy(t->e0), (void)hipEventDestroy(t->e1);
+            delete t;
+        }
+        v->clear();
     }
-    g_prof_done.clear();
     g_prof_mask.store(0);
     if(g_prof_units) (void)hipFree(g_prof_units), g_prof_units = nullptr;
 }
@@ -177,8 +192,8 @@ extern "C" int xeve_hip_prof_enable(int class_mask)
 {
     XH_ENTER();
     if(class_mask && !g_prof_units) {
-        XH_HIP(hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES));
-        XH_HIP(hipMemset(g_prof_units, 0, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES));
+        XH_HIP(hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES * XH_PROF_STRIPES));
+        XH_HIP(hipMemset(g_prof_units, 0, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES * XH_PROF_STRIPES));
     }
     g_prof_mask.store((unsigned)class_mask & ((1u << XEVE_HIP_PROF_CLASSES) - 1));
     return XEVE_HIP_OK;
@@ -195,14 +210,17 @@ extern "C" int xeve_hip_prof_read(double *ms, uint64_t *launches, uint64_t *unit
         for(ProfTok *k : g_prof_done) {
             float f = 0.f;
             if(hipEventElapsedTime(&f, k->e0, k->e1) == hipSuccess && k->cls >= 0 && k->cls < XEVE_HIP_PROF_CLASSES) t[k->cls] += f, c[k->cls]++;
-            (void)hipEventDestroy(k->e0), (void)hipEventDestroy(k->e1);
-            delete k;
+            g_prof_free.push_back(k);
         }
         g_prof_done.clear();
     }
     if(g_prof_units) {
-        XH_HIP(hipMemcpy(u, g_prof_units, sizeof(u), hipMemcpyDeviceToHost));
-        XH_HIP(hipMemset(g_prof_units, 0, sizeof(u)));
+        static unsigned long long raw[XEVE_HIP_PROF_CLASSES * XH_PROF_STRIPES];
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        XH_HIP(hipMemcpy(raw, g_prof_units, sizeof(raw), hipMemcpyDeviceToHost));
+        XH_HIP(hipMemset(g_prof_units, 0, sizeof(raw)));
+        for(int i = 0; i < XEVE_HIP_PROF_CLASSES; i++)
+            for(int k = 0; k < XH_PROF_STRIPES; k++) u[i] += raw[i * XH_PROF_STRIPES + k];
     }
     for(int i = 0; i < n; i++) {
         if(ms) ms[i] = t[i];

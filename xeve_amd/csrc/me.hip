@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_me_diamond(const pel *__restrict__ org0
         res = me_diamond<S, BI>(org, ref0, s_ref, jb, shift, P, lane, nullptr, units ? &nev : nullptr);
     }
     if(lane == 0) out[j] = res;
-    if(units && lane == 0) atomicAdd(units, (unsigned long long)nev * (S * S / 64));
+    if(units && lane == 0) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)nev * (S * S / 64));
 }
 
 extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref,
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         if(rc < s.cost) s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2);
     }
     if(lane == 0) st[j] = s;
-    if(units && lane == 0) atomicAdd(units, (unsigned long long)nev * (S * S / 64));
+    if(units && lane == 0) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)nev * (S * S / 64));
 }
 
 __global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj)

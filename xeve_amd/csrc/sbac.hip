@@ -502,7 +502,7 @@ __device__ __forceinline__ void code_block(Sbac &s, CtxTab s_ctx, int lane, cons
     const unsigned nb = hdr[0], nev = hdr[1];
     if(nb != BIN_OVF && nev == (unsigned)nnz) code_string<FULL>(s, s_ctx, lane, reinterpret_cast<const unsigned char *>(hdr) + BIN_HDR, (int)nb);
     else {
-        if(slow) atomicAdd(slow, 1ull); // measurement only: blocks coded from their event lists
+        if(slow) atomicAdd(XH_PROF_SLOT(slow), 1ull); // measurement only: blocks coded from their event lists
         code_events<FULL>(s, s_ctx, lane, ev + coef_off, (int)(nev < (unsigned)nnz ? nev : (unsigned)nnz), nnz, c != 0, cm_init);
     }
 }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
         const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
         if(first) *cnt = 0;
         atomicAdd(cnt, s.bins - (cont ? in.bin_counter : 0u));
-        if(first) atomicAdd(units, (unsigned long long)*cnt);
+        if(first) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)*cnt);
     }
     if(!FULL && sout) { // what feeds forward into later bit counts: the range and the models (xeve_sbac_bit_reset discards the rest but the
                         // low bits of the code register, and those never reach a bit count)
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
         const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);
         if(first) *cnt = 0;
         atomicAdd(cnt, total_bins);
-        if(first) atomicAdd(units, (unsigned long long)*cnt);
+        if(first) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)*cnt);
     }
 }
 

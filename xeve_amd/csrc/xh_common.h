@@ -42,7 +42,11 @@ enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3
 bool  xh_prof_on(int cls);
 void *xh_prof_begin(int cls, hipStream_t st);
 void  xh_prof_end(void *tok, hipStream_t st);
-unsigned long long *xh_prof_units(int cls); // device counter of the class, NULL while the timers are off
+// device counters of the class, NULL while the timers are off: XH_PROF_STRIPES words, a wave adds to word (its workgroup index & (XH_PROF_STRIPES - 1)) -- one
+// word for everybody serialised 259 000 same-address atomics per search launch (+5 ms per 4K step, measured)
+#define XH_PROF_STRIPES 256
+unsigned long long *xh_prof_units(int cls);
+#define XH_PROF_SLOT(units) ((units) + (blockIdx.x & (XH_PROF_STRIPES - 1)))
 struct XhProf {
     void       *tok;
     hipStream_t st;
