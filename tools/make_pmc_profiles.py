@@ -19,7 +19,7 @@ per = {}
 for k, v in ks.items():
     n = v["FETCH_SIZE"]["launches"]  # launches of this kernel in one step (one pass, one rep)
     d = v["_duration_ns"]["mean"] * 1e-9
-    row = {"launches_per_step": n, "avg_launch_us": round(d * 1e6, 1),
+    row = {"launches_in_run": n, "avg_launch_us": round(d * 1e6, 1),
            "hbm_bytes_x2": int(mean(v, "FETCH_SIZE") * 1024 * 2), "l2_read_bytes": int(mean(v, "TCP_TCC_READ_REQ_sum") * 64),
            "l2_hit_rate": round(mean(v, "TCC_HIT_sum") / max(1.0, mean(v, "TCC_HIT_sum") + mean(v, "TCC_MISS_sum")), 4),
            "waves": int(mean(v, "SQ_WAVES")), "valu_insts": int(mean(v, "SQ_INSTS_VALU")), "salu_insts": int(mean(v, "SQ_INSTS_SALU")),
@@ -34,7 +34,7 @@ out = {"what": "rocprofv3 --pmc passes (FETCH_SIZE | TCP_TCC_READ_REQ_sum TCC_HI
                "(tools/probe_step.py 1 --serial: 3840x2160 i.i.d. picture, the four levels one after the other on one stream); per-launch means of every k_me_epzs instantiation",
        "units": "FETCH_SIZE is reported in KiB and under-counts wide reads 2x on gfx950 (MI355X_MICROARCH.md, HBM): x 1024 x 2 = an upper bound of the HBM bytes; TCP_TCC_READ_REQ x 64 B = bytes the "
                 "vector L1s asked L2 for; SQ_*_CYCLES in quad-cycles",
-       "launches_per_step": tot["launches"], "avg_launch_s": tot["seconds"] / tot["launches"],
+       "launches_in_run": tot["launches"], "avg_launch_s": tot["seconds"] / tot["launches"],
        "hbm_bytes_per_launch_x2": int(tot["hbm_bytes_x2"] / tot["launches"]), "l2_read_bytes_per_launch": int(tot["l2_read_bytes"] / tot["launches"]),
        "per_kernel": per}
 json.dump(out, open("profiles/r02_search_pmc.json", "w"), indent=1)
