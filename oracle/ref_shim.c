@@ -436,6 +436,103 @@ static double shim_pintra_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
     return R.cost;
 }
 
+/* XEVE_SHIM_SHADOW_TREE=<path of libxeve_oracle.so>: SHADOW MODE for the CTU mode decision of I pictures (ctx->fn_mode_analyze_lcu = mode_analyze_lcu ->
+ * mode_coding_tree, xeve_mode.c:2007-2610).  Before the reference analyses a CTU the adapter snapshots what the walk reads (the picture being reconstructed, the
+ * unit maps, the entry coder state); after the reference has run it lets the oracle's restatement (xo_mode_analyze_ctu_intra) walk the same CTU on the snapshot
+ * and compares everything the walk produces: split modes, prediction modes, coded-block counts, unit maps, coefficients, reconstruction, exit coder state.  The
+ * encoder continues with the reference's own results; mismatches are counted and reported at exit.  CPU only: this pins the ORACLE against the live encoder. */
+#include "xeve_oracle.h"
+static double (*xo_tree)(const xo_pel *const *, int, int, xo_pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
+                         const xo_tree_params *, int, int, xo_ctu_data *, xo_sbac *);
+static int (*orig_mode_analyze_lcu)(XEVE_CTX *, XEVE_CORE *);
+static unsigned long long shadow_ctus, shadow_bad, shadow_skipped;
+
+static void sbac_to_flat(xo_sbac *h, const XEVE_SBAC *sb)
+{
+    memset(h, 0, sizeof(*h));
+    h->range = sb->range, h->code = sb->code, h->code_bits = sb->code_bits, h->stacked_ff = sb->stacked_ff, h->stacked_zero = sb->stacked_zero;
+    h->pending_byte = sb->pending_byte, h->is_pending_byte = sb->is_pending_byte, h->bitcounter = sb->bitcounter, h->bin_counter = sb->bin_counter;
+#define F(name, at, n) memcpy(h->ctx + at, sb->ctx.name, 2 * n);
+    SBAC_MAP(F)
+#undef F
+}
+
+static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
+{
+    const int L = ctx->log2_max_cuwh - 2, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
+    if(ctx->sh->slice_type != SLICE_I || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp ||
+       ctx->log2_max_cuwh != 6 || idc == 2 || ctx->param.threads != 1) {
+        shadow_skipped++;
+        return orig_mode_analyze_lcu(ctx, core);
+    }
+    XEVE_PIC *pm = PIC_MODE(ctx);
+    XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
+    const int nscu = ctx->w_scu * ctx->h_scu, hl = ctx->h, hc = ctx->h >> hs;
+    /* snapshot */
+    xo_pel *mod[3] = {malloc(sizeof(pel) * pm->s_l * (hl + 1)), malloc(sizeof(pel) * pm->s_c * (hc + 1)), malloc(sizeof(pel) * pm->s_c * (hc + 1))};
+    memcpy(mod[0], pm->y, sizeof(pel) * pm->s_l * hl), memcpy(mod[1], pm->u, sizeof(pel) * pm->s_c * hc), memcpy(mod[2], pm->v, sizeof(pel) * pm->s_c * hc);
+    uint32_t *m_scu = malloc(4 * nscu), *m_cum = malloc(4 * nscu);
+    int8_t   *m_ipm = malloc(nscu);
+    memcpy(m_scu, ctx->map_scu, 4 * nscu), memcpy(m_cum, ctx->map_cu_mode, 4 * nscu), memcpy(m_ipm, ctx->map_ipm, nscu);
+    xo_sbac entry, next, ref_next;
+    sbac_to_flat(&entry, &core->s_curr_best[L][L]);
+    const int x0 = core->x_pel, y0 = core->y_pel, lcu = core->lcu_num;
+
+    const int rc = orig_mode_analyze_lcu(ctx, core); /* the reference decides; its results stay */
+
+    xo_tree_params P;
+    memset(&P, 0, sizeof(P));
+    P.ip.w_scu = ctx->w_scu, P.ip.h_scu = ctx->h_scu, P.ip.slice_type = 2, P.ip.chroma_format_idc = idc, P.ip.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8;
+    P.ip.tool_iqt = 0, P.ip.constrained_intra_pred = ctx->pps.constrained_intra_pred_flag;
+    P.ip.qp[0] = core->qp_y, P.ip.qp[1] = core->qp_u, P.ip.qp[2] = core->qp_v; /* (mode_cu_init derives them from the tile QP: the same for every CU without delta QP) */
+    for(int c = 0; c < 3; c++) P.ip.lambda[c] = core->lambda[c];
+    P.ip.sqrt_lambda0 = core->sqrt_lambda[0], P.ip.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.max_cu = ctx->param.max_cu_intra, P.min_cu = ctx->param.min_cu_intra, P.min_cuwh = ctx->min_cuwh;
+    P.slice_qp = ctx->tile[core->tile_idx].qp, P.slice_num = ctx->slice_num;
+    static __thread xo_ctu_data out;
+    const xo_pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+    (void)xo_tree(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, x0, y0, &out, &next);
+
+    /* compare */
+    int bad = 0;
+    const XEVE_CU_DATA *cd = &ctx->map_cu_data[lcu];
+    const int nu = 16, wu = XEVE_MIN(nu, ctx->w_scu - (x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (y0 >> 2));
+#define BAD(what, ...) do { if(bad++ < 6 && shadow_bad < 6) fprintf(stderr, "[shadow] CTU %d (%d,%d): " what "\n", lcu, x0, y0, __VA_ARGS__); } while(0)
+    for(int j = 0; j < hu; j++)
+        for(int i = 0; i < wu; i++) {
+            const int u = j * nu + i;
+            for(int d = 0; d < XO_CU_DEPTHS; d++)
+                if(cd->split_mode[d][SQUARE][u] != out.split_mode[d][u]) BAD("split_mode[%d][%d] %d vs %d", d, u, cd->split_mode[d][SQUARE][u], out.split_mode[d][u]);
+            if(cd->pred_mode[u] != out.pred_mode[u]) BAD("pred_mode[%d] %d vs %d", u, cd->pred_mode[u], out.pred_mode[u]);
+            if(cd->ipm[0][u] != out.ipm[0][u] || (idc && cd->ipm[1][u] != out.ipm[1][u])) BAD("ipm[%d] %d,%d vs %d,%d", u, cd->ipm[0][u], cd->ipm[1][u], out.ipm[0][u], out.ipm[1][u]);
+            if(cd->depth[u] != out.depth[u]) BAD("depth[%d] %d vs %d", u, cd->depth[u], out.depth[u]);
+            for(int c = 0; c < (idc ? 3 : 1); c++)
+                if(cd->nnz[c][u] != out.nnz[c][u]) BAD("nnz[%d][%d] %d vs %d", c, u, cd->nnz[c][u], out.nnz[c][u]);
+            if(cd->map_scu[u] != out.map_scu[u]) BAD("map_scu[%d] %08x vs %08x", u, cd->map_scu[u], out.map_scu[u]);
+            if(cd->map_cu_mode[u] != out.map_cu_mode[u]) BAD("map_cu_mode[%d] %08x vs %08x", u, cd->map_cu_mode[u], out.map_cu_mode[u]);
+            const int g = ((y0 >> 2) + j) * ctx->w_scu + (x0 >> 2) + i;
+            if((ctx->map_scu[g] | (1u << 31)) != m_scu[g]) BAD("ctx->map_scu[%d] %08x vs %08x", g, ctx->map_scu[g], m_scu[g]);
+            if(ctx->map_ipm[g] != m_ipm[g]) BAD("ctx->map_ipm[%d] %d vs %d", g, ctx->map_ipm[g], m_ipm[g]);
+        }
+    for(int c = 0; c < (idc ? 3 : 1); c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, cs = 64 >> sx, w = (wu * 4) >> sx, h = (hu * 4) >> sy, s = c ? pm->s_c : pm->s_l;
+        const pel *pr = (c == 0 ? pm->y : c == 1 ? pm->u : pm->v) + (y0 >> sy) * s + (x0 >> sx);
+        const xo_pel *po = mod[c] + (y0 >> sy) * s + (x0 >> sx);
+        for(int yy = 0; yy < h; yy++)
+            for(int xx = 0; xx < w; xx++) {
+                if(cd->coef[c][yy * cs + xx] != out.coef[c][yy * cs + xx]) BAD("coef[%d] (%d,%d) %d vs %d", c, xx, yy, cd->coef[c][yy * cs + xx], out.coef[c][yy * cs + xx]);
+                if(cd->reco[c][yy * cs + xx] != out.reco[c][yy * cs + xx]) BAD("reco[%d] (%d,%d) %d vs %d", c, xx, yy, cd->reco[c][yy * cs + xx], out.reco[c][yy * cs + xx]);
+                if(pr[yy * s + xx] != po[yy * s + xx]) BAD("picture[%d] (%d,%d) %d vs %d", c, xx, yy, pr[yy * s + xx], po[yy * s + xx]);
+            }
+    }
+    sbac_to_flat(&ref_next, &core->s_next_best[L][L]);
+    if(memcmp(&ref_next, &next, sizeof(next))) BAD("exit coder state differs (range %u vs %u)", ref_next.range, next.range);
+    shadow_ctus++;
+    if(bad) shadow_bad++;
+    free(mod[0]), free(mod[1]), free(mod[2]), free(m_scu), free(m_cum), free(m_ipm);
+    return rc;
+}
+
 static void report(void)
 {
     if(hip_resident_stats) {
@@ -445,6 +542,7 @@ static void report(void)
     }
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
+    if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered)\n", shadow_ctus, shadow_bad, shadow_skipped);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
@@ -468,6 +566,13 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
             if(mc) ctx->pinter[i].me_complexity = atoi(mc);
             if(ml) ctx->pinter[i].me_level = atoi(ml);
         }
+    }
+    if(getenv("XEVE_SHIM_SHADOW_TREE") && ctx->fn_mode_analyze_lcu && ctx->fn_mode_analyze_lcu != shim_mode_analyze_lcu) {
+        void *oh = dlopen(getenv("XEVE_SHIM_SHADOW_TREE"), RTLD_NOW | RTLD_LOCAL);
+        if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
+        orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
+        fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
+        atexit(report);
     }
     const char *lib = getenv("XEVE_HIP_LIB");
     if(!lib) return; /* plain reference run */

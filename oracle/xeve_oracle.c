@@ -2100,3 +2100,199 @@ void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
 #undef LEFT
 #undef UP
 }
+
+/* ===================================================================================================================
+ * The mode decision of one CTU of an I picture: mode_analyze_lcu -> mode_coding_tree (src_base/xeve_mode.c:2007-2375, 2518-2610) with
+ * mode_coding_unit -> mode_check_intra -> pintra_analyze_cu at every node; Baseline quad-tree, no delta QP, rdo_dbk_switch 0.
+ * Every node: [the CU as a whole: split_cu_flag = 0 priced from the node's entry coder state, then the intra analysis] -- unless the CU is larger
+ * than max_cu_intra or crosses the picture edge -- then, unless the early-termination rule for I pictures fires, [split_cu_flag = 1 priced from the
+ * same entry state, the four quadrants in z order, each starting from the coder state its predecessor left]; the cheaper alternative's data, reconstruction
+ * and coder state are kept (a split must be cheaper by more than 0.0001).  The 4x4-unit maps and the picture being reconstructed are updated as the walk
+ * goes, because the next CU's neighbours are read from them: clear_map_scu (:1129), update_map_scu (:1036), mode_cpy_rec_to_ref (:797).
+ * =================================================================================================================== */
+typedef struct tree_ctx {
+    const xo_pel *const *org;
+    xo_pel *const       *mod;
+    int                  s_org_l, s_org_c, s_mod_l, s_mod_c;
+    uint32_t            *map_scu, *map_cu_mode;
+    int8_t              *map_ipm;
+    const uint8_t       *map_tidx;
+    const xo_tree_params *P;
+    xo_sbac              curr_best[5], next_best[5]; /* core->s_curr_best / s_next_best [log2 - 2][log2 - 2] */
+    xo_ctu_data         *best[5], *temp[5];          /* core->cu_data_best / cu_data_temp, node-local indexing (pitch = the node's size) */
+    int32_t              dist_cu_best;               /* core->dist_cu_best */
+} tree_ctx;
+
+static void cud_init(xo_ctu_data *d, int log2)
+{   /* init_cu_data (:374-428): what the I-slice walk reads back -- split modes and luma / chroma modes cleared */
+    const int n = 1 << (2 * (log2 - 2));
+    for(int k = 0; k < XO_CU_DEPTHS; k++) memset(d->split_mode[k], 0, n);
+    memset(d->ipm[0], 0, n), memset(d->ipm[1], 0, n);
+}
+/* copy_cu_data (:430-620): the sub-block (x, y; log2 size) of dst (pitch 1 << log2_cus) <- all of src, split modes from depth cud on */
+static void cud_copy(xo_ctu_data *dst, const xo_ctu_data *src, int x, int y, int log2, int log2_cus, int cud, int idc)
+{
+    const int ws = idc <= 2, hs = idc <= 1, n = 1 << (log2 - 2), cus = 1 << (log2_cus - 2), cw = 1 << log2, cs = 1 << log2_cus;
+    for(int j = 0; j < n; j++) {
+        const int di = ((y >> 2) + j) * cus + (x >> 2), si = j * n;
+        for(int k = cud; k < XO_CU_DEPTHS; k++) memcpy(dst->split_mode[k] + di, src->split_mode[k] + si, n);
+        memcpy(dst->pred_mode + di, src->pred_mode + si, n), memcpy(dst->ipm[0] + di, src->ipm[0] + si, n), memcpy(dst->ipm[1] + di, src->ipm[1] + si, n);
+        memcpy(dst->depth + di, src->depth + si, n);
+        memcpy(dst->map_scu + di, src->map_scu + si, 4 * n), memcpy(dst->map_cu_mode + di, src->map_cu_mode + si, 4 * n);
+        for(int c = 0; c < 3; c++) memcpy(dst->nnz[c] + di, src->nnz[c] + si, 4 * n);
+    }
+    for(int j = 0; j < cw; j++) {
+        memcpy(dst->coef[0] + (y + j) * cs + x, src->coef[0] + j * cw, 2 * cw);
+        memcpy(dst->reco[0] + (y + j) * cs + x, src->reco[0] + j * cw, 2 * cw);
+    }
+    if(idc)
+        for(int c = 1; c < 3; c++)
+            for(int j = 0; j < cw >> hs; j++) {
+                memcpy(dst->coef[c] + ((y >> hs) + j) * (cs >> ws) + (x >> ws), src->coef[c] + j * (cw >> ws), 2 * (cw >> ws));
+                memcpy(dst->reco[c] + ((y >> hs) + j) * (cs >> ws) + (x >> ws), src->reco[c] + j * (cw >> ws), 2 * (cw >> ws));
+            }
+}
+static void tree_clear_map(tree_ctx *T, int x, int y, int cu)
+{   /* clear_map_scu (:1129-1155) */
+    const xo_tree_params *P = T->P;
+    const int w = ((x + cu > P->pic_w ? P->pic_w - x : cu) >> 2), h = ((y + cu > P->pic_h ? P->pic_h - y : cu) >> 2);
+    for(int i = 0; i < h; i++) {
+        memset(T->map_scu + ((y >> 2) + i) * P->ip.w_scu + (x >> 2), 0, 4 * w);
+        memset(T->map_cu_mode + ((y >> 2) + i) * P->ip.w_scu + (x >> 2), 0, 4 * w);
+    }
+}
+static void tree_update_map(tree_ctx *T, const xo_ctu_data *d, int x, int y, int cu)
+{   /* update_map_scu (:1036-1127): the maps the intra analysis of later CUs reads */
+    const xo_tree_params *P = T->P;
+    const int w = ((x + cu > P->pic_w ? P->pic_w - x : cu) >> 2), h = ((y + cu > P->pic_h ? P->pic_h - y : cu) >> 2), n = cu >> 2;
+    for(int i = 0; i < h; i++) {
+        const int g = ((y >> 2) + i) * P->ip.w_scu + (x >> 2);
+        memcpy(T->map_scu + g, d->map_scu + i * n, 4 * w), memcpy(T->map_cu_mode + g, d->map_cu_mode + i * n, 4 * w);
+        memcpy(T->map_ipm + g, d->ipm[0] + i * n, w);
+    }
+}
+static void tree_rec_to_pic(tree_ctx *T, const xo_ctu_data *d, int x, int y, int cu)
+{   /* mode_cpy_rec_to_ref (:797-866) */
+    const xo_tree_params *P = T->P;
+    const int idc = P->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
+    const int w = x + cu > P->pic_w ? P->pic_w - x : cu, h = y + cu > P->pic_h ? P->pic_h - y : cu;
+    for(int j = 0; j < h; j++) memcpy(T->mod[0] + (size_t)(y + j) * T->s_mod_l + x, d->reco[0] + j * cu, 2 * w);
+    if(idc)
+        for(int c = 1; c < 3; c++)
+            for(int j = 0; j < h >> hs; j++) memcpy(T->mod[c] + (size_t)((y >> hs) + j) * T->s_mod_c + (x >> ws), d->reco[c] + j * (cu >> ws), 2 * (w >> ws));
+}
+static uint32_t tree_split_bits(const xo_sbac *from, xo_sbac *to, int split)
+{   /* SBAC_LOAD + xeve_sbac_bit_reset + xeve_eco_split_mode (xeve_eco.c:1377-1429; Baseline: one bin on split_cu_flag) + xeve_get_bit_number */
+    *to = *from;
+    xo_sbac_bit_reset(to);
+    xo_sbac_bin(to, XO_CTX_SPLIT_CU, split != 0);
+    return xo_sbac_bits(to);
+}
+
+static double tree_node(tree_ctx *T, int x0, int y0, int log2, int cud, int next_split)
+{
+    const xo_tree_params *P = T->P;
+    const int L = log2 - 2, cu = 1 << log2, idc = P->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
+    const int boundary = !(x0 + cu <= P->pic_w && y0 + cu <= P->pic_h);
+    const xo_sbac before_split = T->curr_best[L];
+    xo_sbac       temp_depth;
+    double        cost_best = 1.7e+308, cost_temp;
+    int           best_split = 0;
+    memset(&temp_depth, 0, sizeof(temp_depth));
+    if(!boundary) {
+        cost_temp = 0.0;
+        cud_init(T->temp[L], log2);
+        if(cu <= P->max_cu) {
+            if(cu > P->min_cuwh) { /* split_cu_flag = 0 (:2079-2091) */
+                xo_sbac run;
+                cost_temp += (double)(int)tree_split_bits(&T->curr_best[L], &run, 0) * P->ip.lambda[0];
+                T->curr_best[L] = run;
+            }
+            cud_init(T->temp[L], log2);
+            tree_clear_map(T, x0, y0, cu);
+            /* mode_coding_unit (:1310-1350) in an I slice: mode_cu_init + mode_check_intra -> the intra analysis always becomes the CU's mode */
+            xo_intra_params ip = P->ip;
+            ip.log2_cuw = ip.log2_cuh = log2;
+            xo_intra_job ij;
+            memset(&ij, 0, sizeof(ij));
+            ij.x = x0, ij.y = y0, ij.inter_satd = 0xFFFFFFFFu, ij.sbac = 0;
+            xo_intra_result ir;
+            xo_ctu_data    *t = T->temp[L];
+            const xo_pel *const mod_c[3] = {T->mod[0], T->mod[1], T->mod[2]};
+            xo_pintra_analyze_cu(T->org, T->s_org_l, T->s_org_c, mod_c, T->s_mod_l, T->s_mod_c, T->map_scu, T->map_ipm, T->map_tidx, &T->curr_best[L], &ip, &ij, &ir,
+                                 t->coef[0], t->coef[1], t->coef[2], t->reco[0], t->reco[1], t->reco[2], &T->next_best[L]);
+            T->dist_cu_best = ir.dist_cu;
+            /* copy_to_cu_data (:868-1034) for an intra CU */
+            for(int i = 0; i < 1 << (2 * L); i++) {
+                t->pred_mode[i] = 0 /* MODE_INTRA */, t->ipm[0][i] = ir.ipm[0], t->ipm[1][i] = idc ? ir.ipm[1] : 0, t->depth[i] = (int8_t)cud;
+                t->nnz[0][i] = ir.nnz[0], t->nnz[1][i] = idc ? ir.nnz[1] : 0, t->nnz[2][i] = idc ? ir.nnz[2] : 0;
+                t->map_scu[i]     = ((uint32_t)P->slice_num & 0x7F) | ((uint32_t)P->slice_qp << 16) | (1u << 15) | (1u << 31); /* MCU_SET_IF_COD_SN_QP, SF clear */
+                t->map_cu_mode[i] = ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);                                            /* MCU_SET_LOGW / LOGH */
+            }
+            (void)ws, (void)hs;
+            cost_temp += ir.cost;
+            if(cost_best > cost_temp) { /* (:2116-2135) */
+                cud_copy(T->best[L], t, 0, 0, log2, log2, cud, idc);
+                cost_best = cost_temp, best_split = 0, temp_depth = T->next_best[L];
+                tree_rec_to_pic(T, T->best[L], x0, y0, cu);
+            }
+            cost_temp = cost_best;
+        }
+        else cost_temp = 1.7e+308;
+    }
+    /* early termination in I pictures (:2174-2187) */
+    if(cost_best != 1.7e+308) {
+        const int dist_cu = T->dist_cu_best, th = 1 << (2 * log2 + 7);
+        if(dist_cu < th) {
+            const int bits_inc = (2 * log2 >= 6 ? 2 : 0) + 8;
+            if(dist_cu < P->ip.lambda[0] * bits_inc) next_split = 0;
+        }
+    }
+    if(cu > 4 && next_split && cu > P->min_cu && cu > P->min_cuwh) { /* SPLIT_QUAD (:2189-2329) */
+        xo_sbac run;
+        cud_init(T->temp[L], log2);
+        tree_clear_map(T, x0, y0, cu);
+        cost_temp = (double)(int)tree_split_bits(&before_split, &run, 1) * P->ip.lambda[0];
+        T->curr_best[L] = run;
+        cud_init(T->temp[L], log2);
+        tree_clear_map(T, x0, y0, cu);
+        const int half = cu >> 1;
+        int first = 1;
+        for(int part = 0; part < 4; part++) {
+            const int xp = x0 + (part & 1) * half, yp = y0 + (part >> 1) * half;
+            if(xp < P->pic_w && yp < P->pic_h) {
+                T->curr_best[L - 1] = part == 0 ? T->curr_best[L] : T->next_best[L - 1];
+                (void)first;
+                cost_temp += tree_node(T, xp, yp, log2 - 1, cud + 2, 1); /* a quad split counts as two binary levels (xeve_split_get_part_structure, xeve_util.c:1407-1410) */
+                cud_copy(T->temp[L], T->best[L - 1], xp - x0, yp - y0, log2 - 1, log2, cud, idc);
+                tree_update_map(T, T->best[L - 1], xp, yp, half);
+            }
+        }
+        if(cost_best - 0.0001 > cost_temp) {
+            cud_copy(T->best[L], T->temp[L], 0, 0, log2, log2, cud, idc);
+            cost_best = cost_temp, temp_depth = T->next_best[L - 1], best_split = 5 /* SPLIT_QUAD */;
+        }
+    }
+    tree_rec_to_pic(T, T->best[L], x0, y0, cu);
+    if(cu >= 8) T->best[L]->split_mode[cud][((cu >> 1) >> 2) * (cu >> 2) + ((cu >> 1) >> 2)] = (int8_t)best_split; /* xeve_set_split_mode (xeve_util.c:1148-1161), cup 0, pitch = the node */
+    T->next_best[L] = temp_depth;
+    return cost_best;
+}
+
+double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
+                                 int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
+                                 xo_ctu_data *out, xo_sbac *next_best)
+{
+    tree_ctx T;
+    memset(&T, 0, sizeof(T));
+    T.org = org, T.mod = mod, T.s_org_l = s_org_l, T.s_org_c = s_org_c, T.s_mod_l = s_mod_l, T.s_mod_c = s_mod_c;
+    T.map_scu = map_scu, T.map_ipm = map_ipm, T.map_tidx = map_tidx, T.map_cu_mode = map_cu_mode, T.P = P;
+    for(int l = 0; l < 5; l++) T.best[l] = calloc(1, sizeof(xo_ctu_data)), T.temp[l] = calloc(1, sizeof(xo_ctu_data));
+    const int L = P->log2_ctu - 2;
+    T.curr_best[L] = *entry;
+    const double cost = tree_node(&T, x0, y0, P->log2_ctu, 0, 1);
+    tree_update_map(&T, T.best[L], x0, y0, 1 << P->log2_ctu); /* update_to_ctx_map + update_map_scu (:2455-2516) */
+    *out = *T.best[L], *next_best = T.next_best[L];
+    for(int l = 0; l < 5; l++) free(T.best[l]), free(T.temp[l]);
+    return cost;
+}

@@ -436,6 +436,32 @@ void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
                           const int8_t *map_ipm, const uint8_t *map_tidx, const xo_sbac *states, const xo_intra_params *p, const xo_intra_job *job,
                           xo_intra_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *best);
 
+/* ---- the mode decision of one CTU of an I picture: mode_analyze_lcu -> mode_coding_tree (src_base/xeve_mode.c:2007-2375, 2518-2610), Baseline ---- */
+#define XO_CU_DEPTHS 10 /* cud = 0, 2, 4, 6, 8 for 64 .. 4 (a quad split counts as two levels): the rows of XEVE_CU_DATA.split_mode[][SQUARE][] the walk can touch */
+typedef struct xo_tree_params {
+    xo_intra_params ip;     /* what every CU's intra analysis gets (log2_cuw / log2_cuh are set per node) */
+    int32_t pic_w, pic_h;   /* ctx->w, ctx->h */
+    int32_t log2_ctu;       /* ctx->log2_max_cuwh */
+    int32_t max_cu, min_cu; /* ctx->param.max_cu_intra, min_cu_intra (samples) */
+    int32_t min_cuwh;       /* ctx->min_cuwh */
+    int32_t slice_qp, slice_num; /* ctx->tile[].qp (the QP field of map_scu), ctx->slice_num */
+    int32_t pad_;
+} xo_tree_params;
+typedef struct xo_ctu_data { /* the fields of XEVE_CU_DATA (xeve_type.h:573-617) an I-slice CTU carries; 4x4 units in raster order, pitch = the block's width in units */
+    int8_t   split_mode[XO_CU_DEPTHS][256]; /* [depth][unit]: shape SQUARE */
+    uint8_t  pred_mode[256];
+    int8_t   ipm[2][256], depth[256];
+    int32_t  nnz[3][256];
+    uint32_t map_scu[256], map_cu_mode[256];
+    int16_t  coef[3][64 * 64];
+    xo_pel   reco[3][64 * 64];
+} xo_ctu_data;
+/* mod (the picture being reconstructed), map_scu, map_ipm, map_cu_mode are read AND updated as the reference's walk updates them; on return they hold the CTU's
+ * decision (as after update_to_ctx_map + update_map_scu; the caller's reset of the coded flags, xeve_mode.c:2591-2607, is not applied).  Returns the CTU's cost. */
+double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
+                                 int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
+                                 xo_ctu_data *out, xo_sbac *next_best);
+
 #ifdef __cplusplus
 }
 #endif

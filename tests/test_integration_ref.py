@@ -282,3 +282,22 @@ def test_bitstream_identical_with_inter_and_intra_analysis_on_the_gpu(tmp_path, 
     me = re.search(r"CUs whose whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
     assert mi and me and int(mi.group(1)) > 300 and int(me.group(1)) > 300 and int(mi.group(2)) == 0, err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.parametrize("name,nctu", [("noise_allintra_medium", 8), ("moving_cif_allintra_fast", 60), ("tiny_ra_medium", 2)])
+def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu):
+    """xo_mode_analyze_ctu_intra (the I-picture mode_analyze_lcu -> mode_coding_tree walk, xeve_mode.c:2007-2610, restated in oracle/) runs BESIDE the unmodified
+    reference inside the live encoder (oracle/ref_shim.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every product of the
+    walk -- split flags, modes, depths, levels, reconstruction, the context maps, the picture and the coder state handed to the next CTU -- is compared
+    per CTU.  CPU only: this pins the oracle the device-side tree walk is checked against; moving_cif has partial CTUs at the right and bottom edges."""
+    from _libs import ORACLE_SO
+
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_SHADOW_TREE": ORACLE_SO})
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])  # the shadow run leaves the encode untouched
+    m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ", err)
+    assert m, err[-800:]
+    assert (int(m.group(1)), int(m.group(2))) == (nctu, 0), err[-1500:]
