@@ -52,7 +52,7 @@ uint64_t    xeve_hip_table_calls(void);
 uint64_t    xeve_hip_table_calls_main(void);
 /* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
  * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
- * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result (0 .. 26); -1 past the end.  For bindings in
+ * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result, _tree_params, _ctu_job, _ctu_data (0 .. 29); -1 past the end.  For bindings in
  * other languages to check their record layouts at load time (no GPU needed). */
 int         xeve_hip_sizeof(int i);
 
@@ -730,6 +730,51 @@ int xeve_hip_pintra_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_
                                     const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, const xeve_hip_sbac *state,
                                     const xeve_hip_intra_params *params, const xeve_hip_intra_job *job, xeve_hip_intra_result *result, int16_t *coef_y, int16_t *coef_u,
                                     int16_t *coef_v, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_sbac *best);
+
+/* ------------------------------------------------------------------------------------------- */
+/* The mode decision of a batch of CTUs of I pictures: mode_analyze_lcu -> mode_coding_tree          */
+/* (src_base/xeve_mode.c:2007-2375, 2518-2610) = ctx->fn_mode_analyze_lcu for an I slice, on the device.*/
+/* Baseline quad-tree, no delta QP, rdo_dbk_switch 0.  Every chain (one CTU of one picture) walks its */
+/* tree in the reference's order -- the CU as a whole (split_cu_flag = 0 + the intra analysis above), */
+/* the early-termination rule of I pictures, the four quadrants (split_cu_flag = 1), the cheaper one   */
+/* kept -- updating the picture being reconstructed and the 4x4-unit maps as it goes (clear_map_scu     */
+/* :1129, copy_to_cu_data :868, update_map_scu :1036, mode_cpy_rec_to_ref :797), because the next CU's   */
+/* neighbours are read from them.  Chains of one call must not overlap (different pictures, or CTUs   */
+/* that are not neighbours); they advance in lockstep, one batched intra analysis per tree node.       */
+/* ------------------------------------------------------------------------------------------- */
+#define XEVE_HIP_CU_DEPTHS 10 /* cud = 0, 2, .. 8 for 64 .. 4 (a quad split counts as two levels, xeve_util.c:1407-1410): rows of XEVE_CU_DATA.split_mode[][SQUARE][] */
+typedef struct xeve_hip_tree_params {
+    xeve_hip_intra_params ip;   /* what every CU's intra analysis gets (log2_cuw / log2_cuh are set per node) */
+    int32_t pic_w, pic_h;       /* ctx->w, ctx->h */
+    int32_t log2_ctu;           /* ctx->log2_max_cuwh (3 .. 6) */
+    int32_t max_cu, min_cu;     /* ctx->param.max_cu_intra, min_cu_intra (samples) */
+    int32_t min_cuwh;           /* ctx->min_cuwh */
+    int32_t slice_qp, slice_num;/* ctx->tile[].qp (the QP field of map_scu), ctx->slice_num */
+    int32_t pad_;
+} xeve_hip_tree_params;
+typedef struct xeve_hip_ctu_job {
+    int32_t x, y;   /* core->x_pel, core->y_pel */
+    int32_t sbac;   /* index of core->s_curr_best[log2_max_cuwh - 2][log2_max_cuwh - 2] in `states` */
+    int32_t pic;    /* picture of a multi-picture batch (0 with pic_elems == NULL) */
+} xeve_hip_ctu_job;
+typedef struct xeve_hip_ctu_data { /* the fields of XEVE_CU_DATA (xeve_type.h:573-617) an I-slice CTU carries; 4x4 units in raster order, pitch = the CTU's width in units */
+    int8_t   split_mode[XEVE_HIP_CU_DEPTHS][256]; /* [depth][unit], shape SQUARE */
+    uint8_t  pred_mode[256];
+    int8_t   ipm[2][256], depth[256];
+    int32_t  nnz[3][256];
+    uint32_t map_scu[256], map_cu_mode[256];
+    int16_t  coef[3][64 * 64];
+    xeve_hip_pel reco[3][64 * 64];
+} xeve_hip_ctu_data;
+/* org / mod: HOST arrays of three device pointers at sample (0, 0); mod (PIC_MODE(ctx)), map_scu, map_ipm, map_cu_mode are read AND updated; on return
+ * they hold the CTUs' decisions as after update_to_ctx_map + update_map_scu (the caller's reset of the coded flags, xeve_mode.c:2591-2607, is not applied).
+ * pic_elems as in xeve_hip_pintra_analyze_cu_jobs (map_cu_mode strides like map_scu).  states, jobs, out, next_best (core->s_next_best[..][..]), cost
+ * (the tree's cost), workspace: device. */
+size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *params);
+int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                         uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
+                                         const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,
+                                         xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

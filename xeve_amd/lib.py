@@ -56,6 +56,15 @@ class IntraParams(C.Structure):  # xeve_hip_intra_params
                 ("lambda_", C.c_double * 3), ("sqrt_lambda0", C.c_double), ("dist_chroma_weight", C.c_double * 2)]
 
 
+class TreeParams(C.Structure):  # xeve_hip_tree_params
+    _fields_ = [("ip", IntraParams), ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("log2_ctu", C.c_int32), ("max_cu", C.c_int32), ("min_cu", C.c_int32),
+                ("min_cuwh", C.c_int32), ("slice_qp", C.c_int32), ("slice_num", C.c_int32), ("pad_", C.c_int32)]
+
+
+CU_DEPTHS = 10  # XEVE_HIP_CU_DEPTHS
+CTU_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("sbac", "<i4"), ("pic", "<i4")]  # xeve_hip_ctu_job (16 B)
+CTU_DATA_DTYPE = [("split_mode", "i1", (CU_DEPTHS, 256)), ("pred_mode", "u1", (256,)), ("ipm", "i1", (2, 256)), ("depth", "i1", (256,)), ("nnz", "<i4", (3, 256)),
+                  ("map_scu", "<u4", (256,)), ("map_cu_mode", "<u4", (256,)), ("coef", "<i2", (3, 4096)), ("reco", "<i2", (3, 4096))]  # xeve_hip_ctu_data (57856 B)
 INTRA_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("inter_satd", "<u4"), ("sbac", "<i4"), ("pic", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"),
                    ("pad_", "u1", (2,))]  # xeve_hip_intra_job (24 B)
 INTRA_RESULT_DTYPE = [("cost", "<f8"), ("dist_cu", "<i4"), ("nnz", "<i4", (3,)), ("pred_cnt", "<i4"), ("ipm", "i1", (2,)), ("pad_", "i1", (2,))]  # xeve_hip_intra_result (32 B)
@@ -180,6 +189,9 @@ FUNCTIONS = {
     "xeve_hip_pintra_analyze_cu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 5 +
                                         [C.c_size_t, c_void_p]),
     "xeve_hip_pintra_analyze_cu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 14),
+    "xeve_hip_mode_analyze_ctu_intra_workspace": (C.c_size_t, [c_int, c_void_p]),
+    "xeve_hip_mode_analyze_ctu_intra_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4 +
+                                             [C.c_size_t, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
