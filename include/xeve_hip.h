@@ -775,6 +775,13 @@ int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,
                                          xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace, size_t workspace_bytes, void *stream);
+/* Host-memory form of ONE call of ctx->fn_mode_analyze_lcu in an I slice (one host<->device exchange per CTU): every pointer is HOST memory -- org / mod =
+ * sample (0, 0) of the original picture's planes and of PIC_MODE(ctx) with their strides, the maps = ctx->map_scu / map_ipm / map_tidx / map_cu_mode, entry =
+ * core->s_curr_best[log2_max_cuwh - 2][log2_max_cuwh - 2], (x0, y0) = core->x_pel, y_pel.  Moves the CTU, one unit to its left and above and the CTU's width
+ * to its right (clipped to the picture); writes the CTU's reconstruction and map entries back, out = what the walk leaves in core->cu_data_best[..][..]. */
+int xeve_hip_mode_analyze_ctu_intra_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                         uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
+                                         const xeve_hip_tree_params *params, int x0, int y0, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost);
 
 #ifdef __cplusplus
 }

@@ -498,11 +498,14 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     const XEVE_CU_DATA *cd = &ctx->map_cu_data[lcu];
     const int nu = 16, wu = XEVE_MIN(nu, ctx->w_scu - (x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (y0 >> 2));
 #define BAD(what, ...) do { if(bad++ < 6 && shadow_bad < 6) fprintf(stderr, "[shadow] CTU %d (%d,%d): " what "\n", lcu, x0, y0, __VA_ARGS__); } while(0)
+    /* split modes: every unit of the CTU -- the flag of a node the picture edge cuts sits at the node's centre, which may lie outside the picture, and the
+     * bitstream writer reads it there (xeve_get_split_mode, xeve_util.c:1125-1144) */
+    for(int u = 0; u < nu * nu; u++)
+        for(int d = 0; d < XO_CU_DEPTHS; d++)
+            if(cd->split_mode[d][SQUARE][u] != out.split_mode[d][u]) BAD("split_mode[%d][%d] %d vs %d", d, u, cd->split_mode[d][SQUARE][u], out.split_mode[d][u]);
     for(int j = 0; j < hu; j++)
         for(int i = 0; i < wu; i++) {
             const int u = j * nu + i;
-            for(int d = 0; d < XO_CU_DEPTHS; d++)
-                if(cd->split_mode[d][SQUARE][u] != out.split_mode[d][u]) BAD("split_mode[%d][%d] %d vs %d", d, u, cd->split_mode[d][SQUARE][u], out.split_mode[d][u]);
             if(cd->pred_mode[u] != out.pred_mode[u]) BAD("pred_mode[%d] %d vs %d", u, cd->pred_mode[u], out.pred_mode[u]);
             if(cd->ipm[0][u] != out.ipm[0][u] || (idc && cd->ipm[1][u] != out.ipm[1][u])) BAD("ipm[%d] %d,%d vs %d,%d", u, cd->ipm[0][u], cd->ipm[1][u], out.ipm[0][u], out.ipm[1][u]);
             if(cd->depth[u] != out.depth[u]) BAD("depth[%d] %d vs %d", u, cd->depth[u], out.depth[u]);
@@ -533,6 +536,110 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     return rc;
 }
 
+
+/* XEVE_HIP_SHIM_TREE=1 (with XEVE_HIP_LIB): ROUTE MODE for the CTU mode decision of I pictures -- ctx->fn_mode_analyze_lcu served by the device-side tree walk
+ * (xeve_hip_mode_analyze_ctu_intra_host): ONE host<->device exchange per CTU instead of one per CU.  The adapter hands over what the walk reads (the original,
+ * the picture being reconstructed, the unit maps, the entry coder state) and stores what mode_analyze_lcu leaves behind (xeve_mode.c:2518-2610): the CTU's
+ * XEVE_CU_DATA in ctx->map_cu_data (copy_to_cu_data's fields for an intra CU, :868-1034), the context maps (update_to_ctx_map :2445-2516 + update_map_scu
+ * :1036-1127), the reconstruction in PIC_MODE, the coded flags reset (:2591-2607).  XEVE_SHIM_TREE_ORACLE=<path of libxeve_oracle.so> runs the same adapter with
+ * the oracle's restatement as the engine: CPU only, to test the adapter's stores without a GPU. */
+typedef int (*hip_tree_host_fn)(const pel *const *, int, int, pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
+                                const xo_tree_params *, int, int, xo_ctu_data *, xo_sbac *, double *);
+static hip_tree_host_fn hip_tree_host;
+static int               tree_engine_oracle;
+static unsigned long long tree_calls, tree_fallbacks;
+static double             tree_seconds;
+
+static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
+{
+    const int L = ctx->log2_max_cuwh - 2, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
+    if(ctx->sh->slice_type != SLICE_I || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp ||
+       ctx->log2_max_cuwh > 6 || ctx->log2_max_cuwh < 3 || idc == 2) {
+        __sync_fetch_and_add(&tree_fallbacks, 1);
+        return orig_mode_analyze_lcu(ctx, core);
+    }
+    XEVE_PIC    *pm = PIC_MODE(ctx);
+    XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
+    XEVE_MODE   *mi = &ctx->mode[core->thread_cnt];
+    memset(mi->mvp_idx, 0, sizeof(u8) * REFP_NUM), memset(mi->mvd, 0, sizeof(s16) * REFP_NUM * MV_D);
+    /* what mode_cu_init (:1157-1220) derives for every CU of the slice when there is no delta QP */
+    core->qp = ctx->tile[core->tile_idx].qp;
+    core->qp_y = GET_LUMA_QP(core->qp, ctx->sps.bit_depth_luma_minus8);
+    {
+        const int qp_i_cb = XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_u_offset);
+        const int qp_i_cr = XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_v_offset);
+        core->qp_u = ctx->qp_chroma_dynamic[0][qp_i_cb] + 6 * ctx->sps.bit_depth_chroma_minus8;
+        core->qp_v = ctx->qp_chroma_dynamic[1][qp_i_cr] + 6 * ctx->sps.bit_depth_chroma_minus8;
+    }
+    xo_tree_params P;
+    memset(&P, 0, sizeof(P));
+    P.ip.w_scu = ctx->w_scu, P.ip.h_scu = ctx->h_scu, P.ip.slice_type = 2, P.ip.chroma_format_idc = idc, P.ip.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8;
+    P.ip.tool_iqt = 0, P.ip.constrained_intra_pred = ctx->pps.constrained_intra_pred_flag;
+    P.ip.qp[0] = core->qp_y, P.ip.qp[1] = core->qp_u, P.ip.qp[2] = core->qp_v;
+    for(int c = 0; c < 3; c++) P.ip.lambda[c] = core->lambda[c];
+    P.ip.sqrt_lambda0 = core->sqrt_lambda[0], P.ip.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.max_cu = ctx->param.max_cu_intra, P.min_cu = ctx->param.min_cu_intra, P.min_cuwh = ctx->min_cuwh;
+    P.slice_qp = ctx->tile[core->tile_idx].qp, P.slice_num = ctx->slice_num;
+    static __thread xo_ctu_data out;
+    xo_sbac entry, next;
+    sbac_to_flat(&entry, &core->s_curr_best[L][L]);
+    const int  x0 = core->x_pel, y0 = core->y_pel;
+    const pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+    pel       *mod[3] = {pm->y, pm->u, pm->v};
+    double     cost = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if(tree_engine_oracle) cost = xo_tree((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, x0, y0, &out, &next);
+    else if(hip_tree_host(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, x0, y0, &out, &next, &cost) != 0) {
+        fprintf(stderr, "[xeve_hip_shim] xeve_hip_mode_analyze_ctu_intra_host: %s\n", hip_err ? hip_err() : "?");
+        abort();
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    (void)cost;
+    /* the CTU's data for the entropy coder (xeve_eco_tree -> xeve_eco_unit reads ctx->map_cu_data[lcu_num]) */
+    XEVE_CU_DATA *cd = &ctx->map_cu_data[core->lcu_num];
+    const int nu = 1 << L, ctu = 1 << ctx->log2_max_cuwh, wu = XEVE_MIN(nu, ctx->w_scu - (x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (y0 >> 2));
+    for(int u = 0; u < nu * nu; u++) /* (every unit: the flag of a node the picture edge cuts sits at the node's centre, possibly outside the picture) */
+        for(int d = 0; d < XO_CU_DEPTHS; d++) cd->split_mode[d][SQUARE][u] = out.split_mode[d][u];
+    for(int j = 0; j < hu; j++)
+        for(int i = 0; i < wu; i++) {
+            const int u = j * nu + i, g = ((y0 >> 2) + j) * ctx->w_scu + (x0 >> 2) + i;
+            cd->pred_mode[u] = out.pred_mode[u], cd->pred_mode_chroma[u] = out.pred_mode[u], cd->skip_flag[u] = 0, cd->mmvd_flag[u] = 0, cd->affine_flag[u] = 0;
+            cd->ipm[0][u] = out.ipm[0][u], cd->ipm[1][u] = out.ipm[1][u], cd->depth[u] = out.depth[u];
+            cd->qp_y[u] = core->qp_y, cd->qp_u[u] = core->qp_u, cd->qp_v[u] = core->qp_v;
+            for(int c = 0; c < N_C; c++) {
+                cd->nnz[c][u] = out.nnz[c][u];
+                cd->nnz_sub[c][0][u] = out.nnz[c][u], cd->nnz_sub[c][1][u] = cd->nnz_sub[c][2][u] = cd->nnz_sub[c][3][u] = 0; /* one transform block per CU up to 64x64 */
+            }
+            cd->map_scu[u] = out.map_scu[u], cd->map_cu_mode[u] = out.map_cu_mode[u];
+            memset(cd->mv[u], 0, sizeof(cd->mv[u])), memset(cd->unrefined_mv[u], 0, sizeof(cd->unrefined_mv[u]));
+            cd->refi[u][REFP_0] = cd->refi[u][REFP_1] = -1;
+            /* the context maps the walk does not carry: motion of an intra unit, depth (update_map_scu); then the coded flag reset */
+            memset(ctx->map_mv[g], 0, sizeof(ctx->map_mv[g])), memset(ctx->map_unrefined_mv[g], 0, sizeof(ctx->map_unrefined_mv[g]));
+            ctx->map_refi[g][REFP_0] = ctx->map_refi[g][REFP_1] = -1;
+            ctx->map_depth[g] = out.depth[u];
+            MCU_CLR_COD(ctx->map_scu[g]);
+        }
+    for(int c = 0; c < (idc ? 3 : 1); c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, cs = ctu >> sx, w = (wu * 4) >> sx, h = (hu * 4) >> sy;
+        for(int yy = 0; yy < h; yy++) {
+            memcpy(cd->coef[c] + yy * cs, out.coef[c] + yy * cs, sizeof(s16) * w);
+            memcpy(cd->reco[c] + yy * cs, out.reco[c] + yy * cs, sizeof(pel) * w);
+        }
+    }
+    /* core->s_next_best[L][L]: the coder state of the winner (the next CTU starts from the bitstream writer's own state, xeve_enc.c:139, not from this one) */
+    XEVE_SBAC *nb = &core->s_next_best[L][L];
+    *nb = core->s_curr_best[L][L];
+    nb->range = next.range, nb->code = next.code, nb->code_bits = next.code_bits, nb->stacked_ff = next.stacked_ff, nb->stacked_zero = next.stacked_zero;
+    nb->pending_byte = next.pending_byte, nb->is_pending_byte = next.is_pending_byte, nb->bitcounter = next.bitcounter, nb->bin_counter = next.bin_counter;
+#define F(name, at, n) memcpy(nb->ctx.name, next.ctx + at, 2 * n);
+    SBAC_MAP(F)
+#undef F
+    __sync_fetch_and_add(&tree_calls, 1);
+    tree_seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec); /* (per-thread sums would be exact; this is a report line) */
+    return XEVE_OK;
+}
+
 static void report(void)
 {
     if(hip_resident_stats) {
@@ -542,6 +649,7 @@ static void report(void)
     }
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
+    if(tree_calls || tree_fallbacks) fprintf(stderr, "[xeve_hip_shim] CTUs whose whole mode decision ran on the %s: %llu (left to the reference: %llu), %.1f ms per CTU\n", tree_engine_oracle ? "oracle (CPU)" : "GPU", tree_calls, tree_fallbacks, tree_calls ? 1e3 * tree_seconds / (double)tree_calls : 0.0);
     if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered)\n", shadow_ctus, shadow_bad, shadow_skipped);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
@@ -572,6 +680,13 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
         fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
+        atexit(report);
+    }
+    if(getenv("XEVE_SHIM_TREE_ORACLE") && ctx->fn_mode_analyze_lcu && ctx->fn_mode_analyze_lcu != shim_route_mode_analyze_lcu) {
+        void *oh = dlopen(getenv("XEVE_SHIM_TREE_ORACLE"), RTLD_NOW | RTLD_LOCAL);
+        if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] tree route (oracle engine): %s\n", dlerror()); abort(); }
+        orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_route_mode_analyze_lcu, tree_engine_oracle = 1;
+        fprintf(stderr, "[xeve_hip_shim] CTU mode decision of I pictures served by the ORACLE through the route adapter (CPU test of the adapter)\n");
         atexit(report);
     }
     const char *lib = getenv("XEVE_HIP_LIB");
@@ -635,6 +750,12 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         if(!hip_intra_host) { fprintf(stderr, "[xeve_hip_shim] intra-analysis entry point missing\n"); abort(); }
         orig_pintra_analyze_cu = ctx->fn_pintra_analyze_cu, ctx->fn_pintra_analyze_cu = shim_pintra_analyze_cu;
         fprintf(stderr, "[xeve_hip_shim] intra analysis of a CU routed to the GPU\n");
+    }
+    if(getenv("XEVE_HIP_SHIM_TREE") && atoi(getenv("XEVE_HIP_SHIM_TREE")) && ctx->fn_mode_analyze_lcu) {
+        hip_tree_host = (hip_tree_host_fn)dlsym(h, "xeve_hip_mode_analyze_ctu_intra_host"), hip_err = err;
+        if(!hip_tree_host) { fprintf(stderr, "[xeve_hip_shim] CTU tree-walk entry point missing\n"); abort(); }
+        orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_route_mode_analyze_lcu;
+        fprintf(stderr, "[xeve_hip_shim] CTU mode decision of I pictures routed to the GPU (one exchange per CTU)\n");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

@@ -87,7 +87,7 @@ def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500):
 
 
 def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, df=False, me=False, tq=False, eco=False, mc=False, inter=False, shim_env=None, resident=False, tables=True,
-            intra=False):
+            intra=False, tree=False):
     cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     if seek is not None:
         cmd += ["--seek", str(seek)]
@@ -106,6 +106,8 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
                 env["XEVE_HIP_SHIM_RESIDENT"] = "1"  # planes uploaded once per picture (xeve_hip_picture_begin from ctx->fn_mode_analyze_frame)
         if intra:
             env["XEVE_HIP_SHIM_INTRA"] = "1"  # the intra analysis of a CU (ctx->fn_pintra_analyze_cu)
+        if tree:
+            env["XEVE_HIP_SHIM_TREE"] = "1"  # the whole mode decision of an I-picture CTU (ctx->fn_mode_analyze_lcu): one exchange per CTU
         if mc:
             env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:

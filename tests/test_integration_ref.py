@@ -301,3 +301,36 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu)
     m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ", err)
     assert m, err[-800:]
     assert (int(m.group(1)), int(m.group(2))) == (nctu, 0), err[-1500:]
+
+
+@needs_ref
+@pytest.mark.parametrize("name,nctu,left", [("noise_allintra_medium", 8, 0), ("cfg1_cif_allintra_fast", 240, 0), ("tiny_ldb_fast_2threads", 4, 4)])
+def test_route_adapter_of_the_ctu_mode_decision_with_the_oracle_as_engine(tmp_path, name, nctu, left):
+    """the adapter that serves ctx->fn_mode_analyze_lcu from an external tree walk (oracle/ref_shim.c, shim_route_mode_analyze_lcu: what it hands over and what it
+    stores back into ctx->map_cu_data, the context maps and PIC_MODE) run with the ORACLE's walk as the engine: the bitstream must not change.  CPU only -- this
+    tests the adapter (test infrastructure); the same adapter with the GPU as the engine is the gpu test below."""
+    from _libs import ORACLE_SO
+
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_TREE_ORACLE": ORACLE_SO})
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+    m = re.search(r"mode decision ran on the oracle \(CPU\): (\d+) \(left to the reference: (\d+)\)", err)
+    assert m and (int(m.group(1)), int(m.group(2))) == (nctu, left), err[-800:]
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nctu", [("noise_allintra_medium", 8), ("moving_cif_allintra_fast", 60), ("tiny_ra_medium", 2), ("tiny_ldb_fast_2threads", 4)])
+def test_bitstream_identical_with_the_ctu_mode_decision_on_the_gpu(tmp_path, name, nctu):
+    """ctx->fn_mode_analyze_lcu of every I-picture CTU served by the device-side tree walk (xeve_hip_mode_analyze_ctu_intra_host): ONE exchange per CTU -- the CU
+    loop, the split decisions, the map and picture updates all happen on the device -- and the bitstream is byte-identical.  P / B pictures stay with the reference
+    (their CTUs are counted as left to it)."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, hip=True, tables=False, tree=True)
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+    m = re.search(r"mode decision ran on the GPU: (\d+) \(left", err)
+    assert m and int(m.group(1)) == nctu, err[-800:]

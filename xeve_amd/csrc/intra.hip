@@ -402,44 +402,6 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
 // ctx->map_scu / map_ipm / map_tidx.  Only what the analysis reads is moved: the CU's block of the original, the line above and the column left of the CU in the
 // mode picture (cuw + cuh samples each, clipped to the picture), the map entries of the 4x4 units those samples lie in.  They are laid out as a small local
 // picture (the CU at unit (1, 1), or on the edge where the real CU is on the picture's edge) so that the batched entry point runs unchanged on it.
-namespace {
-struct IntraHostCtx {
-    uint32_t    gen = 0;
-    hipStream_t st  = nullptr;
-    char       *dev = nullptr, *pin = nullptr;
-    size_t      dev_bytes = 0, pin_bytes = 0;
-    void release()
-    {
-        if(st) (void)hipStreamDestroy(st);
-        if(dev) (void)hipFree(dev);
-        if(pin) (void)hipHostFree(pin);
-        st = nullptr, dev = pin = nullptr, dev_bytes = pin_bytes = 0;
-    }
-    int ensure(size_t io_bytes, size_t ws_bytes)
-    {
-        if(gen != xh_generation()) release(), gen = xh_generation(); // the library was shut down or re-bound since
-        if(!st) XH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        if(pin_bytes < io_bytes) {
-            if(pin) (void)hipHostFree(pin);
-            pin = nullptr, pin_bytes = 0;
-            XH_HIP(hipHostMalloc((void **)&pin, io_bytes + (io_bytes >> 1), hipHostMallocDefault));
-            pin_bytes = io_bytes + (io_bytes >> 1);
-        }
-        const size_t need = io_bytes + 256 + ws_bytes;
-        if(dev_bytes < need) {
-            if(dev) {
-                XH_HIP(hipStreamSynchronize(st));
-                (void)hipFree(dev);
-                dev = nullptr, dev_bytes = 0;
-            }
-            XH_HIP(hipMalloc((void **)&dev, need + (need >> 2)));
-            dev_bytes = need + (need >> 2);
-        }
-        return XEVE_HIP_OK;
-    }
-    ~IntraHostCtx() { release(); }
-};
-} // namespace
 
 extern "C" int xeve_hip_pintra_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                                const uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, const xeve_hip_sbac *state,
@@ -467,7 +429,7 @@ extern "C" int xeve_hip_pintra_analyze_cu_host(const xeve_hip_pel *const org[3],
     xeve_hip_intra_params pl = *p;
     pl.w_scu = Wl, pl.h_scu = Hl;
     const size_t wsb = xeve_hip_pintra_analyze_cu_workspace(1, 1, &pl);
-    static thread_local IntraHostCtx C;
+    static thread_local XhHostArena C;
     int rc = C.ensure(io_bytes, wsb);
     if(rc != XEVE_HIP_OK) return rc;
     char *H = C.pin, *D = C.dev;

@@ -489,3 +489,82 @@ extern "C" int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const or
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// ---- host-memory form of ONE call of ctx->fn_mode_analyze_lcu in an I slice (stage, launch, synchronise: one exchange per CTU) --------------------------------
+// Every pointer is HOST memory: org / mod = sample (0, 0) of the original picture's planes and of the picture being reconstructed, the maps = ctx->map_scu / map_ipm /
+// map_tidx / map_cu_mode.  What the walk reads is moved as a small LOCAL PICTURE: the CTU, one unit to its left and above (none on the picture's edge), and the
+// CTU's width again to the right (the samples up-right of its CUs); the picture's own right / bottom edge stays an edge, so a CTU the picture cuts is cut the
+// same way.  The CTU's part of the reconstruction and of the maps is written back.
+extern "C" int xeve_hip_mode_analyze_ctu_intra_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                                    uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
+                                                    const xeve_hip_tree_params *p, int x0, int y0, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost)
+{
+    XH_ENTER();
+    XH_REQUIRE(org && mod && map_scu && map_ipm && map_tidx && map_cu_mode && entry && out && next_best && cost && tree_params_ok(p));
+    const int idc = p->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, ctu = 1 << p->log2_ctu, n = ctu >> 2;
+    XH_REQUIRE(org[0] && mod[0] && (!idc || (org[1] && org[2] && mod[1] && mod[2])));
+    XH_REQUIRE(x0 >= 0 && y0 >= 0 && x0 < p->pic_w && y0 < p->pic_h && (x0 & (ctu - 1)) == 0 && (y0 & (ctu - 1)) == 0);
+    const int x_scu = x0 >> 2, y_scu = y0 >> 2, lx = x_scu > 0, ly = y_scu > 0, nw = std::min(2 * n, p->ip.w_scu - x_scu), nh = std::min(n, p->ip.h_scu - y_scu);
+    const int Wl = lx + nw, Hl = ly + nh, cw = std::min(n, p->ip.w_scu - x_scu); // cw x nh units: the CTU's part inside the picture
+    const size_t nmap = (size_t)Wl * Hl;
+    const int    pw[3] = {Wl * 4, Wl * (4 >> ws), Wl * (4 >> ws)}, ph[3] = {Hl * 4, Hl * (4 >> hs), Hl * (4 >> hs)};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 63) & ~(size_t)63; return at; };
+    xeve_hip_ctu_job jl;
+    jl.x = 4 * lx, jl.y = 4 * ly, jl.sbac = 0, jl.pic = 0;
+    const size_t o_job = take(sizeof(jl)), o_st = take(sizeof(*entry)), o_tidx = take(nmap);
+    size_t o_org[3] = {0, 0, 0};
+    for(int c = 0; c < ncomp; c++) o_org[c] = take((size_t)pw[c] * ph[c] * 2);
+    const size_t o_scu = take(nmap * 4), o_ipm = take(nmap), o_cum = take(nmap * 4); // from here on the buffers come back too
+    size_t o_mod[3] = {0, 0, 0};
+    for(int c = 0; c < ncomp; c++) o_mod[c] = take((size_t)pw[c] * ph[c] * 2);
+    const size_t in_bytes = o;
+    const size_t o_out = take(sizeof(*out)), o_next = take(sizeof(*next_best)), o_cost = take(sizeof(double));
+    const size_t io_bytes = o;
+    xeve_hip_tree_params pl = *p;
+    pl.ip.w_scu = Wl, pl.ip.h_scu = Hl, pl.pic_w = Wl * 4, pl.pic_h = Hl * 4;
+    const size_t wsb = xeve_hip_mode_analyze_ctu_intra_workspace(1, &pl);
+    XH_REQUIRE(wsb > 0);
+    static thread_local XhHostArena C;
+    int rc = C.ensure(io_bytes, wsb);
+    if(rc != XEVE_HIP_OK) return rc;
+    char *H = C.pin, *D = C.dev;
+    memcpy(H + o_job, &jl, sizeof(jl)), memcpy(H + o_st, entry, sizeof(*entry));
+    const int gu0 = (y_scu - ly) * p->ip.w_scu + x_scu - lx; // the window's first unit in the picture's maps
+    for(int j = 0; j < Hl; j++) {
+        const size_t g = (size_t)gu0 + (size_t)j * p->ip.w_scu, l = (size_t)j * Wl;
+        memcpy(H + o_scu + 4 * l, map_scu + g, 4 * (size_t)Wl), memcpy(H + o_cum + 4 * l, map_cu_mode + g, 4 * (size_t)Wl);
+        memcpy(H + o_ipm + l, map_ipm + g, Wl), memcpy(H + o_tidx + l, map_tidx + g, Wl);
+    }
+    for(int c = 0; c < ncomp; c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, so = c ? s_org_c : s_org_l, sm = c ? s_mod_c : s_mod_l;
+        const int xw = (x0 >> sx) - lx * (4 >> sx), yw = (y0 >> sy) - ly * (4 >> sy); // the window's first sample in the plane
+        pel *lo = (pel *)(H + o_org[c]), *lm = (pel *)(H + o_mod[c]);
+        for(int r = 0; r < ph[c]; r++) {
+            memcpy(lo + (size_t)r * pw[c], org[c] + (size_t)(yw + r) * so + xw, sizeof(pel) * pw[c]);
+            memcpy(lm + (size_t)r * pw[c], mod[c] + (size_t)(yw + r) * sm + xw, sizeof(pel) * pw[c]);
+        }
+    }
+    XH_HIP(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, C.st));
+    const pel *d_org[3] = {(const pel *)(D + o_org[0]), idc ? (const pel *)(D + o_org[1]) : nullptr, idc ? (const pel *)(D + o_org[2]) : nullptr};
+    pel       *d_mod[3] = {(pel *)(D + o_mod[0]), idc ? (pel *)(D + o_mod[1]) : nullptr, idc ? (pel *)(D + o_mod[2]) : nullptr};
+    char *d_ws = D + ((io_bytes + 255) & ~(size_t)255);
+    rc = xeve_hip_mode_analyze_ctu_intra_jobs(d_org, pw[0], pw[1], d_mod, pw[0], pw[1], (uint32_t *)(D + o_scu), (int8_t *)(D + o_ipm), (const uint8_t *)(D + o_tidx),
+                                              (uint32_t *)(D + o_cum), nullptr, (const xeve_hip_sbac *)(D + o_st), 1, &pl, (const xeve_hip_ctu_job *)(D + o_job), 1,
+                                              (xeve_hip_ctu_data *)(D + o_out), (xeve_hip_sbac *)(D + o_next), (double *)(D + o_cost), d_ws,
+                                              C.dev_bytes - (size_t)(d_ws - D), C.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    XH_HIP(hipMemcpyAsync(H + o_scu, D + o_scu, io_bytes - o_scu, hipMemcpyDeviceToHost, C.st));
+    XH_HIP(hipStreamSynchronize(C.st));
+    memcpy(out, H + o_out, sizeof(*out)), memcpy(next_best, H + o_next, sizeof(*next_best)), memcpy(cost, H + o_cost, sizeof(double));
+    for(int j = 0; j < nh; j++) { // the CTU's units
+        const size_t g = (size_t)(y_scu + j) * p->ip.w_scu + x_scu, l = (size_t)(ly + j) * Wl + lx;
+        memcpy(map_scu + g, H + o_scu + 4 * l, 4 * (size_t)cw), memcpy(map_cu_mode + g, H + o_cum + 4 * l, 4 * (size_t)cw), memcpy(map_ipm + g, H + o_ipm + l, cw);
+    }
+    for(int c = 0; c < ncomp; c++) { // the CTU's samples
+        const int sx = c ? ws : 0, sy = c ? hs : 0, sm = c ? s_mod_c : s_mod_l, bw = (cw * 4) >> sx, bh = (nh * 4) >> sy, xl = lx * (4 >> sx), yl = ly * (4 >> sy);
+        const pel *lm = (const pel *)(H + o_mod[c]);
+        for(int r = 0; r < bh; r++) memcpy(mod[c] + (size_t)((y0 >> sy) + r) * sm + (x0 >> sx), lm + (size_t)(yl + r) * pw[c] + xl, sizeof(pel) * bw);
+    }
+    return XEVE_HIP_OK;
+}

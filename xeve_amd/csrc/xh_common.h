@@ -96,6 +96,45 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
                            int bit_depth, const int16_t (*coef)[8], const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results,
                            void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes); // me.hip
 
+// per-thread staging of the host-memory forms that run a batched entry point on ONE unit (intra.hip, tree.hip): a stream, a pinned host buffer and a device arena
+// that grow on demand and re-create themselves after xeve_hip_shutdown / _init
+struct XhHostArena {
+    uint32_t    gen = 0;
+    hipStream_t st  = nullptr;
+    char       *dev = nullptr, *pin = nullptr;
+    size_t      dev_bytes = 0, pin_bytes = 0;
+    void release()
+    {
+        if(st) (void)hipStreamDestroy(st);
+        if(dev) (void)hipFree(dev);
+        if(pin) (void)hipHostFree(pin);
+        st = nullptr, dev = pin = nullptr, dev_bytes = pin_bytes = 0;
+    }
+    int ensure(size_t io_bytes, size_t ws_bytes)
+    {
+        if(gen != xh_generation()) release(), gen = xh_generation(); // the library was shut down or re-bound since
+        if(!st) XH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if(pin_bytes < io_bytes) {
+            if(pin) (void)hipHostFree(pin);
+            pin = nullptr, pin_bytes = 0;
+            XH_HIP(hipHostMalloc((void **)&pin, io_bytes + (io_bytes >> 1), hipHostMallocDefault));
+            pin_bytes = io_bytes + (io_bytes >> 1);
+        }
+        const size_t need = io_bytes + 256 + ws_bytes;
+        if(dev_bytes < need) {
+            if(dev) {
+                XH_HIP(hipStreamSynchronize(st));
+                (void)hipFree(dev);
+                dev = nullptr, dev_bytes = 0;
+            }
+            XH_HIP(hipMalloc((void **)&dev, need + (need >> 2)));
+            dev_bytes = need + (need >> 2);
+        }
+        return XEVE_HIP_OK;
+    }
+    ~XhHostArena() { release(); }
+};
+
 static inline int xh_ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
 static inline bool xh_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
