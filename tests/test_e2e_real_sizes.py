@@ -18,12 +18,12 @@ needs_ref = pytest.mark.skipif(not (os.path.exists(REF_APP) and os.path.exists(S
 pytestmark = [pytest.mark.gpu, needs_ref]
 
 
-def _encode(tmp_path, name, cases, min_cus, tables=False):
+def _encode(tmp_path, name, cases, min_cus, tables=False, tree_ctus=0):
     w, h, n, seed, extra = cases[name]
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     t0 = time.perf_counter()
-    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, resident=True, tables=tables)
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, inter=True, resident=True, tables=tables, tree=tree_ctus > 0)
     dt = time.perf_counter() - t0
     m = re.search(r"whole inter analysis ran on the GPU: (\d+) \(left to the reference: (\d+)\)", err)
     r = re.search(r"resident pictures: (\d+) pictures announced, (\d+) planes uploaded \((\d+) bytes\), (\d+) plane look-ups", err)
@@ -34,6 +34,10 @@ def _encode(tmp_path, name, cases, min_cus, tables=False):
     print("%s: %d CUs on the GPU in %.1f s wall (%.0f us per CU incl. the host side of the encoder; inside the GPU calls, summed over the encoder threads: %s s = %s us per CU), "
           "%d pictures, %d plane uploads, %d look-ups from HBM" % (name, cus, dt, 1e6 * dt / max(1, cus), t.group(1) if t else "?", t.group(2) if t else "?", pics, uploads, hits))
     assert cus >= min_cus and left == 0, err
+    if tree_ctus:
+        k = re.search(r"mode decision ran on the GPU: (\d+) \(left to the reference: (\d+)\), ([0-9.]+) ms per CTU", err)
+        assert k and int(k.group(1)) == tree_ctus, err
+        print("%s: %d I-picture CTUs decided on the GPU, %s ms per CTU (one exchange each)" % (name, tree_ctus, k.group(3)))
     assert pics == n and uploads <= 9 * pics and hits > 5 * cus, err  # (each inter picture: the original + at most two reference pictures, three planes each)
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "bitstream differs with the inter analysis on the GPU at %dx%d" % (w, h)
 
@@ -47,6 +51,12 @@ def test_small_clips_with_resident_pictures(tmp_path, name):
 
 def test_cfg2_1280x720_low_delay_fast(tmp_path):
     _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000)
+
+
+def test_cfg2_1280x720_with_the_i_picture_decided_per_ctu_on_the_gpu(tmp_path):
+    """the same clip with the I picture's 240 CTUs (12 rows: 720 = 11 * 64 + 16, the last row cut by the picture) decided by the device-side tree walk, one
+    exchange per CTU, and the P picture's CUs analysed per CU as above"""
+    _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000, tree_ctus=240)
 
 
 def test_cfg3_1920x1080_random_access_medium(tmp_path):
