@@ -444,8 +444,45 @@ static double shim_pintra_analyze_cu(XEVE_CTX *ctx, XEVE_CORE *core, int x, int 
 #include "xeve_oracle.h"
 static double (*xo_tree)(const xo_pel *const *, int, int, xo_pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
                          const xo_tree_params *, int, int, xo_ctu_data *, xo_sbac *);
+static double (*xo_tree_any)(const xo_pel *const *, int, int, xo_pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
+                             const xo_tree_params *, const xo_tree_inter *, int, int, xo_ctu_data *, xo_sbac *);
 static int (*orig_mode_analyze_lcu)(XEVE_CTX *, XEVE_CORE *);
-static unsigned long long shadow_ctus, shadow_bad, shadow_skipped;
+static unsigned long long shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus;
+
+/* what the inter side of the walk is handed (the same derivation as shim_pinter_analyze_cu above, once per CTU); tab: 16 entries */
+static int tree_inter_setup(XEVE_CTX *ctx, XEVE_CORE *core, xo_tree_inter *I, xo_refpic *tab, int16_t (*map_mv)[2][2], int8_t (*map_refi)[2])
+{
+    XEVE_PINTER *pi = &ctx->pinter[core->thread_cnt];
+    const int isb = ctx->sh->slice_type == SLICE_B, idc = ctx->sps.chroma_format_idc;
+    const int nr[2] = {ctx->rpm.num_refp[REFP_0], isb ? ctx->rpm.num_refp[REFP_1] : 0};
+    if(nr[0] > 8 || nr[1] > nr[0] || nr[0] < 1 || (isb && nr[1] < 1) || ctx->param.min_cu_inter < 8) return -1;
+    memset(I, 0, sizeof(*I)), memset(tab, 0, 16 * sizeof(*tab));
+    xo_inter_params *P = &I->ipar;
+    P->rdo.pic_w = ctx->w, P->rdo.pic_h = ctx->h, P->rdo.slice_type = ctx->sh->slice_type;
+    P->rdo.num_refp[0] = nr[0], P->rdo.num_refp[1] = nr[1], P->rdo.chroma_format_idc = idc, P->rdo.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8, P->rdo.tool_iqt = 0;
+    P->rdo.qp[0] = core->qp_y, P->rdo.qp[1] = core->qp_u, P->rdo.qp[2] = core->qp_v;
+    for(int c = 0; c < 3; c++) P->rdo.lambda[c] = core->lambda[c];
+    P->rdo.dist_chroma_weight[0] = core->dist_chroma_weight[0], P->rdo.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    P->me.me.lambda_mv = pi->lambda_mv, P->me.me.faststep = 3, P->me.me.max_search_range = pi->max_search_range;
+    P->me.me.min_clip[0] = pi->min_clip[MV_X], P->me.me.min_clip[1] = pi->min_clip[MV_Y], P->me.me.max_clip[0] = pi->max_clip[MV_X], P->me.me.max_clip[1] = pi->max_clip[MV_Y];
+    P->me.spel.lambda_mv = pi->lambda_mv;
+    P->me.spel.hpel_cnt = pi->me_level > ME_LEV_IPEL ? pi->search_pattern_hpel_cnt : 0, P->me.spel.qpel_cnt = pi->me_level > ME_LEV_HPEL ? pi->search_pattern_qpel_cnt : 0;
+    P->me.me.reserved = pi->me_complexity > 1 ? 1 : 0;
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            XEVE_PIC *rp = pi->refp[r][l].pic;
+            tab[r * 2 + l].y = rp->y, tab[r * 2 + l].u = rp->u, tab[r * 2 + l].v = rp->v, tab[r * 2 + l].poc = pi->refp[r][l].poc;
+            P->refi_bits[l][r] = xeve_tbl_refi_bits[nr[l]][r];
+            P->range_recentre[l][r] = XEVE_CLIP3(pi->max_search_range >> 2, pi->max_search_range, /* get_range_ipel (xeve_pinter.c:122-129) */
+                                                 (pi->max_search_range * XEVE_ABS((int)ctx->poc.poc_val - (int)pi->refp[r][l].poc) + (ctx->param.gop_size >> 1)) / ctx->param.gop_size);
+        }
+    P->max_cand = pi->skip_merge_cand_num, P->poc = ctx->poc.poc_val, P->col_list_poc0 = isb ? (int)pi->refp[0][REFP_1].list_poc[0] : 0, P->skip_th = ctx->param.skip_th;
+    XEVE_PIC *any = pi->refp[0][REFP_0].pic;
+    I->refp = tab, I->s_ref_l = any->s_l, I->s_ref_c = any->s_c, I->map_mv = map_mv, I->map_refi = map_refi;
+    I->col0 = (const int16_t(*)[2][2])pi->refp[0][REFP_0].map_mv, I->col1 = isb ? (const int16_t(*)[2][2])pi->refp[0][REFP_1].map_mv : I->col0;
+    I->ecu_depth = (ctx->poc.poc_val % 2) ? ENC_ECU_DEPTH_B - 2 : ENC_ECU_DEPTH_B; /* ENC_ECU_ADAPTIVE (xeve_mode.c:2162-2166) */
+    return 0;
+}
 
 static void sbac_to_flat(xo_sbac *h, const XEVE_SBAC *sb)
 {
@@ -460,10 +497,29 @@ static void sbac_to_flat(xo_sbac *h, const XEVE_SBAC *sb)
 static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
 {
     const int L = ctx->log2_max_cuwh - 2, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
-    if(ctx->sh->slice_type != SLICE_I || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp ||
-       ctx->log2_max_cuwh != 6 || idc == 2 || ctx->param.threads != 1) {
+    const int is_i = ctx->sh->slice_type == SLICE_I;
+    xo_tree_inter  TI;
+    xo_refpic      tab[16];
+    const int nscu0 = ctx->w_scu * ctx->h_scu;
+    int16_t (*m_mv)[2][2] = NULL;
+    int8_t  (*m_refi)[2]  = NULL;
+    if(ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp || ctx->log2_max_cuwh != 6 || idc == 2 ||
+       ctx->param.threads != 1 || (!is_i && (!xo_tree_any || getenv("XEVE_SHIM_SHADOW_I_ONLY")))) {
         shadow_skipped++;
         return orig_mode_analyze_lcu(ctx, core);
+    }
+    if(!is_i) {
+        /* (mode_cu_init's QPs: the inter parameters are read before the reference has run on this CTU) */
+        core->qp = ctx->tile[core->tile_idx].qp, core->qp_y = GET_LUMA_QP(core->qp, ctx->sps.bit_depth_luma_minus8);
+        core->qp_u = ctx->qp_chroma_dynamic[0][XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_u_offset)] + 6 * ctx->sps.bit_depth_chroma_minus8;
+        core->qp_v = ctx->qp_chroma_dynamic[1][XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_v_offset)] + 6 * ctx->sps.bit_depth_chroma_minus8;
+        m_mv = malloc(sizeof(*m_mv) * nscu0), m_refi = malloc(sizeof(*m_refi) * nscu0);
+        memcpy(m_mv, ctx->map_mv, sizeof(*m_mv) * nscu0), memcpy(m_refi, ctx->map_refi, sizeof(*m_refi) * nscu0);
+        if(tree_inter_setup(ctx, core, &TI, tab, m_mv, m_refi) != 0) {
+            free(m_mv), free(m_refi);
+            shadow_skipped++;
+            return orig_mode_analyze_lcu(ctx, core);
+        }
     }
     XEVE_PIC *pm = PIC_MODE(ctx);
     XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
@@ -487,11 +543,17 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     P.ip.qp[0] = core->qp_y, P.ip.qp[1] = core->qp_u, P.ip.qp[2] = core->qp_v; /* (mode_cu_init derives them from the tile QP: the same for every CU without delta QP) */
     for(int c = 0; c < 3; c++) P.ip.lambda[c] = core->lambda[c];
     P.ip.sqrt_lambda0 = core->sqrt_lambda[0], P.ip.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = core->dist_chroma_weight[1];
-    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.max_cu = ctx->param.max_cu_intra, P.min_cu = ctx->param.min_cu_intra, P.min_cuwh = ctx->min_cuwh;
+    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.min_cuwh = ctx->min_cuwh;
+    P.max_cu = is_i ? ctx->param.max_cu_intra : ctx->param.max_cu_inter, P.min_cu = is_i ? ctx->param.min_cu_intra : ctx->param.min_cu_inter;
     P.slice_qp = ctx->tile[core->tile_idx].qp, P.slice_num = ctx->slice_num;
     static __thread xo_ctu_data out;
     const xo_pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
-    (void)xo_tree(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, x0, y0, &out, &next);
+    if(is_i) (void)xo_tree(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, x0, y0, &out, &next);
+    else {
+        P.ip.slice_type = ctx->sh->slice_type;
+        (void)xo_tree_any(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, &TI, x0, y0, &out, &next);
+        shadow_inter_ctus++;
+    }
 
     /* compare */
     int bad = 0;
@@ -514,6 +576,19 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
             if(cd->map_scu[u] != out.map_scu[u]) BAD("map_scu[%d] %08x vs %08x", u, cd->map_scu[u], out.map_scu[u]);
             if(cd->map_cu_mode[u] != out.map_cu_mode[u]) BAD("map_cu_mode[%d] %08x vs %08x", u, cd->map_cu_mode[u], out.map_cu_mode[u]);
             const int g = ((y0 >> 2) + j) * ctx->w_scu + (x0 >> 2) + i;
+            if(!is_i) {
+                if(cd->skip_flag[u] != (out.pred_mode[u] == MODE_SKIP)) BAD("skip_flag[%d] %d (mode %d)", u, cd->skip_flag[u], out.pred_mode[u]);
+                for(int l = 0; l < 2; l++) {
+                    if(cd->refi[u][l] != out.refi[u][l]) BAD("refi[%d][%d] %d vs %d", u, l, cd->refi[u][l], out.refi[u][l]);
+                    if(cd->mv[u][l][0] != out.mv[u][l][0] || cd->mv[u][l][1] != out.mv[u][l][1]) BAD("mv[%d][%d] (%d,%d) vs (%d,%d)", u, l, cd->mv[u][l][0], cd->mv[u][l][1], out.mv[u][l][0], out.mv[u][l][1]);
+                    if(out.pred_mode[u] != MODE_INTRA && out.refi[u][l] >= 0 && out.pred_mode[u] != MODE_DIR) {
+                        if(cd->mvp_idx[u][l] != out.mvp_idx[u][l]) BAD("mvp_idx[%d][%d] %d vs %d", u, l, cd->mvp_idx[u][l], out.mvp_idx[u][l]);
+                        if(out.pred_mode[u] == MODE_INTER && (cd->mvd[u][l][0] != out.mvd[u][l][0] || cd->mvd[u][l][1] != out.mvd[u][l][1])) BAD("mvd[%d][%d] (%d,%d) vs (%d,%d)", u, l, cd->mvd[u][l][0], cd->mvd[u][l][1], out.mvd[u][l][0], out.mvd[u][l][1]);
+                    }
+                    if(ctx->map_refi[g][l] != m_refi[g][l]) BAD("ctx->map_refi[%d][%d] %d vs %d", g, l, ctx->map_refi[g][l], m_refi[g][l]);
+                    if(ctx->map_mv[g][l][0] != m_mv[g][l][0] || ctx->map_mv[g][l][1] != m_mv[g][l][1]) BAD("ctx->map_mv[%d][%d] (%d,%d) vs (%d,%d)", g, l, ctx->map_mv[g][l][0], ctx->map_mv[g][l][1], m_mv[g][l][0], m_mv[g][l][1]);
+                }
+            }
             if((ctx->map_scu[g] | (1u << 31)) != m_scu[g]) BAD("ctx->map_scu[%d] %08x vs %08x", g, ctx->map_scu[g], m_scu[g]);
             if(ctx->map_ipm[g] != m_ipm[g]) BAD("ctx->map_ipm[%d] %d vs %d", g, ctx->map_ipm[g], m_ipm[g]);
         }
@@ -523,7 +598,8 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
         const xo_pel *po = mod[c] + (y0 >> sy) * s + (x0 >> sx);
         for(int yy = 0; yy < h; yy++)
             for(int xx = 0; xx < w; xx++) {
-                if(cd->coef[c][yy * cs + xx] != out.coef[c][yy * cs + xx]) BAD("coef[%d] (%d,%d) %d vs %d", c, xx, yy, cd->coef[c][yy * cs + xx], out.coef[c][yy * cs + xx]);
+                if(cd->nnz[c][(((yy << sy) >> 2) * nu) + ((xx << sx) >> 2)] /* (a CU without coded levels keeps stale ones in the reference) */ &&
+                   cd->coef[c][yy * cs + xx] != out.coef[c][yy * cs + xx]) BAD("coef[%d] (%d,%d) %d vs %d", c, xx, yy, cd->coef[c][yy * cs + xx], out.coef[c][yy * cs + xx]);
                 if(cd->reco[c][yy * cs + xx] != out.reco[c][yy * cs + xx]) BAD("reco[%d] (%d,%d) %d vs %d", c, xx, yy, cd->reco[c][yy * cs + xx], out.reco[c][yy * cs + xx]);
                 if(pr[yy * s + xx] != po[yy * s + xx]) BAD("picture[%d] (%d,%d) %d vs %d", c, xx, yy, pr[yy * s + xx], po[yy * s + xx]);
             }
@@ -532,7 +608,7 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     if(memcmp(&ref_next, &next, sizeof(next))) BAD("exit coder state differs (range %u vs %u)", ref_next.range, next.range);
     shadow_ctus++;
     if(bad) shadow_bad++;
-    free(mod[0]), free(mod[1]), free(mod[2]), free(m_scu), free(m_cum), free(m_ipm);
+    free(mod[0]), free(mod[1]), free(mod[2]), free(m_scu), free(m_cum), free(m_ipm), free(m_mv), free(m_refi);
     return rc;
 }
 
@@ -650,7 +726,7 @@ static void report(void)
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
     if(tree_calls || tree_fallbacks) fprintf(stderr, "[xeve_hip_shim] CTUs whose whole mode decision ran on the %s: %llu (left to the reference: %llu), %.1f ms per CTU\n", tree_engine_oracle ? "oracle (CPU)" : "GPU", tree_calls, tree_fallbacks, tree_calls ? 1e3 * tree_seconds / (double)tree_calls : 0.0);
-    if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered)\n", shadow_ctus, shadow_bad, shadow_skipped);
+    if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered), %llu of them in P / B pictures\n", shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
     if(eco_calls) fprintf(stderr, "[xeve_hip_shim] CUs whose coefficient bits were counted on the GPU: %llu\n", eco_calls);
@@ -678,6 +754,7 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
     if(getenv("XEVE_SHIM_SHADOW_TREE") && ctx->fn_mode_analyze_lcu && ctx->fn_mode_analyze_lcu != shim_mode_analyze_lcu) {
         void *oh = dlopen(getenv("XEVE_SHIM_SHADOW_TREE"), RTLD_NOW | RTLD_LOCAL);
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
+        xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
         fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
         atexit(report);

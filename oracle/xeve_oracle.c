@@ -1665,9 +1665,19 @@ int xo_check_best_mvp(const xo_sbac *entry, int slice_type, const int8_t refi[2]
     return best_idx;
 }
 
+static void pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                              const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                              xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best, xo_pel *pred_y_best);
 void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
                           const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
                           xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best)
+{
+    pinter_analyze_cu(org, s_org_l, s_org_c, refp, s_l, s_c, states, P, job, res, coef_y, coef_u, coef_v, rec_y, rec_u, rec_v, next_best, NULL);
+}
+/* pred_y_best (may be NULL): mi->pred_y_best = the winner's luma prediction (:2034), which mode_check_intra prices the intra candidates against */
+static void pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_refpic *refp, int s_l, int s_c, const xo_sbac *states,
+                              const xo_inter_params *P, const xo_inter_job *job, xo_inter_result *res, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                              xo_pel *rec_y, xo_pel *rec_u, xo_pel *rec_v, xo_sbac *next_best, xo_pel *pred_y_best)
 {
     enum { L0 = 0, L1 = 1, BI = 2, SKIP = 3, DIR = 4, NP = 5 };
     const xo_rdo_params *p = &P->rdo;
@@ -1812,6 +1822,7 @@ void xo_pinter_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
         mj.x = x, mj.y = y, memcpy(mj.mv, mv[best_idx], sizeof(mj.mv)), mj.refi[0] = refi[best_idx][0], mj.refi[1] = refi[best_idx][1];
         xo_mc_cu(refp, s_l, s_c, p->pic_w, p->pic_h, &mj, w, h, bd, bd, idc, pr[0], pr[1], pr[2]);
     }
+    if(pred_y_best) memcpy(pred_y_best, pr[0], sizeof(xo_pel) * (size_t)n0);
     for(int c = 0; c < ncomp; c++) {
         const int n = c ? n1 : n0, l2w = c ? lw - ws : lw, l2h = c ? lh - hs : lh;
         memcpy(co[c], coef[best_idx][c], sizeof(int16_t) * (size_t)n);
@@ -2118,6 +2129,8 @@ typedef struct tree_ctx {
     int8_t              *map_ipm;
     const uint8_t       *map_tidx;
     const xo_tree_params *P;
+    const xo_tree_inter *I;                          /* NULL in I slices */
+    int                  cu_mode;                    /* core->cu_mode of the last mode_coding_unit */
     xo_sbac              curr_best[5], next_best[5]; /* core->s_curr_best / s_next_best [log2 - 2][log2 - 2] */
     xo_ctu_data         *best[5], *temp[5];          /* core->cu_data_best / cu_data_temp, node-local indexing (pitch = the node's size) */
     int32_t              dist_cu_best;               /* core->dist_cu_best */
@@ -2140,6 +2153,8 @@ static void cud_copy(xo_ctu_data *dst, const xo_ctu_data *src, int x, int y, int
         memcpy(dst->depth + di, src->depth + si, n);
         memcpy(dst->map_scu + di, src->map_scu + si, 4 * n), memcpy(dst->map_cu_mode + di, src->map_cu_mode + si, 4 * n);
         for(int c = 0; c < 3; c++) memcpy(dst->nnz[c] + di, src->nnz[c] + si, 4 * n);
+        memcpy(dst->mv + di, src->mv + si, sizeof(src->mv[0]) * n), memcpy(dst->mvd + di, src->mvd + si, sizeof(src->mvd[0]) * n);
+        memcpy(dst->refi + di, src->refi + si, 2 * n), memcpy(dst->mvp_idx + di, src->mvp_idx + si, 2 * n);
     }
     for(int j = 0; j < cw; j++) {
         memcpy(dst->coef[0] + (y + j) * cs + x, src->coef[0] + j * cw, 2 * cw);
@@ -2169,6 +2184,7 @@ static void tree_update_map(tree_ctx *T, const xo_ctu_data *d, int x, int y, int
         const int g = ((y >> 2) + i) * P->ip.w_scu + (x >> 2);
         memcpy(T->map_scu + g, d->map_scu + i * n, 4 * w), memcpy(T->map_cu_mode + g, d->map_cu_mode + i * n, 4 * w);
         memcpy(T->map_ipm + g, d->ipm[0] + i * n, w);
+        if(T->I) memcpy(T->I->map_mv + g, d->mv + i * n, sizeof(d->mv[0]) * w), memcpy(T->I->map_refi + g, d->refi + i * n, 2 * w);
     }
 }
 static void tree_rec_to_pic(tree_ctx *T, const xo_ctu_data *d, int x, int y, int cu)
@@ -2189,10 +2205,79 @@ static uint32_t tree_split_bits(const xo_sbac *from, xo_sbac *to, int split)
     return xo_sbac_bits(to);
 }
 
+/* mode_coding_unit (:1310-1350): mode_cu_init, then mode_check_inter (:1169-1222) and mode_check_intra (:1226-1308); the cheaper mode's data into the node's
+ * cu_data_temp (copy_to_cu_data, :868-1034), its coder state into s_next_best.  I slices: the intra analysis alone.  P / B slices (Baseline, tool_admvp 0):
+ * the whole inter analysis first; the intra analysis only when the inter winner has a residual, its candidate list cut against the SATD of the inter
+ * winner's luma prediction. */
+static double tree_unit(tree_ctx *T, int x0, int y0, int log2, int cud, xo_ctu_data *t)
+{
+    const xo_tree_params *P = T->P;
+    const int L = log2 - 2, cu = 1 << log2, idc = P->ip.chroma_format_idc, n = 1 << (2 * L), n0 = cu * cu;
+    const uint32_t scu_base = ((uint32_t)P->slice_num & 0x7F) | ((uint32_t)P->slice_qp << 16) | (1u << 31); /* MCU_SET_IF_COD_SN_QP without the intra flag */
+    const uint32_t cum      = ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);                                /* MCU_SET_LOGW / LOGH */
+    double   cost_best = 1.7e+308;
+    uint32_t inter_satd = 0xFFFFFFFFu;
+    int      try_intra = 1;
+    T->cu_mode = 0, T->dist_cu_best = 0x7FFFFFFF;
+    if(T->I) { /* mode_check_inter */
+        const xo_tree_inter *I = T->I;
+        xo_inter_params ipar = I->ipar;
+        ipar.rdo.log2_cuw = ipar.rdo.log2_cuh = log2;
+        xo_inter_job ij;
+        memset(&ij, 0, sizeof(ij));
+        ij.x = x0, ij.y = y0, ij.sbac = 0; /* ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288) */
+        xo_inter_candidates(T->map_scu, T->map_tidx, (const int16_t(*)[2][2])I->map_mv, I->col0, I->col1, P->ip.w_scu, P->ip.h_scu, log2, log2, P->ip.slice_type, &ij);
+        xo_inter_result r;
+        xo_pel *pred_y = malloc(sizeof(xo_pel) * (size_t)n0);
+        pinter_analyze_cu(T->org, T->s_org_l, T->s_org_c, I->refp, I->s_ref_l, I->s_ref_c, &T->curr_best[L], &ipar, &ij, &r, t->coef[0], t->coef[1], t->coef[2], t->reco[0],
+                          t->reco[1], t->reco[2], &T->next_best[L], pred_y);
+        cost_best = r.cost, T->cu_mode = r.cu_mode;
+        for(int i = 0; i < n; i++) { /* copy_to_cu_data of an inter CU */
+            t->pred_mode[i] = (uint8_t)r.cu_mode, t->depth[i] = (int8_t)cud;
+            t->nnz[0][i] = r.nnz[0], t->nnz[1][i] = idc ? r.nnz[1] : 0, t->nnz[2][i] = idc ? r.nnz[2] : 0;
+            t->map_scu[i] = scu_base | (r.cu_mode == 2 /* MODE_SKIP */ ? 1u << 23 : 0), t->map_cu_mode[i] = cum;
+            memcpy(t->mv[i], r.mv, sizeof(r.mv)), memcpy(t->mvd[i], r.mvd, sizeof(r.mvd));
+            t->refi[i][0] = r.refi[0], t->refi[i][1] = r.refi[1], t->mvp_idx[i][0] = r.mvp_idx[0], t->mvp_idx[i][1] = r.mvp_idx[1];
+        }
+        try_intra = r.nnz[0] != 0 || r.nnz[1] != 0 || r.nnz[2] != 0; /* (:1245-1247; cost_best cannot be MAX_COST here) */
+        if(try_intra) inter_satd = (uint32_t)xo_satd(cu, cu, T->org[0] + (size_t)y0 * T->s_org_l + x0, pred_y, T->s_org_l, cu, P->ip.bit_depth);
+        free(pred_y);
+    }
+    if(try_intra) { /* mode_check_intra */
+        xo_intra_params ip = P->ip;
+        ip.log2_cuw = ip.log2_cuh = log2;
+        xo_intra_job ij;
+        memset(&ij, 0, sizeof(ij));
+        ij.x = x0, ij.y = y0, ij.inter_satd = inter_satd, ij.sbac = 0;
+        xo_intra_result ir;
+        xo_sbac         best;
+        const xo_pel *const mod_c[3] = {T->mod[0], T->mod[1], T->mod[2]};
+        int16_t *cf[3];
+        xo_pel  *rc[3];
+        for(int c = 0; c < 3; c++) cf[c] = malloc(sizeof(int16_t) * (size_t)n0), rc[c] = malloc(sizeof(xo_pel) * (size_t)n0);
+        xo_pintra_analyze_cu(T->org, T->s_org_l, T->s_org_c, mod_c, T->s_mod_l, T->s_mod_c, T->map_scu, T->map_ipm, T->map_tidx, &T->curr_best[L], &ip, &ij, &ir, cf[0],
+                             cf[1], cf[2], rc[0], rc[1], rc[2], &best);
+        if(ir.cost < cost_best) {
+            const int n1 = idc ? n0 >> ((idc <= 2) + (idc <= 1)) : 0;
+            cost_best = ir.cost, T->cu_mode = 0, T->next_best[L] = best, T->dist_cu_best = ir.dist_cu;
+            for(int c = 0; c < (idc ? 3 : 1); c++) memcpy(t->coef[c], cf[c], sizeof(int16_t) * (size_t)(c ? n1 : n0)), memcpy(t->reco[c], rc[c], sizeof(xo_pel) * (size_t)(c ? n1 : n0));
+            for(int i = 0; i < n; i++) { /* copy_to_cu_data of an intra CU */
+                t->pred_mode[i] = 0 /* MODE_INTRA */, t->ipm[0][i] = ir.ipm[0], t->ipm[1][i] = idc ? ir.ipm[1] : 0, t->depth[i] = (int8_t)cud;
+                t->nnz[0][i] = ir.nnz[0], t->nnz[1][i] = idc ? ir.nnz[1] : 0, t->nnz[2][i] = idc ? ir.nnz[2] : 0;
+                t->map_scu[i] = scu_base | (1u << 15), t->map_cu_mode[i] = cum;
+                memset(t->mv[i], 0, sizeof(t->mv[i])), memset(t->mvd[i], 0, sizeof(t->mvd[i]));
+                t->refi[i][0] = t->refi[i][1] = -1, t->mvp_idx[i][0] = t->mvp_idx[i][1] = 0;
+            }
+        }
+        for(int c = 0; c < 3; c++) free(cf[c]), free(rc[c]);
+    }
+    return cost_best;
+}
+
 static double tree_node(tree_ctx *T, int x0, int y0, int log2, int cud, int next_split)
 {
     const xo_tree_params *P = T->P;
-    const int L = log2 - 2, cu = 1 << log2, idc = P->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1;
+    const int L = log2 - 2, cu = 1 << log2, idc = P->ip.chroma_format_idc;
     const int boundary = !(x0 + cu <= P->pic_w && y0 + cu <= P->pic_h);
     const xo_sbac before_split = T->curr_best[L];
     xo_sbac       temp_depth;
@@ -2210,27 +2295,8 @@ static double tree_node(tree_ctx *T, int x0, int y0, int log2, int cud, int next
             }
             cud_init(T->temp[L], log2);
             tree_clear_map(T, x0, y0, cu);
-            /* mode_coding_unit (:1310-1350) in an I slice: mode_cu_init + mode_check_intra -> the intra analysis always becomes the CU's mode */
-            xo_intra_params ip = P->ip;
-            ip.log2_cuw = ip.log2_cuh = log2;
-            xo_intra_job ij;
-            memset(&ij, 0, sizeof(ij));
-            ij.x = x0, ij.y = y0, ij.inter_satd = 0xFFFFFFFFu, ij.sbac = 0;
-            xo_intra_result ir;
-            xo_ctu_data    *t = T->temp[L];
-            const xo_pel *const mod_c[3] = {T->mod[0], T->mod[1], T->mod[2]};
-            xo_pintra_analyze_cu(T->org, T->s_org_l, T->s_org_c, mod_c, T->s_mod_l, T->s_mod_c, T->map_scu, T->map_ipm, T->map_tidx, &T->curr_best[L], &ip, &ij, &ir,
-                                 t->coef[0], t->coef[1], t->coef[2], t->reco[0], t->reco[1], t->reco[2], &T->next_best[L]);
-            T->dist_cu_best = ir.dist_cu;
-            /* copy_to_cu_data (:868-1034) for an intra CU */
-            for(int i = 0; i < 1 << (2 * L); i++) {
-                t->pred_mode[i] = 0 /* MODE_INTRA */, t->ipm[0][i] = ir.ipm[0], t->ipm[1][i] = idc ? ir.ipm[1] : 0, t->depth[i] = (int8_t)cud;
-                t->nnz[0][i] = ir.nnz[0], t->nnz[1][i] = idc ? ir.nnz[1] : 0, t->nnz[2][i] = idc ? ir.nnz[2] : 0;
-                t->map_scu[i]     = ((uint32_t)P->slice_num & 0x7F) | ((uint32_t)P->slice_qp << 16) | (1u << 15) | (1u << 31); /* MCU_SET_IF_COD_SN_QP, SF clear */
-                t->map_cu_mode[i] = ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);                                            /* MCU_SET_LOGW / LOGH */
-            }
-            (void)ws, (void)hs;
-            cost_temp += ir.cost;
+            xo_ctu_data *t = T->temp[L];
+            cost_temp += tree_unit(T, x0, y0, log2, cud, t);
             if(cost_best > cost_temp) { /* (:2116-2135) */
                 cud_copy(T->best[L], t, 0, 0, log2, log2, cud, idc);
                 cost_best = cost_temp, best_split = 0, temp_depth = T->next_best[L];
@@ -2240,8 +2306,10 @@ static double tree_node(tree_ctx *T, int x0, int y0, int log2, int cud, int next
         }
         else cost_temp = 1.7e+308;
     }
+    /* early CU termination outside I pictures (:2162-2172): a skipped CU at or below a depth that depends on the POC's parity is not split */
+    if(cost_best != 1.7e+308 && T->I && cud >= T->I->ecu_depth && T->cu_mode == 2 /* MODE_SKIP */) next_split = 0;
     /* early termination in I pictures (:2174-2187) */
-    if(cost_best != 1.7e+308) {
+    if(cost_best != 1.7e+308 && P->ip.slice_type == 2) {
         const int dist_cu = T->dist_cu_best, th = 1 << (2 * log2 + 7);
         if(dist_cu < th) {
             const int bits_inc = (2 * log2 >= 6 ? 2 : 0) + 8;
@@ -2279,14 +2347,14 @@ static double tree_node(tree_ctx *T, int x0, int y0, int log2, int cud, int next
     return cost_best;
 }
 
-double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
-                                 int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
-                                 xo_ctu_data *out, xo_sbac *next_best)
+static double analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
+                          const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, const xo_tree_inter *I, int x0, int y0,
+                          xo_ctu_data *out, xo_sbac *next_best)
 {
     tree_ctx T;
     memset(&T, 0, sizeof(T));
     T.org = org, T.mod = mod, T.s_org_l = s_org_l, T.s_org_c = s_org_c, T.s_mod_l = s_mod_l, T.s_mod_c = s_mod_c;
-    T.map_scu = map_scu, T.map_ipm = map_ipm, T.map_tidx = map_tidx, T.map_cu_mode = map_cu_mode, T.P = P;
+    T.map_scu = map_scu, T.map_ipm = map_ipm, T.map_tidx = map_tidx, T.map_cu_mode = map_cu_mode, T.P = P, T.I = I;
     for(int l = 0; l < 5; l++) T.best[l] = calloc(1, sizeof(xo_ctu_data)), T.temp[l] = calloc(1, sizeof(xo_ctu_data));
     const int L = P->log2_ctu - 2;
     T.curr_best[L] = *entry;
@@ -2295,4 +2363,19 @@ double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_
     *out = *T.best[L], *next_best = T.next_best[L];
     for(int l = 0; l < 5; l++) free(T.best[l]), free(T.temp[l]);
     return cost;
+}
+
+double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
+                                 int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
+                                 xo_ctu_data *out, xo_sbac *next_best)
+{
+    return analyze_ctu(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, entry, P, NULL, x0, y0, out, next_best);
+}
+
+double xo_mode_analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
+                           const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, const xo_tree_inter *I, int x0, int y0,
+                           xo_ctu_data *out, xo_sbac *next_best)
+{
+    return analyze_ctu(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, entry, P, P->ip.slice_type == 2 ? NULL : I, x0, y0, out,
+                       next_best);
 }

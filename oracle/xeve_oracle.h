@@ -455,9 +455,27 @@ typedef struct xo_ctu_data { /* the fields of XEVE_CU_DATA (xeve_type.h:573-617)
     uint32_t map_scu[256], map_cu_mode[256];
     int16_t  coef[3][64 * 64];
     xo_pel   reco[3][64 * 64];
+    int16_t  mv[256][2][2], mvd[256][2][2]; /* P / B slices: [unit][list][x, y]; zero for an intra unit and for a list the CU does not use */
+    int8_t   refi[256][2];
+    uint8_t  mvp_idx[256][2];
 } xo_ctu_data;
+/* the inter side of the walk (P / B slices) */
+typedef struct xo_tree_inter {
+    const xo_refpic *refp;          /* [refi * 2 + list], as for xo_pinter_analyze_cu */
+    int32_t          s_ref_l, s_ref_c;
+    xo_inter_params  ipar;          /* rdo.log2_cuw / log2_cuh are set per node */
+    int16_t        (*map_mv)[2][2]; /* ctx->map_mv: read for the candidates, updated with every decided CU */
+    int8_t         (*map_refi)[2];  /* ctx->map_refi: updated */
+    const int16_t  (*col0)[2][2], (*col1)[2][2]; /* refp[0][REFP_0 / REFP_1].map_mv */
+    int32_t          ecu_depth;     /* the depth from which a skipped CU ends the split: ENC_ECU_DEPTH_B 4, minus 2 on odd POCs (xeve_mode.c:2162-2172) */
+    int32_t          pad_;
+} xo_tree_inter;
 /* mod (the picture being reconstructed), map_scu, map_ipm, map_cu_mode are read AND updated as the reference's walk updates them; on return they hold the CTU's
  * decision (as after update_to_ctx_map + update_map_scu; the caller's reset of the coded flags, xeve_mode.c:2591-2607, is not applied).  Returns the CTU's cost. */
+/* every slice type: P->ip.slice_type 0 B / 1 P with `inter` (max_cu / min_cu = ctx->param.max_cu_inter / min_cu_inter), 2 I as below (inter ignored) */
+double xo_mode_analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
+                           const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, const xo_tree_inter *inter, int x0, int y0,
+                           xo_ctu_data *out, xo_sbac *next_best);
 double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
                                  int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
                                  xo_ctu_data *out, xo_sbac *next_best);

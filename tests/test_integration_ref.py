@@ -285,12 +285,14 @@ def test_bitstream_identical_with_inter_and_intra_analysis_on_the_gpu(tmp_path, 
 
 
 @needs_ref
-@pytest.mark.parametrize("name,nctu", [("noise_allintra_medium", 8), ("moving_cif_allintra_fast", 60), ("tiny_ra_medium", 2)])
-def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu):
-    """xo_mode_analyze_ctu_intra (the I-picture mode_analyze_lcu -> mode_coding_tree walk, xeve_mode.c:2007-2610, restated in oracle/) runs BESIDE the unmodified
-    reference inside the live encoder (oracle/ref_shim.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every product of the
-    walk -- split flags, modes, depths, levels, reconstruction, the context maps, the picture and the coder state handed to the next CTU -- is compared
-    per CTU.  CPU only: this pins the oracle the device-side tree walk is checked against; moving_cif has partial CTUs at the right and bottom edges."""
+@pytest.mark.parametrize("name,nctu,ninter", [("noise_allintra_medium", 8, 0), ("moving_cif_allintra_fast", 60, 0), ("tiny_ra_medium", 8, 6), ("moving_cif_ra_medium", 150, 120),
+                                             ("moving_ldb_ref3", 20, 16), ("moving_ra_b3_medium", 18, 16), ("jumpy_ldb_fast", 24, 18)])
+def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu, ninter):
+    """xo_mode_analyze_ctu (mode_analyze_lcu -> mode_coding_tree -> mode_coding_unit, xeve_mode.c:1169-1350, 2007-2610, restated in oracle/: I, P and B slices) runs
+    BESIDE the unmodified reference inside the live encoder (oracle/ref_shim.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every
+    product of the walk -- split flags, CU modes, intra modes, motion data, depths, levels, reconstruction, the context maps (units, intra modes, vectors,
+    reference indices), the picture and the coder state handed on -- is compared per CTU.  CPU only: this pins the oracle the device-side tree walk is checked
+    against; the CIF clips have partial CTUs at the right and bottom edges, the B clips temporal direct and bi-prediction."""
     from _libs import ORACLE_SO
 
     w, h, n, seed, extra = CASES[name]
@@ -298,9 +300,9 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu)
     make_yuv(yuv, w, h, n, seed)
     md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_SHADOW_TREE": ORACLE_SO})
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])  # the shadow run leaves the encode untouched
-    m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ", err)
+    m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ \((\d+) not covered\), (\d+) of them in P / B", err)
     assert m, err[-800:]
-    assert (int(m.group(1)), int(m.group(2))) == (nctu, 0), err[-1500:]
+    assert tuple(int(m.group(k)) for k in (1, 2, 3, 4)) == (nctu, 0, 0, ninter), err[-1500:]
 
 
 @needs_ref
