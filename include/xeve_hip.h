@@ -52,7 +52,7 @@ uint64_t    xeve_hip_table_calls(void);
 uint64_t    xeve_hip_table_calls_main(void);
 /* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
  * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
- * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result, _tree_params, _ctu_job, _ctu_data (0 .. 29); -1 past the end.  For bindings in
+ * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result, _tree_params, _ctu_job, _ctu_data, _tree_inter (0 .. 30); -1 past the end.  For bindings in
  * other languages to check their record layouts at load time (no GPU needed). */
 int         xeve_hip_sizeof(int i);
 
@@ -765,12 +765,38 @@ typedef struct xeve_hip_ctu_data { /* the fields of XEVE_CU_DATA (xeve_type.h:57
     uint32_t map_scu[256], map_cu_mode[256];
     int16_t  coef[3][64 * 64];
     xeve_hip_pel reco[3][64 * 64];
+    int16_t  mv[256][2][2], mvd[256][2][2]; /* P / B slices: [unit][list][x, y]; zero for an intra unit and for a list the CU does not use */
+    int8_t   refi[256][2];                  /* (-1, -1) for an intra unit */
+    uint8_t  mvp_idx[256][2];
 } xeve_hip_ctu_data;
+/* The inter side of the walk (P / B slices): mode_coding_unit (xeve_mode.c:1310-1350) = mode_check_inter (the whole inter analysis above) then, when
+ * the inter winner has a residual, mode_check_intra with the candidate list cut against the SATD of the inter winner's luma prediction; a skipped CU
+ * at depth >= ecu_depth ends the split (:2162-2172).  Baseline (tool_admvp 0), square CUs 8 .. 64 (min_cu_inter >= 8). */
+typedef struct xeve_hip_tree_inter {
+    const xeve_hip_refpic *refp;        /* HOST table [refi * 2 + list] of device planes, as for xeve_hip_pinter_analyze_cu_jobs */
+    int32_t                s_ref_l, s_ref_c;
+    xeve_hip_inter_params  ipar;        /* rdo.log2_cuw / log2_cuh are set per node */
+    int16_t               *map_mv;      /* device, ctx->map_mv [unit][list][x, y]: read for the candidates, updated with every decided CU */
+    int8_t                *map_refi;    /* device, ctx->map_refi [unit][list]: updated */
+    const int16_t         *col_mv0, *col_mv1; /* device, refp[0][REFP_0 / REFP_1].map_mv */
+    const int16_t        (*coef_l)[8];  /* HOST: the interpolation filters (pi->mc_l_coeff / mc_c_coeff) */
+    const int16_t        (*coef_c)[4];
+    int32_t                ecu_depth;   /* ENC_ECU_DEPTH_B 4, minus 2 on odd POCs (ENC_ECU_ADAPTIVE) */
+    int32_t                pad_;
+} xeve_hip_tree_inter;
 /* org / mod: HOST arrays of three device pointers at sample (0, 0); mod (PIC_MODE(ctx)), map_scu, map_ipm, map_cu_mode are read AND updated; on return
  * they hold the CTUs' decisions as after update_to_ctx_map + update_map_scu (the caller's reset of the coded flags, xeve_mode.c:2591-2607, is not applied).
  * pic_elems as in xeve_hip_pintra_analyze_cu_jobs (map_cu_mode strides like map_scu).  states, jobs, out, next_best (core->s_next_best[..][..]), cost
  * (the tree's cost), workspace: device. */
 size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *params);
+/* Every slice type: params->ip.slice_type 0 B / 1 P with `inter` (max_cu / min_cu = ctx->param.max_cu_inter / min_cu_inter), 2 I with inter == NULL (the
+ * function below).  P / B: the chains of one call belong to ONE picture (jobs[].pic 0, pic_elems NULL) -- e.g. the CTU rows of a wavefront. */
+size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter, int s_org_l, int s_org_c);
+int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                   uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
+                                   const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter,
+                                   const xeve_hip_ctu_job *jobs, int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace,
+                                   size_t workspace_bytes, void *stream);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,

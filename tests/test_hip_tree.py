@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from _libs import SBAC_DTYPE
-from _tree_cases import CASES, CTU_DATA_DTYPE, CTU_JOB_DTYPE, make_case, run_oracle_picture
+from _tree_cases import CASES, CTU_DATA_DTYPE, CTU_JOB_DTYPE, INTER_CASES, make_case, make_inter_case, run_oracle_inter_picture, run_oracle_picture
 
 pytestmark = pytest.mark.gpu
 
@@ -63,3 +63,69 @@ def test_hip_ctu_mode_decision_matches_oracle(case):
     # the walk did decide something: some CTU is split and some CU is kept whole
     depths = np.concatenate([g[0]["depth"].reshape(-1) for g in got])
     assert len(np.unique(depths)) >= 2
+
+
+# ---- P / B slices ---------------------------------------------------------------------------------------------------------------------------------------------
+def run_hip_inter_case(c):
+    import ctypes as C
+
+    import torch
+    import xeve_amd
+    from test_hip_inter import hip_params
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from _mc_cases import refpic_table
+
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    refs, org = c["refs"], c["org"]
+    dplanes = [[torch.from_numpy(x).to(dev) for x in pic] for pic in refs["pics"]]
+    lut = {id(x): t for pic, dp in zip(refs["pics"], dplanes) for x, t in zip(pic, dp)}
+    dev_tab = refpic_table(refs, lambda a, off: lut[id(a)].data_ptr() + 2 * off)
+    dorg = [torch.from_numpy(x).to(dev) for x in org]
+    org_ptrs = [dorg[0].data_ptr() + 2 * refs["org_l"], dorg[1].data_ptr() + 2 * refs["org_c"], dorg[2].data_ptr() + 2 * refs["org_c"]]
+    mod = [torch.from_numpy(a.copy()).to(dev) for a in c["mod"]]
+    m = c["maps"]
+    ms, mc = (torch.from_numpy(m[k].view(np.int32).copy()).to(dev) for k in ("scu", "cu_mode"))
+    mi, mt, mv, mr = (torch.from_numpy(m[k].copy()).to(dev) for k in ("ipm", "tidx", "mv", "refi"))
+    col = [torch.from_numpy(a.copy()).to(dev) for a in c["col"]]
+    P = lib.TreeParams.from_buffer_copy(bytes(c["P"]))
+    I = lib.TreeInter()
+    I.refp, I.s_ref_l, I.s_ref_c, I.ipar = dev_tab.ctypes.data, refs["s_l"], refs["s_c"], hip_params(c["ipar"])
+    I.map_mv, I.map_refi, I.col_mv0, I.col_mv1, I.ecu_depth = mv.data_ptr(), mr.data_ptr(), col[0].data_ptr(), col[1].data_ptr(), c["ecu_depth"]
+    states = torch.from_numpy(c["entry"][0:1].view(np.uint8).copy()).to(dev)
+    per_ctu = []
+    for (x, y) in c["order"]:
+        jobs = np.zeros(1, CTU_JOB_DTYPE)
+        jobs["x"], jobs["y"] = x, y
+        out, nxt, cost = D.mode_analyze_ctu_jobs(org_ptrs, refs["s_l"], refs["s_c"], [t.data_ptr() for t in mod], mod[0].shape[1], mod[1].shape[1], ms, mi, mt, mc, states, P,
+                                                 torch.from_numpy(jobs.view(np.uint8).copy()).to(dev), inter=I)
+        torch.cuda.synchronize()
+        per_ctu.append((out.cpu().numpy().reshape(-1).view(CTU_DATA_DTYPE), nxt.cpu().numpy().reshape(-1).view(SBAC_DTYPE), cost.cpu().numpy()))
+        states = nxt.clone()
+    final = dict(mod=[t.cpu().numpy() for t in mod], scu=ms.cpu().numpy().view(np.uint32), ipm=mi.cpu().numpy(), cu_mode=mc.cpu().numpy().view(np.uint32), mv=mv.cpu().numpy(),
+                 refi=mr.cpu().numpy())
+    return per_ctu, final
+
+
+@pytest.mark.parametrize("case", INTER_CASES, ids=[str(c[0]) for c in INTER_CASES])
+def test_hip_ctu_mode_decision_of_p_and_b_slices_matches_oracle(case):
+    """mode_coding_unit on the device: the whole inter analysis, the intra analysis cut against the inter winner where that has a residual, the cheaper one kept;
+    the motion maps updated CU by CU (they are the next CU's merge / MVP candidates); a skipped CU ends the split from a POC-dependent depth on"""
+    c = make_inter_case(*case)
+    got, final = run_hip_inter_case(c)
+    exp = run_oracle_inter_picture(c)  # updates c["mod"], c["maps"] in place
+    modes = set()
+    for k in range(len(c["order"])):
+        d, nb, cost = got[k]
+        ed, enb, ecost = exp[k]
+        for f in CTU_DATA_DTYPE.names:
+            assert np.array_equal(d[f][0], ed[f][0]), (case, "ctu", k, f, np.argwhere(d[f][0] != ed[f][0])[:4].tolist())
+        assert nb[0:1].tobytes() == enb.tobytes(), (case, k, "coder state")
+        assert np.float64(cost[0]).tobytes() == np.float64(ecost).tobytes(), (case, k, cost[0], ecost)
+        modes |= set(np.unique(ed["pred_mode"][0]).tolist())
+    for j in range(3 if c["idc"] else 1):
+        assert np.array_equal(final["mod"][j], c["mod"][j]), (case, "picture", j)
+    for f in ("scu", "ipm", "cu_mode", "mv", "refi"):
+        assert np.array_equal(final[f].reshape(c["maps"][f].shape), c["maps"][f]), (case, "map", f)
+    assert len(modes) >= 3, modes  # intra, inter and skip CUs all occur

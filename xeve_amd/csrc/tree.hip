@@ -12,7 +12,10 @@
 //     LEAF(L)         copy_to_cu_data (:868) of the intra CU, mode_cpy_rec_to_ref (:797), the early termination (:2174-2187), split_cu_flag = 1 priced
 //     4 x { the quadrant's subtree; CHILD_DONE(L): its cost added, copy_cu_data (:430) into the parent, update_map_scu (:1036) }
 //     EXIT(L)         the cheaper alternative kept (a split must win by more than 0.0001), picture + split mode + coder state of the winner
-// and consecutive tree operations between two intra analyses are ONE launch (k_tree_ops, one workgroup per chain).
+// and consecutive tree operations between two analyses are ONE launch (k_tree_ops, one workgroup per chain).
+// P / B slices (mode_coding_unit, :1310-1350): between ENTER and LEAF the node runs [candidates from the maps, xeve_hip_inter_candidates] [the whole inter
+// analysis, xeve_hip_pinter_analyze_cu_jobs] [SATD of the inter winner's luma prediction] MID(L) [the intra analysis, cut against that SATD]; LEAF keeps the intra
+// result only where the inter winner has a residual and the intra cost is smaller (mode_check_intra, :1226-1308); a skipped CU at depth >= ecu_depth is not split.
 // All costs are doubles built with the reference's operations in the reference's order (-ffp-contract=off), compared as the reference compares them.
 #include <algorithm>
 #include <cstring>
@@ -24,8 +27,8 @@ typedef xeve_hip_ctu_data CtuData;
 typedef xeve_hip_sbac     SbacState;
 
 struct Node { // one per (level, chain)
-    int    active, x0, y0, leaf, do_split, best_split, dist_cu, pad_;
-    double cost_best, cost_temp;
+    int    active, x0, y0, leaf, do_split, best_split, dist_cu, cu_mode, try_intra, pad_;
+    double cost_best, cost_temp, unit_cost;
 };
 
 struct TreeK {
@@ -50,9 +53,20 @@ struct TreeK {
     const xeve_hip_intra_result *ires;                         // [nchains]
     const int16_t              *icoef;                         // dense blocks of the node's analysis: Y of all chains, then U, then V
     const pel                  *irec;
+    // P / B slices
+    int                         inter, ecu_depth, s_org_l, pad_;
+    int16_t                   (*map_mv)[2][2];
+    int8_t                    (*map_refi)[2];
+    xeve_hip_inter_job         *ejobs;                         // [nchains]
+    xeve_hip_job               *sjobs;                         // [nchains]: SATD(original, inter winner's luma prediction)
+    const xeve_hip_inter_result *eres;
+    const int16_t              *ecoef;                         // Y of all chains, then U, then V
+    const pel                  *erec[3];                       // [nchains][block] per component
+    const int32_t              *esatd;
+    const SbacState            *enext;                         // [nchains]: core->s_next_best of the inter analysis
 };
 
-enum { OP_ENTER = 0, OP_LEAF = 1, OP_CHILD_DONE = 2, OP_EXIT = 3, OP_ROOT_DONE = 4 };
+enum { OP_ENTER = 0, OP_LEAF = 1, OP_CHILD_DONE = 2, OP_EXIT = 3, OP_ROOT_DONE = 4, OP_MID = 5 };
 #define MAX_OPS 12
 struct OpList {
     int           n;
@@ -129,6 +143,8 @@ __device__ static void cud_copy(CtuData *dst, const CtuData *src, int x, int y, 
         dst->pred_mode[di] = src->pred_mode[si], dst->ipm[0][di] = src->ipm[0][si], dst->ipm[1][di] = src->ipm[1][si], dst->depth[di] = src->depth[si];
         dst->map_scu[di] = src->map_scu[si], dst->map_cu_mode[di] = src->map_cu_mode[si];
         for(int c = 0; c < 3; c++) dst->nnz[c][di] = src->nnz[c][si];
+        for(int k = 0; k < 4; k++) (&dst->mv[di][0][0])[k] = (&src->mv[si][0][0])[k], (&dst->mvd[di][0][0])[k] = (&src->mvd[si][0][0])[k];
+        for(int k = 0; k < 2; k++) dst->refi[di][k] = src->refi[si][k], dst->mvp_idx[di][k] = src->mvp_idx[si][k];
     }
     for(int t = threadIdx.x; t < cw * cw; t += blockDim.x) {
         const int j = t >> log2, i = t & (cw - 1), d = (y + j) * cs + x + i;
@@ -160,6 +176,10 @@ __device__ static void update_map(const TreeK &K, int pic, const CtuData *d, int
     for(int t = threadIdx.x; t < w * h; t += blockDim.x) {
         const int j = t / w, i = t - j * w, g = ((y >> 2) + j) * K.w_scu + (x >> 2) + i, u = j * n + i;
         ms[g] = d->map_scu[u], mc[g] = d->map_cu_mode[u], mi[g] = d->ipm[0][u];
+        if(K.inter) {
+            for(int k = 0; k < 4; k++) (&K.map_mv[g][0][0])[k] = (&d->mv[u][0][0])[k];
+            K.map_refi[g][0] = d->refi[u][0], K.map_refi[g][1] = d->refi[u][1];
+        }
     }
 }
 __device__ static void rec_to_pic(const TreeK &K, int pic, const CtuData *d, int x, int y, int cu)
@@ -222,10 +242,20 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
             nd->cost_temp = cost_temp;
         }
         nd->active = active, nd->x0 = x0, nd->y0 = y0, nd->leaf = leaf;
+        // a chain whose node is off analyses a CU of this size that lies inside the picture (the schedule runs no analysis of a size the picture cannot hold)
+        const int jx = leaf ? x0 : max(0, min(J.x, K.pic_w - cu)), jy = leaf ? y0 : max(0, min(J.y, K.pic_h - cu));
         xeve_hip_intra_job ij;
         memset(&ij, 0, sizeof(ij));
-        ij.x = leaf ? x0 : J.x, ij.y = leaf ? y0 : J.y, ij.inter_satd = 0xFFFFFFFFu, ij.sbac = c, ij.pic = J.pic; // a chain that is off analyses its CTU's first CU again
+        ij.x = jx, ij.y = jy, ij.inter_satd = 0xFFFFFFFFu, ij.sbac = c, ij.pic = J.pic;
         K.ijobs[c] = ij;
+        if(K.inter) {
+            xeve_hip_inter_job ej;
+            memset(&ej, 0, sizeof(ej));
+            ej.x = jx, ej.y = jy, ej.sbac = c; // ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288)
+            K.ejobs[c] = ej;
+            K.sjobs[c].off1 = jy * K.s_org_l + jx, K.sjobs[c].off2 = c * cu * cu;
+            nd->try_intra = 0, nd->cu_mode = 0, nd->unit_cost = MAX_COST;
+        }
         sh[0] = active, sh[1] = leaf, sh[2] = boundary, sh[3] = x0, sh[4] = y0;
     }
     __syncthreads();
@@ -235,6 +265,41 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
     if(leaf) clear_map(K, J.pic, x0, y0, cu);
 }
 
+// copy_to_cu_data (:868-1034) of the node's CU into its cu_data_temp: the unit fields, then the dense blocks
+__device__ static void unit_to_temp(const TreeK &K, CtuData *t, int log2, int cud, int n, int cu_mode, const int8_t *ipm, const int32_t *nnz, const xeve_hip_inter_result *R,
+                                    const int16_t *cy, const int16_t *cu_, const int16_t *cv, const pel *ry, const pel *ru, const pel *rv, int n0, int n1)
+{
+    const uint32_t scu = ((uint32_t)K.slice_num & 0x7F) | ((uint32_t)K.slice_qp << 16) | (1u << 31) | (cu_mode == 0 ? 1u << 15 : 0) | (cu_mode == 2 ? 1u << 23 : 0); // _SN, _QP, _COD, _IF, _SF
+    const uint32_t cum = ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);                                                                                            // MCU_SET_LOGW / LOGH
+    for(int u = threadIdx.x; u < n; u += blockDim.x) {
+        t->pred_mode[u] = (uint8_t)cu_mode, t->depth[u] = (int8_t)cud;
+        if(cu_mode == 0) t->ipm[0][u] = ipm[0], t->ipm[1][u] = K.idc ? ipm[1] : 0;
+        t->nnz[0][u] = nnz[0], t->nnz[1][u] = K.idc ? nnz[1] : 0, t->nnz[2][u] = K.idc ? nnz[2] : 0;
+        t->map_scu[u] = scu, t->map_cu_mode[u] = cum;
+        for(int k = 0; k < 4; k++) (&t->mv[u][0][0])[k] = R ? (&R->mv[0][0])[k] : 0, (&t->mvd[u][0][0])[k] = R ? (&R->mvd[0][0])[k] : 0;
+        for(int k = 0; k < 2; k++) t->refi[u][k] = R ? R->refi[k] : -1, t->mvp_idx[u][k] = R ? R->mvp_idx[k] : 0;
+    }
+    for(int i = threadIdx.x; i < n0; i += blockDim.x) t->coef[0][i] = cy[i], t->reco[0][i] = ry[i];
+    if(K.idc)
+        for(int i = threadIdx.x; i < n1; i += blockDim.x) t->coef[1][i] = cu_[i], t->reco[1][i] = ru[i], t->coef[2][i] = cv[i], t->reco[2][i] = rv[i];
+}
+
+// P / B slices, after the inter analysis: mode_check_inter's store (:1199-1218) and what mode_check_intra needs (:1245-1262)
+__device__ static void op_mid(const TreeK &K, int c, int L)
+{
+    Node *nd = AT(K.node, L);
+    if(!nd->leaf) return;
+    const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
+    const xeve_hip_inter_result R = K.eres[c];
+    unit_to_temp(K, AT(K.temp, L), log2, cud, n, R.cu_mode, nullptr, R.nnz, &K.eres[c], K.ecoef + (long)c * n0, K.ecoef + (long)K.nchains * n0 + (long)c * n1,
+                 K.ecoef + (long)K.nchains * (n0 + n1) + (long)c * n1, K.erec[0] + (long)c * n0, K.erec[1] + (long)c * n1, K.erec[2] + (long)c * n1, n0, n1);
+    if(threadIdx.x == 0) {
+        nd->unit_cost = R.cost, nd->cu_mode = R.cu_mode;
+        nd->try_intra = R.nnz[0] != 0 || R.nnz[1] != 0 || R.nnz[2] != 0;
+        if(nd->try_intra) K.ijobs[c].inter_satd = (uint32_t)K.esatd[c]; // core->inter_satd (a chain that does not try intra keeps the job: its result is dropped)
+    }
+}
+
 __device__ static void op_leaf(const TreeK &K, int c, int L, int *sh)
 {
     const xeve_hip_ctu_job J = K.jobs[c];
@@ -242,28 +307,20 @@ __device__ static void op_leaf(const TreeK &K, int c, int L, int *sh)
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
     const int active = nd->active, leaf = nd->leaf, x0 = nd->x0, y0 = nd->y0;
     CtuData *t = AT(K.temp, L), *b = AT(K.best, L);
-    if(leaf) { // mode_coding_unit (:1310-1350) in an I slice: the intra analysis always becomes the CU's mode; copy_to_cu_data (:868-1034)
+    if(leaf) { // mode_coding_unit (:1310-1350): the intra analysis becomes the CU's mode in an I slice, and in a P / B slice where it is cheaper than the inter winner
         const xeve_hip_intra_result R = K.ires[c];
-        const uint32_t scu = ((uint32_t)K.slice_num & 0x7F) | ((uint32_t)K.slice_qp << 16) | (1u << 15) | (1u << 31); // MCU_SET_IF, _COD, _SN, _QP
-        const uint32_t cum = ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);                                          // MCU_SET_LOGW / LOGH
-        for(int u = threadIdx.x; u < n; u += blockDim.x) {
-            t->pred_mode[u] = 0 /* MODE_INTRA */, t->ipm[0][u] = R.ipm[0], t->ipm[1][u] = K.idc ? R.ipm[1] : 0, t->depth[u] = (int8_t)cud;
-            t->nnz[0][u] = R.nnz[0], t->nnz[1][u] = K.idc ? R.nnz[1] : 0, t->nnz[2][u] = K.idc ? R.nnz[2] : 0;
-            t->map_scu[u] = scu, t->map_cu_mode[u] = cum;
-        }
-        const int16_t *cy = K.icoef + (long)c * n0;
-        const pel     *ry = K.irec + (long)c * n0;
-        for(int i = threadIdx.x; i < n0; i += blockDim.x) t->coef[0][i] = cy[i], t->reco[0][i] = ry[i];
-        for(int k = 1; k <= 2 && K.idc; k++) {
-            const long o = (long)K.nchains * (n0 + (long)(k - 1) * n1) + (long)c * n1;
-            for(int i = threadIdx.x; i < n1; i += blockDim.x) t->coef[k][i] = K.icoef[o + i], t->reco[k][i] = K.irec[o + i];
-        }
+        const int intra_wins = !K.inter || (nd->try_intra && R.cost < nd->unit_cost);
+        if(intra_wins)
+            unit_to_temp(K, t, log2, cud, n, 0, R.ipm, R.nnz, nullptr, K.icoef + (long)c * n0, K.icoef + (long)K.nchains * n0 + (long)c * n1,
+                         K.icoef + (long)K.nchains * (n0 + n1) + (long)c * n1, K.irec + (long)c * n0, K.irec + (long)K.nchains * n0 + (long)c * n1,
+                         K.irec + (long)K.nchains * (n0 + n1) + (long)c * n1, n0, n1);
         __syncthreads();
         if(threadIdx.x == 0) {
-            const double cost_temp = nd->cost_temp + R.cost;
-            nd->dist_cu = R.dist_cu;
+            if(intra_wins) nd->unit_cost = R.cost, nd->cu_mode = 0, nd->dist_cu = R.dist_cu;
+            else nd->dist_cu = 0x7FFFFFFF;
+            const double cost_temp = nd->cost_temp + nd->unit_cost;
             sh[0] = nd->cost_best > cost_temp;
-            if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0, *AT(K.tdepth, L) = K.sbest[c]; // (:2116-2135)
+            if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0, *AT(K.tdepth, L) = intra_wins ? K.sbest[c] : K.enext[c]; // (:2116-2135)
             nd->cost_temp = nd->cost_best;
         }
         __syncthreads();
@@ -277,7 +334,8 @@ __device__ static void op_leaf(const TreeK &K, int c, int L, int *sh)
     }
     if(threadIdx.x == 0) {
         int next_split = 1;
-        if(active && nd->cost_best != MAX_COST) { // early termination in I pictures (:2174-2187)
+        if(active && nd->cost_best != MAX_COST && K.inter && cud >= K.ecu_depth && nd->cu_mode == 2 /* MODE_SKIP */) next_split = 0; // early CU termination (:2162-2172)
+        if(active && nd->cost_best != MAX_COST && !K.inter) { // early termination in I pictures (:2174-2187)
             const int th = 1 << (2 * log2 + 7);
             if(nd->dist_cu < th) {
                 const int bits_inc = (2 * log2 >= 6 ? 2 : 0) + 8;
@@ -361,6 +419,7 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeK K, OpList ops)
         case OP_LEAF: op_leaf(K, c, L, sh); break;
         case OP_CHILD_DONE: op_child_done(K, c, L, part); break;
         case OP_EXIT: op_exit(K, c, L, sh); break;
+        case OP_MID: op_mid(K, c, L); break;
         default: op_root_done(K, c, L); break;
         }
         __syncthreads(); // (a workgroup-scope release / acquire: the next operation reads what this one wrote to global memory)
@@ -368,9 +427,12 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeK K, OpList ops)
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------------------
+extern "C" int xeve_hip_satd_jobs(const pel *p1, int s1, const pel *p2, int s2, const xeve_hip_job *jobs, int njobs, const int32_t *cand_off, int ncand, int w, int h,
+                                  int bit_depth, int32_t *out, void *stream);
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 struct TreeLayout {
     size_t node, curr, next, before, tdepth, sbest, best, temp, ijobs, ires, icoef, irec, iws, iws_bytes, total, zero_from, zero_bytes;
+    size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, zero32, ews, ews_bytes; // P / B slices
 };
 static bool tree_params_ok(const xeve_hip_tree_params *p)
 {
@@ -378,15 +440,31 @@ static bool tree_params_ok(const xeve_hip_tree_params *p)
            xh_pow2(p->min_cu) && p->min_cu >= 4 && p->max_cu >= p->min_cu && p->min_cuwh >= 4 && xh_pow2(p->min_cuwh) &&
            p->ip.w_scu == (p->pic_w + 3) >> 2 && p->ip.h_scu == (p->pic_h + 3) >> 2;
 }
+static bool tree_inter_ok(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I)
+{   // the inter analysis is composed for square CUs 8 .. 64 (every inter CU of the Baseline quad-tree at the presets that keep min_cu_inter at 8)
+    return I && (p->ip.slice_type == 0 || p->ip.slice_type == 1) && p->min_cu >= 8 && I->refp && I->map_mv && I->map_refi && I->col_mv0 && I->coef_l && I->coef_c &&
+           (p->ip.slice_type == 1 || I->col_mv1) && I->ipar.rdo.slice_type == p->ip.slice_type && I->ipar.rdo.pic_w == p->pic_w && I->ipar.rdo.pic_h == p->pic_h &&
+           I->ipar.rdo.chroma_format_idc == p->ip.chroma_format_idc && I->ipar.rdo.bit_depth == p->ip.bit_depth;
+}
 static xeve_hip_intra_params level_params(const xeve_hip_tree_params *p, int log2)
 {
     xeve_hip_intra_params ip = p->ip;
     ip.log2_cuw = ip.log2_cuh = log2;
     return ip;
 }
-static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p)
+static xeve_hip_inter_params level_inter_params(const xeve_hip_tree_inter *I, int log2)
+{
+    xeve_hip_inter_params ep = I->ipar;
+    ep.rdo.log2_cuw = ep.rdo.log2_cuh = log2;
+    return ep;
+}
+// a node of this size can be a CU at all: within max_cu and no larger than the picture (the analyses of a size the picture cannot hold are left out of the schedule)
+static bool level_has_cu(const xeve_hip_tree_params *p, int log2) { return (1 << log2) <= p->max_cu && (1 << log2) <= p->pic_w && (1 << log2) <= p->pic_h; }
+
+static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c)
 {
     TreeLayout L;
+    memset(&L, 0, sizeof(L));
     const size_t N = (size_t)nchains;
     const int    idc = p->ip.chroma_format_idc, top = std::min(1 << p->log2_ctu, p->max_cu), n0 = top * top, n1 = idc ? n0 >> ((idc <= 2) + (idc <= 1)) : 0;
     size_t o = 0;
@@ -394,41 +472,68 @@ static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p)
     L.zero_from = o;
     L.node = take(5 * N * sizeof(Node)), L.curr = take(5 * N * sizeof(SbacState)), L.next = take(5 * N * sizeof(SbacState)), L.before = take(5 * N * sizeof(SbacState));
     L.tdepth = take(5 * N * sizeof(SbacState)), L.sbest = take(N * sizeof(SbacState)), L.best = take(5 * N * sizeof(CtuData)), L.temp = take(5 * N * sizeof(CtuData));
+    L.zero32 = take(64);
     L.zero_bytes = o - L.zero_from;
     L.ijobs = take(N * sizeof(xeve_hip_intra_job)), L.ires = take(N * sizeof(xeve_hip_intra_result));
     L.icoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64), L.irec = take(N * ((size_t)n0 + 2 * (size_t)n1) * sizeof(pel) + 64);
-    L.iws = o, L.iws_bytes = 0;
+    if(I) {
+        L.ejobs = take(N * sizeof(xeve_hip_inter_job)), L.sjobs = take(N * sizeof(xeve_hip_job)), L.eres = take(N * sizeof(xeve_hip_inter_result));
+        L.ecoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64);
+        for(int c = 0; c < 3; c++) L.erec[c] = take(N * (size_t)(c ? n1 : n0) * sizeof(pel) + 64);
+        L.epred = take(N * (size_t)n0 * sizeof(pel) + 64), L.esatd = take(N * 4), L.enext = take(N * sizeof(SbacState));
+    }
+    L.iws = o;
     for(int log2 = 2; log2 <= p->log2_ctu; log2++) {
-        if((1 << log2) > p->max_cu) continue;
+        if(!level_has_cu(p, log2)) continue;
         const xeve_hip_intra_params ip = level_params(p, log2);
         L.iws_bytes = std::max(L.iws_bytes, xeve_hip_pintra_analyze_cu_workspace(nchains, nchains, &ip));
+        if(I) {
+            const xeve_hip_inter_params ep = level_inter_params(I, log2);
+            L.ews_bytes = std::max(L.ews_bytes, xeve_hip_pinter_analyze_cu_workspace(nchains, nchains, &ep, s_org_l, s_org_c));
+        }
     }
-    L.total = o + al(L.iws_bytes);
+    o += al(L.iws_bytes);
+    L.ews = o;
+    L.total = o + al(L.ews_bytes);
     return L;
 }
 
+extern "C" size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c)
+{
+    if(!tree_params_ok(p) || nchains <= 0 || (p->ip.slice_type != 2 && !tree_inter_ok(p, I))) return 0;
+    return tree_layout(nchains, p, p->ip.slice_type == 2 ? nullptr : I, s_org_l, s_org_c).total;
+}
 extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *p)
 {
-    if(!tree_params_ok(p) || nchains <= 0) return 0;
-    return tree_layout(nchains, p).total;
+    if(!tree_params_ok(p) || nchains <= 0 || p->ip.slice_type != 2) return 0;
+    return tree_layout(nchains, p, nullptr, 0, 0).total;
 }
 
 namespace {
-struct Walk { // the static schedule of one CTU: every node of the full quad-tree in the reference's order; operations between two intra analyses fused
+enum { AN_NONE = 0, AN_INTRA = 1, AN_INTER = 2 };
+struct Walk { // the static schedule of one CTU: every node of the full quad-tree in the reference's order; operations between two analyses fused
     const xeve_hip_tree_params *p;
-    std::vector<OpList>         launches;   // launches[i] runs before analysis i (and the last one after the last analysis)
-    std::vector<int>            analysis;   // log2 of the CU size of analysis i
+    bool                        inter;
+    std::vector<OpList>         launches; // launches[i] runs before analysis i (and the last one after the last analysis)
+    std::vector<int>            kind, size; // of analysis i: AN_*, log2 of the CU size
     OpList                      cur;
+    void flush(int k, int log2) { launches.push_back(cur), kind.push_back(k), size.push_back(log2), cur.n = 0; }
     void add(int op, int L, int part)
     {
-        if(cur.n == MAX_OPS) launches.push_back(cur), analysis.push_back(0), cur.n = 0; // (0 = no analysis between)
+        if(cur.n == MAX_OPS) flush(AN_NONE, 0);
         cur.op[cur.n] = (unsigned char)op, cur.lvl[cur.n] = (unsigned char)L, cur.part[cur.n] = (signed char)part, cur.n++;
     }
     void node(int L, int part)
     {
         const int cu = 1 << (L + 2);
         add(OP_ENTER, L, part);
-        if(cu <= p->max_cu) launches.push_back(cur), analysis.push_back(L + 2), cur.n = 0;
+        if(level_has_cu(p, L + 2)) {
+            if(inter) {
+                flush(AN_INTER, L + 2);
+                add(OP_MID, L, 0);
+            }
+            flush(AN_INTRA, L + 2);
+        }
         add(OP_LEAF, L, 0);
         if(cu > 4 && cu > p->min_cu && cu > p->min_cuwh)
             for(int q = 0; q < 4; q++) {
@@ -440,18 +545,20 @@ struct Walk { // the static schedule of one CTU: every node of the full quad-tre
 };
 } // namespace
 
-extern "C" int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
-                                                    uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
-                                                    const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *p, const xeve_hip_ctu_job *jobs,
-                                                    int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace,
-                                                    size_t workspace_bytes, void *stream)
+extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                              uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
+                                              const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I,
+                                              const xeve_hip_ctu_job *jobs, int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost,
+                                              void *workspace, size_t workspace_bytes, void *stream)
 {
     XH_ENTER();
     XH_REQUIRE(org && mod && map_scu && map_ipm && map_tidx && map_cu_mode && states && nstates > 0 && jobs && nchains >= 0 && out && next_best && cost && workspace);
     XH_REQUIRE(tree_params_ok(p));
     XH_REQUIRE(org[0] && mod[0] && (p->ip.chroma_format_idc == 0 || (org[1] && org[2] && mod[1] && mod[2])));
+    if(p->ip.slice_type == 2) I = nullptr;
+    else XH_REQUIRE(tree_inter_ok(p, I) && pic_elems == nullptr); // (the inter analysis takes one set of pictures per call)
     if(nchains == 0) return XEVE_HIP_OK;
-    const TreeLayout L = tree_layout(nchains, p);
+    const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c);
     XH_REQUIRE(workspace_bytes >= L.total);
     hipStream_t st = (hipStream_t)stream;
     char       *W = (char *)workspace;
@@ -467,27 +574,58 @@ extern "C" int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const or
     K.node = (Node *)(W + L.node), K.curr = (SbacState *)(W + L.curr), K.next = (SbacState *)(W + L.next), K.before = (SbacState *)(W + L.before);
     K.tdepth = (SbacState *)(W + L.tdepth), K.sbest = (SbacState *)(W + L.sbest), K.best = (CtuData *)(W + L.best), K.temp = (CtuData *)(W + L.temp);
     K.ijobs = (xeve_hip_intra_job *)(W + L.ijobs), K.ires = (xeve_hip_intra_result *)(W + L.ires), K.icoef = (int16_t *)(W + L.icoef), K.irec = (pel *)(W + L.irec);
+    if(I) {
+        K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
+        K.ejobs = (xeve_hip_inter_job *)(W + L.ejobs), K.sjobs = (xeve_hip_job *)(W + L.sjobs), K.eres = (xeve_hip_inter_result *)(W + L.eres), K.ecoef = (int16_t *)(W + L.ecoef);
+        for(int c = 0; c < 3; c++) K.erec[c] = (pel *)(W + L.erec[c]);
+        K.esatd = (int32_t *)(W + L.esatd), K.enext = (SbacState *)(W + L.enext);
+    }
     XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
 
     Walk wk;
-    wk.p = p, wk.cur.n = 0;
+    wk.p = p, wk.inter = I != nullptr, wk.cur.n = 0;
     wk.node(p->log2_ctu - 2, -1);
     wk.add(OP_ROOT_DONE, p->log2_ctu - 2, 0);
-    wk.launches.push_back(wk.cur), wk.analysis.push_back(0);
+    wk.flush(AN_NONE, 0);
     const pel *const modc[3] = {mod[0], mod[1], mod[2]};
     for(size_t i = 0; i < wk.launches.size(); i++) {
         k_tree_ops<<<nchains, 256, 0, st>>>(K, wk.launches[i]);
-        const int log2 = wk.analysis[i];
-        if(!log2) continue;
-        const xeve_hip_intra_params ip = level_params(p, log2);
-        const int rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems,
-                                                       K.curr + (size_t)(log2 - 2) * nchains, nchains, &ip, K.ijobs, nchains,
-                                                       (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest, W + L.iws,
-                                                       L.iws_bytes, stream);
+        const int log2 = wk.size[i], cu = 1 << log2;
+        int rc = XEVE_HIP_OK;
+        if(wk.kind[i] == AN_INTRA) {
+            const xeve_hip_intra_params ip = level_params(p, log2);
+            rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
+                                                 nchains, &ip, K.ijobs, nchains, (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest,
+                                                 W + L.iws, L.iws_bytes, stream);
+        }
+        else if(wk.kind[i] == AN_INTER) {
+            const xeve_hip_inter_params ep = level_inter_params(I, log2);
+            rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
+                                           p->ip.slice_type, K.ejobs, nchains, stream);
+            if(rc == XEVE_HIP_OK)
+                rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, K.ejobs, nchains,
+                                                     I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + L.eres), (int16_t *)(W + L.ecoef), (pel *)(W + L.erec[0]),
+                                                     (pel *)(W + L.erec[1]), (pel *)(W + L.erec[2]), (pel *)(W + L.epred), (xeve_hip_sbac *)(W + L.enext), W + L.ews,
+                                                     L.ews_bytes, stream);
+            if(rc == XEVE_HIP_OK) // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
+                rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + L.epred), cu, K.sjobs, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
+                                        (int32_t *)(W + L.esatd), stream);
+        }
         if(rc != XEVE_HIP_OK) return rc;
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                                    uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
+                                                    const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *p, const xeve_hip_ctu_job *jobs,
+                                                    int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace,
+                                                    size_t workspace_bytes, void *stream)
+{
+    XH_REQUIRE(p && p->ip.slice_type == 2);
+    return xeve_hip_mode_analyze_ctu_jobs(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, nstates, p, nullptr, jobs,
+                                          nchains, out, next_best, cost, workspace, workspace_bytes, stream);
 }
 
 // ---- host-memory form of ONE call of ctx->fn_mode_analyze_lcu in an I slice (stage, launch, synchronise: one exchange per CTU) --------------------------------

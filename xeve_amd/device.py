@@ -323,28 +323,39 @@ def pintra_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_
     return res, coef, rec, best
 
 
-def mode_analyze_ctu_intra_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, pic_elems=None,
-                                workspace=None):
-    """the mode decision of a batch of I-picture CTUs (xeve_hip_mode_analyze_ctu_intra_jobs): one chain per job, walked in lockstep.  params: lib.TreeParams; jobs:
-    uint8 tensor of lib.CTU_JOB_DTYPE records; the planes of the picture being reconstructed (mod_ptrs) and map_scu / map_ipm / map_cu_mode are updated in place.
-    Returns (ctu data uint8 [nchains, 57856], next_best uint8 [nchains, 180], cost float64 [nchains])."""
+def mode_analyze_ctu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, inter=None, pic_elems=None,
+                          workspace=None):
+    """the mode decision of a batch of CTUs (xeve_hip_mode_analyze_ctu_jobs): one chain per job, walked in lockstep.  params: lib.TreeParams; inter: lib.TreeInter for a
+    P / B slice (its refp = address of a HOST table of lib.REFPIC_DTYPE records with device planes; map_mv / map_refi / col_mv*: device addresses; coef_l / coef_c are
+    filled in here), None for an I slice; jobs: uint8 tensor of lib.CTU_JOB_DTYPE records.  The planes of the picture being reconstructed (mod_ptrs) and the maps are
+    updated in place.  Returns (ctu data uint8 [nchains, 62976], next_best uint8 [nchains, 180], cost float64 [nchains])."""
     L = _lib.load()
     n, nstates, dev = jobs.numel() // 16, states.numel() // SBAC_BYTES, jobs.device
-    out = torch.zeros((n, 57856), dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, _lib.CTU_DATA_BYTES), dtype=torch.uint8, device=dev)
     nxt = torch.zeros((n, SBAC_BYTES), dtype=torch.uint8, device=dev)
     cost = torch.zeros(n, dtype=torch.float64, device=dev)
-    need = L.xeve_hip_mode_analyze_ctu_intra_workspace(n, C.byref(params))
+    ip = None
+    if inter is not None:
+        inter.coef_l, inter.coef_c = baseline_coef_l().ctypes.data, baseline_coef_c().ctypes.data
+        ip = C.byref(inter)
+    need = L.xeve_hip_mode_analyze_ctu_workspace(n, C.byref(params), ip, s_org_l, s_org_c)
     if need == 0 and n:
-        raise _lib.XeveHipError("xeve_hip_mode_analyze_ctu_intra_workspace: parameters outside the supported set")
+        raise _lib.XeveHipError("xeve_hip_mode_analyze_ctu_workspace: parameters outside the supported set")
     if workspace is None:
         workspace = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
     org = (C.c_void_p * 3)(*[int(a) for a in org_ptrs])
     mod = (C.c_void_p * 3)(*[int(a) for a in mod_ptrs])
     pe = (C.c_int64 * 5)(*[int(v) for v in pic_elems]) if pic_elems is not None else None
-    _lib.check(L.xeve_hip_mode_analyze_ctu_intra_jobs(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, _ptr(map_scu), _ptr(map_ipm), _ptr(map_tidx), _ptr(map_cu_mode), pe,
-                                                      _ptr(states), nstates, C.byref(params), _ptr(jobs), n, _ptr(out), _ptr(nxt), _ptr(cost), _ptr(workspace),
-                                                      workspace.numel(), _stream()))
+    _lib.check(L.xeve_hip_mode_analyze_ctu_jobs(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, _ptr(map_scu), _ptr(map_ipm), _ptr(map_tidx), _ptr(map_cu_mode), pe,
+                                                _ptr(states), nstates, C.byref(params), ip, _ptr(jobs), n, _ptr(out), _ptr(nxt), _ptr(cost), _ptr(workspace),
+                                                workspace.numel(), _stream()))
     return out, nxt, cost
+
+
+def mode_analyze_ctu_intra_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, pic_elems=None,
+                                workspace=None):
+    """the I-slice form (chains may belong to different pictures: pic_elems)"""
+    return mode_analyze_ctu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, None, pic_elems, workspace)
 
 
 def inter_candidates(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, h_scu, log2_cuw, log2_cuh, slice_type, jobs):

@@ -64,7 +64,15 @@ class TreeParams(C.Structure):  # xeve_hip_tree_params
 CU_DEPTHS = 10  # XEVE_HIP_CU_DEPTHS
 CTU_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("sbac", "<i4"), ("pic", "<i4")]  # xeve_hip_ctu_job (16 B)
 CTU_DATA_DTYPE = [("split_mode", "i1", (CU_DEPTHS, 256)), ("pred_mode", "u1", (256,)), ("ipm", "i1", (2, 256)), ("depth", "i1", (256,)), ("nnz", "<i4", (3, 256)),
-                  ("map_scu", "<u4", (256,)), ("map_cu_mode", "<u4", (256,)), ("coef", "<i2", (3, 4096)), ("reco", "<i2", (3, 4096))]  # xeve_hip_ctu_data (57856 B)
+                  ("map_scu", "<u4", (256,)), ("map_cu_mode", "<u4", (256,)), ("coef", "<i2", (3, 4096)), ("reco", "<i2", (3, 4096)), ("mv", "<i2", (256, 2, 2)),
+                  ("mvd", "<i2", (256, 2, 2)), ("refi", "i1", (256, 2)), ("mvp_idx", "u1", (256, 2))]  # xeve_hip_ctu_data (62976 B)
+CTU_DATA_BYTES = 62976
+
+
+class TreeInter(C.Structure):  # xeve_hip_tree_inter
+    _fields_ = [("refp", C.c_void_p), ("s_ref_l", C.c_int32), ("s_ref_c", C.c_int32), ("ipar", InterParams), ("map_mv", C.c_void_p), ("map_refi", C.c_void_p),
+                ("col_mv0", C.c_void_p), ("col_mv1", C.c_void_p), ("coef_l", C.c_void_p), ("coef_c", C.c_void_p), ("ecu_depth", C.c_int32), ("pad_", C.c_int32)]
+
 INTRA_JOB_DTYPE = [("x", "<i4"), ("y", "<i4"), ("inter_satd", "<u4"), ("sbac", "<i4"), ("pic", "<i4"), ("ctx_skip", "u1"), ("ctx_pred_mode", "u1"),
                    ("pad_", "u1", (2,))]  # xeve_hip_intra_job (24 B)
 INTRA_RESULT_DTYPE = [("cost", "<f8"), ("dist_cu", "<i4"), ("nnz", "<i4", (3,)), ("pred_cnt", "<i4"), ("ipm", "i1", (2,)), ("pad_", "i1", (2,))]  # xeve_hip_intra_result (32 B)
@@ -192,6 +200,9 @@ FUNCTIONS = {
     "xeve_hip_mode_analyze_ctu_intra_workspace": (C.c_size_t, [c_int, c_void_p]),
     "xeve_hip_mode_analyze_ctu_intra_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4 +
                                              [C.c_size_t, c_void_p]),
+    "xeve_hip_mode_analyze_ctu_workspace": (C.c_size_t, [c_int, c_void_p, c_void_p, c_int, c_int]),
+    "xeve_hip_mode_analyze_ctu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 4 +
+                                       [C.c_size_t, c_void_p]),
     "xeve_hip_mode_analyze_ctu_intra_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 3),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
