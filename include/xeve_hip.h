@@ -808,6 +808,14 @@ int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s
 int xeve_hip_mode_analyze_ctu_intra_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
                                          const xeve_hip_tree_params *params, int x0, int y0, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost);
+/* The same for every slice type.  I slices (inter == NULL): the function above.  P / B slices: `inter` with HOST pointers throughout -- refp[].y/u/v = sample
+ * (0, 0) of the reference pictures' host planes, which extend pad_l / pad_c samples around the picture; map_mv / map_refi = ctx->map_mv / map_refi (read and
+ * updated); col_mv0 / col_mv1 = refp[0][REFP_0 / REFP_1].map_mv -- and resident pictures (xeve_hip_picture_begin once per picture): the original, the reference
+ * pictures, the collocated maps and the tile map are uploaded once per picture, the CTU's neighbourhood of PIC_MODE and of the maps per call. */
+int xeve_hip_mode_analyze_ctu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                   uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
+                                   const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter, int pad_l, int pad_c, int x0, int y0,
+                                   xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost);
 
 #ifdef __cplusplus
 }

@@ -622,6 +622,10 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
 typedef int (*hip_tree_host_fn)(const pel *const *, int, int, pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
                                 const xo_tree_params *, int, int, xo_ctu_data *, xo_sbac *, double *);
 static hip_tree_host_fn hip_tree_host;
+typedef struct { const void *refp; int s_ref_l, s_ref_c; hip_inter_params ipar; int16_t *map_mv; int8_t *map_refi; const int16_t *col0, *col1; const void *coef_l, *coef_c; int ecu_depth, pad_; } hip_tree_inter;
+typedef int (*hip_tree_any_host_fn)(const pel *const *, int, int, pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
+                                    const xo_tree_params *, const hip_tree_inter *, int, int, int, int, xo_ctu_data *, xo_sbac *, double *);
+static hip_tree_any_host_fn hip_tree_any_host;
 static int               tree_engine_oracle;
 static unsigned long long tree_calls, tree_fallbacks;
 static double             tree_seconds;
@@ -629,8 +633,9 @@ static double             tree_seconds;
 static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
 {
     const int L = ctx->log2_max_cuwh - 2, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
-    if(ctx->sh->slice_type != SLICE_I || ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp ||
-       ctx->log2_max_cuwh > 6 || ctx->log2_max_cuwh < 3 || idc == 2) {
+    const int is_i = ctx->sh->slice_type == SLICE_I;
+    if(ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp || ctx->log2_max_cuwh > 6 || ctx->log2_max_cuwh < 3 ||
+       idc == 2 || (!is_i && (ctx->log2_max_cuwh != 6 || !(tree_engine_oracle ? (void *)xo_tree_any : (void *)hip_tree_any_host)))) {
         __sync_fetch_and_add(&tree_fallbacks, 1);
         return orig_mode_analyze_lcu(ctx, core);
     }
@@ -654,7 +659,9 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     P.ip.qp[0] = core->qp_y, P.ip.qp[1] = core->qp_u, P.ip.qp[2] = core->qp_v;
     for(int c = 0; c < 3; c++) P.ip.lambda[c] = core->lambda[c];
     P.ip.sqrt_lambda0 = core->sqrt_lambda[0], P.ip.dist_chroma_weight[0] = core->dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = core->dist_chroma_weight[1];
-    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.max_cu = ctx->param.max_cu_intra, P.min_cu = ctx->param.min_cu_intra, P.min_cuwh = ctx->min_cuwh;
+    P.pic_w = ctx->w, P.pic_h = ctx->h, P.log2_ctu = ctx->log2_max_cuwh, P.min_cuwh = ctx->min_cuwh;
+    P.max_cu = is_i ? ctx->param.max_cu_intra : ctx->param.max_cu_inter, P.min_cu = is_i ? ctx->param.min_cu_intra : ctx->param.min_cu_inter;
+    P.ip.slice_type = ctx->sh->slice_type;
     P.slice_qp = ctx->tile[core->tile_idx].qp, P.slice_num = ctx->slice_num;
     static __thread xo_ctu_data out;
     xo_sbac entry, next;
@@ -664,8 +671,34 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     pel       *mod[3] = {pm->y, pm->u, pm->v};
     double     cost = 0;
     struct timespec t0, t1;
+    xo_tree_inter TI;
+    xo_refpic     tab[16];
+    if(!is_i && tree_inter_setup(ctx, core, &TI, tab, (int16_t(*)[2][2])ctx->map_mv, (int8_t(*)[2])ctx->map_refi) != 0) {
+        __sync_fetch_and_add(&tree_fallbacks, 1);
+        return orig_mode_analyze_lcu(ctx, core);
+    }
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    if(tree_engine_oracle) cost = xo_tree((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, x0, y0, &out, &next);
+    if(!is_i) {
+        if(tree_engine_oracle) cost = xo_tree_any((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, &TI, x0, y0, &out, &next);
+        else {
+            XEVE_PINTER *pin = &ctx->pinter[core->thread_cnt];
+            XEVE_PIC    *any = pin->refp[0][REFP_0].pic;
+            hip_tree_inter HI;
+            memset(&HI, 0, sizeof(HI));
+            HI.refp = tab, HI.s_ref_l = TI.s_ref_l, HI.s_ref_c = TI.s_ref_c, HI.map_mv = (int16_t *)ctx->map_mv, HI.map_refi = (int8_t *)ctx->map_refi;
+            HI.col0 = (const int16_t *)TI.col0, HI.col1 = (const int16_t *)TI.col1, HI.coef_l = pin->mc_l_coeff, HI.coef_c = pin->mc_c_coeff, HI.ecu_depth = TI.ecu_depth;
+            memcpy(&HI.ipar.rdo, &TI.ipar.rdo, sizeof(HI.ipar.rdo)), memcpy(&HI.ipar.me, &TI.ipar.me.me, sizeof(TI.ipar.me.me));
+            HI.ipar.me.hpel_cnt = TI.ipar.me.spel.hpel_cnt, HI.ipar.me.qpel_cnt = TI.ipar.me.spel.qpel_cnt;
+            memcpy(HI.ipar.refi_bits, TI.ipar.refi_bits, sizeof(HI.ipar.refi_bits)), memcpy(HI.ipar.range_recentre, TI.ipar.range_recentre, sizeof(HI.ipar.range_recentre));
+            HI.ipar.max_cand = TI.ipar.max_cand, HI.ipar.poc = TI.ipar.poc, HI.ipar.col_list_poc0 = TI.ipar.col_list_poc0, HI.ipar.skip_th = TI.ipar.skip_th;
+            if(hip_tree_any_host(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, &HI, any->pad_l,
+                                 any->pad_c, x0, y0, &out, &next, &cost) != 0) {
+                fprintf(stderr, "[xeve_hip_shim] xeve_hip_mode_analyze_ctu_host: %s\n", hip_err ? hip_err() : "?");
+                abort();
+            }
+        }
+    }
+    else if(tree_engine_oracle) cost = xo_tree((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, x0, y0, &out, &next);
     else if(hip_tree_host(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, x0, y0, &out, &next, &cost) != 0) {
         fprintf(stderr, "[xeve_hip_shim] xeve_hip_mode_analyze_ctu_intra_host: %s\n", hip_err ? hip_err() : "?");
         abort();
@@ -680,7 +713,8 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     for(int j = 0; j < hu; j++)
         for(int i = 0; i < wu; i++) {
             const int u = j * nu + i, g = ((y0 >> 2) + j) * ctx->w_scu + (x0 >> 2) + i;
-            cd->pred_mode[u] = out.pred_mode[u], cd->pred_mode_chroma[u] = out.pred_mode[u], cd->skip_flag[u] = 0, cd->mmvd_flag[u] = 0, cd->affine_flag[u] = 0;
+            cd->pred_mode[u] = out.pred_mode[u], cd->pred_mode_chroma[u] = out.pred_mode[u], cd->skip_flag[u] = out.pred_mode[u] == MODE_SKIP, cd->mmvd_flag[u] = 0, cd->affine_flag[u] = 0;
+            cd->dmvr_flag[u] = 0, cd->mvr_idx[u] = 0, cd->bi_idx[u] = 0;
             cd->ipm[0][u] = out.ipm[0][u], cd->ipm[1][u] = out.ipm[1][u], cd->depth[u] = out.depth[u];
             cd->qp_y[u] = core->qp_y, cd->qp_u[u] = core->qp_u, cd->qp_v[u] = core->qp_v;
             for(int c = 0; c < N_C; c++) {
@@ -688,11 +722,12 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
                 cd->nnz_sub[c][0][u] = out.nnz[c][u], cd->nnz_sub[c][1][u] = cd->nnz_sub[c][2][u] = cd->nnz_sub[c][3][u] = 0; /* one transform block per CU up to 64x64 */
             }
             cd->map_scu[u] = out.map_scu[u], cd->map_cu_mode[u] = out.map_cu_mode[u];
-            memset(cd->mv[u], 0, sizeof(cd->mv[u])), memset(cd->unrefined_mv[u], 0, sizeof(cd->unrefined_mv[u]));
-            cd->refi[u][REFP_0] = cd->refi[u][REFP_1] = -1;
-            /* the context maps the walk does not carry: motion of an intra unit, depth (update_map_scu); then the coded flag reset */
-            memset(ctx->map_mv[g], 0, sizeof(ctx->map_mv[g])), memset(ctx->map_unrefined_mv[g], 0, sizeof(ctx->map_unrefined_mv[g]));
-            ctx->map_refi[g][REFP_0] = ctx->map_refi[g][REFP_1] = -1;
+            memcpy(cd->mv[u], out.mv[u], sizeof(cd->mv[u])), memcpy(cd->unrefined_mv[u], out.mv[u], sizeof(cd->unrefined_mv[u])), memcpy(cd->mvd[u], out.mvd[u], sizeof(cd->mvd[u]));
+            cd->refi[u][REFP_0] = out.refi[u][0], cd->refi[u][REFP_1] = out.refi[u][1], cd->mvp_idx[u][REFP_0] = out.mvp_idx[u][0], cd->mvp_idx[u][REFP_1] = out.mvp_idx[u][1];
+            /* the context maps: motion (the walk keeps them in P / B slices; an I slice's units are intra: zero vectors, no reference), unrefined motion = motion
+             * without DMVR, depth (update_map_scu); then the coded flag reset */
+            memcpy(ctx->map_mv[g], out.mv[u], sizeof(ctx->map_mv[g])), memcpy(ctx->map_unrefined_mv[g], out.mv[u], sizeof(ctx->map_unrefined_mv[g]));
+            ctx->map_refi[g][REFP_0] = out.refi[u][0], ctx->map_refi[g][REFP_1] = out.refi[u][1];
             ctx->map_depth[g] = out.depth[u];
             MCU_CLR_COD(ctx->map_scu[g]);
         }
@@ -762,6 +797,7 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
     if(getenv("XEVE_SHIM_TREE_ORACLE") && ctx->fn_mode_analyze_lcu && ctx->fn_mode_analyze_lcu != shim_route_mode_analyze_lcu) {
         void *oh = dlopen(getenv("XEVE_SHIM_TREE_ORACLE"), RTLD_NOW | RTLD_LOCAL);
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] tree route (oracle engine): %s\n", dlerror()); abort(); }
+        if(!getenv("XEVE_SHIM_TREE_I_ONLY")) xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_route_mode_analyze_lcu, tree_engine_oracle = 1;
         fprintf(stderr, "[xeve_hip_shim] CTU mode decision of I pictures served by the ORACLE through the route adapter (CPU test of the adapter)\n");
         atexit(report);
@@ -832,7 +868,13 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         hip_tree_host = (hip_tree_host_fn)dlsym(h, "xeve_hip_mode_analyze_ctu_intra_host"), hip_err = err;
         if(!hip_tree_host) { fprintf(stderr, "[xeve_hip_shim] CTU tree-walk entry point missing\n"); abort(); }
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_route_mode_analyze_lcu;
-        fprintf(stderr, "[xeve_hip_shim] CTU mode decision of I pictures routed to the GPU (one exchange per CTU)\n");
+        if(atoi(getenv("XEVE_HIP_SHIM_TREE")) > 1) { /* 2: P and B pictures too (needs resident pictures: one upload per plane and picture) */
+            hip_tree_any_host = (hip_tree_any_host_fn)dlsym(h, "xeve_hip_mode_analyze_ctu_host");
+            hip_picture_begin = dlsym(h, "xeve_hip_picture_begin"), hip_resident_stats = dlsym(h, "xeve_hip_resident_stats");
+            if(!hip_tree_any_host || !hip_picture_begin || !hip_resident_stats) { fprintf(stderr, "[xeve_hip_shim] CTU tree-walk (P / B) entry points missing\n"); abort(); }
+            if(ctx->fn_mode_analyze_frame != shim_analyze_frame) orig_analyze_frame = ctx->fn_mode_analyze_frame, ctx->fn_mode_analyze_frame = shim_analyze_frame;
+        }
+        fprintf(stderr, "[xeve_hip_shim] CTU mode decision of %s pictures routed to the GPU (one exchange per CTU)\n", hip_tree_any_host ? "I, P and B" : "I");
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

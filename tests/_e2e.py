@@ -107,7 +107,7 @@ def run_app(yuv, out, w, h, frames, extra, hip=False, seek=None, timeout=1500, d
         if intra:
             env["XEVE_HIP_SHIM_INTRA"] = "1"  # the intra analysis of a CU (ctx->fn_pintra_analyze_cu)
         if tree:
-            env["XEVE_HIP_SHIM_TREE"] = "1"  # the whole mode decision of an I-picture CTU (ctx->fn_mode_analyze_lcu): one exchange per CTU
+            env["XEVE_HIP_SHIM_TREE"] = str(int(tree))  # the whole mode decision of a CTU (ctx->fn_mode_analyze_lcu), one exchange per CTU: 1 = I pictures, 2 = P and B too
         if mc:
             env["XEVE_HIP_SHIM_MC"] = "1"  # also pi->fn_mc (pinter_mc -> xeve_mc), the whole CU prediction
         if eco:

@@ -306,7 +306,8 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
 
 
 @needs_ref
-@pytest.mark.parametrize("name,nctu,left", [("noise_allintra_medium", 8, 0), ("cfg1_cif_allintra_fast", 240, 0), ("tiny_ldb_fast_2threads", 4, 4)])
+@pytest.mark.parametrize("name,nctu,left", [("noise_allintra_medium", 8, 0), ("cfg1_cif_allintra_fast", 240, 0), ("tiny_ldb_fast_2threads", 8, 0), ("moving_cif_ra_medium", 150, 0),
+                                            ("moving_ra_b3_medium", 18, 0), ("jumpy_ldb_fast", 24, 0)])
 def test_route_adapter_of_the_ctu_mode_decision_with_the_oracle_as_engine(tmp_path, name, nctu, left):
     """the adapter that serves ctx->fn_mode_analyze_lcu from an external tree walk (oracle/ref_shim.c, shim_route_mode_analyze_lcu: what it hands over and what it
     stores back into ctx->map_cu_data, the context maps and PIC_MODE) run with the ORACLE's walk as the engine: the bitstream must not change.  CPU only -- this
@@ -336,3 +337,21 @@ def test_bitstream_identical_with_the_ctu_mode_decision_on_the_gpu(tmp_path, nam
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
     m = re.search(r"mode decision ran on the GPU: (\d+) \(left", err)
     assert m and int(m.group(1)) == nctu, err[-800:]
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nctu", [("tiny_ldb_fast", 8), ("tiny_ra_medium", 8), ("moving_ra_medium", 10), ("moving_ldb_ref3", 20), ("moving_ra_b3_medium", 18), ("jumpy_ldb_fast", 24),
+                                       ("tiny_ldb_fast_2threads", 8), ("moving_cif_ra_medium", 150)])
+def test_bitstream_identical_with_every_ctu_decided_on_the_gpu(tmp_path, name, nctu):
+    """ctx->fn_mode_analyze_lcu of EVERY CTU -- I, P and B pictures -- served by the device-side tree walk (xeve_hip_mode_analyze_ctu_host): the quad-tree, the inter and
+    intra analysis of every node, the mode comparison, the map / motion / picture updates all on the device, ONE exchange per CTU; the reference keeps the frame
+    loop, the entropy coder and the loop filter.  Byte-identical bitstreams; no CTU is left to the reference."""
+    w, h, n, seed, extra = CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, hip=True, tables=False, tree=2)
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+    m = re.search(r"mode decision ran on the GPU: (\d+) \(left to the reference: (\d+)\), ([0-9.]+) ms per CTU", err)
+    assert m and (int(m.group(1)), int(m.group(2))) == (nctu, 0), err[-800:]
+    print("%s: %d CTUs, %s ms per CTU" % (name, nctu, m.group(3)))

@@ -706,3 +706,153 @@ extern "C" int xeve_hip_mode_analyze_ctu_intra_host(const xeve_hip_pel *const or
     }
     return XEVE_HIP_OK;
 }
+
+// ---- host-memory form for every slice type (P / B: needs resident pictures, xeve_hip_picture_begin) -------------------------------------------------------------
+// The inter analysis addresses the reference pictures with the CU's position in the picture, so a P / B CTU is walked in PICTURE coordinates: the original, the
+// reference pictures, the collocated motion maps and the tile map are resident copies (one upload per picture); the picture being reconstructed and the maps the
+// walk updates live in per-thread device buffers of picture size, of which only the CTU's neighbourhood is current -- it is uploaded before the walk (the CTU, one
+// unit to its left and above, the CTU's width again to the right) and the CTU's own part is read back after it.
+namespace {
+struct TreePicCtx {
+    uint32_t    gen = 0;
+    hipStream_t st  = nullptr;
+    char       *buf[12] = {};
+    size_t      cap[12] = {};
+    void release()
+    {
+        if(st) (void)hipStreamDestroy(st);
+        for(int i = 0; i < 12; i++) {
+            if(buf[i]) (void)hipFree(buf[i]);
+            buf[i] = nullptr, cap[i] = 0;
+        }
+        st = nullptr;
+    }
+    int ensure(int i, size_t bytes)
+    {
+        if(cap[i] >= bytes) return XEVE_HIP_OK;
+        if(buf[i]) {
+            XH_HIP(hipStreamSynchronize(st));
+            (void)hipFree(buf[i]);
+            buf[i] = nullptr, cap[i] = 0;
+        }
+        XH_HIP(hipMalloc((void **)&buf[i], bytes + (bytes >> 3)));
+        XH_HIP(hipMemsetAsync(buf[i], 0, bytes + (bytes >> 3), st));
+        cap[i] = bytes + (bytes >> 3);
+        return XEVE_HIP_OK;
+    }
+    int begin()
+    {
+        if(gen != xh_generation()) release(), gen = xh_generation();
+        if(!st) XH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return XEVE_HIP_OK;
+    }
+    ~TreePicCtx() { release(); }
+};
+enum { B_MOD0 = 0, B_MOD1 = 1, B_MOD2 = 2, B_SCU = 3, B_IPM = 4, B_CUM = 5, B_MV = 6, B_REFI = 7, B_IO = 8, B_WS = 9 };
+} // namespace
+
+extern "C" int xeve_hip_mode_analyze_ctu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
+                                              uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
+                                              const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int pad_l, int pad_c, int x0, int y0,
+                                              xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost)
+{
+    XH_ENTER();
+    XH_REQUIRE(p);
+    if(p->ip.slice_type == 2)
+        return xeve_hip_mode_analyze_ctu_intra_host(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, entry, p, x0, y0, out, next_best, cost);
+    XH_REQUIRE(org && mod && map_scu && map_ipm && map_tidx && map_cu_mode && entry && out && next_best && cost && tree_params_ok(p) && tree_inter_ok(p, I) && pad_l >= 0 && pad_c >= 0);
+    if(!xh_resident_on()) {
+        xh_set_error("xeve_hip_mode_analyze_ctu_host: a P / B CTU needs resident pictures (announce each picture with xeve_hip_picture_begin)");
+        return XEVE_HIP_ERR_ARG;
+    }
+    const int idc = p->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, ncomp = idc ? 3 : 1, ctu = 1 << p->log2_ctu, n = ctu >> 2, isb = p->ip.slice_type == 0;
+    XH_REQUIRE(org[0] && mod[0] && (!idc || (org[1] && org[2] && mod[1] && mod[2])));
+    XH_REQUIRE(x0 >= 0 && y0 >= 0 && x0 < p->pic_w && y0 < p->pic_h && (x0 & (ctu - 1)) == 0 && (y0 & (ctu - 1)) == 0);
+    const int w_scu = p->ip.w_scu, h_scu = p->ip.h_scu, nscu = w_scu * h_scu, hc = p->pic_h >> hs;
+    const int x_scu = x0 >> 2, y_scu = y0 >> 2, lx = x_scu > 0, ly = y_scu > 0, nw = std::min(2 * n, w_scu - x_scu), nh = std::min(n, h_scu - y_scu), cw = std::min(n, w_scu - x_scu);
+    static thread_local TreePicCtx C;
+    int rc = C.begin();
+    if(rc != XEVE_HIP_OK) return rc;
+    // resident: the original, the reference pictures of both lists, the collocated maps, the tile map
+    const size_t eo[3] = {(size_t)s_org_l * p->pic_h, (size_t)s_org_c * hc, (size_t)s_org_c * hc};
+    const size_t er[3] = {(size_t)I->s_ref_l * (p->pic_h + 2 * pad_l), (size_t)I->s_ref_c * (hc + 2 * pad_c), (size_t)I->s_ref_c * (hc + 2 * pad_c)};
+    const size_t orr[3] = {(size_t)pad_l * I->s_ref_l + pad_l, (size_t)pad_c * I->s_ref_c + pad_c, (size_t)pad_c * I->s_ref_c + pad_c};
+    const pel *dorg[3] = {nullptr, nullptr, nullptr};
+    for(int c = 0; c < ncomp; c++)
+        if(!(dorg[c] = (const pel *)xh_resident(org[c], eo[c] * sizeof(pel)))) return XEVE_HIP_ERR_DEVICE;
+    xeve_hip_refpic tab[2 * XEVE_HIP_MAX_REFP];
+    memset(tab, 0, sizeof(tab));
+    const int nr[2] = {I->ipar.rdo.num_refp[0], isb ? I->ipar.rdo.num_refp[1] : 0};
+    XH_REQUIRE(nr[0] >= 1 && nr[0] <= XEVE_HIP_MAX_REFP && nr[1] <= XEVE_HIP_MAX_REFP);
+    for(int l = 0; l < 2; l++)
+        for(int r = 0; r < nr[l]; r++) {
+            const xeve_hip_refpic &e = I->refp[r * 2 + l];
+            XH_REQUIRE(e.y && (idc == 0 || (e.u && e.v)));
+            const xeve_hip_pel *hp[3] = {e.y, e.u, e.v};
+            const pel *dp[3] = {nullptr, nullptr, nullptr};
+            for(int c = 0; c < ncomp; c++) {
+                const pel *d = (const pel *)xh_resident(hp[c] - orr[c], er[c] * sizeof(pel));
+                if(!d) return XEVE_HIP_ERR_DEVICE;
+                dp[c] = d + orr[c];
+            }
+            tab[r * 2 + l].y = dp[0], tab[r * 2 + l].u = dp[1], tab[r * 2 + l].v = dp[2], tab[r * 2 + l].poc = e.poc;
+        }
+    if(!isb) tab[0 * 2 + 1] = tab[0 * 2 + 0]; // (P slices never read list 1; keep the table addressable)
+    const int16_t *dcol0 = (const int16_t *)xh_resident(I->col_mv0, (size_t)nscu * 8), *dcol1 = isb ? (const int16_t *)xh_resident(I->col_mv1, (size_t)nscu * 8) : dcol0;
+    const uint8_t *dtidx = (const uint8_t *)xh_resident(map_tidx, (size_t)nscu);
+    if(!dcol0 || !dcol1 || !dtidx) return XEVE_HIP_ERR_DEVICE;
+    // per-thread picture-sized buffers + the call's small records + the workspace
+    xeve_hip_tree_inter Id = *I;
+    const size_t wsb = xeve_hip_mode_analyze_ctu_workspace(1, p, I, s_org_l, s_org_c);
+    XH_REQUIRE(wsb > 0);
+    const size_t o_job = 0, o_st = 256, o_out = 512, o_next = o_out + al(sizeof(*out)), o_cost = o_next + 256, io_bytes = o_cost + 256;
+    const size_t need[10] = {(size_t)s_mod_l * p->pic_h * 2, (size_t)s_mod_c * hc * 2, (size_t)s_mod_c * hc * 2, (size_t)nscu * 4, (size_t)nscu, (size_t)nscu * 4, (size_t)nscu * 8,
+                             (size_t)nscu * 2, io_bytes, wsb};
+    for(int i = 0; i < 10; i++)
+        if((i == B_MOD1 || i == B_MOD2) && !idc) continue;
+        else if((rc = C.ensure(i, need[i])) != XEVE_HIP_OK) return rc;
+    pel *dmod[3] = {(pel *)C.buf[B_MOD0], (pel *)C.buf[B_MOD1], (pel *)C.buf[B_MOD2]};
+    Id.refp = tab, Id.map_mv = (int16_t *)C.buf[B_MV], Id.map_refi = (int8_t *)C.buf[B_REFI], Id.col_mv0 = dcol0, Id.col_mv1 = dcol1;
+    // the neighbourhood in: rows [y_scu - ly, y_scu + nh) x columns [x_scu - lx, x_scu + nw) of every map, the same window of the planes
+    const size_t u0 = (size_t)(y_scu - ly) * w_scu + (x_scu - lx);
+    const int    Wl = lx + nw, Hl = ly + nh;
+    auto copy2d = [&](void *dst, const void *src, size_t pitch, size_t width, size_t height, hipMemcpyKind kind) {
+        return width && height ? hipMemcpy2DAsync(dst, pitch, src, pitch, width, height, kind, C.st) : hipSuccess;
+    };
+    XH_HIP(copy2d(C.buf[B_SCU] + u0 * 4, map_scu + u0, (size_t)w_scu * 4, (size_t)Wl * 4, Hl, hipMemcpyHostToDevice));
+    XH_HIP(copy2d(C.buf[B_CUM] + u0 * 4, map_cu_mode + u0, (size_t)w_scu * 4, (size_t)Wl * 4, Hl, hipMemcpyHostToDevice));
+    XH_HIP(copy2d(C.buf[B_IPM] + u0, map_ipm + u0, (size_t)w_scu, (size_t)Wl, Hl, hipMemcpyHostToDevice));
+    XH_HIP(copy2d(C.buf[B_MV] + u0 * 8, I->map_mv + u0 * 4, (size_t)w_scu * 8, (size_t)Wl * 8, Hl, hipMemcpyHostToDevice));
+    XH_HIP(copy2d(C.buf[B_REFI] + u0 * 2, I->map_refi + u0 * 2, (size_t)w_scu * 2, (size_t)Wl * 2, Hl, hipMemcpyHostToDevice));
+    for(int c = 0; c < ncomp; c++) {
+        const int    sx = c ? ws : 0, sy = c ? hs : 0, sm = c ? s_mod_c : s_mod_l;
+        const size_t s0 = (size_t)((y0 >> sy) - ly * (4 >> sy)) * sm + ((x0 >> sx) - lx * (4 >> sx));
+        XH_HIP(copy2d(dmod[c] + s0, mod[c] + s0, (size_t)sm * 2, (size_t)(Wl * (4 >> sx)) * 2, (size_t)Hl * (4 >> sy), hipMemcpyHostToDevice));
+    }
+    xeve_hip_ctu_job jl;
+    jl.x = x0, jl.y = y0, jl.sbac = 0, jl.pic = 0;
+    XH_HIP(hipMemcpyAsync(C.buf[B_IO] + o_job, &jl, sizeof(jl), hipMemcpyHostToDevice, C.st));
+    XH_HIP(hipMemcpyAsync(C.buf[B_IO] + o_st, entry, sizeof(*entry), hipMemcpyHostToDevice, C.st));
+    rc = xeve_hip_mode_analyze_ctu_jobs(dorg, s_org_l, s_org_c, dmod, s_mod_l, s_mod_c, (uint32_t *)C.buf[B_SCU], (int8_t *)C.buf[B_IPM], dtidx, (uint32_t *)C.buf[B_CUM], nullptr,
+                                        (const xeve_hip_sbac *)(C.buf[B_IO] + o_st), 1, p, &Id, (const xeve_hip_ctu_job *)(C.buf[B_IO] + o_job), 1,
+                                        (xeve_hip_ctu_data *)(C.buf[B_IO] + o_out), (xeve_hip_sbac *)(C.buf[B_IO] + o_next), (double *)(C.buf[B_IO] + o_cost), C.buf[B_WS],
+                                        C.cap[B_WS], C.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    // the CTU's part out
+    const size_t c0 = (size_t)y_scu * w_scu + x_scu;
+    XH_HIP(hipMemcpyAsync(out, C.buf[B_IO] + o_out, sizeof(*out), hipMemcpyDeviceToHost, C.st));
+    XH_HIP(hipMemcpyAsync(next_best, C.buf[B_IO] + o_next, sizeof(*next_best), hipMemcpyDeviceToHost, C.st));
+    XH_HIP(hipMemcpyAsync(cost, C.buf[B_IO] + o_cost, sizeof(double), hipMemcpyDeviceToHost, C.st));
+    XH_HIP(copy2d(map_scu + c0, C.buf[B_SCU] + c0 * 4, (size_t)w_scu * 4, (size_t)cw * 4, nh, hipMemcpyDeviceToHost));
+    XH_HIP(copy2d(map_cu_mode + c0, C.buf[B_CUM] + c0 * 4, (size_t)w_scu * 4, (size_t)cw * 4, nh, hipMemcpyDeviceToHost));
+    XH_HIP(copy2d(map_ipm + c0, C.buf[B_IPM] + c0, (size_t)w_scu, (size_t)cw, nh, hipMemcpyDeviceToHost));
+    XH_HIP(copy2d(I->map_mv + c0 * 4, C.buf[B_MV] + c0 * 8, (size_t)w_scu * 8, (size_t)cw * 8, nh, hipMemcpyDeviceToHost));
+    XH_HIP(copy2d(I->map_refi + c0 * 2, C.buf[B_REFI] + c0 * 2, (size_t)w_scu * 2, (size_t)cw * 2, nh, hipMemcpyDeviceToHost));
+    for(int c = 0; c < ncomp; c++) {
+        const int    sx = c ? ws : 0, sy = c ? hs : 0, sm = c ? s_mod_c : s_mod_l;
+        const size_t s0 = (size_t)(y0 >> sy) * sm + (x0 >> sx);
+        XH_HIP(copy2d(mod[c] + s0, dmod[c] + s0, (size_t)sm * 2, (size_t)((cw * 4) >> sx) * 2, (size_t)((nh * 4) >> sy), hipMemcpyDeviceToHost));
+    }
+    XH_HIP(hipStreamSynchronize(C.st));
+    return XEVE_HIP_OK;
+}
