@@ -20,7 +20,8 @@ The JSON line also carries
                  ceiling the counters say binds it, and the physical HBM / L2 / LDS figures of the PMC passes in profiles/;
   kernels      : per kernel class, HIP-event time per picture (search, sub-pel, CABAC bit counting, prediction, residual
                  chain, RDOQ) from an untimed pass with every class's timer on;
-  secondary    : the same step on SURVEY 8(d)'s structured input, at 1920x1080, the round-1 synthetic-vector pass A..E, the intra analysis of every CU;
+  secondary    : the same step on SURVEY 8(d)'s structured input, at 1920x1080, the round-1 synthetic-vector pass A..E, the intra analysis of every CU, the CTU mode
+                 decision of I pictures on the device (chains in lockstep);
   cpu_baseline : the reference encoder itself (oracle/_ref/xeveb_app, compiled in place from the reference) on this box's
                  host cores, -m 8 and -m 1, on the first frames of the same kind of input -- rank 0, N = 1 only.
 """
@@ -324,6 +325,21 @@ def main():
                                                                         "note": "xeve_amd/workload.py intra(): pintra_analyze_cu of every CU of the levels 64, 32, 16, 8, 4"}
         del ws
         torch.cuda.empty_cache()
+        # (5) the caller above the CU on the device: the CTU mode decision of I pictures (quad-tree 64 .. 4, intra analysis of every node, maps + reconstruction updated
+        # CU by CU), chains = pictures in lockstep; one chain alone = the latency of one CTU
+        from xeve_amd.workload import CtuWalkIntra
+        walk = {}
+        for chains in (1, 1024):
+            wk = CtuWalkIntra(chains, dev, "noise")
+            wk.step()
+            ms = time_steps(wk.step, 3, sync)
+            walk["chains_%d" % chains] = {"ms_per_ctu_step": round(ms, 2), "ctus_per_s": round(chains / ms * 1e3, 1),
+                                          "equivalent_%dx%d_pictures_per_s" % (a.width, a.height): round(chains / ms * 1e3 / (((a.width + 63) // 64) * ((a.height + 63) // 64)), 3)}
+            del wk
+            torch.cuda.empty_cache()
+        walk["note"] = ("xeve_amd/workload.py CtuWalkIntra: xeve_hip_mode_analyze_ctu_jobs on i.i.d. content (every node of the tree decided), max_cu_intra 32, min 4; the "
+                        "decision of a CTU is serial (neighbours' reconstruction, coder state), so the rate scales with the pictures in flight, not within one")
+        sec["ctu_mode_decision_I_pictures"] = walk
         for content in ("iid", "structured"):
             p, sec["%s_1920x1080" % content] = one(1920, 1080, content, 20)
             del p

@@ -53,10 +53,19 @@ def test_cfg2_1280x720_low_delay_fast(tmp_path):
     _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000)
 
 
-def test_cfg2_1280x720_with_the_i_picture_decided_per_ctu_on_the_gpu(tmp_path):
-    """the same clip with the I picture's 240 CTUs (12 rows: 720 = 11 * 64 + 16, the last row cut by the picture) decided by the device-side tree walk, one
-    exchange per CTU, and the P picture's CUs analysed per CU as above"""
-    _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000, tree_ctus=240)
+def test_cfg2_1280x720_with_every_ctu_decided_on_the_gpu(tmp_path):
+    """the same clip with ctx->fn_mode_analyze_lcu of all 480 CTUs (the I and the P picture) served by the device-side tree walk: one exchange per CTU, nothing per CU"""
+    name = "cfg2_720p_ldb_fast"
+    w, h, n, seed, extra = REAL_CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    t0 = time.perf_counter()
+    md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, tables=False, tree=2)
+    dt = time.perf_counter() - t0
+    k = re.search(r"mode decision ran on the GPU: (\d+) \(left to the reference: (\d+)\), ([0-9.]+) ms per CTU", err)
+    assert k and (int(k.group(1)), int(k.group(2))) == (480, 0), err[-800:]
+    print("%s: 480 CTUs decided on the GPU in %.1f s wall, %s ms per CTU (one exchange each)" % (name, dt, k.group(3)))
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
 
 
 def test_cfg3_1920x1080_random_access_medium(tmp_path):

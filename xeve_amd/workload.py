@@ -515,3 +515,65 @@ def D_same_jobs(lv, c):
         off = lv["off_l"] if c == 0 else lv["off_c"]
         lv[key] = torch.stack([off, off], dim=1).contiguous()
     return lv[key]
+
+
+class CtuWalkIntra:
+    """The CTU mode decision of I pictures on the device (xeve_hip_mode_analyze_ctu_jobs), chains = pictures in lockstep: every chain is a 128x128 picture of its
+    own (four CTUs); a step decides the same CTU of every picture -- the quad-tree 64 .. 4 with the intra analysis of every node, the maps and the reconstruction
+    updated CU by CU.  content "noise": every node is visited and decided; "smooth": the early termination of I pictures prunes the tree."""
+
+    CTUS = [(0, 0), (64, 0), (0, 64), (64, 64)]
+
+    def __init__(self, chains, device, content="noise", seed=7, qp8=32, bit_depth=10, max_cu=32):
+        import ctypes as C
+
+        from . import lib
+        self.n, self.dev, w = chains, device, 128
+        P = lib.TreeParams()
+        qp = qp8 + 6 * (bit_depth - 8)
+        P.ip.w_scu, P.ip.h_scu, P.ip.slice_type, P.ip.chroma_format_idc, P.ip.bit_depth = w // 4, w // 4, 2, 1, bit_depth
+        P.ip.qp[0], P.ip.qp[1], P.ip.qp[2] = qp, qp - 1, qp - 2
+        lam = 0.57 * 2.0 ** ((qp8 - 12) / 3.0)
+        P.ip.lambda_[0], P.ip.sqrt_lambda0 = lam, lam ** 0.5
+        P.ip.dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = 2.0 ** (1 / 3.0), 2.0 ** (2 / 3.0)
+        P.ip.lambda_[1], P.ip.lambda_[2] = lam / P.ip.dist_chroma_weight[0], lam / P.ip.dist_chroma_weight[1]
+        P.pic_w, P.pic_h, P.log2_ctu, P.max_cu, P.min_cu, P.min_cuwh, P.slice_qp = w, w, 6, max_cu, 4, 4, qp
+        self.P, self.w = P, w
+        g = torch.Generator(device=device).manual_seed(seed)
+        n, maxv = chains, (1 << bit_depth) - 1
+        if content == "noise":
+            self.org = [torch.randint(0, maxv + 1, (n, w >> s, w >> s), device=device, generator=g, dtype=torch.int16) for s in (0, 1, 1)]
+        else:
+            yy, xx = torch.meshgrid(torch.arange(w, device=device), torch.arange(w, device=device), indexing="ij")
+            base = (maxv / 2) * (1 + 0.6 * torch.sin(xx / 19.0) * torch.cos(yy / 23.0))
+            luma = (base[None] + torch.randint(-3, 4, (n, w, w), device=device, generator=g)).clamp(0, maxv).to(torch.int16)
+            self.org = [luma, luma[:, ::2, ::2].contiguous(), luma[:, ::2, ::2].contiguous()]
+        nscu = (w // 4) ** 2
+        self.mod = [torch.full_like(t, 1 << (bit_depth - 1)) for t in self.org]
+        self.ms, self.mc = torch.zeros((n, nscu), dtype=torch.int32, device=device), torch.zeros((n, nscu), dtype=torch.int32, device=device)
+        self.mi, self.mt = torch.zeros((n, nscu), dtype=torch.int8, device=device), torch.zeros((n, nscu), dtype=torch.uint8, device=device)
+        st = np.zeros(n, lib.SBAC_DTYPE)
+        st["range"], st["code_bits"], st["ctx"] = 16384, 11, 512  # the coder state at the start of a slice
+        self.states = torch.from_numpy(st.view(np.uint8).copy()).to(device)
+        self.need = int(lib.load().xeve_hip_mode_analyze_ctu_workspace(n, C.byref(P), None, w, w // 2))
+        self.ws = torch.empty(self.need, dtype=torch.uint8, device=device)
+        self.pe = (self.org[0][0].numel(), self.org[1][0].numel(), self.mod[0][0].numel(), self.mod[1][0].numel(), nscu)
+        self.jobs = []
+        for (x, y) in self.CTUS:
+            j = np.zeros(n, lib.CTU_JOB_DTYPE)
+            j["x"], j["y"], j["sbac"], j["pic"] = x, y, np.arange(n), np.arange(n)
+            self.jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(device))
+        self.k, self.out = 0, None
+
+    def step(self):
+        """decides CTU (k mod 4) of every picture; the coder state of each chain carries over"""
+        from . import device as D
+        w = self.w
+        self.out, nxt, self.cost = D.mode_analyze_ctu_jobs([t.data_ptr() for t in self.org], w, w // 2, [t.data_ptr() for t in self.mod], w, w // 2, self.ms, self.mi, self.mt, self.mc,
+                                                           self.states, self.P, self.jobs[self.k % 4], pic_elems=self.pe, workspace=self.ws)
+        self.states = nxt
+        self.k += 1
+
+    def mean_depth(self):
+        from . import lib
+        return float(self.out.cpu().numpy().reshape(-1).view(np.dtype(lib.CTU_DATA_DTYPE))["depth"].mean())
