@@ -129,3 +129,77 @@ def test_hip_ctu_mode_decision_of_p_and_b_slices_matches_oracle(case):
     for f in ("scu", "ipm", "cu_mode", "mv", "refi"):
         assert np.array_equal(final[f].reshape(c["maps"][f].shape), c["maps"][f]), (case, "map", f)
     assert len(modes) >= 3, modes  # intra, inter and skip CUs all occur
+
+
+def test_hip_ctu_rows_of_a_b_picture_as_chains_of_one_call():
+    """two CTU rows of one B picture walked as a wavefront: row 1 starts when row 0 is two CTUs ahead (its up-right neighbour is decided), and from then on each call
+    advances BOTH rows -- two chains of one picture in lockstep, sharing the maps and the picture being reconstructed.  Each row carries its own coder state.
+    The oracle walks the same CTUs one at a time in the same order."""
+    import ctypes as C
+
+    import torch
+    import xeve_amd
+    from test_hip_inter import hip_params
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from _mc_cases import refpic_table
+    from _tree_cases import TreeInter, oracle_tree_any
+    from _libs import c_void_p, ptr
+    from _sbac_cases import make_states
+
+    c = make_inter_case(4201, 256, 128, 10, 1, 0, 1, 0, 0.0)
+    steps = [[(0, 0)], [(64, 0)], [(128, 0), (0, 64)], [(192, 0), (64, 64)], [(128, 64)], [(192, 64)]]
+    entry = make_states(np.random.default_rng(5), 2)  # one coder state per row
+    # device
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    refs, org = c["refs"], c["org"]
+    dplanes = [[torch.from_numpy(x).to(dev) for x in pic] for pic in refs["pics"]]
+    lut = {id(x): t for pic, dp in zip(refs["pics"], dplanes) for x, t in zip(pic, dp)}
+    dev_tab = refpic_table(refs, lambda a, off: lut[id(a)].data_ptr() + 2 * off)
+    dorg = [torch.from_numpy(x).to(dev) for x in org]
+    org_ptrs = [dorg[0].data_ptr() + 2 * refs["org_l"], dorg[1].data_ptr() + 2 * refs["org_c"], dorg[2].data_ptr() + 2 * refs["org_c"]]
+    mod = [torch.from_numpy(a.copy()).to(dev) for a in c["mod"]]
+    m = c["maps"]
+    ms, mc = (torch.from_numpy(m[k].view(np.int32).copy()).to(dev) for k in ("scu", "cu_mode"))
+    mi, mt, mv, mr = (torch.from_numpy(m[k].copy()).to(dev) for k in ("ipm", "tidx", "mv", "refi"))
+    col = [torch.from_numpy(a.copy()).to(dev) for a in c["col"]]
+    P = lib.TreeParams.from_buffer_copy(bytes(c["P"]))
+    I = lib.TreeInter()
+    I.refp, I.s_ref_l, I.s_ref_c, I.ipar = dev_tab.ctypes.data, refs["s_l"], refs["s_c"], hip_params(c["ipar"])
+    I.map_mv, I.map_refi, I.col_mv0, I.col_mv1, I.ecu_depth = mv.data_ptr(), mr.data_ptr(), col[0].data_ptr(), col[1].data_ptr(), c["ecu_depth"]
+    states = torch.from_numpy(entry.view(np.uint8).copy()).to(dev)
+    got = {}
+    for ctus in steps:
+        jobs = np.zeros(len(ctus), CTU_JOB_DTYPE)
+        for k, (x, y) in enumerate(ctus):
+            jobs["x"][k], jobs["y"][k], jobs["sbac"][k] = x, y, y // 64
+        out, nxt, cost = D.mode_analyze_ctu_jobs(org_ptrs, refs["s_l"], refs["s_c"], [t.data_ptr() for t in mod], mod[0].shape[1], mod[1].shape[1], ms, mi, mt, mc, states, P,
+                                                 torch.from_numpy(jobs.view(np.uint8).copy()).to(dev), inter=I)
+        torch.cuda.synchronize()
+        o, nb, cs = out.cpu().numpy().reshape(-1).view(CTU_DATA_DTYPE), nxt.cpu().numpy().reshape(-1).view(SBAC_DTYPE), cost.cpu().numpy()
+        st = states.cpu().numpy().reshape(-1).view(SBAC_DTYPE).copy()
+        for k, (x, y) in enumerate(ctus):
+            got[(x, y)] = (o[k:k + 1].copy(), nb[k:k + 1].copy(), cs[k])
+            st[y // 64] = nb[k]
+        states = torch.from_numpy(st.view(np.uint8).copy()).to(dev)
+    # oracle, CTU by CTU in the same order
+    O = oracle_tree_any()
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    TI = TreeInter()
+    TI.refp, TI.s_ref_l, TI.s_ref_c, TI.ipar = tab.ctypes.data, refs["s_l"], refs["s_c"], c["ipar"]
+    TI.map_mv, TI.map_refi, TI.col0, TI.col1, TI.ecu_depth = m["mv"].ctypes.data, m["refi"].ctypes.data, c["col"][0].ctypes.data, c["col"][1].ctypes.data, c["ecu_depth"]
+    orgp = (c_void_p * 3)(int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"])
+    modp = (c_void_p * 3)(*[a.ctypes.data for a in c["mod"]])
+    st = entry.copy()
+    for ctus in steps:
+        for (x, y) in ctus:
+            d, nb = np.zeros(1, CTU_DATA_DTYPE), np.zeros(1, SBAC_DTYPE)
+            cost = O.xo_mode_analyze_ctu(orgp, refs["s_l"], refs["s_c"], modp, c["mod"][0].shape[1], c["mod"][1].shape[1], ptr(m["scu"]), ptr(m["ipm"]), ptr(m["tidx"]),
+                                         ptr(m["cu_mode"]), ptr(st[y // 64:y // 64 + 1]), C.byref(c["P"]), C.byref(TI), x, y, ptr(d), ptr(nb))
+            st[y // 64] = nb[0]
+            gd, gnb, gcost = got[(x, y)]
+            for f in CTU_DATA_DTYPE.names:
+                assert np.array_equal(gd[f][0], d[f][0]), ((x, y), f)
+            assert gnb.tobytes() == nb.tobytes() and np.float64(gcost).tobytes() == np.float64(cost).tobytes(), (x, y)
+    assert np.array_equal(mod[0].cpu().numpy(), c["mod"][0]) and np.array_equal(mv.cpu().numpy(), m["mv"]) and np.array_equal(ms.cpu().numpy().view(np.uint32), m["scu"])

@@ -18,6 +18,7 @@
 // result only where the inter winner has a residual and the intra cost is smaller (mode_check_intra, :1226-1308); a skipped CU at depth >= ecu_depth is not split.
 // All costs are doubles built with the reference's operations in the reference's order (-ffp-contract=off), compared as the reference compares them.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "xh_common.h"
@@ -510,6 +511,40 @@ extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const x
 }
 
 namespace {
+struct TreeGraph {
+    std::vector<char> key;
+    int               seen  = 0;
+    hipGraph_t        graph = nullptr;
+    hipGraphExec_t    exec  = nullptr;
+};
+struct TreeGraphs { // per thread; dropped when the library is re-bound
+    uint32_t               gen = 0;
+    std::vector<TreeGraph> v;
+    void drop()
+    {
+        if(!v.empty()) (void)hipDeviceSynchronize(); // (a replay may still be in flight)
+        for(auto &g : v) {
+            if(g.exec) (void)hipGraphExecDestroy(g.exec);
+            if(g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        v.clear();
+    }
+    TreeGraph *find(const std::vector<char> &key)
+    {
+        if(gen != xh_generation()) drop(), gen = xh_generation();
+        for(auto &g : v)
+            if(g.key == key) return &g;
+        return nullptr;
+    }
+    void add(const std::vector<char> &key)
+    {
+        if(v.size() >= 16) drop();
+        TreeGraph g;
+        g.key = key;
+        v.push_back(std::move(g));
+    }
+    ~TreeGraphs() { drop(); }
+};
 enum { AN_NONE = 0, AN_INTRA = 1, AN_INTER = 2 };
 struct Walk { // the static schedule of one CTU: every node of the full quad-tree in the reference's order; operations between two analyses fused
     const xeve_hip_tree_params *p;
@@ -580,39 +615,76 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
         for(int c = 0; c < 3; c++) K.erec[c] = (pel *)(W + L.erec[c]);
         K.esatd = (int32_t *)(W + L.esatd), K.enext = (SbacState *)(W + L.enext);
     }
-    XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
-
     Walk wk;
     wk.p = p, wk.inter = I != nullptr, wk.cur.n = 0;
     wk.node(p->log2_ctu - 2, -1);
     wk.add(OP_ROOT_DONE, p->log2_ctu - 2, 0);
     wk.flush(AN_NONE, 0);
     const pel *const modc[3] = {mod[0], mod[1], mod[2]};
-    for(size_t i = 0; i < wk.launches.size(); i++) {
-        k_tree_ops<<<nchains, 256, 0, st>>>(K, wk.launches[i]);
-        const int log2 = wk.size[i], cu = 1 << log2;
-        int rc = XEVE_HIP_OK;
-        if(wk.kind[i] == AN_INTRA) {
-            const xeve_hip_intra_params ip = level_params(p, log2);
-            rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
-                                                 nchains, &ip, K.ijobs, nchains, (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest,
-                                                 W + L.iws, L.iws_bytes, stream);
+    auto enqueue = [&]() -> int { // the whole walk on `st`
+        XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
+        for(size_t i = 0; i < wk.launches.size(); i++) {
+            k_tree_ops<<<nchains, 256, 0, st>>>(K, wk.launches[i]);
+            const int log2 = wk.size[i], cu = 1 << log2;
+            int rc = XEVE_HIP_OK;
+            if(wk.kind[i] == AN_INTRA) {
+                const xeve_hip_intra_params ip = level_params(p, log2);
+                rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
+                                                     nchains, &ip, K.ijobs, nchains, (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest,
+                                                     W + L.iws, L.iws_bytes, stream);
+            }
+            else if(wk.kind[i] == AN_INTER) {
+                const xeve_hip_inter_params ep = level_inter_params(I, log2);
+                rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
+                                               p->ip.slice_type, K.ejobs, nchains, stream);
+                if(rc == XEVE_HIP_OK)
+                    rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, K.ejobs,
+                                                         nchains, I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + L.eres), (int16_t *)(W + L.ecoef), (pel *)(W + L.erec[0]),
+                                                         (pel *)(W + L.erec[1]), (pel *)(W + L.erec[2]), (pel *)(W + L.epred), (xeve_hip_sbac *)(W + L.enext), W + L.ews,
+                                                         L.ews_bytes, stream);
+                if(rc == XEVE_HIP_OK) // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
+                    rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + L.epred), cu, K.sjobs, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
+                                            (int32_t *)(W + L.esatd), stream);
+            }
+            if(rc != XEVE_HIP_OK) return rc;
         }
-        else if(wk.kind[i] == AN_INTER) {
-            const xeve_hip_inter_params ep = level_inter_params(I, log2);
-            rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
-                                           p->ip.slice_type, K.ejobs, nchains, stream);
-            if(rc == XEVE_HIP_OK)
-                rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, K.ejobs, nchains,
-                                                     I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + L.eres), (int16_t *)(W + L.ecoef), (pel *)(W + L.erec[0]),
-                                                     (pel *)(W + L.erec[1]), (pel *)(W + L.erec[2]), (pel *)(W + L.epred), (xeve_hip_sbac *)(W + L.enext), W + L.ews,
-                                                     L.ews_bytes, stream);
-            if(rc == XEVE_HIP_OK) // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
-                rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + L.epred), cu, K.sjobs, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
-                                        (int32_t *)(W + L.esatd), stream);
+        return XEVE_HIP_OK;
+    };
+    // The schedule is static (10 000 launches per I-picture CTU, 20 000 per P / B CTU) and every operand sits at an address the caller chose, so a call whose
+    // arguments repeat can be captured into a HIP graph and replayed.  MEASURED (profiles/r02_tree_graph.log): the replay frees the host -- 2.8 ms instead of
+    // 56 .. 100 ms of launch calls per CTU step -- but the GPU runs the same step 8 .. 10 ms SLOWER (dependent kernel nodes of a graph dispatch no faster than
+    // stream launches here), so it is OFF unless XEVE_HIP_TREE_GRAPH=1: for a caller that needs its host thread, not for speed.
+    static const int use_graph = getenv("XEVE_HIP_TREE_GRAPH") ? atoi(getenv("XEVE_HIP_TREE_GRAPH")) : 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if(st) (void)hipStreamIsCapturing(st, &cap);
+    if(use_graph && st && cap == hipStreamCaptureStatusNone && !xh_prof_on(XH_PROF_SEARCH) && !xh_prof_on(XH_PROF_CU_BITS)) {
+        static thread_local TreeGraphs G;
+        std::vector<char> key;
+        auto put = [&](const void *a, size_t n) { key.insert(key.end(), (const char *)a, (const char *)a + n); };
+        const void *ptrs[] = {org[0], org[1], org[2], mod[0], mod[1], mod[2], map_scu, map_ipm, map_tidx, map_cu_mode, states, jobs, out, next_best, cost, workspace, stream};
+        const long  ints[] = {s_org_l, s_org_c, s_mod_l, s_mod_c, nstates, nchains, (long)workspace_bytes, pic_elems ? 1 : 0};
+        put(ptrs, sizeof(ptrs)), put(ints, sizeof(ints)), put(p, sizeof(*p));
+        if(pic_elems) put(pic_elems, 5 * sizeof(int64_t));
+        if(I) put(I, sizeof(*I)), put(I->refp, sizeof(xeve_hip_refpic) * 2 * (size_t)std::max(I->ipar.rdo.num_refp[0], I->ipar.rdo.num_refp[1]));
+        TreeGraph *g = G.find(key);
+        if(g && g->exec) {
+            XH_HIP(hipGraphLaunch(g->exec, st));
+            return XEVE_HIP_OK;
         }
-        if(rc != XEVE_HIP_OK) return rc;
+        if(g && ++g->seen >= 2) {
+            XH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int        rc = enqueue();
+            const hipError_t ec = hipStreamEndCapture(st, &g->graph);
+            if(rc != XEVE_HIP_OK) return rc;
+            XH_HIP(ec);
+            XH_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+            XH_HIP(hipGraphLaunch(g->exec, st));
+            return XEVE_HIP_OK;
+        }
+        if(!g) G.add(key);
     }
+    const int rc = enqueue();
+    if(rc != XEVE_HIP_OK) return rc;
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

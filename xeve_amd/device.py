@@ -324,7 +324,7 @@ def pintra_analyze_cu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_
 
 
 def mode_analyze_ctu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, inter=None, pic_elems=None,
-                          workspace=None):
+                          workspace=None, outputs=None):
     """the mode decision of a batch of CTUs (xeve_hip_mode_analyze_ctu_jobs): one chain per job, walked in lockstep.  params: lib.TreeParams; inter: lib.TreeInter for a
     P / B slice (its refp = address of a HOST table of lib.REFPIC_DTYPE records with device planes; map_mv / map_refi / col_mv*: device addresses; coef_l / coef_c are
     filled in here), None for an I slice; jobs: uint8 tensor of lib.CTU_JOB_DTYPE records.  The planes of the picture being reconstructed (mod_ptrs) and the maps are

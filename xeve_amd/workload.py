@@ -563,15 +563,22 @@ class CtuWalkIntra:
             j = np.zeros(n, lib.CTU_JOB_DTYPE)
             j["x"], j["y"], j["sbac"], j["pic"] = x, y, np.arange(n), np.arange(n)
             self.jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(device))
+        self.job = self.jobs[0].clone()  # the call's operands stay at fixed addresses: the library replays the walk from a HIP graph
+        self.outputs = (torch.zeros((n, lib.CTU_DATA_BYTES), dtype=torch.uint8, device=device), torch.zeros((n, D.SBAC_BYTES), dtype=torch.uint8, device=device),
+                        torch.zeros(n, dtype=torch.float64, device=device))
+        self.stream = torch.cuda.Stream(device=device)  # (a graph cannot be captured on the default stream)
         self.k, self.out = 0, None
 
     def step(self):
         """decides CTU (k mod 4) of every picture; the coder state of each chain carries over"""
-        from . import device as D
         w = self.w
-        self.out, nxt, self.cost = D.mode_analyze_ctu_jobs([t.data_ptr() for t in self.org], w, w // 2, [t.data_ptr() for t in self.mod], w, w // 2, self.ms, self.mi, self.mt, self.mc,
-                                                           self.states, self.P, self.jobs[self.k % 4], pic_elems=self.pe, workspace=self.ws)
-        self.states = nxt
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.job.copy_(self.jobs[self.k % 4])
+            self.out, nxt, self.cost = D.mode_analyze_ctu_jobs([t.data_ptr() for t in self.org], w, w // 2, [t.data_ptr() for t in self.mod], w, w // 2, self.ms, self.mi, self.mt,
+                                                               self.mc, self.states, self.P, self.job, pic_elems=self.pe, workspace=self.ws, outputs=self.outputs)
+            self.states.view(-1).copy_(nxt.view(-1))
+        torch.cuda.current_stream().wait_stream(self.stream)
         self.k += 1
 
     def mean_depth(self):
