@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One bench.py step under a profiler: HotPathPass.inter() (the whole inter analysis of every CU of every level of one picture), `reps` times after one
-warm-up call.  Usage: probe_step.py [reps] [--1080p] [--structured] [--serial] [--mfma] [--intra]
+warm-up call.  Usage: probe_step.py [reps] [--1080p] [--structured] [--serial] [--mfma] [--intra] [--graph]
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_step -o st -- python tools/probe_step.py 3
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python tools/probe_step.py 1
 --serial runs the four levels one after the other on one stream (per-kernel counters are cleaner without overlap);
@@ -59,3 +59,19 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 print("%dx%d %s: %.2f ms per step (%d reps)%s" % (w, h, wl.content, 1e3 * dt, reps, "" if npic == 1 else ", %d pictures per step = %.2f pictures/s" % (npic, npic / dt)), flush=True)
+if "--graph" in sys.argv:  # the same step captured into one HIP graph (all four level streams fork from and join the capture stream) and replayed
+    cs = torch.cuda.Stream(device=dev)
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        wl.inter()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cs):
+            wl.inter()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    print("%dx%d %s: %.2f ms per step replayed from ONE HIP graph (%d reps)" % (w, h, wl.content, 1e3 * (time.perf_counter() - t0) / reps, reps), flush=True)
