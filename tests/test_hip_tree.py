@@ -203,3 +203,17 @@ def test_hip_ctu_rows_of_a_b_picture_as_chains_of_one_call():
                 assert np.array_equal(gd[f][0], d[f][0]), ((x, y), f)
             assert gnb.tobytes() == nb.tobytes() and np.float64(gcost).tobytes() == np.float64(cost).tobytes(), (x, y)
     assert np.array_equal(mod[0].cpu().numpy(), c["mod"][0]) and np.array_equal(mv.cpu().numpy(), m["mv"]) and np.array_equal(ms.cpu().numpy().view(np.uint32), m["scu"])
+
+
+def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path):
+    """XEVE_HIP_TREE_LANE=1 (off by default: measured slower): the 4x4 / 8x8 nodes decided by one lane per chain (csrc/cu_lane.h).  The switch is read
+    once per process, so a fresh interpreter runs two of the cases above with it on; the same comparison against the oracle must hold."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, XEVE_HIP_TREE_LANE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-k", "3101 or 3104 or 4103"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void k_rdoq(int16_t *__restrict__ coef, int nb
 // only look them up, so a first call inside a stream capture or on a latency-sensitive stream never allocates or synchronises.
 static uint16_t *g_scan[7][7];
 static int      *g_entropy; // entropy_bits[1024] of xeve_init_bits_est (xeve_mode.c:304-313), device copy
+const int *xh_entropy_table() { return g_entropy; }
 int xh_get_scan(int log2w, int log2h, const uint16_t **out)
 {
     if(log2w < 0 || log2w > 6 || log2h < 0 || log2h > 6 || !g_scan[log2w][log2h]) {

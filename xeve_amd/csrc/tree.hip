@@ -18,10 +18,12 @@
 // result only where the inter winner has a residual and the intra cost is smaller (mode_check_intra, :1226-1308); a skipped CU at depth >= ecu_depth is not split.
 // All costs are doubles built with the reference's operations in the reference's order (-ffp-contract=off), compared as the reference compares them.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "xh_common.h"
+#include "cu_lane.h"
 
 #define MAX_COST 1.7e+308
 typedef xeve_hip_ctu_data CtuData;
@@ -427,6 +429,29 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeK K, OpList ops)
     }
 }
 
+// ---- the intra analysis of a 4x4 / 8x8 node: one LANE per chain (cu_lane.h) ------------------------------------------------------------------------------------------
+// 320 of the 341 nodes of an I-picture CTU.  Same inputs and outputs as the batched composite (xeve_hip_pintra_analyze_cu_jobs): the node's job, the chain's entry
+// coder state; result record, dense levels and reconstruction (Y of all chains, then U, then V), core->s_temp_best -- so the tree operations around it do not change.
+template <int LOG2> __global__ void __launch_bounds__(64) k_intra_lane(TreeK K, xl::Params P, const pel *org_y, const pel *org_u, const pel *org_v, const uint8_t *map_tidx,
+                                                                        long org_pic_l, long org_pic_c)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, L = LOG2 - 2;
+    if(c >= K.nchains) return;
+    const Node *nd = AT(K.node, L);
+    if(!nd->leaf || (K.inter && !nd->try_intra)) return; // (nothing reads the result of a chain whose node is off)
+    const xeve_hip_intra_job J = K.ijobs[c];
+    const int  n0 = 1 << (2 * LOG2), n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
+    const pel *org[3] = {org_y + J.pic * org_pic_l, org_u ? org_u + J.pic * org_pic_c : nullptr, org_v ? org_v + J.pic * org_pic_c : nullptr};
+    const pel *mod[3] = {K.mod[0] + J.pic * K.mod_pic_l, K.mod[1] ? K.mod[1] + J.pic * K.mod_pic_c : nullptr, K.mod[2] ? K.mod[2] + J.pic * K.mod_pic_c : nullptr};
+    int16_t *coef = const_cast<int16_t *>(K.icoef);
+    pel     *rec = const_cast<pel *>(K.irec);
+    const long oy = (long)c * n0, ou = (long)K.nchains * n0 + (long)c * n1, ov = (long)K.nchains * (n0 + n1) + (long)c * n1;
+    xeve_hip_intra_result R;
+    xl::intra_cu<LOG2>(P, org, mod, K.map_scu + J.pic * K.map_pic, K.map_ipm + J.pic * K.map_pic, map_tidx + J.pic * K.map_pic, *AT(K.curr, L), J, R, coef + oy, coef + ou, coef + ov,
+                       rec + oy, rec + ou, rec + ov, K.sbest[c]);
+    const_cast<xeve_hip_intra_result *>(K.ires)[c] = R;
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------------------
 extern "C" int xeve_hip_satd_jobs(const pel *p1, int s1, const pel *p2, int s2, const xeve_hip_job *jobs, int njobs, const int32_t *cand_off, int ncand, int w, int h,
                                   int bit_depth, int32_t *out, void *stream);
@@ -458,6 +483,25 @@ static xeve_hip_inter_params level_inter_params(const xeve_hip_tree_inter *I, in
     xeve_hip_inter_params ep = I->ipar;
     ep.rdo.log2_cuw = ep.rdo.log2_cuh = log2;
     return ep;
+}
+static xl::Params lane_params(const xeve_hip_tree_params *p, int log2, int s_org_l, int s_org_c, int s_mod_l, int s_mod_c)
+{
+    static const int q_scale[6] = {26214, 23302, 20560, 18396, 16384, 14764}, dq_scale[6] = {40, 45, 51, 57, 64, 71}; // xeve_quant_scale[0] (xeve_tq.c:37), xeve_tbl_dq_scale_b (xeve_tbl.c:237)
+    xl::Params P;
+    const xeve_hip_intra_params &ip = p->ip;
+    const int idc = ip.chroma_format_idc, bd = ip.bit_depth, lc = log2 - (idc <= 2 ? 1 : 0);
+    P.idc = idc, P.bd = bd, P.slice_type = ip.slice_type, P.cip = ip.constrained_intra_pred != 0, P.w_scu = ip.w_scu, P.h_scu = ip.h_scu;
+    P.s_org_l = s_org_l, P.s_org_c = s_org_c, P.s_mod_l = s_mod_l, P.s_mod_c = s_mod_c;
+    for(int c = 0; c < 3; c++) {
+        const int q = ip.qp[c], log2_size = c ? lc : log2, tr_shift = 15 - bd - log2_size;
+        P.qp[c] = q, P.q_scale[c] = q_scale[q % 6], P.dq_scale[c] = dq_scale[q % 6] << (q / 6), P.lambda[c] = ip.lambda[c];
+        double e = (double)(1 << 15) * pow(2.0, -tr_shift); // ctx->err_scale[qp % 6][log2_size - 1], xeve_init_err_scale (xeve_tq.c:406-423)
+        e = e / q_scale[q % 6] / (1 << (bd - 8));
+        P.err_scale[c] = (int64_t)(e * (double)(1 << 20));
+    }
+    P.sqrt_lambda0 = ip.sqrt_lambda0, P.wgt[0] = ip.dist_chroma_weight[0], P.wgt[1] = ip.dist_chroma_weight[1];
+    P.entropy = xh_entropy_table();
+    return P;
 }
 // a node of this size can be a CU at all: within max_cu and no larger than the picture (the analyses of a size the picture cannot hold are left out of the schedule)
 static bool level_has_cu(const xeve_hip_tree_params *p, int log2) { return (1 << log2) <= p->max_cu && (1 << log2) <= p->pic_w && (1 << log2) <= p->pic_h; }
@@ -621,13 +665,26 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     wk.add(OP_ROOT_DONE, p->log2_ctu - 2, 0);
     wk.flush(AN_NONE, 0);
     const pel *const modc[3] = {mod[0], mod[1], mod[2]};
+    // XEVE_HIP_TREE_LANE=1: the 4x4 / 8x8 nodes decided by one lane per chain (cu_lane.h, k_intra_lane) instead of the batched composite.  MEASURED
+    // (profiles/r02_tree_lane.log): 3 launches per node instead of 29 and 3.5 ms of host time per CTU step instead of 56, but the serial lane code runs ~ 560 us per
+    // node (a single wave issues one dependent instruction every ~ 9 cycles and the chains of a wave diverge): 179 ms per CTU step for one chain against 68 ms, 583 ms
+    // against 217 ms for 8192 chains.  It only pays with >= 8 waves per SIMD, i.e. >= 65 000 chains in flight.  OFF by default; kept because it is the bit-exact,
+    // CPU-tested (tests/test_cu_lane.py) starting point of a wave-per-chain node kernel.
+    static const int use_lane = getenv("XEVE_HIP_TREE_LANE") ? atoi(getenv("XEVE_HIP_TREE_LANE")) : 0;
+    XH_REQUIRE(xh_entropy_table() != nullptr);
     auto enqueue = [&]() -> int { // the whole walk on `st`
         XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
         for(size_t i = 0; i < wk.launches.size(); i++) {
             k_tree_ops<<<nchains, 256, 0, st>>>(K, wk.launches[i]);
             const int log2 = wk.size[i], cu = 1 << log2;
             int rc = XEVE_HIP_OK;
-            if(wk.kind[i] == AN_INTRA) {
+            if(wk.kind[i] == AN_INTRA && log2 <= 3 && use_lane) { // one lane per chain decides the node (cu_lane.h)
+                const xl::Params LP = lane_params(p, log2, s_org_l, s_org_c, s_mod_l, s_mod_c);
+                const int grid = (nchains + 63) / 64;
+                if(log2 == 2) k_intra_lane<2><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
+                else k_intra_lane<3><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
+            }
+            else if(wk.kind[i] == AN_INTRA) {
                 const xeve_hip_intra_params ip = level_params(p, log2);
                 rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
                                                      nchains, &ip, K.ijobs, nchains, (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest,

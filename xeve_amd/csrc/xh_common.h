@@ -74,6 +74,7 @@ struct RdoParams {
 
 // zig-zag scan of a (1 << log2w) x (1 << log2h) block (xeve_tbl_scan), device memory, built once (rdoq.hip)
 int xh_get_scan(int log2w, int log2h, const uint16_t **out);
+const int *xh_entropy_table(); // entropy_bits[1024] of xeve_init_bits_est (device memory, built by xeve_hip_init; rdoq.hip)
 int xh_cu_bits_jobs_round(const int16_t *coef, size_t coef_elems, const xeve_hip_sbac *sbac_in, const xeve_hip_cu_bits_job *jobs, int njobs,
                           const xeve_hip_cu_bits_params *p, void *workspace, size_t workspace_bytes, uint32_t *bits, xeve_hip_sbac *state_out, int full, int reuse,
                           void *stream, int ev_first = 0, int ev_count = -1); // sbac.hip
