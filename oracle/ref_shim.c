@@ -627,7 +627,8 @@ typedef int (*hip_tree_any_host_fn)(const pel *const *, int, int, pel *const *, 
                                     const xo_tree_params *, const hip_tree_inter *, int, int, int, int, xo_ctu_data *, xo_sbac *, double *);
 static hip_tree_any_host_fn hip_tree_any_host;
 static int               tree_engine_oracle;
-static unsigned long long tree_calls, tree_fallbacks;
+static unsigned long long tree_calls, tree_fallbacks, tree_check_ctus, tree_check_bad;
+static int                tree_check;
 static double             tree_seconds;
 
 static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
@@ -677,6 +678,29 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
         __sync_fetch_and_add(&tree_fallbacks, 1);
         return orig_mode_analyze_lcu(ctx, core);
     }
+    /* XEVE_SHIM_TREE_CHECK=<libxeve_oracle.so> (with the GPU as the engine): the oracle walks a snapshot of the same inputs first and the two results are compared per CTU
+     * -- locates a deviation of the device walk inside a long encode (which CTU, which field) */
+    static __thread xo_ctu_data chk;
+    xo_sbac   chk_next;
+    xo_pel   *cm[3] = {NULL, NULL, NULL};
+    uint32_t *c_scu = NULL, *c_cum = NULL;
+    int8_t   *c_ipm = NULL, (*c_refi)[2] = NULL;
+    int16_t (*c_mv)[2][2] = NULL;
+    const int do_check = tree_check && !tree_engine_oracle;
+    if(do_check) {
+        const int nscu = ctx->w_scu * ctx->h_scu, hc = ctx->h >> hs;
+        cm[0] = malloc(sizeof(pel) * pm->s_l * (ctx->h + 1)), cm[1] = malloc(sizeof(pel) * pm->s_c * (hc + 1)), cm[2] = malloc(sizeof(pel) * pm->s_c * (hc + 1));
+        memcpy(cm[0], pm->y, sizeof(pel) * pm->s_l * ctx->h), memcpy(cm[1], pm->u, sizeof(pel) * pm->s_c * hc), memcpy(cm[2], pm->v, sizeof(pel) * pm->s_c * hc);
+        c_scu = malloc(4 * nscu), c_cum = malloc(4 * nscu), c_ipm = malloc(nscu), c_mv = malloc(sizeof(*c_mv) * nscu), c_refi = malloc(sizeof(*c_refi) * nscu);
+        memcpy(c_scu, ctx->map_scu, 4 * nscu), memcpy(c_cum, ctx->map_cu_mode, 4 * nscu), memcpy(c_ipm, ctx->map_ipm, nscu);
+        memcpy(c_mv, ctx->map_mv, sizeof(*c_mv) * nscu), memcpy(c_refi, ctx->map_refi, sizeof(*c_refi) * nscu);
+        if(is_i) (void)xo_tree((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], cm, pm->s_l, pm->s_c, c_scu, c_ipm, ctx->map_tidx, c_cum, &entry, &P, x0, y0, &chk, &chk_next);
+        else {
+            xo_tree_inter TC = TI;
+            TC.map_mv = c_mv, TC.map_refi = c_refi;
+            (void)xo_tree_any((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], cm, pm->s_l, pm->s_c, c_scu, c_ipm, ctx->map_tidx, c_cum, &entry, &P, &TC, x0, y0, &chk, &chk_next);
+        }
+    }
     clock_gettime(CLOCK_MONOTONIC, &t0);
     if(!is_i) {
         if(tree_engine_oracle) cost = xo_tree_any((const xo_pel *const *)org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, ctx->map_scu, ctx->map_ipm, ctx->map_tidx, ctx->map_cu_mode, &entry, &P, &TI, x0, y0, &out, &next);
@@ -705,6 +729,20 @@ static int shim_route_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     (void)cost;
+    if(do_check) {
+        int bad = 0;
+#define CHK(field) do { if(memcmp(out.field, chk.field, sizeof(out.field))) { if(tree_check_bad < 8) { size_t k_ = 0; while(((const char *)out.field)[k_] == ((const char *)chk.field)[k_]) k_++; \
+            fprintf(stderr, "[tree check] CTU %d (%d,%d) slice %d: %s differs at byte %zu\n", core->lcu_num, x0, y0, ctx->sh->slice_type, #field, k_); } bad = 1; } } while(0)
+        CHK(split_mode); CHK(pred_mode); CHK(ipm); CHK(depth); CHK(nnz); CHK(map_scu); CHK(map_cu_mode); CHK(coef); CHK(reco); CHK(mv); CHK(mvd); CHK(refi); CHK(mvp_idx);
+#undef CHK
+        if(memcmp(&next, &chk_next, sizeof(next))) { if(tree_check_bad < 8) fprintf(stderr, "[tree check] CTU %d (%d,%d): exit coder state differs\n", core->lcu_num, x0, y0); bad = 1; }
+        const int nscu = ctx->w_scu * ctx->h_scu;
+        if(memcmp(c_scu, ctx->map_scu, 4 * nscu) || memcmp(c_ipm, ctx->map_ipm, nscu) || memcmp(c_cum, ctx->map_cu_mode, 4 * nscu)) { if(tree_check_bad < 8) fprintf(stderr, "[tree check] CTU %d (%d,%d): unit maps differ\n", core->lcu_num, x0, y0); bad = 1; }
+        if(!is_i && (memcmp(c_mv, ctx->map_mv, sizeof(*c_mv) * nscu) || memcmp(c_refi, ctx->map_refi, sizeof(*c_refi) * nscu))) { if(tree_check_bad < 8) fprintf(stderr, "[tree check] CTU %d (%d,%d): motion maps differ\n", core->lcu_num, x0, y0); bad = 1; }
+        if(memcmp(cm[0], pm->y, sizeof(pel) * pm->s_l * ctx->h)) { if(tree_check_bad < 8) fprintf(stderr, "[tree check] CTU %d (%d,%d): luma picture differs\n", core->lcu_num, x0, y0); bad = 1; }
+        tree_check_ctus++, tree_check_bad += bad;
+        free(cm[0]), free(cm[1]), free(cm[2]), free(c_scu), free(c_cum), free(c_ipm), free(c_mv), free(c_refi);
+    }
     /* the CTU's data for the entropy coder (xeve_eco_tree -> xeve_eco_unit reads ctx->map_cu_data[lcu_num]) */
     XEVE_CU_DATA *cd = &ctx->map_cu_data[core->lcu_num];
     const int nu = 1 << L, ctu = 1 << ctx->log2_max_cuwh, wu = XEVE_MIN(nu, ctx->w_scu - (x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (y0 >> 2));
@@ -761,6 +799,7 @@ static void report(void)
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
     if(tree_calls || tree_fallbacks) fprintf(stderr, "[xeve_hip_shim] CTUs whose whole mode decision ran on the %s: %llu (left to the reference: %llu), %.1f ms per CTU\n", tree_engine_oracle ? "oracle (CPU)" : "GPU", tree_calls, tree_fallbacks, tree_calls ? 1e3 * tree_seconds / (double)tree_calls : 0.0);
+    if(tree_check) fprintf(stderr, "[xeve_hip_shim] device walk checked against the oracle per CTU: %llu CTUs, %llu differ\n", tree_check_ctus, tree_check_bad);
     if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered), %llu of them in P / B pictures\n", shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
     if(hip_table_calls) fprintf(stderr, "[xeve_hip_shim] dispatch-table calls served by HIP: %llu\n", hip_table_calls());
@@ -875,6 +914,11 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
             if(ctx->fn_mode_analyze_frame != shim_analyze_frame) orig_analyze_frame = ctx->fn_mode_analyze_frame, ctx->fn_mode_analyze_frame = shim_analyze_frame;
         }
         fprintf(stderr, "[xeve_hip_shim] CTU mode decision of %s pictures routed to the GPU (one exchange per CTU)\n", hip_tree_any_host ? "I, P and B" : "I");
+        if(getenv("XEVE_SHIM_TREE_CHECK")) {
+            void *oh = dlopen(getenv("XEVE_SHIM_TREE_CHECK"), RTLD_NOW | RTLD_LOCAL);
+            if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra")) || !(xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu"))) { fprintf(stderr, "[xeve_hip_shim] tree check: %s\n", dlerror()); abort(); }
+            tree_check = 1;
+        }
     }
     if(getenv("XEVE_HIP_SHIM_ME") && atoi(getenv("XEVE_HIP_SHIM_ME"))) {
         hip_me_epzs_host = dlsym(h, "xeve_hip_me_epzs_host"), hip_err = err;

@@ -53,9 +53,7 @@ def test_cfg2_1280x720_low_delay_fast(tmp_path):
     _encode(tmp_path, "cfg2_720p_ldb_fast", REAL_CASES, 15000)
 
 
-def test_cfg2_1280x720_with_every_ctu_decided_on_the_gpu(tmp_path):
-    """the same clip with ctx->fn_mode_analyze_lcu of all 480 CTUs (the I and the P picture) served by the device-side tree walk: one exchange per CTU, nothing per CU"""
-    name = "cfg2_720p_ldb_fast"
+def _encode_per_ctu(tmp_path, name, nctu):
     w, h, n, seed, extra = REAL_CASES[name]
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
@@ -63,9 +61,20 @@ def test_cfg2_1280x720_with_every_ctu_decided_on_the_gpu(tmp_path):
     md5, size, err = run_app(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, timeout=3000, tables=False, tree=2)
     dt = time.perf_counter() - t0
     k = re.search(r"mode decision ran on the GPU: (\d+) \(left to the reference: (\d+)\), ([0-9.]+) ms per CTU", err)
-    assert k and (int(k.group(1)), int(k.group(2))) == (480, 0), err[-800:]
-    print("%s: 480 CTUs decided on the GPU in %.1f s wall, %s ms per CTU (one exchange each)" % (name, dt, k.group(3)))
+    assert k and (int(k.group(1)), int(k.group(2))) == (nctu, 0), err[-800:]
+    print("%s: %d CTUs decided on the GPU in %.1f s wall, %s ms per CTU (one exchange each)" % (name, nctu, dt, k.group(3)))
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+def test_cfg2_1280x720_with_every_ctu_decided_on_the_gpu(tmp_path):
+    """the same clip with ctx->fn_mode_analyze_lcu of all 480 CTUs (the I and the P picture) served by the device-side tree walk: one exchange per CTU, nothing per CU"""
+    _encode_per_ctu(tmp_path, "cfg2_720p_ldb_fast", 480)
+
+
+def test_cfg3_1920x1080_with_every_ctu_decided_on_the_gpu(tmp_path):
+    """1920x1080 random access (I, B, B in coding order: POC-scaled search ranges, temporal direct, both ECU depths, the bottom CTU row cut at 1080 = 16 * 64 + 56):
+    all 3 x 510 CTUs decided on the device"""
+    _encode_per_ctu(tmp_path, "cfg3_1080p_ra_medium", 1530)
 
 
 def test_cfg3_1920x1080_random_access_medium(tmp_path):

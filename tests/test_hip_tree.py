@@ -217,3 +217,49 @@ def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path):
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-k", "3101 or 3104 or 4103"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
+
+
+def test_hip_ctu_host_form_over_two_b_pictures():
+    """xeve_hip_mode_analyze_ctu_host (what ctx->fn_mode_analyze_lcu is pointed at) called directly, CTU by CTU, over TWO B pictures of one size one after the other:
+    host planes and maps, resident pictures announced per picture, the per-thread device buffers reused -- what the first picture left in them (every unit coded)
+    must not leak into the second: the left neighbours of the CUs in a CTU's bottom rows reach into the CTU row below, which is not coded yet."""
+    import ctypes as C
+
+    import xeve_amd
+    from test_hip_inter import hip_params
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from _mc_cases import PAD_L, refpic_table
+
+    xeve_amd.init(0)
+    L = lib.load()
+    for seed in (4301, 4302):  # (this pair failed before the units below the CTU were handed over: picture 1 had left them "coded" in the device buffers)
+        c = make_inter_case(seed, 192, 192, 10, 1, 0, 1, 0, 0.0)
+        refs, org = c["refs"], c["org"]
+        exp_c = make_inter_case(seed, 192, 192, 10, 1, 0, 1, 0, 0.0)
+        exp = run_oracle_inter_picture(exp_c)
+        lib.check(L.xeve_hip_picture_begin())
+        tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+        P = lib.TreeParams.from_buffer_copy(bytes(c["P"]))
+        I = lib.TreeInter()
+        m = c["maps"]
+        I.refp, I.s_ref_l, I.s_ref_c, I.ipar = tab.ctypes.data, refs["s_l"], refs["s_c"], hip_params(c["ipar"])
+        I.map_mv, I.map_refi, I.col_mv0, I.col_mv1, I.ecu_depth = m["mv"].ctypes.data, m["refi"].ctypes.data, c["col"][0].ctypes.data, c["col"][1].ctypes.data, c["ecu_depth"]
+        I.coef_l, I.coef_c = D.baseline_coef_l().ctypes.data, D.baseline_coef_c().ctypes.data
+        orgp = (C.c_void_p * 3)(int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"])
+        modp = (C.c_void_p * 3)(*[a.ctypes.data for a in c["mod"]])
+        state = c["entry"][0:1].copy()
+        for k, (x, y) in enumerate(c["order"]):
+            d, nb, cost = np.zeros(1, CTU_DATA_DTYPE), np.zeros(1, SBAC_DTYPE), np.zeros(1, np.float64)
+            lib.check(L.xeve_hip_mode_analyze_ctu_host(orgp, refs["s_l"], refs["s_c"], modp, c["mod"][0].shape[1], c["mod"][1].shape[1], m["scu"].ctypes.data, m["ipm"].ctypes.data,
+                                                       m["tidx"].ctypes.data, m["cu_mode"].ctypes.data, state.ctypes.data, C.byref(P), C.byref(I), PAD_L, PAD_L, x, y,
+                                                       d.ctypes.data, nb.ctypes.data, cost.ctypes.data))
+            ed, enb, ecost = exp[k]
+            for f in CTU_DATA_DTYPE.names:
+                assert np.array_equal(d[f][0], ed[f][0]), (seed, "ctu", k, f)
+            assert nb.tobytes() == enb.tobytes() and cost.tobytes() == np.float64(ecost).tobytes(), (seed, k)
+            state = nb.copy()
+        for j in range(3):
+            assert np.array_equal(c["mod"][j], exp_c["mod"][j]), (seed, "picture", j)
+        for f in ("scu", "ipm", "cu_mode", "mv", "refi"):
+            assert np.array_equal(m[f], exp_c["maps"][f]), (seed, "map", f)

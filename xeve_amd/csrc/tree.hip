@@ -949,6 +949,11 @@ extern "C" int xeve_hip_mode_analyze_ctu_host(const xeve_hip_pel *const org[3], 
         return width && height ? hipMemcpy2DAsync(dst, pitch, src, pitch, width, height, kind, C.st) : hipSuccess;
     };
     XH_HIP(copy2d(C.buf[B_SCU] + u0 * 4, map_scu + u0, (size_t)w_scu * 4, (size_t)Wl * 4, Hl, hipMemcpyHostToDevice));
+    if(y_scu + nh < h_scu) { // the units BELOW the CTU and its left margin: the left neighbours of a CU reach as far below it as it is high, i.e. out of the CTU's bottom row
+                             // into units that are not coded yet -- their flags must say so here too (the buffers keep what earlier pictures left)
+        const size_t b0 = (size_t)(y_scu + nh) * w_scu + (x_scu - lx);
+        XH_HIP(copy2d(C.buf[B_SCU] + b0 * 4, map_scu + b0, (size_t)w_scu * 4, (size_t)(lx + cw) * 4, std::min(n, h_scu - (y_scu + nh)), hipMemcpyHostToDevice));
+    }
     XH_HIP(copy2d(C.buf[B_CUM] + u0 * 4, map_cu_mode + u0, (size_t)w_scu * 4, (size_t)Wl * 4, Hl, hipMemcpyHostToDevice));
     XH_HIP(copy2d(C.buf[B_IPM] + u0, map_ipm + u0, (size_t)w_scu, (size_t)Wl, Hl, hipMemcpyHostToDevice));
     XH_HIP(copy2d(C.buf[B_MV] + u0 * 8, I->map_mv + u0 * 4, (size_t)w_scu * 8, (size_t)Wl * 8, Hl, hipMemcpyHostToDevice));
