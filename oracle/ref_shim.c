@@ -494,8 +494,63 @@ static void sbac_to_flat(xo_sbac *h, const XEVE_SBAC *sb)
 #undef F
 }
 
+/* the writer's side in shadow mode: when CTU n + 1 enters, the reference has written CTU n with xeve_eco_tree; the oracle's xo_eco_ctu writes the same CTU from the
+ * state CTU n entered with, on the maps as the decision left them, and must arrive at the state CTU n + 1 enters with (it is loaded from the writer, xeve_enc.c:139),
+ * at the same bytes in the bitstream buffer and at the same unit flags */
+static int (*xo_eco)(xo_sbac *, const xo_ctu_data *, const xo_tree_params *, const int *, uint32_t *, const int8_t *, const uint8_t *, uint32_t *, int, int, uint8_t *, int);
+static unsigned long long eco_ctus, eco_bad, eco_bytes;
+static struct {
+    int            valid, lcu, x0, y0, num_refp[2];
+    long           byte_pos;
+    const void    *pic;
+    xo_sbac        entry;
+    xo_ctu_data    out;
+    xo_tree_params P;
+    uint32_t      *scu, *cum;
+    int8_t        *ipm;
+} W;
+static long bsw_pos(const XEVE_BSW *bs) { return (long)(bs->cur - bs->beg) + ((32 - bs->leftbits) >> 3); }
+static int  bsw_byte(const XEVE_BSW *bs, long pos)
+{
+    const long flushed = (long)(bs->cur - bs->beg);
+    return pos < flushed ? bs->beg[pos] : (int)((bs->code >> (24 - 8 * (pos - flushed))) & 0xFF);
+}
+static void shadow_writer_check(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *now)
+{
+    const XEVE_BSW *bs = &ctx->bs[core->thread_cnt];
+    if(W.valid && W.pic == (const void *)PIC_MODE(ctx) && core->lcu_num == W.lcu + 1 && xo_eco) {
+        static uint8_t bytes[1 << 16];
+        xo_sbac s = W.entry;
+        const int n = xo_eco(&s, &W.out, &W.P, W.num_refp, W.scu, W.ipm, ctx->map_tidx, W.cum, W.x0, W.y0, bytes, (int)sizeof(bytes));
+        int bad = 0;
+        if(s.range != now->range || s.code != now->code || s.code_bits != now->code_bits || s.stacked_ff != now->stacked_ff || s.stacked_zero != now->stacked_zero ||
+           s.pending_byte != now->pending_byte || s.is_pending_byte != now->is_pending_byte || memcmp(s.ctx, now->ctx, sizeof(s.ctx))) {
+            if(eco_bad < 6) fprintf(stderr, "[shadow writer] CTU %d: coder state differs (range %u vs %u, code %u vs %u, bits %u vs %u)\n", W.lcu, s.range, now->range, s.code, now->code, s.code_bits, now->code_bits);
+            bad = 1;
+        }
+        const long p1 = bsw_pos(bs);
+        if(p1 - W.byte_pos != n) { if(eco_bad < 6) fprintf(stderr, "[shadow writer] CTU %d: %d bytes vs %ld in the bitstream\n", W.lcu, n, p1 - W.byte_pos); bad = 1; }
+        else
+            for(int i = 0; i < n && i < (int)sizeof(bytes); i++)
+                if(bytes[i] != bsw_byte(bs, W.byte_pos + i)) { if(eco_bad < 6) fprintf(stderr, "[shadow writer] CTU %d: byte %d differs\n", W.lcu, i); bad = 1; break; }
+        const int nu = 1 << (ctx->log2_max_cuwh - 2), wu = XEVE_MIN(nu, ctx->w_scu - (W.x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (W.y0 >> 2));
+        for(int j = 0; j < hu && !bad; j++)
+            for(int i = 0; i < wu; i++) {
+                const int g = ((W.y0 >> 2) + j) * ctx->w_scu + (W.x0 >> 2) + i;
+                if(W.scu[g] != ctx->map_scu[g] || W.cum[g] != ctx->map_cu_mode[g]) { if(eco_bad < 6) fprintf(stderr, "[shadow writer] CTU %d: unit %d flags %08x / %08x vs %08x / %08x\n", W.lcu, g, W.scu[g], W.cum[g], ctx->map_scu[g], ctx->map_cu_mode[g]); bad = 1; break; }
+            }
+        eco_ctus++, eco_bad += bad, eco_bytes += (unsigned long long)n;
+    }
+    W.valid = 0;
+}
+
 static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
 {
+    if(ctx->param.threads == 1 && xo_eco) { /* (the entry state of this CTU = the writer's state after the previous one) */
+        xo_sbac now;
+        sbac_to_flat(&now, &core->s_curr_best[ctx->log2_max_cuwh - 2][ctx->log2_max_cuwh - 2]);
+        shadow_writer_check(ctx, core, &now);
+    }
     const int L = ctx->log2_max_cuwh - 2, idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift;
     const int is_i = ctx->sh->slice_type == SLICE_I;
     xo_tree_inter  TI;
@@ -608,6 +663,14 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     if(memcmp(&ref_next, &next, sizeof(next))) BAD("exit coder state differs (range %u vs %u)", ref_next.range, next.range);
     shadow_ctus++;
     if(bad) shadow_bad++;
+    if(xo_eco && !bad) { /* what the writer is about to write: kept for the check at the next CTU's entry */
+        const int nscu2 = ctx->w_scu * ctx->h_scu;
+        W.scu = realloc(W.scu, 4 * nscu2), W.cum = realloc(W.cum, 4 * nscu2), W.ipm = realloc(W.ipm, nscu2);
+        memcpy(W.scu, ctx->map_scu, 4 * nscu2), memcpy(W.cum, ctx->map_cu_mode, 4 * nscu2), memcpy(W.ipm, ctx->map_ipm, nscu2);
+        W.valid = 1, W.lcu = lcu, W.x0 = x0, W.y0 = y0, W.pic = (const void *)PIC_MODE(ctx), W.entry = entry, W.out = out, W.P = P;
+        W.num_refp[0] = ctx->rpm.num_refp[REFP_0], W.num_refp[1] = ctx->rpm.num_refp[REFP_1];
+        W.byte_pos = bsw_pos(&ctx->bs[core->thread_cnt]);
+    }
     free(mod[0]), free(mod[1]), free(mod[2]), free(m_scu), free(m_cum), free(m_ipm), free(m_mv), free(m_refi);
     return rc;
 }
@@ -799,6 +862,7 @@ static void report(void)
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
     if(tree_calls || tree_fallbacks) fprintf(stderr, "[xeve_hip_shim] CTUs whose whole mode decision ran on the %s: %llu (left to the reference: %llu), %.1f ms per CTU\n", tree_engine_oracle ? "oracle (CPU)" : "GPU", tree_calls, tree_fallbacks, tree_calls ? 1e3 * tree_seconds / (double)tree_calls : 0.0);
+    if(eco_ctus) fprintf(stderr, "[xeve_hip_shim] shadow writer: %llu CTUs written by the oracle beside xeve_eco_tree (%llu bytes of bitstream compared), %llu differ\n", eco_ctus, eco_bytes, eco_bad);
     if(tree_check) fprintf(stderr, "[xeve_hip_shim] device walk checked against the oracle per CTU: %llu CTUs, %llu differ\n", tree_check_ctus, tree_check_bad);
     if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered), %llu of them in P / B pictures\n", shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus);
     if(inter_calls) fprintf(stderr, "[xeve_hip_shim] time inside the GPU calls: %.2f s = %.0f us per CU\n", inter_seconds, 1e6 * inter_seconds / (double)inter_calls);
@@ -829,6 +893,7 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         void *oh = dlopen(getenv("XEVE_SHIM_SHADOW_TREE"), RTLD_NOW | RTLD_LOCAL);
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
         xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu");
+        xo_eco = dlsym(oh, "xo_eco_ctu");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
         fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
         atexit(report);

@@ -967,10 +967,22 @@ uint32_t xo_sbac_bits(const xo_sbac *s)
 }
 
 /* sbac_put_byte with is_bitcount set (xeve_eco.c:397-427): written bytes only advance bitcounter (xeve_bsw_write_est, :392) */
+/* write mode (is_bitcount clear: the bitstream writer's coder): the bytes go to the sink xo_eco_ctu sets instead of advancing the counter */
+static __thread uint8_t *g_sink;
+static __thread int      g_sink_n, g_sink_cap;
+static void sink_put(uint8_t b)
+{
+    if(g_sink_n < g_sink_cap) g_sink[g_sink_n] = b;
+    g_sink_n++;
+}
 static void sbac_byte(xo_sbac *s, uint8_t b)
 {
     if(s->is_pending_byte) {
         if(s->pending_byte == 0) s->stacked_zero++;
+        else if(g_sink) {
+            for(; s->stacked_zero; s->stacked_zero--) sink_put(0x00);
+            sink_put((uint8_t)s->pending_byte);
+        }
         else {
             s->bitcounter += 8 * s->stacked_zero + 8;
             s->stacked_zero = 0;
@@ -2378,4 +2390,117 @@ double xo_mode_analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c,
 {
     return analyze_ctu(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, entry, P, P->ip.slice_type == 2 ? NULL : I, x0, y0, out,
                        next_best);
+}
+
+
+/* ===================================================================================================================
+ * The bitstream writer's side of one CTU: xeve_eco_tree (src_base/xeve_enc.c:35-100) -> xeve_eco_split_mode (xeve_eco.c:1377-1429) and xeve_eco_unit
+ * (:1431-1640) for every CU of the decided tree, on the WRITER's coder (no reset between CUs or CTUs: CTU n + 1 starts its mode decision from the state this leaves,
+ * xeve_enc.c:139).  Baseline, no delta QP.  The syntax is not the rate estimate's: in P slices the writer codes neither direct_mode_flag nor inter_pred_idc, the
+ * estimate (xeve_rdo_bit_cnt_cu_inter, xeve_mode.c:201-274) codes both.  As the CUs are written their units get what xeve_eco_unit stores: the coded flag, the skip
+ * flag, the luma cbf flag, the CU's size.  Bytes the coder emits are collected (the pending byte and the code register stay in the state).
+ * =================================================================================================================== */
+typedef struct eco_ctx {
+    xo_sbac              *s;
+    const xo_ctu_data    *d;
+    const xo_tree_params *P;
+    int                   num_refp[2], x0, y0, pitch;
+    uint32_t             *map_scu, *map_cu_mode;
+    const int8_t         *map_ipm;
+    const uint8_t        *map_tidx;
+} eco_ctx;
+
+static void eco_unit(eco_ctx *E, int x, int y, int log2, int cup)
+{
+    const xo_tree_params *P = E->P;
+    const xo_ctu_data    *d = E->d;
+    xo_sbac *s = E->s;
+    const int idc = P->ip.chroma_format_idc, ws = idc <= 2, hs = idc <= 1, cu = 1 << log2, st = P->ip.slice_type, mode = d->pred_mode[cup], skip = mode == 2 /* MODE_SKIP */;
+    const int ctu = 1 << P->log2_ctu, lx = x - E->x0, ly = y - E->y0;
+    xo_cu_bits_params bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.log2_cuw = bp.log2_cuh = log2, bp.slice_type = st, bp.num_refp[0] = E->num_refp[0], bp.num_refp[1] = E->num_refp[1], bp.chroma_format_idc = idc;
+    if(st != 2) {
+        xo_sbac_bin(s, XO_CTX_SKIP_FLAG, skip); /* (ctx_flags: 0 without sps_cm_init_flag) */
+        if(skip) {
+            sbac_mvp_idx(s, d->mvp_idx[cup][0]);
+            if(st == 0) sbac_mvp_idx(s, d->mvp_idx[cup][1]);
+        }
+        else {
+            xo_sbac_bin(s, XO_CTX_PRED_MODE, mode == 0);
+            if(mode != 0) {
+                if(st == 0) xo_sbac_bin(s, XO_CTX_DIRECT, mode == 3 /* MODE_DIR */);
+                if(mode != 3) {
+                    const int r0 = d->refi[cup][0], r1 = d->refi[cup][1];
+                    if(st == 0) { /* xeve_eco_inter_pred_idc (xeve_eco.c:1123-1156) */
+                        if(r0 >= 0 && r1 >= 0) xo_sbac_bin(s, XO_CTX_INTER_DIR, 0);
+                        else xo_sbac_bin(s, XO_CTX_INTER_DIR, 1), xo_sbac_bin(s, XO_CTX_INTER_DIR + 1, r0 >= 0 ? 0 : 1);
+                    }
+                    if(r0 >= 0) sbac_refi(s, E->num_refp[0], r0), sbac_mvp_idx(s, d->mvp_idx[cup][0]), sbac_mvd1(s, d->mvd[cup][0][0]), sbac_mvd1(s, d->mvd[cup][0][1]);
+                    if(st == 0 && r1 >= 0) sbac_refi(s, E->num_refp[1], r1), sbac_mvp_idx(s, d->mvp_idx[cup][1]), sbac_mvd1(s, d->mvd[cup][1][0]), sbac_mvd1(s, d->mvd[cup][1][1]);
+                }
+            }
+        }
+    }
+    if(mode == 0) { /* xeve_get_mpm from the live maps: the units written so far are coded */
+        const uint8_t *mpm = xo_get_mpm(x >> 2, y >> 2, E->map_scu, E->map_ipm, E->map_tidx, P->ip.w_scu);
+        sbac_unary2(s, mpm[d->ipm[0][cup]], XO_CTX_INTRA_DIR);
+    }
+    int nnz[3] = {0, 0, 0};
+    if(!skip) { /* coef_rect_to_series + xeve_eco_coef(RUN_L | RUN_CB | RUN_CR) */
+        static const int run_all[3] = {1, 1, 1};
+        const int n0 = cu * cu, cw = cu >> ws, ch = cu >> hs, n1 = idc ? cw * ch : 0;
+        int16_t *all = malloc(sizeof(int16_t) * (size_t)(n0 + 2 * n1 + 1));
+        for(int j = 0; j < cu; j++) memcpy(all + j * cu, d->coef[0] + (ly + j) * ctu + lx, sizeof(int16_t) * (size_t)cu);
+        for(int c = 1; c < 3 && idc; c++)
+            for(int j = 0; j < ch; j++) memcpy(all + n0 + (c - 1) * n1 + j * cw, d->coef[c] + ((ly >> hs) + j) * (ctu >> ws) + (lx >> ws), sizeof(int16_t) * (size_t)cw);
+        xo_cu_bits_job bj;
+        memset(&bj, 0, sizeof(bj));
+        bj.coef_off[1] = n0, bj.coef_off[2] = n0 + n1;
+        for(int c = 0; c < 3; c++) nnz[c] = bj.nnz[c] = d->nnz[c][cup];
+        sbac_coef(s, &bp, &bj, all, run_all, mode == 0, 0);
+        free(all);
+    }
+    for(int j = 0; j < cu >> 2; j++)
+        for(int i = 0; i < cu >> 2; i++) {
+            const int g = ((y >> 2) + j) * P->ip.w_scu + (x >> 2) + i;
+            uint32_t  m = E->map_scu[g];
+            m = skip ? m | (1u << 23) : m & ~(1u << 23);       /* MCU_SET_SF / CLR_SF */
+            m = nnz[0] > 0 ? m | (1u << 24) : m & ~(1u << 24); /* MCU_SET_CBFL / CLR_CBFL: core->nnz_sub[Y_C][0] */
+            E->map_scu[g] = m | (1u << 31);                    /* MCU_SET_COD */
+            E->map_cu_mode[g] = (E->map_cu_mode[g] & 0x00FFFFFFu) | ((uint32_t)log2 << 24) | ((uint32_t)log2 << 28);
+        }
+}
+
+static void eco_node(eco_ctx *E, int x, int y, int log2, int cud, int cup)
+{
+    const xo_tree_params *P = E->P;
+    const int cu = 1 << log2, half = cu >> 1;
+    const int split = cu >= 8 ? E->d->split_mode[cud][cup + (half >> 2) * E->pitch + (half >> 2)] : 0; /* xeve_get_split_mode (xeve_util.c:1125-1144) */
+    if(split) {
+        xo_sbac_bin(E->s, XO_CTX_SPLIT_CU, 1); /* (always coded without sps_btt_flag, also where the picture edge implies it) */
+        for(int part = 0; part < 4; part++) {
+            const int xp = x + (part & 1) * half, yp = y + (part >> 1) * half;
+            if(xp < P->pic_w && yp < P->pic_h) eco_node(E, xp, yp, log2 - 1, cud + 2, cup + (part & 1) * (half >> 2) + (part >> 1) * (half >> 2) * E->pitch);
+        }
+    }
+    else {
+        if(cu > 4) xo_sbac_bin(E->s, XO_CTX_SPLIT_CU, 0);
+        eco_unit(E, x, y, log2, cup);
+    }
+}
+
+int xo_eco_ctu(xo_sbac *s, const xo_ctu_data *d, const xo_tree_params *P, const int num_refp[2], uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx,
+               uint32_t *map_cu_mode, int x0, int y0, uint8_t *bytes, int bytes_cap)
+{
+    eco_ctx E;
+    memset(&E, 0, sizeof(E));
+    E.s = s, E.d = d, E.P = P, E.num_refp[0] = num_refp[0], E.num_refp[1] = num_refp[1], E.x0 = x0, E.y0 = y0, E.pitch = 1 << (P->log2_ctu - 2);
+    E.map_scu = map_scu, E.map_cu_mode = map_cu_mode, E.map_ipm = map_ipm, E.map_tidx = map_tidx;
+    static uint8_t none[1];
+    g_sink = bytes ? bytes : none, g_sink_n = 0, g_sink_cap = bytes ? bytes_cap : 0;
+    eco_node(&E, x0, y0, P->log2_ctu, 0, 0);
+    const int n = g_sink_n;
+    g_sink = NULL, g_sink_n = g_sink_cap = 0;
+    return n;
 }

@@ -476,6 +476,12 @@ typedef struct xo_tree_inter {
 double xo_mode_analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
                            const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, const xo_tree_inter *inter, int x0, int y0,
                            xo_ctu_data *out, xo_sbac *next_best);
+/* The bitstream writer's side of a decided CTU: xeve_eco_tree (xeve_enc.c:35-100) with the writer's coder `s` (continued, never reset inside a tile): split flags and the
+ * syntax of every CU as xeve_eco_unit writes it (xeve_eco.c:1431-1640; not the rate estimate's syntax: no direct_mode_flag / inter_pred_idc in P slices).  map_scu /
+ * map_cu_mode (the CTU's units: coded flags cleared on entry) receive what xeve_eco_unit stores.  Returns the number of bytes the coder emitted; the first bytes_cap of
+ * them are stored (bytes may be NULL). */
+int xo_eco_ctu(xo_sbac *s, const xo_ctu_data *d, const xo_tree_params *P, const int num_refp[2], uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx,
+               uint32_t *map_cu_mode, int x0, int y0, uint8_t *bytes, int bytes_cap);
 double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
                                  int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
                                  xo_ctu_data *out, xo_sbac *next_best);

@@ -303,6 +303,10 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
     m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ \((\d+) not covered\), (\d+) of them in P / B", err)
     assert m, err[-800:]
     assert tuple(int(m.group(k)) for k in (1, 2, 3, 4)) == (nctu, 0, 0, ninter), err[-1500:]
+    # the writer's side: xo_eco_ctu (xeve_eco_tree restated) wrote every CTU but the last of each picture beside the reference -- the coder state the next CTU enters
+    # with, the bytes in the bitstream buffer, the unit flags xeve_eco_unit stores
+    k = re.search(r"shadow writer: (\d+) CTUs written by the oracle beside xeve_eco_tree \((\d+) bytes of bitstream compared\), (\d+) differ", err)
+    assert k and int(k.group(1)) == nctu - n and int(k.group(2)) > 0 and int(k.group(3)) == 0, err[-1500:]
 
 
 @needs_ref
