@@ -11,7 +11,7 @@ import re
 
 import pytest
 
-from _e2e import CASES, SHIM, make_yuv, run_app
+from _e2e import CASES, REAL_CASES, SHIM, make_yuv, run_app
 from _libs import REF_APP
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_v1.json")))
@@ -286,7 +286,7 @@ def test_bitstream_identical_with_inter_and_intra_analysis_on_the_gpu(tmp_path, 
 
 @needs_ref
 @pytest.mark.parametrize("name,nctu,ninter", [("noise_allintra_medium", 8, 0), ("moving_cif_allintra_fast", 60, 0), ("tiny_ra_medium", 8, 6), ("moving_cif_ra_medium", 150, 120),
-                                             ("moving_ldb_ref3", 20, 16), ("moving_ra_b3_medium", 18, 16), ("jumpy_ldb_fast", 24, 18)])
+                                             ("moving_ldb_ref3", 20, 16), ("moving_ra_b3_medium", 18, 16), ("jumpy_ldb_fast", 24, 18), ("cfg2_720p_ldb_fast", 480, 240)])
 def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu, ninter):
     """xo_mode_analyze_ctu (mode_analyze_lcu -> mode_coding_tree -> mode_coding_unit, xeve_mode.c:1169-1350, 2007-2610, restated in oracle/: I, P and B slices) runs
     BESIDE the unmodified reference inside the live encoder (oracle/ref_shim.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every
@@ -295,7 +295,7 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
     against; the CIF clips have partial CTUs at the right and bottom edges, the B clips temporal direct and bi-prediction."""
     from _libs import ORACLE_SO
 
-    w, h, n, seed, extra = CASES[name]
+    w, h, n, seed, extra = (CASES[name] if name in CASES else REAL_CASES[name])  # (the 1280x720 clip: a real picture size, the bottom CTU row cut at 720 = 11 * 64 + 16)
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_SHADOW_TREE": ORACLE_SO})
