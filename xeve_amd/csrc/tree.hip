@@ -707,7 +707,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
         }
         return XEVE_HIP_OK;
     };
-    // The schedule is static (10 000 launches per I-picture CTU, 20 000 per P / B CTU) and every operand sits at an address the caller chose, so a call whose
+    // The schedule is static (10 000 launches per I-picture CTU, 15 600 per P / B CTU) and every operand sits at an address the caller chose, so a call whose
     // arguments repeat can be captured into a HIP graph and replayed.  MEASURED (profiles/r02_tree_graph.log): the replay frees the host -- 2.8 ms instead of
     // 56 .. 100 ms of launch calls per CTU step -- but the GPU runs the same step 8 .. 10 ms SLOWER (dependent kernel nodes of a graph dispatch no faster than
     // stream launches here), so it is OFF unless XEVE_HIP_TREE_GRAPH=1: for a caller that needs its host thread, not for speed.
