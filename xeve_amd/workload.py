@@ -543,10 +543,13 @@ class CtuWalkIntra:
         n, maxv = chains, (1 << bit_depth) - 1
         if content == "noise":
             self.org = [torch.randint(0, maxv + 1, (n, w >> s, w >> s), device=device, generator=g, dtype=torch.int16) for s in (0, 1, 1)]
-        else:
+        else:  # "smooth": the early termination prunes at 32x32; "texture": detail the predictors cannot follow, small levels -- the tree goes down to 4x4 like on noise
             yy, xx = torch.meshgrid(torch.arange(w, device=device), torch.arange(w, device=device), indexing="ij")
             base = (maxv / 2) * (1 + 0.6 * torch.sin(xx / 19.0) * torch.cos(yy / 23.0))
-            luma = (base[None] + torch.randint(-3, 4, (n, w, w), device=device, generator=g)).clamp(0, maxv).to(torch.int16)
+            if content == "texture":
+                base = base + (maxv / 16) * torch.sin(xx / 1.3 + yy / 2.9) * torch.cos(xx / 3.1 - yy / 1.7)
+            amp = 3 if content == "smooth" else 12
+            luma = (base[None] + torch.randint(-amp, amp + 1, (n, w, w), device=device, generator=g)).clamp(0, maxv).to(torch.int16)
             self.org = [luma, luma[:, ::2, ::2].contiguous(), luma[:, ::2, ::2].contiguous()]
         nscu = (w // 4) ** 2
         self.mod = [torch.full_like(t, 1 << (bit_depth - 1)) for t in self.org]
