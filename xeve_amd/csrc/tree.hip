@@ -461,10 +461,18 @@ struct TreeLayout {
     size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, zero32, ews, ews_bytes; // P / B slices
 };
 static bool tree_params_ok(const xeve_hip_tree_params *p)
-{
-    return p && p->log2_ctu >= 3 && p->log2_ctu <= 6 && p->pic_w > 0 && p->pic_h > 0 && (p->pic_w & 3) == 0 && (p->pic_h & 3) == 0 && xh_pow2(p->max_cu) &&
-           xh_pow2(p->min_cu) && p->min_cu >= 4 && p->max_cu >= p->min_cu && p->min_cuwh >= 4 && xh_pow2(p->min_cuwh) &&
-           p->ip.w_scu == (p->pic_w + 3) >> 2 && p->ip.h_scu == (p->pic_h + 3) >> 2;
+{   // everything the analyses of the walk would refuse is refused here, before the first launch (a walk that stops half way leaves half-written maps behind)
+    if(!(p && p->log2_ctu >= 3 && p->log2_ctu <= 6 && p->pic_w > 0 && p->pic_h > 0 && (p->pic_w & 3) == 0 && (p->pic_h & 3) == 0 && xh_pow2(p->max_cu) &&
+         xh_pow2(p->min_cu) && p->min_cu >= 4 && p->max_cu >= p->min_cu && p->min_cuwh >= 4 && xh_pow2(p->min_cuwh) && p->ip.w_scu == (p->pic_w + 3) >> 2 &&
+         p->ip.h_scu == (p->pic_h + 3) >> 2))
+        return false;
+    const xeve_hip_intra_params &ip = p->ip;
+    if(!(ip.tool_iqt == 0 && ip.bit_depth >= 8 && ip.bit_depth <= 14 && (ip.chroma_format_idc == 0 || ip.chroma_format_idc == 1 || ip.chroma_format_idc == 3) &&
+         ip.slice_type >= 0 && ip.slice_type <= 2 && p->slice_qp >= 0 && p->slice_qp <= 127))
+        return false;
+    for(int k = 0; k < (ip.chroma_format_idc ? 3 : 1); k++)
+        if(ip.qp[k] < 0 || ip.qp[k] > 51 + 6 * (ip.bit_depth - 8)) return false;
+    return true;
 }
 static bool tree_inter_ok(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I)
 {   // the inter analysis is composed for square CUs 8 .. 64 (every inter CU of the Baseline quad-tree at the presets that keep min_cu_inter at 8)
