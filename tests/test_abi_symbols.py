@@ -101,3 +101,40 @@ def test_python_record_layouts_match_the_library():
     for i, t in want.items():
         assert L.xeve_hip_sizeof(i) == (t if isinstance(t, int) else sz(t)), (i, t)
     assert L.xeve_hip_sizeof(12) == 4 * lib.EST_FULL_INTS and L.xeve_hip_sizeof(31) == -1
+
+
+def test_tree_walk_workspace_refuses_what_the_walk_cannot_do():
+    """xeve_hip_mode_analyze_ctu_workspace is pure host arithmetic (no GPU): 0 = these parameters are outside the walk, and the walk itself refuses them with the same
+    test before its first launch; a supported set gives a size that grows with the number of chains"""
+    import ctypes as C
+
+    from xeve_amd import lib
+
+    L = lib.load()
+
+    def params(**kw):
+        P = lib.TreeParams()
+        P.ip.w_scu, P.ip.h_scu, P.ip.slice_type, P.ip.chroma_format_idc, P.ip.bit_depth = 32, 16, 2, 1, 10
+        P.ip.qp[0], P.ip.qp[1], P.ip.qp[2] = 44, 43, 42
+        P.ip.lambda_[0] = P.ip.lambda_[1] = P.ip.lambda_[2] = 50.0
+        P.ip.sqrt_lambda0, P.ip.dist_chroma_weight[0], P.ip.dist_chroma_weight[1] = 7.07, 1.0, 1.0
+        P.pic_w, P.pic_h, P.log2_ctu, P.max_cu, P.min_cu, P.min_cuwh, P.slice_qp = 128, 64, 6, 32, 4, 4, 32
+        for k, v in kw.items():
+            if k.startswith("ip_"):
+                setattr(P.ip, k[3:], v)
+            else:
+                setattr(P, k, v)
+        return P
+
+    ws = lambda P, n=1: L.xeve_hip_mode_analyze_ctu_workspace(n, C.byref(P), None, 128, 64)
+    assert 0 < ws(params()) < ws(params(), 8) < ws(params(), 64)
+    assert L.xeve_hip_mode_analyze_ctu_intra_workspace(4, C.byref(params())) == ws(params(), 4)
+    for bad in (dict(log2_ctu=7), dict(log2_ctu=2), dict(pic_w=130), dict(max_cu=48), dict(min_cu=2), dict(max_cu=4, min_cu=8), dict(ip_w_scu=31), dict(ip_bit_depth=7),
+                dict(ip_chroma_format_idc=2), dict(ip_tool_iqt=1), dict(slice_qp=200), dict(ip_slice_type=5)):
+        assert ws(params(**bad)) == 0, bad
+    P = params()
+    P.ip.qp[0] = 80  # above 51 + 6 * (bit depth - 8)
+    assert ws(P) == 0
+    assert ws(params(), 0) == 0
+    # a P / B slice needs its inter side
+    assert ws(params(ip_slice_type=0)) == 0 and L.xeve_hip_mode_analyze_ctu_intra_workspace(1, C.byref(params(ip_slice_type=1))) == 0
