@@ -52,7 +52,7 @@ uint64_t    xeve_hip_table_calls(void);
 uint64_t    xeve_hip_table_calls_main(void);
 /* sizeof() of the i-th record type of this header as the library was compiled, in the order xeve_hip_job, _mc_job, _me_params, _me_job, _me_result,
  * _spel_params, _spel_job, _epzs_job, _epzs_params, _sbac, _cu_bits_params, _cu_bits_job, _rdoq_est_full, _deblock_params, _refpic, _cu_mc_job,
- * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result, _tree_params, _ctu_job, _ctu_data, _tree_inter (0 .. 30); -1 past the end.  For bindings in
+ * _rdo_params, _rdo_job, _rdo_result, _skip_job, _skip_result, _inter_params, _inter_job, _inter_result, _intra_params, _intra_job, _intra_result, _tree_params, _ctu_job, _ctu_data, _tree_inter, _eco_params (0 .. 31); -1 past the end.  For bindings in
  * other languages to check their record layouts at load time (no GPU needed). */
 int         xeve_hip_sizeof(int i);
 
@@ -816,6 +816,27 @@ int xeve_hip_mode_analyze_ctu_host(const xeve_hip_pel *const org[3], int s_org_l
                                    uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xeve_hip_sbac *entry,
                                    const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter, int pad_l, int pad_c, int x0, int y0,
                                    xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost);
+
+/* ------------------------------------------------------------------------------------------- */
+/* The bitstream writer's side of a batch of decided CTUs: xeve_eco_tree (src_base/xeve_enc.c:35-100) */
+/* -> xeve_eco_split_mode, xeve_eco_unit (xeve_eco.c:1377-1640) for every CU of each chain's CTU, on */
+/* the WRITER's coder: states[jobs[c].sbac] is read, advanced and stored back -- it then is the state */
+/* the chain's next CTU starts its mode decision from (xeve_enc.c:139).  The syntax is the writer's,  */
+/* not the rate estimate's (P slices: no direct_mode_flag, no inter_pred_idc).  The coded flags of    */
+/* the CTU's units are reset first (xeve_mode.c:2591-2607), then every CU stores what xeve_eco_unit   */
+/* stores (coded / skip / luma cbf flags, CU size).  Baseline, no delta QP.                          */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_eco_params {
+    int32_t chroma_format_idc, slice_type, log2_ctu, pic_w, pic_h, w_scu, h_scu;
+    int32_t num_refp[2];  /* ctx->rpm.num_refp (P / B slices) */
+    int32_t pad_;
+} xeve_hip_eco_params;
+/* ctus[c]: the CTU xeve_hip_mode_analyze_ctu_jobs decided for chain c (jobs as there); bytes: [nchains][bytes_cap], nbytes[c] = bytes the coder emitted for chain
+ * c (the first bytes_cap of them stored; the pending byte and the code register stay in the state); map_pic_elems: element distance between the pictures' maps
+ * (0: one picture).  Everything but params is device memory. */
+int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sbac *states, int nstates, const xeve_hip_eco_params *params, uint32_t *map_scu, const int8_t *map_ipm,
+                          const uint8_t *map_tidx, uint32_t *map_cu_mode, int64_t map_pic_elems, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes, int bytes_cap,
+                          int32_t *nbytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ from _libs import ROOT, c_int, c_void_p, oracle
 
 SRC = os.path.join(ROOT, "tests", "native", "cu_lane_host.cpp")
 HDR = os.path.join(ROOT, "xeve_amd", "csrc", "cu_lane.h")
+HDR2 = os.path.join(ROOT, "xeve_amd", "csrc", "eco_lane.h")
 OUT = os.path.join(ROOT, "tests", "native", "build", "libcu_lane_host.so")
 HIPCC = "/opt/rocm/bin/hipcc"
 
@@ -34,13 +35,15 @@ def available():
 def lane():
     global _lib
     if _lib is None:
-        if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
             subprocess.run([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-o", OUT, SRC], check=True)
         _lib = C.CDLL(OUT)
         _lib.xl_host_intra_cu.restype = None
         _lib.xl_host_intra_cu.argtypes = [c_int, C.POINTER(LaneParams)] + [c_void_p] * 15
         assert _lib.xl_host_sizeof_params() == C.sizeof(LaneParams)
+        _lib.xl_host_eco_ctu.restype = c_int
+        _lib.xl_host_eco_ctu.argtypes = [c_int] * 8 + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_int]
     return _lib
 
 
@@ -72,3 +75,21 @@ def lane_params(ip, log2, s_org_l, s_org_c, s_mod_l, s_mod_c):
     P.sqrt_lambda0, P.wgt[0], P.wgt[1] = ip.sqrt_lambda0, ip.dist_chroma_weight[0], ip.dist_chroma_weight[1]
     P.entropy = entropy_table().ctypes.data
     return P
+
+
+_scans = None
+
+
+def scans():
+    """zig-zag scans of the 16x16, 32x32, 64x64 blocks (xeve_tbl_scan) from the oracle's xo_zigzag"""
+    global _scans
+    if _scans is None:
+        O = oracle()
+        O.xo_zigzag.restype = None
+        O.xo_zigzag.argtypes = [c_int, c_int, c_void_p]
+        _scans = []
+        for l in (4, 5, 6):
+            a = np.zeros(1 << (2 * l), np.uint16)
+            O.xo_zigzag(l, l, a.ctypes.data)
+            _scans.append(a)
+    return _scans

@@ -12,3 +12,18 @@ extern "C" void xl_host_intra_cu(int log2, const xl::Params *P, const int16_t *c
     else xl::intra_cu<3>(*P, org, mod, map_scu, map_ipm, map_tidx, *entry, *job, *res, coef_y, coef_u, coef_v, rec_y, rec_u, rec_v, *best);
 }
 extern "C" int xl_host_sizeof_params(void) { return (int)sizeof(xl::Params); }
+
+#include "../../xeve_amd/csrc/eco_lane.h"
+// the host side of eco_lane.h: one CTU written on the coder state *s (in / out); returns the number of bytes emitted (the first `cap` stored)
+extern "C" int xl_host_eco_ctu(int idc, int slice_type, int log2_ctu, int pic_w, int pic_h, int w_scu, int num_refp0, int num_refp1, const uint16_t *scan16, const uint16_t *scan32,
+                               const uint16_t *scan64, xeve_hip_sbac *s, const xeve_hip_ctu_data *d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx,
+                               uint32_t *map_cu_mode, int x0, int y0, uint8_t *bytes, int cap)
+{
+    xl::EcoParams E;
+    E.idc = idc, E.slice_type = slice_type, E.log2_ctu = log2_ctu, E.pic_w = pic_w, E.pic_h = pic_h, E.w_scu = w_scu, E.num_refp[0] = num_refp0, E.num_refp[1] = num_refp1;
+    for(int i = 0; i < 7; i++) E.scan[i] = nullptr;
+    E.scan[4] = scan16, E.scan[5] = scan32, E.scan[6] = scan64;
+    xl::Sink o = {bytes, cap, 0};
+    xl::eco_ctu(E, *s, *d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, &o);
+    return o.n;
+}

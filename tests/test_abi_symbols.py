@@ -97,10 +97,10 @@ def test_python_record_layouts_match_the_library():
             9: lib.SBAC_DTYPE, 10: lib.CuBitsParams, 11: lib.CU_BITS_JOB_DTYPE, 13: lib.DeblockParams, 14: lib.REFPIC_DTYPE, 15: lib.CU_MC_JOB_DTYPE, 16: lib.RdoParams,
             17: lib.RDO_JOB_DTYPE, 18: lib.RDO_RESULT_DTYPE, 19: lib.SKIP_JOB_DTYPE, 20: lib.SKIP_RESULT_DTYPE, 21: lib.InterParams, 22: lib.INTER_JOB_DTYPE,
             23: lib.INTER_RESULT_DTYPE, 24: lib.IntraParams, 25: lib.INTRA_JOB_DTYPE, 26: lib.INTRA_RESULT_DTYPE, 27: lib.TreeParams, 28: lib.CTU_JOB_DTYPE,
-            29: lib.CTU_DATA_DTYPE, 30: lib.TreeInter}
+            29: lib.CTU_DATA_DTYPE, 30: lib.TreeInter, 31: lib.EcoParams}
     for i, t in want.items():
         assert L.xeve_hip_sizeof(i) == (t if isinstance(t, int) else sz(t)), (i, t)
-    assert L.xeve_hip_sizeof(12) == 4 * lib.EST_FULL_INTS and L.xeve_hip_sizeof(31) == -1
+    assert L.xeve_hip_sizeof(12) == 4 * lib.EST_FULL_INTS and L.xeve_hip_sizeof(32) == -1
 
 
 def test_tree_walk_workspace_refuses_what_the_walk_cannot_do():

@@ -263,3 +263,75 @@ def test_hip_ctu_host_form_over_two_b_pictures():
             assert np.array_equal(c["mod"][j], exp_c["mod"][j]), (seed, "picture", j)
         for f in ("scu", "ipm", "cu_mode", "mv", "refi"):
             assert np.array_equal(m[f], exp_c["maps"][f]), (seed, "map", f)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3]], ids=["3101", "3104"])
+def test_hip_i_pictures_decided_and_written_ctu_by_ctu_on_the_device(case):
+    """the closed loop of a chain on the device: every CTU is decided (xeve_hip_mode_analyze_ctu_jobs) from the WRITER's coder state and then written
+    (xeve_hip_eco_ctu_jobs: xeve_eco_tree, one lane per chain), which advances that state in place -- the next CTU enters with it (xeve_enc.c:139), no host in between.
+    The pictures of the case are the chains.  Against the oracle's same chain (xo_mode_analyze_ctu_intra + xo_eco_ctu, both pinned beside the live encoder): the writer's
+    state after every CTU, the bytes that came out, at the end the maps and the reconstructed pictures."""
+    import ctypes as C
+
+    import torch
+    import xeve_amd
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from _libs import c_int, c_void_p, oracle, ptr
+    from _tree_cases import oracle_tree
+
+    c = make_case(*case)
+    n = c["npic"]
+    entry = c["entry"].copy()
+    entry["bitcounter"] = 0
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    org = [torch.from_numpy(a.copy()).to(dev) for a in c["org"]]
+    mod = [torch.from_numpy(a.copy()).to(dev) for a in c["mod"]]
+    m = c["maps"]
+    ms, mi, mt, mc = (torch.from_numpy(m[k].view(np.int32 if m[k].dtype == np.uint32 else m[k].dtype).copy()).to(dev) for k in ("scu", "ipm", "tidx", "cu_mode"))
+    P = lib.TreeParams.from_buffer_copy(bytes(c["P"]))
+    EP = lib.EcoParams()
+    EP.chroma_format_idc, EP.slice_type, EP.log2_ctu, EP.pic_w, EP.pic_h, EP.w_scu, EP.h_scu = c["idc"], 2, P.log2_ctu, P.pic_w, P.pic_h, P.ip.w_scu, P.ip.h_scu
+    states = torch.from_numpy(entry.view(np.uint8).copy()).to(dev)
+    pe = (org[0][0].numel(), org[1][0].numel(), mod[0][0].numel(), mod[1][0].numel(), m["scu"].shape[1])
+    got = []
+    for (x, y) in c["order"]:
+        jobs = np.zeros(n, CTU_JOB_DTYPE)
+        jobs["x"], jobs["y"], jobs["sbac"], jobs["pic"] = x, y, np.arange(n), np.arange(n)
+        jt = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        out, _, _ = D.mode_analyze_ctu_jobs([t.data_ptr() for t in org], org[0].shape[2], org[1].shape[2], [t.data_ptr() for t in mod], mod[0].shape[2], mod[1].shape[2], ms, mi, mt,
+                                            mc, states, P, jt, pic_elems=pe)
+        by, nb = D.eco_ctu_jobs(out, states, EP, ms, mi, mt, mc, jt, map_pic_elems=m["scu"].shape[1])
+        torch.cuda.synchronize()
+        got.append((states.cpu().numpy().reshape(-1).view(SBAC_DTYPE).copy(), by.cpu().numpy(), nb.cpu().numpy()))
+    # the oracle's chain, picture by picture
+    O = oracle_tree()
+    OE = oracle()
+    OE.xo_eco_ctu.restype = c_int
+    OE.xo_eco_ctu.argtypes = [c_void_p, c_void_p, C.c_void_p, c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_void_p, c_int]
+    total = 0
+    for p in range(n):
+        orgp = (c_void_p * 3)(*[a[p].ctypes.data for a in c["org"]])
+        modp = (c_void_p * 3)(*[a[p].ctypes.data for a in c["mod"]])
+        state = entry[p:p + 1].copy()
+        for k, (x, y) in enumerate(c["order"]):
+            d, nx = np.zeros(1, CTU_DATA_DTYPE), np.zeros(1, SBAC_DTYPE)
+            O.xo_mode_analyze_ctu_intra(orgp, c["org"][0].shape[2], c["org"][1].shape[2], modp, c["mod"][0].shape[2], c["mod"][1].shape[2], ptr(m["scu"][p]), ptr(m["ipm"][p]),
+                                        ptr(m["tidx"][p]), ptr(m["cu_mode"][p]), ptr(state), C.byref(c["P"]), x, y, ptr(d), ptr(nx))
+            ctu, w_scu = 1 << c["P"].log2_ctu, c["P"].ip.w_scu
+            for j in range(min(ctu, c["h"] - y) // 4):  # mode_analyze_lcu's tail: the CTU's coded flags reset
+                g = (y // 4 + j) * w_scu + x // 4
+                m["scu"][p][g:g + min(ctu, c["w"] - x) // 4] &= np.uint32(0x7FFFFFFF)
+            eb = np.zeros(1 << 15, np.uint8)
+            ne = OE.xo_eco_ctu(ptr(state), ptr(d), C.addressof(c["P"]), ptr(np.zeros(2, np.int32)), ptr(m["scu"][p]), ptr(m["ipm"][p]), ptr(m["tidx"][p]), ptr(m["cu_mode"][p]), x, y,
+                               ptr(eb), eb.size)
+            gs, gb, gn = got[k]
+            for f in ("range", "code", "code_bits", "stacked_ff", "stacked_zero", "pending_byte", "is_pending_byte", "bin_counter", "ctx"):
+                assert np.array_equal(gs[f][p], state[f][0]), (case, "picture", p, "ctu", k, f)
+            assert int(gn[p]) == ne and np.array_equal(gb[p][:ne], eb[:ne]), (case, p, k, "bytes", int(gn[p]), ne)
+            total += ne
+    assert total > 100
+    for j in range(3 if c["idc"] else 1):
+        assert np.array_equal(mod[j].cpu().numpy(), c["mod"][j]), (case, "picture", j)
+    assert np.array_equal(ms.cpu().numpy().view(np.uint32).reshape(m["scu"].shape), m["scu"]) and np.array_equal(mc.cpu().numpy().view(np.uint32).reshape(m["cu_mode"].shape), m["cu_mode"])

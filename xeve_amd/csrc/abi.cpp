@@ -70,7 +70,7 @@ extern "C" int xeve_hip_sizeof(int i)
                              (int)sizeof(xeve_hip_rdo_params), (int)sizeof(xeve_hip_rdo_job), (int)sizeof(xeve_hip_rdo_result), (int)sizeof(xeve_hip_skip_job),
                              (int)sizeof(xeve_hip_skip_result), (int)sizeof(xeve_hip_inter_params), (int)sizeof(xeve_hip_inter_job), (int)sizeof(xeve_hip_inter_result),
                              (int)sizeof(xeve_hip_intra_params), (int)sizeof(xeve_hip_intra_job), (int)sizeof(xeve_hip_intra_result),
-                             (int)sizeof(xeve_hip_tree_params), (int)sizeof(xeve_hip_ctu_job), (int)sizeof(xeve_hip_ctu_data), (int)sizeof(xeve_hip_tree_inter)};
+                             (int)sizeof(xeve_hip_tree_params), (int)sizeof(xeve_hip_ctu_job), (int)sizeof(xeve_hip_ctu_data), (int)sizeof(xeve_hip_tree_inter), (int)sizeof(xeve_hip_eco_params)};
     return i >= 0 && i < (int)(sizeof(sz) / sizeof(sz[0])) ? sz[i] : -1;
 }
 

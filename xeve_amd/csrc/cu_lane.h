@@ -56,33 +56,46 @@ XL int mpm_rank(int l, int u, int m)
 }
 
 // ---- the arithmetic coder in bit-count mode (xeve_eco.c:392-575, xeve_mode.c:39-55): every field of XEVE_SBAC kept exactly ---------------------------------------
-XL void sb_byte(Sbac &s, unsigned b)
+// write mode (the bitstream writer's coder, is_bitcount clear): the bytes go to a sink instead of advancing the counter
+struct Sink {
+    uint8_t *p;
+    int      cap, n;
+};
+XL void sb_byte(Sbac &s, unsigned b, Sink *o = nullptr)
 {
     if(s.is_pending_byte) {
         if(s.pending_byte == 0) s.stacked_zero++;
+        else if(o) {
+            for(; s.stacked_zero; s.stacked_zero--) {
+                if(o->n < o->cap) o->p[o->n] = 0;
+                o->n++;
+            }
+            if(o->n < o->cap) o->p[o->n] = (uint8_t)s.pending_byte;
+            o->n++;
+        }
         else s.bitcounter += 8 * s.stacked_zero + 8, s.stacked_zero = 0;
     }
     s.pending_byte = b & 0xFF, s.is_pending_byte = 1;
 }
-XL void sb_shift(Sbac &s)
+XL void sb_shift(Sbac &s, Sink *o = nullptr)
 {
     s.code <<= 1;
     if(--s.code_bits) return;
     const unsigned out = s.code >> 17;
     s.code &= (1u << 17) - 1;
     if(out < 0xFF) {
-        for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0xFF);
-        sb_byte(s, out);
+        for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0xFF, o);
+        sb_byte(s, out, o);
     }
     else if(out > 0xFF) {
         s.pending_byte++;
-        for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0);
-        sb_byte(s, out);
+        for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0, o);
+        sb_byte(s, out, o);
     }
     else s.stacked_ff++;
     s.code_bits = 8;
 }
-XL void sb_bin(Sbac &s, int ci, unsigned bin)
+XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
 {
     unsigned state = s.ctx[ci] >> 1, mps = s.ctx[ci] & 1;
     unsigned lps = (state * s.range) >> 9;
@@ -96,15 +109,15 @@ XL void sb_bin(Sbac &s, int ci, unsigned bin)
     }
     else state = state - ((state + 16) >> 5);
     s.ctx[ci] = (uint16_t)((state << 1) + mps);
-    while(s.range < 8192) s.range <<= 1, sb_shift(s);
+    while(s.range < 8192) s.range <<= 1, sb_shift(s, o);
 }
-XL void sb_bin_ep(Sbac &s, unsigned bin)
+XL void sb_bin_ep(Sbac &s, unsigned bin, Sink *o = nullptr)
 {   // (the range loses its LSB, xeve_eco.c:455-472)
     s.bin_counter++;
     s.range >>= 1;
     if(bin) s.code += s.range;
     s.range <<= 1;
-    sb_shift(s);
+    sb_shift(s, o);
 }
 XL void sb_bit_reset(Sbac &s)
 {
@@ -112,32 +125,32 @@ XL void sb_bit_reset(Sbac &s)
     s.pending_byte = s.is_pending_byte = s.stacked_ff = s.stacked_zero = s.bitcounter = s.bin_counter = 0;
 }
 XL unsigned sb_bits(const Sbac &s) { return s.bitcounter + 8 * (s.stacked_zero + s.stacked_ff) + 8 * (s.is_pending_byte ? 1 : 0) + 8 - s.code_bits + 3; }
-XL void sb_unary2(Sbac &s, unsigned sym, int ci)
+XL void sb_unary2(Sbac &s, unsigned sym, int ci, Sink *o = nullptr)
 {   // sbac_write_unary_sym with two models (xeve_eco.c:474-490)
-    sb_bin(s, ci, sym ? 1 : 0);
+    sb_bin(s, ci, sym ? 1 : 0, o);
     while(sym) {
         sym--;
-        sb_bin(s, ci + 1, sym ? 1 : 0);
+        sb_bin(s, ci + 1, sym ? 1 : 0, o);
     }
 }
-// xeve_eco_run_length_cc (xeve_eco.c:707-771), Baseline contexts (sps_cm_init_flag 0)
-XL void sb_run_length(Sbac &s, const int16_t *coef, int n, int num_sig, int ch)
+// xeve_eco_run_length_cc (xeve_eco.c:707-771), Baseline contexts (sps_cm_init_flag 0); n: 2, 4, 8 through the tables, larger blocks through the scan the caller passes
+XL void sb_run_length(Sbac &s, const int16_t *coef, int n, int num_sig, int ch, Sink *o = nullptr, const uint16_t *scan = nullptr)
 {
     unsigned run = 0;
     const int t0 = ch ? 2 : 0, nn = n * n;
     for(int pos = 0; pos < nn; pos++) {
-        const int c = coef[zigzag(n, pos)];
+        const int c = coef[scan ? scan[pos] : zigzag(n, pos)];
         if(!c) {
             run++;
             continue;
         }
         const unsigned level = (unsigned)(c < 0 ? -c : c) & 0xFFFF;
-        sb_unary2(s, run, XEVE_HIP_CTX_RUN + t0);
-        sb_unary2(s, level - 1, XEVE_HIP_CTX_LEVEL + t0);
-        sb_bin_ep(s, c < 0);
+        sb_unary2(s, run, XEVE_HIP_CTX_RUN + t0, o);
+        sb_unary2(s, level - 1, XEVE_HIP_CTX_LEVEL + t0, o);
+        sb_bin_ep(s, c < 0, o);
         if(pos == nn - 1) break;
         run = 0, num_sig--;
-        sb_bin(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0), num_sig == 0);
+        sb_bin(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0), num_sig == 0, o);
         if(num_sig == 0) break;
     }
 }

@@ -1,0 +1,44 @@
+// xeve_amd/csrc/eco.hip -- the bitstream writer's side of a batch of decided CTUs on the device: xeve_eco_tree (src_base/xeve_enc.c:35-100) per chain, one LANE per
+// chain (eco_lane.h).  The coder state a chain carries is the WRITER's: after this call it is the state the chain's next CTU starts its mode decision from
+// (xeve_enc.c:139) -- with xeve_hip_mode_analyze_ctu_jobs (tree.hip) a chain runs from CTU to CTU without the host, and the bytes collected here are the picture's
+// slice data (up to the pending byte and the code register, which stay in the state until the tile ends).
+#include "xh_common.h"
+#include "eco_lane.h"
+
+__global__ void __launch_bounds__(64) k_eco_ctu(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+                                                const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, const xeve_hip_ctu_job *__restrict__ jobs,
+                                                int nchains, uint8_t *__restrict__ bytes, int bytes_cap, int32_t *__restrict__ nbytes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= nchains) return;
+    const xeve_hip_ctu_job J = jobs[c];
+    xl::Sbac s = states[J.sbac];
+    xl::Sink o = {bytes + (long)c * bytes_cap, bytes_cap, 0};
+    xl::eco_ctu(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
+    states[J.sbac] = s;
+    nbytes[c] = o.n;
+}
+
+extern "C" int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sbac *states, int nstates, const xeve_hip_eco_params *p, uint32_t *map_scu, const int8_t *map_ipm,
+                                     const uint8_t *map_tidx, uint32_t *map_cu_mode, int64_t map_pic_elems, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes,
+                                     int bytes_cap, int32_t *nbytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(ctus && states && nstates > 0 && p && map_scu && map_ipm && map_tidx && map_cu_mode && jobs && nchains >= 0 && bytes && bytes_cap > 0 && nbytes);
+    XH_REQUIRE(p->log2_ctu >= 3 && p->log2_ctu <= 6 && p->pic_w > 0 && p->pic_h > 0 && (p->pic_w & 3) == 0 && (p->pic_h & 3) == 0 && p->w_scu == (p->pic_w + 3) >> 2 &&
+               p->h_scu == (p->pic_h + 3) >> 2 && p->slice_type >= 0 && p->slice_type <= 2 &&
+               (p->chroma_format_idc == 0 || p->chroma_format_idc == 1 || p->chroma_format_idc == 3));
+    XH_REQUIRE(p->slice_type == 2 || (p->num_refp[0] >= 1 && p->num_refp[0] <= XEVE_HIP_MAX_REFP && p->num_refp[1] >= 0 && p->num_refp[1] <= XEVE_HIP_MAX_REFP));
+    if(nchains == 0) return XEVE_HIP_OK;
+    xl::EcoParams E;
+    E.idc = p->chroma_format_idc, E.slice_type = p->slice_type, E.log2_ctu = p->log2_ctu, E.pic_w = p->pic_w, E.pic_h = p->pic_h, E.w_scu = p->w_scu;
+    E.num_refp[0] = p->num_refp[0], E.num_refp[1] = p->num_refp[1];
+    for(int i = 0; i < 7; i++) E.scan[i] = nullptr;
+    for(int l = 4; l <= p->log2_ctu; l++) {
+        const int rc = xh_get_scan(l, l, &E.scan[l]);
+        if(rc != XEVE_HIP_OK) return rc;
+    }
+    k_eco_ctu<<<(nchains + 63) / 64, 64, 0, (hipStream_t)stream>>>(ctus, states, E, map_scu, map_ipm, map_tidx, map_cu_mode, (long)map_pic_elems, jobs, nchains, bytes, bytes_cap, nbytes);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -352,6 +352,22 @@ def mode_analyze_ctu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c
     return out, nxt, cost
 
 
+def eco_ctu_jobs(ctus, states, params, map_scu, map_ipm, map_tidx, map_cu_mode, jobs, map_pic_elems=0, bytes_cap=1 << 15, out=None):
+    """the bitstream writer's side of a batch of decided CTUs (xeve_hip_eco_ctu_jobs): ctus = the ctu data tensor of mode_analyze_ctu_jobs; states (uint8 [nstates, 180])
+    is advanced IN PLACE -- it is the writer's coder, and afterwards the entry state of each chain's next CTU; the maps receive the written CUs' flags.  params:
+    lib.EcoParams.  Returns (bytes uint8 [nchains, bytes_cap], nbytes int32 [nchains])."""
+    L = _lib.load()
+    n, dev = jobs.numel() // 16, jobs.device
+    if out is not None:
+        by, nb = out
+    else:
+        by = torch.zeros((n, bytes_cap), dtype=torch.uint8, device=dev)
+        nb = torch.zeros(n, dtype=torch.int32, device=dev)
+    _lib.check(L.xeve_hip_eco_ctu_jobs(_ptr(ctus), _ptr(states), states.numel() // SBAC_BYTES, C.byref(params), _ptr(map_scu), _ptr(map_ipm), _ptr(map_tidx), _ptr(map_cu_mode),
+                                       int(map_pic_elems), _ptr(jobs), n, _ptr(by), by.shape[1], _ptr(nb), _stream()))
+    return by, nb
+
+
 def mode_analyze_ctu_intra_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, pic_elems=None,
                                 workspace=None):
     """the I-slice form (chains may belong to different pictures: pic_elems)"""

@@ -69,6 +69,11 @@ CTU_DATA_DTYPE = [("split_mode", "i1", (CU_DEPTHS, 256)), ("pred_mode", "u1", (2
 CTU_DATA_BYTES = 62976
 
 
+class EcoParams(C.Structure):  # xeve_hip_eco_params
+    _fields_ = [("chroma_format_idc", C.c_int32), ("slice_type", C.c_int32), ("log2_ctu", C.c_int32), ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("w_scu", C.c_int32),
+                ("h_scu", C.c_int32), ("num_refp", C.c_int32 * 2), ("pad_", C.c_int32)]
+
+
 class TreeInter(C.Structure):  # xeve_hip_tree_inter
     _fields_ = [("refp", C.c_void_p), ("s_ref_l", C.c_int32), ("s_ref_c", C.c_int32), ("ipar", InterParams), ("map_mv", C.c_void_p), ("map_refi", C.c_void_p),
                 ("col_mv0", C.c_void_p), ("col_mv1", C.c_void_p), ("coef_l", C.c_void_p), ("coef_c", C.c_void_p), ("ecu_depth", C.c_int32), ("pad_", C.c_int32)]
@@ -205,6 +210,7 @@ FUNCTIONS = {
                                        [C.c_size_t, c_void_p]),
     "xeve_hip_mode_analyze_ctu_intra_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 3),
     "xeve_hip_mode_analyze_ctu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_void_p] * 3),
+    "xeve_hip_eco_ctu_jobs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
