@@ -524,7 +524,7 @@ class CtuWalkIntra:
 
     CTUS = [(0, 0), (64, 0), (0, 64), (64, 64)]
 
-    def __init__(self, chains, device, content="noise", seed=7, qp8=32, bit_depth=10, max_cu=32):
+    def __init__(self, chains, device, content="noise", seed=7, qp8=32, bit_depth=10, max_cu=32, write=False):
         import ctypes as C
 
         from . import lib
@@ -570,6 +570,15 @@ class CtuWalkIntra:
         self.outputs = (torch.zeros((n, lib.CTU_DATA_BYTES), dtype=torch.uint8, device=device), torch.zeros((n, D.SBAC_BYTES), dtype=torch.uint8, device=device),
                         torch.zeros(n, dtype=torch.float64, device=device))
         self.stream = torch.cuda.Stream(device=device)  # (a graph cannot be captured on the default stream)
+        # write=True: every decided CTU is also WRITTEN on the device (xeve_hip_eco_ctu_jobs) -- the coder state of a chain is then the writer's, advanced in place, and
+        # what a step produces is slice data
+        self.write = write
+        if write:
+            EP = lib.EcoParams()
+            EP.chroma_format_idc, EP.slice_type, EP.log2_ctu, EP.pic_w, EP.pic_h, EP.w_scu, EP.h_scu = 1, 2, 6, w, w, w // 4, w // 4
+            self.EP = EP
+            self.bytes = (torch.zeros((n, 1 << 14), dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.int32, device=device))
+            self.nscu = nscu
         self.k, self.out = 0, None
 
     def step(self):
@@ -580,7 +589,10 @@ class CtuWalkIntra:
             self.job.copy_(self.jobs[self.k % 4])
             self.out, nxt, self.cost = D.mode_analyze_ctu_jobs([t.data_ptr() for t in self.org], w, w // 2, [t.data_ptr() for t in self.mod], w, w // 2, self.ms, self.mi, self.mt,
                                                                self.mc, self.states, self.P, self.job, pic_elems=self.pe, workspace=self.ws, outputs=self.outputs)
-            self.states.view(-1).copy_(nxt.view(-1))
+            if self.write:
+                D.eco_ctu_jobs(self.out, self.states, self.EP, self.ms, self.mi, self.mt, self.mc, self.job, map_pic_elems=self.nscu, out=self.bytes)
+            else:
+                self.states.view(-1).copy_(nxt.view(-1))
         torch.cuda.current_stream().wait_stream(self.stream)
         self.k += 1
 
