@@ -544,8 +544,104 @@ static void shadow_writer_check(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *n
     W.valid = 0;
 }
 
+/* the whole picture in shadow mode: at a picture's first CTU the oracle decides AND writes every CTU of the picture on its own -- private copies of the picture being
+ * reconstructed and of the maps, every CTU entering with the state the oracle's own writer left (the closed chain), the tile end and xeve_sbac_finish at the end -- and
+ * when the reference has written the picture (ctx->fn_loop_filter is called right after its CTU loop) the bytes in its bitstream buffer must be the oracle's */
+static int (*xo_tile_end)(xo_sbac *, uint8_t *, int);
+static int (*orig_shadow_loop_filter)(XEVE_CTX *, XEVE_CORE *);
+static unsigned long long ap_pics, ap_bad, ap_bytes;
+static struct {
+    int      valid, n, n_ctus, cap; /* n: all of the slice data; n_ctus: the part before the tile's end */
+    long     pos0;
+    uint8_t *bytes;
+} AP;
+static void build_tree_params(XEVE_CTX *ctx, XEVE_CORE *core, xo_tree_params *P)
+{
+    const int is_i = ctx->sh->slice_type == SLICE_I;
+    memset(P, 0, sizeof(*P));
+    P->ip.w_scu = ctx->w_scu, P->ip.h_scu = ctx->h_scu, P->ip.slice_type = ctx->sh->slice_type, P->ip.chroma_format_idc = ctx->sps.chroma_format_idc;
+    P->ip.bit_depth = ctx->sps.bit_depth_luma_minus8 + 8, P->ip.tool_iqt = 0, P->ip.constrained_intra_pred = ctx->pps.constrained_intra_pred_flag;
+    P->ip.qp[0] = core->qp_y, P->ip.qp[1] = core->qp_u, P->ip.qp[2] = core->qp_v;
+    for(int c = 0; c < 3; c++) P->ip.lambda[c] = core->lambda[c];
+    P->ip.sqrt_lambda0 = core->sqrt_lambda[0], P->ip.dist_chroma_weight[0] = core->dist_chroma_weight[0], P->ip.dist_chroma_weight[1] = core->dist_chroma_weight[1];
+    P->pic_w = ctx->w, P->pic_h = ctx->h, P->log2_ctu = ctx->log2_max_cuwh, P->min_cuwh = ctx->min_cuwh;
+    P->max_cu = is_i ? ctx->param.max_cu_intra : ctx->param.max_cu_inter, P->min_cu = is_i ? ctx->param.min_cu_intra : ctx->param.min_cu_inter;
+    P->slice_qp = ctx->tile[core->tile_idx].qp, P->slice_num = ctx->slice_num;
+}
+static void shadow_whole_picture(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *entry)
+{
+    AP.valid = 0;
+    if(!xo_eco || !xo_tile_end || !xo_tree_any || ctx->tile_cnt != 1 || getenv("XEVE_SHIM_SHADOW_NO_PICTURE")) return;
+    const int is_i = ctx->sh->slice_type == SLICE_I, hs = ctx->param.cs_h_shift, nscu = ctx->w_scu * ctx->h_scu, hc = ctx->h >> hs, ctu = ctx->max_cuwh;
+    XEVE_PIC    *pm = PIC_MODE(ctx);
+    XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
+    /* (mode_cu_init's QPs and the slice's lambdas: set_lambda has run for this slice in xeve_pic, the QPs follow from the tile QP) */
+    core->qp = ctx->tile[core->tile_idx].qp, core->qp_y = GET_LUMA_QP(core->qp, ctx->sps.bit_depth_luma_minus8);
+    core->qp_u = ctx->qp_chroma_dynamic[0][XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_u_offset)] + 6 * ctx->sps.bit_depth_chroma_minus8;
+    core->qp_v = ctx->qp_chroma_dynamic[1][XEVE_CLIP3(-6 * ctx->sps.bit_depth_chroma_minus8, 57, core->qp + ctx->sh->qp_v_offset)] + 6 * ctx->sps.bit_depth_chroma_minus8;
+    xo_tree_params P;
+    build_tree_params(ctx, core, &P);
+    xo_pel   *mod[3] = {malloc(sizeof(pel) * pm->s_l * (ctx->h + 1)), malloc(sizeof(pel) * pm->s_c * (hc + 1)), malloc(sizeof(pel) * pm->s_c * (hc + 1))};
+    uint32_t *scu = malloc(4 * nscu), *cum = malloc(4 * nscu);
+    int8_t   *ipm = malloc(nscu), (*refi)[2] = malloc(sizeof(*refi) * nscu);
+    int16_t (*mv)[2][2] = malloc(sizeof(*mv) * nscu);
+    memcpy(mod[0], pm->y, sizeof(pel) * pm->s_l * ctx->h), memcpy(mod[1], pm->u, sizeof(pel) * pm->s_c * hc), memcpy(mod[2], pm->v, sizeof(pel) * pm->s_c * hc);
+    memcpy(scu, ctx->map_scu, 4 * nscu), memcpy(cum, ctx->map_cu_mode, 4 * nscu), memcpy(ipm, ctx->map_ipm, nscu);
+    memcpy(mv, ctx->map_mv, sizeof(*mv) * nscu), memcpy(refi, ctx->map_refi, sizeof(*refi) * nscu);
+    xo_tree_inter TI;
+    xo_refpic     tab[16];
+    int ok = 1;
+    if(!is_i) ok = tree_inter_setup(ctx, core, &TI, tab, mv, refi) == 0;
+    if(ok) {
+        static xo_ctu_data out;
+        xo_sbac   state = *entry, next;
+        const int num_refp[2] = {ctx->rpm.num_refp[REFP_0], ctx->rpm.num_refp[REFP_1]};
+        const xo_pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+        if(AP.cap < (1 << 24)) AP.bytes = realloc(AP.bytes, 1 << 24), AP.cap = 1 << 24;
+        AP.n = 0;
+        for(int y0 = 0; y0 < ctx->h; y0 += ctu)
+            for(int x0 = 0; x0 < ctx->w; x0 += ctu) {
+                (void)xo_tree_any(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, scu, ipm, ctx->map_tidx, cum, &state, &P, is_i ? NULL : &TI, x0, y0, &out, &next);
+                for(int j = 0; j < XEVE_MIN(ctu, ctx->h - y0) >> 2; j++) /* mode_analyze_lcu's tail: the CTU's coded flags reset */
+                    for(int i = 0; i < XEVE_MIN(ctu, ctx->w - x0) >> 2; i++) scu[((y0 >> 2) + j) * ctx->w_scu + (x0 >> 2) + i] &= 0x7FFFFFFFu;
+                AP.n += xo_eco(&state, &out, &P, num_refp, scu, ipm, ctx->map_tidx, cum, x0, y0, AP.bytes + AP.n, AP.cap - AP.n);
+            }
+        AP.n_ctus = AP.n;
+        AP.n += xo_tile_end(&state, AP.bytes + AP.n, AP.cap - AP.n);
+        AP.pos0 = bsw_pos(&ctx->bs[core->thread_cnt]), AP.valid = 1;
+        if(getenv("XEVE_SHIM_SHADOW_DUMP")) { /* [poc, n, bytes] per picture: the test looks for them at the end of the slice NAL units of the bitstream file */
+            FILE *f = fopen(getenv("XEVE_SHIM_SHADOW_DUMP"), "ab");
+            const int32_t hd[2] = {(int32_t)ctx->poc.poc_val, AP.n};
+            if(f) fwrite(hd, 4, 2, f), fwrite(AP.bytes, 1, (size_t)AP.n, f), fclose(f);
+        }
+    }
+    free(mod[0]), free(mod[1]), free(mod[2]), free(scu), free(cum), free(ipm), free(mv), free(refi);
+}
+static int shim_shadow_loop_filter(XEVE_CTX *ctx, XEVE_CORE *core)
+{
+    if(AP.valid) { /* the reference's CTU loop has written the CTUs once (the pass that feeds the mode decision; xeve_pic writes them again behind it and a third time, after
+                    * the loop filter, into the output): the first pass's bytes must be the oracle's, up to what the coder still holds at the tile's end */
+        const XEVE_BSW *bs = &ctx->bs[0];
+        const long n = bsw_pos(bs) - AP.pos0;
+        int  bad = n < AP.n_ctus;
+        long k = 0;
+        while(!bad && k < AP.n_ctus && AP.bytes[k] == bsw_byte(bs, AP.pos0 + k)) k++;
+        bad |= k < AP.n_ctus;
+        if(bad && ap_bad < 4) fprintf(stderr, "[shadow picture] poc %d: the oracle's slice data (%d bytes before the tile's end) differs from the reference's at byte %ld\n", (int)ctx->poc.poc_val, AP.n_ctus, k);
+        ap_pics++, ap_bad += bad, ap_bytes += (unsigned long long)AP.n_ctus;
+        AP.valid = 0;
+    }
+    return orig_shadow_loop_filter(ctx, core);
+}
+
 static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
 {
+    if(ctx->param.threads == 1 && xo_eco && core->lcu_num == 0 && !ctx->pps.cu_qp_delta_enabled_flag && !ctx->param.rdo_dbk_switch && !ctx->param.tool_iqt && !ctx->sps.tool_admvp &&
+       ctx->log2_max_cuwh == 6 && ctx->sps.chroma_format_idc != 2) {
+        xo_sbac first;
+        sbac_to_flat(&first, &core->s_curr_best[ctx->log2_max_cuwh - 2][ctx->log2_max_cuwh - 2]);
+        shadow_whole_picture(ctx, core, &first);
+    }
     if(ctx->param.threads == 1 && xo_eco) { /* (the entry state of this CTU = the writer's state after the previous one) */
         xo_sbac now;
         sbac_to_flat(&now, &core->s_curr_best[ctx->log2_max_cuwh - 2][ctx->log2_max_cuwh - 2]);
@@ -862,6 +958,7 @@ static void report(void)
     if(inter_calls || inter_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose whole inter analysis ran on the GPU: %llu (left to the reference: %llu)\n", inter_calls, inter_fallbacks);
     if(intra_calls || intra_fallbacks) fprintf(stderr, "[xeve_hip_shim] CUs whose intra analysis ran on the GPU: %llu (left to the reference: %llu)\n", intra_calls, intra_fallbacks);
     if(tree_calls || tree_fallbacks) fprintf(stderr, "[xeve_hip_shim] CTUs whose whole mode decision ran on the %s: %llu (left to the reference: %llu), %.1f ms per CTU\n", tree_engine_oracle ? "oracle (CPU)" : "GPU", tree_calls, tree_fallbacks, tree_calls ? 1e3 * tree_seconds / (double)tree_calls : 0.0);
+    if(ap_pics) fprintf(stderr, "[xeve_hip_shim] shadow pictures: %llu pictures decided and written by the oracle on its own (%llu bytes of slice data), %llu differ from the reference's\n", ap_pics, ap_bytes, ap_bad);
     if(eco_ctus) fprintf(stderr, "[xeve_hip_shim] shadow writer: %llu CTUs written by the oracle beside xeve_eco_tree (%llu bytes of bitstream compared), %llu differ\n", eco_ctus, eco_bytes, eco_bad);
     if(tree_check) fprintf(stderr, "[xeve_hip_shim] device walk checked against the oracle per CTU: %llu CTUs, %llu differ\n", tree_check_ctus, tree_check_bad);
     if(shadow_ctus || shadow_skipped) fprintf(stderr, "[xeve_hip_shim] shadow tree walk: %llu CTUs compared, %llu differ (%llu not covered), %llu of them in P / B pictures\n", shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus);
@@ -893,8 +990,9 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         void *oh = dlopen(getenv("XEVE_SHIM_SHADOW_TREE"), RTLD_NOW | RTLD_LOCAL);
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
         xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu");
-        xo_eco = dlsym(oh, "xo_eco_ctu");
+        xo_eco = dlsym(oh, "xo_eco_ctu"), xo_tile_end = dlsym(oh, "xo_eco_tile_end");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
+        if(ctx->fn_loop_filter != shim_shadow_loop_filter) orig_shadow_loop_filter = ctx->fn_loop_filter, ctx->fn_loop_filter = shim_shadow_loop_filter;
         fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
         atexit(report);
     }

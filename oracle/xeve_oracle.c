@@ -2504,3 +2504,29 @@ int xo_eco_ctu(xo_sbac *s, const xo_ctu_data *d, const xo_tree_params *P, const 
     g_sink = NULL, g_sink_n = g_sink_cap = 0;
     return n;
 }
+
+
+/* The end of a tile on the writer's coder: xeve_eco_tile_end_flag(bs, 1) = xeve_sbac_encode_bin_trm (xeve_eco.c:577-595) and xeve_sbac_finish (:622-672).  Returns the
+ * bytes that come out (the first cap of them stored): what the coder still held, then -- where no pending byte is left and fewer than four code bits remain -- the
+ * zero bits up to the byte boundary. */
+int xo_eco_tile_end(xo_sbac *s, uint8_t *bytes, int cap)
+{
+    static uint8_t none[1];
+    g_sink = bytes ? bytes : none, g_sink_n = 0, g_sink_cap = bytes ? cap : 0;
+    s->bin_counter++;
+    s->range--;
+    s->code += s->range, s->range = 1; /* bin = 1 */
+    while(s->range < 8192) s->range <<= 1, sbac_shift(s);
+    uint32_t tmp = (s->code + s->range - 1) & (0xFFFFFFFFu << 14);
+    if(tmp < s->code) tmp += 8192;
+    s->code = tmp << s->code_bits;
+    sbac_carry(s);
+    s->code <<= 8;
+    sbac_carry(s);
+    for(; s->stacked_zero; s->stacked_zero--) sink_put(0x00);
+    if(s->pending_byte != 0) sink_put((uint8_t)s->pending_byte);
+    else if(s->code_bits < 4) sink_put(0x00); /* 4 - code_bits zero bits, then zero bits to the byte boundary: one zero byte */
+    const int n = g_sink_n;
+    g_sink = NULL, g_sink_n = g_sink_cap = 0;
+    return n;
+}

@@ -482,6 +482,8 @@ double xo_mode_analyze_ctu(const xo_pel *const org[3], int s_org_l, int s_org_c,
  * them are stored (bytes may be NULL). */
 int xo_eco_ctu(xo_sbac *s, const xo_ctu_data *d, const xo_tree_params *P, const int num_refp[2], uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx,
                uint32_t *map_cu_mode, int x0, int y0, uint8_t *bytes, int bytes_cap);
+/* the end of a tile: the terminating bin (1) and xeve_sbac_finish (xeve_eco.c:577-595, 622-672); returns the bytes that come out */
+int xo_eco_tile_end(xo_sbac *s, uint8_t *bytes, int cap);
 double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_org_c, xo_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu,
                                  int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
                                  xo_ctu_data *out, xo_sbac *next_best);

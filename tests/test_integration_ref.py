@@ -298,7 +298,8 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
     w, h, n, seed, extra = (CASES[name] if name in CASES else REAL_CASES[name])  # (the 1280x720 clip: a real picture size, the bottom CTU row cut at 720 = 11 * 64 + 16)
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
-    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_SHADOW_TREE": ORACLE_SO})
+    dump = str(tmp_path / "slice_data.bin")
+    md5, size, err = run_app(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim_env={"XEVE_SHIM_SHADOW_TREE": ORACLE_SO, "XEVE_SHIM_SHADOW_DUMP": dump})
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])  # the shadow run leaves the encode untouched
     m = re.search(r"shadow tree walk: (\d+) CTUs compared, (\d+) differ \((\d+) not covered\), (\d+) of them in P / B", err)
     assert m, err[-800:]
@@ -307,6 +308,27 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
     # with, the bytes in the bitstream buffer, the unit flags xeve_eco_unit stores
     k = re.search(r"shadow writer: (\d+) CTUs written by the oracle beside xeve_eco_tree \((\d+) bytes of bitstream compared\), (\d+) differ", err)
     assert k and int(k.group(1)) == nctu - n and int(k.group(2)) > 0 and int(k.group(3)) == 0, err[-1500:]
+    # the whole picture: at every picture's first CTU the oracle decides AND writes all CTUs on its own -- each CTU entering with the state its own writer left -- then
+    # the tile's end.  Its bytes before the tile's end are what the reference's CTU loop wrote; all of them are the tail of that picture's slice NAL unit in the output
+    # file: the oracle reproduces the slice data of I, P and B pictures.
+    q = re.search(r"shadow pictures: (\d+) pictures decided and written by the oracle on its own \((\d+) bytes of slice data\), (\d+) differ", err)
+    assert q and (int(q.group(1)), int(q.group(3))) == (n, 0), err[-1500:]
+    import struct
+    evc, nals, pos = open(str(tmp_path / "o.evc"), "rb").read(), [], 0
+    while pos + 4 <= len(evc):  # NAL units behind a 4-byte length
+        ln = struct.unpack(">I", evc[pos:pos + 4])[0]
+        nals.append(evc[pos + 4:pos + 4 + ln])
+        pos += 4 + ln
+    assert pos == len(evc)
+    d, at, used = open(dump, "rb").read(), 0, set()
+    while at < len(d):
+        poc, nb = struct.unpack("<ii", d[at:at + 8])
+        body = d[at + 8:at + 8 + nb]
+        at += 8 + nb
+        hit = [i for i, x in enumerate(nals) if i not in used and x.endswith(body) and len(x) - len(body) < 64]
+        assert len(hit) == 1, (name, "poc", poc, nb, hit)
+        used.add(hit[0])
+    assert len(used) == n
 
 
 @needs_ref
