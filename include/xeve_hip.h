@@ -837,6 +837,9 @@ typedef struct xeve_hip_eco_params {
 int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sbac *states, int nstates, const xeve_hip_eco_params *params, uint32_t *map_scu, const int8_t *map_ipm,
                           const uint8_t *map_tidx, uint32_t *map_cu_mode, int64_t map_pic_elems, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes, int bytes_cap,
                           int32_t *nbytes, void *stream);
+/* The end of a tile on each chain's writer state (states[jobs[c].sbac], in place): xeve_eco_tile_end_flag(bs, 1) and xeve_sbac_finish (xeve_eco.c:577-595, 622-672).
+ * bytes: [nchains][bytes_cap], nbytes[c] = what comes out -- appended to the bytes of the chain's CTUs it completes the slice data of the tile. */
+int xeve_hip_eco_tile_end_jobs(xeve_hip_sbac *states, int nstates, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes, int bytes_cap, int32_t *nbytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,8 @@ def lane():
         assert _lib.xl_host_sizeof_params() == C.sizeof(LaneParams)
         _lib.xl_host_eco_ctu.restype = c_int
         _lib.xl_host_eco_ctu.argtypes = [c_int] * 8 + [c_void_p] * 9 + [c_int, c_int, c_void_p, c_int]
+        _lib.xl_host_eco_tile_end.restype = c_int
+        _lib.xl_host_eco_tile_end.argtypes = [c_void_p, c_void_p, c_int]
     return _lib
 
 

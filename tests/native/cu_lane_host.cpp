@@ -27,3 +27,10 @@ extern "C" int xl_host_eco_ctu(int idc, int slice_type, int log2_ctu, int pic_w,
     xl::eco_ctu(E, *s, *d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, &o);
     return o.n;
 }
+
+extern "C" int xl_host_eco_tile_end(xeve_hip_sbac *s, uint8_t *bytes, int cap)
+{
+    xl::Sink o = {bytes, cap, 0};
+    xl::eco_tile_end(*s, &o);
+    return o.n;
+}

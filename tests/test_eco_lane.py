@@ -89,3 +89,31 @@ def test_lane_writer_on_p_and_b_pictures(case):
         total += n
         modes |= set(np.unique(d["pred_mode"][0]).tolist())
     assert total > 10 and len(modes) >= 2  # bytes did come out; more than one kind of CU was written
+
+
+def test_lane_tile_end_matches_oracle():
+    """xeve_eco_tile_end_flag(1) + xeve_sbac_finish from many coder states (the states the writer tests above end in, and random ones): bytes and the state left behind"""
+    from _sbac_cases import make_states
+
+    O, L = oracle(), _lane.lane()
+    O.xo_eco_tile_end.restype = c_int
+    O.xo_eco_tile_end.argtypes = [c_void_p, c_void_p, c_int]
+    r = np.random.default_rng(12)
+    st = make_states(r, 400)
+    st["bitcounter"] = 0
+    st["code"] &= (1 << 19) - 1
+    st["pending_byte"] = r.integers(0, 256, size=len(st))
+    st["is_pending_byte"] = r.integers(0, 2, size=len(st))
+    st["stacked_zero"] = r.integers(0, 3, size=len(st)) * st["is_pending_byte"]
+    st["pending_byte"][::7] = 0
+    st["code_bits"] = r.integers(1, 12, size=len(st))
+    kinds = set()
+    for i in range(len(st)):
+        a, b = st[i:i + 1].copy(), st[i:i + 1].copy()
+        ba, bb = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        na, nb = O.xo_eco_tile_end(ptr(a), ptr(ba), 64), L.xl_host_eco_tile_end(ptr(b), ptr(bb), 64)
+        assert na == nb and np.array_equal(ba[:na], bb[:nb]), (i, na, nb, ba[:8], bb[:8])
+        for f in ("range", "code", "code_bits", "stacked_ff", "stacked_zero", "pending_byte", "is_pending_byte"):
+            assert a[f][0] == b[f][0], (i, f)
+        kinds.add(na)
+    assert len(kinds) >= 3

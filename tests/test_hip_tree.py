@@ -305,6 +305,9 @@ def test_hip_i_pictures_decided_and_written_ctu_by_ctu_on_the_device(case):
         by, nb = D.eco_ctu_jobs(out, states, EP, ms, mi, mt, mc, jt, map_pic_elems=m["scu"].shape[1])
         torch.cuda.synchronize()
         got.append((states.cpu().numpy().reshape(-1).view(SBAC_DTYPE).copy(), by.cpu().numpy(), nb.cpu().numpy()))
+    eby, enb = D.eco_tile_end_jobs(states, jt)  # the tile's end: with it the bytes of a chain are the picture's slice data
+    torch.cuda.synchronize()
+    eby, enb = eby.cpu().numpy(), enb.cpu().numpy()
     # the oracle's chain, picture by picture
     O = oracle_tree()
     OE = oracle()
@@ -331,6 +334,11 @@ def test_hip_i_pictures_decided_and_written_ctu_by_ctu_on_the_device(case):
                 assert np.array_equal(gs[f][p], state[f][0]), (case, "picture", p, "ctu", k, f)
             assert int(gn[p]) == ne and np.array_equal(gb[p][:ne], eb[:ne]), (case, p, k, "bytes", int(gn[p]), ne)
             total += ne
+        OE.xo_eco_tile_end.restype = c_int
+        OE.xo_eco_tile_end.argtypes = [c_void_p, c_void_p, c_int]
+        tb = np.zeros(64, np.uint8)
+        nt = OE.xo_eco_tile_end(ptr(state), ptr(tb), 64)
+        assert int(enb[p]) == nt and np.array_equal(eby[p][:nt], tb[:nt]), (case, p, "tile end", int(enb[p]), nt)
     assert total > 100
     for j in range(3 if c["idc"] else 1):
         assert np.array_equal(mod[j].cpu().numpy(), c["mod"][j]), (case, "picture", j)

@@ -42,3 +42,27 @@ extern "C" int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sba
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// the end of a tile for a batch of chains: the terminating bin and xeve_sbac_finish on each chain's writer state (eco_lane.h eco_tile_end)
+__global__ void __launch_bounds__(64) k_eco_tile_end(xeve_hip_sbac *__restrict__ states, const xeve_hip_ctu_job *__restrict__ jobs, int nchains, uint8_t *__restrict__ bytes,
+                                                     int bytes_cap, int32_t *__restrict__ nbytes)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= nchains) return;
+    const int si = jobs[c].sbac;
+    xl::Sbac s = states[si];
+    xl::Sink o = {bytes + (long)c * bytes_cap, bytes_cap, 0};
+    xl::eco_tile_end(s, &o);
+    states[si] = s;
+    nbytes[c] = o.n;
+}
+
+extern "C" int xeve_hip_eco_tile_end_jobs(xeve_hip_sbac *states, int nstates, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes, int bytes_cap, int32_t *nbytes, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(states && nstates > 0 && jobs && nchains >= 0 && bytes && bytes_cap > 0 && nbytes);
+    if(nchains == 0) return XEVE_HIP_OK;
+    k_eco_tile_end<<<(nchains + 63) / 64, 64, 0, (hipStream_t)stream>>>(states, jobs, nchains, bytes, bytes_cap, nbytes);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}

@@ -192,4 +192,38 @@ XL void eco_ctu(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_
         }
     }
 }
+// The end of a tile on the writer's coder: xeve_eco_tile_end_flag(bs, 1) = xeve_sbac_encode_bin_trm (xeve_eco.c:577-595), then xeve_sbac_finish (:622-672): what the coder
+// still held, and -- where no pending byte is left and fewer than four code bits remain -- the zero bits up to the byte boundary (one zero byte)
+XL void eco_tile_end(Sbac &s, Sink *o)
+{
+    s.bin_counter++;
+    s.range--;
+    s.code += s.range, s.range = 1; // the terminating bin is 1
+    while(s.range < 8192) s.range <<= 1, sb_shift(s, o);
+    uint32_t tmp = (s.code + s.range - 1) & (0xFFFFFFFFu << 14);
+    if(tmp < s.code) tmp += 8192;
+    s.code = tmp << s.code_bits;
+    for(int pass = 0; pass < 2; pass++) { // sbac_carry_propagate, twice (the second time after code <<= 8)
+        if(pass) s.code <<= 8;
+        const unsigned out = s.code >> 17;
+        s.code &= (1u << 17) - 1;
+        if(out < 0xFF) {
+            for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0xFF, o);
+            sb_byte(s, out, o);
+        }
+        else if(out > 0xFF) {
+            s.pending_byte++;
+            for(; s.stacked_ff; s.stacked_ff--) sb_byte(s, 0, o);
+            sb_byte(s, out, o);
+        }
+        else s.stacked_ff++;
+    }
+    auto put = [&](unsigned b) {
+        if(o->n < o->cap) o->p[o->n] = (uint8_t)b;
+        o->n++;
+    };
+    for(; s.stacked_zero; s.stacked_zero--) put(0);
+    if(s.pending_byte != 0) put(s.pending_byte);
+    else if(s.code_bits < 4) put(0);
+}
 } // namespace xl

@@ -368,6 +368,15 @@ def eco_ctu_jobs(ctus, states, params, map_scu, map_ipm, map_tidx, map_cu_mode, 
     return by, nb
 
 
+def eco_tile_end_jobs(states, jobs, bytes_cap=64):
+    """the end of a tile on every chain's writer state (xeve_hip_eco_tile_end_jobs; states advanced in place).  Returns (bytes uint8 [nchains, bytes_cap], nbytes int32)."""
+    n, dev = jobs.numel() // 16, jobs.device
+    by = torch.zeros((n, bytes_cap), dtype=torch.uint8, device=dev)
+    nb = torch.zeros(n, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().xeve_hip_eco_tile_end_jobs(_ptr(states), states.numel() // SBAC_BYTES, _ptr(jobs), n, _ptr(by), bytes_cap, _ptr(nb), _stream()))
+    return by, nb
+
+
 def mode_analyze_ctu_intra_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, states, params, jobs, pic_elems=None,
                                 workspace=None):
     """the I-slice form (chains may belong to different pictures: pic_elems)"""
