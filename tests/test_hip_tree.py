@@ -343,3 +343,90 @@ def test_hip_i_pictures_decided_and_written_ctu_by_ctu_on_the_device(case):
     for j in range(3 if c["idc"] else 1):
         assert np.array_equal(mod[j].cpu().numpy(), c["mod"][j]), (case, "picture", j)
     assert np.array_equal(ms.cpu().numpy().view(np.uint32).reshape(m["scu"].shape), m["scu"]) and np.array_equal(mc.cpu().numpy().view(np.uint32).reshape(m["cu_mode"].shape), m["cu_mode"])
+
+
+@pytest.mark.parametrize("case", [INTER_CASES[1], INTER_CASES[2]], ids=["4102", "4103"])
+def test_hip_b_picture_decided_and_written_ctu_by_ctu_on_the_device(case):
+    """the same closed loop for a B picture (one chain: its CTUs in raster order): decided from the writer's state, written -- skip, direct, uni- and bi-predicted and intra
+    CUs in the writer's syntax -- the state advanced in place, the tile's end; against the oracle's chain"""
+    import ctypes as C
+
+    import torch
+    import xeve_amd
+    from test_hip_inter import hip_params
+    from xeve_amd import device as D
+    from xeve_amd import lib
+    from _libs import c_int, c_void_p, oracle, ptr
+    from _mc_cases import refpic_table
+    from _tree_cases import TreeInter, oracle_tree_any
+
+    c = make_inter_case(*case)
+    exp_c = make_inter_case(*case)
+    entry = c["entry"][0:1].copy()
+    entry["bitcounter"] = 0
+    xeve_amd.init(0)
+    dev = torch.device("cuda:0")
+    refs, org = c["refs"], c["org"]
+    dplanes = [[torch.from_numpy(x).to(dev) for x in pic] for pic in refs["pics"]]
+    lut = {id(x): t for pic, dp in zip(refs["pics"], dplanes) for x, t in zip(pic, dp)}
+    dev_tab = refpic_table(refs, lambda a, off: lut[id(a)].data_ptr() + 2 * off)
+    dorg = [torch.from_numpy(x).to(dev) for x in org]
+    org_ptrs = [dorg[0].data_ptr() + 2 * refs["org_l"], dorg[1].data_ptr() + 2 * refs["org_c"], dorg[2].data_ptr() + 2 * refs["org_c"]]
+    mod = [torch.from_numpy(a.copy()).to(dev) for a in c["mod"]]
+    m = c["maps"]
+    ms, mc = (torch.from_numpy(m[k].view(np.int32).copy()).to(dev) for k in ("scu", "cu_mode"))
+    mi, mt, mv, mr = (torch.from_numpy(m[k].copy()).to(dev) for k in ("ipm", "tidx", "mv", "refi"))
+    col = [torch.from_numpy(a.copy()).to(dev) for a in c["col"]]
+    P = lib.TreeParams.from_buffer_copy(bytes(c["P"]))
+    I = lib.TreeInter()
+    I.refp, I.s_ref_l, I.s_ref_c, I.ipar = dev_tab.ctypes.data, refs["s_l"], refs["s_c"], hip_params(c["ipar"])
+    I.map_mv, I.map_refi, I.col_mv0, I.col_mv1, I.ecu_depth = mv.data_ptr(), mr.data_ptr(), col[0].data_ptr(), col[1].data_ptr(), c["ecu_depth"]
+    nref = (c["ipar"].rdo.num_refp[0], c["ipar"].rdo.num_refp[1])
+    EP = lib.EcoParams()
+    EP.chroma_format_idc, EP.slice_type, EP.log2_ctu, EP.pic_w, EP.pic_h, EP.w_scu, EP.h_scu = c["idc"], c["slice_type"], 6, P.pic_w, P.pic_h, P.ip.w_scu, P.ip.h_scu
+    EP.num_refp[0], EP.num_refp[1] = nref
+    states = torch.from_numpy(entry.view(np.uint8).copy()).to(dev)
+    got = []
+    for (x, y) in c["order"]:
+        jobs = np.zeros(1, CTU_JOB_DTYPE)
+        jobs["x"], jobs["y"] = x, y
+        jt = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        out, _, _ = D.mode_analyze_ctu_jobs(org_ptrs, refs["s_l"], refs["s_c"], [t.data_ptr() for t in mod], mod[0].shape[1], mod[1].shape[1], ms, mi, mt, mc, states, P, jt, inter=I)
+        by, nb = D.eco_ctu_jobs(out, states, EP, ms, mi, mt, mc, jt)
+        torch.cuda.synchronize()
+        got.append((states.cpu().numpy().reshape(-1).view(SBAC_DTYPE).copy(), by.cpu().numpy()[0], int(nb.cpu().numpy()[0])))
+    eby, enb = D.eco_tile_end_jobs(states, jt)
+    torch.cuda.synchronize()
+    # the oracle's chain
+    O, OE = oracle_tree_any(), oracle()
+    OE.xo_eco_ctu.restype = c_int
+    OE.xo_eco_ctu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_void_p] * 4 + [c_int, c_int, c_void_p, c_int]
+    OE.xo_eco_tile_end.restype = c_int
+    OE.xo_eco_tile_end.argtypes = [c_void_p, c_void_p, c_int]
+    erefs, eorg, em = exp_c["refs"], exp_c["org"], exp_c["maps"]
+    tab = refpic_table(erefs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    TI = TreeInter()
+    TI.refp, TI.s_ref_l, TI.s_ref_c, TI.ipar = tab.ctypes.data, erefs["s_l"], erefs["s_c"], exp_c["ipar"]
+    TI.map_mv, TI.map_refi, TI.col0, TI.col1, TI.ecu_depth = em["mv"].ctypes.data, em["refi"].ctypes.data, exp_c["col"][0].ctypes.data, exp_c["col"][1].ctypes.data, exp_c["ecu_depth"]
+    orgp = (c_void_p * 3)(int(eorg[0].ctypes.data) + 2 * erefs["org_l"], int(eorg[1].ctypes.data) + 2 * erefs["org_c"], int(eorg[2].ctypes.data) + 2 * erefs["org_c"])
+    modp = (c_void_p * 3)(*[a.ctypes.data for a in exp_c["mod"]])
+    state, nr, total = entry.copy(), np.array(nref, np.int32), 0
+    for k, (x, y) in enumerate(c["order"]):
+        d, nx = np.zeros(1, CTU_DATA_DTYPE), np.zeros(1, SBAC_DTYPE)
+        O.xo_mode_analyze_ctu(orgp, erefs["s_l"], erefs["s_c"], modp, exp_c["mod"][0].shape[1], exp_c["mod"][1].shape[1], ptr(em["scu"]), ptr(em["ipm"]), ptr(em["tidx"]),
+                              ptr(em["cu_mode"]), ptr(state), C.byref(exp_c["P"]), C.byref(TI), x, y, ptr(d), ptr(nx))
+        for j in range(min(64, c["h"] - y) // 4):
+            g = (y // 4 + j) * (c["w"] // 4) + x // 4
+            em["scu"][g:g + min(64, c["w"] - x) // 4] &= np.uint32(0x7FFFFFFF)
+        eb = np.zeros(1 << 15, np.uint8)
+        ne = OE.xo_eco_ctu(ptr(state), ptr(d), C.addressof(exp_c["P"]), ptr(nr), ptr(em["scu"]), ptr(em["ipm"]), ptr(em["tidx"]), ptr(em["cu_mode"]), x, y, ptr(eb), eb.size)
+        gs, gb, gn = got[k]
+        for f in ("range", "code", "code_bits", "stacked_ff", "stacked_zero", "pending_byte", "is_pending_byte", "bin_counter", "ctx"):
+            assert np.array_equal(gs[f][0], state[f][0]), (case, "ctu", k, f)
+        assert gn == ne and np.array_equal(gb[:ne], eb[:ne]), (case, k, "bytes", gn, ne)
+        total += ne
+    tb = np.zeros(64, np.uint8)
+    nt = OE.xo_eco_tile_end(ptr(state), ptr(tb), 64)
+    assert int(enb.cpu().numpy()[0]) == nt and np.array_equal(eby.cpu().numpy()[0][:nt], tb[:nt]), (case, "tile end")
+    assert total > 10
+    assert np.array_equal(ms.cpu().numpy().view(np.uint32), em["scu"]) and np.array_equal(mv.cpu().numpy(), em["mv"]) and np.array_equal(mod[0].cpu().numpy(), exp_c["mod"][0])
