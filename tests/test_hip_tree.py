@@ -214,7 +214,7 @@ def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path):
 
     env = dict(os.environ, XEVE_HIP_TREE_LANE="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-k", "3101 or 3104 or 4103"], env=env, capture_output=True, text=True,
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-k", "matches_oracle and (3101 or 3104 or 4103)"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
 
