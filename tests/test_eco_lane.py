@@ -117,3 +117,11 @@ def test_lane_tile_end_matches_oracle():
             assert a[f][0] == b[f][0], (i, f)
         kinds.add(na)
     assert len(kinds) >= 3
+
+
+def test_lane_writer_on_more_pictures():
+    """more seeds: 4:4:4 and 4:0:0 I pictures with partial CTUs, B pictures with two reference pictures per list and both early-termination depths"""
+    for case in [(3201, 2, 104, 72, 10, 3, 6, 64, 4, 28), (3202, 2, 72, 104, 8, 0, 6, 32, 8, 36), (3203, 1, 96, 96, 10, 1, 5, 32, 4, 24)]:
+        test_lane_writer_on_i_pictures(case)
+    for case in [(4401, 136, 72, 10, 1, 0, 2, 1, 0.0), (4402, 128, 128, 10, 1, 1, 2, 0, 0.0), (4403, 72, 136, 10, 1, 0, 1, 0, 4.0)]:
+        test_lane_writer_on_p_and_b_pictures(case)
