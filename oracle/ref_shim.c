@@ -993,7 +993,7 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         xo_eco = dlsym(oh, "xo_eco_ctu"), xo_tile_end = dlsym(oh, "xo_eco_tile_end");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
         if(ctx->fn_loop_filter != shim_shadow_loop_filter) orig_shadow_loop_filter = ctx->fn_loop_filter, ctx->fn_loop_filter = shim_shadow_loop_filter;
-        fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks every I-picture CTU beside the reference\n");
+        fprintf(stderr, "[xeve_hip_shim] shadow mode: the oracle walks and writes every CTU beside the reference\n");
         atexit(report);
     }
     if(getenv("XEVE_SHIM_TREE_ORACLE") && ctx->fn_mode_analyze_lcu && ctx->fn_mode_analyze_lcu != shim_route_mode_analyze_lcu) {
