@@ -544,6 +544,104 @@ static void shadow_writer_check(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *n
     W.valid = 0;
 }
 
+/* XEVE_SHIM_TREE_GOLDEN=<file> (shadow mode): for the CTUs listed in XEVE_SHIM_TREE_GOLDEN_CTUS (default "0") of every picture, append a record of what the CTU mode
+ * decision was handed and of what THE REFERENCE made of it -- the raw material of tests/golden/tree_v1.npz (tests/golden/make_tree_golden.py turns the records into
+ * arrays).  A record is a sequence of named blobs: name[16], int64 size, data; "end" closes it. */
+static void gblob(FILE *f, const char *name, const void *data, size_t n)
+{
+    char    nm[16] = {0};
+    int64_t sz = (int64_t)n;
+    strncpy(nm, name, 15);
+    fwrite(nm, 1, 16, f), fwrite(&sz, 8, 1, f);
+    if(n) fwrite(data, 1, n, f);
+}
+static void gplane(FILE *f, const char *name, const pel *p, int stride, int w, int h)
+{   /* the picture area, rows packed */
+    pel *t = malloc(sizeof(pel) * (size_t)w * h);
+    for(int y = 0; y < h; y++) memcpy(t + (size_t)y * w, p + (size_t)y * stride, sizeof(pel) * w);
+    gblob(f, name, t, sizeof(pel) * (size_t)w * h);
+    free(t);
+}
+static int golden_wanted(int lcu)
+{
+    const char *l = getenv("XEVE_SHIM_TREE_GOLDEN_CTUS");
+    if(!l) return lcu == 0;
+    for(const char *q = l; *q;) {
+        if(atoi(q) == lcu) return 1;
+        while(*q && *q != ',') q++;
+        if(*q) q++;
+    }
+    return 0;
+}
+static void golden_dump(XEVE_CTX *ctx, XEVE_CORE *core, const xo_tree_params *P, const xo_tree_inter *TI, xo_pel *const mod_before[3], const uint32_t *scu, const int8_t *ipm,
+                        const uint32_t *cum, const int16_t (*mv)[2][2], const int8_t (*refi)[2], const xo_sbac *entry, int x0, int y0, int lcu)
+{
+    FILE *f = fopen(getenv("XEVE_SHIM_TREE_GOLDEN"), "ab");
+    if(!f) return;
+    XEVE_PIC    *pm = PIC_MODE(ctx);
+    XEVE_PINTRA *pi = &ctx->pintra[core->thread_cnt];
+    const int idc = ctx->sps.chroma_format_idc, ws = ctx->param.cs_w_shift, hs = ctx->param.cs_h_shift, w = ctx->w, h = ctx->h, wc = idc ? w >> ws : 0, hc = idc ? h >> hs : 0;
+    const int nscu = ctx->w_scu * ctx->h_scu, L = ctx->log2_max_cuwh - 2;
+    const int32_t hd[8] = {(int32_t)ctx->poc.poc_val, ctx->sh->slice_type, x0, y0, lcu, TI ? TI->s_ref_l : 0, TI ? TI->s_ref_c : 0, TI ? TI->ecu_depth : 0};
+    gblob(f, "head", hd, sizeof(hd)), gblob(f, "params", P, sizeof(*P)), gblob(f, "entry", entry, sizeof(*entry));
+    gplane(f, "org_y", pi->o[Y_C], pi->s_o[Y_C], w, h), gplane(f, "mod_y", mod_before[0], pm->s_l, w, h);
+    if(idc) {
+        gplane(f, "org_u", pi->o[U_C], pi->s_o[U_C], wc, hc), gplane(f, "org_v", pi->o[V_C], pi->s_o[U_C], wc, hc);
+        gplane(f, "mod_u", mod_before[1], pm->s_c, wc, hc), gplane(f, "mod_v", mod_before[2], pm->s_c, wc, hc);
+    }
+    gblob(f, "map_scu", scu, 4 * (size_t)nscu), gblob(f, "map_ipm", ipm, (size_t)nscu), gblob(f, "map_tidx", ctx->map_tidx, (size_t)nscu), gblob(f, "map_cu_mode", cum, 4 * (size_t)nscu);
+    if(TI) {
+        XEVE_PINTER *pin = &ctx->pinter[core->thread_cnt];
+        XEVE_PIC    *any = pin->refp[0][REFP_0].pic;
+        const int32_t rh[6] = {TI->ipar.rdo.num_refp[0], TI->ipar.rdo.num_refp[1], any->pad_l, any->pad_c, any->s_l, any->s_c};
+        gblob(f, "ref_head", rh, sizeof(rh)), gblob(f, "inter_params", &TI->ipar, sizeof(TI->ipar));
+        gblob(f, "map_mv", mv, sizeof(*mv) * (size_t)nscu), gblob(f, "map_refi", refi, sizeof(*refi) * (size_t)nscu);
+        gblob(f, "col0", TI->col0, 8 * (size_t)nscu), gblob(f, "col1", TI->col1, 8 * (size_t)nscu);
+        for(int l = 0; l < 2; l++)
+            for(int r = 0; r < rh[l]; r++) { /* whole padded planes: the searches and the interpolation read around the picture */
+                XEVE_PIC *rp = pin->refp[r][l].pic;
+                char nm[16];
+                const int32_t poc = (int32_t)pin->refp[r][l].poc;
+                snprintf(nm, sizeof(nm), "ref%d_%d_poc", r, l), gblob(f, nm, &poc, 4);
+                snprintf(nm, sizeof(nm), "ref%d_%d_y", r, l), gblob(f, nm, rp->y - rp->pad_l * rp->s_l - rp->pad_l, sizeof(pel) * (size_t)rp->s_l * (h + 2 * rp->pad_l));
+                if(idc) {
+                    snprintf(nm, sizeof(nm), "ref%d_%d_u", r, l), gblob(f, nm, rp->u - rp->pad_c * rp->s_c - rp->pad_c, sizeof(pel) * (size_t)rp->s_c * (hc + 2 * rp->pad_c));
+                    snprintf(nm, sizeof(nm), "ref%d_%d_v", r, l), gblob(f, nm, rp->v - rp->pad_c * rp->s_c - rp->pad_c, sizeof(pel) * (size_t)rp->s_c * (hc + 2 * rp->pad_c));
+                }
+            }
+    }
+    /* what the reference made of it: the CTU's XEVE_CU_DATA in the oracle's record layout (units inside the picture; split modes of all units), the maps and the
+     * picture after, core->s_next_best */
+    static xo_ctu_data g;
+    memset(&g, 0, sizeof(g));
+    const XEVE_CU_DATA *cd = &ctx->map_cu_data[lcu];
+    const int nu = 1 << L, ctu = 1 << ctx->log2_max_cuwh, wu = XEVE_MIN(nu, ctx->w_scu - (x0 >> 2)), hu = XEVE_MIN(nu, ctx->h_scu - (y0 >> 2));
+    for(int u = 0; u < nu * nu; u++)
+        for(int d = 0; d < XO_CU_DEPTHS; d++) g.split_mode[d][u] = cd->split_mode[d][SQUARE][u];
+    for(int j = 0; j < hu; j++)
+        for(int i = 0; i < wu; i++) {
+            const int u = j * nu + i;
+            g.pred_mode[u] = cd->pred_mode[u], g.ipm[0][u] = cd->ipm[0][u], g.ipm[1][u] = cd->ipm[1][u], g.depth[u] = cd->depth[u];
+            for(int c = 0; c < 3; c++) g.nnz[c][u] = cd->nnz[c][u];
+            g.map_scu[u] = cd->map_scu[u], g.map_cu_mode[u] = cd->map_cu_mode[u];
+            memcpy(g.mv[u], cd->mv[u], sizeof(g.mv[u])), memcpy(g.mvd[u], cd->mvd[u], sizeof(g.mvd[u]));
+            g.refi[u][0] = cd->refi[u][0], g.refi[u][1] = cd->refi[u][1], g.mvp_idx[u][0] = cd->mvp_idx[u][0], g.mvp_idx[u][1] = cd->mvp_idx[u][1];
+        }
+    for(int c = 0; c < (idc ? 3 : 1); c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, cs = ctu >> sx, ww = (wu * 4) >> sx, hh = (hu * 4) >> sy;
+        for(int yy = 0; yy < hh; yy++) memcpy(g.coef[c] + yy * cs, cd->coef[c] + yy * cs, sizeof(s16) * ww), memcpy(g.reco[c] + yy * cs, cd->reco[c] + yy * cs, sizeof(pel) * ww);
+    }
+    xo_sbac nb;
+    sbac_to_flat(&nb, &core->s_next_best[L][L]);
+    gblob(f, "ref_ctu", &g, sizeof(g)), gblob(f, "ref_next", &nb, sizeof(nb));
+    gblob(f, "ref_scu", ctx->map_scu, 4 * (size_t)nscu), gblob(f, "ref_ipm", ctx->map_ipm, (size_t)nscu), gblob(f, "ref_cu_mode", ctx->map_cu_mode, 4 * (size_t)nscu);
+    if(TI) gblob(f, "ref_mv", ctx->map_mv, sizeof(*ctx->map_mv) * (size_t)nscu), gblob(f, "ref_refi", ctx->map_refi, sizeof(*ctx->map_refi) * (size_t)nscu);
+    gplane(f, "ref_mod_y", pm->y, pm->s_l, w, h);
+    if(idc) gplane(f, "ref_mod_u", pm->u, pm->s_c, wc, hc), gplane(f, "ref_mod_v", pm->v, pm->s_c, wc, hc);
+    gblob(f, "end", NULL, 0);
+    fclose(f);
+}
+
 /* the whole picture in shadow mode: at a picture's first CTU the oracle decides AND writes every CTU of the picture on its own -- private copies of the picture being
  * reconstructed and of the maps, every CTU entering with the state the oracle's own writer left (the closed chain), the tile end and xeve_sbac_finish at the end -- and
  * when the reference has written the picture (ctx->fn_loop_filter is called right after its CTU loop) the bytes in its bitstream buffer must be the oracle's */
@@ -699,9 +797,10 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     P.slice_qp = ctx->tile[core->tile_idx].qp, P.slice_num = ctx->slice_num;
     static __thread xo_ctu_data out;
     const xo_pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
+    if(!is_i) P.ip.slice_type = ctx->sh->slice_type;
+    if(getenv("XEVE_SHIM_TREE_GOLDEN") && golden_wanted(lcu)) golden_dump(ctx, core, &P, is_i ? NULL : &TI, mod, m_scu, m_ipm, m_cum, (const int16_t(*)[2][2])m_mv, (const int8_t(*)[2])m_refi, &entry, x0, y0, lcu);
     if(is_i) (void)xo_tree(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, x0, y0, &out, &next);
     else {
-        P.ip.slice_type = ctx->sh->slice_type;
         (void)xo_tree_any(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, &TI, x0, y0, &out, &next);
         shadow_inter_ctus++;
     }
