@@ -515,6 +515,8 @@ static int  bsw_byte(const XEVE_BSW *bs, long pos)
     const long flushed = (long)(bs->cur - bs->beg);
     return pos < flushed ? bs->beg[pos] : (int)((bs->code >> (24 - 8 * (pos - flushed))) & 0xFF);
 }
+static void gblob(FILE *f, const char *name, const void *data, size_t n);
+static int  golden_wanted(int lcu);
 static void shadow_writer_check(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *now)
 {
     const XEVE_BSW *bs = &ctx->bs[core->thread_cnt];
@@ -540,6 +542,18 @@ static void shadow_writer_check(XEVE_CTX *ctx, XEVE_CORE *core, const xo_sbac *n
                 if(W.scu[g] != ctx->map_scu[g] || W.cum[g] != ctx->map_cu_mode[g]) { if(eco_bad < 6) fprintf(stderr, "[shadow writer] CTU %d: unit %d flags %08x / %08x vs %08x / %08x\n", W.lcu, g, W.scu[g], W.cum[g], ctx->map_scu[g], ctx->map_cu_mode[g]); bad = 1; break; }
             }
         eco_ctus++, eco_bad += bad, eco_bytes += (unsigned long long)n;
+        if(getenv("XEVE_SHIM_TREE_GOLDEN") && golden_wanted(W.lcu)) { /* the reference writer's side of a recorded CTU: the state it left (= this CTU's entry state), its bytes */
+            FILE *f = fopen(getenv("XEVE_SHIM_TREE_GOLDEN"), "ab");
+            if(f) {
+                const int32_t hd[8] = {(int32_t)ctx->poc.poc_val, ctx->sh->slice_type, W.x0, W.y0, W.lcu, W.num_refp[0], W.num_refp[1], (int32_t)(p1 - W.byte_pos)};
+                uint8_t *rb = malloc((size_t)(p1 - W.byte_pos) + 1);
+                for(long i = 0; i < p1 - W.byte_pos; i++) rb[i] = (uint8_t)bsw_byte(bs, W.byte_pos + i);
+                gblob(f, "wr_head", hd, sizeof(hd)), gblob(f, "wr_state", now, sizeof(*now)), gblob(f, "wr_bytes", rb, (size_t)(p1 - W.byte_pos));
+                gblob(f, "wr_scu", ctx->map_scu, 4 * (size_t)(ctx->w_scu * ctx->h_scu)), gblob(f, "wr_cu_mode", ctx->map_cu_mode, 4 * (size_t)(ctx->w_scu * ctx->h_scu));
+                gblob(f, "end", NULL, 0);
+                free(rb), fclose(f);
+            }
+        }
     }
     W.valid = 0;
 }

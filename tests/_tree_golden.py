@@ -30,6 +30,10 @@ def load():
                  ref_ctu=f("ref_ctu").view(CTU_DATA_DTYPE).copy(), ref_next=f("ref_next").view(SBAC_DTYPE).copy(),
                  ref_maps=dict(scu=f("ref_scu").view(np.uint32), ipm=f("ref_ipm").view(np.int8), cu_mode=f("ref_cu_mode").view(np.uint32)),
                  ref_mod=[pl("ref_mod_y", h, w), pl("ref_mod_u", hc, wc), pl("ref_mod_v", hc, wc)])
+        if has("wr_head"):  # the reference WRITER's side of this CTU (xeve_eco_tree): the coder state it left, its bytes, the unit flags after
+            wh = f("wr_head").view(np.int32)
+            r["wr"] = dict(num_refp=(int(wh[5]), int(wh[6])), state=f("wr_state").view(SBAC_DTYPE).copy(), bytes=f("wr_bytes").copy() if int(wh[7]) else np.zeros(0, np.uint8),
+                           scu=f("wr_scu").view(np.uint32), cu_mode=f("wr_cu_mode").view(np.uint32))
         if r["slice_type"] != 2:
             rh = f("ref_head").view(np.int32)
             nr, pad_l, pad_c, s_l, s_c = (int(rh[0]), int(rh[1])), int(rh[2]), int(rh[3]), int(rh[4]), int(rh[5])
@@ -189,3 +193,25 @@ def oracle_as_engine(r):
                                                   C.byref(I), int(j["x"]), int(j["y"]), ptr(d), ptr(nb))
         return torch.from_numpy(d.view(np.uint8).copy()), torch.from_numpy(nb.view(np.uint8).copy()), None
     return call
+
+
+WRITER_FIELDS = ("range", "code", "code_bits", "stacked_ff", "stacked_zero", "pending_byte", "is_pending_byte", "ctx")
+
+
+def writer_inputs(r):
+    """what the reference's writer had in front of it for the record's CTU: the CTU's data as the reference decided it, the maps as the decision left them (coded flags of
+    the CTU reset), the entry state = the state the decision entered with (it is the writer's: xeve_enc.c:139)"""
+    maps = dict(scu=r["ref_maps"]["scu"].copy(), ipm=r["ref_maps"]["ipm"].copy(), tidx=r["maps"]["tidx"].copy(), cu_mode=r["ref_maps"]["cu_mode"].copy())
+    state = r["entry"].copy()
+    state["bitcounter"] = 0
+    return r["ref_ctu"].copy(), state, maps
+
+
+def writer_same_as_reference(r, state, out_bytes, maps):
+    w, what = r["wr"], ("record", r["k"], r["clip"], "poc", r["poc"], "writer")
+    for f in WRITER_FIELDS:
+        assert np.array_equal(state[f], w["state"][f]), (what, f)
+    assert np.array_equal(out_bytes, w["bytes"]), (what, "bytes", len(out_bytes), len(w["bytes"]))
+    ctu, w_scu = 1 << r["P"].log2_ctu, r["w"] // 4
+    glob = np.array([(r["y0"] // 4 + j) * w_scu + r["x0"] // 4 + i for j in range(min(ctu, r["h"] - r["y0"]) // 4) for i in range(min(ctu, r["w"] - r["x0"]) // 4)])
+    assert np.array_equal(maps["scu"][glob], w["scu"][glob]) and np.array_equal(maps["cu_mode"][glob], w["cu_mode"][glob]), (what, "unit flags")

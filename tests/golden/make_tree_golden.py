@@ -17,7 +17,7 @@ from _e2e import CASES, REF_APP, SHIM, make_yuv  # noqa: E402
 from _libs import ORACLE_SO  # noqa: E402
 
 # clip, CTUs recorded of every picture
-PLAN = [("noise_allintra_medium", "0"), ("moving_ldb_fast", "0,3"), ("moving_ra_medium", "1")]  # noise (every node decided), then drifting texture: skip / direct / uni- and bi-predicted CUs
+PLAN = [("noise_allintra_medium", "0"), ("moving_ldb_fast", "0,3"), ("moving_ra_medium", "0,1")]  # noise (every node decided), then drifting texture: skip / direct / uni- and bi-predicted CUs
 
 
 def records(path):
@@ -47,7 +47,13 @@ def main():
             env = dict(os.environ, LD_PRELOAD=SHIM, XEVE_SHIM_SHADOW_TREE=ORACLE_SO, XEVE_SHIM_TREE_GOLDEN=dump, XEVE_SHIM_TREE_GOLDEN_CTUS=ctus, XEVE_SHIM_SHADOW_NO_PICTURE="1")
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
             assert p.returncode == 0 and ", 0 differ" in p.stderr, p.stderr[-800:]
-            for rec in records(dump):
+            recs = list(records(dump))
+            writer = {tuple(np.frombuffer(r["wr_head"], np.int32)[[0, 4]]): r for r in recs if "wr_head" in r}  # (poc, lcu) -> the reference writer's side of that CTU
+            for rec in recs:
+                if "wr_head" in rec:
+                    continue
+                hd = np.frombuffer(rec["head"], np.int32)
+                rec.update({k_: v for k_, v in writer.get((hd[0], hd[4]), {}).items()})  # (absent for the last CTU of a picture: the tile's end follows it)
                 for name, body in rec.items():
                     if name.startswith("ref") and name[3].isdigit() and not name.endswith("_poc"):  # a reference plane: stored once per content
                         key = hashlib.md5(body).hexdigest()[:12]
