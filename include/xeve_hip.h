@@ -841,6 +841,44 @@ int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sbac *states, 
  * bytes: [nchains][bytes_cap], nbytes[c] = what comes out -- appended to the bytes of the chain's CTUs it completes the slice data of the tile. */
 int xeve_hip_eco_tile_end_jobs(xeve_hip_sbac *states, int nstates, const xeve_hip_ctu_job *jobs, int nchains, uint8_t *bytes, int bytes_cap, int32_t *nbytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------- */
+/* The closed-GOP batch encoder: the reference's encoder API (inc/xeve.h: xeve_create :441,      */
+/* xeve_push :443, xeve_encode :444, xeve_delete :442; the frame loop xeve_enc / xeve_pic,        */
+/* src_base/xeve_enc.c:226-640) for NGOPS independent encoder runs at once.  Every run codes one  */
+/* closed GOP of `frames` pictures exactly as `xeveb_app --seek g*frames --frames frames` does    */
+/* (the concatenation of the runs is the bitstream of the whole sequence); the    */
+/* runs advance in lockstep through the device entry points above (CTU mode decision -> writer    */
+/* -> tile end -> loop filter -> padding), every picture resident in HBM.  Baseline profile,      */
+/* constant QP, presets fast / medium, 4:2:0, 8-bit input coded at 10 bits -- the application's    */
+/* defaults.  `threads` is the reference's -m: the CTU-row chains of a picture (the bitstream     */
+/* depends on it, as the reference's does).                                                       */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_enc_config {
+    int32_t w, h;             /* -w / -h: multiples of 8 */
+    int32_t fps_num, fps_den; /* -z (only the SEI text carries it) */
+    int32_t qp;               /* -q */
+    int32_t keyint;           /* -I */
+    int32_t bframes;          /* -b: 0, 1, 3, 7, 15 */
+    int32_t closed_gop;       /* --closed-gop */
+    int32_t preset;           /* 0 fast, 1 medium */
+    int32_t threads;          /* -m: 1 .. 8 */
+    int32_t inter_slice_type; /* --inter-slice-type: 0 B, 1 P */
+    int32_t ref;              /* --ref (0: the preset's) */
+    int32_t reserved[4];
+} xeve_hip_enc_config;
+typedef struct xeve_hip_enc xeve_hip_enc;
+/* A batch of `ngops` runs of `frames` pictures each.  NULL + xeve_hip_last_error() when the configuration is outside the supported set or HBM does not hold the batch. */
+xeve_hip_enc *xeve_hip_enc_create(const xeve_hip_enc_config *cfg, int ngops, int frames);
+void          xeve_hip_enc_delete(xeve_hip_enc *e);
+/* Frame `frame` of run `gop`: planar 8-bit 4:2:0 (w*h luma bytes, then U, then V), host memory (on_device 0) or device memory (1).  The frame is copied into HBM. */
+int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device);
+/* Codes every run (synchronous).  May be called again after new frames were pushed. */
+int xeve_hip_enc_encode(xeve_hip_enc *e);
+/* Run `gop`'s bitstream (what the application would have written to its output file); valid until the next encode / delete. */
+int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes);
+/* Lockstep statistics of the last encode: CTU steps issued, seconds inside the step calls / the picture-end calls (loop filter, second writer pass, padding). */
+int xeve_hip_enc_stats(xeve_hip_enc *e, int64_t *ctu_steps, double *step_seconds, double *picture_end_seconds);
+
 #ifdef __cplusplus
 }
 #endif

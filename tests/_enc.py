@@ -1,0 +1,120 @@
+"""Helpers of the batch-encoder tests: the configuration record of include/xeve_hip.h, the CPU harness (oracle/libxeve_enc_oracle.so = the product's frame loop
+on the oracle's engine; test infrastructure), the command-line <-> configuration mapping, and the cases whose goldens tests/golden/make_enc_golden.py records."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+from _libs import ORACLE_DIR, ROOT
+
+ENC_ORACLE_SO = os.path.join(ORACLE_DIR, "libxeve_enc_oracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "enc_v1.json")
+
+
+class EncConfig(C.Structure):  # xeve_hip_enc_config
+    _fields_ = [(n, C.c_int32) for n in "w h fps_num fps_den qp keyint bframes closed_gop preset threads inter_slice_type ref".split()] + [("reserved", C.c_int32 * 4)]
+
+
+def config(w, h, cli, threads=1):
+    """the application's options -> the configuration record (defaults: xeve_param_init, xeve_enc.c:2290-2324)"""
+    c = EncConfig()
+    c.w, c.h, c.fps_num, c.fps_den, c.qp, c.bframes, c.preset, c.threads = w, h, 30, 1, 32, 15, 1, threads
+    i = 0
+    while i < len(cli):
+        a = cli[i]
+        if a == "--preset":
+            c.preset = {"fast": 0, "medium": 1}[cli[i + 1]]
+        elif a == "-I":
+            c.keyint = int(cli[i + 1])
+        elif a == "-b":
+            c.bframes = int(cli[i + 1])
+        elif a == "--ref":
+            c.ref = int(cli[i + 1])
+        elif a == "-q":
+            c.qp = int(cli[i + 1])
+        elif a == "-m":
+            c.threads = int(cli[i + 1])
+        elif a == "--closed-gop":
+            c.closed_gop = 1
+            i -= 1
+        else:
+            raise ValueError(a)
+        i += 2
+    return c
+
+
+_harness = None
+
+
+def harness():
+    global _harness
+    if _harness is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("enc_oracle.cpp", "xeve_oracle.c", "xeve_oracle.h")] + [os.path.join(ROOT, "xeve_amd", "csrc", f) for f in ("enc_host.h", "enc_plan.h")]
+        if not os.path.exists(ENC_ORACLE_SO) or os.path.getmtime(ENC_ORACLE_SO) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "enc"])
+        _harness = C.CDLL(ENC_ORACLE_SO)
+    return _harness
+
+
+def plan_cpu(cfg, frames):
+    """[(frame, poc, slice type, tid, qp, idr, L0 poc, L1 poc)] of the coded pictures, from the product's frame loop"""
+    buf = (C.c_int32 * (8 * frames))()
+    n = harness().xo_encode_plan(C.byref(cfg), frames, buf, frames)
+    assert n == frames, n
+    return [tuple(buf[8 * i:8 * i + 8]) for i in range(n)]
+
+
+def encode_cpu(cfg, gops, frames, always_rewrite=False):
+    """gops: list of bytes objects (planar 8-bit 4:2:0 frames of one run each) -> list of bitstreams"""
+    G = len(gops)
+    arr = (C.c_char_p * G)(*gops)
+    out, nb, err = (C.POINTER(C.c_uint8) * G)(), (C.c_size_t * G)(), C.create_string_buffer(512)
+    rc = harness().xo_encode_gops(C.byref(cfg), C.cast(arr, C.POINTER(C.c_void_p)), G, frames, int(always_rewrite), out, nb, err, 512)
+    if rc:
+        raise RuntimeError(err.value.decode())
+    res = [bytes(bytearray(out[g][:nb[g]])) for g in range(G)]
+    for g in range(G):
+        harness().xo_encode_free(out[g])
+    return res
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+# Frame-loop grid: (options, frame counts) whose picture tables (POC order, temporal id, type, QP, first reference of each list) the golden file records from the
+# reference application's own report
+PLAN_GRID = [
+    (["--preset", "fast", "-I", "0", "-b", "0"], (1, 2, 5, 9, 17)),
+    (["--preset", "fast", "-I", "5", "-b", "0"], (3, 8, 12)),
+    (["--preset", "fast", "-I", "6", "-b", "0", "--closed-gop"], (5, 13)),
+    (["--preset", "fast", "-I", "1", "-b", "0"], (3,)),
+    (["--preset", "fast", "-b", "1"], (2, 3, 8, 9)),
+    (["--preset", "medium"], (1, 2, 3, 5, 8, 9, 17, 20, 33)),
+    (["--preset", "medium", "-b", "7"], (3, 8, 9, 17, 20)),
+    (["--preset", "medium", "-b", "3", "-I", "8"], (5, 8, 9, 17, 20)),
+    (["--preset", "medium", "-b", "15", "-I", "32"], (17, 33, 40)),
+    (["--preset", "medium", "--closed-gop", "-I", "8"], (1, 2, 3, 4, 5, 6, 7, 8, 9, 17, 20)),
+    (["--preset", "medium", "--closed-gop", "-I", "8", "-b", "3"], (5, 8, 20)),
+    (["--preset", "medium", "--closed-gop", "-I", "4", "-b", "7"], (5, 9, 17)),
+    (["--preset", "medium", "--closed-gop", "-I", "12", "-b", "7"], (9, 20, 33)),
+]
+
+# Batches of closed GOPs: name -> (w, h, gops, frames per gop, seed, options, threads).  The golden holds one md5 per GOP, from the reference application run with
+# --seek g * frames --frames frames.  Seeds as in tests/_e2e.py make_yuv (>= 5000: drifting texture).
+BATCH_CASES = {
+    "gops_128x64_noise": (128, 64, 3, 8, 21, ["--preset", "medium", "--closed-gop", "-I", "8"], 1),
+    "gops_128x128_moving_m2": (128, 128, 2, 8, 5021, ["--preset", "medium", "--closed-gop", "-I", "8"], 2),
+    "gops_192x256_noise_m3": (192, 256, 2, 4, 23, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "3"], 3),
+    "gops_cif_moving": (352, 288, 4, 8, 5024, ["--preset", "medium", "--closed-gop", "-I", "8"], 1),  # G >= 4 GOPs x 8 frames at 352x288
+    "gops_cif_noise_m8": (352, 288, 2, 8, 25, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
+}
+# the same at BASELINE's picture sizes (GPU suite only; the CPU harness would need minutes): >= 2 GOPs at 1920x1080
+BATCH_CASES_REAL = {
+    "gops_1080p_moving_m8": (1920, 1080, 2, 8, 5026, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
+}
+
+
+def golden():
+    return json.load(open(GOLDEN))

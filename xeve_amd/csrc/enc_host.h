@@ -1,0 +1,129 @@
+// xeve_amd/csrc/enc_host.h -- the closed-GOP batch encoder: G independent encoder runs (one closed GOP of F frames each, coded as the reference codes
+// `--seek g*F --frames F`) advance in LOCKSTEP -- the same picture of every GOP at the same time, the same CTU of every picture in the same step -- so that one batched
+// device call decides a CTU of every GOP.  This file is the frame loop above the engine: xeve_enc -> xeve_pic_prepare / xeve_header / xeve_pic / xeve_pic_finish
+// (src_base/xeve_enc.c:602-640, 226-600, 1184-1337) with xeve_ctu_mt_core's row chains (:103-175) as the lockstep axis inside a picture.
+//
+// Engine = where the pictures live and who decides a CTU.  The product instantiates it with the HIP engine (encode.cpp: everything resident in HBM); the test
+// harness under oracle/ instantiates the SAME template with a CPU engine built on the oracle, which pins this file and enc_plan.h against bitstreams of the
+// unmodified reference without a GPU.  There is no run-time switch between the two.
+//
+//   struct Engine {
+//       void begin_picture(const PicSetup &);     // every GOP: load the original of frame `frame`, clear the unit maps, take store `cur_slot` for the reconstruction
+//       void reset_chain(int t);                  // every GOP: row chain t's writer = a freshly reset coder (fn_eco_sbac_reset, xeve_enc.c:114-118)
+//       void step(const ChainCtu *c, int n);      // every GOP: decide CTU c[i] from chain c[i].t's writer state (:138-142), write it on that writer (xeve_eco_tree, :152), keep it
+//       void end_picture(bool rewrite, std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins);
+//                                                 // every GOP: loop filter (:462); the slice data = all CTUs written again in raster order on a fresh coder + the tile's end
+//                                                 // (:466-560; rewrite == false: chain 0's own bytes, which are the same when there is one chain); padding (xeve_pic_finish)
+//   };
+#pragma once
+#include "enc_plan.h"
+
+namespace xenc {
+
+struct PicSetup {
+    int frame, poc, slice_type, cur_slot, nchains;
+    int nref[2];
+    RefPic ref[MAX_ACTIVE_REF][2]; // [refi][list]
+    xeve_hip_tree_params    tp;
+    xeve_hip_tree_inter     ti;    // (pointers are the engine's to fill)
+    xeve_hip_eco_params     ep;
+    xeve_hip_deblock_params dp;
+};
+
+template <class Engine> class BatchEncoder {
+  public:
+    BatchEncoder(Engine &e, const Param &p, int ngops, int nframes) : E(e), P(p), G(ngops), F(nframes) {}
+    std::vector<PicPlan> plan() const { return Planner(P, F).run(); }
+    // picture stores the run needs at once: the reference pictures alive at some point plus the picture being coded (a dry run of the bookkeeping)
+    static int slots_needed(const Param &P, int nframes)
+    {
+        Dpb dpb(64);
+        int need = 1, last_intra = 0;
+        for(const PicPlan &pp : Planner(P, nframes).run()) {
+            if(pp.slice_type == ST_I) last_intra = pp.poc;
+            (void)dpb.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra);
+            const int slot = dpb.get_empty();
+            if(slot < 0) return -1;
+            need = std::max(need, slot + 1);
+            dpb.put(slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length);
+        }
+        return need;
+    }
+
+    // out[g] = the bitstream of GOP g (what the reference application writes to its output file for that run)
+    int run(std::vector<std::vector<uint8_t>> &out)
+    {
+        out.assign(G, std::vector<uint8_t>());
+        const std::vector<PicPlan> pics = plan();
+        if((int)pics.size() != F) return fail("the frame loop did not code every frame");
+        Dpb dpb(slots_needed(P, F));
+        const int w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU;
+        const std::vector<std::vector<ChainCtu>> steps = wavefront(w_lcu, h_lcu, P.threads);
+        const int T = std::min(P.threads, h_lcu);
+        int last_intra_poc = 0;
+        std::vector<std::vector<uint8_t>> slice;
+        std::vector<uint32_t> bins;
+        for(const PicPlan &pp : pics) {
+            if(pp.frame < 0 || pp.frame >= F) return fail("the frame loop asked for a frame that was never pushed");
+            if(pp.slice_type == ST_I) last_intra_poc = pp.poc; // xeve_pic_prepare (:1217-1218)
+            const int qp = slice_qp(P, pp.depth);
+            const PicNumbers num = pic_numbers(qp);
+            if(!dpb.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra_poc)) return fail("no reference picture for an inter picture");
+            PicSetup S;
+            memset(&S, 0, sizeof(S));
+            S.frame = pp.frame, S.poc = pp.poc, S.slice_type = pp.slice_type, S.nchains = T;
+            if((S.cur_slot = dpb.get_empty()) < 0) return fail("no free picture store");
+            fill_tree_params(S.tp, P, pp.slice_type, num);
+            if(pp.slice_type != ST_I) {
+                fill_inter_params(S.ti, P, pp.slice_type, pp.poc, num, dpb);
+                S.nref[0] = dpb.num_refp[0], S.nref[1] = pp.slice_type == ST_B ? dpb.num_refp[1] : 0;
+                for(int l = 0; l < 2; l++)
+                    for(int r = 0; r < S.nref[l]; r++) S.ref[r][l] = dpb.refp[r][l];
+                if(pp.slice_type == ST_B && S.nref[1] > S.nref[0]) return fail("list 1 longer than list 0: outside what the inter analysis takes");
+            }
+            S.ep.chroma_format_idc = 1, S.ep.slice_type = pp.slice_type, S.ep.log2_ctu = LOG2_CTU, S.ep.pic_w = P.w, S.ep.pic_h = P.h, S.ep.w_scu = P.w >> 2, S.ep.h_scu = P.h >> 2;
+            S.ep.num_refp[0] = dpb.num_refp[0], S.ep.num_refp[1] = dpb.num_refp[1];
+            fill_deblock_params(S.dp, P);
+            E.begin_picture(S);
+            for(int t = 0; t < T; t++) E.reset_chain(t);
+            for(const std::vector<ChainCtu> &s : steps) E.step(s.data(), (int)s.size());
+            E.end_picture(T > 1 || always_rewrite, slice, bins);
+            if((int)slice.size() != G || (int)bins.size() != G) return fail("the engine returned no slice data");
+            // the access unit: parameter sets in front of an IDR picture (xeve_header), then the slice NAL unit (xeve_pic :466-590)
+            for(int g = 0; g < G; g++) {
+                std::vector<uint8_t> &o = out[g];
+                if(pp.idr) {
+                    const std::vector<uint8_t> sps = make_sps(P), pps = make_pps(pp.tid), sei = make_sei(P, pp.tid);
+                    o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end()), o.insert(o.end(), sei.begin(), sei.end());
+                }
+                Bits bs;
+                slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp);
+                std::vector<uint8_t> nal = bs.b;
+                nal.insert(nal.end(), slice[g].begin(), slice[g].end());
+                // cabac_zero_words when the slice's bins outrun its bytes (:562-583)
+                const uint32_t num_bytes = ((uint32_t)nal.size() & ~3u) - 4; // (bs->cur counts whole flushed words, xeve_bsw.c:32-44)
+                const int      pw = ((P.w + 3) / 4) * 4, ph = ((P.h + 3) / 4) * 4, raw_bits = pw * ph * (BIT_DEPTH + 2 * (BIT_DEPTH >> 2));
+                const uint32_t threshold = (32 / 3) * num_bytes + (uint32_t)(raw_bits / 32);
+                if(bins[g] >= threshold) {
+                    const uint32_t target = ((bins[g] - (uint32_t)(raw_bits / 32)) * 3 + 31) / 32;
+                    if(target > num_bytes)
+                        for(uint32_t i = 0, words = (target - num_bytes + 2) / 3; i < words; i++) nal.push_back(0), nal.push_back(0);
+                }
+                nal_close(nal);
+                o.insert(o.end(), nal.begin(), nal.end());
+            }
+            dpb.put(S.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length); // xeve_pic_finish -> xeve_picman_put_pic
+        }
+        return 0;
+    }
+    std::string error;
+    bool always_rewrite = false; // (tests: one chain through the second pass too)
+
+  private:
+    Engine     &E;
+    const Param P;
+    const int   G, F;
+    int fail(const char *m) { error = m; return -1; }
+};
+
+} // namespace xenc
