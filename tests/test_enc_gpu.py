@@ -1,0 +1,109 @@
+"""The closed-GOP batch encoder on the GPU (xeve_hip_enc_*, xeve_amd/encode.py): every GOP's bitstream must be byte-identical to the reference application's run
+over that GOP's frames.  Goldens: tests/golden/enc_v1.json (make_enc_golden.py) and e2e_v1.json (make_e2e_golden.py), recorded from the unmodified reference; no oracle
+in between, and nothing of /root/reference is read here."""
+import json
+import os
+
+import pytest
+
+import _e2e
+import _enc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import xeve_amd
+    from xeve_amd import encode
+
+    xeve_amd.init(0)
+    return encode
+
+
+@pytest.fixture(scope="module")
+def yuv_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("enc_gpu_yuv")
+
+
+def _frames(yuv_dir, name, w, h, n, seed):
+    p = os.path.join(yuv_dir, name + ".yuv")
+    if not os.path.exists(p):
+        _e2e.make_yuv(p, w, h, n, seed)
+    return open(p, "rb").read()
+
+
+def _cfg(encode, w, h, cli, threads=1, **kw):
+    c = _enc.config(w, h, cli, threads)
+    return encode.config(w, h, qp=c.qp, keyint=c.keyint, bframes=c.bframes, closed_gop=c.closed_gop, preset=c.preset, threads=c.threads, ref=c.ref, **kw)
+
+
+def _run(encode, cfg, gops_data, frames):
+    enc = encode.BatchEncoder(cfg, len(gops_data), frames)
+    for g, d in enumerate(gops_data):
+        enc.push_gop(g, d)
+    out = enc.encode()
+    st = enc.stats()
+    enc.close()
+    return out, st
+
+
+E2E = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "e2e_v1.json")))
+SINGLE = ["tiny_ldb_fast", "tiny_ra_medium", "tiny_closed_gop", "tiny_ldb_fast_2threads", "moving_ra_medium", "moving_ldb_ref3", "moving_ra_b3_medium", "jumpy_ldb_fast",
+          "noise_allintra_medium", "moving_cif_ra_medium"]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_single_runs_on_the_gpu_reproduce_the_reference_bitstreams(name, hip, yuv_dir):
+    """one encoder run per clip (a batch of one): all-intra, low-delay B incl. several reference pictures, random access with 1 and 3 B pictures, closed GOP, two row
+    chains (second writer pass), CIF with partial CTUs"""
+    w, h, n, seed, cli = _e2e.CASES[name]
+    out, _ = _run(hip, _cfg(hip, w, h, cli), [_frames(yuv_dir, name, w, h, n, seed)], n)
+    assert (len(out[0]), _enc.md5(out[0])) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("name", sorted(_enc.BATCH_CASES))
+def test_batches_of_closed_gops_on_the_gpu(name, hip, yuv_dir):
+    """G closed GOPs in lockstep -- I, P-like and B pictures of different GOPs decided by the same launches (the stacked-picture form of the inter analysis) -- with
+    1 .. 8 row chains per picture: every GOP = the reference application's run over its frames (4 GOPs x 8 frames at 352x288 among them)"""
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    print(name, st)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+def test_one_chain_through_the_second_writer_pass_on_the_gpu(hip, yuv_dir):
+    w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]
+    f = _frames(yuv_dir, "tiny_closed_gop", w, h, n, seed)
+    out, _ = _run(hip, _cfg(hip, w, h, cli, always_second_pass=True), [f], n)
+    assert _enc.md5(out[0]) == E2E["tiny_closed_gop"]["md5"]
+
+
+def test_a_batch_is_the_same_as_its_gops_coded_alone(hip, yuv_dir):
+    """the lockstep axis must not leak between GOPs: GOP 1 of a batch of three = the same GOP as a batch of one"""
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES["gops_128x64_noise"]
+    data, fb = _frames(yuv_dir, "gops_128x64_noise", w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    alone, _ = _run(hip, _cfg(hip, w, h, cli, threads), [data[fb:2 * fb]], frames)
+    assert _enc.md5(alone[0]) == _enc.golden()["batches"]["gops_128x64_noise"]["per_gop"][1]["md5"]
+
+
+@pytest.mark.parametrize("name", sorted(_enc.BATCH_CASES_REAL))
+def test_batches_at_real_picture_sizes_on_the_gpu(name, hip, yuv_dir):
+    """>= 2 GOPs x 8 frames at 1920x1080 (8 row chains per picture: 16 chains in lockstep, the second writer pass over 510 CTUs per picture)"""
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES_REAL[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    print(name, st)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+def test_configurations_outside_the_supported_set_are_refused_by_the_library(hip):
+    import xeve_amd
+
+    for kw in (dict(w=130, h=64), dict(w=128, h=64, preset=2), dict(w=128, h=64, bframes=2)):
+        c = hip.config(kw.pop("w"), kw.pop("h"), **kw)
+        with pytest.raises(xeve_amd.XeveHipError):
+            hip.BatchEncoder(c, 1, 1)

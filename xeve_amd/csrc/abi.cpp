@@ -49,6 +49,10 @@ void xh_set_error(const char *fmt, ...)
 }
 bool xh_ready() { return g_device.load() >= 0; }
 uint32_t xh_generation() { return g_generation.load(); }
+static thread_local int t_vh = 0; // the virtual picture height of the batch this thread is walking (xh_common.h)
+int xh_vh() { return t_vh; }
+XhVhScope::XhVhScope(int vh) : prev(t_vh) { t_vh = vh; }
+XhVhScope::~XhVhScope() { t_vh = prev; }
 
 // the calling thread's last message; a thread that has none gets a copy of the process-wide last one (taken under the lock)
 extern "C" const char *xeve_hip_last_error(void)

@@ -1,0 +1,358 @@
+// xeve_amd/csrc/encode.hip -- the closed-GOP batch encoder on the device: the engine behind enc_host.h's frame loop + the C-ABI entry points xeve_hip_enc_*.
+//
+// What the reference does per picture (xeve_pic, src_base/xeve_enc.c:226-600) happens here for G pictures at once -- the same picture of G independent closed GOPs:
+//   begin_picture   8-bit original -> 10-bit planes (the application's conversion), maps cleared (xeve_pic_prepare :1220-1237)
+//   step            one CTU of every row chain of every picture: xeve_hip_mode_analyze_ctu_jobs (mode_analyze_lcu), then the writer on the chain's coder
+//                   (xeve_eco_tree, :152), whose state the chain's next CTU starts from (:138-139)
+//   end_picture     xeve_hip_deblock (:462), the slice data -- every CTU written again in raster order on a fresh coder + the tile's end (:466-560), or chain 0's own
+//                   bytes when the picture has one chain --, xeve_hip_picbuf_expand (xeve_pic_finish)
+// Everything a GOP needs stays in HBM: the frames (8 bit), the current original, the picture stores with their motion maps, the unit maps, the decided CTUs.  The
+// pictures of the batch are STACKED VERTICALLY (xh_common.h): GOP g's planes and maps lie g * vh luma rows below GOP 0's, so the intra analysis / the tree operations
+// address them with a picture index and element distances (pic_elems) and the inter analysis as one tall picture.
+#include <chrono>
+#include <memory>
+#include <string>
+#include "xh_common.h"
+#include "eco_lane.h"
+#include "enc_host.h"
+
+using namespace xenc;
+
+namespace {
+struct StepDesc { // the CTUs of one lockstep step (the same for every GOP): at most one per row chain
+    int n;
+    int t[8], x[8], y[8], lcu[8];
+};
+
+// frames: [G][F][w * h * 3 / 2] bytes; one thread per luma sample pair / chroma sample; blockIdx.y = GOP
+__global__ void k_enc_load(const uint8_t *__restrict__ frames, long gop_bytes, long frame_off, pel *__restrict__ y, pel *__restrict__ u, pel *__restrict__ v, int w, int h,
+                           long pic_l, long pic_c)
+{
+    const int      g = blockIdx.y;
+    const uint8_t *f = frames + g * gop_bytes + frame_off;
+    const long     nl = (long)w * h, nc = nl >> 2, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < nl) y[g * pic_l + i] = (pel)(f[i] << (BIT_DEPTH - 8)); // (the original planes have no padding: stride = width)
+    if(i < nc) u[g * pic_c + i] = (pel)(f[nl + i] << (BIT_DEPTH - 8)), v[g * pic_c + i] = (pel)(f[nl + nc + i] << (BIT_DEPTH - 8));
+}
+__global__ void k_enc_reset_chain(xeve_hip_sbac *__restrict__ states, int stride, int at, int G)
+{ // xeve_sbac_reset (xeve_eco.c:597-620) without sps_cm_init_flag: every model at 1/2
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if(g >= G) return;
+    xeve_hip_sbac s;
+    memset(&s, 0, sizeof(s));
+    s.range = 16384, s.code_bits = 11;
+    for(int i = 0; i < (int)(sizeof(s.ctx) / sizeof(s.ctx[0])); i++) s.ctx[i] = 512;
+    states[(long)g * stride + at] = s;
+}
+__global__ void k_enc_jobs(StepDesc D, int G, int T, xeve_hip_ctu_job *__restrict__ jobs)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= D.n * G) return;
+    const int i = c / G, g = c - i * G;
+    xeve_hip_ctu_job j;
+    j.x = D.x[i] * CTU, j.y = D.y[i] * CTU, j.sbac = g * T + D.t[i], j.pic = g;
+    jobs[c] = j;
+}
+// the decided CTUs of the step into the picture's store (the second writer pass reads them): 16 bytes per thread
+__global__ void k_enc_keep(const xeve_hip_ctu_data *__restrict__ out, xeve_hip_ctu_data *__restrict__ store, StepDesc D, int G, int f_lcu)
+{
+    constexpr int V = (int)(sizeof(xeve_hip_ctu_data) / 16);
+    const int     c = blockIdx.y, i = c / G, g = c - i * G;
+    const uint4  *s = reinterpret_cast<const uint4 *>(out + c);
+    uint4        *d = reinterpret_cast<uint4 *>(store + (long)g * f_lcu + D.lcu[i]);
+    for(int k = blockIdx.x * blockDim.x + threadIdx.x; k < V; k += gridDim.x * blockDim.x) d[k] = s[k];
+}
+static_assert(sizeof(xeve_hip_ctu_data) % 16 == 0, "CTU records are moved 16 bytes at a time");
+// the writer of the first pass: chain c writes the CTU it has just decided on its own coder; the bytes are kept only where they are the slice data (one chain per
+// picture: cap > 0), appended at pos[g]
+__global__ void __launch_bounds__(64) k_enc_write(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+                                                  const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic,
+                                                  const xeve_hip_ctu_job *__restrict__ jobs, int nchains, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= nchains) return;
+    const xeve_hip_ctu_job J = jobs[c];
+    xl::Sbac s = states[J.sbac];
+    const int at = cap ? pos[J.pic] : 0;
+    xl::Sink o = {cap ? bytes + (long)J.pic * cap + at : nullptr, cap ? (int)(cap - at) : 0, 0};
+    xl::eco_ctu(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
+    states[J.sbac] = s;
+    if(cap) pos[J.pic] = at + o.n;
+}
+// the second pass (xeve_enc.c:466-560): GOP g's CTUs [lcu0, lcu1) in raster order on the picture's own coder
+__global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__restrict__ store, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+                                                    const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, int G, int f_lcu, int w_lcu,
+                                                    int lcu0, int lcu1, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if(g >= G) return;
+    xl::Sbac s = states[g];
+    int at = pos[g];
+    for(int lcu = lcu0; lcu < lcu1; lcu++) {
+        xl::Sink o = {bytes + (long)g * cap + at, (int)(cap - at), 0};
+        xl::eco_ctu(E, s, store[(long)g * f_lcu + lcu], map_scu + g * map_pic, map_ipm + g * map_pic, map_tidx + g * map_pic, map_cu_mode + g * map_pic, (lcu % w_lcu) * CTU,
+                    (lcu / w_lcu) * CTU, &o);
+        at += o.n;
+    }
+    states[g] = s, pos[g] = at;
+}
+__global__ void __launch_bounds__(64) k_enc_tile_end(xeve_hip_sbac *__restrict__ states, int stride, int G, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if(g >= G) return;
+    xl::Sbac s = states[(long)g * stride];
+    const int at = pos[g];
+    xl::Sink o = {bytes + (long)g * cap + at, (int)(cap - at), 0};
+    xl::eco_tile_end(s, &o);
+    states[(long)g * stride] = s, pos[g] = at + o.n;
+}
+__global__ void k_enc_clear_cod(uint32_t *__restrict__ map_scu, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) map_scu[i] &= 0x7FFFFFFFu;
+}
+
+static const int16_t k_coef_l[16][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {0}, {0}, {0}, {0, 1, -5, 52, 20, -5, 1, 0}, {0}, {0}, {0}, {0, 2, -10, 40, 40, -10, 2, 0}, {0}, {0}, {0},
+                                        {0, 1, -5, 20, 52, -5, 1, 0}, {0}, {0}, {0}}; // xeve_tbl_mc_l_coeff (xeve_mc.c:39-57)
+static const int16_t k_coef_c8[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 52, 20, -4}, {-6, 46, 30, -6}, {-8, 40, 40, -8}, {-6, 30, 46, -6}, {-4, 20, 52, -4}, {-2, 10, 58, -2}};
+
+struct DevBuf {
+    void  *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if(p) (void)hipFree(p); }
+    bool need(size_t n)
+    {
+        if(bytes >= n) return true;
+        if(p) (void)hipFree(p), p = nullptr, bytes = 0;
+        if(hipMalloc(&p, n) != hipSuccess) { p = nullptr; return false; }
+        bytes = n;
+        return true;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+} // namespace
+
+struct xeve_hip_enc {
+    // ---- the engine (enc_host.h) --------------------------------------------------------------------------------------------------------------------------------
+    Param P;
+    int   G = 0, F = 0, T = 1, nslots = 0, w_scu = 0, h_scu = 0, w_lcu = 0, h_lcu = 0, f_lcu = 0, vh = 0, s_l = 0, s_c = 0;
+    long  org_l = 0, org_c = 0, pic_l = 0, pic_c = 0, map_pic = 0, frame_bytes = 0, slice_cap = 0;
+    hipStream_t st = nullptr;
+    DevBuf frames, org[3], slot_planes, slot_mv, slot_refi, scu, cum, ipm, tidx, store, states, rw_states, jobs, out, next_best, cost, ws, slice, pos;
+    std::vector<xeve_hip_sbac> h_states;
+    std::vector<int32_t>       h_pos;
+    std::vector<uint8_t>       h_bytes;
+    int16_t coef_c[32][4];
+    PicSetup S;
+    xeve_hip_refpic tab[2 * XEVE_HIP_MAX_REFP];
+    xl::EcoParams   E;
+    std::string     error;
+    int64_t n_steps = 0;
+    double  t_steps = 0, t_ends = 0;
+    std::vector<std::vector<uint8_t>> bitstreams;
+
+    bool fail(const std::string &m)
+    {
+        if(error.empty()) error = m;
+        return false;
+    }
+    bool hip_ok(hipError_t e, const char *what) { return e == hipSuccess ? true : fail(std::string(what) + ": " + hipGetErrorString(e)); }
+    bool rc_ok(int rc, const char *what) { return rc == XEVE_HIP_OK ? true : fail(std::string(what) + ": " + xeve_hip_last_error()); }
+    pel *slot_plane(int slot, int c) const // sample (0, 0) of GOP 0's picture in store `slot`
+    {
+        pel *base = slot_planes.as<pel>() + (size_t)slot * ((size_t)G * (pic_l + 2 * pic_c));
+        return c == 0 ? base + (size_t)PAD_L * s_l + PAD_L : base + (size_t)G * pic_l + (size_t)(c - 1) * G * pic_c + (size_t)PAD_C * s_c + PAD_C;
+    }
+    int16_t *slot_map_mv(int slot) const { return slot_mv.as<int16_t>() + (size_t)slot * G * map_pic * 4; }
+    int8_t  *slot_map_refi(int slot) const { return slot_refi.as<int8_t>() + (size_t)slot * G * map_pic * 2; }
+
+    bool create(const Param &p, int ngops, int nframes)
+    {
+        P = p, G = ngops, F = nframes;
+        w_scu = P.w >> 2, h_scu = P.h >> 2, w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU, f_lcu = w_lcu * h_lcu, T = std::min(P.threads, h_lcu);
+        vh = (P.h + 2 * PAD_L + 63) & ~63, s_l = P.w + 2 * PAD_L, s_c = P.w / 2 + 2 * PAD_C;
+        org_l = (long)vh * P.w, org_c = (long)(vh / 2) * (P.w / 2), pic_l = (long)vh * s_l, pic_c = (long)(vh / 2) * s_c, map_pic = (long)(vh / 4) * w_scu;
+        frame_bytes = (long)P.w * P.h * 3 / 2, slice_cap = frame_bytes + 4096;
+        if((double)G * pic_l >= 2147483648.0) return fail("too many GOPs for one batch at this picture size: the stacked planes must stay below 2^31 samples");
+        nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
+        if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
+        memset(coef_c, 0, sizeof(coef_c));
+        for(int i = 0; i < 8; i++) memcpy(coef_c[4 * i], k_coef_c8[i], sizeof(k_coef_c8[i])); // xeve_tbl_mc_c_coeff (xeve_mc.c:59-93)
+        if(!hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate")) return false;
+        const size_t nst = (size_t)G * T;
+        bool ok = frames.need((size_t)G * F * frame_bytes) && org[0].need((size_t)G * org_l * 2) && org[1].need((size_t)G * org_c * 2) && org[2].need((size_t)G * org_c * 2) &&
+                  slot_planes.need((size_t)nslots * G * (pic_l + 2 * pic_c) * 2) && slot_mv.need((size_t)nslots * G * map_pic * 8) && slot_refi.need((size_t)nslots * G * map_pic * 2) &&
+                  scu.need((size_t)G * map_pic * 4) && cum.need((size_t)G * map_pic * 4) && ipm.need((size_t)G * map_pic) && tidx.need((size_t)G * map_pic) &&
+                  states.need(nst * sizeof(xeve_hip_sbac)) && rw_states.need((size_t)G * sizeof(xeve_hip_sbac)) && jobs.need(nst * sizeof(xeve_hip_ctu_job)) &&
+                  out.need(nst * sizeof(xeve_hip_ctu_data)) && next_best.need(nst * sizeof(xeve_hip_sbac)) && cost.need(nst * 8) && slice.need((size_t)G * slice_cap) &&
+                  pos.need((size_t)G * 4) && (T == 1 && !(P_reserved0 & 1) ? true : store.need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data)));
+        if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
+        // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
+        // the pictures must say "not coded"
+        for(DevBuf *b : {&org[0], &org[1], &org[2], &slot_planes, &slot_mv, &scu, &cum, &ipm, &tidx})
+            if(!hip_ok(hipMemsetAsync(b->p, 0, b->bytes, st), "hipMemset")) return false;
+        if(!hip_ok(hipMemsetAsync(slot_refi.p, 0xFF, slot_refi.bytes, st), "hipMemset")) return false;
+        memset(&E, 0, sizeof(E));
+        for(int l = 4; l <= LOG2_CTU; l++)
+            if(!rc_ok(xh_get_scan(l, l, &E.scan[l]), "scan tables")) return false;
+        h_states.resize(G), h_pos.resize(G);
+        return hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+    }
+    int P_reserved0 = 0; // bit 0: always run the second writer pass (tests)
+    ~xeve_hip_enc()
+    {
+        if(st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
+    }
+
+    void begin_picture(const PicSetup &setup)
+    {
+        S = setup;
+        if(!error.empty()) return;
+        const long n = (long)P.w * P.h;
+        k_enc_load<<<dim3((unsigned)((n + 255) / 256), G), 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(),
+                                                                         org[1].as<pel>(), org[2].as<pel>(), P.w, P.h, org_l, org_c);
+        hip_ok(hipMemsetAsync(scu.p, 0, scu.bytes, st), "hipMemset"), hip_ok(hipMemsetAsync(cum.p, 0, cum.bytes, st), "hipMemset"); // xeve_pic_prepare (:1236-1237)
+        hip_ok(hipMemsetAsync(slot_map_mv(S.cur_slot), 0, (size_t)G * map_pic * 8, st), "hipMemset"); // (:1220-1225)
+        hip_ok(hipMemsetAsync(slot_map_refi(S.cur_slot), 0xFF, (size_t)G * map_pic * 2, st), "hipMemset");
+        hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset");
+        memset(tab, 0, sizeof(tab));
+        if(S.slice_type != ST_I) {
+            for(int l = 0; l < 2; l++)
+                for(int r = 0; r < S.nref[l]; r++) {
+                    xeve_hip_refpic &e = tab[r * 2 + l];
+                    e.y = slot_plane(S.ref[r][l].slot, 0), e.u = slot_plane(S.ref[r][l].slot, 1), e.v = slot_plane(S.ref[r][l].slot, 2), e.poc = S.ref[r][l].poc;
+                }
+            if(S.slice_type == ST_P) tab[1] = tab[0]; // (P slices never read list 1; the table stays addressable)
+            S.ti.refp = tab, S.ti.s_ref_l = s_l, S.ti.s_ref_c = s_c, S.ti.map_mv = slot_map_mv(S.cur_slot), S.ti.map_refi = slot_map_refi(S.cur_slot);
+            S.ti.col_mv0 = slot_map_mv(S.ref[0][0].slot), S.ti.col_mv1 = S.slice_type == ST_B ? slot_map_mv(S.ref[0][1].slot) : S.ti.col_mv0;
+            S.ti.coef_l = k_coef_l, S.ti.coef_c = coef_c;
+        }
+        const size_t need = xeve_hip_mode_analyze_ctu_workspace(G * T, &S.tp, S.slice_type == ST_I ? nullptr : &S.ti, P.w, P.w / 2);
+        if(need == 0) fail(std::string("the CTU walk refuses the picture's parameters: ") + xeve_hip_last_error());
+        else if(!ws.need(need)) fail("not enough device memory for the CTU walk's workspace");
+        E.idc = 1, E.slice_type = S.slice_type, E.log2_ctu = LOG2_CTU, E.pic_w = P.w, E.pic_h = P.h, E.w_scu = w_scu, E.num_refp[0] = S.ep.num_refp[0], E.num_refp[1] = S.ep.num_refp[1];
+    }
+    void reset_chain(int t)
+    {
+        if(error.empty()) k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st>>>(states.as<xeve_hip_sbac>(), T, t, G);
+    }
+    bool keeps_store() const { return store.p != nullptr; }
+    void step(const ChainCtu *c, int n)
+    {
+        if(!error.empty()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        StepDesc D;
+        memset(&D, 0, sizeof(D));
+        D.n = n;
+        for(int i = 0; i < n; i++) D.t[i] = c[i].t, D.x[i] = c[i].x, D.y[i] = c[i].y, D.lcu[i] = c[i].lcu;
+        const int nch = n * G;
+        k_enc_jobs<<<(nch + 255) / 256, 256, 0, st>>>(D, G, T, jobs.as<xeve_hip_ctu_job>());
+        const pel *o[3] = {org[0].as<pel>(), org[1].as<pel>(), org[2].as<pel>()};
+        pel       *m[3] = {slot_plane(S.cur_slot, 0), slot_plane(S.cur_slot, 1), slot_plane(S.cur_slot, 2)};
+        const int64_t pe[5] = {org_l, org_c, pic_l, pic_c, map_pic};
+        if(!rc_ok(xeve_hip_mode_analyze_ctu_jobs(o, P.w, P.w / 2, m, s_l, s_c, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(), pe,
+                                                 states.as<xeve_hip_sbac>(), G * T, &S.tp, S.slice_type == ST_I ? nullptr : &S.ti, jobs.as<xeve_hip_ctu_job>(), nch,
+                                                 out.as<xeve_hip_ctu_data>(), next_best.as<xeve_hip_sbac>(), cost.as<double>(), ws.p, ws.bytes, st),
+                  "xeve_hip_mode_analyze_ctu_jobs"))
+            return;
+        if(keeps_store()) k_enc_keep<<<dim3(4, nch), 256, 0, st>>>(out.as<xeve_hip_ctu_data>(), store.as<xeve_hip_ctu_data>(), D, G, f_lcu);
+        k_enc_write<<<(nch + 63) / 64, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(),
+                                                    cum.as<uint32_t>(), map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), T == 1 ? slice_cap : 0, pos.as<int32_t>());
+        hip_ok(hipGetLastError(), "step kernels");
+        n_steps++, t_steps += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void end_picture(bool rewrite, std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins)
+    {
+        slice_data.clear(), bins.clear();
+        if(!error.empty()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        for(int g = 0; g < G; g++) // xeve_loop_filter
+            if(!rc_ok(xeve_hip_deblock(slot_plane(S.cur_slot, 0) + (size_t)g * pic_l, slot_plane(S.cur_slot, 1) + (size_t)g * pic_c, slot_plane(S.cur_slot, 2) + (size_t)g * pic_c, s_l,
+                                       s_c, scu.as<uint32_t>() + (size_t)g * map_pic, cum.as<uint32_t>() + (size_t)g * map_pic, tidx.as<uint8_t>() + (size_t)g * map_pic,
+                                       slot_map_refi(S.cur_slot) + (size_t)g * map_pic * 2, slot_map_mv(S.cur_slot) + (size_t)g * map_pic * 4, &S.dp, st),
+                      "xeve_hip_deblock"))
+                return;
+        xeve_hip_sbac *fin = states.as<xeve_hip_sbac>();
+        int            stride = T;
+        if(rewrite) {
+            if(!keeps_store()) { fail("the second writer pass needs the CTU store"); return; }
+            const long n = (long)G * map_pic;
+            k_enc_clear_cod<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(scu.as<uint32_t>(), n); // MCU_CLR_COD over the picture (:466-468)
+            hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset");
+            fin = rw_states.as<xeve_hip_sbac>(), stride = 1;
+            k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st>>>(fin, 1, 0, G);
+            for(int row = 0; row < h_lcu; row++)
+                k_enc_rewrite<<<(G + 63) / 64, 64, 0, st>>>(store.as<xeve_hip_ctu_data>(), fin, E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(),
+                                                            map_pic, G, f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+        }
+        k_enc_tile_end<<<(G + 63) / 64, 64, 0, st>>>(fin, stride, G, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+        for(int g = 0; g < G; g++) // xeve_pic_finish: the picture becomes a reference
+            if(!rc_ok(xeve_hip_picbuf_expand(slot_plane(S.cur_slot, 0) + (size_t)g * pic_l, slot_plane(S.cur_slot, 1) + (size_t)g * pic_c, slot_plane(S.cur_slot, 2) + (size_t)g * pic_c,
+                                             s_l, s_c, P.w, P.h, P.w / 2, P.h / 2, PAD_L, PAD_C, 1, st),
+                      "xeve_hip_picbuf_expand"))
+                return;
+        if(!hip_ok(hipMemcpy2DAsync(h_states.data(), sizeof(xeve_hip_sbac), fin, sizeof(xeve_hip_sbac) * (size_t)stride, sizeof(xeve_hip_sbac), G, hipMemcpyDeviceToHost, st), "copy states") ||
+           !hip_ok(hipMemcpyAsync(h_pos.data(), pos.p, (size_t)G * 4, hipMemcpyDeviceToHost, st), "copy sizes") || !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+            return;
+        slice_data.resize(G), bins.resize(G);
+        for(int g = 0; g < G; g++) {
+            if(h_pos[g] < 0 || h_pos[g] > slice_cap) { fail("a picture's slice data outgrew its buffer"); slice_data.clear(), bins.clear(); return; }
+            slice_data[g].resize(h_pos[g]);
+            if(h_pos[g] && !hip_ok(hipMemcpyAsync(slice_data[g].data(), slice.as<uint8_t>() + (size_t)g * slice_cap, h_pos[g], hipMemcpyDeviceToHost, st), "copy slice data")) {
+                slice_data.clear(), bins.clear();
+                return;
+            }
+            bins[g] = h_states[g].bin_counter;
+        }
+        if(!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) slice_data.clear(), bins.clear();
+        t_ends += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+// ---- C-ABI ---------------------------------------------------------------------------------------------------------------------------------------------------------
+extern "C" xeve_hip_enc *xeve_hip_enc_create(const xeve_hip_enc_config *cfg, int ngops, int frames)
+{
+    if(!xh_ready()) { xh_set_error("xeve_hip_init() has not been called"); return nullptr; }
+    if(!cfg || ngops < 1 || frames < 1) { xh_set_error("xeve_hip_enc_create: invalid argument"); return nullptr; }
+    Param P;
+    if(!P.finish(*cfg)) { xh_set_error("xeve_hip_enc_create: %s", P.error.c_str()); return nullptr; }
+    std::unique_ptr<xeve_hip_enc> e(new xeve_hip_enc);
+    e->P_reserved0 = cfg->reserved[0];
+    if(!e->create(P, ngops, frames)) { xh_set_error("xeve_hip_enc_create: %s", e->error.c_str()); return nullptr; }
+    return e.release();
+}
+extern "C" void xeve_hip_enc_delete(xeve_hip_enc *e) { delete e; }
+extern "C" int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device)
+{
+    XH_ENTER();
+    XH_REQUIRE(e && yuv && gop >= 0 && gop < e->G && frame >= 0 && frame < e->F);
+    XH_HIP(hipMemcpyAsync(e->frames.as<uint8_t>() + ((size_t)gop * e->F + frame) * e->frame_bytes, yuv, e->frame_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->st));
+    XH_HIP(hipStreamSynchronize(e->st));
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_encode(xeve_hip_enc *e)
+{
+    XH_ENTER();
+    XH_REQUIRE(e);
+    e->error.clear(), e->n_steps = 0, e->t_steps = e->t_ends = 0;
+    BatchEncoder<xeve_hip_enc> enc(*e, e->P, e->G, e->F);
+    enc.always_rewrite = (e->P_reserved0 & 1) != 0;
+    const int rc = enc.run(e->bitstreams);
+    if(!e->error.empty()) { xh_set_error("xeve_hip_enc_encode: %s", e->error.c_str()); return XEVE_HIP_ERR_DEVICE; }
+    if(rc != 0) { xh_set_error("xeve_hip_enc_encode: %s", enc.error.c_str()); return XEVE_HIP_ERR_ARG; }
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes)
+{
+    XH_REQUIRE(e && data && bytes && gop >= 0 && gop < (int)e->bitstreams.size());
+    *data = e->bitstreams[gop].data(), *bytes = e->bitstreams[gop].size();
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_stats(xeve_hip_enc *e, int64_t *ctu_steps, double *step_seconds, double *picture_end_seconds)
+{
+    XH_REQUIRE(e);
+    if(ctu_steps) *ctu_steps = e->n_steps;
+    if(step_seconds) *step_seconds = e->t_steps;
+    if(picture_end_seconds) *picture_end_seconds = e->t_ends;
+    return XEVE_HIP_OK;
+}

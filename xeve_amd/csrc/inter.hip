@@ -583,12 +583,14 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
 // temporal direct mode.  One thread per CU; the maps are [unit][list][x, y] as the reference keeps them.
 __global__ void k_inter_candidates(const uint32_t *__restrict__ map_scu, const uint8_t *__restrict__ map_tidx, const int16_t *__restrict__ map_mv,
                                    const int16_t *__restrict__ col0, const int16_t *__restrict__ col1, int w_scu, int scuw, int scuh, int isb,
-                                   xeve_hip_inter_job *__restrict__ jobs, int njobs)
+                                   xeve_hip_inter_job *__restrict__ jobs, int njobs, int vh)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
     xeve_hip_inter_job J = jobs[j];
-    const int x_scu = J.x >> 2, y_scu = J.y >> 2, scup = y_scu * w_scu + x_scu;
+    // (a batch of pictures stacked vertically, xh_common.h: the maps are stacked like the planes, so the unit addresses follow from y as it is; only "is there a row
+    // above" asks for the row inside the job's own picture)
+    const int x_scu = J.x >> 2, y_scu = J.y >> 2, scup = y_scu * w_scu + x_scu, y_in_pic = (J.y - xh_vh_base(J.y, vh)) >> 2;
     auto tile = [&](int at) { return map_tidx ? (int)map_tidx[at] : 0; };
     const int t = tile(scup);
     bool ok[3] = {false, false, false};
@@ -597,7 +599,7 @@ __global__ void k_inter_candidates(const uint32_t *__restrict__ map_scu, const u
         const uint32_t m = map_scu[at[0]];
         ok[0] = !((m >> 15) & 1) && (m >> 31) && tile(at[0]) == t && !((m >> 26) & 1); // !IF && COD && same tile && !IBC
     }
-    if(y_scu > 0) {
+    if(y_in_pic > 0) {
         const uint32_t m = map_scu[at[1]];
         ok[1] = !((m >> 15) & 1) && tile(at[1]) == t && !((m >> 26) & 1); // (no COD test for the unit above, :681-684)
         if(x_scu + scuw < w_scu) {
@@ -632,7 +634,7 @@ extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t 
     if(njobs == 0) return XEVE_HIP_OK;
     XH_REQUIRE(map_scu && map_mv && col_mv0 && jobs && (slice_type == 1 || col_mv1));
     k_inter_candidates<<<(njobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, 1 << (log2_cuw - 2), 1 << (log2_cuh - 2),
-                                                                            slice_type == 0, jobs, njobs);
+                                                                            slice_type == 0, jobs, njobs, xh_vh());
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -348,7 +348,8 @@ __device__ __constant__ int8_t c_pat_qpel[8][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, 
 
 // stage 0: centre = mvi; stage 1: centre = the half-pel winner stored in res[j].mv
 __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, int s_org, int blk_elems, int bi,
-                            const xeve_hip_me_result *__restrict__ res, xeve_hip_mc_job *__restrict__ mc, int per_plane, const unsigned char *__restrict__ job_plane)
+                            const xeve_hip_me_result *__restrict__ res, xeve_hip_mc_job *__restrict__ mc, int per_plane, const unsigned char *__restrict__ job_plane,
+                            int vh)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= njobs * cnt) return;
@@ -356,9 +357,10 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
     const xeve_hip_spel_job jb = jobs[j];
     const int mvx = stage ? res[j].mv[0] : jb.mvi[0], mvy = stage ? res[j].mv[1] : jb.mvi[1];
     const int8_t(*pat)[2] = stage ? c_pat_qpel : c_pat_hpel;
-    const int mx = mvx + (jb.x << 2) + pat[i][0], my = mvy + (jb.y << 2) + pat[i][1]; // quarter pel, picture coordinates
+    const int mx = mvx + (jb.x << 2) + pat[i][0], my = mvy + (jb.y << 2) + pat[i][1]; // quarter pel, picture coordinates (of the stacked batch: jb.y carries the picture)
     xeve_hip_mc_job m;
     m.gmv_x = mx << 2, m.gmv_y = my << 2; // 1/16 pel, as the reference passes (mv_x << 2), xeve_pinter.c:608
+    (void)vh;
     m.pred_off = bi ? jb.org_off : jb.y * s_org + jb.x;
     m.frac = ((mx & 3) != 0 ? 1 : 0) | ((my & 3) != 0 ? 2 : 0);
     if(per_plane) m.frac |= xh_plane_of_job(job_plane, per_plane, j) << 3; // the job's reference picture (PlaneTab)
@@ -372,12 +374,13 @@ struct SpelBits {
     const unsigned char *job_plane;
 };
 __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, xeve_hip_spel_params P,
-                              const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res, SpelBits sb)
+                              const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res, SpelBits sb, int vh)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
     if(sb.per_plane) P.refi_bits = sb.refi_bits[xh_plane_of_job(sb.job_plane, sb.per_plane, j)];
-    const xeve_hip_spel_job jb = jobs[j];
+    xeve_hip_spel_job jb = jobs[j];
+    jb.y -= xh_vh_base(jb.y, vh); // (the predictor jb.gmvp is in the picture's own coordinates)
     xeve_hip_me_result r;
     if(stage) r = res[j];
     else r.mv[0] = jb.mvi[0], r.mv[1] = jb.mvi[1], r.cost = 0xFFFFFFFFu, r.beststep = 0, r.best_mv_bits = 0;
@@ -435,15 +438,16 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
     int32_t         *sad = reinterpret_cast<int32_t *>(mc + (size_t)njobs * 8);
     const pel *cmp = P.bi ? org_bi : org0;
     const int  s_c = P.bi ? w : s_org;
+    const int  vh = xh_vh();
     for(int stage = 0; stage < 2; stage++) {
         const int cnt = stage ? P.qpel_cnt : P.hpel_cnt;
         if(cnt == 0) break;
         const int items = njobs * cnt;
-        k_spel_make<<<(items + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, s_org, w * h, P.bi, results, mc, sb.per_plane, sb.job_plane);
+        k_spel_make<<<(items + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, s_org, w * h, P.bi, results, mc, sb.per_plane, sb.job_plane, vh);
         XH_HIP(hipGetLastError());
         int rc = mc_launch<8, 1>(ref0, s_ref, nullptr, 0, mc, items, w, h, bit_depth, &coef[0][0], st, cmp, s_c, sad, pt.n ? &pt : nullptr);
         if(rc != XEVE_HIP_OK) return rc;
-        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, extra, sad, results, sb);
+        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, extra, sad, results, sb, vh);
         XH_HIP(hipGetLastError());
     }
     return XEVE_HIP_OK;
@@ -458,6 +462,7 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
 #define XH_MAX_REF 8
 struct CuMcK {
     int pic_w, pic_h, w, h, cw, ch, wfac, hfac, nref[2], poc[2][XH_MAX_REF];
+    int vh; // a batch of pictures stacked vertically (xh_common.h): 0 = one picture
 };
 
 __global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int njobs, CuMcK P, xeve_hip_mc_job *__restrict__ jl,
@@ -466,7 +471,8 @@ __global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int nj
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
     const xeve_hip_cu_mc_job J = jobs[j];
-    const int x4 = J.x << 2, y4 = J.y << 2, w4 = P.w << 2, h4 = P.h << 2;
+    const int yb = xh_vh_base(J.y, P.vh); // the vectors are clipped against the job's own picture; the rows of its picture in the stack are added to the positions below
+    const int x4 = J.x << 2, y4 = (J.y - yb) << 2, w4 = P.w << 2, h4 = P.h << 2;
     const int min_c = -(128 << 2), max_x = (P.pic_w - 1 + 128) << 2, max_y = (P.pic_h - 1 + 128) << 2; // MAX_CU_SIZE margin
     int  mvt[2][2];
     bool valid[2];
@@ -488,7 +494,7 @@ __global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int nj
 #pragma unroll
     for(int l = 0; l < 2; l++) {
         const bool on = l == 0 ? valid[0] : use1;
-        const int  gx = (x4 + mvt[l][0]) << 2, gy = (y4 + mvt[l][1]) << 2;
+        const int  gx = (x4 + mvt[l][0]) << 2, gy = (y4 + (yb << 2) + mvt[l][1]) << 2;
         xeve_hip_mc_job a, c;
         a.gmv_x = gx, a.gmv_y = gy, a.pred_off = j * P.w * P.h;
         a.frac = ((J.mv[l][0] & 3) ? 1 : 0) | ((J.mv[l][1] & 3) ? 2 : 0);
@@ -557,7 +563,7 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
     if(njobs == 0) return XEVE_HIP_OK;
     const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT
     CuMcK P;
-    P.pic_w = pic_w, P.pic_h = pic_h, P.w = w, P.h = h, P.cw = w >> ws, P.ch = h >> hs, P.wfac = 2 / (ws + 1), P.hfac = 2 / (hs + 1);
+    P.vh = xh_vh(), P.pic_w = pic_w, P.pic_h = pic_h, P.w = w, P.h = h, P.cw = w >> ws, P.ch = h >> hs, P.wfac = 2 / (ws + 1), P.hfac = 2 / (hs + 1);
     P.nref[0] = num_refp0, P.nref[1] = num_refp1;
     const int nmax = num_refp0 > num_refp1 ? num_refp0 : num_refp1;
     for(int r = 0; r < XH_MAX_REF; r++)

@@ -545,7 +545,11 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         const int q = uni(xh_plane_of_job(pl.job_plane, pl.per_plane, j));
         ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q], P.reserved = (P.reserved & 0xFF) | (pl.refi[q] << 8);
     }
-    const xeve_hip_epzs_job e = jobs[j];
+    xeve_hip_epzs_job e = jobs[j];
+    if(pl.vh) { // a batch of pictures stacked vertically (xh_common.h): from here on the job's own picture, in its own coordinates
+        const int yb = uni(xh_vh_base(e.y, pl.vh));
+        org0 += (long)yb * s_org, ref0 += (long)yb * s_ref, e.y -= yb;
+    }
     if(e.x < 0) { // job switched off
         EpzsState z;
         z.cost = 0xFFFFFFFFu, z.mv[0] = e.mv_start[0], z.mv[1] = e.mv_start[1], z.tmpstep = 0, z.searches = 0, z.mot_bits = 0;
@@ -634,14 +638,14 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
     if(units && lane == 0) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)nev * (S * S / 64));
 }
 
-__global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj)
+__global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj, int vh)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= n) return;
     const xeve_hip_epzs_job e = jobs[j];
     xeve_hip_spel_job s;
-    s.x = e.x, s.y = e.y, s.org_off = e.org_off;
-    s.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), s.gmvp[1] = (int16_t)(e.mvp[1] + (e.y << 2));
+    s.x = e.x, s.y = e.y, s.org_off = e.org_off; // (y keeps the picture of a stacked batch; the predictor is in the picture's own coordinates, 16 bits)
+    s.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), s.gmvp[1] = (int16_t)(e.mvp[1] + ((e.y - xh_vh_base(e.y, vh)) << 2));
     s.mvi[0] = st[j].mv[0], s.mvi[1] = st[j].mv[1];
     sj[j] = s;
 }
@@ -700,6 +704,7 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         pl = *planes;
         for(int i = pl.n; i < XH_MAX_PLANES; i++) pl.ref[i] = pl.ref[0], pl.refi_bits[i] = pl.refi_bits[0], pl.range[i] = pl.range[0], pl.refi[i] = pl.refi[0];
     }
+    pl.vh = xh_vh();
     XH_REQUIRE(workspace_bytes >= xeve_hip_me_epzs_workspace(njobs) && ((uintptr_t)workspace & 15) == 0);
     XH_REQUIRE(params->me.bi == 0 || params->me.bi == 1);
     XH_REQUIRE(log2w == log2h && log2w >= 3 && log2w <= 6 && bit_depth >= 8 && bit_depth <= 14 && (params->me.bi == 0 || org_bi != nullptr));
@@ -750,7 +755,7 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         XH_HIP(hipGetLastError());
         return XEVE_HIP_OK;
     }
-    k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj);
+    k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj, pl.vh);
     XH_HIP(hipGetLastError());
     xeve_hip_spel_params SP;
     SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;

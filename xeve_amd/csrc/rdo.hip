@@ -376,7 +376,8 @@ static RdoLayout rdo_layout(int njobs, int n0, int n1, int nstates, size_t rec_l
     L.mc = take(n * sizeof(xeve_hip_cu_mc_job)), L.rl = take(n * sizeof(xeve_hip_job)), L.rc = take(n * sizeof(xeve_hip_job));
     L.est_idx = take(n * 4), L.est = take((size_t)nstates * sizeof(xeve_hip_rdoq_est_full));
     L.pred[0] = take(n * n0 * 2), L.pred[1] = take(n * n1 * 2 + 8), L.pred[2] = take(n * n1 * 2 + 8);
-    L.rec[0] = take(rec_l * 2), L.rec[1] = take(rec_c * 2 + 8), L.rec[2] = take(rec_c * 2 + 8);
+    (void)rec_l, (void)rec_c;
+    L.rec[0] = take(n * n0 * 2), L.rec[1] = take(n * n1 * 2 + 8), L.rec[2] = take(n * n1 * 2 + 8); // dense blocks (nothing reads them: pinter_residue_rdo's reconstruction only feeds the SSD)
     for(int k = 0; k < 3; k++) L.nnz[k] = take(n * 4), L.ssd[k] = take(n * 16);
     L.cand = take(n * sizeof(Cand)), L.prev = take(n * sizeof(xeve_hip_sbac));
     const size_t kinds = rdo_use_spec(njobs) ? 8 : 4; // whole-CU job kinds per candidate (the one-round form adds 4 chain lanes with 4 counts each)
@@ -453,7 +454,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
         XH_REQUIRE(q >= 0 && q <= 51 + 6 * (bd - 8)); // MAX_QUANT + the bit-depth offset
         rc_ = xeve_hip_residual_rdoq_dev(org[k], k ? s_org_c : s_org_l, pred[k], 1 << lw[k], k ? rc : rl, njobs, lw[k], lh[k], bd, q, k_q_scale[q % 6],
                                          k_dq_scale[q % 6] << (q / 6), p->slice_type == 2, p->lambda[k], k, p->tool_iqt, est, est_idx, cf[k], rec[k],
-                                         k ? s_org_c : s_org_l, nnz[k], (int64_t *)ssd[k], stream);
+                                         -(1 << lw[k]), nnz[k], (int64_t *)ssd[k], stream);
         if(rc_ != XEVE_HIP_OK) return rc_;
     }
     // the decision

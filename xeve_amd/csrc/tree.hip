@@ -57,7 +57,7 @@ struct TreeK {
     const int16_t              *icoef;                         // dense blocks of the node's analysis: Y of all chains, then U, then V
     const pel                  *irec;
     // P / B slices
-    int                         inter, ecu_depth, s_org_l, pad_;
+    int                         inter, ecu_depth, s_org_l, vh; // vh: P / B chains of several pictures -- the batch as one tall picture for the inter analysis (xh_common.h)
     int16_t                   (*map_mv)[2][2];
     int8_t                    (*map_refi)[2];
     xeve_hip_inter_job         *ejobs;                         // [nchains]
@@ -180,8 +180,9 @@ __device__ static void update_map(const TreeK &K, int pic, const CtuData *d, int
         const int j = t / w, i = t - j * w, g = ((y >> 2) + j) * K.w_scu + (x >> 2) + i, u = j * n + i;
         ms[g] = d->map_scu[u], mc[g] = d->map_cu_mode[u], mi[g] = d->ipm[0][u];
         if(K.inter) {
-            for(int k = 0; k < 4; k++) (&K.map_mv[g][0][0])[k] = (&d->mv[u][0][0])[k];
-            K.map_refi[g][0] = d->refi[u][0], K.map_refi[g][1] = d->refi[u][1];
+            const long gm = (long)pic * K.map_pic + g;
+            for(int k = 0; k < 4; k++) (&K.map_mv[gm][0][0])[k] = (&d->mv[u][0][0])[k];
+            K.map_refi[gm][0] = d->refi[u][0], K.map_refi[gm][1] = d->refi[u][1];
         }
     }
 }
@@ -254,9 +255,9 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
         if(K.inter) {
             xeve_hip_inter_job ej;
             memset(&ej, 0, sizeof(ej));
-            ej.x = jx, ej.y = jy, ej.sbac = c; // ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288)
+            ej.x = jx, ej.y = jy + J.pic * K.vh, ej.sbac = c; // ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288)
             K.ejobs[c] = ej;
-            K.sjobs[c].off1 = jy * K.s_org_l + jx, K.sjobs[c].off2 = c * cu * cu;
+            K.sjobs[c].off1 = (jy + J.pic * K.vh) * K.s_org_l + jx, K.sjobs[c].off2 = c * cu * cu;
             nd->try_intra = 0, nd->cu_mode = 0, nd->unit_cost = MAX_COST;
         }
         sh[0] = active, sh[1] = leaf, sh[2] = boundary, sh[3] = x0, sh[4] = y0;
@@ -643,7 +644,19 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     XH_REQUIRE(tree_params_ok(p));
     XH_REQUIRE(org[0] && mod[0] && (p->ip.chroma_format_idc == 0 || (org[1] && org[2] && mod[1] && mod[2])));
     if(p->ip.slice_type == 2) I = nullptr;
-    else XH_REQUIRE(tree_inter_ok(p, I) && pic_elems == nullptr); // (the inter analysis takes one set of pictures per call)
+    else XH_REQUIRE(tree_inter_ok(p, I));
+    // P / B chains of several pictures: the inter analysis addresses the batch as one tall picture (xh_common.h), so the pictures must be stacked vertically -- every
+    // plane and map of picture p exactly p * vh luma rows below picture 0's, vh a multiple of 64 that covers the padded reference pictures
+    int vh = 0;
+    if(I && pic_elems) {
+        const int ws_ = p->ip.chroma_format_idc <= 2, hs_ = p->ip.chroma_format_idc <= 1;
+        XH_REQUIRE(s_org_l > 0 && pic_elems[0] > 0 && pic_elems[0] % s_org_l == 0);
+        vh = (int)(pic_elems[0] / s_org_l);
+        XH_REQUIRE(vh % 64 == 0 && vh >= p->pic_h && pic_elems[2] == (int64_t)vh * s_mod_l && pic_elems[4] == (int64_t)(vh >> 2) * p->ip.w_scu);
+        XH_REQUIRE(s_mod_l == I->s_ref_l && s_mod_c == I->s_ref_c);
+        if(p->ip.chroma_format_idc) XH_REQUIRE(pic_elems[1] == (int64_t)(vh >> hs_) * s_org_c && pic_elems[3] == (int64_t)(vh >> hs_) * s_mod_c);
+        (void)ws_;
+    }
     if(nchains == 0) return XEVE_HIP_OK;
     const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c);
     XH_REQUIRE(workspace_bytes >= L.total);
@@ -662,7 +675,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     K.tdepth = (SbacState *)(W + L.tdepth), K.sbest = (SbacState *)(W + L.sbest), K.best = (CtuData *)(W + L.best), K.temp = (CtuData *)(W + L.temp);
     K.ijobs = (xeve_hip_intra_job *)(W + L.ijobs), K.ires = (xeve_hip_intra_result *)(W + L.ires), K.icoef = (int16_t *)(W + L.icoef), K.irec = (pel *)(W + L.irec);
     if(I) {
-        K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
+        K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.vh = vh, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
         K.ejobs = (xeve_hip_inter_job *)(W + L.ejobs), K.sjobs = (xeve_hip_job *)(W + L.sjobs), K.eres = (xeve_hip_inter_result *)(W + L.eres), K.ecoef = (int16_t *)(W + L.ecoef);
         for(int c = 0; c < 3; c++) K.erec[c] = (pel *)(W + L.erec[c]);
         K.esatd = (int32_t *)(W + L.esatd), K.enext = (SbacState *)(W + L.enext);
@@ -700,6 +713,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
             }
             else if(wk.kind[i] == AN_INTER) {
                 const xeve_hip_inter_params ep = level_inter_params(I, log2);
+                XhVhScope tall(vh);
                 rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
                                                p->ip.slice_type, K.ejobs, nchains, stream);
                 if(rc == XEVE_HIP_OK)

@@ -88,7 +88,22 @@ struct XhSearchPlanes {
     int        refi_bits[XH_MAX_PLANES], range[XH_MAX_PLANES], refi[XH_MAX_PLANES]; // refi: me_raster's step scales with it
     int        n, per_plane;
     const unsigned char *job_plane; // device array or NULL: the plane of job j when the jobs are not laid out plane by plane
+    int        vh;                  // the batch's virtual picture height (below); 0: one picture
 };
+
+// PICTURES OF A BATCH STACKED VERTICALLY.  The CTU walk of a closed-GOP batch (encode.cpp) decides CTUs of many pictures in one call.  The intra analysis and the tree
+// operations carry a picture index (job.pic + pic_elems); the inter analysis, whose job records have no room for one, sees the batch as ONE TALL PICTURE: every plane
+// and unit map of picture p lies p * vh luma rows below picture 0's (vh = the virtual picture height, a multiple of 64 that covers the padded picture), a job's y
+// is pic * vh + its row in the picture, and `plane + y * stride + x` addresses the right picture with no further help.  Only the few kernels that compare y with the
+// picture's bounds (search ranges, vector clipping, neighbour availability, picture coordinates kept in 16 bits) split y again with xh_vh_base.  The stacked planes
+// stay below 2^31 elements (the caller's duty), so 32-bit element offsets keep working.  The height travels per host thread: the walk sets it around the inter calls.
+int xh_vh();
+struct XhVhScope {
+    int prev;
+    explicit XhVhScope(int vh);
+    ~XhVhScope();
+};
+__host__ __device__ __forceinline__ int xh_vh_base(int y, int vh) { return vh > 0 ? (y / vh) * vh : 0; }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,

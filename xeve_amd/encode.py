@@ -1,0 +1,82 @@
+"""The closed-GOP batch encoder (include/xeve_hip.h: xeve_hip_enc_*; xeve_amd/csrc/encode.hip + enc_host.h): G independent runs of F frames each -- one closed GOP
+per run, coded as the reference application codes `--seek g*F --frames F` -- advance in lockstep on the device; every run's bitstream is byte-identical to the
+reference's.  This module is the ctypes face of it plus the file plumbing (YUV in, .evc out).  No CPU path: it raises when the library or the GPU is missing."""
+import ctypes as C
+
+from . import lib as _lib
+
+PRESETS = {"fast": 0, "medium": 1}
+
+
+def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False):
+    """the options of the reference application (xeve_app: -w -h -q -I -b --closed-gop --preset -m -z --ref) as the library's configuration record"""
+    c = _lib.EncConfig()
+    c.w, c.h, c.fps_num, c.fps_den, c.qp, c.keyint, c.bframes, c.closed_gop = w, h, fps[0], fps[1], qp, keyint, bframes, int(bool(closed_gop))
+    c.preset, c.threads, c.inter_slice_type, c.ref = PRESETS[preset] if isinstance(preset, str) else int(preset), threads, 0, ref
+    c.reserved[0] = 1 if always_second_pass else 0
+    return c
+
+
+class BatchEncoder:
+    """enc = BatchEncoder(cfg, ngops, frames); enc.push(g, f, frame_bytes | device tensor) ...; streams = enc.encode()"""
+
+    def __init__(self, cfg, ngops, frames):
+        L = _lib.load()
+        self._L, self.cfg, self.ngops, self.frames = L, cfg, ngops, frames
+        self.frame_bytes = cfg.w * cfg.h * 3 // 2
+        self._h = L.xeve_hip_enc_create(C.byref(cfg), ngops, frames)
+        if not self._h:
+            raise _lib.XeveHipError(_lib.last_error())
+
+    def close(self):
+        if self._h:
+            self._L.xeve_hip_enc_delete(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def push(self, gop, frame, data):
+        """data: bytes-like of one planar 8-bit 4:2:0 frame (host), or a uint8 torch tensor on the GPU"""
+        if hasattr(data, "data_ptr"):
+            assert data.numel() == self.frame_bytes and data.is_contiguous()
+            _lib.check(self._L.xeve_hip_enc_push(self._h, gop, frame, C.c_void_p(data.data_ptr()), 1 if data.is_cuda else 0))
+        else:
+            b = bytes(data)
+            assert len(b) == self.frame_bytes
+            _lib.check(self._L.xeve_hip_enc_push(self._h, gop, frame, b, 0))
+
+    def push_gop(self, gop, data):
+        for f in range(self.frames):
+            self.push(gop, f, data[f * self.frame_bytes:(f + 1) * self.frame_bytes])
+
+    def encode(self):
+        """codes every run; returns the list of bitstreams (bytes), one per GOP"""
+        _lib.check(self._L.xeve_hip_enc_encode(self._h))
+        out = []
+        for g in range(self.ngops):
+            p, n = C.c_void_p(), C.c_size_t()
+            _lib.check(self._L.xeve_hip_enc_bitstream(self._h, g, C.byref(p), C.byref(n)))
+            out.append(C.string_at(p.value, n.value) if n.value else b"")
+        return out
+
+    def stats(self):
+        steps, a, b = C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self._L.xeve_hip_enc_stats(self._h, C.byref(steps), C.byref(a), C.byref(b)))
+        return {"ctu_steps": steps.value, "step_seconds": a.value, "picture_end_seconds": b.value}
+
+
+def encode_file(yuv_path, out_path, cfg, gops, frames):
+    """the whole sequence: GOP g = frames [g * frames, (g + 1) * frames) of the file; the concatenated bitstreams are what the reference writes for the same sequence
+    with --closed-gop -I frames"""
+    enc = BatchEncoder(cfg, gops, frames)
+    fb = enc.frame_bytes
+    with open(yuv_path, "rb") as f:
+        for g in range(gops):
+            for k in range(frames):
+                enc.push(g, k, f.read(fb))
+    streams = enc.encode()
+    with open(out_path, "wb") as f:
+        for s in streams:
+            f.write(s)
+    return streams, enc.stats()

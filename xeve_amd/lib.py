@@ -45,6 +45,10 @@ class RdoParams(C.Structure):  # xeve_hip_rdo_params
                 ("qp", C.c_int32 * 3), ("pad_", C.c_int32), ("lambda_", C.c_double * 3), ("dist_chroma_weight", C.c_double * 2)]
 
 
+class EncConfig(C.Structure):  # xeve_hip_enc_config
+    _fields_ = [(n, C.c_int32) for n in "w h fps_num fps_den qp keyint bframes closed_gop preset threads inter_slice_type ref".split()] + [("reserved", C.c_int32 * 4)]
+
+
 class InterParams(C.Structure):  # xeve_hip_inter_params
     _fields_ = [("rdo", RdoParams), ("me", EpzsParams), ("refi_bits", (C.c_int32 * 8) * 2), ("range_recentre", (C.c_int32 * 8) * 2), ("max_cand", C.c_int32),
                 ("poc", C.c_int32), ("col_list_poc0", C.c_int32), ("pad_", C.c_int32), ("skip_th", C.c_double)]
@@ -230,6 +234,13 @@ FUNCTIONS = {
     "xeve_hip_eco_coef_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int]),
     "xeve_hip_mc_cu_host": (c_int, [c_void_p] + [c_int] * 8 + [c_void_p] + [c_int] * 5 + [c_void_p] * 5),
     "xeve_hip_recon": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    # the closed-GOP batch encoder (xeve_amd/encode.py)
+    "xeve_hip_enc_create": (c_void_p, [c_void_p, c_int, c_int]),
+    "xeve_hip_enc_delete": (None, [c_void_p]),
+    "xeve_hip_enc_push": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
+    "xeve_hip_enc_encode": (c_int, [c_void_p]),
+    "xeve_hip_enc_bitstream": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "xeve_hip_enc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 TABLES = {
     "xeve_tbl_sad_16b_hip": FN_SAD * 64,
