@@ -874,6 +874,12 @@ void          xeve_hip_enc_delete(xeve_hip_enc *e);
 int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device);
 /* Codes every run (synchronous).  May be called again after new frames were pushed. */
 int xeve_hip_enc_encode(xeve_hip_enc *e);
+/* The same in slices: xeve_hip_enc_begin, then xeve_hip_enc_advance until *remaining is 0.  The unit is the LOCKSTEP STEP -- one CTU of every row chain of every
+ * run decided and written (xeve_ctu_mt_core's loop body, xeve_enc.c:128-170) -- a picture's set-up rides on its first step, its end (loop filter, slice data, NAL
+ * units) on its last.  advance returns when max_steps more steps are ISSUED; xeve_hip_enc_sync waits for the device (what a timer needs around a slice). */
+int xeve_hip_enc_begin(xeve_hip_enc *e);
+int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining);
+int xeve_hip_enc_sync(xeve_hip_enc *e);
 /* Run `gop`'s bitstream (what the application would have written to its output file); valid until the next encode / delete. */
 int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes);
 /* Lockstep statistics of the last encode: CTU steps issued, seconds inside the step calls / the picture-end calls (loop filter, second writer pass, padding). */

@@ -32,7 +32,7 @@ struct PicSetup {
 
 template <class Engine> class BatchEncoder {
   public:
-    BatchEncoder(Engine &e, const Param &p, int ngops, int nframes) : E(e), P(p), G(ngops), F(nframes) {}
+    BatchEncoder(Engine &e, const Param &p, int ngops, int nframes) : E(e), P(p), G(ngops), F(nframes), dpb(1) {}
     std::vector<PicPlan> plan() const { return Planner(P, F).run(); }
     // picture stores the run needs at once: the reference pictures alive at some point plus the picture being coded (a dry run of the bookkeeping)
     static int slots_needed(const Param &P, int nframes)
@@ -50,71 +50,40 @@ template <class Engine> class BatchEncoder {
         return need;
     }
 
-    // out[g] = the bitstream of GOP g (what the reference application writes to its output file for that run)
-    int run(std::vector<std::vector<uint8_t>> &out)
+    // The run as a resumable sequence of LOCKSTEP STEPS (one CTU of every row chain of every GOP each): begin(), then advance() until it returns 0.  A picture's
+    // set-up rides on its first step, its end (loop filter, slice data, NAL units, reference bookkeeping) on its last.  out[g] = the bitstream of GOP g (what the
+    // reference application writes to its output file for that run), complete when advance() has returned 0.
+    int begin(std::vector<std::vector<uint8_t>> &out_)
     {
-        out.assign(G, std::vector<uint8_t>());
-        const std::vector<PicPlan> pics = plan();
+        out = &out_;
+        out->assign(G, std::vector<uint8_t>());
+        pics = plan();
         if((int)pics.size() != F) return fail("the frame loop did not code every frame");
-        Dpb dpb(slots_needed(P, F));
+        dpb = Dpb(slots_needed(P, F));
         const int w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU;
-        const std::vector<std::vector<ChainCtu>> steps = wavefront(w_lcu, h_lcu, P.threads);
-        const int T = std::min(P.threads, h_lcu);
-        int last_intra_poc = 0;
-        std::vector<std::vector<uint8_t>> slice;
-        std::vector<uint32_t> bins;
-        for(const PicPlan &pp : pics) {
-            if(pp.frame < 0 || pp.frame >= F) return fail("the frame loop asked for a frame that was never pushed");
-            if(pp.slice_type == ST_I) last_intra_poc = pp.poc; // xeve_pic_prepare (:1217-1218)
-            const int qp = slice_qp(P, pp.depth);
-            const PicNumbers num = pic_numbers(qp);
-            if(!dpb.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra_poc)) return fail("no reference picture for an inter picture");
-            PicSetup S;
-            memset(&S, 0, sizeof(S));
-            S.frame = pp.frame, S.poc = pp.poc, S.slice_type = pp.slice_type, S.nchains = T;
-            if((S.cur_slot = dpb.get_empty()) < 0) return fail("no free picture store");
-            fill_tree_params(S.tp, P, pp.slice_type, num);
-            if(pp.slice_type != ST_I) {
-                fill_inter_params(S.ti, P, pp.slice_type, pp.poc, num, dpb);
-                S.nref[0] = dpb.num_refp[0], S.nref[1] = pp.slice_type == ST_B ? dpb.num_refp[1] : 0;
-                for(int l = 0; l < 2; l++)
-                    for(int r = 0; r < S.nref[l]; r++) S.ref[r][l] = dpb.refp[r][l];
-                if(pp.slice_type == ST_B && S.nref[1] > S.nref[0]) return fail("list 1 longer than list 0: outside what the inter analysis takes");
-            }
-            S.ep.chroma_format_idc = 1, S.ep.slice_type = pp.slice_type, S.ep.log2_ctu = LOG2_CTU, S.ep.pic_w = P.w, S.ep.pic_h = P.h, S.ep.w_scu = P.w >> 2, S.ep.h_scu = P.h >> 2;
-            S.ep.num_refp[0] = dpb.num_refp[0], S.ep.num_refp[1] = dpb.num_refp[1];
-            fill_deblock_params(S.dp, P);
-            E.begin_picture(S);
-            for(int t = 0; t < T; t++) E.reset_chain(t);
-            for(const std::vector<ChainCtu> &s : steps) E.step(s.data(), (int)s.size());
-            E.end_picture(T > 1 || always_rewrite, slice, bins);
-            if((int)slice.size() != G || (int)bins.size() != G) return fail("the engine returned no slice data");
-            // the access unit: parameter sets in front of an IDR picture (xeve_header), then the slice NAL unit (xeve_pic :466-590)
-            for(int g = 0; g < G; g++) {
-                std::vector<uint8_t> &o = out[g];
-                if(pp.idr) {
-                    const std::vector<uint8_t> sps = make_sps(P), pps = make_pps(pp.tid), sei = make_sei(P, pp.tid);
-                    o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end()), o.insert(o.end(), sei.begin(), sei.end());
-                }
-                Bits bs;
-                slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp);
-                std::vector<uint8_t> nal = bs.b;
-                nal.insert(nal.end(), slice[g].begin(), slice[g].end());
-                // cabac_zero_words when the slice's bins outrun its bytes (:562-583)
-                const uint32_t num_bytes = ((uint32_t)nal.size() & ~3u) - 4; // (bs->cur counts whole flushed words, xeve_bsw.c:32-44)
-                const int      pw = ((P.w + 3) / 4) * 4, ph = ((P.h + 3) / 4) * 4, raw_bits = pw * ph * (BIT_DEPTH + 2 * (BIT_DEPTH >> 2));
-                const uint32_t threshold = (32 / 3) * num_bytes + (uint32_t)(raw_bits / 32);
-                if(bins[g] >= threshold) {
-                    const uint32_t target = ((bins[g] - (uint32_t)(raw_bits / 32)) * 3 + 31) / 32;
-                    if(target > num_bytes)
-                        for(uint32_t i = 0, words = (target - num_bytes + 2) / 3; i < words; i++) nal.push_back(0), nal.push_back(0);
-                }
-                nal_close(nal);
-                o.insert(o.end(), nal.begin(), nal.end());
-            }
-            dpb.put(S.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length); // xeve_pic_finish -> xeve_picman_put_pic
-        }
+        steps = wavefront(w_lcu, h_lcu, P.threads);
+        T = std::min(P.threads, h_lcu), last_intra_poc = 0, pic = 0, step = 0;
         return 0;
+    }
+    long total_steps() const { return (long)pics.size() * (long)steps.size(); }
+    long remaining() const { return total_steps() - ((long)pic * (long)steps.size() + step); }
+    // up to max_steps further steps; returns the steps still to do (0: the run is complete), -1 on error
+    long advance(long max_steps)
+    {
+        for(long done = 0; done < max_steps && pic < (int)pics.size(); done++) {
+            if(step == 0 && begin_picture() != 0) return -1;
+            E.step(steps[step].data(), (int)steps[step].size());
+            if(++step == (int)steps.size()) {
+                if(end_picture() != 0) return -1;
+                step = 0, pic++;
+            }
+        }
+        return remaining();
+    }
+    int run(std::vector<std::vector<uint8_t>> &out_)
+    {
+        if(begin(out_) != 0) return -1;
+        return advance(total_steps() + 1) == 0 ? 0 : -1;
     }
     std::string error;
     bool always_rewrite = false; // (tests: one chain through the second pass too)
@@ -123,7 +92,73 @@ template <class Engine> class BatchEncoder {
     Engine     &E;
     const Param P;
     const int   G, F;
+    std::vector<std::vector<uint8_t>> *out = nullptr;
+    std::vector<PicPlan> pics;
+    std::vector<std::vector<ChainCtu>> steps;
+    Dpb dpb;
+    int T = 1, last_intra_poc = 0, pic = 0, step = 0, qp = 0;
+    PicSetup S;
+    std::vector<std::vector<uint8_t>> slice;
+    std::vector<uint32_t> bins;
     int fail(const char *m) { error = m; return -1; }
+
+    int begin_picture()
+    {
+        const PicPlan &pp = pics[pic];
+        if(pp.frame < 0 || pp.frame >= F) return fail("the frame loop asked for a frame that was never pushed");
+        if(pp.slice_type == ST_I) last_intra_poc = pp.poc; // xeve_pic_prepare (:1217-1218)
+        qp = slice_qp(P, pp.depth);
+        const PicNumbers num = pic_numbers(qp);
+        if(!dpb.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra_poc)) return fail("no reference picture for an inter picture");
+        memset(&S, 0, sizeof(S));
+        S.frame = pp.frame, S.poc = pp.poc, S.slice_type = pp.slice_type, S.nchains = T;
+        if((S.cur_slot = dpb.get_empty()) < 0) return fail("no free picture store");
+        fill_tree_params(S.tp, P, pp.slice_type, num);
+        if(pp.slice_type != ST_I) {
+            fill_inter_params(S.ti, P, pp.slice_type, pp.poc, num, dpb);
+            S.nref[0] = dpb.num_refp[0], S.nref[1] = pp.slice_type == ST_B ? dpb.num_refp[1] : 0;
+            for(int l = 0; l < 2; l++)
+                for(int r = 0; r < S.nref[l]; r++) S.ref[r][l] = dpb.refp[r][l];
+            if(pp.slice_type == ST_B && S.nref[1] > S.nref[0]) return fail("list 1 longer than list 0: outside what the inter analysis takes");
+        }
+        S.ep.chroma_format_idc = 1, S.ep.slice_type = pp.slice_type, S.ep.log2_ctu = LOG2_CTU, S.ep.pic_w = P.w, S.ep.pic_h = P.h, S.ep.w_scu = P.w >> 2, S.ep.h_scu = P.h >> 2;
+        S.ep.num_refp[0] = dpb.num_refp[0], S.ep.num_refp[1] = dpb.num_refp[1];
+        fill_deblock_params(S.dp, P);
+        E.begin_picture(S);
+        for(int t = 0; t < T; t++) E.reset_chain(t);
+        return 0;
+    }
+    int end_picture()
+    {
+        const PicPlan &pp = pics[pic];
+        E.end_picture(T > 1 || always_rewrite, slice, bins);
+        if((int)slice.size() != G || (int)bins.size() != G) return fail("the engine returned no slice data");
+        // the access unit: parameter sets in front of an IDR picture (xeve_header), then the slice NAL unit (xeve_pic :466-590)
+        for(int g = 0; g < G; g++) {
+            std::vector<uint8_t> &o = (*out)[g];
+            if(pp.idr) {
+                const std::vector<uint8_t> sps = make_sps(P), pps = make_pps(pp.tid), sei = make_sei(P, pp.tid);
+                o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end()), o.insert(o.end(), sei.begin(), sei.end());
+            }
+            Bits bs;
+            slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp);
+            std::vector<uint8_t> nal = bs.b;
+            nal.insert(nal.end(), slice[g].begin(), slice[g].end());
+            // cabac_zero_words when the slice's bins outrun its bytes (:562-583)
+            const uint32_t num_bytes = ((uint32_t)nal.size() & ~3u) - 4; // (bs->cur counts whole flushed words, xeve_bsw.c:32-44)
+            const int      pw = ((P.w + 3) / 4) * 4, ph = ((P.h + 3) / 4) * 4, raw_bits = pw * ph * (BIT_DEPTH + 2 * (BIT_DEPTH >> 2));
+            const uint32_t threshold = (32 / 3) * num_bytes + (uint32_t)(raw_bits / 32);
+            if(bins[g] >= threshold) {
+                const uint32_t target = ((bins[g] - (uint32_t)(raw_bits / 32)) * 3 + 31) / 32;
+                if(target > num_bytes)
+                    for(uint32_t i = 0, words = (target - num_bytes + 2) / 3; i < words; i++) nal.push_back(0), nal.push_back(0);
+            }
+            nal_close(nal);
+            o.insert(o.end(), nal.begin(), nal.end());
+        }
+        dpb.put(S.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length); // xeve_pic_finish -> xeve_picman_put_pic
+        return 0;
+    }
 };
 
 } // namespace xenc

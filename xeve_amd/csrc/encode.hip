@@ -150,6 +150,7 @@ struct xeve_hip_enc {
     int64_t n_steps = 0;
     double  t_steps = 0, t_ends = 0;
     std::vector<std::vector<uint8_t>> bitstreams;
+    std::unique_ptr<BatchEncoder<xeve_hip_enc>> loop; // the frame loop of the run in progress (xeve_hip_enc_begin .. the advance that returns 0)
 
     bool fail(const std::string &m)
     {
@@ -330,17 +331,39 @@ extern "C" int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint
     XH_HIP(hipStreamSynchronize(e->st));
     return XEVE_HIP_OK;
 }
-extern "C" int xeve_hip_enc_encode(xeve_hip_enc *e)
+extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
 {
     XH_ENTER();
     XH_REQUIRE(e);
     e->error.clear(), e->n_steps = 0, e->t_steps = e->t_ends = 0;
-    BatchEncoder<xeve_hip_enc> enc(*e, e->P, e->G, e->F);
-    enc.always_rewrite = (e->P_reserved0 & 1) != 0;
-    const int rc = enc.run(e->bitstreams);
-    if(!e->error.empty()) { xh_set_error("xeve_hip_enc_encode: %s", e->error.c_str()); return XEVE_HIP_ERR_DEVICE; }
-    if(rc != 0) { xh_set_error("xeve_hip_enc_encode: %s", enc.error.c_str()); return XEVE_HIP_ERR_ARG; }
+    e->loop.reset(new BatchEncoder<xeve_hip_enc>(*e, e->P, e->G, e->F));
+    e->loop->always_rewrite = (e->P_reserved0 & 1) != 0;
+    if(e->loop->begin(e->bitstreams) != 0) { xh_set_error("xeve_hip_enc_begin: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
     return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining)
+{
+    XH_ENTER();
+    XH_REQUIRE(e && e->loop && max_steps >= 0);
+    const long left = e->loop->advance((long)max_steps);
+    if(!e->error.empty()) { xh_set_error("xeve_hip_enc_advance: %s", e->error.c_str()); return XEVE_HIP_ERR_DEVICE; }
+    if(left < 0) { xh_set_error("xeve_hip_enc_advance: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
+    if(remaining) *remaining = left;
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_sync(xeve_hip_enc *e)
+{
+    XH_ENTER();
+    XH_REQUIRE(e);
+    XH_HIP(hipStreamSynchronize(e->st));
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_enc_encode(xeve_hip_enc *e)
+{
+    int rc = xeve_hip_enc_begin(e);
+    int64_t left = 1;
+    while(rc == XEVE_HIP_OK && left > 0) rc = xeve_hip_enc_advance(e, 1 << 20, &left);
+    return rc == XEVE_HIP_OK ? xeve_hip_enc_sync(e) : rc;
 }
 extern "C" int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes)
 {

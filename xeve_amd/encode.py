@@ -50,6 +50,26 @@ class BatchEncoder:
         for f in range(self.frames):
             self.push(gop, f, data[f * self.frame_bytes:(f + 1) * self.frame_bytes])
 
+    def begin(self):
+        _lib.check(self._L.xeve_hip_enc_begin(self._h))
+
+    def advance(self, max_steps):
+        """issues up to max_steps lockstep steps (one CTU of every row chain of every GOP each); returns the steps still to do"""
+        left = C.c_int64()
+        _lib.check(self._L.xeve_hip_enc_advance(self._h, int(max_steps), C.byref(left)))
+        return left.value
+
+    def sync(self):
+        _lib.check(self._L.xeve_hip_enc_sync(self._h))
+
+    def bitstreams(self):
+        out = []
+        for g in range(self.ngops):
+            p, n = C.c_void_p(), C.c_size_t()
+            _lib.check(self._L.xeve_hip_enc_bitstream(self._h, g, C.byref(p), C.byref(n)))
+            out.append(C.string_at(p.value, n.value) if n.value else b"")
+        return out
+
     def encode(self):
         """codes every run; returns the list of bitstreams (bytes), one per GOP"""
         _lib.check(self._L.xeve_hip_enc_encode(self._h))

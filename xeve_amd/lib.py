@@ -239,6 +239,9 @@ FUNCTIONS = {
     "xeve_hip_enc_delete": (None, [c_void_p]),
     "xeve_hip_enc_push": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "xeve_hip_enc_encode": (c_int, [c_void_p]),
+    "xeve_hip_enc_begin": (c_int, [c_void_p]),
+    "xeve_hip_enc_advance": (c_int, [c_void_p, c_i64, c_void_p]),
+    "xeve_hip_enc_sync": (c_int, [c_void_p]),
     "xeve_hip_enc_bitstream": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_enc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
