@@ -662,6 +662,8 @@ int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, 
  * change between two of them.  Never called: every host-memory call stages its planes itself (the round-1 behaviour).  _stats: pictures announced, planes
  * uploaded (+ bytes) and cache hits since init. */
 int xeve_hip_picture_begin(void);
+/* Leaves resident mode (every later host-memory call stages its planes itself) until the next xeve_hip_picture_begin(): for a caller that stops announcing pictures. */
+int xeve_hip_picture_end(void);
 int xeve_hip_resident_stats(uint64_t *pictures, uint64_t *uploads, uint64_t *upload_bytes, uint64_t *hits);
 
 /* One xeve_pinter_analyze_cu call on HOST memory (synchronous; without resident pictures the original and every reference picture of both lists are staged per call): what

@@ -47,7 +47,20 @@ void xh_set_error(const char *fmt, ...)
     std::lock_guard<std::mutex> lk(g_err_mu);
     memcpy(g_err, t_err, sizeof(g_err));
 }
-bool xh_ready() { return g_device.load() >= 0; }
+// Every entry point runs XH_ENTER -> xh_ready(): a thread that has not yet worked for this binding of the library (a worker thread of the reference encoder starts
+// on HIP device 0) is bound to the library's device first, so that its streams, arenas and resident planes land where the constant tables live.
+bool xh_ready()
+{
+    const int dev = g_device.load();
+    if(dev < 0) return false;
+    static thread_local uint32_t t_bound_gen = 0xFFFFFFFFu;
+    const uint32_t gen = g_generation.load();
+    if(t_bound_gen != gen) {
+        if(hipSetDevice(dev) != hipSuccess) return false;
+        t_bound_gen = gen;
+    }
+    return true;
+}
 uint32_t xh_generation() { return g_generation.load(); }
 static thread_local int t_vh = 0; // the virtual picture height of the batch this thread is walking (xh_common.h)
 int xh_vh() { return t_vh; }
@@ -101,22 +114,24 @@ extern "C" int xeve_hip_init(int device_ordinal)
     if(g_device.load() >= 0) { // re-binding to another device: everything built for the old one goes first
         (void)hipSetDevice(g_device.load());
         (void)hipDeviceSynchronize();
+        prof_reset_locked(); // (the pooled events and unit counters live on the old device)
         xh_rdoq_tables_free();
         xh_resident_free_all();
         g_device.store(-1);
+        g_generation++;
     }
     XH_HIP(hipSetDevice(device_ordinal));
     int rc = xh_tq_init();
     if(rc != XEVE_HIP_OK) return rc;
+    g_generation++;                 // (threads bound to an earlier binding re-bind on their next entry)
     g_device.store(device_ordinal); // (the table builders below go through entry-point checks that want a bound device)
     rc = xh_main_tools_init();
-    if(rc != XEVE_HIP_OK) return rc;
-    rc = xh_rdoq_tables_init();
-    if(rc != XEVE_HIP_OK) {
+    if(rc == XEVE_HIP_OK) rc = xh_rdoq_tables_init();
+    if(rc != XEVE_HIP_OK) { // a half-initialised library must not look ready
         g_device.store(-1);
+        g_generation++;
         return rc;
     }
-    g_generation++;
     return XEVE_HIP_OK;
 }
 
@@ -196,6 +211,7 @@ static void prof_reset_locked()
 extern "C" int xeve_hip_prof_enable(int class_mask)
 {
     XH_ENTER();
+    std::lock_guard<std::mutex> lk(g_prof_mu); // (g_prof_units is shared with prof_reset_locked / xeve_hip_prof_read)
     if(class_mask && !g_prof_units) {
         XH_HIP(hipMalloc((void **)&g_prof_units, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES * XH_PROF_STRIPES));
         XH_HIP(hipMemset(g_prof_units, 0, sizeof(unsigned long long) * XEVE_HIP_PROF_CLASSES * XH_PROF_STRIPES));

@@ -25,13 +25,15 @@ struct Entry {
 std::mutex                       g_mu;
 std::map<const void *, Entry>    g_live;   // host base pointer -> copy of the current picture
 std::vector<Entry>               g_free;   // buffers of earlier pictures, reused
+std::vector<Entry>               g_retired; // buffers replaced WITHIN the current picture: another thread may still read them, so they rest until the next picture
 uint64_t                         g_epoch = 0, g_uploads = 0, g_hits = 0, g_upload_bytes = 0;
+bool                             g_on = false; // between xeve_hip_picture_begin and xeve_hip_picture_end / shutdown
 } // namespace
 
 bool xh_resident_on()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    return g_epoch != 0;
+    return g_on;
 }
 
 // device copy of host[0 .. bytes); nullptr on a HIP error (message set)
@@ -45,6 +47,7 @@ void *xh_resident(const void *host, size_t bytes)
     }
     Entry e;
     if(it != g_live.end()) e = it->second, g_live.erase(it);
+    if(e.dev && e.epoch == g_epoch) g_retired.push_back(e), e = Entry(); // a live copy of this picture is never recycled inside the picture (a reader may hold it)
     if(e.cap < bytes) {
         if(e.dev) g_free.push_back(e), e = Entry();
         for(size_t i = 0; i < g_free.size(); i++)
@@ -76,17 +79,32 @@ void xh_resident_free_all()
     std::lock_guard<std::mutex> lk(g_mu);
     for(auto &kv : g_live) (void)hipFree(kv.second.dev);
     for(auto &e : g_free) (void)hipFree(e.dev);
-    g_live.clear(), g_free.clear();
-    g_epoch = 0;
+    for(auto &e : g_retired) (void)hipFree(e.dev);
+    g_live.clear(), g_free.clear(), g_retired.clear();
+    g_epoch = 0, g_on = false;
 }
 
 extern "C" int xeve_hip_picture_begin(void)
 {
     XH_ENTER();
     std::lock_guard<std::mutex> lk(g_mu);
-    g_epoch++;
+    g_epoch++, g_on = true;
     for(auto &kv : g_live) g_free.push_back(kv.second); // every copy is stale now; the buffers are reused
-    g_live.clear();
+    for(auto &e : g_retired) g_free.push_back(e);
+    g_live.clear(), g_retired.clear();
+    return XEVE_HIP_OK;
+}
+
+// Leaves resident mode: the host-memory entry points stage their planes per call again until the next xeve_hip_picture_begin().  For a caller that stops announcing
+// pictures (another encoder instance in the same process, the end of a sequence): a stale hit on a re-used host address is impossible afterwards.
+extern "C" int xeve_hip_picture_end(void)
+{
+    XH_ENTER();
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = false;
+    for(auto &kv : g_live) g_free.push_back(kv.second);
+    for(auto &e : g_retired) g_free.push_back(e);
+    g_live.clear(), g_retired.clear();
     return XEVE_HIP_OK;
 }
 

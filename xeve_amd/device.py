@@ -331,9 +331,13 @@ def mode_analyze_ctu_jobs(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c
     updated in place.  Returns (ctu data uint8 [nchains, 62976], next_best uint8 [nchains, 180], cost float64 [nchains])."""
     L = _lib.load()
     n, nstates, dev = jobs.numel() // 16, states.numel() // SBAC_BYTES, jobs.device
-    out = torch.zeros((n, _lib.CTU_DATA_BYTES), dtype=torch.uint8, device=dev)
-    nxt = torch.zeros((n, SBAC_BYTES), dtype=torch.uint8, device=dev)
-    cost = torch.zeros(n, dtype=torch.float64, device=dev)
+    if outputs is not None:  # the caller's own buffers (fixed addresses: what the library's graph replay is keyed on; no per-call zero fill)
+        out, nxt, cost = outputs
+        assert out.numel() >= n * _lib.CTU_DATA_BYTES and nxt.numel() >= n * SBAC_BYTES and cost.numel() >= n
+    else:
+        out = torch.zeros((n, _lib.CTU_DATA_BYTES), dtype=torch.uint8, device=dev)
+        nxt = torch.zeros((n, SBAC_BYTES), dtype=torch.uint8, device=dev)
+        cost = torch.zeros(n, dtype=torch.float64, device=dev)
     ip = None
     if inter is not None:
         inter.coef_l, inter.coef_c = baseline_coef_l().ctypes.data, baseline_coef_c().ctypes.data

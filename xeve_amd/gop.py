@@ -81,20 +81,23 @@ def run_shards(encoder_cmd, yuv, out, total_frames, keyint, devices, env=None, w
         e = dict(os.environ)
         e.update(env or {})
         e["HIP_VISIBLE_DEVICES"], e["XEVE_HIP_DEVICE"] = str(slots[i]), "0"
-        p = subprocess.Popen(list(encoder_cmd) + app_args(s) + ["-o", part], env=e, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-        running[i] = (p, s, part, time.perf_counter())
+        log = open(part + ".stderr", "w+")  # (a file, not a pipe: a chatty child must never block on a full pipe buffer while we only poll)
+        p = subprocess.Popen(list(encoder_cmd) + app_args(s) + ["-o", part], env=e, stdout=subprocess.DEVNULL, stderr=log, text=True)
+        running[i] = (p, s, part, time.perf_counter(), log)
 
     try:
         for i in range(len(slots)):
             start(i)
         while running:
             for i in list(running):
-                p, s, part, ts = running[i]
+                p, s, part, ts, log = running[i]
                 if p.poll() is None:
-                    if timeout and time.perf_counter() - t0 > timeout:
-                        raise TimeoutError("shard encode exceeded %s s" % timeout)
+                    if timeout and time.perf_counter() - ts > timeout:  # per shard
+                        raise TimeoutError("the encode of GOP %d exceeded %s s" % (s.gop, timeout))
                     continue
-                err = p.stderr.read()
+                log.seek(0)
+                err = log.read()
+                log.close()
                 if p.returncode != 0 or not os.path.exists(part):
                     raise RuntimeError("encoder failed on GOP %d (device %s, rc %s): %s" % (s.gop, slots[i], p.returncode, err[-800:]))
                 done.append((s.gop, slots[i], time.perf_counter() - ts, part))
@@ -112,7 +115,9 @@ def run_shards(encoder_cmd, yuv, out, total_frames, keyint, devices, env=None, w
                     n += f.write(g.read())
         return {"bytes": n, "shards": [(g, d, round(t, 3)) for g, d, t, _ in done], "seconds": wall, "fps": total_frames / wall}
     finally:
-        for p, _, _, _ in running.values():
+        for p, _, _, _, log in running.values():
             p.kill()
+            p.wait()
+            log.close()
         if own_dir:
             shutil.rmtree(work_dir, ignore_errors=True)

@@ -218,6 +218,7 @@ FUNCTIONS = {
     "xeve_hip_eco_tile_end_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_sizeof": (c_int, [c_int]),
     "xeve_hip_picture_begin": (c_int, []),
+    "xeve_hip_picture_end": (c_int, []),
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_prof_enable": (c_int, [c_int]),
     "xeve_hip_prof_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
