@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per GPU (0: as many as the picture size allows, at most 192)")
     ap.add_argument("--frames", type=int, default=2, help="frames per GOP (2: the IDR picture and one inter picture, the CPU baseline's sample)")
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
+    ap.add_argument("--batches", type=int, default=1, help="independent batches of --gops GOPs encoded side by side on this GPU (one host thread and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed per-kernel-class pass")
     a = ap.parse_args()
@@ -175,50 +176,78 @@ def main():
     vh = (H + 288 + 63) & ~63
     G = a.gops or max(1, min(192, int((2 ** 31 - 1) // (vh * (W + 288)))))
     cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
-    enc = encode.BatchEncoder(cfg, G, F)
+    B = max(1, a.batches)
+    encs = [encode.BatchEncoder(cfg, G, F) for _ in range(B)]
+    enc = encs[0]
 
     # inputs: GOP 0 of rank 0 = the reference recipe's seed-4 clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
     clip = reference_noise(fb * F, 4) if rank == 0 else None
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
-    for g in range(G):
-        if g == 0 and clip is not None:
-            d = torch.from_numpy(clip).to(dev)
-        else:
-            d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
-        for f in range(F):
-            enc.push(g, f, d[f * fb:(f + 1) * fb])
+    for b, e in enumerate(encs):
+        for g in range(G):
+            if b == 0 and g == 0 and clip is not None:
+                d = torch.from_numpy(clip).to(dev)
+            else:
+                d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
+            for f in range(F):
+                e.push(g, f, d[f * fb:(f + 1) * fb])
     del d
     cpu = CpuApp(W, H, F, clip) if solo and not a.no_cpu_baseline else None  # (host cores only; runs while the GPU encodes)
 
     def fence():
-        enc.sync()
+        for e in encs:
+            e.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    enc.begin()
+    for e in encs:
+        e.begin()
     total = enc.advance(0)
     per_picture = total // F
     n = a.warmup + a.steps
     per = max(1, total // n)
     sizes = [per] * (n - 1) + [max(0, total - per * (n - 1))]
-    for i in range(a.warmup):
-        enc.advance(sizes[i])
+
+    live = {"search": [0.0, 0, 0]}
+
+    def drain():
+        for k, v in lib.prof_read().items():  # (waits for the device: only between slices; keeps the pool of timing events small -- creating them costs host time)
+            if k in live:
+                live[k] = [live[k][0] + v[0], live[k][1] + v[1], live[k][2] + v[2]]
+
+    def run_slices(lo, hi, timers=False):
+        """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL).  timers: HIP events on the search kernel's
+        launches -- with one batch in every slice (read out after each), with several only in the last slice (a read-out would stall the other batches)"""
+        def one(e):
+            left = None
+            for i in range(lo, hi):
+                if timers and (B == 1 or i == hi - 1) and e is enc:
+                    lib.prof_enable(["search"])
+                left = e.advance(sizes[i])
+                if timers and B == 1:
+                    drain()
+            return left
+        if B == 1:
+            return [one(enc)]
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(B) as ex:
+            return list(ex.map(one, encs))
+
+    run_slices(0, a.warmup)
     fence()
-    lib.prof_enable(["search"])  # the roofline's kernel: HIP events on its launches, live in the timed region
     lib.prof_read()
     fence()
     t0 = time.perf_counter()
-    for i in range(a.warmup, n):
-        left = enc.advance(sizes[i])
+    lefts = run_slices(a.warmup, n, timers=True)  # the roofline's kernel: HIP events on its launches, live in the timed region
     fence()
     dt = time.perf_counter() - t0
-    live = lib.prof_read()
+    drain()
     lib.prof_enable(None)
-    assert left == 0, left
+    assert all(v == 0 for v in lefts), lefts
     timed_steps = sum(sizes[a.warmup:])
-    frames_timed = G * timed_steps / per_picture
+    frames_timed = B * G * timed_steps / per_picture
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,10 +299,10 @@ def main():
             "value_is": "encoded frames/s of the closed-GOP batch encoder: a real encode to EVC bitstreams (every stage of the reference's xeve_pic on the device, NAL assembly "
                         "on the host), byte-identical to the reference encoder; frames = the timed share of the job's frames",
             "config": {
-                "workload": "one encode of %d closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop -I 8 -m %d semantics), "
+                "workload": "one encode of %d x %d closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop -I 8 -m %d semantics), "
                             "i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; the job's %d lockstep CTU steps cut into %d + %d equal slices"
-                            % (G, F, W, H, T, total, a.warmup, a.steps),
-                "gops_in_lockstep": G, "frames_per_gop": F, "row_chains_per_picture": T, "chains_in_lockstep": G * min(T, h_lcu), "lockstep_steps_per_picture": per_picture,
+                            % (B, G, F, W, H, T, total, a.warmup, a.steps),
+                "batches_side_by_side": B, "gops_in_lockstep": G, "frames_per_gop": F, "row_chains_per_picture": T, "chains_in_lockstep": G * min(T, h_lcu), "lockstep_steps_per_picture": per_picture,
                 "lockstep_steps_timed": timed_steps, "frames_in_timed_region": round(frames_timed, 2), "ctus_per_picture": w_lcu * h_lcu,
                 "parallelism": "closed-GOP shards per GPU, no collectives" + (" [SELF-TEST: all ranks share GPU 0, gloo]" if share else ""),
                 "library_built_in_this_run": built_here,
@@ -330,7 +359,8 @@ def main():
             except Exception:
                 pass
         print(json.dumps(line), flush=True)
-    enc.close()
+    for e in encs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

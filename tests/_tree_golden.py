@@ -1,6 +1,6 @@
 """tests/golden/tree_v1.npz (made by tests/golden/make_tree_golden.py from the reference encoder): CTUs of real encodes -- what the CTU mode decision was handed and what
 the REFERENCE made of it.  The loader turns a record into the arrays the oracle / the library take; `same_as_reference` compares a walk's products with the
-reference's the way oracle/ref_shim.c's shadow mode does (fields the reference leaves stale are not compared: motion data of unused lists, levels behind nnz = 0)."""
+reference's the way oracle/ref_shadow.c's shadow mode does (fields the reference leaves stale are not compared: motion data of unused lists, levels behind nnz = 0)."""
 import ctypes as C
 import os
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Makes tests/golden/tree_v1.npz: CTUs of real encodes -- what the CTU mode decision (mode_analyze_lcu -> mode_coding_tree, src_base/xeve_mode.c:2007-2610) was handed
-and what THE REFERENCE made of it -- recorded by the LD_PRELOAD adapter (oracle/ref_shim.c, XEVE_SHIM_TREE_GOLDEN) inside the unmodified encoder compiled in place under
+and what THE REFERENCE made of it -- recorded by the LD_PRELOAD adapter (oracle/ref_shadow.c, XEVE_SHIM_TREE_GOLDEN) inside the unmodified encoder compiled in place under
 oracle/_ref.  Run here (needs /root/reference); the .npz holds numeric arrays only.  Reference pictures that several records share are stored once."""
 import hashlib
 import os
@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from _e2e import CASES, REF_APP, SHIM, make_yuv  # noqa: E402
+from _e2e import CASES, REF_APP, SHADOW, make_yuv  # noqa: E402
 from _libs import ORACLE_SO  # noqa: E402
 
 # clip, CTUs recorded of every picture
@@ -44,7 +44,7 @@ def main():
             if os.path.exists(dump):
                 os.remove(dump)
             cmd = [REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(n), "-m", "1", "-v", "0", "-o", os.path.join(tmp, "o.evc")] + list(extra)
-            env = dict(os.environ, LD_PRELOAD=SHIM, XEVE_SHIM_SHADOW_TREE=ORACLE_SO, XEVE_SHIM_TREE_GOLDEN=dump, XEVE_SHIM_TREE_GOLDEN_CTUS=ctus, XEVE_SHIM_SHADOW_NO_PICTURE="1")
+            env = dict(os.environ, LD_PRELOAD=SHADOW, XEVE_SHIM_SHADOW_TREE=ORACLE_SO, XEVE_SHIM_TREE_GOLDEN=dump, XEVE_SHIM_TREE_GOLDEN_CTUS=ctus, XEVE_SHIM_SHADOW_NO_PICTURE="1")
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
             assert p.returncode == 0 and ", 0 differ" in p.stderr, p.stderr[-800:]
             recs = list(records(dump))

@@ -3,7 +3,7 @@
   (cpu)  to the committed goldens                                     -- pins the reference build itself;
   (cpu)  when closed-GOP shards are encoded separately and concatenated -- the multi-GPU path, SURVEY.md 4(2);
   (gpu)  when every hot-path dispatch table is replaced by libxeve_hip.so's tables (LD_PRELOAD interposer
-         oracle/ref_shim.c = the integration INTEGRATION.md describes), with xeve_pinter.c / xeve_mode.c unchanged.
+         shim/xeve_hip_shim.c = the integration INTEGRATION.md describes), with xeve_pinter.c / xeve_mode.c unchanged.
 """
 import json
 import os
@@ -289,7 +289,7 @@ def test_bitstream_identical_with_inter_and_intra_analysis_on_the_gpu(tmp_path, 
                                              ("moving_ldb_ref3", 20, 16), ("moving_ra_b3_medium", 18, 16), ("jumpy_ldb_fast", 24, 18), ("cfg2_720p_ldb_fast", 480, 240)])
 def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu, ninter):
     """xo_mode_analyze_ctu (mode_analyze_lcu -> mode_coding_tree -> mode_coding_unit, xeve_mode.c:1169-1350, 2007-2610, restated in oracle/: I, P and B slices) runs
-    BESIDE the unmodified reference inside the live encoder (oracle/ref_shim.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every
+    BESIDE the unmodified reference inside the live encoder (oracle/ref_shadow.c: ctx->fn_mode_analyze_lcu hooked in shadow mode) from the same entry state, and every
     product of the walk -- split flags, CU modes, intra modes, motion data, depths, levels, reconstruction, the context maps (units, intra modes, vectors,
     reference indices), the picture and the coder state handed on -- is compared per CTU.  CPU only: this pins the oracle the device-side tree walk is checked
     against; the CIF clips have partial CTUs at the right and bottom edges, the B clips temporal direct and bi-prediction."""
@@ -335,7 +335,7 @@ def test_oracle_ctu_mode_decision_matches_the_live_encoder(tmp_path, name, nctu,
 @pytest.mark.parametrize("name,nctu,left", [("noise_allintra_medium", 8, 0), ("cfg1_cif_allintra_fast", 240, 0), ("tiny_ldb_fast_2threads", 8, 0), ("moving_cif_ra_medium", 150, 0),
                                             ("moving_ra_b3_medium", 18, 0), ("jumpy_ldb_fast", 24, 0)])
 def test_route_adapter_of_the_ctu_mode_decision_with_the_oracle_as_engine(tmp_path, name, nctu, left):
-    """the adapter that serves ctx->fn_mode_analyze_lcu from an external tree walk (oracle/ref_shim.c, shim_route_mode_analyze_lcu: what it hands over and what it
+    """the adapter that serves ctx->fn_mode_analyze_lcu from an external tree walk (shim/xeve_hip_shim.c, shim_route_mode_analyze_lcu: what it hands over and what it
     stores back into ctx->map_cu_data, the context maps and PIC_MODE) run with the ORACLE's walk as the engine: the bitstream must not change.  CPU only -- this
     tests the adapter (test infrastructure); the same adapter with the GPU as the engine is the gpu test below."""
     from _libs import ORACLE_SO

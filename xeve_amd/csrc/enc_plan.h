@@ -480,7 +480,7 @@ inline void fill_deblock_params(xeve_hip_deblock_params &d, const Param &P)
     for(int c = 0; c < 2; c++)
         for(int q = -off; q <= 57; q++) d.qp_chroma[c][q + off] = chroma_qp(q);
 }
-// what the CTU walk of a picture is given (the fields oracle/ref_shim.c reads out of the live encoder's context, computed here)
+// what the CTU walk of a picture is given (the fields shim/xeve_hip_shim.c reads out of the live encoder's context, computed here)
 inline void fill_tree_params(xeve_hip_tree_params &t, const Param &P, int slice_type, const PicNumbers &n)
 {
     memset(&t, 0, sizeof(t));
