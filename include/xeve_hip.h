@@ -157,7 +157,8 @@ int xeve_hip_install_tables(void *fn_itxb_slot);
 /*     a hipStream_t (NULL = default stream); calls are asynchronous on that stream.             */
 /* ------------------------------------------------------------------------------------------- */
 typedef struct xeve_hip_job {
-    int32_t off1; /* element offset of the block's top-left sample inside plane 1 (e.g. the original) */
+    int32_t off1; /* element offset of the block's top-left sample inside plane 1 (e.g. the original): never negative, and read as an UNSIGNED 32-bit number (the stacked
+                     originals of a picture batch span up to 2^32 samples) */
     int32_t off2; /* element offset inside plane 2 (e.g. the reference picture at the search centre)    */
 } xeve_hip_job;
 

@@ -127,7 +127,10 @@ struct CpuEngine {
             }
         }
     }
-    void end_picture(bool rewrite, std::vector<std::vector<uint8_t>> &slice, std::vector<uint32_t> &bins)
+    std::vector<std::vector<uint8_t>> slice;
+    std::vector<uint32_t> bins;
+    void collect(std::vector<std::vector<uint8_t>> &s, std::vector<uint32_t> &b) { s = slice, b = bins; }
+    void end_picture(bool rewrite)
     {
         slice.assign(G, std::vector<uint8_t>()), bins.assign(G, 0);
         std::vector<uint8_t> buf(1 << 18);

@@ -46,12 +46,16 @@ REAL_CASES = {
 def make_yuv(path, w, h, frames, seed):
     """seeds below 5000: i.i.d. noise (SURVEY.md 8d recipe); from 5000: a smooth texture drifting over the frames plus light noise -- content on
     which skip / merge, temporal direct and bi-prediction actually win"""
-    random.seed(seed)
-    if seed < 5000:
-        with open(path, "wb") as f:
-            f.write(bytes(random.getrandbits(8) for _ in range(w * h * 3 // 2 * frames)))
-        return
     import numpy as np
+
+    random.seed(seed)
+    if seed < 5000:  # bytes(random.getrandbits(8) ...) without the Python loop: getrandbits(8) is the top byte of one MT19937 output, and numpy's legacy generator runs
+        # the same twister from the same state (tests/test_bench_inputs.py holds the two against each other)
+        st = random.getstate()
+        rs = np.random.RandomState()
+        rs.set_state(("MT19937", np.array(st[1][:624], dtype=np.uint32), st[1][624]))
+        (rs.randint(0, 2 ** 32, size=w * h * 3 // 2 * frames, dtype=np.uint32) >> 24).astype(np.uint8).tofile(path)
+        return
 
     r = np.random.default_rng(seed)
     with open(path, "wb") as f:

@@ -113,6 +113,12 @@ BATCH_CASES = {
 # the same at BASELINE's picture sizes (GPU suite only; the CPU harness would need minutes): >= 2 GOPs at 1920x1080
 BATCH_CASES_REAL = {
     "gops_1080p_moving_m8": (1920, 1080, 2, 8, 5026, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
+    # BASELINE.json's configs 2, 3, 4 as single runs through the batch encoder: 720p low-delay B with 8 frames, 1080p random access with 9 frames
+    # (two B layers below the key pictures, reference distances 8 / 4 / 2 / 1), 2160p closed GOP (the IDR picture and one inter picture; the input of
+    # tests/golden/e2e_v1.json cfg4_2160p_closedgop_medium_m8, whose md5 this golden repeats)
+    "cfg2_720p_ldb_fast_8f_m8": (1280, 720, 1, 8, 2, ["--preset", "fast", "-b", "0", "-I", "0"], 8),
+    "cfg3_1080p_ra_medium_9f_m8": (1920, 1080, 1, 9, 3, ["--preset", "medium"], 8),
+    "cfg4_2160p_closedgop_medium_2f_m8": (3840, 2160, 1, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
 }
 
 

@@ -11,7 +11,14 @@
 #include <stdint.h>
 #include "../../include/xeve_hip.h"
 
+// A translation unit may define XL (e.g. with always_inline) and XL_CTX (where the coder's context models live) before including this header: the bitstream
+// writer's kernels (encode.hip) keep the models in LDS and the coder core in registers that way.  The defaults are the plain record.
+#ifndef XL
 #define XL __host__ __device__ static inline
+#endif
+#ifndef XL_CTX
+#define XL_CTX(s, ci) (s).ctx[ci]
+#endif
 
 namespace xl {
 typedef int16_t pel;
@@ -95,9 +102,21 @@ XL void sb_shift(Sbac &s, Sink *o = nullptr)
     else s.stacked_ff++;
     s.code_bits = 8;
 }
+// n sb_shift steps at once (a context-coded bin renormalises by 0 .. 5 bits, so at most one byte leaves): the code register reaches the byte boundary with the same
+// value as bit by bit, the byte leaves there, the rest of the shift follows
+XL void sb_shift_n(Sbac &s, int n, Sink *o = nullptr)
+{
+    while(n >= (int)s.code_bits) {
+        n -= (int)s.code_bits;
+        s.code <<= s.code_bits - 1, s.code_bits = 1;
+        sb_shift(s, o); // the boundary step itself: byte out, code_bits = 8
+    }
+    s.code <<= n, s.code_bits -= n;
+}
 XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
 {
-    unsigned state = s.ctx[ci] >> 1, mps = s.ctx[ci] & 1;
+    const unsigned model = XL_CTX(s, ci);
+    unsigned state = model >> 1, mps = model & 1;
     unsigned lps = (state * s.range) >> 9;
     if(lps < 437) lps = 437;
     s.bin_counter++;
@@ -108,8 +127,12 @@ XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
         if(state > 256) mps = 1 - mps, state = 512 - state;
     }
     else state = state - ((state + 16) >> 5);
-    s.ctx[ci] = (uint16_t)((state << 1) + mps);
-    while(s.range < 8192) s.range <<= 1, sb_shift(s, o);
+    XL_CTX(s, ci) = (uint16_t)((state << 1) + mps);
+    if(s.range < 8192) { // (xeve_sbac_encode_bin's renormalisation loop, :559-575, in one step)
+        const int n = __builtin_clz(s.range) - 18;
+        s.range <<= n;
+        sb_shift_n(s, n, o);
+    }
 }
 XL void sb_bin_ep(Sbac &s, unsigned bin, Sink *o = nullptr)
 {   // (the range loses its LSB, xeve_eco.c:455-472)

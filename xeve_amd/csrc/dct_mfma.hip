@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
 #pragma unroll
         for(int ks = 0; ks < NT; ks++) {
             const int y = 32 * mt + l32, x = 32 * ks + 16 * kg;
-            const pel *po = org + jb.off1 + (long)y * s_org + x, *pp = pred + jb.off2 + (long)y * s_pred + x;
+            const pel *po = org + xh_u(jb.off1) + (long)y * s_org + x, *pp = pred + jb.off2 + (long)y * s_pred + x;
             u32x4 d[2];
 #pragma unroll
             for(int hq = 0; hq < 2; hq++) {

@@ -11,9 +11,11 @@
 //       void begin_picture(const PicSetup &);     // every GOP: load the original of frame `frame`, clear the unit maps, take store `cur_slot` for the reconstruction
 //       void reset_chain(int t);                  // every GOP: row chain t's writer = a freshly reset coder (fn_eco_sbac_reset, xeve_enc.c:114-118)
 //       void step(const ChainCtu *c, int n);      // every GOP: decide CTU c[i] from chain c[i].t's writer state (:138-142), write it on that writer (xeve_eco_tree, :152), keep it
-//       void end_picture(bool rewrite, std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins);
-//                                                 // every GOP: loop filter (:462); the slice data = all CTUs written again in raster order on a fresh coder + the tile's end
-//                                                 // (:466-560; rewrite == false: chain 0's own bytes, which are the same when there is one chain); padding (xeve_pic_finish)
+//       void end_picture(bool rewrite);           // every GOP: loop filter (:462); the slice data = all CTUs written again in raster order on a fresh coder + the tile's end
+//                                                 // (:466-560; rewrite == false: chain 0's own bytes, which are the same when there is one chain); padding (xeve_pic_finish).
+//                                                 // ISSUES the work: the next picture may begin while the second writer pass is still running
+//       void collect(std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins);
+//                                                 // the slice data + bin count of the picture last ended (waits for it); called before the next end_picture
 //   };
 #pragma once
 #include "enc_plan.h"
@@ -62,7 +64,7 @@ template <class Engine> class BatchEncoder {
         dpb = Dpb(slots_needed(P, F));
         const int w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU;
         steps = wavefront(w_lcu, h_lcu, P.threads);
-        T = std::min(P.threads, h_lcu), last_intra_poc = 0, pic = 0, step = 0;
+        T = std::min(P.threads, h_lcu), last_intra_poc = 0, pic = 0, step = 0, pending = -1;
         return 0;
     }
     long total_steps() const { return (long)pics.size() * (long)steps.size(); }
@@ -74,8 +76,13 @@ template <class Engine> class BatchEncoder {
             if(step == 0 && begin_picture() != 0) return -1;
             E.step(steps[step].data(), (int)steps[step].size());
             if(++step == (int)steps.size()) {
-                if(end_picture() != 0) return -1;
+                if(pending >= 0 && finish_picture() != 0) return -1; // (the picture before this one: its second writer pass ran beside this picture's steps)
+                E.end_picture(T > 1 || always_rewrite);
+                const PicPlan &pp = pics[pic];
+                dpb.put(S.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length); // xeve_pic_finish -> xeve_picman_put_pic
+                pending = pic, pending_qp = qp;
                 step = 0, pic++;
+                if(pic == (int)pics.size() && finish_picture() != 0) return -1;
             }
         }
         return remaining();
@@ -96,7 +103,7 @@ template <class Engine> class BatchEncoder {
     std::vector<PicPlan> pics;
     std::vector<std::vector<ChainCtu>> steps;
     Dpb dpb;
-    int T = 1, last_intra_poc = 0, pic = 0, step = 0, qp = 0;
+    int T = 1, last_intra_poc = 0, pic = 0, step = 0, qp = 0, pending = -1, pending_qp = 0;
     PicSetup S;
     std::vector<std::vector<uint8_t>> slice;
     std::vector<uint32_t> bins;
@@ -128,10 +135,12 @@ template <class Engine> class BatchEncoder {
         for(int t = 0; t < T; t++) E.reset_chain(t);
         return 0;
     }
-    int end_picture()
+    int finish_picture() // the access unit of the picture whose end was issued last
     {
-        const PicPlan &pp = pics[pic];
-        E.end_picture(T > 1 || always_rewrite, slice, bins);
+        const PicPlan &pp = pics[pending];
+        const int qp = pending_qp;
+        pending = -1;
+        E.collect(slice, bins);
         if((int)slice.size() != G || (int)bins.size() != G) return fail("the engine returned no slice data");
         // the access unit: parameter sets in front of an IDR picture (xeve_header), then the slice NAL unit (xeve_pic :466-590)
         for(int g = 0; g < G; g++) {
@@ -156,7 +165,6 @@ template <class Engine> class BatchEncoder {
             nal_close(nal);
             o.insert(o.end(), nal.begin(), nal.end());
         }
-        dpb.put(S.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length); // xeve_pic_finish -> xeve_picman_put_pic
         return 0;
     }
 };

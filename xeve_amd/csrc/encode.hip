@@ -13,6 +13,15 @@
 #include <memory>
 #include <string>
 #include "xh_common.h"
+// The writer kernels of this file run eco_lane.h's lane code with the coder's 72 context models in LDS ([model][lane]: no bank conflicts, no scratch) and, every
+// function forced inline, the coder core (range, code, pending bytes) and the byte sink in registers.  The lane-serial form with the whole record in scratch
+// (round 2: 13 ms per CTU of noise for one chain, 346 ms per step for 2048 chains) was bound by the scratch round trip of every bin's model.
+#define XL_NCTX 72
+static __shared__ uint16_t xl_lds_ctx[XL_NCTX * 64];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XL __host__ __device__ static inline __attribute__((always_inline))
+#define XL_CTX(s, ci) xl_lds_ctx[(ci) * 64 + (threadIdx.x & 63)]
+#endif
 #include "eco_lane.h"
 #include "enc_host.h"
 
@@ -63,20 +72,37 @@ __global__ void k_enc_keep(const xeve_hip_ctu_data *__restrict__ out, xeve_hip_c
     for(int k = blockIdx.x * blockDim.x + threadIdx.x; k < V; k += gridDim.x * blockDim.x) d[k] = s[k];
 }
 static_assert(sizeof(xeve_hip_ctu_data) % 16 == 0, "CTU records are moved 16 bytes at a time");
+static_assert(sizeof(((xeve_hip_sbac *)0)->ctx) == XL_NCTX * sizeof(uint16_t), "the models' LDS image");
+__device__ __forceinline__ void sbac_in(xl::Sbac &s, const xeve_hip_sbac *__restrict__ g)
+{
+    s = *g;
+#pragma unroll
+    for(int i = 0; i < XL_NCTX; i++) xl_lds_ctx[i * 64 + (threadIdx.x & 63)] = s.ctx[i];
+}
+__device__ __forceinline__ void sbac_out(xeve_hip_sbac *__restrict__ g, xl::Sbac &s)
+{
+#pragma unroll
+    for(int i = 0; i < XL_NCTX; i++) s.ctx[i] = xl_lds_ctx[i * 64 + (threadIdx.x & 63)];
+    *g = s;
+}
 // the writer of the first pass: chain c writes the CTU it has just decided on its own coder; the bytes are kept only where they are the slice data (one chain per
 // picture: cap > 0), appended at pos[g]
 __global__ void __launch_bounds__(64) k_enc_write(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
                                                   const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic,
                                                   const xeve_hip_ctu_job *__restrict__ jobs, int nchains, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if(c >= nchains) return;
+    // ONE CHAIN PER WAVE, one lane working: an arithmetic coder's control flow follows its data bin by bin, so chains packed into the lanes of a wave run one after
+    // the other (measured: 16 chains per wave, 78 ms per CTU of noise; a lone chain, 13 ms) -- a wave per chain keeps every chain at the speed of a lone one, and the
+    // chip holds a thousand waves
+    const int c = blockIdx.x;
+    if(c >= nchains || threadIdx.x != 0) return;
     const xeve_hip_ctu_job J = jobs[c];
-    xl::Sbac s = states[J.sbac];
+    xl::Sbac s;
+    sbac_in(s, states + J.sbac);
     const int at = cap ? pos[J.pic] : 0;
     xl::Sink o = {cap ? bytes + (long)J.pic * cap + at : nullptr, cap ? (int)(cap - at) : 0, 0};
     xl::eco_ctu(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
-    states[J.sbac] = s;
+    sbac_out(states + J.sbac, s);
     if(cap) pos[J.pic] = at + o.n;
 }
 // the second pass (xeve_enc.c:466-560): GOP g's CTUs [lcu0, lcu1) in raster order on the picture's own coder
@@ -84,9 +110,10 @@ __global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__r
                                                     const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, int G, int f_lcu, int w_lcu,
                                                     int lcu0, int lcu1, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if(g >= G) return;
-    xl::Sbac s = states[g];
+    const int g = blockIdx.x; // (one GOP per wave, one lane working: see k_enc_write)
+    if(g >= G || threadIdx.x != 0) return;
+    xl::Sbac s;
+    sbac_in(s, states + g);
     int at = pos[g];
     for(int lcu = lcu0; lcu < lcu1; lcu++) {
         xl::Sink o = {bytes + (long)g * cap + at, (int)(cap - at), 0};
@@ -94,13 +121,14 @@ __global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__r
                     (lcu / w_lcu) * CTU, &o);
         at += o.n;
     }
-    states[g] = s, pos[g] = at;
+    sbac_out(states + g, s);
+    pos[g] = at;
 }
 __global__ void __launch_bounds__(64) k_enc_tile_end(xeve_hip_sbac *__restrict__ states, int stride, int G, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if(g >= G) return;
-    xl::Sbac s = states[(long)g * stride];
+    const int g = blockIdx.x;
+    if(g >= G || threadIdx.x != 0) return;
+    xl::Sbac s = states[(long)g * stride]; // (no context-coded bin here: the models stay where they are)
     const int at = pos[g];
     xl::Sink o = {bytes + (long)g * cap + at, (int)(cap - at), 0};
     xl::eco_tile_end(s, &o);
@@ -137,10 +165,16 @@ struct xeve_hip_enc {
     Param P;
     int   G = 0, F = 0, T = 1, nslots = 0, w_scu = 0, h_scu = 0, w_lcu = 0, h_lcu = 0, f_lcu = 0, vh = 0, s_l = 0, s_c = 0;
     long  org_l = 0, org_c = 0, pic_l = 0, pic_c = 0, map_pic = 0, frame_bytes = 0, slice_cap = 0;
-    hipStream_t st = nullptr;
-    DevBuf frames, org[3], slot_planes, slot_mv, slot_refi, scu, cum, ipm, tidx, store, states, rw_states, jobs, out, next_best, cost, ws, slice, pos;
-    std::vector<xeve_hip_sbac> h_states;
-    std::vector<int32_t>       h_pos;
+    hipStream_t st = nullptr, st2 = nullptr, collect_stream = nullptr; // st2: the second writer pass, beside the next picture's steps
+    hipEvent_t  ev_ready = nullptr, ev_done = nullptr;
+    bool rows_pending = false, two_stores = false;
+    int  cur_store = 0; // the store the picture being decided fills
+    xeve_hip_sbac *fin = nullptr;
+    int fin_stride = 1;
+    DevBuf frames, org[3], slot_planes, slot_mv, slot_refi, scu, cum, ipm, tidx, rw_scu, rw_cum, rw_ipm, store2[2], states, rw_states, jobs, out, next_best, cost, ws, slice, pos;
+    xeve_hip_sbac *h_states = nullptr; // pinned: the copies behind the second writer pass must not stall the host
+    int32_t       *h_pos = nullptr;
+    bool           rewrite_mode = false; // the slice data comes from the second writer pass (several chains per picture, or asked for)
     std::vector<uint8_t>       h_bytes;
     int16_t coef_c[32][4];
     PicSetup S;
@@ -174,19 +208,32 @@ struct xeve_hip_enc {
         vh = (P.h + 2 * PAD_L + 63) & ~63, s_l = P.w + 2 * PAD_L, s_c = P.w / 2 + 2 * PAD_C;
         org_l = (long)vh * P.w, org_c = (long)(vh / 2) * (P.w / 2), pic_l = (long)vh * s_l, pic_c = (long)(vh / 2) * s_c, map_pic = (long)(vh / 4) * w_scu;
         frame_bytes = (long)P.w * P.h * 3 / 2, slice_cap = frame_bytes + 4096;
-        if((double)G * pic_l >= 2147483648.0) return fail("too many GOPs for one batch at this picture size: the stacked planes must stay below 2^31 samples");
+        if((double)G * org_l >= 4294967296.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^32 samples (xh_common.h)");
+        rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
         memset(coef_c, 0, sizeof(coef_c));
         for(int i = 0; i < 8; i++) memcpy(coef_c[4 * i], k_coef_c8[i], sizeof(k_coef_c8[i])); // xeve_tbl_mc_c_coeff (xeve_mc.c:59-93)
-        if(!hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate")) return false;
+        int pr_low = 0, pr_high = 0; // (different priorities = different hardware queues: two streams sharing one run strictly one after the other -- measured: the walk
+                                     // stood still for the whole of the second pass)
+        (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
+        if(!hip_ok(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr_high), "hipStreamCreate") || !hip_ok(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, pr_low), "hipStreamCreate") ||
+           !hip_ok(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming), "hipEventCreate") || !hip_ok(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming), "hipEventCreate"))
+            return false;
+
         const size_t nst = (size_t)G * T;
         bool ok = frames.need((size_t)G * F * frame_bytes) && org[0].need((size_t)G * org_l * 2) && org[1].need((size_t)G * org_c * 2) && org[2].need((size_t)G * org_c * 2) &&
                   slot_planes.need((size_t)nslots * G * (pic_l + 2 * pic_c) * 2) && slot_mv.need((size_t)nslots * G * map_pic * 8) && slot_refi.need((size_t)nslots * G * map_pic * 2) &&
                   scu.need((size_t)G * map_pic * 4) && cum.need((size_t)G * map_pic * 4) && ipm.need((size_t)G * map_pic) && tidx.need((size_t)G * map_pic) &&
                   states.need(nst * sizeof(xeve_hip_sbac)) && rw_states.need((size_t)G * sizeof(xeve_hip_sbac)) && jobs.need(nst * sizeof(xeve_hip_ctu_job)) &&
                   out.need(nst * sizeof(xeve_hip_ctu_data)) && next_best.need(nst * sizeof(xeve_hip_sbac)) && cost.need(nst * 8) && slice.need((size_t)G * slice_cap) &&
-                  pos.need((size_t)G * 4) && (T == 1 && !(P_reserved0 & 1) ? true : store.need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data)));
+                  pos.need((size_t)G * 4) &&
+                  (!rewrite_mode ? true
+                                                : store2[0].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data)) && rw_scu.need((size_t)G * map_pic * 4) &&
+                                                      rw_cum.need((size_t)G * map_pic * 4) && rw_ipm.need((size_t)G * map_pic));
+        // a second CTU store lets the second writer pass of a picture run beside the next picture's steps (which fill the other store); without the memory for it the
+        // next picture waits for the pass
+        if(ok && rewrite_mode) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"
@@ -196,13 +243,20 @@ struct xeve_hip_enc {
         memset(&E, 0, sizeof(E));
         for(int l = 4; l <= LOG2_CTU; l++)
             if(!rc_ok(xh_get_scan(l, l, &E.scan[l]), "scan tables")) return false;
-        h_states.resize(G), h_pos.resize(G);
+        if(!hip_ok(hipHostMalloc((void **)&h_states, (size_t)G * sizeof(xeve_hip_sbac), hipHostMallocDefault), "hipHostMalloc") ||
+           !hip_ok(hipHostMalloc((void **)&h_pos, (size_t)G * 4, hipHostMallocDefault), "hipHostMalloc"))
+            return false;
         return hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
     int P_reserved0 = 0; // bit 0: always run the second writer pass (tests)
     ~xeve_hip_enc()
     {
+        if(st2) (void)hipStreamSynchronize(st2), (void)hipStreamDestroy(st2);
         if(st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
+        if(ev_ready) (void)hipEventDestroy(ev_ready);
+        if(ev_done) (void)hipEventDestroy(ev_done);
+        if(h_states) (void)hipHostFree(h_states);
+        if(h_pos) (void)hipHostFree(h_pos);
     }
 
     void begin_picture(const PicSetup &setup)
@@ -215,7 +269,7 @@ struct xeve_hip_enc {
         hip_ok(hipMemsetAsync(scu.p, 0, scu.bytes, st), "hipMemset"), hip_ok(hipMemsetAsync(cum.p, 0, cum.bytes, st), "hipMemset"); // xeve_pic_prepare (:1236-1237)
         hip_ok(hipMemsetAsync(slot_map_mv(S.cur_slot), 0, (size_t)G * map_pic * 8, st), "hipMemset"); // (:1220-1225)
         hip_ok(hipMemsetAsync(slot_map_refi(S.cur_slot), 0xFF, (size_t)G * map_pic * 2, st), "hipMemset");
-        hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset");
+        if(!rewrite_mode) hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset"); // (the first pass's bytes are the slice data; otherwise the second pass owns the buffers)
         memset(tab, 0, sizeof(tab));
         if(S.slice_type != ST_I) {
             for(int l = 0; l < 2; l++)
@@ -237,7 +291,8 @@ struct xeve_hip_enc {
     {
         if(error.empty()) k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st>>>(states.as<xeve_hip_sbac>(), T, t, G);
     }
-    bool keeps_store() const { return store.p != nullptr; }
+    bool keeps_store() const { return store2[0].p != nullptr; }
+    xeve_hip_ctu_data *store_now() const { return store2[cur_store].as<xeve_hip_ctu_data>(); }
     void step(const ChainCtu *c, int n)
     {
         if(!error.empty()) return;
@@ -247,6 +302,10 @@ struct xeve_hip_enc {
         D.n = n;
         for(int i = 0; i < n; i++) D.t[i] = c[i].t, D.x[i] = c[i].x, D.y[i] = c[i].y, D.lcu[i] = c[i].lcu;
         const int nch = n * G;
+        if(rows_pending && !two_stores) { // (one store: it is about to be overwritten -- the pass must be through)
+            if(!hip_ok(hipStreamWaitEvent(st, ev_done, 0), "event")) return;
+            rows_pending = false;
+        }
         k_enc_jobs<<<(nch + 255) / 256, 256, 0, st>>>(D, G, T, jobs.as<xeve_hip_ctu_job>());
         const pel *o[3] = {org[0].as<pel>(), org[1].as<pel>(), org[2].as<pel>()};
         pel       *m[3] = {slot_plane(S.cur_slot, 0), slot_plane(S.cur_slot, 1), slot_plane(S.cur_slot, 2)};
@@ -256,15 +315,18 @@ struct xeve_hip_enc {
                                                  out.as<xeve_hip_ctu_data>(), next_best.as<xeve_hip_sbac>(), cost.as<double>(), ws.p, ws.bytes, st),
                   "xeve_hip_mode_analyze_ctu_jobs"))
             return;
-        if(keeps_store()) k_enc_keep<<<dim3(4, nch), 256, 0, st>>>(out.as<xeve_hip_ctu_data>(), store.as<xeve_hip_ctu_data>(), D, G, f_lcu);
-        k_enc_write<<<(nch + 63) / 64, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(),
-                                                    cum.as<uint32_t>(), map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), T == 1 ? slice_cap : 0, pos.as<int32_t>());
+        if(keeps_store()) k_enc_keep<<<dim3(4, nch), 256, 0, st>>>(out.as<xeve_hip_ctu_data>(), store_now(), D, G, f_lcu);
+        k_enc_write<<<nch, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(),
+                                                    cum.as<uint32_t>(), map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), rewrite_mode ? 0 : slice_cap, pos.as<int32_t>());
         hip_ok(hipGetLastError(), "step kernels");
         n_steps++, t_steps += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    void end_picture(bool rewrite, std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins)
+    // The picture's end, ISSUED: loop filter and padding on the main stream (the next picture may start behind them); the slice data on the second stream, from private
+    // copies of the unit maps and from the picture's own CTU store (the next picture fills the other one) -- the second writer pass (2040 serial CTUs per 3840x2160
+    // picture: seconds) runs beside the next picture's steps, and nothing on the main stream waits for it.  (A wait on an event of the second stream turned out to
+    // cover everything queued there: measured, the walk stood still for the whole pass.)
+    void end_picture(bool rewrite)
     {
-        slice_data.clear(), bins.clear();
         if(!error.empty()) return;
         const auto t0 = std::chrono::steady_clock::now();
         for(int g = 0; g < G; g++) // xeve_loop_filter
@@ -273,39 +335,67 @@ struct xeve_hip_enc {
                                        slot_map_refi(S.cur_slot) + (size_t)g * map_pic * 2, slot_map_mv(S.cur_slot) + (size_t)g * map_pic * 4, &S.dp, st),
                       "xeve_hip_deblock"))
                 return;
-        xeve_hip_sbac *fin = states.as<xeve_hip_sbac>();
-        int            stride = T;
+        fin = states.as<xeve_hip_sbac>(), fin_stride = T;
+        hipStream_t ws_ = st;
         if(rewrite) {
             if(!keeps_store()) { fail("the second writer pass needs the CTU store"); return; }
-            const long n = (long)G * map_pic;
-            k_enc_clear_cod<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(scu.as<uint32_t>(), n); // MCU_CLR_COD over the picture (:466-468)
-            hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset");
-            fin = rw_states.as<xeve_hip_sbac>(), stride = 1;
-            k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st>>>(fin, 1, 0, G);
-            for(int row = 0; row < h_lcu; row++)
-                k_enc_rewrite<<<(G + 63) / 64, 64, 0, st>>>(store.as<xeve_hip_ctu_data>(), fin, E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(),
-                                                            map_pic, G, f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+            const size_t n = (size_t)G * map_pic;
+            if(!hip_ok(hipMemcpyAsync(rw_scu.p, scu.p, n * 4, hipMemcpyDeviceToDevice, st), "copy maps") || !hip_ok(hipMemcpyAsync(rw_cum.p, cum.p, n * 4, hipMemcpyDeviceToDevice, st), "copy maps") ||
+               !hip_ok(hipMemcpyAsync(rw_ipm.p, ipm.p, n, hipMemcpyDeviceToDevice, st), "copy maps") || !hip_ok(hipEventRecord(ev_ready, st), "event") ||
+               !hip_ok(hipStreamWaitEvent(st2, ev_ready, 0), "event"))
+                return;
+            ws_ = st2;
+            k_enc_clear_cod<<<(unsigned)((n + 255) / 256), 256, 0, st2>>>(rw_scu.as<uint32_t>(), (long)n); // MCU_CLR_COD over the picture (:466-468)
+            hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st2), "hipMemset");
+            fin = rw_states.as<xeve_hip_sbac>(), fin_stride = 1;
+            k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st2>>>(fin, 1, 0, G);
+            xl::EcoParams Ew = E; // (the pass's own copy: E follows the next picture)
+            for(int row = 0; row < h_lcu; row++) {
+                k_enc_rewrite<<<G, 64, 0, st2>>>(store_now(), fin, Ew, rw_scu.as<uint32_t>(), rw_ipm.as<int8_t>(), tidx.as<uint8_t>(), rw_cum.as<uint32_t>(),
+                                                 map_pic, G, f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+            }
+            rows_pending = true;
+            if(two_stores) cur_store ^= 1;
         }
-        k_enc_tile_end<<<(G + 63) / 64, 64, 0, st>>>(fin, stride, G, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+        k_enc_tile_end<<<G, 64, 0, ws_>>>(fin, fin_stride, G, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
         for(int g = 0; g < G; g++) // xeve_pic_finish: the picture becomes a reference
             if(!rc_ok(xeve_hip_picbuf_expand(slot_plane(S.cur_slot, 0) + (size_t)g * pic_l, slot_plane(S.cur_slot, 1) + (size_t)g * pic_c, slot_plane(S.cur_slot, 2) + (size_t)g * pic_c,
                                              s_l, s_c, P.w, P.h, P.w / 2, P.h / 2, PAD_L, PAD_C, 1, st),
                       "xeve_hip_picbuf_expand"))
                 return;
-        if(!hip_ok(hipMemcpy2DAsync(h_states.data(), sizeof(xeve_hip_sbac), fin, sizeof(xeve_hip_sbac) * (size_t)stride, sizeof(xeve_hip_sbac), G, hipMemcpyDeviceToHost, st), "copy states") ||
-           !hip_ok(hipMemcpyAsync(h_pos.data(), pos.p, (size_t)G * 4, hipMemcpyDeviceToHost, st), "copy sizes") || !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+        if(!hip_ok(hipMemcpy2DAsync(h_states, sizeof(xeve_hip_sbac), fin, sizeof(xeve_hip_sbac) * (size_t)fin_stride, sizeof(xeve_hip_sbac), G, hipMemcpyDeviceToHost, ws_), "copy states") ||
+           !hip_ok(hipMemcpyAsync(h_pos, pos.p, (size_t)G * 4, hipMemcpyDeviceToHost, ws_), "copy sizes") || !hip_ok(hipEventRecord(ev_done, ws_), "event"))
             return;
+        collect_stream = ws_, have_held = false;
+        t_ends += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if(ws_ == st) fetch(held, held_bins), have_held = true; // (one chain per picture: the next picture's writer appends to the same buffers, so they are read out now)
+    }
+    std::vector<std::vector<uint8_t>> held;
+    std::vector<uint32_t> held_bins;
+    bool have_held = false;
+    void collect(std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins)
+    {
+        if(have_held) slice_data.swap(held), bins.swap(held_bins), have_held = false;
+        else fetch(slice_data, bins);
+    }
+    void fetch(std::vector<std::vector<uint8_t>> &slice_data, std::vector<uint32_t> &bins)
+    {
+        slice_data.clear(), bins.clear();
+        if(!error.empty()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        if(!hip_ok(hipEventSynchronize(ev_done), "hipEventSynchronize")) return;
         slice_data.resize(G), bins.resize(G);
         for(int g = 0; g < G; g++) {
             if(h_pos[g] < 0 || h_pos[g] > slice_cap) { fail("a picture's slice data outgrew its buffer"); slice_data.clear(), bins.clear(); return; }
             slice_data[g].resize(h_pos[g]);
-            if(h_pos[g] && !hip_ok(hipMemcpyAsync(slice_data[g].data(), slice.as<uint8_t>() + (size_t)g * slice_cap, h_pos[g], hipMemcpyDeviceToHost, st), "copy slice data")) {
+            if(h_pos[g] && !hip_ok(hipMemcpyAsync(slice_data[g].data(), slice.as<uint8_t>() + (size_t)g * slice_cap, h_pos[g], hipMemcpyDeviceToHost, collect_stream), "copy slice data")) {
                 slice_data.clear(), bins.clear();
                 return;
             }
             bins[g] = h_states[g].bin_counter;
         }
-        if(!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) slice_data.clear(), bins.clear();
+        if(!hip_ok(hipStreamSynchronize(collect_stream), "hipStreamSynchronize")) slice_data.clear(), bins.clear();
+        rows_pending = false;
         t_ends += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 };

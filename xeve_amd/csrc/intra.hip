@@ -131,8 +131,8 @@ __global__ void k_intra_pred(const pel *__restrict__ nb, const int *__restrict__
 }
 
 // ---- 3. jobs of the SATD and of the mode-index bit count ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int org_off_l(const xeve_hip_intra_job &J, const IntraK &P) { return (int)((long)J.pic * P.org_pic_l + (long)J.y * P.s_org_l + J.x); }
-__device__ __forceinline__ int org_off_c(const xeve_hip_intra_job &J, const IntraK &P) { return (int)((long)J.pic * P.org_pic_c + (long)(J.y >> P.hs) * P.s_org_c + (J.x >> P.ws)); }
+__device__ __forceinline__ int org_off_l(const xeve_hip_intra_job &J, const IntraK &P) { return (int)(uint32_t)((long)J.pic * P.org_pic_l + (long)J.y * P.s_org_l + J.x); }
+__device__ __forceinline__ int org_off_c(const xeve_hip_intra_job &J, const IntraK &P) { return (int)(uint32_t)((long)J.pic * P.org_pic_c + (long)(J.y >> P.hs) * P.s_org_c + (J.x >> P.ws)); }
 
 __global__ void k_intra_jobs1(const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const unsigned char *__restrict__ mpm_row, xeve_hip_job *__restrict__ sj,
                               xeve_hip_cu_bits_job *__restrict__ bj, int32_t *__restrict__ zero)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_sad_sq(const pel *__restrict__ p1, int 
 
     u32x4 org[G::NP];
 #pragma unroll
-    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + jb.off1 + (row0 + p * G::RPP) * s1 + col);
+    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + xh_u(jb.off1) + (row0 + p * G::RPP) * s1 + col);
 
     const long base2 = (long)jb.off2 + row0 * s2 + col; // element index into plane 2
     int32_t   *o     = out + (size_t)job * ncand;
@@ -129,7 +129,7 @@ __global__ void k_sad_any(const pel *__restrict__ p1, int s1, const pel *__restr
     const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(item >= njobs * ncand) return;
     const xeve_hip_job jb = jobs[item / ncand];
-    const pel *a = p1 + jb.off1, *b = p2 + jb.off2 + cand_off[item % ncand];
+    const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     int acc = 0;
     for(int i = lane; i < w * h; i += 64) {
         int y = i / w, x = i - y * w;
@@ -149,7 +149,7 @@ __global__ void k_dist_tiny(const pel *__restrict__ p1, int s1, const pel *__res
     const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if(item >= items) return;
     const xeve_hip_job jb = jobs[item / ncand];
-    const pel *a = p1 + jb.off1, *b = p2 + jb.off2 + cand_off[item % ncand];
+    const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     long acc = 0;
     for(int y = 0; y < h; y++)
         for(int x = 0; x < w; x++) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_ssd_sq(const pel *__restrict__ p1, int 
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
     u32x4 org[G::NP];
 #pragma unroll
-    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + jb.off1 + (row0 + p * G::RPP) * s1 + col);
+    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + xh_u(jb.off1) + (row0 + p * G::RPP) * s1 + col);
     const pel *base2 = p2 + jb.off2 + row0 * s2 + col;
     for(int c0 = 0; c0 < ncand; c0 += G::CPP) {
         const int c   = c0 + slot;
@@ -221,7 +221,7 @@ __global__ void k_ssd_any(const pel *__restrict__ p1, int s1, const pel *__restr
     const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(item >= njobs * ncand) return;
     const xeve_hip_job jb = jobs[item / ncand];
-    const pel *a = p1 + jb.off1, *b = p2 + jb.off2 + cand_off[item % ncand];
+    const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     uint64_t acc = 0;
     for(int i = lane; i < w * h; i += 64) {
         int y = i / w, x = i - y * w;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_satd_sq(const pel *__restrict__ p1, int
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
     u32x4 org[G::NP];
 #pragma unroll
-    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + jb.off1 + (row0 + p * G::RPP) * s1 + col);
+    for(int p = 0; p < G::NP; p++) org[p] = xh_ld8(p1 + xh_u(jb.off1) + (row0 + p * G::RPP) * s1 + col);
     const pel *base2  = p2 + jb.off2 + row0 * s2 + col;
     const int  trow   = row0 & 7; // row inside the 8x8 tile (RPP is a multiple of 8 or equals S=8)
     for(int c0 = 0; c0 < ncand; c0 += G::CPP) {
@@ -325,7 +325,7 @@ __global__ void k_satd_tiles(const pel *__restrict__ p1, int s1, const pel *__re
     const int item = (int)(t / tiles), tile = (int)(t % tiles);
     const xeve_hip_job jb = jobs[item / ncand];
     const int ty = tile / tiles_x, tx = tile % tiles_x;
-    const pel *a = p1 + jb.off1 + ty * th * s1 + tx * tw;
+    const pel *a = p1 + xh_u(jb.off1) + ty * th * s1 + tx * tw;
     const pel *b = p2 + jb.off2 + cand_off[item % ncand] + ty * th * s2 + tx * tw;
     int v[128];
     for(int y = 0; y < th; y++)
@@ -373,7 +373,7 @@ __global__ void k_diff(const pel *__restrict__ p1, int s1, const pel *__restrict
     if(t >= (long)njobs * per) return;
     const int j = (int)(t / per), r = (int)(t % per), y = r / segs, x0 = (r % segs) * 8;
     const xeve_hip_job jb = jobs[j];
-    const pel *a = p1 + jb.off1 + y * s1 + x0, *b = p2 + jb.off2 + y * s2 + x0;
+    const pel *a = p1 + xh_u(jb.off1) + y * s1 + x0, *b = p2 + jb.off2 + y * s2 + x0;
     int16_t   *d = diff + (size_t)j * w * h + y * w + x0;
     if(w - x0 >= 8) {
         u32x4 va = xh_ld8(a), vb = xh_ld8(b), vd;

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
         unsigned long long s = 0;
         for(int i = t; i < n; i += tpb) {
             const int y = i >> log2w, x = i & (w - 1);
-            const int d = (int)org[jb.off1 + y * s_org + x] - (int)pred[jb.off2 + y * s_pred + x];
+            const int d = (int)org[xh_u(jb.off1) + y * s_org + x] - (int)pred[jb.off2 + y * s_pred + x];
             X[i] = d;
             s += (unsigned)((d * d) >> P.ssd_shift);
         }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
             int r = (int)(int16_t)((int)a + (int)pred[jb.off2 + y * s_pred + x]);
             r     = r < 0 ? 0 : (r > P.maxv ? P.maxv : r);
             rec[(s_rec > 0 ? (long)jb.off1 + (long)y * s_rec : (long)j * n - (long)y * s_rec) + x] = (pel)r; // (s_rec < 0: dense blocks, block j at j * n, pitch -s_rec)
-            const int e = (int)org[jb.off1 + y * s_org + x] - r;
+            const int e = (int)org[xh_u(jb.off1) + y * s_org + x] - r;
             s += (unsigned)((e * e) >> P.ssd_shift);
         }
         atomicAdd(&acc64[1], s);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
     int o[N], p[N], v[N];
     unsigned long long ssd_p = 0, ssd_r = 0;
     if(live) { // one row = N pels: 8-byte (N = 4) or 16-byte vector loads at any 2-byte alignment
-        const pel *po = org + jb.off1 + (long)y * s_org, *pp = pred + jb.off2 + (long)y * s_pred;
+        const pel *po = org + xh_u(jb.off1) + (long)y * s_org, *pp = pred + jb.off2 + (long)y * s_pred;
         if(N == 4) {
             const u32x2 a = xh_ld4(po), b = xh_ld4(pp);
 #pragma unroll

@@ -95,8 +95,9 @@ struct XhSearchPlanes {
 // operations carry a picture index (job.pic + pic_elems); the inter analysis, whose job records have no room for one, sees the batch as ONE TALL PICTURE: every plane
 // and unit map of picture p lies p * vh luma rows below picture 0's (vh = the virtual picture height, a multiple of 64 that covers the padded picture), a job's y
 // is pic * vh + its row in the picture, and `plane + y * stride + x` addresses the right picture with no further help.  Only the few kernels that compare y with the
-// picture's bounds (search ranges, vector clipping, neighbour availability, picture coordinates kept in 16 bits) split y again with xh_vh_base.  The stacked planes
-// stay below 2^31 elements (the caller's duty), so 32-bit element offsets keep working.  The height travels per host thread: the walk sets it around the inter calls.
+// picture's bounds (search ranges, vector clipping, neighbour availability, picture coordinates kept in 16 bits) split y again with xh_vh_base.  Reference planes
+// are addressed through (x, y) with 64-bit row arithmetic; offsets into the stacked ORIGINALS are unsigned 32-bit (xh_u below), so a batch's originals stay below 2^32
+// samples (the caller's duty).  The height travels per host thread: the walk sets it around the inter calls.
 int xh_vh();
 struct XhVhScope {
     int prev;
@@ -104,6 +105,10 @@ struct XhVhScope {
     ~XhVhScope();
 };
 __host__ __device__ __forceinline__ int xh_vh_base(int y, int vh) { return vh > 0 ? (y / vh) * vh : 0; }
+// Offsets into the ORIGINAL (xeve_hip_job.off1, the fused comparison's pred_off) are 32-bit element counts read as UNSIGNED: the stacked originals of a batch may span up
+// to 2^32 samples (448 pictures of 3840x2160).  Producers compute in 64 bits and keep the low 32 (xh_org_off), consumers widen without sign (xh_u).
+__host__ __device__ __forceinline__ size_t xh_u(int off) { return (size_t)(uint32_t)off; }
+__host__ __device__ __forceinline__ int    xh_org_off(long y, long stride, long x) { return (int)(uint32_t)(y * stride + x); }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
