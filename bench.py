@@ -72,7 +72,7 @@ class CpuApp:
     """the reference encoder on this box's host cores: xeveb_app -m 8 and -m 1 side by side on the first `frames` frames of the seed-4 clip (started in the background
     while the GPU encodes; `result()` waits for them)"""
 
-    def __init__(self, width, height, frames, clip):
+    def __init__(self, width, height, frames, clip, with_m1=False):
         self.w, self.h, self.frames, self.procs, self.err = width, height, frames, {}, None
         self.exe = os.path.join(ROOT, "oracle", "_ref", "xeveb_app")
         if not os.path.exists(self.exe):
@@ -82,7 +82,7 @@ class CpuApp:
             self.dir = tempfile.mkdtemp(prefix="xeve_bench_")
             yuv = os.path.join(self.dir, "in.yuv")
             clip.tofile(yuv)
-            for m in (8, 1):
+            for m in ((8, 1) if with_m1 else (8,)):
                 cmd = [self.exe, "-i", yuv, "-w", str(width), "-h", str(height), "-z", "30", "--preset", "medium", "--closed-gop", "-I", "8", "--frames", str(frames),
                        "-m", str(m), "-o", os.path.join(self.dir, "m%d.evc" % m)]
                 self.procs[m] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), time.perf_counter(), cmd)
@@ -115,7 +115,7 @@ class CpuApp:
         return {"value": m8.get("fps"), "unit": "frames/s", "cores": 8, "kind": "reference",
                 "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit "
                           "4:2:0 clip (frame 0 is the IDR picture, the rest inter pictures) = GOP 0 of the GPU job; `value` = -m 8 (the library's thread maximum, the setting the "
-                          "GPU job reproduces byte for byte), `m1` = -m 1; the two ran side by side on different cores while the GPU encoded" % (self.w, self.h, self.frames),
+                          "GPU job reproduces byte for byte); `m1` = -m 1 when asked for (--cpu-m1; 0.053 frames/s in profiles/r03_bench.json); on the host's cores while the GPU encoded" % (self.w, self.h, self.frames),
                 "m8": m8, "m1": m1, "host": host_info()}
 
 
@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
     ap.add_argument("--batches", type=int, default=1, help="independent batches of --gops GOPs encoded side by side on this GPU (one host thread and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-m1", action="store_true", help="time the reference with one thread too (-m 1: ~3 minutes at 3840x2160; profiles/r03_bench.json has it)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed per-kernel-class pass")
     a = ap.parse_args()
 
@@ -193,7 +194,7 @@ def main():
             for f in range(F):
                 e.push(g, f, d[f * fb:(f + 1) * fb])
     del d
-    cpu = CpuApp(W, H, F, clip) if solo and not a.no_cpu_baseline else None  # (host cores only; runs while the GPU encodes)
+    cpu = CpuApp(W, H, F, clip, a.cpu_m1) if solo and not a.no_cpu_baseline else None  # (host cores only; runs while the GPU encodes)
 
     def fence():
         for e in encs:
@@ -271,6 +272,7 @@ def main():
         try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_search_pmc.json")))
             roof["traffic"] = pmc.get("hbm_bytes_per_launch_x2")
+            roof["traffic_is"] = "HBM bytes per launch of the kernel in the PMC run of profiles/r03_search_pmc.json (128 chains in lockstep; this job's launches carry %d)" % (G * min(T, h_lcu))
             if pmc.get("hbm_bytes_per_launch_x2") and pmc.get("avg_launch_s"):
                 roof["hbm_physical_GBps"] = round(pmc["hbm_bytes_per_launch_x2"] / pmc["avg_launch_s"] / 1e9, 1)
                 roof["hbm_physical_frac"] = round(roof["hbm_physical_GBps"] / HBM_PEAK_GBS, 4)

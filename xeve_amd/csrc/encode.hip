@@ -10,6 +10,7 @@
 // pictures of the batch are STACKED VERTICALLY (xh_common.h): GOP g's planes and maps lie g * vh luma rows below GOP 0's, so the intra analysis / the tree operations
 // address them with a picture index and element distances (pic_elems) and the inter analysis as one tall picture.
 #include <chrono>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include "xh_common.h"
@@ -214,9 +215,10 @@ struct xeve_hip_enc {
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
         memset(coef_c, 0, sizeof(coef_c));
         for(int i = 0; i < 8; i++) memcpy(coef_c[4 * i], k_coef_c8[i], sizeof(k_coef_c8[i])); // xeve_tbl_mc_c_coeff (xeve_mc.c:59-93)
-        int pr_low = 0, pr_high = 0; // (different priorities = different hardware queues: two streams sharing one run strictly one after the other -- measured: the walk
-                                     // stood still for the whole of the second pass)
+        int pr_low = 0, pr_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
+        const char *pe = getenv("XEVE_HIP_ENC_PRIO"); // developer switch: 1 = the walk's stream above the second pass's
+        if(!(pe && atoi(pe) == 1)) pr_low = pr_high = 0;
         if(!hip_ok(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr_high), "hipStreamCreate") || !hip_ok(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, pr_low), "hipStreamCreate") ||
            !hip_ok(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming), "hipEventCreate") || !hip_ok(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming), "hipEventCreate"))
             return false;
