@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per GPU (0: as many as the picture size allows, at most 384)")
+    ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per GPU (0: as many as the picture size allows, at most 448)")
     ap.add_argument("--frames", type=int, default=2, help="frames per GOP (2: the IDR picture and one inter picture, the CPU baseline's sample)")
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
     ap.add_argument("--batches", type=int, default=1, help="independent batches of --gops GOPs encoded side by side on this GPU (one host thread and HIP stream each)")
@@ -175,7 +175,7 @@ def main():
     fb = W * H * 3 // 2
     w_lcu, h_lcu = (W + 63) // 64, (H + 63) // 64
     vh = (H + 288 + 63) & ~63
-    G = a.gops or max(1, min(384, int((2 ** 32 - 1) // (vh * W))))  # (the library's limit: the stacked originals of a batch below 2^32 samples)
+    G = a.gops or max(1, min(448, int((2 ** 32 - 1) // (vh * W))))  # (the library's limit: the stacked originals of a batch below 2^32 samples)
     cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
     B = max(1, a.batches)
     encs = [encode.BatchEncoder(cfg, G, F) for _ in range(B)]

@@ -113,9 +113,9 @@ XL void sb_shift_n(Sbac &s, int n, Sink *o = nullptr)
     }
     s.code <<= n, s.code_bits -= n;
 }
-XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
+// one context-coded bin on a model the caller holds in a register (a run of bins on one model -- the tail of a unary symbol -- loads and stores it once)
+XL void sb_bin_m(Sbac &s, unsigned &model, unsigned bin, Sink *o = nullptr)
 {
-    const unsigned model = XL_CTX(s, ci);
     unsigned state = model >> 1, mps = model & 1;
     unsigned lps = (state * s.range) >> 9;
     if(lps < 437) lps = 437;
@@ -127,12 +127,18 @@ XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
         if(state > 256) mps = 1 - mps, state = 512 - state;
     }
     else state = state - ((state + 16) >> 5);
-    XL_CTX(s, ci) = (uint16_t)((state << 1) + mps);
+    model = (state << 1) + mps;
     if(s.range < 8192) { // (xeve_sbac_encode_bin's renormalisation loop, :559-575, in one step)
         const int n = __builtin_clz(s.range) - 18;
         s.range <<= n;
         sb_shift_n(s, n, o);
     }
+}
+XL void sb_bin(Sbac &s, int ci, unsigned bin, Sink *o = nullptr)
+{
+    unsigned model = XL_CTX(s, ci);
+    sb_bin_m(s, model, bin, o);
+    XL_CTX(s, ci) = (uint16_t)model;
 }
 XL void sb_bin_ep(Sbac &s, unsigned bin, Sink *o = nullptr)
 {   // (the range loses its LSB, xeve_eco.c:455-472)
@@ -151,10 +157,13 @@ XL unsigned sb_bits(const Sbac &s) { return s.bitcounter + 8 * (s.stacked_zero +
 XL void sb_unary2(Sbac &s, unsigned sym, int ci, Sink *o = nullptr)
 {   // sbac_write_unary_sym with two models (xeve_eco.c:474-490)
     sb_bin(s, ci, sym ? 1 : 0, o);
+    if(!sym) return;
+    unsigned model = XL_CTX(s, ci + 1);
     while(sym) {
         sym--;
-        sb_bin(s, ci + 1, sym ? 1 : 0, o);
+        sb_bin_m(s, model, sym ? 1 : 0, o);
     }
+    XL_CTX(s, ci + 1) = (uint16_t)model;
 }
 // xeve_eco_run_length_cc (xeve_eco.c:707-771), Baseline contexts (sps_cm_init_flag 0); n: 2, 4, 8 through the tables, larger blocks through the scan the caller passes
 XL void sb_run_length(Sbac &s, const int16_t *coef, int n, int num_sig, int ch, Sink *o = nullptr, const uint16_t *scan = nullptr)

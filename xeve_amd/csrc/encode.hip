@@ -235,7 +235,10 @@ struct xeve_hip_enc {
                                                       rw_cum.need((size_t)G * map_pic * 4) && rw_ipm.need((size_t)G * map_pic));
         // a second CTU store lets the second writer pass of a picture run beside the next picture's steps (which fill the other store); without the memory for it the
         // next picture waits for the pass
-        if(ok && rewrite_mode) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
+        // (MEASURED, profiles/r03f_probe_4k_g384.log + the kernel trace of README's r03h: the device runs the two streams one after the other -- 0.6 ms of other
+        // kernels inside 1.4 s of second pass, with or without stream priorities -- so the second store buys nothing today; XEVE_HIP_ENC_TWO_STORES=1 keeps the path alive)
+        const char *ts = getenv("XEVE_HIP_ENC_TWO_STORES");
+        if(ok && rewrite_mode && ts && atoi(ts) == 1) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"

@@ -241,8 +241,9 @@ __global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK
     }
 }
 
-__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej, unsigned char *__restrict__ job_plane)
+__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej, unsigned char *__restrict__ job_plane, int32_t *__restrict__ cnt)
 {
+    if(blockIdx.x == 0 && threadIdx.x < 2) cnt[threadIdx.x] = 0; // (the round's job counters: k_bi_me_jobs, the next launch, counts from zero)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= P.nb * P.n) return;
     ej[t].x = -1, job_plane[t] = 0;
@@ -532,8 +533,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
                                      pred[2], scr, L.scratch_bytes, stream);
             if(rc != XEVE_HIP_OK) return rc;
             k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], org_bi);
-            XH_HIP(hipMemsetAsync(cnt, 0, 8, s));
-            k_bi_jobs_off<<<(P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej, job_plane);
+            k_bi_jobs_off<<<(P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej, job_plane, cnt);
             k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt, job_plane);
             planes_for(2, 1);
             pl.job_plane = job_plane;

@@ -436,8 +436,10 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeK K, OpList ops)
 template <int LOG2> __global__ void __launch_bounds__(64) k_intra_lane(TreeK K, xl::Params P, const pel *org_y, const pel *org_u, const pel *org_v, const uint8_t *map_tidx,
                                                                         long org_pic_l, long org_pic_c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, L = LOG2 - 2;
-    if(c >= K.nchains) return;
+    // one chain per WAVE, one lane working: the chains of a wave took every branch of this long scalar code one after the other (the writer kernels of encode.hip
+    // met the same wall: 16 chains per wave ran 13 x slower than a wave each)
+    const int c = blockIdx.x, L = LOG2 - 2;
+    if(c >= K.nchains || threadIdx.x != 0) return;
     const Node *nd = AT(K.node, L);
     if(!nd->leaf || (K.inter && !nd->try_intra)) return; // (nothing reads the result of a chain whose node is off)
     const xeve_hip_intra_job J = K.ijobs[c];
@@ -701,7 +703,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
             int rc = XEVE_HIP_OK;
             if(wk.kind[i] == AN_INTRA && log2 <= 3 && use_lane) { // one lane per chain decides the node (cu_lane.h)
                 const xl::Params LP = lane_params(p, log2, s_org_l, s_org_c, s_mod_l, s_mod_c);
-                const int grid = (nchains + 63) / 64;
+                const int grid = nchains;
                 if(log2 == 2) k_intra_lane<2><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
                 else k_intra_lane<3><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
             }
