@@ -56,5 +56,9 @@ with tempfile.TemporaryDirectory() as d:
             b = open(evc, "rb").read()
             per.append({"md5": md5(b), "bytes": len(b)})
         out["batches"][name] = {"w": w, "h": h, "gops": gops, "frames": frames, "seed": seed, "cli": cli, "threads": threads, "per_gop": per}
-        print(name, per)
+        if gops > 1 and name in BATCH_CASES:  # the whole sequence in ONE run of the reference: what the concatenated per-GOP bitstreams must be
+            app(yuv, evc, w, h, gops * frames, cli, threads)
+            b = open(evc, "rb").read()
+            out["batches"][name]["whole"] = {"md5": md5(b), "bytes": len(b)}
+        print(name, per, out["batches"][name].get("whole"))
 json.dump(out, open(GOLDEN, "w"), indent=1)

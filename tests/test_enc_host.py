@@ -55,6 +55,61 @@ def test_batches_of_closed_gops_reproduce_the_reference_run_per_gop(name, yuv_di
     data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
     outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+    whole = b"".join(outs)  # and the concatenation = the reference's ONE run over the whole sequence (what makes closed GOPs shardable)
+    assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+import _e2e, _enc
+from xeve_amd import gop
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+name, work = sys.argv[2], sys.argv[3]
+W, H, gops, frames, seed, cli, threads = _enc.BATCH_CASES[name]
+yuv = os.path.join(work, "in.yuv")
+if r == 0:
+    _e2e.make_yuv(yuv, W, H, gops * frames, seed)
+dist.barrier()
+data, fb = open(yuv, "rb").read(), W * H * 3 // 2 * frames
+mine = [s.gop for s in gop.shards_for_rank(gops * frames, frames, r, w)]            # GOP g -> rank g mod world: the driver's partition
+outs = _enc.encode_cpu(_enc.config(W, H, cli, threads), [data[g * fb:(g + 1) * fb] for g in mine], frames)   # this rank's batch, in lockstep
+for g, o in zip(mine, outs):
+    open(os.path.join(work, "gop%03d.evc" % g), "wb").write(o)
+sizes = torch.zeros(gops, dtype=torch.int64)
+for g, o in zip(mine, outs):
+    sizes[g] = len(o)
+dist.all_reduce(sizes)                                                              # control plane only: the data path has no collective
+dist.barrier()
+if r == 0:
+    whole = b"".join(open(os.path.join(work, "gop%03d.evc" % g), "rb").read() for g in range(gops))
+    gold = _enc.golden()["batches"][name]
+    assert sizes.tolist() == [p["bytes"] for p in gold["per_gop"]], sizes
+    assert (len(whole), _enc.md5(whole)) == (gold["whole"]["bytes"], gold["whole"]["md5"])
+    print("OK", sizes.tolist())
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_encode_their_gops_and_the_concatenation_is_the_reference_stream(tmp_path):
+    """the N > 1 path on the CPU (gloo, world size 2): every rank runs the batch encoder's frame loop over its own closed GOPs (rank = GOP mod world, as bench.py --gpus N
+    and xeve_amd/gop.py shard them), nothing but sizes crosses ranks, and the concatenated bitstreams are the reference's single run over the whole sequence"""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          str(script), _enc.ROOT, "gops_128x64_noise", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "OK" in out.stdout
 
 
 def test_one_chain_through_the_second_writer_pass_gives_the_same_bytes(yuv_dir):
