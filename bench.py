@@ -101,7 +101,8 @@ class CpuApp:
                 out[m] = {"error": "timeout"}
                 continue
             fps = re.search(r"Average encoding speed\s*=\s*([0-9.]+)", txt)  # the app's own figure: times xeve_encode only (app/xeve_app.c:1401)
-            out[m] = {"fps": float(fps.group(1)) if fps else None, "wall_s": round(time.perf_counter() - t0, 1), "rc": p.returncode}
+            tot = re.search(r"Total encoding time\s*=\s*[0-9.]+ msec,\s*([0-9.]+) sec", txt)
+            out[m] = {"fps": float(fps.group(1)) if fps else None, "encoding_s": float(tot.group(1)) if tot else None, "rc": p.returncode}
             try:
                 out[m]["md5"] = hashlib.md5(open(os.path.join(self.dir, "m%d.evc" % m), "rb").read()).hexdigest()
             except Exception:
