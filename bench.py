@@ -182,13 +182,13 @@ def main():
     encs = [encode.BatchEncoder(cfg, G, F) for _ in range(B)]
     enc = encs[0]
 
-    # inputs: GOP 0 of rank 0 = the reference recipe's seed-4 clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
+    # inputs: GOP 0 and the last GOP of rank 0 = the reference recipe's seed-4 clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
     clip = reference_noise(fb * F, 4) if rank == 0 else None
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     for b, e in enumerate(encs):
         for g in range(G):
-            if b == 0 and g == 0 and clip is not None:
+            if b == 0 and (g == 0 or g == G - 1) and clip is not None:  # (the last GOP carries the same clip: its bytes must be GOP 0's -- a check at the far end of the batch)
                 d = torch.from_numpy(clip).to(dev)
             else:
                 d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
@@ -280,6 +280,8 @@ def main():
         except Exception:
             pass
         check = {"gop0_md5": hashlib.md5(streams[0]).hexdigest(), "gop0_bytes": len(streams[0]), "total_bytes": int(sum(len(s) for s in streams))}
+        if G > 1:
+            check["last_gop_same_clip_same_bytes"] = streams[G - 1] == streams[0]
         try:
             gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))
             key = {(3840, 2160, 2, 8): "cfg4_2160p_closedgop_medium_m8", (3840, 2160, 2, 1): "cfg4_2160p_closedgop_medium"}.get((W, H, F, T))

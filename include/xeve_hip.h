@@ -873,7 +873,9 @@ typedef struct xeve_hip_enc xeve_hip_enc;
 /* A batch of `ngops` runs of `frames` pictures each.  NULL + xeve_hip_last_error() when the configuration is outside the supported set or HBM does not hold the batch. */
 xeve_hip_enc *xeve_hip_enc_create(const xeve_hip_enc_config *cfg, int ngops, int frames);
 void          xeve_hip_enc_delete(xeve_hip_enc *e);
-/* Frame `frame` of run `gop`: planar 8-bit 4:2:0 (w*h luma bytes, then U, then V), host memory (on_device 0) or device memory (1).  The frame is copied into HBM. */
+/* Frame `frame` of run `gop`: planar 8-bit 4:2:0 (w*h luma bytes, then U, then V), host memory (on_device 0) or device memory (1).  The frame is copied into HBM
+ * before the call returns (as xeve_push copies its image); the copy runs on the encoder's own stream, so device memory must be COMPLETE when the call is made --
+ * work still queued on another stream that produces it is not waited for. */
 int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device);
 /* Codes every run (synchronous).  May be called again after new frames were pushed. */
 int xeve_hip_enc_encode(xeve_hip_enc *e);

@@ -89,6 +89,26 @@ def test_a_batch_is_the_same_as_its_gops_coded_alone(hip, yuv_dir):
     assert _enc.md5(alone[0]) == _enc.golden()["batches"]["gops_128x64_noise"]["per_gop"][1]["md5"]
 
 
+def test_a_wide_batch_fed_from_device_memory_keeps_every_gop_exact(hip, yuv_dir):
+    """288 GOPs in lockstep (96 copies of the three GOPs of the noise case), the frames pushed as device tensors that torch is still producing on its own stream when
+    push is called: GOP i of the batch = the reference's bytes of GOP i % 3, at both ends of the batch and everywhere between"""
+    import torch
+
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES["gops_128x64_noise"]
+    gold = _enc.golden()["batches"]["gops_128x64_noise"]["per_gop"]
+    data, fb = _frames(yuv_dir, "gops_128x64_noise", w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    G = 96 * gops
+    enc = hip.BatchEncoder(_cfg(hip, w, h, cli, threads), G, frames)
+    for g in range(G):
+        d = (src[(g % gops) * fb:(g % gops + 1) * fb].to(torch.int32) + 0).to(torch.uint8)  # (a fresh tensor from kernels queued on torch's stream)
+        enc.push_gop(g, d)
+    outs = enc.encode()
+    enc.close()
+    bad = [g for g in range(G) if (len(outs[g]), _enc.md5(outs[g])) != (gold[g % gops]["bytes"], gold[g % gops]["md5"])]
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("name", sorted(_enc.BATCH_CASES_REAL))
 def test_batches_at_real_picture_sizes_on_the_gpu(name, hip, yuv_dir):
     """>= 2 GOPs x 8 frames at 1920x1080 (8 row chains per picture: 16 chains in lockstep, the second writer pass over 510 CTUs per picture)"""

@@ -2,6 +2,7 @@
 """Times the batch encoder in chunks of lockstep steps (device fence after every chunk): where a picture's time goes -- the steps of the I picture, of the inter
 picture, the picture ends.  usage: probe_enc.py --width W --height H --gops G --threads T --frames F --chunk N [--batches B] [--content noise|moving]"""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -67,7 +68,8 @@ def main():
                           "host_issue_ms_per_step": round(1e3 * (st1["step_seconds"] - st0["step_seconds"]) / n, 2),
                           "picture_end_s": round(st1["picture_end_seconds"] - st0["picture_end_seconds"], 2)}), flush=True)
     print(json.dumps({"total_steps": total, "per_picture": per_pic, "chains": G * min(a.threads, (H + 63) // 64), "stats": enc.stats(),
-                      "bytes": [len(s) for s in enc.bitstreams()][:4] if left == 0 else None}), flush=True)
+                      "bytes": [len(s) for s in enc.bitstreams()][:4] if left == 0 else None,
+                      "md5_of_all": hashlib.md5(b"".join(enc.bitstreams())).hexdigest() if left == 0 else None}), flush=True)
     enc.close()
 
 

@@ -66,6 +66,10 @@ static thread_local int t_vh = 0; // the virtual picture height of the batch thi
 int xh_vh() { return t_vh; }
 XhVhScope::XhVhScope(int vh) : prev(t_vh) { t_vh = vh; }
 XhVhScope::~XhVhScope() { t_vh = prev; }
+static thread_local int t_count_states = 0; // (xh_common.h, XhCountStatesScope)
+int xh_count_states() { return t_count_states; }
+XhCountStatesScope::XhCountStatesScope() : prev(t_count_states) { t_count_states = 1; }
+XhCountStatesScope::~XhCountStatesScope() { t_count_states = prev; }
 
 // the calling thread's last message; a thread that has none gets a copy of the process-wide last one (taken under the lock)
 extern "C" const char *xeve_hip_last_error(void)

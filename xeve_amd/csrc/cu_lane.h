@@ -19,6 +19,11 @@
 #ifndef XL_CTX
 #define XL_CTX(s, ci) (s).ctx[ci]
 #endif
+// XL_SINK(o): does this coder write bytes?  A writer-only translation unit defines it as true: a comparison of the sink's (private) address with null is one the
+// compiler does not fold, and it keeps the sink's fields in scratch memory instead of registers.
+#ifndef XL_SINK
+#define XL_SINK(o) ((o) != nullptr)
+#endif
 
 namespace xl {
 typedef int16_t pel;
@@ -72,7 +77,7 @@ XL void sb_byte(Sbac &s, unsigned b, Sink *o = nullptr)
 {
     if(s.is_pending_byte) {
         if(s.pending_byte == 0) s.stacked_zero++;
-        else if(o) {
+        else if(XL_SINK(o)) {
             for(; s.stacked_zero; s.stacked_zero--) {
                 if(o->n < o->cap) o->p[o->n] = 0;
                 o->n++;

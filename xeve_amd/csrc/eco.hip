@@ -9,22 +9,23 @@ static __shared__ uint16_t xl_lds_ctx[XL_NCTX * 64];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define XL __host__ __device__ static inline __attribute__((always_inline))
 #define XL_CTX(s, ci) xl_lds_ctx[(ci) * 64 + (threadIdx.x & 63)]
+#define XL_SINK(o) true // (every coder of this file writes: see cu_lane.h)
 #endif
 #include "eco_lane.h"
 static_assert(sizeof(((xeve_hip_sbac *)0)->ctx) == XL_NCTX * sizeof(uint16_t), "the models' LDS image");
 
-__global__ void __launch_bounds__(64) k_eco_ctu(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+template <bool WAVE> __global__ void __launch_bounds__(64) k_eco_ctu(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
                                                 const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, const xeve_hip_ctu_job *__restrict__ jobs,
                                                 int nchains, uint8_t *__restrict__ bytes, int bytes_cap, int32_t *__restrict__ nbytes)
 {
     const int c = blockIdx.x; // one chain per wave, one lane working (an arithmetic coder's control flow follows its data: chains sharing a wave run one after the other)
-    if(c >= nchains || threadIdx.x != 0) return;
+    if(c >= nchains || (!WAVE && threadIdx.x != 0)) return; // (WAVE: all 64 lanes run the writer in step and share the coefficient scans, eco_lane.h eco_levels)
     const xeve_hip_ctu_job J = jobs[c];
     xl::Sbac s = states[J.sbac];
 #pragma unroll
     for(int i = 0; i < XL_NCTX; i++) xl_lds_ctx[i * 64 + (threadIdx.x & 63)] = s.ctx[i];
     xl::Sink o = {bytes + (long)c * bytes_cap, bytes_cap, 0};
-    xl::eco_ctu(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
+    xl::eco_ctu<WAVE>(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
 #pragma unroll
     for(int i = 0; i < XL_NCTX; i++) s.ctx[i] = xl_lds_ctx[i * 64 + (threadIdx.x & 63)];
     states[J.sbac] = s;
@@ -50,7 +51,9 @@ extern "C" int xeve_hip_eco_ctu_jobs(const xeve_hip_ctu_data *ctus, xeve_hip_sba
         const int rc = xh_get_scan(l, l, &E.scan[l]);
         if(rc != XEVE_HIP_OK) return rc;
     }
-    k_eco_ctu<<<nchains, 64, 0, (hipStream_t)stream>>>(ctus, states, E, map_scu, map_ipm, map_tidx, map_cu_mode, (long)map_pic_elems, jobs, nchains, bytes, bytes_cap, nbytes);
+    static const bool wave = !getenv("XEVE_HIP_WRITER_WAVE") || atoi(getenv("XEVE_HIP_WRITER_WAVE")) != 0; // (developer switch: 0 = the lone-lane form)
+    if(wave) k_eco_ctu<true><<<nchains, 64, 0, (hipStream_t)stream>>>(ctus, states, E, map_scu, map_ipm, map_tidx, map_cu_mode, (long)map_pic_elems, jobs, nchains, bytes, bytes_cap, nbytes);
+    else k_eco_ctu<false><<<nchains, 64, 0, (hipStream_t)stream>>>(ctus, states, E, map_scu, map_ipm, map_tidx, map_cu_mode, (long)map_pic_elems, jobs, nchains, bytes, bytes_cap, nbytes);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

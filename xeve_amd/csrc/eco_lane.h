@@ -60,10 +60,44 @@ XL void eco_refi(Sbac &s, int num_refp, int refi, Sink *o)
     }
 }
 // xeve_eco_run_length_cc on a block that sits inside the CTU's coefficient image (pitch = the CTU's width in that component)
-XL void eco_levels(Sbac &s, const EcoParams &E, const int16_t *blk, int pitch, int log2n, int num_sig, int ch, Sink *o)
+// WAVE (device only): the kernel runs the writer on ALL 64 lanes of its wave in step -- same state, same bins, same bytes in every lane -- so that this scan can be
+// shared: the lanes fetch 64 scan positions at a time (the next 64 already in flight), a ballot finds the non-zero ones, and the coder only ever visits those.  The
+// lone lane of the serial form waits for one dependent global load per POSITION (4096 of them in a 64x64 block), which is where the second writer pass spent its time.
+template <bool WAVE = false> XL void eco_levels(Sbac &s, const EcoParams &E, const int16_t *blk, int pitch, int log2n, int num_sig, int ch, Sink *o)
 {
     const int n = 1 << log2n, nn = n * n, t0 = ch ? 2 : 0;
     const uint16_t *scan = log2n >= 4 ? E.scan[log2n] : nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr(WAVE) {
+        const int lane = threadIdx.x & 63;
+        auto fetch = [&](int base) -> int {
+            const int pos = base + lane;
+            if(pos >= nn) return 0;
+            const int at = scan ? scan[pos] : zigzag(n, pos);
+            return blk[(at >> log2n) * pitch + (at & (n - 1))];
+        };
+        int c = fetch(0), prev = -1;
+        for(int base = 0; base < nn; base += 64) {
+            const int cn = base + 64 < nn ? fetch(base + 64) : 0;
+            unsigned long long mask = __ballot(c != 0);
+            while(mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int pos = base + b, v = __builtin_amdgcn_readlane(c, b);
+                const unsigned level = (unsigned)(v < 0 ? -v : v) & 0xFFFF;
+                sb_unary2(s, (unsigned)(pos - prev - 1), XEVE_HIP_CTX_RUN + t0, o);
+                sb_unary2(s, level - 1, XEVE_HIP_CTX_LEVEL + t0, o);
+                sb_bin_ep(s, v < 0, o);
+                if(pos == nn - 1) return;
+                prev = pos, num_sig--;
+                sb_bin(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0), num_sig == 0, o);
+                if(num_sig == 0) return;
+            }
+            c = cn;
+        }
+        return;
+    }
+#endif
     unsigned run = 0;
     for(int pos = 0; pos < nn; pos++) {
         const int at = scan ? scan[pos] : zigzag(n, pos), c = blk[(at >> log2n) * pitch + (at & (n - 1))];
@@ -83,7 +117,7 @@ XL void eco_levels(Sbac &s, const EcoParams &E, const int16_t *blk, int pitch, i
 }
 
 // xeve_eco_unit (xeve_eco.c:1431-1640) of the CU at (x, y), unit index cup inside the CTU
-XL void eco_unit(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0,
+template <bool WAVE = false> XL void eco_unit(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0,
                  int x, int y, int log2, int cup, Sink *o)
 {
     const int idc = E.idc, ws = idc <= 2, hs = idc <= 1, cu = 1 << log2, st = E.slice_type, mode = d.pred_mode[cup], skip = mode == 2 /* MODE_SKIP */;
@@ -136,9 +170,9 @@ XL void eco_unit(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32
             sb_bin(s, XEVE_HIP_CTX_CBF_LUMA, cy, o);
         }
         if(coded) {
-            if(nnz[0]) eco_levels(s, E, d.coef[0] + ly * ctu + lx, ctu, log2, nnz[0], 0, o);
+            if(nnz[0]) eco_levels<WAVE>(s, E, d.coef[0] + ly * ctu + lx, ctu, log2, nnz[0], 0, o);
             for(int c = 1; c < 3; c++)
-                if(nnz[c]) eco_levels(s, E, d.coef[c] + (ly >> hs) * (ctu >> ws) + (lx >> ws), ctu >> ws, log2 - ws, nnz[c], 1, o);
+                if(nnz[c]) eco_levels<WAVE>(s, E, d.coef[c] + (ly >> hs) * (ctu >> ws) + (lx >> ws), ctu >> ws, log2 - ws, nnz[c], 1, o);
         }
     }
     for(int j = 0; j < cu >> 2; j++)
@@ -153,7 +187,7 @@ XL void eco_unit(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32
 }
 
 // xeve_eco_tree of the CTU at (x0, y0): the coded flags of its units reset first, then the tree in z order (an explicit stack: the walk is five levels deep at most)
-XL void eco_ctu(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0, Sink *o)
+template <bool WAVE = false> XL void eco_ctu(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0, Sink *o)
 {
     const int pitch = 1 << (E.log2_ctu - 2), ctu = 1 << E.log2_ctu;
     {
@@ -173,7 +207,7 @@ XL void eco_ctu(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_
             const int split = cu >= 8 ? d.split_mode[f.cud][f.cup + (half >> 2) * pitch + (half >> 2)] : 0; // xeve_get_split_mode (xeve_util.c:1125-1144)
             if(!split) {
                 if(cu > 4) sb_bin(s, XEVE_HIP_CTX_SPLIT_CU, 0, o);
-                eco_unit(E, s, d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, f.x, f.y, f.log2, f.cup, o);
+                eco_unit<WAVE>(E, s, d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, f.x, f.y, f.log2, f.cup, o);
                 sp--;
                 continue;
             }

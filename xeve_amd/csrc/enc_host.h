@@ -92,6 +92,20 @@ template <class Engine> class BatchEncoder {
         if(begin(out_) != 0) return -1;
         return advance(total_steps() + 1) == 0 ? 0 : -1;
     }
+    // every picture's set-up, in coding order, from a dry run of the bookkeeping: what an engine sizes its buffers by before the first step (empty: the run is refused)
+    std::vector<PicSetup> dry_setups() const
+    {
+        std::vector<PicSetup> v;
+        Dpb d(slots_needed(P, F));
+        int last_intra = 0, q = 0;
+        for(const PicPlan &pp : plan()) {
+            PicSetup s;
+            if(make_setup(pp, d, last_intra, s, q)) return {};
+            v.push_back(s);
+            d.put(s.cur_slot, pp.idr != 0, pp.poc, pp.tid, pp.ref_flag != 0, P.ref_pic_gap_length);
+        }
+        return v;
+    }
     std::string error;
     bool always_rewrite = false; // (tests: one chain through the second pass too)
 
@@ -109,28 +123,34 @@ template <class Engine> class BatchEncoder {
     std::vector<uint32_t> bins;
     int fail(const char *m) { error = m; return -1; }
 
+    // the set-up of picture pp against the bookkeeping d (xeve_pic_prepare, xeve_set_sh, xeve_picman_refp_init); nullptr: fine, else what is wrong
+    const char *make_setup(const PicPlan &pp, Dpb &d, int &last_intra, PicSetup &S_, int &qp_) const
+    {
+        if(pp.frame < 0 || pp.frame >= F) return "the frame loop asked for a frame that was never pushed";
+        if(pp.slice_type == ST_I) last_intra = pp.poc; // xeve_pic_prepare (:1217-1218)
+        qp_ = slice_qp(P, pp.depth);
+        const PicNumbers num = pic_numbers(qp_);
+        if(!d.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra)) return "no reference picture for an inter picture";
+        memset(&S_, 0, sizeof(S_));
+        S_.frame = pp.frame, S_.poc = pp.poc, S_.slice_type = pp.slice_type, S_.nchains = std::min(P.threads, (P.h + CTU - 1) / CTU);
+        if((S_.cur_slot = d.get_empty()) < 0) return "no free picture store";
+        fill_tree_params(S_.tp, P, pp.slice_type, num);
+        if(pp.slice_type != ST_I) {
+            fill_inter_params(S_.ti, P, pp.slice_type, pp.poc, num, d);
+            S_.nref[0] = d.num_refp[0], S_.nref[1] = pp.slice_type == ST_B ? d.num_refp[1] : 0;
+            for(int l = 0; l < 2; l++)
+                for(int r = 0; r < S_.nref[l]; r++) S_.ref[r][l] = d.refp[r][l];
+            if(pp.slice_type == ST_B && S_.nref[1] > S_.nref[0]) return "list 1 longer than list 0: outside what the inter analysis takes";
+        }
+        S_.ep.chroma_format_idc = 1, S_.ep.slice_type = pp.slice_type, S_.ep.log2_ctu = LOG2_CTU, S_.ep.pic_w = P.w, S_.ep.pic_h = P.h, S_.ep.w_scu = P.w >> 2, S_.ep.h_scu = P.h >> 2;
+        S_.ep.num_refp[0] = d.num_refp[0], S_.ep.num_refp[1] = d.num_refp[1];
+        fill_deblock_params(S_.dp, P);
+        return nullptr;
+    }
     int begin_picture()
     {
-        const PicPlan &pp = pics[pic];
-        if(pp.frame < 0 || pp.frame >= F) return fail("the frame loop asked for a frame that was never pushed");
-        if(pp.slice_type == ST_I) last_intra_poc = pp.poc; // xeve_pic_prepare (:1217-1218)
-        qp = slice_qp(P, pp.depth);
-        const PicNumbers num = pic_numbers(qp);
-        if(!dpb.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra_poc)) return fail("no reference picture for an inter picture");
-        memset(&S, 0, sizeof(S));
-        S.frame = pp.frame, S.poc = pp.poc, S.slice_type = pp.slice_type, S.nchains = T;
-        if((S.cur_slot = dpb.get_empty()) < 0) return fail("no free picture store");
-        fill_tree_params(S.tp, P, pp.slice_type, num);
-        if(pp.slice_type != ST_I) {
-            fill_inter_params(S.ti, P, pp.slice_type, pp.poc, num, dpb);
-            S.nref[0] = dpb.num_refp[0], S.nref[1] = pp.slice_type == ST_B ? dpb.num_refp[1] : 0;
-            for(int l = 0; l < 2; l++)
-                for(int r = 0; r < S.nref[l]; r++) S.ref[r][l] = dpb.refp[r][l];
-            if(pp.slice_type == ST_B && S.nref[1] > S.nref[0]) return fail("list 1 longer than list 0: outside what the inter analysis takes");
-        }
-        S.ep.chroma_format_idc = 1, S.ep.slice_type = pp.slice_type, S.ep.log2_ctu = LOG2_CTU, S.ep.pic_w = P.w, S.ep.pic_h = P.h, S.ep.w_scu = P.w >> 2, S.ep.h_scu = P.h >> 2;
-        S.ep.num_refp[0] = dpb.num_refp[0], S.ep.num_refp[1] = dpb.num_refp[1];
-        fill_deblock_params(S.dp, P);
+        const char *bad = make_setup(pics[pic], dpb, last_intra_poc, S, qp);
+        if(bad) return fail(bad);
         E.begin_picture(S);
         for(int t = 0; t < T; t++) E.reset_chain(t);
         return 0;

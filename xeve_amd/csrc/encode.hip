@@ -10,6 +10,7 @@
 // pictures of the batch are STACKED VERTICALLY (xh_common.h): GOP g's planes and maps lie g * vh luma rows below GOP 0's, so the intra analysis / the tree operations
 // address them with a picture index and element distances (pic_elems) and the inter analysis as one tall picture.
 #include <chrono>
+#include <optional>
 #include <cstdlib>
 #include <memory>
 #include <string>
@@ -22,6 +23,7 @@ static __shared__ uint16_t xl_lds_ctx[XL_NCTX * 64];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define XL __host__ __device__ static inline __attribute__((always_inline))
 #define XL_CTX(s, ci) xl_lds_ctx[(ci) * 64 + (threadIdx.x & 63)]
+#define XL_SINK(o) true // (every coder of this file writes: see cu_lane.h)
 #endif
 #include "eco_lane.h"
 #include "enc_host.h"
@@ -88,37 +90,38 @@ __device__ __forceinline__ void sbac_out(xeve_hip_sbac *__restrict__ g, xl::Sbac
 }
 // the writer of the first pass: chain c writes the CTU it has just decided on its own coder; the bytes are kept only where they are the slice data (one chain per
 // picture: cap > 0), appended at pos[g]
-__global__ void __launch_bounds__(64) k_enc_write(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_write(const xeve_hip_ctu_data *__restrict__ ctus, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
                                                   const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic,
                                                   const xeve_hip_ctu_job *__restrict__ jobs, int nchains, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
     // ONE CHAIN PER WAVE, one lane working: an arithmetic coder's control flow follows its data bin by bin, so chains packed into the lanes of a wave run one after
     // the other (measured: 16 chains per wave, 78 ms per CTU of noise; a lone chain, 13 ms) -- a wave per chain keeps every chain at the speed of a lone one, and the
-    // chip holds a thousand waves
+    // chip holds a thousand waves.  WAVE: the 64 lanes run the chain's writer in step (identical state, bins and bytes) and share the scan of the coefficient
+    // blocks (eco_lane.h eco_levels); without it lane 0 works alone
     const int c = blockIdx.x;
-    if(c >= nchains || threadIdx.x != 0) return;
+    if(c >= nchains || (!WAVE && threadIdx.x != 0)) return;
     const xeve_hip_ctu_job J = jobs[c];
     xl::Sbac s;
     sbac_in(s, states + J.sbac);
     const int at = cap ? pos[J.pic] : 0;
     xl::Sink o = {cap ? bytes + (long)J.pic * cap + at : nullptr, cap ? (int)(cap - at) : 0, 0};
-    xl::eco_ctu(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
+    xl::eco_ctu<WAVE>(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
     sbac_out(states + J.sbac, s);
     if(cap) pos[J.pic] = at + o.n;
 }
 // the second pass (xeve_enc.c:466-560): GOP g's CTUs [lcu0, lcu1) in raster order on the picture's own coder
-__global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__restrict__ store, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__restrict__ store, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
                                                     const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, int G, int f_lcu, int w_lcu,
                                                     int lcu0, int lcu1, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
     const int g = blockIdx.x; // (one GOP per wave, one lane working: see k_enc_write)
-    if(g >= G || threadIdx.x != 0) return;
+    if(g >= G || (!WAVE && threadIdx.x != 0)) return;
     xl::Sbac s;
     sbac_in(s, states + g);
     int at = pos[g];
     for(int lcu = lcu0; lcu < lcu1; lcu++) {
         xl::Sink o = {bytes + (long)g * cap + at, (int)(cap - at), 0};
-        xl::eco_ctu(E, s, store[(long)g * f_lcu + lcu], map_scu + g * map_pic, map_ipm + g * map_pic, map_tidx + g * map_pic, map_cu_mode + g * map_pic, (lcu % w_lcu) * CTU,
+        xl::eco_ctu<WAVE>(E, s, store[(long)g * f_lcu + lcu], map_scu + g * map_pic, map_ipm + g * map_pic, map_tidx + g * map_pic, map_cu_mode + g * map_pic, (lcu % w_lcu) * CTU,
                     (lcu / w_lcu) * CTU, &o);
         at += o.n;
     }
@@ -235,10 +238,9 @@ struct xeve_hip_enc {
                                                       rw_cum.need((size_t)G * map_pic * 4) && rw_ipm.need((size_t)G * map_pic));
         // a second CTU store lets the second writer pass of a picture run beside the next picture's steps (which fill the other store); without the memory for it the
         // next picture waits for the pass
-        // (MEASURED, profiles/r03f_probe_4k_g384.log + the kernel trace of README's r03h: the device runs the two streams one after the other -- 0.6 ms of other
-        // kernels inside 1.4 s of second pass, with or without stream priorities -- so the second store buys nothing today; XEVE_HIP_ENC_TWO_STORES=1 keeps the path alive)
+        // (XEVE_HIP_ENC_TWO_STORES=0: developer switch, the one-store form)
         const char *ts = getenv("XEVE_HIP_ENC_TWO_STORES");
-        if(ok && rewrite_mode && ts && atoi(ts) == 1) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
+        if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"
@@ -264,6 +266,34 @@ struct xeve_hip_enc {
         if(h_pos) (void)hipHostFree(h_pos);
     }
 
+    // the device side of an inter picture's set-up: the reference table and the motion maps of the stores the frame loop named
+    void bind_inter(PicSetup &s)
+    {
+        memset(tab, 0, sizeof(tab));
+        if(s.slice_type == ST_I) return;
+        for(int l = 0; l < 2; l++)
+            for(int r = 0; r < s.nref[l]; r++) {
+                xeve_hip_refpic &e = tab[r * 2 + l];
+                e.y = slot_plane(s.ref[r][l].slot, 0), e.u = slot_plane(s.ref[r][l].slot, 1), e.v = slot_plane(s.ref[r][l].slot, 2), e.poc = s.ref[r][l].poc;
+            }
+        if(s.slice_type == ST_P) tab[1] = tab[0]; // (P slices never read list 1; the table stays addressable)
+        s.ti.refp = tab, s.ti.s_ref_l = s_l, s.ti.s_ref_c = s_c, s.ti.map_mv = slot_map_mv(s.cur_slot), s.ti.map_refi = slot_map_refi(s.cur_slot);
+        s.ti.col_mv0 = slot_map_mv(s.ref[0][0].slot), s.ti.col_mv1 = s.slice_type == ST_B ? slot_map_mv(s.ref[0][1].slot) : s.ti.col_mv0;
+        s.ti.coef_l = k_coef_l, s.ti.coef_c = coef_c;
+    }
+    // The walk's workspace at the size of the run's most demanding picture, BEFORE the first step: growing it between two pictures means hipFree + hipMalloc, and hipFree
+    // waits for the whole device -- for the second writer pass of the picture before, which is meant to run beside the next picture's steps.
+    bool reserve(const std::vector<PicSetup> &setups)
+    {
+        size_t most = 0;
+        for(PicSetup s : setups) {
+            bind_inter(s);
+            const size_t need = xeve_hip_mode_analyze_ctu_workspace(G * T, &s.tp, s.slice_type == ST_I ? nullptr : &s.ti, P.w, P.w / 2);
+            if(need == 0) return fail(std::string("the CTU walk refuses a picture's parameters: ") + xeve_hip_last_error());
+            most = std::max(most, need);
+        }
+        return ws.need(most) || fail("not enough device memory for the CTU walk's workspace");
+    }
     void begin_picture(const PicSetup &setup)
     {
         S = setup;
@@ -275,21 +305,10 @@ struct xeve_hip_enc {
         hip_ok(hipMemsetAsync(slot_map_mv(S.cur_slot), 0, (size_t)G * map_pic * 8, st), "hipMemset"); // (:1220-1225)
         hip_ok(hipMemsetAsync(slot_map_refi(S.cur_slot), 0xFF, (size_t)G * map_pic * 2, st), "hipMemset");
         if(!rewrite_mode) hip_ok(hipMemsetAsync(pos.p, 0, pos.bytes, st), "hipMemset"); // (the first pass's bytes are the slice data; otherwise the second pass owns the buffers)
-        memset(tab, 0, sizeof(tab));
-        if(S.slice_type != ST_I) {
-            for(int l = 0; l < 2; l++)
-                for(int r = 0; r < S.nref[l]; r++) {
-                    xeve_hip_refpic &e = tab[r * 2 + l];
-                    e.y = slot_plane(S.ref[r][l].slot, 0), e.u = slot_plane(S.ref[r][l].slot, 1), e.v = slot_plane(S.ref[r][l].slot, 2), e.poc = S.ref[r][l].poc;
-                }
-            if(S.slice_type == ST_P) tab[1] = tab[0]; // (P slices never read list 1; the table stays addressable)
-            S.ti.refp = tab, S.ti.s_ref_l = s_l, S.ti.s_ref_c = s_c, S.ti.map_mv = slot_map_mv(S.cur_slot), S.ti.map_refi = slot_map_refi(S.cur_slot);
-            S.ti.col_mv0 = slot_map_mv(S.ref[0][0].slot), S.ti.col_mv1 = S.slice_type == ST_B ? slot_map_mv(S.ref[0][1].slot) : S.ti.col_mv0;
-            S.ti.coef_l = k_coef_l, S.ti.coef_c = coef_c;
-        }
+        bind_inter(S);
         const size_t need = xeve_hip_mode_analyze_ctu_workspace(G * T, &S.tp, S.slice_type == ST_I ? nullptr : &S.ti, P.w, P.w / 2);
         if(need == 0) fail(std::string("the CTU walk refuses the picture's parameters: ") + xeve_hip_last_error());
-        else if(!ws.need(need)) fail("not enough device memory for the CTU walk's workspace");
+        else if(!ws.need(need)) fail("not enough device memory for the CTU walk's workspace"); // (reserve() has sized it: no allocation here in a run that began with begin())
         E.idc = 1, E.slice_type = S.slice_type, E.log2_ctu = LOG2_CTU, E.pic_w = P.w, E.pic_h = P.h, E.w_scu = w_scu, E.num_refp[0] = S.ep.num_refp[0], E.num_refp[1] = S.ep.num_refp[1];
     }
     void reset_chain(int t)
@@ -297,6 +316,12 @@ struct xeve_hip_enc {
         if(error.empty()) k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st>>>(states.as<xeve_hip_sbac>(), T, t, G);
     }
     bool keeps_store() const { return store2[0].p != nullptr; }
+    // the writer kernels on whole waves (eco_lane.h eco_levels) unless XEVE_HIP_WRITER_WAVE=0 (developer switch: the lone-lane form, for comparison)
+    static bool writer_wave()
+    {
+        static const bool v = !getenv("XEVE_HIP_WRITER_WAVE") || atoi(getenv("XEVE_HIP_WRITER_WAVE")) != 0;
+        return v;
+    }
     xeve_hip_ctu_data *store_now() const { return store2[cur_store].as<xeve_hip_ctu_data>(); }
     void step(const ChainCtu *c, int n)
     {
@@ -315,14 +340,22 @@ struct xeve_hip_enc {
         const pel *o[3] = {org[0].as<pel>(), org[1].as<pel>(), org[2].as<pel>()};
         pel       *m[3] = {slot_plane(S.cur_slot, 0), slot_plane(S.cur_slot, 1), slot_plane(S.cur_slot, 2)};
         const int64_t pe[5] = {org_l, org_c, pic_l, pic_c, map_pic};
+        // (the walk's exit states are never loaded by anything but further counts -- the next CTU starts from the writer's state: count-only states, xh_common.h)
+        static const bool full_states = getenv("XEVE_HIP_ENC_FULL_STATES") && atoi(getenv("XEVE_HIP_ENC_FULL_STATES"));
+        std::optional<XhCountStatesScope> count_only;
+        if(!full_states) count_only.emplace();
         if(!rc_ok(xeve_hip_mode_analyze_ctu_jobs(o, P.w, P.w / 2, m, s_l, s_c, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(), pe,
                                                  states.as<xeve_hip_sbac>(), G * T, &S.tp, S.slice_type == ST_I ? nullptr : &S.ti, jobs.as<xeve_hip_ctu_job>(), nch,
                                                  out.as<xeve_hip_ctu_data>(), next_best.as<xeve_hip_sbac>(), cost.as<double>(), ws.p, ws.bytes, st),
                   "xeve_hip_mode_analyze_ctu_jobs"))
             return;
         if(keeps_store()) k_enc_keep<<<dim3(4, nch), 256, 0, st>>>(out.as<xeve_hip_ctu_data>(), store_now(), D, G, f_lcu);
-        k_enc_write<<<nch, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(),
-                                                    cum.as<uint32_t>(), map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), rewrite_mode ? 0 : slice_cap, pos.as<int32_t>());
+        if(writer_wave())
+            k_enc_write<true><<<nch, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(),
+                                                  map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), rewrite_mode ? 0 : slice_cap, pos.as<int32_t>());
+        else
+            k_enc_write<false><<<nch, 64, 0, st>>>(out.as<xeve_hip_ctu_data>(), states.as<xeve_hip_sbac>(), E, scu.as<uint32_t>(), ipm.as<int8_t>(), tidx.as<uint8_t>(), cum.as<uint32_t>(),
+                                                   map_pic, jobs.as<xeve_hip_ctu_job>(), nch, slice.as<uint8_t>(), rewrite_mode ? 0 : slice_cap, pos.as<int32_t>());
         hip_ok(hipGetLastError(), "step kernels");
         n_steps++, t_steps += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -356,8 +389,12 @@ struct xeve_hip_enc {
             k_enc_reset_chain<<<(G + 63) / 64, 64, 0, st2>>>(fin, 1, 0, G);
             xl::EcoParams Ew = E; // (the pass's own copy: E follows the next picture)
             for(int row = 0; row < h_lcu; row++) {
-                k_enc_rewrite<<<G, 64, 0, st2>>>(store_now(), fin, Ew, rw_scu.as<uint32_t>(), rw_ipm.as<int8_t>(), tidx.as<uint8_t>(), rw_cum.as<uint32_t>(),
-                                                 map_pic, G, f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+                if(writer_wave())
+                    k_enc_rewrite<true><<<G, 64, 0, st2>>>(store_now(), fin, Ew, rw_scu.as<uint32_t>(), rw_ipm.as<int8_t>(), tidx.as<uint8_t>(), rw_cum.as<uint32_t>(), map_pic, G,
+                                                           f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
+                else
+                    k_enc_rewrite<false><<<G, 64, 0, st2>>>(store_now(), fin, Ew, rw_scu.as<uint32_t>(), rw_ipm.as<int8_t>(), tidx.as<uint8_t>(), rw_cum.as<uint32_t>(), map_pic, G,
+                                                            f_lcu, w_lcu, row * w_lcu, (row + 1) * w_lcu, slice.as<uint8_t>(), slice_cap, pos.as<int32_t>());
             }
             rows_pending = true;
             if(two_stores) cur_store ^= 1;
@@ -434,6 +471,8 @@ extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
     e->loop.reset(new BatchEncoder<xeve_hip_enc>(*e, e->P, e->G, e->F));
     e->loop->always_rewrite = (e->P_reserved0 & 1) != 0;
     if(e->loop->begin(e->bitstreams) != 0) { xh_set_error("xeve_hip_enc_begin: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
+    const std::vector<PicSetup> setups = e->loop->dry_setups();
+    if(setups.empty() || !e->reserve(setups)) { xh_set_error("xeve_hip_enc_begin: %s", e->error.empty() ? "the frame loop refuses the run" : e->error.c_str()); return XEVE_HIP_ERR_ARG; }
     return XEVE_HIP_OK;
 }
 extern "C" int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining)

@@ -707,6 +707,7 @@ static int cu_bits_launch(const int16_t *coef, size_t coef_elems, const xeve_hip
     XH_REQUIRE(p->slice_type >= 0 && p->slice_type <= 2 && p->chroma_format_idc >= 0 && p->chroma_format_idc <= 3);
     XH_REQUIRE(p->num_refp[0] >= 0 && p->num_refp[0] <= 21 && p->num_refp[1] >= 0 && p->num_refp[1] <= 21);
     if(njobs == 0) return XEVE_HIP_OK;
+    if(xh_count_states()) full = false; // (xh_common.h: the caller only ever loads these states into further counts)
     XH_REQUIRE(sbac_in && jobs && bits && workspace); // coef == NULL: no job codes coefficients (skip / mvp jobs only) -- the event pass is left out
     XH_REQUIRE(workspace_bytes >= xeve_hip_cu_bits_workspace(njobs, coef_elems));
     CuBitsK P;

@@ -104,6 +104,16 @@ struct XhVhScope {
     explicit XhVhScope(int vh);
     ~XhVhScope();
 };
+// COUNT-ONLY CODER STATES.  A bit count starts with xeve_sbac_bit_reset (xeve_mode.c:39-49), which keeps of the state it was loaded with the range and the context
+// models (and low bits of the code register that never reach a count).  A caller whose exit states are only ever loaded into further counts -- the encoder's CTU walk:
+// the next CTU's counts start from the WRITER's state (xeve_enc.c:138-139), never from the walk's -- asks for exactly that much: within the scope every bit-count
+// launch runs the count-only kernel, whose states carry range + models and a reset remainder.  The C-ABI's own callers get the complete state (the default).
+int xh_count_states();
+struct XhCountStatesScope {
+    int prev;
+    XhCountStatesScope();
+    ~XhCountStatesScope();
+};
 __host__ __device__ __forceinline__ int xh_vh_base(int y, int vh) { return vh > 0 ? (y / vh) * vh : 0; }
 // Offsets into the ORIGINAL (xeve_hip_job.off1, the fused comparison's pred_off) are 32-bit element counts read as UNSIGNED: the stacked originals of a batch may span up
 // to 2^32 samples (448 pictures of 3840x2160).  Producers compute in 64 bits and keep the low 32 (xh_org_off), consumers widen without sign (xh_u).

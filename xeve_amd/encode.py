@@ -40,6 +40,10 @@ class BatchEncoder:
         """data: bytes-like of one planar 8-bit 4:2:0 frame (host), or a uint8 torch tensor on the GPU"""
         if hasattr(data, "data_ptr"):
             assert data.numel() == self.frame_bytes and data.is_contiguous()
+            if data.is_cuda:  # the library copies on its own stream: whatever produced the tensor on torch's stream must be through
+                import torch
+
+                torch.cuda.current_stream(data.device).synchronize()
             _lib.check(self._L.xeve_hip_enc_push(self._h, gop, frame, C.c_void_p(data.data_ptr()), 1 if data.is_cuda else 0))
         else:
             b = bytes(data)
