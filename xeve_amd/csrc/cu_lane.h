@@ -121,8 +121,8 @@ XL void sb_shift_n(Sbac &s, int n, Sink *o = nullptr)
 // one context-coded bin on a model the caller holds in a register (a run of bins on one model -- the tail of a unary symbol -- loads and stores it once)
 XL void sb_bin_m(Sbac &s, unsigned &model, unsigned bin, Sink *o = nullptr)
 {
-    unsigned state = model >> 1, mps = model & 1;
-    unsigned lps = (state * s.range) >> 9;
+    unsigned state = (model >> 1) & 511u, mps = model & 1;
+    unsigned lps = (state * (s.range & 0xFFFFu)) >> 9; // (the masks change nothing -- 9-bit state, 16-bit range -- and let the device use its full-rate 24-bit multiply)
     if(lps < 437) lps = 437;
     s.bin_counter++;
     s.range -= lps;

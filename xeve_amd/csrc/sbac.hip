@@ -167,8 +167,41 @@ template <int LPB> __global__ __launch_bounds__(256) void k_coef_events(const in
 // renormalisation shifts -- which IS xeve_get_bit_number after xeve_sbac_bit_reset: every shift moves one bit out of the
 // 11 + 8k bit window the formula measures (bitcounter + 8 * (stacked + pending) + 8 - code_bits + 3 == total shifts;
 // tests/test_sbac_golden.py::test_bit_count_is_the_number_of_renormalisation_shifts).
+// THE MODEL TRANSITIONS AS A TABLE.  xeve_sbac_encode_bin's update of a context model (xeve_eco.c:540-557) is a function of the model and of "was it the LPS": both
+// outcomes of all 1024 models sit in one 32-bit word each (low half: after an MPS, high half: after an LPS; k_model_tab below, built at compile time from the
+// reference's arithmetic), copied into LDS when a kernel starts.  The word is fetched as soon as the model is known, the range arithmetic of the bin runs while it is
+// on its way, and one select replaces the twelve instructions that computed both successors -- on a coder whose speed IS its instruction count per bin (one wave
+// per SIMD, every lane at a different bin), a fifth of them.
+struct ModelTab {
+    uint32_t v[1024];
+};
+static constexpr ModelTab make_model_tab()
+{
+    ModelTab t{};
+    for(unsigned m = 0; m < 1024; m++) {
+        const unsigned state = m >> 1, mps = m & 1;
+        unsigned       sl = state + ((528 - state) >> 5); // LPS: towards 1/2, swapping the MPS past it
+        const bool     flip = sl > 256;
+        sl = flip ? 512 - sl : sl;
+        const unsigned sm = state - ((state + 16) >> 5);  // MPS
+        const unsigned after_mps = (sm << 1) | mps, after_lps = (sl << 1) | (flip ? mps ^ 1 : mps);
+        t.v[m] = (after_mps & 0xFFFFu) | ((after_lps & 0xFFFFu) << 16);
+    }
+    return t;
+}
+__device__ const ModelTab k_model_tab = make_model_tab();
+// into LDS by the whole wave (call before any lane leaves); one wave per workgroup
+__device__ __forceinline__ void load_model_tab(uint32_t *s_tab)
+{
+    const uint4 *g = reinterpret_cast<const uint4 *>(k_model_tab.v);
+    uint4       *d = reinterpret_cast<uint4 *>(s_tab);
+    for(int i = threadIdx.x; i < 256; i += 64) d[i] = g[i];
+    __syncthreads();
+}
+
 struct Sbac {
     unsigned range, shifts, bins;
+    const uint32_t *tab; // k_model_tab in LDS
     // FULL only.  code / cb are the reference's code register and code_bits, bin for bin (the byte that leaves at a boundary is cut out branch-free).  What is
     // DEFERRED is the bookkeeping of the bytes that left (sbac_carry_propagate / sbac_put_byte: pending byte, stacked 0xFF / 0x00, bit counter): they queue up in
     // `fifo` (16 bits each, oldest on top) and sb_drain() works them off in order every four bins.  64 lanes cross byte boundaries at 64 different bins, so a
@@ -223,21 +256,24 @@ __device__ __forceinline__ void sb_drain(Sbac &s)
 // in the part every bin executes: 64 lanes are at 64 different places of 64 different bin strings.
 template <bool FULL> __device__ __forceinline__ unsigned sb_encode(Sbac &s, unsigned m, unsigned bin, bool ep)
 {
-    const unsigned R = s.range, state = m >> 1, mps = m & 1;
-    unsigned lps = (state * R) >> 9;
+    const unsigned R = s.range & 0xFFFFu, state = (m >> 1) & 511u, mps = m & 1; // (the masks cost nothing where the values are: they let the 24-bit multiply be chosen)
+    const unsigned both = s.tab[m & 1023u];           // the model after an MPS (low half) / after an LPS (high half): on its way while the range is worked out
+    __builtin_amdgcn_sched_barrier(0);                // (issued HERE, in front of the range arithmetic ...)
+    unsigned lps = (state * R) >> 9;                  // (state < 2^9, range < 2^16: the full-rate 24-bit multiply)
     lps = lps < 437 ? 437 : lps;
     const unsigned rm = R - lps;                      // range after taking the MPS branch
     const bool     isl = bin != mps, cut = isl && rm >= lps;
     const unsigned r = cut ? lps : rm;
-    unsigned sl = state + ((528 - state) >> 5);       // LPS: towards 1/2, swapping the MPS past it
-    const bool flip = sl > 256;
-    sl = flip ? 512 - sl : sl;
-    const unsigned sm = state - ((state + 16) >> 5);  // MPS
-    const unsigned m1 = ((isl ? sl : sm) << 1) | (isl && flip ? mps ^ 1 : mps);
-    const int      lz = __clz((int)r) - 18;           // r >= 437: at most 5 shifts back to >= 8192
+    const int      lz = __builtin_clz(r) - 18;        // 437 <= r < 2^16: at most 5 shifts back to >= 8192
     unsigned n = lz > 0 ? (unsigned)lz : 0;
+    unsigned rn = r << n;
+    // (the bin's arithmetic stays unconditional: the lanes of a wave are at different bins of different strings, so a branch around it for the bypass bins is taken
+    // both ways by every wave and only adds its own cost)
+    asm volatile("" : "+v"(rn), "+v"(n));
+    __builtin_amdgcn_sched_barrier(0);                // (... and waited for here, behind it)
+    const unsigned m1 = isl ? both >> 16 : both & 0xFFFFu;
     const unsigned half = R >> 1;                     // bypass: the range loses its LSB (xeve_eco.c:459-467), one shift
-    s.range = ep ? half << 1 : r << n;
+    s.range = ep ? R & ~1u : rn;
     n = ep ? 1 : n;
     s.shifts += n, s.bins++;
     if(FULL) { // the code register as the reference moves it; a byte that leaves (n >= cb; at most one: n <= 7) is queued for sb_drain
@@ -507,8 +543,9 @@ __device__ __forceinline__ void code_block(Sbac &s, CtxTab s_ctx, int lane, cons
     }
 }
 
-__device__ __forceinline__ void sbac_load(Sbac &s, const xeve_hip_sbac &in, CtxTab s_ctx, int lane, bool continue_coder)
+__device__ __forceinline__ void sbac_load(Sbac &s, const xeve_hip_sbac &in, CtxTab s_ctx, int lane, bool continue_coder, const uint32_t *s_tab)
 {
+    s.tab = s_tab;
     s.range = in.range, s.shifts = s.bins = 0;
     s.code = in.code & 0x7FFFF, s.fifo = 0, s.cnt = 0, s.cb = 11, s.sff = s.sz = s.pb = s.ipb = s.bc = 0; // SBAC_LOAD + xeve_sbac_bit_reset (xeve_mode.c:39-49)
     if(continue_coder) { // continue the coder where the state stands
@@ -526,13 +563,15 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
 {
     __shared__ uint16_t s_ctx[NCTX + 1][64]; // (+ the dummy row of the bypass bins)
     __shared__ uint8_t  s_q[QCAP][64];
+    __shared__ uint32_t s_tab[1024];
+    load_model_tab(s_tab);
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
     const xeve_hip_sbac &in = sin[J.sbac];
     const bool cont = FULL && J.mode == XEVE_HIP_BITS_ECO_COEF && (J.dir_flag & XEVE_HIP_ECO_NO_RESET);
     Sbac s;
-    sbac_load(s, in, s_ctx, lane, cont);
+    sbac_load(s, in, s_ctx, lane, cont, s_tab);
     Queue Q{&s_q[0][lane], 0, 0};
     const unsigned coded = q_header(Q, J, P);
     code_queue<FULL>(s, s_ctx, s_q, lane, Q.n < QCAP ? Q.n : QCAP);
@@ -582,12 +621,14 @@ __global__ __launch_bounds__(64) void k_cu_bits_chain(const xeve_hip_sbac *__res
 {
     __shared__ uint16_t s_ctx[NCTX + 1][64];
     __shared__ uint8_t  s_q[QCAP][64];
+    __shared__ uint32_t s_tab[1024];
+    load_model_tab(s_tab);
     const int lane = threadIdx.x, j = blockIdx.x * 64 + lane;
     if(j >= njobs) return;
     const xeve_hip_cu_bits_job J = jobs[j];
     if(J.mode == XEVE_HIP_BITS_CU_SKIP) return; // lane switched off (an assumption that cannot occur: the component has no coefficients)
     Sbac s;
-    sbac_load(s, sin[J.sbac], s_ctx, lane, false);
+    sbac_load(s, sin[J.sbac], s_ctx, lane, false, s_tab);
     const int keep[3] = {J.dir_flag & 1, (J.dir_flag >> 1) & 1, 1};
     unsigned total_bins = 0;
     for(int c = 0; c < 3; c++) {
