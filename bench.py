@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per GPU (0: as many as the picture size allows, at most 448)")
     ap.add_argument("--frames", type=int, default=2, help="frames per GOP (2: the IDR picture and one inter picture, the CPU baseline's sample)")
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
-    ap.add_argument("--batches", type=int, default=1, help="independent batches of --gops GOPs encoded side by side on this GPU (one host thread and HIP stream each)")
+    ap.add_argument("--batches", type=int, default=3, help="batches encoded side by side on this GPU (one host thread and HIP stream each): the first of --gops GOPs, the others as the memory allows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-m1", action="store_true", help="time the reference with one thread too (-m 1: ~3 minutes at 3840x2160; profiles/r03_bench.json has it)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed per-kernel-class pass")
@@ -178,8 +178,19 @@ def main():
     vh = (H + 288 + 63) & ~63
     G = a.gops or max(1, min(448, int((2 ** 32 - 1) // (vh * W))))  # (the library's limit: the stacked originals of a batch below 2^32 samples)
     cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
-    B = max(1, a.batches)
-    encs = [encode.BatchEncoder(cfg, G, F) for _ in range(B)]
+    # BATCHES: a batch's originals are addressed with 32 bits (448 pictures of 3840x2160), HBM holds more, and a step's time hardly moves with the chains it carries -- so
+    # the job is B batches side by side (a host thread and a HIP stream each: profiles/r03s_*): the first as large as the limit allows, the others as large as the
+    # memory left over
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    encs, Gs = [encode.BatchEncoder(cfg, G, F)], [G]
+    per_gop = (free0 - torch.cuda.mem_get_info(dev)[0]) / G + (16 << 20)  # (+ the walk's workspace, allocated when the encode begins)
+    for _ in range(1, max(1, a.batches)):
+        room = torch.cuda.mem_get_info(dev)[0] - (16 << 20) * sum(Gs) - (8 << 30)
+        g = int(min(G, room // per_gop))
+        if g < max(1, G // 8):
+            break
+        encs.append(encode.BatchEncoder(cfg, g, F)), Gs.append(g)
+    B = len(encs)
     enc = encs[0]
 
     # inputs: GOP 0 and the last GOP of rank 0 = the reference recipe's seed-4 clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
@@ -187,8 +198,8 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     for b, e in enumerate(encs):
-        for g in range(G):
-            if b == 0 and (g == 0 or g == G - 1) and clip is not None:  # (the last GOP carries the same clip: its bytes must be GOP 0's -- a check at the far end of the batch)
+        for g in range(Gs[b]):
+            if (g == 0 or g == Gs[b] - 1) and clip is not None:  # (both ends of every batch carry the clip: their bytes must be GOP 0's)
                 d = torch.from_numpy(clip).to(dev)
             else:
                 d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
@@ -204,8 +215,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for e in encs:
-        e.begin()
+    for i in range(len(encs) - 1, -1, -1):  # (the walk's workspace is allocated here: a batch beyond the first that no longer fits is left out rather than failing the run)
+        try:
+            encs[i].begin()
+        except Exception:
+            if i == 0:
+                raise
+            encs[i].close()
+            del encs[i], Gs[i]
+    B = len(encs)
     total = enc.advance(0)
     per_picture = total // F
     n = a.warmup + a.steps
@@ -249,13 +267,15 @@ def main():
     lib.prof_enable(None)
     assert all(v == 0 for v in lefts), lefts
     timed_steps = sum(sizes[a.warmup:])
-    frames_timed = B * G * timed_steps / per_picture
+    frames_timed = sum(Gs) * timed_steps / per_picture
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = enc.stats()
-    streams = enc.bitstreams()
+    streams = [enc.bitstream(0)]
+    ends_same = all(e.bitstream(g) == streams[0] for e, n in zip(encs, Gs) for g in (0, n - 1)) if rank == 0 else None
+    total_bytes = int(sum(sum(e.bitstream_sizes()) for e in encs)) if rank == 0 else 0
     for e in encs:  # (the job's HBM goes back before the untimed extras)
         e.close()
 
@@ -273,15 +293,14 @@ def main():
         try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_search_pmc.json")))
             roof["traffic"] = pmc.get("hbm_bytes_per_launch_x2")
-            roof["traffic_is"] = "HBM bytes per launch of the kernel in the PMC run of profiles/r03_search_pmc.json (128 chains in lockstep; this job's launches carry %d)" % (G * min(T, h_lcu))
+            roof["traffic_is"] = "HBM bytes per launch of the kernel in the PMC run of profiles/r03_search_pmc.json (128 chains in lockstep; this job's launches carry %d)" % (Gs[0] * min(T, h_lcu))
             if pmc.get("hbm_bytes_per_launch_x2") and pmc.get("avg_launch_s"):
                 roof["hbm_physical_GBps"] = round(pmc["hbm_bytes_per_launch_x2"] / pmc["avg_launch_s"] / 1e9, 1)
                 roof["hbm_physical_frac"] = round(roof["hbm_physical_GBps"] / HBM_PEAK_GBS, 4)
         except Exception:
             pass
-        check = {"gop0_md5": hashlib.md5(streams[0]).hexdigest(), "gop0_bytes": len(streams[0]), "total_bytes": int(sum(len(s) for s in streams))}
-        if G > 1:
-            check["last_gop_same_clip_same_bytes"] = streams[G - 1] == streams[0]
+        check = {"gop0_md5": hashlib.md5(streams[0]).hexdigest(), "gop0_bytes": len(streams[0]), "total_bytes": total_bytes,
+                 "first_and_last_gop_of_every_batch_same_clip_same_bytes": ends_same}
         try:
             gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))
             key = {(3840, 2160, 2, 8): "cfg4_2160p_closedgop_medium_m8", (3840, 2160, 2, 1): "cfg4_2160p_closedgop_medium"}.get((W, H, F, T))
@@ -306,10 +325,11 @@ def main():
             "value_is": "encoded frames/s of the closed-GOP batch encoder: a real encode to EVC bitstreams (every stage of the reference's xeve_pic on the device, NAL assembly "
                         "on the host), byte-identical to the reference encoder; frames = the timed share of the job's frames",
             "config": {
-                "workload": "one encode of %d x %d closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop -I 8 -m %d semantics), "
+                "workload": "one encode of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop -I 8 -m %d semantics), "
                             "i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; the job's %d lockstep CTU steps cut into %d + %d equal slices"
-                            % (B, G, F, W, H, T, total, a.warmup, a.steps),
-                "batches_side_by_side": B, "gops_in_lockstep": G, "frames_per_gop": F, "row_chains_per_picture": T, "chains_in_lockstep": G * min(T, h_lcu), "lockstep_steps_per_picture": per_picture,
+                            % (B, "+".join(str(g) for g in Gs), F, W, H, T, total, a.warmup, a.steps),
+                "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "row_chains_per_picture": T, "chains_in_lockstep": [g * min(T, h_lcu) for g in Gs],
+                "lockstep_steps_per_picture": per_picture,
                 "lockstep_steps_timed": timed_steps, "frames_in_timed_region": round(frames_timed, 2), "ctus_per_picture": w_lcu * h_lcu,
                 "parallelism": "closed-GOP shards per GPU, no collectives" + (" [SELF-TEST: all ranks share GPU 0, gloo]" if share else ""),
                 "library_built_in_this_run": built_here,

@@ -18,6 +18,24 @@ struct EcoParams {
     const uint16_t *scan[7]; // zig-zag scans of the square blocks 16x16, 32x32, 64x64 at [4], [5], [6] (xeve_tbl_scan); smaller blocks use the built-in tables
 };
 
+// What the writer reads of a decided CTU -- a third of the walk's record (no reconstruction, no maps, no motion vectors, the chroma levels dense): the form in which
+// a picture's CTUs wait for the second writer pass (encode.hip keeps 2040 of them per 3840x2160 picture and GOP).  4:2:0.  Field names as in xeve_hip_ctu_data, so
+// the lane code below is written once for both (xl_coef / xl_ipm0 hide the two differences).
+struct CtuSyntax {
+    int8_t  split_mode[XEVE_HIP_CU_DEPTHS][256];
+    uint8_t pred_mode[256];
+    int8_t  ipm0[256];
+    int32_t nnz[3][256];
+    int16_t coef_y[64 * 64], coef_u[32 * 32], coef_v[32 * 32];
+    int16_t mvd[256][2][2];
+    int8_t  refi[256][2];
+    uint8_t mvp_idx[256][2];
+};
+XL const int16_t *xl_coef(const xeve_hip_ctu_data &d, int c) { return d.coef[c]; }
+XL const int16_t *xl_coef(const CtuSyntax &d, int c) { return c == 0 ? d.coef_y : c == 1 ? d.coef_u : d.coef_v; }
+XL int xl_ipm0(const xeve_hip_ctu_data &d, int u) { return d.ipm[0][u]; }
+XL int xl_ipm0(const CtuSyntax &d, int u) { return d.ipm0[u]; }
+
 // xeve_eco_abs_mvd + sign (xeve_eco.c:1205-1270): exp-Golomb, the first two bins on the mvd model
 XL void eco_mvd1(Sbac &s, int v, Sink *o)
 {
@@ -117,7 +135,7 @@ template <bool WAVE = false> XL void eco_levels(Sbac &s, const EcoParams &E, con
 }
 
 // xeve_eco_unit (xeve_eco.c:1431-1640) of the CU at (x, y), unit index cup inside the CTU
-template <bool WAVE = false> XL void eco_unit(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0,
+template <bool WAVE = false, class D = xeve_hip_ctu_data> XL void eco_unit(const EcoParams &E, Sbac &s, const D &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0,
                  int x, int y, int log2, int cup, Sink *o)
 {
     const int idc = E.idc, ws = idc <= 2, hs = idc <= 1, cu = 1 << log2, st = E.slice_type, mode = d.pred_mode[cup], skip = mode == 2 /* MODE_SKIP */;
@@ -149,7 +167,7 @@ template <bool WAVE = false> XL void eco_unit(const EcoParams &E, Sbac &s, const
         int l = 0, u = 0;
         if(x_scu > 0 && XL_IF(map_scu[scup - 1]) && XL_COD(map_scu[scup - 1]) && map_tidx[scup] == map_tidx[scup - 1]) l = map_ipm[scup - 1] + 1;
         if(y_scu > 0 && XL_IF(map_scu[scup - E.w_scu]) && XL_COD(map_scu[scup - E.w_scu]) && map_tidx[scup] == map_tidx[scup - E.w_scu]) u = map_ipm[scup - E.w_scu] + 1;
-        sb_unary2(s, (unsigned)mpm_rank(l, u, d.ipm[0][cup]), XEVE_HIP_CTX_INTRA_DIR, o);
+        sb_unary2(s, (unsigned)mpm_rank(l, u, xl_ipm0(d, cup)), XEVE_HIP_CTX_INTRA_DIR, o);
     }
     int nnz[3] = {0, 0, 0};
     if(!skip) { // xeve_eco_coef(RUN_L | RUN_CB | RUN_CR): xeve_eco_cbf (xeve_eco.c:793-894), then the levels of the coded components
@@ -170,9 +188,9 @@ template <bool WAVE = false> XL void eco_unit(const EcoParams &E, Sbac &s, const
             sb_bin(s, XEVE_HIP_CTX_CBF_LUMA, cy, o);
         }
         if(coded) {
-            if(nnz[0]) eco_levels<WAVE>(s, E, d.coef[0] + ly * ctu + lx, ctu, log2, nnz[0], 0, o);
+            if(nnz[0]) eco_levels<WAVE>(s, E, xl_coef(d, 0) + ly * ctu + lx, ctu, log2, nnz[0], 0, o);
             for(int c = 1; c < 3; c++)
-                if(nnz[c]) eco_levels<WAVE>(s, E, d.coef[c] + (ly >> hs) * (ctu >> ws) + (lx >> ws), ctu >> ws, log2 - ws, nnz[c], 1, o);
+                if(nnz[c]) eco_levels<WAVE>(s, E, xl_coef(d, c) + (ly >> hs) * (ctu >> ws) + (lx >> ws), ctu >> ws, log2 - ws, nnz[c], 1, o);
         }
     }
     for(int j = 0; j < cu >> 2; j++)
@@ -187,7 +205,7 @@ template <bool WAVE = false> XL void eco_unit(const EcoParams &E, Sbac &s, const
 }
 
 // xeve_eco_tree of the CTU at (x0, y0): the coded flags of its units reset first, then the tree in z order (an explicit stack: the walk is five levels deep at most)
-template <bool WAVE = false> XL void eco_ctu(const EcoParams &E, Sbac &s, const xeve_hip_ctu_data &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0, Sink *o)
+template <bool WAVE = false, class D = xeve_hip_ctu_data> XL void eco_ctu(const EcoParams &E, Sbac &s, const D &d, uint32_t *map_scu, const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, int x0, int y0, Sink *o)
 {
     const int pitch = 1 << (E.log2_ctu - 2), ctu = 1 << E.log2_ctu;
     {
@@ -207,7 +225,7 @@ template <bool WAVE = false> XL void eco_ctu(const EcoParams &E, Sbac &s, const 
             const int split = cu >= 8 ? d.split_mode[f.cud][f.cup + (half >> 2) * pitch + (half >> 2)] : 0; // xeve_get_split_mode (xeve_util.c:1125-1144)
             if(!split) {
                 if(cu > 4) sb_bin(s, XEVE_HIP_CTX_SPLIT_CU, 0, o);
-                eco_unit<WAVE>(E, s, d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, f.x, f.y, f.log2, f.cup, o);
+                eco_unit<WAVE, D>(E, s, d, map_scu, map_ipm, map_tidx, map_cu_mode, x0, y0, f.x, f.y, f.log2, f.cup, o);
                 sp--;
                 continue;
             }

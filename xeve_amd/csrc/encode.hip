@@ -65,15 +65,45 @@ __global__ void k_enc_jobs(StepDesc D, int G, int T, xeve_hip_ctu_job *__restric
     j.x = D.x[i] * CTU, j.y = D.y[i] * CTU, j.sbac = g * T + D.t[i], j.pic = g;
     jobs[c] = j;
 }
-// the decided CTUs of the step into the picture's store (the second writer pass reads them): 16 bytes per thread
-__global__ void k_enc_keep(const xeve_hip_ctu_data *__restrict__ out, xeve_hip_ctu_data *__restrict__ store, StepDesc D, int G, int f_lcu)
+// the decided CTUs of the step into the picture's store, in the writer's form (eco_lane.h CtuSyntax: the ten pieces of the walk's record the writer reads, 21 of its
+// 62 KB): 16 bytes per thread and turn; blockIdx.y = chain
+struct KeepSeg {
+    int src, dst, n16; // byte offsets in xeve_hip_ctu_data / CtuSyntax, length in 16-byte units
+};
+#define KEEP_SEG(SRC_FIELD, SRC_EXTRA, DST_FIELD, BYTES) \
+    { (int)offsetof(xeve_hip_ctu_data, SRC_FIELD) + (SRC_EXTRA), (int)offsetof(xl::CtuSyntax, DST_FIELD), (int)((BYTES) / 16) }
+__constant__ const KeepSeg k_keep_segs[10] = {
+    KEEP_SEG(split_mode, 0, split_mode, sizeof(((xl::CtuSyntax *)0)->split_mode)),
+    KEEP_SEG(pred_mode, 0, pred_mode, 256),
+    KEEP_SEG(ipm, 0, ipm0, 256),
+    KEEP_SEG(nnz, 0, nnz, 3 * 256 * 4),
+    KEEP_SEG(coef, 0, coef_y, 64 * 64 * 2),
+    KEEP_SEG(coef, 64 * 64 * 2, coef_u, 32 * 32 * 2), // (a 4:2:0 CTU's chroma levels: the first 32 x 32 of their 64 x 64 planes, pitch 32)
+    KEEP_SEG(coef, 2 * 64 * 64 * 2, coef_v, 32 * 32 * 2),
+    KEEP_SEG(mvd, 0, mvd, 256 * 8),
+    KEEP_SEG(refi, 0, refi, 512),
+    KEEP_SEG(mvp_idx, 0, mvp_idx, 512),
+};
+__global__ void k_enc_keep(const xeve_hip_ctu_data *__restrict__ out, xl::CtuSyntax *__restrict__ store, StepDesc D, int G, int f_lcu)
 {
-    constexpr int V = (int)(sizeof(xeve_hip_ctu_data) / 16);
-    const int     c = blockIdx.y, i = c / G, g = c - i * G;
-    const uint4  *s = reinterpret_cast<const uint4 *>(out + c);
-    uint4        *d = reinterpret_cast<uint4 *>(store + (long)g * f_lcu + D.lcu[i]);
-    for(int k = blockIdx.x * blockDim.x + threadIdx.x; k < V; k += gridDim.x * blockDim.x) d[k] = s[k];
+    const int   c = blockIdx.y, i = c / G, g = c - i * G;
+    const char *s = reinterpret_cast<const char *>(out + c);
+    char       *d = reinterpret_cast<char *>(store + (long)g * f_lcu + D.lcu[i]);
+    for(int k = 0; k < 10; k++) {
+        const KeepSeg  sg = k_keep_segs[k];
+        const uint4   *sp = reinterpret_cast<const uint4 *>(s + sg.src);
+        uint4         *dp = reinterpret_cast<uint4 *>(d + sg.dst);
+        for(int t = blockIdx.x * blockDim.x + threadIdx.x; t < sg.n16; t += gridDim.x * blockDim.x) dp[t] = sp[t];
+    }
 }
+static_assert(sizeof(xl::CtuSyntax) % 16 == 0 && offsetof(xl::CtuSyntax, pred_mode) % 16 == 0 && offsetof(xl::CtuSyntax, ipm0) % 16 == 0 && offsetof(xl::CtuSyntax, nnz) % 16 == 0 &&
+                  offsetof(xl::CtuSyntax, coef_y) % 16 == 0 && offsetof(xl::CtuSyntax, coef_u) % 16 == 0 && offsetof(xl::CtuSyntax, coef_v) % 16 == 0 &&
+                  offsetof(xl::CtuSyntax, mvd) % 16 == 0 && offsetof(xl::CtuSyntax, refi) % 16 == 0 && offsetof(xl::CtuSyntax, mvp_idx) % 16 == 0,
+              "the writer's record is moved 16 bytes at a time");
+static_assert(offsetof(xeve_hip_ctu_data, pred_mode) % 16 == 0 && offsetof(xeve_hip_ctu_data, ipm) % 16 == 0 && offsetof(xeve_hip_ctu_data, nnz) % 16 == 0 &&
+                  offsetof(xeve_hip_ctu_data, coef) % 16 == 0 && offsetof(xeve_hip_ctu_data, mvd) % 16 == 0 && offsetof(xeve_hip_ctu_data, refi) % 16 == 0 &&
+                  offsetof(xeve_hip_ctu_data, mvp_idx) % 16 == 0 && sizeof(((xeve_hip_ctu_data *)0)->split_mode) == sizeof(((xl::CtuSyntax *)0)->split_mode),
+              "the walk's record: the pieces the writer takes start on 16-byte boundaries");
 static_assert(sizeof(xeve_hip_ctu_data) % 16 == 0, "CTU records are moved 16 bytes at a time");
 static_assert(sizeof(((xeve_hip_sbac *)0)->ctx) == XL_NCTX * sizeof(uint16_t), "the models' LDS image");
 __device__ __forceinline__ void sbac_in(xl::Sbac &s, const xeve_hip_sbac *__restrict__ g)
@@ -110,7 +140,7 @@ template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_write(const xev
     if(cap) pos[J.pic] = at + o.n;
 }
 // the second pass (xeve_enc.c:466-560): GOP g's CTUs [lcu0, lcu1) in raster order on the picture's own coder
-template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_rewrite(const xeve_hip_ctu_data *__restrict__ store, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
+template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_rewrite(const xl::CtuSyntax *__restrict__ store, xeve_hip_sbac *__restrict__ states, xl::EcoParams E, uint32_t *map_scu,
                                                     const int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, long map_pic, int G, int f_lcu, int w_lcu,
                                                     int lcu0, int lcu1, uint8_t *__restrict__ bytes, long cap, int32_t *__restrict__ pos)
 {
@@ -234,13 +264,13 @@ struct xeve_hip_enc {
                   out.need(nst * sizeof(xeve_hip_ctu_data)) && next_best.need(nst * sizeof(xeve_hip_sbac)) && cost.need(nst * 8) && slice.need((size_t)G * slice_cap) &&
                   pos.need((size_t)G * 4) &&
                   (!rewrite_mode ? true
-                                                : store2[0].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data)) && rw_scu.need((size_t)G * map_pic * 4) &&
+                                                : store2[0].need((size_t)G * f_lcu * sizeof(xl::CtuSyntax)) && rw_scu.need((size_t)G * map_pic * 4) &&
                                                       rw_cum.need((size_t)G * map_pic * 4) && rw_ipm.need((size_t)G * map_pic));
         // a second CTU store lets the second writer pass of a picture run beside the next picture's steps (which fill the other store); without the memory for it the
         // next picture waits for the pass
         // (XEVE_HIP_ENC_TWO_STORES=0: developer switch, the one-store form)
         const char *ts = getenv("XEVE_HIP_ENC_TWO_STORES");
-        if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xeve_hip_ctu_data));
+        if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xl::CtuSyntax));
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"
@@ -322,7 +352,7 @@ struct xeve_hip_enc {
         static const bool v = !getenv("XEVE_HIP_WRITER_WAVE") || atoi(getenv("XEVE_HIP_WRITER_WAVE")) != 0;
         return v;
     }
-    xeve_hip_ctu_data *store_now() const { return store2[cur_store].as<xeve_hip_ctu_data>(); }
+    xl::CtuSyntax *store_now() const { return store2[cur_store].as<xl::CtuSyntax>(); }
     void step(const ChainCtu *c, int n)
     {
         if(!error.empty()) return;

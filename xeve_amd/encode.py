@@ -66,13 +66,22 @@ class BatchEncoder:
     def sync(self):
         _lib.check(self._L.xeve_hip_enc_sync(self._h))
 
-    def bitstreams(self):
+    def bitstream(self, gop):
+        """the bitstream of one GOP (bytes)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self._L.xeve_hip_enc_bitstream(self._h, gop, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value) if n.value else b""
+
+    def bitstream_sizes(self):
         out = []
         for g in range(self.ngops):
             p, n = C.c_void_p(), C.c_size_t()
             _lib.check(self._L.xeve_hip_enc_bitstream(self._h, g, C.byref(p), C.byref(n)))
-            out.append(C.string_at(p.value, n.value) if n.value else b"")
+            out.append(int(n.value))
         return out
+
+    def bitstreams(self):
+        return [self.bitstream(g) for g in range(self.ngops)]
 
     def encode(self):
         """codes every run; returns the list of bitstreams (bytes), one per GOP"""
