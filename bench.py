@@ -4,15 +4,15 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-THE JOB (per GPU) is ONE real encode: G independent closed GOPs of F frames each (default F = 2: the IDR picture and one inter picture, the sample the CPU baseline
-codes too) of synthetic i.i.d. uniform 8-bit 4:2:0 frames, resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h) exactly as
+THE JOB (per GPU) is ONE real encode: independent closed GOPs of F frames each (default F = 2: the IDR picture and one inter picture, the sample the CPU baseline
+codes too), in --batches batches side by side (the first of G GOPs -- a batch ends at 2^32 original samples --, the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames, resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h) exactly as
 `xeveb_app --preset medium --closed-gop -I 8 -m 8` codes them: CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ, CABAC bit counts),
-entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  GOP 0 of rank 0 is the reference's own seed-4 input, and its
-bitstream is checked against the md5 recorded from the unmodified reference (tests/golden/e2e_v1.json) in the same run.
+entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  The first and the last GOP of every batch of rank 0 are the reference's
+own seed-4 input: their bitstreams are checked against each other and against the md5 recorded from the unmodified reference (tests/golden/e2e_v1.json) in the same run.
 
 A STEP.  The encode is a sequence of lockstep CTU steps (one CTU of every row chain of every GOP decided and written per step; a picture's set-up rides on its first
 step, its end -- loop filter, slice data, NAL units -- on its last).  The job's steps are cut into W + K equal slices: the first W slices are the untimed warm-up, the
-K others are timed between device fences + barriers.  `value` = frames coded inside the timed slices (G x F x the timed share of the job) / the timed seconds, over all
+K others are timed between device fences + barriers.  `value` = frames coded inside the timed slices (GOPs x F x the timed share of the job) / the timed seconds, over all
 ranks; the whole job always runs, so the default and the driver's K / W time the same work.  Every rank encodes its own GOPs ("weak"); no collective in the data path.
 
 The JSON line also carries
@@ -43,7 +43,7 @@ CUS, SIMDS, CLOCK_GHZ = 256, 4, 2.4
 VALU_SAD_PEAK_GBS = CUS * SIMDS * 32 * 8 * CLOCK_GHZ  # v_sad_u16: 2 sample pairs = 8 algorithmic bytes per lane, 32 lanes per clock and SIMD (a wave64 issues over 2 clocks)
 VALU_ISSUE_PEAK_GINST = CUS * SIMDS * CLOCK_GHZ / 2.0  # wave64 VALU instructions per ns: one per SIMD every 2 clocks
 BYTES_PER_SEARCH_UNIT = 256  # 64 sample pairs x (2 + 2) bytes (4*w*h per block SAD)
-INSTR_PER_BIN = 38  # k_cu_bits: measured instructions per coded bin (profiles/r02h_pmc_all_kernels.json)
+INSTR_PER_BIN = 32  # k_cu_bits: measured instructions per coded bin (counted in the kernel's ISA, 16 bins unrolled)
 
 
 def reference_noise(nbytes, seed):
@@ -371,7 +371,7 @@ def main():
             line["roofline"]["by_time"] = {
                 "kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None,
                 "bound": "valu-issue", "achieved": round(bins_s * INSTR_PER_BIN / 64 / 1e9, 3), "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
-                "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 4),
+                "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
                 "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
                        "a serial chain per lane, so the roof is only reachable with every lane of every wave busy" % (INSTR_PER_BIN, CUS, SIMDS, CLOCK_GHZ)}
         except Exception as e:  # noqa: BLE001
