@@ -889,6 +889,11 @@ int xeve_hip_enc_sync(xeve_hip_enc *e);
 int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes);
 /* Lockstep statistics of the last encode: CTU steps issued, seconds inside the step calls / the picture-end calls (loop filter, second writer pass, padding). */
 int xeve_hip_enc_stats(xeve_hip_enc *e, int64_t *ctu_steps, double *step_seconds, double *picture_end_seconds);
+/* How large may a batch be, and what does it cost?  *max_gops: the runs one batch can hold at this picture size (its stacked originals are addressed with 32 bits:
+ * 448 pictures of 3840x2160); *device_bytes: the HBM a batch of `ngops` x `frames` takes between create and delete (picture stores, maps, both CTU stores, the
+ * walk's workspace).  No device call: usable before xeve_hip_init.  A job larger than one batch is several xeve_hip_enc objects, a host thread each -- the device runs
+ * their launch chains side by side (xeve_amd/encode.py encode_gops does the split). */
+int xeve_hip_enc_footprint(const xeve_hip_enc_config *cfg, int ngops, int frames, uint64_t *device_bytes, int32_t *max_gops);
 
 #ifdef __cplusplus
 }

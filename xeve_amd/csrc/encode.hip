@@ -10,6 +10,7 @@
 // pictures of the batch are STACKED VERTICALLY (xh_common.h): GOP g's planes and maps lie g * vh luma rows below GOP 0's, so the intra analysis / the tree operations
 // address them with a picture index and element distances (pic_elems) and the inter analysis as one tall picture.
 #include <chrono>
+#include <cmath>
 #include <optional>
 #include <cstdlib>
 #include <memory>
@@ -235,7 +236,8 @@ struct xeve_hip_enc {
     int16_t *slot_map_mv(int slot) const { return slot_mv.as<int16_t>() + (size_t)slot * G * map_pic * 4; }
     int8_t  *slot_map_refi(int slot) const { return slot_refi.as<int8_t>() + (size_t)slot * G * map_pic * 2; }
 
-    bool create(const Param &p, int ngops, int nframes)
+    // the batch's dimensions (no device call)
+    bool dims(const Param &p, int ngops, int nframes)
     {
         P = p, G = ngops, F = nframes;
         w_scu = P.w >> 2, h_scu = P.h >> 2, w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU, f_lcu = w_lcu * h_lcu, T = std::min(P.threads, h_lcu);
@@ -246,6 +248,44 @@ struct xeve_hip_enc {
         rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
+        return true;
+    }
+    // every device buffer of the batch with its size (the second CTU store apart: the batch runs without it)
+    std::vector<std::pair<DevBuf *, size_t>> buffers()
+    {
+        const size_t nst = (size_t)G * T, m = (size_t)G * map_pic;
+        std::vector<std::pair<DevBuf *, size_t>> v = {
+            {&frames, (size_t)G * F * frame_bytes}, {&org[0], (size_t)G * org_l * 2}, {&org[1], (size_t)G * org_c * 2}, {&org[2], (size_t)G * org_c * 2},
+            {&slot_planes, (size_t)nslots * G * (pic_l + 2 * pic_c) * 2}, {&slot_mv, (size_t)nslots * m * 8}, {&slot_refi, (size_t)nslots * m * 2},
+            {&scu, m * 4}, {&cum, m * 4}, {&ipm, m}, {&tidx, m}, {&states, nst * sizeof(xeve_hip_sbac)}, {&rw_states, (size_t)G * sizeof(xeve_hip_sbac)},
+            {&jobs, nst * sizeof(xeve_hip_ctu_job)}, {&out, nst * sizeof(xeve_hip_ctu_data)}, {&next_best, nst * sizeof(xeve_hip_sbac)}, {&cost, nst * 8},
+            {&slice, (size_t)G * slice_cap}, {&pos, (size_t)G * 4}};
+        if(rewrite_mode) v.insert(v.end(), {{&store2[0], store_bytes()}, {&rw_scu, m * 4}, {&rw_cum, m * 4}, {&rw_ipm, m}});
+        return v;
+    }
+    size_t store_bytes() const { return (size_t)G * f_lcu * sizeof(xl::CtuSyntax); }
+    // the walk's workspace for the run's most demanding picture (no device call: the tables of an inter picture are bound to placeholders)
+    size_t workspace_bytes(const std::vector<PicSetup> &setups)
+    {
+        size_t most = 0;
+        for(PicSetup s : setups) {
+            bind_inter(s);
+            if(s.slice_type != ST_I) { // (a size query dereferences none of them; a batch that has no buffers yet has no addresses to give)
+                static int16_t dummy[4];
+                if(!s.ti.map_mv) s.ti.map_mv = dummy;
+                if(!s.ti.map_refi) s.ti.map_refi = reinterpret_cast<int8_t *>(dummy);
+                if(!s.ti.col_mv0) s.ti.col_mv0 = dummy;
+                if(!s.ti.col_mv1) s.ti.col_mv1 = dummy;
+            }
+            const size_t need = xeve_hip_mode_analyze_ctu_workspace(G * T, &s.tp, s.slice_type == ST_I ? nullptr : &s.ti, P.w, P.w / 2);
+            if(need == 0) { fail(std::string("the CTU walk refuses a picture's parameters: ") + xeve_hip_last_error()); return 0; }
+            most = std::max(most, need);
+        }
+        return most;
+    }
+    bool create(const Param &p, int ngops, int nframes)
+    {
+        if(!dims(p, ngops, nframes)) return false;
         memset(coef_c, 0, sizeof(coef_c));
         for(int i = 0; i < 8; i++) memcpy(coef_c[4 * i], k_coef_c8[i], sizeof(k_coef_c8[i])); // xeve_tbl_mc_c_coeff (xeve_mc.c:59-93)
         int pr_low = 0, pr_high = 0;
@@ -256,21 +296,13 @@ struct xeve_hip_enc {
            !hip_ok(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming), "hipEventCreate") || !hip_ok(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming), "hipEventCreate"))
             return false;
 
-        const size_t nst = (size_t)G * T;
-        bool ok = frames.need((size_t)G * F * frame_bytes) && org[0].need((size_t)G * org_l * 2) && org[1].need((size_t)G * org_c * 2) && org[2].need((size_t)G * org_c * 2) &&
-                  slot_planes.need((size_t)nslots * G * (pic_l + 2 * pic_c) * 2) && slot_mv.need((size_t)nslots * G * map_pic * 8) && slot_refi.need((size_t)nslots * G * map_pic * 2) &&
-                  scu.need((size_t)G * map_pic * 4) && cum.need((size_t)G * map_pic * 4) && ipm.need((size_t)G * map_pic) && tidx.need((size_t)G * map_pic) &&
-                  states.need(nst * sizeof(xeve_hip_sbac)) && rw_states.need((size_t)G * sizeof(xeve_hip_sbac)) && jobs.need(nst * sizeof(xeve_hip_ctu_job)) &&
-                  out.need(nst * sizeof(xeve_hip_ctu_data)) && next_best.need(nst * sizeof(xeve_hip_sbac)) && cost.need(nst * 8) && slice.need((size_t)G * slice_cap) &&
-                  pos.need((size_t)G * 4) &&
-                  (!rewrite_mode ? true
-                                                : store2[0].need((size_t)G * f_lcu * sizeof(xl::CtuSyntax)) && rw_scu.need((size_t)G * map_pic * 4) &&
-                                                      rw_cum.need((size_t)G * map_pic * 4) && rw_ipm.need((size_t)G * map_pic));
+        bool ok = true;
+        for(auto &b : buffers()) ok = ok && b.first->need(b.second);
         // a second CTU store lets the second writer pass of a picture run beside the next picture's steps (which fill the other store); without the memory for it the
         // next picture waits for the pass
         // (XEVE_HIP_ENC_TWO_STORES=0: developer switch, the one-store form)
         const char *ts = getenv("XEVE_HIP_ENC_TWO_STORES");
-        if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need((size_t)G * f_lcu * sizeof(xl::CtuSyntax));
+        if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need(store_bytes());
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"
@@ -315,13 +347,8 @@ struct xeve_hip_enc {
     // waits for the whole device -- for the second writer pass of the picture before, which is meant to run beside the next picture's steps.
     bool reserve(const std::vector<PicSetup> &setups)
     {
-        size_t most = 0;
-        for(PicSetup s : setups) {
-            bind_inter(s);
-            const size_t need = xeve_hip_mode_analyze_ctu_workspace(G * T, &s.tp, s.slice_type == ST_I ? nullptr : &s.ti, P.w, P.w / 2);
-            if(need == 0) return fail(std::string("the CTU walk refuses a picture's parameters: ") + xeve_hip_last_error());
-            most = std::max(most, need);
-        }
+        const size_t most = workspace_bytes(setups);
+        if(most == 0) return false;
         return ws.need(most) || fail("not enough device memory for the CTU walk's workspace");
     }
     void begin_picture(const PicSetup &setup)
@@ -485,6 +512,28 @@ extern "C" xeve_hip_enc *xeve_hip_enc_create(const xeve_hip_enc_config *cfg, int
     return e.release();
 }
 extern "C" void xeve_hip_enc_delete(xeve_hip_enc *e) { delete e; }
+extern "C" int xeve_hip_enc_footprint(const xeve_hip_enc_config *cfg, int ngops, int frames, uint64_t *device_bytes, int32_t *max_gops)
+{
+    XH_REQUIRE(cfg && ngops >= 1 && frames >= 1);
+    Param P;
+    if(!P.finish(*cfg)) { xh_set_error("xeve_hip_enc_footprint: %s", P.error.c_str()); return XEVE_HIP_ERR_ARG; }
+    const long vh = (P.h + 2 * PAD_L + 63) & ~63;
+    const int  most = (int)std::min<double>(1 << 20, std::floor((4294967296.0 - 1) / ((double)vh * P.w)));
+    if(max_gops) *max_gops = most;
+    if(!device_bytes) return XEVE_HIP_OK;
+    xeve_hip_enc e; // (dimensions and sizes only: nothing of it touches the device)
+    e.P_reserved0 = cfg->reserved[0];
+    if(!e.dims(P, ngops, frames)) { xh_set_error("xeve_hip_enc_footprint: %s", e.error.c_str()); return XEVE_HIP_ERR_ARG; }
+    size_t total = 0;
+    for(auto &b : e.buffers()) total += (b.second + 255) & ~(size_t)255;
+    if(e.rewrite_mode) total += e.store_bytes(); // the second CTU store
+    BatchEncoder<xeve_hip_enc> loop(e, P, ngops, frames);
+    const std::vector<PicSetup> setups = loop.dry_setups();
+    const size_t ws = setups.empty() ? 0 : e.workspace_bytes(setups);
+    if(ws == 0) { xh_set_error("xeve_hip_enc_footprint: %s", e.error.empty() ? "the frame loop refuses the run" : e.error.c_str()); return XEVE_HIP_ERR_ARG; }
+    *device_bytes = (uint64_t)(total + ws);
+    return XEVE_HIP_OK;
+}
 extern "C" int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device)
 {
     XH_ENTER();

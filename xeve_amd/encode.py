@@ -99,17 +99,80 @@ class BatchEncoder:
         return {"ctu_steps": steps.value, "step_seconds": a.value, "picture_end_seconds": b.value}
 
 
-def encode_file(yuv_path, out_path, cfg, gops, frames):
+def footprint(cfg, ngops, frames):
+    """(device bytes a batch of ngops x frames takes, the most GOPs one batch can hold at this picture size) -- xeve_hip_enc_footprint; no device call"""
+    L = _lib.load()
+    b, m = C.c_uint64(), C.c_int32()
+    _lib.check(L.xeve_hip_enc_footprint(C.byref(cfg), int(ngops), int(frames), C.byref(b), C.byref(m)))
+    return int(b.value), int(m.value)
+
+
+def plan_batches(cfg, ngops, frames, free_bytes, max_batches=3, reserve_bytes=8 << 30, batch_gops=None):
+    """How `ngops` GOPs are cut into batches that run side by side on one GPU (a host thread and a stream each): as few batches as the per-batch limit (32-bit offsets into
+    the stacked originals) and the free HBM allow, at most max_batches AT A TIME -- what is left over waits for the next round.  Returns a list of rounds, each a list of
+    (first GOP, GOPs).  A step's time hardly depends on the chains it carries and the device runs the batches' launch chains side by side, so frames/s grows with the
+    GOPs in flight (profiles/r03t_*): a round is filled as far as the memory goes.  batch_gops: a lower cap on a batch than the library's (tests)."""
+    one, most = footprint(cfg, 1, frames)
+    if batch_gops:
+        most = min(most, int(batch_gops))
+    two, _ = footprint(cfg, 2, frames)
+    per_gop, fixed = max(1, two - one), max(0, 2 * one - two)
+    rounds, at = [], 0
+    while at < ngops:
+        room, batches = free_bytes - reserve_bytes, []
+        while at < ngops and len(batches) < max_batches:
+            g = int(min(most, ngops - at, (room - fixed) // per_gop))
+            if g < 1:
+                break
+            batches.append((at, g))
+            at += g
+            room -= fixed + g * per_gop
+        if not batches:
+            raise _lib.XeveHipError("not enough device memory for a single GOP of this size")
+        rounds.append(batches)
+    return rounds
+
+
+def encode_gops(cfg, ngops, frames, feed, free_bytes=None, max_batches=3, batch_gops=None):
+    """codes `ngops` closed GOPs of `frames` pictures each on the current GPU and returns their bitstreams in order.  feed(encoder, first_gop, count) pushes the frames of
+    GOPs [first_gop, first_gop + count) into `encoder` as its GOPs 0 .. count - 1.  The GOPs are cut into batches by plan_batches; the batches of a round are encoded
+    side by side, one host thread each (the library call releases the GIL)."""
+    import concurrent.futures as cf
+
+    if free_bytes is None:
+        import torch
+
+        free_bytes = torch.cuda.mem_get_info()[0]
+    out = [None] * ngops
+    for batches in plan_batches(cfg, ngops, frames, free_bytes, max_batches, batch_gops=batch_gops):
+        encs = [BatchEncoder(cfg, n, frames) for _, n in batches]
+        try:
+            for e, (first, n) in zip(encs, batches):
+                feed(e, first, n)
+            with cf.ThreadPoolExecutor(len(encs)) as ex:
+                results = list(ex.map(lambda e: e.encode(), encs))
+            for (first, n), streams in zip(batches, results):
+                out[first:first + n] = streams
+        finally:
+            for e in encs:
+                e.close()
+    return out
+
+
+def encode_file(yuv_path, out_path, cfg, gops, frames, max_batches=3):
     """the whole sequence: GOP g = frames [g * frames, (g + 1) * frames) of the file; the concatenated bitstreams are what the reference writes for the same sequence
-    with --closed-gop -I frames"""
-    enc = BatchEncoder(cfg, gops, frames)
-    fb = enc.frame_bytes
-    with open(yuv_path, "rb") as f:
-        for g in range(gops):
-            for k in range(frames):
-                enc.push(g, k, f.read(fb))
-    streams = enc.encode()
+    with --closed-gop -I frames.  Sequences beyond one batch are cut into batches that run side by side (encode_gops)."""
+    fb = cfg.w * cfg.h * 3 // 2
+
+    def feed(enc, first, n):
+        with open(yuv_path, "rb") as f:
+            f.seek(first * frames * fb)
+            for g in range(n):
+                for k in range(frames):
+                    enc.push(g, k, f.read(fb))
+
+    streams = encode_gops(cfg, gops, frames, feed, max_batches=max_batches)
     with open(out_path, "wb") as f:
         for s in streams:
             f.write(s)
-    return streams, enc.stats()
+    return streams

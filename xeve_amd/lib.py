@@ -245,6 +245,7 @@ FUNCTIONS = {
     "xeve_hip_enc_sync": (c_int, [c_void_p]),
     "xeve_hip_enc_bitstream": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_enc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_enc_footprint": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 TABLES = {
     "xeve_tbl_sad_16b_hip": FN_SAD * 64,
