@@ -867,13 +867,15 @@ typedef struct xeve_hip_enc_config {
     int32_t threads;          /* -m: 1 .. 8 */
     int32_t inter_slice_type; /* --inter-slice-type: 0 B, 1 P */
     int32_t ref;              /* --ref (0: the preset's) */
-    int32_t reserved[4];
+    int32_t reserved[4];      /* [0] bit 0: always run the second writer pass (tests).  [1]: the application's -d, the input's bit depth -- 0 / 8: one byte per sample;
+                               * 10: 16-bit little-endian samples (frames pushed are twice as long).  Either way the codec works at 10 bits (--codec-bit-depth). */
 } xeve_hip_enc_config;
 typedef struct xeve_hip_enc xeve_hip_enc;
 /* A batch of `ngops` runs of `frames` pictures each.  NULL + xeve_hip_last_error() when the configuration is outside the supported set or HBM does not hold the batch. */
 xeve_hip_enc *xeve_hip_enc_create(const xeve_hip_enc_config *cfg, int ngops, int frames);
 void          xeve_hip_enc_delete(xeve_hip_enc *e);
-/* Frame `frame` of run `gop`: planar 8-bit 4:2:0 (w*h luma bytes, then U, then V), host memory (on_device 0) or device memory (1).  The frame is copied into HBM
+/* Frame `frame` of run `gop`: planar 4:2:0 (w*h luma samples, then U, then V; one byte each, or two with an input depth of 10), host memory (on_device 0) or device
+ * memory (1).  The frame is copied into HBM
  * before the call returns (as xeve_push copies its image); the copy runs on the encoder's own stream, so device memory must be COMPLETE when the call is made --
  * work still queued on another stream that produces it is not waited for. */
 int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device);

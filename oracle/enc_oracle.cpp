@@ -72,11 +72,14 @@ struct CpuEngine {
         S = setup;
         for(int g = 0; g < G; g++) {
             Gop &q = gop[g];
-            const uint8_t *f = yuv[g] + (size_t)S.frame * P.w * P.h * 3 / 2;
-            for(size_t i = 0; i < q.org[0].size(); i++) q.org[0][i] = (xo_pel)(f[i] << (BIT_DEPTH - 8)); // the application's 8 -> 10 bit conversion (imgb_cpy_conv_8b_to_16b)
-            f += q.org[0].size();
-            for(int c = 1; c < 3; c++, f += q.org[1].size())
-                for(size_t i = 0; i < q.org[c].size(); i++) q.org[c][i] = (xo_pel)(f[i] << (BIT_DEPTH - 8));
+            const uint8_t *f = yuv[g] + (size_t)S.frame * P.frame_bytes();
+            const bool     wide = P.input_depth > 8; // -d 10: 16-bit little-endian samples, copied as they are; -d 8: the application's 8 -> 10 bit conversion (imgb_cpy_conv_8b_to_16b)
+            size_t         at = 0;
+            auto sample = [&](size_t i) { return wide ? (xo_pel)(f[2 * i] | (f[2 * i + 1] << 8)) : (xo_pel)(f[i] << (BIT_DEPTH - 8)); };
+            for(int c = 0; c < 3; c++) {
+                for(size_t i = 0; i < q.org[c].size(); i++) q.org[c][i] = sample(at + i);
+                at += q.org[c].size();
+            }
             std::fill(q.scu.begin(), q.scu.end(), 0u), std::fill(q.cum.begin(), q.cum.end(), 0u); // xeve_pic_prepare (:1236-1237)
             Store &cur = q.st[S.cur_slot];
             std::fill(cur.mv.begin(), cur.mv.end(), (int16_t)0), std::fill(cur.refi.begin(), cur.refi.end(), (int8_t)-1); // (:1220-1225)

@@ -35,6 +35,8 @@ def config(w, h, cli, threads=1):
             c.qp = int(cli[i + 1])
         elif a == "-m":
             c.threads = int(cli[i + 1])
+        elif a == "-d":
+            c.reserved[1] = int(cli[i + 1])
         elif a == "--closed-gop":
             c.closed_gop = 1
             i -= 1
@@ -120,6 +122,20 @@ BATCH_CASES_REAL = {
     "cfg3_1080p_ra_medium_9f_m8": (1920, 1080, 1, 9, 3, ["--preset", "medium"], 8),
     "cfg4_2160p_closedgop_medium_2f_m8": (3840, 2160, 1, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
 }
+
+# 10-bit input (the application's -d 10: 16-bit little-endian samples, handed to the codec as they are): the 8-bit clip of the seed widened by widen10
+DEPTH10_CASES = {
+    "gops_128x64_10bit_m2": (128, 64, 2, 8, 27, ["--preset", "medium", "--closed-gop", "-I", "8", "-d", "10"], 2),
+    "gops_192x128_10bit_b3": (192, 128, 2, 4, 5028, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "3", "-d", "10"], 1),
+}
+
+
+def widen10(data8):
+    """8-bit samples -> 10-bit samples in 16-bit little-endian words: the byte in the upper eight bits, two position-dependent bits below (so that the low bits matter)"""
+    import numpy as np
+
+    b = np.frombuffer(data8, dtype=np.uint8).astype(np.uint16)
+    return ((b << 2) | ((b * 3 + np.arange(b.size, dtype=np.uint16)) & 3)).astype("<u2").tobytes()
 
 
 def golden():

@@ -74,6 +74,16 @@ def test_batches_of_closed_gops_on_the_gpu(name, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("name", sorted(_enc.DEPTH10_CASES))
+def test_ten_bit_input_on_the_gpu(name, hip, yuv_dir):
+    """the application's -d 10 (16-bit little-endian samples, twice the bytes per frame): every GOP = the reference's run over it"""
+    w, h, gops, frames, seed, cli, threads = _enc.DEPTH10_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _enc.widen10(_frames(yuv_dir, name, w, h, gops * frames, seed)), w * h * 3 * frames
+    outs, _ = _run(hip, _cfg(hip, w, h, cli, threads, input_depth=10), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_one_chain_through_the_second_writer_pass_on_the_gpu(hip, yuv_dir):
     w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]
     f = _frames(yuv_dir, "tiny_closed_gop", w, h, n, seed)

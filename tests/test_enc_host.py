@@ -59,6 +59,20 @@ def test_batches_of_closed_gops_reproduce_the_reference_run_per_gop(name, yuv_di
     assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
 
 
+@pytest.mark.parametrize("name", sorted(_enc.DEPTH10_CASES))
+def test_ten_bit_input_is_handed_to_the_codec_as_it_is(name, yuv_dir):
+    """the application's -d 10: 16-bit samples, no conversion -- every GOP = the reference's run over it, and the concatenation = its one run over the sequence"""
+    w, h, gops, frames, seed, cli, threads = _enc.DEPTH10_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _enc.widen10(_frames(yuv_dir, name, w, h, gops * frames, seed)), w * h * 3 * frames  # (two bytes per sample)
+    cfg = _enc.config(w, h, cli, threads)
+    assert cfg.reserved[1] == 10
+    outs = _enc.encode_cpu(cfg, [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+    whole = b"".join(outs)
+    assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
+
+
 WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

@@ -29,6 +29,7 @@ enum { PAD_L = 144, PAD_C = 72, BIT_DEPTH = 10, LOG2_CTU = 6, CTU = 64, MAX_ACTI
 struct Param {
     int w = 0, h = 0, fps_num = 30, fps_den = 1, qp = 32, keyint = 0, bframes = 15, closed_gop = 0, threads = 1, inter_slice_type = 0, ref = 0;
     int preset = 1; // 0 fast, 1 medium
+    int input_depth = 8; // the application's -d: 8 = one byte per sample, 10 = 16-bit little-endian samples (both go to the codec's 10 bits, xeve_app.c:1153-1158)
     // derived
     int gop_size = 16, ref_pic_gap_length = 0, me_ref_num = 1, me_range = 64, me_sub = 2, me_sub_pos = 4, me_sub_range = 1, merge_num = 3, me_algo = 1;
     int max_cu_intra = 32, min_cu_intra = 4, max_cu_inter = 64, min_cu_inter = 8, lookahead = 17;
@@ -37,13 +38,14 @@ struct Param {
     bool finish(const xeve_hip_enc_config &c)
     {
         w = c.w, h = c.h, fps_num = c.fps_num, fps_den = c.fps_den, qp = c.qp, keyint = c.keyint, bframes = c.bframes, closed_gop = c.closed_gop != 0;
-        threads = c.threads, inter_slice_type = c.inter_slice_type, ref = c.ref, preset = c.preset;
+        threads = c.threads, inter_slice_type = c.inter_slice_type, ref = c.ref, preset = c.preset, input_depth = c.reserved[1] ? c.reserved[1] : 8;
         auto bad = [&](const char *m) { error = m; return false; };
         if(w <= 0 || h <= 0 || (w & 7) || (h & 7)) return bad("picture size must be a positive multiple of 8 in both directions");
         if(w > 8192 || h > 4320) return bad("picture larger than 8192x4320");
         if(qp < 0 || qp > 51 || keyint < 0 || threads < 1 || threads > 8 || fps_num <= 0 || fps_den <= 0) return bad("qp / keyint / threads / fps out of range");
         if(!(bframes == 0 || bframes == 1 || bframes == 3 || bframes == 7 || bframes == 15)) return bad("bframes must be 0, 1, 3, 7 or 15");
         if(bframes && !closed_gop && keyint % (bframes + 1) != 0) return bad("an open GOP needs keyint to be a multiple of bframes + 1");
+        if(input_depth != 8 && input_depth != 10) return bad("input depth must be 8 or 10 bits");
         if(inter_slice_type != 0) return bad("inter_slice_type must be 0 (B): the reference application cannot select P slices (its --inter-slice-type fails to parse), so they have no pin");
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
@@ -54,6 +56,7 @@ struct Param {
         lookahead = std::min(std::max(0, 17), MAX_INBUF >> 1);
         return true;
     }
+    long frame_bytes() const { return (long)w * h * 3 / 2 * (input_depth > 8 ? 2 : 1); } // one planar 4:2:0 input frame
     int max_num_ref_pics() const { return bframes > 0 ? me_ref_num : ref_pic_gap_length; } // xeve_set_sps (xeve_enc.c:1413-1419)
 };
 

@@ -37,15 +37,17 @@ struct StepDesc { // the CTUs of one lockstep step (the same for every GOP): at 
     int t[8], x[8], y[8], lcu[8];
 };
 
-// frames: [G][F][w * h * 3 / 2] bytes; one thread per luma sample pair / chroma sample; blockIdx.y = GOP
+// frames: [G][F][w * h * 3 / 2] samples of one byte (the application's -d 8) or of two (-d 10, little-endian); one thread per luma sample and its share of the chroma;
+// blockIdx.y = GOP.  Both depths land in the codec's 10 bits (imgb_cpy_conv_8b_to_16b / the plain copy of xeve_app.c's imgb_cpy)
+template <class SAMPLE, int SHIFT>
 __global__ void k_enc_load(const uint8_t *__restrict__ frames, long gop_bytes, long frame_off, pel *__restrict__ y, pel *__restrict__ u, pel *__restrict__ v, int w, int h,
                            long pic_l, long pic_c)
 {
-    const int      g = blockIdx.y;
-    const uint8_t *f = frames + g * gop_bytes + frame_off;
-    const long     nl = (long)w * h, nc = nl >> 2, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if(i < nl) y[g * pic_l + i] = (pel)(f[i] << (BIT_DEPTH - 8)); // (the original planes have no padding: stride = width)
-    if(i < nc) u[g * pic_c + i] = (pel)(f[nl + i] << (BIT_DEPTH - 8)), v[g * pic_c + i] = (pel)(f[nl + nc + i] << (BIT_DEPTH - 8));
+    const int     g = blockIdx.y;
+    const SAMPLE *f = reinterpret_cast<const SAMPLE *>(frames + g * gop_bytes + frame_off);
+    const long    nl = (long)w * h, nc = nl >> 2, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < nl) y[g * pic_l + i] = (pel)(f[i] << SHIFT); // (the original planes have no padding: stride = width)
+    if(i < nc) u[g * pic_c + i] = (pel)(f[nl + i] << SHIFT), v[g * pic_c + i] = (pel)(f[nl + nc + i] << SHIFT);
 }
 __global__ void k_enc_reset_chain(xeve_hip_sbac *__restrict__ states, int stride, int at, int G)
 { // xeve_sbac_reset (xeve_eco.c:597-620) without sps_cm_init_flag: every model at 1/2
@@ -243,7 +245,7 @@ struct xeve_hip_enc {
         w_scu = P.w >> 2, h_scu = P.h >> 2, w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU, f_lcu = w_lcu * h_lcu, T = std::min(P.threads, h_lcu);
         vh = (P.h + 2 * PAD_L + 63) & ~63, s_l = P.w + 2 * PAD_L, s_c = P.w / 2 + 2 * PAD_C;
         org_l = (long)vh * P.w, org_c = (long)(vh / 2) * (P.w / 2), pic_l = (long)vh * s_l, pic_c = (long)(vh / 2) * s_c, map_pic = (long)(vh / 4) * w_scu;
-        frame_bytes = (long)P.w * P.h * 3 / 2, slice_cap = frame_bytes + 4096;
+        frame_bytes = P.frame_bytes(), slice_cap = (long)P.w * P.h * 3 / 2 + 4096;
         if((double)G * org_l >= 4294967296.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^32 samples (xh_common.h)");
         rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
@@ -356,8 +358,13 @@ struct xeve_hip_enc {
         S = setup;
         if(!error.empty()) return;
         const long n = (long)P.w * P.h;
-        k_enc_load<<<dim3((unsigned)((n + 255) / 256), G), 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(),
-                                                                         org[1].as<pel>(), org[2].as<pel>(), P.w, P.h, org_l, org_c);
+        const dim3 lg((unsigned)((n + 255) / 256), G);
+        if(P.input_depth > 8)
+            k_enc_load<uint16_t, 0><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(), org[1].as<pel>(), org[2].as<pel>(),
+                                                        P.w, P.h, org_l, org_c);
+        else
+            k_enc_load<uint8_t, BIT_DEPTH - 8><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(), org[1].as<pel>(),
+                                                                   org[2].as<pel>(), P.w, P.h, org_l, org_c);
         hip_ok(hipMemsetAsync(scu.p, 0, scu.bytes, st), "hipMemset"), hip_ok(hipMemsetAsync(cum.p, 0, cum.bytes, st), "hipMemset"); // xeve_pic_prepare (:1236-1237)
         hip_ok(hipMemsetAsync(slot_map_mv(S.cur_slot), 0, (size_t)G * map_pic * 8, st), "hipMemset"); // (:1220-1225)
         hip_ok(hipMemsetAsync(slot_map_refi(S.cur_slot), 0xFF, (size_t)G * map_pic * 2, st), "hipMemset");

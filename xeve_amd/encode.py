@@ -8,12 +8,13 @@ from . import lib as _lib
 PRESETS = {"fast": 0, "medium": 1}
 
 
-def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False):
-    """the options of the reference application (xeve_app: -w -h -q -I -b --closed-gop --preset -m -z --ref) as the library's configuration record"""
+def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False, input_depth=8):
+    """the options of the reference application (xeve_app: -w -h -q -I -b --closed-gop --preset -m -z --ref -d) as the library's configuration record"""
     c = _lib.EncConfig()
     c.w, c.h, c.fps_num, c.fps_den, c.qp, c.keyint, c.bframes, c.closed_gop = w, h, fps[0], fps[1], qp, keyint, bframes, int(bool(closed_gop))
     c.preset, c.threads, c.inter_slice_type, c.ref = PRESETS[preset] if isinstance(preset, str) else int(preset), threads, 0, ref
     c.reserved[0] = 1 if always_second_pass else 0
+    c.reserved[1] = int(input_depth)
     return c
 
 
@@ -23,7 +24,7 @@ class BatchEncoder:
     def __init__(self, cfg, ngops, frames):
         L = _lib.load()
         self._L, self.cfg, self.ngops, self.frames = L, cfg, ngops, frames
-        self.frame_bytes = cfg.w * cfg.h * 3 // 2
+        self.frame_bytes = cfg.w * cfg.h * 3 // 2 * (2 if cfg.reserved[1] > 8 else 1)
         self._h = L.xeve_hip_enc_create(C.byref(cfg), ngops, frames)
         if not self._h:
             raise _lib.XeveHipError(_lib.last_error())
@@ -37,7 +38,7 @@ class BatchEncoder:
         self.close()
 
     def push(self, gop, frame, data):
-        """data: bytes-like of one planar 8-bit 4:2:0 frame (host), or a uint8 torch tensor on the GPU"""
+        """data: bytes-like of one planar 4:2:0 frame (host; one byte per sample, two little-endian with input_depth 10), or a uint8 torch tensor of those bytes on the GPU"""
         if hasattr(data, "data_ptr"):
             assert data.numel() == self.frame_bytes and data.is_contiguous()
             if data.is_cuda:  # the library copies on its own stream: whatever produced the tensor on torch's stream must be through
@@ -162,7 +163,7 @@ def encode_gops(cfg, ngops, frames, feed, free_bytes=None, max_batches=3, batch_
 def encode_file(yuv_path, out_path, cfg, gops, frames, max_batches=3):
     """the whole sequence: GOP g = frames [g * frames, (g + 1) * frames) of the file; the concatenated bitstreams are what the reference writes for the same sequence
     with --closed-gop -I frames.  Sequences beyond one batch are cut into batches that run side by side (encode_gops)."""
-    fb = cfg.w * cfg.h * 3 // 2
+    fb = cfg.w * cfg.h * 3 // 2 * (2 if cfg.reserved[1] > 8 else 1)
 
     def feed(enc, first, n):
         with open(yuv_path, "rb") as f:
