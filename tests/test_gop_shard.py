@@ -67,3 +67,75 @@ def test_two_rank_gloo_shards(tmp_path):
         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK" in out.stdout
+
+
+# ---- the shard driver on the batch encoder (gop.run_encoder_shards): two workers, a sequence whose last GOP is short ----------------------------------------------------
+FAKE_WORKER = r"""
+# a worker of gop.run_encoder_shards with the GPU engine swapped for the CPU harness (tests/_enc.py: the product's frame loop on the oracle) -- everything else,
+# from the job file to the per-GOP part files, is the product's protocol
+import json, os, sys
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import _enc
+from xeve_amd import gop
+spec = json.load(open(sys.argv[2]))
+c = spec["config"]
+cli = ["--preset", c["preset"], "--closed-gop", "-I", str(c["keyint"]), "-b", str(c["bframes"])]
+cfg = _enc.config(c["w"], c["h"], cli, c.get("threads", 1))
+fb = c["w"] * c["h"] * 3 // 2
+data = open(spec["yuv"], "rb").read()
+mine = gop.shards_for_rank(spec["total_frames"], spec["keyint"], spec["rank"], spec["world"])
+by_len = {}
+for s in mine:
+    by_len.setdefault(s.frames, []).append(s)
+for frames, group in by_len.items():
+    outs = _enc.encode_cpu(cfg, [data[s.seek * fb:(s.seek + frames) * fb] for s in group], frames)
+    for s, o in zip(group, outs):
+        open(os.path.join(spec["dir"], "gop%06d.evc" % s.gop), "wb").write(o)
+"""
+
+
+def _closed_gop_case(tmp_path):
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _e2e
+
+    w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]  # 10 frames, --closed-gop -I 4 -b 1: GOPs of 4, 4 and 2 frames
+    yuv = str(tmp_path / "in.yuv")
+    _e2e.make_yuv(yuv, w, h, n, seed)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))["tiny_closed_gop"]
+    return yuv, dict(w=w, h=h, qp=32, bframes=1, preset="fast", threads=1), n, 4, gold
+
+
+def test_two_workers_code_their_gops_and_the_concatenation_is_the_references_one_run(tmp_path):
+    """world size 2 on the CPU: worker 0 takes GOPs 0 and 2 (the short tail), worker 1 GOP 1; the joined file = the reference's single run over the ten frames"""
+    import hashlib
+
+    yuv, config, n, keyint, gold = _closed_gop_case(tmp_path)
+    script = tmp_path / "fake_worker.py"
+    script.write_text(FAKE_WORKER)
+    out = str(tmp_path / "out.evc")
+    r = gop.run_encoder_shards(yuv, out, config, n, keyint, devices=[0, 1], worker_cmd=[sys.executable, str(script), ROOT], timeout=600)
+    b = open(out, "rb").read()
+    assert (len(b), hashlib.md5(b).hexdigest()) == (gold["bytes"], gold["md5"]) and r["bytes"] == len(b) and sorted(w for w, _, _ in r["workers"]) == [0, 1]
+
+
+def test_a_failing_worker_fails_the_run(tmp_path):
+    yuv, config, n, keyint, _ = _closed_gop_case(tmp_path)
+    script = tmp_path / "bad_worker.py"
+    script.write_text("import sys\nsys.stderr.write('no GPU here')\nsys.exit(3)\n")
+    with pytest.raises(RuntimeError, match="no GPU here"):
+        gop.run_encoder_shards(yuv, str(tmp_path / "o.evc"), config, n, keyint, devices=[0], worker_cmd=[sys.executable, str(script)], timeout=60)
+
+
+@pytest.mark.gpu
+def test_two_worker_processes_on_the_gpu_reproduce_the_references_one_run(tmp_path):
+    """the real workers (xeve_amd.shard_worker on the batch encoder), two processes sharing GPU 0"""
+    import hashlib
+
+    yuv, config, n, keyint, gold = _closed_gop_case(tmp_path)
+    out = str(tmp_path / "out.evc")
+    gop.run_encoder_shards(yuv, out, config, n, keyint, devices=[0], per_device=2, timeout=600, env={"PYTHONPATH": ROOT})
+    b = open(out, "rb").read()
+    assert (len(b), hashlib.md5(b).hexdigest()) == (gold["bytes"], gold["md5"])

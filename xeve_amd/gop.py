@@ -121,3 +121,80 @@ def run_shards(encoder_cmd, yuv, out, total_frames, keyint, devices, env=None, w
             log.close()
         if own_dir:
             shutil.rmtree(work_dir, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the same on the batch encoder (xeve_amd/encode.py): one PROCESS per GPU, each coding ITS closed GOPs in lockstep batches
+# ---------------------------------------------------------------------------------------------------------------------------
+def run_encoder_shards(yuv, out, config, total_frames, keyint, devices, per_device=1, work_dir=None, timeout=None, worker_cmd=None, env=None):
+    """Encode `yuv` as closed GOPs of `keyint` frames on the batch encoder, one worker PROCESS per entry of `devices` (x per_device): worker i of n codes the GOPs
+    g = i, i + n, i + 2n, ... -- all of them at once, in lockstep batches side by side (encode.encode_gops) -- and the host concatenates the per-GOP bitstreams in order.
+
+    config     : the keyword arguments of xeve_amd.encode.config (w, h, qp, bframes, preset, threads, input_depth, ...); closed_gop and keyint are set here.
+    worker_cmd : argv prefix of the worker (default: this interpreter running xeve_amd.shard_worker); it gets one argument, the path of its job file (JSON).
+    No exchange between the workers (no RCCL, nothing over xGMI): the only joint operation is the concatenation.
+    Returns {"bytes": n, "workers": [(worker, device, seconds)], "seconds": wall, "fps": frames / wall}."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    import time
+
+    shards = plan(total_frames, keyint)
+    if not shards:
+        raise ValueError("nothing to encode")
+    slots = [d for d in devices for _ in range(per_device)]
+    if not slots:
+        raise ValueError("no device given")
+    own_dir = work_dir is None
+    work_dir = work_dir or tempfile.mkdtemp(prefix="xeve_shards_")
+    cfg = dict(config)
+    cfg.update(closed_gop=True, keyint=keyint)
+    procs, t0 = [], time.perf_counter()
+    try:
+        for i, d in enumerate(slots):
+            if not any(s.gop % len(slots) == i for s in shards):
+                continue
+            job = os.path.join(work_dir, "worker%03d.json" % i)
+            with open(job, "w") as f:
+                json.dump({"yuv": os.path.abspath(yuv), "config": cfg, "total_frames": total_frames, "keyint": keyint, "rank": i, "world": len(slots), "dir": work_dir}, f)
+            e = dict(os.environ)
+            e.update(env or {})
+            e["HIP_VISIBLE_DEVICES"], e["XEVE_HIP_DEVICE"] = str(d), "0"  # (every worker sees exactly one GPU)
+            log = open(job + ".stderr", "w+")
+            p = subprocess.Popen(list(worker_cmd or [sys.executable, "-m", "xeve_amd.shard_worker"]) + [job], env=e, stdout=subprocess.DEVNULL, stderr=log, text=True)
+            procs.append([p, i, d, time.perf_counter(), log, None])
+        while any(r[5] is None for r in procs):
+            for r in procs:
+                p, i, d, ts, log, secs = r
+                if secs is not None:
+                    continue
+                if p.poll() is None:
+                    if timeout and time.perf_counter() - ts > timeout:
+                        raise TimeoutError("worker %d (device %s) exceeded %s s" % (i, d, timeout))
+                    continue
+                log.seek(0)
+                err = log.read()
+                if p.returncode != 0:
+                    raise RuntimeError("worker %d failed (device %s, rc %s): %s" % (i, d, p.returncode, err[-800:]))
+                r[5] = time.perf_counter() - ts
+            time.sleep(0.02)
+        wall, n = time.perf_counter() - t0, 0
+        with open(out, "wb") as f:
+            for s in shards:
+                part = os.path.join(work_dir, "gop%06d.evc" % s.gop)
+                if not os.path.exists(part):
+                    raise RuntimeError("no bitstream for GOP %d" % s.gop)
+                with open(part, "rb") as g:
+                    n += f.write(g.read())
+        return {"bytes": n, "workers": [(i, d, round(secs, 3)) for _, i, d, _, _, secs in procs], "seconds": wall, "fps": total_frames / wall}
+    finally:
+        for p, _, _, _, log, _ in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+            log.close()
+        if own_dir:
+            shutil.rmtree(work_dir, ignore_errors=True)
