@@ -807,7 +807,7 @@ static int inter_host_resident(const xeve_hip_pel *const org[3], int s_org_l, in
 }
 
 // ---- host-memory form of one xeve_pinter_analyze_cu call (the table layer's style: synchronous, every plane staged per call) ----------
-// What ctx->fn_pinter_analyze_cu can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org / refp: HOST pointers to
+// What ctx->fn_pinter_analyze_cu can be pointed at (tests/test_integration_ref.py does, through shim/xeve_hip_shim.c).  org / refp: HOST pointers to
 // sample (0, 0); the reference planes extend pad_l / pad_c samples around the picture.
 extern "C" int xeve_hip_pinter_analyze_cu_host(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, int pad_l,
                                                int pad_c, const xeve_hip_sbac *state, const xeve_hip_inter_params *p, const xeve_hip_inter_job *job,

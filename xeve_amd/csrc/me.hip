@@ -774,7 +774,7 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
 
 
 // ---- host-memory form of one pinter_me_epzs call (the table layer's style: synchronous, planes staged per call) ------------------
-// What pi->fn_me can be pointed at (tests/test_integration_ref.py does, through oracle/ref_shim.c).  org0 / ref0: sample (0, 0) of
+// What pi->fn_me can be pointed at (tests/test_integration_ref.py does, through shim/xeve_hip_shim.c).  org0 / ref0: sample (0, 0) of
 // the original luma plane (rows 0 .. pic_h - 1 are read) and of the padded reference luma plane (pad samples around the picture).
 extern "C" int xeve_hip_me_epzs_host(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, int pad, int pic_h,
                                      const xeve_hip_epzs_job *job, int log2w, int log2h, int bit_depth, const int16_t (*coef)[8],
