@@ -143,3 +143,12 @@ def test_configurations_outside_the_supported_set_are_refused():
             setattr(c, k, v)
         with pytest.raises(RuntimeError):
             _enc.encode_cpu(c, [bytes(128 * 64 * 3 // 2)], 1)
+    # a picture one CTU wide with several row chains: the reference's row threads do not wait for each other there (xeve_enc.c:130-133) and its own output changes from run
+    # to run (tests/golden/fuzz_enc_host.py found it) -- refused rather than answered
+    c = _enc.config(64, 136, ["--preset", "fast"], threads=2)
+    with pytest.raises(RuntimeError, match="one CTU wide"):
+        _enc.encode_cpu(c, [bytes(64 * 136 * 3 // 2)], 1)
+    d = _enc.config(128, 64, ["--preset", "fast", "-d", "10"])
+    d.reserved[1] = 12
+    with pytest.raises(RuntimeError, match="input depth"):
+        _enc.encode_cpu(d, [bytes(128 * 64 * 3)], 1)

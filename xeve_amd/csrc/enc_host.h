@@ -60,7 +60,10 @@ template <class Engine> class BatchEncoder {
         out = &out_;
         out->assign(G, std::vector<uint8_t>());
         pics = plan();
-        if((int)pics.size() != F) return fail("the frame loop did not code every frame");
+        if((int)pics.size() != F) // (e.g. low-delay closed GOPs with an odd keyint and more frames than one GOP: the reference picks its input slot from the picture's
+                                  // count inside the GOP while the frames sit at their count in the sequence, xeve_enc.c:1080 vs :661 -- its own output there codes
+                                  // stale slots and its application does not terminate cleanly; nothing to reproduce)
+            return fail("the frame loop did not code every frame (the reference has no defined output for this combination of options and frame count)");
         dpb = Dpb(slots_needed(P, F));
         const int w_lcu = (P.w + CTU - 1) / CTU, h_lcu = (P.h + CTU - 1) / CTU;
         steps = wavefront(w_lcu, h_lcu, P.threads);
