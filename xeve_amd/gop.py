@@ -159,7 +159,8 @@ def run_encoder_shards(yuv, out, config, total_frames, keyint, devices, per_devi
                 continue
             job = os.path.join(work_dir, "worker%03d.json" % i)
             with open(job, "w") as f:
-                json.dump({"yuv": os.path.abspath(yuv), "config": cfg, "total_frames": total_frames, "keyint": keyint, "rank": i, "world": len(slots), "dir": work_dir}, f)
+                json.dump({"yuv": os.path.abspath(yuv), "config": cfg, "total_frames": total_frames, "keyint": keyint, "rank": i, "world": len(slots), "dir": work_dir,
+                           "memory_share": 1.0 / per_device}, f)  # (workers sharing a GPU plan their batches on their share of its free memory)
             e = dict(os.environ)
             e.update(env or {})
             e["HIP_VISIBLE_DEVICES"], e["XEVE_HIP_DEVICE"] = str(d), "0"  # (every worker sees exactly one GPU)

@@ -17,6 +17,9 @@ def main(argv):
     by_len = {}
     for s in mine:  # (a batch's GOPs have one length: the sequence's last GOP may be shorter and then goes alone)
         by_len.setdefault(s.frames, []).append(s)
+    import torch
+
+    free = int(torch.cuda.mem_get_info()[0] * float(spec.get("memory_share", 1.0)))
     with open(spec["yuv"], "rb") as f:
         for frames, group in sorted(by_len.items(), reverse=True):
 
@@ -26,7 +29,7 @@ def main(argv):
                     for k in range(frames):
                         enc.push(j, k, f.read(fb))
 
-            for s, stream in zip(group, encode.encode_gops(cfg, len(group), frames, feed)):
+            for s, stream in zip(group, encode.encode_gops(cfg, len(group), frames, feed, free_bytes=free)):
                 tmp = os.path.join(spec["dir"], "gop%06d.evc.part" % s.gop)
                 with open(tmp, "wb") as o:
                     o.write(stream)
