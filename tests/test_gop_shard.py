@@ -121,6 +121,13 @@ def test_two_workers_code_their_gops_and_the_concatenation_is_the_references_one
     assert (len(b), hashlib.md5(b).hexdigest()) == (gold["bytes"], gold["md5"]) and r["bytes"] == len(b) and sorted(w for w, _, _ in r["workers"]) == [0, 1]
 
 
+def test_a_keyint_that_cuts_a_sub_gop_short_is_not_split_silently(tmp_path):
+    """with -b 3 -I 5 the reference's own --seek / --frames runs do not join to its single run: the driver refuses unless told to split anyway"""
+    yuv, config, n, keyint, _ = _closed_gop_case(tmp_path)
+    with pytest.raises(ValueError, match="multiple of bframes"):
+        gop.run_encoder_shards(yuv, str(tmp_path / "o.evc"), dict(config, bframes=3), n, 5, devices=[0], worker_cmd=["true"])
+
+
 def test_a_failing_worker_fails_the_run(tmp_path):
     yuv, config, n, keyint, _ = _closed_gop_case(tmp_path)
     script = tmp_path / "bad_worker.py"

@@ -126,13 +126,16 @@ def run_shards(encoder_cmd, yuv, out, total_frames, keyint, devices, env=None, w
 # ---------------------------------------------------------------------------------------------------------------------------
 # the same on the batch encoder (xeve_amd/encode.py): one PROCESS per GPU, each coding ITS closed GOPs in lockstep batches
 # ---------------------------------------------------------------------------------------------------------------------------
-def run_encoder_shards(yuv, out, config, total_frames, keyint, devices, per_device=1, work_dir=None, timeout=None, worker_cmd=None, env=None):
+def run_encoder_shards(yuv, out, config, total_frames, keyint, devices, per_device=1, work_dir=None, timeout=None, worker_cmd=None, env=None, aligned_only=True):
     """Encode `yuv` as closed GOPs of `keyint` frames on the batch encoder, one worker PROCESS per entry of `devices` (x per_device): worker i of n codes the GOPs
     g = i, i + n, i + 2n, ... -- all of them at once, in lockstep batches side by side (encode.encode_gops) -- and the host concatenates the per-GOP bitstreams in order.
 
     config     : the keyword arguments of xeve_amd.encode.config (w, h, qp, bframes, preset, threads, input_depth, ...); closed_gop and keyint are set here.
     worker_cmd : argv prefix of the worker (default: this interpreter running xeve_amd.shard_worker); it gets one argument, the path of its job file (JSON).
     No exchange between the workers (no RCCL, nothing over xGMI): the only joint operation is the concatenation.
+    The joined file is the reference's ONE run over the sequence when keyint is a multiple of bframes + 1 (or bframes is 0): with a keyint that cuts a sub-GOP short the
+    reference itself codes a GOP's tail differently inside a sequence than as a run of its own (its --seek / --frames runs do not concatenate to its single run either;
+    found with tests/golden/fuzz_enc_host.py-style runs), so such a split is refused unless aligned_only=False -- every part is then still the reference's run over that GOP.
     Returns {"bytes": n, "workers": [(worker, device, seconds)], "seconds": wall, "fps": frames / wall}."""
     import json
     import os
@@ -145,6 +148,9 @@ def run_encoder_shards(yuv, out, config, total_frames, keyint, devices, per_devi
     shards = plan(total_frames, keyint)
     if not shards:
         raise ValueError("nothing to encode")
+    bframes = int(config.get("bframes", 15))
+    if aligned_only and bframes and keyint % (bframes + 1) != 0:
+        raise ValueError("keyint %d is not a multiple of bframes + 1 = %d: the parts would not join to the reference's single run (aligned_only=False to split anyway)" % (keyint, bframes + 1))
     slots = [d for d in devices for _ in range(per_device)]
     if not slots:
         raise ValueError("no device given")
