@@ -37,6 +37,10 @@ def config(w, h, cli, threads=1):
             c.threads = int(cli[i + 1])
         elif a == "-d":
             c.reserved[1] = int(cli[i + 1])
+        elif a == "--qp-cb-offset":
+            c.reserved[2] = int(cli[i + 1])
+        elif a == "--qp-cr-offset":
+            c.reserved[3] = int(cli[i + 1])
         elif a == "--closed-gop":
             c.closed_gop = 1
             i -= 1

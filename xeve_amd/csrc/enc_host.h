@@ -132,7 +132,7 @@ template <class Engine> class BatchEncoder {
         if(pp.frame < 0 || pp.frame >= F) return "the frame loop asked for a frame that was never pushed";
         if(pp.slice_type == ST_I) last_intra = pp.poc; // xeve_pic_prepare (:1217-1218)
         qp_ = slice_qp(P, pp.depth);
-        const PicNumbers num = pic_numbers(qp_);
+        const PicNumbers num = pic_numbers(qp_, P.qp_cb_offset, P.qp_cr_offset);
         if(!d.refp_init(P.max_num_ref_pics(), pp.slice_type, pp.poc, pp.tid, last_intra)) return "no reference picture for an inter picture";
         memset(&S_, 0, sizeof(S_));
         S_.frame = pp.frame, S_.poc = pp.poc, S_.slice_type = pp.slice_type, S_.nchains = std::min(P.threads, (P.h + CTU - 1) / CTU);
@@ -173,7 +173,7 @@ template <class Engine> class BatchEncoder {
                 o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end()), o.insert(o.end(), sei.begin(), sei.end());
             }
             Bits bs;
-            slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp);
+            slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp, P.qp_cb_offset, P.qp_cr_offset);
             std::vector<uint8_t> nal = bs.b;
             nal.insert(nal.end(), slice[g].begin(), slice[g].end());
             // cabac_zero_words when the slice's bins outrun its bytes (:562-583)

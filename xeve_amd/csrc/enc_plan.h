@@ -29,6 +29,7 @@ enum { PAD_L = 144, PAD_C = 72, BIT_DEPTH = 10, LOG2_CTU = 6, CTU = 64, MAX_ACTI
 struct Param {
     int w = 0, h = 0, fps_num = 30, fps_den = 1, qp = 32, keyint = 0, bframes = 15, closed_gop = 0, threads = 1, inter_slice_type = 0, ref = 0;
     int preset = 1; // 0 fast, 1 medium
+    int qp_cb_offset = 0, qp_cr_offset = 0; // --qp-cb-offset / --qp-cr-offset (sh->qp_u_offset / qp_v_offset, xeve_enc.c:1509-1510)
     int input_depth = 8; // the application's -d: 8 = one byte per sample, 10 = 16-bit little-endian samples (both go to the codec's 10 bits, xeve_app.c:1153-1158)
     // derived
     int gop_size = 16, ref_pic_gap_length = 0, me_ref_num = 1, me_range = 64, me_sub = 2, me_sub_pos = 4, me_sub_range = 1, merge_num = 3, me_algo = 1;
@@ -39,6 +40,7 @@ struct Param {
     {
         w = c.w, h = c.h, fps_num = c.fps_num, fps_den = c.fps_den, qp = c.qp, keyint = c.keyint, bframes = c.bframes, closed_gop = c.closed_gop != 0;
         threads = c.threads, inter_slice_type = c.inter_slice_type, ref = c.ref, preset = c.preset, input_depth = c.reserved[1] ? c.reserved[1] : 8;
+        qp_cb_offset = c.reserved[2], qp_cr_offset = c.reserved[3];
         auto bad = [&](const char *m) { error = m; return false; };
         if(w <= 0 || h <= 0 || (w & 7) || (h & 7)) return bad("picture size must be a positive multiple of 8 in both directions");
         if(w > 8192 || h > 4320) return bad("picture larger than 8192x4320");
@@ -46,6 +48,9 @@ struct Param {
         if(!(bframes == 0 || bframes == 1 || bframes == 3 || bframes == 7 || bframes == 15)) return bad("bframes must be 0, 1, 3, 7 or 15");
         if(bframes && !closed_gop && keyint % (bframes + 1) != 0) return bad("an open GOP needs keyint to be a multiple of bframes + 1");
         if(input_depth != 8 && input_depth != 10) return bad("input depth must be 8 or 10 bits");
+        // (the plumbing below follows xeve_enc.c:1509-1512, xeve_mode.c:660-679 and xeve_eco.c:277-278, but nothing can pin it: the reference application lists
+        // --qp-cb-offset / --qp-cr-offset and fails to parse them, like --inter-slice-type)
+        if(qp_cb_offset != 0 || qp_cr_offset != 0) return bad("chroma qp offsets must be 0: the reference application cannot set them (its options fail to parse), so they have no pin");
         // (xeve_ctu_mt_core waits for the CTU up-right only in front of a row's last column, xeve_enc.c:130-133: in a picture ONE CTU wide no row waits for the row
         // above at all, and the reference's own output changes from run to run -- 5 different bitstreams in 12 runs of 64x200 -m 3 -- so there is nothing to reproduce)
         if(threads > 1 && w <= CTU) return bad("a picture one CTU wide must be coded with threads = 1: the reference's row threads race there");
@@ -396,7 +401,7 @@ inline std::string sei_text(const Param &P) // xeve_eco_emitsei's banner + xeve_
     std::string s = " xeve - MPEG-5 EVC codec - ESSENTIAL VIDEO CODING https://github.com/mpeg5/xeve - options: ";
     struct KV { const char *k; int v; };
     s += fmt("profile=%d threads=%d input-res=%dx%d fps=%.3f keyint=%d color-space=%d rc-type=CQP", 0, P.threads, P.w, P.h, (float)P.fps_num / P.fps_den, P.keyint, cs);
-    const KV a[] = {{"qp", P.qp}, {"qp_cb_offset", 0}, {"qp_cr_offset", 0}, {"info", 1}, {"hash", 0}, {"bframes", P.bframes}, {"aq-mode", 0}, {"lookahead", P.lookahead},
+    const KV a[] = {{"qp", P.qp}, {"qp_cb_offset", P.qp_cb_offset}, {"qp_cr_offset", P.qp_cr_offset}, {"info", 1}, {"hash", 0}, {"bframes", P.bframes}, {"aq-mode", 0}, {"lookahead", P.lookahead},
                     {"closed-gop", P.closed_gop}, {"disable-hgop", 0}, {"ref_pic_gap_length", P.ref_pic_gap_length}, {"codec-bit-depth", BIT_DEPTH}, {"level-idc", 40},
                     {"cu-tree", 0}, {"constrained-ip", 0}, {"use-deblock", 1}, {"inter-slice-type", P.inter_slice_type}, {"rdo-deblk-switch", 0},
                     {"qp-increased-frame", 0}, {"forced-idr-frame-flag", 0}, {"qp-increased-frame", 0}};
@@ -430,13 +435,13 @@ inline std::vector<uint8_t> make_sei(const Param &P, int tid) // xeve_encode_sei
     return bs.b;
 }
 // the slice NAL unit's head: NAL header + xeve_eco_sh (Baseline: no POC, no reference picture lists)
-inline void slice_head(Bits &bs, bool idr, int tid, int slice_type, int qp)
+inline void slice_head(Bits &bs, bool idr, int tid, int slice_type, int qp, int qp_u_offset = 0, int qp_v_offset = 0)
 {
     nal_open(bs, idr ? NUT_IDR : NUT_NONIDR, tid);
     bs.ue(0), bs.ue((uint32_t)slice_type);
     if(idr) bs.put(0, 1);                    // no_output_of_prior_pics_flag
     if(slice_type != ST_I) bs.put(0, 1);     // num_ref_idx_active_override_flag
-    bs.put(1, 1), bs.put((uint32_t)qp, 6), bs.se(0), bs.se(0); // deblocking_filter_on, qp, qp_u_offset, qp_v_offset
+    bs.put(1, 1), bs.put((uint32_t)qp, 6), bs.se(qp_u_offset), bs.se(qp_v_offset); // deblocking_filter_on, qp, qp_u_offset, qp_v_offset (xeve_eco.c:275-278)
     bs.align();
 }
 
@@ -466,13 +471,14 @@ struct PicNumbers {
     double lambda[3], sqrt_lambda0, dcw[2];
     uint32_t lambda_mv;
 };
-inline PicNumbers pic_numbers(int qp) // set_lambda with the tile's QP; mode_cu_init's QPs (xeve_mode.c:780-784); xeve_pinter_init_lcu
+inline PicNumbers pic_numbers(int qp, int qp_u_offset = 0, int qp_v_offset = 0) // set_lambda with the tile's QP (xeve_mode.c:660-679); mode_cu_init's QPs (:780-784)
 {
     PicNumbers n;
-    const int  off = 6 * (BIT_DEPTH - 8), qi = std::min(57, std::max(-off, qp)); // (qp_u_offset = qp_v_offset = 0)
-    n.qp = qp, n.qp_y = qp + off, n.qp_u = n.qp_v = chroma_qp(qi) + off;
+    const int  off = 6 * (BIT_DEPTH - 8);
+    const int  qu = chroma_qp(std::min(57, std::max(-off, qp + qp_u_offset))), qv = chroma_qp(std::min(57, std::max(-off, qp + qp_v_offset)));
+    n.qp = qp, n.qp_y = qp + off, n.qp_u = qu + off, n.qp_v = qv + off;
     n.lambda[0] = 0.57 * std::pow(2.0, (qp - 12.0) / 3.0);
-    n.dcw[0] = n.dcw[1] = std::pow(2.0, (qp - chroma_qp(qi)) / 3.0);
+    n.dcw[0] = std::pow(2.0, (qp - qu) / 3.0), n.dcw[1] = std::pow(2.0, (qp - qv) / 3.0);
     n.lambda[1] = n.lambda[0] / n.dcw[0], n.lambda[2] = n.lambda[0] / n.dcw[1];
     n.sqrt_lambda0 = std::sqrt(n.lambda[0]);
     n.lambda_mv    = (uint32_t)std::floor(65536.0 * n.sqrt_lambda0);
@@ -482,6 +488,7 @@ inline void fill_deblock_params(xeve_hip_deblock_params &d, const Param &P)
 {
     memset(&d, 0, sizeof(d));
     d.w = P.w, d.h = P.h, d.w_scu = P.w >> 2, d.h_scu = P.h >> 2, d.log2_max_cuwh = LOG2_CTU, d.bit_depth_luma = d.bit_depth_chroma = BIT_DEPTH, d.chroma_format_idc = 1;
+    d.qp_u_offset = P.qp_cb_offset, d.qp_v_offset = P.qp_cr_offset;
     const int off = 6 * (BIT_DEPTH - 8);
     for(int c = 0; c < 2; c++)
         for(int q = -off; q <= 57; q++) d.qp_chroma[c][q + off] = chroma_qp(q);
