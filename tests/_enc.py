@@ -37,6 +37,8 @@ def config(w, h, cli, threads=1):
             c.threads = int(cli[i + 1])
         elif a == "-d":
             c.reserved[1] = int(cli[i + 1])
+        elif a == "--inter-slice-type":
+            c.inter_slice_type = int(cli[i + 1])
         elif a == "--qp-cb-offset":
             c.reserved[2] = int(cli[i + 1])
         elif a == "--qp-cr-offset":
@@ -132,6 +134,32 @@ DEPTH10_CASES = {
     "gops_128x64_10bit_m2": (128, 64, 2, 8, 27, ["--preset", "medium", "--closed-gop", "-I", "8", "-d", "10"], 2),
     "gops_192x128_10bit_b3": (192, 128, 2, 4, 5028, ["--preset", "fast", "--closed-gop", "-I", "4", "-b", "3", "-d", "10"], 1),
 }
+
+# Options the reference APPLICATION lists and fails to parse (--inter-slice-type, --qp-cb-offset, --qp-cr-offset): the goldens come from the reference library with the
+# parameter set on the way into xeve_create (oracle/ref_param_pin.c, LD_PRELOAD).  Host side only: the product refuses these until the device path has coded them.
+HOST_PINNED_CASES = {
+    "p_slices_ldb_9f": (128, 64, 1, 9, 5031, ["--preset", "fast", "-b", "0", "--inter-slice-type", "1"], 1),
+    "p_slices_ldb_ref3_m2": (136, 72, 1, 8, 6032, ["--preset", "medium", "-b", "0", "--ref", "3", "--inter-slice-type", "1"], 2),
+    "p_slices_hierarchical_closed": (128, 128, 2, 8, 5033, ["--preset", "medium", "--closed-gop", "-I", "8", "-b", "7", "--inter-slice-type", "1"], 2),
+    "chroma_qp_offsets": (136, 72, 2, 4, 29, ["--preset", "medium", "--closed-gop", "-I", "4", "-b", "3", "--qp-cb-offset", "5", "--qp-cr-offset", "-6"], 1),
+    "chroma_qp_offsets_low_qp_p": (128, 64, 1, 6, 5034, ["--preset", "fast", "-b", "0", "-q", "14", "--qp-cb-offset", "-12", "--qp-cr-offset", "12", "--inter-slice-type", "1"], 1),
+}
+_PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
+
+
+def app_args_and_env(cli):
+    """the options the application can parse, and the environment that carries the others into the library (oracle/_ref/libxeve_param_pin.so)"""
+    args, env, i = [], {}, 0
+    while i < len(cli):
+        if cli[i] in _PIN_ENV:
+            env[_PIN_ENV[cli[i]]] = str(cli[i + 1])
+            i += 2
+        else:
+            args.append(cli[i])
+            i += 1
+    if env:
+        env["LD_PRELOAD"] = os.path.join(ORACLE_DIR, "_ref", "libxeve_param_pin.so")
+    return args, env
 
 
 def widen10(data8):

@@ -29,6 +29,10 @@ with tempfile.TemporaryDirectory() as d:
             cli += ["-I", str(k)]
         if rnd.random() < 0.3:
             cli += ["--ref", str(rnd.choice([1, 2, 3]))]
+        if rnd.random() < 0.35:  # (options the application cannot parse: they reach the library through oracle/ref_param_pin.c)
+            cli += ["--inter-slice-type", "1"]
+        if rnd.random() < 0.3:
+            cli += ["--qp-cb-offset", str(rnd.randint(-12, 12)), "--qp-cr-offset", str(rnd.randint(-12, 12))]
         depth10 = rnd.random() < 0.25
         if depth10:
             cli += ["-d", "10"]
@@ -40,7 +44,9 @@ with tempfile.TemporaryDirectory() as d:
         if depth10:
             data = _enc.widen10(data)
             open(yuv, "wb").write(data)
-        p = subprocess.run([REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", str(threads), "-v", "0", "-o", evc] + cli, capture_output=True, text=True)
+        args, pin = _enc.app_args_and_env(cli)
+        p = subprocess.run([REF_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", str(threads), "-v", "0", "-o", evc] + args, capture_output=True,
+                           text=True, env=dict(os.environ, **pin))
         if p.returncode != 0:
             print("ref refuses", w, h, frames, threads, cli)
             continue

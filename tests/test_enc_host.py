@@ -73,6 +73,32 @@ def test_ten_bit_input_is_handed_to_the_codec_as_it_is(name, yuv_dir):
     assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
 
 
+@pytest.mark.parametrize("name", sorted(_enc.HOST_PINNED_CASES))
+def test_p_slices_and_chroma_qp_offsets_on_the_host_side(name, yuv_dir):
+    """options the reference application cannot parse, set on the way into the reference LIBRARY (oracle/ref_param_pin.c): the frame loop, the reference lists of P
+    pictures, the chroma QPs / lambdas / slice header offsets reproduce its bitstreams.  Host side only -- the product build refuses them (next test)"""
+    w, h, gops, frames, seed, cli, threads = _enc.HOST_PINNED_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+    if "whole" in g:
+        whole = b"".join(outs)
+        assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
+
+
+def test_the_product_library_refuses_what_only_the_host_side_has_seen():
+    """xeve_hip_enc_footprint runs the product's own configuration check (no device needed)"""
+    from xeve_amd import encode, lib
+
+    for kw in (dict(inter_slice_type=1), dict(cb=3), dict(cr=-2)):
+        c = encode.config(128, 64, keyint=8, closed_gop=True)
+        c.inter_slice_type = kw.get("inter_slice_type", 0)
+        c.reserved[2], c.reserved[3] = kw.get("cb", 0), kw.get("cr", 0)
+        with pytest.raises(lib.XeveHipError, match="host side only"):
+            encode.footprint(c, 1, 2)
+
+
 WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

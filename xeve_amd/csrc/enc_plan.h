@@ -48,13 +48,16 @@ struct Param {
         if(!(bframes == 0 || bframes == 1 || bframes == 3 || bframes == 7 || bframes == 15)) return bad("bframes must be 0, 1, 3, 7 or 15");
         if(bframes && !closed_gop && keyint % (bframes + 1) != 0) return bad("an open GOP needs keyint to be a multiple of bframes + 1");
         if(input_depth != 8 && input_depth != 10) return bad("input depth must be 8 or 10 bits");
-        // (the plumbing below follows xeve_enc.c:1509-1512, xeve_mode.c:660-679 and xeve_eco.c:277-278, but nothing can pin it: the reference application lists
-        // --qp-cb-offset / --qp-cr-offset and fails to parse them, like --inter-slice-type)
-        if(qp_cb_offset != 0 || qp_cr_offset != 0) return bad("chroma qp offsets must be 0: the reference application cannot set them (its options fail to parse), so they have no pin");
-        // (xeve_ctu_mt_core waits for the CTU up-right only in front of a row's last column, xeve_enc.c:130-133: in a picture ONE CTU wide no row waits for the row
-        // above at all, and the reference's own output changes from run to run -- 5 different bitstreams in 12 runs of 64x200 -m 3 -- so there is nothing to reproduce)
-        if(threads > 1 && w <= CTU) return bad("a picture one CTU wide must be coded with threads = 1: the reference's row threads race there");
-        if(inter_slice_type != 0) return bad("inter_slice_type must be 0 (B): the reference application cannot select P slices (its --inter-slice-type fails to parse), so they have no pin");
+        // P slices (--inter-slice-type 1) and chroma qp offsets (--qp-cb-offset / --qp-cr-offset): options the reference application lists and fails to parse.  The
+        // host logic for both follows the reference's sources and IS held to the reference LIBRARY run with those parameters (oracle/ref_param_pin.c sets them on the
+        // way into xeve_create; tests/test_enc_host.py, on the CPU harness, which defines XENC_HOST_PINNED_OPTIONS) -- the device path has not been run with them yet, so
+        // the product keeps refusing them until a GPU test has
+        if(inter_slice_type != 0 && inter_slice_type != 1) return bad("inter_slice_type must be 0 (B) or 1 (P)");
+        if(qp_cb_offset < -12 || qp_cb_offset > 12 || qp_cr_offset < -12 || qp_cr_offset > 12) return bad("chroma qp offsets must lie in -12 .. 12");
+#ifndef XENC_HOST_PINNED_OPTIONS
+        if(inter_slice_type != 0) return bad("inter_slice_type must be 0 (B): P slices are pinned on the host side only, the device path has not coded them yet");
+        if(qp_cb_offset != 0 || qp_cr_offset != 0) return bad("chroma qp offsets must be 0: pinned on the host side only, the device path has not coded with them yet");
+#endif
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
         else return bad("preset must be 0 (fast) or 1 (medium): slow / placebo need rdo_dbk_switch, which the device path does not have");
