@@ -867,7 +867,7 @@ typedef struct xeve_hip_enc_config {
     int32_t threads;          /* -m: 1 .. 8 */
     int32_t inter_slice_type; /* --inter-slice-type: 0 B, 1 P */
     int32_t ref;              /* --ref (0: the preset's) */
-    int32_t reserved[4];      /* [0] bit 0: always run the second writer pass (tests).  [1]: the application's -d, the input's bit depth -- 0 / 8: one byte per sample;
+    int32_t reserved[4];      /* [0] bit 0: always run the second writer pass (tests); bit 1: the application's --info 0 (no SEI with the option list); bits 8-15: --level-idc (0: 40).  [1]: the application's -d, the input's bit depth -- 0 / 8: one byte per sample;
                                * 10: 16-bit little-endian samples (frames pushed are twice as long).  Either way the codec works at 10 bits (--codec-bit-depth).  [2], [3]: chroma qp offsets; must be 0 (the application cannot set them: unpinned). */
 } xeve_hip_enc_config;
 typedef struct xeve_hip_enc xeve_hip_enc;

@@ -37,6 +37,10 @@ def config(w, h, cli, threads=1):
             c.threads = int(cli[i + 1])
         elif a == "-d":
             c.reserved[1] = int(cli[i + 1])
+        elif a == "--info":
+            c.reserved[0] = (c.reserved[0] & ~2) | (0 if int(cli[i + 1]) else 2)
+        elif a == "--level-idc":
+            c.reserved[0] = (c.reserved[0] & ~0xFF00) | (int(cli[i + 1]) << 8)
         elif a == "--inter-slice-type":
             c.inter_slice_type = int(cli[i + 1])
         elif a == "--qp-cb-offset":
@@ -143,6 +147,11 @@ HOST_PINNED_CASES = {
     "p_slices_hierarchical_closed": (128, 128, 2, 8, 5033, ["--preset", "medium", "--closed-gop", "-I", "8", "-b", "7", "--inter-slice-type", "1"], 2),
     "chroma_qp_offsets": (136, 72, 2, 4, 29, ["--preset", "medium", "--closed-gop", "-I", "4", "-b", "3", "--qp-cb-offset", "5", "--qp-cr-offset", "-6"], 1),
     "chroma_qp_offsets_low_qp_p": (128, 64, 1, 6, 5034, ["--preset", "fast", "-b", "0", "-q", "14", "--qp-cb-offset", "-12", "--qp-cr-offset", "12", "--inter-slice-type", "1"], 1),
+}
+# header-only options (--info 0: no SEI with the option list; --level-idc): nothing on the device changes
+HEADER_OPTION_CASES = {
+    "no_info_sei_level_51": (128, 64, 2, 4, 5035, ["--preset", "medium", "--closed-gop", "-I", "4", "-b", "3", "--info", "0", "--level-idc", "51"], 1),
+    "level_62_m2": (136, 72, 1, 5, 37, ["--preset", "fast", "-b", "0", "--level-idc", "62"], 2),
 }
 _PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
 

@@ -33,6 +33,10 @@ with tempfile.TemporaryDirectory() as d:
             cli += ["--inter-slice-type", "1"]
         if rnd.random() < 0.3:
             cli += ["--qp-cb-offset", str(rnd.randint(-12, 12)), "--qp-cr-offset", str(rnd.randint(-12, 12))]
+        if rnd.random() < 0.2:
+            cli += ["--info", "0"]
+        if rnd.random() < 0.2:
+            cli += ["--level-idc", str(rnd.choice([10, 30, 41, 51, 62]))]
         depth10 = rnd.random() < 0.25
         if depth10:
             cli += ["-d", "10"]

@@ -84,6 +84,20 @@ def test_ten_bit_input_on_the_gpu(name, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("name", sorted(_enc.HEADER_OPTION_CASES))
+def test_header_only_options_on_the_gpu(name, hip, yuv_dir):
+    """--info 0 and --level-idc through the library's configuration record (reserved[0] bit 1 and bits 8-15)"""
+    w, h, gops, frames, seed, cli, threads = _enc.HEADER_OPTION_CASES[name]
+    g = _enc.golden()["batches"][name]
+    c = _enc.config(w, h, cli, threads)
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    cfg = hip.config(w, h, qp=c.qp, keyint=c.keyint, bframes=c.bframes, closed_gop=c.closed_gop, preset=c.preset, threads=c.threads, ref=c.ref,
+                     sei_info=not (c.reserved[0] & 2), level_idc=((c.reserved[0] >> 8) & 0xFF) or 40)
+    assert cfg.reserved[0] == c.reserved[0]
+    outs, _ = _run(hip, cfg, [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_one_chain_through_the_second_writer_pass_on_the_gpu(hip, yuv_dir):
     w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]
     f = _frames(yuv_dir, "tiny_closed_gop", w, h, n, seed)

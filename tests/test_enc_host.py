@@ -87,6 +87,16 @@ def test_p_slices_and_chroma_qp_offsets_on_the_host_side(name, yuv_dir):
         assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
 
 
+@pytest.mark.parametrize("name", sorted(_enc.HEADER_OPTION_CASES))
+def test_header_only_options(name, yuv_dir):
+    """--info 0 (no SEI with the option list) and --level-idc: parameter sets and SEI only"""
+    w, h, gops, frames, seed, cli, threads = _enc.HEADER_OPTION_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_the_product_library_refuses_what_only_the_host_side_has_seen():
     """xeve_hip_enc_footprint runs the product's own configuration check (no device needed)"""
     from xeve_amd import encode, lib

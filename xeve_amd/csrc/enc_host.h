@@ -170,7 +170,8 @@ template <class Engine> class BatchEncoder {
             std::vector<uint8_t> &o = (*out)[g];
             if(pp.idr) {
                 const std::vector<uint8_t> sps = make_sps(P), pps = make_pps(pp.tid), sei = make_sei(P, pp.tid);
-                o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end()), o.insert(o.end(), sei.begin(), sei.end());
+                o.insert(o.end(), sps.begin(), sps.end()), o.insert(o.end(), pps.begin(), pps.end());
+                if(P.sei_info) o.insert(o.end(), sei.begin(), sei.end()); // (--info 0: no SEI with the options, xeve_enc.c:1989)
             }
             Bits bs;
             slice_head(bs, pp.idr != 0, pp.tid, pp.slice_type, qp, P.qp_cb_offset, P.qp_cr_offset);

@@ -30,6 +30,7 @@ struct Param {
     int w = 0, h = 0, fps_num = 30, fps_den = 1, qp = 32, keyint = 0, bframes = 15, closed_gop = 0, threads = 1, inter_slice_type = 0, ref = 0;
     int preset = 1; // 0 fast, 1 medium
     int qp_cb_offset = 0, qp_cr_offset = 0; // --qp-cb-offset / --qp-cr-offset (sh->qp_u_offset / qp_v_offset, xeve_enc.c:1509-1510)
+    int level_idc = 40, sei_info = 1; // --level-idc (sps->level_idc = 3 x, xeve_enc.c:1402) and --info (the SEI that lists the options, :1989)
     int input_depth = 8; // the application's -d: 8 = one byte per sample, 10 = 16-bit little-endian samples (both go to the codec's 10 bits, xeve_app.c:1153-1158)
     // derived
     int gop_size = 16, ref_pic_gap_length = 0, me_ref_num = 1, me_range = 64, me_sub = 2, me_sub_pos = 4, me_sub_range = 1, merge_num = 3, me_algo = 1;
@@ -41,6 +42,7 @@ struct Param {
         w = c.w, h = c.h, fps_num = c.fps_num, fps_den = c.fps_den, qp = c.qp, keyint = c.keyint, bframes = c.bframes, closed_gop = c.closed_gop != 0;
         threads = c.threads, inter_slice_type = c.inter_slice_type, ref = c.ref, preset = c.preset, input_depth = c.reserved[1] ? c.reserved[1] : 8;
         qp_cb_offset = c.reserved[2], qp_cr_offset = c.reserved[3];
+        level_idc = ((c.reserved[0] >> 8) & 0xFF) ? ((c.reserved[0] >> 8) & 0xFF) : 40, sei_info = (c.reserved[0] & 2) ? 0 : 1;
         auto bad = [&](const char *m) { error = m; return false; };
         if(w <= 0 || h <= 0 || (w & 7) || (h & 7)) return bad("picture size must be a positive multiple of 8 in both directions");
         if(w > 8192 || h > 4320) return bad("picture larger than 8192x4320");
@@ -367,7 +369,7 @@ inline std::vector<uint8_t> make_sps(const Param &P) // xeve_set_sps + xeve_eco_
 {
     Bits bs;
     nal_open(bs, NUT_SPS, 0);
-    bs.ue(0), bs.put(0, 8) /* profile_idc: baseline */, bs.put(40 * 3, 8) /* level_idc */, bs.put(0, 32), bs.put(0, 32) /* toolset_idc_h / _l */;
+    bs.ue(0), bs.put(0, 8) /* profile_idc: baseline */, bs.put((uint32_t)(P.level_idc * 3) & 0xFF, 8) /* level_idc */, bs.put(0, 32), bs.put(0, 32) /* toolset_idc_h / _l */;
     bs.ue(1) /* 4:2:0 */, bs.ue((uint32_t)P.w), bs.ue((uint32_t)P.h), bs.ue(BIT_DEPTH - 8), bs.ue(BIT_DEPTH - 8);
     bs.put(0, 13); // btt, suco, admvp, eipd, cm_init, iqt, addb, alf, htdf, rpl, pocs, dquant, dra
     const int log2_sub_gop = (int)(std::log2((double)P.gop_size) + .5);
@@ -404,8 +406,8 @@ inline std::string sei_text(const Param &P) // xeve_eco_emitsei's banner + xeve_
     std::string s = " xeve - MPEG-5 EVC codec - ESSENTIAL VIDEO CODING https://github.com/mpeg5/xeve - options: ";
     struct KV { const char *k; int v; };
     s += fmt("profile=%d threads=%d input-res=%dx%d fps=%.3f keyint=%d color-space=%d rc-type=CQP", 0, P.threads, P.w, P.h, (float)P.fps_num / P.fps_den, P.keyint, cs);
-    const KV a[] = {{"qp", P.qp}, {"qp_cb_offset", P.qp_cb_offset}, {"qp_cr_offset", P.qp_cr_offset}, {"info", 1}, {"hash", 0}, {"bframes", P.bframes}, {"aq-mode", 0}, {"lookahead", P.lookahead},
-                    {"closed-gop", P.closed_gop}, {"disable-hgop", 0}, {"ref_pic_gap_length", P.ref_pic_gap_length}, {"codec-bit-depth", BIT_DEPTH}, {"level-idc", 40},
+    const KV a[] = {{"qp", P.qp}, {"qp_cb_offset", P.qp_cb_offset}, {"qp_cr_offset", P.qp_cr_offset}, {"info", P.sei_info}, {"hash", 0}, {"bframes", P.bframes}, {"aq-mode", 0}, {"lookahead", P.lookahead},
+                    {"closed-gop", P.closed_gop}, {"disable-hgop", 0}, {"ref_pic_gap_length", P.ref_pic_gap_length}, {"codec-bit-depth", BIT_DEPTH}, {"level-idc", P.level_idc},
                     {"cu-tree", 0}, {"constrained-ip", 0}, {"use-deblock", 1}, {"inter-slice-type", P.inter_slice_type}, {"rdo-deblk-switch", 0},
                     {"qp-increased-frame", 0}, {"forced-idr-frame-flag", 0}, {"qp-increased-frame", 0}};
     for(const KV &e : a) s += fmt(" %s=%d", e.k, e.v);
