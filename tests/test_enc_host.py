@@ -173,7 +173,7 @@ def test_one_chain_through_the_second_writer_pass_gives_the_same_bytes(yuv_dir):
 
 
 def test_configurations_outside_the_supported_set_are_refused():
-    for bad in (dict(w=130), dict(preset=2), dict(bframes=2), dict(threads=9), dict(inter_slice_type=1)):
+    for bad in (dict(w=130), dict(preset=2), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
         c = _enc.config(128, 64, ["--preset", "fast"])
         for k, v in bad.items():
             setattr(c, k, v)

@@ -20,7 +20,7 @@
 #pragma once
 #include "enc_plan.h"
 
-namespace xenc {
+namespace xenc __attribute__((visibility("hidden"))) { // (hidden: the test harness instantiates the same inline code in its own library, and the two must not bind to each other)
 
 struct PicSetup {
     int frame, poc, slice_type, cur_slot, nchains;

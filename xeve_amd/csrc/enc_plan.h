@@ -19,7 +19,7 @@
 #include <vector>
 #include "../../include/xeve_hip.h"
 
-namespace xenc {
+namespace xenc __attribute__((visibility("hidden"))) { // (hidden: the test harness instantiates the same inline code in its own library, and the two must not bind to each other)
 
 enum { ST_B = 0, ST_P = 1, ST_I = 2 };                                     // XEVE_ST_* (inc/xeve.h:168-172)
 enum { NUT_NONIDR = 0, NUT_IDR = 1, NUT_SPS = 24, NUT_PPS = 25, NUT_SEI = 28 }; // inc/xeve.h:158-164
@@ -50,6 +50,9 @@ struct Param {
         if(!(bframes == 0 || bframes == 1 || bframes == 3 || bframes == 7 || bframes == 15)) return bad("bframes must be 0, 1, 3, 7 or 15");
         if(bframes && !closed_gop && keyint % (bframes + 1) != 0) return bad("an open GOP needs keyint to be a multiple of bframes + 1");
         if(input_depth != 8 && input_depth != 10) return bad("input depth must be 8 or 10 bits");
+        // (xeve_ctu_mt_core waits for the CTU up-right only in front of a row's last column, xeve_enc.c:130-133: in a picture ONE CTU wide no row waits for the row
+        // above at all, and the reference's own output changes from run to run -- 5 different bitstreams in 12 runs of 64x200 -m 3 -- so there is nothing to reproduce)
+        if(threads > 1 && w <= CTU) return bad("a picture one CTU wide must be coded with threads = 1: the reference's row threads race there");
         // P slices (--inter-slice-type 1) and chroma qp offsets (--qp-cb-offset / --qp-cr-offset): options the reference application lists and fails to parse.  The
         // host logic for both follows the reference's sources and IS held to the reference LIBRARY run with those parameters (oracle/ref_param_pin.c sets them on the
         // way into xeve_create; tests/test_enc_host.py, on the CPU harness, which defines XENC_HOST_PINNED_OPTIONS) -- the device path has not been run with them yet, so
