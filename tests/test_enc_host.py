@@ -184,6 +184,10 @@ def test_configurations_outside_the_supported_set_are_refused():
     c = _enc.config(64, 136, ["--preset", "fast"], threads=2)
     with pytest.raises(RuntimeError, match="one CTU wide"):
         _enc.encode_cpu(c, [bytes(64 * 136 * 3 // 2)], 1)
+    # low-delay closed GOPs with an odd keyint over more than one GOP: the reference fetches stale input slots (xeve_enc.c:661 vs :1080) -- one GOP of it is fine
+    e = _enc.config(128, 64, ["--preset", "fast", "-b", "0", "--closed-gop", "-I", "5"])
+    with pytest.raises(RuntimeError, match="even keyint"):
+        _enc.encode_cpu(e, [bytes(128 * 64 * 3 // 2 * 6)], 6)
     d = _enc.config(128, 64, ["--preset", "fast", "-d", "10"])
     d.reserved[1] = 12
     with pytest.raises(RuntimeError, match="input depth"):

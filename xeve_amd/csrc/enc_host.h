@@ -59,6 +59,10 @@ template <class Engine> class BatchEncoder {
     {
         out = &out_;
         out->assign(G, std::vector<uint8_t>());
+        // low-delay closed GOPs with an odd keyint over more than one GOP: the reference keeps two input slots there (xeve_enc.c:1693-1695), files a frame under its count
+        // in the SEQUENCE (:661) and fetches it under its count in the GOP (:1080) -- with an odd keyint the two part ways after the first GOP and it codes stale slots
+        if(P.bframes == 0 && P.closed_gop && P.keyint > 1 && (P.keyint & 1) && F > P.keyint)
+            return fail("low-delay closed GOPs need an even keyint when a run holds more than one GOP: the reference codes stale input slots otherwise");
         pics = plan();
         if((int)pics.size() != F) // (e.g. low-delay closed GOPs with an odd keyint and more frames than one GOP: the reference picks its input slot from the picture's
                                   // count inside the GOP while the frames sit at their count in the sequence, xeve_enc.c:1080 vs :661 -- its own output there codes
