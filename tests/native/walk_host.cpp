@@ -1,0 +1,37 @@
+// tests/native/walk_host.cpp -- TEST INFRASTRUCTURE: the HOST side of xeve_amd/csrc/walk.h (the fused CTU walk libxeve_hip.so runs as one kernel, every function
+// __host__ __device__) as a team of ONE thread, so that `pytest -m "not gpu"` holds it bit for bit against the pinned oracle without a GPU.  Built with
+// hipcc -x hip --cuda-host-only by tests/_walk.py; nothing of this is linked into the product library.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <vector>
+#include "../../xeve_amd/csrc/walk_setup.h"
+
+extern "C" {
+size_t xw_host_sizeof_cw(void) { return sizeof(xw::Cw); }
+size_t xw_host_sizeof_lds(void) { return sizeof(xw::Lds); }
+size_t xw_host_sizeof_p(void) { return sizeof(xw::P); }
+// all pointers are host memory; I (may be NULL) carries a host refp table and the filter tables; C = chains per team; full = complete coder states
+int xw_host_walk(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
+                 const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems, const xeve_hip_sbac *states, const xeve_hip_tree_params *p,
+                 const xeve_hip_tree_inter *I, const xeve_hip_ctu_job *jobs, int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, int C, int full, int vh)
+{
+    static xw::Tables T;
+    if(T.dct.empty()) xw::make_tables(T);
+    if(p->ip.slice_type == 2) I = nullptr;
+    xw::P q;
+    xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
+    const std::vector<xw::Op> ops = xw::make_ops(p, I != nullptr);
+    std::vector<xw::Cw> cw((size_t)nchains);
+    q.C = C < 1 ? 1 : C > XW_MAXC ? XW_MAXC : C, q.full = full;
+    q.entropy = T.entropy.data(), q.dct = T.dct.data(), q.scan = T.scan.data(), q.ops = ops.data(), q.nops = (int)ops.size(), q.cw = cw.data();
+    if(I) q.mc_l = &I->coef_l[0][0], q.mc_c = I->coef_c ? &I->coef_c[0][0] : nullptr;
+    xw::Lds *S = (xw::Lds *)calloc(1, sizeof(xw::Lds));
+    const xw::Tm tm = {0, 1};
+    for(int team = 0; team * q.C < nchains; team++) {
+        if(full) xw::walk_team<true>(tm, q, *S, team);
+        else xw::walk_team<false>(tm, q, *S, team);
+    }
+    free(S);
+    return 0;
+}
+}

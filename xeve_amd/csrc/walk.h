@@ -1,0 +1,790 @@
+// xeve_amd/csrc/walk.h -- the CTU mode decision (mode_analyze_lcu -> mode_coding_tree -> mode_coding_unit, src_base/xeve_mode.c:1310-1350, 2007-2610) of a GROUP of
+// chains executed by ONE TEAM of threads from the first tree node to the last, without leaving the kernel.
+//
+// Why this form.  The composed walk (tree.hip) is 10 000 .. 15 600 dependent launches per CTU step, every one a load -> compute -> store of a few waves, all chains of
+// the batch in lockstep: its wall time is the host's issue time.  What is serial inside a chain cannot be made parallel (a CU's predictors are its neighbours'
+// reconstruction, its bit counts start from the coder state its predecessor's winner left, an arithmetic coder is a recurrence per bin), so the form that removes the
+// launches without giving up the only parallel axis the coder has -- independent bit-count jobs -- is:
+//   * a team = one workgroup, 256 threads; it owns C chains (C <= 16) and walks them in TEAM-LOCAL lockstep through the static quad-tree schedule; where a launch
+//     boundary was there is a workgroup barrier, what passed through HBM between two launches passes through the team's slice of the workspace (L2) or LDS;
+//   * every stage spreads the union of its chains' work over all lanes: samples / transform outputs / search candidates one item per lane, the serial automata
+//     (RDOQ, the CABAC counter) one JOB per lane with the jobs of the C chains side by side, so that a wave of the counter carries C x (candidates) busy lanes
+//     instead of the 3 .. 5 a single chain has;
+//   * teams are independent of each other: no grid-wide lockstep, a team that is done with its CTUs ends.
+// Everything is __host__ __device__ and written against Tm {thread, team size} + sync(): libxeve_hip.so instantiates the device side (walk.hip: k_walk), the test
+// harness (tests/native/walk_host.cpp) builds the SAME functions for the host as a team of one thread, where every stage degenerates to a plain loop -- that is how the
+// CPU suite holds this file bit for bit against the pinned oracle without a GPU.
+//
+// Costs are doubles built with the reference's operations in the reference's order (-ffp-contract=off).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "../../include/xeve_hip.h"
+
+#ifndef XW
+#define XW __host__ __device__ static inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XW_DEVICE 1
+#else
+#define XW_DEVICE 0
+#endif
+
+namespace xw {
+typedef int16_t            pel;
+typedef xeve_hip_sbac      Sbac;
+typedef xeve_hip_ctu_data  CtuData;
+typedef unsigned long long u64;
+
+#define XW_MAXC 16  // chains per team
+#define XW_NT 256   // threads per team on the device
+#define XW_CODL 128 // lanes of a team that can run the coder at once (their models live in LDS)
+#define XW_MAXR XEVE_HIP_MAX_REFP
+#define XW_MAX_COST 1.7e+308
+#define XW_NB 136   // one neighbour line: [0] = the corner sample, then up to 2 * 64 samples (+ slack)
+#define XW_NCTX XEVE_HIP_SBAC_NCTX
+
+struct Tm {
+    int tid, n;
+};
+XW void sync(const Tm &)
+{
+#if XW_DEVICE
+    __syncthreads();
+#endif
+}
+XW void aadd(int *p, int v)
+{
+#if XW_DEVICE
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
+XW void aadd64(u64 *p, u64 v)
+{
+#if XW_DEVICE
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
+XW void aor(int *p, int v)
+{
+#if XW_DEVICE
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+// stage classes of the in-kernel profiler (XEVE_HIP_WALK_PROF=1: thread 0 of team 0 adds the cycles between two marks to its class)
+enum { PR_CLEAR = 0, PR_ENTER, PR_LEAF, PR_CHILD, PR_EXIT, PR_ROOT, PR_MID, PR_I_SETUP, PR_I_NBR, PR_I_PRED, PR_I_SATD, PR_I_LIST, PR_I_BITS, PR_I_PICK, PR_I_CPRED, PR_I_FINAL,
+       PR_B_DIFF, PR_B_T0, PR_B_T1, PR_B_RDOQ, PR_B_DQ, PR_B_T2, PR_B_T3, PR_B_REC, PR_E_CAND, PR_E_SKIP, PR_E_ME, PR_E_SPEL, PR_E_MC, PR_E_BITS, PR_E_GLUE, PR_E_FINAL, PR_N };
+XW int iabs(int v) { return v < 0 ? -v : v; }
+XW int imin(int a, int b) { return a < b ? a : b; }
+XW int imax(int a, int b) { return a > b ? a : b; }
+XW int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+XW int ilog2(unsigned v) { int l = 0; while((1u << (l + 1)) <= v) l++; return l; }
+
+// ---- records ---------------------------------------------------------------------------------------------------------------------------------------------------
+struct Node { // one per (level, chain)
+    int    active, x0, y0, leaf, do_split, best_split, dist_cu, cu_mode, try_intra, pad_;
+    double cost_best, cost_temp, unit_cost;
+};
+// scratch of one transform block: everything the residual chain of a candidate leaves behind
+struct Slot {
+    int16_t  coef[4096]; // residual -> DCT coefficients -> (after RDOQ) dequantised levels -> inverse transform output
+    int32_t  tb[4096];   // between the two passes of a transform
+    int16_t  lev[4096];  // quantised levels (what is coded)
+    pel      rec[4096];  // reconstruction
+    uint32_t ev[4096];   // the levels as (zero run, |level| - 1, sign, at-the-end) events in scan order
+};
+struct IntraRes {
+    double  cost;
+    int32_t dist_cu, nnz[3], pred_cnt, ipm, slot, on;
+};
+struct InterRes {
+    double  cost, cost_inter[5];
+    int32_t cu_mode, best_idx, nnz[3], slot; // slot: first of the winner's three Slots (Y, U, V); -1: skipped (no coefficients)
+    int16_t mv[2][2], mvd[2][2];
+    int8_t  refi[2];
+    uint8_t mvp_idx[2];
+    uint32_t satd;                           // core->inter_satd
+};
+#define XW_NSLOT 12
+struct Cw { // the workspace of one chain
+    Node     node[5];
+    Sbac     curr[5], next[5], before[5], tdepth[5], sbest, enext;
+    IntraRes ires;
+    InterRes eres;
+    pel      nb[3][2][XW_NB];
+    pel      ipred[5][4096];     // the five luma predictors of the intra analysis
+    pel      cpred[2][4096];     // chroma predictors of its winner
+    pel      epred[4][3][4096];  // inter: prediction of the candidates DIR / L0 / L1 / BI
+    pel      spred[2][3][4096];  // inter: skip prediction (best so far, candidate under test)
+    pel      wpred[3][4096];     // inter: the winner's prediction
+    pel      wrec[3][4096];      // inter: the winner's reconstruction
+    int16_t  org_bi[4096];
+    Slot     slot[XW_NSLOT];
+    CtuData  best[5], temp[5];
+};
+
+enum { OP_ENTER = 0, OP_LEAF = 1, OP_CHILD_DONE = 2, OP_EXIT = 3, OP_ROOT_DONE = 4, OP_MID = 5, OP_INTRA = 6, OP_INTER = 7 };
+struct Op {
+    unsigned char op, lvl;
+    signed char   part, pad_;
+};
+struct RefPic {
+    const pel *y, *u, *v;
+    int32_t    poc, pad_;
+};
+
+struct P { // one call
+    int    nchains, C, full;
+    int    log2_ctu, pic_w, pic_h, w_scu, h_scu, max_cu, min_cu, min_cuwh, idc, ws, hs, bd, slice_type, slice_qp, slice_num, cip;
+    int    s_org_l, s_org_c, s_mod_l, s_mod_c;
+    long   org_pic_l, org_pic_c, mod_pic_l, mod_pic_c, map_pic;
+    int    qp[3], q_scale[3], dq_scale[3];
+    int64_t err_scale[3][7]; // [component][log2 of the block size]
+    double lambda[3], sqrt_lambda0, wgt[2];
+    const pel *org[3];
+    pel       *mod[3];
+    uint32_t  *map_scu, *map_cu_mode;
+    int8_t    *map_ipm;
+    const uint8_t *map_tidx;
+    const Sbac *states;
+    const xeve_hip_ctu_job *jobs;
+    CtuData *out;
+    Sbac    *out_next;
+    double  *out_cost;
+    const int32_t  *entropy; // entropy_bits[1024] of xeve_init_bits_est
+    const int8_t   *dct;     // the six DCT-II matrices [k][x], then the six transposed ones [x][k]
+    const uint16_t *scan;    // zig-zag scans of the square blocks 2 .. 64
+    const Op       *ops;
+    int             nops;
+    Cw             *cw;
+    // P / B slices
+    int    inter, isb, ecu_depth, vh, nref[2], max_cand, poc, col_list_poc0, s_ref_l, s_ref_c;
+    int    refi_bits[2][XW_MAXR], range_recentre[2][XW_MAXR];
+    xeve_hip_epzs_params me;
+    double skip_th;
+    RefPic refp[2 * XW_MAXR]; // [refi * 2 + list]
+    int16_t (*map_mv)[2][2];
+    int8_t  (*map_refi)[2];
+    const int16_t (*col0)[2][2], (*col1)[2][2];
+    const int16_t *mc_l, *mc_c; // [16][8], [32][4]
+    u64 *prof;                  // [PR_N] cycles + [PR_N] marks, or null
+};
+XW int dct_off(int log2n) { return ((1 << (2 * log2n)) - 4) / 3; }       // 0, 4, 20, 84, 340, 1364 (log2n 1 .. 6)
+#define XW_DCT_ELEMS (4 + 16 + 64 + 256 + 1024 + 4096)
+XW const int8_t *dct_m(const P &p, int log2n) { return p.dct + dct_off(log2n); }                  // [k][x]
+XW const int8_t *dct_t(const P &p, int log2n) { return p.dct + XW_DCT_ELEMS + dct_off(log2n); }   // [x][k]
+XW const uint16_t *scan_of(const P &p, int log2n) { return p.scan + dct_off(log2n); }
+
+struct Blk { // one transform block of a stage
+    const pel *org, *pred;
+    Slot      *s;
+    int        s_org, comp, on, nnz, nev, k, is_intra, pad_;
+    u64        ssd[2]; // SSD(prediction, original), SSD(reconstruction, original)
+};
+
+struct Lds { // the team's shared memory
+    uint16_t ctx[XW_NCTX * XW_CODL]; // [model][coder lane]
+    Blk      blk[XW_MAXC * XW_NSLOT];
+    int      sh[XW_MAXC][24];        // per-chain scalars of the running stage
+    int      acc[XW_MAXC * 40];      // integer sums of a stage (SATD per mode, SAD per candidate)
+    int32_t  est[XW_MAXC][28];       // the rate tables RDOQ reads, of each chain's entry state
+    int      flag[4];
+    long long t0;
+};
+// a mark: everything since the previous mark belongs to class `cls` (call right after a sync)
+XW void mark(const Tm &tm, const P &p, Lds &S, int cls)
+{
+#if XW_DEVICE
+    if(p.prof && tm.tid == 0) {
+        const long long t = clock64();
+        if(blockIdx.x == 0) p.prof[cls] += (u64)(t - S.t0), p.prof[PR_N + cls] += 1;
+        S.t0 = t;
+    }
+#else
+    (void)tm, (void)p, (void)S, (void)cls;
+#endif
+}
+
+// ---- tables ------------------------------------------------------------------------------------------------------------------------------------------------------
+// xeve_tbl_mpm (xeve_tbl.c:40-48): [left mode + 1 | 0][up mode + 1 | 0] -> rank of every mode
+XW int mpm_rank(int row, int m)
+{
+    constexpr uint8_t t[36][5] = {{0, 2, 3, 1, 4}, {0, 2, 1, 3, 4}, {0, 2, 1, 3, 4}, {1, 2, 0, 3, 4}, {0, 2, 1, 3, 4}, {0, 1, 2, 3, 4}, {1, 0, 2, 3, 4}, {0, 1, 2, 3, 4}, {0, 1, 2, 3, 4},
+                                  {1, 2, 0, 3, 4}, {0, 1, 3, 2, 4}, {0, 2, 1, 4, 3}, {1, 0, 2, 3, 4}, {1, 0, 2, 3, 4}, {1, 0, 2, 3, 4}, {2, 0, 1, 3, 4}, {1, 0, 3, 2, 4}, {0, 1, 2, 4, 3},
+                                  {1, 0, 2, 3, 4}, {0, 2, 1, 3, 4}, {1, 0, 2, 3, 4}, {1, 2, 0, 3, 4}, {0, 1, 2, 3, 4}, {0, 2, 1, 4, 3}, {0, 1, 2, 3, 4}, {0, 3, 2, 1, 4}, {1, 0, 2, 3, 4},
+                                  {1, 2, 0, 3, 4}, {1, 2, 3, 0, 4}, {0, 2, 1, 4, 3}, {0, 1, 2, 3, 4}, {0, 1, 2, 4, 3}, {0, 1, 2, 4, 3}, {0, 2, 1, 4, 3}, {0, 1, 2, 3, 4}, {0, 1, 2, 4, 3}};
+    return t[row][m];
+}
+
+// ---- the arithmetic coder in bit-count mode (xeve_eco.c:392-575, xeve_mode.c:39-55) --------------------------------------------------------------------------------
+// FULL: every field of XEVE_SBAC kept exactly (the C-ABI's callers compare exit states field for field).  !FULL: what a later COUNT depends on -- the range and the
+// context models -- plus the number of renormalisation shifts, which IS xeve_get_bit_number's result: every shift decrements code_bits, every 8th moves a byte out of
+// the code register, and bitcounter + 8 * (stacked + pending bytes) + 8 - code_bits + 3 counts exactly the shifts since xeve_sbac_bit_reset set code_bits to 11.
+struct Cod {
+    uint32_t  range, code, code_bits, stacked_ff, stacked_zero, pending_byte, is_pending_byte, bitcounter, bin_counter, shifts;
+    uint16_t *m; // the lane's models: model i at m[i * ms]
+    int       ms;
+};
+#define XW_M(c, i) (c).m[(i) * (c).ms]
+XW void cod_load(Cod &c, const Sbac &s, uint16_t *m, int ms)
+{
+    c.range = s.range, c.code = s.code, c.code_bits = s.code_bits, c.stacked_ff = s.stacked_ff, c.stacked_zero = s.stacked_zero, c.pending_byte = s.pending_byte;
+    c.is_pending_byte = s.is_pending_byte, c.bitcounter = s.bitcounter, c.bin_counter = s.bin_counter, c.shifts = 0, c.m = m, c.ms = ms;
+    for(int i = 0; i < XW_NCTX; i++) m[i * ms] = s.ctx[i];
+}
+XW void cod_reset(Cod &c)
+{ // xeve_sbac_bit_reset
+    c.code &= 0x7FFFF, c.code_bits = 11;
+    c.pending_byte = c.is_pending_byte = c.stacked_ff = c.stacked_zero = c.bitcounter = c.bin_counter = 0, c.shifts = 0;
+}
+template <bool FULL> XW void cod_store(const Cod &c, Sbac &s)
+{
+    if(FULL) {
+        s.range = c.range, s.code = c.code, s.code_bits = c.code_bits, s.stacked_ff = c.stacked_ff, s.stacked_zero = c.stacked_zero, s.pending_byte = c.pending_byte;
+        s.is_pending_byte = c.is_pending_byte, s.bitcounter = c.bitcounter, s.bin_counter = c.bin_counter;
+    }
+    else {
+        s.range = c.range, s.code = 0, s.code_bits = 11, s.stacked_ff = s.stacked_zero = s.pending_byte = s.is_pending_byte = s.bitcounter = s.bin_counter = 0;
+    }
+    for(int i = 0; i < XW_NCTX; i++) s.ctx[i] = c.m[i * c.ms];
+}
+template <bool FULL> XW unsigned cod_bits(const Cod &c)
+{
+    if(FULL) return c.bitcounter + 8 * (c.stacked_zero + c.stacked_ff) + 8 * (c.is_pending_byte ? 1 : 0) + 8 - c.code_bits + 3;
+    return c.shifts;
+}
+XW void cod_byte(Cod &s, unsigned b)
+{
+    if(s.is_pending_byte) {
+        if(s.pending_byte == 0) s.stacked_zero++;
+        else s.bitcounter += 8 * s.stacked_zero + 8, s.stacked_zero = 0;
+    }
+    s.pending_byte = b & 0xFF, s.is_pending_byte = 1;
+}
+XW void cod_shift1(Cod &s)
+{
+    s.code <<= 1;
+    if(--s.code_bits) return;
+    const unsigned out = s.code >> 17;
+    s.code &= (1u << 17) - 1;
+    if(out < 0xFF) {
+        for(; s.stacked_ff; s.stacked_ff--) cod_byte(s, 0xFF);
+        cod_byte(s, out);
+    }
+    else if(out > 0xFF) {
+        s.pending_byte++;
+        for(; s.stacked_ff; s.stacked_ff--) cod_byte(s, 0);
+        cod_byte(s, out);
+    }
+    else s.stacked_ff++;
+    s.code_bits = 8;
+}
+template <bool FULL> XW void cod_shift(Cod &s, int n)
+{ // n renormalisation shifts (a context-coded bin renormalises by 0 .. 5 bits, so at most one byte leaves)
+    if(!FULL) {
+        s.shifts += n;
+        return;
+    }
+    while(n >= (int)s.code_bits) {
+        n -= (int)s.code_bits;
+        s.code <<= s.code_bits - 1, s.code_bits = 1;
+        cod_shift1(s);
+    }
+    s.code <<= n, s.code_bits -= n;
+}
+// one context-coded bin on a model the caller holds in a register (xeve_sbac_encode_bin, xeve_eco.c:521-575)
+template <bool FULL> XW void cod_bin_m(Cod &s, unsigned &model, unsigned bin)
+{
+    unsigned state = (model >> 1) & 511u, mps = model & 1;
+    unsigned lps = (state * (s.range & 0xFFFFu)) >> 9;
+    if(lps < 437) lps = 437;
+    if(FULL) s.bin_counter++;
+    s.range -= lps;
+    if((bin != 0) != (mps != 0)) {
+        if(s.range >= lps) {
+            if(FULL) s.code += s.range;
+            s.range = lps;
+        }
+        state = state + ((512 - state + 16) >> 5);
+        if(state > 256) mps = 1 - mps, state = 512 - state;
+    }
+    else state = state - ((state + 16) >> 5);
+    model = (state << 1) + mps;
+    if(s.range < 8192) {
+        const int n = __builtin_clz(s.range) - 18;
+        s.range <<= n;
+        cod_shift<FULL>(s, n);
+    }
+}
+template <bool FULL> XW void cod_bin(Cod &s, int ci, unsigned bin)
+{
+    unsigned model = XW_M(s, ci);
+    cod_bin_m<FULL>(s, model, bin);
+    XW_M(s, ci) = (uint16_t)model;
+}
+template <bool FULL> XW void cod_ep(Cod &s, unsigned bin)
+{ // sbac_encode_bin_ep (xeve_eco.c:455-472): the range loses its LSB
+    if(FULL) {
+        s.bin_counter++;
+        s.range >>= 1;
+        if(bin) s.code += s.range;
+        s.range <<= 1;
+        cod_shift1(s);
+    }
+    else s.range &= ~1u, s.shifts++;
+}
+template <bool FULL> XW void cod_unary_m(Cod &s, unsigned &m0, unsigned &m1, unsigned sym)
+{ // sbac_write_unary_sym with two models (xeve_eco.c:474-490)
+    cod_bin_m<FULL>(s, m0, sym ? 1 : 0);
+    while(sym) {
+        sym--;
+        cod_bin_m<FULL>(s, m1, sym ? 1 : 0);
+    }
+}
+template <bool FULL> XW void cod_unary2(Cod &s, unsigned sym, int ci)
+{
+    unsigned m0 = XW_M(s, ci), m1 = XW_M(s, ci + 1);
+    cod_unary_m<FULL>(s, m0, m1, sym);
+    XW_M(s, ci) = (uint16_t)m0, XW_M(s, ci + 1) = (uint16_t)m1;
+}
+// xeve_eco_run_length_cc (xeve_eco.c:707-771), Baseline contexts (sps_cm_init_flag 0), from the block's event list
+XW uint32_t ev_pack(int v, int run, int at_end)
+{
+    const unsigned a = (unsigned)(v < 0 ? -v : v) & 0xFFFFu;
+    return ((a - 1) & 0x7FFFu) | ((unsigned)(v < 0) << 15) | ((unsigned)run << 16) | ((unsigned)at_end << 28);
+}
+// count-only form of one context-coded bin: branch-free, the model as (state, mps) in registers.  11 dependent operations from range to range.
+struct Mdl {
+    unsigned s, m;
+};
+XW Mdl mdl_of(unsigned v) { Mdl a; a.s = (v >> 1) & 511u, a.m = v & 1u; return a; }
+XW unsigned mdl_pack(const Mdl &a) { return (a.s << 1) + a.m; }
+XW void cnt_bin(unsigned &range, unsigned &shifts, Mdl &a, unsigned bin)
+{
+    unsigned lps = (a.s * (range & 0xFFFFu)) >> 9;
+    lps = lps < 437u ? 437u : lps;
+    const unsigned r2 = range - lps, is_lps = (bin ^ a.m) & 1u, msk = 0u - is_lps;
+    const unsigned sl = a.s + ((528u - a.s) >> 5), flip = sl > 256u ? 1u : 0u, sl2 = flip ? 512u - sl : sl, sm = a.s - ((a.s + 16u) >> 5);
+    const unsigned rl = r2 < lps ? r2 : lps, r = r2 ^ ((r2 ^ rl) & msk);
+    a.s = sm ^ ((sm ^ sl2) & msk), a.m = a.m ^ (flip & is_lps);
+    const unsigned n = r < 8192u ? (unsigned)__builtin_clz(r) - 18u : 0u;
+    range = r << n, shifts += n;
+}
+XW void cnt_unary(unsigned &range, unsigned &shifts, Mdl &m0, Mdl &m1, unsigned sym)
+{
+    cnt_bin(range, shifts, m0, sym ? 1u : 0u);
+    while(sym) {
+        sym--;
+        cnt_bin(range, shifts, m1, sym ? 1u : 0u);
+    }
+}
+template <bool FULL> XW void cod_events(Cod &s, const uint32_t *ev, int nev, int ch)
+{
+    const int t0 = ch ? 2 : 0;
+    if(!FULL) {
+        Mdl r0 = mdl_of(XW_M(s, XEVE_HIP_CTX_RUN + t0)), r1 = mdl_of(XW_M(s, XEVE_HIP_CTX_RUN + t0 + 1)), l0 = mdl_of(XW_M(s, XEVE_HIP_CTX_LEVEL + t0));
+        Mdl l1 = mdl_of(XW_M(s, XEVE_HIP_CTX_LEVEL + t0 + 1)), la = mdl_of(XW_M(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0)));
+        unsigned range = s.range, shifts = s.shifts;
+        uint32_t e = nev > 0 ? ev[0] : 0u;
+        for(int i = 0; i < nev; i++) {
+            const uint32_t en = i + 1 < nev ? ev[i + 1] : 0u; // (the next event is on its way while this one is coded)
+            cnt_unary(range, shifts, r0, r1, (e >> 16) & 0xFFFu);
+            cnt_unary(range, shifts, l0, l1, e & 0x7FFFu);
+            range &= ~1u, shifts++; // the sign, bypass coded
+            if((e >> 28) & 1u) break;
+            cnt_bin(range, shifts, la, i == nev - 1 ? 1u : 0u);
+            e = en;
+        }
+        s.range = range, s.shifts = shifts;
+        XW_M(s, XEVE_HIP_CTX_RUN + t0) = (uint16_t)mdl_pack(r0), XW_M(s, XEVE_HIP_CTX_RUN + t0 + 1) = (uint16_t)mdl_pack(r1);
+        XW_M(s, XEVE_HIP_CTX_LEVEL + t0) = (uint16_t)mdl_pack(l0), XW_M(s, XEVE_HIP_CTX_LEVEL + t0 + 1) = (uint16_t)mdl_pack(l1);
+        XW_M(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0)) = (uint16_t)mdl_pack(la);
+        return;
+    }
+    unsigned r0 = XW_M(s, XEVE_HIP_CTX_RUN + t0), r1 = XW_M(s, XEVE_HIP_CTX_RUN + t0 + 1), l0 = XW_M(s, XEVE_HIP_CTX_LEVEL + t0), l1 = XW_M(s, XEVE_HIP_CTX_LEVEL + t0 + 1);
+    unsigned la = XW_M(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0));
+    for(int i = 0; i < nev; i++) {
+        const uint32_t e = ev[i];
+        cod_unary_m<FULL>(s, r0, r1, (e >> 16) & 0xFFFu);
+        cod_unary_m<FULL>(s, l0, l1, e & 0x7FFFu);
+        cod_ep<FULL>(s, (e >> 15) & 1u);
+        if((e >> 28) & 1u) break; // the last scan position: no flag follows
+        cod_bin_m<FULL>(s, la, i == nev - 1);
+    }
+    XW_M(s, XEVE_HIP_CTX_RUN + t0) = (uint16_t)r0, XW_M(s, XEVE_HIP_CTX_RUN + t0 + 1) = (uint16_t)r1;
+    XW_M(s, XEVE_HIP_CTX_LEVEL + t0) = (uint16_t)l0, XW_M(s, XEVE_HIP_CTX_LEVEL + t0 + 1) = (uint16_t)l1, XW_M(s, XEVE_HIP_CTX_LAST + (ch ? 1 : 0)) = (uint16_t)la;
+}
+// xeve_eco_abs_mvd + sign (xeve_eco.c:1205-1270)
+template <bool FULL> XW void cod_mvd1(Cod &s, int v)
+{
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    uint32_t nn = (a + 1) >> 1;
+    int len = 0;
+    for(; len < 16 && nn; len++) nn >>= 1;
+    const uint32_t code = (1u << len) | ((a + 1 - (1u << len)) & ((1u << len) - 1));
+    const int nbin = 2 * len + 1;
+    for(int i = 0; i < nbin; i++) {
+        const uint32_t b = (code >> (nbin - 1 - i)) & 1;
+        if(i <= 1) cod_bin<FULL>(s, XEVE_HIP_CTX_MVD, b);
+        else cod_ep<FULL>(s, b);
+    }
+    if(a) cod_ep<FULL>(s, v < 0);
+}
+template <bool FULL> XW void cod_mvp_idx(Cod &s, int idx)
+{ // sbac_write_truncate_unary_sym(idx, 3, 4) (xeve_eco.c:492-511, 1190-1203)
+    for(int i = 0; i < 3; i++) {
+        const int sym = i == idx ? 0 : 1;
+        cod_bin<FULL>(s, XEVE_HIP_CTX_MVP_IDX + i, sym);
+        if(!sym) break;
+    }
+}
+template <bool FULL> XW void cod_refi(Cod &s, int num_refp, int refi)
+{ // xeve_eco_refi (xeve_eco.c:1158-1188)
+    if(num_refp <= 1) return;
+    if(refi == 0) {
+        cod_bin<FULL>(s, XEVE_HIP_CTX_REFI, 0);
+        return;
+    }
+    cod_bin<FULL>(s, XEVE_HIP_CTX_REFI, 1);
+    for(int i = 2; i < num_refp; i++) {
+        const int bin = i == refi + 1 ? 0 : 1;
+        if(i == 2) cod_bin<FULL>(s, XEVE_HIP_CTX_REFI + 1, bin);
+        else cod_ep<FULL>(s, bin);
+        if(!bin) break;
+    }
+}
+// the coefficient part of a CU (xeve_eco_coef -> xeve_eco_cbf + xeve_eco_run_length_cc, xeve_eco.c:793-894, 1067-1089): nnz / events of Y, U, V; run = the components
+// this call covers (bit 0 Y, 1 U, 2 V)
+struct CoefSet {
+    const uint32_t *ev[3];
+    int             nev[3], nnz[3];
+};
+template <bool FULL> XW void cod_coef(Cod &s, int idc, const CoefSet &q, int run, int is_intra)
+{
+    const int cbf[3] = {q.nnz[0] != 0, q.nnz[1] != 0, q.nnz[2] != 0}, r0 = run & 1, r1 = (run >> 1) & 1, r2 = (run >> 2) & 1;
+    const int cbf_all = (r0 && cbf[0]) + (r1 && cbf[1]) + (r2 && cbf[2]);
+    if(!is_intra) {
+        if(r0 + r1 + r2 == 3) {
+            cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_ALL, cbf_all != 0);
+            if(!cbf_all) return;
+        }
+        if(r1 && idc) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_CB, cbf[1]);
+        if(r2 && idc) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_CR, cbf[2]);
+        if(r0 && cbf[1] + cbf[2] != 0) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_LUMA, cbf[0]);
+    }
+    else {
+        if(r1 && idc) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_CB, cbf[1]);
+        if(r2 && idc) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_CR, cbf[2]);
+        if(r0) cod_bin<FULL>(s, XEVE_HIP_CTX_CBF_LUMA, cbf[0]);
+    }
+    if(r0 && cbf[0]) cod_events<FULL>(s, q.ev[0], q.nev[0], 0);
+    if(r1 && cbf[1]) cod_events<FULL>(s, q.ev[1], q.nev[1], 1);
+    if(r2 && cbf[2]) cod_events<FULL>(s, q.ev[2], q.nev[2], 1);
+}
+// the split_cu_flag of a node (xeve_eco_split_mode, Baseline: one bin) counted from `from`; the state after it into `to`
+template <bool FULL> XW unsigned split_flag_bits(const Sbac &from, Sbac &to, int split, uint16_t *m, int ms)
+{
+    Cod c;
+    cod_load(c, from, m, ms);
+    cod_reset(c);
+    cod_bin<FULL>(c, XEVE_HIP_CTX_SPLIT_CU, split != 0);
+    cod_store<FULL>(c, to);
+    return cod_bits<FULL>(c);
+}
+
+// ---- rate tables of RDOQ (xeve_rdoq_bit_est, xeve_mode.c:315-372): the Baseline run / level syntax touches contexts 0 .. 3 only ------------------------------------
+enum { E_CBF_L = 0, E_CBF_CB = 2, E_CBF_CR = 4, E_CBF_ALL = 6, E_RUN = 8, E_LEVEL = 16, E_LAST = 24 }; // est[...][bin]
+XW int32_t no_bits(const P &p, int symbol, uint16_t cm)
+{
+    const unsigned mps = cm & 1;
+    unsigned state = cm >> 1;
+    state = ((unsigned)(symbol != 0) != mps) ? state : 512 - state;
+    return p.entropy[state << 1];
+}
+XW void est_entry(const P &p, const Sbac &s, int i, int32_t *e)
+{ // entry i of the 28
+    const int b = i & 1, g = i >> 1;
+    int ci;
+    if(g == 0) ci = XEVE_HIP_CTX_CBF_LUMA;
+    else if(g == 1) ci = XEVE_HIP_CTX_CBF_CB;
+    else if(g == 2) ci = XEVE_HIP_CTX_CBF_CR;
+    else if(g == 3) ci = XEVE_HIP_CTX_CBF_ALL;
+    else if(g < 8) ci = XEVE_HIP_CTX_RUN + (g - 4);
+    else if(g < 12) ci = XEVE_HIP_CTX_LEVEL + (g - 8);
+    else ci = XEVE_HIP_CTX_LAST + (g - 12);
+    e[i] = no_bits(p, b, s.ctx[ci]);
+}
+
+// ---- stages over transform blocks ------------------------------------------------------------------------------------------------------------------------------------
+// residual = original - prediction into coef; optionally SSD(prediction, original) (the shift per sample, xeve_ssd_16b)
+XW void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
+{
+    const int N = 1 << log2n, per = N * N / (N >= 4 ? 4 : 2), g = N >= 4 ? 4 : 2, sh = (bd - 8) * 2;
+    for(int i = tm.tid; i < nb * per; i += tm.n) {
+        const int bi = i / per, e = (i - bi * per) * g, y = e >> log2n, x = e & (N - 1);
+        Blk &B = b[bi];
+        if(!B.on) continue;
+        const pel *o = B.org + (long)y * B.s_org + x, *q = B.pred + e;
+        int16_t   *d = B.s->coef + e;
+        u64 acc = 0;
+        for(int t = 0; t < g; t++) {
+            const int v = (int)o[t] - (int)q[t];
+            d[t] = (int16_t)v;
+            acc += (u64)((v * v) >> sh);
+        }
+        if(want_ssd) aadd64(&B.ssd[0], acc);
+    }
+}
+// one pass of a transform over every block: pass 0 / 1 = xeve_trans rows / columns (xeve_tq.c:396-404), 2 / 3 = xeve_itrans (xeve_itdq.c:435-440)
+XW void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
+{
+    const int N = 1 << log2n, G = N >= 4 ? 4 : N, per = N * (N / G);
+    const int8_t *M = dct_m(p, log2n), *Mt = dct_t(p, log2n);
+    const int fshift = (log2n - 1 + p.bd - 8) + (log2n + 6), ishift = 7 + (12 - (p.bd - 8));
+    for(int i = tm.tid; i < nb * per; i += tm.n) {
+        const int bi = i / per, e = i - bi * per, j = e / (N / G), g0 = (e - j * (N / G)) * G;
+        Blk &B = b[bi];
+        if(!B.on || (pass >= 2 && !B.nnz)) continue;
+        Slot *s = B.s;
+        if(pass == 0) { // tb[k * N + j] = sum_x M[k][x] * coef[j * N + x]
+            int32_t a[4] = {0, 0, 0, 0};
+            const int16_t *src = s->coef + j * N;
+            for(int x = 0; x < N; x++) {
+                const int v = src[x];
+                const int8_t *m = Mt + x * N + g0;
+                for(int t = 0; t < G; t++) a[t] += (int32_t)m[t] * v;
+            }
+            for(int t = 0; t < G; t++) s->tb[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? 0 : a[t];
+        }
+        else if(pass == 1) { // coef[k * N + j] = (sum_x M[k][x] * tb[j * N + x] + add) >> shift
+            int64_t a[4] = {0, 0, 0, 0};
+            const int32_t *src = s->tb + j * N;
+            for(int x = 0; x < N; x++) {
+                const int64_t v = src[x];
+                const int8_t *m = Mt + x * N + g0;
+                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
+            }
+            const int64_t add = (int64_t)1 << (fshift - 1);
+            for(int t = 0; t < G; t++) s->coef[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? (int16_t)0 : (int16_t)((a[t] + add) >> fshift);
+        }
+        else if(pass == 2) { // tb[j * N + x] = clip32(sum_k M[k][x] * coef[k * N + j])
+            int64_t a[4] = {0, 0, 0, 0};
+            const int K = N == 64 ? 32 : N; // (the 64-point inverse reads the 32 rows a forward transform can leave)
+            for(int k = 0; k < K; k++) {
+                const int64_t v = s->coef[k * N + j];
+                const int8_t *m = M + k * N + g0;
+                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
+            }
+            for(int t = 0; t < G; t++) s->tb[j * N + g0 + t] = (int32_t)(a[t] < INT32_MIN ? INT32_MIN : a[t] > INT32_MAX ? INT32_MAX : a[t]);
+        }
+        else { // coef[j * N + x] = clip16((sum_k M[k][x] * tb[k * N + j] + add) >> shift)
+            int64_t a[4] = {0, 0, 0, 0};
+            const int K = N == 64 ? 32 : N;
+            for(int k = 0; k < K; k++) {
+                const int64_t v = s->tb[k * N + j];
+                const int8_t *m = M + k * N + g0;
+                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
+            }
+            const int64_t add = (int64_t)1 << (ishift - 1);
+            for(int t = 0; t < G; t++) {
+                const int64_t v = (a[t] + add) >> ishift;
+                s->coef[j * N + g0 + t] = (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+            }
+        }
+    }
+}
+// get_ic_rate_cost_rl (xeve_tq.c:425-456): s32 rate arithmetic as the reference; c = 0 luma / 2 chroma
+XW int64_t rl_cost(unsigned abs_level, int run_nonzero, int c, int64_t lambda, const int32_t *e)
+{
+    uint32_t rate;
+    if(abs_level == 0) rate = (uint32_t)e[E_RUN + 2 * (c + run_nonzero) + 1];
+    else {
+        rate = 32768u + (uint32_t)e[E_RUN + 2 * (c + run_nonzero)];
+        if(abs_level == 1) rate += (uint32_t)e[E_LEVEL + 2 * c];
+        else rate += (uint32_t)e[E_LEVEL + 2 * c + 1] + (uint32_t)e[E_LEVEL + 2 * (c + 1) + 1] * (abs_level - 2) + (uint32_t)e[E_LEVEL + 2 * (c + 1)];
+    }
+    return (int64_t)(int32_t)rate * lambda;
+}
+// the zero-block pre-test (xeve_tq.c:666-699) + xeve_rdoq_run_length_cc (:497-649) of one square block, then its event list: ONE lane per block
+XW void rdoq_block(const P &p, Blk &B, int log2n, const int32_t *est)
+{
+    const int N = 1 << log2n, nn = N * N, comp = B.comp, qp = p.qp[comp], q_value = p.q_scale[comp], bd = p.bd;
+    const int q_bits = 14 + (15 - bd - log2n) + qp / 6, c = comp ? 2 : 0, ctx_last = comp ? 1 : 0;
+    const uint16_t *scan = scan_of(p, log2n);
+    Slot *s = B.s;
+    const int16_t *coef = s->coef;
+    int16_t       *lev = s->lev;
+    // the 64-point transform leaves the low 32 x 32 corner: positions outside it hold zeros, and a zero adds the same to every path below
+    const int64_t zthr = ((int64_t)1 << q_bits) - ((int64_t)(p.slice_type == 2 ? 201 : 153) << (q_bits - 9));
+    int any = 0;
+    for(int i = 0; i < nn && !any; i++) any = (int64_t)iabs(coef[i]) * q_value >= zthr;
+    int nnz = 0, nev = 0;
+    uint32_t best_last = 0;
+    if(any) {
+        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5), es = p.err_scale[comp][log2n];
+        const int64_t cap = (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1));
+        const int32_t *cbf = est + (B.is_intra ? (comp == 0 ? E_CBF_L : comp == 1 ? E_CBF_CB : E_CBF_CR) : (comp == 0 ? E_CBF_ALL : comp == 1 ? E_CBF_CB : E_CBF_CR));
+        int64_t block_uncoded = 0;
+        int     sum_all = 0;
+        for(int q = 0; q < nn; q++) {
+            const int v = coef[scan[q]];
+            if(!v) continue;
+            const int64_t t = (int64_t)iabs(v) * q_value, ld = (int)(t < cap ? t : cap);
+            uint32_t m = (uint32_t)(ld >> q_bits);
+            if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
+            const int64_t err = (ld * es) >> 20;
+            block_uncoded += err * err;
+            sum_all += (int)m;
+        }
+        if(sum_all != 0) {
+            int64_t  best_cost = block_uncoded + (int64_t)cbf[0] * lambda, base_cost = block_uncoded + (int64_t)cbf[1] * lambda;
+            uint32_t run = 0;
+            for(int q = 0; q < nn; q++) {
+                const int v = coef[scan[q]];
+                const int64_t t = (int64_t)iabs(v) * q_value, ld = (int)(t < cap ? t : cap);
+                uint32_t m = (uint32_t)(ld >> q_bits);
+                if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
+                const int16_t  mx = (int16_t)(v > 0 ? (int16_t)m : -(int16_t)m);
+                const uint32_t max_abs = (uint32_t)iabs(mx);
+                const int64_t  e1 = (ld * es) >> 20, uncoded = e1 * e1;
+                int64_t  coded = uncoded + rl_cost(0, run != 0, c, lambda, est);
+                uint32_t best = 0;
+                const uint32_t lo = max_abs > 1 ? max_abs - 1 : 1;
+                for(uint32_t a = max_abs; a >= lo; a--) { // get_coded_level_rl (xeve_tq.c:458-490)
+                    const int64_t d = ld - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, run != 0, c, lambda, est);
+                    if(cost < coded) best = a, coded = cost;
+                }
+                lev[scan[q]] = (int16_t)(mx < 0 ? -(int32_t)best : (int32_t)best);
+                base_cost += coded - uncoded;
+                if(best) {
+                    const int64_t cur_is_last = base_cost + (int64_t)est[E_LAST + 2 * ctx_last + 1] * lambda;
+                    base_cost += (int64_t)est[E_LAST + 2 * ctx_last] * lambda;
+                    if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)q + 1;
+                    run = 0;
+                }
+                else run++;
+            }
+        }
+    }
+    // the levels kept (positions before best_last), the rest cleared; the event list
+    int run = 0;
+    for(int q = 0; q < nn; q++) {
+        const int at = scan[q];
+        if((uint32_t)q >= best_last) {
+            lev[at] = 0;
+            continue;
+        }
+        const int v = lev[at];
+        if(!v) {
+            run++;
+            continue;
+        }
+        s->ev[nev++] = ev_pack(v, run, q == nn - 1);
+        run = 0, nnz++;
+    }
+    B.nnz = nnz, B.nev = nev;
+}
+XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
+{
+    for(int i = tm.tid; i < nb; i += tm.n)
+        if(b[i].on) rdoq_block(p, b[i], log2n, S.est[b[i].k]);
+}
+// xeve_dquant (xeve_itdq.c:442-475) of the levels into coef, for the blocks that have any
+XW void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
+{
+    const int nn = 1 << (2 * log2n), shift = (uint8_t)(20 - 14 - (15 - p.bd - log2n));
+    const int32_t offset = shift == 0 ? 0 : 1 << (shift - 1);
+    for(int i = tm.tid; i < nb * nn; i += tm.n) {
+        const int bi = i >> (2 * log2n), e = i & (nn - 1);
+        Blk &B = b[bi];
+        if(!B.on || !B.nnz) continue;
+        const int64_t l = ((int64_t)B.s->lev[e] * p.dq_scale[B.comp] + offset) >> shift;
+        B.s->coef[e] = (int16_t)(l < -32768 ? -32768 : l > 32767 ? 32767 : l);
+    }
+}
+// xeve_recon_blk (xeve_recon.c:34-57: the sum wraps to s16 before the clip) + SSD(reconstruction, original)
+XW void st_recon(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
+{
+    const int N = 1 << log2n, g = N >= 4 ? 4 : 2, per = N * N / g, sh = (p.bd - 8) * 2, maxv = (1 << p.bd) - 1;
+    for(int i = tm.tid; i < nb * per; i += tm.n) {
+        const int bi = i / per, e = (i - bi * per) * g, y = e >> log2n, x = e & (N - 1);
+        Blk &B = b[bi];
+        if(!B.on) continue;
+        const pel *o = B.org + (long)y * B.s_org + x, *q = B.pred + e;
+        const int16_t *r = B.s->coef + e;
+        pel *d = B.s->rec + e;
+        u64 acc = 0;
+        for(int t = 0; t < g; t++) {
+            const int16_t w = B.nnz ? (int16_t)(r[t] + q[t]) : q[t];
+            const int v = w < 0 ? 0 : w > maxv ? maxv : w, df = v - (int)o[t];
+            d[t] = (pel)v;
+            acc += (u64)((df * df) >> sh);
+        }
+        aadd64(&B.ssd[1], acc);
+    }
+}
+// residual .. reconstruction of the blocks (all of one size): what pintra_residue_rdo / pinter_residue_rdo do between the prediction and the bit count
+XW void blocks_chain(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n, int want_pred_ssd)
+{
+    st_diff(tm, b, nb, log2n, want_pred_ssd, p.bd);
+    sync(tm), mark(tm, p, S, PR_B_DIFF);
+    st_tpass(tm, p, b, nb, log2n, 0);
+    sync(tm), mark(tm, p, S, PR_B_T0);
+    st_tpass(tm, p, b, nb, log2n, 1);
+    sync(tm), mark(tm, p, S, PR_B_T1);
+    st_rdoq(tm, p, S, b, nb, log2n);
+    sync(tm), mark(tm, p, S, PR_B_RDOQ);
+    st_dquant(tm, p, b, nb, log2n);
+    sync(tm), mark(tm, p, S, PR_B_DQ);
+    st_tpass(tm, p, b, nb, log2n, 2);
+    sync(tm), mark(tm, p, S, PR_B_T2);
+    st_tpass(tm, p, b, nb, log2n, 3);
+    sync(tm), mark(tm, p, S, PR_B_T3);
+    st_recon(tm, p, b, nb, log2n);
+    sync(tm), mark(tm, p, S, PR_B_REC);
+}
+
+// xeve_had of one 8x8 or 4x4 tile of (org - cur) (xeve_sad.c:419-602): unnormalised Hadamard, the DC term >> 2, rounding per size.  Fully unrolled: the tile
+// lives in registers.
+template <int n> XW int had_tile_n(const pel *org, int s_org, const pel *cur, int s_cur)
+{
+    int t[n * n];
+#pragma unroll
+    for(int y = 0; y < n; y++)
+#pragma unroll
+        for(int x = 0; x < n; x++) t[y * n + x] = (int)org[y * s_org + x] - (int)cur[y * s_cur + x];
+#pragma unroll
+    for(int pass = 0; pass < 2; pass++) {
+        const int st = pass ? n : 1, line = pass ? 1 : n;
+#pragma unroll
+        for(int r = 0; r < n; r++)
+#pragma unroll
+            for(int len = 1; len < n; len <<= 1)
+#pragma unroll
+                for(int base = 0; base < n; base += 2 * len)
+#pragma unroll
+                    for(int i = base; i < base + len; i++) {
+                        const int a = t[r * line + i * st], c = t[r * line + (i + len) * st];
+                        t[r * line + i * st] = a + c, t[r * line + (i + len) * st] = a - c;
+                    }
+    }
+    int sum = iabs(t[0]) >> 2;
+#pragma unroll
+    for(int i = 1; i < n * n; i++) sum += iabs(t[i]);
+    return n == 4 ? (sum + 1) >> 1 : (sum + 2) >> 2;
+}
+XW int had_tile(const pel *org, int s_org, const pel *cur, int s_cur, int n)
+{
+    return n == 4 ? had_tile_n<4>(org, s_org, cur, s_cur) : had_tile_n<8>(org, s_org, cur, s_cur);
+}
+
+} // namespace xw
+#include "walk_intra.h"
+#include "walk_inter.h"
+#include "walk_tree.h"

@@ -1,0 +1,142 @@
+// xeve_amd/csrc/walk.hip -- the fused CTU walk on the device: ONE kernel launch decides a CTU of every chain of the call (walk.h: a workgroup per team of chains, the
+// whole quad-tree schedule executed inside the kernel).  This file is the launcher: device copies of the tables and of the schedule, the parameter record, the launch.
+// xeve_hip_mode_analyze_ctu_jobs (tree.hip) routes here unless XEVE_HIP_WALK=0 (the composed walk: ~10 000 launches per CTU step, kept for A/B measurements).
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+#include "xh_common.h"
+#include "walk_setup.h"
+
+template <bool FULL> __global__ void __launch_bounds__(XW_NT) k_walk(xw::P p)
+{
+    __shared__ xw::Lds S;
+    const xw::Tm tm = {(int)threadIdx.x, (int)blockDim.x};
+    xw::walk_team<FULL>(tm, p, S, (int)blockIdx.x);
+}
+
+namespace {
+struct OpsEntry {
+    int                 key[8];
+    xw::Op             *dev;
+    int                 n;
+};
+struct WalkDev { // device copies, rebuilt when the library is re-bound
+    uint32_t  gen = 0;
+    int8_t   *dct = nullptr;
+    uint16_t *scan = nullptr;
+    int32_t  *entropy = nullptr;
+    unsigned long long *prof = nullptr;
+    int16_t  *mc = nullptr; // [16][8] luma, then [32][4] chroma (the tables of the last call; compared before reuse)
+    std::vector<int16_t> mc_host;
+    std::vector<OpsEntry> ops;
+    std::mutex mu;
+    void drop()
+    {
+        if(dct) (void)hipFree(dct);
+        if(scan) (void)hipFree(scan);
+        if(entropy) (void)hipFree(entropy);
+        if(mc) (void)hipFree(mc);
+        if(prof) (void)hipFree(prof);
+        prof = nullptr;
+        for(auto &e : ops) (void)hipFree(e.dev);
+        dct = nullptr, scan = nullptr, entropy = nullptr, mc = nullptr, ops.clear(), mc_host.clear();
+    }
+};
+WalkDev g_walk;
+} // namespace
+
+bool xh_walk_enabled()
+{
+    static const int on = getenv("XEVE_HIP_WALK") ? atoi(getenv("XEVE_HIP_WALK")) : 1;
+    return on != 0;
+}
+bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I)
+{
+    if(!xh_walk_enabled()) return false;
+    if(p->ip.slice_type != 2 && I) {
+        static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 0;
+        if(!inter_on) return false;
+        const int n0 = I->ipar.rdo.num_refp[0], n1 = I->ipar.rdo.num_refp[1];
+        if(n0 > XW_MAXR || n1 > XW_MAXR) return false;
+    }
+    return p->log2_ctu <= 6;
+}
+size_t xh_walk_workspace(int nchains) { return (size_t)nchains * sizeof(xw::Cw) + 256; }
+
+int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
+                const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems, const xeve_hip_sbac *states, const xeve_hip_tree_params *p,
+                const xeve_hip_tree_inter *I, const xeve_hip_ctu_job *jobs, int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace,
+                size_t workspace_bytes, int vh, hipStream_t st)
+{
+    XH_REQUIRE(workspace_bytes >= xh_walk_workspace(nchains));
+    static const int C_env = getenv("XEVE_HIP_WALK_C") ? atoi(getenv("XEVE_HIP_WALK_C")) : 8;
+    static const int NT_env = getenv("XEVE_HIP_WALK_NT") ? atoi(getenv("XEVE_HIP_WALK_NT")) : XW_NT;
+    const int C = C_env < 1 ? 1 : C_env > XW_MAXC ? XW_MAXC : C_env, NT = NT_env < 64 ? 64 : NT_env > XW_NT ? XW_NT : (NT_env & ~63);
+    xw::P q;
+    xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
+    q.C = C, q.full = !xh_count_states();
+    {
+        std::lock_guard<std::mutex> lk(g_walk.mu);
+        WalkDev &D = g_walk;
+        if(D.gen != xh_generation()) D.drop(), D.gen = xh_generation();
+        if(!D.dct) {
+            xw::Tables T;
+            xw::make_tables(T);
+            XH_HIP(hipMalloc((void **)&D.dct, T.dct.size()));
+            XH_HIP(hipMalloc((void **)&D.scan, T.scan.size() * 2));
+            XH_HIP(hipMalloc((void **)&D.entropy, T.entropy.size() * 4));
+            XH_HIP(hipMemcpy(D.dct, T.dct.data(), T.dct.size(), hipMemcpyHostToDevice));
+            XH_HIP(hipMemcpy(D.scan, T.scan.data(), T.scan.size() * 2, hipMemcpyHostToDevice));
+            XH_HIP(hipMemcpy(D.entropy, T.entropy.data(), T.entropy.size() * 4, hipMemcpyHostToDevice));
+        }
+        if(I) { // the interpolation filters: the caller's host tables (pi->mc_l_coeff / mc_c_coeff)
+            std::vector<int16_t> h(16 * 8 + 32 * 4, 0);
+            memcpy(h.data(), I->coef_l, 16 * 8 * 2);
+            if(I->coef_c) memcpy(h.data() + 128, I->coef_c, 32 * 4 * 2);
+            if(!D.mc || h != D.mc_host) {
+                if(!D.mc) XH_HIP(hipMalloc((void **)&D.mc, h.size() * 2));
+                else XH_HIP(hipDeviceSynchronize()); // (a different filter set than the last call's: wait for the launches that read the old one)
+                XH_HIP(hipMemcpy(D.mc, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+                D.mc_host = h;
+            }
+            q.mc_l = D.mc, q.mc_c = D.mc + 128;
+        }
+        const int key[8] = {p->log2_ctu, p->max_cu, p->min_cu, p->min_cuwh, p->pic_w, p->pic_h, I != nullptr, 0};
+        const OpsEntry *hit = nullptr;
+        for(const auto &e : D.ops)
+            if(!memcmp(e.key, key, sizeof(key))) hit = &e;
+        if(!hit) {
+            const std::vector<xw::Op> ops = xw::make_ops(p, I != nullptr);
+            OpsEntry e;
+            memcpy(e.key, key, sizeof(key)), e.n = (int)ops.size();
+            XH_HIP(hipMalloc((void **)&e.dev, ops.size() * sizeof(xw::Op)));
+            XH_HIP(hipMemcpy(e.dev, ops.data(), ops.size() * sizeof(xw::Op), hipMemcpyHostToDevice));
+            D.ops.push_back(e);
+            hit = &D.ops.back();
+        }
+        q.ops = hit->dev, q.nops = hit->n, q.dct = D.dct, q.scan = D.scan, q.entropy = D.entropy;
+        static const int prof_on = getenv("XEVE_HIP_WALK_PROF") ? atoi(getenv("XEVE_HIP_WALK_PROF")) : 0;
+        if(prof_on && !D.prof) {
+            XH_HIP(hipMalloc((void **)&D.prof, 2 * xw::PR_N * 8));
+            XH_HIP(hipMemset(D.prof, 0, 2 * xw::PR_N * 8));
+        }
+        q.prof = D.prof;
+    }
+    q.cw = (xw::Cw *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const int teams = (nchains + C - 1) / C;
+    if(q.full) k_walk<true><<<teams, NT, 0, st>>>(q);
+    else k_walk<false><<<teams, NT, 0, st>>>(q);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
+// XEVE_HIP_WALK_PROF=1: cycles and marks per stage class of team 0 since the last call (out[0 .. n): cycles, out[n .. 2n): marks); returns the number of classes
+extern "C" int xeve_hip_walk_prof(unsigned long long *out, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_walk.mu);
+    if(!g_walk.prof || cap < 2 * xw::PR_N) return 0;
+    if(hipDeviceSynchronize() != hipSuccess) return 0;
+    if(hipMemcpy(out, g_walk.prof, 2 * xw::PR_N * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    (void)hipMemset(g_walk.prof, 0, 2 * xw::PR_N * 8);
+    return xw::PR_N;
+}
