@@ -8,8 +8,15 @@
 #include <cstdlib>
 #include <memory>
 #include "../xeve_amd/csrc/enc_host.h"
+#include "../xeve_amd/csrc/walk_setup.h" // the fused CTU walk's host side (XO_ENC_WALK=1: every CTU decided by it instead of the oracle -- pins walk.h end to end)
 extern "C" {
 #include "xeve_oracle.h"
+}
+static int g_use_walk = -1;
+static bool use_walk()
+{
+    if(g_use_walk < 0) g_use_walk = getenv("XO_ENC_WALK") ? atoi(getenv("XO_ENC_WALK")) : 0;
+    return g_use_walk != 0;
 }
 
 using namespace xenc;
@@ -117,12 +124,43 @@ struct CpuEngine {
                 TI.col1 = S.slice_type == ST_B ? (const int16_t(*)[2][2])q.st[S.ref[0][1].slot].mv.data() : TI.col0;
             }
             const int num_refp[2] = {S.ep.num_refp[0], S.ep.num_refp[1]};
+            std::vector<xeve_hip_ctu_data> wout;
+            if(use_walk()) { // the step's chains of this picture in ONE call of the fused walk (team-local lockstep, the chains share the picture and the maps)
+                static xw::Tables T;
+                if(T.dct.empty()) xw::make_tables(T);
+                xeve_hip_tree_inter HI = S.ti;
+                xeve_hip_refpic htab[2 * MAX_ACTIVE_REF];
+                memcpy(htab, tab, sizeof(htab));
+                if(inter) {
+                    HI.refp = htab, HI.s_ref_l = s_l, HI.s_ref_c = s_c, HI.map_mv = cur.mv.data(), HI.map_refi = cur.refi.data();
+                    HI.col_mv0 = q.st[S.ref[0][0].slot].mv.data(), HI.col_mv1 = S.slice_type == ST_B ? q.st[S.ref[0][1].slot].mv.data() : HI.col_mv0;
+                    HI.coef_l = xo_mc_l_coeff, HI.coef_c = xo_mc_c_coeff;
+                }
+                std::vector<xeve_hip_ctu_job> jobs(n);
+                for(int i = 0; i < n; i++) jobs[i].x = c[i].x * CTU, jobs[i].y = c[i].y * CTU, jobs[i].sbac = c[i].t, jobs[i].pic = 0;
+                wout.resize(n);
+                std::vector<xeve_hip_sbac> nxt(n);
+                std::vector<double> cost(n);
+                xw::P wp;
+                xw::fill_params(wp, (const xeve_hip_pel *const *)org, P.w, P.w / 2, (xeve_hip_pel *const *)mod, s_l, s_c, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), nullptr,
+                                (const xeve_hip_sbac *)q.chain.data(), &S.tp, inter ? &HI : nullptr, jobs.data(), n, wout.data(), nxt.data(), cost.data(), 0);
+                const std::vector<xw::Op> ops = xw::make_ops(&S.tp, inter);
+                std::vector<xw::Cw> cw((size_t)n);
+                wp.C = n < XW_MAXC ? n : XW_MAXC, wp.full = 0;
+                wp.entropy = T.entropy.data(), wp.dct = T.dct.data(), wp.scan = T.scan.data(), wp.ops = ops.data(), wp.nops = (int)ops.size(), wp.cw = cw.data();
+                if(inter) wp.mc_l = &xo_mc_l_coeff[0][0], wp.mc_c = &xo_mc_c_coeff[0][0];
+                std::unique_ptr<xw::Lds> lds(new xw::Lds());
+                const xw::Tm tm = {0, 1};
+                for(int team = 0; team * wp.C < n; team++) xw::walk_team<false>(tm, wp, *lds, team);
+            }
             for(int i = 0; i < n; i++) {
                 const int x0 = c[i].x * CTU, y0 = c[i].y * CTU;
                 xo_sbac   next;
                 xo_ctu_data &out = q.ctus[c[i].lcu];
-                (void)xo_mode_analyze_ctu(org, P.w, P.w / 2, mod, s_l, s_c, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), &q.chain[c[i].t],
-                                          (const xo_tree_params *)&S.tp, inter ? &TI : nullptr, x0, y0, &out, &next);
+                if(use_walk()) memcpy(&out, &wout[i], sizeof(out));
+                else
+                    (void)xo_mode_analyze_ctu(org, P.w, P.w / 2, mod, s_l, s_c, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), &q.chain[c[i].t],
+                                              (const xo_tree_params *)&S.tp, inter ? &TI : nullptr, x0, y0, &out, &next);
                 for(int j = 0; j < std::min((int)CTU, P.h - y0) >> 2; j++) // mode_analyze_lcu's tail: the CTU's coded flags reset (xeve_mode.c:2591-2607)
                     for(int k = 0; k < std::min((int)CTU, P.w - x0) >> 2; k++) q.scu[(size_t)((y0 >> 2) + j) * w_scu + (x0 >> 2) + k] &= 0x7FFFFFFFu;
                 const int nb = xo_eco_ctu(&q.chain[c[i].t], &out, (const xo_tree_params *)&S.tp, num_refp, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), x0, y0,
@@ -165,6 +203,13 @@ struct CpuEngine {
 } // namespace
 
 extern "C" {
+// 1: every CTU decided by the fused walk's host side (xeve_amd/csrc/walk.h) instead of the oracle; 0: the oracle; returns the previous setting
+int xo_encode_use_walk(int on)
+{
+    const int was = use_walk();
+    g_use_walk = on != 0;
+    return was;
+}
 // out[g] is malloc'ed (release with xo_encode_free); returns 0, or -1 with a message in err
 int xo_encode_gops(const xeve_hip_enc_config *cfg, const uint8_t *const *yuv, int ngops, int frames, int always_rewrite, uint8_t **out, size_t *out_bytes, char *err, int err_cap)
 {

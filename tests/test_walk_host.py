@@ -62,3 +62,97 @@ def test_walk_i_pictures_with_count_only_states(case):
     c = make_case(*case)
     got, final = run_walk_case(c, chains_per_team=3, full=0)
     compare(case, c, got, final, full=0)
+
+
+# ---- P / B slices ------------------------------------------------------------------------------------------------------------------------------------------------
+from _tree_cases import INTER_CASES, make_inter_case, run_oracle_inter_picture  # noqa: E402
+
+
+def run_walk_inter_case(c, full=1):
+    import ctypes as C
+
+    from _mc_cases import refpic_table
+    from test_hip_inter import hip_params
+    from xeve_amd import lib
+    from xeve_amd.device import baseline_coef_c, baseline_coef_l
+
+    refs, org = c["refs"], c["org"]
+    tab = refpic_table(refs, lambda a, off: int(a.ctypes.data) + 2 * off)
+    org_ptrs = [int(org[0].ctypes.data) + 2 * refs["org_l"], int(org[1].ctypes.data) + 2 * refs["org_c"], int(org[2].ctypes.data) + 2 * refs["org_c"]]
+    mod = [a.copy() for a in c["mod"]]
+    m = {k: v.copy() for k, v in c["maps"].items()}
+    col = [a.copy() for a in c["col"]]
+    I = lib.TreeInter()
+    I.refp, I.s_ref_l, I.s_ref_c, I.ipar = tab.ctypes.data, refs["s_l"], refs["s_c"], hip_params(c["ipar"])
+    I.map_mv, I.map_refi, I.col_mv0, I.col_mv1, I.ecu_depth = m["mv"].ctypes.data, m["refi"].ctypes.data, col[0].ctypes.data, col[1].ctypes.data, c["ecu_depth"]
+    cl, cc = baseline_coef_l(), baseline_coef_c()
+    I.coef_l, I.coef_c = cl.ctypes.data, cc.ctypes.data
+    states = c["entry"][0:1].copy()
+    per_ctu = []
+    for (x, y) in c["order"]:
+        jobs = np.zeros(1, CTU_JOB_DTYPE)
+        jobs["x"], jobs["y"] = x, y
+        out, nxt, cost = _walk.host_walk(org_ptrs, refs["s_l"], refs["s_c"], [a.ctypes.data for a in mod], mod[0].shape[1], mod[1].shape[1], m["scu"], m["ipm"], m["tidx"],
+                                         m["cu_mode"], None, states, c["P"], I, jobs, 1, full)
+        per_ctu.append((out, nxt, cost))
+        states = nxt.copy()
+    return per_ctu, dict(mod=mod, scu=m["scu"], ipm=m["ipm"], cu_mode=m["cu_mode"], mv=m["mv"], refi=m["refi"])
+
+
+@pytest.mark.parametrize("case", INTER_CASES, ids=[str(c[0]) for c in INTER_CASES])
+def test_walk_p_and_b_pictures_match_oracle(case):
+    c = make_inter_case(*case)
+    got, final = run_walk_inter_case(c)
+    exp = run_oracle_inter_picture(c)  # updates c["mod"], c["maps"] in place
+    for k in range(len(c["order"])):
+        d, nb, cost = got[k]
+        ed, enb, ecost = exp[k]
+        for f in CTU_DATA_DTYPE.names:
+            assert np.array_equal(d[f][0], ed[f][0]), (case, "ctu", k, f, np.argwhere(d[f][0] != ed[f][0])[:4].tolist())
+        assert nb[0:1].tobytes() == enb.tobytes(), (case, k, "coder state")
+        assert np.float64(cost[0]).tobytes() == np.float64(ecost).tobytes(), (case, k, cost[0], ecost)
+    for j in range(3 if c["idc"] else 1):
+        assert np.array_equal(final["mod"][j], c["mod"][j]), (case, "picture", j)
+    for f in ("scu", "ipm", "cu_mode", "mv", "refi"):
+        assert np.array_equal(final[f].reshape(c["maps"][f].shape), c["maps"][f]), (case, "map", f)
+
+
+# ---- end to end: the batch encoder's frame loop with EVERY CTU decided by the fused walk's host side, against bitstreams of the unmodified reference application ----------
+import json  # noqa: E402
+import os  # noqa: E402
+
+import _e2e  # noqa: E402
+import _enc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def walk_engine():
+    h = _enc.harness()
+    was = h.xo_encode_use_walk(1)
+    yield h
+    h.xo_encode_use_walk(was)
+
+
+def _clip(tmp, name, w, h, n, seed):
+    p = os.path.join(tmp, name + ".yuv")
+    if not os.path.exists(p):
+        _e2e.make_yuv(p, w, h, n, seed)
+    return open(p, "rb").read()
+
+
+@pytest.mark.parametrize("name", sorted(_e2e.CASES))
+def test_walk_decides_every_ctu_of_the_single_runs(name, walk_engine, tmp_path_factory):
+    """all-intra, low-delay B, random access, closed GOP, two row chains, partial CTUs: count-only coder states, the chains of a wavefront step as one team"""
+    E2E = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "e2e_v1.json")))
+    w, h, n, seed, cli = _e2e.CASES[name]
+    out = _enc.encode_cpu(_enc.config(w, h, cli), [_clip(str(tmp_path_factory.getbasetemp()), name, w, h, n, seed)], n)[0]
+    assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("name", sorted(_enc.BATCH_CASES))
+def test_walk_decides_every_ctu_of_the_closed_gop_batches(name, walk_engine, tmp_path_factory):
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]

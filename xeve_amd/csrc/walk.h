@@ -21,6 +21,10 @@
 #include <string.h>
 #include "../../include/xeve_hip.h"
 
+#if !defined(__HIPCC__) && !defined(__host__) // (a plain C++ compiler builds the host side: the test harnesses under tests/native and oracle/)
+#define __host__
+#define __device__
+#endif
 #ifndef XW
 #define XW __host__ __device__ static inline
 #endif
@@ -121,8 +125,10 @@ struct Cw { // the workspace of one chain
     pel      ipred[5][4096];     // the five luma predictors of the intra analysis
     pel      cpred[2][4096];     // chroma predictors of its winner
     pel      epred[4][3][4096];  // inter: prediction of the candidates DIR / L0 / L1 / BI
-    pel      spred[2][3][4096];  // inter: skip prediction (best so far, candidate under test)
-    pel      wpred[3][4096];     // inter: the winner's prediction
+    pel      upred[2][4][3][4096]; // inter: the uni-directional predictions of the merge candidates [list][index][component]
+    pel      spred[3][4096];     // inter: the skip winner's prediction
+    pel      bpred[4096];        // inter: the fixed list's luma prediction of a bi round
+    u64      sk_ssd[16][3];      // inter: SSD of every merge candidate pair, per component
     pel      wrec[3][4096];      // inter: the winner's reconstruction
     int16_t  org_bi[4096];
     Slot     slot[XW_NSLOT];
@@ -181,20 +187,72 @@ XW const int8_t *dct_m(const P &p, int log2n) { return p.dct + dct_off(log2n); }
 XW const int8_t *dct_t(const P &p, int log2n) { return p.dct + XW_DCT_ELEMS + dct_off(log2n); }   // [x][k]
 XW const uint16_t *scan_of(const P &p, int log2n) { return p.scan + dct_off(log2n); }
 
-struct Blk { // one transform block of a stage
+struct Blk { // one transform block of a stage; its scratch arrays (a Slot of the chain's workspace, or -- small blocks -- the team's LDS arena)
     const pel *org, *pred;
-    Slot      *s;
-    int        s_org, comp, on, nnz, nev, k, is_intra, pad_;
+    int16_t   *coef, *lev; // residual -> DCT coefficients -> dequantised levels -> inverse transform output; the quantised levels
+    int32_t   *tb;         // between the two passes of a transform
+    pel       *rec;        // reconstruction (RDOQ's scan-ordered buffer before that)
+    uint32_t  *ev;         // the levels as events
+    int        s_org, comp, on, nnz, nev, k, is_intra, any;
+    int        sum_all, best_last;
     u64        ssd[2]; // SSD(prediction, original), SSD(reconstruction, original)
+    u64        unc;    // RDOQ: the block's distortion with every level zero
+};
+
+XW void blk_slot(Blk &B, Slot *s) { B.coef = s->coef, B.lev = s->lev, B.tb = s->tb, B.rec = s->rec, B.ev = s->ev; }
+
+enum { M_L0 = 0, M_L1 = 1, M_BI = 2, M_SKIP = 3, M_DIR = 4, M_NUM = 5 }; // PRED_* (xeve_def.h:461-469)
+struct ISt { // the inter analysis of one chain's CU, between the stages
+    int      on, go, x, y, pic;
+    int16_t  mvp[2][4][2], mv_col[2];
+    int16_t  mv[M_NUM][2][2], mvd[M_NUM][2][2];
+    int8_t   refi[M_NUM][2];
+    uint8_t  mvpi[M_NUM][2];
+    int16_t  mv_scale[2][XW_MAXR][2];
+    int32_t  mot_bits[2];
+    double   cost_inter[M_NUM];
+    int32_t  nnz[M_NUM][3];
+    // skip / merge
+    int32_t  dup[2];             // bit i: candidate i of the list repeats an earlier one
+    // analyze_bi
+    int32_t  lidx_ref, active, refi_best, changed;
+    uint32_t best_mecost, best_mecost_l[2];
+    int8_t   rf[2];
+    int8_t   best, cu_mode;
+};
+#define XW_MEJ 16   // searches of one pass
+#define XW_MEC 128  // candidates of one search round
+enum { PH_D1 = 0, PH_RASTER, PH_RASTER_REF, PH_DREF, PH_IREF, PH_HPEL, PH_QPEL, PH_DONE };
+enum { CT_NONE = 0, CT_DENSE, CT_LIST, CT_GRID, CT_SPEL };
+struct MeJob { // one pinter_me_epzs call (xeve_pinter.c:699-869) as a state machine: rounds of candidates, evaluated by all lanes
+    int        on, k, l, r, bi, x, y, so;
+    const pel *ref, *org;
+    int        gmvp[2], mvp[2], refi_bits, extra_bits, range_rc, range[4];
+    int        phase, tmpstep, beststep, mv[2], mot_bits;
+    unsigned   cost_best;
+    int        step, not_found, faststep, bx, by, ix, iy, d_beststep, d_bits, d_run; // the running me_ipel_diamond
+    unsigned   d_cost;
+    int        r_mv[2], r_bits, r_pos, r_total, r_nx, r_stp, r_ss, r_cx, r_cy;       // me_raster
+    unsigned   r_cost;
+    int        s_mv[2], s_bits;                                                     // me_spel_pattern / me_ipel_refinement
+    unsigned   s_cost;
+    int        ctype, nc, c0, c1, c2;                                               // the round under evaluation
+    short      cx[17], cy[17];
 };
 
 struct Lds { // the team's shared memory
     uint16_t ctx[XW_NCTX * XW_CODL]; // [model][coder lane]
-    Blk      blk[XW_MAXC * XW_NSLOT];
+    Blk      blk[XW_MAXC * 9];
+    ISt      ist[XW_MAXC];
+    MeJob    mej[XW_MEJ];
+    unsigned mcost[XW_MEJ * XW_MEC];
+    short    mbits[XW_MEJ * XW_MEC];
     int      sh[XW_MAXC][24];        // per-chain scalars of the running stage
     int      acc[XW_MAXC * 40];      // integer sums of a stage (SATD per mode, SAD per candidate)
     int32_t  est[XW_MAXC][28];       // the rate tables RDOQ reads, of each chain's entry state
     int      flag[4];
+    const Sbac *jsrc[XW_CODL]; // the coder lanes' entry states / where their exit states go (null: nowhere)
+    Sbac       *jdst[XW_CODL];
     long long t0;
 };
 // a mark: everything since the previous mark belongs to class `cls` (call right after a sync)
@@ -487,14 +545,19 @@ template <bool FULL> XW void cod_coef(Cod &s, int idc, const CoefSet &q, int run
     if(r1 && cbf[1]) cod_events<FULL>(s, q.ev[1], q.nev[1], 1);
     if(r2 && cbf[2]) cod_events<FULL>(s, q.ev[2], q.nev[2], 1);
 }
-// the split_cu_flag of a node (xeve_eco_split_mode, Baseline: one bin) counted from `from`; the state after it into `to`
-template <bool FULL> XW unsigned split_flag_bits(const Sbac &from, Sbac &to, int split, uint16_t *m, int ms)
+// the split_cu_flag of a node (xeve_eco_split_mode, Baseline: one bin) counted from `from`; the state after it into `to` (the one model it touches is updated in place)
+template <bool FULL> XW unsigned split_flag_bits(const Sbac &from, Sbac &to, int split)
 {
+    to = from;
     Cod c;
-    cod_load(c, from, m, ms);
+    c.range = from.range, c.code = from.code, c.code_bits = from.code_bits, c.shifts = 0, c.m = to.ctx, c.ms = 1;
     cod_reset(c);
     cod_bin<FULL>(c, XEVE_HIP_CTX_SPLIT_CU, split != 0);
-    cod_store<FULL>(c, to);
+    if(FULL) {
+        to.range = c.range, to.code = c.code, to.code_bits = c.code_bits, to.stacked_ff = c.stacked_ff, to.stacked_zero = c.stacked_zero, to.pending_byte = c.pending_byte;
+        to.is_pending_byte = c.is_pending_byte, to.bitcounter = c.bitcounter, to.bin_counter = c.bin_counter;
+    }
+    else to.range = c.range, to.code = 0, to.code_bits = 11, to.stacked_ff = to.stacked_zero = to.pending_byte = to.is_pending_byte = to.bitcounter = to.bin_counter = 0;
     return cod_bits<FULL>(c);
 }
 
@@ -521,6 +584,57 @@ XW void est_entry(const P &p, const Sbac &s, int i, int32_t *e)
     e[i] = no_bits(p, b, s.ctx[ci]);
 }
 
+// ---- a stage of bit-count jobs: job j on coder lane j (further rounds when there are more jobs than lanes) --------------------------------------------------------------
+// src(j, in, out) -> is the job on, its entry state, where its exit state goes (null: nowhere); run(j, coder) codes the job's syntax and takes the bits.  The context
+// models travel between the states (HBM / L2) and the lanes' LDS rows cooperatively, a word per lane.
+XW int coder_lanes(const Tm &tm) { return imin(tm.n, XW_CODL); }
+template <bool FULL, class Src, class Run> XW void coder_stage(const Tm &tm, Lds &S, int njobs, Src src, Run run)
+{
+    const int cl = coder_lanes(tm);
+    for(int base = 0; base < njobs; base += cl) {
+        const int cnt = imin(cl, njobs - base);
+        for(int l = tm.tid; l < cnt; l += tm.n) {
+            const Sbac *in = nullptr;
+            Sbac       *out = nullptr;
+            const bool  on = src(base + l, in, out);
+            S.jsrc[l] = on ? in : nullptr, S.jdst[l] = on ? out : nullptr;
+        }
+        sync(tm);
+        for(int i = tm.tid; i < cnt * (XW_NCTX / 2); i += tm.n) {
+            const int l = i / (XW_NCTX / 2), w = i - l * (XW_NCTX / 2);
+            const Sbac *in = S.jsrc[l];
+            if(!in) continue;
+            const uint32_t v = ((const uint32_t *)in->ctx)[w];
+            S.ctx[(2 * w) * XW_CODL + l] = (uint16_t)v, S.ctx[(2 * w + 1) * XW_CODL + l] = (uint16_t)(v >> 16);
+        }
+        sync(tm);
+        if(tm.tid < cnt && S.jsrc[tm.tid]) {
+            const Sbac &in = *S.jsrc[tm.tid];
+            Cod c;
+            c.range = in.range, c.code = in.code, c.code_bits = in.code_bits, c.stacked_ff = in.stacked_ff, c.stacked_zero = in.stacked_zero, c.pending_byte = in.pending_byte;
+            c.is_pending_byte = in.is_pending_byte, c.bitcounter = in.bitcounter, c.bin_counter = in.bin_counter, c.shifts = 0, c.m = S.ctx + tm.tid, c.ms = XW_CODL;
+            cod_reset(c);
+            run(base + tm.tid, c);
+            Sbac *o = S.jdst[tm.tid];
+            if(o) {
+                if(FULL) {
+                    o->range = c.range, o->code = c.code, o->code_bits = c.code_bits, o->stacked_ff = c.stacked_ff, o->stacked_zero = c.stacked_zero, o->pending_byte = c.pending_byte;
+                    o->is_pending_byte = c.is_pending_byte, o->bitcounter = c.bitcounter, o->bin_counter = c.bin_counter;
+                }
+                else o->range = c.range, o->code = 0, o->code_bits = 11, o->stacked_ff = o->stacked_zero = o->pending_byte = o->is_pending_byte = o->bitcounter = o->bin_counter = 0;
+            }
+        }
+        sync(tm);
+        for(int i = tm.tid; i < cnt * (XW_NCTX / 2); i += tm.n) {
+            const int l = i / (XW_NCTX / 2), w = i - l * (XW_NCTX / 2);
+            Sbac *o = S.jdst[l];
+            if(!o) continue;
+            ((uint32_t *)o->ctx)[w] = (uint32_t)S.ctx[(2 * w) * XW_CODL + l] | ((uint32_t)S.ctx[(2 * w + 1) * XW_CODL + l] << 16);
+        }
+        sync(tm);
+    }
+}
+
 // ---- stages over transform blocks ------------------------------------------------------------------------------------------------------------------------------------
 // residual = original - prediction into coef; optionally SSD(prediction, original) (the shift per sample, xeve_ssd_16b)
 XW void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
@@ -531,7 +645,7 @@ XW void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
         Blk &B = b[bi];
         if(!B.on) continue;
         const pel *o = B.org + (long)y * B.s_org + x, *q = B.pred + e;
-        int16_t   *d = B.s->coef + e;
+        int16_t   *d = B.coef + e;
         u64 acc = 0;
         for(int t = 0; t < g; t++) {
             const int v = (int)o[t] - (int)q[t];
@@ -551,7 +665,7 @@ XW void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
         const int bi = i / per, e = i - bi * per, j = e / (N / G), g0 = (e - j * (N / G)) * G;
         Blk &B = b[bi];
         if(!B.on || (pass >= 2 && !B.nnz)) continue;
-        Slot *s = B.s;
+        const Blk *s = &B;
         if(pass == 0) { // tb[k * N + j] = sum_x M[k][x] * coef[j * N + x]
             int32_t a[4] = {0, 0, 0, 0};
             const int16_t *src = s->coef + j * N;
@@ -611,89 +725,108 @@ XW int64_t rl_cost(unsigned abs_level, int run_nonzero, int c, int64_t lambda, c
     }
     return (int64_t)(int32_t)rate * lambda;
 }
-// the zero-block pre-test (xeve_tq.c:666-699) + xeve_rdoq_run_length_cc (:497-649) of one square block, then its event list: ONE lane per block
-XW void rdoq_block(const P &p, Blk &B, int log2n, const int32_t *est)
+// The zero-block pre-test (xeve_tq.c:666-699) + xeve_rdoq_run_length_cc (:497-649) of square blocks + their event lists, in four steps:
+//   a (lane per position)  the coefficients into scan order (rec serves as the buffer: the reconstruction is written later), the pre-test, the sums over the block
+//   b (lane per block)     the run-length automaton over the scan: the level kept per position written back in place, best_last
+//   c (lane per position)  the levels into the block, zero from best_last on;   d (lane per block)  the event list and the number of levels
+XW void rdoq_level(int v, int q_value, int q_bits, int64_t cap, int64_t &ld, uint32_t &m)
 {
-    const int N = 1 << log2n, nn = N * N, comp = B.comp, qp = p.qp[comp], q_value = p.q_scale[comp], bd = p.bd;
-    const int q_bits = 14 + (15 - bd - log2n) + qp / 6, c = comp ? 2 : 0, ctx_last = comp ? 1 : 0;
-    const uint16_t *scan = scan_of(p, log2n);
-    Slot *s = B.s;
-    const int16_t *coef = s->coef;
-    int16_t       *lev = s->lev;
-    // the 64-point transform leaves the low 32 x 32 corner: positions outside it hold zeros, and a zero adds the same to every path below
-    const int64_t zthr = ((int64_t)1 << q_bits) - ((int64_t)(p.slice_type == 2 ? 201 : 153) << (q_bits - 9));
-    int any = 0;
-    for(int i = 0; i < nn && !any; i++) any = (int64_t)iabs(coef[i]) * q_value >= zthr;
-    int nnz = 0, nev = 0;
-    uint32_t best_last = 0;
-    if(any) {
-        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5), es = p.err_scale[comp][log2n];
-        const int64_t cap = (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1));
-        const int32_t *cbf = est + (B.is_intra ? (comp == 0 ? E_CBF_L : comp == 1 ? E_CBF_CB : E_CBF_CR) : (comp == 0 ? E_CBF_ALL : comp == 1 ? E_CBF_CB : E_CBF_CR));
-        int64_t block_uncoded = 0;
-        int     sum_all = 0;
-        for(int q = 0; q < nn; q++) {
-            const int v = coef[scan[q]];
-            if(!v) continue;
-            const int64_t t = (int64_t)iabs(v) * q_value, ld = (int)(t < cap ? t : cap);
-            uint32_t m = (uint32_t)(ld >> q_bits);
-            if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
-            const int64_t err = (ld * es) >> 20;
-            block_uncoded += err * err;
-            sum_all += (int)m;
-        }
-        if(sum_all != 0) {
-            int64_t  best_cost = block_uncoded + (int64_t)cbf[0] * lambda, base_cost = block_uncoded + (int64_t)cbf[1] * lambda;
-            uint32_t run = 0;
-            for(int q = 0; q < nn; q++) {
-                const int v = coef[scan[q]];
-                const int64_t t = (int64_t)iabs(v) * q_value, ld = (int)(t < cap ? t : cap);
-                uint32_t m = (uint32_t)(ld >> q_bits);
-                if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
-                const int16_t  mx = (int16_t)(v > 0 ? (int16_t)m : -(int16_t)m);
-                const uint32_t max_abs = (uint32_t)iabs(mx);
-                const int64_t  e1 = (ld * es) >> 20, uncoded = e1 * e1;
-                int64_t  coded = uncoded + rl_cost(0, run != 0, c, lambda, est);
-                uint32_t best = 0;
-                const uint32_t lo = max_abs > 1 ? max_abs - 1 : 1;
-                for(uint32_t a = max_abs; a >= lo; a--) { // get_coded_level_rl (xeve_tq.c:458-490)
-                    const int64_t d = ld - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, run != 0, c, lambda, est);
-                    if(cost < coded) best = a, coded = cost;
-                }
-                lev[scan[q]] = (int16_t)(mx < 0 ? -(int32_t)best : (int32_t)best);
-                base_cost += coded - uncoded;
-                if(best) {
-                    const int64_t cur_is_last = base_cost + (int64_t)est[E_LAST + 2 * ctx_last + 1] * lambda;
-                    base_cost += (int64_t)est[E_LAST + 2 * ctx_last] * lambda;
-                    if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)q + 1;
-                    run = 0;
-                }
-                else run++;
-            }
-        }
-    }
-    // the levels kept (positions before best_last), the rest cleared; the event list
-    int run = 0;
-    for(int q = 0; q < nn; q++) {
-        const int at = scan[q];
-        if((uint32_t)q >= best_last) {
-            lev[at] = 0;
-            continue;
-        }
-        const int v = lev[at];
-        if(!v) {
-            run++;
-            continue;
-        }
-        s->ev[nev++] = ev_pack(v, run, q == nn - 1);
-        run = 0, nnz++;
-    }
-    B.nnz = nnz, B.nev = nev;
+    const int64_t t = (int64_t)iabs(v) * q_value;
+    ld = (int)(t < cap ? t : cap);
+    m = (uint32_t)(ld >> q_bits);
+    if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
 }
 XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
 {
-    for(int i = tm.tid; i < nb; i += tm.n)
-        if(b[i].on) rdoq_block(p, b[i], log2n, S.est[b[i].k]);
+    const int N = 1 << log2n, nn = N * N, bd = p.bd;
+    const uint16_t *scan = scan_of(p, log2n);
+    for(int i = tm.tid; i < nb; i += tm.n) b[i].any = 0, b[i].sum_all = 0, b[i].unc = 0, b[i].best_last = 0, b[i].nnz = 0, b[i].nev = 0;
+    sync(tm);
+    for(int i = tm.tid; i < nb * nn; i += tm.n) { // a
+        const int bi = i >> (2 * log2n), q = i & (nn - 1);
+        Blk &B = b[bi];
+        if(!B.on) continue;
+        const int comp = B.comp, qp = p.qp[comp], q_value = p.q_scale[comp], q_bits = 14 + (15 - bd - log2n) + qp / 6;
+        const int v = B.coef[scan[q]];
+        B.rec[q] = (pel)v;
+        if(!v) continue;
+        const int64_t zthr = ((int64_t)1 << q_bits) - ((int64_t)(p.slice_type == 2 ? 201 : 153) << (q_bits - 9));
+        if((int64_t)iabs(v) * q_value >= zthr) aor(&B.any, 1);
+        int64_t  ld;
+        uint32_t m;
+        rdoq_level(v, q_value, q_bits, (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1)), ld, m);
+        const int64_t err = (ld * p.err_scale[comp][log2n]) >> 20;
+        aadd64(&B.unc, (u64)(err * err));
+        if(m) aadd(&B.sum_all, (int)m);
+    }
+    sync(tm);
+    for(int i = tm.tid; i < nb; i += tm.n) { // b
+        Blk &B = b[i];
+        if(!B.on || !B.any || !B.sum_all) continue;
+        const int comp = B.comp, qp = p.qp[comp], q_value = p.q_scale[comp], q_bits = 14 + (15 - bd - log2n) + qp / 6, c = comp ? 2 : 0, ctx_last = comp ? 1 : 0;
+        const int32_t *est = S.est[B.k];
+        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5), es = p.err_scale[comp][log2n];
+        const int64_t cap = (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1));
+        const int32_t *cbf = est + (B.is_intra ? (comp == 0 ? E_CBF_L : comp == 1 ? E_CBF_CB : E_CBF_CR) : (comp == 0 ? E_CBF_ALL : comp == 1 ? E_CBF_CB : E_CBF_CR));
+        const int64_t z0 = rl_cost(0, 0, c, lambda, est), z1 = rl_cost(0, 1, c, lambda, est), last0 = (int64_t)est[E_LAST + 2 * ctx_last] * lambda;
+        const int64_t last1 = (int64_t)est[E_LAST + 2 * ctx_last + 1] * lambda;
+        int64_t  best_cost = (int64_t)B.unc + (int64_t)cbf[0] * lambda, base_cost = (int64_t)B.unc + (int64_t)cbf[1] * lambda;
+        uint32_t run = 0, best_last = 0;
+        pel *sc = B.rec;
+        for(int q = 0; q < nn; q++) {
+            const int v = sc[q];
+            if(!v) { // a zero: the rate of one more zero of the run
+                base_cost += run ? z1 : z0;
+                run++;
+                continue;
+            }
+            int64_t  ld;
+            uint32_t m;
+            rdoq_level(v, q_value, q_bits, cap, ld, m);
+            const int16_t  mx = (int16_t)(v > 0 ? (int16_t)m : -(int16_t)m);
+            const uint32_t max_abs = (uint32_t)iabs(mx);
+            const int64_t  e1 = (ld * es) >> 20, uncoded = e1 * e1;
+            int64_t  coded = uncoded + (run ? z1 : z0);
+            uint32_t best = 0;
+            const uint32_t lo = max_abs > 1 ? max_abs - 1 : 1;
+            for(uint32_t a = max_abs; a >= lo; a--) { // get_coded_level_rl (xeve_tq.c:458-490)
+                const int64_t d = ld - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, run != 0, c, lambda, est);
+                if(cost < coded) best = a, coded = cost;
+            }
+            sc[q] = (pel)(mx < 0 ? -(int32_t)best : (int32_t)best);
+            base_cost += coded - uncoded;
+            if(best) {
+                const int64_t cur_is_last = base_cost + last1;
+                base_cost += last0;
+                if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)q + 1;
+                run = 0;
+            }
+            else run++;
+        }
+        B.best_last = (int)best_last;
+    }
+    sync(tm);
+    for(int i = tm.tid; i < nb * nn; i += tm.n) { // c
+        const int bi = i >> (2 * log2n), q = i & (nn - 1);
+        const Blk &B = b[bi];
+        if(B.on) B.lev[scan[q]] = q < B.best_last ? B.rec[q] : (pel)0;
+    }
+    for(int i = tm.tid; i < nb; i += tm.n) { // d
+        Blk &B = b[i];
+        if(!B.on) continue;
+        const pel *sc = B.rec;
+        int run = 0, nnz = 0;
+        for(int q = 0; q < B.best_last; q++) {
+            const int v = sc[q];
+            if(!v) {
+                run++;
+                continue;
+            }
+            B.ev[nnz++] = ev_pack(v, run, q == nn - 1);
+            run = 0;
+        }
+        B.nnz = nnz, B.nev = nnz;
+    }
 }
 // xeve_dquant (xeve_itdq.c:442-475) of the levels into coef, for the blocks that have any
 XW void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
@@ -704,8 +837,8 @@ XW void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
         const int bi = i >> (2 * log2n), e = i & (nn - 1);
         Blk &B = b[bi];
         if(!B.on || !B.nnz) continue;
-        const int64_t l = ((int64_t)B.s->lev[e] * p.dq_scale[B.comp] + offset) >> shift;
-        B.s->coef[e] = (int16_t)(l < -32768 ? -32768 : l > 32767 ? 32767 : l);
+        const int64_t l = ((int64_t)B.lev[e] * p.dq_scale[B.comp] + offset) >> shift;
+        B.coef[e] = (int16_t)(l < -32768 ? -32768 : l > 32767 ? 32767 : l);
     }
 }
 // xeve_recon_blk (xeve_recon.c:34-57: the sum wraps to s16 before the clip) + SSD(reconstruction, original)
@@ -717,8 +850,8 @@ XW void st_recon(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
         Blk &B = b[bi];
         if(!B.on) continue;
         const pel *o = B.org + (long)y * B.s_org + x, *q = B.pred + e;
-        const int16_t *r = B.s->coef + e;
-        pel *d = B.s->rec + e;
+        const int16_t *r = B.coef + e;
+        pel *d = B.rec + e;
         u64 acc = 0;
         for(int t = 0; t < g; t++) {
             const int16_t w = B.nnz ? (int16_t)(r[t] + q[t]) : q[t];

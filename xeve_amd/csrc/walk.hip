@@ -74,7 +74,8 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
     const int C = C_env < 1 ? 1 : C_env > XW_MAXC ? XW_MAXC : C_env, NT = NT_env < 64 ? 64 : NT_env > XW_NT ? XW_NT : (NT_env & ~63);
     xw::P q;
     xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
-    q.C = C, q.full = !xh_count_states();
+    static const int force_count = getenv("XEVE_HIP_WALK_COUNT") ? atoi(getenv("XEVE_HIP_WALK_COUNT")) : 0; // (probes: the encoder's count-only states from any caller)
+    q.C = C, q.full = !xh_count_states() && !force_count;
     {
         std::lock_guard<std::mutex> lk(g_walk.mu);
         WalkDev &D = g_walk;

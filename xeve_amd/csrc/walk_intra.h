@@ -12,7 +12,6 @@ enum { SH_ON = 0, SH_X, SH_Y, SH_PIC, SH_MPM, SH_CNT, SH_LIST, SH_BEST = SH_LIST
 #define XW_COD_IF(m) (((m) >> 15) & 1u)
 #define XW_COD_COD(m) (((m) >> 31) & 1u)
 
-XW int coder_lanes(const Tm &tm) { return imin(tm.n, XW_CODL); }
 
 // the head of an intra CU (xeve_rdo_bit_cnt_cu_intra*, xeve_mode.c:81-175): skip flag and pred_mode outside I slices, the mode as its rank among the most probable
 template <bool FULL> XW void cod_intra_head(Cod &c, const P &p, int rank)
@@ -123,23 +122,25 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
             const pel *o = p.org[0] + (long)sh[SH_PIC] * p.org_pic_l + (long)(sh[SH_Y] + ty) * p.s_org_l + sh[SH_X] + tx;
             aadd(&S.acc[k * XW_ACC + m], had_tile(o, p.s_org_l, W.ipred[m] + ty * N + tx, N, ts));
         }
-        const int cl = coder_lanes(tm);
-        if(tm.tid < cl)
-            for(int j = tm.tid; j < nC * 5; j += cl) {
-                const int k = j / 5, m = j - k * 5;
-                if(!S.sh[k][SH_ON]) continue;
-                Cod c;
-                cod_load(c, p.cw[c0 + k].curr[L], S.ctx + tm.tid, XW_CODL);
-                cod_reset(c);
-                cod_unary2<FULL>(c, (unsigned)mpm_rank(S.sh[k][SH_MPM], m), XEVE_HIP_CTX_INTRA_DIR);
-                S.acc[k * XW_ACC + 8 + m] = (int)cod_bits<FULL>(c);
-            }
         for(int i = tm.tid; i < nC * 28; i += tm.n) {
             const int k = i / 28, e = i - k * 28;
             if(S.sh[k][SH_ON]) est_entry(p, p.cw[c0 + k].curr[L], e, S.est[k]);
         }
     }
     sync(tm), mark(tm, p, S, PR_I_SATD);
+    coder_stage<FULL>(
+        tm, S, nC * 5,
+        [&](int j, const Sbac *&in, Sbac *&out) {
+            const int k = j / 5;
+            in = &p.cw[c0 + k].curr[L], out = nullptr;
+            return S.sh[k][SH_ON] != 0;
+        },
+        [&](int j, Cod &c) {
+            const int k = j / 5, m = j - k * 5;
+            cod_unary2<FULL>(c, (unsigned)mpm_rank(S.sh[k][SH_MPM], m), XEVE_HIP_CTX_INTRA_DIR);
+            S.acc[k * XW_ACC + 8 + m] = (int)cod_bits<FULL>(c);
+        });
+    mark(tm, p, S, PR_I_BITS);
     // F: make_ipred_list (xeve_pintra.c:308-374) per chain; the luma blocks of the list
     for(int k = tm.tid; k < nC; k += tm.n) {
         if(!S.sh[k][SH_ON]) continue;
@@ -174,34 +175,27 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
         Blk &B = S.blk[i];
         B.on = sh[SH_ON] && sl < sh[SH_CNT];
         B.org = p.org[0] + (long)sh[SH_PIC] * p.org_pic_l + (long)sh[SH_Y] * p.s_org_l + sh[SH_X], B.s_org = p.s_org_l;
-        B.pred = W.ipred[sh[SH_ON] ? sh[SH_LIST + sl] : 0], B.s = &W.slot[sl], B.comp = 0, B.nnz = 0, B.nev = 0, B.k = k, B.is_intra = 1, B.ssd[0] = B.ssd[1] = 0;
+        B.pred = W.ipred[sh[SH_ON] ? sh[SH_LIST + sl] : 0], blk_slot(B, &W.slot[sl]), B.comp = 0, B.nnz = 0, B.nev = 0, B.k = k, B.is_intra = 1, B.ssd[0] = B.ssd[1] = 0;
     }
     sync(tm), mark(tm, p, S, PR_I_LIST);
     // G: the luma RDO of the list (:604-637; pintra_residue_rdo mode 0)
     blocks_chain(tm, p, S, S.blk, nC * 5, log2n, 0);
-    {
-        const int cl = coder_lanes(tm);
-        if(tm.tid < cl)
-            for(int j = tm.tid; j < nC * 5; j += cl) {
-                const Blk &B = S.blk[j];
-                if(!B.on) continue;
-                const int k = j / 5, sl = j - k * 5;
-                Cod c;
-                mark(tm, p, S, PR_E_CAND);
-                cod_load(c, p.cw[c0 + k].curr[L], S.ctx + tm.tid, XW_CODL);
-                mark(tm, p, S, PR_E_SKIP);
-                cod_reset(c);
-                cod_intra_head<FULL>(c, p, mpm_rank(S.sh[k][SH_MPM], S.sh[k][SH_LIST + sl]));
-                mark(tm, p, S, PR_E_ME);
-                CoefSet q;
-                q.ev[0] = B.s->ev, q.nev[0] = B.nev, q.nnz[0] = B.nnz, q.ev[1] = q.ev[2] = nullptr, q.nev[1] = q.nev[2] = q.nnz[1] = q.nnz[2] = 0;
-                cod_coef<FULL>(c, p.idc, q, 1, 1); // xeve_rdo_bit_cnt_cu_intra_luma (xeve_mode.c:81-117)
-                S.acc[k * XW_ACC + 8 + sl] = (int)cod_bits<FULL>(c);
-                mark(tm, p, S, PR_E_SPEL);
-                if(tm.tid == 0 && p.prof) p.prof[PR_E_MC] += B.nev, p.prof[PR_N + PR_E_MC] += 1;
-            }
-    }
-    sync(tm), mark(tm, p, S, PR_I_BITS);
+    coder_stage<FULL>(
+        tm, S, nC * 5,
+        [&](int j, const Sbac *&in, Sbac *&out) {
+            in = &p.cw[c0 + j / 5].curr[L], out = nullptr;
+            return S.blk[j].on != 0;
+        },
+        [&](int j, Cod &c) {
+            const Blk &B = S.blk[j];
+            const int k = j / 5, sl = j - k * 5;
+            cod_intra_head<FULL>(c, p, mpm_rank(S.sh[k][SH_MPM], S.sh[k][SH_LIST + sl]));
+            CoefSet q;
+            q.ev[0] = B.ev, q.nev[0] = B.nev, q.nnz[0] = B.nnz, q.ev[1] = q.ev[2] = nullptr, q.nev[1] = q.nev[2] = q.nnz[1] = q.nnz[2] = 0;
+            cod_coef<FULL>(c, p.idc, q, 1, 1); // xeve_rdo_bit_cnt_cu_intra_luma (xeve_mode.c:81-117)
+            S.acc[k * XW_ACC + 8 + sl] = (int)cod_bits<FULL>(c);
+        });
+    mark(tm, p, S, PR_I_BITS);
     // H: the luma decision (first strictly smallest cost); the chroma blocks of the winner's mode
     for(int k = tm.tid; k < nC; k += tm.n) {
         if(!S.sh[k][SH_ON]) continue;
@@ -229,7 +223,7 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
             Blk &B = cb[i];
             B.on = sh[SH_ON];
             B.org = p.org[c] + (long)sh[SH_PIC] * p.org_pic_c + (long)(sh[SH_Y] >> p.hs) * p.s_org_c + (sh[SH_X] >> p.ws), B.s_org = p.s_org_c;
-            B.pred = W.cpred[c - 1], B.s = &W.slot[4 + c], B.comp = c, B.nnz = 0, B.nev = 0, B.k = k, B.is_intra = 1, B.ssd[0] = B.ssd[1] = 0;
+            B.pred = W.cpred[c - 1], blk_slot(B, &W.slot[4 + c]), B.comp = c, B.nnz = 0, B.nev = 0, B.k = k, B.is_intra = 1, B.ssd[0] = B.ssd[1] = 0;
         }
         for(int i = tm.tid; i < nC * 2 * n1; i += tm.n) {
             const int px = i % n1, kc = i / n1, k = kc >> 1, c = 1 + (kc & 1);
@@ -250,41 +244,38 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
         blocks_chain(tm, p, S, cb, nC * 2, lc, 0); // pintra_residue_rdo mode 1 (:150-269)
     }
     // I: the CU's cost (:679-695): the whole syntax from the entry state; its exit state is core->s_temp_best
-    {
-        const int cl = coder_lanes(tm);
-        if(tm.tid < cl)
-            for(int k = tm.tid; k < nC; k += cl) {
-                if(!S.sh[k][SH_ON]) continue;
-                Cw &W = p.cw[c0 + k];
-                const Blk &Y = S.blk[k * 5 + S.sh[k][SH_BEST]];
-                Cod c;
-                cod_load(c, W.curr[L], S.ctx + tm.tid, XW_CODL);
-                cod_reset(c);
-                cod_intra_head<FULL>(c, p, mpm_rank(S.sh[k][SH_MPM], S.sh[k][SH_IPD]));
-                CoefSet q;
-                q.ev[0] = Y.s->ev, q.nev[0] = Y.nev, q.nnz[0] = Y.nnz;
-                for(int cc = 1; cc < 3; cc++) {
-                    const Blk &B = cb[k * 2 + cc - 1];
-                    q.ev[cc] = ncomp > 1 ? B.s->ev : nullptr, q.nev[cc] = ncomp > 1 ? B.nev : 0, q.nnz[cc] = ncomp > 1 ? B.nnz : 0;
-                }
-                cod_coef<FULL>(c, p.idc, q, 7, 1);
-                cod_store<FULL>(c, W.sbest);
-                int dist_c = 0;
-                if(ncomp > 1) { // (xeve_pintra.c:216-233, :266: the weighted sum as a double, then (s32))
-                    double d = 0;
-                    d += p.wgt[0] * (double)(int64_t)cb[k * 2].ssd[1];
-                    d += p.wgt[1] * (double)(int64_t)cb[k * 2 + 1].ssd[1];
-                    dist_c = (int)d;
-                }
-                const int dist_y = W.ires.dist_cu;
-                double cost = (double)(int)cod_bits<FULL>(c) * p.lambda[0];
-                cost += dist_y;
-                if(ncomp > 1) cost += dist_c;
-                W.ires.cost = cost, W.ires.dist_cu = dist_y + (ncomp > 1 ? dist_c : 0);
-                W.ires.nnz[1] = ncomp > 1 ? cb[k * 2].nnz : 0, W.ires.nnz[2] = ncomp > 1 ? cb[k * 2 + 1].nnz : 0;
+    coder_stage<FULL>(
+        tm, S, nC,
+        [&](int k, const Sbac *&in, Sbac *&out) {
+            in = &p.cw[c0 + k].curr[L], out = &p.cw[c0 + k].sbest;
+            return S.sh[k][SH_ON] != 0;
+        },
+        [&](int k, Cod &c) {
+            Cw &W = p.cw[c0 + k];
+            const Blk &Y = S.blk[k * 5 + S.sh[k][SH_BEST]];
+            cod_intra_head<FULL>(c, p, mpm_rank(S.sh[k][SH_MPM], S.sh[k][SH_IPD]));
+            CoefSet q;
+            q.ev[0] = Y.ev, q.nev[0] = Y.nev, q.nnz[0] = Y.nnz;
+            for(int cc = 1; cc < 3; cc++) {
+                const Blk &B = cb[k * 2 + cc - 1];
+                q.ev[cc] = ncomp > 1 ? B.ev : nullptr, q.nev[cc] = ncomp > 1 ? B.nev : 0, q.nnz[cc] = ncomp > 1 ? B.nnz : 0;
             }
-    }
-    sync(tm), mark(tm, p, S, PR_I_FINAL);
+            cod_coef<FULL>(c, p.idc, q, 7, 1);
+            int dist_c = 0;
+            if(ncomp > 1) { // (xeve_pintra.c:216-233, :266: the weighted sum as a double, then (s32))
+                double d = 0;
+                d += p.wgt[0] * (double)(int64_t)cb[k * 2].ssd[1];
+                d += p.wgt[1] * (double)(int64_t)cb[k * 2 + 1].ssd[1];
+                dist_c = (int)d;
+            }
+            const int dist_y = W.ires.dist_cu;
+            double cost = (double)(int)cod_bits<FULL>(c) * p.lambda[0];
+            cost += dist_y;
+            if(ncomp > 1) cost += dist_c;
+            W.ires.cost = cost, W.ires.dist_cu = dist_y + (ncomp > 1 ? dist_c : 0);
+            W.ires.nnz[1] = ncomp > 1 ? cb[k * 2].nnz : 0, W.ires.nnz[2] = ncomp > 1 ? cb[k * 2 + 1].nnz : 0;
+        });
+    mark(tm, p, S, PR_I_FINAL);
 }
 
 } // namespace xw

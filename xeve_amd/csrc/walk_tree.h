@@ -137,7 +137,7 @@ template <bool FULL> XW void op_enter(const Tm &tm, const P &p, Lds &S, int c0, 
                 if(leaf) {
                     if(cu > p.min_cuwh) { // split_cu_flag = 0 (:2079-2091)
                         Sbac run;
-                        cost_temp += (double)(int)split_flag_bits<FULL>(W.curr[L], run, 0, S.ctx + (tm.tid & (XW_CODL - 1)), XW_CODL) * p.lambda[0];
+                        cost_temp += (double)(int)split_flag_bits<FULL>(W.curr[L], run, 0) * p.lambda[0];
                         W.curr[L] = run;
                     }
                 }
@@ -244,7 +244,7 @@ XW void op_leaf(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L, bool fu
         nd->do_split = do_split;
         if(do_split) { // SPLIT_QUAD (:2189-2329): split_cu_flag = 1 from the node's entry state
             Sbac run;
-            const unsigned bits = full ? split_flag_bits<true>(W.before[L], run, 1, S.ctx + (tm.tid & (XW_CODL - 1)), XW_CODL) : split_flag_bits<false>(W.before[L], run, 1, S.ctx + (tm.tid & (XW_CODL - 1)), XW_CODL);
+            const unsigned bits = full ? split_flag_bits<true>(W.before[L], run, 1) : split_flag_bits<false>(W.before[L], run, 1);
             nd->cost_temp = (double)(int)bits * p.lambda[0];
             W.curr[L] = run;
         }
