@@ -22,10 +22,12 @@ int xw_host_walk(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xev
     xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
     const std::vector<xw::Op> ops = xw::make_ops(p, I != nullptr);
     std::vector<xw::Cw> cw((size_t)nchains);
+    memset((void *)cw.data(), 0xCD, cw.size() * sizeof(xw::Cw)); // (the device's workspace and LDS start with whatever was there: nothing may depend on zeros)
     q.C = C < 1 ? 1 : C > XW_MAXC ? XW_MAXC : C, q.full = full;
     q.entropy = T.entropy.data(), q.dct = T.dct.data(), q.scan = T.scan.data(), q.ops = ops.data(), q.nops = (int)ops.size(), q.cw = cw.data();
     if(I) q.mc_l = &I->coef_l[0][0], q.mc_c = I->coef_c ? &I->coef_c[0][0] : nullptr;
-    xw::Lds *S = (xw::Lds *)calloc(1, sizeof(xw::Lds));
+    xw::Lds *S = (xw::Lds *)malloc(sizeof(xw::Lds));
+    memset((void *)S, 0xCD, sizeof(xw::Lds));
     const xw::Tm tm = {0, 1};
     for(int team = 0; team * q.C < nchains; team++) {
         if(full) xw::walk_team<true>(tm, q, *S, team);

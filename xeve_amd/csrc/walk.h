@@ -42,7 +42,7 @@ typedef unsigned long long u64;
 
 #define XW_MAXC 16  // chains per team
 #define XW_NT 256   // threads per team on the device
-#define XW_CODL 128 // lanes of a team that can run the coder at once (their models live in LDS)
+#define XW_CODL 96  // lanes of a team that can run the coder at once (their models live in LDS)
 #define XW_MAXR XEVE_HIP_MAX_REFP
 #define XW_MAX_COST 1.7e+308
 #define XW_NB 136   // one neighbour line: [0] = the corner sample, then up to 2 * 64 samples (+ slack)
@@ -180,6 +180,7 @@ struct P { // one call
     const int16_t (*col0)[2][2], (*col1)[2][2];
     const int16_t *mc_l, *mc_c; // [16][8], [32][4]
     u64 *prof;                  // [PR_N] cycles + [PR_N] marks, or null
+    int  dbg;                   // debugging: the inter analysis stops after stage `dbg` (0: runs whole)
 };
 XW int dct_off(int log2n) { return ((1 << (2 * log2n)) - 4) / 3; }       // 0, 4, 20, 84, 340, 1364 (log2n 1 .. 6)
 #define XW_DCT_ELEMS (4 + 16 + 64 + 256 + 1024 + 4096)

@@ -7,7 +7,7 @@
 #include "xh_common.h"
 #include "walk_setup.h"
 
-template <bool FULL> __global__ void __launch_bounds__(XW_NT) k_walk(xw::P p)
+template <bool FULL> __global__ void __launch_bounds__(XW_NT, 2) k_walk(xw::P p)
 {
     __shared__ xw::Lds S;
     const xw::Tm tm = {(int)threadIdx.x, (int)blockDim.x};
@@ -54,7 +54,7 @@ bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter 
 {
     if(!xh_walk_enabled()) return false;
     if(p->ip.slice_type != 2 && I) {
-        static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 0;
+        static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 1;
         if(!inter_on) return false;
         const int n0 = I->ipar.rdo.num_refp[0], n1 = I->ipar.rdo.num_refp[1];
         if(n0 > XW_MAXR || n1 > XW_MAXR) return false;
@@ -123,6 +123,8 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
         }
         q.prof = D.prof;
     }
+    static const int dbg = getenv("XEVE_HIP_WALK_DBG") ? atoi(getenv("XEVE_HIP_WALK_DBG")) : 0;
+    q.dbg = dbg;
     q.cw = (xw::Cw *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const int teams = (nchains + C - 1) / C;
     if(q.full) k_walk<true><<<teams, NT, 0, st>>>(q);

@@ -253,6 +253,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
         }
     }
     sync(tm), mark(tm, p, S, PR_E_CAND);
+    if(p.dbg == 1) return;
     // ---- skip / merge (xeve_analyze_skip, xeve_pinter.c:1337-1530): every candidate's uni-directional prediction once ...
     {
         const int ncl = isb ? 2 : 1, per = N + (ncomp > 1 ? 2 * Nc : 0), pk = ncl * p.max_cand * per;
@@ -264,6 +265,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
             mc_uni_column(p, I.x, I.y, N, I.pic, l, 0, I.mvp[l][idx], c, col, p.cw[c0 + k].upred[l][idx][c]);
         }
         sync(tm);
+        if(p.dbg == 21) return;
         // ... the SSD of every pair (idx0, idx1) against the original, per component (a lane per (chain, pair, component))
         const int np = p.max_cand * (isb ? p.max_cand : 1);
         for(int i = tm.tid; i < nC * np * ncomp; i += tm.n) {
@@ -285,6 +287,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
                 }
             W.sk_ssd[pr][c] = acc;
         }
+        if(p.dbg == 22) { sync(tm); return; }
         // the pairs' bits: skip flag + candidate indices from the CU's entry state (xeve_rdo_bit_cnt_cu_skip, xeve_mode.c:276-295)
         int *sbits = S.acc; // [chain][pair]
         coder_stage<FULL>(
@@ -301,6 +304,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
                 if(isb) cod_mvp_idx<FULL>(c, i1);
                 sbits[k * 16 + pr] = (int)cod_bits<FULL>(c);
             });
+        if(p.dbg == 23) return;
         // the first pair with the strictly smallest cost; does the CU go on (:1885-1887); the direct candidate (analyze_t_direct + xeve_get_mv_dir)
         for(int k = tm.tid; k < nC; k += tm.n) {
             ISt &I = S.ist[k];
@@ -334,6 +338,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
             }
         }
         sync(tm);
+        if(p.dbg == 24) return;
         // the skip winner's prediction kept (pi->pred[PRED_SKIP])
         for(int i = tm.tid; i < nC * (n0 + 2 * n1); i += tm.n) {
             const int k = i / (n0 + 2 * n1), e = i - k * (n0 + 2 * n1), c = e < n0 ? 0 : e < n0 + n1 ? 1 : 2, q = c == 0 ? e : c == 1 ? e - n0 : e - n0 - n1;
@@ -341,12 +346,16 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
             if(!I.on || I.cost_inter[M_SKIP] >= XW_MAX_COST) continue;
             Cw &W = p.cw[c0 + k];
             const int i0 = I.mvpi[M_SKIP][0], i1 = I.mvpi[M_SKIP][1];
-            const bool two = isb && !mc_identical(p, I.x, I.y, N, I.refi[M_SKIP], I.mv[M_SKIP]);
-            W.spred[c][q] = (pel)(two ? (W.upred[0][i0][c][q] + W.upred[1][i1][c][q] + 1) >> 1 : W.upred[0][i0][c][q]);
+            const int8_t  rf[2] = {I.refi[M_SKIP][0], I.refi[M_SKIP][1]};
+            const int16_t mvv[2][2] = {{I.mv[M_SKIP][0][0], I.mv[M_SKIP][0][1]}, {I.mv[M_SKIP][1][0], I.mv[M_SKIP][1][1]}};
+            const bool two = isb && !mc_identical(p, I.x, I.y, N, rf, mvv);
+            const pel *a = W.upred[0][i0][c], *b = W.upred[1][isb ? i1 : 0][c];
+            W.spred[c][q] = (pel)(two ? (a[q] + b[q] + 1) >> 1 : a[q]);
         }
         sync(tm);
     }
     mark(tm, p, S, PR_E_SKIP);
+    if(p.dbg == 2) return;
     // ---- the motion search per list over every reference picture (:1906-1950)
     const int nl = 1 + isb, nrmax = imax(p.nref[0], p.nref[1]);
     {
@@ -380,6 +389,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
             }
     }
     mark(tm, p, S, PR_E_ME);
+    if(p.dbg == 3) return;
     // ---- check_best_mvp (:1773-1837): the bits of mvp_idx + mvd for the entry index, then for every index
     {
         for(int k = tm.tid; k < nC; k += tm.n) {
@@ -430,11 +440,13 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
         sync(tm);
     }
     mark(tm, p, S, PR_E_GLUE);
+    if(p.dbg == 4) return;
     // ---- pinter_residue_rdo of direct + L0 + L1 side by side
     {
         const int mB[3] = {M_DIR, M_L0, M_L1}, mP[1] = {M_L0};
         residue_rdo<FULL>(tm, p, S, c0, nC, L, isb ? mB : mP, isb ? 3 : 1);
     }
+    if(p.dbg == 5) return;
     // ---- analyze_bi (:1567-1714)
     if(isb) {
         const int nb = p.nref[1]; // pi->num_refp as the list-1 search left it
@@ -524,6 +536,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
         const int mBI[1] = {M_BI};
         residue_rdo<FULL>(tm, p, S, c0, nC, L, mBI, 1);
     }
+    if(p.dbg == 6) return;
     // ---- the decision (:1872-2001): first strictly smaller cost in the order skip, direct, L0, L1, bi; the winner's data
     for(int k = tm.tid; k < nC; k += tm.n) {
         ISt &I = S.ist[k];
@@ -593,6 +606,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
         sync(tm);
     }
     mark(tm, p, S, PR_E_FINAL);
+    if(p.dbg == 7) return;
     // core->s_next_best: the winner's syntax once more from the CU's entry state, the state kept (every candidate evaluation above only counted)
     coder_stage<FULL>(
         tm, S, nC,
