@@ -67,6 +67,14 @@ def main():
         print(json.dumps({"steps": [done - n, done], "picture": (done - 1) // per_pic, "wall_ms_per_step": round(1e3 * dt / n, 2),
                           "host_issue_ms_per_step": round(1e3 * (st1["step_seconds"] - st0["step_seconds"]) / n, 2),
                           "picture_end_s": round(st1["picture_end_seconds"] - st0["picture_end_seconds"], 2)}), flush=True)
+    if os.environ.get("XEVE_HIP_WALK_PROF"):
+        from tools.probe_walk import prof
+        rows = prof()
+        tot = sum(r[1] for r in rows) or 1
+        print("walk profile of team 0 over the whole run: %.0f cycles" % tot)
+        for name, cyc, marks in sorted(rows, key=lambda r: -r[1]):
+            if marks:
+                print("  %-12s %6.2f %%  %12d cycles  %7d marks  %8.0f cycles/mark" % (name, 100.0 * cyc / tot, cyc, marks, cyc / marks))
     print(json.dumps({"total_steps": total, "per_picture": per_pic, "chains": G * min(a.threads, (H + 63) // 64), "stats": enc.stats(),
                       "bytes": [len(s) for s in enc.bitstreams()][:4] if left == 0 else None,
                       "md5_of_all": hashlib.md5(b"".join(enc.bitstreams())).hexdigest() if left == 0 else None}), flush=True)

@@ -102,6 +102,7 @@ struct Slot {
     int16_t  lev[4096];  // quantised levels (what is coded)
     pel      rec[4096];  // reconstruction
     uint32_t ev[4096];   // the levels as (zero run, |level| - 1, sign, at-the-end) events in scan order
+    int64_t  rq[2][4096]; // RDOQ: per scan position, cost of the best level minus cost of no level, after a non-zero / after a zero (the run state)
 };
 struct IntraRes {
     double  cost;
@@ -194,13 +195,14 @@ struct Blk { // one transform block of a stage; its scratch arrays (a Slot of th
     int32_t   *tb;         // between the two passes of a transform
     pel       *rec;        // reconstruction (RDOQ's scan-ordered buffer before that)
     uint32_t  *ev;         // the levels as events
+    int64_t   *rq;         // RDOQ scratch: [2][n]
     int        s_org, comp, on, nnz, nev, k, is_intra, any;
     int        sum_all, best_last;
     u64        ssd[2]; // SSD(prediction, original), SSD(reconstruction, original)
     u64        unc;    // RDOQ: the block's distortion with every level zero
 };
 
-XW void blk_slot(Blk &B, Slot *s) { B.coef = s->coef, B.lev = s->lev, B.tb = s->tb, B.rec = s->rec, B.ev = s->ev; }
+XW void blk_slot(Blk &B, Slot *s) { B.coef = s->coef, B.lev = s->lev, B.tb = s->tb, B.rec = s->rec, B.ev = s->ev, B.rq = &s->rq[0][0]; }
 
 enum { M_L0 = 0, M_L1 = 1, M_BI = 2, M_SKIP = 3, M_DIR = 4, M_NUM = 5 }; // PRED_* (xeve_def.h:461-469)
 struct ISt { // the inter analysis of one chain's CU, between the stages
@@ -656,6 +658,40 @@ XW void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
         if(want_ssd) aadd64(&B.ssd[0], acc);
     }
 }
+// four (G) outputs of a transform pass: acc[t] = sum_i m[i * ms + t] * v[i * vs], i < n.  The loads of eight terms are issued together (a pass is a chain of
+// memory round trips otherwise); an s32 source is split at 14 bits so that both partial sums stay in s32 (|v| < 2^29, n <= 64, |m| <= 90) -- exact.
+template <class T> XW void dot4(const int8_t *m, int ms, const T *v, int vs, int n, int G, int64_t acc[4])
+{
+    constexpr bool wide = sizeof(T) == 4;
+    int32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    int i = 0;
+    if(G == 4)
+        for(; i + 8 <= n; i += 8) {
+            int32_t  x[8];
+            uint32_t w[8];
+#pragma unroll
+            for(int t = 0; t < 8; t++) x[t] = (int32_t)v[(i + t) * vs], w[t] = *reinterpret_cast<const uint32_t *>(m + (i + t) * ms);
+#pragma unroll
+            for(int t = 0; t < 8; t++) {
+                const int32_t xl = wide ? (x[t] & 16383) : x[t], xh = wide ? (x[t] >> 14) : 0;
+#pragma unroll
+                for(int q = 0; q < 4; q++) {
+                    const int32_t c = (int8_t)(w[t] >> (8 * q));
+                    lo[q] += c * xl;
+                    if(wide) hi[q] += c * xh;
+                }
+            }
+        }
+    for(; i < n; i++) {
+        const int32_t x = (int32_t)v[i * vs], xl = wide ? (x & 16383) : x, xh = wide ? (x >> 14) : 0;
+        for(int q = 0; q < G; q++) {
+            const int32_t c = m[i * ms + q];
+            lo[q] += c * xl;
+            if(wide) hi[q] += c * xh;
+        }
+    }
+    for(int q = 0; q < 4; q++) acc[q] = wide ? ((int64_t)hi[q] << 14) + lo[q] : (int64_t)lo[q];
+}
 // one pass of a transform over every block: pass 0 / 1 = xeve_trans rows / columns (xeve_tq.c:396-404), 2 / 3 = xeve_itrans (xeve_itdq.c:435-440)
 XW void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
 {
@@ -666,50 +702,26 @@ XW void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
         const int bi = i / per, e = i - bi * per, j = e / (N / G), g0 = (e - j * (N / G)) * G;
         Blk &B = b[bi];
         if(!B.on || (pass >= 2 && !B.nnz)) continue;
-        const Blk *s = &B;
+        int64_t a[4];
         if(pass == 0) { // tb[k * N + j] = sum_x M[k][x] * coef[j * N + x]
-            int32_t a[4] = {0, 0, 0, 0};
-            const int16_t *src = s->coef + j * N;
-            for(int x = 0; x < N; x++) {
-                const int v = src[x];
-                const int8_t *m = Mt + x * N + g0;
-                for(int t = 0; t < G; t++) a[t] += (int32_t)m[t] * v;
-            }
-            for(int t = 0; t < G; t++) s->tb[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? 0 : a[t];
+            dot4(Mt + g0, N, B.coef + j * N, 1, N, G, a);
+            for(int t = 0; t < G; t++) B.tb[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? 0 : (int32_t)a[t];
         }
         else if(pass == 1) { // coef[k * N + j] = (sum_x M[k][x] * tb[j * N + x] + add) >> shift
-            int64_t a[4] = {0, 0, 0, 0};
-            const int32_t *src = s->tb + j * N;
-            for(int x = 0; x < N; x++) {
-                const int64_t v = src[x];
-                const int8_t *m = Mt + x * N + g0;
-                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
-            }
+            dot4(Mt + g0, N, B.tb + j * N, 1, N, G, a);
             const int64_t add = (int64_t)1 << (fshift - 1);
-            for(int t = 0; t < G; t++) s->coef[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? (int16_t)0 : (int16_t)((a[t] + add) >> fshift);
+            for(int t = 0; t < G; t++) B.coef[(g0 + t) * N + j] = (N == 64 && g0 + t >= 32) ? (int16_t)0 : (int16_t)((a[t] + add) >> fshift);
         }
-        else if(pass == 2) { // tb[j * N + x] = clip32(sum_k M[k][x] * coef[k * N + j])
-            int64_t a[4] = {0, 0, 0, 0};
-            const int K = N == 64 ? 32 : N; // (the 64-point inverse reads the 32 rows a forward transform can leave)
-            for(int k = 0; k < K; k++) {
-                const int64_t v = s->coef[k * N + j];
-                const int8_t *m = M + k * N + g0;
-                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
-            }
-            for(int t = 0; t < G; t++) s->tb[j * N + g0 + t] = (int32_t)(a[t] < INT32_MIN ? INT32_MIN : a[t] > INT32_MAX ? INT32_MAX : a[t]);
+        else if(pass == 2) { // tb[j * N + x] = clip32(sum_k M[k][x] * coef[k * N + j]); (the 64-point inverse reads the 32 rows a forward transform can leave)
+            dot4(M + g0, N, B.coef + j, N, N == 64 ? 32 : N, G, a);
+            for(int t = 0; t < G; t++) B.tb[j * N + g0 + t] = (int32_t)(a[t] < INT32_MIN ? INT32_MIN : a[t] > INT32_MAX ? INT32_MAX : a[t]);
         }
         else { // coef[j * N + x] = clip16((sum_k M[k][x] * tb[k * N + j] + add) >> shift)
-            int64_t a[4] = {0, 0, 0, 0};
-            const int K = N == 64 ? 32 : N;
-            for(int k = 0; k < K; k++) {
-                const int64_t v = s->tb[k * N + j];
-                const int8_t *m = M + k * N + g0;
-                for(int t = 0; t < G; t++) a[t] += (int64_t)m[t] * v;
-            }
+            dot4(M + g0, N, B.tb + j, N, N == 64 ? 32 : N, G, a);
             const int64_t add = (int64_t)1 << (ishift - 1);
             for(int t = 0; t < G; t++) {
                 const int64_t v = (a[t] + add) >> ishift;
-                s->coef[j * N + g0 + t] = (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+                B.coef[j * N + g0 + t] = (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
             }
         }
     }
@@ -756,53 +768,75 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
         int64_t  ld;
         uint32_t m;
         rdoq_level(v, q_value, q_bits, (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1)), ld, m);
-        const int64_t err = (ld * p.err_scale[comp][log2n]) >> 20;
-        aadd64(&B.unc, (u64)(err * err));
+        const int64_t es = p.err_scale[comp][log2n], err = (ld * es) >> 20, uncoded = err * err;
+        aadd64(&B.unc, (u64)uncoded);
         if(m) aadd(&B.sum_all, (int)m);
+        // get_coded_level_rl (xeve_tq.c:458-490) for both run states: the best level and what it costs beyond coding nothing
+        const int32_t *est = S.est[B.k];
+        const int c = comp ? 2 : 0;
+        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5);
+        const int16_t  mx = (int16_t)(v > 0 ? (int16_t)m : -(int16_t)m);
+        const uint32_t max_abs = (uint32_t)iabs(mx), lo = max_abs > 1 ? max_abs - 1 : 1;
+        uint32_t packed = 0;
+        for(int rs = 0; rs < 2; rs++) {
+            int64_t  coded = uncoded + rl_cost(0, rs, c, lambda, est);
+            uint32_t best = 0;
+            for(uint32_t a = max_abs; a >= lo; a--) {
+                const int64_t d = ld - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, rs, c, lambda, est);
+                if(cost < coded) best = a, coded = cost;
+            }
+            B.rq[rs * nn + q] = coded - uncoded, packed |= (best & 0xFFFFu) << (16 * rs);
+        }
+        B.tb[q] = (int32_t)packed;
     }
     sync(tm);
     for(int i = tm.tid; i < nb; i += tm.n) { // b
         Blk &B = b[i];
         if(!B.on || !B.any || !B.sum_all) continue;
-        const int comp = B.comp, qp = p.qp[comp], q_value = p.q_scale[comp], q_bits = 14 + (15 - bd - log2n) + qp / 6, c = comp ? 2 : 0, ctx_last = comp ? 1 : 0;
+        const int comp = B.comp, c = comp ? 2 : 0, ctx_last = comp ? 1 : 0;
         const int32_t *est = S.est[B.k];
-        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5), es = p.err_scale[comp][log2n];
-        const int64_t cap = (int64_t)INT32_MAX - ((int64_t)1 << (q_bits - 1));
+        const int64_t lambda = (int64_t)(p.lambda[comp] * (double)(1 << 15) + 0.5);
         const int32_t *cbf = est + (B.is_intra ? (comp == 0 ? E_CBF_L : comp == 1 ? E_CBF_CB : E_CBF_CR) : (comp == 0 ? E_CBF_ALL : comp == 1 ? E_CBF_CB : E_CBF_CR));
         const int64_t z0 = rl_cost(0, 0, c, lambda, est), z1 = rl_cost(0, 1, c, lambda, est), last0 = (int64_t)est[E_LAST + 2 * ctx_last] * lambda;
         const int64_t last1 = (int64_t)est[E_LAST + 2 * ctx_last + 1] * lambda;
         int64_t  best_cost = (int64_t)B.unc + (int64_t)cbf[0] * lambda, base_cost = (int64_t)B.unc + (int64_t)cbf[1] * lambda;
         uint32_t run = 0, best_last = 0;
         pel *sc = B.rec;
-        for(int q = 0; q < nn; q++) {
-            const int v = sc[q];
-            if(!v) { // a zero: the rate of one more zero of the run
-                base_cost += run ? z1 : z0;
-                run++;
-                continue;
+        // (eight positions at a time: their operands are fetched together -- the scan is a chain of memory round trips otherwise)
+        for(int q0 = 0; q0 < nn; q0 += 8) {
+            const int cnt = nn - q0 < 8 ? nn - q0 : 8;
+            int      v8[8];
+            int32_t  t8[8];
+            int64_t  r0[8], r1[8];
+            int      any = 0;
+#pragma unroll
+            for(int t = 0; t < 8; t++) v8[t] = t < cnt ? sc[q0 + t] : 0, any |= v8[t];
+            if(any) {
+#pragma unroll
+                for(int t = 0; t < 8; t++)
+                    if(t < cnt) t8[t] = B.tb[q0 + t], r0[t] = B.rq[q0 + t], r1[t] = B.rq[nn + q0 + t];
             }
-            int64_t  ld;
-            uint32_t m;
-            rdoq_level(v, q_value, q_bits, cap, ld, m);
-            const int16_t  mx = (int16_t)(v > 0 ? (int16_t)m : -(int16_t)m);
-            const uint32_t max_abs = (uint32_t)iabs(mx);
-            const int64_t  e1 = (ld * es) >> 20, uncoded = e1 * e1;
-            int64_t  coded = uncoded + (run ? z1 : z0);
-            uint32_t best = 0;
-            const uint32_t lo = max_abs > 1 ? max_abs - 1 : 1;
-            for(uint32_t a = max_abs; a >= lo; a--) { // get_coded_level_rl (xeve_tq.c:458-490)
-                const int64_t d = ld - ((int64_t)a << q_bits), e2 = (d * es) >> 20, cost = e2 * e2 + rl_cost(a, run != 0, c, lambda, est);
-                if(cost < coded) best = a, coded = cost;
+#pragma unroll
+            for(int t = 0; t < 8; t++) {
+                if(t >= cnt) break;
+                const int v = v8[t];
+                if(!v) { // a zero: the rate of one more zero of the run
+                    base_cost += run ? z1 : z0;
+                    run++;
+                    continue;
+                }
+                const int rs = run != 0;
+                const uint32_t best = ((uint32_t)t8[t] >> (16 * rs)) & 0xFFFFu;
+                sc[q0 + t] = (pel)(v < 0 ? -(int32_t)best : (int32_t)best);
+                base_cost += rs ? r1[t] : r0[t];
+                if(best) {
+                    const int64_t cur_is_last = base_cost + last1;
+                    base_cost += last0;
+                    if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)(q0 + t) + 1;
+                    run = 0;
+                }
+                else run++;
             }
-            sc[q] = (pel)(mx < 0 ? -(int32_t)best : (int32_t)best);
-            base_cost += coded - uncoded;
-            if(best) {
-                const int64_t cur_is_last = base_cost + last1;
-                base_cost += last0;
-                if(cur_is_last < best_cost) best_cost = cur_is_last, best_last = (uint32_t)q + 1;
-                run = 0;
-            }
-            else run++;
         }
         B.best_last = (int)best_last;
     }
@@ -817,14 +851,21 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
         if(!B.on) continue;
         const pel *sc = B.rec;
         int run = 0, nnz = 0;
-        for(int q = 0; q < B.best_last; q++) {
-            const int v = sc[q];
-            if(!v) {
-                run++;
-                continue;
+        for(int q0 = 0; q0 < B.best_last; q0 += 8) {
+            const int cnt = B.best_last - q0 < 8 ? B.best_last - q0 : 8;
+            int v8[8];
+#pragma unroll
+            for(int t = 0; t < 8; t++) v8[t] = t < cnt ? sc[q0 + t] : 0;
+#pragma unroll
+            for(int t = 0; t < 8; t++) {
+                if(t >= cnt) break;
+                if(!v8[t]) {
+                    run++;
+                    continue;
+                }
+                B.ev[nnz++] = ev_pack(v8[t], run, q0 + t == nn - 1);
+                run = 0;
             }
-            B.ev[nnz++] = ev_pack(v, run, q == nn - 1);
-            run = 0;
         }
         B.nnz = nnz, B.nev = nnz;
     }

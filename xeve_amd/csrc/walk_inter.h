@@ -28,6 +28,29 @@ XW int mvd_bits(int mvd)
 }
 
 // ---- motion compensation (xeve_mc.c:99-381, 401-610) ------------------------------------------------------------------------------------------------------------
+// sum_t c[t] * r[t] over the taps of one filter position: the samples come in with ONE (unaligned) vector load instead of a load per tap
+template <int TAPS> XW int dot_taps(const int16_t *c, const pel *r)
+{
+#if XW_DEVICE
+    if(TAPS == 8) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4    u32x4_a2 __attribute__((aligned(2)));
+        const u32x4 v = *reinterpret_cast<const u32x4_a2 *>(r);
+        return c[0] * (int)(int16_t)(v.x & 0xFFFF) + c[1] * ((int)v.x >> 16) + c[2] * (int)(int16_t)(v.y & 0xFFFF) + c[3] * ((int)v.y >> 16) + c[4] * (int)(int16_t)(v.z & 0xFFFF) +
+               c[5] * ((int)v.z >> 16) + c[6] * (int)(int16_t)(v.w & 0xFFFF) + c[7] * ((int)v.w >> 16);
+    }
+    else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef u32x2    u32x2_a2 __attribute__((aligned(2)));
+        const u32x2 v = *reinterpret_cast<const u32x2_a2 *>(r);
+        return c[0] * (int)(int16_t)(v.x & 0xFFFF) + c[1] * ((int)v.x >> 16) + c[2] * (int)(int16_t)(v.y & 0xFFFF) + c[3] * ((int)v.y >> 16);
+    }
+#else
+    int acc = 0;
+    for(int t = 0; t < TAPS; t++) acc += c[t] * r[t];
+    return acc;
+#endif
+}
 // one output column of one block: TAPS-tap separable interpolation at the fractions the position carries; variant from the UNCLIPPED vector's fractions (fx, fy)
 template <int TAPS, class F> XW void mc_column(const pel *ref, int s, int gx, int gy, int fshift, const int16_t *coef, int fx, int fy, int x, int h, int bd, F out)
 {
@@ -39,9 +62,7 @@ template <int TAPS, class F> XW void mc_column(const pel *ref, int s, int gx, in
     }
     if(fx && !fy) {
         for(int y = 0; y < h; y++) {
-            const pel *r = ref + (long)(iy + y) * s + ix + x - back;
-            int acc = 0;
-            for(int t = 0; t < TAPS; t++) acc += cx[t] * r[t];
+            const int acc = dot_taps<TAPS>(cx, ref + (long)(iy + y) * s + ix + x - back);
             out(y, clip3(0, maxv, acc >> 6));
         }
         return;
@@ -61,9 +82,7 @@ template <int TAPS, class F> XW void mc_column(const pel *ref, int s, int gx, in
     }
     const int shift1 = bd - 8 < 4 ? bd - 8 : 4, shift2 = 20 - bd > 8 ? 20 - bd : 8, round2 = 1 << (shift2 - 1);
     for(int rr = 0; rr < h + TAPS - 1; rr++) {
-        const pel *r = ref + (long)(iy + rr - back) * s + ix + x - back;
-        int acc = 0;
-        for(int t = 0; t < TAPS; t++) acc += cx[t] * r[t];
+        const int acc = dot_taps<TAPS>(cx, ref + (long)(iy + rr - back) * s + ix + x - back);
         for(int t = 0; t < TAPS - 1; t++) win[t] = win[t + 1];
         win[TAPS - 1] = (int16_t)(acc >> shift1);
         if(rr >= TAPS - 1) {
@@ -357,59 +376,101 @@ XW void me_advance(const P &p, MeJob &J, bool first, unsigned cost, int idx, int
     default: J.nc = 0; return;
     }
 }
-// the cost of one candidate: get_mv_bits + MV_COST + SAD (xeve_pinter.c:47, 200-209, 323-341, 443-451, 600-627); false: outside the search range
-XW bool me_cand_cost(const P &p, const MeJob &J, int i, int N, unsigned &cost, int &bits)
+// SAD of 8 samples of a row: packed 16-bit absolute differences (v_sad_u16 is unsigned: a bi search's org_bi, which may be negative, is biased together with the
+// reference)
+XW int sad8(const pel *o, const pel *r, int bi)
 {
-    const xeve_hip_me_params &m = p.me.me;
+#if XW_DEVICE
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4    u32x4_a2 __attribute__((aligned(2)));
+    u32x4 a = *reinterpret_cast<const u32x4_a2 *>(o), b = *reinterpret_cast<const u32x4_a2 *>(r);
+    if(bi) a ^= 0x80008000u, b ^= 0x80008000u;
+    unsigned acc = 0;
+    acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc), acc = __builtin_amdgcn_sad_u16(a.y, b.y, acc);
+    acc = __builtin_amdgcn_sad_u16(a.z, b.z, acc), acc = __builtin_amdgcn_sad_u16(a.w, b.w, acc);
+    return (int)acc;
+#else
+    (void)bi;
+    int acc = 0;
+    for(int t = 0; t < 8; t++) acc += iabs((int)o[t] - (int)r[t]);
+    return acc;
+#endif
+}
+// one candidate's validity and bits (get_mv_bits, xeve_pinter.c:74-120): < 0 = outside the search range
+XW int me_cand_bits(const MeJob &J, int i)
+{
     int mx, my;
     cand_xy(J, i, mx, my);
-    if(J.ctype == CT_SPEL) {
-        bits = mvd_bits(mx - J.gmvp[0]) + mvd_bits(my - J.gmvp[1]) + J.refi_bits;
-        if(J.bi) bits += J.extra_bits;
-        cost = (uint32_t)(m.lambda_mv * (uint32_t)bits + (1u << 15)) >> 16;
-        // xeve_mc_l picks the variant from the low 4 bits of (mv << 2) and positions with the same value; SAD of the prediction against the block
-        int sad = 0;
-        const int gx = mx << 2, gy = my << 2;
-        for(int col = 0; col < N; col++)
-            mc_column<8>(J.ref, p.s_ref_l, gx, gy, 4, p.mc_l, gx & 15, gy & 15, col, N, p.bd, [&](int yy, int v) { sad += iabs((int)J.org[(long)yy * J.so + col] - v); });
-        sad >>= (p.bd - 8);
-        cost += (uint32_t)(J.bi ? sad >> 1 : sad);
-        return true;
-    }
-    if(mx > J.range[2] || mx < J.range[0] || my > J.range[3] || my < J.range[1]) return false;
-    bits = mvd_bits((mx << 2) - J.gmvp[0]) + mvd_bits((my << 2) - J.gmvp[1]) + J.refi_bits;
-    if(J.bi) bits += J.extra_bits;
-    if(J.phase == PH_D1 || J.phase == PH_DREF) cost = (uint32_t)(m.lambda_mv * (uint32_t)bits + (1u << 15)) >> 16; // u32 arithmetic as MV_COST
-    else cost = (uint32_t)(((uint64_t)m.lambda_mv * (uint32_t)bits + (1u << 15)) >> 16);
-    const pel *r = J.ref + (long)my * p.s_ref_l + mx;
-    int sad = 0;
-    for(int yy = 0; yy < N; yy++) {
-        const pel *o = J.org + (long)yy * J.so, *q = r + (long)yy * p.s_ref_l;
-        for(int xx = 0; xx < N; xx++) sad += iabs((int)o[xx] - (int)q[xx]);
-    }
-    sad >>= (p.bd - 8);
-    cost += (uint32_t)(J.bi ? sad >> 1 : sad);
-    return true;
+    if(J.ctype == CT_SPEL) return mvd_bits(mx - J.gmvp[0]) + mvd_bits(my - J.gmvp[1]) + J.refi_bits + (J.bi ? J.extra_bits : 0);
+    if(mx > J.range[2] || mx < J.range[0] || my > J.range[3] || my < J.range[1]) return -1;
+    return mvd_bits((mx << 2) - J.gmvp[0]) + mvd_bits((my << 2) - J.gmvp[1]) + J.refi_bits + (J.bi ? J.extra_bits : 0);
 }
-// all searches of S.mej[0 .. nj) to their end: rounds of {evaluate every (search, candidate) on a lane, the search's control on its own thread}
+// part `part` of `parts` of one candidate's SAD: rows [part * N / parts ..) of an integer position, columns [part * N / parts ..) of a sub-pel position (each column
+// interpolated on the fly: xeve_mc_l picks the variant from the low 4 bits of (mv << 2) and positions with the same value)
+XW int me_cand_sad_part(const P &p, const MeJob &J, int i, int N, int part, int parts)
+{
+    int mx, my;
+    cand_xy(J, i, mx, my);
+    int sad = 0;
+    if(J.ctype != CT_SPEL && parts > N / 8) { // (a round that mixes sub-pel and integer searches is cut for the sub-pel ones: whole groups of 8 rows here)
+        const int g = parts / (N / 8);
+        if(part % g) return 0;
+        part /= g, parts = N / 8;
+    }
+    const int n = N / parts, from = part * n;
+    if(J.ctype == CT_SPEL) {
+        const int gx = mx << 2, gy = my << 2;
+        for(int col = from; col < from + n; col++)
+            mc_column<8>(J.ref, p.s_ref_l, gx, gy, 4, p.mc_l, gx & 15, gy & 15, col, N, p.bd, [&](int yy, int v) { sad += iabs((int)J.org[(long)yy * J.so + col] - v); });
+        return sad;
+    }
+    const pel *r = J.ref + (long)my * p.s_ref_l + mx;
+    for(int yy = from; yy < from + n; yy++) {
+        const pel *o = J.org + (long)yy * J.so, *q = r + (long)yy * p.s_ref_l;
+        for(int xx = 0; xx < N; xx += 8) sad += sad8(o + xx, q + xx, J.bi);
+    }
+    return sad;
+}
+// MV_COST + the SAD term (xeve_pinter.c:47, 200-209, 323-341, 443-451, 600-627)
+XW unsigned me_cand_total(const P &p, const MeJob &J, int bits, int sad)
+{
+    const xeve_hip_me_params &m = p.me.me;
+    unsigned cost;
+    if(J.ctype == CT_SPEL || J.phase == PH_D1 || J.phase == PH_DREF) cost = (uint32_t)(m.lambda_mv * (uint32_t)bits + (1u << 15)) >> 16; // u32 arithmetic as MV_COST
+    else cost = (uint32_t)(((uint64_t)m.lambda_mv * (uint32_t)bits + (1u << 15)) >> 16);
+    sad >>= (p.bd - 8);
+    return cost + (uint32_t)(J.bi ? sad >> 1 : sad);
+}
+// all searches of S.mej[0 .. nj) to their end: rounds of {every candidate's bits, the candidates' SADs spread over all lanes in parts, the search's control on its own thread}
 XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
 {
     const int N = 1 << log2n;
+    int *msad = (int *)S.mcost;
     for(int j = tm.tid; j < nj; j += tm.n)
         if(S.mej[j].on) me_advance(p, S.mej[j], true, 0, -1, 0);
         else S.mej[j].nc = 0, S.mej[j].phase = PH_DONE;
     sync(tm);
     for(;;) {
         if(tm.tid == 0) S.flag[0] = 0;
-        sync(tm);
         for(int i = tm.tid; i < nj * XW_MEC; i += tm.n) {
             const int j = i / XW_MEC, c = i - j * XW_MEC;
             const MeJob &J = S.mej[j];
             if(c >= J.nc) continue;
-            unsigned cost = 0xFFFFFFFFu;
-            int bits = 0;
-            const bool ok = me_cand_cost(p, J, c, N, cost, bits);
-            S.mcost[i] = ok ? cost : 0xFFFFFFFFu, S.mbits[i] = (short)(ok ? bits : -1);
+            S.mbits[i] = (short)me_cand_bits(J, c), msad[i] = 0;
+        }
+        sync(tm);
+        // the SADs: every candidate in `parts` parts (whole rows of an integer position, columns of a sub-pel position) so that a round fills the lanes
+        int total = 0;
+        for(int j = 0; j < nj; j++) total += S.mej[j].nc;
+        int parts = 1, spel = 0;
+        for(int j = 0; j < nj; j++) spel |= S.mej[j].nc > 0 && S.mej[j].ctype == CT_SPEL;
+        while(parts < (spel ? N : N / 8) && total * parts < 4 * tm.n) parts <<= 1; // (rows of an integer position in groups of >= 8; a sub-pel position down to single columns)
+        if(tm.n == 1) parts = 1;
+        for(int i = tm.tid; i < nj * XW_MEC * parts; i += tm.n) {
+            const int part = i % parts, e = i / parts, j = e / XW_MEC, c = e - j * XW_MEC;
+            const MeJob &J = S.mej[j];
+            if(c >= J.nc || S.mbits[e] < 0) continue;
+            aadd(&msad[e], me_cand_sad_part(p, J, c, N, part, parts));
         }
         sync(tm);
         for(int j = tm.tid; j < nj; j += tm.n) {
@@ -418,9 +479,10 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
             unsigned best = 0xFFFFFFFFu;
             int idx = -1, bits = 0;
             for(int c = 0; c < J.nc; c++) { // the first strictly cheaper candidate in evaluation order wins
-                if(S.mbits[j * XW_MEC + c] < 0) continue;
-                const unsigned v = S.mcost[j * XW_MEC + c];
-                if(idx < 0 || v < best) best = v, idx = c, bits = S.mbits[j * XW_MEC + c];
+                const int b = S.mbits[j * XW_MEC + c];
+                if(b < 0) continue;
+                const unsigned v = me_cand_total(p, J, b, msad[j * XW_MEC + c]);
+                if(idx < 0 || v < best) best = v, idx = c, bits = b;
             }
             me_advance(p, J, false, best, idx, bits);
             if(J.nc) S.flag[0] = 1;
