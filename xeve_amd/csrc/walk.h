@@ -40,7 +40,7 @@ typedef xeve_hip_sbac      Sbac;
 typedef xeve_hip_ctu_data  CtuData;
 typedef unsigned long long u64;
 
-#define XW_MAXC 16  // chains per team
+#define XW_MAXC 8   // chains per team
 #define XW_NT 256   // threads per team on the device
 #define XW_CODL 96  // lanes of a team that can run the coder at once (their models live in LDS)
 #define XW_MAXR XEVE_HIP_MAX_REFP
@@ -83,12 +83,20 @@ XW void aor(int *p, int v)
 }
 // stage classes of the in-kernel profiler (XEVE_HIP_WALK_PROF=1: thread 0 of team 0 adds the cycles between two marks to its class)
 enum { PR_CLEAR = 0, PR_ENTER, PR_LEAF, PR_CHILD, PR_EXIT, PR_ROOT, PR_MID, PR_I_SETUP, PR_I_NBR, PR_I_PRED, PR_I_SATD, PR_I_LIST, PR_I_BITS, PR_I_PICK, PR_I_CPRED, PR_I_FINAL,
-       PR_B_DIFF, PR_B_T0, PR_B_T1, PR_B_RDOQ, PR_B_DQ, PR_B_T2, PR_B_T3, PR_B_REC, PR_E_CAND, PR_E_SKIP, PR_E_ME, PR_E_SPEL, PR_E_MC, PR_E_BITS, PR_E_GLUE, PR_E_FINAL, PR_N };
+       PR_B_DIFF, PR_B_T0, PR_B_T1, PR_B_RDOQ, PR_B_DQ, PR_B_T2, PR_B_T3, PR_B_REC, PR_E_CAND, PR_E_SKIP, PR_E_ME, PR_E_SPEL, PR_E_MC, PR_E_BITS, PR_E_GLUE, PR_E_FINAL, PR_M_BITS, PR_M_SAD, PR_M_SEL, PR_Q_A, PR_Q_B, PR_N };
 XW int iabs(int v) { return v < 0 ? -v : v; }
+XW unsigned mul24(unsigned a, unsigned b)
+{
+#if XW_DEVICE
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 XW int imin(int a, int b) { return a < b ? a : b; }
 XW int imax(int a, int b) { return a > b ? a : b; }
 XW int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
-XW int ilog2(unsigned v) { int l = 0; while((1u << (l + 1)) <= v) l++; return l; }
+XW int ilog2(unsigned v) { return v ? 31 - __builtin_clz(v) : 0; }
 
 // ---- records ---------------------------------------------------------------------------------------------------------------------------------------------------
 struct Node { // one per (level, chain)
@@ -130,6 +138,7 @@ struct Cw { // the workspace of one chain
     pel      spred[3][4096];     // inter: the skip winner's prediction
     pel      bpred[4096];        // inter: the fixed list's luma prediction of a bi round
     u64      sk_ssd[16][3];      // inter: SSD of every merge candidate pair, per component
+    Sbac     cst[4][3];          // inter: exit coder states of a candidate's counts: all-zero CU, CU as quantised, the chosen combination
     pel      wrec[3][4096];      // inter: the winner's reconstruction
     int16_t  org_bi[4096];
     Slot     slot[XW_NSLOT];
@@ -222,11 +231,12 @@ struct ISt { // the inter analysis of one chain's CU, between the stages
     uint32_t best_mecost, best_mecost_l[2];
     int8_t   rf[2];
     int8_t   best, cu_mode;
+    int8_t   csel[M_NUM];        // which of a candidate's counts gave its cost (index into Cw::cst[..])
 };
 #define XW_MEJ 16   // searches of one pass
 #define XW_MEC 128  // candidates of one search round
 enum { PH_D1 = 0, PH_RASTER, PH_RASTER_REF, PH_DREF, PH_IREF, PH_HPEL, PH_QPEL, PH_DONE };
-enum { CT_NONE = 0, CT_DENSE, CT_LIST, CT_GRID, CT_SPEL };
+enum { CT_NONE = 0, CT_DENSE, CT_LIST, CT_GRID, CT_SPEL, CT_RINGS };
 struct MeJob { // one pinter_me_epzs call (xeve_pinter.c:699-869) as a state machine: rounds of candidates, evaluated by all lanes
     int        on, k, l, r, bi, x, y, so;
     const pel *ref, *org;
@@ -240,16 +250,23 @@ struct MeJob { // one pinter_me_epzs call (xeve_pinter.c:699-869) as a state mac
     int        s_mv[2], s_bits;                                                     // me_spel_pattern / me_ipel_refinement
     unsigned   s_cost;
     int        ctype, nc, c0, c1, c2;                                               // the round under evaluation
-    short      cx[17], cy[17];
+    short      cx[96], cy[96];
+    short      ring_n, ring_end[8], ring_step[8];                                   // CT_RINGS: every remaining ring of the diamond in one round
 };
 
 struct Lds { // the team's shared memory
-    uint16_t ctx[XW_NCTX * XW_CODL]; // [model][coder lane]
-    Blk      blk[XW_MAXC * 9];
+    union { // (the motion search and the residual / coder stages never run at the same time: they share their space)
+        struct {
+            uint16_t ctx[XW_NCTX * XW_CODL]; // [model][coder lane]
+            Blk      blk[XW_MAXC * 9];
+        };
+        struct {
+            MeJob    mej[XW_MEJ];
+            unsigned mcost[XW_MEJ * XW_MEC];
+            short    mbits[XW_MEJ * XW_MEC];
+        };
+    };
     ISt      ist[XW_MAXC];
-    MeJob    mej[XW_MEJ];
-    unsigned mcost[XW_MEJ * XW_MEC];
-    short    mbits[XW_MEJ * XW_MEC];
     int      sh[XW_MAXC][24];        // per-chain scalars of the running stage
     int      acc[XW_MAXC * 40];      // integer sums of a stage (SATD per mode, SAD per candidate)
     int32_t  est[XW_MAXC][28];       // the rate tables RDOQ reads, of each chain's entry state
@@ -363,7 +380,7 @@ template <bool FULL> XW void cod_shift(Cod &s, int n)
 template <bool FULL> XW void cod_bin_m(Cod &s, unsigned &model, unsigned bin)
 {
     unsigned state = (model >> 1) & 511u, mps = model & 1;
-    unsigned lps = (state * (s.range & 0xFFFFu)) >> 9;
+    unsigned lps = mul24(state, s.range & 0xFFFFu) >> 9;
     if(lps < 437) lps = 437;
     if(FULL) s.bin_counter++;
     s.range -= lps;
@@ -428,7 +445,7 @@ XW Mdl mdl_of(unsigned v) { Mdl a; a.s = (v >> 1) & 511u, a.m = v & 1u; return a
 XW unsigned mdl_pack(const Mdl &a) { return (a.s << 1) + a.m; }
 XW void cnt_bin(unsigned &range, unsigned &shifts, Mdl &a, unsigned bin)
 {
-    unsigned lps = (a.s * (range & 0xFFFFu)) >> 9;
+    unsigned lps = mul24(a.s, range & 0xFFFFu) >> 9;
     lps = lps < 437u ? 437u : lps;
     const unsigned r2 = range - lps, is_lps = (bin ^ a.m) & 1u, msk = 0u - is_lps;
     const unsigned sl = a.s + ((528u - a.s) >> 5), flip = sl > 256u ? 1u : 0u, sl2 = flip ? 512u - sl : sl, sm = a.s - ((a.s + 16u) >> 5);
@@ -789,7 +806,7 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
         }
         B.tb[q] = (int32_t)packed;
     }
-    sync(tm);
+    sync(tm), mark(tm, p, S, PR_Q_A);
     for(int i = tm.tid; i < nb; i += tm.n) { // b
         Blk &B = b[i];
         if(!B.on || !B.any || !B.sum_all) continue;
@@ -840,7 +857,7 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
         }
         B.best_last = (int)best_last;
     }
-    sync(tm);
+    sync(tm), mark(tm, p, S, PR_Q_B);
     for(int i = tm.tid; i < nb * nn; i += tm.n) { // c
         const int bi = i >> (2 * log2n), q = i & (nn - 1);
         const Blk &B = b[bi];

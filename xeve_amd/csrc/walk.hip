@@ -6,8 +6,11 @@
 #include <vector>
 #include "xh_common.h"
 #include "walk_setup.h"
+#ifndef XW_WG_PER_CU
+#define XW_WG_PER_CU 4
+#endif
 
-template <bool FULL> __global__ void __launch_bounds__(XW_NT, 2) k_walk(xw::P p)
+template <bool FULL> __global__ void __launch_bounds__(XW_NT, XW_WG_PER_CU) k_walk(xw::P p)
 {
     __shared__ xw::Lds S;
     const xw::Tm tm = {(int)threadIdx.x, (int)blockDim.x};

@@ -28,30 +28,48 @@ XW int mvd_bits(int mvd)
 }
 
 // ---- motion compensation (xeve_mc.c:99-381, 401-610) ------------------------------------------------------------------------------------------------------------
-// sum_t c[t] * r[t] over the taps of one filter position: the samples come in with ONE (unaligned) vector load instead of a load per tap
-template <int TAPS> XW int dot_taps(const int16_t *c, const pel *r)
+// the samples under the taps of one filter position, fetched with ONE (unaligned) vector load instead of a load per tap; sum_t c[t] * r[t] over them
+template <int TAPS> struct TapVec {
+#if XW_DEVICE
+    uint32_t w[TAPS / 2];
+#else
+    int v[TAPS];
+#endif
+};
+template <int TAPS> XW TapVec<TAPS> ld_taps(const pel *r)
 {
+    TapVec<TAPS> t;
 #if XW_DEVICE
     if(TAPS == 8) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef u32x4    u32x4_a2 __attribute__((aligned(2)));
         const u32x4 v = *reinterpret_cast<const u32x4_a2 *>(r);
-        return c[0] * (int)(int16_t)(v.x & 0xFFFF) + c[1] * ((int)v.x >> 16) + c[2] * (int)(int16_t)(v.y & 0xFFFF) + c[3] * ((int)v.y >> 16) + c[4] * (int)(int16_t)(v.z & 0xFFFF) +
-               c[5] * ((int)v.z >> 16) + c[6] * (int)(int16_t)(v.w & 0xFFFF) + c[7] * ((int)v.w >> 16);
+        t.w[0] = v.x, t.w[1] = v.y, t.w[TAPS / 2 - 2] = v.z, t.w[TAPS / 2 - 1] = v.w;
     }
     else {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         typedef u32x2    u32x2_a2 __attribute__((aligned(2)));
         const u32x2 v = *reinterpret_cast<const u32x2_a2 *>(r);
-        return c[0] * (int)(int16_t)(v.x & 0xFFFF) + c[1] * ((int)v.x >> 16) + c[2] * (int)(int16_t)(v.y & 0xFFFF) + c[3] * ((int)v.y >> 16);
+        t.w[0] = v.x, t.w[1] = v.y;
     }
 #else
-    int acc = 0;
-    for(int t = 0; t < TAPS; t++) acc += c[t] * r[t];
-    return acc;
+    for(int i = 0; i < TAPS; i++) t.v[i] = r[i];
 #endif
+    return t;
 }
-// one output column of one block: TAPS-tap separable interpolation at the fractions the position carries; variant from the UNCLIPPED vector's fractions (fx, fy)
+template <int TAPS> XW int dot_taps(const int16_t *c, const TapVec<TAPS> &t)
+{
+    int acc = 0;
+#if XW_DEVICE
+#pragma unroll
+    for(int i = 0; i < TAPS / 2; i++) acc += c[2 * i] * (int)(int16_t)(t.w[i] & 0xFFFF) + c[2 * i + 1] * ((int)t.w[i] >> 16);
+#else
+    for(int i = 0; i < TAPS; i++) acc += c[i] * t.v[i];
+#endif
+    return acc;
+}
+// one output column of one block: TAPS-tap separable interpolation at the fractions the position carries; variant from the UNCLIPPED vector's fractions (fx, fy).
+// Rows are fetched four at a time (their loads in flight together).
 template <int TAPS, class F> XW void mc_column(const pel *ref, int s, int gx, int gy, int fshift, const int16_t *coef, int fx, int fy, int x, int h, int bd, F out)
 {
     const int fmask = (1 << fshift) - 1, back = TAPS / 2 - 1, maxv = (1 << bd) - 1, ix = gx >> fshift, iy = gy >> fshift;
@@ -61,34 +79,58 @@ template <int TAPS, class F> XW void mc_column(const pel *ref, int s, int gx, in
         return;
     }
     if(fx && !fy) {
-        for(int y = 0; y < h; y++) {
-            const int acc = dot_taps<TAPS>(cx, ref + (long)(iy + y) * s + ix + x - back);
-            out(y, clip3(0, maxv, acc >> 6));
+        for(int y0 = 0; y0 < h; y0 += 4) {
+            TapVec<TAPS> v[4];
+#pragma unroll
+            for(int t = 0; t < 4; t++)
+                if(y0 + t < h) v[t] = ld_taps<TAPS>(ref + (long)(iy + y0 + t) * s + ix + x - back);
+#pragma unroll
+            for(int t = 0; t < 4; t++)
+                if(y0 + t < h) out(y0 + t, clip3(0, maxv, dot_taps<TAPS>(cx, v[t]) >> 6));
         }
         return;
     }
     int win[TAPS];
+    const int rows = h + TAPS - 1;
     if(!fx) {
-        for(int rr = 0; rr < h + TAPS - 1; rr++) {
-            for(int t = 0; t < TAPS - 1; t++) win[t] = win[t + 1];
-            win[TAPS - 1] = ref[(long)(iy + rr - back) * s + ix + x];
-            if(rr >= TAPS - 1) {
-                int acc = 0;
-                for(int t = 0; t < TAPS; t++) acc += cy[t] * win[t];
-                out(rr - (TAPS - 1), clip3(0, maxv, acc >> 6));
+        for(int r0 = 0; r0 < rows; r0 += 4) {
+            int v[4];
+#pragma unroll
+            for(int t = 0; t < 4; t++)
+                if(r0 + t < rows) v[t] = ref[(long)(iy + r0 + t - back) * s + ix + x];
+#pragma unroll
+            for(int t = 0; t < 4; t++) {
+                const int rr = r0 + t;
+                if(rr >= rows) break;
+                for(int q = 0; q < TAPS - 1; q++) win[q] = win[q + 1];
+                win[TAPS - 1] = v[t];
+                if(rr >= TAPS - 1) {
+                    int acc = 0;
+                    for(int q = 0; q < TAPS; q++) acc += cy[q] * win[q];
+                    out(rr - (TAPS - 1), clip3(0, maxv, acc >> 6));
+                }
             }
         }
         return;
     }
     const int shift1 = bd - 8 < 4 ? bd - 8 : 4, shift2 = 20 - bd > 8 ? 20 - bd : 8, round2 = 1 << (shift2 - 1);
-    for(int rr = 0; rr < h + TAPS - 1; rr++) {
-        const int acc = dot_taps<TAPS>(cx, ref + (long)(iy + rr - back) * s + ix + x - back);
-        for(int t = 0; t < TAPS - 1; t++) win[t] = win[t + 1];
-        win[TAPS - 1] = (int16_t)(acc >> shift1);
-        if(rr >= TAPS - 1) {
-            int a2 = 0;
-            for(int t = 0; t < TAPS; t++) a2 += cy[t] * win[t];
-            out(rr - (TAPS - 1), clip3(0, maxv, (a2 + round2) >> shift2));
+    for(int r0 = 0; r0 < rows; r0 += 4) {
+        TapVec<TAPS> v[4];
+#pragma unroll
+        for(int t = 0; t < 4; t++)
+            if(r0 + t < rows) v[t] = ld_taps<TAPS>(ref + (long)(iy + r0 + t - back) * s + ix + x - back);
+#pragma unroll
+        for(int t = 0; t < 4; t++) {
+            const int rr = r0 + t;
+            if(rr >= rows) break;
+            const int acc = dot_taps<TAPS>(cx, v[t]);
+            for(int q = 0; q < TAPS - 1; q++) win[q] = win[q + 1];
+            win[TAPS - 1] = (int16_t)(acc >> shift1);
+            if(rr >= TAPS - 1) {
+                int a2 = 0;
+                for(int q = 0; q < TAPS; q++) a2 += cy[q] * win[q];
+                out(rr - (TAPS - 1), clip3(0, maxv, (a2 + round2) >> shift2));
+            }
         }
     }
 }
@@ -185,7 +227,7 @@ XW void dia_begin(const P &p, MeJob &J, int faststep, int beststep_in, int mvix,
     J.bx = clip3(m.min_clip[0], m.max_clip[0], mvix >> 2), J.by = clip3(m.min_clip[1], m.max_clip[1], mviy >> 2), J.ix = J.bx, J.iy = J.by, J.d_run = 1;
 }
 // the candidates of the running diamond's next round
-XW void dia_round(MeJob &J)
+XW void dia_round(MeJob &J, int max_range)
 {
     constexpr signed char dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1, 3}, {0, 4}, {1, 3}, {2, 2}, {3, 1}, {4, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -4}, {-1, -3}, {-2, -2}, {-3, -1}};
     J.not_found++;
@@ -195,19 +237,40 @@ XW void dia_round(MeJob &J)
         const int x1 = J.bx >= J.range[2] ? J.bx : J.bx + d, y1 = J.by >= J.range[3] ? J.by : J.by + d;
         J.ctype = CT_DENSE, J.c0 = x0, J.c1 = y0, J.c2 = x1 - x0 + 1, J.nc = (x1 - x0 + 1) * (y1 - y0 + 1);
     }
-    else {
-        const int coarse = J.step > 8;
-        int nc = 0;
-        for(int i = 0; i < 16; i++) {
-            if(!coarse && i > 8) continue;
-            if(J.step == 4 && (i == 1 || i == 3 || i == 5 || i == 7)) continue;
-            int dx, dy;
-            if(coarse) dx = dia16[i][0], dy = dia16[i][1];
-            else if(i < 8) dx = dia16[2 * i][0] / 2, dy = dia16[2 * i][1] / 2;
-            else dx = dy = 0;
-            J.cx[nc] = (short)(J.ix + (J.step >> (coarse ? 2 : 1)) * dx), J.cy[nc] = (short)(J.iy + (J.step >> (coarse ? 2 : 1)) * dy), nc++;
+    else { // every ring still to come, in one round: their candidates sit around the search's FIRST centre and the range no longer moves, so nothing a ring decides
+           // changes what the next one evaluates -- only whether it is evaluated at all (dia_rings applies that afterwards, in order)
+        int nc = 0, nr = 0;
+        for(int st = J.step; st <= max_range && nr < 8; st <<= 1) {
+            const int coarse = st > 8;
+            for(int i = 0; i < 16; i++) {
+                if(!coarse && i > 8) continue;
+                if(st == 4 && (i == 1 || i == 3 || i == 5 || i == 7)) continue;
+                int dx, dy;
+                if(coarse) dx = dia16[i][0], dy = dia16[i][1];
+                else if(i < 8) dx = dia16[2 * i][0] / 2, dy = dia16[2 * i][1] / 2;
+                else dx = dy = 0;
+                J.cx[nc] = (short)(J.ix + (st >> (coarse ? 2 : 1)) * dx), J.cy[nc] = (short)(J.iy + (st >> (coarse ? 2 : 1)) * dy), nc++;
+            }
+            J.ring_end[nr] = (short)nc, J.ring_step[nr] = (short)st, nr++;
+            if(J.bi == 1) break;
         }
-        J.ctype = CT_LIST, J.nc = nc;
+        J.ring_n = (short)nr, J.ctype = CT_RINGS, J.nc = nc;
+    }
+}
+// the rings of a CT_RINGS round, one after the other as me_ipel_diamond walks them: the first strictly cheaper candidate of a ring moves the best, a ring without
+// one counts towards faststep; the diamond is over when that count is reached or the step outgrows the search range.  cost / bits: per candidate (bits < 0: outside)
+XW void dia_rings(const P &p, MeJob &J, const unsigned *cost, const short *bits)
+{
+    int from = 0;
+    for(int r = 0; r < J.ring_n; r++) {
+        if(r > 0) J.not_found++; // (the first ring's count was taken when the round was set up)
+        const int st = J.ring_step[r];
+        for(int k = from; k < J.ring_end[r]; k++) {
+            if(bits[k] < 0) continue;
+            if(cost[k] < J.d_cost) J.bx = J.cx[k], J.by = J.cy[k], J.d_beststep = st, J.not_found = 0, J.d_cost = cost[k], J.d_bits = bits[k];
+        }
+        from = J.ring_end[r];
+        if(J.not_found == J.faststep || J.bi == 1) return;
     }
 }
 XW void cand_xy(const MeJob &J, int i, int &mx, int &my)
@@ -217,7 +280,7 @@ XW void cand_xy(const MeJob &J, int i, int &mx, int &my)
         const int g = J.r_pos + i;
         my = J.range[1] + (g / J.r_nx) * J.r_stp, mx = J.range[0] + (g % J.r_nx) * J.r_stp;
     }
-    else mx = J.cx[i], my = J.cy[i];
+    else mx = J.cx[i], my = J.cy[i]; // CT_LIST, CT_SPEL, CT_RINGS
 }
 // after a round of the diamond: the best candidate (lowest index among the cheapest) against the running best; true when the search is over
 XW bool dia_finish(const P &p, MeJob &J, unsigned cost, int idx, int bits)
@@ -278,7 +341,7 @@ XW void me_refine_or_last(const P &p, MeJob &J)
         epzs_range(p, J, J.x + (J.mv[0] >> 2), J.y + (J.mv[1] >> 2), J.range);
         J.beststep = 0, J.phase = PH_DREF;
         dia_begin(p, J, 2, J.tmpstep, (int16_t)(J.mv[0] + (J.x << 2)), (int16_t)(J.mv[1] + (J.y << 2)));
-        dia_round(J);
+        dia_round(J, p.me.me.max_search_range);
         return;
     }
     me_last_stage(p, J);
@@ -291,18 +354,19 @@ XW void me_raster_done(const P &p, MeJob &J)
 }
 // One step of the search's control: takes the result of the round just evaluated (its cheapest candidate: cost, index, bits; index < 0: none was inside the range)
 // and sets up the next round, or ends the search (phase PH_DONE, nc 0).  first: nothing has been evaluated yet (the first diamond's first round is set up).
-XW void me_advance(const P &p, MeJob &J, bool first, unsigned cost, int idx, int bits)
+XW void me_advance(const P &p, MeJob &J, bool first, unsigned cost, int idx, int bits, const unsigned *costs = nullptr, const short *bitv = nullptr)
 {
     const xeve_hip_me_params &m = p.me.me;
     if(first) {
-        dia_round(J);
+        dia_round(J, p.me.me.max_search_range);
         return;
     }
     switch(J.phase) {
     case PH_D1:
     case PH_DREF: {
-        if(!dia_finish(p, J, cost, idx, bits)) {
-            dia_round(J);
+        if(J.ctype == CT_RINGS) dia_rings(p, J, costs, bitv); // (every remaining ring was in the round: the diamond is over)
+        else if(!dia_finish(p, J, cost, idx, bits)) {
+            dia_round(J, p.me.me.max_search_range);
             return;
         }
         // the diamond is over: its result against the running best (xeve_pinter.c:742-756, 790-806)
@@ -425,11 +489,33 @@ XW int me_cand_sad_part(const P &p, const MeJob &J, int i, int N, int part, int 
         return sad;
     }
     const pel *r = J.ref + (long)my * p.s_ref_l + mx;
+#if XW_DEVICE
+    { // four rows at a time, their loads issued together (v_sad_u16 is unsigned: a bi search's org_bi is biased together with the reference)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4    u32x4_a2 __attribute__((aligned(2)));
+        unsigned acc = 0;
+        for(int yy = from; yy < from + n; yy += 4)
+            for(int xx = 0; xx < N; xx += 8) {
+                u32x4 a[4], b[4];
+#pragma unroll
+                for(int t = 0; t < 4; t++)
+                    a[t] = *reinterpret_cast<const u32x4_a2 *>(J.org + (long)(yy + t) * J.so + xx), b[t] = *reinterpret_cast<const u32x4_a2 *>(r + (long)(yy + t) * p.s_ref_l + xx);
+#pragma unroll
+                for(int t = 0; t < 4; t++) {
+                    if(J.bi) a[t] ^= 0x80008000u, b[t] ^= 0x80008000u;
+                    acc = __builtin_amdgcn_sad_u16(a[t].x, b[t].x, acc), acc = __builtin_amdgcn_sad_u16(a[t].y, b[t].y, acc);
+                    acc = __builtin_amdgcn_sad_u16(a[t].z, b[t].z, acc), acc = __builtin_amdgcn_sad_u16(a[t].w, b[t].w, acc);
+                }
+            }
+        return (int)acc;
+    }
+#else
     for(int yy = from; yy < from + n; yy++) {
         const pel *o = J.org + (long)yy * J.so, *q = r + (long)yy * p.s_ref_l;
         for(int xx = 0; xx < N; xx += 8) sad += sad8(o + xx, q + xx, J.bi);
     }
     return sad;
+#endif
 }
 // MV_COST + the SAD term (xeve_pinter.c:47, 200-209, 323-341, 443-451, 600-627)
 XW unsigned me_cand_total(const P &p, const MeJob &J, int bits, int sad)
@@ -458,7 +544,7 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
             if(c >= J.nc) continue;
             S.mbits[i] = (short)me_cand_bits(J, c), msad[i] = 0;
         }
-        sync(tm);
+        sync(tm), mark(tm, p, S, PR_M_BITS);
         // the SADs: every candidate in `parts` parts (whole rows of an integer position, columns of a sub-pel position) so that a round fills the lanes
         int total = 0;
         for(int j = 0; j < nj; j++) total += S.mej[j].nc;
@@ -466,13 +552,16 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
         for(int j = 0; j < nj; j++) spel |= S.mej[j].nc > 0 && S.mej[j].ctype == CT_SPEL;
         while(parts < (spel ? N : N / 8) && total * parts < 4 * tm.n) parts <<= 1; // (rows of an integer position in groups of >= 8; a sub-pel position down to single columns)
         if(tm.n == 1) parts = 1;
-        for(int i = tm.tid; i < nj * XW_MEC * parts; i += tm.n) {
-            const int part = i % parts, e = i / parts, j = e / XW_MEC, c = e - j * XW_MEC;
+        for(int it = tm.tid; it < total * parts; it += tm.n) { // (the items are the candidates that exist, search after search)
+            const int part = it % parts;
+            int c = it / parts, j = 0;
+            while(c >= S.mej[j].nc) c -= S.mej[j].nc, j++;
+            const int e = j * XW_MEC + c;
             const MeJob &J = S.mej[j];
-            if(c >= J.nc || S.mbits[e] < 0) continue;
+            if(S.mbits[e] < 0) continue;
             aadd(&msad[e], me_cand_sad_part(p, J, c, N, part, parts));
         }
-        sync(tm);
+        sync(tm), mark(tm, p, S, PR_M_SAD);
         for(int j = tm.tid; j < nj; j += tm.n) {
             MeJob &J = S.mej[j];
             if(J.nc == 0) continue;
@@ -482,12 +571,13 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
                 const int b = S.mbits[j * XW_MEC + c];
                 if(b < 0) continue;
                 const unsigned v = me_cand_total(p, J, b, msad[j * XW_MEC + c]);
+                S.mcost[j * XW_MEC + c] = v;
                 if(idx < 0 || v < best) best = v, idx = c, bits = b;
             }
-            me_advance(p, J, false, best, idx, bits);
+            me_advance(p, J, false, best, idx, bits, S.mcost + j * XW_MEC, S.mbits + j * XW_MEC);
             if(J.nc) S.flag[0] = 1;
         }
-        sync(tm);
+        sync(tm), mark(tm, p, S, PR_M_SEL);
         if(!S.flag[0]) break;
         sync(tm);
     }

@@ -80,8 +80,8 @@ template <bool FULL> XW void residue_rdo(const Tm &tm, const P &p, Lds &S, int c
     coder_stage<FULL>(
         tm, S, 3 * nl,
         [&](int j, const Sbac *&in, Sbac *&out) {
-            const int e = j % nl, k = e / ncand;
-            in = &p.cw[c0 + k].curr[L], out = nullptr;
+            const int lane = j / nl, e = j - lane * nl, k = e / ncand, ci = e - k * ncand;
+            in = &p.cw[c0 + k].curr[L], out = lane < 2 ? &p.cw[c0 + k].cst[cand_slot(modes[ci])][lane] : nullptr; // (the winner's state is core->s_next_best)
             return lb[e].on != 0;
         },
         [&](int j, Cod &c) {
@@ -135,8 +135,8 @@ template <bool FULL> XW void residue_rdo(const Tm &tm, const P &p, Lds &S, int c
     coder_stage<FULL>(
         tm, S, nl,
         [&](int e, const Sbac *&in, Sbac *&out) {
-            const int k = e / ncand;
-            in = &p.cw[c0 + k].curr[L], out = nullptr;
+            const int k = e / ncand, ci = e - k * ncand;
+            in = &p.cw[c0 + k].curr[L], out = &p.cw[c0 + k].cst[cand_slot(modes[ci])][2];
             if(!lb[e].on) return false;
             const int store[3] = {lb[e].nnz, ncomp > 1 ? cb[e].nnz : 0, ncomp > 1 ? cb[nl + e].nnz : 0};
             if(store[0] + store[1] + store[2] == 0) return false;
@@ -175,12 +175,12 @@ template <bool FULL> XW void residue_rdo(const Tm &tm, const P &p, Lds &S, int c
             if(m != M_DIR) { // the all-zero alternative (:1103-1142)
                 cost = XW_SUM_COST(0, 0, 0);
                 cost += (double)r[0] * p.lambda[0];
-                if(cost < cost_best) cost_best = cost, cbf[0] = cbf[1] = cbf[2] = 0;
+                if(cost < cost_best) cost_best = cost, cbf[0] = cbf[1] = cbf[2] = 0, I.csel[m] = 0;
             }
             int iy = store[0] > 0, iu = store[1] > 0, iv = store[2] > 0;
             cost = XW_SUM_COST(iy, iu, iv);
             cost += (double)r[1] * p.lambda[0];
-            if(cost < cost_best) cost_best = cost, cbf[0] = iy, cbf[1] = iu, cbf[2] = iv;
+            if(cost < cost_best) cost_best = cost, cbf[0] = iy, cbf[1] = iu, cbf[2] = iv, I.csel[m] = 1;
             int nz[3] = {store[0], store[1], store[2]};
             if(r[2] || r[3] || r[4]) {
                 iy = r[2], iu = r[3], iv = r[4];
@@ -189,14 +189,14 @@ template <bool FULL> XW void residue_rdo(const Tm &tm, const P &p, Lds &S, int c
             if(nz[0] != store[0] || nz[1] != store[1] || nz[2] != store[2]) {
                 cost = XW_SUM_COST(iy, iu, iv);
                 cost += (double)r[5] * p.lambda[0];
-                if(cost < cost_best) cost_best = cost, cbf[0] = iy, cbf[1] = iu, cbf[2] = iv;
+                if(cost < cost_best) cost_best = cost, cbf[0] = iy, cbf[1] = iu, cbf[2] = iv, I.csel[m] = 2;
             }
             for(int c = 0; c < 3; c++) I.nnz[m][c] = cbf[c] ? store[c] : 0;
         }
         else { // nothing survived quantisation (:1276-1331)
             cost_best = (double)dist[0][0] + (p.wgt[0] * (double)dist[0][1]) + (p.wgt[1] * (double)dist[0][2]);
             cost_best += (double)r[0] * p.lambda[0];
-            I.nnz[m][0] = I.nnz[m][1] = I.nnz[m][2] = 0;
+            I.nnz[m][0] = I.nnz[m][1] = I.nnz[m][2] = 0, I.csel[m] = 0;
         }
 #undef XW_SUM_COST
         I.cost_inter[m] = cost_best;
@@ -607,33 +607,28 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
     }
     mark(tm, p, S, PR_E_FINAL);
     if(p.dbg == 7) return;
-    // core->s_next_best: the winner's syntax once more from the CU's entry state, the state kept (every candidate evaluation above only counted)
+    // core->s_next_best: the state the winner's deciding count left (kept by that count); a skipped CU's three bins are counted again
     coder_stage<FULL>(
         tm, S, nC,
         [&](int k, const Sbac *&in, Sbac *&out) {
             in = &p.cw[c0 + k].curr[L], out = &p.cw[c0 + k].enext;
-            return S.ist[k].on && S.ist[k].cu_mode >= 0;
+            return S.ist[k].on && S.ist[k].cu_mode >= 0 && S.ist[k].best == M_SKIP;
         },
         [&](int k, Cod &c) {
             const ISt &I = S.ist[k];
-            Cw &W = p.cw[c0 + k];
-            const int best = I.best;
-            W.eres.satd = (uint32_t)(S.acc[k * XW_ACC] >> (p.bd - 8));
-            if(best == M_SKIP) {
-                cod_bin<FULL>(c, XEVE_HIP_CTX_SKIP_FLAG, 1);
-                cod_mvp_idx<FULL>(c, I.mvpi[M_SKIP][0]);
-                if(isb) cod_mvp_idx<FULL>(c, I.mvpi[M_SKIP][1]);
-                return;
-            }
-            const int8_t rd[2] = {0, 0};
-            cod_inter_head<FULL>(c, p, best == M_DIR, best == M_DIR ? rd : I.refi[best], I.mvpi[best], I.mvd[best]);
-            CoefSet q;
-            for(int cc = 0; cc < 3; cc++) {
-                const Slot &sl = W.slot[3 * cand_slot(best) + cc];
-                q.ev[cc] = sl.ev, q.nnz[cc] = cc < ncomp ? I.nnz[best][cc] : 0, q.nev[cc] = q.nnz[cc]; // (the events of a block are its levels: nev == nnz)
-            }
-            cod_coef<FULL>(c, p.idc, q, 7, 0);
+            cod_bin<FULL>(c, XEVE_HIP_CTX_SKIP_FLAG, 1);
+            cod_mvp_idx<FULL>(c, I.mvpi[M_SKIP][0]);
+            if(isb) cod_mvp_idx<FULL>(c, I.mvpi[M_SKIP][1]);
         });
+    for(int i = tm.tid; i < nC * (int)(sizeof(Sbac) / 4); i += tm.n) {
+        const int k = i / (int)(sizeof(Sbac) / 4), w = i - k * (int)(sizeof(Sbac) / 4);
+        const ISt &I = S.ist[k];
+        if(!I.on || I.cu_mode < 0) continue;
+        Cw &W = p.cw[c0 + k];
+        if(w == 0) W.eres.satd = (uint32_t)(S.acc[k * XW_ACC] >> (p.bd - 8));
+        if(I.best != M_SKIP) ((uint32_t *)&W.enext)[w] = ((const uint32_t *)&W.cst[cand_slot(I.best)][I.csel[I.best]])[w];
+    }
+    sync(tm);
     mark(tm, p, S, PR_E_BITS);
 }
 

@@ -106,6 +106,20 @@ XW void unit_to_temp(const Tm &tm, const P &p, CtuData *t, int log2, int cud, in
 
 enum { T_ACT = 0, T_LEAF, T_BND, T_X, T_Y, T_F0, T_F1 };
 
+// body(k, sub) for every chain of the team: the lanes split evenly among the chains, each share copying its own chain's data side by side (chain after chain on a
+// team smaller than its chains: the host build).  The bodies hold no barrier.
+template <class F> XW void for_chains(const Tm &tm, int nC, F body)
+{
+    if(tm.n >= 2 * nC) {
+        const int g = tm.n / nC, k = tm.tid / g;
+        Tm sub;
+        sub.tid = tm.tid - k * g, sub.n = g;
+        if(k < nC) body(k, sub);
+    }
+    else
+        for(int k = 0; k < nC; k++) body(k, tm);
+}
+
 template <bool FULL> XW void op_enter(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L, int part)
 {
     const int log2 = L + 2, cu = 1 << log2;
@@ -151,11 +165,11 @@ template <bool FULL> XW void op_enter(const Tm &tm, const P &p, Lds &S, int c0, 
         sh[T_ACT] = active, sh[T_LEAF] = leaf, sh[T_BND] = boundary, sh[T_X] = x0, sh[T_Y] = y0;
     }
     sync(tm);
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         const int *sh = S.sh[k];
-        if(sh[T_ACT] && !sh[T_BND]) cud_init(tm, &p.cw[c0 + k].temp[L], log2);
-        if(sh[T_LEAF]) clear_map(tm, p, p.jobs[c0 + k].pic, sh[T_X], sh[T_Y], cu);
-    }
+        if(sh[T_ACT] && !sh[T_BND]) cud_init(sub, &p.cw[c0 + k].temp[L], log2);
+        if(sh[T_LEAF]) clear_map(sub, p, p.jobs[c0 + k].pic, sh[T_X], sh[T_Y], cu);
+    });
     sync(tm);
 }
 
@@ -163,16 +177,16 @@ template <bool FULL> XW void op_enter(const Tm &tm, const P &p, Lds &S, int c0, 
 XW void op_mid(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L)
 {
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (p.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = p.idc ? n0 >> (p.ws + p.hs) : 0;
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         Cw &W = p.cw[c0 + k];
         Node *nd = &W.node[L];
-        if(!nd->leaf) continue;
+        if(!nd->leaf) return;
         const InterRes &R = W.eres;
         const Slot *sy = R.slot >= 0 ? &W.slot[R.slot] : nullptr;
         // (a winner without levels of a component leaves that component's coefficients zero: pi->coef[best] is cleared where cbf drops out, xeve_pinter.c:1264-1274)
-        unit_to_temp(tm, p, &W.temp[L], log2, cud, n, R.cu_mode, 0, R.nnz, &R, sy && R.nnz[0] ? sy[0].lev : nullptr, sy && R.nnz[1] ? sy[1].lev : nullptr,
+        unit_to_temp(sub, p, &W.temp[L], log2, cud, n, R.cu_mode, 0, R.nnz, &R, sy && R.nnz[0] ? sy[0].lev : nullptr, sy && R.nnz[1] ? sy[1].lev : nullptr,
                      sy && R.nnz[2] ? sy[2].lev : nullptr, W.wrec[0], W.wrec[1], W.wrec[2], n0, n1);
-    }
+    });
     for(int k = tm.tid; k < nC; k += tm.n) {
         Cw &W = p.cw[c0 + k];
         Node *nd = &W.node[L];
@@ -195,13 +209,13 @@ XW void op_leaf(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L, bool fu
         S.sh[k][T_F0] = nd.leaf && (!p.inter || (nd.try_intra && W.ires.cost < nd.unit_cost));
     }
     sync(tm);
-    for(int k = 0; k < nC; k++) {
-        if(!S.sh[k][T_F0]) continue;
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
+        if(!S.sh[k][T_F0]) return;
         Cw &W = p.cw[c0 + k];
         const IntraRes &R = W.ires;
-        unit_to_temp(tm, p, &W.temp[L], log2, cud, n, 0, R.ipm, R.nnz, nullptr, W.slot[R.slot].lev, W.slot[5].lev, W.slot[6].lev, W.slot[R.slot].rec, W.slot[5].rec,
+        unit_to_temp(sub, p, &W.temp[L], log2, cud, n, 0, R.ipm, R.nnz, nullptr, W.slot[R.slot].lev, W.slot[5].lev, W.slot[6].lev, W.slot[R.slot].rec, W.slot[5].rec,
                      W.slot[6].rec, n0, n1);
-    }
+    });
     sync(tm);
     for(int k = tm.tid; k < nC; k += tm.n) {
         Cw &W = p.cw[c0 + k];
@@ -219,14 +233,16 @@ XW void op_leaf(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L, bool fu
         S.sh[k][T_F1] = better;
     }
     sync(tm);
-    for(int k = 0; k < nC; k++)
-        if(S.sh[k][T_F1]) cud_copy(tm, p, &p.cw[c0 + k].best[L], &p.cw[c0 + k].temp[L], 0, 0, log2, log2, cud);
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
+        if(S.sh[k][T_F1]) cud_copy(sub, p, &p.cw[c0 + k].best[L], &p.cw[c0 + k].temp[L], 0, 0, log2, log2, cud);
+    });
     sync(tm);
-    for(int k = 0; k < nC; k++)
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         if(S.sh[k][T_F1]) {
             const Node &nd = p.cw[c0 + k].node[L];
-            rec_to_pic(tm, p, p.jobs[c0 + k].pic, &p.cw[c0 + k].best[L], nd.x0, nd.y0, cu);
+            rec_to_pic(sub, p, p.jobs[c0 + k].pic, &p.cw[c0 + k].best[L], nd.x0, nd.y0, cu);
         }
+    });
     for(int k = tm.tid; k < nC; k += tm.n) {
         Cw &W = p.cw[c0 + k];
         Node *nd = &W.node[L];
@@ -251,27 +267,28 @@ XW void op_leaf(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L, bool fu
         S.sh[k][T_F0] = do_split;
     }
     sync(tm);
-    for(int k = 0; k < nC; k++)
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         if(S.sh[k][T_F0]) {
             const Node &nd = p.cw[c0 + k].node[L];
-            cud_init(tm, &p.cw[c0 + k].temp[L], log2);
-            clear_map(tm, p, p.jobs[c0 + k].pic, nd.x0, nd.y0, cu);
+            cud_init(sub, &p.cw[c0 + k].temp[L], log2);
+            clear_map(sub, p, p.jobs[c0 + k].pic, nd.x0, nd.y0, cu);
         }
+    });
     sync(tm);
 }
 
 XW void op_child_done(const Tm &tm, const P &p, int c0, int nC, int L)
 { // L = the parent's level; the quadrant just left is node (L - 1)
     const int log2 = L + 2, cud = 2 * (p.log2_ctu - log2), half = 1 << (log2 - 1);
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         Cw &W = p.cw[c0 + k];
         Node       *pn = &W.node[L];
         const Node *ch = &W.node[L - 1];
-        if(!ch->active) continue;
-        if(tm.tid == 0) pn->cost_temp += ch->cost_best;
-        cud_copy(tm, p, &W.temp[L], &W.best[L - 1], ch->x0 - pn->x0, ch->y0 - pn->y0, log2 - 1, log2, cud);
-        update_map(tm, p, p.jobs[c0 + k].pic, &W.best[L - 1], ch->x0, ch->y0, half);
-    }
+        if(!ch->active) return;
+        if(sub.tid == 0) pn->cost_temp += ch->cost_best;
+        cud_copy(sub, p, &W.temp[L], &W.best[L - 1], ch->x0 - pn->x0, ch->y0 - pn->y0, log2 - 1, log2, cud);
+        update_map(sub, p, p.jobs[c0 + k].pic, &W.best[L - 1], ch->x0, ch->y0, half);
+    });
     sync(tm);
 }
 
@@ -290,46 +307,47 @@ XW void op_exit(const Tm &tm, const P &p, Lds &S, int c0, int nC, int L)
         S.sh[k][T_F0] = split_wins;
     }
     sync(tm);
-    for(int k = 0; k < nC; k++)
-        if(S.sh[k][T_F0]) cud_copy(tm, p, &p.cw[c0 + k].best[L], &p.cw[c0 + k].temp[L], 0, 0, log2, log2, cud);
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
+        if(S.sh[k][T_F0]) cud_copy(sub, p, &p.cw[c0 + k].best[L], &p.cw[c0 + k].temp[L], 0, 0, log2, log2, cud);
+    });
     sync(tm);
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         Cw &W = p.cw[c0 + k];
         const Node &nd = W.node[L];
-        if(!nd.active) continue;
-        rec_to_pic(tm, p, p.jobs[c0 + k].pic, &W.best[L], nd.x0, nd.y0, cu);
-        if(cu >= 8 && tm.tid == 0) W.best[L].split_mode[cud][((cu >> 1) >> 2) * (cu >> 2) + ((cu >> 1) >> 2)] = (int8_t)nd.best_split; // xeve_set_split_mode (xeve_util.c:1148-1161)
-    }
+        if(!nd.active) return;
+        rec_to_pic(sub, p, p.jobs[c0 + k].pic, &W.best[L], nd.x0, nd.y0, cu);
+        if(cu >= 8 && sub.tid == 0) W.best[L].split_mode[cud][((cu >> 1) >> 2) * (cu >> 2) + ((cu >> 1) >> 2)] = (int8_t)nd.best_split; // xeve_set_split_mode (xeve_util.c:1148-1161)
+    });
     sync(tm);
 }
 
 XW void op_root_done(const Tm &tm, const P &p, int c0, int nC, int L)
 { // update_to_ctx_map + update_map_scu (:2455-2516), then the products the caller takes
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         const int c = c0 + k;
         Cw &W = p.cw[c];
         const Node    &nd = W.node[L];
         const CtuData *b = &W.best[L];
-        update_map(tm, p, p.jobs[c].pic, b, nd.x0, nd.y0, 1 << (L + 2));
+        update_map(sub, p, p.jobs[c].pic, b, nd.x0, nd.y0, 1 << (L + 2));
         const uint32_t *s = (const uint32_t *)b;
         uint32_t       *d = (uint32_t *)(p.out + c);
-        for(int i = tm.tid; i < (int)(sizeof(CtuData) / 4); i += tm.n) d[i] = s[i];
-        if(tm.tid == 0) p.out_next[c] = W.next[L], p.out_cost[c] = nd.cost_best;
-    }
+        for(int i = sub.tid; i < (int)(sizeof(CtuData) / 4); i += sub.n) d[i] = s[i];
+        if(sub.tid == 0) p.out_next[c] = W.next[L], p.out_cost[c] = nd.cost_best;
+    });
     sync(tm);
 }
 
 // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
 XW void walk_clear(const Tm &tm, const P &p, int c0, int nC)
 {
-    for(int k = 0; k < nC; k++) {
+    for_chains(tm, nC, [&](int k, const Tm &sub) {
         Cw &W = p.cw[c0 + k];
         uint32_t *a = (uint32_t *)&W.node[0];
         const size_t head = (size_t)((char *)&W.nb[0][0][0] - (char *)&W.node[0]) / 4;
-        for(size_t i = tm.tid; i < head; i += tm.n) a[i] = 0;
+        for(size_t i = sub.tid; i < head; i += sub.n) a[i] = 0;
         uint32_t *b = (uint32_t *)&W.best[0];
-        for(size_t i = tm.tid; i < 10 * sizeof(CtuData) / 4; i += tm.n) b[i] = 0;
-    }
+        for(size_t i = sub.tid; i < 10 * sizeof(CtuData) / 4; i += sub.n) b[i] = 0;
+    });
     sync(tm);
 }
 
