@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- encoded frames/s of the closed-GOP batch encoder on MI355X (3840x2160 Baseline preset medium), next to the reference encoder on the host.
+"""bench.py -- encoded frames/s of the closed-GOP batch encoder on MI355X (3840x2160 Baseline preset medium, FULL `-I 8` closed GOPs), next to the reference encoder on the host.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-THE JOB (per GPU) is ONE real encode: independent closed GOPs of F frames each (default F = 2: the IDR picture and one inter picture, the sample the CPU baseline
-codes too), in --batches batches side by side (the first of G GOPs -- a batch ends at 2^32 original samples --, the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames, resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h) exactly as
-`xeveb_app --preset medium --closed-gop -I 8 -m 8` codes them: CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ, CABAC bit counts),
-entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  The first and the last GOP of every batch of rank 0 are the reference's
-own seed-4 input: their bitstreams are checked against each other and against the md5 recorded from the unmodified reference (tests/golden/e2e_v1.json) in the same run.
+THE JOB (per GPU) is a real encode: independent closed GOPs of F = 8 frames each (1 IDR + 7 hierarchical B pictures: what `xeveb_app --preset medium --closed-gop -I 8 -m 8`
+codes), in --batches batches side by side (a batch ends at 2^32 original samples; the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames
+resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h): CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ,
+CABAC bit counts -- ONE fused kernel per lockstep CTU step, xeve_amd/csrc/walk.h), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL
+units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
 
-A STEP.  The encode is a sequence of lockstep CTU steps (one CTU of every row chain of every GOP decided and written per step; a picture's set-up rides on its first
-step, its end -- loop filter, slice data, NAL units -- on its last).  The job's steps are cut into W + K equal slices: the first W slices are the untimed warm-up, the
-K others are timed between device fences + barriers.  `value` = frames coded inside the timed slices (GOPs x F x the timed share of the job) / the timed seconds, over all
-ranks; the whole job always runs, so the default and the driver's K / W time the same work.  Every rank encodes its own GOPs ("weak"); no collective in the data path.
+BOUNDED.  A whole 8-frame 3840x2160 job is 8 x 302 lockstep steps of a few hundred ms each whatever the batch size (a CTU's mode decision is a serial chain; the width is in
+the GOPs) -- a quarter of an hour.  The bench therefore runs the job's first --pictures pictures in coding order (default 3: the IDR picture and the first two B
+pictures) and stops; what GOP 0 has produced by then is checked byte for byte against the PREFIX of the reference's bitstream that ends with the same picture
+(tests/golden/cfg4_8f_v1.json, recorded from the unmodified reference application; the WHOLE 8-frame GOP is pinned by tests/test_enc_gpu.py on the same library).
+--pictures 0 runs the whole job.
+
+A STEP.  The steps that are run are cut into W + K equal slices: the first W are the untimed warm-up, the K others are timed between device fences + barriers.  `value` =
+frames coded inside the timed slices (GOPs x the timed share of a picture's steps) / the timed seconds, over all ranks.  With the driver's K = 20, W = 5 and 3 pictures the
+timed region is the last 40 % of the IDR picture and two whole B pictures (IDR share 17 %; 12.5 % in a whole GOP, and an IDR step is the cheaper one: the figure is within a
+few per cent of the whole-GOP rate, `config.timed_picture_mix` says exactly what was timed).  Every rank encodes its own GOPs ("weak"); no collective in the data path.
 
 The JSON line also carries
-  roofline     : the SAD kernel of the path (k_me_epzs, the integer motion search): v_sad_u16 work against the VALU roof (what binds a search that re-reads its window
-                 from cache), with the algorithmic-bytes-over-HBM-peak figure of BASELINE's metric and the physical HBM traffic of the PMC passes as secondary keys;
-                 `by_time` = the kernel class that dominates the GPU time (CABAC bit counting) against an instruction-issue roof;
-  cpu_baseline : oracle/_ref/xeveb_app (the unmodified reference, compiled in place) on this box's host cores, -m 8 and -m 1, same picture size, same kind of input.
+  roofline     : the dominant kernel = k_walk (the whole CTU mode decision of a step in one launch): the motion search's SAD work inside it (sample pairs counted on the
+                 device) over the kernel's HIP-event time on its own stream, against the VALU roof for v_sad_u16, with BASELINE's algorithmic-bytes-over-HBM-peak figure and
+                 the PMC HBM traffic as secondary keys; `by_time` = the kernel's own stage profile (in-kernel cycle marks): which stage class owns its time;
+  cpu_baseline : oracle/_ref/xeveb_app (the unmodified reference, compiled in place) on this box's host cores: -m 8 on the same 8-frame GOP (= `value`), -m 1, and
+                 `all_cores`: floor(physical cores / 8) concurrent -m 8 processes over distinct GOPs.
 """
 import argparse
 import hashlib
@@ -30,6 +37,7 @@ import re
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -41,9 +49,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 CUS, SIMDS, CLOCK_GHZ = 256, 4, 2.4
 VALU_SAD_PEAK_GBS = CUS * SIMDS * 32 * 8 * CLOCK_GHZ  # v_sad_u16: 2 sample pairs = 8 algorithmic bytes per lane, 32 lanes per clock and SIMD (a wave64 issues over 2 clocks)
-VALU_ISSUE_PEAK_GINST = CUS * SIMDS * CLOCK_GHZ / 2.0  # wave64 VALU instructions per ns: one per SIMD every 2 clocks
-BYTES_PER_SEARCH_UNIT = 256  # 64 sample pairs x (2 + 2) bytes (4*w*h per block SAD)
-INSTR_PER_BIN = 32  # k_cu_bits: measured instructions per coded bin (counted in the kernel's ISA, 16 bins unrolled)
+BYTES_PER_SAMPLE_PAIR = 4  # a block SAD reads 2 x (w * h * 2 B)
+STAGE_NAMES = ["clear", "enter", "leaf", "child_done", "exit", "root", "mid", "i_setup", "i_nbr", "i_pred", "i_satd", "i_list", "i_bits", "i_pick", "i_cpred", "i_final", "b_diff",
+               "b_t0", "b_t1", "b_rdoq", "b_dq", "b_t2", "b_t3", "b_rec", "e_cand", "e_skip", "e_me", "e_spel", "e_mc", "e_bits", "e_glue", "e_final", "m_bits", "m_sad", "m_sel",
+               "q_a", "q_b"]
+STAGE_GROUPS = {"cabac_bit_counts": ("i_bits", "i_final", "e_bits"), "motion_search": ("m_bits", "m_sad", "m_sel", "e_me"), "rdoq": ("q_a", "q_b", "b_rdoq"),
+                "transforms_residual_recon": ("b_diff", "b_t0", "b_t1", "b_dq", "b_t2", "b_t3", "b_rec"), "tree_operations": ("clear", "enter", "leaf", "child_done", "exit", "root", "mid"),
+                "prediction_satd_glue": ("i_setup", "i_nbr", "i_pred", "i_satd", "i_list", "i_pick", "i_cpred", "e_cand", "e_skip", "e_mc", "e_glue", "e_final", "e_spel")}
 
 
 def reference_noise(nbytes, seed):
@@ -57,67 +69,310 @@ def reference_noise(nbytes, seed):
 
 
 def host_info():
-    model = "unknown"
+    model, phys = "unknown", set()
     try:
+        pid = cid = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
+            if line.startswith("model name") and model == "unknown":
                 model = line.split(":", 1)[1].strip()
-                break
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
     except Exception:
         pass
-    return {"cpu_model": model, "logical_cores": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0))}
+    usable = len(os.sched_getaffinity(0))
+    physical = len(phys) if phys else max(1, (os.cpu_count() or 2) // 2)
+    return {"cpu_model": model, "logical_cores": os.cpu_count(), "usable_cores": usable, "physical_cores": min(physical, usable)}
 
 
 class CpuApp:
-    """the reference encoder on this box's host cores: xeveb_app -m 8 and -m 1 side by side on the first `frames` frames of the seed-4 clip (started in the background
-    while the GPU encodes; `result()` waits for them)"""
+    """the reference encoder on this box's host cores while the GPU encodes: first -m 8 on the 8-frame seed-4 GOP and -m 1 on its first two frames, side by side (9 threads);
+    when -m 8 is through, floor(physical cores / 8) concurrent -m 8 processes, each on a GOP of its own (`all_cores`)"""
 
-    def __init__(self, width, height, frames, clip, with_m1=False):
-        self.w, self.h, self.frames, self.procs, self.err = width, height, frames, {}, None
+    def __init__(self, width, height, frames, clip, with_m1=True):
+        self.w, self.h, self.frames, self.err, self.out = width, height, frames, None, {}
         self.exe = os.path.join(ROOT, "oracle", "_ref", "xeveb_app")
+        self.host = host_info()
         if not os.path.exists(self.exe):
             self.err = "oracle/_ref/xeveb_app not built"
             return
         try:
             self.dir = tempfile.mkdtemp(prefix="xeve_bench_")
-            yuv = os.path.join(self.dir, "in.yuv")
-            clip.tofile(yuv)
-            for m in ((8, 1) if with_m1 else (8,)):
-                cmd = [self.exe, "-i", yuv, "-w", str(width), "-h", str(height), "-z", "30", "--preset", "medium", "--closed-gop", "-I", "8", "--frames", str(frames),
-                       "-m", str(m), "-o", os.path.join(self.dir, "m%d.evc" % m)]
-                self.procs[m] = (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), time.perf_counter(), cmd)
+            clip.tofile(os.path.join(self.dir, "in.yuv"))
         except Exception as e:  # noqa: BLE001 -- a reported extra, never a reason to lose the GPU number
             self.err = repr(e)[:200]
+            return
+        self.with_m1 = with_m1
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
 
-    def result(self, timeout=900):
-        if self.err:
-            return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: " + self.err}
-        out = {}
-        for m, (p, t0, cmd) in self.procs.items():
+    def _cmd(self, yuv, frames, m, out):
+        return [self.exe, "-i", yuv, "-w", str(self.w), "-h", str(self.h), "-z", "30", "--preset", "medium", "--closed-gop", "-I", "8", "--frames", str(frames), "-m", str(m), "-o", out]
+
+    @staticmethod
+    def _parse(txt, rc):
+        fps = re.search(r"Average encoding speed\s*=\s*([0-9.]+)", txt)  # the app's own figure: times xeve_encode only (app/xeve_app.c:1401)
+        tot = re.search(r"Total encoding time\s*=\s*[0-9.]+ msec,\s*([0-9.]+) sec", txt)
+        return {"fps": float(fps.group(1)) if fps else None, "encoding_s": float(tot.group(1)) if tot else None, "rc": rc}
+
+    def _run(self):
+        try:
+            yuv = os.path.join(self.dir, "in.yuv")
+            p8 = subprocess.Popen(self._cmd(yuv, self.frames, 8, os.path.join(self.dir, "m8.evc")), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            p1 = subprocess.Popen(self._cmd(yuv, 2, 1, os.path.join(self.dir, "m1.evc")), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if self.with_m1 else None
+            txt, _ = p8.communicate(timeout=900)
+            self.out["m8"] = self._parse(txt, p8.returncode)
+            self.out["m8"]["frames"] = self.frames
             try:
-                txt, _ = p.communicate(timeout=timeout)
-            except subprocess.TimeoutExpired:
-                p.kill()
-                out[m] = {"error": "timeout"}
-                continue
-            fps = re.search(r"Average encoding speed\s*=\s*([0-9.]+)", txt)  # the app's own figure: times xeve_encode only (app/xeve_app.c:1401)
-            tot = re.search(r"Total encoding time\s*=\s*[0-9.]+ msec,\s*([0-9.]+) sec", txt)
-            out[m] = {"fps": float(fps.group(1)) if fps else None, "encoding_s": float(tot.group(1)) if tot else None, "rc": p.returncode}
-            try:
-                out[m]["md5"] = hashlib.md5(open(os.path.join(self.dir, "m%d.evc" % m), "rb").read()).hexdigest()
+                self.out["m8"]["md5"] = hashlib.md5(open(os.path.join(self.dir, "m8.evc"), "rb").read()).hexdigest()
             except Exception:
                 pass
+            if p1 is not None:
+                txt, _ = p1.communicate(timeout=900)
+                self.out["m1"] = self._parse(txt, p1.returncode)
+                self.out["m1"]["frames"] = 2
+            # all cores: N processes of 8 threads each, every one on its own GOP (the seed-4 GOP and N - 1 GOPs of fresh uniform bytes)
+            n = max(1, self.host["physical_cores"] // 8)
+            rng = np.random.default_rng(5)
+            files = [yuv]
+            for i in range(1, n):
+                f = os.path.join(self.dir, "g%d.yuv" % i)
+                rng.integers(0, 256, size=self.w * self.h * 3 // 2 * self.frames, dtype=np.uint8).tofile(f)
+                files.append(f)
+            t0 = time.perf_counter()
+            ps = [subprocess.Popen(self._cmd(f, self.frames, 8, os.path.join(self.dir, "a%d.evc" % i)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i, f in enumerate(files)]
+            res = []
+            for p in ps:
+                txt, _ = p.communicate(timeout=1200)
+                res.append(self._parse(txt, p.returncode))
+            wall = time.perf_counter() - t0
+            enc_s = [r["encoding_s"] for r in res if r["encoding_s"]]
+            self.out["all_cores"] = {"processes": n, "threads_each": 8, "cores": n * 8, "frames": n * self.frames,
+                                     "fps": round(n * self.frames / max(enc_s), 4) if len(enc_s) == n else None,  # every process's frames over the slowest one's encoding time
+                                     "wall_s_incl_file_io": round(wall, 2), "per_process_fps": [r["fps"] for r in res]}
+        except Exception as e:  # noqa: BLE001
+            self.err = repr(e)[:200]
+
+    def result(self, timeout=1500):
+        if self.err and not self.out:
+            return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: " + self.err}
+        self.th.join(timeout)
         try:
             import shutil
             shutil.rmtree(self.dir, ignore_errors=True)
         except Exception:
             pass
-        m8, m1 = out.get(8, {}), out.get(1, {})
+        m8 = self.out.get("m8", {})
         return {"value": m8.get("fps"), "unit": "frames/s", "cores": 8, "kind": "reference",
-                "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit "
-                          "4:2:0 clip (frame 0 is the IDR picture, the rest inter pictures) = GOP 0 of the GPU job; `value` = -m 8 (the library's thread maximum, the setting the "
-                          "GPU job reproduces byte for byte); `m1` = -m 1 when asked for (--cpu-m1; 0.053 frames/s in profiles/r03_bench.json); on the host's cores while the GPU encoded" % (self.w, self.h, self.frames),
-                "m8": m8, "m1": m1, "host": host_info()}
+                "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit 4:2:0 "
+                          "clip = GOP 0 of the GPU job (1 IDR + 7 B pictures); `value` = -m 8 (the library's thread maximum, the setting the GPU job reproduces byte for byte); "
+                          "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(physical cores / 8) such processes side by side, each on its own GOP; on the host's cores "
+                          "while the GPU encoded" % (self.w, self.h, self.frames),
+                "m8": m8, "m1": self.out.get("m1", {}), "all_cores": self.out.get("all_cores", {}), "host": self.host, "error": self.err}
+
+
+def golden_prefix(width, height, frames, threads):
+    """the reference's bitstream of the seed clip at this size, as (bytes, md5) after every coded picture (tests/golden/cfg4_8f_v1.json), or None"""
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4_8f_v1.json")))
+        for name, r in g.items():
+            if (r["w"], r["h"], r["frames"]) == (width, height, frames) and threads == 8:
+                return name, r
+    except Exception:
+        pass
+    return None, None
+
+
+def check_prefix(stream, gold):
+    """how many coded pictures of the golden bitstream `stream` is exactly the prefix of (0: none)"""
+    for k, p in enumerate(gold["after_picture"]):
+        if len(stream) == p["bytes"]:
+            return k + 1 if hashlib.md5(stream).hexdigest() == p["md5"] else 0
+    return 0
+
+
+def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
+    """one bounded encode at W x H; returns the result record (rank 0) or None"""
+    from xeve_amd import encode, lib
+
+    F, T = a.frames, a.threads
+    fb = W * H * 3 // 2
+    w_lcu, h_lcu = (W + 63) // 64, (H + 63) // 64
+    seed = {(3840, 2160): 4, (1920, 1080): 3}.get((W, H), 4)
+    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    one, most = encode.footprint(cfg, 1, F)
+    two, _ = encode.footprint(cfg, 2, F)
+    per_gop, fixed = max(1, two - one), max(0, 2 * one - two)
+    Gs, room = [], free0 - (10 << 30)
+    want = a.gops or most
+    for _ in range(max(1, a.batches)):
+        g = int(min(want, most, (room - fixed) // per_gop))
+        if g < max(1, min(want, most) // 8):
+            break
+        Gs.append(g)
+        room -= fixed + g * per_gop
+    if not Gs:
+        raise SystemExit("bench.py: not enough device memory for one GOP at %dx%d" % (W, H))
+    encs = [encode.BatchEncoder(cfg, g, F) for g in Gs]
+    B, enc = len(encs), encs[0]
+
+    # inputs: 16 GOPs of every batch of rank 0 = the reference recipe's seed clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
+    clip = reference_noise(fb * F, seed) if rank == 0 else None
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    seeded = [sorted({int(round(i * (g - 1) / max(1, min(g, 16) - 1))) for i in range(min(g, 16))}) for g in Gs]  # 16 GOPs spread over every batch, its first and last among them
+    for b, e in enumerate(encs):
+        for g in range(Gs[b]):
+            if g in seeded[b] and clip is not None:
+                d = torch.from_numpy(clip).to(dev)
+            else:
+                d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
+            for f in range(F):
+                e.push(g, f, d[f * fb:(f + 1) * fb])
+    del d
+    cpu = CpuApp(W, H, F, clip, True) if with_cpu else None  # (host cores only; runs while the GPU encodes)
+
+    def fence():
+        for e in encs:
+            e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for e in encs:
+        e.begin()
+    total = enc.advance(0)
+    per_picture = total // F
+    P = F if a.pictures <= 0 else min(F, a.pictures)
+    run_steps = P * per_picture
+    n = a.warmup + a.steps
+    per = max(1, run_steps // n)
+    sizes = [per] * (n - 1) + [max(0, run_steps - per * (n - 1))]
+
+    def run_slices(lo, hi):
+        """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL)"""
+        def one(e):
+            for i in range(lo, hi):
+                e.advance(sizes[i])
+        if B == 1:
+            one(enc)
+            return
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(B) as ex:
+            list(ex.map(one, encs))
+
+    run_slices(0, a.warmup)
+    fence()
+    lib.prof_enable(["walk"])  # HIP events around the walk's one launch per step, on its own stream; the SAD sample pairs counted in the kernel
+    lib.prof_read()
+    fence()
+    t0 = time.perf_counter()
+    run_slices(a.warmup, n)
+    fence()
+    dt = time.perf_counter() - t0
+    walk_ms, walk_n, walk_pairs = lib.prof_read()["walk"]
+    lib.prof_enable(None)
+    timed_steps = sum(sizes[a.warmup:])
+    first_timed = sum(sizes[:a.warmup])
+    frames_timed = sum(Gs) * timed_steps / per_picture
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if os.environ.get("XEVE_BENCH_SHARE_GPU") == "1" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = enc.stats()
+    mix = {}  # which pictures (coding order) the timed steps belong to
+    for s in range(first_timed, first_timed + timed_steps):
+        k = s // per_picture
+        mix[k] = mix.get(k, 0) + 1
+    rec = None
+    if rank == 0:
+        gname, gold = golden_prefix(W, H, F, T)
+        streams = [[e.bitstream(g) for g in idx] for e, idx in zip(encs, seeded)]
+        same = all(s == streams[0][0] for b in streams for s in b)
+        check = {"gop0_bytes_so_far": len(streams[0][0]), "gop0_md5_so_far": hashlib.md5(streams[0][0]).hexdigest(),
+                 "seeded_gops": {"per_batch": [len(i) for i in seeded], "what": "GOPs spread evenly over every batch (its first and its last among them) that carry the golden clip"},
+                 "all_seeded_gops_same_bytes": same}
+        if gold is not None:
+            k = check_prefix(streams[0][0], gold)
+            check.update({"reference_golden": "tests/golden/cfg4_8f_v1.json:" + gname, "pictures_of_the_golden_gop_matched": k,
+                          "byte_identical_to_the_reference": bool(k > 0 and same),
+                          "note": "the bitstream GOP 0 has produced when the bounded job stops (the pictures whose access units are complete) against the reference's "
+                                  "bitstream up to the same picture; the whole 8-frame GOP: tests/test_enc_gpu.py"})
+        alg = walk_pairs * BYTES_PER_SAMPLE_PAIR
+        alg_gbs = alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        roof = {"kernel": "k_walk (xeve_amd/csrc/walk.h: the whole CTU mode decision of a lockstep step in ONE launch; the motion search's SAD rounds run inside it)",
+                "bound": "valu", "achieved": round(alg_gbs, 2), "peak": VALU_SAD_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / VALU_SAD_PEAK_GBS, 6),
+                "how": "algorithmic bytes of the motion search (4 per sample pair compared, counted on the device) over the HIP-event time of the kernel's launches in the timed "
+                       "region (events on the walk's own streams), against the rate at which the chip's VALUs can issue v_sad_u16.  The kernel is the whole analysis: the search is "
+                       "one stage class of it (`by_time`), so this is the SAD work per second of a kernel that spends most of its time elsewhere",
+                "launches_in_region": walk_n, "avg_launch_ms": round(walk_ms / max(1, walk_n), 3), "algorithmic_bytes_per_launch": int(alg / max(1, walk_n)),
+                "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 6), "traffic": None}
+        try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_walk_pmc.json")))
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["traffic_is"] = pmc.get("what")
+            for k in ("valu_insts_per_launch", "valu_issue_frac", "wait_any_frac", "waves_per_launch", "avg_launch_s"):
+                if k in pmc:
+                    roof[k] = pmc[k]
+        except Exception:
+            pass
+        rec = {"value": round(world * frames_timed / dt, 4), "ms_per_step": round(1e3 * dt / a.steps, 3),
+               "config": {
+                   "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
+                               "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
+                               % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, T, run_steps, a.warmup, a.steps),
+                   "walk": "composed (XEVE_HIP_WALK=0: ~10 000 launches per step)" if os.environ.get("XEVE_HIP_WALK") == "0" else "fused (one k_walk launch per step)",
+                   "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "pictures_run": P, "row_chains_per_picture": T,
+                   "chains_in_lockstep": [g * min(T, h_lcu) for g in Gs], "lockstep_steps_per_picture": per_picture, "lockstep_steps_timed": timed_steps,
+                   "timed_picture_mix": {"picture_%d%s" % (k, "_IDR" if k == 0 else "_B"): round(v / per_picture, 3) for k, v in sorted(mix.items())},
+                   "frames_in_timed_region": round(frames_timed, 2), "ctus_per_picture": w_lcu * h_lcu,
+                   "parallelism": "closed-GOP shards per GPU, no collectives" + (" [SELF-TEST: all ranks share GPU 0, gloo]" if os.environ.get("XEVE_BENCH_SHARE_GPU") == "1" else "")},
+               "encode": {"host_seconds_issuing_steps": round(stats["step_seconds"], 3), "seconds_in_picture_ends": round(stats["picture_end_seconds"], 2),
+                          "note": "time the host spent inside the library's step calls (the fused walk is one launch per step) and inside the picture ends"},
+               "bitstream_check": check, "roofline": roof, "cpu": cpu}
+    for e in encs:  # (the job's HBM goes back; an unfinished run is abandoned)
+        e.close()
+    return rec, (cfg, Gs, per_picture, fb)
+
+
+def stage_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=4):
+    """the kernel's own stage profile: a short untimed encode with the in-kernel cycle marks on -- thread 0 of team 0, steps of the first B picture"""
+    from xeve_amd import encode, lib
+    import ctypes as C
+
+    L = lib.load()
+    e = encode.BatchEncoder(cfg, gops, frames)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    d = torch.randint(0, 256, (fb * frames,), dtype=torch.uint8, device=dev, generator=gen)
+    for g in range(gops):
+        for f in range(frames):
+            e.push(g, f, d[f * fb:(f + 1) * fb])
+    e.begin()
+    e.advance(per_picture)  # the IDR picture
+    e.sync()
+    L.xeve_hip_walk_prof_enable(1)
+    buf = (C.c_uint64 * (2 * len(STAGE_NAMES) + 8))()
+    e.advance(1)
+    e.sync()
+    L.xeve_hip_walk_prof(buf, len(buf))  # (the first profiled step allocates the counters: dropped)
+    e.advance(steps)
+    e.sync()
+    n = L.xeve_hip_walk_prof(buf, len(buf))
+    L.xeve_hip_walk_prof_enable(0)
+    e.close()
+    if n <= 0:
+        return None
+    cyc = {STAGE_NAMES[i]: int(buf[i]) for i in range(min(n, len(STAGE_NAMES)))}
+    tot = sum(cyc.values()) or 1
+    groups = {g: round(sum(cyc.get(k, 0) for k in ks) / tot, 4) for g, ks in STAGE_GROUPS.items()}
+    top = max(groups, key=groups.get)
+    return {"kernel": "k_walk, its own stage classes (shader cycles of team 0's thread 0 between stage marks; %d lockstep steps of the first B picture, %d GOPs)" % (steps, gops),
+            "share_of_kernel_time": groups, "dominant": top, "bound": "latency of serial lanes (a CABAC bit count is a recurrence per bin: ~170 cycles per bin and lane, "
+            "tools/scratch/cod_bench.hip; the stage lasts as long as its longest lane)", "cycles_per_step_team0": tot // max(1, steps)}
 
 
 def main():
@@ -127,14 +382,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per GPU (0: as many as the picture size allows, at most 448)")
-    ap.add_argument("--frames", type=int, default=2, help="frames per GOP (2: the IDR picture and one inter picture, the CPU baseline's sample)")
+    ap.add_argument("--gops", type=int, default=0, help="closed GOPs in lockstep per batch (0: as many as a batch holds at this picture size)")
+    ap.add_argument("--frames", type=int, default=8, help="frames per GOP (8: the full -I 8 closed GOP, 1 IDR + 7 B pictures)")
+    ap.add_argument("--pictures", type=int, default=3, help="coded pictures of every GOP the bounded job runs (0: the whole job)")
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
-    ap.add_argument("--batches", type=int, default=3, help="batches encoded side by side on this GPU (one host thread and HIP stream each): the first of --gops GOPs, the others as the memory allows")
+    ap.add_argument("--batches", type=int, default=3, help="batches encoded side by side on this GPU (a host thread and a HIP stream each)")
+    ap.add_argument("--walk", default=os.environ.get("XEVE_BENCH_WALK", "auto"), choices=["auto", "fused", "composed"], help="the CTU walk: one kernel per step (fused) or ~10 000 launches (composed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-m1", action="store_true", help="time the reference with one thread too (-m 1: ~3 minutes at 3840x2160; profiles/r03_bench.json has it)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed per-kernel-class pass")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (the kernel's stage profile, the 1920x1080 figure)")
     a = ap.parse_args()
+    if a.walk == "composed":
+        os.environ["XEVE_HIP_WALK"] = "0"
+    elif a.walk == "fused":
+        os.environ["XEVE_HIP_WALK"] = "1"
 
     import torch
     import torch.distributed as dist
@@ -168,221 +428,40 @@ def main():
     if world > 1:
         dist.barrier()
     import xeve_amd
-    from xeve_amd import encode, lib
 
     xeve_amd.init(local)
     solo = rank == 0 and world == 1
-    W, H, F, T = a.width, a.height, a.frames, a.threads
-    fb = W * H * 3 // 2
-    w_lcu, h_lcu = (W + 63) // 64, (H + 63) // 64
-    vh = (H + 288 + 63) & ~63
-    G = a.gops or max(1, min(448, int((2 ** 32 - 1) // (vh * W))))  # (the library's limit: the stacked originals of a batch below 2^32 samples)
-    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
-    # BATCHES: a batch's originals are addressed with 32 bits (448 pictures of 3840x2160), HBM holds more, and a step's time hardly moves with the chains it carries -- so
-    # the job is B batches side by side (a host thread and a HIP stream each: profiles/r03s_*): the first as large as the limit allows, the others as large as the
-    # memory left over
-    free0 = torch.cuda.mem_get_info(dev)[0]
-    encs, Gs = [encode.BatchEncoder(cfg, G, F)], [G]
-    per_gop = (free0 - torch.cuda.mem_get_info(dev)[0]) / G + (16 << 20)  # (+ the walk's workspace, allocated when the encode begins)
-    for _ in range(1, max(1, a.batches)):
-        room = torch.cuda.mem_get_info(dev)[0] - (16 << 20) * sum(Gs) - (8 << 30)
-        g = int(min(G, room // per_gop))
-        if g < max(1, G // 8):
-            break
-        encs.append(encode.BatchEncoder(cfg, g, F)), Gs.append(g)
-    B = len(encs)
-    enc = encs[0]
-
-    # inputs: GOP 0 and the last GOP of rank 0 = the reference recipe's seed-4 clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
-    clip = reference_noise(fb * F, 4) if rank == 0 else None
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    for b, e in enumerate(encs):
-        for g in range(Gs[b]):
-            if (g == 0 or g == Gs[b] - 1) and clip is not None:  # (both ends of every batch carry the clip: their bytes must be GOP 0's)
-                d = torch.from_numpy(clip).to(dev)
-            else:
-                d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
-            for f in range(F):
-                e.push(g, f, d[f * fb:(f + 1) * fb])
-    del d
-    cpu = CpuApp(W, H, F, clip, a.cpu_m1) if solo and not a.no_cpu_baseline else None  # (host cores only; runs while the GPU encodes)
-
-    def fence():
-        for e in encs:
-            e.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for i in range(len(encs) - 1, -1, -1):  # (the walk's workspace is allocated here: a batch beyond the first that no longer fits is left out rather than failing the run)
-        try:
-            encs[i].begin()
-        except Exception:
-            if i == 0:
-                raise
-            encs[i].close()
-            del encs[i], Gs[i]
-    B = len(encs)
-    total = enc.advance(0)
-    per_picture = total // F
-    n = a.warmup + a.steps
-    per = max(1, total // n)
-    sizes = [per] * (n - 1) + [max(0, total - per * (n - 1))]
-
-    live = {"search": [0.0, 0, 0]}
-
-    def drain():
-        for k, v in lib.prof_read().items():  # (waits for the device: only between slices; keeps the pool of timing events small -- creating them costs host time)
-            if k in live:
-                live[k] = [live[k][0] + v[0], live[k][1] + v[1], live[k][2] + v[2]]
-
-    def run_slices(lo, hi, timers=False):
-        """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL).  timers: HIP events on the search kernel's
-        launches -- with one batch in every slice (read out after each), with several only in the last slice (a read-out would stall the other batches)"""
-        def one(e):
-            left = None
-            for i in range(lo, hi):
-                if timers and (B == 1 or i == hi - 1) and e is enc:
-                    lib.prof_enable(["search"])
-                left = e.advance(sizes[i])
-                if timers and B == 1:
-                    drain()
-            return left
-        if B == 1:
-            return [one(enc)]
-        import concurrent.futures as cf
-        with cf.ThreadPoolExecutor(B) as ex:
-            return list(ex.map(one, encs))
-
-    run_slices(0, a.warmup)
-    fence()
-    lib.prof_read()
-    fence()
-    t0 = time.perf_counter()
-    lefts = run_slices(a.warmup, n, timers=True)  # the roofline's kernel: HIP events on its launches, live in the timed region
-    fence()
-    dt = time.perf_counter() - t0
-    drain()
-    lib.prof_enable(None)
-    assert all(v == 0 for v in lefts), lefts
-    timed_steps = sum(sizes[a.warmup:])
-    frames_timed = sum(Gs) * timed_steps / per_picture
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stats = enc.stats()
-    streams = [enc.bitstream(0)]
-    ends_same = all(e.bitstream(g) == streams[0] for e, n in zip(encs, Gs) for g in (0, n - 1)) if rank == 0 else None
-    total_bytes = int(sum(sum(e.bitstream_sizes()) for e in encs)) if rank == 0 else 0
-    for e in encs:  # (the job's HBM goes back before the untimed extras)
-        e.close()
-
+    rec, (cfg, Gs, per_picture, fb) = run_job(a, torch, dist, dev, rank, world, a.width, a.height, "headline", solo and not a.no_cpu_baseline)
     line = None
     if rank == 0:
-        s_ms, s_n, s_u = live["search"]
-        alg = s_u * BYTES_PER_SEARCH_UNIT
-        alg_gbs = alg / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
-        roof = {"kernel": "k_me_epzs<8|16|32|64, uni|bi> (the integer motion search inside xeve_hip_mode_analyze_ctu_jobs; the SAD kernel of the path)",
-                "bound": "valu", "achieved": round(alg_gbs, 1), "peak": VALU_SAD_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / VALU_SAD_PEAK_GBS, 4),
-                "how": "algorithmic bytes (256 per 64 sample pairs evaluated, counted on the device) over the kernel's HIP-event time in the timed region, against the rate at "
-                       "which the chip's VALUs can issue v_sad_u16 (8 algorithmic bytes per lane and instruction)",
-                "launches_in_region": s_n, "avg_launch_ms": round(s_ms / max(1, s_n), 4), "algorithmic_bytes_per_launch": int(alg / max(1, s_n)),
-                "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 4), "traffic": None}
-        try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_search_pmc.json")))
-            roof["traffic"] = pmc.get("hbm_bytes_per_launch_x2")
-            roof["traffic_is"] = "HBM bytes per launch of the kernel in the PMC run of profiles/r03_search_pmc.json (128 chains in lockstep; this job's launches carry %d)" % (Gs[0] * min(T, h_lcu))
-            if pmc.get("hbm_bytes_per_launch_x2") and pmc.get("avg_launch_s"):
-                roof["hbm_physical_GBps"] = round(pmc["hbm_bytes_per_launch_x2"] / pmc["avg_launch_s"] / 1e9, 1)
-                roof["hbm_physical_frac"] = round(roof["hbm_physical_GBps"] / HBM_PEAK_GBS, 4)
-        except Exception:
-            pass
-        check = {"gop0_md5": hashlib.md5(streams[0]).hexdigest(), "gop0_bytes": len(streams[0]), "total_bytes": total_bytes,
-                 "first_and_last_gop_of_every_batch_same_clip_same_bytes": ends_same}
-        try:
-            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))
-            key = {(3840, 2160, 2, 8): "cfg4_2160p_closedgop_medium_m8", (3840, 2160, 2, 1): "cfg4_2160p_closedgop_medium"}.get((W, H, F, T))
-            if key:
-                check["reference_golden"] = key
-                check["byte_identical_to_the_reference"] = gold[key]["md5"] == check["gop0_md5"]
-        except Exception:
-            pass
-        line = {
-            "metric": "encoded frames/sec @ 2160p Baseline medium; SAD-kernel HBM GB/s vs peak",
-            "value": round(world * frames_timed / dt, 4),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "s16 samples, s32/s64 accumulation, f64 cost comparisons (bit-exact)",
-            "data": "synthetic",
-            "value_is": "encoded frames/s of the closed-GOP batch encoder: a real encode to EVC bitstreams (every stage of the reference's xeve_pic on the device, NAL assembly "
-                        "on the host), byte-identical to the reference encoder; frames = the timed share of the job's frames",
-            "config": {
-                "workload": "one encode of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop -I 8 -m %d semantics), "
-                            "i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; the job's %d lockstep CTU steps cut into %d + %d equal slices"
-                            % (B, "+".join(str(g) for g in Gs), F, W, H, T, total, a.warmup, a.steps),
-                "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "row_chains_per_picture": T, "chains_in_lockstep": [g * min(T, h_lcu) for g in Gs],
-                "lockstep_steps_per_picture": per_picture,
-                "lockstep_steps_timed": timed_steps, "frames_in_timed_region": round(frames_timed, 2), "ctus_per_picture": w_lcu * h_lcu,
-                "parallelism": "closed-GOP shards per GPU, no collectives" + (" [SELF-TEST: all ranks share GPU 0, gloo]" if share else ""),
-                "library_built_in_this_run": built_here,
-            },
-            "encode": {"host_seconds_issuing_steps": round(stats["step_seconds"], 2), "seconds_in_picture_ends": round(stats["picture_end_seconds"], 2),
-                       "note": "whole job (warm-up slices included): time the host spent issuing the lockstep steps, and inside the picture ends (loop filter, second writer "
-                               "pass, padding, read-back of the slice data)"},
-            "bitstream_check": check,
-            "roofline": roof,
-        }
-
+        cpu = rec.pop("cpu")
+        line = {"metric": "encoded frames/sec @ 2160p Baseline medium; SAD-kernel HBM GB/s vs peak", "value": rec["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "s16 samples, s32/s64 accumulation, f64 cost comparisons (bit-exact)", "data": "synthetic",
+                "value_is": "encoded frames/s of the closed-GOP batch encoder on full 8-frame closed GOPs: a real encode to EVC bitstreams (every stage of the reference's xeve_pic "
+                            "on the device, NAL assembly on the host), byte-identical to the reference encoder; frames = the timed share of the pictures that were run",
+                "config": rec["config"], "encode": rec["encode"], "bitstream_check": rec["bitstream_check"], "roofline": rec["roofline"]}
+        line["config"]["library_built_in_this_run"] = built_here
     if solo and not a.no_secondary:
-        # per kernel class: a short untimed encode (few GOPs, small picture share) with every class's timer on
         try:
-            g2 = max(1, G // 4)
-            e2 = encode.BatchEncoder(cfg, g2, F)
-            d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
-            for g in range(g2):
-                for f in range(F):
-                    e2.push(g, f, d[f * fb:(f + 1) * fb])
-            e2.begin()
-            k = 6
-            e2.advance(per_picture)       # the IDR picture, untimed and without timers
-            e2.sync()
-            lib.prof_enable(lib.PROF_CLASSES)
-            lib.prof_read()
-            e2.advance(k)                 # k steps of the inter picture
-            e2.sync()
-            allc = lib.prof_read()
-            lib.prof_enable(None)
-            e2.close()
-            kern = {c: {"ms_per_step": round(v[0] / k, 3), "launches_per_step": v[1] // k} for c, v in allc.items()}
-            cb = allc["cu_bits"]
-            bins_s = cb[2] / (cb[0] * 1e-3) if cb[0] > 0 else 0.0
-            kern["cu_bits"].update({"bins_per_step": int(cb[2] / k), "Gbin_per_s": round(bins_s / 1e9, 3)})
-            line["kernels"] = kern
-            line["kernels"]["note"] = "HIP-event time per lockstep step of the inter picture with %d GOPs (%d chains) in lockstep, all class timers on (untimed extra encode)" % (g2, g2 * min(T, h_lcu))
-            tot = sum(v[0] for c, v in allc.items() if c != "cu_bits_slow")
-            line["roofline"]["by_time"] = {
-                "kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None,
-                "bound": "valu-issue", "achieved": round(bins_s * INSTR_PER_BIN / 64 / 1e9, 3), "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
-                "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
-                "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
-                       "a serial chain per lane, so the roof is only reachable with every lane of every wave busy" % (INSTR_PER_BIN, CUS, SIMDS, CLOCK_GHZ)}
+            line["roofline"]["by_time"] = stage_profile(torch, dev, cfg, max(8, Gs[0] // 4), a.frames, per_picture, fb)
         except Exception as e:  # noqa: BLE001
-            line["kernels"] = {"error": repr(e)[:300]}
+            line["roofline"]["by_time"] = {"error": repr(e)[:300]}
+        if (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
+            try:
+                r2, _ = run_job(a, torch, dist, dev, rank, world, 1920, 1080, "secondary", False)
+                r2.pop("cpu")
+                line["at_1920x1080"] = {"value": r2["value"], "unit": "frames/s", "ms_per_step": r2["ms_per_step"], "config": r2["config"], "bitstream_check": r2["bitstream_check"],
+                                        "roofline_frac": r2["roofline"]["frac"]}
+            except Exception as e:  # noqa: BLE001
+                line["at_1920x1080"] = {"error": repr(e)[:300]}
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu.result()
             try:
-                m8 = line["cpu_baseline"].get("m8", {})
-                if m8.get("md5") and F == 2 and T == 8:
-                    line["bitstream_check"]["same_as_this_runs_cpu_reference_m8"] = m8["md5"] == line["bitstream_check"]["gop0_md5"]
+                ac = line["cpu_baseline"].get("all_cores", {}).get("fps")
+                line["vs_cpu"] = {"gpu_over_m8": round(line["value"] / line["cpu_baseline"]["value"], 2) if line["cpu_baseline"].get("value") else None,
+                                  "gpu_over_all_cores": round(line["value"] / ac, 2) if ac else None}
             except Exception:
                 pass
         print(json.dumps(line), flush=True)

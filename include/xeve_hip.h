@@ -800,6 +800,11 @@ int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l
                                    const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter,
                                    const xeve_hip_ctu_job *jobs, int nchains, xeve_hip_ctu_data *out, xeve_hip_sbac *next_best, double *cost, void *workspace,
                                    size_t workspace_bytes, void *stream);
+/* The walk runs as ONE kernel per call (xeve_amd/csrc/walk.h: a workgroup per team of chains executes the whole quad-tree schedule; XEVE_HIP_WALK=0 selects the composed
+ * walk of ~10 000 launches per step instead).  Its in-kernel stage profile: _enable(1) makes thread 0 of team 0 add the shader cycles between two stage marks to the
+ * stage's class; _prof copies {cycles[n], marks[n]} of the classes since the last call into out (cap >= 2 n entries) and returns n (0: the profile is off). */
+int xeve_hip_walk_prof_enable(int on);
+int xeve_hip_walk_prof(unsigned long long *out, int cap);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,

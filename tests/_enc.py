@@ -131,6 +131,10 @@ BATCH_CASES_REAL = {
     "cfg2_720p_ldb_fast_8f_m8": (1280, 720, 1, 8, 2, ["--preset", "fast", "-b", "0", "-I", "0"], 8),
     "cfg3_1080p_ra_medium_9f_m8": (1920, 1080, 1, 9, 3, ["--preset", "medium"], 8),
     "cfg4_2160p_closedgop_medium_2f_m8": (3840, 2160, 1, 2, 4, ["--preset", "medium", "--closed-gop", "-I", "8"], 8),
+    # configs 2 and 3 over a whole 16-picture sub-GOP and the key picture after it (17 frames: four B layers, reference distances 16 / 8 / 4 / 2 / 1 in
+    # config 3; sixteen low-delay B pictures whose reference lists slide over the decoded picture buffer in config 2)
+    "cfg2_720p_ldb_fast_17f_m8": (1280, 720, 1, 17, 2, ["--preset", "fast", "-b", "0", "-I", "0"], 8),
+    "cfg3_1080p_ra_medium_17f_m8": (1920, 1080, 1, 17, 3, ["--preset", "medium"], 8),
 }
 
 # 10-bit input (the application's -d 10: 16-bit little-endian samples, handed to the codec as they are): the 8-bit clip of the seed widened by widen10

@@ -188,6 +188,16 @@ def test_configurations_outside_the_supported_set_are_refused():
     e = _enc.config(128, 64, ["--preset", "fast", "-b", "0", "--closed-gop", "-I", "5"])
     with pytest.raises(RuntimeError, match="even keyint"):
         _enc.encode_cpu(e, [bytes(128 * 64 * 3 // 2 * 6)], 6)
+    # more reference pictures than the frame loop's and the device path's tables hold (5 / 4 per list): refused before anything indexes them
+    for ref in (5, 6, 15, -1):
+        r = _enc.config(128, 64, ["--preset", "fast"])
+        r.ref = ref
+        with pytest.raises(RuntimeError, match="ref must lie"):
+            _enc.encode_cpu(r, [bytes(128 * 64 * 3 // 2 * 2)], 2)
+    # a low-delay closed GOP without an intra period: the reference divides by it (xeve_enc.c:1115-1117) -- refused, not a SIGFPE
+    z = _enc.config(128, 64, ["--preset", "fast", "-b", "0", "--closed-gop", "-I", "0"])
+    with pytest.raises(RuntimeError, match="keyint > 0"):
+        _enc.encode_cpu(z, [bytes(128 * 64 * 3 // 2 * 2)], 2)
     d = _enc.config(128, 64, ["--preset", "fast", "-d", "10"])
     d.reserved[1] = 12
     with pytest.raises(RuntimeError, match="input depth"):

@@ -66,6 +66,10 @@ struct Param {
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
         else return bad("preset must be 0 (fast) or 1 (medium): slow / placebo need rdo_dbk_switch, which the device path does not have");
+        // (the reference picture tables of the frame loop and of the device path hold 5 / 4 entries per list -- Dpb::refp, PicSetup::ref, the refi_bits table of
+        // fill_inter_params, XEVE_HIP_MAX_REFP planes per search: more reference pictures than that are refused here, before anything indexes them)
+        if(ref < 0 || ref > 4) return bad("ref must lie in 0 .. 4 (0: the preset's one reference picture per list)");
+        if(closed_gop && keyint == 0 && bframes == 0) return bad("low-delay closed GOPs need keyint > 0 (the reference divides by the intra period there)");
         if(ref) me_ref_num = bframes == 0 ? std::min(5, ref) : std::min(ref, bframes);
         if(bframes == 0) ref_pic_gap_length = 1;
         gop_size  = bframes + 1;

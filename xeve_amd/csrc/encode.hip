@@ -189,7 +189,7 @@ struct DevBuf {
     {
         if(bytes >= n) return true;
         if(p) (void)hipFree(p), p = nullptr, bytes = 0;
-        if(hipMalloc(&p, n) != hipSuccess) { p = nullptr; return false; }
+        if(hipMalloc(&p, n) != hipSuccess) { p = nullptr, (void)hipGetLastError(); return false; } // (the caller reports the failure: the runtime's sticky error is cleared)
         bytes = n;
         return true;
     }
@@ -247,6 +247,8 @@ struct xeve_hip_enc {
         org_l = (long)vh * P.w, org_c = (long)(vh / 2) * (P.w / 2), pic_l = (long)vh * s_l, pic_c = (long)(vh / 2) * s_c, map_pic = (long)(vh / 4) * w_scu;
         frame_bytes = P.frame_bytes(), slice_cap = (long)P.w * P.h * 3 / 2 + 4096;
         if((double)G * org_l >= 4294967296.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^32 samples (xh_common.h)");
+        if((long)G * T > 65535) return fail("too many GOPs for one batch: GOPs x row chains is a grid dimension (at most 65535)");
+        if((double)G * vh * 32 >= 2147483648.0) return fail("too many GOPs for one batch at this picture size: the tall picture's rows in 1/16 sample units must fit 31 bits");
         rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
@@ -305,6 +307,7 @@ struct xeve_hip_enc {
         // (XEVE_HIP_ENC_TWO_STORES=0: developer switch, the one-store form)
         const char *ts = getenv("XEVE_HIP_ENC_TWO_STORES");
         if(ok && rewrite_mode && !(ts && atoi(ts) == 0)) two_stores = store2[1].need(store_bytes());
+        if(!two_stores) (void)hipGetLastError(); // (the second store is optional: a failed allocation must not be reported by the next error check)
         if(!ok) return fail("not enough device memory for this batch (hipMalloc failed)");
         // everything starts from zero: the stores' padding and the rows between the stacked pictures are read by nobody before they are written, the maps' rows between
         // the pictures must say "not coded"
@@ -320,8 +323,15 @@ struct xeve_hip_enc {
         return hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
     int P_reserved0 = 0; // bit 0: always run the second writer pass (tests)
+    long walk_load = 0; // chains announced to the fused walk while a run is in progress (walk.hip: xh_walk_load)
+    void announce(long chains)
+    {
+        xh_walk_load(chains - walk_load);
+        walk_load = chains;
+    }
     ~xeve_hip_enc()
     {
+        announce(0);
         if(st2) (void)hipStreamSynchronize(st2), (void)hipStreamDestroy(st2);
         if(st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st);
         if(ev_ready) (void)hipEventDestroy(ev_ready);
@@ -525,7 +535,9 @@ extern "C" int xeve_hip_enc_footprint(const xeve_hip_enc_config *cfg, int ngops,
     Param P;
     if(!P.finish(*cfg)) { xh_set_error("xeve_hip_enc_footprint: %s", P.error.c_str()); return XEVE_HIP_ERR_ARG; }
     const long vh = (P.h + 2 * PAD_L + 63) & ~63;
-    const int  most = (int)std::min<double>(1 << 20, std::floor((4294967296.0 - 1) / ((double)vh * P.w)));
+    const int  T_ = std::min(P.threads, (P.h + CTU - 1) / CTU);
+    // (the batch's limits: stacked originals below 2^32 samples, GOPs x row chains a grid dimension, the tall picture's rows in 1/16 sample units in 31 bits -- dims())
+    const int  most = (int)std::min<double>(std::min<double>(65535 / std::max(1, T_), std::floor((2147483648.0 - 1) / ((double)vh * 32))), std::floor((4294967296.0 - 1) / ((double)vh * P.w)));
     if(max_gops) *max_gops = most;
     if(!device_bytes) return XEVE_HIP_OK;
     xeve_hip_enc e; // (dimensions and sizes only: nothing of it touches the device)
@@ -559,6 +571,7 @@ extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
     if(e->loop->begin(e->bitstreams) != 0) { xh_set_error("xeve_hip_enc_begin: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
     const std::vector<PicSetup> setups = e->loop->dry_setups();
     if(setups.empty() || !e->reserve(setups)) { xh_set_error("xeve_hip_enc_begin: %s", e->error.empty() ? "the frame loop refuses the run" : e->error.c_str()); return XEVE_HIP_ERR_ARG; }
+    e->announce((long)e->G * e->T);
     return XEVE_HIP_OK;
 }
 extern "C" int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining)
@@ -566,6 +579,7 @@ extern "C" int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t 
     XH_ENTER();
     XH_REQUIRE(e && e->loop && max_steps >= 0);
     const long left = e->loop->advance((long)max_steps);
+    if(left <= 0) e->announce(0);
     if(!e->error.empty()) { xh_set_error("xeve_hip_enc_advance: %s", e->error.c_str()); return XEVE_HIP_ERR_DEVICE; }
     if(left < 0) { xh_set_error("xeve_hip_enc_advance: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
     if(remaining) *remaining = left;
@@ -576,6 +590,7 @@ extern "C" int xeve_hip_enc_sync(xeve_hip_enc *e)
     XH_ENTER();
     XH_REQUIRE(e);
     XH_HIP(hipStreamSynchronize(e->st));
+    XH_HIP(hipStreamSynchronize(e->st2)); // (the second writer pass, the tile end and the read-back of a picture run there: a fence covers both)
     return XEVE_HIP_OK;
 }
 extern "C" int xeve_hip_enc_encode(xeve_hip_enc *e)

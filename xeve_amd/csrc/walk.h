@@ -191,6 +191,7 @@ struct P { // one call
     const int16_t *mc_l, *mc_c; // [16][8], [32][4]
     u64 *prof;                  // [PR_N] cycles + [PR_N] marks, or null
     int  dbg;                   // debugging: the inter analysis stops after stage `dbg` (0: runs whole)
+    u64 *sad_units;             // the walk's kernel-class timer is on: sample pairs the motion search compared are added here (XH_PROF_STRIPES words), else null
 };
 XW int dct_off(int log2n) { return ((1 << (2 * log2n)) - 4) / 3; }       // 0, 4, 20, 84, 340, 1364 (log2n 1 .. 6)
 #define XW_DCT_ELEMS (4 + 16 + 64 + 256 + 1024 + 4096)
@@ -628,14 +629,17 @@ template <bool FULL, class Src, class Run> XW void coder_stage(const Tm &tm, Lds
             S.ctx[(2 * w) * XW_CODL + l] = (uint16_t)v, S.ctx[(2 * w + 1) * XW_CODL + l] = (uint16_t)(v >> 16);
         }
         sync(tm);
-        if(tm.tid < cnt && S.jsrc[tm.tid]) {
-            const Sbac &in = *S.jsrc[tm.tid];
+        // job slot of this thread: the jobs are dealt round-robin over the team's waves (a wave runs as long as its longest lane per symbol: the fewer lanes of one
+        // wave are busy, the less they wait for each other -- and the other waves sit on SIMDs that have nothing else to do in a coder stage)
+        const int nw = tm.n >= 64 ? tm.n / 64 : 1, slot = tm.n >= 64 ? (tm.tid & 63) * nw + (tm.tid >> 6) : tm.tid;
+        if(slot < cnt && S.jsrc[slot]) {
+            const Sbac &in = *S.jsrc[slot];
             Cod c;
             c.range = in.range, c.code = in.code, c.code_bits = in.code_bits, c.stacked_ff = in.stacked_ff, c.stacked_zero = in.stacked_zero, c.pending_byte = in.pending_byte;
-            c.is_pending_byte = in.is_pending_byte, c.bitcounter = in.bitcounter, c.bin_counter = in.bin_counter, c.shifts = 0, c.m = S.ctx + tm.tid, c.ms = XW_CODL;
+            c.is_pending_byte = in.is_pending_byte, c.bitcounter = in.bitcounter, c.bin_counter = in.bin_counter, c.shifts = 0, c.m = S.ctx + slot, c.ms = XW_CODL;
             cod_reset(c);
-            run(base + tm.tid, c);
-            Sbac *o = S.jdst[tm.tid];
+            run(base + slot, c);
+            Sbac *o = S.jdst[slot];
             if(o) {
                 if(FULL) {
                     o->range = c.range, o->code = c.code, o->code_bits = c.code_bits, o->stacked_ff = c.stacked_ff, o->stacked_zero = c.stacked_zero, o->pending_byte = c.pending_byte;
@@ -828,7 +832,11 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
             int      any = 0;
 #pragma unroll
             for(int t = 0; t < 8; t++) v8[t] = t < cnt ? sc[q0 + t] : 0, any |= v8[t];
-            if(any) {
+            if(!any) { // eight zeros: the first continues the run it finds, the rest are zeros after a zero
+                base_cost += (run ? z1 : z0) + (int64_t)(cnt - 1) * z1, run += cnt;
+                continue;
+            }
+            {
 #pragma unroll
                 for(int t = 0; t < 8; t++)
                     if(t < cnt) t8[t] = B.tb[q0 + t], r0[t] = B.rq[q0 + t], r1[t] = B.rq[nn + q0 + t];

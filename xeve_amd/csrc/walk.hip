@@ -2,6 +2,7 @@
 // whole quad-tree schedule executed inside the kernel).  This file is the launcher: device copies of the tables and of the schedule, the parameter record, the launch.
 // xeve_hip_mode_analyze_ctu_jobs (tree.hip) routes here unless XEVE_HIP_WALK=0 (the composed walk: ~10 000 launches per CTU step, kept for A/B measurements).
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "xh_common.h"
@@ -46,7 +47,12 @@ struct WalkDev { // device copies, rebuilt when the library is re-bound
     }
 };
 WalkDev g_walk;
+std::atomic<int> g_walk_prof_on{0};
+std::atomic<long> g_walk_load{0}; // chains of the batch encoders with a run in progress in this process (they launch side by side, a stream each)
 } // namespace
+
+// a batch encoder starts (+) or ends (-) a run of `chains` lockstep chains: the walks of all running encoders share the chip's workgroup slots
+void xh_walk_load(long chains) { g_walk_load.fetch_add(chains); }
 
 bool xh_walk_enabled()
 {
@@ -72,9 +78,18 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
                 size_t workspace_bytes, int vh, hipStream_t st)
 {
     XH_REQUIRE(workspace_bytes >= xh_walk_workspace(nchains));
-    static const int C_env = getenv("XEVE_HIP_WALK_C") ? atoi(getenv("XEVE_HIP_WALK_C")) : 8;
+    static const int C_env = getenv("XEVE_HIP_WALK_C") ? atoi(getenv("XEVE_HIP_WALK_C")) : 0;
     static const int NT_env = getenv("XEVE_HIP_WALK_NT") ? atoi(getenv("XEVE_HIP_WALK_NT")) : XW_NT;
-    const int C = C_env < 1 ? 1 : C_env > XW_MAXC ? XW_MAXC : C_env, NT = NT_env < 64 ? 64 : NT_env > XW_NT ? XW_NT : (NT_env & ~63);
+    static const int wg_slots = [] {
+        int dev = 0, cus = 256;
+        if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (cus > 0 ? cus : 256) * XW_WG_PER_CU;
+    }();
+    // chains per team: a team's step takes the longer the more chains it carries (its stages run them in lockstep), so as few as keep every chain in flight resident at once --
+    // all running encoders' chains over the chip's workgroup slots (XEVE_HIP_WALK_C pins it)
+    const long in_flight = std::max<long>(g_walk_load.load(), nchains);
+    const int  C_auto = (int)std::min<long>(XW_MAXC, (in_flight + wg_slots - 1) / wg_slots);
+    const int  C = C_env < 1 ? std::max(1, C_auto) : C_env > XW_MAXC ? XW_MAXC : C_env, NT = NT_env < 64 ? 64 : NT_env > XW_NT ? XW_NT : (NT_env & ~63);
     xw::P q;
     xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
     static const int force_count = getenv("XEVE_HIP_WALK_COUNT") ? atoi(getenv("XEVE_HIP_WALK_COUNT")) : 0; // (probes: the encoder's count-only states from any caller)
@@ -119,17 +134,21 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
             hit = &D.ops.back();
         }
         q.ops = hit->dev, q.nops = hit->n, q.dct = D.dct, q.scan = D.scan, q.entropy = D.entropy;
-        static const int prof_on = getenv("XEVE_HIP_WALK_PROF") ? atoi(getenv("XEVE_HIP_WALK_PROF")) : 0;
+        static const int prof_env = getenv("XEVE_HIP_WALK_PROF") ? atoi(getenv("XEVE_HIP_WALK_PROF")) : 0;
+        const int prof_on = prof_env || g_walk_prof_on.load();
+        if(!prof_on) q.prof = nullptr;
         if(prof_on && !D.prof) {
             XH_HIP(hipMalloc((void **)&D.prof, 2 * xw::PR_N * 8));
             XH_HIP(hipMemset(D.prof, 0, 2 * xw::PR_N * 8));
         }
-        q.prof = D.prof;
+        q.prof = prof_on ? D.prof : nullptr;
     }
     static const int dbg = getenv("XEVE_HIP_WALK_DBG") ? atoi(getenv("XEVE_HIP_WALK_DBG")) : 0;
     q.dbg = dbg;
     q.cw = (xw::Cw *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const int teams = (nchains + C - 1) / C;
+    q.sad_units = xh_prof_units(XH_PROF_WALK);
+    XhProf timer(XH_PROF_WALK, st); // (HIP events on the walk's own stream around its one launch, when the class is switched on)
     if(q.full) k_walk<true><<<teams, NT, 0, st>>>(q);
     else k_walk<false><<<teams, NT, 0, st>>>(q);
     XH_HIP(hipGetLastError());
@@ -145,4 +164,11 @@ extern "C" int xeve_hip_walk_prof(unsigned long long *out, int cap)
     if(hipMemcpy(out, g_walk.prof, 2 * xw::PR_N * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     (void)hipMemset(g_walk.prof, 0, 2 * xw::PR_N * 8);
     return xw::PR_N;
+}
+
+// the in-kernel stage profile on / off for the walks launched from now on (the same switch as XEVE_HIP_WALK_PROF=1, at run time)
+extern "C" int xeve_hip_walk_prof_enable(int on)
+{
+    g_walk_prof_on.store(on != 0);
+    return XEVE_HIP_OK;
 }

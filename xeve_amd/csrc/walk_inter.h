@@ -538,16 +538,15 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
     sync(tm);
     for(;;) {
         if(tm.tid == 0) S.flag[0] = 0;
-        for(int i = tm.tid; i < nj * XW_MEC; i += tm.n) {
-            const int j = i / XW_MEC, c = i - j * XW_MEC;
-            const MeJob &J = S.mej[j];
-            if(c >= J.nc) continue;
-            S.mbits[i] = (short)me_cand_bits(J, c), msad[i] = 0;
+        int total = 0;
+        for(int j = 0; j < nj; j++) total += S.mej[j].nc;
+        for(int it = tm.tid; it < total; it += tm.n) { // (the items are the candidates that exist, search after search)
+            int c = it, j = 0;
+            while(c >= S.mej[j].nc) c -= S.mej[j].nc, j++;
+            S.mbits[j * XW_MEC + c] = (short)me_cand_bits(S.mej[j], c), msad[j * XW_MEC + c] = 0;
         }
         sync(tm), mark(tm, p, S, PR_M_BITS);
         // the SADs: every candidate in `parts` parts (whole rows of an integer position, columns of a sub-pel position) so that a round fills the lanes
-        int total = 0;
-        for(int j = 0; j < nj; j++) total += S.mej[j].nc;
         int parts = 1, spel = 0;
         for(int j = 0; j < nj; j++) spel |= S.mej[j].nc > 0 && S.mej[j].ctype == CT_SPEL;
         while(parts < (spel ? N : N / 8) && total * parts < 4 * tm.n) parts <<= 1; // (rows of an integer position in groups of >= 8; a sub-pel position down to single columns)
@@ -560,6 +559,16 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
             const MeJob &J = S.mej[j];
             if(S.mbits[e] < 0) continue;
             aadd(&msad[e], me_cand_sad_part(p, J, c, N, part, parts));
+#if XW_DEVICE
+            if(p.sad_units) atomicAdd(p.sad_units + (blockIdx.x & 255), (u64)(N * N / (J.ctype != CT_SPEL && parts > N / 8 ? N / 8 : parts))); // (roofline: algorithmic work)
+#endif
+        }
+        sync(tm);
+        for(int it = tm.tid; it < total; it += tm.n) { // MV_COST + the SAD term of every candidate
+            int c = it, j = 0;
+            while(c >= S.mej[j].nc) c -= S.mej[j].nc, j++;
+            const int e = j * XW_MEC + c;
+            if(S.mbits[e] >= 0) S.mcost[e] = me_cand_total(p, S.mej[j], S.mbits[e], msad[e]);
         }
         sync(tm), mark(tm, p, S, PR_M_SAD);
         for(int j = tm.tid; j < nj; j += tm.n) {
@@ -570,8 +579,7 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
             for(int c = 0; c < J.nc; c++) { // the first strictly cheaper candidate in evaluation order wins
                 const int b = S.mbits[j * XW_MEC + c];
                 if(b < 0) continue;
-                const unsigned v = me_cand_total(p, J, b, msad[j * XW_MEC + c]);
-                S.mcost[j * XW_MEC + c] = v;
+                const unsigned v = S.mcost[j * XW_MEC + c];
                 if(idx < 0 || v < best) best = v, idx = c, bits = b;
             }
             me_advance(p, J, false, best, idx, bits, S.mcost + j * XW_MEC, S.mbits + j * XW_MEC);

@@ -38,7 +38,7 @@ bool xh_ready();
     } while(0)
 
 // ---- kernel-class timers (abi.cpp; include/xeve_hip.h "xeve_hip_prof_*") ----------------------
-enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3, XH_PROF_RESID = 4, XH_PROF_RDOQ = 5, XH_PROF_CU_BITS_SLOW = 6 };
+enum { XH_PROF_SEARCH = 0, XH_PROF_SPEL = 1, XH_PROF_CU_BITS = 2, XH_PROF_MC = 3, XH_PROF_RESID = 4, XH_PROF_RDOQ = 5, XH_PROF_CU_BITS_SLOW = 6, XH_PROF_WALK = 7 };
 bool  xh_prof_on(int cls);
 void *xh_prof_begin(int cls, hipStream_t st);
 void  xh_prof_end(void *tok, hipStream_t st);
@@ -109,6 +109,7 @@ struct XhVhScope {
 // the next CTU's counts start from the WRITER's state (xeve_enc.c:138-139), never from the walk's -- asks for exactly that much: within the scope every bit-count
 // launch runs the count-only kernel, whose states carry range + models and a reset remainder.  The C-ABI's own callers get the complete state (the default).
 int xh_count_states();
+void xh_walk_load(long chains); // walk.hip: a batch encoder starts (+) / ends (-) a run of that many lockstep chains
 struct XhCountStatesScope {
     int prev;
     XhCountStatesScope();

@@ -213,6 +213,8 @@ FUNCTIONS = {
     "xeve_hip_mode_analyze_ctu_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 4 +
                                        [C.c_size_t, c_void_p]),
     "xeve_hip_mode_analyze_ctu_intra_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 3),
+    "xeve_hip_walk_prof_enable": (c_int, [c_int]),
+    "xeve_hip_walk_prof": (c_int, [c_void_p, c_int]),
     "xeve_hip_mode_analyze_ctu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_void_p] * 3),
     "xeve_hip_eco_ctu_jobs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_eco_tile_end_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -304,7 +306,7 @@ def table_calls():
     return int(load().xeve_hip_table_calls())
 
 
-PROF_CLASSES = ("search", "spel", "cu_bits", "mc", "resid", "rdoq", "cu_bits_slow")  # include/xeve_hip.h: xeve_hip_prof_*
+PROF_CLASSES = ("search", "spel", "cu_bits", "mc", "resid", "rdoq", "cu_bits_slow", "walk")  # include/xeve_hip.h: xeve_hip_prof_*
 
 
 def prof_enable(classes=PROF_CLASSES):
