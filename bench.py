@@ -26,7 +26,7 @@ The JSON line also carries
                  device) over the kernel's HIP-event time on its own stream, against the VALU roof for v_sad_u16, with BASELINE's algorithmic-bytes-over-HBM-peak figure and
                  the PMC HBM traffic as secondary keys; `by_time` = the kernel's own stage profile (in-kernel cycle marks): which stage class owns its time;
   cpu_baseline : oracle/_ref/xeveb_app (the unmodified reference, compiled in place) on this box's host cores: -m 8 on the same 8-frame GOP (= `value`), -m 1, and
-                 `all_cores`: floor(physical cores / 8) concurrent -m 8 processes over distinct GOPs.
+                 `all_cores`: floor(cores available / 8) concurrent -m 8 processes over distinct GOPs.
 """
 import argparse
 import hashlib
@@ -50,6 +50,9 @@ HBM_PEAK_GBS = 8000.0
 CUS, SIMDS, CLOCK_GHZ = 256, 4, 2.4
 VALU_SAD_PEAK_GBS = CUS * SIMDS * 32 * 8 * CLOCK_GHZ  # v_sad_u16: 2 sample pairs = 8 algorithmic bytes per lane, 32 lanes per clock and SIMD (a wave64 issues over 2 clocks)
 BYTES_PER_SAMPLE_PAIR = 4  # a block SAD reads 2 x (w * h * 2 B)
+BYTES_PER_SEARCH_UNIT = 256  # the composed walk's search kernel counts units of 64 sample pairs
+VALU_ISSUE_PEAK_GINST = CUS * SIMDS * CLOCK_GHZ / 2  # wave64 VALU instructions/s (G): one per SIMD every 2 clocks
+INSTR_PER_BIN = 40  # k_cu_bits: VALU instructions per bin (profiles/r03_cu_bits_pmc.txt)
 STAGE_NAMES = ["clear", "enter", "leaf", "child_done", "exit", "root", "mid", "i_setup", "i_nbr", "i_pred", "i_satd", "i_list", "i_bits", "i_pick", "i_cpred", "i_final", "b_diff",
                "b_t0", "b_t1", "b_rdoq", "b_dq", "b_t2", "b_t3", "b_rec", "e_cand", "e_skip", "e_me", "e_spel", "e_mc", "e_bits", "e_glue", "e_final", "m_bits", "m_sad", "m_sel",
                "q_a", "q_b"]
@@ -83,13 +86,23 @@ def host_info():
     except Exception:
         pass
     usable = len(os.sched_getaffinity(0))
+    quota = None
+    try:  # the container's CPU-time quota (cgroup v2 cpu.max = "<quota> <period>" or "max ..."): what "every core" means for a process in here
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(q) // int(per))
+    except Exception:
+        pass
     physical = len(phys) if phys else max(1, (os.cpu_count() or 2) // 2)
-    return {"cpu_model": model, "logical_cores": os.cpu_count(), "usable_cores": usable, "physical_cores": min(physical, usable)}
+    return {"cpu_model": model, "logical_cores": os.cpu_count(), "usable_cores": usable, "physical_cores": physical, "cgroup_cpu_quota": quota,
+            "cores_available": min(physical, usable, quota) if quota else min(physical, usable)}
 
 
 class CpuApp:
-    """the reference encoder on this box's host cores while the GPU encodes: first -m 8 on the 8-frame seed-4 GOP and -m 1 on its first two frames, side by side (9 threads);
-    when -m 8 is through, floor(physical cores / 8) concurrent -m 8 processes, each on a GOP of its own (`all_cores`)"""
+    """the reference encoder on this box's host cores: -m 8 on the 8-frame seed-4 GOP and -m 1 on its first two frames, side by side (9 threads) while the GPU encodes;
+    once the GPU's timed region is over (all_cores_may_start: the composed walk's host threads issue ~90 000 launches a second each and must not lose their cores to the
+    baseline), floor(cores available / 8) concurrent -m 8 processes, each on a GOP of its own (`all_cores`; cores available = physical cores, capped by the container's
+    CPU quota)"""
 
     def __init__(self, width, height, frames, clip, with_m1=True):
         self.w, self.h, self.frames, self.err, self.out = width, height, frames, None, {}
@@ -105,6 +118,7 @@ class CpuApp:
             self.err = repr(e)[:200]
             return
         self.with_m1 = with_m1
+        self.go_all = threading.Event()
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
@@ -134,7 +148,8 @@ class CpuApp:
                 self.out["m1"] = self._parse(txt, p1.returncode)
                 self.out["m1"]["frames"] = 2
             # all cores: N processes of 8 threads each, every one on its own GOP (the seed-4 GOP and N - 1 GOPs of fresh uniform bytes)
-            n = max(1, self.host["physical_cores"] // 8)
+            self.go_all.wait(1800)
+            n = max(1, self.host["cores_available"] // 8)
             rng = np.random.default_rng(5)
             files = [yuv]
             for i in range(1, n):
@@ -155,9 +170,14 @@ class CpuApp:
         except Exception as e:  # noqa: BLE001
             self.err = repr(e)[:200]
 
+    def all_cores_may_start(self):
+        if not self.err:
+            self.go_all.set()
+
     def result(self, timeout=1500):
         if self.err and not self.out:
             return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: " + self.err}
+        self.go_all.set()
         self.th.join(timeout)
         try:
             import shutil
@@ -168,8 +188,8 @@ class CpuApp:
         return {"value": m8.get("fps"), "unit": "frames/s", "cores": 8, "kind": "reference",
                 "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit 4:2:0 "
                           "clip = GOP 0 of the GPU job (1 IDR + 7 B pictures); `value` = -m 8 (the library's thread maximum, the setting the GPU job reproduces byte for byte); "
-                          "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(physical cores / 8) such processes side by side, each on its own GOP; on the host's cores "
-                          "while the GPU encoded" % (self.w, self.h, self.frames),
+                          "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(cores available / 8) such processes side by side, each on its own GOP (after the GPU's timed region; cores available = "
+                          "physical cores capped by the container's CPU quota, `host`); -m 8 and -m 1 ran on the host's cores while the GPU encoded" % (self.w, self.h, self.frames),
                 "m8": m8, "m1": self.out.get("m1", {}), "all_cores": self.out.get("all_cores", {}), "host": self.host, "error": self.err}
 
 
@@ -252,11 +272,28 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     per = max(1, run_steps // n)
     sizes = [per] * (n - 1) + [max(0, run_steps - per * (n - 1))]
 
-    def run_slices(lo, hi):
-        """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL)"""
+    L = lib.load()
+    fused = [bool(L.xeve_hip_walk_fused(g * min(T, h_lcu))) for g in Gs]  # which walk every batch's steps run (walk.hip: by the chains in lockstep, or pinned by --walk)
+    cls = "walk" if fused[0] else "search"
+    live = [0.0, 0, 0]
+
+    def drain():
+        v = lib.prof_read()[cls]  # (waits for the device: only at a fence or, with one batch, between slices -- keeps the pool of timing events small)
+        live[0] += v[0]
+        live[1] += v[1]
+        live[2] += v[2]
+
+    def run_slices(lo, hi, timers=False):
+        """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL).  timers: HIP events around the roofline
+        kernel's launches on their own stream, live in the timed region -- the fused walk's one launch per step throughout; the composed walk's search kernel (hundreds of
+        launches per step) in every slice with one batch (read out after each), in the last slice only with several (a read-out would stall the other batches)"""
         def one(e):
             for i in range(lo, hi):
+                if timers and (cls == "walk" or B == 1 or (i == hi - 1 and e is enc)):
+                    lib.prof_enable([cls])
                 e.advance(sizes[i])
+                if timers and cls == "search" and B == 1:
+                    drain()
         if B == 1:
             one(enc)
             return
@@ -266,15 +303,18 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
 
     run_slices(0, a.warmup)
     fence()
-    lib.prof_enable(["walk"])  # HIP events around the walk's one launch per step, on its own stream; the SAD sample pairs counted in the kernel
+    lib.prof_enable(None)
     lib.prof_read()
     fence()
     t0 = time.perf_counter()
-    run_slices(a.warmup, n)
+    run_slices(a.warmup, n, timers=True)
     fence()
     dt = time.perf_counter() - t0
-    walk_ms, walk_n, walk_pairs = lib.prof_read()["walk"]
+    drain()
     lib.prof_enable(None)
+    k_ms, k_n, k_units = live
+    if cpu is not None:
+        cpu.all_cores_may_start()
     timed_steps = sum(sizes[a.warmup:])
     first_timed = sum(sizes[:a.warmup])
     frames_timed = sum(Gs) * timed_steps / per_picture
@@ -301,17 +341,20 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                           "byte_identical_to_the_reference": bool(k > 0 and same),
                           "note": "the bitstream GOP 0 has produced when the bounded job stops (the pictures whose access units are complete) against the reference's "
                                   "bitstream up to the same picture; the whole 8-frame GOP: tests/test_enc_gpu.py"})
-        alg = walk_pairs * BYTES_PER_SAMPLE_PAIR
-        alg_gbs = alg / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
-        roof = {"kernel": "k_walk (xeve_amd/csrc/walk.h: the whole CTU mode decision of a lockstep step in ONE launch; the motion search's SAD rounds run inside it)",
+        alg = k_units * (BYTES_PER_SAMPLE_PAIR if cls == "walk" else BYTES_PER_SEARCH_UNIT)
+        alg_gbs = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        roof = {"kernel": "k_walk (xeve_amd/csrc/walk.h: the whole CTU mode decision of a lockstep step in ONE launch; the motion search's SAD rounds run inside it)" if cls == "walk" else
+                          "k_me_epzs<8|16|32|64, uni|bi> (the integer motion search inside xeve_hip_mode_analyze_ctu_jobs; the SAD kernel of the path)",
                 "bound": "valu", "achieved": round(alg_gbs, 2), "peak": VALU_SAD_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / VALU_SAD_PEAK_GBS, 6),
-                "how": "algorithmic bytes of the motion search (4 per sample pair compared, counted on the device) over the HIP-event time of the kernel's launches in the timed "
-                       "region (events on the walk's own streams), against the rate at which the chip's VALUs can issue v_sad_u16.  The kernel is the whole analysis: the search is "
-                       "one stage class of it (`by_time`), so this is the SAD work per second of a kernel that spends most of its time elsewhere",
-                "launches_in_region": walk_n, "avg_launch_ms": round(walk_ms / max(1, walk_n), 3), "algorithmic_bytes_per_launch": int(alg / max(1, walk_n)),
+                "how": ("algorithmic bytes of the motion search (4 per sample pair compared, counted on the device) over the HIP-event time of the kernel's launches in the timed "
+                        "region (events on the walk's own streams), against the rate at which the chip's VALUs can issue v_sad_u16.  The kernel is the whole analysis: the search is "
+                        "one stage class of it (`by_time`), so this is the SAD work per second of a kernel that spends most of its time elsewhere") if cls == "walk" else
+                       ("algorithmic bytes (256 per 64 sample pairs evaluated, counted on the device) over the kernel's HIP-event time in the timed region, against the rate at "
+                        "which the chip's VALUs can issue v_sad_u16 (8 algorithmic bytes per lane and instruction)"),
+                "launches_in_region": k_n, "avg_launch_ms": round(k_ms / max(1, k_n), 4), "algorithmic_bytes_per_launch": int(alg / max(1, k_n)),
                 "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 6), "traffic": None}
         try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_walk_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")))
             roof["traffic"] = pmc.get("hbm_bytes_per_launch")
             roof["traffic_is"] = pmc.get("what")
             for k in ("valu_insts_per_launch", "valu_issue_frac", "wait_any_frac", "waves_per_launch", "avg_launch_s"):
@@ -324,7 +367,10 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                    "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
                                "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
                                % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, T, run_steps, a.warmup, a.steps),
-                   "walk": "composed (XEVE_HIP_WALK=0: ~10 000 launches per step)" if os.environ.get("XEVE_HIP_WALK") == "0" else "fused (one k_walk launch per step)",
+                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
+                   "walk_choice": "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
+                                  "by the chains in lockstep (walk.hip: the fused kernel up to 1024 chains -- it finishes a step of few chains sooner --, the composed walk above: "
+                                  "its kernels pack the lanes of many chains and code more CTUs per second; profiles/r04_walks.md)",
                    "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "pictures_run": P, "row_chains_per_picture": T,
                    "chains_in_lockstep": [g * min(T, h_lcu) for g in Gs], "lockstep_steps_per_picture": per_picture, "lockstep_steps_timed": timed_steps,
                    "timed_picture_mix": {"picture_%d%s" % (k, "_IDR" if k == 0 else "_B"): round(v / per_picture, 3) for k, v in sorted(mix.items())},
@@ -335,7 +381,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                "bitstream_check": check, "roofline": roof, "cpu": cpu}
     for e in encs:  # (the job's HBM goes back; an unfinished run is abandoned)
         e.close()
-    return rec, (cfg, Gs, per_picture, fb)
+    return rec, (cfg, Gs, per_picture, fb, cls)
 
 
 def stage_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=4):
@@ -375,6 +421,40 @@ def stage_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=4):
             "tools/scratch/cod_bench.hip; the stage lasts as long as its longest lane)", "cycles_per_step_team0": tot // max(1, steps)}
 
 
+def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
+    """the composed walk per kernel class: a short untimed encode with every class's HIP-event timer on, steps of the first B picture"""
+    from xeve_amd import encode, lib
+
+    e = encode.BatchEncoder(cfg, gops, frames)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    d = torch.randint(0, 256, (fb * frames,), dtype=torch.uint8, device=dev, generator=gen)
+    for g in range(gops):
+        for f in range(frames):
+            e.push(g, f, d[f * fb:(f + 1) * fb])
+    e.begin()
+    e.advance(per_picture)  # the IDR picture, untimed and without timers
+    e.sync()
+    lib.prof_enable([c for c in lib.PROF_CLASSES if c != "walk"])
+    lib.prof_read()
+    e.advance(steps)
+    e.sync()
+    allc = lib.prof_read()
+    lib.prof_enable(None)
+    e.close()
+    kern = {c: {"ms_per_step": round(v[0] / steps, 3), "launches_per_step": v[1] // steps} for c, v in allc.items() if c != "walk"}
+    cb = allc["cu_bits"]
+    bins_s = cb[2] / (cb[0] * 1e-3) if cb[0] > 0 else 0.0
+    kern["cu_bits"].update({"bins_per_step": int(cb[2] / steps), "Gbin_per_s": round(bins_s / 1e9, 3)})
+    tot = sum(v[0] for c, v in allc.items() if c not in ("cu_bits_slow", "walk"))
+    return {"kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None,
+            "bound": "valu-issue", "achieved": round(bins_s * INSTR_PER_BIN / 64 / 1e9, 3), "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+            "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
+            "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
+                   "a serial chain per lane, so the roof is only reachable with every lane of every wave busy" % (INSTR_PER_BIN, CUS, SIMDS, CLOCK_GHZ),
+            "kernels": kern, "kernels_note": "HIP-event time per lockstep step of the first B picture with %d GOPs in lockstep, all class timers on (untimed extra encode)" % gops}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,7 +467,8 @@ def main():
     ap.add_argument("--pictures", type=int, default=3, help="coded pictures of every GOP the bounded job runs (0: the whole job)")
     ap.add_argument("--threads", type=int, default=8, help="row chains per picture = the reference's -m")
     ap.add_argument("--batches", type=int, default=3, help="batches encoded side by side on this GPU (a host thread and a HIP stream each)")
-    ap.add_argument("--walk", default=os.environ.get("XEVE_BENCH_WALK", "auto"), choices=["auto", "fused", "composed"], help="the CTU walk: one kernel per step (fused) or ~10 000 launches (composed)")
+    ap.add_argument("--walk", default=os.environ.get("XEVE_BENCH_WALK", "auto"), choices=["auto", "fused", "composed"],
+                    help="the CTU walk: one kernel per step (fused), ~10 000 launches per step (composed), or the library's choice by the chains in lockstep (auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (the kernel's stage profile, the 1920x1080 figure)")
     a = ap.parse_args()
@@ -431,7 +512,7 @@ def main():
 
     xeve_amd.init(local)
     solo = rank == 0 and world == 1
-    rec, (cfg, Gs, per_picture, fb) = run_job(a, torch, dist, dev, rank, world, a.width, a.height, "headline", solo and not a.no_cpu_baseline)
+    rec, (cfg, Gs, per_picture, fb, cls) = run_job(a, torch, dist, dev, rank, world, a.width, a.height, "headline", solo and not a.no_cpu_baseline)
     line = None
     if rank == 0:
         cpu = rec.pop("cpu")
@@ -444,7 +525,7 @@ def main():
         line["config"]["library_built_in_this_run"] = built_here
     if solo and not a.no_secondary:
         try:
-            line["roofline"]["by_time"] = stage_profile(torch, dev, cfg, max(8, Gs[0] // 4), a.frames, per_picture, fb)
+            line["roofline"]["by_time"] = (stage_profile if cls == "walk" else class_profile)(torch, dev, cfg, max(8, Gs[0] // 4) if cls == "walk" else max(136, Gs[0] // 2), a.frames, per_picture, fb)
         except Exception as e:  # noqa: BLE001
             line["roofline"]["by_time"] = {"error": repr(e)[:300]}
         if (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)

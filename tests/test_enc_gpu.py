@@ -133,7 +133,12 @@ def test_a_wide_batch_fed_from_device_memory_keeps_every_gop_exact(hip, yuv_dir)
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("name", sorted(_enc.BATCH_CASES_REAL))
+# (the 8- / 9-frame forms of configs 2 and 3 and the 2-frame form of config 4 keep their goldens -- tests/test_enc_host.py and bench history use them -- but the GPU suite runs
+# the forms that contain them: 17 frames of configs 2 and 3 here, the whole 8-frame GOP of config 4 below)
+CONTAINED = {"cfg2_720p_ldb_fast_8f_m8", "cfg3_1080p_ra_medium_9f_m8", "cfg4_2160p_closedgop_medium_2f_m8"}
+
+
+@pytest.mark.parametrize("name", sorted(set(_enc.BATCH_CASES_REAL) - CONTAINED))
 def test_batches_at_real_picture_sizes_on_the_gpu(name, hip, yuv_dir):
     """>= 2 GOPs x 8 frames at 1920x1080 (8 row chains per picture: 16 chains in lockstep, the second writer pass over 510 CTUs per picture)"""
     w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES_REAL[name]
@@ -142,6 +147,30 @@ def test_batches_at_real_picture_sizes_on_the_gpu(name, hip, yuv_dir):
     outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
     print(name, st)
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+FULL_GOPS = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "cfg4_8f_v1.json")))  # make_cfg4_8f_golden.py: the unmodified reference on the bench's own clips
+
+
+@pytest.mark.parametrize("name", sorted(FULL_GOPS))
+def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, hip):
+    """BASELINE config 4 (3840x2160) and 1920x1080 as FULL `-I 8` closed GOPs (1 IDR + 7 hierarchical B pictures, -m 8) -- the clip bench.py seeds its
+    batches with; GOP 1 of the batch is the same clip with its frames in reverse order (another GOP beside it in lockstep), GOP 0 must be the reference's file byte for byte
+    and the bitstream after every picture the golden's prefix"""
+    import numpy as np
+
+    from bench import check_prefix, reference_noise
+
+    r = FULL_GOPS[name]
+    w, h, frames = r["w"], r["h"], r["frames"]
+    fb = w * h * 3 // 2
+    clip = reference_noise(fb * frames, r["seed"])
+    back = np.ascontiguousarray(clip.reshape(frames, fb)[::-1]).reshape(-1)
+    outs, st = _run(hip, hip.config(w, h, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=8), [clip.tobytes(), back.tobytes()], frames)
+    print(name, st)
+    assert (len(outs[0]), _enc.md5(outs[0])) == (r["bytes"], r["md5"])
+    assert check_prefix(outs[0], r) == frames
+    assert outs[1] != outs[0] and len(outs[1]) > r["bytes"] // 2
 
 
 def test_configurations_outside_the_supported_set_are_refused_by_the_library(hip):

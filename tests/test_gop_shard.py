@@ -146,3 +146,30 @@ def test_two_worker_processes_on_the_gpu_reproduce_the_references_one_run(tmp_pa
     gop.run_encoder_shards(yuv, out, config, n, keyint, devices=[0], per_device=2, timeout=600, env={"PYTHONPATH": ROOT})
     b = open(out, "rb").read()
     assert (len(b), hashlib.md5(b).hexdigest()) == (gold["bytes"], gold["md5"])
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """the N > 1 control path of bench.py (rendezvous, barriers, max over ranks, rank 0's one JSON line) with two ranks on GPU 0 (XEVE_BENCH_SHARE_GPU=1:
+    gloo, never used for numbers); every rank encodes its own GOPs, the aggregate counts both"""
+    import json
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "256", "--height", "128", "--gops", "6", "--frames", "8", "--pictures", "3",
+           "--batches", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, XEVE_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 alone speaks
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["gops_in_lockstep"] == [6, 6] and r["config"]["pictures_run"] == 3
+    assert r["bitstream_check"]["all_seeded_gops_same_bytes"] and r["bitstream_check"]["gop0_bytes_so_far"] > 0
+    # both ranks' frames are in the aggregate: 2 ranks x 12 GOPs x the timed share (3 of 4 slices of 3 pictures)
+    assert abs(r["config"]["frames_in_timed_region"] - 12 * 3 * 0.75) < 4.0
+    assert r["roofline"]["launches_in_region"] > 0

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=25)
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many lockstep steps (0: the whole job)")
     ap.add_argument("--content", default="noise")
+    ap.add_argument("--prof-after", type=int, default=-1, help="switch the walk's in-kernel stage profile on once this many steps are done (e.g. a picture's steps: the inter picture alone)")
     a = ap.parse_args()
     import torch
 
@@ -57,6 +58,10 @@ def main():
     done, left = 0, total
     while left > 0 and (a.max_steps == 0 or done < a.max_steps):
         n = min(a.chunk, per_pic - done % per_pic)  # (a chunk never crosses a picture's end: its last step carries the picture end)
+        if a.prof_after >= 0 and done >= a.prof_after and not os.environ.get("XEVE_HIP_WALK_PROF"):
+            from xeve_amd import lib
+            lib.load().xeve_hip_walk_prof_enable(1)
+            os.environ["XEVE_HIP_WALK_PROF"] = "runtime"
         t = time.perf_counter()
         st0 = enc.stats()
         left = enc.advance(n)

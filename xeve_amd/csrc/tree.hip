@@ -555,7 +555,7 @@ static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const 
 }
 
 // the fused walk (walk.hip): one launch per call
-bool   xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I);
+bool   xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int nchains);
 size_t xh_walk_workspace(int nchains);
 int    xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
                    const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems, const xeve_hip_sbac *states, const xeve_hip_tree_params *p,
@@ -566,13 +566,13 @@ extern "C" size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hi
 {
     if(!tree_params_ok(p) || nchains <= 0 || (p->ip.slice_type != 2 && !tree_inter_ok(p, I))) return 0;
     if(p->ip.slice_type == 2) I = nullptr;
-    if(xh_walk_supported(p, I)) return xh_walk_workspace(nchains);
+    if(xh_walk_supported(p, I, nchains)) return xh_walk_workspace(nchains);
     return tree_layout(nchains, p, I, s_org_l, s_org_c).total;
 }
 extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *p)
 {
     if(!tree_params_ok(p) || nchains <= 0 || p->ip.slice_type != 2) return 0;
-    if(xh_walk_supported(p, nullptr)) return xh_walk_workspace(nchains);
+    if(xh_walk_supported(p, nullptr, nchains)) return xh_walk_workspace(nchains);
     return tree_layout(nchains, p, nullptr, 0, 0).total;
 }
 
@@ -671,7 +671,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
         (void)ws_;
     }
     if(nchains == 0) return XEVE_HIP_OK;
-    if(xh_walk_supported(p, I)) // the fused walk: the whole schedule inside one kernel (walk.hip)
+    if(xh_walk_supported(p, I, nchains)) // the fused walk: the whole schedule inside one kernel (walk.hip)
         return xh_walk_run(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost,
                            workspace, workspace_bytes, vh, (hipStream_t)stream);
     const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c);

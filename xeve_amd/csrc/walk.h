@@ -190,6 +190,7 @@ struct P { // one call
     const int16_t (*col0)[2][2], (*col1)[2][2];
     const int16_t *mc_l, *mc_c; // [16][8], [32][4]
     u64 *prof;                  // [PR_N] cycles + [PR_N] marks, or null
+    int  deal;                  // how a coder stage deals its jobs to the lanes: 0 round-robin over the team's waves, 1 packed into as few waves as hold them
     int  dbg;                   // debugging: the inter analysis stops after stage `dbg` (0: runs whole)
     u64 *sad_units;             // the walk's kernel-class timer is on: sample pairs the motion search compared are added here (XH_PROF_STRIPES words), else null
 };
@@ -275,6 +276,7 @@ struct Lds { // the team's shared memory
     const Sbac *jsrc[XW_CODL]; // the coder lanes' entry states / where their exit states go (null: nowhere)
     Sbac       *jdst[XW_CODL];
     long long t0;
+    int deal;
 };
 // a mark: everything since the previous mark belongs to class `cls` (call right after a sync)
 XW void mark(const Tm &tm, const P &p, Lds &S, int cls)
@@ -446,13 +448,13 @@ XW Mdl mdl_of(unsigned v) { Mdl a; a.s = (v >> 1) & 511u, a.m = v & 1u; return a
 XW unsigned mdl_pack(const Mdl &a) { return (a.s << 1) + a.m; }
 XW void cnt_bin(unsigned &range, unsigned &shifts, Mdl &a, unsigned bin)
 {
-    unsigned lps = mul24(a.s, range & 0xFFFFu) >> 9;
+    unsigned lps = mul24(a.s, range) >> 9; // (range <= 2^14)
     lps = lps < 437u ? 437u : lps;
     const unsigned r2 = range - lps, is_lps = (bin ^ a.m) & 1u, msk = 0u - is_lps;
     const unsigned sl = a.s + ((528u - a.s) >> 5), flip = sl > 256u ? 1u : 0u, sl2 = flip ? 512u - sl : sl, sm = a.s - ((a.s + 16u) >> 5);
-    const unsigned rl = r2 < lps ? r2 : lps, r = r2 ^ ((r2 ^ rl) & msk);
+    const unsigned rl = r2 < lps ? r2 : lps, r = is_lps ? rl : r2;
     a.s = sm ^ ((sm ^ sl2) & msk), a.m = a.m ^ (flip & is_lps);
-    const unsigned n = r < 8192u ? (unsigned)__builtin_clz(r) - 18u : 0u;
+    const unsigned n = (unsigned)__builtin_clz(r) - 18u; // 437 <= r < 2^14: no shift from 2^13 on
     range = r << n, shifts += n;
 }
 XW void cnt_unary(unsigned &range, unsigned &shifts, Mdl &m0, Mdl &m1, unsigned sym)
@@ -631,7 +633,7 @@ template <bool FULL, class Src, class Run> XW void coder_stage(const Tm &tm, Lds
         sync(tm);
         // job slot of this thread: the jobs are dealt round-robin over the team's waves (a wave runs as long as its longest lane per symbol: the fewer lanes of one
         // wave are busy, the less they wait for each other -- and the other waves sit on SIMDs that have nothing else to do in a coder stage)
-        const int nw = tm.n >= 64 ? tm.n / 64 : 1, slot = tm.n >= 64 ? (tm.tid & 63) * nw + (tm.tid >> 6) : tm.tid;
+        const int nw = tm.n >= 64 ? tm.n / 64 : 1, slot = tm.n >= 64 && !S.deal ? (tm.tid & 63) * nw + (tm.tid >> 6) : tm.tid;
         if(slot < cnt && S.jsrc[slot]) {
             const Sbac &in = *S.jsrc[slot];
             Cod c;

@@ -54,14 +54,18 @@ std::atomic<long> g_walk_load{0}; // chains of the batch encoders with a run in 
 // a batch encoder starts (+) or ends (-) a run of `chains` lockstep chains: the walks of all running encoders share the chip's workgroup slots
 void xh_walk_load(long chains) { g_walk_load.fetch_add(chains); }
 
-bool xh_walk_enabled()
+// which walk a call of `nchains` chains runs: the fused kernel finishes a step of FEW chains sooner (a team per chain: ~60 / 120 ms per intra / inter CTU of noise at
+// 3840x2160 against the composed walk's launch-bound ~110 / 185 ms), the composed walk's kernels pack the lanes of MANY chains densely and code more CTUs per second
+// from ~2 000 chains on (profiles/r04_walks.md).  XEVE_HIP_WALK=1 / 0 pins the fused / the composed walk; unset: fused up to XEVE_HIP_WALK_AUTO_MAX chains (1024).
+bool xh_walk_enabled(int nchains)
 {
-    static const int on = getenv("XEVE_HIP_WALK") ? atoi(getenv("XEVE_HIP_WALK")) : 1;
-    return on != 0;
+    static const int on = getenv("XEVE_HIP_WALK") && *getenv("XEVE_HIP_WALK") && strcmp(getenv("XEVE_HIP_WALK"), "auto") ? atoi(getenv("XEVE_HIP_WALK")) : -1;
+    static const int auto_max = getenv("XEVE_HIP_WALK_AUTO_MAX") ? atoi(getenv("XEVE_HIP_WALK_AUTO_MAX")) : 1024;
+    return on < 0 ? nchains <= auto_max : on != 0;
 }
-bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I)
+bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int nchains)
 {
-    if(!xh_walk_enabled()) return false;
+    if(!xh_walk_enabled(nchains)) return false;
     if(p->ip.slice_type != 2 && I) {
         static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 1;
         if(!inter_on) return false;
@@ -70,6 +74,7 @@ bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter 
     }
     return p->log2_ctu <= 6;
 }
+extern "C" int xeve_hip_walk_fused(int nchains) { return xh_walk_enabled(nchains) ? 1 : 0; }
 size_t xh_walk_workspace(int nchains) { return (size_t)nchains * sizeof(xw::Cw) + 256; }
 
 int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, uint32_t *map_scu, int8_t *map_ipm,
@@ -145,6 +150,8 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
     }
     static const int dbg = getenv("XEVE_HIP_WALK_DBG") ? atoi(getenv("XEVE_HIP_WALK_DBG")) : 0;
     q.dbg = dbg;
+    static const int deal = getenv("XEVE_HIP_WALK_DEAL") ? atoi(getenv("XEVE_HIP_WALK_DEAL")) : 0;
+    q.deal = deal;
     q.cw = (xw::Cw *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const int teams = (nchains + C - 1) / C;
     q.sad_units = xh_prof_units(XH_PROF_WALK);

@@ -359,6 +359,7 @@ template <bool FULL> XW void walk_team(const Tm &tm, const P &p, Lds &S, int tea
 #if XW_DEVICE
     if(tm.tid == 0) S.t0 = clock64();
 #endif
+    if(tm.tid == 0) S.deal = p.deal;
     walk_clear(tm, p, c0, nC);
     mark(tm, p, S, PR_CLEAR);
     for(int i = 0; i < p.nops; i++) {
