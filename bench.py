@@ -99,10 +99,10 @@ def host_info():
 
 
 class CpuApp:
-    """the reference encoder on this box's host cores: -m 8 on the 8-frame seed-4 GOP and -m 1 on its first two frames, side by side (9 threads) while the GPU encodes;
-    once the GPU's timed region is over (all_cores_may_start: the composed walk's host threads issue ~90 000 launches a second each and must not lose their cores to the
-    baseline), floor(cores available / 8) concurrent -m 8 processes, each on a GOP of its own (`all_cores`; cores available = physical cores, capped by the container's
-    CPU quota)"""
+    """the reference encoder on this box's host cores, AFTER the GPU's timed region (the composed walk's host threads issue ~90 000 launches a second each: beside a
+    9-thread baseline inside a 16-CPU container quota the GPU figure dropped 7 %): start() = -m 8 on the 8-frame seed-4 GOP and -m 1 on its first two frames, side by
+    side, while the GPU runs the untimed extras; all_cores_may_start() = then floor(cores available / 8) concurrent -m 8 processes, each on a GOP of its own, once the
+    GPU is idle (`all_cores`; cores available = physical cores, capped by the container's CPU quota)"""
 
     def __init__(self, width, height, frames, clip, with_m1=True):
         self.w, self.h, self.frames, self.err, self.out = width, height, frames, None, {}
@@ -120,7 +120,12 @@ class CpuApp:
         self.with_m1 = with_m1
         self.go_all = threading.Event()
         self.th = threading.Thread(target=self._run, daemon=True)
-        self.th.start()
+        self.started = False
+
+    def start(self):
+        if not self.err and not self.started:
+            self.started = True
+            self.th.start()
 
     def _cmd(self, yuv, frames, m, out):
         return [self.exe, "-i", yuv, "-w", str(self.w), "-h", str(self.h), "-z", "30", "--preset", "medium", "--closed-gop", "-I", "8", "--frames", str(frames), "-m", str(m), "-o", out]
@@ -171,13 +176,14 @@ class CpuApp:
             self.err = repr(e)[:200]
 
     def all_cores_may_start(self):
+        self.start()
         if not self.err:
             self.go_all.set()
 
     def result(self, timeout=1500):
         if self.err and not self.out:
             return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "failed: " + self.err}
-        self.go_all.set()
+        self.all_cores_may_start()
         self.th.join(timeout)
         try:
             import shutil
@@ -188,8 +194,8 @@ class CpuApp:
         return {"value": m8.get("fps"), "unit": "frames/s", "cores": 8, "kind": "reference",
                 "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit 4:2:0 "
                           "clip = GOP 0 of the GPU job (1 IDR + 7 B pictures); `value` = -m 8 (the library's thread maximum, the setting the GPU job reproduces byte for byte); "
-                          "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(cores available / 8) such processes side by side, each on its own GOP (after the GPU's timed region; cores available = "
-                          "physical cores capped by the container's CPU quota, `host`); -m 8 and -m 1 ran on the host's cores while the GPU encoded" % (self.w, self.h, self.frames),
+                          "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(cores available / 8) such processes side by side, each on its own GOP (cores available = "
+                          "physical cores capped by the container's CPU quota, `host`); -m 8 and -m 1 ran after the GPU's timed region beside its untimed extras, all_cores with the GPU idle" % (self.w, self.h, self.frames),
                 "m8": m8, "m1": self.out.get("m1", {}), "all_cores": self.out.get("all_cores", {}), "host": self.host, "error": self.err}
 
 
@@ -253,7 +259,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
             for f in range(F):
                 e.push(g, f, d[f * fb:(f + 1) * fb])
     del d
-    cpu = CpuApp(W, H, F, clip, True) if with_cpu else None  # (host cores only; runs while the GPU encodes)
+    cpu = CpuApp(W, H, F, clip, True) if with_cpu else None  # (started after the timed region)
 
     def fence():
         for e in encs:
@@ -314,7 +320,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     lib.prof_enable(None)
     k_ms, k_n, k_units = live
     if cpu is not None:
-        cpu.all_cores_may_start()
+        cpu.start()
     timed_steps = sum(sizes[a.warmup:])
     first_timed = sum(sizes[:a.warmup])
     frames_timed = sum(Gs) * timed_steps / per_picture
@@ -355,7 +361,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 6), "traffic": None}
         try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")))
-            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch") or pmc.get("hbm_bytes_per_launch_x2")
             roof["traffic_is"] = pmc.get("what")
             for k in ("valu_insts_per_launch", "valu_issue_frac", "wait_any_frac", "waves_per_launch", "avg_launch_s"):
                 if k in pmc:
@@ -367,7 +373,8 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                    "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
                                "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
                                % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, T, run_steps, a.warmup, a.steps),
-                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
+                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step; the ramp steps of a picture, where at most 1024 chains are active, run the fused kernel)"
+                            for f in fused],
                    "walk_choice": "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
                                   "by the chains in lockstep (walk.hip: the fused kernel up to 1024 chains -- it finishes a step of few chains sooner --, the composed walk above: "
                                   "its kernels pack the lanes of many chains and code more CTUs per second; profiles/r04_walks.md)",
@@ -433,7 +440,7 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
         for f in range(frames):
             e.push(g, f, d[f * fb:(f + 1) * fb])
     e.begin()
-    e.advance(per_picture)  # the IDR picture, untimed and without timers
+    e.advance(per_picture + 16)  # the IDR picture and the first B picture's ramp (a picture's first steps carry one or two row chains per GOP: few enough for the fused kernel)
     e.sync()
     lib.prof_enable([c for c in lib.PROF_CLASSES if c != "walk"])
     lib.prof_read()
@@ -452,7 +459,7 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
             "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
             "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
                    "a serial chain per lane, so the roof is only reachable with every lane of every wave busy" % (INSTR_PER_BIN, CUS, SIMDS, CLOCK_GHZ),
-            "kernels": kern, "kernels_note": "HIP-event time per lockstep step of the first B picture with %d GOPs in lockstep, all class timers on (untimed extra encode)" % gops}
+            "kernels": kern, "kernels_note": "HIP-event time per lockstep step of the first B picture (steps 16 .. %d: all 8 row chains of every GOP active) with %d GOPs in lockstep, all class timers on (untimed extra encode)" % (16 + steps, gops)}
 
 
 def main():

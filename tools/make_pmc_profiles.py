@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Distils tools/pmc_summary.py output (per-kernel means of rocprofv3 --pmc passes over a batch-encoder run, tools/probe_enc.py) into profiles/r03_search_pmc.json
 (the integer motion search k_me_epzs = the SAD kernel of the path: what bench.py's roofline.traffic quotes) and profiles/r03_cu_bits_pmc.json (CABAC bit counting,
-the class with the largest share of the GPU time).  usage: make_pmc_profiles.py pmc.json "<what was run>" """
+the class with the largest share of the GPU time).  usage: make_pmc_profiles.py pmc.json "<what was run>" [round prefix, default r03]; a k_walk row (the fused walk) goes to profiles/<prefix>_walk_pmc.json """
 import json
 import sys
 
 ser, what = json.load(open(sys.argv[1])), sys.argv[2]
+RND = sys.argv[3] if len(sys.argv) > 3 else "r03"
 
 
 def mean(v, c):
@@ -44,12 +45,19 @@ if tot:
            "hbm_bytes_per_launch_x2": int(tot.get("hbm_bytes_x2", 0) / tot["launches"]) if "hbm_bytes_x2" in tot else None,
            "valu_insts_per_launch": int(tot.get("valu_insts", 0) / tot["launches"]) if "valu_insts" in tot else None,
            "salu_insts_per_launch": int(tot.get("salu_insts", 0) / tot["launches"]) if "salu_insts" in tot else None, "per_kernel": per}
-    json.dump(out, open("profiles/r03_search_pmc.json", "w"), indent=1)
+    json.dump(out, open("profiles/%s_search_pmc.json" % RND, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
 tot, per = rows("k_cu_bits")
 if tot:
     out = {"what": what, "units": units, "launches_in_run": tot["launches"], "avg_launch_s": tot["seconds"] / tot["launches"],
            "valu_insts_per_launch": int(tot.get("valu_insts", 0) / tot["launches"]) if "valu_insts" in tot else None,
            "wave_quad_cycles_per_launch": int(tot.get("wave_quad_cycles", 0) / tot["launches"]) if "wave_quad_cycles" in tot else None, "per_kernel": per}
-    json.dump(out, open("profiles/r03_cu_bits_pmc.json", "w"), indent=1)
+    json.dump(out, open("profiles/%s_cu_bits_pmc.json" % RND, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
+tot, per = rows("k_walk")
+if tot:
+    out = {"what": what, "units": units, "launches_in_run": tot["launches"], "avg_launch_s": tot["seconds"] / tot["launches"],
+           "hbm_bytes_per_launch": int(tot.get("hbm_bytes_x2", 0) / tot["launches"]) if "hbm_bytes_x2" in tot else None,
+           "valu_insts_per_launch": int(tot.get("valu_insts", 0) / tot["launches"]) if "valu_insts" in tot else None, "per_kernel": per}
+    json.dump(out, open("profiles/%s_walk_pmc.json" % RND, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
