@@ -477,7 +477,8 @@ def main():
     ap.add_argument("--walk", default=os.environ.get("XEVE_BENCH_WALK", "auto"), choices=["auto", "fused", "composed"],
                     help="the CTU walk: one kernel per step (fused), ~10 000 launches per step (composed), or the library's choice by the chains in lockstep (auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (the kernel's stage profile, the 1920x1080 figure)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra (the per-class / per-stage profile of the walk)")
+    ap.add_argument("--with-1080p", action="store_true", help="also run the same bounded job at 1920x1080 (north_star names both sizes; ~2 more minutes; profiles/r04_bench.json holds a run)")
     a = ap.parse_args()
     if a.walk == "composed":
         os.environ["XEVE_HIP_WALK"] = "0"
@@ -535,7 +536,7 @@ def main():
             line["roofline"]["by_time"] = (stage_profile if cls == "walk" else class_profile)(torch, dev, cfg, max(8, Gs[0] // 4) if cls == "walk" else max(136, Gs[0] // 2), a.frames, per_picture, fb)
         except Exception as e:  # noqa: BLE001
             line["roofline"]["by_time"] = {"error": repr(e)[:300]}
-        if (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
+        if a.with_1080p and (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
             try:
                 r2, _ = run_job(a, torch, dist, dev, rank, world, 1920, 1080, "secondary", False)
                 r2.pop("cpu")
