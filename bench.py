@@ -373,8 +373,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                    "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
                                "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
                                % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, T, run_steps, a.warmup, a.steps),
-                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step; the ramp steps of a picture, where at most 1024 chains are active, run the fused kernel)"
-                            for f in fused],
+                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
                    "walk_choice": "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
                                   "by the chains in lockstep (walk.hip: the fused kernel up to 1024 chains -- it finishes a step of few chains sooner --, the composed walk above: "
                                   "its kernels pack the lanes of many chains and code more CTUs per second; profiles/r04_walks.md)",
@@ -440,7 +439,7 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
         for f in range(frames):
             e.push(g, f, d[f * fb:(f + 1) * fb])
     e.begin()
-    e.advance(per_picture + 16)  # the IDR picture and the first B picture's ramp (a picture's first steps carry one or two row chains per GOP: few enough for the fused kernel)
+    e.advance(per_picture + 16)  # the IDR picture and the first B picture's ramp (a picture's first steps carry one or two row chains per GOP)
     e.sync()
     lib.prof_enable([c for c in lib.PROF_CLASSES if c != "walk"])
     lib.prof_read()

@@ -805,7 +805,8 @@ int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l
  * stage's class; _prof copies {cycles[n], marks[n]} of the classes since the last call into out (cap >= 2 n entries) and returns n (0: the profile is off). */
 int xeve_hip_walk_prof_enable(int on);
 int xeve_hip_walk_prof(unsigned long long *out, int cap);
-/* 1: a call of nchains chains runs the fused walk, 0: the composed walk (XEVE_HIP_WALK=1 / 0 pins one; unset: fused up to XEVE_HIP_WALK_AUTO_MAX = 1024 chains -- the
+/* 1: a call in a batch of nchains chains (max(nchains, nstates) of the call) runs the fused walk, 0: the composed walk (XEVE_HIP_WALK=1 / 0 pins one; unset: fused up to
+ * XEVE_HIP_WALK_AUTO_MAX = 1024 chains -- the
  * fused kernel finishes a step of few chains sooner, the composed walk's kernels code more CTUs per second once thousands of chains are in lockstep). */
 int xeve_hip_walk_fused(int nchains);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,

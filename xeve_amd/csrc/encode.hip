@@ -571,7 +571,7 @@ extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
     if(e->loop->begin(e->bitstreams) != 0) { xh_set_error("xeve_hip_enc_begin: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
     const std::vector<PicSetup> setups = e->loop->dry_setups();
     if(setups.empty() || !e->reserve(setups)) { xh_set_error("xeve_hip_enc_begin: %s", e->error.empty() ? "the frame loop refuses the run" : e->error.c_str()); return XEVE_HIP_ERR_ARG; }
-    e->announce((long)e->G * e->T);
+    e->announce(xeve_hip_walk_fused(e->G * e->T) ? (long)e->G * e->T : 0); // (only the fused kernel's teams share the workgroup slots)
     return XEVE_HIP_OK;
 }
 extern "C" int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining)

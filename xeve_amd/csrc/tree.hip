@@ -671,7 +671,9 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
         (void)ws_;
     }
     if(nchains == 0) return XEVE_HIP_OK;
-    if(xh_walk_supported(p, I, nchains)) // the fused walk: the whole schedule inside one kernel (walk.hip)
+    // which walk: by the WIDTH OF THE BATCH the call belongs to (the caller's state records: every chain of every GOP), not by the chains this step carries -- the ramp
+    // steps of a wide batch's pictures stay on the composed walk (a long-running fused launch between the other streams' short kernels cost 7 %, profiles/r04_walks.md)
+    if(xh_walk_supported(p, I, std::max(nchains, nstates))) // the fused walk: the whole schedule inside one kernel (walk.hip)
         return xh_walk_run(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost,
                            workspace, workspace_bytes, vh, (hipStream_t)stream);
     const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c);

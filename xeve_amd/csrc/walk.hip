@@ -56,7 +56,8 @@ void xh_walk_load(long chains) { g_walk_load.fetch_add(chains); }
 
 // which walk a call of `nchains` chains runs: the fused kernel finishes a step of FEW chains sooner (a team per chain: ~60 / 120 ms per intra / inter CTU of noise at
 // 3840x2160 against the composed walk's launch-bound ~110 / 185 ms), the composed walk's kernels pack the lanes of MANY chains densely and code more CTUs per second
-// from ~2 000 chains on (profiles/r04_walks.md).  XEVE_HIP_WALK=1 / 0 pins the fused / the composed walk; unset: fused up to XEVE_HIP_WALK_AUTO_MAX chains (1024).
+// from ~2 000 chains on (profiles/r04_walks.md).  nchains = the width of the batch the call belongs to (tree.hip).  XEVE_HIP_WALK=1 / 0 pins the fused / the composed
+// walk; unset: fused up to XEVE_HIP_WALK_AUTO_MAX chains (1024).
 bool xh_walk_enabled(int nchains)
 {
     static const int on = getenv("XEVE_HIP_WALK") && *getenv("XEVE_HIP_WALK") && strcmp(getenv("XEVE_HIP_WALK"), "auto") ? atoi(getenv("XEVE_HIP_WALK")) : -1;
