@@ -424,7 +424,7 @@ def stage_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=4):
     top = max(groups, key=groups.get)
     return {"kernel": "k_walk, its own stage classes (shader cycles of team 0's thread 0 between stage marks; %d lockstep steps of the first B picture, %d GOPs)" % (steps, gops),
             "share_of_kernel_time": groups, "dominant": top, "bound": "latency of serial lanes (a CABAC bit count is a recurrence per bin: ~170 cycles per bin and lane, "
-            "tools/scratch/cod_bench.hip; the stage lasts as long as its longest lane)", "cycles_per_step_team0": tot // max(1, steps)}
+            "tools/cod_bench.hip; the stage lasts as long as its longest lane)", "cycles_per_step_team0": tot // max(1, steps)}
 
 
 def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
