@@ -25,17 +25,23 @@ def available():
 def walk():
     global _lib
     if _lib is None:
-        if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in DEPS):
+        alt = os.environ.get("XW_WALK_HOST_LIB")  # (tests/test_walk_race.py: the ThreadSanitizer build of the same harness)
+        if alt:
+            _lib = C.CDLL(alt)
+        elif not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in DEPS):
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
-            subprocess.run([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", OUT, SRC],
+            subprocess.run([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread", "-o", OUT, SRC],
                            check=True)
-        _lib = C.CDLL(OUT)
+        if _lib is None:
+            _lib = C.CDLL(OUT)
+        _lib.xw_host_walk_mt.restype = c_int
+        _lib.xw_host_walk_mt.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int, c_int]
         _lib.xw_host_walk.restype = c_int
         _lib.xw_host_walk.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_int]
     return _lib
 
 
-def host_walk(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, scu, ipm, tidx, cu_mode, pic_elems, states, P, inter, jobs, chains_per_team=1, full=1, vh=0):
+def host_walk(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, scu, ipm, tidx, cu_mode, pic_elems, states, P, inter, jobs, chains_per_team=1, full=1, vh=0, threads=1):
     """one call of the walk over `jobs` (CTU_JOB_DTYPE records): returns (ctu data records, next_best records, costs); the planes behind mod_ptrs and the maps are updated"""
     L = walk()
     n = len(jobs)
@@ -43,7 +49,7 @@ def host_walk(org_ptrs, s_org_l, s_org_c, mod_ptrs, s_mod_l, s_mod_c, scu, ipm, 
     org = (c_void_p * 3)(*[int(a) for a in org_ptrs])
     mod = (c_void_p * 3)(*[int(a) for a in mod_ptrs])
     pe = (C.c_int64 * 5)(*[int(v) for v in pic_elems]) if pic_elems is not None else None
-    rc = L.xw_host_walk(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, ptr(scu), ptr(ipm), ptr(tidx), ptr(cu_mode), pe, ptr(states), C.byref(P),
-                        C.byref(inter) if inter is not None else None, ptr(jobs), n, ptr(out), ptr(nxt), ptr(cost), chains_per_team, full, vh)
+    rc = L.xw_host_walk_mt(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, ptr(scu), ptr(ipm), ptr(tidx), ptr(cu_mode), pe, ptr(states), C.byref(P),
+                           C.byref(inter) if inter is not None else None, ptr(jobs), n, ptr(out), ptr(nxt), ptr(cost), chains_per_team, full, vh, threads)
     assert rc == 0
     return out, nxt, cost

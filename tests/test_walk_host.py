@@ -2,6 +2,8 @@
 __host__ __device__ and tests/native builds their host side as a team of one thread.  Whole small pictures coded CTU by CTU, the pictures of a case as the chains of one
 call (several chains per team: the team-local lockstep is exercised too).  After every CTU: the CTU's data byte for byte, the coder state handed on field for field,
 the cost as the bit pattern of the double; at the end the reconstructed pictures and the 4x4-unit maps."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,7 @@ from _tree_cases import CASES, CTU_DATA_DTYPE, CTU_JOB_DTYPE, make_case, run_ora
 pytestmark = pytest.mark.skipif(not _walk.available(), reason="hipcc not found")
 
 
-def run_walk_case(c, chains_per_team, full=1):
+def run_walk_case(c, chains_per_team, full=1, threads=1):
     n = c["npic"]
     org = [a.copy() for a in c["org"]]
     mod = [a.copy() for a in c["mod"]]
@@ -24,7 +26,7 @@ def run_walk_case(c, chains_per_team, full=1):
         jobs = np.zeros(n, CTU_JOB_DTYPE)
         jobs["x"], jobs["y"], jobs["sbac"], jobs["pic"] = x, y, np.arange(n), np.arange(n)
         out, nxt, cost = _walk.host_walk([a.ctypes.data for a in org], org[0].shape[2], org[1].shape[2], [a.ctypes.data for a in mod], mod[0].shape[2], mod[1].shape[2],
-                                         m["scu"], m["ipm"], m["tidx"], m["cu_mode"], pe, states, c["P"], None, jobs, chains_per_team, full)
+                                         m["scu"], m["ipm"], m["tidx"], m["cu_mode"], pe, states, c["P"], None, jobs, chains_per_team, full, 0, threads)
         per_ctu.append((out, nxt, cost))
         states = nxt.copy()
     return per_ctu, dict(mod=mod, scu=m["scu"], ipm=m["ipm"], cu_mode=m["cu_mode"])
@@ -68,7 +70,7 @@ def test_walk_i_pictures_with_count_only_states(case):
 from _tree_cases import INTER_CASES, make_inter_case, run_oracle_inter_picture  # noqa: E402
 
 
-def run_walk_inter_case(c, full=1):
+def run_walk_inter_case(c, full=1, threads=1):
     import ctypes as C
 
     from _mc_cases import refpic_table
@@ -93,16 +95,15 @@ def run_walk_inter_case(c, full=1):
         jobs = np.zeros(1, CTU_JOB_DTYPE)
         jobs["x"], jobs["y"] = x, y
         out, nxt, cost = _walk.host_walk(org_ptrs, refs["s_l"], refs["s_c"], [a.ctypes.data for a in mod], mod[0].shape[1], mod[1].shape[1], m["scu"], m["ipm"], m["tidx"],
-                                         m["cu_mode"], None, states, c["P"], I, jobs, 1, full)
+                                         m["cu_mode"], None, states, c["P"], I, jobs, 1, full, 0, threads)
         per_ctu.append((out, nxt, cost))
         states = nxt.copy()
     return per_ctu, dict(mod=mod, scu=m["scu"], ipm=m["ipm"], cu_mode=m["cu_mode"], mv=m["mv"], refi=m["refi"])
 
 
-@pytest.mark.parametrize("case", INTER_CASES, ids=[str(c[0]) for c in INTER_CASES])
-def test_walk_p_and_b_pictures_match_oracle(case):
+def check_inter(case, threads=1):
     c = make_inter_case(*case)
-    got, final = run_walk_inter_case(c)
+    got, final = run_walk_inter_case(c, threads=threads)
     exp = run_oracle_inter_picture(c)  # updates c["mod"], c["maps"] in place
     for k in range(len(c["order"])):
         d, nb, cost = got[k]
@@ -117,9 +118,33 @@ def test_walk_p_and_b_pictures_match_oracle(case):
         assert np.array_equal(final[f].reshape(c["maps"][f].shape), c["maps"][f]), (case, "map", f)
 
 
+@pytest.mark.parametrize("case", INTER_CASES, ids=[str(c[0]) for c in INTER_CASES])
+def test_walk_p_and_b_pictures_match_oracle(case):
+    check_inter(case)
+
+
+# ---- the device's team as REAL threads, sync() a barrier: the lane mapping of every stage as the kernel runs it (64 lanes = one wave by default; XEVE_RACE_TESTS=1: the whole
+# 256, larger pictures -- minutes on 8 cores, 10 000 barriers per CTU).  The results must not depend on the team's size.  tests/test_walk_race.py runs the same team under
+# ThreadSanitizer.
+SLOW = bool(os.environ.get("XEVE_RACE_TESTS"))
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_walk_i_picture_with_a_team_of_real_threads(threads):
+    for case, C, full in ((CASES[0], 2, 1), (CASES[1], 3, 0)) if SLOW else ((CASES[4], 2, 0),):
+        c = make_case(*case)
+        got, final = run_walk_case(c, chains_per_team=C, full=full, threads=threads)
+        compare(case, c, got, final, full=full)
+
+
+@pytest.mark.parametrize("case", INTER_CASES[:3] if SLOW else INTER_CASES[3:4], ids=[str(c[0]) for c in (INTER_CASES[:3] if SLOW else INTER_CASES[3:4])])
+@pytest.mark.parametrize("threads", [64, 256] if SLOW else [64])
+def test_walk_p_and_b_pictures_with_a_team_of_real_threads(case, threads):
+    check_inter(case, threads=threads)
+
+
 # ---- end to end: the batch encoder's frame loop with EVERY CTU decided by the fused walk's host side, against bitstreams of the unmodified reference application ----------
 import json  # noqa: E402
-import os  # noqa: E402
 
 import _e2e  # noqa: E402
 import _enc  # noqa: E402

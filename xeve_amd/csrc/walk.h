@@ -51,10 +51,27 @@ typedef unsigned long long u64;
 struct Tm {
     int tid, n;
 };
+#if !XW_DEVICE
+// A host team of SEVERAL threads (tests/native/walk_host.cpp, threads > 1: the device's lane mapping with real threads -- the results must not depend on the team's size, and
+// under ThreadSanitizer every access two lanes share without a barrier between them shows up): the harness registers the team's barrier with each of its threads; without
+// one, sync() is free (a team of one thread).
+struct HostTeam {
+    void (*barrier)(void *);
+    void *arg;
+};
+inline HostTeam &host_team()
+{
+    static thread_local HostTeam t = {nullptr, nullptr};
+    return t;
+}
+#endif
 XW void sync(const Tm &)
 {
 #if XW_DEVICE
     __syncthreads();
+#else
+    HostTeam &t = host_team();
+    if(t.barrier) t.barrier(t.arg);
 #endif
 }
 XW void aadd(int *p, int v)
@@ -62,7 +79,7 @@ XW void aadd(int *p, int v)
 #if XW_DEVICE
     atomicAdd(p, v);
 #else
-    *p += v;
+    __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 #endif
 }
 XW void aadd64(u64 *p, u64 v)
@@ -70,7 +87,7 @@ XW void aadd64(u64 *p, u64 v)
 #if XW_DEVICE
     atomicAdd(p, v);
 #else
-    *p += v;
+    __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 #endif
 }
 XW void aor(int *p, int v)
@@ -78,7 +95,7 @@ XW void aor(int *p, int v)
 #if XW_DEVICE
     atomicOr(p, v);
 #else
-    *p |= v;
+    __atomic_fetch_or(p, v, __ATOMIC_RELAXED);
 #endif
 }
 // stage classes of the in-kernel profiler (XEVE_HIP_WALK_PROF=1: thread 0 of team 0 adds the cycles between two marks to its class)
