@@ -5,8 +5,10 @@
 // against bitstreams of the unmodified reference application (tests/test_enc_host.py): that pins the host side of the batch encoder without a GPU.  The product never
 // links this file; libxeve_hip.so instantiates the same template with its HIP engine (xeve_amd/csrc/encode.cpp).
 #define XENC_HOST_PINNED_OPTIONS 1 // (enc_plan.h: options the reference application cannot set, pinned through oracle/ref_param_pin.c; the product build refuses them)
+#include <pthread.h>
 #include <cstdlib>
 #include <memory>
+#include <thread>
 #include "../xeve_amd/csrc/enc_host.h"
 #include "../xeve_amd/csrc/walk_setup.h" // the fused CTU walk's host side (XO_ENC_WALK=1: every CTU decided by it instead of the oracle -- pins walk.h end to end)
 extern "C" {
@@ -150,8 +152,28 @@ struct CpuEngine {
                 wp.entropy = T.entropy.data(), wp.dct = T.dct.data(), wp.scan = T.scan.data(), wp.ops = ops.data(), wp.nops = (int)ops.size(), wp.cw = cw.data();
                 if(inter) wp.mc_l = &xo_mc_l_coeff[0][0], wp.mc_c = &xo_mc_c_coeff[0][0];
                 std::unique_ptr<xw::Lds> lds(new xw::Lds());
-                const xw::Tm tm = {0, 1};
-                for(int team = 0; team * wp.C < n; team++) xw::walk_team<false>(tm, wp, *lds, team);
+                static const int nt = getenv("XO_ENC_WALK_THREADS") ? atoi(getenv("XO_ENC_WALK_THREADS")) : 1; // (tests/test_walk_race.py: the team as real threads)
+                if(nt <= 1) {
+                    const xw::Tm tm = {0, 1};
+                    for(int team = 0; team * wp.C < n; team++) xw::walk_team<false>(tm, wp, *lds, team);
+                }
+                else {
+                    pthread_barrier_t bar;
+                    pthread_barrier_init(&bar, nullptr, (unsigned)nt);
+                    std::vector<std::thread> th;
+                    for(int t = 0; t < nt; t++)
+                        th.emplace_back([&, t] {
+                            xw::host_team() = {[](void *b) { pthread_barrier_wait((pthread_barrier_t *)b); }, &bar};
+                            const xw::Tm tm = {t, nt};
+                            for(int team = 0; team * wp.C < n; team++) {
+                                xw::walk_team<false>(tm, wp, *lds, team);
+                                pthread_barrier_wait(&bar);
+                            }
+                            xw::host_team() = {nullptr, nullptr};
+                        });
+                    for(auto &t : th) t.join();
+                    pthread_barrier_destroy(&bar);
+                }
             }
             for(int i = 0; i < n; i++) {
                 const int x0 = c[i].x * CTU, y0 = c[i].y * CTU;

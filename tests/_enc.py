@@ -61,6 +61,8 @@ _harness = None
 
 def harness():
     global _harness
+    if _harness is None and os.environ.get("XO_ENC_ORACLE_LIB"):  # (tests/test_walk_race.py: the ThreadSanitizer build of the same harness)
+        _harness = C.CDLL(os.environ["XO_ENC_ORACLE_LIB"])
     if _harness is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("enc_oracle.cpp", "xeve_oracle.c", "xeve_oracle.h")] + [os.path.join(ROOT, "xeve_amd", "csrc", f) for f in ("enc_host.h", "enc_plan.h")]
         if not os.path.exists(ENC_ORACLE_SO) or os.path.getmtime(ENC_ORACLE_SO) < max(os.path.getmtime(s) for s in srcs):

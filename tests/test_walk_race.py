@@ -48,6 +48,24 @@ def test_the_detector_is_alive(tsan_lib):
 
 def test_no_stage_of_the_walk_races(tsan_lib):
     """an I picture (two chains per team, count-only states) and a B picture with teams of 64 and 256 real threads: every result still the oracle's, and no report"""
-    p = _run(["-m", "pytest", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_walk_host.py"), "-k", "real_threads"], tsan_lib, 1500)
+    p = _run(["-m", "pytest", "-q", "-s", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_walk_host.py"), "-k", "real_threads"], tsan_lib, 1500)
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[:6000]
+
+
+ENC_OUT = os.path.join(ROOT, "tests", "native", "build", "libxeve_enc_oracle_tsan.so")
+
+
+@pytest.mark.skipif(not os.environ.get("XEVE_RACE_TESTS"), reason="XEVE_RACE_TESTS=1: a whole encode with every team as 64 real threads under ThreadSanitizer takes tens of minutes")
+def test_no_stage_races_in_whole_encodes(tsan_lib):
+    """the batch encoder's frame loop on the CPU engine (oracle/enc_oracle.cpp) with every CTU decided by the fused walk run by a team of 64 real threads: two and three row
+    chains per team through I and B pictures of moving and noise content -- the reference's bitstreams, and no report"""
+    tmp = os.path.join(os.path.dirname(ENC_OUT), "enc_oracle_c_tsan.o")
+    subprocess.run(["gcc", "-fsanitize=thread", "-O1", "-g", "-std=c99", "-fPIC", "-ffp-contract=off", "-c", os.path.join(ROOT, "oracle", "xeve_oracle.c"), "-o", tmp], check=True)
+    subprocess.run(["g++", "-fsanitize=thread", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", ENC_OUT, os.path.join(ROOT, "oracle", "enc_oracle.cpp"),
+                    tmp, "-lm"], check=True)
+    env = dict(os.environ, LD_PRELOAD=TSAN, TSAN_OPTIONS="report_signal_unsafe=0 exitcode=0", XO_ENC_ORACLE_LIB=ENC_OUT, XO_ENC_WALK_THREADS="64", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-s", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_walk_host.py"), "-k",
+                        "closed_gop_batches and (gops_128x128_moving_m2 or gops_192x256_noise_m3)"], capture_output=True, text=True, timeout=4 * 3600, cwd=ROOT, env=env)
     assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
     assert "ThreadSanitizer" not in p.stderr, p.stderr[:6000]

@@ -583,7 +583,7 @@ XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
                 if(idx < 0 || v < best) best = v, idx = c, bits = b;
             }
             me_advance(p, J, false, best, idx, bits, S.mcost + j * XW_MEC, S.mbits + j * XW_MEC);
-            if(J.nc) S.flag[0] = 1;
+            if(J.nc) aor(&S.flag[0], 1); // (several jobs may say so at once)
         }
         sync(tm), mark(tm, p, S, PR_M_SEL);
         if(!S.flag[0]) break;

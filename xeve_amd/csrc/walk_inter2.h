@@ -518,7 +518,7 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
                 const int l = I.lidx_ref;
                 I.rf[l] = (int8_t)I.refi_best, I.rf[1 - l] = -1;
                 if(!I.changed) I.active = 0;
-                else S.flag[1] = 1;
+                else aor(&S.flag[1], 1);
             }
             sync(tm);
             const int more = S.flag[1];
