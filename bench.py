@@ -7,8 +7,8 @@
 THE JOB (per GPU) is a real encode: independent closed GOPs of F = 8 frames each (1 IDR + 7 hierarchical B pictures: what `xeveb_app --preset medium --closed-gop -I 8 -m 8`
 codes), in --batches batches side by side (a batch ends at 2^32 original samples; the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames
 resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h): CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ,
-CABAC bit counts -- ONE fused kernel per lockstep CTU step, xeve_amd/csrc/walk.h), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL
-units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
+CABAC bit counts -- the composed walk's ~10 000 launches per lockstep CTU step at this width, ONE fused kernel per step for batches of up to 1024 chains or with --walk fused:
+xeve_amd/csrc/walk.h, profiles/r04_walks.md), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
 
 BOUNDED.  A whole 8-frame 3840x2160 job is 8 x 302 lockstep steps of a few hundred ms each whatever the batch size (a CTU's mode decision is a serial chain; the width is in
 the GOPs) -- a quarter of an hour.  The bench therefore runs the job's first --pictures pictures in coding order (default 3: the IDR picture and the first two B
@@ -22,9 +22,10 @@ timed region is the last 40 % of the IDR picture and two whole B pictures (IDR s
 few per cent of the whole-GOP rate, `config.timed_picture_mix` says exactly what was timed).  Every rank encodes its own GOPs ("weak"); no collective in the data path.
 
 The JSON line also carries
-  roofline     : the dominant kernel = k_walk (the whole CTU mode decision of a step in one launch): the motion search's SAD work inside it (sample pairs counted on the
-                 device) over the kernel's HIP-event time on its own stream, against the VALU roof for v_sad_u16, with BASELINE's algorithmic-bytes-over-HBM-peak figure and
-                 the PMC HBM traffic as secondary keys; `by_time` = the kernel's own stage profile (in-kernel cycle marks): which stage class owns its time;
+  roofline     : the SAD kernel of the path = k_me_epzs (composed walk; with the fused walk k_walk, the whole CTU mode decision of a step in one launch): the motion search's
+                 SAD work (sample pairs counted on the device) over the kernel's HIP-event time on its own stream, against the VALU roof for v_sad_u16, with BASELINE's
+                 algorithmic-bytes-over-HBM-peak figure and the PMC HBM traffic (profiles/r04_*_pmc.json) as secondary keys; `by_time` = the class that owns the GPU time:
+                 k_cu_bits against a wave-instruction issue roof + every kernel class per step (composed), the kernel's own stage profile (fused);
   cpu_baseline : oracle/_ref/xeveb_app (the unmodified reference, compiled in place) on this box's host cores: -m 8 on the same 8-frame GOP (= `value`), -m 1, and
                  `all_cores`: floor(cores available / 8) concurrent -m 8 processes over distinct GOPs.
 """
