@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxeve_hip.so")
+LIB_PATH = os.environ.get("XEVE_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "libxeve_hip.so")  # (the override: experiment builds, tools/gpu/)
 
 c_int, c_void_p, c_i64 = C.c_int, C.c_void_p, C.c_int64
 
