@@ -209,6 +209,12 @@ def golden_prefix(width, height, frames, threads):
                 return name, r
     except Exception:
         pass
+    try:  # the 2-frame job of rounds 1-3 (--frames 2 --pictures 0): the whole file's golden
+        if (width, height, frames, threads) == (3840, 2160, 2, 8):
+            r = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))["cfg4_2160p_closedgop_medium_m8"]
+            return "e2e_v1.json:cfg4_2160p_closedgop_medium_m8", {"after_picture": [{"bytes": -1, "md5": ""}, {"bytes": r["bytes"], "md5": r["md5"]}]}
+    except Exception:
+        pass
     return None, None
 
 
@@ -344,7 +350,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                  "all_seeded_gops_same_bytes": same}
         if gold is not None:
             k = check_prefix(streams[0][0], gold)
-            check.update({"reference_golden": "tests/golden/cfg4_8f_v1.json:" + gname, "pictures_of_the_golden_gop_matched": k,
+            check.update({"reference_golden": "tests/golden/" + (gname if gname.startswith("e2e") else "cfg4_8f_v1.json:" + gname), "pictures_of_the_golden_gop_matched": k,
                           "byte_identical_to_the_reference": bool(k > 0 and same),
                           "note": "the bitstream GOP 0 has produced when the bounded job stops (the pictures whose access units are complete) against the reference's "
                                   "bitstream up to the same picture; the whole 8-frame GOP: tests/test_enc_gpu.py"})
