@@ -474,6 +474,27 @@ XW void cnt_bin(unsigned &range, unsigned &shifts, Mdl &a, unsigned bin)
     const unsigned n = (unsigned)__builtin_clz(r) - 18u; // 437 <= r < 2^14: no shift from 2^13 on
     range = r << n, shifts += n;
 }
+#if defined(XW_CODER_PAIRS) && XW_CODER_PAIRS
+// EXPERIMENT SWITCH (off in every shipped build; tools/gpu/r05_variants.sh measures it): two bins of a unary code per loop trip, the second one predicated -- half the
+// loop branches (a branch on a vector condition costs a VALU -> SALU round trip per trip) for one wasted bin's arithmetic on odd lengths
+XW void cnt_bin_if(unsigned &range, unsigned &shifts, Mdl &a, unsigned bin, bool on)
+{
+    unsigned r = range, sh = shifts;
+    Mdl      b = a;
+    cnt_bin(r, sh, b, bin);
+    range = on ? r : range, shifts = on ? sh : shifts, a.s = on ? b.s : a.s, a.m = on ? b.m : a.m;
+}
+XW void cnt_unary(unsigned &range, unsigned &shifts, Mdl &m0, Mdl &m1, unsigned sym)
+{
+    cnt_bin(range, shifts, m0, sym ? 1u : 0u);
+    while(sym) {
+        const bool two = sym >= 2;
+        cnt_bin(range, shifts, m1, sym > 1 ? 1u : 0u);
+        cnt_bin_if(range, shifts, m1, sym > 2 ? 1u : 0u, two);
+        sym -= two ? 2u : 1u;
+    }
+}
+#else
 XW void cnt_unary(unsigned &range, unsigned &shifts, Mdl &m0, Mdl &m1, unsigned sym)
 {
     cnt_bin(range, shifts, m0, sym ? 1u : 0u);
@@ -482,6 +503,7 @@ XW void cnt_unary(unsigned &range, unsigned &shifts, Mdl &m0, Mdl &m1, unsigned 
         cnt_bin(range, shifts, m1, sym ? 1u : 0u);
     }
 }
+#endif
 // the count-only event loop of a coefficient block: range, shift count and the five models it touches, in and out.  XW_NOINLINE_CODER=1 (walk.hip sets it) builds it as a
 // real function -- a register allocation of its own instead of the enclosing stage's, where the coder's range travelled through a spill slot every event: 32 VGPRs, no
 // scratch access inside the loops, -5 % per step on the device.
@@ -698,9 +720,16 @@ template <bool FULL, class Src, class Run> XW void coder_stage(const Tm &tm, Lds
     }
 }
 
+// EXPERIMENT SWITCH (off in every shipped build; tools/gpu/r05_variants.sh measures it): XW_NOINLINE_STAGES=1 builds the block stages and the motion search's rounds as real
+// functions -- a register allocation each instead of the one 128-VGPR allocation of the whole walk (static: 3966 -> 3528 scratch accesses in the kernel)
+#if defined(XW_NOINLINE_STAGES) && XW_NOINLINE_STAGES
+#define XW_ST __host__ __device__ static __attribute__((noinline))
+#else
+#define XW_ST XW
+#endif
 // ---- stages over transform blocks ------------------------------------------------------------------------------------------------------------------------------------
 // residual = original - prediction into coef; optionally SSD(prediction, original) (the shift per sample, xeve_ssd_16b)
-XW void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
+XW_ST void st_diff(const Tm &tm, Blk *b, int nb, int log2n, int want_ssd, int bd)
 {
     const int N = 1 << log2n, per = N * N / (N >= 4 ? 4 : 2), g = N >= 4 ? 4 : 2, sh = (bd - 8) * 2;
     for(int i = tm.tid; i < nb * per; i += tm.n) {
@@ -753,7 +782,7 @@ template <class T> XW void dot4(const int8_t *m, int ms, const T *v, int vs, int
     for(int q = 0; q < 4; q++) acc[q] = wide ? ((int64_t)hi[q] << 14) + lo[q] : (int64_t)lo[q];
 }
 // one pass of a transform over every block: pass 0 / 1 = xeve_trans rows / columns (xeve_tq.c:396-404), 2 / 3 = xeve_itrans (xeve_itdq.c:435-440)
-XW void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
+XW_ST void st_tpass(const Tm &tm, const P &p, Blk *b, int nb, int log2n, int pass)
 {
     const int N = 1 << log2n, G = N >= 4 ? 4 : N, per = N * (N / G);
     const int8_t *M = dct_m(p, log2n), *Mt = dct_t(p, log2n);
@@ -809,7 +838,7 @@ XW void rdoq_level(int v, int q_value, int q_bits, int64_t cap, int64_t &ld, uin
     m = (uint32_t)(ld >> q_bits);
     if(!((ld - ((int64_t)m << q_bits)) < ((int64_t)1 << (q_bits - 1)))) m++;
 }
-XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
+XW_ST void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
 {
     const int N = 1 << log2n, nn = N * N, bd = p.bd;
     const uint16_t *scan = scan_of(p, log2n);
@@ -935,7 +964,7 @@ XW void st_rdoq(const Tm &tm, const P &p, Lds &S, Blk *b, int nb, int log2n)
     }
 }
 // xeve_dquant (xeve_itdq.c:442-475) of the levels into coef, for the blocks that have any
-XW void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
+XW_ST void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
 {
     const int nn = 1 << (2 * log2n), shift = (uint8_t)(20 - 14 - (15 - p.bd - log2n));
     const int32_t offset = shift == 0 ? 0 : 1 << (shift - 1);
@@ -948,7 +977,7 @@ XW void st_dquant(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
     }
 }
 // xeve_recon_blk (xeve_recon.c:34-57: the sum wraps to s16 before the clip) + SSD(reconstruction, original)
-XW void st_recon(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
+XW_ST void st_recon(const Tm &tm, const P &p, Blk *b, int nb, int log2n)
 {
     const int N = 1 << log2n, g = N >= 4 ? 4 : 2, per = N * N / g, sh = (p.bd - 8) * 2, maxv = (1 << p.bd) - 1;
     for(int i = tm.tid; i < nb * per; i += tm.n) {

@@ -528,7 +528,7 @@ XW unsigned me_cand_total(const P &p, const MeJob &J, int bits, int sad)
     return cost + (uint32_t)(J.bi ? sad >> 1 : sad);
 }
 // all searches of S.mej[0 .. nj) to their end: rounds of {every candidate's bits, the candidates' SADs spread over all lanes in parts, the search's control on its own thread}
-XW void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
+XW_ST void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
 {
     const int N = 1 << log2n;
     int *msad = (int *)S.mcost;
