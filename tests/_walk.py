@@ -30,8 +30,10 @@ def walk():
             _lib = C.CDLL(alt)
         elif not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in DEPS):
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
-            subprocess.run([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread", "-o", OUT, SRC],
+            tmp = "%s.%d.tmp" % (OUT, os.getpid())  # (several test processes may build at once: each its own file, the rename is atomic)
+            subprocess.run([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread", "-o", tmp, SRC],
                            check=True)
+            os.replace(tmp, OUT)
         if _lib is None:
             _lib = C.CDLL(OUT)
         _lib.xw_host_walk_mt.restype = c_int

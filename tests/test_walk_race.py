@@ -31,8 +31,10 @@ pytestmark = pytest.mark.skipif(TSAN is None or not os.path.exists("/opt/rocm/in
 def tsan_lib():
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in DEPS):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        tmp = "%s.%d.tmp" % (OUT, os.getpid())
         subprocess.run(["g++", "-fsanitize=thread", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                        "-o", OUT, SRC], check=True)
+                        "-o", tmp, SRC], check=True)
+        os.replace(tmp, OUT)
     return OUT
 
 
