@@ -5,7 +5,7 @@
 // the batch in lockstep: its wall time is the host's issue time.  What is serial inside a chain cannot be made parallel (a CU's predictors are its neighbours'
 // reconstruction, its bit counts start from the coder state its predecessor's winner left, an arithmetic coder is a recurrence per bin), so the form that removes the
 // launches without giving up the only parallel axis the coder has -- independent bit-count jobs -- is:
-//   * a team = one workgroup, 256 threads; it owns C chains (C <= 16) and walks them in TEAM-LOCAL lockstep through the static quad-tree schedule; where a launch
+//   * a team = one workgroup, 256 threads; it owns C chains (C <= 8) and walks them in TEAM-LOCAL lockstep through the static quad-tree schedule; where a launch
 //     boundary was there is a workgroup barrier, what passed through HBM between two launches passes through the team's slice of the workspace (L2) or LDS;
 //   * every stage spreads the union of its chains' work over all lanes: samples / transform outputs / search candidates one item per lane, the serial automata
 //     (RDOQ, the CABAC counter) one JOB per lane with the jobs of the C chains side by side, so that a wave of the counter carries C x (candidates) busy lanes
