@@ -280,6 +280,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     total = enc.advance(0)
     per_picture = total // F
     P = F if a.pictures <= 0 else min(F, a.pictures)
+    SAMPLE_STEPS = 2
     run_steps = P * per_picture
     n = a.warmup + a.steps
     per = max(1, run_steps // n)
@@ -302,7 +303,18 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
         launches per step) in every slice with one batch (read out after each), in the last slice only with several (a read-out would stall the other batches)"""
         def one(e):
             for i in range(lo, hi):
-                if timers and (cls == "walk" or B == 1 or (i == hi - 1 and e is enc)):
+                if timers and cls == "search" and B > 1:
+                    # several batches: the search kernel's events are live in the LAST SAMPLE_STEPS steps of EVERY timed slice (batch 0's thread switches them on and off;
+                    # the mask is the library's, so the other batches' search launches of those moments are sampled too) -- a sample spread over every picture the timed
+                    # region covers (round 4 timed the last slice only and the per-launch figures moved 27 % between two runs); read out once, after the region
+                    k = min(SAMPLE_STEPS, sizes[i]) if e is enc else 0
+                    e.advance(sizes[i] - k)
+                    if k:
+                        lib.prof_enable([cls])
+                        e.advance(k)
+                        lib.prof_enable(None)
+                    continue
+                if timers:
                     lib.prof_enable([cls])
                 e.advance(sizes[i])
                 if timers and cls == "search" and B == 1:
@@ -343,6 +355,8 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     rec = None
     if rank == 0:
         gname, gold = golden_prefix(W, H, F, T)
+        for e in encs:
+            e.flush()  # (the access unit of the last picture run: appended now instead of at the next picture's end, so that every picture that was run is checked)
         streams = [[e.bitstream(g) for g in idx] for e, idx in zip(encs, seeded)]
         same = all(s == streams[0][0] for b in streams for s in b)
         check = {"gop0_bytes_so_far": len(streams[0][0]), "gop0_md5_so_far": hashlib.md5(streams[0][0]).hexdigest(),
@@ -352,8 +366,8 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
             k = check_prefix(streams[0][0], gold)
             check.update({"reference_golden": "tests/golden/" + (gname if gname.startswith("e2e") else "cfg4_8f_v1.json:" + gname), "pictures_of_the_golden_gop_matched": k,
                           "byte_identical_to_the_reference": bool(k > 0 and same),
-                          "note": "the bitstream GOP 0 has produced when the bounded job stops (the pictures whose access units are complete) against the reference's "
-                                  "bitstream up to the same picture; the whole 8-frame GOP: tests/test_enc_gpu.py"})
+                          "note": "the bitstream GOP 0 has produced when the bounded job stops (every picture that was run: xeve_hip_enc_flush) against the reference's "
+                                  "bitstream after the same picture; whole 8-frame GOPs: tests/test_enc_gpu.py (1920x1080) and profiles/r05_bench_whole_gop.json (3840x2160)"})
         alg = k_units * (BYTES_PER_SAMPLE_PAIR if cls == "walk" else BYTES_PER_SEARCH_UNIT)
         alg_gbs = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         roof = {"kernel": "k_walk (xeve_amd/csrc/walk.h: the whole CTU mode decision of a lockstep step in ONE launch; the motion search's SAD rounds run inside it)" if cls == "walk" else
@@ -484,7 +498,8 @@ def main():
                     help="the CTU walk: one kernel per step (fused), ~10 000 launches per step (composed), or the library's choice by the chains in lockstep (auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra (the per-class / per-stage profile of the walk)")
-    ap.add_argument("--with-1080p", action="store_true", help="also run the same bounded job at 1920x1080 (north_star names both sizes; ~2 more minutes; profiles/r04_bench.json holds a run)")
+    ap.add_argument("--no-1080p", action="store_true", help="skip the same bounded job at 1920x1080 that follows the headline (north_star names both sizes; ~2 more minutes, after the timed region)")
+    ap.add_argument("--with-1080p", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
     a = ap.parse_args()
     if a.walk == "composed":
         os.environ["XEVE_HIP_WALK"] = "0"
@@ -542,7 +557,7 @@ def main():
             line["roofline"]["by_time"] = (stage_profile if cls == "walk" else class_profile)(torch, dev, cfg, max(8, Gs[0] // 4) if cls == "walk" else max(136, Gs[0] // 2), a.frames, per_picture, fb)
         except Exception as e:  # noqa: BLE001
             line["roofline"]["by_time"] = {"error": repr(e)[:300]}
-        if a.with_1080p and (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
+        if not a.no_1080p and (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
             try:
                 r2, _ = run_job(a, torch, dist, dev, rank, world, 1920, 1080, "secondary", False)
                 r2.pop("cpu")

@@ -793,7 +793,9 @@ typedef struct xeve_hip_tree_inter {
  * (the tree's cost), workspace: device. */
 size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *params);
 /* Every slice type: params->ip.slice_type 0 B / 1 P with `inter` (max_cu / min_cu = ctx->param.max_cu_inter / min_cu_inter), 2 I with inter == NULL (the
- * function below).  P / B: the chains of one call belong to ONE picture (jobs[].pic 0, pic_elems NULL) -- e.g. the CTU rows of a wavefront. */
+ * function below).  P / B: the chains of one call belong to ONE picture (jobs[].pic 0, pic_elems NULL) -- e.g. the CTU rows of a wavefront.
+ * _workspace's nchains is the WIDTH OF THE BATCH: max(nchains, nstates) over the calls that will use the workspace (the library picks the walk -- and with it the
+ * workspace layout -- by that width, xeve_hip_walk_fused; a run whose workspace is too small for the layout it picks returns XEVE_HIP_ERR_ARG). */
 size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hip_tree_params *params, const xeve_hip_tree_inter *inter, int s_org_l, int s_org_c);
 int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                    uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
@@ -809,6 +811,13 @@ int xeve_hip_walk_prof(unsigned long long *out, int cap);
  * XEVE_HIP_WALK_AUTO_MAX = 1024 chains -- the
  * fused kernel finishes a step of few chains sooner, the composed walk's kernels code more CTUs per second once thousands of chains are in lockstep). */
 int xeve_hip_walk_fused(int nchains);
+/* Moves that choice at run time: mode -1 by the width (the default), 0 the composed walk, 1 the fused kernel; returns the mode before the call (any other value only
+ * reads it).  Process-wide; workspaces are sized by the choice in force when xeve_hip_mode_analyze_ctu_workspace / xeve_hip_enc_create is called, so select BEFORE
+ * creating an encoder or sizing a workspace and keep it until that object is gone. */
+int xeve_hip_walk_select(int mode);
+/* Chains a team of the fused kernel carries: 0 (the default) = as few as keep every chain of the running encoders resident (1 up to ~1000 chains), 1..8 pins it
+ * (XEVE_HIP_WALK_C); returns the value before the call (a value outside 0..8 only reads it).  Results do not depend on it. */
+int xeve_hip_walk_team(int chains_per_team);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,
@@ -896,6 +905,10 @@ int xeve_hip_enc_encode(xeve_hip_enc *e);
 int xeve_hip_enc_begin(xeve_hip_enc *e);
 int xeve_hip_enc_advance(xeve_hip_enc *e, int64_t max_steps, int64_t *remaining);
 int xeve_hip_enc_sync(xeve_hip_enc *e);
+/* A picture's access unit is appended to its run's bitstream when the NEXT picture ends (its second writer pass runs beside that picture's steps).  _flush appends the
+ * one still outstanding now (waits for it): afterwards xeve_hip_enc_bitstream holds every picture whose steps have all been issued -- for a caller that stops part way
+ * (a bounded measurement, a check against the reference's bitstream after k pictures).  The run may be advanced further afterwards. */
+int xeve_hip_enc_flush(xeve_hip_enc *e);
 /* Run `gop`'s bitstream (what the application would have written to its output file); valid until the next encode / delete. */
 int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes);
 /* Lockstep statistics of the last encode: CTU steps issued, seconds inside the step calls / the picture-end calls (loop filter, second writer pass, padding). */

@@ -249,6 +249,34 @@ int xo_encode_gops(const xeve_hip_enc_config *cfg, const uint8_t *const *yuv, in
     }
     return 0;
 }
+// the same run cut after every `pictures_per_slice` pictures with BatchEncoder::flush() at each cut: after[k] = bytes of GOP 0's bitstream after the k-th cut (cap entries,
+// *ncuts of them used); out / out_bytes as xo_encode_gops.  What the product's xeve_hip_enc_flush does to the frame loop, pinned without a GPU: the final bytes must be
+// the un-flushed run's and every cut a prefix of them.
+int xo_encode_gops_flushed(const xeve_hip_enc_config *cfg, const uint8_t *const *yuv, int ngops, int frames, int pictures_per_slice, uint8_t **out, size_t *out_bytes,
+                           size_t *after, int cap, int *ncuts, char *err, int err_cap)
+{
+    Param P;
+    auto  say = [&](const std::string &m) { if(err && err_cap > 0) snprintf(err, (size_t)err_cap, "%s", m.c_str()); return -1; };
+    if(!P.finish(*cfg)) return say(P.error);
+    CpuEngine               E(P, ngops, frames, BatchEncoder<CpuEngine>::slots_needed(P, frames), yuv);
+    BatchEncoder<CpuEngine> enc(E, P, ngops, frames);
+    std::vector<std::vector<uint8_t>> o;
+    if(enc.begin(o) != 0) return say(enc.error);
+    const long per_picture = enc.total_steps() / frames;
+    int n = 0;
+    for(long left = enc.total_steps(); left > 0;) {
+        left = enc.advance(per_picture * std::max(1, pictures_per_slice));
+        if(left < 0 || enc.flush() != 0) return say(enc.error);
+        if(n < cap) after[n++] = o[0].size();
+        if(enc.flush() != 0) return say(enc.error); // (a second flush has nothing to do)
+    }
+    *ncuts = n;
+    for(int g = 0; g < ngops; g++) {
+        out[g] = (uint8_t *)malloc(o[g].size() ? o[g].size() : 1);
+        memcpy(out[g], o[g].data(), o[g].size()), out_bytes[g] = o[g].size();
+    }
+    return 0;
+}
 void xo_encode_free(uint8_t *p) { free(p); }
 // the frame loop alone: plan[i] = {frame, poc, slice type, temporal id, slice QP, idr, L0 POC or -1, L1 POC or -1} of the i-th coded picture; returns their number
 int xo_encode_plan(const xeve_hip_enc_config *cfg, int frames, int32_t *plan, int cap)

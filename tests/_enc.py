@@ -64,9 +64,9 @@ def harness():
     if _harness is None and os.environ.get("XO_ENC_ORACLE_LIB"):  # (tests/test_walk_race.py: the ThreadSanitizer build of the same harness)
         _harness = C.CDLL(os.environ["XO_ENC_ORACLE_LIB"])
     if _harness is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("enc_oracle.cpp", "xeve_oracle.c", "xeve_oracle.h")] + [os.path.join(ROOT, "xeve_amd", "csrc", f) for f in ("enc_host.h", "enc_plan.h")]
-        if not os.path.exists(ENC_ORACLE_SO) or os.path.getmtime(ENC_ORACLE_SO) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "enc"])
+        # make decides (oracle/Makefile lists enc_oracle.cpp, the oracle, enc_host.h / enc_plan.h AND every walk*.h the harness compiles: an edit to the walk alone
+        # must not be tested against a stale build)
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "enc"])
         _harness = C.CDLL(ENC_ORACLE_SO)
     return _harness
 
@@ -91,6 +91,21 @@ def encode_cpu(cfg, gops, frames, always_rewrite=False):
     for g in range(G):
         harness().xo_encode_free(out[g])
     return res
+
+
+def encode_cpu_flushed(cfg, gops, frames, pictures_per_slice=1):
+    """the same run cut after every `pictures_per_slice` pictures with the frame loop's flush() at each cut -> (bitstreams, [bytes of GOP 0's stream after each cut])"""
+    G = len(gops)
+    arr = (C.c_char_p * G)(*gops)
+    out, nb, err = (C.POINTER(C.c_uint8) * G)(), (C.c_size_t * G)(), C.create_string_buffer(512)
+    after, ncuts = (C.c_size_t * (frames + 2))(), C.c_int()
+    rc = harness().xo_encode_gops_flushed(C.byref(cfg), C.cast(arr, C.POINTER(C.c_void_p)), G, frames, int(pictures_per_slice), out, nb, after, frames + 2, C.byref(ncuts), err, 512)
+    if rc:
+        raise RuntimeError(err.value.decode())
+    res = [bytes(bytearray(out[g][:nb[g]])) for g in range(G)]
+    for g in range(G):
+        harness().xo_encode_free(out[g])
+    return res, [int(after[i]) for i in range(ncuts.value)]
 
 
 def md5(b):

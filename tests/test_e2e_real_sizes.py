@@ -15,7 +15,7 @@ from _libs import REF_APP
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_v1.json")))
 needs_ref = pytest.mark.skipif(not (os.path.exists(REF_APP) and os.path.exists(SHIM)), reason="oracle/_ref not built")
-pytestmark = [pytest.mark.gpu, needs_ref]
+pytestmark = [pytest.mark.gpu, pytest.mark.gpu_last, needs_ref]
 
 
 def _encode(tmp_path, name, cases, min_cus, tables=False, tree_ctus=0):
@@ -66,11 +66,13 @@ def _encode_per_ctu(tmp_path, name, nctu):
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
 
 
+@pytest.mark.gpu_full  # (46 s: the per-CTU host form at 1280x720; the default suite keeps it at 352x288, tests/test_integration_ref.py)
 def test_cfg2_1280x720_with_every_ctu_decided_on_the_gpu(tmp_path):
     """the same clip with ctx->fn_mode_analyze_lcu of all 480 CTUs (the I and the P picture) served by the device-side tree walk: one exchange per CTU, nothing per CU"""
     _encode_per_ctu(tmp_path, "cfg2_720p_ldb_fast", 480)
 
 
+@pytest.mark.gpu_full  # (158 s: one exchange per CTU at 1920x1080 -- parity plumbing, not a product path)
 def test_cfg3_1920x1080_with_every_ctu_decided_on_the_gpu(tmp_path):
     """1920x1080 random access (I, B, B in coding order: POC-scaled search ranges, temporal direct, both ECU depths, the bottom CTU row cut at 1080 = 16 * 64 + 56):
     all 3 x 510 CTUs decided on the device"""

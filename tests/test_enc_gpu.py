@@ -133,30 +133,47 @@ def test_a_wide_batch_fed_from_device_memory_keeps_every_gop_exact(hip, yuv_dir)
     assert not bad, bad[:10]
 
 
-# (the 8- / 9-frame forms of configs 2 and 3 and the 2-frame form of config 4 keep their goldens -- tests/test_enc_host.py and bench history use them -- but the GPU suite runs
-# the forms that contain them: 17 frames of configs 2 and 3 here, the whole 8-frame GOP of config 4 below)
-CONTAINED = {"cfg2_720p_ldb_fast_8f_m8", "cfg3_1080p_ra_medium_9f_m8", "cfg4_2160p_closedgop_medium_2f_m8"}
+# BASELINE's configs at their real picture sizes (gpu_last: after every other GPU test).  The default suite has to fit the driver's 1200 s on one MI355X (tests/conftest.py),
+# so it runs the forms that add something -- config 3 over a whole 16-picture sub-GOP on the library's own choice of walk, config 2 on the COMPOSED walk (the bench's path
+# at width), the whole 8-frame 1080p GOP on BOTH walks, config 4 (3840x2160) as IDR + two B pictures against the reference's per-picture prefixes -- and leaves the forms
+# those contain (9 frames of config 3, 2 frames of config 4) and the repeats (17 frames of config 2, the moving 1080p GOPs, the whole 4K GOP: 400 s) to XEVE_GPU_FULL=1.
+REAL_DEFAULT = {"cfg3_1080p_ra_medium_17f_m8": -1, "cfg2_720p_ldb_fast_8f_m8": 0}  # name -> walk (xeve_hip_walk_select)
+REAL_FULL = {"cfg2_720p_ldb_fast_17f_m8": -1, "gops_1080p_moving_m8": 0, "cfg3_1080p_ra_medium_9f_m8": 0, "cfg4_2160p_closedgop_medium_2f_m8": -1}
+assert set(REAL_DEFAULT) | set(REAL_FULL) == set(_enc.BATCH_CASES_REAL)
+WALK_NAME = {-1: "by_width", 0: "composed", 1: "fused"}
 
 
-@pytest.mark.parametrize("name", sorted(set(_enc.BATCH_CASES_REAL) - CONTAINED))
-def test_batches_at_real_picture_sizes_on_the_gpu(name, hip, yuv_dir):
-    """>= 2 GOPs x 8 frames at 1920x1080 (8 row chains per picture: 16 chains in lockstep, the second writer pass over 510 CTUs per picture)"""
+@pytest.mark.gpu_last
+@pytest.mark.parametrize("name,walk", [pytest.param(n, w, id="%s-%s" % (n, WALK_NAME[w])) for n, w in sorted(REAL_DEFAULT.items())] +
+                         [pytest.param(n, w, id="%s-%s" % (n, WALK_NAME[w]), marks=pytest.mark.gpu_full) for n, w in sorted(REAL_FULL.items())])
+def test_batches_at_real_picture_sizes_on_the_gpu(name, walk, hip, yuv_dir):
+    """BASELINE's configs 2 and 3 as runs of 8 / 17 frames at 1280x720 / 1920x1080 (8 row chains per picture, the second writer pass over 510
+    CTUs per picture, four B layers with reference distances 16 / 8 / 4 / 2 / 1) = the reference application's bitstreams"""
     w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES_REAL[name]
     g = _enc.golden()["batches"][name]
     data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
-    outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
-    print(name, st)
+    with hip.walk_select(walk):
+        outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    print(name, WALK_NAME[walk], st)
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
 FULL_GOPS = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "cfg4_8f_v1.json")))  # make_cfg4_8f_golden.py: the unmodified reference on the bench's own clips
+C3, C4 = "cfg3_1080p_closedgop_medium_8f_m8", "cfg4_2160p_closedgop_medium_8f_m8"
+assert {C3, C4} == set(FULL_GOPS), sorted(FULL_GOPS)
 
 
-@pytest.mark.parametrize("name", sorted(FULL_GOPS))
-def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, hip):
-    """BASELINE config 4 (3840x2160) and 1920x1080 as FULL `-I 8` closed GOPs (1 IDR + 7 hierarchical B pictures, -m 8) -- the clip bench.py seeds its
-    batches with; GOP 1 of the batch is the same clip with its frames in reverse order (another GOP beside it in lockstep), GOP 0 must be the reference's file byte for byte
-    and the bitstream after every picture the golden's prefix"""
+@pytest.mark.gpu_last
+@pytest.mark.parametrize("name,walk,pictures", [
+    pytest.param(C4, 0, 3, id="2160p-composed-idr_and_two_b"),
+    pytest.param(C3, 0, 8, id="1080p-composed-whole_gop"), pytest.param(C3, 1, 8, id="1080p-fused-whole_gop"),
+    pytest.param(C4, 1, 3, id="2160p-fused-idr_and_two_b", marks=pytest.mark.gpu_full), pytest.param(C4, -1, 8, id="2160p-by_width-whole_gop", marks=pytest.mark.gpu_full)])
+def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, walk, pictures, hip):
+    """BASELINE config 4 (3840x2160) and 1920x1080 as FULL `-I 8` closed GOPs (1 IDR + 7 hierarchical B pictures, -m 8) -- the clip
+    bench.py seeds its batches with -- on the composed walk (what the bench runs at width) AND the fused kernel.  GOP 1 of the batch is the same clip with its frames in
+    reverse order (another GOP beside it in lockstep); GOP 0 must be the reference's file byte for byte: after `pictures` pictures (xeve_hip_enc_flush) the golden's prefix
+    after the same picture, and with the whole GOP run, the file.  3840x2160 in the default suite = the IDR picture and two B pictures (POC 4 from the IDR picture alone,
+    POC 2 from two different reference pictures); the whole 4K GOP is bench.py --pictures 0's in-run check (profiles/r05_bench_whole_gop.json) and XEVE_GPU_FULL=1"""
     import numpy as np
 
     from bench import check_prefix, reference_noise
@@ -166,11 +183,22 @@ def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, hip):
     fb = w * h * 3 // 2
     clip = reference_noise(fb * frames, r["seed"])
     back = np.ascontiguousarray(clip.reshape(frames, fb)[::-1]).reshape(-1)
-    outs, st = _run(hip, hip.config(w, h, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=8), [clip.tobytes(), back.tobytes()], frames)
-    print(name, st)
-    assert (len(outs[0]), _enc.md5(outs[0])) == (r["bytes"], r["md5"])
-    assert check_prefix(outs[0], r) == frames
-    assert outs[1] != outs[0] and len(outs[1]) > r["bytes"] // 2
+    with hip.walk_select(walk):
+        enc = hip.BatchEncoder(hip.config(w, h, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=8), 2, frames)
+        for g, d in enumerate((clip.tobytes(), back.tobytes())):
+            enc.push_gop(g, d)
+        enc.begin()
+        per_picture = enc.advance(0) // frames
+        left = enc.advance(pictures * per_picture)
+        enc.sync()
+        enc.flush()
+        outs, st = enc.bitstreams(), enc.stats()
+        enc.close()
+    print(name, WALK_NAME[walk], pictures, st)
+    assert check_prefix(outs[0], r) == pictures
+    assert outs[1] != outs[0] and len(outs[1]) > len(outs[0]) // 2
+    if pictures == frames:
+        assert left == 0 and (len(outs[0]), _enc.md5(outs[0])) == (r["bytes"], r["md5"])
 
 
 def test_configurations_outside_the_supported_set_are_refused_by_the_library(hip):

@@ -172,6 +172,28 @@ def test_one_chain_through_the_second_writer_pass_gives_the_same_bytes(yuv_dir):
     assert a == b and _enc.md5(a) == E2E["tiny_closed_gop"]["md5"]
 
 
+@pytest.mark.parametrize("name", ["gops_128x64_noise", "gops_128x128_moving_m2"])
+def test_flushing_after_every_picture_changes_no_byte_and_cuts_at_access_units(name, yuv_dir):
+    """BatchEncoder::flush (the product's xeve_hip_enc_flush): the access unit of the picture just ended appended at once instead of at the next picture's end -- one and
+    two row chains (the second writer pass pending at the cut).  The final streams are the reference's; GOP 0's stream after cut k is a prefix of it and ends where an
+    access unit ends (the next bytes are a NAL unit's length field, and the lengths walk exactly to the cut)"""
+    import struct
+
+    w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    chunks = [data[i * fb:(i + 1) * fb] for i in range(gops)]
+    for per in (1, 3):
+        outs, after = _enc.encode_cpu_flushed(_enc.config(w, h, cli, threads), chunks, frames, per)
+        assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+        assert len(after) == -(-frames // per) and after == sorted(after) and len(set(after)) == len(after) and after[-1] == len(outs[0])
+        ends, pos = set(), 0
+        while pos < len(outs[0]):  # the application's output: a 4-byte big-endian length in front of every NAL unit
+            pos += 4 + struct.unpack_from(">I", outs[0], pos)[0]
+            ends.add(pos)
+        assert pos == len(outs[0]) and set(after) <= ends
+
+
 def test_configurations_outside_the_supported_set_are_refused():
     for bad in (dict(w=130), dict(preset=2), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
         c = _enc.config(128, 64, ["--preset", "fast"])

@@ -10,6 +10,11 @@ from _tree_cases import CASES, CTU_DATA_DTYPE, CTU_JOB_DTYPE, INTER_CASES, make_
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _every_test_here_on_each_walk(each_walk):  # (tests/conftest.py: the library's choice, the composed walk pinned, the fused kernel with 3 chains per team)
+    return each_walk
+
+
 def run_hip_case(c):
     import torch
     import xeve_amd
@@ -205,17 +210,19 @@ def test_hip_ctu_rows_of_a_b_picture_as_chains_of_one_call():
     assert np.array_equal(mod[0].cpu().numpy(), c["mod"][0]) and np.array_equal(mv.cpu().numpy(), m["mv"]) and np.array_equal(ms.cpu().numpy().view(np.uint32), m["scu"])
 
 
-def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path):
-    """XEVE_HIP_TREE_LANE=1 (off by default: measured slower): the 4x4 / 8x8 nodes decided by one lane per chain (csrc/cu_lane.h).  The switch is read
-    once per process, so a fresh interpreter runs two of the cases above with it on; the same comparison against the oracle must hold."""
+def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path, each_walk):
+    """XEVE_HIP_TREE_LANE=1 (off by default: measured slower): the 4x4 / 8x8 nodes of the COMPOSED walk decided by one lane per chain (csrc/cu_lane.h).  The
+    switch is read once per process, so a fresh interpreter runs three of the cases above with it on (composed walk pinned); the same comparison against the oracle must hold."""
     import os
     import subprocess
     import sys
 
+    if each_walk != "composed":
+        pytest.skip("the lane-serial node kernel belongs to the composed walk: run once, with it pinned")
     env = dict(os.environ, XEVE_HIP_TREE_LANE="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-k", "matches_oracle and (3101 or 3104 or 4103)"], env=env, capture_output=True, text=True,
-                       timeout=900)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "matches_oracle and composed and (3101 or 3104 or 4103)"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
 
 

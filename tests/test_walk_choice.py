@@ -27,3 +27,14 @@ def test_the_environment_pins_a_walk_or_moves_the_width():
     assert ask(XEVE_HIP_WALK="0") == [0] * 6
     assert ask(XEVE_HIP_WALK_AUTO_MAX="4000") == [1, 1, 1, 1, 1, 0]
     assert ask(XEVE_HIP_WALK_AUTO_MAX="0") == [0] * 6
+
+
+def test_the_choice_moves_at_run_time_and_comes_back():
+    """xeve_hip_walk_select / xeve_hip_walk_team (encode.walk_select): what the GPU suite uses to run one process through both walks"""
+    code = ("from xeve_amd import lib, encode; L = lib.load(); f = lambda: [L.xeve_hip_walk_fused(n) for n in (8, 5000)]; a = f()\n"
+            "with encode.walk_select(0):\n b = f()\n with encode.walk_select(1, 3):\n  c = f(); t = L.xeve_hip_walk_team(-1)\n d = f()\n"
+            "print(a, b, c, t, d, f(), L.xeve_hip_walk_team(99), L.xeve_hip_walk_select(7))")
+    e = {k: v for k, v in os.environ.items() if not k.startswith("XEVE_HIP_WALK")}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(e, PYTHONPATH=ROOT), timeout=120)
+    assert p.returncode == 0, p.stderr[-800:]
+    assert p.stdout.strip() == "[1, 0] [0, 0] [1, 1] 3 [0, 0] [1, 0] 0 -1", p.stdout

@@ -1,22 +1,49 @@
 """Both CTU walks stay pinned on the GPU whatever the library's own choice is (walk.hip: the fused kernel up to 1024 chains in lockstep, the composed walk above -- the
-suite's own batches are all narrow): the same reference-bitstream and CTU-tree tests once more in a process with the composed walk pinned (XEVE_HIP_WALK=0) and in one
-with the fused walk carrying three chains per team (XEVE_HIP_WALK=1 XEVE_HIP_WALK_C=3: teams of several chains are otherwise only formed beyond 1024 chains)."""
-import os
-import subprocess
-import sys
-
+suite's own batches are all narrow): reference-bitstream cases of the batch encoder once more with the composed walk pinned (the bench's path at width) and with the fused
+kernel carrying three chains per team (teams of several chains are otherwise only formed beyond ~1000 chains).  In process (xeve_hip_walk_select / _team; round 4 spawned an
+interpreter per pin); the CTU-tree tests take the same three settings through tests/conftest.py `each_walk`, the real-size cases through tests/test_enc_gpu.py."""
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PICK = "tiny_ldb_fast or tiny_ra_medium or moving_ldb_ref3 or jumpy_ldb_fast or gops_128x64_noise or gops_cif_noise_m8 or the_same_as_its_gops"
+import _e2e
+import _enc
+import test_enc_gpu as T
+
+pytestmark = pytest.mark.gpu
+
+SINGLE = ["tiny_ldb_fast", "tiny_ra_medium", "moving_ldb_ref3", "jumpy_ldb_fast"]
+BATCHES = ["gops_128x64_noise", "gops_cif_noise_m8"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"XEVE_HIP_WALK": "0"}, {"XEVE_HIP_WALK": "1", "XEVE_HIP_WALK_C": "3"}], ids=["composed", "fused_3_chains_per_team"])
-def test_the_encoder_and_tree_tests_with_the_walk_pinned(env):
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_enc_gpu.py"), os.path.join(ROOT, "tests", "test_hip_tree.py"),
-           "-k", PICK + " or tree"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, **env))
-    tail = p.stdout[-1500:]
-    assert p.returncode == 0, (tail, p.stderr[-1500:])
-    assert " passed" in tail and "failed" not in tail, tail
+@pytest.fixture(scope="module")
+def hip():
+    import xeve_amd
+    from xeve_amd import encode
+
+    xeve_amd.init(0)
+    return encode
+
+
+@pytest.fixture(scope="module")
+def yuv_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("walk_choice_yuv")
+
+
+@pytest.mark.parametrize("pin", ["composed", "fused_3_chains_per_team"])
+def test_the_encoder_with_the_walk_pinned(pin, hip, yuv_dir):
+    from conftest import WALKS
+
+    mode, team = WALKS[pin]
+    L = __import__("xeve_amd.lib", fromlist=["load"]).load()
+    with hip.walk_select(mode, team):
+        assert L.xeve_hip_walk_fused(8) == mode and L.xeve_hip_walk_fused(100000) == mode  # (pinned: whatever the width)
+        for name in SINGLE:
+            w, h, n, seed, cli = _e2e.CASES[name]
+            out, _ = T._run(hip, T._cfg(hip, w, h, cli), [T._frames(yuv_dir, name, w, h, n, seed)], n)
+            assert (len(out[0]), _enc.md5(out[0])) == (T.E2E[name]["bytes"], T.E2E[name]["md5"]), (pin, name)
+        for name in BATCHES:
+            w, h, gops, frames, seed, cli, threads = _enc.BATCH_CASES[name]
+            g = _enc.golden()["batches"][name]
+            data, fb = T._frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+            outs, _ = T._run(hip, T._cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+            assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]], (pin, name)
+    assert L.xeve_hip_walk_fused(8) == 1 and L.xeve_hip_walk_fused(100000) == 0  # back to the choice by width

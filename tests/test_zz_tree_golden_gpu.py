@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_hip_ctu_mode_decision_matches_the_reference_goldens():
+def test_hip_ctu_mode_decision_matches_the_reference_goldens(each_walk):
     """the device walk against tests/golden/tree_v1.npz: CTUs of real encodes (I, P and B pictures, intra / inter / skip / direct CUs) with what the REFERENCE made of them,
     recorded inside the unmodified encoder (tests/golden/make_tree_golden.py) -- no oracle in between"""
     import torch

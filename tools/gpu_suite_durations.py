@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""junit XML of a `pytest tests -m gpu --junitxml=...` run on the GPU box -> tests/golden/gpu_suite_durations.json: seconds per test (set-up + call + tear-down), the
+run's wall time, what failed or was skipped.  tests/test_gpu_suite_budget.py (CPU suite) holds the default GPU suite to 900 s with it.
+usage: gpu_suite_durations.py run.xml [pytest.log] > tests/golden/gpu_suite_durations.json"""
+import json
+import re
+import sys
+import xml.etree.ElementTree as ET
+
+root = ET.parse(sys.argv[1]).getroot()
+suite = root if root.tag == "testsuite" else root.find("testsuite")
+tests, bad, skipped = {}, [], []
+for tc in suite.iter("testcase"):
+    cls, name = tc.get("classname", ""), tc.get("name", "")
+    nodeid = cls.replace(".", "/") + ".py::" + name  # (module-level tests only: classname = the dotted module path)
+    if tc.find("skipped") is not None:
+        skipped.append(nodeid)
+        continue
+    tests[nodeid] = round(tests.get(nodeid, 0.0) + float(tc.get("time", 0.0)), 3)
+    if tc.find("failure") is not None or tc.find("error") is not None:
+        bad.append(nodeid)
+wall = float(suite.get("time", 0.0))
+if len(sys.argv) > 2:  # pytest's own last line ("356 passed, 298 deselected in 612.34s") is the figure that includes collection and imports
+    m = re.findall(r" in ([0-9.]+)s", open(sys.argv[2]).read())
+    if m:
+        wall = max(wall, float(m[-1]))
+json.dump({"what": "seconds per test of the default GPU suite (`pytest tests -m gpu`, heavy repeats skipped: tests/conftest.py gpu_full) on one MI355X box",
+           "source": sys.argv[1], "wall_s": round(wall, 1), "sum_s": round(sum(tests.values()), 1), "passed": len(tests) - len(bad), "failed": bad, "skipped": skipped,
+           "tests": dict(sorted(tests.items()))}, sys.stdout, indent=1)
+print()

@@ -94,6 +94,10 @@ template <class Engine> class BatchEncoder {
         }
         return remaining();
     }
+    // the access unit of the picture whose end was issued last, NOW instead of at the next picture's end (waits for its second writer pass): afterwards out[g] holds every
+    // picture whose steps have all been issued -- what a caller that stops a run part way (a bounded measurement, a test against the reference's per-picture prefixes)
+    // reads.  The run can go on after it.
+    int flush() { return pending >= 0 ? finish_picture() : 0; }
     int run(std::vector<std::vector<uint8_t>> &out_)
     {
         if(begin(out_) != 0) return -1;

@@ -593,6 +593,15 @@ extern "C" int xeve_hip_enc_sync(xeve_hip_enc *e)
     XH_HIP(hipStreamSynchronize(e->st2)); // (the second writer pass, the tile end and the read-back of a picture run there: a fence covers both)
     return XEVE_HIP_OK;
 }
+extern "C" int xeve_hip_enc_flush(xeve_hip_enc *e)
+{
+    XH_ENTER();
+    XH_REQUIRE(e && e->loop);
+    const int rc = e->loop->flush();
+    if(!e->error.empty()) { xh_set_error("xeve_hip_enc_flush: %s", e->error.c_str()); return XEVE_HIP_ERR_DEVICE; }
+    if(rc != 0) { xh_set_error("xeve_hip_enc_flush: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }
+    return XEVE_HIP_OK;
+}
 extern "C" int xeve_hip_enc_encode(xeve_hip_enc *e)
 {
     int rc = xeve_hip_enc_begin(e);

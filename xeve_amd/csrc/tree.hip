@@ -481,7 +481,12 @@ static bool tree_inter_ok(const xeve_hip_tree_params *p, const xeve_hip_tree_int
 {   // the inter analysis is composed for square CUs 8 .. 64 (every inter CU of the Baseline quad-tree at the presets that keep min_cu_inter at 8)
     return I && (p->ip.slice_type == 0 || p->ip.slice_type == 1) && p->min_cu >= 8 && I->refp && I->map_mv && I->map_refi && I->col_mv0 && I->coef_l && I->coef_c &&
            (p->ip.slice_type == 1 || I->col_mv1) && I->ipar.rdo.slice_type == p->ip.slice_type && I->ipar.rdo.pic_w == p->pic_w && I->ipar.rdo.pic_h == p->pic_h &&
-           I->ipar.rdo.chroma_format_idc == p->ip.chroma_format_idc && I->ipar.rdo.bit_depth == p->ip.bit_depth;
+           I->ipar.rdo.chroma_format_idc == p->ip.chroma_format_idc && I->ipar.rdo.bit_depth == p->ip.bit_depth &&
+           // what xeve_hip_pinter_analyze_cu_jobs requires of its parameters (inter.hip inter_params_ok), checked HERE so that both walks refuse the same calls: the fused
+           // kernel indexes per-candidate and per-list arrays with these and divides by max_cand
+           I->ipar.max_cand >= 1 && I->ipar.max_cand <= 4 && I->ipar.rdo.tool_iqt == 0 && I->ipar.rdo.num_refp[0] >= 1 && I->ipar.rdo.num_refp[0] <= XEVE_HIP_MAX_REFP &&
+           (p->ip.slice_type == 1 || (I->ipar.rdo.num_refp[1] >= 1 && I->ipar.rdo.num_refp[1] <= I->ipar.rdo.num_refp[0])) && I->ipar.me.hpel_cnt >= 0 &&
+           I->ipar.me.hpel_cnt <= 8 && I->ipar.me.qpel_cnt >= 0 && I->ipar.me.qpel_cnt <= 8;
 }
 static xeve_hip_intra_params level_params(const xeve_hip_tree_params *p, int log2)
 {

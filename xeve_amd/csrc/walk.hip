@@ -61,11 +61,34 @@ void xh_walk_load(long chains) { g_walk_load.fetch_add(chains); }
 // 3840x2160 against the composed walk's launch-bound ~110 / 185 ms), the composed walk's kernels pack the lanes of MANY chains densely and code more CTUs per second
 // from ~2 000 chains on (profiles/r04_walks.md).  nchains = the width of the batch the call belongs to (tree.hip).  XEVE_HIP_WALK=1 / 0 pins the fused / the composed
 // walk; unset: fused up to XEVE_HIP_WALK_AUTO_MAX chains (1024).
+namespace {
+// the walk choice: -1 by the width (fused up to g_walk_auto_max chains), 0 the composed walk, 1 the fused kernel.  Starts from XEVE_HIP_WALK / XEVE_HIP_WALK_AUTO_MAX;
+// xeve_hip_walk_select moves it at run time (one process can then pin each walk in turn: tests/test_enc_gpu.py)
+int walk_env_mode()
+{
+    const char *e = getenv("XEVE_HIP_WALK");
+    return e && *e && strcmp(e, "auto") ? (atoi(e) != 0) : -1;
+}
+std::atomic<int> g_walk_mode{walk_env_mode()};
+std::atomic<int> g_walk_auto_max{getenv("XEVE_HIP_WALK_AUTO_MAX") ? atoi(getenv("XEVE_HIP_WALK_AUTO_MAX")) : 1024};
+} // namespace
 bool xh_walk_enabled(int nchains)
 {
-    static const int on = getenv("XEVE_HIP_WALK") && *getenv("XEVE_HIP_WALK") && strcmp(getenv("XEVE_HIP_WALK"), "auto") ? atoi(getenv("XEVE_HIP_WALK")) : -1;
-    static const int auto_max = getenv("XEVE_HIP_WALK_AUTO_MAX") ? atoi(getenv("XEVE_HIP_WALK_AUTO_MAX")) : 1024;
-    return on < 0 ? nchains <= auto_max : on != 0;
+    const int on = g_walk_mode.load(std::memory_order_relaxed);
+    return on < 0 ? nchains <= g_walk_auto_max.load(std::memory_order_relaxed) : on != 0;
+}
+std::atomic<int> g_walk_team{getenv("XEVE_HIP_WALK_C") ? atoi(getenv("XEVE_HIP_WALK_C")) : 0};
+extern "C" int xeve_hip_walk_team(int chains_per_team)
+{
+    const int before = g_walk_team.load();
+    if(chains_per_team >= 0 && chains_per_team <= XW_MAXC) g_walk_team.store(chains_per_team);
+    return before;
+}
+extern "C" int xeve_hip_walk_select(int mode)
+{
+    const int before = g_walk_mode.load();
+    if(mode >= -1 && mode <= 1) g_walk_mode.store(mode);
+    return before;
 }
 bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int nchains)
 {
@@ -75,6 +98,9 @@ bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter 
         if(!inter_on) return false;
         const int n0 = I->ipar.rdo.num_refp[0], n1 = I->ipar.rdo.num_refp[1];
         if(n0 > XW_MAXR || n1 > XW_MAXR) return false;
+        // a diamond's remaining rings are one round of the fused search (walk_inter.h dia_round: 5 + 9 + 16 per doubling of the step from 16 on): they fit MeJob::cx[96] up
+        // to a range of 256; beyond it the composed walk runs the call
+        if(I->ipar.me.me.max_search_range > 256) return false;
     }
     return p->log2_ctu <= 6;
 }
@@ -87,9 +113,9 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
                 size_t workspace_bytes, int vh, hipStream_t st)
 {
     XH_REQUIRE(workspace_bytes >= xh_walk_workspace(nchains));
-    static const int C_env = getenv("XEVE_HIP_WALK_C") ? atoi(getenv("XEVE_HIP_WALK_C")) : 0;
+    const int C_env = g_walk_team.load(std::memory_order_relaxed); // (XEVE_HIP_WALK_C / xeve_hip_walk_team; 0: by the load)
     static const int NT_env = getenv("XEVE_HIP_WALK_NT") ? atoi(getenv("XEVE_HIP_WALK_NT")) : XW_NT;
-    static const int wg_slots = [] {
+    const int wg_slots = [] { // of the device this thread is bound to NOW (the library can be re-bound to another GPU: xh_generation)
         int dev = 0, cus = 256;
         if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return (cus > 0 ? cus : 256) * XW_WG_PER_CU;
@@ -103,55 +129,67 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
     xw::fill_params(q, org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost, vh);
     static const int force_count = getenv("XEVE_HIP_WALK_COUNT") ? atoi(getenv("XEVE_HIP_WALK_COUNT")) : 0; // (probes: the encoder's count-only states from any caller)
     q.C = C, q.full = !xh_count_states() && !force_count;
-    {
-        std::lock_guard<std::mutex> lk(g_walk.mu);
-        WalkDev &D = g_walk;
-        if(D.gen != xh_generation()) D.drop(), D.gen = xh_generation();
-        if(!D.dct) {
-            xw::Tables T;
-            xw::make_tables(T);
-            XH_HIP(hipMalloc((void **)&D.dct, T.dct.size()));
-            XH_HIP(hipMalloc((void **)&D.scan, T.scan.size() * 2));
-            XH_HIP(hipMalloc((void **)&D.entropy, T.entropy.size() * 4));
-            XH_HIP(hipMemcpy(D.dct, T.dct.data(), T.dct.size(), hipMemcpyHostToDevice));
-            XH_HIP(hipMemcpy(D.scan, T.scan.data(), T.scan.size() * 2, hipMemcpyHostToDevice));
-            XH_HIP(hipMemcpy(D.entropy, T.entropy.data(), T.entropy.size() * 4, hipMemcpyHostToDevice));
+    // (the lock is held over the launch: a call with another filter set must not rewrite the table between this call's copy and its kernel reading it)
+    std::lock_guard<std::mutex> lk(g_walk.mu);
+    WalkDev &D = g_walk;
+    if(D.gen != xh_generation()) D.drop(), D.gen = xh_generation();
+    if(!D.dct) { // all three tables or none: a failure half way must not leave later calls with a null or unwritten table
+        xw::Tables T;
+        xw::make_tables(T);
+        int8_t *d = nullptr;
+        uint16_t *sc = nullptr;
+        int32_t *en = nullptr;
+        const bool ok = hipMalloc((void **)&d, T.dct.size()) == hipSuccess && hipMalloc((void **)&sc, T.scan.size() * 2) == hipSuccess &&
+                        hipMalloc((void **)&en, T.entropy.size() * 4) == hipSuccess && hipMemcpy(d, T.dct.data(), T.dct.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(sc, T.scan.data(), T.scan.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(en, T.entropy.data(), T.entropy.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if(!ok) {
+            (void)hipFree(d), (void)hipFree(sc), (void)hipFree(en);
+            xh_set_error("xeve_hip walk: the device tables could not be set up");
+            return XEVE_HIP_ERR_DEVICE;
         }
-        if(I) { // the interpolation filters: the caller's host tables (pi->mc_l_coeff / mc_c_coeff)
-            std::vector<int16_t> h(16 * 8 + 32 * 4, 0);
-            memcpy(h.data(), I->coef_l, 16 * 8 * 2);
-            if(I->coef_c) memcpy(h.data() + 128, I->coef_c, 32 * 4 * 2);
-            if(!D.mc || h != D.mc_host) {
-                if(!D.mc) XH_HIP(hipMalloc((void **)&D.mc, h.size() * 2));
-                else XH_HIP(hipDeviceSynchronize()); // (a different filter set than the last call's: wait for the launches that read the old one)
-                XH_HIP(hipMemcpy(D.mc, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-                D.mc_host = h;
-            }
-            q.mc_l = D.mc, q.mc_c = D.mc + 128;
-        }
-        const int key[8] = {p->log2_ctu, p->max_cu, p->min_cu, p->min_cuwh, p->pic_w, p->pic_h, I != nullptr, 0};
-        const OpsEntry *hit = nullptr;
-        for(const auto &e : D.ops)
-            if(!memcmp(e.key, key, sizeof(key))) hit = &e;
-        if(!hit) {
-            const std::vector<xw::Op> ops = xw::make_ops(p, I != nullptr);
-            OpsEntry e;
-            memcpy(e.key, key, sizeof(key)), e.n = (int)ops.size();
-            XH_HIP(hipMalloc((void **)&e.dev, ops.size() * sizeof(xw::Op)));
-            XH_HIP(hipMemcpy(e.dev, ops.data(), ops.size() * sizeof(xw::Op), hipMemcpyHostToDevice));
-            D.ops.push_back(e);
-            hit = &D.ops.back();
-        }
-        q.ops = hit->dev, q.nops = hit->n, q.dct = D.dct, q.scan = D.scan, q.entropy = D.entropy;
-        static const int prof_env = getenv("XEVE_HIP_WALK_PROF") ? atoi(getenv("XEVE_HIP_WALK_PROF")) : 0;
-        const int prof_on = prof_env || g_walk_prof_on.load();
-        if(!prof_on) q.prof = nullptr;
-        if(prof_on && !D.prof) {
-            XH_HIP(hipMalloc((void **)&D.prof, 2 * xw::PR_N * 8));
-            XH_HIP(hipMemset(D.prof, 0, 2 * xw::PR_N * 8));
-        }
-        q.prof = prof_on ? D.prof : nullptr;
+        D.dct = d, D.scan = sc, D.entropy = en;
     }
+    if(I) { // the interpolation filters: the caller's host tables (pi->mc_l_coeff / mc_c_coeff)
+        std::vector<int16_t> h(16 * 8 + 32 * 4, 0);
+        memcpy(h.data(), I->coef_l, 16 * 8 * 2);
+        if(I->coef_c) memcpy(h.data() + 128, I->coef_c, 32 * 4 * 2);
+        if(!D.mc || h != D.mc_host) {
+            int16_t *m = D.mc;
+            if(!m) XH_HIP(hipMalloc((void **)&m, h.size() * 2));
+            else XH_HIP(hipDeviceSynchronize()); // (a different filter set than the last call's: wait for the launches that read the old one)
+            if(hipMemcpy(m, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                if(!D.mc) (void)hipFree(m);
+                D.mc_host.clear(); // (the old table's content is no longer known)
+                xh_set_error("xeve_hip walk: the interpolation filters could not be copied");
+                return XEVE_HIP_ERR_DEVICE;
+            }
+            D.mc = m, D.mc_host = h;
+        }
+        q.mc_l = D.mc, q.mc_c = D.mc + 128;
+    }
+    const int key[8] = {p->log2_ctu, p->max_cu, p->min_cu, p->min_cuwh, p->pic_w, p->pic_h, I != nullptr, 0};
+    const OpsEntry *hit = nullptr;
+    for(const auto &e : D.ops)
+        if(!memcmp(e.key, key, sizeof(key))) hit = &e;
+    if(!hit) {
+        const std::vector<xw::Op> ops = xw::make_ops(p, I != nullptr);
+        OpsEntry e;
+        memcpy(e.key, key, sizeof(key)), e.n = (int)ops.size();
+        XH_HIP(hipMalloc((void **)&e.dev, ops.size() * sizeof(xw::Op)));
+        XH_HIP(hipMemcpy(e.dev, ops.data(), ops.size() * sizeof(xw::Op), hipMemcpyHostToDevice));
+        D.ops.push_back(e);
+        hit = &D.ops.back();
+    }
+    q.ops = hit->dev, q.nops = hit->n, q.dct = D.dct, q.scan = D.scan, q.entropy = D.entropy;
+    static const int prof_env = getenv("XEVE_HIP_WALK_PROF") ? atoi(getenv("XEVE_HIP_WALK_PROF")) : 0;
+    const int prof_on = prof_env || g_walk_prof_on.load();
+    if(!prof_on) q.prof = nullptr;
+    if(prof_on && !D.prof) {
+        XH_HIP(hipMalloc((void **)&D.prof, 2 * xw::PR_N * 8));
+        XH_HIP(hipMemset(D.prof, 0, 2 * xw::PR_N * 8));
+    }
+    q.prof = prof_on ? D.prof : nullptr;
     static const int dbg = getenv("XEVE_HIP_WALK_DBG") ? atoi(getenv("XEVE_HIP_WALK_DBG")) : 0;
     q.dbg = dbg;
     static const int deal = getenv("XEVE_HIP_WALK_DEAL") ? atoi(getenv("XEVE_HIP_WALK_DEAL")) : 0;

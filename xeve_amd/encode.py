@@ -67,6 +67,10 @@ class BatchEncoder:
     def sync(self):
         _lib.check(self._L.xeve_hip_enc_sync(self._h))
 
+    def flush(self):
+        """appends the access unit still outstanding (a picture's is appended when the next picture ends): bitstream() then holds every picture whose steps were issued"""
+        _lib.check(self._L.xeve_hip_enc_flush(self._h))
+
     def bitstream(self, gop):
         """the bitstream of one GOP (bytes)"""
         p, n = C.c_void_p(), C.c_size_t()
@@ -98,6 +102,24 @@ class BatchEncoder:
         steps, a, b = C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self._L.xeve_hip_enc_stats(self._h, C.byref(steps), C.byref(a), C.byref(b)))
         return {"ctu_steps": steps.value, "step_seconds": a.value, "picture_end_seconds": b.value}
+
+
+class walk_select:
+    """with walk_select(0 | 1 | -1, chains_per_team=0): ... -- pins the composed walk (0) / the fused kernel (1) / the choice by width (-1) for the encoders created
+    inside, and optionally how many chains a team of the fused kernel carries (xeve_hip_walk_select / _team: process-wide; create AND close the encoder inside)"""
+
+    def __init__(self, mode, chains_per_team=0):
+        self.mode, self.team = int(mode), int(chains_per_team)
+
+    def __enter__(self):
+        L = _lib.load()
+        self.before, self.team_before = L.xeve_hip_walk_select(self.mode), L.xeve_hip_walk_team(self.team)
+        return self
+
+    def __exit__(self, *exc):
+        L = _lib.load()
+        L.xeve_hip_walk_select(self.before), L.xeve_hip_walk_team(self.team_before)
+        return False
 
 
 def footprint(cfg, ngops, frames):

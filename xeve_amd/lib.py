@@ -216,6 +216,8 @@ FUNCTIONS = {
     "xeve_hip_walk_prof_enable": (c_int, [c_int]),
     "xeve_hip_walk_prof": (c_int, [c_void_p, c_int]),
     "xeve_hip_walk_fused": (c_int, [c_int]),
+    "xeve_hip_walk_select": (c_int, [c_int]),
+    "xeve_hip_walk_team": (c_int, [c_int]),
     "xeve_hip_mode_analyze_ctu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_void_p] * 3),
     "xeve_hip_eco_ctu_jobs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_eco_tile_end_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -246,6 +248,7 @@ FUNCTIONS = {
     "xeve_hip_enc_begin": (c_int, [c_void_p]),
     "xeve_hip_enc_advance": (c_int, [c_void_p, c_i64, c_void_p]),
     "xeve_hip_enc_sync": (c_int, [c_void_p]),
+    "xeve_hip_enc_flush": (c_int, [c_void_p]),
     "xeve_hip_enc_bitstream": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_enc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_enc_footprint": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
