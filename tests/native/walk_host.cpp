@@ -41,6 +41,10 @@ int xw_host_walk_mt(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, 
     xw::Lds *S = (xw::Lds *)malloc(sizeof(xw::Lds));
     memset((void *)S, 0xCD, sizeof(xw::Lds));
     const int nt = threads < 1 ? 1 : threads;
+    // XW_HOST_DEAL / XW_HOST_ROTATE: the device's two lane layouts of the serial stages (walk.hip: P::deal; k_walk's rotation of a team's waves) on the host's teams of
+    // real threads -- the results must not depend on either
+    q.deal = getenv("XW_HOST_DEAL") ? atoi(getenv("XW_HOST_DEAL")) : 0;
+    const int rot = getenv("XW_HOST_ROTATE") && nt >= 128 && nt % 64 == 0 ? atoi(getenv("XW_HOST_ROTATE")) % (nt / 64) : 0;
     if(nt == 1) {
         const xw::Tm tm = {0, 1};
         for(int team = 0; team * q.C < nchains; team++) {
@@ -55,7 +59,7 @@ int xw_host_walk_mt(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, 
         for(int t = 0; t < nt; t++)
             th.emplace_back([&, t] {
                 xw::host_team() = {[](void *b) { pthread_barrier_wait((pthread_barrier_t *)b); }, &bar};
-                const xw::Tm tm = {t, nt};
+                const xw::Tm tm = {rot ? ((((t >> 6) - rot + nt / 64) % (nt / 64)) << 6) | (t & 63) : t, nt};
                 for(int team = 0; team * q.C < nchains; team++) {
                     if(full) xw::walk_team<true>(tm, q, *S, team);
                     else xw::walk_team<false>(tm, q, *S, team);

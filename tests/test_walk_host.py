@@ -143,6 +143,19 @@ def test_walk_p_and_b_pictures_with_a_team_of_real_threads(case, threads):
     check_inter(case, threads=threads)
 
 
+@pytest.mark.parametrize("rotate", [1, 3])
+def test_the_serial_stages_packed_into_a_rotated_wave_change_nothing(rotate, monkeypatch):
+    """walk.hip runs a team's serial stages (coder jobs, RDOQ scans) on ONE wave and takes that wave from a different SIMD for each of a CU's four teams: the logical thread
+    index is the hardware one with the waves rotated.  The same layouts on the host's team of 256 real threads (P::deal = 1, the thread indices rotated by whole waves) must
+    give the oracle's results: an I picture with two chains per team and a B picture"""
+    monkeypatch.setenv("XW_HOST_DEAL", "1")
+    monkeypatch.setenv("XW_HOST_ROTATE", str(rotate))
+    c = make_case(*CASES[4])
+    got, final = run_walk_case(c, chains_per_team=2, full=0, threads=256)
+    compare(CASES[4], c, got, final, full=0)
+    check_inter(INTER_CASES[3], threads=256)
+
+
 # ---- end to end: the batch encoder's frame loop with EVERY CTU decided by the fused walk's host side, against bitstreams of the unmodified reference application ----------
 import json  # noqa: E402
 

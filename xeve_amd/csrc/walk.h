@@ -520,15 +520,16 @@ XW_CNT void cnt_events(CntState &st, const uint32_t *ev, int nev)
 {
     Mdl      r0 = st.r0, r1 = st.r1, l0 = st.l0, l1 = st.l1, la = st.la;
     unsigned range = st.range, shifts = st.shifts;
-    uint32_t e = nev > 0 ? ev[0] : 0u;
+    // (four events are on their way while one is coded: an event is 3 .. 10 bins of ~40 instructions, a load from the chain's workspace ~1 us)
+    uint32_t e = nev > 0 ? ev[0] : 0u, e1 = nev > 1 ? ev[1] : 0u, e2 = nev > 2 ? ev[2] : 0u, e3 = nev > 3 ? ev[3] : 0u;
     for(int i = 0; i < nev; i++) {
-        const uint32_t en = i + 1 < nev ? ev[i + 1] : 0u; // (the next event is on its way while this one is coded)
+        const uint32_t en = i + 4 < nev ? ev[i + 4] : 0u;
         cnt_unary(range, shifts, r0, r1, (e >> 16) & 0xFFFu);
         cnt_unary(range, shifts, l0, l1, e & 0x7FFFu);
         range &= ~1u, shifts++; // the sign, bypass coded
         if((e >> 28) & 1u) break;
         cnt_bin(range, shifts, la, i == nev - 1 ? 1u : 0u);
-        e = en;
+        e = e1, e1 = e2, e2 = e3, e3 = en;
     }
     st.r0 = r0, st.r1 = r1, st.l0 = l0, st.l1 = l1, st.la = la, st.range = range, st.shifts = shifts;
 }

@@ -14,10 +14,35 @@
 #define XW_WG_PER_CU 4
 #endif
 
-template <bool FULL> __global__ void __launch_bounds__(XW_NT, XW_WG_PER_CU) k_walk(xw::P p)
+// A team's SERIAL stages (a coder job, an RDOQ scan, a per-chain decision per lane: 3 .. 60 busy lanes, ~55 % of a step's time) land on its logical threads 0 .. 63.  A CU
+// holds four teams, one wave of each on every SIMD, and a SIMD issues ONE wave instruction per 4 clocks however many waves are resident: with every team's serial lanes in
+// its wave 0, the four teams' coder loops share one SIMD's issue slots (a bin: ~40 instructions -> 640 clocks per bin instead of 160) while three SIMDs idle at the
+// barrier.  So a team takes its LOGICAL wave 0 from the SIMD its arrival order on the CU names (p.cu_arrivals: a counter per physical CU, read from HW_ID / XCC_ID):
+// the logical thread index is the hardware one with the waves rotated; whole waves move, lanes keep their place, nothing else in the walk knows.  Results cannot
+// depend on it (the host harness runs the same code with rotated teams of real threads).
+template <bool FULL> __global__ void __launch_bounds__(XW_NT, XW_WG_PER_CU) k_walk(xw::P p, int *cu_arrivals)
 {
     __shared__ xw::Lds S;
-    const xw::Tm tm = {(int)threadIdx.x, (int)blockDim.x};
+    __shared__ int s_simd[XW_NT / 64], s_order;
+    int tid = (int)threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if(cu_arrivals && blockDim.x == XW_NT) {
+        constexpr int REG_HW_ID = 4, REG_XCC_ID = 20; // s_getreg_b32 operands: (size - 1) << 11 | offset << 6 | register (gfx950: hip/amd_detail/amd_device_functions.h)
+        const unsigned hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | REG_HW_ID);
+        if((tid & 63) == 0) s_simd[tid >> 6] = (int)((hw >> 4) & 3u); // SIMD_ID
+        if(tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | REG_XCC_ID);
+            s_order = atomicAdd(&cu_arrivals[((xcc & 15u) << 7) | ((hw >> 8) & 127u)], 1); // CU_ID 11:8, SH_ID 12, SE_ID 14:13
+        }
+        __syncthreads();
+        const int want = s_order & 3;
+        int first = want; // (the wave on the SIMD this team's arrival order names; waves that all sit on other SIMDs: the wave of that index)
+        for(int w = XW_NT / 64 - 1; w >= 0; w--)
+            if(s_simd[w] == want) first = w;
+        tid = ((((tid >> 6) - first) & (XW_NT / 64 - 1)) << 6) | (tid & 63);
+    }
+#endif
+    const xw::Tm tm = {tid, (int)blockDim.x};
     xw::walk_team<FULL>(tm, p, S, (int)blockIdx.x);
 }
 
@@ -33,6 +58,7 @@ struct WalkDev { // device copies, rebuilt when the library is re-bound
     uint16_t *scan = nullptr;
     int32_t  *entropy = nullptr;
     unsigned long long *prof = nullptr;
+    int      *arrivals = nullptr; // teams that have arrived on every physical CU so far (k_walk: a team's serial wave by its arrival order); 2048 counters
     int16_t  *mc = nullptr; // [16][8] luma, then [32][4] chroma (the tables of the last call; compared before reuse)
     std::vector<int16_t> mc_host;
     std::vector<OpsEntry> ops;
@@ -44,7 +70,8 @@ struct WalkDev { // device copies, rebuilt when the library is re-bound
         if(entropy) (void)hipFree(entropy);
         if(mc) (void)hipFree(mc);
         if(prof) (void)hipFree(prof);
-        prof = nullptr;
+        if(arrivals) (void)hipFree(arrivals);
+        prof = nullptr, arrivals = nullptr;
         for(auto &e : ops) (void)hipFree(e.dev);
         dct = nullptr, scan = nullptr, entropy = nullptr, mc = nullptr, ops.clear(), mc_host.clear();
     }
@@ -192,14 +219,27 @@ int xh_walk_run(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve
     q.prof = prof_on ? D.prof : nullptr;
     static const int dbg = getenv("XEVE_HIP_WALK_DBG") ? atoi(getenv("XEVE_HIP_WALK_DBG")) : 0;
     q.dbg = dbg;
-    static const int deal = getenv("XEVE_HIP_WALK_DEAL") ? atoi(getenv("XEVE_HIP_WALK_DEAL")) : 0;
+    // the serial stages' lanes: packed into the team's logical wave 0 (1), which k_walk takes from a different SIMD for each of a CU's teams (spread) -- or, as round 4
+    // shipped, dealt over the team's four waves (XEVE_HIP_WALK_DEAL=0 XEVE_HIP_WALK_SPREAD=0)
+    static const int spread = getenv("XEVE_HIP_WALK_SPREAD") ? atoi(getenv("XEVE_HIP_WALK_SPREAD")) : 1;
+    static const int deal = getenv("XEVE_HIP_WALK_DEAL") ? atoi(getenv("XEVE_HIP_WALK_DEAL")) : (spread ? 1 : 0);
     q.deal = deal;
+    if(spread && !D.arrivals) {
+        int *a = nullptr;
+        if(hipMalloc((void **)&a, 2048 * sizeof(int)) != hipSuccess || hipMemset(a, 0, 2048 * sizeof(int)) != hipSuccess) {
+            (void)hipFree(a);
+            xh_set_error("xeve_hip walk: the arrival counters could not be set up");
+            return XEVE_HIP_ERR_DEVICE;
+        }
+        D.arrivals = a;
+    }
+    int *const arrivals = spread && NT == XW_NT ? D.arrivals : nullptr;
     q.cw = (xw::Cw *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const int teams = (nchains + C - 1) / C;
     q.sad_units = xh_prof_units(XH_PROF_WALK);
     XhProf timer(XH_PROF_WALK, st); // (HIP events on the walk's own stream around its one launch, when the class is switched on)
-    if(q.full) k_walk<true><<<teams, NT, 0, st>>>(q);
-    else k_walk<false><<<teams, NT, 0, st>>>(q);
+    if(q.full) k_walk<true><<<teams, NT, 0, st>>>(q, arrivals);
+    else k_walk<false><<<teams, NT, 0, st>>>(q, arrivals);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
