@@ -300,13 +300,14 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     def run_slices(lo, hi, timers=False):
         """slices [lo, hi) of every batch; the batches' host threads issue side by side (the library call releases the GIL).  timers: HIP events around the roofline
         kernel's launches on their own stream, live in the timed region -- the fused walk's one launch per step throughout; the composed walk's search kernel (hundreds of
-        launches per step) in every slice with one batch (read out after each), in the last slice only with several (a read-out would stall the other batches)"""
+        launches per step) in the last steps of every slice"""
         def one(e):
             for i in range(lo, hi):
-                if timers and cls == "search" and B > 1:
-                    # several batches: the search kernel's events are live in the LAST SAMPLE_STEPS steps of EVERY timed slice (batch 0's thread switches them on and off;
-                    # the mask is the library's, so the other batches' search launches of those moments are sampled too) -- a sample spread over every picture the timed
-                    # region covers (round 4 timed the last slice only and the per-launch figures moved 27 % between two runs); read out once, after the region
+                if timers and cls == "search":
+                    # the composed walk: the search kernel's events are live in the LAST SAMPLE_STEPS steps of EVERY timed slice (batch 0's thread switches them on and
+                    # off; the mask is the library's, so other batches' search launches of those moments are sampled too) -- a sample spread over every picture the timed
+                    # region covers (round 4 timed the last slice only and the per-launch figures moved 27 % between two runs), ~850 event pairs per slice instead of one
+                    # per launch; read out once, after the region (a read-out waits for the device)
                     k = min(SAMPLE_STEPS, sizes[i]) if e is enc else 0
                     e.advance(sizes[i] - k)
                     if k:
@@ -317,8 +318,6 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 if timers:
                     lib.prof_enable([cls])
                 e.advance(sizes[i])
-                if timers and cls == "search" and B == 1:
-                    drain()
         if B == 1:
             one(enc)
             return

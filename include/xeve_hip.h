@@ -159,7 +159,9 @@ int xeve_hip_install_tables(void *fn_itxb_slot);
 typedef struct xeve_hip_job {
     int32_t off1; /* element offset of the block's top-left sample inside plane 1 (e.g. the original): never negative, and read as an UNSIGNED 32-bit number (the stacked
                      originals of a picture batch span up to 2^32 samples) */
-    int32_t off2; /* element offset inside plane 2 (e.g. the reference picture at the search centre)    */
+    int32_t off2; /* element offset inside plane 2 (e.g. the reference picture at the search centre), below 2^30 or negative.  (A non-negative off2 with bit 30 set marks
+                     a record the library built for itself: off1 counts PAIRS of samples there -- 2^33 samples, one batch over all of a GPU's HBM -- and the low 30 bits of
+                     off2 are the offset; a caller's records never need it.) */
 } xeve_hip_job;
 
 #define XEVE_HIP_SRC1_SIGNED 1 /* plane 1 may hold negative samples (org_bi = 2*org - pred, xeve_pinter.c:143-156) */

@@ -10,22 +10,25 @@ def _cfg(w, h, threads=8):
     return encode.config(w, h, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=threads)
 
 
-def test_a_batch_ends_where_its_stacked_originals_reach_32_bits():
+def test_a_batch_ends_where_its_halved_offsets_into_the_stacked_originals_reach_32_bits():
+    """the library's own job records count PAIRS of samples (xh_common.h XH_OFF2_HALF): 2^33 samples of stacked originals per batch -- 896 pictures of 3840x2160, more
+    than a GPU's HBM holds of 8-frame GOPs, so a GPU's job is ONE batch"""
     c = _cfg(3840, 2160)
-    assert encode.footprint(c, 1, 2)[1] == 448  # (2496 rows x 3840 samples per stacked picture)
-    assert encode.footprint(_cfg(1920, 1080), 1, 2)[1] == (2 ** 32 - 1) // (1408 * 1920)
+    assert encode.footprint(c, 1, 2)[1] == 896  # (2496 rows x 3840 samples per stacked picture)
+    assert encode.footprint(_cfg(1920, 1080), 1, 2)[1] == (2 ** 33 - 1) // (1408 * 1920)
+    encode.footprint(c, 896, 2)
     with pytest.raises(Exception):
-        encode.footprint(c, 449, 2)
+        encode.footprint(c, 897, 2)
 
 
 def test_the_footprint_is_linear_in_the_gops_and_grows_with_the_frames():
     c = _cfg(3840, 2160)
-    b = [encode.footprint(c, n, 2)[0] for n in (1, 2, 3, 448)]
+    b = [encode.footprint(c, n, 2)[0] for n in (1, 2, 3, 896)]
     assert abs((b[1] - b[0]) - (b[2] - b[1])) <= 4096
     per_gop = b[1] - b[0]
     assert 200e6 < per_gop < 300e6  # two picture stores, original, input, maps, both CTU stores in the writer's form, the walk's state of 8 chains
     # (the walk's workspace is the fused kernel's up to 1024 chains in lockstep and the composed walk's above -- walk.hip -- : linear on either side of that width)
-    assert abs(b[3] - 448 * per_gop) < 0.01 * b[3]
+    assert abs(b[3] - 896 * per_gop) < 0.01 * b[3]
     w = [encode.footprint(c, n, 2)[0] for n in (200, 300, 400)]
     assert abs((w[1] - w[0]) - (w[2] - w[1])) <= 65536 and abs((w[1] - w[0]) / 100 - per_gop) < 0.01 * per_gop
     assert encode.footprint(c, 16, 8)[0] > encode.footprint(c, 16, 2)[0]  # more frames to hold, more picture stores alive
@@ -40,9 +43,9 @@ def test_a_job_is_cut_into_rounds_of_batches_that_fit():
     flat = [b for r in rounds for b in r]
     assert [f for f, _ in flat] == [sum(n for _, n in flat[:i]) for i in range(len(flat))] and sum(n for _, n in flat) == 3000  # every GOP once, in order
     for r in rounds:
-        assert len(r) <= 3 and all(1 <= n <= 448 for _, n in r)
+        assert len(r) <= 3 and all(1 <= n <= 896 for _, n in r)
         assert sum(n for _, n in r) * per_gop <= free - (8 << 30)
-    assert [n for _, n in rounds[0][:2]] == [448, 448]  # a round is filled as far as the limit and the memory go
+    assert rounds[0][0][1] == 896  # a round is filled as far as the limit and the memory go
     assert encode.plan_batches(c, 5, 2, free) == [[(0, 5)]]
     assert encode.plan_batches(c, 10, 2, free, max_batches=2, batch_gops=4) == [[(0, 4), (4, 4)], [(8, 2)]]
     with pytest.raises(Exception):

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_rdo_mfma(const pel *__restrict__ org, i
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l32 = lane & 31, kg = lane >> 5;
     const int j = blockIdx.x * 4 + wave;
     if(j >= njobs) return;
-    const xeve_hip_job jb = jobs[j];
+    const XhJob jb = xh_job(jobs[j]);
     int16_t *T = tile[wave];
     const int8_t  *M  = N == 32 ? g_dct.m32 : g_dct.m64;
     const int8_t  *MT = N == 32 ? g_dct.t32 : g_dct.t64;

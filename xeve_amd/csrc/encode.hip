@@ -246,7 +246,7 @@ struct xeve_hip_enc {
         vh = (P.h + 2 * PAD_L + 63) & ~63, s_l = P.w + 2 * PAD_L, s_c = P.w / 2 + 2 * PAD_C;
         org_l = (long)vh * P.w, org_c = (long)(vh / 2) * (P.w / 2), pic_l = (long)vh * s_l, pic_c = (long)(vh / 2) * s_c, map_pic = (long)(vh / 4) * w_scu;
         frame_bytes = P.frame_bytes(), slice_cap = (long)P.w * P.h * 3 / 2 + 4096;
-        if((double)G * org_l >= 4294967296.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^32 samples (xh_common.h)");
+        if((double)G * org_l >= 8589934592.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^33 samples (xh_common.h: halved 32-bit offsets)");
         if((long)G * T > 65535) return fail("too many GOPs for one batch: GOPs x row chains is a grid dimension (at most 65535)");
         if((double)G * vh * 32 >= 2147483648.0) return fail("too many GOPs for one batch at this picture size: the tall picture's rows in 1/16 sample units must fit 31 bits");
         rewrite_mode = T > 1 || (P_reserved0 & 1);
@@ -536,8 +536,8 @@ extern "C" int xeve_hip_enc_footprint(const xeve_hip_enc_config *cfg, int ngops,
     if(!P.finish(*cfg)) { xh_set_error("xeve_hip_enc_footprint: %s", P.error.c_str()); return XEVE_HIP_ERR_ARG; }
     const long vh = (P.h + 2 * PAD_L + 63) & ~63;
     const int  T_ = std::min(P.threads, (P.h + CTU - 1) / CTU);
-    // (the batch's limits: stacked originals below 2^32 samples, GOPs x row chains a grid dimension, the tall picture's rows in 1/16 sample units in 31 bits -- dims())
-    const int  most = (int)std::min<double>(std::min<double>(65535 / std::max(1, T_), std::floor((2147483648.0 - 1) / ((double)vh * 32))), std::floor((4294967296.0 - 1) / ((double)vh * P.w)));
+    // (the batch's limits: stacked originals below 2^33 samples, GOPs x row chains a grid dimension, the tall picture's rows in 1/16 sample units in 31 bits -- dims())
+    const int  most = (int)std::min<double>(std::min<double>(65535 / std::max(1, T_), std::floor((2147483648.0 - 1) / ((double)vh * 32))), std::floor((8589934592.0 - 1) / ((double)vh * P.w)));
     if(max_gops) *max_gops = most;
     if(!device_bytes) return XEVE_HIP_OK;
     xeve_hip_enc e; // (dimensions and sizes only: nothing of it touches the device)

@@ -131,8 +131,9 @@ __global__ void k_intra_pred(const pel *__restrict__ nb, const int *__restrict__
 }
 
 // ---- 3. jobs of the SATD and of the mode-index bit count ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int org_off_l(const xeve_hip_intra_job &J, const IntraK &P) { return (int)(uint32_t)((long)J.pic * P.org_pic_l + (long)J.y * P.s_org_l + J.x); }
-__device__ __forceinline__ int org_off_c(const xeve_hip_intra_job &J, const IntraK &P) { return (int)(uint32_t)((long)J.pic * P.org_pic_c + (long)(J.y >> P.hs) * P.s_org_c + (J.x >> P.ws)); }
+// (element offsets into the stacked originals; xh_make_job halves and marks the even ones: xh_common.h XH_OFF2_HALF)
+__device__ __forceinline__ size_t org_off_l(const xeve_hip_intra_job &J, const IntraK &P) { return (size_t)((long)J.pic * P.org_pic_l + (long)J.y * P.s_org_l + J.x); }
+__device__ __forceinline__ size_t org_off_c(const xeve_hip_intra_job &J, const IntraK &P) { return (size_t)((long)J.pic * P.org_pic_c + (long)(J.y >> P.hs) * P.s_org_c + (J.x >> P.ws)); }
 
 __global__ void k_intra_jobs1(const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const unsigned char *__restrict__ mpm_row, xeve_hip_job *__restrict__ sj,
                               xeve_hip_cu_bits_job *__restrict__ bj, int32_t *__restrict__ zero)
@@ -142,7 +143,7 @@ __global__ void k_intra_jobs1(const xeve_hip_intra_job *__restrict__ jobs, Intra
     if(t >= P.njobs * SLOTS) return;
     const int j = t / SLOTS, m = t - j * SLOTS;
     const xeve_hip_intra_job J = jobs[j];
-    sj[t].off1 = org_off_l(J, P), sj[t].off2 = t * P.n0;
+    sj[t] = xh_make_job(org_off_l(J, P), t * P.n0);
     xeve_hip_cu_bits_job b;
     b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
     b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0, b.refi[0] = b.refi[1] = -1, b.mvp_idx[0] = c_mpm[mpm_row[j]][m], b.mvp_idx[1] = 0;
@@ -181,7 +182,7 @@ __global__ void k_intra_list(const xeve_hip_intra_job *__restrict__ jobs, IntraK
     for(int k = 0; k < SLOTS; k++) {
         const int t = j * SLOTS + k;
         list[t] = lst[k];
-        sj[t].off1 = org_off_l(J, P), sj[t].off2 = (j * SLOTS + lst[k]) * P.n0;
+        sj[t] = xh_make_job(org_off_l(J, P), (j * SLOTS + lst[k]) * P.n0);
         est_idx[t] = J.sbac;
     }
 }
@@ -220,7 +221,7 @@ __global__ void k_intra_pick(const xeve_hip_intra_job *__restrict__ jobs, IntraK
     }
     const int t = j * SLOTS + bs;
     best_slot[j] = t, best_ipd[j] = list[t], dist_y[j] = (int)(double)ssd[2 * t + 1], nnz_y[j] = nnz[t];
-    cj[j].off1 = org_off_c(J, P), cj[j].off2 = j * P.n1, est_idx_c[j] = J.sbac;
+    cj[j] = xh_make_job(org_off_c(J, P), j * P.n1), est_idx_c[j] = J.sbac;
 }
 
 // winner's coefficients and reconstruction -> the output blocks

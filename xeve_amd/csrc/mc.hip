@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_mc(const pel *__restrict__ ref, int s_r
         if(OUT == 0) SegIO<SEG>::st(out, pack<SEG>(acc));
         else {
             int o[SEG];
-            unpack<SEG>(SegIO<SEG>::ld(org + xh_u(jb.pred_off) + (long)y * s_org + x0), o);
+            unpack<SEG>(SegIO<SEG>::ld(org + ((jb.frac & XH_FRAC_HALF) ? (size_t)(uint32_t)jb.pred_off << 1 : xh_u(jb.pred_off)) + (long)y * s_org + x0), o);
             unsigned long long dsum = 0;
 #pragma unroll
             for(int i = 0; i < SEG; i++) {
@@ -361,9 +361,11 @@ __global__ void k_spel_make(const xeve_hip_spel_job *__restrict__ jobs, int njob
     xeve_hip_mc_job m;
     m.gmv_x = mx << 2, m.gmv_y = my << 2; // 1/16 pel, as the reference passes (mv_x << 2), xeve_pinter.c:608
     (void)vh;
-    m.pred_off = bi ? jb.org_off : xh_org_off(jb.y, s_org, jb.x);
+    const size_t oo = (size_t)((long)jb.y * s_org + jb.x); // the block in the stacked originals: halved and marked when even (xh_common.h XH_FRAC_HALF)
+    m.pred_off = bi ? jb.org_off : (int)(uint32_t)((oo & 1) ? oo : oo >> 1);
     m.frac = ((mx & 3) != 0 ? 1 : 0) | ((my & 3) != 0 ? 2 : 0);
     if(per_plane) m.frac |= xh_plane_of_job(job_plane, per_plane, j) << 3; // the job's reference picture (PlaneTab)
+    if(!bi && !(oo & 1)) m.frac |= XH_FRAC_HALF;
     if(jb.x < 0) m.gmv_x = m.gmv_y = 0, m.pred_off = 0, m.frac = 4; // job switched off
     (void)blk_elems;
     mc[t] = m;

@@ -64,8 +64,8 @@ __global__ void k_rdo_prep(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, xe
     m.x = J.x, m.y = J.y, m.mv[0][0] = J.mv[0][0], m.mv[0][1] = J.mv[0][1], m.mv[1][0] = J.mv[1][0], m.mv[1][1] = J.mv[1][1];
     m.refi[0] = J.refi[0], m.refi[1] = J.refi[1], m.pad_[0] = m.pad_[1] = 0;
     mc[j] = m;
-    rl[j].off1 = xh_org_off(J.y, P.s_org_l, J.x), rl[j].off2 = j * P.n0;
-    rc[j].off1 = xh_org_off(J.y >> P.hs, P.s_org_c, J.x >> P.ws), rc[j].off2 = j * P.n1;
+    rl[j] = xh_make_job(J.y, P.s_org_l, J.x, j * P.n0);
+    rc[j] = xh_make_job(J.y >> P.hs, P.s_org_c, J.x >> P.ws, j * P.n1);
     est_idx[j] = J.sbac;
 }
 
@@ -532,8 +532,8 @@ __global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P,
     if(m.refi[0] < 0 && m.refi[1] < 0) ok = false; // (:1444)
     if(!ok) m.refi[0] = m.refi[1] = -1;            // no prediction work for a slot that is not evaluated
     mc[t] = m;
-    rl[t].off1 = xh_org_off(J.y, P.s_org_l, J.x), rl[t].off2 = t * P.n0;
-    rc[t].off1 = xh_org_off(J.y >> P.hs, P.s_org_c, J.x >> P.ws), rc[t].off2 = t * P.n1;
+    rl[t] = xh_make_job(J.y, P.s_org_l, J.x, t * P.n0);
+    rc[t] = xh_make_job(J.y >> P.hs, P.s_org_c, J.x >> P.ws, t * P.n1);
     xeve_hip_cu_bits_job b;
     b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
     b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0, b.refi[0] = b.refi[1] = 0;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_sad_sq(const pel *__restrict__ p1, int 
     const int widx = xh_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int job  = widx / SPLIT, part = widx % SPLIT;
     if(job >= njobs) return;
-    const xeve_hip_job jb = jobs[job];
+    const XhJob jb = xh_job(jobs[job]);
 
     const int slot = lane / G::GROUP;                  // which of the CPP candidates of a pass
     const int gl   = lane % G::GROUP;                  // lane inside the candidate group
@@ -128,7 +128,7 @@ __global__ void k_sad_any(const pel *__restrict__ p1, int s1, const pel *__restr
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(item >= njobs * ncand) return;
-    const xeve_hip_job jb = jobs[item / ncand];
+    const XhJob jb = xh_job(jobs[item / ncand]);
     const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     int acc = 0;
     for(int i = lane; i < w * h; i += 64) {
@@ -148,7 +148,7 @@ __global__ void k_dist_tiny(const pel *__restrict__ p1, int s1, const pel *__res
 {
     const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if(item >= items) return;
-    const xeve_hip_job jb = jobs[item / ncand];
+    const XhJob jb = xh_job(jobs[item / ncand]);
     const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     long acc = 0;
     for(int y = 0; y < h; y++)
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_ssd_sq(const pel *__restrict__ p1, int 
     const int lane = threadIdx.x & 63;
     const int job  = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(job >= njobs) return;
-    const xeve_hip_job jb = jobs[job];
+    const XhJob jb = xh_job(jobs[job]);
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
     u32x4 org[G::NP];
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ void k_ssd_any(const pel *__restrict__ p1, int s1, const pel *__restr
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(item >= njobs * ncand) return;
-    const xeve_hip_job jb = jobs[item / ncand];
+    const XhJob jb = xh_job(jobs[item / ncand]);
     const pel *a = p1 + xh_u(jb.off1), *b = p2 + jb.off2 + cand_off[item % ncand];
     uint64_t acc = 0;
     for(int i = lane; i < w * h; i += 64) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_satd_sq(const pel *__restrict__ p1, int
     const int lane = threadIdx.x & 63;
     const int job  = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if(job >= njobs) return;
-    const xeve_hip_job jb = jobs[job];
+    const XhJob jb = xh_job(jobs[job]);
     const int slot = lane / G::GROUP, gl = lane % G::GROUP, row0 = gl / G::LPR, col = (gl % G::LPR) * 8;
     u32x4 org[G::NP];
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ void k_satd_tiles(const pel *__restrict__ p1, int s1, const pel *__re
     const long t      = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= (long)njobs * ncand * tiles) return;
     const int item = (int)(t / tiles), tile = (int)(t % tiles);
-    const xeve_hip_job jb = jobs[item / ncand];
+    const XhJob jb = xh_job(jobs[item / ncand]);
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const pel *a = p1 + xh_u(jb.off1) + ty * th * s1 + tx * tw;
     const pel *b = p2 + jb.off2 + cand_off[item % ncand] + ty * th * s2 + tx * tw;
@@ -372,7 +372,7 @@ __global__ void k_diff(const pel *__restrict__ p1, int s1, const pel *__restrict
     const long t    = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= (long)njobs * per) return;
     const int j = (int)(t / per), r = (int)(t % per), y = r / segs, x0 = (r % segs) * 8;
-    const xeve_hip_job jb = jobs[j];
+    const XhJob jb = xh_job(jobs[j]);
     const pel *a = p1 + xh_u(jb.off1) + y * s1 + x0, *b = p2 + jb.off2 + y * s2 + x0;
     int16_t   *d = diff + (size_t)j * w * h + y * w + x0;
     if(w - x0 >= 8) {

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_rdo_valu(const pel *__restrict__ org, i
     int32_t *mh = mw + w * w;
     for(int i = threadIdx.x; i < w * w; i += blockDim.x) mw[i] = c_tm[xh_tm_off(log2w) + i];
     for(int i = threadIdx.x; i < h * h; i += blockDim.x) mh[i] = c_tm[xh_tm_off(log2h) + i];
-    const xeve_hip_job jb = live ? jobs[j] : xeve_hip_job{0, 0};
+    const XhJob jb = live ? xh_job(jobs[j]) : XhJob{0, 0};
     if(t == 0) acc64[0] = acc64[1] = 0, acc32[0] = acc32[1] = 0;
     __syncthreads();
     // 1. residual + SSD(org, pred)
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_rdo_rows(const pel *__restrict__ org, i
     int *T = tile[wave] + bl * N * PITCH;
     const int  j    = (xh_xcd_block(blockIdx.x, gridDim.x) * 4 + wave) * BPW + bl;
     const bool live = j < njobs;
-    const xeve_hip_job jb = live ? jobs[j] : xeve_hip_job{0, 0};
+    const XhJob jb = live ? xh_job(jobs[j]) : XhJob{0, 0};
     // 1. my row of the original and of the prediction; residual; SSD(org, pred)
     int o[N], p[N], v[N];
     unsigned long long ssd_p = 0, ssd_r = 0;

@@ -257,7 +257,7 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
             memset(&ej, 0, sizeof(ej));
             ej.x = jx, ej.y = jy + J.pic * K.vh, ej.sbac = c; // ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288)
             K.ejobs[c] = ej;
-            K.sjobs[c].off1 = xh_org_off(jy + J.pic * K.vh, K.s_org_l, jx), K.sjobs[c].off2 = c * cu * cu;
+            K.sjobs[c] = xh_make_job((long)jy + (long)J.pic * K.vh, K.s_org_l, jx, c * cu * cu);
             nd->try_intra = 0, nd->cu_mode = 0, nd->unit_cost = MAX_COST;
         }
         sh[0] = active, sh[1] = leaf, sh[2] = boundary, sh[3] = x0, sh[4] = y0;

@@ -116,10 +116,36 @@ struct XhCountStatesScope {
     ~XhCountStatesScope();
 };
 __host__ __device__ __forceinline__ int xh_vh_base(int y, int vh) { return vh > 0 ? (y / vh) * vh : 0; }
-// Offsets into the ORIGINAL (xeve_hip_job.off1, the fused comparison's pred_off) are 32-bit element counts read as UNSIGNED: the stacked originals of a batch may span up
-// to 2^32 samples (448 pictures of 3840x2160).  Producers compute in 64 bits and keep the low 32 (xh_org_off), consumers widen without sign (xh_u).
+// Offsets into the ORIGINAL (xeve_hip_job.off1, the fused comparison's pred_off) are 32-bit element counts read as UNSIGNED: 2^32 samples = 448 stacked pictures of
+// 3840x2160.  The job lists the library builds ITSELF go further: every offset it produces is EVEN (CUs start on multiples of 4 luma / 2 chroma samples, strides and
+// picture distances are multiples of 4), so it travels HALVED -- 2^33 samples, 896 pictures of 3840x2160, all a GPU's HBM holds in ONE batch -- and says so in the record:
+// bit 30 of off2 (XH_OFF2_HALF; the dense second operand's offsets stay far below it) resp. bit 8 of an interpolation job's frac (XH_FRAC_HALF).  A caller's own records
+// (any offset, odd ones too) carry no mark and mean what include/xeve_hip.h says.  Consumers decode a record once (xh_job) and use the decoded fields.
+#define XH_OFF2_HALF 0x40000000
+#define XH_FRAC_HALF 0x100
+struct XhJob {
+    size_t off1; // element offset into plane 1 (the original)
+    int    off2; // element offset into plane 2
+};
+__host__ __device__ __forceinline__ XhJob xh_job(const xeve_hip_job &j)
+{
+    const bool half = ((uint32_t)j.off2 & 0xC0000000u) == (uint32_t)XH_OFF2_HALF; // (a negative off2 of a caller's record has bit 31 set: never taken for the mark)
+    XhJob r;
+    r.off1 = half ? (size_t)(uint32_t)j.off1 << 1 : (size_t)(uint32_t)j.off1, r.off2 = half ? (int)((uint32_t)j.off2 & 0x3FFFFFFFu) : j.off2;
+    return r;
+}
+__host__ __device__ __forceinline__ size_t xh_u(size_t off) { return off; } // (a decoded record's offset)
 __host__ __device__ __forceinline__ size_t xh_u(int off) { return (size_t)(uint32_t)off; }
-__host__ __device__ __forceinline__ int    xh_org_off(long y, long stride, long x) { return (int)(uint32_t)(y * stride + x); }
+// a job record of the library's own making for the block at element offset o of plane 1: halved and marked when o is even (always, for the encoder's pictures); an odd
+// offset (a C-ABI caller's CU at an odd position or with an odd stride) stays as it is, below 2^32
+__host__ __device__ __forceinline__ xeve_hip_job xh_make_job(size_t o, int off2)
+{
+    xeve_hip_job j;
+    if(o & 1) j.off1 = (int)(uint32_t)o, j.off2 = off2;
+    else j.off1 = (int)(uint32_t)(o >> 1), j.off2 = off2 | XH_OFF2_HALF;
+    return j;
+}
+__host__ __device__ __forceinline__ xeve_hip_job xh_make_job(long y, long stride, long x, int off2) { return xh_make_job((size_t)(y * stride + x), off2); }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
