@@ -379,15 +379,34 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                         "which the chip's VALUs can issue v_sad_u16 (8 algorithmic bytes per lane and instruction)"),
                 "launches_in_region": k_n, "avg_launch_ms": round(k_ms / max(1, k_n), 4), "algorithmic_bytes_per_launch": int(alg / max(1, k_n)),
                 "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 6), "traffic": None}
-        try:  # physical HBM bytes per launch of the same kernel from the committed PMC passes (separate runs, profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")))
+        # from the committed PMC passes (rocprofv3 --pmc in runs of their own, profiles/: the newest round's file that exists): physical HBM bytes per launch of the same
+        # kernel (`traffic`), what its wave cycles were spent on, and the matrix-core kernels' utilisation
+        def committed(*names):
+            for nm in names:
+                try:
+                    return json.load(open(os.path.join(ROOT, "profiles", nm))), nm
+                except Exception:
+                    continue
+            return None, None
+        pmc, src = committed(*(("r05_walk_pmc.json", "r04_walk_pmc.json") if cls == "walk" else ("r05_search_pmc.json", "r04_search_pmc.json")))
+        if pmc:
             roof["traffic"] = pmc.get("hbm_bytes_per_launch") or pmc.get("hbm_bytes_per_launch_x2")
             roof["traffic_is"] = pmc.get("what")
-            for k in ("valu_insts_per_launch", "valu_issue_frac", "wait_any_frac", "waves_per_launch", "avg_launch_s"):
+            roof["pmc_file"] = "profiles/" + src
+            for k in ("valu_insts_per_launch", "valu_issue_frac", "wait_any_frac", "active_lane_frac", "waves_per_launch", "avg_launch_s"):
                 if k in pmc:
                     roof[k] = pmc[k]
-        except Exception:
-            pass
+            if roof["traffic"] is None:  # (a pass without FETCH_SIZE: the traffic figure of the last pass that took it)
+                old, osrc = committed("r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")
+                if old:
+                    roof["traffic"], roof["traffic_is"] = old.get("hbm_bytes_per_launch") or old.get("hbm_bytes_per_launch_x2"), old.get("what")
+        mf, msrc = committed("r05_mfma_pmc.json")
+        if mf:
+            roof["mfma"] = {"kernels": "k_rdo_mfma<32|64>, k_dct_mfma<32|64> (v_mfma_i32_32x32x32_i8, exact byte-limb split: the residual chain of the 32x32 / 64x64 luma blocks)",
+                            "bound": "mfma", "achieved": mf.get("achieved_TOPS"), "peak": mf.get("peak_TOPS_i8_dense"), "unit": "TOP/s", "frac": mf.get("mfma_utilisation"),
+                            "mfma_busy_over_all_simd_cycles": mf.get("mfma_busy_over_all_simd_cycles"), "avg_launch_s": mf.get("avg_launch_s"),
+                            "mfma_i8_insts_per_launch": mf.get("mfma_i8_insts_per_launch"), "pmc_file": "profiles/" + msrc, "what": mf.get("what"),
+                            "note": "a 32x32 / 64x64 transform is the only dense matrix product on the path; those blocks are < 1 % of a step's kernel time"}
         rec = {"value": round(world * frames_timed / dt, 4), "ms_per_step": round(1e3 * dt / a.steps, 3),
                "config": {
                    "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
@@ -473,7 +492,14 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
     bins_s = cb[2] / (cb[0] * 1e-3) if cb[0] > 0 else 0.0
     kern["cu_bits"].update({"bins_per_step": int(cb[2] / steps), "Gbin_per_s": round(bins_s / 1e9, 3)})
     tot = sum(v[0] for c, v in allc.items() if c not in ("cu_bits_slow", "walk"))
-    return {"kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None,
+    lanes = {}
+    try:  # (the PMC pass over the same kernel at the bench's width: how many of a wave's lanes its VALU work keeps busy, what its cycles wait for)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r05_cu_bits_pmc.json")))
+        lanes = {k: pm[k] for k in ("active_lane_frac", "active_lane_frac_note", "wait_any_frac", "valu_issue_frac", "waves_per_launch") if k in pm}
+        lanes["pmc_file"] = "profiles/r05_cu_bits_pmc.json"
+    except Exception:
+        pass
+    return {"kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None, **lanes,
             "bound": "valu-issue", "achieved": round(bins_s * INSTR_PER_BIN / 64 / 1e9, 3), "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
             "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
             "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
