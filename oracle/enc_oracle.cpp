@@ -4,7 +4,6 @@
 // CPU engine that keeps the pictures in host memory and lets the oracle (xeve_oracle.c, pinned to the reference) decide and write every CTU.  What comes out is held
 // against bitstreams of the unmodified reference application (tests/test_enc_host.py): that pins the host side of the batch encoder without a GPU.  The product never
 // links this file; libxeve_hip.so instantiates the same template with its HIP engine (xeve_amd/csrc/encode.cpp).
-#define XENC_HOST_PINNED_OPTIONS 1 // (enc_plan.h: options the reference application cannot set, pinned through oracle/ref_param_pin.c; the product build refuses them)
 #include <pthread.h>
 #include <cstdlib>
 #include <memory>

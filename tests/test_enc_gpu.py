@@ -98,6 +98,24 @@ def test_header_only_options_on_the_gpu(name, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("walk", [0, 1], ids=["composed", "fused"])
+@pytest.mark.parametrize("name", sorted(_enc.HOST_PINNED_CASES))
+def test_p_slices_and_chroma_qp_offsets_on_the_gpu(name, walk, hip, yuv_dir):
+    """--inter-slice-type 1 (P pictures: low delay with one and three reference pictures, the hierarchical closed GOP) and --qp-cb-offset / --qp-cr-offset (chroma QPs,
+    lambdas and distortion weights of their own; the offsets in the slice header): options the reference APPLICATION cannot parse, so the goldens come from the reference
+    LIBRARY with the parameters set on the way into xeve_create (oracle/ref_param_pin.c).  Both walks."""
+    w, h, gops, frames, seed, cli, threads = _enc.HOST_PINNED_CASES[name]
+    g = _enc.golden()["batches"][name]
+    c = _enc.config(w, h, cli, threads)
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    cfg = hip.config(w, h, qp=c.qp, keyint=c.keyint, bframes=c.bframes, closed_gop=c.closed_gop, preset=c.preset, threads=c.threads, ref=c.ref,
+                     inter_slice_type=c.inter_slice_type, qp_cb_offset=c.reserved[2], qp_cr_offset=c.reserved[3])
+    assert cfg.inter_slice_type or cfg.reserved[2] or cfg.reserved[3]
+    with hip.walk_select(walk):
+        outs, _ = _run(hip, cfg, [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_one_chain_through_the_second_writer_pass_on_the_gpu(hip, yuv_dir):
     w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]
     f = _frames(yuv_dir, "tiny_closed_gop", w, h, n, seed)

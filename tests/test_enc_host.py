@@ -76,7 +76,7 @@ def test_ten_bit_input_is_handed_to_the_codec_as_it_is(name, yuv_dir):
 @pytest.mark.parametrize("name", sorted(_enc.HOST_PINNED_CASES))
 def test_p_slices_and_chroma_qp_offsets_on_the_host_side(name, yuv_dir):
     """options the reference application cannot parse, set on the way into the reference LIBRARY (oracle/ref_param_pin.c): the frame loop, the reference lists of P
-    pictures, the chroma QPs / lambdas / slice header offsets reproduce its bitstreams.  Host side only -- the product build refuses them (next test)"""
+    pictures, the chroma QPs / lambdas / slice header offsets reproduce its bitstreams (the device: tests/test_enc_gpu.py)"""
     w, h, gops, frames, seed, cli, threads = _enc.HOST_PINNED_CASES[name]
     g = _enc.golden()["batches"][name]
     data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
@@ -97,16 +97,15 @@ def test_header_only_options(name, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
-def test_the_product_library_refuses_what_only_the_host_side_has_seen():
-    """xeve_hip_enc_footprint runs the product's own configuration check (no device needed)"""
+def test_the_product_library_takes_p_slices_and_chroma_qp_offsets_inside_their_ranges():
+    """xeve_hip_enc_footprint runs the product's own configuration check (no device needed): since round 5 the options are coded on the device too (tests/test_enc_gpu.py)"""
     from xeve_amd import encode, lib
 
-    for kw in (dict(inter_slice_type=1), dict(cb=3), dict(cr=-2)):
-        c = encode.config(128, 64, keyint=8, closed_gop=True)
-        c.inter_slice_type = kw.get("inter_slice_type", 0)
-        c.reserved[2], c.reserved[3] = kw.get("cb", 0), kw.get("cr", 0)
-        with pytest.raises(lib.XeveHipError, match="host side only"):
-            encode.footprint(c, 1, 2)
+    for kw in (dict(inter_slice_type=1), dict(qp_cb_offset=3), dict(qp_cr_offset=-2), dict(inter_slice_type=1, qp_cb_offset=-12, qp_cr_offset=12)):
+        assert encode.footprint(encode.config(128, 64, keyint=8, closed_gop=True, **kw), 1, 2)[0] > 0
+    for kw in (dict(inter_slice_type=2), dict(qp_cb_offset=13), dict(qp_cr_offset=-13)):
+        with pytest.raises(lib.XeveHipError):
+            encode.footprint(encode.config(128, 64, keyint=8, closed_gop=True, **kw), 1, 2)
 
 
 WORKER = r"""

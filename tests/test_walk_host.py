@@ -194,3 +194,14 @@ def test_walk_decides_every_ctu_of_the_closed_gop_batches(name, walk_engine, tmp
     data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
     outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+@pytest.mark.parametrize("name", sorted(_enc.HOST_PINNED_CASES))
+def test_walk_decides_every_ctu_with_p_slices_and_chroma_qp_offsets(name, walk_engine, tmp_path_factory):
+    """--inter-slice-type 1 and --qp-cb-offset / --qp-cr-offset (goldens from the reference LIBRARY, oracle/ref_param_pin.c): P pictures through the fused walk's
+    one-list inter analysis, chroma QPs / lambdas / weights of their own -- what the product accepts since round 5"""
+    w, h, gops, frames, seed, cli, threads = _enc.HOST_PINNED_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]

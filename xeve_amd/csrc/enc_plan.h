@@ -54,15 +54,11 @@ struct Param {
         // above at all, and the reference's own output changes from run to run -- 5 different bitstreams in 12 runs of 64x200 -m 3 -- so there is nothing to reproduce)
         if(threads > 1 && w <= CTU) return bad("a picture one CTU wide must be coded with threads = 1: the reference's row threads race there");
         // P slices (--inter-slice-type 1) and chroma qp offsets (--qp-cb-offset / --qp-cr-offset): options the reference application lists and fails to parse.  The
-        // host logic for both follows the reference's sources and IS held to the reference LIBRARY run with those parameters (oracle/ref_param_pin.c sets them on the
-        // way into xeve_create; tests/test_enc_host.py, on the CPU harness, which defines XENC_HOST_PINNED_OPTIONS) -- the device path has not been run with them yet, so
-        // the product keeps refusing them until a GPU test has
+        // host logic for both follows the reference's sources and is held to the reference LIBRARY run with those parameters (oracle/ref_param_pin.c sets them on the
+        // way into xeve_create): tests/test_enc_host.py on the CPU harness, tests/test_walk_host.py with every CTU decided by the fused walk's host side, and -- since
+        // round 5 -- tests/test_enc_gpu.py on the device with both walks.
         if(inter_slice_type != 0 && inter_slice_type != 1) return bad("inter_slice_type must be 0 (B) or 1 (P)");
         if(qp_cb_offset < -12 || qp_cb_offset > 12 || qp_cr_offset < -12 || qp_cr_offset > 12) return bad("chroma qp offsets must lie in -12 .. 12");
-#ifndef XENC_HOST_PINNED_OPTIONS
-        if(inter_slice_type != 0) return bad("inter_slice_type must be 0 (B): P slices are pinned on the host side only, the device path has not coded them yet");
-        if(qp_cb_offset != 0 || qp_cr_offset != 0) return bad("chroma qp offsets must be 0: pinned on the host side only, the device path has not coded with them yet");
-#endif
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
         else return bad("preset must be 0 (fast) or 1 (medium): slow / placebo need rdo_dbk_switch, which the device path does not have");

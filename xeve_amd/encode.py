@@ -8,11 +8,14 @@ from . import lib as _lib
 PRESETS = {"fast": 0, "medium": 1}
 
 
-def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False, input_depth=8, level_idc=40, sei_info=True):
-    """the options of the reference application (xeve_app: -w -h -q -I -b --closed-gop --preset -m -z --ref -d) as the library's configuration record"""
+def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False, input_depth=8, level_idc=40, sei_info=True,
+           inter_slice_type=0, qp_cb_offset=0, qp_cr_offset=0):
+    """the options of the reference application (xeve_app: -w -h -q -I -b --closed-gop --preset -m -z --ref -d; --inter-slice-type 0 B / 1 P, --qp-cb-offset,
+    --qp-cr-offset as the reference LIBRARY takes them) as the library's configuration record"""
     c = _lib.EncConfig()
     c.w, c.h, c.fps_num, c.fps_den, c.qp, c.keyint, c.bframes, c.closed_gop = w, h, fps[0], fps[1], qp, keyint, bframes, int(bool(closed_gop))
-    c.preset, c.threads, c.inter_slice_type, c.ref = PRESETS[preset] if isinstance(preset, str) else int(preset), threads, 0, ref
+    c.preset, c.threads, c.inter_slice_type, c.ref = PRESETS[preset] if isinstance(preset, str) else int(preset), threads, int(inter_slice_type), ref
+    c.reserved[2], c.reserved[3] = int(qp_cb_offset), int(qp_cr_offset)
     c.reserved[0] = (1 if always_second_pass else 0) | (0 if sei_info else 2) | ((int(level_idc) & 0xFF) << 8)  # (--info 0, --level-idc)
     c.reserved[1] = int(input_depth)
     return c
