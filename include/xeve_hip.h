@@ -755,7 +755,8 @@ typedef struct xeve_hip_tree_params {
     int32_t max_cu, min_cu;     /* ctx->param.max_cu_intra, min_cu_intra (samples) */
     int32_t min_cuwh;           /* ctx->min_cuwh */
     int32_t slice_qp, slice_num;/* ctx->tile[].qp (the QP field of map_scu), ctx->slice_num */
-    int32_t pad_;
+    int32_t rdo_dbk;            /* ctx->param.rdo_dbk_switch (preset slow): every candidate's distortion includes what the loop filter will do to its left / top
+                                   boundary (calc_delta_dist_filter_boundary, xeve_mode.c:1534-2005).  Fused walk only: the composed walk refuses 1 */
 } xeve_hip_tree_params;
 typedef struct xeve_hip_ctu_job {
     int32_t x, y;   /* core->x_pel, core->y_pel */

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <memory>
 #include <thread>
+#define XENC_TEST_OVERRIDES 1 // (enc_plan.h: XO_PIN_* take a preset apart)
 #include "../xeve_amd/csrc/enc_host.h"
 #include "../xeve_amd/csrc/walk_setup.h" // the fused CTU walk's host side (XO_ENC_WALK=1: every CTU decided by it instead of the oracle -- pins walk.h end to end)
 extern "C" {
@@ -179,9 +180,18 @@ struct CpuEngine {
                 xo_sbac   next;
                 xo_ctu_data &out = q.ctus[c[i].lcu];
                 if(use_walk()) memcpy(&out, &wout[i], sizeof(out));
-                else
+                else {
+                    if(S.tp.rdo_dbk) { // rdo_dbk_switch: the candidates' distortions include the loop filter's share, read off the reconstruction so far and the unit maps
+                        xo_dbk_ctx D;
+                        memset(&D, 0, sizeof(D));
+                        D.mod[0] = mod[0], D.mod[1] = mod[1], D.mod[2] = mod[2], D.s_mod_l = s_l, D.s_mod_c = s_c, D.qp = S.tp.slice_qp;
+                        D.map_scu = q.scu.data(), D.map_refi = cur.refi.data(), D.map_mv = cur.mv.data(), D.map_tidx = q.tidx.data(), D.dp = (const xo_deblock_params *)&S.dp;
+                        xo_rdo_dbk_begin(&D);
+                    }
                     (void)xo_mode_analyze_ctu(org, P.w, P.w / 2, mod, s_l, s_c, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), &q.chain[c[i].t],
                                               (const xo_tree_params *)&S.tp, inter ? &TI : nullptr, x0, y0, &out, &next);
+                    if(S.tp.rdo_dbk) xo_rdo_dbk_end();
+                }
                 for(int j = 0; j < std::min((int)CTU, P.h - y0) >> 2; j++) // mode_analyze_lcu's tail: the CTU's coded flags reset (xeve_mode.c:2591-2607)
                     for(int k = 0; k < std::min((int)CTU, P.w - x0) >> 2; k++) q.scu[(size_t)((y0 >> 2) + j) * w_scu + (x0 >> 2) + k] &= 0x7FFFFFFFu;
                 const int nb = xo_eco_ctu(&q.chain[c[i].t], &out, (const xo_tree_params *)&S.tp, num_refp, q.scu.data(), q.ipm.data(), q.tidx.data(), q.cum.data(), x0, y0,

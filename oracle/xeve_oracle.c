@@ -15,6 +15,7 @@
 #include "xeve_oracle.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1397,6 +1398,79 @@ void xo_deblock_picture_tiles(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c,
     }
 }
 
+/* ===================================================================================================================
+ * calc_delta_dist_filter_boundary (src_base/xeve_mode.c:1534-2005): rdo_dbk_switch = 1 (preset slow).  What the loop filter will do to a candidate's
+ * reconstruction enters its distortion: the candidate block `src` is laid into a scratch picture with the 4 rows above and the 4 columns to its left of the
+ * reconstruction so far (PIC_MODE, not yet filtered), its TOP edge is filtered, then its LEFT edge (xeve_deblock_unit(.., is_hor_edge 1) first, :1852, then 0,
+ * :1864 -- the reverse of the picture's own order), and delta = SSD after - SSD before over the block, 2 rows above it and 2 columns to its left (chroma: 1).
+ * The current side of an edge takes the candidate's flags (intra, luma cbf, motion), the far side what the unit maps hold: flags and motion of decided CUs,
+ * the luma cbf flag only of CTUs the WRITER has been through (xeve_eco_unit sets it, xeve_eco.c:1591; copy_to_cu_data never does).  The scratch picture's own
+ * chroma qp offsets are zero (a zeroed XEVE_PIC nobody sets them on, xeve_enc.c:1201-1203).  One tile; the right neighbour is never coded before the CU
+ * (avail_lr is LR_00 or LR_10).  The reference leaves its maps altered (the CU's motion and QP fields; flags restored from the top-left unit): nothing reads
+ * them before the CU's decision rewrites them, so this restatement has no side effect.
+ * =================================================================================================================== */
+static __thread xo_dbk_ctx g_dbk; /* set around a CTU's analysis (xo_rdo_dbk_begin / _end); on == 0: rdo_dbk_switch 0 */
+void xo_rdo_dbk_begin(const xo_dbk_ctx *c) { g_dbk = *c, g_dbk.on = 1; }
+void xo_rdo_dbk_end(void) { g_dbk.on = 0; }
+int  xo_rdo_dbk_on(void) { return g_dbk.on; }
+
+void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_pel *const src[3], int x, int y, int cuw, int cuh,
+                   int intra_flag, int cbf_l, const int8_t refi[2], const int16_t mv[2][2], int64_t delta[3])
+{
+    const xo_deblock_params *p = D->dp;
+    const int idc = p->chroma_format_idc, ws = idc <= 2, hs = idc <= 1, w_scu = p->w_scu, t = (x >> 2) + (y >> 2) * w_scu;
+    const int top = y > 0 && (!D->map_tidx || D->map_tidx[t] == D->map_tidx[t - w_scu]);
+    const int left = x > 0 && SCU_COD(D->map_scu[t - 1]) && (!D->map_tidx || D->map_tidx[t] == D->map_tidx[t - 1]);
+    const int bl = p->bit_depth_luma - 8, bc = p->bit_depth_chroma - 8, qp = D->qp;
+    /* the current side of every edge: the candidate's flags and motion (xeve_mode.c:1800-1843) */
+    const uint32_t m_cur = ((uint32_t)(intra_flag != 0) << 15) | ((uint32_t)qp << 16) | ((uint32_t)(cbf_l != 0) << 24);
+    int8_t  r_cur[2] = {-1, -1};
+    int16_t v_cur[4] = {0, 0, 0, 0};
+    if(refi) r_cur[0] = refi[0], r_cur[1] = refi[1], v_cur[0] = mv[0][0], v_cur[1] = mv[0][1], v_cur[2] = mv[1][0], v_cur[3] = mv[1][1];
+    delta[0] = delta[1] = delta[2] = 0;
+    for(int c = 0; c < (idc ? 3 : 1); c++) {
+        const int sx = c ? ws : 0, sy = c ? hs : 0, w = cuw >> sx, h = cuh >> sy, xo_ = 4 >> sx, yo = 4 >> sy, xt = 2 >> sx, yt = 2 >> sy, bd = c ? p->bit_depth_chroma : p->bit_depth_luma;
+        const int S = w + xo_, so = c ? s_org_c : s_org_l, sm = c ? D->s_mod_c : D->s_mod_l, xc = x >> sx, yc = y >> sy, maxv = (1 << bd) - 1;
+        if(!src[c]) continue; /* (the luma-only call of the intra analysis: the reference copies stale chroma there and never reads the result) */
+        xo_pel *buf = calloc((size_t)S * (h + yo), sizeof(xo_pel)), *dst = buf + (size_t)yo * S + xo_;
+        const xo_pel *o = org[c] + (size_t)yc * so + xc, *rec = D->mod[c] + (size_t)yc * sm + xc;
+        for(int i = 0; i < h; i++) memcpy(dst + (size_t)i * S, src[c] + (size_t)i * w, sizeof(xo_pel) * (size_t)w);
+        if(top)
+            for(int i = 0; i < yo; i++) memcpy(dst + (ptrdiff_t)(i - yo) * S, rec + (ptrdiff_t)(i - yo) * sm, sizeof(xo_pel) * (size_t)w);
+        if(left)
+            for(int i = 0; i < h; i++) memcpy(dst + (size_t)i * S - xo_, rec + (size_t)i * sm - xo_, sizeof(xo_pel) * (size_t)xo_);
+        int64_t before = xo_ssd(w, h, dst, o, S, so, bd);
+        if(top) before += xo_ssd(w, yt, dst - (ptrdiff_t)yt * S, o - (ptrdiff_t)yt * so, S, so, bd);
+        if(left) before += xo_ssd(xt, h, dst - xt, o - xt, S, so, bd);
+        /* the top edge, then the left edge: 4-sample segments (chroma: 4 >> shift), the strength from the two units across the segment */
+        if(top)
+            for(int i = 0; i < cuw >> 2; i++) {
+                const int nb = t + i - w_scu;
+                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, D->map_mv + 4 * nb);
+                if(c == 0) df_edge(dst + 4 * i, 4, 1, S, xo_df_st[cls][qp] << bl, maxv, 0);
+                else {
+                    const int q = clip3i(-6 * bc, 57, qp);
+                    df_edge(dst + ((4 * i) >> ws), 4 >> ws, 1, S, xo_df_st[cls][p->qp_chroma[c - 1][q + 6 * bc]] << bc, maxv, 1);
+                }
+            }
+        if(left)
+            for(int i = 0; i < cuh >> 2; i++) {
+                const int nb = t + i * w_scu - 1;
+                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, D->map_mv + 4 * nb);
+                if(c == 0) df_edge(dst + (size_t)(4 * i) * S, 4, S, 1, xo_df_st[cls][qp] << bl, maxv, 0);
+                else {
+                    const int q = clip3i(-6 * bc, 57, qp);
+                    df_edge(dst + (size_t)((4 * i) >> hs) * S, 4 >> hs, S, 1, xo_df_st[cls][p->qp_chroma[c - 1][q + 6 * bc]] << bc, maxv, 1);
+                }
+            }
+        int64_t after = xo_ssd(w, h, dst, o, S, so, bd);
+        if(top) after += xo_ssd(w, yt, dst - (ptrdiff_t)yt * S, o - (ptrdiff_t)yt * so, S, so, bd);
+        if(left) after += xo_ssd(xt, h, dst - xt, o - xt, S, so, bd);
+        delta[c] = after - before;
+        free(buf);
+    }
+}
+
 void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp)
 {   /* xeve_util.c:190-238 */
     for(int i = 0; i < h; i++)
@@ -1521,11 +1595,24 @@ void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const 
     int    cbf_idx[3] = {0, 0, 0}, nnz[3];
 #define FULL_BITS(N0, N1, N2) (bj.mode = XO_BITS_CU_INTER, bj.sbac = 0, bj.nnz[0] = (N0), bj.nnz[1] = (N1), bj.nnz[2] = (N2), xo_cu_bits(entry, &run, &bp, &bj, all))
 #define SUM_COST(IY, IU, IV) ((double)dist[IY][0] + (((double)dist[IU][1] * p->dist_chroma_weight[0]) + ((double)dist[IV][2] * p->dist_chroma_weight[1])))
+    /* rdo_dbk_switch (:1016-1095, 1290-1312): what the loop filter will do to the CU's left / top boundary, for the prediction alone (no luma cbf) and for the
+     * reconstruction (luma cbf as quantised) */
+    const int64_t dist_no_resi[3] = {dist[0][0], dist[0][1], dist[0][2]};
+    const int     dbk = xo_rdo_dbk_on();
+    if(dbk) {
+        int64_t d[3];
+        const xo_pel *const src[3] = {pred[0], idc ? pred[1] : NULL, idc ? pred[2] : NULL};
+        xo_delta_dist(&g_dbk, org, s_org_l, s_org_c, src, job->x, job->y, 1 << lw[0], 1 << lh[0], 0, 0, job->refi, job->mv, d);
+        for(int c = 0; c < ncomp; c++) dist[0][c] += d[c];
+    }
     if(tnnz) {
         /* reconstruct what was quantised (:1000-1051): dist[1] */
+        xo_pel *recs[3] = {NULL, NULL, NULL};
+        for(int c = 0; c < ncomp && dbk; c++) recs[c] = malloc(sizeof(xo_pel) << (lw[c] + lh[c]));
         for(int c = 0; c < ncomp; c++) {
             if(!nnz_store[c]) {
-                dist[1][c] = dist[0][c];
+                dist[1][c] = dist_no_resi[c];
+                if(dbk) memcpy(recs[c], pred[c], sizeof(xo_pel) << (lw[c] + lh[c])); /* "complete rec" (:1061-1076) */
                 continue;
             }
             const int w = 1 << lw[c], h = 1 << lh[c], so = c ? s_org_c : s_org_l;
@@ -1535,8 +1622,15 @@ void xo_residue_rdo(const xo_pel *const org[3], int s_org_l, int s_org_c, const 
             xo_itrans(tmp, lw[c], lh[c], bd);
             xo_recon(tmp, pred[c], nnz_store[c], w, h, w, rec, bd);
             dist[1][c] = xo_ssd(w, h, rec, o, w, so, bd);
+            if(dbk) memcpy(recs[c], rec, sizeof(xo_pel) << (lw[c] + lh[c]));
         }
         for(int c = ncomp; c < 3; c++) dist[1][c] = 0;
+        if(dbk) {
+            int64_t d[3];
+            const xo_pel *const src[3] = {recs[0], recs[1], recs[2]};
+            xo_delta_dist(&g_dbk, org, s_org_l, s_org_c, src, job->x, job->y, 1 << lw[0], 1 << lh[0], 0, nnz_store[0] != 0, job->refi, job->mv, d);
+            for(int c = 0; c < ncomp; c++) dist[1][c] += d[c], free(recs[c]);
+        }
         if(!job->dir_flag) { /* all-zero alternative (:1103-1142) */
             cost = SUM_COST(0, 0, 0);
             cost += (double)(int)FULL_BITS(0, 0, 0) * p->lambda[0];
@@ -1631,6 +1725,14 @@ void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const
                 const int off = (job->y >> hs) * s_org_c + (job->x >> ws);
                 cu = xo_ssd(cw, ch, t[1], org[1] + off, cw, s_org_c, bd), cv = xo_ssd(cw, ch, t[2], org[2] + off, cw, s_org_c, bd);
             }
+            const int64_t temp_ssd = cy + cu + cv; /* (pi->best_ssd: without the loop filter's share, :1461) */
+            if(xo_rdo_dbk_on()) { /* (:1463-1485) */
+                int64_t d[3];
+                const xo_pel *const src[3] = {t[0], idc ? t[1] : NULL, idc ? t[2] : NULL};
+                xo_delta_dist(&g_dbk, org, s_org_l, s_org_c, src, job->x, job->y, w, h, 0, 0, mj.refi, mj.mv, d);
+                cy += d[0];
+                if(idc) cu += d[1], cv += d[2];
+            }
             double cost = (double)cy + (p->dist_chroma_weight[0] * (double)cu) + (p->dist_chroma_weight[1] * (double)cv);
             xo_cu_bits_job bj;
             memset(&bj, 0, sizeof(bj));
@@ -1639,7 +1741,7 @@ void xo_analyze_skip(const xo_pel *const org[3], int s_org_l, int s_org_c, const
             cost += (double)(int)xo_cu_bits(states, &run, &bp, &bj, (const int16_t *)t[0]) * p->lambda[0];
             if(cost < cost_best) {
                 cost_best = cost;
-                res->idx0 = i0, res->idx1 = i1, res->best_ssd = cy + cu + cv;
+                res->idx0 = i0, res->idx1 = i1, res->best_ssd = temp_ssd;
                 memcpy(res->mv, mj.mv, sizeof(res->mv)), res->refi[0] = mj.refi[0], res->refi[1] = mj.refi[1];
                 memcpy(pred_y, t[0], sizeof(xo_pel) * (size_t)w * h);
                 if(idc) memcpy(pred_u, t[1], sizeof(xo_pel) * (size_t)cw * ch), memcpy(pred_v, t[2], sizeof(xo_pel) * (size_t)cw * ch);
@@ -2069,6 +2171,12 @@ void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
         xo_recon(tmp, pr, nnz, cuw, cuh, cuw, rec_t, bd);
         double cost = 0;
         cost += (double)xo_ssd(cuw, cuh, rec_t, o[0], cuw, s_org_l, bd);
+        if(xo_rdo_dbk_on()) { /* (xeve_pintra.c:131-149) */
+            int64_t d[3];
+            const xo_pel *const src[3] = {rec_t, NULL, NULL};
+            xo_delta_dist(&g_dbk, org, s_org_l, s_org_c, src, x, y, cuw, cuh, 1, nnz != 0, NULL, NULL, d);
+            cost += d[0];
+        }
         const int32_t dist = (int32_t)cost;
         cost += (double)bits * p->lambda[0];
         if(cost < cost_best) {
@@ -2106,6 +2214,12 @@ void xo_pintra_analyze_cu(const xo_pel *const org[3], int s_org_l, int s_org_c, 
         (void)xo_cu_bits(&after_luma, &run, &bp, &bj, all); /* (its bits only enter the local cost the reference discards: cost_t is not used after, :643-646) */
         cost += p->dist_chroma_weight[0] * (double)xo_ssd(1 << lw[1], 1 << lh[1], rec[1], o[1], 1 << lw[1], s_org_c, bd);
         cost += p->dist_chroma_weight[1] * (double)xo_ssd(1 << lw[2], 1 << lh[2], rec[2], o[2], 1 << lw[2], s_org_c, bd);
+        if(xo_rdo_dbk_on()) { /* (xeve_pintra.c:244-263; the luma plane it copies does not reach the chroma figures) */
+            int64_t d[3];
+            const xo_pel *const src[3] = {NULL, rec[1], rec[2]};
+            xo_delta_dist(&g_dbk, org, s_org_l, s_org_c, src, x, y, cuw, cuh, 1, 0, NULL, NULL, d);
+            cost += ((double)d[1] * p->dist_chroma_weight[0]) + ((double)d[2] * p->dist_chroma_weight[1]);
+        }
         best_dist_c = (int32_t)cost;
     }
 

@@ -275,6 +275,23 @@ void xo_deblock_picture(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint3
 void xo_deblock_picture_tiles(xo_pel *y, xo_pel *u, xo_pel *v, int s_l, int s_c, uint32_t *map_scu, const uint32_t *map_cu_mode, const uint8_t *map_tidx,
                               const int8_t *map_refi, const int16_t *map_mv, const xo_deblock_params *p);
 /* xeve_picbuf_expand (xeve_util.c:190-248) on one plane: a = sample (0, 0) */
+/* rdo_dbk_switch = 1 (preset slow): calc_delta_dist_filter_boundary (xeve_mode.c:1534-2005).  D = what it reads besides its arguments: the reconstruction so far
+ * (PIC_MODE, unfiltered) and the unit maps; dp: the picture's deblock parameters (its qp offsets are NOT used: the scratch picture's are zero); qp: ctx->tile[].qp.
+ * xo_rdo_dbk_begin / _end switch it on for the analyses of the calling thread (xo_mode_analyze_ctu and everything below it). */
+typedef struct xo_dbk_ctx {
+    const xo_pel   *mod[3];
+    int32_t         s_mod_l, s_mod_c, qp, on;
+    const uint32_t *map_scu;
+    const int8_t   *map_refi;   /* [unit][list] */
+    const int16_t  *map_mv;     /* [unit][list][x, y] */
+    const uint8_t  *map_tidx;   /* or NULL */
+    const xo_deblock_params *dp;
+} xo_dbk_ctx;
+void xo_rdo_dbk_begin(const xo_dbk_ctx *c);
+void xo_rdo_dbk_end(void);
+int  xo_rdo_dbk_on(void);
+void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l, int s_org_c, const xo_pel *const src[3], int x, int y, int cuw, int cuh,
+                   int intra_flag, int cbf_l, const int8_t refi[2], const int16_t mv[2][2], int64_t delta[3]);
 void xo_picbuf_expand(xo_pel *a, int s, int w, int h, int exp);
 
 /* ---- a8: the motion-compensation driver of one CU (reference: xeve_mc, src_base/xeve_mc.c:465-610, with xeve_mv_clip :401-447) -- */
@@ -445,7 +462,7 @@ typedef struct xo_tree_params {
     int32_t max_cu, min_cu; /* ctx->param.max_cu_intra, min_cu_intra (samples) */
     int32_t min_cuwh;       /* ctx->min_cuwh */
     int32_t slice_qp, slice_num; /* ctx->tile[].qp (the QP field of map_scu), ctx->slice_num */
-    int32_t pad_;
+    int32_t rdo_dbk; /* rdo_dbk_switch: the callers of xo_mode_analyze_ctu switch it on with xo_rdo_dbk_begin (the context it needs is theirs) */
 } xo_tree_params;
 typedef struct xo_ctu_data { /* the fields of XEVE_CU_DATA (xeve_type.h:573-617) an I-slice CTU carries; 4x4 units in raster order, pitch = the block's width in units */
     int8_t   split_mode[XO_CU_DEPTHS][256]; /* [depth][unit]: shape SQUARE */

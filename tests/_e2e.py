@@ -30,6 +30,17 @@ CASES = {
     "noise_allintra_medium": (128, 128, 2, 11, ["--preset", "medium", "-I", "1", "-b", "0"]),
 }
 
+# --preset slow (xeve_enc.c:2473-2489): the quarter-pel stage of the motion search, ME range 128 and rdo_dbk_switch = 1 -- every candidate's distortion includes what
+# the loop filter will do to the CU's left / top boundary (calc_delta_dist_filter_boundary).  Goldens: make_e2e_golden.py, from the unmodified reference.
+SLOW_CASES = {
+    "slow_tiny_ldb": (128, 128, 3, 7, ["--preset", "slow", "-I", "0", "-b", "0"]),
+    "slow_moving_ra_b3": (128, 64, 9, 5004, ["--preset", "slow", "-b", "3"]),
+    "slow_moving_ldb_2threads": (128, 128, 3, 5002, ["--preset", "slow", "-I", "0", "-b", "0", "-m", "2"]),
+    "slow_cif_closed_gop": (352, 288, 4, 5006, ["--preset", "slow", "--closed-gop", "-I", "4", "-b", "3"]),  # partial CTUs at the right and bottom edge
+    "slow_noise_allintra": (128, 128, 2, 11, ["--preset", "slow", "-I", "1", "-b", "0"]),
+    "slow_jumpy_ldb": (192, 128, 4, 6001, ["--preset", "slow", "-I", "0", "-b", "0"]),
+}
+
 # BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes (first frames only): goldens are made by tests/golden/make_e2e_golden.py from the reference app; the
 # GPU suite encodes them once with the whole inter analysis served by the GPU (tests/test_e2e_real_sizes.py).  Not part of CASES: the CPU suite does not re-encode them.
 REAL_CASES = {

@@ -24,7 +24,7 @@ def config(w, h, cli, threads=1):
     while i < len(cli):
         a = cli[i]
         if a == "--preset":
-            c.preset = {"fast": 0, "medium": 1}[cli[i + 1]]
+            c.preset = {"fast": 0, "medium": 1, "slow": 2}[cli[i + 1]]
         elif a == "-I":
             c.keyint = int(cli[i + 1])
         elif a == "-b":

@@ -33,7 +33,7 @@ struct Param {
     int level_idc = 40, sei_info = 1; // --level-idc (sps->level_idc = 3 x, xeve_enc.c:1402) and --info (the SEI that lists the options, :1989)
     int input_depth = 8; // the application's -d: 8 = one byte per sample, 10 = 16-bit little-endian samples (both go to the codec's 10 bits, xeve_app.c:1153-1158)
     // derived
-    int gop_size = 16, ref_pic_gap_length = 0, me_ref_num = 1, me_range = 64, me_sub = 2, me_sub_pos = 4, me_sub_range = 1, merge_num = 3, me_algo = 1;
+    int gop_size = 16, ref_pic_gap_length = 0, me_ref_num = 1, me_range = 64, me_sub = 2, me_sub_pos = 4, me_sub_range = 1, merge_num = 3, me_algo = 1, rdo_dbk = 0;
     int max_cu_intra = 32, min_cu_intra = 4, max_cu_inter = 64, min_cu_inter = 8, lookahead = 17;
     std::string error;
 
@@ -61,7 +61,13 @@ struct Param {
         if(qp_cb_offset < -12 || qp_cb_offset > 12 || qp_cr_offset < -12 || qp_cr_offset > 12) return bad("chroma qp offsets must lie in -12 .. 12");
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
-        else return bad("preset must be 0 (fast) or 1 (medium): slow / placebo need rdo_dbk_switch, which the device path does not have");
+        else if(preset == 2) me_range = 128, me_sub = 3, me_sub_pos = 4, me_sub_range = 2, merge_num = 3, rdo_dbk = 1; // slow (xeve_enc.c:2473-2489): quarter-pel search, rdo_dbk_switch
+        else return bad("preset must be 0 (fast), 1 (medium) or 2 (slow): placebo needs 4x4 inter CUs, 64x64 intra CUs and a second reference picture per list");
+#ifdef XENC_TEST_OVERRIDES // (the CPU harness only: a preset taken apart, against the reference library pinned the same way -- oracle/ref_param_pin.c)
+        if(getenv("XO_PIN_RDO_DBK")) rdo_dbk = atoi(getenv("XO_PIN_RDO_DBK"));
+        if(getenv("XO_PIN_ME_SUB")) me_sub = atoi(getenv("XO_PIN_ME_SUB"));
+        if(getenv("XO_PIN_ME_RANGE")) me_range = atoi(getenv("XO_PIN_ME_RANGE"));
+#endif
         // (the reference picture tables of the frame loop and of the device path hold 5 / 4 entries per list -- Dpb::refp, PicSetup::ref, the refi_bits table of
         // fill_inter_params, XEVE_HIP_MAX_REFP planes per search: more reference pictures than that are refused here, before anything indexes them)
         if(ref < 0 || ref > 4) return bad("ref must lie in 0 .. 4 (0: the preset's one reference picture per list)");
@@ -411,7 +417,7 @@ inline std::string sei_text(const Param &P) // xeve_eco_emitsei's banner + xeve_
     s += fmt("profile=%d threads=%d input-res=%dx%d fps=%.3f keyint=%d color-space=%d rc-type=CQP", 0, P.threads, P.w, P.h, (float)P.fps_num / P.fps_den, P.keyint, cs);
     const KV a[] = {{"qp", P.qp}, {"qp_cb_offset", P.qp_cb_offset}, {"qp_cr_offset", P.qp_cr_offset}, {"info", P.sei_info}, {"hash", 0}, {"bframes", P.bframes}, {"aq-mode", 0}, {"lookahead", P.lookahead},
                     {"closed-gop", P.closed_gop}, {"disable-hgop", 0}, {"ref_pic_gap_length", P.ref_pic_gap_length}, {"codec-bit-depth", BIT_DEPTH}, {"level-idc", P.level_idc},
-                    {"cu-tree", 0}, {"constrained-ip", 0}, {"use-deblock", 1}, {"inter-slice-type", P.inter_slice_type}, {"rdo-deblk-switch", 0},
+                    {"cu-tree", 0}, {"constrained-ip", 0}, {"use-deblock", 1}, {"inter-slice-type", P.inter_slice_type}, {"rdo-deblk-switch", P.rdo_dbk},
                     {"qp-increased-frame", 0}, {"forced-idr-frame-flag", 0}, {"qp-increased-frame", 0}};
     for(const KV &e : a) s += fmt(" %s=%d", e.k, e.v);
     s += fmt(" qp-max=%d qp-min=%d gop-size=%d use-fcst=%d chroma-format-idc=%d cs-w-shift=%d cs-h-shift=%d", 51, 0, P.gop_size, 0, 1, 1, 1);
@@ -511,7 +517,7 @@ inline void fill_tree_params(xeve_hip_tree_params &t, const Param &P, int slice_
     t.ip.sqrt_lambda0 = n.sqrt_lambda0, t.ip.dist_chroma_weight[0] = n.dcw[0], t.ip.dist_chroma_weight[1] = n.dcw[1];
     t.pic_w = P.w, t.pic_h = P.h, t.log2_ctu = LOG2_CTU, t.min_cuwh = 4;
     t.max_cu = slice_type == ST_I ? P.max_cu_intra : P.max_cu_inter, t.min_cu = slice_type == ST_I ? P.min_cu_intra : P.min_cu_inter;
-    t.slice_qp = n.qp, t.slice_num = 0;
+    t.slice_qp = n.qp, t.slice_num = 0, t.rdo_dbk = P.rdo_dbk;
 }
 inline void fill_inter_params(xeve_hip_tree_inter &I, const Param &P, int slice_type, int poc, const PicNumbers &n, const Dpb &dpb)
 {

@@ -467,7 +467,7 @@ static bool tree_params_ok(const xeve_hip_tree_params *p)
 {   // everything the analyses of the walk would refuse is refused here, before the first launch (a walk that stops half way leaves half-written maps behind)
     if(!(p && p->log2_ctu >= 3 && p->log2_ctu <= 6 && p->pic_w > 0 && p->pic_h > 0 && (p->pic_w & 3) == 0 && (p->pic_h & 3) == 0 && xh_pow2(p->max_cu) &&
          xh_pow2(p->min_cu) && p->min_cu >= 4 && p->max_cu >= p->min_cu && p->min_cuwh >= 4 && xh_pow2(p->min_cuwh) && p->ip.w_scu == (p->pic_w + 3) >> 2 &&
-         p->ip.h_scu == (p->pic_h + 3) >> 2))
+         p->ip.h_scu == (p->pic_h + 3) >> 2 && p->rdo_dbk == 0)) // (rdo_dbk_switch: not on the device yet)
         return false;
     const xeve_hip_intra_params &ip = p->ip;
     if(!(ip.tool_iqt == 0 && ip.bit_depth >= 8 && ip.bit_depth <= 14 && (ip.chroma_format_idc == 0 || ip.chroma_format_idc == 1 || ip.chroma_format_idc == 3) &&
