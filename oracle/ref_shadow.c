@@ -22,6 +22,8 @@ static double (*xo_tree)(const xo_pel *const *, int, int, xo_pel *const *, int, 
 static double (*xo_tree_any)(const xo_pel *const *, int, int, xo_pel *const *, int, int, uint32_t *, int8_t *, const uint8_t *, uint32_t *, const xo_sbac *,
                              const xo_tree_params *, const xo_tree_inter *, int, int, xo_ctu_data *, xo_sbac *);
 static unsigned long long shadow_ctus, shadow_bad, shadow_skipped, shadow_inter_ctus;
+static void (*xo_dbk_begin)(const xo_dbk_ctx *);
+static void (*xo_dbk_end)(void);
 
 /* what the inter side of the walk is handed (the same derivation as shim_pinter_analyze_cu above, once per CTU); tab: 16 entries */
 static int shadow_inter_setup(XEVE_CTX *ctx, XEVE_CORE *core, xo_tree_inter *I, xo_refpic *tab, int16_t (*map_mv)[2][2], int8_t (*map_refi)[2])
@@ -332,7 +334,7 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     const int nscu0 = ctx->w_scu * ctx->h_scu;
     int16_t (*m_mv)[2][2] = NULL;
     int8_t  (*m_refi)[2]  = NULL;
-    if(ctx->pps.cu_qp_delta_enabled_flag || ctx->param.rdo_dbk_switch || ctx->param.tool_iqt || ctx->sps.tool_admvp || ctx->log2_max_cuwh != 6 || idc == 2 ||
+    if(ctx->pps.cu_qp_delta_enabled_flag || (ctx->param.rdo_dbk_switch && !xo_dbk_begin) || ctx->param.tool_iqt || ctx->sps.tool_admvp || ctx->log2_max_cuwh != 6 || idc == 2 ||
        ctx->param.threads != 1 || (!is_i && (!xo_tree_any || getenv("XEVE_SHIM_SHADOW_I_ONLY")))) {
         shadow_skipped++;
         return orig_mode_analyze_lcu(ctx, core);
@@ -379,11 +381,30 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     const xo_pel *org[3] = {pi->o[Y_C], pi->o[U_C], pi->o[V_C]};
     if(!is_i) P.ip.slice_type = ctx->sh->slice_type;
     if(getenv("XEVE_SHIM_TREE_GOLDEN") && golden_wanted(lcu)) golden_dump(ctx, core, &P, is_i ? NULL : &TI, mod, m_scu, m_ipm, m_cum, (const int16_t(*)[2][2])m_mv, (const int8_t(*)[2])m_refi, &entry, x0, y0, lcu);
+    xo_deblock_params dbk_dp;
+    int8_t  *z_refi = NULL;
+    int16_t *z_mv = NULL;
+    if(ctx->param.rdo_dbk_switch) { /* preset slow: the oracle's candidates get the loop filter's share too, read off the SNAPSHOT (reconstruction so far, unit maps) */
+        const int bc = ctx->sps.bit_depth_chroma_minus8;
+        memset(&dbk_dp, 0, sizeof(dbk_dp));
+        dbk_dp.w = ctx->w, dbk_dp.h = ctx->h, dbk_dp.w_scu = ctx->w_scu, dbk_dp.h_scu = ctx->h_scu, dbk_dp.log2_max_cuwh = ctx->log2_max_cuwh;
+        dbk_dp.bit_depth_luma = ctx->sps.bit_depth_luma_minus8 + 8, dbk_dp.bit_depth_chroma = bc + 8, dbk_dp.chroma_format_idc = idc;
+        for(int c = 0; c < 2; c++)
+            for(int i = 0; i < 100; i++) dbk_dp.qp_chroma[c][i] = i <= 57 + 6 * bc ? ctx->qp_chroma_dynamic_ext[c][i] : 0;
+        if(!m_refi) z_refi = malloc(2 * nscu), z_mv = calloc(4 * nscu, sizeof(int16_t)), memset(z_refi, -1, 2 * nscu);
+        xo_dbk_ctx D;
+        memset(&D, 0, sizeof(D));
+        D.mod[0] = mod[0], D.mod[1] = mod[1], D.mod[2] = mod[2], D.s_mod_l = pm->s_l, D.s_mod_c = pm->s_c, D.qp = ctx->tile[core->tile_idx].qp;
+        D.map_scu = m_scu, D.map_refi = m_refi ? (const int8_t *)m_refi : z_refi, D.map_mv = m_mv ? (const int16_t *)m_mv : z_mv, D.map_tidx = ctx->map_tidx, D.dp = &dbk_dp;
+        P.rdo_dbk = 1;
+        xo_dbk_begin(&D);
+    }
     if(is_i) (void)xo_tree(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, x0, y0, &out, &next);
     else {
         (void)xo_tree_any(org, pi->s_o[Y_C], pi->s_o[U_C], mod, pm->s_l, pm->s_c, m_scu, m_ipm, ctx->map_tidx, m_cum, &entry, &P, &TI, x0, y0, &out, &next);
         shadow_inter_ctus++;
     }
+    if(ctx->param.rdo_dbk_switch) xo_dbk_end(), free(z_refi), free(z_mv);
 
     /* compare */
     int bad = 0;
@@ -450,6 +471,25 @@ static int shim_mode_analyze_lcu(XEVE_CTX *ctx, XEVE_CORE *core)
     return rc;
 }
 
+
+
+/* XEVE_SHIM_DBK_LOG=<file>: every call of the reference's calc_delta_dist_filter_boundary with what it returned -- held against the oracle's own log (XO_DBK_LOG) when a
+ * preset-slow bitstream differs */
+void calc_delta_dist_filter_boundary(XEVE_CTX *ctx, XEVE_PIC *pic_rec, XEVE_PIC *pic_org, int cuw, int cuh, pel (*src)[MAX_CU_DIM], int s_src, int x, int y, u16 avail_lr,
+                                     u8 intra_flag, u8 cbf_l, s8 *refi, s16 (*mv)[MV_D], u8 is_mv_from_mvf, XEVE_CORE *core)
+{
+    static void (*real)(XEVE_CTX *, XEVE_PIC *, XEVE_PIC *, int, int, pel (*)[MAX_CU_DIM], int, int, int, u16, u8, u8, s8 *, s16 (*)[MV_D], u8, XEVE_CORE *);
+    if(!real) real = dlsym(RTLD_NEXT, "calc_delta_dist_filter_boundary");
+    real(ctx, pic_rec, pic_org, cuw, cuh, src, s_src, x, y, avail_lr, intra_flag, cbf_l, refi, mv, is_mv_from_mvf, core);
+    const char *f = getenv("XEVE_SHIM_DBK_LOG");
+    if(f) {
+        FILE *o = fopen(f, "a");
+        fprintf(o, "poc %d x %d y %d cu %d intra %d cbf %d refi %d %d mv %d %d %d %d lr %d -> %lld %lld %lld\n", (int)ctx->poc.poc_val, x, y, cuw, intra_flag, cbf_l, refi ? refi[0] : -9,
+                refi ? refi[1] : -9, mv ? mv[0][0] : 0, mv ? mv[0][1] : 0, mv ? mv[1][0] : 0, mv ? mv[1][1] : 0, avail_lr, (long long)core->delta_dist[0], (long long)core->delta_dist[1],
+                (long long)core->delta_dist[2]);
+        fclose(o);
+    }
+}
 
 /* ---- the shim's CTU route adapter with the ORACLE as its engine (XEVE_SHIM_TREE_ORACLE) -------------------------------------------------------------------------- */
 static void inter_to_oracle(xo_tree_inter *T, xo_refpic *tab, const xeve_hip_tree_inter *H)
@@ -551,6 +591,7 @@ void xeve_platform_init_func(XEVE_CTX *ctx)
         void *oh = dlopen(getenv("XEVE_SHIM_SHADOW_TREE"), RTLD_NOW | RTLD_LOCAL);
         if(!oh || !(xo_tree = dlsym(oh, "xo_mode_analyze_ctu_intra"))) { fprintf(stderr, "[xeve_hip_shim] shadow tree: %s\n", dlerror()); abort(); }
         xo_tree_any = dlsym(oh, "xo_mode_analyze_ctu");
+        xo_dbk_begin = dlsym(oh, "xo_rdo_dbk_begin"), xo_dbk_end = dlsym(oh, "xo_rdo_dbk_end");
         xo_eco = dlsym(oh, "xo_eco_ctu"), xo_tile_end = dlsym(oh, "xo_eco_tile_end");
         orig_mode_analyze_lcu = ctx->fn_mode_analyze_lcu, ctx->fn_mode_analyze_lcu = shim_mode_analyze_lcu;
         if(ctx->fn_loop_filter != shim_shadow_loop_filter) orig_shadow_loop_filter = ctx->fn_loop_filter, ctx->fn_loop_filter = shim_shadow_loop_filter;

@@ -16,6 +16,7 @@
 
 #include <math.h>
 #include <stddef.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1427,6 +1428,12 @@ void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l,
     int8_t  r_cur[2] = {-1, -1};
     int16_t v_cur[4] = {0, 0, 0, 0};
     if(refi) r_cur[0] = refi[0], r_cur[1] = refi[1], v_cur[0] = mv[0][0], v_cur[1] = mv[0][1], v_cur[2] = mv[1][0], v_cur[3] = mv[1][1];
+    /* The filter compares ctx->map_unrefined_mv, not map_mv (xeve_deblock_unit, xeve_df.c:491,509).  The picture's own filter pass copies map_mv into it first
+     * (xeve_deblock, :545-549); during the mode decision it holds what update_map_scu (xeve_mode.c:1102) copies out of cu_data->unrefined_mv -- after every decided
+     * CU and once more at the end of update_to_ctx_map (:2518), over what that function had just stored -- and nothing in the Baseline encoder ever writes that array:
+     * it is zero.  So every neighbour compares as MOTIONLESS (its reference indices are real); only the candidate's own side carries vectors (:1827-1830). */
+    static const int16_t zero4[4] = {0, 0, 0, 0};
+    const int top_in_ctu = 1, left_in_ctu = 1;
     delta[0] = delta[1] = delta[2] = 0;
     for(int c = 0; c < (idc ? 3 : 1); c++) {
         const int sx = c ? ws : 0, sy = c ? hs : 0, w = cuw >> sx, h = cuh >> sy, xo_ = 4 >> sx, yo = 4 >> sy, xt = 2 >> sx, yt = 2 >> sy, bd = c ? p->bit_depth_chroma : p->bit_depth_luma;
@@ -1446,7 +1453,7 @@ void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l,
         if(top)
             for(int i = 0; i < cuw >> 2; i++) {
                 const int nb = t + i - w_scu;
-                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, D->map_mv + 4 * nb);
+                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, top_in_ctu ? zero4 : D->map_mv + 4 * nb);
                 if(c == 0) df_edge(dst + 4 * i, 4, 1, S, xo_df_st[cls][qp] << bl, maxv, 0);
                 else {
                     const int q = clip3i(-6 * bc, 57, qp);
@@ -1456,7 +1463,7 @@ void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l,
         if(left)
             for(int i = 0; i < cuh >> 2; i++) {
                 const int nb = t + i * w_scu - 1;
-                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, D->map_mv + 4 * nb);
+                const int cls = df_class(m_cur, D->map_scu[nb], r_cur, D->map_refi + 2 * nb, v_cur, left_in_ctu ? zero4 : D->map_mv + 4 * nb);
                 if(c == 0) df_edge(dst + (size_t)(4 * i) * S, 4, S, 1, xo_df_st[cls][qp] << bl, maxv, 0);
                 else {
                     const int q = clip3i(-6 * bc, 57, qp);
@@ -1468,6 +1475,12 @@ void xo_delta_dist(const xo_dbk_ctx *D, const xo_pel *const org[3], int s_org_l,
         if(left) after += xo_ssd(xt, h, dst - xt, o - xt, S, so, bd);
         delta[c] = after - before;
         free(buf);
+    }
+    if(getenv("XO_DBK_LOG")) { /* (debugging aid: the same line oracle/ref_shadow.c logs for the reference's own function) */
+        FILE *f = fopen(getenv("XO_DBK_LOG"), "a");
+        fprintf(f, "x %d y %d cu %d intra %d cbf %d refi %d %d mv %d %d %d %d lr %d -> %lld %lld %lld\n", x, y, cuw, intra_flag, cbf_l, refi ? refi[0] : -9, refi ? refi[1] : -9,
+                mv ? mv[0][0] : 0, mv ? mv[0][1] : 0, mv ? mv[1][0] : 0, mv ? mv[1][1] : 0, left, src[0] ? (long long)delta[0] : -999999LL, src[1 % 3] && idc ? (long long)delta[1] : -999999LL, src[2] && idc ? (long long)delta[2] : -999999LL);
+        fclose(f);
     }
 }
 
