@@ -174,6 +174,12 @@ HEADER_OPTION_CASES = {
     "no_info_sei_level_51": (128, 64, 2, 4, 5035, ["--preset", "medium", "--closed-gop", "-I", "4", "-b", "3", "--info", "0", "--level-idc", "51"], 1),
     "level_62_m2": (136, 72, 1, 5, 37, ["--preset", "fast", "-b", "0", "--level-idc", "62"], 2),
 }
+# --preset slow (quarter-pel search, ME range 128, rdo_dbk_switch = 1: walk_dbk.h / xo_delta_dist) as batches of closed GOPs: several GOPs in lockstep, 3 and 8 row chains
+# (a CU at the top of a CTU row filters against the row chain above it: written CTUs, whose luma cbf flags the writer has set)
+SLOW_BATCH_CASES = {
+    "slow_gops_192x128_moving_m3": (192, 128, 3, 4, 5041, ["--preset", "slow", "--closed-gop", "-I", "4", "-b", "3"], 3),
+    "slow_gops_256x192_noise_m8": (256, 192, 2, 2, 43, ["--preset", "slow", "--closed-gop", "-I", "8"], 8),
+}
 _PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
 
 

@@ -116,6 +116,43 @@ def test_p_slices_and_chroma_qp_offsets_on_the_gpu(name, walk, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("name", sorted(_e2e.SLOW_CASES))
+def test_preset_slow_single_runs_on_the_gpu(name, hip, yuv_dir):
+    """--preset slow on the device (the fused walk: walk_dbk.h estimates the loop filter's share of every candidate's distortion -- rdo_dbk_switch = 1 --, the search
+    runs its quarter-pel stage, ME range 128): low delay, hierarchical B pictures, closed GOPs with partial CTUs, all-intra, two row chains = the reference's bitstreams"""
+    w, h, n, seed, cli = _e2e.SLOW_CASES[name]
+    threads = int(cli[cli.index("-m") + 1]) if "-m" in cli else 1
+    cli = [a for i, a in enumerate(cli) if a != "-m" and (i == 0 or cli[i - 1] != "-m")]
+    out, _ = _run(hip, _cfg(hip, w, h, cli, threads), [_frames(yuv_dir, name, w, h, n, seed)], n)
+    assert (len(out[0]), _enc.md5(out[0])) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("team", [0, 3], ids=["one_chain_per_team", "three_chains_per_team"])
+@pytest.mark.parametrize("name", sorted(_enc.SLOW_BATCH_CASES))
+def test_preset_slow_batches_on_the_gpu(name, team, hip, yuv_dir):
+    """... closed GOPs in lockstep with 3 / 8 row chains, teams of one and of three chains"""
+    w, h, gops, frames, seed, cli, threads = _enc.SLOW_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    with hip.walk_select(-1, team):
+        outs, _ = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+def test_preset_slow_is_refused_where_the_fused_walk_is_switched_off(hip):
+    import xeve_amd
+
+    with hip.walk_select(0):
+        enc = hip.BatchEncoder(hip.config(128, 64, keyint=4, bframes=3, closed_gop=True, preset="slow"), 1, 2)
+        for f in range(2):
+            enc.push(0, f, bytes(128 * 64 * 3 // 2))
+        with pytest.raises(xeve_amd.XeveHipError, match="fused walk"):
+            enc.encode()
+        enc.close()
+    with pytest.raises(xeve_amd.XeveHipError, match="chroma qp offsets"):
+        hip.BatchEncoder(hip.config(128, 64, preset="slow", qp_cb_offset=1), 1, 1)
+
+
 def test_one_chain_through_the_second_writer_pass_on_the_gpu(hip, yuv_dir):
     w, h, n, seed, cli = _e2e.CASES["tiny_closed_gop"]
     f = _frames(yuv_dir, "tiny_closed_gop", w, h, n, seed)
@@ -223,7 +260,7 @@ def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, walk, pictures
 def test_configurations_outside_the_supported_set_are_refused_by_the_library(hip):
     import xeve_amd
 
-    for kw in (dict(w=130, h=64), dict(w=128, h=64, preset=2), dict(w=128, h=64, bframes=2)):
+    for kw in (dict(w=130, h=64), dict(w=128, h=64, preset=3), dict(w=128, h=64, bframes=2)):
         c = hip.config(kw.pop("w"), kw.pop("h"), **kw)
         with pytest.raises(xeve_amd.XeveHipError):
             hip.BatchEncoder(c, 1, 1)

@@ -87,6 +87,34 @@ def test_p_slices_and_chroma_qp_offsets_on_the_host_side(name, yuv_dir):
         assert (len(whole), _enc.md5(whole)) == (g["whole"]["bytes"], g["whole"]["md5"])
 
 
+@pytest.mark.parametrize("name", sorted(_e2e.SLOW_CASES))
+def test_preset_slow_single_runs(name, yuv_dir):
+    """--preset slow: the search's quarter-pel stage, ME range 128 and rdo_dbk_switch = 1 -- every candidate's distortion includes what the loop filter will do to the CU's
+    top and left edge (oracle/xeve_oracle.c xo_delta_dist = calc_delta_dist_filter_boundary) -- low delay, random access with hierarchical B pictures, closed GOPs with
+    partial CTUs, all-intra, two row chains: the reference application's bitstreams"""
+    w, h, n, seed, cli = _e2e.SLOW_CASES[name]
+    threads = int(cli[cli.index("-m") + 1]) if "-m" in cli else 1
+    cli = [a for i, a in enumerate(cli) if a != "-m" and (i == 0 or cli[i - 1] != "-m")]
+    out = _enc.encode_cpu(_enc.config(w, h, cli, threads), [_frames(yuv_dir, name, w, h, n, seed)], n)[0]
+    assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("name", sorted(_enc.SLOW_BATCH_CASES))
+def test_preset_slow_batches_of_closed_gops(name, yuv_dir):
+    """... and as closed GOPs in lockstep with 3 / 8 row chains: a CU at the top of a CTU row filters against CTUs another chain's writer has been through"""
+    w, h, gops, frames, seed, cli, threads = _enc.SLOW_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+def test_preset_slow_with_chroma_qp_offsets_is_refused():
+    c = _enc.config(128, 64, ["--preset", "slow", "--qp-cb-offset", "2"])
+    with pytest.raises(RuntimeError, match="chroma qp offsets"):
+        _enc.encode_cpu(c, [bytes(128 * 64 * 3 // 2)], 1)
+
+
 @pytest.mark.parametrize("name", sorted(_enc.HEADER_OPTION_CASES))
 def test_header_only_options(name, yuv_dir):
     """--info 0 (no SEI with the option list) and --level-idc: parameter sets and SEI only"""
@@ -194,7 +222,7 @@ def test_flushing_after_every_picture_changes_no_byte_and_cuts_at_access_units(n
 
 
 def test_configurations_outside_the_supported_set_are_refused():
-    for bad in (dict(w=130), dict(preset=2), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
+    for bad in (dict(w=130), dict(preset=3), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
         c = _enc.config(128, 64, ["--preset", "fast"])
         for k, v in bad.items():
             setattr(c, k, v)

@@ -205,3 +205,22 @@ def test_walk_decides_every_ctu_with_p_slices_and_chroma_qp_offsets(name, walk_e
     data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
     outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
+@pytest.mark.parametrize("name", ["slow_moving_ra_b3", "slow_cif_closed_gop", "slow_noise_allintra", "slow_jumpy_ldb"])
+def test_walk_decides_every_ctu_at_preset_slow(name, walk_engine, tmp_path_factory):
+    """--preset slow through the fused walk's host side: the quarter-pel stage of its search and walk_dbk.h -- the loop filter's share of every candidate's distortion
+    (merge pairs, the inter candidates' prediction and reconstruction, the intra candidates' luma and chroma) -- against the reference application's bitstreams"""
+    E2E = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "e2e_v1.json")))
+    w, h, n, seed, cli = _e2e.SLOW_CASES[name]
+    out = _enc.encode_cpu(_enc.config(w, h, cli), [_clip(str(tmp_path_factory.getbasetemp()), name, w, h, n, seed)], n)[0]
+    assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+def test_walk_decides_every_ctu_of_a_preset_slow_batch(walk_engine, tmp_path_factory):
+    name = "slow_gops_192x128_moving_m3"
+    w, h, gops, frames, seed, cli, threads = _enc.SLOW_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]

@@ -63,6 +63,7 @@ struct Param {
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
         else if(preset == 2) me_range = 128, me_sub = 3, me_sub_pos = 4, me_sub_range = 2, merge_num = 3, rdo_dbk = 1; // slow (xeve_enc.c:2473-2489): quarter-pel search, rdo_dbk_switch
         else return bad("preset must be 0 (fast), 1 (medium) or 2 (slow): placebo needs 4x4 inter CUs, 64x64 intra CUs and a second reference picture per list");
+        if(rdo_dbk && (qp_cb_offset || qp_cr_offset)) return bad("preset slow with chroma qp offsets: the loop filter's share of the chroma distortions is coded for offsets of 0 only (walk_dbk.h)");
 #ifdef XENC_TEST_OVERRIDES // (the CPU harness only: a preset taken apart, against the reference library pinned the same way -- oracle/ref_param_pin.c)
         if(getenv("XO_PIN_RDO_DBK")) rdo_dbk = atoi(getenv("XO_PIN_RDO_DBK"));
         if(getenv("XO_PIN_ME_SUB")) me_sub = atoi(getenv("XO_PIN_ME_SUB"));

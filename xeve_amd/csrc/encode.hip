@@ -249,7 +249,6 @@ struct xeve_hip_enc {
         if((double)G * org_l >= 8589934592.0) return fail("too many GOPs for one batch at this picture size: the stacked originals must stay below 2^33 samples (xh_common.h: halved 32-bit offsets)");
         if((long)G * T > 65535) return fail("too many GOPs for one batch: GOPs x row chains is a grid dimension (at most 65535)");
         if((double)G * vh * 32 >= 2147483648.0) return fail("too many GOPs for one batch at this picture size: the tall picture's rows in 1/16 sample units must fit 31 bits");
-        if(P.rdo_dbk) return fail("preset slow (rdo_dbk_switch = 1): the device path does not estimate the loop filter's share of a candidate's distortion yet");
         rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");

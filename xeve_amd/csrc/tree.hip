@@ -467,7 +467,7 @@ static bool tree_params_ok(const xeve_hip_tree_params *p)
 {   // everything the analyses of the walk would refuse is refused here, before the first launch (a walk that stops half way leaves half-written maps behind)
     if(!(p && p->log2_ctu >= 3 && p->log2_ctu <= 6 && p->pic_w > 0 && p->pic_h > 0 && (p->pic_w & 3) == 0 && (p->pic_h & 3) == 0 && xh_pow2(p->max_cu) &&
          xh_pow2(p->min_cu) && p->min_cu >= 4 && p->max_cu >= p->min_cu && p->min_cuwh >= 4 && xh_pow2(p->min_cuwh) && p->ip.w_scu == (p->pic_w + 3) >> 2 &&
-         p->ip.h_scu == (p->pic_h + 3) >> 2 && p->rdo_dbk == 0)) // (rdo_dbk_switch: not on the device yet)
+         p->ip.h_scu == (p->pic_h + 3) >> 2 && (p->rdo_dbk == 0 || p->rdo_dbk == 1)))
         return false;
     const xeve_hip_intra_params &ip = p->ip;
     if(!(ip.tool_iqt == 0 && ip.bit_depth >= 8 && ip.bit_depth <= 14 && (ip.chroma_format_idc == 0 || ip.chroma_format_idc == 1 || ip.chroma_format_idc == 3) &&
@@ -572,12 +572,14 @@ extern "C" size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hi
     if(!tree_params_ok(p) || nchains <= 0 || (p->ip.slice_type != 2 && !tree_inter_ok(p, I))) return 0;
     if(p->ip.slice_type == 2) I = nullptr;
     if(xh_walk_supported(p, I, nchains)) return xh_walk_workspace(nchains);
+    if(p->rdo_dbk) { xh_set_error("rdo_dbk_switch (preset slow) runs on the fused walk only: it is switched off (XEVE_HIP_WALK=0 / xeve_hip_walk_select) or does not take these parameters"); return 0; }
     return tree_layout(nchains, p, I, s_org_l, s_org_c).total;
 }
 extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *p)
 {
     if(!tree_params_ok(p) || nchains <= 0 || p->ip.slice_type != 2) return 0;
     if(xh_walk_supported(p, nullptr, nchains)) return xh_walk_workspace(nchains);
+    if(p->rdo_dbk) return 0;
     return tree_layout(nchains, p, nullptr, 0, 0).total;
 }
 
@@ -678,6 +680,8 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     if(nchains == 0) return XEVE_HIP_OK;
     // which walk: by the WIDTH OF THE BATCH the call belongs to (the caller's state records: every chain of every GOP), not by the chains this step carries -- the ramp
     // steps of a wide batch's pictures stay on the composed walk (a long-running fused launch between the other streams' short kernels cost 7 %, profiles/r04_walks.md)
+    // rdo_dbk_switch (preset slow) lives in the fused walk alone (walk_dbk.h): the composed walk's stages do not estimate the loop filter's share
+    XH_REQUIRE(!p->rdo_dbk || xh_walk_supported(p, I, std::max(nchains, nstates)));
     if(xh_walk_supported(p, I, std::max(nchains, nstates))) // the fused walk: the whole schedule inside one kernel (walk.hip)
         return xh_walk_run(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost,
                            workspace, workspace_bytes, vh, (hipStream_t)stream);

@@ -155,6 +155,7 @@ struct Cw { // the workspace of one chain
     pel      spred[3][4096];     // inter: the skip winner's prediction
     pel      bpred[4096];        // inter: the fixed list's luma prediction of a bi round
     u64      sk_ssd[16][3];      // inter: SSD of every merge candidate pair, per component
+    u64      sk_dbk[16][3];      // inter, rdo_dbk_switch: the loop filter's share of it (two's complement)
     Sbac     cst[4][3];          // inter: exit coder states of a candidate's counts: all-zero CU, CU as quantised, the chosen combination
     pel      wrec[3][4096];      // inter: the winner's reconstruction
     int16_t  org_bi[4096];
@@ -173,7 +174,7 @@ struct RefPic {
 };
 
 struct P { // one call
-    int    nchains, C, full;
+    int    nchains, C, full, rdo_dbk;
     int    log2_ctu, pic_w, pic_h, w_scu, h_scu, max_cu, min_cu, min_cuwh, idc, ws, hs, bd, slice_type, slice_qp, slice_num, cip;
     int    s_org_l, s_org_c, s_mod_l, s_mod_c;
     long   org_pic_l, org_pic_c, mod_pic_l, mod_pic_c, map_pic;
@@ -1054,6 +1055,7 @@ XW int had_tile(const pel *org, int s_org, const pel *cur, int s_cur, int n)
 }
 
 } // namespace xw
+#include "walk_dbk.h"
 #include "walk_intra.h"
 #include "walk_inter.h"
 #include "walk_tree.h"

@@ -119,7 +119,8 @@ extern "C" int xeve_hip_walk_select(int mode)
 }
 bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int nchains)
 {
-    if(!xh_walk_enabled(nchains)) return false;
+    // (rdo_dbk_switch is the fused walk's alone: whatever the width, unless the composed walk is pinned -- then the call is refused, tree.hip)
+    if(p->rdo_dbk ? g_walk_mode.load(std::memory_order_relaxed) == 0 : !xh_walk_enabled(nchains)) return false;
     if(p->ip.slice_type != 2 && I) {
         static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 1;
         if(!inter_on) return false;

@@ -68,6 +68,22 @@ template <bool FULL> XW void residue_rdo(const Tm &tm, const P &p, Lds &S, int c
     sync(tm);
     blocks_chain(tm, p, S, lb, nl, log2n, 1);
     if(ncomp > 1) blocks_chain(tm, p, S, cb, 2 * nl, lc, 1);
+    if(p.rdo_dbk) { // rdo_dbk_switch (:1016-1095, 1290-1312): the loop filter's share -- of the prediction alone (no luma cbf) into ssd[0], of the reconstruction into ssd[1]
+        dbk_stage(tm, p, 2 * nl, log2n, [&](int j, DbkJob &J) {
+            const int v = j / nl, e = j - v * nl, k = e / ncand, ci = e - k * ncand, m = modes[ci], sl = cand_slot(m);
+            const ISt &I = S.ist[k];
+            Cw &W = p.cw[c0 + k];
+            J.on = lb[e].on, J.pic = I.pic, J.x = I.x, J.y = I.y, J.intra = 0, J.cbf = v ? lb[e].nnz != 0 : 0, J.two = 0;
+            J.refi[0] = m == M_DIR ? 0 : I.refi[m][0], J.refi[1] = m == M_DIR ? 0 : I.refi[m][1];
+            for(int l = 0; l < 2; l++) J.mv[2 * l] = I.mv[m][l][0], J.mv[2 * l + 1] = I.mv[m][l][1];
+            for(int c = 0; c < 3; c++) {
+                const bool has = c < ncomp;
+                Blk &B = c == 0 ? lb[e] : cb[(c - 1) * nl + e];
+                J.a[c] = !has ? nullptr : v ? B.rec : W.epred[sl][c], J.b[c] = nullptr, J.acc[c] = has ? &B.ssd[v] : nullptr;
+            }
+        });
+        sync(tm);
+    }
     // the bit counts, round 1: lanes A (all zero), B (as quantised), C (the component tests) of every (chain, candidate)
     auto blk_of = [&](int e, int c) -> Blk & { return c == 0 ? lb[e] : cb[(c - 1) * nl + e]; };
     auto coefs_of = [&](int e, CoefSet &q, const int nz[3]) {
@@ -285,7 +301,22 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
                     const int q = yy * w + xx, v = two ? (a[q] + b[q] + 1) >> 1 : a[q], d = v - (int)o[(long)yy * so + xx];
                     acc += (u64)((d * d) >> sh);
                 }
-            W.sk_ssd[pr][c] = acc;
+            W.sk_ssd[pr][c] = acc, W.sk_dbk[pr][c] = 0;
+        }
+        if(p.rdo_dbk) { // (:1463-1485) every pair's prediction through the loop filter's estimate; pi->best_ssd stays without it
+            sync(tm);
+            dbk_stage(tm, p, nC * np, log2n, [&](int j, DbkJob &J) {
+                const int k = j / np, pr = j - k * np, i0 = isb ? pr / p.max_cand : pr, i1 = isb ? pr - i0 * p.max_cand : 0;
+                const ISt &I = S.ist[k];
+                Cw &W = p.cw[c0 + k];
+                J.on = I.on && !((I.dup[0] >> i0) & 1) && !(isb && ((I.dup[1] >> i1) & 1));
+                J.pic = I.pic, J.x = I.x, J.y = I.y, J.intra = 0, J.cbf = 0;
+                J.refi[0] = 0, J.refi[1] = (int8_t)(isb ? 0 : -1);
+                J.mv[0] = I.mvp[0][i0][0], J.mv[1] = I.mvp[0][i0][1], J.mv[2] = I.mvp[1][i1][0], J.mv[3] = I.mvp[1][i1][1];
+                const int16_t mv[2][2] = {{J.mv[0], J.mv[1]}, {J.mv[2], J.mv[3]}};
+                J.two = isb && !mc_identical(p, I.x, I.y, N, J.refi, mv);
+                for(int c = 0; c < 3; c++) J.a[c] = c < ncomp ? W.upred[0][i0][c] : nullptr, J.b[c] = c < ncomp ? W.upred[1][i1][c] : nullptr, J.acc[c] = (u64 *)&W.sk_dbk[pr][c];
+            });
         }
         if(p.dbg == 22) { sync(tm); return; }
         // the pairs' bits: skip flag + candidate indices from the CU's entry state (xeve_rdo_bit_cnt_cu_skip, xeve_mode.c:276-295)
@@ -318,10 +349,12 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
                 for(int i1 = 0; i1 < (isb ? p.max_cand : 1); i1++) {
                     if(isb && ((I.dup[1] >> i1) & 1)) continue;
                     const int pr = isb ? i0 * p.max_cand + i1 : i0;
-                    const long long cy = (long long)W.sk_ssd[pr][0], cu = ncomp > 1 ? (long long)W.sk_ssd[pr][1] : 0, cv = ncomp > 1 ? (long long)W.sk_ssd[pr][2] : 0;
+                    long long cy = (long long)W.sk_ssd[pr][0], cu = ncomp > 1 ? (long long)W.sk_ssd[pr][1] : 0, cv = ncomp > 1 ? (long long)W.sk_ssd[pr][2] : 0;
+                    const long long temp_ssd = cy + cu + cv;
+                    if(p.rdo_dbk) cy += (long long)W.sk_dbk[pr][0], cu += ncomp > 1 ? (long long)W.sk_dbk[pr][1] : 0, cv += ncomp > 1 ? (long long)W.sk_dbk[pr][2] : 0;
                     double cost = (double)cy + (p.wgt[0] * (double)cu) + (p.wgt[1] * (double)cv);
                     cost += (double)sbits[k * 16 + pr] * p.lambda[0];
-                    if(cost < cost_best) cost_best = cost, b0 = i0, b1 = i1, best_ssd = cy + cu + cv;
+                    if(cost < cost_best) cost_best = cost, b0 = i0, b1 = i1, best_ssd = temp_ssd;
                 }
             }
             I.cost_inter[M_SKIP] = cost_best;

@@ -180,6 +180,16 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
     sync(tm), mark(tm, p, S, PR_I_LIST);
     // G: the luma RDO of the list (:604-637; pintra_residue_rdo mode 0)
     blocks_chain(tm, p, S, S.blk, nC * 5, log2n, 0);
+    if(p.rdo_dbk) { // rdo_dbk_switch (xeve_pintra.c:131-149): the loop filter's share of every candidate's luma distortion (an intra CU: the strongest filter class)
+        dbk_stage(tm, p, nC * 5, log2n, [&](int j, DbkJob &J) {
+            Blk &B = S.blk[j];
+            const int *sh = S.sh[j / 5];
+            J.on = B.on, J.pic = sh[SH_PIC], J.x = sh[SH_X], J.y = sh[SH_Y], J.intra = 1, J.cbf = B.nnz != 0, J.two = 0, J.refi[0] = J.refi[1] = -1;
+            J.mv[0] = J.mv[1] = J.mv[2] = J.mv[3] = 0;
+            J.a[0] = B.rec, J.a[1] = J.a[2] = nullptr, J.b[0] = J.b[1] = J.b[2] = nullptr, J.acc[0] = &B.ssd[1], J.acc[1] = J.acc[2] = nullptr;
+        });
+        sync(tm);
+    }
     coder_stage<FULL>(
         tm, S, nC * 5,
         [&](int j, const Sbac *&in, Sbac *&out) {
@@ -242,6 +252,18 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
         }
         sync(tm), mark(tm, p, S, PR_I_CPRED);
         blocks_chain(tm, p, S, cb, nC * 2, lc, 0); // pintra_residue_rdo mode 1 (:150-269)
+        if(p.rdo_dbk) { // (:244-263) the chroma blocks' share; kept apart from their SSD: it enters the cost as delta x weight (ssd[0] of a chroma block is unused here)
+            for(int i = tm.tid; i < nC * 2; i += tm.n) cb[i].ssd[0] = 0;
+            sync(tm);
+            dbk_stage(tm, p, nC, log2n, [&](int k, DbkJob &J) {
+                const int *sh = S.sh[k];
+                J.on = sh[SH_ON], J.pic = sh[SH_PIC], J.x = sh[SH_X], J.y = sh[SH_Y], J.intra = 1, J.cbf = 0, J.two = 0, J.refi[0] = J.refi[1] = -1;
+                J.mv[0] = J.mv[1] = J.mv[2] = J.mv[3] = 0;
+                J.a[0] = nullptr, J.a[1] = cb[k * 2].rec, J.a[2] = cb[k * 2 + 1].rec, J.b[0] = J.b[1] = J.b[2] = nullptr;
+                J.acc[0] = nullptr, J.acc[1] = &cb[k * 2].ssd[0], J.acc[2] = &cb[k * 2 + 1].ssd[0];
+            });
+            sync(tm);
+        }
     }
     // I: the CU's cost (:679-695): the whole syntax from the entry state; its exit state is core->s_temp_best
     coder_stage<FULL>(
@@ -266,6 +288,7 @@ template <bool FULL> XW void intra_node(const Tm &tm, const P &p, Lds &S, int c0
                 double d = 0;
                 d += p.wgt[0] * (double)(int64_t)cb[k * 2].ssd[1];
                 d += p.wgt[1] * (double)(int64_t)cb[k * 2 + 1].ssd[1];
+                if(p.rdo_dbk) d += ((double)(int64_t)cb[k * 2].ssd[0] * p.wgt[0]) + ((double)(int64_t)cb[k * 2 + 1].ssd[0] * p.wgt[1]);
                 dist_c = (int)d;
             }
             const int dist_y = W.ires.dist_cu;

@@ -88,7 +88,7 @@ inline void fill_params(P &q, const xeve_hip_pel *const org[3], int s_org_l, int
     const int idc = ip.chroma_format_idc, bd = ip.bit_depth;
     q.nchains = nchains, q.log2_ctu = p->log2_ctu, q.pic_w = p->pic_w, q.pic_h = p->pic_h, q.w_scu = ip.w_scu, q.h_scu = ip.h_scu, q.max_cu = p->max_cu, q.min_cu = p->min_cu;
     q.min_cuwh = p->min_cuwh, q.idc = idc, q.ws = idc <= 2, q.hs = idc <= 1, q.bd = bd, q.slice_type = ip.slice_type, q.slice_qp = p->slice_qp, q.slice_num = p->slice_num;
-    q.cip = ip.constrained_intra_pred != 0;
+    q.cip = ip.constrained_intra_pred != 0, q.rdo_dbk = p->rdo_dbk != 0;
     q.s_org_l = s_org_l, q.s_org_c = s_org_c, q.s_mod_l = s_mod_l, q.s_mod_c = s_mod_c;
     q.org_pic_l = pic_elems ? pic_elems[0] : 0, q.org_pic_c = pic_elems ? pic_elems[1] : 0, q.mod_pic_l = pic_elems ? pic_elems[2] : 0;
     q.mod_pic_c = pic_elems ? pic_elems[3] : 0, q.map_pic = pic_elems ? pic_elems[4] : 0;
