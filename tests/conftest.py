@@ -19,6 +19,14 @@ GPU_FILE_ORDER = [
     "test_integration_ref", "test_e2e_real_sizes", "test_enc_gpu",
 ]
 GPU_FULL = os.environ.get("XEVE_GPU_FULL") == "1"
+# in-encoder route tests (tests/test_integration_ref.py) that repeat a route on a second or third small clip: 57 s of the default suite for no further row
+GPU_FULL_REPEATS = {
+    "test_bitstream_identical_with_raster_search_and_integer_refinement_on_the_gpu[jumpy_ldb_fast-me_env1]",
+    "test_bitstream_identical_with_deblocking_and_padding_on_the_gpu[tiny_ra_medium]", "test_bitstream_identical_with_deblocking_and_padding_on_the_gpu[tiny_ldb_fast]",
+    "test_bitstream_identical_with_rdoq_on_the_gpu[tiny_ra_medium]", "test_bitstream_identical_with_cabac_bit_counting_on_the_gpu[tiny_ldb_fast]",
+    "test_bitstream_identical_with_hip_tables_installed[tiny_ldb_fast]", "test_bitstream_identical_with_cu_prediction_on_the_gpu[tiny_ldb_fast]",
+    "test_bitstream_identical_with_everything_on_the_gpu[tiny_ldb_fast_2threads]",
+}
 
 
 def pytest_configure(config):
@@ -38,6 +46,9 @@ def pytest_collection_modifyitems(config, items):
         stem = os.path.splitext(os.path.basename(str(it.fspath)))[0]
         return (1 if it.get_closest_marker("gpu_last") else 0, rank.get(stem, len(rank)), i)
 
+    for it in items:
+        if it.name in GPU_FULL_REPEATS and "test_integration_ref" in str(it.fspath):
+            it.add_marker(pytest.mark.gpu_full)
     items[:] = [it for _, it in sorted(enumerate(items), key=key)]
     if not GPU_FULL:
         skip = pytest.mark.skip(reason="gpu_full: runs with XEVE_GPU_FULL=1 (kept out of the default GPU suite to fit the driver's window)")
