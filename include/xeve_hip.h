@@ -752,10 +752,11 @@ typedef struct xeve_hip_tree_params {
     xeve_hip_intra_params ip;   /* what every CU's intra analysis gets (log2_cuw / log2_cuh are set per node) */
     int32_t pic_w, pic_h;       /* ctx->w, ctx->h */
     int32_t log2_ctu;           /* ctx->log2_max_cuwh (3 .. 6) */
-    int32_t max_cu, min_cu;     /* ctx->param.max_cu_intra, min_cu_intra (samples) */
+    int32_t max_cu, min_cu;     /* ctx->param.max_cu_intra, min_cu_intra in an I slice, max_cu_inter, min_cu_inter otherwise (samples; xeve_mode.c:2047-2054).  min_cu 4 in
+                                   an inter slice (preset placebo: 4x4 inter CUs): fused walk only */
     int32_t min_cuwh;           /* ctx->min_cuwh */
     int32_t slice_qp, slice_num;/* ctx->tile[].qp (the QP field of map_scu), ctx->slice_num */
-    int32_t rdo_dbk;            /* ctx->param.rdo_dbk_switch (preset slow): every candidate's distortion includes what the loop filter will do to its left / top
+    int32_t rdo_dbk;            /* ctx->param.rdo_dbk_switch (presets slow, placebo): every candidate's distortion includes what the loop filter will do to its left / top
                                    boundary (calc_delta_dist_filter_boundary, xeve_mode.c:1534-2005).  Fused walk only: the composed walk refuses 1 */
 } xeve_hip_tree_params;
 typedef struct xeve_hip_ctu_job {
@@ -873,7 +874,8 @@ int xeve_hip_eco_tile_end_jobs(xeve_hip_sbac *states, int nstates, const xeve_hi
 /* (the concatenation of the runs is the bitstream of the whole sequence); the    */
 /* runs advance in lockstep through the device entry points above (CTU mode decision -> writer    */
 /* -> tile end -> loop filter -> padding), every picture resident in HBM.  Baseline profile,      */
-/* constant QP, presets fast / medium, 4:2:0, 8-bit input coded at 10 bits -- the application's    */
+/* constant QP, all four presets (slow and placebo on the fused CTU walk: rdo_dbk_switch and     */
+/* 4x4 inter CUs live there), 4:2:0, 8- or 10-bit input coded at 10 bits -- the application's      */
 /* defaults.  `threads` is the reference's -m: the CTU-row chains of a picture (the bitstream     */
 /* depends on it, as the reference's does).                                                       */
 /* ------------------------------------------------------------------------------------------- */
@@ -884,12 +886,13 @@ typedef struct xeve_hip_enc_config {
     int32_t keyint;           /* -I */
     int32_t bframes;          /* -b: 0, 1, 3, 7, 15 */
     int32_t closed_gop;       /* --closed-gop */
-    int32_t preset;           /* 0 fast, 1 medium */
+    int32_t preset;           /* 0 fast, 1 medium, 2 slow, 3 placebo (xeve_param_apply_ppt_baseline, xeve_enc.c:2431-2506) */
     int32_t threads;          /* -m: 1 .. 8 */
     int32_t inter_slice_type; /* --inter-slice-type: 0 B, 1 P */
     int32_t ref;              /* --ref (0: the preset's) */
     int32_t reserved[4];      /* [0] bit 0: always run the second writer pass (tests); bit 1: the application's --info 0 (no SEI with the option list); bits 8-15: --level-idc (0: 40).  [1]: the application's -d, the input's bit depth -- 0 / 8: one byte per sample;
-                               * 10: 16-bit little-endian samples (frames pushed are twice as long).  Either way the codec works at 10 bits (--codec-bit-depth).  [2], [3]: chroma qp offsets; must be 0 (the application cannot set them: unpinned). */
+                               * 10: 16-bit little-endian samples (frames pushed are twice as long).  Either way the codec works at 10 bits (--codec-bit-depth).  [2], [3]: --qp-cb-offset / --qp-cr-offset, -12 .. 12
+                               * (pinned against the reference LIBRARY: the application lists the options and cannot parse them; 0 with presets slow / placebo). */
 } xeve_hip_enc_config;
 typedef struct xeve_hip_enc xeve_hip_enc;
 /* A batch of `ngops` runs of `frames` pictures each.  NULL + xeve_hip_last_error() when the configuration is outside the supported set or HBM does not hold the batch. */

@@ -41,6 +41,17 @@ SLOW_CASES = {
     "slow_jumpy_ldb": (192, 128, 4, 6001, ["--preset", "slow", "-I", "0", "-b", "0"]),
 }
 
+# --preset placebo (xeve_enc.c:2490-2506): on top of preset slow, 4x4 CUs in inter slices (inter AND intra analysis of every 4x4 node), 64x64 intra CUs in I slices, two
+# reference pictures per list, the raster search behind the first diamond (me_algo 2), ME range 384, eight half- and quarter-pel positions, four merge candidates.
+PLACEBO_CASES = {
+    "placebo_tiny_ldb": (128, 128, 3, 7, ["--preset", "placebo", "-I", "0", "-b", "0"]),  # noise: 4x4 inter CUs are chosen
+    "placebo_moving_ra_b3": (128, 64, 9, 5004, ["--preset", "placebo", "-b", "3"]),  # hierarchical B pictures, the range scaled by the POC distance
+    "placebo_moving_ldb_2threads": (128, 128, 3, 5002, ["--preset", "placebo", "-I", "0", "-b", "0", "-m", "2"]),
+    "placebo_cif_closed_gop": (352, 288, 4, 5006, ["--preset", "placebo", "--closed-gop", "-I", "4", "-b", "3"]),  # partial CTUs at the right and bottom edge
+    "placebo_noise_allintra": (128, 128, 2, 11, ["--preset", "placebo", "-I", "1", "-b", "0"]),  # 64x64 intra CUs in I slices
+    "placebo_jumpy_ldb": (192, 128, 4, 6001, ["--preset", "placebo", "-I", "0", "-b", "0"]),  # 23 x 17 samples of motion per frame: the raster search runs
+}
+
 # BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes (first frames only): goldens are made by tests/golden/make_e2e_golden.py from the reference app; the
 # GPU suite encodes them once with the whole inter analysis served by the GPU (tests/test_e2e_real_sizes.py).  Not part of CASES: the CPU suite does not re-encode them.
 REAL_CASES = {

@@ -24,7 +24,7 @@ def config(w, h, cli, threads=1):
     while i < len(cli):
         a = cli[i]
         if a == "--preset":
-            c.preset = {"fast": 0, "medium": 1, "slow": 2}[cli[i + 1]]
+            c.preset = {"fast": 0, "medium": 1, "slow": 2, "placebo": 3}[cli[i + 1]]
         elif a == "-I":
             c.keyint = int(cli[i + 1])
         elif a == "-b":
@@ -179,6 +179,11 @@ HEADER_OPTION_CASES = {
 SLOW_BATCH_CASES = {
     "slow_gops_192x128_moving_m3": (192, 128, 3, 4, 5041, ["--preset", "slow", "--closed-gop", "-I", "4", "-b", "3"], 3),
     "slow_gops_256x192_noise_m8": (256, 192, 2, 2, 43, ["--preset", "slow", "--closed-gop", "-I", "8"], 8),
+}
+# --preset placebo the same way (4x4 inter CUs, two reference pictures per list, raster search, four merge candidates)
+PLACEBO_BATCH_CASES = {
+    "placebo_gops_192x128_moving_m3": (192, 128, 3, 4, 5047, ["--preset", "placebo", "--closed-gop", "-I", "4", "-b", "3"], 3),
+    "placebo_gops_256x192_noise_m8": (256, 192, 2, 2, 48, ["--preset", "placebo", "--closed-gop", "-I", "8"], 8),
 }
 _PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
 

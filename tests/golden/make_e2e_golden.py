@@ -7,14 +7,14 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _e2e import CASES, REAL_CASES, SLOW_CASES, make_yuv, run_app  # noqa: E402
+from _e2e import CASES, PLACEBO_CASES, REAL_CASES, SLOW_CASES, make_yuv, run_app  # noqa: E402
 
 # usage: make_e2e_golden.py [case names ...] -- without names every case is (re)made; with names only those, merged into the existing file
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "e2e_v1.json")
 only = sys.argv[1:]
 out = json.load(open(PATH)) if only else {}
 with tempfile.TemporaryDirectory() as d:
-    for name, (w, h, n, seed, extra) in list(CASES.items()) + list(REAL_CASES.items()) + list(SLOW_CASES.items()):
+    for name, (w, h, n, seed, extra) in list(CASES.items()) + list(REAL_CASES.items()) + list(SLOW_CASES.items()) + list(PLACEBO_CASES.items()):
         if only and name not in only:
             continue
         yuv = os.path.join(d, name + ".yuv")

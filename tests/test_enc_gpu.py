@@ -139,11 +139,39 @@ def test_preset_slow_batches_on_the_gpu(name, team, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("name", sorted(_e2e.PLACEBO_CASES))
+def test_preset_placebo_single_runs_on_the_gpu(name, hip, yuv_dir):
+    """--preset placebo on the device (the fused walk): inter CUs of 4x4 beside the intra analysis of every 4x4 node, 64x64 intra CUs in I slices, two reference pictures
+    per list, the raster search, ME range 384, eight sub-pel positions per stage, four merge candidates, rdo_dbk_switch = the reference application's bitstreams"""
+    w, h, n, seed, cli = _e2e.PLACEBO_CASES[name]
+    threads = int(cli[cli.index("-m") + 1]) if "-m" in cli else 1
+    cli = [a for i, a in enumerate(cli) if a != "-m" and (i == 0 or cli[i - 1] != "-m")]
+    out, _ = _run(hip, _cfg(hip, w, h, cli, threads), [_frames(yuv_dir, name, w, h, n, seed)], n)
+    assert (len(out[0]), _enc.md5(out[0])) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("team", [0, 3], ids=["one_chain_per_team", "three_chains_per_team"])
+@pytest.mark.parametrize("name", sorted(_enc.PLACEBO_BATCH_CASES))
+def test_preset_placebo_batches_on_the_gpu(name, team, hip, yuv_dir):
+    w, h, gops, frames, seed, cli, threads = _enc.PLACEBO_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    with hip.walk_select(-1, team):
+        outs, _ = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_preset_slow_is_refused_where_the_fused_walk_is_switched_off(hip):
     import xeve_amd
 
     with hip.walk_select(0):
         enc = hip.BatchEncoder(hip.config(128, 64, keyint=4, bframes=3, closed_gop=True, preset="slow"), 1, 2)
+        for f in range(2):
+            enc.push(0, f, bytes(128 * 64 * 3 // 2))
+        with pytest.raises(xeve_amd.XeveHipError, match="fused walk"):
+            enc.encode()
+        enc.close()
+        enc = hip.BatchEncoder(hip.config(128, 64, bframes=0, preset="placebo"), 1, 2)  # (its I picture is the composed walk's to code; the 4x4 inter CUs of the next are not)
         for f in range(2):
             enc.push(0, f, bytes(128 * 64 * 3 // 2))
         with pytest.raises(xeve_amd.XeveHipError, match="fused walk"):

@@ -109,6 +109,27 @@ def test_preset_slow_batches_of_closed_gops(name, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+@pytest.mark.parametrize("name", sorted(_e2e.PLACEBO_CASES))
+def test_preset_placebo_single_runs(name, yuv_dir):
+    """--preset placebo: preset slow plus 4x4 CUs in inter slices (both analyses at every 4x4 node: 2x2 chroma blocks, the 4x4 SAD and Hadamard), 64x64 intra CUs in I
+    slices, two reference pictures per list, the raster search behind the first diamond, ME range 384, eight sub-pel positions per stage, four merge candidates --
+    the reference application's bitstreams"""
+    w, h, n, seed, cli = _e2e.PLACEBO_CASES[name]
+    threads = int(cli[cli.index("-m") + 1]) if "-m" in cli else 1
+    cli = [a for i, a in enumerate(cli) if a != "-m" and (i == 0 or cli[i - 1] != "-m")]
+    out = _enc.encode_cpu(_enc.config(w, h, cli, threads), [_frames(yuv_dir, name, w, h, n, seed)], n)[0]
+    assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("name", sorted(_enc.PLACEBO_BATCH_CASES))
+def test_preset_placebo_batches_of_closed_gops(name, yuv_dir):
+    w, h, gops, frames, seed, cli, threads = _enc.PLACEBO_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_preset_slow_with_chroma_qp_offsets_is_refused():
     c = _enc.config(128, 64, ["--preset", "slow", "--qp-cb-offset", "2"])
     with pytest.raises(RuntimeError, match="chroma qp offsets"):
@@ -222,7 +243,7 @@ def test_flushing_after_every_picture_changes_no_byte_and_cuts_at_access_units(n
 
 
 def test_configurations_outside_the_supported_set_are_refused():
-    for bad in (dict(w=130), dict(preset=3), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
+    for bad in (dict(w=130), dict(preset=4), dict(preset=-1), dict(bframes=2), dict(threads=9), dict(inter_slice_type=2)):
         c = _enc.config(128, 64, ["--preset", "fast"])
         for k, v in bad.items():
             setattr(c, k, v)

@@ -217,6 +217,27 @@ def test_walk_decides_every_ctu_at_preset_slow(name, walk_engine, tmp_path_facto
     assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
 
 
+@pytest.mark.parametrize("name", sorted(_e2e.PLACEBO_CASES))
+def test_walk_decides_every_ctu_at_preset_placebo(name, walk_engine, tmp_path_factory):
+    """--preset placebo through the fused walk's host side: inter CUs of 4x4 (the search's 4-sample rows, 2x2 chroma blocks, the 4x4 Hadamard of the winner), two reference
+    pictures per list, the raster search (CT_GRID rounds), the diamond's rings up to 256 of a range of 384, 64x64 intra CUs in I slices, four merge candidates = 16 pairs"""
+    E2E = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "e2e_v1.json")))
+    w, h, n, seed, cli = _e2e.PLACEBO_CASES[name]
+    threads = int(cli[cli.index("-m") + 1]) if "-m" in cli else 1
+    cli = [a for i, a in enumerate(cli) if a != "-m" and (i == 0 or cli[i - 1] != "-m")]
+    out = _enc.encode_cpu(_enc.config(w, h, cli, threads), [_clip(str(tmp_path_factory.getbasetemp()), name, w, h, n, seed)], n)[0]
+    assert (len(out), _enc.md5(out)) == (E2E[name]["bytes"], E2E[name]["md5"])
+
+
+@pytest.mark.parametrize("name", sorted(_enc.PLACEBO_BATCH_CASES))
+def test_walk_decides_every_ctu_of_a_preset_placebo_batch(name, walk_engine, tmp_path_factory):
+    w, h, gops, frames, seed, cli, threads = _enc.PLACEBO_BATCH_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _clip(str(tmp_path_factory.getbasetemp()), name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs = _enc.encode_cpu(_enc.config(w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 def test_walk_decides_every_ctu_of_a_preset_slow_batch(walk_engine, tmp_path_factory):
     name = "slow_gops_192x128_moving_m3"
     w, h, gops, frames, seed, cli, threads = _enc.SLOW_BATCH_CASES[name]

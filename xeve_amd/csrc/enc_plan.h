@@ -28,7 +28,7 @@ enum { PAD_L = 144, PAD_C = 72, BIT_DEPTH = 10, LOG2_CTU = 6, CTU = 64, MAX_ACTI
 // ---- encoder parameters: xeve_param_init (xeve_enc.c:2290-2324) + xeve_param_apply_ppt_baseline (:2431-2531) + xeve_set_init_param (:2210-2288) -----------------------
 struct Param {
     int w = 0, h = 0, fps_num = 30, fps_den = 1, qp = 32, keyint = 0, bframes = 15, closed_gop = 0, threads = 1, inter_slice_type = 0, ref = 0;
-    int preset = 1; // 0 fast, 1 medium
+    int preset = 1; // 0 fast, 1 medium, 2 slow, 3 placebo
     int qp_cb_offset = 0, qp_cr_offset = 0; // --qp-cb-offset / --qp-cr-offset (sh->qp_u_offset / qp_v_offset, xeve_enc.c:1509-1510)
     int level_idc = 40, sei_info = 1; // --level-idc (sps->level_idc = 3 x, xeve_enc.c:1402) and --info (the SEI that lists the options, :1989)
     int input_depth = 8; // the application's -d: 8 = one byte per sample, 10 = 16-bit little-endian samples (both go to the codec's 10 bits, xeve_app.c:1153-1158)
@@ -62,8 +62,10 @@ struct Param {
         if(preset == 0) me_range = 32, me_sub_pos = 2, merge_num = 2;
         else if(preset == 1) me_range = 64, me_sub_pos = 4, merge_num = 3;
         else if(preset == 2) me_range = 128, me_sub = 3, me_sub_pos = 4, me_sub_range = 2, merge_num = 3, rdo_dbk = 1; // slow (xeve_enc.c:2473-2489): quarter-pel search, rdo_dbk_switch
-        else return bad("preset must be 0 (fast), 1 (medium) or 2 (slow): placebo needs 4x4 inter CUs, 64x64 intra CUs and a second reference picture per list");
-        if(rdo_dbk && (qp_cb_offset || qp_cr_offset)) return bad("preset slow with chroma qp offsets: the loop filter's share of the chroma distortions is coded for offsets of 0 only (walk_dbk.h)");
+        else if(preset == 3) // placebo (xeve_enc.c:2490-2506): 64x64 intra CUs in I slices, 4x4 CUs in inter slices, two reference pictures per list, the raster search
+            max_cu_intra = 64, min_cu_inter = 4, me_ref_num = 2, me_algo = 2, me_range = 384, me_sub = 3, me_sub_pos = 8, me_sub_range = 3, merge_num = 4, rdo_dbk = 1;
+        else return bad("preset must be 0 (fast), 1 (medium), 2 (slow) or 3 (placebo)");
+        if(rdo_dbk && (qp_cb_offset || qp_cr_offset)) return bad("presets slow / placebo with chroma qp offsets: the loop filter's share of the chroma distortions is coded for offsets of 0 only (walk_dbk.h)");
 #ifdef XENC_TEST_OVERRIDES // (the CPU harness only: a preset taken apart, against the reference library pinned the same way -- oracle/ref_param_pin.c)
         if(getenv("XO_PIN_RDO_DBK")) rdo_dbk = atoi(getenv("XO_PIN_RDO_DBK"));
         if(getenv("XO_PIN_ME_SUB")) me_sub = atoi(getenv("XO_PIN_ME_SUB"));

@@ -478,8 +478,9 @@ static bool tree_params_ok(const xeve_hip_tree_params *p)
     return true;
 }
 static bool tree_inter_ok(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I)
-{   // the inter analysis is composed for square CUs 8 .. 64 (every inter CU of the Baseline quad-tree at the presets that keep min_cu_inter at 8)
-    return I && (p->ip.slice_type == 0 || p->ip.slice_type == 1) && p->min_cu >= 8 && I->refp && I->map_mv && I->map_refi && I->col_mv0 && I->coef_l && I->coef_c &&
+{   // (the composed inter analysis covers square CUs 8 .. 64 -- every inter CU of the Baseline quad-tree at the presets that keep min_cu_inter at 8; 4x4 inter CUs
+    // -- preset placebo -- are the fused walk's: xh_walk_only)
+    return I && (p->ip.slice_type == 0 || p->ip.slice_type == 1) && p->min_cu >= 4 && I->refp && I->map_mv && I->map_refi && I->col_mv0 && I->coef_l && I->coef_c &&
            (p->ip.slice_type == 1 || I->col_mv1) && I->ipar.rdo.slice_type == p->ip.slice_type && I->ipar.rdo.pic_w == p->pic_w && I->ipar.rdo.pic_h == p->pic_h &&
            I->ipar.rdo.chroma_format_idc == p->ip.chroma_format_idc && I->ipar.rdo.bit_depth == p->ip.bit_depth &&
            // what xeve_hip_pinter_analyze_cu_jobs requires of its parameters (inter.hip inter_params_ok), checked HERE so that both walks refuse the same calls: the fused
@@ -572,14 +573,14 @@ extern "C" size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hi
     if(!tree_params_ok(p) || nchains <= 0 || (p->ip.slice_type != 2 && !tree_inter_ok(p, I))) return 0;
     if(p->ip.slice_type == 2) I = nullptr;
     if(xh_walk_supported(p, I, nchains)) return xh_walk_workspace(nchains);
-    if(p->rdo_dbk) { xh_set_error("rdo_dbk_switch (preset slow) runs on the fused walk only: it is switched off (XEVE_HIP_WALK=0 / xeve_hip_walk_select) or does not take these parameters"); return 0; }
+    if(xh_walk_only(p)) { xh_set_error("rdo_dbk_switch and 4x4 inter CUs (presets slow, placebo) run on the fused walk only: it is switched off (XEVE_HIP_WALK=0 / xeve_hip_walk_select) or does not take these parameters"); return 0; }
     return tree_layout(nchains, p, I, s_org_l, s_org_c).total;
 }
 extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *p)
 {
     if(!tree_params_ok(p) || nchains <= 0 || p->ip.slice_type != 2) return 0;
     if(xh_walk_supported(p, nullptr, nchains)) return xh_walk_workspace(nchains);
-    if(p->rdo_dbk) return 0;
+    if(xh_walk_only(p)) return 0;
     return tree_layout(nchains, p, nullptr, 0, 0).total;
 }
 
@@ -680,8 +681,8 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     if(nchains == 0) return XEVE_HIP_OK;
     // which walk: by the WIDTH OF THE BATCH the call belongs to (the caller's state records: every chain of every GOP), not by the chains this step carries -- the ramp
     // steps of a wide batch's pictures stay on the composed walk (a long-running fused launch between the other streams' short kernels cost 7 %, profiles/r04_walks.md)
-    // rdo_dbk_switch (preset slow) lives in the fused walk alone (walk_dbk.h): the composed walk's stages do not estimate the loop filter's share
-    XH_REQUIRE(!p->rdo_dbk || xh_walk_supported(p, I, std::max(nchains, nstates)));
+    // rdo_dbk_switch and 4x4 inter CUs (presets slow, placebo) live in the fused walk alone (walk_dbk.h, walk_inter.h): the composed walk's stages do neither
+    XH_REQUIRE(!xh_walk_only(p) || xh_walk_supported(p, I, std::max(nchains, nstates)));
     if(xh_walk_supported(p, I, std::max(nchains, nstates))) // the fused walk: the whole schedule inside one kernel (walk.hip)
         return xh_walk_run(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost,
                            workspace, workspace_bytes, vh, (hipStream_t)stream);

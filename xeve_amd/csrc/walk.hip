@@ -119,16 +119,17 @@ extern "C" int xeve_hip_walk_select(int mode)
 }
 bool xh_walk_supported(const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int nchains)
 {
-    // (rdo_dbk_switch is the fused walk's alone: whatever the width, unless the composed walk is pinned -- then the call is refused, tree.hip)
-    if(p->rdo_dbk ? g_walk_mode.load(std::memory_order_relaxed) == 0 : !xh_walk_enabled(nchains)) return false;
+    // (rdo_dbk_switch and inter CUs of 4x4 -- presets slow and placebo -- are the fused walk's alone: whatever the width, unless the composed walk is pinned -- then the
+    // call is refused, tree.hip)
+    if(xh_walk_only(p) ? g_walk_mode.load(std::memory_order_relaxed) == 0 : !xh_walk_enabled(nchains)) return false;
     if(p->ip.slice_type != 2 && I) {
         static const int inter_on = getenv("XEVE_HIP_WALK_INTER") ? atoi(getenv("XEVE_HIP_WALK_INTER")) : 1;
         if(!inter_on) return false;
         const int n0 = I->ipar.rdo.num_refp[0], n1 = I->ipar.rdo.num_refp[1];
         if(n0 > XW_MAXR || n1 > XW_MAXR) return false;
-        // a diamond's remaining rings are one round of the fused search (walk_inter.h dia_round: 5 + 9 + 16 per doubling of the step from 16 on): they fit MeJob::cx[96] up
-        // to a range of 256; beyond it the composed walk runs the call
-        if(I->ipar.me.me.max_search_range > 256) return false;
+        // a diamond's remaining rings are one round of the fused search (walk_inter.h dia_round: 5 + 9 + 16 per doubling of the step from 16 on, 94 candidates for the
+        // steps 4 .. 256): they fit MeJob::cx[96] while the range stays below 512 (placebo's 384 has the rings of 256); beyond it the composed walk runs the call
+        if(I->ipar.me.me.max_search_range > 511) return false;
     }
     return p->log2_ctu <= 6;
 }

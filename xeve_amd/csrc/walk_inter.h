@@ -476,10 +476,11 @@ XW int me_cand_sad_part(const P &p, const MeJob &J, int i, int N, int part, int 
     int mx, my;
     cand_xy(J, i, mx, my);
     int sad = 0;
-    if(J.ctype != CT_SPEL && parts > N / 8) { // (a round that mixes sub-pel and integer searches is cut for the sub-pel ones: whole groups of 8 rows here)
-        const int g = parts / (N / 8);
+    const int groups = N >= 8 ? N / 8 : 1; // (rows of an integer position go in groups of 8; a 4x4 CU is one group)
+    if(J.ctype != CT_SPEL && parts > groups) { // (a round that mixes sub-pel and integer searches is cut for the sub-pel ones: whole groups of rows here)
+        const int g = parts / groups;
         if(part % g) return 0;
-        part /= g, parts = N / 8;
+        part /= g, parts = groups;
     }
     const int n = N / parts, from = part * n;
     if(J.ctype == CT_SPEL) {
@@ -489,6 +490,11 @@ XW int me_cand_sad_part(const P &p, const MeJob &J, int i, int N, int part, int 
         return sad;
     }
     const pel *r = J.ref + (long)my * p.s_ref_l + mx;
+    if(N < 8) { // a 4x4 CU (preset placebo's min_cu_inter): rows of four samples
+        for(int yy = from; yy < from + n; yy++)
+            for(int xx = 0; xx < N; xx++) sad += iabs((int)J.org[(long)yy * J.so + xx] - (int)r[(long)yy * p.s_ref_l + xx]);
+        return sad;
+    }
 #if XW_DEVICE
     { // four rows at a time, their loads issued together (v_sad_u16 is unsigned: a bi search's org_bi is biased together with the reference)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -560,7 +566,7 @@ XW_ST void me_run(const Tm &tm, const P &p, Lds &S, int nj, int log2n)
             if(S.mbits[e] < 0) continue;
             aadd(&msad[e], me_cand_sad_part(p, J, c, N, part, parts));
 #if XW_DEVICE
-            if(p.sad_units) atomicAdd(p.sad_units + (blockIdx.x & 255), (u64)(N * N / (J.ctype != CT_SPEL && parts > N / 8 ? N / 8 : parts))); // (roofline: algorithmic work)
+            if(p.sad_units) atomicAdd(p.sad_units + (blockIdx.x & 255), (u64)(N * N / (J.ctype != CT_SPEL && parts > (N >= 8 ? N / 8 : 1) ? (N >= 8 ? N / 8 : 1) : parts))); // (roofline: algorithmic work)
 #endif
         }
         sync(tm);

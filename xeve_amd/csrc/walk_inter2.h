@@ -629,12 +629,12 @@ template <bool FULL> XW void inter_node(const Tm &tm, const P &p, Lds &S, int c0
         st_recon(tm, p, wb, nC, log2n);
         if(ncomp > 1) st_recon(tm, p, wb + nC, 2 * nC, log2n - p.ws);
         // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
-        const int tl = N / 8, tiles = tl * tl;
+        const int tn = N >= 8 ? 8 : 4, tl = N / tn, tiles = tl * tl; // (a 4x4 CU is one 4x4 tile, xeve_had_4x4)
         for(int i = tm.tid; i < nC * tiles; i += tm.n) {
-            const int k = i / tiles, t = i - k * tiles, ty = (t / tl) * 8, tx = (t % tl) * 8;
+            const int k = i / tiles, t = i - k * tiles, ty = (t / tl) * tn, tx = (t % tl) * tn;
             const Blk &B = wb[k];
             if(!B.on) continue;
-            aadd(&S.acc[k * XW_ACC], had_tile(B.org + (long)ty * B.s_org + tx, B.s_org, B.pred + ty * N + tx, N, 8));
+            aadd(&S.acc[k * XW_ACC], had_tile(B.org + (long)ty * B.s_org + tx, B.s_org, B.pred + ty * N + tx, N, tn));
         }
         sync(tm);
     }

@@ -123,6 +123,10 @@ __host__ __device__ __forceinline__ int xh_vh_base(int y, int vh) { return vh > 
 // (any offset, odd ones too) carry no mark and mean what include/xeve_hip.h says.  Consumers decode a record once (xh_job) and use the decoded fields.
 #define XH_OFF2_HALF 0x40000000
 #define XH_FRAC_HALF 0x100
+// what only the fused CTU walk (walk.hip) codes: rdo_dbk_switch (the loop filter's share of the distortions, walk_dbk.h) and inter CUs of 4x4 (min_cu_inter 4) --
+// presets slow and placebo.  The composed walk's stage kernels cover square inter CUs of 8 .. 64 without the filter estimate.
+inline bool xh_walk_only(const xeve_hip_tree_params *p) { return p->rdo_dbk != 0 || (p->ip.slice_type != 2 && p->min_cu < 8); }
+
 struct XhJob {
     size_t off1; // element offset into plane 1 (the original)
     int    off2; // element offset into plane 2

@@ -5,7 +5,7 @@ import ctypes as C
 
 from . import lib as _lib
 
-PRESETS = {"fast": 0, "medium": 1, "slow": 2}
+PRESETS = {"fast": 0, "medium": 1, "slow": 2, "placebo": 3}
 
 
 def config(w, h, qp=32, keyint=0, bframes=15, closed_gop=False, preset="medium", threads=1, fps=(30, 1), ref=0, always_second_pass=False, input_depth=8, level_idc=40, sei_info=True,
