@@ -185,6 +185,11 @@ PLACEBO_BATCH_CASES = {
     "placebo_gops_192x128_moving_m3": (192, 128, 3, 4, 5047, ["--preset", "placebo", "--closed-gop", "-I", "4", "-b", "3"], 3),
     "placebo_gops_256x192_noise_m8": (256, 192, 2, 2, 48, ["--preset", "placebo", "--closed-gop", "-I", "8"], 8),
 }
+# presets slow and placebo at BASELINE's 1920x1080 with the reference's maximum of 8 row chains (GPU suite only): noise for slow, the drifting texture for placebo
+PRESET_REAL_CASES = {
+    "slow_1080p_noise_3f_m8": (1920, 1080, 1, 3, 3, ["--preset", "slow", "--closed-gop", "-I", "8"], 8),
+    "placebo_1080p_moving_3f_m8": (1920, 1080, 1, 3, 5049, ["--preset", "placebo", "--closed-gop", "-I", "8"], 8),
+}
 _PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
 
 

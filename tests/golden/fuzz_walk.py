@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random option sets of the supported space, each coded twice by the product's frame loop on the CPU harness (tests/_enc.py encode_cpu): every CTU decided by the pinned
 oracle, and every CTU decided by the HOST side of the fused walk (xeve_amd/csrc/walk.h, the code libxeve_hip.so runs as one kernel per step).  Any difference between the
-two bitstreams is printed.  No reference needed (runs anywhere the CPU suite runs).  usage: fuzz_walk.py [count] [seed] [big]"""
+two bitstreams is printed.  No reference needed (runs anywhere the CPU suite runs).  usage: fuzz_walk.py [count] [seed] [big|small] [presets, comma-separated: default fast,medium,slow,placebo]"""
 import os
 import random
 import sys
@@ -14,6 +14,7 @@ from _e2e import make_yuv  # noqa: E402
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+PRESETS = sys.argv[4].split(",") if len(sys.argv) > 4 else ["fast", "medium", "slow", "placebo"]
 h_ = _enc.harness()
 bad = done = 0
 with tempfile.TemporaryDirectory() as d:
@@ -21,7 +22,8 @@ with tempfile.TemporaryDirectory() as d:
         w, h = rnd.choice([(64, 64), (128, 64), (72, 40), (136, 72), (64, 136), (128, 136), (200, 72), (136, 264)] + ([(264, 200), (320, 192), (256, 256), (352, 288)] if BIG else []))
         frames = rnd.choice([1, 2, 3, 5, 8, 9, 12, 17])
         bf = rnd.choice([0, 1, 3, 7, 15])
-        cli = ["--preset", rnd.choice(["fast", "medium"]), "-b", str(bf), "-q", str(rnd.choice([18, 27, 32, 37, 45]))]
+        preset = rnd.choice(PRESETS)
+        cli = ["--preset", preset, "-b", str(bf), "-q", str(rnd.choice([18, 27, 32, 37, 45]))]
         if rnd.random() < 0.5:
             cli += ["--closed-gop", "-I", str(rnd.choice([1, 2, 4, 5, 8, 12, 16]))]
         else:
@@ -30,7 +32,7 @@ with tempfile.TemporaryDirectory() as d:
             cli += ["--ref", str(rnd.choice([1, 2, 3]))]
         if rnd.random() < 0.3:
             cli += ["--inter-slice-type", "1"]
-        if rnd.random() < 0.3:
+        if rnd.random() < 0.3 and preset in ("fast", "medium"):  # (slow / placebo: the loop filter's share of the chroma distortions is coded for offsets of 0)
             cli += ["--qp-cb-offset", str(rnd.randint(-12, 12)), "--qp-cr-offset", str(rnd.randint(-12, 12))]
         depth10 = rnd.random() < 0.2
         if depth10:

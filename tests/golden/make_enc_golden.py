@@ -12,7 +12,7 @@ import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _e2e import make_yuv  # noqa: E402
-from _enc import BATCH_CASES, BATCH_CASES_REAL, DEPTH10_CASES, GOLDEN, HEADER_OPTION_CASES, HOST_PINNED_CASES, PLACEBO_BATCH_CASES, PLAN_GRID, SLOW_BATCH_CASES, app_args_and_env, md5, widen10  # noqa: E402
+from _enc import BATCH_CASES, BATCH_CASES_REAL, DEPTH10_CASES, GOLDEN, HEADER_OPTION_CASES, HOST_PINNED_CASES, PLACEBO_BATCH_CASES, PLAN_GRID, PRESET_REAL_CASES, SLOW_BATCH_CASES, app_args_and_env, md5, widen10  # noqa: E402
 from _libs import REF_APP  # noqa: E402
 
 ROW = re.compile(r"^(?:\[.*?\] )*(\d+)\s+(\d+)\s+\((.)\)\s+(\d+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+\d+\s+\d+\s*(.*)$")
@@ -46,7 +46,7 @@ with tempfile.TemporaryDirectory() as d:
                 assert len(rows) == n, (cli, n, rows)
                 out["plans"].append({"cli": cli, "frames": n, "rows": rows})
         print("plans:", len(out["plans"]))
-    for name, (w, h, gops, frames, seed, cli, threads) in list(BATCH_CASES.items()) + list(BATCH_CASES_REAL.items()) + list(DEPTH10_CASES.items()) + list(HOST_PINNED_CASES.items()) + list(HEADER_OPTION_CASES.items()) + list(SLOW_BATCH_CASES.items()) + list(PLACEBO_BATCH_CASES.items()):
+    for name, (w, h, gops, frames, seed, cli, threads) in list(BATCH_CASES.items()) + list(BATCH_CASES_REAL.items()) + list(DEPTH10_CASES.items()) + list(HOST_PINNED_CASES.items()) + list(HEADER_OPTION_CASES.items()) + list(SLOW_BATCH_CASES.items()) + list(PLACEBO_BATCH_CASES.items()) + list(PRESET_REAL_CASES.items()):
         if only and name not in only:
             continue
         yuv, evc = os.path.join(d, name + ".yuv"), os.path.join(d, name + ".evc")

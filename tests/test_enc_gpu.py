@@ -216,6 +216,20 @@ def test_a_wide_batch_fed_from_device_memory_keeps_every_gop_exact(hip, yuv_dir)
     assert not bad, bad[:10]
 
 
+@pytest.mark.gpu_last
+@pytest.mark.gpu_full
+@pytest.mark.parametrize("name", sorted(_enc.PRESET_REAL_CASES))
+def test_presets_slow_and_placebo_at_1920x1080_on_the_gpu(name, hip, yuv_dir):
+    """--preset slow (noise) and --preset placebo (drifting texture) at 1920x1080 with 8 row chains: 510 CTUs per picture through the fused walk's loop-filter estimate, its
+    quarter-pel and raster searches and its 4x4 inter CUs = the reference application's bitstreams.  XEVE_GPU_FULL=1 (profiles/r05i_*.log): a repeat at a larger size"""
+    w, h, gops, frames, seed, cli, threads = _enc.PRESET_REAL_CASES[name]
+    g = _enc.golden()["batches"][name]
+    data, fb = _frames(yuv_dir, name, w, h, gops * frames, seed), w * h * 3 // 2 * frames
+    outs, st = _run(hip, _cfg(hip, w, h, cli, threads), [data[i * fb:(i + 1) * fb] for i in range(gops)], frames)
+    print(name, st)
+    assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
+
+
 # BASELINE's configs at their real picture sizes (gpu_last: after every other GPU test).  The default suite has to fit the driver's 1200 s on one MI355X (tests/conftest.py),
 # so it runs the forms that add something -- config 3 over a whole 16-picture sub-GOP on the library's own choice of walk, config 2 on the COMPOSED walk (the bench's path
 # at width), the whole 8-frame 1080p GOP on the composed walk, config 4 (3840x2160) as IDR + two B pictures against the reference's per-picture prefixes -- and leaves the forms

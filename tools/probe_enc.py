@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the batch encoder in chunks of lockstep steps (device fence after every chunk): where a picture's time goes -- the steps of the I picture, of the inter
-picture, the picture ends.  usage: probe_enc.py --width W --height H --gops G --threads T --frames F --chunk N [--batches B] [--content noise|moving]"""
+picture, the picture ends.  usage: probe_enc.py --width W --height H --gops G --threads T --frames F --chunk N [--content noise|moving] [--preset P]"""
 import argparse
 import hashlib
 import json
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=25)
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many lockstep steps (0: the whole job)")
     ap.add_argument("--content", default="noise")
+    ap.add_argument("--preset", default="medium", help="fast | medium | slow | placebo (slow and placebo run on the fused walk at any width)")
     ap.add_argument("--prof-after", type=int, default=-1, help="switch the walk's in-kernel stage profile on once this many steps are done (e.g. a picture's steps: the inter picture alone)")
     a = ap.parse_args()
     import torch
@@ -32,7 +33,7 @@ def main():
     dev = torch.device("cuda", 0)
     W, H, F, G = a.width, a.height, a.frames, a.gops
     fb = W * H * 3 // 2
-    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=a.threads)
+    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset=a.preset, threads=a.threads)
     t0 = time.perf_counter()
     enc = encode.BatchEncoder(cfg, G, F)
     gen = torch.Generator(device=dev)
