@@ -105,8 +105,8 @@ class CpuApp:
     side, while the GPU runs the untimed extras; all_cores_may_start() = then floor(cores available / 8) concurrent -m 8 processes, each on a GOP of its own, once the
     GPU is idle (`all_cores`; cores available = physical cores, capped by the container's CPU quota)"""
 
-    def __init__(self, width, height, frames, clip, with_m1=True):
-        self.w, self.h, self.frames, self.err, self.out = width, height, frames, None, {}
+    def __init__(self, width, height, frames, clip, with_m1=True, preset="medium"):
+        self.w, self.h, self.frames, self.err, self.out, self.preset = width, height, frames, None, {}, preset
         self.exe = os.path.join(ROOT, "oracle", "_ref", "xeveb_app")
         self.host = host_info()
         if not os.path.exists(self.exe):
@@ -129,7 +129,7 @@ class CpuApp:
             self.th.start()
 
     def _cmd(self, yuv, frames, m, out):
-        return [self.exe, "-i", yuv, "-w", str(self.w), "-h", str(self.h), "-z", "30", "--preset", "medium", "--closed-gop", "-I", "8", "--frames", str(frames), "-m", str(m), "-o", out]
+        return [self.exe, "-i", yuv, "-w", str(self.w), "-h", str(self.h), "-z", "30", "--preset", self.preset, "--closed-gop", "-I", "8", "--frames", str(frames), "-m", str(m), "-o", out]
 
     @staticmethod
     def _parse(txt, rc):
@@ -193,24 +193,24 @@ class CpuApp:
             pass
         m8 = self.out.get("m8", {})
         return {"value": m8.get("fps"), "unit": "frames/s", "cores": 8, "kind": "reference",
-                "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset medium --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit 4:2:0 "
+                "sample": "oracle/_ref/xeveb_app (the unmodified reference, AVX2 dispatch) -w %d -h %d --preset %s --closed-gop -I 8 --frames %d on the seed-4 uniform 8-bit 4:2:0 "
                           "clip = GOP 0 of the GPU job (1 IDR + 7 B pictures); `value` = -m 8 (the library's thread maximum, the setting the GPU job reproduces byte for byte); "
                           "`m1` = -m 1 on the clip's first 2 frames; `all_cores` = floor(cores available / 8) such processes side by side, each on its own GOP (cores available = "
-                          "physical cores capped by the container's CPU quota, `host`); -m 8 and -m 1 ran after the GPU's timed region beside its untimed extras, all_cores with the GPU idle" % (self.w, self.h, self.frames),
+                          "physical cores capped by the container's CPU quota, `host`); -m 8 and -m 1 ran after the GPU's timed region beside its untimed extras, all_cores with the GPU idle" % (self.w, self.h, self.preset, self.frames),
                 "m8": m8, "m1": self.out.get("m1", {}), "all_cores": self.out.get("all_cores", {}), "host": self.host, "error": self.err}
 
 
-def golden_prefix(width, height, frames, threads):
-    """the reference's bitstream of the seed clip at this size, as (bytes, md5) after every coded picture (tests/golden/cfg4_8f_v1.json), or None"""
+def golden_prefix(width, height, frames, threads, preset="medium"):
+    """the reference's bitstream of the seed clip at this size and preset, as (bytes, md5) after every coded picture (tests/golden/cfg4_8f_v1.json), or None"""
     try:
         g = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4_8f_v1.json")))
         for name, r in g.items():
-            if (r["w"], r["h"], r["frames"]) == (width, height, frames) and threads == 8:
+            if (r["w"], r["h"], r["frames"]) == (width, height, frames) and threads == 8 and r["cli"][1] == preset:
                 return name, r
     except Exception:
         pass
     try:  # the 2-frame job of rounds 1-3 (--frames 2 --pictures 0): the whole file's golden
-        if (width, height, frames, threads) == (3840, 2160, 2, 8):
+        if (width, height, frames, threads, preset) == (3840, 2160, 2, 8, "medium"):
             r = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_v1.json")))["cfg4_2160p_closedgop_medium_m8"]
             return "e2e_v1.json:cfg4_2160p_closedgop_medium_m8", {"after_picture": [{"bytes": -1, "md5": ""}, {"bytes": r["bytes"], "md5": r["md5"]}]}
     except Exception:
@@ -234,7 +234,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     fb = W * H * 3 // 2
     w_lcu, h_lcu = (W + 63) // 64, (H + 63) // 64
     seed = {(3840, 2160): 4, (1920, 1080): 3}.get((W, H), 4)
-    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset="medium", threads=T)
+    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset=a.preset, threads=T)
     free0 = torch.cuda.mem_get_info(dev)[0]
     one, most = encode.footprint(cfg, 1, F)
     two, _ = encode.footprint(cfg, 2, F)
@@ -266,7 +266,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
             for f in range(F):
                 e.push(g, f, d[f * fb:(f + 1) * fb])
     del d
-    cpu = CpuApp(W, H, F, clip, True) if with_cpu else None  # (started after the timed region)
+    cpu = CpuApp(W, H, F, clip, True, a.preset) if with_cpu else None  # (started after the timed region)
 
     def fence():
         for e in encs:
@@ -287,7 +287,8 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     sizes = [per] * (n - 1) + [max(0, run_steps - per * (n - 1))]
 
     L = lib.load()
-    fused = [bool(L.xeve_hip_walk_fused(g * min(T, h_lcu))) for g in Gs]  # which walk every batch's steps run (walk.hip: by the chains in lockstep, or pinned by --walk)
+    # which walk every batch's steps run (walk.hip: by the chains in lockstep, or pinned by --walk; presets slow and placebo: the fused walk at any width, xh_walk_only)
+    fused = [bool(L.xeve_hip_walk_fused(g * min(T, h_lcu))) or a.preset in ("slow", "placebo") for g in Gs]
     cls = "walk" if fused[0] else "search"
     live = [0.0, 0, 0]
 
@@ -353,7 +354,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
         mix[k] = mix.get(k, 0) + 1
     rec = None
     if rank == 0:
-        gname, gold = golden_prefix(W, H, F, T)
+        gname, gold = golden_prefix(W, H, F, T, a.preset)
         for e in encs:
             e.flush()  # (the access unit of the last picture run: appended now instead of at the next picture's end, so that every picture that was run is checked)
         streams = [[e.bitstream(g) for g in idx] for e, idx in zip(encs, seeded)]
@@ -409,11 +410,12 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                             "note": "a 32x32 / 64x64 transform is the only dense matrix product on the path; those blocks are < 1 % of a step's kernel time"}
         rec = {"value": round(world * frames_timed / dt, 4), "ms_per_step": round(1e3 * dt / a.steps, 3),
                "config": {
-                   "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset medium (xeveb_app --preset medium --closed-gop "
+                   "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset %s (xeveb_app --preset %s --closed-gop "
                                "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
-                               % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, T, run_steps, a.warmup, a.steps),
+                               % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, a.preset, a.preset, T, run_steps, a.warmup, a.steps),
                    "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
-                   "walk_choice": "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
+                   "walk_choice": "presets slow and placebo run on the fused walk at any width (rdo_dbk_switch, 4x4 inter CUs: xh_common.h xh_walk_only)" if a.preset in ("slow", "placebo") else
+                                  "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
                                   "by the chains in lockstep (walk.hip: the fused kernel up to 1024 chains -- it finishes a step of few chains sooner --, the composed walk above: "
                                   "its kernels pack the lanes of many chains and code more CTUs per second; profiles/r04_walks.md)",
                    "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "pictures_run": P, "row_chains_per_picture": T,
@@ -521,6 +523,8 @@ def main():
     ap.add_argument("--batches", type=int, default=3, help="batches encoded side by side on this GPU (a host thread and a HIP stream each)")
     ap.add_argument("--walk", default=os.environ.get("XEVE_BENCH_WALK", "auto"), choices=["auto", "fused", "composed"],
                     help="the CTU walk: one kernel per step (fused), ~10 000 launches per step (composed), or the library's choice by the chains in lockstep (auto)")
+    ap.add_argument("--preset", default="medium", choices=["fast", "medium", "slow", "placebo"],
+                    help="the headline is preset medium (BASELINE.json); slow and placebo run on the fused walk at any width, their lines are secondary records (profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra (the per-class / per-stage profile of the walk)")
     ap.add_argument("--no-1080p", action="store_true", help="skip the same bounded job at 1920x1080 that follows the headline (north_star names both sizes; ~2 more minutes, after the timed region)")
@@ -570,7 +574,7 @@ def main():
     line = None
     if rank == 0:
         cpu = rec.pop("cpu")
-        line = {"metric": "encoded frames/sec @ 2160p Baseline medium; SAD-kernel HBM GB/s vs peak", "value": rec["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        line = {"metric": "encoded frames/sec @ 2160p Baseline %s; SAD-kernel HBM GB/s vs peak" % a.preset, "value": rec["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "s16 samples, s32/s64 accumulation, f64 cost comparisons (bit-exact)", "data": "synthetic",
                 "value_is": "encoded frames/s of the closed-GOP batch encoder on full 8-frame closed GOPs: a real encode to EVC bitstreams (every stage of the reference's xeve_pic "

@@ -9,6 +9,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -29,23 +30,29 @@ def prefixes(evc):
     return out
 
 
-def run(w, h, frames, seed, name, out):
+def run(w, h, frames, seed, name, out, preset="medium"):
     exe = os.path.join(ROOT, "oracle", "_ref", "xeveb_app")
     with tempfile.TemporaryDirectory() as d:
         yuv, evc = os.path.join(d, "in.yuv"), os.path.join(d, "o.evc")
         reference_noise(w * h * 3 // 2 * frames, seed).tofile(yuv)
-        cli = ["--preset", "medium", "--closed-gop", "-I", "8", "-m", "8"]
+        cli = ["--preset", preset, "--closed-gop", "-I", "8", "-m", "8"]
+        t = time.time()
         subprocess.run([exe, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-o", evc] + cli, check=True, stdout=subprocess.DEVNULL)
+        wall = time.time() - t
         b = open(evc, "rb").read()
-    out[name] = {"w": w, "h": h, "frames": frames, "seed": seed, "cli": cli, "bytes": len(b), "md5": hashlib.md5(b).hexdigest(), "after_picture": prefixes(b)}
+    out[name] = {"w": w, "h": h, "frames": frames, "seed": seed, "cli": cli, "bytes": len(b), "md5": hashlib.md5(b).hexdigest(), "after_picture": prefixes(b),
+                 "reference_wall_s_in_the_build_container": round(wall, 1)}
     assert len(out[name]["after_picture"]) == frames
 
 
 if __name__ == "__main__":
     path = os.path.join(ROOT, "tests", "golden", "cfg4_8f_v1.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    for (w, h, seed, name) in ((1920, 1080, 3, "cfg3_1080p_closedgop_medium_8f_m8"), (3840, 2160, 4, "cfg4_2160p_closedgop_medium_8f_m8")):
+    # (round 5: the same two clips at presets slow and placebo -- bench.py --preset; the application's wall time in the build container is kept beside them)
+    for (w, h, seed, name, preset) in ((1920, 1080, 3, "cfg3_1080p_closedgop_medium_8f_m8", "medium"), (3840, 2160, 4, "cfg4_2160p_closedgop_medium_8f_m8", "medium"),
+                                       (1920, 1080, 3, "cfg3_1080p_closedgop_slow_8f_m8", "slow"), (3840, 2160, 4, "cfg4_2160p_closedgop_slow_8f_m8", "slow"),
+                                       (1920, 1080, 3, "cfg3_1080p_closedgop_placebo_8f_m8", "placebo"), (3840, 2160, 4, "cfg4_2160p_closedgop_placebo_8f_m8", "placebo")):
         if name not in out:
-            run(w, h, 8, seed, name, out)
+            run(w, h, 8, seed, name, out, preset)
             json.dump(out, open(path, "w"), indent=1)
             print(name, out[name]["bytes"], out[name]["md5"], flush=True)

@@ -257,7 +257,7 @@ def test_batches_at_real_picture_sizes_on_the_gpu(name, walk, hip, yuv_dir):
 
 FULL_GOPS = json.load(open(os.path.join(_enc.ROOT, "tests", "golden", "cfg4_8f_v1.json")))  # make_cfg4_8f_golden.py: the unmodified reference on the bench's own clips
 C3, C4 = "cfg3_1080p_closedgop_medium_8f_m8", "cfg4_2160p_closedgop_medium_8f_m8"
-assert {C3, C4} == set(FULL_GOPS), sorted(FULL_GOPS)
+assert {C3, C4} <= set(FULL_GOPS), sorted(FULL_GOPS)  # (the file also holds the clips at presets slow and placebo: bench.py --preset)
 
 
 @pytest.mark.gpu_last
