@@ -2657,3 +2657,160 @@ int xo_eco_tile_end(xo_sbac *s, uint8_t *bytes, int cap)
     g_sink = NULL, g_sink_n = g_sink_cap = 0;
     return n;
 }
+
+/* ==================================================================================================================================================================
+ * Main profile: the adaptive loop filter's sample kernels (src_main/xevem_alf.c).  TEST INFRASTRUCTURE like the rest of this file.
+ * ================================================================================================================================================================== */
+void xo_alf_copy_and_extend(xo_pel *tmp, int s_tmp, const xo_pel *rec, int s_rec, int w, int h, int m)
+{ /* xevem_alf.c:91-168: rows copied, left / right margins from the row's end samples, then whole bottom / top rows (margins included) repeated */
+    for(int r = 0; r < h; r++) {
+        xo_pel *d = tmp + (ptrdiff_t)r * s_tmp;
+        memcpy(d, rec + (ptrdiff_t)r * s_rec, sizeof(xo_pel) * (size_t)w);
+        for(int k = 1; k <= m; k++) d[-k] = d[0], d[w - 1 + k] = d[w - 1];
+    }
+    for(int k = 1; k <= m; k++) {
+        memcpy(tmp + (ptrdiff_t)(h - 1 + k) * s_tmp - m, tmp + (ptrdiff_t)(h - 1) * s_tmp - m, sizeof(xo_pel) * (size_t)(w + 2 * m));
+        memcpy(tmp - (ptrdiff_t)k * s_tmp - m, tmp - m, sizeof(xo_pel) * (size_t)(w + 2 * m));
+    }
+}
+
+/* alf_derive_classification_blk (:488-654) of one piece of at most 32 x 32: 2x2-subsampled sums of four 1-D Laplacians, summed over the 8x8 window around every 4x4 block */
+static void xo_alf_classify_piece(uint8_t *classifier, int s_cls, const xo_pel *src, int s_src, int px, int py, int pw, int ph, int bit_depth)
+{
+    static const int th[16] = {0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4};
+    static const int trans_tbl[8] = {0, 1, 0, 2, 2, 3, 1, 3};
+    enum { XV = 0, XH = 1, XD0 = 2, XD1 = 3 };
+    int lap[4][32 + 5][32 + 5];
+    const int rows = ph + 4, cols = pw + 4;
+    for(int i = 0; i < rows; i += 2) {
+        /* the 2x2 group of samples (r, c) .. (r + 1, c + 1), r = py - 2 + i, c = px - 2 + j */
+        const xo_pel *rm = src + (ptrdiff_t)(py - 3 + i) * s_src, *r0 = rm + s_src, *r1 = r0 + s_src, *r2 = r1 + s_src;
+        for(int j = 0; j < cols; j += 2) {
+            const int c = px - 2 + j;
+            /* (xo_pel)(v << 1): the doubled centre is held in a pel in the reference (:534-537) */
+            const int a0 = (xo_pel)(r0[c] << 1), a1 = (xo_pel)(r0[c + 1] << 1), b0 = (xo_pel)(r1[c] << 1), b1 = (xo_pel)(r1[c + 1] << 1);
+            lap[XV][i][j]  = abs(a0 - rm[c] - r1[c]) + abs(a1 - rm[c + 1] - r1[c + 1]) + abs(b0 - r0[c] - r2[c]) + abs(b1 - r0[c + 1] - r2[c + 1]);
+            lap[XH][i][j]  = abs(a0 - r0[c + 1] - r0[c - 1]) + abs(a1 - r0[c + 2] - r0[c]) + abs(b0 - r1[c + 1] - r1[c - 1]) + abs(b1 - r1[c + 2] - r1[c]);
+            lap[XD0][i][j] = abs(a0 - rm[c - 1] - r1[c + 1]) + abs(a1 - rm[c] - r1[c + 2]) + abs(b0 - r0[c - 1] - r2[c + 1]) + abs(b1 - r0[c] - r2[c + 2]);
+            lap[XD1][i][j] = abs(a0 - r1[c - 1] - rm[c + 1]) + abs(a1 - r1[c] - rm[c + 2]) + abs(b0 - r2[c - 1] - r0[c + 1]) + abs(b1 - r2[c] - r0[c + 2]);
+            if(j > 4 && (j - 6) % 4 == 0) /* every fourth group closes a run of four: their sum lands in the run's first entry (:551-559) */
+                for(int d = 0; d < 4; d++) lap[d][i][j - 6] += lap[d][i][j - 4] + lap[d][i][j - 2] + lap[d][i][j];
+        }
+    }
+    for(int i = 0; i < ph; i += 4)
+        for(int j = 0; j < pw; j += 4) {
+            int sum[4];
+            for(int d = 0; d < 4; d++) sum[d] = lap[d][i][j] + lap[d][i + 2][j] + lap[d][i + 4][j] + lap[d][i + 6][j];
+            const int sv = sum[XV], sh = sum[XH], sd0 = sum[XD0], sd1 = sum[XD1];
+            int act = (sv + sh) >> (bit_depth - 2);
+            act = (xo_pel)(act < 0 ? 0 : act > 15 ? 15 : act);
+            int cls = th[act];
+            const int hv1 = sv > sh ? sv : sh, hv0 = sv > sh ? sh : sv, dir_hv = sv > sh ? 1 : 3;
+            const int d1 = sd0 > sd1 ? sd0 : sd1, d0 = sd0 > sd1 ? sd1 : sd0, dir_d = sd0 > sd1 ? 0 : 2;
+            /* `d1 * hv0 > hv1 * d0` in int arithmetic (:607): on noise the products pass 2^31 and wrap, and the compiled reference compares the wrapped values */
+            const int32_t pa = (int32_t)((uint32_t)d1 * (uint32_t)hv0), pb = (int32_t)((uint32_t)hv1 * (uint32_t)d0);
+            const int diag = pa > pb;
+            const int hvd1 = diag ? d1 : hv1, hvd0 = diag ? d0 : hv0, main_dir = diag ? dir_d : dir_hv, sec_dir = diag ? dir_hv : dir_d;
+            int strength = 0;
+            if(hvd1 > 2 * hvd0) strength = 1;
+            if(hvd1 * 2 > 9 * hvd0) strength = 2;
+            if(strength) cls += (((main_dir & 1) << 1) + strength) * 5;
+            const uint8_t v = (uint8_t)(((cls << 2) + trans_tbl[main_dir * 2 + (sec_dir >> 1)]) & 0xFF);
+            for(int a = 0; a < 4; a++)
+                for(int b = 0; b < 4; b++) classifier[(ptrdiff_t)(py + i + a) * s_cls + px + j + b] = v;
+        }
+}
+void xo_alf_classify(uint8_t *classifier, int s_cls, const xo_pel *src, int s_src, const xo_alf_area *blk, int bit_depth)
+{ /* alf_derive_classification (:463-486) */
+    for(int i = blk->y; i < blk->y + blk->h; i += 32)
+        for(int j = blk->x; j < blk->x + blk->w; j += 32) {
+            const int h = (i + 32 < blk->y + blk->h ? i + 32 : blk->y + blk->h) - i, w = (j + 32 < blk->x + blk->w ? j + 32 : blk->x + blk->w) - j;
+            xo_alf_classify_piece(classifier, s_cls, src, s_src, j, i, w, h, bit_depth);
+        }
+}
+void xo_alf_filter7(const uint8_t *classifier, int s_cls, xo_pel *dst, int s_dst, const xo_pel *src, int s_src, const xo_alf_area *blk, const int16_t *filter_set,
+                    int clip_min, int clip_max)
+{ /* alf_filter_blk_7 (:656-787): per 4x4 block the class's 13 coefficients in the block's transposition, a 7x7 diamond with point symmetry, rounding shift 9 */
+    static const int order[4][13] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12}, {9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12}, {0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12},
+                                     {9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12}};
+    for(int i = 0; i < blk->h; i += 4)
+        for(int j = 0; j < blk->w; j += 4) {
+            const uint8_t cl = classifier[(ptrdiff_t)(blk->y + i) * s_cls + blk->x + j];
+            const int16_t *set = filter_set + ((cl >> 2) & 0x1F) * 13;
+            xo_pel c[13];
+            for(int k = 0; k < 13; k++) c[k] = set[order[cl & 3][k]];
+            for(int a = 0; a < 4; a++)
+                for(int b = 0; b < 4; b++) {
+                    const xo_pel *p = src + (ptrdiff_t)(i + a) * s_src + j + b;
+                    const ptrdiff_t s = s_src;
+                    int sum = c[0] * (p[3 * s] + p[-3 * s]);
+                    sum += c[1] * (p[2 * s + 1] + p[-2 * s - 1]) + c[2] * (p[2 * s] + p[-2 * s]) + c[3] * (p[2 * s - 1] + p[-2 * s + 1]);
+                    sum += c[4] * (p[s + 2] + p[-s - 2]) + c[5] * (p[s + 1] + p[-s - 1]) + c[6] * (p[s] + p[-s]) + c[7] * (p[s - 1] + p[-s + 1]) + c[8] * (p[s - 2] + p[-s + 2]);
+                    sum += c[9] * (p[3] + p[-3]) + c[10] * (p[2] + p[-2]) + c[11] * (p[1] + p[-1]) + c[12] * p[0];
+                    sum = (sum + 256) >> 9;
+                    dst[(ptrdiff_t)(i + a) * s_dst + j + b] = (xo_pel)(sum < clip_min ? clip_min : sum > clip_max ? clip_max : sum);
+                }
+        }
+}
+void xo_alf_filter5(xo_pel *dst, int s_dst, const xo_pel *src, int s_src, const xo_alf_area *blk, const int16_t *filter_set, int clip_min, int clip_max)
+{ /* alf_filter_blk_5 (:789-882): one 7-coefficient filter for the whole area, a 5x5 diamond */
+    xo_pel c[7];
+    for(int k = 0; k < 7; k++) c[k] = filter_set[k];
+    for(int i = 0; i < blk->h; i++)
+        for(int j = 0; j < blk->w; j++) {
+            const xo_pel *p = src + (ptrdiff_t)i * s_src + j;
+            const ptrdiff_t s = s_src;
+            int sum = c[0] * (p[2 * s] + p[-2 * s]) + c[1] * (p[s + 1] + p[-s - 1]) + c[2] * (p[s] + p[-s]) + c[3] * (p[s - 1] + p[-s + 1]);
+            sum += c[4] * (p[2] + p[-2]) + c[5] * (p[1] + p[-1]) + c[6] * p[0];
+            sum = (sum + 256) >> 9;
+            dst[(ptrdiff_t)i * s_dst + j] = (xo_pel)(sum < clip_min ? clip_min : sum > clip_max ? clip_max : sum);
+        }
+}
+/* xeve_alf_clac_covariance (:3890-3952): the sums of the sample pairs every coefficient multiplies, in the block's transposition */
+static void xo_alf_local(int *e, const xo_pel *rec, int stride, const int *pattern, int half, int trans_idx)
+{
+    int k = 0;
+    const ptrdiff_t s = stride;
+    if(trans_idx == 0 || trans_idx == 2) { /* rows above the centre with their mirror rows; transposition 2 walks every row right to left */
+        for(int i = -half; i < 0; i++)
+            for(int t = -half - i; t <= half + i; t++) {
+                const int j = trans_idx == 0 ? t : -t;
+                e[pattern[k++]] += rec[i * s + j] + rec[-i * s - j];
+            }
+        for(int j = -half; j < 0; j++) e[pattern[k++]] += rec[j] + rec[-j];
+    }
+    else { /* 1, 3: the same walk with rows and columns exchanged */
+        for(int j = -half; j < 0; j++)
+            for(int t = -half - j; t <= half + j; t++) {
+                const int i = trans_idx == 1 ? t : -t;
+                e[pattern[k++]] += rec[i * s + j] + rec[-i * s - j];
+            }
+        for(int i = -half; i < 0; i++) e[pattern[k++]] += rec[i * s] + rec[-i * s];
+    }
+    e[pattern[k++]] += rec[0];
+}
+void xo_alf_blk_stats(int taps, const uint8_t *classifier, int s_cls, const xo_pel *org, int s_org, const xo_pel *rec, int s_rec, int x, int y, int w, int h,
+                      double *E, double *yv, double *pix)
+{ /* xeve_alf_get_blk_stats (:3836-3888) */
+    static const int pattern5[13] = {0, 1, 2, 3, 4, 5, 6, 5, 4, 3, 2, 1, 0}, pattern7[25] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0}; /* xevem_alf.h:118-136 */
+    const int ncoef = taps * taps / 4 + 1, *pattern = taps == 5 ? pattern5 : pattern7, nclasses = classifier ? 25 : 1;
+    for(int i = 0; i < h; i++)
+        for(int j = 0; j < w; j++) {
+            int e[13] = {0}, cls = 0, tr = 0;
+            if(classifier) {
+                const uint8_t cl = classifier[(ptrdiff_t)(y + i) * s_cls + x + j];
+                tr = cl & 3, cls = (cl >> 2) & 0x1F;
+            }
+            const xo_pel *r = rec + (ptrdiff_t)(y + i) * s_rec + x + j;
+            const int d = org[(ptrdiff_t)(y + i) * s_org + x + j] - r[0];
+            xo_alf_local(e, r, s_rec, pattern, taps >> 1, tr);
+            for(int k = 0; k < ncoef; k++) {
+                for(int l = k; l < ncoef; l++) E[(cls * 13 + k) * 13 + l] += e[k] * e[l];
+                yv[cls * 13 + k] += e[k] * d;
+            }
+            pix[cls] += d * d;
+        }
+    for(int c = 0; c < nclasses; c++) /* (:3880-3887) the lower triangle from the upper one */
+        for(int k = 1; k < ncoef; k++)
+            for(int l = 0; l < k; l++) E[(c * 13 + k) * 13 + l] = E[(c * 13 + l) * 13 + k];
+}

@@ -505,6 +505,24 @@ double xo_mode_analyze_ctu_intra(const xo_pel *const org[3], int s_org_l, int s_
                                  int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const xo_sbac *entry, const xo_tree_params *P, int x0, int y0,
                                  xo_ctu_data *out, xo_sbac *next_best);
 
+/* ---- Main profile: the adaptive loop filter's sample kernels (reference: src_main/xevem_alf.c) ------------------------------------------------------------------ */
+typedef struct xo_alf_area { int32_t x, y, w, h; } xo_alf_area; /* AREA (xevem_alf.h:65-71) */
+/* alf_copy_and_extend / alf_copy_and_extend_tile (:91-168): rec -> tmp (both at sample (0, 0) of the w x h area), then m samples of edge replication on every side */
+void xo_alf_copy_and_extend(xo_pel *tmp, int s_tmp, const xo_pel *rec, int s_rec, int w, int h, int m);
+/* alf_derive_classification (:463-486) = alf_derive_classification_blk (:488-654) over 32x32 pieces of the area: classifier[(y + i) * s_cls + x + j] of every sample =
+ * (class << 2) | transpose index of its 4x4 block.  src at sample (0, 0) of the picture the area's coordinates count in; reads 3 samples around the area. */
+void xo_alf_classify(uint8_t *classifier, int s_cls, const xo_pel *src, int s_src, const xo_alf_area *blk, int bit_depth);
+/* alf_filter_blk_7 (:656-787) / alf_filter_blk_5 (:789-882): dst / src at the area's first sample; the classifier is indexed with the area's own coordinates (7-tap
+ * form); filter_set: 25 x 13 coefficients (7-tap) or 7 (5-tap) */
+void xo_alf_filter7(const uint8_t *classifier, int s_cls, xo_pel *dst, int s_dst, const xo_pel *src, int s_src, const xo_alf_area *blk, const int16_t *filter_set,
+                    int clip_min, int clip_max);
+void xo_alf_filter5(xo_pel *dst, int s_dst, const xo_pel *src, int s_src, const xo_alf_area *blk, const int16_t *filter_set, int clip_min, int clip_max);
+/* xeve_alf_get_blk_stats (:3836-3888) + xeve_alf_clac_covariance (:3890-3952): per class the auto-correlation E[13][13] (the leading ncoef x ncoef part, symmetric), the
+ * cross-correlation y[13] and the energy of (org - rec) over the w x h samples at (x, y).  taps 5 | 7 (ncoef 7 | 13).  classifier NULL (chroma): class 0, no
+ * transposition.  E / y / pix are ADDED to (the reference accumulates into the CTU's record), nclasses = 25 with a classifier, else 1. */
+void xo_alf_blk_stats(int taps, const uint8_t *classifier, int s_cls, const xo_pel *org, int s_org, const xo_pel *rec, int s_rec, int x, int y, int w, int h,
+                      double *E /* [nclasses][13][13] */, double *yv /* [nclasses][13] */, double *pix /* [nclasses] */);
+
 #ifdef __cplusplus
 }
 #endif
