@@ -919,11 +919,52 @@ int xeve_hip_enc_flush(xeve_hip_enc *e);
 int xeve_hip_enc_bitstream(xeve_hip_enc *e, int gop, const uint8_t **data, size_t *bytes);
 /* Lockstep statistics of the last encode: CTU steps issued, seconds inside the step calls / the picture-end calls (loop filter, second writer pass, padding). */
 int xeve_hip_enc_stats(xeve_hip_enc *e, int64_t *ctu_steps, double *step_seconds, double *picture_end_seconds);
-/* How large may a batch be, and what does it cost?  *max_gops: the runs one batch can hold at this picture size (its stacked originals are addressed with 32 bits:
- * 448 pictures of 3840x2160); *device_bytes: the HBM a batch of `ngops` x `frames` takes between create and delete (picture stores, maps, both CTU stores, the
+/* How large may a batch be, and what does it cost?  *max_gops: the runs one batch can hold at this picture size (its stacked originals are addressed in pairs of samples with 32 bits:
+ * 2^33 samples, 896 pictures of 3840x2160); *device_bytes: the HBM a batch of `ngops` x `frames` takes between create and delete (picture stores, maps, both CTU stores, the
  * walk's workspace).  No device call: usable before xeve_hip_init.  A job larger than one batch is several xeve_hip_enc objects, a host thread each -- the device runs
  * their launch chains side by side (xeve_amd/encode.py encode_gops does the split). */
 int xeve_hip_enc_footprint(const xeve_hip_enc_config *cfg, int ngops, int frames, uint64_t *device_bytes, int32_t *max_gops);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Main profile: the adaptive loop filter's sample kernels ("ALF           */
+/* classification / filter").  reference: src_main/xevem_alf.c -- alf_copy_and_extend            */
+/* (:91-168), alf_derive_classification / _blk (:463-654), alf_filter_blk_7 / _5 (:656-882;       */
+/* the ADAPTIVE_LOOP_FILTER object's derive_classification_blk / filter_7x7_blk /                 */
+/* filter_5x5_blk pointers, :50-53, xevem_alf.h:264-266), xeve_alf_get_blk_stats +                */
+/* xeve_alf_clac_covariance (:3836-3952).  Planes, classifier and job lists are DEVICE            */
+/* memory; the filter derivation between statistics and filtering (Cholesky solves, rate          */
+/* estimates: xeve_alf_encode) stays the caller's.                                                */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_alf_area { int32_t x, y, w, h; } xeve_hip_alf_area; /* AREA (xevem_alf.h:65-71): multiples of 4 */
+typedef struct xeve_hip_alf_filter_job {
+    int32_t x, y, w, h;       /* the area: its position in the classifier plane (7-tap filter; ignored by the 5-tap one) and its size, multiples of 4 */
+    int64_t dst_off, src_off; /* elements from `dst` / `src` to the area's first sample (the reference passes pre-offset pointers: rec_dst, rec_src) */
+} xeve_hip_alf_filter_job;
+typedef struct xeve_hip_alf_clip_range { int32_t min, max, bd, n; } xeve_hip_alf_clip_range; /* CLIP_RANGE (xevem_alf.h:89-95) */
+/* alf_copy_and_extend / alf_copy_and_extend_tile: the w x h samples at rec -> tmp (both point at sample (0, 0) of the area), then m samples of edge replication all round */
+int xeve_hip_alf_copy_and_extend(xeve_hip_pel *tmp, int s_tmp, const xeve_hip_pel *rec, int s_rec, int w, int h, int m, void *stream);
+/* alf_derive_classification over one area (HOST pointer; picture coordinates): classifier[(y + i) * s_cls + x + j] = (class << 2) | transposition of the sample's 4x4
+ * block.  src_luma at sample (0, 0) of the picture the area counts in; reads 3 samples around the area (the class of a block is a function of the 10 x 10 samples around
+ * it, so any partition into areas gives the same plane).  classifier 4-byte aligned, s_cls a multiple of 4. */
+int xeve_hip_alf_classify(uint8_t *classifier, int s_cls, const xeve_hip_pel *src_luma, int s_src, const xeve_hip_alf_area *area, int bit_depth, void *stream);
+/* alf_filter_blk_7 (taps 7: per 4x4 block the 13 coefficients of its class -- filter_set[25][13], HOST memory -- in its transposition) / alf_filter_blk_5 (taps 5:
+ * filter_set[7], classifier unused) of every job; src carries 3 samples of margin around every area (the CTU window xeve_alf_recon cuts, :2133-2170, or the extended
+ * picture); dst and src must not overlap.  out = clip(clip_min, clip_max, (sum + 256) >> 9). */
+int xeve_hip_alf_filter_jobs(int taps, xeve_hip_pel *dst, int s_dst, const xeve_hip_pel *src, int s_src, const uint8_t *classifier, int s_cls,
+                             const xeve_hip_alf_filter_job *jobs, int njobs, const int16_t *filter_set, int clip_min, int clip_max, void *stream);
+/* xeve_alf_get_blk_stats of every job (an area in picture coordinates; org / rec / classifier at sample (0, 0); rec with 3 samples of margin): per class the
+ * auto-correlation of the local sums, E [njobs][nclasses][13][13] (full, symmetric; zero beyond the shape's coefficients: taps 7 -> 13, 5 -> 7), their
+ * cross-correlation with org - rec, y [njobs][nclasses][13], and the energy pix_acc [njobs][nclasses].  nclasses = 25 with a classifier, 1 without (chroma: class 0,
+ * no transposition).  WRITTEN, not accumulated (the reference adds into records it has just reset, :3754-3762): exact integers, so sums over jobs are exact too. */
+int xeve_hip_alf_blk_stats_jobs(int taps, const uint8_t *classifier, int s_cls, const xeve_hip_pel *org, int s_org, const xeve_hip_pel *rec, int s_rec,
+                                const xeve_hip_alf_area *jobs, int njobs, double *E, double *y, double *pix_acc, void *stream);
+/* HOST-memory forms with the reference's own signatures: what alf->derive_classification_blk / filter_7x7_blk / filter_5x5_blk (set in alf_init, :50-53) can be
+ * pointed at.  Synchronous, the area and its margin staged per call; like the table functions of section (1) they cannot report failure and abort with a message. */
+void xeve_hip_alf_derive_classification_blk_host(uint8_t **classifier, const xeve_hip_pel *src_luma, int src_stride, const xeve_hip_alf_area *blk, int shift, int bit_depth);
+void xeve_hip_alf_filter_blk_7_host(uint8_t **classifier, xeve_hip_pel *rec_dst, int dst_stride, const xeve_hip_pel *rec_src, int src_stride, const xeve_hip_alf_area *blk,
+                                    uint8_t comp_id, short *filter_set, const xeve_hip_alf_clip_range *clip_range);
+void xeve_hip_alf_filter_blk_5_host(uint8_t **classifier, xeve_hip_pel *rec_dst, int dst_stride, const xeve_hip_pel *rec_src, int src_stride, const xeve_hip_alf_area *blk,
+                                    uint8_t comp_id, short *filter_set, const xeve_hip_alf_clip_range *clip_range);
 
 #ifdef __cplusplus
 }

@@ -244,3 +244,51 @@ def run_case(impl, name):
     out["Ec"], out["yc"], out["pixc"] = E, yv, pix
     out["ext"] = impl.copy_and_extend(org_l, w, h)
     return out
+
+
+# ---- the kernels' per-element code on the host (tests/native/alf_host.cpp over xeve_amd/csrc/alf_core.h) ---------------------------------------------------------------
+HOST_SRC = os.path.join(ROOT, "tests", "native", "alf_host.cpp")
+HOST_HDR = os.path.join(ROOT, "xeve_amd", "csrc", "alf_core.h")
+HOST_OUT = os.path.join(ROOT, "tests", "native", "build", "libalf_host.so")
+
+
+class HostAlf(OracleAlf):
+    """alf_core.h compiled by g++: classification, filters and statistics from the kernels' own per-lane functions; copy_and_extend stays the oracle's (a clamp, in alf.hip)"""
+    name = "alf_core.h on the host"
+
+    def __init__(self):
+        import subprocess
+
+        OracleAlf.__init__(self)
+        if not os.path.exists(HOST_OUT) or os.path.getmtime(HOST_OUT) < max(os.path.getmtime(HOST_SRC), os.path.getmtime(HOST_HDR)):
+            os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT, HOST_SRC], check=True)
+        self.H = C.CDLL(HOST_OUT)
+        for f in ("xa_host_classify", "xa_host_filter", "xa_host_stats"):
+            getattr(self.H, f).restype = None
+
+    def classify(self, src, w, h, area):
+        cls = np.zeros((h, w), np.uint8)
+        self.H.xa_host_classify(_p(cls), C.c_int(w), C.c_void_p(interior(src)), C.c_int(src.shape[1]), *[C.c_int(v) for v in area], C.c_int(BD))
+        return cls
+
+    def _filter(self, taps, cls, src, w, h, area, fset, clip):
+        dst = np.full((h, w), -1, np.int16)
+        x, y, aw, ah = area
+        s = src.shape[1]
+        self.H.xa_host_filter(C.c_int(taps), _p(cls) if cls is not None else None, C.c_int(w), _p(dst, y * w + x), C.c_int(w), C.c_void_p(interior(src) + 2 * (y * s + x)), C.c_int(s),
+                              C.c_int(x), C.c_int(y), C.c_int(aw), C.c_int(ah), _p(fset), C.c_int(clip[0]), C.c_int(clip[1]))
+        return dst
+
+    def filter7(self, cls, src, w, h, area, fset, clip=(0, 1023)):
+        return self._filter(7, cls, src, w, h, area, fset, clip)
+
+    def filter5(self, src, w, h, area, fset, clip=(0, 1023)):
+        return self._filter(5, None, src, w, h, area, fset, clip)
+
+    def stats(self, taps, cls, org, rec, w, area):
+        nc = 25 if cls is not None else 1
+        E, yv, pix = np.full((nc, 13, 13), -1.0), np.full((nc, 13), -1.0), np.full(nc, -1.0)
+        self.H.xa_host_stats(C.c_int(taps), _p(cls) if cls is not None else None, C.c_int(w), _p(org), C.c_int(org.shape[1]), C.c_void_p(interior(rec)), C.c_int(rec.shape[1]),
+                             *[C.c_int(v) for v in area], _p(E), _p(yv), _p(pix))
+        return E, yv, pix

@@ -73,3 +73,137 @@ def test_statistics_add_up_over_pieces():
             ps += p_
     assert np.array_equal(E, Es) and np.array_equal(yv, ys) and np.array_equal(pix, ps)
     assert np.array_equal(E, np.transpose(E, (0, 2, 1)))
+
+
+@pytest.mark.parametrize("name", sorted(_alf.CASES))
+def test_the_kernels_per_lane_code_on_the_host_matches_the_goldens(name):
+    """xeve_amd/csrc/alf_core.h (block_class, filter_sample, local_sums, stat_entry: what a lane of alf.hip runs) compiled for the host, driven in the kernels' decomposition"""
+    _check(_alf.HostAlf(), name, golden)
+
+
+# ---- the HIP entry points ------------------------------------------------------------------------------------------------------------------------------------------------
+FILTER_JOB = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("dst_off", "<i8"), ("src_off", "<i8")])  # xeve_hip_alf_filter_job
+AREA = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4")])  # xeve_hip_alf_area
+assert FILTER_JOB.itemsize == 32 and AREA.itemsize == 16
+
+
+class HipAlf(_alf.OracleAlf):
+    """xeve_hip_alf_* on planes resident in HBM (torch tensors as device memory); an area larger than 64x64 is handed over as ONE job (the kernel tiles it) and, for the
+    statistics, also as 64x64 jobs whose records are added up"""
+    name = "hip"
+
+    def __init__(self):
+        import torch
+
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        self.t, self.L, self.check = torch, lib.load(), lib.check
+        self.dev = torch.device("cuda:0")
+
+    def up(self, a):
+        return self.t.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(self.dev)
+
+    def classify(self, src, w, h, area):
+        d_src, cls = self.up(src), self.t.zeros(h * w, dtype=self.t.uint8, device=self.dev)
+        a = _alf.Area(*area)
+        self.check(self.L.xeve_hip_alf_classify(cls.data_ptr(), w, d_src.data_ptr() + 2 * (_alf.M * src.shape[1] + _alf.M), src.shape[1], _alf.C.addressof(a), _alf.BD, None))
+        self.t.cuda.synchronize()
+        return cls.cpu().numpy().reshape(h, w)
+
+    def _filter(self, taps, cls, src, w, h, area, fset, clip):
+        x, y, aw, ah = area
+        s = src.shape[1]
+        d_src, dst = self.up(src), self.t.full((h * w,), -1, dtype=self.t.int16, device=self.dev)
+        d_cls = self.up(cls) if cls is not None else None
+        job = np.zeros(1, FILTER_JOB)
+        job[0] = (x, y, aw, ah, y * w + x, (_alf.M + y) * s + _alf.M + x)
+        d_job = self.up(job)
+        self.check(self.L.xeve_hip_alf_filter_jobs(taps, dst.data_ptr(), w, d_src.data_ptr(), s, d_cls.data_ptr() if d_cls is not None else None, w, d_job.data_ptr(), 1,
+                                                   fset.ctypes.data, clip[0], clip[1], None))
+        self.t.cuda.synchronize()
+        return dst.cpu().numpy().reshape(h, w)
+
+    def filter7(self, cls, src, w, h, area, fset, clip=(0, 1023)):
+        return self._filter(7, cls, src, w, h, area, fset, clip)
+
+    def filter5(self, src, w, h, area, fset, clip=(0, 1023)):
+        return self._filter(5, None, src, w, h, area, fset, clip)
+
+    def stats(self, taps, cls, org, rec, w, area):
+        nc = 25 if cls is not None else 1
+        x, y, aw, ah = area
+        out = []
+        for jobs in ([(x, y, aw, ah)], [(x + i, y + j, min(64, aw - i), min(64, ah - j)) for j in range(0, ah, 64) for i in range(0, aw, 64)]):
+            ja = np.zeros(len(jobs), AREA)
+            for i, jb in enumerate(jobs):
+                ja[i] = jb
+            n = len(jobs)
+            E, yv, pix = (self.t.full((n * nc * k,), -1.0, dtype=self.t.float64, device=self.dev) for k in (169, 13, 1))
+            d_org, d_rec, d_job = self.up(org), self.up(rec), self.up(ja)
+            d_cls = self.up(cls) if cls is not None else None
+            self.check(self.L.xeve_hip_alf_blk_stats_jobs(taps, d_cls.data_ptr() if d_cls is not None else None, w, d_org.data_ptr(), org.shape[1],
+                                                          d_rec.data_ptr() + 2 * (_alf.M * rec.shape[1] + _alf.M), rec.shape[1], d_job.data_ptr(), n, E.data_ptr(), yv.data_ptr(),
+                                                          pix.data_ptr(), None))
+            self.t.cuda.synchronize()
+            out.append((E.cpu().numpy().reshape(n, nc, 13, 13).sum(axis=0), yv.cpu().numpy().reshape(n, nc, 13).sum(axis=0), pix.cpu().numpy().reshape(n, nc).sum(axis=0)))
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)  # (one job tiled by the kernel = its 64x64 jobs added up)
+        return out[0]
+
+    def copy_and_extend(self, rec, w, h):
+        m = _alf.M
+        d_rec, tmp = self.up(rec), self.t.full(((h + 2 * m) * (w + 2 * m),), -7, dtype=self.t.int16, device=self.dev)
+        self.check(self.L.xeve_hip_alf_copy_and_extend(tmp.data_ptr() + 2 * (m * (w + 2 * m) + m), w + 2 * m, d_rec.data_ptr(), w, w, h, m, None))
+        self.t.cuda.synchronize()
+        return tmp.cpu().numpy().reshape(h + 2 * m, w + 2 * m)
+
+
+class HipAlfHost(_alf.RefAlf):
+    """the host-memory forms with the reference's signatures (what alf->derive_classification_blk / filter_7x7_blk / filter_5x5_blk can be pointed at): driven exactly as
+    tests/_alf.py drives the reference's own functions"""
+    name = "hip host forms"
+
+    def __init__(self):
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        L = lib.load()
+
+        class Fns:
+            alf_derive_classification_blk = L.xeve_hip_alf_derive_classification_blk_host
+            alf_filter_blk_7 = L.xeve_hip_alf_filter_blk_7_host
+            alf_filter_blk_5 = L.xeve_hip_alf_filter_blk_5_host
+
+        self.L = Fns
+
+    def stats(self, *a):
+        raise NotImplementedError
+
+    def copy_and_extend(self, *a):
+        raise NotImplementedError
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_alf.CASES))
+def test_hip_alf_matches_oracle_and_goldens(name):
+    want = _alf.run_case(_alf.OracleAlf(), name)
+    got = _check(HipAlf(), name, golden)
+    assert all(np.array_equal(got[k], want[k]) for k in want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stripes_64x64", "combs_64x48", "noise_72x72"])
+def test_hip_alf_host_forms_with_the_references_signatures(name):
+    w, h, content, seed = _alf.CASES[name]
+    H = HipAlfHost()
+    luma, cb = _alf.plane(w, h, content, seed, 0), _alf.plane(w // 2, h // 2, content, seed, 1)
+    fl, fc = _alf.filter_sets(seed)
+    cls = H.classify(luma, w, h, (0, 0, w, h))
+    assert np.array_equal(cls, GOLD[name + "/cls"])
+    assert np.array_equal(H.filter7(cls, luma, w, h, (0, 0, w, h), fl), GOLD[name + "/f7"])
+    piece = (8, 4, min(64, w - 8) // 4 * 4, min(64, h - 4) // 4 * 4)
+    assert np.array_equal(H.filter7(cls, luma, w, h, piece, fl, clip=(64, 940)), GOLD[name + "/f7_piece_clip"])
+    assert np.array_equal(H.filter5(cb, w // 2, h // 2, (0, 0, w // 2, h // 2), fc), GOLD[name + "/f5"])

@@ -28,7 +28,7 @@ with tempfile.TemporaryDirectory() as d:
                 dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
             except Exception:
                 dem = name
-            rows.append((os.path.basename(f), re.sub(r"\(.*", "", dem)[:90], g("vgpr_count"), g("agpr_count"), g("sgpr_count"), g("group_segment_fixed_size"),
+            rows.append((os.path.basename(f), re.sub(r"\(.*", "", dem.replace("(anonymous namespace)::", ""))[:90], g("vgpr_count"), g("agpr_count"), g("sgpr_count"), g("group_segment_fixed_size"),
                          g("private_segment_fixed_size"), g("max_flat_workgroup_size"), sizes.get(name, "")))
 with open(sys.argv[1], "w") as o:
     o.write("file,kernel,vgprs,agprs,sgprs,lds_bytes,scratch_bytes_per_lane,max_workgroup,instructions\n")

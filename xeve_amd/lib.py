@@ -150,6 +150,14 @@ FUNCTIONS = {
     "xevem_scaled_horizontal_sobel_filter_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
     "xevem_scaled_vertical_sobel_filter_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
     "xevem_equal_coeff_computer_hip": (None, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
+    # Main profile: the adaptive loop filter's sample kernels (include/xeve_hip.h, src_main/xevem_alf.c)
+    "xeve_hip_alf_copy_and_extend": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "xeve_hip_alf_classify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "xeve_hip_alf_filter_jobs": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "xeve_hip_alf_blk_stats_jobs": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_alf_derive_classification_blk_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]),
+    "xeve_hip_alf_filter_blk_7_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, C.c_uint8, c_void_p, c_void_p]),
+    "xeve_hip_alf_filter_blk_5_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, C.c_uint8, c_void_p, c_void_p]),
     "xeve_average_16b_no_clip_hip": (None, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "xeve_recon_blk_hip": (None, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "xeve_hip_sad_jobs": (c_int, _JOB_ARGS + [c_int, c_void_p, c_void_p]),
