@@ -102,11 +102,24 @@ MAIN_CASES = {
 }
 
 
-def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500):
+# clips on which the Main encoder's adaptive loop filter ends up ON (tool_alf is the Main default, but on the tiny clips above every picture decides against it): counted
+# with oracle/ref_shim_alf.c in its count-only mode -- 64 classification calls, 4 x 7x7, 8 x 5x5 on the first; 80 / 8 / 0 on the second
+MAIN_ALF_CASES = {
+    "main_alf_moving_q22": (128, 128, 3, 5002, ["--profile", "main", "--preset", "fast", "-I", "0", "-b", "0", "-q", "22"]),
+    "main_alf_noise_q37": (128, 128, 3, 11, ["--profile", "main", "--preset", "fast", "-I", "0", "-b", "0", "-q", "37"]),
+}
+SHIM_ALF = os.path.join(ROOT, "oracle", "_ref", "libxeve_hip_shim_alf.so")
+
+
+def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500, shim=None, env_extra=None):
     cmd = [MAIN_APP, "-i", yuv, "-w", str(w), "-h", str(h), "-z", "30", "--frames", str(frames), "-m", "1", "-v", "0", "-o", out] + list(extra)
     env = dict(os.environ)
+    if env_extra:
+        env.update(env_extra)
+    if shim and not hip:
+        env["LD_PRELOAD"] = shim
     if hip:
-        env["LD_PRELOAD"], env["XEVE_HIP_LIB"] = SHIM_MAIN, HIP_LIB
+        env["LD_PRELOAD"], env["XEVE_HIP_LIB"] = shim or SHIM_MAIN, HIP_LIB
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     data = open(out, "rb").read()

@@ -7,11 +7,11 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _e2e import MAIN_CASES, make_yuv, run_app_main  # noqa: E402
+from _e2e import MAIN_ALF_CASES, MAIN_CASES, make_yuv, run_app_main  # noqa: E402
 
 out = {}
 with tempfile.TemporaryDirectory() as d:
-    for name, (w, h, n, seed, extra) in MAIN_CASES.items():
+    for name, (w, h, n, seed, extra) in list(MAIN_CASES.items()) + list(MAIN_ALF_CASES.items()):
         yuv = os.path.join(d, name + ".yuv")
         make_yuv(yuv, w, h, n, seed)
         md5, size, _ = run_app_main(yuv, os.path.join(d, name + ".evc"), w, h, n, extra)

@@ -10,7 +10,7 @@ import re
 import numpy as np
 import pytest
 
-from _e2e import MAIN_APP, MAIN_CASES, SHIM_MAIN, make_yuv, run_app_main
+from _e2e import MAIN_ALF_CASES, MAIN_APP, MAIN_CASES, SHIM_ALF, SHIM_MAIN, make_yuv, run_app_main
 from _main_cases import HIP_NAMES, OracleMain, TableMain, check_golden, run_all
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_main_v1.json")))
@@ -63,9 +63,9 @@ def test_hip_main_tables_touch_only_the_reference_footprint(hip_tables):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", sorted(MAIN_CASES))
+@pytest.mark.parametrize("name", sorted(MAIN_CASES) + sorted(MAIN_ALF_CASES))
 def test_main_reference_app_reproduces_golden_bitstreams(tmp_path, name):
-    w, h, n, seed, extra = MAIN_CASES[name]
+    w, h, n, seed, extra = (MAIN_CASES.get(name) or MAIN_ALF_CASES[name])
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     md5, size, _ = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra)
@@ -84,3 +84,39 @@ def test_main_bitstream_identical_with_hip_tables_installed(tmp_path, name):
     m = re.search(r"calls served by HIP: (\d+), of them by the Main-profile entries: (\d+)", err)
     assert m and int(m.group(2)) > 50000 and int(m.group(1)) > int(m.group(2)), err
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the HIP tables installed"
+
+
+def _alf_counts(err):
+    m = re.search(r"ALF calls ([^:]+): classification (\d+), 7x7 filter (\d+), 5x5 filter (\d+)", err)
+    assert m, err
+    return m.group(1), tuple(int(m.group(i)) for i in (2, 3, 4))
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(SHIM_ALF), reason="oracle/_ref/libxeve_hip_shim_alf.so not built")
+@pytest.mark.parametrize("name", sorted(MAIN_ALF_CASES))
+def test_the_alf_clips_reach_classification_and_filters(tmp_path, name):
+    """(cpu) the interposer in its count-only mode: the reference's own ALF functions, counted -- the clips the GPU test runs do filter"""
+    w, h, n, seed, extra = MAIN_ALF_CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim=SHIM_ALF, env_extra={"XEVE_HIP_SHIM_ALF_COUNT": "1"})
+    how, (ncls, n7, n5) = _alf_counts(err)
+    assert "reference" in how and ncls >= 48 and n7 >= 4 and (n5 >= 8 or name != "main_alf_moving_q22")
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIM_ALF), reason="oracle/_ref/libxeve_hip_shim_alf.so not built")
+@pytest.mark.parametrize("name", sorted(MAIN_ALF_CASES))
+def test_main_bitstream_identical_with_the_alf_kernels_on_the_gpu(tmp_path, name):
+    """the UNMODIFIED Main-profile encoder with its ADAPTIVE_LOOP_FILTER object's three function pointers bound to the HIP host forms (oracle/ref_shim_alf.c, as
+    INTEGRATION.md shows): classification of every tile and CTU, the 7x7 luma and 5x5 chroma filters of every enabled CTU on the GPU -- the same bitstream"""
+    w, h, n, seed, extra = MAIN_ALF_CASES[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, shim=SHIM_ALF, timeout=600)
+    how, (ncls, n7, n5) = _alf_counts(err)
+    assert how == "served by HIP" and ncls >= 48 and n7 >= 4
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the ALF kernels on the GPU"
