@@ -959,7 +959,12 @@ int xeve_hip_alf_filter_jobs(int taps, xeve_hip_pel *dst, int s_dst, const xeve_
 int xeve_hip_alf_blk_stats_jobs(int taps, const uint8_t *classifier, int s_cls, const xeve_hip_pel *org, int s_org, const xeve_hip_pel *rec, int s_rec,
                                 const xeve_hip_alf_area *jobs, int njobs, double *E, double *y, double *pix_acc, void *stream);
 /* HOST-memory forms with the reference's own signatures: what alf->derive_classification_blk / filter_7x7_blk / filter_5x5_blk (set in alf_init, :50-53) can be
- * pointed at.  Synchronous, the area and its margin staged per call; like the table functions of section (1) they cannot report failure and abort with a message. */
+ * pointed at, and what xeve_alf_derive_stats_filtering can call instead of xeve_alf_get_blk_stats (:3810; the filter shape replaced by its length).  Synchronous, the area and its margin staged per call; like the table functions of section (1) they cannot report failure and abort with a message. */
+typedef struct xeve_hip_alf_covariance { int32_t num_coef; double *y; double **E; double pix_acc; } xeve_hip_alf_covariance; /* ALF_COVARIANCE (xevem_alf.h:291-297) */
+/* xeve_alf_get_blk_stats (:3836-3888) on host memory: alf_cov[25] (classifier given) or alf_cov[1]; taps = shape->filterLength (5 | 7).  As the reference: the upper
+ * triangle of E, y and pix_acc are ADDED to, then every class's lower triangle is set from its upper one. */
+void xeve_hip_alf_get_blk_stats_host(int taps, xeve_hip_alf_covariance *alf_cov, uint8_t **classifier, const xeve_hip_pel *org0, int org_stride, const xeve_hip_pel *rec0,
+                                     int rec_stride, int x, int y, int width, int height);
 void xeve_hip_alf_derive_classification_blk_host(uint8_t **classifier, const xeve_hip_pel *src_luma, int src_stride, const xeve_hip_alf_area *blk, int shift, int bit_depth);
 void xeve_hip_alf_filter_blk_7_host(uint8_t **classifier, xeve_hip_pel *rec_dst, int dst_stride, const xeve_hip_pel *rec_src, int src_stride, const xeve_hip_alf_area *blk,
                                     uint8_t comp_id, short *filter_set, const xeve_hip_alf_clip_range *clip_range);

@@ -177,10 +177,28 @@ class HipAlfHost(_alf.RefAlf):
             alf_filter_blk_7 = L.xeve_hip_alf_filter_blk_7_host
             alf_filter_blk_5 = L.xeve_hip_alf_filter_blk_5_host
 
-        self.L = Fns
+        self.L, self.hip = Fns, L
 
-    def stats(self, *a):
-        raise NotImplementedError
+    def stats(self, taps, cls, org, rec, w, area, preset=0.0):
+        """xeve_hip_alf_get_blk_stats_host on records that already hold `preset` in their upper triangles: added to, the lower triangles set from the upper ones"""
+        C = _alf.C
+
+        class Cov(C.Structure):  # xeve_hip_alf_covariance = ALF_COVARIANCE
+            _fields_ = [("num_coef", C.c_int), ("y", C.POINTER(C.c_double)), ("E", C.POINTER(C.POINTER(C.c_double))), ("pix_acc", C.c_double)]
+
+        nc, ncoef = (25 if cls is not None else 1), taps * taps // 4 + 1
+        Es, ys = np.full((nc, ncoef, ncoef), preset), np.full((nc, ncoef), preset)
+        rows = [(C.POINTER(C.c_double) * ncoef)(*[C.cast(Es[c, k].ctypes.data, C.POINTER(C.c_double)) for k in range(ncoef)]) for c in range(nc)]
+        cov = (Cov * nc)()
+        for c in range(nc):
+            cov[c].num_coef, cov[c].y, cov[c].E, cov[c].pix_acc = ncoef, C.cast(ys[c].ctypes.data, C.POINTER(C.c_double)), rows[c], preset
+        x, y, aw, ah = area
+        self.hip.xeve_hip_alf_get_blk_stats_host(taps, cov, self._rows(cls) if cls is not None else None, org.ctypes.data, org.shape[1], _alf.interior(rec), rec.shape[1], x, y, aw, ah)
+        E, yv, pix = np.zeros((nc, 13, 13)), np.zeros((nc, 13)), np.zeros(nc)
+        E[:, :ncoef, :ncoef], yv[:, :ncoef] = Es, ys
+        for c in range(nc):
+            pix[c] = cov[c].pix_acc
+        return E, yv, pix
 
     def copy_and_extend(self, *a):
         raise NotImplementedError
@@ -207,3 +225,15 @@ def test_hip_alf_host_forms_with_the_references_signatures(name):
     piece = (8, 4, min(64, w - 8) // 4 * 4, min(64, h - 4) // 4 * 4)
     assert np.array_equal(H.filter7(cls, luma, w, h, piece, fl, clip=(64, 940)), GOLD[name + "/f7_piece_clip"])
     assert np.array_equal(H.filter5(cb, w // 2, h // 2, (0, 0, w // 2, h // 2), fc), GOLD[name + "/f5"])
+    # the statistics form adds into the caller's records (upper triangle, y, energy) and mirrors the triangle, as xeve_alf_get_blk_stats does
+    org = np.ascontiguousarray(_alf.plane(w, h, content, seed + 50, 0)[_alf.M:_alf.M + h, _alf.M:_alf.M + w])
+    for taps in (5, 7):
+        E, yv, pix = H.stats(taps, cls, org, luma, w, (0, 0, w, h))
+        assert np.array_equal(E, GOLD[name + "/E%d" % taps]) and np.array_equal(yv, GOLD[name + "/y%d" % taps]) and np.array_equal(pix, GOLD[name + "/pix%d" % taps])
+    E, yv, pix = H.stats(7, cls, org, luma, w, piece, preset=1000.0)
+    n = 13
+    want = GOLD[name + "/E7_piece"] + 1000.0
+    assert np.array_equal(E[:, :n, :n], want) and np.array_equal(yv, GOLD[name + "/y7_piece"] + 1000.0) and np.array_equal(pix, GOLD[name + "/pix7_piece"] + 1000.0)
+    org_c = np.ascontiguousarray(_alf.plane(w // 2, h // 2, content, seed + 50, 1)[_alf.M:_alf.M + h // 2, _alf.M:_alf.M + w // 2])
+    E, yv, pix = H.stats(5, None, org_c, cb, w // 2, (0, 0, w // 2, h // 2))
+    assert np.array_equal(E, GOLD[name + "/Ec"]) and np.array_equal(yv, GOLD[name + "/yc"]) and np.array_equal(pix, GOLD[name + "/pixc"])

@@ -87,9 +87,9 @@ def test_main_bitstream_identical_with_hip_tables_installed(tmp_path, name):
 
 
 def _alf_counts(err):
-    m = re.search(r"ALF calls ([^:]+): classification (\d+), 7x7 filter (\d+), 5x5 filter (\d+)", err)
+    m = re.search(r"ALF calls ([^:]+): classification (\d+), 7x7 filter (\d+), 5x5 filter (\d+), statistics (\d+)", err)
     assert m, err
-    return m.group(1), tuple(int(m.group(i)) for i in (2, 3, 4))
+    return m.group(1), tuple(int(m.group(i)) for i in (2, 3, 4, 5))
 
 
 @needs_ref
@@ -101,8 +101,8 @@ def test_the_alf_clips_reach_classification_and_filters(tmp_path, name):
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     md5, size, err = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim=SHIM_ALF, env_extra={"XEVE_HIP_SHIM_ALF_COUNT": "1"})
-    how, (ncls, n7, n5) = _alf_counts(err)
-    assert "reference" in how and ncls >= 48 and n7 >= 4 and (n5 >= 8 or name != "main_alf_moving_q22")
+    how, (ncls, n7, n5, nst) = _alf_counts(err)
+    assert "reference" in how and ncls >= 48 and n7 >= 4 and (n5 >= 8 or name != "main_alf_moving_q22") and nst >= 48
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
 
 
@@ -112,11 +112,12 @@ def test_the_alf_clips_reach_classification_and_filters(tmp_path, name):
 @pytest.mark.parametrize("name", sorted(MAIN_ALF_CASES))
 def test_main_bitstream_identical_with_the_alf_kernels_on_the_gpu(tmp_path, name):
     """the UNMODIFIED Main-profile encoder with its ADAPTIVE_LOOP_FILTER object's three function pointers bound to the HIP host forms (oracle/ref_shim_alf.c, as
-    INTEGRATION.md shows): classification of every tile and CTU, the 7x7 luma and 5x5 chroma filters of every enabled CTU on the GPU -- the same bitstream"""
+    INTEGRATION.md shows): classification of every tile and CTU, the correlation statistics of every CTU, component and filter shape (xeve_alf_get_blk_stats, interposed by
+    name), the 7x7 luma and 5x5 chroma filters of every enabled CTU on the GPU -- the same bitstream"""
     w, h, n, seed, extra = MAIN_ALF_CASES[name]
     yuv = str(tmp_path / "in.yuv")
     make_yuv(yuv, w, h, n, seed)
     md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, shim=SHIM_ALF, timeout=600)
-    how, (ncls, n7, n5) = _alf_counts(err)
-    assert how == "served by HIP" and ncls >= 48 and n7 >= 4
+    how, (ncls, n7, n5, nst) = _alf_counts(err)
+    assert how == "served by HIP" and ncls >= 48 and n7 >= 4 and nst >= 48
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the ALF kernels on the GPU"

@@ -282,3 +282,40 @@ extern "C" void xeve_hip_alf_filter_blk_5_host(uint8_t **classifier, xeve_hip_pe
     (void)comp_id;
     filter_host(5, classifier, rec_dst, dst_stride, rec_src, src_stride, blk, filter_set, clip_range, "xeve_hip_alf_filter_blk_5_host");
 }
+extern "C" void xeve_hip_alf_get_blk_stats_host(int taps, xeve_hip_alf_covariance *alf_cov, uint8_t **classifier, const xeve_hip_pel *org0, int org_stride,
+                                                const xeve_hip_pel *rec0, int rec_stride, int x, int y, int width, int height)
+{
+    const char *what = "xeve_hip_alf_get_blk_stats_host";
+    if(!xh_ready()) xh_set_error("xeve_hip_init() has not been called"), alf_die(what);
+    if(!((taps == 5 || taps == 7) && alf_cov && org0 && rec0 && width > 0 && height > 0 && ((width | height) & 3) == 0)) xh_set_error("invalid argument"), alf_die(what);
+    const int w = width, h = height, sw = w + 2 * MG, nclasses = classifier ? 25 : 1, ncoef = taps * taps / 4 + 1;
+    for(int c = 0; c < nclasses; c++)
+        if(alf_cov[c].num_coef < ncoef || !alf_cov[c].E || !alf_cov[c].y) xh_set_error("a covariance record smaller than the filter shape"), alf_die(what);
+    DevBuf rec((size_t)sw * (h + 2 * MG) * sizeof(pel), what), org((size_t)w * h * sizeof(pel), what), cls((size_t)w * h, what), job(sizeof(xeve_hip_alf_area), what);
+    DevBuf out((size_t)nclasses * (169 + 13 + 1) * sizeof(double), what);
+    rows_to_device(rec.p, rec0, rec_stride, sizeof(pel), y - MG, x - MG, h + 2 * MG, sw, what);
+    rows_to_device(org.p, org0, org_stride, sizeof(pel), y, x, h, w, what);
+    if(classifier) {
+        std::vector<uint8_t> c((size_t)w * h);
+        for(int i = 0; i < h; i++) memcpy(c.data() + (size_t)i * w, classifier[y + i] + x, (size_t)w);
+        if(hipMemcpy(cls.p, c.data(), c.size(), hipMemcpyHostToDevice) != hipSuccess) xh_set_error("copy to the device"), alf_die(what);
+    }
+    const xeve_hip_alf_area a = {0, 0, w, h};
+    if(hipMemcpy(job.p, &a, sizeof(a), hipMemcpyHostToDevice) != hipSuccess) xh_set_error("copy to the device"), alf_die(what);
+    double *dE = (double *)out.p, *dy = dE + (size_t)nclasses * 169, *dp = dy + (size_t)nclasses * 13;
+    if(xeve_hip_alf_blk_stats_jobs(taps, classifier ? (const uint8_t *)cls.p : nullptr, w, (const pel *)org.p, w, (const pel *)rec.p + (size_t)MG * sw + MG, sw,
+                                   (const xeve_hip_alf_area *)job.p, 1, dE, dy, dp, nullptr) != XEVE_HIP_OK)
+        alf_die(what);
+    std::vector<double> r((size_t)nclasses * (169 + 13 + 1));
+    if(hipMemcpy(r.data(), out.p, r.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) xh_set_error("copy from the device"), alf_die(what);
+    const double *E = r.data(), *yv = E + (size_t)nclasses * 169, *pp = yv + (size_t)nclasses * 13;
+    for(int c = 0; c < nclasses; c++) {
+        for(int k = 0; k < ncoef; k++) {
+            for(int l = k; l < ncoef; l++) alf_cov[c].E[k][l] += E[(c * 13 + k) * 13 + l];
+            alf_cov[c].y[k] += yv[c * 13 + k];
+        }
+        alf_cov[c].pix_acc += pp[c];
+        for(int k = 1; k < ncoef; k++)
+            for(int l = 0; l < k; l++) alf_cov[c].E[k][l] = alf_cov[c].E[l][k];
+    }
+}

@@ -155,6 +155,7 @@ FUNCTIONS = {
     "xeve_hip_alf_classify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "xeve_hip_alf_filter_jobs": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "xeve_hip_alf_blk_stats_jobs": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xeve_hip_alf_get_blk_stats_host": (None, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "xeve_hip_alf_derive_classification_blk_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]),
     "xeve_hip_alf_filter_blk_7_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, C.c_uint8, c_void_p, c_void_p]),
     "xeve_hip_alf_filter_blk_5_host": (None, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, C.c_uint8, c_void_p, c_void_p]),
