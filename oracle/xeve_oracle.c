@@ -2814,3 +2814,176 @@ void xo_alf_blk_stats(int taps, const uint8_t *classifier, int s_cls, const xo_p
         for(int k = 1; k < ncoef; k++)
             for(int l = 0; l < k; l++) E[(c * 13 + k) * 13 + l] = E[(c * 13 + l) * 13 + k];
 }
+
+/* ==================================================================================================================================================================
+ * Main profile: affine motion compensation (src_main/xevem_mc.c:1457-2339, xevem_util.c:1190-1480).  TEST INFRASTRUCTURE like the rest of this file.
+ * ================================================================================================================================================================== */
+static int xa_log2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
+static int xa_round(int v, int rs) { return (v + (rs > 0 ? 1 << (rs - 1) : 0) - (v >= 0)) >> rs; } /* xeve_rounding_s32 with left_shift 0 (xevem_util.c:1197-1201) */
+/* the model's per-sample increments at `bit` extra bits: calculate_affine_motion_model_parameters (xevem_util.c:1331-1356) = the head of xeve_affine_mc_lc (:1717-1728) */
+static void xa_model(const int16_t mv[3][2], int cuw, int cuh, int vertex_num, int bit, int d_hor[2], int d_ver[2])
+{
+    for(int c = 0; c < 2; c++) d_hor[c] = ((mv[1][c] - mv[0][c]) << bit) >> xa_log2(cuw);
+    if(vertex_num == 3)
+        for(int c = 0; c < 2; c++) d_ver[c] = ((mv[2][c] - mv[0][c]) << bit) >> xa_log2(cuh);
+    else d_ver[0] = -d_hor[1], d_ver[1] = d_hor[0];
+}
+/* check_eif_applicability_uni (xevem_util.c:1421-1449): the 4x4 sub-block's bounding box in the reference picture (memory bandwidth) and the lines its first row fetches */
+static int xa_eif_ok_uni(const int16_t mv[3][2], int cuw, int cuh, int vertex_num, int *mem_ok)
+{
+    const int prec = 2 + 7;
+    int d_hor[2], d_ver[2], mx[2], mn[2], diff[2];
+    xa_model(mv, cuw, cuh, vertex_num, 7, d_hor, d_ver);
+    for(int c = 0; c < 2; c++) { /* calculate_bounding_box_size (:1358-1404) with w = h = EIF_SUBBLOCK_SIZE 4 */
+        const int c1 = 5 * (d_hor[c] + (c == 0 ? 1 << prec : 0)), c2 = 5 * (d_ver[c] + (c == 1 ? 1 << prec : 0)), c3 = c1 + c2;
+        mx[c] = 0, mn[c] = 0;
+        if(c1 > mx[c]) mx[c] = c1;
+        if(c2 > mx[c]) mx[c] = c2;
+        if(c3 > mx[c]) mx[c] = c3;
+        if(c1 < mn[c]) mn[c] = c1;
+        if(c2 < mn[c]) mn[c] = c2;
+        if(c3 < mn[c]) mn[c] = c3;
+        diff[c] = (mx[c] - mn[c] + (1 << prec) - 1) >> prec;
+    }
+    *mem_ok = (diff[0] + 2) * (diff[1] + 2) <= 72; /* MAX_MEMORY_ACCESS_BI */
+    if(d_ver[1] < -(1 << prec)) return 0; /* check_eif_num_fetched_lines_restrictions (:1406-1419) */
+    if(((d_ver[1] > 0 ? d_ver[1] : 0) + abs(d_hor[1])) * (1 + 4) > (3 - 2) << prec) return 0;
+    return 1;
+}
+static void xa_subblock_size(const xo_affine_job *j, int cuw, int cuh, int *sub_w, int *sub_h, int *mem_ok)
+{ /* derive_affine_subblock_size_bi (xevem_util.c:1203-1272) */
+    static const int lut[4] = {32, 16, 8, 8};
+    int eif = 1;
+    *sub_w = cuw, *sub_h = cuh, *mem_ok = 1;
+    for(int l = 0; l < 2; l++) {
+        if(j->refi[l] < 0) continue;
+        int d_hor[2], d_ver[2];
+        xa_model(j->mv[l], cuw, cuh, j->vertex_num, 7, d_hor, d_ver);
+        const int wx = abs(d_hor[0]) > abs(d_hor[1]) ? abs(d_hor[0]) : abs(d_hor[1]), wy = abs(d_ver[0]) > abs(d_ver[1]) ? abs(d_ver[0]) : abs(d_ver[1]);
+        const int w = wx > 4 ? 4 : wx == 0 ? cuw : lut[wx - 1], h = wy > 4 ? 4 : wy == 0 ? cuh : lut[wy - 1];
+        if(w < *sub_w) *sub_w = w;
+        if(h < *sub_h) *sub_h = h;
+    }
+    for(int l = 0; l < 2 && eif; l++) { /* check_eif_applicability_bi (:1451-1480): stops at the first list that fails (the later list's bandwidth answer is then not taken) */
+        if(j->refi[l] < 0) continue;
+        int m = 0;
+        const int ok = xa_eif_ok_uni(j->mv[l], cuw, cuh, j->vertex_num, &m);
+        *mem_ok &= m;
+        if(!ok) eif = 0;
+    }
+    if(!eif) {
+        if(*sub_w < 8) *sub_w = 8;
+        if(*sub_h < 8) *sub_h = 8;
+    }
+}
+/* xeve_eif_mc (xevem_mc.c:2123-2234) of one component: bw x bh samples at (x, y) of `ref` */
+static void xa_eif(int bw, int bh, int x, int y, const int mv0_in[2], const int dx_in[2], const int dy_in[2], const int mv_max_in[2], const int mv_min_in[2], const xo_pel *ref,
+                   int s_ref, xo_pel *dst, int s_dst, int chroma, int bit_depth)
+{
+    int mv0[2] = {mv0_in[0], mv0_in[1]}, mx[2] = {mv_max_in[0], mv_max_in[1]}, mn[2] = {mv_min_in[0], mv_min_in[1]};
+    if(chroma) { /* (:2163-2175; the per-sample increments are NOT halved: a chroma sample is two luma samples apart) */
+        for(int c = 0; c < 2; c++) mv0[c] >>= 1, mx[c] >>= 1, mn[c] >>= 1;
+        bw >>= 1, bh >>= 1, x >>= 1, y >>= 1;
+    }
+    ref += (ptrdiff_t)s_ref * y + x;
+    const int ts = 128 + 2, sh2 = bit_depth + 5 - 16 > 0 ? bit_depth + 5 - 16 : 0, sh3 = 6 - sh2, of2 = sh2 > 0 ? 1 << (sh2 - 1) : 0, of3 = 1 << (sh3 - 1);
+    const int s1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, s2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8, o2 = 1 << (s2 - 1);
+    xo_pel *buf = (xo_pel *)malloc(sizeof(xo_pel) * (size_t)ts * ts);
+    /* can_mv_clipping_occurs (:1917-1957): the vectors of the four corners of the (bw + 2) x (bh + 2) positions against the range */
+    int clip = 0;
+    for(int c = 0; c < 2; c++) {
+        const int m = mv0[c] - dx_in[c] - dy_in[c], k[4] = {m >> 4, (m + (bw + 1) * dx_in[c]) >> 4, (m + (bh + 1) * dy_in[c]) >> 4, (m + (bw + 1) * dx_in[c] + (bh + 1) * dy_in[c]) >> 4};
+        for(int q = 0; q < 4; q++)
+            if(k[q] > mx[c] || k[q] < mn[c]) clip = 1;
+    }
+    /* xeve_eif_bilinear_clip / _no_clip (:1991-2121): position (px, py) in -1 .. bw / bh takes the sample its own vector (1/32 pel after >> 4) points at */
+    for(int py = -1; py <= bh; py++)
+        for(int px = -1; px <= bw; px++) {
+            int v[2];
+            for(int c = 0; c < 2; c++) {
+                v[c] = (mv0[c] + px * dx_in[c] + py * dy_in[c]) >> 4;
+                if(clip) v[c] = v[c] < mn[c] ? mn[c] : v[c] > mx[c] ? mx[c] : v[c];
+            }
+            const xo_pel *r = ref + (ptrdiff_t)(py + (v[1] >> 5)) * s_ref + px + (v[0] >> 5);
+            const int fx = v[0] & 31, fy = v[1] & 31;
+            const xo_pel a = (xo_pel)(((64 - 2 * fx) * r[0] + 2 * fx * r[1]) >> s1), b = (xo_pel)(((64 - 2 * fx) * r[s_ref] + 2 * fx * r[s_ref + 1]) >> s1);
+            buf[(py + 1) * ts + px + 1] = (xo_pel)(((64 - 2 * fy) * a + 2 * fy * b + o2) >> s2);
+        }
+    /* xeve_eif_filter (:1959-1989): {-1, 10, -1} along the rows in place (the result one column to the left), then down the columns */
+    for(int r = 0; r <= bh + 1; r++) {
+        xo_pel *t = buf + r * ts;
+        for(int c = 0; c < bw; c++) t[c] = (xo_pel)((-t[c] + t[c + 1] * 10 - t[c + 2] + of2) >> sh2);
+    }
+    for(int r = 0; r < bh; r++)
+        for(int c = 0; c < bw; c++) {
+            const xo_pel *t = buf + (r + 1) * ts + c;
+            const xo_pel res = (xo_pel)((-t[-ts] + t[0] * 10 - t[ts] + of3) >> sh3);
+            dst[r * s_dst + c] = (xo_pel)clip3i(0, (1 << bit_depth) - 1, res);
+        }
+    free(buf);
+}
+/* xeve_affine_mc_lc (xevem_mc.c:1671-1915) */
+static void xa_mc_lc(int x, int y, int pic_w, int pic_h, int cuw, int cuh, const int16_t mv[3][2], const xo_refpic *rp, int s_l, int s_c, xo_pel *pred[3], int vertex_num,
+                     int sub_w, int sub_h, int mem_ok, int bit_depth)
+{
+    const int bit = 7, mc_prec = 4, shift = bit - 2;
+    const int msh = mv[0][0] << bit, msv = mv[0][1] << bit;
+    int d_hor[2], d_ver[2];
+    xa_model(mv, cuw, cuh, vertex_num, bit, d_hor, d_ver);
+    if(sub_w < 8 || sub_h < 8) { /* AFFINE_ADAPT_EIF_SIZE */
+        /* eif_derive_mv_clip_range (:1481-1530) */
+        const int max_pic[2] = {(pic_w + 128 - x - cuw - 1) << 5, (pic_h + 128 - y - cuh - 1) << 5}, min_pic[2] = {(-x - 128) << 5, (-y - 128) << 5};
+        static const int dev[5] = {128, 256, 544, 1120, 2272};
+        const int scale[2] = {msh, msv}, centre[2] = {cuw >> 1, cuh >> 1};
+        int mx[2], mn[2];
+        for(int c = 0; c < 2; c++) {
+            if(mem_ok) mx[c] = max_pic[c], mn[c] = min_pic[c];
+            else {
+                const int mid = xa_round(scale[c] + d_hor[c] * centre[0] + d_ver[c] * centre[1], 4), spread = dev[xa_log2(c == 0 ? cuw : cuh) - 3];
+                mn[c] = mid - spread, mx[c] = mid + spread;
+                if(mn[c] < min_pic[c]) mn[c] = min_pic[c], mx[c] = max_pic[c] < min_pic[c] + 2 * spread ? max_pic[c] : min_pic[c] + 2 * spread;
+                else if(mx[c] > max_pic[c]) mx[c] = max_pic[c], mn[c] = min_pic[c] > max_pic[c] - 2 * spread ? min_pic[c] : max_pic[c] - 2 * spread;
+            }
+            mx[c] = clip3i(-(1 << 17), (1 << 17) - 1, mx[c]), mn[c] = clip3i(-(1 << 17), (1 << 17) - 1, mn[c]);
+        }
+        /* (affine_mv_prec = bit + 2 = EIF_MV_PRECISION_INTERNAL: no further shift of the model, :2150-2156) */
+        xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->y, s_l, pred[0], cuw, 0, bit_depth);
+        xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->u, s_c, pred[1], cuw >> 1, 1, bit_depth);
+        xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->v, s_c, pred[2], cuw >> 1, 1, bit_depth);
+        return;
+    }
+    const int hor_max = (pic_w + 128 - x - cuw) << mc_prec, ver_max = (pic_h + 128 - y - cuh) << mc_prec, hor_min = (-128 - x) << mc_prec, ver_min = (-128 - y) << mc_prec;
+    const int half_w = sub_w >> 1, half_h = sub_h >> 1;
+    for(int h = 0; h < cuh; h += sub_h)
+        for(int w = 0; w < cuw; w += sub_w) {
+            /* (the reference adds half_w / half_h to a running position that never moves, :1829-1830: every sub-block takes the FIRST sub-block's centre -- see below) */
+            int th = xa_round(msh + d_hor[0] * half_w + d_ver[0] * half_h, shift), tv = xa_round(msv + d_hor[1] * half_w + d_ver[1] * half_h, shift);
+            th = clip3i(-(1 << 17), (1 << 17) - 1, th), tv = clip3i(-(1 << 17), (1 << 17) - 1, tv);
+            const int oh = th, ov = tv;
+            th = th < hor_min ? hor_min : th > hor_max ? hor_max : th, tv = tv < ver_min ? ver_min : tv > ver_max ? ver_max : tv;
+            const int gx = ((x + w) << mc_prec) + th, gy = ((y + h) << mc_prec) + tv;
+            xo_mc_l((oh & 15) != 0, (ov & 15) != 0, rp->y, gx, gy, s_l, cuw, pred[0] + h * cuw + w, sub_w, sub_h, bit_depth, xom_mc_l_coeff);
+            xo_mc_c((oh & 31) != 0, (ov & 31) != 0, rp->u, gx, gy, s_c, cuw >> 1, pred[1] + (h >> 1) * (cuw >> 1) + (w >> 1), sub_w >> 1, sub_h >> 1, bit_depth, xom_mc_c_coeff);
+            xo_mc_c((oh & 31) != 0, (ov & 31) != 0, rp->v, gx, gy, s_c, cuw >> 1, pred[2] + (h >> 1) * (cuw >> 1) + (w >> 1), sub_w >> 1, sub_h >> 1, bit_depth, xom_mc_c_coeff);
+        }
+}
+void xo_affine_mc(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_affine_job *job, int w, int h, int bit_depth, xo_pel *pred_y, xo_pel *pred_u,
+                  xo_pel *pred_v, int *path)
+{
+    int sub_w, sub_h, mem_ok, n = 0;
+    xa_subblock_size(job, w, h, &sub_w, &sub_h, &mem_ok);
+    if(path) path[0] = sub_w, path[1] = sub_h, path[2] = mem_ok;
+    const size_t nl = (size_t)w * h, nc = nl / 4;
+    xo_pel *second = (xo_pel *)malloc(sizeof(xo_pel) * (nl + 2 * nc));
+    for(int l = 0; l < 2; l++) {
+        if(job->refi[l] < 0) continue;
+        xo_pel *p[3] = {n ? second : pred_y, n ? second + nl : pred_u, n ? second + nl + nc : pred_v};
+        xa_mc_lc(job->x, job->y, pic_w, pic_h, w, h, job->mv[l], &refp[job->refi[l] * 2 + l], s_l, s_c, p, job->vertex_num, sub_w, sub_h, mem_ok, bit_depth);
+        n++;
+    }
+    if(n == 2) { /* (:2305-2338) */
+        for(size_t i = 0; i < nl; i++) pred_y[i] = (xo_pel)((pred_y[i] + second[i] + 1) >> 1);
+        for(size_t i = 0; i < nc; i++) pred_u[i] = (xo_pel)((pred_u[i] + second[nl + i] + 1) >> 1), pred_v[i] = (xo_pel)((pred_v[i] + second[nl + nc + i] + 1) >> 1);
+    }
+    free(second);
+}

@@ -523,6 +523,21 @@ void xo_alf_filter5(xo_pel *dst, int s_dst, const xo_pel *src, int s_src, const 
 void xo_alf_blk_stats(int taps, const uint8_t *classifier, int s_cls, const xo_pel *org, int s_org, const xo_pel *rec, int s_rec, int x, int y, int w, int h,
                       double *E /* [nclasses][13][13] */, double *yv /* [nclasses][13] */, double *pix /* [nclasses] */);
 
+/* ---- Main profile: affine motion compensation of one CU (reference: xeve_affine_mc, src_main/xevem_mc.c:2236-2339) ---------------------------------------------------- */
+typedef struct xo_affine_job {
+    int32_t x, y;         /* CU position, luma samples */
+    int16_t mv[2][3][2];  /* per list the control-point vectors (top-left, top-right, bottom-left), quarter pel */
+    int8_t  refi[2];      /* < 0: list unused */
+    int8_t  vertex_num;   /* 2 (four-parameter model: the third vector is not read) | 3 */
+    int8_t  pad_;
+} xo_affine_job;
+/* derive_affine_subblock_size_bi (xevem_util.c:1203-1272, with check_eif_applicability_bi :1451-1480), then per used list xeve_affine_mc_lc (:1671-1915: blocks of
+ * sub_w x sub_h through the Main 8- / 4-tap filters at the block centre's vector, or -- sub-blocks below 8 -- the enhanced interpolation filter, xeve_eif_mc :2123-2234:
+ * a bilinear sample per position at the position's own vector, then the 3-tap {-1, 10, -1} filter in both directions), then the average of two lists.  refp[refi * 2 + list];
+ * pred_* dense (w, w / 2); 4:2:0.  path (may be NULL): sub_w, sub_h, the memory-bandwidth condition. */
+void xo_affine_mc(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_affine_job *job, int w, int h, int bit_depth, xo_pel *pred_y, xo_pel *pred_u,
+                  xo_pel *pred_v, int *path);
+
 #ifdef __cplusplus
 }
 #endif
