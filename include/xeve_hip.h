@@ -971,6 +971,26 @@ void xeve_hip_alf_filter_blk_7_host(uint8_t **classifier, xeve_hip_pel *rec_dst,
 void xeve_hip_alf_filter_blk_5_host(uint8_t **classifier, xeve_hip_pel *rec_dst, int dst_stride, const xeve_hip_pel *rec_src, int src_stride, const xeve_hip_alf_area *blk,
                                     uint8_t comp_id, short *filter_set, const xeve_hip_alf_clip_range *clip_range);
 
+/* ------------------------------------------------------------------------------------------- */
+/* Main profile: affine motion compensation of a batch of CUs of one size (*/
+/* "affine MC").  reference: xeve_affine_mc (src_main/xevem_mc.c:2236-2339) =                      */
+/* derive_affine_subblock_size_bi (xevem_util.c:1203-1272), per list in use xeve_affine_mc_lc      */
+/* (:1671-1915: the Main 8- / 4-tap filters, or -- sub-blocks below 8 -- the enhanced              */
+/* interpolation filter, xeve_eif_mc :2123-2234), the average of two lists.  4:2:0.                */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_affine_job {
+    int32_t x, y;         /* CU position in luma samples (multiples of 4) */
+    int16_t mv[2][3][2];  /* mv[list][VER_NUM][MV_D]: the control-point vectors (top-left, top-right, bottom-left), quarter pel */
+    int8_t  refi[2];      /* < 0: list unused; else below the list's num_refp */
+    int8_t  vertex_num;   /* 2: four-parameter model (the third vector is not read) | 3 */
+    int8_t  pad_;
+} xeve_hip_affine_job;
+/* refp: HOST array indexed [refi * 2 + list] of DEVICE planes (sample (0, 0); padded like the reference's: the vectors are clipped to 128 samples around the picture,
+ * the filters reach 4 further); jobs, pred_*: device memory.  pred_y [njobs][h * w], pred_u / pred_v [njobs][(h / 2) * (w / 2)] receive what the reference leaves in
+ * pred[0][Y_C / U_C / V_C].  w, h: powers of two, 8 .. 128. */
+int xeve_hip_affine_mc_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h, const xeve_hip_affine_job *jobs, int njobs,
+                            int w, int h, int bit_depth, xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

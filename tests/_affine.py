@@ -128,3 +128,35 @@ def digests(Y, U, V):
     import hashlib
 
     return np.stack([np.frombuffer(hashlib.md5(Y[i].tobytes() + U[i].tobytes() + V[i].tobytes()).digest(), np.uint8) for i in range(len(Y))])
+
+
+HOST_SRC = os.path.join(ROOT, "tests", "native", "affine_host.cpp")
+HOST_HDR = os.path.join(ROOT, "xeve_amd", "csrc", "affine_core.h")
+HOST_OUT = os.path.join(ROOT, "tests", "native", "build", "libaffine_host.so")
+
+
+class HostAffine(OracleAffine):
+    """affine_core.h compiled by g++ (tests/native/affine_host.cpp): the kernel's per-CU set-up and per-sample functions"""
+    name = "affine_core.h on the host"
+
+    def __init__(self):
+        import subprocess
+
+        OracleAffine.__init__(self)
+        if not os.path.exists(HOST_OUT) or os.path.getmtime(HOST_OUT) < max(os.path.getmtime(HOST_SRC), os.path.getmtime(HOST_HDR)):
+            os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT, HOST_SRC], check=True)
+        self.H = C.CDLL(HOST_OUT)
+        self.H.xa_host_affine_mc.restype = None
+        self.cl = (C.c_int16 * 128).in_dll(self.L, "xom_mc_l_coeff")  # the Main filters (pinned against the reference's tables by tests/test_main_oracle_vs_ref.py)
+        self.cc = (C.c_int16 * 128).in_dll(self.L, "xom_mc_c_coeff")
+
+    def run(self, pics, jobs, w, h):
+        n, t = len(jobs), refp_table(pics)
+        s_l, s_c = strides(pics)
+        Y, U, V, path = np.zeros((n, h, w), np.int16), np.zeros((n, h // 2, w // 2), np.int16), np.zeros((n, h // 2, w // 2), np.int16), np.zeros((n, 3), np.int32)
+        for i in range(n):
+            self.H.xa_host_affine_mc(C.c_void_p(t.ctypes.data), C.c_int(s_l), C.c_int(s_c), C.c_int(PIC_W), C.c_int(PIC_H), C.c_void_p(jobs[i:i + 1].ctypes.data), C.c_int(w), C.c_int(h),
+                                     C.c_int(BD), self.cl, self.cc, C.c_void_p(Y[i].ctypes.data), C.c_void_p(U[i].ctypes.data), C.c_void_p(V[i].ctypes.data),
+                                     C.c_void_p(path[i].ctypes.data))
+        return Y, U, V, path

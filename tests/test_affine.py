@@ -58,3 +58,56 @@ def test_oracle_affine_mc_matches_the_reference_in_place(size):
     for k in range(4):
         assert np.array_equal(a[k], b[k]), k
     check(A.RefAffine(), w, h)  # (and the committed goldens are what the reference produces today)
+
+
+@pytest.mark.parametrize("size", A.SIZES, ids=["%dx%d" % s for s in A.SIZES])
+def test_the_kernels_per_lane_code_on_the_host_matches_the_goldens(size):
+    """xeve_amd/csrc/affine_core.h (subblock_size, block_vector, mc_sample, eif_range / eif_bilinear / eif_out: what the lanes of affine.hip run) compiled for the host"""
+    check(A.HostAffine(), *size)
+
+
+class HipAffine:
+    """xeve_hip_affine_mc_jobs: all jobs of a size in ONE launch, the reference pictures resident in HBM"""
+    name = "hip"
+
+    def __init__(self):
+        import torch
+
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        self.t, self.L, self.check, self.dev = torch, lib.load(), lib.check, torch.device("cuda:0")
+        self.planes = None
+
+    def run(self, pics_, jobs, w, h):
+        t = self.t
+        if self.planes is None:  # upload once: [refi][list][c] -> device tensor
+            self.planes = [[[t.from_numpy(c).to(self.dev) for c in comps] for comps in row] for row in pics_]
+        tab = np.zeros(len(pics_) * 2, A.REFPIC)
+        for r, row in enumerate(self.planes):
+            for l, comps in enumerate(row):
+                ptr = [comps[c].data_ptr() + 2 * ((A.PAD if c == 0 else A.PAD // 2) * (comps[c].shape[1] + 1)) for c in range(3)]
+                tab[r * 2 + l] = (ptr[0], ptr[1], ptr[2], 8 * r + l, 0)
+        s_l, s_c = A.strides(pics_)
+        n = len(jobs)
+        d_jobs = t.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        Y, U, V = (t.full((n * k,), -1, dtype=t.int16, device=self.dev) for k in (h * w, h * w // 4, h * w // 4))
+        self.check(self.L.xeve_hip_affine_mc_jobs(tab.ctypes.data, len(pics_), len(pics_), s_l, s_c, A.PIC_W, A.PIC_H, d_jobs.data_ptr(), n, w, h, A.BD, Y.data_ptr(), U.data_ptr(),
+                                                  V.data_ptr(), None))
+        t.cuda.synchronize()
+        return Y.cpu().numpy().reshape(n, h, w), U.cpu().numpy().reshape(n, h // 2, w // 2), V.cpu().numpy().reshape(n, h // 2, w // 2), None
+
+
+@pytest.fixture(scope="module")
+def hip_affine():
+    return HipAffine()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", A.SIZES, ids=["%dx%d" % s for s in A.SIZES])
+def test_hip_affine_mc_matches_oracle_and_goldens(size, hip_affine):
+    w, h = size
+    Y, U, V = check(hip_affine, w, h)
+    a = A.OracleAffine().run(pics(), A.make_jobs(w, h, 7 + w + h), w, h)
+    assert np.array_equal(Y, a[0]) and np.array_equal(U, a[1]) and np.array_equal(V, a[2])

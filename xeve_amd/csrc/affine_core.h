@@ -1,0 +1,150 @@
+// xeve_amd/csrc/affine_core.h -- Main profile, affine motion compensation of a CU (xeve_affine_mc, src_main/xevem_mc.c:2236-2339) as per-CU set-up and per-sample
+// functions: what the lanes of affine.hip compute.  __host__ __device__: tests/native/affine_host.cpp compiles the same source for the host and holds it to goldens of the
+// reference's own function without a GPU.
+//   derive_affine_subblock_size_bi + check_eif_applicability_bi (xevem_util.c:1203-1272, 1421-1480)  -> subblock_size
+//   xeve_affine_mc_lc's sub-block branch (:1826-1915)                                                 -> block_vector + mc_sample<8 | 4>
+//   eif_derive_mv_clip_range + xeve_eif_mc (:1481-1530, 2123-2234)                                     -> eif_range, eif_vector, eif_bilinear, eif_out
+// Two facts of the reference this form rests on (both held by the goldens): every sub-block of a CU takes the vector of the FIRST sub-block's centre (the loop adds
+// half_w / half_h to a position that never moves, :1832-1833), so the sub-block branch is one translation of the whole CU and the partition cannot show; and the vector of
+// a position of the enhanced filter is monotone in the position, so clipping it always = the reference's choice between a clipping and a non-clipping loop by the four
+// corner vectors (can_mv_clipping_occurs, :1917-1957).
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#define XF __host__ __device__ inline
+#else
+#define XF inline
+#endif
+
+namespace xaff {
+
+XF int iabs(int v) { return v < 0 ? -v : v; }
+XF int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+XF int ilog2(int v) { int l = 0; while((1 << l) < v) l++; return l; }
+XF int round_s32(int v, int rs) { return (v + (rs > 0 ? 1 << (rs - 1) : 0) - (v >= 0)) >> rs; } // xeve_rounding_s32 (xevem_util.c:1197-1201)
+
+struct Model { // one list's motion model at 2 + 7 fractional bits: the CU's top-left vector and the change per luma sample to the right / down
+    int scale[2], d_hor[2], d_ver[2];
+};
+XF Model model(const int16_t mv[3][2], int cuw, int cuh, int vertex_num)
+{ // (:1697-1728; calculate_affine_motion_model_parameters, xevem_util.c:1331-1356)
+    Model m;
+    for(int c = 0; c < 2; c++) m.scale[c] = mv[0][c] << 7, m.d_hor[c] = ((mv[1][c] - mv[0][c]) << 7) >> ilog2(cuw);
+    if(vertex_num == 3)
+        for(int c = 0; c < 2; c++) m.d_ver[c] = ((mv[2][c] - mv[0][c]) << 7) >> ilog2(cuh);
+    else m.d_ver[0] = -m.d_hor[1], m.d_ver[1] = m.d_hor[0];
+    return m;
+}
+
+// sub_w x sub_h and whether the 4x4 block's footprint stays within the memory-bandwidth budget, over the lists in use
+XF void subblock_size(const int8_t refi[2], const int16_t mv[2][3][2], int vertex_num, int cuw, int cuh, int &sub_w, int &sub_h, bool &mem_ok)
+{
+    bool eif = true, checking = true;
+    sub_w = cuw, sub_h = cuh, mem_ok = true;
+    for(int l = 0; l < 2; l++) {
+        if(refi[l] < 0) continue;
+        const Model m = model(mv[l], cuw, cuh, vertex_num);
+        const int wx = iabs(m.d_hor[0]) > iabs(m.d_hor[1]) ? iabs(m.d_hor[0]) : iabs(m.d_hor[1]), wy = iabs(m.d_ver[0]) > iabs(m.d_ver[1]) ? iabs(m.d_ver[0]) : iabs(m.d_ver[1]);
+        const int w = wx > 4 ? 4 : wx == 0 ? cuw : wx == 1 ? 32 : wx == 2 ? 16 : 8, h = wy > 4 ? 4 : wy == 0 ? cuh : wy == 1 ? 32 : wy == 2 ? 16 : 8;
+        sub_w = w < sub_w ? w : sub_w, sub_h = h < sub_h ? h : sub_h;
+        if(!checking) continue; // (check_eif_applicability_bi returns at the first list that fails: a later list's bandwidth answer is not taken, xevem_util.c:1465-1476)
+        // check_eif_applicability_uni: the bounding box of a 4x4 block (+ 1 sample each way) in the reference picture ...
+        int box[2];
+        for(int c = 0; c < 2; c++) {
+            const int c1 = 5 * (m.d_hor[c] + (c == 0 ? 512 : 0)), c2 = 5 * (m.d_ver[c] + (c == 1 ? 512 : 0)), c3 = c1 + c2;
+            int mx = 0, mn = 0;
+            mx = c1 > mx ? c1 : mx, mx = c2 > mx ? c2 : mx, mx = c3 > mx ? c3 : mx, mn = c1 < mn ? c1 : mn, mn = c2 < mn ? c2 : mn, mn = c3 < mn ? c3 : mn;
+            box[c] = ((mx - mn + 511) >> 9) + 2;
+        }
+        mem_ok = mem_ok && box[0] * box[1] <= 72;
+        // ... and the lines its first row fetches
+        if(m.d_ver[1] < -512 || ((m.d_ver[1] > 0 ? m.d_ver[1] : 0) + iabs(m.d_hor[1])) * 5 > 512) eif = false, checking = false;
+    }
+    if(!eif) sub_w = sub_w < 8 ? 8 : sub_w, sub_h = sub_h < 8 ? 8 : sub_h;
+}
+
+// the sub-block branch's vector in 1/16 sample: (oh, ov) as rounded -- its fractions choose the filter variant -- and (th, tv) clipped to 128 samples around the picture
+XF void block_vector(const Model &m, int sub_w, int sub_h, int x, int y, int cuw, int cuh, int pic_w, int pic_h, int &th, int &tv, int &oh, int &ov)
+{
+    oh = clip3(-(1 << 17), (1 << 17) - 1, round_s32(m.scale[0] + m.d_hor[0] * (sub_w >> 1) + m.d_ver[0] * (sub_h >> 1), 5));
+    ov = clip3(-(1 << 17), (1 << 17) - 1, round_s32(m.scale[1] + m.d_hor[1] * (sub_w >> 1) + m.d_ver[1] * (sub_h >> 1), 5));
+    th = clip3((-128 - x) << 4, (pic_w + 128 - x - cuw) << 4, oh), tv = clip3((-128 - y) << 4, (pic_h + 128 - y - cuh) << 4, ov);
+}
+
+// one sample of xeve_mc_l / xeve_mc_c's four variants (xeve_mc.c:99-381 with the Main coefficient tables): at(dy, dx) = the reference sample dy / dx from the sample the
+// vector's integer part points at; cx / cy: the TAPS coefficients of the vector's fractions; fx / fy: does the UNCLIPPED vector have a fraction (the variant)
+template <int TAPS, class At> XF int mc_sample(At at, bool fx, bool fy, const int16_t *cx, const int16_t *cy, int bit_depth)
+{
+    constexpr int back = TAPS / 2 - 1;
+    const int maxv = (1 << bit_depth) - 1;
+    if(!fx && !fy) return at(0, 0);
+    if(!fy) {
+        int acc = 0;
+        for(int t = 0; t < TAPS; t++) acc += cx[t] * at(0, t - back);
+        return clip3(0, maxv, acc >> 6);
+    }
+    if(!fx) {
+        int acc = 0;
+        for(int t = 0; t < TAPS; t++) acc += cy[t] * at(t - back, 0);
+        return clip3(0, maxv, acc >> 6);
+    }
+    const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
+    int acc2 = 0;
+    for(int r = 0; r < TAPS; r++) {
+        int acc = 0;
+        for(int t = 0; t < TAPS; t++) acc += cx[t] * at(r - back, t - back);
+        acc2 += cy[r] * (int16_t)(acc >> shift1);
+    }
+    return clip3(0, maxv, (acc2 + (1 << (shift2 - 1))) >> shift2);
+}
+
+// ---- the enhanced interpolation filter --------------------------------------------------------------------------------------------------------------------------------
+// the range the positions' vectors are clipped to, in 1/32 luma sample (eif_derive_mv_clip_range): the picture plus 128 samples, or -- bandwidth condition failed -- a
+// window around the CU centre's vector
+XF void eif_range(const Model &m, bool mem_ok, int x, int y, int cuw, int cuh, int pic_w, int pic_h, int mx[2], int mn[2])
+{
+    const int max_pic[2] = {(pic_w + 128 - x - cuw - 1) << 5, (pic_h + 128 - y - cuh - 1) << 5}, min_pic[2] = {(-x - 128) << 5, (-y - 128) << 5};
+    for(int c = 0; c < 2; c++) {
+        if(mem_ok) mx[c] = max_pic[c], mn[c] = min_pic[c];
+        else {
+            const int lg = ilog2(c == 0 ? cuw : cuh), spread = lg == 3 ? 128 : lg == 4 ? 256 : lg == 5 ? 544 : lg == 6 ? 1120 : 2272; // aff_mv_dev_bb2_125 (:104)
+            const int mid = round_s32(m.scale[c] + m.d_hor[c] * (cuw >> 1) + m.d_ver[c] * (cuh >> 1), 4);
+            mn[c] = mid - spread, mx[c] = mid + spread;
+            if(mn[c] < min_pic[c]) mn[c] = min_pic[c], mx[c] = max_pic[c] < min_pic[c] + 2 * spread ? max_pic[c] : min_pic[c] + 2 * spread;
+            else if(mx[c] > max_pic[c]) mx[c] = max_pic[c], mn[c] = min_pic[c] > max_pic[c] - 2 * spread ? min_pic[c] : max_pic[c] - 2 * spread;
+        }
+        mx[c] = clip3(-(1 << 17), (1 << 17) - 1, mx[c]), mn[c] = clip3(-(1 << 17), (1 << 17) - 1, mn[c]);
+    }
+}
+// a component's view of model and range: chroma halves the top-left vector and the range, not the change per (chroma) sample (xeve_eif_mc, :2163-2175)
+struct Eif {
+    int mv0[2], dx[2], dy[2], mx[2], mn[2];
+};
+XF Eif eif_component(const Model &m, const int mx[2], const int mn[2], bool chroma)
+{
+    Eif e;
+    for(int c = 0; c < 2; c++) e.mv0[c] = m.scale[c] >> (chroma ? 1 : 0), e.dx[c] = m.d_hor[c], e.dy[c] = m.d_ver[c], e.mx[c] = mx[c] >> (chroma ? 1 : 0), e.mn[c] = mn[c] >> (chroma ? 1 : 0);
+    return e;
+}
+// the bilinear sample of position (px, py), -1 .. bw / bh: at(dy, dx) = the component's reference sample dy / dx from the CU's first sample (xeve_eif_bilinear_clip, :1991-2058)
+template <class At> XF int eif_bilinear(At at, const Eif &e, int px, int py, int bit_depth)
+{
+    int v[2];
+    for(int c = 0; c < 2; c++) v[c] = clip3(e.mn[c], e.mx[c], (e.mv0[c] + px * e.dx[c] + py * e.dy[c]) >> 4);
+    const int ix = px + (v[0] >> 5), iy = py + (v[1] >> 5), fx = v[0] & 31, fy = v[1] & 31;
+    const int s1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, s2 = 20 - bit_depth > 8 ? 20 - bit_depth : 8;
+    const int16_t a = (int16_t)(((64 - 2 * fx) * at(iy, ix) + 2 * fx * at(iy, ix + 1)) >> s1), b = (int16_t)(((64 - 2 * fx) * at(iy + 1, ix) + 2 * fx * at(iy + 1, ix + 1)) >> s1);
+    return (int16_t)(((64 - 2 * fy) * a + 2 * fy * b + (1 << (s2 - 1))) >> s2);
+}
+// the output sample (px, py) from the bilinear samples: bl(r, c) = the one of position (c - 1, r - 1); {-1, 10, -1} along the rows, then down the columns, 16-bit
+// intermediates (xeve_eif_filter, :1959-1989)
+template <class Bl> XF int eif_out(Bl bl, int px, int py, int bit_depth)
+{
+    const int sh2 = bit_depth + 5 - 16 > 0 ? bit_depth + 5 - 16 : 0, sh3 = 6 - sh2, of2 = sh2 > 0 ? 1 << (sh2 - 1) : 0, of3 = 1 << (sh3 - 1);
+    int hrow[3];
+    for(int r = 0; r < 3; r++) hrow[r] = (int16_t)((-bl(py + r, px) + bl(py + r, px + 1) * 10 - bl(py + r, px + 2) + of2) >> sh2);
+    const int16_t res = (int16_t)((-hrow[0] + hrow[1] * 10 - hrow[2] + of3) >> sh3);
+    return clip3(0, (1 << bit_depth) - 1, res);
+}
+
+} // namespace xaff
