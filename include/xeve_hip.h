@@ -132,6 +132,10 @@ extern const XEVE_HIP_INTRA_PRED_ANG xeve_tbl_intra_pred_ang_hip[3][2];
 typedef void (*XEVE_HIP_INV_TRANS)(int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
 /* replaces xeve_itrans_map_tbl{,_sse} (xevem_itdq.c:42-47): [0] DCT-VIII, [1] DST-VII; [.][log2 N - 1], N = 4 .. 32 ([.][0] and rows 2 .. 15 are NULL there too) */
 extern const XEVE_HIP_INV_TRANS xeve_itrans_map_tbl_hip[16][5];
+/* the forward passes: the entries of xeve_trans_map_tbl (xevem_tq.c:53-56; `Trans`, :40-41: (block, coef, shift, line, skip_line, skip_line_2), the same argument list with
+ * input and output exchanged) -- an array the reference indexes directly (xeve_t_MxN_ats_intra, :698-699), so the binding assigns its entries:
+ * xeve_trans_map_tbl[t][n] = xeve_trans_map_tbl_hip[t][n] for t < 2, n = 1 .. 4 */
+extern const XEVE_HIP_INV_TRANS xeve_trans_map_tbl_hip[16][5];
 /* replace xevem_scaled_horizontal / _vertical_sobel_filter{,_sse} and xevem_equal_coeff_computer{,_sse} (xevem_mc.c:2341-2447): the kernels of the affine
  * gradient search; 3 <= width, height <= 128; equal_coeff is accumulated into (the caller zeroes it); residue is read with derivate_buf_stride, as the reference does */
 void xevem_scaled_horizontal_sobel_filter_hip(xeve_hip_pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height);

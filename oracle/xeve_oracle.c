@@ -296,6 +296,21 @@ void xo_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int
             block[i * n + j] = (int16_t)sum;
         }
 }
+void xo_trans_ats(int type, int log2n, const int16_t *block, int16_t *coef, int shift, int line, int skip_line, int skip_line_2)
+{ /* xeve_trans_DST7_B4 .. _DCT8_B32 (xevem_tq.c:336-680): the 4-point forms are the same products factorised (29 + 55 = 84) */
+    const int n = 1 << log2n, cut = log2n == 2 ? 4 : n - skip_line_2, rnd = 1 << (shift - 1);
+    int8_t    m[32 * 32];
+    xo_ats_matrix(type, log2n, m);
+    for(int j = 0; j < n; j++)
+        for(int i = 0; i < line; i++) {
+            int sum = 0;
+            if(i < line - skip_line && j < cut) {
+                for(int k = 0; k < n; k++) sum += m[j * n + k] * block[i * n + k];
+                sum = (sum + rnd) >> shift;
+            }
+            coef[j * line + i] = (int16_t)sum;
+        }
+}
 /* xevem_scaled_horizontal / _vertical_sobel_filter (xevem_mc.c:2341-2395): 3x3 Sobel gradient (weights 1 2 1, unnormalised) of the interior samples; the border
  * row / column / corner take the value of the nearest interior sample -- both functions write the border that way, in different orders.  w, h >= 3. */
 void xo_sobel(int vertical, const xo_pel *pred, int s_pred, int32_t *der, int s_der, int w, int h)

@@ -65,6 +65,9 @@ void xo_mc_main(int kind, int frac_x, int frac_y, const xo_pel *ref, int gmv_x, 
 void xo_ipred_ang(int group, int right, const xo_pel *le, const xo_pel *up, const xo_pel *ri, xo_pel *dst, int w, int h, int ipm, int bit_depth);
 void xo_ats_matrix(int type, int log2n, int8_t *m);
 void xo_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2);
+/* the forward passes, xeve_trans_map_tbl[type][log2 N - 1] (xevem_tq.c:53-56, 336-680): coef[j * line + i] = (sum_k M[j][k] block[i * N + k] + rnd) >> shift (no clip, 16-bit
+ * store) for i < line - skip_line and j < N - skip_line_2 (the 4-point forms ignore skip_line_2), zero elsewhere */
+void xo_trans_ats(int type, int log2n, const int16_t *block, int16_t *coef, int shift, int line, int skip_line, int skip_line_2);
 void xo_sobel(int vertical, const xo_pel *pred, int s_pred, int32_t *der, int s_der, int w, int h);
 void xo_equal_coeff(const xo_pel *residue, const int32_t *d0, const int32_t *d1, int s_der, int64_t (*eq)[7], int w, int h, int vertex_num);
 

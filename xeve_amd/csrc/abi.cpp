@@ -23,6 +23,7 @@
 int xh_tq_init();
 int xh_main_tools_init(); // main_tools.hip: the ATS matrices
 int xh_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int shift, int line, int skip_line, int skip_line_2, hipStream_t st);
+int xh_trans_ats(int type, int log2n, const int16_t *block, int16_t *coef, int shift, int line, int skip_line, int skip_line_2, hipStream_t st);
 int xh_sobel(int vertical, const pel *pred, int s_pred, int32_t *der, int s_der, int w, int h, hipStream_t st);
 int xh_ipred_ang(int group, int right, const pel *lines, pel *dst, int w, int h, int ipm, int bit_depth, hipStream_t st);
 int xh_equal_coeff(const pel *residue, const int32_t *d0, const int32_t *d1, int s_der, long *eq, int w, int h, int vertex_num, hipStream_t st);
@@ -557,6 +558,21 @@ template <int TYPE, int LOG2N> static void tbl_itrans_ats(int16_t *coef, int16_t
     S.sync();
     memcpy(block, S.h<char>(REG_OUT), bytes);
 }
+// forward ATS passes (xeve_trans_map_tbl[type][log2 N - 1], xevem_tq.c:53-56)
+template <int TYPE, int LOG2N> static void tbl_trans_ats(int16_t *block, int16_t *coef, int shift, int line, int skip_line, int skip_line_2)
+{
+    Stage &S = stage();
+    g_table_calls++, g_table_calls_main++;
+    const size_t bytes = sizeof(int16_t) * (size_t)(1 << LOG2N) * line;
+    if(bytes > (64 << 10)) {
+        xh_set_error("forward ATS table call N=%d line=%d exceeds the staging tile", 1 << LOG2N, line);
+        die(__func__);
+    }
+    memcpy(S.h<char>(REG_A), block, bytes);
+    TBL_RC(xh_trans_ats(TYPE, LOG2N, S.d<int16_t>(REG_A), S.d<int16_t>(REG_OUT), shift, line, skip_line, skip_line_2, S.st));
+    S.sync();
+    memcpy(coef, S.h<char>(REG_OUT), bytes);
+}
 // Sobel derivatives of an affine prediction (xevem_func_aff_h / v_sobel_flt, xevem_mc.c:2341-2395)
 template <int VERTICAL> static void tbl_sobel(pel *pred, int pred_stride, int *derivate, int derivate_buf_stride, int width, int height)
 {
@@ -597,6 +613,10 @@ static void tbl_ipred_ang(pel *src_le, pel *src_up, pel *src_ri, uint16_t avail_
 extern "C" {
 const XEVE_HIP_INTRA_PRED_ANG xeve_tbl_intra_pred_ang_hip[3][2] = {{tbl_ipred_ang<0, 0>, tbl_ipred_ang<0, 1>}, {tbl_ipred_ang<1, 0>, tbl_ipred_ang<1, 1>},
                                                                    {tbl_ipred_ang<2, 0>, tbl_ipred_ang<2, 1>}};
+const XEVE_HIP_INV_TRANS xeve_trans_map_tbl_hip[16][5] = {
+    {nullptr, tbl_trans_ats<0, 2>, tbl_trans_ats<0, 3>, tbl_trans_ats<0, 4>, tbl_trans_ats<0, 5>},
+    {nullptr, tbl_trans_ats<1, 2>, tbl_trans_ats<1, 3>, tbl_trans_ats<1, 4>, tbl_trans_ats<1, 5>},
+};
 const XEVE_HIP_INV_TRANS xeve_itrans_map_tbl_hip[16][5] = {
     {nullptr, tbl_itrans_ats<0, 2>, tbl_itrans_ats<0, 3>, tbl_itrans_ats<0, 4>, tbl_itrans_ats<0, 5>},
     {nullptr, tbl_itrans_ats<1, 2>, tbl_itrans_ats<1, 3>, tbl_itrans_ats<1, 4>, tbl_itrans_ats<1, 5>},

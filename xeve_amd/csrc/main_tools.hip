@@ -54,6 +54,32 @@ int xh_itrans_ats(int type, int log2n, const int16_t *coef, int16_t *block, int 
     return XEVE_HIP_OK;
 }
 
+// the forward pass: coef[j * line + i] = (sum_k M[j][k] * block[i * N + k] + rnd) >> shift for i < line - skip_line, j < cut, 0 elsewhere (xeve_trans_DST7_B4 .. _DCT8_B32,
+// xevem_tq.c:336-680: no clip, the sum is stored in 16 bits); one thread per output
+__global__ void k_trans_ats(const int16_t *__restrict__ block, int16_t *__restrict__ coef, int type, int log2n, int shift, int line, int skip_line, int cut)
+{
+    const int n = 1 << log2n, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= n * line) return;
+    const int j = t / line, i = t - j * line;
+    int sum = 0;
+    if(i < line - skip_line && j < cut) {
+        const int8_t *m = c_ats[type] + ats_off(log2n) + j * n;
+        for(int k = 0; k < n; k++) sum += m[k] * block[i * n + k];
+        sum = (sum + (1 << (shift - 1))) >> shift;
+    }
+    coef[t] = (int16_t)sum;
+}
+int xh_trans_ats(int type, int log2n, const int16_t *block, int16_t *coef, int shift, int line, int skip_line, int skip_line_2, hipStream_t st)
+{
+    XH_ENTER();
+    XH_REQUIRE(block && coef && (type == 0 || type == 1) && log2n >= 2 && log2n <= 5 && shift >= 1 && shift <= 24 && line >= 1 && line <= 64);
+    XH_REQUIRE(skip_line >= 0 && skip_line <= line && skip_line_2 >= 0 && skip_line_2 <= (1 << log2n));
+    const int n = 1 << log2n, total = n * line;
+    k_trans_ats<<<(total + 255) / 256, 256, 0, st>>>(block, coef, type, log2n, shift, line, skip_line, log2n == 2 ? 4 : n - skip_line_2); // (the 4-point forms ignore skip_line_2)
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+
 // 3x3 Sobel gradient (weights 1 2 1) at the sample clamped into the interior: the reference copies the nearest interior value to the border (xevem_mc.c:2341-2395)
 __global__ void k_sobel(const pel *__restrict__ pred, int s_pred, int32_t *__restrict__ der, int s_der, int w, int h, int vertical)
 {

@@ -279,6 +279,7 @@ TABLES = {
     "xeve_tbl_tx_hip": FN_TX * 6,
     "xeve_tbl_itx_hip": FN_TX * 6,
     "xeve_itrans_map_tbl_hip": FN_ITR * 80,  # [16][5]
+    "xeve_trans_map_tbl_hip": FN_ITR * 80,  # [16][5]
     "xeve_tbl_intra_pred_ang_hip": FN_ANG * 6,  # [3][2]
 }
 
