@@ -50,6 +50,7 @@ PLACEBO_CASES = {
     "placebo_cif_closed_gop": (352, 288, 4, 5006, ["--preset", "placebo", "--closed-gop", "-I", "4", "-b", "3"]),  # partial CTUs at the right and bottom edge
     "placebo_noise_allintra": (128, 128, 2, 11, ["--preset", "placebo", "-I", "1", "-b", "0"]),  # 64x64 intra CUs in I slices
     "placebo_jumpy_ldb": (192, 128, 4, 6001, ["--preset", "placebo", "-I", "0", "-b", "0"]),  # 23 x 17 samples of motion per frame: the raster search runs
+    "placebo_one_ctu_ldb": (64, 64, 2, 5041, ["--preset", "placebo", "-I", "0", "-b", "0"]),  # one CTU, I + B: what the race detector's long form walks with 64 real threads
 }
 
 # BASELINE.json's configs 2, 3 and 4 at their REAL picture sizes (first frames only): goldens are made by tests/golden/make_e2e_golden.py from the reference app; the

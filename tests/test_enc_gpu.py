@@ -139,7 +139,7 @@ def test_preset_slow_batches_on_the_gpu(name, team, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
-@pytest.mark.parametrize("name", sorted(_e2e.PLACEBO_CASES))
+@pytest.mark.parametrize("name", sorted(n for n in _e2e.PLACEBO_CASES if n != "placebo_one_ctu_ldb"))  # (that one is the CPU race detector's clip)
 def test_preset_placebo_single_runs_on_the_gpu(name, hip, yuv_dir):
     """--preset placebo on the device (the fused walk): inter CUs of 4x4 beside the intra analysis of every 4x4 node, 64x64 intra CUs in I slices, two reference pictures
     per list, the raster search, ME range 384, eight sub-pel positions per stage, four merge candidates, rdo_dbk_switch = the reference application's bitstreams"""

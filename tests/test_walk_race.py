@@ -67,7 +67,9 @@ def test_no_stage_races_in_whole_encodes(tsan_lib):
     subprocess.run(["g++", "-fsanitize=thread", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", ENC_OUT, os.path.join(ROOT, "oracle", "enc_oracle.cpp"),
                     tmp, "-lm"], check=True)
     env = dict(os.environ, LD_PRELOAD=TSAN, TSAN_OPTIONS="report_signal_unsafe=0 exitcode=0", XO_ENC_ORACLE_LIB=ENC_OUT, XO_ENC_WALK_THREADS="64", PYTHONPATH=ROOT)
+    # (round 5: + one CTU of an I and a B picture at preset placebo -- walk_dbk.h's edge-position stage, the quarter-pel and raster searches, 4x4 inter CUs)
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-s", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_walk_host.py"), "-k",
-                        "closed_gop_batches and (gops_128x128_moving_m2 or gops_192x256_noise_m3)"], capture_output=True, text=True, timeout=4 * 3600, cwd=ROOT, env=env)
+                        "(closed_gop_batches and (gops_128x128_moving_m2 or gops_192x256_noise_m3)) or placebo_one_ctu_ldb"], capture_output=True, text=True, timeout=6 * 3600, cwd=ROOT,
+                       env=env)
     assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
     assert "ThreadSanitizer" not in p.stderr, p.stderr[:6000]
