@@ -190,6 +190,26 @@ PRESET_REAL_CASES = {
     "slow_1080p_noise_3f_m8": (1920, 1080, 1, 3, 3, ["--preset", "slow", "--closed-gop", "-I", "8"], 8),
     "placebo_1080p_moving_3f_m8": (1920, 1080, 1, 3, 5049, ["--preset", "placebo", "--closed-gop", "-I", "8"], 8),
 }
+# What the PRODUCT library's configuration check (enc_plan.h Param::finish) takes and what it refuses -- ONE table, read by tests/test_enc_host.py through
+# xeve_hip_enc_footprint (no device: a change of the accepted set fails in the build container) and by tests/test_enc_gpu.py through xeve_hip_enc_create.
+# (kwargs of xeve_amd.encode.config beside w / h, accepted?)
+CONFIG_ACCEPTANCE = [
+    (dict(w=128, h=64), True),
+    (dict(w=128, h=64, preset=0), True), (dict(w=128, h=64, preset=1), True), (dict(w=128, h=64, preset=2), True), (dict(w=128, h=64, preset=3), True),
+    (dict(w=128, h=64, preset=4), False), (dict(w=128, h=64, preset=-1), False),
+    (dict(w=130, h=64), False), (dict(w=128, h=60), False), (dict(w=0, h=64), False), (dict(w=8200, h=64), False),
+    (dict(w=128, h=64, bframes=2), False), (dict(w=128, h=64, bframes=7), True),
+    (dict(w=128, h=64, qp=52), False), (dict(w=128, h=64, threads=9), False), (dict(w=64, h=128, threads=2), False), (dict(w=64, h=128, threads=1), True),
+    (dict(w=128, h=64, input_depth=12), False), (dict(w=128, h=64, input_depth=10), True),
+    (dict(w=128, h=64, inter_slice_type=1), True), (dict(w=128, h=64, inter_slice_type=2), False),
+    (dict(w=128, h=64, qp_cb_offset=3), True), (dict(w=128, h=64, qp_cr_offset=-2), True), (dict(w=128, h=64, inter_slice_type=1, qp_cb_offset=-12, qp_cr_offset=12), True),
+    (dict(w=128, h=64, qp_cb_offset=13), False), (dict(w=128, h=64, qp_cr_offset=-13), False),
+    (dict(w=128, h=64, preset=2, qp_cb_offset=2), False), (dict(w=128, h=64, preset=3, qp_cr_offset=-1), False),
+    (dict(w=128, h=64, ref=5), False), (dict(w=128, h=64, ref=2), True),
+    (dict(w=128, h=64, bframes=0, keyint=0, closed_gop=True), False),
+]
+
+
 _PIN_ENV = {"--inter-slice-type": "XEVE_PIN_INTER_SLICE_TYPE", "--qp-cb-offset": "XEVE_PIN_QP_CB_OFFSET", "--qp-cr-offset": "XEVE_PIN_QP_CR_OFFSET"}
 
 

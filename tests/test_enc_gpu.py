@@ -300,9 +300,13 @@ def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, walk, pictures
 
 
 def test_configurations_outside_the_supported_set_are_refused_by_the_library(hip):
+    """the refusals of tests/_enc.py CONFIG_ACCEPTANCE through xeve_hip_enc_create (the same table is held on the CPU through xeve_hip_enc_footprint, tests/test_enc_host.py)"""
     import xeve_amd
 
-    for kw in (dict(w=130, h=64), dict(w=128, h=64, preset=3), dict(w=128, h=64, bframes=2)):
+    refused = [dict(kw) for kw, ok in _enc.CONFIG_ACCEPTANCE if not ok]
+    assert len(refused) >= 10
+    for kw in refused:
+        kw.setdefault("keyint", 8), kw.setdefault("closed_gop", True)
         c = hip.config(kw.pop("w"), kw.pop("h"), **kw)
         with pytest.raises(xeve_amd.XeveHipError):
             hip.BatchEncoder(c, 1, 1)

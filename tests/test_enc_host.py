@@ -157,6 +157,22 @@ def test_the_product_library_takes_p_slices_and_chroma_qp_offsets_inside_their_r
             encode.footprint(encode.config(128, 64, keyint=8, closed_gop=True, **kw), 1, 2)
 
 
+@pytest.mark.parametrize("kw,accepted", _enc.CONFIG_ACCEPTANCE, ids=[",".join("%s=%s" % i for i in k.items()) for k, _ in _enc.CONFIG_ACCEPTANCE])
+def test_the_product_library_accepts_and_refuses_what_the_table_says(kw, accepted):
+    """The table tests/test_enc_gpu.py reads on the device, held here without one (the refusal test went stale when preset placebo was accepted and
+    nothing in the build container noticed): xeve_hip_enc_footprint runs Param::finish, the same check xeve_hip_enc_create runs"""
+    from xeve_amd import encode, lib
+
+    kw = dict(kw)
+    kw.setdefault("keyint", 8), kw.setdefault("closed_gop", True)
+    c = encode.config(kw.pop("w"), kw.pop("h"), **kw)
+    if accepted:
+        assert encode.footprint(c, 1, 2)[0] > 0
+    else:
+        with pytest.raises(lib.XeveHipError):
+            encode.footprint(c, 1, 2)
+
+
 WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
