@@ -826,6 +826,11 @@ int xeve_hip_walk_select(int mode);
 /* Chains a team of the fused kernel carries: 0 (the default) = as few as keep every chain of the running encoders resident (1 up to ~1000 chains), 1..8 pins it
  * (XEVE_HIP_WALK_C); returns the value before the call (a value outside 0..8 only reads it).  Results do not depend on it. */
 int xeve_hip_walk_team(int chains_per_team);
+/* The composed walk's SIDE STREAM (round 6): the analyses of every node that has children (the unsplit alternative of mode_coding_tree, xeve_mode.c:2073-2146) run on a
+ * second stream of the library's while the caller's stream walks on into the children (:2189-2262) -- neither needs anything of the other until the two costs are compared
+ * (:2306-2329) --, joined with events in front of that comparison: two launch chains side by side.  1 on (the default; XEVE_HIP_TREE_SIDE=0 starts with it off), 0 the
+ * one-stream walk; returns the value before the call (any other value only reads it).  Results do not depend on it; the workspace query covers both. */
+int xeve_hip_walk_side(int on);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,
                                          const xeve_hip_sbac *states, int nstates, const xeve_hip_tree_params *params, const xeve_hip_ctu_job *jobs, int nchains,

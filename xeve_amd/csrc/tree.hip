@@ -18,6 +18,7 @@
 // result only where the inter winner has a residual and the intra cost is smaller (mode_check_intra, :1226-1308); a skipped CU at depth >= ecu_depth is not split.
 // All costs are doubles built with the reference's operations in the reference's order (-ffp-contract=off), compared as the reference compares them.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -30,8 +31,8 @@ typedef xeve_hip_ctu_data CtuData;
 typedef xeve_hip_sbac     SbacState;
 
 struct Node { // one per (level, chain)
-    int    active, x0, y0, leaf, do_split, best_split, dist_cu, cu_mode, try_intra, pad_;
-    double cost_best, cost_temp, unit_cost;
+    int    active, x0, y0, leaf, do_split, best_split, dist_cu, cu_mode, try_intra, next_split; // next_split: a side node's early-termination verdict (op_leaf_side -> op_exit)
+    double cost_best, cost_temp, unit_cost, cost_split;                                         // cost_split: a side node's split alternative (cost_temp is then the unsplit one's alone)
 };
 
 struct TreeK {
@@ -50,26 +51,35 @@ struct TreeK {
     // workspace (device)
     Node                       *node;                          // [5][nchains]
     SbacState                  *curr, *next, *before, *tdepth; // [5][nchains] each: core->s_curr_best / s_next_best [L][L], s_temp_prev_comp_best, s_temp_depth
-    SbacState                  *sbest;                         // [nchains]: core->s_temp_best of the node's intra analysis
     CtuData                    *best, *temp;                   // [5][nchains]: core->cu_data_best / cu_data_temp [L][L]
-    xeve_hip_intra_job         *ijobs;                         // [nchains]
-    const xeve_hip_intra_result *ires;                         // [nchains]
-    const int16_t              *icoef;                         // dense blocks of the node's analysis: Y of all chains, then U, then V
-    const pel                  *irec;
     // P / B slices
     int                         inter, ecu_depth, s_org_l, vh; // vh: P / B chains of several pictures -- the batch as one tall picture for the inter analysis (xh_common.h)
     int16_t                   (*map_mv)[2][2];
     int8_t                    (*map_refi)[2];
-    xeve_hip_inter_job         *ejobs;                         // [nchains]
-    xeve_hip_job               *sjobs;                         // [nchains]: SATD(original, inter winner's luma prediction)
-    const xeve_hip_inter_result *eres;
-    const int16_t              *ecoef;                         // Y of all chains, then U, then V
-    const pel                  *erec[3];                       // [nchains][block] per component
-    const int32_t              *esatd;
-    const SbacState            *enext;                         // [nchains]: core->s_next_best of the inter analysis
+    // THE SIDE STREAM (round 6).  The analysis of a node that has children needs nothing its children produce and they need nothing of it -- both start from the node's
+    // entry state and from neighbours outside the node (xeve_mode.c:2061-2262: s_curr_before_split; the maps inside the node are cleared for either) -- until op_exit
+    // compares the two costs.  A call with a side stream runs the analyses of every such node there while the main stream walks on into the children: two launch
+    // chains side by side instead of one.  Every array an analysis reads or writes exists once per stream (ac[0] main, ac[1] side); side_of[L] says which a level uses.
+    struct Ac {
+        xeve_hip_intra_job          *ijobs; // [5][nchains]: the job arrays per LEVEL -- the main stream enters the next side node while the side stream may still be reading an outer one's
+        const xeve_hip_intra_result *ires;  // [nchains]
+        const int16_t               *icoef; // dense blocks of the node's analysis: Y of all chains, then U, then V
+        const pel                   *irec;
+        SbacState                   *sbest; // [nchains]: core->s_temp_best of the node's intra analysis
+        xeve_hip_inter_job          *ejobs; // [5][nchains]
+        xeve_hip_job                *sjobs; // [5][nchains]: SATD(original, inter winner's luma prediction)
+        const xeve_hip_inter_result *eres;
+        const int16_t               *ecoef;   // Y of all chains, then U, then V
+        const pel                   *erec[3]; // [nchains][block] per component
+        const int32_t               *esatd;
+        const SbacState             *enext;   // [nchains]: core->s_next_best of the inter analysis
+    } ac[2];
+    unsigned char side_of[8]; // per level L: 1 = the node's analyses run on the side stream (it has a CU of its size AND children), 0 = in line
+    SbacState    *csplit;     // [5][nchains]: the state the FIRST child of a node starts from (the node's entry state + split_cu_flag = 1)
+    CtuData      *tsplit;     // [5][nchains]: a side node's cu_data_temp of the split alternative (temp stays the staging block of its own analysis)
 };
 
-enum { OP_ENTER = 0, OP_LEAF = 1, OP_CHILD_DONE = 2, OP_EXIT = 3, OP_ROOT_DONE = 4, OP_MID = 5 };
+enum { OP_ENTER = 0, OP_LEAF = 1, OP_CHILD_DONE = 2, OP_EXIT = 3, OP_ROOT_DONE = 4, OP_MID = 5, OP_SPLIT_PREP = 6, OP_LEAF_SIDE = 7 };
 #define MAX_OPS 12
 struct OpList {
     int           n;
@@ -223,7 +233,7 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
             const Node *p = AT(K.node, L + 1);
             x0 = p->x0 + (part & 1) * cu, y0 = p->y0 + (part >> 1) * cu;
             active = p->active && p->do_split && x0 < K.pic_w && y0 < K.pic_h;
-            if(active) *AT(K.curr, L) = part == 0 ? *AT(K.curr, L + 1) : *AT(K.next, L); // the state the previous quadrant's winner left (:2248-2262)
+            if(active) *AT(K.curr, L) = part == 0 ? *AT(K.csplit, L + 1) : *AT(K.next, L); // the state the previous quadrant's winner left (:2248-2262)
         }
         int leaf = 0, boundary = 0;
         if(active) {
@@ -251,13 +261,14 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
         xeve_hip_intra_job ij;
         memset(&ij, 0, sizeof(ij));
         ij.x = jx, ij.y = jy, ij.inter_satd = 0xFFFFFFFFu, ij.sbac = c, ij.pic = J.pic;
-        K.ijobs[c] = ij;
+        const TreeK::Ac &A = K.ac[K.side_of[L]];
+        *AT(A.ijobs, L) = ij;
         if(K.inter) {
             xeve_hip_inter_job ej;
             memset(&ej, 0, sizeof(ej));
             ej.x = jx, ej.y = jy + J.pic * K.vh, ej.sbac = c; // ctx_skip / ctx_pred_mode: 0 without sps_cm_init_flag (xeve_get_ctx_some_flags, xeve_util.c:1181-1288)
-            K.ejobs[c] = ej;
-            K.sjobs[c] = xh_make_job((long)jy + (long)J.pic * K.vh, K.s_org_l, jx, c * cu * cu);
+            *AT(A.ejobs, L) = ej;
+            *AT(A.sjobs, L) = xh_make_job((long)jy + (long)J.pic * K.vh, K.s_org_l, jx, c * cu * cu);
             nd->try_intra = 0, nd->cu_mode = 0, nd->unit_cost = MAX_COST;
         }
         sh[0] = active, sh[1] = leaf, sh[2] = boundary, sh[3] = x0, sh[4] = y0;
@@ -294,64 +305,82 @@ __device__ static void op_mid(const TreeK &K, int c, int L)
     Node *nd = AT(K.node, L);
     if(!nd->leaf) return;
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
-    const xeve_hip_inter_result R = K.eres[c];
-    unit_to_temp(K, AT(K.temp, L), log2, cud, n, R.cu_mode, nullptr, R.nnz, &K.eres[c], K.ecoef + (long)c * n0, K.ecoef + (long)K.nchains * n0 + (long)c * n1,
-                 K.ecoef + (long)K.nchains * (n0 + n1) + (long)c * n1, K.erec[0] + (long)c * n0, K.erec[1] + (long)c * n1, K.erec[2] + (long)c * n1, n0, n1);
+    const TreeK::Ac &A = K.ac[K.side_of[L]];
+    const xeve_hip_inter_result R = A.eres[c];
+    unit_to_temp(K, AT(K.temp, L), log2, cud, n, R.cu_mode, nullptr, R.nnz, &A.eres[c], A.ecoef + (long)c * n0, A.ecoef + (long)K.nchains * n0 + (long)c * n1,
+                 A.ecoef + (long)K.nchains * (n0 + n1) + (long)c * n1, A.erec[0] + (long)c * n0, A.erec[1] + (long)c * n1, A.erec[2] + (long)c * n1, n0, n1);
     if(threadIdx.x == 0) {
         nd->unit_cost = R.cost, nd->cu_mode = R.cu_mode;
         nd->try_intra = R.nnz[0] != 0 || R.nnz[1] != 0 || R.nnz[2] != 0;
-        if(nd->try_intra) K.ijobs[c].inter_satd = (uint32_t)K.esatd[c]; // core->inter_satd (a chain that does not try intra keeps the job: its result is dropped)
+        if(nd->try_intra) AT(A.ijobs, L)->inter_satd = (uint32_t)A.esatd[c]; // core->inter_satd (a chain that does not try intra keeps the job: its result is dropped)
     }
+}
+
+// mode_coding_unit's end (:1310-1350) and the store of the unsplit alternative (:2116-2137): the intra analysis becomes the CU's mode in an I slice, and in a P / B slice
+// where it is cheaper than the inter winner.  to_pic: mode_cpy_rec_to_ref now (a side node leaves it to op_exit: its children are writing the same samples meanwhile,
+// nothing reads the node's own reconstruction before op_exit puts the winner's there anyway)
+__device__ static void leaf_decide(const TreeK &K, int c, int L, int *sh, bool to_pic)
+{
+    const xeve_hip_ctu_job J = K.jobs[c];
+    Node *nd = AT(K.node, L);
+    const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
+    CtuData *t = AT(K.temp, L), *b = AT(K.best, L);
+    const TreeK::Ac &A = K.ac[K.side_of[L]];
+    const xeve_hip_intra_result R = A.ires[c];
+    const int intra_wins = !K.inter || (nd->try_intra && R.cost < nd->unit_cost);
+    if(intra_wins)
+        unit_to_temp(K, t, log2, cud, n, 0, R.ipm, R.nnz, nullptr, A.icoef + (long)c * n0, A.icoef + (long)K.nchains * n0 + (long)c * n1,
+                     A.icoef + (long)K.nchains * (n0 + n1) + (long)c * n1, A.irec + (long)c * n0, A.irec + (long)K.nchains * n0 + (long)c * n1,
+                     A.irec + (long)K.nchains * (n0 + n1) + (long)c * n1, n0, n1);
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        if(intra_wins) nd->unit_cost = R.cost, nd->cu_mode = 0, nd->dist_cu = R.dist_cu;
+        else nd->dist_cu = 0x7FFFFFFF;
+        const double cost_temp = nd->cost_temp + nd->unit_cost;
+        sh[0] = nd->cost_best > cost_temp;
+        if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0, *AT(K.tdepth, L) = intra_wins ? A.sbest[c] : A.enext[c]; // (:2116-2135)
+        nd->cost_temp = nd->cost_best;
+    }
+    __syncthreads();
+    const int better = sh[0];
+    __syncthreads();
+    if(better) {
+        cud_copy(b, t, 0, 0, log2, log2, cud, K.idc, K.ws, K.hs);
+        __syncthreads();
+        if(to_pic) rec_to_pic(K, J.pic, b, nd->x0, nd->y0, cu);
+    }
+}
+// the early terminations behind the unsplit alternative (:2162-2187): 0 = the node is not split whatever its children would cost
+__device__ static int leaf_next_split(const TreeK &K, const Node *nd, int L)
+{
+    const int log2 = L + 2, cud = 2 * (K.log2_ctu - log2);
+    int next_split = 1;
+    if(nd->active && nd->cost_best != MAX_COST && K.inter && cud >= K.ecu_depth && nd->cu_mode == 2 /* MODE_SKIP */) next_split = 0; // early CU termination (:2162-2172)
+    if(nd->active && nd->cost_best != MAX_COST && !K.inter) { // early termination in I pictures (:2174-2187)
+        const int th = 1 << (2 * log2 + 7);
+        if(nd->dist_cu < th) {
+            const int bits_inc = (2 * log2 >= 6 ? 2 : 0) + 8;
+            if(nd->dist_cu < K.lambda0 * bits_inc) next_split = 0;
+        }
+    }
+    return next_split;
 }
 
 __device__ static void op_leaf(const TreeK &K, int c, int L, int *sh)
 {
     const xeve_hip_ctu_job J = K.jobs[c];
     Node *nd = AT(K.node, L);
-    const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
-    const int active = nd->active, leaf = nd->leaf, x0 = nd->x0, y0 = nd->y0;
-    CtuData *t = AT(K.temp, L), *b = AT(K.best, L);
-    if(leaf) { // mode_coding_unit (:1310-1350): the intra analysis becomes the CU's mode in an I slice, and in a P / B slice where it is cheaper than the inter winner
-        const xeve_hip_intra_result R = K.ires[c];
-        const int intra_wins = !K.inter || (nd->try_intra && R.cost < nd->unit_cost);
-        if(intra_wins)
-            unit_to_temp(K, t, log2, cud, n, 0, R.ipm, R.nnz, nullptr, K.icoef + (long)c * n0, K.icoef + (long)K.nchains * n0 + (long)c * n1,
-                         K.icoef + (long)K.nchains * (n0 + n1) + (long)c * n1, K.irec + (long)c * n0, K.irec + (long)K.nchains * n0 + (long)c * n1,
-                         K.irec + (long)K.nchains * (n0 + n1) + (long)c * n1, n0, n1);
-        __syncthreads();
-        if(threadIdx.x == 0) {
-            if(intra_wins) nd->unit_cost = R.cost, nd->cu_mode = 0, nd->dist_cu = R.dist_cu;
-            else nd->dist_cu = 0x7FFFFFFF;
-            const double cost_temp = nd->cost_temp + nd->unit_cost;
-            sh[0] = nd->cost_best > cost_temp;
-            if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0, *AT(K.tdepth, L) = intra_wins ? K.sbest[c] : K.enext[c]; // (:2116-2135)
-            nd->cost_temp = nd->cost_best;
-        }
-        __syncthreads();
-        const int better = sh[0];
-        __syncthreads();
-        if(better) {
-            cud_copy(b, t, 0, 0, log2, log2, cud, K.idc, K.ws, K.hs);
-            __syncthreads();
-            rec_to_pic(K, J.pic, b, x0, y0, cu);
-        }
-    }
+    const int log2 = L + 2, cu = 1 << log2;
+    const int active = nd->active, x0 = nd->x0, y0 = nd->y0;
+    CtuData *t = AT(K.temp, L);
+    if(nd->leaf) leaf_decide(K, c, L, sh, true);
     if(threadIdx.x == 0) {
-        int next_split = 1;
-        if(active && nd->cost_best != MAX_COST && K.inter && cud >= K.ecu_depth && nd->cu_mode == 2 /* MODE_SKIP */) next_split = 0; // early CU termination (:2162-2172)
-        if(active && nd->cost_best != MAX_COST && !K.inter) { // early termination in I pictures (:2174-2187)
-            const int th = 1 << (2 * log2 + 7);
-            if(nd->dist_cu < th) {
-                const int bits_inc = (2 * log2 >= 6 ? 2 : 0) + 8;
-                if(nd->dist_cu < K.lambda0 * bits_inc) next_split = 0;
-            }
-        }
-        const int do_split = active && cu > 4 && next_split && cu > K.min_cu && cu > K.min_cuwh;
+        const int do_split = active && cu > 4 && leaf_next_split(K, nd, L) && cu > K.min_cu && cu > K.min_cuwh;
         nd->do_split = do_split;
         if(do_split) { // SPLIT_QUAD (:2189-2329): split_cu_flag = 1 from the node's entry state
             SbacState run;
             nd->cost_temp = (double)(int)split_flag_bits(*AT(K.before, L), run, 1) * K.lambda0;
-            *AT(K.curr, L) = run;
+            *AT(K.curr, L) = run, *AT(K.csplit, L) = run;
         }
         sh[0] = do_split;
     }
@@ -364,6 +393,42 @@ __device__ static void op_leaf(const TreeK &K, int c, int L, int *sh)
     }
 }
 
+// ---- a node whose analyses run on the side stream ------------------------------------------------------------------------------------------------------------
+// main stream, right behind op_enter: the split alternative is set up WITHOUT the node's own verdict -- whether the early terminations (leaf_next_split) forbid the
+// split is only known when the side stream is through, so the children are walked in any case (in lockstep they are analysed in any case: a chain whose node is
+// off rides along) and op_exit drops them where the verdict says so.  What the children leave in the picture and in the maps meanwhile lies inside the node: op_exit
+// puts the winner's reconstruction there and the parent's op_child_done / op_root_done the winner's map entries, before anything reads either.
+__device__ static void op_split_prep(const TreeK &K, int c, int L, int *sh)
+{
+    const xeve_hip_ctu_job J = K.jobs[c];
+    Node *nd = AT(K.node, L);
+    const int log2 = L + 2, cu = 1 << log2;
+    if(threadIdx.x == 0) {
+        const int do_split = nd->active && cu > 4 && cu > K.min_cu && cu > K.min_cuwh;
+        nd->do_split = do_split, nd->next_split = 1;
+        if(do_split) {
+            SbacState run;
+            nd->cost_split = (double)(int)split_flag_bits(*AT(K.before, L), run, 1) * K.lambda0;
+            *AT(K.csplit, L) = run;
+        }
+        sh[0] = do_split;
+    }
+    __syncthreads();
+    const int do_split = sh[0];
+    __syncthreads();
+    if(do_split) {
+        cud_init(AT(K.tsplit, L), log2);
+        clear_map(K, J.pic, nd->x0, nd->y0, cu);
+    }
+}
+// side stream, behind the node's analyses: the unsplit alternative and the verdict
+__device__ static void op_leaf_side(const TreeK &K, int c, int L, int *sh)
+{
+    Node *nd = AT(K.node, L);
+    if(nd->leaf) leaf_decide(K, c, L, sh, false);
+    if(threadIdx.x == 0) nd->next_split = leaf_next_split(K, nd, L);
+}
+
 __device__ static void op_child_done(const TreeK &K, int c, int L, int part)
 {   // L = the parent's level; the quadrant just left is node (L - 1)
     const xeve_hip_ctu_job J = K.jobs[c];
@@ -371,8 +436,9 @@ __device__ static void op_child_done(const TreeK &K, int c, int L, int part)
     const Node *ch = AT(K.node, L - 1);
     if(!ch->active) return;
     const int log2 = L + 2, cud = 2 * (K.log2_ctu - log2), half = 1 << (log2 - 1);
-    if(threadIdx.x == 0) p->cost_temp += ch->cost_best;
-    cud_copy(AT(K.temp, L), AT(K.best, L - 1), ch->x0 - p->x0, ch->y0 - p->y0, log2 - 1, log2, cud, K.idc, K.ws, K.hs);
+    const int side = K.side_of[L];
+    if(threadIdx.x == 0) (side ? p->cost_split : p->cost_temp) += ch->cost_best;
+    cud_copy(side ? AT(K.tsplit, L) : AT(K.temp, L), AT(K.best, L - 1), ch->x0 - p->x0, ch->y0 - p->y0, log2 - 1, log2, cud, K.idc, K.ws, K.hs);
     update_map(K, J.pic, AT(K.best, L - 1), ch->x0, ch->y0, half);
     (void)part;
 }
@@ -383,9 +449,11 @@ __device__ static void op_exit(const TreeK &K, int c, int L, int *sh)
     Node *nd = AT(K.node, L);
     if(!nd->active) return;
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2);
+    const int side = K.side_of[L];
     if(threadIdx.x == 0) {
-        sh[0] = nd->do_split && nd->cost_best - 0.0001 > nd->cost_temp;
-        if(sh[0]) nd->cost_best = nd->cost_temp, nd->best_split = 5 /* SPLIT_QUAD */, *AT(K.tdepth, L) = *AT(K.next, L - 1);
+        const double cost_split = side ? nd->cost_split : nd->cost_temp;
+        sh[0] = nd->do_split && (!side || nd->next_split) && nd->cost_best - 0.0001 > cost_split;
+        if(sh[0]) nd->cost_best = cost_split, nd->best_split = 5 /* SPLIT_QUAD */, *AT(K.tdepth, L) = *AT(K.next, L - 1);
         *AT(K.next, L) = *AT(K.tdepth, L);
     }
     __syncthreads();
@@ -393,7 +461,7 @@ __device__ static void op_exit(const TreeK &K, int c, int L, int *sh)
     __syncthreads();
     CtuData *b = AT(K.best, L);
     if(split_wins) {
-        cud_copy(b, AT(K.temp, L), 0, 0, log2, log2, cud, K.idc, K.ws, K.hs);
+        cud_copy(b, side ? AT(K.tsplit, L) : AT(K.temp, L), 0, 0, log2, log2, cud, K.idc, K.ws, K.hs);
         __syncthreads();
     }
     rec_to_pic(K, J.pic, b, nd->x0, nd->y0, cu);
@@ -424,6 +492,8 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeK K, OpList ops)
         case OP_CHILD_DONE: op_child_done(K, c, L, part); break;
         case OP_EXIT: op_exit(K, c, L, sh); break;
         case OP_MID: op_mid(K, c, L); break;
+        case OP_SPLIT_PREP: op_split_prep(K, c, L, sh); break;
+        case OP_LEAF_SIDE: op_leaf_side(K, c, L, sh); break;
         default: op_root_done(K, c, L); break;
         }
         __syncthreads(); // (a workgroup-scope release / acquire: the next operation reads what this one wrote to global memory)
@@ -442,17 +512,18 @@ template <int LOG2> __global__ void __launch_bounds__(64) k_intra_lane(TreeK K, 
     if(c >= K.nchains || threadIdx.x != 0) return;
     const Node *nd = AT(K.node, L);
     if(!nd->leaf || (K.inter && !nd->try_intra)) return; // (nothing reads the result of a chain whose node is off)
-    const xeve_hip_intra_job J = K.ijobs[c];
+    const TreeK::Ac &A = K.ac[K.side_of[L]];
+    const xeve_hip_intra_job J = *AT(A.ijobs, L);
     const int  n0 = 1 << (2 * LOG2), n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
     const pel *org[3] = {org_y + J.pic * org_pic_l, org_u ? org_u + J.pic * org_pic_c : nullptr, org_v ? org_v + J.pic * org_pic_c : nullptr};
     const pel *mod[3] = {K.mod[0] + J.pic * K.mod_pic_l, K.mod[1] ? K.mod[1] + J.pic * K.mod_pic_c : nullptr, K.mod[2] ? K.mod[2] + J.pic * K.mod_pic_c : nullptr};
-    int16_t *coef = const_cast<int16_t *>(K.icoef);
-    pel     *rec = const_cast<pel *>(K.irec);
+    int16_t *coef = const_cast<int16_t *>(A.icoef);
+    pel     *rec = const_cast<pel *>(A.irec);
     const long oy = (long)c * n0, ou = (long)K.nchains * n0 + (long)c * n1, ov = (long)K.nchains * (n0 + n1) + (long)c * n1;
     xeve_hip_intra_result R;
     xl::intra_cu<LOG2>(P, org, mod, K.map_scu + J.pic * K.map_pic, K.map_ipm + J.pic * K.map_pic, map_tidx + J.pic * K.map_pic, *AT(K.curr, L), J, R, coef + oy, coef + ou, coef + ov,
-                       rec + oy, rec + ou, rec + ov, K.sbest[c]);
-    const_cast<xeve_hip_intra_result *>(K.ires)[c] = R;
+                       rec + oy, rec + ou, rec + ov, A.sbest[c]);
+    const_cast<xeve_hip_intra_result *>(A.ires)[c] = R;
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------------------------
@@ -460,8 +531,12 @@ extern "C" int xeve_hip_satd_jobs(const pel *p1, int s1, const pel *p2, int s2, 
                                   int bit_depth, int32_t *out, void *stream);
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 struct TreeLayout {
-    size_t node, curr, next, before, tdepth, sbest, best, temp, ijobs, ires, icoef, irec, iws, iws_bytes, total, zero_from, zero_bytes;
-    size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, zero32, ews, ews_bytes; // P / B slices
+    size_t node, curr, next, before, tdepth, csplit, best, temp, tsplit, zero32, total, zero_from, zero_bytes;
+    struct Ac {
+        size_t sbest, ijobs, ires, icoef, irec, iws, iws_bytes;
+        size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, ews, ews_bytes; // P / B slices
+    } ac[2]; // the arrays of the analyses, per stream (TreeK::Ac)
+    unsigned char side_of[8];
 };
 static bool tree_params_ok(const xeve_hip_tree_params *p)
 {   // everything the analyses of the walk would refuse is refused here, before the first launch (a walk that stops half way leaves half-written maps behind)
@@ -523,41 +598,67 @@ static xl::Params lane_params(const xeve_hip_tree_params *p, int log2, int s_org
 // a node of this size can be a CU at all: within max_cu and no larger than the picture (the analyses of a size the picture cannot hold are left out of the schedule)
 static bool level_has_cu(const xeve_hip_tree_params *p, int log2) { return (1 << log2) <= p->max_cu && (1 << log2) <= p->pic_w && (1 << log2) <= p->pic_h; }
 
-static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c)
+// a node of this size has children in the walk (op_leaf's static part of do_split)
+static bool level_has_kids(const xeve_hip_tree_params *p, int log2) { return (1 << log2) > 4 && (1 << log2) > p->min_cu && (1 << log2) > p->min_cuwh; }
+// the side stream (TreeK): on unless switched off (XEVE_HIP_TREE_SIDE=0 / xeve_hip_walk_side(0): the one-stream walk of rounds 2-5, kept for A / B measurements and pinned by
+// the GPU suite beside the default)
+static std::atomic<int> g_tree_side{getenv("XEVE_HIP_TREE_SIDE") ? atoi(getenv("XEVE_HIP_TREE_SIDE")) != 0 : 1};
+extern "C" int xeve_hip_walk_side(int on)
+{
+    const int before = g_tree_side.load();
+    if(on == 0 || on == 1) g_tree_side.store(on);
+    return before;
+}
+
+static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c, bool side)
 {
     TreeLayout L;
     memset(&L, 0, sizeof(L));
     const size_t N = (size_t)nchains;
-    const int    idc = p->ip.chroma_format_idc, top = std::min(1 << p->log2_ctu, p->max_cu), n0 = top * top, n1 = idc ? n0 >> ((idc <= 2) + (idc <= 1)) : 0;
+    const int    idc = p->ip.chroma_format_idc;
+    for(int log2 = 2; log2 <= p->log2_ctu; log2++) L.side_of[log2 - 2] = side && level_has_cu(p, log2) && level_has_kids(p, log2);
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
     L.zero_from = o;
     L.node = take(5 * N * sizeof(Node)), L.curr = take(5 * N * sizeof(SbacState)), L.next = take(5 * N * sizeof(SbacState)), L.before = take(5 * N * sizeof(SbacState));
-    L.tdepth = take(5 * N * sizeof(SbacState)), L.sbest = take(N * sizeof(SbacState)), L.best = take(5 * N * sizeof(CtuData)), L.temp = take(5 * N * sizeof(CtuData));
+    L.tdepth = take(5 * N * sizeof(SbacState)), L.csplit = take(5 * N * sizeof(SbacState)), L.best = take(5 * N * sizeof(CtuData)), L.temp = take(5 * N * sizeof(CtuData));
+    L.tsplit = side ? take(5 * N * sizeof(CtuData)) : L.temp;
+    for(int a = 0; a < 2; a++) L.ac[a].sbest = take(N * sizeof(SbacState));
     L.zero32 = take(64);
     L.zero_bytes = o - L.zero_from;
-    L.ijobs = take(N * sizeof(xeve_hip_intra_job)), L.ires = take(N * sizeof(xeve_hip_intra_result));
-    L.icoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64), L.irec = take(N * ((size_t)n0 + 2 * (size_t)n1) * sizeof(pel) + 64);
-    if(I) {
-        L.ejobs = take(N * sizeof(xeve_hip_inter_job)), L.sjobs = take(N * sizeof(xeve_hip_job)), L.eres = take(N * sizeof(xeve_hip_inter_result));
-        L.ecoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64);
-        for(int c = 0; c < 3; c++) L.erec[c] = take(N * (size_t)(c ? n1 : n0) * sizeof(pel) + 64);
-        L.epred = take(N * (size_t)n0 * sizeof(pel) + 64), L.esatd = take(N * 4), L.enext = take(N * sizeof(SbacState));
-    }
-    L.iws = o;
-    for(int log2 = 2; log2 <= p->log2_ctu; log2++) {
-        if(!level_has_cu(p, log2)) continue;
-        const xeve_hip_intra_params ip = level_params(p, log2);
-        L.iws_bytes = std::max(L.iws_bytes, xeve_hip_pintra_analyze_cu_workspace(nchains, nchains, &ip));
+    for(int a = 0; a < 2; a++) { // every array of the analyses at the size of the largest CU its stream analyses (one stream: all of them in ac[0])
+        TreeLayout::Ac &A = L.ac[a];
+        int top = 0;
+        for(int log2 = 2; log2 <= p->log2_ctu; log2++)
+            if(level_has_cu(p, log2) && L.side_of[log2 - 2] == a) top = 1 << log2;
+        if(!top) continue;
+        const int n0 = top * top, n1 = idc ? n0 >> ((idc <= 2) + (idc <= 1)) : 0;
+        A.ijobs = take(5 * N * sizeof(xeve_hip_intra_job)), A.ires = take(N * sizeof(xeve_hip_intra_result));
+        A.icoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64), A.irec = take(N * ((size_t)n0 + 2 * (size_t)n1) * sizeof(pel) + 64);
         if(I) {
-            const xeve_hip_inter_params ep = level_inter_params(I, log2);
-            L.ews_bytes = std::max(L.ews_bytes, xeve_hip_pinter_analyze_cu_workspace(nchains, nchains, &ep, s_org_l, s_org_c));
+            A.ejobs = take(5 * N * sizeof(xeve_hip_inter_job)), A.sjobs = take(5 * N * sizeof(xeve_hip_job)), A.eres = take(N * sizeof(xeve_hip_inter_result));
+            A.ecoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64);
+            for(int c = 0; c < 3; c++) A.erec[c] = take(N * (size_t)(c ? n1 : n0) * sizeof(pel) + 64);
+            A.epred = take(N * (size_t)n0 * sizeof(pel) + 64), A.esatd = take(N * 4), A.enext = take(N * sizeof(SbacState));
         }
+        for(int log2 = 2; log2 <= p->log2_ctu; log2++) {
+            if(!level_has_cu(p, log2) || L.side_of[log2 - 2] != a) continue;
+            const xeve_hip_intra_params ip = level_params(p, log2);
+            A.iws_bytes = std::max(A.iws_bytes, xeve_hip_pintra_analyze_cu_workspace(nchains, nchains, &ip));
+            if(I) {
+                const xeve_hip_inter_params ep = level_inter_params(I, log2);
+                A.ews_bytes = std::max(A.ews_bytes, xeve_hip_pinter_analyze_cu_workspace(nchains, nchains, &ep, s_org_l, s_org_c));
+            }
+        }
+        A.iws = take(A.iws_bytes), A.ews = take(A.ews_bytes);
     }
-    o += al(L.iws_bytes);
-    L.ews = o;
-    L.total = o + al(L.ews_bytes);
+    L.total = o;
     return L;
+}
+// what a workspace must hold whichever way the call then runs (the side stream can be switched between the query and the call)
+static size_t tree_workspace(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c)
+{
+    return std::max(tree_layout(nchains, p, I, s_org_l, s_org_c, false).total, tree_layout(nchains, p, I, s_org_l, s_org_c, true).total);
 }
 
 // the fused walk (walk.hip): one launch per call
@@ -574,14 +675,14 @@ extern "C" size_t xeve_hip_mode_analyze_ctu_workspace(int nchains, const xeve_hi
     if(p->ip.slice_type == 2) I = nullptr;
     if(xh_walk_supported(p, I, nchains)) return xh_walk_workspace(nchains);
     if(xh_walk_only(p)) { xh_set_error("rdo_dbk_switch and 4x4 inter CUs (presets slow, placebo) run on the fused walk only: it is switched off (XEVE_HIP_WALK=0 / xeve_hip_walk_select) or does not take these parameters"); return 0; }
-    return tree_layout(nchains, p, I, s_org_l, s_org_c).total;
+    return tree_workspace(nchains, p, I, s_org_l, s_org_c);
 }
 extern "C" size_t xeve_hip_mode_analyze_ctu_intra_workspace(int nchains, const xeve_hip_tree_params *p)
 {
     if(!tree_params_ok(p) || nchains <= 0 || p->ip.slice_type != 2) return 0;
     if(xh_walk_supported(p, nullptr, nchains)) return xh_walk_workspace(nchains);
     if(xh_walk_only(p)) return 0;
-    return tree_layout(nchains, p, nullptr, 0, 0).total;
+    return tree_workspace(nchains, p, nullptr, 0, 0);
 }
 
 namespace {
@@ -620,23 +721,71 @@ struct TreeGraphs { // per thread; dropped when the library is re-bound
     ~TreeGraphs() { drop(); }
 };
 enum { AN_NONE = 0, AN_INTRA = 1, AN_INTER = 2 };
+// one entry of the schedule: [wait for an event] [tree operations] [an analysis] [record an event], all on one of the call's two streams
+struct Item {
+    int    st;               // 0 the caller's stream, 1 the side stream
+    OpList ops;              // run before the analysis
+    int    kind, size;       // the analysis: AN_*, log2 of the CU size
+    int    wait_ev, rec_ev;  // -1: none
+};
+inline int ev_enter(int L) { return 2 * L; }    // main stream: the side node of level L is entered (its jobs and entry state stand)
+inline int ev_done(int L) { return 2 * L + 1; } // side stream: its unsplit alternative is decided
 struct Walk { // the static schedule of one CTU: every node of the full quad-tree in the reference's order; operations between two analyses fused
     const xeve_hip_tree_params *p;
-    bool                        inter;
-    std::vector<OpList>         launches; // launches[i] runs before analysis i (and the last one after the last analysis)
-    std::vector<int>            kind, size; // of analysis i: AN_*, log2 of the CU size
+    bool                        inter, side;
+    std::vector<Item>           items;
+    std::vector<int>            pending; // side nodes entered whose analyses are not yet queued (innermost last)
     OpList                      cur;
-    void flush(int k, int log2) { launches.push_back(cur), kind.push_back(k), size.push_back(log2), cur.n = 0; }
+    int                         wait_next = -1; // the next main-stream entry starts with this wait
+    void flush(int k, int log2, int rec = -1)
+    {
+        Item it;
+        it.st = 0, it.ops = cur, it.kind = k, it.size = log2, it.wait_ev = wait_next, it.rec_ev = rec;
+        items.push_back(it), cur.n = 0, wait_next = -1;
+    }
     void add(int op, int L, int part)
     {
         if(cur.n == MAX_OPS) flush(AN_NONE, 0);
         cur.op[cur.n] = (unsigned char)op, cur.lvl[cur.n] = (unsigned char)L, cur.part[cur.n] = (signed char)part, cur.n++;
     }
+    // The side stream's work of the nodes entered so far, INNERMOST FIRST: the main stream needs the innermost node's verdict soonest (after four children of the next
+    // level down), the outer ones' only when whole subtrees are through.  Called before the main stream's next analysis is queued.
+    void queue_pending()
+    {
+        for(; !pending.empty(); pending.pop_back()) {
+            const int L = pending.back();
+            Item it;
+            it.st = 1, it.ops.n = 0, it.kind = inter ? AN_INTER : AN_INTRA, it.size = L + 2, it.wait_ev = ev_enter(L), it.rec_ev = -1;
+            items.push_back(it);
+            if(inter) {
+                it.ops.n = 1, it.ops.op[0] = OP_MID, it.ops.lvl[0] = (unsigned char)L, it.ops.part[0] = 0, it.kind = AN_INTRA, it.wait_ev = -1;
+                items.push_back(it);
+            }
+            it.ops.n = 1, it.ops.op[0] = OP_LEAF_SIDE, it.ops.lvl[0] = (unsigned char)L, it.ops.part[0] = 0, it.kind = AN_NONE, it.size = 0, it.wait_ev = -1, it.rec_ev = ev_done(L);
+            items.push_back(it);
+        }
+    }
     void node(int L, int part)
     {
-        const int cu = 1 << (L + 2);
+        const int  cu = 1 << (L + 2);
+        const bool has = level_has_cu(p, L + 2), kids = level_has_kids(p, L + 2);
         add(OP_ENTER, L, part);
-        if(level_has_cu(p, L + 2)) {
+        if(side && has && kids) { // analyses on the side stream, the children on this one, joined in front of op_exit
+            add(OP_SPLIT_PREP, L, 0);
+            flush(AN_NONE, 0, ev_enter(L));
+            pending.push_back(L);
+            for(int q = 0; q < 4; q++) {
+                node(L - 1, q);
+                add(OP_CHILD_DONE, L, q);
+            }
+            queue_pending(); // (nothing is left by now: the first node without children below queued it)
+            if(cur.n) flush(AN_NONE, 0);
+            wait_next = ev_done(L);
+            add(OP_EXIT, L, 0);
+            return;
+        }
+        if(has) {
+            queue_pending();
             if(inter) {
                 flush(AN_INTER, L + 2);
                 add(OP_MID, L, 0);
@@ -644,13 +793,36 @@ struct Walk { // the static schedule of one CTU: every node of the full quad-tre
             flush(AN_INTRA, L + 2);
         }
         add(OP_LEAF, L, 0);
-        if(cu > 4 && cu > p->min_cu && cu > p->min_cuwh)
+        if(kids)
             for(int q = 0; q < 4; q++) {
                 node(L - 1, q);
                 add(OP_CHILD_DONE, L, q);
             }
         add(OP_EXIT, L, 0);
+        (void)cu;
     }
+};
+// the side stream and the events of the fork / join, per host thread (an encoder walks from one thread; the bench's batches have a thread each)
+struct TreeSide {
+    uint32_t    gen = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t  ev[10] = {};
+    void drop()
+    {
+        if(st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st), st = nullptr;
+        for(auto &e : ev)
+            if(e) (void)hipEventDestroy(e), e = nullptr;
+    }
+    bool ready()
+    {
+        if(gen != xh_generation()) drop(), gen = xh_generation();
+        if(st) return true;
+        if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return false; }
+        for(auto &e : ev)
+            if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { drop(); return false; }
+        return true;
+    }
+    ~TreeSide() { drop(); }
 };
 } // namespace
 
@@ -686,9 +858,15 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     if(xh_walk_supported(p, I, std::max(nchains, nstates))) // the fused walk: the whole schedule inside one kernel (walk.hip)
         return xh_walk_run(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, map_cu_mode, pic_elems, states, p, I, jobs, nchains, out, next_best, cost,
                            workspace, workspace_bytes, vh, (hipStream_t)stream);
-    const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c);
-    XH_REQUIRE(workspace_bytes >= L.total);
     hipStream_t st = (hipStream_t)stream;
+    // the side stream: unless switched off, the caller is capturing its stream into a graph, or the walk replays from a graph of its own
+    static const int use_graph = getenv("XEVE_HIP_TREE_GRAPH") ? atoi(getenv("XEVE_HIP_TREE_GRAPH")) : 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if(st) (void)hipStreamIsCapturing(st, &cap);
+    static thread_local TreeSide side_res;
+    const bool side = g_tree_side.load(std::memory_order_relaxed) && !use_graph && cap == hipStreamCaptureStatusNone && side_res.ready();
+    const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c, side);
+    XH_REQUIRE(workspace_bytes >= L.total);
     char       *W = (char *)workspace;
     const int   idc = p->ip.chroma_format_idc;
     TreeK K;
@@ -700,16 +878,23 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     K.mod[0] = mod[0], K.mod[1] = mod[1], K.mod[2] = mod[2], K.map_scu = map_scu, K.map_cu_mode = map_cu_mode, K.map_ipm = map_ipm, K.states = states, K.jobs = jobs;
     K.out = out, K.out_next = next_best, K.out_cost = cost;
     K.node = (Node *)(W + L.node), K.curr = (SbacState *)(W + L.curr), K.next = (SbacState *)(W + L.next), K.before = (SbacState *)(W + L.before);
-    K.tdepth = (SbacState *)(W + L.tdepth), K.sbest = (SbacState *)(W + L.sbest), K.best = (CtuData *)(W + L.best), K.temp = (CtuData *)(W + L.temp);
-    K.ijobs = (xeve_hip_intra_job *)(W + L.ijobs), K.ires = (xeve_hip_intra_result *)(W + L.ires), K.icoef = (int16_t *)(W + L.icoef), K.irec = (pel *)(W + L.irec);
-    if(I) {
-        K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.vh = vh, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
-        K.ejobs = (xeve_hip_inter_job *)(W + L.ejobs), K.sjobs = (xeve_hip_job *)(W + L.sjobs), K.eres = (xeve_hip_inter_result *)(W + L.eres), K.ecoef = (int16_t *)(W + L.ecoef);
-        for(int c = 0; c < 3; c++) K.erec[c] = (pel *)(W + L.erec[c]);
-        K.esatd = (int32_t *)(W + L.esatd), K.enext = (SbacState *)(W + L.enext);
+    K.tdepth = (SbacState *)(W + L.tdepth), K.csplit = (SbacState *)(W + L.csplit), K.best = (CtuData *)(W + L.best), K.temp = (CtuData *)(W + L.temp);
+    K.tsplit = (CtuData *)(W + L.tsplit);
+    memcpy(K.side_of, L.side_of, sizeof(K.side_of));
+    if(I) K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.vh = vh, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
+    for(int a = 0; a < 2; a++) {
+        TreeK::Ac &A = K.ac[a];
+        const TreeLayout::Ac &LA = L.ac[a];
+        A.sbest = (SbacState *)(W + LA.sbest);
+        A.ijobs = (xeve_hip_intra_job *)(W + LA.ijobs), A.ires = (xeve_hip_intra_result *)(W + LA.ires), A.icoef = (int16_t *)(W + LA.icoef), A.irec = (pel *)(W + LA.irec);
+        if(I) {
+            A.ejobs = (xeve_hip_inter_job *)(W + LA.ejobs), A.sjobs = (xeve_hip_job *)(W + LA.sjobs), A.eres = (xeve_hip_inter_result *)(W + LA.eres), A.ecoef = (int16_t *)(W + LA.ecoef);
+            for(int c = 0; c < 3; c++) A.erec[c] = (pel *)(W + LA.erec[c]);
+            A.esatd = (int32_t *)(W + LA.esatd), A.enext = (SbacState *)(W + LA.enext);
+        }
     }
     Walk wk;
-    wk.p = p, wk.inter = I != nullptr, wk.cur.n = 0;
+    wk.p = p, wk.inter = I != nullptr, wk.side = side, wk.cur.n = 0;
     wk.node(p->log2_ctu - 2, -1);
     wk.add(OP_ROOT_DONE, p->log2_ctu - 2, 0);
     wk.flush(AN_NONE, 0);
@@ -721,39 +906,54 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     // CPU-tested (tests/test_cu_lane.py) starting point of a wave-per-chain node kernel.
     static const int use_lane = getenv("XEVE_HIP_TREE_LANE") ? atoi(getenv("XEVE_HIP_TREE_LANE")) : 0;
     XH_REQUIRE(xh_entropy_table() != nullptr);
-    auto enqueue = [&]() -> int { // the whole walk on `st`
+    auto enqueue = [&]() -> int { // the whole walk: on `st`, and on the side stream between the events
         XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
-        for(size_t i = 0; i < wk.launches.size(); i++) {
-            k_tree_ops<<<nchains, 256, 0, st>>>(K, wk.launches[i]);
-            const int log2 = wk.size[i], cu = 1 << log2;
+        hipStream_t sts[2] = {st, side ? side_res.st : st};
+        bool recorded[10] = {};
+        for(const Item &it : wk.items) {
+            hipStream_t s = sts[it.st];
+            void *sv = (void *)s;
+            if(it.wait_ev >= 0) {
+                XH_REQUIRE(side && recorded[it.wait_ev]); // (a wait on an event not yet recorded would not wait)
+                XH_HIP(hipStreamWaitEvent(s, side_res.ev[it.wait_ev], 0));
+            }
+            if(it.ops.n) k_tree_ops<<<nchains, 256, 0, s>>>(K, it.ops);
+            const int log2 = it.size, cu = 1 << log2;
+            const TreeK::Ac       &A = K.ac[it.st];
+            const TreeLayout::Ac &LA = L.ac[it.st];
             int rc = XEVE_HIP_OK;
-            if(wk.kind[i] == AN_INTRA && log2 <= 3 && use_lane) { // one lane per chain decides the node (cu_lane.h)
+            if(it.kind == AN_INTRA && log2 <= 3 && use_lane) { // one lane per chain decides the node (cu_lane.h)
                 const xl::Params LP = lane_params(p, log2, s_org_l, s_org_c, s_mod_l, s_mod_c);
                 const int grid = nchains;
-                if(log2 == 2) k_intra_lane<2><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
-                else k_intra_lane<3><<<grid, 64, 0, st>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
+                if(log2 == 2) k_intra_lane<2><<<grid, 64, 0, s>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
+                else k_intra_lane<3><<<grid, 64, 0, s>>>(K, LP, org[0], org[1], org[2], map_tidx, pic_elems ? pic_elems[0] : 0, pic_elems ? pic_elems[1] : 0);
             }
-            else if(wk.kind[i] == AN_INTRA) {
+            else if(it.kind == AN_INTRA) {
                 const xeve_hip_intra_params ip = level_params(p, log2);
                 rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
-                                                     nchains, &ip, K.ijobs, nchains, (xeve_hip_intra_result *)(W + L.ires), (int16_t *)(W + L.icoef), (pel *)(W + L.irec), K.sbest,
-                                                     W + L.iws, L.iws_bytes, stream);
+                                                     nchains, &ip, A.ijobs + (size_t)(log2 - 2) * nchains, nchains, (xeve_hip_intra_result *)(W + LA.ires), (int16_t *)(W + LA.icoef), (pel *)(W + LA.irec), A.sbest,
+                                                     W + LA.iws, LA.iws_bytes, sv);
             }
-            else if(wk.kind[i] == AN_INTER) {
+            else if(it.kind == AN_INTER) {
                 const xeve_hip_inter_params ep = level_inter_params(I, log2);
                 XhVhScope tall(vh);
                 rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
-                                               p->ip.slice_type, K.ejobs, nchains, stream);
+                                               p->ip.slice_type, A.ejobs + (size_t)(log2 - 2) * nchains, nchains, sv);
                 if(rc == XEVE_HIP_OK)
-                    rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, K.ejobs,
-                                                         nchains, I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + L.eres), (int16_t *)(W + L.ecoef), (pel *)(W + L.erec[0]),
-                                                         (pel *)(W + L.erec[1]), (pel *)(W + L.erec[2]), (pel *)(W + L.epred), (xeve_hip_sbac *)(W + L.enext), W + L.ews,
-                                                         L.ews_bytes, stream);
+                    rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, A.ejobs + (size_t)(log2 - 2) * nchains,
+                                                         nchains, I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + LA.eres), (int16_t *)(W + LA.ecoef), (pel *)(W + LA.erec[0]),
+                                                         (pel *)(W + LA.erec[1]), (pel *)(W + LA.erec[2]), (pel *)(W + LA.epred), (xeve_hip_sbac *)(W + LA.enext), W + LA.ews,
+                                                         LA.ews_bytes, sv);
                 if(rc == XEVE_HIP_OK) // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
-                    rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + L.epred), cu, K.sjobs, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
-                                            (int32_t *)(W + L.esatd), stream);
+                    rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + LA.epred), cu, A.sjobs + (size_t)(log2 - 2) * nchains, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
+                                            (int32_t *)(W + LA.esatd), sv);
             }
             if(rc != XEVE_HIP_OK) return rc;
+            if(it.rec_ev >= 0) {
+                XH_REQUIRE(side);
+                XH_HIP(hipEventRecord(side_res.ev[it.rec_ev], s));
+                recorded[it.rec_ev] = true;
+            }
         }
         return XEVE_HIP_OK;
     };
@@ -761,9 +961,6 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     // arguments repeat can be captured into a HIP graph and replayed.  MEASURED (profiles/r02_tree_graph.log): the replay frees the host -- 2.8 ms instead of
     // 56 .. 100 ms of launch calls per CTU step -- but the GPU runs the same step 8 .. 10 ms SLOWER (dependent kernel nodes of a graph dispatch no faster than
     // stream launches here), so it is OFF unless XEVE_HIP_TREE_GRAPH=1: for a caller that needs its host thread, not for speed.
-    static const int use_graph = getenv("XEVE_HIP_TREE_GRAPH") ? atoi(getenv("XEVE_HIP_TREE_GRAPH")) : 0;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if(st) (void)hipStreamIsCapturing(st, &cap);
     if(use_graph && st && cap == hipStreamCaptureStatusNone && !xh_prof_on(XH_PROF_SEARCH) && !xh_prof_on(XH_PROF_CU_BITS)) {
         static thread_local TreeGraphs G;
         std::vector<char> key;

@@ -108,20 +108,21 @@ class BatchEncoder:
 
 
 class walk_select:
-    """with walk_select(0 | 1 | -1, chains_per_team=0): ... -- pins the composed walk (0) / the fused kernel (1) / the choice by width (-1) for the encoders created
-    inside, and optionally how many chains a team of the fused kernel carries (xeve_hip_walk_select / _team: process-wide; create AND close the encoder inside)"""
+    """with walk_select(0 | 1 | -1, chains_per_team=0, side=-1): ... -- pins the composed walk (0) / the fused kernel (1) / the choice by width (-1) for the encoders created
+    inside, optionally how many chains a team of the fused kernel carries, and whether the composed walk uses its side stream (1 / 0; -1 leaves it as it is)
+    (xeve_hip_walk_select / _team / _side: process-wide; create AND close the encoder inside)"""
 
-    def __init__(self, mode, chains_per_team=0):
-        self.mode, self.team = int(mode), int(chains_per_team)
+    def __init__(self, mode, chains_per_team=0, side=-1):
+        self.mode, self.team, self.side = int(mode), int(chains_per_team), int(side)
 
     def __enter__(self):
         L = _lib.load()
-        self.before, self.team_before = L.xeve_hip_walk_select(self.mode), L.xeve_hip_walk_team(self.team)
+        self.before, self.team_before, self.side_before = L.xeve_hip_walk_select(self.mode), L.xeve_hip_walk_team(self.team), L.xeve_hip_walk_side(self.side)
         return self
 
     def __exit__(self, *exc):
         L = _lib.load()
-        L.xeve_hip_walk_select(self.before), L.xeve_hip_walk_team(self.team_before)
+        L.xeve_hip_walk_select(self.before), L.xeve_hip_walk_team(self.team_before), L.xeve_hip_walk_side(self.side_before)
         return False
 
 

@@ -228,6 +228,7 @@ FUNCTIONS = {
     "xeve_hip_walk_fused": (c_int, [c_int]),
     "xeve_hip_walk_select": (c_int, [c_int]),
     "xeve_hip_walk_team": (c_int, [c_int]),
+    "xeve_hip_walk_side": (c_int, [c_int]),
     "xeve_hip_mode_analyze_ctu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int] * 4 + [c_void_p] * 3),
     "xeve_hip_eco_ctu_jobs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "xeve_hip_eco_tile_end_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
