@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <vector>
 #include "xh_common.h"
+#include "mc_cu.h"
 
 #define MAXR XEVE_HIP_MAX_REFP
 #define MAX_COST 1.7e+308
@@ -76,9 +77,10 @@ __global__ void k_inter_skip_jobs(const xeve_hip_inter_job *__restrict__ jobs, I
 
 // after the skip analysis: does the CU go on (:1885-1887); the direct candidate (analyze_t_direct, xeve_get_mv_dir); the search jobs
 __global__ void k_inter_stage1(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const xeve_hip_skip_result *__restrict__ sres, InterSt *__restrict__ st,
-                               xeve_hip_rdo_job *__restrict__ rj, xeve_hip_epzs_job *__restrict__ ej)
+                               xeve_hip_rdo_job *__restrict__ rj, xeve_hip_epzs_job *__restrict__ ej, int32_t *__restrict__ cnt)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j < 8) cnt[j] = 0; // (the slot counters of analyze_bi's rounds, two per round: k_bi_head)
     if(j >= P.n) return;
     const xeve_hip_inter_job   J = jobs[j];
     const xeve_hip_skip_result R = sres[j];
@@ -172,89 +174,20 @@ __global__ void k_inter_uni_b(const xeve_hip_inter_job *__restrict__ jobs, Inter
 }
 
 // ---- analyze_bi (:1567-1714) -------------------------------------------------------------------------------------------------------
-__global__ void k_bi_init(InterK P, const xeve_hip_rdo_result *__restrict__ rres, InterSt *__restrict__ st)
+// One kernel per round in front of the round's prediction and search (round 6: k_bi_init / k_bi_update, k_bi_mc_jobs, the prediction's own front half, k_bi_jobs_off and
+// k_bi_me_jobs were five launches of one thread per CU each): the previous round's results taken in (round 0: the set-up), the prediction job from the fixed list with
+// its interpolation jobs (mc_cu.h), the list swap and the search jobs of the round.
+__device__ __forceinline__ void bi_init(const InterK &P, const xeve_hip_rdo_result *__restrict__ rres, InterSt &S, int j)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n) return;
-    InterSt &S = st[j];
     const int lref = rres[P.n + j].cost <= rres[2 * (size_t)P.n + j].cost ? 0 : 1; // cost_inter[PRED_L0] <= cost_inter[PRED_L1]
     S.lidx_ref = lref;
     S.mvpi[M_BI][0] = S.mvpi[M_L0][0], S.mvpi[M_BI][1] = S.mvpi[M_L1][1], S.refi[M_BI][0] = S.refi[M_L0][0], S.refi[M_BI][1] = S.refi[M_L1][1];
     S.mv[M_BI][0][0] = S.mv[M_L0][0][0], S.mv[M_BI][0][1] = S.mv[M_L0][0][1], S.mv[M_BI][1][0] = S.mv[M_L1][1][0], S.mv[M_BI][1][1] = S.mv[M_L1][1][1];
     S.rf[lref] = S.refi[M_BI][lref], S.rf[1 - lref] = -1;
 }
-
-// one round, first half: the prediction from the fixed list
-__global__ void k_bi_mc_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, xeve_hip_cu_mc_job *__restrict__ mc)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n) return;
-    const InterSt &S = st[j];
-    xeve_hip_cu_mc_job m;
-    m.x = jobs[j].x, m.y = jobs[j].y, m.pad_[0] = m.pad_[1] = 0;
-    for(int l = 0; l < 2; l++) m.mv[l][0] = S.mv[M_BI][l][0], m.mv[l][1] = S.mv[M_BI][l][1], m.refi[l] = S.active ? S.rf[l] : -1;
-    mc[j] = m;
-}
-
-// get_org_bi (:143-156), then the list swap and the search jobs of the round
-__global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const pel *__restrict__ org, const pel *__restrict__ pred, int16_t *__restrict__ org_bi)
-{
-    const int nbx = P.n0 >= 1024 ? 4 : 1, j = blockIdx.x / nbx, bx = blockIdx.x % nbx, w = 1 << P.lw;
-    const xeve_hip_inter_job J = jobs[j];
-    for(int i = bx * blockDim.x + threadIdx.x; i < P.n0; i += nbx * blockDim.x) {
-        const int yy = i >> P.lw, xx = i & (w - 1);
-        org_bi[(size_t)j * P.n0 + i] = (int16_t)((org[(size_t)(J.y + yy) * P.s_org_l + J.x + xx] << 1) - pred[(size_t)j * P.n0 + i]);
-    }
-}
-
-__global__ void k_bi_me_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_epzs_job *__restrict__ ej,
-                             int32_t *__restrict__ extra, int32_t *__restrict__ cnt, unsigned char *__restrict__ job_plane)
-{
-    const int  j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    const bool act = j < P.n && st[j].active;
-    int l = 0;
-    if(act) { // SWAP(refi[lidx_ref], refi[lidx_cnd]), SWAP(lidx_ref, lidx_cnd) (:1626-1628)
-        InterSt &S = st[j];
-        const int8_t t = S.rf[0];
-        S.rf[0] = S.rf[1], S.rf[1] = t;
-        l = S.lidx_ref = 1 - S.lidx_ref;
-    }
-    // The still-searching CUs are compacted to the front of the job arrays (slots handed out per wave with one atomic; the order is
-    // arbitrary, results come back through bi_slot); a CU's jobs -- one per reference picture of the list it searches -- carry their plane
-    // (list, picture) in job_plane.  Slots beyond the count stay switched off.
-    const unsigned long long m = __ballot(act);
-    int b = 0;
-    if(lane == 0 && m) b = atomicAdd(&cnt[0], __popcll(m));
-    b = __shfl(b, 0, 64);
-    if(!act) return;
-    const int k = b + __popcll(m & ((1ull << lane) - 1));
-    const xeve_hip_inter_job J = jobs[j];
-    InterSt &S = st[j];
-    const int idx = S.mvpi[M_BI][l];
-    S.bi_slot = k;
-    for(int r = 0; r < P.nb; r++) {
-        xeve_hip_epzs_job e;
-        e.x = J.x, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
-        e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
-        const size_t at = (size_t)r * P.n + k;
-        ej[at] = e, extra[at] = S.mot_bits[1 - l], job_plane[at] = (unsigned char)(l * P.np + r);
-    }
-}
-
-__global__ void k_bi_jobs_off(InterK P, xeve_hip_epzs_job *__restrict__ ej, unsigned char *__restrict__ job_plane, int32_t *__restrict__ cnt)
-{
-    if(blockIdx.x == 0 && threadIdx.x < 2) cnt[threadIdx.x] = 0; // (the round's job counters: k_bi_me_jobs, the next launch, counts from zero)
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if(t >= P.nb * P.n) return;
-    ej[t].x = -1, job_plane[t] = 0;
-}
-
 // one round, second half (:1633-1663): every reference picture of the searched list against the running best
-__global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mres, InterSt *__restrict__ st)
+__device__ __forceinline__ void bi_update(const InterK &P, const xeve_hip_me_result *__restrict__ mres, InterSt &S)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n) return;
-    InterSt &S = st[j];
     if(!S.active) return;
     const int l = S.lidx_ref;
     int changed = 0;
@@ -270,13 +203,78 @@ __global__ void k_bi_update(InterK P, const xeve_hip_me_result *__restrict__ mre
     S.rf[l] = (int8_t)S.refi_best, S.rf[1 - l] = -1;
     if(!changed) S.active = 0;
 }
+// cnt: this round's two counters (zero: k_inter_stage1 clears all of them).  The still-searching CUs are compacted to the FRONT of the search-job arrays (slots handed out
+// per wave with one atomic; the order is arbitrary, results come back through bi_slot), the others take the slots from the BACK and switch them off: every slot is
+// written exactly once, nothing has to be cleared beforehand.  A CU's jobs -- one per reference picture of the list it searches -- carry their plane (list, picture)
+// in job_plane.
+__global__ void k_bi_head(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, const xeve_hip_rdo_result *__restrict__ rres,
+                          const xeve_hip_me_result *__restrict__ mres, int first, CuMcPrep C, xeve_hip_epzs_job *__restrict__ ej, int32_t *__restrict__ extra,
+                          int32_t *__restrict__ cnt, unsigned char *__restrict__ job_plane)
+{
+    const int  j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool in = j < P.n;
+    bool act = false;
+    int  l = 0;
+    xeve_hip_inter_job J;
+    if(in) {
+        InterSt &S = st[j];
+        J = jobs[j];
+        if(first) bi_init(P, rres, S, j);
+        else bi_update(P, mres, S);
+        // first half of the round: the prediction from the fixed list
+        xeve_hip_cu_mc_job m;
+        m.x = J.x, m.y = J.y, m.pad_[0] = m.pad_[1] = 0;
+        for(int q = 0; q < 2; q++) m.mv[q][0] = S.mv[M_BI][q][0], m.mv[q][1] = S.mv[M_BI][q][1], m.refi[q] = S.active ? S.rf[q] : -1;
+        xh_cu_mc_prep_one(m, j, C);
+        act = S.active != 0;
+        if(act) { // SWAP(refi[lidx_ref], refi[lidx_cnd]), SWAP(lidx_ref, lidx_cnd) (:1626-1628)
+            const int8_t t = S.rf[0];
+            S.rf[0] = S.rf[1], S.rf[1] = t;
+            l = S.lidx_ref = 1 - S.lidx_ref;
+        }
+    }
+    const unsigned long long ma = __ballot(act), mi = __ballot(in && !act);
+    int ba = 0, bi = 0;
+    if(lane == 0 && ma) ba = atomicAdd(&cnt[0], __popcll(ma));
+    if(lane == 0 && mi) bi = atomicAdd(&cnt[1], __popcll(mi));
+    ba = __shfl(ba, 0, 64), bi = __shfl(bi, 0, 64);
+    if(!in) return;
+    const unsigned long long below = (1ull << lane) - 1;
+    const int k = act ? ba + __popcll(ma & below) : P.n - 1 - (bi + __popcll(mi & below));
+    InterSt &S = st[j];
+    if(act) S.bi_slot = k;
+    const int idx = S.mvpi[M_BI][l];
+    for(int r = 0; r < P.nb; r++) {
+        xeve_hip_epzs_job e;
+        e.x = act ? J.x : -1, e.y = J.y, e.org_off = j * P.n0, e.mvp[0] = J.mvp[l][idx][0], e.mvp[1] = J.mvp[l][idx][1];
+        e.mv_start[0] = S.mv_scale[l][r][0], e.mv_start[1] = S.mv_scale[l][r][1];
+        const size_t at = (size_t)r * P.n + k;
+        ej[at] = e, extra[at] = S.mot_bits[1 - l], job_plane[at] = act ? (unsigned char)(l * P.np + r) : 0;
+    }
+}
 
-__global__ void k_bi_finish(const xeve_hip_inter_job *__restrict__ jobs, InterK P, InterSt *__restrict__ st, xeve_hip_rdo_job *__restrict__ rj)
+// get_org_bi (:143-156): 2 * org - pred, the prediction taken from where the interpolation left it (list 0's buffer, or list 1's when the fixed list is list 1)
+__global__ void k_bi_org(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const pel *__restrict__ org, const pel *__restrict__ pred0, const pel *__restrict__ pred1,
+                         const uint8_t *__restrict__ mode, int16_t *__restrict__ org_bi)
+{
+    const int nbx = P.n0 >= 1024 ? 4 : 1, j = blockIdx.x / nbx, bx = blockIdx.x % nbx, w = 1 << P.lw;
+    const xeve_hip_inter_job J = jobs[j];
+    const pel *pred = mode[j] == 2 ? pred1 : pred0;
+    for(int i = bx * blockDim.x + threadIdx.x; i < P.n0; i += nbx * blockDim.x) {
+        const int yy = i >> P.lw, xx = i & (w - 1);
+        org_bi[(size_t)j * P.n0 + i] = (int16_t)((org[(size_t)(J.y + yy) * P.s_org_l + J.x + xx] << 1) - pred[(size_t)j * P.n0 + i]);
+    }
+}
+
+// after the last round: its results taken in, then the candidate of pinter_residue_rdo
+__global__ void k_bi_tail(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const xeve_hip_me_result *__restrict__ mres, InterSt *__restrict__ st,
+                          xeve_hip_rdo_job *__restrict__ rj)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.n) return;
     const xeve_hip_inter_job J = jobs[j];
     InterSt &S = st[j];
+    bi_update(P, mres, S);
     for(int l = 0; l < 2; l++)
         for(int d = 0; d < 2; d++) S.mvd[M_BI][l][d] = (int16_t)(S.mv[M_BI][l][d] - J.mvp[l][S.mvpi[M_BI][l]][d]);
     rdo_job(rj[j], J, S, M_BI, 0);
@@ -285,10 +283,11 @@ __global__ void k_bi_finish(const xeve_hip_inter_job *__restrict__ jobs, InterK 
 // ---- the decision (:1872-2001) and the winner's data ---------------------------------------------------------------------------------
 __global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, const xeve_hip_skip_result *__restrict__ sres,
                                const xeve_hip_rdo_result *__restrict__ ra, const xeve_hip_rdo_result *__restrict__ rb, xeve_hip_inter_result *__restrict__ res,
-                               int *__restrict__ win, xeve_hip_cu_mc_job *__restrict__ mc)
+                               int *__restrict__ win, CuMcPrep C, int32_t *__restrict__ off0, int32_t *__restrict__ off1)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.n) return;
+    off0[j] = j * P.n0, off1[j] = j * P.n1; // (where xeve_hip_recon finds the CU's blocks: dense)
     const InterSt &S = st[j];
     double ci[M_NUM];
     int    nz[M_NUM][3];
@@ -323,7 +322,7 @@ __global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, Inte
     xeve_hip_cu_mc_job m; // the winner's prediction (a skipped CU keeps the one the skip analysis produced)
     m.x = jobs[j].x, m.y = jobs[j].y, m.pad_[0] = m.pad_[1] = 0;
     for(int l = 0; l < 2; l++) m.mv[l][0] = S.mv[best][l][0], m.mv[l][1] = S.mv[best][l][1], m.refi[l] = best == M_SKIP ? -1 : S.refi[best][l];
-    mc[j] = m;
+    xh_cu_mc_prep_one(m, j, C); // (the prediction's per-list interpolation jobs: mc_cu.h)
 }
 
 // per (CU, component): the winner's coefficients out (zero for a skipped CU) and into the scratch block that is dequantised; the skip
@@ -358,36 +357,17 @@ __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hi
     }
 }
 
-// core->s_next_best: the winner's syntax once more through the exact coder from the CU's entry state -- skip flag + candidate indices for a skipped CU, the
-// inter-CU syntax with the final coded-block flags and coefficients otherwise.  (Every candidate evaluation above only counts bits; carrying the exact coder
-// through all of them, as SBAC_STORE does in the reference, would be four exact rounds per candidate for a state only the winner's is kept of.)
-__global__ void k_inter_bits_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, const xeve_hip_inter_result *__restrict__ res,
-                                  xeve_hip_cu_bits_job *__restrict__ bj)
+// core->s_next_best: the coder state the winning mode's evaluation left (SBAC_STORE(core->s_next_best, core->s_temp_best), :1888 / :1963 / :1997) -- the skip analysis and
+// both pinter_residue_rdo batches hand out core->s_temp_best per candidate, the winner's is copied (round 6: was the winner's syntax once more through the coder, three
+// launches and a CU's worth of bins at the end of every node's chain)
+__global__ void k_inter_states(InterK P, const xeve_hip_inter_result *__restrict__ res, const xeve_hip_sbac *__restrict__ st_s, const xeve_hip_sbac *__restrict__ st_a,
+                               const xeve_hip_sbac *__restrict__ st_b, xeve_hip_sbac *__restrict__ next_best)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n) return;
-    const xeve_hip_inter_job    J = jobs[j];
-    const xeve_hip_inter_result R = res[j];
-    const InterSt &S = st[j];
-    const int m = R.best_idx;
-    xeve_hip_cu_bits_job b;
-    b.coef_off[0] = j * P.n0, b.coef_off[1] = P.n * P.n0 + j * P.n1, b.coef_off[2] = P.n * (P.n0 + P.n1) + j * P.n1;
-    b.nnz[0] = R.nnz[0], b.nnz[1] = R.nnz[1], b.nnz[2] = R.nnz[2], b.sbac = J.sbac;
-    for(int l = 0; l < 2; l++) b.mvd[l][0] = S.mvd[m][l][0], b.mvd[l][1] = S.mvd[m][l][1], b.refi[l] = S.refi[m][l], b.mvp_idx[l] = S.mvpi[m][l];
-    b.mode = m == M_SKIP ? XEVE_HIP_BITS_CU_SKIP : XEVE_HIP_BITS_CU_INTER, b.dir_flag = m == M_DIR, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = J.ctx_pred_mode;
-    bj[j] = b;
-}
-
-__global__ void k_inter_states(InterK P, const xeve_hip_inter_result *__restrict__ res, const xeve_hip_sbac *__restrict__ stw, xeve_hip_sbac *__restrict__ next_best)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j < P.n && res[j].cu_mode >= 0) copy_sbac(next_best + j, stw + j);
-}
-
-__global__ void k_iota_off(int n, int step, int32_t *__restrict__ off)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j < n) off[j] = j * step;
+    if(j >= P.n || res[j].cu_mode < 0) return;
+    const int m = res[j].best_idx;
+    const xeve_hip_sbac *src = m == M_SKIP ? st_s + j : m == M_BI ? st_b + j : st_a + (P.isb ? (size_t)(m == M_DIR ? 0 : m == M_L0 ? 1 : 2) * P.n + j : j);
+    copy_sbac(next_best + j, src);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------
@@ -395,7 +375,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_w, bjw, bits_w, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
+    size_t st, sj, sres, sk[3], st_s, st_a, st_b, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
         scratch, scratch_bytes, total;
 };
 
@@ -409,7 +389,7 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
     L.st = take(N * sizeof(InterSt)), L.sj = take(N * sizeof(xeve_hip_skip_job)), L.sres = take(N * sizeof(xeve_hip_skip_result));
     L.sk[0] = take(N * n0 * 2), L.sk[1] = take(N * n1 * 2 + 8), L.sk[2] = take(N * n1 * 2 + 8);
-    L.st_w = take(N * sizeof(xeve_hip_sbac)), L.bjw = take(N * sizeof(xeve_hip_cu_bits_job)), L.bits_w = take(N * 4);
+    L.st_s = take(N * sizeof(xeve_hip_sbac)), L.st_a = take(na * sizeof(xeve_hip_sbac)), L.st_b = take(N * sizeof(xeve_hip_sbac));
     L.ej = take(2 * MAXR * N * sizeof(xeve_hip_epzs_job)), L.mres = take(2 * MAXR * N * sizeof(xeve_hip_me_result));
     L.bjm = take(10 * N * sizeof(xeve_hip_cu_bits_job)), L.bitsm = take(10 * N * 4);
     L.rja = take(na * sizeof(xeve_hip_rdo_job)), L.rra = take(na * sizeof(xeve_hip_rdo_result)), L.coef_a = take(na * ne * 2);
@@ -469,9 +449,7 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *sj = (xeve_hip_skip_job *)(W + L.sj);
     auto *sres = (xeve_hip_skip_result *)(W + L.sres);
     pel  *sk[3] = {(pel *)(W + L.sk[0]), (pel *)(W + L.sk[1]), (pel *)(W + L.sk[2])}, *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
-    auto *st_w = (xeve_hip_sbac *)(W + L.st_w);
-    auto *bjw = (xeve_hip_cu_bits_job *)(W + L.bjw);
-    auto *bits_w = (unsigned *)(W + L.bits_w);
+    auto *st_s = (xeve_hip_sbac *)(W + L.st_s), *st_a = (xeve_hip_sbac *)(W + L.st_a), *st_b = (xeve_hip_sbac *)(W + L.st_b);
     auto *ej = (xeve_hip_epzs_job *)(W + L.ej);
     auto *mres = (xeve_hip_me_result *)(W + L.mres);
     auto *bjm = (xeve_hip_cu_bits_job *)(W + L.bjm);
@@ -479,7 +457,6 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *rja = (xeve_hip_rdo_job *)(W + L.rja), *rjb = (xeve_hip_rdo_job *)(W + L.rjb);
     auto *rra = (xeve_hip_rdo_result *)(W + L.rra), *rrb = (xeve_hip_rdo_result *)(W + L.rrb);
     auto *coef_a = (int16_t *)(W + L.coef_a), *coef_b = (int16_t *)(W + L.coef_b), *tmp = (int16_t *)(W + L.tmp), *org_bi = (int16_t *)(W + L.org_bi);
-    auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
     auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win), *off0 = (int32_t *)(W + L.off[0]), *off1 = (int32_t *)(W + L.off[1]);
     auto *is_coef = (unsigned char *)(W + L.is_coef);
     auto *cnt = (int32_t *)(W + L.cnt);
@@ -492,9 +469,9 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     // skip mode
     k_inter_skip_jobs<<<G, 256, 0, s>>>(jobs, P, sj);
     rc = xeve_hip_analyze_skip_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, sj, njobs, p->max_cand, coef_l, coef_c, sres, sk[0], sk[1], sk[2],
-                                    nullptr, scr, L.scratch_bytes, stream);
+                                    st_s, scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
-    k_inter_stage1<<<G, 256, 0, s>>>(jobs, P, sres, st, rja, ej);
+    k_inter_stage1<<<G, 256, 0, s>>>(jobs, P, sres, st, rja, ej, cnt);
     // motion search per list and reference picture (:1906-1950)
     // ONE launch chain over every (list, reference picture): the job arrays are laid out [list][plane][CU], the plane supplies the picture
     xeve_hip_epzs_params ep = p->me;
@@ -523,44 +500,40 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     rc = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_uni_b<<<G, 256, 0, s>>>(jobs, P, bitsm, st, rja);
-    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, nullptr, scr, L.scratch_bytes, stream);
+    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
     if(P.isb) { // analyze_bi
-        k_bi_init<<<G, 256, 0, s>>>(P, rra, st);
+        CuMcPrep C; // (the prediction from the fixed list: luma alone, read by k_bi_org from whichever list's buffer holds it)
+        rc = xh_mc_cu_prep_params(refp, rp.num_refp[0], rp.num_refp[1], rp.pic_w, rp.pic_h, njobs, w, w, idc, scr, L.scratch_bytes, &C);
+        if(rc != XEVE_HIP_OK) return rc;
         for(int it = 0; it < 4; it++) { // BI_ITER
-            k_bi_mc_jobs<<<G, 256, 0, s>>>(jobs, P, st, mc);
-            rc = xeve_hip_mc_cu_jobs(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, mc, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
-                                     pred[2], scr, L.scratch_bytes, stream);
+            k_bi_head<<<G, 256, 0, s>>>(jobs, P, st, rra, mres, it == 0, C, ej, extra, cnt + 2 * it, job_plane);
+            rc = xh_mc_cu_jobs_x(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, nullptr, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
+                                 pred[2], scr, L.scratch_bytes, stream, XH_MC_PREPPED | XH_MC_LUMA_ONLY | XH_MC_NO_COMBINE);
             if(rc != XEVE_HIP_OK) return rc;
-            k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], org_bi);
-            k_bi_jobs_off<<<(P.nb * njobs + 255) / 256, 256, 0, s>>>(P, ej, job_plane, cnt);
-            k_bi_me_jobs<<<G, 256, 0, s>>>(jobs, P, st, ej, extra, cnt, job_plane);
+            k_bi_org<<<njobs * (P.n0 >= 1024 ? 4 : 1), P.n0 >= 256 ? 256 : 64, 0, s>>>(jobs, P, org[0], pred[0], C.p1[0], C.mode, org_bi);
             planes_for(2, 1);
             pl.job_plane = job_plane;
             ep.me.bi = 1, ep.me.extra_bits = 0;
             rc = xh_me_epzs_jobs_planes(org[0], s_org_l, (const pel *)org_bi, nullptr, s_l, ej, P.nb * njobs, lw, lw, bd, coef_l, &ep, extra, mres, scr, L.scratch_bytes, stream,
                                         &pl);
             if(rc != XEVE_HIP_OK) return rc;
-            k_bi_update<<<G, 256, 0, s>>>(P, mres, st);
         }
-        k_bi_finish<<<G, 256, 0, s>>>(jobs, P, st, rjb);
-        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, nullptr, scr, L.scratch_bytes,
+        k_bi_tail<<<G, 256, 0, s>>>(jobs, P, mres, st, rjb);
+        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, st_b, scr, L.scratch_bytes,
                                        stream);
         if(rc != XEVE_HIP_OK) return rc;
     }
     // the decision; the winner's prediction, coefficients, reconstruction (:2004-2032) and coder state
-    k_inter_decide<<<G, 256, 0, s>>>(jobs, P, st, sres, rra, rrb, results, win, mc);
-    rc = xeve_hip_mc_cu_jobs(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, mc, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1], pred[2],
-                             scr, L.scratch_bytes, stream);
+    CuMcPrep Cw;
+    rc = xh_mc_cu_prep_params(refp, rp.num_refp[0], rp.num_refp[1], rp.pic_w, rp.pic_h, njobs, w, w, idc, scr, L.scratch_bytes, &Cw);
+    if(rc != XEVE_HIP_OK) return rc;
+    k_inter_decide<<<G, 256, 0, s>>>(jobs, P, st, sres, rra, rrb, results, win, Cw, off0, off1);
+    rc = xh_mc_cu_jobs_x(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, nullptr, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1], pred[2],
+                         scr, L.scratch_bytes, stream, XH_MC_PREPPED);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, tmp, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], is_coef);
-    // core->s_next_best of the winners
-    k_inter_bits_jobs<<<G, 256, 0, s>>>(jobs, P, st, results, bjw);
-    rc = xeve_hip_cu_bits_jobs(coef, (size_t)njobs * (P.n0 + 2 * (size_t)P.n1), states, bjw, njobs, &bp, scr, L.scratch_bytes, bits_w, st_w, stream);
-    if(rc != XEVE_HIP_OK) return rc;
-    k_inter_states<<<G, 256, 0, s>>>(P, results, st_w, next_best);
-    k_iota_off<<<G, 256, 0, s>>>(njobs, P.n0, off0);
-    k_iota_off<<<G, 256, 0, s>>>(njobs, P.n1, off1);
+    k_inter_states<<<G, 256, 0, s>>>(P, results, st_s, st_a, st_b, next_best); // core->s_next_best of the winners
     static const int k_dq_scale[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237)
     pel *rec[3] = {rec_y, rec_u, rec_v};
     for(int k = 0; k < P.ncomp; k++) {

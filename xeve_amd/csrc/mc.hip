@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include "xh_common.h"
+#include "mc_cu.h"
 
 template <int TAPS> struct CoefTab {
     int16_t c[(TAPS == 8 ? 16 : 32)][TAPS]; // passed by value in the kernarg segment (256 B)
@@ -376,7 +377,8 @@ struct SpelBits {
     const unsigned char *job_plane;
 };
 __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int njobs, int cnt, int stage, xeve_hip_spel_params P,
-                              const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res, SpelBits sb, int vh)
+                              const int32_t *__restrict__ extra, const int32_t *__restrict__ sad, xeve_hip_me_result *__restrict__ res, SpelBits sb, int vh,
+                              XhSpelFinish fin)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= njobs) return;
@@ -400,6 +402,14 @@ __global__ void k_spel_select(const xeve_hip_spel_job *__restrict__ jobs, int nj
         }
     }
     res[j] = r;
+    if(fin.out) { // the last stage of a pinter_me_epzs call: the search's final result (xeve_pinter.c:828-833; me_spel_pattern's side effect on pi->mot_bits, :690-692)
+        const EpzsState z = fin.state[j];
+        xeve_hip_me_result o;
+        o.cost = z.cost, o.mv[0] = z.mv[0], o.mv[1] = z.mv[1], o.beststep = 0, o.best_mv_bits = z.mot_bits;
+        if(!P.bi && r.best_mv_bits > 0) o.best_mv_bits = r.best_mv_bits;
+        if(r.cost < o.cost) o.cost = r.cost, o.mv[0] = r.mv[0], o.mv[1] = r.mv[1];
+        fin.out[j] = o;
+    }
 }
 
 extern "C" size_t xeve_hip_me_spel_workspace(int njobs) { return (size_t)(njobs > 0 ? njobs : 0) * 8 * (sizeof(xeve_hip_mc_job) + sizeof(int32_t)); }
@@ -416,7 +426,7 @@ extern "C" int xeve_hip_me_spel_pattern_jobs(const pel *org0, int s_org, const p
 // extra: pi->mot_bits[other list] per job (device memory) instead of params->extra_bits; NULL = the common value
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
-                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes)
+                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes, const XhSpelFinish *finish)
 {
     XH_ENTER();
     XH_REQUIRE(org0 && (ref0 || (planes && planes->n > 0)) && jobs && coef && params && results && workspace && njobs >= 0);
@@ -449,7 +459,10 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
         XH_HIP(hipGetLastError());
         int rc = mc_launch<8, 1>(ref0, s_ref, nullptr, 0, mc, items, w, h, bit_depth, &coef[0][0], st, cmp, s_c, sad, pt.n ? &pt : nullptr);
         if(rc != XEVE_HIP_OK) return rc;
-        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, extra, sad, results, sb, vh);
+        const bool last = stage == 1 || P.qpel_cnt == 0;
+        XhSpelFinish fin = {nullptr, nullptr};
+        if(finish && last) fin = *finish;
+        k_spel_select<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, cnt, stage, P, extra, sad, results, sb, vh, fin);
         XH_HIP(hipGetLastError());
     }
     return XEVE_HIP_OK;
@@ -461,52 +474,11 @@ int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, con
 // average when two predictions remain.  One small kernel turns the jobs into per-(list, reference picture) interpolation jobs
 // (switched off where a job does not use that picture); list 0 lands in the caller's buffers, list 1 in the workspace; a
 // last kernel averages / copies per job.
-#define XH_MAX_REF 8
-struct CuMcK {
-    int pic_w, pic_h, w, h, cw, ch, wfac, hfac, nref[2], poc[2][XH_MAX_REF];
-    int vh; // a batch of pictures stacked vertically (xh_common.h): 0 = one picture
-};
-
-__global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, int njobs, CuMcK P, xeve_hip_mc_job *__restrict__ jl,
-                             xeve_hip_mc_job *__restrict__ jc, uint8_t *__restrict__ mode)
+__global__ void k_cu_mc_prep(const xeve_hip_cu_mc_job *__restrict__ jobs, CuMcPrep C)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= njobs) return;
-    const xeve_hip_cu_mc_job J = jobs[j];
-    const int yb = xh_vh_base(J.y, P.vh); // the vectors are clipped against the job's own picture; the rows of its picture in the stack are added to the positions below
-    const int x4 = J.x << 2, y4 = (J.y - yb) << 2, w4 = P.w << 2, h4 = P.h << 2;
-    const int min_c = -(128 << 2), max_x = (P.pic_w - 1 + 128) << 2, max_y = (P.pic_h - 1 + 128) << 2; // MAX_CU_SIZE margin
-    int  mvt[2][2];
-    bool valid[2];
-#pragma unroll
-    for(int l = 0; l < 2; l++) {
-        valid[l] = J.refi[l] >= 0;
-        int mx = J.mv[l][0], my = J.mv[l][1];
-        if(valid[l]) {
-            if(x4 + J.mv[l][0] < min_c) mx = (int16_t)(min_c - x4);
-            if(y4 + J.mv[l][1] < min_c) my = (int16_t)(min_c - y4);
-            if(x4 + J.mv[l][0] + w4 - 4 > max_x) mx = (int16_t)(max_x - x4 - w4 + 4);
-            if(y4 + J.mv[l][1] + h4 - 4 > max_y) my = (int16_t)(max_y - y4 - h4 + 4);
-        }
-        mvt[l][0] = mx, mvt[l][1] = my;
-    }
-    bool use1 = valid[1];
-    if(valid[0] && valid[1] && P.poc[0][J.refi[0]] == P.poc[1][J.refi[1]] && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1]) use1 = false;
-    mode[j] = (uint8_t)(use1 ? (valid[0] ? 1 : 2) : 0); // 1 average the two, 2 list 1 alone: copy it over
-#pragma unroll
-    for(int l = 0; l < 2; l++) {
-        const bool on = l == 0 ? valid[0] : use1;
-        const int  gx = (x4 + mvt[l][0]) << 2, gy = (y4 + (yb << 2) + mvt[l][1]) << 2;
-        xeve_hip_mc_job a, c;
-        a.gmv_x = gx, a.gmv_y = gy, a.pred_off = j * P.w * P.h;
-        a.frac = ((J.mv[l][0] & 3) ? 1 : 0) | ((J.mv[l][1] & 3) ? 2 : 0);
-        c.gmv_x = gx * P.wfac, c.gmv_y = gy * P.hfac, c.pred_off = j * P.cw * P.ch;
-        c.frac = ((J.mv[l][0] & 7) ? 1 : 0) | ((J.mv[l][1] & 7) ? 2 : 0);
-        // one job array per list; the reference picture rides in frac bits 3.. (PlaneTab); bit 2 switches a job off
-        const int sel = (on && J.refi[l] < P.nref[l]) ? (J.refi[l] << 3) : 4;
-        a.frac |= sel, c.frac |= sel;
-        jl[(size_t)l * njobs + j] = a, jc[(size_t)l * njobs + j] = c;
-    }
+    if(j >= C.njobs) return;
+    xh_cu_mc_prep_one(jobs[j], j, C);
 }
 
 __global__ void k_cu_mc_combine(pel *__restrict__ p0, const pel *__restrict__ p1, const uint8_t *__restrict__ mode, int njobs, int n)
@@ -551,34 +523,65 @@ extern "C" size_t xeve_hip_mc_cu_workspace(int njobs, int w, int h, int num_refp
     return ((n + 15) & ~(size_t)15) + 2 * q * n * sizeof(xeve_hip_mc_job) + 3 * n * (size_t)w * h * sizeof(pel);
 }
 
-extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h,
-                                   const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h, int bit_depth_luma, int bit_depth_chroma,
-                                   int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], pel *pred_y, pel *pred_u,
-                                   pel *pred_v, void *workspace, size_t workspace_bytes, void *stream)
+// the layout of the prediction workspace and the parameters of the per-CU front half (mc_cu.h)
+int xh_mc_cu_prep_params(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int pic_w, int pic_h, int njobs, int w, int h, int chroma_format_idc, void *workspace,
+                         size_t workspace_bytes, CuMcPrep *out)
 {
-    XH_ENTER();
-    XH_REQUIRE(refp && jobs && njobs >= 0 && coef_l && pred_y && workspace);
+    XH_REQUIRE(refp && njobs >= 0 && workspace && out);
     XH_REQUIRE(num_refp0 >= 0 && num_refp0 <= XH_MAX_REF && num_refp1 >= 0 && num_refp1 <= XH_MAX_REF && num_refp0 + num_refp1 > 0);
     XH_REQUIRE(w >= 4 && h >= 4 && w <= 128 && h <= 128 && (w & 3) == 0 && (h & 3) == 0 && chroma_format_idc >= 0 && chroma_format_idc <= 3);
-    XH_REQUIRE(chroma_format_idc == 0 || (pred_u && pred_v && coef_c));
     XH_REQUIRE(workspace_bytes >= xeve_hip_mc_cu_workspace(njobs, w, h, num_refp0, num_refp1));
-    if(njobs == 0) return XEVE_HIP_OK;
     const int ws = chroma_format_idc <= 2, hs = chroma_format_idc <= 1; // XEVE_GET_CHROMA_{W,H}_SHIFT
-    CuMcK P;
+    CuMcK &P = out->P;
     P.vh = xh_vh(), P.pic_w = pic_w, P.pic_h = pic_h, P.w = w, P.h = h, P.cw = w >> ws, P.ch = h >> hs, P.wfac = 2 / (ws + 1), P.hfac = 2 / (hs + 1);
     P.nref[0] = num_refp0, P.nref[1] = num_refp1;
     const int nmax = num_refp0 > num_refp1 ? num_refp0 : num_refp1;
     for(int r = 0; r < XH_MAX_REF; r++)
         for(int l = 0; l < 2; l++) P.poc[l][r] = r < nmax ? refp[r * 2 + l].poc : 0;
     const size_t n = njobs, q = 2;
-    uint8_t         *mode = (uint8_t *)workspace;
-    xeve_hip_mc_job *jl   = (xeve_hip_mc_job *)(mode + ((n + 15) & ~(size_t)15)), *jc = jl + q * n;
-    pel             *p1[3];
-    p1[0] = (pel *)(jc + q * n), p1[1] = p1[0] + n * w * h, p1[2] = p1[1] + n * P.cw * P.ch;
+    out->njobs = njobs;
+    out->mode = (uint8_t *)workspace;
+    out->jl = (xeve_hip_mc_job *)(out->mode + ((n + 15) & ~(size_t)15)), out->jc = out->jl + q * n;
+    out->p1[0] = (pel *)(out->jc + q * n), out->p1[1] = out->p1[0] + n * w * h, out->p1[2] = out->p1[1] + n * P.cw * P.ch;
+    return XEVE_HIP_OK;
+}
+
+extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h,
+                                   const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h, int bit_depth_luma, int bit_depth_chroma,
+                                   int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], pel *pred_y, pel *pred_u,
+                                   pel *pred_v, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return xh_mc_cu_jobs_x(refp, num_refp0, num_refp1, s_l, s_c, pic_w, pic_h, jobs, njobs, w, h, bit_depth_luma, bit_depth_chroma, chroma_format_idc, coef_l, coef_c, pred_y,
+                           pred_u, pred_v, workspace, workspace_bytes, stream, 0);
+}
+
+// flags: XH_MC_PREPPED -- the caller's own kernel has run xh_cu_mc_prep_one for every job (xh_mc_cu_prep_params with the same arguments): no front-half launch, `jobs` is not
+// read; XH_MC_LUMA_ONLY -- the luma prediction alone (analyze_bi's prediction from the fixed list, xeve_pinter.c:1618-1624: get_org_bi reads Y only); XH_MC_NO_COMBINE --
+// no last kernel: list 0's prediction stays in pred_*, list 1's in CuMcPrep::p1, CuMcPrep::mode says per job what the reader has to make of them
+int xh_mc_cu_jobs_x(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h, const xeve_hip_cu_mc_job *jobs, int njobs, int w, int h,
+                    int bit_depth_luma, int bit_depth_chroma, int chroma_format_idc, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], pel *pred_y, pel *pred_u, pel *pred_v,
+                    void *workspace, size_t workspace_bytes, void *stream, int flags)
+{
+    XH_ENTER();
+    const bool prepped = (flags & XH_MC_PREPPED) != 0, luma_only = (flags & XH_MC_LUMA_ONLY) != 0;
+    XH_REQUIRE(refp && (jobs || prepped) && njobs >= 0 && coef_l && pred_y && workspace);
+    XH_REQUIRE(chroma_format_idc == 0 || luma_only || (pred_u && pred_v && coef_c));
+    if(njobs == 0) return XEVE_HIP_OK;
+    CuMcPrep C;
+    int rc0 = xh_mc_cu_prep_params(refp, num_refp0, num_refp1, pic_w, pic_h, njobs, w, h, chroma_format_idc, workspace, workspace_bytes, &C);
+    if(rc0 != XEVE_HIP_OK) return rc0;
+    const CuMcK &P = C.P;
+    const size_t n = njobs, q = 2;
+    uint8_t         *mode = C.mode;
+    xeve_hip_mc_job *jl = C.jl, *jc = C.jc;
+    pel             *p1[3] = {C.p1[0], C.p1[1], C.p1[2]};
     hipStream_t st = (hipStream_t)stream;
     XhProf prof(XH_PROF_MC, st);
-    k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, njobs, P, jl, jc, mode);
-    XH_HIP(hipGetLastError());
+    if(!prepped) {
+        k_cu_mc_prep<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, C);
+        XH_HIP(hipGetLastError());
+    }
+    const bool chroma = chroma_format_idc && !luma_only;
     // two interpolation launches: luma of both lists, then {Cb, Cr} of both lists (blockIdx.y picks list / plane; the jobs pick their reference
     // picture from the pass's table).  Shapes the packed kernel cannot take (chroma width not a multiple of 4) go list by list, plane by plane.
     PlaneTab ty[2], tu[2], tv[2];
@@ -589,11 +592,11 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
         ty[l].n = tu[l].n = tv[l].n = P.nref[l];
         for(int r = 0; r < XH_MAX_PLANES; r++) {
             const xeve_hip_refpic &R = refp[(r < P.nref[l] ? r : 0) * 2 + l];
-            XH_REQUIRE(R.y && (chroma_format_idc == 0 || (R.u && R.v)));
+            XH_REQUIRE(R.y && (!chroma || (R.u && R.v)));
             ty[l].p[r] = R.y, tu[l].p[r] = R.u, tv[l].p[r] = R.v;
         }
     }
-    const bool packed_l = w % 8 == 0, packed_c = chroma_format_idc && P.cw % 4 == 0;
+    const bool packed_l = w % 8 == 0, packed_c = chroma && P.cw % 4 == 0;
     if(packed_l) {
         McMulti mv;
         mv.n = nl;
@@ -621,19 +624,18 @@ extern "C" int xeve_hip_mc_cu_jobs(const xeve_hip_refpic *refp, int num_refp0, i
             int rc = mc_launch<8, 0>(nullptr, s_l, l ? p1[0] : pred_y, w, jl + (size_t)l * n, njobs, w, h, bit_depth_luma, &coef_l[0][0], st, nullptr, 0, nullptr, &ty[l]);
             if(rc != XEVE_HIP_OK) return rc;
         }
-        if(chroma_format_idc && !packed_c) {
+        if(chroma && !packed_c) {
             int rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[1] : pred_u, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tu[l]);
             if(rc != XEVE_HIP_OK) return rc;
             rc = mc_launch<4, 0>(nullptr, s_c, l ? p1[2] : pred_v, P.cw, jc + (size_t)l * n, njobs, P.cw, P.ch, bit_depth_chroma, &coef_c[0][0], st, nullptr, 0, nullptr, &tv[l]);
             if(rc != XEVE_HIP_OK) return rc;
         }
     }
-    if(num_refp1 > 0) {
-        const long tl = ((long)njobs * w * h) / 4, tc = ((long)njobs * P.cw * P.ch) / 4;
-        if(chroma_format_idc)
+    if(num_refp1 > 0 && !(flags & XH_MC_NO_COMBINE)) {
+        const long tl = ((long)njobs * w * h) / 4;
+        if(chroma)
             k_cu_mc_combine3<<<dim3((unsigned)((tl + 255) / 256), 3), 256, 0, st>>>(pred_y, p1[0], pred_u, p1[1], pred_v, p1[2], mode, njobs, w * h, P.cw * P.ch);
         else k_cu_mc_combine<<<(unsigned)((tl + 255) / 256), 256, 0, st>>>(pred_y, p1[0], mode, njobs, w * h);
-        (void)tc;
     }
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

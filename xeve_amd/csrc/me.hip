@@ -510,13 +510,6 @@ extern "C" int xeve_hip_me_ipel_diamond_jobs(const pel *org0, int s_org, const p
 // =========================================================================================================
 // pinter_me_epzs per job (xeve_hip_me_epzs_jobs)
 // =========================================================================================================
-struct EpzsState {
-    uint32_t cost;
-    int16_t  mv[2];
-    int32_t  tmpstep, searches;
-    int32_t  mot_bits; // what the searches leave in pi->mot_bits[lidx] (0 = untouched; xeve_pinter.c:546-548,690-692)
-};
-
 __device__ __forceinline__ void epzs_range(const xeve_hip_me_params &P, int cx, int cy, int16_t (&range)[4])
 {
     const int sr = P.bi == 1 ? 5 : P.range_recentre; // get_range_ipel, xeve_pinter.c:122-140
@@ -532,7 +525,7 @@ template <int S, bool BI, bool EXTRA, int LDSM, bool CPL>
 __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, const pel *__restrict__ ref0, int s_ref,
                                                  const xeve_hip_epzs_job *__restrict__ jobs, int njobs, int shift, xeve_hip_me_params P,
                                                  const int32_t *__restrict__ extra, EpzsState *__restrict__ st, XhSearchPlanes pl, int ipel_only,
-                                                 unsigned long long *__restrict__ units)
+                                                 unsigned long long *__restrict__ units, xeve_hip_spel_job *__restrict__ sj)
 {
     __shared__ __attribute__((aligned(16))) pel s_win[LDSM ? 4 * LDSM * MWin<S, BI>::PELS : 8];
     __shared__ __attribute__((aligned(16))) pel s_lorg[CPL ? 4 * S * S : 8];
@@ -546,14 +539,26 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         ref0 = pl.ref[q], P.refi_bits = pl.refi_bits[q], P.range_recentre = pl.range[q], P.reserved = (P.reserved & 0xFF) | (pl.refi[q] << 8);
     }
     xeve_hip_epzs_job e = jobs[j];
+    int yb = 0;
     if(pl.vh) { // a batch of pictures stacked vertically (xh_common.h): from here on the job's own picture, in its own coordinates
-        const int yb = uni(xh_vh_base(e.y, pl.vh));
+        yb = uni(xh_vh_base(e.y, pl.vh));
         org0 += (long)yb * s_org, ref0 += (long)yb * s_ref, e.y -= yb;
     }
+    // the job of the sub-pel stage that follows (round 6: was a launch of its own, k_epzs_spel_jobs): y keeps the picture of a stacked batch, the predictor is in the
+    // picture's own coordinates (16 bits), the centre is where the integer searches ended
+    auto put_spel_job = [&](const EpzsState &z) {
+        if(!sj || lane != 0) return;
+        xeve_hip_spel_job q;
+        q.x = e.x, q.y = e.y + yb, q.org_off = e.org_off;
+        q.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), q.gmvp[1] = (int16_t)(e.mvp[1] + (e.y << 2));
+        q.mvi[0] = z.mv[0], q.mvi[1] = z.mv[1];
+        sj[j] = q;
+    };
     if(e.x < 0) { // job switched off
         EpzsState z;
         z.cost = 0xFFFFFFFFu, z.mv[0] = e.mv_start[0], z.mv[1] = e.mv_start[1], z.tmpstep = 0, z.searches = 0, z.mot_bits = 0;
         if(lane == 0) st[j] = z;
+        put_spel_job(z);
         return;
     }
     if(BI && extra) P.extra_bits = uni(extra[j]); // pi->mot_bits[other list] of this CU
@@ -635,19 +640,8 @@ __global__ __launch_bounds__(256) void k_me_epzs(const pel *__restrict__ org0, i
         if(rc < s.cost) s.cost = rc, s.mv[0] = (int16_t)((rx - e.x) << 2), s.mv[1] = (int16_t)((ry - e.y) << 2);
     }
     if(lane == 0) st[j] = s;
+    put_spel_job(s);
     if(units && lane == 0) atomicAdd(XH_PROF_SLOT(units), (unsigned long long)nev * (S * S / 64));
-}
-
-__global__ void k_epzs_spel_jobs(const xeve_hip_epzs_job *__restrict__ jobs, int n, const EpzsState *__restrict__ st, xeve_hip_spel_job *__restrict__ sj, int vh)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= n) return;
-    const xeve_hip_epzs_job e = jobs[j];
-    xeve_hip_spel_job s;
-    s.x = e.x, s.y = e.y, s.org_off = e.org_off; // (y keeps the picture of a stacked batch; the predictor is in the picture's own coordinates, 16 bits)
-    s.gmvp[0] = (int16_t)(e.mvp[0] + (e.x << 2)), s.gmvp[1] = (int16_t)(e.mvp[1] + ((e.y - xh_vh_base(e.y, vh)) << 2));
-    s.mvi[0] = st[j].mv[0], s.mvi[1] = st[j].mv[1];
-    sj[j] = s;
 }
 
 __global__ void k_epzs_finish(int n, int bi, const EpzsState *__restrict__ st, const xeve_hip_me_result *__restrict__ spel, xeve_hip_me_result *__restrict__ out)
@@ -720,6 +714,7 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     xeve_hip_me_params P = params->me;
     const int ipel_only = params->hpel_cnt == 0; // me_level <= ME_LEV_IPEL: no sub-pel stage, an integer refinement inside the search kernel
     const bool extra_branches = ipel_only || (P.reserved & 1);
+    xeve_hip_spel_job *sj_out = ipel_only ? nullptr : sj; // (the integer searches' kernel writes the sub-pel stage's jobs)
     {
         const dim3 grid((njobs + 3) / 4);
         const int  shift = bit_depth - 8;
@@ -729,11 +724,11 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
 #define EPZS_LAUNCH_M(S, M, C)                                                                                     \
     do {                                                                                                           \
         if(extra_branches) {                                                                                       \
-            if(P.bi) k_me_epzs<S, true, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);            \
-            else k_me_epzs<S, false, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units);               \
+            if(P.bi) k_me_epzs<S, true, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units, sj_out);    \
+            else k_me_epzs<S, false, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units, sj_out);       \
         }                                                                                                          \
-        else if(P.bi) k_me_epzs<S, true, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                  \
-        else k_me_epzs<S, false, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units);                          \
+        else if(P.bi) k_me_epzs<S, true, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units, sj_out);          \
+        else k_me_epzs<S, false, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units, sj_out);                  \
     } while(0)
 #define EPZS_LAUNCH(S)                                                                                             \
     do {                                                                                                           \
@@ -755,21 +750,17 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         XH_HIP(hipGetLastError());
         return XEVE_HIP_OK;
     }
-    k_epzs_spel_jobs<<<g, 256, 0, st>>>(jobs, njobs, state, sj, pl.vh);
-    XH_HIP(hipGetLastError());
     xeve_hip_spel_params SP;
     SP.lambda_mv = P.lambda_mv, SP.refi_bits = P.refi_bits, SP.extra_bits = P.extra_bits, SP.bi = P.bi;
     SP.hpel_cnt = params->hpel_cnt, SP.qpel_cnt = params->qpel_cnt;
     int rc;
     {
         XhProf prof(XH_PROF_SPEL, st);
+        const XhSpelFinish fin = {state, results}; // (round 6: k_epzs_finish's merge rides on the sub-pel stage's last selection)
         rc = xh_me_spel_pattern_jobs_x(org0, s_org, org_bi, ref0, s_ref, sj, njobs, log2w, log2h, bit_depth, coef, &SP, extra_bits, sres, sws,
-                                       xeve_hip_me_spel_workspace(njobs), st, pl.n ? &pl : nullptr);
+                                       xeve_hip_me_spel_workspace(njobs), st, pl.n ? &pl : nullptr, &fin);
     }
-    if(rc != XEVE_HIP_OK) return rc;
-    k_epzs_finish<<<g, 256, 0, st>>>(njobs, P.bi, state, sres, results);
-    XH_HIP(hipGetLastError());
-    return XEVE_HIP_OK;
+    return rc;
 }
 
 

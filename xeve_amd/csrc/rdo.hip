@@ -17,6 +17,7 @@
 // core->s_temp_best.
 #include <cstdlib>
 #include "xh_common.h"
+#include "mc_cu.h"
 
 extern "C" int xeve_hip_residual_rdoq_dev(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h,
                                           int bit_depth, int qp, int qscale, int dqscale, int is_intra_slice, double lambda, int ch_type, int tool_iqt,
@@ -54,8 +55,8 @@ __device__ __forceinline__ void fill_bits_job(xeve_hip_cu_bits_job &b, const xev
 }
 
 // jobs of the building blocks: prediction, residual chain (luma / chroma), estimate record per block
-__global__ void k_rdo_prep(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, xeve_hip_cu_mc_job *__restrict__ mc, xeve_hip_job *__restrict__ rl,
-                           xeve_hip_job *__restrict__ rc, int *__restrict__ est_idx)
+__global__ void k_rdo_prep(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, CuMcPrep C, xeve_hip_job *__restrict__ rl, xeve_hip_job *__restrict__ rc,
+                           int *__restrict__ est_idx)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.njobs) return;
@@ -63,7 +64,7 @@ __global__ void k_rdo_prep(const xeve_hip_rdo_job *__restrict__ jobs, RdoK P, xe
     xeve_hip_cu_mc_job m;
     m.x = J.x, m.y = J.y, m.mv[0][0] = J.mv[0][0], m.mv[0][1] = J.mv[0][1], m.mv[1][0] = J.mv[1][0], m.mv[1][1] = J.mv[1][1];
     m.refi[0] = J.refi[0], m.refi[1] = J.refi[1], m.pad_[0] = m.pad_[1] = 0;
-    mc[j] = m;
+    xh_cu_mc_prep_one(m, j, C); // (the prediction's per-list interpolation jobs: mc_cu.h)
     rl[j] = xh_make_job(J.y, P.s_org_l, J.x, j * P.n0);
     rc[j] = xh_make_job(J.y >> P.hs, P.s_org_c, J.x >> P.ws, j * P.n1);
     est_idx[j] = J.sbac;
@@ -422,7 +423,6 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     P.wgt[0] = p->dist_chroma_weight[0], P.wgt[1] = p->dist_chroma_weight[1];
     const RdoLayout L = rdo_layout(njobs, P.n0, P.n1, nstates, (size_t)s_org_l * p->pic_h, (size_t)s_org_c * (p->pic_h >> hs), P.w, P.h, p->num_refp[0], p->num_refp[1]);
     char *W = (char *)workspace;
-    auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
     auto *rl = (xeve_hip_job *)(W + L.rl), *rc = (xeve_hip_job *)(W + L.rc);
     int  *est_idx = (int *)(W + L.est_idx);
     auto *est = (xeve_hip_rdoq_est_full *)(W + L.est);
@@ -439,10 +439,13 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     const int   G  = (njobs + 255) / 256;
     int rc_;
 
-    k_rdo_prep<<<G, 256, 0, st>>>(jobs, P, mc, rl, rc, est_idx);
+    CuMcPrep C;
+    rc_ = xh_mc_cu_prep_params(refp, p->num_refp[0], p->num_refp[1], p->pic_w, p->pic_h, njobs, P.w, P.h, idc, W + L.mcws, L.bitws - L.mcws, &C);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    k_rdo_prep<<<G, 256, 0, st>>>(jobs, P, C, rl, rc, est_idx);
     // prediction (:962)
-    rc_ = xeve_hip_mc_cu_jobs(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, mc, njobs, P.w, P.h, bd, bd, idc, coef_l, coef_c, pred[0],
-                              pred[1], pred[2], W + L.mcws, L.bitws - L.mcws, stream);
+    rc_ = xh_mc_cu_jobs_x(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, nullptr, njobs, P.w, P.h, bd, bd, idc, coef_l, coef_c, pred[0],
+                          pred[1], pred[2], W + L.mcws, L.bitws - L.mcws, stream, XH_MC_PREPPED);
     if(rc_ != XEVE_HIP_OK) return rc_;
     // the estimates of every entry state (xeve_mode.c:792)
     rc_ = xeve_hip_rdoq_bit_est(states, nstates, est, stream);
@@ -511,10 +514,11 @@ struct SkipK {
     double lambda0, wgt[2];
 };
 
-__global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, xeve_hip_cu_mc_job *__restrict__ mc, xeve_hip_job *__restrict__ rl,
-                            xeve_hip_job *__restrict__ rc, xeve_hip_cu_bits_job *__restrict__ bj, unsigned char *__restrict__ valid)
+__global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, CuMcPrep C, xeve_hip_cu_mc_job *__restrict__ mc, xeve_hip_job *__restrict__ rl,
+                            xeve_hip_job *__restrict__ rc, xeve_hip_cu_bits_job *__restrict__ bj, unsigned char *__restrict__ valid, int *__restrict__ zero)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t < 64) zero[t] = 0; // (the one-candidate offset table of the SSD launches below)
     if(t >= P.njobs * P.S) return;
     const int j = t / P.S, s = t % P.S;
     const int i0 = P.isb ? s / P.mc : s, i1 = P.isb ? s % P.mc : 0;
@@ -532,6 +536,7 @@ __global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P,
     if(m.refi[0] < 0 && m.refi[1] < 0) ok = false; // (:1444)
     if(!ok) m.refi[0] = m.refi[1] = -1;            // no prediction work for a slot that is not evaluated
     mc[t] = m;
+    xh_cu_mc_prep_one(m, t, C); // (the prediction's per-list interpolation jobs: mc_cu.h)
     rl[t] = xh_make_job(J.y, P.s_org_l, J.x, t * P.n0);
     rc[t] = xh_make_job(J.y >> P.hs, P.s_org_c, J.x >> P.ws, t * P.n1);
     xeve_hip_cu_bits_job b;
@@ -586,7 +591,7 @@ __global__ void k_skip_copy(SkipK P, const int *__restrict__ win, const pel *__r
     const pel   *s = (k == 0 ? sy : k == 1 ? su : sv) + t * n;
     pel         *d = (k == 0 ? py : k == 1 ? pu : pv) + (size_t)j * n;
     for(int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
-    if(k == 0 && best && threadIdx.x == 0) copy_state(best + j, st + j);
+    if(k == 0 && best && threadIdx.x == 0) copy_state(best + j, st + t); // (the slot's state after its skip flag and candidate indices: SBAC_STORE(core->s_temp_best, *sbac), :1519)
 }
 
 struct SkipLayout {
@@ -602,7 +607,7 @@ static SkipLayout skip_layout(int njobs, int S, int n0, int n1, int w, int h, in
     L.pred[0] = take(n * n0 * 2), L.pred[1] = take(n * n1 * 2 + 8), L.pred[2] = take(n * n1 * 2 + 8);
     for(int k = 0; k < 3; k++) L.ssd[k] = take(n * 8);
     L.bits = take(n * 4), L.win = take((size_t)njobs * 4), L.bjw = take((size_t)njobs * sizeof(xeve_hip_cu_bits_job));
-    L.bitsw = take((size_t)njobs * 4), L.stw = take((size_t)njobs * sizeof(xeve_hip_sbac)), L.zero = take(256);
+    L.bitsw = take((size_t)njobs * 4), L.stw = take(n * sizeof(xeve_hip_sbac)), L.zero = take(256);
     L.mcws = take(xeve_hip_mc_cu_workspace((int)n, w, h, nr0, nr1));
     L.bitws = take(xeve_hip_cu_bits_workspace((int)n, 64));
     L.total = o;
@@ -650,17 +655,19 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
     auto *valid = (unsigned char *)(W + L.valid);
     pel  *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
     long *ssd[3]  = {(long *)(W + L.ssd[0]), (long *)(W + L.ssd[1]), (long *)(W + L.ssd[2])};
-    auto *bits = (unsigned *)(W + L.bits), *bitsw = (unsigned *)(W + L.bitsw);
+    auto *bits = (unsigned *)(W + L.bits);
     int  *win = (int *)(W + L.win), *zero = (int *)(W + L.zero);
     auto *stw = (xeve_hip_sbac *)(W + L.stw);
     hipStream_t st = (hipStream_t)stream;
     int rc_;
 
-    XH_HIP(hipMemsetAsync(zero, 0, 256, st));
-    k_skip_prep<<<(nt + 255) / 256, 256, 0, st>>>(jobs, P, mc, rl, rc, bj, valid);
+    CuMcPrep C;
+    rc_ = xh_mc_cu_prep_params(refp, p->num_refp[0], p->num_refp[1], p->pic_w, p->pic_h, nt, w, h, idc, W + L.mcws, L.bitws - L.mcws, &C);
+    if(rc_ != XEVE_HIP_OK) return rc_;
+    k_skip_prep<<<(nt + 255) / 256, 256, 0, st>>>(jobs, P, C, mc, rl, rc, bj, valid, zero);
     // xeve_mc of every pair (:1453)
-    rc_ = xeve_hip_mc_cu_jobs(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, mc, nt, w, h, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
-                              pred[2], W + L.mcws, L.bitws - L.mcws, stream);
+    rc_ = xh_mc_cu_jobs_x(refp, p->num_refp[0], p->num_refp[1], s_l, s_c, p->pic_w, p->pic_h, nullptr, nt, w, h, bd, bd, idc, coef_l, coef_c, pred[0], pred[1],
+                          pred[2], W + L.mcws, L.bitws - L.mcws, stream, XH_MC_PREPPED);
     if(rc_ != XEVE_HIP_OK) return rc_;
     // xeve_ssd per component (:1455-1465)
     for(int k = 0; k < P.ncomp; k++) {
@@ -672,13 +679,11 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
     xeve_hip_cu_bits_params bp;
     bp.log2_cuw = p->log2_cuw, bp.log2_cuh = p->log2_cuh, bp.slice_type = p->slice_type, bp.num_refp[0] = p->num_refp[0], bp.num_refp[1] = p->num_refp[1];
     bp.cm_init = 0, bp.chroma_format_idc = idc;
-    rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, nullptr, stream);
+    // (with `best`: every slot's coder state comes out of the same launch -- a handful of header bins per lane -- and k_skip_copy takes the winner's: round 6, was a
+    // second count of the winners alone on the dependent chain)
+    rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, best ? stw : nullptr, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_skip_decide<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, P, mc, valid, ssd[0], ssd[1], ssd[2], bits, bj, results, win, bjw);
-    if(best) { // the winner's complete coder state (SBAC_STORE(core->s_temp_best, *sbac), :1519)
-        rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjw, njobs, &bp, W + L.bitws, workspace_bytes - L.bitws, bitsw, stw, stream);
-        if(rc_ != XEVE_HIP_OK) return rc_;
-    }
     k_skip_copy<<<3 * njobs, 64, 0, st>>>(P, win, pred[0], pred[1], pred[2], pred_y, pred_u, pred_v, stw, best);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;

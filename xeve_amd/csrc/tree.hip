@@ -917,7 +917,14 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
                 XH_REQUIRE(side && recorded[it.wait_ev]); // (a wait on an event not yet recorded would not wait)
                 XH_HIP(hipStreamWaitEvent(s, side_res.ev[it.wait_ev], 0));
             }
-            if(it.ops.n) k_tree_ops<<<nchains, 256, 0, s>>>(K, it.ops);
+            if(it.ops.n) {
+                // one wave per chain where every operation of the list moves a CU of at most 16x16 (256 luma samples, 16 units): the operations are a dozen phases between
+                // barriers with a global-memory round trip each, so a launch lasts (phases x latency) x (blocks / blocks resident at once) -- 5344 blocks of four waves
+                // are 2.6 rounds on 256 CUs, of one wave a single round (224 -> see profiles/r06_tree_ops.md); the large levels keep four waves for their 4096-sample copies
+                int top = 0;
+                for(int i = 0; i < it.ops.n; i++) top = std::max(top, (int)it.ops.lvl[i]);
+                k_tree_ops<<<nchains, top <= 2 ? 64 : 256, 0, s>>>(K, it.ops);
+            }
             const int log2 = it.size, cu = 1 << log2;
             const TreeK::Ac       &A = K.ac[it.st];
             const TreeLayout::Ac &LA = L.ac[it.st];

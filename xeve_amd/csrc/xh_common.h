@@ -151,9 +151,21 @@ __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(size_t o, int off2)
 }
 __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(long y, long stride, long x, int off2) { return xh_make_job((size_t)(y * stride + x), off2); }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
+// what the integer searches of pinter_me_epzs leave per job (me.hip) and the merge of the sub-pel stage's result into it (xeve_pinter.c:828-833, 690-692): with `finish`
+// the sub-pel stage's last selection kernel writes the search's final result itself
+struct EpzsState {
+    uint32_t cost;
+    int16_t  mv[2];
+    int32_t  tmpstep, searches;
+    int32_t  mot_bits; // what the searches leave in pi->mot_bits[lidx] (0 = untouched; xeve_pinter.c:546-548,690-692)
+};
+struct XhSpelFinish {
+    const EpzsState    *state;
+    xeve_hip_me_result *out;
+};
 int xh_me_spel_pattern_jobs_x(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_spel_job *jobs, int njobs, int log2w,
                               int log2h, int bit_depth, const int16_t (*coef)[8], const xeve_hip_spel_params *params, const int32_t *extra,
-                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes = nullptr); // mc.hip
+                              xeve_hip_me_result *results, void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes = nullptr, const struct XhSpelFinish *finish = nullptr); // mc.hip
 int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const pel *ref0, int s_ref, const xeve_hip_epzs_job *jobs, int njobs, int log2w, int log2h,
                            int bit_depth, const int16_t (*coef)[8], const xeve_hip_epzs_params *params, const int32_t *extra_bits, xeve_hip_me_result *results,
                            void *workspace, size_t workspace_bytes, void *stream, const XhSearchPlanes *planes); // me.hip
