@@ -828,8 +828,9 @@ int xeve_hip_walk_select(int mode);
 int xeve_hip_walk_team(int chains_per_team);
 /* The composed walk's SIDE STREAM (round 6): the analyses of every node that has children (the unsplit alternative of mode_coding_tree, xeve_mode.c:2073-2146) run on a
  * second stream of the library's while the caller's stream walks on into the children (:2189-2262) -- neither needs anything of the other until the two costs are compared
- * (:2306-2329) --, joined with events in front of that comparison: two launch chains side by side.  1 on (the default; XEVE_HIP_TREE_SIDE=0 starts with it off), 0 the
- * one-stream walk; returns the value before the call (any other value only reads it).  Results do not depend on it; the workspace query covers both. */
+ * (:2306-2329) --, joined with events in front of that comparison: launch chains side by side, a side stream per node size.  1 on (the default; XEVE_HIP_TREE_SIDE=0 starts
+ * with it off), 0 the one-stream walk, 2 one side stream for all sizes (a measurement setting); returns the value before the call (any other value only reads it).  Results
+ * do not depend on it; the workspace query covers all three. */
 int xeve_hip_walk_side(int on);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,

@@ -68,7 +68,7 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
 
 
-WALKS = {"by_width": (-1, 0, -1), "composed": (0, 0, 1), "composed_one_stream": (0, 0, 0), "fused_3_chains_per_team": (1, 3, -1)}
+WALKS = {"by_width": (-1, 0, -1), "composed": (0, 0, 1), "composed_one_stream": (0, 0, 0), "composed_one_side_stream": (0, 0, 2), "fused_3_chains_per_team": (1, 3, -1)}
 
 
 @pytest.fixture(scope="module", params=list(WALKS))

@@ -25,7 +25,7 @@ enum { M_L0 = 0, M_L1 = 1, M_BI = 2, M_SKIP = 3, M_DIR = 4, M_NUM = 5 }; // PRED
 
 struct InterK {
     int    n, isb, lw, n0, n1, ncomp, bd, max_cand, nref[2], nb, na, np; // np: planes per list in the search job / result arrays // na: candidates of the first pinter_residue_rdo batch (3n in B, n in P)
-    int    s_org_l;
+    int    s_org_l, s_org_c, ws, hs;
     int    dpoc_co, dpoc_l0, dpoc_l1;
     double thr, lambda0;
 };
@@ -283,11 +283,12 @@ __global__ void k_bi_tail(const xeve_hip_inter_job *__restrict__ jobs, InterK P,
 // ---- the decision (:1872-2001) and the winner's data ---------------------------------------------------------------------------------
 __global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, InterK P, const InterSt *__restrict__ st, const xeve_hip_skip_result *__restrict__ sres,
                                const xeve_hip_rdo_result *__restrict__ ra, const xeve_hip_rdo_result *__restrict__ rb, xeve_hip_inter_result *__restrict__ res,
-                               int *__restrict__ win, CuMcPrep C, int32_t *__restrict__ off0, int32_t *__restrict__ off1)
+                               int *__restrict__ win, CuMcPrep C, xeve_hip_job *__restrict__ wl, xeve_hip_job *__restrict__ wc)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.n) return;
-    off0[j] = j * P.n0, off1[j] = j * P.n1; // (where xeve_hip_recon finds the CU's blocks: dense)
+    wl[j] = xh_make_job(jobs[j].y, P.s_org_l, jobs[j].x, j * P.n0); // (the winner's blocks for the reconstruction: original and dense prediction, as k_rdo_prep's)
+    wc[j] = xh_make_job(jobs[j].y >> P.hs, P.s_org_c, jobs[j].x >> P.ws, j * P.n1);
     const InterSt &S = st[j];
     double ci[M_NUM];
     int    nz[M_NUM][3];
@@ -325,14 +326,23 @@ __global__ void k_inter_decide(const xeve_hip_inter_job *__restrict__ jobs, Inte
     xh_cu_mc_prep_one(m, j, C); // (the prediction's per-list interpolation jobs: mc_cu.h)
 }
 
-// per (CU, component): the winner's coefficients out (zero for a skipped CU) and into the scratch block that is dequantised; the skip
-// prediction where the CU is skipped; is_coef
+// per (CU, component): the winner's coefficients out (zero for a skipped CU); the skip prediction where the CU is skipped; and, by the luma block's threads,
+// core->s_next_best: the coder state the winning mode's evaluation left (SBAC_STORE(core->s_next_best, core->s_temp_best), :1888 / :1963 / :1997) -- the skip analysis and
+// both pinter_residue_rdo batches hand out core->s_temp_best per candidate, the winner's is copied (round 6: was the winner's syntax once more through the coder, three
+// launches and a CU's worth of bins at the end of every node's chain)
 __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hip_inter_result *__restrict__ res, const int16_t *__restrict__ coef_a,
-                            const int16_t *__restrict__ coef_b, int16_t *__restrict__ coef_out, int16_t *__restrict__ tmp, pel *__restrict__ pred_y,
+                            const int16_t *__restrict__ coef_b, int16_t *__restrict__ coef_out, pel *__restrict__ pred_y,
                             pel *__restrict__ pred_u, pel *__restrict__ pred_v, const pel *__restrict__ sk_y, const pel *__restrict__ sk_u, const pel *__restrict__ sk_v,
-                            unsigned char *__restrict__ is_coef)
+                            const xeve_hip_sbac *__restrict__ st_s, const xeve_hip_sbac *__restrict__ st_a, const xeve_hip_sbac *__restrict__ st_b,
+                            xeve_hip_sbac *__restrict__ next_best)
 {
     const int j = blockIdx.x / 3, k = blockIdx.x % 3, best = win[j];
+    if(k == 0 && res[j].cu_mode >= 0) {
+        const xeve_hip_sbac *src = best == M_SKIP ? st_s + j : best == M_BI ? st_b + j : st_a + (P.isb ? (size_t)(best == M_DIR ? 0 : best == M_L0 ? 1 : 2) * P.n + j : j);
+        const unsigned *a = (const unsigned *)src;
+        unsigned       *b = (unsigned *)(next_best + j);
+        for(int i = threadIdx.x; i < (int)(sizeof(xeve_hip_sbac) / 4); i += blockDim.x) b[i] = a[i];
+    }
     if(k && P.ncomp == 1) return;
     const int    nk = k ? P.n1 : P.n0;
     const size_t n = P.n;
@@ -341,33 +351,13 @@ __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hi
     const size_t   nn = best == M_BI ? n : (size_t)P.na;
     const int16_t *src = (best == M_BI ? coef_b : coef_a) + (k == 0 ? (size_t)slot * P.n0 : nn * P.n0 + (size_t)(k - 1) * nn * P.n1 + (size_t)slot * P.n1);
     int16_t       *dst = coef_out + (k == 0 ? (size_t)j * P.n0 : n * P.n0 + (size_t)(k - 1) * n * P.n1 + (size_t)j * P.n1);
-    int16_t       *t = tmp + (k == 0 ? (size_t)j * P.n0 : n * P.n0 + (size_t)(k - 1) * n * P.n1 + (size_t)j * P.n1);
     const bool     skip = best == M_SKIP;
-    for(int i = threadIdx.x; i < nk; i += blockDim.x) {
-        const int16_t v = skip ? (int16_t)0 : src[i];
-        dst[i] = v, t[i] = v;
-    }
+    for(int i = threadIdx.x; i < nk; i += blockDim.x) dst[i] = skip ? (int16_t)0 : src[i];
     if(skip) {
         const pel *s = (k == 0 ? sk_y : k == 1 ? sk_u : sk_v) + (size_t)j * nk;
         pel       *d = (k == 0 ? pred_y : k == 1 ? pred_u : pred_v) + (size_t)j * nk;
         for(int i = threadIdx.x; i < nk; i += blockDim.x) d[i] = s[i];
     }
-    if(threadIdx.x == 0) {
-        is_coef[(size_t)k * n + j] = res[j].nnz[k] != 0;
-    }
-}
-
-// core->s_next_best: the coder state the winning mode's evaluation left (SBAC_STORE(core->s_next_best, core->s_temp_best), :1888 / :1963 / :1997) -- the skip analysis and
-// both pinter_residue_rdo batches hand out core->s_temp_best per candidate, the winner's is copied (round 6: was the winner's syntax once more through the coder, three
-// launches and a CU's worth of bins at the end of every node's chain)
-__global__ void k_inter_states(InterK P, const xeve_hip_inter_result *__restrict__ res, const xeve_hip_sbac *__restrict__ st_s, const xeve_hip_sbac *__restrict__ st_a,
-                               const xeve_hip_sbac *__restrict__ st_b, xeve_hip_sbac *__restrict__ next_best)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.n || res[j].cu_mode < 0) return;
-    const int m = res[j].best_idx;
-    const xeve_hip_sbac *src = m == M_SKIP ? st_s + j : m == M_BI ? st_b + j : st_a + (P.isb ? (size_t)(m == M_DIR ? 0 : m == M_L0 ? 1 : 2) * P.n + j : j);
-    copy_sbac(next_best + j, src);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------
@@ -375,7 +365,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_s, st_a, st_b, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, tmp, is_coef, off[2],
+    size_t st, sj, sres, sk[3], st_s, st_a, st_b, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, wl, wc, wssd, wnnz,
         scratch, scratch_bytes, total;
 };
 
@@ -396,8 +386,8 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     L.rjb = take(N * sizeof(xeve_hip_rdo_job)), L.rrb = take(N * sizeof(xeve_hip_rdo_result)), L.coef_b = take(N * ne * 2);
     L.mc = take(N * sizeof(xeve_hip_cu_mc_job));
     L.pred[0] = take(N * n0 * 2), L.pred[1] = take(N * n1 * 2 + 8), L.pred[2] = take(N * n1 * 2 + 8);
-    L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.job_plane = take(MAXR * N), L.cnt = take(256), L.win = take(N * 4), L.tmp = take(N * ne * 2), L.is_coef = take(3 * N);
-    L.off[0] = take(N * 4), L.off[1] = take(N * 4);
+    L.org_bi = take(N * n0 * 2), L.extra = take(2 * MAXR * N * 4), L.job_plane = take(MAXR * N), L.cnt = take(256), L.win = take(N * 4);
+    L.wl = take(N * sizeof(xeve_hip_job)), L.wc = take(N * sizeof(xeve_hip_job)), L.wssd = take(N * 16), L.wnnz = take(N * 4);
     // the building blocks run one after the other on the stream: one scratch region, as large as the hungriest
     size_t s = xeve_hip_analyze_skip_workspace(n, &rp, p->max_cand);
     s = max2(s, xeve_hip_me_epzs_workspace(2 * (rp.num_refp[0] > rp.num_refp[1] ? rp.num_refp[0] : rp.num_refp[1]) * n));
@@ -441,14 +431,14 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     InterK P;
     P.n = njobs, P.isb = rp.slice_type == 0, P.lw = lw, P.n0 = w * w, P.n1 = idc ? P.n0 >> (ws + hs) : 0, P.ncomp = idc ? 3 : 1, P.bd = bd;
     P.max_cand = p->max_cand, P.nref[0] = rp.num_refp[0], P.nref[1] = P.isb ? rp.num_refp[1] : 0, P.nb = rp.num_refp[1], P.na = P.isb ? 3 * njobs : njobs, P.np = rp.num_refp[0] > P.nref[1] ? rp.num_refp[0] : P.nref[1];
-    P.s_org_l = s_org_l;
+    P.s_org_l = s_org_l, P.s_org_c = s_org_c, P.ws = ws, P.hs = hs;
     P.dpoc_co = refp[0 * 2 + 1].poc - p->col_list_poc0, P.dpoc_l0 = p->poc - refp[0 * 2 + 0].poc, P.dpoc_l1 = refp[0 * 2 + 1].poc - p->poc; // xeve_util.c:634-636
     P.thr = (double)((int64_t)1 << (2 * lw + 2 * (bd - 8))) * p->skip_th, P.lambda0 = rp.lambda[0];
     char *W = (char *)workspace;
     auto *st = (InterSt *)(W + L.st);
     auto *sj = (xeve_hip_skip_job *)(W + L.sj);
     auto *sres = (xeve_hip_skip_result *)(W + L.sres);
-    pel  *sk[3] = {(pel *)(W + L.sk[0]), (pel *)(W + L.sk[1]), (pel *)(W + L.sk[2])}, *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
+    pel  *sk[3] = {(pel *)(W + L.sk[0]), (pel *)(W + L.sk[1]), (pel *)(W + L.sk[2])}, *pred[3] = {pred_y ? pred_y : (pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])}; // (mi->pred_y_best, :2040: the winner's luma prediction is the last thing written there)
     auto *st_s = (xeve_hip_sbac *)(W + L.st_s), *st_a = (xeve_hip_sbac *)(W + L.st_a), *st_b = (xeve_hip_sbac *)(W + L.st_b);
     auto *ej = (xeve_hip_epzs_job *)(W + L.ej);
     auto *mres = (xeve_hip_me_result *)(W + L.mres);
@@ -456,9 +446,9 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *bitsm = (unsigned *)(W + L.bitsm);
     auto *rja = (xeve_hip_rdo_job *)(W + L.rja), *rjb = (xeve_hip_rdo_job *)(W + L.rjb);
     auto *rra = (xeve_hip_rdo_result *)(W + L.rra), *rrb = (xeve_hip_rdo_result *)(W + L.rrb);
-    auto *coef_a = (int16_t *)(W + L.coef_a), *coef_b = (int16_t *)(W + L.coef_b), *tmp = (int16_t *)(W + L.tmp), *org_bi = (int16_t *)(W + L.org_bi);
-    auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win), *off0 = (int32_t *)(W + L.off[0]), *off1 = (int32_t *)(W + L.off[1]);
-    auto *is_coef = (unsigned char *)(W + L.is_coef);
+    auto *coef_a = (int16_t *)(W + L.coef_a), *coef_b = (int16_t *)(W + L.coef_b), *org_bi = (int16_t *)(W + L.org_bi);
+    auto *extra = (int32_t *)(W + L.extra), *win = (int32_t *)(W + L.win);
+    auto *wl = (xeve_hip_job *)(W + L.wl), *wc = (xeve_hip_job *)(W + L.wc);
     auto *cnt = (int32_t *)(W + L.cnt);
     auto *job_plane = (unsigned char *)(W + L.job_plane);
     void *scr = W + L.scratch;
@@ -528,25 +518,23 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     CuMcPrep Cw;
     rc = xh_mc_cu_prep_params(refp, rp.num_refp[0], rp.num_refp[1], rp.pic_w, rp.pic_h, njobs, w, w, idc, scr, L.scratch_bytes, &Cw);
     if(rc != XEVE_HIP_OK) return rc;
-    k_inter_decide<<<G, 256, 0, s>>>(jobs, P, st, sres, rra, rrb, results, win, Cw, off0, off1);
+    k_inter_decide<<<G, 256, 0, s>>>(jobs, P, st, sres, rra, rrb, results, win, Cw, wl, wc);
     rc = xh_mc_cu_jobs_x(refp, rp.num_refp[0], rp.num_refp[1], s_l, s_c, rp.pic_w, rp.pic_h, nullptr, njobs, w, w, bd, bd, idc, coef_l, coef_c, pred[0], pred[1], pred[2],
                          scr, L.scratch_bytes, stream, XH_MC_PREPPED);
     if(rc != XEVE_HIP_OK) return rc;
-    k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, tmp, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], is_coef);
-    k_inter_states<<<G, 256, 0, s>>>(P, results, st_s, st_a, st_b, next_best); // core->s_next_best of the winners
+    k_inter_out<<<3 * njobs, 64, 0, s>>>(P, win, results, coef_a, coef_b, coef, pred[0], pred[1], pred[2], sk[0], sk[1], sk[2], st_s, st_a, st_b, next_best);
+    // the winner's reconstruction (xeve_itdq + xeve_recon, :2004-2032): the back half of the fused residual chain, one launch per component (round 6: was dequantisation,
+    // inverse transform and reconstruction as three); a component without coefficients comes out as its prediction
     static const int k_dq_scale[6] = {40, 45, 51, 57, 64, 71}; // xeve_tbl_dq_scale_b (xeve_tbl.c:237)
     pel *rec[3] = {rec_y, rec_u, rec_v};
     for(int k = 0; k < P.ncomp; k++) {
         const int lk = k ? lw - ws : lw, lhk = k ? lw - hs : lw, q = rp.qp[k];
-        XH_REQUIRE(q >= 0 && q <= 51 + 6 * (bd - 8)); // MAX_QUANT + the bit-depth offset
-        int16_t *t = tmp + (k == 0 ? 0 : (size_t)njobs * P.n0 + (size_t)(k - 1) * njobs * P.n1);
-        rc = xeve_hip_dquant(t, njobs, lk, lhk, k_dq_scale[q % 6] << (q / 6), bd, stream);
-        if(rc == XEVE_HIP_OK) rc = xeve_hip_itrans(t, njobs, lk, lhk, bd, stream);
-        if(rc == XEVE_HIP_OK)
-            rc = xeve_hip_recon(t, pred[k], is_coef + (size_t)k * njobs, njobs, 1 << lk, 1 << lhk, k ? off1 : off0, 1 << lk, rec[k], bd, stream);
+        XH_REQUIRE(q >= 0 && q <= 51 + 6 * (bd - 8) && lk == lhk); // MAX_QUANT + the bit-depth offset; square blocks (4:2:0, 4:4:4)
+        const int16_t *t = coef + (k == 0 ? 0 : (size_t)njobs * P.n0 + (size_t)(k - 1) * njobs * P.n1);
+        rc = xh_residual_back(org[k], k ? s_org_c : s_org_l, pred[k], 1 << lk, k ? wc : wl, njobs, lk, lhk, bd, q, k_dq_scale[q % 6] << (q / 6), t, rec[k], -(1 << lk),
+                              (int32_t *)(W + L.wnnz), (int64_t *)(W + L.wssd), s);
         if(rc != XEVE_HIP_OK) return rc;
     }
-    if(pred_y) XH_HIP(hipMemcpyAsync(pred_y, pred[0], (size_t)njobs * P.n0 * sizeof(pel), hipMemcpyDeviceToDevice, s)); // mi->pred_y_best (:2040)
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

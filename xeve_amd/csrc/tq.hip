@@ -693,6 +693,14 @@ extern "C" int xeve_hip_residual_rdo(const pel *org, int s_org, const pel *pred,
                            rec, s_rec, nnz, ssd, (hipStream_t)stream);
 }
 
+// the back half alone: dequantisation, inverse transform and reconstruction of the levels in `coef` (xeve_itdq + xeve_recon of a decided CU, xeve_pinter.c:2004-2032), one
+// launch per component instead of xeve_hip_dquant + xeve_hip_itrans + xeve_hip_recon; ssd: scratch of 2 * njobs entries (the kernel's by-product)
+int xh_residual_back(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h, int bit_depth, int qp, int dqscale,
+                     const int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st)
+{
+    return residual_launch(org, s_org, pred, s_pred, jobs, njobs, log2w, log2h, bit_depth, qp, 16384, dqscale, 0, 0, 2, const_cast<int16_t *>(coef), rec, s_rec, nnz, ssd, st);
+}
+
 // The chain as the presets actually run it (rdoq = 1, xeve_enc.c:2452,2469): front half (DIFF, SSD, DCT), then
 // xeve_quant_nnz's zero pre-test + xeve_rdoq_run_length_cc (rdoq.hip), then the back half (dequant, IDCT, recon, SSD).
 extern "C" int xeve_hip_residual_rdoq(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w,

@@ -35,6 +35,7 @@ struct Node { // one per (level, chain)
     double cost_best, cost_temp, unit_cost, cost_split;                                         // cost_split: a side node's split alternative (cost_temp is then the unsplit one's alone)
 };
 
+#define XT_STREAMS 5 // the caller's stream + one side stream per level 1 .. 4 (8x8 .. 64x64 nodes)
 struct TreeK {
     int    nchains, log2_ctu, pic_w, pic_h, w_scu, h_scu, max_cu, min_cu, min_cuwh, idc, ws, hs, slice_qp, slice_num, s_mod_l, s_mod_c;
     long   mod_pic_l, mod_pic_c, map_pic;
@@ -59,7 +60,8 @@ struct TreeK {
     // THE SIDE STREAM (round 6).  The analysis of a node that has children needs nothing its children produce and they need nothing of it -- both start from the node's
     // entry state and from neighbours outside the node (xeve_mode.c:2061-2262: s_curr_before_split; the maps inside the node are cleared for either) -- until op_exit
     // compares the two costs.  A call with a side stream runs the analyses of every such node there while the main stream walks on into the children: two launch
-    // chains side by side instead of one.  Every array an analysis reads or writes exists once per stream (ac[0] main, ac[1] side); side_of[L] says which a level uses.
+    // chains side by side instead of one -- and, every level of such nodes on a stream of its own (the 16x16 nodes' verdicts are needed after four 8x8 nodes, a 64x64
+    // node's only at the end of the CTU), up to four.  Every array an analysis reads or writes exists once per stream (ac[0] main); side_of[L] says which a level uses.
     struct Ac {
         xeve_hip_intra_job          *ijobs; // [5][nchains]: the job arrays per LEVEL -- the main stream enters the next side node while the side stream may still be reading an outer one's
         const xeve_hip_intra_result *ires;  // [nchains]
@@ -73,8 +75,8 @@ struct TreeK {
         const pel                   *erec[3]; // [nchains][block] per component
         const int32_t               *esatd;
         const SbacState             *enext;   // [nchains]: core->s_next_best of the inter analysis
-    } ac[2];
-    unsigned char side_of[8]; // per level L: 1 = the node's analyses run on the side stream (it has a CU of its size AND children), 0 = in line
+    } ac[XT_STREAMS];
+    unsigned char side_of[8]; // per level L: 0 = the node's analyses run in line, s > 0 = on side stream s (the node has a CU of its size AND children): a stream per level
     SbacState    *csplit;     // [5][nchains]: the state the FIRST child of a node starts from (the node's entry state + split_cu_flag = 1)
     CtuData      *tsplit;     // [5][nchains]: a side node's cu_data_temp of the split alternative (temp stays the staging block of its own analysis)
 };
@@ -535,7 +537,7 @@ struct TreeLayout {
     struct Ac {
         size_t sbest, ijobs, ires, icoef, irec, iws, iws_bytes;
         size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, ews, ews_bytes; // P / B slices
-    } ac[2]; // the arrays of the analyses, per stream (TreeK::Ac)
+    } ac[XT_STREAMS]; // the arrays of the analyses, per stream (TreeK::Ac)
     unsigned char side_of[8];
 };
 static bool tree_params_ok(const xeve_hip_tree_params *p)
@@ -602,31 +604,31 @@ static bool level_has_cu(const xeve_hip_tree_params *p, int log2) { return (1 <<
 static bool level_has_kids(const xeve_hip_tree_params *p, int log2) { return (1 << log2) > 4 && (1 << log2) > p->min_cu && (1 << log2) > p->min_cuwh; }
 // the side stream (TreeK): on unless switched off (XEVE_HIP_TREE_SIDE=0 / xeve_hip_walk_side(0): the one-stream walk of rounds 2-5, kept for A / B measurements and pinned by
 // the GPU suite beside the default)
-static std::atomic<int> g_tree_side{getenv("XEVE_HIP_TREE_SIDE") ? atoi(getenv("XEVE_HIP_TREE_SIDE")) != 0 : 1};
+static std::atomic<int> g_tree_side{getenv("XEVE_HIP_TREE_SIDE") ? std::min(2, std::max(0, atoi(getenv("XEVE_HIP_TREE_SIDE")))) : 1};
 extern "C" int xeve_hip_walk_side(int on)
 {
     const int before = g_tree_side.load();
-    if(on == 0 || on == 1) g_tree_side.store(on);
+    if(on >= 0 && on <= 2) g_tree_side.store(on);
     return before;
 }
 
-static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c, bool side)
+static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c, int side)
 {
     TreeLayout L;
     memset(&L, 0, sizeof(L));
     const size_t N = (size_t)nchains;
     const int    idc = p->ip.chroma_format_idc;
-    for(int log2 = 2; log2 <= p->log2_ctu; log2++) L.side_of[log2 - 2] = side && level_has_cu(p, log2) && level_has_kids(p, log2);
+    for(int log2 = 2; log2 <= p->log2_ctu; log2++) L.side_of[log2 - 2] = side && level_has_cu(p, log2) && level_has_kids(p, log2) ? (side == 2 ? 1 : log2 - 2) : 0; // (2: ONE side stream for every level, a measurement setting)
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
     L.zero_from = o;
     L.node = take(5 * N * sizeof(Node)), L.curr = take(5 * N * sizeof(SbacState)), L.next = take(5 * N * sizeof(SbacState)), L.before = take(5 * N * sizeof(SbacState));
     L.tdepth = take(5 * N * sizeof(SbacState)), L.csplit = take(5 * N * sizeof(SbacState)), L.best = take(5 * N * sizeof(CtuData)), L.temp = take(5 * N * sizeof(CtuData));
     L.tsplit = side ? take(5 * N * sizeof(CtuData)) : L.temp;
-    for(int a = 0; a < 2; a++) L.ac[a].sbest = take(N * sizeof(SbacState));
+    for(int a = 0; a < XT_STREAMS; a++) L.ac[a].sbest = take(N * sizeof(SbacState));
     L.zero32 = take(64);
     L.zero_bytes = o - L.zero_from;
-    for(int a = 0; a < 2; a++) { // every array of the analyses at the size of the largest CU its stream analyses (one stream: all of them in ac[0])
+    for(int a = 0; a < XT_STREAMS; a++) { // every array of the analyses at the size of the largest CU its stream analyses (one stream: all of them in ac[0])
         TreeLayout::Ac &A = L.ac[a];
         int top = 0;
         for(int log2 = 2; log2 <= p->log2_ctu; log2++)
@@ -658,7 +660,8 @@ static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const 
 // what a workspace must hold whichever way the call then runs (the side stream can be switched between the query and the call)
 static size_t tree_workspace(int nchains, const xeve_hip_tree_params *p, const xeve_hip_tree_inter *I, int s_org_l, int s_org_c)
 {
-    return std::max(tree_layout(nchains, p, I, s_org_l, s_org_c, false).total, tree_layout(nchains, p, I, s_org_l, s_org_c, true).total);
+    return std::max(std::max(tree_layout(nchains, p, I, s_org_l, s_org_c, 0).total, tree_layout(nchains, p, I, s_org_l, s_org_c, 1).total),
+                    tree_layout(nchains, p, I, s_org_l, s_org_c, 2).total);
 }
 
 // the fused walk (walk.hip): one launch per call
@@ -733,6 +736,7 @@ inline int ev_done(int L) { return 2 * L + 1; } // side stream: its unsplit alte
 struct Walk { // the static schedule of one CTU: every node of the full quad-tree in the reference's order; operations between two analyses fused
     const xeve_hip_tree_params *p;
     bool                        inter, side;
+    const unsigned char        *side_of = nullptr; // TreeLayout::side_of: the stream of a side node's level
     std::vector<Item>           items;
     std::vector<int>            pending; // side nodes entered whose analyses are not yet queued (innermost last)
     OpList                      cur;
@@ -755,7 +759,7 @@ struct Walk { // the static schedule of one CTU: every node of the full quad-tre
         for(; !pending.empty(); pending.pop_back()) {
             const int L = pending.back();
             Item it;
-            it.st = 1, it.ops.n = 0, it.kind = inter ? AN_INTER : AN_INTRA, it.size = L + 2, it.wait_ev = ev_enter(L), it.rec_ev = -1;
+            it.st = side_of[L], it.ops.n = 0, it.kind = inter ? AN_INTER : AN_INTRA, it.size = L + 2, it.wait_ev = ev_enter(L), it.rec_ev = -1;
             items.push_back(it);
             if(inter) {
                 it.ops.n = 1, it.ops.op[0] = OP_MID, it.ops.lvl[0] = (unsigned char)L, it.ops.part[0] = 0, it.kind = AN_INTRA, it.wait_ev = -1;
@@ -805,19 +809,21 @@ struct Walk { // the static schedule of one CTU: every node of the full quad-tre
 // the side stream and the events of the fork / join, per host thread (an encoder walks from one thread; the bench's batches have a thread each)
 struct TreeSide {
     uint32_t    gen = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st[XT_STREAMS] = {}; // [1 ..]: the side stream of level 1 ..
     hipEvent_t  ev[10] = {};
     void drop()
     {
-        if(st) (void)hipStreamSynchronize(st), (void)hipStreamDestroy(st), st = nullptr;
+        for(auto &q : st)
+            if(q) (void)hipStreamSynchronize(q), (void)hipStreamDestroy(q), q = nullptr;
         for(auto &e : ev)
             if(e) (void)hipEventDestroy(e), e = nullptr;
     }
     bool ready()
     {
         if(gen != xh_generation()) drop(), gen = xh_generation();
-        if(st) return true;
-        if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return false; }
+        if(st[1]) return true;
+        for(int a = 1; a < XT_STREAMS; a++)
+            if(hipStreamCreateWithFlags(&st[a], hipStreamNonBlocking) != hipSuccess) { st[a] = nullptr, drop(); return false; }
         for(auto &e : ev)
             if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { drop(); return false; }
         return true;
@@ -864,7 +870,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if(st) (void)hipStreamIsCapturing(st, &cap);
     static thread_local TreeSide side_res;
-    const bool side = g_tree_side.load(std::memory_order_relaxed) && !use_graph && cap == hipStreamCaptureStatusNone && side_res.ready();
+    const int side = !use_graph && cap == hipStreamCaptureStatusNone && side_res.ready() ? g_tree_side.load(std::memory_order_relaxed) : 0;
     const TreeLayout L = tree_layout(nchains, p, I, s_org_l, s_org_c, side);
     XH_REQUIRE(workspace_bytes >= L.total);
     char       *W = (char *)workspace;
@@ -882,7 +888,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     K.tsplit = (CtuData *)(W + L.tsplit);
     memcpy(K.side_of, L.side_of, sizeof(K.side_of));
     if(I) K.inter = 1, K.ecu_depth = I->ecu_depth, K.s_org_l = s_org_l, K.vh = vh, K.map_mv = (int16_t(*)[2][2])I->map_mv, K.map_refi = (int8_t(*)[2])I->map_refi;
-    for(int a = 0; a < 2; a++) {
+    for(int a = 0; a < XT_STREAMS; a++) {
         TreeK::Ac &A = K.ac[a];
         const TreeLayout::Ac &LA = L.ac[a];
         A.sbest = (SbacState *)(W + LA.sbest);
@@ -894,7 +900,7 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
         }
     }
     Walk wk;
-    wk.p = p, wk.inter = I != nullptr, wk.side = side, wk.cur.n = 0;
+    wk.p = p, wk.inter = I != nullptr, wk.side = side != 0, wk.side_of = L.side_of, wk.cur.n = 0;
     wk.node(p->log2_ctu - 2, -1);
     wk.add(OP_ROOT_DONE, p->log2_ctu - 2, 0);
     wk.flush(AN_NONE, 0);
@@ -908,7 +914,9 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
     XH_REQUIRE(xh_entropy_table() != nullptr);
     auto enqueue = [&]() -> int { // the whole walk: on `st`, and on the side stream between the events
         XH_HIP(hipMemsetAsync(W + L.zero_from, 0, L.zero_bytes, st)); // the walk's own state starts from zero (a node the picture cuts leaves its outside part untouched)
-        hipStream_t sts[2] = {st, side ? side_res.st : st};
+        hipStream_t sts[XT_STREAMS] = {st, st, st, st, st};
+        if(side)
+            for(int a = 1; a < XT_STREAMS; a++) sts[a] = side_res.st[a];
         bool recorded[10] = {};
         for(const Item &it : wk.items) {
             hipStream_t s = sts[it.st];

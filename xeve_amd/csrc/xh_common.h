@@ -151,6 +151,8 @@ __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(size_t o, int off2)
 }
 __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(long y, long stride, long x, int off2) { return xh_make_job((size_t)(y * stride + x), off2); }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
+int xh_residual_back(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h, int bit_depth, int qp, int dqscale,
+                     const int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st); // tq.hip
 // what the integer searches of pinter_me_epzs leave per job (me.hip) and the merge of the sub-pel stage's result into it (xeve_pinter.c:828-833, 690-692): with `finish`
 // the sub-pel stage's last selection kernel writes the search's final result itself
 struct EpzsState {
