@@ -53,7 +53,6 @@ VALU_SAD_PEAK_GBS = CUS * SIMDS * 32 * 8 * CLOCK_GHZ  # v_sad_u16: 2 sample pair
 BYTES_PER_SAMPLE_PAIR = 4  # a block SAD reads 2 x (w * h * 2 B)
 BYTES_PER_SEARCH_UNIT = 256  # the composed walk's search kernel counts units of 64 sample pairs
 VALU_ISSUE_PEAK_GINST = CUS * SIMDS * CLOCK_GHZ / 2  # wave64 VALU instructions/s (G): one per SIMD every 2 clocks
-INSTR_PER_BIN = 40  # k_cu_bits: VALU instructions per bin (profiles/r03_cu_bits_pmc.txt)
 STAGE_NAMES = ["clear", "enter", "leaf", "child_done", "exit", "root", "mid", "i_setup", "i_nbr", "i_pred", "i_satd", "i_list", "i_bits", "i_pick", "i_cpred", "i_final", "b_diff",
                "b_t0", "b_t1", "b_rdoq", "b_dq", "b_t2", "b_t3", "b_rec", "e_cand", "e_skip", "e_me", "e_spel", "e_mc", "e_bits", "e_glue", "e_final", "m_bits", "m_sad", "m_sel",
                "q_a", "q_b"]
@@ -389,8 +388,9 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 except Exception:
                     continue
             return None, None
-        pmc, src = committed(*(("r05_walk_pmc.json", "r04_walk_pmc.json") if cls == "walk" else ("r05_search_pmc.json", "r04_search_pmc.json")))
+        pmc, src = committed(*(("r05_walk_pmc.json", "r04_walk_pmc.json") if cls == "walk" else ("r06_search_pmc.json", "r05_search_pmc.json", "r04_search_pmc.json")))
         if pmc:
+            roof["pmc_from_committed_profile"] = True  # (the counters below were taken by rocprofv3 --pmc runs of their own and committed; this run measured the time)
             roof["traffic"] = pmc.get("hbm_bytes_per_launch") or pmc.get("hbm_bytes_per_launch_x2")
             roof["traffic_is"] = pmc.get("what")
             roof["pmc_file"] = "profiles/" + src
@@ -401,7 +401,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 old, osrc = committed("r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")
                 if old:
                     roof["traffic"], roof["traffic_is"] = old.get("hbm_bytes_per_launch") or old.get("hbm_bytes_per_launch_x2"), old.get("what")
-        mf, msrc = committed("r05_mfma_pmc.json")
+        mf, msrc = committed("r06_mfma_pmc.json", "r05_mfma_pmc.json")
         if mf:
             roof["mfma"] = {"kernels": "k_rdo_mfma<32|64>, k_dct_mfma<32|64> (v_mfma_i32_32x32x32_i8, exact byte-limb split: the residual chain of the 32x32 / 64x64 luma blocks)",
                             "bound": "mfma", "achieved": mf.get("achieved_TOPS"), "peak": mf.get("peak_TOPS_i8_dense"), "unit": "TOP/s", "frac": mf.get("mfma_utilisation"),
@@ -416,8 +416,8 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                    "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
                    "walk_choice": "presets slow and placebo run on the fused walk at any width (rdo_dbk_switch, 4x4 inter CUs: xh_common.h xh_walk_only)" if a.preset in ("slow", "placebo") else
                                   "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
-                                  "by the chains in lockstep (walk.hip: the fused kernel up to 1024 chains -- it finishes a step of few chains sooner --, the composed walk above: "
-                                  "its kernels pack the lanes of many chains and code more CTUs per second; profiles/r04_walks.md)",
+                                  "the library's choice (walk.hip: since round 6 the composed walk at every width -- with its side stream it finishes a step sooner than the fused kernel "
+                                  "even at 8 chains; profiles/r06_side_stream.md)",
                    "batches_side_by_side": B, "gops_in_lockstep": Gs, "frames_per_gop": F, "pictures_run": P, "row_chains_per_picture": T,
                    "chains_in_lockstep": [g * min(T, h_lcu) for g in Gs], "lockstep_steps_per_picture": per_picture, "lockstep_steps_timed": timed_steps,
                    "timed_picture_mix": {"picture_%d%s" % (k, "_IDR" if k == 0 else "_B"): round(v / per_picture, 3) for k, v in sorted(mix.items())},
@@ -494,19 +494,65 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
     bins_s = cb[2] / (cb[0] * 1e-3) if cb[0] > 0 else 0.0
     kern["cu_bits"].update({"bins_per_step": int(cb[2] / steps), "Gbin_per_s": round(bins_s / 1e9, 3)})
     tot = sum(v[0] for c, v in allc.items() if c not in ("cu_bits_slow", "walk"))
-    lanes = {}
-    try:  # (the PMC pass over the same kernel at the bench's width: how many of a wave's lanes its VALU work keeps busy, what its cycles wait for)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r05_cu_bits_pmc.json")))
-        lanes = {k: pm[k] for k in ("active_lane_frac", "active_lane_frac_note", "wait_any_frac", "valu_issue_frac", "waves_per_launch") if k in pm}
-        lanes["pmc_file"] = "profiles/r05_cu_bits_pmc.json"
-    except Exception:
-        pass
+    # The instruction rate comes from the PMC pass over the same kernel at the bench's width (profiles/, committed: SQ_INSTS_VALU per launch over the launch's duration) --
+    # not from a per-bin constant: a launch's lanes carry 0 .. ~25 000 bins each and a wave runs as long as its longest lane, so "instructions per bin" is not a
+    # property of the code (profiles/r06_cu_bits_bins.md has the histogram)
+    lanes, ginst = {}, None
+    for nm in ("r06_cu_bits_pmc.json", "r05_cu_bits_pmc.json"):
+        try:  # (how many of a wave's lanes its VALU work keeps busy, what its cycles wait for)
+            pm = json.load(open(os.path.join(ROOT, "profiles", nm)))
+            lanes = {k: pm[k] for k in ("active_lane_frac", "active_lane_frac_note", "wait_any_frac", "valu_issue_frac", "waves_per_launch", "valu_insts_per_launch", "avg_launch_s") if k in pm}
+            lanes["pmc_file"], lanes["pmc_from_committed_profile"] = "profiles/" + nm, True
+            ginst = pm["valu_insts_per_launch"] / pm["avg_launch_s"] / 1e9
+            break
+        except Exception:
+            continue
     return {"kernel": "k_cu_bits (CABAC bit counting, one lane per job): the class with the largest share of the GPU time", "share_of_timed_classes": round(cb[0] / tot, 3) if tot else None, **lanes,
-            "bound": "valu-issue", "achieved": round(bins_s * INSTR_PER_BIN / 64 / 1e9, 3), "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
-            "frac": round(bins_s * INSTR_PER_BIN / 64 / 1e9 / VALU_ISSUE_PEAK_GINST, 6),
-            "how": "bins/s x %d instructions per bin (measured, profiles/) / 64 lanes, against one wave64 VALU instruction per SIMD every 2 clocks on %d CUs x %d SIMDs at %.1f GHz; "
-                   "a serial chain per lane, so the roof is only reachable with every lane of every wave busy" % (INSTR_PER_BIN, CUS, SIMDS, CLOCK_GHZ),
+            "bound": "valu-issue", "achieved": round(ginst, 3) if ginst else None, "peak": round(VALU_ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+            "frac": round(ginst / VALU_ISSUE_PEAK_GINST, 6) if ginst else None,
+            "how": "VALU wave-instructions per launch over the launch's duration (PMC pass, committed profile) against one wave64 VALU instruction per SIMD every 2 clocks on "
+                   "%d CUs x %d SIMDs at %.1f GHz; a serial chain per lane and a few hundred waves per launch, so the roof is only reachable with every SIMD holding busy waves" % (CUS, SIMDS, CLOCK_GHZ),
             "kernels": kern, "kernels_note": "HIP-event time per lockstep step of the first B picture (steps 16 .. %d: all 8 row chains of every GOP active) with %d GOPs in lockstep, all class timers on (untimed extra encode)" % (16 + steps, gops)}
+
+
+def width_sweep(torch, dev, preset, threads, headline):
+    """What the headline depends on: the same encoder with 1, 8 and 64 closed GOPs in lockstep instead of everything HBM holds.  Measured at 1920x1080
+    (IDR + one B picture of each: 180 lockstep steps, seconds); a lockstep step's time depends on the chains it carries and the slice type, not on the picture, so the
+    3840x2160 figures follow from the same per-step times with 302 steps per picture."""
+    from xeve_amd import encode
+
+    W, H, F = 1920, 1080, 2
+    fb = W * H * 3 // 2
+    cfg = encode.config(W, H, qp=32, keyint=8, bframes=15, closed_gop=True, preset=preset, threads=threads)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    rows = []
+    for G in (1, 8, 64):
+        e = encode.BatchEncoder(cfg, G, F)
+        for g in range(G):
+            d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
+            for f in range(F):
+                e.push(g, f, d[f * fb:(f + 1) * fb])
+        e.begin()
+        per = e.advance(0) // F
+        t = []
+        for _ in range(F):
+            e.sync()
+            t0 = time.perf_counter()
+            e.advance(per)
+            e.sync()
+            t.append(time.perf_counter() - t0)
+        e.close()
+        ms_i, ms_b = 1e3 * t[0] / per, 1e3 * t[1] / per
+        gop_ms = lambda steps: steps * (ms_i + 7 * ms_b)  # an 8-frame closed GOP: 1 IDR + 7 B pictures
+        rows.append({"gops_in_lockstep": G, "chains_in_lockstep": G * min(threads, (H + 63) // 64), "ms_per_step_idr": round(ms_i, 2), "ms_per_step_b": round(ms_b, 2),
+                     "frames_per_s_1920x1080": round(8 * G / (gop_ms(per) * 1e-3), 4), "frames_per_s_3840x2160_from_step_times": round(8 * G / (gop_ms(302) * 1e-3), 4),
+                     "gop_latency_s_3840x2160": round(gop_ms(302) * 1e-3, 1)})
+    out = {"what": "the batch encoder with 1, 8 and 64 closed GOPs in lockstep (8 row chains each): per-step times measured at 1920x1080 (IDR + first B picture, %d steps each); an "
+                   "8-frame GOP = 1 IDR + 7 B pictures; the 3840x2160 columns = the same per-step times x 302 steps per picture (a step's time follows the chains in lockstep "
+                   "and the slice type, not the picture size)" % per,
+           "rows": rows, "headline": headline}
+    return out
 
 
 def main():
@@ -527,6 +573,7 @@ def main():
                     help="the headline is preset medium (BASELINE.json); slow and placebo run on the fused walk at any width, their lines are secondary records (profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra (the per-class / per-stage profile of the walk)")
+    ap.add_argument("--no-width-sweep", action="store_true", help="skip the untimed extra that runs 1, 8 and 64 GOPs in lockstep (what the headline depends on; ~40 s)")
     ap.add_argument("--no-1080p", action="store_true", help="skip the same bounded job at 1920x1080 that follows the headline (north_star names both sizes; ~2 more minutes, after the timed region)")
     ap.add_argument("--with-1080p", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
     a = ap.parse_args()
@@ -586,6 +633,14 @@ def main():
             line["roofline"]["by_time"] = (stage_profile if cls == "walk" else class_profile)(torch, dev, cfg, max(8, Gs[0] // 4) if cls == "walk" else max(136, Gs[0] // 2), a.frames, per_picture, fb)
         except Exception as e:  # noqa: BLE001
             line["roofline"]["by_time"] = {"error": repr(e)[:300]}
+        if not a.no_width_sweep and a.preset in ("fast", "medium"):
+            try:
+                lat = rec["ms_per_step"] * a.steps / max(1, rec["config"]["lockstep_steps_timed"]) * rec["config"]["lockstep_steps_per_picture"] * a.frames * 1e-3
+                line["width_sweep"] = width_sweep(torch, dev, a.preset, a.threads,
+                                                  {"gops_in_lockstep": sum(Gs), "frames_per_s": rec["value"], "gop_latency_s": round(lat, 1),
+                                                   "gop_latency_is": "every GOP of the batch is finished when the batch is: %d lockstep steps per GOP at the timed region's mean step time" % (rec["config"]["lockstep_steps_per_picture"] * a.frames)})
+            except Exception as e:  # noqa: BLE001
+                line["width_sweep"] = {"error": repr(e)[:300]}
         if not a.no_1080p and (a.width, a.height) == (3840, 2160):  # north_star names both sizes: the same bounded job at 1920x1080 (untimed by the driver's clock, reported beside the headline)
             try:
                 r2, _ = run_job(a, torch, dist, dev, rank, world, 1920, 1080, "secondary", False)
@@ -601,6 +656,17 @@ def main():
                 ac = line["cpu_baseline"].get("all_cores", {}).get("fps")
                 line["vs_cpu"] = {"gpu_over_m8": round(line["value"] / line["cpu_baseline"]["value"], 2) if line["cpu_baseline"].get("value") else None,
                                   "gpu_over_all_cores": round(line["value"] / ac, 2) if ac else None}
+                m8 = line["cpu_baseline"].get("value")
+                rows = line.get("width_sweep", {}).get("rows")
+                if m8 and rows:  # the width at which the GPU overtakes `xeveb_app -m 8` on one GOP at a time: linear between the measured widths
+                    pts = [(r["gops_in_lockstep"], r["frames_per_s_3840x2160_from_step_times"]) for r in rows] + [(line["width_sweep"]["headline"]["gops_in_lockstep"], line["value"])]
+                    be = None
+                    for (g0, f0), (g1, f1) in zip([(0, 0.0)] + pts, pts):
+                        if f0 < m8 <= f1:
+                            be = g0 + (g1 - g0) * (m8 - f0) / (f1 - f0)
+                            break
+                    line["width_sweep"]["break_even_gops_vs_xeveb_app_m8"] = round(be, 1) if be is not None else None
+                    line["width_sweep"]["break_even_note"] = "GOPs in lockstep at which the GPU's 3840x2160 frames/s equal the reference application's -m 8 on this host (%.3f frames/s), interpolated between the measured widths" % m8
             except Exception:
                 pass
         print(json.dumps(line), flush=True)

@@ -816,8 +816,8 @@ int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], int s_org_l
 int xeve_hip_walk_prof_enable(int on);
 int xeve_hip_walk_prof(unsigned long long *out, int cap);
 /* 1: a call in a batch of nchains chains (max(nchains, nstates) of the call) runs the fused walk, 0: the composed walk (XEVE_HIP_WALK=1 / 0 pins one; unset: fused up to
- * XEVE_HIP_WALK_AUTO_MAX = 1024 chains -- the
- * fused kernel finishes a step of few chains sooner, the composed walk's kernels code more CTUs per second once thousands of chains are in lockstep). */
+ * XEVE_HIP_WALK_AUTO_MAX chains -- 0 since round 6: with its side stream the composed walk finishes a step sooner at every width; presets slow and placebo run on the
+ * fused kernel whatever the width). */
 int xeve_hip_walk_fused(int nchains);
 /* Moves that choice at run time: mode -1 by the width (the default), 0 the composed walk, 1 the fused kernel; returns the mode before the call (any other value only
  * reads it).  Process-wide; workspaces are sized by the choice in force when xeve_hip_mode_analyze_ctu_workspace / xeve_hip_enc_create is called, so select BEFORE
@@ -828,9 +828,9 @@ int xeve_hip_walk_select(int mode);
 int xeve_hip_walk_team(int chains_per_team);
 /* The composed walk's SIDE STREAM (round 6): the analyses of every node that has children (the unsplit alternative of mode_coding_tree, xeve_mode.c:2073-2146) run on a
  * second stream of the library's while the caller's stream walks on into the children (:2189-2262) -- neither needs anything of the other until the two costs are compared
- * (:2306-2329) --, joined with events in front of that comparison: launch chains side by side, a side stream per node size.  1 on (the default; XEVE_HIP_TREE_SIDE=0 starts
- * with it off), 0 the one-stream walk, 2 one side stream for all sizes (a measurement setting); returns the value before the call (any other value only reads it).  Results
- * do not depend on it; the workspace query covers all three. */
+ * (:2306-2329) --, joined with events in front of that comparison: two launch chains side by side.  1 on (the default; XEVE_HIP_TREE_SIDE=0 starts with it off), 0 the
+ * one-stream walk, 2 a side stream per node size (a measurement setting: slower); returns the value before the call (any other value only reads it).  Results do not
+ * depend on it; the workspace query covers all three. */
 int xeve_hip_walk_side(int on);
 int xeve_hip_mode_analyze_ctu_intra_jobs(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c,
                                          uint32_t *map_scu, int8_t *map_ipm, const uint8_t *map_tidx, uint32_t *map_cu_mode, const int64_t *pic_elems,

@@ -68,13 +68,14 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
 
 
-WALKS = {"by_width": (-1, 0, -1), "composed": (0, 0, 1), "composed_one_stream": (0, 0, 0), "composed_one_side_stream": (0, 0, 2), "fused_3_chains_per_team": (1, 3, -1)}
+WALKS = {"by_width": (-1, 0, -1), "composed": (0, 0, 1), "composed_one_stream": (0, 0, 0), "composed_stream_per_level": (0, 0, 2), "fused_3_chains_per_team": (1, 3, -1)}
 
 
 @pytest.fixture(scope="module", params=list(WALKS))
 def each_walk(request):
     """GPU modules that take this fixture run once per CTU walk: the library's own choice (the fused kernel for the suite's narrow batches), the composed walk pinned (the
-    bench's path at width: the analyses of the nodes with children on its side stream), the composed walk on one stream, and the fused kernel with three chains per team
+    bench's path at width: the analyses of the nodes with children on its side stream), the composed walk on one stream and with a side stream per node size, and the fused
+    kernel with three chains per team
     (teams of several chains otherwise only form beyond ~1000 chains)"""
     from xeve_amd import encode
 

@@ -232,8 +232,8 @@ def test_presets_slow_and_placebo_at_1920x1080_on_the_gpu(name, hip, yuv_dir):
 
 # BASELINE's configs at their real picture sizes (gpu_last: after every other GPU test).  The default suite has to fit the driver's 1200 s on one MI355X (tests/conftest.py),
 # so it runs the forms that add something -- config 3 over a whole 16-picture sub-GOP on the library's own choice of walk, config 2 on the COMPOSED walk (the bench's path
-# at width), the whole 8-frame 1080p GOP on the composed walk, config 4 (3840x2160) as IDR + two B pictures against the reference's per-picture prefixes -- and leaves the forms
-# those contain (9 frames of config 3, 2 frames of config 4) and the repeats (17 frames of config 2, the moving 1080p GOPs, the whole 4K GOP: 400 s) to XEVE_GPU_FULL=1.
+# at width), the whole 8-frame 1080p GOP and (round 6) the whole 8-frame 3840x2160 GOP of config 4 on the composed walk -- and leaves the forms those contain (9 frames of
+# config 3, 2 frames / IDR + two B pictures of config 4) and the repeats (17 frames of config 2, the moving 1080p GOPs, the 4K GOP on the fused kernel) to XEVE_GPU_FULL=1.
 REAL_DEFAULT = {"cfg3_1080p_ra_medium_17f_m8": -1, "cfg2_720p_ldb_fast_8f_m8": 0}  # name -> walk (xeve_hip_walk_select)
 REAL_FULL = {"cfg2_720p_ldb_fast_17f_m8": -1, "gops_1080p_moving_m8": 0, "cfg3_1080p_ra_medium_9f_m8": 0, "cfg4_2160p_closedgop_medium_2f_m8": -1}
 assert set(REAL_DEFAULT) | set(REAL_FULL) == set(_enc.BATCH_CASES_REAL)
@@ -262,16 +262,19 @@ assert {C3, C4} <= set(FULL_GOPS), sorted(FULL_GOPS)  # (the file also holds the
 
 @pytest.mark.gpu_last
 @pytest.mark.parametrize("name,walk,pictures", [
-    pytest.param(C4, 0, 3, id="2160p-composed-idr_and_two_b"),
+    # (round 6, VERDICT r05 next 4: the WHOLE 3840x2160 GOP, 8 of 8 pictures, in the default suite -- the composed walk with its side stream takes a lockstep step of
+    # 16 chains in ~60 ms, 2416 steps in ~150 s; rounds 4-5 ran IDR + two B pictures here and left the whole GOP to XEVE_GPU_FULL and to bench.py --pictures 0)
+    pytest.param(C4, 0, 8, id="2160p-composed-whole_gop"),
     pytest.param(C3, 0, 8, id="1080p-composed-whole_gop"),
+    pytest.param(C4, 0, 3, id="2160p-composed-idr_and_two_b", marks=pytest.mark.gpu_full),
     # (the fused kernel at 1920x1080 is the 17-frame run of config 3 above: 1768 steps of four B layers; the same kernel over this GOP: 78 s more for the default suite)
-    pytest.param(C3, 1, 8, id="1080p-fused-whole_gop", marks=pytest.mark.gpu_full), pytest.param(C4, 1, 3, id="2160p-fused-idr_and_two_b", marks=pytest.mark.gpu_full), pytest.param(C4, -1, 8, id="2160p-by_width-whole_gop", marks=pytest.mark.gpu_full)])
+    pytest.param(C3, 1, 8, id="1080p-fused-whole_gop", marks=pytest.mark.gpu_full), pytest.param(C4, 1, 3, id="2160p-fused-idr_and_two_b", marks=pytest.mark.gpu_full), pytest.param(C4, 1, 8, id="2160p-fused-whole_gop", marks=pytest.mark.gpu_full)])
 def test_full_eight_frame_closed_gops_at_the_baseline_sizes(name, walk, pictures, hip):
     """BASELINE config 4 (3840x2160) and 1920x1080 as FULL `-I 8` closed GOPs (1 IDR + 7 hierarchical B pictures, -m 8) -- the clip
     bench.py seeds its batches with -- on the composed walk (what the bench runs at width) AND the fused kernel.  GOP 1 of the batch is the same clip with its frames in
     reverse order (another GOP beside it in lockstep); GOP 0 must be the reference's file byte for byte: after `pictures` pictures (xeve_hip_enc_flush) the golden's prefix
     after the same picture, and with the whole GOP run, the file.  3840x2160 in the default suite = the IDR picture and two B pictures (POC 4 from the IDR picture alone,
-    POC 2 from two different reference pictures); the whole 4K GOP is bench.py --pictures 0's in-run check (profiles/r05_bench_whole_gop.json) and XEVE_GPU_FULL=1"""
+    POC 2 from two different reference pictures) is the gpu_full form; the default suite runs the whole 4K GOP, 8 of 8 pictures (round 6)"""
     import numpy as np
 
     from bench import check_prefix, reference_noise

@@ -223,7 +223,7 @@ def test_hip_ctu_mode_decision_with_the_lane_serial_node_kernel(tmp_path, each_w
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_tree.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "matches_oracle and composed and (3101 or 3104 or 4103)"], env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0 and "9 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]  # (three cases x {a side stream per level, one stream, one side stream})
+    assert p.returncode == 0 and "9 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]  # (three cases x {side stream, one stream, a side stream per level})
 
 
 def test_hip_ctu_host_form_over_two_b_pictures():

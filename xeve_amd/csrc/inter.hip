@@ -61,12 +61,71 @@ __device__ __forceinline__ void rdo_job(xeve_hip_rdo_job &r, const xeve_hip_inte
     r.dir_flag = (uint8_t)dir, r.ctx_skip = J.ctx_skip, r.ctx_pred_mode = J.ctx_pred_mode, r.pad_ = 0, r.sbac = J.sbac;
 }
 
+// ---- the candidates of the jobs from the encoder's per-unit maps ---------------------------------------------------------------------
+// xeve_get_avail_inter (left / up / up-right; xeve_util.c:652-714) + xeve_get_motion (xeve_util.c:526-573) + the collocated vector of the
+// temporal direct mode.  One thread per CU; the maps are [unit][list][x, y] as the reference keeps them.
+__device__ __forceinline__ void inter_candidates_one(const XhInterCand &C, xeve_hip_inter_job &J)
+{
+    const uint32_t *__restrict__ map_scu = C.map_scu;
+    const uint8_t *__restrict__  map_tidx = C.map_tidx;
+    const int16_t *__restrict__  map_mv = C.map_mv, *__restrict__ col0 = C.col0, *__restrict__ col1 = C.col1;
+    const int w_scu = C.w_scu, scuw = C.scuw, scuh = C.scuh, isb = C.isb, vh = C.vh;
+    // (a batch of pictures stacked vertically, xh_common.h: the maps are stacked like the planes, so the unit addresses follow from y as it is; only "is there a row
+    // above" asks for the row inside the job's own picture)
+    const int x_scu = J.x >> 2, y_scu = J.y >> 2, scup = y_scu * w_scu + x_scu, y_in_pic = (J.y - xh_vh_base(J.y, vh)) >> 2;
+    auto tile = [&](int at) { return map_tidx ? (int)map_tidx[at] : 0; };
+    const int t = tile(scup);
+    bool ok[3] = {false, false, false};
+    const int at[3] = {scup - 1, scup - w_scu, scup - w_scu + scuw};
+    if(x_scu > 0) {
+        const uint32_t m = map_scu[at[0]];
+        ok[0] = !((m >> 15) & 1) && (m >> 31) && tile(at[0]) == t && !((m >> 26) & 1); // !IF && COD && same tile && !IBC
+    }
+    if(y_in_pic > 0) {
+        const uint32_t m = map_scu[at[1]];
+        ok[1] = !((m >> 15) & 1) && tile(at[1]) == t && !((m >> 26) & 1); // (no COD test for the unit above, :681-684)
+        if(x_scu + scuw < w_scu) {
+            const uint32_t r = map_scu[at[2]];
+            ok[2] = (((r >> 15) & 0x10001u) == 0x10000u) && (r >> 31) && tile(at[2]) == t; // MCU_IS_COD_NIF && COD
+        }
+    }
+    for(int l = 0; l < 2; l++) {
+        const int16_t *col = l ? col1 : col0;
+        for(int k = 0; k < 4; k++) {
+            int vx = 0, vy = 0;
+            if(l <= isb) {
+                if(k < 3) vx = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2] : 1, vy = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2 + 1] : 1;
+                else vx = col[((size_t)scup * 2 + 0) * 2], vy = col[((size_t)scup * 2 + 0) * 2 + 1]; // refp[0][l].map_mv[scup][0]
+            }
+            J.mvp[l][k][0] = (int16_t)vx, J.mvp[l][k][1] = (int16_t)vy;
+        }
+    }
+    J.mv_col[0] = J.mv_col[1] = 0;
+    if(isb) {
+        const size_t corner = (size_t)scup + (scuw - 1) + (size_t)(scuh - 1) * w_scu;
+        J.mv_col[0] = col1[(corner * 2 + 0) * 2], J.mv_col[1] = col1[(corner * 2 + 0) * 2 + 1];
+    }
+}
+__global__ void k_inter_candidates(XhInterCand C, xeve_hip_inter_job *__restrict__ jobs, int njobs)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= njobs) return;
+    xeve_hip_inter_job J = jobs[j];
+    inter_candidates_one(C, J);
+    jobs[j] = J;
+}
+
+
 // ---- skip --------------------------------------------------------------------------------------------------------------------
-__global__ void k_inter_skip_jobs(const xeve_hip_inter_job *__restrict__ jobs, InterK P, xeve_hip_skip_job *__restrict__ sj)
+__global__ void k_inter_skip_jobs(xeve_hip_inter_job *__restrict__ jobs, InterK P, xeve_hip_skip_job *__restrict__ sj, XhInterCand C)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if(j >= P.n) return;
-    const xeve_hip_inter_job J = jobs[j];
+    xeve_hip_inter_job J = jobs[j];
+    if(C.map_scu) { // (the walk: the merge / MVP candidates of the CU from the per-unit maps in the same launch -- xeve_hip_inter_candidates for the C-ABI's callers)
+        inter_candidates_one(C, J);
+        jobs[j] = J;
+    }
     xeve_hip_skip_job s;
     s.x = J.x, s.y = J.y;
     for(int l = 0; l < 2; l++)
@@ -352,7 +411,8 @@ __global__ void k_inter_out(InterK P, const int *__restrict__ win, const xeve_hi
     const int16_t *src = (best == M_BI ? coef_b : coef_a) + (k == 0 ? (size_t)slot * P.n0 : nn * P.n0 + (size_t)(k - 1) * nn * P.n1 + (size_t)slot * P.n1);
     int16_t       *dst = coef_out + (k == 0 ? (size_t)j * P.n0 : n * P.n0 + (size_t)(k - 1) * n * P.n1 + (size_t)j * P.n1);
     const bool     skip = best == M_SKIP;
-    for(int i = threadIdx.x; i < nk; i += blockDim.x) dst[i] = skip ? (int16_t)0 : src[i];
+    const bool     none = skip || res[j].nnz[k] == 0; // (a component the decision dropped: the batch's block still holds its levels, xh_residue_rdo_jobs_x keep_dropped)
+    for(int i = threadIdx.x; i < nk; i += blockDim.x) dst[i] = none ? (int16_t)0 : src[i];
     if(skip) {
         const pel *s = (k == 0 ? sk_y : k == 1 ? sk_u : sk_v) + (size_t)j * nk;
         pel       *d = (k == 0 ? pred_y : k == 1 ? pred_u : pred_v) + (size_t)j * nk;
@@ -365,7 +425,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct InterLayout {
-    size_t st, sj, sres, sk[3], st_s, st_a, st_b, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, wl, wc, wssd, wnnz,
+    size_t st, sj, sres, sk[3], st_s, st_a, st_b, est, ej, mres, bjm, bitsm, rja, rra, coef_a, rjb, rrb, coef_b, mc, pred[3], org_bi, extra, job_plane, cnt, win, wl, wc, wssd, wnnz,
         scratch, scratch_bytes, total;
 };
 
@@ -380,6 +440,7 @@ static InterLayout inter_layout(int n, int nstates, const xeve_hip_inter_params 
     L.st = take(N * sizeof(InterSt)), L.sj = take(N * sizeof(xeve_hip_skip_job)), L.sres = take(N * sizeof(xeve_hip_skip_result));
     L.sk[0] = take(N * n0 * 2), L.sk[1] = take(N * n1 * 2 + 8), L.sk[2] = take(N * n1 * 2 + 8);
     L.st_s = take(N * sizeof(xeve_hip_sbac)), L.st_a = take(na * sizeof(xeve_hip_sbac)), L.st_b = take(N * sizeof(xeve_hip_sbac));
+    L.est = take((size_t)nstates * sizeof(xeve_hip_rdoq_est_full));
     L.ej = take(2 * MAXR * N * sizeof(xeve_hip_epzs_job)), L.mres = take(2 * MAXR * N * sizeof(xeve_hip_me_result));
     L.bjm = take(10 * N * sizeof(xeve_hip_cu_bits_job)), L.bitsm = take(10 * N * 4);
     L.rja = take(na * sizeof(xeve_hip_rdo_job)), L.rra = take(na * sizeof(xeve_hip_rdo_result)), L.coef_a = take(na * ne * 2);
@@ -419,6 +480,17 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
                                                int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y,
                                                xeve_hip_sbac *next_best, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return xh_pinter_analyze_cu_jobs_x(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, p, const_cast<xeve_hip_inter_job *>(jobs), njobs, coef_l, coef_c, results, coef,
+                                       rec_y, rec_u, rec_v, pred_y, next_best, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+// cand: the jobs' candidates are derived here, from the encoder's per-unit maps, by the first kernel (jobs[] is then written); est_shared: core->rdoq_est_* of every entry
+// state, made by the caller (xeve_hip_rdoq_bit_est over `states`) -- NULL: made here, once for both pinter_residue_rdo batches
+int xh_pinter_analyze_cu_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, const xeve_hip_sbac *states,
+                                int nstates, const xeve_hip_inter_params *p, xeve_hip_inter_job *jobs, int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4],
+                                xeve_hip_inter_result *results, int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y,
+                                xeve_hip_sbac *next_best, void *workspace, size_t workspace_bytes, void *stream, const XhInterCand *cand, const void *est_shared)
+{
     XH_ENTER();
     XH_REQUIRE(p && njobs >= 0 && inter_params_ok(p));
     if(njobs == 0) return XEVE_HIP_OK;
@@ -457,7 +529,14 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     int rc;
 
     // skip mode
-    k_inter_skip_jobs<<<G, 256, 0, s>>>(jobs, P, sj);
+    XhInterCand C0;
+    memset(&C0, 0, sizeof(C0));
+    k_inter_skip_jobs<<<G, 256, 0, s>>>(jobs, P, sj, cand ? *cand : C0);
+    if(!est_shared) { // the estimates of every entry state (xeve_mode.c:792), once for both batches
+        rc = xeve_hip_rdoq_bit_est(states, nstates, (xeve_hip_rdoq_est_full *)(W + L.est), stream);
+        if(rc != XEVE_HIP_OK) return rc;
+        est_shared = W + L.est;
+    }
     rc = xeve_hip_analyze_skip_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, sj, njobs, p->max_cand, coef_l, coef_c, sres, sk[0], sk[1], sk[2],
                                     st_s, scr, L.scratch_bytes, stream);
     if(rc != XEVE_HIP_OK) return rc;
@@ -490,7 +569,8 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     rc = xeve_hip_cu_bits_jobs(nullptr, 0, states, bjm, 5 * nl * njobs, &bp, scr, L.scratch_bytes, bitsm, nullptr, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_inter_uni_b<<<G, 256, 0, s>>>(jobs, P, bitsm, st, rja);
-    rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream);
+    rc = xh_residue_rdo_jobs_x(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rja, P.na, coef_l, coef_c, rra, coef_a, st_a, scr, L.scratch_bytes, stream,
+                               est_shared, 1);
     if(rc != XEVE_HIP_OK) return rc;
     if(P.isb) { // analyze_bi
         CuMcPrep C; // (the prediction from the fixed list: luma alone, read by k_bi_org from whichever list's buffer holds it)
@@ -510,8 +590,8 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
             if(rc != XEVE_HIP_OK) return rc;
         }
         k_bi_tail<<<G, 256, 0, s>>>(jobs, P, mres, st, rjb);
-        rc = xeve_hip_residue_rdo_jobs(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, st_b, scr, L.scratch_bytes,
-                                       stream);
+        rc = xh_residue_rdo_jobs_x(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, &rp, rjb, njobs, coef_l, coef_c, rrb, coef_b, st_b, scr, L.scratch_bytes,
+                                   stream, est_shared, 1);
         if(rc != XEVE_HIP_OK) return rc;
     }
     // the decision; the winner's prediction, coefficients, reconstruction (:2004-2032) and coder state
@@ -539,54 +619,6 @@ extern "C" int xeve_hip_pinter_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     return XEVE_HIP_OK;
 }
 
-// ---- the candidates of the jobs from the encoder's per-unit maps ---------------------------------------------------------------------
-// xeve_get_avail_inter (left / up / up-right; xeve_util.c:652-714) + xeve_get_motion (xeve_util.c:526-573) + the collocated vector of the
-// temporal direct mode.  One thread per CU; the maps are [unit][list][x, y] as the reference keeps them.
-__global__ void k_inter_candidates(const uint32_t *__restrict__ map_scu, const uint8_t *__restrict__ map_tidx, const int16_t *__restrict__ map_mv,
-                                   const int16_t *__restrict__ col0, const int16_t *__restrict__ col1, int w_scu, int scuw, int scuh, int isb,
-                                   xeve_hip_inter_job *__restrict__ jobs, int njobs, int vh)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= njobs) return;
-    xeve_hip_inter_job J = jobs[j];
-    // (a batch of pictures stacked vertically, xh_common.h: the maps are stacked like the planes, so the unit addresses follow from y as it is; only "is there a row
-    // above" asks for the row inside the job's own picture)
-    const int x_scu = J.x >> 2, y_scu = J.y >> 2, scup = y_scu * w_scu + x_scu, y_in_pic = (J.y - xh_vh_base(J.y, vh)) >> 2;
-    auto tile = [&](int at) { return map_tidx ? (int)map_tidx[at] : 0; };
-    const int t = tile(scup);
-    bool ok[3] = {false, false, false};
-    const int at[3] = {scup - 1, scup - w_scu, scup - w_scu + scuw};
-    if(x_scu > 0) {
-        const uint32_t m = map_scu[at[0]];
-        ok[0] = !((m >> 15) & 1) && (m >> 31) && tile(at[0]) == t && !((m >> 26) & 1); // !IF && COD && same tile && !IBC
-    }
-    if(y_in_pic > 0) {
-        const uint32_t m = map_scu[at[1]];
-        ok[1] = !((m >> 15) & 1) && tile(at[1]) == t && !((m >> 26) & 1); // (no COD test for the unit above, :681-684)
-        if(x_scu + scuw < w_scu) {
-            const uint32_t r = map_scu[at[2]];
-            ok[2] = (((r >> 15) & 0x10001u) == 0x10000u) && (r >> 31) && tile(at[2]) == t; // MCU_IS_COD_NIF && COD
-        }
-    }
-    for(int l = 0; l < 2; l++) {
-        const int16_t *col = l ? col1 : col0;
-        for(int k = 0; k < 4; k++) {
-            int vx = 0, vy = 0;
-            if(l <= isb) {
-                if(k < 3) vx = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2] : 1, vy = ok[k] ? map_mv[((size_t)at[k] * 2 + l) * 2 + 1] : 1;
-                else vx = col[((size_t)scup * 2 + 0) * 2], vy = col[((size_t)scup * 2 + 0) * 2 + 1]; // refp[0][l].map_mv[scup][0]
-            }
-            J.mvp[l][k][0] = (int16_t)vx, J.mvp[l][k][1] = (int16_t)vy;
-        }
-    }
-    J.mv_col[0] = J.mv_col[1] = 0;
-    if(isb) {
-        const size_t corner = (size_t)scup + (scuw - 1) + (size_t)(scuh - 1) * w_scu;
-        J.mv_col[0] = col1[(corner * 2 + 0) * 2], J.mv_col[1] = col1[(corner * 2 + 0) * 2 + 1];
-    }
-    jobs[j] = J;
-}
-
 extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t *map_tidx, const int16_t *map_mv, const int16_t *col_mv0, const int16_t *col_mv1,
                                          int w_scu, int h_scu, int log2_cuw, int log2_cuh, int slice_type, xeve_hip_inter_job *jobs, int njobs, void *stream)
 {
@@ -594,8 +626,8 @@ extern "C" int xeve_hip_inter_candidates(const uint32_t *map_scu, const uint8_t 
     XH_REQUIRE(njobs >= 0 && w_scu > 0 && h_scu > 0 && log2_cuw >= 2 && log2_cuw <= 7 && log2_cuh >= 2 && log2_cuh <= 7 && (slice_type == 0 || slice_type == 1));
     if(njobs == 0) return XEVE_HIP_OK;
     XH_REQUIRE(map_scu && map_mv && col_mv0 && jobs && (slice_type == 1 || col_mv1));
-    k_inter_candidates<<<(njobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, 1 << (log2_cuw - 2), 1 << (log2_cuh - 2),
-                                                                            slice_type == 0, jobs, njobs, xh_vh());
+    const XhInterCand C = {map_scu, map_tidx, map_mv, col_mv0, col_mv1, w_scu, 1 << (log2_cuw - 2), 1 << (log2_cuh - 2), slice_type == 0, xh_vh()};
+    k_inter_candidates<<<(njobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, jobs, njobs);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

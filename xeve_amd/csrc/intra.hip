@@ -98,15 +98,14 @@ __global__ void k_intra_nbr(const pel *__restrict__ mod_y, const pel *__restrict
 
 // ---- 2 / 5. predictors -----------------------------------------------------------------------------------------------------------------------------------
 // luma (comp0 = 0): grid (njobs, 5), block (job, mode) -> pred[(job * 5 + mode) * n0]; chroma (comp0 = 1): grid (njobs, 2), the winner's mode -> pred[(c - 1) * njobs * n1 + job * n1]
-__global__ void k_intra_pred(const pel *__restrict__ nb, const int *__restrict__ mode_of_job, IntraK P, int comp0, pel *__restrict__ pred)
+// component c of job j with mode ipm into dst; every thread of the block calls it (the DC predictor's reduction synchronises)
+__device__ __forceinline__ void intra_pred_block(const pel *__restrict__ nb, const IntraK &P, int j, int c, int ipm, pel *__restrict__ dst)
 {
-    const int j = blockIdx.x, c = comp0 ? 1 + blockIdx.y : 0;
-    const int ipm = comp0 ? mode_of_job[j] : blockIdx.y;
     const int w = c ? P.w >> P.ws : P.w, h = c ? P.h >> P.hs : P.h, n = w * h;
     const pel *left = nb + ((long)(j * 3 + c) * 2) * NB + 1, *up = left + NB;
-    pel *dst = comp0 ? pred + (long)(c - 1) * P.njobs * P.n1 + (long)j * P.n1 : pred + ((long)j * SLOTS + ipm) * P.n0;
     __shared__ int s_dc;
     if(ipm == 0) { // DC: (sum + w) >> (log2 w + 1) (xeve_ipred.c:133-150)
+        __syncthreads(); // (a second call in the same kernel: nobody still reads the first one's sum)
         if(threadIdx.x == 0) s_dc = 0;
         __syncthreads();
         int a = 0;
@@ -135,20 +134,23 @@ __global__ void k_intra_pred(const pel *__restrict__ nb, const int *__restrict__
 __device__ __forceinline__ size_t org_off_l(const xeve_hip_intra_job &J, const IntraK &P) { return (size_t)((long)J.pic * P.org_pic_l + (long)J.y * P.s_org_l + J.x); }
 __device__ __forceinline__ size_t org_off_c(const xeve_hip_intra_job &J, const IntraK &P) { return (size_t)((long)J.pic * P.org_pic_c + (long)(J.y >> P.hs) * P.s_org_c + (J.x >> P.ws)); }
 
-__global__ void k_intra_jobs1(const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const unsigned char *__restrict__ mpm_row, xeve_hip_job *__restrict__ sj,
-                              xeve_hip_cu_bits_job *__restrict__ bj, int32_t *__restrict__ zero)
+// the five luma predictors: grid (njobs, 5), block (job, mode) -> pred[(job * 5 + mode) * n0]; the block's first thread also writes the slot's SATD job and its
+// mode-index bit-count job (round 6: was a launch of its own behind this one)
+__global__ void k_intra_pred_luma(const pel *__restrict__ nb, const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const unsigned char *__restrict__ mpm_row,
+                                  pel *__restrict__ pred, xeve_hip_job *__restrict__ sj, xeve_hip_cu_bits_job *__restrict__ bj, int32_t *__restrict__ zero)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if(t == 0) zero[0] = 0;
-    if(t >= P.njobs * SLOTS) return;
-    const int j = t / SLOTS, m = t - j * SLOTS;
-    const xeve_hip_intra_job J = jobs[j];
-    sj[t] = xh_make_job(org_off_l(J, P), t * P.n0);
-    xeve_hip_cu_bits_job b;
-    b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
-    b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0, b.refi[0] = b.refi[1] = -1, b.mvp_idx[0] = c_mpm[mpm_row[j]][m], b.mvp_idx[1] = 0;
-    b.mode = XEVE_HIP_BITS_INTRA_DIR, b.dir_flag = 0, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = J.ctx_pred_mode;
-    bj[t] = b;
+    const int j = blockIdx.x, m = blockIdx.y, t = j * SLOTS + m;
+    if(threadIdx.x == 0) {
+        if(t == 0) zero[0] = 0;
+        const xeve_hip_intra_job J = jobs[j];
+        sj[t] = xh_make_job(org_off_l(J, P), t * P.n0);
+        xeve_hip_cu_bits_job b;
+        b.coef_off[0] = b.coef_off[1] = b.coef_off[2] = 0, b.nnz[0] = b.nnz[1] = b.nnz[2] = 0, b.sbac = J.sbac;
+        b.mvd[0][0] = b.mvd[0][1] = b.mvd[1][0] = b.mvd[1][1] = 0, b.refi[0] = b.refi[1] = -1, b.mvp_idx[0] = c_mpm[mpm_row[j]][m], b.mvp_idx[1] = 0;
+        b.mode = XEVE_HIP_BITS_INTRA_DIR, b.dir_flag = 0, b.ctx_skip = J.ctx_skip, b.ctx_pred_mode = J.ctx_pred_mode;
+        bj[t] = b;
+    }
+    intra_pred_block(nb, P, j, 0, m, pred + (long)t * P.n0);
 }
 
 // make_ipred_list (xeve_pintra.c:308-374) per CU; then the slots of the luma RDO: chain jobs and estimate indices
@@ -203,34 +205,39 @@ __global__ void k_intra_jobs2(const xeve_hip_intra_job *__restrict__ jobs, Intra
 }
 
 // ---- 4. the luma decision (xeve_pintra.c:604-637); chroma chain jobs ---------------------------------------------------------------------------------------
-__global__ void k_intra_pick(const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const int *__restrict__ list, const int *__restrict__ pred_cnt,
-                             const long *__restrict__ ssd, const unsigned *__restrict__ bits, const int *__restrict__ nnz, int *__restrict__ best_slot,
-                             int *__restrict__ best_ipd, int *__restrict__ dist_y, int *__restrict__ nnz_y, xeve_hip_job *__restrict__ cj, int *__restrict__ est_idx_c)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.njobs) return;
-    const xeve_hip_intra_job J = jobs[j];
-    double best = MAX_COST;
-    int    bs = 0;
-    for(int k = 0; k < pred_cnt[j]; k++) {
-        const int t = j * SLOTS + k;
-        double cost = 0;
-        cost += (double)ssd[2 * t + 1];
-        cost += (double)(int)bits[t] * P.lambda0;
-        if(cost < best) best = cost, bs = k;
-    }
-    const int t = j * SLOTS + bs;
-    best_slot[j] = t, best_ipd[j] = list[t], dist_y[j] = (int)(double)ssd[2 * t + 1], nnz_y[j] = nnz[t];
-    cj[j] = xh_make_job(org_off_c(J, P), j * P.n1), est_idx_c[j] = J.sbac;
-}
-
-// winner's coefficients and reconstruction -> the output blocks
-__global__ void k_intra_copy(IntraK P, const int *__restrict__ best_slot, const int16_t *__restrict__ coef_s, const pel *__restrict__ rec_s,
-                             int16_t *__restrict__ coef, pel *__restrict__ rec)
-{
+__global__ void k_intra_pick_copy(const xeve_hip_intra_job *__restrict__ jobs, IntraK P, const int *__restrict__ list, const int *__restrict__ pred_cnt,
+                                  const long *__restrict__ ssd, const unsigned *__restrict__ bits, const int *__restrict__ nnz, int *__restrict__ best_ipd,
+                                  int *__restrict__ dist_y, int *__restrict__ nnz_y, xeve_hip_job *__restrict__ cj, int *__restrict__ est_idx_c,
+                                  const int16_t *__restrict__ coef_s, const pel *__restrict__ rec_s, int16_t *__restrict__ coef, pel *__restrict__ rec,
+                                  const pel *__restrict__ nb, pel *__restrict__ predc)
+{   // one block per CU (round 6: the pick, the copy of the winner's blocks and the chroma prediction with its mode were three launches)
+    __shared__ int s_slot, s_ipd;
     const int j = blockIdx.x;
-    const long src = (long)best_slot[j] * P.n0, dst = (long)j * P.n0;
+    if(threadIdx.x == 0) {
+        const xeve_hip_intra_job J = jobs[j];
+        double best = MAX_COST;
+        int    bs = 0;
+        for(int k = 0; k < pred_cnt[j]; k++) {
+            const int t = j * SLOTS + k;
+            double cost = 0;
+            cost += (double)ssd[2 * t + 1];
+            cost += (double)(int)bits[t] * P.lambda0;
+            if(cost < best) best = cost, bs = k;
+        }
+        const int t = j * SLOTS + bs;
+        best_ipd[j] = list[t], dist_y[j] = (int)(double)ssd[2 * t + 1], nnz_y[j] = nnz[t];
+        cj[j] = xh_make_job(org_off_c(J, P), j * P.n1), est_idx_c[j] = J.sbac;
+        s_slot = t, s_ipd = list[t];
+    }
+    __syncthreads();
+    // winner's coefficients and reconstruction -> the output blocks
+    const long src = (long)s_slot * P.n0, dst = (long)j * P.n0;
     for(int t = threadIdx.x; t < P.n0; t += blockDim.x) coef[dst + t] = coef_s[src + t], rec[dst + t] = rec_s[src + t];
+    // 5: chroma with the winner's mode -> predc[(c - 1) * njobs * n1 + job * n1]
+    if(P.ncomp > 1) {
+        const int ipd = s_ipd;
+        for(int c = 1; c <= 2; c++) intra_pred_block(nb, P, j, c, ipd, predc + (long)(c - 1) * P.njobs * P.n1 + (long)j * P.n1);
+    }
 }
 
 // ---- 6. the CU's bit-count job (xeve_rdo_bit_cnt_cu_intra) and the result --------------------------------------------------------------------------------
@@ -317,6 +324,16 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
                                                xeve_hip_intra_result *results, int16_t *coef, xeve_hip_pel *rec, xeve_hip_sbac *best, void *workspace,
                                                size_t workspace_bytes, void *stream)
 {
+    return xh_pintra_analyze_cu_jobs_x(org, s_org_l, s_org_c, mod, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, states, nstates, p, jobs, njobs, results, coef, rec, best,
+                                       workspace, workspace_bytes, stream, nullptr);
+}
+
+// est_shared: core->rdoq_est_* of every entry state, made by the caller (xeve_hip_rdoq_bit_est over `states`; the walk makes them once per node) -- NULL: made here
+int xh_pintra_analyze_cu_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, const uint32_t *map_scu,
+                                const int8_t *map_ipm, const uint8_t *map_tidx, const int64_t *pic_elems, const xeve_hip_sbac *states, int nstates,
+                                const xeve_hip_intra_params *p, const xeve_hip_intra_job *jobs, int njobs, xeve_hip_intra_result *results, int16_t *coef, xeve_hip_pel *rec,
+                                xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream, const void *est_shared)
+{
     XH_ENTER();
     XH_REQUIRE(org && mod && map_scu && map_ipm && map_tidx && states && nstates > 0 && jobs && njobs >= 0 && results && coef && rec && workspace);
     XH_REQUIRE(intra_params_ok(p));
@@ -338,7 +355,7 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     auto *mpm = (unsigned char *)(W + L.mpm);
     auto *zero = (int32_t *)(W + L.zero), *satd = (int32_t *)(W + L.satd);
     auto *sj = (xeve_hip_job *)(W + L.sj), *cj = (xeve_hip_job *)(W + L.cj);
-    int  *est_idx = (int *)(W + L.est_idx), *est_idx_c = (int *)(W + L.est_idx_c), *nnz_s = (int *)(W + L.nnz_s), *list = (int *)(W + L.list), *cnt = (int *)(W + L.cnt), *slot = (int *)(W + L.slot);
+    int  *est_idx = (int *)(W + L.est_idx), *est_idx_c = (int *)(W + L.est_idx_c), *nnz_s = (int *)(W + L.nnz_s), *list = (int *)(W + L.list), *cnt = (int *)(W + L.cnt);
     int  *ipd = (int *)(W + L.ipd), *dist_y = (int *)(W + L.dist_y), *nnz_y = (int *)(W + L.nnz_y);
     int  *nnz_c[2] = {(int *)(W + L.nnz_c[0]), (int *)(W + L.nnz_c[1])};
     long *ssd_s = (long *)(W + L.ssd_s), *ssd_c[2] = {(long *)(W + L.ssd_c[0]), (long *)(W + L.ssd_c[1])};
@@ -355,17 +372,19 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
 
     // 1, 2: neighbours, rank row, the five predictors
     k_intra_nbr<<<dim3(njobs, 3), 128, 0, st>>>(mod[0], mod[1], mod[2], map_scu, map_ipm, map_tidx, jobs, P, nb, mpm);
-    k_intra_pred<<<dim3(njobs, 5), P.n0 >= 256 ? 256 : 64, 0, st>>>(nb, nullptr, P, 0, pred);
+    k_intra_pred_luma<<<dim3(njobs, 5), P.n0 >= 256 ? 256 : 64, 0, st>>>(nb, jobs, P, mpm, pred, sj, bj, zero);
     // 3: SATD, mode bits, the list
-    k_intra_jobs1<<<GS, 256, 0, st>>>(jobs, P, mpm, sj, bj, zero);
     rc = xeve_hip_satd_jobs(org[0], s_org_l, pred, P.w, sj, S, zero, 1, P.w, P.h, bd, satd, stream);
     if(rc != XEVE_HIP_OK) return rc;
     rc = xh_cu_bits_jobs_round(nullptr, 0, states, bj, S, &bp, W + L.bitws, bws, bits, nullptr, 0, 0, stream);
     if(rc != XEVE_HIP_OK) return rc;
     k_intra_list<<<GJ, 256, 0, st>>>(jobs, P, satd, bits, list, cnt, sj, est_idx);
     // 4: the luma RDO of the slots
-    rc = xeve_hip_rdoq_bit_est(states, nstates, est, stream); // core->rdoq_est_* of mode_coding_unit (xeve_mode.c:792)
-    if(rc != XEVE_HIP_OK) return rc;
+    if(est_shared) est = (xeve_hip_rdoq_est_full *)est_shared;
+    else {
+        rc = xeve_hip_rdoq_bit_est(states, nstates, est, stream); // core->rdoq_est_* of mode_coding_unit (xeve_mode.c:792)
+        if(rc != XEVE_HIP_OK) return rc;
+    }
     {
         const int q = p->qp[0];
         rc = xh_residual_rdoq(org[0], s_org_l, pred, P.w, sj, S, lw, lw, bd, q, k_q_scale[q % 6], k_dq_scale[q % 6] << (q / 6), p->slice_type == 2, 1, p->lambda[0], 0,
@@ -375,11 +394,9 @@ extern "C" int xeve_hip_pintra_analyze_cu_jobs(const xeve_hip_pel *const org[3],
     k_intra_jobs2<<<GS, 256, 0, st>>>(jobs, P, mpm, list, nnz_s, bj);
     rc = xh_cu_bits_jobs_round(coef_s, (size_t)S * P.n0, states, bj, S, &bp, W + L.bitws, bws, bits, nullptr, 0, 0, stream);
     if(rc != XEVE_HIP_OK) return rc;
-    k_intra_pick<<<GJ, 256, 0, st>>>(jobs, P, list, cnt, ssd_s, bits, nnz_s, slot, ipd, dist_y, nnz_y, cj, est_idx_c);
-    k_intra_copy<<<njobs, P.n0 >= 256 ? 256 : 64, 0, st>>>(P, slot, coef_s, rec_s, coef, rec);
-    // 5: chroma with the winner's mode
+    k_intra_pick_copy<<<njobs, P.n0 >= 256 ? 256 : 64, 0, st>>>(jobs, P, list, cnt, ssd_s, bits, nnz_s, ipd, dist_y, nnz_y, cj, est_idx_c, coef_s, rec_s, coef, rec, nb, predc);
+    // 5: chroma with the winner's mode (predicted by the launch above)
     if(P.ncomp > 1) {
-        k_intra_pred<<<dim3(njobs, 2), P.n1 >= 256 ? 256 : 64, 0, st>>>(nb, ipd, P, 1, predc);
         for(int k = 1; k <= 2; k++) {
             const int q = p->qp[k];
             rc = xh_residual_rdoq(org[k], s_org_c, predc + (size_t)(k - 1) * njobs * P.n1, P.w >> ws, cj, njobs, lw - ws, lw - hs, bd, q, k_q_scale[q % 6],

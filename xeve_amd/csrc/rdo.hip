@@ -407,6 +407,17 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
                                          const int16_t (*coef_l)[8], const int16_t (*coef_c)[4], xeve_hip_rdo_result *results, int16_t *coef,
                                          xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return xh_residue_rdo_jobs_x(org, s_org_l, s_org_c, refp, s_l, s_c, states, nstates, p, jobs, njobs, coef_l, coef_c, results, coef, best, workspace, workspace_bytes, stream,
+                                 nullptr, 0);
+}
+
+// est_shared: core->rdoq_est_* of every entry state, made by the caller (xeve_hip_rdoq_bit_est over the same states) -- NULL: made here; keep_dropped: the coefficient
+// blocks of components the decision drops are NOT zeroed (the caller goes by results[].nnz) -- the inter analysis' two launches less per batch
+int xh_residue_rdo_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, const xeve_hip_sbac *states, int nstates,
+                          const xeve_hip_rdo_params *p, const xeve_hip_rdo_job *jobs, int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4],
+                          xeve_hip_rdo_result *results, int16_t *coef, xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream,
+                          const void *est_shared, int keep_dropped)
+{
     XH_ENTER();
     XH_REQUIRE(org && refp && states && nstates > 0 && p && jobs && njobs >= 0 && results && coef && workspace && coef_l);
     XH_REQUIRE(p->log2_cuw >= 2 && p->log2_cuw <= 6 && p->log2_cuh >= 2 && p->log2_cuh <= 6 && p->tool_iqt == 0);
@@ -425,7 +436,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     char *W = (char *)workspace;
     auto *rl = (xeve_hip_job *)(W + L.rl), *rc = (xeve_hip_job *)(W + L.rc);
     int  *est_idx = (int *)(W + L.est_idx);
-    auto *est = (xeve_hip_rdoq_est_full *)(W + L.est);
+    auto *est = est_shared ? (xeve_hip_rdoq_est_full *)est_shared : (xeve_hip_rdoq_est_full *)(W + L.est);
     pel  *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
     pel  *rec[3]  = {(pel *)(W + L.rec[0]), (pel *)(W + L.rec[1]), (pel *)(W + L.rec[2])};
     int  *nnz[3]  = {(int *)(W + L.nnz[0]), (int *)(W + L.nnz[1]), (int *)(W + L.nnz[2])};
@@ -448,8 +459,10 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
                           pred[1], pred[2], W + L.mcws, L.bitws - L.mcws, stream, XH_MC_PREPPED);
     if(rc_ != XEVE_HIP_OK) return rc_;
     // the estimates of every entry state (xeve_mode.c:792)
-    rc_ = xeve_hip_rdoq_bit_est(states, nstates, est, stream);
-    if(rc_ != XEVE_HIP_OK) return rc_;
+    if(!est_shared) {
+        rc_ = xeve_hip_rdoq_bit_est(states, nstates, est, stream);
+        if(rc_ != XEVE_HIP_OK) return rc_;
+    }
     // residual, SSD, transform, zero pre-test + RDOQ, reconstruction, SSD (:969-1051)
     int16_t *cf[3] = {coef, coef + (size_t)njobs * P.n0, coef + (size_t)njobs * (P.n0 + P.n1)};
     for(int k = 0; k < P.ncomp; k++) {
@@ -475,7 +488,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
         rc_ = xh_cu_bits_chain_round(coef_elems, states, cj, 4 * njobs, &bp, W + L.bitws, bws, cbits, stream);
         if(rc_ != XEVE_HIP_OK) return rc_;
         k_rdo_spec_decide<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cbits, st_out, cand, results, drop, best);
-        k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
+        if(!keep_dropped) k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
         XH_HIP(hipGetLastError());
         return XEVE_HIP_OK;
     }
@@ -497,7 +510,7 @@ extern "C" int xeve_hip_residue_rdo_jobs(const xeve_hip_pel *const org[3], int s
     rc_ = xh_cu_bits_jobs_round(coef, coef_elems, states, bj, njobs, &bp, W + L.bitws, bws, bits, best ? st_out : nullptr, best != nullptr, 1, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
     k_rdo_finish<<<G, 256, 0, st>>>(jobs, P, ssd[0], ssd[1], ssd[2], bits, cand, results, drop, st_out, best);
-    k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
+    if(!keep_dropped) k_rdo_zero_dropped<<<(3 * njobs + 3) / 4, 256, 0, st>>>(coef, drop, P);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
@@ -547,51 +560,56 @@ __global__ void k_skip_prep(const xeve_hip_skip_job *__restrict__ jobs, SkipK P,
     valid[t] = ok;
 }
 
-// the walk over the slots in (idx0, idx1) order (:1391-1521); also the winner's bit-count job for the state pass
-__global__ void k_skip_decide(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, const xeve_hip_cu_mc_job *__restrict__ mc, const unsigned char *__restrict__ valid,
-                              const long *__restrict__ ssd_y, const long *__restrict__ ssd_u, const long *__restrict__ ssd_v, const unsigned *__restrict__ bits,
-                              const xeve_hip_cu_bits_job *__restrict__ bj, xeve_hip_skip_result *__restrict__ res, int *__restrict__ win,
-                              xeve_hip_cu_bits_job *__restrict__ bj_win)
+// the walk over the slots in (idx0, idx1) order (:1391-1521) by the block's first thread, then pi->pred[PRED_SKIP][0] and core->s_temp_best of the winner (both untouched
+// when no pair was usable) by all of them: one block per CU (round 6: was a decision kernel and a copy kernel)
+__global__ void k_skip_decide_copy(const xeve_hip_skip_job *__restrict__ jobs, SkipK P, const xeve_hip_cu_mc_job *__restrict__ mc, const unsigned char *__restrict__ valid,
+                                   const long *__restrict__ ssd_y, const long *__restrict__ ssd_u, const long *__restrict__ ssd_v, const unsigned *__restrict__ bits,
+                                   xeve_hip_skip_result *__restrict__ res, int *__restrict__ win, const pel *__restrict__ sy, const pel *__restrict__ su,
+                                   const pel *__restrict__ sv, pel *__restrict__ py, pel *__restrict__ pu, pel *__restrict__ pv, const xeve_hip_sbac *__restrict__ st,
+                                   xeve_hip_sbac *__restrict__ best)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if(j >= P.njobs) return;
-    double cost_best = MAX_COST;
-    int    sb = -1;
-    long   ssd_best = 1L << P.best_shift;
-    for(int s = 0; s < P.S; s++) {
-        const int t = j * P.S + s;
-        if(!valid[t]) continue;
-        const long cy = ssd_y[t], cu = P.ncomp > 1 ? ssd_u[t] : 0, cv = P.ncomp > 1 ? ssd_v[t] : 0;
-        double cost = (double)cy + (P.wgt[0] * (double)cu) + (P.wgt[1] * (double)cv); // (:1467-1473)
-        cost += (double)(int)bits[t] * P.lambda0;                                      // RATE_TO_COST_LAMBDA (:1488)
-        if(cost < cost_best) cost_best = cost, sb = s, ssd_best = cy + cu + cv;
+    __shared__ int s_win;
+    const int j = blockIdx.x;
+    if(threadIdx.x == 0) {
+        double cost_best = MAX_COST;
+        int    sb = -1;
+        long   ssd_best = 1L << P.best_shift;
+        for(int s = 0; s < P.S; s++) {
+            const int t = j * P.S + s;
+            if(!valid[t]) continue;
+            const long cy = ssd_y[t], cu = P.ncomp > 1 ? ssd_u[t] : 0, cv = P.ncomp > 1 ? ssd_v[t] : 0;
+            double cost = (double)cy + (P.wgt[0] * (double)cu) + (P.wgt[1] * (double)cv); // (:1467-1473)
+            cost += (double)(int)bits[t] * P.lambda0;                                      // RATE_TO_COST_LAMBDA (:1488)
+            if(cost < cost_best) cost_best = cost, sb = s, ssd_best = cy + cu + cv;
+        }
+        xeve_hip_skip_result r;
+        r.cost = cost_best, r.best_ssd = ssd_best, r.idx0 = r.idx1 = 0;
+        r.mv[0][0] = r.mv[0][1] = r.mv[1][0] = r.mv[1][1] = 0, r.refi[0] = r.refi[1] = 0;
+        for(int k = 0; k < 6; k++) r.pad_[k] = 0;
+        if(sb >= 0) {
+            const xeve_hip_cu_mc_job m = mc[j * P.S + sb];
+            r.idx0 = P.isb ? sb / P.mc : sb, r.idx1 = P.isb ? sb % P.mc : 0;
+            r.mv[0][0] = m.mv[0][0], r.mv[0][1] = m.mv[0][1], r.mv[1][0] = m.mv[1][0], r.mv[1][1] = m.mv[1][1], r.refi[0] = m.refi[0], r.refi[1] = m.refi[1];
+        }
+        res[j] = r;
+        win[j] = sb;
+        s_win = sb;
     }
-    xeve_hip_skip_result r;
-    r.cost = cost_best, r.best_ssd = ssd_best, r.idx0 = r.idx1 = 0;
-    r.mv[0][0] = r.mv[0][1] = r.mv[1][0] = r.mv[1][1] = 0, r.refi[0] = r.refi[1] = 0;
-    for(int k = 0; k < 6; k++) r.pad_[k] = 0;
-    if(sb >= 0) {
-        const xeve_hip_cu_mc_job m = mc[j * P.S + sb];
-        r.idx0 = P.isb ? sb / P.mc : sb, r.idx1 = P.isb ? sb % P.mc : 0;
-        r.mv[0][0] = m.mv[0][0], r.mv[0][1] = m.mv[0][1], r.mv[1][0] = m.mv[1][0], r.mv[1][1] = m.mv[1][1], r.refi[0] = m.refi[0], r.refi[1] = m.refi[1];
-    }
-    res[j] = r;
-    win[j] = sb;
-    bj_win[j] = bj[j * P.S + (sb >= 0 ? sb : 0)];
-}
-
-// pi->pred[PRED_SKIP][0] and core->s_temp_best of the winner (both untouched when no pair was usable)
-__global__ void k_skip_copy(SkipK P, const int *__restrict__ win, const pel *__restrict__ sy, const pel *__restrict__ su, const pel *__restrict__ sv,
-                            pel *__restrict__ py, pel *__restrict__ pu, pel *__restrict__ pv, const xeve_hip_sbac *__restrict__ st, xeve_hip_sbac *__restrict__ best)
-{
-    const int j = blockIdx.x / 3, k = blockIdx.x % 3, sb = win[j];
-    if(sb < 0 || (k && P.ncomp == 1)) return;
-    const int    n = k ? P.n1 : P.n0;
+    __syncthreads();
+    const int sb = s_win;
+    if(sb < 0) return;
     const size_t t = (size_t)j * P.S + sb;
-    const pel   *s = (k == 0 ? sy : k == 1 ? su : sv) + t * n;
-    pel         *d = (k == 0 ? py : k == 1 ? pu : pv) + (size_t)j * n;
-    for(int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
-    if(k == 0 && best && threadIdx.x == 0) copy_state(best + j, st + t); // (the slot's state after its skip flag and candidate indices: SBAC_STORE(core->s_temp_best, *sbac), :1519)
+    for(int k = 0; k < P.ncomp; k++) {
+        const int  n = k ? P.n1 : P.n0;
+        const pel *s = (k == 0 ? sy : k == 1 ? su : sv) + t * n;
+        pel       *d = (k == 0 ? py : k == 1 ? pu : pv) + (size_t)j * n;
+        for(int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    }
+    if(best) { // (the slot's state after its skip flag and candidate indices: SBAC_STORE(core->s_temp_best, *sbac), :1519)
+        const unsigned *a = (const unsigned *)(st + t);
+        unsigned       *b = (unsigned *)(best + j);
+        for(int i = threadIdx.x; i < (int)(sizeof(xeve_hip_sbac) / 4); i += blockDim.x) b[i] = a[i];
+    }
 }
 
 struct SkipLayout {
@@ -651,7 +669,7 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
     char *W  = (char *)workspace;
     auto *mc = (xeve_hip_cu_mc_job *)(W + L.mc);
     auto *rl = (xeve_hip_job *)(W + L.rl), *rc = (xeve_hip_job *)(W + L.rc);
-    auto *bj = (xeve_hip_cu_bits_job *)(W + L.bj), *bjw = (xeve_hip_cu_bits_job *)(W + L.bjw);
+    auto *bj = (xeve_hip_cu_bits_job *)(W + L.bj);
     auto *valid = (unsigned char *)(W + L.valid);
     pel  *pred[3] = {(pel *)(W + L.pred[0]), (pel *)(W + L.pred[1]), (pel *)(W + L.pred[2])};
     long *ssd[3]  = {(long *)(W + L.ssd[0]), (long *)(W + L.ssd[1]), (long *)(W + L.ssd[2])};
@@ -683,8 +701,8 @@ extern "C" int xeve_hip_analyze_skip_jobs(const xeve_hip_pel *const org[3], int 
     // second count of the winners alone on the dependent chain)
     rc_ = xeve_hip_cu_bits_jobs(nullptr, 0, states, bj, nt, &bp, W + L.bitws, workspace_bytes - L.bitws, bits, best ? stw : nullptr, stream);
     if(rc_ != XEVE_HIP_OK) return rc_;
-    k_skip_decide<<<(njobs + 255) / 256, 256, 0, st>>>(jobs, P, mc, valid, ssd[0], ssd[1], ssd[2], bits, bj, results, win, bjw);
-    k_skip_copy<<<3 * njobs, 64, 0, st>>>(P, win, pred[0], pred[1], pred[2], pred_y, pred_u, pred_v, stw, best);
+    k_skip_decide_copy<<<njobs, P.n0 >= 256 ? 256 : 64, 0, st>>>(jobs, P, mc, valid, ssd[0], ssd[1], ssd[2], bits, results, win, pred[0], pred[1], pred[2], pred_y, pred_u,
+                                                                 pred_v, stw, best);
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }

@@ -60,8 +60,8 @@ struct TreeK {
     // THE SIDE STREAM (round 6).  The analysis of a node that has children needs nothing its children produce and they need nothing of it -- both start from the node's
     // entry state and from neighbours outside the node (xeve_mode.c:2061-2262: s_curr_before_split; the maps inside the node are cleared for either) -- until op_exit
     // compares the two costs.  A call with a side stream runs the analyses of every such node there while the main stream walks on into the children: two launch
-    // chains side by side instead of one -- and, every level of such nodes on a stream of its own (the 16x16 nodes' verdicts are needed after four 8x8 nodes, a 64x64
-    // node's only at the end of the CTU), up to four.  Every array an analysis reads or writes exists once per stream (ac[0] main); side_of[L] says which a level uses.
+    // chains side by side instead of one (setting 2: every level of such nodes on a side stream of its own, up to four -- measured slower: the device's kernels then
+    // contend four ways).  Every array an analysis reads or writes exists once per stream (ac[0] main); side_of[L] says which a level uses.
     struct Ac {
         xeve_hip_intra_job          *ijobs; // [5][nchains]: the job arrays per LEVEL -- the main stream enters the next side node while the side stream may still be reading an outer one's
         const xeve_hip_intra_result *ires;  // [nchains]
@@ -535,7 +535,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 struct TreeLayout {
     size_t node, curr, next, before, tdepth, csplit, best, temp, tsplit, zero32, total, zero_from, zero_bytes;
     struct Ac {
-        size_t sbest, ijobs, ires, icoef, irec, iws, iws_bytes;
+        size_t sbest, ijobs, ires, icoef, irec, iws, iws_bytes, est;
         size_t ejobs, sjobs, eres, ecoef, erec[3], epred, esatd, enext, ews, ews_bytes; // P / B slices
     } ac[XT_STREAMS]; // the arrays of the analyses, per stream (TreeK::Ac)
     unsigned char side_of[8];
@@ -618,7 +618,7 @@ static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const 
     memset(&L, 0, sizeof(L));
     const size_t N = (size_t)nchains;
     const int    idc = p->ip.chroma_format_idc;
-    for(int log2 = 2; log2 <= p->log2_ctu; log2++) L.side_of[log2 - 2] = side && level_has_cu(p, log2) && level_has_kids(p, log2) ? (side == 2 ? 1 : log2 - 2) : 0; // (2: ONE side stream for every level, a measurement setting)
+    for(int log2 = 2; log2 <= p->log2_ctu; log2++) L.side_of[log2 - 2] = side && level_has_cu(p, log2) && level_has_kids(p, log2) ? (side == 2 ? log2 - 2 : 1) : 0; // (2: a side stream per LEVEL, a measurement setting: 5 % slower than one side stream at the bench's width, profiles/r06_side_stream.md)
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
     L.zero_from = o;
@@ -635,7 +635,7 @@ static TreeLayout tree_layout(int nchains, const xeve_hip_tree_params *p, const 
             if(level_has_cu(p, log2) && L.side_of[log2 - 2] == a) top = 1 << log2;
         if(!top) continue;
         const int n0 = top * top, n1 = idc ? n0 >> ((idc <= 2) + (idc <= 1)) : 0;
-        A.ijobs = take(5 * N * sizeof(xeve_hip_intra_job)), A.ires = take(N * sizeof(xeve_hip_intra_result));
+        A.ijobs = take(5 * N * sizeof(xeve_hip_intra_job)), A.ires = take(N * sizeof(xeve_hip_intra_result)), A.est = take(N * sizeof(xeve_hip_rdoq_est_full));
         A.icoef = take(N * ((size_t)n0 + 2 * (size_t)n1) * 2 + 64), A.irec = take(N * ((size_t)n0 + 2 * (size_t)n1) * sizeof(pel) + 64);
         if(I) {
             A.ejobs = take(5 * N * sizeof(xeve_hip_inter_job)), A.sjobs = take(5 * N * sizeof(xeve_hip_job)), A.eres = take(N * sizeof(xeve_hip_inter_result));
@@ -822,8 +822,13 @@ struct TreeSide {
     {
         if(gen != xh_generation()) drop(), gen = xh_generation();
         if(st[1]) return true;
+        // (XEVE_HIP_TREE_SIDE_PRIO=1, a measurement switch: the side streams at the device's lowest priority -- the main stream's chain of small kernels is the critical
+        // one, the side stream's wide kernels should give way to it)
+        static const int low_prio = getenv("XEVE_HIP_TREE_SIDE_PRIO") ? atoi(getenv("XEVE_HIP_TREE_SIDE_PRIO")) : 0;
+        int pr_low = 0, pr_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
         for(int a = 1; a < XT_STREAMS; a++)
-            if(hipStreamCreateWithFlags(&st[a], hipStreamNonBlocking) != hipSuccess) { st[a] = nullptr, drop(); return false; }
+            if(hipStreamCreateWithPriority(&st[a], hipStreamNonBlocking, low_prio ? pr_low : 0) != hipSuccess) { st[a] = nullptr, drop(); return false; }
         for(auto &e : ev)
             if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { drop(); return false; }
         return true;
@@ -937,6 +942,13 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
             const TreeK::Ac       &A = K.ac[it.st];
             const TreeLayout::Ac &LA = L.ac[it.st];
             int rc = XEVE_HIP_OK;
+            // core->rdoq_est_* of the node's entry states (xeve_mode.c:792): once per node, for its inter analysis' two pinter_residue_rdo batches and its intra analysis
+            // (round 6: each of the three made its own)
+            auto *est = (xeve_hip_rdoq_est_full *)(W + LA.est);
+            if(it.kind == AN_INTER || (it.kind == AN_INTRA && !I && !(log2 <= 3 && use_lane))) {
+                rc = xeve_hip_rdoq_bit_est(K.curr + (size_t)(log2 - 2) * nchains, nchains, est, sv);
+                if(rc != XEVE_HIP_OK) return rc;
+            }
             if(it.kind == AN_INTRA && log2 <= 3 && use_lane) { // one lane per chain decides the node (cu_lane.h)
                 const xl::Params LP = lane_params(p, log2, s_org_l, s_org_c, s_mod_l, s_mod_c);
                 const int grid = nchains;
@@ -945,20 +957,20 @@ extern "C" int xeve_hip_mode_analyze_ctu_jobs(const xeve_hip_pel *const org[3], 
             }
             else if(it.kind == AN_INTRA) {
                 const xeve_hip_intra_params ip = level_params(p, log2);
-                rc = xeve_hip_pintra_analyze_cu_jobs(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
-                                                     nchains, &ip, A.ijobs + (size_t)(log2 - 2) * nchains, nchains, (xeve_hip_intra_result *)(W + LA.ires), (int16_t *)(W + LA.icoef), (pel *)(W + LA.irec), A.sbest,
-                                                     W + LA.iws, LA.iws_bytes, sv);
+                rc = xh_pintra_analyze_cu_jobs_x(org, s_org_l, s_org_c, modc, s_mod_l, s_mod_c, map_scu, map_ipm, map_tidx, pic_elems, K.curr + (size_t)(log2 - 2) * nchains,
+                                                 nchains, &ip, A.ijobs + (size_t)(log2 - 2) * nchains, nchains, (xeve_hip_intra_result *)(W + LA.ires), (int16_t *)(W + LA.icoef), (pel *)(W + LA.irec), A.sbest,
+                                                 W + LA.iws, LA.iws_bytes, sv, est);
             }
             else if(it.kind == AN_INTER) {
                 const xeve_hip_inter_params ep = level_inter_params(I, log2);
                 XhVhScope tall(vh);
-                rc = xeve_hip_inter_candidates(map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, p->ip.h_scu, log2, log2,
-                                               p->ip.slice_type, A.ejobs + (size_t)(log2 - 2) * nchains, nchains, sv);
-                if(rc == XEVE_HIP_OK)
-                    rc = xeve_hip_pinter_analyze_cu_jobs(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, A.ejobs + (size_t)(log2 - 2) * nchains,
-                                                         nchains, I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + LA.eres), (int16_t *)(W + LA.ecoef), (pel *)(W + LA.erec[0]),
-                                                         (pel *)(W + LA.erec[1]), (pel *)(W + LA.erec[2]), (pel *)(W + LA.epred), (xeve_hip_sbac *)(W + LA.enext), W + LA.ews,
-                                                         LA.ews_bytes, sv);
+                // (the CUs' merge / MVP candidates from the per-unit maps -- xeve_hip_inter_candidates -- by the analysis' first kernel)
+                const XhInterCand C = {map_scu, map_tidx, I->map_mv, I->col_mv0, I->col_mv1 ? I->col_mv1 : I->col_mv0, p->ip.w_scu, 1 << (log2 - 2), 1 << (log2 - 2),
+                                       p->ip.slice_type == 0, vh};
+                rc = xh_pinter_analyze_cu_jobs_x(org, s_org_l, s_org_c, I->refp, I->s_ref_l, I->s_ref_c, K.curr + (size_t)(log2 - 2) * nchains, nchains, &ep, A.ejobs + (size_t)(log2 - 2) * nchains,
+                                                 nchains, I->coef_l, I->coef_c, (xeve_hip_inter_result *)(W + LA.eres), (int16_t *)(W + LA.ecoef), (pel *)(W + LA.erec[0]),
+                                                 (pel *)(W + LA.erec[1]), (pel *)(W + LA.erec[2]), (pel *)(W + LA.epred), (xeve_hip_sbac *)(W + LA.enext), W + LA.ews,
+                                                 LA.ews_bytes, sv, &C, est);
                 if(rc == XEVE_HIP_OK) // core->inter_satd = xeve_satd_16b(original, mi->pred_y_best) (mode_check_intra, :1250-1262)
                     rc = xeve_hip_satd_jobs(org[0], s_org_l, (const pel *)(W + LA.epred), cu, A.sjobs + (size_t)(log2 - 2) * nchains, nchains, (const int32_t *)(W + L.zero32), 1, cu, cu, p->ip.bit_depth,
                                             (int32_t *)(W + LA.esatd), sv);

@@ -84,10 +84,11 @@ std::atomic<long> g_walk_load{0}; // chains of the batch encoders with a run in 
 // a batch encoder starts (+) or ends (-) a run of `chains` lockstep chains: the walks of all running encoders share the chip's workgroup slots
 void xh_walk_load(long chains) { g_walk_load.fetch_add(chains); }
 
-// which walk a call of `nchains` chains runs: the fused kernel finishes a step of FEW chains sooner (a team per chain: ~60 / 120 ms per intra / inter CTU of noise at
-// 3840x2160 against the composed walk's launch-bound ~110 / 185 ms), the composed walk's kernels pack the lanes of MANY chains densely and code more CTUs per second
-// from ~2 000 chains on (profiles/r04_walks.md).  nchains = the width of the batch the call belongs to (tree.hip).  XEVE_HIP_WALK=1 / 0 pins the fused / the composed
-// walk; unset: fused up to XEVE_HIP_WALK_AUTO_MAX chains (1024).
+// which walk a call of `nchains` chains runs.  Rounds 4-5: the fused kernel up to 1024 chains (it finished a step of few chains sooner: ~60 / 120 ms per intra / inter CTU
+// of noise against the composed walk's launch-bound ~110 / 185 ms), the composed walk above.  Round 6: with its side stream and a third fewer launches the composed walk
+// finishes a step sooner at EVERY width (8 chains: 55 / 62 ms against 69 / 103; 1024 chains: 67 / 81 against 79 / 116 -- profiles/r06_side_stream.md), so the choice by
+// width is the composed walk throughout (XEVE_HIP_WALK_AUTO_MAX = 0); the fused kernel keeps what only it codes (presets slow and placebo: xh_walk_only) and stays
+// pinned by XEVE_HIP_WALK=1 / xeve_hip_walk_select(1).  nchains = the width of the batch the call belongs to (tree.hip).
 namespace {
 // the walk choice: -1 by the width (fused up to g_walk_auto_max chains), 0 the composed walk, 1 the fused kernel.  Starts from XEVE_HIP_WALK / XEVE_HIP_WALK_AUTO_MAX;
 // xeve_hip_walk_select moves it at run time (one process can then pin each walk in turn: tests/test_enc_gpu.py)
@@ -97,7 +98,7 @@ int walk_env_mode()
     return e && *e && strcmp(e, "auto") ? (atoi(e) != 0) : -1;
 }
 std::atomic<int> g_walk_mode{walk_env_mode()};
-std::atomic<int> g_walk_auto_max{getenv("XEVE_HIP_WALK_AUTO_MAX") ? atoi(getenv("XEVE_HIP_WALK_AUTO_MAX")) : 1024};
+std::atomic<int> g_walk_auto_max{getenv("XEVE_HIP_WALK_AUTO_MAX") ? atoi(getenv("XEVE_HIP_WALK_AUTO_MAX")) : 0};
 } // namespace
 bool xh_walk_enabled(int nchains)
 {

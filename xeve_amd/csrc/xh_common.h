@@ -151,6 +151,25 @@ __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(size_t o, int off2)
 }
 __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(long y, long stride, long x, int off2) { return xh_make_job((size_t)(y * stride + x), off2); }
 __device__ __forceinline__ int xh_plane_of_job(const unsigned char *job_plane, int per_plane, int j) { return job_plane ? job_plane[j] : j / per_plane; }
+// the encoder's per-unit maps a CU's merge / MVP candidates are derived from (xeve_hip_inter_candidates' arguments; inter.hip)
+struct XhInterCand {
+    const uint32_t *map_scu;
+    const uint8_t  *map_tidx;
+    const int16_t  *map_mv, *col0, *col1;
+    int             w_scu, scuw, scuh, isb, vh;
+};
+int xh_pinter_analyze_cu_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, const xeve_hip_sbac *states,
+                                int nstates, const xeve_hip_inter_params *p, xeve_hip_inter_job *jobs, int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4],
+                                xeve_hip_inter_result *results, int16_t *coef, xeve_hip_pel *rec_y, xeve_hip_pel *rec_u, xeve_hip_pel *rec_v, xeve_hip_pel *pred_y,
+                                xeve_hip_sbac *next_best, void *workspace, size_t workspace_bytes, void *stream, const XhInterCand *cand, const void *est_shared); // inter.hip
+int xh_pintra_analyze_cu_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_pel *const mod[3], int s_mod_l, int s_mod_c, const uint32_t *map_scu,
+                                const int8_t *map_ipm, const uint8_t *map_tidx, const int64_t *pic_elems, const xeve_hip_sbac *states, int nstates,
+                                const xeve_hip_intra_params *p, const xeve_hip_intra_job *jobs, int njobs, xeve_hip_intra_result *results, int16_t *coef, xeve_hip_pel *rec,
+                                xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream, const void *est_shared); // intra.hip
+int xh_residue_rdo_jobs_x(const xeve_hip_pel *const org[3], int s_org_l, int s_org_c, const xeve_hip_refpic *refp, int s_l, int s_c, const xeve_hip_sbac *states, int nstates,
+                          const xeve_hip_rdo_params *p, const xeve_hip_rdo_job *jobs, int njobs, const int16_t (*coef_l)[8], const int16_t (*coef_c)[4],
+                          xeve_hip_rdo_result *results, int16_t *coef, xeve_hip_sbac *best, void *workspace, size_t workspace_bytes, void *stream,
+                          const void *est_shared, int keep_dropped); // rdo.hip
 int xh_residual_back(const pel *org, int s_org, const pel *pred, int s_pred, const xeve_hip_job *jobs, int njobs, int log2w, int log2h, int bit_depth, int qp, int dqscale,
                      const int16_t *coef, pel *rec, int s_rec, int32_t *nnz, int64_t *ssd, hipStream_t st); // tq.hip
 // what the integer searches of pinter_me_epzs leave per job (me.hip) and the merge of the sub-pel stage's result into it (xeve_pinter.c:828-833, 690-692): with `finish`
