@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_alf_filter(pel *__restrict__ dst, long 
             int16_t c[TAPS == 7 ? 13 : 7];
             if(TAPS == 7) {
                 const uint8_t cl = cls[(long)(jb.y + ty + by) * s_cls + jb.x + tx + bx];
-                const int16_t *set = fs.c + ((cl >> 2) & 0x1F) * 13;
+                const int16_t *set = fs.c + min((cl >> 2) & 0x1F, 24) * 13; // (25 classes: a stale classifier byte cannot index past the filter set)
 #pragma unroll
                 for(int k = 0; k < 13; k++) c[k] = set[xalf::order7(cl & 3, k)];
             }
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_alf_stats(const uint8_t *__restrict__ c
                         long long part = 0;
 #pragma unroll
                         for(int q = 0; q < 16; q++) part += loc[b * 16 + q][ia] * loc[b * 16 + q][ib];
-                        acc[(bcls[b] >> 2) & 0x1F][threadIdx.x] += part;
+                        acc[min((bcls[b] >> 2) & 0x1F, 24)][threadIdx.x] += part;
                     }
                 __syncthreads();
             }

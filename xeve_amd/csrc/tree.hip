@@ -822,13 +822,9 @@ struct TreeSide {
     {
         if(gen != xh_generation()) drop(), gen = xh_generation();
         if(st[1]) return true;
-        // (XEVE_HIP_TREE_SIDE_PRIO=1, a measurement switch: the side streams at the device's lowest priority -- the main stream's chain of small kernels is the critical
-        // one, the side stream's wide kernels should give way to it)
-        static const int low_prio = getenv("XEVE_HIP_TREE_SIDE_PRIO") ? atoi(getenv("XEVE_HIP_TREE_SIDE_PRIO")) : 0;
-        int pr_low = 0, pr_high = 0;
-        (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
+        // (stream priorities -- the side stream at the device's lowest, the caller's at its highest -- change nothing: measured, profiles/r06_side_stream.md)
         for(int a = 1; a < XT_STREAMS; a++)
-            if(hipStreamCreateWithPriority(&st[a], hipStreamNonBlocking, low_prio ? pr_low : 0) != hipSuccess) { st[a] = nullptr, drop(); return false; }
+            if(hipStreamCreateWithFlags(&st[a], hipStreamNonBlocking) != hipSuccess) { st[a] = nullptr, drop(); return false; }
         for(auto &e : ev)
             if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { drop(); return false; }
         return true;

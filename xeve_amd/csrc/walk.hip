@@ -25,7 +25,7 @@ template <bool FULL> __global__ void __launch_bounds__(XW_NT, XW_WG_PER_CU) k_wa
     __shared__ xw::Lds S;
     __shared__ int s_simd[XW_NT / 64], s_order;
     int tid = (int)threadIdx.x;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__gfx950__) || defined(__gfx942__) // (the HW_ID / XCC_ID register numbers and bit fields below are these targets': any other keeps the launch order -- ADVICE r05)
     if(cu_arrivals && blockDim.x == XW_NT) {
         constexpr int REG_HW_ID = 4, REG_XCC_ID = 20; // s_getreg_b32 operands: (size - 1) << 11 | offset << 6 | register (gfx950: hip/amd_detail/amd_device_functions.h)
         const unsigned hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | REG_HW_ID);

@@ -8,6 +8,17 @@ typedef int16_t pel;
 
 #define XH_WAVE 64
 
+// ---- DEVELOPER SWITCHES (environment, read once per process; results never depend on them: tests/test_dev_switches_gpu.py runs a reference-bitstream case under each) ------
+//   XEVE_HIP_WALK = 0 | 1 | auto, XEVE_HIP_WALK_AUTO_MAX = n       which CTU walk (composed / fused / by width: fused up to n chains, 0 since round 6); xeve_hip_walk_select
+//   XEVE_HIP_TREE_SIDE = 0 | 1 | 2                                 the composed walk on one stream / with its side stream (default) / a side stream per node size; xeve_hip_walk_side
+//   XEVE_HIP_TREE_GRAPH = 1, XEVE_HIP_TREE_LANE = 1                the one-stream walk replayed from a HIP graph; 4x4 / 8x8 intra nodes by the lane-serial kernel (both measured slower)
+//   XEVE_HIP_RDO_SPEC = n                                          pinter_residue_rdo's four bit-count rounds as one speculative round for batches of up to n candidates (256)
+//   XEVE_HIP_ME_CPL = 0, XEVE_HIP_ME_LDS = 1                       the search kernel's older lane mappings (rows per lane; the LDS-staged window)
+//   XEVE_HIP_DCT = valu                                            32x32 / 64x64 transforms on the VALU path instead of the matrix cores
+//   XEVE_HIP_WRITER_WAVE = 0, XEVE_HIP_ENC_TWO_STORES = 0          the entropy writer on a lone lane; one CTU store instead of two
+//   XEVE_HIP_ENC_PRIO = 1, XEVE_HIP_ENC_FULL_STATES = 1            the encoder's main stream above its second-pass stream; complete coder states through the walk
+//   XEVE_HIP_HOST_GRAPH = 0                                        the host-memory form of the inter analysis without its per-CU graph replay
+//   XEVE_HIP_WALK_C / _NT / _SPREAD / _DEAL / _INTER / _COUNT / _PROF / _DBG   the fused kernel's team shape, wave placement, stage profile and debug counters (walk.hip)
 // ---- error plumbing (abi.cpp) -------------------------------------------------------------
 void xh_set_error(const char *fmt, ...);
 bool xh_ready();
@@ -145,7 +156,8 @@ __host__ __device__ __forceinline__ size_t xh_u(int off) { return (size_t)(uint3
 __host__ __device__ __forceinline__ xeve_hip_job xh_make_job(size_t o, int off2)
 {
     xeve_hip_job j;
-    if(o & 1) j.off1 = (int)(uint32_t)o, j.off2 = off2;
+    // (the halved form keeps bit 30 of off2 for its mark: an off2 outside 0 .. 2^30 - 1 -- a dense offset beyond a gigasample, ADVICE r05 -- stays unhalved)
+    if((o & 1) || off2 < 0 || off2 >= XH_OFF2_HALF) j.off1 = (int)(uint32_t)o, j.off2 = off2;
     else j.off1 = (int)(uint32_t)(o >> 1), j.off2 = off2 | XH_OFF2_HALF;
     return j;
 }
