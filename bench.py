@@ -484,15 +484,19 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
     e.sync()
     lib.prof_enable([c for c in lib.PROF_CLASSES if c != "walk"])
     lib.prof_read()
+    lib.prof_cu_bits_hist(reset=True)
     e.advance(steps)
     e.sync()
     allc = lib.prof_read()
+    hist = lib.prof_cu_bits_hist()
     lib.prof_enable(None)
     e.close()
     kern = {c: {"ms_per_step": round(v[0] / steps, 3), "launches_per_step": v[1] // steps} for c, v in allc.items() if c != "walk"}
     cb = allc["cu_bits"]
     bins_s = cb[2] / (cb[0] * 1e-3) if cb[0] > 0 else 0.0
-    kern["cu_bits"].update({"bins_per_step": int(cb[2] / steps), "Gbin_per_s": round(bins_s / 1e9, 3)})
+    kern["cu_bits"].update({"bins_per_step": int(cb[2] / steps), "Gbin_per_s": round(bins_s / 1e9, 3), "bins_per_job_histogram": hist,
+                            "bins_per_job_note": "jobs (lanes) of the %d steps by their bin count: most lanes of a launch carry a handful of header bins (candidate indices, "
+                                                 "all-zero alternatives, mode bits), a few carry a CU's coefficients -- a launch lasts as long as its longest lane" % steps})
     tot = sum(v[0] for c, v in allc.items() if c not in ("cu_bits_slow", "walk"))
     # The instruction rate comes from the PMC pass over the same kernel at the bench's width (profiles/, committed: SQ_INSTS_VALU per launch over the launch's duration) --
     # not from a per-bin constant: a launch's lanes carry 0 .. ~25 000 bins each and a wave runs as long as its longest lane, so "instructions per bin" is not a

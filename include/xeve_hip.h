@@ -68,6 +68,9 @@ int         xeve_hip_sizeof(int i);
 #define XEVE_HIP_PROF_CLASSES 8
 int         xeve_hip_prof_enable(int class_mask);
 int         xeve_hip_prof_read(double *ms, uint64_t *launches, uint64_t *units, int n);
+/* bins-per-job histogram of the CABAC bit-count launches that ran with their class timer on: out[b] (32 entries) = jobs whose bin count has bit length b (0: no bin, 1: one,
+ * 2: 2-3, 3: 4-7, ...); reset != 0 clears it.  Measurement only. */
+int         xeve_hip_prof_cu_bits_hist(unsigned long long *out, int reset);
 
 /* ------------------------------------------------------------------------------------------- */
 /* (1) drop-in dispatch tables                                                                 */

@@ -556,6 +556,27 @@ __device__ __forceinline__ void sbac_load(Sbac &s, const xeve_hip_sbac &in, CtxT
     s_ctx[BYP][lane] = 0;
 }
 
+__device__ unsigned long long g_bins_hist[16 * 32]; // (16 stripes of 32 buckets: same-address atomics of thousands of lanes serialise)
+// bins-per-job histogram of every k_cu_bits launch that ran with the class timer on (xeve_hip_prof_enable): out[b] = jobs whose bin count has bit length b (b = 0: no bin);
+// reset != 0 clears it.  Measurement only.
+extern "C" int xeve_hip_prof_cu_bits_hist(unsigned long long *out, int reset)
+{
+    XH_ENTER();
+    unsigned long long h[16 * 32];
+    XH_HIP(hipDeviceSynchronize());
+    XH_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bins_hist), sizeof(h)));
+    if(out)
+        for(int b = 0; b < 32; b++) {
+            out[b] = 0;
+            for(int s = 0; s < 16; s++) out[b] += h[s * 32 + b];
+        }
+    if(reset) {
+        memset(h, 0, sizeof(h));
+        XH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bins_hist), h, sizeof(h)));
+    }
+    return XEVE_HIP_OK;
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict__ sin, const xeve_hip_cu_bits_job *__restrict__ jobs, int njobs, CuBitsK P,
                                                 const unsigned char *__restrict__ bins, const unsigned *__restrict__ ev, unsigned *__restrict__ bits,
@@ -583,6 +604,10 @@ __global__ __launch_bounds__(64) void k_cu_bits(const xeve_hip_sbac *__restrict_
     for(int c = 0; c < 3; c++)
         if((coded >> c) & 1) code_block<FULL>(s, s_ctx, lane, bins, ev, J.coef_off[c], J.nnz[c], c, P.cm_init, slow);
     bits[j] = s.shifts;
+    if(units) { // measurement only: the lane's bins into the histogram of bins per job (bucket = bit length of the count: 0, 1, 2-3, 4-7, ...; xeve_hip_prof_cu_bits_hist)
+        const unsigned nb = s.bins - (cont ? in.bin_counter : 0u);
+        atomicAdd(&g_bins_hist[((blockIdx.x & 15) << 5) + (nb ? 32 - __clz(nb) : 0)], 1ull);
+    }
     if(units) { // measurement only (xeve_hip_prof_*): bins coded by this wave (lanes may have left: the sum goes through one LDS word)
         unsigned *cnt = reinterpret_cast<unsigned *>(&s_q[0][0]);
         const bool first = lane == (int)(__ffsll((long long)__ballot(true)) - 1);

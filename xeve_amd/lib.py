@@ -238,6 +238,7 @@ FUNCTIONS = {
     "xeve_hip_resident_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_prof_enable": (c_int, [c_int]),
     "xeve_hip_prof_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "xeve_hip_prof_cu_bits_hist": (c_int, [c_void_p, c_int]),
     "xeve_hip_inter_candidates": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "xeve_hip_pinter_analyze_cu_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 14),
     "xeve_hip_me_epzs_jobs_x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -331,6 +332,15 @@ def prof_enable(classes=PROF_CLASSES):
     for c in classes or ():
         mask |= 1 << PROF_CLASSES.index(c)
     check(load().xeve_hip_prof_enable(mask))
+
+
+def prof_cu_bits_hist(reset=False):
+    """{bucket label: jobs} -- the bins-per-job histogram of the CABAC bit-count launches that ran with their class timer on (xeve_hip_prof_cu_bits_hist)"""
+    h = (C.c_uint64 * 32)()
+    check(load().xeve_hip_prof_cu_bits_hist(h, 1 if reset else 0))
+    lab = lambda b: "0" if b == 0 else "1" if b == 1 else "%d-%d" % (1 << (b - 1), (1 << b) - 1)
+    top = max([b for b in range(32) if h[b]] or [0])
+    return {lab(b): int(h[b]) for b in range(top + 1)}
 
 
 def prof_read():
