@@ -136,9 +136,15 @@ template <bool WAVE> __global__ void __launch_bounds__(64) k_enc_write(const xev
     const xeve_hip_ctu_job J = jobs[c];
     xl::Sbac s;
     sbac_in(s, states + J.sbac);
+    // cap == 0 (a second writer pass follows: the bytes of this one are dropped): what the pass leaves is the next CTU's ENTRY STATE, and every reader of that -- the walk's
+    // bit counts (xeve_sbac_bit_reset, xeve_mode.c:39-49), this writer's next CTU -- keeps the range and the context models of it and nothing else.  A code-bit count that no
+    // shift can exhaust switches the coder's byte output off (sb_shift / sb_shift_n, cu_lane.h: the boundary branch is never taken), the register fields are then
+    // normalised so that the record does not depend on how the bins fell
+    if(!cap) s.code_bits = 0x3FFFFFFFu;
     const int at = cap ? pos[J.pic] : 0;
     xl::Sink o = {cap ? bytes + (long)J.pic * cap + at : nullptr, cap ? (int)(cap - at) : 0, 0};
     xl::eco_ctu<WAVE>(E, s, ctus[c], map_scu + J.pic * map_pic, map_ipm + J.pic * map_pic, map_tidx + J.pic * map_pic, map_cu_mode + J.pic * map_pic, J.x, J.y, &o);
+    if(!cap) s.code = 0, s.code_bits = 11, s.stacked_ff = s.stacked_zero = s.pending_byte = s.is_pending_byte = 0, s.bitcounter = 0;
     sbac_out(states + J.sbac, s);
     if(cap) pos[J.pic] = at + o.n;
 }
