@@ -7,8 +7,8 @@
 THE JOB (per GPU) is a real encode: independent closed GOPs of F = 8 frames each (1 IDR + 7 hierarchical B pictures: what `xeveb_app --preset medium --closed-gop -I 8 -m 8`
 codes), in --batches batches side by side (a batch ends at 2^32 original samples; the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames
 resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h): CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ,
-CABAC bit counts -- the composed walk's ~10 000 launches per lockstep CTU step at this width, ONE fused kernel per step for batches of up to 1024 chains or with --walk fused:
-xeve_amd/csrc/walk.h, profiles/r04_walks.md), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
+CABAC bit counts -- the composed walk's ~7 000 / ~11 000 launches per lockstep CTU step of an I / B picture on two streams (tree.hip; the library's choice at every width
+since round 6), ONE fused kernel per step with --walk fused or presets slow / placebo: xeve_amd/csrc/walk.h), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
 
 BOUNDED.  A whole 8-frame 3840x2160 job is 8 x 302 lockstep steps of a few hundred ms each whatever the batch size (a CTU's mode decision is a serial chain; the width is in
 the GOPs) -- a quarter of an hour.  The bench therefore runs the job's first --pictures pictures in coding order (default 3: the IDR picture and the first two B
@@ -413,7 +413,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                    "workload": "%s: the first %d of %d pictures of %d batches of %s closed GOPs x %d frames per GPU, %dx%d Baseline preset %s (xeveb_app --preset %s --closed-gop "
                                "-I 8 -m %d semantics), i.i.d. uniform 8-bit 4:2:0 input resident in HBM, QP 32; %d lockstep CTU steps cut into %d + %d equal slices"
                                % (label, P, F, B, "+".join(str(g) for g in Gs), F, W, H, a.preset, a.preset, T, run_steps, a.warmup, a.steps),
-                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~10 000 launches per step)" for f in fused],
+                   "walk": ["fused (one k_walk launch per step)" if f else "composed (~7 000 / ~11 000 launches per I / B step, on two streams)" for f in fused],
                    "walk_choice": "presets slow and placebo run on the fused walk at any width (rdo_dbk_switch, 4x4 inter CUs: xh_common.h xh_walk_only)" if a.preset in ("slow", "placebo") else
                                   "pinned by --walk / XEVE_HIP_WALK" if os.environ.get("XEVE_HIP_WALK") in ("0", "1") else
                                   "the library's choice (walk.hip: since round 6 the composed walk at every width -- with its side stream it finishes a step sooner than the fused kernel "
