@@ -1003,6 +1003,12 @@ typedef struct xeve_hip_affine_job {
  * pred[0][Y_C / U_C / V_C].  w, h: powers of two, 8 .. 128. */
 int xeve_hip_affine_mc_jobs(const xeve_hip_refpic *refp, int num_refp0, int num_refp1, int s_l, int s_c, int pic_w, int pic_h, const xeve_hip_affine_job *jobs, int njobs,
                             int w, int h, int bit_depth, xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, void *stream);
+/* Host-memory form of ONE xeve_affine_mc call with the reference's arguments (src_main/xevem_mc.h:106-120): refi / mv as the encoder holds them, refp = HOST table
+ * [refi * 2 + list] of HOST planes (sample (0, 0), padded by pad_l / pad_c samples), pred_* = HOST blocks (pred[0][Y_C / U_C / V_C]).  Synchronous.  What the Main encoder's
+ * by-name calls of xeve_affine_mc are routed to in situ (oracle/ref_shim_affine.c). */
+int xeve_hip_affine_mc_host(int x, int y, int pic_w, int pic_h, int w, int h, const int8_t refi[2], const int16_t mv[2][3][2], const xeve_hip_refpic *refp, int num_refp0,
+                            int num_refp1, int s_l, int s_c, int pad_l, int pad_c, xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, int vertex_num,
+                            int bit_depth);
 
 #ifdef __cplusplus
 }

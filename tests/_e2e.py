@@ -110,6 +110,7 @@ MAIN_ALF_CASES = {
     "main_alf_noise_q37": (128, 128, 3, 11, ["--profile", "main", "--preset", "fast", "-I", "0", "-b", "0", "-q", "37"]),
 }
 SHIM_ALF = os.path.join(ROOT, "oracle", "_ref", "libxeve_hip_shim_alf.so")
+SHIM_AFFINE = os.path.join(ROOT, "oracle", "_ref", "libxeve_hip_shim_affine.so")  # xeve_affine_mc, called by name, forwarded to xeve_hip_affine_mc_host (oracle/ref_shim_affine.c)
 
 
 def run_app_main(yuv, out, w, h, frames, extra, hip=False, timeout=1500, shim=None, env_extra=None):

@@ -111,3 +111,41 @@ def test_hip_affine_mc_matches_oracle_and_goldens(size, hip_affine):
     Y, U, V = check(hip_affine, w, h)
     a = A.OracleAffine().run(pics(), A.make_jobs(w, h, 7 + w + h), w, h)
     assert np.array_equal(Y, a[0]) and np.array_equal(U, a[1]) and np.array_equal(V, a[2])
+
+
+class HipAffineHost:
+    """xeve_hip_affine_mc_host: ONE CU per call with the reference's arguments and HOST planes (what oracle/ref_shim_affine.c routes the Main encoder's by-name calls of
+    xeve_affine_mc to); the table names the pictures the CU uses and nothing else, as the shim's does"""
+    name = "hip_host"
+
+    def __init__(self):
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        self.L, self.check = lib.load(), lib.check
+
+    def run(self, pics_, jobs, w, h):
+        s_l, s_c = A.strides(pics_)
+        n = len(jobs)
+        Y, U, V = np.full((n, h, w), -1, np.int16), np.full((n, h // 2, w // 2), -1, np.int16), np.full((n, h // 2, w // 2), -1, np.int16)
+        for i, j in enumerate(jobs):
+            tab = np.zeros(len(pics_) * 2, A.REFPIC)
+            nr = [0, 0]
+            for l in range(2):
+                r = int(j["refi"][l])
+                if r >= 0:
+                    comps = pics_[r][l]
+                    tab[r * 2 + l] = (A.plane_ptr(comps[0], 0), A.plane_ptr(comps[1], 1), A.plane_ptr(comps[2], 2), 8 * r + l, 0)
+                    nr[l] = r + 1
+            refi, mv = np.ascontiguousarray(j["refi"]), np.ascontiguousarray(j["mv"])
+            self.check(self.L.xeve_hip_affine_mc_host(int(j["x"]), int(j["y"]), A.PIC_W, A.PIC_H, w, h, refi.ctypes.data, mv.ctypes.data, tab.ctypes.data, nr[0], nr[1], s_l, s_c,
+                                                      A.PAD, A.PAD // 2, Y[i].ctypes.data, U[i].ctypes.data, V[i].ctypes.data, int(j["vertex_num"]), A.BD))
+        return Y, U, V, None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(8, 8), (64, 64), (16, 8), (32, 128)], ids=["8x8", "64x64", "16x8", "32x128"])
+def test_hip_affine_mc_host_form_matches_the_goldens(size):
+    """the per-call host form (round 6) over the same jobs: list 0 alone, list 1 alone, both; every path"""
+    check(HipAffineHost(), *size)

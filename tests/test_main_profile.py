@@ -10,7 +10,7 @@ import re
 import numpy as np
 import pytest
 
-from _e2e import MAIN_ALF_CASES, MAIN_APP, MAIN_CASES, SHIM_ALF, SHIM_MAIN, make_yuv, run_app_main
+from _e2e import MAIN_ALF_CASES, MAIN_APP, MAIN_CASES, SHIM_AFFINE, SHIM_ALF, SHIM_MAIN, make_yuv, run_app_main
 from _main_cases import HIP_NAMES, OracleMain, TableMain, check_golden, run_all
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_main_v1.json")))
@@ -121,3 +121,43 @@ def test_main_bitstream_identical_with_the_alf_kernels_on_the_gpu(tmp_path, name
     how, (ncls, n7, n5, nst) = _alf_counts(err)
     assert how == "served by HIP" and ncls >= 48 and n7 >= 4 and nst >= 48
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the ALF kernels on the GPU"
+
+
+def _affine_counts(err):
+    m = re.search(r"xeve_affine_mc calls ([^:]+): (\d+) \(of (\d+)\)", err)
+    assert m, err
+    return m.group(1), int(m.group(2)), int(m.group(3))
+
+
+AFFINE_CLIPS = {**MAIN_CASES, **MAIN_ALF_CASES}  # (tool_affine is a Main default: every Main clip of the suite calls xeve_affine_mc a thousand times or more)
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(SHIM_AFFINE), reason="oracle/_ref/libxeve_hip_shim_affine.so not built")
+@pytest.mark.parametrize("name", sorted(AFFINE_CLIPS))
+def test_the_main_clips_reach_affine_motion_compensation(tmp_path, name):
+    """(cpu) the interposer in its count-only mode: the reference's own xeve_affine_mc, counted -- the clips the GPU test runs do predict affine CUs"""
+    w, h, n, seed, extra = AFFINE_CLIPS[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim=SHIM_AFFINE, env_extra={"XEVE_HIP_SHIM_AFFINE_COUNT": "1"})
+    how, served, calls = _affine_counts(err)
+    assert "reference" in how and calls >= 900 and served == calls
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIM_AFFINE), reason="oracle/_ref/libxeve_hip_shim_affine.so not built")
+@pytest.mark.parametrize("name", sorted(AFFINE_CLIPS))
+def test_main_bitstream_identical_with_affine_motion_compensation_on_the_gpu(tmp_path, name):
+    """round 6 (first half): the UNMODIFIED Main-profile encoder with every xeve_affine_mc call -- the affine merge candidates, every round of the affine
+    gradient search, the affine bi-prediction (xevem_pinter.c:1947, 4659, 4918) -- served by xeve_hip_affine_mc_host (oracle/ref_shim_affine.c interposes the symbol): the
+    affine search around it stays the reference's and decides from the GPU's predictions -- the same bitstream"""
+    w, h, n, seed, extra = AFFINE_CLIPS[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, shim=SHIM_AFFINE, timeout=900)
+    how, served, calls = _affine_counts(err)
+    assert how == "served by HIP" and served == calls and calls >= 900
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with affine motion compensation on the GPU"

@@ -121,3 +121,55 @@ extern "C" int xeve_hip_affine_mc_jobs(const xeve_hip_refpic *refp, int num_refp
     XH_HIP(hipGetLastError());
     return XEVE_HIP_OK;
 }
+
+// ---- host-memory form of ONE xeve_affine_mc call (src_main/xevem_mc.c:2236-2339): what the Main-profile encoder's by-name calls can be routed to (the affine merge
+// analysis, every round of the affine gradient search, the affine bi-prediction: xevem_pinter.c:1947, 4659, 4918 -- oracle/ref_shim_affine.c does).
+// refp: table [refi * 2 + list] of HOST plane pointers (sample (0, 0)) of the pictures the CU uses; the planes extend pad_l / pad_c samples around the picture; pred_y /
+// pred_u / pred_v: HOST blocks of w * h and (w / 2) * (h / 2) samples, what the reference leaves in pred[0][Y_C / U_C / V_C].  Per calling thread one stream and one device
+// arena (grow-only): a call is the upload of the (at most two) pictures it uses, one launch, the download of three blocks.
+extern "C" int xeve_hip_affine_mc_host(int x, int y, int pic_w, int pic_h, int w, int h, const int8_t refi[2], const int16_t mv[2][3][2], const xeve_hip_refpic *refp,
+                                       int num_refp0, int num_refp1, int s_l, int s_c, int pad_l, int pad_c, xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v,
+                                       int vertex_num, int bit_depth)
+{
+    XH_ENTER();
+    XH_REQUIRE(refi && mv && refp && pred_y && pred_u && pred_v && (vertex_num == 2 || vertex_num == 3) && pad_l >= 0 && pad_c >= 0 && s_l > 0 && s_c > 0 && pic_w > 0 && pic_h > 0);
+    XH_REQUIRE(num_refp0 >= 0 && num_refp1 >= 0 && num_refp0 <= MAXREF && num_refp1 <= MAXREF && (refi[0] < 0 || refi[0] < num_refp0) && (refi[1] < 0 || refi[1] < num_refp1) &&
+               (refi[0] >= 0 || refi[1] >= 0));
+    const size_t el = (size_t)s_l * (pic_h + 2 * pad_l), ec = (size_t)s_c * ((pic_h >> 1) + 2 * pad_c), ol = (size_t)pad_l * s_l + pad_l, oc = (size_t)pad_c * s_c + pad_c;
+    const size_t n0 = (size_t)w * h, n1 = n0 >> 2, plane = (el + 2 * ec) * sizeof(pel), o_planes = 256, o_pred = o_planes + 2 * ((plane + 255) & ~(size_t)255);
+    static thread_local XhHostArena A;
+    const int rc0 = A.ensure(o_pred + (n0 + 2 * n1) * sizeof(pel), 0);
+    if(rc0 != XEVE_HIP_OK) return rc0;
+    xeve_hip_affine_job J;
+    memset(&J, 0, sizeof(J));
+    J.x = x, J.y = y, J.vertex_num = (int8_t)vertex_num;
+    xeve_hip_refpic tab[2 * MAXREF];
+    memset(tab, 0, sizeof(tab));
+    pel *first = nullptr;
+    for(int l = 0; l < 2; l++) {
+        J.refi[l] = refi[l];
+        for(int v = 0; v < 3; v++) J.mv[l][v][0] = mv[l][v][0], J.mv[l][v][1] = mv[l][v][1];
+        if(refi[l] < 0) continue;
+        const xeve_hip_refpic &src = refp[refi[l] * 2 + l];
+        XH_REQUIRE(src.y && src.u && src.v);
+        pel *d = (pel *)(A.dev + o_planes + (size_t)l * ((plane + 255) & ~(size_t)255));
+        XH_HIP(hipMemcpyAsync(d, src.y - ol, el * sizeof(pel), hipMemcpyHostToDevice, A.st));
+        XH_HIP(hipMemcpyAsync(d + el, src.u - oc, ec * sizeof(pel), hipMemcpyHostToDevice, A.st));
+        XH_HIP(hipMemcpyAsync(d + el + ec, src.v - oc, ec * sizeof(pel), hipMemcpyHostToDevice, A.st));
+        if(!first) first = d;
+        // every picture index a list is asked to hold must be addressable: all of them alias the staged one (the job names refi[l] alone)
+        for(int r = 0; r < (l ? num_refp1 : num_refp0); r++) tab[r * 2 + l].y = d + ol, tab[r * 2 + l].u = d + el + oc, tab[r * 2 + l].v = d + el + ec + oc, tab[r * 2 + l].poc = src.poc;
+    }
+    for(int l = 0; l < 2; l++) // (a list the CU does not use: valid pointers for the table's check, never read)
+        if(refi[l] < 0)
+            for(int r = 0; r < (l ? num_refp1 : num_refp0); r++) tab[r * 2 + l].y = first + ol, tab[r * 2 + l].u = first + el + oc, tab[r * 2 + l].v = first + el + ec + oc;
+    XH_HIP(hipMemcpyAsync(A.dev, &J, sizeof(J), hipMemcpyHostToDevice, A.st));
+    pel *dp = (pel *)(A.dev + o_pred);
+    const int rc = xeve_hip_affine_mc_jobs(tab, num_refp0, num_refp1, s_l, s_c, pic_w, pic_h, (const xeve_hip_affine_job *)A.dev, 1, w, h, bit_depth, dp, dp + n0, dp + n0 + n1, A.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    XH_HIP(hipMemcpyAsync(pred_y, dp, n0 * sizeof(pel), hipMemcpyDeviceToHost, A.st));
+    XH_HIP(hipMemcpyAsync(pred_u, dp + n0, n1 * sizeof(pel), hipMemcpyDeviceToHost, A.st));
+    XH_HIP(hipMemcpyAsync(pred_v, dp + n0 + n1, n1 * sizeof(pel), hipMemcpyDeviceToHost, A.st));
+    XH_HIP(hipStreamSynchronize(A.st));
+    return XEVE_HIP_OK;
+}
