@@ -139,7 +139,50 @@ __device__ static unsigned split_flag_bits(const SbacState &from, SbacState &to,
     return s.bitcounter + 8 * (s.stacked_zero + s.stacked_ff) + 8 * (s.is_pending_byte ? 1 : 0) + 8 - s.code_bits + 3;
 }
 
+// the same on the state where it lies: only the coder's registers and the one model change (round 6: the operations below move a state with all lanes of the block and
+// thread 0 touches these ten words -- a 180-byte copy in, the bin, a 180-byte copy out by one lane were three dependent round trips to HBM per call)
+__device__ static unsigned split_flag_inplace(SbacState *st, int split)
+{
+    SbacState s;
+    s.range = st->range, s.code = st->code & 0x7FFFF, s.code_bits = 11;
+    s.pending_byte = s.is_pending_byte = s.stacked_ff = s.stacked_zero = s.bitcounter = s.bin_counter = 0;
+    const unsigned m = st->ctx[XEVE_HIP_CTX_SPLIT_CU];
+    unsigned state = m >> 1, mps = m & 1;
+    unsigned lps = (state * s.range) >> 9;
+    if(lps < 437) lps = 437;
+    s.bin_counter++;
+    s.range -= lps;
+    if((unsigned)(split != 0) != mps) {
+        if(s.range >= lps) s.code += s.range, s.range = lps;
+        state = state + ((512 - state + 16) >> 5);
+        if(state > 256) mps = 1 - mps, state = 512 - state;
+    }
+    else state = state - ((state + 16) >> 5);
+    while(s.range < 8192) s.range <<= 1, bc_shift(s);
+    st->range = s.range, st->code = s.code, st->code_bits = s.code_bits, st->stacked_ff = s.stacked_ff, st->stacked_zero = s.stacked_zero, st->pending_byte = s.pending_byte;
+    st->is_pending_byte = s.is_pending_byte, st->bitcounter = s.bitcounter, st->bin_counter = s.bin_counter;
+    st->ctx[XEVE_HIP_CTX_SPLIT_CU] = (uint16_t)((state << 1) + mps);
+    return s.bitcounter + 8 * (s.stacked_zero + s.stacked_ff) + 8 * (s.is_pending_byte ? 1 : 0) + 8 - s.code_bits + 3;
+}
+
 // ---- block-cooperative pieces (every thread of the workgroup calls them with the same arguments) ---------------------------------------------------------------
+static_assert(sizeof(SbacState) % 4 == 0, "coder states are moved word by word");
+// a coder state moved by all lanes (word i by the lane(s) with i = threadIdx.x mod blockDim.x); two destinations at once where a state is kept twice
+__device__ static void st_copy(SbacState *dst, const SbacState *src, SbacState *dst2 = nullptr)
+{
+    const unsigned *a = (const unsigned *)src;
+    unsigned       *b = (unsigned *)dst, *b2 = (unsigned *)dst2;
+    for(int i = threadIdx.x; i < (int)(sizeof(SbacState) / 4); i += blockDim.x) {
+        const unsigned v = a[i];
+        b[i] = v;
+        if(b2) b2[i] = v;
+    }
+}
+__device__ static void st_zero(SbacState *dst)
+{
+    unsigned *b = (unsigned *)dst;
+    for(int i = threadIdx.x; i < (int)(sizeof(SbacState) / 4); i += blockDim.x) b[i] = 0;
+}
 __device__ static void cud_init(CtuData *d, int log2)
 {   // init_cu_data (:374-428): what the I-slice walk reads back -- split modes and luma / chroma modes cleared
     const int n = 1 << (2 * (log2 - 2));
@@ -227,36 +270,13 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
     const int log2 = L + 2, cu = 1 << log2;
     if(threadIdx.x == 0) {
         int active, x0, y0;
-        if(part < 0) {
-            active = 1, x0 = J.x, y0 = J.y;
-            *AT(K.curr, L) = K.states[J.sbac];
-        }
+        if(part < 0) active = 1, x0 = J.x, y0 = J.y;
         else {
             const Node *p = AT(K.node, L + 1);
             x0 = p->x0 + (part & 1) * cu, y0 = p->y0 + (part >> 1) * cu;
             active = p->active && p->do_split && x0 < K.pic_w && y0 < K.pic_h;
-            if(active) *AT(K.curr, L) = part == 0 ? *AT(K.csplit, L + 1) : *AT(K.next, L); // the state the previous quadrant's winner left (:2248-2262)
         }
-        int leaf = 0, boundary = 0;
-        if(active) {
-            boundary = !(x0 + cu <= K.pic_w && y0 + cu <= K.pic_h);
-            leaf = !boundary && cu <= K.max_cu;
-            *AT(K.before, L) = *AT(K.curr, L);
-            memset(AT(K.tdepth, L), 0, sizeof(SbacState));
-            nd->cost_best = MAX_COST, nd->best_split = 0, nd->do_split = 0, nd->dist_cu = 0;
-            double cost_temp = 0.0;
-            if(!boundary) {
-                if(leaf) {
-                    if(cu > K.min_cuwh) { // split_cu_flag = 0 (:2079-2091)
-                        SbacState run;
-                        cost_temp += (double)(int)split_flag_bits(*AT(K.curr, L), run, 0) * K.lambda0;
-                        *AT(K.curr, L) = run;
-                    }
-                }
-                else cost_temp = MAX_COST;
-            }
-            nd->cost_temp = cost_temp;
-        }
+        const int boundary = active && !(x0 + cu <= K.pic_w && y0 + cu <= K.pic_h), leaf = active && !boundary && cu <= K.max_cu;
         nd->active = active, nd->x0 = x0, nd->y0 = y0, nd->leaf = leaf;
         // a chain whose node is off analyses a CU of this size that lies inside the picture (the schedule runs no analysis of a size the picture cannot hold)
         const int jx = leaf ? x0 : max(0, min(J.x, K.pic_w - cu)), jy = leaf ? y0 : max(0, min(J.y, K.pic_h - cu));
@@ -277,8 +297,26 @@ __device__ static void op_enter(const TreeK &K, int c, int L, int part, int *sh)
     }
     __syncthreads();
     const int active = sh[0], leaf = sh[1], boundary = sh[2], x0 = sh[3], y0 = sh[4];
+    if(active) { // the node's entry state: the caller's (root), the one behind the parent's split flag (first quadrant), what the previous quadrant's winner left (:2248-2262);
+                 // kept twice (s_curr_best / s_curr_before_split, :2061); s_temp_depth cleared (:2031)
+        const SbacState *src = part < 0 ? K.states + J.sbac : part == 0 ? AT(K.csplit, L + 1) : AT(K.next, L);
+        st_copy(AT(K.curr, L), src, AT(K.before, L));
+        st_zero(AT(K.tdepth, L));
+    }
     __syncthreads();
-    if(active && !boundary) cud_init(AT(K.temp, L), log2);
+    if(threadIdx.x == 0 && active) {
+        nd->cost_best = MAX_COST, nd->best_split = 0, nd->do_split = 0, nd->dist_cu = 0;
+        double cost_temp = 0.0;
+        if(!boundary) {
+            if(leaf) {
+                if(cu > K.min_cuwh) cost_temp += (double)(int)split_flag_inplace(AT(K.curr, L), 0) * K.lambda0; // split_cu_flag = 0 (:2079-2091)
+            }
+            else cost_temp = MAX_COST;
+        }
+        nd->cost_temp = cost_temp;
+    }
+    // the node's own CU is staged straight into cu_data_best (round 6: it went through cu_data_temp and was copied: the unsplit alternative is always the first one stored)
+    if(active && !boundary) cud_init(AT(K.best, L), log2);
     if(leaf) clear_map(K, J.pic, x0, y0, cu);
 }
 
@@ -309,7 +347,7 @@ __device__ static void op_mid(const TreeK &K, int c, int L)
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
     const TreeK::Ac &A = K.ac[K.side_of[L]];
     const xeve_hip_inter_result R = A.eres[c];
-    unit_to_temp(K, AT(K.temp, L), log2, cud, n, R.cu_mode, nullptr, R.nnz, &A.eres[c], A.ecoef + (long)c * n0, A.ecoef + (long)K.nchains * n0 + (long)c * n1,
+    unit_to_temp(K, AT(K.best, L), log2, cud, n, R.cu_mode, nullptr, R.nnz, &A.eres[c], A.ecoef + (long)c * n0, A.ecoef + (long)K.nchains * n0 + (long)c * n1,
                  A.ecoef + (long)K.nchains * (n0 + n1) + (long)c * n1, A.erec[0] + (long)c * n0, A.erec[1] + (long)c * n1, A.erec[2] + (long)c * n1, n0, n1);
     if(threadIdx.x == 0) {
         nd->unit_cost = R.cost, nd->cu_mode = R.cu_mode;
@@ -326,31 +364,29 @@ __device__ static void leaf_decide(const TreeK &K, int c, int L, int *sh, bool t
     const xeve_hip_ctu_job J = K.jobs[c];
     Node *nd = AT(K.node, L);
     const int log2 = L + 2, cu = 1 << log2, cud = 2 * (K.log2_ctu - log2), n = 1 << (2 * L), n0 = cu * cu, n1 = K.idc ? n0 >> (K.ws + K.hs) : 0;
-    CtuData *t = AT(K.temp, L), *b = AT(K.best, L);
+    CtuData *b = AT(K.best, L);
     const TreeK::Ac &A = K.ac[K.side_of[L]];
     const xeve_hip_intra_result R = A.ires[c];
     const int intra_wins = !K.inter || (nd->try_intra && R.cost < nd->unit_cost);
-    if(intra_wins)
-        unit_to_temp(K, t, log2, cud, n, 0, R.ipm, R.nnz, nullptr, A.icoef + (long)c * n0, A.icoef + (long)K.nchains * n0 + (long)c * n1,
+    if(intra_wins) // (over the inter winner op_mid left there)
+        unit_to_temp(K, b, log2, cud, n, 0, R.ipm, R.nnz, nullptr, A.icoef + (long)c * n0, A.icoef + (long)K.nchains * n0 + (long)c * n1,
                      A.icoef + (long)K.nchains * (n0 + n1) + (long)c * n1, A.irec + (long)c * n0, A.irec + (long)K.nchains * n0 + (long)c * n1,
                      A.irec + (long)K.nchains * (n0 + n1) + (long)c * n1, n0, n1);
-    __syncthreads();
     if(threadIdx.x == 0) {
         if(intra_wins) nd->unit_cost = R.cost, nd->cu_mode = 0, nd->dist_cu = R.dist_cu;
         else nd->dist_cu = 0x7FFFFFFF;
         const double cost_temp = nd->cost_temp + nd->unit_cost;
         sh[0] = nd->cost_best > cost_temp;
-        if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0, *AT(K.tdepth, L) = intra_wins ? A.sbest[c] : A.enext[c]; // (:2116-2135)
+        if(sh[0]) nd->cost_best = cost_temp, nd->best_split = 0; // (:2116-2135)
         nd->cost_temp = nd->cost_best;
     }
-    __syncthreads();
+    __syncthreads(); // (also: the CU's blocks above are in cu_data_best for every thread)
     const int better = sh[0];
-    __syncthreads();
     if(better) {
-        cud_copy(b, t, 0, 0, log2, log2, cud, K.idc, K.ws, K.hs);
-        __syncthreads();
+        st_copy(AT(K.tdepth, L), intra_wins ? A.sbest + c : A.enext + c);
         if(to_pic) rec_to_pic(K, J.pic, b, nd->x0, nd->y0, cu);
     }
+    __syncthreads();
 }
 // the early terminations behind the unsplit alternative (:2162-2187): 0 = the node is not split whatever its children would cost
 __device__ static int leaf_next_split(const TreeK &K, const Node *nd, int L)
@@ -455,11 +491,13 @@ __device__ static void op_exit(const TreeK &K, int c, int L, int *sh)
     if(threadIdx.x == 0) {
         const double cost_split = side ? nd->cost_split : nd->cost_temp;
         sh[0] = nd->do_split && (!side || nd->next_split) && nd->cost_best - 0.0001 > cost_split;
-        if(sh[0]) nd->cost_best = cost_split, nd->best_split = 5 /* SPLIT_QUAD */, *AT(K.tdepth, L) = *AT(K.next, L - 1);
-        *AT(K.next, L) = *AT(K.tdepth, L);
+        if(sh[0]) nd->cost_best = cost_split, nd->best_split = 5 /* SPLIT_QUAD */;
     }
     __syncthreads();
     const int split_wins = sh[0];
+    // s_temp_depth = the last quadrant's exit state where the split wins; s_next_best of the node = s_temp_depth (a lane re-reads the word it wrote itself)
+    if(split_wins) st_copy(AT(K.tdepth, L), AT(K.next, L - 1));
+    st_copy(AT(K.next, L), AT(K.tdepth, L));
     __syncthreads();
     CtuData *b = AT(K.best, L);
     if(split_wins) {
