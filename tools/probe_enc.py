@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many lockstep steps (0: the whole job)")
     ap.add_argument("--content", default="noise")
     ap.add_argument("--preset", default="medium", help="fast | medium | slow | placebo (slow and placebo run on the fused walk at any width)")
+    ap.add_argument("--same-clip", action="store_true", help="every GOP codes the SAME frames: all bitstreams must come out equal -- a lockstep chain that goes wrong anywhere in the batch shows as a second md5")
     ap.add_argument("--prof-after", type=int, default=-1, help="switch the walk's in-kernel stage profile on once this many steps are done (e.g. a picture's steps: the inter picture alone)")
     a = ap.parse_args()
     import torch
@@ -38,8 +39,11 @@ def main():
     enc = encode.BatchEncoder(cfg, G, F)
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
+    same = None
     for g in range(G):
-        if a.content == "noise":
+        if a.same_clip and same is not None:
+            d = same
+        elif a.content == "noise":
             d = torch.randint(0, 256, (fb * F,), dtype=torch.uint8, device=dev, generator=gen)
         else:  # a drifting gradient + 3 bits of noise (SURVEY.md 8d's structured input)
             parts = []
@@ -50,6 +54,7 @@ def main():
                 parts.append((((xx + f) * 3 + yy + torch.randint(0, 4, (H // 2, W // 2), device=dev, generator=gen)) & 255).to(torch.uint8).reshape(-1))
                 parts.append(((xx + (yy + 2 * f) * 2 + torch.randint(0, 4, (H // 2, W // 2), device=dev, generator=gen)) & 255).to(torch.uint8).reshape(-1))
             d = torch.cat(parts)
+        same = d
         for f in range(F):
             enc.push(g, f, d[f * fb:(f + 1) * fb])
     print(json.dumps({"setup_s": round(time.perf_counter() - t0, 2)}), flush=True)
@@ -83,7 +88,8 @@ def main():
                 print("  %-12s %6.2f %%  %12d cycles  %7d marks  %8.0f cycles/mark" % (name, 100.0 * cyc / tot, cyc, marks, cyc / marks))
     print(json.dumps({"total_steps": total, "per_picture": per_pic, "chains": G * min(a.threads, (H + 63) // 64), "stats": enc.stats(),
                       "bytes": [len(s) for s in enc.bitstreams()][:4] if left == 0 else None,
-                      "md5_of_all": hashlib.md5(b"".join(enc.bitstreams())).hexdigest() if left == 0 else None}), flush=True)
+                      "md5_of_all": hashlib.md5(b"".join(enc.bitstreams())).hexdigest() if left == 0 else None,
+                      "distinct_bitstreams": (lambda m: {"count": len(set(m)), "gops_that_differ_from_gop_0": [i for i, x in enumerate(m) if x != m[0]][:40]})([hashlib.md5(b).hexdigest() for b in enc.bitstreams()]) if left == 0 and a.same_clip else None}), flush=True)
     enc.close()
 
 

@@ -372,6 +372,7 @@ __device__ static void leaf_decide(const TreeK &K, int c, int L, int *sh, bool t
         unit_to_temp(K, b, log2, cud, n, 0, R.ipm, R.nnz, nullptr, A.icoef + (long)c * n0, A.icoef + (long)K.nchains * n0 + (long)c * n1,
                      A.icoef + (long)K.nchains * (n0 + n1) + (long)c * n1, A.irec + (long)c * n0, A.irec + (long)K.nchains * n0 + (long)c * n1,
                      A.irec + (long)K.nchains * (n0 + n1) + (long)c * n1, n0, n1);
+    __syncthreads(); // (every wave has read nd->unit_cost for intra_wins above before thread 0 moves it below: a block of four waves, levels 32x32 and 64x64)
     if(threadIdx.x == 0) {
         if(intra_wins) nd->unit_cost = R.cost, nd->cu_mode = 0, nd->dist_cu = R.dist_cu;
         else nd->dist_cu = 0x7FFFFFFF;
