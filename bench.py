@@ -8,7 +8,7 @@ THE JOB (per GPU) is a real encode: independent closed GOPs of F = 8 frames each
 codes), in --batches batches side by side (a batch ends at 2^32 original samples; the others as large as HBM still allows), of synthetic i.i.d. uniform 8-bit 4:2:0 frames
 resident in HBM before the clock starts, coded by xeve_hip_enc_* (include/xeve_hip.h): CTU mode decision (quad-tree, intra + inter analysis with motion search, RDOQ,
 CABAC bit counts -- the composed walk's ~7 000 / ~11 000 launches per lockstep CTU step of an I / B picture on two streams (tree.hip; the library's choice at every width
-since round 6), ONE fused kernel per step with --walk fused or presets slow / placebo: xeve_amd/csrc/walk.h), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  Sixteen GOPs spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
+since round 6), ONE fused kernel per step with --walk fused or presets slow / placebo: xeve_amd/csrc/walk.h), entropy writer, loop filter, second writer pass, padding, parameter sets + SEI + slice NAL units.  Sixty-four GOPs (--seeded) spread over every batch of rank 0 (its first and last among them) are the reference's own seed-4 input.
 
 BOUNDED.  A whole 8-frame 3840x2160 job is 8 x 302 lockstep steps of a few hundred ms each whatever the batch size (a CTU's mode decision is a serial chain; the width is in
 the GOPs) -- a quarter of an hour.  The bench therefore runs the job's first --pictures pictures in coding order (default 3: the IDR picture and the first two B
@@ -251,11 +251,14 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
     encs = [encode.BatchEncoder(cfg, g, F) for g in Gs]
     B, enc = len(encs), encs[0]
 
-    # inputs: 16 GOPs of every batch of rank 0 = the reference recipe's seed clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the device
+    # inputs: a.seeded GOPs (64) of every batch of rank 0 = the reference recipe's seed clip (its bitstream has a golden); every other GOP i.i.d. uniform bytes made on the
+    # device.  (Round 6 raised the count from 16: it was this check -- one of the seeded GOPs coming out different from GOP 0 -- that caught a one-in-250 000 race of the
+    # tree operations which every test of the suite had passed.)
     clip = reference_noise(fb * F, seed) if rank == 0 else None
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
-    seeded = [sorted({int(round(i * (g - 1) / max(1, min(g, 16) - 1))) for i in range(min(g, 16))}) for g in Gs]  # 16 GOPs spread over every batch, its first and last among them
+    NS = max(2, a.seeded)
+    seeded = [sorted({int(round(i * (g - 1) / max(1, min(g, NS) - 1))) for i in range(min(g, NS))}) for g in Gs]  # spread over every batch, its first and last among them
     for b, e in enumerate(encs):
         for g in range(Gs[b]):
             if g in seeded[b] and clip is not None:
@@ -577,6 +580,7 @@ def main():
                     help="the headline is preset medium (BASELINE.json); slow and placebo run on the fused walk at any width, their lines are secondary records (profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra (the per-class / per-stage profile of the walk)")
+    ap.add_argument("--seeded", type=int, default=64, help="GOPs of every batch that carry the reference's clip and are compared with its golden bitstream after the run")
     ap.add_argument("--no-width-sweep", action="store_true", help="skip the untimed extra that runs 1, 8 and 64 GOPs in lockstep (what the headline depends on; ~40 s)")
     ap.add_argument("--no-1080p", action="store_true", help="skip the same bounded job at 1920x1080 that follows the headline (north_star names both sizes; ~2 more minutes, after the timed region)")
     ap.add_argument("--with-1080p", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
