@@ -1010,6 +1010,38 @@ int xeve_hip_affine_mc_host(int x, int y, int pic_w, int pic_h, int w, int h, co
                             int num_refp1, int s_l, int s_c, int pad_l, int pad_c, xeve_hip_pel *pred_y, xeve_hip_pel *pred_u, xeve_hip_pel *pred_v, int vertex_num,
                             int bit_depth);
 
+/* ------------------------------------------------------------------------------------------- */
+/* Main profile: the affine gradient search ("affine MC + gradient ME").   */
+/* reference: pinter_affine_me_gradient (src_main/xevem_pinter.c:4290-4501; pi->fn_affine_me,      */
+/* src_base/xeve_type.h:448) = luma affine compensation (xeve_affine_mc_l, xevem_mc.c:1532-1669),  */
+/* SATD + vector bits (get_affine_mv_bits :4257-4288), then per round the error, the prediction's  */
+/* Sobel derivatives, the normal equations (xevem_func_aff_h_sobel_flt / _v_sobel_flt /            */
+/* _eq_coef_comp), solve_equal (:4213-4255) in double and the control points' rounded update;      */
+/* 7 / 5 rounds (uni / bi), two fewer with three control points; the best vectors are kept.        */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct xeve_hip_affine_me_job {
+    int32_t  x, y;           /* CU position in luma samples */
+    int16_t  mvp[3][2];      /* the predictor's control points (the vector bits are counted against them) */
+    int16_t  mv[3][2];       /* in: the start vectors; out: the best ones found (vertex_num of them) */
+    int8_t   refi, list;     /* the reference picture: refp[refi * 2 + list] */
+    int8_t   bi;             /* 1: the original is the job's block of org_bi (pi->org_bi: 2 * org - the other list's prediction), SATD >> 1, + mot_bits_other */
+    int8_t   vertex_num;     /* 2 | 3 */
+    int32_t  mot_bits_other; /* pi->mot_bits[1 - list] */
+    uint32_t cost;           /* out: the function's value, cost_best - MV_COST(best_bits) */
+} xeve_hip_affine_me_job;
+/* Every search of ONE CU size in one call (a workgroup per search, all rounds inside the kernel).  refp: HOST array [refi * 2 + list] (ntab0 / ntab1 entries per list) of
+ * DEVICE luma planes (sample (0, 0); u / v are not read), padded like the reference's; org: DEVICE original luma plane (sample (0, 0)), pitch s_org; org_bi: DEVICE
+ * [njobs][h * w] 16-bit blocks, read for the jobs that have bi set (may be NULL when none has); jobs: DEVICE, read and written.  lambda_mv = pi->lambda_mv; num_refp0 / 1 =
+ * ctx->rpm.num_refp[list] (the reference-index bits).  w, h: powers of two, 16 .. 128 (the encoder searches affine vectors for CUs of 16 x 16 and more, :5516). */
+int xeve_hip_affine_me_jobs(const xeve_hip_refpic *refp, int ntab0, int ntab1, int s_l, int pic_w, int pic_h, const xeve_hip_pel *org, int s_org, const int16_t *org_bi,
+                            xeve_hip_affine_me_job *jobs, int njobs, int w, int h, int bit_depth, uint32_t lambda_mv, int num_refp0, int num_refp1, void *stream);
+/* Host-memory form of ONE pinter_affine_me_gradient call: ref_y = HOST luma plane (sample (0, 0)) of refp[refi][list].pic, padded by pad_l samples; org = the CU's first
+ * original sample with its pitch (bi: pi->org_bi, pitch w); mv in / out; *cost = the function's value.  Synchronous.  What the Main encoder's pi->fn_affine_me is bound to in
+ * situ (oracle/ref_shim_affine.c). */
+int xeve_hip_affine_me_host(int x, int y, int pic_w, int pic_h, int w, int h, int refi, int list, const int16_t mvp[3][2], int16_t mv[3][2], int bi, int vertex_num,
+                            const xeve_hip_pel *ref_y, int s_l, int pad_l, const int16_t *org, int s_org, int bit_depth, uint32_t lambda_mv, int num_refp, int mot_bits_other,
+                            uint32_t *cost);
+
 #ifdef __cplusplus
 }
 #endif

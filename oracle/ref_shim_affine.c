@@ -3,7 +3,11 @@
  * the affine gradient search (:4659) and from the affine bi-prediction (:4918) -- so the symbol is interposed and forwards to the HIP host form
  * (xeve_hip_affine_mc_host: the reference's arguments, host planes).  Nothing else of the encoder is touched: the affine SEARCH around it stays the reference's.
  * XEVE_HIP_LIB unset = plain reference run; with XEVE_HIP_SHIM_AFFINE_COUNT=1 the calls are counted and go to the reference's own function (which clips reach affine MC
- * at all).  Needs the reference's headers (XEVE_REFP / XEVE_PIC layouts): built by oracle/Makefile into oracle/_ref/. */
+ * at all).  Needs the reference's headers (XEVE_REFP / XEVE_PIC layouts): built by oracle/Makefile into oracle/_ref/.
+ *   Round 6, second route: with XEVE_HIP_SHIM_AFFINE_ME=1 the affine gradient SEARCH itself goes to the GPU -- xevem_pinter_create (called by name, xevem_util.c:3979) is
+ * interposed and, once the reference has filled its inter-prediction objects, every thread's pi->fn_affine_me (src_base/xeve_type.h:448; the reference binds the static
+ * pinter_affine_me_gradient, xevem_pinter.c:6285) is bound to a forwarder to xeve_hip_affine_me_host.  XEVE_HIP_SHIM_AFFINE_VERIFY=1 then runs the reference's own function
+ * behind every call and reports the first difference (vectors or value). */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <stdio.h>
@@ -15,14 +19,19 @@ typedef struct {
     int        poc, pad_;
 } hip_refpic; /* xeve_hip_refpic (include/xeve_hip.h) */
 static void *hip;
+static int   hip_mc_off;
 static int (*h_mc)(int, int, int, int, int, int, const s8 *, const s16 (*)[3][MV_D], const hip_refpic *, int, int, int, int, int, int, pel *, pel *, pel *, int, int);
 static const char *(*h_err)(void);
 static unsigned long long n_calls, n_eligible;
 static void (*orig)(int, int, int, int, int, int, s8 *, s16 (*)[VER_NUM][MV_D], XEVE_REFP (*)[REFP_NUM], pel (*)[N_C][MAX_CU_DIM], int, pel *, int, int, int);
 
+static int (*h_me)(int, int, int, int, int, int, int, int, const s16 (*)[MV_D], s16 (*)[MV_D], int, int, const pel *, int, int, const s16 *, int, int, u32, int, int, u32 *);
+static u32 (*orig_me)(XEVE_PINTER *, int, int, int, int, s8 *, int, s16 (*)[MV_D], s16 (*)[MV_D], int, int, pel *, int, int, int);
+static unsigned long long n_me, n_me_hip;
 static void report(void)
 {
-    fprintf(stderr, "[xeve_hip_shim_affine] xeve_affine_mc calls %s: %llu (of %llu)\n", hip ? "served by HIP" : "counted (reference's own function)", n_eligible, n_calls);
+    if(n_me) fprintf(stderr, "[xeve_hip_shim_affine] affine gradient searches %s: %llu (of %llu)\n", h_me ? "served by HIP" : "counted (reference's own function)", h_me ? n_me_hip : n_me, n_me);
+    fprintf(stderr, "[xeve_hip_shim_affine] xeve_affine_mc calls %s: %llu (of %llu)\n", hip && !hip_mc_off ? "served by HIP" : "counted (reference's own function)", n_eligible, n_calls);
 }
 static void bind(void)
 {
@@ -41,7 +50,12 @@ static void bind(void)
     int (*init)(int) = (int (*)(int))dlsym(hip, "xeve_hip_init");
     h_err = (const char *(*)(void))dlsym(hip, "xeve_hip_last_error");
     h_mc = dlsym(hip, "xeve_hip_affine_mc_host");
-    if(!init || !h_err || !h_mc) { fprintf(stderr, "[xeve_hip_shim_affine] entry points missing\n"); abort(); }
+    if(getenv("XEVE_HIP_SHIM_AFFINE_ME")) {
+        h_me = dlsym(hip, "xeve_hip_affine_me_host");
+        if(!h_me) { fprintf(stderr, "[xeve_hip_shim_affine] xeve_hip_affine_me_host missing\n"); abort(); }
+    }
+    if(getenv("XEVE_HIP_SHIM_AFFINE_MC_OFF")) h_mc = NULL, hip_mc_off = 1; /* (the search's route alone: xeve_affine_mc stays the reference's) */
+    if(!init || !h_err || (!h_mc && !hip_mc_off)) { fprintf(stderr, "[xeve_hip_shim_affine] entry points missing\n"); abort(); }
     const char *dev = getenv("XEVE_HIP_DEVICE");
     if(init(dev ? atoi(dev) : 0) != 0) { fprintf(stderr, "[xeve_hip_shim_affine] init: %s\n", h_err()); abort(); }
     fprintf(stderr, "[xeve_hip_shim_affine] HIP affine motion compensation bound\n");
@@ -55,7 +69,7 @@ void xeve_affine_mc(int x, int y, int pic_w, int pic_h, int w, int h, s8 refi[RE
     n_calls++;
     /* what the HIP entry covers: 4:2:0, one bit depth, CUs of 8 .. 128 (the reference's affine CUs are >= 8x8: xevem_pinter.c) */
     const int ok = chroma_format_idc == 1 && bit_depth_luma == bit_depth_chroma && w >= 8 && h >= 8 && (refi[0] >= 0 || refi[1] >= 0);
-    if(!hip || !ok) {
+    if(!hip || !ok || hip_mc_off) {
         n_eligible += ok;
         orig(x, y, pic_w, pic_h, w, h, refi, mv, refp, pred, vertex_num, tmp_buffer, bit_depth_luma, bit_depth_chroma, chroma_format_idc);
         /* XEVE_HIP_SHIM_AFFINE_CHECK=<oracle/libxeve_oracle.so>: the C restatement (xo_affine_mc: same layouts as the library's) beside the reference on every call of the live
@@ -139,4 +153,60 @@ void xeve_affine_mc(int x, int y, int pic_w, int pic_h, int w, int h, s8 refi[RE
                 }
         }
     }
+}
+
+/* ---- the affine gradient search: pi->fn_affine_me bound to the HIP host form ---------------------------------------------------------------------------------------------- */
+static u32 shim_affine_me(XEVE_PINTER *pi, int x, int y, int log2_cuw, int log2_cuh, s8 *refi, int lidx, s16 mvp[VER_NUM][MV_D], s16 mv[VER_NUM][MV_D], int bi, int vertex_num,
+                          pel *tmp, int bit_depth_luma, int bit_depth_chroma, int chroma_format_idc)
+{
+    n_me++;
+    const int cuw = 1 << log2_cuw, cuh = 1 << log2_cuh, ri = *refi;
+    /* what the HIP entry covers: CUs of 16 .. 128 (the encoder searches affine vectors for nothing smaller, xevem_pinter.c:5516), reference indices below 8 */
+    if(!h_me || cuw < 16 || cuh < 16 || ri < 0 || ri >= 8) return orig_me(pi, x, y, log2_cuw, log2_cuh, refi, lidx, mvp, mv, bi, vertex_num, tmp, bit_depth_luma, bit_depth_chroma, chroma_format_idc);
+    n_me_hip++;
+    const XEVE_PIC *rp = pi->refp[ri][lidx].pic;
+    const s16 *org = bi ? pi->org_bi : pi->o[Y_C] + x + y * pi->s_o[Y_C];
+    const int  s_org = bi ? cuw : pi->s_o[Y_C];
+    s16 start[VER_NUM][MV_D];
+    memcpy(start, mv, sizeof(start));
+    u32 cost = 0;
+    /* (a row of the reference's arrays is one control point, VER_NUM = 4 of them: the first three are what the library's [3][2] reads) */
+    if(h_me(x, y, rp->w_l, rp->h_l, cuw, cuh, ri, lidx, (const s16(*)[MV_D])mvp, mv, bi, vertex_num, rp->y, rp->s_l, rp->pad_l, org, s_org, bit_depth_luma, pi->lambda_mv, pi->num_refp,
+            pi->mot_bits[1 - lidx], &cost) != 0) {
+        fprintf(stderr, "[xeve_hip_shim_affine] xeve_hip_affine_me_host: %s\n", h_err());
+        abort();
+    }
+    if(getenv("XEVE_HIP_SHIM_AFFINE_VERIFY")) { /* the reference's own search behind the GPU's: the first differing call is printed, the reference's result is kept */
+        static int reported;
+        s16 got[VER_NUM][MV_D];
+        memcpy(got, mv, sizeof(got)), memcpy(mv, start, sizeof(start));
+        const u32 want = orig_me(pi, x, y, log2_cuw, log2_cuh, refi, lidx, mvp, mv, bi, vertex_num, tmp, bit_depth_luma, bit_depth_chroma, chroma_format_idc);
+        int same = want == cost;
+        for(int v = 0; v < vertex_num; v++) same = same && got[v][MV_X] == mv[v][MV_X] && got[v][MV_Y] == mv[v][MV_Y];
+        if(!same && !reported) {
+            fprintf(stderr, "[xeve_hip_shim_affine] VERIFY: search %llu differs: x %d y %d cu %dx%d refi %d list %d bi %d vertex %d lambda %u num_refp %d: reference %u (%d,%d) (%d,%d) (%d,%d) "
+                            "gpu %u (%d,%d) (%d,%d) (%d,%d); start (%d,%d) (%d,%d) (%d,%d)\n", n_me, x, y, cuw, cuh, ri, lidx, bi, vertex_num, pi->lambda_mv, pi->num_refp, want, mv[0][0], mv[0][1],
+                    mv[1][0], mv[1][1], mv[2][0], mv[2][1], cost, got[0][0], got[0][1], got[1][0], got[1][1], got[2][0], got[2][1], start[0][0], start[0][1], start[1][0], start[1][1],
+                    start[2][0], start[2][1]);
+            reported = 1;
+        }
+        return want;
+    }
+    return cost;
+}
+int xevem_pinter_create(XEVE_CTX *ctx, int complexity)
+{
+    static int (*create)(XEVE_CTX *, int);
+    bind();
+    if(!create) create = dlsym(RTLD_NEXT, "xevem_pinter_create");
+    if(!create) { fprintf(stderr, "[xeve_hip_shim_affine] reference xevem_pinter_create not found\n"); abort(); }
+    const int ret = create(ctx, complexity);
+    if(ret == XEVE_OK && (h_me || getenv("XEVE_HIP_SHIM_AFFINE_COUNT"))) {
+        for(int i = 0; i < ctx->param.threads; i++) {
+            if(!orig_me) orig_me = ctx->pinter[i].fn_affine_me;
+            ctx->pinter[i].fn_affine_me = shim_affine_me;
+        }
+        if(h_me) fprintf(stderr, "[xeve_hip_shim_affine] HIP affine gradient search bound (%d inter-prediction objects)\n", ctx->param.threads);
+    }
+    return ret;
 }

@@ -2963,6 +2963,7 @@ static void xa_mc_lc(int x, int y, int pic_w, int pic_h, int cuw, int cuh, const
         }
         /* (affine_mv_prec = bit + 2 = EIF_MV_PRECISION_INTERNAL: no further shift of the model, :2150-2156) */
         xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->y, s_l, pred[0], cuw, 0, bit_depth);
+        if(!pred[1]) return; /* (xeve_affine_mc_l, :1592-1634: the luma plane alone) */
         xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->u, s_c, pred[1], cuw >> 1, 1, bit_depth);
         xa_eif(cuw, cuh, x, y, scale, d_hor, d_ver, mx, mn, rp->v, s_c, pred[2], cuw >> 1, 1, bit_depth);
         return;
@@ -2978,6 +2979,7 @@ static void xa_mc_lc(int x, int y, int pic_w, int pic_h, int cuw, int cuh, const
             th = th < hor_min ? hor_min : th > hor_max ? hor_max : th, tv = tv < ver_min ? ver_min : tv > ver_max ? ver_max : tv;
             const int gx = ((x + w) << mc_prec) + th, gy = ((y + h) << mc_prec) + tv;
             xo_mc_l((oh & 15) != 0, (ov & 15) != 0, rp->y, gx, gy, s_l, cuw, pred[0] + h * cuw + w, sub_w, sub_h, bit_depth, xom_mc_l_coeff);
+            if(!pred[1]) continue; /* (xeve_affine_mc_l, :1636-1668) */
             xo_mc_c((oh & 31) != 0, (ov & 31) != 0, rp->u, gx, gy, s_c, cuw >> 1, pred[1] + (h >> 1) * (cuw >> 1) + (w >> 1), sub_w >> 1, sub_h >> 1, bit_depth, xom_mc_c_coeff);
             xo_mc_c((oh & 31) != 0, (ov & 31) != 0, rp->v, gx, gy, s_c, cuw >> 1, pred[2] + (h >> 1) * (cuw >> 1) + (w >> 1), sub_w >> 1, sub_h >> 1, bit_depth, xom_mc_c_coeff);
         }
@@ -3001,4 +3003,124 @@ void xo_affine_mc(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h,
         for(size_t i = 0; i < nc; i++) pred_u[i] = (xo_pel)((pred_u[i] + second[nl + i] + 1) >> 1), pred_v[i] = (xo_pel)((pred_v[i] + second[nl + nc + i] + 1) >> 1);
     }
     free(second);
+}
+
+/* ==================================================================================================================================================================
+ * Main profile: the affine gradient search (src_main/xevem_pinter.c:4213-4501).  TEST INFRASTRUCTURE like the rest of this file.
+ * ================================================================================================================================================================== */
+/* xeve_affine_mc_l (xevem_mc.c:1532-1669) = derive_affine_subblock_size (xevem_util.c:1273-1330: one list's model) + the luma part of the per-list compensation */
+void xo_affine_mc_l(const xo_pel *ref_y, int s_l, int pic_w, int pic_h, int x, int y, const int16_t mv[3][2], int vertex_num, int w, int h, int bit_depth, xo_pel *pred)
+{
+    xo_affine_job j;
+    memset(&j, 0, sizeof(j));
+    j.x = x, j.y = y, j.refi[0] = 0, j.refi[1] = -1, j.vertex_num = (int8_t)vertex_num;
+    memcpy(j.mv[0], mv, sizeof(j.mv[0]));
+    int sub_w, sub_h, mem_ok;
+    xa_subblock_size(&j, w, h, &sub_w, &sub_h, &mem_ok);
+    xo_refpic rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.y = ref_y;
+    xo_pel *p[3] = {pred, NULL, NULL};
+    xa_mc_lc(x, y, pic_w, pic_h, w, h, mv, &rp, s_l, 0, p, vertex_num, sub_w, sub_h, mem_ok, bit_depth);
+}
+void xo_affine_solve(double (*eq)[7], int order, double *para)
+{ /* solve_equal (:4213-4255) */
+    for(int i = 1; i < order; i++) {
+        double best = fabs(eq[i][i - 1]);
+        int    at = i;
+        for(int j = i + 1; j < order + 1; j++)
+            if(fabs(eq[j][i - 1]) > best) best = fabs(eq[j][i - 1]), at = j;
+        if(at != i)
+            for(int j = 0; j < order + 1; j++) eq[0][j] = eq[i][j], eq[i][j] = eq[at][j], eq[at][j] = eq[0][j];
+        for(int j = i + 1; j < order + 1; j++)
+            for(int k = i; k < order + 1; k++) eq[j][k] = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
+    }
+    para[order - 1] = eq[order][order] / eq[order][order - 1];
+    for(int i = order - 2; i >= 0; i--) {
+        double t = 0;
+        for(int j = i + 1; j < order; j++) t += eq[i + 1][j] * para[j];
+        para[i] = (eq[i + 1][order] - t) / eq[i + 1][i];
+    }
+}
+/* one component of get_affine_mv_bits: xeve_tbl_mv_bits inside (-2048, 2048], the MAIN profile's exp-Golomb length beyond (xevem_pinter.c:217-237: other than the
+ * Baseline one -- every bit of the prefix counted from 0, the sign only with a non-zero value) */
+static int xa_mvd_bits(int mvd)
+{
+    if(mvd > 2048 || mvd <= -2048) {
+        unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd), nn = (a + 1) >> 1;
+        int len_i;
+        for(len_i = 0; len_i < 16 && nn != 0; len_i++) nn >>= 1;
+        return (len_i << 1) + 1 + (a ? 1 : 0);
+    }
+    return mvd_bits(mvd);
+}
+static int xa_refi_bits(int num_refp, int refi) { return num_refp <= 1 ? 0 : refi == num_refp - 1 ? refi : refi + 1; } /* xeve_tbl_refi_bits (xeve_tbl.c:498-516) */
+static int xa_mv_bits(const int16_t mv[3][2], const int16_t mvp[3][2], int num_refp, int refi, int vertex_num)
+{ /* get_affine_mv_bits (:4257-4288) */
+    int zero = 1, bits = 1;
+    for(int v = 0; v < vertex_num; v++)
+        if(mv[v][0] != mvp[v][0] || mv[v][1] != mvp[v][1]) { zero = 0; break; }
+    if(zero) return bits;
+    for(int v = 0; v < vertex_num; v++) {
+        int dx = mv[v][0] - mvp[v][0], dy = mv[v][1] - mvp[v][1];
+        if(v) dx -= mv[0][0] - mvp[0][0], dy -= mv[0][1] - mvp[0][1];
+        bits += xa_mvd_bits(dx) + xa_mvd_bits(dy);
+    }
+    return bits + xa_refi_bits(num_refp, refi);
+}
+/* (s16)(double): what the reference's build does with the conversion -- cvttsd2si to 32 bits (0x80000000 for NaN and values beyond the range), the low 16 bits kept */
+static int16_t xa_to_s16(double v)
+{
+    const int32_t t = (v >= -2147483648.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+    return (int16_t)(uint16_t)(uint32_t)t;
+}
+void xo_affine_me_gradient(const xo_refpic *refp, int s_l, int pic_w, int pic_h, const int16_t *org_in, int s_org_in, xo_affine_me_job *job, int w, int h, int bit_depth,
+                           uint32_t lambda_mv, int num_refp)
+{
+    const int bi = job->bi, vn = job->vertex_num, ri = job->refi, np = vn << 1;
+    const xo_pel *ref = refp[ri * 2 + job->list].y;
+    const int16_t *org = bi ? org_in : org_in + (ptrdiff_t)job->y * s_org_in + job->x;
+    const int s_org = bi ? w : s_org_in;
+    xo_pel  *pred = (xo_pel *)malloc(sizeof(xo_pel) * w * h), *err = (xo_pel *)malloc(sizeof(xo_pel) * w * h);
+    int32_t *der[2] = {(int32_t *)malloc(sizeof(int32_t) * w * h), (int32_t *)malloc(sizeof(int32_t) * w * h)};
+    int16_t mvt[3][2], mvd[3][2];
+    memcpy(mvt, job->mv, sizeof(mvt)), memset(mvd, 0, sizeof(mvd));
+#define XA_MV_COST(bits) ((uint32_t)((lambda_mv * (uint32_t)(bits) + (1 << 15)) >> 16)) /* MV_COST (:53): 32-bit unsigned arithmetic */
+    xo_affine_mc_l(ref, s_l, pic_w, pic_h, job->x, job->y, mvt, vn, w, h, bit_depth, pred);
+    int best_bits = xa_mv_bits(mvt, job->mvp, num_refp, ri, vn) + (bi ? job->mot_bits_other : 0);
+    uint32_t cost_best = XA_MV_COST(best_bits) + (uint32_t)(xo_satd(w, h, org, pred, s_org, w, bit_depth) >> bi);
+    int rounds = bi ? 5 : 7; /* AF_ITER_BI / AF_ITER_UNI (xeve_def.h:168-169) */
+    if(vn == 3) rounds -= 2;
+    for(int it = 0; it < rounds; it++) {
+        for(int r = 0; r < h; r++)
+            for(int c = 0; c < w; c++) err[r * w + c] = (xo_pel)(org[r * s_org + c] - pred[r * w + c]); /* xeve_diff_16b */
+        xo_sobel(0, pred, w, der[0], w, w, h), xo_sobel(1, pred, w, der[1], w, w, h);
+        int64_t eqi[7][7];
+        double  eq[7][7], para[6], dmv[6];
+        memset(eqi, 0, sizeof(eqi));
+        xo_equal_coeff(err, der[0], der[1], w, eqi, w, h, vn);
+        for(int r = 0; r < np + 1; r++)
+            for(int c = 0; c < np + 1; c++) eq[r][c] = (double)eqi[r][c];
+        xo_affine_solve(eq, np, para);
+        dmv[0] = para[0], dmv[2] = para[2], dmv[1] = para[1] * w + para[0];
+        if(vn == 3) dmv[3] = para[3] * w + para[2], dmv[4] = para[4] * h + para[0], dmv[5] = para[5] * h + para[2];
+        else dmv[3] = -para[3] * w + para[2];
+#define XA_Q(d) xa_to_s16((d) * 4 + ((d) >= 0 ? 0.5 : -0.5))
+        mvd[0][0] = XA_Q(dmv[0]), mvd[0][1] = XA_Q(dmv[2]), mvd[1][0] = XA_Q(dmv[1]), mvd[1][1] = XA_Q(dmv[3]);
+        if(vn == 3) mvd[2][0] = XA_Q(dmv[4]), mvd[2][1] = XA_Q(dmv[5]);
+        int zero = 1;
+        for(int v = 0; v < vn; v++)
+            if(mvd[v][0] || mvd[v][1]) zero = 0;
+        if(zero) break;
+        for(int v = 0; v < vn; v++) mvt[v][0] = (int16_t)(mvt[v][0] + mvd[v][0]), mvt[v][1] = (int16_t)(mvt[v][1] + mvd[v][1]);
+        xo_affine_mc_l(ref, s_l, pic_w, pic_h, job->x, job->y, mvt, vn, w, h, bit_depth, pred);
+        const int bits = xa_mv_bits(mvt, job->mvp, num_refp, ri, vn) + (bi ? job->mot_bits_other : 0);
+        const uint32_t cost = XA_MV_COST(bits) + (uint32_t)(xo_satd(w, h, org, pred, s_org, w, bit_depth) >> bi);
+        if(cost < cost_best) {
+            cost_best = cost, best_bits = bits;
+            for(int v = 0; v < vn; v++) job->mv[v][0] = mvt[v][0], job->mv[v][1] = mvt[v][1];
+        }
+    }
+    job->cost = cost_best - XA_MV_COST(best_bits);
+    free(pred), free(err), free(der[0]), free(der[1]);
 }

@@ -541,6 +541,28 @@ typedef struct xo_affine_job {
 void xo_affine_mc(const xo_refpic *refp, int s_l, int s_c, int pic_w, int pic_h, const xo_affine_job *job, int w, int h, int bit_depth, xo_pel *pred_y, xo_pel *pred_u,
                   xo_pel *pred_v, int *path);
 
+/* ---- Main profile: the affine gradient search of one CU on one reference picture (reference: pinter_affine_me_gradient, src_main/xevem_pinter.c:4290-4501, with solve_equal
+ * :4213-4255, get_affine_mv_bits :4257-4288 and the luma-only compensation xeve_affine_mc_l, xevem_mc.c:1532-1669) -------------------------------------------------------- */
+typedef struct xo_affine_me_job {
+    int32_t  x, y;           /* CU position, luma samples */
+    int16_t  mvp[3][2];      /* the predictor's control points (bits of the difference) */
+    int16_t  mv[3][2];       /* in: the start vectors; out: the best ones found */
+    int8_t   refi, list;     /* the reference picture: refp[refi * 2 + list] */
+    int8_t   bi;             /* 1: the original is the job's org_bi block (2 * org - the other list's prediction), SATD >> 1, + mot_bits_other */
+    int8_t   vertex_num;     /* 2 | 3 */
+    int32_t  mot_bits_other; /* pi->mot_bits[1 - list] */
+    uint32_t cost;           /* out: cost_best - MV_COST(best_bits) */
+} xo_affine_me_job;
+/* org: the picture's original luma plane (sample (0, 0)), pitch s_org -- or, job->bi, the job's dense w x h block of 16-bit values (pitch w).  Per round: error = org - pred,
+ * Sobel derivatives of the prediction, the normal equations (64-bit sums), solve_equal in double, the control points moved by the rounded solution, compensation + SATD + vector
+ * bits; 7 / 5 rounds (uni / bi), two fewer with three control points; stops when the update is zero. */
+void xo_affine_me_gradient(const xo_refpic *refp, int s_l, int pic_w, int pic_h, const int16_t *org, int s_org, xo_affine_me_job *job, int w, int h, int bit_depth,
+                           uint32_t lambda_mv, int num_refp);
+/* the luma prediction alone (xeve_affine_mc_l): pred dense w x h */
+void xo_affine_mc_l(const xo_pel *ref_y, int s_l, int pic_w, int pic_h, int x, int y, const int16_t mv[3][2], int vertex_num, int w, int h, int bit_depth, xo_pel *pred);
+/* solve_equal (xevem_pinter.c:4213-4255): Gaussian elimination with row pivoting on eq[1 .. order][0 .. order], row 0 as scratch */
+void xo_affine_solve(double (*eq)[7], int order, double *para);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,7 +145,7 @@ class HostAffine(OracleAffine):
         OracleAffine.__init__(self)
         if not os.path.exists(HOST_OUT) or os.path.getmtime(HOST_OUT) < max(os.path.getmtime(HOST_SRC), os.path.getmtime(HOST_HDR)):
             os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT, HOST_SRC], check=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-o", HOST_OUT, HOST_SRC], check=True)
         self.H = C.CDLL(HOST_OUT)
         self.H.xa_host_affine_mc.restype = None
         self.cl = (C.c_int16 * 128).in_dll(self.L, "xom_mc_l_coeff")  # the Main filters (pinned against the reference's tables by tests/test_main_oracle_vs_ref.py)

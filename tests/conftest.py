@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 #    to more than 900 s or when a collected GPU test has no entry.
 GPU_FILE_ORDER = [
     "test_hip_tables", "test_hip_batched", "test_rdoq", "test_hip_mc_cu", "test_hip_me", "test_hip_sbac", "test_hip_rdo", "test_hip_df", "test_hip_skip", "test_hip_inter",
-    "test_hip_intra", "test_workload", "test_hip_tree", "test_zz_tree_golden_gpu", "test_walk_choice_gpu", "test_gop_shard", "test_enc_batches", "test_main_profile", "test_main_ats_fwd", "test_alf", "test_affine",
+    "test_hip_intra", "test_workload", "test_hip_tree", "test_zz_tree_golden_gpu", "test_walk_choice_gpu", "test_gop_shard", "test_enc_batches", "test_main_profile", "test_main_ats_fwd", "test_alf", "test_affine", "test_affine_me",
     "test_integration_ref", "test_dev_switches_gpu", "test_e2e_real_sizes", "test_enc_gpu",
 ]
 GPU_FULL = os.environ.get("XEVE_GPU_FULL") == "1"

@@ -1,0 +1,164 @@
+"""Main profile, the affine gradient search of a CU ("affine MC + gradient ME"): pinter_affine_me_gradient (src_main/xevem_pinter.c:4290-4501) = luma affine
+compensation (xeve_affine_mc_l), SATD + vector bits, and per round the prediction's Sobel derivatives, the normal equations, solve_equal in double, the control points' update.
+  (cpu) the oracle's restatement against goldens recorded from the reference's own (static) function, and against that function called in place where oracle/_ref exists;
+  (cpu) the kernel's scalar steps and decomposition (xeve_amd/csrc/affine_core.h) compiled for the host against the goldens;
+  (gpu) xeve_hip_affine_me_jobs (every search of a size in ONE launch) and the per-call host form against oracle and goldens."""
+import os
+
+import numpy as np
+import pytest
+
+import _affine as A
+import _affine_me as M
+
+GOLD = np.load(M.GOLDEN)
+CACHE = {}
+
+
+def inputs():
+    if not CACHE:
+        CACHE["pics"], CACHE["org"] = M.ref_pictures(), M.org_picture()
+    return CACHE["pics"], CACHE["org"]
+
+
+def check(impl, w, h):
+    pics, org = inputs()
+    jobs, org_bi = M.make_jobs(w, h, 11 + w + h)
+    mv, cost = impl.run(pics, org, jobs, org_bi, w, h)
+    want_mv, want_cost = GOLD["%dx%d/mv" % (w, h)], GOLD["%dx%d/cost" % (w, h)]
+    three = jobs["vertex_num"] == 3  # (with two control points the third vector is not the search's: left as it came)
+    bad = [i for i in range(len(jobs)) if not (np.array_equal(mv[i][:3 if three[i] else 2], want_mv[i][:3 if three[i] else 2]) and cost[i] == want_cost[i])]
+    assert not bad, (impl.name, w, h, bad[:8], [(mv[i].tolist(), int(cost[i]), want_mv[i].tolist(), int(want_cost[i])) for i in bad[:3]])
+    return jobs, mv, cost
+
+
+@pytest.mark.parametrize("size", M.SIZES, ids=["%dx%d" % s for s in M.SIZES])
+def test_oracle_affine_me_matches_the_reference_goldens(size):
+    check(M.OracleAffineMe(), *size)
+
+
+def test_the_cases_cover_the_searchs_branches():
+    pics, org = inputs()
+    H = M.HostAffineMe()
+    rounds, moved, kept, flat_kept = set(), 0, 0, 0
+    for (w, h) in M.SIZES:
+        jobs, mv, cost = check(H, w, h)
+        rounds |= set((int(j["bi"]), int(j["vertex_num"]), int(r)) for j, r in zip(jobs, H.rounds))
+        for i, j in enumerate(jobs):
+            same = np.array_equal(mv[i][:j["vertex_num"]], j["mv"][:j["vertex_num"]])
+            moved, kept = moved + (not same), kept + same
+            flat_kept += int(j["refi"] == 2 and same)
+    # every round budget is used up by some search (7 / 5 rounds uni / bi with two control points, 5 / 3 with three) and some stop early on a zero update (incl. round 0:
+    # the flat picture's singular equations)
+    for bi in (0, 1):
+        for vn in (2, 3):
+            full = (5 if bi else 7) - (2 if vn == 3 else 0)
+            got = sorted(r for (b, v, r) in rounds if b == bi and v == vn)
+            assert full in got, (bi, vn, got)
+    early = sorted(r for (b, v, r) in rounds if r < (5 if b else 7) - (2 if v == 3 else 0))
+    assert early and early[0] == 0 and early[-1] > 0, early
+    assert moved > 100 and kept > 8 and flat_kept > 4, (moved, kept, flat_kept)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not os.path.exists(M.REF_SO), reason="oracle/_ref/libref_affine_me.so not built")
+@pytest.mark.parametrize("size", [(16, 16), (64, 64), (128, 32), (64, 128)], ids=lambda s: "%dx%d" % s)
+def test_oracle_affine_me_matches_the_reference_in_place(size):
+    w, h = size
+    pics, org = inputs()
+    O = M.OracleAffineMe()
+    for seed, lam, nr in ((900, 300000, 3), (901, 4000000, 4)):  # (other seeds, lambdas and list lengths than the goldens')
+        jobs, org_bi = M.make_jobs(w, h, seed + w + h, n=30)
+        for simd in (0, 1):  # the plain C kernels and the SSE ones agree
+            a, b = O.run(pics, org, jobs, org_bi, w, h, lam, nr), M.RefAffineMe(simd).run(pics, org, jobs, org_bi, w, h, lam, nr)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (seed, simd)
+    check(M.RefAffineMe(1), w, h)  # (and the committed goldens are what the reference produces today)
+
+
+@pytest.mark.parametrize("size", M.SIZES, ids=["%dx%d" % s for s in M.SIZES])
+def test_the_kernels_scalar_steps_on_the_host_match_the_goldens(size):
+    """xeve_amd/csrc/affine_core.h (me_mv_bits, me_solve, me_update, me_terms, me_to_s16 + the compensation's functions: what k_affine_me runs) compiled for the host"""
+    check(M.HostAffineMe(), *size)
+
+
+class HipAffineMe:
+    """xeve_hip_affine_me_jobs: all searches of a size in ONE launch (a workgroup per search, every round inside the kernel), reference pictures and original resident in HBM"""
+    name = "hip"
+
+    def __init__(self):
+        import torch
+
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        self.t, self.L, self.check, self.dev = torch, lib.load(), lib.check, torch.device("cuda:0")
+        self.planes = None
+
+    def run(self, pics, org, jobs, org_bi, w, h, lambda_mv=M.LAMBDA_MV, num_refp=M.NUM_REFP):
+        t = self.t
+        if self.planes is None:
+            self.planes = [[t.from_numpy(y).to(self.dev) for y in row] for row in pics]
+            self.org = t.from_numpy(org).to(self.dev)
+        tab = np.zeros(len(pics) * 2, A.REFPIC)
+        for r, row in enumerate(self.planes):
+            for l, y in enumerate(row):
+                p = y.data_ptr() + 2 * (M.PAD * (y.shape[1] + 1))
+                tab[r * 2 + l] = (p, p, p, 8 * r + l, 0)
+        d_jobs = t.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        d_bi = t.from_numpy(np.ascontiguousarray(org_bi)).to(self.dev)
+        self.check(self.L.xeve_hip_affine_me_jobs(tab.ctypes.data, len(pics), len(pics), pics[0][0].shape[1], M.PIC_W, M.PIC_H, self.org.data_ptr(), org.shape[1], d_bi.data_ptr(),
+                                                  d_jobs.data_ptr(), len(jobs), w, h, M.BD, lambda_mv, num_refp, num_refp, None))
+        t.cuda.synchronize()
+        out = d_jobs.cpu().numpy().view(M.JOB)
+        return out["mv"].copy(), out["cost"].copy()
+
+
+@pytest.fixture(scope="module")
+def hip_me():
+    return HipAffineMe()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", M.SIZES, ids=["%dx%d" % s for s in M.SIZES])
+def test_hip_affine_me_matches_oracle_and_goldens(size, hip_me):
+    w, h = size
+    check(hip_me, w, h)
+    pics, org = inputs()
+    jobs, org_bi = M.make_jobs(w, h, 500 + w + h, n=64)  # (other seeds, another lambda and list length: against the oracle)
+    a, b = hip_me.run(pics, org, jobs, org_bi, w, h, 700000, 4), M.OracleAffineMe().run(pics, org, jobs, org_bi, w, h, 700000, 4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+class HipAffineMeHost:
+    """xeve_hip_affine_me_host: ONE search per call with the reference's arguments and HOST memory (what oracle/ref_shim_affine.c binds pi->fn_affine_me to)"""
+    name = "hip_host"
+
+    def __init__(self):
+        import xeve_amd
+        from xeve_amd import lib
+
+        xeve_amd.init(0)
+        self.L, self.check = lib.load(), lib.check
+
+    def run(self, pics, org, jobs, org_bi, w, h, lambda_mv=M.LAMBDA_MV, num_refp=M.NUM_REFP):
+        import ctypes as C
+
+        n = len(jobs)
+        mv, cost = np.zeros((n, 3, 2), np.int16), np.zeros(n, np.uint32)
+        for i, j in enumerate(jobs):
+            ref = pics[int(j["refi"])][int(j["list"])]
+            src = np.ascontiguousarray(org_bi[i]) if j["bi"] else org
+            ptr = src.ctypes.data if j["bi"] else src.ctypes.data + 2 * (int(j["y"]) * src.shape[1] + int(j["x"]))
+            mvp, m, c = np.ascontiguousarray(j["mvp"]), np.ascontiguousarray(j["mv"]).copy(), C.c_uint32()
+            self.check(self.L.xeve_hip_affine_me_host(int(j["x"]), int(j["y"]), M.PIC_W, M.PIC_H, w, h, int(j["refi"]), int(j["list"]), mvp.ctypes.data, m.ctypes.data, int(j["bi"]),
+                                                      int(j["vertex_num"]), A.plane_ptr(ref, 0), ref.shape[1], M.PAD, ptr, src.shape[1], M.BD, lambda_mv, num_refp,
+                                                      int(j["mot_bits_other"]), C.byref(c)))
+            mv[i], cost[i] = m, c.value
+        return mv, cost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(16, 16), (64, 64), (128, 32)], ids=["16x16", "64x64", "128x32"])
+def test_hip_affine_me_host_form_matches_the_goldens(size):
+    check(HipAffineMeHost(), *size)

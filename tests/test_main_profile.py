@@ -129,6 +129,12 @@ def _affine_counts(err):
     return m.group(1), int(m.group(2)), int(m.group(3))
 
 
+def _affine_search_counts(err):
+    m = re.search(r"affine gradient searches ([^:]+): (\d+) \(of (\d+)\)", err)
+    assert m, err
+    return m.group(1), int(m.group(2)), int(m.group(3))
+
+
 AFFINE_CLIPS = {**MAIN_CASES, **MAIN_ALF_CASES}  # (tool_affine is a Main default: every Main clip of the suite calls xeve_affine_mc a thousand times or more)
 
 
@@ -143,6 +149,8 @@ def test_the_main_clips_reach_affine_motion_compensation(tmp_path, name):
     md5, size, err = run_app_main(yuv, str(tmp_path / "o.evc"), w, h, n, extra, shim=SHIM_AFFINE, env_extra={"XEVE_HIP_SHIM_AFFINE_COUNT": "1"})
     how, served, calls = _affine_counts(err)
     assert "reference" in how and calls >= 900 and served == calls
+    how, served, calls = _affine_search_counts(err)  # (pi->fn_affine_me bound to a counting forwarder: the affine gradient searches of CUs of 16x16 and more)
+    assert "reference" in how and calls >= 300 and served == calls
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])
 
 
@@ -161,3 +169,41 @@ def test_main_bitstream_identical_with_affine_motion_compensation_on_the_gpu(tmp
     how, served, calls = _affine_counts(err)
     assert how == "served by HIP" and served == calls and calls >= 900
     assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with affine motion compensation on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIM_AFFINE), reason="oracle/_ref/libxeve_hip_shim_affine.so not built")
+@pytest.mark.parametrize("name", sorted(AFFINE_CLIPS))
+def test_main_bitstream_identical_with_the_affine_gradient_search_on_the_gpu(tmp_path, name):
+    """round 6 (second half): the UNMODIFIED Main-profile encoder with every thread's pi->fn_affine_me (the reference binds its static
+    pinter_affine_me_gradient, xevem_pinter.c:6285) bound to xeve_hip_affine_me_host -- a whole search per call on the GPU: the start compensation, every round's normal
+    equations, solve_equal and update, the SATD comparison -- and xeve_affine_mc on the GPU as well (oracle/ref_shim_affine.c): the same bitstream"""
+    w, h, n, seed, extra = AFFINE_CLIPS[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, shim=SHIM_AFFINE, timeout=900, env_extra={"XEVE_HIP_SHIM_AFFINE_ME": "1"})
+    assert "HIP affine gradient search bound" in err, err
+    how, served, calls = _affine_search_counts(err)
+    assert how == "served by HIP" and served == calls and calls >= 300
+    how, served, calls = _affine_counts(err)
+    assert how == "served by HIP" and served == calls and calls >= 900
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"]), "Main-profile bitstream differs with the affine gradient search on the GPU"
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIM_AFFINE), reason="oracle/_ref/libxeve_hip_shim_affine.so not built")
+@pytest.mark.parametrize("name", ["main_alf_noise_q37", "main_moving_ra_b3_fast"])
+def test_every_affine_search_of_a_live_encode_matches_the_references_own(tmp_path, name):
+    """the interposer's verify mode: the reference's own pinter_affine_me_gradient behind the GPU's on EVERY search of the live encoder (its real originals, bi-prediction
+    targets, predictors, lambdas) -- vectors and value compared call by call; the search's route alone (xeve_affine_mc stays the reference's)"""
+    w, h, n, seed, extra = AFFINE_CLIPS[name]
+    yuv = str(tmp_path / "in.yuv")
+    make_yuv(yuv, w, h, n, seed)
+    md5, size, err = run_app_main(yuv, str(tmp_path / "hip.evc"), w, h, n, extra, hip=True, shim=SHIM_AFFINE, timeout=900,
+                                  env_extra={"XEVE_HIP_SHIM_AFFINE_ME": "1", "XEVE_HIP_SHIM_AFFINE_VERIFY": "1", "XEVE_HIP_SHIM_AFFINE_MC_OFF": "1"})
+    how, served, calls = _affine_search_counts(err)
+    assert how == "served by HIP" and served == calls and calls >= 300
+    assert "VERIFY:" not in err, [l for l in err.splitlines() if "VERIFY" in l]
+    assert (md5, size) == (GOLD[name]["md5"], GOLD[name]["bytes"])

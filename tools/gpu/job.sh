@@ -7,6 +7,7 @@
 #   trace:<gops>:<step from the end>      rocprofv3 --kernel-trace of the probe, distilled by tools/trace_step.py (one lockstep step: sequence, per-kernel totals, queues)
 #   stats:<gops>                          rocprofv3 --kernel-trace --stats of a 3840x2160 encode's IDR picture + 40 B steps (the per-kernel summary committed under profiles/)
 #   smoke:                                __graft_entry__.smoke()
+#   par:<name>:<env assignments>:<args>   tools/probe_par.py (G GOPs as K encoders on K host threads), args comma-separated
 #   pmc:<gops>                            the PMC passes (SQ counters; FETCH_SIZE) over the same 3840x2160 steps, each in a run of its own, distilled by tools/pmc_summary.py
 # (steps are separated by spaces: quote the whole argument list once, e.g. 'tests:tests/test_hip_tree.py probe:side0:XEVE_HIP_TREE_SIDE=0:668')
 cd "$GRAFT_REPO_ROOT" || exit 2
@@ -44,6 +45,9 @@ for step in "$@"; do
        timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --kernel-include-regex "k_me_epzs|k_cu_bits|k_rdo_mfma|k_dct_mfma" --output-format csv -d /tmp/pmc_sq -o s -- python $R/$PROBE4K --gops $arg > $R/gpurun_out/${TAG}_pmc_sq_probe.log 2>&1; echo "pmc sq rc $?"
        timeout 1500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "k_me_epzs" --output-format csv -d /tmp/pmc_fetch -o f -- python $R/$PROBE4K --gops $arg > $R/gpurun_out/${TAG}_pmc_fetch_probe.log 2>&1; echo "pmc fetch rc $?")
       python tools/pmc_summary.py gpurun_out/${TAG}_pmc_all.json /tmp/pmc_sq /tmp/pmc_fetch 2>&1 | tail -1; rm -rf /tmp/pmc_sq /tmp/pmc_fetch ;;
+    par)
+      n=${arg%%:*}; r=${arg#*:}; e=${r%%:*}; g=${r#*:}
+      env ${e//,/ } timeout 1200 python tools/probe_par.py ${g//,/ } > gpurun_out/${TAG}_par_$n.log 2>&1; echo "par $n rc $?"; grep parts gpurun_out/${TAG}_par_$n.log | cut -c1-400 ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc $?"; tail -n 2 gpurun_out/${TAG}_smoke.log ;;
     *) echo "unknown step $step" ;;

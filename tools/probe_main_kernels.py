@@ -103,6 +103,36 @@ def main():
         timed("affine_mc 32x32 bi (%s)" % label, alg,
               lambda d_jobs=d_jobs, py=py, pu=pu, pv=pv: check(L.xeve_hip_affine_mc_jobs(tab.ctypes.data, 1, 1, SL, SC, W, H, d_jobs.data_ptr(), len(cus), cw, cw, 10, py.data_ptr(), pu.data_ptr(), pv.data_ptr(), None)))
         out["kernels"]["affine_mc 32x32 bi (%s)" % label]["cus"] = len(cus)
+    # the affine gradient search: every 32x32 (64x64) CU of the picture in ONE launch; a smooth texture, the original = the reference moved by a fraction of a sample + noise,
+    # so the searches run their rounds; algorithmic bytes at the full round budget: per compensation the window + per SATD and per error pass the original
+    yy, xx = torch.meshgrid(torch.arange(H + 2 * P, device=dev, dtype=torch.float32), torch.arange(SL, device=dev, dtype=torch.float32), indexing="ij")
+    tex = lambda x, y: 512 + 280 * torch.sin(x / 6.0 + y / 9.0) + 150 * torch.cos(y / 4.0 - x / 13.0)  # noqa: E731
+    ref = (tex(xx, yy) + torch.randint(-20, 21, xx.shape, device=dev, generator=g)).clamp(0, 1023).to(torch.int16).reshape(-1).contiguous()
+    cur = (tex(xx * 1.004 + 1.3, yy * 0.997 - 0.8) + torch.randint(-20, 21, xx.shape, device=dev, generator=g)).clamp(0, 1023).to(torch.int16)[P:P + H, P:P + W].contiguous()
+    tab_me = np.zeros(2, dtype=tab.dtype)
+    for l in range(2):
+        tab_me[l] = (ref.data_ptr() + 2 * (P * SL + P), 0, 0, l, 0)
+    MEJOB = np.dtype([("x", "<i4"), ("y", "<i4"), ("mvp", "<i2", (3, 2)), ("mv", "<i2", (3, 2)), ("refi", "i1"), ("list", "i1"), ("bi", "i1"), ("vertex_num", "i1"), ("mot_bits_other", "<i4"),
+                      ("cost", "<u4")])
+    for cw, vn in ((32, 2), (32, 3), (64, 2), (64, 3)):
+        cus = [(x, y) for y in range(0, H - cw + 1, cw) for x in range(0, W - cw + 1, cw)]
+        jobs = np.zeros(len(cus), MEJOB)
+        for i, (x, y) in enumerate(cus):
+            jobs[i]["x"], jobs[i]["y"], jobs[i]["vertex_num"] = x, y, vn
+        h_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy())
+        d_jobs = h_jobs.to(dev)
+        rounds = 7 - (2 if vn == 3 else 0)
+        alg = len(cus) * ((rounds + 1) * ((cw + 7) ** 2 + cw * cw) * 2 + rounds * cw * cw * 2 + 88)
+
+        def run(d_jobs=d_jobs, h_jobs=h_jobs, cw=cw, n=len(cus)):
+            d_jobs.copy_(h_jobs, non_blocking=True)  # (the launch moves the jobs' vectors: every repetition starts from the same ones)
+            check(L.xeve_hip_affine_me_jobs(tab_me.ctypes.data, 1, 1, SL, W, H, cur.data_ptr(), W, None, d_jobs.data_ptr(), n, cw, cw, 10, 1234567, 1, 1, None))
+
+        name = "affine_me %dx%d uni, %d control points" % (cw, cw, vn)
+        timed(name, alg, run)
+        res = d_jobs.cpu().numpy().view(MEJOB)
+        out["kernels"][name].update({"searches": len(cus), "moved": int(np.sum(np.any(res["mv"].reshape(len(cus), -1) != 0, axis=1))),
+                                     "searches_per_s": round(len(cus) / out["kernels"][name]["ms"] * 1e3) if "ms" in out["kernels"][name] else None})
     print(json.dumps(out))
 
 

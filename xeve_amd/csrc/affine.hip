@@ -39,6 +39,50 @@ struct LdsAt {
     __device__ int operator()(int r, int c) const { return p[r * pitch + c]; }
 };
 
+// one component (c: 0 luma, 1 / 2 chroma) of one list's prediction of the CU at (x, y): the reference samples it can touch are staged in LDS (buf) once, then the lanes of the
+// block take the component's samples in turn and write dst (dense); nth: the value is averaged into what the same lane wrote for the first list.  org: the component's
+// reference sample at the CU's first sample, s its pitch.
+__device__ void mc_component(const xaff::Model &m, bool eif, bool mem_ok, int sub_w, int sub_h, int x, int y, int w, int h, int pic_w, int pic_h, int c, const pel *org, long s,
+                             pel *dst, int nth, int bit_depth, pel *buf)
+{
+    const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h;
+    __syncthreads(); // (the previous component's readers are done with buf)
+    if(eif) {
+        int mx[2], mn[2];
+        xaff::eif_range(m, mem_ok, x, y, w, h, pic_w, pic_h, mx, mn);
+        const xaff::Eif e = xaff::eif_component(m, mx, mn, c != 0);
+        const int pitch = cw + 2;
+        for(int i = threadIdx.x; i < pitch * (ch + 2); i += blockDim.x) {
+            const int r = i / pitch, q = i - r * pitch;
+            buf[r * pitch + q] = (pel)xaff::eif_bilinear(GlobalAt{org, s}, e, q - 1, r - 1, bit_depth);
+        }
+        __syncthreads();
+        for(int i = threadIdx.x; i < cw * ch; i += blockDim.x) {
+            const int py = i / cw, px = i - py * cw, v = xaff::eif_out(LdsAt{buf, pitch}, px, py, bit_depth);
+            dst[i] = (pel)(nth ? (dst[i] + v + 1) >> 1 : v);
+        }
+    }
+    else {
+        int th, tv, oh, ov;
+        xaff::block_vector(m, sub_w, sub_h, x, y, w, h, pic_w, pic_h, th, tv, oh, ov);
+        const int fs = c ? 5 : 4, fm = (1 << fs) - 1, taps = c ? 4 : 8, back = taps / 2 - 1, pitch = cw + taps - 1;
+        const pel *win = org + (long)((tv >> fs) - back) * s + (th >> fs) - back; // the translated CU's first sample, `back` rows / columns earlier
+        for(int i = threadIdx.x; i < pitch * (ch + taps - 1); i += blockDim.x) {
+            const int r = i / pitch, q = i - r * pitch;
+            buf[r * pitch + q] = win[(long)r * s + q];
+        }
+        __syncthreads();
+        const bool     fx = (oh & fm) != 0, fy = (ov & fm) != 0;
+        const int16_t *cx = c ? c_main_c[th & fm] : c_main_l[th & fm], *cy = c ? c_main_c[tv & fm] : c_main_l[tv & fm];
+        for(int i = threadIdx.x; i < cw * ch; i += blockDim.x) {
+            const int   py = i / cw, px = i - py * cw;
+            const LdsAt at{buf + (py + back) * pitch + px + back, pitch};
+            const int   v = c ? xaff::mc_sample<4>(at, fx, fy, cx, cy, bit_depth) : xaff::mc_sample<8>(at, fx, fy, cx, cy, bit_depth);
+            dst[i] = (pel)(nth ? (dst[i] + v + 1) >> 1 : v);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_affine_mc(RefTab tab, long s_l, long s_c, int pic_w, int pic_h, const xeve_hip_affine_job *__restrict__ jobs, int w, int h, int bit_depth,
                                                    pel *__restrict__ pred_y, pel *__restrict__ pred_u, pel *__restrict__ pred_v)
 {
@@ -57,44 +101,169 @@ __global__ void __launch_bounds__(256) k_affine_mc(RefTab tab, long s_l, long s_
             const int  cw = c ? w >> 1 : w, ch = c ? h >> 1 : h;
             const long s = c ? s_c : s_l;
             const pel *org = (c == 0 ? rp.y : c == 1 ? rp.u : rp.v) + (long)(c ? jb.y >> 1 : jb.y) * s + (c ? jb.x >> 1 : jb.x);
-            pel *dst = (c == 0 ? pred_y : c == 1 ? pred_u : pred_v) + (size_t)blockIdx.x * cw * ch;
-            __syncthreads(); // (the previous component's readers are done with buf)
-            if(eif) {
-                int mx[2], mn[2];
-                xaff::eif_range(m, mem_ok, jb.x, jb.y, w, h, pic_w, pic_h, mx, mn);
-                const xaff::Eif e = xaff::eif_component(m, mx, mn, c != 0);
-                const int pitch = cw + 2;
-                for(int i = threadIdx.x; i < pitch * (ch + 2); i += blockDim.x) {
-                    const int r = i / pitch, q = i - r * pitch;
-                    buf[r * pitch + q] = (pel)xaff::eif_bilinear(GlobalAt{org, s}, e, q - 1, r - 1, bit_depth);
-                }
-                __syncthreads();
-                for(int i = threadIdx.x; i < cw * ch; i += blockDim.x) {
-                    const int py = i / cw, px = i - py * cw, v = xaff::eif_out(LdsAt{buf, pitch}, px, py, bit_depth);
-                    dst[i] = (pel)(nth ? (dst[i] + v + 1) >> 1 : v);
-                }
-            }
-            else {
-                int th, tv, oh, ov;
-                xaff::block_vector(m, sub_w, sub_h, jb.x, jb.y, w, h, pic_w, pic_h, th, tv, oh, ov);
-                const int fs = c ? 5 : 4, fm = (1 << fs) - 1, taps = c ? 4 : 8, back = taps / 2 - 1, pitch = cw + taps - 1;
-                const pel *win = org + (long)((tv >> fs) - back) * s + (th >> fs) - back; // the translated CU's first sample, `back` rows / columns earlier
-                for(int i = threadIdx.x; i < pitch * (ch + taps - 1); i += blockDim.x) {
-                    const int r = i / pitch, q = i - r * pitch;
-                    buf[r * pitch + q] = win[(long)r * s + q];
-                }
-                __syncthreads();
-                const bool     fx = (oh & fm) != 0, fy = (ov & fm) != 0;
-                const int16_t *cx = c ? c_main_c[th & fm] : c_main_l[th & fm], *cy = c ? c_main_c[tv & fm] : c_main_l[tv & fm];
-                for(int i = threadIdx.x; i < cw * ch; i += blockDim.x) {
-                    const int   py = i / cw, px = i - py * cw;
-                    const LdsAt at{buf + (py + back) * pitch + px + back, pitch};
-                    const int   v = c ? xaff::mc_sample<4>(at, fx, fy, cx, cy, bit_depth) : xaff::mc_sample<8>(at, fx, fy, cx, cy, bit_depth);
-                    dst[i] = (pel)(nth ? (dst[i] + v + 1) >> 1 : v);
-                }
-            }
+            mc_component(m, eif, mem_ok, sub_w, sub_h, jb.x, jb.y, w, h, pic_w, pic_h, c, org, s, (c == 0 ? pred_y : c == 1 ? pred_u : pred_v) + (size_t)blockIdx.x * cw * ch, nth,
+                         bit_depth, buf);
         }
         nth++;
+    }
+}
+
+// ---- the affine gradient search (pinter_affine_me_gradient, src_main/xevem_pinter.c:4290-4501): ONE workgroup carries a whole search -- the start compensation, then per
+// round the normal equations, the update and the next compensation -- with the CU's prediction resident in LDS from the compensation that writes it to the SATD, the error and
+// the Sobel derivatives that read it (the reference keeps pred / error / two derivative planes in memory and makes five passes over them per round; here a round is the
+// compensation's pass, one pass for the SATD and ONE fused pass that forms error, both derivatives and the 27 (14) sums of the normal equations in registers).  The scalar
+// steps (vector bits, solve_equal in double, the rounded update, the comparison) are lane 0's: affine_core.h me_*, held to the reference's goldens on the host as well.
+//   HBM traffic per round: the reference window ((w + 7) x (h + 7) samples) + the original twice (SATD, error); algorithmic bytes per search in DESIGN.md 5e.
+struct AffMeArgs {
+    RefTab         tab;
+    long           s_l, s_org;
+    const int16_t *org;        // the picture's original luma plane (sample (0, 0)); with org_dense: unused
+    const int16_t *org_blocks; // dense w x h block per job: the bi-prediction target of the jobs that have bi set (every job's original with org_dense)
+    xeve_hip_affine_me_job *jobs;
+    int      pic_w, pic_h, w, h, bit_depth, org_dense, num_refp[2];
+    uint32_t lambda_mv;
+};
+__device__ __forceinline__ long long wave_sum64(long long v)
+{
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) {
+        const int lo = __shfl_xor((int)(unsigned)(unsigned long long)v, m, 64), hi = __shfl_xor((int)((unsigned long long)v >> 32), m, 64);
+        v += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+    return v;
+}
+// SATD of the CU (xeve_had's tiling for CUs of 16 and more, xeve_sad.c:1051-1135: TW x TH = 16x8 when wider than high, 8x16 when higher, 8x8 when square): a lane per tile
+// ROW -- the row's Hadamard in registers, the columns' across the TH lanes of the tile by lane exchanges --, the tile's sum normalised on its first lane.  Returns the block's
+// total on every lane.  red: 4 ints of LDS.
+template <int TW, int TH> __device__ int satd_block(const int16_t *org, long s_org, const pel *pred, int w, int h, int *red)
+{
+    const int tiles_x = w / TW, rows = (w / TW) * h; // rows of tiles in all: a multiple of TH (and lanes of a tile are consecutive)
+    int acc = 0;
+    for(int base = 0; base < rows; base += blockDim.x) {
+        const int  item = base + threadIdx.x;
+        const bool on = item < rows;
+        const int  tile = item / TH, trow = item % TH, ty = tile / tiles_x, tx = tile - ty * tiles_x, r = ty * TH + trow, c0 = tx * TW;
+        int v[TW];
+#pragma unroll
+        for(int k = 0; k < TW; k++) v[k] = on ? (int)org[(long)r * s_org + c0 + k] - (int)pred[r * w + c0 + k] : 0;
+#pragma unroll
+        for(int len = 1; len < TW; len <<= 1)
+#pragma unroll
+            for(int i = 0; i < TW; i++)
+                if(!(i & len)) {
+                    const int a = v[i], b = v[i + len];
+                    v[i] = a + b, v[i + len] = a - b;
+                }
+#pragma unroll
+        for(int len = 1; len < TH; len <<= 1)
+#pragma unroll
+            for(int k = 0; k < TW; k++) {
+                const int o = __shfl_xor(v[k], len, 64);
+                v[k] = (trow & len) ? o - v[k] : v[k] + o;
+            }
+        int sa = 0;
+#pragma unroll
+        for(int k = 0; k < TW; k++) {
+            int a = v[k] < 0 ? -v[k] : v[k];
+            if(k == 0 && trow == 0) a >>= 2; // the tile's DC
+            sa += a;
+        }
+#pragma unroll
+        for(int len = 1; len < TH; len <<= 1) sa += __shfl_xor(sa, len, 64);
+        if(on && trow == 0) acc += TW == TH ? (sa + 2) >> 2 : (int)(sa / (2.0 * 2.8284271247461903)); // (xeve_sad.c:602; :748, :885: / (2 * sqrt(8)) in double)
+    }
+#pragma unroll
+    for(int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    __syncthreads(); // (red's previous readers)
+    if((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+template <int VN> __global__ void __launch_bounds__(256) k_affine_me(AffMeArgs A)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    constexpr int NP = 2 * VN, NS = NP * (NP + 1) / 2 + NP; // the upper triangle of the symmetric part + the right-hand side
+    const int w = A.w, h = A.h, n = w * h;
+    pel       *pred = reinterpret_cast<pel *>(lds), *buf = pred + n;
+    const int  nbuf = (w + 7) * (h + 7);
+    long long *red64 = reinterpret_cast<long long *>(lds + (((size_t)(n + nbuf) * sizeof(pel) + 15) & ~(size_t)15)); // [4][NS]
+    __shared__ int     red[4], s_stop;
+    __shared__ int16_t s_mvt[3][2];
+    xeve_hip_affine_me_job *const jp = A.jobs + blockIdx.x;
+    const xeve_hip_affine_me_job  jb = *jp;
+    if(jb.vertex_num != VN) return; // (the other model's launch carries it)
+    const int  bi = jb.bi, ri = jb.refi, num_refp = A.num_refp[jb.list & 1];
+    const bool dense = bi || A.org_dense;
+    const int16_t *org = dense ? A.org_blocks + (size_t)blockIdx.x * n : A.org + (long)jb.y * A.s_org + jb.x;
+    const long     s_org = dense ? w : A.s_org;
+    const pel     *ref = A.tab.r[ri * 2 + (jb.list & 1)].y + (long)jb.y * A.s_l + jb.x;
+    int16_t mvt[3][2], best[3][2];
+    for(int v = 0; v < 3; v++) mvt[v][0] = best[v][0] = jb.mv[v][0], mvt[v][1] = best[v][1] = jb.mv[v][1];
+    auto compensate = [&]() { // xeve_affine_mc_l (xevem_mc.c:1532-1669): the sub-block size of ONE list's model, the luma plane alone
+        const int8_t one[2] = {0, -1};
+        int16_t two[2][3][2];
+        for(int v = 0; v < 3; v++) two[0][v][0] = mvt[v][0], two[0][v][1] = mvt[v][1], two[1][v][0] = two[1][v][1] = 0;
+        int  sub_w, sub_h;
+        bool mem_ok;
+        xaff::subblock_size(one, two, VN, w, h, sub_w, sub_h, mem_ok);
+        mc_component(xaff::model(mvt, w, h, VN), sub_w < 8 || sub_h < 8, mem_ok, sub_w, sub_h, jb.x, jb.y, w, h, A.pic_w, A.pic_h, 0, ref, A.s_l, pred, 0, A.bit_depth, buf);
+        __syncthreads();
+    };
+    auto satd = [&]() { return w > h ? satd_block<16, 8>(org, s_org, pred, w, h, red) : w < h ? satd_block<8, 16>(org, s_org, pred, w, h, red) : satd_block<8, 8>(org, s_org, pred, w, h, red); };
+    compensate();
+    int      best_bits = xaff::me_mv_bits(mvt, jb.mvp, num_refp, ri, VN) + (bi ? jb.mot_bits_other : 0);
+    uint32_t cost_best = xaff::me_mv_cost(A.lambda_mv, best_bits) + (uint32_t)((satd() >> (A.bit_depth - 8)) >> bi);
+    const int rounds = (bi ? 5 : 7) - (VN == 3 ? 2 : 0); // AF_ITER_BI / AF_ITER_UNI (xeve_def.h:168-169), two fewer with three control points (:4380-4382)
+    for(int it = 0; it < rounds; it++) {
+        // error, both Sobel derivatives and the sample's products in one pass (xeve_diff_16b, xevem_scaled_*_sobel_filter, xevem_equal_coeff_computer: :4385-4404)
+        long long acc[NS];
+#pragma unroll
+        for(int q = 0; q < NS; q++) acc[q] = 0;
+        for(int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int j = i / w, k = i - j * w;
+            int32_t   c[6];
+            xaff::me_terms(LdsAt{pred, w}, w, h, j, k, VN, c);
+            const long long e8 = (long long)(int16_t)((int)org[(long)j * s_org + k] - (int)pred[i]) * 8;
+            int q = 0;
+#pragma unroll
+            for(int col = 0; col < NP; col++) {
+#pragma unroll
+                for(int row = col; row < NP; row++) acc[q++] += (long long)c[col] * c[row];
+                acc[q++] += (long long)c[col] * e8;
+            }
+        }
+#pragma unroll
+        for(int q = 0; q < NS; q++) acc[q] = wave_sum64(acc[q]);
+        if((threadIdx.x & 63) == 0)
+#pragma unroll
+            for(int q = 0; q < NS; q++) red64[(threadIdx.x >> 6) * NS + q] = acc[q];
+        __syncthreads();
+        if(threadIdx.x == 0) {
+            int64_t sums[7][7];
+            int q = 0;
+            for(int col = 0; col < NP; col++) {
+                for(int row = col; row < NP; row++, q++) sums[col + 1][row] = sums[row + 1][col] = red64[q] + red64[NS + q] + red64[2 * NS + q] + red64[3 * NS + q];
+                sums[col + 1][NP] = red64[q] + red64[NS + q] + red64[2 * NS + q] + red64[3 * NS + q], q++;
+            }
+            for(int c = 0; c <= NP; c++) sums[0][c] = 0;
+            int16_t mvd[3][2];
+            s_stop = xaff::me_update(sums, VN, w, h, mvd);
+            for(int v = 0; v < 3; v++) s_mvt[v][0] = (int16_t)(mvt[v][0] + mvd[v][0]), s_mvt[v][1] = (int16_t)(mvt[v][1] + mvd[v][1]);
+        }
+        __syncthreads();
+        if(s_stop) break; // (:4449-4458)
+        for(int v = 0; v < VN; v++) mvt[v][0] = s_mvt[v][0], mvt[v][1] = s_mvt[v][1];
+        compensate();
+        const int      bits = xaff::me_mv_bits(mvt, jb.mvp, num_refp, ri, VN) + (bi ? jb.mot_bits_other : 0);
+        const uint32_t cost = xaff::me_mv_cost(A.lambda_mv, bits) + (uint32_t)((satd() >> (A.bit_depth - 8)) >> bi);
+        if(cost < cost_best) {
+            cost_best = cost, best_bits = bits;
+            for(int v = 0; v < VN; v++) best[v][0] = mvt[v][0], best[v][1] = mvt[v][1];
+        }
+    }
+    if(threadIdx.x == 0) {
+        for(int v = 0; v < VN; v++) jp->mv[v][0] = best[v][0], jp->mv[v][1] = best[v][1];
+        jp->cost = cost_best - xaff::me_mv_cost(A.lambda_mv, best_bits);
     }
 }
 
@@ -171,5 +340,85 @@ extern "C" int xeve_hip_affine_mc_host(int x, int y, int pic_w, int pic_h, int w
     XH_HIP(hipMemcpyAsync(pred_u, dp + n0, n1 * sizeof(pel), hipMemcpyDeviceToHost, A.st));
     XH_HIP(hipMemcpyAsync(pred_v, dp + n0 + n1, n1 * sizeof(pel), hipMemcpyDeviceToHost, A.st));
     XH_HIP(hipStreamSynchronize(A.st));
+    return XEVE_HIP_OK;
+}
+
+// ---- the affine gradient search: every search of one CU size in ONE launch (a workgroup per search) ------------------------------------------------------------------------
+static int affine_me_launch(const AffMeArgs &A, int njobs, hipStream_t st)
+{
+    const int    n = A.w * A.h, nbuf = (A.w + 7) * (A.h + 7);
+    const size_t lds = (((size_t)(n + nbuf) * sizeof(pel) + 15) & ~(size_t)15) + 4 * 27 * sizeof(long long);
+    static bool  raised = false; // CUs of 128 need more than the 64 KB a kernel gets by default (gfx950: 160 KB per workgroup)
+    if(lds > 60000 && !raised) {
+        XH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_affine_me<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        XH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_affine_me<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        raised = true;
+    }
+    // a job belongs to the launch of its model (two / three control points); the other launch's workgroup returns at once
+    k_affine_me<2><<<njobs, 256, lds, st>>>(A);
+    XH_HIP(hipGetLastError());
+    k_affine_me<3><<<njobs, 256, lds, st>>>(A);
+    XH_HIP(hipGetLastError());
+    return XEVE_HIP_OK;
+}
+extern "C" int xeve_hip_affine_me_jobs(const xeve_hip_refpic *refp, int ntab0, int ntab1, int s_l, int pic_w, int pic_h, const xeve_hip_pel *org, int s_org, const int16_t *org_bi,
+                                       xeve_hip_affine_me_job *jobs, int njobs, int w, int h, int bit_depth, uint32_t lambda_mv, int num_refp0, int num_refp1, void *stream)
+{
+    XH_ENTER();
+    XH_REQUIRE(refp && ntab0 >= 0 && ntab1 >= 0 && ntab0 <= MAXREF && ntab1 <= MAXREF && ntab0 + ntab1 > 0 && s_l > 0 && pic_w > 0 && pic_h > 0 && org && s_org > 0);
+    XH_REQUIRE(njobs >= 0 && (njobs == 0 || jobs) && xh_pow2(w) && xh_pow2(h) && w >= 16 && h >= 16 && w <= 128 && h <= 128 && bit_depth >= 8 && bit_depth <= 12);
+    XH_REQUIRE(num_refp0 >= 0 && num_refp1 >= 0 && num_refp0 <= 16 && num_refp1 <= 16);
+    if(njobs == 0) return XEVE_HIP_OK;
+    AffMeArgs A;
+    memset(&A, 0, sizeof(A));
+    const int nr = ntab0 > ntab1 ? ntab0 : ntab1;
+    for(int r = 0; r < nr; r++)
+        for(int l = 0; l < 2; l++)
+            if(r < (l ? ntab1 : ntab0)) {
+                A.tab.r[r * 2 + l] = refp[r * 2 + l];
+                XH_REQUIRE(A.tab.r[r * 2 + l].y);
+            }
+    A.s_l = s_l, A.s_org = s_org, A.org = org, A.org_blocks = org_bi, A.jobs = jobs, A.pic_w = pic_w, A.pic_h = pic_h, A.w = w, A.h = h, A.bit_depth = bit_depth, A.org_dense = 0;
+    A.num_refp[0] = num_refp0, A.num_refp[1] = num_refp1, A.lambda_mv = lambda_mv;
+    return affine_me_launch(A, njobs, (hipStream_t)stream);
+}
+
+// ---- host-memory form of ONE pinter_affine_me_gradient call (src_main/xevem_pinter.c:4290-4501): what the Main-profile encoder's pi->fn_affine_me can be bound to
+// (oracle/ref_shim_affine.c does).  ref_y: HOST luma plane (sample (0, 0)) of refp[refi][list].pic, extending pad_l samples around the picture; org: the CU's
+// first original sample with its pitch (bi: pi->org_bi, pitch w); mv: in the start vectors, out the best ones (vertex_num of them); *cost: the function's value.  Per calling
+// thread one stream and one device arena (grow-only): a call is the upload of the picture and of the CU's original, two launches, the download of the job record.
+extern "C" int xeve_hip_affine_me_host(int x, int y, int pic_w, int pic_h, int w, int h, int refi, int list, const int16_t mvp[3][2], int16_t mv[3][2], int bi, int vertex_num,
+                                       const xeve_hip_pel *ref_y, int s_l, int pad_l, const int16_t *org, int s_org, int bit_depth, uint32_t lambda_mv, int num_refp,
+                                       int mot_bits_other, uint32_t *cost)
+{
+    XH_ENTER();
+    XH_REQUIRE(mvp && mv && ref_y && org && cost && (vertex_num == 2 || vertex_num == 3) && pad_l >= 0 && s_l > 0 && s_org > 0 && pic_w > 0 && pic_h > 0);
+    XH_REQUIRE(refi >= 0 && refi < MAXREF && (list == 0 || list == 1) && num_refp > refi && num_refp <= 16 && xh_pow2(w) && xh_pow2(h) && w >= 16 && h >= 16 && w <= 128 && h <= 128);
+    const size_t el = (size_t)s_l * (pic_h + 2 * pad_l), ol = (size_t)pad_l * s_l + pad_l, n = (size_t)w * h;
+    const size_t o_plane = 256, o_org = o_plane + ((el * sizeof(pel) + 255) & ~(size_t)255), total = o_org + n * sizeof(int16_t);
+    static thread_local XhHostArena A;
+    const int rc0 = A.ensure(total, 0);
+    if(rc0 != XEVE_HIP_OK) return rc0;
+    xeve_hip_affine_me_job *J = reinterpret_cast<xeve_hip_affine_me_job *>(A.pin);
+    memset(J, 0, sizeof(*J));
+    J->x = x, J->y = y, J->refi = (int8_t)refi, J->list = (int8_t)list, J->bi = (int8_t)(bi != 0), J->vertex_num = (int8_t)vertex_num, J->mot_bits_other = mot_bits_other;
+    for(int v = 0; v < 3; v++)
+        for(int c = 0; c < 2; c++) J->mvp[v][c] = v < vertex_num ? mvp[v][c] : (int16_t)0, J->mv[v][c] = v < vertex_num ? mv[v][c] : (int16_t)0;
+    int16_t *ho = reinterpret_cast<int16_t *>(A.pin + o_org);
+    for(int r = 0; r < h; r++) memcpy(ho + (size_t)r * w, org + (size_t)r * s_org, (size_t)w * sizeof(int16_t));
+    XH_HIP(hipMemcpyAsync(A.dev, J, sizeof(*J), hipMemcpyHostToDevice, A.st));
+    XH_HIP(hipMemcpyAsync(A.dev + o_org, ho, n * sizeof(int16_t), hipMemcpyHostToDevice, A.st));
+    XH_HIP(hipMemcpyAsync(A.dev + o_plane, ref_y - ol, el * sizeof(pel), hipMemcpyHostToDevice, A.st));
+    AffMeArgs K;
+    memset(&K, 0, sizeof(K));
+    K.tab.r[refi * 2 + list].y = reinterpret_cast<const pel *>(A.dev + o_plane) + ol;
+    K.s_l = s_l, K.s_org = w, K.org = nullptr, K.org_blocks = reinterpret_cast<const int16_t *>(A.dev + o_org), K.jobs = reinterpret_cast<xeve_hip_affine_me_job *>(A.dev);
+    K.pic_w = pic_w, K.pic_h = pic_h, K.w = w, K.h = h, K.bit_depth = bit_depth, K.org_dense = 1, K.num_refp[0] = K.num_refp[1] = num_refp, K.lambda_mv = lambda_mv;
+    const int rc = affine_me_launch(K, 1, A.st);
+    if(rc != XEVE_HIP_OK) return rc;
+    XH_HIP(hipMemcpyAsync(J, A.dev, sizeof(*J), hipMemcpyDeviceToHost, A.st));
+    XH_HIP(hipStreamSynchronize(A.st));
+    for(int v = 0; v < vertex_num; v++) mv[v][0] = J->mv[v][0], mv[v][1] = J->mv[v][1];
+    *cost = J->cost;
     return XEVE_HIP_OK;
 }

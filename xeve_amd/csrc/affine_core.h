@@ -147,4 +147,100 @@ template <class Bl> XF int eif_out(Bl bl, int px, int py, int bit_depth)
     return clip3(0, (1 << bit_depth) - 1, res);
 }
 
+// ---- the affine gradient search's scalar steps (pinter_affine_me_gradient, src_main/xevem_pinter.c:4290-4501): what ONE lane of k_affine_me does between the block-wide
+// passes (compensation, SATD, the normal equations' sums).  Double arithmetic exactly as the reference's build does it: no contraction (the library is compiled with
+// -ffp-contract=off), IEEE division.
+// one component of get_affine_mv_bits (:4257-4288): xeve_tbl_mv_bits in closed form inside (-2048, 2048] (xeve_tbl.c:286-496, its -2047 entry holds 22), the MAIN profile's
+// exp-Golomb length beyond (xevem_pinter.c:217-237)
+XF int me_mvd_bits(int mvd)
+{
+    const unsigned a = (unsigned)(mvd < 0 ? -mvd : mvd);
+    if(mvd > 2048 || mvd <= -2048) {
+        unsigned nn = (a + 1) >> 1;
+        int len = 0;
+        for(; len < 16 && nn != 0; len++) nn >>= 1;
+        return (len << 1) + 2; // (a != 0 here: the sign bit)
+    }
+    if(mvd == 0) return 1;
+    if(mvd == -2047) return 22;
+    int l = 0;
+    while(((a + 1) >> (l + 1)) != 0) l++;
+    return 2 * l + 2;
+}
+XF int me_refi_bits(int num_refp, int refi) { return num_refp <= 1 ? 0 : refi == num_refp - 1 ? refi : refi + 1; } // xeve_tbl_refi_bits (xeve_tbl.c:498-516)
+XF int me_mv_bits(const int16_t mv[3][2], const int16_t mvp[3][2], int num_refp, int refi, int vertex_num)
+{
+    bool zero = true;
+    for(int v = 0; v < vertex_num; v++) zero = zero && mv[v][0] == mvp[v][0] && mv[v][1] == mvp[v][1];
+    if(zero) return 1;
+    int bits = 1;
+    for(int v = 0; v < vertex_num; v++) {
+        int dx = mv[v][0] - mvp[v][0], dy = mv[v][1] - mvp[v][1];
+        if(v) dx -= mv[0][0] - mvp[0][0], dy -= mv[0][1] - mvp[0][1];
+        bits += me_mvd_bits(dx) + me_mvd_bits(dy);
+    }
+    return bits + me_refi_bits(num_refp, refi);
+}
+XF uint32_t me_mv_cost(uint32_t lambda_mv, int bits) { return (lambda_mv * (uint32_t)bits + (1u << 15)) >> 16; } // MV_COST (:53)
+// (s16)(double) as the reference's x86-64 build converts: cvttsd2si to 32 bits (0x80000000 for NaN and anything outside the range), the low 16 bits kept
+XF int16_t me_to_s16(double v)
+{
+    const int32_t t = (v >= -2147483648.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
+    return (int16_t)(uint16_t)(uint32_t)t;
+}
+XF double me_abs(double v) { return v < 0 ? -v : v; } // (fabs of a NaN stays a NaN, of -0.0 becomes -0.0 here: neither changes a `>` comparison below)
+// solve_equal (:4213-4255): Gaussian elimination with row pivoting on eq[1 .. order][0 .. order], row 0 as scratch
+XF void me_solve(double (*eq)[7], int order, double *para)
+{
+    for(int i = 1; i < order; i++) {
+        double best = me_abs(eq[i][i - 1]);
+        int at = i;
+        for(int j = i + 1; j < order + 1; j++)
+            if(me_abs(eq[j][i - 1]) > best) best = me_abs(eq[j][i - 1]), at = j;
+        if(at != i)
+            for(int j = 0; j < order + 1; j++) eq[0][j] = eq[i][j], eq[i][j] = eq[at][j], eq[at][j] = eq[0][j];
+        for(int j = i + 1; j < order + 1; j++)
+            for(int k = i; k < order + 1; k++) eq[j][k] = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
+    }
+    para[order - 1] = eq[order][order] / eq[order][order - 1];
+    for(int i = order - 2; i >= 0; i--) {
+        double t = 0;
+        for(int j = i + 1; j < order; j++) t += eq[i + 1][j] * para[j];
+        para[i] = (eq[i + 1][order] - t) / eq[i + 1][i];
+    }
+}
+// the round's update of the control points from the 64-bit sums (:4404-4447): sums[r][c] = equal_coeff_t[r][c], rows 1 .. 2 * vertex_num; returns whether it is all zero
+XF bool me_update(const int64_t (*sums)[7], int vertex_num, int cuw, int cuh, int16_t mvd[3][2])
+{
+    const int np = vertex_num << 1;
+    double eq[7][7], para[6], d[6];
+    for(int r = 0; r < np + 1; r++)
+        for(int c = 0; c < np + 1; c++) eq[r][c] = (double)sums[r][c];
+    me_solve(eq, np, para);
+    d[0] = para[0], d[2] = para[2], d[1] = para[1] * cuw + para[0];
+    if(vertex_num == 3) d[3] = para[3] * cuw + para[2], d[4] = para[4] * cuh + para[0], d[5] = para[5] * cuh + para[2];
+    else d[3] = -para[3] * cuw + para[2], d[4] = d[5] = 0;
+    const int order[6] = {0, 2, 1, 3, 4, 5}; // mvd[0] = (d0, d2), mvd[1] = (d1, d3), mvd[2] = (d4, d5)
+    bool zero = true;
+    for(int v = 0; v < 3; v++)
+        for(int c = 0; c < 2; c++) {
+            const double t = d[order[v * 2 + c]];
+            mvd[v][c] = v < vertex_num ? me_to_s16(t * 4 + (t >= 0 ? 0.5 : -0.5)) : (int16_t)0;
+            zero = zero && mvd[v][c] == 0;
+        }
+    return zero;
+}
+// the Sobel derivatives of the prediction at (row j, column k) (xevem_scaled_horizontal / _vertical_sobel_filter, xevem_mc.c:2341-2395: border samples take the inner
+// neighbour's value) and the sample's terms of the normal equations (xevem_equal_coeff_computer, :2397-2447: 32-bit products, wrapping)
+template <class P> XF void me_terms(P pred /* (row, col) */, int w, int h, int j, int k, int vertex_num, int32_t c[6])
+{
+    const int cy = clip3(1, h - 2, j), cx = clip3(1, w - 2, k);
+    const int a = pred(cy - 1, cx - 1), b = pred(cy - 1, cx), e = pred(cy - 1, cx + 1), l = pred(cy, cx - 1), r = pred(cy, cx + 1), f = pred(cy + 1, cx - 1), g = pred(cy + 1, cx),
+              q = pred(cy + 1, cx + 1);
+    const int32_t d0 = e - a + 2 * r - 2 * l + q - f, d1 = f - a + 2 * g - 2 * b + q - e;
+    const uint32_t u0 = (uint32_t)d0, u1 = (uint32_t)d1, uj = (uint32_t)j, uk = (uint32_t)k;
+    if(vertex_num == 2) c[0] = d0, c[1] = (int32_t)(uk * u0 + uj * u1), c[2] = d1, c[3] = (int32_t)(uj * u0 - uk * u1), c[4] = c[5] = 0;
+    else c[0] = d0, c[1] = (int32_t)(uk * u0), c[2] = d1, c[3] = (int32_t)(uk * u1), c[4] = (int32_t)(uj * u0), c[5] = (int32_t)(uj * u1);
+}
+
 } // namespace xaff

@@ -153,6 +153,9 @@ FUNCTIONS = {
     # Main profile: the adaptive loop filter's sample kernels (include/xeve_hip.h, src_main/xevem_alf.c)
     "xeve_hip_affine_mc_host": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int]),
+    "xeve_hip_affine_me_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.c_uint32, c_int, c_int, c_void_p]),
+    "xeve_hip_affine_me_host": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, C.c_uint32,
+                                        c_int, c_int, c_void_p]),
     "xeve_hip_affine_mc_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xeve_hip_alf_copy_and_extend": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "xeve_hip_alf_classify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
