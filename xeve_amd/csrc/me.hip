@@ -37,6 +37,32 @@ __device__ __constant__ int8_t c_dia16[16][2] = {{-4, 0}, {-3, 1}, {-2, 2}, {-1,
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// ---- per-block minima by DPP alone (wave64): quad exchanges and the two row mirrors make every row of 16 lanes uniform, row_bcast:15 / :31 carry the rows' minima up to lane
+// 63, v_readlane brings the wave's minimum back as a scalar.  No LDS crossbar (ds_bpermute) on the search's critical path.
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_rows(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); } // (rows not named keep v)
+#define XH_DPP_ROW_BCAST15 0x142 // lane 15 of a row -> every lane of the next row
+#define XH_DPP_ROW_BCAST31 0x143 // lane 31 -> every lane of rows 2 and 3
+// the minimum of a 64-bit key over the wave and the payload of the lane that holds it; both wave-uniform on return (keys are distinct, or ~0 with no payload of interest)
+__device__ __forceinline__ void wave_min_key(unsigned long long &key, int &pay)
+{
+#define XH_KEY_STEP(EX)                                                                      \
+    {                                                                                        \
+        const unsigned lo = (unsigned)EX((int)(unsigned)key), hi = (unsigned)EX((int)(unsigned)(key >> 32)); \
+        const int      ob = EX(pay);                                                         \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                   \
+        if(o < key) key = o, pay = ob;                                                       \
+    }
+    XH_KEY_STEP(xh_dpp<XH_DPP_QUAD_XOR1>)
+    XH_KEY_STEP(xh_dpp<XH_DPP_QUAD_XOR2>)
+    XH_KEY_STEP(xh_dpp<XH_DPP_ROW_HALF_MIRROR>)
+    XH_KEY_STEP(xh_dpp<XH_DPP_ROW_MIRROR>)
+    XH_KEY_STEP((dpp_rows<XH_DPP_ROW_BCAST15, 0xA>))
+    XH_KEY_STEP((dpp_rows<XH_DPP_ROW_BCAST31, 0xC>))
+#undef XH_KEY_STEP
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), 63);
+    key = ((unsigned long long)hi << 32) | lo, pay = __builtin_amdgcn_readlane(pay, 63);
+}
+
 // the original block of a job (org_bi for bi-prediction refinement: 2*org - pred, may be negative): loaded once, kept in registers
 template <int S, bool BI>
 __device__ __forceinline__ void me_load_org(const pel *__restrict__ org0, int s_org, const pel *__restrict__ org_bi, int x, int y, int org_off, int lane,
@@ -155,13 +181,7 @@ __device__ __forceinline__ xeve_hip_me_result me_diamond(const u32x4 (&org)[MGeo
             unsigned long long key = valid ? ((unsigned long long)cost << 32) | (order + (unsigned)k) : ~0ull;
             int kb = bits;
             // minimum over the CPP candidate groups of this pass (every lane of a group holds the same key)
-#pragma unroll
-            for(int m = G::GROUP; m < 64; m <<= 1) {
-                const unsigned lo = __shfl_xor((unsigned)key, m, 64), hi = __shfl_xor((unsigned)(key >> 32), m, 64);
-                const int ob = __shfl_xor(kb, m, 64);
-                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-                if(o < key) key = o, kb = ob;
-            }
+            wave_min_key(key, kb);
             if(key < round_key) round_key = key, round_bits = kb;
         }
         // ---- wave-uniform bookkeeping (everything below is identical in all lanes; force it into SGPRs)
@@ -240,13 +260,7 @@ __device__ __forceinline__ void me_eval(const u32x4 (&org)[MGeo<S>::NP], const p
         const unsigned cost = ((P.lambda_mv * (unsigned)bits + (1u << 15)) >> 16) + (unsigned)(BI ? sad >> 1 : sad);
         unsigned long long key = valid ? ((unsigned long long)cost << 32) | (unsigned)(k + 1) : ~0ull;
         int kb = bits;
-#pragma unroll
-        for(int m = G::GROUP; m < 64; m <<= 1) {
-            const unsigned lo = __shfl_xor((unsigned)key, m, 64), hi = __shfl_xor((unsigned)(key >> 32), m, 64);
-            const int ob = __shfl_xor(kb, m, 64);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            if(o < key) key = o, kb = ob;
-        }
+        wave_min_key(key, kb);
         if(key < best_key) best_key = key, win = (int)(unsigned)key - 1, win_bits = kb;
     }
     win = uni(win);
@@ -312,9 +326,9 @@ __device__ __forceinline__ unsigned cpl_wave_min(unsigned v)
     v = min(v, (unsigned)xh_dpp<XH_DPP_QUAD_XOR2>((int)v));
     v = min(v, (unsigned)xh_dpp<XH_DPP_ROW_HALF_MIRROR>((int)v));
     v = min(v, (unsigned)xh_dpp<XH_DPP_ROW_MIRROR>((int)v));
-    v = min(v, (unsigned)__shfl_xor((int)v, 16, 64));
-    v = min(v, (unsigned)__shfl_xor((int)v, 32, 64));
-    return v;
+    v = min(v, (unsigned)dpp_rows<XH_DPP_ROW_BCAST15, 0xA>((int)v));
+    v = min(v, (unsigned)dpp_rows<XH_DPP_ROW_BCAST31, 0xC>((int)v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63); // (a scalar: the comparisons against it and the ballot that follow are wave-uniform by construction)
 }
 
 template <bool BI> __device__ __forceinline__ unsigned cpl_cost(int mx, int my, int sad_raw, int shift, int gx, int gy, const xeve_hip_me_params &P, int &bits)
