@@ -152,6 +152,9 @@ BATCH_CASES_REAL = {
     # config 3; sixteen low-delay B pictures whose reference lists slide over the decoded picture buffer in config 2)
     "cfg2_720p_ldb_fast_17f_m8": (1280, 720, 1, 17, 2, ["--preset", "fast", "-b", "0", "-I", "0"], 8),
     "cfg3_1080p_ra_medium_17f_m8": (1920, 1080, 1, 17, 3, ["--preset", "medium"], 8),
+    # VERDICT r05 "missing" 4: config 2 at its STATED length -- one 64-frame low-delay GOP at 1280x720 (63 B pictures behind the I picture: the reference lists slide over the
+    # decoded picture buffer for four sub-GOPs, the QP offsets of the low-delay hierarchy repeat every 8 pictures)
+    "cfg2_720p_ldb_fast_64f_m8": (1280, 720, 1, 64, 2, ["--preset", "fast", "-b", "0", "-I", "0"], 8),
 }
 
 # 10-bit input (the application's -d 10: 16-bit little-endian samples, handed to the codec as they are): the 8-bit clip of the seed widened by widen10

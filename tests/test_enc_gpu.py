@@ -258,7 +258,7 @@ def test_presets_slow_and_placebo_at_1920x1080_on_the_gpu(name, hip, yuv_dir):
 # at width), the whole 8-frame 1080p GOP and (round 6) the whole 8-frame 3840x2160 GOP of config 4 on the composed walk -- and leaves the forms those contain (9 frames of
 # config 3, 2 frames / IDR + two B pictures of config 4) and the repeats (17 frames of config 2, the moving 1080p GOPs, the 4K GOP on the fused kernel) to XEVE_GPU_FULL=1.
 REAL_DEFAULT = {"cfg3_1080p_ra_medium_17f_m8": -1, "cfg2_720p_ldb_fast_8f_m8": 0}  # name -> walk (xeve_hip_walk_select)
-REAL_FULL = {"cfg2_720p_ldb_fast_17f_m8": -1, "gops_1080p_moving_m8": 0, "cfg3_1080p_ra_medium_9f_m8": 0, "cfg4_2160p_closedgop_medium_2f_m8": -1}
+REAL_FULL = {"cfg2_720p_ldb_fast_17f_m8": -1, "cfg2_720p_ldb_fast_64f_m8": 0, "gops_1080p_moving_m8": 0, "cfg3_1080p_ra_medium_9f_m8": 0, "cfg4_2160p_closedgop_medium_2f_m8": -1}
 assert set(REAL_DEFAULT) | set(REAL_FULL) == set(_enc.BATCH_CASES_REAL)
 WALK_NAME = {-1: "by_width", 0: "composed", 1: "fused"}
 
