@@ -916,7 +916,8 @@ void          xeve_hip_enc_delete(xeve_hip_enc *e);
  * before the call returns (as xeve_push copies its image); the copy runs on the encoder's own stream, so device memory must be COMPLETE when the call is made --
  * work still queued on another stream that produces it is not waited for. */
 int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint8_t *yuv, int on_device);
-/* Codes every run (synchronous).  May be called again after new frames were pushed. */
+/* Codes every run (synchronous).  A run CONSUMES its frames -- the picture stores of later pictures reuse the memory of frames already coded -- so every frame
+ * must be pushed again before the next run of the same object (xeve_hip_enc_begin refuses otherwise). */
 int xeve_hip_enc_encode(xeve_hip_enc *e);
 /* The same in slices: xeve_hip_enc_begin, then xeve_hip_enc_advance until *remaining is 0.  The unit is the LOCKSTEP STEP -- one CTU of every row chain of every
  * run decided and written (xeve_ctu_mt_core's loop body, xeve_enc.c:128-170) -- a picture's set-up rides on its first step, its end (loop filter, slice data, NAL

@@ -16,6 +16,7 @@ SETTINGS = {
     "transforms_on_the_valu_path": {"XEVE_HIP_DCT": "valu"},
     "writer_on_a_lone_lane": {"XEVE_HIP_WRITER_WAVE": "0"},
     "one_ctu_store": {"XEVE_HIP_ENC_TWO_STORES": "0"},
+    "stores_in_memory_of_their_own": {"XEVE_HIP_ENC_SHARE": "0"},
     "rdo_rounds_speculated_at_any_width": {"XEVE_HIP_RDO_SPEC": "100000000"},
     "rdo_rounds_never_speculated": {"XEVE_HIP_RDO_SPEC": "0"},
     "walk_from_a_graph": {"XEVE_HIP_TREE_SIDE": "0", "XEVE_HIP_TREE_GRAPH": "1"},

@@ -211,6 +211,17 @@ struct xeve_hip_enc {
     hipStream_t st = nullptr, st2 = nullptr, collect_stream = nullptr; // st2: the second writer pass, beside the next picture's steps
     hipEvent_t  ev_ready = nullptr, ev_done = nullptr;
     bool rows_pending = false, two_stores = false;
+    // The stores of later pictures live in the memory of input frames already coded: the frames are kept in CODING order ([position][GOP]), a picture's frame is dead once
+    // begin_picture has widened it into `org`, and store s is first written while the picture at position >= s is coded (the frame loop takes the lowest free store) -- so
+    // the a-th store placed over the frames' buffer may take [a, a + 1) store sizes of it as soon as that ends inside the first s + 1 frames.  At 3840x2160 two of the five
+    // stores of an 8-frame GOP (62 MB of 452 MB per GOP).  A run consumes its frames: push them again before the next begin().
+    std::vector<int>  pos_of_frame;           // input frame -> coding position
+    std::vector<long> slot_in_frames;         // per store: its index among the stores placed over the frames' buffer, or -1 (a store of slot_planes)
+    std::vector<int>  slot_own;               // per store: its index inside slot_planes (stores that are not placed over the frames)
+    std::vector<char> slot_clean;             // per store placed over the frames: zeroed in this run (the stores start from zero, as create() leaves slot_planes)
+    int  n_own = 0;
+    long pushed = 0;                          // frames pushed since the last run began
+    bool ran = false;
     int  cur_store = 0; // the store the picture being decided fills
     xeve_hip_sbac *fin = nullptr;
     int fin_stride = 1;
@@ -238,7 +249,8 @@ struct xeve_hip_enc {
     bool rc_ok(int rc, const char *what) { return rc == XEVE_HIP_OK ? true : fail(std::string(what) + ": " + xeve_hip_last_error()); }
     pel *slot_plane(int slot, int c) const // sample (0, 0) of GOP 0's picture in store `slot`
     {
-        pel *base = slot_planes.as<pel>() + (size_t)slot * ((size_t)G * (pic_l + 2 * pic_c));
+        const size_t store = (size_t)G * (pic_l + 2 * pic_c);
+        pel *base = slot_in_frames[slot] >= 0 ? frames.as<pel>() + (size_t)slot_in_frames[slot] * store : slot_planes.as<pel>() + (size_t)slot_own[slot] * store;
         return c == 0 ? base + (size_t)PAD_L * s_l + PAD_L : base + (size_t)G * pic_l + (size_t)(c - 1) * G * pic_c + (size_t)PAD_C * s_c + PAD_C;
     }
     int16_t *slot_map_mv(int slot) const { return slot_mv.as<int16_t>() + (size_t)slot * G * map_pic * 4; }
@@ -258,6 +270,22 @@ struct xeve_hip_enc {
         rewrite_mode = T > 1 || (P_reserved0 & 1);
         nslots = BatchEncoder<xeve_hip_enc>::slots_needed(P, F);
         if(nslots < 1) return fail("the frame loop needs more picture stores than there are");
+        const std::vector<PicPlan> plan = Planner(P, F).run();
+        pos_of_frame.assign(F, -1);
+        for(size_t i = 0; i < plan.size(); i++)
+            if(plan[i].frame >= 0 && plan[i].frame < F && pos_of_frame[plan[i].frame] < 0) pos_of_frame[plan[i].frame] = (int)i;
+        bool in_order = (int)plan.size() == F;
+        for(int f = 0; f < F; f++) in_order = in_order && pos_of_frame[f] >= 0;
+        static const bool share = !(getenv("XEVE_HIP_ENC_SHARE") && atoi(getenv("XEVE_HIP_ENC_SHARE")) == 0); // developer switch: 0 = every store in slot_planes
+        slot_in_frames.assign(nslots, -1), slot_own.assign(nslots, 0), slot_clean.assign(nslots, 0), n_own = 0;
+        if(!in_order) // (a run whose plan does not code every frame exactly once keeps the frames where they were pushed)
+            for(int f = 0; f < F; f++) pos_of_frame[f] = f;
+        const double store = (double)(pic_l + 2 * pic_c) * 2, frame = (double)frame_bytes;
+        long a = 0;
+        for(int sl = 0; sl < nslots; sl++) {
+            if(share && in_order && (a + 1) * store <= (sl + 1) * frame && (a + 1) * store <= (double)F * frame) slot_in_frames[sl] = a++;
+            else slot_own[sl] = n_own++;
+        }
         return true;
     }
     // every device buffer of the batch with its size (the second CTU store apart: the batch runs without it)
@@ -266,7 +294,7 @@ struct xeve_hip_enc {
         const size_t nst = (size_t)G * T, m = (size_t)G * map_pic;
         std::vector<std::pair<DevBuf *, size_t>> v = {
             {&frames, (size_t)G * F * frame_bytes}, {&org[0], (size_t)G * org_l * 2}, {&org[1], (size_t)G * org_c * 2}, {&org[2], (size_t)G * org_c * 2},
-            {&slot_planes, (size_t)nslots * G * (pic_l + 2 * pic_c) * 2}, {&slot_mv, (size_t)nslots * m * 8}, {&slot_refi, (size_t)nslots * m * 2},
+            {&slot_planes, std::max<size_t>(1, (size_t)n_own) * G * (pic_l + 2 * pic_c) * 2}, {&slot_mv, (size_t)nslots * m * 8}, {&slot_refi, (size_t)nslots * m * 2},
             {&scu, m * 4}, {&cum, m * 4}, {&ipm, m}, {&tidx, m}, {&states, nst * sizeof(xeve_hip_sbac)}, {&rw_states, (size_t)G * sizeof(xeve_hip_sbac)},
             {&jobs, nst * sizeof(xeve_hip_ctu_job)}, {&out, nst * sizeof(xeve_hip_ctu_data)}, {&next_best, nst * sizeof(xeve_hip_sbac)}, {&cost, nst * 8},
             {&slice, (size_t)G * slice_cap}, {&pos, (size_t)G * 4}};
@@ -376,11 +404,16 @@ struct xeve_hip_enc {
         const long n = (long)P.w * P.h;
         const dim3 lg((unsigned)((n + 255) / 256), G);
         if(P.input_depth > 8)
-            k_enc_load<uint16_t, 0><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(), org[1].as<pel>(), org[2].as<pel>(),
-                                                        P.w, P.h, org_l, org_c);
+            k_enc_load<uint16_t, 0><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), frame_bytes, (long)pos_of_frame[S.frame] * G * frame_bytes, org[0].as<pel>(), org[1].as<pel>(),
+                                                        org[2].as<pel>(), P.w, P.h, org_l, org_c);
         else
-            k_enc_load<uint8_t, BIT_DEPTH - 8><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), (long)F * frame_bytes, (long)S.frame * frame_bytes, org[0].as<pel>(), org[1].as<pel>(),
-                                                                   org[2].as<pel>(), P.w, P.h, org_l, org_c);
+            k_enc_load<uint8_t, BIT_DEPTH - 8><<<lg, 256, 0, st>>>(frames.as<uint8_t>(), frame_bytes, (long)pos_of_frame[S.frame] * G * frame_bytes, org[0].as<pel>(),
+                                                                   org[1].as<pel>(), org[2].as<pel>(), P.w, P.h, org_l, org_c);
+        if(slot_in_frames[S.cur_slot] >= 0 && !slot_clean[S.cur_slot]) { // (behind the load on the same stream: this picture's own frame may lie inside the store)
+            if(pos_of_frame[S.frame] < S.cur_slot) fail("a picture store over the frames' buffer is taken before the frames it covers are coded");
+            hip_ok(hipMemsetAsync(slot_plane(S.cur_slot, 0) - ((size_t)PAD_L * s_l + PAD_L), 0, (size_t)G * (pic_l + 2 * pic_c) * 2, st), "hipMemset");
+            slot_clean[S.cur_slot] = 1;
+        }
         hip_ok(hipMemsetAsync(scu.p, 0, scu.bytes, st), "hipMemset"), hip_ok(hipMemsetAsync(cum.p, 0, cum.bytes, st), "hipMemset"); // xeve_pic_prepare (:1236-1237)
         hip_ok(hipMemsetAsync(slot_map_mv(S.cur_slot), 0, (size_t)G * map_pic * 8, st), "hipMemset"); // (:1220-1225)
         hip_ok(hipMemsetAsync(slot_map_refi(S.cur_slot), 0xFF, (size_t)G * map_pic * 2, st), "hipMemset");
@@ -563,8 +596,10 @@ extern "C" int xeve_hip_enc_push(xeve_hip_enc *e, int gop, int frame, const uint
 {
     XH_ENTER();
     XH_REQUIRE(e && yuv && gop >= 0 && gop < e->G && frame >= 0 && frame < e->F);
-    XH_HIP(hipMemcpyAsync(e->frames.as<uint8_t>() + ((size_t)gop * e->F + frame) * e->frame_bytes, yuv, e->frame_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->st));
+    XH_HIP(hipMemcpyAsync(e->frames.as<uint8_t>() + ((size_t)e->pos_of_frame[frame] * e->G + gop) * e->frame_bytes, yuv, e->frame_bytes,
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->st));
     XH_HIP(hipStreamSynchronize(e->st));
+    e->pushed++;
     return XEVE_HIP_OK;
 }
 extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
@@ -572,6 +607,14 @@ extern "C" int xeve_hip_enc_begin(xeve_hip_enc *e)
     XH_ENTER();
     XH_REQUIRE(e);
     e->error.clear(), e->n_steps = 0, e->t_steps = e->t_ends = 0;
+    bool shares = false;
+    for(long v : e->slot_in_frames) shares = shares || v >= 0;
+    if(shares && e->ran && e->pushed < (long)e->G * e->F) {
+        xh_set_error("xeve_hip_enc_begin: the last run consumed its frames (picture stores reuse the memory of frames already coded): push every frame again before the next run");
+        return XEVE_HIP_ERR_ARG;
+    }
+    e->ran = true, e->pushed = 0;
+    std::fill(e->slot_clean.begin(), e->slot_clean.end(), 0);
     e->loop.reset(new BatchEncoder<xeve_hip_enc>(*e, e->P, e->G, e->F));
     e->loop->always_rewrite = (e->P_reserved0 & 1) != 0;
     if(e->loop->begin(e->bitstreams) != 0) { xh_set_error("xeve_hip_enc_begin: %s", e->loop->error.c_str()); return XEVE_HIP_ERR_ARG; }

@@ -17,6 +17,7 @@ typedef int16_t pel;
 //   XEVE_HIP_DCT = valu                                            32x32 / 64x64 transforms on the VALU path instead of the matrix cores
 //   XEVE_HIP_WRITER_WAVE = 0, XEVE_HIP_ENC_TWO_STORES = 0          the entropy writer on a lone lane; one CTU store instead of two
 //   XEVE_HIP_ENC_PRIO = 1, XEVE_HIP_ENC_FULL_STATES = 1            the encoder's main stream above its second-pass stream; complete coder states through the walk
+//   XEVE_HIP_ENC_SHARE = 0                                         every picture store in memory of its own (default: later stores over the frames already coded, encode.hip)
 //   XEVE_HIP_HOST_GRAPH = 0                                        the host-memory form of the inter analysis without its per-CU graph replay
 //   XEVE_HIP_WALK_C / _NT / _SPREAD / _DEAL / _INTER / _COUNT / _PROF / _DBG   the fused kernel's team shape, wave placement, stage profile and debug counters (walk.hip)
 // ---- error plumbing (abi.cpp) -------------------------------------------------------------
