@@ -391,7 +391,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 except Exception:
                     continue
             return None, None
-        pmc, src = committed(*(("r05_walk_pmc.json", "r04_walk_pmc.json") if cls == "walk" else ("r06_search_pmc.json", "r05_search_pmc.json", "r04_search_pmc.json")))
+        pmc, src = committed(*(("r05_walk_pmc.json", "r04_walk_pmc.json") if cls == "walk" else ("r07_search_pmc.json", "r06_search_pmc.json", "r05_search_pmc.json", "r04_search_pmc.json")))
         if pmc:
             roof["pmc_from_committed_profile"] = True  # (the counters below were taken by rocprofv3 --pmc runs of their own and committed; this run measured the time)
             roof["traffic"] = pmc.get("hbm_bytes_per_launch") or pmc.get("hbm_bytes_per_launch_x2")
@@ -404,7 +404,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 old, osrc = committed("r04_walk_pmc.json" if cls == "walk" else "r04_search_pmc.json")
                 if old:
                     roof["traffic"], roof["traffic_is"] = old.get("hbm_bytes_per_launch") or old.get("hbm_bytes_per_launch_x2"), old.get("what")
-        mf, msrc = committed("r06_mfma_pmc.json", "r05_mfma_pmc.json")
+        mf, msrc = committed("r07_mfma_pmc.json", "r06_mfma_pmc.json", "r05_mfma_pmc.json")
         if mf:
             roof["mfma"] = {"kernels": "k_rdo_mfma<32|64>, k_dct_mfma<32|64> (v_mfma_i32_32x32x32_i8, exact byte-limb split: the residual chain of the 32x32 / 64x64 luma blocks)",
                             "bound": "mfma", "achieved": mf.get("achieved_TOPS"), "peak": mf.get("peak_TOPS_i8_dense"), "unit": "TOP/s", "frac": mf.get("mfma_utilisation"),
@@ -505,7 +505,7 @@ def class_profile(torch, dev, cfg, gops, frames, per_picture, fb, steps=6):
     # not from a per-bin constant: a launch's lanes carry 0 .. ~25 000 bins each and a wave runs as long as its longest lane, so "instructions per bin" is not a
     # property of the code (profiles/r06_cu_bits_bins.md has the histogram)
     lanes, ginst = {}, None
-    for nm in ("r06_cu_bits_pmc.json", "r05_cu_bits_pmc.json"):
+    for nm in ("r07_cu_bits_pmc.json", "r06_cu_bits_pmc.json", "r05_cu_bits_pmc.json"):
         try:  # (how many of a wave's lanes its VALU work keeps busy, what its cycles wait for)
             pm = json.load(open(os.path.join(ROOT, "profiles", nm)))
             lanes = {k: pm[k] for k in ("active_lane_frac", "active_lane_frac_note", "wait_any_frac", "valu_issue_frac", "waves_per_launch", "valu_insts_per_launch", "avg_launch_s") if k in pm}

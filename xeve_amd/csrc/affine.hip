@@ -179,6 +179,44 @@ template <int TW, int TH> __device__ int satd_block(const int16_t *org, long s_o
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
+// solve_equal (xevem_pinter.c:4213-4255) on the matrix in LDS by the block's first lanes: per pivot the column's largest row (every lane finds the same), the two rows swapped by
+// NP + 1 lanes, then every element below the pivot row eliminated by a lane of its own -- the same expression eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1] on the same
+// operands as the reference's loops (within a pivot step no element it reads is one it writes) -- and the back substitution by lane 0.  A serial solve is 76 dependent
+// double divisions for three control points; this is 5 + 6.
+template <int NP> __device__ void solve_by_lanes(double (*eq)[7], double *para)
+{
+    const int t = threadIdx.x;
+    for(int i = 1; i < NP; i++) {
+        double best = xaff::me_abs(eq[i][i - 1]);
+        int    at = i;
+        for(int j = i + 1; j < NP + 1; j++) {
+            const double v = xaff::me_abs(eq[j][i - 1]);
+            if(v > best) best = v, at = j;
+        }
+        const bool sw = at != i && t <= NP;
+        double a = 0, b = 0;
+        if(sw) a = eq[i][t], b = eq[at][t];
+        __syncthreads();
+        if(sw) eq[i][t] = b, eq[at][t] = a;
+        __syncthreads();
+        const int  nk = NP + 1 - i, nj = NP - i; // columns i .. NP of rows i + 1 .. NP
+        const bool on = t < nj * nk;
+        const int  j = i + 1 + (on ? t / nk : 0), k = i + (on ? t % nk : 0);
+        double v = 0;
+        if(on) v = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
+        __syncthreads();
+        if(on) eq[j][k] = v;
+        __syncthreads();
+    }
+    if(t == 0) {
+        para[NP - 1] = eq[NP][NP] / eq[NP][NP - 1];
+        for(int i = NP - 2; i >= 0; i--) {
+            double acc = 0;
+            for(int j = i + 1; j < NP; j++) acc += eq[i + 1][j] * para[j];
+            para[i] = (eq[i + 1][NP] - acc) / eq[i + 1][i];
+        }
+    }
+}
 template <int VN> __global__ void __launch_bounds__(256) k_affine_me(AffMeArgs A)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -189,6 +227,7 @@ template <int VN> __global__ void __launch_bounds__(256) k_affine_me(AffMeArgs A
     long long *red64 = reinterpret_cast<long long *>(lds + (((size_t)(n + nbuf) * sizeof(pel) + 15) & ~(size_t)15)); // [4][NS]
     __shared__ int     red[4], s_stop;
     __shared__ int16_t s_mvt[3][2];
+    __shared__ double  s_eq[7][7], s_para[6];
     xeve_hip_affine_me_job *const jp = A.jobs + blockIdx.x;
     const xeve_hip_affine_me_job  jb = *jp;
     if(jb.vertex_num != VN) return; // (the other model's launch carries it)
@@ -238,16 +277,21 @@ template <int VN> __global__ void __launch_bounds__(256) k_affine_me(AffMeArgs A
 #pragma unroll
             for(int q = 0; q < NS; q++) red64[(threadIdx.x >> 6) * NS + q] = acc[q];
         __syncthreads();
-        if(threadIdx.x == 0) {
-            int64_t sums[7][7];
-            int q = 0;
-            for(int col = 0; col < NP; col++) {
-                for(int row = col; row < NP; row++, q++) sums[col + 1][row] = sums[row + 1][col] = red64[q] + red64[NS + q] + red64[2 * NS + q] + red64[3 * NS + q];
-                sums[col + 1][NP] = red64[q] + red64[NS + q] + red64[2 * NS + q] + red64[3 * NS + q], q++;
+        if(threadIdx.x < (NP + 1) * (NP + 1)) { // equal_coeff_t -> equal_coeff (:4405-4409): a lane per element; the sums are symmetric, stored as the upper triangle + right-hand side
+            const int r = threadIdx.x / (NP + 1), c = threadIdx.x - r * (NP + 1);
+            long long v = 0;
+            if(r > 0) {
+                const int col = r - 1, lo = c < NP ? (c < col ? c : col) : col, hi = c < NP ? (c < col ? col : c) : NP; // (column NP: the right-hand side, behind its row's triangle)
+                const int q = lo * (NP + 1) - lo * (lo - 1) / 2 + (hi - lo);
+                v = red64[q] + red64[NS + q] + red64[2 * NS + q] + red64[3 * NS + q];
             }
-            for(int c = 0; c <= NP; c++) sums[0][c] = 0;
+            s_eq[r][c] = (double)v;
+        }
+        __syncthreads();
+        solve_by_lanes<NP>(s_eq, s_para);
+        if(threadIdx.x == 0) {
             int16_t mvd[3][2];
-            s_stop = xaff::me_update(sums, VN, w, h, mvd);
+            s_stop = xaff::me_step(s_para, VN, w, h, mvd);
             for(int v = 0; v < 3; v++) s_mvt[v][0] = (int16_t)(mvt[v][0] + mvd[v][0]), s_mvt[v][1] = (int16_t)(mvt[v][1] + mvd[v][1]);
         }
         __syncthreads();

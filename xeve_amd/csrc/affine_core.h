@@ -209,14 +209,10 @@ XF void me_solve(double (*eq)[7], int order, double *para)
         para[i] = (eq[i + 1][order] - t) / eq[i + 1][i];
     }
 }
-// the round's update of the control points from the 64-bit sums (:4404-4447): sums[r][c] = equal_coeff_t[r][c], rows 1 .. 2 * vertex_num; returns whether it is all zero
-XF bool me_update(const int64_t (*sums)[7], int vertex_num, int cuw, int cuh, int16_t mvd[3][2])
+// the solution as the control points' update (:4407-4447): the change per sample at the CU's corners, rounded to quarter samples; returns whether it is all zero
+XF bool me_step(const double para[6], int vertex_num, int cuw, int cuh, int16_t mvd[3][2])
 {
-    const int np = vertex_num << 1;
-    double eq[7][7], para[6], d[6];
-    for(int r = 0; r < np + 1; r++)
-        for(int c = 0; c < np + 1; c++) eq[r][c] = (double)sums[r][c];
-    me_solve(eq, np, para);
+    double d[6];
     d[0] = para[0], d[2] = para[2], d[1] = para[1] * cuw + para[0];
     if(vertex_num == 3) d[3] = para[3] * cuw + para[2], d[4] = para[4] * cuh + para[0], d[5] = para[5] * cuh + para[2];
     else d[3] = -para[3] * cuw + para[2], d[4] = d[5] = 0;
@@ -229,6 +225,16 @@ XF bool me_update(const int64_t (*sums)[7], int vertex_num, int cuw, int cuh, in
             zero = zero && mvd[v][c] == 0;
         }
     return zero;
+}
+// the round's update of the control points from the 64-bit sums (:4404-4447): sums[r][c] = equal_coeff_t[r][c], rows 1 .. 2 * vertex_num; returns whether it is all zero
+XF bool me_update(const int64_t (*sums)[7], int vertex_num, int cuw, int cuh, int16_t mvd[3][2])
+{
+    const int np = vertex_num << 1;
+    double eq[7][7], para[6];
+    for(int r = 0; r < np + 1; r++)
+        for(int c = 0; c < np + 1; c++) eq[r][c] = (double)sums[r][c];
+    me_solve(eq, np, para);
+    return me_step(para, vertex_num, cuw, cuh, mvd);
 }
 // the Sobel derivatives of the prediction at (row j, column k) (xevem_scaled_horizontal / _vertical_sobel_filter, xevem_mc.c:2341-2395: border samples take the inner
 // neighbour's value) and the sample's terms of the normal equations (xevem_equal_coeff_computer, :2397-2447: 32-bit products, wrapping)
