@@ -2,6 +2,7 @@
 """junit XML of a `pytest tests -m gpu --junitxml=...` run on the GPU box -> tests/golden/gpu_suite_durations.json: seconds per test (set-up + call + tear-down), the
 run's wall time, what failed or was skipped.  tests/test_gpu_suite_budget.py (CPU suite) holds the default GPU suite to 900 s with it.
 usage: gpu_suite_durations.py run.xml [pytest.log] > tests/golden/gpu_suite_durations.json
+       gpu_suite_durations.py --drop full.json "<node id>" ... > new.json   (cases since moved behind XEVE_GPU_FULL: removed with their seconds, and recorded)
        gpu_suite_durations.py --merge base.json part.xml > new.json   (tests added since the last full run, measured in a run of their own: their seconds are added
                                                                         to the full run's wall time and sum; tests the part repeats keep the full run's figure)"""
 import json
@@ -10,6 +11,15 @@ import sys
 import xml.etree.ElementTree as ET
 
 base = None
+if sys.argv[1] == "--drop":  # gpu_suite_durations.py --drop full.json "<node id>" ... > new.json: cases of that run since moved behind XEVE_GPU_FULL leave with their seconds
+    d = json.load(open(sys.argv[2]))
+    gone = {k: d["tests"].pop(k) for k in sys.argv[3:]}
+    d["wall_s"], d["sum_s"], d["passed"] = round(d["wall_s"] - sum(gone.values()), 1), round(d["sum_s"] - sum(gone.values()), 1), d["passed"] - len(gone)
+    d["moved_behind_gpu_full_since"] = d.get("moved_behind_gpu_full_since", []) + [{"test": k, "seconds": v, "the_run_took_s": round(d["wall_s"] + sum(gone.values()), 1)} for k, v in gone.items()]
+    d["skipped"] = d["skipped"] + list(gone)
+    json.dump(d, sys.stdout, indent=1)
+    print()
+    sys.exit(0)
 if sys.argv[1] == "--merge":
     base = json.load(open(sys.argv[2]))
     del sys.argv[1:3]

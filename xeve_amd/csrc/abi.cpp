@@ -200,6 +200,30 @@ void xh_prof_end(void *tok, hipStream_t st)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_done.push_back(t);
 }
+void *xh_prof_begin_kernel(int cls, hipEvent_t *start, hipEvent_t *stop)
+{
+    ProfTok *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if(!g_prof_free.empty()) t = g_prof_free.back(), g_prof_free.pop_back();
+    }
+    if(!t) {
+        t = new ProfTok{cls, nullptr, nullptr};
+        if(hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) {
+            if(t->e0) (void)hipEventDestroy(t->e0);
+            if(t->e1) (void)hipEventDestroy(t->e1);
+            delete t;
+            return nullptr;
+        }
+    }
+    t->cls = cls, *start = t->e0, *stop = t->e1;
+    return t;
+}
+void xh_prof_end_kernel(void *tok)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_done.push_back(static_cast<ProfTok *>(tok));
+}
 static void prof_reset_locked()
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);

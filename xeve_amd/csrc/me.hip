@@ -8,6 +8,7 @@
 // minimum over 64-bit keys (cost << 32 | evaluation order), which reproduces the reference's
 // "first strictly smaller cost wins" tie-break exactly.
 #include <cstdlib>
+#include <hip/hip_ext.h>
 #include "xh_common.h"
 
 // developer switch (measurement): 0 = every candidate row through the vector L1 (default: measured fastest), 1 = dense round from an LDS window
@@ -732,17 +733,24 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
     {
         const dim3 grid((njobs + 3) / 4);
         const int  shift = bit_depth - 8;
-        XhProf prof(XH_PROF_SEARCH, st);
+        // (class timer on: the launch records its own begin and end -- the roofline kernel's duration as rocprofv3 sees it, not the stream's wait in front of it)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        void      *ptok = xh_prof_on(XH_PROF_SEARCH) ? xh_prof_begin_kernel(XH_PROF_SEARCH, &ev0, &ev1) : nullptr;
         unsigned long long *units = xh_prof_units(XH_PROF_SEARCH);
 #define EPZS_ARGS org0, s_org, org_bi, ref0, s_ref, jobs, njobs, shift, P, extra_bits, state, pl
+#define EPZS_GO(K, ...)                                                                                            \
+    do {                                                                                                           \
+        if(ptok) hipExtLaunchKernelGGL((K), grid, dim3(256), 0, st, ev0, ev1, 0, __VA_ARGS__);                     \
+        else (K)<<<grid, 256, 0, st>>>(__VA_ARGS__);                                                               \
+    } while(0)
 #define EPZS_LAUNCH_M(S, M, C)                                                                                     \
     do {                                                                                                           \
         if(extra_branches) {                                                                                       \
-            if(P.bi) k_me_epzs<S, true, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units, sj_out);    \
-            else k_me_epzs<S, false, true, 0, C><<<grid, 256, 0, st>>>(EPZS_ARGS, ipel_only, units, sj_out);       \
+            if(P.bi) EPZS_GO((k_me_epzs<S, true, true, 0, C>), EPZS_ARGS, ipel_only, units, sj_out);               \
+            else EPZS_GO((k_me_epzs<S, false, true, 0, C>), EPZS_ARGS, ipel_only, units, sj_out);                  \
         }                                                                                                          \
-        else if(P.bi) k_me_epzs<S, true, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units, sj_out);          \
-        else k_me_epzs<S, false, false, M, C><<<grid, 256, 0, st>>>(EPZS_ARGS, 0, units, sj_out);                  \
+        else if(P.bi) EPZS_GO((k_me_epzs<S, true, false, M, C>), EPZS_ARGS, 0, units, sj_out);                     \
+        else EPZS_GO((k_me_epzs<S, false, false, M, C>), EPZS_ARGS, 0, units, sj_out);                             \
     } while(0)
 #define EPZS_LAUNCH(S)                                                                                             \
     do {                                                                                                           \
@@ -756,7 +764,9 @@ int xh_me_epzs_jobs_planes(const pel *org0, int s_org, const pel *org_bi, const 
         else EPZS_LAUNCH(64);
 #undef EPZS_LAUNCH
 #undef EPZS_LAUNCH_M
+#undef EPZS_GO
 #undef EPZS_ARGS
+        if(ptok) xh_prof_end_kernel(ptok);
         XH_HIP(hipGetLastError());
     }
     if(ipel_only) {

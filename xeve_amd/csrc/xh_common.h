@@ -59,6 +59,11 @@ void  xh_prof_end(void *tok, hipStream_t st);
 #define XH_PROF_STRIPES 256
 unsigned long long *xh_prof_units(int cls);
 #define XH_PROF_SLOT(units) ((units) + (blockIdx.x & (XH_PROF_STRIPES - 1)))
+// the same for ONE kernel whose launch records the events itself (hipExtLaunchKernelGGL's start / stop events = the dispatch's own begin and end on the device): events
+// recorded around a launch on the stream include what the stream waited for between the previous kernel's end and this one's start -- the host's enqueue gap, other
+// streams' kernels holding the CUs -- and do not agree with rocprofv3's per-kernel durations; these do.
+void *xh_prof_begin_kernel(int cls, hipEvent_t *start, hipEvent_t *stop);
+void  xh_prof_end_kernel(void *tok);
 struct XhProf {
     void       *tok;
     hipStream_t st;
