@@ -378,7 +378,7 @@ def run_job(a, torch, dist, dev, rank, world, W, H, label, with_cpu):
                 "how": ("algorithmic bytes of the motion search (4 per sample pair compared, counted on the device) over the HIP-event time of the kernel's launches in the timed "
                         "region (events on the walk's own streams), against the rate at which the chip's VALUs can issue v_sad_u16.  The kernel is the whole analysis: the search is "
                         "one stage class of it (`by_time`), so this is the SAD work per second of a kernel that spends most of its time elsewhere") if cls == "walk" else
-                       ("algorithmic bytes (256 per 64 sample pairs evaluated, counted on the device) over the kernel's HIP-event time in the timed region, against the rate at "
+                       ("algorithmic bytes (256 per 64 sample pairs evaluated, counted on the device) over the kernel's HIP-event time in the timed region (the launch's own start / stop events, hipExtLaunchKernelGGL: the dispatch's begin and end, not the stream's wait in front of it), against the rate at "
                         "which the chip's VALUs can issue v_sad_u16 (8 algorithmic bytes per lane and instruction)"),
                 "launches_in_region": k_n, "avg_launch_ms": round(k_ms / max(1, k_n), 4), "algorithmic_bytes_per_launch": int(alg / max(1, k_n)),
                 "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 6), "traffic": None}
