@@ -161,6 +161,37 @@ def test_preset_placebo_batches_on_the_gpu(name, team, hip, yuv_dir):
     assert [(len(o), _enc.md5(o)) for o in outs] == [(p["bytes"], p["md5"]) for p in g["per_gop"]]
 
 
+def test_a_run_consumes_its_frames_and_says_so(hip):
+    """round 6: the picture stores of later pictures live in the memory of frames already coded (encode.hip dims(): a store over the frames' buffer as soon as it ends inside the
+    frames coded so far).  1280x720 with 10-bit input (a frame is 2.8 MB, a padded store 4.8 MB): the second store of a two-picture GOP lies over both frames.  A second run
+    of the same object without new frames is refused; with the frames pushed again it writes the same bytes.  (That the bytes are the reference's with stores placed so is what
+    the cases at 1920x1080 and 3840x2160 hold: their goldens.)"""
+    import xeve_amd
+
+    w, h, frames = 1280, 720, 2
+    cfg = hip.config(w, h, keyint=8, closed_gop=True, preset="medium", threads=8, input_depth=10)
+    import numpy as np
+
+    cfg8 = hip.config(w, h, keyint=8, closed_gop=True, preset="medium", threads=8)
+    # (with 8-bit input a store is 3.5 frames and both stores are memory of their own: the 10-bit batch, whose frames are twice the size, is the SMALLER one)
+    assert hip.footprint(cfg, 1, frames)[0] < hip.footprint(cfg8, 1, frames)[0], "the second store is not over the frames"
+    clip = np.random.default_rng(9).integers(0, 1024, size=2 * frames * w * h * 3 // 2, dtype=np.uint16).tobytes()
+    fb = w * h * 3 * frames  # bytes of a GOP: two bytes per sample
+    enc = hip.BatchEncoder(cfg, 2, frames)
+    for g in range(2):
+        enc.push_gop(g, clip[g * fb:(g + 1) * fb])
+    first = enc.encode()
+    with pytest.raises(xeve_amd.XeveHipError, match="consumed its frames"):
+        enc.encode()
+    enc.push_gop(0, clip[:fb])
+    with pytest.raises(xeve_amd.XeveHipError, match="consumed its frames"):  # (every frame, not some)
+        enc.encode()
+    enc.push_gop(0, clip[:fb]), enc.push_gop(1, clip[fb:])
+    again = enc.encode()
+    enc.close()
+    assert again == first and len(first[0]) > 1000 and first[0] != first[1]
+
+
 def test_preset_slow_is_refused_where_the_fused_walk_is_switched_off(hip):
     import xeve_amd
 
