@@ -161,4 +161,15 @@ class HipAffineMeHost:
 @pytest.mark.gpu
 @pytest.mark.parametrize("size", [(16, 16), (64, 64), (128, 32)], ids=["16x16", "64x64", "128x32"])
 def test_hip_affine_me_host_form_matches_the_goldens(size):
-    check(HipAffineMeHost(), *size)
+    """in an interpreter of its own: ONE call of this host form (a per-thread arena with pinned staging on a stream of its own) leaves the calling process issuing every later
+    launch ~1.5 us slower -- the real-size encodes at the end of the suite took a quarter longer behind it (profiles/r07k_trials.log)"""
+    if os.environ.get("XEVE_AFFINE_ME_HOST_INNER") == "1":
+        check(HipAffineMeHost(), *size)
+        return
+    import subprocess
+    import sys
+
+    node = "%s::test_hip_affine_me_host_form_matches_the_goldens[%dx%d]" % (os.path.abspath(__file__), size[0], size[1])
+    p = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"], env=dict(os.environ, XEVE_AFFINE_ME_HOST_INNER="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
