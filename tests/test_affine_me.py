@@ -173,3 +173,42 @@ def test_hip_affine_me_host_form_matches_the_goldens(size):
     p = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"], env=dict(os.environ, XEVE_AFFINE_ME_HOST_INNER="1"),
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
+
+
+SAN_SCRIPT = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, sys.argv[2])
+import _affine as A, _affine_me as M
+H = C.CDLL(sys.argv[1])
+H.xa_host_affine_me.restype = None
+cl = (C.c_int16 * 128).in_dll(A.OracleAffine().L, "xom_mc_l_coeff")
+pics, org = M.ref_pictures(), M.org_picture()
+t, gold, n = M.refp_table(pics), np.load(M.GOLDEN), 0
+for (w, h) in M.SIZES:
+    jobs, ob = M.make_jobs(w, h, 11 + w + h)
+    out, r = jobs.copy(), np.zeros(1, np.int32)
+    for i in range(len(out)):
+        src = ob[i] if out[i]["bi"] else org
+        H.xa_host_affine_me(C.c_void_p(t.ctypes.data), C.c_int(pics[0][0].shape[1]), C.c_int(M.PIC_W), C.c_int(M.PIC_H), C.c_void_p(src.ctypes.data), C.c_int(src.shape[1]),
+                            C.c_void_p(out[i:i + 1].ctypes.data), C.c_int(w), C.c_int(h), C.c_int(M.BD), C.c_uint32(M.LAMBDA_MV), C.c_int(M.NUM_REFP), cl, C.c_void_p(r.ctypes.data))
+    assert np.array_equal(out["cost"], gold["%dx%d/cost" % (w, h)])
+    n += len(out)
+print("clean", n)
+"""
+
+
+def test_the_kernels_host_code_is_clean_under_the_sanitizers(tmp_path):
+    """affine_core.h + the harness built with AddressSanitizer and UndefinedBehaviorSanitizer (CPU build: GPU sanitizers are not available on the pool), every golden search
+    through it: the window / neighbour indexing of the compensation, the Sobel terms at the CU's borders, the conversions of the solve.  (-fno-sanitize=shift: the vector
+    clipping shifts negative values left, as the reference does; defined since C++20 and by every compiler in use.)"""
+    import subprocess
+    import sys
+
+    so = str(tmp_path / "libaffine_host_san.so")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize=shift", "-fno-sanitize-recover=undefined",
+                    "-ffp-contract=off", "-o", so, A.HOST_SRC], check=True)
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    p = subprocess.run([sys.executable, "-c", SAN_SCRIPT, so, os.path.dirname(os.path.abspath(__file__))], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0"))
+    assert p.returncode == 0 and "clean 192" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
