@@ -143,7 +143,7 @@ def test_walk_p_and_b_pictures_with_a_team_of_real_threads(case, threads):
     check_inter(case, threads=threads)
 
 
-@pytest.mark.parametrize("rotate", [1, 3])
+@pytest.mark.parametrize("rotate", [1, 3] if SLOW else [3])  # (a rotation by one wave is the same code path with another constant: 65 s more, with XEVE_RACE_TESTS=1)
 def test_the_serial_stages_packed_into_a_rotated_wave_change_nothing(rotate, monkeypatch):
     """walk.hip runs a team's serial stages (coder jobs, RDOQ scans) on ONE wave and takes that wave from a different SIMD for each of a CU's four teams: the logical thread
     index is the hardware one with the waves rotated.  The same layouts on the host's team of 256 real threads (P::deal = 1, the thread indices rotated by whole waves) must
